@@ -1,0 +1,249 @@
+"""ctypes binding for the CPU oracle (oracle/artemis_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under artemis_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+
+RS = {"hllc": 0, "hlle": 1, "llf": 2}
+RC = {"pcm": 0, "plm": 1, "ppm": 2}
+BC = {"periodic": 0, "outflow": 1, "reflecting": 2, "reflect": 2, "none": 3}
+INTEG = {"rk1": 0, "rk2": 1, "vl2": 2, "rk3": 3}
+GAS, DUST = 0, 1
+
+# field ids of oracle_field()
+F_GPRIM, F_GU0, F_GU1 = 0, 1, 2
+F_GFLUX, F_GPFLUX, F_GVFACE = 3, 6, 9
+F_DPRIM, F_DU0, F_DU1, F_DFLUX = 12, 13, 14, 15
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("nx1", C.c_int), ("nx2", C.c_int), ("nx3", C.c_int), ("ng", C.c_int),
+        ("x1min", C.c_double), ("x1max", C.c_double), ("x2min", C.c_double),
+        ("x2max", C.c_double), ("x3min", C.c_double), ("x3max", C.c_double),
+        ("ns_gas", C.c_int), ("ns_dust", C.c_int),
+        ("recon_gas", C.c_int), ("riemann_gas", C.c_int),
+        ("recon_dust", C.c_int), ("riemann_dust", C.c_int),
+        ("gamma", C.c_double), ("dfloor_gas", C.c_double), ("siefloor_gas", C.c_double),
+        ("de_switch", C.c_double), ("dfloor_dust", C.c_double),
+        ("cfl_gas", C.c_double), ("cfl_dust", C.c_double),
+        ("bc", C.c_int * 6), ("integrator", C.c_int), ("nthreads", C.c_int),
+    ]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
+            os.path.join(_HERE, "artemis_oracle.cpp")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.POINTER(Cfg)]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_field.restype = C.POINTER(C.c_double)
+        L.oracle_field.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.oracle_set_mesh_bounds.argtypes = [C.c_void_p] + [C.c_double] * 6
+        L.oracle_calculate_fluxes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.oracle_apply_update.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.oracle_flux_source.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        for f in ("set_aux", "cons_to_prim", "prim_to_cons", "deep_copy", "apply_bcs"):
+            getattr(L, "oracle_" + f).argtypes = [C.c_void_p]
+        L.oracle_estimate_dt.restype = C.c_double
+        L.oracle_estimate_dt.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_new_dt.restype = C.c_double
+        L.oracle_new_dt.argtypes = [C.c_void_p]
+        L.oracle_time.restype = C.c_double
+        L.oracle_time.argtypes = [C.c_void_p]
+        L.oracle_dt.restype = C.c_double
+        L.oracle_dt.argtypes = [C.c_void_p]
+        L.oracle_ncycle.restype = C.c_long
+        L.oracle_ncycle.argtypes = [C.c_void_p]
+        L.oracle_set_dt.argtypes = [C.c_void_p, C.c_double]
+        L.oracle_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_evolve.restype = C.c_long
+        L.oracle_evolve.argtypes = [C.c_void_p, C.c_double, C.c_long]
+        L.oracle_pgen_blast.argtypes = [C.c_void_p] + [C.c_double] * 7 + [C.c_int, C.c_int]
+        L.oracle_pgen_linear_wave.restype = C.c_double
+        L.oracle_pgen_linear_wave.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                              C.c_int, C.c_int, C.c_int, C.c_double]
+        L.oracle_pgen_advection.restype = C.c_double
+        L.oracle_pgen_advection.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                            C.c_int, C.c_int, C.c_double]
+        L.oracle_linear_wave_errors.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        L.oracle_advection_errors.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.oracle_history.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.oracle_plm.argtypes = [C.c_double] * 3 + [C.POINTER(C.c_double)] * 2
+        L.oracle_ppm4.argtypes = [C.c_double] * 5 + [C.POINTER(C.c_double)] * 2
+        L.oracle_riemann.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+EXCH = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class Oracle:
+    """One block of the CPU oracle.  Keyword arguments follow the reference's input-deck
+    names (inputs/*/*.in): reconstruct, riemann, gamma, cfl, dfloor, siefloor, integrator."""
+
+    def __init__(self, nx, xmin, xmax, ng=2, ns_gas=1, ns_dust=0, reconstruct="plm",
+                 riemann="hllc", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.66666666667,
+                 dfloor=1.0e-20, siefloor=1.0e-20, de_switch=0.0, dust_dfloor=1.0e-20, cfl=0.8,
+                 dust_cfl=0.8, bc=("periodic",) * 6, integrator="rk2", mesh_bounds=None):
+        self.L = lib()
+        c = Cfg()
+        c.nx1, c.nx2, c.nx3 = nx
+        c.ng = ng
+        c.x1min, c.x2min, c.x3min = xmin
+        c.x1max, c.x2max, c.x3max = xmax
+        c.ns_gas, c.ns_dust = ns_gas, ns_dust
+        c.recon_gas, c.riemann_gas = RC[reconstruct], RS[riemann]
+        c.recon_dust, c.riemann_dust = RC[dust_reconstruct], RS[dust_riemann]
+        c.gamma, c.dfloor_gas, c.siefloor_gas = gamma, dfloor, siefloor
+        c.de_switch, c.dfloor_dust = de_switch, dust_dfloor
+        c.cfl_gas, c.cfl_dust = cfl, dust_cfl
+        for i, b in enumerate(bc):
+            c.bc[i] = BC[b] if isinstance(b, str) else b
+        c.integrator = INTEG[integrator]
+        c.nthreads = 0
+        self.cfg = c
+        self.h = C.c_void_p(self.L.oracle_create(C.byref(c)))
+        d = (C.c_int * 10)()
+        self.L.oracle_dims(self.h, d)
+        (self.ni, self.nj, self.nk, self.is_, self.ie, self.js, self.je, self.ks, self.ke,
+         self.ndim) = list(d)
+        self.N = self.ni * self.nj * self.nk
+        if mesh_bounds is not None:
+            self.L.oracle_set_mesh_bounds(self.h, *[float(x) for x in mesh_bounds])
+        self._cb = None
+
+    def __del__(self):
+        try:
+            self.L.oracle_destroy(self.h)
+        except Exception:
+            pass
+
+    # numpy views [nvar, nk, nj, ni] of the oracle's own arrays (no copy)
+    def field(self, which, nvar):
+        p = self.L.oracle_field(self.h, which)
+        a = np.ctypeslib.as_array(p, shape=(nvar * self.N,))
+        return a.reshape(nvar, self.nk, self.nj, self.ni)
+
+    @property
+    def gprim(self): return self.field(F_GPRIM, 6 * self.cfg.ns_gas)
+    @property
+    def gu0(self): return self.field(F_GU0, 6 * self.cfg.ns_gas)
+    @property
+    def gu1(self): return self.field(F_GU1, 6 * self.cfg.ns_gas)
+    def gflux(self, d): return self.field(F_GFLUX + d, 6 * self.cfg.ns_gas)
+    def gpflux(self, d): return self.field(F_GPFLUX + d, self.cfg.ns_gas)
+    def gvface(self, d): return self.field(F_GVFACE + d, self.cfg.ns_gas)
+    @property
+    def dprim(self): return self.field(F_DPRIM, 4 * self.cfg.ns_dust)
+    @property
+    def du0(self): return self.field(F_DU0, 4 * self.cfg.ns_dust)
+    @property
+    def du1(self): return self.field(F_DU1, 4 * self.cfg.ns_dust)
+    def dflux(self, d): return self.field(F_DFLUX + d, 4 * self.cfg.ns_dust)
+
+    def interior(self, a):
+        return a[..., self.ks:self.ke + 1, self.js:self.je + 1, self.is_:self.ie + 1]
+
+    # reference task names (artemis_driver.cpp:145-273)
+    def CalculateFluxes(self, fluid=GAS, pcm=False): self.L.oracle_calculate_fluxes(self.h, fluid, int(pcm))
+    def ApplyUpdate(self, gam0, gam1, beta_dt): self.L.oracle_apply_update(self.h, gam0, gam1, beta_dt)
+    def FluxSource(self, dt, fluid=GAS): self.L.oracle_flux_source(self.h, fluid, dt)
+    def SetAuxillaryFields(self): self.L.oracle_set_aux(self.h)
+    def ConsToPrim(self): self.L.oracle_cons_to_prim(self.h)
+    def PrimToCons(self): self.L.oracle_prim_to_cons(self.h)
+    def DeepCopyConservedData(self): self.L.oracle_deep_copy(self.h)
+    def EstimateTimestepMesh(self, fluid=GAS): return self.L.oracle_estimate_dt(self.h, fluid)
+    def ApplyBoundaryConditions(self): self.L.oracle_apply_bcs(self.h)
+    def new_dt(self): return self.L.oracle_new_dt(self.h)
+
+    @property
+    def time(self): return self.L.oracle_time(self.h)
+    @property
+    def dt(self): return self.L.oracle_dt(self.h)
+    @dt.setter
+    def dt(self, v): self.L.oracle_set_dt(self.h, v)
+    @property
+    def ncycle(self): return self.L.oracle_ncycle(self.h)
+
+    def step(self, exchange=None):
+        if exchange is None:
+            self.L.oracle_step(self.h, None, None)
+        else:
+            cb = EXCH(lambda ctx: exchange())
+            self.L.oracle_step(self.h, C.cast(cb, C.c_void_p), None)
+
+    def evolve(self, tlim=-1.0, nlim=-1):
+        return self.L.oracle_evolve(self.h, tlim, nlim)
+
+    # problem generators (pgen/*.hpp)
+    def pgen_blast(self, radius=1.0, internal_energy=1.0, p0=1.0, d0=1.0, x0=(0.0, 0.0, 0.0),
+                   samples=-1, symmetry="spherical"):
+        self.L.oracle_pgen_blast(self.h, radius, internal_energy, p0, d0, x0[0], x0[1], x0[2],
+                                 samples, 1 if symmetry == "spherical" else 2)
+
+    def pgen_linear_wave(self, wave_flag, amp, vflow=0.0, along=(False, False, False), nperiod=1.0):
+        return self.L.oracle_pgen_linear_wave(self.h, wave_flag, amp, vflow, *map(int, along), nperiod)
+
+    def pgen_advection(self, amp, vflow=1.0, along=(False, False, False), nperiod=1.0):
+        return self.L.oracle_pgen_advection(self.h, amp, vflow, *map(int, along), nperiod)
+
+    def linear_wave_errors(self, do_rms=True):
+        out = (C.c_double * 6)()
+        self.L.oracle_linear_wave_errors(self.h, out, int(do_rms))
+        return np.array(out[:])
+
+    def advection_errors(self):
+        out = (C.c_double * 16)()
+        self.L.oracle_advection_errors(self.h, out)
+        return np.array(out[:])
+
+    def history(self):
+        n = 6 + 4 * self.cfg.ns_dust
+        out = (C.c_double * n)()
+        self.L.oracle_history(self.h, out)
+        return np.array(out[:])
+
+
+def plm(qm, q, qp):
+    a, b = C.c_double(), C.c_double()
+    lib().oracle_plm(qm, q, qp, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def ppm4(qmm, qm, q, qp, qpp):
+    a, b = C.c_double(), C.c_double()
+    lib().oracle_ppm4(qmm, qm, q, qp, qpp, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def riemann(fluid, solver, gm1, wl, wr):
+    wl = np.ascontiguousarray(wl, dtype=np.float64)
+    wr = np.ascontiguousarray(wr, dtype=np.float64)
+    out = np.zeros(8)
+    P = C.POINTER(C.c_double)
+    lib().oracle_riemann(fluid, RS[solver] if isinstance(solver, str) else solver, gm1,
+                         wl.ctypes.data_as(P), wr.ctypes.data_as(P), out.ctypes.data_as(P))
+    return out
