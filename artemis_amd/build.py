@@ -1,0 +1,72 @@
+"""Build recipe for the HIP library and the host driver (in-tree, no JIT cache)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# -ffp-contract=off: every expression tree stays unfused so results are bit-identical to the
+# CPU oracle (oracle/Makefile uses the same flag).  See DESIGN.md "Floating point".
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+             "-Wall", "-Wno-unused-function"]
+
+HIP_SOURCES = ["abi.hip", "kernels_unfused.hip", "kernels_fused.hip"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _deps():
+    out = []
+    for d in (CSRC, os.path.join(CSRC, "driver"), os.path.join(ROOT, "include")):
+        if os.path.isdir(d):
+            out += [os.path.join(d, f) for f in os.listdir(d)
+                    if f.endswith((".hip", ".hpp", ".h", ".cpp"))]
+    return out
+
+
+def build_hip(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    target = os.path.join(LIBDIR, "libartemis_hip.so")
+    if not (force or _newer(target, _deps())):
+        return target
+    objs = []
+    procs = []
+    for src in HIP_SOURCES:
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        cmd = [HIPCC] + HIP_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    drv_dir = os.path.join(CSRC, "driver")
+    if os.path.isdir(drv_dir):
+        for f in sorted(os.listdir(drv_dir)):
+            if f.endswith(".cpp"):
+                obj = os.path.join(LIBDIR, "driver_" + f.replace(".cpp", ".o"))
+                cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off",
+                       "-I", os.path.join(ROOT, "include"), "-c", os.path.join(drv_dir, f), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", target] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return target
+
+
+if __name__ == "__main__":
+    print(build_hip(force="-f" in sys.argv, verbose=True))

@@ -1,0 +1,134 @@
+"""ctypes mirror of include/artemis_hip.h and include/artemis_rt.h.
+
+The shared library is the product; this module only declares prototypes.  If the library is
+missing or no GPU is visible, calls fail loudly -- there is no Python or CPU fallback.
+"""
+import ctypes as C
+import os
+
+# torch bundles its own libamdhip64.so; importing it first makes the loader resolve our
+# DT_NEEDED libamdhip64.so.7 to that single copy instead of loading a second HIP runtime.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libartemis_hip.so")
+
+OK, EINVAL, EDEVICE, EUNSUPPORTED = 0, 1, 2, 3
+CARTESIAN = 0
+HLLC, HLLE, LLF = 0, 1, 2
+PCM, PLM, PPM = 0, 1, 2
+GAS, DUST = 0, 1
+BC_PERIODIC, BC_OUTFLOW, BC_REFLECT, BC_NONE = 0, 1, 2, 3
+RSOLVER = {"hllc": HLLC, "hlle": HLLE, "llf": LLF}
+RECON = {"pcm": PCM, "plm": PLM, "ppm": PPM}
+BCS = {"periodic": BC_PERIODIC, "outflow": BC_OUTFLOW, "reflecting": BC_REFLECT,
+       "reflect": BC_REFLECT, "none": BC_NONE}
+
+PP = C.c_void_p  # device pointer tables are opaque to the host
+
+
+class FluidPack(C.Structure):
+    _fields_ = [
+        ("nspecies", C.c_int), ("recon", C.c_int), ("riemann", C.c_int),
+        ("dfloor", C.c_double), ("siefloor", C.c_double), ("de_switch", C.c_double),
+        ("prim", PP), ("cons0", PP), ("cons1", PP),
+        ("flux", PP * 3), ("pflux", PP * 3), ("vface", PP * 3),
+    ]
+
+
+class Pack(C.Structure):
+    _fields_ = [
+        ("nblocks", C.c_int), ("nghost", C.c_int),
+        ("nx1", C.c_int), ("nx2", C.c_int), ("nx3", C.c_int),
+        ("coords", C.c_int), ("gm1", C.c_double), ("geom", C.c_void_p),
+        ("gas", FluidPack), ("dust", FluidPack),
+    ]
+
+
+class StageArgs(C.Structure):
+    _fields_ = [
+        ("gam0", C.c_double), ("gam1", C.c_double), ("beta_dt", C.c_double), ("bdt", C.c_double),
+        ("pcm", C.c_int),
+        ("prim_in", PP), ("prim_u1", PP), ("prim_out", PP), ("cons_out", PP),
+        ("cfl", C.c_double), ("dt_dev", C.c_void_p),
+    ]
+
+
+class ArtemisHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"artemis_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen libartemis_hip.so (built by __graft_entry__.build()); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc --offload-arch=gfx950). No fallback exists.")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    PPk, vp, d, i = C.POINTER(Pack), C.c_void_p, C.c_double, C.c_int
+    sig = {
+        "artemis_hip_calculate_fluxes": (i, [PPk, i, i, vp]),
+        "artemis_hip_apply_update": (i, [PPk, d, d, d, vp]),
+        "artemis_hip_flux_source": (i, [PPk, i, d, vp]),
+        "artemis_hip_set_aux": (i, [PPk, vp]),
+        "artemis_hip_cons_to_prim": (i, [PPk, vp]),
+        "artemis_hip_prim_to_cons": (i, [PPk, vp]),
+        "artemis_hip_deep_copy_conserved": (i, [PPk, vp]),
+        "artemis_hip_estimate_dt": (i, [PPk, i, d, C.POINTER(d), vp]),
+        "artemis_hip_estimate_dt_async": (i, [PPk, i, d, vp, vp]),
+        "artemis_hip_apply_bc": (i, [PPk, C.POINTER(i), vp]),
+        "artemis_hip_stage_fused": (i, [PPk, C.POINTER(StageArgs), vp]),
+        "artemis_hip_halo_count": (C.c_long, [PPk, i]),
+        "artemis_hip_halo_pack": (i, [PPk, i, i, vp, vp]),
+        "artemis_hip_halo_unpack": (i, [PPk, i, i, vp, vp]),
+        "artemis_hip_last_error": (C.c_char_p, []),
+        "artemis_hip_device_count": (i, []),
+        "artemis_hip_version": (C.c_char_p, []),
+        "artemis_rt_set_device": (i, [i]),
+        "artemis_rt_malloc": (vp, [C.c_size_t]),
+        "artemis_rt_free": (None, [vp]),
+        "artemis_rt_malloc_host": (vp, [C.c_size_t]),
+        "artemis_rt_free_host": (None, [vp]),
+        "artemis_rt_memcpy_h2d": (i, [vp, vp, C.c_size_t, vp]),
+        "artemis_rt_memcpy_d2h": (i, [vp, vp, C.c_size_t, vp]),
+        "artemis_rt_memcpy_d2d": (i, [vp, vp, C.c_size_t, vp]),
+        "artemis_rt_memset": (i, [vp, i, C.c_size_t, vp]),
+        "artemis_rt_stream_create": (vp, []),
+        "artemis_rt_stream_destroy": (None, [vp]),
+        "artemis_rt_stream_sync": (i, [vp]),
+        "artemis_rt_device_sync": (i, []),
+        "artemis_rt_event_create": (vp, []),
+        "artemis_rt_event_destroy": (None, [vp]),
+        "artemis_rt_event_record": (i, [vp, vp]),
+        "artemis_rt_stream_wait_event": (i, [vp, vp]),
+        "artemis_rt_event_sync": (i, [vp]),
+        "artemis_rt_event_elapsed_ms": (d, [vp, vp]),
+        "artemis_rt_tables_changed": (None, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if the header and the library disagree
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+EXPORTS_HIP = [
+    "artemis_hip_calculate_fluxes", "artemis_hip_apply_update", "artemis_hip_flux_source",
+    "artemis_hip_set_aux", "artemis_hip_cons_to_prim", "artemis_hip_prim_to_cons",
+    "artemis_hip_deep_copy_conserved", "artemis_hip_estimate_dt", "artemis_hip_estimate_dt_async",
+    "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_halo_count",
+    "artemis_hip_halo_pack", "artemis_hip_halo_unpack", "artemis_hip_last_error",
+    "artemis_hip_device_count", "artemis_hip_version",
+]
+
+
+def check(rc):
+    if rc != 0:
+        raise ArtemisHipError(rc, load().artemis_hip_last_error().decode())

@@ -1,0 +1,317 @@
+// extern "C" surface of libartemis_hip.so: validates arguments the way the reference's
+// PARTHENON_REQUIRE/FAIL guards do, builds the by-value kernel view and enqueues kernels.
+// No CPU fallback: without a HIP device every compute entry point returns
+// ARTEMIS_HIP_EDEVICE.
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/artemis_hip.h"
+#include "../../include/artemis_rt.h"
+#include "kernels.hpp"
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+int check_hip(hipError_t e, const char *what) {
+  if (e == hipSuccess) return 0;
+  return fail(ARTEMIS_HIP_EDEVICE, "%s: %s", what, hipGetErrorString(e));
+}
+int device_ready() {
+  static int ndev = -1;
+  if (ndev < 0) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    ndev = n;
+  }
+  if (ndev <= 0)
+    return fail(ARTEMIS_HIP_EDEVICE,
+                "no HIP device visible: libartemis_hip has no CPU fallback (gfx950 required)");
+  return 0;
+}
+
+// Guards shared by every entry point (gas.cpp:59-96, dust.cpp:50-86, fluid_fluxes.hpp:290).
+int validate(const artemis_pack_t *p, bool need_gas_cons = false) {
+  if (!p) return fail(ARTEMIS_HIP_EINVAL, "null pack");
+  if (p->nblocks < 1 || p->nx1 < 1 || p->nx2 < 1 || p->nx3 < 1)
+    return fail(ARTEMIS_HIP_EINVAL, "bad pack extents nblocks=%d nx=(%d,%d,%d)", p->nblocks, p->nx1,
+                p->nx2, p->nx3);
+  if (p->nx3 > 1 && p->nx2 == 1)
+    return fail(ARTEMIS_HIP_EINVAL, "nx3 > 1 requires nx2 > 1");
+  if (p->coords < ARTEMIS_CARTESIAN || p->coords > ARTEMIS_AXISYMMETRIC)
+    return fail(ARTEMIS_HIP_EINVAL, "Coordinate type not recognized!");
+  if (p->coords != ARTEMIS_CARTESIAN)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "only cartesian coordinates are built (DESIGN.md)");
+  if (!p->geom) return fail(ARTEMIS_HIP_EINVAL, "null geom table");
+  if (p->gas.nspecies < 0 || p->dust.nspecies < 0 || (p->gas.nspecies == 0 && p->dust.nspecies == 0))
+    return fail(ARTEMIS_HIP_EINVAL, "no fluid species in pack");
+  if (p->gas.nspecies > 0 && !(p->gm1 > 0.0))
+    return fail(ARTEMIS_HIP_EINVAL, "gm1 must be positive (ideal gas)");
+  (void)need_gas_cons;
+  return device_ready();
+}
+int validate_fluid(const artemis_pack_t *p, int fluid, int pcm) {
+  if (fluid != ARTEMIS_GAS && fluid != ARTEMIS_DUST)
+    return fail(ARTEMIS_HIP_EINVAL, "Fluid type not recognized!");
+  const artemis_fluid_pack_t &f = (fluid == ARTEMIS_GAS) ? p->gas : p->dust;
+  if (f.nspecies == 0) return 0;
+  if (f.recon < ARTEMIS_PCM || f.recon > ARTEMIS_PPM)
+    return fail(ARTEMIS_HIP_EINVAL, "Reconstruction method not recognized!");
+  if (f.riemann < ARTEMIS_HLLC || f.riemann > ARTEMIS_LLF)
+    return fail(ARTEMIS_HIP_EINVAL, "Riemann solver not recognized!");
+  if (fluid == ARTEMIS_DUST && f.riemann == ARTEMIS_HLLC)
+    return fail(ARTEMIS_HIP_EINVAL, "Riemann solver (dust) not recognized."); // dust.cpp:77-85
+  const int recon = pcm ? ARTEMIS_PCM : f.recon;
+  const int need = (recon == ARTEMIS_PCM) ? 1 : ((recon == ARTEMIS_PLM) ? 2 : 3);
+  if (p->nghost < need)
+    return fail(ARTEMIS_HIP_EINVAL, "%s requires at least %d ghost cells.",
+                recon == ARTEMIS_PCM ? "PCM" : (recon == ARTEMIS_PLM ? "PLM" : "PPM"), need);
+  return 0;
+}
+inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
+int after_launch(const char *what) { return check_hip(hipGetLastError(), what); }
+
+// device scalar + pinned mirror for the synchronous dt entry point
+struct DtScratch {
+  double *dev = nullptr;
+  double *host = nullptr;
+};
+thread_local DtScratch g_dt;
+int ensure_dt_scratch() {
+  if (g_dt.dev) return 0;
+  if (int rc = check_hip(hipMalloc(reinterpret_cast<void **>(&g_dt.dev), sizeof(double)), "hipMalloc"))
+    return rc;
+  return check_hip(hipHostMalloc(reinterpret_cast<void **>(&g_dt.host), sizeof(double)),
+                   "hipHostMalloc");
+}
+} // namespace
+
+extern "C" {
+
+const char *artemis_hip_last_error(void) { return g_err.c_str(); }
+const char *artemis_hip_version(void) { return "artemis_hip 0.1 (gfx950, fp64, -ffp-contract=off)"; }
+int artemis_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int artemis_hip_calculate_fluxes(const artemis_pack_t *p, int fluid, int pcm, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (int rc = validate_fluid(p, fluid, pcm)) return rc;
+  const artemis_fluid_pack_t &f = (fluid == ARTEMIS_GAS) ? p->gas : p->dust;
+  if (f.nspecies == 0) return 0;
+  const artemis::PackView P = artemis::make_pack_view(*p);
+  artemis::launch_calculate_fluxes(P, fluid, f.riemann, pcm ? ARTEMIS_PCM : f.recon, S(stream));
+  return after_launch("CalculateFluxes");
+}
+
+int artemis_hip_apply_update(const artemis_pack_t *p, double gam0, double gam1, double beta_dt,
+                             void *stream) {
+  if (int rc = validate(p)) return rc;
+  artemis::launch_apply_update(artemis::make_pack_view(*p), gam0, gam1, beta_dt, S(stream));
+  return after_launch("ApplyUpdate");
+}
+
+int artemis_hip_flux_source(const artemis_pack_t *p, int fluid, double dt, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (fluid != ARTEMIS_GAS && fluid != ARTEMIS_DUST)
+    return fail(ARTEMIS_HIP_EINVAL, "Fluid type not recognized!");
+  // Dust is pressureless: Dust::FluxSource returns immediately for Cartesian (dust.cpp:310-323).
+  if (fluid == ARTEMIS_DUST || p->gas.nspecies == 0) return 0;
+  if (p->nghost < 1) return fail(ARTEMIS_HIP_EINVAL, "FluxSource needs >= 1 ghost cell");
+  artemis::launch_flux_source_gas(artemis::make_pack_view(*p), dt, S(stream));
+  return after_launch("FluxSource");
+}
+
+int artemis_hip_set_aux(const artemis_pack_t *p, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (p->gas.nspecies == 0) return 0; // fill_derived.cpp:37-38
+  artemis::launch_set_aux(artemis::make_pack_view(*p), S(stream));
+  return after_launch("SetAuxillaryFields");
+}
+
+int artemis_hip_cons_to_prim(const artemis_pack_t *p, void *stream) {
+  if (int rc = validate(p)) return rc;
+  artemis::launch_cons_to_prim(artemis::make_pack_view(*p), S(stream));
+  return after_launch("ConsToPrim");
+}
+
+int artemis_hip_prim_to_cons(const artemis_pack_t *p, void *stream) {
+  if (int rc = validate(p)) return rc;
+  artemis::launch_prim_to_cons(artemis::make_pack_view(*p), S(stream));
+  return after_launch("PrimToCons");
+}
+
+int artemis_hip_deep_copy_conserved(const artemis_pack_t *p, void *stream) {
+  if (int rc = validate(p)) return rc;
+  artemis::launch_deep_copy(artemis::make_pack_view(*p), S(stream));
+  return after_launch("DeepCopyConservedData");
+}
+
+int artemis_hip_estimate_dt_async(const artemis_pack_t *p, int fluid, double cfl, double *dt_dev,
+                                  void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (fluid != ARTEMIS_GAS && fluid != ARTEMIS_DUST)
+    return fail(ARTEMIS_HIP_EINVAL, "Fluid type not recognized!");
+  if (!dt_dev) return fail(ARTEMIS_HIP_EINVAL, "null dt_dev");
+  const artemis_fluid_pack_t &f = (fluid == ARTEMIS_GAS) ? p->gas : p->dust;
+  if (f.nspecies == 0) return 0;
+  artemis::launch_estimate_dt(artemis::make_pack_view(*p), fluid, cfl, dt_dev, S(stream));
+  return after_launch("EstimateTimestepMesh");
+}
+
+int artemis_hip_estimate_dt(const artemis_pack_t *p, int fluid, double cfl, double *dt_out,
+                            void *stream) {
+  if (!dt_out) return fail(ARTEMIS_HIP_EINVAL, "null dt_out");
+  if (int rc = validate(p)) return rc;
+  if (int rc = ensure_dt_scratch()) return rc;
+  *g_dt.host = DBL_MAX;
+  if (int rc = check_hip(hipMemcpyAsync(g_dt.dev, g_dt.host, sizeof(double), hipMemcpyHostToDevice,
+                                        S(stream)), "hipMemcpyAsync"))
+    return rc;
+  if (int rc = artemis_hip_estimate_dt_async(p, fluid, cfl, g_dt.dev, stream)) return rc;
+  if (int rc = check_hip(hipMemcpyAsync(g_dt.host, g_dt.dev, sizeof(double), hipMemcpyDeviceToHost,
+                                        S(stream)), "hipMemcpyAsync"))
+    return rc;
+  if (int rc = check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize")) return rc;
+  *dt_out = *g_dt.host;
+  return 0;
+}
+
+int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (!bc) return fail(ARTEMIS_HIP_EINVAL, "null bc array");
+  for (int i = 0; i < 6 * p->nblocks; ++i)
+    if (bc[i] < ARTEMIS_BC_PERIODIC || bc[i] > ARTEMIS_BC_NONE)
+      return fail(ARTEMIS_HIP_EINVAL, "unknown boundary flag %d", bc[i]);
+  const int rc = artemis::launch_apply_bc(artemis::make_pack_view(*p), bc, S(stream));
+  if (rc == 1) return fail(ARTEMIS_HIP_EDEVICE, "could not read pointer tables from the device");
+  if (rc == 2) return fail(ARTEMIS_HIP_EUNSUPPORTED, "too many FillGhost variables (max 64)");
+  return after_launch("ApplyBoundaryConditions");
+}
+
+long artemis_hip_halo_count(const artemis_pack_t *p, int face) {
+  if (!p || face < 0 || face > 5) return -1;
+  return artemis::halo_count(artemis::make_pack_view(*p), face);
+}
+static int halo_common(const artemis_pack_t *p, int block, int face, double *buf, int unpack,
+                       void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (block < 0 || block >= p->nblocks) return fail(ARTEMIS_HIP_EINVAL, "bad block %d", block);
+  if (face < 0 || face > 5) return fail(ARTEMIS_HIP_EINVAL, "bad face %d", face);
+  const artemis::PackView P = artemis::make_pack_view(*p);
+  if (face / 2 >= P.ndim) return fail(ARTEMIS_HIP_EINVAL, "face %d is not an active direction", face);
+  if (!buf) return fail(ARTEMIS_HIP_EINVAL, "null halo buffer");
+  const int rc = artemis::launch_halo(P, block, face, buf, unpack, S(stream));
+  if (rc == 1) return fail(ARTEMIS_HIP_EDEVICE, "could not read pointer tables from the device");
+  if (rc == 2) return fail(ARTEMIS_HIP_EUNSUPPORTED, "too many FillGhost variables (max 64)");
+  return after_launch(unpack ? "halo unpack" : "halo pack");
+}
+int artemis_hip_halo_pack(const artemis_pack_t *p, int block, int face, double *buf, void *stream) {
+  return halo_common(p, block, face, buf, 0, stream);
+}
+int artemis_hip_halo_unpack(const artemis_pack_t *p, int block, int face, const double *buf,
+                            void *stream) {
+  return halo_common(p, block, face, const_cast<double *>(buf), 1, stream);
+}
+
+int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");
+  if (p->gas.nspecies != 1 || p->dust.nspecies != 0)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "fused stage: one gas species, no dust (DESIGN.md)");
+  if (int rc = validate_fluid(p, ARTEMIS_GAS, a->pcm)) return rc;
+  if (!a->prim_in || !a->prim_u1 || !a->prim_out)
+    return fail(ARTEMIS_HIP_EINVAL, "fused stage: prim_in / prim_u1 / prim_out are required");
+  if (a->prim_in == a->prim_out)
+    return fail(ARTEMIS_HIP_EINVAL, "fused stage: prim_out must not alias prim_in");
+  const int recon = a->pcm ? ARTEMIS_PCM : p->gas.recon;
+  const int rc = artemis::launch_stage_fused(artemis::make_pack_view(*p), *a, p->gas.riemann, recon,
+                                             S(stream));
+  if (rc) return fail(ARTEMIS_HIP_EUNSUPPORTED, "fused stage: configuration not built (rc=%d)", rc);
+  return after_launch("stage_fused");
+}
+
+// ---- runtime shim (include/artemis_rt.h) ------------------------------------------------
+int artemis_rt_set_device(int dev) {
+  if (int rc = device_ready()) return rc;
+  return check_hip(hipSetDevice(dev), "hipSetDevice");
+}
+void *artemis_rt_malloc(size_t bytes) {
+  if (device_ready()) return nullptr;
+  void *p = nullptr;
+  if (check_hip(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc")) return nullptr;
+  return p;
+}
+void artemis_rt_free(void *p) {
+  if (p) (void)hipFree(p);
+}
+void *artemis_rt_malloc_host(size_t bytes) {
+  if (device_ready()) return nullptr;
+  void *p = nullptr;
+  if (check_hip(hipHostMalloc(&p, bytes ? bytes : 8), "hipHostMalloc")) return nullptr;
+  return p;
+}
+void artemis_rt_free_host(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+int artemis_rt_memcpy_h2d(void *dst, const void *src, size_t n, void *stream) {
+  return check_hip(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, S(stream)), "memcpy h2d");
+}
+int artemis_rt_memcpy_d2h(void *dst, const void *src, size_t n, void *stream) {
+  return check_hip(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, S(stream)), "memcpy d2h");
+}
+int artemis_rt_memcpy_d2d(void *dst, const void *src, size_t n, void *stream) {
+  return check_hip(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, S(stream)), "memcpy d2d");
+}
+int artemis_rt_memset(void *dst, int value, size_t n, void *stream) {
+  return check_hip(hipMemsetAsync(dst, value, n, S(stream)), "memset");
+}
+void *artemis_rt_stream_create(void) {
+  if (device_ready()) return nullptr;
+  hipStream_t s = nullptr;
+  if (check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
+  return s;
+}
+void artemis_rt_stream_destroy(void *s) {
+  if (s) (void)hipStreamDestroy(S(s));
+}
+int artemis_rt_stream_sync(void *s) { return check_hip(hipStreamSynchronize(S(s)), "stream sync"); }
+int artemis_rt_device_sync(void) { return check_hip(hipDeviceSynchronize(), "device sync"); }
+void *artemis_rt_event_create(void) {
+  if (device_ready()) return nullptr;
+  hipEvent_t e = nullptr;
+  if (check_hip(hipEventCreate(&e), "hipEventCreate")) return nullptr;
+  return e;
+}
+void artemis_rt_event_destroy(void *e) {
+  if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+}
+int artemis_rt_event_record(void *e, void *stream) {
+  return check_hip(hipEventRecord(static_cast<hipEvent_t>(e), S(stream)), "event record");
+}
+int artemis_rt_stream_wait_event(void *stream, void *e) {
+  return check_hip(hipStreamWaitEvent(S(stream), static_cast<hipEvent_t>(e), 0), "stream wait event");
+}
+int artemis_rt_event_sync(void *e) {
+  return check_hip(hipEventSynchronize(static_cast<hipEvent_t>(e)), "event sync");
+}
+double artemis_rt_event_elapsed_ms(void *e0, void *e1) {
+  float ms = -1.0f;
+  if (hipEventElapsedTime(&ms, static_cast<hipEvent_t>(e0), static_cast<hipEvent_t>(e1)) != hipSuccess)
+    return -1.0;
+  return ms;
+}
+void artemis_rt_tables_changed(void) { artemis::invalidate_table_cache(); }
+
+} // extern "C"

@@ -1,0 +1,23 @@
+// Host-side launchers of the HIP kernels (internal; the public surface is include/artemis_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pack_view.hpp"
+
+namespace artemis {
+void launch_calculate_fluxes(const PackView &P, int fluid, int riemann, int recon, hipStream_t s);
+void launch_apply_update(const PackView &P, double gam0, double gam1, double beta_dt, hipStream_t s);
+void launch_flux_source_gas(const PackView &P, double dt, hipStream_t s);
+void launch_set_aux(const PackView &P, hipStream_t s);
+void launch_cons_to_prim(const PackView &P, hipStream_t s);
+void launch_prim_to_cons(const PackView &P, hipStream_t s);
+void launch_deep_copy(const PackView &P, hipStream_t s);
+void launch_estimate_dt(const PackView &P, int fluid, double cfl, double *dt_dev, hipStream_t s);
+int launch_apply_bc(const PackView &P, const int *bc, hipStream_t s);
+long halo_count(const PackView &P, int face);
+int launch_halo(const PackView &P, int block, int face, double *buf, int unpack, hipStream_t s);
+void invalidate_table_cache();
+// kernels_fused.hip
+int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon,
+                       hipStream_t s);
+} // namespace artemis

@@ -1,0 +1,579 @@
+// One HIP kernel per Parthenon task of the reference's stage (artemis_driver.cpp:182-261).
+// These back the per-task C-ABI entry points (drop-in granularity); the fast path is the
+// fused stage kernel in kernels_fused.hip, which must agree with this chain bit for bit.
+//
+// Thread mapping everywhere: threadIdx.x walks i (contiguous, coalesced 8-byte lanes),
+// blockIdx.y/threadIdx.y walk j, blockIdx.z walks (block, k).
+#include <cfloat>
+#include <vector>
+
+#include "device_math.hpp"
+#include "kernels.hpp"
+#include "pack_view.hpp"
+
+namespace artemis {
+
+namespace {
+constexpr int TX = 64, TY = 4;
+
+struct Range3 {
+  int il, iu, jl, ju, kl, ku;
+};
+inline dim3 grid_for(const Range3 &r, int nb) {
+  const int nx = r.iu - r.il + 1, ny = r.ju - r.jl + 1, nz = r.ku - r.kl + 1;
+  return dim3((nx + TX - 1) / TX, (ny + TY - 1) / TY, nz * nb);
+}
+#define CELL_FROM_GRID(r)                                                                  \
+  const int i = (r).il + blockIdx.x * TX + threadIdx.x;                                    \
+  const int j = (r).jl + blockIdx.y * TY + threadIdx.y;                                    \
+  const int nkr = (r).ku - (r).kl + 1;                                                     \
+  const int b = blockIdx.z / nkr;                                                          \
+  const int k = (r).kl + blockIdx.z % nkr;                                                 \
+  if (i > (r).iu || j > (r).ju) return;                                                    \
+  const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
+
+// ---------------------------------------------------------------------------------------
+// CalculateFluxesImpl (fluid_fluxes.hpp:78-213): one thread per FACE.  The thread
+// reconstructs the upper face value of the cell below the face and the lower face value of
+// the cell above it straight from global memory (neighbouring threads share those lines in
+// L1/L2), then solves the Riemann problem and writes the 8 (gas) / 4 (dust) face outputs.
+template <int FLUID, int RIEMANN, int RECON>
+__global__ __launch_bounds__(TX *TY) void flux_kernel(const PackView P, const Range3 r,
+                                                      const int dir) {
+  CELL_FROM_GRID(r)
+  const FluidView &f = (FLUID == 0) ? P.gas : P.dust;
+  const int ns = f.ns;
+  const int nv = (FLUID == 0) ? 6 * ns : 4 * ns;
+  const long st = (dir == 1) ? 1 : ((dir == 2) ? P.sj : P.sk);
+  const int d = dir - 1;
+  for (int n = 0; n < ns; ++n) {
+    const int IDN = n;
+    const int ivx = ns + 3 * n + d;
+    const int ivy = ns + 3 * n + (d + 1) % 3;
+    const int ivz = ns + 3 * n + (d + 2) % 3;
+    const int IPR = 4 * ns + n, ISE = 5 * ns + n;
+    double unused;
+    FaceFlux F;
+    if constexpr (FLUID == 0) {
+      Prim6 L, R;
+      const double *q;
+      q = f.prim[b * nv + IDN] + c;
+      recon_cell<RECON>(q - st, st, L.d, unused), recon_cell<RECON>(q, st, unused, R.d);
+      q = f.prim[b * nv + ivx] + c;
+      recon_cell<RECON>(q - st, st, L.vx, unused), recon_cell<RECON>(q, st, unused, R.vx);
+      q = f.prim[b * nv + ivy] + c;
+      recon_cell<RECON>(q - st, st, L.vy, unused), recon_cell<RECON>(q, st, unused, R.vy);
+      q = f.prim[b * nv + ivz] + c;
+      recon_cell<RECON>(q - st, st, L.vz, unused), recon_cell<RECON>(q, st, unused, R.vz);
+      q = f.prim[b * nv + IPR] + c;
+      recon_cell<RECON>(q - st, st, L.p, unused), recon_cell<RECON>(q, st, unused, R.p);
+      q = f.prim[b * nv + ISE] + c;
+      recon_cell<RECON>(q - st, st, L.e, unused), recon_cell<RECON>(q, st, unused, R.e);
+      riemann_gas<RIEMANN>(P.gm1, L, R, F);
+      f.flux[d][b * nv + IDN][c] = F.fd;
+      f.flux[d][b * nv + ivx][c] = F.fmx;
+      f.flux[d][b * nv + ivy][c] = F.fmy;
+      f.flux[d][b * nv + ivz][c] = F.fmz;
+      f.flux[d][b * nv + IPR][c] = F.fe;  // IEN shares the IPR slot (hllc.hpp:72)
+      f.flux[d][b * nv + ISE][c] = F.feg; // IEG shares the ISE slot (hllc.hpp:73)
+      f.pflux[d][b * ns + n][c] = F.pf;
+      f.vface[d][b * ns + n][c] = F.vf;
+    } else {
+      Prim4 L, R;
+      const double *q;
+      q = f.prim[b * nv + IDN] + c;
+      recon_cell<RECON>(q - st, st, L.d, unused), recon_cell<RECON>(q, st, unused, R.d);
+      q = f.prim[b * nv + ivx] + c;
+      recon_cell<RECON>(q - st, st, L.vx, unused), recon_cell<RECON>(q, st, unused, R.vx);
+      q = f.prim[b * nv + ivy] + c;
+      recon_cell<RECON>(q - st, st, L.vy, unused), recon_cell<RECON>(q, st, unused, R.vy);
+      q = f.prim[b * nv + ivz] + c;
+      recon_cell<RECON>(q - st, st, L.vz, unused), recon_cell<RECON>(q, st, unused, R.vz);
+      riemann_dust<RIEMANN>(L, R, F);
+      f.flux[d][b * nv + IDN][c] = F.fd;
+      f.flux[d][b * nv + ivx][c] = F.fmx;
+      f.flux[d][b * nv + ivy][c] = F.fmy;
+      f.flux[d][b * nv + ivz][c] = F.fmz;
+    }
+  }
+}
+
+template <int FLUID, int RIEMANN, int RECON>
+void launch_flux_dirs(const PackView &P, hipStream_t s) {
+  for (int dir = 1; dir <= P.ndim; ++dir) {
+    Range3 r{P.is, P.ie, P.js, P.je, P.ks, P.ke};
+    if (dir == 1) r.iu = P.ie + 1; // fluid_fluxes.hpp:105
+    if (dir == 2) r.ju = P.je + 1; // :130 (faces js..je+1)
+    if (dir == 3) r.ku = P.ke + 1; // :172
+    hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON>), grid_for(r, P.nb), dim3(TX, TY), 0, s,
+                       P, r, dir);
+  }
+}
+template <int FLUID, int RIEMANN>
+void launch_flux_recon(const PackView &P, int recon, hipStream_t s) {
+  if (recon == ARTEMIS_PCM) launch_flux_dirs<FLUID, RIEMANN, 0>(P, s);
+  else if (recon == ARTEMIS_PLM) launch_flux_dirs<FLUID, RIEMANN, 1>(P, s);
+  else launch_flux_dirs<FLUID, RIEMANN, 2>(P, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// ApplyUpdate (artemis_integrator.hpp:79-108)
+template <int FLUID>
+__device__ __forceinline__ void update_fluid(const PackView &P, const FluidView &f, int b, long c,
+                                             const CellGeom &g, double gam0, double gam1,
+                                             double beta_dt) {
+  const int nv = (FLUID == 0 ? 6 : 4) * f.ns;
+  const bool multi_d = P.ndim > 1, three_d = P.ndim > 2;
+  const double ax1 = g.dx2 * g.dx3; // geometry.hpp:199-204
+  const double ax2 = g.dx1 * g.dx3; // :205-210
+  const double ax3 = g.dx1 * g.dx2; // :211-216
+  const double vol = g.dx1 * g.dx2 * g.dx3; // :219-225
+  for (int n = 0; n < nv; ++n) {
+    const double *f1 = f.flux[0][b * nv + n];
+    double divf = (ax1 * f1[c] - ax1 * f1[c + 1]);
+    if (multi_d) {
+      const double *f2 = f.flux[1][b * nv + n];
+      divf += (ax2 * f2[c] - ax2 * f2[c + P.sj]);
+    }
+    if (three_d) {
+      const double *f3 = f.flux[2][b * nv + n];
+      divf += (ax3 * f3[c] - ax3 * f3[c + P.sk]);
+    }
+    double *v0 = f.cons0[b * nv + n];
+    const double *v1 = f.cons1[b * nv + n];
+    v0[c] = gam0 * v0[c] + gam1 * v1[c] + divf * beta_dt / vol;
+  }
+}
+__global__ __launch_bounds__(TX *TY) void apply_update_kernel(const PackView P, const Range3 r,
+                                                              double gam0, double gam1,
+                                                              double beta_dt) {
+  CELL_FROM_GRID(r)
+  const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
+  if (P.gas.ns) update_fluid<0>(P, P.gas, b, c, g, gam0, gam1, beta_dt);
+  if (P.dust.ns) update_fluid<1>(P, P.dust, b, c, g, gam0, gam1, beta_dt);
+}
+
+// ---------------------------------------------------------------------------------------
+// FluxSourceImpl, gas, Cartesian (fluid_fluxes.hpp:323-393).  Interior cells only.
+__global__ __launch_bounds__(TX *TY) void flux_source_kernel(const PackView P, const Range3 r,
+                                                             double dt) {
+  CELL_FROM_GRID(r)
+  const FluidView &f = P.gas;
+  const int ns = f.ns, nv = 6 * ns;
+  const bool multi_d = P.ndim >= 2, three_d = P.ndim == 3;
+  const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
+  const double ax1 = g.dx2 * g.dx3, ax2 = g.dx1 * g.dx3, ax3 = g.dx1 * g.dx2;
+  const double vol = g.dx1 * g.dx2 * g.dx3;
+  for (int n = 0; n < ns; ++n) {
+    double *mx = f.cons0[b * nv + ns + 3 * n + 0];
+    double *my = f.cons0[b * nv + ns + 3 * n + 1];
+    double *mz = f.cons0[b * nv + ns + 3 * n + 2];
+    double *eg = f.cons0[b * nv + 5 * ns + n];
+    const double *p1 = f.pflux[0][b * ns + n], *v1 = f.vface[0][b * ns + n];
+    double m = mx[c], e = eg[c];
+    m += dt / g.dx1 * (p1[c] - p1[c + 1]);
+    e -= dt / vol * 0.5 * (p1[c] + p1[c + 1]) * (ax1 * v1[c + 1] - ax1 * v1[c]);
+    mx[c] = m;
+    if (multi_d) {
+      const double *p2 = f.pflux[1][b * ns + n], *v2 = f.vface[1][b * ns + n];
+      double m2 = my[c];
+      m2 += dt / g.dx2 * (p2[c] - p2[c + P.sj]);
+      e -= dt / vol * 0.5 * (p2[c] + p2[c + P.sj]) * (ax2 * v2[c + P.sj] - ax2 * v2[c]);
+      my[c] = m2;
+    }
+    if (three_d) {
+      const double *p3 = f.pflux[2][b * ns + n], *v3 = f.vface[2][b * ns + n];
+      double m3 = mz[c];
+      m3 += dt / g.dx3 * (p3[c] - p3[c + P.sk]);
+      e -= dt / vol * 0.5 * (p3[c] + p3[c + P.sk]) * (ax3 * v3[c + P.sk] - ax3 * v3[c]);
+      mz[c] = m3;
+    }
+    eg[c] = e;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// SetAuxillaryFields (fill_derived.cpp:54-73) + GetSpecificInternalEnergy
+// (artemis_utils.hpp:43-62); Cartesian scale factors are 1.
+__global__ __launch_bounds__(TX *TY) void set_aux_kernel(const PackView P, const Range3 r) {
+  CELL_FROM_GRID(r)
+  const FluidView &f = P.gas;
+  const int ns = f.ns, nv = 6 * ns;
+  for (int n = 0; n < ns; ++n) {
+    const double D = f.cons0[b * nv + n][c];
+    const double u_d = (D > f.dfloor) ? D : f.dfloor;
+    const double u_d2 = amax(D, f.dfloor);
+    const double rv1 = f.cons0[b * nv + ns + 3 * n + 0][c] / 1.0;
+    const double rv2 = f.cons0[b * nv + ns + 3 * n + 1][c] / 1.0;
+    const double rv3 = f.cons0[b * nv + ns + 3 * n + 2][c] / 1.0;
+    const double ke = 0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)) / u_d2;
+    const double e_cons = f.cons0[b * nv + 4 * ns + n][c];
+    const double ue_cons = e_cons - ke;
+    double *eg = f.cons0[b * nv + 5 * ns + n];
+    double sie = (ue_cons > f.de_switch * e_cons) ? ue_cons / u_d2 : eg[c] / u_d2;
+    sie = amax(sie, f.siefloor);
+    double u_u = sie * u_d;
+    const double uflr = f.siefloor * u_d;
+    u_u = (u_u > uflr) ? u_u : uflr;
+    eg[c] = u_u;
+  }
+}
+
+// ConsToPrim (fill_derived.cpp:120-166), interior
+__global__ __launch_bounds__(TX *TY) void cons_to_prim_kernel(const PackView P, const Range3 r) {
+  CELL_FROM_GRID(r)
+  {
+    const FluidView &f = P.gas;
+    const int ns = f.ns, nv = 6 * ns;
+    for (int n = 0; n < ns; ++n) {
+      const double u_d = f.cons0[b * nv + n][c];
+      const double w_d = (u_d > f.dfloor) ? u_d : f.dfloor;
+      f.prim[b * nv + n][c] = w_d;
+      for (int d = 0; d < 3; ++d)
+        f.prim[b * nv + ns + 3 * n + d][c] = f.cons0[b * nv + ns + 3 * n + d][c] / (w_d * 1.0);
+      const double w_s = f.cons0[b * nv + 5 * ns + n][c] / w_d;
+      f.prim[b * nv + 5 * ns + n][c] = (w_s > f.siefloor) ? w_s : f.siefloor;
+    }
+  }
+  {
+    const FluidView &f = P.dust;
+    const int ns = f.ns, nv = 4 * ns;
+    for (int n = 0; n < ns; ++n) {
+      const double u_d = f.cons0[b * nv + n][c];
+      const double w_d = (u_d > f.dfloor) ? u_d : f.dfloor;
+      f.prim[b * nv + n][c] = w_d;
+      for (int d = 0; d < 3; ++d)
+        f.prim[b * nv + ns + 3 * n + d][c] = f.cons0[b * nv + ns + 3 * n + d][c] / (w_d * 1.0);
+    }
+  }
+}
+
+// PrimToCons (fill_derived.cpp:212-276), entire block.  P = IdealGas (gm1*rho)*sie clamped
+// at 0 (singularity-eos, recalled).
+__global__ __launch_bounds__(TX *TY) void prim_to_cons_kernel(const PackView P, const Range3 r) {
+  CELL_FROM_GRID(r)
+  {
+    const FluidView &f = P.gas;
+    const int ns = f.ns, nv = 6 * ns;
+    for (int n = 0; n < ns; ++n) {
+      double w_d = f.prim[b * nv + n][c];
+      w_d = (w_d > f.dfloor) ? w_d : f.dfloor;
+      f.prim[b * nv + n][c] = w_d;
+      f.cons0[b * nv + n][c] = w_d;
+      const double vel1 = f.prim[b * nv + ns + 3 * n + 0][c];
+      const double vel2 = f.prim[b * nv + ns + 3 * n + 1][c];
+      const double vel3 = f.prim[b * nv + ns + 3 * n + 2][c];
+      f.cons0[b * nv + ns + 3 * n + 0][c] = w_d * vel1 * 1.0;
+      f.cons0[b * nv + ns + 3 * n + 1][c] = w_d * vel2 * 1.0;
+      f.cons0[b * nv + ns + 3 * n + 2][c] = w_d * vel3 * 1.0;
+      double w_s = f.prim[b * nv + 5 * ns + n][c];
+      w_s = (w_s > f.siefloor) ? w_s : f.siefloor;
+      f.prim[b * nv + 5 * ns + n][c] = w_s;
+      const double u_u = w_s * w_d;
+      f.cons0[b * nv + 5 * ns + n][c] = u_u;
+      f.prim[b * nv + 4 * ns + n][c] = amax(0.0, P.gm1 * w_d * w_s);
+      const double ke = 0.5 * w_d * (sqr(vel1) + sqr(vel2) + sqr(vel3));
+      f.cons0[b * nv + 4 * ns + n][c] = u_u + ke;
+    }
+  }
+  {
+    const FluidView &f = P.dust;
+    const int ns = f.ns, nv = 4 * ns;
+    for (int n = 0; n < ns; ++n) {
+      double w_d = f.prim[b * nv + n][c];
+      w_d = (w_d > f.dfloor) ? w_d : f.dfloor;
+      f.prim[b * nv + n][c] = w_d;
+      f.cons0[b * nv + n][c] = w_d;
+      for (int d = 0; d < 3; ++d)
+        f.cons0[b * nv + ns + 3 * n + d][c] = w_d * f.prim[b * nv + ns + 3 * n + d][c] * 1.0;
+    }
+  }
+}
+
+// DeepCopyConservedData (artemis_integrator.hpp:42-49), entire block
+__global__ __launch_bounds__(TX *TY) void deep_copy_kernel(const PackView P, const Range3 r) {
+  CELL_FROM_GRID(r)
+  for (int n = 0; n < 6 * P.gas.ns; ++n)
+    P.gas.cons1[b * 6 * P.gas.ns + n][c] = P.gas.cons0[b * 6 * P.gas.ns + n][c];
+  for (int n = 0; n < 4 * P.dust.ns; ++n)
+    P.dust.cons1[b * 4 * P.dust.ns + n][c] = P.dust.cons0[b * 4 * P.dust.ns + n][c];
+}
+
+// ---------------------------------------------------------------------------------------
+// EstimateTimestepMesh (gas.cpp:411-433, dust.cpp:256-272): wave64 shuffle min -> LDS min over
+// the 4 waves -> one atomicMin per workgroup on the bit pattern (positive doubles order like
+// unsigned integers).
+template <int FLUID>
+__global__ __launch_bounds__(TX *TY) void estimate_dt_kernel(const PackView P, const Range3 r,
+                                                             double cfl,
+                                                             unsigned long long *dt_bits) {
+  const int i = r.il + blockIdx.x * TX + threadIdx.x;
+  const int j = r.jl + blockIdx.y * TY + threadIdx.y;
+  const int nkr = r.ku - r.kl + 1;
+  const int b = blockIdx.z / nkr;
+  const int k = r.kl + blockIdx.z % nkr;
+  double ldt = DBL_MAX;
+  if (i <= r.iu && j <= r.ju) {
+    const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
+    const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
+    const double dx[3] = {1.0 * g.dx1, 1.0 * g.dx2, 1.0 * g.dx3};
+    const FluidView &f = (FLUID == 0) ? P.gas : P.dust;
+    const int ns = f.ns, nv = (FLUID == 0 ? 6 : 4) * ns;
+    for (int n = 0; n < ns; ++n) {
+      double denom = 0.0;
+      if constexpr (FLUID == 0) {
+        const double dens = f.prim[b * nv + n][c];
+        const double sie = f.prim[b * nv + 5 * ns + n][c];
+        const double bulk = (P.gm1 + 1.0) * P.gm1 * dens * sie; // IdealGas bulk modulus
+        const double cs = sqrt(bulk / dens);
+        for (int d = 0; d < P.ndim; d++) {
+          const double ss = fabs(f.prim[b * nv + ns + 3 * n + d][c]) + cs;
+          denom += ss / dx[d];
+        }
+      } else {
+        for (int d = 0; d < P.ndim; d++) denom += fabs(f.prim[b * nv + ns + 3 * n + d][c]) / dx[d];
+      }
+      ldt = amin(ldt, 1.0 / denom);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) ldt = fmin(ldt, __shfl_down(ldt, off, 64));
+  __shared__ double wmin[TY];
+  const int lane = threadIdx.x, wave = threadIdx.y;
+  if (lane == 0) wmin[wave] = ldt;
+  __syncthreads();
+  if (wave == 0 && lane == 0) {
+    double m = wmin[0];
+    for (int w = 1; w < TY; ++w) m = fmin(m, wmin[w]);
+    atomicMin(dt_bits, static_cast<unsigned long long>(__double_as_longlong(cfl * m)));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Ghost fill of one face of one block (see artemis_hip_apply_bc).  The slab spans the ENTIRE
+// extent of the other two dimensions.  `table` holds nfill pointers chosen by the host:
+// gas rho, v, sie and dust rho, v (pressure is not FillGhost).
+struct BcArgs {
+  int d, side, bc;    // direction 0..2, 0 inner / 1 outer, artemis_bc
+  int nfill;          // entries used in ptrs/normal
+  int n_act;          // interior cells along d
+  int st, en;         // interior bounds along d
+  int ng;
+};
+constexpr int MAX_FILL = 64;
+struct BcTable {
+  double *ptr[MAX_FILL];
+  signed char normal[MAX_FILL]; // 1 if this variable is the velocity component along d
+};
+
+__global__ __launch_bounds__(256) void bc_kernel(const BcArgs a, const BcTable t, int ni, int nj,
+                                                 int nk) {
+  // slab extents: ng along d, full extent along the others
+  int ext[3] = {ni, nj, nk};
+  ext[a.d] = a.ng;
+  const long ncell = static_cast<long>(ext[0]) * ext[1] * ext[2];
+  const long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (tid >= ncell) return;
+  int idx[3];
+  idx[0] = tid % ext[0];
+  idx[1] = (tid / ext[0]) % ext[1];
+  idx[2] = tid / (static_cast<long>(ext[0]) * ext[1]);
+  const int g = idx[a.d];
+  int gi, si;
+  if (a.side == 0) {
+    gi = a.st - 1 - g;
+    si = (a.bc == ARTEMIS_BC_PERIODIC) ? gi + a.n_act
+                                       : ((a.bc == ARTEMIS_BC_OUTFLOW) ? a.st : 2 * a.st - 1 - gi);
+  } else {
+    gi = a.en + 1 + g;
+    si = (a.bc == ARTEMIS_BC_PERIODIC) ? gi - a.n_act
+                                       : ((a.bc == ARTEMIS_BC_OUTFLOW) ? a.en : 2 * a.en + 1 - gi);
+  }
+  int dst[3] = {idx[0], idx[1], idx[2]}, src[3] = {idx[0], idx[1], idx[2]};
+  dst[a.d] = gi, src[a.d] = si;
+  const long cd = (static_cast<long>(dst[2]) * nj + dst[1]) * ni + dst[0];
+  const long cs = (static_cast<long>(src[2]) * nj + src[1]) * ni + src[0];
+  for (int v = 0; v < a.nfill; ++v) {
+    const double sgn = (a.bc == ARTEMIS_BC_REFLECT && t.normal[v]) ? -1.0 : 1.0;
+    t.ptr[v][cd] = sgn * t.ptr[v][cs];
+  }
+}
+
+// Halo slab pack/unpack: slab spans the INTERIOR extent of the other dimensions.
+struct HaloArgs {
+  int d, side, ng, nfill;
+  int lo[3], n[3]; // slab origin and extents (in cells)
+};
+__global__ __launch_bounds__(256) void halo_kernel(const HaloArgs a, const BcTable t, int ni, int nj,
+                                                   double *buf, int unpack) {
+  const long ncell = static_cast<long>(a.n[0]) * a.n[1] * a.n[2];
+  const long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (tid >= ncell) return;
+  const int i = a.lo[0] + tid % a.n[0];
+  const int j = a.lo[1] + (tid / a.n[0]) % a.n[1];
+  const int k = a.lo[2] + tid / (static_cast<long>(a.n[0]) * a.n[1]);
+  const long c = (static_cast<long>(k) * nj + j) * ni + i;
+  for (int v = 0; v < a.nfill; ++v) {
+    if (unpack) t.ptr[v][c] = buf[v * ncell + tid];
+    else buf[v * ncell + tid] = t.ptr[v][c];
+  }
+}
+
+} // namespace
+
+// =======================================================================================
+// Host launchers (declared in kernels.hpp)
+#define DISPATCH_GAS(RS)                                                                   \
+  case RS: launch_flux_recon<0, RS>(P, recon, s); break;
+
+void launch_calculate_fluxes(const PackView &P, int fluid, int riemann, int recon, hipStream_t s) {
+  if (fluid == ARTEMIS_GAS) {
+    switch (riemann) {
+      DISPATCH_GAS(0)
+      DISPATCH_GAS(1)
+      DISPATCH_GAS(2)
+    }
+  } else {
+    if (riemann == ARTEMIS_HLLE) launch_flux_recon<1, 1>(P, recon, s);
+    else launch_flux_recon<1, 2>(P, recon, s);
+  }
+}
+
+static Range3 interior(const PackView &P) { return Range3{P.is, P.ie, P.js, P.je, P.ks, P.ke}; }
+static Range3 entire(const PackView &P) { return Range3{0, P.ni - 1, 0, P.nj - 1, 0, P.nk - 1}; }
+
+void launch_apply_update(const PackView &P, double gam0, double gam1, double beta_dt, hipStream_t s) {
+  const Range3 r = interior(P);
+  hipLaunchKernelGGL(apply_update_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r, gam0, gam1,
+                     beta_dt);
+}
+void launch_flux_source_gas(const PackView &P, double dt, hipStream_t s) {
+  const Range3 r = interior(P);
+  hipLaunchKernelGGL(flux_source_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r, dt);
+}
+void launch_set_aux(const PackView &P, hipStream_t s) {
+  const Range3 r = interior(P);
+  hipLaunchKernelGGL(set_aux_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
+}
+void launch_cons_to_prim(const PackView &P, hipStream_t s) {
+  const Range3 r = interior(P);
+  hipLaunchKernelGGL(cons_to_prim_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
+}
+void launch_prim_to_cons(const PackView &P, hipStream_t s) {
+  const Range3 r = entire(P);
+  hipLaunchKernelGGL(prim_to_cons_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
+}
+void launch_deep_copy(const PackView &P, hipStream_t s) {
+  const Range3 r = entire(P);
+  hipLaunchKernelGGL(deep_copy_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
+}
+void launch_estimate_dt(const PackView &P, int fluid, double cfl, double *dt_dev, hipStream_t s) {
+  const Range3 r = interior(P);
+  auto *bits = reinterpret_cast<unsigned long long *>(dt_dev);
+  if (fluid == ARTEMIS_GAS)
+    hipLaunchKernelGGL(estimate_dt_kernel<0>, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r, cfl, bits);
+  else
+    hipLaunchKernelGGL(estimate_dt_kernel<1>, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r, cfl, bits);
+}
+
+// The pointer tables live on the device; the BC / halo kernels need a handful of them as
+// kernel arguments, so the host fetches the block's row once and caches it (tables are
+// rebuilt only when the mesh changes).
+struct HostTables {
+  const void *key_gas = nullptr, *key_dust = nullptr;
+  int nb = 0, nsg = 0, nsd = 0;
+  std::vector<double *> gas, dust; // host copies of the prim tables
+};
+static thread_local HostTables g_tables;
+
+static int fetch_tables(const PackView &P) {
+  HostTables &T = g_tables;
+  if (T.key_gas == P.gas.prim && T.key_dust == P.dust.prim && T.nb == P.nb && T.nsg == P.gas.ns &&
+      T.nsd == P.dust.ns)
+    return 0;
+  T.gas.assign(static_cast<size_t>(P.nb) * 6 * P.gas.ns, nullptr);
+  T.dust.assign(static_cast<size_t>(P.nb) * 4 * P.dust.ns, nullptr);
+  if (!T.gas.empty() &&
+      hipMemcpy(T.gas.data(), P.gas.prim, T.gas.size() * sizeof(double *), hipMemcpyDeviceToHost) !=
+          hipSuccess)
+    return 1;
+  if (!T.dust.empty() && hipMemcpy(T.dust.data(), P.dust.prim, T.dust.size() * sizeof(double *),
+                                   hipMemcpyDeviceToHost) != hipSuccess)
+    return 1;
+  T.key_gas = P.gas.prim, T.key_dust = P.dust.prim, T.nb = P.nb, T.nsg = P.gas.ns, T.nsd = P.dust.ns;
+  return 0;
+}
+void invalidate_table_cache() { g_tables = HostTables(); }
+
+// FillGhost variables of block b: gas rho, v, sie; dust rho, v.
+static int fill_table(const PackView &P, int b, int d, BcTable &t) {
+  const HostTables &T = g_tables;
+  int n = 0;
+  const int nsg = P.gas.ns, nsd = P.dust.ns;
+  for (int v = 0; v < 6 * nsg; ++v) {
+    if (v >= 4 * nsg && v < 5 * nsg) continue; // pressure: not FillGhost (gas.cpp:251-252)
+    t.ptr[n] = T.gas[static_cast<size_t>(b) * 6 * nsg + v];
+    t.normal[n] = (v >= nsg && v < 4 * nsg && ((v - nsg) % 3) == d) ? 1 : 0;
+    ++n;
+  }
+  for (int v = 0; v < 4 * nsd; ++v) {
+    t.ptr[n] = T.dust[static_cast<size_t>(b) * 4 * nsd + v];
+    t.normal[n] = (v >= nsd && ((v - nsd) % 3) == d) ? 1 : 0;
+    ++n;
+  }
+  return n;
+}
+
+int launch_apply_bc(const PackView &P, const int *bc, hipStream_t s) {
+  if (5 * P.gas.ns + 4 * P.dust.ns > MAX_FILL) return 2;
+  if (fetch_tables(P)) return 1;
+  const int n_act[3] = {P.ie - P.is + 1, P.je - P.js + 1, P.ke - P.ks + 1};
+  const int st[3] = {P.is, P.js, P.ks}, en[3] = {P.ie, P.je, P.ke};
+  for (int pass = 0; pass < 2; ++pass)
+    for (int d = 0; d < P.ndim; ++d)
+      for (int b = 0; b < P.nb; ++b)
+        for (int side = 0; side < 2; ++side) {
+          const int flag = bc[b * 6 + 2 * d + side];
+          if (flag == ARTEMIS_BC_NONE) continue;
+          if ((pass == 0) != (flag == ARTEMIS_BC_PERIODIC)) continue;
+          BcTable t;
+          BcArgs a;
+          a.d = d, a.side = side, a.bc = flag, a.n_act = n_act[d], a.st = st[d], a.en = en[d];
+          a.ng = P.ng;
+          a.nfill = fill_table(P, b, d, t);
+          int ext[3] = {P.ni, P.nj, P.nk};
+          ext[d] = P.ng;
+          const long ncell = static_cast<long>(ext[0]) * ext[1] * ext[2];
+          hipLaunchKernelGGL(bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P.ni, P.nj,
+                             P.nk);
+        }
+  return 0;
+}
+
+static void halo_args(const PackView &P, int face, int unpack, HaloArgs &a) {
+  const int d = face / 2, side = face % 2;
+  a.d = d, a.side = side, a.ng = P.ng;
+  const int st[3] = {P.is, P.js, P.ks}, en[3] = {P.ie, P.je, P.ke};
+  for (int q = 0; q < 3; ++q) a.lo[q] = st[q], a.n[q] = en[q] - st[q] + 1;
+  a.n[d] = P.ng;
+  if (!unpack) a.lo[d] = (side == 0) ? st[d] : en[d] - P.ng + 1; // interior slab next to the face
+  else a.lo[d] = (side == 0) ? st[d] - P.ng : en[d] + 1;         // ghost slab behind the face
+}
+long halo_count(const PackView &P, int face) {
+  HaloArgs a;
+  halo_args(P, face, 0, a);
+  return static_cast<long>(a.n[0]) * a.n[1] * a.n[2] * (5 * P.gas.ns + 4 * P.dust.ns);
+}
+int launch_halo(const PackView &P, int block, int face, double *buf, int unpack, hipStream_t s) {
+  if (5 * P.gas.ns + 4 * P.dust.ns > MAX_FILL) return 2;
+  if (fetch_tables(P)) return 1;
+  HaloArgs a;
+  halo_args(P, face, unpack, a);
+  BcTable t;
+  a.nfill = fill_table(P, block, a.d, t);
+  const long ncell = static_cast<long>(a.n[0]) * a.n[1] * a.n[2];
+  hipLaunchKernelGGL(halo_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P.ni, P.nj, buf,
+                     unpack);
+  return 0;
+}
+
+} // namespace artemis

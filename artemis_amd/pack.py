@@ -1,0 +1,154 @@
+"""MeshBlockPack: device arrays + pointer tables for a set of equal-sized mesh blocks, with
+methods named after the reference's Parthenon tasks (artemis_driver.cpp:145-273).  Every
+method is a single call through the C ABI of libartemis_hip.so; torch only owns the HBM
+allocations and the stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+def _ptr_table(t):
+    """Device int64 table of pointers to t[b, v] planes; t is [nb, nvar, nk, nj, ni]."""
+    nb, nv = t.shape[0], t.shape[1]
+    stride = t.stride(1) * t.element_size()
+    bstride = t.stride(0) * t.element_size()
+    base = t.data_ptr()
+    host = np.array([base + b * bstride + v * stride for b in range(nb) for v in range(nv)],
+                    dtype=np.int64)
+    return torch.from_numpy(host).to(t.device)
+
+
+class MeshBlockPack:
+    def __init__(self, nblocks, nx, xmin, xmax, ng=2, ns_gas=1, ns_dust=0, reconstruct="plm",
+                 riemann="hllc", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.66666666667,
+                 dfloor=1.0e-20, siefloor=1.0e-20, de_switch=0.0, dust_dfloor=1.0e-20,
+                 device="cuda:0", with_fluxes=True):
+        """xmin/xmax: per-block interior bounds, arrays of shape [nblocks, 3]."""
+        self.L = capi.load()
+        self.dev = torch.device(device)
+        self.nb, self.ng = nblocks, ng
+        self.nx = tuple(int(n) for n in nx)
+        self.ndim = 3 if nx[2] > 1 else (2 if nx[1] > 1 else 1)
+        g = [ng, ng if nx[1] > 1 else 0, ng if nx[2] > 1 else 0]
+        self.ni, self.nj, self.nk = nx[0] + 2 * g[0], nx[1] + 2 * g[1], nx[2] + 2 * g[2]
+        self.is_, self.js, self.ks = g
+        self.ie, self.je, self.ke = g[0] + nx[0] - 1, g[1] + nx[1] - 1, g[2] + nx[2] - 1
+        self.nsg, self.nsd = ns_gas, ns_dust
+        xmin = np.asarray(xmin, dtype=np.float64).reshape(nblocks, 3)
+        xmax = np.asarray(xmax, dtype=np.float64).reshape(nblocks, 3)
+        geom = np.zeros((nblocks, 6))
+        for d in range(3):
+            dx = (xmax[:, d] - xmin[:, d]) / nx[d]  # parthenon UniformCartesian (upstream)
+            geom[:, 2 * d] = xmin[:, d] - g[d] * dx
+            geom[:, 2 * d + 1] = dx
+        self.geom_host = geom
+        self.geom = torch.from_numpy(geom).to(self.dev)
+        shp = (self.nk, self.nj, self.ni)
+
+        def alloc(nv):
+            return torch.zeros((nblocks, max(nv, 0)) + shp, dtype=torch.float64, device=self.dev)
+
+        self.gas_prim, self.gas_u0, self.gas_u1 = alloc(6 * ns_gas), alloc(6 * ns_gas), alloc(6 * ns_gas)
+        self.dust_prim, self.dust_u0, self.dust_u1 = alloc(4 * ns_dust), alloc(4 * ns_dust), alloc(4 * ns_dust)
+        nf = 3 if with_fluxes else 0
+        self.gas_flux = [alloc(6 * ns_gas) for _ in range(nf)]
+        self.gas_pflux = [alloc(ns_gas) for _ in range(nf)]
+        self.gas_vface = [alloc(ns_gas) for _ in range(nf)]
+        self.dust_flux = [alloc(4 * ns_dust) for _ in range(nf)]
+        self._tables = []
+
+        def tab(t):
+            if t.shape[1] == 0:
+                return None
+            tt = _ptr_table(t)
+            self._tables.append(tt)
+            return tt.data_ptr()
+
+        p = capi.Pack()
+        p.nblocks, p.nghost = nblocks, ng
+        p.nx1, p.nx2, p.nx3 = self.nx
+        p.coords = capi.CARTESIAN
+        p.gm1 = gamma - 1.0
+        p.geom = self.geom.data_ptr()
+        p.gas.nspecies, p.gas.recon, p.gas.riemann = ns_gas, capi.RECON[reconstruct], capi.RSOLVER[riemann]
+        p.gas.dfloor, p.gas.siefloor, p.gas.de_switch = dfloor, siefloor, de_switch
+        p.gas.prim, p.gas.cons0, p.gas.cons1 = tab(self.gas_prim), tab(self.gas_u0), tab(self.gas_u1)
+        p.dust.nspecies, p.dust.recon, p.dust.riemann = ns_dust, capi.RECON[dust_reconstruct], capi.RSOLVER[dust_riemann]
+        p.dust.dfloor = dust_dfloor
+        p.dust.prim, p.dust.cons0, p.dust.cons1 = tab(self.dust_prim), tab(self.dust_u0), tab(self.dust_u1)
+        for d in range(nf):
+            p.gas.flux[d], p.gas.pflux[d], p.gas.vface[d] = tab(self.gas_flux[d]), tab(self.gas_pflux[d]), tab(self.gas_vface[d])
+            p.dust.flux[d] = tab(self.dust_flux[d])
+        self.pack = p
+        self.gas_prim_table = p.gas.prim
+        self._extra_prim = {}
+
+    # ---- helpers -------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _call(self, fn, *args):
+        capi.check(fn(C.byref(self.pack), *args, self._stream()))
+
+    def new_prim_buffer(self, name):
+        """Extra gas-prim buffer (ping-pong target of the fused stage); returns its table."""
+        t = torch.zeros_like(self.gas_prim)
+        tt = _ptr_table(t)
+        self._extra_prim[name] = (t, tt)
+        return t, tt.data_ptr()
+
+    # ---- reference task names --------------------------------------------------------------
+    def CalculateFluxes(self, fluid=capi.GAS, pcm=False):
+        self._call(self.L.artemis_hip_calculate_fluxes, fluid, int(pcm))
+
+    def ApplyUpdate(self, gam0, gam1, beta_dt):
+        self._call(self.L.artemis_hip_apply_update, gam0, gam1, beta_dt)
+
+    def FluxSource(self, dt, fluid=capi.GAS):
+        self._call(self.L.artemis_hip_flux_source, fluid, dt)
+
+    def SetAuxillaryFields(self):
+        self._call(self.L.artemis_hip_set_aux)
+
+    def ConsToPrim(self):
+        self._call(self.L.artemis_hip_cons_to_prim)
+
+    def PrimToCons(self):
+        self._call(self.L.artemis_hip_prim_to_cons)
+
+    def DeepCopyConservedData(self):
+        self._call(self.L.artemis_hip_deep_copy_conserved)
+
+    def EstimateTimestepMesh(self, fluid=capi.GAS, cfl=1.0):
+        out = C.c_double(0.0)
+        self._call(self.L.artemis_hip_estimate_dt, fluid, cfl, C.byref(out))
+        return out.value
+
+    def ApplyBoundaryConditions(self, bc):
+        """bc: per-block list of 6 names/flags (ix1, ox1, ix2, ox2, ix3, ox3)."""
+        flat = []
+        for row in bc:
+            flat += [capi.BCS[x] if isinstance(x, str) else int(x) for x in row]
+        arr = (C.c_int * len(flat))(*flat)
+        self._call(self.L.artemis_hip_apply_bc, arr)
+
+    def stage_fused(self, gam0, gam1, beta_dt, bdt, prim_in, prim_u1, prim_out, cons_out=None,
+                    pcm=False, cfl=0.0, dt_dev=None):
+        a = capi.StageArgs()
+        a.gam0, a.gam1, a.beta_dt, a.bdt, a.pcm = gam0, gam1, beta_dt, bdt, int(pcm)
+        a.prim_in, a.prim_u1, a.prim_out, a.cons_out = prim_in, prim_u1, prim_out, cons_out
+        a.cfl, a.dt_dev = cfl, dt_dev
+        self._call(self.L.artemis_hip_stage_fused, C.byref(a))
+
+    def halo_count(self, face):
+        return self.L.artemis_hip_halo_count(C.byref(self.pack), face)
+
+    def halo_pack(self, block, face, buf):
+        self._call(self.L.artemis_hip_halo_pack, block, face, C.c_void_p(buf.data_ptr()))
+
+    def halo_unpack(self, block, face, buf):
+        self._call(self.L.artemis_hip_halo_unpack, block, face, C.c_void_p(buf.data_ptr()))

@@ -1,0 +1,188 @@
+/* =======================================================================================
+ * artemis_hip.h -- C ABI of the MI355X-native finite-volume hydro update for Artemis.
+ *
+ * This is the drop-in boundary: every entry point replaces one Parthenon task / package
+ * callback of lanl/artemis (reference @ 2025-01-17; file:line cited per function, paths
+ * relative to the reference's src/).  Plain pointers and sizes only -- no Kokkos, no torch,
+ * no C++ types.  A host adapter fills `artemis_pack_t` from a MeshData's SparsePacks (see
+ * INTEGRATION.md) and forwards the call; the repo's own host driver (artemis_driver.h)
+ * fills the same struct when Parthenon is absent.
+ *
+ * Conventions
+ *  - All arrays are fp64 (`Real` = double in the reference).
+ *  - A cell array of one variable of one block is contiguous [nk][nj][ni], i fastest, with
+ *    ni = nx1 + 2*nghost, nj = nx2 + 2*nghost if nx2 > 1 else 1, nk likewise (Parthenon's
+ *    layout; ndim = 3 if nx3 > 1, else 2 if nx2 > 1, else 1).
+ *  - Face-centred quantities (fluxes, interface pressure, face velocity) of direction d are
+ *    stored at the cell index of the cell whose LOWER d-face they live on
+ *    (fluid_fluxes.hpp:119-121 writes faces [is, ie+1] at cell indices [is, ie+1]).
+ *  - Pointer tables (`double *const *`) are DEVICE arrays of DEVICE pointers, indexed
+ *    [block * nvar + var] -- exactly what a SparsePack holds.  Variable order inside a table
+ *    follows the reference's pack order (hllc.hpp:66-73, hlle.hpp:78-86, gas.cpp:479-486):
+ *      gas  prim : rho[n], vel[ns + 3n + d], P[4ns + n], sie[5ns + n]            (6*ns)
+ *      gas  cons : D[n],   mom[ns + 3n + d], E[4ns + n], eint[5ns + n]           (6*ns)
+ *      dust prim : rho[n], vel[ns + 3n + d]                                      (4*ns)
+ *      dust cons : D[n],   mom[ns + 3n + d]                                      (4*ns)
+ *    flux[d] tables use the cons order; pflux[d] / vface[d] have one entry per gas species
+ *    (the flux slot of gas.prim.pressure, hllc.hpp:166, and gas.face.velocity, hllc.hpp:179).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue
+ *    work and return; only the functions documented as synchronous wait for the device.
+ *  - Return value 0 = TaskStatus::complete.  Non-zero = error code; the message is
+ *    available from artemis_hip_last_error() (thread-local).  Nothing throws across the ABI.
+ *    PARTHENON_FAIL conditions of the reference (unknown solver / reconstruction / coordinate
+ *    system, fluid_fluxes.hpp:235,258,290; too few ghost cells, gas.cpp:61-76) map to
+ *    ARTEMIS_HIP_EINVAL.
+ * ===================================================================================== */
+#ifndef ARTEMIS_HIP_H_
+#define ARTEMIS_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARTEMIS_HIP_OK 0
+#define ARTEMIS_HIP_EINVAL 1   /* bad argument / unsupported option combination */
+#define ARTEMIS_HIP_EDEVICE 2  /* HIP runtime error (no device, launch failure, OOM) */
+#define ARTEMIS_HIP_EUNSUPPORTED 3 /* valid in the reference, not built yet */
+
+/* Enumerations use the reference's order (artemis.hpp:78-90). */
+enum artemis_coords { ARTEMIS_CARTESIAN = 0, ARTEMIS_CYLINDRICAL = 1, ARTEMIS_SPHERICAL1D = 2,
+                      ARTEMIS_SPHERICAL2D = 3, ARTEMIS_SPHERICAL3D = 4, ARTEMIS_AXISYMMETRIC = 5 };
+enum artemis_rsolver { ARTEMIS_HLLC = 0, ARTEMIS_HLLE = 1, ARTEMIS_LLF = 2 };
+enum artemis_recon { ARTEMIS_PCM = 0, ARTEMIS_PLM = 1, ARTEMIS_PPM = 2 };
+enum artemis_fluid { ARTEMIS_GAS = 0, ARTEMIS_DUST = 1 };
+/* Physical boundary flags understood by artemis_hip_apply_bc (parthenon outflow /
+ * reflecting / periodic, upstream; `none` = face is filled by a neighbour exchange). */
+enum artemis_bc { ARTEMIS_BC_PERIODIC = 0, ARTEMIS_BC_OUTFLOW = 1, ARTEMIS_BC_REFLECT = 2,
+                  ARTEMIS_BC_NONE = 3 };
+
+typedef struct artemis_fluid_pack {
+  int nspecies;              /* 0 = fluid absent (physics/gas|dust = false, artemis.cpp:63-64) */
+  int recon;                 /* <gas|dust>/reconstruct  (gas.cpp:59-82, dust.cpp:50-74)  */
+  int riemann;               /* <gas|dust>/riemann      (gas.cpp:84-96, dust.cpp:76-86); dust: hlle|llf only */
+  double dfloor;             /* <gas|dust>/dfloor       (gas.cpp:170, dust.cpp:93) */
+  double siefloor;           /* gas/siefloor            (gas.cpp:171) */
+  double de_switch;          /* gas/de_switch           (gas.cpp:177) */
+  double *const *prim;       /* [nblocks * nprim] */
+  double *const *cons0;      /* u0: [nblocks * ncons] */
+  double *const *cons1;      /* u1 (start-of-step copy, artemis_driver.cpp:157-163) */
+  double *const *flux[3];    /* [nblocks * ncons] per direction */
+  double *const *pflux[3];   /* gas only: [nblocks * ns] interface pressure */
+  double *const *vface[3];   /* gas only: [nblocks * ns] face-normal velocity */
+} artemis_fluid_pack_t;
+
+typedef struct artemis_pack {
+  int nblocks;               /* MeshData::NumBlocks() */
+  int nghost;                /* parthenon/mesh/nghost */
+  int nx1, nx2, nx3;         /* interior cells per block (parthenon/meshblock) */
+  int coords;                /* artemis/coordinates; only ARTEMIS_CARTESIAN is built */
+  double gm1;                /* gamma - 1 = IdealGas Gruneisen parameter (hllc.hpp:60) */
+  const double *geom;        /* DEVICE [nblocks][6] = {x1f0, dx1, x2f0, dx2, x3f0, dx3}:
+                                Coordinates_t::Xf<d>(idx) = xf0 + idx*dx, idx counted from the
+                                first ghost cell (geometry.hpp:65-72) */
+  artemis_fluid_pack_t gas, dust;
+} artemis_pack_t;
+
+/* ---- Parthenon task functions ---------------------------------------------------------*/
+
+/* Gas::CalculateFluxes / Dust::CalculateFluxes (gas.cpp:473-494, dust.cpp:281-298) ->
+ * ArtemisUtils::CalculateFluxes<FLUID> (fluid_fluxes.hpp:78-292).  Reads prim (stencil +-2
+ * PLM / +-3 PPM per direction), writes flux[d], and for gas pflux[d], vface[d], on faces
+ * [s, e+1] of every active direction.  `pcm` forces first-order reconstruction (VL2 stage
+ * 1, artemis_driver.cpp:182). */
+int artemis_hip_calculate_fluxes(const artemis_pack_t *p, int fluid, int pcm, void *stream);
+
+/* ArtemisUtils::ApplyUpdate<GEOM> (artemis_integrator.hpp:57-110) for every
+ * Conserved+WithFluxes variable of both fluids: u0 = gam0*u0 + gam1*u1 + beta_dt/V*div(F). */
+int artemis_hip_apply_update(const artemis_pack_t *p, double gam0, double gam1, double beta_dt,
+                             void *stream);
+
+/* Gas::FluxSource / Dust::FluxSource (gas.cpp:499-519, dust.cpp:303-326) ->
+ * FluxSourceImpl (fluid_fluxes.hpp:300-420): pressure gradient on momentum and -P div(v)
+ * on internal energy.  Interior cells only (the reference also scribbles on ghost cells
+ * [is-2, ie+1] that PrimToCons overwrites).  Cartesian dust: no-op. */
+int artemis_hip_flux_source(const artemis_pack_t *p, int fluid, double dt, void *stream);
+
+/* ArtemisDerived::SetAuxillaryFields<GEOM> (fill_derived.cpp:30-75). */
+int artemis_hip_set_aux(const artemis_pack_t *p, void *stream);
+
+/* ArtemisDerived::ConsToPrim<GEOM> (fill_derived.cpp:82-167), interior cells. */
+int artemis_hip_cons_to_prim(const artemis_pack_t *p, void *stream);
+
+/* ArtemisDerived::PrimToCons<MeshData, GEOM> (fill_derived.cpp:173-277), entire block. */
+int artemis_hip_prim_to_cons(const artemis_pack_t *p, void *stream);
+
+/* ArtemisUtils::DeepCopyConservedData (artemis_integrator.hpp:30-51): u1 <- u0, entire. */
+int artemis_hip_deep_copy_conserved(const artemis_pack_t *p, void *stream);
+
+/* Gas::EstimateTimestepMesh / Dust::EstimateTimestepMesh (gas.cpp:392-468,
+ * dust.cpp:239-276): *dt_out = cfl * min over interior cells.  SYNCHRONOUS (returns a host
+ * Real like the reference's par_reduce). */
+int artemis_hip_estimate_dt(const artemis_pack_t *p, int fluid, double cfl, double *dt_out,
+                            void *stream);
+/* Asynchronous form: min-combines cfl*min(...) into the DEVICE scalar *dt_dev (the caller
+ * initialises it, e.g. to DBL_MAX). */
+int artemis_hip_estimate_dt_async(const artemis_pack_t *p, int fluid, double cfl, double *dt_dev,
+                                  void *stream);
+
+/* Physical boundary conditions on the FillGhost primitives (gas rho, v, sie; dust rho, v;
+ * gas.cpp:244-270, dust.cpp:201-213) of every block: bc[b*6 + {ix1,ox1,ix2,ox2,ix3,ox3}]
+ * is a HOST array of artemis_bc values.  Parthenon order: periodic images first, then
+ * x1, x2, x3, each over the entire extent of the other dimensions. */
+int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, void *stream);
+
+/* ---- Fused stage (the fast path) --------------------------------------------------------
+ * One RK stage of artemis_driver.cpp:182-261 with every optional package disabled, i.e.
+ *   CalculateFluxes -> ApplyUpdate -> FluxSource -> SetAuxillaryFields -> ConsToPrim ->
+ *   [interior part of] PrimToCons
+ * in ONE pass over the block, fluxes kept in registers/LDS.  It exploits the invariant that
+ * at the start of a stage u0 == PrimToCons(prim) cell by cell (fill_derived.cpp:212-276 is
+ * applied to the entire block at the end of every stage and by PostInitialization), so the
+ * conserved state is rebuilt in registers instead of being read.
+ *
+ *   prim_in   : gas prim table at stage start (ghosts filled); read with the stencil.
+ *   prim_u1   : gas prim table of the start-of-STEP state (read cell-wise, to rebuild u1);
+ *               pass prim_in itself for stage 1.
+ *   prim_out  : where the new interior primitives go.  May alias prim_u1 (cell-wise access
+ *               only) but NOT prim_in.
+ *   cons_out  : optional cons table for u0 (NULL = do not materialise; call
+ *               artemis_hip_prim_to_cons when the conserved state is needed).
+ *   dt_dev    : optional DEVICE scalar; when non-NULL the new-state timestep estimate
+ *               cfl*min(...) of gas.cpp:411-433 is min-combined into it (fused
+ *               EstimateTimestepMesh for the last stage).
+ * Results are bit-identical to the unfused sequence above. Gas only (dust: DESIGN.md).
+ * The P entries of prim_out are written; ghosts of prim_out are NOT touched (apply_bc /
+ * halo exchange follow, as in the reference). */
+typedef struct artemis_stage_args {
+  double gam0, gam1, beta_dt; /* LowStorageIntegrator weights, artemis_integrator.hpp:64-66 */
+  double bdt;                 /* beta*dt handed to FluxSource, artemis_driver.cpp:168,211 */
+  int pcm;                    /* artemis_driver.cpp:182 */
+  double *const *prim_in, *const *prim_u1, *const *prim_out, *const *cons_out;
+  double cfl;
+  double *dt_dev;
+} artemis_stage_args_t;
+int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
+
+/* ---- Halo slabs (inter-block / inter-GPU ghost exchange of FillGhost primitives) -------
+ * Pack the `nghost`-deep interior slab adjacent to face `face` (0..5 = ix1,ox1,ix2,ox2,
+ * ix3,ox3) of block `block` into the contiguous DEVICE buffer `buf`
+ * ([nfill][slab cells], nfill = 5*ns_gas + 4*ns_dust), or unpack such a buffer into the
+ * ghost slab behind that face.  Slabs span the interior extent of the other dimensions
+ * (the hydro stencil never reads edge/corner ghosts: fluid_fluxes.hpp:105-106,130-131,
+ * 172-173).  artemis_hip_halo_count returns the number of doubles in one slab buffer. */
+long artemis_hip_halo_count(const artemis_pack_t *p, int face);
+int artemis_hip_halo_pack(const artemis_pack_t *p, int block, int face, double *buf, void *stream);
+int artemis_hip_halo_unpack(const artemis_pack_t *p, int block, int face, const double *buf,
+                            void *stream);
+
+/* ---- Library state ---------------------------------------------------------------------*/
+const char *artemis_hip_last_error(void);
+/* Number of visible HIP devices (0 = none; every compute entry point then fails loudly with
+ * ARTEMIS_HIP_EDEVICE -- there is no CPU fallback in this library). */
+int artemis_hip_device_count(void);
+const char *artemis_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTEMIS_HIP_H_ */

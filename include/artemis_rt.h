@@ -1,0 +1,47 @@
+/* =======================================================================================
+ * artemis_rt.h -- tiny device-runtime shim exported by libartemis_hip.so next to the compute
+ * entry points of artemis_hip.h.
+ *
+ * The host driver (artemis_amd/csrc/driver, plain C++ built with g++) owns no HIP code: it
+ * allocates, copies and orders work only through these calls, the way Artemis reaches the
+ * device only through Kokkos/Parthenon (DevExecSpace(), ParArray allocations, par_for
+ * launches; e.g. artemis_integrator.hpp:42, fill_derived.cpp:54).  Streams and events are
+ * hipStream_t / hipEvent_t passed as void*.
+ *
+ * All functions returning int use the artemis_hip.h error codes; pointer-returning
+ * functions return NULL on failure (message in artemis_hip_last_error()).
+ * ===================================================================================== */
+#ifndef ARTEMIS_RT_H_
+#define ARTEMIS_RT_H_
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int artemis_rt_set_device(int dev);
+void *artemis_rt_malloc(size_t bytes);      /* device memory (HBM) */
+void artemis_rt_free(void *p);
+void *artemis_rt_malloc_host(size_t bytes); /* pinned host memory */
+void artemis_rt_free_host(void *p);
+int artemis_rt_memcpy_h2d(void *dst, const void *src, size_t n, void *stream);
+int artemis_rt_memcpy_d2h(void *dst, const void *src, size_t n, void *stream);
+int artemis_rt_memcpy_d2d(void *dst, const void *src, size_t n, void *stream);
+int artemis_rt_memset(void *dst, int value, size_t n, void *stream);
+void *artemis_rt_stream_create(void);
+void artemis_rt_stream_destroy(void *stream);
+int artemis_rt_stream_sync(void *stream);
+int artemis_rt_device_sync(void);
+void *artemis_rt_event_create(void);
+void artemis_rt_event_destroy(void *ev);
+int artemis_rt_event_record(void *ev, void *stream);
+int artemis_rt_stream_wait_event(void *stream, void *ev);
+int artemis_rt_event_sync(void *ev);
+double artemis_rt_event_elapsed_ms(void *ev0, void *ev1);
+/* Call after rebuilding any pointer table in place (drops the host-side cache that
+ * artemis_hip_apply_bc / halo_pack keep of the FillGhost rows). */
+void artemis_rt_tables_changed(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTEMIS_RT_H_ */

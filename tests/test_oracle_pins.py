@@ -1,0 +1,126 @@
+"""Pin the CPU oracle against every known answer the reference's own regression tests hold
+for the hot path.  The reference executable cannot be built here
+(Parthenon/Kokkos/singularity-eos submodules are empty), so these numbers -- copied from the
+reference's test scripts, cited per test -- are what anchors parity."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+
+LW = dict(ng=4, gamma=1.66666666667, cfl=0.9, bc=("periodic",) * 6, integrator="rk2")
+
+
+def _linwave(N, recon, riem, wave, vflow):
+    # tst/scripts/hydro/linwave.py:41-63 overrides on inputs/linwave/linear_wave.in
+    o = Oracle((N, N // 2, N // 2), (0, 0, 0), (3.0, 1.5, 1.5), reconstruct=recon, riemann=riem, **LW)
+    tlim = o.pgen_linear_wave(wave, 1.0e-6, vflow)
+    o.evolve(tlim, 1000)
+    return o.linear_wave_errors()[0]
+
+
+@pytest.mark.parametrize("recon", ["plm", "ppm"])
+@pytest.mark.parametrize("riem", ["hllc", "hlle", "llf"])
+def test_linwave_thresholds(recon, riem):
+    # thresholds: tst/scripts/hydro/linwave.py:95-107
+    if recon == "plm":
+        err_thr, conv_thr = [2.23e-7, 2.23e-7, 2.21e-7], [0.29, 0.29, 0.30]
+    else:
+        err_thr, conv_thr = [1.75e-7, 1.75e-7, 1.11e-7], [0.44, 0.44, 0.42]
+    waves = [(0, 0.0), (4, 0.0), (3, 1.0)]  # L-sound, R-sound, entropy (linwave.py:64-72)
+    e32 = []
+    for wi, (wave, vflow) in enumerate(waves):
+        e16 = _linwave(16, recon, riem, wave, vflow)
+        e = _linwave(32, recon, riem, wave, vflow)
+        e32.append(e)
+        assert e <= err_thr[wi], (recon, riem, wave, e)
+        assert e / e16 <= conv_thr[wi], (recon, riem, wave, e / e16)
+    # linwave.py:135-143 compares the L and R errors as parsed from the "%e" column of
+    # -errs.dat (linear_wave.hpp:368): identical to the printed precision.
+    assert "%e" % e32[0] == "%e" % e32[1]
+
+
+def test_linwave_threshold_is_tight():
+    """The reference's thresholds sit <1% above its own results (plm+hlle sound 2.23e-7,
+    plm+llf entropy 2.21e-7): the oracle must land within that margin, not just below."""
+    assert 2.20e-7 < _linwave(32, "plm", "hlle", 0, 0.0) <= 2.23e-7
+    assert 2.19e-7 < _linwave(32, "plm", "llf", 3, 1.0) <= 2.21e-7
+    assert 1.73e-7 < _linwave(32, "ppm", "llf", 0, 0.0) <= 1.75e-7
+    assert 1.09e-7 < _linwave(32, "ppm", "llf", 3, 1.0) <= 1.11e-7
+
+
+def _advection(N, riem):
+    # tst/scripts/advection/advection.py:44-68 on inputs/advection/advection.in
+    o = Oracle((N, N // 2, N // 2), (0, 0, 0), (3.0, 1.5, 1.5), ns_gas=1, ns_dust=2,
+               reconstruct="plm", riemann=riem, dust_reconstruct="plm", dust_riemann=riem,
+               dust_cfl=0.9, **LW)
+    tlim = o.pgen_advection(1.0e-6, 1.0)
+    n = o.evolve(tlim, 1000)
+    return o, n
+
+
+@pytest.mark.parametrize("riem", ["hlle", "llf"])
+def test_advection_history_and_errors(riem):
+    def equiv(a, b, tol=1.0e-4):  # advection.py:95-99
+        return 2.0 * abs(a - b) / (abs(a) + abs(b)) <= tol
+    o16, _ = _advection(16, riem)
+    o, n = _advection(32, riem)
+    # advection.py:100-118 (history at t = 1 of the last run: llf, N = 32; hlle agrees to 1e-4)
+    assert n == 56
+    assert equiv(o.time, 1.0)
+    assert equiv(o.dt, 1.11612e-02)
+    h = o.history()
+    expected = [6.75, 2.25, 4.5, 4.5, 9.45, 6.075, 6.75, 2.25, 4.5, 4.5, 6.75, -2.25, -4.5, -4.5]
+    for got, exp in zip(h, expected):
+        assert equiv(got, exp), (got, exp)
+    # advection.py:137-178: plm thresholds for gas, dust1, dust2
+    e16, e32 = o16.advection_errors(), o.advection_errors()
+    for s in range(3):
+        assert e32[s] <= 2.21e-7
+        assert e32[s] / e16[s] <= 0.30
+    # advection.py:179-187: L- and R-going dust errors identical as printed
+    assert "%e" % e32[1] == "%e" % e32[2]
+
+
+def test_sedov_shock_radius_2d():
+    """inputs/blast/blast.in as shipped (2-D Cartesian 256^2, hlle+plm, cylindrical blast)
+    at reduced resolution: the pressure jump must sit at the Sedov radius
+    r_s = xi0 (E t^2 / rho0)^(1/4), xi0 ~= 1.0 for gamma = 1.4 in 2-D planar symmetry
+    (tst/scripts/coords/blast.py:118-183 checks the pressure profile against ExactPack with a
+    loose L2 < 1 bound; here the front position is the sharper, table-free check)."""
+    N = 128
+    o = Oracle((N, N, 1), (-1, -1, -0.5), (1, 1, 0.5), ng=2, reconstruct="plm", riemann="hlle",
+               gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3, bc=("outflow",) * 6,
+               integrator="rk2")
+    o.pgen_blast(radius=0.02, internal_energy=1.0, p0=1e-5, d0=1.0, samples=10,
+                 symmetry="cylindrical")
+    e0 = o.history()[4]
+    o.evolve(0.1, -1)
+    P = o.interior(o.gprim)[4, 0]
+    x = -1 + (np.arange(N) + 0.5) * 2.0 / N
+    X, Y = np.meshgrid(x, x)
+    r = np.hypot(X, Y)
+    r_peak = r.ravel()[np.argmax(P)]
+    r_s = 1.0 * (1.0 * 0.1 ** 2 / 1.0) ** 0.25  # ~0.316
+    assert abs(r_peak - r_s) < 0.03, (r_peak, r_s)
+    # total energy is conserved to round-off while the shock is inside the box
+    assert abs(e0 - 1.0) < 0.05  # sub-sampled deposit ~ internal_energy = 1
+    assert abs(o.history()[4] - e0) < 1e-12 * e0
+
+
+def test_leaf_edge_cases():
+    from oracle import oracle as orc
+    # plm.hpp:41: dq2 <= 0 -> zero slope; harmonic mean otherwise
+    assert orc.plm(1.0, 2.0, 1.0) == (2.0, 2.0)
+    assert orc.plm(1.0, 1.0, 1.0) == (1.0, 1.0)
+    ql, qr = orc.plm(0.0, 1.0, 3.0)
+    assert (ql, qr) == (1.0 + 2.0 / 3.0, 1.0 - 2.0 / 3.0)
+    # ppm.hpp:49-52: local extremum -> flat
+    assert orc.ppm4(0.0, 1.0, 2.0, 1.0, 0.0) == (2.0, 2.0)
+    # hllc.hpp:112-113: identical states at rest -> zero mass flux, interface pressure = P
+    w = [1.0, 0.0, 0.0, 0.0, 1.0, 1.5]
+    out = orc.riemann(0, "hllc", 2.0 / 3.0, w, w)
+    assert out[0] == 0.0 and out[6] == 1.0 and out[7] == 0.0
+    # supersonic to the right: upwind flux = left flux; energy flux includes P*v
+    wl = [1.0, 10.0, 0.0, 0.0, 1.0, 1.5]
+    out = orc.riemann(0, "hllc", 2.0 / 3.0, wl, wl)
+    assert out[0] == 10.0 and abs(out[4] - (1.5 + 50.0 + 1.0) * 10.0) < 1e-12
