@@ -1,5 +1,471 @@
-// placeholder until the fused stage kernel lands
+// Fused RK stage for gas (one species), Cartesian, PCM/PLM: CalculateFluxes -> ApplyUpdate ->
+// FluxSource -> SetAuxillaryFields -> ConsToPrim -> PrimToCons(interior) in ONE pass
+// (artemis_driver.cpp:182-261 with every optional package disabled).
+//
+// Shape of the computation on gfx950
+//   * 2.5-D streaming: a 256-thread workgroup owns a 32(i) x 8(j) column of cells and marches
+//     along k through a chunk of planes.  Each thread keeps its own cell column's rolling
+//     window (planes k, k+1, k+2), the carried left state and the carried lower x3-face flux
+//     in registers, so the x3 sweep needs no LDS and no redundant work inside a chunk.
+//   * Per plane the x1/x2 sweeps exchange only what a neighbour cannot recompute cheaply:
+//     staged primitives (with a 2-cell halo), the upper face value of the lower neighbour, and
+//     the 8 face outputs of the upper neighbour - three barriers per plane, 80 KiB of LDS per
+//     workgroup, two workgroups per CU.
+//   * Every slope and every Riemann problem inside a tile is computed exactly once; the tile's
+//     perimeter (one extra face per row/column and the two halo slopes behind it) is packed
+//     into spare waves.
+//   * The conserved state never comes from HBM: u0 = PrimToCons(prim_in) and
+//     u1 = PrimToCons(prim_u1) are rebuilt in registers (fill_derived.cpp:212-276 is applied to
+//     the whole block at the end of every stage, so this is an identity, not an approximation).
+//     Pressure of stencil cells is likewise recomputed as (gm1*rho)*sie.
+// HBM traffic per cell-stage: 5 reads (+5 for u1 after stage 1) + 6 writes instead of the
+// reference's ~124 doubles.  Results are bit-identical to the per-task kernels.
+#include <cfloat>
+
+#include "device_math.hpp"
 #include "kernels.hpp"
+#include "pack_view.hpp"
+
 namespace artemis {
-int launch_stage_fused(const PackView &, const artemis_stage_args_t &, int, int, hipStream_t) { return 99; }
+namespace {
+
+constexpr int FTX = 32, FTY = 8, FH = 2;      // tile and halo
+constexpr int QX = FTX + 2 * FH, QY = FTY + 2 * FH;
+constexpr int NT = FTX * FTY;
+
+struct StageK {
+  double gam0, gam1, beta_dt, bdt, cfl;
+  double *const *prim_in, *const *prim_u1, *const *prim_out, *const *cons_out;
+  unsigned long long *dt_bits;
+  int kchunk; // planes per chunk
+  int nchunk;
+};
+
+struct LdsTile {
+  double Q[6][QY][QX];          // staged primitives of plane k (rho, v1, v2, v3, P, sie)
+  double UPX[6][FTY][FTX + 1];  // upper x1-face value of cells i0-1 .. i0+31
+  double LOX[6][FTY];           // lower x1-face value of cell i0+32
+  double UPY[6][FTY + 1][FTX];  // upper x2-face value of rows j0-1 .. j0+7
+  double LOY[6][FTX];           // lower x2-face value of row j0+8
+  double FX[8][FTY][FTX];       // x1 faces i0+1 .. i0+32 (upper faces of the tile's cells)
+  double FY[8][FTY][FTX];       // x2 faces j0+1 .. j0+8
+};
+static_assert(sizeof(LdsTile) <= 80 * 1024, "two workgroups per CU need <= 80 KiB each");
+
+struct Cell6 {
+  double d, v1, v2, v3, p, e;
+};
+
+ADEV Cell6 load_cell(const double *__restrict__ r, const double *__restrict__ v1,
+                     const double *__restrict__ v2, const double *__restrict__ v3,
+                     const double *__restrict__ se, long c, double gm1) {
+  Cell6 q;
+  q.d = r[c], q.v1 = v1[c], q.v2 = v2[c], q.v3 = v3[c], q.e = se[c];
+  q.p = amax(0.0, gm1 * q.d * q.e); // fill_derived.cpp:247 (IdealGas P)
+  return q;
 }
+
+template <int RECON>
+ADEV double slope(double qm, double q, double qp) {
+  if constexpr (RECON == 0) return 0.0;
+  else return plm_dqm(qm, q, qp);
+}
+// q + 0.0 == q and q - 0.0 == q bitwise for every finite q except that -0.0 + 0.0 = +0.0;
+// PCM therefore bypasses the add to stay identical to pcm.hpp:34-88.
+template <int RECON>
+ADEV double up_val(double q, double dqm) {
+  if constexpr (RECON == 0) return q;
+  else return q + dqm;
+}
+template <int RECON>
+ADEV double lo_val(double q, double dqm) {
+  if constexpr (RECON == 0) return q;
+  else return q - dqm;
+}
+
+// Riemann problem of sweep direction DIR (1..3) between global-order states L and R; the
+// result is returned in GLOBAL momentum order (f.m1, f.m2, f.m3).
+struct Flux8 {
+  double d, m1, m2, m3, e, eg, pf, vf;
+};
+template <int RIEMANN, int DIR>
+ADEV Flux8 solve_face(double gm1, const Cell6 &L, const Cell6 &R) {
+  Prim6 l, r;
+  l.d = L.d, l.p = L.p, l.e = L.e, r.d = R.d, r.p = R.p, r.e = R.e;
+  if constexpr (DIR == 1) {
+    l.vx = L.v1, l.vy = L.v2, l.vz = L.v3, r.vx = R.v1, r.vy = R.v2, r.vz = R.v3;
+  } else if constexpr (DIR == 2) { // hllc.hpp:67-69: (ivx,ivy,ivz) = (v2,v3,v1)
+    l.vx = L.v2, l.vy = L.v3, l.vz = L.v1, r.vx = R.v2, r.vy = R.v3, r.vz = R.v1;
+  } else { // (v3,v1,v2)
+    l.vx = L.v3, l.vy = L.v1, l.vz = L.v2, r.vx = R.v3, r.vy = R.v1, r.vz = R.v2;
+  }
+  FaceFlux F;
+  riemann_gas<RIEMANN>(gm1, l, r, F);
+  Flux8 o;
+  o.d = F.fd, o.e = F.fe, o.eg = F.feg, o.pf = F.pf, o.vf = F.vf;
+  if constexpr (DIR == 1) o.m1 = F.fmx, o.m2 = F.fmy, o.m3 = F.fmz;
+  else if constexpr (DIR == 2) o.m2 = F.fmx, o.m3 = F.fmy, o.m1 = F.fmz;
+  else o.m3 = F.fmx, o.m1 = F.fmy, o.m2 = F.fmz;
+  return o;
+}
+
+#define FOR6(X) X(d) X(v1) X(v2) X(v3) X(p) X(e)
+
+struct Ctx { // per-thread constants of the march
+  int tx, ty, t, b, i0, j0;
+  bool active, multi_d, three_d;
+  long col, sj, sk;
+  double dx1, dx2, gm1;
+  const double *g;
+  const double *in_r, *in_1, *in_2, *in_3, *in_e;
+};
+
+ADEV void put6(double (*A)[QY][QX], int r, int c, const Cell6 &q) {
+  A[0][r][c] = q.d, A[1][r][c] = q.v1, A[2][r][c] = q.v2;
+  A[3][r][c] = q.v3, A[4][r][c] = q.p, A[5][r][c] = q.e;
+}
+#define GET6(dst, A, ...)                                                                  \
+  dst.d = A[0] __VA_ARGS__, dst.v1 = A[1] __VA_ARGS__, dst.v2 = A[2] __VA_ARGS__,          \
+  dst.v3 = A[3] __VA_ARGS__, dst.p = A[4] __VA_ARGS__, dst.e = A[5] __VA_ARGS__
+#define PUT8(A, fl, ...)                                                                   \
+  A[0] __VA_ARGS__ = fl.d, A[1] __VA_ARGS__ = fl.m1, A[2] __VA_ARGS__ = fl.m2,             \
+  A[3] __VA_ARGS__ = fl.m3, A[4] __VA_ARGS__ = fl.e, A[5] __VA_ARGS__ = fl.eg,             \
+  A[6] __VA_ARGS__ = fl.pf, A[7] __VA_ARGS__ = fl.vf
+#define GET8(fl, A, ...)                                                                   \
+  fl.d = A[0] __VA_ARGS__, fl.m1 = A[1] __VA_ARGS__, fl.m2 = A[2] __VA_ARGS__,             \
+  fl.m3 = A[3] __VA_ARGS__, fl.e = A[4] __VA_ARGS__, fl.eg = A[5] __VA_ARGS__,             \
+  fl.pf = A[6] __VA_ARGS__, fl.vf = A[7] __VA_ARGS__
+
+// One plane of the march: x1/x2 sweeps through LDS, then the cell update with the x3 face
+// fluxes handed in from registers.
+template <int RIEMANN, int RECON, bool HAS_U1, bool WRITE_CONS, bool WITH_DT>
+ADEV void plane_body(LdsTile &S, const PackView &P, const StageK &a, const Ctx &x, const int k,
+                     const Cell6 &qc, const Flux8 &fz_lo, const Flux8 &fz_hi, double &ldt) {
+  const int tx = x.tx, ty = x.ty, t = x.t;
+  const double gm1 = x.gm1;
+  const FluidView &f = P.gas;
+  // ---- P0: stage plane k (own cell + 2-cell halo in x1 and x2) ---------------------------
+  put6(S.Q, ty + FH, tx + FH, qc);
+  {
+    int hr = -1, hc = -1;
+    if (t < 4 * FTX) { // x2 halo rows: Q rows 0,1,10,11 (waves 0,1)
+      const int rr = t >> 5;
+      hr = (rr < 2) ? rr : FTY + rr;
+      hc = (t & 31) + FH;
+    } else if (t >= 128 && t < 128 + 4 * FTY) { // x1 halo columns: Q cols 0,1,34,35 (wave 2)
+      const int u = t - 128, cc = u & 3;
+      hr = (u >> 2) + FH;
+      hc = (cc < 2) ? cc : FTX + cc;
+    }
+    if (hr >= 0) {
+      const int gi = min(max(x.i0 - FH + hc, 0), P.ni - 1);
+      const int gj = min(max(x.j0 - FH + hr, 0), P.nj - 1);
+      const Cell6 h = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e,
+                                static_cast<long>(k) * x.sk + static_cast<long>(gj) * x.sj + gi, gm1);
+      put6(S.Q, hr, hc, h);
+    }
+  }
+  __syncthreads();
+  // ---- P1: slopes of the own cell; perimeter slopes on waves 2 (x1) and 3 (x2) -----------
+  Cell6 lox, loy;
+#define SLX(m, n)                                                                          \
+  {                                                                                        \
+    const double s_ =                                                                      \
+        slope<RECON>(S.Q[n][ty + FH][tx + FH - 1], qc.m, S.Q[n][ty + FH][tx + FH + 1]);    \
+    lox.m = lo_val<RECON>(qc.m, s_);                                                       \
+    S.UPX[n][ty][tx + 1] = up_val<RECON>(qc.m, s_);                                        \
+  }
+  SLX(d, 0) SLX(v1, 1) SLX(v2, 2) SLX(v3, 3) SLX(p, 4) SLX(e, 5)
+#undef SLX
+  if (x.multi_d) {
+#define SLY(m, n)                                                                          \
+  {                                                                                        \
+    const double s_ =                                                                      \
+        slope<RECON>(S.Q[n][ty + FH - 1][tx + FH], qc.m, S.Q[n][ty + FH + 1][tx + FH]);    \
+    loy.m = lo_val<RECON>(qc.m, s_);                                                       \
+    S.UPY[n][ty + 1][tx] = up_val<RECON>(qc.m, s_);                                        \
+  }
+    SLY(d, 0) SLY(v1, 1) SLY(v2, 2) SLY(v3, 3) SLY(p, 4) SLY(e, 5)
+#undef SLY
+  }
+  if (t >= 128 && t < 128 + 2 * FTY) { // cells i0-1 (upper value) and i0+32 (lower value)
+    const int u = t - 128, row = u >> 1, side = u & 1;
+    const int cx = side ? FTX + FH : FH - 1;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const double q = S.Q[n][row + FH][cx];
+      const double s_ = slope<RECON>(S.Q[n][row + FH][cx - 1], q, S.Q[n][row + FH][cx + 1]);
+      if (side) S.LOX[n][row] = lo_val<RECON>(q, s_);
+      else S.UPX[n][row][0] = up_val<RECON>(q, s_);
+    }
+  }
+  if (x.multi_d && t >= 192) { // rows j0-1 (upper value) and j0+8 (lower value)
+    const int u = t - 192, cx = u & 31, side = u >> 5;
+    const int ry = side ? FTY + FH : FH - 1;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const double q = S.Q[n][ry][cx + FH];
+      const double s_ = slope<RECON>(S.Q[n][ry - 1][cx + FH], q, S.Q[n][ry + 1][cx + FH]);
+      if (side) S.LOY[n][cx] = lo_val<RECON>(q, s_);
+      else S.UPY[n][0][cx] = up_val<RECON>(q, s_);
+    }
+  }
+  __syncthreads();
+  // ---- P2: Riemann problems at the own lower faces; perimeter faces on wave 1 ------------
+  Cell6 L;
+  GET6(L, S.UPX, [ty][tx]);
+  const Flux8 fx_lo = solve_face<RIEMANN, 1>(gm1, L, lox);
+  if (tx > 0) { PUT8(S.FX, fx_lo, [ty][tx - 1]); }
+  Flux8 fy_lo = fx_lo;
+  if (x.multi_d) {
+    GET6(L, S.UPY, [ty][tx]);
+    fy_lo = solve_face<RIEMANN, 2>(gm1, L, loy);
+    if (ty > 0) { PUT8(S.FY, fy_lo, [ty - 1][tx]); }
+  }
+  if (t >= 64 && t < 128) { // lanes 0..7: x1 face i0+32 per row; lanes 32..63: x2 face j0+8
+    const int u = t - 64;
+    if (u < FTY) {
+      Cell6 l, r;
+      GET6(l, S.UPX, [u][FTX]);
+      GET6(r, S.LOX, [u]);
+      const Flux8 fe_ = solve_face<RIEMANN, 1>(gm1, l, r);
+      PUT8(S.FX, fe_, [u][FTX - 1]);
+    } else if (x.multi_d && u >= 32) {
+      const int cx = u - 32;
+      Cell6 l, r;
+      GET6(l, S.UPY, [FTY][cx]);
+      GET6(r, S.LOY, [cx]);
+      const Flux8 fe_ = solve_face<RIEMANN, 2>(gm1, l, r);
+      PUT8(S.FY, fe_, [FTY - 1][cx]);
+    }
+  }
+  __syncthreads();
+  // ---- P3: upper-face fluxes from the neighbours, then the whole per-cell chain ----------
+  Flux8 fx_hi, fy_hi = fx_lo;
+  GET8(fx_hi, S.FX, [ty][tx]);
+  if (x.multi_d) { GET8(fy_hi, S.FY, [ty][tx]); }
+  if (!x.active) return;
+  const double *g = x.g;
+  const double dx1 = x.dx1, dx2 = x.dx2;
+  const double dx3 = (g[4] + (k + 1) * g[5]) - (g[4] + k * g[5]);
+  const double ax1 = dx2 * dx3, ax2 = dx1 * dx3, ax3 = dx1 * dx2; // geometry.hpp:199-216
+  const double vol = dx1 * dx2 * dx3;                             // geometry.hpp:219-225
+  const int b = x.b;
+  const long c = x.col + static_cast<long>(k) * x.sk;
+  // u0 = PrimToCons(prim_in), u1 = PrimToCons(prim_u1)  (fill_derived.cpp:226-255)
+  const double D0 = qc.d;
+  const double M10 = qc.d * qc.v1 * 1.0, M20 = qc.d * qc.v2 * 1.0, M30 = qc.d * qc.v3 * 1.0;
+  const double G0 = qc.e * qc.d;
+  const double E0 = G0 + 0.5 * qc.d * (sqr(qc.v1) + sqr(qc.v2) + sqr(qc.v3));
+  double D1 = D0, M11 = M10, M21 = M20, M31 = M30, G1 = G0, E1 = E0;
+  if constexpr (HAS_U1) {
+    const double r1 = a.prim_u1[b * 6 + 0][c], e1 = a.prim_u1[b * 6 + 5][c];
+    const double a1 = a.prim_u1[b * 6 + 1][c], a2 = a.prim_u1[b * 6 + 2][c];
+    const double a3 = a.prim_u1[b * 6 + 3][c];
+    D1 = r1, M11 = r1 * a1 * 1.0, M21 = r1 * a2 * 1.0, M31 = r1 * a3 * 1.0;
+    G1 = e1 * r1;
+    E1 = G1 + 0.5 * r1 * (sqr(a1) + sqr(a2) + sqr(a3));
+  }
+  // ApplyUpdate (artemis_integrator.hpp:88-106)
+  auto upd = [&](double u0, double u1, double f1l, double f1h, double f2l, double f2h, double f3l,
+                 double f3h) {
+    double divf = (ax1 * f1l - ax1 * f1h);
+    if (x.multi_d) divf += (ax2 * f2l - ax2 * f2h);
+    if (x.three_d) divf += (ax3 * f3l - ax3 * f3h);
+    return a.gam0 * u0 + a.gam1 * u1 + divf * a.beta_dt / vol;
+  };
+  const double D = upd(D0, D1, fx_lo.d, fx_hi.d, fy_lo.d, fy_hi.d, fz_lo.d, fz_hi.d);
+  double M1 = upd(M10, M11, fx_lo.m1, fx_hi.m1, fy_lo.m1, fy_hi.m1, fz_lo.m1, fz_hi.m1);
+  double M2 = upd(M20, M21, fx_lo.m2, fx_hi.m2, fy_lo.m2, fy_hi.m2, fz_lo.m2, fz_hi.m2);
+  double M3 = upd(M30, M31, fx_lo.m3, fx_hi.m3, fy_lo.m3, fy_hi.m3, fz_lo.m3, fz_hi.m3);
+  const double E = upd(E0, E1, fx_lo.e, fx_hi.e, fy_lo.e, fy_hi.e, fz_lo.e, fz_hi.e);
+  double G = upd(G0, G1, fx_lo.eg, fx_hi.eg, fy_lo.eg, fy_hi.eg, fz_lo.eg, fz_hi.eg);
+  // FluxSource (fluid_fluxes.hpp:365-392)
+  M1 += a.bdt / dx1 * (fx_lo.pf - fx_hi.pf);
+  G -= a.bdt / vol * 0.5 * (fx_lo.pf + fx_hi.pf) * (ax1 * fx_hi.vf - ax1 * fx_lo.vf);
+  if (x.multi_d) {
+    M2 += a.bdt / dx2 * (fy_lo.pf - fy_hi.pf);
+    G -= a.bdt / vol * 0.5 * (fy_lo.pf + fy_hi.pf) * (ax2 * fy_hi.vf - ax2 * fy_lo.vf);
+  }
+  if (x.three_d) {
+    M3 += a.bdt / dx3 * (fz_lo.pf - fz_hi.pf);
+    G -= a.bdt / vol * 0.5 * (fz_lo.pf + fz_hi.pf) * (ax3 * fz_hi.vf - ax3 * fz_lo.vf);
+  }
+  // SetAuxillaryFields (fill_derived.cpp:54-73, artemis_utils.hpp:43-62)
+  {
+    const double u_d = (D > f.dfloor) ? D : f.dfloor;
+    const double u_d2 = amax(D, f.dfloor);
+    const double ke = 0.5 * (sqr(M1 / 1.0) + sqr(M2 / 1.0) + sqr(M3 / 1.0)) / u_d2;
+    const double ue = E - ke;
+    double sie = (ue > f.de_switch * E) ? ue / u_d2 : G / u_d2;
+    sie = amax(sie, f.siefloor);
+    G = sie * u_d;
+    const double uflr = f.siefloor * u_d;
+    G = (G > uflr) ? G : uflr;
+  }
+  // ConsToPrim (fill_derived.cpp:137-151); the PrimToCons floors that follow
+  // (fill_derived.cpp:229,244) are idempotent on these values.
+  const double w_d = (D > f.dfloor) ? D : f.dfloor;
+  const double w1 = M1 / (w_d * 1.0), w2 = M2 / (w_d * 1.0), w3 = M3 / (w_d * 1.0);
+  double w_s = G / w_d;
+  w_s = (w_s > f.siefloor) ? w_s : f.siefloor;
+  const double w_p = amax(0.0, gm1 * w_d * w_s); // fill_derived.cpp:247
+  a.prim_out[b * 6 + 0][c] = w_d;
+  a.prim_out[b * 6 + 1][c] = w1;
+  a.prim_out[b * 6 + 2][c] = w2;
+  a.prim_out[b * 6 + 3][c] = w3;
+  a.prim_out[b * 6 + 4][c] = w_p;
+  a.prim_out[b * 6 + 5][c] = w_s;
+  if constexpr (WRITE_CONS) { // PrimToCons (fill_derived.cpp:226-255)
+    const double u_u = w_s * w_d;
+    a.cons_out[b * 6 + 0][c] = w_d;
+    a.cons_out[b * 6 + 1][c] = w_d * w1 * 1.0;
+    a.cons_out[b * 6 + 2][c] = w_d * w2 * 1.0;
+    a.cons_out[b * 6 + 3][c] = w_d * w3 * 1.0;
+    a.cons_out[b * 6 + 4][c] = u_u + 0.5 * w_d * (sqr(w1) + sqr(w2) + sqr(w3));
+    a.cons_out[b * 6 + 5][c] = u_u;
+  }
+  if constexpr (WITH_DT) { // Gas::EstimateTimestepMesh on the new state (gas.cpp:411-433)
+    const double bulk = (gm1 + 1.0) * gm1 * w_d * w_s;
+    const double cs = sqrt(bulk / w_d);
+    double denom = 0.0;
+    denom += (fabs(w1) + cs) / (1.0 * dx1);
+    if (x.multi_d) denom += (fabs(w2) + cs) / (1.0 * dx2);
+    if (x.three_d) denom += (fabs(w3) + cs) / (1.0 * dx3);
+    ldt = amin(ldt, 1.0 / denom);
+  }
+}
+
+template <int RIEMANN, int RECON, bool HAS_U1, bool WRITE_CONS, bool WITH_DT>
+__global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, const StageK a) {
+  __shared__ LdsTile S;
+  Ctx x;
+  x.tx = threadIdx.x, x.ty = threadIdx.y, x.t = x.ty * FTX + x.tx;
+  x.b = blockIdx.z / a.nchunk;
+  const int chunk = blockIdx.z % a.nchunk;
+  x.three_d = P.ndim > 2, x.multi_d = P.ndim > 1;
+  x.i0 = P.is + blockIdx.x * FTX, x.j0 = P.js + blockIdx.y * FTY;
+  const int i = x.i0 + x.tx, j = x.j0 + x.ty;
+  x.active = (i <= P.ie) && (j <= P.je);
+  // clamped indices: inactive lanes still serve as neighbours and face owners
+  const int il = min(i, P.ni - 1), jl = min(j, P.nj - 1);
+  const int k0 = P.ks + chunk * a.kchunk;
+  const int k1 = min(P.ke, k0 + a.kchunk - 1);
+  if (k0 > k1) return;
+  x.gm1 = P.gm1;
+  x.g = P.geom + 6 * x.b;
+  x.in_r = a.prim_in[x.b * 6 + 0], x.in_1 = a.prim_in[x.b * 6 + 1];
+  x.in_2 = a.prim_in[x.b * 6 + 2], x.in_3 = a.prim_in[x.b * 6 + 3];
+  x.in_e = a.prim_in[x.b * 6 + 5];
+  x.sj = P.sj, x.sk = P.sk;
+  x.col = static_cast<long>(jl) * x.sj + il;
+  // geometry.hpp:65-72: widths along x1 and x2 do not change along the march
+  x.dx1 = (x.g[0] + (i + 1) * x.g[1]) - (x.g[0] + i * x.g[1]);
+  x.dx2 = (x.g[2] + (j + 1) * x.g[3]) - (x.g[2] + j * x.g[3]);
+  double ldt = DBL_MAX;
+
+  if (!x.three_d) {
+    const Cell6 qc = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + k0 * x.sk, x.gm1);
+    Flux8 fz;
+    fz.d = fz.m1 = fz.m2 = fz.m3 = fz.e = fz.eg = fz.pf = fz.vf = 0.0;
+    plane_body<RIEMANN, RECON, HAS_U1, WRITE_CONS, WITH_DT>(S, P, a, x, k0, qc, fz, fz, ldt);
+  } else {
+    // x3 state carried in registers: planes k, k+1, the upper face value of cell k and the
+    // flux through face k.
+    Cell6 qc = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k0 - 1) * x.sk, x.gm1);
+    Cell6 qn = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + k0 * x.sk, x.gm1);
+    Cell6 zl;
+    {
+      const Cell6 qmm =
+          load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k0 - 2) * x.sk, x.gm1);
+#define ZL0(m) zl.m = up_val<RECON>(qc.m, slope<RECON>(qmm.m, qc.m, qn.m));
+      FOR6(ZL0)
+#undef ZL0
+    }
+    Flux8 fz_lo;
+    fz_lo.d = fz_lo.m1 = fz_lo.m2 = fz_lo.m3 = fz_lo.e = fz_lo.eg = fz_lo.pf = fz_lo.vf = 0.0;
+    for (int k = k0 - 1; k <= k1; ++k) { // the first trip only primes fz_lo (face k0)
+      const Cell6 qnn =
+          load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k + 2) * x.sk, x.gm1);
+      Cell6 zr, zl_next;
+#define ZSL(m)                                                                             \
+  {                                                                                        \
+    const double s_ = slope<RECON>(qc.m, qn.m, qnn.m);                                     \
+    zr.m = lo_val<RECON>(qn.m, s_);                                                        \
+    zl_next.m = up_val<RECON>(qn.m, s_);                                                   \
+  }
+      FOR6(ZSL)
+#undef ZSL
+      const Flux8 fz_hi = solve_face<RIEMANN, 3>(x.gm1, zl, zr);
+      if (k >= k0)
+        plane_body<RIEMANN, RECON, HAS_U1, WRITE_CONS, WITH_DT>(S, P, a, x, k, qc, fz_lo, fz_hi, ldt);
+      fz_lo = fz_hi, zl = zl_next, qc = qn, qn = qnn;
+    }
+  }
+
+  if constexpr (WITH_DT) {
+    __syncthreads(); // LOX is reused as reduction scratch
+    for (int off = 32; off > 0; off >>= 1) ldt = fmin(ldt, __shfl_down(ldt, off, 64));
+    double *wmin = &S.LOX[0][0];
+    if ((x.t & 63) == 0) wmin[x.t >> 6] = ldt;
+    __syncthreads();
+    if (x.t == 0) {
+      const double m = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+      if (m < DBL_MAX)
+        atomicMin(a.dt_bits, static_cast<unsigned long long>(__double_as_longlong(a.cfl * m)));
+    }
+  }
+}
+
+template <int RIEMANN, int RECON>
+int launch_cfg(const PackView &P, const StageK &k, bool has_u1, bool cons, bool dt, hipStream_t s) {
+  const dim3 grid((P.ie - P.is + FTX) / FTX, (P.je - P.js + FTY) / FTY, P.nb * k.nchunk);
+  const dim3 block(FTX, FTY);
+#define GO(U, C, D)                                                                        \
+  hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, U, C, D>), grid, block, 0, s, P, k)
+  if (has_u1) {
+    if (cons) { if (dt) GO(true, true, true); else GO(true, true, false); }
+    else { if (dt) GO(true, false, true); else GO(true, false, false); }
+  } else {
+    if (cons) { if (dt) GO(false, true, true); else GO(false, true, false); }
+    else { if (dt) GO(false, false, true); else GO(false, false, false); }
+  }
+#undef GO
+  return 0;
+}
+
+} // namespace
+
+int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon,
+                       hipStream_t s) {
+  if (recon == ARTEMIS_PPM) return 3; // PPM stays on the per-task path
+  StageK k;
+  k.gam0 = a.gam0, k.gam1 = a.gam1, k.beta_dt = a.beta_dt, k.bdt = a.bdt, k.cfl = a.cfl;
+  k.prim_in = a.prim_in, k.prim_u1 = a.prim_u1, k.prim_out = a.prim_out, k.cons_out = a.cons_out;
+  k.dt_bits = reinterpret_cast<unsigned long long *>(a.dt_dev);
+  const int nz = P.ke - P.ks + 1;
+  // enough workgroups to fill 256 CUs x 2 several times over, chunks of >= 16 planes
+  const long tiles = static_cast<long>((P.ie - P.is + FTX) / FTX) * ((P.je - P.js + FTY) / FTY) * P.nb;
+  int nchunk = 1;
+  if (P.ndim > 2) {
+    while (nchunk * 2 <= nz / 16 && tiles * nchunk < 4096) nchunk *= 2;
+  }
+  k.nchunk = nchunk;
+  k.kchunk = (nz + nchunk - 1) / nchunk;
+  const bool has_u1 = (a.prim_u1 != a.prim_in);
+  const bool cons = (a.cons_out != nullptr);
+  const bool dt = (a.dt_dev != nullptr);
+#define RC(RS)                                                                             \
+  case RS:                                                                                 \
+    return (recon == ARTEMIS_PCM) ? launch_cfg<RS, 0>(P, k, has_u1, cons, dt, s)           \
+                                  : launch_cfg<RS, 1>(P, k, has_u1, cons, dt, s);
+  switch (riemann) {
+    RC(0)
+    RC(1)
+    RC(2)
+  }
+#undef RC
+  return 4;
+}
+
+} // namespace artemis

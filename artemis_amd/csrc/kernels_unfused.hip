@@ -483,13 +483,25 @@ struct HostTables {
   int nb = 0, nsg = 0, nsd = 0;
   std::vector<double *> gas, dust; // host copies of the prim tables
 };
-static thread_local HostTables g_tables;
+// A driver that ping-pongs primitive buffers alternates between a few tables; keep several
+// so the (synchronous) device-to-host fetch happens once per table, not once per call.
+constexpr int NCACHE = 8;
+static thread_local HostTables g_cache[NCACHE];
+static thread_local int g_cache_next = 0;
+static thread_local const HostTables *g_cur = nullptr;
 
 static int fetch_tables(const PackView &P) {
-  HostTables &T = g_tables;
-  if (T.key_gas == P.gas.prim && T.key_dust == P.dust.prim && T.nb == P.nb && T.nsg == P.gas.ns &&
-      T.nsd == P.dust.ns)
-    return 0;
+  for (int e = 0; e < NCACHE; ++e) {
+    const HostTables &T = g_cache[e];
+    if (T.nb == P.nb && T.key_gas == P.gas.prim && T.key_dust == P.dust.prim && T.nsg == P.gas.ns &&
+        T.nsd == P.dust.ns && T.nb > 0) {
+      g_cur = &T;
+      return 0;
+    }
+  }
+  HostTables &T = g_cache[g_cache_next];
+  g_cache_next = (g_cache_next + 1) % NCACHE;
+  T.nb = 0;
   T.gas.assign(static_cast<size_t>(P.nb) * 6 * P.gas.ns, nullptr);
   T.dust.assign(static_cast<size_t>(P.nb) * 4 * P.dust.ns, nullptr);
   if (!T.gas.empty() &&
@@ -500,13 +512,17 @@ static int fetch_tables(const PackView &P) {
                                    hipMemcpyDeviceToHost) != hipSuccess)
     return 1;
   T.key_gas = P.gas.prim, T.key_dust = P.dust.prim, T.nb = P.nb, T.nsg = P.gas.ns, T.nsd = P.dust.ns;
+  g_cur = &T;
   return 0;
 }
-void invalidate_table_cache() { g_tables = HostTables(); }
+void invalidate_table_cache() {
+  for (int e = 0; e < NCACHE; ++e) g_cache[e] = HostTables();
+  g_cur = nullptr;
+}
 
 // FillGhost variables of block b: gas rho, v, sie; dust rho, v.
 static int fill_table(const PackView &P, int b, int d, BcTable &t) {
-  const HostTables &T = g_tables;
+  const HostTables &T = *g_cur;
   int n = 0;
   const int nsg = P.gas.ns, nsd = P.dust.ns;
   for (int v = 0; v < 6 * nsg; ++v) {

@@ -152,3 +152,14 @@ class MeshBlockPack:
 
     def halo_unpack(self, block, face, buf):
         self._call(self.L.artemis_hip_halo_unpack, block, face, C.c_void_p(buf.data_ptr()))
+
+    def pack_with_prim(self, prim_table):
+        """Shallow copy of the C pack whose gas.prim table points at another buffer (the
+        fused stage ping-pongs primitives; BCs and PrimToCons then act on that buffer)."""
+        p = capi.Pack()
+        C.memmove(C.byref(p), C.byref(self.pack), C.sizeof(capi.Pack))
+        p.gas.prim = prim_table
+        return p
+
+    def call_on(self, pack, fn, *args):
+        capi.check(fn(C.byref(pack), *args, self._stream()))
