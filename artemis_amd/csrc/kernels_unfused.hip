@@ -359,13 +359,28 @@ struct BcArgs {
   int st, en;         // interior bounds along d
   int ng;
 };
-constexpr int MAX_FILL = 64;
-struct BcTable {
-  double *ptr[MAX_FILL];
-  signed char normal[MAX_FILL]; // 1 if this variable is the velocity component along d
+// FillGhost variables are enumerated on the device straight from the pack's pointer tables
+// (no host copy of the tables, hence no synchronisation and nothing to go stale).
+struct FillTabs {
+  double *const *gas;  // [nb][6*nsg]
+  double *const *dust; // [nb][4*nsd]
+  int nsg, nsd, b;
 };
+// v-th FillGhost variable of block b and whether it is the velocity component along d
+__device__ __forceinline__ double *fill_var(const FillTabs &t, int v, int d, bool &normal) {
+  const int ngas = 5 * t.nsg;
+  if (v < ngas) {
+    // gas order with the pressure block [4ns,5ns) skipped (gas.cpp:251-252)
+    const int slot = (v < 4 * t.nsg) ? v : v + t.nsg;
+    normal = (slot >= t.nsg && slot < 4 * t.nsg && ((slot - t.nsg) % 3) == d);
+    return t.gas[t.b * 6 * t.nsg + slot];
+  }
+  const int w = v - ngas;
+  normal = (w >= t.nsd && ((w - t.nsd) % 3) == d);
+  return t.dust[t.b * 4 * t.nsd + w];
+}
 
-__global__ __launch_bounds__(256) void bc_kernel(const BcArgs a, const BcTable t, int ni, int nj,
+__global__ __launch_bounds__(256) void bc_kernel(const BcArgs a, const FillTabs t, int ni, int nj,
                                                  int nk) {
   // slab extents: ng along d, full extent along the others
   int ext[3] = {ni, nj, nk};
@@ -393,8 +408,10 @@ __global__ __launch_bounds__(256) void bc_kernel(const BcArgs a, const BcTable t
   const long cd = (static_cast<long>(dst[2]) * nj + dst[1]) * ni + dst[0];
   const long cs = (static_cast<long>(src[2]) * nj + src[1]) * ni + src[0];
   for (int v = 0; v < a.nfill; ++v) {
-    const double sgn = (a.bc == ARTEMIS_BC_REFLECT && t.normal[v]) ? -1.0 : 1.0;
-    t.ptr[v][cd] = sgn * t.ptr[v][cs];
+    bool normal;
+    double *q = fill_var(t, v, a.d, normal);
+    const double sgn = (a.bc == ARTEMIS_BC_REFLECT && normal) ? -1.0 : 1.0;
+    q[cd] = sgn * q[cs];
   }
 }
 
@@ -403,7 +420,7 @@ struct HaloArgs {
   int d, side, ng, nfill;
   int lo[3], n[3]; // slab origin and extents (in cells)
 };
-__global__ __launch_bounds__(256) void halo_kernel(const HaloArgs a, const BcTable t, int ni, int nj,
+__global__ __launch_bounds__(256) void halo_kernel(const HaloArgs a, const FillTabs t, int ni, int nj,
                                                    double *buf, int unpack) {
   const long ncell = static_cast<long>(a.n[0]) * a.n[1] * a.n[2];
   const long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -413,8 +430,10 @@ __global__ __launch_bounds__(256) void halo_kernel(const HaloArgs a, const BcTab
   const int k = a.lo[2] + tid / (static_cast<long>(a.n[0]) * a.n[1]);
   const long c = (static_cast<long>(k) * nj + j) * ni + i;
   for (int v = 0; v < a.nfill; ++v) {
-    if (unpack) t.ptr[v][c] = buf[v * ncell + tid];
-    else buf[v * ncell + tid] = t.ptr[v][c];
+    bool normal;
+    double *q = fill_var(t, v, a.d, normal);
+    if (unpack) q[c] = buf[v * ncell + tid];
+    else buf[v * ncell + tid] = q[c];
   }
 }
 
@@ -475,73 +494,15 @@ void launch_estimate_dt(const PackView &P, int fluid, double cfl, double *dt_dev
     hipLaunchKernelGGL(estimate_dt_kernel<1>, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r, cfl, bits);
 }
 
-// The pointer tables live on the device; the BC / halo kernels need a handful of them as
-// kernel arguments, so the host fetches the block's row once and caches it (tables are
-// rebuilt only when the mesh changes).
-struct HostTables {
-  const void *key_gas = nullptr, *key_dust = nullptr;
-  int nb = 0, nsg = 0, nsd = 0;
-  std::vector<double *> gas, dust; // host copies of the prim tables
-};
-// A driver that ping-pongs primitive buffers alternates between a few tables; keep several
-// so the (synchronous) device-to-host fetch happens once per table, not once per call.
-constexpr int NCACHE = 8;
-static thread_local HostTables g_cache[NCACHE];
-static thread_local int g_cache_next = 0;
-static thread_local const HostTables *g_cur = nullptr;
+void invalidate_table_cache() {} // nothing is cached on the host any more
 
-static int fetch_tables(const PackView &P) {
-  for (int e = 0; e < NCACHE; ++e) {
-    const HostTables &T = g_cache[e];
-    if (T.nb == P.nb && T.key_gas == P.gas.prim && T.key_dust == P.dust.prim && T.nsg == P.gas.ns &&
-        T.nsd == P.dust.ns && T.nb > 0) {
-      g_cur = &T;
-      return 0;
-    }
-  }
-  HostTables &T = g_cache[g_cache_next];
-  g_cache_next = (g_cache_next + 1) % NCACHE;
-  T.nb = 0;
-  T.gas.assign(static_cast<size_t>(P.nb) * 6 * P.gas.ns, nullptr);
-  T.dust.assign(static_cast<size_t>(P.nb) * 4 * P.dust.ns, nullptr);
-  if (!T.gas.empty() &&
-      hipMemcpy(T.gas.data(), P.gas.prim, T.gas.size() * sizeof(double *), hipMemcpyDeviceToHost) !=
-          hipSuccess)
-    return 1;
-  if (!T.dust.empty() && hipMemcpy(T.dust.data(), P.dust.prim, T.dust.size() * sizeof(double *),
-                                   hipMemcpyDeviceToHost) != hipSuccess)
-    return 1;
-  T.key_gas = P.gas.prim, T.key_dust = P.dust.prim, T.nb = P.nb, T.nsg = P.gas.ns, T.nsd = P.dust.ns;
-  g_cur = &T;
-  return 0;
-}
-void invalidate_table_cache() {
-  for (int e = 0; e < NCACHE; ++e) g_cache[e] = HostTables();
-  g_cur = nullptr;
-}
-
-// FillGhost variables of block b: gas rho, v, sie; dust rho, v.
-static int fill_table(const PackView &P, int b, int d, BcTable &t) {
-  const HostTables &T = *g_cur;
-  int n = 0;
-  const int nsg = P.gas.ns, nsd = P.dust.ns;
-  for (int v = 0; v < 6 * nsg; ++v) {
-    if (v >= 4 * nsg && v < 5 * nsg) continue; // pressure: not FillGhost (gas.cpp:251-252)
-    t.ptr[n] = T.gas[static_cast<size_t>(b) * 6 * nsg + v];
-    t.normal[n] = (v >= nsg && v < 4 * nsg && ((v - nsg) % 3) == d) ? 1 : 0;
-    ++n;
-  }
-  for (int v = 0; v < 4 * nsd; ++v) {
-    t.ptr[n] = T.dust[static_cast<size_t>(b) * 4 * nsd + v];
-    t.normal[n] = (v >= nsd && ((v - nsd) % 3) == d) ? 1 : 0;
-    ++n;
-  }
-  return n;
+static FillTabs fill_tabs(const PackView &P, int b) {
+  FillTabs t;
+  t.gas = P.gas.prim, t.dust = P.dust.prim, t.nsg = P.gas.ns, t.nsd = P.dust.ns, t.b = b;
+  return t;
 }
 
 int launch_apply_bc(const PackView &P, const int *bc, hipStream_t s) {
-  if (5 * P.gas.ns + 4 * P.dust.ns > MAX_FILL) return 2;
-  if (fetch_tables(P)) return 1;
   const int n_act[3] = {P.ie - P.is + 1, P.je - P.js + 1, P.ke - P.ks + 1};
   const int st[3] = {P.is, P.js, P.ks}, en[3] = {P.ie, P.je, P.ke};
   for (int pass = 0; pass < 2; ++pass)
@@ -551,11 +512,11 @@ int launch_apply_bc(const PackView &P, const int *bc, hipStream_t s) {
           const int flag = bc[b * 6 + 2 * d + side];
           if (flag == ARTEMIS_BC_NONE) continue;
           if ((pass == 0) != (flag == ARTEMIS_BC_PERIODIC)) continue;
-          BcTable t;
+          const FillTabs t = fill_tabs(P, b);
           BcArgs a;
           a.d = d, a.side = side, a.bc = flag, a.n_act = n_act[d], a.st = st[d], a.en = en[d];
           a.ng = P.ng;
-          a.nfill = fill_table(P, b, d, t);
+          a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;
           int ext[3] = {P.ni, P.nj, P.nk};
           ext[d] = P.ng;
           const long ncell = static_cast<long>(ext[0]) * ext[1] * ext[2];
@@ -580,12 +541,10 @@ long halo_count(const PackView &P, int face) {
   return static_cast<long>(a.n[0]) * a.n[1] * a.n[2] * (5 * P.gas.ns + 4 * P.dust.ns);
 }
 int launch_halo(const PackView &P, int block, int face, double *buf, int unpack, hipStream_t s) {
-  if (5 * P.gas.ns + 4 * P.dust.ns > MAX_FILL) return 2;
-  if (fetch_tables(P)) return 1;
   HaloArgs a;
   halo_args(P, face, unpack, a);
-  BcTable t;
-  a.nfill = fill_table(P, block, a.d, t);
+  const FillTabs t = fill_tabs(P, block);
+  a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;
   const long ncell = static_cast<long>(a.n[0]) * a.n[1] * a.n[2];
   hipLaunchKernelGGL(halo_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P.ni, P.nj, buf,
                      unpack);

@@ -37,8 +37,7 @@ int artemis_rt_event_record(void *ev, void *stream);
 int artemis_rt_stream_wait_event(void *stream, void *ev);
 int artemis_rt_event_sync(void *ev);
 double artemis_rt_event_elapsed_ms(void *ev0, void *ev1);
-/* Call after rebuilding any pointer table in place (drops the host-side cache that
- * artemis_hip_apply_bc / halo_pack keep of the FillGhost rows). */
+/* Kept for ABI stability: pointer tables are always read on the device, nothing is cached. */
 void artemis_rt_tables_changed(void);
 
 #ifdef __cplusplus
