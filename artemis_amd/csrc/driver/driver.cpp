@@ -1,0 +1,1104 @@
+// Host driver: the stand-in for Parthenon + ArtemisDriver<GEOM> when the hydro path runs
+// outside Artemis.  Plain C++ (no HIP here): device work goes through include/artemis_hip.h
+// and include/artemis_rt.h only.  Structure and names follow the reference:
+//   ProcessPackages      artemis.cpp:37-164   (physics switches, Gas/Dust::Initialize params)
+//   ProblemGenerator     pgen/pgen.hpp:38-64  (blast, linear_wave, advection)
+//   PostInitialization   derived/fill_derived.cpp:284-287
+//   Step / StepTasks     artemis_driver.cpp:102-273
+//   PostStepTasks        artemis_driver.cpp:279-297 (EstimateTimestep)
+//   Execute loop / SetGlobalTimeStep   parthenon EvolutionDriver (upstream, recalled)
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "artemis_driver.h"
+#include "artemis_hip.h"
+#include "artemis_rt.h"
+#include "parameter_input.hpp"
+
+#define SQR(x) ((x) * (x))
+typedef double Real;
+
+namespace {
+thread_local std::string g_sim_err;
+
+struct HipFail : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+void CK(int rc, const char *what) {
+  if (rc != 0) throw HipFail(std::string(what) + ": " + artemis_hip_last_error());
+}
+
+// Device buffer of doubles owned by the driver
+struct DevBuf {
+  double *p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    release();
+    n = count;
+    p = static_cast<double *>(artemis_rt_malloc(std::max<size_t>(count, 1) * sizeof(double)));
+    if (!p) throw HipFail(std::string("device allocation failed: ") + artemis_hip_last_error());
+    CK(artemis_rt_memset(p, 0, std::max<size_t>(count, 1) * sizeof(double), nullptr), "memset");
+  }
+  void release() {
+    if (p) artemis_rt_free(p);
+    p = nullptr, n = 0;
+  }
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+};
+
+// A field group: [nb][nvar][N] doubles + the device table of [nb*nvar] pointers into it.
+struct Field {
+  DevBuf data;
+  void *table = nullptr; // device array of double*
+  int nb = 0, nvar = 0;
+  size_t N = 0;
+  bool ok() const { return data.p != nullptr; }
+  void alloc(int nb_, int nvar_, size_t N_) {
+    nb = nb_, nvar = nvar_, N = N_;
+    if (nvar == 0) return;
+    data.alloc(static_cast<size_t>(nb) * nvar * N);
+    std::vector<double *> h(static_cast<size_t>(nb) * nvar);
+    for (size_t q = 0; q < h.size(); ++q) h[q] = data.p + q * N;
+    table = artemis_rt_malloc(h.size() * sizeof(double *));
+    if (!table) throw HipFail("table allocation failed");
+    CK(artemis_rt_memcpy_h2d(table, h.data(), h.size() * sizeof(double *), nullptr), "h2d");
+    CK(artemis_rt_device_sync(), "sync");
+  }
+  double *const *tab() const { return static_cast<double *const *>(table); }
+  double *var(int b, int v) const { return data.p + (static_cast<size_t>(b) * nvar + v) * N; }
+  ~Field() {
+    if (table) artemis_rt_free(table);
+  }
+};
+
+struct Block {
+  int lx[3];            // logical location in the global block grid
+  Real xmin[3], xmax[3];
+  int bc[6];            // artemis_bc per face (NONE where a neighbour block exists)
+  int nbr_rank[6], nbr_block[6];
+  long gid;             // global block id
+};
+
+struct Link { // one directed ghost-slab transfer out of local block b through face f
+  int b, face;
+  int nbr_rank, nbr_block; // destination (its face is face^1)
+  long count;
+  DevBuf sbuf, rbuf;       // rbuf used for remote links only
+  int tag_send, tag_recv;
+};
+
+enum { PG_BLAST, PG_LINWAVE, PG_ADVECTION };
+
+} // namespace
+
+struct artemis_sim {
+  artemis_host::ParameterInput pin;
+  artemis_comm_t comm;
+  bool has_comm = false;
+  int rank = 0, nranks = 1;
+
+  // mesh
+  int nx[3], mbnx[3], nblk[3], rgrid[3], rcoord[3], lblk[3];
+  Real xmin[3], xmax[3];
+  int mesh_bc[6];
+  int ng, ndim, ni, nj, nk, is, ie, js, je, ks, ke;
+  size_t N;
+  std::vector<Block> blocks;
+  int nb = 0;
+
+  // physics (artemis.cpp:63-72, gas.cpp:55-208, dust.cpp:45-110)
+  bool do_gas = true, do_dust = false;
+  int ns_gas = 0, ns_dust = 0;
+  int recon_gas = ARTEMIS_PLM, riemann_gas = ARTEMIS_HLLC, recon_dust = ARTEMIS_PLM,
+      riemann_dust = ARTEMIS_HLLE;
+  Real gamma = 1.66666666667, dfloor_gas = 1e-20, siefloor_gas = 1e-20, de_switch = 0.0;
+  Real dfloor_dust = 1e-20, cfl_gas = 0.8, cfl_dust = 0.8;
+  std::string integrator = "rk2";
+  int nstages = 2;
+  Real gam0[3], gam1[3], beta[3];
+  int pgen = PG_BLAST;
+
+  // state
+  Field gprim[3];               // primitive ping-pong buffers (fused path); [0..2]
+  int base = 0;                 // index of the buffer holding the current state
+  Field gu0, gu1, gflux[3], gpflux[3], gvface[3];
+  Field dprim, du0, du1, dflux[3];
+  DevBuf geom, dt_dev;
+  double *dt_host = nullptr;    // pinned
+  bool unfused_ready = false;
+  bool use_fused = false, fused_possible = false, overlap = false;
+  bool cons_valid = false;
+
+  std::vector<std::unique_ptr<Link>> links;
+  std::vector<int> bc_flat;
+
+  void *stream = nullptr, *comm_stream = nullptr;
+  void *ev0 = nullptr, *ev1 = nullptr;
+  double kernel_ms_sum = 0.0;
+  long kernel_launches = 0;
+  bool time_kernels = false;
+  std::vector<std::pair<void *, void *>> kev; // event pairs of the timed region
+
+  Real time = 0.0, dt = DBL_MAX, tlim = -1.0;
+  long ncycle = 0, nlim = -1;
+  double last_wall = 0.0;
+
+  // linear_wave / advection parameters (linear_wave.hpp:44-53, advection.hpp:43-51)
+  struct {
+    int wave_flag = 0;
+    Real amp = 0, vflow = 0, lambda = 0, d0 = 1, p0 = 0, v1_0 = 0, k_par = 0;
+    Real cos_a2 = 1, cos_a3 = 1, sin_a2 = 0, sin_a3 = 0, rem[5][5], ev[5], gamma = 0, gm1 = 0;
+  } lw;
+
+  // ---------------------------------------------------------------------------------------
+  artemis_pack_t make_pack(int prim_idx) const {
+    artemis_pack_t p;
+    std::memset(&p, 0, sizeof p);
+    p.nblocks = nb, p.nghost = ng, p.nx1 = mbnx[0], p.nx2 = mbnx[1], p.nx3 = mbnx[2];
+    p.coords = ARTEMIS_CARTESIAN;
+    p.gm1 = gamma - 1.0;
+    p.geom = geom.p;
+    p.gas.nspecies = ns_gas, p.gas.recon = recon_gas, p.gas.riemann = riemann_gas;
+    p.gas.dfloor = dfloor_gas, p.gas.siefloor = siefloor_gas, p.gas.de_switch = de_switch;
+    p.gas.prim = gprim[prim_idx].tab(), p.gas.cons0 = gu0.tab(), p.gas.cons1 = gu1.tab();
+    p.dust.nspecies = ns_dust, p.dust.recon = recon_dust, p.dust.riemann = riemann_dust;
+    p.dust.dfloor = dfloor_dust;
+    p.dust.prim = dprim.tab(), p.dust.cons0 = du0.tab(), p.dust.cons1 = du1.tab();
+    for (int d = 0; d < 3; ++d) {
+      p.gas.flux[d] = gflux[d].tab(), p.gas.pflux[d] = gpflux[d].tab();
+      p.gas.vface[d] = gvface[d].tab(), p.dust.flux[d] = dflux[d].tab();
+    }
+    return p;
+  }
+
+  void setup(const char *deck, int nover, const char *const *over, const artemis_comm_t *c);
+  void build_mesh();
+  void allocate();
+  void ensure_unfused();
+  void problem_generator();
+  void fill_ghosts(int prim_idx);
+  void fill_ghosts_start(int prim_idx);
+  void fill_ghosts_finish(int prim_idx);
+  void materialise_cons();
+  Real new_dt_unfused();
+  void step_fused(bool want_dt);
+  void step_unfused();
+  long evolve(long max_cycles);
+  void upload_block(Field &f, int b, const std::vector<Real> &h);
+  std::vector<Real> download(const Field &f, int b);
+  void lw_setup(bool eigen);
+  int history(double *out);
+  int errors(double *out);
+};
+
+namespace {
+
+int parse_bc(const std::string &s) {
+  if (s == "periodic") return ARTEMIS_BC_PERIODIC;
+  if (s == "outflow") return ARTEMIS_BC_OUTFLOW;
+  if (s == "reflecting" || s == "reflect") return ARTEMIS_BC_REFLECT;
+  throw std::runtime_error("boundary flag '" + s + "' is not built (periodic|outflow|reflecting)");
+}
+
+// Factor nranks into a rank grid that divides the block grid, preferring to cut the slowest
+// dimension first (keeps x1 rows long).
+void choose_rank_grid(int nranks, const int nblk[3], int rg[3]) {
+  rg[0] = rg[1] = rg[2] = 1;
+  int rem = nranks;
+  for (int p = 2; rem > 1;) {
+    if (rem % p != 0) {
+      ++p;
+      continue;
+    }
+    int best = -1;
+    for (int d = 2; d >= 0; --d) {
+      if ((nblk[d] / rg[d]) % p == 0 && (best < 0 || nblk[d] / rg[d] > nblk[best] / rg[best])) best = d;
+    }
+    if (best < 0)
+      throw std::runtime_error("cannot split the mesh-block grid over " + std::to_string(nranks) +
+                               " ranks");
+    rg[best] *= p;
+    rem /= p;
+  }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------
+void artemis_sim::setup(const char *deck, int nover, const char *const *over,
+                        const artemis_comm_t *c) {
+  pin.LoadFromString(deck);
+  for (int q = 0; q < nover; ++q) pin.ApplyOverride(over[q]);
+  if (c) {
+    comm = *c, has_comm = true, rank = c->rank, nranks = c->nranks;
+  }
+  // <artemis> (artemis.cpp:48-53,93-97)
+  const std::string problem = pin.GetString("artemis", "problem");
+  const std::string sys = pin.GetOrAddString("artemis", "coordinates", "cartesian");
+  if (sys != "cartesian")
+    throw std::runtime_error("coordinates = " + sys + " is not built yet (cartesian only)");
+  if (problem == "blast") pgen = PG_BLAST;
+  else if (problem == "linear_wave") pgen = PG_LINWAVE;
+  else if (problem == "advection") pgen = PG_ADVECTION;
+  else throw std::runtime_error("problem generator '" + problem + "' is not built");
+  // <physics> (artemis.cpp:63-72); everything but gas/dust must stay off
+  do_gas = pin.GetOrAddBoolean("physics", "gas", true);
+  do_dust = pin.GetOrAddBoolean("physics", "dust", false);
+  for (const char *k : {"gravity", "nbody", "rotating_frame", "cooling", "drag", "viscosity",
+                        "conduction", "radiation"})
+    if (pin.GetOrAddBoolean("physics", k, false))
+      throw std::runtime_error(std::string("physics/") + k + " is out of scope of this build");
+  // <parthenon/mesh>
+  ng = pin.GetOrAddInteger("parthenon/mesh", "nghost", 2);
+  const char *xn[3] = {"x1", "x2", "x3"};
+  for (int d = 0; d < 3; ++d) {
+    nx[d] = pin.GetOrAddInteger("parthenon/mesh", std::string("n") + xn[d], 1);
+    xmin[d] = pin.GetOrAddReal("parthenon/mesh", std::string(xn[d]) + "min", -0.5);
+    xmax[d] = pin.GetOrAddReal("parthenon/mesh", std::string(xn[d]) + "max", 0.5);
+    mesh_bc[2 * d] = parse_bc(pin.GetOrAddString("parthenon/mesh", std::string("i") + xn[d] + "_bc", "outflow"));
+    mesh_bc[2 * d + 1] = parse_bc(pin.GetOrAddString("parthenon/mesh", std::string("o") + xn[d] + "_bc", "outflow"));
+    mbnx[d] = pin.GetOrAddInteger("parthenon/meshblock", std::string("n") + xn[d], nx[d]);
+    if (mbnx[d] < 1 || nx[d] % mbnx[d] != 0)
+      throw std::runtime_error("mesh size must be a multiple of the meshblock size");
+    nblk[d] = nx[d] / mbnx[d];
+  }
+  ndim = (nx[2] > 1) ? 3 : ((nx[1] > 1) ? 2 : 1);
+  // <parthenon/time>
+  tlim = pin.GetOrAddReal("parthenon/time", "tlim", -1.0);
+  nlim = pin.GetOrAddInteger("parthenon/time", "nlim", -1);
+  integrator = pin.GetOrAddString("parthenon/time", "integrator", "rk2");
+  // parthenon LowStorageIntegrator (upstream, recalled)
+  if (integrator == "rk1") {
+    nstages = 1, gam0[0] = 0.0, gam1[0] = 1.0, beta[0] = 1.0;
+  } else if (integrator == "rk2") {
+    nstages = 2, gam0[0] = 0.0, gam1[0] = 1.0, beta[0] = 1.0;
+    gam0[1] = 0.5, gam1[1] = 0.5, beta[1] = 0.5;
+  } else if (integrator == "vl2") {
+    nstages = 2, gam0[0] = 0.0, gam1[0] = 1.0, beta[0] = 0.5;
+    gam0[1] = 0.0, gam1[1] = 1.0, beta[1] = 1.0;
+  } else if (integrator == "rk3") {
+    nstages = 3, gam0[0] = 0.0, gam1[0] = 1.0, beta[0] = 1.0;
+    gam0[1] = 0.25, gam1[1] = 0.75, beta[1] = 0.25;
+    gam0[2] = 2.0 / 3.0, gam1[2] = 1.0 / 3.0, beta[2] = 2.0 / 3.0;
+  } else {
+    throw std::runtime_error("integrator '" + integrator + "' not recognized");
+  }
+  auto recon_of = [&](const std::string &s) {
+    if (s == "pcm") return (int)ARTEMIS_PCM;
+    if (s == "plm") return (int)ARTEMIS_PLM;
+    if (s == "ppm") return (int)ARTEMIS_PPM;
+    throw std::runtime_error("Reconstruction method not recognized.");
+  };
+  // <gas> (gas.cpp:59-208)
+  if (do_gas) {
+    recon_gas = recon_of(pin.GetOrAddString("gas", "reconstruct", "plm"));
+    const std::string r = pin.GetOrAddString("gas", "riemann", "hllc");
+    if (r == "hllc") riemann_gas = ARTEMIS_HLLC;
+    else if (r == "hlle") riemann_gas = ARTEMIS_HLLE;
+    else if (r == "llf") riemann_gas = ARTEMIS_LLF;
+    else throw std::runtime_error("Riemann solver (gas) not recognized.");
+    cfl_gas = pin.GetOrAddReal("gas", "cfl", 0.8);
+    if (pin.GetOrAddString("gas", "eos", "ideal") != "ideal")
+      throw std::runtime_error("only the ideal-gas EOS exists in the reference");
+    gamma = pin.GetOrAddReal("gas", "gamma", 1.66666666667);
+    dfloor_gas = pin.GetOrAddReal("gas", "dfloor", 1.0e-20);
+    siefloor_gas = pin.GetOrAddReal("gas", "siefloor", 1.0e-20);
+    de_switch = pin.GetOrAddReal("gas", "de_switch", 0.0);
+    ns_gas = pin.GetOrAddInteger("gas", "nspecies", 1);
+  }
+  // <dust> (dust.cpp:45-110)
+  if (do_dust) {
+    recon_dust = recon_of(pin.GetOrAddString("dust", "reconstruct", "plm"));
+    const std::string r = pin.GetOrAddString("dust", "riemann", "hlle");
+    if (r == "hlle") riemann_dust = ARTEMIS_HLLE;
+    else if (r == "llf") riemann_dust = ARTEMIS_LLF;
+    else throw std::runtime_error("Riemann solver (dust) not recognized.");
+    cfl_dust = pin.GetOrAddReal("dust", "cfl", 0.8);
+    dfloor_dust = pin.GetOrAddReal("dust", "dfloor", 1.0e-20);
+    ns_dust = pin.GetOrAddInteger("dust", "nspecies", 1);
+  }
+  auto need = [&](int recon) { return recon == ARTEMIS_PCM ? 1 : (recon == ARTEMIS_PLM ? 2 : 3); };
+  if ((do_gas && ng < need(recon_gas)) || (do_dust && ng < need(recon_dust)))
+    throw std::runtime_error("reconstruction requires more ghost cells (gas.cpp:61-76)");
+
+  build_mesh();
+  allocate();
+  fused_possible = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2;
+  use_fused = fused_possible;
+  if (!use_fused) ensure_unfused();
+  problem_generator();
+}
+
+void artemis_sim::build_mesh() {
+  choose_rank_grid(nranks, nblk, rgrid);
+  // rank -> coordinates in the rank grid (x1 fastest)
+  rcoord[0] = rank % rgrid[0];
+  rcoord[1] = (rank / rgrid[0]) % rgrid[1];
+  rcoord[2] = rank / (rgrid[0] * rgrid[1]);
+  for (int d = 0; d < 3; ++d) lblk[d] = nblk[d] / rgrid[d];
+  const int g[3] = {ng, ndim > 1 ? ng : 0, ndim > 2 ? ng : 0};
+  ni = mbnx[0] + 2 * g[0], nj = mbnx[1] + 2 * g[1], nk = mbnx[2] + 2 * g[2];
+  is = g[0], ie = g[0] + mbnx[0] - 1, js = g[1], je = g[1] + mbnx[1] - 1;
+  ks = g[2], ke = g[2] + mbnx[2] - 1;
+  N = static_cast<size_t>(ni) * nj * nk;
+  nb = lblk[0] * lblk[1] * lblk[2];
+  auto rank_of = [&](const int lx[3], int &lb) {
+    int rc[3], l[3];
+    for (int d = 0; d < 3; ++d) rc[d] = lx[d] / lblk[d], l[d] = lx[d] % lblk[d];
+    lb = (l[2] * lblk[1] + l[1]) * lblk[0] + l[0];
+    return (rc[2] * rgrid[1] + rc[1]) * rgrid[0] + rc[0];
+  };
+  blocks.resize(nb);
+  for (int b = 0; b < nb; ++b) {
+    Block &B = blocks[b];
+    int l[3] = {b % lblk[0], (b / lblk[0]) % lblk[1], b / (lblk[0] * lblk[1])};
+    for (int d = 0; d < 3; ++d) {
+      B.lx[d] = rcoord[d] * lblk[d] + l[d];
+      // parthenon default (uniform) mesh generator on the logical location (upstream,
+      // recalled): x(r) = xmin*(1-r) + xmax*r with r = lx/nblk
+      const Real rl = static_cast<Real>(B.lx[d]) / nblk[d];
+      const Real rr = static_cast<Real>(B.lx[d] + 1) / nblk[d];
+      B.xmin[d] = (B.lx[d] == 0) ? xmin[d] : xmin[d] * (1.0 - rl) + xmax[d] * rl;
+      B.xmax[d] = (B.lx[d] + 1 == nblk[d]) ? xmax[d] : xmin[d] * (1.0 - rr) + xmax[d] * rr;
+    }
+    B.gid = (static_cast<long>(B.lx[2]) * nblk[1] + B.lx[1]) * nblk[0] + B.lx[0];
+    for (int f = 0; f < 6; ++f) {
+      const int d = f / 2, side = f % 2;
+      B.nbr_rank[f] = -1, B.nbr_block[f] = -1, B.bc[f] = ARTEMIS_BC_NONE;
+      if (d >= ndim) {
+        B.bc[f] = ARTEMIS_BC_OUTFLOW; // never used: inactive direction
+        continue;
+      }
+      int nl[3] = {B.lx[0], B.lx[1], B.lx[2]};
+      nl[d] += side ? 1 : -1;
+      const bool outside = nl[d] < 0 || nl[d] >= nblk[d];
+      if (outside) {
+        if (mesh_bc[f] != ARTEMIS_BC_PERIODIC) {
+          B.bc[f] = mesh_bc[f];
+          continue;
+        }
+        if (nblk[d] == 1) { // my own periodic image: plain periodic copy on the device
+          B.bc[f] = ARTEMIS_BC_PERIODIC;
+          continue;
+        }
+        nl[d] = (nl[d] + nblk[d]) % nblk[d];
+      }
+      B.nbr_rank[f] = rank_of(nl, B.nbr_block[f]);
+    }
+  }
+  bc_flat.resize(6 * nb);
+  for (int b = 0; b < nb; ++b)
+    for (int f = 0; f < 6; ++f) bc_flat[6 * b + f] = blocks[b].bc[f];
+}
+
+void artemis_sim::allocate() {
+  CK(artemis_rt_set_device(0), "set device"); // one visible GPU per process (launcher pins it)
+  stream = artemis_rt_stream_create();
+  comm_stream = artemis_rt_stream_create();
+  ev0 = artemis_rt_event_create(), ev1 = artemis_rt_event_create();
+  if (!stream || !comm_stream || !ev0 || !ev1) throw HipFail("stream/event creation failed");
+  std::vector<Real> hg(6 * nb);
+  for (int b = 0; b < nb; ++b)
+    for (int d = 0; d < 3; ++d) {
+      // parthenon UniformCartesian (upstream, recalled): dx = (xmax-xmin)/nx,
+      // Xf(idx) = (xmin - istart*dx) + idx*dx
+      const Real dx = (blocks[b].xmax[d] - blocks[b].xmin[d]) / mbnx[d];
+      const int g = (d < ndim) ? ng : 0;
+      hg[6 * b + 2 * d] = blocks[b].xmin[d] - g * dx;
+      hg[6 * b + 2 * d + 1] = dx;
+    }
+  geom.alloc(hg.size());
+  CK(artemis_rt_memcpy_h2d(geom.p, hg.data(), hg.size() * sizeof(Real), nullptr), "h2d geom");
+  dt_dev.alloc(1);
+  dt_host = static_cast<double *>(artemis_rt_malloc_host(sizeof(double)));
+  if (!dt_host) throw HipFail("pinned allocation failed");
+  gprim[0].alloc(nb, 6 * ns_gas, N);
+  gu0.alloc(nb, 6 * ns_gas, N);
+  dprim.alloc(nb, 4 * ns_dust, N);
+  du0.alloc(nb, 4 * ns_dust, N);
+  // ghost-slab links
+  for (int b = 0; b < nb; ++b)
+    for (int f = 0; f < 2 * ndim; ++f) {
+      if (blocks[b].nbr_rank[f] < 0) continue;
+      auto L = std::make_unique<Link>();
+      L->b = b, L->face = f, L->nbr_rank = blocks[b].nbr_rank[f], L->nbr_block = blocks[b].nbr_block[f];
+      const artemis_pack_t p = make_pack(0);
+      L->count = artemis_hip_halo_count(&p, f);
+      L->sbuf.alloc(L->count);
+      if (L->nbr_rank != rank) L->rbuf.alloc(L->count);
+      // tag = (destination global block id, destination face)
+      int nl[3] = {blocks[b].lx[0], blocks[b].lx[1], blocks[b].lx[2]};
+      const int d = f / 2;
+      nl[d] = (nl[d] + ((f % 2) ? 1 : -1) + nblk[d]) % nblk[d];
+      const long ngid = (static_cast<long>(nl[2]) * nblk[1] + nl[1]) * nblk[0] + nl[0];
+      L->tag_send = static_cast<int>(ngid * 6 + (f ^ 1));
+      L->tag_recv = static_cast<int>(blocks[b].gid * 6 + f);
+      links.push_back(std::move(L));
+    }
+  CK(artemis_rt_device_sync(), "sync");
+}
+
+void artemis_sim::ensure_unfused() {
+  if (unfused_ready) return;
+  gu1.alloc(nb, 6 * ns_gas, N);
+  du1.alloc(nb, 4 * ns_dust, N);
+  for (int d = 0; d < 3; ++d) {
+    gflux[d].alloc(nb, 6 * ns_gas, N);
+    gpflux[d].alloc(nb, ns_gas, N);
+    gvface[d].alloc(nb, ns_gas, N);
+    dflux[d].alloc(nb, 4 * ns_dust, N);
+  }
+  unfused_ready = true;
+}
+
+void artemis_sim::upload_block(Field &f, int b, const std::vector<Real> &h) {
+  CK(artemis_rt_memcpy_h2d(f.var(b, 0), h.data(), h.size() * sizeof(Real), stream), "h2d");
+  CK(artemis_rt_stream_sync(stream), "sync");
+}
+std::vector<Real> artemis_sim::download(const Field &f, int b) {
+  std::vector<Real> h(static_cast<size_t>(f.nvar) * N);
+  CK(artemis_rt_stream_sync(stream), "sync");
+  CK(artemis_rt_memcpy_d2h(h.data(), f.var(b, 0), h.size() * sizeof(Real), stream), "d2h");
+  CK(artemis_rt_stream_sync(stream), "sync");
+  return h;
+}
+
+// ---------------------------------------------------------------------------------------
+// Ghost fill of the FillGhost primitives of buffer `prim_idx`: neighbour slabs (device copy
+// within the rank, comm callbacks between ranks), then physical BCs.  This is where
+// AddBoundaryExchangeTasks sits in the reference (artemis_driver.cpp:258).
+void artemis_sim::fill_ghosts_start(int prim_idx) {
+  if (links.empty()) return;
+  const artemis_pack_t p = make_pack(prim_idx);
+  std::vector<artemis_msg_t> msgs;
+  for (auto &L : links) {
+    CK(artemis_hip_halo_pack(&p, L->b, L->face, L->sbuf.p, stream), "halo pack");
+    if (L->nbr_rank != rank) {
+      artemis_msg_t m;
+      m.peer = L->nbr_rank, m.tag = L->tag_send, m.send = L->sbuf.p, m.recv = nullptr, m.count = L->count;
+      msgs.push_back(m);
+      m.tag = L->tag_recv, m.send = nullptr, m.recv = L->rbuf.p;
+      msgs.push_back(m);
+    }
+  }
+  if (!msgs.empty()) {
+    if (!has_comm) throw std::runtime_error("remote neighbours but no communicator");
+    // sends may start once the packs are done: order the comm stream after the compute stream
+    CK(artemis_rt_event_record(ev0, stream), "event");
+    CK(artemis_rt_stream_wait_event(comm_stream, ev0), "wait");
+    if (comm.exchange_start(comm.ctx, static_cast<int>(msgs.size()), msgs.data(), comm_stream))
+      throw std::runtime_error("exchange_start failed");
+  }
+}
+void artemis_sim::fill_ghosts_finish(int prim_idx) {
+  const artemis_pack_t p = make_pack(prim_idx);
+  bool remote = false;
+  for (auto &L : links) remote = remote || (L->nbr_rank != rank);
+  if (remote) {
+    if (comm.exchange_finish(comm.ctx, comm_stream)) throw std::runtime_error("exchange_finish failed");
+    CK(artemis_rt_event_record(ev1, comm_stream), "event");
+    CK(artemis_rt_stream_wait_event(stream, ev1), "wait");
+  }
+  for (auto &L : links) {
+    if (L->nbr_rank == rank) {
+      CK(artemis_hip_halo_unpack(&p, L->nbr_block, L->face ^ 1, L->sbuf.p, stream), "halo unpack");
+    } else {
+      // what I received through face f came from the neighbour's opposite face
+      CK(artemis_hip_halo_unpack(&p, L->b, L->face, L->rbuf.p, stream), "halo unpack");
+    }
+  }
+  CK(artemis_hip_apply_bc(&p, bc_flat.data(), stream), "apply_bc");
+}
+void artemis_sim::fill_ghosts(int prim_idx) {
+  fill_ghosts_start(prim_idx);
+  fill_ghosts_finish(prim_idx);
+}
+
+void artemis_sim::materialise_cons() {
+  if (cons_valid) return;
+  const artemis_pack_t p = make_pack(base);
+  CK(artemis_hip_prim_to_cons(&p, stream), "PrimToCons");
+  cons_valid = true;
+}
+
+// ---------------------------------------------------------------------------------------
+// pgen/linear_wave.hpp:117-215 and pgen/advection.hpp:62-168: wavevector set-up
+void artemis_sim::lw_setup(bool eigen) {
+  const bool multi_d = ndim > 1, three_d = ndim > 2;
+  const bool along_x1 = pin.GetOrAddBoolean("problem", "along_x1", false);
+  const bool along_x2 = pin.GetOrAddBoolean("problem", "along_x2", false);
+  const bool along_x3 = pin.GetOrAddBoolean("problem", "along_x3", false);
+  if ((along_x1 && (along_x2 || along_x3)) || (along_x2 && along_x3))
+    throw std::runtime_error("Can only specify one of along_x1/2/3 to be true");
+  if ((along_x2 || along_x3) && ndim == 1)
+    throw std::runtime_error("Cannot specify waves along x2 or x3 axis in 1D");
+  if (along_x3 && ndim == 2) throw std::runtime_error("Cannot specify waves along x3 axis in 2D");
+  const Real x1size = xmax[0] - xmin[0], x2size = xmax[1] - xmin[1], x3size = xmax[2] - xmin[2];
+  lw.cos_a3 = 1.0, lw.sin_a3 = 0.0, lw.cos_a2 = 1.0, lw.sin_a2 = 0.0;
+  if (multi_d && !along_x1) {
+    const Real ang_3 = std::atan(x1size / x2size);
+    lw.sin_a3 = std::sin(ang_3), lw.cos_a3 = std::cos(ang_3);
+  }
+  if (three_d && !along_x1) {
+    const Real ang_2 = std::atan(0.5 * (x1size * lw.cos_a3 + x2size * lw.sin_a3) / x3size);
+    lw.sin_a2 = std::sin(ang_2), lw.cos_a2 = std::cos(ang_2);
+  }
+  if (along_x2) lw.cos_a3 = 0.0, lw.sin_a3 = 1.0, lw.cos_a2 = 1.0, lw.sin_a2 = 0.0;
+  if (along_x3) lw.cos_a3 = 0.0, lw.sin_a3 = 1.0, lw.cos_a2 = 0.0, lw.sin_a2 = 1.0;
+  lw.lambda = std::numeric_limits<float>::max();
+  if (lw.cos_a2 * lw.cos_a3 > 0.0) lw.lambda = std::min(lw.lambda, x1size * lw.cos_a2 * lw.cos_a3);
+  if (lw.cos_a2 * lw.sin_a3 > 0.0) lw.lambda = std::min(lw.lambda, x2size * lw.cos_a2 * lw.sin_a3);
+  if (lw.sin_a2 > 0.0) lw.lambda = std::min(lw.lambda, x3size * lw.sin_a2);
+  lw.k_par = 2.0 * (M_PI) / lw.lambda;
+  lw.d0 = 1.0, lw.v1_0 = lw.vflow;
+  lw.gamma = gamma, lw.gm1 = gamma - 1.0, lw.p0 = 1.0 / gamma;
+  if (eigen) { // linear_wave.hpp:58-111 HydroEigensystem(d0, v1_0, 0, 0, p0, gamma)
+    const Real d = lw.d0, v1 = lw.v1_0, v2 = 0.0, v3 = 0.0, p = lw.p0;
+    const Real vsq = v1 * v1 + v2 * v2 + v3 * v3;
+    const Real h = (p / (gamma - 1.0) + 0.5 * d * vsq + p) / d;
+    const Real a = std::sqrt(gamma * p / d);
+    lw.ev[0] = v1 - a, lw.ev[1] = v1, lw.ev[2] = v1, lw.ev[3] = v1, lw.ev[4] = v1 + a;
+    Real(&r)[5][5] = lw.rem;
+    r[0][0] = 1.0, r[1][0] = v1 - a, r[2][0] = v2, r[3][0] = v3, r[4][0] = h - v1 * a;
+    r[0][1] = 0.0, r[1][1] = 0.0, r[2][1] = 1.0, r[3][1] = 0.0, r[4][1] = v2;
+    r[0][2] = 0.0, r[1][2] = 0.0, r[2][2] = 0.0, r[3][2] = 1.0, r[4][2] = v3;
+    r[0][3] = 1.0, r[1][3] = v1, r[2][3] = v2, r[3][3] = v3, r[4][3] = 0.5 * vsq;
+    r[0][4] = 1.0, r[1][4] = v1 + a, r[2][4] = v2, r[3][4] = v3, r[4][4] = h + v1 * a;
+  }
+}
+
+void artemis_sim::problem_generator() {
+  const Real gm1 = gamma - 1.0;
+  auto xf = [&](int b, int d, int idx) { // Coordinates_t::Xf (geometry.hpp:65-72)
+    const Real dx = (blocks[b].xmax[d] - blocks[b].xmin[d]) / mbnx[d];
+    const int g = (d < ndim) ? ng : 0;
+    return (blocks[b].xmin[d] - g * dx) + idx * dx;
+  };
+  if (pgen == PG_LINWAVE) {
+    lw.wave_flag = pin.GetInteger("problem", "wave_flag");
+    lw.amp = pin.GetReal("problem", "amp");
+    lw.vflow = pin.GetOrAddReal("problem", "vflow", 0.0);
+    lw_setup(true);
+    const Real nperiod = pin.GetOrAddReal("problem", "nperiod", 1.0);
+    tlim = nperiod * (std::abs(lw.lambda / lw.ev[lw.wave_flag])); // linear_wave.hpp:214-215
+  } else if (pgen == PG_ADVECTION) {
+    lw.amp = pin.GetReal("problem", "amp");
+    lw.vflow = pin.GetOrAddReal("problem", "vflow", 0.0);
+    if (do_gas && ns_gas != 1) throw std::runtime_error("Advection pgen requires a single gas species.");
+    if (do_dust && ns_dust != 2) throw std::runtime_error("Advection pgen requires two dust species.");
+    lw_setup(false);
+    const Real nperiod = pin.GetOrAddReal("problem", "nperiod", 1.0);
+    tlim = nperiod * (std::abs(lw.lambda / lw.v1_0)); // advection.hpp:167-168
+  }
+  // blast parameters (blast.hpp:137-155)
+  const Real rinit = pin.GetOrAddReal("problem", "radius", 1.0);
+  const Real ienergy = pin.GetOrAddReal("problem", "internal_energy", 1.0);
+  const Real p0 = pin.GetOrAddReal("problem", "p0", 1.0);
+  const Real d0 = pin.GetOrAddReal("problem", "d0", 1.0);
+  const Real x0[3] = {pin.GetOrAddReal("problem", "x1", 0.0), pin.GetOrAddReal("problem", "x2", 0.0),
+                      pin.GetOrAddReal("problem", "x3", 0.0)};
+  const int samples = pin.GetOrAddInteger("problem", "samples", -1);
+  const std::string sym = pin.GetOrAddString("problem", "symmetry", "spherical");
+  if (pgen == PG_BLAST && sym != "spherical" && sym != "cylindrical")
+    throw std::runtime_error("Bad blast wave symmetry parameter in <problem>!");
+  const int btype = (sym == "spherical") ? 1 : 2;
+
+  std::vector<Real> hg(static_cast<size_t>(6) * ns_gas * N), hd(static_cast<size_t>(4) * ns_dust * N);
+  for (int b = 0; b < nb; ++b) {
+    std::fill(hg.begin(), hg.end(), 0.0);
+    std::fill(hd.begin(), hd.end(), 0.0);
+    for (int k = 0; k < nk; ++k)
+      for (int j = 0; j < nj; ++j)
+        for (int i = 0; i < ni; ++i) {
+          const Real b1[2] = {xf(b, 0, i), xf(b, 0, i + 1)}, b2[2] = {xf(b, 1, j), xf(b, 1, j + 1)};
+          const Real b3[2] = {xf(b, 2, k), xf(b, 2, k + 1)};
+          const Real xv[3] = {0.5 * (b1[0] + b1[1]), 0.5 * (b2[0] + b2[1]), 0.5 * (b3[0] + b3[1])};
+          const size_t c = (static_cast<size_t>(k) * nj + j) * ni + i;
+          if (pgen == PG_BLAST) { // blast.hpp:168-228
+            const Real total_vol = (b1[1] - b1[0]) * (b2[1] - b2[0]) * (b3[1] - b3[0]);
+            const Real e0 = p0 / gm1;
+            Real xc[3] = {xv[0], xv[1], xv[2]};
+            for (int n = 0; n < 3; n++) xc[n] -= x0[n];
+            Real vol;
+            if (samples > 0) {
+              // compute_overlap_{sph,cyl} (blast.hpp:65-106): sub-sample the zone.  Zones whose
+              // sample points are all outside (inside) the sphere are counted directly; the
+              // counts, and so the products below, are the same as the loops would give.
+              const bool sph = (btype == 1);
+              const Real dxf = (b1[1] - b1[0]) / (Real)samples, dyf = (b2[1] - b2[0]) / (Real)samples;
+              const Real dzf = (b3[1] - b3[0]) / (Real)samples;
+              auto nearest = [](const Real *bb) { return (bb[0] > 0) ? bb[0] : ((bb[1] < 0) ? -bb[1] : 0.0); };
+              auto farthest = [](const Real *bb) { return std::max(std::abs(bb[0]), std::abs(bb[1])); };
+              const Real nz = sph ? nearest(b3) : 0.0, fz = sph ? farthest(b3) : 0.0;
+              const Real dmin2 = SQR(nearest(b1)) + SQR(nearest(b2)) + SQR(nz);
+              const Real dmax2 = SQR(farthest(b1)) + SQR(farthest(b2)) + SQR(fz);
+              long tot = 0;
+              const long full = sph ? (long)samples * samples * samples : (long)samples * samples;
+              if (dmin2 > SQR(rinit) * (1.0 + 1e-12)) {
+                tot = 0;
+              } else if (dmax2 < SQR(rinit) * (1.0 - 1e-12)) {
+                tot = full;
+              } else {
+                for (int ii = 0; ii < samples; ii++) {
+                  const Real xs = b1[0] + (ii + 0.5) * dxf;
+                  for (int jj = 0; jj < samples; jj++) {
+                    const Real ys = b2[0] + (jj + 0.5) * dyf;
+                    if (sph) {
+                      for (int kk = 0; kk < samples; kk++) {
+                        const Real zs = b3[0] + (kk + 0.5) * dzf;
+                        if (SQR(xs) + SQR(ys) + SQR(zs) <= SQR(rinit)) tot++;
+                      }
+                    } else if (SQR(xs) + SQR(ys) <= SQR(rinit)) {
+                      tot++;
+                    }
+                  }
+                }
+              }
+              vol = sph ? tot * dxf * dyf * dzf : tot * dxf * dyf;
+            } else {
+              vol = ((SQR(xc[0]) + SQR(xc[1]) + SQR(xc[2]) < rinit * rinit) ? total_vol : 0.0);
+            }
+            Real ie_;
+            if (btype == 1)
+              ie_ = e0 * (1.0 - vol / total_vol) +
+                    ienergy * vol / total_vol / (4.0 * M_PI / 3.0 * rinit * rinit * rinit);
+            else
+              ie_ = e0 * (1.0 - vol / total_vol) + ienergy * vol / total_vol / (M_PI * rinit * rinit);
+            hg[0 * N + c] = d0;
+            hg[(5 * ns_gas) * N + c] = ie_ / d0;
+          } else { // linear_wave.hpp:231-258 / advection.hpp:185-216
+            const Real x = lw.cos_a2 * (xv[0] * lw.cos_a3 + xv[1] * lw.sin_a3) + xv[2] * lw.sin_a2;
+            const Real sn = std::sin(lw.k_par * x);
+            Real cd, cm1, cm2, cm3, ce;
+            if (pgen == PG_LINWAVE) {
+              const int wf = lw.wave_flag;
+              const Real mx = lw.d0 * lw.vflow + lw.amp * sn * lw.rem[1][wf];
+              const Real my = lw.amp * sn * lw.rem[2][wf];
+              const Real mz = lw.amp * sn * lw.rem[3][wf];
+              cd = lw.d0 + lw.amp * sn * lw.rem[0][wf];
+              cm1 = mx * lw.cos_a2 * lw.cos_a3 - my * lw.sin_a3 - mz * lw.sin_a2 * lw.cos_a3;
+              cm2 = mx * lw.cos_a2 * lw.sin_a3 + my * lw.cos_a3 - mz * lw.sin_a2 * lw.sin_a3;
+              cm3 = mx * lw.sin_a2 + mz * lw.cos_a2;
+              ce = lw.p0 / lw.gm1 + 0.5 * lw.d0 * (lw.v1_0) * (lw.v1_0) + lw.amp * sn * lw.rem[4][wf];
+            } else {
+              const Real mx = lw.d0 * lw.vflow + lw.amp * sn * lw.v1_0;
+              cd = lw.d0 + lw.amp * sn;
+              cm1 = mx * lw.cos_a2 * lw.cos_a3;
+              cm2 = mx * lw.cos_a2 * lw.sin_a3;
+              cm3 = mx * lw.sin_a2;
+              ce = lw.p0 / lw.gm1 + 0.5 * lw.d0 * SQR(lw.v1_0) + 0.5 * lw.d0 * lw.amp * sn * SQR(lw.v1_0);
+            }
+            const Real cu = ce - 0.5 * (SQR(cm1) + SQR(cm2) + SQR(cm3)) / cd;
+            if (do_gas) {
+              hg[0 * N + c] = cd;
+              hg[(ns_gas + 0) * N + c] = cm1 / cd;
+              hg[(ns_gas + 1) * N + c] = cm2 / cd;
+              hg[(ns_gas + 2) * N + c] = cm3 / cd;
+              hg[(5 * ns_gas) * N + c] = cu / cd;
+            }
+            if (do_dust && pgen == PG_ADVECTION) {
+              hd[0 * N + c] = cd;
+              hd[(ns_dust + 0) * N + c] = cm1 / cd;
+              hd[(ns_dust + 1) * N + c] = cm2 / cd;
+              hd[(ns_dust + 2) * N + c] = cm3 / cd;
+              hd[1 * N + c] = cd;
+              hd[(ns_dust + 3) * N + c] = -cm1 / cd;
+              hd[(ns_dust + 4) * N + c] = -cm2 / cd;
+              hd[(ns_dust + 5) * N + c] = -cm3 / cd;
+            }
+          }
+        }
+    if (do_gas) upload_block(gprim[0], b, hg);
+    if (do_dust) upload_block(dprim, b, hd);
+  }
+  base = 0;
+  // PostInitialization = PrimToCons on every block (main.cpp:43, fill_derived.cpp:284-287),
+  // then parthenon Mesh::Initialize communicates boundaries (upstream, recalled):
+  // PreCommFillDerived (ConsToPrim, artemis.cpp:122) -> exchange + physical BCs ->
+  // FillDerived (PrimToCons, artemis.cpp:123).
+  const artemis_pack_t p = make_pack(0);
+  CK(artemis_hip_prim_to_cons(&p, stream), "PrimToCons");
+  CK(artemis_hip_cons_to_prim(&p, stream), "ConsToPrim");
+  fill_ghosts(0);
+  CK(artemis_hip_prim_to_cons(&p, stream), "PrimToCons");
+  cons_valid = true;
+  CK(artemis_rt_stream_sync(stream), "sync");
+}
+
+// ---------------------------------------------------------------------------------------
+// PostStepTasks -> EstimateTimestep (artemis_driver.cpp:279-297): min over packages, local.
+Real artemis_sim::new_dt_unfused() {
+  const artemis_pack_t p = make_pack(base);
+  *dt_host = DBL_MAX;
+  CK(artemis_rt_memcpy_h2d(dt_dev.p, dt_host, sizeof(double), stream), "h2d");
+  if (do_gas) CK(artemis_hip_estimate_dt_async(&p, ARTEMIS_GAS, cfl_gas, dt_dev.p, stream), "dt gas");
+  if (do_dust) CK(artemis_hip_estimate_dt_async(&p, ARTEMIS_DUST, cfl_dust, dt_dev.p, stream), "dt dust");
+  CK(artemis_rt_memcpy_d2h(dt_host, dt_dev.p, sizeof(double), stream), "d2h");
+  CK(artemis_rt_stream_sync(stream), "sync");
+  return *dt_host;
+}
+
+// One step on the fused path: one kernel per stage, primitives ping-ponged between buffers.
+void artemis_sim::step_fused(bool want_dt) {
+  for (int q = 1; q < 3; ++q)
+    if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
+  const int A = base;
+  int cur = A;
+  if (want_dt) {
+    *dt_host = DBL_MAX;
+    CK(artemis_rt_memcpy_h2d(dt_dev.p, dt_host, sizeof(double), stream), "h2d");
+  }
+  for (int stage = 1; stage <= nstages; ++stage) {
+    const bool last = (stage == nstages);
+    int out;
+    if (last && cur != A) out = A; // aliases prim_u1: cell-wise access only
+    else out = (cur + 1) % 3 == A ? (cur + 2) % 3 : (cur + 1) % 3;
+    const artemis_pack_t p = make_pack(cur);
+    artemis_stage_args_t a;
+    std::memset(&a, 0, sizeof a);
+    a.gam0 = gam0[stage - 1], a.gam1 = gam1[stage - 1];
+    a.beta_dt = beta[stage - 1] * dt; // artemis_integrator.hpp:66
+    a.bdt = beta[stage - 1] * dt;     // artemis_driver.cpp:168
+    a.pcm = (stage == 1 && integrator == "vl2"); // artemis_driver.cpp:182
+    a.prim_in = gprim[cur].tab(), a.prim_u1 = gprim[A].tab(), a.prim_out = gprim[out].tab();
+    a.cons_out = nullptr;
+    a.cfl = cfl_gas;
+    a.dt_dev = (last && want_dt) ? dt_dev.p : nullptr;
+    void *e0 = nullptr, *e1 = nullptr;
+    if (time_kernels) {
+      e0 = artemis_rt_event_create(), e1 = artemis_rt_event_create();
+      CK(artemis_rt_event_record(e0, stream), "event");
+    }
+    CK(artemis_hip_stage_fused(&p, &a, stream), "stage_fused");
+    if (time_kernels) {
+      CK(artemis_rt_event_record(e1, stream), "event");
+      kev.emplace_back(e0, e1);
+    }
+    fill_ghosts(out);
+    cur = out;
+  }
+  base = cur;
+  cons_valid = false;
+}
+
+// One step on the per-task path (artemis_driver.cpp:157-261 literally).
+void artemis_sim::step_unfused() {
+  ensure_unfused();
+  materialise_cons();
+  const artemis_pack_t p = make_pack(base);
+  CK(artemis_hip_deep_copy_conserved(&p, stream), "DeepCopyConservedData");
+  for (int stage = 1; stage <= nstages; ++stage) {
+    const Real bdt = beta[stage - 1] * dt;
+    const int do_pcm = (stage == 1 && integrator == "vl2");
+    if (do_gas) CK(artemis_hip_calculate_fluxes(&p, ARTEMIS_GAS, do_pcm, stream), "Gas::CalculateFluxes");
+    if (do_dust) CK(artemis_hip_calculate_fluxes(&p, ARTEMIS_DUST, do_pcm, stream), "Dust::CalculateFluxes");
+    CK(artemis_hip_apply_update(&p, gam0[stage - 1], gam1[stage - 1], beta[stage - 1] * dt, stream), "ApplyUpdate");
+    if (do_gas) CK(artemis_hip_flux_source(&p, ARTEMIS_GAS, bdt, stream), "Gas::FluxSource");
+    if (do_dust) CK(artemis_hip_flux_source(&p, ARTEMIS_DUST, bdt, stream), "Dust::FluxSource");
+    CK(artemis_hip_set_aux(&p, stream), "SetAuxillaryFields");
+    CK(artemis_hip_cons_to_prim(&p, stream), "ConsToPrim");
+    fill_ghosts(base);
+    CK(artemis_hip_prim_to_cons(&p, stream), "PrimToCons");
+  }
+  cons_valid = true;
+}
+
+// parthenon EvolutionDriver::Execute + SetGlobalTimeStep (upstream, recalled; pinned by
+// tst/scripts/advection/advection.py:100-118).
+long artemis_sim::evolve(long max_cycles) {
+  auto global_min = [&](Real v) {
+    if (has_comm && nranks > 1 && comm.allreduce_min(comm.ctx, &v)) throw std::runtime_error("allreduce failed");
+    return v;
+  };
+  if (ncycle == 0 && time == 0.0 && dt == DBL_MAX) {
+    dt = global_min(new_dt_unfused());
+    if (tlim > 0.0 && time < tlim && (tlim - time) < dt) dt = tlim - time;
+  }
+  for (auto &pr : kev) artemis_rt_event_destroy(pr.first), artemis_rt_event_destroy(pr.second);
+  kev.clear();
+  CK(artemis_rt_device_sync(), "sync");
+  const auto t0 = std::chrono::steady_clock::now();
+  long n = 0;
+  while ((tlim < 0.0 || time < tlim) && (nlim < 0 || ncycle < nlim) && (max_cycles < 0 || n < max_cycles)) {
+    Real est;
+    if (use_fused) {
+      step_fused(true);
+      CK(artemis_rt_memcpy_d2h(dt_host, dt_dev.p, sizeof(double), stream), "d2h");
+      CK(artemis_rt_stream_sync(stream), "sync");
+      est = *dt_host;
+    } else {
+      step_unfused();
+      est = new_dt_unfused();
+    }
+    time += dt;
+    ncycle++, n++;
+    Real ndt = dt;
+    if (ndt < 0.1 * DBL_MAX) ndt *= 2.0;
+    ndt = std::min(ndt, global_min(est));
+    if (tlim > 0.0 && time < tlim && (tlim - time) < ndt) ndt = tlim - time;
+    dt = ndt;
+  }
+  CK(artemis_rt_device_sync(), "sync");
+  last_wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  kernel_ms_sum = 0.0, kernel_launches = 0;
+  for (auto &pr : kev) {
+    const double ms = artemis_rt_event_elapsed_ms(pr.first, pr.second);
+    if (ms >= 0.0) kernel_ms_sum += ms, kernel_launches++;
+  }
+  return n;
+}
+
+// utils/history.hpp:29-100 (volume integrals of the conserved fields)
+int artemis_sim::history(double *out) {
+  materialise_cons();
+  const int nout = 6 + 4 * ns_dust;
+  for (int q = 0; q < nout; ++q) out[q] = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    std::vector<Real> g, d;
+    if (do_gas) g = download(gu0, b);
+    if (do_dust) d = download(du0, b);
+    const Real dx[3] = {(blocks[b].xmax[0] - blocks[b].xmin[0]) / mbnx[0],
+                        (blocks[b].xmax[1] - blocks[b].xmin[1]) / mbnx[1],
+                        (blocks[b].xmax[2] - blocks[b].xmin[2]) / mbnx[2]};
+    const Real f0[3] = {blocks[b].xmin[0] - is * dx[0], blocks[b].xmin[1] - js * dx[1],
+                        blocks[b].xmin[2] - ks * dx[2]};
+    for (int k = ks; k <= ke; ++k)
+      for (int j = js; j <= je; ++j)
+        for (int i = is; i <= ie; ++i) {
+          const Real vv = ((f0[0] + (i + 1) * dx[0]) - (f0[0] + i * dx[0])) *
+                          ((f0[1] + (j + 1) * dx[1]) - (f0[1] + j * dx[1])) *
+                          ((f0[2] + (k + 1) * dx[2]) - (f0[2] + k * dx[2]));
+          const size_t c = (static_cast<size_t>(k) * nj + j) * ni + i;
+          if (do_gas) {
+            out[0] += g[0 * N + c] * vv;
+            for (int q = 0; q < 3; ++q) out[1 + q] += g[(ns_gas + q) * N + c] * vv;
+            out[4] += g[(4 * ns_gas) * N + c] * vv;
+            out[5] += g[(5 * ns_gas) * N + c] * vv;
+          }
+          for (int n = 0; n < ns_dust; ++n) {
+            out[6 + 4 * n] += d[n * N + c] * vv;
+            for (int q = 0; q < 3; ++q) out[6 + 4 * n + 1 + q] += d[(ns_dust + 3 * n + q) * N + c] * vv;
+          }
+        }
+  }
+  if (has_comm && nranks > 1 && comm.allreduce_sum(comm.ctx, out, nout)) throw std::runtime_error("allreduce failed");
+  return nout;
+}
+
+// linear_wave.hpp:267-377 / advection.hpp:224-405 UserWorkAfterLoop
+int artemis_sim::errors(double *out) {
+  if (pgen == PG_BLAST) return 0;
+  materialise_cons();
+  Real l1[13];
+  for (int q = 0; q < 13; ++q) l1[q] = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    std::vector<Real> g, d;
+    if (do_gas) g = download(gu0, b);
+    if (do_dust) d = download(du0, b);
+    const Real dx[3] = {(blocks[b].xmax[0] - blocks[b].xmin[0]) / mbnx[0],
+                        (blocks[b].xmax[1] - blocks[b].xmin[1]) / mbnx[1],
+                        (blocks[b].xmax[2] - blocks[b].xmin[2]) / mbnx[2]};
+    const Real f0[3] = {blocks[b].xmin[0] - is * dx[0], blocks[b].xmin[1] - js * dx[1],
+                        blocks[b].xmin[2] - ks * dx[2]};
+    for (int k = ks; k <= ke; ++k)
+      for (int j = js; j <= je; ++j)
+        for (int i = is; i <= ie; ++i) {
+          const Real b1[2] = {f0[0] + i * dx[0], f0[0] + (i + 1) * dx[0]};
+          const Real b2[2] = {f0[1] + j * dx[1], f0[1] + (j + 1) * dx[1]};
+          const Real b3[2] = {f0[2] + k * dx[2], f0[2] + (k + 1) * dx[2]};
+          const Real x1v = 0.5 * (b1[0] + b1[1]), x2v = 0.5 * (b2[0] + b2[1]), x3v = 0.5 * (b3[0] + b3[1]);
+          const Real vol = (b1[1] - b1[0]) * (b2[1] - b2[0]) * (b3[1] - b3[0]);
+          const Real x = lw.cos_a2 * (x1v * lw.cos_a3 + x2v * lw.sin_a3) + x3v * lw.sin_a2;
+          const Real sn = std::sin(lw.k_par * x);
+          const size_t c = (static_cast<size_t>(k) * nj + j) * ni + i;
+          if (pgen == PG_LINWAVE) {
+            const int wf = lw.wave_flag;
+            const Real mx = lw.d0 * lw.vflow + lw.amp * sn * lw.rem[1][wf];
+            const Real my = lw.amp * sn * lw.rem[2][wf];
+            const Real mz = lw.amp * sn * lw.rem[3][wf];
+            const Real ca = lw.d0 + lw.amp * sn * lw.rem[0][wf];
+            const Real cm1 = mx * lw.cos_a2 * lw.cos_a3 - my * lw.sin_a3 - mz * lw.sin_a2 * lw.cos_a3;
+            const Real cm2 = mx * lw.cos_a2 * lw.sin_a3 + my * lw.cos_a3 - mz * lw.sin_a2 * lw.sin_a3;
+            const Real cm3 = mx * lw.sin_a2 + mz * lw.cos_a2;
+            const Real ce = lw.p0 / lw.gm1 + 0.5 * lw.d0 * (lw.v1_0) * (lw.v1_0) + lw.amp * sn * lw.rem[4][wf];
+            l1[0] += vol * std::abs(g[0 * N + c] - ca);
+            l1[1] += vol * std::abs(g[(ns_gas + 0) * N + c] - cm1);
+            l1[2] += vol * std::abs(g[(ns_gas + 1) * N + c] - cm2);
+            l1[3] += vol * std::abs(g[(ns_gas + 2) * N + c] - cm3);
+            l1[4] += vol * std::abs(g[(4 * ns_gas) * N + c] - ce);
+          } else {
+            const Real mx = lw.d0 * lw.vflow + lw.amp * sn * lw.v1_0;
+            const Real cd = lw.d0 + lw.amp * sn;
+            const Real cm1 = mx * lw.cos_a2 * lw.cos_a3, cm2 = mx * lw.cos_a2 * lw.sin_a3, cm3 = mx * lw.sin_a2;
+            const Real ce = lw.p0 / lw.gm1 + 0.5 * lw.d0 * SQR(lw.v1_0) + 0.5 * lw.d0 * lw.amp * sn * SQR(lw.v1_0);
+            if (do_gas) {
+              l1[0] += vol * std::abs(g[0 * N + c] - cd);
+              l1[1] += vol * std::abs(g[(ns_gas + 0) * N + c] - cm1);
+              l1[2] += vol * std::abs(g[(ns_gas + 1) * N + c] - cm2);
+              l1[3] += vol * std::abs(g[(ns_gas + 2) * N + c] - cm3);
+              l1[4] += vol * std::abs(g[(4 * ns_gas) * N + c] - ce);
+            }
+            if (do_dust) {
+              l1[5] += vol * std::abs(d[0 * N + c] - cd);
+              l1[6] += vol * std::abs(d[(ns_dust + 0) * N + c] - cm1);
+              l1[7] += vol * std::abs(d[(ns_dust + 1) * N + c] - cm2);
+              l1[8] += vol * std::abs(d[(ns_dust + 2) * N + c] - cm3);
+              l1[9] += vol * std::abs(d[1 * N + c] - cd);
+              l1[10] += vol * std::abs(d[(ns_dust + 3) * N + c] + cm1);
+              l1[11] += vol * std::abs(d[(ns_dust + 4) * N + c] + cm2);
+              l1[12] += vol * std::abs(d[(ns_dust + 5) * N + c] + cm3);
+            }
+          }
+        }
+  }
+  const int nv = (pgen == PG_LINWAVE) ? 5 : 13;
+  if (has_comm && nranks > 1 && comm.allreduce_sum(comm.ctx, l1, nv)) throw std::runtime_error("allreduce failed");
+  const Real vol = (xmax[0] - xmin[0]) * (xmax[1] - xmin[1]) * (xmax[2] - xmin[2]);
+  for (int q = 0; q < nv; ++q) l1[q] = l1[q] / vol;
+  if (pgen == PG_LINWAVE) {
+    Real rms = 0.0;
+    for (int q = 0; q < 5; ++q) rms += SQR(l1[q]), out[1 + q] = l1[q];
+    out[0] = std::sqrt(rms);
+    return 6;
+  }
+  Real rg = 0, r1 = 0, r2 = 0;
+  for (int q = 0; q < 5; ++q) rg += SQR(l1[q]);
+  for (int q = 5; q < 9; ++q) r1 += SQR(l1[q]);
+  for (int q = 9; q < 13; ++q) r2 += SQR(l1[q]);
+  out[0] = std::sqrt(rg), out[1] = std::sqrt(r1), out[2] = std::sqrt(r2);
+  for (int q = 0; q < 13; ++q) out[3 + q] = l1[q];
+  return 16;
+}
+
+// =======================================================================================
+#define GUARD(expr, onerr)                                                                 \
+  try {                                                                                    \
+    expr;                                                                                  \
+  } catch (const std::exception &e) {                                                      \
+    g_sim_err = e.what();                                                                  \
+    onerr;                                                                                 \
+  }
+
+extern "C" {
+
+const char *artemis_sim_last_error(void) { return g_sim_err.c_str(); }
+
+artemis_sim_t *artemis_sim_create(const char *deck_text, int noverrides,
+                                  const char *const *overrides, const artemis_comm_t *comm) {
+  if (!deck_text) {
+    g_sim_err = "null deck";
+    return nullptr;
+  }
+  artemis_sim *s = nullptr;
+  GUARD(s = new artemis_sim(); s->setup(deck_text, noverrides, overrides, comm), {
+    delete s;
+    return nullptr;
+  })
+  return s;
+}
+void artemis_sim_destroy(artemis_sim_t *sim) {
+  if (!sim) return;
+  artemis_rt_device_sync();
+  for (auto &pr : sim->kev) artemis_rt_event_destroy(pr.first), artemis_rt_event_destroy(pr.second);
+  if (sim->dt_host) artemis_rt_free_host(sim->dt_host);
+  artemis_rt_event_destroy(sim->ev0), artemis_rt_event_destroy(sim->ev1);
+  artemis_rt_stream_destroy(sim->stream), artemis_rt_stream_destroy(sim->comm_stream);
+  delete sim;
+}
+long artemis_sim_evolve(artemis_sim_t *sim, long max_cycles) {
+  long n = -1;
+  GUARD(n = sim->evolve(max_cycles), return -1)
+  return n;
+}
+double artemis_sim_time(const artemis_sim_t *s) { return s->time; }
+double artemis_sim_dt(const artemis_sim_t *s) { return s->dt; }
+double artemis_sim_tlim(const artemis_sim_t *s) { return s->tlim; }
+long artemis_sim_ncycle(const artemis_sim_t *s) { return s->ncycle; }
+long artemis_sim_local_zones(const artemis_sim_t *s) {
+  return static_cast<long>(s->nb) * s->mbnx[0] * s->mbnx[1] * s->mbnx[2];
+}
+long artemis_sim_total_zones(const artemis_sim_t *s) {
+  return static_cast<long>(s->nx[0]) * s->nx[1] * s->nx[2];
+}
+int artemis_sim_uses_fused_path(const artemis_sim_t *s) { return s->use_fused ? 1 : 0; }
+int artemis_sim_set_path(artemis_sim_t *s, const char *which) {
+  const std::string w = which ? which : "";
+  if (w == "fused") {
+    if (!s->fused_possible) {
+      g_sim_err = "fused path needs: one gas species, no dust, pcm|plm, nghost >= 2";
+      return 1;
+    }
+    s->use_fused = true;
+    return 0;
+  }
+  if (w == "unfused") {
+    GUARD(s->ensure_unfused(), return 1)
+    s->use_fused = false;
+    return 0;
+  }
+  g_sim_err = "path must be fused|unfused";
+  return 1;
+}
+int artemis_sim_set_overlap(artemis_sim_t *s, int overlap) {
+  s->overlap = overlap != 0;
+  return 0;
+}
+void artemis_sim_set_kernel_timing(artemis_sim_t *s, int on) { s->time_kernels = on != 0; }
+void artemis_sim_dims(const artemis_sim_t *s, int *d) {
+  d[0] = s->nb, d[1] = s->ni, d[2] = s->nj, d[3] = s->nk, d[4] = s->is, d[5] = s->ie;
+  d[6] = s->js, d[7] = s->je, d[8] = s->ks, d[9] = s->ke, d[10] = s->ng;
+}
+void artemis_sim_block_bounds(const artemis_sim_t *s, int b, double *o) {
+  for (int d = 0; d < 3; ++d) o[2 * d] = s->blocks[b].xmin[d], o[2 * d + 1] = s->blocks[b].xmax[d];
+}
+int artemis_sim_get_field(artemis_sim_t *s, const char *field, int block, double *host_out) {
+  const std::string f = field ? field : "";
+  if (block < 0 || block >= s->nb) {
+    g_sim_err = "bad block";
+    return -1;
+  }
+  int nv = -1;
+  GUARD(
+      {
+        s->materialise_cons();
+        const Field *F = nullptr;
+        if (f == "gas.prim") F = &s->gprim[s->base];
+        else if (f == "gas.cons") F = &s->gu0;
+        else if (f == "dust.prim") F = &s->dprim;
+        else if (f == "dust.cons") F = &s->du0;
+        else throw std::runtime_error("unknown field " + f);
+        const std::vector<Real> h = s->download(*F, block);
+        std::memcpy(host_out, h.data(), h.size() * sizeof(Real));
+        nv = F->nvar;
+      },
+      return -1)
+  return nv;
+}
+int artemis_sim_history(artemis_sim_t *s, double *out) {
+  int n = -1;
+  GUARD(n = s->history(out), return -1)
+  return n;
+}
+int artemis_sim_errors(artemis_sim_t *s, double *out) {
+  int n = -1;
+  GUARD(n = s->errors(out), return -1)
+  return n;
+}
+double artemis_sim_last_wall_seconds(const artemis_sim_t *s) { return s->last_wall; }
+double artemis_sim_kernel_ms(const artemis_sim_t *s, long *nlaunch) {
+  if (nlaunch) *nlaunch = s->kernel_launches;
+  return s->kernel_launches ? s->kernel_ms_sum / s->kernel_launches : 0.0;
+}
+
+} // extern "C"

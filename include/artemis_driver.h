@@ -1,0 +1,98 @@
+/* =======================================================================================
+ * artemis_driver.h -- C ABI of the host driver that stands in for Parthenon + ArtemisDriver
+ * when the path runs outside Artemis (bench, tests, the `artemis` command-line tool).
+ *
+ * It consumes the reference's own input decks (inputs/<problem>/<name>.in, Parthenon
+ * `<block>` / `key = value # comment` syntax with `&` continuation) and `block/key=value`
+ * overrides exactly like `artemis -i deck block/key=value ...` (tst/scripts/utils/
+ * artemis.py:122-156), builds a uniform Cartesian mesh of equal mesh blocks, runs the problem
+ * generator, and advances with the stage order of ArtemisDriver<GEOM>::StepTasks
+ * (artemis_driver.cpp:145-273).  All device work goes through artemis_hip.h / artemis_rt.h;
+ * this layer contains no HIP code.
+ *
+ * Decomposition: `nranks` processes, one GPU each; the mesh-block grid is split into a
+ * Cartesian grid of rank bricks.  Ghost slabs between blocks of one rank are copied on the
+ * device; slabs between ranks go through the `artemis_comm_t` callbacks supplied by the
+ * launcher (bench.py binds them to torch.distributed = RCCL over xGMI; tests bind gloo).
+ * ===================================================================================== */
+#ifndef ARTEMIS_DRIVER_H_
+#define ARTEMIS_DRIVER_H_
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct artemis_sim artemis_sim_t;
+
+typedef struct artemis_msg {
+  int peer;          /* rank on the other side */
+  int tag;           /* unique per (destination block, destination face) */
+  double *send;      /* DEVICE buffer to send (NULL if none) */
+  double *recv;      /* DEVICE buffer to receive into (NULL if none) */
+  long count;        /* doubles in each direction */
+} artemis_msg_t;
+
+typedef struct artemis_comm {
+  void *ctx;
+  int rank, nranks;
+  /* Post every send/recv of one halo exchange.  Ordered after work already enqueued on
+   * `stream`; returns without waiting. */
+  int (*exchange_start)(void *ctx, int nmsg, const artemis_msg_t *msgs, void *stream);
+  /* Make work enqueued on `stream` after this call wait for the exchange posted last. */
+  int (*exchange_finish)(void *ctx, void *stream);
+  int (*allreduce_min)(void *ctx, double *value);        /* host scalar, in place */
+  int (*allreduce_sum)(void *ctx, double *values, int n); /* host array, in place */
+} artemis_comm_t;
+
+/* deck_text: contents of an input deck; overrides: `block/key=value` strings (may be NULL).
+ * comm: NULL for a single process.  Returns NULL on error (artemis_sim_last_error()). */
+artemis_sim_t *artemis_sim_create(const char *deck_text, int noverrides, const char *const *overrides,
+                                  const artemis_comm_t *comm);
+void artemis_sim_destroy(artemis_sim_t *sim);
+const char *artemis_sim_last_error(void);
+
+/* EvolutionDriver::Execute (parthenon, upstream): advance until tlim / nlim of the deck, or by
+ * at most `max_cycles` further cycles if max_cycles >= 0.  Returns cycles taken, < 0 on error. */
+long artemis_sim_evolve(artemis_sim_t *sim, long max_cycles);
+
+double artemis_sim_time(const artemis_sim_t *sim);
+double artemis_sim_dt(const artemis_sim_t *sim);
+double artemis_sim_tlim(const artemis_sim_t *sim);
+long artemis_sim_ncycle(const artemis_sim_t *sim);
+/* interior cells owned by this rank / by all ranks */
+long artemis_sim_local_zones(const artemis_sim_t *sim);
+long artemis_sim_total_zones(const artemis_sim_t *sim);
+int artemis_sim_uses_fused_path(const artemis_sim_t *sim);
+/* which: "fused" | "unfused"; selects the kernel path (fused only where supported). */
+int artemis_sim_set_path(artemis_sim_t *sim, const char *which);
+/* overlap = 1: halo exchange on a second stream concurrently with interior compute */
+int artemis_sim_set_overlap(artemis_sim_t *sim, int overlap);
+
+/* Block layout of this rank. dims = {nblocks_local, ni, nj, nk, is, ie, js, je, ks, ke, ng}. */
+void artemis_sim_dims(const artemis_sim_t *sim, int *dims);
+/* Copy one field of one local block to the host, [nvar][nk][nj][ni] doubles (ghosts included).
+ * field: "gas.prim" (6*ns), "gas.cons" (6*ns), "dust.prim" (4*ns), "dust.cons" (4*ns).
+ * Conserved fields and pressure are materialised (PrimToCons) first.  Returns nvar or < 0. */
+int artemis_sim_get_field(artemis_sim_t *sim, const char *field, int block, double *host_out);
+/* interior bounds of a local block: out = {x1min,x1max,x2min,x2max,x3min,x3max} */
+void artemis_sim_block_bounds(const artemis_sim_t *sim, int block, double *out);
+
+/* History integrals (utils/history.hpp:29-100, gas.cpp:648-676, dust.cpp:332-352), reduced
+ * over ranks: out = [gas mass, mom1..3, energy, internal energy] (species 0) then
+ * [mass, mom1..3] per dust species.  Returns the number of values. */
+int artemis_sim_history(artemis_sim_t *sim, double *out);
+/* Post-loop error norms of the problem generator (linear_wave.hpp:267-377: out[0] rms,
+ * out[1..5]; advection.hpp:224-405: out[0..2] rms gas/dust1/dust2, out[3..15]).  Returns the
+ * number of values, 0 if the pgen defines none. */
+int artemis_sim_errors(artemis_sim_t *sim, double *out);
+
+/* Seconds spent inside the timed region of the last artemis_sim_evolve (device-synchronised
+ * at both ends), and the average duration in ms of the dominant kernel's launches measured
+ * with HIP events on the compute stream. */
+void artemis_sim_set_kernel_timing(artemis_sim_t *sim, int on);
+double artemis_sim_last_wall_seconds(const artemis_sim_t *sim);
+double artemis_sim_kernel_ms(const artemis_sim_t *sim, long *nlaunch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTEMIS_DRIVER_H_ */

@@ -967,6 +967,16 @@ void oracle_set_dt(void *h, double dt) { static_cast<Sim *>(h)->dt = dt; }
 void oracle_step(void *h, void (*xchg)(void *), void *ctx) {
   step(*static_cast<Sim *>(h), xchg, ctx);
 }
+// parthenon Mesh::Initialize after ProblemGenerator + PostInitialization (upstream, recalled):
+// boundaries are communicated once before the first step, i.e. PreCommFillDerived (ConsToPrim,
+// artemis.cpp:122) -> exchange + physical BCs -> FillDerived (PrimToCons, artemis.cpp:123).
+void oracle_post_init(void *h, void (*xchg)(void *), void *ctx) {
+  Sim &s = *static_cast<Sim *>(h);
+  cons_to_prim(s);
+  if (xchg) xchg(ctx);
+  apply_bcs(s);
+  prim_to_cons(s);
+}
 // Local (this block) dt estimate: min over fluids, cfl included.
 double oracle_new_dt(void *h) { return new_dt(*static_cast<Sim *>(h)); }
 

@@ -77,6 +77,7 @@ def lib():
         L.oracle_ncycle.argtypes = [C.c_void_p]
         L.oracle_set_dt.argtypes = [C.c_void_p, C.c_double]
         L.oracle_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_post_init.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_evolve.restype = C.c_long
         L.oracle_evolve.argtypes = [C.c_void_p, C.c_double, C.c_long]
         L.oracle_pgen_blast.argtypes = [C.c_void_p] + [C.c_double] * 7 + [C.c_int, C.c_int]
@@ -199,16 +200,33 @@ class Oracle:
         return self.L.oracle_evolve(self.h, tlim, nlim)
 
     # problem generators (pgen/*.hpp)
+    def post_init(self, exchange=None):
+        """Mesh::Initialize's first boundary communication (ConsToPrim, ghosts, PrimToCons)."""
+        if exchange is None:
+            self.L.oracle_post_init(self.h, None, None)
+        else:
+            cb = EXCH(lambda ctx: exchange())
+            self.L.oracle_post_init(self.h, C.cast(cb, C.c_void_p), None)
+
     def pgen_blast(self, radius=1.0, internal_energy=1.0, p0=1.0, d0=1.0, x0=(0.0, 0.0, 0.0),
-                   samples=-1, symmetry="spherical"):
+                   samples=-1, symmetry="spherical", post_init=True):
         self.L.oracle_pgen_blast(self.h, radius, internal_energy, p0, d0, x0[0], x0[1], x0[2],
                                  samples, 1 if symmetry == "spherical" else 2)
+        if post_init:
+            self.post_init()
 
-    def pgen_linear_wave(self, wave_flag, amp, vflow=0.0, along=(False, False, False), nperiod=1.0):
-        return self.L.oracle_pgen_linear_wave(self.h, wave_flag, amp, vflow, *map(int, along), nperiod)
+    def pgen_linear_wave(self, wave_flag, amp, vflow=0.0, along=(False, False, False), nperiod=1.0,
+                         post_init=True):
+        t = self.L.oracle_pgen_linear_wave(self.h, wave_flag, amp, vflow, *map(int, along), nperiod)
+        if post_init:
+            self.post_init()
+        return t
 
-    def pgen_advection(self, amp, vflow=1.0, along=(False, False, False), nperiod=1.0):
-        return self.L.oracle_pgen_advection(self.h, amp, vflow, *map(int, along), nperiod)
+    def pgen_advection(self, amp, vflow=1.0, along=(False, False, False), nperiod=1.0, post_init=True):
+        t = self.L.oracle_pgen_advection(self.h, amp, vflow, *map(int, along), nperiod)
+        if post_init:
+            self.post_init()
+        return t
 
     def linear_wave_errors(self, do_rms=True):
         out = (C.c_double * 6)()
