@@ -403,7 +403,7 @@ void artemis_sim::build_mesh() {
 }
 
 void artemis_sim::allocate() {
-  CK(artemis_rt_set_device(0), "set device"); // one visible GPU per process (launcher pins it)
+  // the launcher selects the GPU (artemis_rt_set_device) before creating the simulation
   stream = artemis_rt_stream_create();
   comm_stream = artemis_rt_stream_create();
   ev0 = artemis_rt_event_create(), ev1 = artemis_rt_event_create();

@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- zone-cycles/s of the Artemis hydro update on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): the
+reference's Sedov deck inputs/blast/blast.in in 3-D -- Cartesian 256^3 cells per GPU, gas only,
+HLLC + PLM, rk2, cfl 0.3, gamma 1.4, outflow, nghost 2, floors 1e-10 -- weak-scaled over the
+GPUs of one node (512x256x256, 512x512x256, 512^3 for 2/4/8 GPUs, one 256^3 mesh block per
+rank).  One "step" = one full cycle: every RK stage (fused flux/update/source/c2p kernel +
+ghost fill), the CFL reduction and, for N > 1, the halo exchange and the dt all-reduce.
+Initial data are generated on the host and are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the fused stage
+kernel) with the ALGORITHMIC bytes of SURVEY.md section 8(d) -- 240 B per cell-stage -- over
+its HIP-event-timed launch duration; `cpu_baseline` times the CPU oracle (a restatement of
+the reference's CPU path, NOT the Artemis executable, which cannot be built here) on the host
+cores for a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_CELL_STAGE = 240.0   # 30 doubles
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def overrides(n_gpus, per_gpu, steps_total, extra=()):
+    shape = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(n_gpus)
+    if shape is None:
+        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    ov = ["gas/riemann=hllc", "problem/symmetry=spherical", "problem/radius=0.03",
+          "problem/samples=0", "parthenon/time/tlim=-1.0", f"parthenon/time/nlim={steps_total}"]
+    for d, (s, n) in enumerate(zip(shape, per_gpu), start=1):
+        half = float(s) * n / per_gpu[0] * (per_gpu[0] / 256.0)  # dx = 2/256 whatever the size
+        ov += [f"parthenon/mesh/nx{d}={s * n}", f"parthenon/meshblock/nx{d}={n}",
+               f"parthenon/mesh/x{d}min={-half}", f"parthenon/mesh/x{d}max={half}"]
+    return ov + list(extra)
+
+
+def cpu_baseline(n, cycles):
+    """Time the CPU oracle on the host cores: n^3 Sedov, `cycles` cycles after one warm-up."""
+    from oracle.oracle import Oracle
+    o = Oracle((n, n, n), (-n / 256.0,) * 3, (n / 256.0,) * 3, ng=2, reconstruct="plm",
+               riemann="hllc", gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
+               bc=("outflow",) * 6, integrator="rk2")
+    o.pgen_blast(radius=0.03, internal_energy=1.0, p0=1e-5, d0=1.0, samples=0)
+    o.evolve(-1.0, 1)
+    t0 = time.perf_counter()
+    done = o.evolve(-1.0, 1 + cycles)
+    dt = time.perf_counter() - t0
+    return n ** 3 * done / dt, dt, done
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=256, help="cells per GPU per dimension")
+    ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=256)
+    ap.add_argument("--cpu-cycles", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    from artemis_amd import capi
+    from artemis_amd.driver import Simulation, TorchComm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    L = capi.load()
+    capi.check(L.artemis_rt_set_device(local_rank))
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = TorchComm(torch.device("cuda", local_rank))
+
+    per_gpu = (args.n, args.n, args.n)
+    deck = os.path.join(ROOT, "inputs", "blast", "blast.in")
+    sim = Simulation(deck, overrides(args.gpus, per_gpu, args.warmup + args.steps), comm=comm)
+    if args.path == "unfused":
+        sim.set_path("unfused")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sim.evolve(args.warmup)
+    sim.set_kernel_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    done = sim.evolve(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert done == args.steps, (done, args.steps)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kms, nlaunch = sim.kernel_ms()
+    total_zones = sim.total_zones
+    local_zones = sim.local_zones
+    fused = sim.uses_fused_path
+    hist = sim.history()
+
+    if rank == 0:
+        value = total_zones * args.steps / elapsed
+        out = {
+            "metric": "cell-updates/sec (zone-cycles/s), 256^3/GPU Sedov",
+            "value": value, "unit": "zone-cycles/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1.0e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "inputs/blast 3-D Sedov (BASELINE configs[1]): Cartesian %d^3 cells/GPU, "
+                            "gas HLLC+PLM, rk2, cfl 0.3, gamma 1.4, outflow, nghost 2, radius 0.03, "
+                            "samples 0" % args.n,
+                "mesh": [int(x) for x in (total_zones // (per_gpu[1] * per_gpu[2] * (1 if args.gpus < 4 else 2) * (1 if args.gpus < 8 else 2)),)] if False else None,
+                "cells_per_gpu": local_zones, "path": "fused" if fused else "unfused",
+                "decomposition": "%d rank(s), one %d^3 mesh block each, face-slab halo exchange" % (args.gpus, args.n),
+                "total_energy_check": float(hist[4]),
+            },
+        }
+        out["config"].pop("mesh")
+        if fused and nlaunch:
+            alg = ALG_BYTES_PER_CELL_STAGE * local_zones  # bytes per launch (one stage, one rank)
+            achieved = alg / (kms * 1.0e-3) / 1.0e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "kernel": "stage_fused_kernel<hllc,plm>", "launch_ms": kms,
+                               "launches_timed": nlaunch,
+                               "algorithmic_bytes_per_launch": alg}
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            v, secs, cyc = cpu_baseline(args.cpu_n, args.cpu_cycles)
+            out["cpu_baseline"] = {
+                "value": v, "unit": "zone-cycles/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": "CPU oracle (OpenMP, all host cores), Sedov %d^3, %d cycles, %.1f s; a "
+                          "restatement of the reference's CPU path, not the Artemis executable"
+                          % (args.cpu_n, cyc, secs)}
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
