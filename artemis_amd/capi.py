@@ -88,6 +88,7 @@ def load():
         "artemis_hip_halo_count": (C.c_long, [PPk, i]),
         "artemis_hip_halo_pack": (i, [PPk, i, i, vp, vp]),
         "artemis_hip_halo_unpack": (i, [PPk, i, i, vp, vp]),
+        "artemis_hip_selftest_divsqrt": (i, [C.c_long, vp, vp, vp, vp, vp, vp, vp]),
         "artemis_hip_last_error": (C.c_char_p, []),
         "artemis_hip_device_count": (i, []),
         "artemis_hip_version": (C.c_char_p, []),

@@ -17,6 +17,58 @@ ADEV double amax(double a, double b) { return (a < b) ? b : a; }
 ADEV double amin(double a, double b) { return (b < a) ? b : a; }
 ADEV double sqr(double x) { return x * x; }
 
+// ---- fp64 division and square root, hand-scheduled ------------------------------------------
+// hipcc lowers `a / b` to  v_div_scale x2 -> v_rcp_f64 -> two Newton steps on the reciprocal ->
+// q = a*y -> one Markstein correction (v_div_fmas) -> v_div_fixup.  The pre-scaling and the
+// fix-up only matter when an operand or the quotient sits within ~2^100 of the fp64 exponent
+// limits, is zero/inf/NaN or subnormal; everywhere else the quotient is produced by exactly
+// the fma chain below, so `div` returns the same bits (checked against IEEE division on the
+// device over wide-range random operands by tests/test_parity_fused.py::test_fast_div_sqrt and
+// implicitly by every fused-kernel parity test).  Hydro operands here are floored densities,
+// pressures, cell sizes and wave-speed differences: comfortably inside that window; a zero
+// NUMERATOR is handled exactly (q = 0, r = 0).  What the split buys: a refined reciprocal is
+// computed once per denominator and reused by every division that shares it (6 by the cell
+// volume, 6 by the density, 2 by ml+mr, ...), and the quarter-rate v_rcp_f64 count drops by a
+// third.  -ffp-contract=off does not touch explicit __builtin_fma.
+struct Recip {
+  double b, y; // denominator and its refined reciprocal
+};
+ADEV Recip recip(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  Recip r;
+  r.b = b, r.y = y;
+  return r;
+}
+ADEV double div(double a, const Recip &r) {
+  const double q = a * r.y;
+  const double e = __builtin_fma(-r.b, q, a);
+  return __builtin_fma(e, r.y, q);
+}
+ADEV double div(double a, double b) { return div(a, recip(b)); }
+ADEV Recip pick(bool c, const Recip &a, const Recip &b) {
+  Recip r;
+  r.b = c ? a.b : b.b, r.y = c ? a.y : b.y;
+  return r;
+}
+// Square root of a strictly positive, normal x: the Goldschmidt chain hipcc emits for sqrt()
+// minus its 2^256 range scaling and its 0/inf pass-through.
+ADEV double sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double s0 = x * y;
+  const double h0 = y * 0.5;
+  const double r0 = __builtin_fma(-h0, s0, 0.5);
+  const double s1 = __builtin_fma(s0, r0, s0);
+  const double h1 = __builtin_fma(h0, r0, h0);
+  const double d0 = __builtin_fma(-s1, s1, x);
+  const double s2 = __builtin_fma(d0, h1, s1);
+  const double d1 = __builtin_fma(-s2, s2, x);
+  return __builtin_fma(d1, h1, s2);
+}
+
 struct Prim6 { // gas face/cell state in sweep-local order
   double d, vx, vy, vz, p, e;
 };
@@ -35,6 +87,15 @@ ADEV double plm_dqm(double qm, double q, double qp) {
   const double dqr = qp - q;
   const double dq2 = dql * dqr;
   const double dqm = dq2 / (dql + dqr);
+  return (dq2 <= 0.0) ? 0.0 : dqm;
+}
+
+// same slope with the hand-scheduled division (fused kernel)
+ADEV double plm_dqm_fast(double qm, double q, double qp) {
+  const double dql = q - qm;
+  const double dqr = qp - q;
+  const double dq2 = dql * dqr;
+  const double dqm = div(dq2, dql + dqr);
   return (dq2 <= 0.0) ? 0.0 : dqm;
 }
 
@@ -130,6 +191,56 @@ ADEV void hllc_gas(const double gm1, const Prim6 &L, const Prim6 &R, FaceFlux &F
   F.fe = wl_ * fle + wr_ * fre + wc_ * cp * am;
   F.feg = frho * ((frho >= 0.0) ? L.e : R.e);
   F.vf = frho / ((frho >= 0.0) ? L.d : R.d);
+}
+
+// hllc.hpp:50-182 again, same expression trees, with shared refined reciprocals: rho_l and rho_r
+// serve the sound speeds and the face velocity, ml+mr serves am and cp, and the two flux
+// weights share one denominator (the am >= 0 / < 0 branches select operands, not results).
+ADEV void hllc_gas_fast(const double gm1, const double igm1, const double gamma, const double alpha,
+                        const Prim6 &L, const Prim6 &R, FaceFlux &F) {
+  const Recip rdl = recip(L.d), rdr = recip(R.d);
+  const double cl = sqrt_pos(div(gamma * L.p, rdl));
+  const double cr = sqrt_pos(div(gamma * R.p, rdr));
+  const double el = L.p * igm1 + 0.5 * L.d * (sqr(L.vx) + sqr(L.vy) + sqr(L.vz));
+  const double er = R.p * igm1 + 0.5 * R.d * (sqr(R.vx) + sqr(R.vy) + sqr(R.vz));
+  const double rc_avg = 0.25 * (L.d + R.d) * (cl + cr);
+  const double pmid = 0.5 * (L.p + R.p + (L.vx - R.vx) * rc_avg);
+  const double ql = (pmid <= L.p) ? 1.0 : sqrt_pos(1.0 + alpha * (div(pmid, L.p) - 1.0));
+  const double qr = (pmid <= R.p) ? 1.0 : sqrt_pos(1.0 + alpha * (div(pmid, R.p) - 1.0));
+  const double sl = L.vx - cl * ql;
+  const double sr = R.vx + cr * qr;
+  const double bp = sr > 0.0 ? sr : 1.0e-20;
+  const double bm = sl < 0.0 ? sl : -1.0e-20;
+  const double vxl = L.vx - sl;
+  const double vxr = R.vx - sr;
+  const double tl = L.p + vxl * L.d * L.vx;
+  const double tr = R.p + vxr * R.d * R.vx;
+  const double ml = L.d * vxl;
+  const double mr = -(R.d * vxr);
+  const Recip rm = recip(ml + mr);
+  const double am = div(tl - tr, rm);
+  double cp = div(ml * tr + mr * tl, rm);
+  cp = cp > 0.0 ? cp : 0.0;
+  const double fld = L.d * (L.vx - bm);
+  const double frd = R.d * (R.vx - bp);
+  const double fle = el * (L.vx - bm) + L.p * L.vx;
+  const double fre = er * (R.vx - bp) + R.p * R.vx;
+  const bool pos = (am >= 0.0);
+  const Recip rw = recip(pos ? (am - bm) : (bp - am));
+  const double wa = div(pos ? am : -am, rw);
+  const double wc_ = div(pos ? -bm : bp, rw);
+  const double wl_ = pos ? wa : 0.0;
+  const double wr_ = pos ? 0.0 : wa;
+  F.pf = wl_ * L.p + wr_ * R.p + wc_ * cp;
+  const double frho = wl_ * fld + wr_ * frd;
+  F.fd = frho;
+  F.fmx = wl_ * (fld * L.vx) + wr_ * (frd * R.vx);
+  F.fmy = wl_ * (fld * L.vy) + wr_ * (frd * R.vy);
+  F.fmz = wl_ * (fld * L.vz) + wr_ * (frd * R.vz);
+  F.fe = wl_ * fle + wr_ * fre + wc_ * cp * am;
+  const bool up = (frho >= 0.0);
+  F.feg = frho * (up ? L.e : R.e);
+  F.vf = div(frho, pick(up, rdl, rdr));
 }
 
 // utils/fluxes/riemann/hlle.hpp:56-222, gas branch

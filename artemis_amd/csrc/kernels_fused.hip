@@ -20,7 +20,9 @@
 //     Pressure of stencil cells is likewise recomputed as (gm1*rho)*sie.
 // HBM traffic per cell-stage: 5 reads (+5 for u1 after stage 1) + 6 writes instead of the
 // reference's ~124 doubles.  Results are bit-identical to the per-task kernels.
+#include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 #include "device_math.hpp"
 #include "kernels.hpp"
@@ -56,11 +58,18 @@ struct Cell6 {
   double d, v1, v2, v3, p, e;
 };
 
+// Pointers fetched from the pack's tables are generic to the compiler; the arrays live in HBM,
+// so tell it: global_load/global_store instead of flat_* (no LDS-aperture check, vmcnt only).
+typedef const double __attribute__((address_space(1))) *gcptr;
+typedef double __attribute__((address_space(1))) *gptr;
+ADEV double gld(const double *p, long c) { return ((gcptr)p)[c]; }
+ADEV void gst(double *p, long c, double v) { ((gptr)p)[c] = v; }
+
 ADEV Cell6 load_cell(const double *__restrict__ r, const double *__restrict__ v1,
                      const double *__restrict__ v2, const double *__restrict__ v3,
                      const double *__restrict__ se, long c, double gm1) {
   Cell6 q;
-  q.d = r[c], q.v1 = v1[c], q.v2 = v2[c], q.v3 = v3[c], q.e = se[c];
+  q.d = gld(r, c), q.v1 = gld(v1, c), q.v2 = gld(v2, c), q.v3 = gld(v3, c), q.e = gld(se, c);
   q.p = amax(0.0, gm1 * q.d * q.e); // fill_derived.cpp:247 (IdealGas P)
   return q;
 }
@@ -68,7 +77,7 @@ ADEV Cell6 load_cell(const double *__restrict__ r, const double *__restrict__ v1
 template <int RECON>
 ADEV double slope(double qm, double q, double qp) {
   if constexpr (RECON == 0) return 0.0;
-  else return plm_dqm(qm, q, qp);
+  else return plm_dqm_fast(qm, q, qp);
 }
 // q + 0.0 == q and q - 0.0 == q bitwise for every finite q except that -0.0 + 0.0 = +0.0;
 // PCM therefore bypasses the add to stay identical to pcm.hpp:34-88.
@@ -88,8 +97,17 @@ ADEV double lo_val(double q, double dqm) {
 struct Flux8 {
   double d, m1, m2, m3, e, eg, pf, vf;
 };
+struct GasK { // per-thread constants of the solver (hllc.hpp:75-77)
+  double gm1, igm1, gamma, alpha;
+};
+ADEV GasK gas_constants(double gm1) {
+  GasK g;
+  g.gm1 = gm1, g.igm1 = 1.0 / gm1, g.gamma = gm1 + 1.0;
+  g.alpha = (g.gamma + 1.0) / (2.0 * g.gamma);
+  return g;
+}
 template <int RIEMANN, int DIR>
-ADEV Flux8 solve_face(double gm1, const Cell6 &L, const Cell6 &R) {
+ADEV Flux8 solve_face(const GasK &gk, const Cell6 &L, const Cell6 &R) {
   Prim6 l, r;
   l.d = L.d, l.p = L.p, l.e = L.e, r.d = R.d, r.p = R.p, r.e = R.e;
   if constexpr (DIR == 1) {
@@ -100,7 +118,8 @@ ADEV Flux8 solve_face(double gm1, const Cell6 &L, const Cell6 &R) {
     l.vx = L.v3, l.vy = L.v1, l.vz = L.v2, r.vx = R.v3, r.vy = R.v1, r.vz = R.v2;
   }
   FaceFlux F;
-  riemann_gas<RIEMANN>(gm1, l, r, F);
+  if constexpr (RIEMANN == 0) hllc_gas_fast(gk.gm1, gk.igm1, gk.gamma, gk.alpha, l, r, F);
+  else riemann_gas<RIEMANN>(gk.gm1, l, r, F);
   Flux8 o;
   o.d = F.fd, o.e = F.fe, o.eg = F.feg, o.pf = F.pf, o.vf = F.vf;
   if constexpr (DIR == 1) o.m1 = F.fmx, o.m2 = F.fmy, o.m3 = F.fmz;
@@ -116,6 +135,8 @@ struct Ctx { // per-thread constants of the march
   bool active, multi_d, three_d;
   long col, sj, sk;
   double dx1, dx2, gm1;
+  GasK gk;
+  Recip rdx1, rdx2;
   const double *g;
   const double *in_r, *in_1, *in_2, *in_3, *in_e;
 };
@@ -214,12 +235,12 @@ ADEV void plane_body(LdsTile &S, const PackView &P, const StageK &a, const Ctx &
   // ---- P2: Riemann problems at the own lower faces; perimeter faces on wave 1 ------------
   Cell6 L;
   GET6(L, S.UPX, [ty][tx]);
-  const Flux8 fx_lo = solve_face<RIEMANN, 1>(gm1, L, lox);
+  const Flux8 fx_lo = solve_face<RIEMANN, 1>(x.gk, L, lox);
   if (tx > 0) { PUT8(S.FX, fx_lo, [ty][tx - 1]); }
   Flux8 fy_lo = fx_lo;
   if (x.multi_d) {
     GET6(L, S.UPY, [ty][tx]);
-    fy_lo = solve_face<RIEMANN, 2>(gm1, L, loy);
+    fy_lo = solve_face<RIEMANN, 2>(x.gk, L, loy);
     if (ty > 0) { PUT8(S.FY, fy_lo, [ty - 1][tx]); }
   }
   if (t >= 64 && t < 128) { // lanes 0..7: x1 face i0+32 per row; lanes 32..63: x2 face j0+8
@@ -228,14 +249,14 @@ ADEV void plane_body(LdsTile &S, const PackView &P, const StageK &a, const Ctx &
       Cell6 l, r;
       GET6(l, S.UPX, [u][FTX]);
       GET6(r, S.LOX, [u]);
-      const Flux8 fe_ = solve_face<RIEMANN, 1>(gm1, l, r);
+      const Flux8 fe_ = solve_face<RIEMANN, 1>(x.gk, l, r);
       PUT8(S.FX, fe_, [u][FTX - 1]);
     } else if (x.multi_d && u >= 32) {
       const int cx = u - 32;
       Cell6 l, r;
       GET6(l, S.UPY, [FTY][cx]);
       GET6(r, S.LOY, [cx]);
-      const Flux8 fe_ = solve_face<RIEMANN, 2>(gm1, l, r);
+      const Flux8 fe_ = solve_face<RIEMANN, 2>(x.gk, l, r);
       PUT8(S.FY, fe_, [FTY - 1][cx]);
     }
   }
@@ -259,20 +280,23 @@ ADEV void plane_body(LdsTile &S, const PackView &P, const StageK &a, const Ctx &
   const double E0 = G0 + 0.5 * qc.d * (sqr(qc.v1) + sqr(qc.v2) + sqr(qc.v3));
   double D1 = D0, M11 = M10, M21 = M20, M31 = M30, G1 = G0, E1 = E0;
   if constexpr (HAS_U1) {
-    const double r1 = a.prim_u1[b * 6 + 0][c], e1 = a.prim_u1[b * 6 + 5][c];
-    const double a1 = a.prim_u1[b * 6 + 1][c], a2 = a.prim_u1[b * 6 + 2][c];
-    const double a3 = a.prim_u1[b * 6 + 3][c];
+    const double r1 = gld(a.prim_u1[b * 6 + 0], c), e1 = gld(a.prim_u1[b * 6 + 5], c);
+    const double a1 = gld(a.prim_u1[b * 6 + 1], c), a2 = gld(a.prim_u1[b * 6 + 2], c);
+    const double a3 = gld(a.prim_u1[b * 6 + 3], c);
     D1 = r1, M11 = r1 * a1 * 1.0, M21 = r1 * a2 * 1.0, M31 = r1 * a3 * 1.0;
     G1 = e1 * r1;
     E1 = G1 + 0.5 * r1 * (sqr(a1) + sqr(a2) + sqr(a3));
   }
-  // ApplyUpdate (artemis_integrator.hpp:88-106)
+  // ApplyUpdate (artemis_integrator.hpp:88-106); the six divisions by the cell volume and the
+  // three bdt/vol of FluxSource share one refined reciprocal.
+  const Recip rvol = recip(vol);
+  const Recip rdx3 = recip(dx3);
   auto upd = [&](double u0, double u1, double f1l, double f1h, double f2l, double f2h, double f3l,
                  double f3h) {
     double divf = (ax1 * f1l - ax1 * f1h);
     if (x.multi_d) divf += (ax2 * f2l - ax2 * f2h);
     if (x.three_d) divf += (ax3 * f3l - ax3 * f3h);
-    return a.gam0 * u0 + a.gam1 * u1 + divf * a.beta_dt / vol;
+    return a.gam0 * u0 + a.gam1 * u1 + div(divf * a.beta_dt, rvol);
   };
   const double D = upd(D0, D1, fx_lo.d, fx_hi.d, fy_lo.d, fy_hi.d, fz_lo.d, fz_hi.d);
   double M1 = upd(M10, M11, fx_lo.m1, fx_hi.m1, fy_lo.m1, fy_hi.m1, fz_lo.m1, fz_hi.m1);
@@ -281,58 +305,58 @@ ADEV void plane_body(LdsTile &S, const PackView &P, const StageK &a, const Ctx &
   const double E = upd(E0, E1, fx_lo.e, fx_hi.e, fy_lo.e, fy_hi.e, fz_lo.e, fz_hi.e);
   double G = upd(G0, G1, fx_lo.eg, fx_hi.eg, fy_lo.eg, fy_hi.eg, fz_lo.eg, fz_hi.eg);
   // FluxSource (fluid_fluxes.hpp:365-392)
-  M1 += a.bdt / dx1 * (fx_lo.pf - fx_hi.pf);
-  G -= a.bdt / vol * 0.5 * (fx_lo.pf + fx_hi.pf) * (ax1 * fx_hi.vf - ax1 * fx_lo.vf);
+  const double bdt_vol = div(a.bdt, rvol);
+  M1 += div(a.bdt, x.rdx1) * (fx_lo.pf - fx_hi.pf);
+  G -= bdt_vol * 0.5 * (fx_lo.pf + fx_hi.pf) * (ax1 * fx_hi.vf - ax1 * fx_lo.vf);
   if (x.multi_d) {
-    M2 += a.bdt / dx2 * (fy_lo.pf - fy_hi.pf);
-    G -= a.bdt / vol * 0.5 * (fy_lo.pf + fy_hi.pf) * (ax2 * fy_hi.vf - ax2 * fy_lo.vf);
+    M2 += div(a.bdt, x.rdx2) * (fy_lo.pf - fy_hi.pf);
+    G -= bdt_vol * 0.5 * (fy_lo.pf + fy_hi.pf) * (ax2 * fy_hi.vf - ax2 * fy_lo.vf);
   }
   if (x.three_d) {
-    M3 += a.bdt / dx3 * (fz_lo.pf - fz_hi.pf);
-    G -= a.bdt / vol * 0.5 * (fz_lo.pf + fz_hi.pf) * (ax3 * fz_hi.vf - ax3 * fz_lo.vf);
+    M3 += div(a.bdt, rdx3) * (fz_lo.pf - fz_hi.pf);
+    G -= bdt_vol * 0.5 * (fz_lo.pf + fz_hi.pf) * (ax3 * fz_hi.vf - ax3 * fz_lo.vf);
   }
-  // SetAuxillaryFields (fill_derived.cpp:54-73, artemis_utils.hpp:43-62)
+  // SetAuxillaryFields (fill_derived.cpp:54-73, artemis_utils.hpp:43-62) and ConsToPrim
+  // (fill_derived.cpp:137-151) divide six times by the same floored density.
+  const double w_d = (D > f.dfloor) ? D : f.dfloor; // == max(D, dfloor) of artemis_utils.hpp:49
+  const Recip rd = recip(w_d);
   {
-    const double u_d = (D > f.dfloor) ? D : f.dfloor;
-    const double u_d2 = amax(D, f.dfloor);
-    const double ke = 0.5 * (sqr(M1 / 1.0) + sqr(M2 / 1.0) + sqr(M3 / 1.0)) / u_d2;
+    const double ke = div(0.5 * (sqr(M1 / 1.0) + sqr(M2 / 1.0) + sqr(M3 / 1.0)), rd);
     const double ue = E - ke;
-    double sie = (ue > f.de_switch * E) ? ue / u_d2 : G / u_d2;
+    double sie = div((ue > f.de_switch * E) ? ue : G, rd);
     sie = amax(sie, f.siefloor);
-    G = sie * u_d;
-    const double uflr = f.siefloor * u_d;
+    G = sie * w_d;
+    const double uflr = f.siefloor * w_d;
     G = (G > uflr) ? G : uflr;
   }
-  // ConsToPrim (fill_derived.cpp:137-151); the PrimToCons floors that follow
-  // (fill_derived.cpp:229,244) are idempotent on these values.
-  const double w_d = (D > f.dfloor) ? D : f.dfloor;
-  const double w1 = M1 / (w_d * 1.0), w2 = M2 / (w_d * 1.0), w3 = M3 / (w_d * 1.0);
-  double w_s = G / w_d;
+  // the PrimToCons floors that follow (fill_derived.cpp:229,244) are idempotent here
+  const double w1 = div(M1, rd), w2 = div(M2, rd), w3 = div(M3, rd);
+  double w_s = div(G, rd);
   w_s = (w_s > f.siefloor) ? w_s : f.siefloor;
   const double w_p = amax(0.0, gm1 * w_d * w_s); // fill_derived.cpp:247
-  a.prim_out[b * 6 + 0][c] = w_d;
-  a.prim_out[b * 6 + 1][c] = w1;
-  a.prim_out[b * 6 + 2][c] = w2;
-  a.prim_out[b * 6 + 3][c] = w3;
-  a.prim_out[b * 6 + 4][c] = w_p;
-  a.prim_out[b * 6 + 5][c] = w_s;
+  gst(a.prim_out[b * 6 + 0], c, w_d);
+  gst(a.prim_out[b * 6 + 1], c, w1);
+  gst(a.prim_out[b * 6 + 2], c, w2);
+  gst(a.prim_out[b * 6 + 3], c, w3);
+  gst(a.prim_out[b * 6 + 4], c, w_p);
+  gst(a.prim_out[b * 6 + 5], c, w_s);
   if constexpr (WRITE_CONS) { // PrimToCons (fill_derived.cpp:226-255)
     const double u_u = w_s * w_d;
-    a.cons_out[b * 6 + 0][c] = w_d;
-    a.cons_out[b * 6 + 1][c] = w_d * w1 * 1.0;
-    a.cons_out[b * 6 + 2][c] = w_d * w2 * 1.0;
-    a.cons_out[b * 6 + 3][c] = w_d * w3 * 1.0;
-    a.cons_out[b * 6 + 4][c] = u_u + 0.5 * w_d * (sqr(w1) + sqr(w2) + sqr(w3));
-    a.cons_out[b * 6 + 5][c] = u_u;
+    gst(a.cons_out[b * 6 + 0], c, w_d);
+    gst(a.cons_out[b * 6 + 1], c, w_d * w1 * 1.0);
+    gst(a.cons_out[b * 6 + 2], c, w_d * w2 * 1.0);
+    gst(a.cons_out[b * 6 + 3], c, w_d * w3 * 1.0);
+    gst(a.cons_out[b * 6 + 4], c, u_u + 0.5 * w_d * (sqr(w1) + sqr(w2) + sqr(w3)));
+    gst(a.cons_out[b * 6 + 5], c, u_u);
   }
   if constexpr (WITH_DT) { // Gas::EstimateTimestepMesh on the new state (gas.cpp:411-433)
     const double bulk = (gm1 + 1.0) * gm1 * w_d * w_s;
-    const double cs = sqrt(bulk / w_d);
+    const double cs = sqrt_pos(div(bulk, rd));
     double denom = 0.0;
-    denom += (fabs(w1) + cs) / (1.0 * dx1);
-    if (x.multi_d) denom += (fabs(w2) + cs) / (1.0 * dx2);
-    if (x.three_d) denom += (fabs(w3) + cs) / (1.0 * dx3);
-    ldt = amin(ldt, 1.0 / denom);
+    denom += div(fabs(w1) + cs, x.rdx1); // 1.0*dx == dx
+    if (x.multi_d) denom += div(fabs(w2) + cs, x.rdx2);
+    if (x.three_d) denom += div(fabs(w3) + cs, rdx3);
+    ldt = amin(ldt, div(1.0, denom));
   }
 }
 
@@ -353,6 +377,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   const int k1 = min(P.ke, k0 + a.kchunk - 1);
   if (k0 > k1) return;
   x.gm1 = P.gm1;
+  x.gk = gas_constants(P.gm1);
   x.g = P.geom + 6 * x.b;
   x.in_r = a.prim_in[x.b * 6 + 0], x.in_1 = a.prim_in[x.b * 6 + 1];
   x.in_2 = a.prim_in[x.b * 6 + 2], x.in_3 = a.prim_in[x.b * 6 + 3];
@@ -362,6 +387,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   // geometry.hpp:65-72: widths along x1 and x2 do not change along the march
   x.dx1 = (x.g[0] + (i + 1) * x.g[1]) - (x.g[0] + i * x.g[1]);
   x.dx2 = (x.g[2] + (j + 1) * x.g[3]) - (x.g[2] + j * x.g[3]);
+  x.rdx1 = recip(x.dx1), x.rdx2 = recip(x.dx2);
   double ldt = DBL_MAX;
 
   if (!x.three_d) {
@@ -396,7 +422,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   }
       FOR6(ZSL)
 #undef ZSL
-      const Flux8 fz_hi = solve_face<RIEMANN, 3>(x.gm1, zl, zr);
+      const Flux8 fz_hi = solve_face<RIEMANN, 3>(x.gk, zl, zr);
       if (k >= k0)
         plane_body<RIEMANN, RECON, HAS_U1, WRITE_CONS, WITH_DT>(S, P, a, x, k, qc, fz_lo, fz_hi, ldt);
       fz_lo = fz_hi, zl = zl_next, qc = qn, qn = qnn;
@@ -449,6 +475,10 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   int nchunk = 1;
   if (P.ndim > 2) {
     while (nchunk * 2 <= nz / 16 && tiles * nchunk < 4096) nchunk *= 2;
+  }
+  if (const char *e = getenv("ARTEMIS_FUSED_NCHUNK")) { // tuning knob
+    const int v = atoi(e);
+    if (v >= 1 && P.ndim > 2) nchunk = std::min(v, nz);
   }
   k.nchunk = nchunk;
   k.kchunk = (nz + nchunk - 1) / nchunk;

@@ -175,6 +175,12 @@ int artemis_hip_halo_pack(const artemis_pack_t *p, int block, int face, double *
 int artemis_hip_halo_unpack(const artemis_pack_t *p, int block, int face, const double *buf,
                             void *stream);
 
+/* Self test (device): q_fast/s_fast from the hand-scheduled division / square root of the fused
+ * kernel (device_math.hpp), q_ieee/s_ieee from the compiler's IEEE-correct a/b and sqrt(|b|).
+ * All pointers are DEVICE arrays of n doubles. */
+int artemis_hip_selftest_divsqrt(long n, const double *a, const double *b, double *q_fast,
+                                 double *q_ieee, double *s_fast, double *s_ieee, void *stream);
+
 /* ---- Library state ---------------------------------------------------------------------*/
 const char *artemis_hip_last_error(void);
 /* Number of visible HIP devices (0 = none; every compute entry point then fails loudly with

@@ -115,3 +115,36 @@ def test_fused_rejects_unsupported(hiplib):
     with pytest.raises(capi.ArtemisHipError) as e:
         mb.stage_fused(0.0, 1.0, 1e-3, 1e-3, bufs[0][1], bufs[0][1], bufs[0][1])
     assert e.value.code == capi.EINVAL
+
+
+def test_fast_div_sqrt(hiplib):
+    """The fused kernel's hand-scheduled division (refined reciprocal shared between divisions)
+    and square root return the same bits as the compiler's IEEE-correct a/b and sqrt() for
+    operands anywhere within 2^+-400 -- 4e7 random pairs, plus mantissa edge patterns."""
+    n = 1 << 22
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    for rep in range(10):
+        mant = torch.rand(2, n, dtype=torch.float64, device="cuda", generator=g) + 1.0
+        expo = torch.randint(-400, 400, (2, n), device="cuda", generator=g).to(torch.float64)
+        sign = torch.where(torch.rand(2, n, device="cuda", generator=g) < 0.5, -1.0, 1.0).to(torch.float64)
+        ab = sign * torch.ldexp(mant, expo.to(torch.int32))
+        if rep == 0:  # mantissas of all ones / one ulp above a power of two / exact quotients
+            ab[0, :1000] = torch.nextafter(torch.full((1000,), 2.0, dtype=torch.float64, device="cuda"),
+                                           torch.zeros(1000, dtype=torch.float64, device="cuda"))
+            ab[1, 1000:2000] = torch.nextafter(torch.ones(1000, dtype=torch.float64, device="cuda"),
+                                               torch.full((1000,), 2.0, dtype=torch.float64, device="cuda"))
+            ab[0, 2000:3000] = 0.0
+            ab[0, 3000:4000] = ab[1, 3000:4000] * 3.0
+        outs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(4)]
+        rc = hiplib.artemis_hip_selftest_divsqrt(n, *(C.c_void_p(t.data_ptr()) for t in (ab[0], ab[1], *outs)),
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        qf, qi, sf, si = outs
+        assert torch.equal(qf.view(torch.int64), qi.view(torch.int64)), "fast division != IEEE division"
+        assert torch.equal(sf.view(torch.int64), si.view(torch.int64)), "fast sqrt != IEEE sqrt"
+        # and the device results equal the host's correctly rounded ones
+        if rep == 0:
+            a, b = ab[0].cpu().numpy(), ab[1].cpu().numpy()
+            assert np.array_equal(qi.cpu().numpy(), a / b)
+            assert np.array_equal(si.cpu().numpy(), np.sqrt(np.abs(b)))
