@@ -415,6 +415,78 @@ __global__ __launch_bounds__(256) void bc_kernel(const BcArgs a, const FillTabs 
   }
 }
 
+// All ghost cells of one block in ONE launch.  Parthenon applies periodic images, then x1, x2, x3
+// physical conditions, each pass over the entire extent of the other dimensions; every pass
+// remaps one index (and flips the sign of the normal velocity for reflecting walls), so the
+// passes compose into independent per-dimension index maps: ghost cell (i,j,k) receives
+// sgn * q[map3(k)][map2(j)][map1(i)].  Faces flagged `none` keep their index (their slabs were
+// filled by the neighbour exchange).  Destinations are ghost in >= 1 mapped dimension, sources
+// are interior in every mapped dimension: no cell is both, so the fill is race-free in place.
+struct ShellArgs {
+  int bc[6];
+  int lo[3], hi[3], ext[3]; // interior bounds and array extents
+  int ng, ndim, nfill;
+  long nA, nB, nC;          // cells in the x3-, x2-, x1-ghost regions
+};
+__global__ __launch_bounds__(256) void bc_shell_kernel(const ShellArgs a, const FillTabs t) {
+  long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  int idx[3];
+  const int g2 = 2 * a.ng;
+  if (tid < a.nA) { // k in ghost planes, all j, all i
+    idx[0] = tid % a.ext[0];
+    idx[1] = (tid / a.ext[0]) % a.ext[1];
+    const int kk = tid / (static_cast<long>(a.ext[0]) * a.ext[1]);
+    idx[2] = (kk < a.ng) ? kk : a.hi[2] + 1 + (kk - a.ng);
+  } else if (tid < a.nA + a.nB) { // k interior, j in ghost rows
+    tid -= a.nA;
+    idx[0] = tid % a.ext[0];
+    const int jj = (tid / a.ext[0]) % g2;
+    idx[1] = (jj < a.ng) ? jj : a.hi[1] + 1 + (jj - a.ng);
+    idx[2] = a.lo[2] + tid / (static_cast<long>(a.ext[0]) * g2);
+  } else if (tid < a.nA + a.nB + a.nC) { // k, j interior, i in ghost columns
+    tid -= a.nA + a.nB;
+    const int ii = tid % g2;
+    idx[0] = (ii < a.ng) ? ii : a.hi[0] + 1 + (ii - a.ng);
+    const int ny = a.hi[1] - a.lo[1] + 1;
+    idx[1] = a.lo[1] + (tid / g2) % ny;
+    idx[2] = a.lo[2] + tid / (static_cast<long>(g2) * ny);
+  } else {
+    return;
+  }
+  int src[3] = {idx[0], idx[1], idx[2]};
+  int refl = 0; // bit d set: reflecting wall crossed along d
+  bool moved = false;
+  for (int d = 0; d < a.ndim; ++d) {
+    const int n_act = a.hi[d] - a.lo[d] + 1;
+    int flag = ARTEMIS_BC_NONE;
+    if (idx[d] < a.lo[d]) flag = a.bc[2 * d];
+    else if (idx[d] > a.hi[d]) flag = a.bc[2 * d + 1];
+    else continue;
+    if (flag == ARTEMIS_BC_NONE) continue;
+    const bool inner = idx[d] < a.lo[d];
+    if (flag == ARTEMIS_BC_PERIODIC) src[d] = inner ? idx[d] + n_act : idx[d] - n_act;
+    else if (flag == ARTEMIS_BC_OUTFLOW) src[d] = inner ? a.lo[d] : a.hi[d];
+    else src[d] = inner ? 2 * a.lo[d] - 1 - idx[d] : 2 * a.hi[d] + 1 - idx[d], refl |= (1 << d);
+    moved = true;
+  }
+  if (!moved) return;
+  const long cd = (static_cast<long>(idx[2]) * a.ext[1] + idx[1]) * a.ext[0] + idx[0];
+  const long cs = (static_cast<long>(src[2]) * a.ext[1] + src[1]) * a.ext[0] + src[0];
+  for (int v = 0; v < a.nfill; ++v) {
+    bool n0, n1, n2;
+    double *q = fill_var(t, v, 0, n0);
+    fill_var(t, v, 1, n1);
+    fill_var(t, v, 2, n2);
+    // sequential passes multiply by -1.0 once per reflecting wall crossed along the
+    // component's own direction
+    double val = q[cs];
+    if ((refl & 1) && n0) val = -1.0 * val;
+    if ((refl & 2) && n1) val = -1.0 * val;
+    if ((refl & 4) && n2) val = -1.0 * val;
+    q[cd] = val;
+  }
+}
+
 // Halo slab pack/unpack: slab spans the INTERIOR extent of the other dimensions.
 struct HaloArgs {
   int d, side, ng, nfill;
@@ -503,26 +575,24 @@ static FillTabs fill_tabs(const PackView &P, int b) {
 }
 
 int launch_apply_bc(const PackView &P, const int *bc, hipStream_t s) {
-  const int n_act[3] = {P.ie - P.is + 1, P.je - P.js + 1, P.ke - P.ks + 1};
-  const int st[3] = {P.is, P.js, P.ks}, en[3] = {P.ie, P.je, P.ke};
-  for (int pass = 0; pass < 2; ++pass)
-    for (int d = 0; d < P.ndim; ++d)
-      for (int b = 0; b < P.nb; ++b)
-        for (int side = 0; side < 2; ++side) {
-          const int flag = bc[b * 6 + 2 * d + side];
-          if (flag == ARTEMIS_BC_NONE) continue;
-          if ((pass == 0) != (flag == ARTEMIS_BC_PERIODIC)) continue;
-          const FillTabs t = fill_tabs(P, b);
-          BcArgs a;
-          a.d = d, a.side = side, a.bc = flag, a.n_act = n_act[d], a.st = st[d], a.en = en[d];
-          a.ng = P.ng;
-          a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;
-          int ext[3] = {P.ni, P.nj, P.nk};
-          ext[d] = P.ng;
-          const long ncell = static_cast<long>(ext[0]) * ext[1] * ext[2];
-          hipLaunchKernelGGL(bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P.ni, P.nj,
-                             P.nk);
-        }
+  for (int b = 0; b < P.nb; ++b) {
+    ShellArgs a;
+    bool any = false;
+    for (int f = 0; f < 6; ++f) {
+      a.bc[f] = (f / 2 < P.ndim) ? bc[b * 6 + f] : ARTEMIS_BC_NONE;
+      any = any || (a.bc[f] != ARTEMIS_BC_NONE);
+    }
+    if (!any) continue;
+    a.lo[0] = P.is, a.lo[1] = P.js, a.lo[2] = P.ks, a.hi[0] = P.ie, a.hi[1] = P.je, a.hi[2] = P.ke;
+    a.ext[0] = P.ni, a.ext[1] = P.nj, a.ext[2] = P.nk;
+    a.ng = P.ng, a.ndim = P.ndim, a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;
+    const long nz = P.ke - P.ks + 1, ny = P.je - P.js + 1;
+    a.nA = (P.ndim > 2) ? 2L * P.ng * P.nj * P.ni : 0;
+    a.nB = (P.ndim > 1) ? nz * 2L * P.ng * P.ni : 0;
+    a.nC = nz * ny * 2L * P.ng;
+    const long n = a.nA + a.nB + a.nC;
+    hipLaunchKernelGGL(bc_shell_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, fill_tabs(P, b));
+  }
   return 0;
 }
 

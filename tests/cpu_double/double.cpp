@@ -1,0 +1,319 @@
+// TEST DOUBLE of libartemis_hip.so for machines without a GPU.
+//
+// It exports the C ABI of include/artemis_hip.h and include/artemis_rt.h on HOST memory, each
+// entry point implemented with the CPU oracle (oracle/artemis_oracle.cpp is compiled into this
+// library).  Linked with the UNMODIFIED product driver sources (artemis_amd/csrc/driver/*.cpp)
+// it lets the `-m "not gpu"` tests exercise the host logic -- deck parsing, mesh-block
+// decomposition, ghost-slab links, message tags, the dt all-reduce, the step loop -- under
+// torch.distributed/gloo with world_size > 1.  It lives under tests/ and is never built into,
+// loaded by, or shipped with the product.
+#include <cfloat>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../oracle/artemis_oracle.cpp"
+
+#include "../../include/artemis_hip.h"
+#include "../../include/artemis_rt.h"
+
+namespace {
+thread_local std::string d_err;
+
+oracle_cfg cfg_of(const artemis_pack_t *p) {
+  oracle_cfg c;
+  std::memset(&c, 0, sizeof c);
+  c.nx1 = p->nx1, c.nx2 = p->nx2, c.nx3 = p->nx3, c.ng = p->nghost;
+  c.ns_gas = p->gas.nspecies, c.ns_dust = p->dust.nspecies;
+  c.recon_gas = p->gas.recon, c.riemann_gas = p->gas.riemann;
+  c.recon_dust = p->dust.recon, c.riemann_dust = p->dust.riemann;
+  c.gamma = p->gm1 + 1.0;
+  c.dfloor_gas = p->gas.dfloor, c.siefloor_gas = p->gas.siefloor, c.de_switch = p->gas.de_switch;
+  c.dfloor_dust = p->dust.dfloor;
+  c.cfl_gas = 1.0, c.cfl_dust = 1.0;
+  for (int i = 0; i < 6; ++i) c.bc[i] = BC_NONE;
+  c.integrator = INT_RK2;
+  return c;
+}
+
+// An oracle Sim whose geometry is block b's; arrays are copied in/out per call.
+struct Bound {
+  Sim *s;
+  const artemis_pack_t *p;
+  int b;
+  Bound(const artemis_pack_t *p_, int b_) : p(p_), b(b_) {
+    oracle_cfg c = cfg_of(p);
+    // block bounds from the geom table: f0 = xmin - g*dx
+    const double *g = p->geom + 6 * b;
+    const int nx[3] = {p->nx1, p->nx2, p->nx3};
+    const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
+    double lo[3], hi[3];
+    for (int d = 0; d < 3; ++d) {
+      const int gh = (d < ndim) ? p->nghost : 0;
+      lo[d] = g[2 * d] + gh * g[2 * d + 1];
+      hi[d] = lo[d] + nx[d] * g[2 * d + 1];
+    }
+    c.x1min = lo[0], c.x1max = hi[0], c.x2min = lo[1], c.x2max = hi[1], c.x3min = lo[2], c.x3max = hi[2];
+    s = static_cast<Sim *>(oracle_create(&c));
+    // use the table's f0/dx verbatim so cell edges match the product's kernels bit for bit
+    for (int d = 0; d < 3; ++d) s->f0[d] = g[2 * d], s->dx[d] = g[2 * d + 1];
+  }
+  ~Bound() { oracle_destroy(s); }
+  void in(std::vector<Real> &dst, double *const *tab, int nvar) {
+    if (!tab) return;
+    for (int v = 0; v < nvar; ++v) std::memcpy(dst.data() + v * s->N, tab[b * nvar + v], s->N * sizeof(Real));
+  }
+  void out(const std::vector<Real> &src, double *const *tab, int nvar) {
+    if (!tab) return;
+    for (int v = 0; v < nvar; ++v) std::memcpy(tab[b * nvar + v], src.data() + v * s->N, s->N * sizeof(Real));
+  }
+  void load_state() {
+    in(s->gprim, p->gas.prim, s->nvg), in(s->gu0, p->gas.cons0, s->nvg), in(s->gu1, p->gas.cons1, s->nvg);
+    in(s->dprim, p->dust.prim, s->nvd), in(s->du0, p->dust.cons0, s->nvd), in(s->du1, p->dust.cons1, s->nvd);
+  }
+  void load_fluxes() {
+    for (int d = 0; d < 3; ++d) {
+      in(s->gflux[d], p->gas.flux[d], s->nvg), in(s->gpflux[d], p->gas.pflux[d], s->c.ns_gas);
+      in(s->gvface[d], p->gas.vface[d], s->c.ns_gas), in(s->dflux[d], p->dust.flux[d], s->nvd);
+    }
+  }
+};
+int bad(const char *m) {
+  d_err = m;
+  return ARTEMIS_HIP_EINVAL;
+}
+} // namespace
+
+extern "C" {
+const char *artemis_hip_last_error(void) { return d_err.c_str(); }
+const char *artemis_hip_version(void) { return "artemis_hip CPU TEST DOUBLE (tests/cpu_double)"; }
+int artemis_hip_device_count(void) { return 0; }
+
+int artemis_hip_calculate_fluxes(const artemis_pack_t *p, int fluid, int pcm, void *) {
+  if (!p) return bad("null pack");
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state();
+    calculate_fluxes(*B.s, fluid, pcm != 0);
+    for (int d = 0; d < B.s->ndim; ++d) {
+      if (fluid == FL_GAS) {
+        B.out(B.s->gflux[d], p->gas.flux[d], B.s->nvg), B.out(B.s->gpflux[d], p->gas.pflux[d], p->gas.nspecies);
+        B.out(B.s->gvface[d], p->gas.vface[d], p->gas.nspecies);
+      } else {
+        B.out(B.s->dflux[d], p->dust.flux[d], B.s->nvd);
+      }
+    }
+  }
+  return 0;
+}
+int artemis_hip_apply_update(const artemis_pack_t *p, double g0, double g1, double bdt, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state(), B.load_fluxes();
+    apply_update(*B.s, g0, g1, bdt);
+    B.out(B.s->gu0, p->gas.cons0, B.s->nvg), B.out(B.s->du0, p->dust.cons0, B.s->nvd);
+  }
+  return 0;
+}
+int artemis_hip_flux_source(const artemis_pack_t *p, int fluid, double dt, void *) {
+  if (fluid != FL_GAS || p->gas.nspecies == 0) return 0;
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state(), B.load_fluxes();
+    // interior only, like the product (the oracle's literal [is-2, ie+1] range only scribbles
+    // on ghost cells that PrimToCons overwrites)
+    std::vector<Real> before = B.s->gu0;
+    flux_source_gas(*B.s, dt);
+    Sim &s = *B.s;
+    for (int v = 0; v < s.nvg; ++v)
+      for (int k = 0; k < s.nk; ++k)
+        for (int j = 0; j < s.nj; ++j)
+          for (int i = 0; i < s.ni; ++i)
+            if (i < s.is || i > s.ie) s.gu0[v * s.N + IDX(s, k, j, i)] = before[v * s.N + IDX(s, k, j, i)];
+    B.out(B.s->gu0, p->gas.cons0, B.s->nvg);
+  }
+  return 0;
+}
+int artemis_hip_set_aux(const artemis_pack_t *p, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state();
+    set_aux(*B.s);
+    B.out(B.s->gu0, p->gas.cons0, B.s->nvg);
+  }
+  return 0;
+}
+int artemis_hip_cons_to_prim(const artemis_pack_t *p, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state();
+    cons_to_prim(*B.s);
+    B.out(B.s->gprim, p->gas.prim, B.s->nvg), B.out(B.s->dprim, p->dust.prim, B.s->nvd);
+  }
+  return 0;
+}
+int artemis_hip_prim_to_cons(const artemis_pack_t *p, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state();
+    prim_to_cons(*B.s);
+    B.out(B.s->gprim, p->gas.prim, B.s->nvg), B.out(B.s->dprim, p->dust.prim, B.s->nvd);
+    B.out(B.s->gu0, p->gas.cons0, B.s->nvg), B.out(B.s->du0, p->dust.cons0, B.s->nvd);
+  }
+  return 0;
+}
+int artemis_hip_deep_copy_conserved(const artemis_pack_t *p, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state();
+    B.out(B.s->gu0, p->gas.cons1, B.s->nvg), B.out(B.s->du0, p->dust.cons1, B.s->nvd);
+  }
+  return 0;
+}
+int artemis_hip_estimate_dt_async(const artemis_pack_t *p, int fluid, double cfl, double *dt_dev, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state();
+    if ((fluid == FL_GAS ? p->gas.nspecies : p->dust.nspecies) == 0) continue;
+    *dt_dev = std::min(*dt_dev, cfl * estimate_dt(*B.s, fluid)); // Bound's cfl is 1
+  }
+  return 0;
+}
+int artemis_hip_estimate_dt(const artemis_pack_t *p, int fluid, double cfl, double *out, void *s) {
+  *out = DBL_MAX;
+  return artemis_hip_estimate_dt_async(p, fluid, cfl, out, s);
+}
+int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state();
+    for (int f = 0; f < 6; ++f) B.s->c.bc[f] = bc[6 * b + f];
+    apply_bcs(*B.s);
+    B.out(B.s->gprim, p->gas.prim, B.s->nvg), B.out(B.s->dprim, p->dust.prim, B.s->nvd);
+  }
+  return 0;
+}
+
+// The fused-stage CONTRACT restated with the unfused oracle chain: u0 := PrimToCons(prim_in),
+// u1 := PrimToCons(prim_u1), then the reference's task order; prim_out receives the interior.
+int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *) {
+  if (p->gas.nspecies != 1 || p->dust.nspecies != 0) {
+    d_err = "fused stage: one gas species, no dust";
+    return ARTEMIS_HIP_EUNSUPPORTED;
+  }
+  if (p->gas.recon == RC_PPM && !a->pcm) {
+    d_err = "fused stage: pcm|plm";
+    return ARTEMIS_HIP_EUNSUPPORTED;
+  }
+  if (a->prim_in == a->prim_out) return bad("prim_out must not alias prim_in");
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    Sim &s = *B.s;
+    B.in(s.gprim, a->prim_u1, 6);
+    prim_to_cons(s);
+    s.gu1 = s.gu0;
+    B.in(s.gprim, a->prim_in, 6);
+    prim_to_cons(s);
+    calculate_fluxes(s, FL_GAS, a->pcm != 0);
+    apply_update(s, a->gam0, a->gam1, a->beta_dt);
+    flux_source_gas(s, a->bdt);
+    set_aux(s);
+    cons_to_prim(s);
+    // pressure of the interior cells as PrimToCons would set it
+    const Real gm1 = p->gm1;
+    for (int k = s.ks; k <= s.ke; ++k)
+      for (int j = s.js; j <= s.je; ++j)
+        for (int i = s.is; i <= s.ie; ++i) {
+          const size_t c = IDX(s, k, j, i);
+          s.gprim[4 * s.N + c] = std::max(0.0, gm1 * s.gprim[0 * s.N + c] * s.gprim[5 * s.N + c]);
+        }
+    for (int v = 0; v < 6; ++v)
+      for (int k = s.ks; k <= s.ke; ++k)
+        for (int j = s.js; j <= s.je; ++j)
+          std::memcpy(a->prim_out[b * 6 + v] + IDX(s, k, j, s.is), s.gprim.data() + v * s.N + IDX(s, k, j, s.is),
+                      (s.ie - s.is + 1) * sizeof(Real));
+    if (a->cons_out) {
+      prim_to_cons(s);
+      for (int v = 0; v < 6; ++v)
+        for (int k = s.ks; k <= s.ke; ++k)
+          for (int j = s.js; j <= s.je; ++j)
+            std::memcpy(a->cons_out[b * 6 + v] + IDX(s, k, j, s.is), s.gu0.data() + v * s.N + IDX(s, k, j, s.is),
+                        (s.ie - s.is + 1) * sizeof(Real));
+    }
+    if (a->dt_dev) *a->dt_dev = std::min(*a->dt_dev, a->cfl * estimate_dt(s, FL_GAS));
+  }
+  return 0;
+}
+
+static void slab(const artemis_pack_t *p, int face, int unpack, int lo[3], int n[3]) {
+  const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
+  const int nx[3] = {p->nx1, p->nx2, p->nx3};
+  const int d = face / 2, side = face % 2, ng = p->nghost;
+  for (int q = 0; q < 3; ++q) lo[q] = (q < ndim) ? ng : 0, n[q] = nx[q];
+  n[d] = ng;
+  const int st = lo[d], en = st + nx[d] - 1;
+  if (!unpack) lo[d] = side ? en - ng + 1 : st;
+  else lo[d] = side ? en + 1 : st - ng;
+}
+long artemis_hip_halo_count(const artemis_pack_t *p, int face) {
+  int lo[3], n[3];
+  slab(p, face, 0, lo, n);
+  return static_cast<long>(n[0]) * n[1] * n[2] * (5 * p->gas.nspecies + 4 * p->dust.nspecies);
+}
+static int halo(const artemis_pack_t *p, int b, int face, double *buf, int unpack) {
+  int lo[3], n[3];
+  slab(p, face, unpack, lo, n);
+  const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
+  const int ni = p->nx1 + 2 * p->nghost, nj = p->nx2 + (ndim > 1 ? 2 * p->nghost : 0);
+  const long ncell = static_cast<long>(n[0]) * n[1] * n[2];
+  const int nsg = p->gas.nspecies, nsd = p->dust.nspecies;
+  int v = 0;
+  auto doit = [&](double *q) {
+    long t = 0;
+    for (int k = 0; k < n[2]; ++k)
+      for (int j = 0; j < n[1]; ++j)
+        for (int i = 0; i < n[0]; ++i, ++t) {
+          const size_t c = (static_cast<size_t>(lo[2] + k) * nj + lo[1] + j) * ni + lo[0] + i;
+          if (unpack) q[c] = buf[v * ncell + t];
+          else buf[v * ncell + t] = q[c];
+        }
+    ++v;
+  };
+  for (int s = 0; s < 6 * nsg; ++s)
+    if (!(s >= 4 * nsg && s < 5 * nsg)) doit(p->gas.prim[b * 6 * nsg + s]);
+  for (int s = 0; s < 4 * nsd; ++s) doit(p->dust.prim[b * 4 * nsd + s]);
+  return 0;
+}
+int artemis_hip_halo_pack(const artemis_pack_t *p, int b, int face, double *buf, void *) {
+  return halo(p, b, face, buf, 0);
+}
+int artemis_hip_halo_unpack(const artemis_pack_t *p, int b, int face, const double *buf, void *) {
+  return halo(p, b, face, const_cast<double *>(buf), 1);
+}
+int artemis_hip_selftest_divsqrt(long, const double *, const double *, double *, double *, double *,
+                                 double *, void *) {
+  return ARTEMIS_HIP_EUNSUPPORTED;
+}
+
+// ---- runtime shim on host memory ----------------------------------------------------------
+int artemis_rt_set_device(int) { return 0; }
+void *artemis_rt_malloc(size_t n) { return std::calloc(1, n ? n : 8); }
+void artemis_rt_free(void *p) { std::free(p); }
+void *artemis_rt_malloc_host(size_t n) { return std::calloc(1, n ? n : 8); }
+void artemis_rt_free_host(void *p) { std::free(p); }
+int artemis_rt_memcpy_h2d(void *d, const void *s, size_t n, void *) { std::memcpy(d, s, n); return 0; }
+int artemis_rt_memcpy_d2h(void *d, const void *s, size_t n, void *) { std::memcpy(d, s, n); return 0; }
+int artemis_rt_memcpy_d2d(void *d, const void *s, size_t n, void *) { std::memmove(d, s, n); return 0; }
+int artemis_rt_memset(void *d, int v, size_t n, void *) { std::memset(d, v, n); return 0; }
+void *artemis_rt_stream_create(void) { return std::malloc(8); }
+void artemis_rt_stream_destroy(void *s) { std::free(s); }
+int artemis_rt_stream_sync(void *) { return 0; }
+int artemis_rt_device_sync(void) { return 0; }
+void *artemis_rt_event_create(void) { return std::malloc(8); }
+void artemis_rt_event_destroy(void *e) { std::free(e); }
+int artemis_rt_event_record(void *, void *) { return 0; }
+int artemis_rt_stream_wait_event(void *, void *) { return 0; }
+int artemis_rt_event_sync(void *) { return 0; }
+double artemis_rt_event_elapsed_ms(void *, void *) { return 0.0; }
+void artemis_rt_tables_changed(void) {}
+}

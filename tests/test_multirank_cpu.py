@@ -1,0 +1,124 @@
+"""Host-logic tests without a GPU: the product's C++ driver (unmodified sources) linked against
+the CPU test double of the C ABI (tests/cpu_double, oracle-backed), single process and under
+torch.distributed/gloo with world_size 2 and 4.  What is under test is everything ABOVE the
+kernels: deck parsing, the rank grid / mesh-block bricks, ghost-slab links and tags (including
+periodic wrap-around between ranks), TorchComm's batched isend/irecv, the dt all-reduce and the
+EvolutionDriver loop.  The N-rank result must equal the 1-rank run of the same block layout
+BIT FOR BIT (same per-block arithmetic, only the transport differs)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def double_lib():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpu_double"), "-s"])
+    return os.path.join(ROOT, "tests", "_build", "libartemis_cpudouble.so")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(world, spec, tmp_path, tag):
+    spec = dict(spec, out=str(tmp_path / tag))
+    port = str(free_port())
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mr_worker.py"),
+                                       json.dumps(spec)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    res = []
+    for r in range(world):
+        z = np.load(spec["out"] + ".rank%d.npz" % r)
+        res.append(dict(meta=json.loads(str(z["meta"])), hist=z["hist"], errs=z["errs"],
+                        blocks=[(z["bounds%d" % b], z["prim%d" % b]) for b in range(json.loads(str(z["meta"]))["nblocks"])]))
+    return res
+
+
+def by_bounds(results):
+    d = {}
+    for r in results:
+        for bounds, prim in r["blocks"]:
+            d[tuple(np.round(bounds, 12))] = prim
+    return d
+
+
+BLAST = dict(deck=["blast", "blast.in"], cycles=6, overrides=[
+    "parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16",
+    "parthenon/mesh/x3min=-1.0", "parthenon/mesh/x3max=1.0", "parthenon/meshblock/nx1=16",
+    "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8", "gas/riemann=hllc",
+    "problem/symmetry=spherical", "problem/radius=0.3", "problem/samples=0"])
+
+LINWAVE = dict(deck=["linwave", "linear_wave.in"], overrides=[
+    "parthenon/mesh/nghost=2", "parthenon/mesh/nx1=16", "parthenon/mesh/nx2=8", "parthenon/mesh/nx3=8",
+    "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=4", "parthenon/meshblock/nx3=4",
+    "problem/amp=1.0e-6", "problem/wave_flag=0", "problem/vflow=0.0", "parthenon/time/nlim=1000"])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_blast_ranks_equal_single_process_bitwise(double_lib, tmp_path, world):
+    one = run_world(1, BLAST, tmp_path, "one")
+    many = run_world(world, BLAST, tmp_path, "w%d" % world)
+    assert one[0]["meta"]["nblocks"] == 8 and sum(r["meta"]["nblocks"] for r in many) == 8
+    assert one[0]["meta"]["fused"]
+    for r in many:
+        for k in ("ncycle", "time", "dt"):
+            assert r["meta"][k] == one[0]["meta"][k], k
+        assert np.allclose(r["hist"], one[0]["hist"], rtol=1e-13)
+    a, b = by_bounds(one), by_bounds(many)
+    assert a.keys() == b.keys()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+
+
+def test_linwave_periodic_wraparound_two_ranks(double_lib, tmp_path):
+    """Periodic images cross the rank boundary (2x2x2 blocks, 2 ranks): bitwise equal to the
+    single-process run, full period, reference error threshold shape (not value: N = 16)."""
+    one = run_world(1, LINWAVE, tmp_path, "one")
+    two = run_world(2, LINWAVE, tmp_path, "two")
+    assert one[0]["meta"]["ncycle"] == two[0]["meta"]["ncycle"] == two[1]["meta"]["ncycle"] > 10
+    a, b = by_bounds(one), by_bounds(two)
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    # error norms are all-reduced sums: identical on both ranks, equal to 1 rank to round-off
+    assert np.array_equal(two[0]["errs"], two[1]["errs"])
+    assert np.allclose(two[0]["errs"], one[0]["errs"], rtol=1e-10)
+    assert 1e-8 < one[0]["errs"][0] < 2e-6
+
+
+def test_unfused_path_and_block_layouts_single_process(double_lib, tmp_path):
+    """Per-task path == fused path through the double, and the 8-block layout agrees with the
+    1-block layout to round-off (block-local cell edges differ in the last bit)."""
+    spec1 = dict(BLAST, overrides=[o for o in BLAST["overrides"] if "meshblock" not in o] +
+                 ["parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16"])
+    f8 = run_world(1, BLAST, tmp_path, "f8")
+    u8 = run_world(1, dict(BLAST, path="unfused"), tmp_path, "u8")
+    f1 = run_world(1, spec1, tmp_path, "f1")
+    assert not u8[0]["meta"]["fused"]
+    a, b = by_bounds(f8), by_bounds(u8)
+    for key in a:
+        assert np.array_equal(a[key], b[key])
+    full = f1[0]["blocks"][0][1]
+    for bounds, prim in f8[0]["blocks"]:
+        i0 = int(round((bounds[0] + 1.0) / (2.0 / 32)))
+        j0 = int(round((bounds[2] + 1.0) / (2.0 / 16)))
+        k0 = int(round((bounds[4] + 1.0) / (2.0 / 16)))
+        ref = full[:, k0:k0 + 8, j0:j0 + 8, i0:i0 + 16]
+        assert np.max(np.abs(prim - ref) / (np.abs(ref) + 1e-30)) < 1e-11
