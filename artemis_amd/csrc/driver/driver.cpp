@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -138,6 +139,10 @@ struct artemis_sim {
   double *dt_host = nullptr;    // pinned
   bool unfused_ready = false;
   bool use_fused = false, fused_possible = false, overlap = false;
+  // test hook (ARTEMIS_LOOPBACK_COMM=1): route same-rank ghost slabs through the communicator
+  // as messages to self, so one GPU exercises the RCCL send/recv path end to end
+  bool loopback = false;
+  bool remote(const Link &L) const { return L.nbr_rank != rank || loopback; }
   bool cons_valid = false;
 
   std::vector<std::unique_ptr<Link>> links;
@@ -242,6 +247,8 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   for (int q = 0; q < nover; ++q) pin.ApplyOverride(over[q]);
   if (c) {
     comm = *c, has_comm = true, rank = c->rank, nranks = c->nranks;
+    const char *lb = std::getenv("ARTEMIS_LOOPBACK_COMM");
+    loopback = lb && lb[0] == '1';
   }
   // <artemis> (artemis.cpp:48-53,93-97)
   const std::string problem = pin.GetString("artemis", "problem");
@@ -436,7 +443,7 @@ void artemis_sim::allocate() {
       const artemis_pack_t p = make_pack(0);
       L->count = artemis_hip_halo_count(&p, f);
       L->sbuf.alloc(L->count);
-      if (L->nbr_rank != rank) L->rbuf.alloc(L->count);
+      if (remote(*L)) L->rbuf.alloc(L->count);
       // tag = (destination global block id, destination face)
       int nl[3] = {blocks[b].lx[0], blocks[b].lx[1], blocks[b].lx[2]};
       const int d = f / 2;
@@ -484,7 +491,7 @@ void artemis_sim::fill_ghosts_start(int prim_idx) {
   std::vector<artemis_msg_t> msgs;
   for (auto &L : links) {
     CK(artemis_hip_halo_pack(&p, L->b, L->face, L->sbuf.p, stream), "halo pack");
-    if (L->nbr_rank != rank) {
+    if (remote(*L)) {
       artemis_msg_t m;
       m.peer = L->nbr_rank, m.tag = L->tag_send, m.send = L->sbuf.p, m.recv = nullptr, m.count = L->count;
       msgs.push_back(m);
@@ -504,14 +511,14 @@ void artemis_sim::fill_ghosts_start(int prim_idx) {
 void artemis_sim::fill_ghosts_finish(int prim_idx) {
   const artemis_pack_t p = make_pack(prim_idx);
   bool remote = false;
-  for (auto &L : links) remote = remote || (L->nbr_rank != rank);
+  for (auto &L : links) remote = remote || this->remote(*L);
   if (remote) {
     if (comm.exchange_finish(comm.ctx, comm_stream)) throw std::runtime_error("exchange_finish failed");
     CK(artemis_rt_event_record(ev1, comm_stream), "event");
     CK(artemis_rt_stream_wait_event(stream, ev1), "wait");
   }
   for (auto &L : links) {
-    if (L->nbr_rank == rank) {
+    if (!this->remote(*L)) {
       CK(artemis_hip_halo_unpack(&p, L->nbr_block, L->face ^ 1, L->sbuf.p, stream), "halo unpack");
     } else {
       // what I received through face f came from the neighbour's opposite face
