@@ -50,7 +50,7 @@ class StageArgs(C.Structure):
         ("gam0", C.c_double), ("gam1", C.c_double), ("beta_dt", C.c_double), ("bdt", C.c_double),
         ("pcm", C.c_int),
         ("prim_in", PP), ("prim_u1", PP), ("prim_out", PP), ("cons_out", PP),
-        ("cfl", C.c_double), ("dt_dev", C.c_void_p),
+        ("cfl", C.c_double), ("dt_dev", C.c_void_p), ("region", C.c_int),
     ]
 
 

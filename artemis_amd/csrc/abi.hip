@@ -235,6 +235,8 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
     return fail(ARTEMIS_HIP_EINVAL, "fused stage: prim_in / prim_u1 / prim_out are required");
   if (a->prim_in == a->prim_out)
     return fail(ARTEMIS_HIP_EINVAL, "fused stage: prim_out must not alias prim_in");
+  if (a->region < 0 || a->region > 2) return fail(ARTEMIS_HIP_EINVAL, "fused stage: region must be 0, 1 or 2");
+  if (p->nghost < 2) return fail(ARTEMIS_HIP_EUNSUPPORTED, "fused stage: needs nghost >= 2");
   const int recon = a->pcm ? ARTEMIS_PCM : p->gas.recon;
   const int rc = artemis::launch_stage_fused(artemis::make_pack_view(*p), *a, p->gas.riemann, recon,
                                              S(stream));

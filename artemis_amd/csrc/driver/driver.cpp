@@ -193,8 +193,8 @@ struct artemis_sim {
   void ensure_unfused();
   void problem_generator();
   void fill_ghosts(int prim_idx);
-  void fill_ghosts_start(int prim_idx);
-  void fill_ghosts_finish(int prim_idx);
+  void fill_ghosts_start(int prim_idx, void *hs);
+  void fill_ghosts_finish(int prim_idx, void *hs);
   void materialise_cons();
   Real new_dt_unfused();
   void step_fused(bool want_dt);
@@ -485,12 +485,15 @@ std::vector<Real> artemis_sim::download(const Field &f, int b) {
 // Ghost fill of the FillGhost primitives of buffer `prim_idx`: neighbour slabs (device copy
 // within the rank, comm callbacks between ranks), then physical BCs.  This is where
 // AddBoundaryExchangeTasks sits in the reference (artemis_driver.cpp:258).
-void artemis_sim::fill_ghosts_start(int prim_idx) {
+// `hs` is the stream the pack/unpack kernels run on: the compute stream normally, the comm stream
+// when the exchange overlaps the bulk of the stage kernel (then everything between "shell done"
+// and "ghosts filled" lives on the comm stream and the compute stream keeps computing).
+void artemis_sim::fill_ghosts_start(int prim_idx, void *hs) {
   if (links.empty()) return;
   const artemis_pack_t p = make_pack(prim_idx);
   std::vector<artemis_msg_t> msgs;
   for (auto &L : links) {
-    CK(artemis_hip_halo_pack(&p, L->b, L->face, L->sbuf.p, stream), "halo pack");
+    CK(artemis_hip_halo_pack(&p, L->b, L->face, L->sbuf.p, hs), "halo pack");
     if (remote(*L)) {
       artemis_msg_t m;
       m.peer = L->nbr_rank, m.tag = L->tag_send, m.send = L->sbuf.p, m.recv = nullptr, m.count = L->count;
@@ -501,35 +504,42 @@ void artemis_sim::fill_ghosts_start(int prim_idx) {
   }
   if (!msgs.empty()) {
     if (!has_comm) throw std::runtime_error("remote neighbours but no communicator");
-    // sends may start once the packs are done: order the comm stream after the compute stream
-    CK(artemis_rt_event_record(ev0, stream), "event");
-    CK(artemis_rt_stream_wait_event(comm_stream, ev0), "wait");
+    if (hs != comm_stream) { // sends may start once the packs are done
+      CK(artemis_rt_event_record(ev0, hs), "event");
+      CK(artemis_rt_stream_wait_event(comm_stream, ev0), "wait");
+    }
     if (comm.exchange_start(comm.ctx, static_cast<int>(msgs.size()), msgs.data(), comm_stream))
       throw std::runtime_error("exchange_start failed");
   }
 }
-void artemis_sim::fill_ghosts_finish(int prim_idx) {
+void artemis_sim::fill_ghosts_finish(int prim_idx, void *hs) {
   const artemis_pack_t p = make_pack(prim_idx);
-  bool remote = false;
-  for (auto &L : links) remote = remote || this->remote(*L);
-  if (remote) {
+  bool any_remote = false;
+  for (auto &L : links) any_remote = any_remote || remote(*L);
+  if (any_remote) {
     if (comm.exchange_finish(comm.ctx, comm_stream)) throw std::runtime_error("exchange_finish failed");
-    CK(artemis_rt_event_record(ev1, comm_stream), "event");
-    CK(artemis_rt_stream_wait_event(stream, ev1), "wait");
+    if (hs != comm_stream) {
+      CK(artemis_rt_event_record(ev1, comm_stream), "event");
+      CK(artemis_rt_stream_wait_event(hs, ev1), "wait");
+    }
   }
   for (auto &L : links) {
-    if (!this->remote(*L)) {
-      CK(artemis_hip_halo_unpack(&p, L->nbr_block, L->face ^ 1, L->sbuf.p, stream), "halo unpack");
+    if (!remote(*L)) {
+      CK(artemis_hip_halo_unpack(&p, L->nbr_block, L->face ^ 1, L->sbuf.p, hs), "halo unpack");
     } else {
       // what I received through face f came from the neighbour's opposite face
-      CK(artemis_hip_halo_unpack(&p, L->b, L->face, L->rbuf.p, stream), "halo unpack");
+      CK(artemis_hip_halo_unpack(&p, L->b, L->face, L->rbuf.p, hs), "halo unpack");
     }
+  }
+  if (hs != stream) { // hand the filled ghosts back to the compute stream
+    CK(artemis_rt_event_record(ev1, hs), "event");
+    CK(artemis_rt_stream_wait_event(stream, ev1), "wait");
   }
   CK(artemis_hip_apply_bc(&p, bc_flat.data(), stream), "apply_bc");
 }
 void artemis_sim::fill_ghosts(int prim_idx) {
-  fill_ghosts_start(prim_idx);
-  fill_ghosts_finish(prim_idx);
+  fill_ghosts_start(prim_idx, stream);
+  fill_ghosts_finish(prim_idx, stream);
 }
 
 void artemis_sim::materialise_cons() {
@@ -782,17 +792,37 @@ void artemis_sim::step_fused(bool want_dt) {
     a.cons_out = nullptr;
     a.cfl = cfl_gas;
     a.dt_dev = (last && want_dt) ? dt_dev.p : nullptr;
+    bool any_remote = false;
+    for (auto &L : links) any_remote = any_remote || remote(*L);
+    const bool ovl = overlap && any_remote;
     void *e0 = nullptr, *e1 = nullptr;
     if (time_kernels) {
       e0 = artemis_rt_event_create(), e1 = artemis_rt_event_create();
       CK(artemis_rt_event_record(e0, stream), "event");
     }
-    CK(artemis_hip_stage_fused(&p, &a, stream), "stage_fused");
-    if (time_kernels) {
-      CK(artemis_rt_event_record(e1, stream), "event");
-      kev.emplace_back(e0, e1);
+    if (!ovl) {
+      a.region = 0;
+      CK(artemis_hip_stage_fused(&p, &a, stream), "stage_fused");
+      if (time_kernels) {
+        CK(artemis_rt_event_record(e1, stream), "event");
+        kev.emplace_back(e0, e1);
+      }
+      fill_ghosts(out);
+    } else {
+      // boundary shell first; its slabs travel on the comm stream while the bulk is computed
+      a.region = 1;
+      CK(artemis_hip_stage_fused(&p, &a, stream), "stage_fused shell");
+      CK(artemis_rt_event_record(ev0, stream), "event");
+      CK(artemis_rt_stream_wait_event(comm_stream, ev0), "wait");
+      fill_ghosts_start(out, comm_stream);
+      a.region = 2;
+      CK(artemis_hip_stage_fused(&p, &a, stream), "stage_fused bulk");
+      if (time_kernels) {
+        CK(artemis_rt_event_record(e1, stream), "event");
+        kev.emplace_back(e0, e1);
+      }
+      fill_ghosts_finish(out, comm_stream);
     }
-    fill_ghosts(out);
     cur = out;
   }
   base = cur;

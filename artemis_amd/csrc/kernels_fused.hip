@@ -39,8 +39,12 @@ struct StageK {
   double gam0, gam1, beta_dt, bdt, cfl;
   double *const *prim_in, *const *prim_u1, *const *prim_out, *const *cons_out;
   unsigned long long *dt_bits;
-  int kchunk; // planes per chunk
-  int nchunk;
+  // Work decomposition: up to 7 boxes of (i-tiles x j-tiles x k-range), each k-range cut into
+  // chunks; workgroup `id` belongs to box q with start[q] <= id < start[q+1].
+  int nbox;
+  int ti0[7], nti[7], tj0[7], ntj[7], kb0[7], kb1[7], nchunk[7], kchunk[7];
+  int start[8];
+  int xcd_swizzle; // remap ids so that each XCD's L2 sees neighbouring tiles
 };
 
 struct LdsTile {
@@ -365,16 +369,28 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   __shared__ LdsTile S;
   Ctx x;
   x.tx = threadIdx.x, x.ty = threadIdx.y, x.t = x.ty * FTX + x.tx;
-  x.b = blockIdx.z / a.nchunk;
-  const int chunk = blockIdx.z % a.nchunk;
+  int id = blockIdx.x;
+  if (a.xcd_swizzle) { // T1: ids round-robin over the 8 XCDs; give each XCD a contiguous run
+    const int per = gridDim.x >> 3;
+    id = (id & 7) * per + (id >> 3);
+  }
+  int q = 0;
+  while (q + 1 < a.nbox && id >= a.start[q + 1]) ++q;
+  int local = id - a.start[q];
+  const int ti = a.ti0[q] + local % a.nti[q];
+  local /= a.nti[q];
+  const int tj = a.tj0[q] + local % a.ntj[q];
+  local /= a.ntj[q];
+  const int chunk = local % a.nchunk[q];
+  x.b = local / a.nchunk[q];
   x.three_d = P.ndim > 2, x.multi_d = P.ndim > 1;
-  x.i0 = P.is + blockIdx.x * FTX, x.j0 = P.js + blockIdx.y * FTY;
+  x.i0 = P.is + ti * FTX, x.j0 = P.js + tj * FTY;
   const int i = x.i0 + x.tx, j = x.j0 + x.ty;
   x.active = (i <= P.ie) && (j <= P.je);
   // clamped indices: inactive lanes still serve as neighbours and face owners
   const int il = min(i, P.ni - 1), jl = min(j, P.nj - 1);
-  const int k0 = P.ks + chunk * a.kchunk;
-  const int k1 = min(P.ke, k0 + a.kchunk - 1);
+  const int k0 = a.kb0[q] + chunk * a.kchunk[q];
+  const int k1 = min(a.kb1[q], k0 + a.kchunk[q] - 1);
   if (k0 > k1) return;
   x.gm1 = P.gm1;
   x.gk = gas_constants(P.gm1);
@@ -445,7 +461,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
 
 template <int RIEMANN, int RECON>
 int launch_cfg(const PackView &P, const StageK &k, bool has_u1, bool cons, bool dt, hipStream_t s) {
-  const dim3 grid((P.ie - P.is + FTX) / FTX, (P.je - P.js + FTY) / FTY, P.nb * k.nchunk);
+  const dim3 grid(k.start[k.nbox]);
   const dim3 block(FTX, FTY);
 #define GO(U, C, D)                                                                        \
   hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, U, C, D>), grid, block, 0, s, P, k)
@@ -470,18 +486,41 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   k.prim_in = a.prim_in, k.prim_u1 = a.prim_u1, k.prim_out = a.prim_out, k.cons_out = a.cons_out;
   k.dt_bits = reinterpret_cast<unsigned long long *>(a.dt_dev);
   const int nz = P.ke - P.ks + 1;
-  // enough workgroups to fill 256 CUs x 2 several times over, chunks of >= 16 planes
-  const long tiles = static_cast<long>((P.ie - P.is + FTX) / FTX) * ((P.je - P.js + FTY) / FTY) * P.nb;
-  int nchunk = 1;
-  if (P.ndim > 2) {
-    while (nchunk * 2 <= nz / 16 && tiles * nchunk < 4096) nchunk *= 2;
+  const int NTI = (P.ie - P.is + FTX) / FTX, NTJ = (P.je - P.js + FTY) / FTY;
+  int target_chunk = 16; // planes per chunk: >= 8 workgroup rounds on 256 CUs x 2 at 256^3
+  if (const char *e = getenv("ARTEMIS_FUSED_KCHUNK")) target_chunk = std::max(1, atoi(e)); // tuning knob
+  k.nbox = 0;
+  k.start[0] = 0;
+  auto add_box = [&](int ti0, int nti, int tj0, int ntj, int kb0, int kb1) {
+    if (nti <= 0 || ntj <= 0 || kb1 < kb0) return;
+    const int q = k.nbox++;
+    k.ti0[q] = ti0, k.nti[q] = nti, k.tj0[q] = tj0, k.ntj[q] = ntj, k.kb0[q] = kb0, k.kb1[q] = kb1;
+    const int planes = kb1 - kb0 + 1;
+    k.nchunk[q] = (P.ndim > 2) ? std::max(1, planes / target_chunk) : 1;
+    k.kchunk[q] = (planes + k.nchunk[q] - 1) / k.nchunk[q];
+    k.nchunk[q] = (planes + k.kchunk[q] - 1) / k.kchunk[q];
+    k.start[q + 1] = k.start[q] + nti * ntj * k.nchunk[q] * P.nb;
+  };
+  // region 0: whole block.  region 1: boundary shell = everything a neighbour's ghost slab is cut
+  // from, rounded out to whole tiles (x1, x2) / nghost planes (x3).  region 2: the complement.
+  const int g = P.ng;
+  const bool zsplit = (P.ndim > 2) && nz > 2 * g, ysplit = (P.ndim > 1) && NTJ > 2, xsplit = NTI > 2;
+  // the shell/bulk split exists only if every active dimension can be cut; otherwise the whole
+  // block is "shell" and the bulk is empty (region 1 must always contain every boundary cell)
+  const bool split = xsplit && (P.ndim < 2 || ysplit) && (P.ndim < 3 || zsplit);
+  const int km0 = zsplit ? P.ks + g : P.ks, km1 = zsplit ? P.ke - g : P.ke; // middle k-range
+  const int tjm0 = ysplit ? 1 : 0, ntjm = ysplit ? NTJ - 2 : NTJ;           // middle j-tiles
+  if (a.region == 0 || (a.region == 1 && !split)) {
+    add_box(0, NTI, 0, NTJ, P.ks, P.ke);
+  } else if (a.region == 1) {
+    if (zsplit) add_box(0, NTI, 0, NTJ, P.ks, P.ks + g - 1), add_box(0, NTI, 0, NTJ, P.ke - g + 1, P.ke);
+    if (ysplit) add_box(0, NTI, 0, 1, km0, km1), add_box(0, NTI, NTJ - 1, 1, km0, km1);
+    add_box(0, 1, tjm0, ntjm, km0, km1), add_box(NTI - 1, 1, tjm0, ntjm, km0, km1);
+  } else if (split) {
+    add_box(1, NTI - 2, tjm0, ntjm, km0, km1);
   }
-  if (const char *e = getenv("ARTEMIS_FUSED_NCHUNK")) { // tuning knob
-    const int v = atoi(e);
-    if (v >= 1 && P.ndim > 2) nchunk = std::min(v, nz);
-  }
-  k.nchunk = nchunk;
-  k.kchunk = (nz + nchunk - 1) / nchunk;
+  if (k.nbox == 0) return 0; // nothing to do in this region
+  k.xcd_swizzle = (k.start[k.nbox] % 8 == 0 && getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
   const bool has_u1 = (a.prim_u1 != a.prim_in);
   const bool cons = (a.cons_out != nullptr);
   const bool dt = (a.dt_dev != nullptr);

@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--n", type=int, default=256, help="cells per GPU per dimension")
     ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: exchange halos after the whole stage kernel instead of behind its bulk")
     ap.add_argument("--cpu-n", type=int, default=256)
     ap.add_argument("--cpu-cycles", type=int, default=3)
     args = ap.parse_args()
@@ -96,6 +98,7 @@ def main():
     sim = Simulation(deck, overrides(args.gpus, per_gpu, args.warmup + args.steps), comm=comm)
     if args.path == "unfused":
         sim.set_path("unfused")
+    sim.set_overlap(world > 1 and not args.no_overlap)
 
     def barrier():
         if world > 1:
@@ -134,7 +137,10 @@ def main():
                             "samples 0" % args.n,
                 "mesh": [int(x) for x in (total_zones // (per_gpu[1] * per_gpu[2] * (1 if args.gpus < 4 else 2) * (1 if args.gpus < 8 else 2)),)] if False else None,
                 "cells_per_gpu": local_zones, "path": "fused" if fused else "unfused",
-                "decomposition": "%d rank(s), one %d^3 mesh block each, face-slab halo exchange" % (args.gpus, args.n),
+                "decomposition": "%d rank(s), one %d^3 mesh block each, face-slab halo exchange%s"
+                                 % (args.gpus, args.n, "" if world == 1 else
+                                    (" on RCCL, not overlapped" if args.no_overlap else
+                                     " on RCCL on a second stream behind the bulk of the stage kernel")),
                 "total_energy_check": float(hist[4]),
             },
         }

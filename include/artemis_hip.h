@@ -160,6 +160,10 @@ typedef struct artemis_stage_args {
   double *const *prim_in, *const *prim_u1, *const *prim_out, *const *cons_out;
   double cfl;
   double *dt_dev;
+  int region;                 /* 0 = all interior cells; 1 = only the boundary shell (the cells
+                                 neighbours' ghost slabs are cut from, rounded out to whole
+                                 tiles); 2 = only the rest.  1 then 2 == 0: lets a driver send
+                                 halos while the bulk is still being computed. */
 } artemis_stage_args_t;
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
 

@@ -206,6 +206,8 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
     return ARTEMIS_HIP_EUNSUPPORTED;
   }
   if (a->prim_in == a->prim_out) return bad("prim_out must not alias prim_in");
+  // region 1 (shell, "rounded out") is the whole block here, so region 2 (the rest) is empty
+  if (a->region == 2) return 0;
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);
     Sim &s = *B.s;

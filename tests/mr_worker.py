@@ -28,6 +28,8 @@ def main():
     sim = Simulation(os.path.join(ROOT, "inputs", *spec["deck"]), spec["overrides"], comm=comm, lib=lib)
     if spec.get("path"):
         sim.set_path(spec["path"])
+    if spec.get("overlap"):
+        sim.set_overlap(True)
     n = sim.evolve(spec.get("cycles", -1))
     out = {"ncycle": sim.ncycle, "time": sim.time, "dt": sim.dt, "n": n, "nblocks": sim.nblocks,
            "fused": sim.uses_fused_path}

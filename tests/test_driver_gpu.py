@@ -181,6 +181,8 @@ def test_rccl_loopback_halo_exchange(hiplib, monkeypatch):
     import torch
     import torch.distributed as dist
     from artemis_amd.driver import Simulation, TorchComm
+    # 128x32x32 in blocks of 128x16x16: each block's tile grid (4 x 2 x 16 planes) is too small to
+    # split in x2, so also run a 96x32x24-block layout that does split into shell + bulk
     ov = linwave_overrides(32, "plm", "hllc", 0, 0.0, mb=(16, 8, 8)) + ["parthenon/time/nlim=12"]
     ref = Simulation(DECK("linwave", "linear_wave.in"), ov)
     ref.evolve()
@@ -193,12 +195,53 @@ def test_rccl_loopback_halo_exchange(hiplib, monkeypatch):
     try:
         monkeypatch.setenv("ARTEMIS_LOOPBACK_COMM", "1")
         comm = TorchComm(torch.device("cuda", 0))
-        sim = Simulation(DECK("linwave", "linear_wave.in"), ov, comm=comm)
-        sim.evolve()
-        assert sim.ncycle == ref.ncycle == 12 and sim.dt == ref.dt
-        for b in range(sim.nblocks):
-            assert np.array_equal(sim.interior(sim.field("gas.prim", b)), ref.interior(ref.field("gas.prim", b)))
-        assert np.array_equal(sim.history(), ref.history())
-        sim.close()
+        for overlap in (False, True):
+            # overlap: shell kernel -> slabs on the comm stream || bulk kernel on the compute stream
+            sim = Simulation(DECK("linwave", "linear_wave.in"), ov, comm=comm)
+            sim.set_overlap(overlap)
+            sim.evolve()
+            assert sim.ncycle == ref.ncycle == 12 and sim.dt == ref.dt
+            for b in range(sim.nblocks):
+                assert np.array_equal(sim.interior(sim.field("gas.prim", b)),
+                                      ref.interior(ref.field("gas.prim", b))), (overlap, b)
+            assert np.array_equal(sim.history(), ref.history())
+            sim.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_loopback_overlap_split_blocks(hiplib, monkeypatch):
+    """Same loopback route with blocks big enough (96x32x24 cells = 3x4 tiles x 24 planes) for the
+    stage kernel to really split into boundary shell + bulk: overlap on/off and the plain
+    device-copy run agree bit for bit (Sedov deck, outflow + block-to-block faces)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from artemis_amd.driver import Simulation, TorchComm
+    ov = ["parthenon/mesh/nx1=192", "parthenon/mesh/nx2=64", "parthenon/mesh/nx3=48",
+          "parthenon/mesh/x3min=-1.0", "parthenon/mesh/x3max=1.0", "parthenon/meshblock/nx1=96",
+          "parthenon/meshblock/nx2=32", "parthenon/meshblock/nx3=24", "gas/riemann=hllc",
+          "problem/symmetry=spherical", "problem/radius=0.2", "problem/samples=0", "parthenon/time/nlim=8"]
+    ref = Simulation(DECK("blast", "blast.in"), ov)
+    assert ref.nblocks == 8
+    ref.evolve()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        monkeypatch.setenv("ARTEMIS_LOOPBACK_COMM", "1")
+        comm = TorchComm(torch.device("cuda", 0))
+        for overlap in (True, False):
+            sim = Simulation(DECK("blast", "blast.in"), ov, comm=comm)
+            sim.set_overlap(overlap)
+            sim.evolve()
+            assert sim.ncycle == 8 and sim.dt == ref.dt
+            for b in range(8):
+                assert np.array_equal(sim.field("gas.prim", b)[[0, 1, 2, 3, 5]],
+                                      ref.field("gas.prim", b)[[0, 1, 2, 3, 5]]), (overlap, b)
+            sim.close()
     finally:
         dist.destroy_process_group()

@@ -86,6 +86,10 @@ def test_blast_ranks_equal_single_process_bitwise(double_lib, tmp_path, world):
     assert a.keys() == b.keys()
     for key in a:
         assert np.array_equal(a[key], b[key]), key
+    if world == 2:  # shell-first ordering with the exchange on the comm stream
+        ovl = by_bounds(run_world(world, dict(BLAST, overlap=True), tmp_path, "ovl"))
+        for key in a:
+            assert np.array_equal(a[key], ovl[key]), key
 
 
 def test_linwave_periodic_wraparound_two_ranks(double_lib, tmp_path):

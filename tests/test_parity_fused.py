@@ -148,3 +148,31 @@ def test_fast_div_sqrt(hiplib):
             a, b = ab[0].cpu().numpy(), ab[1].cpu().numpy()
             assert np.array_equal(qi.cpu().numpy(), a / b)
             assert np.array_equal(si.cpu().numpy(), np.sqrt(np.abs(b)))
+
+
+@pytest.mark.parametrize("nx", [(96, 32, 24), (100, 30, 9), (40, 20, 36), (70, 23, 1)])
+def test_fused_shell_then_bulk_equals_whole(hiplib, nx):
+    """region 1 (boundary shell) followed by region 2 (bulk) writes exactly what region 0 writes,
+    and the shell alone already contains every cell a neighbour's ghost slab is cut from."""
+    bc = ("outflow",) * 6
+    o, mb, bufs = setup(nx, 2, "plm", "hllc", bc, seed=21)
+    A, B, Cc = bufs
+    dt = o.new_dt()
+    args = (0.5, 0.5, 0.5 * dt, 0.5 * dt, A[1], A[1])
+    mb.stage_fused(*args, B[1], region=0)
+    mb.stage_fused(*args, Cc[1], region=1)
+    shell_only = Cc[0].clone()
+    mb.stage_fused(*args, Cc[1], region=2)
+    torch.cuda.synchronize()
+    assert torch.equal(B[0], Cc[0])
+    g = 2
+    I = (slice(None), slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    whole, shell = B[0][I], shell_only[I]
+    for d in range(o.ndim):  # the nghost layers next to every face are final after region 1
+        ax = 4 - d
+        n = whole.shape[ax]
+        lo = [slice(None)] * 5
+        hi = [slice(None)] * 5
+        lo[ax], hi[ax] = slice(0, g), slice(n - g, n)
+        assert torch.equal(whole[tuple(lo)], shell[tuple(lo)])
+        assert torch.equal(whole[tuple(hi)], shell[tuple(hi)])
