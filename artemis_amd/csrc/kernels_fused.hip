@@ -161,14 +161,32 @@ ADEV void put6(double (*A)[QY][QX], int r, int c, const Cell6 &q) {
   fl.m3 = A[3] __VA_ARGS__, fl.e = A[4] __VA_ARGS__, fl.eg = A[5] __VA_ARGS__,             \
   fl.pf = A[6] __VA_ARGS__, fl.vf = A[7] __VA_ARGS__
 
-// One plane of the march: x1/x2 sweeps through LDS, then the cell update with the x3 face
-// fluxes handed in from registers.
-template <int RIEMANN, int RECON, bool HAS_U1, bool WRITE_CONS, bool WITH_DT>
-ADEV void plane_body(LdsTile &S, const PackView &P, const StageK &a, const Ctx &x, const int k,
-                     const Cell6 &qc, const Flux8 &fz_lo, const Flux8 &fz_hi, double &ldt) {
-  const int tx = x.tx, ty = x.ty, t = x.t;
+struct Raw5 { // a cell's five stored primitives, as loaded (pressure not yet derived)
+  double d, v1, v2, v3, e;
+};
+ADEV Raw5 load_raw(const double *r, const double *v1, const double *v2, const double *v3,
+                   const double *se, long c) {
+  Raw5 q;
+  q.d = gld(r, c), q.v1 = gld(v1, c), q.v2 = gld(v2, c), q.v3 = gld(v3, c), q.e = gld(se, c);
+  return q;
+}
+ADEV Cell6 finish_cell(const Raw5 &r, double gm1) {
+  Cell6 q;
+  q.d = r.d, q.v1 = r.v1, q.v2 = r.v2, q.v3 = r.v3, q.e = r.e;
+  q.p = amax(0.0, gm1 * q.d * q.e); // fill_derived.cpp:247 (IdealGas P)
+  return q;
+}
+
+// x1/x2 sweeps of one plane through LDS (phases P0-P2, three barriers).  Returns the fluxes
+// through the own cell's lower x1/x2 faces; the upper ones are left in S.FX / S.FY for
+// plane_update.  The perimeter duties rotate over the four waves with k so that no wave (and
+// no SIMD) carries the extra Riemann pass every plane.
+template <int RIEMANN, int RECON>
+ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k, const Cell6 &qc,
+                       Flux8 &fx_lo, Flux8 &fy_lo) {
+  const int tx = x.tx, ty = x.ty;
+  const int t = (x.t + 64 * (k & 3)) & (NT - 1); // duty index: wave roles rotate with k
   const double gm1 = x.gm1;
-  const FluidView &f = P.gas;
   // ---- P0: stage plane k (own cell + 2-cell halo in x1 and x2) ---------------------------
   put6(S.Q, ty + FH, tx + FH, qc);
   {
@@ -239,9 +257,9 @@ ADEV void plane_body(LdsTile &S, const PackView &P, const StageK &a, const Ctx &
   // ---- P2: Riemann problems at the own lower faces; perimeter faces on wave 1 ------------
   Cell6 L;
   GET6(L, S.UPX, [ty][tx]);
-  const Flux8 fx_lo = solve_face<RIEMANN, 1>(x.gk, L, lox);
+  fx_lo = solve_face<RIEMANN, 1>(x.gk, L, lox);
   if (tx > 0) { PUT8(S.FX, fx_lo, [ty][tx - 1]); }
-  Flux8 fy_lo = fx_lo;
+  fy_lo = fx_lo;
   if (x.multi_d) {
     GET6(L, S.UPY, [ty][tx]);
     fy_lo = solve_face<RIEMANN, 2>(x.gk, L, loy);
@@ -265,7 +283,17 @@ ADEV void plane_body(LdsTile &S, const PackView &P, const StageK &a, const Ctx &
     }
   }
   __syncthreads();
-  // ---- P3: upper-face fluxes from the neighbours, then the whole per-cell chain ----------
+}
+
+// Phase P3: gather the upper-face fluxes published by the neighbours, then the whole per-cell
+// chain update -> sources -> aux -> c2p -> p2c -> store (and the CFL reduction).
+template <bool HAS_U1, bool WRITE_CONS, bool WITH_DT>
+ADEV void plane_update(LdsTile &S, const PackView &P, const StageK &a, const Ctx &x, const int k,
+                       const Cell6 &qc, const Flux8 &fx_lo, const Flux8 &fy_lo, const Flux8 &fz_lo,
+                       const Flux8 &fz_hi, const Raw5 &u1raw, double &ldt) {
+  const int tx = x.tx, ty = x.ty;
+  const double gm1 = x.gm1;
+  const FluidView &f = P.gas;
   Flux8 fx_hi, fy_hi = fx_lo;
   GET8(fx_hi, S.FX, [ty][tx]);
   if (x.multi_d) { GET8(fy_hi, S.FY, [ty][tx]); }
@@ -284,9 +312,7 @@ ADEV void plane_body(LdsTile &S, const PackView &P, const StageK &a, const Ctx &
   const double E0 = G0 + 0.5 * qc.d * (sqr(qc.v1) + sqr(qc.v2) + sqr(qc.v3));
   double D1 = D0, M11 = M10, M21 = M20, M31 = M30, G1 = G0, E1 = E0;
   if constexpr (HAS_U1) {
-    const double r1 = gld(a.prim_u1[b * 6 + 0], c), e1 = gld(a.prim_u1[b * 6 + 5], c);
-    const double a1 = gld(a.prim_u1[b * 6 + 1], c), a2 = gld(a.prim_u1[b * 6 + 2], c);
-    const double a3 = gld(a.prim_u1[b * 6 + 3], c);
+    const double r1 = u1raw.d, e1 = u1raw.e, a1 = u1raw.v1, a2 = u1raw.v2, a3 = u1raw.v3;
     D1 = r1, M11 = r1 * a1 * 1.0, M21 = r1 * a2 * 1.0, M31 = r1 * a3 * 1.0;
     G1 = e1 * r1;
     E1 = G1 + 0.5 * r1 * (sqr(a1) + sqr(a2) + sqr(a3));
@@ -374,23 +400,32 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
     const int per = gridDim.x >> 3;
     id = (id & 7) * per + (id >> 3);
   }
-  int q = 0;
-  while (q + 1 < a.nbox && id >= a.start[q + 1]) ++q;
-  int local = id - a.start[q];
-  const int ti = a.ti0[q] + local % a.nti[q];
-  local /= a.nti[q];
-  const int tj = a.tj0[q] + local % a.ntj[q];
-  local /= a.ntj[q];
-  const int chunk = local % a.nchunk[q];
-  x.b = local / a.nchunk[q];
+  // box lookup with static indices only (a dynamically indexed by-value argument would be
+  // spilled to scratch); everything here is wave-uniform scalar work
+  int bstart = a.start[0], bti0 = a.ti0[0], bnti = a.nti[0], btj0 = a.tj0[0], bntj = a.ntj[0];
+  int bkb0 = a.kb0[0], bkb1 = a.kb1[0], bnchunk = a.nchunk[0], bkchunk = a.kchunk[0];
+#pragma unroll
+  for (int r = 1; r < 7; ++r) {
+    if (r < a.nbox && id >= a.start[r]) {
+      bstart = a.start[r], bti0 = a.ti0[r], bnti = a.nti[r], btj0 = a.tj0[r], bntj = a.ntj[r];
+      bkb0 = a.kb0[r], bkb1 = a.kb1[r], bnchunk = a.nchunk[r], bkchunk = a.kchunk[r];
+    }
+  }
+  int local = id - bstart;
+  const int ti = bti0 + local % bnti;
+  local /= bnti;
+  const int tj = btj0 + local % bntj;
+  local /= bntj;
+  const int chunk = local % bnchunk;
+  x.b = local / bnchunk;
   x.three_d = P.ndim > 2, x.multi_d = P.ndim > 1;
   x.i0 = P.is + ti * FTX, x.j0 = P.js + tj * FTY;
   const int i = x.i0 + x.tx, j = x.j0 + x.ty;
   x.active = (i <= P.ie) && (j <= P.je);
   // clamped indices: inactive lanes still serve as neighbours and face owners
   const int il = min(i, P.ni - 1), jl = min(j, P.nj - 1);
-  const int k0 = a.kb0[q] + chunk * a.kchunk[q];
-  const int k1 = min(a.kb1[q], k0 + a.kchunk[q] - 1);
+  const int k0 = bkb0 + chunk * bkchunk;
+  const int k1 = min(bkb1, k0 + bkchunk - 1);
   if (k0 > k1) return;
   x.gm1 = P.gm1;
   x.gk = gas_constants(P.gm1);
@@ -406,11 +441,18 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   x.rdx1 = recip(x.dx1), x.rdx2 = recip(x.dx2);
   double ldt = DBL_MAX;
 
+  const double *u1_r = a.prim_u1[x.b * 6 + 0], *u1_1 = a.prim_u1[x.b * 6 + 1];
+  const double *u1_2 = a.prim_u1[x.b * 6 + 2], *u1_3 = a.prim_u1[x.b * 6 + 3];
+  const double *u1_e = a.prim_u1[x.b * 6 + 5];
+  Raw5 u1raw;
+  u1raw.d = u1raw.v1 = u1raw.v2 = u1raw.v3 = u1raw.e = 0.0;
   if (!x.three_d) {
     const Cell6 qc = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + k0 * x.sk, x.gm1);
-    Flux8 fz;
+    if constexpr (HAS_U1) u1raw = load_raw(u1_r, u1_1, u1_2, u1_3, u1_e, x.col + k0 * x.sk);
+    Flux8 fz, fx_lo, fy_lo;
     fz.d = fz.m1 = fz.m2 = fz.m3 = fz.e = fz.eg = fz.pf = fz.vf = 0.0;
-    plane_body<RIEMANN, RECON, HAS_U1, WRITE_CONS, WITH_DT>(S, P, a, x, k0, qc, fz, fz, ldt);
+    plane_sweeps<RIEMANN, RECON>(S, P, x, k0, qc, fx_lo, fy_lo);
+    plane_update<HAS_U1, WRITE_CONS, WITH_DT>(S, P, a, x, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
   } else {
     // x3 state carried in registers: planes k, k+1, the upper face value of cell k and the
     // flux through face k.
@@ -427,8 +469,16 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
     Flux8 fz_lo;
     fz_lo.d = fz_lo.m1 = fz_lo.m2 = fz_lo.m3 = fz_lo.e = fz_lo.eg = fz_lo.pf = fz_lo.vf = 0.0;
     for (int k = k0 - 1; k <= k1; ++k) { // the first trip only primes fz_lo (face k0)
-      const Cell6 qnn =
-          load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k + 2) * x.sk, x.gm1);
+      // Issue this trip's HBM loads first; they are consumed after the plane's LDS phases, so
+      // their latency hides behind the x1/x2 sweeps (barriers do not drain vmcnt).
+      const Raw5 rnn = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k + 2) * x.sk);
+      if constexpr (HAS_U1) {
+        if (k >= k0) u1raw = load_raw(u1_r, u1_1, u1_2, u1_3, u1_e, x.col + static_cast<long>(k) * x.sk);
+      }
+      Flux8 fx_lo, fy_lo;
+      if (k >= k0) plane_sweeps<RIEMANN, RECON>(S, P, x, k, qc, fx_lo, fy_lo);
+      // x3 sweep, registers only: slope of cell k+1, face k+1
+      const Cell6 qnn = finish_cell(rnn, x.gm1);
       Cell6 zr, zl_next;
 #define ZSL(m)                                                                             \
   {                                                                                        \
@@ -440,7 +490,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
 #undef ZSL
       const Flux8 fz_hi = solve_face<RIEMANN, 3>(x.gk, zl, zr);
       if (k >= k0)
-        plane_body<RIEMANN, RECON, HAS_U1, WRITE_CONS, WITH_DT>(S, P, a, x, k, qc, fz_lo, fz_hi, ldt);
+        plane_update<HAS_U1, WRITE_CONS, WITH_DT>(S, P, a, x, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt);
       fz_lo = fz_hi, zl = zl_next, qc = qn, qn = qnn;
     }
   }
