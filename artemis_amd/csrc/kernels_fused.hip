@@ -141,6 +141,8 @@ struct Ctx { // per-thread constants of the march
   double dx1, dx2, gm1;
   GasK gk;
   Recip rdx1, rdx2;
+  int hr, hc;   // LDS slot (Q row/col) of the halo cell this thread stages, or hr < 0
+  long hcol;    // its column offset within a plane
   const double *g;
   const double *in_r, *in_1, *in_2, *in_3, *in_e;
 };
@@ -183,31 +185,13 @@ ADEV Cell6 finish_cell(const Raw5 &r, double gm1) {
 // no SIMD) carries the extra Riemann pass every plane.
 template <int RIEMANN, int RECON>
 ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k, const Cell6 &qc,
-                       Flux8 &fx_lo, Flux8 &fy_lo) {
+                       const Raw5 &hal, Flux8 &fx_lo, Flux8 &fy_lo) {
   const int tx = x.tx, ty = x.ty;
   const int t = (x.t + 64 * (k & 3)) & (NT - 1); // duty index: wave roles rotate with k
   const double gm1 = x.gm1;
   // ---- P0: stage plane k (own cell + 2-cell halo in x1 and x2) ---------------------------
   put6(S.Q, ty + FH, tx + FH, qc);
-  {
-    int hr = -1, hc = -1;
-    if (t < 4 * FTX) { // x2 halo rows: Q rows 0,1,10,11 (waves 0,1)
-      const int rr = t >> 5;
-      hr = (rr < 2) ? rr : FTY + rr;
-      hc = (t & 31) + FH;
-    } else if (t >= 128 && t < 128 + 4 * FTY) { // x1 halo columns: Q cols 0,1,34,35 (wave 2)
-      const int u = t - 128, cc = u & 3;
-      hr = (u >> 2) + FH;
-      hc = (cc < 2) ? cc : FTX + cc;
-    }
-    if (hr >= 0) {
-      const int gi = min(max(x.i0 - FH + hc, 0), P.ni - 1);
-      const int gj = min(max(x.j0 - FH + hr, 0), P.nj - 1);
-      const Cell6 h = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e,
-                                static_cast<long>(k) * x.sk + static_cast<long>(gj) * x.sj + gi, gm1);
-      put6(S.Q, hr, hc, h);
-    }
-  }
+  if (x.hr >= 0) put6(S.Q, x.hr, x.hc, finish_cell(hal, gm1)); // halo cell, loaded a plane ago
   __syncthreads();
   // ---- P1: slopes of the own cell; perimeter slopes on waves 2 (x1) and 3 (x2) -----------
   Cell6 lox, loy;
@@ -439,6 +423,23 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   x.dx1 = (x.g[0] + (i + 1) * x.g[1]) - (x.g[0] + i * x.g[1]);
   x.dx2 = (x.g[2] + (j + 1) * x.g[3]) - (x.g[2] + j * x.g[3]);
   x.rdx1 = recip(x.dx1), x.rdx2 = recip(x.dx2);
+  // halo duty: threads 0..127 stage the x2 halo rows (Q rows 0,1,10,11), threads 128..159 the x1
+  // halo columns (Q cols 0,1,34,35); each owns one halo column for the whole march
+  x.hr = -1, x.hc = -1, x.hcol = 0;
+  if (x.t < 4 * FTX) {
+    const int rr = x.t >> 5;
+    x.hr = (rr < 2) ? rr : FTY + rr;
+    x.hc = (x.t & 31) + FH;
+  } else if (x.t >= 128 && x.t < 128 + 4 * FTY) {
+    const int u = x.t - 128, cc = u & 3;
+    x.hr = (u >> 2) + FH;
+    x.hc = (cc < 2) ? cc : FTX + cc;
+  }
+  if (x.hr >= 0) {
+    const int gi = min(max(x.i0 - FH + x.hc, 0), P.ni - 1);
+    const int gj = min(max(x.j0 - FH + x.hr, 0), P.nj - 1);
+    x.hcol = static_cast<long>(gj) * x.sj + gi;
+  }
   double ldt = DBL_MAX;
 
   const double *u1_r = a.prim_u1[x.b * 6 + 0], *u1_1 = a.prim_u1[x.b * 6 + 1];
@@ -451,7 +452,9 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
     if constexpr (HAS_U1) u1raw = load_raw(u1_r, u1_1, u1_2, u1_3, u1_e, x.col + k0 * x.sk);
     Flux8 fz, fx_lo, fy_lo;
     fz.d = fz.m1 = fz.m2 = fz.m3 = fz.e = fz.eg = fz.pf = fz.vf = 0.0;
-    plane_sweeps<RIEMANN, RECON>(S, P, x, k0, qc, fx_lo, fy_lo);
+    Raw5 hal = u1raw;
+    if (x.hr >= 0) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + k0 * x.sk);
+    plane_sweeps<RIEMANN, RECON>(S, P, x, k0, qc, hal, fx_lo, fy_lo);
     plane_update<HAS_U1, WRITE_CONS, WITH_DT>(S, P, a, x, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
   } else {
     // x3 state carried in registers: planes k, k+1, the upper face value of cell k and the
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
     }
     Flux8 fz_lo;
     fz_lo.d = fz_lo.m1 = fz_lo.m2 = fz_lo.m3 = fz_lo.e = fz_lo.eg = fz_lo.pf = fz_lo.vf = 0.0;
+    Raw5 hal = u1raw; // halo cell of the plane about to be swept
     for (int k = k0 - 1; k <= k1; ++k) { // the first trip only primes fz_lo (face k0)
       // Issue this trip's HBM loads first; they are consumed after the plane's LDS phases, so
       // their latency hides behind the x1/x2 sweeps (barriers do not drain vmcnt).
@@ -476,7 +480,9 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
         if (k >= k0) u1raw = load_raw(u1_r, u1_1, u1_2, u1_3, u1_e, x.col + static_cast<long>(k) * x.sk);
       }
       Flux8 fx_lo, fy_lo;
-      if (k >= k0) plane_sweeps<RIEMANN, RECON>(S, P, x, k, qc, fx_lo, fy_lo);
+      if (k >= k0) plane_sweeps<RIEMANN, RECON>(S, P, x, k, qc, hal, fx_lo, fy_lo);
+      // halo cell of plane k+1: in flight while this plane's Riemann problems are solved
+      if (x.hr >= 0 && k < k1) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + (k + 1) * x.sk);
       // x3 sweep, registers only: slope of cell k+1, face k+1
       const Cell6 qnn = finish_cell(rnn, x.gm1);
       Cell6 zr, zl_next;
