@@ -871,18 +871,21 @@ long artemis_sim::evolve(long max_cycles) {
     Real est;
     if (use_fused) {
       step_fused(true);
+      const bool dev_reduce = has_comm && (nranks > 1 || loopback) && comm.allreduce_min_dev;
+      if (dev_reduce && comm.allreduce_min_dev(comm.ctx, dt_dev.p, stream))
+        throw std::runtime_error("allreduce_min_dev failed");
       CK(artemis_rt_memcpy_d2h(dt_host, dt_dev.p, sizeof(double), stream), "d2h");
       CK(artemis_rt_stream_sync(stream), "sync");
-      est = *dt_host;
+      est = dev_reduce ? *dt_host : global_min(*dt_host);
     } else {
       step_unfused();
-      est = new_dt_unfused();
+      est = global_min(new_dt_unfused());
     }
     time += dt;
     ncycle++, n++;
     Real ndt = dt;
     if (ndt < 0.1 * DBL_MAX) ndt *= 2.0;
-    ndt = std::min(ndt, global_min(est));
+    ndt = std::min(ndt, est);
     if (tlim > 0.0 && time < tlim && (tlim - time) < ndt) ndt = tlim - time;
     dt = ndt;
   }

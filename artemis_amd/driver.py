@@ -27,12 +27,14 @@ EXCH_START = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(Msg), C.c_void_
 EXCH_FINISH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 ALLRED_MIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
 ALLRED_SUM = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+ALLRED_MIN_DEV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
 class Comm(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
                 ("exchange_start", EXCH_START), ("exchange_finish", EXCH_FINISH),
-                ("allreduce_min", ALLRED_MIN), ("allreduce_sum", ALLRED_SUM)]
+                ("allreduce_min", ALLRED_MIN), ("allreduce_min_dev", ALLRED_MIN_DEV),
+                ("allreduce_sum", ALLRED_SUM)]
 
 
 class _DevView:
@@ -65,9 +67,9 @@ class TorchComm:
         import torch.distributed as dist
         self.dist, self.group, self.device = dist, group, torch.device(device)
         self.rank, self.nranks = dist.get_rank(group), dist.get_world_size(group)
-        self._cache, self._works = {}, []
+        self._cache, self._works, self._opcache = {}, [], {}
         self._cbs = (EXCH_START(self._start), EXCH_FINISH(self._finish),
-                     ALLRED_MIN(self._min), ALLRED_SUM(self._sum))
+                     ALLRED_MIN(self._min), ALLRED_MIN_DEV(self._min_dev), ALLRED_SUM(self._sum))
         self.struct = Comm(None, self.rank, self.nranks, *self._cbs)
 
     def _stream_ctx(self, stream_ptr):
@@ -79,16 +81,22 @@ class TorchComm:
     def _start(self, ctx, nmsg, msgs, stream):
         try:
             dist = self.dist
-            ops = []
-            # deterministic global order: by tag, receives and sends alike
-            items = sorted((msgs[i] for i in range(nmsg)), key=lambda m: (m.tag, m.send is None))
-            for m in items:
-                if m.send:
-                    ops.append(dist.P2POp(dist.isend, _tensor_of(m.send, m.count, self.device, self._cache),
-                                          m.peer, group=self.group, tag=m.tag))
-                if m.recv:
-                    ops.append(dist.P2POp(dist.irecv, _tensor_of(m.recv, m.count, self.device, self._cache),
-                                          m.peer, group=self.group, tag=m.tag))
+            # the same message set comes back every stage: build the P2POp list once
+            key = tuple((m.peer, m.tag, m.send, m.recv, m.count) for m in (msgs[i] for i in range(nmsg)))
+            ops = self._opcache.get(key)
+            if ops is None:
+                ops = []
+                # deterministic global order (RCCL matches sends and receives by posting order,
+                # not by tag): sort by tag, receives and sends alike
+                items = sorted((msgs[i] for i in range(nmsg)), key=lambda m: (m.tag, m.send is None))
+                for m in items:
+                    if m.send:
+                        ops.append(dist.P2POp(dist.isend, _tensor_of(m.send, m.count, self.device, self._cache),
+                                              m.peer, group=self.group, tag=m.tag))
+                    if m.recv:
+                        ops.append(dist.P2POp(dist.irecv, _tensor_of(m.recv, m.count, self.device, self._cache),
+                                              m.peer, group=self.group, tag=m.tag))
+                self._opcache[key] = ops
             with self._stream_ctx(stream):
                 self._works = dist.batch_isend_irecv(ops) if ops else []
             return 0
@@ -115,6 +123,16 @@ class TorchComm:
             return 0
         except Exception as e:
             print("TorchComm.allreduce_min failed:", repr(e), flush=True)
+            return 1
+
+    def _min_dev(self, ctx, dev_value, stream):
+        try:
+            t = _tensor_of(dev_value, 1, self.device, self._cache)
+            with self._stream_ctx(stream):
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+            return 0
+        except Exception as e:
+            print("TorchComm.allreduce_min_dev failed:", repr(e), flush=True)
             return 1
 
     def _sum(self, ctx, values, n):

@@ -40,6 +40,9 @@ typedef struct artemis_comm {
   /* Make work enqueued on `stream` after this call wait for the exchange posted last. */
   int (*exchange_finish)(void *ctx, void *stream);
   int (*allreduce_min)(void *ctx, double *value);        /* host scalar, in place */
+  /* optional (may be NULL): min-all-reduce one DEVICE double in place, ordered on `stream`;
+   * lets the per-cycle dt reduction ride the stream instead of costing a host round trip */
+  int (*allreduce_min_dev)(void *ctx, double *dev_value, void *stream);
   int (*allreduce_sum)(void *ctx, double *values, int n); /* host array, in place */
 } artemis_comm_t;
 
