@@ -236,12 +236,21 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
   if (a->prim_in == a->prim_out)
     return fail(ARTEMIS_HIP_EINVAL, "fused stage: prim_out must not alias prim_in");
   if (a->region < 0 || a->region > 2) return fail(ARTEMIS_HIP_EINVAL, "fused stage: region must be 0, 1 or 2");
+  if (a->shell_done && a->region != 0)
+    return fail(ARTEMIS_HIP_EINVAL, "fused stage: shell_done requires region 0");
   if (p->nghost < 2) return fail(ARTEMIS_HIP_EUNSUPPORTED, "fused stage: needs nghost >= 2");
   const int recon = a->pcm ? ARTEMIS_PCM : p->gas.recon;
   const int rc = artemis::launch_stage_fused(artemis::make_pack_view(*p), *a, p->gas.riemann, recon,
                                              S(stream));
   if (rc) return fail(ARTEMIS_HIP_EUNSUPPORTED, "fused stage: configuration not built (rc=%d)", rc);
   return after_launch("stage_fused");
+}
+
+int artemis_hip_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, void *stream) {
+  if (int rc = device_ready()) return rc;
+  if (!counter) return fail(ARTEMIS_HIP_EINVAL, "null counter");
+  artemis::launch_wait_counter(counter, target, timeout_flag, S(stream));
+  return after_launch("wait_counter");
 }
 
 // ---- runtime shim (include/artemis_rt.h) ------------------------------------------------

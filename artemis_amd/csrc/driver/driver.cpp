@@ -138,7 +138,9 @@ struct artemis_sim {
   DevBuf geom, dt_dev;
   double *dt_host = nullptr;    // pinned
   bool unfused_ready = false;
-  bool use_fused = false, fused_possible = false, overlap = false;
+  bool use_fused = false, fused_possible = false;
+  int overlap = 0; // 0 off, 1 shell launch + bulk launch, 2 one launch with in-kernel shell signalling
+  DevBuf signal; // [0] shell-done counter, [1] wait-kernel timeout flag (as 32-bit words)
   // test hook (ARTEMIS_LOOPBACK_COMM=1): route same-rank ghost slabs through the communicator
   // as messages to self, so one GPU exercises the RCCL send/recv path end to end
   bool loopback = false;
@@ -428,6 +430,7 @@ void artemis_sim::allocate() {
   geom.alloc(hg.size());
   CK(artemis_rt_memcpy_h2d(geom.p, hg.data(), hg.size() * sizeof(Real), nullptr), "h2d geom");
   dt_dev.alloc(1);
+  signal.alloc(2);
   dt_host = static_cast<double *>(artemis_rt_malloc_host(sizeof(double)));
   if (!dt_host) throw HipFail("pinned allocation failed");
   gprim[0].alloc(nb, 6 * ns_gas, N);
@@ -793,8 +796,12 @@ void artemis_sim::step_fused(bool want_dt) {
     a.cfl = cfl_gas;
     a.dt_dev = (last && want_dt) ? dt_dev.p : nullptr;
     bool any_remote = false;
-    for (auto &L : links) any_remote = any_remote || remote(*L);
-    const bool ovl = overlap && any_remote;
+    int faces = 0; // faces through which some block of the pack feeds a neighbour
+    for (auto &L : links) any_remote = any_remote || remote(*L), faces |= (1 << L->face);
+    a.shell_faces = faces;
+    // (ARTEMIS_FORCE_OVERLAP=1: diagnostic, shell-first ordering even when every link is local)
+    static const bool force_ovl = std::getenv("ARTEMIS_FORCE_OVERLAP") != nullptr;
+    const bool ovl = overlap && (any_remote || (force_ovl && !links.empty()));
     void *e0 = nullptr, *e1 = nullptr;
     if (time_kernels) {
       e0 = artemis_rt_event_create(), e1 = artemis_rt_event_create();
@@ -808,6 +815,24 @@ void artemis_sim::step_fused(bool want_dt) {
         kev.emplace_back(e0, e1);
       }
       fill_ghosts(out);
+    } else if (overlap == 2) {
+      // ONE launch, boundary-shell workgroups first; they count themselves into a device counter
+      // that a one-wave kernel on the comm stream waits for, so the slabs are packed and sent
+      // while the bulk of the same launch is still running.
+      unsigned *counter = reinterpret_cast<unsigned *>(signal.p);
+      unsigned target = 0;
+      CK(artemis_rt_memset(counter, 0, sizeof(unsigned), stream), "memset");
+      CK(artemis_rt_event_record(ev0, stream), "event");
+      a.region = 0, a.shell_done = counter, a.shell_target = &target;
+      CK(artemis_hip_stage_fused(&p, &a, stream), "stage_fused");
+      if (time_kernels) {
+        CK(artemis_rt_event_record(e1, stream), "event");
+        kev.emplace_back(e0, e1);
+      }
+      CK(artemis_rt_stream_wait_event(comm_stream, ev0), "wait");
+      CK(artemis_hip_wait_counter(counter, target, counter + 1, comm_stream), "wait_counter");
+      fill_ghosts_start(out, comm_stream);
+      fill_ghosts_finish(out, comm_stream);
     } else {
       // boundary shell first; its slabs travel on the comm stream while the bulk is computed
       a.region = 1;
@@ -1091,7 +1116,11 @@ int artemis_sim_set_path(artemis_sim_t *s, const char *which) {
   return 1;
 }
 int artemis_sim_set_overlap(artemis_sim_t *s, int overlap) {
-  s->overlap = overlap != 0;
+  if (overlap < 0 || overlap > 2) {
+    g_sim_err = "overlap must be 0 (off), 1 (two launches) or 2 (in-kernel signalling)";
+    return 1;
+  }
+  s->overlap = overlap;
   return 0;
 }
 void artemis_sim_set_kernel_timing(artemis_sim_t *s, int on) { s->time_kernels = on != 0; }

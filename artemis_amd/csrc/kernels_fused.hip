@@ -45,6 +45,10 @@ struct StageK {
   int ti0[7], nti[7], tj0[7], ntj[7], kb0[7], kb1[7], nchunk[7], kchunk[7];
   int start[8];
   int xcd_swizzle; // remap ids so that each XCD's L2 sees neighbouring tiles
+  // shell-first signalling: workgroups with id < nshell publish their stores (agent-scope
+  // release) and count themselves into *shell_done when finished
+  int nshell;
+  unsigned *shell_done;
 };
 
 struct LdsTile {
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   Ctx x;
   x.tx = threadIdx.x, x.ty = threadIdx.y, x.t = x.ty * FTX + x.tx;
   int id = blockIdx.x;
+  const bool shell_wg = static_cast<int>(blockIdx.x) < a.nshell;
   if (a.xcd_swizzle) { // T1: ids round-robin over the 8 XCDs; give each XCD a contiguous run
     const int per = gridDim.x >> 3;
     id = (id & 7) * per + (id >> 3);
@@ -410,7 +415,11 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   const int il = min(i, P.ni - 1), jl = min(j, P.nj - 1);
   const int k0 = bkb0 + chunk * bkchunk;
   const int k1 = min(bkb1, k0 + bkchunk - 1);
-  if (k0 > k1) return;
+  if (k0 > k1) { // empty chunk (cannot happen with the box builder, kept for safety)
+    if (shell_wg && x.t == 0)
+      __hip_atomic_fetch_add(a.shell_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   x.gm1 = P.gm1;
   x.gk = gas_constants(P.gm1);
   x.g = P.geom + 6 * x.b;
@@ -513,6 +522,35 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
         atomicMin(a.dt_bits, static_cast<unsigned long long>(__double_as_longlong(a.cfl * m)));
     }
   }
+  if (shell_wg) {
+    // MI355X: per-CU L1 and per-XCD L2 are not coherent across CUs/XCDs.  Every wave drains its
+    // stores, the workgroup meets, then ONE lane releases at agent scope (writes back this
+    // XCD's dirty L2 lines) and bumps the counter the comm stream's wait kernel polls.
+    // (Write-through sc1 stores instead of the fence measured 2 % slower: 8-byte sc1 stores.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (x.t == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(a.shell_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// Comm-stream side of the shell-first hand-off: one wave polls the counter (relaxed, agent
+// scope, with s_sleep) until `target` workgroups have published, then acquires.  Kernels queued
+// behind it on the same stream (halo packs) start with clean caches and see the shell's stores.
+__global__ void wait_counter_kernel(unsigned *counter, unsigned target, unsigned *timeout_flag) {
+  if (threadIdx.x != 0) return;
+  unsigned long long spins = 0;
+  while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(32);
+    if (++spins > (1ull << 26)) { // ~seconds: never hang the GPU on a logic error
+      if (timeout_flag) *timeout_flag = 1u;
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 template <int RIEMANN, int RECON>
@@ -533,6 +571,10 @@ int launch_cfg(const PackView &P, const StageK &k, bool has_u1, bool cons, bool 
 }
 
 } // namespace
+
+void launch_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, hipStream_t s) {
+  hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, s, counter, target, timeout_flag);
+}
 
 int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon,
                        hipStream_t s) {
@@ -560,23 +602,55 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   // region 0: whole block.  region 1: boundary shell = everything a neighbour's ghost slab is cut
   // from, rounded out to whole tiles (x1, x2) / nghost planes (x3).  region 2: the complement.
   const int g = P.ng;
-  const bool zsplit = (P.ndim > 2) && nz > 2 * g, ysplit = (P.ndim > 1) && NTJ > 2, xsplit = NTI > 2;
-  // the shell/bulk split exists only if every active dimension can be cut; otherwise the whole
-  // block is "shell" and the bulk is empty (region 1 must always contain every boundary cell)
-  const bool split = xsplit && (P.ndim < 2 || ysplit) && (P.ndim < 3 || zsplit);
-  const int km0 = zsplit ? P.ks + g : P.ks, km1 = zsplit ? P.ke - g : P.ke; // middle k-range
-  const int tjm0 = ysplit ? 1 : 0, ntjm = ysplit ? NTJ - 2 : NTJ;           // middle j-tiles
-  if (a.region == 0 || (a.region == 1 && !split)) {
+  // Which faces' boundary cells form the shell (bit f of shell_faces; 0 = all six).  x3 part:
+  // `zt` planes at a flagged end.  Separate launches (regions 1/2) keep it as thin as the ghost
+  // depth; the single-launch shell-first mode uses whole chunks, which cost nothing extra there
+  // and avoid 2-plane workgroups that pay the priming trip for nothing.
+  const int faces = (a.shell_faces & 63) ? (a.shell_faces & 63) : 63;
+  const int xlo = (faces >> 0) & 1, xhi = (faces >> 1) & 1;
+  const int ylo = (P.ndim > 1) ? (faces >> 2) & 1 : 0, yhi = (P.ndim > 1) ? (faces >> 3) & 1 : 0;
+  const int zlo = (P.ndim > 2) ? (faces >> 4) & 1 : 0, zhi = (P.ndim > 2) ? (faces >> 5) & 1 : 0;
+  const int zt = a.shell_done ? std::max(g, std::min(target_chunk, nz / 3)) : g;
+  // the shell/bulk split exists only if every flagged side can be cut off and something is
+  // left; otherwise the whole block is "shell" and the bulk is empty (region 1 must always
+  // contain every flagged boundary cell)
+  const bool split = (NTI > xlo + xhi) && (NTJ > ylo + yhi) && (nz > (zlo + zhi) * zt);
+  const int km0 = P.ks + zlo * zt, km1 = P.ke - zhi * zt;  // middle k-range
+  const int tjm0 = ylo, ntjm = NTJ - ylo - yhi;            // middle j-tiles
+  const int tim0 = xlo, ntim = NTI - xlo - xhi;            // middle i-tiles
+  auto add_shell = [&]() {
+    if (zlo) add_box(0, NTI, 0, NTJ, P.ks, P.ks + zt - 1);
+    if (zhi) add_box(0, NTI, 0, NTJ, P.ke - zt + 1, P.ke);
+    if (ylo) add_box(0, NTI, 0, 1, km0, km1);
+    if (yhi) add_box(0, NTI, NTJ - 1, 1, km0, km1);
+    if (xlo) add_box(0, 1, tjm0, ntjm, km0, km1);
+    if (xhi) add_box(NTI - 1, 1, tjm0, ntjm, km0, km1);
+  };
+  k.nshell = 0, k.shell_done = nullptr;
+  if (a.shell_done) {
+    // whole block in ONE launch, boundary shell first: shell workgroups get the lowest ids and
+    // count themselves into *shell_done (target returned through *shell_target)
+    if (split) {
+      add_shell();
+      k.nshell = k.start[k.nbox];
+      add_box(tim0, ntim, tjm0, ntjm, km0, km1);
+    } else {
+      add_box(0, NTI, 0, NTJ, P.ks, P.ke);
+      k.nshell = k.start[k.nbox];
+    }
+    k.shell_done = a.shell_done;
+    if (a.shell_target) *a.shell_target = static_cast<unsigned>(k.nshell);
+  } else if (a.region == 0 || (a.region == 1 && !split)) {
     add_box(0, NTI, 0, NTJ, P.ks, P.ke);
   } else if (a.region == 1) {
-    if (zsplit) add_box(0, NTI, 0, NTJ, P.ks, P.ks + g - 1), add_box(0, NTI, 0, NTJ, P.ke - g + 1, P.ke);
-    if (ysplit) add_box(0, NTI, 0, 1, km0, km1), add_box(0, NTI, NTJ - 1, 1, km0, km1);
-    add_box(0, 1, tjm0, ntjm, km0, km1), add_box(NTI - 1, 1, tjm0, ntjm, km0, km1);
+    add_shell();
   } else if (split) {
-    add_box(1, NTI - 2, tjm0, ntjm, km0, km1);
+    add_box(tim0, ntim, tjm0, ntjm, km0, km1);
   }
   if (k.nbox == 0) return 0; // nothing to do in this region
-  k.xcd_swizzle = (k.start[k.nbox] % 8 == 0 && getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
+  // (an XCD-aware id remap measured no gain here -- the kernel is not L2-bound -- and would
+  // break the shell-first id order; kept as an opt-in knob)
+  k.xcd_swizzle = (!k.shell_done && k.start[k.nbox] % 8 == 0 && getenv("ARTEMIS_FUSED_SWIZZLE") != nullptr) ? 1 : 0;
   const bool has_u1 = (a.prim_u1 != a.prim_in);
   const bool cons = (a.cons_out != nullptr);
   const bool dt = (a.dt_dev != nullptr);

@@ -226,8 +226,11 @@ class Simulation:
         if self.L.artemis_sim_set_path(self.h, which.encode()):
             raise RuntimeError(self.L.artemis_sim_last_error().decode())
 
-    def set_overlap(self, on):
-        self.L.artemis_sim_set_overlap(self.h, int(on))
+    def set_overlap(self, mode):
+        """False/0 off, True/2 one launch with in-kernel shell signalling, 1 shell + bulk launches."""
+        mode = 2 if mode is True else int(mode)
+        if self.L.artemis_sim_set_overlap(self.h, mode):
+            raise RuntimeError(self.L.artemis_sim_last_error().decode())
 
     def set_kernel_timing(self, on):
         self.L.artemis_sim_set_kernel_timing(self.h, int(on))

@@ -7,8 +7,8 @@
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): the
 reference's Sedov deck inputs/blast/blast.in in 3-D -- Cartesian 256^3 cells per GPU, gas only,
 HLLC + PLM, rk2, cfl 0.3, gamma 1.4, outflow, nghost 2, floors 1e-10 -- weak-scaled over the
-GPUs of one node (512x256x256, 512x512x256, 512^3 for 2/4/8 GPUs, one 256^3 mesh block per
-rank).  One "step" = one full cycle: every RK stage (fused flux/update/source/c2p kernel +
+GPUs of one node (256x256x512, 256x512x512, 256x512x1024 for 2/4/8 GPUs, one 256^3 mesh block
+per rank, ranks cut along x3 then x2).  One "step" = one full cycle: every RK stage (fused flux/update/source/c2p kernel +
 ghost fill), the CFL reduction and, for N > 1, the halo exchange and the dt all-reduce.
 Initial data are generated on the host and are resident in HBM before the timed region.
 
@@ -32,7 +32,9 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def overrides(n_gpus, per_gpu, steps_total, extra=()):
-    shape = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(n_gpus)
+    # weak scaling grows the mesh along x3, then x2: ranks are never cut along x1, so rows stay
+    # 256 cells long and the boundary shell of the stage kernel stays thin
+    shape = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (1, 2, 4)}.get(n_gpus)
     if shape is None:
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
     ov = ["gas/riemann=hllc", "problem/symmetry=spherical", "problem/radius=0.03",
@@ -68,6 +70,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: exchange halos after the whole stage kernel instead of behind its bulk")
+    ap.add_argument("--overlap-mode", type=int, default=2, choices=[1, 2],
+                    help="2: one launch, shell workgroups first + device counter; 1: shell and bulk launches")
+    ap.add_argument("--blocks-per-gpu", type=int, default=1,
+                    help="diagnostic: cut each rank's 256^3 into this many mesh blocks along x3")
+    ap.add_argument("--loopback", action="store_true",
+                    help="diagnostic: route block-to-block slabs of ONE GPU through RCCL send/recv-to-self")
     ap.add_argument("--cpu-n", type=int, default=256)
     ap.add_argument("--cpu-cycles", type=int, default=3)
     args = ap.parse_args()
@@ -87,21 +95,30 @@ def main():
     L = capi.load()
     capi.check(L.artemis_rt_set_device(local_rank))
     comm = None
-    if world > 1:
+    if world > 1 or args.loopback:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            os.environ["ARTEMIS_LOOPBACK_COMM"] = "1"
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29411", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", 0))
         comm = TorchComm(torch.device("cuda", local_rank))
 
     per_gpu = (args.n, args.n, args.n)
     deck = os.path.join(ROOT, "inputs", "blast", "blast.in")
-    sim = Simulation(deck, overrides(args.gpus, per_gpu, args.warmup + args.steps), comm=comm)
+    extra = []
+    if args.blocks_per_gpu > 1:
+        extra = ["parthenon/meshblock/nx3=%d" % (args.n // args.blocks_per_gpu)]
+    sim = Simulation(deck, overrides(args.gpus, per_gpu, args.warmup + args.steps, extra), comm=comm)
     if args.path == "unfused":
         sim.set_path("unfused")
-    sim.set_overlap(world > 1 and not args.no_overlap)
+    want_overlap = (world > 1 or args.loopback or bool(os.environ.get("ARTEMIS_FORCE_OVERLAP"))) and not args.no_overlap
+    sim.set_overlap(args.overlap_mode if want_overlap else 0)
 
     def barrier():
-        if world > 1:
+        if world > 1 or args.loopback:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,7 +186,7 @@ def main():
                           % (args.cpu_n, cyc, secs)}
         print(json.dumps(out), flush=True)
     sim.close()
-    if world > 1:
+    if world > 1 or args.loopback:
         dist.destroy_process_group()
 
 

@@ -67,7 +67,9 @@ long artemis_sim_total_zones(const artemis_sim_t *sim);
 int artemis_sim_uses_fused_path(const artemis_sim_t *sim);
 /* which: "fused" | "unfused"; selects the kernel path (fused only where supported). */
 int artemis_sim_set_path(artemis_sim_t *sim, const char *which);
-/* overlap = 1: halo exchange on a second stream concurrently with interior compute */
+/* Halo exchange on a second stream concurrently with interior compute (fused path, remote
+ * neighbours only).  0 = off; 1 = boundary-shell launch, then bulk launch; 2 = one launch whose
+ * shell workgroups run first and signal a device counter the comm stream waits on. */
 int artemis_sim_set_overlap(artemis_sim_t *sim, int overlap);
 
 /* Block layout of this rank. dims = {nblocks_local, ni, nj, nk, is, ie, js, je, ks, ke, ng}. */

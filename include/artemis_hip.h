@@ -164,8 +164,22 @@ typedef struct artemis_stage_args {
                                  neighbours' ghost slabs are cut from, rounded out to whole
                                  tiles); 2 = only the rest.  1 then 2 == 0: lets a driver send
                                  halos while the bulk is still being computed. */
+  unsigned *shell_done;       /* optional DEVICE counter (zeroed by the caller before the launch).
+                                 When non-NULL (region must be 0) the whole block is computed in
+                                 ONE launch with the boundary-shell workgroups first; each of them
+                                 publishes its stores at agent scope and increments the counter
+                                 when done.  *shell_target (HOST, optional) receives the count to
+                                 wait for with artemis_hip_wait_counter on another stream. */
+  unsigned *shell_target;
+  int shell_faces;            /* bit f set: face f (0..5 = ix1,ox1,ix2,ox2,ix3,ox3) has a neighbour
+                                 whose ghosts are cut from this block; 0 = all six */
 } artemis_stage_args_t;
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
+/* Enqueue on `stream` a one-wave kernel that returns once *counter >= target (agent-scope
+ * poll + acquire).  Work queued behind it on that stream sees everything the counting
+ * workgroups published.  `timeout_flag` (DEVICE, optional) is set to 1 if the poll gives up
+ * after ~seconds instead of hanging the GPU. */
+int artemis_hip_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, void *stream);
 
 /* ---- Halo slabs (inter-block / inter-GPU ghost exchange of FillGhost primitives) -------
  * Pack the `nghost`-deep interior slab adjacent to face `face` (0..5 = ix1,ox1,ix2,ox2,

@@ -208,6 +208,10 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
   if (a->prim_in == a->prim_out) return bad("prim_out must not alias prim_in");
   // region 1 (shell, "rounded out") is the whole block here, so region 2 (the rest) is empty
   if (a->region == 2) return 0;
+  if (a->shell_done) { // synchronous double: everything is done when the call returns
+    *a->shell_done = 1u;
+    if (a->shell_target) *a->shell_target = 1u;
+  }
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);
     Sim &s = *B.s;
@@ -292,6 +296,7 @@ int artemis_hip_halo_pack(const artemis_pack_t *p, int b, int face, double *buf,
 int artemis_hip_halo_unpack(const artemis_pack_t *p, int b, int face, const double *buf, void *) {
   return halo(p, b, face, const_cast<double *>(buf), 1);
 }
+int artemis_hip_wait_counter(unsigned *, unsigned, unsigned *, void *) { return 0; }
 int artemis_hip_selftest_divsqrt(long, const double *, const double *, double *, double *, double *,
                                  double *, void *) {
   return ARTEMIS_HIP_EUNSUPPORTED;

@@ -195,7 +195,7 @@ def test_rccl_loopback_halo_exchange(hiplib, monkeypatch):
     try:
         monkeypatch.setenv("ARTEMIS_LOOPBACK_COMM", "1")
         comm = TorchComm(torch.device("cuda", 0))
-        for overlap in (False, True):
+        for overlap in (0, 1, 2):
             # overlap: shell kernel -> slabs on the comm stream || bulk kernel on the compute stream
             sim = Simulation(DECK("linwave", "linear_wave.in"), ov, comm=comm)
             sim.set_overlap(overlap)
@@ -234,7 +234,7 @@ def test_rccl_loopback_overlap_split_blocks(hiplib, monkeypatch):
     try:
         monkeypatch.setenv("ARTEMIS_LOOPBACK_COMM", "1")
         comm = TorchComm(torch.device("cuda", 0))
-        for overlap in (True, False):
+        for overlap in (2, 1, 0):
             sim = Simulation(DECK("blast", "blast.in"), ov, comm=comm)
             sim.set_overlap(overlap)
             sim.evolve()

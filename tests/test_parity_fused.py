@@ -160,6 +160,13 @@ def test_fused_shell_then_bulk_equals_whole(hiplib, nx):
     dt = o.new_dt()
     args = (0.5, 0.5, 0.5 * dt, 0.5 * dt, A[1], A[1])
     mb.stage_fused(*args, B[1], region=0)
+    for faces in (0b110000, 0b001100, 0b100101):  # any subset of faces: 1 then 2 still == 0
+        Cc[0].zero_()
+        mb.stage_fused(*args, Cc[1], region=1, shell_faces=faces)
+        mb.stage_fused(*args, Cc[1], region=2, shell_faces=faces)
+        torch.cuda.synchronize()
+        assert torch.equal(B[0], Cc[0]), bin(faces)
+    Cc[0].zero_()
     mb.stage_fused(*args, Cc[1], region=1)
     shell_only = Cc[0].clone()
     mb.stage_fused(*args, Cc[1], region=2)
