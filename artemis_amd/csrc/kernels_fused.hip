@@ -31,9 +31,13 @@
 namespace artemis {
 namespace {
 
-constexpr int FTX = 32, FTY = 8, FH = 2;      // tile and halo
+#ifndef ARTEMIS_FTY
+#define ARTEMIS_FTY 8
+#endif
+constexpr int FTX = 32, FTY = ARTEMIS_FTY, FH = 2; // tile and halo
 constexpr int QX = FTX + 2 * FH, QY = FTY + 2 * FH;
 constexpr int NT = FTX * FTY;
+constexpr int NW = NT / 64; // waves per workgroup
 
 struct StageK {
   double gam0, gam1, beta_dt, bdt, cfl;
@@ -60,7 +64,7 @@ struct LdsTile {
   double FX[8][FTY][FTX];       // x1 faces i0+1 .. i0+32 (upper faces of the tile's cells)
   double FY[8][FTY][FTX];       // x2 faces j0+1 .. j0+8
 };
-static_assert(sizeof(LdsTile) <= 80 * 1024, "two workgroups per CU need <= 80 KiB each");
+static_assert(sizeof(LdsTile) <= (FTY == 8 ? 80 : 160) * 1024, "LDS budget: two 32x8 workgroups (or one 32x16) per CU");
 
 struct Cell6 {
   double d, v1, v2, v3, p, e;
@@ -183,20 +187,26 @@ ADEV Cell6 finish_cell(const Raw5 &r, double gm1) {
   return q;
 }
 
-// x1/x2 sweeps of one plane through LDS (phases P0-P2, three barriers).  Returns the fluxes
-// through the own cell's lower x1/x2 faces; the upper ones are left in S.FX / S.FY for
-// plane_update.  The perimeter duties rotate over the four waves with k so that no wave (and
-// no SIMD) carries the extra Riemann pass every plane.
+// Stage one plane's primitives (own cell + this thread's halo cell) into S.Q.
+ADEV void stage_plane(LdsTile &S, const Ctx &x, const Cell6 &q, const Raw5 &hal) {
+  put6(S.Q, x.ty + FH, x.tx + FH, q);
+  if (x.hr >= 0) put6(S.Q, x.hr, x.hc, finish_cell(hal, x.gm1));
+}
+
+// x1/x2 sweeps of one plane through LDS.  Plane k's primitives are already staged in S.Q (by
+// the previous plane's call, or by the prologue).  TWO barriers per plane:
+//   P1  slopes from S.Q, publish upper face values              -- barrier --
+//   P2  Riemann problems, publish face outputs; S.Q is dead now, so the NEXT plane's
+//       primitives (`qn`, `hal_next`) are staged into it here    -- barrier --
+// Returns the fluxes through the own cell's lower x1/x2 faces; the upper ones are left in
+// S.FX / S.FY for plane_update.  The perimeter duties rotate over the waves with k so that no
+// wave (and no SIMD) carries the extra Riemann pass every plane.
 template <int RIEMANN, int RECON>
 ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k, const Cell6 &qc,
-                       const Raw5 &hal, Flux8 &fx_lo, Flux8 &fy_lo) {
+                       const bool stage_next, const Cell6 &qn, const Raw5 &hal_next, Flux8 &fx_lo,
+                       Flux8 &fy_lo) {
   const int tx = x.tx, ty = x.ty;
-  const int t = (x.t + 64 * (k & 3)) & (NT - 1); // duty index: wave roles rotate with k
-  const double gm1 = x.gm1;
-  // ---- P0: stage plane k (own cell + 2-cell halo in x1 and x2) ---------------------------
-  put6(S.Q, ty + FH, tx + FH, qc);
-  if (x.hr >= 0) put6(S.Q, x.hr, x.hc, finish_cell(hal, gm1)); // halo cell, loaded a plane ago
-  __syncthreads();
+  const int t = (x.t + 64 * (k % NW)) % NT; // duty index: wave roles rotate with k
   // ---- P1: slopes of the own cell; perimeter slopes on waves 2 (x1) and 3 (x2) -----------
   Cell6 lox, loy;
 #define SLX(m, n)                                                                          \
@@ -230,7 +240,7 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
       else S.UPX[n][row][0] = up_val<RECON>(q, s_);
     }
   }
-  if (x.multi_d && t >= 192) { // rows j0-1 (upper value) and j0+8 (lower value)
+  if (x.multi_d && t >= 192 && t < 256) { // rows j0-1 (upper value) and j0+8 (lower value)
     const int u = t - 192, cx = u & 31, side = u >> 5;
     const int ry = side ? FTY + FH : FH - 1;
 #pragma unroll
@@ -270,6 +280,7 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
       PUT8(S.FY, fe_, [FTY - 1][cx]);
     }
   }
+  if (stage_next) stage_plane(S, x, qn, hal_next);
   __syncthreads();
 }
 
@@ -463,7 +474,9 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
     fz.d = fz.m1 = fz.m2 = fz.m3 = fz.e = fz.eg = fz.pf = fz.vf = 0.0;
     Raw5 hal = u1raw;
     if (x.hr >= 0) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + k0 * x.sk);
-    plane_sweeps<RIEMANN, RECON>(S, P, x, k0, qc, hal, fx_lo, fy_lo);
+    stage_plane(S, x, qc, hal);
+    __syncthreads();
+    plane_sweeps<RIEMANN, RECON>(S, P, x, k0, qc, false, qc, hal, fx_lo, fy_lo);
     plane_update<HAS_U1, WRITE_CONS, WITH_DT>(S, P, a, x, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
   } else {
     // x3 state carried in registers: planes k, k+1, the upper face value of cell k and the
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
     }
     Flux8 fz_lo;
     fz_lo.d = fz_lo.m1 = fz_lo.m2 = fz_lo.m3 = fz_lo.e = fz_lo.eg = fz_lo.pf = fz_lo.vf = 0.0;
-    Raw5 hal = u1raw; // halo cell of the plane about to be swept
+    Raw5 hal = u1raw; // halo cell of plane k+1 (staged by trip k)
     for (int k = k0 - 1; k <= k1; ++k) { // the first trip only primes fz_lo (face k0)
       // Issue this trip's HBM loads first; they are consumed after the plane's LDS phases, so
       // their latency hides behind the x1/x2 sweeps (barriers do not drain vmcnt).
@@ -488,10 +501,16 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
       if constexpr (HAS_U1) {
         if (k >= k0) u1raw = load_raw(u1_r, u1_1, u1_2, u1_3, u1_e, x.col + static_cast<long>(k) * x.sk);
       }
-      Flux8 fx_lo, fy_lo;
-      if (k >= k0) plane_sweeps<RIEMANN, RECON>(S, P, x, k, qc, hal, fx_lo, fy_lo);
-      // halo cell of plane k+1: in flight while this plane's Riemann problems are solved
+      // halo cell of plane k+1: staged at the end of this trip's P2, so its latency hides behind
+      // the slopes and Riemann problems of plane k
       if (x.hr >= 0 && k < k1) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + (k + 1) * x.sk);
+      Flux8 fx_lo, fy_lo;
+      if (k >= k0) {
+        plane_sweeps<RIEMANN, RECON>(S, P, x, k, qc, k < k1, qn, hal, fx_lo, fy_lo);
+      } else { // priming trip: stage the first plane
+        stage_plane(S, x, qn, hal);
+        __syncthreads();
+      }
       // x3 sweep, registers only: slope of cell k+1, face k+1
       const Cell6 qnn = finish_cell(rnn, x.gm1);
       Cell6 zr, zl_next;
@@ -517,7 +536,8 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
     if ((x.t & 63) == 0) wmin[x.t >> 6] = ldt;
     __syncthreads();
     if (x.t == 0) {
-      const double m = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+      double m = wmin[0];
+      for (int w = 1; w < NW; ++w) m = fmin(m, wmin[w]);
       if (m < DBL_MAX)
         atomicMin(a.dt_bits, static_cast<unsigned long long>(__double_as_longlong(a.cfl * m)));
     }
