@@ -51,7 +51,8 @@ class StageArgs(C.Structure):
         ("pcm", C.c_int),
         ("prim_in", PP), ("prim_u1", PP), ("prim_out", PP), ("cons_out", PP),
         ("cfl", C.c_double), ("dt_dev", C.c_void_p), ("region", C.c_int),
-        ("shell_done", C.c_void_p), ("shell_target", C.POINTER(C.c_uint)), ("shell_faces", C.c_int),
+        ("shell_done", C.c_void_p), ("shell_target", C.POINTER(C.c_uint)),
+        ("beta_dt_dev", C.c_void_p), ("shell_faces", C.c_int),
     ]
 
 
@@ -87,6 +88,7 @@ def load():
         "artemis_hip_apply_bc": (i, [PPk, C.POINTER(i), vp]),
         "artemis_hip_stage_fused": (i, [PPk, C.POINTER(StageArgs), vp]),
         "artemis_hip_wait_counter": (i, [vp, C.c_uint, vp, vp]),
+        "artemis_hip_advance_dt": (i, [vp, d, i, C.POINTER(d), vp]),
         "artemis_hip_halo_count": (C.c_long, [PPk, i]),
         "artemis_hip_halo_pack": (i, [PPk, i, i, vp, vp]),
         "artemis_hip_halo_unpack": (i, [PPk, i, i, vp, vp]),

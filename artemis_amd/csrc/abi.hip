@@ -246,6 +246,13 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
   return after_launch("stage_fused");
 }
 
+int artemis_hip_advance_dt(double *state, double tlim, int nstages, const double *beta, void *stream) {
+  if (int rc = device_ready()) return rc;
+  if (!state || !beta || nstages < 1 || nstages > 3) return fail(ARTEMIS_HIP_EINVAL, "bad advance_dt arguments");
+  artemis::launch_advance_dt(state, tlim, nstages, beta, S(stream));
+  return after_launch("advance_dt");
+}
+
 int artemis_hip_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, void *stream) {
   if (int rc = device_ready()) return rc;
   if (!counter) return fail(ARTEMIS_HIP_EINVAL, "null counter");

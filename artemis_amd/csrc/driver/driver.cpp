@@ -136,6 +136,7 @@ struct artemis_sim {
   Field gu0, gu1, gflux[3], gpflux[3], gvface[3];
   Field dprim, du0, du1, dflux[3];
   DevBuf geom, dt_dev;
+  DevBuf tstate; // device-resident {time, dt, dt_est, beta_dt[3]} for the synchronisation-free loop
   double *dt_host = nullptr;    // pinned
   bool unfused_ready = false;
   bool use_fused = false, fused_possible = false;
@@ -199,7 +200,7 @@ struct artemis_sim {
   void fill_ghosts_finish(int prim_idx, void *hs);
   void materialise_cons();
   Real new_dt_unfused();
-  void step_fused(bool want_dt);
+  void step_fused(bool want_dt, bool device_dt);
   void step_unfused();
   long evolve(long max_cycles);
   void upload_block(Field &f, int b, const std::vector<Real> &h);
@@ -430,6 +431,7 @@ void artemis_sim::allocate() {
   geom.alloc(hg.size());
   CK(artemis_rt_memcpy_h2d(geom.p, hg.data(), hg.size() * sizeof(Real), nullptr), "h2d geom");
   dt_dev.alloc(1);
+  tstate.alloc(6);
   signal.alloc(2);
   dt_host = static_cast<double *>(artemis_rt_malloc_host(sizeof(double)));
   if (!dt_host) throw HipFail("pinned allocation failed");
@@ -770,12 +772,12 @@ Real artemis_sim::new_dt_unfused() {
 }
 
 // One step on the fused path: one kernel per stage, primitives ping-ponged between buffers.
-void artemis_sim::step_fused(bool want_dt) {
+void artemis_sim::step_fused(bool want_dt, bool device_dt) {
   for (int q = 1; q < 3; ++q)
     if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
   const int A = base;
   int cur = A;
-  if (want_dt) {
+  if (want_dt && !device_dt) {
     *dt_host = DBL_MAX;
     CK(artemis_rt_memcpy_h2d(dt_dev.p, dt_host, sizeof(double), stream), "h2d");
   }
@@ -794,7 +796,8 @@ void artemis_sim::step_fused(bool want_dt) {
     a.prim_in = gprim[cur].tab(), a.prim_u1 = gprim[A].tab(), a.prim_out = gprim[out].tab();
     a.cons_out = nullptr;
     a.cfl = cfl_gas;
-    a.dt_dev = (last && want_dt) ? dt_dev.p : nullptr;
+    a.dt_dev = (last && want_dt) ? (device_dt ? tstate.p + 2 : dt_dev.p) : nullptr;
+    if (device_dt) a.beta_dt_dev = tstate.p + 3 + (stage - 1); // beta*dt stays on the device
     bool any_remote = false;
     int faces = 0; // faces through which some block of the pack feeds a neighbour
     for (auto &L : links) any_remote = any_remote || remote(*L), faces |= (1 << L->face);
@@ -892,10 +895,37 @@ long artemis_sim::evolve(long max_cycles) {
   CK(artemis_rt_device_sync(), "sync");
   const auto t0 = std::chrono::steady_clock::now();
   long n = 0;
-  while ((tlim < 0.0 || time < tlim) && (nlim < 0 || ncycle < nlim) && (max_cycles < 0 || n < max_cycles)) {
+  // Without a time limit nothing on the host depends on dt: keep {time, dt, dt_est} on the device
+  // (kernels read dt there, artemis_hip_advance_dt applies SetGlobalTimeStep's rules) and never
+  // synchronise inside the loop, so launches queue ahead of the GPU.
+  const bool multi = has_comm && (nranks > 1 || loopback);
+  const bool async_loop = use_fused && tlim <= 0.0 && (!multi || comm.allreduce_min_dev) &&
+                          std::getenv("ARTEMIS_SYNC_LOOP") == nullptr;
+  if (async_loop) {
+    long todo = -1;
+    if (nlim >= 0) todo = nlim - ncycle;
+    if (max_cycles >= 0) todo = (todo < 0) ? max_cycles : std::min(todo, max_cycles);
+    if (todo < 0) throw std::runtime_error("no tlim, no nlim and no cycle budget: nothing bounds the run");
+    double h[6] = {time, dt, DBL_MAX, 0.0, 0.0, 0.0};
+    for (int q = 0; q < nstages; ++q) h[3 + q] = beta[q] * dt;
+    CK(artemis_rt_memcpy_h2d(tstate.p, h, sizeof h, stream), "h2d");
+    CK(artemis_rt_stream_sync(stream), "sync");
+    for (; n < todo; ++n) {
+      step_fused(true, true);
+      if (multi && comm.allreduce_min_dev(comm.ctx, tstate.p + 2, stream))
+        throw std::runtime_error("allreduce_min_dev failed");
+      CK(artemis_hip_advance_dt(tstate.p, tlim, nstages, beta, stream), "advance_dt");
+      ncycle++;
+    }
+    CK(artemis_rt_memcpy_d2h(h, tstate.p, sizeof h, stream), "d2h");
+    CK(artemis_rt_stream_sync(stream), "sync");
+    time = h[0], dt = h[1];
+  }
+  while (!async_loop && (tlim < 0.0 || time < tlim) && (nlim < 0 || ncycle < nlim) &&
+         (max_cycles < 0 || n < max_cycles)) {
     Real est;
     if (use_fused) {
-      step_fused(true);
+      step_fused(true, false);
       const bool dev_reduce = has_comm && (nranks > 1 || loopback) && comm.allreduce_min_dev;
       if (dev_reduce && comm.allreduce_min_dev(comm.ctx, dt_dev.p, stream))
         throw std::runtime_error("allreduce_min_dev failed");

@@ -18,6 +18,7 @@ long halo_count(const PackView &P, int face);
 int launch_halo(const PackView &P, int block, int face, double *buf, int unpack, hipStream_t s);
 void invalidate_table_cache();
 // kernels_fused.hip
+void launch_advance_dt(double *state, double tlim, int nstages, const double *beta, hipStream_t s);
 void launch_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, hipStream_t s);
 int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon,
                        hipStream_t s);

@@ -41,6 +41,7 @@ constexpr int NW = NT / 64; // waves per workgroup
 
 struct StageK {
   double gam0, gam1, beta_dt, bdt, cfl;
+  const double *bdt_ptr; // optional device scalar beta*dt (replaces beta_dt and bdt)
   double *const *prim_in, *const *prim_u1, *const *prim_out, *const *cons_out;
   unsigned long long *dt_bits;
   // Work decomposition: up to 7 boxes of (i-tiles x j-tiles x k-range), each k-range cut into
@@ -147,6 +148,7 @@ struct Ctx { // per-thread constants of the march
   bool active, multi_d, three_d;
   long col, sj, sk;
   double dx1, dx2, gm1;
+  double beta_dt, bdt; // artemis_integrator.hpp:66, artemis_driver.cpp:168
   GasK gk;
   Recip rdx1, rdx2;
   int hr, hc;   // LDS slot (Q row/col) of the halo cell this thread stages, or hr < 0
@@ -325,7 +327,7 @@ ADEV void plane_update(LdsTile &S, const PackView &P, const StageK &a, const Ctx
     double divf = (ax1 * f1l - ax1 * f1h);
     if (x.multi_d) divf += (ax2 * f2l - ax2 * f2h);
     if (x.three_d) divf += (ax3 * f3l - ax3 * f3h);
-    return a.gam0 * u0 + a.gam1 * u1 + div(divf * a.beta_dt, rvol);
+    return a.gam0 * u0 + a.gam1 * u1 + div(divf * x.beta_dt, rvol);
   };
   const double D = upd(D0, D1, fx_lo.d, fx_hi.d, fy_lo.d, fy_hi.d, fz_lo.d, fz_hi.d);
   double M1 = upd(M10, M11, fx_lo.m1, fx_hi.m1, fy_lo.m1, fy_hi.m1, fz_lo.m1, fz_hi.m1);
@@ -334,15 +336,15 @@ ADEV void plane_update(LdsTile &S, const PackView &P, const StageK &a, const Ctx
   const double E = upd(E0, E1, fx_lo.e, fx_hi.e, fy_lo.e, fy_hi.e, fz_lo.e, fz_hi.e);
   double G = upd(G0, G1, fx_lo.eg, fx_hi.eg, fy_lo.eg, fy_hi.eg, fz_lo.eg, fz_hi.eg);
   // FluxSource (fluid_fluxes.hpp:365-392)
-  const double bdt_vol = div(a.bdt, rvol);
-  M1 += div(a.bdt, x.rdx1) * (fx_lo.pf - fx_hi.pf);
+  const double bdt_vol = div(x.bdt, rvol);
+  M1 += div(x.bdt, x.rdx1) * (fx_lo.pf - fx_hi.pf);
   G -= bdt_vol * 0.5 * (fx_lo.pf + fx_hi.pf) * (ax1 * fx_hi.vf - ax1 * fx_lo.vf);
   if (x.multi_d) {
-    M2 += div(a.bdt, x.rdx2) * (fy_lo.pf - fy_hi.pf);
+    M2 += div(x.bdt, x.rdx2) * (fy_lo.pf - fy_hi.pf);
     G -= bdt_vol * 0.5 * (fy_lo.pf + fy_hi.pf) * (ax2 * fy_hi.vf - ax2 * fy_lo.vf);
   }
   if (x.three_d) {
-    M3 += div(a.bdt, rdx3) * (fz_lo.pf - fz_hi.pf);
+    M3 += div(x.bdt, rdx3) * (fz_lo.pf - fz_hi.pf);
     G -= bdt_vol * 0.5 * (fz_lo.pf + fz_hi.pf) * (ax3 * fz_hi.vf - ax3 * fz_lo.vf);
   }
   // SetAuxillaryFields (fill_derived.cpp:54-73, artemis_utils.hpp:43-62) and ConsToPrim
@@ -433,6 +435,8 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   }
   x.gm1 = P.gm1;
   x.gk = gas_constants(P.gm1);
+  x.beta_dt = a.beta_dt, x.bdt = a.bdt;
+  if (a.bdt_ptr) x.beta_dt = x.bdt = *a.bdt_ptr; // dt lives on the device: scalar load
   x.g = P.geom + 6 * x.b;
   x.in_r = a.prim_in[x.b * 6 + 0], x.in_1 = a.prim_in[x.b * 6 + 1];
   x.in_2 = a.prim_in[x.b * 6 + 2], x.in_3 = a.prim_in[x.b * 6 + 3];
@@ -592,6 +596,29 @@ int launch_cfg(const PackView &P, const StageK &k, bool has_u1, bool cons, bool 
 
 } // namespace
 
+struct Betas {
+  double b[3];
+  int n;
+};
+__global__ void advance_dt_kernel(double *st, double tlim, const Betas be) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double time = st[0], dt = st[1];
+  const double est = st[2];
+  time += dt;
+  double ndt = dt;
+  if (ndt < 0.1 * DBL_MAX) ndt *= 2.0;
+  ndt = (est < ndt) ? est : ndt; // std::min(ndt, est)
+  if (tlim > 0.0 && time < tlim && (tlim - time) < ndt) ndt = tlim - time;
+  st[0] = time, st[1] = ndt, st[2] = DBL_MAX;
+  for (int q = 0; q < be.n; ++q) st[3 + q] = be.b[q] * ndt;
+}
+void launch_advance_dt(double *state, double tlim, int nstages, const double *beta, hipStream_t s) {
+  Betas be;
+  be.n = nstages;
+  for (int q = 0; q < 3; ++q) be.b[q] = (q < nstages) ? beta[q] : 0.0;
+  hipLaunchKernelGGL(advance_dt_kernel, dim3(1), dim3(64), 0, s, state, tlim, be);
+}
+
 void launch_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, hipStream_t s) {
   hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, s, counter, target, timeout_flag);
 }
@@ -601,6 +628,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   if (recon == ARTEMIS_PPM) return 3; // PPM stays on the per-task path
   StageK k;
   k.gam0 = a.gam0, k.gam1 = a.gam1, k.beta_dt = a.beta_dt, k.bdt = a.bdt, k.cfl = a.cfl;
+  k.bdt_ptr = a.beta_dt_dev;
   k.prim_in = a.prim_in, k.prim_u1 = a.prim_u1, k.prim_out = a.prim_out, k.cons_out = a.cons_out;
   k.dt_bits = reinterpret_cast<unsigned long long *>(a.dt_dev);
   const int nz = P.ke - P.ks + 1;

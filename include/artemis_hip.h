@@ -171,10 +171,20 @@ typedef struct artemis_stage_args {
                                  when done.  *shell_target (HOST, optional) receives the count to
                                  wait for with artemis_hip_wait_counter on another stream. */
   unsigned *shell_target;
+  const double *beta_dt_dev;  /* optional DEVICE scalar holding beta*dt for this stage: when
+                                 non-NULL it replaces the host values beta_dt and bdt above
+                                 (artemis_integrator.hpp:66, artemis_driver.cpp:168), so a driver
+                                 can keep dt on the device and never synchronise */
   int shell_faces;            /* bit f set: face f (0..5 = ix1,ox1,ix2,ox2,ix3,ox3) has a neighbour
                                  whose ghosts are cut from this block; 0 = all six */
 } artemis_stage_args_t;
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
+/* Device-side SetGlobalTimeStep (parthenon EvolutionDriver, upstream): state = DEVICE
+ * {time, dt, dt_est, beta_dt[0..2]}.  time += dt; dt = min(2*dt, dt_est), clipped so that
+ * time + dt <= tlim (tlim <= 0: no limit); dt_est = DBL_MAX for the next cycle's reduction;
+ * beta_dt[s] = beta[s]*dt for the nstages (<= 3) stage weights in `beta` (HOST array). */
+int artemis_hip_advance_dt(double *state, double tlim, int nstages, const double *beta, void *stream);
+
 /* Enqueue on `stream` a one-wave kernel that returns once *counter >= target (agent-scope
  * poll + acquire).  Work queued behind it on that stream sees everything the counting
  * workgroups published.  `timeout_flag` (DEVICE, optional) is set to 1 if the poll gives up

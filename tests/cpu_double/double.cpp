@@ -221,8 +221,10 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
     B.in(s.gprim, a->prim_in, 6);
     prim_to_cons(s);
     calculate_fluxes(s, FL_GAS, a->pcm != 0);
-    apply_update(s, a->gam0, a->gam1, a->beta_dt);
-    flux_source_gas(s, a->bdt);
+    const double beta_dt = a->beta_dt_dev ? *a->beta_dt_dev : a->beta_dt;
+    const double bdt = a->beta_dt_dev ? *a->beta_dt_dev : a->bdt;
+    apply_update(s, a->gam0, a->gam1, beta_dt);
+    flux_source_gas(s, bdt);
     set_aux(s);
     cons_to_prim(s);
     // pressure of the interior cells as PrimToCons would set it
@@ -297,6 +299,18 @@ int artemis_hip_halo_unpack(const artemis_pack_t *p, int b, int face, const doub
   return halo(p, b, face, const_cast<double *>(buf), 1);
 }
 int artemis_hip_wait_counter(unsigned *, unsigned, unsigned *, void *) { return 0; }
+int artemis_hip_advance_dt(double *st, double tlim, int nstages, const double *beta, void *) {
+  double time = st[0], dt = st[1];
+  const double est = st[2];
+  time += dt;
+  double ndt = dt;
+  if (ndt < 0.1 * DBL_MAX) ndt *= 2.0;
+  ndt = std::min(ndt, est);
+  if (tlim > 0.0 && time < tlim && (tlim - time) < ndt) ndt = tlim - time;
+  st[0] = time, st[1] = ndt, st[2] = DBL_MAX;
+  for (int q = 0; q < nstages; ++q) st[3 + q] = beta[q] * ndt;
+  return 0;
+}
 int artemis_hip_selftest_divsqrt(long, const double *, const double *, double *, double *, double *,
                                  double *, void *) {
   return ARTEMIS_HIP_EUNSUPPORTED;

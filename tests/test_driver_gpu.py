@@ -245,3 +245,28 @@ def test_rccl_loopback_overlap_split_blocks(hiplib, monkeypatch):
             sim.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_sync_free_loop_matches_host_dt_loop(hiplib, monkeypatch):
+    """No time limit -> {time, dt, dt_est} live on the device, the stage kernels read dt there
+    and the loop never synchronises.  Same bits as the host-side dt loop and as the oracle."""
+    from artemis_amd.driver import Simulation
+    ov = BLAST3D + ["parthenon/time/tlim=-1.0", "parthenon/time/nlim=14"]
+    a = Simulation(DECK("blast", "blast.in"), ov)
+    a.evolve()
+    monkeypatch.setenv("ARTEMIS_SYNC_LOOP", "1")
+    b = Simulation(DECK("blast", "blast.in"), ov)
+    b.evolve()
+    o = Oracle((48, 40, 32), (-1, -1, -1), (1, 1, 1), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3, bc=("outflow",) * 6)
+    o.pgen_blast(radius=0.2, internal_energy=1.0, p0=1e-5, d0=1.0, samples=4)
+    o.evolve(-1.0, 14)
+    assert a.ncycle == b.ncycle == o.ncycle == 14
+    assert a.time == b.time == o.time and a.dt == b.dt == o.dt
+    assert np.array_equal(a.field("gas.prim"), b.field("gas.prim"))
+    assert np.array_equal(a.field("gas.prim"), o.gprim)
+    # the loop can be resumed: 6 + 8 cycles == 14 cycles
+    c = Simulation(DECK("blast", "blast.in"), ov)
+    c.evolve(6)
+    c.evolve(8)
+    assert c.ncycle == 14 and c.time == a.time and np.array_equal(c.field("gas.prim"), a.field("gas.prim"))

@@ -86,6 +86,14 @@ def test_blast_ranks_equal_single_process_bitwise(double_lib, tmp_path, world):
     assert a.keys() == b.keys()
     for key in a:
         assert np.array_equal(a[key], b[key]), key
+    if world == 2:  # no time limit: dt stays in "device" memory, reduced in place by the communicator
+        spec = dict(BLAST, overrides=BLAST["overrides"] + ["parthenon/time/tlim=-1.0"])
+        fa, fb = run_world(1, spec, tmp_path, "nolim1"), run_world(2, spec, tmp_path, "nolim2")
+        assert fb[0]["meta"]["dt"] == fb[1]["meta"]["dt"] == fa[0]["meta"]["dt"]
+        assert fb[0]["meta"]["time"] == fa[0]["meta"]["time"]
+        xa, xb = by_bounds(fa), by_bounds(fb)
+        for key in xa:
+            assert np.array_equal(xa[key], xb[key]), key
     if world == 2:  # shell-first ordering with the exchange on the comm stream
         ovl = by_bounds(run_world(world, dict(BLAST, overlap=True), tmp_path, "ovl"))
         for key in a:
