@@ -166,7 +166,7 @@ def main():
             alg = ALG_BYTES_PER_CELL_STAGE * local_zones  # bytes per launch (one stage, one rank)
             achieved = alg / (kms * 1.0e-3) / 1.0e9
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
                     traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
