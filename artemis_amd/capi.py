@@ -14,7 +14,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libartemis_hip.so")
 
 OK, EINVAL, EDEVICE, EUNSUPPORTED = 0, 1, 2, 3
-CARTESIAN = 0
+CARTESIAN, CYLINDRICAL, SPHERICAL1D, SPHERICAL2D, SPHERICAL3D, AXISYMMETRIC = range(6)
+
+
+def coord_select(sys, ndim):
+    """geometry::CoordSelect (geometry.hpp:38-56)."""
+    if sys == "spherical":
+        return (SPHERICAL1D, SPHERICAL1D, SPHERICAL2D, SPHERICAL3D)[ndim]
+    return {"cartesian": CARTESIAN, "cylindrical": CYLINDRICAL,
+            "axisymmetric": AXISYMMETRIC}[sys]
+
+
 HLLC, HLLE, LLF = 0, 1, 2
 PCM, PLM, PPM = 0, 1, 2
 GAS, DUST = 0, 1
@@ -41,6 +51,7 @@ class Pack(C.Structure):
         ("nblocks", C.c_int), ("nghost", C.c_int),
         ("nx1", C.c_int), ("nx2", C.c_int), ("nx3", C.c_int),
         ("coords", C.c_int), ("gm1", C.c_double), ("geom", C.c_void_p),
+        ("metric", C.c_void_p),
         ("gas", FluidPack), ("dust", FluidPack),
     ]
 
@@ -89,6 +100,8 @@ def load():
         "artemis_hip_stage_fused": (i, [PPk, C.POINTER(StageArgs), vp]),
         "artemis_hip_wait_counter": (i, [vp, C.c_uint, vp, vp]),
         "artemis_hip_advance_dt": (i, [vp, d, i, C.POINTER(d), vp]),
+        "artemis_hip_metric_count": (C.c_long, [PPk]),
+        "artemis_hip_metric_fill": (i, [PPk, vp, vp]),
         "artemis_hip_halo_count": (C.c_long, [PPk, i]),
         "artemis_hip_halo_pack": (i, [PPk, i, i, vp, vp]),
         "artemis_hip_halo_unpack": (i, [PPk, i, i, vp, vp]),
@@ -128,7 +141,8 @@ EXPORTS_HIP = [
     "artemis_hip_calculate_fluxes", "artemis_hip_apply_update", "artemis_hip_flux_source",
     "artemis_hip_set_aux", "artemis_hip_cons_to_prim", "artemis_hip_prim_to_cons",
     "artemis_hip_deep_copy_conserved", "artemis_hip_estimate_dt", "artemis_hip_estimate_dt_async",
-    "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_halo_count",
+    "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_metric_count",
+    "artemis_hip_metric_fill", "artemis_hip_halo_count",
     "artemis_hip_halo_pack", "artemis_hip_halo_unpack", "artemis_hip_last_error",
     "artemis_hip_device_count", "artemis_hip_version",
 ]

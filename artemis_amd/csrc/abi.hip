@@ -3,6 +3,7 @@
 // No CPU fallback: without a HIP device every compute entry point returns
 // ARTEMIS_HIP_EDEVICE.
 #include <cfloat>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -49,8 +50,18 @@ int validate(const artemis_pack_t *p, bool need_gas_cons = false) {
     return fail(ARTEMIS_HIP_EINVAL, "nx3 > 1 requires nx2 > 1");
   if (p->coords < ARTEMIS_CARTESIAN || p->coords > ARTEMIS_AXISYMMETRIC)
     return fail(ARTEMIS_HIP_EINVAL, "Coordinate type not recognized!");
-  if (p->coords != ARTEMIS_CARTESIAN)
-    return fail(ARTEMIS_HIP_EUNSUPPORTED, "only cartesian coordinates are built (DESIGN.md)");
+  {
+    // geometry::CoordSelect (geometry.hpp:38-56) ties the spherical variant to the dimension
+    const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
+    const int want = (ndim == 1) ? ARTEMIS_SPHERICAL1D
+                                 : ((ndim == 2) ? ARTEMIS_SPHERICAL2D : ARTEMIS_SPHERICAL3D);
+    const bool sph = p->coords >= ARTEMIS_SPHERICAL1D && p->coords <= ARTEMIS_SPHERICAL3D;
+    if (sph && p->coords != want)
+      return fail(ARTEMIS_HIP_EINVAL, "spherical%dD coordinates on a %d-D block", p->coords - 1, ndim);
+    if (sph && ndim > 1 && !p->metric)
+      return fail(ARTEMIS_HIP_EINVAL,
+                  "spherical 2-D/3-D needs the x2 metric tables (artemis_hip_metric_fill)");
+  }
   if (!p->geom) return fail(ARTEMIS_HIP_EINVAL, "null geom table");
   if (p->gas.nspecies < 0 || p->dust.nspecies < 0 || (p->gas.nspecies == 0 && p->dust.nspecies == 0))
     return fail(ARTEMIS_HIP_EINVAL, "no fluid species in pack");
@@ -127,9 +138,10 @@ int artemis_hip_flux_source(const artemis_pack_t *p, int fluid, double dt, void 
   if (fluid != ARTEMIS_GAS && fluid != ARTEMIS_DUST)
     return fail(ARTEMIS_HIP_EINVAL, "Fluid type not recognized!");
   // Dust is pressureless: Dust::FluxSource returns immediately for Cartesian (dust.cpp:310-323).
-  if (fluid == ARTEMIS_DUST || p->gas.nspecies == 0) return 0;
+  if ((fluid == ARTEMIS_DUST ? p->dust.nspecies : p->gas.nspecies) == 0) return 0;
+  if (fluid == ARTEMIS_DUST && p->coords == ARTEMIS_CARTESIAN) return 0;
   if (p->nghost < 1) return fail(ARTEMIS_HIP_EINVAL, "FluxSource needs >= 1 ghost cell");
-  artemis::launch_flux_source_gas(artemis::make_pack_view(*p), dt, S(stream));
+  artemis::launch_flux_source(artemis::make_pack_view(*p), fluid, dt, S(stream));
   return after_launch("FluxSource");
 }
 
@@ -200,6 +212,42 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, void *stream) {
   return after_launch("ApplyBoundaryConditions");
 }
 
+// Host-side metric tables (see include/artemis_hip.h and csrc/geometry.hpp: rows MT_COSF,
+// MT_SINF, MT_X2V, MT_SINV, MT_SINC, each nj+1 doubles per block).  Expressions follow
+// spherical.hpp:61-68 (x2v) and :53-55, :88-104 (the sine arguments).
+long artemis_hip_metric_count(const artemis_pack_t *p) {
+  if (!p) return -1;
+  if (p->coords != ARTEMIS_SPHERICAL2D && p->coords != ARTEMIS_SPHERICAL3D) return 0;
+  const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0);
+  return static_cast<long>(p->nblocks) * 5 * (nj + 1);
+}
+int artemis_hip_metric_fill(const artemis_pack_t *p, const double *geom_host, double *out_host) {
+  if (!p || !geom_host || !out_host) return fail(ARTEMIS_HIP_EINVAL, "null argument");
+  if (artemis_hip_metric_count(p) == 0) return 0;
+  const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0);
+  const int st = nj + 1;
+  for (int b = 0; b < p->nblocks; ++b) {
+    const double f0 = geom_host[6 * b + 2], dx = geom_host[6 * b + 3];
+    double *m = out_host + static_cast<long>(b) * 5 * st;
+    for (int j = 0; j <= nj; ++j) {
+      const double xf = f0 + j * dx;
+      m[0 * st + j] = std::cos(xf);
+      m[1 * st + j] = std::sin(xf);
+    }
+    for (int j = 0; j < nj; ++j) {
+      const double x0 = f0 + j * dx, x1 = f0 + (j + 1) * dx;
+      const double ctm = m[0 * st + j], ctp = m[0 * st + j + 1];
+      const double dst = m[1 * st + j + 1] - m[1 * st + j];
+      const double x2v = (dst - x1 * ctp + x0 * ctm) / std::abs(ctm - ctp);
+      m[2 * st + j] = x2v;
+      m[3 * st + j] = std::sin(x2v);
+      m[4 * st + j] = std::sin(0.5 * (x0 + x1));
+    }
+    m[2 * st + nj] = m[3 * st + nj] = m[4 * st + nj] = 0.0;
+  }
+  return 0;
+}
+
 long artemis_hip_halo_count(const artemis_pack_t *p, int face) {
   if (!p || face < 0 || face > 5) return -1;
   return artemis::halo_count(artemis::make_pack_view(*p), face);
@@ -230,6 +278,9 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
   if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");
   if (p->gas.nspecies != 1 || p->dust.nspecies != 0)
     return fail(ARTEMIS_HIP_EUNSUPPORTED, "fused stage: one gas species, no dust (DESIGN.md)");
+  if (p->coords != ARTEMIS_CARTESIAN)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED,
+                "fused stage: Cartesian only; curvilinear systems use the per-task kernels");
   if (int rc = validate_fluid(p, ARTEMIS_GAS, a->pcm)) return rc;
   if (!a->prim_in || !a->prim_u1 || !a->prim_out)
     return fail(ARTEMIS_HIP_EINVAL, "fused stage: prim_in / prim_u1 / prim_out are required");

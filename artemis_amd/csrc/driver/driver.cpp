@@ -22,6 +22,7 @@
 #include "artemis_driver.h"
 #include "artemis_hip.h"
 #include "artemis_rt.h"
+#include "../geometry_core.hpp"
 #include "parameter_input.hpp"
 
 #define SQR(x) ((x) * (x))
@@ -135,7 +136,14 @@ struct artemis_sim {
   int base = 0;                 // index of the buffer holding the current state
   Field gu0, gu1, gflux[3], gpflux[3], gvface[3];
   Field dprim, du0, du1, dflux[3];
-  DevBuf geom, dt_dev;
+  DevBuf geom, dt_dev, metric;
+  std::vector<Real> hgeom, hmetric; // host copies of the edge and x2-trig tables
+  int coords = ARTEMIS_CARTESIAN;   // geometry::CoordSelect(artemis/coordinates, ndim)
+  // geometry::Coords<GEOM> of cell (k,j,i) of local block b (host side: pgens, history)
+  artemis::DCoords cell_coords(int b, int k, int j, int i) const {
+    const Real *m = hmetric.empty() ? nullptr : hmetric.data() + static_cast<size_t>(b) * 5 * (nj + 1);
+    return artemis::coords_of(coords, hgeom.data() + 6 * b, m, nj, k, j, i);
+  }
   DevBuf tstate; // device-resident {time, dt, dt_est, beta_dt[3]} for the synchronisation-free loop
   double *dt_host = nullptr;    // pinned
   bool unfused_ready = false;
@@ -174,9 +182,10 @@ struct artemis_sim {
     artemis_pack_t p;
     std::memset(&p, 0, sizeof p);
     p.nblocks = nb, p.nghost = ng, p.nx1 = mbnx[0], p.nx2 = mbnx[1], p.nx3 = mbnx[2];
-    p.coords = ARTEMIS_CARTESIAN;
+    p.coords = coords;
     p.gm1 = gamma - 1.0;
     p.geom = geom.p;
+    p.metric = metric.p;
     p.gas.nspecies = ns_gas, p.gas.recon = recon_gas, p.gas.riemann = riemann_gas;
     p.gas.dfloor = dfloor_gas, p.gas.siefloor = siefloor_gas, p.gas.de_switch = de_switch;
     p.gas.prim = gprim[prim_idx].tab(), p.gas.cons0 = gu0.tab(), p.gas.cons1 = gu1.tab();
@@ -256,8 +265,6 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   // <artemis> (artemis.cpp:48-53,93-97)
   const std::string problem = pin.GetString("artemis", "problem");
   const std::string sys = pin.GetOrAddString("artemis", "coordinates", "cartesian");
-  if (sys != "cartesian")
-    throw std::runtime_error("coordinates = " + sys + " is not built yet (cartesian only)");
   if (problem == "blast") pgen = PG_BLAST;
   else if (problem == "linear_wave") pgen = PG_LINWAVE;
   else if (problem == "advection") pgen = PG_ADVECTION;
@@ -284,6 +291,15 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
     nblk[d] = nx[d] / mbnx[d];
   }
   ndim = (nx[2] > 1) ? 3 : ((nx[1] > 1) ? 2 : 1);
+  // geometry::CoordSelect (geometry.hpp:38-56, artemis.cpp:94-97)
+  if (sys == "cartesian") coords = ARTEMIS_CARTESIAN;
+  else if (sys == "spherical")
+    coords = (ndim == 1) ? ARTEMIS_SPHERICAL1D : ((ndim == 2) ? ARTEMIS_SPHERICAL2D : ARTEMIS_SPHERICAL3D);
+  else if (sys == "cylindrical") coords = ARTEMIS_CYLINDRICAL;
+  else if (sys == "axisymmetric") coords = ARTEMIS_AXISYMMETRIC;
+  else throw std::runtime_error("Coordinate type not recognized!");
+  if (coords != ARTEMIS_CARTESIAN && pgen != PG_BLAST)
+    throw std::runtime_error("problem generator '" + problem + "' is Cartesian-only");
   // <parthenon/time>
   tlim = pin.GetOrAddReal("parthenon/time", "tlim", -1.0);
   nlim = pin.GetOrAddInteger("parthenon/time", "nlim", -1);
@@ -344,7 +360,8 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
 
   build_mesh();
   allocate();
-  fused_possible = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2;
+  fused_possible = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
+                   coords == ARTEMIS_CARTESIAN; // curvilinear systems run the per-task kernels
   use_fused = fused_possible;
   if (!use_fused) ensure_unfused();
   problem_generator();
@@ -430,6 +447,21 @@ void artemis_sim::allocate() {
     }
   geom.alloc(hg.size());
   CK(artemis_rt_memcpy_h2d(geom.p, hg.data(), hg.size() * sizeof(Real), nullptr), "h2d geom");
+  hgeom = hg;
+  {
+    // x2 trigonometry tables of spherical2D/3D, filled with the host libm (artemis_hip.h)
+    artemis_pack_t p0;
+    std::memset(&p0, 0, sizeof p0);
+    p0.nblocks = nb, p0.nghost = ng, p0.nx1 = mbnx[0], p0.nx2 = mbnx[1], p0.nx3 = mbnx[2];
+    p0.coords = coords;
+    const long nm = artemis_hip_metric_count(&p0);
+    if (nm > 0) {
+      hmetric.assign(nm, 0.0);
+      CK(artemis_hip_metric_fill(&p0, hgeom.data(), hmetric.data()), "metric tables");
+      metric.alloc(nm);
+      CK(artemis_rt_memcpy_h2d(metric.p, hmetric.data(), nm * sizeof(Real), nullptr), "h2d metric");
+    }
+  }
   dt_dev.alloc(1);
   tstate.alloc(6);
   signal.alloc(2);
@@ -600,6 +632,28 @@ void artemis_sim::lw_setup(bool eigen) {
   }
 }
 
+// Coords<GEOM>::ConvertCoordsToCart (geometry.hpp:248, cylindrical.hpp:88-92,
+// spherical.hpp:166-173 / :355-362 / :528-534, axisymmetric.hpp:77-82)
+static void to_cart(int sys, const Real xi[3], Real xc[3]) {
+  if (sys == ARTEMIS_SPHERICAL3D || sys == ARTEMIS_SPHERICAL2D) {
+    const Real cp = (sys == ARTEMIS_SPHERICAL3D) ? std::cos(xi[2]) : 1.0;
+    const Real sp = (sys == ARTEMIS_SPHERICAL3D) ? std::sin(xi[2]) : 0.0;
+    const Real ct = std::cos(xi[1]), st = std::sin(xi[1]);
+    xc[0] = xi[0] * st * cp, xc[1] = xi[0] * st * sp, xc[2] = xi[0] * ct;
+  } else if (sys == ARTEMIS_SPHERICAL1D) {
+    const Real cp = 1.0, sp = 0.0, ct = 0.0, st = 1.0;
+    xc[0] = xi[0] * st * cp, xc[1] = xi[0] * st * sp, xc[2] = xi[0] * ct;
+  } else if (sys == ARTEMIS_CYLINDRICAL) {
+    const Real cp = std::cos(xi[1]), sp = std::sin(xi[1]);
+    xc[0] = xi[0] * cp, xc[1] = xi[0] * sp, xc[2] = xi[2];
+  } else if (sys == ARTEMIS_AXISYMMETRIC) {
+    const Real cp = std::cos(xi[2]), sp = std::sin(xi[2]);
+    xc[0] = xi[0] * cp, xc[1] = xi[0] * sp, xc[2] = xi[1];
+  } else {
+    xc[0] = xi[0], xc[1] = xi[1], xc[2] = xi[2];
+  }
+}
+
 void artemis_sim::problem_generator() {
   const Real gm1 = gamma - 1.0;
   auto xf = [&](int b, int d, int idx) { // Coordinates_t::Xf (geometry.hpp:65-72)
@@ -648,12 +702,32 @@ void artemis_sim::problem_generator() {
           const Real xv[3] = {0.5 * (b1[0] + b1[1]), 0.5 * (b2[0] + b2[1]), 0.5 * (b3[0] + b3[1])};
           const size_t c = (static_cast<size_t>(k) * nj + j) * ni + i;
           if (pgen == PG_BLAST) { // blast.hpp:168-228
-            const Real total_vol = (b1[1] - b1[0]) * (b2[1] - b2[0]) * (b3[1] - b3[0]);
+            const artemis::DCoords co = cell_coords(b, k, j, i);
+            const Real total_vol = co.volume();
             const Real e0 = p0 / gm1;
-            Real xc[3] = {xv[0], xv[1], xv[2]};
-            for (int n = 0; n < 3; n++) xc[n] -= x0[n];
+            // cell centroid and blast centre in Cartesian coordinates (blast.hpp:181-185)
+            const Real xcen[3] = {co.x1v(), co.x2v(), co.x3v()};
+            Real xc[3], xb[3];
+            to_cart(coords, xcen, xc);
+            to_cart(coords, x0, xb);
+            for (int n = 0; n < 3; n++) xc[n] -= xb[n];
             Real vol;
-            if (samples > 0) {
+            if (samples > 0 && coords == ARTEMIS_AXISYMMETRIC && btype == 1) {
+              // compute_overlap_sph, axisymmetric branch (blast.hpp:107-121): r-weighted samples
+              const Real dxf = (b1[1] - b1[0]) / (Real)samples, dyf = (b2[1] - b2[0]) / (Real)samples;
+              const Real dV = dxf * dyf;
+              Real tot = 0.0;
+              for (int ii = 0; ii < samples; ii++) {
+                const Real xs = b1[0] + (ii + 0.5) * dxf;
+                for (int jj = 0; jj < samples; jj++) {
+                  const Real ys = b2[0] + (jj + 0.5) * dyf;
+                  if (SQR(xs) + SQR(ys) <= SQR(rinit)) tot += xs * dV;
+                }
+              }
+              vol = tot;
+            } else if (samples > 0 && coords != ARTEMIS_CARTESIAN) {
+              vol = 0.0; // the other overlap helpers have a Cartesian branch only (blast.hpp:68,122)
+            } else if (samples > 0) {
               // compute_overlap_{sph,cyl} (blast.hpp:65-106): sub-sample the zone.  Zones whose
               // sample points are all outside (inside) the sphere are counted directly; the
               // counts, and so the products below, are the same as the loops would give.
@@ -963,17 +1037,10 @@ int artemis_sim::history(double *out) {
     std::vector<Real> g, d;
     if (do_gas) g = download(gu0, b);
     if (do_dust) d = download(du0, b);
-    const Real dx[3] = {(blocks[b].xmax[0] - blocks[b].xmin[0]) / mbnx[0],
-                        (blocks[b].xmax[1] - blocks[b].xmin[1]) / mbnx[1],
-                        (blocks[b].xmax[2] - blocks[b].xmin[2]) / mbnx[2]};
-    const Real f0[3] = {blocks[b].xmin[0] - is * dx[0], blocks[b].xmin[1] - js * dx[1],
-                        blocks[b].xmin[2] - ks * dx[2]};
     for (int k = ks; k <= ke; ++k)
       for (int j = js; j <= je; ++j)
         for (int i = is; i <= ie; ++i) {
-          const Real vv = ((f0[0] + (i + 1) * dx[0]) - (f0[0] + i * dx[0])) *
-                          ((f0[1] + (j + 1) * dx[1]) - (f0[1] + j * dx[1])) *
-                          ((f0[2] + (k + 1) * dx[2]) - (f0[2] + k * dx[2]));
+          const Real vv = cell_coords(b, k, j, i).volume(); // history.hpp:49-50
           const size_t c = (static_cast<size_t>(k) * nj + j) * ni + i;
           if (do_gas) {
             out[0] += g[0 * N + c] * vv;

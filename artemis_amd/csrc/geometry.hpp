@@ -1,0 +1,54 @@
+// Device glue for geometry_core.hpp: Coords of a PackView cell, PLM_G and its per-cell inputs.
+#pragma once
+#include "geometry_core.hpp"
+#include "pack_view.hpp"
+
+namespace artemis {
+
+GDEV DCoords make_coords(const PackView &P, int b, int k, int j, int i) {
+  const double *m =
+      P.metric ? P.metric + static_cast<long>(b) * MT_ROWS * (P.nj + 1) : nullptr;
+  return coords_of(P.coords, P.geom + 6 * b, m, P.nj, k, j, i);
+}
+
+// x_d centroid of the cell at index idx along direction dir, other indices irrelevant
+// (x1v depends on i only, x2v on j only, x3v on k only).
+GDEV double centroid_along(const PackView &P, int b, int dir, int idx) {
+  DCoords c = (dir == 1)   ? make_coords(P, b, 0, 0, idx)
+              : (dir == 2) ? make_coords(P, b, 0, idx, 0)
+                           : make_coords(P, b, idx, 0, 0);
+  return (dir == 1) ? c.x1v() : ((dir == 2) ? c.x2v() : c.x3v());
+}
+
+// PLM_G (plm.hpp:54-73), Mignone (2013) weights.  Returns both face values of cell i.
+GDEV void plm_g(double q_im1, double q_i, double q_ip1, double &ql_ip1, double &qr_i, double x_im1,
+                double x_i, double x_ip1, double xf0, double xf1, double dx) {
+  const double dql = (q_i - q_im1) * dx / (x_i - x_im1);
+  const double dqr = (q_ip1 - q_i) * dx / (x_ip1 - x_i);
+  const double dq2 = dql * dqr;
+  const double cr = (x_ip1 - x_i) / (xf1 - x_i);
+  const double cl = (x_i - x_im1) / (x_i - xf0);
+  const double dqm =
+      (dq2 <= 0.0) ? 0.0
+                   : dq2 * (cr * dql + cl * dqr) / (dql * dql + dqr * dqr + dq2 * (cl + cr - 2.0));
+  ql_ip1 = q_i + dqm * (xf1 - x_i) / dx;
+  qr_i = q_i - dqm * (x_i - xf0) / dx;
+}
+
+// What PLM_G needs for the cell (k,j,i) along dir (plm.hpp:93-101, :127-135, :161-169).
+struct PlmGeo {
+  double xvm, xvc, xvp, xf0, xf1, dx;
+};
+GDEV PlmGeo plm_geo(const PackView &P, int b, int dir, int k, int j, int i) {
+  PlmGeo g;
+  const DCoords c = make_coords(P, b, k, j, i);
+  const int idx = (dir == 1) ? i : ((dir == 2) ? j : k);
+  g.xvm = centroid_along(P, b, dir, idx - 1);
+  g.xvp = centroid_along(P, b, dir, idx + 1);
+  if (dir == 1) g.xvc = c.x1v(), g.xf0 = c.x1[0], g.xf1 = c.x1[1], g.dx = c.width1();
+  else if (dir == 2) g.xvc = c.x2v(), g.xf0 = c.x2[0], g.xf1 = c.x2[1], g.dx = c.width2();
+  else g.xvc = c.x3v(), g.xf0 = c.x3[0], g.xf1 = c.x3[1], g.dx = c.width3();
+  return g;
+}
+
+} // namespace artemis

@@ -1,0 +1,189 @@
+// Device-side geometry::Coords<GEOM> (reference geometry/geometry.hpp:145-420 for the Cartesian
+// defaults, cylindrical.hpp, spherical.hpp, axisymmetric.hpp for the overrides).
+//
+// One struct serves the six coordinate systems through a wave-uniform runtime switch: these
+// per-task kernels are bandwidth-bound and the metric arithmetic is a few dozen flops, so the
+// 6x template fan-out of the reference buys nothing here.  Cell edges come from the same
+// Xf(idx) = xf0 + idx*dx formula the Cartesian kernels use.  Every transcendental the
+// reference evaluates per cell (cos/sin of the x2 faces, of the x2 centroid and of the x2
+// midpoint) depends on j only and is read from a per-block table that the host fills with
+// libm (artemis_hip_metric_fill), so results do not depend on a device sin/cos
+// implementation; everything else is the reference's expression tree evaluated in place.
+//
+// This header holds the system-independent core (usable from the g++-compiled host driver for
+// problem generators and history integrals as well as from kernels); geometry.hpp adds the
+// PackView glue for device code.
+#pragma once
+#include <cmath>
+
+#include "../../include/artemis_hip.h"
+
+#ifdef __HIPCC__
+#define GDEV __host__ __device__ __forceinline__
+#else
+#define GDEV inline
+#endif
+
+namespace artemis {
+
+// Table rows of one block: stride nj + 1 doubles each.
+enum { MT_COSF = 0, MT_SINF = 1, MT_X2V = 2, MT_SINV = 3, MT_SINC = 4, MT_ROWS = 5 };
+
+struct DCoords {
+  int sys;
+  double x1[2], x2[2], x3[2];
+  double cf[2], sf[2]; // cos / sin of the two x2 faces         (spherical2D/3D only)
+  double x2c, sv, sc;  // x2 centroid, sin(centroid), sin(0.5*(x2[0]+x2[1]))
+
+  GDEV bool sph23() const { return sys == ARTEMIS_SPHERICAL2D || sys == ARTEMIS_SPHERICAL3D; }
+  GDEV bool sph() const { return sys == ARTEMIS_SPHERICAL1D || sph23(); }
+  // geometry.hpp:98-110
+  GDEV bool x1dep() const { return sys != ARTEMIS_CARTESIAN; }
+  GDEV bool x2dep() const { return sph23(); }
+
+  // sum of squares-and-product that every curvilinear radius formula shares
+  GDEV double rsq3() const { return x1[0] * x1[0] + x1[0] * x1[1] + x1[1] * x1[1]; }
+
+  GDEV double x1v() const {
+    if (sph()) { // spherical.hpp:57-60
+      const double dr2 = x1[0] * x1[0] + x1[1] * x1[1];
+      return 0.75 * (x1[0] + x1[1]) * dr2 / (dr2 + x1[0] * x1[1]);
+    }
+    if (sys == ARTEMIS_CYLINDRICAL || sys == ARTEMIS_AXISYMMETRIC) // cylindrical.hpp:41-45
+      return 2.0 / 3.0 * rsq3() / (x1[0] + x1[1]);
+    return 0.5 * (x1[0] + x1[1]);
+  }
+  GDEV double x2v() const { return sph23() ? x2c : 0.5 * (x2[0] + x2[1]); }
+  GDEV double x3v() const { return 0.5 * (x3[0] + x3[1]); }
+  GDEV double rcen() const { return 2.0 / 3.0 * rsq3() / (x1[0] + x1[1]); }
+
+  // volume-averaged scale factors (GetScaleFactors, geometry.hpp:384-388)
+  GDEV double hx2v() const { // spherical.hpp:70, cylindrical.hpp:51; spherical1D keeps 1
+    return (sph23() || sys == ARTEMIS_CYLINDRICAL) ? x1v() : 1.0;
+  }
+  GDEV double hx3v() const {
+    if (sph23()) { // spherical.hpp:71-82
+      const double dsc = sf[1] * cf[1] - sf[0] * cf[0];
+      const double dx2 = x2[1] - x2[0];
+      return x1v() * 0.5 * (dx2 - dsc) / fabs(cf[0] - cf[1]);
+    }
+    if (sys == ARTEMIS_AXISYMMETRIC) return x1v(); // axisymmetric.hpp:46
+    return 1.0;
+  }
+  // GetCellWidths (geometry.hpp:352-361): h_d(x1v, x2v, x3v) * coordinate width
+  GDEV double width1() const { return 1.0 * (x1[1] - x1[0]); }
+  GDEV double width2() const {
+    const double h = (sph() || sys == ARTEMIS_CYLINDRICAL) ? x1v() : 1.0;
+    return h * (x2[1] - x2[0]);
+  }
+  GDEV double width3() const {
+    double h = 1.0;
+    if (sph23()) h = x1v() * sv;                        // spherical.hpp:53-55
+    else if (sys == ARTEMIS_AXISYMMETRIC) h = x1v();    // axisymmetric.hpp:43-45
+    return h * (x3[1] - x3[0]);
+  }
+
+  // face areas; f = 0 lower, 1 upper (GetFaceAreaX?, geometry.hpp:390-405)
+  GDEV double area1(int f) const {
+    const double x1f = x1[f];
+    const double dx2 = x2[1] - x2[0], dx3 = x3[1] - x3[0];
+    switch (sys) {
+    case ARTEMIS_SPHERICAL3D: return x1f * x1f * fabs(cf[0] - cf[1]) * dx3; // spherical.hpp:106-109
+    case ARTEMIS_SPHERICAL2D: return x1f * x1f * fabs(cf[0] - cf[1]);
+    case ARTEMIS_SPHERICAL1D: return x1f * x1f;
+    case ARTEMIS_CYLINDRICAL:
+    case ARTEMIS_AXISYMMETRIC: return x1f * dx2 * dx3; // cylindrical.hpp:62-66
+    default: return dx2 * dx3;
+    }
+  }
+  GDEV double area2(int f) const {
+    const double dx1 = x1[1] - x1[0], dx3 = x3[1] - x3[0];
+    switch (sys) {
+    case ARTEMIS_SPHERICAL3D: return 0.5 * (x1[1] + x1[0]) * sf[f] * dx1 * dx3; // spherical.hpp:110-114
+    case ARTEMIS_SPHERICAL2D: return 0.5 * (x1[1] + x1[0]) * sf[f] * dx1;
+    case ARTEMIS_SPHERICAL1D: return 0.5 * (x1[1] + x1[0]) * dx1;
+    case ARTEMIS_AXISYMMETRIC: return (x1[0] + x1[1]) * 0.5 * dx1 * dx3; // axisymmetric.hpp:60-64
+    default: return dx1 * dx3;
+    }
+  }
+  GDEV double area3(int) const {
+    const double dx1 = x1[1] - x1[0], dx2 = x2[1] - x2[0];
+    switch (sys) {
+    case ARTEMIS_SPHERICAL3D:
+    case ARTEMIS_SPHERICAL2D:
+    case ARTEMIS_CYLINDRICAL: return 0.5 * (x1[0] + x1[1]) * dx1 * dx2; // spherical.hpp:115-119
+    case ARTEMIS_SPHERICAL1D: return 0.5 * (x1[0] + x1[1]) * dx1;
+    default: return dx1 * dx2;
+    }
+  }
+  GDEV double volume() const {
+    const double dx1 = x1[1] - x1[0], dx2 = x2[1] - x2[0], dx3 = x3[1] - x3[0];
+    if (sph()) { // spherical.hpp:124-133
+      const double rfac = rsq3() / 3.0;
+      if (sys == ARTEMIS_SPHERICAL1D) return rfac * dx1;
+      const double dc = fabs(cf[0] - cf[1]);
+      if (sys == ARTEMIS_SPHERICAL2D) return rfac * dx1 * dc;
+      return rfac * dx1 * dc * dx3;
+    }
+    if (sys == ARTEMIS_CYLINDRICAL || sys == ARTEMIS_AXISYMMETRIC) // cylindrical.hpp:73-78
+      return (x1[0] + x1[1]) * 0.5 * dx1 * dx2 * dx3;
+    return dx1 * dx2 * dx3;
+  }
+  // connection coefficients (GetConnX1/X2, geometry.hpp:407-418)
+  GDEV double dh2dx1() const {
+    if (sph()) return 3.0 / 2.0 * (x1[0] + x1[1]) / rsq3(); // spherical.hpp:135-138
+    if (sys == ARTEMIS_CYLINDRICAL) return 1.0 / (0.5 * (x1[0] + x1[1])); // cylindrical.hpp:80
+    return 0.0;
+  }
+  GDEV double dh3dx1() const {
+    if (sph()) return 3.0 / 2.0 * (x1[0] + x1[1]) / rsq3(); // spherical.hpp:139-142
+    if (sys == ARTEMIS_AXISYMMETRIC) return 1.0 / (0.5 * (x1[0] + x1[1])); // axisymmetric.hpp:71
+    return 0.0;
+  }
+  GDEV double dh3dx2() const { // spherical.hpp:143-146
+    return sph23() ? (sf[1] - sf[0]) / fabs(cf[0] - cf[1]) : 0.0;
+  }
+  // Scale factors at the centroid of the LOWER face of direction dir (ScaleMomentumFlux,
+  // fluid_fluxes.hpp:56-66 with FaceCenX? of each system).
+  GDEV void face_scale(int dir, double h[3]) const {
+    h[0] = 1.0, h[1] = 1.0, h[2] = 1.0;
+    if (dir == 1) { // FaceCenX1 = {x1f, x2v, x3v} for every system (geometry.hpp:182-186)
+      if (sph() || sys == ARTEMIS_CYLINDRICAL) h[1] = x1[0];
+      if (sph23()) h[2] = x1[0] * sv;
+      else if (sys == ARTEMIS_AXISYMMETRIC) h[2] = x1[0];
+    } else if (dir == 2) {
+      // spherical*/axisymmetric use the area-weighted radius, cylindrical/cartesian x1v
+      const bool rc = sph() || sys == ARTEMIS_AXISYMMETRIC;
+      const double r = rc ? rcen() : x1v();
+      if (sph() || sys == ARTEMIS_CYLINDRICAL) h[1] = r;
+      if (sph23()) h[2] = r * sf[0];
+      else if (sys == ARTEMIS_AXISYMMETRIC) h[2] = r;
+    } else {
+      const bool rc = sph() || sys == ARTEMIS_CYLINDRICAL;
+      const double r = rc ? rcen() : x1v();
+      if (sph() || sys == ARTEMIS_CYLINDRICAL) h[1] = r;
+      if (sph23()) h[2] = r * sc;
+      else if (sys == ARTEMIS_AXISYMMETRIC) h[2] = r;
+    }
+  }
+};
+
+// Cell (k,j,i) of a block with edge table g6 = {x1f0, dx1, x2f0, dx2, x3f0, dx3}; `m` = the
+// block's metric rows (stride nj+1) or null when the system needs none.
+GDEV DCoords coords_of(int sys, const double *g, const double *m, int nj, int k, int j, int i) {
+  DCoords c;
+  c.sys = sys;
+  c.x1[0] = g[0] + i * g[1], c.x1[1] = g[0] + (i + 1) * g[1];
+  c.x2[0] = g[2] + j * g[3], c.x2[1] = g[2] + (j + 1) * g[3];
+  c.x3[0] = g[4] + k * g[5], c.x3[1] = g[4] + (k + 1) * g[5];
+  c.cf[0] = c.cf[1] = c.sf[0] = c.sf[1] = c.x2c = c.sv = c.sc = 0.0;
+  if (c.sph23()) {
+    const int st = nj + 1;
+    c.cf[0] = m[MT_COSF * st + j], c.cf[1] = m[MT_COSF * st + j + 1];
+    c.sf[0] = m[MT_SINF * st + j], c.sf[1] = m[MT_SINF * st + j + 1];
+    c.x2c = m[MT_X2V * st + j], c.sv = m[MT_SINV * st + j], c.sc = m[MT_SINC * st + j];
+  }
+  return c;
+}
+
+} // namespace artemis

@@ -7,7 +7,7 @@
 namespace artemis {
 void launch_calculate_fluxes(const PackView &P, int fluid, int riemann, int recon, hipStream_t s);
 void launch_apply_update(const PackView &P, double gam0, double gam1, double beta_dt, hipStream_t s);
-void launch_flux_source_gas(const PackView &P, double dt, hipStream_t s);
+void launch_flux_source(const PackView &P, int fluid, double dt, hipStream_t s);
 void launch_set_aux(const PackView &P, hipStream_t s);
 void launch_cons_to_prim(const PackView &P, hipStream_t s);
 void launch_prim_to_cons(const PackView &P, hipStream_t s);

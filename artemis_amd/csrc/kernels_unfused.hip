@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "device_math.hpp"
+#include "geometry.hpp"
 #include "kernels.hpp"
 #include "pack_view.hpp"
 
@@ -37,10 +38,33 @@ inline dim3 grid_for(const Range3 &r, int nb) {
 // reconstructs the upper face value of the cell below the face and the lower face value of
 // the cell above it straight from global memory (neighbouring threads share those lines in
 // L1/L2), then solves the Riemann problem and writes the 8 (gas) / 4 (dust) face outputs.
-template <int FLUID, int RIEMANN, int RECON>
+// Face states of one variable at the face below cell c: L from the cell below, R from cell c.
+// CURV && PLM uses PLM_G with the Mignone weights of each of the two cells (plm.hpp:90-103).
+template <int RECON, bool CURV>
+__device__ __forceinline__ void face_states(const double *q, long st, const PlmGeo &gl,
+                                            const PlmGeo &gr, double &L, double &R) {
+  double unused;
+  if constexpr (CURV && RECON == 1) {
+    plm_g(q[-2 * st], q[-st], q[0], L, unused, gl.xvm, gl.xvc, gl.xvp, gl.xf0, gl.xf1, gl.dx);
+    plm_g(q[-st], q[0], q[st], unused, R, gr.xvm, gr.xvc, gr.xvp, gr.xf0, gr.xf1, gr.dx);
+  } else {
+    recon_cell<RECON>(q - st, st, L, unused), recon_cell<RECON>(q, st, unused, R);
+  }
+}
+
+template <int FLUID, int RIEMANN, int RECON, bool CURV>
 __global__ __launch_bounds__(TX *TY) void flux_kernel(const PackView P, const Range3 r,
                                                       const int dir) {
   CELL_FROM_GRID(r)
+  PlmGeo gl{}, gr{};
+  double hs[3] = {1.0, 1.0, 1.0}; // ScaleMomentumFlux factors (fluid_fluxes.hpp:33-70)
+  if constexpr (CURV) {
+    if constexpr (RECON == 1) {
+      gl = plm_geo(P, b, dir, k - (dir == 3), j - (dir == 2), i - (dir == 1));
+      gr = plm_geo(P, b, dir, k, j, i);
+    }
+    make_coords(P, b, k, j, i).face_scale(dir, hs);
+  }
   const FluidView &f = (FLUID == 0) ? P.gas : P.dust;
   const int ns = f.ns;
   const int nv = (FLUID == 0) ? 6 * ns : 4 * ns;
@@ -52,24 +76,24 @@ __global__ __launch_bounds__(TX *TY) void flux_kernel(const PackView P, const Ra
     const int ivy = ns + 3 * n + (d + 1) % 3;
     const int ivz = ns + 3 * n + (d + 2) % 3;
     const int IPR = 4 * ns + n, ISE = 5 * ns + n;
-    double unused;
     FaceFlux F;
     if constexpr (FLUID == 0) {
       Prim6 L, R;
       const double *q;
       q = f.prim[b * nv + IDN] + c;
-      recon_cell<RECON>(q - st, st, L.d, unused), recon_cell<RECON>(q, st, unused, R.d);
+      face_states<RECON, CURV>(q, st, gl, gr, L.d, R.d);
       q = f.prim[b * nv + ivx] + c;
-      recon_cell<RECON>(q - st, st, L.vx, unused), recon_cell<RECON>(q, st, unused, R.vx);
+      face_states<RECON, CURV>(q, st, gl, gr, L.vx, R.vx);
       q = f.prim[b * nv + ivy] + c;
-      recon_cell<RECON>(q - st, st, L.vy, unused), recon_cell<RECON>(q, st, unused, R.vy);
+      face_states<RECON, CURV>(q, st, gl, gr, L.vy, R.vy);
       q = f.prim[b * nv + ivz] + c;
-      recon_cell<RECON>(q - st, st, L.vz, unused), recon_cell<RECON>(q, st, unused, R.vz);
+      face_states<RECON, CURV>(q, st, gl, gr, L.vz, R.vz);
       q = f.prim[b * nv + IPR] + c;
-      recon_cell<RECON>(q - st, st, L.p, unused), recon_cell<RECON>(q, st, unused, R.p);
+      face_states<RECON, CURV>(q, st, gl, gr, L.p, R.p);
       q = f.prim[b * nv + ISE] + c;
-      recon_cell<RECON>(q - st, st, L.e, unused), recon_cell<RECON>(q, st, unused, R.e);
+      face_states<RECON, CURV>(q, st, gl, gr, L.e, R.e);
       riemann_gas<RIEMANN>(P.gm1, L, R, F);
+      if constexpr (CURV) F.fmx *= hs[d], F.fmy *= hs[(d + 1) % 3], F.fmz *= hs[(d + 2) % 3];
       f.flux[d][b * nv + IDN][c] = F.fd;
       f.flux[d][b * nv + ivx][c] = F.fmx;
       f.flux[d][b * nv + ivy][c] = F.fmy;
@@ -82,14 +106,15 @@ __global__ __launch_bounds__(TX *TY) void flux_kernel(const PackView P, const Ra
       Prim4 L, R;
       const double *q;
       q = f.prim[b * nv + IDN] + c;
-      recon_cell<RECON>(q - st, st, L.d, unused), recon_cell<RECON>(q, st, unused, R.d);
+      face_states<RECON, CURV>(q, st, gl, gr, L.d, R.d);
       q = f.prim[b * nv + ivx] + c;
-      recon_cell<RECON>(q - st, st, L.vx, unused), recon_cell<RECON>(q, st, unused, R.vx);
+      face_states<RECON, CURV>(q, st, gl, gr, L.vx, R.vx);
       q = f.prim[b * nv + ivy] + c;
-      recon_cell<RECON>(q - st, st, L.vy, unused), recon_cell<RECON>(q, st, unused, R.vy);
+      face_states<RECON, CURV>(q, st, gl, gr, L.vy, R.vy);
       q = f.prim[b * nv + ivz] + c;
-      recon_cell<RECON>(q - st, st, L.vz, unused), recon_cell<RECON>(q, st, unused, R.vz);
+      face_states<RECON, CURV>(q, st, gl, gr, L.vz, R.vz);
       riemann_dust<RIEMANN>(L, R, F);
+      if constexpr (CURV) F.fmx *= hs[d], F.fmy *= hs[(d + 1) % 3], F.fmz *= hs[(d + 2) % 3];
       f.flux[d][b * nv + IDN][c] = F.fd;
       f.flux[d][b * nv + ivx][c] = F.fmx;
       f.flux[d][b * nv + ivy][c] = F.fmy;
@@ -105,8 +130,12 @@ void launch_flux_dirs(const PackView &P, hipStream_t s) {
     if (dir == 1) r.iu = P.ie + 1; // fluid_fluxes.hpp:105
     if (dir == 2) r.ju = P.je + 1; // :130 (faces js..je+1)
     if (dir == 3) r.ku = P.ke + 1; // :172
-    hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON>), grid_for(r, P.nb), dim3(TX, TY), 0, s,
-                       P, r, dir);
+    if (P.coords == ARTEMIS_CARTESIAN)
+      hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, false>), grid_for(r, P.nb),
+                         dim3(TX, TY), 0, s, P, r, dir);
+    else
+      hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, true>), grid_for(r, P.nb),
+                         dim3(TX, TY), 0, s, P, r, dir);
   }
 }
 template <int FLUID, int RIEMANN>
@@ -118,94 +147,146 @@ void launch_flux_recon(const PackView &P, int recon, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------
 // ApplyUpdate (artemis_integrator.hpp:79-108)
+struct CellMetric {
+  double ax1[2], ax2[2], ax3[2], vol; // GetFaceAreaX?, Volume
+  double dx[3];                       // coordinate widths bnds.x?[1] - bnds.x?[0]
+};
+template <bool CURV>
+__device__ __forceinline__ CellMetric cell_metric(const PackView &P, int b, int k, int j, int i) {
+  CellMetric m;
+  if constexpr (CURV) {
+    const DCoords co = make_coords(P, b, k, j, i);
+    m.ax1[0] = co.area1(0), m.ax1[1] = co.area1(1);
+    m.ax2[0] = co.area2(0), m.ax2[1] = co.area2(1);
+    m.ax3[0] = co.area3(0), m.ax3[1] = co.area3(1);
+    m.vol = co.volume();
+    m.dx[0] = co.x1[1] - co.x1[0], m.dx[1] = co.x2[1] - co.x2[0], m.dx[2] = co.x3[1] - co.x3[0];
+  } else {
+    const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
+    m.ax1[0] = m.ax1[1] = g.dx2 * g.dx3; // geometry.hpp:199-204
+    m.ax2[0] = m.ax2[1] = g.dx1 * g.dx3; // :205-210
+    m.ax3[0] = m.ax3[1] = g.dx1 * g.dx2; // :211-216
+    m.vol = g.dx1 * g.dx2 * g.dx3;       // :219-225
+    m.dx[0] = g.dx1, m.dx[1] = g.dx2, m.dx[2] = g.dx3;
+  }
+  return m;
+}
+
 template <int FLUID>
 __device__ __forceinline__ void update_fluid(const PackView &P, const FluidView &f, int b, long c,
-                                             const CellGeom &g, double gam0, double gam1,
+                                             const CellMetric &g, double gam0, double gam1,
                                              double beta_dt) {
   const int nv = (FLUID == 0 ? 6 : 4) * f.ns;
   const bool multi_d = P.ndim > 1, three_d = P.ndim > 2;
-  const double ax1 = g.dx2 * g.dx3; // geometry.hpp:199-204
-  const double ax2 = g.dx1 * g.dx3; // :205-210
-  const double ax3 = g.dx1 * g.dx2; // :211-216
-  const double vol = g.dx1 * g.dx2 * g.dx3; // :219-225
   for (int n = 0; n < nv; ++n) {
     const double *f1 = f.flux[0][b * nv + n];
-    double divf = (ax1 * f1[c] - ax1 * f1[c + 1]);
+    double divf = (g.ax1[0] * f1[c] - g.ax1[1] * f1[c + 1]);
     if (multi_d) {
       const double *f2 = f.flux[1][b * nv + n];
-      divf += (ax2 * f2[c] - ax2 * f2[c + P.sj]);
+      divf += (g.ax2[0] * f2[c] - g.ax2[1] * f2[c + P.sj]);
     }
     if (three_d) {
       const double *f3 = f.flux[2][b * nv + n];
-      divf += (ax3 * f3[c] - ax3 * f3[c + P.sk]);
+      divf += (g.ax3[0] * f3[c] - g.ax3[1] * f3[c + P.sk]);
     }
     double *v0 = f.cons0[b * nv + n];
     const double *v1 = f.cons1[b * nv + n];
-    v0[c] = gam0 * v0[c] + gam1 * v1[c] + divf * beta_dt / vol;
+    v0[c] = gam0 * v0[c] + gam1 * v1[c] + divf * beta_dt / g.vol;
   }
 }
+template <bool CURV>
 __global__ __launch_bounds__(TX *TY) void apply_update_kernel(const PackView P, const Range3 r,
                                                               double gam0, double gam1,
                                                               double beta_dt) {
   CELL_FROM_GRID(r)
-  const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
+  const CellMetric g = cell_metric<CURV>(P, b, k, j, i);
   if (P.gas.ns) update_fluid<0>(P, P.gas, b, c, g, gam0, gam1, beta_dt);
   if (P.dust.ns) update_fluid<1>(P, P.dust, b, c, g, gam0, gam1, beta_dt);
 }
 
 // ---------------------------------------------------------------------------------------
-// FluxSourceImpl, gas, Cartesian (fluid_fluxes.hpp:323-393).  Interior cells only.
+// FluxSourceImpl (fluid_fluxes.hpp:323-418), interior cells only.  Gas: pressure gradient
+// and P div(v) work (:361-393).  Metric-dependent systems, both fluids: coordinate source
+// rho*dt*sum_d dh_d/dx_a*v_d^2 on momentum a (:395-415; the rotating-frame velocity is zero
+// without <rotating_frame>).
+template <int FLUID, bool CURV>
 __global__ __launch_bounds__(TX *TY) void flux_source_kernel(const PackView P, const Range3 r,
                                                              double dt) {
   CELL_FROM_GRID(r)
-  const FluidView &f = P.gas;
-  const int ns = f.ns, nv = 6 * ns;
+  const FluidView &f = (FLUID == 0) ? P.gas : P.dust;
+  const int ns = f.ns, nv = (FLUID == 0 ? 6 : 4) * ns;
   const bool multi_d = P.ndim >= 2, three_d = P.ndim == 3;
-  const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
-  const double ax1 = g.dx2 * g.dx3, ax2 = g.dx1 * g.dx3, ax3 = g.dx1 * g.dx2;
-  const double vol = g.dx1 * g.dx2 * g.dx3;
+  const CellMetric g = cell_metric<CURV>(P, b, k, j, i);
   for (int n = 0; n < ns; ++n) {
     double *mx = f.cons0[b * nv + ns + 3 * n + 0];
     double *my = f.cons0[b * nv + ns + 3 * n + 1];
     double *mz = f.cons0[b * nv + ns + 3 * n + 2];
-    double *eg = f.cons0[b * nv + 5 * ns + n];
-    const double *p1 = f.pflux[0][b * ns + n], *v1 = f.vface[0][b * ns + n];
-    double m = mx[c], e = eg[c];
-    m += dt / g.dx1 * (p1[c] - p1[c + 1]);
-    e -= dt / vol * 0.5 * (p1[c] + p1[c + 1]) * (ax1 * v1[c + 1] - ax1 * v1[c]);
-    mx[c] = m;
-    if (multi_d) {
-      const double *p2 = f.pflux[1][b * ns + n], *v2 = f.vface[1][b * ns + n];
-      double m2 = my[c];
-      m2 += dt / g.dx2 * (p2[c] - p2[c + P.sj]);
-      e -= dt / vol * 0.5 * (p2[c] + p2[c + P.sj]) * (ax2 * v2[c + P.sj] - ax2 * v2[c]);
-      my[c] = m2;
+    double m1 = mx[c], m2 = multi_d || CURV ? my[c] : 0.0;
+    if constexpr (FLUID == 0) {
+      double *eg = f.cons0[b * nv + 5 * ns + n];
+      const double *p1 = f.pflux[0][b * ns + n], *v1 = f.vface[0][b * ns + n];
+      double e = eg[c];
+      m1 += dt / g.dx[0] * (p1[c] - p1[c + 1]);
+      e -= dt / g.vol * 0.5 * (p1[c] + p1[c + 1]) * (g.ax1[1] * v1[c + 1] - g.ax1[0] * v1[c]);
+      if (multi_d) {
+        const double *p2 = f.pflux[1][b * ns + n], *v2 = f.vface[1][b * ns + n];
+        m2 += dt / g.dx[1] * (p2[c] - p2[c + P.sj]);
+        e -= dt / g.vol * 0.5 * (p2[c] + p2[c + P.sj]) *
+             (g.ax2[1] * v2[c + P.sj] - g.ax2[0] * v2[c]);
+      }
+      if (three_d) {
+        const double *p3 = f.pflux[2][b * ns + n], *v3 = f.vface[2][b * ns + n];
+        double m3 = mz[c];
+        m3 += dt / g.dx[2] * (p3[c] - p3[c + P.sk]);
+        e -= dt / g.vol * 0.5 * (p3[c] + p3[c + P.sk]) *
+             (g.ax3[1] * v3[c + P.sk] - g.ax3[0] * v3[c]);
+        mz[c] = m3;
+      }
+      eg[c] = e;
     }
-    if (three_d) {
-      const double *p3 = f.pflux[2][b * ns + n], *v3 = f.vface[2][b * ns + n];
-      double m3 = mz[c];
-      m3 += dt / g.dx3 * (p3[c] - p3[c + P.sk]);
-      e -= dt / vol * 0.5 * (p3[c] + p3[c + P.sk]) * (ax3 * v3[c + P.sk] - ax3 * v3[c]);
-      mz[c] = m3;
+    if constexpr (CURV) {
+      const DCoords co = make_coords(P, b, k, j, i);
+      const double rdt = f.prim[b * nv + n][c] * dt;
+      const double vx = f.prim[b * nv + ns + 3 * n + 0][c];
+      const double vy = f.prim[b * nv + ns + 3 * n + 1][c];
+      const double vz = f.prim[b * nv + ns + 3 * n + 2][c];
+      if (co.x1dep())
+        m1 += rdt * (0.0 * sqr(vx) + co.dh2dx1() * sqr(vy) + co.dh3dx1() * sqr(vz));
+      if (co.x2dep() && multi_d) {
+        m2 += rdt * (0.0 * sqr(vx) + 0.0 * sqr(vy) + co.dh3dx2() * sqr(vz));
+      }
     }
-    eg[c] = e;
+    mx[c] = m1;
+    if (multi_d || CURV) my[c] = m2;
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // SetAuxillaryFields (fill_derived.cpp:54-73) + GetSpecificInternalEnergy
 // (artemis_utils.hpp:43-62); Cartesian scale factors are 1.
+template <bool CURV>
+__device__ __forceinline__ void scale_factors(const PackView &P, int b, int k, int j, int i,
+                                              double hx[3]) {
+  hx[0] = 1.0, hx[1] = 1.0, hx[2] = 1.0; // GetScaleFactors (geometry.hpp:384-388)
+  if constexpr (CURV) {
+    const DCoords co = make_coords(P, b, k, j, i);
+    hx[1] = co.hx2v(), hx[2] = co.hx3v();
+  }
+}
+template <bool CURV>
 __global__ __launch_bounds__(TX *TY) void set_aux_kernel(const PackView P, const Range3 r) {
   CELL_FROM_GRID(r)
   const FluidView &f = P.gas;
   const int ns = f.ns, nv = 6 * ns;
+  double hx[3];
+  scale_factors<CURV>(P, b, k, j, i, hx);
   for (int n = 0; n < ns; ++n) {
     const double D = f.cons0[b * nv + n][c];
     const double u_d = (D > f.dfloor) ? D : f.dfloor;
     const double u_d2 = amax(D, f.dfloor);
-    const double rv1 = f.cons0[b * nv + ns + 3 * n + 0][c] / 1.0;
-    const double rv2 = f.cons0[b * nv + ns + 3 * n + 1][c] / 1.0;
-    const double rv3 = f.cons0[b * nv + ns + 3 * n + 2][c] / 1.0;
+    const double rv1 = f.cons0[b * nv + ns + 3 * n + 0][c] / hx[0];
+    const double rv2 = f.cons0[b * nv + ns + 3 * n + 1][c] / hx[1];
+    const double rv3 = f.cons0[b * nv + ns + 3 * n + 2][c] / hx[2];
     const double ke = 0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)) / u_d2;
     const double e_cons = f.cons0[b * nv + 4 * ns + n][c];
     const double ue_cons = e_cons - ke;
@@ -220,8 +301,11 @@ __global__ __launch_bounds__(TX *TY) void set_aux_kernel(const PackView P, const
 }
 
 // ConsToPrim (fill_derived.cpp:120-166), interior
+template <bool CURV>
 __global__ __launch_bounds__(TX *TY) void cons_to_prim_kernel(const PackView P, const Range3 r) {
   CELL_FROM_GRID(r)
+  double hx[3];
+  scale_factors<CURV>(P, b, k, j, i, hx);
   {
     const FluidView &f = P.gas;
     const int ns = f.ns, nv = 6 * ns;
@@ -230,7 +314,7 @@ __global__ __launch_bounds__(TX *TY) void cons_to_prim_kernel(const PackView P, 
       const double w_d = (u_d > f.dfloor) ? u_d : f.dfloor;
       f.prim[b * nv + n][c] = w_d;
       for (int d = 0; d < 3; ++d)
-        f.prim[b * nv + ns + 3 * n + d][c] = f.cons0[b * nv + ns + 3 * n + d][c] / (w_d * 1.0);
+        f.prim[b * nv + ns + 3 * n + d][c] = f.cons0[b * nv + ns + 3 * n + d][c] / (w_d * hx[d]);
       const double w_s = f.cons0[b * nv + 5 * ns + n][c] / w_d;
       f.prim[b * nv + 5 * ns + n][c] = (w_s > f.siefloor) ? w_s : f.siefloor;
     }
@@ -243,15 +327,18 @@ __global__ __launch_bounds__(TX *TY) void cons_to_prim_kernel(const PackView P, 
       const double w_d = (u_d > f.dfloor) ? u_d : f.dfloor;
       f.prim[b * nv + n][c] = w_d;
       for (int d = 0; d < 3; ++d)
-        f.prim[b * nv + ns + 3 * n + d][c] = f.cons0[b * nv + ns + 3 * n + d][c] / (w_d * 1.0);
+        f.prim[b * nv + ns + 3 * n + d][c] = f.cons0[b * nv + ns + 3 * n + d][c] / (w_d * hx[d]);
     }
   }
 }
 
 // PrimToCons (fill_derived.cpp:212-276), entire block.  P = IdealGas (gm1*rho)*sie clamped
 // at 0 (singularity-eos, recalled).
+template <bool CURV>
 __global__ __launch_bounds__(TX *TY) void prim_to_cons_kernel(const PackView P, const Range3 r) {
   CELL_FROM_GRID(r)
+  double hx[3];
+  scale_factors<CURV>(P, b, k, j, i, hx);
   {
     const FluidView &f = P.gas;
     const int ns = f.ns, nv = 6 * ns;
@@ -263,9 +350,9 @@ __global__ __launch_bounds__(TX *TY) void prim_to_cons_kernel(const PackView P, 
       const double vel1 = f.prim[b * nv + ns + 3 * n + 0][c];
       const double vel2 = f.prim[b * nv + ns + 3 * n + 1][c];
       const double vel3 = f.prim[b * nv + ns + 3 * n + 2][c];
-      f.cons0[b * nv + ns + 3 * n + 0][c] = w_d * vel1 * 1.0;
-      f.cons0[b * nv + ns + 3 * n + 1][c] = w_d * vel2 * 1.0;
-      f.cons0[b * nv + ns + 3 * n + 2][c] = w_d * vel3 * 1.0;
+      f.cons0[b * nv + ns + 3 * n + 0][c] = w_d * vel1 * hx[0];
+      f.cons0[b * nv + ns + 3 * n + 1][c] = w_d * vel2 * hx[1];
+      f.cons0[b * nv + ns + 3 * n + 2][c] = w_d * vel3 * hx[2];
       double w_s = f.prim[b * nv + 5 * ns + n][c];
       w_s = (w_s > f.siefloor) ? w_s : f.siefloor;
       f.prim[b * nv + 5 * ns + n][c] = w_s;
@@ -285,7 +372,7 @@ __global__ __launch_bounds__(TX *TY) void prim_to_cons_kernel(const PackView P, 
       f.prim[b * nv + n][c] = w_d;
       f.cons0[b * nv + n][c] = w_d;
       for (int d = 0; d < 3; ++d)
-        f.cons0[b * nv + ns + 3 * n + d][c] = w_d * f.prim[b * nv + ns + 3 * n + d][c] * 1.0;
+        f.cons0[b * nv + ns + 3 * n + d][c] = w_d * f.prim[b * nv + ns + 3 * n + d][c] * hx[d];
     }
   }
 }
@@ -303,7 +390,7 @@ __global__ __launch_bounds__(TX *TY) void deep_copy_kernel(const PackView P, con
 // EstimateTimestepMesh (gas.cpp:411-433, dust.cpp:256-272): wave64 shuffle min -> LDS min over
 // the 4 waves -> one atomicMin per workgroup on the bit pattern (positive doubles order like
 // unsigned integers).
-template <int FLUID>
+template <int FLUID, bool CURV>
 __global__ __launch_bounds__(TX *TY) void estimate_dt_kernel(const PackView P, const Range3 r,
                                                              double cfl,
                                                              unsigned long long *dt_bits) {
@@ -315,8 +402,14 @@ __global__ __launch_bounds__(TX *TY) void estimate_dt_kernel(const PackView P, c
   double ldt = DBL_MAX;
   if (i <= r.iu && j <= r.ju) {
     const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
-    const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
-    const double dx[3] = {1.0 * g.dx1, 1.0 * g.dx2, 1.0 * g.dx3};
+    double dx[3]; // GetCellWidths (geometry.hpp:352-361)
+    if constexpr (CURV) {
+      const DCoords co = make_coords(P, b, k, j, i);
+      dx[0] = co.width1(), dx[1] = co.width2(), dx[2] = co.width3();
+    } else {
+      const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
+      dx[0] = 1.0 * g.dx1, dx[1] = 1.0 * g.dx2, dx[2] = 1.0 * g.dx3;
+    }
     const FluidView &f = (FLUID == 0) ? P.gas : P.dust;
     const int ns = f.ns, nv = (FLUID == 0 ? 6 : 4) * ns;
     for (int n = 0; n < ns; ++n) {
@@ -532,26 +625,44 @@ void launch_calculate_fluxes(const PackView &P, int fluid, int riemann, int reco
 static Range3 interior(const PackView &P) { return Range3{P.is, P.ie, P.js, P.je, P.ks, P.ke}; }
 static Range3 entire(const PackView &P) { return Range3{0, P.ni - 1, 0, P.nj - 1, 0, P.nk - 1}; }
 
+// CURV = any non-Cartesian system; the Cartesian instantiations are the ones the fused kernel
+// is checked against and keep their constant-folded unit scale factors.
+#define LAUNCH_GEOM(kern, r, ...)                                                               \
+  do {                                                                                          \
+    if (P.coords == ARTEMIS_CARTESIAN)                                                          \
+      hipLaunchKernelGGL((kern<false>), grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r,            \
+                         ##__VA_ARGS__);                                                        \
+    else                                                                                        \
+      hipLaunchKernelGGL((kern<true>), grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r,             \
+                         ##__VA_ARGS__);                                                        \
+  } while (0)
+
 void launch_apply_update(const PackView &P, double gam0, double gam1, double beta_dt, hipStream_t s) {
   const Range3 r = interior(P);
-  hipLaunchKernelGGL(apply_update_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r, gam0, gam1,
-                     beta_dt);
+  LAUNCH_GEOM(apply_update_kernel, r, gam0, gam1, beta_dt);
 }
-void launch_flux_source_gas(const PackView &P, double dt, hipStream_t s) {
+void launch_flux_source(const PackView &P, int fluid, double dt, hipStream_t s) {
   const Range3 r = interior(P);
-  hipLaunchKernelGGL(flux_source_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r, dt);
+  const dim3 g = grid_for(r, P.nb), t(TX, TY);
+  const bool curv = P.coords != ARTEMIS_CARTESIAN;
+  if (fluid == ARTEMIS_GAS) {
+    if (curv) hipLaunchKernelGGL((flux_source_kernel<0, true>), g, t, 0, s, P, r, dt);
+    else hipLaunchKernelGGL((flux_source_kernel<0, false>), g, t, 0, s, P, r, dt);
+  } else if (curv) { // Dust::FluxSource skips metric-free systems (dust.cpp:310-311)
+    hipLaunchKernelGGL((flux_source_kernel<1, true>), g, t, 0, s, P, r, dt);
+  }
 }
 void launch_set_aux(const PackView &P, hipStream_t s) {
   const Range3 r = interior(P);
-  hipLaunchKernelGGL(set_aux_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
+  LAUNCH_GEOM(set_aux_kernel, r);
 }
 void launch_cons_to_prim(const PackView &P, hipStream_t s) {
   const Range3 r = interior(P);
-  hipLaunchKernelGGL(cons_to_prim_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
+  LAUNCH_GEOM(cons_to_prim_kernel, r);
 }
 void launch_prim_to_cons(const PackView &P, hipStream_t s) {
   const Range3 r = entire(P);
-  hipLaunchKernelGGL(prim_to_cons_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
+  LAUNCH_GEOM(prim_to_cons_kernel, r);
 }
 void launch_deep_copy(const PackView &P, hipStream_t s) {
   const Range3 r = entire(P);
@@ -560,10 +671,15 @@ void launch_deep_copy(const PackView &P, hipStream_t s) {
 void launch_estimate_dt(const PackView &P, int fluid, double cfl, double *dt_dev, hipStream_t s) {
   const Range3 r = interior(P);
   auto *bits = reinterpret_cast<unsigned long long *>(dt_dev);
-  if (fluid == ARTEMIS_GAS)
-    hipLaunchKernelGGL(estimate_dt_kernel<0>, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r, cfl, bits);
-  else
-    hipLaunchKernelGGL(estimate_dt_kernel<1>, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r, cfl, bits);
+  const dim3 g = grid_for(r, P.nb), t(TX, TY);
+  const bool curv = P.coords != ARTEMIS_CARTESIAN;
+  if (fluid == ARTEMIS_GAS) {
+    if (curv) hipLaunchKernelGGL((estimate_dt_kernel<0, true>), g, t, 0, s, P, r, cfl, bits);
+    else hipLaunchKernelGGL((estimate_dt_kernel<0, false>), g, t, 0, s, P, r, cfl, bits);
+  } else {
+    if (curv) hipLaunchKernelGGL((estimate_dt_kernel<1, true>), g, t, 0, s, P, r, cfl, bits);
+    else hipLaunchKernelGGL((estimate_dt_kernel<1, false>), g, t, 0, s, P, r, cfl, bits);
+  }
 }
 
 void invalidate_table_cache() {} // nothing is cached on the host any more

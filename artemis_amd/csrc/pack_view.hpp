@@ -25,6 +25,8 @@ struct PackView {
   long sj, sk;                // strides of j and k
   double gm1;
   const double *geom; // [nb][6]
+  int coords;           // enum artemis_coords
+  const double *metric; // [nb][5][nj+1] x2 trig tables (spherical2D/3D), else null
   FluidView gas, dust;
 };
 
@@ -50,6 +52,8 @@ inline PackView make_pack_view(const artemis_pack_t &p) {
   v.sj = v.ni, v.sk = static_cast<long>(v.ni) * v.nj;
   v.gm1 = p.gm1;
   v.geom = p.geom;
+  v.coords = p.coords;
+  v.metric = p.metric;
   v.gas = make_fluid_view(p.gas);
   v.dust = make_fluid_view(p.dust);
   return v;

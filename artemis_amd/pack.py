@@ -26,7 +26,7 @@ class MeshBlockPack:
     def __init__(self, nblocks, nx, xmin, xmax, ng=2, ns_gas=1, ns_dust=0, reconstruct="plm",
                  riemann="hllc", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.66666666667,
                  dfloor=1.0e-20, siefloor=1.0e-20, de_switch=0.0, dust_dfloor=1.0e-20,
-                 device="cuda:0", with_fluxes=True):
+                 device="cuda:0", with_fluxes=True, coordinates="cartesian"):
         """xmin/xmax: per-block interior bounds, arrays of shape [nblocks, 3]."""
         self.L = capi.load()
         self.dev = torch.device(device)
@@ -71,7 +71,7 @@ class MeshBlockPack:
         p = capi.Pack()
         p.nblocks, p.nghost = nblocks, ng
         p.nx1, p.nx2, p.nx3 = self.nx
-        p.coords = capi.CARTESIAN
+        p.coords = capi.coord_select(coordinates, self.ndim)
         p.gm1 = gamma - 1.0
         p.geom = self.geom.data_ptr()
         p.gas.nspecies, p.gas.recon, p.gas.riemann = ns_gas, capi.RECON[reconstruct], capi.RSOLVER[riemann]
@@ -84,6 +84,13 @@ class MeshBlockPack:
             p.gas.flux[d], p.gas.pflux[d], p.gas.vface[d] = tab(self.gas_flux[d]), tab(self.gas_pflux[d]), tab(self.gas_vface[d])
             p.dust.flux[d] = tab(self.dust_flux[d])
         self.pack = p
+        # x2 trigonometry tables of spherical2D/3D (host libm, see include/artemis_hip.h)
+        nmetric = self.L.artemis_hip_metric_count(C.byref(p))
+        if nmetric > 0:
+            mt = np.zeros(nmetric)
+            capi.check(self.L.artemis_hip_metric_fill(C.byref(p), geom.ctypes.data, mt.ctypes.data))
+            self.metric = torch.from_numpy(mt).to(self.dev)
+            p.metric = self.metric.data_ptr()
         self.gas_prim_table = p.gas.prim
         self._extra_prim = {}
 

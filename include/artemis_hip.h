@@ -75,11 +75,14 @@ typedef struct artemis_pack {
   int nblocks;               /* MeshData::NumBlocks() */
   int nghost;                /* parthenon/mesh/nghost */
   int nx1, nx2, nx3;         /* interior cells per block (parthenon/meshblock) */
-  int coords;                /* artemis/coordinates; only ARTEMIS_CARTESIAN is built */
+  int coords;                /* artemis/coordinates after geometry::CoordSelect (geometry.hpp:38-56) */
   double gm1;                /* gamma - 1 = IdealGas Gruneisen parameter (hllc.hpp:60) */
   const double *geom;        /* DEVICE [nblocks][6] = {x1f0, dx1, x2f0, dx2, x3f0, dx3}:
                                 Coordinates_t::Xf<d>(idx) = xf0 + idx*dx, idx counted from the
                                 first ghost cell (geometry.hpp:65-72) */
+  const double *metric;      /* DEVICE x2 trigonometry tables, required for spherical2D/3D only
+                                (NULL otherwise): artemis_hip_metric_count() doubles filled by
+                                artemis_hip_metric_fill() */
   artemis_fluid_pack_t gas, dust;
 } artemis_pack_t;
 
@@ -124,6 +127,15 @@ int artemis_hip_estimate_dt(const artemis_pack_t *p, int fluid, double cfl, doub
  * initialises it, e.g. to DBL_MAX). */
 int artemis_hip_estimate_dt_async(const artemis_pack_t *p, int fluid, double cfl, double *dt_dev,
                                   void *stream);
+
+/* Metric tables for artemis/coordinates = spherical in 2-D/3-D.  geometry::Coords<spherical2D|
+ * 3D> (spherical.hpp:61-146) evaluates cos/sin of the x2 faces, the x2 centroid and the x2
+ * midpoint in every cell; all depend on j only, so the adapter tabulates them once per mesh
+ * with the host libm.  artemis_hip_metric_count = number of doubles (0 when the system needs
+ * no table); artemis_hip_metric_fill writes them to HOST memory from a HOST copy of p->geom
+ * (p->geom itself is a device pointer and is not read).  Upload the result and set p->metric. */
+long artemis_hip_metric_count(const artemis_pack_t *p);
+int artemis_hip_metric_fill(const artemis_pack_t *p, const double *geom_host, double *out_host);
 
 /* Physical boundary conditions on the FillGhost primitives (gas rho, v, sie; dust rho, v;
  * gas.cpp:244-270, dust.cpp:201-213) of every block: bc[b*6 + {ix1,ox1,ix2,ox2,ix3,ox3}]

@@ -57,6 +57,7 @@ struct oracle_cfg {
   int bc[6]; // ix1, ox1, ix2, ox2, ix3, ox3
   int integrator;
   int nthreads;
+  int coords; // artemis.hpp:78-86 order: cartesian, cylindrical, spherical1D/2D/3D, axisymmetric
 };
 }
 
@@ -120,6 +121,230 @@ inline Real x1v(const BBox &b) { return 0.5 * (b.x1[0] + b.x1[1]); }
 inline Real x2v(const BBox &b) { return 0.5 * (b.x2[0] + b.x2[1]); }
 inline Real x3v(const BBox &b) { return 0.5 * (b.x3[0] + b.x3[1]); }
 
+
+// ---------------------------------------------------------------------------------------
+// geometry::Coords<GEOM> (geometry.hpp:145-420 base = Cartesian defaults; cylindrical.hpp:28-80;
+// spherical.hpp:36-146 (3D), :240-345 (2D), :441-512 (1D); axisymmetric.hpp:27-75).  The
+// reference uses CRTP classes; here one class switches on the runtime enum and every method
+// restates the expression of the class that overrides it (or the base default).
+enum { CO_CART = 0, CO_CYL = 1, CO_SPH1D = 2, CO_SPH2D = 3, CO_SPH3D = 4, CO_AXI = 5 };
+struct Coords {
+  int sys;
+  BBox bnds;
+  Coords(const Sim &s, int k, int j, int i);
+  bool sph23() const { return sys == CO_SPH2D || sys == CO_SPH3D; }
+  bool sph() const { return sys == CO_SPH1D || sph23(); }
+  // geometry.hpp:98-110
+  bool x1dep() const { return sph() || sys == CO_CYL || sys == CO_AXI; }
+  bool x2dep() const { return sph23(); }
+  bool x3dep() const { return false; }
+
+  Real x1v() const {
+    if (sph()) { // spherical.hpp:57-60, :261-264, :458-461
+      const Real dr2 = bnds.x1[0] * bnds.x1[0] + bnds.x1[1] * bnds.x1[1];
+      return 0.75 * (bnds.x1[0] + bnds.x1[1]) * dr2 / (dr2 + bnds.x1[0] * bnds.x1[1]);
+    }
+    if (sys == CO_CYL || sys == CO_AXI) // cylindrical.hpp:41-45, axisymmetric.hpp:38-42
+      return 2.0 / 3.0 *
+             (bnds.x1[0] * bnds.x1[0] + bnds.x1[0] * bnds.x1[1] + bnds.x1[1] * bnds.x1[1]) /
+             (bnds.x1[0] + bnds.x1[1]);
+    return 0.5 * (bnds.x1[0] + bnds.x1[1]); // geometry.hpp:163
+  }
+  Real x2v() const {
+    if (sph23()) { // spherical.hpp:61-68, :265-270
+      const Real ctm = std::cos(bnds.x2[0]);
+      const Real ctp = std::cos(bnds.x2[1]);
+      const Real dst = std::sin(bnds.x2[1]) - std::sin(bnds.x2[0]);
+      return (dst - bnds.x2[1] * ctp + bnds.x2[0] * ctm) / std::abs(ctm - ctp);
+    }
+    return 0.5 * (bnds.x2[0] + bnds.x2[1]);
+  }
+  Real x3v() const { return 0.5 * (bnds.x3[0] + bnds.x3[1]); }
+
+  Real hx1(Real, Real, Real) const { return 1.0; }
+  Real hx2(Real x1, Real, Real) const { // spherical.hpp:50,254,454; cylindrical.hpp:47
+    return (sph() || sys == CO_CYL) ? x1 : 1.0;
+  }
+  Real hx3(Real x1, Real x2, Real) const {
+    if (sph23()) return x1 * std::sin(x2); // spherical.hpp:53-55, :257-259
+    if (sys == CO_AXI) return x1;          // axisymmetric.hpp:43-45
+    return 1.0;                            // spherical1D and cylindrical keep the base default
+  }
+  Real hx1v() const { return 1.0; }
+  Real hx2v() const { // spherical.hpp:70,274; cylindrical.hpp:51 (spherical1D: base default)
+    return (sph23() || sys == CO_CYL) ? x1v() : 1.0;
+  }
+  Real hx3v() const {
+    if (sph23()) { // spherical.hpp:71-82, :275-286
+      const Real ctm = std::cos(bnds.x2[0]);
+      const Real ctp = std::cos(bnds.x2[1]);
+      const Real stm = std::sin(bnds.x2[0]);
+      const Real stp = std::sin(bnds.x2[1]);
+      const Real dsc = stp * ctp - stm * ctm;
+      const Real dx2 = bnds.x2[1] - bnds.x2[0];
+      return x1v() * 0.5 * (dx2 - dsc) / std::abs(ctm - ctp);
+    }
+    if (sys == CO_AXI) return x1v(); // axisymmetric.hpp:46
+    return 1.0;
+  }
+  Real rcen() const { // the 2/3 (r0^2+r0r1+r1^2)/(r0+r1) face-centroid radius
+    return 2.0 / 3.0 *
+           (bnds.x1[0] * bnds.x1[0] + bnds.x1[0] * bnds.x1[1] + bnds.x1[1] * bnds.x1[1]) /
+           (bnds.x1[0] + bnds.x1[1]);
+  }
+  // geometry.hpp:182-197 defaults; overrides spherical.hpp:88-104, :288-304, :463-479,
+  // cylindrical.hpp:53-60 (X3 only), axisymmetric.hpp:47-54 (X2 only)
+  void FaceCenX1(int f, Real xf[3]) const {
+    xf[0] = bnds.x1[f];
+    xf[1] = x2v();
+    xf[2] = x3v();
+  }
+  void FaceCenX2(int f, Real xf[3]) const {
+    if (sys == CO_SPH3D || sys == CO_AXI) {
+      xf[0] = rcen(), xf[1] = bnds.x2[f], xf[2] = 0.5 * (bnds.x3[0] + bnds.x3[1]);
+    } else if (sys == CO_SPH2D) {
+      xf[0] = rcen(), xf[1] = bnds.x2[f], xf[2] = 0.0;
+    } else if (sys == CO_SPH1D) {
+      xf[0] = rcen(), xf[1] = M_PI * 0.5, xf[2] = 0.0;
+    } else {
+      xf[0] = x1v(), xf[1] = bnds.x2[f], xf[2] = x3v();
+    }
+  }
+  void FaceCenX3(int f, Real xf[3]) const {
+    if (sys == CO_SPH3D || sys == CO_CYL) {
+      xf[0] = rcen(), xf[1] = 0.5 * (bnds.x2[0] + bnds.x2[1]), xf[2] = bnds.x3[f];
+    } else if (sys == CO_SPH2D) {
+      xf[0] = rcen(), xf[1] = 0.5 * (bnds.x2[0] + bnds.x2[1]), xf[2] = 0.0;
+    } else if (sys == CO_SPH1D) {
+      xf[0] = rcen(), xf[1] = M_PI * 0.5, xf[2] = 0.0;
+    } else {
+      xf[0] = x1v(), xf[1] = x2v(), xf[2] = bnds.x3[f];
+    }
+  }
+  Real AreaX1(const Real x1f) const {
+    const Real dx2 = bnds.x2[1] - bnds.x2[0];
+    const Real dx3 = bnds.x3[1] - bnds.x3[0];
+    switch (sys) {
+    case CO_SPH3D: // spherical.hpp:106-109
+      return x1f * x1f * std::abs(std::cos(bnds.x2[0]) - std::cos(bnds.x2[1])) * dx3;
+    case CO_SPH2D: // :306-308
+      return x1f * x1f * std::abs(std::cos(bnds.x2[0]) - std::cos(bnds.x2[1]));
+    case CO_SPH1D: // :481-483
+      return x1f * x1f;
+    case CO_CYL: // cylindrical.hpp:62-66
+    case CO_AXI: // axisymmetric.hpp:55-59
+      return x1f * dx2 * dx3;
+    default:
+      return dx2 * dx3; // geometry.hpp:199-204
+    }
+  }
+  Real AreaX2(const Real x2f) const {
+    const Real dx1 = bnds.x1[1] - bnds.x1[0];
+    const Real dx3 = bnds.x3[1] - bnds.x3[0];
+    switch (sys) {
+    case CO_SPH3D: // spherical.hpp:110-114
+      return 0.5 * (bnds.x1[1] + bnds.x1[0]) * std::sin(x2f) * dx1 * dx3;
+    case CO_SPH2D: // :309-312
+      return 0.5 * (bnds.x1[1] + bnds.x1[0]) * std::sin(x2f) * dx1;
+    case CO_SPH1D: // :484-487
+      return 0.5 * (bnds.x1[1] + bnds.x1[0]) * dx1;
+    case CO_AXI: // axisymmetric.hpp:60-64
+      return (bnds.x1[0] + bnds.x1[1]) * 0.5 * dx1 * dx3;
+    default: // cylindrical keeps the base (geometry.hpp:205-210)
+      return dx1 * dx3;
+    }
+  }
+  Real AreaX3(const Real) const {
+    const Real dx1 = bnds.x1[1] - bnds.x1[0];
+    const Real dx2 = bnds.x2[1] - bnds.x2[0];
+    switch (sys) {
+    case CO_SPH3D: // spherical.hpp:115-119, :313-317
+    case CO_SPH2D:
+    case CO_CYL: // cylindrical.hpp:67-71
+      return 0.5 * (bnds.x1[0] + bnds.x1[1]) * dx1 * dx2;
+    case CO_SPH1D: // spherical.hpp:488-491
+      return 0.5 * (bnds.x1[0] + bnds.x1[1]) * dx1;
+    default: // axisymmetric keeps the base (geometry.hpp:211-216)
+      return dx1 * dx2;
+    }
+  }
+  Real Volume() const {
+    const Real dx1 = bnds.x1[1] - bnds.x1[0];
+    const Real dx2 = bnds.x2[1] - bnds.x2[0];
+    const Real dx3 = bnds.x3[1] - bnds.x3[0];
+    if (sph()) { // spherical.hpp:124-133, :319-326, :493-499
+      const Real rfac =
+          (bnds.x1[0] * bnds.x1[0] + bnds.x1[0] * bnds.x1[1] + bnds.x1[1] * bnds.x1[1]) / 3.0;
+      if (sys == CO_SPH1D) return rfac * dx1;
+      const Real dc = std::abs(std::cos(bnds.x2[0]) - std::cos(bnds.x2[1]));
+      if (sys == CO_SPH2D) return rfac * dx1 * dc;
+      return rfac * dx1 * dc * dx3;
+    }
+    if (sys == CO_CYL || sys == CO_AXI) // cylindrical.hpp:73-78, axisymmetric.hpp:65-70
+      return (bnds.x1[0] + bnds.x1[1]) * 0.5 * dx1 * dx2 * dx3;
+    return dx1 * dx2 * dx3; // geometry.hpp:219-225
+  }
+  // connection coefficients (geometry.hpp:236-246 zero defaults)
+  Real dh2dx1() const {
+    if (sph()) // spherical.hpp:135-138, :328-331, :501-504
+      return 3.0 / 2.0 * (bnds.x1[0] + bnds.x1[1]) /
+             (bnds.x1[0] * bnds.x1[0] + bnds.x1[0] * bnds.x1[1] + bnds.x1[1] * bnds.x1[1]);
+    if (sys == CO_CYL) return 1.0 / (0.5 * (bnds.x1[0] + bnds.x1[1])); // cylindrical.hpp:80
+    return 0.0;
+  }
+  Real dh3dx1() const {
+    if (sph()) // spherical.hpp:139-142, :332-335, :505-508
+      return 3.0 / 2.0 * (bnds.x1[0] + bnds.x1[1]) /
+             (bnds.x1[0] * bnds.x1[0] + bnds.x1[0] * bnds.x1[1] + bnds.x1[1] * bnds.x1[1]);
+    if (sys == CO_AXI) return 1.0 / (0.5 * (bnds.x1[0] + bnds.x1[1])); // axisymmetric.hpp:71
+    return 0.0;
+  }
+  Real dh3dx2() const {
+    if (sph23()) // spherical.hpp:143-146, :336-339
+      return (std::sin(bnds.x2[1]) - std::sin(bnds.x2[0])) /
+             std::abs(std::cos(bnds.x2[0]) - std::cos(bnds.x2[1]));
+    return 0.0;
+  }
+  // aggregate helpers, geometry.hpp:330-420
+  void GetCellWidths(Real w[3]) const {
+    const Real xv[3] = {x1v(), x2v(), x3v()};
+    w[0] = hx1(xv[0], xv[1], xv[2]) * (bnds.x1[1] - bnds.x1[0]);
+    w[1] = hx2(xv[0], xv[1], xv[2]) * (bnds.x2[1] - bnds.x2[0]);
+    w[2] = hx3(xv[0], xv[1], xv[2]) * (bnds.x3[1] - bnds.x3[0]);
+  }
+  void GetScaleFactors(Real h[3]) const { h[0] = hx1v(), h[1] = hx2v(), h[2] = hx3v(); }
+  void GetFaceAreaX1(Real a[2]) const { a[0] = AreaX1(bnds.x1[0]), a[1] = AreaX1(bnds.x1[1]); }
+  void GetFaceAreaX2(Real a[2]) const { a[0] = AreaX2(bnds.x2[0]), a[1] = AreaX2(bnds.x2[1]); }
+  void GetFaceAreaX3(Real a[2]) const { a[0] = AreaX3(bnds.x3[0]), a[1] = AreaX3(bnds.x3[1]); }
+  void GetConnX1(Real c[3]) const { c[0] = 0.0, c[1] = dh2dx1(), c[2] = dh3dx1(); }
+  void GetConnX2(Real c[3]) const { c[0] = 0.0, c[1] = 0.0, c[2] = dh3dx2(); }
+  // ConvertCoordsToCart: spherical.hpp:166-173 (3D), :355-362 (2D), :528-534 (1D);
+  // cylindrical.hpp:88-92; axisymmetric.hpp:77-82; identity for Cartesian (geometry.hpp:248)
+  void ConvertToCart(const Real xi[3], Real xc[3]) const {
+    if (sys == CO_SPH3D || sys == CO_SPH2D) {
+      const Real cp = (sys == CO_SPH3D) ? std::cos(xi[2]) : 1.0;
+      const Real sp = (sys == CO_SPH3D) ? std::sin(xi[2]) : 0.0;
+      const Real ct = std::cos(xi[1]);
+      const Real st = std::sin(xi[1]);
+      xc[0] = xi[0] * st * cp, xc[1] = xi[0] * st * sp, xc[2] = xi[0] * ct;
+    } else if (sys == CO_SPH1D) {
+      const Real cp = 1.0, sp = 0.0, ct = 0.0, st = 1.0;
+      xc[0] = xi[0] * st * cp, xc[1] = xi[0] * st * sp, xc[2] = xi[0] * ct;
+    } else if (sys == CO_CYL) {
+      const Real cp = std::cos(xi[1]);
+      const Real sp = std::sin(xi[1]);
+      xc[0] = xi[0] * cp, xc[1] = xi[0] * sp, xc[2] = xi[2];
+    } else if (sys == CO_AXI) {
+      const Real cp = std::cos(xi[2]);
+      const Real sp = std::sin(xi[2]);
+      xc[0] = xi[0] * cp, xc[1] = xi[0] * sp, xc[2] = xi[1];
+    } else {
+      xc[0] = xi[0], xc[1] = xi[1], xc[2] = xi[2];
+    }
+  }
+};
+inline Coords::Coords(const Sim &s, int k, int j, int i) : sys(s.c.coords), bnds(bbox(s, k, j, i)) {}
+
 // ---------------------------------------------------------------------------------------
 // Reconstruction
 // utils/fluxes/reconstruction/plm.hpp:32-47
@@ -158,15 +383,59 @@ inline void PPM4(const Real q_im2, const Real q_im1, const Real q_i, const Real 
   qr_i = qlv;
 }
 
+// utils/fluxes/reconstruction/plm.hpp:54-73  (Mignone 2013 weights)
+inline void PLM_G(const Real q_im1, const Real q_i, const Real q_ip1, Real &ql_ip1, Real &qr_i,
+                  const Real x_im1, const Real x_i, const Real x_ip1, const Real xf[2],
+                  const Real dx) {
+  const Real dql = (q_i - q_im1) * dx / (x_i - x_im1);
+  const Real dqr = (q_ip1 - q_i) * dx / (x_ip1 - x_i);
+  const Real dq2 = dql * dqr;
+  const Real cr = (x_ip1 - x_i) / (xf[1] - x_i);
+  const Real cl = (x_i - x_im1) / (x_i - xf[0]);
+  const Real dqm = (dq2 <= 0.0) ? 0.0
+                                : dq2 * (cr * dql + cl * dqr) /
+                                      (dql * dql + dqr * dqr + dq2 * (cl + cr - 2.0));
+  ql_ip1 = q_i + dqm * (xf[1] - x_i) / dx;
+  qr_i = q_i - dqm * (x_i - xf[0]) / dx;
+}
+// Centroids, face pair and physical width PLM_G receives for cell (k,j,i) along `dir`
+// (plm.hpp:93-101, :127-135, :161-169).
+struct PlmGeo {
+  Real xvm, xvc, xvp, xf[2], dx;
+};
+inline PlmGeo plm_geo(const Sim &s, int dir, int k, int j, int i) {
+  PlmGeo g;
+  const int dk = (dir == 3), dj = (dir == 2), di = (dir == 1);
+  Coords cm(s, k - dk, j - dj, i - di), cc(s, k, j, i), cp(s, k + dk, j + dj, i + di);
+  Real w[3];
+  cc.GetCellWidths(w);
+  if (dir == 1) {
+    g.xvm = cm.x1v(), g.xvc = cc.x1v(), g.xvp = cp.x1v();
+    g.xf[0] = cc.bnds.x1[0], g.xf[1] = cc.bnds.x1[1];
+  } else if (dir == 2) {
+    g.xvm = cm.x2v(), g.xvc = cc.x2v(), g.xvp = cp.x2v();
+    g.xf[0] = cc.bnds.x2[0], g.xf[1] = cc.bnds.x2[1];
+  } else {
+    g.xvm = cm.x3v(), g.xvc = cc.x3v(), g.xvp = cp.x3v();
+    g.xf[0] = cc.bnds.x3[0], g.xf[1] = cc.bnds.x3[1];
+  }
+  g.dx = w[dir - 1];
+  return g;
+}
+
 // One row of reconstruction along a stride: cells c in [lo,hi] write wl[c+1], wr[c]
 // (pcm.hpp:34-88, plm.hpp:82-175, ppm.hpp:75-130).  `q` points at cell index 0 of the row
 // along the sweep direction, `st` is the stride between consecutive cells of the sweep.
-inline void recon_cell(int recon, const Real *q, ptrdiff_t st, Real &ql_next, Real &qr_here) {
+inline void recon_cell(int recon, const Real *q, ptrdiff_t st, Real &ql_next, Real &qr_here,
+                       const PlmGeo *g = nullptr) {
   if (recon == RC_PCM) {
     ql_next = q[0];
     qr_here = q[0];
   } else if (recon == RC_PLM) {
-    PLM(q[-st], q[0], q[st], ql_next, qr_here);
+    if (g == nullptr) // GEOM == cartesian (plm.hpp:90)
+      PLM(q[-st], q[0], q[st], ql_next, qr_here);
+    else
+      PLM_G(q[-st], q[0], q[st], ql_next, qr_here, g->xvm, g->xvc, g->xvp, g->xf, g->dx);
   } else {
     PPM4(q[-2 * st], q[-st], q[0], q[st], q[2 * st], ql_next, qr_here);
   }
@@ -442,6 +711,32 @@ void solve_row(const Sim &s, int fluid, int riemann, int dir, int nsp, const Rea
   }
 }
 
+// utils/fluxes/fluid_fluxes.hpp:33-70 ScaleMomentumFlux: the three momentum fluxes of every
+// face in [il,iu] of row (k,j) are multiplied by the scale factors at the face centroid
+// (lower face of the cell that stores the flux).  No-op for Cartesian (:36).
+void scale_momentum_flux(const Sim &s, int dir, int nsp, int k, int j, int il, int iu,
+                         std::vector<Real> *flux) {
+  if (s.c.coords == CO_CART) return;
+  const int d = dir - 1;
+  for (int n = 0; n < nsp; ++n) {
+    const int IVX = nsp + 3 * n + 0, IVY = nsp + 3 * n + 1, IVZ = nsp + 3 * n + 2;
+    for (int i = il; i <= iu; ++i) {
+      Coords coords(s, k, j, i);
+      Real xf[3];
+      if (dir == 1)
+        coords.FaceCenX1(0, xf);
+      else if (dir == 2)
+        coords.FaceCenX2(0, xf);
+      else
+        coords.FaceCenX3(0, xf);
+      const size_t c = IDX(s, k, j, i);
+      flux[d][IVX * s.N + c] *= coords.hx1(xf[0], xf[1], xf[2]);
+      flux[d][IVY * s.N + c] *= coords.hx2(xf[0], xf[1], xf[2]);
+      flux[d][IVZ * s.N + c] *= coords.hx3(xf[0], xf[1], xf[2]);
+    }
+  }
+}
+
 void calculate_fluxes(Sim &s, int fluid, bool pcm) {
   const bool gas = (fluid == FL_GAS);
   const int nsp = gas ? s.c.ns_gas : s.c.ns_dust;
@@ -454,6 +749,8 @@ void calculate_fluxes(Sim &s, int fluid, bool pcm) {
   std::vector<Real> *flux = gas ? s.gflux : s.dflux;
   const Real gm1 = s.c.gamma - 1.0;
   const int ni = s.ni, nj = s.nj, nk = s.nk;
+  // plm.hpp:90,124,158: PLM_G for every non-Cartesian system; PCM and PPM4 ignore GEOM
+  const bool plmg = (recon == RC_PLM) && (s.c.coords != CO_CART);
 
   // X1 sweep
   {
@@ -464,11 +761,18 @@ void calculate_fluxes(Sim &s, int fluid, bool pcm) {
         const size_t base = IDX(s, k, j, 0);
         for (int n = 0; n < nvars; ++n) {
           const Real *q = prim.data() + n * s.N + base;
-          for (int i = s.is - 1; i <= s.ie + 1; ++i)
-            recon_cell(recon, q + i, 1, wl[n * ni + i + 1], wr[n * ni + i]);
+          for (int i = s.is - 1; i <= s.ie + 1; ++i) {
+            if (plmg) {
+              const PlmGeo g = plm_geo(s, 1, k, j, i);
+              recon_cell(recon, q + i, 1, wl[n * ni + i + 1], wr[n * ni + i], &g);
+            } else {
+              recon_cell(recon, q + i, 1, wl[n * ni + i + 1], wr[n * ni + i]);
+            }
+          }
         }
         solve_row(s, fluid, riemann, 1, nsp, wl.data(), wr.data(), ni, s.is, s.ie + 1, base, 1,
                   flux, s.gpflux, s.gvface, gm1);
+        scale_momentum_flux(s, 1, nsp, k, j, s.is, s.ie + 1, flux);
       }
     }
   }
@@ -482,12 +786,19 @@ void calculate_fluxes(Sim &s, int fluid, bool pcm) {
         const size_t base = IDX(s, k, j, 0);
         for (int n = 0; n < nvars; ++n) {
           const Real *q = prim.data() + n * s.N + base;
-          for (int i = s.is; i <= s.ie; ++i)
-            recon_cell(recon, q + i, ni, wl_jp1[n * ni + i], wr[n * ni + i]);
+          for (int i = s.is; i <= s.ie; ++i) {
+            if (plmg) {
+              const PlmGeo g = plm_geo(s, 2, k, j, i);
+              recon_cell(recon, q + i, ni, wl_jp1[n * ni + i], wr[n * ni + i], &g);
+            } else {
+              recon_cell(recon, q + i, ni, wl_jp1[n * ni + i], wr[n * ni + i]);
+            }
+          }
         }
         if (j > s.js - 1) {
           solve_row(s, fluid, riemann, 2, nsp, wl.data(), wr.data(), ni, s.is, s.ie, base, 1, flux,
                     s.gpflux, s.gvface, gm1);
+          scale_momentum_flux(s, 2, nsp, k, j, s.is, s.ie, flux);
         }
         wl.swap(wl_jp1);
       }
@@ -504,12 +815,19 @@ void calculate_fluxes(Sim &s, int fluid, bool pcm) {
         const size_t base = IDX(s, k, j, 0);
         for (int n = 0; n < nvars; ++n) {
           const Real *q = prim.data() + n * s.N + base;
-          for (int i = s.is; i <= s.ie; ++i)
-            recon_cell(recon, q + i, sk, wl_kp1[n * ni + i], wr[n * ni + i]);
+          for (int i = s.is; i <= s.ie; ++i) {
+            if (plmg) {
+              const PlmGeo g = plm_geo(s, 3, k, j, i);
+              recon_cell(recon, q + i, sk, wl_kp1[n * ni + i], wr[n * ni + i], &g);
+            } else {
+              recon_cell(recon, q + i, sk, wl_kp1[n * ni + i], wr[n * ni + i]);
+            }
+          }
         }
         if (k > s.ks - 1) {
           solve_row(s, fluid, riemann, 3, nsp, wl.data(), wr.data(), ni, s.is, s.ie, base, 1, flux,
                     s.gpflux, s.gvface, gm1);
+          scale_momentum_flux(s, 3, nsp, k, j, s.is, s.ie, flux);
         }
         wl.swap(wl_kp1);
       }
@@ -530,11 +848,12 @@ void apply_update_fluid(Sim &s, std::vector<Real> &u0, const std::vector<Real> &
   for (int k = s.ks; k <= s.ke; ++k)
     for (int j = s.js; j <= s.je; ++j)
       for (int i = s.is; i <= s.ie; ++i) {
-        const BBox b = bbox(s, k, j, i);
-        const Real ax1[2] = {area1(b), area1(b)};
-        const Real ax2[2] = {multi_d ? area2(b) : 0.0, multi_d ? area2(b) : 0.0};
-        const Real ax3[2] = {three_d ? area3(b) : 0.0, three_d ? area3(b) : 0.0};
-        const Real vol = volume(b);
+        Coords coords(s, k, j, i);
+        Real ax1[2], ax2[2] = {0.0, 0.0}, ax3[2] = {0.0, 0.0};
+        coords.GetFaceAreaX1(ax1);
+        if (multi_d) coords.GetFaceAreaX2(ax2);
+        if (three_d) coords.GetFaceAreaX3(ax3);
+        const Real vol = coords.Volume();
         const size_t c = IDX(s, k, j, i);
         for (int n = 0; n < nvars; ++n) {
           const Real *f1 = flux[0].data() + n * s.N;
@@ -565,56 +884,87 @@ void deep_copy(Sim &s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// utils/fluxes/fluid_fluxes.hpp:300-420  FluxSourceImpl, Cartesian (no metric terms: x?dep
-// false, geometry.hpp:98-110).  Gas only: dust has no pressure and Dust::FluxSource skips
-// Cartesian entirely (dust.cpp:303-326).  The reference loops i over [is-2, ie+1] (:325); the
-// ghost-cell writes are overwritten by PrimToCons, so the oracle does the same range to stay
-// a literal restatement (reads stay in bounds because ng >= 2).
-void flux_source_gas(Sim &s, Real dt) {
-  const int nsp = s.c.ns_gas;
+// utils/fluxes/fluid_fluxes.hpp:300-420  FluxSourceImpl: pressure gradient and P div(v) work for
+// gas (:361-393), then the coordinate source rho*dt*sum_d dh_d/dx_a*(v_d + vf_d)^2 on each
+// momentum whose direction the metric depends on (:395-415).  vf = RotationVelocity(xv, omf)
+// is identically zero here (omf = 0 without <rotating_frame>, gas.cpp:497-502), so it is left
+// out of the sums.  Dust::FluxSource runs only for metric-dependent systems (dust.cpp:303-326)
+// and has no pressure terms.  The reference loops i over [is-2, ie+1] (:325); the ghost-cell
+// writes are overwritten by PrimToCons, so the oracle keeps the range to stay literal (reads
+// stay in bounds because ng >= 2).
+void flux_source(Sim &s, int fluid, Real dt) {
+  const bool gas = (fluid == FL_GAS);
+  const int nsp = gas ? s.c.ns_gas : s.c.ns_dust;
   if (!nsp) return;
   const bool multi_d = (s.ndim >= 2), three_d = (s.ndim == 3);
+  {
+    const Coords probe(s, s.ks, s.js, s.is);
+    if (!gas && !(probe.x1dep() || (probe.x2dep() && multi_d) || (probe.x3dep() && three_d)))
+      return;
+  }
   const ptrdiff_t sj = s.ni, sk = static_cast<ptrdiff_t>(s.ni) * s.nj;
+  std::vector<Real> &u0 = gas ? s.gu0 : s.du0;
+  const std::vector<Real> &prim = gas ? s.gprim : s.dprim;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int k = s.ks; k <= s.ke; ++k)
     for (int j = s.js; j <= s.je; ++j)
       for (int i = s.is - 2; i <= s.ie + 1; ++i) {
-        const BBox b = bbox(s, k, j, i);
-        const Real ax1[2] = {area1(b), area1(b)};
-        const Real ax2[2] = {multi_d ? area2(b) : 0.0, multi_d ? area2(b) : 0.0};
-        const Real ax3[2] = {three_d ? area3(b) : 0.0, three_d ? area3(b) : 0.0};
-        const Real vol = volume(b);
+        Coords coords(s, k, j, i);
+        const bool x1dep = coords.x1dep();
+        const bool x2dep = coords.x2dep() && multi_d;
+        const bool x3dep = coords.x3dep() && three_d;
+        Real dhdx1[3] = {0.0, 0.0, 0.0}, dhdx2[3] = {0.0, 0.0, 0.0};
+        if (x1dep) coords.GetConnX1(dhdx1);
+        if (x2dep) coords.GetConnX2(dhdx2);
+        (void)x3dep; // geometry.hpp:107-110: no system has an x3-dependent metric
+        Real ax1[2], ax2[2] = {0.0, 0.0}, ax3[2] = {0.0, 0.0};
+        coords.GetFaceAreaX1(ax1);
+        if (multi_d) coords.GetFaceAreaX2(ax2);
+        if (three_d) coords.GetFaceAreaX3(ax3);
+        const Real vol = coords.Volume();
+        const BBox &b = coords.bnds;
         const Real dx[3] = {b.x1[1] - b.x1[0], b.x2[1] - b.x2[0], b.x3[1] - b.x3[0]};
         const size_t c = IDX(s, k, j, i);
         for (int n = 0; n < nsp; ++n) {
           // cons pack of FluxSource is <momentum, internal_energy> (gas.cpp:505-511); in the
           // oracle's full cons layout those are slots ns+3n+d and 5ns+n.
-          Real *mx = s.gu0.data() + (nsp + 3 * n + 0) * s.N;
-          Real *my = s.gu0.data() + (nsp + 3 * n + 1) * s.N;
-          Real *mz = s.gu0.data() + (nsp + 3 * n + 2) * s.N;
-          Real *eg = s.gu0.data() + (5 * nsp + n) * s.N;
-          const Real *p1 = s.gpflux[0].data() + n * s.N, *v1 = s.gvface[0].data() + n * s.N;
-          mx[c] += dt / dx[0] * (p1[c] - p1[c + 1]);
-          eg[c] -= dt / vol * 0.5 * (p1[c] + p1[c + 1]) * (ax1[1] * v1[c + 1] - ax1[0] * v1[c]);
-          if (multi_d) {
-            const Real *p2 = s.gpflux[1].data() + n * s.N, *v2 = s.gvface[1].data() + n * s.N;
-            my[c] += dt / dx[1] * (p2[c] - p2[c + sj]);
-            eg[c] -=
-                dt / vol * 0.5 * (p2[c] + p2[c + sj]) * (ax2[1] * v2[c + sj] - ax2[0] * v2[c]);
+          Real *mx = u0.data() + (nsp + 3 * n + 0) * s.N;
+          Real *my = u0.data() + (nsp + 3 * n + 1) * s.N;
+          Real *mz = u0.data() + (nsp + 3 * n + 2) * s.N;
+          if (gas) {
+            Real *eg = u0.data() + (5 * nsp + n) * s.N;
+            const Real *p1 = s.gpflux[0].data() + n * s.N, *v1 = s.gvface[0].data() + n * s.N;
+            mx[c] += dt / dx[0] * (p1[c] - p1[c + 1]);
+            eg[c] -= dt / vol * 0.5 * (p1[c] + p1[c + 1]) * (ax1[1] * v1[c + 1] - ax1[0] * v1[c]);
+            if (multi_d) {
+              const Real *p2 = s.gpflux[1].data() + n * s.N, *v2 = s.gvface[1].data() + n * s.N;
+              my[c] += dt / dx[1] * (p2[c] - p2[c + sj]);
+              eg[c] -=
+                  dt / vol * 0.5 * (p2[c] + p2[c + sj]) * (ax2[1] * v2[c + sj] - ax2[0] * v2[c]);
+            }
+            if (three_d) {
+              const Real *p3 = s.gpflux[2].data() + n * s.N, *v3 = s.gvface[2].data() + n * s.N;
+              mz[c] += dt / dx[2] * (p3[c] - p3[c + sk]);
+              eg[c] -=
+                  dt / vol * 0.5 * (p3[c] + p3[c + sk]) * (ax3[1] * v3[c + sk] - ax3[0] * v3[c]);
+            }
           }
-          if (three_d) {
-            const Real *p3 = s.gpflux[2].data() + n * s.N, *v3 = s.gvface[2].data() + n * s.N;
-            mz[c] += dt / dx[2] * (p3[c] - p3[c + sk]);
-            eg[c] -=
-                dt / vol * 0.5 * (p3[c] + p3[c + sk]) * (ax3[1] * v3[c + sk] - ax3[0] * v3[c]);
-          }
+          const Real dens = prim[n * s.N + c];
+          const Real rdt = dens * dt;
+          const Real vx = prim[(nsp + 3 * n + 0) * s.N + c];
+          const Real vy = prim[(nsp + 3 * n + 1) * s.N + c];
+          const Real vz = prim[(nsp + 3 * n + 2) * s.N + c];
+          if (x1dep)
+            mx[c] += rdt * (dhdx1[0] * SQR(vx) + dhdx1[1] * SQR(vy) + dhdx1[2] * SQR(vz));
+          if (x2dep)
+            my[c] += rdt * (dhdx2[0] * SQR(vx) + dhdx2[1] * SQR(vy) + dhdx2[2] * SQR(vz));
         }
       }
 }
 
 // ---------------------------------------------------------------------------------------
 // derived/fill_derived.cpp:30-75 SetAuxillaryFields + utils/artemis_utils.hpp:43-62
-// GetSpecificInternalEnergy (hx = 1 for Cartesian).
+// GetSpecificInternalEnergy (hx = volume-averaged scale factors, fill_derived.cpp:127 analogue).
 void set_aux(Sim &s) {
   const int nsp = s.c.ns_gas;
   if (!nsp) return;
@@ -624,14 +974,16 @@ void set_aux(Sim &s) {
     for (int j = s.js; j <= s.je; ++j)
       for (int i = s.is; i <= s.ie; ++i) {
         const size_t c = IDX(s, k, j, i);
+        Real hx[3];
+        Coords(s, k, j, i).GetScaleFactors(hx); // artemis_utils.hpp:73-75
         for (int n = 0; n < nsp; ++n) {
           Real u_d = s.gu0[n * s.N + c];
           u_d = (u_d > dflr) ? u_d : dflr;
           // GetSpecificInternalEnergy
           const Real u_d2 = std::max(s.gu0[n * s.N + c], dflr);
-          const Real rv1 = s.gu0[(nsp + 3 * n + 0) * s.N + c] / 1.0;
-          const Real rv2 = s.gu0[(nsp + 3 * n + 1) * s.N + c] / 1.0;
-          const Real rv3 = s.gu0[(nsp + 3 * n + 2) * s.N + c] / 1.0;
+          const Real rv1 = s.gu0[(nsp + 3 * n + 0) * s.N + c] / hx[0];
+          const Real rv2 = s.gu0[(nsp + 3 * n + 1) * s.N + c] / hx[1];
+          const Real rv3 = s.gu0[(nsp + 3 * n + 2) * s.N + c] / hx[2];
           const Real ke = 0.5 * (SQR(rv1) + SQR(rv2) + SQR(rv3)) / u_d2;
           const Real e_cons = s.gu0[(4 * nsp + n) * s.N + c];
           const Real ue_cons = e_cons - ke;
@@ -654,7 +1006,8 @@ void cons_to_prim(Sim &s) {
     for (int j = s.js; j <= s.je; ++j)
       for (int i = s.is; i <= s.ie; ++i) {
         const size_t c = IDX(s, k, j, i);
-        const Real hx[3] = {1.0, 1.0, 1.0};
+        Real hx[3];
+        Coords(s, k, j, i).GetScaleFactors(hx); // fill_derived.cpp:125-127, :217-219
         for (int n = 0; n < ng_; ++n) {
           const Real u_d = s.gu0[n * s.N + c];
           Real &w_d = s.gprim[n * s.N + c];
@@ -687,7 +1040,8 @@ void prim_to_cons(Sim &s) {
     for (int j = 0; j < s.nj; ++j)
       for (int i = 0; i < s.ni; ++i) {
         const size_t c = IDX(s, k, j, i);
-        const Real hx[3] = {1.0, 1.0, 1.0};
+        Real hx[3];
+        Coords(s, k, j, i).GetScaleFactors(hx); // fill_derived.cpp:125-127, :217-219
         for (int n = 0; n < ng_; ++n) {
           Real &w_d = s.gprim[n * s.N + c];
           Real &u_d = s.gu0[n * s.N + c];
@@ -732,9 +1086,8 @@ Real estimate_dt(const Sim &s, int fluid) {
   for (int k = s.ks; k <= s.ke; ++k)
     for (int j = s.js; j <= s.je; ++j)
       for (int i = s.is; i <= s.ie; ++i) {
-        const BBox b = bbox(s, k, j, i);
-        const Real dx[3] = {1.0 * (b.x1[1] - b.x1[0]), 1.0 * (b.x2[1] - b.x2[0]),
-                            1.0 * (b.x3[1] - b.x3[0])};
+        Real dx[3];
+        Coords(s, k, j, i).GetCellWidths(dx); // gas.cpp:416-417
         const size_t c = IDX(s, k, j, i);
         for (int n = 0; n < nsp; ++n) {
           Real denom = 0.0;
@@ -854,7 +1207,8 @@ void step(Sim &s, exchange_fn xchg, void *ctx) {
     calculate_fluxes(s, FL_GAS, do_pcm);                                 // :184
     calculate_fluxes(s, FL_DUST, do_pcm);                                // :185
     apply_update(s, g0[stage - 1], g1[stage - 1], be[stage - 1] * s.dt); // :205-207
-    flux_source_gas(s, bdt);                                             // :211
+    flux_source(s, FL_GAS, bdt);                                         // :211
+    flux_source(s, FL_DUST, bdt);                                        // :212
     set_aux(s);                                                          // :251-252
     cons_to_prim(s);                                                     // :255
     if (xchg) xchg(ctx);                                                 // :258 (inter-block)
@@ -949,7 +1303,7 @@ void oracle_apply_update(void *h, double gam0, double gam1, double beta_dt) {
   apply_update(*static_cast<Sim *>(h), gam0, gam1, beta_dt);
 }
 void oracle_flux_source(void *h, int fluid, double dt) {
-  if (fluid == FL_GAS) flux_source_gas(*static_cast<Sim *>(h), dt);
+  flux_source(*static_cast<Sim *>(h), fluid, dt);
 }
 void oracle_set_aux(void *h) { set_aux(*static_cast<Sim *>(h)); }
 void oracle_cons_to_prim(void *h) { cons_to_prim(*static_cast<Sim *>(h)); }
@@ -1008,7 +1362,7 @@ long oracle_evolve(void *h, double tlim, long nlim) {
 }
 
 // ---------------------------------------------------------------------------------------
-// pgen/blast.hpp:134-228 (Cartesian; gas prim rho, v, sie over the entire block incl. ghosts,
+// pgen/blast.hpp:134-228 (gas prim rho, v, sie over the entire block incl. ghosts,
 // then PostInitialization = PrimToCons, main.cpp:43).
 void oracle_pgen_blast(void *h, double rinit, double internal_energy, double p0, double d0,
                        double x0, double y0, double z0, int samples, int type) {
@@ -1018,19 +1372,38 @@ void oracle_pgen_blast(void *h, double rinit, double internal_energy, double p0,
   for (int k = 0; k < s.nk; ++k)
     for (int j = 0; j < s.nj; ++j)
       for (int i = 0; i < s.ni; ++i) {
-        const BBox b = bbox(s, k, j, i);
-        Real total_vol = volume(b);
-        const Real xv[3] = {x1v(b), x2v(b), x3v(b)};
+        const Coords coords(s, k, j, i);
+        const BBox &b = coords.bnds;
+        Real total_vol = coords.Volume();
+        const Real xv[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
         Real den = d0;
         Real e0 = p0 / gm1;
         Real ie = 0.0;
-        Real xcart[3] = {xv[0], xv[1], xv[2]};
-        const Real xc[3] = {x0, y0, z0};
+        Real xcart[3], xc[3];
+        const Real x0v[3] = {x0, y0, z0};
+        coords.ConvertToCart(xv, xcart); // blast.hpp:181-185
+        coords.ConvertToCart(x0v, xc);
         for (int n = 0; n < 3; n++)
           xcart[n] -= xc[n];
         Real vol;
         if (type == 1) { // spherical (blast.hpp:188-201)
-          if (samples > 0) {
+          if (samples > 0 && s.c.coords == CO_AXI) {
+            // compute_overlap_sph, axisymmetric branch (blast.hpp:107-121)
+            const Real dxf = (b.x1[1] - b.x1[0]) / (Real)samples;
+            const Real dyf = (b.x2[1] - b.x2[0]) / (Real)samples;
+            Real dV = dxf * dyf;
+            Real tot = 0.0;
+            for (int ii = 0; ii < samples; ii++) {
+              const Real xc_ = b.x1[0] + (ii + 0.5) * dxf;
+              for (int jj = 0; jj < samples; jj++) {
+                const Real yc_ = b.x2[0] + (jj + 0.5) * dyf;
+                if (SQR(xc_) + SQR(yc_) <= SQR(rinit)) tot += xc_ * dV;
+              }
+            }
+            vol = tot;
+          } else if (samples > 0 && s.c.coords != CO_CART) {
+            vol = 0.0; // blast.hpp:122: every other system falls through to `return 0.0`
+          } else if (samples > 0) {
             // compute_overlap_sph, Cartesian branch (blast.hpp:91-106): NOT offset by x0
             const Real dxf = (b.x1[1] - b.x1[0]) / (Real)samples;
             const Real dyf = (b.x2[1] - b.x2[0]) / (Real)samples;
@@ -1054,7 +1427,9 @@ void oracle_pgen_blast(void *h, double rinit, double internal_energy, double p0,
           ie = e0 * (1.0 - vol / total_vol) +
                internal_energy * vol / total_vol / (4.0 * M_PI / 3.0 * rinit * rinit * rinit);
         } else { // cylindrical (blast.hpp:202-213)
-          if (samples > 0) {
+          if (samples > 0 && s.c.coords != CO_CART) {
+            vol = 0.0; // compute_overlap_cyl has a Cartesian branch only (blast.hpp:68-81)
+          } else if (samples > 0) {
             // compute_overlap_cyl (blast.hpp:65-80)
             const Real dxf = (b.x1[1] - b.x1[0]) / (Real)samples;
             const Real dyf = (b.x2[1] - b.x2[0]) / (Real)samples;
@@ -1314,7 +1689,7 @@ void oracle_history(void *h, double *out) {
   for (int k = s.ks; k <= s.ke; ++k)
     for (int j = s.js; j <= s.je; ++j)
       for (int i = s.is; i <= s.ie; ++i) {
-        const Real vv = volume(bbox(s, k, j, i));
+        const Real vv = Coords(s, k, j, i).Volume(); // history.hpp:49-50
         const size_t c = IDX(s, k, j, i);
         if (ng_) {
           out[0] += s.gu0[0 * s.N + c] * vv;

@@ -36,7 +36,19 @@ class Cfg(C.Structure):
         ("de_switch", C.c_double), ("dfloor_dust", C.c_double),
         ("cfl_gas", C.c_double), ("cfl_dust", C.c_double),
         ("bc", C.c_int * 6), ("integrator", C.c_int), ("nthreads", C.c_int),
+        ("coords", C.c_int),
     ]
+
+
+COORDS = {"cartesian": 0, "cylindrical": 1, "spherical1D": 2, "spherical2D": 3,
+          "spherical3D": 4, "axisymmetric": 5}
+
+
+def coord_select(sys, ndim):
+    """geometry.hpp:38-56 CoordSelect: `spherical` picks its variant from the problem dimension."""
+    if sys == "spherical":
+        return (2, 2, 3, 4)[ndim]
+    return COORDS[sys]
 
 
 def build(force=False):
@@ -108,7 +120,8 @@ class Oracle:
     def __init__(self, nx, xmin, xmax, ng=2, ns_gas=1, ns_dust=0, reconstruct="plm",
                  riemann="hllc", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.66666666667,
                  dfloor=1.0e-20, siefloor=1.0e-20, de_switch=0.0, dust_dfloor=1.0e-20, cfl=0.8,
-                 dust_cfl=0.8, bc=("periodic",) * 6, integrator="rk2", mesh_bounds=None):
+                 dust_cfl=0.8, bc=("periodic",) * 6, integrator="rk2", mesh_bounds=None,
+                 coordinates="cartesian"):
         self.L = lib()
         c = Cfg()
         c.nx1, c.nx2, c.nx3 = nx
@@ -125,6 +138,7 @@ class Oracle:
             c.bc[i] = BC[b] if isinstance(b, str) else b
         c.integrator = INTEG[integrator]
         c.nthreads = 0
+        c.coords = coord_select(coordinates, sum(n > 1 for n in nx))
         self.cfg = c
         self.h = C.c_void_p(self.L.oracle_create(C.byref(c)))
         d = (C.c_int * 10)()

@@ -33,6 +33,7 @@ oracle_cfg cfg_of(const artemis_pack_t *p) {
   c.cfl_gas = 1.0, c.cfl_dust = 1.0;
   for (int i = 0; i < 6; ++i) c.bc[i] = BC_NONE;
   c.integrator = INT_RK2;
+  c.coords = p->coords;
   return c;
 }
 
@@ -116,21 +117,52 @@ int artemis_hip_apply_update(const artemis_pack_t *p, double g0, double g1, doub
   return 0;
 }
 int artemis_hip_flux_source(const artemis_pack_t *p, int fluid, double dt, void *) {
-  if (fluid != FL_GAS || p->gas.nspecies == 0) return 0;
+  const bool gas = (fluid == FL_GAS);
+  if ((gas ? p->gas.nspecies : p->dust.nspecies) == 0) return 0;
+  if (!gas && p->coords == CO_CART) return 0;
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);
     B.load_state(), B.load_fluxes();
     // interior only, like the product (the oracle's literal [is-2, ie+1] range only scribbles
     // on ghost cells that PrimToCons overwrites)
-    std::vector<Real> before = B.s->gu0;
-    flux_source_gas(*B.s, dt);
     Sim &s = *B.s;
-    for (int v = 0; v < s.nvg; ++v)
+    std::vector<Real> &u0 = gas ? s.gu0 : s.du0;
+    const int nv = gas ? s.nvg : s.nvd;
+    std::vector<Real> before = u0;
+    flux_source(s, fluid, dt);
+    for (int v = 0; v < nv; ++v)
       for (int k = 0; k < s.nk; ++k)
         for (int j = 0; j < s.nj; ++j)
           for (int i = 0; i < s.ni; ++i)
-            if (i < s.is || i > s.ie) s.gu0[v * s.N + IDX(s, k, j, i)] = before[v * s.N + IDX(s, k, j, i)];
-    B.out(B.s->gu0, p->gas.cons0, B.s->nvg);
+            if (i < s.is || i > s.ie) u0[v * s.N + IDX(s, k, j, i)] = before[v * s.N + IDX(s, k, j, i)];
+    B.out(u0, gas ? p->gas.cons0 : p->dust.cons0, nv);
+  }
+  return 0;
+}
+// The double evaluates the metric with the oracle's own per-cell libm calls, but the driver's
+// host-side problem generators read the tables, so fill them the way the product does.
+long artemis_hip_metric_count(const artemis_pack_t *p) {
+  if (p->coords != CO_SPH2D && p->coords != CO_SPH3D) return 0;
+  const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0);
+  return static_cast<long>(p->nblocks) * 5 * (nj + 1);
+}
+int artemis_hip_metric_fill(const artemis_pack_t *p, const double *g, double *out) {
+  if (artemis_hip_metric_count(p) == 0) return 0;
+  const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0), st = nj + 1;
+  for (int b = 0; b < p->nblocks; ++b) {
+    double *m = out + static_cast<long>(b) * 5 * st;
+    for (int j = 0; j <= nj; ++j) {
+      const double xf = g[6 * b + 2] + j * g[6 * b + 3];
+      m[j] = std::cos(xf), m[st + j] = std::sin(xf);
+    }
+    for (int j = 0; j < nj; ++j) {
+      BBox bb{};
+      bb.x2[0] = g[6 * b + 2] + j * g[6 * b + 3], bb.x2[1] = g[6 * b + 2] + (j + 1) * g[6 * b + 3];
+      const Real ctm = std::cos(bb.x2[0]), ctp = std::cos(bb.x2[1]);
+      const Real dst = std::sin(bb.x2[1]) - std::sin(bb.x2[0]);
+      const Real x2v = (dst - bb.x2[1] * ctp + bb.x2[0] * ctm) / std::abs(ctm - ctp);
+      m[2 * st + j] = x2v, m[3 * st + j] = std::sin(x2v), m[4 * st + j] = std::sin(0.5 * (bb.x2[0] + bb.x2[1]));
+    }
   }
   return 0;
 }
@@ -224,7 +256,7 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
     const double beta_dt = a->beta_dt_dev ? *a->beta_dt_dev : a->beta_dt;
     const double bdt = a->beta_dt_dev ? *a->beta_dt_dev : a->bdt;
     apply_update(s, a->gam0, a->gam1, beta_dt);
-    flux_source_gas(s, bdt);
+    flux_source(s, FL_GAS, bdt);
     set_aux(s);
     cons_to_prim(s);
     // pressure of the interior cells as PrimToCons would set it

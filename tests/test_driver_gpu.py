@@ -166,8 +166,10 @@ def test_driver_rejects_out_of_scope(hiplib):
     from artemis_amd.driver import Simulation
     with pytest.raises(RuntimeError, match="out of scope"):
         Simulation(DECK("blast", "blast.in"), ["physics/gravity=true"])
-    with pytest.raises(RuntimeError, match="not built"):
-        Simulation(DECK("blast", "blast.in"), ["artemis/coordinates=spherical"])
+    with pytest.raises(RuntimeError, match="not recognized"):
+        Simulation(DECK("blast", "blast.in"), ["artemis/coordinates=toroidal"])
+    with pytest.raises(RuntimeError, match="Cartesian-only"):
+        Simulation(DECK("linwave", "linear_wave.in"), ["artemis/coordinates=cylindrical"])
     with pytest.raises(RuntimeError, match="ghost"):
         Simulation(DECK("blast", "blast.in"), ["gas/reconstruct=ppm"])
 
@@ -270,3 +272,106 @@ def test_sync_free_loop_matches_host_dt_loop(hiplib, monkeypatch):
     c.evolve(6)
     c.evolve(8)
     assert c.ncycle == 14 and c.time == a.time and np.array_equal(c.field("gas.prim"), a.field("gas.prim"))
+
+
+# tst/scripts/coords/blast.py:36-80: the reference's curvilinear Sedov configurations
+BLAST_GEOM = {
+    "axi": ["artemis/coordinates=axisymmetric", "parthenon/mesh/x1min=0.0", "parthenon/mesh/x1max=2.0",
+            "parthenon/mesh/x2min=-1.0", "parthenon/mesh/x2max=1.0", "parthenon/mesh/x3min=-0.5",
+            "parthenon/mesh/x3max=0.5", "parthenon/mesh/ix1_bc=reflecting", "problem/symmetry=spherical"],
+    "cyl": ["artemis/coordinates=axisymmetric", "parthenon/mesh/x1min=0.0", "parthenon/mesh/x1max=1.0",
+            "parthenon/mesh/x2min=-0.5", "parthenon/mesh/x2max=0.5", "parthenon/mesh/nx1=1024",
+            "parthenon/mesh/nx2=1", "parthenon/mesh/x3min=-0.5", "parthenon/mesh/x3max=0.5",
+            "parthenon/meshblock/nx2=1", "problem/symmetry=cylindrical", "problem/samples=0"],
+    "sph": ["artemis/coordinates=spherical", "parthenon/mesh/x1min=0.0", "parthenon/mesh/x1max=1.0",
+            "parthenon/mesh/x2min=0.0", "parthenon/mesh/x2max={:.16f}".format(np.pi),
+            "parthenon/mesh/nx1=1024", "parthenon/mesh/nx2=1", "parthenon/mesh/x3min=-0.5",
+            "parthenon/mesh/x3max=0.5", "parthenon/mesh/ix1_bc=reflecting", "parthenon/meshblock/nx2=1",
+            "problem/symmetry=spherical", "problem/samples=0"],
+}
+
+
+@pytest.mark.parametrize("g", ["sph", "cyl"])
+def test_blast_reference_curvilinear_1d_bitwise(hiplib, g):
+    """blast.py's `sph` (spherical1D, reflecting centre) and `cyl` (axisymmetric 1-D) runs, hlle +
+    plm as the test sets them, on one 1024-cell block to t = 0.1: every cycle's dt and the final
+    state equal the oracle's bit for bit; the front sits at the Sedov radius of the deposited
+    energy and total energy is conserved (blast.py:177-183 bounds the pressure L2 error by 1)."""
+    from artemis_amd.driver import Simulation
+    s = Simulation(DECK("blast", "blast.in"), BLAST_GEOM[g] + ["parthenon/meshblock/nx1=1024"])
+    assert s.nblocks == 1 and not s.uses_fused_path
+    sph = (g == "sph")
+    o = Oracle((1024, 1, 1), (0.0, 0.0 if sph else -0.5, -0.5), (1.0, float("{:.16f}".format(np.pi)) if sph else 0.5, 0.5),
+               ng=2, reconstruct="plm", riemann="hlle", gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
+               bc=(("reflecting" if sph else "outflow"),) + ("outflow",) * 5, integrator="rk2",
+               coordinates="spherical" if sph else "axisymmetric")
+    o.pgen_blast(radius=0.01, internal_energy=1.0, p0=1e-5, d0=1.0, samples=0,
+                 symmetry="spherical" if sph else "cylindrical")
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    e0 = s.history()[4]
+    assert e0 == o.history()[4]
+    s.evolve(), o.evolve(0.1, -1)
+    assert s.ncycle == o.ncycle and s.time == o.time and s.dt == o.dt
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    assert np.array_equal(s.field("gas.cons"), o.gu0)
+    assert abs(s.history()[4] - e0) < 1e-11 * e0
+    P = s.interior(s.field("gas.prim"))[4, 0, 0]
+    r = (np.arange(1024) + 0.5) / 1024
+    if sph:   # E = 4 pi e0 per steradian-integrated sphere; xi0(gamma=1.4, 3-D) = 1.033
+        r_s = 1.033 * (4 * np.pi * e0 * 0.1 ** 2) ** 0.2
+    else:     # E = 2 pi e0 per unit height; xi0(gamma=1.4, 2-D) = 1.004
+        r_s = 1.004 * (2 * np.pi * e0 * 0.1 ** 2) ** 0.25
+    assert abs(r[np.argmax(P)] - r_s) < 0.01, (r[np.argmax(P)], r_s)
+
+
+def test_blast_reference_curvilinear_blocks(hiplib):
+    """The same `sph` run on the deck's own 32-cell mesh blocks (32 blocks on one rank, ghost
+    slabs copied block to block, reflecting BC on the first block only): agreement with the
+    one-block run to round-off (block-local cell edges differ in the last bit)."""
+    from artemis_amd.driver import Simulation
+    ov = BLAST_GEOM["sph"] + ["parthenon/time/nlim=400"]
+    a = Simulation(DECK("blast", "blast.in"), ov + ["parthenon/meshblock/nx1=1024"])
+    b = Simulation(DECK("blast", "blast.in"), ov)
+    assert b.nblocks == 32
+    a.evolve(), b.evolve()
+    assert a.ncycle == b.ncycle == 400
+    full = a.interior(a.field("gas.prim"))
+    for blk in range(32):
+        part = b.interior(b.field("gas.prim", blk))
+        ref = full[..., blk * 32:(blk + 1) * 32]
+        assert np.max(np.abs(part - ref) / (np.abs(ref) + 1e-3)) < 1e-9, blk
+    assert abs(a.history()[4] - b.history()[4]) < 1e-12
+
+
+def test_blast_reference_axisymmetric_2d(hiplib):
+    """blast.py's `axi` run (axisymmetric 256^2 in 64 blocks, reflecting axis, spherical blast
+    with r-weighted sub-sampling): bitwise against the oracle for the first cycles on one
+    block at 64^2, then the full deck to t = 0.1 with the Sedov front and energy checks."""
+    from artemis_amd.driver import Simulation
+    small = BLAST_GEOM["axi"] + ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/meshblock/nx1=64",
+                                 "parthenon/meshblock/nx2=64", "problem/radius=0.1", "problem/samples=10",
+                                 "parthenon/time/nlim=40"]
+    s = Simulation(DECK("blast", "blast.in"), small)
+    o = Oracle((64, 64, 1), (0.0, -1.0, -0.5), (2.0, 1.0, 0.5), ng=2, reconstruct="plm", riemann="hlle",
+               gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3, integrator="rk2",
+               bc=("reflecting",) + ("outflow",) * 5, coordinates="axisymmetric")
+    o.pgen_blast(radius=0.1, internal_energy=1.0, p0=1e-5, d0=1.0, samples=10, symmetry="spherical")
+    s.evolve(), o.evolve(0.1, 40)
+    assert s.ncycle == o.ncycle == 40 and s.time == o.time
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    full = Simulation(DECK("blast", "blast.in"), BLAST_GEOM["axi"])
+    assert full.nblocks == 64
+    e0 = full.history()[4]
+    assert abs(e0 - 1.0 / (2 * np.pi)) < 1e-3  # E = 1 over the full 2 pi of azimuth
+    full.evolve()
+    assert abs(full.time - 0.1) < 1e-15 and abs(full.history()[4] - e0) < 1e-11 * e0
+    rmax, pmax = 0.0, 0.0
+    for b in range(64):
+        x1a, x1b, x2a, x2b, _, _ = full.block_bounds(b)
+        P = full.interior(full.field("gas.prim", b))[4, 0]
+        x = x1a + (np.arange(32) + 0.5) * (x1b - x1a) / 32
+        y = x2a + (np.arange(32) + 0.5) * (x2b - x2a) / 32
+        X, Y = np.meshgrid(x, y)
+        if P.max() > pmax:
+            pmax, rmax = P.max(), np.hypot(X, Y).ravel()[np.argmax(P)]
+    assert abs(rmax - 1.033 * (0.1 ** 2) ** 0.2) < 0.015, rmax

@@ -134,3 +134,35 @@ def test_unfused_path_and_block_layouts_single_process(double_lib, tmp_path):
         k0 = int(round((bounds[4] + 1.0) / (2.0 / 16)))
         ref = full[:, k0:k0 + 8, j0:j0 + 8, i0:i0 + 16]
         assert np.max(np.abs(prim - ref) / (np.abs(ref) + 1e-30)) < 1e-11
+
+
+SPH3D = dict(deck=["blast", "blast.in"], cycles=5, overrides=[
+    "artemis/coordinates=spherical", "parthenon/mesh/nx1=16", "parthenon/mesh/nx2=8", "parthenon/mesh/nx3=8",
+    "parthenon/mesh/x1min=0.2", "parthenon/mesh/x1max=1.4", "parthenon/mesh/x2min=0.7",
+    "parthenon/mesh/x2max=2.4", "parthenon/mesh/x3min=0.0", "parthenon/mesh/x3max=6.283185307179586",
+    "parthenon/mesh/ix1_bc=reflecting", "parthenon/mesh/ix2_bc=reflecting", "parthenon/mesh/ox2_bc=reflecting",
+    "parthenon/mesh/ix3_bc=periodic", "parthenon/mesh/ox3_bc=periodic",
+    "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=4", "parthenon/meshblock/nx3=4",
+    "problem/symmetry=spherical", "problem/radius=0.6", "problem/samples=0", "problem/p0=1.0e-2"])
+
+
+def test_spherical3d_two_ranks_equal_single_process_bitwise(double_lib, tmp_path):
+    """artemis/coordinates = spherical on a 3-D wedge, 2x2x2 blocks with reflecting radial /
+    polar and periodic azimuthal boundaries: the per-task path (the fused kernel is
+    Cartesian-only) with the metric tables of each rank's own blocks gives the same bits on 2
+    ranks as on 1, and mass is conserved with the spherical cell volumes."""
+    one = run_world(1, SPH3D, tmp_path, "s1")
+    two = run_world(2, SPH3D, tmp_path, "s2")
+    assert not one[0]["meta"]["fused"] and one[0]["meta"]["ncycle"] == 5
+    for r in two:
+        for k in ("ncycle", "time", "dt"):
+            assert r["meta"][k] == one[0]["meta"][k], k
+    a, b = by_bounds(one), by_bounds(two)
+    assert a.keys() == b.keys() and len(a) == 8
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+        assert np.isfinite(a[key]).all()
+    # volume of the wedge x d0 = 1: (r1^3 - r0^3)/3 * (cos t0 - cos t1) * 2 pi
+    vol = (1.4 ** 3 - 0.2 ** 3) / 3.0 * (np.cos(0.7) - np.cos(2.4)) * 2 * np.pi
+    assert abs(one[0]["hist"][0] - vol) < 1e-12 * vol
+    assert np.allclose(two[0]["hist"], one[0]["hist"], rtol=1e-13)

@@ -1,0 +1,157 @@
+"""GPU parity of the curvilinear metric path (SURVEY section 8 rows a4 PLM_G, a8 ScaleMomentumFlux,
+a10 coordinate sources, a16/a17 geometry::Coords) against the CPU oracle: cylindrical,
+spherical 1-D/2-D/3-D and axisymmetric, per task and as a whole stage, BIT-EXACT.  The oracle
+calls libm per cell the way the reference does; the product reads the same cos/sin values from
+the host-filled x2 tables (artemis_hip_metric_fill), so equality also checks the tables."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.oracle import Oracle
+from test_parity_ops import face_slices, push, random_state, same
+
+pytestmark = pytest.mark.gpu
+
+# name, nx, lower corner, upper corner (x1 = radius).  Spherical x2 ranges keep the ghost zones
+# inside (0, pi): the reference's x2v (spherical.hpp:61-68) divides by |cos - cos|, so the mirror
+# cell across a pole gets the SAME centroid as the first active cell and PLM_G's
+# 1/(x_i - x_im1) is 0/0 there (NaN in the oracle and in the product alike); the reference's own
+# spherical tests run 1-D or with the polar boundary away from the axis.
+GEOMS = [
+    ("spherical", (40, 1, 1), (0.0, 0.0, -0.5), (1.0, np.pi, 0.5)),       # blast.py "sph": r from 0
+    ("spherical", (24, 12, 1), (0.4, 0.5, -0.5), (2.5, 2.6, 0.5)),        # 2-D
+    ("spherical", (20, 10, 8), (0.3, 0.7, 0.0), (1.7, 2.5, 2 * np.pi)),   # 3-D
+    ("spherical", (16, 8, 6), (0.0, 0.6, 0.0), (1.0, 2.6, 2 * np.pi)),    # 3-D from r = 0
+    ("cylindrical", (24, 12, 6), (0.5, 0.0, -1.0), (2.0, 2 * np.pi, 1.0)),
+    ("cylindrical", (33, 1, 1), (0.0, -0.5, -0.5), (1.0, 0.5, 0.5)),
+    ("axisymmetric", (24, 12, 1), (0.0, -1.0, -0.5), (2.0, 1.0, 0.5)),    # blast.py "axi"
+    ("axisymmetric", (40, 1, 1), (0.0, -0.5, -0.5), (1.0, 0.5, 0.5)),     # blast.py "cyl"
+    ("axisymmetric", (12, 8, 6), (0.7, -1.0, 0.0), (2.0, 1.0, 1.0)),
+]
+
+
+def make_pair(coordinates, nx, lo, hi, ng=2, ns_gas=1, ns_dust=0, recon="plm", riem="hlle",
+              gamma=1.4, seed=0, bc=("outflow",) * 6, cfl=0.3):
+    from artemis_amd.pack import MeshBlockPack
+    rng = np.random.default_rng(seed)
+    kw = dict(ng=ng, ns_gas=ns_gas, ns_dust=ns_dust, reconstruct=recon, riemann=riem,
+              dust_reconstruct=recon, dust_riemann="hlle", gamma=gamma, dfloor=1e-10,
+              siefloor=1e-10, dust_dfloor=1e-10, coordinates=coordinates)
+    o = Oracle(nx, lo, hi, bc=bc, cfl=cfl, dust_cfl=cfl, **kw)
+    random_state(o, rng)
+    mb = MeshBlockPack(1, nx, [lo], [hi], **kw)
+    push([o], mb)
+    return o, mb
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", GEOMS)
+@pytest.mark.parametrize("recon,riem", [("plm", "hlle"), ("plm", "hllc"), ("ppm", "llf"), ("pcm", "hlle")])
+def test_fluxes_curvilinear(hiplib, coordinates, nx, lo, hi, recon, riem):
+    """PLM_G (plm.hpp:54-73) + ScaleMomentumFlux (fluid_fluxes.hpp:33-70), gas and dust."""
+    ng = 3 if recon == "ppm" else 2
+    o, mb = make_pair(coordinates, nx, lo, hi, ng=ng, ns_gas=2, ns_dust=1, recon=recon, riem=riem, seed=11)
+    for fluid in (0, 1):
+        o.CalculateFluxes(fluid, False)
+        mb.CalculateFluxes(fluid, False)
+    for d in range(o.ndim):
+        sl = face_slices(o, d)
+        same(mb.gas_flux[d][0][sl], o.gflux(d)[sl], f"gas flux x{d+1}")
+        same(mb.gas_pflux[d][0][sl], o.gpflux(d)[sl], f"pflux x{d+1}")
+        same(mb.gas_vface[d][0][sl], o.gvface(d)[sl], f"vface x{d+1}")
+        same(mb.dust_flux[d][0][sl], o.dflux(d)[sl], f"dust flux x{d+1}")
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", GEOMS)
+def test_tasks_curvilinear(hiplib, coordinates, nx, lo, hi):
+    """ApplyUpdate (areas, volume), FluxSource (pressure terms + coordinate sources, gas and
+    dust), SetAuxillaryFields / ConsToPrim / PrimToCons (volume-averaged scale factors) and
+    EstimateTimestepMesh (physical cell widths), one task at a time."""
+    o, mb = make_pair(coordinates, nx, lo, hi, ns_gas=1, ns_dust=2, seed=12)
+    o.DeepCopyConservedData()
+    mb.DeepCopyConservedData()
+    for fluid in (0, 1):
+        o.CalculateFluxes(fluid, False)
+        mb.CalculateFluxes(fluid, False)
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    dt = 1.0e-4
+    o.ApplyUpdate(0.5, 0.5, 0.5 * dt)
+    mb.ApplyUpdate(0.5, 0.5, 0.5 * dt)
+    same(mb.gas_u0[0][I], o.gu0[I], "ApplyUpdate gas")
+    same(mb.dust_u0[0][I], o.du0[I], "ApplyUpdate dust")
+    for fluid in (0, 1):
+        o.FluxSource(0.5 * dt, fluid)
+        mb.FluxSource(0.5 * dt, fluid)
+    same(mb.gas_u0[0][I], o.gu0[I], "FluxSource gas")
+    same(mb.dust_u0[0][I], o.du0[I], "FluxSource dust")
+    o.SetAuxillaryFields()
+    mb.SetAuxillaryFields()
+    same(mb.gas_u0[0][I], o.gu0[I], "SetAuxillaryFields")
+    o.ConsToPrim()
+    mb.ConsToPrim()
+    same(mb.gas_prim[0][I], o.gprim[I], "ConsToPrim gas")
+    same(mb.dust_prim[0][I], o.dprim[I], "ConsToPrim dust")
+    o.PrimToCons()
+    mb.PrimToCons()
+    same(mb.gas_prim[0], o.gprim, "PrimToCons prim (entire)")
+    same(mb.gas_u0[0], o.gu0, "PrimToCons gas cons (entire)")
+    same(mb.dust_u0[0], o.du0, "PrimToCons dust cons (entire)")
+    for fluid in (0, 1):
+        assert mb.EstimateTimestepMesh(fluid, cfl=0.3) == o.EstimateTimestepMesh(fluid)
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", GEOMS[:4] + GEOMS[6:7])
+def test_blast_steps_curvilinear(hiplib, coordinates, nx, lo, hi):
+    """A few RK2 steps of the blast problem generator (blast.hpp incl. ConvertToCart and the
+    axisymmetric sub-sampling) with a reflecting inner radial boundary, task by task on the
+    GPU against oracle.step()."""
+    from artemis_amd.pack import MeshBlockPack
+    bc = ("reflecting", "outflow", "reflecting", "reflecting", "periodic", "periodic")
+    kw = dict(ng=2, reconstruct="plm", riemann="hlle", gamma=1.4, dfloor=1e-10, siefloor=1e-10,
+              coordinates=coordinates)
+    o = Oracle(nx, lo, hi, cfl=0.3, bc=bc, integrator="rk2", **kw)
+    samples = 4 if coordinates == "axisymmetric" else 0
+    rad = lo[0] + 0.3 * (hi[0] - lo[0])
+    o.pgen_blast(radius=rad, internal_energy=1.0, p0=1e-3, d0=1.0, samples=samples)
+    mb = MeshBlockPack(1, nx, [lo], [hi], **kw)
+    push([o], mb)
+    for step in range(4):
+        dt = o.new_dt()
+        assert mb.EstimateTimestepMesh(0, cfl=0.3) == dt
+        o.dt = dt
+        o.step()
+        mb.DeepCopyConservedData()
+        for g0, g1, be in ((0.0, 1.0, 1.0), (0.5, 0.5, 0.5)):
+            mb.CalculateFluxes(0, False)
+            mb.ApplyUpdate(g0, g1, be * dt)
+            mb.FluxSource(be * dt)
+            mb.SetAuxillaryFields()
+            mb.ConsToPrim()
+            mb.ApplyBoundaryConditions([bc])
+            mb.PrimToCons()
+        same(mb.gas_prim[0], o.gprim, f"prim after step {step}")
+        same(mb.gas_u0[0], o.gu0, f"cons after step {step}")
+
+
+def test_metric_abi_contract(hiplib):
+    """spherical 2-D/3-D without tables is rejected; a spherical variant that does not match the
+    block dimension is rejected (geometry::CoordSelect); the fused stage stays Cartesian-only."""
+    import ctypes as C
+    from artemis_amd import capi
+    from artemis_amd.pack import MeshBlockPack
+    mb = MeshBlockPack(1, (8, 8, 1), [(0.5, 0.1, 0.0)], [(1.0, 3.0, 1.0)], coordinates="spherical")
+    L = mb.L
+    assert mb.pack.coords == capi.SPHERICAL2D and L.artemis_hip_metric_count(C.byref(mb.pack)) == 5 * 13
+    keep = mb.pack.metric
+    mb.pack.metric = None
+    assert L.artemis_hip_prim_to_cons(C.byref(mb.pack), None) == capi.EINVAL
+    assert b"metric" in L.artemis_hip_last_error()
+    mb.pack.metric = keep
+    mb.pack.coords = capi.SPHERICAL3D
+    assert L.artemis_hip_prim_to_cons(C.byref(mb.pack), None) == capi.EINVAL
+    mb.pack.coords = capi.SPHERICAL2D
+    mb.PrimToCons()
+    _, t1 = mb.new_prim_buffer("a")
+    with pytest.raises(capi.ArtemisHipError) as e:
+        mb.stage_fused(0.0, 1.0, 1e-3, 1e-3, mb.gas_prim_table, mb.gas_prim_table, t1)
+    assert e.value.code == capi.EUNSUPPORTED
+    torch.cuda.synchronize()
