@@ -39,8 +39,12 @@ def test_no_gpu_fails_loudly_and_validation():
     p.coords = 9
     assert L.artemis_hip_set_aux(C.byref(p), None) == capi.EINVAL
     assert b"Coordinate type not recognized" in L.artemis_hip_last_error()
-    p.coords = 4  # spherical3D: valid in the reference, not built here
-    assert L.artemis_hip_set_aux(C.byref(p), None) == capi.EUNSUPPORTED
+    p.coords = 4  # spherical3D needs the x2 metric tables (artemis_hip_metric_fill)
+    assert L.artemis_hip_set_aux(C.byref(p), None) == capi.EINVAL
+    assert b"metric" in L.artemis_hip_last_error()
+    p.coords = 3  # spherical2D on a 3-D block: geometry::CoordSelect never produces that
+    assert L.artemis_hip_set_aux(C.byref(p), None) == capi.EINVAL
+    assert L.artemis_hip_metric_count(C.byref(p)) == 5 * (8 + 4 + 1)
     p.coords = 0
     p.geom = 1
     p.gas.nspecies = 1
