@@ -14,7 +14,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
              "-Wall", "-Wno-unused-function"]
 
-HIP_SOURCES = ["abi.hip", "kernels_unfused.hip", "kernels_fused.hip", "selftest.hip"]
+HIP_SOURCES = ["abi.hip", "kernels_unfused.hip", "kernels_fused.hip", "kernels_sources.hip",
+               "selftest.hip"]
 
 
 def _newer(target, deps):

@@ -28,11 +28,16 @@ def coord_select(sys, ndim):
 HLLC, HLLE, LLF = 0, 1, 2
 PCM, PLM, PPM = 0, 1, 2
 GAS, DUST = 0, 1
-BC_PERIODIC, BC_OUTFLOW, BC_REFLECT, BC_NONE = 0, 1, 2, 3
+BC_PERIODIC, BC_OUTFLOW, BC_REFLECT, BC_NONE, BC_STRAT_EXTRAP, BC_STRAT_INFLOW = range(6)
+GRAVITY_UNIFORM, GRAVITY_POINT = 1, 2
+DRAG_SIMPLE_DUST, DRAG_SELF = 1, 2
+DRAG_CONSTANT, DRAG_STOKES = 0, 1
+MAX_DUST_SPECIES = 16
 RSOLVER = {"hllc": HLLC, "hlle": HLLE, "llf": LLF}
 RECON = {"pcm": PCM, "plm": PLM, "ppm": PPM}
 BCS = {"periodic": BC_PERIODIC, "outflow": BC_OUTFLOW, "reflecting": BC_REFLECT,
-       "reflect": BC_REFLECT, "none": BC_NONE}
+       "reflect": BC_REFLECT, "none": BC_NONE, "extrap": BC_STRAT_EXTRAP,
+       "inflow": BC_STRAT_INFLOW}
 
 PP = C.c_void_p  # device pointer tables are opaque to the host
 
@@ -67,6 +72,28 @@ class StageArgs(C.Structure):
     ]
 
 
+class BcParams(C.Structure):
+    _fields_ = [("qshear", C.c_double), ("omega", C.c_double)]
+
+
+class Gravity(C.Structure):
+    _fields_ = [("type", C.c_int), ("g", C.c_double * 3), ("gm", C.c_double), ("soft", C.c_double),
+                ("sink", C.c_double), ("sink_rate", C.c_double), ("pos", C.c_double * 3),
+                ("tstart", C.c_double), ("tstop", C.c_double)]
+
+
+class Damping(C.Structure):
+    _fields_ = [("ix", C.c_double * 3), ("ox", C.c_double * 3), ("irate", C.c_double * 3),
+                ("orate", C.c_double * 3)]
+
+
+class Drag(C.Structure):
+    _fields_ = [("type", C.c_int), ("model", C.c_int), ("scale", C.c_double),
+                ("grain_density", C.c_double), ("tau", C.c_double * MAX_DUST_SPECIES),
+                ("sizes", C.c_double * MAX_DUST_SPECIES), ("gas", Damping), ("dust", Damping),
+                ("xmin", C.c_double * 3), ("xmax", C.c_double * 3)]
+
+
 class ArtemisHipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"artemis_hip error {code}: {msg}")
@@ -96,7 +123,10 @@ def load():
         "artemis_hip_deep_copy_conserved": (i, [PPk, vp]),
         "artemis_hip_estimate_dt": (i, [PPk, i, d, C.POINTER(d), vp]),
         "artemis_hip_estimate_dt_async": (i, [PPk, i, d, vp, vp]),
-        "artemis_hip_apply_bc": (i, [PPk, C.POINTER(i), vp]),
+        "artemis_hip_apply_bc": (i, [PPk, C.POINTER(i), C.POINTER(BcParams), vp]),
+        "artemis_hip_external_gravity": (i, [PPk, C.POINTER(Gravity), d, d, vp]),
+        "artemis_hip_rotating_frame_force": (i, [PPk, d, d, d, d, vp]),
+        "artemis_hip_drag_source": (i, [PPk, C.POINTER(Drag), d, d, vp]),
         "artemis_hip_stage_fused": (i, [PPk, C.POINTER(StageArgs), vp]),
         "artemis_hip_wait_counter": (i, [vp, C.c_uint, vp, vp]),
         "artemis_hip_advance_dt": (i, [vp, d, i, C.POINTER(d), vp]),
@@ -142,7 +172,8 @@ EXPORTS_HIP = [
     "artemis_hip_set_aux", "artemis_hip_cons_to_prim", "artemis_hip_prim_to_cons",
     "artemis_hip_deep_copy_conserved", "artemis_hip_estimate_dt", "artemis_hip_estimate_dt_async",
     "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_metric_count",
-    "artemis_hip_metric_fill", "artemis_hip_halo_count",
+    "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_rotating_frame_force",
+    "artemis_hip_drag_source", "artemis_hip_halo_count",
     "artemis_hip_halo_pack", "artemis_hip_halo_unpack", "artemis_hip_last_error",
     "artemis_hip_device_count", "artemis_hip_version",
 ]

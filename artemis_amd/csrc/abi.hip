@@ -200,26 +200,102 @@ int artemis_hip_estimate_dt(const artemis_pack_t *p, int fluid, double cfl, doub
   return 0;
 }
 
-int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, void *stream) {
+int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_bc_params_t *params,
+                         void *stream) {
   if (int rc = validate(p)) return rc;
   if (!bc) return fail(ARTEMIS_HIP_EINVAL, "null bc array");
-  for (int i = 0; i < 6 * p->nblocks; ++i)
-    if (bc[i] < ARTEMIS_BC_PERIODIC || bc[i] > ARTEMIS_BC_NONE)
+  for (int i = 0; i < 6 * p->nblocks; ++i) {
+    if (bc[i] < ARTEMIS_BC_PERIODIC || bc[i] > ARTEMIS_BC_STRAT_INFLOW)
       return fail(ARTEMIS_HIP_EINVAL, "unknown boundary flag %d", bc[i]);
-  const int rc = artemis::launch_apply_bc(artemis::make_pack_view(*p), bc, S(stream));
+    const int d = (i % 6) / 2;
+    if (bc[i] == ARTEMIS_BC_STRAT_EXTRAP || bc[i] == ARTEMIS_BC_STRAT_INFLOW) {
+      const bool extrap = (bc[i] == ARTEMIS_BC_STRAT_EXTRAP);
+      if ((extrap && d == 1) || (!extrap && d != 1)) // problem_modifier.hpp:117-128
+        return fail(ARTEMIS_HIP_EINVAL, "strat conditions: extrap belongs to x1/x3, inflow to x2 faces");
+      if (extrap && d == 2 && p->nx3 > 1) // strat.hpp:520-523 uses std::pow on the density ratio
+        return fail(ARTEMIS_HIP_EUNSUPPORTED, "strat extrap condition on x3 faces is not built");
+      if (p->coords != ARTEMIS_CARTESIAN)
+        return fail(ARTEMIS_HIP_EINVAL, "problem = strat only works for Cartesian Coordinates!");
+      if (p->gas.nspecies > 1)
+        return fail(ARTEMIS_HIP_EINVAL, "strat conditions fill gas species 0 only (strat.hpp:188-199)");
+      if (!params) return fail(ARTEMIS_HIP_EINVAL, "strat conditions need artemis_bc_params_t");
+    }
+  }
+  const int rc = artemis::launch_apply_bc(artemis::make_pack_view(*p), bc, params, S(stream));
   if (rc == 1) return fail(ARTEMIS_HIP_EDEVICE, "could not read pointer tables from the device");
   if (rc == 2) return fail(ARTEMIS_HIP_EUNSUPPORTED, "too many FillGhost variables (max 64)");
   return after_launch("ApplyBoundaryConditions");
 }
 
+int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_t *g, double time,
+                                 double dt, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (!g) return fail(ARTEMIS_HIP_EINVAL, "null gravity parameters");
+  if (g->type != ARTEMIS_GRAVITY_UNIFORM && g->type != ARTEMIS_GRAVITY_POINT)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "gravity type %d (binary / nbody) is not built", g->type);
+  if (g->type == ARTEMIS_GRAVITY_POINT) {
+    if (p->coords == ARTEMIS_CYLINDRICAL || p->coords == ARTEMIS_SPHERICAL3D)
+      return fail(ARTEMIS_HIP_EUNSUPPORTED,
+                  "point-mass gravity in cylindrical / spherical3D coordinates is not built");
+    const bool axi = p->coords == ARTEMIS_AXISYMMETRIC || p->coords == ARTEMIS_SPHERICAL1D ||
+                     p->coords == ARTEMIS_SPHERICAL2D;
+    if (axi && !(g->pos[0] == 0.0 && g->pos[1] == 0.0 && g->pos[2] == 0.0)) // gravity.cpp:66-70
+      return fail(ARTEMIS_HIP_EINVAL,
+                  "In axisymmetric coordinates, the point mass must be at the origin!");
+  }
+  if (!((time >= g->tstart) && (time < g->tstop))) return 0; // gravity.cpp:134
+  artemis::launch_external_gravity(artemis::make_pack_view(*p), *g, dt, S(stream));
+  return after_launch("ExternalGravity");
+}
+
+int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, double qshear,
+                                     double time, double dt, void *stream) {
+  (void)time;
+  if (int rc = validate(p)) return rc;
+  if (omega == 0.0) // rotating_frame.cpp:31-32
+    return fail(ARTEMIS_HIP_EINVAL, "rotating_frame/omega cannot be zero!");
+  if (p->coords != ARTEMIS_CARTESIAN) {
+    if (qshear != 0.0) // rotating_frame.cpp:34-38
+      return fail(ARTEMIS_HIP_EINVAL,
+                  "rotating_frame/qshear must be zero for non-Cartesian coordinate systems!");
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "rotating frame in curvilinear coordinates is not built");
+  }
+  artemis::launch_shearing_box(artemis::make_pack_view(*p), omega, qshear, dt, S(stream));
+  return after_launch("RotatingFrameForce");
+}
+
+int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, double time, double dt,
+                            void *stream) {
+  (void)time;
+  if (int rc = validate(p)) return rc;
+  if (!d) return fail(ARTEMIS_HIP_EINVAL, "null drag parameters");
+  if (d->type != ARTEMIS_DRAG_SIMPLE_DUST && d->type != ARTEMIS_DRAG_SELF)
+    return fail(ARTEMIS_HIP_EINVAL, "Bad choice of drag type"); // drag.hpp:66
+  if (d->type == ARTEMIS_DRAG_SIMPLE_DUST) {
+    if (p->gas.nspecies < 1 || p->dust.nspecies < 1) // drag.cpp:71-72
+      return fail(ARTEMIS_HIP_EINVAL, "drag type simple_dust requires do_gas = do_dust = true");
+    if (p->dust.nspecies > ARTEMIS_MAX_DUST_SPECIES)
+      return fail(ARTEMIS_HIP_EUNSUPPORTED, "simple_dust drag: more than %d dust species",
+                  ARTEMIS_MAX_DUST_SPECIES);
+    if (d->model != ARTEMIS_DRAG_CONSTANT && d->model != ARTEMIS_DRAG_STOKES)
+      return fail(ARTEMIS_HIP_EINVAL, "bad type for stopping time model"); // drag.hpp:150
+  }
+  for (int i = 0; i < 3; ++i) // drag.hpp:110-115
+    if (d->gas.irate[i] < 0.0 || d->dust.irate[i] < 0.0 || d->gas.ix[i] > d->gas.ox[i] ||
+        d->dust.ix[i] > d->dust.ox[i])
+      return fail(ARTEMIS_HIP_EINVAL, "bad damping bounds / rates");
+  artemis::launch_drag_source(artemis::make_pack_view(*p), *d, dt, S(stream));
+  return after_launch("DragSource");
+}
+
 // Host-side metric tables (see include/artemis_hip.h and csrc/geometry.hpp: rows MT_COSF,
-// MT_SINF, MT_X2V, MT_SINV, MT_SINC, each nj+1 doubles per block).  Expressions follow
+// MT_SINF, MT_X2V, MT_SINV, MT_SINC, MT_COSV, each nj+1 doubles per block).  Expressions follow
 // spherical.hpp:61-68 (x2v) and :53-55, :88-104 (the sine arguments).
 long artemis_hip_metric_count(const artemis_pack_t *p) {
   if (!p) return -1;
   if (p->coords != ARTEMIS_SPHERICAL2D && p->coords != ARTEMIS_SPHERICAL3D) return 0;
   const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0);
-  return static_cast<long>(p->nblocks) * 5 * (nj + 1);
+  return static_cast<long>(p->nblocks) * 6 * (nj + 1);
 }
 int artemis_hip_metric_fill(const artemis_pack_t *p, const double *geom_host, double *out_host) {
   if (!p || !geom_host || !out_host) return fail(ARTEMIS_HIP_EINVAL, "null argument");
@@ -228,7 +304,7 @@ int artemis_hip_metric_fill(const artemis_pack_t *p, const double *geom_host, do
   const int st = nj + 1;
   for (int b = 0; b < p->nblocks; ++b) {
     const double f0 = geom_host[6 * b + 2], dx = geom_host[6 * b + 3];
-    double *m = out_host + static_cast<long>(b) * 5 * st;
+    double *m = out_host + static_cast<long>(b) * 6 * st;
     for (int j = 0; j <= nj; ++j) {
       const double xf = f0 + j * dx;
       m[0 * st + j] = std::cos(xf);
@@ -242,8 +318,9 @@ int artemis_hip_metric_fill(const artemis_pack_t *p, const double *geom_host, do
       m[2 * st + j] = x2v;
       m[3 * st + j] = std::sin(x2v);
       m[4 * st + j] = std::sin(0.5 * (x0 + x1));
+      m[5 * st + j] = std::cos(x2v);
     }
-    m[2 * st + nj] = m[3 * st + nj] = m[4 * st + nj] = 0.0;
+    m[2 * st + nj] = m[3 * st + nj] = m[4 * st + nj] = m[5 * st + nj] = 0.0;
   }
   return 0;
 }

@@ -100,7 +100,7 @@ struct Link { // one directed ghost-slab transfer out of local block b through f
   int tag_send, tag_recv;
 };
 
-enum { PG_BLAST, PG_LINWAVE, PG_ADVECTION };
+enum { PG_BLAST, PG_LINWAVE, PG_ADVECTION, PG_CONSTANT, PG_STRAT };
 
 } // namespace
 
@@ -126,6 +126,12 @@ struct artemis_sim {
       riemann_dust = ARTEMIS_HLLE;
   Real gamma = 1.66666666667, dfloor_gas = 1e-20, siefloor_gas = 1e-20, de_switch = 0.0;
   Real dfloor_dust = 1e-20, cfl_gas = 0.8, cfl_dust = 0.8;
+  // optional source packages (artemis.cpp:65-72): gravity, rotating_frame, drag
+  bool do_gravity = false, do_rframe = false, do_drag = false;
+  artemis_gravity_t grav;
+  Real rf_omega = 0.0, rf_qshear = 0.0;
+  artemis_drag_t drag;
+  artemis_bc_params_t bcpar = {0.0, 0.0};
   std::string integrator = "rk2";
   int nstages = 2;
   Real gam0[3], gam1[3], beta[3];
@@ -141,7 +147,7 @@ struct artemis_sim {
   int coords = ARTEMIS_CARTESIAN;   // geometry::CoordSelect(artemis/coordinates, ndim)
   // geometry::Coords<GEOM> of cell (k,j,i) of local block b (host side: pgens, history)
   artemis::DCoords cell_coords(int b, int k, int j, int i) const {
-    const Real *m = hmetric.empty() ? nullptr : hmetric.data() + static_cast<size_t>(b) * 5 * (nj + 1);
+    const Real *m = hmetric.empty() ? nullptr : hmetric.data() + static_cast<size_t>(b) * artemis::MT_ROWS * (nj + 1);
     return artemis::coords_of(coords, hgeom.data() + 6 * b, m, nj, k, j, i);
   }
   DevBuf tstate; // device-resident {time, dt, dt_est, beta_dt[3]} for the synchronisation-free loop
@@ -221,11 +227,15 @@ struct artemis_sim {
 
 namespace {
 
-int parse_bc(const std::string &s) {
+int parse_bc(const std::string &s, int pgen, int dir) {
   if (s == "periodic") return ARTEMIS_BC_PERIODIC;
   if (s == "outflow") return ARTEMIS_BC_OUTFLOW;
   if (s == "reflecting" || s == "reflect") return ARTEMIS_BC_REFLECT;
-  throw std::runtime_error("boundary flag '" + s + "' is not built (periodic|outflow|reflecting)");
+  // user conditions are registered per problem (problem_modifier.hpp:114-128)
+  if (pgen == PG_STRAT && s == "extrap" && dir != 1) return ARTEMIS_BC_STRAT_EXTRAP;
+  if (pgen == PG_STRAT && s == "inflow" && dir == 1) return ARTEMIS_BC_STRAT_INFLOW;
+  throw std::runtime_error("boundary flag '" + s + "' is not built for this problem "
+                           "(periodic|outflow|reflecting; strat: extrap on x1/x3, inflow on x2)");
 }
 
 // Factor nranks into a rank grid that divides the block grid, preferring to cut the slowest
@@ -268,12 +278,16 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   if (problem == "blast") pgen = PG_BLAST;
   else if (problem == "linear_wave") pgen = PG_LINWAVE;
   else if (problem == "advection") pgen = PG_ADVECTION;
+  else if (problem == "constant") pgen = PG_CONSTANT;
+  else if (problem == "strat") pgen = PG_STRAT;
   else throw std::runtime_error("problem generator '" + problem + "' is not built");
   // <physics> (artemis.cpp:63-72); everything but gas/dust must stay off
   do_gas = pin.GetOrAddBoolean("physics", "gas", true);
   do_dust = pin.GetOrAddBoolean("physics", "dust", false);
-  for (const char *k : {"gravity", "nbody", "rotating_frame", "cooling", "drag", "viscosity",
-                        "conduction", "radiation"})
+  do_gravity = pin.GetOrAddBoolean("physics", "gravity", false);
+  do_rframe = pin.GetOrAddBoolean("physics", "rotating_frame", false);
+  do_drag = pin.GetOrAddBoolean("physics", "drag", false);
+  for (const char *k : {"nbody", "cooling", "viscosity", "conduction", "radiation"})
     if (pin.GetOrAddBoolean("physics", k, false))
       throw std::runtime_error(std::string("physics/") + k + " is out of scope of this build");
   // <parthenon/mesh>
@@ -283,8 +297,8 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
     nx[d] = pin.GetOrAddInteger("parthenon/mesh", std::string("n") + xn[d], 1);
     xmin[d] = pin.GetOrAddReal("parthenon/mesh", std::string(xn[d]) + "min", -0.5);
     xmax[d] = pin.GetOrAddReal("parthenon/mesh", std::string(xn[d]) + "max", 0.5);
-    mesh_bc[2 * d] = parse_bc(pin.GetOrAddString("parthenon/mesh", std::string("i") + xn[d] + "_bc", "outflow"));
-    mesh_bc[2 * d + 1] = parse_bc(pin.GetOrAddString("parthenon/mesh", std::string("o") + xn[d] + "_bc", "outflow"));
+    mesh_bc[2 * d] = parse_bc(pin.GetOrAddString("parthenon/mesh", std::string("i") + xn[d] + "_bc", "outflow"), pgen, d);
+    mesh_bc[2 * d + 1] = parse_bc(pin.GetOrAddString("parthenon/mesh", std::string("o") + xn[d] + "_bc", "outflow"), pgen, d);
     mbnx[d] = pin.GetOrAddInteger("parthenon/meshblock", std::string("n") + xn[d], nx[d]);
     if (mbnx[d] < 1 || nx[d] % mbnx[d] != 0)
       throw std::runtime_error("mesh size must be a multiple of the meshblock size");
@@ -300,6 +314,44 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   else throw std::runtime_error("Coordinate type not recognized!");
   if (coords != ARTEMIS_CARTESIAN && pgen != PG_BLAST)
     throw std::runtime_error("problem generator '" + problem + "' is Cartesian-only");
+  // <gravity> (gravity.cpp:25-118); G = 1 in scale-free units (units.cpp:68-76)
+  if (do_gravity) {
+    std::memset(&grav, 0, sizeof grav);
+    grav.tstart = pin.GetOrAddReal("gravity", "tstart", -DBL_MAX);
+    grav.tstop = pin.GetOrAddReal("gravity", "tstop", DBL_MAX);
+    int count = 0;
+    if (pin.DoesBlockExist("gravity/uniform")) {
+      count++, grav.type = ARTEMIS_GRAVITY_UNIFORM;
+      grav.g[0] = pin.GetReal("gravity/uniform", "gx1"), grav.g[1] = pin.GetReal("gravity/uniform", "gx2");
+      grav.g[2] = pin.GetReal("gravity/uniform", "gx3");
+    }
+    if (pin.DoesBlockExist("gravity/point")) {
+      count++, grav.type = ARTEMIS_GRAVITY_POINT;
+      grav.gm = 1.0 * pin.GetReal("gravity/point", "mass");
+      grav.soft = pin.GetOrAddReal("gravity/point", "soft", 0.0);
+      grav.sink = pin.GetOrAddReal("gravity/point", "sink", 0.0);
+      grav.sink_rate = pin.GetOrAddReal("gravity/point", "sink_rate", 0.0);
+      grav.pos[0] = pin.GetOrAddReal("gravity/point", "x", 0.0);
+      grav.pos[1] = pin.GetOrAddReal("gravity/point", "y", 0.0);
+      grav.pos[2] = pin.GetOrAddReal("gravity/point", "z", 0.0);
+    }
+    if (pin.DoesBlockExist("gravity/binary") || pin.DoesBlockExist("gravity/nbody"))
+      throw std::runtime_error("gravity/binary and gravity/nbody are out of scope of this build");
+    if (count == 0) throw std::runtime_error("Unknown gravity node!");
+    if (count != 1) throw std::runtime_error("artemis only supports 1 gravity type at this time");
+  }
+  // <rotating_frame> (rotating_frame.cpp:24-50)
+  if (do_rframe) {
+    rf_omega = pin.GetReal("rotating_frame", "omega");
+    rf_qshear = pin.GetOrAddReal("rotating_frame", "qshear", 0.0);
+    if (rf_omega == 0.0) throw std::runtime_error("rotating_frame/omega cannot be zero!");
+    if (coords != ARTEMIS_CARTESIAN)
+      throw std::runtime_error("rotating frame in curvilinear coordinates is not built yet");
+  }
+  if (pgen == PG_STRAT) { // strat.hpp:55-70 InitStratParams reads the rotating_frame package
+    if (!do_rframe) throw std::runtime_error("problem = strat requires physics/rotating_frame");
+    bcpar.qshear = rf_qshear, bcpar.omega = rf_omega;
+  }
   // <parthenon/time>
   tlim = pin.GetOrAddReal("parthenon/time", "tlim", -1.0);
   nlim = pin.GetOrAddInteger("parthenon/time", "nlim", -1);
@@ -354,6 +406,58 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
     dfloor_dust = pin.GetOrAddReal("dust", "dfloor", 1.0e-20);
     ns_dust = pin.GetOrAddInteger("dust", "nspecies", 1);
   }
+  // <drag> (drag.cpp:25-84, drag.hpp:68-153), <dust> sizes / grain_density (dust.cpp:102-176)
+  if (do_drag) {
+    std::memset(&drag, 0, sizeof drag);
+    const std::string t = pin.GetString("drag", "type");
+    if (t == "self") drag.type = ARTEMIS_DRAG_SELF;
+    else if (t == "simple_dust") drag.type = ARTEMIS_DRAG_SIMPLE_DUST;
+    else throw std::runtime_error("Bad choice of drag type");
+    for (int d = 0; d < 3; ++d) drag.xmin[d] = xmin[d], drag.xmax[d] = xmax[d];
+    auto damping = [&](const std::string &blk, artemis_damping_t &o, bool present) {
+      const char *ax[3] = {"x1", "x2", "x3"};
+      for (int d = 0; d < 3; ++d) {
+        o.ix[d] = -DBL_MAX, o.ox[d] = DBL_MAX, o.irate[d] = 0.0, o.orate[d] = 0.0;
+        if (!present) continue;
+        o.ix[d] = pin.GetOrAddReal(blk, std::string("inner_") + ax[d], -DBL_MAX);
+        o.irate[d] = pin.GetOrAddReal(blk, std::string("inner_") + ax[d] + "_rate", 0.0);
+        o.ox[d] = pin.GetOrAddReal(blk, std::string("outer_") + ax[d], DBL_MAX);
+        o.orate[d] = pin.GetOrAddReal(blk, std::string("outer_") + ax[d] + "_rate", 0.0);
+      }
+      if (present && pin.GetOrAddBoolean(blk, "damp_to_visc", false))
+        throw std::runtime_error("damp_to_visc needs the viscosity package (out of scope)");
+    };
+    const bool gd = do_gas && pin.DoesBlockExist("gas/damping"), dd = do_dust && pin.DoesBlockExist("dust/damping");
+    if (drag.type == ARTEMIS_DRAG_SELF && ((do_gas && !gd) || (do_dust && !dd)))
+      throw std::runtime_error("With do_drag = true you need a gas/damping (dust/damping) node");
+    damping("gas/damping", drag.gas, gd);
+    damping("dust/damping", drag.dust, dd);
+    if (drag.type == ARTEMIS_DRAG_SIMPLE_DUST) {
+      if (!(do_gas && do_dust)) throw std::runtime_error("drag type simple_dust requires do_gas = do_dust = true");
+      if (!pin.DoesBlockExist("dust/stopping_time"))
+        throw std::runtime_error("drag type simple_dust requires a dust/stopping_time node");
+      if (ns_dust > ARTEMIS_MAX_DUST_SPECIES) throw std::runtime_error("too many dust species for simple_dust drag");
+      const std::string m = pin.GetString("dust/stopping_time", "type");
+      drag.scale = pin.GetOrAddReal("dust/stopping_time", "scale", 1.0);
+      if (m == "constant") {
+        drag.model = ARTEMIS_DRAG_CONSTANT;
+        const std::vector<double> taus = pin.GetVector("dust/stopping_time", "tau");
+        if (static_cast<int>(taus.size()) < ns_dust) throw std::runtime_error("dust/stopping_time/tau is too short");
+        for (int n = 0; n < ns_dust; ++n) drag.tau[n] = drag.scale * taus[n];
+      } else if (m == "stokes") {
+        drag.model = ARTEMIS_DRAG_STOKES;
+        for (int n = 0; n < ns_dust; ++n) drag.tau[n] = drag.scale;
+        if (pin.GetOrAddString("dust", "size_input", "direct") != "direct")
+          throw std::runtime_error("dust/size_input: only `direct` is built");
+        const std::vector<double> sz = pin.GetVector("dust", "sizes");
+        if (static_cast<int>(sz.size()) < ns_dust) throw std::runtime_error("dust/sizes is too short");
+        for (int n = 0; n < ns_dust; ++n) drag.sizes[n] = 1.0 * sz[n];
+      } else {
+        throw std::runtime_error("bad type for stopping time model");
+      }
+      drag.grain_density = 1.0 * pin.GetOrAddReal("dust", "grain_density", 1.0);
+    }
+  }
   auto need = [&](int recon) { return recon == ARTEMIS_PCM ? 1 : (recon == ARTEMIS_PLM ? 2 : 3); };
   if ((do_gas && ng < need(recon_gas)) || (do_dust && ng < need(recon_dust)))
     throw std::runtime_error("reconstruction requires more ghost cells (gas.cpp:61-76)");
@@ -361,7 +465,8 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   build_mesh();
   allocate();
   fused_possible = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
-                   coords == ARTEMIS_CARTESIAN; // curvilinear systems run the per-task kernels
+                   coords == ARTEMIS_CARTESIAN && // curvilinear systems run the per-task kernels
+                   !do_gravity && !do_rframe && !do_drag && pgen != PG_STRAT; // so do source terms
   use_fused = fused_possible;
   if (!use_fused) ensure_unfused();
   problem_generator();
@@ -572,7 +677,7 @@ void artemis_sim::fill_ghosts_finish(int prim_idx, void *hs) {
     CK(artemis_rt_event_record(ev1, hs), "event");
     CK(artemis_rt_stream_wait_event(stream, ev1), "wait");
   }
-  CK(artemis_hip_apply_bc(&p, bc_flat.data(), stream), "apply_bc");
+  CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bcpar, stream), "apply_bc");
 }
 void artemis_sim::fill_ghosts(int prim_idx) {
   fill_ghosts_start(prim_idx, stream);
@@ -690,6 +795,30 @@ void artemis_sim::problem_generator() {
     throw std::runtime_error("Bad blast wave symmetry parameter in <problem>!");
   const int btype = (sym == "spherical") ? 1 : 2;
 
+  // constant.hpp:63-78 / strat.hpp:55-70 parameters; Cv = kB / ((gamma-1) amu mu) with
+  // kB = amu = 1 in scale-free units and mu = 1 (gas.cpp:106-116, units.cpp:68-76)
+  struct { Real g_rho = 1, g_v[3] = {0, 0, 0}, g_temp = 1, d_rho = 1, d_v[3] = {0, 0, 0}; } cs;
+  struct { Real h = 1, rho0 = 1, dens_min = 1e-5, d2g = 0.01; } st;
+  const Real cv = 1.0 / ((gamma - 1.) * 1.0 * pin.GetOrAddReal("gas", "mu", 1.));
+  if (pgen == PG_CONSTANT) {
+    if (do_gas && ns_gas != 1) throw std::runtime_error("Constant pgen requires a single gas species.");
+    if (pin.GetString("problem", "system") != "cartesian")
+      throw std::runtime_error("constant pgen: only problem/system = cartesian is built");
+    cs.g_rho = pin.GetOrAddReal("problem", "gas_rho", 1.0);
+    cs.g_v[0] = pin.GetOrAddReal("problem", "gas_vx1", 0.0), cs.g_v[1] = pin.GetOrAddReal("problem", "gas_vx2", 0.0);
+    cs.g_v[2] = pin.GetOrAddReal("problem", "gas_vx3", 0.0);
+    cs.g_temp = pin.GetOrAddReal("problem", "gas_temp", 1.0);
+    cs.d_rho = pin.GetOrAddReal("problem", "dust_rho", 1.0);
+    cs.d_v[0] = pin.GetOrAddReal("problem", "dust_vx1", 0.0), cs.d_v[1] = pin.GetOrAddReal("problem", "dust_vx2", 0.0);
+    cs.d_v[2] = pin.GetOrAddReal("problem", "dust_vx3", 0.0);
+  }
+  if (pgen == PG_STRAT) {
+    if (!do_gas || ns_gas != 1) throw std::runtime_error("strat pgen requires a single gas species.");
+    st.h = pin.GetOrAddReal("problem", "h", 1.0);
+    st.rho0 = pin.GetOrAddReal("problem", "rho0", 1.0);
+    st.dens_min = pin.GetOrAddReal("problem", "dens_min", 1.0e-5);
+    st.d2g = pin.GetOrAddReal("problem", "dust_to_gas", 0.01);
+  }
   std::vector<Real> hg(static_cast<size_t>(6) * ns_gas * N), hd(static_cast<size_t>(4) * ns_dust * N);
   for (int b = 0; b < nb; ++b) {
     std::fill(hg.begin(), hg.end(), 0.0);
@@ -701,7 +830,44 @@ void artemis_sim::problem_generator() {
           const Real b3[2] = {xf(b, 2, k), xf(b, 2, k + 1)};
           const Real xv[3] = {0.5 * (b1[0] + b1[1]), 0.5 * (b2[0] + b2[1]), 0.5 * (b3[0] + b3[1])};
           const size_t c = (static_cast<size_t>(k) * nj + j) * ni + i;
-          if (pgen == PG_BLAST) { // blast.hpp:168-228
+          if (pgen == PG_CONSTANT) { // constant.hpp:100-163, problem/system = cartesian
+            const Real ex1[3] = {1.0, 0.0, 0.0}, ex2[3] = {0.0, 1.0, 0.0}, ex3[3] = {0.0, 0.0, 1.0};
+            if (do_gas) {
+              hg[0 * N + c] = cs.g_rho;
+              hg[(ns_gas + 0) * N + c] = (cs.g_v[0] * ex1[0] + cs.g_v[1] * ex1[1] + cs.g_v[2] * ex1[2]);
+              hg[(ns_gas + 1) * N + c] = (cs.g_v[0] * ex2[0] + cs.g_v[1] * ex2[1] + cs.g_v[2] * ex2[2]);
+              hg[(ns_gas + 2) * N + c] = (cs.g_v[0] * ex3[0] + cs.g_v[1] * ex3[1] + cs.g_v[2] * ex3[2]);
+              hg[(5 * ns_gas) * N + c] = std::max(0.0, cv * cs.g_temp);
+            }
+            for (int n = 0; n < ns_dust; ++n) {
+              hd[n * N + c] = cs.d_rho;
+              hd[(ns_dust + 3 * n + 0) * N + c] = (cs.d_v[0] * ex1[0] + cs.d_v[1] * ex1[1] + cs.d_v[2] * ex1[2]);
+              hd[(ns_dust + 3 * n + 1) * N + c] = (cs.d_v[0] * ex2[0] + cs.d_v[1] * ex2[1] + cs.d_v[2] * ex2[2]);
+              hd[(ns_dust + 3 * n + 2) * N + c] = (cs.d_v[0] * ex3[0] + cs.d_v[1] * ex3[1] + cs.d_v[2] * ex3[2]);
+            }
+          } else if (pgen == PG_STRAT) { // strat.hpp:116-148
+            const Real x = xv[0];
+            const Real z = xv[2];
+            const Real vx1 = 0.0;
+            const Real vx2 = -rf_qshear * rf_omega * x;
+            const Real vx3 = 0.0;
+            const Real temp = SQR(st.h * rf_omega);
+            const Real efac = (ndim == 3) ? std::exp(-SQR(z) / (2.0 * SQR(st.h))) : 1.0;
+            const Real dens = std::max(st.dens_min, efac * st.rho0);
+            const Real sie = std::max(0.0, cv * temp);
+            hg[0 * N + c] = dens;
+            hg[(ns_gas + 0) * N + c] = vx1;
+            hg[(ns_gas + 1) * N + c] = vx2;
+            hg[(ns_gas + 2) * N + c] = vx3;
+            hg[(5 * ns_gas) * N + c] = sie;
+            const Real ddens = dens * st.d2g;
+            for (int n = 0; n < ns_dust; ++n) {
+              hd[n * N + c] = ddens;
+              hd[(ns_dust + 3 * n + 0) * N + c] = vx1;
+              hd[(ns_dust + 3 * n + 1) * N + c] = vx2;
+              hd[(ns_dust + 3 * n + 2) * N + c] = vx3;
+            }
+          } else if (pgen == PG_BLAST) { // blast.hpp:168-228
             const artemis::DCoords co = cell_coords(b, k, j, i);
             const Real total_vol = co.volume();
             const Real e0 = p0 / gm1;
@@ -945,6 +1111,11 @@ void artemis_sim::step_unfused() {
     CK(artemis_hip_apply_update(&p, gam0[stage - 1], gam1[stage - 1], beta[stage - 1] * dt, stream), "ApplyUpdate");
     if (do_gas) CK(artemis_hip_flux_source(&p, ARTEMIS_GAS, bdt, stream), "Gas::FluxSource");
     if (do_dust) CK(artemis_hip_flux_source(&p, ARTEMIS_DUST, bdt, stream), "Dust::FluxSource");
+    // artemis_driver.cpp:222-241: gravity, rotating frame, drag, in this order, with the time at
+    // the start of the step (:167)
+    if (do_gravity) CK(artemis_hip_external_gravity(&p, &grav, time, bdt, stream), "ExternalGravity");
+    if (do_rframe) CK(artemis_hip_rotating_frame_force(&p, rf_omega, rf_qshear, time, bdt, stream), "RotatingFrameForce");
+    if (do_drag) CK(artemis_hip_drag_source(&p, &drag, time, bdt, stream), "DragSource");
     CK(artemis_hip_set_aux(&p, stream), "SetAuxillaryFields");
     CK(artemis_hip_cons_to_prim(&p, stream), "ConsToPrim");
     fill_ghosts(base);
@@ -1060,7 +1231,7 @@ int artemis_sim::history(double *out) {
 
 // linear_wave.hpp:267-377 / advection.hpp:224-405 UserWorkAfterLoop
 int artemis_sim::errors(double *out) {
-  if (pgen == PG_BLAST) return 0;
+  if (pgen != PG_LINWAVE && pgen != PG_ADVECTION) return 0;
   materialise_cons();
   Real l1[13];
   for (int q = 0; q < 13; ++q) l1[q] = 0.0;

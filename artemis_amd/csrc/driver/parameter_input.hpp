@@ -8,6 +8,8 @@
 #pragma once
 #include <cstdlib>
 #include <map>
+#include <vector>
+#include <set>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -35,6 +37,7 @@ class ParameterInput {
         const auto close = line.find('>');
         if (close == std::string::npos) throw std::runtime_error("bad block header: " + line);
         block = trim(line.substr(1, close - 1));
+        blocks_.insert(block);
         continue;
       }
       const auto eq = line.find('=');
@@ -57,6 +60,19 @@ class ParameterInput {
   }
   void Set(const std::string &block, const std::string &key, const std::string &val) {
     data_[block + "/" + key] = val;
+    blocks_.insert(block);
+  }
+  bool DoesBlockExist(const std::string &block) const { return blocks_.count(block) > 0; }
+  // comma-separated list (parthenon ParameterInput::GetVector, upstream)
+  std::vector<double> GetVector(const std::string &b, const std::string &k) const {
+    std::vector<double> out;
+    std::istringstream in(GetString(b, k));
+    std::string tok;
+    while (std::getline(in, tok, ',')) {
+      tok = trim(tok);
+      if (!tok.empty()) out.push_back(std::strtod(tok.c_str(), nullptr));
+    }
+    return out;
   }
   bool DoesParameterExist(const std::string &block, const std::string &key) const {
     return data_.count(block + "/" + key) > 0;
@@ -121,6 +137,7 @@ class ParameterInput {
     return t;
   }
   std::map<std::string, std::string> data_;
+  std::set<std::string> blocks_;
 };
 
 } // namespace artemis_host

@@ -27,13 +27,14 @@
 namespace artemis {
 
 // Table rows of one block: stride nj + 1 doubles each.
-enum { MT_COSF = 0, MT_SINF = 1, MT_X2V = 2, MT_SINV = 3, MT_SINC = 4, MT_ROWS = 5 };
+enum { MT_COSF = 0, MT_SINF = 1, MT_X2V = 2, MT_SINV = 3, MT_SINC = 4, MT_COSV = 5, MT_ROWS = 6 };
 
 struct DCoords {
   int sys;
   double x1[2], x2[2], x3[2];
   double cf[2], sf[2]; // cos / sin of the two x2 faces         (spherical2D/3D only)
   double x2c, sv, sc;  // x2 centroid, sin(centroid), sin(0.5*(x2[0]+x2[1]))
+  double cv;           // cos(centroid) (basis vectors of ConvertVecToCyl, spherical.hpp:198-205)
 
   GDEV bool sph23() const { return sys == ARTEMIS_SPHERICAL2D || sys == ARTEMIS_SPHERICAL3D; }
   GDEV bool sph() const { return sys == ARTEMIS_SPHERICAL1D || sph23(); }
@@ -176,12 +177,13 @@ GDEV DCoords coords_of(int sys, const double *g, const double *m, int nj, int k,
   c.x1[0] = g[0] + i * g[1], c.x1[1] = g[0] + (i + 1) * g[1];
   c.x2[0] = g[2] + j * g[3], c.x2[1] = g[2] + (j + 1) * g[3];
   c.x3[0] = g[4] + k * g[5], c.x3[1] = g[4] + (k + 1) * g[5];
-  c.cf[0] = c.cf[1] = c.sf[0] = c.sf[1] = c.x2c = c.sv = c.sc = 0.0;
+  c.cf[0] = c.cf[1] = c.sf[0] = c.sf[1] = c.x2c = c.sv = c.sc = c.cv = 0.0;
   if (c.sph23()) {
     const int st = nj + 1;
     c.cf[0] = m[MT_COSF * st + j], c.cf[1] = m[MT_COSF * st + j + 1];
     c.sf[0] = m[MT_SINF * st + j], c.sf[1] = m[MT_SINF * st + j + 1];
     c.x2c = m[MT_X2V * st + j], c.sv = m[MT_SINV * st + j], c.sc = m[MT_SINC * st + j];
+    c.cv = m[MT_COSV * st + j];
   }
   return c;
 }

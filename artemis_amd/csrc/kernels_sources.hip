@@ -1,0 +1,367 @@
+// Pointwise source-term tasks that sit between FluxSource and SetAuxillaryFields in the
+// reference's stage (artemis_driver.cpp:222-241): ExternalGravity, RotatingFrameForce,
+// DragSource.  Each reads primitives / conserved variables of one cell and updates the
+// conserved variables of the same cell: pure streaming kernels, thread x walks i.
+#include <cfloat>
+
+#include "device_math.hpp"
+#include "geometry.hpp"
+#include "kernels.hpp"
+#include "pack_view.hpp"
+
+namespace artemis {
+namespace {
+constexpr int TX = 64, TY = 4;
+
+#define INTERIOR_CELL                                                                      \
+  const int i = P.is + blockIdx.x * TX + threadIdx.x;                                      \
+  const int j = P.js + blockIdx.y * TY + threadIdx.y;                                      \
+  const int nkr = P.ke - P.ks + 1;                                                         \
+  const int b = blockIdx.z / nkr;                                                          \
+  const int k = P.ks + blockIdx.z % nkr;                                                   \
+  if (i > P.ie || j > P.je) return;                                                        \
+  const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
+
+inline dim3 interior_grid(const PackView &P) {
+  return dim3((P.ie - P.is + TX) / TX, (P.je - P.js + TY) / TY, (P.ke - P.ks + 1) * P.nb);
+}
+
+// Volume-averaged scale factors of any system (GetScaleFactors, geometry.hpp:384-388)
+__device__ __forceinline__ void scale_factors(const DCoords &co, double hx[3]) {
+  hx[0] = 1.0, hx[1] = co.hx2v(), hx[2] = co.hx3v();
+}
+
+// Coords<GEOM>::ConvertToCylWithVec (geometry.hpp:476-482): cylindrical radius of the cell
+// centroid and the first component of each basis vector (geometry.hpp:289-306,
+// cylindrical.hpp:117-126, spherical.hpp:191-205 / :382-396 / :556-577, axisymmetric.hpp:134-145).
+struct CylVec {
+  double R, e1, e2, e3;
+};
+__device__ __forceinline__ CylVec to_cyl_with_vec(const DCoords &co, const double xv[3]) {
+  CylVec c;
+  switch (co.sys) {
+  case ARTEMIS_CARTESIAN: {
+    const double R = sqrt(xv[0] * xv[0] + xv[1] * xv[1]);
+    c.R = R, c.e1 = xv[0] / (R + 1e-99), c.e2 = xv[1] / (R + 1e-99), c.e3 = 0.0; // Fuzz<Real>()
+  } break;
+  case ARTEMIS_SPHERICAL3D:
+  case ARTEMIS_SPHERICAL2D: c.R = xv[0] * co.sv, c.e1 = co.sv, c.e2 = co.cv, c.e3 = 0.0; break;
+  case ARTEMIS_SPHERICAL1D: c.R = xv[0] * 1.0, c.e1 = 1.0, c.e2 = 0.0, c.e3 = 0.0; break;
+  default: c.R = xv[0], c.e1 = 1.0, c.e2 = 0.0, c.e3 = 0.0;
+  }
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------
+// Gravity::ExternalGravity (gravity.cpp:126-155): UniformGravity (uniform.cpp:28-84) and
+// PointMassGravity (point_mass.cpp:27-198; Cartesian, spherical1D/2D, axisymmetric).
+__global__ __launch_bounds__(TX *TY) void gravity_kernel(const PackView P, const artemis_gravity_t G,
+                                                         double dt) {
+  INTERIOR_CELL
+  const DCoords co = make_coords(P, b, k, j, i);
+  const double dx[3] = {co.x1v(), co.x2v(), co.x3v()};
+  double hx[3];
+  scale_factors(co, hx);
+  const bool multi_d = P.ndim >= 2, three_d = P.ndim == 3;
+  double gx1 = 0.0, gx2 = 0.0, gx3 = 0.0, fd = 0.0;
+  const bool uniform = (G.type == ARTEMIS_GRAVITY_UNIFORM);
+  if (uniform) {
+    gx1 = G.g[0], gx2 = G.g[1], gx3 = G.g[2];
+  } else {
+    const double gm = G.gm, rsft2 = sqr(G.soft);
+    double dr;
+    if (co.sys == ARTEMIS_SPHERICAL1D || co.sys == ARTEMIS_SPHERICAL2D) { // :78-81
+      const double rad2 = sqr(dx[0]) + rsft2;
+      gx1 = -gm / rad2;
+      dr = sqrt(rad2);
+    } else if (co.sys == ARTEMIS_AXISYMMETRIC) { // :82-89
+      const double rsph = sqrt(dx[0] * dx[0] + dx[1] * dx[1]);
+      const double ct = dx[1] / (rsph + 1e-99);
+      const double st = dx[0] / (rsph + 1e-99);
+      dr = rsph;
+      const double rad2 = sqr(dr) + rsft2;
+      const double g = -gm / rad2;
+      gx1 = g * st;
+      gx2 = g * ct;
+    } else { // Cartesian (:91-112)
+      double dxc[3] = {dx[0], dx[1], dx[2]};
+      for (int n = 0; n < 3; n++) dxc[n] -= G.pos[n];
+      const double R = sqrt(dxc[0] * dxc[0] + dxc[1] * dxc[1]);
+      const double r = sqrt(R * R + dxc[2] * dxc[2]);
+      dr = r;
+      const double rad2 = sqr(dr) + rsft2;
+      const double idr3 = 1.0 / (sqrt(rad2) * rad2);
+      const double g[3] = {-gm * dxc[0] * idr3, (multi_d) * (-gm * dxc[1] * idr3),
+                           (three_d) * (-gm * dxc[2] * idr3)};
+      gx1 = g[0] * 1.0 + g[1] * 0.0 + g[2] * 0.0;
+      gx2 = g[0] * 0.0 + g[1] * 1.0 + g[2] * 0.0;
+      gx3 = g[0] * 0.0 + g[1] * 0.0 + g[2] * 1.0;
+    }
+    const double sink_rate = dt * G.sink_rate;
+    const double sramp = sink_rate * sqr((dr - G.sink) / G.sink); // quad_ramp, gravity.hpp:116
+    const double sfrac = sramp / (1.0 + sramp);
+    fd = (sfrac < 0.5) ? sfrac : 0.5; // std::min(0.5, sfrac): a NaN ratio (sink = 0) keeps 0.5
+    fd *= ((sink_rate > 0.0) && (dr <= G.sink));
+  }
+  {
+    const FluidView &f = P.gas;
+    const int ns = f.ns, nv = 6 * ns;
+    for (int n = 0; n < ns; ++n) {
+      const double rho = f.prim[b * nv + n][c];
+      const double v1 = f.prim[b * nv + ns + 3 * n + 0][c];
+      const double v2 = f.prim[b * nv + ns + 3 * n + 1][c];
+      const double v3 = f.prim[b * nv + ns + 3 * n + 2][c];
+      double m1 = f.cons0[b * nv + ns + 3 * n + 0][c], m2 = f.cons0[b * nv + ns + 3 * n + 1][c];
+      double m3 = f.cons0[b * nv + ns + 3 * n + 2][c], en = f.cons0[b * nv + 4 * ns + n][c];
+      if (uniform) {
+        const double rdt = dt * rho;
+        m1 += rdt * hx[0] * gx1, m2 += rdt * hx[1] * gx2, m3 += rdt * hx[2] * gx3;
+        en += rdt * (v1 * gx1 + v2 * gx2 + v3 * gx3);
+      } else {
+        const double sie = f.prim[b * nv + 5 * ns + n][c];
+        const double tote = rho * (sie + 0.5 * (sqr(v1) + sqr(v2) + sqr(v3)));
+        m1 += dt * rho * hx[0] * gx1, m2 += dt * rho * hx[1] * gx2, m3 += dt * rho * hx[2] * gx3;
+        en += dt * rho * (v1 * gx1 + v2 * gx2 + v3 * gx3);
+        f.cons0[b * nv + n][c] -= fd * rho;
+        m1 -= fd * hx[0] * rho * v1, m2 -= fd * hx[1] * rho * v2, m3 -= fd * hx[2] * rho * v3;
+        en -= fd * tote;
+      }
+      f.cons0[b * nv + ns + 3 * n + 0][c] = m1, f.cons0[b * nv + ns + 3 * n + 1][c] = m2;
+      f.cons0[b * nv + ns + 3 * n + 2][c] = m3, f.cons0[b * nv + 4 * ns + n][c] = en;
+    }
+  }
+  {
+    const FluidView &f = P.dust;
+    const int ns = f.ns, nv = 4 * ns;
+    for (int n = 0; n < ns; ++n) {
+      const double rho = f.prim[b * nv + n][c];
+      double m1 = f.cons0[b * nv + ns + 3 * n + 0][c], m2 = f.cons0[b * nv + ns + 3 * n + 1][c];
+      double m3 = f.cons0[b * nv + ns + 3 * n + 2][c];
+      if (uniform) {
+        const double rdt = dt * rho;
+        m1 += rdt * hx[0] * gx1, m2 += rdt * hx[1] * gx2, m3 += rdt * hx[2] * gx3;
+      } else {
+        const double v1 = f.prim[b * nv + ns + 3 * n + 0][c];
+        const double v2 = f.prim[b * nv + ns + 3 * n + 1][c];
+        const double v3 = f.prim[b * nv + ns + 3 * n + 2][c];
+        m1 += dt * rho * hx[0] * gx1, m2 += dt * rho * hx[1] * gx2, m3 += dt * rho * hx[2] * gx3;
+        f.cons0[b * nv + n][c] -= fd * rho;
+        m1 -= fd * hx[0] * rho * v1, m2 -= fd * hx[1] * rho * v2, m3 -= fd * hx[2] * rho * v3;
+      }
+      f.cons0[b * nv + ns + 3 * n + 0][c] = m1, f.cons0[b * nv + ns + 3 * n + 1][c] = m2;
+      f.cons0[b * nv + ns + 3 * n + 2][c] = m3;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// RotatingFrame::ShearingBoxImpl (rotating_frame_impl.hpp:28-93), Cartesian.
+__global__ __launch_bounds__(TX *TY) void shearing_box_kernel(const PackView P, double om0,
+                                                              double qshear, double dt) {
+  INTERIOR_CELL
+  const double *g = P.geom + 6 * b;
+  const double x1a = g[0] + i * g[1], x1b = g[0] + (i + 1) * g[1];
+  const double x3a = g[4] + k * g[5], x3b = g[4] + (k + 1) * g[5];
+  const int three_d = (P.ndim == 3);
+  const double omsq = sqr(om0);
+  const double dx = x1b - x1a;
+  const double dz = x3b - x3a;
+  const double phi_xm1 = -qshear * omsq * x1a * x1a;
+  const double phi_xp1 = -qshear * omsq * x1b * x1b;
+  const double phi_zm1 = 0.5 * omsq * x3a * x3a;
+  const double phi_zp1 = 0.5 * omsq * x3b * x3b;
+  const double dpx = (phi_xp1 - phi_xm1) / dx;
+  const double dpz = three_d * ((phi_zp1 - phi_zm1) / dz);
+  {
+    const FluidView &f = P.gas;
+    const int ns = f.ns, nv = 6 * ns;
+    for (int n = 0; n < ns; ++n) {
+      const double dens = f.prim[b * nv + n][c];
+      const double v1 = f.prim[b * nv + ns + 3 * n + 0][c];
+      const double v2 = f.prim[b * nv + ns + 3 * n + 1][c];
+      const double v3 = f.prim[b * nv + ns + 3 * n + 2][c];
+      const double rdt = dens * dt;
+      f.cons0[b * nv + ns + 3 * n + 0][c] -= rdt * (dpx - 2.0 * om0 * v2);
+      f.cons0[b * nv + ns + 3 * n + 1][c] -= rdt * 2.0 * om0 * v1;
+      f.cons0[b * nv + ns + 3 * n + 2][c] -= rdt * dpz;
+      f.cons0[b * nv + 4 * ns + n][c] -= rdt * (v1 * dpx + v3 * dpz);
+    }
+  }
+  {
+    const FluidView &f = P.dust;
+    const int ns = f.ns, nv = 4 * ns;
+    for (int n = 0; n < ns; ++n) {
+      const double dens = f.prim[b * nv + n][c];
+      const double v1 = f.prim[b * nv + ns + 3 * n + 0][c];
+      const double v2 = f.prim[b * nv + ns + 3 * n + 1][c];
+      const double rdt = dens * dt;
+      f.cons0[b * nv + ns + 3 * n + 0][c] -= rdt * (dpx - 2.0 * om0 * v2);
+      f.cons0[b * nv + ns + 3 * n + 1][c] -= rdt * 2.0 * om0 * v1;
+      f.cons0[b * nv + ns + 3 * n + 2][c] -= rdt * dpz;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Drag::DragSource (drag.cpp:89-175) with damp_to_visc = false.
+__device__ __forceinline__ void damping_ramps(const artemis_damping_t &p, const artemis_drag_t &D,
+                                              int ndim, const double xv[3], double dt,
+                                              double f[3]) {
+  const int multi_d = (ndim >= 2), three_d = (ndim == 3);
+  f[0] = dt * (p.irate[0] * ((xv[0] < p.ix[0]) * sqr((xv[0] - p.ix[0]) / (p.ix[0] - D.xmin[0]))) +
+               p.orate[0] * ((xv[0] > p.ox[0]) * sqr((xv[0] - p.ox[0]) / (p.ox[0] - D.xmax[0]))));
+  f[1] = multi_d * dt *
+         (p.irate[1] * ((xv[1] < p.ix[1]) * sqr((xv[1] - p.ix[1]) / (p.ix[1] - D.xmin[1]))) +
+          p.orate[1] * ((xv[1] > p.ox[1]) * sqr((xv[1] - p.ox[1]) / (p.ox[1] - D.xmax[1]))));
+  f[2] = three_d * dt *
+         (p.irate[2] * ((xv[2] < p.ix[2]) * sqr((xv[2] - p.ix[2]) / (p.ix[2] - D.xmin[2]))) +
+          p.orate[2] * ((xv[2] > p.ox[2]) * sqr((xv[2] - p.ox[2]) / (p.ox[2] - D.xmax[2]))));
+}
+
+// SelfDragSourceImpl (drag.hpp:171-294)
+__global__ __launch_bounds__(TX *TY) void self_drag_kernel(const PackView P, const artemis_drag_t D,
+                                                           double dt) {
+  INTERIOR_CELL
+  const DCoords co = make_coords(P, b, k, j, i);
+  const double xv[3] = {co.x1v(), co.x2v(), co.x3v()};
+  double hx[3];
+  scale_factors(co, hx);
+  const CylVec cv = to_cyl_with_vec(co, xv);
+  double bg[3], bd[3];
+  damping_ramps(D.gas, D, P.ndim, xv, dt, bg);
+  damping_ramps(D.dust, D, P.ndim, xv, dt, bd);
+  {
+    const FluidView &f = P.gas;
+    const int ns = f.ns, nv = 6 * ns;
+    for (int n = 0; n < ns; ++n) {
+      const double dens = f.cons0[b * nv + n][c];
+      double *m1 = f.cons0[b * nv + ns + 3 * n + 0], *m2 = f.cons0[b * nv + ns + 3 * n + 1];
+      double *m3 = f.cons0[b * nv + ns + 3 * n + 2];
+      const double vg[3] = {m1[c] / (hx[0] * dens), m2[c] / (hx[1] * dens), m3[c] / (hx[2] * dens)};
+      const double mu = 0.0; // DiffusionCoeff<null>::Get (diffusion_coeff.hpp:185-189)
+      const double vR = -1.5 * mu / (cv.R * dens);
+      const double vd[3] = {cv.e1 * vR, cv.e2 * vR, cv.e3 * vR};
+      const double dm1 = -bg[0] * dens * (vg[0] - vd[0]) / (1.0 + bg[0]);
+      const double dm2 = -bg[1] * dens * (vg[1] - vd[1]) / (1.0 + bg[1]);
+      const double dm3 = -bg[2] * dens * (vg[2] - vd[2]) / (1.0 + bg[2]);
+      m1[c] += hx[0] * dm1;
+      m2[c] += hx[1] * dm2;
+      m3[c] += hx[2] * dm3;
+      f.cons0[b * nv + 4 * ns + n][c] += dm1 * (vg[0] + 0.5 * dm1 / dens) +
+                                         dm2 * (vg[1] + 0.5 * dm2 / dens) +
+                                         dm3 * (vg[2] + 0.5 * dm3 / dens);
+    }
+  }
+  {
+    const FluidView &f = P.dust;
+    const int ns = f.ns, nv = 4 * ns;
+    for (int n = 0; n < ns; ++n)
+      for (int d = 0; d < 3; ++d) {
+        double *m = f.cons0[b * nv + ns + 3 * n + d];
+        const double mom = m[c];
+        m[c] = mom - bd[d] * mom / (1.0 + bd[d]);
+      }
+  }
+}
+
+// SimpleDragSourceImpl (drag.hpp:296-482): backward-Euler gas-dust momentum exchange for one
+// gas species and ns dust species; two passes over the dust species (sum, then update).
+__global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, const artemis_drag_t D,
+                                                             double dt) {
+  INTERIOR_CELL
+  const DCoords co = make_coords(P, b, k, j, i);
+  const double xv[3] = {co.x1v(), co.x2v(), co.x3v()};
+  double hx[3];
+  scale_factors(co, hx);
+  const CylVec cv = to_cyl_with_vec(co, xv);
+  double bg[3], bd[3];
+  damping_ramps(D.gas, D, P.ndim, xv, dt, bg);
+  damping_ramps(D.dust, D, P.ndim, xv, dt, bd);
+  const FluidView &G = P.gas, &F = P.dust;
+  const int nsg = G.ns, nvg = 6 * nsg, nsd = F.ns, nvd = 4 * nsd;
+  const double dg = G.cons0[b * nvg + 0][c];
+  double *mg[3] = {G.cons0[b * nvg + nsg + 0], G.cons0[b * nvg + nsg + 1], G.cons0[b * nvg + nsg + 2]};
+  const double vg[3] = {mg[0][c] / (hx[0] * dg), mg[1][c] / (hx[1] * dg), mg[2][c] / (hx[2] * dg)};
+  // GetSpecificInternalEnergy (artemis_utils.hpp:43-62), species 0
+  double sieg;
+  {
+    const double u_d = amax(dg, G.dfloor);
+    const double rv1 = mg[0][c] / hx[0], rv2 = mg[1][c] / hx[1], rv3 = mg[2][c] / hx[2];
+    const double ke = 0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)) / u_d;
+    const double e_cons = G.cons0[b * nvg + 4 * nsg][c];
+    const double ue_cons = e_cons - ke;
+    sieg = (ue_cons > G.de_switch * e_cons) ? ue_cons / u_d : G.cons0[b * nvg + 5 * nsg][c] / u_d;
+    sieg = amax(sieg, G.siefloor);
+  }
+  const double mu = 0.0;
+  const double vR = -1.5 * mu / (cv.R * dg);
+  const double vt[3] = {cv.e1 * vR, cv.e2 * vR, cv.e3 * vR};
+  double fd[3] = {0., 0., 0.}, fvd[3] = {0., 0., 0.};
+  double vth = 0.0;
+  const bool stokes = (D.model == ARTEMIS_DRAG_STOKES);
+  if (stokes) vth = sqrt(8.0 / M_PI * P.gm1 * sieg);
+  const double vdt[3] = {0.0, 0.0, 0.0};
+  for (int n = 0; n < nsd; ++n) {
+    const double dens = F.cons0[b * nvd + n][c];
+    const double vd[3] = {F.cons0[b * nvd + nsd + 3 * n + 0][c] / (hx[0] * dens),
+                          F.cons0[b * nvd + nsd + 3 * n + 1][c] / (hx[1] * dens),
+                          F.cons0[b * nvd + nsd + 3 * n + 2][c] / (hx[2] * dens)};
+    double tc = D.tau[n];
+    if (stokes) tc = D.scale * D.grain_density / dg * D.sizes[n] / vth;
+    const double alpha = dt * ((tc <= 0.0) ? DBL_MAX : 1.0 / tc);
+    for (int d = 0; d < 3; d++) {
+      const double rhop = dens * alpha / (1.0 + alpha + bd[d]);
+      fd[d] += rhop * (1.0 + bd[d]);
+      fvd[d] += rhop * (vd[d] + bd[d] * vdt[d]);
+    }
+  }
+  double vgp[3];
+  for (int d = 0; d < 3; d++)
+    vgp[d] = (dg * (vg[d] + bg[d] * vt[d]) + fvd[d]) / (dg * (1.0 + bg[d]) + fd[d]);
+  double delta_g[3] = {0.0, 0.0, 0.0};
+  for (int d = 0; d < 3; d++) fvd[d] = 0.;
+  for (int n = 0; n < nsd; ++n) {
+    const double dens = F.cons0[b * nvd + n][c];
+    const double vd[3] = {F.cons0[b * nvd + nsd + 3 * n + 0][c] / (hx[0] * dens),
+                          F.cons0[b * nvd + nsd + 3 * n + 1][c] / (hx[1] * dens),
+                          F.cons0[b * nvd + nsd + 3 * n + 2][c] / (hx[2] * dens)};
+    double tc = D.tau[n];
+    if (stokes) tc = D.scale * D.grain_density / dg * D.sizes[n] / vth;
+    const double alpha = dt * ((tc <= 0.0) ? DBL_MAX : 1.0 / tc);
+    for (int d = 0; d < 3; d++) {
+      double delta_d = 0.;
+      const double rhop = dens * alpha / (1.0 + alpha + bd[d]);
+      const double delta = rhop * ((vgp[d] - vd[d] + bd[d] * (vgp[d] - vdt[d])));
+      delta_d += delta;
+      delta_g[d] -= delta;
+      delta_d -= bd[d] * dens / (1. + alpha + bd[d]) * (vd[d] - vdt[d] + alpha * (vgp[d] - vdt[d]));
+      fvd[d] += rhop * (vd[d] - vt[d] + bd[d] * (vdt[d] - vt[d]));
+      F.cons0[b * nvd + nsd + 3 * n + d][c] += hx[d] * delta_d;
+    }
+  }
+  double en = G.cons0[b * nvg + 4 * nsg][c];
+  for (int d = 0; d < 3; d++) {
+    const double prefac = dg * bg[d] / (1.0 + bg[d] + fd[d]);
+    delta_g[d] -= prefac * (dg * (vg[d] - vt[d]) + fvd[d]);
+    mg[d][c] += hx[d] * delta_g[d];
+    en += 0.5 * (vg[d] + vgp[d]) * delta_g[d];
+  }
+  G.cons0[b * nvg + 4 * nsg][c] = en;
+}
+
+} // namespace
+
+void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, double dt, hipStream_t s) {
+  hipLaunchKernelGGL(gravity_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, G, dt);
+}
+void launch_shearing_box(const PackView &P, double omega, double qshear, double dt, hipStream_t s) {
+  hipLaunchKernelGGL(shearing_box_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, omega, qshear, dt);
+}
+void launch_drag_source(const PackView &P, const artemis_drag_t &D, double dt, hipStream_t s) {
+  if (D.type == ARTEMIS_DRAG_SELF)
+    hipLaunchKernelGGL(self_drag_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt);
+  else
+    hipLaunchKernelGGL(simple_drag_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt);
+}
+
+} // namespace artemis

@@ -508,6 +508,76 @@ __global__ __launch_bounds__(256) void bc_kernel(const BcArgs a, const FillTabs 
   }
 }
 
+// The `strat` problem's user conditions (pgen/strat.hpp:158-466).  One thread per ghost zone of
+// the (d, side) slab.  x1 `extrap` (:188-226, :262-299): density, sie and v3 copied from the first
+// active zone, v1 copied unless it points into the domain, v2 extrapolated linearly in x1v.
+// x2 `inflow` (:352-392, :437-466): copy, with v2 = -q Om0 x1v where the shear carries material
+// into the box (lower face: x1f >= 0, upper face: x1f < 0) and one-way outflow elsewhere.
+// Gas species 0 and every dust species, like the reference's loops.
+struct StratBcArgs {
+  int d, side, ng, st, en;
+  double q, om0, x1f0, dx1;
+};
+__global__ __launch_bounds__(256) void strat_bc_kernel(const StratBcArgs a, const FillTabs t,
+                                                       const double *geom, int ni, int nj, int nk) {
+  int ext[3] = {ni, nj, nk};
+  ext[a.d] = a.ng;
+  const long ncell = static_cast<long>(ext[0]) * ext[1] * ext[2];
+  const long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (tid >= ncell) return;
+  int idx[3];
+  idx[0] = tid % ext[0];
+  idx[1] = (tid / ext[0]) % ext[1];
+  idx[2] = tid / (static_cast<long>(ext[0]) * ext[1]);
+  idx[a.d] = (a.side == 0) ? a.st - 1 - idx[a.d] : a.en + 1 + idx[a.d];
+  const int i = idx[0], j = idx[1], k = idx[2];
+  const long c = (static_cast<long>(k) * nj + j) * ni + i;
+  const double *g = geom + 6 * t.b;
+  auto x1v = [&](int ii) { return 0.5 * ((g[0] + ii * g[1]) + (g[0] + (ii + 1) * g[1])); };
+  const int nsg = t.nsg, nsd = t.nsd;
+  if (a.d == 0) {
+    const int ia = (a.side == 0) ? a.st : a.en, ib = (a.side == 0) ? a.st + 1 : a.en - 1;
+    const long ca = c - i + ia, cb = c - i + ib;
+    const double x0 = x1v(ia), x1 = x1v(ib);
+    const double dx = (a.side == 0) ? (x1 - x0) : (x0 - x1);
+    const double x = x1v(i);
+    auto fill = [&](double *const *tab, int base, int ns, int n) {
+      double *q1 = tab[base + ns + 3 * n + 0], *q2 = tab[base + ns + 3 * n + 1];
+      double *q3 = tab[base + ns + 3 * n + 2], *qd = tab[base + n];
+      const double v1 = q1[ca], v2 = q2[ca], v3 = q3[ca], v2n = q2[cb];
+      const double vx1 = (a.side == 0) ? ((v1 > 0.0) ? 0.0 : v1) : ((v1 < 0.0) ? 0.0 : v1);
+      const double vx2 = (a.side == 0) ? (v2 + (v2n - v2) * (x - x0) / dx) : (v2 + (v2 - v2n) * (x - x0) / dx);
+      q1[c] = vx1, q2[c] = vx2, q3[c] = v3, qd[c] = qd[ca];
+    };
+    if (nsg) {
+      fill(t.gas, t.b * 6 * nsg, nsg, 0);
+      double *se = t.gas[t.b * 6 * nsg + 5 * nsg];
+      se[c] = se[ca];
+    }
+    for (int n = 0; n < nsd; ++n) fill(t.dust, t.b * 4 * nsd, nsd, n);
+  } else {
+    const int ja = (a.side == 0) ? a.st : a.en;
+    const long ca = c + static_cast<long>(ja - j) * ni;
+    const double x = x1v(i);
+    const double xf = g[0] + i * g[1];
+    const double vy0 = -a.q * a.om0 * x;
+    auto fill = [&](double *const *tab, int base, int ns, int n) {
+      double *q1 = tab[base + ns + 3 * n + 0], *q2 = tab[base + ns + 3 * n + 1];
+      double *q3 = tab[base + ns + 3 * n + 2], *qd = tab[base + n];
+      const double v1 = q1[ca], v2 = q2[ca], v3 = q3[ca];
+      const double vx2 = (a.side == 0) ? ((xf >= 0) ? ((v2 > 0.) ? 0.0 : v2) : vy0)
+                                       : ((xf < 0) ? ((v2 < 0.0) ? 0.0 : v2) : vy0);
+      q1[c] = v1, q2[c] = vx2, q3[c] = v3, qd[c] = qd[ca];
+    };
+    if (nsg) {
+      fill(t.gas, t.b * 6 * nsg, nsg, 0);
+      double *se = t.gas[t.b * 6 * nsg + 5 * nsg];
+      se[c] = se[ca];
+    }
+    for (int n = 0; n < nsd; ++n) fill(t.dust, t.b * 4 * nsd, nsd, n);
+  }
+}
+
 // All ghost cells of one block in ONE launch.  Parthenon applies periodic images, then x1, x2, x3
 // physical conditions, each pass over the entire extent of the other dimensions; every pass
 // remaps one index (and flips the sign of the normal velocity for reflecting walls), so the
@@ -690,15 +760,52 @@ static FillTabs fill_tabs(const PackView &P, int b) {
   return t;
 }
 
-int launch_apply_bc(const PackView &P, const int *bc, hipStream_t s) {
+// Sequential fallback used when a block carries a user (strat) condition: those read
+// neighbouring zones of the fill direction and limit velocities, so they do not compose into
+// index maps.  Order as parthenon applies it: periodic images of every direction, then x1,
+// x2, x3 physical / user conditions, each over the entire extent of the other dimensions.
+static void launch_bc_sequential(const PackView &P, int b, const int *bc6,
+                                 const artemis_bc_params_t *par, hipStream_t s) {
+  const FillTabs t = fill_tabs(P, b);
+  const int st[3] = {P.is, P.js, P.ks}, en[3] = {P.ie, P.je, P.ke}, ext[3] = {P.ni, P.nj, P.nk};
+  for (int pass = 0; pass < 2; ++pass)
+    for (int d = 0; d < P.ndim; ++d)
+      for (int side = 0; side < 2; ++side) {
+        const int flag = bc6[2 * d + side];
+        if (flag == ARTEMIS_BC_NONE || (pass == 0) != (flag == ARTEMIS_BC_PERIODIC)) continue;
+        long ncell = P.ng;
+        for (int q = 0; q < 3; ++q)
+          if (q != d) ncell *= ext[q];
+        if (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW) {
+          StratBcArgs a;
+          a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
+          a.q = par->qshear, a.om0 = par->omega, a.x1f0 = 0.0, a.dx1 = 0.0;
+          hipLaunchKernelGGL(strat_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P.geom,
+                             P.ni, P.nj, P.nk);
+        } else {
+          BcArgs a;
+          a.d = d, a.side = side, a.bc = flag, a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;
+          a.n_act = en[d] - st[d] + 1, a.st = st[d], a.en = en[d], a.ng = P.ng;
+          hipLaunchKernelGGL(bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P.ni, P.nj,
+                             P.nk);
+        }
+      }
+}
+
+int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t *par, hipStream_t s) {
   for (int b = 0; b < P.nb; ++b) {
     ShellArgs a;
-    bool any = false;
+    bool any = false, user = false;
     for (int f = 0; f < 6; ++f) {
       a.bc[f] = (f / 2 < P.ndim) ? bc[b * 6 + f] : ARTEMIS_BC_NONE;
       any = any || (a.bc[f] != ARTEMIS_BC_NONE);
+      user = user || a.bc[f] == ARTEMIS_BC_STRAT_EXTRAP || a.bc[f] == ARTEMIS_BC_STRAT_INFLOW;
     }
     if (!any) continue;
+    if (user) {
+      launch_bc_sequential(P, b, a.bc, par, s);
+      continue;
+    }
     a.lo[0] = P.is, a.lo[1] = P.js, a.lo[2] = P.ks, a.hi[0] = P.ie, a.hi[1] = P.je, a.hi[2] = P.ke;
     a.ext[0] = P.ni, a.ext[1] = P.nj, a.ext[2] = P.nk;
     a.ng = P.ng, a.ndim = P.ndim, a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;

@@ -26,7 +26,7 @@ struct PackView {
   double gm1;
   const double *geom; // [nb][6]
   int coords;           // enum artemis_coords
-  const double *metric; // [nb][5][nj+1] x2 trig tables (spherical2D/3D), else null
+  const double *metric; // [nb][6][nj+1] x2 trig tables (spherical2D/3D), else null
   FluidView gas, dust;
 };
 

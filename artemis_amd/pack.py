@@ -135,13 +135,26 @@ class MeshBlockPack:
         self._call(self.L.artemis_hip_estimate_dt, fluid, cfl, C.byref(out))
         return out.value
 
-    def ApplyBoundaryConditions(self, bc):
-        """bc: per-block list of 6 names/flags (ix1, ox1, ix2, ox2, ix3, ox3)."""
+    def ApplyBoundaryConditions(self, bc, strat=None):
+        """bc: per-block list of 6 names/flags (ix1, ox1, ix2, ox2, ix3, ox3); strat = (qshear,
+        omega) when a block carries the strat problem's `extrap` / `inflow` conditions."""
         flat = []
         for row in bc:
             flat += [capi.BCS[x] if isinstance(x, str) else int(x) for x in row]
         arr = (C.c_int * len(flat))(*flat)
-        self._call(self.L.artemis_hip_apply_bc, arr)
+        par = C.byref(capi.BcParams(*strat)) if strat is not None else None
+        self._call(self.L.artemis_hip_apply_bc, arr, par)
+
+    # ---- source-term tasks (artemis_driver.cpp:222-241) ---------------------------------------
+    def ExternalGravity(self, time, dt, gravity):
+        """gravity: capi.Gravity (see gravity_point / gravity_uniform below)."""
+        self._call(self.L.artemis_hip_external_gravity, C.byref(gravity), time, dt)
+
+    def RotatingFrameForce(self, omega, qshear, time, dt):
+        self._call(self.L.artemis_hip_rotating_frame_force, omega, qshear, time, dt)
+
+    def DragSource(self, time, dt, drag):
+        self._call(self.L.artemis_hip_drag_source, C.byref(drag), time, dt)
 
     def stage_fused(self, gam0, gam1, beta_dt, bdt, prim_in, prim_u1, prim_out, cons_out=None,
                     pcm=False, cfl=0.0, dt_dev=None, region=0, shell_faces=0):
@@ -170,3 +183,46 @@ class MeshBlockPack:
 
     def call_on(self, pack, fn, *args):
         capi.check(fn(C.byref(pack), *args, self._stream()))
+
+
+def gravity_uniform(gx1, gx2, gx3):
+    g = capi.Gravity()
+    g.type = capi.GRAVITY_UNIFORM
+    g.g[:] = [gx1, gx2, gx3]
+    g.tstart, g.tstop = -1.7976931348623157e308, 1.7976931348623157e308
+    return g
+
+
+def gravity_point(mass, soft=0.0, sink=0.0, sink_rate=0.0, pos=(0.0, 0.0, 0.0), G=1.0):
+    g = capi.Gravity()
+    g.type = capi.GRAVITY_POINT
+    g.gm, g.soft, g.sink, g.sink_rate = G * mass, soft, sink, sink_rate
+    g.pos[:] = list(pos)
+    g.tstart, g.tstop = -1.7976931348623157e308, 1.7976931348623157e308
+    return g
+
+
+def drag_params(type="simple_dust", model="constant", tau=(), scale=1.0, grain_density=1.0, sizes=(),
+                mesh_min=(0.0, 0.0, 0.0), mesh_max=(1.0, 1.0, 1.0), gas_damping=None, dust_damping=None):
+    """capi.Drag from deck-style values; damping = dict(inner, inner_rate, outer, outer_rate)."""
+    d = capi.Drag()
+    d.type = {"simple_dust": capi.DRAG_SIMPLE_DUST, "self": capi.DRAG_SELF}[type]
+    d.model = {"constant": capi.DRAG_CONSTANT, "stokes": capi.DRAG_STOKES}[model]
+    d.scale, d.grain_density = scale, grain_density
+    for n, t in enumerate(tau):
+        d.tau[n] = scale * t if model == "constant" else scale  # drag.hpp:129-147
+    if model == "stokes":
+        for n in range(len(sizes)):
+            d.tau[n] = scale
+    for n, sz in enumerate(sizes):
+        d.sizes[n] = sz
+    big = 1.7976931348623157e308
+    for dst, src in ((d.gas, gas_damping), (d.dust, dust_damping)):
+        src = src or {}
+        dst.ix[:] = list(src.get("inner", (-big,) * 3))
+        dst.ox[:] = list(src.get("outer", (big,) * 3))
+        dst.irate[:] = list(src.get("inner_rate", (0.0,) * 3))
+        dst.orate[:] = list(src.get("outer_rate", (0.0,) * 3))
+    d.xmin[:] = list(mesh_min)
+    d.xmax[:] = list(mesh_max)
+    return d

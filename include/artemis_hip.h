@@ -54,7 +54,15 @@ enum artemis_fluid { ARTEMIS_GAS = 0, ARTEMIS_DUST = 1 };
 /* Physical boundary flags understood by artemis_hip_apply_bc (parthenon outflow /
  * reflecting / periodic, upstream; `none` = face is filled by a neighbour exchange). */
 enum artemis_bc { ARTEMIS_BC_PERIODIC = 0, ARTEMIS_BC_OUTFLOW = 1, ARTEMIS_BC_REFLECT = 2,
-                  ARTEMIS_BC_NONE = 3 };
+                  ARTEMIS_BC_NONE = 3,
+                  /* user conditions of the `strat` problem (pgen/strat.hpp:158-466, registered as
+                   * `extrap` / `inflow` at problem_modifier.hpp:114-128): */
+                  ARTEMIS_BC_STRAT_EXTRAP = 4, /* x1 faces */
+                  ARTEMIS_BC_STRAT_INFLOW = 5  /* x2 faces */ };
+enum artemis_gravity_type { ARTEMIS_GRAVITY_UNIFORM = 1, ARTEMIS_GRAVITY_POINT = 2 };
+enum artemis_drag_type { ARTEMIS_DRAG_SIMPLE_DUST = 1, ARTEMIS_DRAG_SELF = 2 }; /* drag.hpp:57 */
+enum artemis_drag_model { ARTEMIS_DRAG_CONSTANT = 0, ARTEMIS_DRAG_STOKES = 1 }; /* drag.hpp:58 */
+#define ARTEMIS_MAX_DUST_SPECIES 16 /* drag parameter arrays travel by value as kernel arguments */
 
 typedef struct artemis_fluid_pack {
   int nspecies;              /* 0 = fluid absent (physics/gas|dust = false, artemis.cpp:63-64) */
@@ -140,8 +148,57 @@ int artemis_hip_metric_fill(const artemis_pack_t *p, const double *geom_host, do
 /* Physical boundary conditions on the FillGhost primitives (gas rho, v, sie; dust rho, v;
  * gas.cpp:244-270, dust.cpp:201-213) of every block: bc[b*6 + {ix1,ox1,ix2,ox2,ix3,ox3}]
  * is a HOST array of artemis_bc values.  Parthenon order: periodic images first, then
- * x1, x2, x3, each over the entire extent of the other dimensions. */
-int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, void *stream);
+ * x1, x2, x3, each over the entire extent of the other dimensions.  `params` (may be NULL
+ * unless a STRAT flag is present) carries what the strat conditions read from StratParams
+ * (strat.hpp:44-52, :60-61): the shear rate q and the frame frequency Om0. */
+typedef struct artemis_bc_params {
+  double qshear, omega;
+} artemis_bc_params_t;
+int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_bc_params_t *params,
+                         void *stream);
+
+/* ---- source-term tasks between FluxSource and SetAuxillaryFields ------------------------*/
+
+/* Gravity::ExternalGravity<GEOM> (gravity/gravity.cpp:126-155), active for
+ * tstart <= time < tstop: UniformGravity (uniform.cpp:28-84, every coordinate system) or
+ * PointMassGravity (point_mass.cpp:27-198: Cartesian with offset mass, softening and sink;
+ * spherical1D/2D and axisymmetric with the mass at the origin).  gm = G*mass in code units
+ * (gravity.cpp:57).  Reads prim, updates cons0 momenta / total energy (/ density for the
+ * sink) of both fluids on interior cells.  cylindrical / spherical3D point mass and the
+ * binary / nbody types: ARTEMIS_HIP_EUNSUPPORTED. */
+typedef struct artemis_gravity {
+  int type;                   /* artemis_gravity_type */
+  double g[3];                /* <gravity/uniform> gx1, gx2, gx3 */
+  double gm, soft, sink, sink_rate, pos[3]; /* <gravity/point> */
+  double tstart, tstop;       /* <gravity> tstart, tstop (gravity.cpp:36-38) */
+} artemis_gravity_t;
+int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_t *g, double time,
+                                 double dt, void *stream);
+
+/* RotatingFrame::RotatingFrameForce (rotating_frame/rotating_frame.cpp:56-86).  Cartesian:
+ * ShearingBoxImpl (rotating_frame_impl.hpp:28-93), tidal potential differenced across the cell
+ * plus the Coriolis force, gas and dust.  Curvilinear flux form (:95-199):
+ * ARTEMIS_HIP_EUNSUPPORTED. */
+int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, double qshear,
+                                     double time, double dt, void *stream);
+
+/* Drag::DragSource<GEOM> (drag/drag.cpp:89-175) without damp_to_visc: `self` =
+ * SelfDragSourceImpl (drag.hpp:171-294, damping ramps towards the mesh edges), `simple_dust` =
+ * SimpleDragSourceImpl (drag.hpp:296-482, implicit gas-dust momentum exchange; one gas species,
+ * <= ARTEMIS_MAX_DUST_SPECIES dust species).  tau[n] already includes `scale` for the constant
+ * model (drag.hpp:129-137); `stokes` uses scale, grain_density, sizes (drag.hpp:407-409). */
+typedef struct artemis_damping {
+  double ix[3], ox[3], irate[3], orate[3]; /* SelfDragParams, drag.hpp:68-117 */
+} artemis_damping_t;
+typedef struct artemis_drag {
+  int type, model;            /* artemis_drag_type, artemis_drag_model */
+  double scale, grain_density;
+  double tau[ARTEMIS_MAX_DUST_SPECIES], sizes[ARTEMIS_MAX_DUST_SPECIES];
+  artemis_damping_t gas, dust;
+  double xmin[3], xmax[3];    /* parthenon/mesh x?min, x?max (drag.cpp:37-42) */
+} artemis_drag_t;
+int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, double time, double dt,
+                            void *stream);
 
 /* ---- Fused stage (the fast path) --------------------------------------------------------
  * One RK stage of artemis_driver.cpp:182-261 with every optional package disabled, i.e.

@@ -44,7 +44,8 @@ extern "C" {
 enum { RS_HLLC = 0, RS_HLLE = 1, RS_LLF = 2 };
 enum { RC_PCM = 0, RC_PLM = 1, RC_PPM = 2 };
 enum { FL_GAS = 0, FL_DUST = 1 };
-enum { BC_PERIODIC = 0, BC_OUTFLOW = 1, BC_REFLECT = 2, BC_NONE = 3 };
+enum { BC_PERIODIC = 0, BC_OUTFLOW = 1, BC_REFLECT = 2, BC_NONE = 3, BC_STRAT_EXTRAP = 4,
+       BC_STRAT_INFLOW = 5 }; // 4/5: the `strat` pgen's user conditions (problem_modifier.hpp:114-128)
 enum { INT_RK1 = 0, INT_RK2 = 1, INT_VL2 = 2, INT_RK3 = 3 };
 
 struct oracle_cfg {
@@ -81,6 +82,35 @@ struct Sim {
   Real lw_cos_a2, lw_cos_a3, lw_sin_a2, lw_sin_a3, lw_rem[5][5], lw_ev[5], lw_gamma, lw_gm1;
   int lw_wave_flag;
   Real gx1min, gx1max, gx2min, gx2max, gx3min, gx3max; // global mesh bounds for pgens
+  // optional source packages (artemis.cpp:63-72); zero-initialised = disabled
+  struct {
+    int type = 0; // 0 off, 1 uniform, 2 point
+    Real g[3] = {0, 0, 0}, gm = 0, soft = 0, sink = 0, sink_rate = 0, pos[3] = {0, 0, 0};
+    Real tstart = std::numeric_limits<Real>::lowest(), tstop = std::numeric_limits<Real>::max();
+  } grav;
+  struct {
+    bool on = false;
+    Real omega = 0, qshear = 0;
+  } rframe;
+  struct SelfDrag { // drag.hpp:68-117 SelfDragParams
+    Real ix[3], ox[3], irate[3], orate[3];
+    SelfDrag() {
+      for (int i = 0; i < 3; i++) {
+        ix[i] = -std::numeric_limits<Real>::max(), ox[i] = std::numeric_limits<Real>::max();
+        irate[i] = 0.0, orate[i] = 0.0;
+      }
+    }
+  };
+  struct {
+    int type = 0;  // 0 off, 1 simple_dust, 2 self
+    int model = 0; // 0 constant, 1 stokes (drag.hpp:58)
+    Real scale = 1.0, grain_density = 1.0;
+    std::vector<Real> tau, sizes;
+    SelfDrag gas, dust;
+  } drag;
+  struct { // pgen/strat.hpp:44-52 (only what the user BCs read)
+    Real q = 0, Om0 = 0;
+  } strat;
 };
 
 inline size_t IDX(const Sim &s, int k, int j, int i) {
@@ -963,6 +993,341 @@ void flux_source(Sim &s, int fluid, Real dt) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Coords<GEOM>::ConvertToCylWithVec (geometry.hpp:476-482): only the cylindrical radius and
+// the first component of each basis vector are used by the callers restated here
+// (geometry.hpp:289-306 Cartesian, cylindrical.hpp:117-126 identity, spherical.hpp:191-205 /
+// :382-396 / :556-577, axisymmetric.hpp:134-145).
+struct CylVec {
+  Real R, e1, e2, e3; // xcyl[0], ex1[0], ex2[0], ex3[0]
+};
+inline CylVec to_cyl_with_vec(const Coords &co, const Real xi[3]) {
+  CylVec c;
+  const Real fuzz = 1e-99; // Fuzz<Real>(), artemis.hpp:113-118
+  switch (co.sys) {
+  case CO_CART: {
+    Real R = std::sqrt(xi[0] * xi[0] + xi[1] * xi[1]);
+    const Real cp = xi[0] / (R + fuzz);
+    const Real sp = xi[1] / (R + fuzz);
+    c.R = R, c.e1 = cp, c.e2 = sp, c.e3 = 0.0;
+  } break;
+  case CO_SPH3D:
+  case CO_SPH2D: {
+    const Real ct = std::cos(xi[1]);
+    const Real st = std::sin(xi[1]);
+    c.R = xi[0] * st, c.e1 = st, c.e2 = ct, c.e3 = 0.0;
+  } break;
+  case CO_SPH1D: {
+    const Real ct = 0.0, st = 1.0;
+    c.R = xi[0] * st, c.e1 = st, c.e2 = ct, c.e3 = 0.0;
+  } break;
+  default: // cylindrical, axisymmetric
+    c.R = xi[0], c.e1 = 1.0, c.e2 = 0.0, c.e3 = 0.0;
+  }
+  return c;
+}
+
+// GetSpecificInternalEnergy (artemis_utils.hpp:43-62) on the oracle's gas cons layout
+inline Real specific_internal_energy(const Sim &s, int n, size_t c, const Real hx[3]) {
+  const int nsp = s.c.ns_gas;
+  const Real u_d = std::max(s.gu0[n * s.N + c], s.c.dfloor_gas);
+  const Real rv1 = s.gu0[(nsp + 3 * n + 0) * s.N + c] / hx[0];
+  const Real rv2 = s.gu0[(nsp + 3 * n + 1) * s.N + c] / hx[1];
+  const Real rv3 = s.gu0[(nsp + 3 * n + 2) * s.N + c] / hx[2];
+  const Real ke = 0.5 * (SQR(rv1) + SQR(rv2) + SQR(rv3)) / u_d;
+  const Real e_cons = s.gu0[(4 * nsp + n) * s.N + c];
+  const Real ue_cons = e_cons - ke;
+  const Real sie = (ue_cons > s.c.de_switch * e_cons) ? ue_cons / u_d
+                                                     : s.gu0[(5 * nsp + n) * s.N + c] / u_d;
+  return std::max(sie, s.c.siefloor_gas);
+}
+
+// ---------------------------------------------------------------------------------------
+// gravity/gravity.cpp:126-155 ExternalGravity -> gravity/uniform.cpp:28-84 UniformGravity,
+// gravity/point_mass.cpp:27-198 PointMassGravity.  Point mass: Cartesian (offset mass,
+// softening, sink), spherical1D/2D and axisymmetric (mass at the origin); cylindrical and
+// spherical3D need the azimuthal basis and are not restated.
+void external_gravity(Sim &s, Real time, Real dt) {
+  if (s.grav.type == 0) return;
+  if (!((time >= s.grav.tstart) && (time < s.grav.tstop))) return; // gravity.cpp:134
+  const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
+  const bool multi_d = (s.ndim >= 2), three_d = (s.ndim == 3);
+  const Real gm = s.grav.gm;
+  const Real sink_rate = dt * s.grav.sink_rate;
+  const Real sink_rad = s.grav.sink;
+  const Real rsft2 = SQR(s.grav.soft);
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = s.ks; k <= s.ke; ++k)
+    for (int j = s.js; j <= s.je; ++j)
+      for (int i = s.is; i <= s.ie; ++i) {
+        const Coords coords(s, k, j, i);
+        const Real dx[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
+        Real hx[3];
+        coords.GetScaleFactors(hx);
+        Real gx1 = 0.0, gx2 = 0.0, gx3 = 0.0, fd = 0.0;
+        if (s.grav.type == 1) {
+          gx1 = s.grav.g[0], gx2 = s.grav.g[1], gx3 = s.grav.g[2];
+        } else {
+          Real dr;
+          if (coords.sys == CO_SPH1D || coords.sys == CO_SPH2D) { // point_mass.cpp:78-81
+            const Real rad2 = SQR(dx[0]) + rsft2;
+            gx1 = -gm / rad2;
+            dr = std::sqrt(rad2);
+          } else if (coords.sys == CO_AXI) { // :82-89 with axisymmetric.hpp ConvertToSphWithVec
+            const Real rsph = std::sqrt(dx[0] * dx[0] + dx[1] * dx[1]);
+            const Real ct = dx[1] / (rsph + 1e-99);
+            const Real st = dx[0] / (rsph + 1e-99);
+            dr = rsph;
+            const Real rad2 = SQR(dr) + rsft2;
+            const Real g = -gm / rad2;
+            gx1 = g * st; // ex1[0]
+            gx2 = g * ct; // ex3[0]
+          } else { // Cartesian: ConvertToCartWithVec is the identity (:91-112)
+            Real dxc[3] = {dx[0], dx[1], dx[2]};
+            for (int n = 0; n < 3; n++)
+              dxc[n] -= s.grav.pos[n];
+            const Real R = std::sqrt(dxc[0] * dxc[0] + dxc[1] * dxc[1]); // geometry.hpp:262-264
+            const Real r = std::sqrt(R * R + dxc[2] * dxc[2]);
+            dr = r;
+            const Real rad2 = SQR(dr) + rsft2;
+            const Real idr3 = 1.0 / (std::sqrt(rad2) * rad2);
+            Real g[3] = {-gm * dxc[0] * idr3, (multi_d) * (-gm * dxc[1] * idr3),
+                         (three_d) * (-gm * dxc[2] * idr3)};
+            gx1 = g[0] * 1.0 + g[1] * 0.0 + g[2] * 0.0;
+            gx2 = g[0] * 0.0 + g[1] * 1.0 + g[2] * 0.0;
+            gx3 = g[0] * 0.0 + g[1] * 0.0 + g[2] * 1.0;
+          }
+          const Real sramp = sink_rate * SQR((dr - sink_rad) / sink_rad); // quad_ramp, gravity.hpp:116
+          fd = std::min(0.5, sramp / (1.0 + sramp));
+          fd *= ((sink_rate > 0.0) && (dr <= sink_rad));
+        }
+        const size_t c = IDX(s, k, j, i);
+        for (int n = 0; n < ng_; ++n) {
+          const Real rho = s.gprim[n * s.N + c];
+          const Real v1 = s.gprim[(ng_ + 3 * n + 0) * s.N + c];
+          const Real v2 = s.gprim[(ng_ + 3 * n + 1) * s.N + c];
+          const Real v3 = s.gprim[(ng_ + 3 * n + 2) * s.N + c];
+          Real &m1 = s.gu0[(ng_ + 3 * n + 0) * s.N + c], &m2 = s.gu0[(ng_ + 3 * n + 1) * s.N + c];
+          Real &m3 = s.gu0[(ng_ + 3 * n + 2) * s.N + c], &en = s.gu0[(4 * ng_ + n) * s.N + c];
+          if (s.grav.type == 1) { // uniform.cpp:58-68
+            const Real rdt = dt * rho;
+            m1 += rdt * hx[0] * gx1;
+            m2 += rdt * hx[1] * gx2;
+            m3 += rdt * hx[2] * gx3;
+            en += rdt * (v1 * gx1 + v2 * gx2 + v3 * gx3);
+          } else { // point_mass.cpp:137-156
+            const Real sie = s.gprim[(5 * ng_ + n) * s.N + c];
+            const Real tote = rho * (sie + 0.5 * (SQR(v1) + SQR(v2) + SQR(v3)));
+            m1 += dt * rho * hx[0] * gx1;
+            m2 += dt * rho * hx[1] * gx2;
+            m3 += dt * rho * hx[2] * gx3;
+            en += dt * rho * (v1 * gx1 + v2 * gx2 + v3 * gx3);
+            s.gu0[n * s.N + c] -= fd * rho;
+            m1 -= fd * hx[0] * rho * v1;
+            m2 -= fd * hx[1] * rho * v2;
+            m3 -= fd * hx[2] * rho * v3;
+            en -= fd * tote;
+          }
+        }
+        for (int n = 0; n < nd_; ++n) {
+          const Real rho = s.dprim[n * s.N + c];
+          const Real v1 = s.dprim[(nd_ + 3 * n + 0) * s.N + c];
+          const Real v2 = s.dprim[(nd_ + 3 * n + 1) * s.N + c];
+          const Real v3 = s.dprim[(nd_ + 3 * n + 2) * s.N + c];
+          Real &m1 = s.du0[(nd_ + 3 * n + 0) * s.N + c], &m2 = s.du0[(nd_ + 3 * n + 1) * s.N + c];
+          Real &m3 = s.du0[(nd_ + 3 * n + 2) * s.N + c];
+          if (s.grav.type == 1) { // uniform.cpp:71-78
+            const Real rdt = dt * rho;
+            m1 += rdt * hx[0] * gx1;
+            m2 += rdt * hx[1] * gx2;
+            m3 += rdt * hx[2] * gx3;
+          } else { // point_mass.cpp:160-176
+            m1 += dt * rho * hx[0] * gx1;
+            m2 += dt * rho * hx[1] * gx2;
+            m3 += dt * rho * hx[2] * gx3;
+            s.du0[n * s.N + c] -= fd * rho;
+            m1 -= fd * hx[0] * rho * v1;
+            m2 -= fd * hx[1] * rho * v2;
+            m3 -= fd * hx[2] * rho * v3;
+          }
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------------------
+// rotating_frame/rotating_frame.cpp:56-86 RotatingFrameForce -> Cartesian:
+// rotating_frame_impl.hpp:28-93 ShearingBoxImpl (tidal potential differenced across the cell
+// + Coriolis force).  The curvilinear flux-form variant (:95-199) is not restated.
+void rotating_frame_force(Sim &s, Real dt) {
+  if (!s.rframe.on) return;
+  const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
+  const int three_d = (s.ndim == 3);
+  const Real om0 = s.rframe.omega, qshear = s.rframe.qshear;
+  const Real omsq = SQR(om0);
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = s.ks; k <= s.ke; ++k)
+    for (int j = s.js; j <= s.je; ++j)
+      for (int i = s.is; i <= s.ie; ++i) {
+        const BBox b = bbox(s, k, j, i);
+        const Real dx = b.x1[1] - b.x1[0];
+        const Real dz = b.x3[1] - b.x3[0];
+        const Real phi_xm1 = -qshear * omsq * b.x1[0] * b.x1[0];
+        const Real phi_xp1 = -qshear * omsq * b.x1[1] * b.x1[1];
+        const Real phi_zm1 = 0.5 * omsq * b.x3[0] * b.x3[0];
+        const Real phi_zp1 = 0.5 * omsq * b.x3[1] * b.x3[1];
+        const Real dpx = (phi_xp1 - phi_xm1) / dx;
+        const Real dpz = three_d * ((phi_zp1 - phi_zm1) / dz);
+        const size_t c = IDX(s, k, j, i);
+        for (int n = 0; n < ng_; ++n) {
+          const Real dens = s.gprim[n * s.N + c];
+          const Real v1 = s.gprim[(ng_ + 3 * n + 0) * s.N + c];
+          const Real v2 = s.gprim[(ng_ + 3 * n + 1) * s.N + c];
+          const Real v3 = s.gprim[(ng_ + 3 * n + 2) * s.N + c];
+          const Real rdt = dens * dt;
+          s.gu0[(ng_ + 3 * n + 0) * s.N + c] -= rdt * (dpx - 2.0 * om0 * v2);
+          s.gu0[(ng_ + 3 * n + 1) * s.N + c] -= rdt * 2.0 * om0 * v1;
+          s.gu0[(ng_ + 3 * n + 2) * s.N + c] -= rdt * dpz;
+          s.gu0[(4 * ng_ + n) * s.N + c] -= rdt * (v1 * dpx + v3 * dpz);
+        }
+        for (int n = 0; n < nd_; ++n) {
+          const Real dens = s.dprim[n * s.N + c];
+          const Real v1 = s.dprim[(nd_ + 3 * n + 0) * s.N + c];
+          const Real v2 = s.dprim[(nd_ + 3 * n + 1) * s.N + c];
+          const Real rdt = dens * dt;
+          s.du0[(nd_ + 3 * n + 0) * s.N + c] -= rdt * (dpx - 2.0 * om0 * v2);
+          s.du0[(nd_ + 3 * n + 1) * s.N + c] -= rdt * 2.0 * om0 * v1;
+          s.du0[(nd_ + 3 * n + 2) * s.N + c] -= rdt * dpz;
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------------------
+// drag/drag.cpp:89-175 DragSource with damp_to_visc = false (DiffType::null: the viscous
+// target velocity has mu = 0, utils/diffusion/diffusion_coeff.hpp:170-190):
+//   type 2 -> drag.hpp:171-294 SelfDragSourceImpl (quadratic damping ramps near the mesh edges)
+//   type 1 -> drag.hpp:296-482 SimpleDragSourceImpl (implicit gas-dust coupling, one gas species)
+inline void damping_ramps(const Sim &s, const Sim::SelfDrag &p, const Real xv[3], Real dt,
+                          Real f[3]) {
+  const int multi_d = (s.ndim >= 2), three_d = (s.ndim == 3);
+  const Real x1min = s.gx1min, x1max = s.gx1max, x2min = s.gx2min, x2max = s.gx2max;
+  const Real x3min = s.gx3min, x3max = s.gx3max;
+  f[0] = dt * (p.irate[0] * ((xv[0] < p.ix[0]) * SQR((xv[0] - p.ix[0]) / (p.ix[0] - x1min))) +
+               p.orate[0] * ((xv[0] > p.ox[0]) * SQR((xv[0] - p.ox[0]) / (p.ox[0] - x1max))));
+  f[1] = multi_d * dt *
+         (p.irate[1] * ((xv[1] < p.ix[1]) * SQR((xv[1] - p.ix[1]) / (p.ix[1] - x2min))) +
+          p.orate[1] * ((xv[1] > p.ox[1]) * SQR((xv[1] - p.ox[1]) / (p.ox[1] - x2max))));
+  f[2] = three_d * dt *
+         (p.irate[2] * ((xv[2] < p.ix[2]) * SQR((xv[2] - p.ix[2]) / (p.ix[2] - x3min))) +
+          p.orate[2] * ((xv[2] > p.ox[2]) * SQR((xv[2] - p.ox[2]) / (p.ox[2] - x3max))));
+}
+void drag_source(Sim &s, Real dt) {
+  if (s.drag.type == 0) return;
+  const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
+  const Real gm1 = s.c.gamma - 1.0;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = s.ks; k <= s.ke; ++k)
+    for (int j = s.js; j <= s.je; ++j)
+      for (int i = s.is; i <= s.ie; ++i) {
+        const Coords coords(s, k, j, i);
+        const Real xv[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
+        Real hx[3];
+        coords.GetScaleFactors(hx);
+        const CylVec cv = to_cyl_with_vec(coords, xv);
+        const size_t c = IDX(s, k, j, i);
+        Real bg[3], bd[3];
+        damping_ramps(s, s.drag.gas, xv, dt, bg);
+        damping_ramps(s, s.drag.dust, xv, dt, bd);
+        if (s.drag.type == 2) { // SelfDragSourceImpl
+          for (int n = 0; n < ng_; ++n) {
+            const Real dens = s.gu0[n * s.N + c];
+            Real *m[3] = {&s.gu0[(ng_ + 3 * n + 0) * s.N + c], &s.gu0[(ng_ + 3 * n + 1) * s.N + c],
+                          &s.gu0[(ng_ + 3 * n + 2) * s.N + c]};
+            const Real vg[3] = {*m[0] / (hx[0] * dens), *m[1] / (hx[1] * dens), *m[2] / (hx[2] * dens)};
+            const Real mu = 0.0;
+            const Real vR = -1.5 * mu / (cv.R * dens);
+            const Real vd[3] = {cv.e1 * vR, cv.e2 * vR, cv.e3 * vR};
+            const Real dm1 = -bg[0] * dens * (vg[0] - vd[0]) / (1.0 + bg[0]);
+            const Real dm2 = -bg[1] * dens * (vg[1] - vd[1]) / (1.0 + bg[1]);
+            const Real dm3 = -bg[2] * dens * (vg[2] - vd[2]) / (1.0 + bg[2]);
+            *m[0] += hx[0] * dm1;
+            *m[1] += hx[1] * dm2;
+            *m[2] += hx[2] * dm3;
+            s.gu0[(4 * ng_ + n) * s.N + c] += dm1 * (vg[0] + 0.5 * dm1 / dens) +
+                                              dm2 * (vg[1] + 0.5 * dm2 / dens) +
+                                              dm3 * (vg[2] + 0.5 * dm3 / dens);
+          }
+          for (int n = 0; n < nd_; ++n) {
+            Real *m[3] = {&s.du0[(nd_ + 3 * n + 0) * s.N + c], &s.du0[(nd_ + 3 * n + 1) * s.N + c],
+                          &s.du0[(nd_ + 3 * n + 2) * s.N + c]};
+            const Real mom[3] = {*m[0], *m[1], *m[2]};
+            *m[0] -= bd[0] * mom[0] / (1.0 + bd[0]);
+            *m[1] -= bd[1] * mom[1] / (1.0 + bd[1]);
+            *m[2] -= bd[2] * mom[2] / (1.0 + bd[2]);
+          }
+          continue;
+        }
+        // SimpleDragSourceImpl
+        const Real dg = s.gu0[0 * s.N + c];
+        Real *mg[3] = {&s.gu0[(ng_ + 0) * s.N + c], &s.gu0[(ng_ + 1) * s.N + c],
+                       &s.gu0[(ng_ + 2) * s.N + c]};
+        const Real vg[3] = {*mg[0] / (hx[0] * dg), *mg[1] / (hx[1] * dg), *mg[2] / (hx[2] * dg)};
+        const Real sieg = specific_internal_energy(s, 0, c, hx);
+        const Real mu = 0.0;
+        const Real vR = -1.5 * mu / (cv.R * dg);
+        const Real vt[3] = {cv.e1 * vR, cv.e2 * vR, cv.e3 * vR};
+        Real fd[3] = {0., 0., 0.};
+        Real fvd[3] = {0., 0., 0.};
+        Real vth = 0.0;
+        if (s.drag.model == 1) vth = std::sqrt(8.0 / M_PI * gm1 * sieg); // Gruneisen = gm1
+        const Real vdt[3] = {0.0, 0.0, 0.0};
+        for (int n = 0; n < nd_; ++n) {
+          const Real dens = s.du0[n * s.N + c];
+          const Real vd[3] = {s.du0[(nd_ + 3 * n + 0) * s.N + c] / (hx[0] * dens),
+                              s.du0[(nd_ + 3 * n + 1) * s.N + c] / (hx[1] * dens),
+                              s.du0[(nd_ + 3 * n + 2) * s.N + c] / (hx[2] * dens)};
+          Real tc = s.drag.tau[n];
+          if (s.drag.model == 1) tc = s.drag.scale * s.drag.grain_density / dg * s.drag.sizes[n] / vth;
+          const Real alpha = dt * ((tc <= 0.0) ? std::numeric_limits<Real>::max() : 1.0 / tc);
+          for (int d = 0; d < 3; d++) {
+            const Real rhop = dens * alpha / (1.0 + alpha + bd[d]);
+            fd[d] += rhop * (1.0 + bd[d]);
+            fvd[d] += rhop * (vd[d] + bd[d] * vdt[d]);
+          }
+        }
+        Real vgp[3];
+        for (int d = 0; d < 3; d++)
+          vgp[d] = (dg * (vg[d] + bg[d] * vt[d]) + fvd[d]) / (dg * (1.0 + bg[d]) + fd[d]);
+        Real delta_g[3] = {0.0, 0.0, 0.0};
+        for (int d = 0; d < 3; d++)
+          fvd[d] = 0.;
+        for (int n = 0; n < nd_; ++n) {
+          const Real dens = s.du0[n * s.N + c];
+          const Real vd[3] = {s.du0[(nd_ + 3 * n + 0) * s.N + c] / (hx[0] * dens),
+                              s.du0[(nd_ + 3 * n + 1) * s.N + c] / (hx[1] * dens),
+                              s.du0[(nd_ + 3 * n + 2) * s.N + c] / (hx[2] * dens)};
+          Real tc = s.drag.tau[n];
+          if (s.drag.model == 1) tc = s.drag.scale * s.drag.grain_density / dg * s.drag.sizes[n] / vth;
+          const Real alpha = dt * ((tc <= 0.0) ? std::numeric_limits<Real>::max() : 1.0 / tc);
+          for (int d = 0; d < 3; d++) {
+            Real delta_d = 0.;
+            const Real rhop = dens * alpha / (1.0 + alpha + bd[d]);
+            const Real delta = rhop * ((vgp[d] - vd[d] + bd[d] * (vgp[d] - vdt[d])));
+            delta_d += delta;
+            delta_g[d] -= delta;
+            delta_d -= bd[d] * dens / (1. + alpha + bd[d]) * (vd[d] - vdt[d] + alpha * (vgp[d] - vdt[d]));
+            fvd[d] += rhop * (vd[d] - vt[d] + bd[d] * (vdt[d] - vt[d]));
+            s.du0[(nd_ + 3 * n + d) * s.N + c] += hx[d] * delta_d;
+          }
+        }
+        for (int d = 0; d < 3; d++) {
+          const Real prefac = dg * bg[d] / (1.0 + bg[d] + fd[d]);
+          delta_g[d] -= prefac * (dg * (vg[d] - vt[d]) + fvd[d]);
+          *mg[d] += hx[d] * delta_g[d];
+          s.gu0[(4 * ng_) * s.N + c] += 0.5 * (vg[d] + vgp[d]) * delta_g[d];
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------------------
 // derived/fill_derived.cpp:30-75 SetAuxillaryFields + utils/artemis_utils.hpp:43-62
 // GetSpecificInternalEnergy (hx = volume-averaged scale factors, fill_derived.cpp:127 analogue).
 void set_aux(Sim &s) {
@@ -1127,7 +1492,7 @@ void fill_dir(Sim &s, std::vector<Real> &prim, int nvar, int nsp, bool gas, int 
   const int ext[3] = {s.ni, s.nj, s.nk};
   for (int side = 0; side < 2; ++side) {
     const int bc = s.c.bc[2 * d + side];
-    if (bc == BC_NONE) continue;
+    if (bc == BC_NONE || bc == BC_STRAT_EXTRAP || bc == BC_STRAT_INFLOW) continue;
     if ((pass == 0) != (bc == BC_PERIODIC)) continue;
     for (int n = 0; n < nvar; ++n) {
       if (gas && n >= 4 * nsp && n < 5 * nsp) continue; // pressure slot is not FillGhost
@@ -1162,11 +1527,88 @@ void fill_dir(Sim &s, std::vector<Real> &prim, int nvar, int nsp, bool gas, int 
     }
   }
 }
+// pgen/strat.hpp:158-466: the `strat` problem's user boundary conditions, registered for
+// `extrap` (x1, x3) and `inflow` (x2) (problem_modifier.hpp:114-128).  par_for_bndry covers the
+// ghost zones of direction d over the ENTIRE extent of the other two (upstream parthenon), like
+// the built-in conditions.  x1 `extrap`: density / sie / v3 copied from the first active zone,
+// v1 copied unless it points into the domain, v2 extrapolated linearly in x (:188-226,
+// :262-299).  x2 `inflow`: copy, except v2 = Keplerian shear where the box inflows (x_face >= 0
+// at the inner edge, < 0 at the outer) and one-way outflow elsewhere (:352-392, :437-466).
+// The x3 `extrap` condition uses std::pow on the density ratio (:520-523) and is not restated.
+void strat_bc(Sim &s, int d, int side) {
+  const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
+  const int lo[3] = {s.is, s.js, s.ks}, hi[3] = {s.ie, s.je, s.ke};
+  int b0[3] = {0, 0, 0}, b1[3] = {s.ni - 1, s.nj - 1, s.nk - 1};
+  if (side == 0) b1[d] = lo[d] - 1;
+  else b0[d] = hi[d] + 1;
+  for (int k = b0[2]; k <= b1[2]; ++k)
+    for (int j = b0[1]; j <= b1[1]; ++j)
+      for (int i = b0[0]; i <= b1[0]; ++i) {
+        const size_t c = IDX(s, k, j, i);
+        if (d == 0) {
+          const int ia = (side == 0) ? s.is : s.ie, ib = (side == 0) ? s.is + 1 : s.ie - 1;
+          const Real x0 = x1v(bbox(s, k, j, ia));
+          const Real x1 = x1v(bbox(s, k, j, ib));
+          const Real dx = (side == 0) ? (x1 - x0) : (x0 - x1);
+          const Real x = x1v(bbox(s, k, j, i));
+          const size_t ca = IDX(s, k, j, ia), cb = IDX(s, k, j, ib);
+          auto fill = [&](std::vector<Real> &q, int nsp, int n) {
+            const Real v1 = q[(nsp + 3 * n + 0) * s.N + ca];
+            const Real v2 = q[(nsp + 3 * n + 1) * s.N + ca];
+            const Real v3 = q[(nsp + 3 * n + 2) * s.N + ca];
+            const Real v2n = q[(nsp + 3 * n + 1) * s.N + cb];
+            const Real vx1 = (side == 0) ? ((v1 > 0.0) ? 0.0 : v1) : ((v1 < 0.0) ? 0.0 : v1);
+            const Real vx2 = (side == 0) ? (v2 + (v2n - v2) * (x - x0) / dx)
+                                         : (v2 + (v2 - v2n) * (x - x0) / dx);
+            q[(nsp + 3 * n + 0) * s.N + c] = vx1;
+            q[(nsp + 3 * n + 1) * s.N + c] = vx2;
+            q[(nsp + 3 * n + 2) * s.N + c] = v3;
+            q[n * s.N + c] = q[n * s.N + ca];
+          };
+          if (ng_) {
+            fill(s.gprim, ng_, 0);
+            s.gprim[(5 * ng_) * s.N + c] = s.gprim[(5 * ng_) * s.N + ca];
+          }
+          for (int n = 0; n < nd_; ++n)
+            fill(s.dprim, nd_, n);
+        } else {
+          const int ja = (side == 0) ? s.js : s.je;
+          const BBox b = bbox(s, k, j, i);
+          const Real x = x1v(b);
+          const Real xf = b.x1[0];
+          const Real vy0 = -s.strat.q * s.strat.Om0 * x;
+          const size_t ca = IDX(s, k, ja, i);
+          auto fill = [&](std::vector<Real> &q, int nsp, int n) {
+            const Real v1 = q[(nsp + 3 * n + 0) * s.N + ca];
+            const Real v2 = q[(nsp + 3 * n + 1) * s.N + ca];
+            const Real v3 = q[(nsp + 3 * n + 2) * s.N + ca];
+            const Real vx2 = (side == 0) ? ((xf >= 0) ? ((v2 > 0.) ? 0.0 : v2) : vy0)
+                                         : ((xf < 0) ? ((v2 < 0.0) ? 0.0 : v2) : vy0);
+            q[(nsp + 3 * n + 0) * s.N + c] = v1;
+            q[(nsp + 3 * n + 1) * s.N + c] = vx2;
+            q[(nsp + 3 * n + 2) * s.N + c] = v3;
+            q[n * s.N + c] = q[n * s.N + ca];
+          };
+          if (ng_) {
+            fill(s.gprim, ng_, 0);
+            s.gprim[(5 * ng_) * s.N + c] = s.gprim[(5 * ng_) * s.N + ca];
+          }
+          for (int n = 0; n < nd_; ++n)
+            fill(s.dprim, nd_, n);
+        }
+      }
+}
 void apply_bcs(Sim &s) {
   for (int pass = 0; pass < 2; ++pass)
     for (int d = 0; d < 3; ++d) {
       if (s.c.ns_gas) fill_dir(s, s.gprim, s.nvg, s.c.ns_gas, true, d, pass);
       if (s.c.ns_dust) fill_dir(s, s.dprim, s.nvd, s.c.ns_dust, false, d, pass);
+      if (pass == 1 && d < s.ndim)
+        for (int side = 0; side < 2; ++side) {
+          const int bc = s.c.bc[2 * d + side];
+          if ((d == 0 && bc == BC_STRAT_EXTRAP) || (d == 1 && bc == BC_STRAT_INFLOW))
+            strat_bc(s, d, side);
+        }
     }
 }
 
@@ -1209,6 +1651,9 @@ void step(Sim &s, exchange_fn xchg, void *ctx) {
     apply_update(s, g0[stage - 1], g1[stage - 1], be[stage - 1] * s.dt); // :205-207
     flux_source(s, FL_GAS, bdt);                                         // :211
     flux_source(s, FL_DUST, bdt);                                        // :212
+    external_gravity(s, s.time, bdt);                                    // :224-228
+    rotating_frame_force(s, bdt);                                        // :231-235
+    drag_source(s, bdt);                                                 // :238-241
     set_aux(s);                                                          // :251-252
     cons_to_prim(s);                                                     // :255
     if (xchg) xchg(ctx);                                                 // :258 (inter-block)
@@ -1455,6 +1900,118 @@ void oracle_pgen_blast(void *h, double rinit, double internal_energy, double p0,
         s.gprim[(nsp + 1) * s.N + c] = 0.0;
         s.gprim[(nsp + 2) * s.N + c] = 0.0;
         s.gprim[(5 * nsp) * s.N + c] = ie / den;
+      }
+  prim_to_cons(s);
+}
+
+// Source-package parameters (gravity.cpp:25-118, rotating_frame.cpp:24-50, drag.cpp:25-84,
+// dust.cpp:102-176 sizes / grain_density).  G = 1 in scale-free units (units.cpp:68-76).
+void oracle_set_gravity_uniform(void *h, double gx1, double gx2, double gx3) {
+  Sim &s = *static_cast<Sim *>(h);
+  s.grav.type = 1, s.grav.g[0] = gx1, s.grav.g[1] = gx2, s.grav.g[2] = gx3;
+}
+void oracle_set_gravity_point(void *h, double mass, double soft, double sink, double sink_rate,
+                              double x, double y, double z) {
+  Sim &s = *static_cast<Sim *>(h);
+  s.grav.type = 2, s.grav.gm = 1.0 * mass, s.grav.soft = soft, s.grav.sink = sink;
+  s.grav.sink_rate = sink_rate, s.grav.pos[0] = x, s.grav.pos[1] = y, s.grav.pos[2] = z;
+}
+void oracle_set_gravity_window(void *h, double tstart, double tstop) {
+  Sim &s = *static_cast<Sim *>(h);
+  s.grav.tstart = tstart, s.grav.tstop = tstop;
+}
+void oracle_set_rotating_frame(void *h, double omega, double qshear) {
+  Sim &s = *static_cast<Sim *>(h);
+  s.rframe.on = true, s.rframe.omega = omega, s.rframe.qshear = qshear;
+  s.strat.q = qshear, s.strat.Om0 = omega; // strat.hpp:60-61
+}
+// type: 1 simple_dust, 2 self; model: 0 constant (tau[n] *= scale, drag.hpp:129-137), 1 stokes
+void oracle_set_drag(void *h, int type, int model, double scale, double grain_density,
+                     const double *tau, const double *sizes) {
+  Sim &s = *static_cast<Sim *>(h);
+  s.drag.type = type, s.drag.model = model, s.drag.scale = scale;
+  s.drag.grain_density = grain_density;
+  s.drag.tau.assign(s.c.ns_dust, 0.0), s.drag.sizes.assign(s.c.ns_dust, 0.0);
+  for (int n = 0; n < s.c.ns_dust; ++n) {
+    s.drag.tau[n] = (model == 0) ? scale * tau[n] : scale;
+    if (sizes) s.drag.sizes[n] = sizes[n];
+  }
+}
+// fluid 0 gas / 1 dust; p = {inner_x1..3, inner_x1..3_rate, outer_x1..3, outer_x1..3_rate}
+void oracle_set_damping(void *h, int fluid, const double *p) {
+  Sim &s = *static_cast<Sim *>(h);
+  Sim::SelfDrag &d = fluid ? s.drag.dust : s.drag.gas;
+  for (int i = 0; i < 3; ++i)
+    d.ix[i] = p[i], d.irate[i] = p[3 + i], d.ox[i] = p[6 + i], d.orate[i] = p[9 + i];
+}
+void oracle_external_gravity(void *h, double time, double dt) {
+  external_gravity(*static_cast<Sim *>(h), time, dt);
+}
+void oracle_rotating_frame_force(void *h, double dt) { rotating_frame_force(*static_cast<Sim *>(h), dt); }
+void oracle_drag_source(void *h, double dt) { drag_source(*static_cast<Sim *>(h), dt); }
+
+// pgen/constant.hpp:58-166 with problem/system = cartesian on a Cartesian mesh (the basis
+// conversion is the identity); sie = Cv*T with Cv = kB/((gamma-1) amu mu) = 1/(gamma-1) in
+// scale-free units (gas.cpp:106-116, units.cpp:68-76; singularity-eos IdealGas, recalled).
+void oracle_pgen_constant(void *h, double g_rho, double g_vx1, double g_vx2, double g_vx3,
+                          double g_temp, double d_rho, double d_vx1, double d_vx2, double d_vx3) {
+  Sim &s = *static_cast<Sim *>(h);
+  const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
+  const Real cv = 1.0 / ((s.c.gamma - 1.) * 1.0 * 1.0);
+  const Real ex1[3] = {1.0, 0.0, 0.0}, ex2[3] = {0.0, 1.0, 0.0}, ex3[3] = {0.0, 0.0, 1.0};
+  for (size_t c = 0; c < s.N; ++c) {
+    if (ng_) {
+      s.gprim[0 * s.N + c] = g_rho;
+      s.gprim[(ng_ + 0) * s.N + c] = (g_vx1 * ex1[0] + g_vx2 * ex1[1] + g_vx3 * ex1[2]);
+      s.gprim[(ng_ + 1) * s.N + c] = (g_vx1 * ex2[0] + g_vx2 * ex2[1] + g_vx3 * ex2[2]);
+      s.gprim[(ng_ + 2) * s.N + c] = (g_vx1 * ex3[0] + g_vx2 * ex3[1] + g_vx3 * ex3[2]);
+      s.gprim[(5 * ng_) * s.N + c] = std::max(0.0, cv * g_temp);
+    }
+    for (int n = 0; n < nd_; ++n) {
+      s.dprim[n * s.N + c] = d_rho;
+      s.dprim[(nd_ + 3 * n + 0) * s.N + c] = (d_vx1 * ex1[0] + d_vx2 * ex1[1] + d_vx3 * ex1[2]);
+      s.dprim[(nd_ + 3 * n + 1) * s.N + c] = (d_vx1 * ex2[0] + d_vx2 * ex2[1] + d_vx3 * ex2[2]);
+      s.dprim[(nd_ + 3 * n + 2) * s.N + c] = (d_vx1 * ex3[0] + d_vx2 * ex3[1] + d_vx3 * ex3[2]);
+    }
+  }
+  prim_to_cons(s);
+}
+
+// pgen/strat.hpp:55-150: isothermal shearing sheet, v2 = -q Om0 x, T0 = (h Om0)^2, Gaussian
+// vertical profile in 3-D; dust at dust_to_gas of the gas density with the gas velocity.
+void oracle_pgen_strat(void *h, double rho0, double dens_min, double hscale, double d2g) {
+  Sim &s = *static_cast<Sim *>(h);
+  const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
+  const bool three_d = (s.ndim == 3);
+  const Real q = s.strat.q, Om0 = s.strat.Om0;
+  const Real temp0 = SQR(hscale * Om0);
+  const Real cv = 1.0 / ((s.c.gamma - 1.) * 1.0 * 1.0);
+  for (int k = 0; k < s.nk; ++k)
+    for (int j = 0; j < s.nj; ++j)
+      for (int i = 0; i < s.ni; ++i) {
+        const BBox b = bbox(s, k, j, i);
+        const Real x = x1v(b);
+        const Real z = x3v(b);
+        const Real vx1 = 0.0;
+        const Real vx2 = -q * Om0 * x;
+        const Real vx3 = 0.0;
+        const Real temp = temp0;
+        const Real efac = (three_d) ? std::exp(-SQR(z) / (2.0 * SQR(hscale))) : 1.0;
+        const Real dens = std::max(dens_min, efac * rho0);
+        const Real sie = std::max(0.0, cv * temp);
+        const size_t c = IDX(s, k, j, i);
+        s.gprim[0 * s.N + c] = dens;
+        s.gprim[(ng_ + 0) * s.N + c] = vx1;
+        s.gprim[(ng_ + 1) * s.N + c] = vx2;
+        s.gprim[(ng_ + 2) * s.N + c] = vx3;
+        s.gprim[(5 * ng_) * s.N + c] = sie;
+        const Real ddens = dens * d2g;
+        for (int n = 0; n < nd_; ++n) {
+          s.dprim[n * s.N + c] = ddens;
+          s.dprim[(nd_ + 3 * n + 0) * s.N + c] = vx1;
+          s.dprim[(nd_ + 3 * n + 1) * s.N + c] = vx2;
+          s.dprim[(nd_ + 3 * n + 2) * s.N + c] = vx3;
+        }
       }
   prim_to_cons(s);
 }

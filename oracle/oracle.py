@@ -14,7 +14,8 @@ _LIB = os.path.join(_HERE, "_build", "liboracle.so")
 
 RS = {"hllc": 0, "hlle": 1, "llf": 2}
 RC = {"pcm": 0, "plm": 1, "ppm": 2}
-BC = {"periodic": 0, "outflow": 1, "reflecting": 2, "reflect": 2, "none": 3}
+BC = {"periodic": 0, "outflow": 1, "reflecting": 2, "reflect": 2, "none": 3,
+      "extrap": 4, "inflow": 5}  # 4/5: the strat pgen's user conditions (problem_modifier.hpp:114-128)
 INTEG = {"rk1": 0, "rk2": 1, "vl2": 2, "rk3": 3}
 GAS, DUST = 0, 1
 
@@ -106,6 +107,18 @@ def lib():
         L.oracle_ppm4.argtypes = [C.c_double] * 5 + [C.POINTER(C.c_double)] * 2
         L.oracle_riemann.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        d, vp, i = C.c_double, C.c_void_p, C.c_int
+        L.oracle_set_gravity_uniform.argtypes = [vp, d, d, d]
+        L.oracle_set_gravity_point.argtypes = [vp] + [d] * 7
+        L.oracle_set_gravity_window.argtypes = [vp, d, d]
+        L.oracle_set_rotating_frame.argtypes = [vp, d, d]
+        L.oracle_set_drag.argtypes = [vp, i, i, d, d, C.POINTER(d), C.POINTER(d)]
+        L.oracle_set_damping.argtypes = [vp, i, C.POINTER(d)]
+        L.oracle_external_gravity.argtypes = [vp, d, d]
+        L.oracle_rotating_frame_force.argtypes = [vp, d]
+        L.oracle_drag_source.argtypes = [vp, d]
+        L.oracle_pgen_constant.argtypes = [vp] + [d] * 9
+        L.oracle_pgen_strat.argtypes = [vp] + [d] * 4
         _lib = L
     return _lib
 
@@ -221,6 +234,52 @@ class Oracle:
         else:
             cb = EXCH(lambda ctx: exchange())
             self.L.oracle_post_init(self.h, C.cast(cb, C.c_void_p), None)
+
+    # ---- optional source packages (deck block names in the docstrings) ------------------------
+    def set_gravity_uniform(self, gx1, gx2, gx3):
+        """<gravity/uniform> gx1, gx2, gx3"""
+        self.L.oracle_set_gravity_uniform(self.h, gx1, gx2, gx3)
+
+    def set_gravity_point(self, mass, soft=0.0, sink=0.0, sink_rate=0.0, x=0.0, y=0.0, z=0.0):
+        """<gravity/point> mass, soft, sink, sink_rate, x, y, z"""
+        self.L.oracle_set_gravity_point(self.h, mass, soft, sink, sink_rate, x, y, z)
+
+    def set_gravity_window(self, tstart, tstop):
+        self.L.oracle_set_gravity_window(self.h, tstart, tstop)
+
+    def set_rotating_frame(self, omega, qshear=0.0):
+        """<rotating_frame> omega, qshear"""
+        self.L.oracle_set_rotating_frame(self.h, omega, qshear)
+
+    def set_drag(self, type="simple_dust", model="constant", tau=None, scale=1.0, grain_density=1.0,
+                 sizes=None):
+        """<drag> type; <dust/stopping_time> type, tau, scale; <dust> sizes, grain_density"""
+        nd = self.cfg.ns_dust
+        arr = lambda v: (C.c_double * max(nd, 1))(*(list(v) if v is not None else [0.0] * nd))
+        self.L.oracle_set_drag(self.h, {"simple_dust": 1, "self": 2}[type],
+                               {"constant": 0, "stokes": 1}[model], scale, grain_density,
+                               arr(tau), arr(sizes))
+
+    def set_damping(self, fluid, inner=(-1.7976931348623157e308,) * 3, inner_rate=(0.0,) * 3,
+                    outer=(1.7976931348623157e308,) * 3, outer_rate=(0.0,) * 3):
+        """<gas/damping> / <dust/damping> inner_x*, inner_x*_rate, outer_x*, outer_x*_rate"""
+        p = (C.c_double * 12)(*inner, *inner_rate, *outer, *outer_rate)
+        self.L.oracle_set_damping(self.h, fluid, p)
+
+    def ExternalGravity(self, time, dt): self.L.oracle_external_gravity(self.h, time, dt)
+    def RotatingFrameForce(self, dt): self.L.oracle_rotating_frame_force(self.h, dt)
+    def DragSource(self, dt): self.L.oracle_drag_source(self.h, dt)
+
+    def pgen_constant(self, gas_rho=1.0, gas_v=(0.0, 0.0, 0.0), gas_temp=1.0, dust_rho=1.0,
+                      dust_v=(0.0, 0.0, 0.0), post_init=True):
+        self.L.oracle_pgen_constant(self.h, gas_rho, *gas_v, gas_temp, dust_rho, *dust_v)
+        if post_init:
+            self.post_init()
+
+    def pgen_strat(self, rho0=1.0, dens_min=1.0e-5, h=1.0, dust_to_gas=0.01, post_init=True):
+        self.L.oracle_pgen_strat(self.h, rho0, dens_min, h, dust_to_gas)
+        if post_init:
+            self.post_init()
 
     def pgen_blast(self, radius=1.0, internal_energy=1.0, p0=1.0, d0=1.0, x0=(0.0, 0.0, 0.0),
                    samples=-1, symmetry="spherical", post_init=True):

@@ -144,13 +144,13 @@ int artemis_hip_flux_source(const artemis_pack_t *p, int fluid, double dt, void 
 long artemis_hip_metric_count(const artemis_pack_t *p) {
   if (p->coords != CO_SPH2D && p->coords != CO_SPH3D) return 0;
   const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0);
-  return static_cast<long>(p->nblocks) * 5 * (nj + 1);
+  return static_cast<long>(p->nblocks) * 6 * (nj + 1);
 }
 int artemis_hip_metric_fill(const artemis_pack_t *p, const double *g, double *out) {
   if (artemis_hip_metric_count(p) == 0) return 0;
   const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0), st = nj + 1;
   for (int b = 0; b < p->nblocks; ++b) {
-    double *m = out + static_cast<long>(b) * 5 * st;
+    double *m = out + static_cast<long>(b) * 6 * st;
     for (int j = 0; j <= nj; ++j) {
       const double xf = g[6 * b + 2] + j * g[6 * b + 3];
       m[j] = std::cos(xf), m[st + j] = std::sin(xf);
@@ -162,6 +162,7 @@ int artemis_hip_metric_fill(const artemis_pack_t *p, const double *g, double *ou
       const Real dst = std::sin(bb.x2[1]) - std::sin(bb.x2[0]);
       const Real x2v = (dst - bb.x2[1] * ctp + bb.x2[0] * ctm) / std::abs(ctm - ctp);
       m[2 * st + j] = x2v, m[3 * st + j] = std::sin(x2v), m[4 * st + j] = std::sin(0.5 * (bb.x2[0] + bb.x2[1]));
+      m[5 * st + j] = std::cos(x2v);
     }
   }
   return 0;
@@ -215,13 +216,60 @@ int artemis_hip_estimate_dt(const artemis_pack_t *p, int fluid, double cfl, doub
   *out = DBL_MAX;
   return artemis_hip_estimate_dt_async(p, fluid, cfl, out, s);
 }
-int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, void *) {
+int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_bc_params_t *par, void *) {
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);
     B.load_state();
     for (int f = 0; f < 6; ++f) B.s->c.bc[f] = bc[6 * b + f];
+    if (par) B.s->strat.q = par->qshear, B.s->strat.Om0 = par->omega;
     apply_bcs(*B.s);
     B.out(B.s->gprim, p->gas.prim, B.s->nvg), B.out(B.s->dprim, p->dust.prim, B.s->nvd);
+  }
+  return 0;
+}
+int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_t *g, double time,
+                                 double dt, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state();
+    Sim &s = *B.s;
+    s.grav.type = g->type, s.grav.gm = g->gm, s.grav.soft = g->soft, s.grav.sink = g->sink;
+    s.grav.sink_rate = g->sink_rate, s.grav.tstart = g->tstart, s.grav.tstop = g->tstop;
+    for (int d = 0; d < 3; ++d) s.grav.g[d] = g->g[d], s.grav.pos[d] = g->pos[d];
+    external_gravity(s, time, dt);
+    B.out(s.gu0, p->gas.cons0, s.nvg), B.out(s.du0, p->dust.cons0, s.nvd);
+  }
+  return 0;
+}
+int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, double qshear, double,
+                                     double dt, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state();
+    B.s->rframe.on = true, B.s->rframe.omega = omega, B.s->rframe.qshear = qshear;
+    rotating_frame_force(*B.s, dt);
+    B.out(B.s->gu0, p->gas.cons0, B.s->nvg), B.out(B.s->du0, p->dust.cons0, B.s->nvd);
+  }
+  return 0;
+}
+int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, double, double dt, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state();
+    Sim &s = *B.s;
+    s.drag.type = d->type, s.drag.model = d->model, s.drag.scale = d->scale;
+    s.drag.grain_density = d->grain_density;
+    s.drag.tau.assign(d->tau, d->tau + s.c.ns_dust), s.drag.sizes.assign(d->sizes, d->sizes + s.c.ns_dust);
+    for (int i = 0; i < 3; ++i) {
+      s.drag.gas.ix[i] = d->gas.ix[i], s.drag.gas.ox[i] = d->gas.ox[i];
+      s.drag.gas.irate[i] = d->gas.irate[i], s.drag.gas.orate[i] = d->gas.orate[i];
+      s.drag.dust.ix[i] = d->dust.ix[i], s.drag.dust.ox[i] = d->dust.ox[i];
+      s.drag.dust.irate[i] = d->dust.irate[i], s.drag.dust.orate[i] = d->dust.orate[i];
+    }
+    s.gx1min = d->xmin[0], s.gx2min = d->xmin[1], s.gx3min = d->xmin[2];
+    s.gx1max = d->xmax[0], s.gx2max = d->xmax[1], s.gx3max = d->xmax[2];
+    drag_source(s, dt);
+    B.out(s.gu0, p->gas.cons0, s.nvg), B.out(s.du0, p->dust.cons0, s.nvd);
   }
   return 0;
 }

@@ -39,6 +39,8 @@ def main():
     for b in range(sim.nblocks):
         arrays["prim%d" % b] = sim.interior(sim.field("gas.prim", b))
         arrays["bounds%d" % b] = np.array(sim.block_bounds(b))
+        if spec.get("dust"):
+            arrays["dust%d" % b] = sim.interior(sim.field("dust.prim", b))
     np.savez(spec["out"] + ".rank%d.npz" % rank, meta=json.dumps(out), hist=hist, errs=errs, **arrays)
     sim.close()
     if world > 1:

@@ -375,3 +375,76 @@ def test_blast_reference_axisymmetric_2d(hiplib):
         if P.max() > pmax:
             pmax, rmax = P.max(), np.hypot(X, Y).ravel()[np.argmax(P)]
     assert abs(rmax - 1.033 * (0.1 ** 2) ** 0.2) < 0.015, rmax
+
+
+def drag_oracle():
+    o = Oracle((128, 1, 1), (0.0, -0.5, -0.5), (1.0, 0.5, 0.5), ng=2, ns_gas=1, ns_dust=4,
+               reconstruct="plm", riemann="hlle", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.4,
+               dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10, cfl=0.3, dust_cfl=0.3,
+               bc=("periodic",) * 6, integrator="rk2")
+    o.set_drag("simple_dust", "constant", tau=[1e-2, 0.1, 1.0, 1e1])
+    o.pgen_constant(gas_rho=10.0, gas_v=(1.0, 0, 0), gas_temp=1.0, dust_rho=0.01, dust_v=(0, 0, 0))
+    return o
+
+
+def test_drag_deck_bitwise_and_reference_pins(hiplib):
+    """inputs/drag/simple_drag.in on the GPU: one block bit for bit against the oracle to
+    t = 0.5 (all four species mid-relaxation), then the shipped 4-block deck to t = 10 against
+    tst/scripts/drag/drag.py:57-59,127-129 (|<v_d - v_g> - ans| <= 3e-3, momentum to 1e-13)."""
+    from artemis_amd.driver import Simulation
+    s = Simulation(DECK("drag", "simple_drag.in"), ["parthenon/meshblock/nx1=128", "parthenon/time/tlim=0.5"])
+    assert s.nblocks == 1 and not s.uses_fused_path
+    o = drag_oracle()
+    s.evolve(), o.evolve(0.5, -1)
+    assert s.ncycle == o.ncycle and s.time == o.time and s.dt == o.dt
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    assert np.array_equal(s.field("dust.prim"), o.dprim)
+    tau, c = [1e-2, 0.1, 1.0, 10.0], 0.01 / 10.0
+    for tlim in (0.5, 10.0):
+        f = Simulation(DECK("drag", "simple_drag.in"), [f"parthenon/time/tlim={tlim}"])
+        assert f.nblocks == 4
+        h0 = f.history()
+        f.evolve()
+        h1 = f.history()
+        vg = np.concatenate([f.interior(f.field("gas.prim", b))[1, 0, 0] for b in range(4)])
+        for d in range(4):
+            vd = np.concatenate([f.interior(f.field("dust.prim", b))[4 + 3 * d, 0, 0] for b in range(4)])
+            assert abs((vd - vg).mean() + np.exp(-(1.0 + c) * f.time / tau[d])) <= 3e-3, (tlim, d)
+        mom = lambda h: h[1] + sum(h[7 + 4 * n] for n in range(4))
+        assert abs(mom(h1) / mom(h0) - 1) <= 1e-13
+
+
+def test_shearing_sheet_deck_bitwise_and_reference_pins(hiplib):
+    """inputs/ssheet/ssheet.in on the GPU (strat pgen, point-mass gravity, shearing box, extrap /
+    inflow user BCs): one 128^2 block bit for bit against the oracle for 60 cycles, then the
+    shipped 16-block deck to t = 2 pi against tst/scripts/ssheet/ssheet.py:70-128 (wake maxima at
+    x = -+0.1 within 0.03 of y = +-3/4 x^2/h)."""
+    from artemis_amd.driver import Simulation
+    s = Simulation(DECK("ssheet", "ssheet.in"), ["parthenon/meshblock/nx1=128", "parthenon/meshblock/nx2=128",
+                                                "parthenon/time/nlim=60"])
+    assert s.nblocks == 1 and not s.uses_fused_path
+    N = 128
+    o = Oracle((N, N, 1), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.000001, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
+               bc=("extrap", "extrap", "inflow", "inflow", "extrap", "extrap"), integrator="rk2")
+    o.set_rotating_frame(1.0, 1.5)
+    o.set_gravity_point(1e-5, soft=0.03)
+    o.pgen_strat(rho0=1.0, dens_min=1e-10, h=0.05)
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    s.evolve(), o.evolve(100.0, 60)
+    assert s.ncycle == o.ncycle == 60 and s.time == o.time and s.dt == o.dt
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    f = Simulation(DECK("ssheet", "ssheet.in"), ["parthenon/time/tlim={:.16f}".format(2.0 * np.pi)])
+    assert f.nblocks == 16
+    f.evolve()
+    d = np.zeros((N, N))
+    for b in range(16):
+        x1a, _, x2a, _, _, _ = f.block_bounds(b)
+        i0, j0 = int(round((x1a + 1.0) * N / 2)), int(round((x2a + 1.0) * N / 2))
+        d[j0:j0 + 32, i0:i0 + 32] = f.interior(f.field("gas.prim", b))[0, 0]
+    x = np.linspace(-1, 1, N + 1)
+    xc = 0.5 * (x[1:] + x[:-1])
+    sig = d - d.mean(axis=0)[None, :]
+    ii, io = np.argwhere(x <= -0.1)[-1][0], np.argwhere(xc >= 0.1)[0][0]
+    assert abs(xc[np.argmax(sig[:, ii])] - 0.75 * 0.1 ** 2 / 0.05) < 0.03
+    assert abs(xc[np.argmax(sig[:, io])] + 0.75 * 0.1 ** 2 / 0.05) < 0.03

@@ -47,8 +47,10 @@ def run_world(world, spec, tmp_path, tag):
     res = []
     for r in range(world):
         z = np.load(spec["out"] + ".rank%d.npz" % r)
+        nblk = json.loads(str(z["meta"]))["nblocks"]
         res.append(dict(meta=json.loads(str(z["meta"])), hist=z["hist"], errs=z["errs"],
-                        blocks=[(z["bounds%d" % b], z["prim%d" % b]) for b in range(json.loads(str(z["meta"]))["nblocks"])]))
+                        blocks=[(z["bounds%d" % b], z["prim%d" % b]) for b in range(nblk)],
+                        dust=[z["dust%d" % b] for b in range(nblk)] if spec.get("dust") else []))
     return res
 
 
@@ -166,3 +168,61 @@ def test_spherical3d_two_ranks_equal_single_process_bitwise(double_lib, tmp_path
     vol = (1.4 ** 3 - 0.2 ** 3) / 3.0 * (np.cos(0.7) - np.cos(2.4)) * 2 * np.pi
     assert abs(one[0]["hist"][0] - vol) < 1e-12 * vol
     assert np.allclose(two[0]["hist"], one[0]["hist"], rtol=1e-13)
+
+
+# ---- source packages through the driver: drag (simple_drag.in) and the shearing sheet (ssheet.in) --
+def test_drag_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
+    """inputs/drag/simple_drag.in (constant pgen, gas + 4 dust species, simple_dust drag,
+    periodic): the driver's task order and deck parsing against oracle.step() bit for bit on one
+    block, and 4 blocks on 2 ranks against 1 rank."""
+    from oracle.oracle import Oracle
+    one_blk = dict(deck=["drag", "simple_drag.in"], cycles=25, dust=True,
+                   overrides=["parthenon/meshblock/nx1=128"])
+    r = run_world(1, one_blk, tmp_path, "d1")[0]
+    assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    o = Oracle((128, 1, 1), (0.0, -0.5, -0.5), (1.0, 0.5, 0.5), ng=2, ns_gas=1, ns_dust=4,
+               reconstruct="plm", riemann="hlle", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.4,
+               dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10, cfl=0.3, dust_cfl=0.3,
+               bc=("periodic",) * 6, integrator="rk2")
+    o.set_drag("simple_dust", "constant", tau=[1e-2, 0.1, 1.0, 1e1])
+    o.pgen_constant(gas_rho=10.0, gas_v=(1.0, 0, 0), gas_temp=1.0, dust_rho=0.01, dust_v=(0, 0, 0))
+    o.evolve(10.0, 25)
+    assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
+    assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+    assert np.array_equal(r["dust"][0], o.interior(o.dprim))
+    assert np.max(np.abs(o.interior(o.dprim)[4] - 0.0)) > 0.5  # the tau = 0.01 grains have caught up
+    four = dict(one_blk, overrides=[])
+    a, b = run_world(1, four, tmp_path, "d4"), run_world(2, four, tmp_path, "d4r2")
+    assert a[0]["meta"]["nblocks"] == 4 and [x["meta"]["nblocks"] for x in b] == [2, 2]
+    xa, xb = by_bounds(a), by_bounds(b)
+    for key in xa:
+        assert np.array_equal(xa[key], xb[key]), key
+    assert a[0]["meta"]["dt"] == b[0]["meta"]["dt"] == b[1]["meta"]["dt"]
+
+
+def test_shearing_sheet_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
+    """inputs/ssheet/ssheet.in (strat pgen, point-mass gravity, shearing-box sources, extrap /
+    inflow user boundary conditions) at 32^2: driver == oracle on one block; 4 blocks on 2 ranks
+    == 1 rank (the user conditions act on the outer blocks only, interior faces exchange)."""
+    from oracle.oracle import Oracle
+    small = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "gravity/point/mass=1.0e-3"]
+    one_blk = dict(deck=["ssheet", "ssheet.in"], cycles=20,
+                   overrides=small + ["parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=32"])
+    r = run_world(1, one_blk, tmp_path, "s1")[0]
+    assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    o = Oracle((32, 32, 1), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.000001, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
+               bc=("extrap", "extrap", "inflow", "inflow", "extrap", "extrap"), integrator="rk2")
+    o.set_rotating_frame(1.0, 1.5)
+    o.set_gravity_point(1e-3, soft=0.03)
+    o.pgen_strat(rho0=1.0, dens_min=1e-10, h=0.05)
+    o.evolve(100.0, 20)
+    assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
+    assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+    assert np.ptp(o.interior(o.gprim)[0]) > 1e-6  # the planet has perturbed the sheet
+    four = dict(one_blk, overrides=small + ["parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=16"])
+    a, b = run_world(1, four, tmp_path, "s4"), run_world(2, four, tmp_path, "s4r2")
+    assert a[0]["meta"]["nblocks"] == 4 and [x["meta"]["nblocks"] for x in b] == [2, 2]
+    xa, xb = by_bounds(a), by_bounds(b)
+    for key in xa:
+        assert np.array_equal(xa[key], xb[key]), key

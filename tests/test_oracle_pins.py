@@ -207,3 +207,60 @@ def test_curvilinear_static_equilibrium_and_geometry_identities():
         assert abs(o.history()[0] - 1.3 * vol(lo, hi)) < 1e-12 * vol(lo, hi), sys_
         o.evolve(-1.0, 5)
         assert np.array_equal(o.gprim, before), sys_
+
+
+# ---- source packages ---------------------------------------------------------
+def test_drag_reference_test_pins():
+    """tst/scripts/drag/drag.py:36-37,57-59,127-129 on inputs/drag/simple_drag.in: for every
+    output time up to t = 10 and each of the four stopping times, |<v_dust - v_gas> - ans| <= 3e-3
+    with ans = -exp(-(1 + 0.01/10) t / tau), and total momentum conserved to 1e-13."""
+    tau = [1e-2, 0.1, 1.0, 10.0]
+    o = Oracle((128, 1, 1), (0.0, -0.5, -0.5), (1.0, 0.5, 0.5), ng=2, ns_gas=1, ns_dust=4,
+               reconstruct="plm", riemann="hlle", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.4,
+               dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10, cfl=0.3, dust_cfl=0.3,
+               bc=("periodic",) * 6, integrator="rk2")
+    o.set_drag("simple_dust", "constant", tau=tau)
+    o.pgen_constant(gas_rho=10.0, gas_v=(1.0, 0, 0), gas_temp=1.0, dust_rho=0.01, dust_v=(0, 0, 0))
+    mom = lambda h: h[1] + sum(h[7 + 4 * n] for n in range(4))
+    m0 = mom(o.history())
+    c = 0.01 / 10.0
+    worst, worst_mom = 0.0, 0.0
+    for tout in np.arange(0.05, 10.0 - 1e-9, 0.05):  # drag.py:61: outputs 1 .. tlim/0.05 - 1
+        o.evolve(tout, -1)
+        vg = o.interior(o.gprim)[1, 0, 0]
+        dp = o.interior(o.dprim)
+        for d in range(4):
+            ans = -np.exp(-(1.0 + c) * o.time / tau[d])
+            worst = max(worst, abs((dp[4 + 3 * d, 0, 0] - vg).mean() - ans))
+        worst_mom = max(worst_mom, abs(mom(o.history()) / m0 - 1))
+    assert worst <= 3e-3, worst          # the oracle gives 2.43e-3: the threshold is a 25 % margin
+    assert worst > 1e-3                  # and not vacuous
+    assert worst_mom <= 1e-13, worst_mom
+
+
+def test_shearing_sheet_reference_test_pins():
+    """tst/scripts/ssheet/ssheet.py:40-128 on inputs/ssheet/ssheet.in to t = 2 pi: the density
+    wake of the embedded point mass, located as the maximum of Sigma - <Sigma>_y on the rings
+    x = -0.1 (last face <= -0.1) and x = +0.1 (first centre >= 0.1), sits within 0.03 of the
+    Ogilvie & Lubow position y = -+ 3/4 x^2 / h.  Exercises the strat pgen, point-mass gravity,
+    the shearing-box source and the extrap / inflow user boundary conditions together."""
+    N = 128
+    o = Oracle((N, N, 1), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.000001, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
+               bc=("extrap", "extrap", "inflow", "inflow", "extrap", "extrap"), integrator="rk2")
+    o.set_rotating_frame(1.0, 1.5)
+    o.set_gravity_point(1e-5, soft=0.03)
+    o.pgen_strat(rho0=1.0, dens_min=1e-10, h=0.05)
+    o.evolve(2.0 * np.pi, -1)
+    d = o.interior(o.gprim)[0, 0]  # [j, i]
+    x = np.linspace(-1, 1, N + 1)
+    xc = 0.5 * (x[1:] + x[:-1])
+    sig = d - d.mean(axis=0)[None, :]
+    ii = np.argwhere(x <= -0.1)[-1][0]
+    io = np.argwhere(xc >= 0.1)[0][0]
+    pi_ = xc[np.argmax(sig[:, ii])]
+    po = xc[np.argmax(sig[:, io])]
+    h = 0.05
+    assert abs(pi_ - 0.75 * 0.1 ** 2 / h) < 0.03, pi_
+    assert abs(po + 0.75 * 0.1 ** 2 / h) < 0.03, po
+    assert 0.01 < sig.max() < 1.0  # a wake exists and the sheet has not blown up

@@ -1,0 +1,192 @@
+"""GPU parity of the source-term tasks and the strat user boundary conditions against the CPU
+oracle, BIT-EXACT: ExternalGravity (uniform, point mass), RotatingFrameForce (shearing box),
+DragSource (simple_dust constant / stokes, self damping) -- reference artemis_driver.cpp:222-241,
+gravity/*.cpp, rotating_frame_impl.hpp:28-93, drag.hpp:171-482, pgen/strat.hpp:158-466."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.oracle import Oracle
+from test_parity_ops import push, random_state, same
+
+pytestmark = pytest.mark.gpu
+BIG = 1.7976931348623157e308
+
+
+def pair(nx, lo, hi, ns_gas=1, ns_dust=2, coordinates="cartesian", seed=0, bc=("outflow",) * 6, ng=2):
+    from artemis_amd.pack import MeshBlockPack
+    kw = dict(ng=ng, ns_gas=ns_gas, ns_dust=ns_dust, reconstruct="plm", riemann="hlle",
+              dust_reconstruct="plm", dust_riemann="hlle", gamma=1.4, dfloor=1e-10, siefloor=1e-10,
+              dust_dfloor=1e-10, coordinates=coordinates)
+    o = Oracle(nx, lo, hi, bc=bc, **kw)
+    random_state(o, np.random.default_rng(seed), shock=False)
+    mb = MeshBlockPack(1, nx, [lo], [hi], **kw)
+    push([o], mb)
+    return o, mb
+
+
+def interior(o):
+    return (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+
+
+def check_cons(o, mb, what):
+    I = interior(o)
+    if o.cfg.ns_gas:
+        same(mb.gas_u0[0][I], o.gu0[I], what + " gas cons")
+    if o.cfg.ns_dust:
+        same(mb.dust_u0[0][I], o.du0[I], what + " dust cons")
+
+
+GRAV_GEOMS = [("cartesian", (20, 12, 8), (-1.0, -0.5, -0.25), (1.0, 0.5, 0.75)),
+              ("cartesian", (33, 9, 1), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2)),
+              ("cartesian", (40, 1, 1), (0.5, -0.5, -0.5), (2.0, 0.5, 0.5)),
+              ("spherical", (40, 1, 1), (0.2, 0.0, -0.5), (2.0, np.pi, 0.5)),
+              ("spherical", (24, 10, 1), (0.3, 0.6, -0.5), (2.0, 2.5, 0.5)),
+              ("axisymmetric", (24, 12, 1), (0.1, -1.0, -0.5), (2.0, 1.0, 0.5))]
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", GRAV_GEOMS)
+def test_point_mass_gravity(hiplib, coordinates, nx, lo, hi):
+    from artemis_amd.pack import gravity_point
+    o, mb = pair(nx, lo, hi, ns_gas=2, ns_dust=2, coordinates=coordinates, seed=21)
+    cart = coordinates == "cartesian"
+    pos = (0.13, -0.07, 0.2) if cart else (0.0, 0.0, 0.0)
+    # softened, with an active sink region so density and energy are drained too
+    o.set_gravity_point(2.5, soft=0.05, sink=0.6, sink_rate=3.0, x=pos[0], y=pos[1], z=pos[2])
+    g = gravity_point(2.5, soft=0.05, sink=0.6, sink_rate=3.0, pos=pos)
+    o.ExternalGravity(0.3, 1.0e-3)
+    mb.ExternalGravity(0.3, 1.0e-3, g)
+    check_cons(o, mb, "PointMassGravity")
+    # sink radius 0: (dr - 0)/0 is inf or nan in the reference arithmetic, the drain stays off
+    o.set_gravity_point(2.5, soft=0.0, sink=0.0, sink_rate=0.0, x=pos[0], y=pos[1], z=pos[2])
+    g = gravity_point(2.5, pos=pos)
+    o.ExternalGravity(0.3, 1.0e-3)
+    mb.ExternalGravity(0.3, 1.0e-3, g)
+    check_cons(o, mb, "PointMassGravity, no sink")
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", GRAV_GEOMS + [
+    ("cylindrical", (16, 8, 6), (0.5, 0.0, -1.0), (2.0, 6.0, 1.0)),
+    ("spherical", (16, 8, 6), (0.3, 0.6, 0.0), (1.5, 2.5, 6.0))])
+def test_uniform_gravity_and_time_window(hiplib, coordinates, nx, lo, hi):
+    from artemis_amd.pack import gravity_uniform
+    o, mb = pair(nx, lo, hi, coordinates=coordinates, seed=22)
+    o.set_gravity_uniform(0.3, -1.1, 0.7)
+    g = gravity_uniform(0.3, -1.1, 0.7)
+    o.ExternalGravity(0.0, 2.0e-3)
+    mb.ExternalGravity(0.0, 2.0e-3, g)
+    check_cons(o, mb, "UniformGravity")
+    before = mb.gas_u0.clone()
+    g.tstart, g.tstop = 1.0, 2.0  # gravity.cpp:134: active for tstart <= time < tstop only
+    mb.ExternalGravity(2.0, 2.0e-3, g)
+    assert torch.equal(mb.gas_u0, before)
+    mb.ExternalGravity(1.0, 2.0e-3, g)
+    assert not torch.equal(mb.gas_u0, before)
+
+
+@pytest.mark.parametrize("nx", [(24, 12, 8), (33, 9, 1), (40, 1, 1)])
+def test_shearing_box(hiplib, nx):
+    o, mb = pair(nx, (-1.0, -0.5, -0.3), (1.0, 0.5, 0.3), ns_gas=2, ns_dust=3, seed=23)
+    o.set_rotating_frame(0.9, 1.5)
+    o.RotatingFrameForce(1.5e-3)
+    mb.RotatingFrameForce(0.9, 1.5, 0.0, 1.5e-3)
+    check_cons(o, mb, "ShearingBox")
+
+
+DRAG_GEOMS = [("cartesian", (20, 12, 8), (-1.0, -0.5, -0.25), (1.0, 0.5, 0.75)),
+              ("cartesian", (40, 1, 1), (0.0, -0.5, -0.5), (1.0, 0.5, 0.5)),
+              ("cylindrical", (16, 8, 6), (0.5, 0.0, -1.0), (2.0, 6.0, 1.0)),
+              ("spherical", (24, 10, 1), (0.3, 0.6, -0.5), (2.0, 2.5, 0.5)),
+              ("spherical", (16, 8, 6), (0.3, 0.6, 0.0), (1.5, 2.5, 6.0)),
+              ("spherical", (40, 1, 1), (0.2, 0.0, -0.5), (2.0, np.pi, 0.5)),
+              ("axisymmetric", (24, 12, 1), (0.1, -1.0, -0.5), (2.0, 1.0, 0.5))]
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", DRAG_GEOMS)
+@pytest.mark.parametrize("model", ["constant", "stokes"])
+def test_simple_dust_drag(hiplib, coordinates, nx, lo, hi, model):
+    """Implicit gas-dust coupling with 4 species spanning stiff to loose stopping times (one is
+    tau <= 0 -> infinitely stiff, drag.hpp:410), with damping ramps active on both fluids."""
+    from artemis_amd.pack import drag_params
+    o, mb = pair(nx, lo, hi, ns_gas=1, ns_dust=4, coordinates=coordinates, seed=24)
+    tau = [1e-3, 0.1, 0.0, 10.0]
+    sizes = [1e-4, 1e-3, 1e-2, 0.1]
+    span = [hi[d] - lo[d] for d in range(3)]
+    inner = tuple(lo[d] + 0.3 * span[d] for d in range(3))
+    outer = tuple(hi[d] - 0.2 * span[d] for d in range(3))
+    damp = dict(inner=inner, inner_rate=(2.0, 0.5, 1.0), outer=outer, outer_rate=(1.0, 3.0, 0.25))
+    o.set_drag("simple_dust", model, tau=tau, scale=1.5, grain_density=2.0, sizes=sizes)
+    o.set_damping(0, **damp)
+    o.set_damping(1, **damp)
+    d = drag_params("simple_dust", model, tau=tau, scale=1.5, grain_density=2.0, sizes=sizes,
+                    mesh_min=lo, mesh_max=hi, gas_damping=damp, dust_damping=damp)
+    o.DragSource(0.02)
+    mb.DragSource(0.0, 0.02, d)
+    check_cons(o, mb, "SimpleDragSource " + model)
+    # total momentum of gas + dust is conserved by the exchange when nothing is damped
+    o.set_damping(0), o.set_damping(1)
+    d = drag_params("simple_dust", model, tau=tau, scale=1.5, grain_density=2.0, sizes=sizes,
+                    mesh_min=lo, mesh_max=hi)
+    m0 = (o.gu0[1:4].sum(axis=0) * 0 + o.gu0[1] + o.du0[4] + o.du0[7] + o.du0[10] + o.du0[13])[interior(o)[1:]]
+    o.DragSource(0.02)
+    mb.DragSource(0.0, 0.02, d)
+    check_cons(o, mb, "SimpleDragSource undamped " + model)
+    m1 = (o.gu0[1] + o.du0[4] + o.du0[7] + o.du0[10] + o.du0[13])[interior(o)[1:]]
+    assert np.max(np.abs(m1 - m0) / (np.abs(m0) + 1.0)) < 1e-12
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", DRAG_GEOMS[:4])
+def test_self_drag(hiplib, coordinates, nx, lo, hi):
+    from artemis_amd.pack import drag_params
+    o, mb = pair(nx, lo, hi, ns_gas=2, ns_dust=2, coordinates=coordinates, seed=25)
+    span = [hi[d] - lo[d] for d in range(3)]
+    damp = dict(inner=tuple(lo[d] + 0.25 * span[d] for d in range(3)), inner_rate=(5.0, 1.0, 2.0),
+                outer=tuple(hi[d] - 0.25 * span[d] for d in range(3)), outer_rate=(0.5, 4.0, 1.0))
+    o.set_drag("self", "constant", tau=[1.0, 1.0])
+    o.set_damping(0, **damp)
+    o.set_damping(1, **damp)
+    d = drag_params("self", mesh_min=lo, mesh_max=hi, gas_damping=damp, dust_damping=damp)
+    o.DragSource(0.05)
+    mb.DragSource(0.0, 0.05, d)
+    check_cons(o, mb, "SelfDragSource")
+
+
+@pytest.mark.parametrize("nx,ns_dust", [((24, 16, 1), 0), ((24, 16, 1), 2), ((16, 12, 6), 1), ((30, 1, 1), 1)])
+def test_strat_boundary_conditions(hiplib, nx, ns_dust):
+    """extrap on x1, inflow on x2 (strat.hpp:158-466) incl. the corner zones, where the x2 pass
+    reads what the x1 pass wrote; outflow on x3 so the three passes mix user and built-in fills."""
+    bc = ("extrap", "extrap", "inflow", "inflow", "outflow", "outflow")
+    o, mb = pair(nx, (-1.0, -1.0, -0.3), (1.0, 1.0, 0.3), ns_gas=1, ns_dust=ns_dust, seed=26, bc=bc)
+    o.set_rotating_frame(1.1, 1.5)
+    o.ApplyBoundaryConditions()
+    mb.ApplyBoundaryConditions([bc], strat=(1.5, 1.1))
+    same(mb.gas_prim[0], o.gprim, "gas ghosts")
+    if ns_dust:
+        same(mb.dust_prim[0], o.dprim, "dust ghosts")
+
+
+def test_source_abi_contract(hiplib):
+    import ctypes as C
+    from artemis_amd import capi
+    from artemis_amd.pack import MeshBlockPack, drag_params, gravity_point
+    mb = MeshBlockPack(1, (8, 8, 4), [(0.5, 0.6, 0.0)], [(1.0, 2.5, 1.0)], ns_dust=1, coordinates="spherical")
+    with pytest.raises(capi.ArtemisHipError) as e:  # needs the azimuthal basis: not built
+        mb.ExternalGravity(0.0, 1e-3, gravity_point(1.0))
+    assert e.value.code == capi.EUNSUPPORTED
+    with pytest.raises(capi.ArtemisHipError) as e:  # rotating_frame.cpp:34-38
+        mb.RotatingFrameForce(1.0, 1.5, 0.0, 1e-3)
+    assert e.value.code == capi.EINVAL and "qshear" in str(e.value)
+    with pytest.raises(capi.ArtemisHipError) as e:  # rotating_frame.cpp:31-32
+        mb.RotatingFrameForce(0.0, 0.0, 0.0, 1e-3)
+    assert "omega cannot be zero" in str(e.value)
+    cart = MeshBlockPack(1, (8, 8, 1), [(0, 0, 0)], [(1, 1, 1)], ns_dust=0)
+    with pytest.raises(capi.ArtemisHipError) as e:  # drag.cpp:71-72
+        cart.DragSource(0.0, 1e-3, drag_params("simple_dust", tau=[1.0]))
+    assert "do_gas = do_dust = true" in str(e.value)
+    with pytest.raises(capi.ArtemisHipError) as e:  # strat flags without their parameters
+        cart.ApplyBoundaryConditions([("extrap", "extrap", "inflow", "inflow", "outflow", "outflow")])
+    assert e.value.code == capi.EINVAL
+    with pytest.raises(capi.ArtemisHipError) as e:  # inflow is an x2 condition
+        cart.ApplyBoundaryConditions([("inflow",) * 6], strat=(1.5, 1.0))
+    assert e.value.code == capi.EINVAL
+    torch.cuda.synchronize()
