@@ -14,7 +14,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
              "-Wall", "-Wno-unused-function"]
 
-HIP_SOURCES = ["abi.hip", "kernels_unfused.hip", "kernels_fused.hip", "kernels_sources.hip",
+HIP_SOURCES = ["abi.hip", "kernels_unfused.hip", "kernels_fused.hip", "kernels_sources.hip", "kernels_stage_cell.hip",
                "selftest.hip"]
 
 

@@ -94,6 +94,18 @@ class Drag(C.Structure):
                 ("xmin", C.c_double * 3), ("xmax", C.c_double * 3)]
 
 
+class StageGeneralArgs(C.Structure):
+    _fields_ = [
+        ("gam0", C.c_double), ("gam1", C.c_double), ("beta_dt", C.c_double), ("bdt", C.c_double),
+        ("pcm", C.c_int), ("time", C.c_double),
+        ("gas_in", PP), ("gas_u1", PP), ("gas_out", PP),
+        ("dust_in", PP), ("dust_u1", PP), ("dust_out", PP),
+        ("gravity", C.POINTER(Gravity)), ("rf_omega", C.c_double), ("rf_qshear", C.c_double),
+        ("drag", C.POINTER(Drag)), ("cfl_gas", C.c_double), ("cfl_dust", C.c_double),
+        ("dt_dev", C.c_void_p),
+    ]
+
+
 class ArtemisHipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"artemis_hip error {code}: {msg}")
@@ -128,6 +140,7 @@ def load():
         "artemis_hip_rotating_frame_force": (i, [PPk, d, d, d, d, vp]),
         "artemis_hip_drag_source": (i, [PPk, C.POINTER(Drag), d, d, vp]),
         "artemis_hip_stage_fused": (i, [PPk, C.POINTER(StageArgs), vp]),
+        "artemis_hip_stage_general": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
         "artemis_hip_wait_counter": (i, [vp, C.c_uint, vp, vp]),
         "artemis_hip_advance_dt": (i, [vp, d, i, C.POINTER(d), vp]),
         "artemis_hip_metric_count": (C.c_long, [PPk]),
@@ -173,7 +186,7 @@ EXPORTS_HIP = [
     "artemis_hip_deep_copy_conserved", "artemis_hip_estimate_dt", "artemis_hip_estimate_dt_async",
     "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_metric_count",
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_rotating_frame_force",
-    "artemis_hip_drag_source", "artemis_hip_halo_count",
+    "artemis_hip_drag_source", "artemis_hip_stage_general", "artemis_hip_halo_count",
     "artemis_hip_halo_pack", "artemis_hip_halo_unpack", "artemis_hip_last_error",
     "artemis_hip_device_count", "artemis_hip_version",
 ]

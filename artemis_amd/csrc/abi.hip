@@ -374,6 +374,42 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
   return after_launch("stage_fused");
 }
 
+int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
+                              void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");
+  if (int rc = validate_fluid(p, ARTEMIS_GAS, a->pcm)) return rc;
+  if (int rc = validate_fluid(p, ARTEMIS_DUST, a->pcm)) return rc;
+  if (p->gas.nspecies && (!a->gas_in || !a->gas_u1 || !a->gas_out))
+    return fail(ARTEMIS_HIP_EINVAL, "general stage: gas_in / gas_u1 / gas_out are required");
+  if (p->dust.nspecies && (!a->dust_in || !a->dust_u1 || !a->dust_out))
+    return fail(ARTEMIS_HIP_EINVAL, "general stage: dust_in / dust_u1 / dust_out are required");
+  if ((p->gas.nspecies && a->gas_in == a->gas_out) || (p->dust.nspecies && a->dust_in == a->dust_out))
+    return fail(ARTEMIS_HIP_EINVAL, "general stage: *_out must not alias *_in");
+  if (a->gravity) { // same guards as artemis_hip_external_gravity
+    const artemis_gravity_t *g = a->gravity;
+    if (g->type != ARTEMIS_GRAVITY_UNIFORM && g->type != ARTEMIS_GRAVITY_POINT)
+      return fail(ARTEMIS_HIP_EUNSUPPORTED, "gravity type %d (binary / nbody) is not built", g->type);
+    if (g->type == ARTEMIS_GRAVITY_POINT &&
+        (p->coords == ARTEMIS_CYLINDRICAL || p->coords == ARTEMIS_SPHERICAL3D))
+      return fail(ARTEMIS_HIP_EUNSUPPORTED,
+                  "point-mass gravity in cylindrical / spherical3D coordinates is not built");
+  }
+  if (a->rf_omega != 0.0 && p->coords != ARTEMIS_CARTESIAN)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "rotating frame in curvilinear coordinates is not built");
+  if (a->drag) {
+    if (a->drag->type == ARTEMIS_DRAG_SIMPLE_DUST && (p->gas.nspecies < 1 || p->dust.nspecies < 1))
+      return fail(ARTEMIS_HIP_EINVAL, "drag type simple_dust requires do_gas = do_dust = true");
+    if (p->dust.nspecies > ARTEMIS_MAX_DUST_SPECIES)
+      return fail(ARTEMIS_HIP_EUNSUPPORTED, "drag: more than %d dust species", ARTEMIS_MAX_DUST_SPECIES);
+    if ((p->gas.nspecies && !p->gas.cons0) || (p->dust.nspecies && !p->dust.cons0))
+      return fail(ARTEMIS_HIP_EINVAL, "general stage with drag: cons0 tables are required as scratch");
+  }
+  artemis::launch_stage_cell(artemis::make_pack_view(*p), *a, p->gas.recon, p->gas.riemann,
+                             p->dust.recon, p->dust.riemann, S(stream));
+  return after_launch("stage_general");
+}
+
 int artemis_hip_advance_dt(double *state, double tlim, int nstages, const double *beta, void *stream) {
   if (int rc = device_ready()) return rc;
   if (!state || !beta || nstages < 1 || nstages > 3) return fail(ARTEMIS_HIP_EINVAL, "bad advance_dt arguments");

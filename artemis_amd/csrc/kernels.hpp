@@ -26,4 +26,7 @@ void launch_advance_dt(double *state, double tlim, int nstages, const double *be
 void launch_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, hipStream_t s);
 int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon,
                        hipStream_t s);
+// kernels_stage_cell.hip
+void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
+                       int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s);
 } // namespace artemis

@@ -8,6 +8,7 @@
 #include "geometry.hpp"
 #include "kernels.hpp"
 #include "pack_view.hpp"
+#include "sources_device.hpp"
 
 namespace artemis {
 namespace {
@@ -26,10 +27,6 @@ inline dim3 interior_grid(const PackView &P) {
   return dim3((P.ie - P.is + TX) / TX, (P.je - P.js + TY) / TY, (P.ke - P.ks + 1) * P.nb);
 }
 
-// Volume-averaged scale factors of any system (GetScaleFactors, geometry.hpp:384-388)
-__device__ __forceinline__ void scale_factors(const DCoords &co, double hx[3]) {
-  hx[0] = 1.0, hx[1] = co.hx2v(), hx[2] = co.hx3v();
-}
 
 // Coords<GEOM>::ConvertToCylWithVec (geometry.hpp:476-482): cylindrical radius of the cell
 // centroid and the first component of each basis vector (geometry.hpp:289-306,
@@ -55,102 +52,62 @@ __device__ __forceinline__ CylVec to_cyl_with_vec(const DCoords &co, const doubl
 // ---------------------------------------------------------------------------------------
 // Gravity::ExternalGravity (gravity.cpp:126-155): UniformGravity (uniform.cpp:28-84) and
 // PointMassGravity (point_mass.cpp:27-198; Cartesian, spherical1D/2D, axisymmetric).
+ADEV FluidPrim load_prim(const FluidView &f, int nv, int b, int n, long c, bool gas) {
+  FluidPrim w;
+  const int ns = f.ns;
+  w.rho = f.prim[b * nv + n][c];
+  w.v1 = f.prim[b * nv + ns + 3 * n + 0][c];
+  w.v2 = f.prim[b * nv + ns + 3 * n + 1][c];
+  w.v3 = f.prim[b * nv + ns + 3 * n + 2][c];
+  w.sie = gas ? f.prim[b * nv + 5 * ns + n][c] : 0.0;
+  return w;
+}
+ADEV GasCons load_gas_cons(const FluidView &f, int b, int n, long c) {
+  const int ns = f.ns, nv = 6 * ns;
+  GasCons u;
+  u.d = f.cons0[b * nv + n][c];
+  u.m1 = f.cons0[b * nv + ns + 3 * n + 0][c], u.m2 = f.cons0[b * nv + ns + 3 * n + 1][c];
+  u.m3 = f.cons0[b * nv + ns + 3 * n + 2][c];
+  u.e = f.cons0[b * nv + 4 * ns + n][c], u.eg = f.cons0[b * nv + 5 * ns + n][c];
+  return u;
+}
+ADEV void store_gas_cons(const FluidView &f, int b, int n, long c, const GasCons &u, bool with_d) {
+  const int ns = f.ns, nv = 6 * ns;
+  if (with_d) f.cons0[b * nv + n][c] = u.d;
+  f.cons0[b * nv + ns + 3 * n + 0][c] = u.m1, f.cons0[b * nv + ns + 3 * n + 1][c] = u.m2;
+  f.cons0[b * nv + ns + 3 * n + 2][c] = u.m3, f.cons0[b * nv + 4 * ns + n][c] = u.e;
+}
+ADEV DustCons load_dust_cons(const FluidView &f, int b, int n, long c) {
+  const int ns = f.ns, nv = 4 * ns;
+  DustCons u;
+  u.d = f.cons0[b * nv + n][c];
+  u.m1 = f.cons0[b * nv + ns + 3 * n + 0][c], u.m2 = f.cons0[b * nv + ns + 3 * n + 1][c];
+  u.m3 = f.cons0[b * nv + ns + 3 * n + 2][c];
+  return u;
+}
+ADEV void store_dust_cons(const FluidView &f, int b, int n, long c, const DustCons &u, bool with_d) {
+  const int ns = f.ns, nv = 4 * ns;
+  if (with_d) f.cons0[b * nv + n][c] = u.d;
+  f.cons0[b * nv + ns + 3 * n + 0][c] = u.m1, f.cons0[b * nv + ns + 3 * n + 1][c] = u.m2;
+  f.cons0[b * nv + ns + 3 * n + 2][c] = u.m3;
+}
+
 __global__ __launch_bounds__(TX *TY) void gravity_kernel(const PackView P, const artemis_gravity_t G,
                                                          double dt) {
   INTERIOR_CELL
   const DCoords co = make_coords(P, b, k, j, i);
-  const double dx[3] = {co.x1v(), co.x2v(), co.x3v()};
   double hx[3];
-  scale_factors(co, hx);
-  const bool multi_d = P.ndim >= 2, three_d = P.ndim == 3;
-  double gx1 = 0.0, gx2 = 0.0, gx3 = 0.0, fd = 0.0;
-  const bool uniform = (G.type == ARTEMIS_GRAVITY_UNIFORM);
-  if (uniform) {
-    gx1 = G.g[0], gx2 = G.g[1], gx3 = G.g[2];
-  } else {
-    const double gm = G.gm, rsft2 = sqr(G.soft);
-    double dr;
-    if (co.sys == ARTEMIS_SPHERICAL1D || co.sys == ARTEMIS_SPHERICAL2D) { // :78-81
-      const double rad2 = sqr(dx[0]) + rsft2;
-      gx1 = -gm / rad2;
-      dr = sqrt(rad2);
-    } else if (co.sys == ARTEMIS_AXISYMMETRIC) { // :82-89
-      const double rsph = sqrt(dx[0] * dx[0] + dx[1] * dx[1]);
-      const double ct = dx[1] / (rsph + 1e-99);
-      const double st = dx[0] / (rsph + 1e-99);
-      dr = rsph;
-      const double rad2 = sqr(dr) + rsft2;
-      const double g = -gm / rad2;
-      gx1 = g * st;
-      gx2 = g * ct;
-    } else { // Cartesian (:91-112)
-      double dxc[3] = {dx[0], dx[1], dx[2]};
-      for (int n = 0; n < 3; n++) dxc[n] -= G.pos[n];
-      const double R = sqrt(dxc[0] * dxc[0] + dxc[1] * dxc[1]);
-      const double r = sqrt(R * R + dxc[2] * dxc[2]);
-      dr = r;
-      const double rad2 = sqr(dr) + rsft2;
-      const double idr3 = 1.0 / (sqrt(rad2) * rad2);
-      const double g[3] = {-gm * dxc[0] * idr3, (multi_d) * (-gm * dxc[1] * idr3),
-                           (three_d) * (-gm * dxc[2] * idr3)};
-      gx1 = g[0] * 1.0 + g[1] * 0.0 + g[2] * 0.0;
-      gx2 = g[0] * 0.0 + g[1] * 1.0 + g[2] * 0.0;
-      gx3 = g[0] * 0.0 + g[1] * 0.0 + g[2] * 1.0;
-    }
-    const double sink_rate = dt * G.sink_rate;
-    const double sramp = sink_rate * sqr((dr - G.sink) / G.sink); // quad_ramp, gravity.hpp:116
-    const double sfrac = sramp / (1.0 + sramp);
-    fd = (sfrac < 0.5) ? sfrac : 0.5; // std::min(0.5, sfrac): a NaN ratio (sink = 0) keeps 0.5
-    fd *= ((sink_rate > 0.0) && (dr <= G.sink));
+  scale_factors_of(co, hx);
+  const GravAcc a = gravity_accel(G, co, P.ndim, dt);
+  for (int n = 0; n < P.gas.ns; ++n) {
+    GasCons u = load_gas_cons(P.gas, b, n, c);
+    gravity_gas(a, dt, hx, load_prim(P.gas, 6 * P.gas.ns, b, n, c, true), u);
+    store_gas_cons(P.gas, b, n, c, u, !a.uniform);
   }
-  {
-    const FluidView &f = P.gas;
-    const int ns = f.ns, nv = 6 * ns;
-    for (int n = 0; n < ns; ++n) {
-      const double rho = f.prim[b * nv + n][c];
-      const double v1 = f.prim[b * nv + ns + 3 * n + 0][c];
-      const double v2 = f.prim[b * nv + ns + 3 * n + 1][c];
-      const double v3 = f.prim[b * nv + ns + 3 * n + 2][c];
-      double m1 = f.cons0[b * nv + ns + 3 * n + 0][c], m2 = f.cons0[b * nv + ns + 3 * n + 1][c];
-      double m3 = f.cons0[b * nv + ns + 3 * n + 2][c], en = f.cons0[b * nv + 4 * ns + n][c];
-      if (uniform) {
-        const double rdt = dt * rho;
-        m1 += rdt * hx[0] * gx1, m2 += rdt * hx[1] * gx2, m3 += rdt * hx[2] * gx3;
-        en += rdt * (v1 * gx1 + v2 * gx2 + v3 * gx3);
-      } else {
-        const double sie = f.prim[b * nv + 5 * ns + n][c];
-        const double tote = rho * (sie + 0.5 * (sqr(v1) + sqr(v2) + sqr(v3)));
-        m1 += dt * rho * hx[0] * gx1, m2 += dt * rho * hx[1] * gx2, m3 += dt * rho * hx[2] * gx3;
-        en += dt * rho * (v1 * gx1 + v2 * gx2 + v3 * gx3);
-        f.cons0[b * nv + n][c] -= fd * rho;
-        m1 -= fd * hx[0] * rho * v1, m2 -= fd * hx[1] * rho * v2, m3 -= fd * hx[2] * rho * v3;
-        en -= fd * tote;
-      }
-      f.cons0[b * nv + ns + 3 * n + 0][c] = m1, f.cons0[b * nv + ns + 3 * n + 1][c] = m2;
-      f.cons0[b * nv + ns + 3 * n + 2][c] = m3, f.cons0[b * nv + 4 * ns + n][c] = en;
-    }
-  }
-  {
-    const FluidView &f = P.dust;
-    const int ns = f.ns, nv = 4 * ns;
-    for (int n = 0; n < ns; ++n) {
-      const double rho = f.prim[b * nv + n][c];
-      double m1 = f.cons0[b * nv + ns + 3 * n + 0][c], m2 = f.cons0[b * nv + ns + 3 * n + 1][c];
-      double m3 = f.cons0[b * nv + ns + 3 * n + 2][c];
-      if (uniform) {
-        const double rdt = dt * rho;
-        m1 += rdt * hx[0] * gx1, m2 += rdt * hx[1] * gx2, m3 += rdt * hx[2] * gx3;
-      } else {
-        const double v1 = f.prim[b * nv + ns + 3 * n + 0][c];
-        const double v2 = f.prim[b * nv + ns + 3 * n + 1][c];
-        const double v3 = f.prim[b * nv + ns + 3 * n + 2][c];
-        m1 += dt * rho * hx[0] * gx1, m2 += dt * rho * hx[1] * gx2, m3 += dt * rho * hx[2] * gx3;
-        f.cons0[b * nv + n][c] -= fd * rho;
-        m1 -= fd * hx[0] * rho * v1, m2 -= fd * hx[1] * rho * v2, m3 -= fd * hx[2] * rho * v3;
-      }
-      f.cons0[b * nv + ns + 3 * n + 0][c] = m1, f.cons0[b * nv + ns + 3 * n + 1][c] = m2;
-      f.cons0[b * nv + ns + 3 * n + 2][c] = m3;
-    }
+  for (int n = 0; n < P.dust.ns; ++n) {
+    DustCons u = load_dust_cons(P.dust, b, n, c);
+    gravity_dust(a, dt, hx, load_prim(P.dust, 4 * P.dust.ns, b, n, c, false), u);
+    store_dust_cons(P.dust, b, n, c, u, !a.uniform);
   }
 }
 
@@ -159,46 +116,16 @@ __global__ __launch_bounds__(TX *TY) void gravity_kernel(const PackView P, const
 __global__ __launch_bounds__(TX *TY) void shearing_box_kernel(const PackView P, double om0,
                                                               double qshear, double dt) {
   INTERIOR_CELL
-  const double *g = P.geom + 6 * b;
-  const double x1a = g[0] + i * g[1], x1b = g[0] + (i + 1) * g[1];
-  const double x3a = g[4] + k * g[5], x3b = g[4] + (k + 1) * g[5];
-  const int three_d = (P.ndim == 3);
-  const double omsq = sqr(om0);
-  const double dx = x1b - x1a;
-  const double dz = x3b - x3a;
-  const double phi_xm1 = -qshear * omsq * x1a * x1a;
-  const double phi_xp1 = -qshear * omsq * x1b * x1b;
-  const double phi_zm1 = 0.5 * omsq * x3a * x3a;
-  const double phi_zp1 = 0.5 * omsq * x3b * x3b;
-  const double dpx = (phi_xp1 - phi_xm1) / dx;
-  const double dpz = three_d * ((phi_zp1 - phi_zm1) / dz);
-  {
-    const FluidView &f = P.gas;
-    const int ns = f.ns, nv = 6 * ns;
-    for (int n = 0; n < ns; ++n) {
-      const double dens = f.prim[b * nv + n][c];
-      const double v1 = f.prim[b * nv + ns + 3 * n + 0][c];
-      const double v2 = f.prim[b * nv + ns + 3 * n + 1][c];
-      const double v3 = f.prim[b * nv + ns + 3 * n + 2][c];
-      const double rdt = dens * dt;
-      f.cons0[b * nv + ns + 3 * n + 0][c] -= rdt * (dpx - 2.0 * om0 * v2);
-      f.cons0[b * nv + ns + 3 * n + 1][c] -= rdt * 2.0 * om0 * v1;
-      f.cons0[b * nv + ns + 3 * n + 2][c] -= rdt * dpz;
-      f.cons0[b * nv + 4 * ns + n][c] -= rdt * (v1 * dpx + v3 * dpz);
-    }
+  const ShearAcc sa = shear_terms(P.geom + 6 * b, P.ndim, k, i, om0, qshear);
+  for (int n = 0; n < P.gas.ns; ++n) {
+    GasCons u = load_gas_cons(P.gas, b, n, c);
+    shear_gas(sa, dt, load_prim(P.gas, 6 * P.gas.ns, b, n, c, true), u);
+    store_gas_cons(P.gas, b, n, c, u, false);
   }
-  {
-    const FluidView &f = P.dust;
-    const int ns = f.ns, nv = 4 * ns;
-    for (int n = 0; n < ns; ++n) {
-      const double dens = f.prim[b * nv + n][c];
-      const double v1 = f.prim[b * nv + ns + 3 * n + 0][c];
-      const double v2 = f.prim[b * nv + ns + 3 * n + 1][c];
-      const double rdt = dens * dt;
-      f.cons0[b * nv + ns + 3 * n + 0][c] -= rdt * (dpx - 2.0 * om0 * v2);
-      f.cons0[b * nv + ns + 3 * n + 1][c] -= rdt * 2.0 * om0 * v1;
-      f.cons0[b * nv + ns + 3 * n + 2][c] -= rdt * dpz;
-    }
+  for (int n = 0; n < P.dust.ns; ++n) {
+    DustCons u = load_dust_cons(P.dust, b, n, c);
+    shear_dust(sa, dt, load_prim(P.dust, 4 * P.dust.ns, b, n, c, false), u);
+    store_dust_cons(P.dust, b, n, c, u, false);
   }
 }
 
@@ -225,7 +152,7 @@ __global__ __launch_bounds__(TX *TY) void self_drag_kernel(const PackView P, con
   const DCoords co = make_coords(P, b, k, j, i);
   const double xv[3] = {co.x1v(), co.x2v(), co.x3v()};
   double hx[3];
-  scale_factors(co, hx);
+  scale_factors_of(co, hx);
   const CylVec cv = to_cyl_with_vec(co, xv);
   double bg[3], bd[3];
   damping_ramps(D.gas, D, P.ndim, xv, dt, bg);
@@ -272,7 +199,7 @@ __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, c
   const DCoords co = make_coords(P, b, k, j, i);
   const double xv[3] = {co.x1v(), co.x2v(), co.x3v()};
   double hx[3];
-  scale_factors(co, hx);
+  scale_factors_of(co, hx);
   const CylVec cv = to_cyl_with_vec(co, xv);
   double bg[3], bd[3];
   damping_ramps(D.gas, D, P.ndim, xv, dt, bg);

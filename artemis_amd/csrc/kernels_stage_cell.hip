@@ -1,0 +1,333 @@
+// Cell-centred fused stage: the general one-kernel-per-fluid form of the reference's stage
+// (artemis_driver.cpp:182-255) for everything the tuned gas kernel (kernels_fused.hip) does not
+// cover -- dust, several species, PPM, curvilinear coordinates, gravity / rotating-frame / drag.
+//
+// One thread owns one cell.  For each species it computes the 2*ndim face fluxes of its own cell
+// straight from the input primitives (each face is therefore solved by both cells that share
+// it: twice the Riemann work of the per-task flux kernel, in exchange for no flux, pressure-flux
+// or face-velocity arrays in HBM, no LDS and no barrier), rebuilds u0 = PrimToCons(prim_in) and
+// u1 = PrimToCons(prim_u1) in registers (PrimToCons runs over the whole block at the end of every
+// stage, fill_derived.cpp:212-276, so this is an identity), applies ApplyUpdate, FluxSource,
+// ExternalGravity and RotatingFrameForce, and -- unless drag couples the fluids -- SetAuxillaryFields
+// and ConsToPrim, writing the new primitives to a second buffer.  With drag the conserved state
+// goes to cons0 and the per-task DragSource / SetAuxillaryFields / ConsToPrim kernels finish.
+// HBM traffic per cell-stage and species: ~5 reads (stencil neighbours hit L2) + 5 for u1 +
+// 5 writes for gas (4+4+4 for dust) instead of the per-task chain's ~124 (gas) doubles.
+// Gas pressure of stencil cells is recomputed as max(0, gm1*rho*sie) (fill_derived.cpp:247), so
+// ghost zones only need the FillGhost variables.  Every expression tree is shared with the
+// per-task kernels (task_device.hpp, sources_device.hpp): results are bit-identical.
+#include "device_math.hpp"
+#include "geometry.hpp"
+#include "kernels.hpp"
+#include "pack_view.hpp"
+#include "sources_device.hpp"
+#include "task_device.hpp"
+
+namespace artemis {
+namespace {
+constexpr int TX = 64, TY = 4;
+
+struct CellStageArgs {
+  double gam0, gam1, beta_dt, bdt;
+  double *const *in, *const *u1, *const *out; // prim tables of this fluid
+  int to_cons;                                // 1: store the post-source conserved state in cons0
+  int grav_on, rf_on;
+  artemis_gravity_t grav;
+  double rf_omega, rf_qshear;
+};
+
+// Stencil of one variable around cell c along a stride: w[3] = cell c, w[3+m] = cell c + m*st.
+template <int RECON>
+ADEV void load_stencil(const double *q, long c, long st, double w[7]) {
+  constexpr int R = (RECON == 2) ? 3 : ((RECON == 1) ? 2 : 1);
+#pragma unroll
+  for (int m = -R; m <= R; ++m) w[3 + m] = q[c + m * st];
+}
+
+// Lower (side 0) or upper (side 1) face of cell (k,j,i) along dir for species n: the body of the
+// per-task flux kernel (fluid_fluxes.hpp:105-126 per direction) evaluated from register stencils.
+template <int FLUID, int RIEMANN, int RECON, bool CURV>
+ADEV FaceFlux face_of_cell(const PackView &P, const FluidView &f, double *const *prim, int b, int n,
+                           int dir, int side, int k, int j, int i, const double wd[7],
+                           const double w1[7], const double w2[7], const double w3[7],
+                           const double wp[7], const double we[7]) {
+  // face index along dir: the cell that stores this face (its lower face)
+  const int fk = k + ((dir == 3) ? side : 0), fj = j + ((dir == 2) ? side : 0),
+            fi = i + ((dir == 1) ? side : 0);
+  PlmGeo gl{}, gr{};
+  double hs[3] = {1.0, 1.0, 1.0};
+  if constexpr (CURV) {
+    if constexpr (RECON == 1) {
+      gl = plm_geo(P, b, dir, fk - (dir == 3), fj - (dir == 2), fi - (dir == 1));
+      gr = plm_geo(P, b, dir, fk, fj, fi);
+    }
+    make_coords(P, b, fk, fj, fi).face_scale(dir, hs);
+  }
+  const int d = dir - 1;
+  const int o = 3 + side; // stencil slot of the cell above the face
+  const double *vx = (d == 0) ? w1 : ((d == 1) ? w2 : w3);
+  const double *vy = (d == 0) ? w2 : ((d == 1) ? w3 : w1);
+  const double *vz = (d == 0) ? w3 : ((d == 1) ? w1 : w2);
+  FaceFlux F;
+  if constexpr (FLUID == 0) {
+    Prim6 L, R;
+    face_states<RECON, CURV>(wd + o, 1, gl, gr, L.d, R.d);
+    face_states<RECON, CURV>(vx + o, 1, gl, gr, L.vx, R.vx);
+    face_states<RECON, CURV>(vy + o, 1, gl, gr, L.vy, R.vy);
+    face_states<RECON, CURV>(vz + o, 1, gl, gr, L.vz, R.vz);
+    face_states<RECON, CURV>(wp + o, 1, gl, gr, L.p, R.p);
+    face_states<RECON, CURV>(we + o, 1, gl, gr, L.e, R.e);
+    riemann_gas<RIEMANN>(P.gm1, L, R, F);
+  } else {
+    Prim4 L, R;
+    face_states<RECON, CURV>(wd + o, 1, gl, gr, L.d, R.d);
+    face_states<RECON, CURV>(vx + o, 1, gl, gr, L.vx, R.vx);
+    face_states<RECON, CURV>(vy + o, 1, gl, gr, L.vy, R.vy);
+    face_states<RECON, CURV>(vz + o, 1, gl, gr, L.vz, R.vz);
+    riemann_dust<RIEMANN>(L, R, F);
+  }
+  if constexpr (CURV) F.fmx *= hs[d], F.fmy *= hs[(d + 1) % 3], F.fmz *= hs[(d + 2) % 3];
+  (void)f, (void)prim, (void)n;
+  return F;
+}
+
+// PrimToCons of one cell (fill_derived.cpp:229-274): floors are re-applied like the reference does
+ADEV GasCons prim_to_cons_gas(const FluidView &f, double d, double v1, double v2, double v3,
+                              double se, const double hx[3]) {
+  GasCons u;
+  const double w_d = (d > f.dfloor) ? d : f.dfloor;
+  u.d = w_d;
+  u.m1 = w_d * v1 * hx[0], u.m2 = w_d * v2 * hx[1], u.m3 = w_d * v3 * hx[2];
+  const double w_s = (se > f.siefloor) ? se : f.siefloor;
+  u.eg = w_s * w_d;
+  const double ke = 0.5 * w_d * (sqr(v1) + sqr(v2) + sqr(v3));
+  u.e = u.eg + ke;
+  return u;
+}
+ADEV DustCons prim_to_cons_dust(const FluidView &f, double d, double v1, double v2, double v3,
+                                const double hx[3]) {
+  DustCons u;
+  const double w_d = (d > f.dfloor) ? d : f.dfloor;
+  u.d = w_d;
+  u.m1 = w_d * v1 * hx[0], u.m2 = w_d * v2 * hx[1], u.m3 = w_d * v3 * hx[2];
+  return u;
+}
+
+template <int FLUID, int RIEMANN, int RECON, bool CURV>
+__global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, const CellStageArgs a) {
+  const int i = P.is + blockIdx.x * TX + threadIdx.x;
+  const int j = P.js + blockIdx.y * TY + threadIdx.y;
+  const int nkr = P.ke - P.ks + 1;
+  const int b = blockIdx.z / nkr;
+  const int k = P.ks + blockIdx.z % nkr;
+  if (i > P.ie || j > P.je) return;
+  const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
+  const FluidView &f = (FLUID == 0) ? P.gas : P.dust;
+  const int ns = f.ns, nv = (FLUID == 0 ? 6 : 4) * ns;
+  const bool multi_d = P.ndim >= 2, three_d = P.ndim == 3;
+  const CellMetric g = cell_metric<CURV>(P, b, k, j, i);
+  double hx[3];
+  scale_factors<CURV>(P, b, k, j, i, hx);
+  DCoords co;
+  if constexpr (CURV) co = make_coords(P, b, k, j, i);
+  GravAcc ga{};
+  if (a.grav_on) {
+    const DCoords cg = make_coords(P, b, k, j, i);
+    ga = gravity_accel(a.grav, cg, P.ndim, a.bdt);
+  }
+  ShearAcc sa{};
+  if (a.rf_on) sa = shear_terms(P.geom + 6 * b, P.ndim, k, i, a.rf_omega, a.rf_qshear);
+
+  for (int n = 0; n < ns; ++n) {
+    const double *qd = a.in[b * nv + n], *q1 = a.in[b * nv + ns + 3 * n + 0];
+    const double *q2 = a.in[b * nv + ns + 3 * n + 1], *q3 = a.in[b * nv + ns + 3 * n + 2];
+    const double *qe = (FLUID == 0) ? a.in[b * nv + 5 * ns + n] : nullptr;
+    // ---- fluxes of the 2*ndim faces; divergence accumulated in ApplyUpdate's order -----------
+    double divf[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // d, m1, m2, m3, e, eg
+    double plo[3] = {0, 0, 0}, pup[3] = {0, 0, 0}, vlo[3] = {0, 0, 0}, vup[3] = {0, 0, 0};
+    FluidPrim w; // this cell's stage-input primitives
+    w.rho = qd[c], w.v1 = q1[c], w.v2 = q2[c], w.v3 = q3[c], w.sie = (FLUID == 0) ? qe[c] : 0.0;
+    for (int dir = 1; dir <= P.ndim; ++dir) {
+      const long st = (dir == 1) ? 1 : ((dir == 2) ? P.sj : P.sk);
+      double wd[7], w1[7], w2[7], w3[7], wp[7], we[7];
+      load_stencil<RECON>(qd, c, st, wd), load_stencil<RECON>(q1, c, st, w1);
+      load_stencil<RECON>(q2, c, st, w2), load_stencil<RECON>(q3, c, st, w3);
+      if constexpr (FLUID == 0) {
+        load_stencil<RECON>(qe, c, st, we);
+        constexpr int R = (RECON == 2) ? 3 : ((RECON == 1) ? 2 : 1);
+#pragma unroll
+        for (int m = -R; m <= R; ++m) wp[3 + m] = amax(0.0, P.gm1 * wd[3 + m] * we[3 + m]);
+      }
+      const FaceFlux lo = face_of_cell<FLUID, RIEMANN, RECON, CURV>(P, f, a.in, b, n, dir, 0, k, j, i,
+                                                                    wd, w1, w2, w3, wp, we);
+      const FaceFlux up = face_of_cell<FLUID, RIEMANN, RECON, CURV>(P, f, a.in, b, n, dir, 1, k, j, i,
+                                                                    wd, w1, w2, w3, wp, we);
+      const double *ax = (dir == 1) ? g.ax1 : ((dir == 2) ? g.ax2 : g.ax3);
+      const int d = dir - 1;
+      // momentum components in global order: component (d+q)%3 carries the sweep's q-th flux
+      double lom[3], upm[3];
+      lom[d] = lo.fmx, lom[(d + 1) % 3] = lo.fmy, lom[(d + 2) % 3] = lo.fmz;
+      upm[d] = up.fmx, upm[(d + 1) % 3] = up.fmy, upm[(d + 2) % 3] = up.fmz;
+      if (dir == 1) {
+        divf[0] = (ax[0] * lo.fd - ax[1] * up.fd);
+        divf[1] = (ax[0] * lom[0] - ax[1] * upm[0]);
+        divf[2] = (ax[0] * lom[1] - ax[1] * upm[1]);
+        divf[3] = (ax[0] * lom[2] - ax[1] * upm[2]);
+        if constexpr (FLUID == 0) {
+          divf[4] = (ax[0] * lo.fe - ax[1] * up.fe);
+          divf[5] = (ax[0] * lo.feg - ax[1] * up.feg);
+        }
+      } else {
+        divf[0] += (ax[0] * lo.fd - ax[1] * up.fd);
+        divf[1] += (ax[0] * lom[0] - ax[1] * upm[0]);
+        divf[2] += (ax[0] * lom[1] - ax[1] * upm[1]);
+        divf[3] += (ax[0] * lom[2] - ax[1] * upm[2]);
+        if constexpr (FLUID == 0) {
+          divf[4] += (ax[0] * lo.fe - ax[1] * up.fe);
+          divf[5] += (ax[0] * lo.feg - ax[1] * up.feg);
+        }
+      }
+      if constexpr (FLUID == 0) plo[d] = lo.pf, pup[d] = up.pf, vlo[d] = lo.vf, vup[d] = up.vf;
+    }
+    // ---- ApplyUpdate (artemis_integrator.hpp:104-106) on u0 = PrimToCons(in), u1 = PrimToCons(u1)
+    const double *rd = a.u1[b * nv + n], *r1 = a.u1[b * nv + ns + 3 * n + 0];
+    const double *r2 = a.u1[b * nv + ns + 3 * n + 1], *r3 = a.u1[b * nv + ns + 3 * n + 2];
+    if constexpr (FLUID == 0) {
+      const double *re = a.u1[b * nv + 5 * ns + n];
+      GasCons u0 = prim_to_cons_gas(f, w.rho, w.v1, w.v2, w.v3, w.sie, hx);
+      const GasCons u1 = prim_to_cons_gas(f, rd[c], r1[c], r2[c], r3[c], re[c], hx);
+      u0.d = a.gam0 * u0.d + a.gam1 * u1.d + divf[0] * a.beta_dt / g.vol;
+      u0.m1 = a.gam0 * u0.m1 + a.gam1 * u1.m1 + divf[1] * a.beta_dt / g.vol;
+      u0.m2 = a.gam0 * u0.m2 + a.gam1 * u1.m2 + divf[2] * a.beta_dt / g.vol;
+      u0.m3 = a.gam0 * u0.m3 + a.gam1 * u1.m3 + divf[3] * a.beta_dt / g.vol;
+      u0.e = a.gam0 * u0.e + a.gam1 * u1.e + divf[4] * a.beta_dt / g.vol;
+      u0.eg = a.gam0 * u0.eg + a.gam1 * u1.eg + divf[5] * a.beta_dt / g.vol;
+      // ---- FluxSource (fluid_fluxes.hpp:361-415)
+      const double dt = a.bdt;
+      u0.m1 += dt / g.dx[0] * (plo[0] - pup[0]);
+      u0.eg -= dt / g.vol * 0.5 * (plo[0] + pup[0]) * (g.ax1[1] * vup[0] - g.ax1[0] * vlo[0]);
+      if (multi_d) {
+        u0.m2 += dt / g.dx[1] * (plo[1] - pup[1]);
+        u0.eg -= dt / g.vol * 0.5 * (plo[1] + pup[1]) * (g.ax2[1] * vup[1] - g.ax2[0] * vlo[1]);
+      }
+      if (three_d) {
+        u0.m3 += dt / g.dx[2] * (plo[2] - pup[2]);
+        u0.eg -= dt / g.vol * 0.5 * (plo[2] + pup[2]) * (g.ax3[1] * vup[2] - g.ax3[0] * vlo[2]);
+      }
+      if constexpr (CURV) {
+        const double rdt = w.rho * dt;
+        if (co.x1dep())
+          u0.m1 += rdt * (0.0 * sqr(w.v1) + co.dh2dx1() * sqr(w.v2) + co.dh3dx1() * sqr(w.v3));
+        if (co.x2dep() && multi_d)
+          u0.m2 += rdt * (0.0 * sqr(w.v1) + 0.0 * sqr(w.v2) + co.dh3dx2() * sqr(w.v3));
+      }
+      if (a.grav_on) gravity_gas(ga, dt, hx, w, u0);
+      if (a.rf_on) shear_gas(sa, dt, w, u0);
+      if (a.to_cons) {
+        f.cons0[b * nv + n][c] = u0.d;
+        f.cons0[b * nv + ns + 3 * n + 0][c] = u0.m1, f.cons0[b * nv + ns + 3 * n + 1][c] = u0.m2;
+        f.cons0[b * nv + ns + 3 * n + 2][c] = u0.m3;
+        f.cons0[b * nv + 4 * ns + n][c] = u0.e, f.cons0[b * nv + 5 * ns + n][c] = u0.eg;
+        continue;
+      }
+      // ---- SetAuxillaryFields (fill_derived.cpp:58-71) + ConsToPrim (:132-146)
+      const double u_d = (u0.d > f.dfloor) ? u0.d : f.dfloor;
+      const double u_d2 = amax(u0.d, f.dfloor);
+      const double rv1 = u0.m1 / hx[0], rv2 = u0.m2 / hx[1], rv3 = u0.m3 / hx[2];
+      const double ke = 0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)) / u_d2;
+      const double ue_cons = u0.e - ke;
+      double sie = (ue_cons > f.de_switch * u0.e) ? ue_cons / u_d2 : u0.eg / u_d2;
+      sie = amax(sie, f.siefloor);
+      double u_u = sie * u_d;
+      const double uflr = f.siefloor * u_d;
+      u_u = (u_u > uflr) ? u_u : uflr;
+      const double w_d = (u0.d > f.dfloor) ? u0.d : f.dfloor;
+      a.out[b * nv + n][c] = w_d;
+      a.out[b * nv + ns + 3 * n + 0][c] = u0.m1 / (w_d * hx[0]);
+      a.out[b * nv + ns + 3 * n + 1][c] = u0.m2 / (w_d * hx[1]);
+      a.out[b * nv + ns + 3 * n + 2][c] = u0.m3 / (w_d * hx[2]);
+      const double w_s = u_u / w_d;
+      a.out[b * nv + 5 * ns + n][c] = (w_s > f.siefloor) ? w_s : f.siefloor;
+    } else {
+      DustCons u0 = prim_to_cons_dust(f, w.rho, w.v1, w.v2, w.v3, hx);
+      const DustCons u1 = prim_to_cons_dust(f, rd[c], r1[c], r2[c], r3[c], hx);
+      u0.d = a.gam0 * u0.d + a.gam1 * u1.d + divf[0] * a.beta_dt / g.vol;
+      u0.m1 = a.gam0 * u0.m1 + a.gam1 * u1.m1 + divf[1] * a.beta_dt / g.vol;
+      u0.m2 = a.gam0 * u0.m2 + a.gam1 * u1.m2 + divf[2] * a.beta_dt / g.vol;
+      u0.m3 = a.gam0 * u0.m3 + a.gam1 * u1.m3 + divf[3] * a.beta_dt / g.vol;
+      const double dt = a.bdt;
+      if constexpr (CURV) { // Dust::FluxSource (dust.cpp:303-326): coordinate source only
+        const double rdt = w.rho * dt;
+        if (co.x1dep())
+          u0.m1 += rdt * (0.0 * sqr(w.v1) + co.dh2dx1() * sqr(w.v2) + co.dh3dx1() * sqr(w.v3));
+        if (co.x2dep() && multi_d)
+          u0.m2 += rdt * (0.0 * sqr(w.v1) + 0.0 * sqr(w.v2) + co.dh3dx2() * sqr(w.v3));
+      }
+      if (a.grav_on) gravity_dust(ga, dt, hx, w, u0);
+      if (a.rf_on) shear_dust(sa, dt, w, u0);
+      if (a.to_cons) {
+        f.cons0[b * nv + n][c] = u0.d;
+        f.cons0[b * nv + ns + 3 * n + 0][c] = u0.m1, f.cons0[b * nv + ns + 3 * n + 1][c] = u0.m2;
+        f.cons0[b * nv + ns + 3 * n + 2][c] = u0.m3;
+        continue;
+      }
+      const double w_d = (u0.d > f.dfloor) ? u0.d : f.dfloor; // ConsToPrim (fill_derived.cpp:155-164)
+      a.out[b * nv + n][c] = w_d;
+      a.out[b * nv + ns + 3 * n + 0][c] = u0.m1 / (w_d * hx[0]);
+      a.out[b * nv + ns + 3 * n + 1][c] = u0.m2 / (w_d * hx[1]);
+      a.out[b * nv + ns + 3 * n + 2][c] = u0.m3 / (w_d * hx[2]);
+    }
+  }
+}
+
+template <int FLUID, int RIEMANN, int RECON>
+void launch_geom(const PackView &P, const CellStageArgs &a, hipStream_t s) {
+  const dim3 grid((P.ie - P.is + TX) / TX, (P.je - P.js + TY) / TY, (P.ke - P.ks + 1) * P.nb);
+  if (P.coords == ARTEMIS_CARTESIAN)
+    hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, false>), grid, dim3(TX, TY), 0, s, P, a);
+  else
+    hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, true>), grid, dim3(TX, TY), 0, s, P, a);
+}
+template <int FLUID, int RIEMANN>
+void launch_recon(const PackView &P, int recon, const CellStageArgs &a, hipStream_t s) {
+  if (recon == ARTEMIS_PCM) launch_geom<FLUID, RIEMANN, 0>(P, a, s);
+  else if (recon == ARTEMIS_PLM) launch_geom<FLUID, RIEMANN, 1>(P, a, s);
+  else launch_geom<FLUID, RIEMANN, 2>(P, a, s);
+}
+} // namespace
+
+void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
+                       int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s) {
+  CellStageArgs a;
+  a.gam0 = g.gam0, a.gam1 = g.gam1, a.beta_dt = g.beta_dt, a.bdt = g.bdt;
+  a.to_cons = g.drag ? 1 : 0;
+  a.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;
+  if (a.grav_on) a.grav = *g.gravity;
+  a.rf_on = (g.rf_omega != 0.0), a.rf_omega = g.rf_omega, a.rf_qshear = g.rf_qshear;
+  if (P.gas.ns) {
+    a.in = g.gas_in, a.u1 = g.gas_u1, a.out = g.gas_out;
+    const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;
+    if (riemann_gas == ARTEMIS_HLLC) launch_recon<0, 0>(P, recon, a, s);
+    else if (riemann_gas == ARTEMIS_HLLE) launch_recon<0, 1>(P, recon, a, s);
+    else launch_recon<0, 2>(P, recon, a, s);
+  }
+  if (P.dust.ns) {
+    a.in = g.dust_in, a.u1 = g.dust_u1, a.out = g.dust_out;
+    const int recon = g.pcm ? ARTEMIS_PCM : recon_dust;
+    if (riemann_dust == ARTEMIS_HLLE) launch_recon<1, 1>(P, recon, a, s);
+    else launch_recon<1, 2>(P, recon, a, s);
+  }
+  PackView Q = P; // the new state: prim tables are the out tables
+  Q.gas.prim = g.gas_out, Q.dust.prim = g.dust_out;
+  if (g.drag) { // coupled update on cons0, then SetAuxillaryFields and ConsToPrim into the out tables
+    launch_drag_source(Q, *g.drag, g.bdt, s);
+    if (Q.gas.ns) launch_set_aux(Q, s);
+    launch_cons_to_prim(Q, s);
+  }
+  if (g.dt_dev) { // EstimateTimestepMesh of the new state (gas.cpp:411-433, dust.cpp:256-272)
+    if (Q.gas.ns) launch_estimate_dt(Q, ARTEMIS_GAS, g.cfl_gas, g.dt_dev, s);
+    if (Q.dust.ns) launch_estimate_dt(Q, ARTEMIS_DUST, g.cfl_dust, g.dt_dev, s);
+  }
+}
+
+} // namespace artemis

@@ -10,6 +10,7 @@
 #include "device_math.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "task_device.hpp"
 #include "pack_view.hpp"
 
 namespace artemis {
@@ -38,20 +39,6 @@ inline dim3 grid_for(const Range3 &r, int nb) {
 // reconstructs the upper face value of the cell below the face and the lower face value of
 // the cell above it straight from global memory (neighbouring threads share those lines in
 // L1/L2), then solves the Riemann problem and writes the 8 (gas) / 4 (dust) face outputs.
-// Face states of one variable at the face below cell c: L from the cell below, R from cell c.
-// CURV && PLM uses PLM_G with the Mignone weights of each of the two cells (plm.hpp:90-103).
-template <int RECON, bool CURV>
-__device__ __forceinline__ void face_states(const double *q, long st, const PlmGeo &gl,
-                                            const PlmGeo &gr, double &L, double &R) {
-  double unused;
-  if constexpr (CURV && RECON == 1) {
-    plm_g(q[-2 * st], q[-st], q[0], L, unused, gl.xvm, gl.xvc, gl.xvp, gl.xf0, gl.xf1, gl.dx);
-    plm_g(q[-st], q[0], q[st], unused, R, gr.xvm, gr.xvc, gr.xvp, gr.xf0, gr.xf1, gr.dx);
-  } else {
-    recon_cell<RECON>(q - st, st, L, unused), recon_cell<RECON>(q, st, unused, R);
-  }
-}
-
 template <int FLUID, int RIEMANN, int RECON, bool CURV>
 __global__ __launch_bounds__(TX *TY) void flux_kernel(const PackView P, const Range3 r,
                                                       const int dir) {
@@ -147,31 +134,6 @@ void launch_flux_recon(const PackView &P, int recon, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------
 // ApplyUpdate (artemis_integrator.hpp:79-108)
-struct CellMetric {
-  double ax1[2], ax2[2], ax3[2], vol; // GetFaceAreaX?, Volume
-  double dx[3];                       // coordinate widths bnds.x?[1] - bnds.x?[0]
-};
-template <bool CURV>
-__device__ __forceinline__ CellMetric cell_metric(const PackView &P, int b, int k, int j, int i) {
-  CellMetric m;
-  if constexpr (CURV) {
-    const DCoords co = make_coords(P, b, k, j, i);
-    m.ax1[0] = co.area1(0), m.ax1[1] = co.area1(1);
-    m.ax2[0] = co.area2(0), m.ax2[1] = co.area2(1);
-    m.ax3[0] = co.area3(0), m.ax3[1] = co.area3(1);
-    m.vol = co.volume();
-    m.dx[0] = co.x1[1] - co.x1[0], m.dx[1] = co.x2[1] - co.x2[0], m.dx[2] = co.x3[1] - co.x3[0];
-  } else {
-    const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
-    m.ax1[0] = m.ax1[1] = g.dx2 * g.dx3; // geometry.hpp:199-204
-    m.ax2[0] = m.ax2[1] = g.dx1 * g.dx3; // :205-210
-    m.ax3[0] = m.ax3[1] = g.dx1 * g.dx2; // :211-216
-    m.vol = g.dx1 * g.dx2 * g.dx3;       // :219-225
-    m.dx[0] = g.dx1, m.dx[1] = g.dx2, m.dx[2] = g.dx3;
-  }
-  return m;
-}
-
 template <int FLUID>
 __device__ __forceinline__ void update_fluid(const PackView &P, const FluidView &f, int b, long c,
                                              const CellMetric &g, double gam0, double gam1,
@@ -264,15 +226,6 @@ __global__ __launch_bounds__(TX *TY) void flux_source_kernel(const PackView P, c
 // ---------------------------------------------------------------------------------------
 // SetAuxillaryFields (fill_derived.cpp:54-73) + GetSpecificInternalEnergy
 // (artemis_utils.hpp:43-62); Cartesian scale factors are 1.
-template <bool CURV>
-__device__ __forceinline__ void scale_factors(const PackView &P, int b, int k, int j, int i,
-                                              double hx[3]) {
-  hx[0] = 1.0, hx[1] = 1.0, hx[2] = 1.0; // GetScaleFactors (geometry.hpp:384-388)
-  if constexpr (CURV) {
-    const DCoords co = make_coords(P, b, k, j, i);
-    hx[1] = co.hx2v(), hx[2] = co.hx3v();
-  }
-}
 template <bool CURV>
 __global__ __launch_bounds__(TX *TY) void set_aux_kernel(const PackView P, const Range3 r) {
   CELL_FROM_GRID(r)

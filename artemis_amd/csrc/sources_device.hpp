@@ -1,0 +1,145 @@
+// Register-level forms of the pointwise source tasks, shared by the per-task kernels
+// (kernels_sources.hip) and the cell-centred fused stage (kernels_stage_cell.hip).
+#pragma once
+#include "device_math.hpp"
+#include "geometry.hpp"
+#include "pack_view.hpp"
+
+namespace artemis {
+
+struct GasCons {
+  double d, m1, m2, m3, e, eg;
+};
+struct DustCons {
+  double d, m1, m2, m3;
+};
+struct FluidPrim { // rho, velocity and (gas) specific internal energy of one species in one cell
+  double rho, v1, v2, v3, sie;
+};
+
+// Volume-averaged scale factors of any system (GetScaleFactors, geometry.hpp:384-388)
+ADEV void scale_factors_of(const DCoords &co, double hx[3]) {
+  hx[0] = 1.0, hx[1] = co.hx2v(), hx[2] = co.hx3v();
+}
+
+// ---- Gravity::ExternalGravity (gravity.cpp:126-155) ---------------------------------------
+// acceleration components along the coordinate basis and the sink fraction of one cell
+struct GravAcc {
+  double gx1, gx2, gx3, fd;
+  bool uniform;
+};
+ADEV GravAcc gravity_accel(const artemis_gravity_t &G, const DCoords &co, int ndim, double dt) {
+  GravAcc a;
+  a.gx1 = 0.0, a.gx2 = 0.0, a.gx3 = 0.0, a.fd = 0.0;
+  a.uniform = (G.type == ARTEMIS_GRAVITY_UNIFORM);
+  if (a.uniform) { // uniform.cpp:39-41
+    a.gx1 = G.g[0], a.gx2 = G.g[1], a.gx3 = G.g[2];
+    return a;
+  }
+  const double dx[3] = {co.x1v(), co.x2v(), co.x3v()};
+  const bool multi_d = ndim >= 2, three_d = ndim == 3;
+  const double gm = G.gm, rsft2 = sqr(G.soft);
+  double dr;
+  if (co.sys == ARTEMIS_SPHERICAL1D || co.sys == ARTEMIS_SPHERICAL2D) { // point_mass.cpp:78-81
+    const double rad2 = sqr(dx[0]) + rsft2;
+    a.gx1 = -gm / rad2;
+    dr = sqrt(rad2);
+  } else if (co.sys == ARTEMIS_AXISYMMETRIC) { // :82-89
+    const double rsph = sqrt(dx[0] * dx[0] + dx[1] * dx[1]);
+    const double ct = dx[1] / (rsph + 1e-99);
+    const double st = dx[0] / (rsph + 1e-99);
+    dr = rsph;
+    const double rad2 = sqr(dr) + rsft2;
+    const double g = -gm / rad2;
+    a.gx1 = g * st;
+    a.gx2 = g * ct;
+  } else { // Cartesian (:91-112)
+    double dxc[3] = {dx[0], dx[1], dx[2]};
+    for (int n = 0; n < 3; n++) dxc[n] -= G.pos[n];
+    const double R = sqrt(dxc[0] * dxc[0] + dxc[1] * dxc[1]);
+    const double r = sqrt(R * R + dxc[2] * dxc[2]);
+    dr = r;
+    const double rad2 = sqr(dr) + rsft2;
+    const double idr3 = 1.0 / (sqrt(rad2) * rad2);
+    const double g[3] = {-gm * dxc[0] * idr3, (multi_d) * (-gm * dxc[1] * idr3),
+                         (three_d) * (-gm * dxc[2] * idr3)};
+    a.gx1 = g[0] * 1.0 + g[1] * 0.0 + g[2] * 0.0;
+    a.gx2 = g[0] * 0.0 + g[1] * 1.0 + g[2] * 0.0;
+    a.gx3 = g[0] * 0.0 + g[1] * 0.0 + g[2] * 1.0;
+  }
+  const double sink_rate = dt * G.sink_rate;
+  const double sramp = sink_rate * sqr((dr - G.sink) / G.sink); // quad_ramp, gravity.hpp:116
+  const double sfrac = sramp / (1.0 + sramp);
+  a.fd = (sfrac < 0.5) ? sfrac : 0.5; // std::min(0.5, sfrac): a NaN ratio (sink = 0) keeps 0.5
+  a.fd *= ((sink_rate > 0.0) && (dr <= G.sink));
+  return a;
+}
+// uniform.cpp:58-68 / point_mass.cpp:137-156
+ADEV void gravity_gas(const GravAcc &a, double dt, const double hx[3], const FluidPrim &w,
+                      GasCons &u) {
+  if (a.uniform) {
+    const double rdt = dt * w.rho;
+    u.m1 += rdt * hx[0] * a.gx1, u.m2 += rdt * hx[1] * a.gx2, u.m3 += rdt * hx[2] * a.gx3;
+    u.e += rdt * (w.v1 * a.gx1 + w.v2 * a.gx2 + w.v3 * a.gx3);
+  } else {
+    const double tote = w.rho * (w.sie + 0.5 * (sqr(w.v1) + sqr(w.v2) + sqr(w.v3)));
+    u.m1 += dt * w.rho * hx[0] * a.gx1, u.m2 += dt * w.rho * hx[1] * a.gx2;
+    u.m3 += dt * w.rho * hx[2] * a.gx3;
+    u.e += dt * w.rho * (w.v1 * a.gx1 + w.v2 * a.gx2 + w.v3 * a.gx3);
+    u.d -= a.fd * w.rho;
+    u.m1 -= a.fd * hx[0] * w.rho * w.v1, u.m2 -= a.fd * hx[1] * w.rho * w.v2;
+    u.m3 -= a.fd * hx[2] * w.rho * w.v3;
+    u.e -= a.fd * tote;
+  }
+}
+// uniform.cpp:71-78 / point_mass.cpp:160-176
+ADEV void gravity_dust(const GravAcc &a, double dt, const double hx[3], const FluidPrim &w,
+                       DustCons &u) {
+  if (a.uniform) {
+    const double rdt = dt * w.rho;
+    u.m1 += rdt * hx[0] * a.gx1, u.m2 += rdt * hx[1] * a.gx2, u.m3 += rdt * hx[2] * a.gx3;
+  } else {
+    u.m1 += dt * w.rho * hx[0] * a.gx1, u.m2 += dt * w.rho * hx[1] * a.gx2;
+    u.m3 += dt * w.rho * hx[2] * a.gx3;
+    u.d -= a.fd * w.rho;
+    u.m1 -= a.fd * hx[0] * w.rho * w.v1, u.m2 -= a.fd * hx[1] * w.rho * w.v2;
+    u.m3 -= a.fd * hx[2] * w.rho * w.v3;
+  }
+}
+
+// ---- RotatingFrame::ShearingBoxImpl (rotating_frame_impl.hpp:28-93) -------------------------
+struct ShearAcc {
+  double dpx, dpz, om0;
+};
+ADEV ShearAcc shear_terms(const double *g, int ndim, int k, int i, double om0, double qshear) {
+  const double x1a = g[0] + i * g[1], x1b = g[0] + (i + 1) * g[1];
+  const double x3a = g[4] + k * g[5], x3b = g[4] + (k + 1) * g[5];
+  const int three_d = (ndim == 3);
+  const double omsq = sqr(om0);
+  const double dx = x1b - x1a;
+  const double dz = x3b - x3a;
+  const double phi_xm1 = -qshear * omsq * x1a * x1a;
+  const double phi_xp1 = -qshear * omsq * x1b * x1b;
+  const double phi_zm1 = 0.5 * omsq * x3a * x3a;
+  const double phi_zp1 = 0.5 * omsq * x3b * x3b;
+  ShearAcc s;
+  s.dpx = (phi_xp1 - phi_xm1) / dx;
+  s.dpz = three_d * ((phi_zp1 - phi_zm1) / dz);
+  s.om0 = om0;
+  return s;
+}
+ADEV void shear_gas(const ShearAcc &s, double dt, const FluidPrim &w, GasCons &u) {
+  const double rdt = w.rho * dt;
+  u.m1 -= rdt * (s.dpx - 2.0 * s.om0 * w.v2);
+  u.m2 -= rdt * 2.0 * s.om0 * w.v1;
+  u.m3 -= rdt * s.dpz;
+  u.e -= rdt * (w.v1 * s.dpx + w.v3 * s.dpz);
+}
+ADEV void shear_dust(const ShearAcc &s, double dt, const FluidPrim &w, DustCons &u) {
+  const double rdt = w.rho * dt;
+  u.m1 -= rdt * (s.dpx - 2.0 * s.om0 * w.v2);
+  u.m2 -= rdt * 2.0 * s.om0 * w.v1;
+  u.m3 -= rdt * s.dpz;
+}
+
+} // namespace artemis

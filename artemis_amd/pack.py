@@ -92,6 +92,7 @@ class MeshBlockPack:
             self.metric = torch.from_numpy(mt).to(self.dev)
             p.metric = self.metric.data_ptr()
         self.gas_prim_table = p.gas.prim
+        self.dust_prim_table = p.dust.prim
         self._extra_prim = {}
 
     # ---- helpers -------------------------------------------------------------------------
@@ -144,6 +145,30 @@ class MeshBlockPack:
         arr = (C.c_int * len(flat))(*flat)
         par = C.byref(capi.BcParams(*strat)) if strat is not None else None
         self._call(self.L.artemis_hip_apply_bc, arr, par)
+
+    def new_dust_prim_buffer(self, name):
+        t = torch.zeros_like(self.dust_prim)
+        tt = _ptr_table(t) if t.shape[1] else None
+        self._extra_prim["dust:" + name] = (t, tt)
+        return t, (tt.data_ptr() if tt is not None else None)
+
+    def stage_general(self, gam0, gam1, beta_dt, bdt, gas=(None, None, None), dust=(None, None, None),
+                      pcm=False, time=0.0, gravity=None, rotating_frame=None, drag=None,
+                      cfl=(0.0, 0.0), dt_dev=None):
+        """artemis_hip_stage_general: gas / dust = (in, u1, out) prim tables."""
+        a = capi.StageGeneralArgs()
+        a.gam0, a.gam1, a.beta_dt, a.bdt, a.pcm, a.time = gam0, gam1, beta_dt, bdt, int(pcm), time
+        a.gas_in, a.gas_u1, a.gas_out = gas
+        a.dust_in, a.dust_u1, a.dust_out = dust
+        if gravity is not None:
+            a.gravity = C.pointer(gravity)
+        if rotating_frame is not None:
+            a.rf_omega, a.rf_qshear = rotating_frame
+        if drag is not None:
+            a.drag = C.pointer(drag)
+        a.cfl_gas, a.cfl_dust = cfl
+        a.dt_dev = dt_dev
+        self._call(self.L.artemis_hip_stage_general, C.byref(a))
 
     # ---- source-term tasks (artemis_driver.cpp:222-241) ---------------------------------------
     def ExternalGravity(self, time, dt, gravity):

@@ -248,6 +248,35 @@ typedef struct artemis_stage_args {
                                  whose ghosts are cut from this block; 0 = all six */
 } artemis_stage_args_t;
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
+/* General fused stage: the same contract as artemis_hip_stage_fused for EVERY configuration the
+ * per-task entry points accept -- gas and/or dust, any number of species, PCM/PLM/PPM, all six
+ * coordinate systems, with ExternalGravity, RotatingFrameForce and DragSource between FluxSource
+ * and SetAuxillaryFields (artemis_driver.cpp:182-255).  One cell-centred kernel per fluid
+ * (csrc/kernels_stage_cell.hip): no flux / pressure-flux / face-velocity arrays are touched.
+ *   *_in  : prim tables of the state at the start of the stage (ghosts filled; only the FillGhost
+ *           variables rho, v, sie are read -- gas pressure is recomputed, fill_derived.cpp:247)
+ *   *_u1  : prim tables of the start-of-step state (cell-wise), *_in itself for stage 1
+ *   *_out : where the new interior primitives go (rho, v, sie); may alias *_u1, not *_in
+ *   gravity / drag : NULL = package off; rf_omega == 0 = rotating frame off
+ *   drag  : the coupled update needs scratch for the conserved state: p->gas.cons0 and
+ *           p->dust.cons0 must be valid tables (their contents are overwritten)
+ *   dt_dev: optional DEVICE scalar min-combined with cfl*min(...) of the new state
+ * Bit-identical to the per-task sequence; p->{gas,dust}.prim are not used. */
+typedef struct artemis_stage_general_args {
+  double gam0, gam1, beta_dt, bdt;
+  int pcm;
+  double time;                /* tm.time at the start of the step (artemis_driver.cpp:167) */
+  double *const *gas_in, *const *gas_u1, *const *gas_out;
+  double *const *dust_in, *const *dust_u1, *const *dust_out;
+  const artemis_gravity_t *gravity;
+  double rf_omega, rf_qshear;
+  const artemis_drag_t *drag;
+  double cfl_gas, cfl_dust;
+  double *dt_dev;
+} artemis_stage_general_args_t;
+int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
+                              void *stream);
+
 /* Device-side SetGlobalTimeStep (parthenon EvolutionDriver, upstream): state = DEVICE
  * {time, dt, dt_est, beta_dt[0..2]}.  time += dt; dt = min(2*dt, dt_est), clipped so that
  * time + dt <= tlim (tlim <= 0: no limit); dt_est = DBL_MAX for the next cycle's reduction;
