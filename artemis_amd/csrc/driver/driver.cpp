@@ -141,7 +141,7 @@ struct artemis_sim {
   Field gprim[3];               // primitive ping-pong buffers (fused path); [0..2]
   int base = 0;                 // index of the buffer holding the current state
   Field gu0, gu1, gflux[3], gpflux[3], gvface[3];
-  Field dprim, du0, du1, dflux[3];
+  Field dprim[3], du0, du1, dflux[3]; // dust primitives ping-pong with the same index as gprim
   DevBuf geom, dt_dev, metric;
   std::vector<Real> hgeom, hmetric; // host copies of the edge and x2-trig tables
   int coords = ARTEMIS_CARTESIAN;   // geometry::CoordSelect(artemis/coordinates, ndim)
@@ -154,6 +154,7 @@ struct artemis_sim {
   double *dt_host = nullptr;    // pinned
   bool unfused_ready = false;
   bool use_fused = false, fused_possible = false;
+  bool tuned = false; // the hand-tuned gas kernel covers this deck; otherwise the general cell-centred stage
   int overlap = 0; // 0 off, 1 shell launch + bulk launch, 2 one launch with in-kernel shell signalling
   DevBuf signal; // [0] shell-done counter, [1] wait-kernel timeout flag (as 32-bit words)
   // test hook (ARTEMIS_LOOPBACK_COMM=1): route same-rank ghost slabs through the communicator
@@ -197,7 +198,7 @@ struct artemis_sim {
     p.gas.prim = gprim[prim_idx].tab(), p.gas.cons0 = gu0.tab(), p.gas.cons1 = gu1.tab();
     p.dust.nspecies = ns_dust, p.dust.recon = recon_dust, p.dust.riemann = riemann_dust;
     p.dust.dfloor = dfloor_dust;
-    p.dust.prim = dprim.tab(), p.dust.cons0 = du0.tab(), p.dust.cons1 = du1.tab();
+    p.dust.prim = dprim[prim_idx].tab(), p.dust.cons0 = du0.tab(), p.dust.cons1 = du1.tab();
     for (int d = 0; d < 3; ++d) {
       p.gas.flux[d] = gflux[d].tab(), p.gas.pflux[d] = gpflux[d].tab();
       p.gas.vface[d] = gvface[d].tab(), p.dust.flux[d] = dflux[d].tab();
@@ -211,6 +212,7 @@ struct artemis_sim {
   void ensure_unfused();
   void problem_generator();
   void fill_ghosts(int prim_idx);
+  void step_general(bool want_dt);
   void fill_ghosts_start(int prim_idx, void *hs);
   void fill_ghosts_finish(int prim_idx, void *hs);
   void materialise_cons();
@@ -464,9 +466,11 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
 
   build_mesh();
   allocate();
-  fused_possible = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
-                   coords == ARTEMIS_CARTESIAN && // curvilinear systems run the per-task kernels
-                   !do_gravity && !do_rframe && !do_drag && pgen != PG_STRAT; // so do source terms
+  // one kernel per stage: the hand-tuned gas kernel where it applies, the general cell-centred
+  // stage (artemis_hip_stage_general) for everything else the per-task path can do
+  tuned = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
+          coords == ARTEMIS_CARTESIAN && !do_gravity && !do_rframe && !do_drag;
+  fused_possible = true;
   use_fused = fused_possible;
   if (!use_fused) ensure_unfused();
   problem_generator();
@@ -574,7 +578,7 @@ void artemis_sim::allocate() {
   if (!dt_host) throw HipFail("pinned allocation failed");
   gprim[0].alloc(nb, 6 * ns_gas, N);
   gu0.alloc(nb, 6 * ns_gas, N);
-  dprim.alloc(nb, 4 * ns_dust, N);
+  dprim[0].alloc(nb, 4 * ns_dust, N);
   du0.alloc(nb, 4 * ns_dust, N);
   // ghost-slab links
   for (int b = 0; b < nb; ++b)
@@ -982,7 +986,7 @@ void artemis_sim::problem_generator() {
           }
         }
     if (do_gas) upload_block(gprim[0], b, hg);
-    if (do_dust) upload_block(dprim, b, hd);
+    if (do_dust) upload_block(dprim[0], b, hd);
   }
   base = 0;
   // PostInitialization = PrimToCons on every block (main.cpp:43, fill_derived.cpp:284-287),
@@ -1012,7 +1016,61 @@ Real artemis_sim::new_dt_unfused() {
 }
 
 // One step on the fused path: one kernel per stage, primitives ping-ponged between buffers.
+// One step on the general fused path: one cell-centred kernel per fluid and stage (plus the drag /
+// SetAuxillaryFields / ConsToPrim trio when drag couples the fluids), primitives of both fluids
+// ping-ponged between buffers exactly like the tuned path.
+void artemis_sim::step_general(bool want_dt) {
+  for (int q = 1; q < 3; ++q) {
+    if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
+    if (!dprim[q].ok()) dprim[q].alloc(nb, 4 * ns_dust, N);
+  }
+  const int A = base;
+  int cur = A;
+  if (want_dt) {
+    *dt_host = DBL_MAX;
+    CK(artemis_rt_memcpy_h2d(dt_dev.p, dt_host, sizeof(double), stream), "h2d");
+  }
+  for (int stage = 1; stage <= nstages; ++stage) {
+    const bool last = (stage == nstages);
+    int out;
+    if (last && cur != A) out = A;
+    else out = (cur + 1) % 3 == A ? (cur + 2) % 3 : (cur + 1) % 3;
+    const artemis_pack_t p = make_pack(cur);
+    artemis_stage_general_args_t a;
+    std::memset(&a, 0, sizeof a);
+    a.gam0 = gam0[stage - 1], a.gam1 = gam1[stage - 1];
+    a.beta_dt = beta[stage - 1] * dt, a.bdt = beta[stage - 1] * dt;
+    a.pcm = (stage == 1 && integrator == "vl2");
+    a.time = time;
+    a.gas_in = gprim[cur].tab(), a.gas_u1 = gprim[A].tab(), a.gas_out = gprim[out].tab();
+    a.dust_in = dprim[cur].tab(), a.dust_u1 = dprim[A].tab(), a.dust_out = dprim[out].tab();
+    a.gravity = do_gravity ? &grav : nullptr;
+    a.rf_omega = do_rframe ? rf_omega : 0.0, a.rf_qshear = rf_qshear;
+    a.drag = do_drag ? &drag : nullptr;
+    a.cfl_gas = cfl_gas, a.cfl_dust = cfl_dust;
+    a.dt_dev = (last && want_dt) ? dt_dev.p : nullptr;
+    void *e0 = nullptr, *e1 = nullptr;
+    if (time_kernels) {
+      e0 = artemis_rt_event_create(), e1 = artemis_rt_event_create();
+      CK(artemis_rt_event_record(e0, stream), "event");
+    }
+    CK(artemis_hip_stage_general(&p, &a, stream), "stage_general");
+    if (time_kernels) {
+      CK(artemis_rt_event_record(e1, stream), "event");
+      kev.emplace_back(e0, e1);
+    }
+    fill_ghosts(out);
+    cur = out;
+  }
+  base = cur;
+  cons_valid = false;
+}
+
 void artemis_sim::step_fused(bool want_dt, bool device_dt) {
+  if (!tuned) {
+    step_general(want_dt);
+    return;
+  }
   for (int q = 1; q < 3; ++q)
     if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
   const int A = base;
@@ -1144,7 +1202,7 @@ long artemis_sim::evolve(long max_cycles) {
   // (kernels read dt there, artemis_hip_advance_dt applies SetGlobalTimeStep's rules) and never
   // synchronise inside the loop, so launches queue ahead of the GPU.
   const bool multi = has_comm && (nranks > 1 || loopback);
-  const bool async_loop = use_fused && tlim <= 0.0 && (!multi || comm.allreduce_min_dev) &&
+  const bool async_loop = use_fused && tuned && tlim <= 0.0 && (!multi || comm.allreduce_min_dev) &&
                           std::getenv("ARTEMIS_SYNC_LOOP") == nullptr;
   if (async_loop) {
     long todo = -1;
@@ -1365,13 +1423,10 @@ long artemis_sim_total_zones(const artemis_sim_t *s) {
   return static_cast<long>(s->nx[0]) * s->nx[1] * s->nx[2];
 }
 int artemis_sim_uses_fused_path(const artemis_sim_t *s) { return s->use_fused ? 1 : 0; }
+int artemis_sim_uses_tuned_kernel(const artemis_sim_t *s) { return (s->use_fused && s->tuned) ? 1 : 0; }
 int artemis_sim_set_path(artemis_sim_t *s, const char *which) {
   const std::string w = which ? which : "";
   if (w == "fused") {
-    if (!s->fused_possible) {
-      g_sim_err = "fused path needs: one gas species, no dust, pcm|plm, nghost >= 2";
-      return 1;
-    }
     s->use_fused = true;
     return 0;
   }
@@ -1412,7 +1467,7 @@ int artemis_sim_get_field(artemis_sim_t *s, const char *field, int block, double
         const Field *F = nullptr;
         if (f == "gas.prim") F = &s->gprim[s->base];
         else if (f == "gas.cons") F = &s->gu0;
-        else if (f == "dust.prim") F = &s->dprim;
+        else if (f == "dust.prim") F = &s->dprim[s->base];
         else if (f == "dust.cons") F = &s->du0;
         else throw std::runtime_error("unknown field " + f);
         const std::vector<Real> h = s->download(*F, block);

@@ -333,6 +333,70 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
   return 0;
 }
 
+// The general-stage CONTRACT restated with the oracle's task chain (both fluids, every source
+// package): u1 := PrimToCons(*_u1), u0 := PrimToCons(*_in), the reference's task order, interior
+// of the new primitives (rho, v, sie) to *_out.
+int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *) {
+  if ((p->gas.nspecies && a->gas_in == a->gas_out) || (p->dust.nspecies && a->dust_in == a->dust_out))
+    return bad("*_out must not alias *_in");
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    Sim &s = *B.s;
+    B.in(s.gprim, a->gas_u1, s.nvg), B.in(s.dprim, a->dust_u1, s.nvd);
+    prim_to_cons(s);
+    s.gu1 = s.gu0, s.du1 = s.du0;
+    B.in(s.gprim, a->gas_in, s.nvg), B.in(s.dprim, a->dust_in, s.nvd);
+    prim_to_cons(s);
+    calculate_fluxes(s, FL_GAS, a->pcm != 0), calculate_fluxes(s, FL_DUST, a->pcm != 0);
+    apply_update(s, a->gam0, a->gam1, a->beta_dt);
+    flux_source(s, FL_GAS, a->bdt), flux_source(s, FL_DUST, a->bdt);
+    if (a->gravity) {
+      const artemis_gravity_t *g = a->gravity;
+      s.grav.type = g->type, s.grav.gm = g->gm, s.grav.soft = g->soft, s.grav.sink = g->sink;
+      s.grav.sink_rate = g->sink_rate, s.grav.tstart = g->tstart, s.grav.tstop = g->tstop;
+      for (int d = 0; d < 3; ++d) s.grav.g[d] = g->g[d], s.grav.pos[d] = g->pos[d];
+      external_gravity(s, a->time, a->bdt);
+    }
+    if (a->rf_omega != 0.0) {
+      s.rframe.on = true, s.rframe.omega = a->rf_omega, s.rframe.qshear = a->rf_qshear;
+      rotating_frame_force(s, a->bdt);
+    }
+    if (a->drag) {
+      const artemis_drag_t *d = a->drag;
+      s.drag.type = d->type, s.drag.model = d->model, s.drag.scale = d->scale;
+      s.drag.grain_density = d->grain_density;
+      s.drag.tau.assign(d->tau, d->tau + s.c.ns_dust), s.drag.sizes.assign(d->sizes, d->sizes + s.c.ns_dust);
+      for (int i = 0; i < 3; ++i) {
+        s.drag.gas.ix[i] = d->gas.ix[i], s.drag.gas.ox[i] = d->gas.ox[i];
+        s.drag.gas.irate[i] = d->gas.irate[i], s.drag.gas.orate[i] = d->gas.orate[i];
+        s.drag.dust.ix[i] = d->dust.ix[i], s.drag.dust.ox[i] = d->dust.ox[i];
+        s.drag.dust.irate[i] = d->dust.irate[i], s.drag.dust.orate[i] = d->dust.orate[i];
+      }
+      s.gx1min = d->xmin[0], s.gx2min = d->xmin[1], s.gx3min = d->xmin[2];
+      s.gx1max = d->xmax[0], s.gx2max = d->xmax[1], s.gx3max = d->xmax[2];
+      drag_source(s, a->bdt);
+    }
+    set_aux(s);
+    cons_to_prim(s);
+    auto put = [&](const std::vector<Real> &src, double *const *tab, int nvar, bool gas) {
+      for (int v = 0; v < nvar; ++v) {
+        if (gas && v >= 4 * s.c.ns_gas && v < 5 * s.c.ns_gas) continue; // P is not an output
+        for (int k = s.ks; k <= s.ke; ++k)
+          for (int j = s.js; j <= s.je; ++j)
+            std::memcpy(tab[b * nvar + v] + IDX(s, k, j, s.is), src.data() + v * s.N + IDX(s, k, j, s.is),
+                        (s.ie - s.is + 1) * sizeof(Real));
+      }
+    };
+    if (s.c.ns_gas) put(s.gprim, a->gas_out, s.nvg, true);
+    if (s.c.ns_dust) put(s.dprim, a->dust_out, s.nvd, false);
+    if (a->dt_dev) {
+      if (s.c.ns_gas) *a->dt_dev = std::min(*a->dt_dev, a->cfl_gas * estimate_dt(s, FL_GAS));
+      if (s.c.ns_dust) *a->dt_dev = std::min(*a->dt_dev, a->cfl_dust * estimate_dt(s, FL_DUST));
+    }
+  }
+  return 0;
+}
+
 static void slab(const artemis_pack_t *p, int face, int unpack, int lo[3], int n[3]) {
   const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
   const int nx[3] = {p->nx1, p->nx2, p->nx3};

@@ -32,7 +32,7 @@ def main():
         sim.set_overlap(True)
     n = sim.evolve(spec.get("cycles", -1))
     out = {"ncycle": sim.ncycle, "time": sim.time, "dt": sim.dt, "n": n, "nblocks": sim.nblocks,
-           "fused": sim.uses_fused_path}
+           "fused": sim.uses_fused_path, "tuned": sim.uses_tuned_kernel}
     hist = sim.history()
     errs = sim.errors()
     arrays = {}

@@ -36,7 +36,7 @@ def test_linwave_single_block_bitwise_and_thresholds(hiplib, recon, riem):
         errs = {}
         for N in (16, 32):
             sim = Simulation(DECK("linwave", "linear_wave.in"), linwave_overrides(N, recon, riem, wave, vflow))
-            assert sim.uses_fused_path == (recon != "ppm")
+            assert sim.uses_fused_path and sim.uses_tuned_kernel == (recon != "ppm")  # ppm: general stage
             sim.evolve()
             errs[N] = sim.errors()[0]
             if N == 32:
@@ -88,7 +88,7 @@ def test_advection_history_pins(hiplib, riem):
         ov = linwave_overrides(N, "plm", riem, 0, 1.0, mb=(N // 4, N // 4, N // 4))
         ov = [o for o in ov if "wave_flag" not in o] + ["dust/reconstruct=plm", f"dust/riemann={riem}"]
         sim = Simulation(DECK("advection", "advection.in"), ov)
-        assert not sim.uses_fused_path  # dust -> per-task kernels
+        assert sim.uses_fused_path and not sim.uses_tuned_kernel  # dust -> general cell-centred stage
         sim.evolve()
         return sim
 
@@ -299,7 +299,7 @@ def test_blast_reference_curvilinear_1d_bitwise(hiplib, g):
     energy and total energy is conserved (blast.py:177-183 bounds the pressure L2 error by 1)."""
     from artemis_amd.driver import Simulation
     s = Simulation(DECK("blast", "blast.in"), BLAST_GEOM[g] + ["parthenon/meshblock/nx1=1024"])
-    assert s.nblocks == 1 and not s.uses_fused_path
+    assert s.nblocks == 1 and s.uses_fused_path and not s.uses_tuned_kernel
     sph = (g == "sph")
     o = Oracle((1024, 1, 1), (0.0, 0.0 if sph else -0.5, -0.5), (1.0, float("{:.16f}".format(np.pi)) if sph else 0.5, 0.5),
                ng=2, reconstruct="plm", riemann="hlle", gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
@@ -393,7 +393,7 @@ def test_drag_deck_bitwise_and_reference_pins(hiplib):
     tst/scripts/drag/drag.py:57-59,127-129 (|<v_d - v_g> - ans| <= 3e-3, momentum to 1e-13)."""
     from artemis_amd.driver import Simulation
     s = Simulation(DECK("drag", "simple_drag.in"), ["parthenon/meshblock/nx1=128", "parthenon/time/tlim=0.5"])
-    assert s.nblocks == 1 and not s.uses_fused_path
+    assert s.nblocks == 1 and s.uses_fused_path and not s.uses_tuned_kernel
     o = drag_oracle()
     s.evolve(), o.evolve(0.5, -1)
     assert s.ncycle == o.ncycle and s.time == o.time and s.dt == o.dt
@@ -422,7 +422,7 @@ def test_shearing_sheet_deck_bitwise_and_reference_pins(hiplib):
     from artemis_amd.driver import Simulation
     s = Simulation(DECK("ssheet", "ssheet.in"), ["parthenon/meshblock/nx1=128", "parthenon/meshblock/nx2=128",
                                                 "parthenon/time/nlim=60"])
-    assert s.nblocks == 1 and not s.uses_fused_path
+    assert s.nblocks == 1 and s.uses_fused_path and not s.uses_tuned_kernel
     N = 128
     o = Oracle((N, N, 1), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2), ng=2, reconstruct="plm", riemann="hllc",
                gamma=1.000001, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
@@ -448,3 +448,31 @@ def test_shearing_sheet_deck_bitwise_and_reference_pins(hiplib):
     ii, io = np.argwhere(x <= -0.1)[-1][0], np.argwhere(xc >= 0.1)[0][0]
     assert abs(xc[np.argmax(sig[:, ii])] - 0.75 * 0.1 ** 2 / 0.05) < 0.03
     assert abs(xc[np.argmax(sig[:, io])] + 0.75 * 0.1 ** 2 / 0.05) < 0.03
+
+
+def test_general_stage_path_equals_per_task_path(hiplib):
+    """Decks the tuned gas kernel does not cover run the general cell-centred stage by default;
+    the per-task chain (set_path("unfused")) must give the same bits: advection (gas + 2 dust,
+    16 blocks, periodic), the 2-D axisymmetric blast, and the shearing sheet with dust + drag
+    (SURVEY config 3 in small)."""
+    from artemis_amd.driver import Simulation
+    adv = [o for o in linwave_overrides(16, "plm", "hlle", 0, 1.0, mb=(4, 4, 4)) if "wave_flag" not in o]
+    cfg3 = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "physics/dust=true", "physics/drag=true",
+            "dust/nspecies=3", "dust/cfl=0.3", "dust/reconstruct=plm", "dust/riemann=hlle", "dust/dfloor=1.0e-10",
+            "dust/stopping_time/type=constant", "dust/stopping_time/tau=0.01, 0.5, 5.0", "drag/type=simple_dust",
+            "gravity/point/mass=1.0e-3", "parthenon/time/nlim=30"]
+    axi = BLAST_GEOM["axi"] + ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "problem/radius=0.1",
+                               "problem/samples=10", "parthenon/time/nlim=30"]
+    for deck, ov, dust in ((("advection", "advection.in"), adv + ["dust/reconstruct=plm", "dust/riemann=hlle"], True),
+                           (("blast", "blast.in"), axi, False), (("ssheet", "ssheet.in"), cfg3, True)):
+        f, u = Simulation(DECK(*deck), ov), Simulation(DECK(*deck), ov)
+        u.set_path("unfused")
+        assert f.uses_fused_path and not f.uses_tuned_kernel and not u.uses_fused_path
+        f.evolve(), u.evolve()
+        assert f.ncycle == u.ncycle and f.time == u.time and f.dt == u.dt
+        for b in range(f.nblocks):
+            I = np.s_[:, f.ks:f.ke + 1, f.js:f.je + 1, f.is_:f.ie + 1]
+            assert np.array_equal(f.field("gas.prim", b)[I], u.field("gas.prim", b)[I]), (deck, b)
+            if dust:
+                assert np.array_equal(f.field("dust.prim", b)[I], u.field("dust.prim", b)[I]), (deck, b)
+        assert np.allclose(f.history(), u.history(), rtol=1e-13, atol=1e-15)

@@ -151,11 +151,12 @@ SPH3D = dict(deck=["blast", "blast.in"], cycles=5, overrides=[
 def test_spherical3d_two_ranks_equal_single_process_bitwise(double_lib, tmp_path):
     """artemis/coordinates = spherical on a 3-D wedge, 2x2x2 blocks with reflecting radial /
     polar and periodic azimuthal boundaries: the per-task path (the fused kernel is
-    Cartesian-only) with the metric tables of each rank's own blocks gives the same bits on 2
+    Cartesian-only; the general cell-centred stage runs instead) with the metric tables of each rank's own blocks gives the same bits on 2
     ranks as on 1, and mass is conserved with the spherical cell volumes."""
     one = run_world(1, SPH3D, tmp_path, "s1")
     two = run_world(2, SPH3D, tmp_path, "s2")
-    assert not one[0]["meta"]["fused"] and one[0]["meta"]["ncycle"] == 5
+    assert one[0]["meta"]["fused"] and not one[0]["meta"]["tuned"] and one[0]["meta"]["ncycle"] == 5
+    per_task = by_bounds(run_world(1, dict(SPH3D, path="unfused"), tmp_path, "s1u"))
     for r in two:
         for k in ("ncycle", "time", "dt"):
             assert r["meta"][k] == one[0]["meta"][k], k
@@ -163,6 +164,7 @@ def test_spherical3d_two_ranks_equal_single_process_bitwise(double_lib, tmp_path
     assert a.keys() == b.keys() and len(a) == 8
     for key in a:
         assert np.array_equal(a[key], b[key]), key
+        assert np.array_equal(a[key], per_task[key]), key  # general fused stage == per-task chain
         assert np.isfinite(a[key]).all()
     # volume of the wedge x d0 = 1: (r1^3 - r0^3)/3 * (cos t0 - cos t1) * 2 pi
     vol = (1.4 ** 3 - 0.2 ** 3) / 3.0 * (np.cos(0.7) - np.cos(2.4)) * 2 * np.pi
@@ -179,7 +181,10 @@ def test_drag_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
     one_blk = dict(deck=["drag", "simple_drag.in"], cycles=25, dust=True,
                    overrides=["parthenon/meshblock/nx1=128"])
     r = run_world(1, one_blk, tmp_path, "d1")[0]
-    assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    assert r["meta"]["fused"] and not r["meta"]["tuned"] and r["meta"]["nblocks"] == 1
+    u = run_world(1, dict(one_blk, path="unfused"), tmp_path, "d1u")[0]
+    assert not u["meta"]["fused"] and np.array_equal(u["blocks"][0][1], r["blocks"][0][1])
+    assert np.array_equal(u["dust"][0], r["dust"][0]) and u["meta"]["dt"] == r["meta"]["dt"]
     o = Oracle((128, 1, 1), (0.0, -0.5, -0.5), (1.0, 0.5, 0.5), ng=2, ns_gas=1, ns_dust=4,
                reconstruct="plm", riemann="hlle", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.4,
                dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10, cfl=0.3, dust_cfl=0.3,
@@ -209,7 +214,9 @@ def test_shearing_sheet_deck_driver_equals_oracle_and_ranks_agree(double_lib, tm
     one_blk = dict(deck=["ssheet", "ssheet.in"], cycles=20,
                    overrides=small + ["parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=32"])
     r = run_world(1, one_blk, tmp_path, "s1")[0]
-    assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    assert r["meta"]["fused"] and not r["meta"]["tuned"] and r["meta"]["nblocks"] == 1
+    u = run_world(1, dict(one_blk, path="unfused"), tmp_path, "s1u")[0]
+    assert not u["meta"]["fused"] and np.array_equal(u["blocks"][0][1], r["blocks"][0][1])
     o = Oracle((32, 32, 1), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2), ng=2, reconstruct="plm", riemann="hllc",
                gamma=1.000001, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
                bc=("extrap", "extrap", "inflow", "inflow", "extrap", "extrap"), integrator="rk2")
