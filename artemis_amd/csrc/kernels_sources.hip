@@ -193,6 +193,11 @@ __global__ __launch_bounds__(TX *TY) void self_drag_kernel(const PackView P, con
 
 // SimpleDragSourceImpl (drag.hpp:296-482): backward-Euler gas-dust momentum exchange for one
 // gas species and ns dust species; two passes over the dust species (sum, then update).
+// FINISH: instead of storing the coupled momenta / energy back to cons0, carry on with
+// SetAuxillaryFields (fill_derived.cpp:58-71) and ConsToPrim (:132-164) of the cell and write the
+// new primitives to P.{gas,dust}.prim -- the tail of the general fused stage in one pass
+// (one gas species).
+template <bool FINISH>
 __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, const artemis_drag_t D,
                                                              double dt) {
   INTERIOR_CELL
@@ -263,17 +268,46 @@ __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, c
       delta_g[d] -= delta;
       delta_d -= bd[d] * dens / (1. + alpha + bd[d]) * (vd[d] - vdt[d] + alpha * (vgp[d] - vdt[d]));
       fvd[d] += rhop * (vd[d] - vt[d] + bd[d] * (vdt[d] - vt[d]));
-      F.cons0[b * nvd + nsd + 3 * n + d][c] += hx[d] * delta_d;
+      if constexpr (FINISH) {
+        const double w_d = (dens > F.dfloor) ? dens : F.dfloor;
+        const double m = F.cons0[b * nvd + nsd + 3 * n + d][c] + hx[d] * delta_d;
+        F.prim[b * nvd + nsd + 3 * n + d][c] = m / (w_d * hx[d]);
+        if (d == 0) F.prim[b * nvd + n][c] = w_d;
+      } else {
+        F.cons0[b * nvd + nsd + 3 * n + d][c] += hx[d] * delta_d;
+      }
     }
   }
   double en = G.cons0[b * nvg + 4 * nsg][c];
+  double mnew[3];
   for (int d = 0; d < 3; d++) {
     const double prefac = dg * bg[d] / (1.0 + bg[d] + fd[d]);
     delta_g[d] -= prefac * (dg * (vg[d] - vt[d]) + fvd[d]);
-    mg[d][c] += hx[d] * delta_g[d];
+    mnew[d] = mg[d][c] + hx[d] * delta_g[d];
+    if constexpr (!FINISH) mg[d][c] = mnew[d];
     en += 0.5 * (vg[d] + vgp[d]) * delta_g[d];
   }
-  G.cons0[b * nvg + 4 * nsg][c] = en;
+  if constexpr (!FINISH) {
+    G.cons0[b * nvg + 4 * nsg][c] = en;
+  } else {
+    const double u_d = (dg > G.dfloor) ? dg : G.dfloor;
+    const double u_d2 = amax(dg, G.dfloor);
+    const double rv1 = mnew[0] / hx[0], rv2 = mnew[1] / hx[1], rv3 = mnew[2] / hx[2];
+    const double ke = 0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)) / u_d2;
+    const double ue_cons = en - ke;
+    double sie = (ue_cons > G.de_switch * en) ? ue_cons / u_d2 : G.cons0[b * nvg + 5 * nsg][c] / u_d2;
+    sie = amax(sie, G.siefloor);
+    double u_u = sie * u_d;
+    const double uflr = G.siefloor * u_d;
+    u_u = (u_u > uflr) ? u_u : uflr;
+    const double w_d = u_d;
+    G.prim[b * nvg + 0][c] = w_d;
+    G.prim[b * nvg + nsg + 0][c] = mnew[0] / (w_d * hx[0]);
+    G.prim[b * nvg + nsg + 1][c] = mnew[1] / (w_d * hx[1]);
+    G.prim[b * nvg + nsg + 2][c] = mnew[2] / (w_d * hx[2]);
+    const double w_s = u_u / w_d;
+    G.prim[b * nvg + 5 * nsg][c] = (w_s > G.siefloor) ? w_s : G.siefloor;
+  }
 }
 
 } // namespace
@@ -288,7 +322,14 @@ void launch_drag_source(const PackView &P, const artemis_drag_t &D, double dt, h
   if (D.type == ARTEMIS_DRAG_SELF)
     hipLaunchKernelGGL(self_drag_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt);
   else
-    hipLaunchKernelGGL(simple_drag_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt);
+    hipLaunchKernelGGL(simple_drag_kernel<false>, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt);
+}
+// simple_dust drag + SetAuxillaryFields + ConsToPrim of a one-gas-species pack in one pass: reads
+// cons0, writes the primitives of P (the general fused stage points them at its out tables)
+bool launch_drag_finish(const PackView &P, const artemis_drag_t &D, double dt, hipStream_t s) {
+  if (D.type != ARTEMIS_DRAG_SIMPLE_DUST || P.gas.ns != 1) return false;
+  hipLaunchKernelGGL(simple_drag_kernel<true>, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt);
+  return true;
 }
 
 } // namespace artemis

@@ -320,9 +320,11 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
   PackView Q = P; // the new state: prim tables are the out tables
   Q.gas.prim = g.gas_out, Q.dust.prim = g.dust_out;
   if (g.drag) { // coupled update on cons0, then SetAuxillaryFields and ConsToPrim into the out tables
-    launch_drag_source(Q, *g.drag, g.bdt, s);
-    if (Q.gas.ns) launch_set_aux(Q, s);
-    launch_cons_to_prim(Q, s);
+    if (!launch_drag_finish(Q, *g.drag, g.bdt, s)) { // one pass when one gas species is coupled
+      launch_drag_source(Q, *g.drag, g.bdt, s);
+      if (Q.gas.ns) launch_set_aux(Q, s);
+      launch_cons_to_prim(Q, s);
+    }
   }
   if (g.dt_dev) { // EstimateTimestepMesh of the new state (gas.cpp:411-433, dust.cpp:256-272)
     if (Q.gas.ns) launch_estimate_dt(Q, ARTEMIS_GAS, g.cfl_gas, g.dt_dev, s);

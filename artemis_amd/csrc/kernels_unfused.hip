@@ -347,13 +347,19 @@ template <int FLUID, bool CURV>
 __global__ __launch_bounds__(TX *TY) void estimate_dt_kernel(const PackView P, const Range3 r,
                                                              double cfl,
                                                              unsigned long long *dt_bits) {
-  const int i = r.il + blockIdx.x * TX + threadIdx.x;
-  const int j = r.jl + blockIdx.y * TY + threadIdx.y;
+  // grid-stride over the 64x4 cell tiles: a bounded number of workgroups, hence a bounded number
+  // of atomics on the single result word (one atomic per tile serialises in L2 on large meshes)
+  const int gx = (r.iu - r.il + TX) / TX, gy = (r.ju - r.jl + TY) / TY;
   const int nkr = r.ku - r.kl + 1;
-  const int b = blockIdx.z / nkr;
-  const int k = r.kl + blockIdx.z % nkr;
+  const long ntile = static_cast<long>(gx) * gy * nkr * P.nb;
   double ldt = DBL_MAX;
-  if (i <= r.iu && j <= r.ju) {
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int i = r.il + static_cast<int>(tile % gx) * TX + threadIdx.x;
+    const int j = r.jl + static_cast<int>((tile / gx) % gy) * TY + threadIdx.y;
+    const int bz = static_cast<int>(tile / (static_cast<long>(gx) * gy));
+    const int b = bz / nkr;
+    const int k = r.kl + bz % nkr;
+    if (i > r.iu || j > r.ju) continue;
     const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
     double dx[3]; // GetCellWidths (geometry.hpp:352-361)
     if constexpr (CURV) {
@@ -694,7 +700,9 @@ void launch_deep_copy(const PackView &P, hipStream_t s) {
 void launch_estimate_dt(const PackView &P, int fluid, double cfl, double *dt_dev, hipStream_t s) {
   const Range3 r = interior(P);
   auto *bits = reinterpret_cast<unsigned long long *>(dt_dev);
-  const dim3 g = grid_for(r, P.nb), t(TX, TY);
+  const dim3 g3 = grid_for(r, P.nb), t(TX, TY);
+  const long ntile = static_cast<long>(g3.x) * g3.y * g3.z;
+  const dim3 g(static_cast<unsigned>(ntile < 4096 ? ntile : 4096));
   const bool curv = P.coords != ARTEMIS_CARTESIAN;
   if (fluid == ARTEMIS_GAS) {
     if (curv) hipLaunchKernelGGL((estimate_dt_kernel<0, true>), g, t, 0, s, P, r, cfl, bits);

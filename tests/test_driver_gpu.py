@@ -165,7 +165,7 @@ def test_blast2d_shipped_deck_sedov_radius(hiplib):
 def test_driver_rejects_out_of_scope(hiplib):
     from artemis_amd.driver import Simulation
     with pytest.raises(RuntimeError, match="out of scope"):
-        Simulation(DECK("blast", "blast.in"), ["physics/gravity=true"])
+        Simulation(DECK("blast", "blast.in"), ["physics/nbody=true"])
     with pytest.raises(RuntimeError, match="not recognized"):
         Simulation(DECK("blast", "blast.in"), ["artemis/coordinates=toroidal"])
     with pytest.raises(RuntimeError, match="Cartesian-only"):

@@ -41,7 +41,7 @@ def fused_step(mb, bufs, integ, dt, bc, cons_out=False, dt_dev=None, cfl=0.0):
         flat = []
         for row in bc:
             flat += [capi.BCS[x] for x in row]
-        mb.call_on(pk, L.artemis_hip_apply_bc, (C.c_int * len(flat))(*flat))
+        mb.call_on(pk, L.artemis_hip_apply_bc, (C.c_int * len(flat))(*flat), None)
         cur = out
 
 
