@@ -44,6 +44,47 @@ ADEV void load_stencil(const double *q, long c, long st, double w[7]) {
   for (int m = -R; m <= R; ++m) w[3 + m] = q[c + m * st];
 }
 
+// Cartesian PLM: the two faces of a cell need the limited slopes of three cells (c-1, c, c+1); the
+// cell's own slope serves both faces.  plm_dqm_fast is plm.hpp:32-47 with the hand-scheduled
+// division of device_math.hpp (same bits as `/`, checked by artemis_hip_selftest_divsqrt and by
+// the parity tests of this kernel against the oracle).
+ADEV void plm_pair_fast(const double w[7], double &Llo, double &Rlo, double &Lup, double &Rup) {
+  const double sm = plm_dqm_fast(w[1], w[2], w[3]);
+  const double sc = plm_dqm_fast(w[2], w[3], w[4]);
+  const double sp = plm_dqm_fast(w[3], w[4], w[5]);
+  Llo = w[2] + sm, Rlo = w[3] - sc; // lower face: ql from cell c-1, qr from cell c
+  Lup = w[3] + sc, Rup = w[4] - sp; // upper face: ql from cell c, qr from cell c+1
+}
+template <int FLUID, int RIEMANN>
+ADEV void solve_pair_fast(const PackView &P, int d, const double wd[7], const double w1[7],
+                          const double w2[7], const double w3[7], const double wp[7],
+                          const double we[7], FaceFlux &lo, FaceFlux &up) {
+  const double *vx = (d == 0) ? w1 : ((d == 1) ? w2 : w3);
+  const double *vy = (d == 0) ? w2 : ((d == 1) ? w3 : w1);
+  const double *vz = (d == 0) ? w3 : ((d == 1) ? w1 : w2);
+  if constexpr (FLUID == 0) {
+    Prim6 Ll, Rl, Lu, Ru;
+    plm_pair_fast(wd, Ll.d, Rl.d, Lu.d, Ru.d), plm_pair_fast(vx, Ll.vx, Rl.vx, Lu.vx, Ru.vx);
+    plm_pair_fast(vy, Ll.vy, Rl.vy, Lu.vy, Ru.vy), plm_pair_fast(vz, Ll.vz, Rl.vz, Lu.vz, Ru.vz);
+    plm_pair_fast(wp, Ll.p, Rl.p, Lu.p, Ru.p), plm_pair_fast(we, Ll.e, Rl.e, Lu.e, Ru.e);
+    if constexpr (RIEMANN == 0) {
+      const double gm1 = P.gm1, igm1 = 1.0 / gm1, gamma = gm1 + 1.0; // hllc.hpp:75-77
+      const double alpha = (gamma + 1.0) / (2.0 * gamma);
+      hllc_gas_fast(gm1, igm1, gamma, alpha, Ll, Rl, lo);
+      hllc_gas_fast(gm1, igm1, gamma, alpha, Lu, Ru, up);
+    } else {
+      riemann_gas<RIEMANN>(P.gm1, Ll, Rl, lo);
+      riemann_gas<RIEMANN>(P.gm1, Lu, Ru, up);
+    }
+  } else {
+    Prim4 Ll, Rl, Lu, Ru;
+    plm_pair_fast(wd, Ll.d, Rl.d, Lu.d, Ru.d), plm_pair_fast(vx, Ll.vx, Rl.vx, Lu.vx, Ru.vx);
+    plm_pair_fast(vy, Ll.vy, Rl.vy, Lu.vy, Ru.vy), plm_pair_fast(vz, Ll.vz, Rl.vz, Lu.vz, Ru.vz);
+    riemann_dust<RIEMANN>(Ll, Rl, lo);
+    riemann_dust<RIEMANN>(Lu, Ru, up);
+  }
+}
+
 // Lower (side 0) or upper (side 1) face of cell (k,j,i) along dir for species n: the body of the
 // per-task flux kernel (fluid_fluxes.hpp:105-126 per direction) evaluated from register stencils.
 template <int FLUID, int RIEMANN, int RECON, bool CURV>
@@ -158,10 +199,15 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
 #pragma unroll
         for (int m = -R; m <= R; ++m) wp[3 + m] = amax(0.0, P.gm1 * wd[3 + m] * we[3 + m]);
       }
-      const FaceFlux lo = face_of_cell<FLUID, RIEMANN, RECON, CURV>(P, f, a.in, b, n, dir, 0, k, j, i,
-                                                                    wd, w1, w2, w3, wp, we);
-      const FaceFlux up = face_of_cell<FLUID, RIEMANN, RECON, CURV>(P, f, a.in, b, n, dir, 1, k, j, i,
-                                                                    wd, w1, w2, w3, wp, we);
+      FaceFlux lo, up;
+      if constexpr (RECON == 1 && !CURV) {
+        solve_pair_fast<FLUID, RIEMANN>(P, dir - 1, wd, w1, w2, w3, wp, we, lo, up);
+      } else {
+        lo = face_of_cell<FLUID, RIEMANN, RECON, CURV>(P, f, a.in, b, n, dir, 0, k, j, i, wd, w1, w2, w3,
+                                                       wp, we);
+        up = face_of_cell<FLUID, RIEMANN, RECON, CURV>(P, f, a.in, b, n, dir, 1, k, j, i, wd, w1, w2, w3,
+                                                       wp, we);
+      }
       const double *ax = (dir == 1) ? g.ax1 : ((dir == 2) ? g.ax2 : g.ax3);
       const int d = dir - 1;
       // momentum components in global order: component (d+q)%3 carries the sweep's q-th flux
