@@ -1,4 +1,5 @@
-// Fused RK stage for gas (one species), Cartesian, PCM/PLM: CalculateFluxes -> ApplyUpdate ->
+// Tuned fused RK stage for gas (one species), Cartesian, PCM/PLM (everything else: the general
+// cell-centred stage in kernels_stage_cell.hip): CalculateFluxes -> ApplyUpdate ->
 // FluxSource -> SetAuxillaryFields -> ConsToPrim -> PrimToCons(interior) in ONE pass
 // (artemis_driver.cpp:182-261 with every optional package disabled).
 //
@@ -9,7 +10,8 @@
 //     in registers, so the x3 sweep needs no LDS and no redundant work inside a chunk.
 //   * Per plane the x1/x2 sweeps exchange only what a neighbour cannot recompute cheaply:
 //     staged primitives (with a 2-cell halo), the upper face value of the lower neighbour, and
-//     the 8 face outputs of the upper neighbour - three barriers per plane, 80 KiB of LDS per
+//     the 8 face outputs of the upper neighbour - two barriers per plane (the next plane is
+//     staged into the dead primitive tile during the Riemann phase), 80 KiB of LDS per
 //     workgroup, two workgroups per CU.
 //   * Every slope and every Riemann problem inside a tile is computed exactly once; the tile's
 //     perimeter (one extra face per row/column and the two halo slopes behind it) is packed
