@@ -102,7 +102,7 @@ class StageGeneralArgs(C.Structure):
         ("dust_in", PP), ("dust_u1", PP), ("dust_out", PP),
         ("gravity", C.POINTER(Gravity)), ("rf_omega", C.c_double), ("rf_qshear", C.c_double),
         ("drag", C.POINTER(Drag)), ("cfl_gas", C.c_double), ("cfl_dust", C.c_double),
-        ("dt_dev", C.c_void_p),
+        ("dt_dev", C.c_void_p), ("beta_dt_dev", C.c_void_p),
     ]
 
 

@@ -284,7 +284,7 @@ int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, do
     if (d->gas.irate[i] < 0.0 || d->dust.irate[i] < 0.0 || d->gas.ix[i] > d->gas.ox[i] ||
         d->dust.ix[i] > d->dust.ox[i])
       return fail(ARTEMIS_HIP_EINVAL, "bad damping bounds / rates");
-  artemis::launch_drag_source(artemis::make_pack_view(*p), *d, dt, S(stream));
+  artemis::launch_drag_source(artemis::make_pack_view(*p), *d, dt, nullptr, S(stream));
   return after_launch("DragSource");
 }
 

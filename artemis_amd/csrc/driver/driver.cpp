@@ -212,7 +212,7 @@ struct artemis_sim {
   void ensure_unfused();
   void problem_generator();
   void fill_ghosts(int prim_idx);
-  void step_general(bool want_dt);
+  void step_general(bool want_dt, bool device_dt);
   void fill_ghosts_start(int prim_idx, void *hs);
   void fill_ghosts_finish(int prim_idx, void *hs);
   void materialise_cons();
@@ -1019,14 +1019,14 @@ Real artemis_sim::new_dt_unfused() {
 // One step on the general fused path: one cell-centred kernel per fluid and stage (plus the drag /
 // SetAuxillaryFields / ConsToPrim trio when drag couples the fluids), primitives of both fluids
 // ping-ponged between buffers exactly like the tuned path.
-void artemis_sim::step_general(bool want_dt) {
+void artemis_sim::step_general(bool want_dt, bool device_dt) {
   for (int q = 1; q < 3; ++q) {
     if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
     if (!dprim[q].ok()) dprim[q].alloc(nb, 4 * ns_dust, N);
   }
   const int A = base;
   int cur = A;
-  if (want_dt) {
+  if (want_dt && !device_dt) {
     *dt_host = DBL_MAX;
     CK(artemis_rt_memcpy_h2d(dt_dev.p, dt_host, sizeof(double), stream), "h2d");
   }
@@ -1048,7 +1048,8 @@ void artemis_sim::step_general(bool want_dt) {
     a.rf_omega = do_rframe ? rf_omega : 0.0, a.rf_qshear = rf_qshear;
     a.drag = do_drag ? &drag : nullptr;
     a.cfl_gas = cfl_gas, a.cfl_dust = cfl_dust;
-    a.dt_dev = (last && want_dt) ? dt_dev.p : nullptr;
+    a.dt_dev = (last && want_dt) ? (device_dt ? tstate.p + 2 : dt_dev.p) : nullptr;
+    if (device_dt) a.beta_dt_dev = tstate.p + 3 + (stage - 1); // beta*dt stays on the device
     void *e0 = nullptr, *e1 = nullptr;
     if (time_kernels) {
       e0 = artemis_rt_event_create(), e1 = artemis_rt_event_create();
@@ -1068,7 +1069,7 @@ void artemis_sim::step_general(bool want_dt) {
 
 void artemis_sim::step_fused(bool want_dt, bool device_dt) {
   if (!tuned) {
-    step_general(want_dt);
+    step_general(want_dt, device_dt);
     return;
   }
   for (int q = 1; q < 3; ++q)
@@ -1202,7 +1203,9 @@ long artemis_sim::evolve(long max_cycles) {
   // (kernels read dt there, artemis_hip_advance_dt applies SetGlobalTimeStep's rules) and never
   // synchronise inside the loop, so launches queue ahead of the GPU.
   const bool multi = has_comm && (nranks > 1 || loopback);
-  const bool async_loop = use_fused && tuned && tlim <= 0.0 && (!multi || comm.allreduce_min_dev) &&
+  // (a gravity time window is evaluated against the host's clock, which the device loop does not keep)
+  const bool grav_window = do_gravity && (grav.tstart > -DBL_MAX || grav.tstop < DBL_MAX);
+  const bool async_loop = use_fused && tlim <= 0.0 && !grav_window && (!multi || comm.allreduce_min_dev) &&
                           std::getenv("ARTEMIS_SYNC_LOOP") == nullptr;
   if (async_loop) {
     long todo = -1;

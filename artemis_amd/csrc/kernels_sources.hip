@@ -147,8 +147,9 @@ __device__ __forceinline__ void damping_ramps(const artemis_damping_t &p, const 
 
 // SelfDragSourceImpl (drag.hpp:171-294)
 __global__ __launch_bounds__(TX *TY) void self_drag_kernel(const PackView P, const artemis_drag_t D,
-                                                           double dt) {
+                                                           double dt_host, const double *dt_dev) {
   INTERIOR_CELL
+  const double dt = dt_dev ? *dt_dev : dt_host;
   const DCoords co = make_coords(P, b, k, j, i);
   const double xv[3] = {co.x1v(), co.x2v(), co.x3v()};
   double hx[3];
@@ -199,8 +200,9 @@ __global__ __launch_bounds__(TX *TY) void self_drag_kernel(const PackView P, con
 // (one gas species).
 template <bool FINISH>
 __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, const artemis_drag_t D,
-                                                             double dt) {
+                                                             double dt_host, const double *dt_dev) {
   INTERIOR_CELL
+  const double dt = dt_dev ? *dt_dev : dt_host;
   const DCoords co = make_coords(P, b, k, j, i);
   const double xv[3] = {co.x1v(), co.x2v(), co.x3v()};
   double hx[3];
@@ -318,17 +320,19 @@ void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, doub
 void launch_shearing_box(const PackView &P, double omega, double qshear, double dt, hipStream_t s) {
   hipLaunchKernelGGL(shearing_box_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, omega, qshear, dt);
 }
-void launch_drag_source(const PackView &P, const artemis_drag_t &D, double dt, hipStream_t s) {
+void launch_drag_source(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
+                        hipStream_t s) {
   if (D.type == ARTEMIS_DRAG_SELF)
-    hipLaunchKernelGGL(self_drag_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt);
+    hipLaunchKernelGGL(self_drag_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt, dt_dev);
   else
-    hipLaunchKernelGGL(simple_drag_kernel<false>, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt);
+    hipLaunchKernelGGL(simple_drag_kernel<false>, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt, dt_dev);
 }
 // simple_dust drag + SetAuxillaryFields + ConsToPrim of a one-gas-species pack in one pass: reads
 // cons0, writes the primitives of P (the general fused stage points them at its out tables)
-bool launch_drag_finish(const PackView &P, const artemis_drag_t &D, double dt, hipStream_t s) {
+bool launch_drag_finish(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
+                        hipStream_t s) {
   if (D.type != ARTEMIS_DRAG_SIMPLE_DUST || P.gas.ns != 1) return false;
-  hipLaunchKernelGGL(simple_drag_kernel<true>, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt);
+  hipLaunchKernelGGL(simple_drag_kernel<true>, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt, dt_dev);
   return true;
 }
 

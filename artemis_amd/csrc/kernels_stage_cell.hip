@@ -29,6 +29,7 @@ constexpr int TX = 64, TY = 4;
 
 struct CellStageArgs {
   double gam0, gam1, beta_dt, bdt;
+  const double *bdt_ptr; // optional device scalar beta*dt (replaces beta_dt and bdt)
   double *const *in, *const *u1, *const *out; // prim tables of this fluid
   int to_cons;                                // 1: store the post-source conserved state in cons0
   int grav_on, rf_on;
@@ -155,7 +156,7 @@ ADEV DustCons prim_to_cons_dust(const FluidView &f, double d, double v1, double 
 }
 
 template <int FLUID, int RIEMANN, int RECON, bool CURV>
-__global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, const CellStageArgs a) {
+__global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, const CellStageArgs a_in) {
   const int i = P.is + blockIdx.x * TX + threadIdx.x;
   const int j = P.js + blockIdx.y * TY + threadIdx.y;
   const int nkr = P.ke - P.ks + 1;
@@ -163,6 +164,8 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
   const int k = P.ks + blockIdx.z % nkr;
   if (i > P.ie || j > P.je) return;
   const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
+  CellStageArgs a = a_in;
+  if (a.bdt_ptr) a.beta_dt = a.bdt = *a.bdt_ptr; // wave-uniform scalar load
   const FluidView &f = (FLUID == 0) ? P.gas : P.dust;
   const int ns = f.ns, nv = (FLUID == 0 ? 6 : 4) * ns;
   const bool multi_d = P.ndim >= 2, three_d = P.ndim == 3;
@@ -346,6 +349,7 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
                        int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s) {
   CellStageArgs a;
   a.gam0 = g.gam0, a.gam1 = g.gam1, a.beta_dt = g.beta_dt, a.bdt = g.bdt;
+  a.bdt_ptr = g.beta_dt_dev;
   a.to_cons = g.drag ? 1 : 0;
   a.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;
   if (a.grav_on) a.grav = *g.gravity;
@@ -366,8 +370,8 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
   PackView Q = P; // the new state: prim tables are the out tables
   Q.gas.prim = g.gas_out, Q.dust.prim = g.dust_out;
   if (g.drag) { // coupled update on cons0, then SetAuxillaryFields and ConsToPrim into the out tables
-    if (!launch_drag_finish(Q, *g.drag, g.bdt, s)) { // one pass when one gas species is coupled
-      launch_drag_source(Q, *g.drag, g.bdt, s);
+    if (!launch_drag_finish(Q, *g.drag, g.bdt, g.beta_dt_dev, s)) { // one pass when one gas species is coupled
+      launch_drag_source(Q, *g.drag, g.bdt, g.beta_dt_dev, s);
       if (Q.gas.ns) launch_set_aux(Q, s);
       launch_cons_to_prim(Q, s);
     }

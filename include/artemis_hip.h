@@ -273,6 +273,8 @@ typedef struct artemis_stage_general_args {
   const artemis_drag_t *drag;
   double cfl_gas, cfl_dust;
   double *dt_dev;
+  const double *beta_dt_dev;  /* optional DEVICE scalar holding beta*dt of this stage; replaces the
+                                 host values beta_dt and bdt (synchronisation-free time loop) */
 } artemis_stage_general_args_t;
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
                               void *stream);

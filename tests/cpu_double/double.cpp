@@ -336,7 +336,10 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
 // The general-stage CONTRACT restated with the oracle's task chain (both fluids, every source
 // package): u1 := PrimToCons(*_u1), u0 := PrimToCons(*_in), the reference's task order, interior
 // of the new primitives (rho, v, sie) to *_out.
-int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *) {
+int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a_in, void *) {
+  artemis_stage_general_args_t args = *a_in;
+  if (args.beta_dt_dev) args.beta_dt = args.bdt = *args.beta_dt_dev; // "device" memory is host memory here
+  const artemis_stage_general_args_t *a = &args;
   if ((p->gas.nspecies && a->gas_in == a->gas_out) || (p->dust.nspecies && a->dust_in == a->dust_out))
     return bad("*_out must not alias *_in");
   for (int b = 0; b < p->nblocks; ++b) {

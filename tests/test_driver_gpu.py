@@ -476,3 +476,23 @@ def test_general_stage_path_equals_per_task_path(hiplib):
             if dust:
                 assert np.array_equal(f.field("dust.prim", b)[I], u.field("dust.prim", b)[I]), (deck, b)
         assert np.allclose(f.history(), u.history(), rtol=1e-13, atol=1e-15)
+
+
+def test_general_stage_sync_free_loop(hiplib, monkeypatch):
+    """Without a time limit the general fused stage also keeps {time, dt, beta*dt} on the device
+    (artemis_hip_advance_dt) and never synchronises; same bits as the host-side dt loop."""
+    from artemis_amd.driver import Simulation
+    ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "physics/dust=true", "physics/drag=true",
+          "dust/nspecies=2", "dust/cfl=0.3", "dust/reconstruct=plm", "dust/riemann=hlle", "dust/dfloor=1.0e-10",
+          "dust/stopping_time/type=constant", "dust/stopping_time/tau=0.01, 2.0", "drag/type=simple_dust",
+          "gravity/point/mass=1.0e-3", "parthenon/time/nlim=25", "parthenon/time/tlim=-1.0"]
+    a = Simulation(DECK("ssheet", "ssheet.in"), ov)
+    assert a.uses_fused_path and not a.uses_tuned_kernel
+    a.evolve()
+    monkeypatch.setenv("ARTEMIS_SYNC_LOOP", "1")
+    b = Simulation(DECK("ssheet", "ssheet.in"), ov)
+    b.evolve()
+    assert a.ncycle == b.ncycle == 25 and a.time == b.time and a.dt == b.dt
+    for blk in range(a.nblocks):
+        assert np.array_equal(a.field("gas.prim", blk), b.field("gas.prim", blk))
+        assert np.array_equal(a.field("dust.prim", blk), b.field("dust.prim", blk))
