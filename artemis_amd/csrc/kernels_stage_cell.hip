@@ -48,7 +48,7 @@ ADEV void load_stencil(const double *q, long c, long st, double w[7]) {
 // Cartesian PLM: the two faces of a cell need the limited slopes of three cells (c-1, c, c+1); the
 // cell's own slope serves both faces.  plm_dqm_fast is plm.hpp:32-47 with the hand-scheduled
 // division of device_math.hpp (same bits as `/`, checked by artemis_hip_selftest_divsqrt and by
-// the parity tests of this kernel against the oracle).
+// the parity tests of this kernel against the CPU restatement of the reference).
 ADEV void plm_pair_fast(const double w[7], double &Llo, double &Rlo, double &Lup, double &Rup) {
   const double sm = plm_dqm_fast(w[1], w[2], w[3]);
   const double sc = plm_dqm_fast(w[2], w[3], w[4]);
