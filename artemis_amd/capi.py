@@ -32,6 +32,7 @@ BC_PERIODIC, BC_OUTFLOW, BC_REFLECT, BC_NONE, BC_STRAT_EXTRAP, BC_STRAT_INFLOW =
 GRAVITY_UNIFORM, GRAVITY_POINT = 1, 2
 DRAG_SIMPLE_DUST, DRAG_SELF = 1, 2
 DRAG_CONSTANT, DRAG_STOKES = 0, 1
+DIFF_OFF, VISCOSITY_PLAW, VISCOSITY_ALPHA, CONDUCTIVITY_PLAW, THERMALDIFF_PLAW = range(5)
 MAX_DUST_SPECIES = 16
 RSOLVER = {"hllc": HLLC, "hlle": HLLE, "llf": LLF}
 RECON = {"pcm": PCM, "plm": PLM, "ppm": PPM}
@@ -47,7 +48,7 @@ class FluidPack(C.Structure):
         ("nspecies", C.c_int), ("recon", C.c_int), ("riemann", C.c_int),
         ("dfloor", C.c_double), ("siefloor", C.c_double), ("de_switch", C.c_double),
         ("prim", PP), ("cons0", PP), ("cons1", PP),
-        ("flux", PP * 3), ("pflux", PP * 3), ("vface", PP * 3),
+        ("flux", PP * 3), ("pflux", PP * 3), ("vface", PP * 3), ("diff_flux", PP * 3),
     ]
 
 
@@ -92,6 +93,17 @@ class Drag(C.Structure):
                 ("grain_density", C.c_double), ("tau", C.c_double * MAX_DUST_SPECIES),
                 ("sizes", C.c_double * MAX_DUST_SPECIES), ("gas", Damping), ("dust", Damping),
                 ("xmin", C.c_double * 3), ("xmax", C.c_double * 3)]
+
+
+class DiffCoeff(C.Structure):
+    _fields_ = [("type", C.c_int), ("avg", C.c_int), ("coeff", C.c_double), ("eta", C.c_double),
+                ("r_exp", C.c_double), ("r0", C.c_double), ("omega0", C.c_double),
+                ("temp_exp", C.c_double), ("rho_exp", C.c_double), ("rho_ref", C.c_double),
+                ("T_ref", C.c_double)]
+
+
+class Diffusion(C.Structure):
+    _fields_ = [("visc", DiffCoeff), ("cond", DiffCoeff), ("cv", C.c_double)]
 
 
 class StageGeneralArgs(C.Structure):
@@ -141,6 +153,11 @@ def load():
         "artemis_hip_drag_source": (i, [PPk, C.POINTER(Drag), d, d, vp]),
         "artemis_hip_stage_fused": (i, [PPk, C.POINTER(StageArgs), vp]),
         "artemis_hip_stage_general": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
+        "artemis_hip_zero_diffusion_flux": (i, [PPk, vp]),
+        "artemis_hip_viscous_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
+        "artemis_hip_thermal_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
+        "artemis_hip_diffusion_update": (i, [PPk, C.POINTER(Diffusion), d, vp]),
+        "artemis_hip_diffusion_dt": (i, [PPk, C.POINTER(Diffusion), d, vp, vp]),
         "artemis_hip_wait_counter": (i, [vp, C.c_uint, vp, vp]),
         "artemis_hip_advance_dt": (i, [vp, d, i, C.POINTER(d), vp]),
         "artemis_hip_metric_count": (C.c_long, [PPk]),
@@ -186,7 +203,9 @@ EXPORTS_HIP = [
     "artemis_hip_deep_copy_conserved", "artemis_hip_estimate_dt", "artemis_hip_estimate_dt_async",
     "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_metric_count",
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_rotating_frame_force",
-    "artemis_hip_drag_source", "artemis_hip_stage_general", "artemis_hip_halo_count",
+    "artemis_hip_drag_source", "artemis_hip_stage_general", "artemis_hip_zero_diffusion_flux",
+    "artemis_hip_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
+    "artemis_hip_diffusion_dt", "artemis_hip_halo_count",
     "artemis_hip_halo_pack", "artemis_hip_halo_unpack", "artemis_hip_last_error",
     "artemis_hip_device_count", "artemis_hip_version",
 ]

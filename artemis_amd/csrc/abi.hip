@@ -374,6 +374,64 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
   return after_launch("stage_fused");
 }
 
+// Diffusion guards shared by the four tasks (see include/artemis_hip.h for what is built)
+static int validate_diffusion(const artemis_pack_t *p, const artemis_diffusion_t *d, bool need_flux) {
+  if (int rc = validate(p)) return rc;
+  if (!d) return fail(ARTEMIS_HIP_EINVAL, "null diffusion parameters");
+  if (p->gas.nspecies < 1) return fail(ARTEMIS_HIP_EINVAL, "diffusion only works with a gas fluid");
+  if (p->coords != ARTEMIS_CARTESIAN)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "gas diffusion in curvilinear coordinates is not built");
+  if (p->nghost < 2) return fail(ARTEMIS_HIP_EINVAL, "gas diffusion needs nghost >= 2");
+  if (!(d->cv > 0.0)) return fail(ARTEMIS_HIP_EINVAL, "diffusion: specific heat cv must be positive");
+  for (const artemis_diffcoeff_t *c : {&d->visc, &d->cond}) {
+    if (c->type == ARTEMIS_DIFF_OFF) continue;
+    const bool is_visc = (c == &d->visc);
+    if (is_visc ? (c->type != ARTEMIS_VISCOSITY_PLAW && c->type != ARTEMIS_VISCOSITY_ALPHA)
+                : (c->type != ARTEMIS_CONDUCTIVITY_PLAW && c->type != ARTEMIS_THERMALDIFF_PLAW))
+      return fail(ARTEMIS_HIP_EINVAL, is_visc ? "Invalid viscosity type" : "Invalid conductivity type");
+    if (c->avg != 0 && c->avg != 1) return fail(ARTEMIS_HIP_EINVAL, "averaging is not supported");
+    if (c->type == ARTEMIS_VISCOSITY_ALPHA || c->r_exp != 0.0 || c->temp_exp != 0.0 || c->rho_exp != 0.0)
+      return fail(ARTEMIS_HIP_EUNSUPPORTED,
+                  "diffusion: power-law / alpha coefficients need std::pow per cell and are not built");
+  }
+  if (need_flux)
+    for (int dd = 0; dd < ((p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1)); ++dd)
+      if (!p->gas.diff_flux[dd]) return fail(ARTEMIS_HIP_EINVAL, "diffusion: gas.diff_flux tables are required");
+  return 0;
+}
+int artemis_hip_zero_diffusion_flux(const artemis_pack_t *p, void *stream) {
+  if (int rc = validate(p)) return rc;
+  for (int dd = 0; dd < ((p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1)); ++dd)
+    if (!p->gas.diff_flux[dd]) return fail(ARTEMIS_HIP_EINVAL, "diffusion: gas.diff_flux tables are required");
+  artemis::launch_zero_diffusion_flux(artemis::make_pack_view(*p), S(stream));
+  return after_launch("ZeroDiffusionFlux");
+}
+int artemis_hip_viscous_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream) {
+  if (int rc = validate_diffusion(p, d, true)) return rc;
+  if (d->visc.type == ARTEMIS_DIFF_OFF) return 0; // gas.cpp:545-546
+  artemis::launch_viscous_flux(artemis::make_pack_view(*p), *d, S(stream));
+  return after_launch("ViscousFlux");
+}
+int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream) {
+  if (int rc = validate_diffusion(p, d, true)) return rc;
+  if (d->cond.type == ARTEMIS_DIFF_OFF) return 0; // gas.cpp:582-583
+  artemis::launch_thermal_flux(artemis::make_pack_view(*p), *d, S(stream));
+  return after_launch("ThermalFlux");
+}
+int artemis_hip_diffusion_update(const artemis_pack_t *p, const artemis_diffusion_t *d, double dt,
+                                 void *stream) {
+  if (int rc = validate_diffusion(p, d, true)) return rc;
+  artemis::launch_diffusion_update(artemis::make_pack_view(*p), *d, dt, S(stream));
+  return after_launch("DiffusionUpdate");
+}
+int artemis_hip_diffusion_dt(const artemis_pack_t *p, const artemis_diffusion_t *d, double cfl,
+                             double *dt_dev, void *stream) {
+  if (int rc = validate_diffusion(p, d, false)) return rc;
+  if (!dt_dev) return fail(ARTEMIS_HIP_EINVAL, "null dt_dev");
+  artemis::launch_diffusion_dt(artemis::make_pack_view(*p), *d, cfl, dt_dev, S(stream));
+  return after_launch("Diffusion::EstimateTimestep");
+}
+
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
                               void *stream) {
   if (int rc = validate(p)) return rc;

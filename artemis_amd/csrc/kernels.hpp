@@ -30,6 +30,13 @@ void launch_advance_dt(double *state, double tlim, int nstages, const double *be
 void launch_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, hipStream_t s);
 int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon,
                        hipStream_t s);
+// kernels_diffusion.hip
+void launch_zero_diffusion_flux(const PackView &P, hipStream_t s);
+void launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s);
+void launch_thermal_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s);
+void launch_diffusion_update(const PackView &P, const artemis_diffusion_t &D, double dt, hipStream_t s);
+void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double cfl, double *dt_dev,
+                         hipStream_t s);
 // kernels_stage_cell.hip
 void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
                        int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s);

@@ -16,6 +16,7 @@ struct FluidView {
   double *const *flux[3];
   double *const *pflux[3];
   double *const *vface[3];
+  double *const *dflux[3]; // diffusion fluxes (gas)
 };
 
 struct PackView {
@@ -35,7 +36,8 @@ inline FluidView make_fluid_view(const artemis_fluid_pack_t &f) {
   v.ns = f.nspecies;
   v.dfloor = f.dfloor, v.siefloor = f.siefloor, v.de_switch = f.de_switch;
   v.prim = f.prim, v.cons0 = f.cons0, v.cons1 = f.cons1;
-  for (int d = 0; d < 3; ++d) v.flux[d] = f.flux[d], v.pflux[d] = f.pflux[d], v.vface[d] = f.vface[d];
+  for (int d = 0; d < 3; ++d)
+    v.flux[d] = f.flux[d], v.pflux[d] = f.pflux[d], v.vface[d] = f.vface[d], v.dflux[d] = f.diff_flux[d];
   return v;
 }
 

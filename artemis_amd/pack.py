@@ -26,7 +26,7 @@ class MeshBlockPack:
     def __init__(self, nblocks, nx, xmin, xmax, ng=2, ns_gas=1, ns_dust=0, reconstruct="plm",
                  riemann="hllc", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.66666666667,
                  dfloor=1.0e-20, siefloor=1.0e-20, de_switch=0.0, dust_dfloor=1.0e-20,
-                 device="cuda:0", with_fluxes=True, coordinates="cartesian"):
+                 device="cuda:0", with_fluxes=True, coordinates="cartesian", with_diffusion=False):
         """xmin/xmax: per-block interior bounds, arrays of shape [nblocks, 3]."""
         self.L = capi.load()
         self.dev = torch.device(device)
@@ -59,6 +59,7 @@ class MeshBlockPack:
         self.gas_pflux = [alloc(ns_gas) for _ in range(nf)]
         self.gas_vface = [alloc(ns_gas) for _ in range(nf)]
         self.dust_flux = [alloc(4 * ns_dust) for _ in range(nf)]
+        self.gas_diff_flux = [alloc(4 * ns_gas) for _ in range(3 if with_diffusion else 0)]
         self._tables = []
 
         def tab(t):
@@ -83,6 +84,8 @@ class MeshBlockPack:
         for d in range(nf):
             p.gas.flux[d], p.gas.pflux[d], p.gas.vface[d] = tab(self.gas_flux[d]), tab(self.gas_pflux[d]), tab(self.gas_vface[d])
             p.dust.flux[d] = tab(self.dust_flux[d])
+        for d in range(len(self.gas_diff_flux)):
+            p.gas.diff_flux[d] = tab(self.gas_diff_flux[d])
         self.pack = p
         # x2 trigonometry tables of spherical2D/3D (host libm, see include/artemis_hip.h)
         nmetric = self.L.artemis_hip_metric_count(C.byref(p))
@@ -170,6 +173,24 @@ class MeshBlockPack:
         a.dt_dev = dt_dev
         self._call(self.L.artemis_hip_stage_general, C.byref(a))
 
+    # ---- gas diffusion (artemis_driver.cpp:189-193, :218-221) -----------------------------------
+    def ZeroDiffusionFlux(self):
+        self._call(self.L.artemis_hip_zero_diffusion_flux)
+
+    def ViscousFlux(self, diffusion):
+        self._call(self.L.artemis_hip_viscous_flux, C.byref(diffusion))
+
+    def ThermalFlux(self, diffusion):
+        self._call(self.L.artemis_hip_thermal_flux, C.byref(diffusion))
+
+    def DiffusionUpdate(self, diffusion, dt):
+        self._call(self.L.artemis_hip_diffusion_update, C.byref(diffusion), dt)
+
+    def DiffusionTimestep(self, diffusion, cfl):
+        t = torch.full((1,), 1.7976931348623157e308, dtype=torch.float64, device=self.dev)
+        self._call(self.L.artemis_hip_diffusion_dt, C.byref(diffusion), cfl, t.data_ptr())
+        return t.item()
+
     # ---- source-term tasks (artemis_driver.cpp:222-241) ---------------------------------------
     def ExternalGravity(self, time, dt, gravity):
         """gravity: capi.Gravity (see gravity_point / gravity_uniform below)."""
@@ -250,4 +271,25 @@ def drag_params(type="simple_dust", model="constant", tau=(), scale=1.0, grain_d
         dst.orate[:] = list(src.get("outer_rate", (0.0,) * 3))
     d.xmin[:] = list(mesh_min)
     d.xmax[:] = list(mesh_max)
+    return d
+
+
+def diffusion_params(gamma, viscosity=None, conductivity=None, mu=1.0):
+    """capi.Diffusion from deck-style dicts: viscosity = dict(type="constant", nu=..., eta_bulk=0,
+    r_exp=0, averaging="arithmetic"), conductivity = dict(type="conductivity"|"diffusivity", cond= |
+    kappa=, temp_exp=0, rho_exp=0, ...).  cv = kB/((gamma-1) amu mu) in scale-free units."""
+    d = capi.Diffusion()
+    d.cv = 1.0 / ((gamma - 1.0) * 1.0 * mu)
+    if viscosity:
+        t = {"constant": capi.VISCOSITY_PLAW, "powerlaw": capi.VISCOSITY_PLAW, "alpha": capi.VISCOSITY_ALPHA}[viscosity.get("type", "constant")]
+        d.visc.type, d.visc.avg = t, {"arithmetic": 0, "harmonic": 1}[viscosity.get("averaging", "arithmetic")]
+        d.visc.coeff = viscosity.get("nu", viscosity.get("alpha", 0.0))
+        d.visc.eta, d.visc.r_exp, d.visc.r0 = viscosity.get("eta_bulk", 0.0), viscosity.get("r_exp", 0.0), viscosity.get("r0", 1.0)
+        d.visc.rho_ref = d.visc.T_ref = 1.0
+    if conductivity:
+        t = {"conductivity": capi.CONDUCTIVITY_PLAW, "diffusivity": capi.THERMALDIFF_PLAW}[conductivity.get("type", "conductivity")]
+        d.cond.type, d.cond.avg = t, {"arithmetic": 0, "harmonic": 1}[conductivity.get("averaging", "arithmetic")]
+        d.cond.coeff = conductivity.get("cond", conductivity.get("kappa", 0.0))
+        d.cond.temp_exp, d.cond.rho_exp = conductivity.get("temp_exp", 0.0), conductivity.get("rho_exp", 0.0)
+        d.cond.rho_ref, d.cond.T_ref, d.cond.r0 = conductivity.get("rho_ref", 1.0), conductivity.get("T_ref", 1.0), 1.0
     return d

@@ -77,6 +77,8 @@ typedef struct artemis_fluid_pack {
   double *const *flux[3];    /* [nblocks * ncons] per direction */
   double *const *pflux[3];   /* gas only: [nblocks * ns] interface pressure */
   double *const *vface[3];   /* gas only: [nblocks * ns] face-normal velocity */
+  double *const *diff_flux[3]; /* gas only, optional: [nblocks * 4ns] diffusion fluxes, gas::diff::momentum
+                                  (3n + component) then gas::diff::energy (3ns + n), gas.cpp:281-284 */
 } artemis_fluid_pack_t;
 
 typedef struct artemis_pack {
@@ -248,6 +250,38 @@ typedef struct artemis_stage_args {
                                  whose ghosts are cut from this block; 0 = all six */
 } artemis_stage_args_t;
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
+/* ---- gas diffusion (viscosity, heat conduction) ------------------------------------------
+ * Gas::ZeroDiffusionFlux / ViscousFlux<GEOM> / ThermalFlux<GEOM> / DiffusionUpdate<GEOM>
+ * (gas.cpp:522-641 -> utils/diffusion/{diffusion,momentum_diffusion,thermal_diffusion}.hpp),
+ * tasks at artemis_driver.cpp:189-193 and :218-221, and the diffusive timestep limit folded into
+ * Gas::EstimateTimestepMesh (gas.cpp:435-467, diffusion.hpp:66-108).  Fluxes go to
+ * p->gas.diff_flux[d] on faces [s, e+1] like the hydro fluxes.
+ * Built: Cartesian coordinates; constant coefficients, i.e. viscosity `constant`/`powerlaw` with
+ * r_exp = 0 and conductivity / diffusivity with temp_exp = rho_exp = 0 (the reference evaluates
+ * std::pow per cell for the power laws and the alpha viscosity: no bit-reproducible device
+ * counterpart), arithmetic or harmonic face averaging.  Everything else: ARTEMIS_HIP_EUNSUPPORTED. */
+enum artemis_diff_type { ARTEMIS_DIFF_OFF = 0, ARTEMIS_VISCOSITY_PLAW = 1, ARTEMIS_VISCOSITY_ALPHA = 2,
+                         ARTEMIS_CONDUCTIVITY_PLAW = 3, ARTEMIS_THERMALDIFF_PLAW = 4 };
+typedef struct artemis_diffcoeff { /* DiffCoeffParams, diffusion_coeff.hpp:58-136 */
+  int type;                   /* artemis_diff_type */
+  int avg;                    /* 0 arithmetic, 1 harmonic (diffusion_coeff.hpp:50-56) */
+  double coeff;               /* nu | alpha | cond | kappa */
+  double eta, r_exp, r0, omega0;
+  double temp_exp, rho_exp, rho_ref, T_ref;
+} artemis_diffcoeff_t;
+typedef struct artemis_diffusion {
+  artemis_diffcoeff_t visc, cond;
+  double cv;                  /* IdealGas specific heat: T = sie / cv (gas.cpp:106-116) */
+} artemis_diffusion_t;
+int artemis_hip_zero_diffusion_flux(const artemis_pack_t *p, void *stream);
+int artemis_hip_viscous_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream);
+int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream);
+int artemis_hip_diffusion_update(const artemis_pack_t *p, const artemis_diffusion_t *d, double dt,
+                                 void *stream);
+/* min-combines cfl * min(viscous, conductive limit) into the DEVICE scalar *dt_dev */
+int artemis_hip_diffusion_dt(const artemis_pack_t *p, const artemis_diffusion_t *d, double cfl,
+                             double *dt_dev, void *stream);
+
 /* General fused stage: the same contract as artemis_hip_stage_fused for EVERY configuration the
  * per-task entry points accept -- gas and/or dust, any number of species, PCM/PLM/PPM, all six
  * coordinate systems, with ExternalGravity, RotatingFrameForce and DragSource between FluxSource

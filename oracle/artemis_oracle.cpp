@@ -111,6 +111,16 @@ struct Sim {
   struct { // pgen/strat.hpp:44-52 (only what the user BCs read)
     Real q = 0, Om0 = 0;
   } strat;
+  // diffusion (utils/diffusion/diffusion_coeff.hpp:58-136 DiffCoeffParams); type 0 = package off
+  struct DiffCoeff {
+    int type = 0; // 1 viscosity_plaw, 2 viscosity_alpha, 3 conductivity_plaw, 4 thermaldiff_plaw
+    int avg = 0;  // 0 arithmetic, 1 harmonic
+    Real nu_s = 0, eta = 0, r_exp = 0, R0 = 1, alpha = 0, Omega0 = 0;
+    Real kappa_0 = 0, hcond_0 = 0, temp_exp = 0, rho_exp = 0, d0 = 1, T0 = 1;
+  };
+  DiffCoeff visc, cond;
+  Real cv = 0; // IdealGas Cv = kB / ((gamma-1) amu mu), gas.cpp:106-116 (set at creation)
+  std::vector<Real> qflux[3]; // gas::diff::momentum (3n+d) and gas::diff::energy (3ns+n) face fluxes
 };
 
 inline size_t IDX(const Sim &s, int k, int j, int i) {
@@ -1328,6 +1338,359 @@ void drag_source(Sim &s, Real dt) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Gas diffusion (artemis_driver.cpp:189-193, :218-221): ZeroDiffusionFlux, ViscousFlux,
+// ThermalFlux, DiffusionUpdate and the diffusive timestep limit.
+//
+// Coords<GEOM>::Distance (geometry.hpp:407-412): Cartesian distance between two points given in
+// the problem's coordinates.
+inline Real distance(const Coords &co, const Real a[3], const Real b[3]) {
+  Real xc1[3], xc2[3];
+  co.ConvertToCart(a, xc1);
+  co.ConvertToCart(b, xc2);
+  return std::sqrt(SQR(xc1[0] - xc2[0]) + SQR(xc1[1] - xc2[1]) + SQR(xc1[2] - xc2[2]));
+}
+// DiffusionCoeff<DIFF>::Get / evaluate (diffusion_coeff.hpp:190-381): dynamic viscosity rho*nu or
+// heat conductivity K of species n in cell (k,j,i).  EOS calls are the IdealGas closed forms
+// (singularity-eos, recalled): T = sie/Cv, Cv constant, B = gamma*gm1*rho*sie.
+inline Real diff_coeff(const Sim &s, const Sim::DiffCoeff &dp, int n, int k, int j, int i) {
+  const int nsp = s.c.ns_gas;
+  const size_t c = IDX(s, k, j, i);
+  const Real dens = s.gprim[n * s.N + c];
+  const Real sie = s.gprim[(5 * nsp + n) * s.N + c];
+  const Coords coords(s, k, j, i);
+  const Real xv[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
+  switch (dp.type) {
+  case 1: { // viscosity_plaw, :222-224
+    const CylVec cv = to_cyl_with_vec(coords, xv);
+    return dp.nu_s * dens * std::pow(cv.R / dp.R0, dp.r_exp);
+  }
+  case 2: { // viscosity_alpha, :262-268 (spherical radius of the cell centre)
+    Real xc[3];
+    coords.ConvertToCart(xv, xc);
+    const Real R = std::sqrt(xc[0] * xc[0] + xc[1] * xc[1]);
+    const Real r = coords.sph() ? xv[0] : std::sqrt(R * R + xc[2] * xc[2]);
+    const Real Omk = dp.Omega0 * std::pow(r / dp.R0, -1.5);
+    const Real gm1 = s.c.gamma - 1.0;
+    const Real blk = (gm1 + 1.0) * gm1 * dens * sie;
+    return dp.alpha * blk / Omk;
+  }
+  case 3: { // conductivity_plaw, :312-316
+    const Real T = std::max(0.0, sie / s.cv);
+    return dp.hcond_0 * std::pow(T / dp.T0, dp.temp_exp) * std::pow(dens / dp.d0, dp.rho_exp);
+  }
+  default: { // thermaldiff_plaw, :353-359
+    const Real cv = s.cv;
+    const Real T = std::max(0.0, sie / s.cv);
+    return dp.kappa_0 * std::pow(T / dp.T0, dp.temp_exp) * std::pow(dens / dp.d0, dp.rho_exp) *
+           dens * cv;
+  }
+  }
+}
+inline Real face_average(int avg, Real mu1, Real mu2) { // diffusion_coeff.hpp:139-150
+  return (avg == 0) ? 0.5 * (mu1 + mu2) : 2.0 * mu1 * mu2 / (mu1 + mu2);
+}
+
+// diffusion.hpp:27-64 ZeroDiffusionImpl
+void zero_diffusion_flux(Sim &s) {
+  for (int d = 0; d < 3; ++d) std::fill(s.qflux[d].begin(), s.qflux[d].end(), 0.0);
+}
+
+// momentum_diffusion.hpp:562-591 VelocityDivergence of cell (k,j,i)
+inline Real velocity_divergence(const Sim &s, int n, int k, int j, int i) {
+  const int nsp = s.c.ns_gas;
+  const int multid = (s.ndim >= 2), threed = (s.ndim == 3);
+  const Coords coords(s, k, j, i);
+  const Real vol = coords.Volume();
+  Real a1[2], a2[2] = {0.0, 0.0}, a3[2] = {0.0, 0.0};
+  coords.GetFaceAreaX1(a1);
+  if (multid) coords.GetFaceAreaX2(a2);
+  if (threed) coords.GetFaceAreaX3(a3);
+  const Real *v1 = s.gprim.data() + (nsp + 3 * n + 0) * s.N;
+  const Real *v2 = s.gprim.data() + (nsp + 3 * n + 1) * s.N;
+  const Real *v3 = s.gprim.data() + (nsp + 3 * n + 2) * s.N;
+  const Real divv = a1[1] * (v1[IDX(s, k, j, i)] + v1[IDX(s, k, j, i + 1)]) -
+                    a1[0] * (v1[IDX(s, k, j, i)] + v1[IDX(s, k, j, i - 1)]) +
+                    multid * a2[1] * (v2[IDX(s, k, j, i)] + v2[IDX(s, k, j + multid, i)]) -
+                    multid * a2[0] * (v2[IDX(s, k, j, i)] + v2[IDX(s, k, j - multid, i)]) +
+                    threed * a3[1] * (v3[IDX(s, k, j, i)] + v3[IDX(s, k + threed, j, i)]) -
+                    threed * a3[0] * (v3[IDX(s, k, j, i)] + v3[IDX(s, k - threed, j, i)]);
+  return divv / (2.0 * vol);
+}
+
+// momentum_diffusion.hpp:28-377 StrainTensorFace<XDIR>: the three components T_*^dir on the lower
+// dir-face of cell (k,j,i).  Written once for the three directions with index offsets:
+// `a` = the face-normal direction, `b`, `c` = the two transverse ones in cyclic x1,x2,x3 order of
+// the reference's per-direction code (x1: b=x2,c=x3; x2: b=x1,c=x3; x3: b=x1,c=x2).
+struct Off {
+  int dk, dj, di;
+};
+inline void strain_face(const Sim &s, int dir, int n, int k, int j, int i, Real flx[3]) {
+  const int nsp = s.c.ns_gas;
+  const int multid = (s.ndim >= 2), threed = (s.ndim == 3);
+  auto vel = [&](int comp, int kk, int jj, int ii) {
+    return s.gprim[(nsp + 3 * n + comp) * s.N + IDX(s, kk, jj, ii)];
+  };
+  auto centre = [&](const Coords &co, Real x[3]) { x[0] = co.x1v(), x[1] = co.x2v(), x[2] = co.x3v(); };
+  const Coords coords(s, k, j, i);
+  Real xv[3], hx[3];
+  centre(coords, xv);
+  coords.GetScaleFactors(hx);
+  const Real v[3] = {vel(0, k, j, i) / hx[0], vel(1, k, j, i) / hx[1], vel(2, k, j, i) / hx[2]};
+  Real xf[3];
+  if (dir == 1) coords.FaceCenX1(0, xf);
+  else if (dir == 2) coords.FaceCenX2(0, xf);
+  else coords.FaceCenX3(0, xf);
+  const Real hxf[3] = {coords.hx1(xf[0], xf[1], xf[2]), coords.hx2(xf[0], xf[1], xf[2]),
+                       coords.hx3(xf[0], xf[1], xf[2])};
+  const Real fuzz = 1e-99;
+  // scaled velocity component `comp` of the cell at (kk,jj,ii): v / hx_v
+  auto sv = [&](int comp, int kk, int jj, int ii) {
+    Real h[3];
+    Coords(s, kk, jj, ii).GetScaleFactors(h);
+    return vel(comp, kk, jj, ii) / h[comp];
+  };
+  auto dist = [&](int k1, int j1, int i1, int k2, int j2, int i2) {
+    Real a[3], b[3];
+    centre(Coords(s, k1, j1, i1), a);
+    centre(Coords(s, k2, j2, i2), b);
+    return distance(coords, a, b);
+  };
+  // dh_a/dx_k contraction v^k dh_a/dx_k / h_a of a cell (only dh2dx1, dh3dx1, dh3dx2 are non-zero)
+  auto src_of = [&](int a, int kk, int jj, int ii) {
+    const Coords co(s, kk, jj, ii);
+    Real h[3];
+    co.GetScaleFactors(h);
+    const Real dh[3][3] = {{0.0, 0.0, 0.0}, {co.dh2dx1(), 0.0, 0.0}, {co.dh3dx1(), co.dh3dx2(), 0.0}};
+    return vel(0, kk, jj, ii) / h[0] * dh[a][0] + vel(1, kk, jj, ii) / h[1] * dh[a][1] +
+           vel(2, kk, jj, ii) / h[2] * dh[a][2];
+  };
+  if (dir == 1) {
+    const Real dx1 = dist(k, j, i, k, j, i - 1);
+    const Real dx2 = multid ? dist(k, j - multid, i, k, j + multid, i) : fuzz;
+    const Real dx2_xm = multid ? dist(k, j - multid, i - 1, k, j + multid, i - 1) : fuzz;
+    const Real dx3 = threed ? dist(k - threed, j, i, k + threed, j, i) : fuzz;
+    const Real dx3_xm = threed ? dist(k - threed, j, i - 1, k + threed, j, i - 1) : fuzz;
+    const Real dv1 = v[0] - sv(0, k, j, i - 1);
+    const Real src = src_of(0, k, j, i);
+    const Real src_xm = src_of(0, k, j, i - 1);
+    flx[0] = 2 * dv1 / dx1 + 0.5 * (src + src_xm);
+    const Real dv2 = v[1] - sv(1, k, j, i - 1);
+    const Real dv12 = sv(0, k, j + multid, i) - sv(0, k, j - multid, i);
+    const Real dv12_xm = sv(0, k, j + multid, i - 1) - sv(0, k, j - multid, i - 1);
+    flx[1] = multid * 0.5 * (dv12 / dx2 + dv12_xm / dx2_xm) + SQR(hxf[1] / hxf[0]) * dv2 / dx1;
+    const Real dv3 = v[2] - sv(2, k, j, i - 1);
+    const Real dv13 = sv(0, k + threed, j, i) - sv(0, k - threed, j, i);
+    const Real dv13_xm = sv(0, k + threed, j, i - 1) - sv(0, k - threed, j, i - 1);
+    flx[2] = threed * 0.5 * (dv13 / dx3 + dv13_xm / dx3_xm) + SQR(hxf[2] / hxf[0]) * dv3 / dx1;
+  } else if (dir == 2) {
+    const Real dx1 = dist(k, j, i - 1, k, j, i + 1);
+    const Real dx1_ym = dist(k, j - 1, i - 1, k, j - 1, i + 1);
+    const Real dx2 = dist(k, j, i, k, j - 1, i);
+    const Real dx3 = threed ? dist(k - threed, j, i, k + threed, j, i) : fuzz;
+    const Real dx3_ym = threed ? dist(k - threed, j - 1, i, k + threed, j - 1, i) : fuzz;
+    const Real dv1 = v[0] - sv(0, k, j - 1, i);
+    const Real dv21 = sv(1, k, j, i + 1) - sv(1, k, j, i - 1);
+    const Real dv21_ym = sv(1, k, j - 1, i + 1) - sv(1, k, j - 1, i - 1);
+    flx[0] = 0.5 * (dv21 / dx1 + dv21_ym / dx1_ym) + SQR(hxf[0] / hxf[1]) * dv1 / dx2;
+    const Real dv2 = v[1] - sv(1, k, j - 1, i);
+    const Real src = src_of(1, k, j, i);
+    const Real src_ym = src_of(1, k, j - 1, i);
+    flx[1] = 2 * dv2 / dx2 + 0.5 * (src + src_ym);
+    const Real dv3 = v[2] - sv(2, k, j - 1, i);
+    const Real dv23 = sv(1, k + threed, j, i) - sv(1, k - threed, j, i);
+    const Real dv23_ym = sv(1, k + threed, j - 1, i) - sv(1, k - threed, j - 1, i);
+    flx[2] = threed * 0.5 * (dv23 / dx3 + dv23_ym / dx3_ym) + SQR(hxf[2] / hxf[1]) * dv3 / dx2;
+  } else {
+    const Real dx1 = dist(k, j, i - 1, k, j, i + 1);
+    const Real dx1_zm = dist(k - 1, j, i - 1, k - 1, j, i + 1);
+    const Real dx2 = dist(k, j - 1, i, k, j + 1, i);
+    const Real dx2_zm = dist(k - 1, j - 1, i, k - 1, j + 1, i);
+    const Real dx3 = dist(k, j, i, k - 1, j, i);
+    const Real dv1 = v[0] - sv(0, k - 1, j, i);
+    const Real dv31 = sv(2, k, j, i + 1) - sv(2, k, j, i - 1);
+    const Real dv31_zm = sv(2, k - 1, j, i + 1) - sv(2, k - 1, j, i - 1);
+    flx[0] = 0.5 * (dv31 / dx1 + dv31_zm / dx1_zm) + SQR(hxf[0] / hxf[2]) * dv1 / dx3;
+    const Real dv2 = v[1] - sv(1, k - 1, j, i);
+    const Real dv32 = sv(2, k, j + 1, i) - sv(2, k, j - 1, i);
+    const Real dv32_zm = sv(2, k - 1, j + 1, i) - sv(2, k - 1, j - 1, i);
+    flx[1] = 0.5 * (dv32 / dx2 + dv32_zm / dx2_zm) + SQR(hxf[1] / hxf[2]) * dv2 / dx3;
+    const Real dv3 = v[2] - sv(2, k - 1, j, i);
+    const Real src = src_of(2, k, j, i);
+    const Real src_zm = src_of(2, k - 1, j, i);
+    flx[2] = 2 * dv3 / dx3 + 0.5 * (src + src_zm);
+  }
+}
+
+// momentum_diffusion.hpp:597-755 MomentumFluxImpl + StressTensorFaceX1/2/3 (:379-560): viscous
+// momentum and energy fluxes ADDED to the diffusion flux arrays on faces [s, e+1] of each active
+// direction (the face's value is a pure function of its neighbourhood, so the reference's
+// scratch-row bookkeeping reduces to a loop over faces).
+void viscous_flux(Sim &s) {
+  const Sim::DiffCoeff &dp = s.visc;
+  if (dp.type == 0 || !s.c.ns_gas) return;
+  const int nsp = s.c.ns_gas;
+  for (int dir = 1; dir <= s.ndim; ++dir) {
+    const int dk = (dir == 3), dj = (dir == 2), di = (dir == 1);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = s.ks; k <= s.ke + dk; ++k)
+      for (int j = s.js; j <= s.je + dj; ++j)
+        for (int i = s.is; i <= s.ie + di; ++i) {
+          const Coords coords(s, k, j, i), coords_m(s, k - dk, j - dj, i - di);
+          Real hx[3], hx_m[3], xf[3];
+          coords.GetScaleFactors(hx), coords_m.GetScaleFactors(hx_m);
+          Real hf;
+          if (dir == 1) coords.FaceCenX1(0, xf), hf = coords.hx1(xf[0], xf[1], xf[2]);
+          else if (dir == 2) coords.FaceCenX2(0, xf), hf = coords.hx2(xf[0], xf[1], xf[2]);
+          else coords.FaceCenX3(0, xf), hf = coords.hx3(xf[0], xf[1], xf[2]);
+          const size_t c = IDX(s, k, j, i), cm = IDX(s, k - dk, j - dj, i - di);
+          for (int n = 0; n < nsp; ++n) {
+            Real flx[3];
+            strain_face(s, dir, n, k, j, i, flx);
+            const Real mu = diff_coeff(s, dp, n, k, j, i);
+            const Real mu_m = diff_coeff(s, dp, n, k - dk, j - dj, i - di);
+            const Real divu = velocity_divergence(s, n, k, j, i);
+            const Real divu_m = velocity_divergence(s, n, k - dk, j - dj, i - di);
+            const Real mus = (dp.avg == 0) * face_average(0, mu, mu_m) + (dp.avg == 1) * face_average(1, mu, mu_m);
+            Real f[3];
+            for (int q = 0; q < 3; ++q) f[q] = hf * mus * flx[q];
+            // the normal component carries the bulk term (:411, :468, :524)
+            f[dir - 1] = hf * mus * (flx[dir - 1] - 1. / 3 * (1. - dp.eta) * (divu + divu_m));
+            std::vector<Real> &qf = s.qflux[dir - 1];
+            for (int q = 0; q < 3; ++q) qf[(3 * n + q) * s.N + c] += f[q];
+            const Real *v1 = s.gprim.data() + (nsp + 3 * n + 0) * s.N;
+            const Real *v2 = s.gprim.data() + (nsp + 3 * n + 1) * s.N;
+            const Real *v3 = s.gprim.data() + (nsp + 3 * n + 2) * s.N;
+            qf[(3 * nsp + n) * s.N + c] += 0.5 * (v1[c] / hx[0] + v1[cm] / hx_m[0]) * f[0] +
+                                           0.5 * (v2[c] / hx[1] + v2[cm] / hx_m[1]) * f[1] +
+                                           0.5 * (v3[c] / hx[2] + v3[cm] / hx_m[2]) * f[2];
+          }
+        }
+  }
+}
+
+// thermal_diffusion.hpp:30-222 ThermalFluxImpl: F = K (T - T_m) / |x - x_m| added to the energy
+// diffusion flux on faces [s, e+1] of each active direction.
+void thermal_flux(Sim &s) {
+  const Sim::DiffCoeff &dp = s.cond;
+  if (dp.type == 0 || !s.c.ns_gas) return;
+  const int nsp = s.c.ns_gas;
+  for (int dir = 1; dir <= s.ndim; ++dir) {
+    const int dk = (dir == 3), dj = (dir == 2), di = (dir == 1);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = s.ks; k <= s.ke + dk; ++k)
+      for (int j = s.js; j <= s.je + dj; ++j)
+        for (int i = s.is; i <= s.ie + di; ++i) {
+          const Coords coords(s, k, j, i), coords_m(s, k - dk, j - dj, i - di);
+          const Real xv[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
+          const Real xv_m[3] = {coords_m.x1v(), coords_m.x2v(), coords_m.x3v()};
+          const Real dx = distance(coords, xv, xv_m);
+          const size_t c = IDX(s, k, j, i), cm = IDX(s, k - dk, j - dj, i - di);
+          for (int n = 0; n < nsp; ++n) {
+            const Real T = std::max(0.0, s.gprim[(5 * nsp + n) * s.N + c] / s.cv);
+            const Real Tm = std::max(0.0, s.gprim[(5 * nsp + n) * s.N + cm] / s.cv);
+            const Real ka = diff_coeff(s, dp, n, k, j, i);
+            const Real kb = diff_coeff(s, dp, n, k - dk, j - dj, i - di);
+            const Real kcond = (dp.avg == 0) * face_average(0, ka, kb) + (dp.avg == 1) * face_average(1, ka, kb);
+            s.qflux[dir - 1][(3 * nsp + n) * s.N + c] += kcond * (T - Tm) / dx;
+          }
+        }
+  }
+}
+
+// diffusion.hpp:110-241 DiffusionUpdateImpl
+void diffusion_update(Sim &s, Real dt) {
+  if ((s.visc.type == 0 && s.cond.type == 0) || !s.c.ns_gas) return;
+  const bool do_viscosity = (s.visc.type != 0);
+  const int nsp = s.c.ns_gas;
+  const int multi_d = (s.ndim > 1), three_d = (s.ndim > 2);
+  const ptrdiff_t sj = s.ni, sk = static_cast<ptrdiff_t>(s.ni) * s.nj;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = s.ks; k <= s.ke; ++k)
+    for (int j = s.js; j <= s.je; ++j)
+      for (int i = s.is; i <= s.ie; ++i) {
+        const Coords coords(s, k, j, i);
+        const bool x1dep = coords.x1dep();
+        const bool x2dep = coords.x2dep() && multi_d;
+        const bool x3dep = false;
+        Real ax1[2], ax2[2] = {0.0, 0.0}, ax3[2] = {0.0, 0.0};
+        coords.GetFaceAreaX1(ax1);
+        if (multi_d) coords.GetFaceAreaX2(ax2);
+        if (three_d) coords.GetFaceAreaX3(ax3);
+        Real dhdx1[3] = {0.0, 0.0, 0.0}, dhdx2[3] = {0.0, 0.0, 0.0}, dhdx3[3] = {0.0, 0.0, 0.0};
+        if (x1dep) coords.GetConnX1(dhdx1);
+        if (x2dep) coords.GetConnX2(dhdx2);
+        Real hx[3];
+        coords.GetScaleFactors(hx);
+        const Real vol = coords.Volume();
+        const size_t c = IDX(s, k, j, i);
+        const size_t c2 = c + multi_d * sj, c3 = c + three_d * sk;
+        for (int n = 0; n < nsp; ++n) {
+          auto F = [&](int d, int var, size_t cc) { return s.qflux[d][var * s.N + cc]; };
+          const int imx1 = 3 * n + 0, imx2 = 3 * n + 1, imx3 = 3 * n + 2, ien = 3 * nsp + n;
+          Real divfxm = 0., divfym = 0., divfzm = 0.;
+          if (do_viscosity) {
+            auto divergence = [&](int var) {
+              return (ax1[0] * F(0, var, c) - ax1[1] * F(0, var, c + 1)) +
+                     multi_d * (ax2[0] * F(1, var, c) - ax2[1] * F(1, var, c2)) +
+                     three_d * (ax3[0] * F(2, var, c) - ax3[1] * F(2, var, c3));
+            };
+            auto metric_src = [&](const Real dh[3]) {
+              return dh[0] * 0.5 * (F(0, imx1, c) + F(0, imx1, c + 1)) +
+                     multi_d * dh[1] * 0.5 * (F(1, imx2, c) + F(1, imx2, c2)) +
+                     three_d * dh[2] * 0.5 * (F(2, imx3, c) + F(2, imx3, c3));
+            };
+            divfxm = divergence(imx1);
+            divfxm /= vol;
+            divfxm += x1dep * metric_src(dhdx1);
+            divfym = divergence(imx2);
+            divfym /= vol;
+            divfym += x2dep * metric_src(dhdx2);
+            divfzm = divergence(imx3);
+            divfzm /= vol;
+            divfzm += x3dep * metric_src(dhdx3);
+          }
+          Real divfe = (ax1[0] * F(0, ien, c) - ax1[1] * F(0, ien, c + 1)) +
+                       multi_d * (ax2[0] * F(1, ien, c) - ax2[1] * F(1, ien, c2)) +
+                       three_d * (ax3[0] * F(2, ien, c) - ax3[1] * F(2, ien, c3));
+          divfe /= vol;
+          s.gu0[(nsp + 3 * n + 0) * s.N + c] -= dt * divfxm;
+          s.gu0[(nsp + 3 * n + 1) * s.N + c] -= dt * divfym;
+          s.gu0[(nsp + 3 * n + 2) * s.N + c] -= dt * divfzm;
+          s.gu0[(4 * nsp + n) * s.N + c] -= dt * divfe;
+          s.gu0[(5 * nsp + n) * s.N + c] -=
+              dt * divfe - dt * (divfxm * s.gprim[(nsp + 3 * n + 0) * s.N + c] / hx[0] +
+                                 divfym * s.gprim[(nsp + 3 * n + 1) * s.N + c] / hx[1] +
+                                 divfzm * s.gprim[(nsp + 3 * n + 2) * s.N + c] / hx[2]);
+        }
+      }
+}
+
+// diffusion.hpp:66-108 EstimateTimestep<DIFF>: min over cells of dx_min^2 / diffusivity, / (2 ndim)
+Real diffusion_dt(const Sim &s, const Sim::DiffCoeff &dp) {
+  Real min_dt = std::numeric_limits<Real>::max();
+  if (dp.type == 0 || !s.c.ns_gas) return min_dt;
+  const int nsp = s.c.ns_gas;
+#pragma omp parallel for collapse(2) schedule(static) reduction(min : min_dt)
+  for (int k = s.ks; k <= s.ke; ++k)
+    for (int j = s.js; j <= s.je; ++j)
+      for (int i = s.is; i <= s.ie; ++i) {
+        Real dx[3];
+        Coords(s, k, j, i).GetCellWidths(dx);
+        Real min_dx = std::numeric_limits<Real>::max();
+        for (int d = 0; d < s.ndim; d++) min_dx = std::min(min_dx, dx[d]);
+        const size_t c = IDX(s, k, j, i);
+        for (int n = 0; n < nsp; ++n) {
+          const Real dens = s.gprim[n * s.N + c];
+          Real mu = diff_coeff(s, dp, n, k, j, i);
+          if (dp.type == 3) mu /= (dens * s.cv);
+          else if (dp.type == 1 || dp.type == 2) mu *= (1.0 + (dp.eta > 1.0) * (dp.eta - 1.0)) / dens;
+          min_dt = std::min(min_dt, SQR(min_dx) / (mu + 1e-99));
+        }
+      }
+  return min_dt / (2.0 * s.ndim);
+}
+
+// ---------------------------------------------------------------------------------------
 // derived/fill_derived.cpp:30-75 SetAuxillaryFields + utils/artemis_utils.hpp:43-62
 // GetSpecificInternalEnergy (hx = volume-averaged scale factors, fill_derived.cpp:127 analogue).
 void set_aux(Sim &s) {
@@ -1472,7 +1835,11 @@ Real estimate_dt(const Sim &s, int fluid) {
           min_dt = std::min(min_dt, 1.0 / denom);
         }
       }
-  return ((fluid == FL_GAS) ? s.c.cfl_gas : s.c.cfl_dust) * min_dt;
+  if (fluid == FL_GAS) { // gas.cpp:435-467: cfl * min(hydro, viscous, conductive)
+    const Real diff_dt = std::min(diffusion_dt(s, s.visc), diffusion_dt(s, s.cond));
+    return s.c.cfl_gas * std::min(min_dt, diff_dt);
+  }
+  return s.c.cfl_dust * min_dt;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1648,9 +2015,15 @@ void step(Sim &s, exchange_fn xchg, void *ctx) {
     const bool do_pcm = ((stage == 1) && (s.c.integrator == INT_VL2));   // :182
     calculate_fluxes(s, FL_GAS, do_pcm);                                 // :184
     calculate_fluxes(s, FL_DUST, do_pcm);                                // :185
+    if (s.visc.type || s.cond.type) {                                    // :189-194
+      zero_diffusion_flux(s);
+      viscous_flux(s);
+      thermal_flux(s);
+    }
     apply_update(s, g0[stage - 1], g1[stage - 1], be[stage - 1] * s.dt); // :205-207
     flux_source(s, FL_GAS, bdt);                                         // :211
     flux_source(s, FL_DUST, bdt);                                        // :212
+    diffusion_update(s, bdt);                                            // :218-221
     external_gravity(s, s.time, bdt);                                    // :224-228
     rotating_frame_force(s, bdt);                                        // :231-235
     drag_source(s, bdt);                                                 // :238-241
@@ -1702,6 +2075,8 @@ void *oracle_create(const oracle_cfg *cfg) {
     s->gvface[d].assign(c.ns_gas * s->N, 0.0);
     s->dflux[d].assign(s->nvd * s->N, 0.0);
   }
+  for (int d = 0; d < 3; ++d) s->qflux[d].assign(static_cast<size_t>(4) * c.ns_gas * s->N, 0.0);
+  s->cv = 1.0 / ((c.gamma - 1.) * 1.0 * 1.0);
   s->time = 0.0, s->dt = std::numeric_limits<Real>::max(), s->ncycle = 0;
   s->gx1min = c.x1min, s->gx1max = c.x1max, s->gx2min = c.x2min, s->gx2max = c.x2max;
   s->gx3min = c.x3min, s->gx3max = c.x3max;
@@ -1949,6 +2324,61 @@ void oracle_external_gravity(void *h, double time, double dt) {
 }
 void oracle_rotating_frame_force(void *h, double dt) { rotating_frame_force(*static_cast<Sim *>(h), dt); }
 void oracle_drag_source(void *h, double dt) { drag_source(*static_cast<Sim *>(h), dt); }
+
+// <gas/viscosity> / <gas/conductivity> (diffusion_coeff.hpp:84-136).  which: 0 viscosity, 1 conductivity;
+// type: 1 viscosity_plaw (constant|powerlaw), 2 viscosity_alpha, 3 conductivity_plaw, 4 thermaldiff_plaw;
+// p = {nu|alpha|cond|kappa, eta_bulk, r_exp, r0, Omega0, temp_exp, rho_exp, rho_ref, T_ref}
+void oracle_set_diffusion(void *h, int which, int type, int avg, const double *p) {
+  Sim &s = *static_cast<Sim *>(h);
+  Sim::DiffCoeff &d = which ? s.cond : s.visc;
+  d.type = type, d.avg = avg;
+  d.nu_s = d.alpha = d.hcond_0 = d.kappa_0 = p[0];
+  d.eta = p[1], d.r_exp = p[2], d.R0 = p[3], d.Omega0 = p[4];
+  d.temp_exp = p[5], d.rho_exp = p[6], d.d0 = p[7], d.T0 = p[8];
+}
+void oracle_zero_diffusion_flux(void *h) { zero_diffusion_flux(*static_cast<Sim *>(h)); }
+void oracle_viscous_flux(void *h) { viscous_flux(*static_cast<Sim *>(h)); }
+void oracle_thermal_flux(void *h) { thermal_flux(*static_cast<Sim *>(h)); }
+void oracle_diffusion_update(void *h, double dt) { diffusion_update(*static_cast<Sim *>(h), dt); }
+double *oracle_qflux(void *h, int d) { return static_cast<Sim *>(h)->qflux[d].data(); }
+
+// pgen/gaussian_bump.hpp:46-196 with problem/system = cartesian on a Cartesian mesh
+void oracle_pgen_gaussian_bump(void *h, const double *xc_bump, double sigma, double dfac, double tfac,
+                               double ufac, double vfac, double wfac, double g_rho, double g_vx1,
+                               double g_vx2, double g_vx3, double g_pres) {
+  Sim &s = *static_cast<Sim *>(h);
+  const int nsp = s.c.ns_gas;
+  const bool multi_d = (s.ndim >= 2), three_d = (s.ndim == 3);
+  const Real gamma = s.c.gamma;
+  const Real ex1[3] = {1.0, 0.0, 0.0}, ex2[3] = {0.0, 1.0, 0.0}, ex3[3] = {0.0, 0.0, 1.0};
+  for (int k = 0; k < s.nk; ++k)
+    for (int j = 0; j < s.nj; ++j)
+      for (int i = 0; i < s.ni; ++i) {
+        const BBox b = bbox(s, k, j, i);
+        const Real xc[3] = {x1v(b), x2v(b), x3v(b)};
+        const Real dx2 = SQR(xc[0] - xc_bump[0]) + SQR(xc[1] - xc_bump[1]) * multi_d +
+                         SQR(xc[2] - xc_bump[2]) * three_d;
+        const Real bump = std::exp(-dx2 / (2.0 * SQR(sigma)));
+        const size_t c = IDX(s, k, j, i);
+        const Real vx1 = (g_vx1 * ex1[0] + g_vx2 * ex1[1] + g_vx3 * ex1[2]);
+        const Real vx2 = (g_vx1 * ex2[0] + g_vx2 * ex2[1] + g_vx3 * ex2[2]);
+        const Real vx3 = (g_vx1 * ex3[0] + g_vx2 * ex3[1] + g_vx3 * ex3[2]);
+        s.gprim[(nsp + 0) * s.N + c] = vx1 + ufac * bump;
+        s.gprim[(nsp + 1) * s.N + c] = vx2 + vfac * bump;
+        s.gprim[(nsp + 2) * s.N + c] = vx3 + wfac * bump;
+        if (tfac > 0.0) {
+          const Real sie0 = g_pres / (g_rho * (gamma - 1.0));
+          const Real sie = sie0 * (1. + tfac * bump);
+          s.gprim[0 * s.N + c] = g_pres / (sie * (gamma - 1.0));
+          s.gprim[(5 * nsp) * s.N + c] = sie;
+        } else {
+          const Real dens = g_rho * (1. + dfac * bump);
+          s.gprim[0 * s.N + c] = dens;
+          s.gprim[(5 * nsp) * s.N + c] = g_pres / ((gamma - 1.0) * dens);
+        }
+      }
+  prim_to_cons(s);
+}
 
 // pgen/constant.hpp:58-166 with problem/system = cartesian on a Cartesian mesh (the basis
 // conversion is the identity); sie = Cv*T with Cv = kB/((gamma-1) amu mu) = 1/(gamma-1) in

@@ -119,6 +119,13 @@ def lib():
         L.oracle_drag_source.argtypes = [vp, d]
         L.oracle_pgen_constant.argtypes = [vp] + [d] * 9
         L.oracle_pgen_strat.argtypes = [vp] + [d] * 4
+        L.oracle_set_diffusion.argtypes = [vp, i, i, i, C.POINTER(d)]
+        for f in ("zero_diffusion_flux", "viscous_flux", "thermal_flux"):
+            getattr(L, "oracle_" + f).argtypes = [vp]
+        L.oracle_diffusion_update.argtypes = [vp, d]
+        L.oracle_qflux.restype = C.POINTER(d)
+        L.oracle_qflux.argtypes = [vp, i]
+        L.oracle_pgen_gaussian_bump.argtypes = [vp, C.POINTER(d)] + [d] * 11
         _lib = L
     return _lib
 
@@ -278,6 +285,40 @@ class Oracle:
 
     def pgen_strat(self, rho0=1.0, dens_min=1.0e-5, h=1.0, dust_to_gas=0.01, post_init=True):
         self.L.oracle_pgen_strat(self.h, rho0, dens_min, h, dust_to_gas)
+        if post_init:
+            self.post_init()
+
+    def set_viscosity(self, type="constant", nu=0.0, alpha=0.0, eta_bulk=0.0, r_exp=0.0, r0=1.0,
+                      Omega0=0.0, averaging="arithmetic"):
+        """<gas/viscosity> type = constant|powerlaw|alpha, nu|alpha, eta_bulk, r_exp, averaging"""
+        t = {"constant": 1, "powerlaw": 1, "alpha": 2}[type]
+        p = (C.c_double * 9)(nu if t == 1 else alpha, eta_bulk, r_exp, r0, Omega0, 0.0, 0.0, 1.0, 1.0)
+        self.L.oracle_set_diffusion(self.h, 0, t, {"arithmetic": 0, "harmonic": 1}[averaging], p)
+
+    def set_conductivity(self, type="conductivity", cond=0.0, kappa=0.0, temp_exp=0.0, rho_exp=0.0,
+                         rho_ref=1.0, T_ref=1.0, averaging="arithmetic"):
+        """<gas/conductivity> type = conductivity|diffusivity, cond|kappa, temp_exp, rho_exp, ..."""
+        t = {"conductivity": 3, "diffusivity": 4}[type]
+        p = (C.c_double * 9)(cond if t == 3 else kappa, 0.0, 0.0, 1.0, 0.0, temp_exp, rho_exp, rho_ref, T_ref)
+        self.L.oracle_set_diffusion(self.h, 1, t, {"arithmetic": 0, "harmonic": 1}[averaging], p)
+
+    def ZeroDiffusionFlux(self): self.L.oracle_zero_diffusion_flux(self.h)
+    def ViscousFlux(self): self.L.oracle_viscous_flux(self.h)
+    def ThermalFlux(self): self.L.oracle_thermal_flux(self.h)
+    def DiffusionUpdate(self, dt): self.L.oracle_diffusion_update(self.h, dt)
+
+    def qflux(self, d):
+        """gas::diff::momentum (3n+c) and gas::diff::energy (3ns+n) face fluxes of direction d"""
+        nv = 4 * self.cfg.ns_gas
+        p = self.L.oracle_qflux(self.h, d)
+        return np.ctypeslib.as_array(p, shape=(nv, self.nk, self.nj, self.ni))
+
+    def pgen_gaussian_bump(self, sigma, centre=(0.0, 0.0, 0.0), density_bump=0.0, temperature_bump=0.0,
+                           v_bump=(0.0, 0.0, 0.0), gas_rho=1.0, gas_v=(0.0, 0.0, 0.0), gas_pres=1.0,
+                           post_init=True):
+        xc = (C.c_double * 3)(*centre)
+        self.L.oracle_pgen_gaussian_bump(self.h, xc, sigma, density_bump, temperature_bump, *v_bump,
+                                         gas_rho, *gas_v, gas_pres)
         if post_init:
             self.post_init()
 

@@ -1,0 +1,79 @@
+"""GPU parity of the gas diffusion tasks (ZeroDiffusionFlux, ViscousFlux, ThermalFlux,
+DiffusionUpdate, diffusive timestep; reference gas.cpp:522-641, utils/diffusion/*.hpp) against
+the CPU oracle, BIT-EXACT, Cartesian 1-D / 2-D / 3-D, several species, both face averagings."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.oracle import Oracle
+from test_parity_ops import face_slices, push, random_state, same
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(nx, ns_gas=1, seed=0, ng=2):
+    from artemis_amd.pack import MeshBlockPack
+    lo, hi = (-1.0, -0.5, 0.25), (1.0, 0.8, 0.95)
+    kw = dict(ng=ng, ns_gas=ns_gas, ns_dust=0, reconstruct="plm", riemann="hlle", gamma=1.4,
+              dfloor=1e-10, siefloor=1e-10)
+    o = Oracle(nx, lo, hi, bc=("outflow",) * 6, cfl=0.3, **kw)
+    random_state(o, np.random.default_rng(seed), shock=False, mach=0.5, contrast=10.0)
+    mb = MeshBlockPack(1, nx, [lo], [hi], with_diffusion=True, **kw)
+    push([o], mb)
+    return o, mb
+
+
+@pytest.mark.parametrize("nx", [(24, 12, 10), (33, 9, 1), (70, 1, 1), (5, 4, 3)])
+@pytest.mark.parametrize("avg", ["arithmetic", "harmonic"])
+@pytest.mark.parametrize("ctype", ["conductivity", "diffusivity"])
+def test_diffusion_tasks(hiplib, nx, avg, ctype):
+    from artemis_amd.pack import diffusion_params
+    o, mb = pair(nx, ns_gas=2, seed=51)
+    o.set_viscosity("constant", nu=0.03, eta_bulk=0.4, averaging=avg)
+    ck = dict(cond=0.07) if ctype == "conductivity" else dict(kappa=0.07)
+    o.set_conductivity(ctype, averaging=avg, **ck)
+    D = diffusion_params(1.4, viscosity=dict(type="constant", nu=0.03, eta_bulk=0.4, averaging=avg),
+                         conductivity=dict(type=ctype, averaging=avg, **ck))
+    o.ZeroDiffusionFlux(), mb.ZeroDiffusionFlux()
+    o.ViscousFlux(), mb.ViscousFlux(D)
+    for d in range(o.ndim):
+        same(mb.gas_diff_flux[d][0][face_slices(o, d)], o.qflux(d)[face_slices(o, d)], f"viscous flux x{d+1}")
+    o.ThermalFlux(), mb.ThermalFlux(D)
+    for d in range(o.ndim):
+        same(mb.gas_diff_flux[d][0][face_slices(o, d)], o.qflux(d)[face_slices(o, d)], f"visc+thermal flux x{d+1}")
+    o.DiffusionUpdate(2.0e-4), mb.DiffusionUpdate(D, 2.0e-4)
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    same(mb.gas_u0[0][I], o.gu0[I], "DiffusionUpdate")
+    # Gas::EstimateTimestepMesh = cfl * min(hydro, viscous, conductive) (gas.cpp:435-467)
+    hyd = mb.EstimateTimestepMesh(0, cfl=0.3)
+    assert min(hyd, mb.DiffusionTimestep(D, 0.3)) == o.EstimateTimestepMesh(0)
+
+
+def test_conduction_only_update_and_contract(hiplib):
+    from artemis_amd import capi
+    from artemis_amd.pack import MeshBlockPack, diffusion_params
+    o, mb = pair((20, 10, 6), seed=52)
+    o.set_conductivity("conductivity", cond=0.2)
+    D = diffusion_params(1.4, conductivity=dict(type="conductivity", cond=0.2))
+    o.ZeroDiffusionFlux(), mb.ZeroDiffusionFlux()
+    o.ViscousFlux(), mb.ViscousFlux(D)  # no-ops: viscosity is off
+    o.ThermalFlux(), mb.ThermalFlux(D)
+    o.DiffusionUpdate(1.0e-3), mb.DiffusionUpdate(D, 1.0e-3)
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    same(mb.gas_u0[0][I], o.gu0[I], "DiffusionUpdate, conduction only")
+    with pytest.raises(capi.ArtemisHipError) as e:  # power laws need std::pow per cell
+        mb.ViscousFlux(diffusion_params(1.4, viscosity=dict(type="powerlaw", nu=0.1, r_exp=-0.5)))
+    assert e.value.code == capi.EUNSUPPORTED
+    with pytest.raises(capi.ArtemisHipError) as e:
+        mb.ViscousFlux(diffusion_params(1.4, viscosity=dict(type="alpha", alpha=0.01)))
+    assert e.value.code == capi.EUNSUPPORTED
+    sph = MeshBlockPack(1, (8, 1, 1), [(0.5, 0.0, -0.5)], [(1.0, 3.0, 0.5)], coordinates="spherical",
+                        with_diffusion=True)
+    with pytest.raises(capi.ArtemisHipError) as e:
+        sph.ThermalFlux(D)
+    assert e.value.code == capi.EUNSUPPORTED
+    nofl = MeshBlockPack(1, (8, 8, 1), [(0, 0, 0)], [(1, 1, 1)])
+    with pytest.raises(capi.ArtemisHipError) as e:
+        nofl.ThermalFlux(D)
+    assert e.value.code == capi.EINVAL
+    torch.cuda.synchronize()
