@@ -163,6 +163,9 @@ def load():
         "artemis_hip_metric_count": (C.c_long, [PPk]),
         "artemis_hip_metric_fill": (i, [PPk, vp, vp]),
         "artemis_hip_halo_count": (C.c_long, [PPk, i]),
+        "artemis_hip_halo_count_ext": (C.c_long, [PPk, i, i]),
+        "artemis_hip_halo_pack_ext": (i, [PPk, i, i, i, vp, vp]),
+        "artemis_hip_halo_unpack_ext": (i, [PPk, i, i, i, vp, vp]),
         "artemis_hip_halo_pack": (i, [PPk, i, i, vp, vp]),
         "artemis_hip_halo_unpack": (i, [PPk, i, i, vp, vp]),
         "artemis_hip_selftest_divsqrt": (i, [C.c_long, vp, vp, vp, vp, vp, vp, vp]),
@@ -205,7 +208,8 @@ EXPORTS_HIP = [
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_rotating_frame_force",
     "artemis_hip_drag_source", "artemis_hip_stage_general", "artemis_hip_zero_diffusion_flux",
     "artemis_hip_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
-    "artemis_hip_diffusion_dt", "artemis_hip_halo_count",
+    "artemis_hip_diffusion_dt", "artemis_hip_halo_count", "artemis_hip_halo_count_ext",
+    "artemis_hip_halo_pack_ext", "artemis_hip_halo_unpack_ext",
     "artemis_hip_halo_pack", "artemis_hip_halo_unpack", "artemis_hip_last_error",
     "artemis_hip_device_count", "artemis_hip_version",
 ]

@@ -325,29 +325,38 @@ int artemis_hip_metric_fill(const artemis_pack_t *p, const double *geom_host, do
   return 0;
 }
 
-long artemis_hip_halo_count(const artemis_pack_t *p, int face) {
+long artemis_hip_halo_count_ext(const artemis_pack_t *p, int face, int extended) {
   if (!p || face < 0 || face > 5) return -1;
-  return artemis::halo_count(artemis::make_pack_view(*p), face);
+  return artemis::halo_count(artemis::make_pack_view(*p), face, extended ? 1 : 0);
 }
+long artemis_hip_halo_count(const artemis_pack_t *p, int face) { return artemis_hip_halo_count_ext(p, face, 0); }
 static int halo_common(const artemis_pack_t *p, int block, int face, double *buf, int unpack,
-                       void *stream) {
+                       int extended, void *stream) {
   if (int rc = validate(p)) return rc;
   if (block < 0 || block >= p->nblocks) return fail(ARTEMIS_HIP_EINVAL, "bad block %d", block);
   if (face < 0 || face > 5) return fail(ARTEMIS_HIP_EINVAL, "bad face %d", face);
   const artemis::PackView P = artemis::make_pack_view(*p);
   if (face / 2 >= P.ndim) return fail(ARTEMIS_HIP_EINVAL, "face %d is not an active direction", face);
   if (!buf) return fail(ARTEMIS_HIP_EINVAL, "null halo buffer");
-  const int rc = artemis::launch_halo(P, block, face, buf, unpack, S(stream));
+  const int rc = artemis::launch_halo(P, block, face, buf, unpack, extended ? 1 : 0, S(stream));
   if (rc == 1) return fail(ARTEMIS_HIP_EDEVICE, "could not read pointer tables from the device");
   if (rc == 2) return fail(ARTEMIS_HIP_EUNSUPPORTED, "too many FillGhost variables (max 64)");
   return after_launch(unpack ? "halo unpack" : "halo pack");
 }
 int artemis_hip_halo_pack(const artemis_pack_t *p, int block, int face, double *buf, void *stream) {
-  return halo_common(p, block, face, buf, 0, stream);
+  return halo_common(p, block, face, buf, 0, 0, stream);
 }
 int artemis_hip_halo_unpack(const artemis_pack_t *p, int block, int face, const double *buf,
                             void *stream) {
-  return halo_common(p, block, face, const_cast<double *>(buf), 1, stream);
+  return halo_common(p, block, face, const_cast<double *>(buf), 1, 0, stream);
+}
+int artemis_hip_halo_pack_ext(const artemis_pack_t *p, int block, int face, int extended, double *buf,
+                              void *stream) {
+  return halo_common(p, block, face, buf, 0, extended, stream);
+}
+int artemis_hip_halo_unpack_ext(const artemis_pack_t *p, int block, int face, int extended,
+                                const double *buf, void *stream) {
+  return halo_common(p, block, face, const_cast<double *>(buf), 1, extended, stream);
 }
 
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream) {

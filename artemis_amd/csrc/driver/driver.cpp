@@ -100,7 +100,7 @@ struct Link { // one directed ghost-slab transfer out of local block b through f
   int tag_send, tag_recv;
 };
 
-enum { PG_BLAST, PG_LINWAVE, PG_ADVECTION, PG_CONSTANT, PG_STRAT };
+enum { PG_BLAST, PG_LINWAVE, PG_ADVECTION, PG_CONSTANT, PG_STRAT, PG_BUMP };
 
 } // namespace
 
@@ -132,6 +132,11 @@ struct artemis_sim {
   Real rf_omega = 0.0, rf_qshear = 0.0;
   artemis_drag_t drag;
   artemis_bc_params_t bcpar = {0.0, 0.0};
+  // gas diffusion (gas.cpp:180-197): viscosity and / or heat conduction
+  bool do_viscosity = false, do_conduction = false;
+  artemis_diffusion_t diff;
+  Field gdflux[3];
+  bool edge_ghosts = false; // sequential x1, x2, x3 exchange with extended slabs (viscosity)
   std::string integrator = "rk2";
   int nstages = 2;
   Real gam0[3], gam1[3], beta[3];
@@ -202,6 +207,7 @@ struct artemis_sim {
     for (int d = 0; d < 3; ++d) {
       p.gas.flux[d] = gflux[d].tab(), p.gas.pflux[d] = gpflux[d].tab();
       p.gas.vface[d] = gvface[d].tab(), p.dust.flux[d] = dflux[d].tab();
+      p.gas.diff_flux[d] = gdflux[d].tab();
     }
     return p;
   }
@@ -213,8 +219,8 @@ struct artemis_sim {
   void problem_generator();
   void fill_ghosts(int prim_idx);
   void step_general(bool want_dt, bool device_dt);
-  void fill_ghosts_start(int prim_idx, void *hs);
-  void fill_ghosts_finish(int prim_idx, void *hs);
+  void fill_ghosts_start(int prim_idx, void *hs, int dim = -1);
+  void fill_ghosts_finish(int prim_idx, void *hs, int dim = -1, bool apply_bcs = true);
   void materialise_cons();
   Real new_dt_unfused();
   void step_fused(bool want_dt, bool device_dt);
@@ -282,6 +288,7 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   else if (problem == "advection") pgen = PG_ADVECTION;
   else if (problem == "constant") pgen = PG_CONSTANT;
   else if (problem == "strat") pgen = PG_STRAT;
+  else if (problem == "gaussian_bump") pgen = PG_BUMP;
   else throw std::runtime_error("problem generator '" + problem + "' is not built");
   // <physics> (artemis.cpp:63-72); everything but gas/dust must stay off
   do_gas = pin.GetOrAddBoolean("physics", "gas", true);
@@ -289,7 +296,9 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   do_gravity = pin.GetOrAddBoolean("physics", "gravity", false);
   do_rframe = pin.GetOrAddBoolean("physics", "rotating_frame", false);
   do_drag = pin.GetOrAddBoolean("physics", "drag", false);
-  for (const char *k : {"nbody", "cooling", "viscosity", "conduction", "radiation"})
+  do_viscosity = pin.GetOrAddBoolean("physics", "viscosity", false);
+  do_conduction = pin.GetOrAddBoolean("physics", "conduction", false);
+  for (const char *k : {"nbody", "cooling", "radiation"})
     if (pin.GetOrAddBoolean("physics", k, false))
       throw std::runtime_error(std::string("physics/") + k + " is out of scope of this build");
   // <parthenon/mesh>
@@ -397,6 +406,50 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
     de_switch = pin.GetOrAddReal("gas", "de_switch", 0.0);
     ns_gas = pin.GetOrAddInteger("gas", "nspecies", 1);
   }
+  // <gas/viscosity>, <gas/conductivity> (gas.cpp:189-197, diffusion_coeff.hpp:84-136)
+  std::memset(&diff, 0, sizeof diff);
+  if (do_viscosity || do_conduction) {
+    if (!do_gas) throw std::runtime_error("Viscosity / conduction requires the gas package");
+    diff.cv = 1.0 / ((gamma - 1.) * 1.0 * pin.GetOrAddReal("gas", "mu", 1.));
+    auto averaging = [&](const std::string &blk) {
+      const std::string a = pin.GetOrAddString(blk, "averaging", "arithmetic");
+      if (a == "arithmetic") return 0;
+      if (a == "harmonic") return 1;
+      throw std::runtime_error(a + " in " + blk + " is not supported");
+    };
+    if (do_viscosity) {
+      artemis_diffcoeff_t &c = diff.visc;
+      const std::string t = pin.GetString("gas/viscosity", "type");
+      c.avg = averaging("gas/viscosity");
+      c.r0 = pin.GetOrAddReal("problem", "r0", 1.0), c.rho_ref = 1.0, c.T_ref = 1.0;
+      if (t == "constant" || t == "powerlaw") {
+        c.type = ARTEMIS_VISCOSITY_PLAW;
+        c.coeff = pin.GetReal("gas/viscosity", "nu");
+        c.eta = pin.GetOrAddReal("gas/viscosity", "eta_bulk", 0.0);
+        c.r_exp = pin.GetOrAddReal("gas/viscosity", "r_exp", 0.0);
+      } else if (t == "alpha") {
+        throw std::runtime_error("gas/viscosity/type = alpha needs the disk setup (out of scope of this build)");
+      } else {
+        throw std::runtime_error(t + " in gas/viscosity is not supported");
+      }
+    }
+    if (do_conduction) {
+      artemis_diffcoeff_t &c = diff.cond;
+      const std::string t = pin.GetString("gas/conductivity", "type");
+      c.avg = averaging("gas/conductivity");
+      c.r0 = 1.0;
+      if (t == "conductivity") c.type = ARTEMIS_CONDUCTIVITY_PLAW, c.coeff = pin.GetReal("gas/conductivity", "cond");
+      else if (t == "diffusivity") c.type = ARTEMIS_THERMALDIFF_PLAW, c.coeff = pin.GetReal("gas/conductivity", "kappa");
+      else throw std::runtime_error(t + " in gas/conductivity is not supported");
+      c.temp_exp = pin.GetOrAddReal("gas/conductivity", "temp_exp", 0.0);
+      c.rho_exp = pin.GetOrAddReal("gas/conductivity", "rho_exp", 0.0);
+      c.rho_ref = pin.GetOrAddReal("gas/conductivity", "rho_ref", 1.0);
+      c.T_ref = pin.GetOrAddReal("gas/conductivity", "T_ref", 1.0);
+    }
+    if (coords != ARTEMIS_CARTESIAN) throw std::runtime_error("gas diffusion in curvilinear coordinates is not built yet");
+    if (ng < 2) throw std::runtime_error("gas diffusion needs nghost >= 2");
+    edge_ghosts = do_viscosity; // the strain tensor reads edge / corner ghost zones
+  }
   // <dust> (dust.cpp:45-110)
   if (do_dust) {
     recon_dust = recon_of(pin.GetOrAddString("dust", "reconstruct", "plm"));
@@ -470,7 +523,8 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   // stage (artemis_hip_stage_general) for everything else the per-task path can do
   tuned = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
           coords == ARTEMIS_CARTESIAN && !do_gravity && !do_rframe && !do_drag;
-  fused_possible = true;
+  fused_possible = !(do_viscosity || do_conduction); // diffusion runs on the per-task chain
+  tuned = tuned && fused_possible;
   use_fused = fused_possible;
   if (!use_fused) ensure_unfused();
   problem_generator();
@@ -587,7 +641,7 @@ void artemis_sim::allocate() {
       auto L = std::make_unique<Link>();
       L->b = b, L->face = f, L->nbr_rank = blocks[b].nbr_rank[f], L->nbr_block = blocks[b].nbr_block[f];
       const artemis_pack_t p = make_pack(0);
-      L->count = artemis_hip_halo_count(&p, f);
+      L->count = artemis_hip_halo_count_ext(&p, f, edge_ghosts ? 1 : 0);
       L->sbuf.alloc(L->count);
       if (remote(*L)) L->rbuf.alloc(L->count);
       // tag = (destination global block id, destination face)
@@ -611,6 +665,7 @@ void artemis_sim::ensure_unfused() {
     gpflux[d].alloc(nb, ns_gas, N);
     gvface[d].alloc(nb, ns_gas, N);
     dflux[d].alloc(nb, 4 * ns_dust, N);
+    if (do_viscosity || do_conduction) gdflux[d].alloc(nb, 4 * ns_gas, N);
   }
   unfused_ready = true;
 }
@@ -634,12 +689,17 @@ std::vector<Real> artemis_sim::download(const Field &f, int b) {
 // `hs` is the stream the pack/unpack kernels run on: the compute stream normally, the comm stream
 // when the exchange overlaps the bulk of the stage kernel (then everything between "shell done"
 // and "ghosts filled" lives on the comm stream and the compute stream keeps computing).
-void artemis_sim::fill_ghosts_start(int prim_idx, void *hs) {
+// dim < 0: every face at once (slabs span the interior of the other dimensions; the hydro stencil
+// reads no edge or corner zone).  dim >= 0: only the faces of that dimension, with slabs extended
+// over the ghost zones of the lower dimensions (edge_ghosts mode, one phase per dimension).
+void artemis_sim::fill_ghosts_start(int prim_idx, void *hs, int dim) {
   if (links.empty()) return;
   const artemis_pack_t p = make_pack(prim_idx);
+  const int ext = (dim >= 0) ? 1 : 0;
   std::vector<artemis_msg_t> msgs;
   for (auto &L : links) {
-    CK(artemis_hip_halo_pack(&p, L->b, L->face, L->sbuf.p, hs), "halo pack");
+    if (dim >= 0 && L->face / 2 != dim) continue;
+    CK(artemis_hip_halo_pack_ext(&p, L->b, L->face, ext, L->sbuf.p, hs), "halo pack");
     if (remote(*L)) {
       artemis_msg_t m;
       m.peer = L->nbr_rank, m.tag = L->tag_send, m.send = L->sbuf.p, m.recv = nullptr, m.count = L->count;
@@ -658,10 +718,11 @@ void artemis_sim::fill_ghosts_start(int prim_idx, void *hs) {
       throw std::runtime_error("exchange_start failed");
   }
 }
-void artemis_sim::fill_ghosts_finish(int prim_idx, void *hs) {
+void artemis_sim::fill_ghosts_finish(int prim_idx, void *hs, int dim, bool apply_bcs) {
   const artemis_pack_t p = make_pack(prim_idx);
+  const int ext = (dim >= 0) ? 1 : 0;
   bool any_remote = false;
-  for (auto &L : links) any_remote = any_remote || remote(*L);
+  for (auto &L : links) any_remote = any_remote || (remote(*L) && (dim < 0 || L->face / 2 == dim));
   if (any_remote) {
     if (comm.exchange_finish(comm.ctx, comm_stream)) throw std::runtime_error("exchange_finish failed");
     if (hs != comm_stream) {
@@ -670,24 +731,34 @@ void artemis_sim::fill_ghosts_finish(int prim_idx, void *hs) {
     }
   }
   for (auto &L : links) {
+    if (dim >= 0 && L->face / 2 != dim) continue;
     if (!remote(*L)) {
-      CK(artemis_hip_halo_unpack(&p, L->nbr_block, L->face ^ 1, L->sbuf.p, hs), "halo unpack");
+      CK(artemis_hip_halo_unpack_ext(&p, L->nbr_block, L->face ^ 1, ext, L->sbuf.p, hs), "halo unpack");
     } else {
       // what I received through face f came from the neighbour's opposite face
-      CK(artemis_hip_halo_unpack(&p, L->b, L->face, L->rbuf.p, hs), "halo unpack");
+      CK(artemis_hip_halo_unpack_ext(&p, L->b, L->face, ext, L->rbuf.p, hs), "halo unpack");
     }
   }
   if (hs != stream) { // hand the filled ghosts back to the compute stream
     CK(artemis_rt_event_record(ev1, hs), "event");
     CK(artemis_rt_stream_wait_event(stream, ev1), "wait");
   }
-  CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bcpar, stream), "apply_bc");
+  if (apply_bcs) CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bcpar, stream), "apply_bc");
 }
 void artemis_sim::fill_ghosts(int prim_idx) {
-  fill_ghosts_start(prim_idx, stream);
-  fill_ghosts_finish(prim_idx, stream);
+  if (!edge_ghosts) {
+    fill_ghosts_start(prim_idx, stream, -1);
+    fill_ghosts_finish(prim_idx, stream, -1, true);
+    return;
+  }
+  // x1, then x2, then x3: each phase forwards the ghost zones the earlier ones filled, so edge and
+  // corner zones arrive from the diagonal neighbours; physical conditions come last, over the
+  // entire extent (parthenon order)
+  for (int d = 0; d < ndim; ++d) {
+    fill_ghosts_start(prim_idx, stream, d);
+    fill_ghosts_finish(prim_idx, stream, d, d == ndim - 1);
+  }
 }
-
 void artemis_sim::materialise_cons() {
   if (cons_valid) return;
   const artemis_pack_t p = make_pack(base);
@@ -823,6 +894,23 @@ void artemis_sim::problem_generator() {
     st.dens_min = pin.GetOrAddReal("problem", "dens_min", 1.0e-5);
     st.d2g = pin.GetOrAddReal("problem", "dust_to_gas", 0.01);
   }
+  struct { Real xc[3] = {0, 0, 0}, sig = 1, dfac = 0, tfac = 0, ufac = 0, vfac = 0, wfac = 0, g_rho = 1, g_v[3] = {0, 0, 0}, g_pres = 1; } bp;
+  if (pgen == PG_BUMP) { // gaussian_bump.hpp:55-74
+    if (!do_gas || ns_gas != 1 || do_dust) throw std::runtime_error("Gaussian bump pgen requires a single gas species (dust is not built).");
+    if (pin.GetString("problem", "system") != "cartesian")
+      throw std::runtime_error("gaussian_bump pgen: only problem/system = cartesian is built");
+    bp.xc[0] = pin.GetOrAddReal("problem", "x1c", 0.0), bp.xc[1] = pin.GetOrAddReal("problem", "x2c", 0.0);
+    bp.xc[2] = pin.GetOrAddReal("problem", "x3c", 0.0);
+    bp.sig = pin.GetReal("problem", "sigma");
+    bp.dfac = pin.GetOrAddReal("problem", "density_bump", 0.0);
+    bp.tfac = pin.GetOrAddReal("problem", "temperature_bump", 0.0);
+    bp.ufac = pin.GetOrAddReal("problem", "vx1_bump", 0.0), bp.vfac = pin.GetOrAddReal("problem", "vx2_bump", 0.0);
+    bp.wfac = pin.GetOrAddReal("problem", "vx3_bump", 0.0);
+    bp.g_rho = pin.GetOrAddReal("problem", "gas_rho", 1.0);
+    bp.g_v[0] = pin.GetOrAddReal("problem", "gas_vx1", 0.0), bp.g_v[1] = pin.GetOrAddReal("problem", "gas_vx2", 0.0);
+    bp.g_v[2] = pin.GetOrAddReal("problem", "gas_vx3", 0.0);
+    bp.g_pres = pin.GetOrAddReal("problem", "gas_pres", 1.0);
+  }
   std::vector<Real> hg(static_cast<size_t>(6) * ns_gas * N), hd(static_cast<size_t>(4) * ns_dust * N);
   for (int b = 0; b < nb; ++b) {
     std::fill(hg.begin(), hg.end(), 0.0);
@@ -848,6 +936,27 @@ void artemis_sim::problem_generator() {
               hd[(ns_dust + 3 * n + 0) * N + c] = (cs.d_v[0] * ex1[0] + cs.d_v[1] * ex1[1] + cs.d_v[2] * ex1[2]);
               hd[(ns_dust + 3 * n + 1) * N + c] = (cs.d_v[0] * ex2[0] + cs.d_v[1] * ex2[1] + cs.d_v[2] * ex2[2]);
               hd[(ns_dust + 3 * n + 2) * N + c] = (cs.d_v[0] * ex3[0] + cs.d_v[1] * ex3[1] + cs.d_v[2] * ex3[2]);
+            }
+          } else if (pgen == PG_BUMP) { // gaussian_bump.hpp:112-178, problem/system = cartesian
+            const Real dxs = SQR(xv[0] - bp.xc[0]) + SQR(xv[1] - bp.xc[1]) * (ndim >= 2) +
+                             SQR(xv[2] - bp.xc[2]) * (ndim == 3);
+            const Real bump = std::exp(-dxs / (2.0 * SQR(bp.sig)));
+            const Real ex1[3] = {1.0, 0.0, 0.0}, ex2[3] = {0.0, 1.0, 0.0}, ex3[3] = {0.0, 0.0, 1.0};
+            const Real vx1 = (bp.g_v[0] * ex1[0] + bp.g_v[1] * ex1[1] + bp.g_v[2] * ex1[2]);
+            const Real vx2 = (bp.g_v[0] * ex2[0] + bp.g_v[1] * ex2[1] + bp.g_v[2] * ex2[2]);
+            const Real vx3 = (bp.g_v[0] * ex3[0] + bp.g_v[1] * ex3[1] + bp.g_v[2] * ex3[2]);
+            hg[(ns_gas + 0) * N + c] = vx1 + bp.ufac * bump;
+            hg[(ns_gas + 1) * N + c] = vx2 + bp.vfac * bump;
+            hg[(ns_gas + 2) * N + c] = vx3 + bp.wfac * bump;
+            if (bp.tfac > 0.0) {
+              const Real sie0 = bp.g_pres / (bp.g_rho * (gamma - 1.0));
+              const Real sie = sie0 * (1. + bp.tfac * bump);
+              hg[0 * N + c] = bp.g_pres / (sie * (gamma - 1.0));
+              hg[(5 * ns_gas) * N + c] = sie;
+            } else {
+              const Real dens = bp.g_rho * (1. + bp.dfac * bump);
+              hg[0 * N + c] = dens;
+              hg[(5 * ns_gas) * N + c] = bp.g_pres / ((gamma - 1.0) * dens);
             }
           } else if (pgen == PG_STRAT) { // strat.hpp:116-148
             const Real x = xv[0];
@@ -1010,6 +1119,8 @@ Real artemis_sim::new_dt_unfused() {
   CK(artemis_rt_memcpy_h2d(dt_dev.p, dt_host, sizeof(double), stream), "h2d");
   if (do_gas) CK(artemis_hip_estimate_dt_async(&p, ARTEMIS_GAS, cfl_gas, dt_dev.p, stream), "dt gas");
   if (do_dust) CK(artemis_hip_estimate_dt_async(&p, ARTEMIS_DUST, cfl_dust, dt_dev.p, stream), "dt dust");
+  if (do_viscosity || do_conduction) // gas.cpp:435-467: cfl * min(hydro, viscous, conductive)
+    CK(artemis_hip_diffusion_dt(&p, &diff, cfl_gas, dt_dev.p, stream), "dt diffusion");
   CK(artemis_rt_memcpy_d2h(dt_host, dt_dev.p, sizeof(double), stream), "d2h");
   CK(artemis_rt_stream_sync(stream), "sync");
   return *dt_host;
@@ -1167,9 +1278,16 @@ void artemis_sim::step_unfused() {
     const int do_pcm = (stage == 1 && integrator == "vl2");
     if (do_gas) CK(artemis_hip_calculate_fluxes(&p, ARTEMIS_GAS, do_pcm, stream), "Gas::CalculateFluxes");
     if (do_dust) CK(artemis_hip_calculate_fluxes(&p, ARTEMIS_DUST, do_pcm, stream), "Dust::CalculateFluxes");
+    if (do_viscosity || do_conduction) { // artemis_driver.cpp:189-194
+      CK(artemis_hip_zero_diffusion_flux(&p, stream), "Gas::ZeroDiffusionFlux");
+      if (do_viscosity) CK(artemis_hip_viscous_flux(&p, &diff, stream), "Gas::ViscousFlux");
+      if (do_conduction) CK(artemis_hip_thermal_flux(&p, &diff, stream), "Gas::ThermalFlux");
+    }
     CK(artemis_hip_apply_update(&p, gam0[stage - 1], gam1[stage - 1], beta[stage - 1] * dt, stream), "ApplyUpdate");
     if (do_gas) CK(artemis_hip_flux_source(&p, ARTEMIS_GAS, bdt, stream), "Gas::FluxSource");
     if (do_dust) CK(artemis_hip_flux_source(&p, ARTEMIS_DUST, bdt, stream), "Dust::FluxSource");
+    if (do_viscosity || do_conduction) // artemis_driver.cpp:218-221
+      CK(artemis_hip_diffusion_update(&p, &diff, bdt, stream), "Gas::DiffusionUpdate");
     // artemis_driver.cpp:222-241: gravity, rotating frame, drag, in this order, with the time at
     // the start of the step (:167)
     if (do_gravity) CK(artemis_hip_external_gravity(&p, &grav, time, bdt, stream), "ExternalGravity");
@@ -1430,6 +1548,10 @@ int artemis_sim_uses_tuned_kernel(const artemis_sim_t *s) { return (s->use_fused
 int artemis_sim_set_path(artemis_sim_t *s, const char *which) {
   const std::string w = which ? which : "";
   if (w == "fused") {
+    if (!s->fused_possible) {
+      g_sim_err = "the fused paths do not cover gas diffusion";
+      return 1;
+    }
     s->use_fused = true;
     return 0;
   }

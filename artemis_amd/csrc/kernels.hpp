@@ -22,8 +22,9 @@ void launch_drag_source(const PackView &P, const artemis_drag_t &D, double dt, c
                         hipStream_t s);
 bool launch_drag_finish(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
                         hipStream_t s);
-long halo_count(const PackView &P, int face);
-int launch_halo(const PackView &P, int block, int face, double *buf, int unpack, hipStream_t s);
+long halo_count(const PackView &P, int face, int extended = 0);
+int launch_halo(const PackView &P, int block, int face, double *buf, int unpack, int extended,
+                hipStream_t s);
 void invalidate_table_cache();
 // kernels_fused.hip
 void launch_advance_dt(double *state, double tlim, int nstages, const double *beta, hipStream_t s);

@@ -780,23 +780,30 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
   return 0;
 }
 
-static void halo_args(const PackView &P, int face, int unpack, HaloArgs &a) {
+// extended: the slab spans the ENTIRE extent (ghosts included) of the dimensions below d, so that
+// exchanging x1, then x2, then x3 slabs carries edge and corner zones along (needed by the
+// viscous cross-derivatives, momentum_diffusion.hpp:95-141)
+static void halo_args(const PackView &P, int face, int unpack, HaloArgs &a, int extended = 0) {
   const int d = face / 2, side = face % 2;
   a.d = d, a.side = side, a.ng = P.ng;
-  const int st[3] = {P.is, P.js, P.ks}, en[3] = {P.ie, P.je, P.ke};
-  for (int q = 0; q < 3; ++q) a.lo[q] = st[q], a.n[q] = en[q] - st[q] + 1;
+  const int st[3] = {P.is, P.js, P.ks}, en[3] = {P.ie, P.je, P.ke}, ext[3] = {P.ni, P.nj, P.nk};
+  for (int q = 0; q < 3; ++q) {
+    a.lo[q] = st[q], a.n[q] = en[q] - st[q] + 1;
+    if (extended && q < d) a.lo[q] = 0, a.n[q] = ext[q];
+  }
   a.n[d] = P.ng;
   if (!unpack) a.lo[d] = (side == 0) ? st[d] : en[d] - P.ng + 1; // interior slab next to the face
   else a.lo[d] = (side == 0) ? st[d] - P.ng : en[d] + 1;         // ghost slab behind the face
 }
-long halo_count(const PackView &P, int face) {
+long halo_count(const PackView &P, int face, int extended) {
   HaloArgs a;
-  halo_args(P, face, 0, a);
+  halo_args(P, face, 0, a, extended);
   return static_cast<long>(a.n[0]) * a.n[1] * a.n[2] * (5 * P.gas.ns + 4 * P.dust.ns);
 }
-int launch_halo(const PackView &P, int block, int face, double *buf, int unpack, hipStream_t s) {
+int launch_halo(const PackView &P, int block, int face, double *buf, int unpack, int extended,
+                hipStream_t s) {
   HaloArgs a;
-  halo_args(P, face, unpack, a);
+  halo_args(P, face, unpack, a, extended);
   const FillTabs t = fill_tabs(P, block);
   a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;
   const long ncell = static_cast<long>(a.n[0]) * a.n[1] * a.n[2];

@@ -333,6 +333,15 @@ int artemis_hip_wait_counter(unsigned *counter, unsigned target, unsigned *timeo
  * (the hydro stencil never reads edge/corner ghosts: fluid_fluxes.hpp:105-106,130-131,
  * 172-173).  artemis_hip_halo_count returns the number of doubles in one slab buffer. */
 long artemis_hip_halo_count(const artemis_pack_t *p, int face);
+/* `_ext` variants with extended != 0: the slab spans the ENTIRE extent (ghost zones included) of the
+ * dimensions below the face's own, so that exchanging x1 slabs, then x2, then x3 also fills the
+ * edge and corner ghost zones (Parthenon fills them from the diagonal neighbours; only the viscous
+ * cross-derivatives read them, momentum_diffusion.hpp:95-141).  extended == 0: as above. */
+long artemis_hip_halo_count_ext(const artemis_pack_t *p, int face, int extended);
+int artemis_hip_halo_pack_ext(const artemis_pack_t *p, int block, int face, int extended, double *buf,
+                              void *stream);
+int artemis_hip_halo_unpack_ext(const artemis_pack_t *p, int block, int face, int extended,
+                                const double *buf, void *stream);
 int artemis_hip_halo_pack(const artemis_pack_t *p, int block, int face, double *buf, void *stream);
 int artemis_hip_halo_unpack(const artemis_pack_t *p, int block, int face, const double *buf,
                             void *stream);

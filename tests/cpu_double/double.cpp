@@ -400,24 +400,28 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
   return 0;
 }
 
-static void slab(const artemis_pack_t *p, int face, int unpack, int lo[3], int n[3]) {
+static void slab(const artemis_pack_t *p, int face, int unpack, int lo[3], int n[3], int extended = 0) {
   const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
   const int nx[3] = {p->nx1, p->nx2, p->nx3};
   const int d = face / 2, side = face % 2, ng = p->nghost;
-  for (int q = 0; q < 3; ++q) lo[q] = (q < ndim) ? ng : 0, n[q] = nx[q];
+  for (int q = 0; q < 3; ++q) {
+    lo[q] = (q < ndim) ? ng : 0, n[q] = nx[q];
+    if (extended && q < d) lo[q] = 0, n[q] = nx[q] + 2 * ng; // dims below d are active: entire extent
+  }
   n[d] = ng;
   const int st = lo[d], en = st + nx[d] - 1;
   if (!unpack) lo[d] = side ? en - ng + 1 : st;
   else lo[d] = side ? en + 1 : st - ng;
 }
-long artemis_hip_halo_count(const artemis_pack_t *p, int face) {
+long artemis_hip_halo_count_ext(const artemis_pack_t *p, int face, int extended) {
   int lo[3], n[3];
-  slab(p, face, 0, lo, n);
+  slab(p, face, 0, lo, n, extended);
   return static_cast<long>(n[0]) * n[1] * n[2] * (5 * p->gas.nspecies + 4 * p->dust.nspecies);
 }
-static int halo(const artemis_pack_t *p, int b, int face, double *buf, int unpack) {
+long artemis_hip_halo_count(const artemis_pack_t *p, int face) { return artemis_hip_halo_count_ext(p, face, 0); }
+static int halo(const artemis_pack_t *p, int b, int face, double *buf, int unpack, int extended = 0) {
   int lo[3], n[3];
-  slab(p, face, unpack, lo, n);
+  slab(p, face, unpack, lo, n, extended);
   const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
   const int ni = p->nx1 + 2 * p->nghost, nj = p->nx2 + (ndim > 1 ? 2 * p->nghost : 0);
   const long ncell = static_cast<long>(n[0]) * n[1] * n[2];
@@ -444,6 +448,74 @@ int artemis_hip_halo_pack(const artemis_pack_t *p, int b, int face, double *buf,
 }
 int artemis_hip_halo_unpack(const artemis_pack_t *p, int b, int face, const double *buf, void *) {
   return halo(p, b, face, const_cast<double *>(buf), 1);
+}
+int artemis_hip_halo_pack_ext(const artemis_pack_t *p, int b, int face, int extended, double *buf, void *) {
+  return halo(p, b, face, buf, 0, extended);
+}
+int artemis_hip_halo_unpack_ext(const artemis_pack_t *p, int b, int face, int extended, const double *buf, void *) {
+  return halo(p, b, face, const_cast<double *>(buf), 1, extended);
+}
+// gas diffusion through the oracle's restatement
+static void set_diffusion(Sim &s, const artemis_diffusion_t *d) {
+  auto cp = [](Sim::DiffCoeff &o, const artemis_diffcoeff_t &c) {
+    o.type = c.type, o.avg = c.avg;
+    o.nu_s = o.alpha = o.hcond_0 = o.kappa_0 = c.coeff;
+    o.eta = c.eta, o.r_exp = c.r_exp, o.R0 = c.r0, o.Omega0 = c.omega0;
+    o.temp_exp = c.temp_exp, o.rho_exp = c.rho_exp, o.d0 = c.rho_ref, o.T0 = c.T_ref;
+  };
+  cp(s.visc, d->visc), cp(s.cond, d->cond);
+  s.cv = d->cv;
+}
+static void dflux_io(Bound &B, const artemis_pack_t *p, bool out) {
+  for (int d = 0; d < 3; ++d) {
+    if (!p->gas.diff_flux[d]) continue;
+    if (out) B.out(B.s->qflux[d], p->gas.diff_flux[d], 4 * B.s->c.ns_gas);
+    else B.in(B.s->qflux[d], p->gas.diff_flux[d], 4 * B.s->c.ns_gas);
+  }
+}
+int artemis_hip_zero_diffusion_flux(const artemis_pack_t *p, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    zero_diffusion_flux(*B.s);
+    dflux_io(B, p, true);
+  }
+  return 0;
+}
+int artemis_hip_viscous_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state(), dflux_io(B, p, false), set_diffusion(*B.s, d);
+    viscous_flux(*B.s);
+    dflux_io(B, p, true);
+  }
+  return 0;
+}
+int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state(), dflux_io(B, p, false), set_diffusion(*B.s, d);
+    thermal_flux(*B.s);
+    dflux_io(B, p, true);
+  }
+  return 0;
+}
+int artemis_hip_diffusion_update(const artemis_pack_t *p, const artemis_diffusion_t *d, double dt, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state(), dflux_io(B, p, false), set_diffusion(*B.s, d);
+    diffusion_update(*B.s, dt);
+    B.out(B.s->gu0, p->gas.cons0, B.s->nvg);
+  }
+  return 0;
+}
+int artemis_hip_diffusion_dt(const artemis_pack_t *p, const artemis_diffusion_t *d, double cfl,
+                             double *dt_dev, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state(), set_diffusion(*B.s, d);
+    *dt_dev = std::min(*dt_dev, cfl * std::min(diffusion_dt(*B.s, B.s->visc), diffusion_dt(*B.s, B.s->cond)));
+  }
+  return 0;
 }
 int artemis_hip_wait_counter(unsigned *, unsigned, unsigned *, void *) { return 0; }
 int artemis_hip_advance_dt(double *st, double tlim, int nstages, const double *beta, void *) {

@@ -496,3 +496,60 @@ def test_general_stage_sync_free_loop(hiplib, monkeypatch):
     for blk in range(a.nblocks):
         assert np.array_equal(a.field("gas.prim", blk), b.field("gas.prim", blk))
         assert np.array_equal(a.field("dust.prim", blk), b.field("dust.prim", blk))
+
+
+def test_viscous_diffusion_deck_bitwise_and_reference_pin(hiplib):
+    """inputs/diffusion/gaussian_bump.in as tst/scripts/diffusion/viscous_diffusion.py:36-85 runs it
+    (2-D, 2x2 blocks, nu = 0.25, v3 bump, t = 2): mean |v3 - analytic| <= 1e-8; and one block with
+    extra v1 / v2 bumps (so the stress tensor's cross terms are live) bit for bit against the oracle."""
+    from artemis_amd.driver import Simulation
+    nu, t0, eps = 0.25, 0.5, 1e-6
+    sig2 = 2.0 * nu * t0
+    base = ["physics/viscosity=true", "physics/conduction=false", f"gas/viscosity/nu={nu:.8e}",
+            "problem/temperature_bump=0.0", f"problem/sigma={np.sqrt(sig2):.8e}", "parthenon/time/tlim=2.0"]
+    s = Simulation(DECK("diffusion", "gaussian_bump.in"),
+                   base + ["problem/vx3_bump={:.16e}".format(eps * (2.0 * np.pi * sig2) ** -1.0)])
+    assert s.nblocks == 4 and not s.uses_fused_path
+    s.evolve()
+    w = np.zeros((64, 64))
+    for b in range(4):
+        x1a, _, x2a, _, _, _ = s.block_bounds(b)
+        i0, j0 = int(round((x1a + 6.0) / 12.0 * 64)), int(round((x2a + 6.0) / 12.0 * 64))
+        w[j0:j0 + 32, i0:i0 + 32] = s.interior(s.field("gas.prim", b))[3, 0]
+    xc = -6.0 + (np.arange(64) + 0.5) * 12.0 / 64
+    s2 = 2.0 * nu * (s.time + t0)
+    X, Y = np.meshgrid(xc, xc)
+    ans = eps / (2.0 * np.pi * s2) * np.exp(-(X ** 2 + Y ** 2) / (2.0 * s2))
+    assert np.abs(ans - w).mean() <= 1e-8
+    ov = base + ["problem/vx3_bump=1.0e-2", "problem/vx1_bump=2.0e-2", "problem/vx2_bump=-1.5e-2", "problem/x1c=0.4",
+                 "problem/x2c=-0.3", "parthenon/meshblock/nx1=64", "parthenon/meshblock/nx2=64", "parthenon/time/nlim=40"]
+    g = Simulation(DECK("diffusion", "gaussian_bump.in"), ov)
+    o = Oracle((64, 64, 1), (-6.0, -6.0, -0.5), (6.0, 6.0, 0.5), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.000001, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
+               bc=("outflow",) * 4 + ("periodic",) * 2, integrator="rk2")
+    o.set_viscosity("constant", nu=nu)
+    o.pgen_gaussian_bump(sigma=float("{:.8e}".format(np.sqrt(sig2))), centre=(0.4, -0.3, 0.0),
+                         v_bump=(2.0e-2, -1.5e-2, 1.0e-2))
+    g.evolve(), o.evolve(2.0, 40)
+    assert g.ncycle == o.ncycle == 40 and g.time == o.time and g.dt == o.dt
+    assert np.array_equal(g.field("gas.prim"), o.gprim)
+
+
+def test_conduction_deck_bitwise(hiplib):
+    """The shipped gaussian_bump.in (heat conduction of a temperature bump) in 3-D with the harmonic
+    average, one block, against the oracle."""
+    from artemis_amd.driver import Simulation
+    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=24", "parthenon/mesh/nx3=16", "parthenon/mesh/x3min=-4.0",
+          "parthenon/mesh/x3max=4.0", "parthenon/mesh/ix3_bc=outflow", "parthenon/mesh/ox3_bc=outflow",
+          "parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=24", "parthenon/meshblock/nx3=16",
+          "gas/gamma=1.4", "gas/conductivity/cond=0.3", "gas/conductivity/averaging=harmonic", "problem/sigma=1.0",
+          "parthenon/time/nlim=25"]
+    g = Simulation(DECK("diffusion", "gaussian_bump.in"), ov)
+    o = Oracle((32, 24, 16), (-6.0, -6.0, -4.0), (6.0, 6.0, 4.0), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3, bc=("outflow",) * 6, integrator="rk2")
+    o.set_conductivity("conductivity", cond=0.3, averaging="harmonic")
+    o.pgen_gaussian_bump(sigma=1.0, temperature_bump=5.0)
+    g.evolve(), o.evolve(1.0, 25)
+    assert g.ncycle == o.ncycle == 25 and g.time == o.time and g.dt == o.dt
+    assert np.array_equal(g.field("gas.prim"), o.gprim)
+    assert g.dt < 0.3 * 0.375 / 3.0  # the conductive limit, not the sound-crossing time, sets dt

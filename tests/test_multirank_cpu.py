@@ -233,3 +233,62 @@ def test_shearing_sheet_deck_driver_equals_oracle_and_ranks_agree(double_lib, tm
     xa, xb = by_bounds(a), by_bounds(b)
     for key in xa:
         assert np.array_equal(xa[key], xb[key]), key
+
+
+# ---- gas diffusion through the driver (viscous_diffusion.py configuration) --------------------------
+VISC = ["physics/viscosity=true", "physics/conduction=false", "gas/viscosity/nu=2.5e-01",
+        "problem/temperature_bump=0.0", "problem/sigma=0.5", "parthenon/time/tlim=2.0"]
+
+
+def test_viscous_diffusion_deck_driver_equals_oracle_and_block_edges(double_lib, tmp_path):
+    """inputs/diffusion/gaussian_bump.in as tst/scripts/diffusion/viscous_diffusion.py runs it (2-D,
+    nu = 0.25, a v3 bump plus -- to make the cross-derivative terms and hence the edge / corner
+    ghost zones matter -- v1 and v2 bumps): one block == oracle bit for bit; 2x2 blocks on 1 and 2
+    ranks agree bit for bit with each other and with the one-block run to round-off, which only
+    holds if the sequential extended-slab exchange delivers the diagonal neighbours' zones."""
+    from oracle.oracle import Oracle
+    bump = ["problem/vx3_bump=1.0e-2", "problem/vx1_bump=2.0e-2", "problem/vx2_bump=-1.5e-2", "problem/x1c=0.4",
+            "problem/x2c=-0.3"]
+    one_blk = dict(deck=["diffusion", "gaussian_bump.in"], cycles=30,
+                   overrides=VISC + bump + ["parthenon/meshblock/nx1=64", "parthenon/meshblock/nx2=64"])
+    r = run_world(1, one_blk, tmp_path, "v1")[0]
+    assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    o = Oracle((64, 64, 1), (-6.0, -6.0, -0.5), (6.0, 6.0, 0.5), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.000001, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
+               bc=("outflow",) * 4 + ("periodic",) * 2, integrator="rk2")
+    o.set_viscosity("constant", nu=0.25)
+    o.pgen_gaussian_bump(sigma=0.5, centre=(0.4, -0.3, 0.0), v_bump=(2.0e-2, -1.5e-2, 1.0e-2))
+    o.evolve(2.0, 30)
+    assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
+    assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+    four = dict(one_blk, overrides=VISC + bump)  # the deck's own 32^2 blocks
+    a, b = run_world(1, four, tmp_path, "v4"), run_world(2, four, tmp_path, "v4r2")
+    assert a[0]["meta"]["nblocks"] == 4 and [x["meta"]["nblocks"] for x in b] == [2, 2]
+    xa, xb = by_bounds(a), by_bounds(b)
+    full = o.interior(o.gprim)
+    for key in xa:
+        assert np.array_equal(xa[key], xb[key]), key
+        i0, j0 = int(round((key[0] + 6.0) / 12.0 * 64)), int(round((key[2] + 6.0) / 12.0 * 64))
+        ref = full[:, :, j0:j0 + 32, i0:i0 + 32]
+        assert np.max(np.abs(xa[key] - ref)) < 1e-13, key
+
+
+def test_conduction_deck_driver_equals_oracle(double_lib, tmp_path):
+    """The shipped deck (heat conduction of a temperature bump, 2x2 blocks): driver == oracle on one
+    block; the temperature peak decays and heat is conserved."""
+    from oracle.oracle import Oracle
+    spec = dict(deck=["diffusion", "gaussian_bump.in"], cycles=40,
+                overrides=["parthenon/meshblock/nx1=64", "parthenon/meshblock/nx2=64", "gas/conductivity/cond=0.05",
+                           "problem/sigma=0.5"])
+    r = run_world(1, spec, tmp_path, "c1")[0]
+    o = Oracle((64, 64, 1), (-6.0, -6.0, -0.5), (6.0, 6.0, 0.5), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.000001, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
+               bc=("outflow",) * 4 + ("periodic",) * 2, integrator="rk2")
+    o.set_conductivity("conductivity", cond=0.05)
+    o.pgen_gaussian_bump(sigma=0.5, temperature_bump=5.0)
+    e0, s0 = o.history()[4], o.interior(o.gprim)[5].max()
+    o.evolve(1.0, 40)
+    assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
+    assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+    # gamma = 1.000001 makes cv = 1e6: the diffusivity K/(rho cv) is tiny, the peak only just moves
+    assert o.interior(o.gprim)[5].max() < s0 and abs(o.history()[4] - e0) < 1e-12 * e0
