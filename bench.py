@@ -60,6 +60,24 @@ def cpu_baseline(n, cycles):
     return n ** 3 * done / dt, dt, done
 
 
+def cpu_baseline_ssheet(n, ndust, cycles):
+    """The config-3 workload on the CPU oracle: n^2 dusty shearing sheet with drag."""
+    from oracle.oracle import Oracle
+    o = Oracle((n, n, 1), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2), ng=2, ns_gas=1, ns_dust=ndust, reconstruct="plm",
+               riemann="hllc", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.000001, dfloor=1e-10,
+               siefloor=1e-10, dust_dfloor=1e-10, cfl=0.3, dust_cfl=0.3,
+               bc=("extrap", "extrap", "inflow", "inflow", "extrap", "extrap"), integrator="rk2")
+    o.set_rotating_frame(1.0, 1.5)
+    o.set_gravity_point(1e-5, soft=0.03)
+    o.set_drag("simple_dust", "constant", tau=[0.1] * ndust)
+    o.pgen_strat(rho0=1.0, dens_min=1e-10, h=0.05)
+    o.evolve(-1.0, 1)
+    t0 = time.perf_counter()
+    done = o.evolve(-1.0, 1 + cycles)
+    dt = time.perf_counter() - t0
+    return n * n * done / dt, dt, done, n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +94,10 @@ def main():
                     help="diagnostic: cut each rank's 256^3 into this many mesh blocks along x3")
     ap.add_argument("--loopback", action="store_true",
                     help="diagnostic: route block-to-block slabs of ONE GPU through RCCL send/recv-to-self")
+    ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "ssheet_dust"],
+                    help="sedov3d = the headline metric (BASELINE configs[1]); ssheet_dust = SURVEY config 3 "
+                         "(2-D dusty shearing sheet with drag, general fused stage; --n is the mesh edge, 1 GPU)")
+    ap.add_argument("--dust", type=int, default=1, help="ssheet_dust: number of dust species")
     ap.add_argument("--cpu-n", type=int, default=256)
     ap.add_argument("--cpu-cycles", type=int, default=3)
     args = ap.parse_args()
@@ -107,11 +129,24 @@ def main():
         comm = TorchComm(torch.device("cuda", local_rank))
 
     per_gpu = (args.n, args.n, args.n)
-    deck = os.path.join(ROOT, "inputs", "blast", "blast.in")
-    extra = []
-    if args.blocks_per_gpu > 1:
-        extra = ["parthenon/meshblock/nx3=%d" % (args.n // args.blocks_per_gpu)]
-    sim = Simulation(deck, overrides(args.gpus, per_gpu, args.warmup + args.steps, extra), comm=comm)
+    if args.workload == "ssheet_dust":
+        if args.gpus != 1:
+            raise SystemExit("--workload ssheet_dust is a single-GPU measurement")
+        deck = os.path.join(ROOT, "inputs", "ssheet", "ssheet.in")
+        n = str(args.n)
+        ov = ["parthenon/mesh/nx1=" + n, "parthenon/mesh/nx2=" + n, "parthenon/meshblock/nx1=" + n,
+              "parthenon/meshblock/nx2=" + n, "physics/dust=true", "physics/drag=true",
+              "dust/nspecies=%d" % args.dust, "dust/cfl=0.3", "dust/reconstruct=plm", "dust/riemann=hlle",
+              "dust/dfloor=1.0e-10", "dust/stopping_time/type=constant",
+              "dust/stopping_time/tau=" + ",".join(["0.1"] * args.dust), "drag/type=simple_dust",
+              "parthenon/time/tlim=-1.0", "parthenon/time/nlim=%d" % (args.warmup + args.steps)]
+        sim = Simulation(deck, ov)
+    else:
+        deck = os.path.join(ROOT, "inputs", "blast", "blast.in")
+        extra = []
+        if args.blocks_per_gpu > 1:
+            extra = ["parthenon/meshblock/nx3=%d" % (args.n // args.blocks_per_gpu)]
+        sim = Simulation(deck, overrides(args.gpus, per_gpu, args.warmup + args.steps, extra), comm=comm)
     if args.path == "unfused":
         sim.set_path("unfused")
     want_overlap = (world > 1 or args.loopback or bool(os.environ.get("ARTEMIS_FORCE_OVERLAP"))) and not args.no_overlap
@@ -152,7 +187,6 @@ def main():
                 "workload": "inputs/blast 3-D Sedov (BASELINE configs[1]): Cartesian %d^3 cells/GPU, "
                             "gas HLLC+PLM, rk2, cfl 0.3, gamma 1.4, outflow, nghost 2, radius 0.03, "
                             "samples 0" % args.n,
-                "mesh": [int(x) for x in (total_zones // (per_gpu[1] * per_gpu[2] * (1 if args.gpus < 4 else 2) * (1 if args.gpus < 8 else 2)),)] if False else None,
                 "cells_per_gpu": local_zones, "path": "fused" if fused else "unfused",
                 "decomposition": "%d rank(s), one %d^3 mesh block each, face-slab halo exchange%s"
                                  % (args.gpus, args.n, "" if world == 1 else
@@ -161,8 +195,23 @@ def main():
                 "total_energy_check": float(hist[4]),
             },
         }
-        out["config"].pop("mesh")
-        if fused and nlaunch:
+        if args.workload == "ssheet_dust":
+            # B_alg per cell-stage = 8 B * 5 * (6 ns_gas + 4 ns_dust); one "launch" = one stage
+            # of the general fused path (gas kernel + dust kernel + drag/aux/c2p finish)
+            bps = 8.0 * 5.0 * (6 + 4 * args.dust)
+            out["metric"] = "cell-updates/sec (zone-cycles/s), %d^2 dusty shearing sheet" % args.n
+            out["config"]["workload"] = ("SURVEY config 3: inputs/ssheet strat problem, Cartesian %d^2, gas + %d dust "
+                                         "species, simple_dust drag, shearing box, point-mass gravity, extrap/inflow "
+                                         "BCs, HLLC gas / HLLE dust + PLM, rk2" % (args.n, args.dust))
+            out["config"]["decomposition"] = "1 rank, one mesh block"
+            if fused and nlaunch:
+                alg = bps * local_zones
+                achieved = alg / (kms * 1.0e-3) / 1.0e9
+                out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "kernel": "general fused stage: stage_cell_kernel<gas> + <dust> + simple_drag_kernel<finish>",
+                                   "launch_ms": kms, "launches_timed": nlaunch, "algorithmic_bytes_per_launch": alg}
+        elif fused and nlaunch:
             alg = ALG_BYTES_PER_CELL_STAGE * local_zones  # bytes per launch (one stage, one rank)
             achieved = alg / (kms * 1.0e-3) / 1.0e9
             traffic = None
@@ -177,7 +226,12 @@ def main():
                                "kernel": "stage_fused_kernel<hllc,plm>", "launch_ms": kms,
                                "launches_timed": nlaunch,
                                "algorithmic_bytes_per_launch": alg}
-        if args.gpus == 1 and not args.no_cpu_baseline:
+        if args.workload == "ssheet_dust" and not args.no_cpu_baseline:
+            v, secs, cyc, cn = cpu_baseline_ssheet(min(args.n, 512), args.dust, args.cpu_cycles)
+            out["cpu_baseline"] = {
+                "value": v, "unit": "zone-cycles/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": "CPU oracle (OpenMP, all host cores), same problem at %d^2, %d cycles, %.1f s" % (cn, cyc, secs)}
+        elif args.gpus == 1 and not args.no_cpu_baseline:
             v, secs, cyc = cpu_baseline(args.cpu_n, args.cpu_cycles)
             out["cpu_baseline"] = {
                 "value": v, "unit": "zone-cycles/s", "cores": os.cpu_count(), "kind": "port",

@@ -1,5 +1,7 @@
 import sys, time, numpy as np
-sys.path.insert(0,'/root/repo')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from artemis_amd.driver import Simulation
 N = sys.argv[2] if len(sys.argv) > 2 else "1024"
 ov = ["parthenon/mesh/nx1="+N,"parthenon/mesh/nx2="+N,"parthenon/meshblock/nx1="+N,"parthenon/meshblock/nx2="+N,
@@ -9,7 +11,7 @@ ov = ["parthenon/mesh/nx1="+N,"parthenon/mesh/nx2="+N,"parthenon/meshblock/nx1="
 if "--sync" not in sys.argv:
     ov.append("parthenon/time/tlim=-1.0")  # no time limit: dt stays on the device, no per-step sync
 sys.argv = [a for a in sys.argv if a != "--sync"]
-s = Simulation("/root/repo/inputs/ssheet/ssheet.in", ov)
+s = Simulation(os.path.join(ROOT, "inputs", "ssheet", "ssheet.in"), ov)
 if len(sys.argv) > 3: s.set_path(sys.argv[3])
 s.evolve(10)
 import torch; torch.cuda.synchronize()
