@@ -207,8 +207,15 @@ def main():
             if fused and nlaunch:
                 alg = bps * local_zones
                 achieved = alg / (kms * 1.0e-3) / 1.0e9
+                traffic = None
+                pmc = os.path.join(ROOT, "profiles", "r01c_cfg3_pmc_traffic.json")
+                if args.n == 4096 and args.dust == 1 and os.path.exists(pmc):  # measured for this size only
+                    try:
+                        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    except Exception:
+                        traffic = None
                 out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                    "kernel": "general fused stage: stage_cell_kernel<gas> + <dust> + simple_drag_kernel<finish>",
                                    "launch_ms": kms, "launches_timed": nlaunch, "algorithmic_bytes_per_launch": alg}
         elif fused and nlaunch:
