@@ -28,7 +28,7 @@ def coord_select(sys, ndim):
 HLLC, HLLE, LLF = 0, 1, 2
 PCM, PLM, PPM = 0, 1, 2
 GAS, DUST = 0, 1
-BC_PERIODIC, BC_OUTFLOW, BC_REFLECT, BC_NONE, BC_STRAT_EXTRAP, BC_STRAT_INFLOW = range(6)
+BC_PERIODIC, BC_OUTFLOW, BC_REFLECT, BC_NONE, BC_STRAT_EXTRAP, BC_STRAT_INFLOW, BC_CONDUCTIVE = range(7)
 GRAVITY_UNIFORM, GRAVITY_POINT = 1, 2
 DRAG_SIMPLE_DUST, DRAG_SELF = 1, 2
 DRAG_CONSTANT, DRAG_STOKES = 0, 1
@@ -38,7 +38,7 @@ RSOLVER = {"hllc": HLLC, "hlle": HLLE, "llf": LLF}
 RECON = {"pcm": PCM, "plm": PLM, "ppm": PPM}
 BCS = {"periodic": BC_PERIODIC, "outflow": BC_OUTFLOW, "reflecting": BC_REFLECT,
        "reflect": BC_REFLECT, "none": BC_NONE, "extrap": BC_STRAT_EXTRAP,
-       "inflow": BC_STRAT_INFLOW}
+       "inflow": BC_STRAT_INFLOW, "conductive": BC_CONDUCTIVE}
 
 PP = C.c_void_p  # device pointer tables are opaque to the host
 
@@ -74,7 +74,9 @@ class StageArgs(C.Structure):
 
 
 class BcParams(C.Structure):
-    _fields_ = [("qshear", C.c_double), ("omega", C.c_double)]
+    _fields_ = [("qshear", C.c_double), ("omega", C.c_double), ("cond_temp", C.c_double),
+                ("cond_flux", C.c_double), ("cond_g", C.c_double * 3), ("cond_coeff", C.c_double),
+                ("cond_cv", C.c_double), ("cond_type", C.c_int)]
 
 
 class Gravity(C.Structure):

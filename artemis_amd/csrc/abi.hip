@@ -205,9 +205,19 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
   if (int rc = validate(p)) return rc;
   if (!bc) return fail(ARTEMIS_HIP_EINVAL, "null bc array");
   for (int i = 0; i < 6 * p->nblocks; ++i) {
-    if (bc[i] < ARTEMIS_BC_PERIODIC || bc[i] > ARTEMIS_BC_STRAT_INFLOW)
+    if (bc[i] < ARTEMIS_BC_PERIODIC || bc[i] > ARTEMIS_BC_CONDUCTIVE)
       return fail(ARTEMIS_HIP_EINVAL, "unknown boundary flag %d", bc[i]);
     const int d = (i % 6) / 2;
+    if (bc[i] == ARTEMIS_BC_CONDUCTIVE) {
+      if (p->coords != ARTEMIS_CARTESIAN)
+        return fail(ARTEMIS_HIP_EUNSUPPORTED, "conductive boundary condition: Cartesian only");
+      if (!params) return fail(ARTEMIS_HIP_EINVAL, "conductive conditions need artemis_bc_params_t");
+      if (params->cond_type != ARTEMIS_CONDUCTIVITY_PLAW && params->cond_type != ARTEMIS_THERMALDIFF_PLAW)
+        return fail(ARTEMIS_HIP_EINVAL, // conduction.hpp:246-248
+                    "Chosen conductivity type is not compatible with conductivity boundaries");
+      if (!(params->cond_cv > 0.0)) return fail(ARTEMIS_HIP_EINVAL, "conductive conditions: cv must be positive");
+      if (p->gas.nspecies > 1) return fail(ARTEMIS_HIP_EINVAL, "Cond pgen requires a single gas species.");
+    }
     if (bc[i] == ARTEMIS_BC_STRAT_EXTRAP || bc[i] == ARTEMIS_BC_STRAT_INFLOW) {
       const bool extrap = (bc[i] == ARTEMIS_BC_STRAT_EXTRAP);
       if ((extrap && d == 1) || (!extrap && d != 1)) // problem_modifier.hpp:117-128

@@ -100,7 +100,7 @@ struct Link { // one directed ghost-slab transfer out of local block b through f
   int tag_send, tag_recv;
 };
 
-enum { PG_BLAST, PG_LINWAVE, PG_ADVECTION, PG_CONSTANT, PG_STRAT, PG_BUMP };
+enum { PG_BLAST, PG_LINWAVE, PG_ADVECTION, PG_CONSTANT, PG_STRAT, PG_BUMP, PG_COND };
 
 } // namespace
 
@@ -131,7 +131,7 @@ struct artemis_sim {
   artemis_gravity_t grav;
   Real rf_omega = 0.0, rf_qshear = 0.0;
   artemis_drag_t drag;
-  artemis_bc_params_t bcpar = {0.0, 0.0};
+  artemis_bc_params_t bcpar = {};
   // gas diffusion (gas.cpp:180-197): viscosity and / or heat conduction
   bool do_viscosity = false, do_conduction = false;
   artemis_diffusion_t diff;
@@ -242,6 +242,7 @@ int parse_bc(const std::string &s, int pgen, int dir) {
   // user conditions are registered per problem (problem_modifier.hpp:114-128)
   if (pgen == PG_STRAT && s == "extrap" && dir != 1) return ARTEMIS_BC_STRAT_EXTRAP;
   if (pgen == PG_STRAT && s == "inflow" && dir == 1) return ARTEMIS_BC_STRAT_INFLOW;
+  if (pgen == PG_COND && s == "conductive") return ARTEMIS_BC_CONDUCTIVE; // problem_modifier.hpp:95-108
   throw std::runtime_error("boundary flag '" + s + "' is not built for this problem "
                            "(periodic|outflow|reflecting; strat: extrap on x1/x3, inflow on x2)");
 }
@@ -289,6 +290,7 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   else if (problem == "constant") pgen = PG_CONSTANT;
   else if (problem == "strat") pgen = PG_STRAT;
   else if (problem == "gaussian_bump") pgen = PG_BUMP;
+  else if (problem == "conduction") pgen = PG_COND;
   else throw std::runtime_error("problem generator '" + problem + "' is not built");
   // <physics> (artemis.cpp:63-72); everything but gas/dust must stay off
   do_gas = pin.GetOrAddBoolean("physics", "gas", true);
@@ -323,7 +325,7 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   else if (sys == "cylindrical") coords = ARTEMIS_CYLINDRICAL;
   else if (sys == "axisymmetric") coords = ARTEMIS_AXISYMMETRIC;
   else throw std::runtime_error("Coordinate type not recognized!");
-  if (coords != ARTEMIS_CARTESIAN && pgen != PG_BLAST)
+  if (coords != ARTEMIS_CARTESIAN && pgen != PG_BLAST && pgen != PG_COND)
     throw std::runtime_error("problem generator '" + problem + "' is Cartesian-only");
   // <gravity> (gravity.cpp:25-118); G = 1 in scale-free units (units.cpp:68-76)
   if (do_gravity) {
@@ -449,6 +451,16 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
     if (coords != ARTEMIS_CARTESIAN) throw std::runtime_error("gas diffusion in curvilinear coordinates is not built yet");
     if (ng < 2) throw std::runtime_error("gas diffusion needs nghost >= 2");
     edge_ghosts = do_viscosity; // the strain tensor reads edge / corner ghost zones
+  }
+  if (pgen == PG_COND) { // conduction.hpp:39-54 InitCondParams + what CondBoundaryImpl reads
+    if (!do_conduction) throw std::runtime_error("problem = conduction requires physics/conduction");
+    if (coords != ARTEMIS_CARTESIAN) throw std::runtime_error("problem = conduction: only Cartesian coordinates are built");
+    bcpar.cond_temp = pin.GetOrAddReal("problem", "gas_temp", 1.0);
+    bcpar.cond_flux = pin.GetOrAddReal("problem", "flux", 0.0);
+    for (int d = 0; d < 3; ++d) bcpar.cond_g[d] = (do_gravity && grav.type == ARTEMIS_GRAVITY_UNIFORM) ? grav.g[d] : 0.0;
+    bcpar.cond_coeff = diff.cond.coeff, bcpar.cond_cv = diff.cv, bcpar.cond_type = diff.cond.type;
+    if (diff.cond.temp_exp != 0.0 || diff.cond.rho_exp != 0.0)
+      throw std::runtime_error("conductive boundaries with power-law conductivity are not built");
   }
   // <dust> (dust.cpp:45-110)
   if (do_dust) {
@@ -894,6 +906,14 @@ void artemis_sim::problem_generator() {
     st.dens_min = pin.GetOrAddReal("problem", "dens_min", 1.0e-5);
     st.d2g = pin.GetOrAddReal("problem", "dust_to_gas", 0.01);
   }
+  struct { Real g_rho = 1, g_v[3] = {0, 0, 0}, g_temp = 1; } cd;
+  if (pgen == PG_COND) {
+    if (!do_gas || ns_gas != 1 || do_dust) throw std::runtime_error("Cond pgen requires a single gas species.");
+    cd.g_rho = pin.GetOrAddReal("problem", "gas_rho", 1.0);
+    cd.g_v[0] = pin.GetOrAddReal("problem", "gas_vx1", 0.0), cd.g_v[1] = pin.GetOrAddReal("problem", "gas_vx2", 0.0);
+    cd.g_v[2] = pin.GetOrAddReal("problem", "gas_vx3", 0.0);
+    cd.g_temp = pin.GetOrAddReal("problem", "gas_temp", 1.0);
+  }
   struct { Real xc[3] = {0, 0, 0}, sig = 1, dfac = 0, tfac = 0, ufac = 0, vfac = 0, wfac = 0, g_rho = 1, g_v[3] = {0, 0, 0}, g_pres = 1; } bp;
   if (pgen == PG_BUMP) { // gaussian_bump.hpp:55-74
     if (!do_gas || ns_gas != 1 || do_dust) throw std::runtime_error("Gaussian bump pgen requires a single gas species (dust is not built).");
@@ -937,6 +957,18 @@ void artemis_sim::problem_generator() {
               hd[(ns_dust + 3 * n + 1) * N + c] = (cs.d_v[0] * ex2[0] + cs.d_v[1] * ex2[1] + cs.d_v[2] * ex2[2]);
               hd[(ns_dust + 3 * n + 2) * N + c] = (cs.d_v[0] * ex3[0] + cs.d_v[1] * ex3[1] + cs.d_v[2] * ex3[2]);
             }
+          } else if (pgen == PG_COND) { // conduction.hpp:88-103
+            const Real gm1c = gamma - 1.0;
+            const Real gx1 = (do_gravity && grav.type == ARTEMIS_GRAVITY_UNIFORM) ? grav.g[0] : 0.0;
+            const Real P0 = std::max(0.0, gm1c * cd.g_rho * cv * cd.g_temp);
+            const Real Rgas = P0 / (cd.g_rho * cd.g_temp);
+            const Real Pz = P0 * std::exp(gx1 * cd.g_rho / P0 * (xv[0] - xmin[0]));
+            const Real dens = Pz / (Rgas * cd.g_temp);
+            hg[0 * N + c] = dens;
+            hg[(ns_gas + 0) * N + c] = cd.g_v[0];
+            hg[(ns_gas + 1) * N + c] = cd.g_v[1];
+            hg[(ns_gas + 2) * N + c] = cd.g_v[2];
+            hg[(5 * ns_gas) * N + c] = std::max(0.0, cv * cd.g_temp);
           } else if (pgen == PG_BUMP) { // gaussian_bump.hpp:112-178, problem/system = cartesian
             const Real dxs = SQR(xv[0] - bp.xc[0]) + SQR(xv[1] - bp.xc[1]) * (ndim >= 2) +
                              SQR(xv[2] - bp.xc[2]) * (ndim == 3);

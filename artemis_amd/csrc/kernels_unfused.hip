@@ -537,6 +537,53 @@ __global__ __launch_bounds__(256) void strat_bc_kernel(const StratBcArgs a, cons
   }
 }
 
+// The `conduction` problem's user condition (pgen/conduction.hpp:105-232), Cartesian, gas species 0:
+// ghost temperature from a fixed heat flux (inner faces) or a fixed value (outer faces), density
+// from hydrostatic balance, velocities copied from the first active zone `ia` along d.
+struct CondBcArgs {
+  int d, side, ng, st, en;
+  double g_temp, flux, gx, coeff, cv, gm1;
+  int type;
+};
+__global__ __launch_bounds__(256) void conductive_bc_kernel(const CondBcArgs a, const FillTabs t,
+                                                            const double *geom, int ni, int nj, int nk) {
+  int ext[3] = {ni, nj, nk};
+  ext[a.d] = a.ng;
+  const long ncell = static_cast<long>(ext[0]) * ext[1] * ext[2];
+  const long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (tid >= ncell || t.nsg == 0) return;
+  int idx[3];
+  idx[0] = tid % ext[0];
+  idx[1] = (tid / ext[0]) % ext[1];
+  idx[2] = tid / (static_cast<long>(ext[0]) * ext[1]);
+  idx[a.d] = (a.side == 0) ? a.st - 1 - idx[a.d] : a.en + 1 + idx[a.d];
+  int ia[3] = {idx[0], idx[1], idx[2]};
+  ia[a.d] = (a.side == 0) ? a.st : a.en;
+  const long c = (static_cast<long>(idx[2]) * nj + idx[1]) * ni + idx[0];
+  const long cA = (static_cast<long>(ia[2]) * nj + ia[1]) * ni + ia[0];
+  const double *g = geom + 6 * t.b;
+  auto centre = [&](int q, int m) { return 0.5 * ((g[2 * q] + m * g[2 * q + 1]) + (g[2 * q] + (m + 1) * g[2 * q + 1])); };
+  // Coords::Distance between the two cell centres (geometry.hpp:407-412)
+  const double dist = sqrt(sqr(centre(0, idx[0]) - centre(0, ia[0])) + sqr(centre(1, idx[1]) - centre(1, ia[1])) +
+                           sqr(centre(2, idx[2]) - centre(2, ia[2])));
+  const bool INNER = (a.side == 0);
+  const double xma = (INNER ? -1. : 1.) * dist;
+  const int nsg = t.nsg;
+  double *rho = t.gas[t.b * 6 * nsg + 0], *se = t.gas[t.b * 6 * nsg + 5 * nsg];
+  const double da = rho[cA], siea = se[cA];
+  const double Ta = amax(0.0, siea / a.cv);
+  const double ka = (a.type == ARTEMIS_CONDUCTIVITY_PLAW) ? a.coeff * 1.0 * 1.0 : a.coeff * 1.0 * 1.0 * da * a.cv;
+  double Tg = a.g_temp;
+  if (INNER) Tg = Ta - a.flux * xma / ka;
+  const double densg = da * (Ta - 0.5 * a.gx * xma) / (Tg + 0.5 * a.gx * xma);
+  const double sieg = amax(0.0, a.cv * Tg);
+  rho[c] = densg, se[c] = sieg;
+  for (int q = 0; q < 3; ++q) {
+    double *v = t.gas[t.b * 6 * nsg + nsg + q];
+    v[c] = v[cA];
+  }
+}
+
 // All ghost cells of one block in ONE launch.  Parthenon applies periodic images, then x1, x2, x3
 // physical conditions, each pass over the entire extent of the other dimensions; every pass
 // remaps one index (and flips the sign of the normal velocity for reflecting walls), so the
@@ -737,7 +784,14 @@ static void launch_bc_sequential(const PackView &P, int b, const int *bc6,
         long ncell = P.ng;
         for (int q = 0; q < 3; ++q)
           if (q != d) ncell *= ext[q];
-        if (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW) {
+        if (flag == ARTEMIS_BC_CONDUCTIVE) {
+          CondBcArgs a;
+          a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
+          a.g_temp = par->cond_temp, a.flux = par->cond_flux, a.gx = par->cond_g[d];
+          a.coeff = par->cond_coeff, a.cv = par->cond_cv, a.gm1 = P.gm1, a.type = par->cond_type;
+          hipLaunchKernelGGL(conductive_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P.geom,
+                             P.ni, P.nj, P.nk);
+        } else if (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW) {
           StratBcArgs a;
           a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
           a.q = par->qshear, a.om0 = par->omega, a.x1f0 = 0.0, a.dx1 = 0.0;
@@ -760,7 +814,8 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
     for (int f = 0; f < 6; ++f) {
       a.bc[f] = (f / 2 < P.ndim) ? bc[b * 6 + f] : ARTEMIS_BC_NONE;
       any = any || (a.bc[f] != ARTEMIS_BC_NONE);
-      user = user || a.bc[f] == ARTEMIS_BC_STRAT_EXTRAP || a.bc[f] == ARTEMIS_BC_STRAT_INFLOW;
+      user = user || a.bc[f] == ARTEMIS_BC_STRAT_EXTRAP || a.bc[f] == ARTEMIS_BC_STRAT_INFLOW ||
+             a.bc[f] == ARTEMIS_BC_CONDUCTIVE;
     }
     if (!any) continue;
     if (user) {

@@ -139,14 +139,24 @@ class MeshBlockPack:
         self._call(self.L.artemis_hip_estimate_dt, fluid, cfl, C.byref(out))
         return out.value
 
-    def ApplyBoundaryConditions(self, bc, strat=None):
+    def ApplyBoundaryConditions(self, bc, strat=None, conductive=None):
         """bc: per-block list of 6 names/flags (ix1, ox1, ix2, ox2, ix3, ox3); strat = (qshear,
         omega) when a block carries the strat problem's `extrap` / `inflow` conditions."""
         flat = []
         for row in bc:
             flat += [capi.BCS[x] if isinstance(x, str) else int(x) for x in row]
         arr = (C.c_int * len(flat))(*flat)
-        par = C.byref(capi.BcParams(*strat)) if strat is not None else None
+        par = None
+        if strat is not None or conductive is not None:
+            bp = capi.BcParams()
+            if strat is not None:
+                bp.qshear, bp.omega = strat
+            if conductive is not None:  # dict(temp, flux, g=(gx1,gx2,gx3), coeff, cv, type)
+                bp.cond_temp, bp.cond_flux = conductive["temp"], conductive["flux"]
+                bp.cond_g[:] = list(conductive.get("g", (0.0, 0.0, 0.0)))
+                bp.cond_coeff, bp.cond_cv = conductive["coeff"], conductive["cv"]
+                bp.cond_type = conductive.get("type", capi.CONDUCTIVITY_PLAW)
+            par = C.byref(bp)
         self._call(self.L.artemis_hip_apply_bc, arr, par)
 
     def new_dust_prim_buffer(self, name):

@@ -58,7 +58,10 @@ enum artemis_bc { ARTEMIS_BC_PERIODIC = 0, ARTEMIS_BC_OUTFLOW = 1, ARTEMIS_BC_RE
                   /* user conditions of the `strat` problem (pgen/strat.hpp:158-466, registered as
                    * `extrap` / `inflow` at problem_modifier.hpp:114-128): */
                   ARTEMIS_BC_STRAT_EXTRAP = 4, /* x1 faces */
-                  ARTEMIS_BC_STRAT_INFLOW = 5  /* x2 faces */ };
+                  ARTEMIS_BC_STRAT_INFLOW = 5, /* x2 faces */
+                  /* `conductive` of the `conduction` problem (pgen/conduction.hpp:105-232): fixed heat
+                   * flux through inner faces, fixed temperature at outer ones; Cartesian */
+                  ARTEMIS_BC_CONDUCTIVE = 6 };
 enum artemis_gravity_type { ARTEMIS_GRAVITY_UNIFORM = 1, ARTEMIS_GRAVITY_POINT = 2 };
 enum artemis_drag_type { ARTEMIS_DRAG_SIMPLE_DUST = 1, ARTEMIS_DRAG_SELF = 2 }; /* drag.hpp:57 */
 enum artemis_drag_model { ARTEMIS_DRAG_CONSTANT = 0, ARTEMIS_DRAG_STOKES = 1 }; /* drag.hpp:58 */
@@ -154,7 +157,12 @@ int artemis_hip_metric_fill(const artemis_pack_t *p, const double *geom_host, do
  * unless a STRAT flag is present) carries what the strat conditions read from StratParams
  * (strat.hpp:44-52, :60-61): the shear rate q and the frame frequency Om0. */
 typedef struct artemis_bc_params {
-  double qshear, omega;
+  double qshear, omega;       /* strat conditions */
+  /* conductive conditions (conduction.hpp:30-37 CondParams, :181-196): boundary temperature, heat
+   * flux, uniform gravity along x1/x2/x3 (0 when gravity is off or not uniform), the constant heat
+   * conductivity K or diffusivity (K = kappa*rho*cv) and the IdealGas specific heat */
+  double cond_temp, cond_flux, cond_g[3], cond_coeff, cond_cv;
+  int cond_type;              /* ARTEMIS_CONDUCTIVITY_PLAW | ARTEMIS_THERMALDIFF_PLAW (zero exponents) */
 } artemis_bc_params_t;
 int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_bc_params_t *params,
                          void *stream);

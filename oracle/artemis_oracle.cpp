@@ -45,7 +45,7 @@ enum { RS_HLLC = 0, RS_HLLE = 1, RS_LLF = 2 };
 enum { RC_PCM = 0, RC_PLM = 1, RC_PPM = 2 };
 enum { FL_GAS = 0, FL_DUST = 1 };
 enum { BC_PERIODIC = 0, BC_OUTFLOW = 1, BC_REFLECT = 2, BC_NONE = 3, BC_STRAT_EXTRAP = 4,
-       BC_STRAT_INFLOW = 5 }; // 4/5: the `strat` pgen's user conditions (problem_modifier.hpp:114-128)
+       BC_STRAT_INFLOW = 5, BC_CONDUCTIVE = 6 }; // 4/5: the `strat` pgen's user conditions (problem_modifier.hpp:114-128)
 enum { INT_RK1 = 0, INT_RK2 = 1, INT_VL2 = 2, INT_RK3 = 3 };
 
 struct oracle_cfg {
@@ -111,6 +111,9 @@ struct Sim {
   struct { // pgen/strat.hpp:44-52 (only what the user BCs read)
     Real q = 0, Om0 = 0;
   } strat;
+  struct { // pgen/conduction.hpp:30-37 CondParams (what the `conductive` conditions read)
+    Real g_temp = 1, flux = 0;
+  } condbc;
   // diffusion (utils/diffusion/diffusion_coeff.hpp:58-136 DiffCoeffParams); type 0 = package off
   struct DiffCoeff {
     int type = 0; // 1 viscosity_plaw, 2 viscosity_alpha, 3 conductivity_plaw, 4 thermaldiff_plaw
@@ -1859,7 +1862,7 @@ void fill_dir(Sim &s, std::vector<Real> &prim, int nvar, int nsp, bool gas, int 
   const int ext[3] = {s.ni, s.nj, s.nk};
   for (int side = 0; side < 2; ++side) {
     const int bc = s.c.bc[2 * d + side];
-    if (bc == BC_NONE || bc == BC_STRAT_EXTRAP || bc == BC_STRAT_INFLOW) continue;
+    if (bc == BC_NONE || bc == BC_STRAT_EXTRAP || bc == BC_STRAT_INFLOW || bc == BC_CONDUCTIVE) continue;
     if ((pass == 0) != (bc == BC_PERIODIC)) continue;
     for (int n = 0; n < nvar; ++n) {
       if (gas && n >= 4 * nsp && n < 5 * nsp) continue; // pressure slot is not FillGhost
@@ -1965,6 +1968,44 @@ void strat_bc(Sim &s, int d, int side) {
         }
       }
 }
+// pgen/conduction.hpp:105-232 CondBoundaryImpl (`conductive`, problem = conduction): fixed heat flux
+// through the inner face, fixed temperature at the outer one, hydrostatic density, velocities
+// copied from the first active zone.  `ia` = the active zone next to the boundary along d.
+void conductive_bc(Sim &s, int d, int side) {
+  const int nsp = s.c.ns_gas;
+  if (!nsp) return;
+  const bool INNER = (side == 0);
+  const int lo[3] = {s.is, s.js, s.ks}, hi[3] = {s.ie, s.je, s.ke};
+  int b0[3] = {0, 0, 0}, b1[3] = {s.ni - 1, s.nj - 1, s.nk - 1};
+  if (INNER) b1[d] = lo[d] - 1;
+  else b0[d] = hi[d] + 1;
+  const Real gx1 = (s.grav.type == 1) ? s.grav.g[d] : 0.0; // :181-196
+  const Real gm1 = s.c.gamma - 1.0;
+  for (int k = b0[2]; k <= b1[2]; ++k)
+    for (int j = b0[1]; j <= b1[1]; ++j)
+      for (int i = b0[0]; i <= b1[0]; ++i) {
+        int ia[3] = {i, j, k};
+        ia[d] = INNER ? lo[d] : hi[d];
+        const Coords coords(s, k, j, i), ca(s, ia[2], ia[1], ia[0]);
+        const Real xv[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
+        const Real xva[3] = {ca.x1v(), ca.x2v(), ca.x3v()};
+        const Real xma = (INNER ? -1. : 1.) * distance(coords, xv, xva);
+        const size_t c = IDX(s, k, j, i), cA = IDX(s, ia[2], ia[1], ia[0]);
+        const Real da = s.gprim[0 * s.N + cA];
+        const Real siea = s.gprim[(5 * nsp) * s.N + cA];
+        const Real Ta = std::max(0.0, siea / s.cv);
+        const Real Pa = std::max(0.0, gm1 * da * siea);
+        (void)Pa;
+        const Real ka = diff_coeff(s, s.cond, 0, ia[2], ia[1], ia[0]);
+        Real Tg = s.condbc.g_temp;
+        if (INNER) Tg = Ta - s.condbc.flux * xma / ka;
+        const Real densg = da * (Ta - 0.5 * gx1 * xma) / (Tg + 0.5 * gx1 * xma);
+        const Real sieg = std::max(0.0, s.cv * Tg);
+        s.gprim[0 * s.N + c] = densg;
+        s.gprim[(5 * nsp) * s.N + c] = sieg;
+        for (int q = 0; q < 3; ++q) s.gprim[(nsp + q) * s.N + c] = s.gprim[(nsp + q) * s.N + cA];
+      }
+}
 void apply_bcs(Sim &s) {
   for (int pass = 0; pass < 2; ++pass)
     for (int d = 0; d < 3; ++d) {
@@ -1975,6 +2016,7 @@ void apply_bcs(Sim &s) {
           const int bc = s.c.bc[2 * d + side];
           if ((d == 0 && bc == BC_STRAT_EXTRAP) || (d == 1 && bc == BC_STRAT_INFLOW))
             strat_bc(s, d, side);
+          if (bc == BC_CONDUCTIVE) conductive_bc(s, d, side);
         }
     }
 }
@@ -2341,6 +2383,35 @@ void oracle_viscous_flux(void *h) { viscous_flux(*static_cast<Sim *>(h)); }
 void oracle_thermal_flux(void *h) { thermal_flux(*static_cast<Sim *>(h)); }
 void oracle_diffusion_update(void *h, double dt) { diffusion_update(*static_cast<Sim *>(h), dt); }
 double *oracle_qflux(void *h, int d) { return static_cast<Sim *>(h)->qflux[d].data(); }
+
+// pgen/conduction.hpp:58-104: isothermal hydrostatic column under uniform gravity gx1 (mass at
+// rest unless gas_vx* say otherwise); P = Gamma rho Cv T for the IdealGas (singularity-eos, recalled).
+void oracle_pgen_conduction(void *h, double g_rho, double g_vx1, double g_vx2, double g_vx3,
+                            double g_temp, double flux) {
+  Sim &s = *static_cast<Sim *>(h);
+  const int nsp = s.c.ns_gas;
+  s.condbc.g_temp = g_temp, s.condbc.flux = flux;
+  const Real gx1 = (s.grav.type == 1) ? s.grav.g[0] : 0.0;
+  const Real x1min = s.gx1min;
+  const Real gm1 = s.c.gamma - 1.0;
+  for (int k = 0; k < s.nk; ++k)
+    for (int j = 0; j < s.nj; ++j)
+      for (int i = 0; i < s.ni; ++i) {
+        const Coords coords(s, k, j, i);
+        const Real xv0 = coords.x1v();
+        const Real P0 = std::max(0.0, gm1 * g_rho * s.cv * g_temp);
+        const Real Rgas = P0 / (g_rho * g_temp);
+        const Real P = P0 * std::exp(gx1 * g_rho / P0 * (xv0 - x1min));
+        const Real dens = P / (Rgas * g_temp);
+        const size_t c = IDX(s, k, j, i);
+        s.gprim[0 * s.N + c] = dens;
+        s.gprim[(nsp + 0) * s.N + c] = g_vx1;
+        s.gprim[(nsp + 1) * s.N + c] = g_vx2;
+        s.gprim[(nsp + 2) * s.N + c] = g_vx3;
+        s.gprim[(5 * nsp) * s.N + c] = std::max(0.0, s.cv * g_temp);
+      }
+  prim_to_cons(s);
+}
 
 // pgen/gaussian_bump.hpp:46-196 with problem/system = cartesian on a Cartesian mesh
 void oracle_pgen_gaussian_bump(void *h, const double *xc_bump, double sigma, double dfac, double tfac,

@@ -15,7 +15,7 @@ _LIB = os.path.join(_HERE, "_build", "liboracle.so")
 RS = {"hllc": 0, "hlle": 1, "llf": 2}
 RC = {"pcm": 0, "plm": 1, "ppm": 2}
 BC = {"periodic": 0, "outflow": 1, "reflecting": 2, "reflect": 2, "none": 3,
-      "extrap": 4, "inflow": 5}  # 4/5: the strat pgen's user conditions (problem_modifier.hpp:114-128)
+      "extrap": 4, "inflow": 5, "conductive": 6}  # 4/5: the strat pgen's user conditions (problem_modifier.hpp:114-128)
 INTEG = {"rk1": 0, "rk2": 1, "vl2": 2, "rk3": 3}
 GAS, DUST = 0, 1
 
@@ -126,6 +126,7 @@ def lib():
         L.oracle_qflux.restype = C.POINTER(d)
         L.oracle_qflux.argtypes = [vp, i]
         L.oracle_pgen_gaussian_bump.argtypes = [vp, C.POINTER(d)] + [d] * 11
+        L.oracle_pgen_conduction.argtypes = [vp] + [d] * 6
         _lib = L
     return _lib
 
@@ -319,6 +320,11 @@ class Oracle:
         xc = (C.c_double * 3)(*centre)
         self.L.oracle_pgen_gaussian_bump(self.h, xc, sigma, density_bump, temperature_bump, *v_bump,
                                          gas_rho, *gas_v, gas_pres)
+        if post_init:
+            self.post_init()
+
+    def pgen_conduction(self, gas_rho=1.0, gas_v=(0.0, 0.0, 0.0), gas_temp=1.0, flux=0.0, post_init=True):
+        self.L.oracle_pgen_conduction(self.h, gas_rho, *gas_v, gas_temp, flux)
         if post_init:
             self.post_init()
 

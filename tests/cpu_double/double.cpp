@@ -221,7 +221,15 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
     Bound B(p, b);
     B.load_state();
     for (int f = 0; f < 6; ++f) B.s->c.bc[f] = bc[6 * b + f];
-    if (par) B.s->strat.q = par->qshear, B.s->strat.Om0 = par->omega;
+    if (par) {
+      Sim &s = *B.s;
+      s.strat.q = par->qshear, s.strat.Om0 = par->omega;
+      s.condbc.g_temp = par->cond_temp, s.condbc.flux = par->cond_flux;
+      s.grav.type = 1;
+      for (int d = 0; d < 3; ++d) s.grav.g[d] = par->cond_g[d];
+      s.cond.type = par->cond_type, s.cond.hcond_0 = s.cond.kappa_0 = par->cond_coeff;
+      if (par->cond_cv > 0.0) s.cv = par->cond_cv;
+    }
     apply_bcs(*B.s);
     B.out(B.s->gprim, p->gas.prim, B.s->nvg), B.out(B.s->dprim, p->dust.prim, B.s->nvd);
   }

@@ -553,3 +553,32 @@ def test_conduction_deck_bitwise(hiplib):
     assert g.ncycle == o.ncycle == 25 and g.time == o.time and g.dt == o.dt
     assert np.array_equal(g.field("gas.prim"), o.gprim)
     assert g.dt < 0.3 * 0.375 / 3.0  # the conductive limit, not the sound-crossing time, sets dt
+
+
+def test_conduction_problem_deck_bitwise_and_reference_pin(hiplib):
+    """inputs/diffusion/conduction.in on the GPU: 300 cycles bit for bit against the oracle (with
+    gravity on, so the hydrostatic part of the conductive condition is live), then the deck as
+    tst/scripts/diffusion/thermal_diffusion.py:36-70 runs its Cartesian case -- t = 50, 372 529
+    cycles -- against the analytic steady state: mean |T/T_ans - 1| <= 5e-3."""
+    from artemis_amd.driver import Simulation
+    s = Simulation(DECK("diffusion", "conduction.in"), ["gravity/uniform/gx1=-0.02", "parthenon/time/nlim=300"])
+    o = Oracle((128, 1, 1), (0.2, -0.5, -0.5), (1.2, 0.5, 0.5), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.66667, dfloor=1e-10, siefloor=1e-15, cfl=0.3,
+               bc=("conductive", "conductive") + ("periodic",) * 4, integrator="rk2")
+    o.set_gravity_uniform(-0.02, 0.0, 0.0)
+    o.set_conductivity("conductivity", cond=0.1)
+    o.set_drag("self", "constant")
+    o.set_damping(0, inner=(4.0, -1.7976931348623157e308, -1.7976931348623157e308), inner_rate=(1.0e4, 0.0, 0.0))
+    o.pgen_conduction(gas_rho=1.0, gas_temp=0.05, flux=0.01)
+    s.evolve(), o.evolve(40.0, 300)
+    assert s.ncycle == o.ncycle == 300 and s.time == o.time and s.dt == o.dt
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    f = Simulation(DECK("diffusion", "conduction.in"), ["parthenon/time/tlim=50.0", "gas/conductivity/cond=0.10000000",
+                                                        "problem/flux=0.01000000", "problem/gas_temp=0.05000000"])
+    f.evolve()
+    assert abs(f.time - 50.0) < 1e-12 and f.ncycle > 300000
+    T = f.interior(f.field("gas.prim"))[5, 0, 0] * (1.66667 - 1.0)
+    xc = 0.2 + (np.arange(128) + 0.5) / 128
+    ans = 0.05 + (xc - 1.2) * -0.01 / 0.1
+    err = np.abs(T / ans - 1.0).mean()
+    assert err <= 5e-3 and abs(err - 4.107e-3) < 5e-5, err  # the oracle's value at this resolution

@@ -292,3 +292,23 @@ def test_conduction_deck_driver_equals_oracle(double_lib, tmp_path):
     assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
     # gamma = 1.000001 makes cv = 1e6: the diffusivity K/(rho cv) is tiny, the peak only just moves
     assert o.interior(o.gprim)[5].max() < s0 and abs(o.history()[4] - e0) < 1e-12 * e0
+
+
+def test_conduction_problem_deck_driver_equals_oracle(double_lib, tmp_path):
+    """inputs/diffusion/conduction.in (conduction pgen, `conductive` user boundary conditions, uniform
+    gravity, self damping, heat conduction): driver == oracle for 200 cycles on the deck's block."""
+    from oracle.oracle import Oracle
+    spec = dict(deck=["diffusion", "conduction.in"], cycles=200, overrides=["gravity/uniform/gx1=-0.02"])
+    r = run_world(1, spec, tmp_path, "k1")[0]
+    assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    o = Oracle((128, 1, 1), (0.2, -0.5, -0.5), (1.2, 0.5, 0.5), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.66667, dfloor=1e-10, siefloor=1e-15, cfl=0.3,
+               bc=("conductive", "conductive") + ("periodic",) * 4, integrator="rk2")
+    o.set_gravity_uniform(-0.02, 0.0, 0.0)
+    o.set_conductivity("conductivity", cond=0.1)
+    o.set_drag("self", "constant")
+    o.set_damping(0, inner=(4.0, -1.7976931348623157e308, -1.7976931348623157e308), inner_rate=(1.0e4, 0.0, 0.0))
+    o.pgen_conduction(gas_rho=1.0, gas_temp=0.05, flux=0.01)
+    o.evolve(40.0, 200)
+    assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
+    assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))

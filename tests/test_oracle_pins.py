@@ -2,6 +2,8 @@
 for the hot path.  The reference executable cannot be built here
 (Parthenon/Kokkos/singularity-eos submodules are empty), so these numbers -- copied from the
 reference's test scripts, cited per test -- are what anchors parity."""
+import os
+
 import numpy as np
 import pytest
 
@@ -293,3 +295,44 @@ def test_viscous_diffusion_reference_test_pins(d):
         err = np.abs(ans.ravel() - w.T.ravel()).mean()
     assert err <= 1e-8, err   # the oracle gives 2.2e-10 (1-D) and 2.6e-11 (2-D)
     assert err > 1e-13        # a second-order scheme on 64 zones is not exact either
+
+
+def _conduction_oracle(g, nx):
+    x2 = (np.pi / 2 - 0.5, np.pi / 2 + 0.5) if g == "spherical" else (-0.5, 0.5)
+    o = Oracle((nx, 1, 1), (0.2, x2[0], -0.5), (1.2, x2[1], 0.5), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.66667, dfloor=1e-10, siefloor=1e-15, cfl=0.3,
+               bc=("conductive", "conductive") + ("periodic",) * 4, integrator="rk2", coordinates=g)
+    o.set_gravity_uniform(0.0, 0.0, 0.0)
+    o.set_conductivity("conductivity", cond=0.1)
+    o.set_drag("self", "constant")
+    o.set_damping(0, inner=(4.0, -1.7976931348623157e308, -1.7976931348623157e308), inner_rate=(1.0e4, 0.0, 0.0))
+    o.pgen_conduction(gas_rho=1.0, gas_temp=0.05, flux=0.01)
+    return o
+
+
+def _conduction_answer(x, d, f=0.01, T0=0.05, x0=1.2, xi=0.2, k=0.1):
+    # steady state of div(K grad T) = 0 with flux f through x = xi and T(x0) = T0 in slab (d = 0),
+    # cylindrical (1) and spherical (2) geometry -- thermal_diffusion.py:72-79
+    f = f * xi ** d
+    return (T0 + (x - x0) * -f / k, T0 + np.log(x / x0) * -f / k, T0 + (1.0 / x - 1.0 / x0) * f / k)[d]
+
+
+@pytest.mark.parametrize("g,d,e64,e128", [("cartesian", 0, 8.34e-3, 4.11e-3), ("axisymmetric", 1, 2.07e-3, 1.04e-3),
+                                          ("spherical", 2, 3.70e-4, 1.91e-4)])
+def test_thermal_diffusion_reference_test_pins(g, d, e64, e128):
+    """tst/scripts/diffusion/thermal_diffusion.py:36-70,99-125 on inputs/diffusion/conduction.in in
+    Cartesian, axisymmetric and spherical coordinates (conduction pgen, `conductive` boundary
+    conditions, heat conduction with the curvilinear face areas / volumes / distances): mean
+    |T/T_analytic - 1| <= 5e-3 at t = 50.  The reference runs 128 zones (372 529 cycles, about a
+    minute of oracle time per geometry); the oracle gives 4.11e-3 / 1.04e-3 / 1.91e-4 there (checked
+    once, numbers below) and exactly twice that at 64 zones -- the error is the first-order
+    boundary closure -- which is what this test runs."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    nx = 64
+    o = _conduction_oracle(g, nx)
+    o.evolve(50.0, -1)
+    T = o.interior(o.gprim)[5, 0, 0] * (1.66667 - 1.0)  # T = sie / cv, cv = 1/(gamma - 1)
+    xc = 0.2 + (np.arange(nx) + 0.5) / nx
+    err = np.abs(T / _conduction_answer(xc, d) - 1.0).mean()
+    assert abs(err - e64) < 0.01 * e64, err
+    assert abs(err / 2.0 - e128) < 0.05 * e128 and e128 <= 5e-3  # the 128-zone value and the reference bound

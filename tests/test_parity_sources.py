@@ -190,3 +190,24 @@ def test_source_abi_contract(hiplib):
         cart.ApplyBoundaryConditions([("inflow",) * 6], strat=(1.5, 1.0))
     assert e.value.code == capi.EINVAL
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("nx", [(24, 10, 6), (33, 9, 1), (40, 1, 1)])
+@pytest.mark.parametrize("ctype", ["conductivity", "diffusivity"])
+def test_conductive_boundary_conditions(hiplib, nx, ctype):
+    """`conductive` on every active face (pgen/conduction.hpp:105-232) with uniform gravity: fixed
+    flux at inner faces, fixed temperature at outer ones, hydrostatic density."""
+    from artemis_amd import capi
+    bc = ("conductive",) * 6
+    o, mb = pair(nx, (0.2, -0.5, -0.3), (1.2, 0.5, 0.3), ns_gas=1, ns_dust=0, seed=27, bc=bc)
+    o.set_gravity_uniform(-0.3, 0.2, 0.1)
+    ck = dict(cond=0.1) if ctype == "conductivity" else dict(kappa=0.1)
+    o.set_conductivity(ctype, **ck)
+    o.pgen_conduction(gas_rho=1.0, gas_temp=0.05, flux=0.01, post_init=False)  # sets the BC parameters
+    random_state(o, np.random.default_rng(28), shock=False, contrast=10.0)
+    push([o], mb)
+    o.ApplyBoundaryConditions()
+    mb.ApplyBoundaryConditions([bc], conductive=dict(
+        temp=0.05, flux=0.01, g=(-0.3, 0.2, 0.1), coeff=0.1, cv=1.0 / ((1.4 - 1.0) * 1.0 * 1.0),
+        type=capi.CONDUCTIVITY_PLAW if ctype == "conductivity" else capi.THERMALDIFF_PLAW))
+    same(mb.gas_prim[0], o.gprim, "gas ghosts")
