@@ -183,3 +183,38 @@ def test_fused_shell_then_bulk_equals_whole(hiplib, nx):
         lo[ax], hi[ax] = slice(0, g), slice(n - g, n)
         assert torch.equal(whole[tuple(lo)], shell[tuple(lo)])
         assert torch.equal(whole[tuple(hi)], shell[tuple(hi)])
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_fused_stage_with_active_floors(hiplib, general):
+    """A step far beyond the CFL limit drives densities and energies through the floors inside the
+    stage (negative updated density, E < KE, tiny internal energy): the fused epilogues
+    (SetAuxillaryFields + ConsToPrim in registers) must floor exactly like the task chain -- tuned
+    kernel and general cell-centred stage."""
+    from artemis_amd.pack import MeshBlockPack
+    nx = (40, 20, 12)
+    kw = dict(ng=2, reconstruct="plm", riemann="hllc", gamma=1.4, dfloor=1e-2, siefloor=1e-3)
+    o = Oracle(nx, (-1.0, -0.7, 0.1), (1.0, 0.9, 1.3), cfl=0.3, bc=("outflow",) * 6, integrator="rk2", **kw)
+    random_state(o, np.random.default_rng(71), mach=3.0, contrast=1.0e3)
+    o.ApplyBoundaryConditions()
+    o.PrimToCons()
+    mb = MeshBlockPack(1, nx, [(-1.0, -0.7, 0.1)], [(1.0, 0.9, 1.3)], with_fluxes=False, **kw)
+    mb.gas_prim[0].copy_(torch.from_numpy(o.gprim.copy()))
+    out, tout = mb.new_prim_buffer("o")
+    dt = 40.0 * o.new_dt()
+    o.DeepCopyConservedData()
+    o.CalculateFluxes(0, False)
+    o.ApplyUpdate(0.0, 1.0, dt)
+    o.FluxSource(dt)
+    hit = o.gu0[0][o.ks:o.ke + 1, o.js:o.je + 1, o.is_:o.ie + 1]
+    assert (hit < 1e-2).mean() > 0.02  # the density floor is really in play
+    o.SetAuxillaryFields()
+    o.ConsToPrim()
+    if general:
+        mb.stage_general(0.0, 1.0, dt, dt, gas=(mb.gas_prim_table, mb.gas_prim_table, tout))
+    else:
+        mb.stage_fused(0.0, 1.0, dt, dt, mb.gas_prim_table, mb.gas_prim_table, tout)
+    I = np.s_[:, o.ks:o.ke + 1, o.js:o.je + 1, o.is_:o.ie + 1]
+    got, ref = out[0].cpu().numpy()[I], o.gprim[I]
+    keep = [0, 1, 2, 3, 5]  # the general stage does not write the pressure slot
+    assert np.array_equal(got[keep], ref[keep])

@@ -327,3 +327,45 @@ def test_error_paths_on_gpu(hiplib):
     assert rc == capi.EINVAL and b"Riemann solver not recognized" in hiplib.artemis_hip_last_error()
     rc = hiplib.artemis_hip_calculate_fluxes(C.byref(mb.pack), 3, 0, None)
     assert rc == capi.EINVAL and b"Fluid type not recognized" in hiplib.artemis_hip_last_error()
+
+
+@pytest.mark.parametrize("de_switch", [0.0, 0.05])
+def test_floors_and_energy_switch(hiplib, de_switch):
+    """Edge cases of the conserved -> primitive chain: densities below dfloor (zero and negative),
+    total energy below the kinetic energy (negative thermal energy -> the internal-energy branch of
+    GetSpecificInternalEnergy, artemis_utils.hpp:57-59), internal energies below siefloor*D, with
+    de_switch = 0 and > 0 (gas.cpp:177): SetAuxillaryFields, ConsToPrim and PrimToCons must apply the
+    same floors as the reference, gas and dust."""
+    (o,), mb = make_pair((20, 10, 6), ns_gas=2, ns_dust=2, riem="hlle", seed=61, dfloor=1e-3, siefloor=1e-2,
+                         de_switch=de_switch)
+    rng = np.random.default_rng(62)
+    shp = o.gu0.shape[1:]
+    for arr in (o.gu0, o.du0):
+        ns = arr.shape[0] // (6 if arr is o.gu0 else 4)
+        for n in range(ns):
+            d = arr[n]
+            d[rng.random(shp) < 0.15] = 0.0            # vacuum
+            d[rng.random(shp) < 0.15] = -0.5           # negative density after a too-large step
+            d[rng.random(shp) < 0.15] = 5e-4           # below the floor
+    E, eg = o.gu0[8:10], o.gu0[10:12]
+    E[rng.random(E.shape) < 0.3] *= 1e-6               # E < KE: negative thermal energy
+    E[rng.random(E.shape) < 0.1] = -1.0
+    eg[rng.random(eg.shape) < 0.3] = 1e-9              # below siefloor * D
+    eg[rng.random(eg.shape) < 0.1] = -2.0
+    push([o], mb)
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    o.SetAuxillaryFields(), mb.SetAuxillaryFields()
+    same(mb.gas_u0[0][I], o.gu0[I], "SetAuxillaryFields with floors")
+    o.ConsToPrim(), mb.ConsToPrim()
+    same(mb.gas_prim[0][I], o.gprim[I], "ConsToPrim gas with floors")
+    same(mb.dust_prim[0][I], o.dprim[I], "ConsToPrim dust with floors")
+    assert (o.gprim[0][I[1:]] >= 1e-3).all() and (o.gprim[10][I[1:]] >= 1e-2).all()
+    # primitives below the floors in ghost zones (e.g. from an extrapolating boundary condition)
+    o.gprim[0, :, :, :2] = 1e-5
+    o.gprim[10, :, :, -2:] = 1e-7
+    o.dprim[1, :2] = -1.0
+    push([o], mb)
+    o.PrimToCons(), mb.PrimToCons()
+    same(mb.gas_prim[0], o.gprim, "PrimToCons floors prim")
+    same(mb.gas_u0[0], o.gu0, "PrimToCons floors cons")
+    same(mb.dust_u0[0], o.du0, "PrimToCons floors dust")
