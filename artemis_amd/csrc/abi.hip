@@ -209,8 +209,9 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
       return fail(ARTEMIS_HIP_EINVAL, "unknown boundary flag %d", bc[i]);
     const int d = (i % 6) / 2;
     if (bc[i] == ARTEMIS_BC_CONDUCTIVE) {
-      if (p->coords != ARTEMIS_CARTESIAN)
-        return fail(ARTEMIS_HIP_EUNSUPPORTED, "conductive boundary condition: Cartesian only");
+      if ((p->coords == ARTEMIS_CYLINDRICAL || p->coords == ARTEMIS_AXISYMMETRIC) && !p->metric)
+        return fail(ARTEMIS_HIP_EINVAL, // Coords::Distance needs cos/sin of the azimuth
+                    "conductive boundary condition: cylindrical / axisymmetric blocks need the metric tables");
       if (!params) return fail(ARTEMIS_HIP_EINVAL, "conductive conditions need artemis_bc_params_t");
       if (params->cond_type != ARTEMIS_CONDUCTIVITY_PLAW && params->cond_type != ARTEMIS_THERMALDIFF_PLAW)
         return fail(ARTEMIS_HIP_EINVAL, // conduction.hpp:246-248
@@ -298,39 +299,58 @@ int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, do
   return after_launch("DragSource");
 }
 
-// Host-side metric tables (see include/artemis_hip.h and csrc/geometry.hpp: rows MT_COSF,
-// MT_SINF, MT_X2V, MT_SINV, MT_SINC, MT_COSV, each nj+1 doubles per block).  Expressions follow
-// spherical.hpp:61-68 (x2v) and :53-55, :88-104 (the sine arguments).
+// Host-side metric tables (see include/artemis_hip.h and csrc/geometry_core.hpp: per block six x2
+// rows of nj+1 doubles, then two x3 rows of nk+1).  Expressions follow spherical.hpp:61-68 (x2v),
+// :53-55, :88-104 (the sine arguments) and the ConvertCoordsToCart of each system.
 long artemis_hip_metric_count(const artemis_pack_t *p) {
   if (!p) return -1;
-  if (p->coords != ARTEMIS_SPHERICAL2D && p->coords != ARTEMIS_SPHERICAL3D) return 0;
+  if (p->coords == ARTEMIS_CARTESIAN || p->coords == ARTEMIS_SPHERICAL1D) return 0;
   const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0);
-  return static_cast<long>(p->nblocks) * 6 * (nj + 1);
+  const int nk = p->nx3 + ((p->nx3 > 1) ? 2 * p->nghost : 0);
+  return static_cast<long>(p->nblocks) * (6L * (nj + 1) + 2L * (nk + 1));
 }
 int artemis_hip_metric_fill(const artemis_pack_t *p, const double *geom_host, double *out_host) {
   if (!p || !geom_host || !out_host) return fail(ARTEMIS_HIP_EINVAL, "null argument");
   if (artemis_hip_metric_count(p) == 0) return 0;
   const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0);
-  const int st = nj + 1;
+  const int nk = p->nx3 + ((p->nx3 > 1) ? 2 * p->nghost : 0);
+  const int st = nj + 1, st3 = nk + 1;
+  const long stride = 6L * st + 2L * st3;
+  const bool sph23 = (p->coords == ARTEMIS_SPHERICAL2D || p->coords == ARTEMIS_SPHERICAL3D);
   for (int b = 0; b < p->nblocks; ++b) {
     const double f0 = geom_host[6 * b + 2], dx = geom_host[6 * b + 3];
-    double *m = out_host + static_cast<long>(b) * 6 * st;
-    for (int j = 0; j <= nj; ++j) {
-      const double xf = f0 + j * dx;
-      m[0 * st + j] = std::cos(xf);
-      m[1 * st + j] = std::sin(xf);
+    double *m = out_host + b * stride;
+    for (long q = 0; q < stride; ++q) m[q] = 0.0;
+    if (sph23) {
+      for (int j = 0; j <= nj; ++j) {
+        const double xf = f0 + j * dx;
+        m[0 * st + j] = std::cos(xf);
+        m[1 * st + j] = std::sin(xf);
+      }
+      for (int j = 0; j < nj; ++j) {
+        const double x0 = f0 + j * dx, x1 = f0 + (j + 1) * dx;
+        const double ctm = m[0 * st + j], ctp = m[0 * st + j + 1];
+        const double dst = m[1 * st + j + 1] - m[1 * st + j];
+        const double x2v = (dst - x1 * ctp + x0 * ctm) / std::abs(ctm - ctp);
+        m[2 * st + j] = x2v;
+        m[3 * st + j] = std::sin(x2v);
+        m[4 * st + j] = std::sin(0.5 * (x0 + x1));
+        m[5 * st + j] = std::cos(x2v);
+      }
+    } else if (p->coords == ARTEMIS_CYLINDRICAL) { // azimuth of the cell centre (cylindrical.hpp:88-92)
+      for (int j = 0; j < nj; ++j) {
+        const double x2v = 0.5 * ((f0 + j * dx) + (f0 + (j + 1) * dx));
+        m[2 * st + j] = x2v, m[3 * st + j] = std::sin(x2v), m[5 * st + j] = std::cos(x2v);
+      }
     }
-    for (int j = 0; j < nj; ++j) {
-      const double x0 = f0 + j * dx, x1 = f0 + (j + 1) * dx;
-      const double ctm = m[0 * st + j], ctp = m[0 * st + j + 1];
-      const double dst = m[1 * st + j + 1] - m[1 * st + j];
-      const double x2v = (dst - x1 * ctp + x0 * ctm) / std::abs(ctm - ctp);
-      m[2 * st + j] = x2v;
-      m[3 * st + j] = std::sin(x2v);
-      m[4 * st + j] = std::sin(0.5 * (x0 + x1));
-      m[5 * st + j] = std::cos(x2v);
+    if (p->coords == ARTEMIS_SPHERICAL3D || p->coords == ARTEMIS_AXISYMMETRIC) {
+      const double g0 = geom_host[6 * b + 4], dz = geom_host[6 * b + 5];
+      double *m3 = m + 6L * st;
+      for (int k = 0; k < nk; ++k) {
+        const double x3v = 0.5 * ((g0 + k * dz) + (g0 + (k + 1) * dz));
+        m3[0 * st3 + k] = std::cos(x3v), m3[1 * st3 + k] = std::sin(x3v);
+      }
     }
-    m[2 * st + nj] = m[3 * st + nj] = m[4 * st + nj] = m[5 * st + nj] = 0.0;
   }
   return 0;
 }
@@ -398,8 +418,9 @@ static int validate_diffusion(const artemis_pack_t *p, const artemis_diffusion_t
   if (int rc = validate(p)) return rc;
   if (!d) return fail(ARTEMIS_HIP_EINVAL, "null diffusion parameters");
   if (p->gas.nspecies < 1) return fail(ARTEMIS_HIP_EINVAL, "diffusion only works with a gas fluid");
-  if (p->coords != ARTEMIS_CARTESIAN)
-    return fail(ARTEMIS_HIP_EUNSUPPORTED, "gas diffusion in curvilinear coordinates is not built");
+  if ((p->coords == ARTEMIS_CYLINDRICAL || p->coords == ARTEMIS_AXISYMMETRIC) && !p->metric)
+    return fail(ARTEMIS_HIP_EINVAL, // Coords::Distance needs cos/sin of the azimuth
+                "gas diffusion: cylindrical / axisymmetric blocks need the metric tables (artemis_hip_metric_fill)");
   if (p->nghost < 2) return fail(ARTEMIS_HIP_EINVAL, "gas diffusion needs nghost >= 2");
   if (!(d->cv > 0.0)) return fail(ARTEMIS_HIP_EINVAL, "diffusion: specific heat cv must be positive");
   for (const artemis_diffcoeff_t *c : {&d->visc, &d->cond}) {

@@ -152,8 +152,8 @@ struct artemis_sim {
   int coords = ARTEMIS_CARTESIAN;   // geometry::CoordSelect(artemis/coordinates, ndim)
   // geometry::Coords<GEOM> of cell (k,j,i) of local block b (host side: pgens, history)
   artemis::DCoords cell_coords(int b, int k, int j, int i) const {
-    const Real *m = hmetric.empty() ? nullptr : hmetric.data() + static_cast<size_t>(b) * artemis::MT_ROWS * (nj + 1);
-    return artemis::coords_of(coords, hgeom.data() + 6 * b, m, nj, k, j, i);
+    const Real *m = hmetric.empty() ? nullptr : hmetric.data() + b * artemis::metric_block_stride(nj, nk);
+    return artemis::coords_of(coords, hgeom.data() + 6 * b, m, nj, nk, k, j, i);
   }
   DevBuf tstate; // device-resident {time, dt, dt_est, beta_dt[3]} for the synchronisation-free loop
   double *dt_host = nullptr;    // pinned
@@ -448,13 +448,11 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
       c.rho_ref = pin.GetOrAddReal("gas/conductivity", "rho_ref", 1.0);
       c.T_ref = pin.GetOrAddReal("gas/conductivity", "T_ref", 1.0);
     }
-    if (coords != ARTEMIS_CARTESIAN) throw std::runtime_error("gas diffusion in curvilinear coordinates is not built yet");
     if (ng < 2) throw std::runtime_error("gas diffusion needs nghost >= 2");
     edge_ghosts = do_viscosity; // the strain tensor reads edge / corner ghost zones
   }
   if (pgen == PG_COND) { // conduction.hpp:39-54 InitCondParams + what CondBoundaryImpl reads
     if (!do_conduction) throw std::runtime_error("problem = conduction requires physics/conduction");
-    if (coords != ARTEMIS_CARTESIAN) throw std::runtime_error("problem = conduction: only Cartesian coordinates are built");
     bcpar.cond_temp = pin.GetOrAddReal("problem", "gas_temp", 1.0);
     bcpar.cond_flux = pin.GetOrAddReal("problem", "flux", 0.0);
     for (int d = 0; d < 3; ++d) bcpar.cond_g[d] = (do_gravity && grav.type == ARTEMIS_GRAVITY_UNIFORM) ? grav.g[d] : 0.0;
@@ -962,7 +960,8 @@ void artemis_sim::problem_generator() {
             const Real gx1 = (do_gravity && grav.type == ARTEMIS_GRAVITY_UNIFORM) ? grav.g[0] : 0.0;
             const Real P0 = std::max(0.0, gm1c * cd.g_rho * cv * cd.g_temp);
             const Real Rgas = P0 / (cd.g_rho * cd.g_temp);
-            const Real Pz = P0 * std::exp(gx1 * cd.g_rho / P0 * (xv[0] - xmin[0]));
+            const Real x1c = cell_coords(b, k, j, i).x1v(); // coords.GetCellCenter()[0]
+            const Real Pz = P0 * std::exp(gx1 * cd.g_rho / P0 * (x1c - xmin[0]));
             const Real dens = Pz / (Rgas * cd.g_temp);
             hg[0 * N + c] = dens;
             hg[(ns_gas + 0) * N + c] = cd.g_v[0];

@@ -6,9 +6,8 @@
 namespace artemis {
 
 GDEV DCoords make_coords(const PackView &P, int b, int k, int j, int i) {
-  const double *m =
-      P.metric ? P.metric + static_cast<long>(b) * MT_ROWS * (P.nj + 1) : nullptr;
-  return coords_of(P.coords, P.geom + 6 * b, m, P.nj, k, j, i);
+  const double *m = P.metric ? P.metric + b * metric_block_stride(P.nj, P.nk) : nullptr;
+  return coords_of(P.coords, P.geom + 6 * b, m, P.nj, P.nk, k, j, i);
 }
 
 // x_d centroid of the cell at index idx along direction dir, other indices irrelevant

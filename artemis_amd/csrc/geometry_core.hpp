@@ -26,8 +26,14 @@
 
 namespace artemis {
 
-// Table rows of one block: stride nj + 1 doubles each.
+// Metric tables of one block: MT_ROWS rows of nj + 1 doubles indexed by j (x2 faces / cells),
+// then MT3_ROWS rows of nk + 1 doubles indexed by k (cos / sin of the x3 cell centre: the azimuth of
+// spherical3D and axisymmetric coordinates, used by ConvertCoordsToCart).
 enum { MT_COSF = 0, MT_SINF = 1, MT_X2V = 2, MT_SINV = 3, MT_SINC = 4, MT_COSV = 5, MT_ROWS = 6 };
+enum { MT3_COS = 0, MT3_SIN = 1, MT3_ROWS = 2 };
+GDEV long metric_block_stride(int nj, int nk) {
+  return static_cast<long>(MT_ROWS) * (nj + 1) + static_cast<long>(MT3_ROWS) * (nk + 1);
+}
 
 struct DCoords {
   int sys;
@@ -35,6 +41,7 @@ struct DCoords {
   double cf[2], sf[2]; // cos / sin of the two x2 faces         (spherical2D/3D only)
   double x2c, sv, sc;  // x2 centroid, sin(centroid), sin(0.5*(x2[0]+x2[1]))
   double cv;           // cos(centroid) (basis vectors of ConvertVecToCyl, spherical.hpp:198-205)
+  double c3, s3;       // cos / sin of the x3 cell centre (spherical3D, axisymmetric)
 
   GDEV bool sph23() const { return sys == ARTEMIS_SPHERICAL2D || sys == ARTEMIS_SPHERICAL3D; }
   GDEV bool sph() const { return sys == ARTEMIS_SPHERICAL1D || sph23(); }
@@ -144,6 +151,19 @@ struct DCoords {
   GDEV double dh3dx2() const { // spherical.hpp:143-146
     return sph23() ? (sf[1] - sf[0]) / fabs(cf[0] - cf[1]) : 0.0;
   }
+  // ConvertCoordsToCart of this cell's centre (geometry.hpp:248, cylindrical.hpp:88-92,
+  // spherical.hpp:166-173 / :355-362 / :528-534, axisymmetric.hpp:77-82); trigonometry from the tables
+  GDEV void centre_to_cart(double xc[3]) const {
+    const double a = x1v(), b = x2v(), c = x3v();
+    switch (sys) {
+    case ARTEMIS_SPHERICAL3D: xc[0] = a * sv * c3, xc[1] = a * sv * s3, xc[2] = a * cv; break;
+    case ARTEMIS_SPHERICAL2D: xc[0] = a * sv * 1.0, xc[1] = a * sv * 0.0, xc[2] = a * cv; break;
+    case ARTEMIS_SPHERICAL1D: xc[0] = a * 1.0 * 1.0, xc[1] = a * 1.0 * 0.0, xc[2] = a * 0.0; break;
+    case ARTEMIS_CYLINDRICAL: xc[0] = a * cv, xc[1] = a * sv, xc[2] = c; break;
+    case ARTEMIS_AXISYMMETRIC: xc[0] = a * c3, xc[1] = a * s3, xc[2] = b; break;
+    default: xc[0] = a, xc[1] = b, xc[2] = c;
+    }
+  }
   // Scale factors at the centroid of the LOWER face of direction dir (ScaleMomentumFlux,
   // fluid_fluxes.hpp:56-66 with FaceCenX? of each system).
   GDEV void face_scale(int dir, double h[3]) const {
@@ -171,19 +191,27 @@ struct DCoords {
 
 // Cell (k,j,i) of a block with edge table g6 = {x1f0, dx1, x2f0, dx2, x3f0, dx3}; `m` = the
 // block's metric rows (stride nj+1) or null when the system needs none.
-GDEV DCoords coords_of(int sys, const double *g, const double *m, int nj, int k, int j, int i) {
+GDEV DCoords coords_of(int sys, const double *g, const double *m, int nj, int nk, int k, int j, int i) {
   DCoords c;
   c.sys = sys;
   c.x1[0] = g[0] + i * g[1], c.x1[1] = g[0] + (i + 1) * g[1];
   c.x2[0] = g[2] + j * g[3], c.x2[1] = g[2] + (j + 1) * g[3];
   c.x3[0] = g[4] + k * g[5], c.x3[1] = g[4] + (k + 1) * g[5];
   c.cf[0] = c.cf[1] = c.sf[0] = c.sf[1] = c.x2c = c.sv = c.sc = c.cv = 0.0;
+  c.c3 = 1.0, c.s3 = 0.0;
+  if (m == nullptr) return c;
+  const int st = nj + 1;
   if (c.sph23()) {
-    const int st = nj + 1;
     c.cf[0] = m[MT_COSF * st + j], c.cf[1] = m[MT_COSF * st + j + 1];
     c.sf[0] = m[MT_SINF * st + j], c.sf[1] = m[MT_SINF * st + j + 1];
     c.x2c = m[MT_X2V * st + j], c.sv = m[MT_SINV * st + j], c.sc = m[MT_SINC * st + j];
     c.cv = m[MT_COSV * st + j];
+  } else if (sys == ARTEMIS_CYLINDRICAL) { // cos / sin of the azimuth x2v (ConvertCoordsToCart only)
+    c.sv = m[MT_SINV * st + j], c.cv = m[MT_COSV * st + j];
+  }
+  if (sys == ARTEMIS_SPHERICAL3D || sys == ARTEMIS_AXISYMMETRIC) {
+    const double *m3 = m + static_cast<long>(MT_ROWS) * st;
+    c.c3 = m3[MT3_COS * (nk + 1) + k], c.s3 = m3[MT3_SIN * (nk + 1) + k];
   }
   return c;
 }

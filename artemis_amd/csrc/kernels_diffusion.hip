@@ -1,19 +1,22 @@
-// Gas diffusion tasks (artemis_driver.cpp:189-193, :218-221), Cartesian coordinates, constant
-// coefficients: ZeroDiffusionFlux, ViscousFlux (momentum_diffusion.hpp), ThermalFlux
+// Gas diffusion tasks (artemis_driver.cpp:189-193, :218-221), constant coefficients, every coordinate
+// system (CURV instantiations read the metric from geometry.hpp; Coords::Distance uses the
+// tabulated trigonometry of the cell centres): ZeroDiffusionFlux, ViscousFlux (momentum_diffusion.hpp), ThermalFlux
 // (thermal_diffusion.hpp), DiffusionUpdate and the diffusive timestep (diffusion.hpp).
 //
 // The reference walks pencils with scratch rows for the strain tensor, div(u) and the
 // coefficient; every face value is a pure function of the primitives around the face, so here
 // one thread owns one face (thread x walks i, coalesced) and evaluates its neighbourhood
 // directly -- the cells involved are shared through L1/L2 with the neighbouring threads.
-// Scale factors are 1 and the connection coefficients 0 in Cartesian coordinates; the terms are
-// kept (multiplications by 1.0 / additions of 0.0 * v) so that NaN/Inf propagate as in the
+// In the Cartesian instantiations scale factors are 1 and the connection coefficients 0; the terms
+// are kept (multiplications by 1.0 / additions of 0.0 * v) so that NaN/Inf propagate as in the
 // reference's arithmetic.
 #include <cfloat>
 
 #include "device_math.hpp"
+#include "geometry.hpp"
 #include "kernels.hpp"
 #include "pack_view.hpp"
+#include "task_device.hpp"
 
 namespace artemis {
 namespace {
@@ -34,17 +37,34 @@ inline dim3 grid_of(const Box &r, int nb) {
   if (i > (r).iu || j > (r).ju) return;                                                    \
   const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
 
-struct Cart { // cell centres and widths of one block (geometry.hpp:163-166, :199-225)
-  const double *g;
-  ADEV double x1v(int i) const { return 0.5 * ((g[0] + i * g[1]) + (g[0] + (i + 1) * g[1])); }
-  ADEV double x2v(int j) const { return 0.5 * ((g[2] + j * g[3]) + (g[2] + (j + 1) * g[3])); }
-  ADEV double x3v(int k) const { return 0.5 * ((g[4] + k * g[5]) + (g[4] + (k + 1) * g[5])); }
-  ADEV double dx1(int i) const { return (g[0] + (i + 1) * g[1]) - (g[0] + i * g[1]); }
-  ADEV double dx2(int j) const { return (g[2] + (j + 1) * g[3]) - (g[2] + j * g[3]); }
-  ADEV double dx3(int k) const { return (g[4] + (k + 1) * g[5]) - (g[4] + k * g[5]); }
-  // Coords::Distance (geometry.hpp:407-412) between the centres of two cells
+// Geometry of one block as the diffusion tasks need it: cell centres, Coords::Distance between two
+// cell centres (geometry.hpp:407-412), volume-averaged scale factors, connection coefficients.
+template <bool CURV>
+struct Geo {
+  const PackView &P;
+  int b;
+  ADEV const double *g() const { return P.geom + 6 * b; }
+  ADEV double x1v(int i) const { return 0.5 * ((g()[0] + i * g()[1]) + (g()[0] + (i + 1) * g()[1])); }
+  ADEV double x2v(int j) const { return 0.5 * ((g()[2] + j * g()[3]) + (g()[2] + (j + 1) * g()[3])); }
+  ADEV double x3v(int k) const { return 0.5 * ((g()[4] + k * g()[5]) + (g()[4] + (k + 1) * g()[5])); }
   ADEV double dist(int k1, int j1, int i1, int k2, int j2, int i2) const {
-    return sqrt(sqr(x1v(i1) - x1v(i2)) + sqr(x2v(j1) - x2v(j2)) + sqr(x3v(k1) - x3v(k2)));
+    if constexpr (CURV) {
+      double a[3], c[3];
+      make_coords(P, b, k1, j1, i1).centre_to_cart(a);
+      make_coords(P, b, k2, j2, i2).centre_to_cart(c);
+      return sqrt(sqr(a[0] - c[0]) + sqr(a[1] - c[1]) + sqr(a[2] - c[2]));
+    } else {
+      return sqrt(sqr(x1v(i1) - x1v(i2)) + sqr(x2v(j1) - x2v(j2)) + sqr(x3v(k1) - x3v(k2)));
+    }
+  }
+  ADEV void hx(int k, int j, int i, double h[3]) const { scale_factors<CURV>(P, b, k, j, i, h); }
+  // {dh2dx1, dh3dx1, dh3dx2}: the only non-zero connection coefficients (geometry.hpp:236-246)
+  ADEV void conn(int k, int j, int i, double &d21, double &d31, double &d32) const {
+    d21 = d31 = d32 = 0.0;
+    if constexpr (CURV) {
+      const DCoords co = make_coords(P, b, k, j, i);
+      d21 = co.dh2dx1(), d31 = co.dh3dx1(), d32 = co.dh3dx2();
+    }
   }
 };
 
@@ -68,47 +88,61 @@ __global__ __launch_bounds__(TX *TY) void zero_dflux_kernel(const PackView P, co
 }
 
 // VelocityDivergence (momentum_diffusion.hpp:562-591) of cell (k,j,i), species n
-ADEV double velocity_divergence(const PackView &P, const Cart &ge, double *const *prim, int b, int n,
-                                int k, int j, int i) {
+template <bool CURV>
+ADEV double velocity_divergence(const PackView &P, double *const *prim, int b, int n, int k, int j, int i) {
   const int ns = P.gas.ns, nv = 6 * ns;
   const int multid = (P.ndim >= 2), threed = (P.ndim == 3);
-  const double d1 = ge.dx1(i), d2 = ge.dx2(j), d3 = ge.dx3(k);
-  const double vol = d1 * d2 * d3;
-  const double a1 = d2 * d3, a2 = multid ? d1 * d3 : 0.0, a3 = threed ? d1 * d2 : 0.0;
+  const CellMetric m = cell_metric<CURV>(P, b, k, j, i);
+  const double a1[2] = {m.ax1[0], m.ax1[1]};
+  const double a2[2] = {multid ? m.ax2[0] : 0.0, multid ? m.ax2[1] : 0.0};
+  const double a3[2] = {threed ? m.ax3[0] : 0.0, threed ? m.ax3[1] : 0.0};
   const double *v1 = prim[b * nv + ns + 3 * n + 0], *v2 = prim[b * nv + ns + 3 * n + 1];
   const double *v3 = prim[b * nv + ns + 3 * n + 2];
   const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
   const long sj = multid * P.sj, sk = threed * P.sk;
-  const double divv = a1 * (v1[c] + v1[c + 1]) - a1 * (v1[c] + v1[c - 1]) +
-                      multid * a2 * (v2[c] + v2[c + sj]) - multid * a2 * (v2[c] + v2[c - sj]) +
-                      threed * a3 * (v3[c] + v3[c + sk]) - threed * a3 * (v3[c] + v3[c - sk]);
-  return divv / (2.0 * vol);
+  const double divv = a1[1] * (v1[c] + v1[c + 1]) - a1[0] * (v1[c] + v1[c - 1]) +
+                      multid * a2[1] * (v2[c] + v2[c + sj]) - multid * a2[0] * (v2[c] + v2[c - sj]) +
+                      threed * a3[1] * (v3[c] + v3[c + sk]) - threed * a3[0] * (v3[c] + v3[c - sk]);
+  return divv / (2.0 * m.vol);
 }
 
 // MomentumFluxImpl (momentum_diffusion.hpp:597-755): StrainTensorFace<XDIR> (:28-377) and
 // StressTensorFaceX? (:379-560) of the lower `dir` face of cell (k,j,i)
-template <int DIR>
+template <int DIR, bool CURV>
 __global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, const Box r,
                                                               const artemis_diffusion_t D) {
   BOX_CELL(r)
   const FluidView &f = P.gas;
   const int ns = f.ns, nv = 6 * ns, nq = 4 * ns;
   const int multid = (P.ndim >= 2), threed = (P.ndim == 3);
-  const Cart ge{P.geom + 6 * b};
+  const Geo<CURV> ge{P, b};
   const artemis_diffcoeff_t &dp = D.visc;
   constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1);
   const long cm = c - ((DIR == 1) ? 1 : ((DIR == 2) ? P.sj : P.sk));
   const double fuzz = 1e-99; // Fuzz<Real>()
+  double hx[3], hx_m[3], hxf[3] = {1.0, 1.0, 1.0};
+  ge.hx(k, j, i, hx), ge.hx(k - dk, j - dj, i - di, hx_m);
+  if constexpr (CURV) make_coords(P, b, k, j, i).face_scale(DIR, hxf); // h_d at the face centroid
   for (int n = 0; n < ns; ++n) {
     const double *q[3] = {f.prim[b * nv + ns + 3 * n + 0], f.prim[b * nv + ns + 3 * n + 1],
                           f.prim[b * nv + ns + 3 * n + 2]};
-    auto sv = [&](int comp, int kk, int jj, int ii) { // v / hx of the cell, hx = 1
-      return q[comp][(static_cast<long>(kk) * P.nj + jj) * P.ni + ii] / 1.0;
+    auto vel = [&](int comp, int kk, int jj, int ii) {
+      return q[comp][(static_cast<long>(kk) * P.nj + jj) * P.ni + ii];
     };
-    auto src_of = [&](int kk, int jj, int ii) { // v^k dh_a/dx_k / h_a: every dh is zero
-      return sv(0, kk, jj, ii) * 0.0 + sv(1, kk, jj, ii) * 0.0 + sv(2, kk, jj, ii) * 0.0;
+    auto sv = [&](int comp, int kk, int jj, int ii) { // v^comp = v / h_comp of that cell
+      double h[3];
+      ge.hx(kk, jj, ii, h);
+      return vel(comp, kk, jj, ii) / h[comp];
     };
-    const double v[3] = {sv(0, k, j, i), sv(1, k, j, i), sv(2, k, j, i)};
+    // v^k dh_a/dx_k / h_a of a cell, a = DIR - 1; only dh2dx1, dh3dx1, dh3dx2 can be non-zero
+    auto src_of = [&](int kk, int jj, int ii) {
+      double h[3], d21, d31, d32;
+      ge.hx(kk, jj, ii, h), ge.conn(kk, jj, ii, d21, d31, d32);
+      const double dh0 = (DIR == 2) ? d21 : ((DIR == 3) ? d31 : 0.0);
+      const double dh1 = (DIR == 3) ? d32 : 0.0;
+      return vel(0, kk, jj, ii) / h[0] * dh0 + vel(1, kk, jj, ii) / h[1] * dh1 + vel(2, kk, jj, ii) / h[2] * 0.0;
+    };
+    const double v[3] = {vel(0, k, j, i) / hx[0], vel(1, k, j, i) / hx[1], vel(2, k, j, i) / hx[2]};
     double flx[3];
     if constexpr (DIR == 1) {
       const double dx1 = ge.dist(k, j, i, k, j, i - 1);
@@ -121,11 +155,11 @@ __global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, 
       const double dv2 = v[1] - sv(1, k, j, i - 1);
       const double dv12 = sv(0, k, j + multid, i) - sv(0, k, j - multid, i);
       const double dv12_xm = sv(0, k, j + multid, i - 1) - sv(0, k, j - multid, i - 1);
-      flx[1] = multid * 0.5 * (dv12 / dx2 + dv12_xm / dx2_xm) + sqr(1.0 / 1.0) * dv2 / dx1;
+      flx[1] = multid * 0.5 * (dv12 / dx2 + dv12_xm / dx2_xm) + sqr(hxf[1] / hxf[0]) * dv2 / dx1;
       const double dv3 = v[2] - sv(2, k, j, i - 1);
       const double dv13 = sv(0, k + threed, j, i) - sv(0, k - threed, j, i);
       const double dv13_xm = sv(0, k + threed, j, i - 1) - sv(0, k - threed, j, i - 1);
-      flx[2] = threed * 0.5 * (dv13 / dx3 + dv13_xm / dx3_xm) + sqr(1.0 / 1.0) * dv3 / dx1;
+      flx[2] = threed * 0.5 * (dv13 / dx3 + dv13_xm / dx3_xm) + sqr(hxf[2] / hxf[0]) * dv3 / dx1;
     } else if constexpr (DIR == 2) {
       const double dx1 = ge.dist(k, j, i - 1, k, j, i + 1);
       const double dx1_ym = ge.dist(k, j - 1, i - 1, k, j - 1, i + 1);
@@ -135,13 +169,13 @@ __global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, 
       const double dv1 = v[0] - sv(0, k, j - 1, i);
       const double dv21 = sv(1, k, j, i + 1) - sv(1, k, j, i - 1);
       const double dv21_ym = sv(1, k, j - 1, i + 1) - sv(1, k, j - 1, i - 1);
-      flx[0] = 0.5 * (dv21 / dx1 + dv21_ym / dx1_ym) + sqr(1.0 / 1.0) * dv1 / dx2;
+      flx[0] = 0.5 * (dv21 / dx1 + dv21_ym / dx1_ym) + sqr(hxf[0] / hxf[1]) * dv1 / dx2;
       const double dv2 = v[1] - sv(1, k, j - 1, i);
       flx[1] = 2 * dv2 / dx2 + 0.5 * (src_of(k, j, i) + src_of(k, j - 1, i));
       const double dv3 = v[2] - sv(2, k, j - 1, i);
       const double dv23 = sv(1, k + threed, j, i) - sv(1, k - threed, j, i);
       const double dv23_ym = sv(1, k + threed, j - 1, i) - sv(1, k - threed, j - 1, i);
-      flx[2] = threed * 0.5 * (dv23 / dx3 + dv23_ym / dx3_ym) + sqr(1.0 / 1.0) * dv3 / dx2;
+      flx[2] = threed * 0.5 * (dv23 / dx3 + dv23_ym / dx3_ym) + sqr(hxf[2] / hxf[1]) * dv3 / dx2;
     } else {
       const double dx1 = ge.dist(k, j, i - 1, k, j, i + 1);
       const double dx1_zm = ge.dist(k - 1, j, i - 1, k - 1, j, i + 1);
@@ -151,39 +185,39 @@ __global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, 
       const double dv1 = v[0] - sv(0, k - 1, j, i);
       const double dv31 = sv(2, k, j, i + 1) - sv(2, k, j, i - 1);
       const double dv31_zm = sv(2, k - 1, j, i + 1) - sv(2, k - 1, j, i - 1);
-      flx[0] = 0.5 * (dv31 / dx1 + dv31_zm / dx1_zm) + sqr(1.0 / 1.0) * dv1 / dx3;
+      flx[0] = 0.5 * (dv31 / dx1 + dv31_zm / dx1_zm) + sqr(hxf[0] / hxf[2]) * dv1 / dx3;
       const double dv2 = v[1] - sv(1, k - 1, j, i);
       const double dv32 = sv(2, k, j + 1, i) - sv(2, k, j - 1, i);
       const double dv32_zm = sv(2, k - 1, j + 1, i) - sv(2, k - 1, j - 1, i);
-      flx[1] = 0.5 * (dv32 / dx2 + dv32_zm / dx2_zm) + sqr(1.0 / 1.0) * dv2 / dx3;
+      flx[1] = 0.5 * (dv32 / dx2 + dv32_zm / dx2_zm) + sqr(hxf[1] / hxf[2]) * dv2 / dx3;
       const double dv3 = v[2] - sv(2, k - 1, j, i);
       flx[2] = 2 * dv3 / dx3 + 0.5 * (src_of(k, j, i) + src_of(k - 1, j, i));
     }
     const double *rho = f.prim[b * nv + n];
     const double mu = coeff_of(dp, D.cv, rho[c]), mu_m = coeff_of(dp, D.cv, rho[cm]);
     const double mus = face_average(dp.avg, mu, mu_m);
-    const double divu = velocity_divergence(P, ge, f.prim, b, n, k, j, i);
-    const double divu_m = velocity_divergence(P, ge, f.prim, b, n, k - dk, j - dj, i - di);
-    const double hf = 1.0;
+    const double divu = velocity_divergence<CURV>(P, f.prim, b, n, k, j, i);
+    const double divu_m = velocity_divergence<CURV>(P, f.prim, b, n, k - dk, j - dj, i - di);
+    const double hf = hxf[DIR - 1];
     double fl[3];
     for (int qq = 0; qq < 3; ++qq) fl[qq] = hf * mus * flx[qq];
     fl[DIR - 1] = hf * mus * (flx[DIR - 1] - 1. / 3 * (1. - dp.eta) * (divu + divu_m));
     double *const *qf = f.dflux[DIR - 1];
     for (int qq = 0; qq < 3; ++qq) qf[b * nq + 3 * n + qq][c] += fl[qq];
-    qf[b * nq + 3 * ns + n][c] += 0.5 * (q[0][c] / 1.0 + q[0][cm] / 1.0) * fl[0] +
-                                  0.5 * (q[1][c] / 1.0 + q[1][cm] / 1.0) * fl[1] +
-                                  0.5 * (q[2][c] / 1.0 + q[2][cm] / 1.0) * fl[2];
+    qf[b * nq + 3 * ns + n][c] += 0.5 * (q[0][c] / hx[0] + q[0][cm] / hx_m[0]) * fl[0] +
+                                  0.5 * (q[1][c] / hx[1] + q[1][cm] / hx_m[1]) * fl[1] +
+                                  0.5 * (q[2][c] / hx[2] + q[2][cm] / hx_m[2]) * fl[2];
   }
 }
 
 // ThermalFluxImpl (thermal_diffusion.hpp:30-222)
-template <int DIR>
+template <int DIR, bool CURV>
 __global__ __launch_bounds__(TX *TY) void thermal_flux_kernel(const PackView P, const Box r,
                                                               const artemis_diffusion_t D) {
   BOX_CELL(r)
   const FluidView &f = P.gas;
   const int ns = f.ns, nv = 6 * ns, nq = 4 * ns;
-  const Cart ge{P.geom + 6 * b};
+  const Geo<CURV> ge{P, b};
   const artemis_diffcoeff_t &dp = D.cond;
   constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1);
   const long cm = c - ((DIR == 1) ? 1 : ((DIR == 2) ? P.sj : P.sk));
@@ -197,37 +231,57 @@ __global__ __launch_bounds__(TX *TY) void thermal_flux_kernel(const PackView P, 
   }
 }
 
-// DiffusionUpdateImpl (diffusion.hpp:110-241), Cartesian: no metric sources
+// DiffusionUpdateImpl (diffusion.hpp:110-241)
+template <bool CURV>
 __global__ __launch_bounds__(TX *TY) void diffusion_update_kernel(const PackView P, const Box r,
                                                                   int do_viscosity, double dt) {
   BOX_CELL(r)
   const FluidView &f = P.gas;
   const int ns = f.ns, nv = 6 * ns, nq = 4 * ns;
   const int multi_d = (P.ndim > 1), three_d = (P.ndim > 2);
-  const Cart ge{P.geom + 6 * b};
-  const double d1 = ge.dx1(i), d2 = ge.dx2(j), d3 = ge.dx3(k);
-  const double ax1 = d2 * d3, ax2 = multi_d ? d1 * d3 : 0.0, ax3 = three_d ? d1 * d2 : 0.0;
-  const double vol = d1 * d2 * d3;
+  const CellMetric m = cell_metric<CURV>(P, b, k, j, i);
+  const double ax1[2] = {m.ax1[0], m.ax1[1]};
+  const double ax2[2] = {multi_d ? m.ax2[0] : 0.0, multi_d ? m.ax2[1] : 0.0};
+  const double ax3[2] = {three_d ? m.ax3[0] : 0.0, three_d ? m.ax3[1] : 0.0};
+  const double vol = m.vol;
+  double hx[3];
+  scale_factors<CURV>(P, b, k, j, i, hx);
+  // GetConnX1 = {0, dh2dx1, dh3dx1}, GetConnX2 = {0, 0, dh3dx2}, GetConnX3 = 0 (geometry.hpp:407-418)
+  double dhdx1[3] = {0.0, 0.0, 0.0}, dhdx2[3] = {0.0, 0.0, 0.0};
+  int x1dep = 0, x2dep = 0;
+  if constexpr (CURV) {
+    const DCoords co = make_coords(P, b, k, j, i);
+    x1dep = co.x1dep(), x2dep = co.x2dep() && multi_d;
+    if (x1dep) dhdx1[1] = co.dh2dx1(), dhdx1[2] = co.dh3dx1();
+    if (x2dep) dhdx2[2] = co.dh3dx2();
+  }
   const long c2 = c + multi_d * P.sj, c3 = c + three_d * P.sk;
   for (int n = 0; n < ns; ++n) {
     auto F = [&](int d, int var, long cc) { return f.dflux[d][b * nq + var][cc]; };
+    const int d2 = multi_d ? 1 : 0, d3 = three_d ? 2 : 0; // inactive directions have no flux table
     auto divergence = [&](int var) {
-      return (ax1 * F(0, var, c) - ax1 * F(0, var, c + 1)) +
-             multi_d * (ax2 * F(multi_d ? 1 : 0, var, c) - ax2 * F(multi_d ? 1 : 0, var, c2)) +
-             three_d * (ax3 * F(three_d ? 2 : 0, var, c) - ax3 * F(three_d ? 2 : 0, var, c3));
+      return (ax1[0] * F(0, var, c) - ax1[1] * F(0, var, c + 1)) +
+             multi_d * (ax2[0] * F(d2, var, c) - ax2[1] * F(d2, var, c2)) +
+             three_d * (ax3[0] * F(d3, var, c) - ax3[1] * F(d3, var, c3));
     };
     const int imx1 = 3 * n + 0, imx2 = 3 * n + 1, imx3 = 3 * n + 2, ien = 3 * ns + n;
+    auto metric_src = [&](const double dh[3]) {
+      return dh[0] * 0.5 * (F(0, imx1, c) + F(0, imx1, c + 1)) +
+             multi_d * dh[1] * 0.5 * (F(d2, imx2, c) + F(d2, imx2, c2)) +
+             three_d * dh[2] * 0.5 * (F(d3, imx3, c) + F(d3, imx3, c3));
+    };
     double divfxm = 0., divfym = 0., divfzm = 0.;
     if (do_viscosity) {
+      const double zero3[3] = {0.0, 0.0, 0.0};
       divfxm = divergence(imx1);
       divfxm /= vol;
-      divfxm += 0 * 0.0; // x1dep * src (false in Cartesian coordinates)
+      divfxm += x1dep * metric_src(dhdx1);
       divfym = divergence(imx2);
       divfym /= vol;
-      divfym += 0 * 0.0;
+      divfym += x2dep * metric_src(dhdx2);
       divfzm = divergence(imx3);
       divfzm /= vol;
-      divfzm += 0 * 0.0;
+      divfzm += 0 * metric_src(zero3); // x3dep is false for every system (geometry.hpp:107-110)
     }
     double divfe = divergence(ien);
     divfe /= vol;
@@ -236,13 +290,14 @@ __global__ __launch_bounds__(TX *TY) void diffusion_update_kernel(const PackView
     f.cons0[b * nv + ns + 3 * n + 2][c] -= dt * divfzm;
     f.cons0[b * nv + 4 * ns + n][c] -= dt * divfe;
     f.cons0[b * nv + 5 * ns + n][c] -=
-        dt * divfe - dt * (divfxm * f.prim[b * nv + ns + 3 * n + 0][c] / 1.0 +
-                           divfym * f.prim[b * nv + ns + 3 * n + 1][c] / 1.0 +
-                           divfzm * f.prim[b * nv + ns + 3 * n + 2][c] / 1.0);
+        dt * divfe - dt * (divfxm * f.prim[b * nv + ns + 3 * n + 0][c] / hx[0] +
+                           divfym * f.prim[b * nv + ns + 3 * n + 1][c] / hx[1] +
+                           divfzm * f.prim[b * nv + ns + 3 * n + 2][c] / hx[2]);
   }
 }
 
 // Diffusion::EstimateTimestep (diffusion.hpp:66-108) for one coefficient; grid-stride reduction
+template <bool CURV>
 __global__ __launch_bounds__(TX *TY) void diffusion_dt_kernel(const PackView P, const Box r,
                                                               const artemis_diffcoeff_t dp, double cv,
                                                               double cfl, unsigned long long *dt_bits) {
@@ -257,8 +312,14 @@ __global__ __launch_bounds__(TX *TY) void diffusion_dt_kernel(const PackView P, 
     const int b = bz / nkr, k = r.kl + bz % nkr;
     if (i > r.iu || j > r.ju) continue;
     const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
-    const Cart ge{P.geom + 6 * b};
-    const double dx[3] = {1.0 * ge.dx1(i), 1.0 * ge.dx2(j), 1.0 * ge.dx3(k)};
+    double dx[3]; // GetCellWidths (geometry.hpp:352-361)
+    if constexpr (CURV) {
+      const DCoords co = make_coords(P, b, k, j, i);
+      dx[0] = co.width1(), dx[1] = co.width2(), dx[2] = co.width3();
+    } else {
+      const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
+      dx[0] = 1.0 * g.dx1, dx[1] = 1.0 * g.dx2, dx[2] = 1.0 * g.dx3;
+    }
     double min_dx = DBL_MAX;
     for (int d = 0; d < P.ndim; d++) min_dx = amin(min_dx, dx[d]);
     const int ns = P.gas.ns, nv = 6 * ns;
@@ -295,22 +356,31 @@ void launch_zero_diffusion_flux(const PackView &P, hipStream_t s) {
   const Box r{0, P.ni - 1, 0, P.nj - 1, 0, P.nk - 1};
   hipLaunchKernelGGL(zero_dflux_kernel, grid_of(r, P.nb), dim3(TX, TY), 0, s, P, r);
 }
+#define LAUNCH_DIR(kern, DIR)                                                                    \
+  do {                                                                                           \
+    const Box fr = faces(P, DIR);                                                                \
+    if (P.coords == ARTEMIS_CARTESIAN)                                                           \
+      hipLaunchKernelGGL((kern<DIR, false>), grid_of(fr, P.nb), dim3(TX, TY), 0, s, P, fr, D);    \
+    else                                                                                         \
+      hipLaunchKernelGGL((kern<DIR, true>), grid_of(fr, P.nb), dim3(TX, TY), 0, s, P, fr, D);     \
+  } while (0)
 void launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s) {
-  const dim3 t(TX, TY);
-  hipLaunchKernelGGL(viscous_flux_kernel<1>, grid_of(faces(P, 1), P.nb), t, 0, s, P, faces(P, 1), D);
-  if (P.ndim > 1) hipLaunchKernelGGL(viscous_flux_kernel<2>, grid_of(faces(P, 2), P.nb), t, 0, s, P, faces(P, 2), D);
-  if (P.ndim > 2) hipLaunchKernelGGL(viscous_flux_kernel<3>, grid_of(faces(P, 3), P.nb), t, 0, s, P, faces(P, 3), D);
+  LAUNCH_DIR(viscous_flux_kernel, 1);
+  if (P.ndim > 1) LAUNCH_DIR(viscous_flux_kernel, 2);
+  if (P.ndim > 2) LAUNCH_DIR(viscous_flux_kernel, 3);
 }
 void launch_thermal_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s) {
-  const dim3 t(TX, TY);
-  hipLaunchKernelGGL(thermal_flux_kernel<1>, grid_of(faces(P, 1), P.nb), t, 0, s, P, faces(P, 1), D);
-  if (P.ndim > 1) hipLaunchKernelGGL(thermal_flux_kernel<2>, grid_of(faces(P, 2), P.nb), t, 0, s, P, faces(P, 2), D);
-  if (P.ndim > 2) hipLaunchKernelGGL(thermal_flux_kernel<3>, grid_of(faces(P, 3), P.nb), t, 0, s, P, faces(P, 3), D);
+  LAUNCH_DIR(thermal_flux_kernel, 1);
+  if (P.ndim > 1) LAUNCH_DIR(thermal_flux_kernel, 2);
+  if (P.ndim > 2) LAUNCH_DIR(thermal_flux_kernel, 3);
 }
 void launch_diffusion_update(const PackView &P, const artemis_diffusion_t &D, double dt, hipStream_t s) {
   const Box r = interior(P);
-  hipLaunchKernelGGL(diffusion_update_kernel, grid_of(r, P.nb), dim3(TX, TY), 0, s, P, r,
-                     D.visc.type != ARTEMIS_DIFF_OFF ? 1 : 0, dt);
+  const int visc = D.visc.type != ARTEMIS_DIFF_OFF ? 1 : 0;
+  if (P.coords == ARTEMIS_CARTESIAN)
+    hipLaunchKernelGGL(diffusion_update_kernel<false>, grid_of(r, P.nb), dim3(TX, TY), 0, s, P, r, visc, dt);
+  else
+    hipLaunchKernelGGL(diffusion_update_kernel<true>, grid_of(r, P.nb), dim3(TX, TY), 0, s, P, r, visc, dt);
 }
 void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double cfl, double *dt_dev,
                          hipStream_t s) {
@@ -319,10 +389,12 @@ void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double
   const long ntile = static_cast<long>(g3.x) * g3.y * g3.z;
   const dim3 g(static_cast<unsigned>(ntile < 4096 ? ntile : 4096));
   auto *bits = reinterpret_cast<unsigned long long *>(dt_dev);
-  if (D.visc.type != ARTEMIS_DIFF_OFF)
-    hipLaunchKernelGGL(diffusion_dt_kernel, g, dim3(TX, TY), 0, s, P, r, D.visc, D.cv, cfl, bits);
-  if (D.cond.type != ARTEMIS_DIFF_OFF)
-    hipLaunchKernelGGL(diffusion_dt_kernel, g, dim3(TX, TY), 0, s, P, r, D.cond, D.cv, cfl, bits);
+  const bool curv = P.coords != ARTEMIS_CARTESIAN;
+  for (const artemis_diffcoeff_t *c : {&D.visc, &D.cond}) {
+    if (c->type == ARTEMIS_DIFF_OFF) continue;
+    if (curv) hipLaunchKernelGGL(diffusion_dt_kernel<true>, g, dim3(TX, TY), 0, s, P, r, *c, D.cv, cfl, bits);
+    else hipLaunchKernelGGL(diffusion_dt_kernel<false>, g, dim3(TX, TY), 0, s, P, r, *c, D.cv, cfl, bits);
+  }
 }
 
 } // namespace artemis

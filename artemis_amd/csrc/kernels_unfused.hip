@@ -546,7 +546,8 @@ struct CondBcArgs {
   int type;
 };
 __global__ __launch_bounds__(256) void conductive_bc_kernel(const CondBcArgs a, const FillTabs t,
-                                                            const double *geom, int ni, int nj, int nk) {
+                                                            const PackView P) {
+  const int ni = P.ni, nj = P.nj, nk = P.nk;
   int ext[3] = {ni, nj, nk};
   ext[a.d] = a.ng;
   const long ncell = static_cast<long>(ext[0]) * ext[1] * ext[2];
@@ -561,11 +562,11 @@ __global__ __launch_bounds__(256) void conductive_bc_kernel(const CondBcArgs a, 
   ia[a.d] = (a.side == 0) ? a.st : a.en;
   const long c = (static_cast<long>(idx[2]) * nj + idx[1]) * ni + idx[0];
   const long cA = (static_cast<long>(ia[2]) * nj + ia[1]) * ni + ia[0];
-  const double *g = geom + 6 * t.b;
-  auto centre = [&](int q, int m) { return 0.5 * ((g[2 * q] + m * g[2 * q + 1]) + (g[2 * q] + (m + 1) * g[2 * q + 1])); };
   // Coords::Distance between the two cell centres (geometry.hpp:407-412)
-  const double dist = sqrt(sqr(centre(0, idx[0]) - centre(0, ia[0])) + sqr(centre(1, idx[1]) - centre(1, ia[1])) +
-                           sqr(centre(2, idx[2]) - centre(2, ia[2])));
+  double xg[3], xa[3];
+  make_coords(P, t.b, idx[2], idx[1], idx[0]).centre_to_cart(xg);
+  make_coords(P, t.b, ia[2], ia[1], ia[0]).centre_to_cart(xa);
+  const double dist = sqrt(sqr(xg[0] - xa[0]) + sqr(xg[1] - xa[1]) + sqr(xg[2] - xa[2]));
   const bool INNER = (a.side == 0);
   const double xma = (INNER ? -1. : 1.) * dist;
   const int nsg = t.nsg;
@@ -789,8 +790,7 @@ static void launch_bc_sequential(const PackView &P, int b, const int *bc6,
           a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
           a.g_temp = par->cond_temp, a.flux = par->cond_flux, a.gx = par->cond_g[d];
           a.coeff = par->cond_coeff, a.cv = par->cond_cv, a.gm1 = P.gm1, a.type = par->cond_type;
-          hipLaunchKernelGGL(conductive_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P.geom,
-                             P.ni, P.nj, P.nk);
+          hipLaunchKernelGGL(conductive_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P);
         } else if (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW) {
           StratBcArgs a;
           a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];

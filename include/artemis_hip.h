@@ -93,9 +93,8 @@ typedef struct artemis_pack {
   const double *geom;        /* DEVICE [nblocks][6] = {x1f0, dx1, x2f0, dx2, x3f0, dx3}:
                                 Coordinates_t::Xf<d>(idx) = xf0 + idx*dx, idx counted from the
                                 first ghost cell (geometry.hpp:65-72) */
-  const double *metric;      /* DEVICE x2 trigonometry tables, required for spherical2D/3D only
-                                (NULL otherwise): artemis_hip_metric_count() doubles filled by
-                                artemis_hip_metric_fill() */
+  const double *metric;      /* DEVICE trigonometry tables (see artemis_hip_metric_count / _fill);
+                                required for spherical2D/3D, optional otherwise */
   artemis_fluid_pack_t gas, dust;
 } artemis_pack_t;
 
@@ -141,12 +140,16 @@ int artemis_hip_estimate_dt(const artemis_pack_t *p, int fluid, double cfl, doub
 int artemis_hip_estimate_dt_async(const artemis_pack_t *p, int fluid, double cfl, double *dt_dev,
                                   void *stream);
 
-/* Metric tables for artemis/coordinates = spherical in 2-D/3-D.  geometry::Coords<spherical2D|
- * 3D> (spherical.hpp:61-146) evaluates cos/sin of the x2 faces, the x2 centroid and the x2
- * midpoint in every cell; all depend on j only, so the adapter tabulates them once per mesh
- * with the host libm.  artemis_hip_metric_count = number of doubles (0 when the system needs
- * no table); artemis_hip_metric_fill writes them to HOST memory from a HOST copy of p->geom
- * (p->geom itself is a device pointer and is not read).  Upload the result and set p->metric. */
+/* Metric tables.  geometry::Coords<GEOM> evaluates transcendentals per cell: for spherical 2-D/3-D
+ * cos/sin of the x2 faces, the x2 centroid and the x2 midpoint (spherical.hpp:61-146); for
+ * ConvertCoordsToCart (used by Coords::Distance in the diffusion tasks) cos/sin of the azimuth of
+ * the cell centre -- x2 in cylindrical, x3 in spherical3D / axisymmetric coordinates.  All depend on
+ * one index only, so the adapter tabulates them once per mesh with the host libm.
+ * artemis_hip_metric_count = number of doubles (0 for Cartesian and spherical1D);
+ * artemis_hip_metric_fill writes them to HOST memory from a HOST copy of p->geom (p->geom itself is
+ * a device pointer and is not read).  Upload the result and set p->metric.  Required for spherical
+ * 2-D/3-D always, for cylindrical / axisymmetric only by the diffusion entry points and the
+ * CONDUCTIVE boundary condition. */
 long artemis_hip_metric_count(const artemis_pack_t *p);
 int artemis_hip_metric_fill(const artemis_pack_t *p, const double *geom_host, double *out_host);
 
@@ -264,7 +267,8 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
  * tasks at artemis_driver.cpp:189-193 and :218-221, and the diffusive timestep limit folded into
  * Gas::EstimateTimestepMesh (gas.cpp:435-467, diffusion.hpp:66-108).  Fluxes go to
  * p->gas.diff_flux[d] on faces [s, e+1] like the hydro fluxes.
- * Built: Cartesian coordinates; constant coefficients, i.e. viscosity `constant`/`powerlaw` with
+ * Built: every coordinate system (cylindrical / axisymmetric blocks need p->metric for
+ * Coords::Distance); constant coefficients, i.e. viscosity `constant`/`powerlaw` with
  * r_exp = 0 and conductivity / diffusivity with temp_exp = rho_exp = 0 (the reference evaluates
  * std::pow per cell for the power laws and the alpha viscosity: no bit-reproducible device
  * counterpart), arithmetic or harmonic face averaging.  Everything else: ARTEMIS_HIP_EUNSUPPORTED. */

@@ -142,28 +142,44 @@ int artemis_hip_flux_source(const artemis_pack_t *p, int fluid, double dt, void 
 // The double evaluates the metric with the oracle's own per-cell libm calls, but the driver's
 // host-side problem generators read the tables, so fill them the way the product does.
 long artemis_hip_metric_count(const artemis_pack_t *p) {
-  if (p->coords != CO_SPH2D && p->coords != CO_SPH3D) return 0;
+  if (p->coords == CO_CART || p->coords == CO_SPH1D) return 0;
   const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0);
-  return static_cast<long>(p->nblocks) * 6 * (nj + 1);
+  const int nk = p->nx3 + ((p->nx3 > 1) ? 2 * p->nghost : 0);
+  return static_cast<long>(p->nblocks) * (6L * (nj + 1) + 2L * (nk + 1));
 }
 int artemis_hip_metric_fill(const artemis_pack_t *p, const double *g, double *out) {
   if (artemis_hip_metric_count(p) == 0) return 0;
   const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0), st = nj + 1;
+  const int nk = p->nx3 + ((p->nx3 > 1) ? 2 * p->nghost : 0), st3 = nk + 1;
+  const long stride = 6L * st + 2L * st3;
   for (int b = 0; b < p->nblocks; ++b) {
-    double *m = out + static_cast<long>(b) * 6 * st;
-    for (int j = 0; j <= nj; ++j) {
-      const double xf = g[6 * b + 2] + j * g[6 * b + 3];
-      m[j] = std::cos(xf), m[st + j] = std::sin(xf);
+    double *m = out + b * stride;
+    for (long q = 0; q < stride; ++q) m[q] = 0.0;
+    if (p->coords == CO_SPH2D || p->coords == CO_SPH3D) {
+      for (int j = 0; j <= nj; ++j) {
+        const double xf = g[6 * b + 2] + j * g[6 * b + 3];
+        m[j] = std::cos(xf), m[st + j] = std::sin(xf);
+      }
+      for (int j = 0; j < nj; ++j) {
+        BBox bb{};
+        bb.x2[0] = g[6 * b + 2] + j * g[6 * b + 3], bb.x2[1] = g[6 * b + 2] + (j + 1) * g[6 * b + 3];
+        const Real ctm = std::cos(bb.x2[0]), ctp = std::cos(bb.x2[1]);
+        const Real dst = std::sin(bb.x2[1]) - std::sin(bb.x2[0]);
+        const Real x2v = (dst - bb.x2[1] * ctp + bb.x2[0] * ctm) / std::abs(ctm - ctp);
+        m[2 * st + j] = x2v, m[3 * st + j] = std::sin(x2v), m[4 * st + j] = std::sin(0.5 * (bb.x2[0] + bb.x2[1]));
+        m[5 * st + j] = std::cos(x2v);
+      }
+    } else if (p->coords == CO_CYL) {
+      for (int j = 0; j < nj; ++j) {
+        const Real x2v = 0.5 * ((g[6 * b + 2] + j * g[6 * b + 3]) + (g[6 * b + 2] + (j + 1) * g[6 * b + 3]));
+        m[2 * st + j] = x2v, m[3 * st + j] = std::sin(x2v), m[5 * st + j] = std::cos(x2v);
+      }
     }
-    for (int j = 0; j < nj; ++j) {
-      BBox bb{};
-      bb.x2[0] = g[6 * b + 2] + j * g[6 * b + 3], bb.x2[1] = g[6 * b + 2] + (j + 1) * g[6 * b + 3];
-      const Real ctm = std::cos(bb.x2[0]), ctp = std::cos(bb.x2[1]);
-      const Real dst = std::sin(bb.x2[1]) - std::sin(bb.x2[0]);
-      const Real x2v = (dst - bb.x2[1] * ctp + bb.x2[0] * ctm) / std::abs(ctm - ctp);
-      m[2 * st + j] = x2v, m[3 * st + j] = std::sin(x2v), m[4 * st + j] = std::sin(0.5 * (bb.x2[0] + bb.x2[1]));
-      m[5 * st + j] = std::cos(x2v);
-    }
+    if (p->coords == CO_SPH3D || p->coords == CO_AXI)
+      for (int k = 0; k < nk; ++k) {
+        const Real x3v = 0.5 * ((g[6 * b + 4] + k * g[6 * b + 5]) + (g[6 * b + 4] + (k + 1) * g[6 * b + 5]));
+        m[6L * st + k] = std::cos(x3v), m[6L * st + st3 + k] = std::sin(x3v);
+      }
   }
   return 0;
 }

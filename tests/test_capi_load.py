@@ -44,7 +44,7 @@ def test_no_gpu_fails_loudly_and_validation():
     assert b"metric" in L.artemis_hip_last_error()
     p.coords = 3  # spherical2D on a 3-D block: geometry::CoordSelect never produces that
     assert L.artemis_hip_set_aux(C.byref(p), None) == capi.EINVAL
-    assert L.artemis_hip_metric_count(C.byref(p)) == 6 * (8 + 4 + 1)
+    assert L.artemis_hip_metric_count(C.byref(p)) == 6 * (8 + 4 + 1) + 2 * (8 + 4 + 1)
     p.coords = 0
     p.geom = 1
     p.gas.nspecies = 1

@@ -582,3 +582,72 @@ def test_conduction_problem_deck_bitwise_and_reference_pin(hiplib):
     ans = 0.05 + (xc - 1.2) * -0.01 / 0.1
     err = np.abs(T / ans - 1.0).mean()
     assert err <= 5e-3 and abs(err - 4.107e-3) < 5e-5, err  # the oracle's value at this resolution
+
+
+@pytest.mark.parametrize("g,d,e64", [("axisymmetric", 1, 2.07e-3), ("spherical", 2, 3.70e-4)])
+def test_conduction_problem_curvilinear_bitwise_and_reference_pin(hiplib, g, d, e64):
+    """thermal_diffusion.py:36-70 in its axisymmetric and spherical geometries (conduction pgen at the
+    volume centroids, `conductive` conditions with Coords::Distance, ThermalFlux / DiffusionUpdate
+    with curvilinear areas and volumes): 300 cycles bit for bit against the oracle with gravity on,
+    then the 64-zone run to t = 50 against the analytic steady state (the 128-zone reference
+    resolution halves the error, tests/test_oracle_pins.py)."""
+    from artemis_amd.driver import Simulation
+    x2 = (np.pi / 2 - 0.5, np.pi / 2 + 0.5) if g == "spherical" else (-0.5, 0.5)
+    geo = [f"artemis/coordinates={g}", f"parthenon/mesh/x2min={x2[0]!r}", f"parthenon/mesh/x2max={x2[1]!r}",
+           "parthenon/mesh/nx1=64", "parthenon/meshblock/nx1=64"]
+    s = Simulation(DECK("diffusion", "conduction.in"), geo + ["gravity/uniform/gx1=-0.02", "parthenon/time/nlim=300"])
+    o = Oracle((64, 1, 1), (0.2, x2[0], -0.5), (1.2, x2[1], 0.5), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.66667, dfloor=1e-10, siefloor=1e-15, cfl=0.3,
+               bc=("conductive", "conductive") + ("periodic",) * 4, integrator="rk2", coordinates=g)
+    o.set_gravity_uniform(-0.02, 0.0, 0.0)
+    o.set_conductivity("conductivity", cond=0.1)
+    o.set_drag("self", "constant")
+    o.set_damping(0, inner=(4.0, -1.7976931348623157e308, -1.7976931348623157e308), inner_rate=(1.0e4, 0.0, 0.0))
+    o.pgen_conduction(gas_rho=1.0, gas_temp=0.05, flux=0.01)
+    s.evolve(), o.evolve(40.0, 300)
+    assert s.ncycle == o.ncycle == 300 and s.time == o.time and s.dt == o.dt
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    f = Simulation(DECK("diffusion", "conduction.in"), geo + ["parthenon/time/tlim=50.0"])
+    f.evolve()
+    assert abs(f.time - 50.0) < 1e-12 and f.ncycle > 80000
+    T = f.interior(f.field("gas.prim"))[5, 0, 0] * (1.66667 - 1.0)
+    xc = 0.2 + (np.arange(64) + 0.5) / 64
+    fl = 0.01 * 0.2 ** d
+    ans = (None, 0.05 + np.log(xc / 1.2) * -fl / 0.1, 0.05 + (1.0 / xc - 1.0 / 1.2) * fl / 0.1)[d]
+    err = np.abs(T / ans - 1.0).mean()
+    assert err <= 5e-3 and abs(err - e64) < 0.01 * e64, err
+
+
+def test_viscous_blast_axisymmetric_bitwise_and_blocks(hiplib):
+    """Viscosity + conduction in curvilinear coordinates through the driver: the axisymmetric blast
+    with constant kinematic viscosity and conductivity, 40 cycles bit for bit against the oracle
+    on one block (scale factors, connection coefficients and Coords::Distance in the strain tensor,
+    metric sources in DiffusionUpdate), and the same run on 2 x 2 blocks (edge / corner ghosts
+    through the extended-slab exchange) against the one-block run to round-off."""
+    from artemis_amd.driver import Simulation
+    ov = BLAST_GEOM["axi"] + ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "problem/radius=0.2",
+                              "problem/samples=10", "parthenon/time/nlim=40", "physics/viscosity=true",
+                              "physics/conduction=true", "gas/viscosity/type=constant", "gas/viscosity/nu=0.02",
+                              "gas/viscosity/eta_bulk=0.3", "gas/conductivity/type=conductivity",
+                              "gas/conductivity/cond=0.01"]
+    one = ["parthenon/meshblock/nx1=64", "parthenon/meshblock/nx2=64"]
+    s = Simulation(DECK("blast", "blast.in"), ov + one)
+    o = Oracle((64, 64, 1), (0.0, -1.0, -0.5), (2.0, 1.0, 0.5), ng=2, reconstruct="plm", riemann="hlle",
+               gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3, integrator="rk2",
+               bc=("reflecting",) + ("outflow",) * 5, coordinates="axisymmetric")
+    o.set_viscosity("constant", nu=0.02, eta_bulk=0.3)
+    o.set_conductivity("conductivity", cond=0.01)
+    o.pgen_blast(radius=0.2, internal_energy=1.0, p0=1e-5, d0=1.0, samples=10, symmetry="spherical")
+    s.evolve(), o.evolve(0.1, 40)
+    assert s.ncycle == o.ncycle == 40 and s.time == o.time
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    four = Simulation(DECK("blast", "blast.in"), ov + ["parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=32"])
+    assert four.nblocks == 4
+    four.evolve()
+    assert four.ncycle == 40
+    full = s.interior(s.field("gas.prim"))
+    for blk in range(4):
+        bi, bj = blk % 2, blk // 2
+        part = four.interior(four.field("gas.prim", blk))
+        ref = full[:, :, bj * 32:(bj + 1) * 32, bi * 32:(bi + 1) * 32]
+        assert np.max(np.abs(part - ref) / (np.abs(ref) + 1e-3)) < 1e-9, blk

@@ -1,6 +1,8 @@
 """GPU parity of the gas diffusion tasks (ZeroDiffusionFlux, ViscousFlux, ThermalFlux,
 DiffusionUpdate, diffusive timestep; reference gas.cpp:522-641, utils/diffusion/*.hpp) against
-the CPU oracle, BIT-EXACT, Cartesian 1-D / 2-D / 3-D, several species, both face averagings."""
+the CPU oracle, BIT-EXACT, Cartesian 1-D / 2-D / 3-D and every curvilinear system (scale
+factors, connection coefficients, Coords::Distance through ConvertToCart), several species, both
+face averagings."""
 import numpy as np
 import pytest
 import torch
@@ -11,11 +13,10 @@ from test_parity_ops import face_slices, push, random_state, same
 pytestmark = pytest.mark.gpu
 
 
-def pair(nx, ns_gas=1, seed=0, ng=2):
+def pair(nx, ns_gas=1, seed=0, ng=2, coordinates="cartesian", lo=(-1.0, -0.5, 0.25), hi=(1.0, 0.8, 0.95)):
     from artemis_amd.pack import MeshBlockPack
-    lo, hi = (-1.0, -0.5, 0.25), (1.0, 0.8, 0.95)
     kw = dict(ng=ng, ns_gas=ns_gas, ns_dust=0, reconstruct="plm", riemann="hlle", gamma=1.4,
-              dfloor=1e-10, siefloor=1e-10)
+              dfloor=1e-10, siefloor=1e-10, coordinates=coordinates)
     o = Oracle(nx, lo, hi, bc=("outflow",) * 6, cfl=0.3, **kw)
     random_state(o, np.random.default_rng(seed), shock=False, mach=0.5, contrast=10.0)
     mb = MeshBlockPack(1, nx, [lo], [hi], with_diffusion=True, **kw)
@@ -23,12 +24,27 @@ def pair(nx, ns_gas=1, seed=0, ng=2):
     return o, mb
 
 
-@pytest.mark.parametrize("nx", [(24, 12, 10), (33, 9, 1), (70, 1, 1), (5, 4, 3)])
+# curvilinear blocks: name, nx, lower and upper corner (spherical x2 ghosts stay inside (0, pi),
+# see test_parity_geometry.py)
+CURVI = [
+    ("spherical", (40, 1, 1), (0.0, 0.0, -0.5), (1.0, np.pi, 0.5)),
+    ("spherical", (24, 12, 1), (0.4, 0.5, -0.5), (2.5, 2.6, 0.5)),
+    ("spherical", (14, 10, 8), (0.3, 0.7, 0.0), (1.7, 2.5, 2 * np.pi)),
+    ("cylindrical", (16, 12, 6), (0.5, 0.0, -1.0), (2.0, 2 * np.pi, 1.0)),
+    ("cylindrical", (33, 1, 1), (0.0, -0.5, -0.5), (1.0, 0.5, 0.5)),
+    ("axisymmetric", (24, 12, 1), (0.0, -1.0, -0.5), (2.0, 1.0, 0.5)),
+    ("axisymmetric", (12, 8, 6), (0.7, -1.0, 0.0), (2.0, 1.0, 1.0)),
+]
+CART = [("cartesian", nx, (-1.0, -0.5, 0.25), (1.0, 0.8, 0.95))
+        for nx in [(24, 12, 10), (33, 9, 1), (70, 1, 1), (5, 4, 3)]]
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", CART + CURVI)
 @pytest.mark.parametrize("avg", ["arithmetic", "harmonic"])
 @pytest.mark.parametrize("ctype", ["conductivity", "diffusivity"])
-def test_diffusion_tasks(hiplib, nx, avg, ctype):
+def test_diffusion_tasks(hiplib, coordinates, nx, lo, hi, avg, ctype):
     from artemis_amd.pack import diffusion_params
-    o, mb = pair(nx, ns_gas=2, seed=51)
+    o, mb = pair(nx, ns_gas=2, seed=51, coordinates=coordinates, lo=lo, hi=hi)
     o.set_viscosity("constant", nu=0.03, eta_bulk=0.4, averaging=avg)
     ck = dict(cond=0.07) if ctype == "conductivity" else dict(kappa=0.07)
     o.set_conductivity(ctype, averaging=avg, **ck)
@@ -67,11 +83,12 @@ def test_conduction_only_update_and_contract(hiplib):
     with pytest.raises(capi.ArtemisHipError) as e:
         mb.ViscousFlux(diffusion_params(1.4, viscosity=dict(type="alpha", alpha=0.01)))
     assert e.value.code == capi.EUNSUPPORTED
-    sph = MeshBlockPack(1, (8, 1, 1), [(0.5, 0.0, -0.5)], [(1.0, 3.0, 0.5)], coordinates="spherical",
+    cyl = MeshBlockPack(1, (8, 4, 1), [(0.5, 0.0, -0.5)], [(1.0, 3.0, 0.5)], coordinates="cylindrical",
                         with_diffusion=True)
+    cyl.pack.metric = None  # Coords::Distance needs the azimuth's cos / sin
     with pytest.raises(capi.ArtemisHipError) as e:
-        sph.ThermalFlux(D)
-    assert e.value.code == capi.EUNSUPPORTED
+        cyl.ThermalFlux(D)
+    assert e.value.code == capi.EINVAL
     nofl = MeshBlockPack(1, (8, 8, 1), [(0, 0, 0)], [(1, 1, 1)])
     with pytest.raises(capi.ArtemisHipError) as e:
         nofl.ThermalFlux(D)

@@ -140,7 +140,7 @@ def test_metric_abi_contract(hiplib):
     from artemis_amd.pack import MeshBlockPack
     mb = MeshBlockPack(1, (8, 8, 1), [(0.5, 0.1, 0.0)], [(1.0, 3.0, 1.0)], coordinates="spherical")
     L = mb.L
-    assert mb.pack.coords == capi.SPHERICAL2D and L.artemis_hip_metric_count(C.byref(mb.pack)) == 6 * 13
+    assert mb.pack.coords == capi.SPHERICAL2D and L.artemis_hip_metric_count(C.byref(mb.pack)) == 6 * 13 + 2 * 2
     keep = mb.pack.metric
     mb.pack.metric = None
     assert L.artemis_hip_prim_to_cons(C.byref(mb.pack), None) == capi.EINVAL

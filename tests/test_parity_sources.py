@@ -192,14 +192,27 @@ def test_source_abi_contract(hiplib):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("nx", [(24, 10, 6), (33, 9, 1), (40, 1, 1)])
+COND_BLOCKS = [
+    ("cartesian", (24, 10, 6), (0.2, -0.5, -0.3), (1.2, 0.5, 0.3)),
+    ("cartesian", (33, 9, 1), (0.2, -0.5, -0.3), (1.2, 0.5, 0.3)),
+    ("cartesian", (40, 1, 1), (0.2, -0.5, -0.3), (1.2, 0.5, 0.3)),
+    ("spherical", (32, 1, 1), (0.2, 0.0, -0.5), (1.2, np.pi, 0.5)),       # thermal_diffusion.py "sph"
+    ("spherical", (16, 10, 6), (0.3, 0.7, 0.0), (1.7, 2.5, 2 * np.pi)),
+    ("axisymmetric", (32, 1, 1), (0.2, -0.5, -0.5), (1.2, 0.5, 0.5)),     # thermal_diffusion.py "axi"
+    ("axisymmetric", (12, 8, 6), (0.7, -1.0, 0.0), (2.0, 1.0, 1.0)),
+    ("cylindrical", (16, 12, 6), (0.5, 0.0, -1.0), (2.0, 2 * np.pi, 1.0)),
+]
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", COND_BLOCKS)
 @pytest.mark.parametrize("ctype", ["conductivity", "diffusivity"])
-def test_conductive_boundary_conditions(hiplib, nx, ctype):
+def test_conductive_boundary_conditions(hiplib, coordinates, nx, lo, hi, ctype):
     """`conductive` on every active face (pgen/conduction.hpp:105-232) with uniform gravity: fixed
-    flux at inner faces, fixed temperature at outer ones, hydrostatic density."""
+    flux at inner faces, fixed temperature at outer ones, hydrostatic density; the ghost-to-active
+    distance is Coords::Distance of each system."""
     from artemis_amd import capi
     bc = ("conductive",) * 6
-    o, mb = pair(nx, (0.2, -0.5, -0.3), (1.2, 0.5, 0.3), ns_gas=1, ns_dust=0, seed=27, bc=bc)
+    o, mb = pair(nx, lo, hi, ns_gas=1, ns_dust=0, seed=27, bc=bc, coordinates=coordinates)
     o.set_gravity_uniform(-0.3, 0.2, 0.1)
     ck = dict(cond=0.1) if ctype == "conductivity" else dict(kappa=0.1)
     o.set_conductivity(ctype, **ck)
