@@ -45,7 +45,7 @@ enum { RS_HLLC = 0, RS_HLLE = 1, RS_LLF = 2 };
 enum { RC_PCM = 0, RC_PLM = 1, RC_PPM = 2 };
 enum { FL_GAS = 0, FL_DUST = 1 };
 enum { BC_PERIODIC = 0, BC_OUTFLOW = 1, BC_REFLECT = 2, BC_NONE = 3, BC_STRAT_EXTRAP = 4,
-       BC_STRAT_INFLOW = 5, BC_CONDUCTIVE = 6 }; // 4/5: the `strat` pgen's user conditions (problem_modifier.hpp:114-128)
+       BC_STRAT_INFLOW = 5, BC_CONDUCTIVE = 6, BC_DISK_IC = 7, BC_DISK_EXTRAP = 8 }; // 4/5: the `strat` pgen's user conditions (problem_modifier.hpp:114-128)
 enum { INT_RK1 = 0, INT_RK2 = 1, INT_VL2 = 2, INT_RK3 = 3 };
 
 struct oracle_cfg {
@@ -114,6 +114,13 @@ struct Sim {
   struct { // pgen/conduction.hpp:30-37 CondParams (what the `conductive` conditions read)
     Real g_temp = 1, flux = 0;
   } condbc;
+  struct DiskParams { // pgen/disk.hpp:50-66 (nbody_temp = false: n-body is out of scope)
+    Real r0 = 1, h0 = 0.05, p = -2.25, q = -0.5, flare = 0.25;
+    Real rho0 = 1, dens_min = 1e-5, pres_min = 1e-8;
+    Real gm = 1, Omega0 = 1, l0 = 0, omf = 0, dust_to_gas = 0.01, rexp = 0, rcav = 0;
+    Real Gamma = 1, gamma_gas = 1.4, alpha = 0, nu0 = 0, nu_indx = 0, mdot = 0, temp_soft2 = 0;
+    bool quiet_start = false;
+  } disk;
   // diffusion (utils/diffusion/diffusion_coeff.hpp:58-136 DiffCoeffParams); type 0 = package off
   struct DiffCoeff {
     int type = 0; // 1 viscosity_plaw, 2 viscosity_alpha, 3 conductivity_plaw, 4 thermaldiff_plaw
@@ -1039,6 +1046,116 @@ inline CylVec to_cyl_with_vec(const Coords &co, const Real xi[3]) {
   return c;
 }
 
+// Coords<GEOM>::ConvertToCylWithVec / ConvertToCartWithVec (geometry.hpp:438-482): the converted
+// point and the three rows ex1, ex2, ex3 (components of the problem's unit vectors in the target
+// basis).  Cartesian geometry.hpp:286-301; cylindrical.hpp:96-107, :128-136; spherical.hpp:172-189,
+// :202-220 (3D), :373-389, :403-421 (2D), :529-545, :559-577 (1D); axisymmetric.hpp:99-111, :135-145.
+struct Frame {
+  Real x[3], e1[3], e2[3], e3[3];
+};
+inline void set3(Real a[3], Real x, Real y, Real z) { a[0] = x, a[1] = y, a[2] = z; }
+inline Frame to_cyl_frame(const Coords &co, const Real xi[3]) {
+  Frame f;
+  const Real fuzz = 1e-99;
+  switch (co.sys) {
+  case CO_CART: {
+    Real R = std::sqrt(xi[0] * xi[0] + xi[1] * xi[1]);
+    const Real cp = xi[0] / (R + fuzz);
+    const Real sp = xi[1] / (R + fuzz);
+    set3(f.x, R, std::atan2(sp, cp), xi[2]);
+    set3(f.e1, cp, -sp, 0.0), set3(f.e2, sp, cp, 0.0), set3(f.e3, 0.0, 0.0, 1.0);
+  } break;
+  case CO_CYL:
+    set3(f.x, xi[0], xi[1], xi[2]);
+    set3(f.e1, 1.0, 0.0, 0.0), set3(f.e2, 0.0, 1.0, 0.0), set3(f.e3, 0.0, 0.0, 1.0);
+    break;
+  case CO_SPH3D:
+  case CO_SPH2D: {
+    const Real ct = std::cos(xi[1]);
+    const Real st = std::sin(xi[1]);
+    set3(f.x, xi[0] * st, (co.sys == CO_SPH3D) ? xi[2] : 0.0, xi[0] * ct);
+    set3(f.e1, st, 0.0, ct), set3(f.e2, ct, 0.0, -st), set3(f.e3, 0.0, 1.0, 0.0);
+  } break;
+  case CO_SPH1D: {
+    const Real ct = 0.0, st = 1.0;
+    set3(f.x, xi[0] * st, 0.0, xi[0] * ct);
+    set3(f.e1, st, 0.0, ct), set3(f.e2, ct, 0.0, -st), set3(f.e3, 0.0, 1.0, 0.0);
+  } break;
+  default: // axisymmetric
+    set3(f.x, xi[0], xi[2], xi[1]);
+    set3(f.e1, 1.0, 0.0, 0.0), set3(f.e2, 0.0, 0.0, 1.0), set3(f.e3, 0.0, 1.0, 0.0);
+  }
+  return f;
+}
+inline Frame to_cart_frame(const Coords &co, const Real xi[3]) {
+  Frame f;
+  switch (co.sys) {
+  case CO_CYL: {
+    const Real cp = std::cos(xi[1]);
+    const Real sp = std::sin(xi[1]);
+    set3(f.x, xi[0] * cp, xi[0] * sp, xi[2]);
+    set3(f.e1, cp, sp, 0.0), set3(f.e2, -sp, cp, 0.0), set3(f.e3, 0.0, 0.0, 1.0);
+  } break;
+  case CO_SPH3D:
+  case CO_SPH2D:
+  case CO_SPH1D: {
+    const Real cp = (co.sys == CO_SPH3D) ? std::cos(xi[2]) : 1.0;
+    const Real sp = (co.sys == CO_SPH3D) ? std::sin(xi[2]) : 0.0;
+    const Real ct = (co.sys == CO_SPH1D) ? 0.0 : std::cos(xi[1]);
+    const Real st = (co.sys == CO_SPH1D) ? 1.0 : std::sin(xi[1]);
+    set3(f.x, xi[0] * st * cp, xi[0] * st * sp, xi[0] * ct);
+    set3(f.e1, st * cp, st * sp, ct), set3(f.e2, ct * cp, ct * sp, -st), set3(f.e3, -sp, cp, 0.0);
+  } break;
+  case CO_AXI: {
+    const Real cp = std::cos(xi[2]);
+    const Real sp = std::sin(xi[2]);
+    set3(f.x, xi[0] * cp, xi[0] * sp, xi[1]);
+    set3(f.e1, cp, 0.0, sp), set3(f.e2, -sp, 0.0, cp), set3(f.e3, 0.0, 1.0, 0.0);
+  } break;
+  default:
+    set3(f.x, xi[0], xi[1], xi[2]);
+    set3(f.e1, 1.0, 0.0, 0.0), set3(f.e2, 0.0, 1.0, 0.0), set3(f.e3, 0.0, 0.0, 1.0);
+  }
+  return f;
+}
+// ConvertToSph(xi)[0]: the spherical radius (geometry.hpp:262-264, cylindrical.hpp:111-112,
+// axisymmetric.hpp:116-117, identity for the spherical systems)
+inline Real to_sph_radius(const Coords &co, const Real xi[3]) {
+  switch (co.sys) {
+  case CO_CART: {
+    const Real R = std::sqrt(xi[0] * xi[0] + xi[1] * xi[1]);
+    return std::sqrt(R * R + xi[2] * xi[2]);
+  }
+  case CO_CYL: return std::sqrt(xi[0] * xi[0] + xi[2] * xi[2]);
+  case CO_AXI: return std::sqrt(xi[0] * xi[0] + xi[1] * xi[1]);
+  default: return xi[0];
+  }
+}
+// RFWeights (geometry.hpp:228-232 zero default; cylindrical.hpp:82-87; axisymmetric.hpp:73-78;
+// spherical.hpp:148-169 (3D), :349-370 (2D), :515-526 (1D)): +-(<R^2>_face - <R^2>) weights of
+// the mass flux in the angular-momentum-conserving rotating-frame source
+inline void rf_weights(const Coords &co, Real bx1[2], Real bx2[2], Real bx3[2]) {
+  bx1[0] = bx1[1] = bx2[0] = bx2[1] = bx3[0] = bx3[1] = 0.0;
+  const BBox &bnds = co.bnds;
+  if (co.sys == CO_CYL || co.sys == CO_AXI) {
+    const Real ans = 0.5 * (bnds.x1[0] + bnds.x1[1]) * (bnds.x1[1] - bnds.x1[0]);
+    bx1[0] = bx1[1] = ans;
+  } else if (co.sys == CO_SPH3D || co.sys == CO_SPH2D) {
+    const Real rv = co.x1v();
+    const Real stv = std::sin(co.x2v());
+    const Real rf = 2.0 / 3.0 *
+                    (bnds.x1[0] * bnds.x1[0] + bnds.x1[0] * bnds.x1[1] + bnds.x1[1] * bnds.x1[1]) /
+                    (bnds.x1[0] + bnds.x1[1]);
+    const Real r2cyl = SQR(rv * stv);
+    bx1[0] = r2cyl - SQR(bnds.x1[0] * stv), bx1[1] = SQR(bnds.x1[1] * stv) - r2cyl;
+    bx2[0] = r2cyl - SQR(rf * std::sin(bnds.x2[0])), bx2[1] = SQR(rf * std::sin(bnds.x2[1])) - r2cyl;
+  } else if (co.sys == CO_SPH1D) {
+    const Real rv = co.x1v();
+    const Real r2cyl = SQR(rv);
+    bx1[0] = r2cyl - SQR(bnds.x1[0]), bx1[1] = SQR(bnds.x1[1]) - r2cyl;
+  }
+}
+
 // GetSpecificInternalEnergy (artemis_utils.hpp:43-62) on the oracle's gas cons layout
 inline Real specific_internal_energy(const Sim &s, int n, size_t c, const Real hx[3]) {
   const int nsp = s.c.ns_gas;
@@ -1058,7 +1175,7 @@ inline Real specific_internal_energy(const Sim &s, int n, size_t c, const Real h
 // gravity/gravity.cpp:126-155 ExternalGravity -> gravity/uniform.cpp:28-84 UniformGravity,
 // gravity/point_mass.cpp:27-198 PointMassGravity.  Point mass: Cartesian (offset mass,
 // softening, sink), spherical1D/2D and axisymmetric (mass at the origin); cylindrical and
-// spherical3D need the azimuthal basis and are not restated.
+// spherical3D go through ConvertToCartWithVec like the Cartesian system.
 void external_gravity(Sim &s, Real time, Real dt) {
   if (s.grav.type == 0) return;
   if (!((time >= s.grav.tstart) && (time < s.grav.tstop))) return; // gravity.cpp:134
@@ -1094,8 +1211,9 @@ void external_gravity(Sim &s, Real time, Real dt) {
             const Real g = -gm / rad2;
             gx1 = g * st; // ex1[0]
             gx2 = g * ct; // ex3[0]
-          } else { // Cartesian: ConvertToCartWithVec is the identity (:91-112)
-            Real dxc[3] = {dx[0], dx[1], dx[2]};
+          } else { // Cartesian, cylindrical, spherical3D: through the Cartesian frame (:91-112)
+            const Frame fr = to_cart_frame(coords, dx);
+            Real dxc[3] = {fr.x[0], fr.x[1], fr.x[2]};
             for (int n = 0; n < 3; n++)
               dxc[n] -= s.grav.pos[n];
             const Real R = std::sqrt(dxc[0] * dxc[0] + dxc[1] * dxc[1]); // geometry.hpp:262-264
@@ -1105,9 +1223,9 @@ void external_gravity(Sim &s, Real time, Real dt) {
             const Real idr3 = 1.0 / (std::sqrt(rad2) * rad2);
             Real g[3] = {-gm * dxc[0] * idr3, (multi_d) * (-gm * dxc[1] * idr3),
                          (three_d) * (-gm * dxc[2] * idr3)};
-            gx1 = g[0] * 1.0 + g[1] * 0.0 + g[2] * 0.0;
-            gx2 = g[0] * 0.0 + g[1] * 1.0 + g[2] * 0.0;
-            gx3 = g[0] * 0.0 + g[1] * 0.0 + g[2] * 1.0;
+            gx1 = g[0] * fr.e1[0] + g[1] * fr.e1[1] + g[2] * fr.e1[2];
+            gx2 = g[0] * fr.e2[0] + g[1] * fr.e2[1] + g[2] * fr.e2[2];
+            gx3 = g[0] * fr.e3[0] + g[1] * fr.e3[1] + g[2] * fr.e3[2];
           }
           const Real sramp = sink_rate * SQR((dr - sink_rad) / sink_rad); // quad_ramp, gravity.hpp:116
           fd = std::min(0.5, sramp / (1.0 + sramp));
@@ -1170,8 +1288,54 @@ void external_gravity(Sim &s, Real time, Real dt) {
 // rotating_frame/rotating_frame.cpp:56-86 RotatingFrameForce -> Cartesian:
 // rotating_frame_impl.hpp:28-93 ShearingBoxImpl (tidal potential differenced across the cell
 // + Coriolis force).  The curvilinear flux-form variant (:95-199) is not restated.
+// rotating_frame_impl.hpp:95-199 RotatingFrameImpl<GEOM>: every non-Cartesian system
+// (rotating_frame.cpp:63-79).  Reads the MASS fluxes of the stage.
+void rotating_frame_curvilinear(Sim &s, Real dt) {
+  const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
+  const int multi_d = (s.ndim >= 2), three_d = (s.ndim == 3);
+  const Real om0 = s.rframe.omega;
+  const Real omdt = om0 * dt;
+  const Real om2dt = omdt * om0;
+  const ptrdiff_t sj = s.ni, sk = static_cast<ptrdiff_t>(s.ni) * s.nj;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = s.ks; k <= s.ke; ++k)
+    for (int j = s.js; j <= s.je; ++j)
+      for (int i = s.is; i <= s.ie; ++i) {
+        const Coords coords(s, k, j, i);
+        const Real xv[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
+        const Frame fr = to_cyl_frame(coords, xv);
+        Real bx1[2], bx2[2], bx3[2];
+        rf_weights(coords, bx1, bx2, bx3);
+        Real ax1[2], ax2[2] = {0.0, 0.0}, ax3[2] = {0.0, 0.0};
+        coords.GetFaceAreaX1(ax1);
+        if (multi_d) coords.GetFaceAreaX2(ax2);
+        if (three_d) coords.GetFaceAreaX3(ax3);
+        const Real vol = coords.Volume();
+        const size_t c = IDX(s, k, j, i);
+        const size_t c2 = c + multi_d * sj, c3 = c + three_d * sk;
+        auto body = [&](const std::vector<Real> *flux, std::vector<Real> &u0, int nsp, int n, bool gas) {
+          const Real *f1 = flux[0].data() + n * s.N, *f2 = flux[1].data() + n * s.N;
+          const Real *f3 = flux[2].data() + n * s.N;
+          const Real divf = (f1[c] * ax1[0] * bx1[0] + f1[c + 1] * ax1[1] * bx1[1]) +
+                            multi_d * (f2[c] * ax2[0] * bx2[0] + f2[c2] * ax2[1] * bx2[1]) +
+                            three_d * (f3[c] * ax3[0] * bx3[0] + f3[c3] * ax3[1] * bx3[1]);
+          u0[(nsp + 3 * n + 0) * s.N + c] -= omdt * (divf / vol) * fr.e1[1];
+          u0[(nsp + 3 * n + 1) * s.N + c] -= omdt * (divf / vol) * fr.e2[1];
+          u0[(nsp + 3 * n + 2) * s.N + c] -= omdt * (divf / vol) * fr.e3[1];
+          if (!gas) return;
+          const Real fx[3] = {0.5 * (f1[c] + f1[c + 1]), multi_d * 0.5 * (f2[c] + f2[c2]),
+                              three_d * 0.5 * (f3[c] + f3[c3])};
+          u0[(4 * nsp + n) * s.N + c] +=
+              om2dt * fr.x[0] * (fx[0] * fr.e1[0] + fx[1] * fr.e2[0] + fx[2] * fr.e3[0]);
+        };
+        for (int n = 0; n < ng_; ++n) body(s.gflux, s.gu0, ng_, n, true);
+        for (int n = 0; n < nd_; ++n) body(s.dflux, s.du0, nd_, n, false);
+      }
+}
+
 void rotating_frame_force(Sim &s, Real dt) {
   if (!s.rframe.on) return;
+  if (s.c.coords != CO_CART) return rotating_frame_curvilinear(s, dt);
   const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
   const int three_d = (s.ndim == 3);
   const Real om0 = s.rframe.omega, qshear = s.rframe.qshear;
@@ -1368,10 +1532,7 @@ inline Real diff_coeff(const Sim &s, const Sim::DiffCoeff &dp, int n, int k, int
     return dp.nu_s * dens * std::pow(cv.R / dp.R0, dp.r_exp);
   }
   case 2: { // viscosity_alpha, :262-268 (spherical radius of the cell centre)
-    Real xc[3];
-    coords.ConvertToCart(xv, xc);
-    const Real R = std::sqrt(xc[0] * xc[0] + xc[1] * xc[1]);
-    const Real r = coords.sph() ? xv[0] : std::sqrt(R * R + xc[2] * xc[2]);
+    const Real r = to_sph_radius(coords, xv); // coords.ConvertToSph(xv)[0]
     const Real Omk = dp.Omega0 * std::pow(r / dp.R0, -1.5);
     const Real gm1 = s.c.gamma - 1.0;
     const Real blk = (gm1 + 1.0) * gm1 * dens * sie;
@@ -1862,7 +2023,9 @@ void fill_dir(Sim &s, std::vector<Real> &prim, int nvar, int nsp, bool gas, int 
   const int ext[3] = {s.ni, s.nj, s.nk};
   for (int side = 0; side < 2; ++side) {
     const int bc = s.c.bc[2 * d + side];
-    if (bc == BC_NONE || bc == BC_STRAT_EXTRAP || bc == BC_STRAT_INFLOW || bc == BC_CONDUCTIVE) continue;
+    if (bc == BC_NONE || bc == BC_STRAT_EXTRAP || bc == BC_STRAT_INFLOW || bc == BC_CONDUCTIVE ||
+        bc == BC_DISK_IC || bc == BC_DISK_EXTRAP)
+      continue;
     if ((pass == 0) != (bc == BC_PERIODIC)) continue;
     for (int n = 0; n < nvar; ++n) {
       if (gas && n >= 4 * nsp && n < 5 * nsp) continue; // pressure slot is not FillGhost
@@ -2006,6 +2169,190 @@ void conductive_bc(Sim &s, int d, int side) {
         for (int q = 0; q < 3; ++q) s.gprim[(nsp + q) * s.N + c] = s.gprim[(nsp + q) * s.N + cA];
       }
 }
+// ---------------------------------------------------------------------------------------
+// pgen/disk.hpp:69-135 profiles.  IdealGas closed forms (singularity-eos, recalled):
+// P(rho, T) = gm1 rho Cv T, sie(rho, T) = Cv T.
+inline Real disk_den(const Sim::DiskParams &pg, const Real R, const Real z) {
+  const Real r = std::sqrt(R * R + z * z);
+  const Real h = pg.h0 * std::pow(R / pg.r0, pg.flare);
+  const Real sig0 = pg.rho0;
+  const Real exp_fac = (pg.rexp == 0.) ? 1. : std::exp(-SQR(R / pg.rexp));
+  const Real dmid = (sig0 * std::pow(R / pg.r0, pg.p)) * (1. - pg.l0 * std::sqrt(pg.r0 / R)) *
+                    (pg.dens_min / pg.rho0 +
+                     (1. - pg.dens_min / pg.rho0) * std::exp(-std::pow(pg.rcav / R, 12.0))) *
+                    exp_fac;
+  const Real sint = (r == 0.0) ? 1.0 : R / r;
+  const Real efac = (1. - sint) / (h * h);
+  if (pg.Gamma == 1.) return std::max(pg.dens_min, dmid * std::exp(-efac));
+  const Real pfac = 1. - (pg.Gamma - 1) * efac;
+  return std::max(pg.dens_min, dmid * std::pow(pfac + 1e-99, 1. / (pg.Gamma - 1)));
+}
+inline Real disk_temp(const Sim::DiskParams &pg, const Real R, const Real z) {
+  const Real rho = disk_den(pg, R, z);
+  const Real rho0 = disk_den(pg, R, 0.0);
+  const Real H = R * pg.h0 * std::pow(R / pg.r0, pg.flare);
+  const Real ir1 = 1.0 / std::sqrt(R * R + pg.temp_soft2);
+  const Real omk2 = SQR(pg.Omega0) * ir1 * ir1 * ir1;
+  const Real T0 = omk2 * H * H / pg.Gamma;
+  return T0 * std::pow(rho / rho0, pg.Gamma - 1.0);
+}
+inline Real disk_pres(const Sim &s, const Real tf, const Real R, const Real z) {
+  const Real df = disk_den(s.disk, R, z);
+  return std::max(s.disk.pres_min, std::max(0.0, (s.c.gamma - 1.0) * df * s.cv * tf));
+}
+inline Real disk_visc(const Sim::DiskParams &pg, const Real R) { return pg.nu0 * std::pow(R / pg.r0, pg.nu_indx); }
+
+struct DiskState {
+  Real gdens, gtemp, gv[3], ddens, dv[3];
+};
+// disk.hpp:141-247 ComputeDiskProfile.  The pressure gradient is restated literally: the two
+// `(pfm = pgen.pres_min) ? ...` conditions (:186, :203, :220) ASSIGN pres_min to pfm, so both face
+// pressures end up equal to pres_min and pgrad = 0 whenever pres_min != 0 -- the rotation
+// profile the reference starts from is exactly Keplerian in R^2+z^2.
+inline DiskState disk_profile(const Sim &s, int k, int j, int i) {
+  const Sim::DiskParams &pg = s.disk;
+  const Coords coords(s, k, j, i);
+  const Real xv[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
+  const Frame fr = to_cyl_frame(coords, xv);
+  const Real *xcyl = fr.x;
+  DiskState o;
+  o.gdens = disk_den(pg, xcyl[0], xcyl[2]);
+  const Real rt = xcyl[0];
+  o.gtemp = disk_temp(pg, rt, xcyl[2]);
+  const Real fpts[3][2][3] = {{{coords.bnds.x1[0], xv[1], xv[2]}, {coords.bnds.x1[1], xv[1], xv[2]}},
+                              {{xv[0], coords.bnds.x2[0], xv[2]}, {xv[0], coords.bnds.x2[1], xv[2]}},
+                              {{xv[0], xv[1], coords.bnds.x3[0]}, {xv[0], xv[1], coords.bnds.x3[1]}}};
+  Real widths[3];
+  coords.GetCellWidths(widths);
+  Real pgrad[3];
+  for (int d = 0; d < 3; ++d) {
+    Frame xf = to_cyl_frame(coords, fpts[d][0]);
+    const Real tfm = disk_temp(pg, xf.x[0], xf.x[2]);
+    Real pfm = disk_pres(s, tfm, xf.x[0], xf.x[2]);
+    xf = to_cyl_frame(coords, fpts[d][1]);
+    const Real tfp = disk_temp(pg, xf.x[0], xf.x[2]);
+    const Real pfp = (pfm = pg.pres_min) ? pg.pres_min : disk_pres(s, tfp, xf.x[0], xf.x[2]);
+    pfm = (pfp == pg.pres_min) ? pg.pres_min : pfm;
+    pgrad[d] = (pfp - pfm) / widths[d];
+  }
+  const Real eR[3] = {fr.e1[0], fr.e2[0], fr.e3[0]};
+  const Real dpdr = pgrad[0] * eR[0] + pgrad[1] * eR[1] + pgrad[2] * eR[2]; // ArtemisUtils::VDot
+  const Real r = std::sqrt(SQR(xcyl[0]) + SQR(xcyl[2]));
+  const Real omk2 = pg.gm / (r * r * r);
+  const Real vk2 = omk2 * SQR(xcyl[0]);
+  const Real vp = std::sqrt(vk2 + dpdr * xcyl[0] / o.gdens);
+  const Real nu = disk_visc(pg, rt);
+  const Real vr = pg.quiet_start ? 0.0 : -1.5 * nu / xcyl[0];
+  const Real vcyl[3] = {vr, vp - pg.omf * xcyl[0], 0.0};
+  auto vdot = [](const Real a[3], const Real b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  o.gv[0] = vdot(vcyl, fr.e1), o.gv[1] = vdot(vcyl, fr.e2), o.gv[2] = vdot(vcyl, fr.e3);
+  o.ddens = pg.dust_to_gas * o.gdens;
+  const Real vkep[3] = {0.0, std::sqrt(vk2) - pg.omf * xcyl[0], 0.0};
+  o.dv[0] = vdot(vkep, fr.e1), o.dv[1] = vdot(vkep, fr.e2), o.dv[2] = vdot(vkep, fr.e3);
+  return o;
+}
+// disk.hpp:325-354 DiskICImpl
+inline void disk_ic_cell(Sim &s, int k, int j, int i) {
+  const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
+  const DiskState o = disk_profile(s, k, j, i);
+  const size_t c = IDX(s, k, j, i);
+  s.gprim[0 * s.N + c] = o.gdens;
+  for (int q = 0; q < 3; ++q) s.gprim[(ng_ + q) * s.N + c] = o.gv[q];
+  s.gprim[(5 * ng_) * s.N + c] = s.cv * o.gtemp;
+  for (int n = 0; n < nd_; ++n) {
+    s.dprim[n * s.N + c] = o.ddens;
+    for (int q = 0; q < 3; ++q) s.dprim[(nd_ + 3 * n + q) * s.N + c] = o.dv[q];
+  }
+}
+// disk.hpp:597-632 DiskBoundaryIC and :634-825 DiskBoundaryExtrap on the ghost slab of face
+// (d, side), over the entire extent of the other dimensions (parthenon par_for_bndry, upstream).
+void disk_bc(Sim &s, int d, int side, bool extrap) {
+  const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
+  const bool INNER = (side == 0);
+  const int lo[3] = {s.is, s.js, s.ks}, hi[3] = {s.ie, s.je, s.ke};
+  int b0[3] = {0, 0, 0}, b1[3] = {s.ni - 1, s.nj - 1, s.nk - 1};
+  if (INNER) b1[d] = lo[d] - 1;
+  else b0[d] = hi[d] + 1;
+  const bool lnx = (s.c.coords != CO_CART);
+  const Sim::DiskParams &dp = s.disk;
+  auto vdot = [](const Real a[3], const Real b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  for (int k = b0[2]; k <= b1[2]; ++k)
+    for (int j = b0[1]; j <= b1[1]; ++j)
+      for (int i = b0[0]; i <= b1[0]; ++i) {
+        if (!extrap) {
+          disk_ic_cell(s, k, j, i);
+          continue;
+        }
+        int ia[3] = {i, j, k}, ip1[3] = {i, j, k}, im1[3] = {i, j, k}; // (i, j, k) order here
+        ia[d] = INNER ? lo[d] : hi[d];
+        ip1[d] = INNER ? lo[d] + 1 : hi[d];
+        im1[d] = INNER ? lo[d] : hi[d] - 1;
+        const int ix1 = d, ix2 = (d + 1) % 3, ix3 = (d + 2) % 3;
+        const Coords coords(s, k, j, i), ca(s, ia[2], ia[1], ia[0]), cp1(s, ip1[2], ip1[1], ip1[0]),
+            cm1(s, im1[2], im1[1], im1[0]);
+        const Real xv[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
+        const Real xva[3] = {ca.x1v(), ca.x2v(), ca.x3v()};
+        const Real xvp1[3] = {cp1.x1v(), cp1.x2v(), cp1.x3v()};
+        const Real xvm1[3] = {cm1.x1v(), cm1.x2v(), cm1.x3v()};
+        const Frame fr = to_cyl_frame(coords, xv), fa = to_cyl_frame(ca, xva);
+        const Frame fp1 = to_cyl_frame(cp1, xvp1), fm1 = to_cyl_frame(cm1, xvm1);
+        const Real eRa[3] = {fa.e1[0], fa.e2[0], fa.e3[0]};
+        const Real epa[3] = {fa.e1[1], fa.e2[1], fa.e3[1]};
+        const Real eza[3] = {fa.e1[2], fa.e2[2], fa.e3[2]};
+        const Real epp1[3] = {fp1.e1[1], fp1.e2[1], fp1.e3[1]};
+        const Real epm1[3] = {fm1.e1[1], fm1.e2[1], fm1.e3[1]};
+        const Real xma = (lnx) ? std::log(xv[ix1] / xva[ix1]) : xv[ix1] - xva[ix1];
+        const Real dx = (lnx) ? std::log(xvp1[ix1] / xvm1[ix1]) : xvp1[ix1] - xvm1[ix1];
+        const Real xmadx = xma / dx;
+        const size_t c = IDX(s, k, j, i), cA = IDX(s, ia[2], ia[1], ia[0]);
+        const size_t cP = IDX(s, ip1[2], ip1[1], ip1[0]), cM = IDX(s, im1[2], im1[1], im1[0]);
+        const Real *rho = s.gprim.data(), *sie = s.gprim.data() + (5 * ng_) * s.N;
+        Real dgvp = 0.0;
+        if (ng_) {
+          Real dgrho = std::log(rho[cP] / rho[cM]);
+          Real dgsie = std::log(sie[cP] / sie[cM]);
+          const Real grhoexp = std::exp(dgrho * xmadx);
+          const Real gsieexp = std::exp(dgsie * xmadx);
+          const Real rhog = rho[cA] * grhoexp;
+          const Real sieg = sie[cA] * gsieexp;
+          auto vel = [&](int q, size_t cc) { return s.gprim[(ng_ + q) * s.N + cc]; };
+          Real gva[3] = {vel(0, cA), vel(1, cA), vel(2, cA)};
+          Real gvp1[3] = {vel(0, cP), vel(1, cP), vel(2, cP)};
+          Real gvm1[3] = {vel(0, cM), vel(1, cM), vel(2, cM)};
+          const Real gvp = vdot(gva, epa) + dp.omf * fa.x[0];
+          const Real gvR = vdot(gva, eRa);
+          const Real gvz = vdot(gva, eza);
+          const Real gvp1p = vdot(gvp1, epp1) + dp.omf * fp1.x[0];
+          const Real gvm1p = vdot(gvm1, epm1) + dp.omf * fm1.x[0];
+          dgvp = std::log(gvp1p / gvm1p);
+          const Real gvcyl[3] = {gvR, gvp * std::exp(dgvp * xmadx) - dp.omf * fr.x[0], gvz};
+          const Real gvel[3] = {vdot(gvcyl, fr.e1), vdot(gvcyl, fr.e2), vdot(gvcyl, fr.e3)};
+          s.gprim[0 * s.N + c] = rhog;
+          s.gprim[(5 * ng_) * s.N + c] = sieg;
+          s.gprim[(ng_ + ix1) * s.N + c] = gvel[ix1];
+          s.gprim[(ng_ + ix2) * s.N + c] = gvel[ix2];
+          s.gprim[(ng_ + ix3) * s.N + c] = gvel[ix3];
+        }
+        for (int n = 0; n < nd_; ++n) {
+          const Real *dr = s.dprim.data() + n * s.N;
+          Real ddrho = std::log(dr[cP] / dr[cM]);
+          const Real drhoexp = std::exp(ddrho * xmadx);
+          const Real rhod = dr[cA] * drhoexp;
+          auto vel = [&](int q, size_t cc) { return s.dprim[(nd_ + 3 * n + q) * s.N + cc]; };
+          Real dva[3] = {vel(0, cA), vel(1, cA), vel(2, cA)};
+          const Real dvp = vdot(dva, epa) + dp.omf * fa.x[0];
+          const Real dvR = vdot(dva, eRa);
+          const Real dvz = vdot(dva, eza);
+          // the dust azimuthal velocity is scaled with the GAS exponent dgvp (:795-797)
+          const Real dvcyl[3] = {dvR, dvp * std::exp(dgvp * xmadx) - dp.omf * fr.x[0], dvz};
+          const Real dvel[3] = {vdot(dvcyl, fr.e1), vdot(dvcyl, fr.e2), vdot(dvcyl, fr.e3)};
+          s.dprim[n * s.N + c] = rhod;
+          s.dprim[(nd_ + 3 * n + ix1) * s.N + c] = dvel[ix1];
+          s.dprim[(nd_ + 3 * n + ix2) * s.N + c] = dvel[ix2];
+          s.dprim[(nd_ + 3 * n + ix3) * s.N + c] = dvel[ix3];
+        }
+      }
+}
 void apply_bcs(Sim &s) {
   for (int pass = 0; pass < 2; ++pass)
     for (int d = 0; d < 3; ++d) {
@@ -2017,6 +2364,7 @@ void apply_bcs(Sim &s) {
           if ((d == 0 && bc == BC_STRAT_EXTRAP) || (d == 1 && bc == BC_STRAT_INFLOW))
             strat_bc(s, d, side);
           if (bc == BC_CONDUCTIVE) conductive_bc(s, d, side);
+          if (bc == BC_DISK_IC || bc == BC_DISK_EXTRAP) disk_bc(s, d, side, bc == BC_DISK_EXTRAP);
         }
     }
 }
@@ -2476,6 +2824,55 @@ void oracle_pgen_constant(void *h, double g_rho, double g_vx1, double g_vx2, dou
     }
   }
   prim_to_cons(s);
+}
+
+// pgen/disk.hpp:253-323 InitDiskParams + :356-413 ProblemGenerator.  par = {r0, rho0, dslope,
+// h0, polytropic_index, dens_min, pres_min, rexp, rcav, l0, dust_to_gas, temp_soft, tslope,
+// flare, quiet_start, mdot (< 0: not given)}; tslope / flare: exactly one is > -1e300.
+// Gravity (gm), the rotating frame (omf) and the viscosity must have been set before.
+int oracle_pgen_disk(void *h, const double *par) {
+  Sim &s = *static_cast<Sim *>(h);
+  Sim::DiskParams &d = s.disk;
+  d.gm = s.grav.gm;
+  d.r0 = par[0];
+  d.Omega0 = std::sqrt(d.gm / (d.r0 * d.r0 * d.r0));
+  d.rho0 = par[1], d.p = par[2], d.h0 = par[3];
+  d.gamma_gas = s.c.gamma;
+  d.Gamma = par[4];
+  if (!(d.Gamma >= 1)) return 1;
+  d.dens_min = par[5], d.pres_min = par[6], d.rexp = par[7], d.rcav = par[8], d.l0 = par[9];
+  d.dust_to_gas = par[10], d.temp_soft2 = par[11];
+  Real q = par[12], flare = par[13];
+  const Real big = -1e300;
+  if (!(flare > big) && !(q > big)) return 2;
+  if (!(flare > big)) flare = 0.5 * (1.0 + q);
+  else if (!(q > big)) q = 2.0 * flare - 1.;
+  else return 3;
+  d.flare = flare, d.q = q;
+  d.alpha = 0.0, d.nu0 = 0.0, d.nu_indx = 0.0, d.mdot = 0.0;
+  d.quiet_start = (par[14] != 0.0);
+  d.omf = s.rframe.on ? s.rframe.omega : 0.0;
+  if (s.visc.type != 0) {
+    if (s.visc.type == 2) {
+      d.alpha = s.visc.alpha;
+      d.nu0 = d.alpha * d.gamma_gas * SQR(d.h0 * d.r0 * d.Omega0);
+      d.nu_indx = 1.5 + d.q;
+    } else {
+      d.nu0 = s.visc.nu_s;
+      d.nu_indx = s.visc.r_exp;
+    }
+    if (par[15] >= 0.0) {
+      d.mdot = par[15];
+      d.rho0 = d.mdot / (3.0 * M_PI * d.nu0);
+    } else {
+      d.mdot = 3.0 * M_PI * d.nu0 * d.rho0;
+    }
+  }
+  for (int k = 0; k < s.nk; ++k)
+    for (int j = 0; j < s.nj; ++j)
+      for (int i = 0; i < s.ni; ++i) disk_ic_cell(s, k, j, i);
+  prim_to_cons(s);
+  return 0;
 }
 
 // pgen/strat.hpp:55-150: isothermal shearing sheet, v2 = -q Om0 x, T0 = (h Om0)^2, Gaussian

@@ -15,7 +15,7 @@ _LIB = os.path.join(_HERE, "_build", "liboracle.so")
 RS = {"hllc": 0, "hlle": 1, "llf": 2}
 RC = {"pcm": 0, "plm": 1, "ppm": 2}
 BC = {"periodic": 0, "outflow": 1, "reflecting": 2, "reflect": 2, "none": 3,
-      "extrap": 4, "inflow": 5, "conductive": 6}  # 4/5: the strat pgen's user conditions (problem_modifier.hpp:114-128)
+      "extrap": 4, "inflow": 5, "conductive": 6, "ic": 7, "disk_extrap": 8}  # 4/5: the strat pgen's user conditions (problem_modifier.hpp:114-128)
 INTEG = {"rk1": 0, "rk2": 1, "vl2": 2, "rk3": 3}
 GAS, DUST = 0, 1
 
@@ -127,6 +127,8 @@ def lib():
         L.oracle_qflux.argtypes = [vp, i]
         L.oracle_pgen_gaussian_bump.argtypes = [vp, C.POINTER(d)] + [d] * 11
         L.oracle_pgen_conduction.argtypes = [vp] + [d] * 6
+        L.oracle_pgen_disk.argtypes = [vp, C.POINTER(d)]
+        L.oracle_pgen_disk.restype = i
         _lib = L
     return _lib
 
@@ -325,6 +327,24 @@ class Oracle:
 
     def pgen_conduction(self, gas_rho=1.0, gas_v=(0.0, 0.0, 0.0), gas_temp=1.0, flux=0.0, post_init=True):
         self.L.oracle_pgen_conduction(self.h, gas_rho, *gas_v, gas_temp, flux)
+        if post_init:
+            self.post_init()
+
+    def pgen_disk(self, r0=1.0, rho0=1.0, dslope=-2.25, h0=0.05, polytropic_index=None, dens_min=1.0e-5,
+                  pres_min=1.0e-8, rexp=0.0, rcav=0.0, l0=0.0, dust_to_gas=0.01, temp_soft=0.0,
+                  tslope=None, flare=None, quiet_start=False, mdot=None, post_init=True):
+        """<problem> block of inputs/disk/*.in (pgen/disk.hpp:253-323); set gravity, the rotating
+        frame and the viscosity first.  BC names: "ic" and "disk_extrap" (the deck's `extrap`)."""
+        none = -1.7976931348623157e308  # -Big<Real>()
+        par = (C.c_double * 16)(r0, rho0, dslope, h0,
+                                self.cfg.gamma if polytropic_index is None else polytropic_index,
+                                dens_min, pres_min, rexp, rcav, l0, dust_to_gas, temp_soft,
+                                none if tslope is None else tslope, none if flare is None else flare,
+                                1.0 if quiet_start else 0.0, -1.0 if mdot is None else mdot)
+        rc = self.L.oracle_pgen_disk(self.h, par)
+        if rc:
+            raise ValueError({1: "problem/gamma needs to be >= 1", 2: "Set flare or tslope in <problem>",
+                              3: "Set either flare or tslope in <problem> not both!"}[rc])
         if post_init:
             self.post_init()
 
