@@ -28,7 +28,7 @@ def coord_select(sys, ndim):
 HLLC, HLLE, LLF = 0, 1, 2
 PCM, PLM, PPM = 0, 1, 2
 GAS, DUST = 0, 1
-BC_PERIODIC, BC_OUTFLOW, BC_REFLECT, BC_NONE, BC_STRAT_EXTRAP, BC_STRAT_INFLOW, BC_CONDUCTIVE = range(7)
+BC_PERIODIC, BC_OUTFLOW, BC_REFLECT, BC_NONE, BC_STRAT_EXTRAP, BC_STRAT_INFLOW, BC_CONDUCTIVE, BC_IC, BC_DISK_EXTRAP = range(9)
 GRAVITY_UNIFORM, GRAVITY_POINT = 1, 2
 DRAG_SIMPLE_DUST, DRAG_SELF = 1, 2
 DRAG_CONSTANT, DRAG_STOKES = 0, 1
@@ -38,7 +38,7 @@ RSOLVER = {"hllc": HLLC, "hlle": HLLE, "llf": LLF}
 RECON = {"pcm": PCM, "plm": PLM, "ppm": PPM}
 BCS = {"periodic": BC_PERIODIC, "outflow": BC_OUTFLOW, "reflecting": BC_REFLECT,
        "reflect": BC_REFLECT, "none": BC_NONE, "extrap": BC_STRAT_EXTRAP,
-       "inflow": BC_STRAT_INFLOW, "conductive": BC_CONDUCTIVE}
+       "inflow": BC_STRAT_INFLOW, "conductive": BC_CONDUCTIVE, "ic": BC_IC, "disk_extrap": BC_DISK_EXTRAP}
 
 PP = C.c_void_p  # device pointer tables are opaque to the host
 
@@ -76,7 +76,8 @@ class StageArgs(C.Structure):
 class BcParams(C.Structure):
     _fields_ = [("qshear", C.c_double), ("omega", C.c_double), ("cond_temp", C.c_double),
                 ("cond_flux", C.c_double), ("cond_g", C.c_double * 3), ("cond_coeff", C.c_double),
-                ("cond_cv", C.c_double), ("cond_type", C.c_int)]
+                ("cond_cv", C.c_double), ("cond_type", C.c_int), ("ic_gas", C.c_void_p),
+                ("ic_dust", C.c_void_p), ("disk_omf", C.c_double)]
 
 
 class Gravity(C.Structure):
@@ -101,7 +102,7 @@ class DiffCoeff(C.Structure):
     _fields_ = [("type", C.c_int), ("avg", C.c_int), ("coeff", C.c_double), ("eta", C.c_double),
                 ("r_exp", C.c_double), ("r0", C.c_double), ("omega0", C.c_double),
                 ("temp_exp", C.c_double), ("rho_exp", C.c_double), ("rho_ref", C.c_double),
-                ("T_ref", C.c_double)]
+                ("T_ref", C.c_double), ("radial", C.c_void_p)]
 
 
 class Diffusion(C.Structure):
@@ -160,6 +161,7 @@ def load():
         "artemis_hip_thermal_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
         "artemis_hip_diffusion_update": (i, [PPk, C.POINTER(Diffusion), d, vp]),
         "artemis_hip_diffusion_dt": (i, [PPk, C.POINTER(Diffusion), d, vp, vp]),
+        "artemis_hip_diffusion_radial_fill": (i, [PPk, vp, vp, C.POINTER(DiffCoeff), i, vp]),
         "artemis_hip_wait_counter": (i, [vp, C.c_uint, vp, vp]),
         "artemis_hip_advance_dt": (i, [vp, d, i, C.POINTER(d), vp]),
         "artemis_hip_metric_count": (C.c_long, [PPk]),
@@ -210,7 +212,7 @@ EXPORTS_HIP = [
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_rotating_frame_force",
     "artemis_hip_drag_source", "artemis_hip_stage_general", "artemis_hip_zero_diffusion_flux",
     "artemis_hip_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
-    "artemis_hip_diffusion_dt", "artemis_hip_halo_count", "artemis_hip_halo_count_ext",
+    "artemis_hip_diffusion_dt", "artemis_hip_diffusion_radial_fill", "artemis_hip_halo_count", "artemis_hip_halo_count_ext",
     "artemis_hip_halo_pack_ext", "artemis_hip_halo_unpack_ext",
     "artemis_hip_halo_pack", "artemis_hip_halo_unpack", "artemis_hip_last_error",
     "artemis_hip_device_count", "artemis_hip_version",

@@ -11,6 +11,7 @@
 #include "../../include/artemis_hip.h"
 #include "../../include/artemis_rt.h"
 #include "kernels.hpp"
+#include "geometry_core.hpp"
 
 namespace {
 thread_local std::string g_err;
@@ -205,9 +206,17 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
   if (int rc = validate(p)) return rc;
   if (!bc) return fail(ARTEMIS_HIP_EINVAL, "null bc array");
   for (int i = 0; i < 6 * p->nblocks; ++i) {
-    if (bc[i] < ARTEMIS_BC_PERIODIC || bc[i] > ARTEMIS_BC_CONDUCTIVE)
+    if (bc[i] < ARTEMIS_BC_PERIODIC || bc[i] > ARTEMIS_BC_DISK_EXTRAP)
       return fail(ARTEMIS_HIP_EINVAL, "unknown boundary flag %d", bc[i]);
     const int d = (i % 6) / 2;
+    if (bc[i] == ARTEMIS_BC_IC || bc[i] == ARTEMIS_BC_DISK_EXTRAP) {
+      if (!params) return fail(ARTEMIS_HIP_EINVAL, "disk conditions need artemis_bc_params_t");
+      if (bc[i] == ARTEMIS_BC_IC && ((p->gas.nspecies && !params->ic_gas) || (p->dust.nspecies && !params->ic_dust)))
+        return fail(ARTEMIS_HIP_EINVAL, "ic condition: ic_gas / ic_dust tables are required");
+      const int nxd[3] = {p->nx1, p->nx2, p->nx3};
+      if (bc[i] == ARTEMIS_BC_DISK_EXTRAP && nxd[d] < 2)
+        return fail(ARTEMIS_HIP_EINVAL, "disk extrap condition needs two active zones along the face normal");
+    }
     if (bc[i] == ARTEMIS_BC_CONDUCTIVE) {
       if ((p->coords == ARTEMIS_CYLINDRICAL || p->coords == ARTEMIS_AXISYMMETRIC) && !p->metric)
         return fail(ARTEMIS_HIP_EINVAL, // Coords::Distance needs cos/sin of the azimuth
@@ -245,9 +254,8 @@ int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_
   if (g->type != ARTEMIS_GRAVITY_UNIFORM && g->type != ARTEMIS_GRAVITY_POINT)
     return fail(ARTEMIS_HIP_EUNSUPPORTED, "gravity type %d (binary / nbody) is not built", g->type);
   if (g->type == ARTEMIS_GRAVITY_POINT) {
-    if (p->coords == ARTEMIS_CYLINDRICAL || p->coords == ARTEMIS_SPHERICAL3D)
-      return fail(ARTEMIS_HIP_EUNSUPPORTED,
-                  "point-mass gravity in cylindrical / spherical3D coordinates is not built");
+    if (p->coords == ARTEMIS_CYLINDRICAL && !p->metric) // ConvertToCartWithVec: cos / sin of x2v
+      return fail(ARTEMIS_HIP_EINVAL, "point-mass gravity on cylindrical blocks needs the metric tables");
     const bool axi = p->coords == ARTEMIS_AXISYMMETRIC || p->coords == ARTEMIS_SPHERICAL1D ||
                      p->coords == ARTEMIS_SPHERICAL2D;
     if (axi && !(g->pos[0] == 0.0 && g->pos[1] == 0.0 && g->pos[2] == 0.0)) // gravity.cpp:66-70
@@ -269,7 +277,13 @@ int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, doub
     if (qshear != 0.0) // rotating_frame.cpp:34-38
       return fail(ARTEMIS_HIP_EINVAL,
                   "rotating_frame/qshear must be zero for non-Cartesian coordinate systems!");
-    return fail(ARTEMIS_HIP_EUNSUPPORTED, "rotating frame in curvilinear coordinates is not built");
+    // RotatingFrameImpl reads the mass fluxes CalculateFluxes left in flux[d] (rotating_frame_impl.hpp:107-111)
+    const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
+    for (int d = 0; d < ndim; ++d)
+      if ((p->gas.nspecies && !p->gas.flux[d]) || (p->dust.nspecies && !p->dust.flux[d]))
+        return fail(ARTEMIS_HIP_EINVAL, "rotating frame (curvilinear): flux tables are required");
+    artemis::launch_rotating_frame(artemis::make_pack_view(*p), omega, dt, S(stream));
+    return after_launch("RotatingFrameForce");
   }
   artemis::launch_shearing_box(artemis::make_pack_view(*p), omega, qshear, dt, S(stream));
   return after_launch("RotatingFrameForce");
@@ -430,13 +444,47 @@ static int validate_diffusion(const artemis_pack_t *p, const artemis_diffusion_t
                 : (c->type != ARTEMIS_CONDUCTIVITY_PLAW && c->type != ARTEMIS_THERMALDIFF_PLAW))
       return fail(ARTEMIS_HIP_EINVAL, is_visc ? "Invalid viscosity type" : "Invalid conductivity type");
     if (c->avg != 0 && c->avg != 1) return fail(ARTEMIS_HIP_EINVAL, "averaging is not supported");
-    if (c->type == ARTEMIS_VISCOSITY_ALPHA || c->r_exp != 0.0 || c->temp_exp != 0.0 || c->rho_exp != 0.0)
+    if (c->temp_exp != 0.0 || c->rho_exp != 0.0)
       return fail(ARTEMIS_HIP_EUNSUPPORTED,
-                  "diffusion: power-law / alpha coefficients need std::pow per cell and are not built");
+                  "diffusion: temperature / density power laws need std::pow of the state per cell and are not built");
+    if (is_visc && (c->type == ARTEMIS_VISCOSITY_ALPHA || c->r_exp != 0.0) && !c->radial)
+      return fail(ARTEMIS_HIP_EINVAL,
+                  "viscosity: alpha / radial power law need the radial table (artemis_hip_diffusion_radial_fill)");
+    if (c->type == ARTEMIS_VISCOSITY_ALPHA && !(c->omega0 > 0.0 && c->r0 > 0.0))
+      return fail(ARTEMIS_HIP_EINVAL, "alpha viscosity: r0 and omega0 = sqrt(gm / r0^3) must be positive");
   }
   if (need_flux)
     for (int dd = 0; dd < ((p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1)); ++dd)
       if (!p->gas.diff_flux[dd]) return fail(ARTEMIS_HIP_EINVAL, "diffusion: gas.diff_flux tables are required");
+  return 0;
+}
+int artemis_hip_diffusion_radial_fill(const artemis_pack_t *p, const double *geom_host,
+                                      const double *metric_host, const artemis_diffcoeff_t *c,
+                                      int block, double *out_host) {
+  if (!p || !geom_host || !c || !out_host) return fail(ARTEMIS_HIP_EINVAL, "null argument");
+  if (block < 0 || block >= p->nblocks) return fail(ARTEMIS_HIP_EINVAL, "bad block index %d", block);
+  if (c->type != ARTEMIS_VISCOSITY_PLAW && c->type != ARTEMIS_VISCOSITY_ALPHA)
+    return fail(ARTEMIS_HIP_EINVAL, "radial table: viscosity laws only");
+  if (artemis_hip_metric_count(p) > 0 && !metric_host &&
+      (p->coords == ARTEMIS_SPHERICAL2D || p->coords == ARTEMIS_SPHERICAL3D))
+    return fail(ARTEMIS_HIP_EINVAL, "radial table: spherical 2-D/3-D blocks need the host metric table");
+  const artemis::PackView P = artemis::make_pack_view(*p);
+  const double *m = metric_host ? metric_host + block * artemis::metric_block_stride(P.nj, P.nk) : nullptr;
+  for (int k = 0; k < P.nk; ++k)
+    for (int j = 0; j < P.nj; ++j)
+      for (int i = 0; i < P.ni; ++i) {
+        const artemis::DCoords co = artemis::coords_of(p->coords, geom_host + 6 * block, m, P.nj, P.nk, k, j, i);
+        double xv[3];
+        co.centre(xv);
+        double v;
+        if (c->type == ARTEMIS_VISCOSITY_PLAW) {
+          const artemis::Frame fr = artemis::cyl_frame(co.sys, xv, co.cv, co.sv);
+          v = std::pow(fr.x[0] / c->r0, c->r_exp);
+        } else {
+          v = c->omega0 * std::pow(artemis::sph_radius(co.sys, xv) / c->r0, -1.5);
+        }
+        out_host[(static_cast<long>(k) * P.nj + j) * P.ni + i] = v;
+      }
   return 0;
 }
 int artemis_hip_zero_diffusion_flux(const artemis_pack_t *p, void *stream) {
@@ -488,13 +536,12 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
     const artemis_gravity_t *g = a->gravity;
     if (g->type != ARTEMIS_GRAVITY_UNIFORM && g->type != ARTEMIS_GRAVITY_POINT)
       return fail(ARTEMIS_HIP_EUNSUPPORTED, "gravity type %d (binary / nbody) is not built", g->type);
-    if (g->type == ARTEMIS_GRAVITY_POINT &&
-        (p->coords == ARTEMIS_CYLINDRICAL || p->coords == ARTEMIS_SPHERICAL3D))
-      return fail(ARTEMIS_HIP_EUNSUPPORTED,
-                  "point-mass gravity in cylindrical / spherical3D coordinates is not built");
+    if (g->type == ARTEMIS_GRAVITY_POINT && p->coords == ARTEMIS_CYLINDRICAL && !p->metric)
+      return fail(ARTEMIS_HIP_EINVAL, "point-mass gravity on cylindrical blocks needs the metric tables");
   }
   if (a->rf_omega != 0.0 && p->coords != ARTEMIS_CARTESIAN)
-    return fail(ARTEMIS_HIP_EUNSUPPORTED, "rotating frame in curvilinear coordinates is not built");
+    return fail(ARTEMIS_HIP_EUNSUPPORTED,
+                "general stage: the curvilinear rotating frame reads stored mass fluxes; use the per-task kernels");
   if (a->drag) {
     if (a->drag->type == ARTEMIS_DRAG_SIMPLE_DUST && (p->gas.nspecies < 1 || p->dust.nspecies < 1))
       return fail(ARTEMIS_HIP_EINVAL, "drag type simple_dust requires do_gas = do_dust = true");

@@ -151,6 +151,28 @@ struct DCoords {
   GDEV double dh3dx2() const { // spherical.hpp:143-146
     return sph23() ? (sf[1] - sf[0]) / fabs(cf[0] - cf[1]) : 0.0;
   }
+  // frames of the cell centre with the tabulated trigonometry
+  GDEV void centre(double xv[3]) const { xv[0] = x1v(), xv[1] = x2v(), xv[2] = x3v(); }
+  // RFWeights (cylindrical.hpp:82-87, axisymmetric.hpp:73-78, spherical.hpp:148-169 / :349-370 /
+  // :515-526; zero for Cartesian): +-(<R^2>_face - <R^2>)
+  GDEV void rf_weights(double bx1[2], double bx2[2], double bx3[2]) const {
+    bx1[0] = bx1[1] = bx2[0] = bx2[1] = bx3[0] = bx3[1] = 0.0;
+    if (sys == ARTEMIS_CYLINDRICAL || sys == ARTEMIS_AXISYMMETRIC) {
+      const double ans = 0.5 * (x1[0] + x1[1]) * (x1[1] - x1[0]);
+      bx1[0] = bx1[1] = ans;
+    } else if (sph23()) {
+      const double rv = x1v();
+      const double stv = sv;
+      const double rf = rcen();
+      const double r2cyl = (rv * stv) * (rv * stv);
+      bx1[0] = r2cyl - (x1[0] * stv) * (x1[0] * stv), bx1[1] = (x1[1] * stv) * (x1[1] * stv) - r2cyl;
+      bx2[0] = r2cyl - (rf * sf[0]) * (rf * sf[0]), bx2[1] = (rf * sf[1]) * (rf * sf[1]) - r2cyl;
+    } else if (sys == ARTEMIS_SPHERICAL1D) {
+      const double rv = x1v();
+      const double r2cyl = rv * rv;
+      bx1[0] = r2cyl - x1[0] * x1[0], bx1[1] = x1[1] * x1[1] - r2cyl;
+    }
+  }
   // ConvertCoordsToCart of this cell's centre (geometry.hpp:248, cylindrical.hpp:88-92,
   // spherical.hpp:166-173 / :355-362 / :528-534, axisymmetric.hpp:77-82); trigonometry from the tables
   GDEV void centre_to_cart(double xc[3]) const {
@@ -188,6 +210,74 @@ struct DCoords {
     }
   }
 };
+
+// ConvertToCylWithVec / ConvertToCartWithVec (geometry.hpp:438-482): the converted point x and the
+// rows e1, e2, e3 = components of the problem's unit vectors in the target basis.  (ct, st) =
+// cos / sin of xi[1] for the spherical systems, (cp, sp) = cos / sin of the azimuth (xi[1]
+// cylindrical, xi[2] spherical3D / axisymmetric): the caller supplies them -- host libm values in
+// problem generators, the tabulated values of a cell centre on the device.
+struct Frame {
+  double x[3], e1[3], e2[3], e3[3];
+};
+GDEV void set3(double a[3], double x, double y, double z) { a[0] = x, a[1] = y, a[2] = z; }
+GDEV Frame cyl_frame(int sys, const double xi[3], double ct, double st) {
+  Frame f;
+  switch (sys) {
+  case ARTEMIS_CARTESIAN: { // geometry.hpp:286-301; atan2 is not evaluated (no caller reads x[1])
+    const double R = sqrt(xi[0] * xi[0] + xi[1] * xi[1]);
+    const double cp = xi[0] / (R + 1e-99);
+    const double sp = xi[1] / (R + 1e-99);
+    set3(f.x, R, 0.0, xi[2]);
+    set3(f.e1, cp, -sp, 0.0), set3(f.e2, sp, cp, 0.0), set3(f.e3, 0.0, 0.0, 1.0);
+  } break;
+  case ARTEMIS_CYLINDRICAL: // cylindrical.hpp:128-136
+    set3(f.x, xi[0], xi[1], xi[2]);
+    set3(f.e1, 1.0, 0.0, 0.0), set3(f.e2, 0.0, 1.0, 0.0), set3(f.e3, 0.0, 0.0, 1.0);
+    break;
+  case ARTEMIS_SPHERICAL3D: // spherical.hpp:202-220, :403-421
+  case ARTEMIS_SPHERICAL2D:
+    set3(f.x, xi[0] * st, (sys == ARTEMIS_SPHERICAL3D) ? xi[2] : 0.0, xi[0] * ct);
+    set3(f.e1, st, 0.0, ct), set3(f.e2, ct, 0.0, -st), set3(f.e3, 0.0, 1.0, 0.0);
+    break;
+  case ARTEMIS_SPHERICAL1D: // :559-577: ct = 0, st = 1
+    set3(f.x, xi[0] * 1.0, 0.0, xi[0] * 0.0);
+    set3(f.e1, 1.0, 0.0, 0.0), set3(f.e2, 0.0, 0.0, -1.0), set3(f.e3, 0.0, 1.0, 0.0);
+    break;
+  default: // axisymmetric.hpp:135-145
+    set3(f.x, xi[0], xi[2], xi[1]);
+    set3(f.e1, 1.0, 0.0, 0.0), set3(f.e2, 0.0, 0.0, 1.0), set3(f.e3, 0.0, 1.0, 0.0);
+  }
+  return f;
+}
+GDEV Frame cart_frame(int sys, const double xi[3], double ct, double st, double cp, double sp) {
+  Frame f;
+  switch (sys) {
+  case ARTEMIS_CYLINDRICAL: // cylindrical.hpp:96-107
+    set3(f.x, xi[0] * cp, xi[0] * sp, xi[2]);
+    set3(f.e1, cp, sp, 0.0), set3(f.e2, -sp, cp, 0.0), set3(f.e3, 0.0, 0.0, 1.0);
+    break;
+  case ARTEMIS_SPHERICAL3D: // spherical.hpp:172-189
+    set3(f.x, xi[0] * st * cp, xi[0] * st * sp, xi[0] * ct);
+    set3(f.e1, st * cp, st * sp, ct), set3(f.e2, ct * cp, ct * sp, -st), set3(f.e3, -sp, cp, 0.0);
+    break;
+  default: // Cartesian (the other systems do not come through here)
+    set3(f.x, xi[0], xi[1], xi[2]);
+    set3(f.e1, 1.0, 0.0, 0.0), set3(f.e2, 0.0, 1.0, 0.0), set3(f.e3, 0.0, 0.0, 1.0);
+  }
+  return f;
+}
+// ConvertToSph(xi)[0] (geometry.hpp:262-264, cylindrical.hpp:111-112, axisymmetric.hpp:116-117)
+GDEV double sph_radius(int sys, const double xi[3]) {
+  switch (sys) {
+  case ARTEMIS_CARTESIAN: {
+    const double R = sqrt(xi[0] * xi[0] + xi[1] * xi[1]);
+    return sqrt(R * R + xi[2] * xi[2]);
+  }
+  case ARTEMIS_CYLINDRICAL: return sqrt(xi[0] * xi[0] + xi[2] * xi[2]);
+  case ARTEMIS_AXISYMMETRIC: return sqrt(xi[0] * xi[0] + xi[1] * xi[1]);
+  default: return xi[0];
+  }
+}
 
 // Cell (k,j,i) of a block with edge table g6 = {x1f0, dx1, x2f0, dx2, x3f0, dx3}; `m` = the
 // block's metric rows (stride nj+1) or null when the system needs none.

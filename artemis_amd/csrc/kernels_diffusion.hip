@@ -68,10 +68,17 @@ struct Geo {
   }
 };
 
-// DiffusionCoeff<DIFF>::Get with zero exponents: std::pow(x, 0.0) == 1.0 for every x
-ADEV double coeff_of(const artemis_diffcoeff_t &dp, double cv, double dens) {
+// DiffusionCoeff<DIFF>::Get of cell c of block b.  State power laws have zero exponents
+// (std::pow(x, 0.0) == 1.0 for every x); the radial factors come from the host-filled table.
+ADEV double coeff_of(const artemis_diffcoeff_t &dp, double cv, double gm1, double dens, double sie, int b,
+                     long c) {
   switch (dp.type) {
-  case ARTEMIS_VISCOSITY_PLAW: return dp.coeff * dens * 1.0;       // diffusion_coeff.hpp:222-224
+  case ARTEMIS_VISCOSITY_PLAW: // diffusion_coeff.hpp:222-224
+    return dp.coeff * dens * (dp.radial ? dp.radial[b][c] : 1.0);
+  case ARTEMIS_VISCOSITY_ALPHA: { // :262-268: alpha B / Omega_K, B = gamma gm1 rho sie (IdealGas)
+    const double blk = (gm1 + 1.0) * gm1 * dens * sie;
+    return dp.coeff * blk / dp.radial[b][c];
+  }
   case ARTEMIS_CONDUCTIVITY_PLAW: return dp.coeff * 1.0 * 1.0;     // :312-316
   default: return dp.coeff * 1.0 * 1.0 * dens * cv;                // thermaldiff_plaw :353-359
   }
@@ -193,8 +200,9 @@ __global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, 
       const double dv3 = v[2] - sv(2, k - 1, j, i);
       flx[2] = 2 * dv3 / dx3 + 0.5 * (src_of(k, j, i) + src_of(k - 1, j, i));
     }
-    const double *rho = f.prim[b * nv + n];
-    const double mu = coeff_of(dp, D.cv, rho[c]), mu_m = coeff_of(dp, D.cv, rho[cm]);
+    const double *rho = f.prim[b * nv + n], *se = f.prim[b * nv + 5 * ns + n];
+    const double mu = coeff_of(dp, D.cv, P.gm1, rho[c], se[c], b, c);
+    const double mu_m = coeff_of(dp, D.cv, P.gm1, rho[cm], se[cm], b, cm);
     const double mus = face_average(dp.avg, mu, mu_m);
     const double divu = velocity_divergence<CURV>(P, f.prim, b, n, k, j, i);
     const double divu_m = velocity_divergence<CURV>(P, f.prim, b, n, k - dk, j - dj, i - di);
@@ -226,7 +234,8 @@ __global__ __launch_bounds__(TX *TY) void thermal_flux_kernel(const PackView P, 
     const double *rho = f.prim[b * nv + n], *se = f.prim[b * nv + 5 * ns + n];
     const double T = amax(0.0, se[c] / D.cv);   // IdealGas TemperatureFromDensityInternalEnergy
     const double Tm = amax(0.0, se[cm] / D.cv);
-    const double kcond = face_average(dp.avg, coeff_of(dp, D.cv, rho[c]), coeff_of(dp, D.cv, rho[cm]));
+    const double kcond = face_average(dp.avg, coeff_of(dp, D.cv, P.gm1, rho[c], se[c], b, c),
+                                      coeff_of(dp, D.cv, P.gm1, rho[cm], se[cm], b, cm));
     f.dflux[DIR - 1][b * nq + 3 * ns + n][c] += kcond * (T - Tm) / dx;
   }
 }
@@ -325,9 +334,9 @@ __global__ __launch_bounds__(TX *TY) void diffusion_dt_kernel(const PackView P, 
     const int ns = P.gas.ns, nv = 6 * ns;
     for (int n = 0; n < ns; ++n) {
       const double dens = P.gas.prim[b * nv + n][c];
-      double mu = coeff_of(dp, cv, dens);
+      double mu = coeff_of(dp, cv, P.gm1, dens, P.gas.prim[b * nv + 5 * ns + n][c], b, c);
       if (dp.type == ARTEMIS_CONDUCTIVITY_PLAW) mu /= (dens * cv);
-      else if (dp.type == ARTEMIS_VISCOSITY_PLAW) mu *= (1.0 + (dp.eta > 1.0) * (dp.eta - 1.0)) / dens;
+      else if (dp.type == ARTEMIS_VISCOSITY_PLAW || dp.type == ARTEMIS_VISCOSITY_ALPHA) mu *= (1.0 + (dp.eta > 1.0) * (dp.eta - 1.0)) / dens;
       ldt = amin(ldt, sqr(min_dx) / (mu + 1e-99));
     }
   }

@@ -129,6 +129,44 @@ __global__ __launch_bounds__(TX *TY) void shearing_box_kernel(const PackView P, 
   }
 }
 
+// RotatingFrame::RotatingFrameImpl<GEOM> (rotating_frame_impl.hpp:95-199), every non-Cartesian
+// system: the angular-momentum-conserving form built from the stage's MASS fluxes with the
+// RFWeights of the cell, plus the centrifugal work on the gas energy.
+__global__ __launch_bounds__(TX *TY) void rotating_frame_kernel(const PackView P, double om0, double dt) {
+  INTERIOR_CELL
+  const int multi_d = (P.ndim >= 2), three_d = (P.ndim == 3);
+  const double omdt = om0 * dt;
+  const double om2dt = omdt * om0;
+  const DCoords co = make_coords(P, b, k, j, i);
+  double xv[3];
+  co.centre(xv);
+  const Frame fr = cyl_frame(co.sys, xv, co.cv, co.sv);
+  double bx1[2], bx2[2], bx3[2];
+  co.rf_weights(bx1, bx2, bx3);
+  const double ax1[2] = {co.area1(0), co.area1(1)};
+  const double ax2[2] = {multi_d ? co.area2(0) : 0.0, multi_d ? co.area2(1) : 0.0};
+  const double ax3[2] = {three_d ? co.area3(0) : 0.0, three_d ? co.area3(1) : 0.0};
+  const double vol = co.volume();
+  const long c2 = c + multi_d * P.sj, c3 = c + three_d * P.sk;
+  const int d2 = multi_d ? 1 : 0, d3 = three_d ? 2 : 0; // inactive directions have no flux table
+  auto body = [&](const FluidView &f, int nv, int n, bool gas) {
+    const double *f1 = f.flux[0][b * nv + n], *f2 = f.flux[d2][b * nv + n], *f3 = f.flux[d3][b * nv + n];
+    const double divf = (f1[c] * ax1[0] * bx1[0] + f1[c + 1] * ax1[1] * bx1[1]) +
+                        multi_d * (f2[c] * ax2[0] * bx2[0] + f2[c2] * ax2[1] * bx2[1]) +
+                        three_d * (f3[c] * ax3[0] * bx3[0] + f3[c3] * ax3[1] * bx3[1]);
+    f.cons0[b * nv + f.ns + 3 * n + 0][c] -= omdt * (divf / vol) * fr.e1[1];
+    f.cons0[b * nv + f.ns + 3 * n + 1][c] -= omdt * (divf / vol) * fr.e2[1];
+    f.cons0[b * nv + f.ns + 3 * n + 2][c] -= omdt * (divf / vol) * fr.e3[1];
+    if (!gas) return;
+    const double fx[3] = {0.5 * (f1[c] + f1[c + 1]), multi_d * 0.5 * (f2[c] + f2[c2]),
+                          three_d * 0.5 * (f3[c] + f3[c3])};
+    f.cons0[b * nv + 4 * f.ns + n][c] +=
+        om2dt * fr.x[0] * (fx[0] * fr.e1[0] + fx[1] * fr.e2[0] + fx[2] * fr.e3[0]);
+  };
+  for (int n = 0; n < P.gas.ns; ++n) body(P.gas, 6 * P.gas.ns, n, true);
+  for (int n = 0; n < P.dust.ns; ++n) body(P.dust, 4 * P.dust.ns, n, false);
+}
+
 // ---------------------------------------------------------------------------------------
 // Drag::DragSource (drag.cpp:89-175) with damp_to_visc = false.
 __device__ __forceinline__ void damping_ramps(const artemis_damping_t &p, const artemis_drag_t &D,
@@ -319,6 +357,9 @@ void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, doub
 }
 void launch_shearing_box(const PackView &P, double omega, double qshear, double dt, hipStream_t s) {
   hipLaunchKernelGGL(shearing_box_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, omega, qshear, dt);
+}
+void launch_rotating_frame(const PackView &P, double omega, double dt, hipStream_t s) {
+  hipLaunchKernelGGL(rotating_frame_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, omega, dt);
 }
 void launch_drag_source(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
                         hipStream_t s) {

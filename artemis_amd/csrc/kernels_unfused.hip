@@ -585,6 +585,107 @@ __global__ __launch_bounds__(256) void conductive_bc_kernel(const CondBcArgs a, 
   }
 }
 
+// The `disk` problem's user conditions.  `ic` (disk.hpp:597-632): ghost zones keep the initial
+// condition -- the reference re-evaluates the disk profile (std::pow / std::exp of the zone's
+// position) on every call; the profile does not depend on time, so the adapter hands over the
+// initial primitives once (ic_gas / ic_dust, laid out like prim) and the kernel copies the ghost
+// zones from there: the same numbers bit for bit.  Gas species 0 and every dust species, like
+// DiskICImpl (:325-354).
+// `extrap` (disk.hpp:634-825): power-law extrapolation in ln(x) (x for Cartesian) of density,
+// sie and the inertial azimuthal velocity along the fill direction, from the first two active
+// zones; R and z velocities copied.  This one evaluates log / exp of the STATE on the device:
+// agreement with a host libm is to rounding (a few ulp), not bitwise.
+struct DiskBcArgs {
+  int d, side, ng, st, en, extrap;
+  double omf;
+  double *const *ic_gas, *const *ic_dust;
+};
+__global__ __launch_bounds__(256) void disk_bc_kernel(const DiskBcArgs a, const FillTabs t, const PackView P) {
+  const int ni = P.ni, nj = P.nj, nk = P.nk;
+  int ext[3] = {ni, nj, nk};
+  ext[a.d] = a.ng;
+  const long ncell = static_cast<long>(ext[0]) * ext[1] * ext[2];
+  const long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (tid >= ncell) return;
+  int idx[3];
+  idx[0] = tid % ext[0];
+  idx[1] = (tid / ext[0]) % ext[1];
+  idx[2] = tid / (static_cast<long>(ext[0]) * ext[1]);
+  idx[a.d] = (a.side == 0) ? a.st - 1 - idx[a.d] : a.en + 1 + idx[a.d];
+  const long c = (static_cast<long>(idx[2]) * nj + idx[1]) * ni + idx[0];
+  const int nsg = t.nsg, nsd = t.nsd;
+  if (!a.extrap) {
+    if (nsg) {
+      const int vars[5] = {0, nsg + 0, nsg + 1, nsg + 2, 5 * nsg};
+      for (int q = 0; q < 5; ++q) t.gas[t.b * 6 * nsg + vars[q]][c] = a.ic_gas[t.b * 6 * nsg + vars[q]][c];
+    }
+    for (int v = 0; v < 4 * nsd; ++v) t.dust[t.b * 4 * nsd + v][c] = a.ic_dust[t.b * 4 * nsd + v][c];
+    return;
+  }
+  const bool INNER = (a.side == 0);
+  int ia[3] = {idx[0], idx[1], idx[2]}, ip1[3] = {idx[0], idx[1], idx[2]}, im1[3] = {idx[0], idx[1], idx[2]};
+  ia[a.d] = INNER ? a.st : a.en;
+  ip1[a.d] = INNER ? a.st + 1 : a.en;
+  im1[a.d] = INNER ? a.st : a.en - 1;
+  const int ix1 = a.d, ix2 = (a.d + 1) % 3, ix3 = (a.d + 2) % 3;
+  auto cell = [&](const int q[3]) { return (static_cast<long>(q[2]) * nj + q[1]) * ni + q[0]; };
+  const long cA = cell(ia), cP = cell(ip1), cM = cell(im1);
+  const DCoords co = make_coords(P, t.b, idx[2], idx[1], idx[0]), ca = make_coords(P, t.b, ia[2], ia[1], ia[0]);
+  const DCoords cp1 = make_coords(P, t.b, ip1[2], ip1[1], ip1[0]), cm1 = make_coords(P, t.b, im1[2], im1[1], im1[0]);
+  double xv[3], xva[3], xvp1[3], xvm1[3];
+  co.centre(xv), ca.centre(xva), cp1.centre(xvp1), cm1.centre(xvm1);
+  const Frame fr = cyl_frame(co.sys, xv, co.cv, co.sv), fa = cyl_frame(ca.sys, xva, ca.cv, ca.sv);
+  const Frame fp1 = cyl_frame(cp1.sys, xvp1, cp1.cv, cp1.sv), fm1 = cyl_frame(cm1.sys, xvm1, cm1.cv, cm1.sv);
+  const double eRa[3] = {fa.e1[0], fa.e2[0], fa.e3[0]};
+  const double epa[3] = {fa.e1[1], fa.e2[1], fa.e3[1]};
+  const double eza[3] = {fa.e1[2], fa.e2[2], fa.e3[2]};
+  const double epp1[3] = {fp1.e1[1], fp1.e2[1], fp1.e3[1]};
+  const double epm1[3] = {fm1.e1[1], fm1.e2[1], fm1.e3[1]};
+  const bool lnx = (P.coords != ARTEMIS_CARTESIAN);
+  const double xma = lnx ? log(xv[ix1] / xva[ix1]) : xv[ix1] - xva[ix1];
+  const double dx = lnx ? log(xvp1[ix1] / xvm1[ix1]) : xvp1[ix1] - xvm1[ix1];
+  const double xmadx = xma / dx;
+  auto vdot = [](const double u[3], const double w[3]) { return u[0] * w[0] + u[1] * w[1] + u[2] * w[2]; };
+  double dgvp = 0.0;
+  if (nsg) {
+    double *rho = t.gas[t.b * 6 * nsg], *sie = t.gas[t.b * 6 * nsg + 5 * nsg];
+    double *v[3] = {t.gas[t.b * 6 * nsg + nsg], t.gas[t.b * 6 * nsg + nsg + 1], t.gas[t.b * 6 * nsg + nsg + 2]};
+    const double dgrho = log(rho[cP] / rho[cM]);
+    const double dgsie = log(sie[cP] / sie[cM]);
+    const double rhog = rho[cA] * exp(dgrho * xmadx);
+    const double sieg = sie[cA] * exp(dgsie * xmadx);
+    const double gva[3] = {v[0][cA], v[1][cA], v[2][cA]};
+    const double gvp1[3] = {v[0][cP], v[1][cP], v[2][cP]};
+    const double gvm1[3] = {v[0][cM], v[1][cM], v[2][cM]};
+    const double gvp = vdot(gva, epa) + a.omf * fa.x[0];
+    const double gvR = vdot(gva, eRa);
+    const double gvz = vdot(gva, eza);
+    const double gvp1p = vdot(gvp1, epp1) + a.omf * fp1.x[0];
+    const double gvm1p = vdot(gvm1, epm1) + a.omf * fm1.x[0];
+    dgvp = log(gvp1p / gvm1p);
+    const double gvcyl[3] = {gvR, gvp * exp(dgvp * xmadx) - a.omf * fr.x[0], gvz};
+    const double gvel[3] = {vdot(gvcyl, fr.e1), vdot(gvcyl, fr.e2), vdot(gvcyl, fr.e3)};
+    rho[c] = rhog, sie[c] = sieg;
+    v[ix1][c] = gvel[ix1], v[ix2][c] = gvel[ix2], v[ix3][c] = gvel[ix3];
+  }
+  for (int n = 0; n < nsd; ++n) {
+    double *dr = t.dust[t.b * 4 * nsd + n];
+    double *v[3] = {t.dust[t.b * 4 * nsd + nsd + 3 * n], t.dust[t.b * 4 * nsd + nsd + 3 * n + 1],
+                    t.dust[t.b * 4 * nsd + nsd + 3 * n + 2]};
+    const double ddrho = log(dr[cP] / dr[cM]);
+    const double rhod = dr[cA] * exp(ddrho * xmadx);
+    const double dva[3] = {v[0][cA], v[1][cA], v[2][cA]};
+    const double dvp = vdot(dva, epa) + a.omf * fa.x[0];
+    const double dvR = vdot(dva, eRa);
+    const double dvz = vdot(dva, eza);
+    // the dust azimuthal velocity is scaled with the GAS exponent (disk.hpp:795-797)
+    const double dvcyl[3] = {dvR, dvp * exp(dgvp * xmadx) - a.omf * fr.x[0], dvz};
+    const double dvel[3] = {vdot(dvcyl, fr.e1), vdot(dvcyl, fr.e2), vdot(dvcyl, fr.e3)};
+    dr[c] = rhod;
+    v[ix1][c] = dvel[ix1], v[ix2][c] = dvel[ix2], v[ix3][c] = dvel[ix3];
+  }
+}
+
 // All ghost cells of one block in ONE launch.  Parthenon applies periodic images, then x1, x2, x3
 // physical conditions, each pass over the entire extent of the other dimensions; every pass
 // remaps one index (and flips the sign of the normal velocity for reflecting walls), so the
@@ -791,6 +892,12 @@ static void launch_bc_sequential(const PackView &P, int b, const int *bc6,
           a.g_temp = par->cond_temp, a.flux = par->cond_flux, a.gx = par->cond_g[d];
           a.coeff = par->cond_coeff, a.cv = par->cond_cv, a.gm1 = P.gm1, a.type = par->cond_type;
           hipLaunchKernelGGL(conductive_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P);
+        } else if (flag == ARTEMIS_BC_IC || flag == ARTEMIS_BC_DISK_EXTRAP) {
+          DiskBcArgs a;
+          a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
+          a.extrap = (flag == ARTEMIS_BC_DISK_EXTRAP), a.omf = par->disk_omf;
+          a.ic_gas = par->ic_gas, a.ic_dust = par->ic_dust;
+          hipLaunchKernelGGL(disk_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P);
         } else if (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW) {
           StratBcArgs a;
           a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
@@ -815,7 +922,7 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
       a.bc[f] = (f / 2 < P.ndim) ? bc[b * 6 + f] : ARTEMIS_BC_NONE;
       any = any || (a.bc[f] != ARTEMIS_BC_NONE);
       user = user || a.bc[f] == ARTEMIS_BC_STRAT_EXTRAP || a.bc[f] == ARTEMIS_BC_STRAT_INFLOW ||
-             a.bc[f] == ARTEMIS_BC_CONDUCTIVE;
+             a.bc[f] == ARTEMIS_BC_CONDUCTIVE || a.bc[f] == ARTEMIS_BC_IC || a.bc[f] == ARTEMIS_BC_DISK_EXTRAP;
     }
     if (!any) continue;
     if (user) {

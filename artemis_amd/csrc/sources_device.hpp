@@ -53,8 +53,10 @@ ADEV GravAcc gravity_accel(const artemis_gravity_t &G, const DCoords &co, int nd
     const double g = -gm / rad2;
     a.gx1 = g * st;
     a.gx2 = g * ct;
-  } else { // Cartesian (:91-112)
-    double dxc[3] = {dx[0], dx[1], dx[2]};
+  } else { // Cartesian, cylindrical, spherical3D: through the Cartesian frame (:91-112)
+    const bool cyl = (co.sys == ARTEMIS_CYLINDRICAL);
+    const Frame fr = cart_frame(co.sys, dx, co.cv, co.sv, cyl ? co.cv : co.c3, cyl ? co.sv : co.s3);
+    double dxc[3] = {fr.x[0], fr.x[1], fr.x[2]};
     for (int n = 0; n < 3; n++) dxc[n] -= G.pos[n];
     const double R = sqrt(dxc[0] * dxc[0] + dxc[1] * dxc[1]);
     const double r = sqrt(R * R + dxc[2] * dxc[2]);
@@ -63,9 +65,9 @@ ADEV GravAcc gravity_accel(const artemis_gravity_t &G, const DCoords &co, int nd
     const double idr3 = 1.0 / (sqrt(rad2) * rad2);
     const double g[3] = {-gm * dxc[0] * idr3, (multi_d) * (-gm * dxc[1] * idr3),
                          (three_d) * (-gm * dxc[2] * idr3)};
-    a.gx1 = g[0] * 1.0 + g[1] * 0.0 + g[2] * 0.0;
-    a.gx2 = g[0] * 0.0 + g[1] * 1.0 + g[2] * 0.0;
-    a.gx3 = g[0] * 0.0 + g[1] * 0.0 + g[2] * 1.0;
+    a.gx1 = g[0] * fr.e1[0] + g[1] * fr.e1[1] + g[2] * fr.e1[2];
+    a.gx2 = g[0] * fr.e2[0] + g[1] * fr.e2[1] + g[2] * fr.e2[2];
+    a.gx3 = g[0] * fr.e3[0] + g[1] * fr.e3[1] + g[2] * fr.e3[2];
   }
   const double sink_rate = dt * G.sink_rate;
   const double sramp = sink_rate * sqr((dr - G.sink) / G.sink); // quad_ramp, gravity.hpp:116

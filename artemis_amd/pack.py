@@ -92,6 +92,7 @@ class MeshBlockPack:
         if nmetric > 0:
             mt = np.zeros(nmetric)
             capi.check(self.L.artemis_hip_metric_fill(C.byref(p), geom.ctypes.data, mt.ctypes.data))
+            self.metric_host = mt
             self.metric = torch.from_numpy(mt).to(self.dev)
             p.metric = self.metric.data_ptr()
         self.gas_prim_table = p.gas.prim
@@ -139,16 +140,20 @@ class MeshBlockPack:
         self._call(self.L.artemis_hip_estimate_dt, fluid, cfl, C.byref(out))
         return out.value
 
-    def ApplyBoundaryConditions(self, bc, strat=None, conductive=None):
+    def ApplyBoundaryConditions(self, bc, strat=None, conductive=None, disk=None):
         """bc: per-block list of 6 names/flags (ix1, ox1, ix2, ox2, ix3, ox3); strat = (qshear,
-        omega) when a block carries the strat problem's `extrap` / `inflow` conditions."""
+        omega) when a block carries the strat problem's `extrap` / `inflow` conditions; disk =
+        dict(ic_gas=table, ic_dust=table, omf=...) for the disk problem's `ic` / `disk_extrap`."""
         flat = []
         for row in bc:
             flat += [capi.BCS[x] if isinstance(x, str) else int(x) for x in row]
         arr = (C.c_int * len(flat))(*flat)
         par = None
-        if strat is not None or conductive is not None:
+        if strat is not None or conductive is not None or disk is not None:
             bp = capi.BcParams()
+            if disk is not None:
+                bp.ic_gas, bp.ic_dust = disk.get("ic_gas"), disk.get("ic_dust")
+                bp.disk_omf = disk.get("omf", 0.0)
             if strat is not None:
                 bp.qshear, bp.omega = strat
             if conductive is not None:  # dict(temp, flux, g=(gx1,gx2,gx3), coeff, cv, type)
@@ -205,6 +210,22 @@ class MeshBlockPack:
     def ExternalGravity(self, time, dt, gravity):
         """gravity: capi.Gravity (see gravity_point / gravity_uniform below)."""
         self._call(self.L.artemis_hip_external_gravity, C.byref(gravity), time, dt)
+
+    def viscosity_radial_table(self, D):
+        """Tabulate the radial factor of D.visc (powerlaw r_exp != 0, alpha) per cell with the host
+        libm (artemis_hip_diffusion_radial_fill), upload it and point D.visc.radial at it."""
+        n = self.pack.nblocks
+        host = np.zeros((n,) + tuple(self.gas_prim.shape[2:]))
+        mh = getattr(self, "metric_host", None)
+        for b in range(n):
+            capi.check(self.L.artemis_hip_diffusion_radial_fill(
+                C.byref(self.pack), self.geom_host.ctypes.data, mh.ctypes.data if mh is not None else None,
+                C.byref(D.visc), b, host[b].ctypes.data))
+        self._radial = torch.from_numpy(host).to(self.dev)
+        self._radial_tab = torch.tensor([self._radial[b].data_ptr() for b in range(n)], dtype=torch.int64,
+                                        device=self.dev)
+        D.visc.radial = self._radial_tab.data_ptr()
+        return self._radial
 
     def RotatingFrameForce(self, omega, qshear, time, dt):
         self._call(self.L.artemis_hip_rotating_frame_force, omega, qshear, time, dt)
@@ -295,6 +316,7 @@ def diffusion_params(gamma, viscosity=None, conductivity=None, mu=1.0):
         d.visc.type, d.visc.avg = t, {"arithmetic": 0, "harmonic": 1}[viscosity.get("averaging", "arithmetic")]
         d.visc.coeff = viscosity.get("nu", viscosity.get("alpha", 0.0))
         d.visc.eta, d.visc.r_exp, d.visc.r0 = viscosity.get("eta_bulk", 0.0), viscosity.get("r_exp", 0.0), viscosity.get("r0", 1.0)
+        d.visc.omega0 = viscosity.get("Omega0", 0.0)  # sqrt(gm / r0^3), diffusion_coeff.hpp:117-119
         d.visc.rho_ref = d.visc.T_ref = 1.0
     if conductivity:
         t = {"conductivity": capi.CONDUCTIVITY_PLAW, "diffusivity": capi.THERMALDIFF_PLAW}[conductivity.get("type", "conductivity")]

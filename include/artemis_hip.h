@@ -60,8 +60,12 @@ enum artemis_bc { ARTEMIS_BC_PERIODIC = 0, ARTEMIS_BC_OUTFLOW = 1, ARTEMIS_BC_RE
                   ARTEMIS_BC_STRAT_EXTRAP = 4, /* x1 faces */
                   ARTEMIS_BC_STRAT_INFLOW = 5, /* x2 faces */
                   /* `conductive` of the `conduction` problem (pgen/conduction.hpp:105-232): fixed heat
-                   * flux through inner faces, fixed temperature at outer ones; Cartesian */
-                  ARTEMIS_BC_CONDUCTIVE = 6 };
+                   * flux through inner faces, fixed temperature at outer ones */
+                  ARTEMIS_BC_CONDUCTIVE = 6,
+                  /* user conditions of the `disk` problem (pgen/disk.hpp, registered as `ic` /
+                   * `extrap` at problem_modifier.hpp:67-96), any face: */
+                  ARTEMIS_BC_IC = 7,          /* DiskBoundaryIC, disk.hpp:597-632 */
+                  ARTEMIS_BC_DISK_EXTRAP = 8  /* DiskBoundaryExtrap, disk.hpp:634-825 */ };
 enum artemis_gravity_type { ARTEMIS_GRAVITY_UNIFORM = 1, ARTEMIS_GRAVITY_POINT = 2 };
 enum artemis_drag_type { ARTEMIS_DRAG_SIMPLE_DUST = 1, ARTEMIS_DRAG_SELF = 2 }; /* drag.hpp:57 */
 enum artemis_drag_model { ARTEMIS_DRAG_CONSTANT = 0, ARTEMIS_DRAG_STOKES = 1 }; /* drag.hpp:58 */
@@ -166,6 +170,13 @@ typedef struct artemis_bc_params {
    * conductivity K or diffusivity (K = kappa*rho*cv) and the IdealGas specific heat */
   double cond_temp, cond_flux, cond_g[3], cond_coeff, cond_cv;
   int cond_type;              /* ARTEMIS_CONDUCTIVITY_PLAW | ARTEMIS_THERMALDIFF_PLAW (zero exponents) */
+  /* disk conditions (pgen/disk.hpp).  IC: DEVICE pointer tables laid out like gas.prim /
+   * dust.prim holding the initial primitives over the entire block (the time-independent disk
+   * profile DiskBoundaryIC re-evaluates per call, :597-632); ghost zones are copied from them.
+   * DISK_EXTRAP (:634-825): the frame frequency DiskParams::omf.  That condition takes log / exp
+   * of the state on the device: it matches a host libm to rounding, not bitwise. */
+  double *const *ic_gas, *const *ic_dust;
+  double disk_omf;
 } artemis_bc_params_t;
 int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_bc_params_t *params,
                          void *stream);
@@ -268,10 +279,13 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
  * Gas::EstimateTimestepMesh (gas.cpp:435-467, diffusion.hpp:66-108).  Fluxes go to
  * p->gas.diff_flux[d] on faces [s, e+1] like the hydro fluxes.
  * Built: every coordinate system (cylindrical / axisymmetric blocks need p->metric for
- * Coords::Distance); constant coefficients, i.e. viscosity `constant`/`powerlaw` with
- * r_exp = 0 and conductivity / diffusivity with temp_exp = rho_exp = 0 (the reference evaluates
- * std::pow per cell for the power laws and the alpha viscosity: no bit-reproducible device
- * counterpart), arithmetic or harmonic face averaging.  Everything else: ARTEMIS_HIP_EUNSUPPORTED. */
+ * Coords::Distance); viscosity `constant`, `powerlaw` (nu (R/r0)^r_exp) and `alpha`
+ * (alpha B / (Omega0 (r/r0)^-1.5)); conductivity / diffusivity with temp_exp = rho_exp = 0;
+ * arithmetic or harmonic face averaging.  The reference evaluates std::pow per cell: the radial
+ * factors depend on the cell centre only, so the adapter tabulates them once per mesh with the
+ * HOST libm (artemis_hip_diffusion_radial_fill -> artemis_diffcoeff_t.radial) and results stay
+ * bit-identical; the temperature / density power laws depend on the state, have no
+ * bit-reproducible device counterpart and return ARTEMIS_HIP_EUNSUPPORTED. */
 enum artemis_diff_type { ARTEMIS_DIFF_OFF = 0, ARTEMIS_VISCOSITY_PLAW = 1, ARTEMIS_VISCOSITY_ALPHA = 2,
                          ARTEMIS_CONDUCTIVITY_PLAW = 3, ARTEMIS_THERMALDIFF_PLAW = 4 };
 typedef struct artemis_diffcoeff { /* DiffCoeffParams, diffusion_coeff.hpp:58-136 */
@@ -280,11 +294,22 @@ typedef struct artemis_diffcoeff { /* DiffCoeffParams, diffusion_coeff.hpp:58-13
   double coeff;               /* nu | alpha | cond | kappa */
   double eta, r_exp, r0, omega0;
   double temp_exp, rho_exp, rho_ref, T_ref;
+  const double *const *radial; /* viscosity only: DEVICE table [nblocks] of per-cell arrays (entire
+                                  block incl. ghosts) filled by artemis_hip_diffusion_radial_fill;
+                                  required for ALPHA and for PLAW with r_exp != 0, else NULL */
 } artemis_diffcoeff_t;
 typedef struct artemis_diffusion {
   artemis_diffcoeff_t visc, cond;
   double cv;                  /* IdealGas specific heat: T = sie / cv (gas.cpp:106-116) */
 } artemis_diffusion_t;
+/* Radial factor of one block's cells for a viscosity law, on the HOST with the host libm:
+ * PLAW  -> std::pow(R / r0, r_exp), R = ConvertToCyl(cell centre)[0]   (diffusion_coeff.hpp:222-224)
+ * ALPHA -> omega0 * std::pow(r / r0, -1.5), r = ConvertToSph(centre)[0]  (:262-264)
+ * geom_host / metric_host = host copies of p->geom / p->metric (metric may be NULL where
+ * artemis_hip_metric_count is 0); out_host receives (nx3+2g)(nx2+2g)(nx1+2g) doubles. */
+int artemis_hip_diffusion_radial_fill(const artemis_pack_t *p, const double *geom_host,
+                                      const double *metric_host, const artemis_diffcoeff_t *c,
+                                      int block, double *out_host);
 int artemis_hip_zero_diffusion_flux(const artemis_pack_t *p, void *stream);
 int artemis_hip_viscous_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream);
 int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream);

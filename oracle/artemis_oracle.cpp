@@ -121,6 +121,9 @@ struct Sim {
     Real Gamma = 1, gamma_gas = 1.4, alpha = 0, nu0 = 0, nu_indx = 0, mdot = 0, temp_soft2 = 0;
     bool quiet_start = false;
   } disk;
+  // optional: initial primitives kept by a caller; when present the `ic` condition copies ghost
+  // zones from here instead of re-evaluating the profile (same values: the profile is static)
+  std::vector<Real> ic_g, ic_d;
   // diffusion (utils/diffusion/diffusion_coeff.hpp:58-136 DiffCoeffParams); type 0 = package off
   struct DiffCoeff {
     int type = 0; // 1 viscosity_plaw, 2 viscosity_alpha, 3 conductivity_plaw, 4 thermaldiff_plaw
@@ -2280,7 +2283,15 @@ void disk_bc(Sim &s, int d, int side, bool extrap) {
     for (int j = b0[1]; j <= b1[1]; ++j)
       for (int i = b0[0]; i <= b1[0]; ++i) {
         if (!extrap) {
-          disk_ic_cell(s, k, j, i);
+          if (s.ic_g.empty() && s.ic_d.empty()) {
+            disk_ic_cell(s, k, j, i);
+          } else {
+            const size_t c0 = IDX(s, k, j, i);
+            const int vars[5] = {0, ng_ + 0, ng_ + 1, ng_ + 2, 5 * ng_};
+            if (ng_)
+              for (int q = 0; q < 5; ++q) s.gprim[vars[q] * s.N + c0] = s.ic_g[vars[q] * s.N + c0];
+            for (int v = 0; v < 4 * nd_; ++v) s.dprim[v * s.N + c0] = s.ic_d[v * s.N + c0];
+          }
           continue;
         }
         int ia[3] = {i, j, k}, ip1[3] = {i, j, k}, im1[3] = {i, j, k}; // (i, j, k) order here

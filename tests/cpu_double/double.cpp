@@ -245,6 +245,9 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
       for (int d = 0; d < 3; ++d) s.grav.g[d] = par->cond_g[d];
       s.cond.type = par->cond_type, s.cond.hcond_0 = s.cond.kappa_0 = par->cond_coeff;
       if (par->cond_cv > 0.0) s.cv = par->cond_cv;
+      s.disk.omf = par->disk_omf;
+      if (par->ic_gas) s.ic_g.resize(s.gprim.size()), B.in(s.ic_g, par->ic_gas, s.nvg);
+      if (par->ic_dust) s.ic_d.resize(s.dprim.size()), B.in(s.ic_d, par->ic_dust, s.nvd);
     }
     apply_bcs(*B.s);
     B.out(B.s->gprim, p->gas.prim, B.s->nvg), B.out(B.s->dprim, p->dust.prim, B.s->nvd);
@@ -271,6 +274,7 @@ int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, doub
     Bound B(p, b);
     B.load_state();
     B.s->rframe.on = true, B.s->rframe.omega = omega, B.s->rframe.qshear = qshear;
+    if (p->coords != ARTEMIS_CARTESIAN) B.load_fluxes(); // RotatingFrameImpl reads the mass fluxes
     rotating_frame_force(*B.s, dt);
     B.out(B.s->gu0, p->gas.cons0, B.s->nvg), B.out(B.s->du0, p->dust.cons0, B.s->nvd);
   }
@@ -496,6 +500,23 @@ static void dflux_io(Bound &B, const artemis_pack_t *p, bool out) {
     if (out) B.out(B.s->qflux[d], p->gas.diff_flux[d], 4 * B.s->c.ns_gas);
     else B.in(B.s->qflux[d], p->gas.diff_flux[d], 4 * B.s->c.ns_gas);
   }
+}
+int artemis_hip_diffusion_radial_fill(const artemis_pack_t *p, const double *geom_host, const double *,
+                                      const artemis_diffcoeff_t *c, int block, double *out) {
+  artemis_pack_t q = *p;
+  q.geom = geom_host;
+  Bound B(&q, block);
+  Sim &s = *B.s;
+  for (int k = 0; k < s.nk; ++k)
+    for (int j = 0; j < s.nj; ++j)
+      for (int i = 0; i < s.ni; ++i) {
+        const Coords co(s, k, j, i);
+        const Real xv[3] = {co.x1v(), co.x2v(), co.x3v()};
+        out[IDX(s, k, j, i)] = (c->type == ARTEMIS_VISCOSITY_PLAW)
+                                   ? std::pow(to_cyl_with_vec(co, xv).R / c->r0, c->r_exp)
+                                   : c->omega0 * std::pow(to_sph_radius(co, xv) / c->r0, -1.5);
+      }
+  return 0;
 }
 int artemis_hip_zero_diffusion_flux(const artemis_pack_t *p, void *) {
   for (int b = 0; b < p->nblocks; ++b) {

@@ -77,11 +77,14 @@ def test_conduction_only_update_and_contract(hiplib):
     o.DiffusionUpdate(1.0e-3), mb.DiffusionUpdate(D, 1.0e-3)
     I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
     same(mb.gas_u0[0][I], o.gu0[I], "DiffusionUpdate, conduction only")
-    with pytest.raises(capi.ArtemisHipError) as e:  # power laws need std::pow per cell
+    with pytest.raises(capi.ArtemisHipError) as e:  # radial laws need their host-filled table
         mb.ViscousFlux(diffusion_params(1.4, viscosity=dict(type="powerlaw", nu=0.1, r_exp=-0.5)))
-    assert e.value.code == capi.EUNSUPPORTED
+    assert e.value.code == capi.EINVAL and "radial" in str(e.value)
     with pytest.raises(capi.ArtemisHipError) as e:
         mb.ViscousFlux(diffusion_params(1.4, viscosity=dict(type="alpha", alpha=0.01)))
+    assert e.value.code == capi.EINVAL
+    with pytest.raises(capi.ArtemisHipError) as e:  # state power laws: std::pow of T, rho per cell
+        mb.ThermalFlux(diffusion_params(1.4, conductivity=dict(type="conductivity", cond=0.1, rho_exp=1.0)))
     assert e.value.code == capi.EUNSUPPORTED
     cyl = MeshBlockPack(1, (8, 4, 1), [(0.5, 0.0, -0.5)], [(1.0, 3.0, 0.5)], coordinates="cylindrical",
                         with_diffusion=True)

@@ -43,13 +43,18 @@ GRAV_GEOMS = [("cartesian", (20, 12, 8), (-1.0, -0.5, -0.25), (1.0, 0.5, 0.75)),
               ("spherical", (40, 1, 1), (0.2, 0.0, -0.5), (2.0, np.pi, 0.5)),
               ("spherical", (24, 10, 1), (0.3, 0.6, -0.5), (2.0, 2.5, 0.5)),
               ("axisymmetric", (24, 12, 1), (0.1, -1.0, -0.5), (2.0, 1.0, 0.5))]
+# systems that go through ConvertToCartWithVec (point_mass.cpp:91-112): an offset mass is allowed
+GRAV_FRAME = [("cylindrical", (16, 12, 6), (0.5, 0.0, -1.0), (2.0, 2 * np.pi, 1.0)),   # disk_cyl.in layout
+              ("cylindrical", (16, 8, 1), (0.5, 0.3, -0.5), (2.0, 2.0, 0.5)),
+              ("spherical", (16, 8, 6), (0.3, 0.6, 0.0), (1.5, 2.5, 6.0)),              # disk_sph.in layout
+              ("spherical", (12, 10, 8), (0.2, 1.06, -np.pi), (5.6, 2.08, np.pi))]
 
 
-@pytest.mark.parametrize("coordinates,nx,lo,hi", GRAV_GEOMS)
+@pytest.mark.parametrize("coordinates,nx,lo,hi", GRAV_GEOMS + GRAV_FRAME)
 def test_point_mass_gravity(hiplib, coordinates, nx, lo, hi):
     from artemis_amd.pack import gravity_point
     o, mb = pair(nx, lo, hi, ns_gas=2, ns_dust=2, coordinates=coordinates, seed=21)
-    cart = coordinates == "cartesian"
+    cart = coordinates == "cartesian" or (coordinates, nx, lo, hi) in GRAV_FRAME
     pos = (0.13, -0.07, 0.2) if cart else (0.0, 0.0, 0.0)
     # softened, with an active sink region so density and energy are drained too
     o.set_gravity_point(2.5, soft=0.05, sink=0.6, sink_rate=3.0, x=pos[0], y=pos[1], z=pos[2])
@@ -91,6 +96,29 @@ def test_shearing_box(hiplib, nx):
     o.RotatingFrameForce(1.5e-3)
     mb.RotatingFrameForce(0.9, 1.5, 0.0, 1.5e-3)
     check_cons(o, mb, "ShearingBox")
+
+
+RF_GEOMS = [("spherical", (40, 1, 1), (0.2, 0.0, -0.5), (2.0, np.pi, 0.5)),
+            ("spherical", (24, 10, 1), (0.3, 0.6, -0.5), (2.0, 2.5, 0.5)),
+            ("spherical", (16, 8, 6), (0.3, 0.6, 0.0), (1.5, 2.5, 6.0)),
+            ("cylindrical", (16, 12, 6), (0.5, 0.0, -1.0), (2.0, 2 * np.pi, 1.0)),
+            ("cylindrical", (33, 1, 1), (0.3, -0.5, -0.5), (1.0, 0.5, 0.5)),
+            ("axisymmetric", (24, 12, 1), (0.1, -1.0, -0.5), (2.0, 1.0, 0.5)),
+            ("axisymmetric", (12, 8, 6), (0.7, -1.0, 0.0), (2.0, 1.0, 1.0))]
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", RF_GEOMS)
+def test_rotating_frame_curvilinear(hiplib, coordinates, nx, lo, hi):
+    """RotatingFrameImpl<GEOM> (rotating_frame_impl.hpp:95-199): angular-momentum-conserving source
+    from the stage's mass fluxes with the RFWeights of each system, gas and dust."""
+    o, mb = pair(nx, lo, hi, ns_gas=2, ns_dust=2, coordinates=coordinates, seed=29)
+    for fluid in (0, 1):
+        o.CalculateFluxes(fluid, False)
+        mb.CalculateFluxes(fluid, False)
+    o.set_rotating_frame(0.9, 0.0)
+    o.RotatingFrameForce(1.5e-3)
+    mb.RotatingFrameForce(0.9, 0.0, 0.0, 1.5e-3)
+    check_cons(o, mb, "RotatingFrame")
 
 
 DRAG_GEOMS = [("cartesian", (20, 12, 8), (-1.0, -0.5, -0.25), (1.0, 0.5, 0.75)),
@@ -170,9 +198,11 @@ def test_source_abi_contract(hiplib):
     from artemis_amd import capi
     from artemis_amd.pack import MeshBlockPack, drag_params, gravity_point
     mb = MeshBlockPack(1, (8, 8, 4), [(0.5, 0.6, 0.0)], [(1.0, 2.5, 1.0)], ns_dust=1, coordinates="spherical")
-    with pytest.raises(capi.ArtemisHipError) as e:  # needs the azimuthal basis: not built
-        mb.ExternalGravity(0.0, 1e-3, gravity_point(1.0))
-    assert e.value.code == capi.EUNSUPPORTED
+    cyl = MeshBlockPack(1, (8, 8, 4), [(0.5, 0.0, 0.0)], [(1.0, 2.5, 1.0)], ns_dust=1, coordinates="cylindrical")
+    cyl.pack.metric = None
+    with pytest.raises(capi.ArtemisHipError) as e:  # ConvertToCartWithVec needs cos / sin of the azimuth
+        cyl.ExternalGravity(0.0, 1e-3, gravity_point(1.0))
+    assert e.value.code == capi.EINVAL and "metric" in str(e.value)
     with pytest.raises(capi.ArtemisHipError) as e:  # rotating_frame.cpp:34-38
         mb.RotatingFrameForce(1.0, 1.5, 0.0, 1e-3)
     assert e.value.code == capi.EINVAL and "qshear" in str(e.value)
