@@ -100,7 +100,7 @@ struct Link { // one directed ghost-slab transfer out of local block b through f
   int tag_send, tag_recv;
 };
 
-enum { PG_BLAST, PG_LINWAVE, PG_ADVECTION, PG_CONSTANT, PG_STRAT, PG_BUMP, PG_COND };
+enum { PG_BLAST, PG_LINWAVE, PG_ADVECTION, PG_CONSTANT, PG_STRAT, PG_BUMP, PG_COND, PG_DISK };
 
 } // namespace
 
@@ -136,6 +136,8 @@ struct artemis_sim {
   bool do_viscosity = false, do_conduction = false;
   artemis_diffusion_t diff;
   Field gdflux[3];
+  Field visc_radial;  // per-cell radial factor of the viscosity law (host libm), diff.visc.radial
+  Field ic_gas, ic_dust; // disk `ic` condition: the initial primitives as generated (disk.hpp:597-632)
   bool edge_ghosts = false; // sequential x1, x2, x3 exchange with extended slabs (viscosity)
   std::string integrator = "rk2";
   int nstages = 2;
@@ -243,6 +245,10 @@ int parse_bc(const std::string &s, int pgen, int dir) {
   if (pgen == PG_STRAT && s == "extrap" && dir != 1) return ARTEMIS_BC_STRAT_EXTRAP;
   if (pgen == PG_STRAT && s == "inflow" && dir == 1) return ARTEMIS_BC_STRAT_INFLOW;
   if (pgen == PG_COND && s == "conductive") return ARTEMIS_BC_CONDUCTIVE; // problem_modifier.hpp:95-108
+  if (pgen == PG_DISK && s == "ic") return ARTEMIS_BC_IC;                 // problem_modifier.hpp:67-96
+  if (pgen == PG_DISK && s == "extrap") return ARTEMIS_BC_DISK_EXTRAP;
+  if (pgen == PG_DISK && s == "viscous")
+    throw std::runtime_error("the disk problem's `viscous` condition (disk.hpp:415-595) is not built");
   throw std::runtime_error("boundary flag '" + s + "' is not built for this problem "
                            "(periodic|outflow|reflecting; strat: extrap on x1/x3, inflow on x2)");
 }
@@ -291,6 +297,7 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   else if (problem == "strat") pgen = PG_STRAT;
   else if (problem == "gaussian_bump") pgen = PG_BUMP;
   else if (problem == "conduction") pgen = PG_COND;
+  else if (problem == "disk") pgen = PG_DISK;
   else throw std::runtime_error("problem generator '" + problem + "' is not built");
   // <physics> (artemis.cpp:63-72); everything but gas/dust must stay off
   do_gas = pin.GetOrAddBoolean("physics", "gas", true);
@@ -325,7 +332,7 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   else if (sys == "cylindrical") coords = ARTEMIS_CYLINDRICAL;
   else if (sys == "axisymmetric") coords = ARTEMIS_AXISYMMETRIC;
   else throw std::runtime_error("Coordinate type not recognized!");
-  if (coords != ARTEMIS_CARTESIAN && pgen != PG_BLAST && pgen != PG_COND)
+  if (coords != ARTEMIS_CARTESIAN && pgen != PG_BLAST && pgen != PG_COND && pgen != PG_DISK)
     throw std::runtime_error("problem generator '" + problem + "' is Cartesian-only");
   // <gravity> (gravity.cpp:25-118); G = 1 in scale-free units (units.cpp:68-76)
   if (do_gravity) {
@@ -358,8 +365,8 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
     rf_omega = pin.GetReal("rotating_frame", "omega");
     rf_qshear = pin.GetOrAddReal("rotating_frame", "qshear", 0.0);
     if (rf_omega == 0.0) throw std::runtime_error("rotating_frame/omega cannot be zero!");
-    if (coords != ARTEMIS_CARTESIAN)
-      throw std::runtime_error("rotating frame in curvilinear coordinates is not built yet");
+    if (coords != ARTEMIS_CARTESIAN && rf_qshear != 0.0) // rotating_frame.cpp:34-38
+      throw std::runtime_error("rotating_frame/qshear must be zero for non-Cartesian coordinate systems!");
   }
   if (pgen == PG_STRAT) { // strat.hpp:55-70 InitStratParams reads the rotating_frame package
     if (!do_rframe) throw std::runtime_error("problem = strat requires physics/rotating_frame");
@@ -429,8 +436,13 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
         c.coeff = pin.GetReal("gas/viscosity", "nu");
         c.eta = pin.GetOrAddReal("gas/viscosity", "eta_bulk", 0.0);
         c.r_exp = pin.GetOrAddReal("gas/viscosity", "r_exp", 0.0);
-      } else if (t == "alpha") {
-        throw std::runtime_error("gas/viscosity/type = alpha needs the disk setup (out of scope of this build)");
+      } else if (t == "alpha") { // diffusion_coeff.hpp:113-119
+        if (!do_gravity || grav.type != ARTEMIS_GRAVITY_POINT)
+          throw std::runtime_error("gas/viscosity/type = alpha reads gm of the gravity package: gravity/point is required");
+        c.type = ARTEMIS_VISCOSITY_ALPHA;
+        c.coeff = pin.GetReal("gas/viscosity", "alpha");
+        c.eta = pin.GetOrAddReal("gas/viscosity", "eta_bulk", 0.0);
+        c.omega0 = std::sqrt(grav.gm / (c.r0 * c.r0 * c.r0));
       } else {
         throw std::runtime_error(t + " in gas/viscosity is not supported");
       }
@@ -533,7 +545,9 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   // stage (artemis_hip_stage_general) for everything else the per-task path can do
   tuned = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
           coords == ARTEMIS_CARTESIAN && !do_gravity && !do_rframe && !do_drag;
-  fused_possible = !(do_viscosity || do_conduction); // diffusion runs on the per-task chain
+  // diffusion and the curvilinear rotating frame (which reads the stored mass fluxes) run on the
+  // per-task chain
+  fused_possible = !(do_viscosity || do_conduction) && !(do_rframe && coords != ARTEMIS_CARTESIAN);
   tuned = tuned && fused_possible;
   use_fused = fused_possible;
   if (!use_fused) ensure_unfused();
@@ -904,6 +918,98 @@ void artemis_sim::problem_generator() {
     st.dens_min = pin.GetOrAddReal("problem", "dens_min", 1.0e-5);
     st.d2g = pin.GetOrAddReal("problem", "dust_to_gas", 0.01);
   }
+  // disk.hpp:50-66 DiskParams, :253-323 InitDiskParams (n-body temperature: out of scope)
+  struct {
+    Real r0, h0, p, q, flare, rho0, dens_min, pres_min, gm, Omega0, l0, omf, dust_to_gas, rexp, rcav;
+    Real Gamma, gamma_gas, alpha, nu0, nu_indx, mdot, temp_soft2;
+    bool quiet_start;
+  } dk = {};
+  if (pgen == PG_DISK) {
+    if (!do_gas || ns_gas != 1) throw std::runtime_error("disk pgen requires a single gas species.");
+    if (!do_gravity) throw std::runtime_error("disk pgen reads gm of the gravity package: physics/gravity is required");
+    if (coords == ARTEMIS_CARTESIAN && pin.DoesBlockExist("parthenon/static_refinement1"))
+      throw std::runtime_error("static mesh refinement is out of scope of this build");
+    dk.gm = grav.gm;
+    dk.r0 = pin.GetOrAddReal("problem", "r0", 1.0);
+    dk.Omega0 = std::sqrt(dk.gm / (dk.r0 * dk.r0 * dk.r0));
+    dk.rho0 = pin.GetOrAddReal("problem", "rho0", 1.0);
+    dk.p = pin.GetOrAddReal("problem", "dslope", -2.25);
+    dk.h0 = pin.GetOrAddReal("problem", "h0", 0.05);
+    dk.gamma_gas = gamma;
+    dk.Gamma = pin.GetOrAddReal("problem", "polytropic_index", dk.gamma_gas);
+    if (!(dk.Gamma >= 1)) throw std::runtime_error("problem/gamma needs to be >= 1");
+    dk.dens_min = pin.GetOrAddReal("problem", "dens_min", 1.0e-5);
+    dk.pres_min = pin.GetOrAddReal("problem", "pres_min", 1.0e-8);
+    dk.rexp = pin.GetOrAddReal("problem", "rexp", 0.0);
+    dk.rcav = pin.GetOrAddReal("problem", "rcav", 0.0);
+    dk.l0 = pin.GetOrAddReal("problem", "l0", 0.0);
+    dk.dust_to_gas = pin.GetOrAddReal("problem", "dust_to_gas", 0.01);
+    dk.temp_soft2 = pin.GetOrAddReal("problem", "temp_soft", 0.0);
+    const Real big = -DBL_MAX; // -Big<Real>()
+    Real q = pin.GetOrAddReal("problem", "tslope", big);
+    Real flare = pin.GetOrAddReal("problem", "flare", big);
+    if (!((flare != big) || (q != big))) throw std::runtime_error("Set flare or tslope in <problem>");
+    if (flare == big) flare = 0.5 * (1.0 + q);
+    else if (q == big) q = 2.0 * flare - 1.;
+    else throw std::runtime_error("Set either flare or tslope in <problem> not both!");
+    dk.flare = flare, dk.q = q;
+    dk.quiet_start = pin.GetOrAddBoolean("problem", "quiet_start", false);
+    dk.omf = do_rframe ? rf_omega : 0.0;
+    if (do_viscosity) {
+      const std::string vtype = pin.GetString("gas/viscosity", "type");
+      if (vtype == "alpha") {
+        dk.alpha = pin.GetReal("gas/viscosity", "alpha");
+        dk.nu0 = dk.alpha * dk.gamma_gas * SQR(dk.h0 * dk.r0 * dk.Omega0);
+        dk.nu_indx = 1.5 + dk.q;
+      } else if (vtype == "powerlaw") {
+        dk.nu0 = pin.GetReal("gas/viscosity", "nu");
+        dk.nu_indx = pin.GetOrAddReal("gas/viscosity", "r_exp", 0.0);
+      } else {
+        throw std::runtime_error("Disk pgen is only compatible with alpha or powerlaw viscosity");
+      }
+      if (pin.DoesParameterExist("problem", "mdot")) {
+        dk.mdot = pin.GetReal("problem", "mdot");
+        dk.rho0 = dk.mdot / (3.0 * M_PI * dk.nu0);
+      } else {
+        dk.mdot = 3.0 * M_PI * dk.nu0 * dk.rho0;
+      }
+    }
+    if (pin.GetOrAddBoolean("problem", "nbody_temp", false) && pin.GetOrAddBoolean("physics", "nbody", false))
+      throw std::runtime_error("problem/nbody_temp needs the n-body package (out of scope of this build)");
+    bool any_ic = false;
+    for (const Block &B : blocks)
+      for (int f = 0; f < 6; ++f) any_ic = any_ic || B.bc[f] == ARTEMIS_BC_IC;
+    if (any_ic) {
+      ic_gas.alloc(nb, 6 * ns_gas, N), ic_dust.alloc(nb, 4 * ns_dust, N);
+      bcpar.ic_gas = ic_gas.tab(), bcpar.ic_dust = do_dust ? ic_dust.tab() : nullptr;
+    }
+    bcpar.disk_omf = dk.omf;
+  }
+  // DenProfile / TempProfile / PresProfile / ViscosityProfile (disk.hpp:69-135) on the host libm
+  auto disk_den = [&](const Real R, const Real z) {
+    const Real r = std::sqrt(R * R + z * z);
+    const Real h = dk.h0 * std::pow(R / dk.r0, dk.flare);
+    const Real sig0 = dk.rho0;
+    const Real exp_fac = (dk.rexp == 0.) ? 1. : std::exp(-SQR(R / dk.rexp));
+    const Real dmid = (sig0 * std::pow(R / dk.r0, dk.p)) * (1. - dk.l0 * std::sqrt(dk.r0 / R)) *
+                      (dk.dens_min / dk.rho0 +
+                       (1. - dk.dens_min / dk.rho0) * std::exp(-std::pow(dk.rcav / R, 12.0))) *
+                      exp_fac;
+    const Real sint = (r == 0.0) ? 1.0 : R / r;
+    const Real efac = (1. - sint) / (h * h);
+    if (dk.Gamma == 1.) return std::max(dk.dens_min, dmid * std::exp(-efac));
+    const Real pfac = 1. - (dk.Gamma - 1) * efac;
+    return std::max(dk.dens_min, dmid * std::pow(pfac + 1e-99, 1. / (dk.Gamma - 1)));
+  };
+  auto disk_temp = [&](const Real R, const Real z) {
+    const Real rho = disk_den(R, z);
+    const Real rho0 = disk_den(R, 0.0);
+    const Real H = R * dk.h0 * std::pow(R / dk.r0, dk.flare);
+    const Real ir1 = 1.0 / std::sqrt(R * R + dk.temp_soft2);
+    const Real omk2 = SQR(dk.Omega0) * ir1 * ir1 * ir1;
+    const Real T0 = omk2 * H * H / dk.Gamma;
+    return T0 * std::pow(rho / rho0, dk.Gamma - 1.0);
+  };
   struct { Real g_rho = 1, g_v[3] = {0, 0, 0}, g_temp = 1; } cd;
   if (pgen == PG_COND) {
     if (!do_gas || ns_gas != 1 || do_dust) throw std::runtime_error("Cond pgen requires a single gas species.");
@@ -954,6 +1060,61 @@ void artemis_sim::problem_generator() {
               hd[(ns_dust + 3 * n + 0) * N + c] = (cs.d_v[0] * ex1[0] + cs.d_v[1] * ex1[1] + cs.d_v[2] * ex1[2]);
               hd[(ns_dust + 3 * n + 1) * N + c] = (cs.d_v[0] * ex2[0] + cs.d_v[1] * ex2[1] + cs.d_v[2] * ex2[2]);
               hd[(ns_dust + 3 * n + 2) * N + c] = (cs.d_v[0] * ex3[0] + cs.d_v[1] * ex3[1] + cs.d_v[2] * ex3[2]);
+            }
+          } else if (pgen == PG_DISK) { // disk.hpp:141-247 ComputeDiskProfile + :325-354 DiskICImpl
+            const artemis::DCoords co = cell_coords(b, k, j, i);
+            Real xc[3];
+            co.centre(xc);
+            auto frame = [&](const Real xi[3]) { // ConvertToCylWithVec of any point, host libm
+              return artemis::cyl_frame(coords, xi, std::cos(xi[1]), std::sin(xi[1]));
+            };
+            const artemis::Frame fr = frame(xc);
+            const Real *xcyl = fr.x;
+            const Real gdens = disk_den(xcyl[0], xcyl[2]);
+            const Real rt = xcyl[0];
+            const Real gtemp = disk_temp(rt, xcyl[2]);
+            // grad(P) restated literally: `(pfm = pres_min) ? pres_min : ...` ASSIGNS (disk.hpp:186, :203,
+            // :220), so both face pressures collapse to pres_min whenever pres_min != 0
+            const Real fpts[3][2][3] = {{{co.x1[0], xc[1], xc[2]}, {co.x1[1], xc[1], xc[2]}},
+                                        {{xc[0], co.x2[0], xc[2]}, {xc[0], co.x2[1], xc[2]}},
+                                        {{xc[0], xc[1], co.x3[0]}, {xc[0], xc[1], co.x3[1]}}};
+            const Real widths[3] = {co.width1(), co.width2(), co.width3()};
+            auto pres = [&](const Real tf, const Real R, const Real z) {
+              return std::max(dk.pres_min, std::max(0.0, (gamma - 1.0) * disk_den(R, z) * cv * tf));
+            };
+            Real pgrad[3];
+            for (int d = 0; d < 3; ++d) {
+              artemis::Frame xfc = frame(fpts[d][0]);
+              const Real tfm = disk_temp(xfc.x[0], xfc.x[2]);
+              Real pfm = pres(tfm, xfc.x[0], xfc.x[2]);
+              xfc = frame(fpts[d][1]);
+              const Real tfp = disk_temp(xfc.x[0], xfc.x[2]);
+              const Real pfp = (pfm = dk.pres_min) ? dk.pres_min : pres(tfp, xfc.x[0], xfc.x[2]);
+              pfm = (pfp == dk.pres_min) ? dk.pres_min : pfm;
+              pgrad[d] = (pfp - pfm) / widths[d];
+            }
+            const Real eR[3] = {fr.e1[0], fr.e2[0], fr.e3[0]};
+            const Real dpdr = pgrad[0] * eR[0] + pgrad[1] * eR[1] + pgrad[2] * eR[2];
+            const Real r = std::sqrt(SQR(xcyl[0]) + SQR(xcyl[2]));
+            const Real omk2 = dk.gm / (r * r * r);
+            const Real vk2 = omk2 * SQR(xcyl[0]);
+            const Real vp = std::sqrt(vk2 + dpdr * xcyl[0] / gdens);
+            const Real nu = dk.nu0 * std::pow(rt / dk.r0, dk.nu_indx);
+            const Real vr = dk.quiet_start ? 0.0 : -1.5 * nu / xcyl[0];
+            const Real vcyl[3] = {vr, vp - dk.omf * xcyl[0], 0.0};
+            auto vdot = [](const Real a[3], const Real w[3]) { return a[0] * w[0] + a[1] * w[1] + a[2] * w[2]; };
+            hg[0 * N + c] = gdens;
+            hg[(ns_gas + 0) * N + c] = vdot(vcyl, fr.e1);
+            hg[(ns_gas + 1) * N + c] = vdot(vcyl, fr.e2);
+            hg[(ns_gas + 2) * N + c] = vdot(vcyl, fr.e3);
+            hg[(5 * ns_gas) * N + c] = cv * gtemp;
+            const Real ddens = dk.dust_to_gas * gdens;
+            const Real vkep[3] = {0.0, std::sqrt(vk2) - dk.omf * xcyl[0], 0.0};
+            for (int n = 0; n < ns_dust; ++n) {
+              hd[n * N + c] = ddens;
+              hd[(ns_dust + 3 * n + 0) * N + c] = vdot(vkep, fr.e1);
+              hd[(ns_dust + 3 * n + 1) * N + c] = vdot(vkep, fr.e2);
+              hd[(ns_dust + 3 * n + 2) * N + c] = vdot(vkep, fr.e3);
             }
           } else if (pgen == PG_COND) { // conduction.hpp:88-103
             const Real gm1c = gamma - 1.0;
@@ -1127,8 +1288,22 @@ void artemis_sim::problem_generator() {
         }
     if (do_gas) upload_block(gprim[0], b, hg);
     if (do_dust) upload_block(dprim[0], b, hd);
+    if (ic_gas.ok()) upload_block(ic_gas, b, hg); // as generated, before PrimToCons applies the floors
+    if (ic_dust.ok()) upload_block(ic_dust, b, hd);
   }
   base = 0;
+  if (do_viscosity && (diff.visc.type == ARTEMIS_VISCOSITY_ALPHA || diff.visc.r_exp != 0.0)) {
+    // the std::pow of the cell position in DiffusionCoeff::Get (diffusion_coeff.hpp:222-224, :262-264)
+    visc_radial.alloc(nb, 1, N);
+    const artemis_pack_t pk = make_pack(0);
+    std::vector<Real> hr(N);
+    for (int b = 0; b < nb; ++b) {
+      CK(artemis_hip_diffusion_radial_fill(&pk, hgeom.data(), hmetric.empty() ? nullptr : hmetric.data(),
+                                           &diff.visc, b, hr.data()), "viscosity radial table");
+      upload_block(visc_radial, b, hr);
+    }
+    diff.visc.radial = visc_radial.tab();
+  }
   // PostInitialization = PrimToCons on every block (main.cpp:43, fill_derived.cpp:284-287),
   // then parthenon Mesh::Initialize communicates boundaries (upstream, recalled):
   // PreCommFillDerived (ConsToPrim, artemis.cpp:122) -> exchange + physical BCs ->

@@ -312,3 +312,27 @@ def test_conduction_problem_deck_driver_equals_oracle(double_lib, tmp_path):
     o.evolve(40.0, 200)
     assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
     assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+
+
+def test_disk_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
+    """inputs/disk/disk_axi.in at half resolution (disk pgen on the host libm, `ic` conditions from
+    the stored initial state, point-mass gravity, alpha viscosity with its radial table, the
+    curvilinear rotating frame): driver == oracle bit for bit on one block; the 2x2-block run on
+    1 and 2 ranks agrees bit for bit with itself."""
+    from test_oracle_pins import disk_oracle
+    half = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "problem/polytropic_index=1.40"]
+    one = dict(deck=["disk", "disk_axi.in"], cycles=6, overrides=half + ["parthenon/meshblock/nx1=64",
+                                                                       "parthenon/meshblock/nx2=32"])
+    r = run_world(1, one, tmp_path, "d1")[0]
+    assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    o = disk_oracle("axi", 1.4, "ic", nx=(64, 32, 1))
+    o.evolve(62.8, 6)
+    assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
+    assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+    four = dict(one, overrides=half)  # the deck's 32-zone blocks: 2 x 1 ... at half resolution 2 x 1
+    four["overrides"] = half + ["parthenon/meshblock/nx2=16"]
+    a, b = run_world(1, four, tmp_path, "d4"), run_world(2, four, tmp_path, "d4r2")
+    assert a[0]["meta"]["nblocks"] == 4 and [x["meta"]["nblocks"] for x in b] == [2, 2]
+    xa, xb = by_bounds(a), by_bounds(b)
+    for key in xa:
+        assert np.array_equal(xa[key], xb[key]), key
