@@ -28,7 +28,7 @@ def coord_select(sys, ndim):
 HLLC, HLLE, LLF = 0, 1, 2
 PCM, PLM, PPM = 0, 1, 2
 GAS, DUST = 0, 1
-BC_PERIODIC, BC_OUTFLOW, BC_REFLECT, BC_NONE, BC_STRAT_EXTRAP, BC_STRAT_INFLOW, BC_CONDUCTIVE, BC_IC, BC_DISK_EXTRAP = range(9)
+BC_PERIODIC, BC_OUTFLOW, BC_REFLECT, BC_NONE, BC_STRAT_EXTRAP, BC_STRAT_INFLOW, BC_CONDUCTIVE, BC_IC, BC_DISK_EXTRAP, BC_DISK_VISC = range(10)
 GRAVITY_UNIFORM, GRAVITY_POINT = 1, 2
 DRAG_SIMPLE_DUST, DRAG_SELF = 1, 2
 DRAG_CONSTANT, DRAG_STOKES = 0, 1
@@ -38,7 +38,8 @@ RSOLVER = {"hllc": HLLC, "hlle": HLLE, "llf": LLF}
 RECON = {"pcm": PCM, "plm": PLM, "ppm": PPM}
 BCS = {"periodic": BC_PERIODIC, "outflow": BC_OUTFLOW, "reflecting": BC_REFLECT,
        "reflect": BC_REFLECT, "none": BC_NONE, "extrap": BC_STRAT_EXTRAP,
-       "inflow": BC_STRAT_INFLOW, "conductive": BC_CONDUCTIVE, "ic": BC_IC, "disk_extrap": BC_DISK_EXTRAP}
+       "inflow": BC_STRAT_INFLOW, "conductive": BC_CONDUCTIVE, "ic": BC_IC, "disk_extrap": BC_DISK_EXTRAP,
+       "viscous": BC_DISK_VISC}
 
 PP = C.c_void_p  # device pointer tables are opaque to the host
 
@@ -77,7 +78,15 @@ class BcParams(C.Structure):
     _fields_ = [("qshear", C.c_double), ("omega", C.c_double), ("cond_temp", C.c_double),
                 ("cond_flux", C.c_double), ("cond_g", C.c_double * 3), ("cond_coeff", C.c_double),
                 ("cond_cv", C.c_double), ("cond_type", C.c_int), ("ic_gas", C.c_void_p),
-                ("ic_dust", C.c_void_p), ("disk_omf", C.c_double)]
+                ("ic_dust", C.c_void_p), ("disk_omf", C.c_double), ("disk_nu0", C.c_double),
+                ("disk_nu_indx", C.c_double), ("disk_r0", C.c_double), ("disk_mdot", C.c_double)]
+
+
+class Cooling(C.Structure):
+    _fields_ = [("beta0", C.c_double), ("beta_min", C.c_double), ("exp_scale", C.c_double),
+                ("tfloor", C.c_double), ("tcyl", C.c_double), ("cyl_plaw", C.c_double), ("tsph", C.c_double),
+                ("sph_plaw", C.c_double), ("gm", C.c_double), ("cv", C.c_double), ("tref", C.c_void_p),
+                ("beta", C.c_void_p)]
 
 
 class Gravity(C.Structure):
@@ -154,6 +163,8 @@ def load():
         "artemis_hip_external_gravity": (i, [PPk, C.POINTER(Gravity), d, d, vp]),
         "artemis_hip_rotating_frame_force": (i, [PPk, d, d, d, d, vp]),
         "artemis_hip_drag_source": (i, [PPk, C.POINTER(Drag), d, d, vp]),
+        "artemis_hip_cooling_source": (i, [PPk, C.POINTER(Cooling), d, d, vp]),
+        "artemis_hip_cooling_table_fill": (i, [PPk, vp, vp, C.POINTER(Cooling), i, vp, vp]),
         "artemis_hip_stage_fused": (i, [PPk, C.POINTER(StageArgs), vp]),
         "artemis_hip_stage_general": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
         "artemis_hip_zero_diffusion_flux": (i, [PPk, vp]),
@@ -210,7 +221,8 @@ EXPORTS_HIP = [
     "artemis_hip_deep_copy_conserved", "artemis_hip_estimate_dt", "artemis_hip_estimate_dt_async",
     "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_metric_count",
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_rotating_frame_force",
-    "artemis_hip_drag_source", "artemis_hip_stage_general", "artemis_hip_zero_diffusion_flux",
+    "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",
+    "artemis_hip_stage_general", "artemis_hip_zero_diffusion_flux",
     "artemis_hip_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
     "artemis_hip_diffusion_dt", "artemis_hip_diffusion_radial_fill", "artemis_hip_halo_count", "artemis_hip_halo_count_ext",
     "artemis_hip_halo_pack_ext", "artemis_hip_halo_unpack_ext",

@@ -206,15 +206,21 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
   if (int rc = validate(p)) return rc;
   if (!bc) return fail(ARTEMIS_HIP_EINVAL, "null bc array");
   for (int i = 0; i < 6 * p->nblocks; ++i) {
-    if (bc[i] < ARTEMIS_BC_PERIODIC || bc[i] > ARTEMIS_BC_DISK_EXTRAP)
+    if (bc[i] < ARTEMIS_BC_PERIODIC || bc[i] > ARTEMIS_BC_DISK_VISC)
       return fail(ARTEMIS_HIP_EINVAL, "unknown boundary flag %d", bc[i]);
     const int d = (i % 6) / 2;
-    if (bc[i] == ARTEMIS_BC_IC || bc[i] == ARTEMIS_BC_DISK_EXTRAP) {
+    if (bc[i] == ARTEMIS_BC_DISK_VISC) { // disk.hpp:420-424, :452-455
+      if (d != 0)
+        return fail(ARTEMIS_HIP_EINVAL, "Viscous boundary conditions only work for the inner or outer radial boundary");
+      if (p->coords == ARTEMIS_CARTESIAN)
+        return fail(ARTEMIS_HIP_EINVAL, "Viscous boundary conditions only work with spherical/cylindrical radial boundaries");
+    }
+    if (bc[i] == ARTEMIS_BC_IC || bc[i] == ARTEMIS_BC_DISK_EXTRAP || bc[i] == ARTEMIS_BC_DISK_VISC) {
       if (!params) return fail(ARTEMIS_HIP_EINVAL, "disk conditions need artemis_bc_params_t");
       if (bc[i] == ARTEMIS_BC_IC && ((p->gas.nspecies && !params->ic_gas) || (p->dust.nspecies && !params->ic_dust)))
         return fail(ARTEMIS_HIP_EINVAL, "ic condition: ic_gas / ic_dust tables are required");
       const int nxd[3] = {p->nx1, p->nx2, p->nx3};
-      if (bc[i] == ARTEMIS_BC_DISK_EXTRAP && nxd[d] < 2)
+      if (bc[i] != ARTEMIS_BC_IC && nxd[d] < 2)
         return fail(ARTEMIS_HIP_EINVAL, "disk extrap condition needs two active zones along the face normal");
     }
     if (bc[i] == ARTEMIS_BC_CONDUCTIVE) {
@@ -287,6 +293,44 @@ int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, doub
   }
   artemis::launch_shearing_box(artemis::make_pack_view(*p), omega, qshear, dt, S(stream));
   return after_launch("RotatingFrameForce");
+}
+
+int artemis_hip_cooling_table_fill(const artemis_pack_t *p, const double *geom_host, const double *metric_host,
+                                   const artemis_cooling_t *c, int block, double *tref_host, double *beta_host) {
+  if (!p || !geom_host || !c || !tref_host || !beta_host) return fail(ARTEMIS_HIP_EINVAL, "null argument");
+  if (block < 0 || block >= p->nblocks) return fail(ARTEMIS_HIP_EINVAL, "bad block index %d", block);
+  if (!metric_host && (p->coords == ARTEMIS_SPHERICAL2D || p->coords == ARTEMIS_SPHERICAL3D))
+    return fail(ARTEMIS_HIP_EINVAL, "cooling table: spherical 2-D/3-D blocks need the host metric table");
+  const artemis::PackView P = artemis::make_pack_view(*p);
+  const double *m = metric_host ? metric_host + block * artemis::metric_block_stride(P.nj, P.nk) : nullptr;
+  for (int k = 0; k < P.nk; ++k)
+    for (int j = 0; j < P.nj; ++j)
+      for (int i = 0; i < P.ni; ++i) {
+        const artemis::DCoords co = artemis::coords_of(p->coords, geom_host + 6 * block, m, P.nj, P.nk, k, j, i);
+        double xv[3];
+        co.centre(xv);
+        const artemis::Frame fr = artemis::cyl_frame(co.sys, xv, co.cv, co.sv);
+        // TemperatureProfile<GEOM, powerlaw> (cooling.hpp:47-58), beta (beta_cooling.cpp:98-99)
+        const double T0 = c->tfloor + c->tcyl * std::pow(fr.x[0], c->cyl_plaw) +
+                          c->tsph * std::pow(artemis::sph_radius(co.sys, xv), c->sph_plaw);
+        const double efac = (T0 > 0.) ? std::exp(-c->exp_scale * fr.x[2] * fr.x[2] / T0) : 1.;
+        const long q = (static_cast<long>(k) * P.nj + j) * P.ni + i;
+        tref_host[q] = T0, beta_host[q] = c->beta_min + c->beta0 * efac;
+      }
+  return 0;
+}
+int artemis_hip_cooling_source(const artemis_pack_t *p, const artemis_cooling_t *c, double time, double dt,
+                               void *stream) {
+  (void)time;
+  if (int rc = validate(p)) return rc;
+  if (!c) return fail(ARTEMIS_HIP_EINVAL, "null cooling parameters");
+  if (p->gas.nspecies < 1) return 0;
+  if (!c->tref || !c->beta)
+    return fail(ARTEMIS_HIP_EINVAL, "cooling: tref / beta tables are required (artemis_hip_cooling_table_fill)");
+  if (!(c->cv > 0.0)) return fail(ARTEMIS_HIP_EINVAL, "cooling: specific heat cv must be positive");
+  if (!p->gas.cons0) return fail(ARTEMIS_HIP_EINVAL, "cooling: gas.cons0 table is required");
+  artemis::launch_cooling(artemis::make_pack_view(*p), *c, dt, S(stream));
+  return after_launch("CoolingSource");
 }
 
 int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, double time, double dt,

@@ -127,7 +127,9 @@ struct artemis_sim {
   Real gamma = 1.66666666667, dfloor_gas = 1e-20, siefloor_gas = 1e-20, de_switch = 0.0;
   Real dfloor_dust = 1e-20, cfl_gas = 0.8, cfl_dust = 0.8;
   // optional source packages (artemis.cpp:65-72): gravity, rotating_frame, drag
-  bool do_gravity = false, do_rframe = false, do_drag = false;
+  bool do_gravity = false, do_rframe = false, do_drag = false, do_cooling = false;
+  artemis_cooling_t cool = {};
+  Field cool_tref, cool_beta; // host-filled Tref / beta of every cell (cooling.hpp:47-58, beta_cooling.cpp:98-99)
   artemis_gravity_t grav;
   Real rf_omega = 0.0, rf_qshear = 0.0;
   artemis_drag_t drag;
@@ -247,8 +249,11 @@ int parse_bc(const std::string &s, int pgen, int dir) {
   if (pgen == PG_COND && s == "conductive") return ARTEMIS_BC_CONDUCTIVE; // problem_modifier.hpp:95-108
   if (pgen == PG_DISK && s == "ic") return ARTEMIS_BC_IC;                 // problem_modifier.hpp:67-96
   if (pgen == PG_DISK && s == "extrap") return ARTEMIS_BC_DISK_EXTRAP;
-  if (pgen == PG_DISK && s == "viscous")
-    throw std::runtime_error("the disk problem's `viscous` condition (disk.hpp:415-595) is not built");
+  if (pgen == PG_DISK && s == "viscous") { // problem_modifier.hpp:98-104, disk.hpp:452-455
+    if (dir != 0)
+      throw std::runtime_error("Viscous boundary conditions only work for the inner or outer radial boundary");
+    return ARTEMIS_BC_DISK_VISC;
+  }
   throw std::runtime_error("boundary flag '" + s + "' is not built for this problem "
                            "(periodic|outflow|reflecting; strat: extrap on x1/x3, inflow on x2)");
 }
@@ -307,7 +312,8 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   do_drag = pin.GetOrAddBoolean("physics", "drag", false);
   do_viscosity = pin.GetOrAddBoolean("physics", "viscosity", false);
   do_conduction = pin.GetOrAddBoolean("physics", "conduction", false);
-  for (const char *k : {"nbody", "cooling", "radiation"})
+  do_cooling = pin.GetOrAddBoolean("physics", "cooling", false);
+  for (const char *k : {"nbody", "radiation"})
     if (pin.GetOrAddBoolean("physics", k, false))
       throw std::runtime_error(std::string("physics/") + k + " is out of scope of this build");
   // <parthenon/mesh>
@@ -367,6 +373,20 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
     if (rf_omega == 0.0) throw std::runtime_error("rotating_frame/omega cannot be zero!");
     if (coords != ARTEMIS_CARTESIAN && rf_qshear != 0.0) // rotating_frame.cpp:34-38
       throw std::runtime_error("rotating_frame/qshear must be zero for non-Cartesian coordinate systems!");
+  }
+  // <cooling> (gas/cooling/cooling.cpp:34-88); the tables are filled once the mesh exists
+  if (do_cooling) {
+    if (pin.GetString("cooling", "type") != "beta") throw std::runtime_error("Unknown cooling type");
+    cool.beta0 = pin.GetReal("cooling", "beta0");
+    cool.beta_min = pin.GetOrAddReal("cooling", "beta_min", 1e-12);
+    cool.exp_scale = pin.GetOrAddReal("cooling", "exp_scale", 0.0);
+    cool.tfloor = pin.GetOrAddReal("cooling", "tfloor", 0.0);
+    const std::string tref = pin.GetString("cooling", "tref");
+    if (tref == "nbody") throw std::runtime_error("cooling/tref = nbody needs the n-body package (out of scope of this build)");
+    if (tref != "powerlaw") throw std::runtime_error("Unknown cooling reference temperature");
+    cool.tcyl = pin.GetOrAddReal("cooling", "tcyl", 0.0), cool.cyl_plaw = pin.GetOrAddReal("cooling", "cyl_plaw", 0.0);
+    cool.tsph = pin.GetOrAddReal("cooling", "tsph", 0.0), cool.sph_plaw = pin.GetOrAddReal("cooling", "sph_plaw", 0.0);
+    cool.gm = do_gravity ? grav.gm : std::nan(""); // Null<Real>() when the gravity package is off
   }
   if (pgen == PG_STRAT) { // strat.hpp:55-70 InitStratParams reads the rotating_frame package
     if (!do_rframe) throw std::runtime_error("problem = strat requires physics/rotating_frame");
@@ -547,7 +567,7 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
           coords == ARTEMIS_CARTESIAN && !do_gravity && !do_rframe && !do_drag;
   // diffusion and the curvilinear rotating frame (which reads the stored mass fluxes) run on the
   // per-task chain
-  fused_possible = !(do_viscosity || do_conduction) && !(do_rframe && coords != ARTEMIS_CARTESIAN);
+  fused_possible = !(do_viscosity || do_conduction || do_cooling) && !(do_rframe && coords != ARTEMIS_CARTESIAN);
   tuned = tuned && fused_possible;
   use_fused = fused_possible;
   if (!use_fused) ensure_unfused();
@@ -984,6 +1004,12 @@ void artemis_sim::problem_generator() {
       bcpar.ic_gas = ic_gas.tab(), bcpar.ic_dust = do_dust ? ic_dust.tab() : nullptr;
     }
     bcpar.disk_omf = dk.omf;
+    bcpar.disk_nu0 = dk.nu0, bcpar.disk_nu_indx = dk.nu_indx, bcpar.disk_r0 = dk.r0, bcpar.disk_mdot = dk.mdot;
+    if (coords == ARTEMIS_CARTESIAN)
+      for (const Block &B : blocks)
+        for (int f = 0; f < 6; ++f)
+          if (B.bc[f] == ARTEMIS_BC_DISK_VISC) // disk.hpp:420-424
+            throw std::runtime_error("Viscous boundary conditions only work with spherical/cylindrical radial boundaries");
   }
   // DenProfile / TempProfile / PresProfile / ViscosityProfile (disk.hpp:69-135) on the host libm
   auto disk_den = [&](const Real R, const Real z) {
@@ -1292,6 +1318,18 @@ void artemis_sim::problem_generator() {
     if (ic_dust.ok()) upload_block(ic_dust, b, hd);
   }
   base = 0;
+  if (do_cooling && do_gas) {
+    cool.cv = 1.0 / ((gamma - 1.) * 1.0 * pin.GetOrAddReal("gas", "mu", 1.));
+    cool_tref.alloc(nb, 1, N), cool_beta.alloc(nb, 1, N);
+    const artemis_pack_t pk = make_pack(0);
+    std::vector<Real> ht(N), hb(N);
+    for (int b = 0; b < nb; ++b) {
+      CK(artemis_hip_cooling_table_fill(&pk, hgeom.data(), hmetric.empty() ? nullptr : hmetric.data(), &cool, b,
+                                        ht.data(), hb.data()), "cooling tables");
+      upload_block(cool_tref, b, ht), upload_block(cool_beta, b, hb);
+    }
+    cool.tref = cool_tref.tab(), cool.beta = cool_beta.tab();
+  }
   if (do_viscosity && (diff.visc.type == ARTEMIS_VISCOSITY_ALPHA || diff.visc.r_exp != 0.0)) {
     // the std::pow of the cell position in DiffusionCoeff::Get (diffusion_coeff.hpp:222-224, :262-264)
     visc_radial.alloc(nb, 1, N);
@@ -1499,6 +1537,7 @@ void artemis_sim::step_unfused() {
     if (do_gravity) CK(artemis_hip_external_gravity(&p, &grav, time, bdt, stream), "ExternalGravity");
     if (do_rframe) CK(artemis_hip_rotating_frame_force(&p, rf_omega, rf_qshear, time, bdt, stream), "RotatingFrameForce");
     if (do_drag) CK(artemis_hip_drag_source(&p, &drag, time, bdt, stream), "DragSource");
+    if (do_cooling && do_gas) CK(artemis_hip_cooling_source(&p, &cool, time, bdt, stream), "CoolingSource"); // :243-248
     CK(artemis_hip_set_aux(&p, stream), "SetAuxillaryFields");
     CK(artemis_hip_cons_to_prim(&p, stream), "ConsToPrim");
     fill_ghosts(base);

@@ -18,6 +18,7 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
 void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, double dt, hipStream_t s);
 void launch_shearing_box(const PackView &P, double omega, double qshear, double dt, hipStream_t s);
 void launch_rotating_frame(const PackView &P, double omega, double dt, hipStream_t s);
+void launch_cooling(const PackView &P, const artemis_cooling_t &C, double dt, hipStream_t s);
 // dt_dev (optional DEVICE scalar) replaces dt
 void launch_drag_source(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
                         hipStream_t s);

@@ -167,6 +167,40 @@ __global__ __launch_bounds__(TX *TY) void rotating_frame_kernel(const PackView P
   for (int n = 0; n < P.dust.ns; ++n) body(P.dust, 4 * P.dust.ns, n, false);
 }
 
+// Gas::Cooling::BetaCooling<GEOM, powerlaw> (beta_cooling.cpp:40-126); Tref and beta of the cell come
+// from the host-filled tables.
+__global__ __launch_bounds__(TX *TY) void cooling_kernel(const PackView P, const artemis_cooling_t C, double dt) {
+  INTERIOR_CELL
+  const DCoords co = make_coords(P, b, k, j, i);
+  double xv[3], hx[3];
+  co.centre(xv);
+  scale_factors_of(co, hx);
+  const Frame fr = cyl_frame(co.sys, xv, co.cv, co.sv);
+  const double rsph2 = fr.x[0] * fr.x[0] + fr.x[2] * fr.x[2];
+  const double ir1 = 1.0 / sqrt(rsph2);
+  const double T0 = C.tref[b][c], beta = C.beta[b][c];
+  const double omdt = dt * sqrt(C.gm * ir1 * ir1 * ir1);
+  const FluidView &G = P.gas;
+  const int ns = G.ns, nv = 6 * ns;
+  for (int n = 0; n < ns; ++n) {
+    // GetSpecificInternalEnergy (artemis_utils.hpp:43-62)
+    const double dens = G.cons0[b * nv + n][c];
+    const double u_d = amax(dens, G.dfloor);
+    const double rv1 = G.cons0[b * nv + ns + 3 * n + 0][c] / hx[0];
+    const double rv2 = G.cons0[b * nv + ns + 3 * n + 1][c] / hx[1];
+    const double rv3 = G.cons0[b * nv + ns + 3 * n + 2][c] / hx[2];
+    const double ke = 0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)) / u_d;
+    double *etot = G.cons0[b * nv + 4 * ns + n], *eint = G.cons0[b * nv + 5 * ns + n];
+    const double e_cons = etot[c];
+    const double ue_cons = e_cons - ke;
+    double sie = (ue_cons > G.de_switch * e_cons) ? ue_cons / u_d : eint[c] / u_d;
+    sie = amax(sie, G.siefloor);
+    const double Tn = amax(0.0, sie / C.cv);
+    const double dE = -dens * C.cv * omdt / (beta + omdt) * (Tn - T0);
+    etot[c] += dE, eint[c] += dE;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Drag::DragSource (drag.cpp:89-175) with damp_to_visc = false.
 __device__ __forceinline__ void damping_ramps(const artemis_damping_t &p, const artemis_drag_t &D,
@@ -357,6 +391,9 @@ void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, doub
 }
 void launch_shearing_box(const PackView &P, double omega, double qshear, double dt, hipStream_t s) {
   hipLaunchKernelGGL(shearing_box_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, omega, qshear, dt);
+}
+void launch_cooling(const PackView &P, const artemis_cooling_t &C, double dt, hipStream_t s) {
+  hipLaunchKernelGGL(cooling_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, C, dt);
 }
 void launch_rotating_frame(const PackView &P, double omega, double dt, hipStream_t s) {
   hipLaunchKernelGGL(rotating_frame_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, omega, dt);

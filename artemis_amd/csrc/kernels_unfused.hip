@@ -593,11 +593,13 @@ __global__ __launch_bounds__(256) void conductive_bc_kernel(const CondBcArgs a, 
 // DiskICImpl (:325-354).
 // `extrap` (disk.hpp:634-825): power-law extrapolation in ln(x) (x for Cartesian) of density,
 // sie and the inertial azimuthal velocity along the fill direction, from the first two active
-// zones; R and z velocities copied.  This one evaluates log / exp of the STATE on the device:
+// zones; R and z velocities copied.  `viscous` (disk.hpp:415-595, x1 faces): the same, except that the
+// gas density and radial velocity follow the steady viscous-accretion solution with the disk's
+// nu(R) = nu0 (R/r0)^nu_indx and mdot.  These two evaluate log / exp / pow on the device:
 // agreement with a host libm is to rounding (a few ulp), not bitwise.
 struct DiskBcArgs {
-  int d, side, ng, st, en, extrap;
-  double omf;
+  int d, side, ng, st, en, extrap, visc;
+  double omf, nu0, nu_indx, r0, mdot;
   double *const *ic_gas, *const *ic_dust;
 };
 __global__ __launch_bounds__(256) void disk_bc_kernel(const DiskBcArgs a, const FillTabs t, const PackView P) {
@@ -650,19 +652,34 @@ __global__ __launch_bounds__(256) void disk_bc_kernel(const DiskBcArgs a, const 
   if (nsg) {
     double *rho = t.gas[t.b * 6 * nsg], *sie = t.gas[t.b * 6 * nsg + 5 * nsg];
     double *v[3] = {t.gas[t.b * 6 * nsg + nsg], t.gas[t.b * 6 * nsg + nsg + 1], t.gas[t.b * 6 * nsg + nsg + 2]};
-    const double dgrho = log(rho[cP] / rho[cM]);
+    const double dgrho = a.visc ? 0.0 : log(rho[cP] / rho[cM]);
     const double dgsie = log(sie[cP] / sie[cM]);
-    const double rhog = rho[cA] * exp(dgrho * xmadx);
+    double rhog = rho[cA] * exp(dgrho * xmadx);
     const double sieg = sie[cA] * exp(dgsie * xmadx);
     const double gva[3] = {v[0][cA], v[1][cA], v[2][cA]};
     const double gvp1[3] = {v[0][cP], v[1][cP], v[2][cP]};
     const double gvm1[3] = {v[0][cM], v[1][cM], v[2][cM]};
     const double gvp = vdot(gva, epa) + a.omf * fa.x[0];
-    const double gvR = vdot(gva, eRa);
+    double gvR = vdot(gva, eRa);
     const double gvz = vdot(gva, eza);
     const double gvp1p = vdot(gvp1, epp1) + a.omf * fp1.x[0];
     const double gvm1p = vdot(gvm1, epm1) + a.omf * fm1.x[0];
     dgvp = log(gvp1p / gvm1p);
+    if (a.visc) { // DiskBoundaryVisc (disk.hpp:415-595): steady viscous accretion sets rho and v_R
+      const double nua = a.nu0 * pow(fa.x[0] / a.r0, a.nu_indx);
+      const double nug = a.nu0 * pow(fr.x[0] / a.r0, a.nu_indx);
+      const double vpg = gvp * exp(dgvp * xmadx);
+      const double rhoa = rho[cA];
+      if (INNER) {
+        rhog = rhoa * nua / nug;
+        gvR = -1.5 * nug / fr.x[0];
+      } else { // dFnu/dl = Mdot
+        const double lg = fr.x[0] * vpg;
+        const double la = fa.x[0] * gvp;
+        rhog = (3.0 * M_PI * rhoa * nua * la + a.mdot * (lg - la)) / (3.0 * M_PI * nug * lg);
+        gvR = -a.mdot / (2 * M_PI * fr.x[0] * rhog);
+      }
+    }
     const double gvcyl[3] = {gvR, gvp * exp(dgvp * xmadx) - a.omf * fr.x[0], gvz};
     const double gvel[3] = {vdot(gvcyl, fr.e1), vdot(gvcyl, fr.e2), vdot(gvcyl, fr.e3)};
     rho[c] = rhog, sie[c] = sieg;
@@ -892,10 +909,11 @@ static void launch_bc_sequential(const PackView &P, int b, const int *bc6,
           a.g_temp = par->cond_temp, a.flux = par->cond_flux, a.gx = par->cond_g[d];
           a.coeff = par->cond_coeff, a.cv = par->cond_cv, a.gm1 = P.gm1, a.type = par->cond_type;
           hipLaunchKernelGGL(conductive_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P);
-        } else if (flag == ARTEMIS_BC_IC || flag == ARTEMIS_BC_DISK_EXTRAP) {
+        } else if (flag == ARTEMIS_BC_IC || flag == ARTEMIS_BC_DISK_EXTRAP || flag == ARTEMIS_BC_DISK_VISC) {
           DiskBcArgs a;
           a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
-          a.extrap = (flag == ARTEMIS_BC_DISK_EXTRAP), a.omf = par->disk_omf;
+          a.extrap = (flag != ARTEMIS_BC_IC), a.visc = (flag == ARTEMIS_BC_DISK_VISC), a.omf = par->disk_omf;
+          a.nu0 = par->disk_nu0, a.nu_indx = par->disk_nu_indx, a.r0 = par->disk_r0, a.mdot = par->disk_mdot;
           a.ic_gas = par->ic_gas, a.ic_dust = par->ic_dust;
           hipLaunchKernelGGL(disk_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P);
         } else if (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW) {
@@ -922,7 +940,8 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
       a.bc[f] = (f / 2 < P.ndim) ? bc[b * 6 + f] : ARTEMIS_BC_NONE;
       any = any || (a.bc[f] != ARTEMIS_BC_NONE);
       user = user || a.bc[f] == ARTEMIS_BC_STRAT_EXTRAP || a.bc[f] == ARTEMIS_BC_STRAT_INFLOW ||
-             a.bc[f] == ARTEMIS_BC_CONDUCTIVE || a.bc[f] == ARTEMIS_BC_IC || a.bc[f] == ARTEMIS_BC_DISK_EXTRAP;
+             a.bc[f] == ARTEMIS_BC_CONDUCTIVE || a.bc[f] == ARTEMIS_BC_IC || a.bc[f] == ARTEMIS_BC_DISK_EXTRAP ||
+             a.bc[f] == ARTEMIS_BC_DISK_VISC;
     }
     if (!any) continue;
     if (user) {

@@ -154,6 +154,8 @@ class MeshBlockPack:
             if disk is not None:
                 bp.ic_gas, bp.ic_dust = disk.get("ic_gas"), disk.get("ic_dust")
                 bp.disk_omf = disk.get("omf", 0.0)
+                bp.disk_nu0, bp.disk_nu_indx = disk.get("nu0", 0.0), disk.get("nu_indx", 0.0)
+                bp.disk_r0, bp.disk_mdot = disk.get("r0", 1.0), disk.get("mdot", 0.0)
             if strat is not None:
                 bp.qshear, bp.omega = strat
             if conductive is not None:  # dict(temp, flux, g=(gx1,gx2,gx3), coeff, cv, type)
@@ -226,6 +228,32 @@ class MeshBlockPack:
                                         device=self.dev)
         D.visc.radial = self._radial_tab.data_ptr()
         return self._radial
+
+    def cooling_params(self, gamma, gm, beta0, beta_min=1e-12, exp_scale=0.0, tfloor=0.0, tcyl=0.0, cyl_plaw=0.0,
+                       tsph=0.0, sph_plaw=0.0, mu=1.0):
+        """capi.Cooling from the <cooling> keys, with the Tref / beta tables filled on the host
+        (artemis_hip_cooling_table_fill) and uploaded."""
+        c = capi.Cooling()
+        c.beta0, c.beta_min, c.exp_scale, c.tfloor = beta0, beta_min, exp_scale, tfloor
+        c.tcyl, c.cyl_plaw, c.tsph, c.sph_plaw = tcyl, cyl_plaw, tsph, sph_plaw
+        c.gm = gm if gm is not None else float("nan")
+        c.cv = 1.0 / ((gamma - 1.0) * 1.0 * mu)
+        n = self.pack.nblocks
+        shape = (n,) + tuple(self.gas_prim.shape[2:])
+        t0, be = np.zeros(shape), np.zeros(shape)
+        mh = getattr(self, "metric_host", None)
+        for b in range(n):
+            capi.check(self.L.artemis_hip_cooling_table_fill(
+                C.byref(self.pack), self.geom_host.ctypes.data, mh.ctypes.data if mh is not None else None,
+                C.byref(c), b, t0[b].ctypes.data, be[b].ctypes.data))
+        self._cool = (torch.from_numpy(t0).to(self.dev), torch.from_numpy(be).to(self.dev))
+        self._cool_tab = tuple(torch.tensor([a[b].data_ptr() for b in range(n)], dtype=torch.int64, device=self.dev)
+                               for a in self._cool)
+        c.tref, c.beta = self._cool_tab[0].data_ptr(), self._cool_tab[1].data_ptr()
+        return c
+
+    def CoolingSource(self, time, dt, cooling):
+        self._call(self.L.artemis_hip_cooling_source, C.byref(cooling), time, dt)
 
     def RotatingFrameForce(self, omega, qshear, time, dt):
         self._call(self.L.artemis_hip_rotating_frame_force, omega, qshear, time, dt)

@@ -65,7 +65,8 @@ enum artemis_bc { ARTEMIS_BC_PERIODIC = 0, ARTEMIS_BC_OUTFLOW = 1, ARTEMIS_BC_RE
                   /* user conditions of the `disk` problem (pgen/disk.hpp, registered as `ic` /
                    * `extrap` at problem_modifier.hpp:67-96), any face: */
                   ARTEMIS_BC_IC = 7,          /* DiskBoundaryIC, disk.hpp:597-632 */
-                  ARTEMIS_BC_DISK_EXTRAP = 8  /* DiskBoundaryExtrap, disk.hpp:634-825 */ };
+                  ARTEMIS_BC_DISK_EXTRAP = 8, /* DiskBoundaryExtrap, disk.hpp:634-825 */
+                  ARTEMIS_BC_DISK_VISC = 9    /* DiskBoundaryVisc (`viscous`), disk.hpp:415-595, x1 faces */ };
 enum artemis_gravity_type { ARTEMIS_GRAVITY_UNIFORM = 1, ARTEMIS_GRAVITY_POINT = 2 };
 enum artemis_drag_type { ARTEMIS_DRAG_SIMPLE_DUST = 1, ARTEMIS_DRAG_SELF = 2 }; /* drag.hpp:57 */
 enum artemis_drag_model { ARTEMIS_DRAG_CONSTANT = 0, ARTEMIS_DRAG_STOKES = 1 }; /* drag.hpp:58 */
@@ -177,6 +178,8 @@ typedef struct artemis_bc_params {
    * of the state on the device: it matches a host libm to rounding, not bitwise. */
   double *const *ic_gas, *const *ic_dust;
   double disk_omf;
+  /* DISK_VISC: ViscosityProfile nu0 (R/r0)^nu_indx (disk.hpp:131-135) and the accretion rate */
+  double disk_nu0, disk_nu_indx, disk_r0, disk_mdot;
 } artemis_bc_params_t;
 int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_bc_params_t *params,
                          void *stream);
@@ -223,6 +226,26 @@ typedef struct artemis_drag {
 } artemis_drag_t;
 int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, double time, double dt,
                             void *stream);
+
+/* Gas::Cooling::CoolingSource<GEOM> (gas/cooling/cooling.cpp:94-106 -> beta_cooling.cpp:40-126), task at
+ * artemis_driver.cpp:243-248 (after DragSource, before SetAuxillaryFields): backward-Euler
+ * relaxation of the gas temperature towards Tref(R, r) = tfloor + tcyl R^a + tsph r^b on the
+ * time scale beta / Omega_K, beta = beta_min + beta0 exp(-exp_scale z^2 / Tref); reads cons0,
+ * updates total and internal energy.  Tref and beta are functions of the cell position with
+ * std::pow / std::exp in them: the adapter tabulates both once per mesh on the host
+ * (artemis_hip_cooling_table_fill; arrays over the entire block) and the task stays bit-exact.
+ * tref = nbody: ARTEMIS_HIP_EUNSUPPORTED. */
+typedef struct artemis_cooling {
+  double beta0, beta_min, exp_scale;           /* <cooling> beta0, beta_min, exp_scale */
+  double tfloor, tcyl, cyl_plaw, tsph, sph_plaw; /* TempParams, cooling.hpp:37-43 */
+  double gm;                                   /* gravity package's gm (NaN = Null<Real>() when gravity is off) */
+  double cv;                                   /* IdealGas specific heat */
+  const double *const *tref, *const *beta;     /* DEVICE tables [nblocks] of per-cell arrays */
+} artemis_cooling_t;
+int artemis_hip_cooling_table_fill(const artemis_pack_t *p, const double *geom_host, const double *metric_host,
+                                   const artemis_cooling_t *c, int block, double *tref_host, double *beta_host);
+int artemis_hip_cooling_source(const artemis_pack_t *p, const artemis_cooling_t *c, double time, double dt,
+                               void *stream);
 
 /* ---- Fused stage (the fast path) --------------------------------------------------------
  * One RK stage of artemis_driver.cpp:182-261 with every optional package disabled, i.e.

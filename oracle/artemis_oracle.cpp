@@ -45,7 +45,7 @@ enum { RS_HLLC = 0, RS_HLLE = 1, RS_LLF = 2 };
 enum { RC_PCM = 0, RC_PLM = 1, RC_PPM = 2 };
 enum { FL_GAS = 0, FL_DUST = 1 };
 enum { BC_PERIODIC = 0, BC_OUTFLOW = 1, BC_REFLECT = 2, BC_NONE = 3, BC_STRAT_EXTRAP = 4,
-       BC_STRAT_INFLOW = 5, BC_CONDUCTIVE = 6, BC_DISK_IC = 7, BC_DISK_EXTRAP = 8 }; // 4/5: the `strat` pgen's user conditions (problem_modifier.hpp:114-128)
+       BC_STRAT_INFLOW = 5, BC_CONDUCTIVE = 6, BC_DISK_IC = 7, BC_DISK_EXTRAP = 8, BC_DISK_VISC = 9 }; // 4/5: the `strat` pgen's user conditions (problem_modifier.hpp:114-128)
 enum { INT_RK1 = 0, INT_RK2 = 1, INT_VL2 = 2, INT_RK3 = 3 };
 
 struct oracle_cfg {
@@ -121,6 +121,10 @@ struct Sim {
     Real Gamma = 1, gamma_gas = 1.4, alpha = 0, nu0 = 0, nu_indx = 0, mdot = 0, temp_soft2 = 0;
     bool quiet_start = false;
   } disk;
+  struct { // gas/cooling/cooling.cpp:34-88: beta cooling towards a power-law reference temperature
+    bool on = false;
+    Real beta0 = 0, beta_min = 1e-12, escale = 0, tfloor = 0, tcyl = 0, cyl_plaw = 0, tsph = 0, sph_plaw = 0;
+  } cool;
   // optional: initial primitives kept by a caller; when present the `ic` condition copies ghost
   // zones from here instead of re-evaluating the profile (same values: the profile is static)
   std::vector<Real> ic_g, ic_d;
@@ -1858,6 +1862,44 @@ Real diffusion_dt(const Sim &s, const Sim::DiffCoeff &dp) {
 }
 
 // ---------------------------------------------------------------------------------------
+// gas/cooling/beta_cooling.cpp:40-126 BetaCooling<GEOM, powerlaw> (cooling.cpp:94-106 dispatch,
+// cooling.hpp:47-58 TemperatureProfile): backward-Euler relaxation of T towards T0(R, r) on the
+// local orbital time scaled by beta; acts on the conserved total and internal energies.
+void cooling_source(Sim &s, Real /*time*/, Real dt) {
+  if (!s.cool.on || !s.c.ns_gas) return;
+  const int nsp = s.c.ns_gas;
+  const Real gm = (s.grav.type != 0) ? s.grav.gm : std::numeric_limits<Real>::quiet_NaN(); // Null<Real>()
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = s.ks; k <= s.ke; ++k)
+    for (int j = s.js; j <= s.je; ++j)
+      for (int i = s.is; i <= s.ie; ++i) {
+        const Coords coords(s, k, j, i);
+        const Real xv[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
+        const Frame fr = to_cyl_frame(coords, xv);
+        const Real *xcyl = fr.x;
+        const Real rsph2 = xcyl[0] * xcyl[0] + xcyl[2] * xcyl[2];
+        Real ir1 = 1.0 / std::sqrt(rsph2);
+        const Real T0 = s.cool.tfloor + s.cool.tcyl * std::pow(xcyl[0], s.cool.cyl_plaw) +
+                        s.cool.tsph * std::pow(to_sph_radius(coords, xv), s.cool.sph_plaw);
+        const Real efac = (T0 > 0.) ? std::exp(-s.cool.escale * xcyl[2] * xcyl[2] / T0) : 1.;
+        const Real beta = s.cool.beta_min + s.cool.beta0 * efac;
+        const Real omdt = dt * std::sqrt(gm * ir1 * ir1 * ir1);
+        Real hx[3];
+        coords.GetScaleFactors(hx);
+        const size_t c = IDX(s, k, j, i);
+        for (int n = 0; n < nsp; ++n) {
+          const Real sie = specific_internal_energy(s, n, c, hx);
+          const Real dens = s.gu0[n * s.N + c];
+          const Real cv = s.cv;
+          const Real Tn = std::max(0.0, sie / s.cv);
+          const Real dE = -dens * cv * omdt / (beta + omdt) * (Tn - T0);
+          s.gu0[(4 * nsp + n) * s.N + c] += dE;
+          s.gu0[(5 * nsp + n) * s.N + c] += dE;
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------------------
 // derived/fill_derived.cpp:30-75 SetAuxillaryFields + utils/artemis_utils.hpp:43-62
 // GetSpecificInternalEnergy (hx = volume-averaged scale factors, fill_derived.cpp:127 analogue).
 void set_aux(Sim &s) {
@@ -2027,7 +2069,7 @@ void fill_dir(Sim &s, std::vector<Real> &prim, int nvar, int nsp, bool gas, int 
   for (int side = 0; side < 2; ++side) {
     const int bc = s.c.bc[2 * d + side];
     if (bc == BC_NONE || bc == BC_STRAT_EXTRAP || bc == BC_STRAT_INFLOW || bc == BC_CONDUCTIVE ||
-        bc == BC_DISK_IC || bc == BC_DISK_EXTRAP)
+        bc == BC_DISK_IC || bc == BC_DISK_EXTRAP || bc == BC_DISK_VISC)
       continue;
     if ((pass == 0) != (bc == BC_PERIODIC)) continue;
     for (int n = 0; n < nvar; ++n) {
@@ -2269,7 +2311,7 @@ inline void disk_ic_cell(Sim &s, int k, int j, int i) {
 }
 // disk.hpp:597-632 DiskBoundaryIC and :634-825 DiskBoundaryExtrap on the ghost slab of face
 // (d, side), over the entire extent of the other dimensions (parthenon par_for_bndry, upstream).
-void disk_bc(Sim &s, int d, int side, bool extrap) {
+void disk_bc(Sim &s, int d, int side, bool extrap, bool visc = false) {
   const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
   const bool INNER = (side == 0);
   const int lo[3] = {s.is, s.js, s.ks}, hi[3] = {s.ie, s.je, s.ke};
@@ -2320,22 +2362,37 @@ void disk_bc(Sim &s, int d, int side, bool extrap) {
         const Real *rho = s.gprim.data(), *sie = s.gprim.data() + (5 * ng_) * s.N;
         Real dgvp = 0.0;
         if (ng_) {
-          Real dgrho = std::log(rho[cP] / rho[cM]);
+          Real dgrho = visc ? 0.0 : std::log(rho[cP] / rho[cM]);
           Real dgsie = std::log(sie[cP] / sie[cM]);
           const Real grhoexp = std::exp(dgrho * xmadx);
           const Real gsieexp = std::exp(dgsie * xmadx);
-          const Real rhog = rho[cA] * grhoexp;
+          Real rhog = rho[cA] * grhoexp;
           const Real sieg = sie[cA] * gsieexp;
           auto vel = [&](int q, size_t cc) { return s.gprim[(ng_ + q) * s.N + cc]; };
           Real gva[3] = {vel(0, cA), vel(1, cA), vel(2, cA)};
           Real gvp1[3] = {vel(0, cP), vel(1, cP), vel(2, cP)};
           Real gvm1[3] = {vel(0, cM), vel(1, cM), vel(2, cM)};
           const Real gvp = vdot(gva, epa) + dp.omf * fa.x[0];
-          const Real gvR = vdot(gva, eRa);
+          Real gvR = vdot(gva, eRa);
           const Real gvz = vdot(gva, eza);
           const Real gvp1p = vdot(gvp1, epp1) + dp.omf * fp1.x[0];
           const Real gvm1p = vdot(gvm1, epm1) + dp.omf * fm1.x[0];
           dgvp = std::log(gvp1p / gvm1p);
+          if (visc) { // disk.hpp:415-595 DiskBoundaryVisc: steady viscous accretion sets rho and v_R
+            const Real nua = disk_visc(dp, fa.x[0]);
+            const Real nug = disk_visc(dp, fr.x[0]);
+            const Real vpg = gvp * std::exp(dgvp * xmadx);
+            const Real rhoa = rho[cA];
+            if (INNER) {
+              rhog = rhoa * nua / nug;
+              gvR = -1.5 * nug / fr.x[0];
+            } else { // dFnu/dl = Mdot
+              const Real lg = fr.x[0] * vpg;
+              const Real la = fa.x[0] * gvp;
+              rhog = (3.0 * M_PI * rhoa * nua * la + dp.mdot * (lg - la)) / (3.0 * M_PI * nug * lg);
+              gvR = -dp.mdot / (2 * M_PI * fr.x[0] * rhog);
+            }
+          }
           const Real gvcyl[3] = {gvR, gvp * std::exp(dgvp * xmadx) - dp.omf * fr.x[0], gvz};
           const Real gvel[3] = {vdot(gvcyl, fr.e1), vdot(gvcyl, fr.e2), vdot(gvcyl, fr.e3)};
           s.gprim[0 * s.N + c] = rhog;
@@ -2376,6 +2433,7 @@ void apply_bcs(Sim &s) {
             strat_bc(s, d, side);
           if (bc == BC_CONDUCTIVE) conductive_bc(s, d, side);
           if (bc == BC_DISK_IC || bc == BC_DISK_EXTRAP) disk_bc(s, d, side, bc == BC_DISK_EXTRAP);
+          if (bc == BC_DISK_VISC && d == 0) disk_bc(s, d, side, true, true); // x1 faces only (:448-455)
         }
     }
 }
@@ -2428,6 +2486,7 @@ void step(Sim &s, exchange_fn xchg, void *ctx) {
     external_gravity(s, s.time, bdt);                                    // :224-228
     rotating_frame_force(s, bdt);                                        // :231-235
     drag_source(s, bdt);                                                 // :238-241
+    cooling_source(s, s.time, bdt);                                      // :243-248
     set_aux(s);                                                          // :251-252
     cons_to_prim(s);                                                     // :255
     if (xchg) xchg(ctx);                                                 // :258 (inter-block)
@@ -2696,6 +2755,14 @@ void oracle_set_gravity_window(void *h, double tstart, double tstop) {
   Sim &s = *static_cast<Sim *>(h);
   s.grav.tstart = tstart, s.grav.tstop = tstop;
 }
+// <cooling> type = beta, tref = powerlaw (cooling.cpp:34-63)
+void oracle_set_cooling(void *h, const double *p) {
+  Sim &s = *static_cast<Sim *>(h);
+  s.cool.on = true;
+  s.cool.beta0 = p[0], s.cool.beta_min = p[1], s.cool.escale = p[2], s.cool.tfloor = p[3];
+  s.cool.tcyl = p[4], s.cool.cyl_plaw = p[5], s.cool.tsph = p[6], s.cool.sph_plaw = p[7];
+}
+void oracle_cooling_source(void *h, double time, double dt) { cooling_source(*static_cast<Sim *>(h), time, dt); }
 void oracle_set_rotating_frame(void *h, double omega, double qshear) {
   Sim &s = *static_cast<Sim *>(h);
   s.rframe.on = true, s.rframe.omega = omega, s.rframe.qshear = qshear;

@@ -15,7 +15,7 @@ _LIB = os.path.join(_HERE, "_build", "liboracle.so")
 RS = {"hllc": 0, "hlle": 1, "llf": 2}
 RC = {"pcm": 0, "plm": 1, "ppm": 2}
 BC = {"periodic": 0, "outflow": 1, "reflecting": 2, "reflect": 2, "none": 3,
-      "extrap": 4, "inflow": 5, "conductive": 6, "ic": 7, "disk_extrap": 8}  # 4/5: the strat pgen's user conditions (problem_modifier.hpp:114-128)
+      "extrap": 4, "inflow": 5, "conductive": 6, "ic": 7, "disk_extrap": 8, "viscous": 9}  # 4/5: the strat pgen's user conditions (problem_modifier.hpp:114-128)
 INTEG = {"rk1": 0, "rk2": 1, "vl2": 2, "rk3": 3}
 GAS, DUST = 0, 1
 
@@ -127,6 +127,8 @@ def lib():
         L.oracle_qflux.argtypes = [vp, i]
         L.oracle_pgen_gaussian_bump.argtypes = [vp, C.POINTER(d)] + [d] * 11
         L.oracle_pgen_conduction.argtypes = [vp] + [d] * 6
+        L.oracle_set_cooling.argtypes = [vp, C.POINTER(d)]
+        L.oracle_cooling_source.argtypes = [vp, d, d]
         L.oracle_pgen_disk.argtypes = [vp, C.POINTER(d)]
         L.oracle_pgen_disk.restype = i
         _lib = L
@@ -329,6 +331,14 @@ class Oracle:
         self.L.oracle_pgen_conduction(self.h, gas_rho, *gas_v, gas_temp, flux)
         if post_init:
             self.post_init()
+
+    def set_cooling(self, beta0, beta_min=1e-12, exp_scale=0.0, tfloor=0.0, tcyl=0.0, cyl_plaw=0.0, tsph=0.0,
+                    sph_plaw=0.0):
+        """<cooling> type = beta, tref = powerlaw (gas/cooling/cooling.cpp:34-63)"""
+        self.L.oracle_set_cooling(self.h, (C.c_double * 8)(beta0, beta_min, exp_scale, tfloor, tcyl, cyl_plaw,
+                                                          tsph, sph_plaw))
+
+    def CoolingSource(self, time, dt): self.L.oracle_cooling_source(self.h, time, dt)
 
     def pgen_disk(self, r0=1.0, rho0=1.0, dslope=-2.25, h0=0.05, polytropic_index=None, dens_min=1.0e-5,
                   pres_min=1.0e-8, rexp=0.0, rcav=0.0, l0=0.0, dust_to_gas=0.01, temp_soft=0.0,

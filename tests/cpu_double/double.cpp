@@ -245,7 +245,8 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
       for (int d = 0; d < 3; ++d) s.grav.g[d] = par->cond_g[d];
       s.cond.type = par->cond_type, s.cond.hcond_0 = s.cond.kappa_0 = par->cond_coeff;
       if (par->cond_cv > 0.0) s.cv = par->cond_cv;
-      s.disk.omf = par->disk_omf;
+      s.disk.omf = par->disk_omf, s.disk.nu0 = par->disk_nu0, s.disk.nu_indx = par->disk_nu_indx;
+      s.disk.r0 = par->disk_r0, s.disk.mdot = par->disk_mdot;
       if (par->ic_gas) s.ic_g.resize(s.gprim.size()), B.in(s.ic_g, par->ic_gas, s.nvg);
       if (par->ic_dust) s.ic_d.resize(s.dprim.size()), B.in(s.ic_d, par->ic_dust, s.nvd);
     }
@@ -277,6 +278,26 @@ int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, doub
     if (p->coords != ARTEMIS_CARTESIAN) B.load_fluxes(); // RotatingFrameImpl reads the mass fluxes
     rotating_frame_force(*B.s, dt);
     B.out(B.s->gu0, p->gas.cons0, B.s->nvg), B.out(B.s->du0, p->dust.cons0, B.s->nvd);
+  }
+  return 0;
+}
+static void set_cooling(Sim &s, const artemis_cooling_t *c) {
+  s.cool.on = true, s.cool.beta0 = c->beta0, s.cool.beta_min = c->beta_min, s.cool.escale = c->exp_scale;
+  s.cool.tfloor = c->tfloor, s.cool.tcyl = c->tcyl, s.cool.cyl_plaw = c->cyl_plaw, s.cool.tsph = c->tsph;
+  s.cool.sph_plaw = c->sph_plaw, s.cv = c->cv;
+  s.grav.type = (c->gm == c->gm) ? 2 : 0, s.grav.gm = c->gm;
+}
+int artemis_hip_cooling_table_fill(const artemis_pack_t *, const double *, const double *, const artemis_cooling_t *,
+                                   int, double *, double *) {
+  return 0; // the oracle evaluates Tref and beta per cell itself
+}
+int artemis_hip_cooling_source(const artemis_pack_t *p, const artemis_cooling_t *c, double time, double dt, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    B.load_state();
+    set_cooling(*B.s, c);
+    cooling_source(*B.s, time, dt);
+    B.out(B.s->gu0, p->gas.cons0, B.s->nvg);
   }
   return 0;
 }

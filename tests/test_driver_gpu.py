@@ -735,3 +735,38 @@ def test_disk_decks_own_block_layout(hiplib, g):
         sl = tuple(slice(q * 32, q * 32 + part.shape[3 - d]) for d, q in ((2, bk), (1, bj), (0, bi)))
         ref = full[(slice(None),) + sl]
         disk_close(part, ref, 1e-12, blk, whole=full)
+
+
+def test_alpha_disk_deck_against_oracle_and_reference_pin(hiplib):
+    """inputs/diffusion/alpha_disk.in as tst/scripts/diffusion/alpha_disk.py:44-75 runs it (1-D axisymmetric,
+    64 zones, alpha = 0.1, h = 0.1, beta cooling to T = h^2/R, `viscous` conditions): 2000 cycles
+    against the oracle to 1e-11 of the field maxima (the `viscous` ghost zones take device log / exp /
+    pow), then the full run to t = 8000 against the reference test's bound -- mean relative errors of
+    Sigma against R^-1/2 and of the accretion rate against 3 pi alpha h^2 <= 2e-3 (oracle: 8.8e-4, 1.81e-3)."""
+    from artemis_amd.driver import Simulation
+    from test_oracle_pins import alpha_disk_oracle
+    al, h = 0.1, 0.1
+    ov = ["parthenon/mesh/x1max=2.0", "physics/viscosity=true", f"gas/viscosity/alpha={al:.8e}",
+          f"cooling/tcyl={h ** 2:.8e}", "cooling/cyl_plaw=-1.0", f"problem/mdot={al * h ** 2 * 3 * np.pi:.8e}",
+          "problem/quiet_start=true", f"problem/h0={h:.8e}", "problem/dslope=0.0", "problem/flare=0.0",
+          "artemis/coordinates=axisymmetric", "parthenon/mesh/nx1=64", "parthenon/meshblock/nx1=64",
+          "parthenon/mesh/nx2=1", "parthenon/meshblock/nx2=1", "parthenon/mesh/nx3=1", "parthenon/meshblock/nx3=1",
+          "parthenon/mesh/x2min=-0.5", "parthenon/mesh/x2max=0.5"]
+    s = Simulation(DECK("diffusion", "alpha_disk.in"), ov + ["parthenon/time/tlim=8000.0", "parthenon/time/nlim=2000"])
+    # the test script prints mdot with 8 significant digits: same override for the oracle
+    o = alpha_disk_oracle()
+    assert np.array_equal(s.interior(s.field("gas.prim")), o.interior(o.gprim))
+    s.evolve(), o.evolve(8e3, 2000)
+    assert s.ncycle == o.ncycle == 2000 and abs(s.time - o.time) < 1e-11 * o.time
+    disk_close(s.interior(s.field("gas.prim")), o.interior(o.gprim), 1e-11)
+    f = Simulation(DECK("diffusion", "alpha_disk.in"), ov + ["parthenon/time/tlim=8000.0"])
+    f.evolve()
+    assert abs(f.time - 8e3) < 1e-9 and f.ncycle > 150000
+    P = f.interior(f.field("gas.prim"))
+    r = 0.3 + (np.arange(64) + 0.5) * 1.7 / 64
+    dens, u = P[0, 0, 0], P[1, 0, 0]
+    mdot = -2 * np.pi * r * dens * u
+    e_d = np.abs((1.0 / np.sqrt(r) - dens) * np.sqrt(r)).mean()
+    e_m = np.abs((3 * np.pi * al * h ** 2 - mdot) / (3 * np.pi * al * h ** 2)).mean()
+    assert e_d <= 2e-3 and e_m <= 2e-3, (e_d, e_m)
+    assert abs(e_d - 8.76e-4) < 5e-5 and abs(e_m - 1.811e-3) < 5e-5, (e_d, e_m)

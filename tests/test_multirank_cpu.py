@@ -336,3 +336,32 @@ def test_disk_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
     xa, xb = by_bounds(a), by_bounds(b)
     for key in xa:
         assert np.array_equal(xa[key], xb[key]), key
+
+
+def test_alpha_disk_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
+    """inputs/diffusion/alpha_disk.in with the overrides of tst/scripts/diffusion/alpha_disk.py (disk pgen with
+    mdot, alpha viscosity, beta cooling, `viscous` conditions): driver == oracle bit for bit on one
+    block for 400 cycles; two blocks on two ranks agree with the one-block run to round-off."""
+    from test_oracle_pins import alpha_disk_oracle
+    al, h = 0.1, 0.1
+    ov = ["parthenon/mesh/x1max=2.0", "physics/viscosity=true", f"gas/viscosity/alpha={al:.8e}",
+          f"cooling/tcyl={h ** 2:.8e}", "cooling/cyl_plaw=-1.0", f"problem/mdot={al * h ** 2 * 3 * np.pi:.8e}",
+          "problem/quiet_start=true", f"problem/h0={h:.8e}", "problem/dslope=0.0", "problem/flare=0.0",
+          "artemis/coordinates=axisymmetric", "parthenon/mesh/nx1=64", "parthenon/mesh/nx2=1",
+          "parthenon/meshblock/nx2=1", "parthenon/mesh/nx3=1", "parthenon/meshblock/nx3=1",
+          "parthenon/mesh/x2min=-0.5", "parthenon/mesh/x2max=0.5", "parthenon/time/tlim=8000.0"]
+    one = dict(deck=["diffusion", "alpha_disk.in"], cycles=400, overrides=ov + ["parthenon/meshblock/nx1=64"])
+    r = run_world(1, one, tmp_path, "a1")[0]
+    assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    o = alpha_disk_oracle()
+    o.evolve(8e3, 400)
+    assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
+    assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+    two = run_world(2, dict(one, overrides=ov), tmp_path, "a2")  # the deck's 32-zone blocks, one per rank
+    assert [x["meta"]["nblocks"] for x in two] == [1, 1]
+    xb = by_bounds(two)
+    full = o.interior(o.gprim)
+    for key, part in xb.items():
+        i0 = int(round((key[0] - 0.3) / 1.7 * 64))
+        ref = full[:, :, :, i0:i0 + 32]
+        assert np.max(np.abs(part - ref)) < 1e-12, key

@@ -386,3 +386,39 @@ def test_disk_reference_test_pins(g, gam, b, err_ref, dt_ref):
     assert 1e-4 < o.dt < 3e-2 and abs(o.dt - dt_ref) < 2e-4 * dt_ref
     err = np.sqrt((d0 * (d - d0) ** 2).sum()) / d0.sum()
     assert err <= 6e-3 and abs(err - err_ref) < 2e-3 * err_ref, err
+
+
+def alpha_disk_oracle(nx=64, alpha=0.1, h=0.1):
+    """inputs/diffusion/alpha_disk.in with the overrides of tst/scripts/diffusion/alpha_disk.py:44-75"""
+    o = Oracle((nx, 1, 1), (0.3, -0.5, -0.5), (2.0, 0.5, 0.5), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.0001, dfloor=1e-10, siefloor=1e-15, cfl=0.3, integrator="rk2",
+               coordinates="axisymmetric", bc=("viscous", "viscous") + ("periodic",) * 4)
+    o.set_gravity_point(mass=1.0)
+    o.set_viscosity("alpha", alpha=alpha, r0=1.0, Omega0=1.0)
+    # the script passes its numbers as "{:.8e}" command-line overrides (alpha_disk.py:52-61)
+    o.set_cooling(beta0=0.0, tcyl=float(f"{h ** 2:.8e}"), cyl_plaw=-1.0)
+    o.pgen_disk(r0=1.0, dslope=0.0, flare=0.0, h0=h, dens_min=1e-10, pres_min=1e-15, polytropic_index=1.0,
+                mdot=float(f"{alpha * h ** 2 * 3 * np.pi:.8e}"), quiet_start=True)
+    return o
+
+
+def test_alpha_disk_reference_test_pin():
+    """tst/scripts/diffusion/alpha_disk.py:36-75,82-139: a 1-D axisymmetric alpha disk (alpha = 0.1,
+    h = 0.1, locally isothermal through beta cooling with beta0 = 0, `viscous` inflow / outflow
+    conditions with the steady accretion rate mdot = 3 pi alpha h^2) relaxes by t = 8000 to
+    Sigma = R^-1/2 and a radially constant accretion rate: mean relative errors of both <= 2e-3.
+    The oracle gives 8.8e-4 and 1.81e-3 (181 938 cycles, half a minute) -- again just inside a
+    tolerance evidently set from the reference's own output.  Exercises the disk pgen, alpha viscosity,
+    point-mass gravity, BetaCooling and DiskBoundaryVisc together."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    o = alpha_disk_oracle()
+    o.evolve(8e3, -1)
+    P = o.interior(o.gprim)
+    r = 0.3 + (np.arange(64) + 0.5) * 1.7 / 64
+    dens, u = P[0, 0, 0], P[1, 0, 0]
+    mdot = -2 * np.pi * r * dens * u
+    e_d = np.abs((1.0 / np.sqrt(r) - dens) * np.sqrt(r)).mean()
+    e_m = np.abs((3 * np.pi * 0.1 * 0.1 ** 2 - mdot) / (3 * np.pi * 0.1 * 0.1 ** 2)).mean()
+    assert abs(o.time - 8e3) < 1e-9 and o.ncycle > 150000
+    assert e_d <= 2e-3 and e_m <= 2e-3, (e_d, e_m)
+    assert abs(e_d - 8.76e-4) < 2e-5 and abs(e_m - 1.811e-3) < 2e-5, (e_d, e_m)

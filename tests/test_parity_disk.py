@@ -163,6 +163,54 @@ def test_disk_extrap_condition(hiplib, coordinates, nx, lo, hi, ns_dust):
         assert np.max(np.abs(a[2:] - b[2:])) < 1e-13 * np.abs(b[2:]).max()
 
 
+@pytest.mark.parametrize("coordinates,nx,lo,hi", BLOCKS[:5])
+@pytest.mark.parametrize("ns_dust", [0, 1])
+def test_disk_viscous_condition(hiplib, coordinates, nx, lo, hi, ns_dust):
+    """`viscous` on the radial faces (DiskBoundaryVisc, disk.hpp:415-595): extrapolated sie and
+    azimuthal velocity, density and radial velocity from the steady viscous solution with
+    nu(R) = nu0 (R/r0)^nu_indx -- log / exp / pow on the device, 1e-13 against glibc."""
+    from artemis_amd.pack import MeshBlockPack
+    bc = ("viscous", "viscous") + ("periodic",) * 4
+    o, mb = pair(coordinates, nx, lo, hi, ns_dust=ns_dust, bc=bc)
+    o.set_gravity_point(mass=1.0)
+    o.set_rotating_frame(0.7, 0.0)
+    o.set_viscosity("alpha", alpha=2e-2, r0=1.0, Omega0=1.0)
+    o.pgen_disk(r0=1.0, rho0=1.0, dslope=-0.5, flare=0.25, h0=0.05, dens_min=1e-10, pres_min=1e-15,
+                polytropic_index=1.0, dust_to_gas=0.02, mdot=3e-4, post_init=False)
+    perturb(o, np.random.default_rng(73))
+    push([o], mb)
+    o.ApplyBoundaryConditions()
+    nu0 = 2e-2 * 1.4 * (0.05 * 1.0 * 1.0) ** 2  # alpha gamma (h0 r0 Omega0)^2, disk.hpp:300-303
+    mb.ApplyBoundaryConditions([bc], disk=dict(omf=0.7, nu0=nu0, nu_indx=1.5 + (2 * 0.25 - 1.0), r0=1.0, mdot=3e-4))
+    a, b = mb.gas_prim[0].cpu().numpy(), o.gprim
+    assert np.isfinite(b).all()
+    assert np.max(np.abs(a[[0, 5]] - b[[0, 5]]) / np.abs(b[[0, 5]])) < 1e-13
+    assert np.max(np.abs(a[1:4] - b[1:4])) < 1e-13 * np.abs(b[1:4]).max()
+    assert not np.array_equal(a[0, :, :, :2], a[0, :, :, 2:4])  # the inner ghost zones were written
+    if ns_dust:
+        a, b = mb.dust_prim[0].cpu().numpy(), o.dprim
+        assert np.max(np.abs(a[:1] - b[:1]) / np.abs(b[:1])) < 1e-13
+        assert np.max(np.abs(a[1:] - b[1:])) < 1e-13 * np.abs(b[1:]).max()
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", BLOCKS)
+def test_beta_cooling(hiplib, coordinates, nx, lo, hi):
+    """Gas::Cooling::BetaCooling<GEOM, powerlaw> (beta_cooling.cpp:40-126): Tref = tfloor + tcyl R^a +
+    tsph r^b and beta = beta_min + beta0 exp(-s z^2/Tref) from the host-filled tables, bit-exact."""
+    o, mb = pair(coordinates, nx, lo, hi, ns_gas=2)
+    random_state(o, np.random.default_rng(81), shock=False, mach=0.5, contrast=10.0)
+    push([o], mb)
+    o.set_gravity_point(mass=1.3)
+    kw = dict(beta0=2.0, beta_min=1e-3, exp_scale=0.3, tfloor=1e-3, tcyl=0.02, cyl_plaw=-1.0, tsph=0.01, sph_plaw=-0.5)
+    o.set_cooling(**kw)
+    c = mb.cooling_params(1.4, 1.3, **kw)
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    before = o.gu0[I].copy()
+    o.CoolingSource(0.0, 3e-3), mb.CoolingSource(0.0, 3e-3, c)
+    same(mb.gas_u0[0][I], o.gu0[I], "BetaCooling")
+    assert np.array_equal(o.gu0[I][:8], before[:8]) and not np.array_equal(o.gu0[I][8:], before[8:])
+
+
 def test_disk_condition_contract(hiplib):
     from artemis_amd import capi
     o, mb, bc, disk, keep = disk_pair("axisymmetric", (8, 8, 1), (0.3, -2.0, -0.5), (4.3, 2.0, 0.5), "ic", 0)
