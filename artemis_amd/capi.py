@@ -29,7 +29,7 @@ HLLC, HLLE, LLF = 0, 1, 2
 PCM, PLM, PPM = 0, 1, 2
 GAS, DUST = 0, 1
 BC_PERIODIC, BC_OUTFLOW, BC_REFLECT, BC_NONE, BC_STRAT_EXTRAP, BC_STRAT_INFLOW, BC_CONDUCTIVE, BC_IC, BC_DISK_EXTRAP, BC_DISK_VISC = range(10)
-GRAVITY_UNIFORM, GRAVITY_POINT = 1, 2
+GRAVITY_UNIFORM, GRAVITY_POINT, GRAVITY_BINARY = 1, 2, 3
 DRAG_SIMPLE_DUST, DRAG_SELF = 1, 2
 DRAG_CONSTANT, DRAG_STOKES = 0, 1
 DIFF_OFF, VISCOSITY_PLAW, VISCOSITY_ALPHA, CONDUCTIVITY_PLAW, THERMALDIFF_PLAW = range(5)
@@ -59,7 +59,7 @@ class Pack(C.Structure):
         ("nx1", C.c_int), ("nx2", C.c_int), ("nx3", C.c_int),
         ("coords", C.c_int), ("gm1", C.c_double), ("geom", C.c_void_p),
         ("metric", C.c_void_p),
-        ("gas", FluidPack), ("dust", FluidPack),
+        ("gas", FluidPack), ("dust", FluidPack), ("omega_frame", C.c_double),
     ]
 
 
@@ -92,7 +92,8 @@ class Cooling(C.Structure):
 class Gravity(C.Structure):
     _fields_ = [("type", C.c_int), ("g", C.c_double * 3), ("gm", C.c_double), ("soft", C.c_double),
                 ("sink", C.c_double), ("sink_rate", C.c_double), ("pos", C.c_double * 3),
-                ("tstart", C.c_double), ("tstop", C.c_double)]
+                ("tstart", C.c_double), ("tstop", C.c_double), ("q", C.c_double), ("soft2", C.c_double),
+                ("sink2", C.c_double), ("sink_rate2", C.c_double), ("pos2", C.c_double * 3)]
 
 
 class Damping(C.Structure):

@@ -257,8 +257,13 @@ int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_
                                  double dt, void *stream) {
   if (int rc = validate(p)) return rc;
   if (!g) return fail(ARTEMIS_HIP_EINVAL, "null gravity parameters");
-  if (g->type != ARTEMIS_GRAVITY_UNIFORM && g->type != ARTEMIS_GRAVITY_POINT)
-    return fail(ARTEMIS_HIP_EUNSUPPORTED, "gravity type %d (binary / nbody) is not built", g->type);
+  if (g->type != ARTEMIS_GRAVITY_UNIFORM && g->type != ARTEMIS_GRAVITY_POINT && g->type != ARTEMIS_GRAVITY_BINARY)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "gravity type %d (nbody) is not built", g->type);
+  if (g->type == ARTEMIS_GRAVITY_BINARY &&
+      (p->coords == ARTEMIS_AXISYMMETRIC || p->coords == ARTEMIS_SPHERICAL1D || p->coords == ARTEMIS_SPHERICAL2D))
+    return fail(ARTEMIS_HIP_EINVAL, "Binary gravity is not compatable with axisymmetric coordinates!"); // gravity.cpp:82-83
+  if (g->type == ARTEMIS_GRAVITY_BINARY && p->coords == ARTEMIS_CYLINDRICAL && !p->metric)
+    return fail(ARTEMIS_HIP_EINVAL, "binary gravity on cylindrical blocks needs the metric tables");
   if (g->type == ARTEMIS_GRAVITY_POINT) {
     if (p->coords == ARTEMIS_CYLINDRICAL && !p->metric) // ConvertToCartWithVec: cos / sin of x2v
       return fail(ARTEMIS_HIP_EINVAL, "point-mass gravity on cylindrical blocks needs the metric tables");
@@ -578,9 +583,12 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
     return fail(ARTEMIS_HIP_EINVAL, "general stage: *_out must not alias *_in");
   if (a->gravity) { // same guards as artemis_hip_external_gravity
     const artemis_gravity_t *g = a->gravity;
-    if (g->type != ARTEMIS_GRAVITY_UNIFORM && g->type != ARTEMIS_GRAVITY_POINT)
-      return fail(ARTEMIS_HIP_EUNSUPPORTED, "gravity type %d (binary / nbody) is not built", g->type);
-    if (g->type == ARTEMIS_GRAVITY_POINT && p->coords == ARTEMIS_CYLINDRICAL && !p->metric)
+    if (g->type != ARTEMIS_GRAVITY_UNIFORM && g->type != ARTEMIS_GRAVITY_POINT && g->type != ARTEMIS_GRAVITY_BINARY)
+      return fail(ARTEMIS_HIP_EUNSUPPORTED, "gravity type %d (nbody) is not built", g->type);
+    if (g->type == ARTEMIS_GRAVITY_BINARY &&
+        (p->coords == ARTEMIS_AXISYMMETRIC || p->coords == ARTEMIS_SPHERICAL1D || p->coords == ARTEMIS_SPHERICAL2D))
+      return fail(ARTEMIS_HIP_EINVAL, "Binary gravity is not compatable with axisymmetric coordinates!");
+    if (g->type != ARTEMIS_GRAVITY_UNIFORM && p->coords == ARTEMIS_CYLINDRICAL && !p->metric)
       return fail(ARTEMIS_HIP_EINVAL, "point-mass gravity on cylindrical blocks needs the metric tables");
   }
   if (a->rf_omega != 0.0 && p->coords != ARTEMIS_CARTESIAN)

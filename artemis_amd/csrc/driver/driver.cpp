@@ -128,6 +128,31 @@ struct artemis_sim {
   Real dfloor_dust = 1e-20, cfl_gas = 0.8, cfl_dust = 0.8;
   // optional source packages (artemis.cpp:65-72): gravity, rotating_frame, drag
   bool do_gravity = false, do_rframe = false, do_drag = false, do_cooling = false;
+  struct { // Orbit of <gravity/binary> (gravity.hpp:30-94) and the pair's centre of mass
+    Real a = 1, e = 0, n = 0, coso = 1, sino = 0, cosO = 1, sinO = 0, cosI = 1, sinI = 0, cosf0 = -1, sinf0 = 0;
+    Real com[3] = {0, 0, 0};
+  } orb;
+  // positions of the two bodies at `time` in the frame rotating with omf (binary_mass.cpp:56-70)
+  void place_binary() {
+    if (!do_gravity || grav.type != ARTEMIS_GRAVITY_BINARY) return;
+    const Real omf = do_rframe ? rf_omega : 0.0;
+    const Real sint = std::sin(time * (orb.n - omf));
+    const Real cost = std::cos(time * (orb.n - omf));
+    Real cosf = orb.cosf0 * cost - orb.sinf0 * sint;
+    Real sinf = orb.cosf0 * sint + orb.sinf0 * cost;
+    const Real rbm = orb.a * (1.0 - SQR(orb.e)) / (1.0 + orb.e * cosf);
+    const Real xb = rbm * cosf;
+    const Real yb = rbm * sinf;
+    cosf = xb * orb.coso - orb.sino * yb;
+    sinf = xb * orb.sino + orb.coso * yb;
+    const Real rb[3] = {(orb.cosO * cosf - orb.sinO * sinf * orb.cosI), (orb.sinO * cosf + orb.cosO * sinf * orb.cosI),
+                        sinf * orb.sinI};
+    const Real mu1 = 1. / (1.0 + grav.q), mu2 = grav.q / (1.0 + grav.q);
+    for (int n = 0; n < 3; n++) {
+      grav.pos[n] = orb.com[n] - mu2 * rb[n];
+      grav.pos2[n] = orb.com[n] + mu1 * rb[n];
+    }
+  }
   artemis_cooling_t cool = {};
   Field cool_tref, cool_beta; // host-filled Tref / beta of every cell (cooling.hpp:47-58, beta_cooling.cpp:98-99)
   artemis_gravity_t grav;
@@ -202,6 +227,7 @@ struct artemis_sim {
     p.gm1 = gamma - 1.0;
     p.geom = geom.p;
     p.metric = metric.p;
+    p.omega_frame = do_rframe ? rf_omega : 0.0; // fluid_fluxes.hpp:433-437
     p.gas.nspecies = ns_gas, p.gas.recon = recon_gas, p.gas.riemann = riemann_gas;
     p.gas.dfloor = dfloor_gas, p.gas.siefloor = siefloor_gas, p.gas.de_switch = de_switch;
     p.gas.prim = gprim[prim_idx].tab(), p.gas.cons0 = gu0.tab(), p.gas.cons1 = gu1.tab();
@@ -361,8 +387,29 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
       grav.pos[1] = pin.GetOrAddReal("gravity/point", "y", 0.0);
       grav.pos[2] = pin.GetOrAddReal("gravity/point", "z", 0.0);
     }
-    if (pin.DoesBlockExist("gravity/binary") || pin.DoesBlockExist("gravity/nbody"))
-      throw std::runtime_error("gravity/binary and gravity/nbody are out of scope of this build");
+    if (pin.DoesBlockExist("gravity/binary")) { // gravity.cpp:77-111
+      count++, grav.type = ARTEMIS_GRAVITY_BINARY;
+      const char *bn = "gravity/binary";
+      if (coords == ARTEMIS_AXISYMMETRIC || coords == ARTEMIS_SPHERICAL1D || coords == ARTEMIS_SPHERICAL2D)
+        throw std::runtime_error("Binary gravity is not compatable with axisymmetric coordinates!");
+      grav.gm = 1.0 * pin.GetReal(bn, "mass");
+      grav.soft = pin.GetOrAddReal(bn, "soft1", 0.0), grav.soft2 = pin.GetOrAddReal(bn, "soft2", 0.0);
+      grav.sink = pin.GetOrAddReal(bn, "sink1", 0.0), grav.sink2 = pin.GetOrAddReal(bn, "sink2", 0.0);
+      grav.sink_rate = pin.GetOrAddReal(bn, "sink_rate1", 0.0), grav.sink_rate2 = pin.GetOrAddReal(bn, "sink_rate2", 0.0);
+      orb.com[0] = pin.GetOrAddReal(bn, "x", 0.0), orb.com[1] = pin.GetOrAddReal(bn, "y", 0.0);
+      orb.com[2] = pin.GetOrAddReal(bn, "z", 0.0);
+      grav.q = pin.GetReal(bn, "q");
+      orb.a = pin.GetReal(bn, "a"), orb.e = pin.GetOrAddReal(bn, "e", 0.0);
+      const Real ibin = pin.GetOrAddReal(bn, "i", 0.0) * M_PI / 180.;
+      const Real obin = pin.GetOrAddReal(bn, "omega", 0.0) * M_PI / 180.;
+      const Real Obin = pin.GetOrAddReal(bn, "Omega", 0.0) * M_PI / 180.;
+      const Real fbin = pin.GetOrAddReal(bn, "f", 180.0) * M_PI / 180.;
+      orb.n = std::sqrt(grav.gm / (orb.a * orb.a * orb.a)); // Orbit::Orbit, gravity.hpp:48-64
+      orb.coso = std::cos(obin), orb.sino = std::sin(obin), orb.cosI = std::cos(ibin), orb.sinI = std::sin(ibin);
+      orb.cosO = std::cos(Obin), orb.sinO = std::sin(Obin), orb.cosf0 = std::cos(fbin), orb.sinf0 = std::sin(fbin);
+    }
+    if (pin.DoesBlockExist("gravity/nbody"))
+      throw std::runtime_error("gravity/nbody is out of scope of this build");
     if (count == 0) throw std::runtime_error("Unknown gravity node!");
     if (count != 1) throw std::runtime_error("artemis only supports 1 gravity type at this time");
   }
@@ -457,8 +504,8 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
         c.eta = pin.GetOrAddReal("gas/viscosity", "eta_bulk", 0.0);
         c.r_exp = pin.GetOrAddReal("gas/viscosity", "r_exp", 0.0);
       } else if (t == "alpha") { // diffusion_coeff.hpp:113-119
-        if (!do_gravity || grav.type != ARTEMIS_GRAVITY_POINT)
-          throw std::runtime_error("gas/viscosity/type = alpha reads gm of the gravity package: gravity/point is required");
+        if (!do_gravity || grav.type == ARTEMIS_GRAVITY_UNIFORM)
+          throw std::runtime_error("gas/viscosity/type = alpha reads gm of the gravity package: gravity/point or gravity/binary is required");
         c.type = ARTEMIS_VISCOSITY_ALPHA;
         c.coeff = pin.GetReal("gas/viscosity", "alpha");
         c.eta = pin.GetOrAddReal("gas/viscosity", "eta_bulk", 0.0);
@@ -1399,6 +1446,7 @@ void artemis_sim::step_general(bool want_dt, bool device_dt) {
     a.time = time;
     a.gas_in = gprim[cur].tab(), a.gas_u1 = gprim[A].tab(), a.gas_out = gprim[out].tab();
     a.dust_in = dprim[cur].tab(), a.dust_u1 = dprim[A].tab(), a.dust_out = dprim[out].tab();
+    place_binary();
     a.gravity = do_gravity ? &grav : nullptr;
     a.rf_omega = do_rframe ? rf_omega : 0.0, a.rf_qshear = rf_qshear;
     a.drag = do_drag ? &drag : nullptr;
@@ -1534,6 +1582,7 @@ void artemis_sim::step_unfused() {
       CK(artemis_hip_diffusion_update(&p, &diff, bdt, stream), "Gas::DiffusionUpdate");
     // artemis_driver.cpp:222-241: gravity, rotating frame, drag, in this order, with the time at
     // the start of the step (:167)
+    place_binary();
     if (do_gravity) CK(artemis_hip_external_gravity(&p, &grav, time, bdt, stream), "ExternalGravity");
     if (do_rframe) CK(artemis_hip_rotating_frame_force(&p, rf_omega, rf_qshear, time, bdt, stream), "RotatingFrameForce");
     if (do_drag) CK(artemis_hip_drag_source(&p, &drag, time, bdt, stream), "DragSource");
@@ -1567,7 +1616,8 @@ long artemis_sim::evolve(long max_cycles) {
   // synchronise inside the loop, so launches queue ahead of the GPU.
   const bool multi = has_comm && (nranks > 1 || loopback);
   // (a gravity time window is evaluated against the host's clock, which the device loop does not keep)
-  const bool grav_window = do_gravity && (grav.tstart > -DBL_MAX || grav.tstop < DBL_MAX);
+  // (so is the orbit of a binary)
+  const bool grav_window = do_gravity && (grav.tstart > -DBL_MAX || grav.tstop < DBL_MAX || grav.type == ARTEMIS_GRAVITY_BINARY);
   const bool async_loop = use_fused && tlim <= 0.0 && !grav_window && (!multi || comm.allreduce_min_dev) &&
                           std::getenv("ARTEMIS_SYNC_LOOP") == nullptr;
   if (async_loop) {

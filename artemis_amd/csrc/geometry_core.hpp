@@ -266,6 +266,17 @@ GDEV Frame cart_frame(int sys, const double xi[3], double ct, double st, double 
   }
   return f;
 }
+// RotatingFrame::RotationVelocity<GEOM>(xv, omf) (rotating_frame.hpp:31-47) at a cell centre
+template <class CO>
+GDEV void rotation_velocity(const CO &co, double omf, double vf[3]) {
+  vf[0] = 0.0, vf[1] = omf, vf[2] = 0.0; // Cartesian (every dh/dx is zero there)
+  if (co.sys == ARTEMIS_CARTESIAN) return;
+  double xv[3];
+  co.centre(xv);
+  const Frame fr = cyl_frame(co.sys, xv, co.cv, co.sv);
+  const double vp = omf * fr.x[0];
+  vf[0] = fr.e1[1] * vp, vf[1] = fr.e2[1] * vp, vf[2] = fr.e3[1] * vp;
+}
 // ConvertToSph(xi)[0] (geometry.hpp:262-264, cylindrical.hpp:111-112, axisymmetric.hpp:116-117)
 GDEV double sph_radius(int sys, const double xi[3]) {
   switch (sys) {

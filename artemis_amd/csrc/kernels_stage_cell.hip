@@ -265,10 +265,12 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
       }
       if constexpr (CURV) {
         const double rdt = w.rho * dt;
+        double vf[3];
+        rotation_velocity(co, P.omf, vf);
         if (co.x1dep())
-          u0.m1 += rdt * (0.0 * sqr(w.v1) + co.dh2dx1() * sqr(w.v2) + co.dh3dx1() * sqr(w.v3));
+          u0.m1 += rdt * (0.0 * sqr(w.v1 + vf[0]) + co.dh2dx1() * sqr(w.v2 + vf[1]) + co.dh3dx1() * sqr(w.v3 + vf[2]));
         if (co.x2dep() && multi_d)
-          u0.m2 += rdt * (0.0 * sqr(w.v1) + 0.0 * sqr(w.v2) + co.dh3dx2() * sqr(w.v3));
+          u0.m2 += rdt * (0.0 * sqr(w.v1 + vf[0]) + 0.0 * sqr(w.v2 + vf[1]) + co.dh3dx2() * sqr(w.v3 + vf[2]));
       }
       if (a.grav_on) gravity_gas(ga, dt, hx, w, u0);
       if (a.rf_on) shear_gas(sa, dt, w, u0);
@@ -307,10 +309,12 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
       const double dt = a.bdt;
       if constexpr (CURV) { // Dust::FluxSource (dust.cpp:303-326): coordinate source only
         const double rdt = w.rho * dt;
+        double vf[3];
+        rotation_velocity(co, P.omf, vf);
         if (co.x1dep())
-          u0.m1 += rdt * (0.0 * sqr(w.v1) + co.dh2dx1() * sqr(w.v2) + co.dh3dx1() * sqr(w.v3));
+          u0.m1 += rdt * (0.0 * sqr(w.v1 + vf[0]) + co.dh2dx1() * sqr(w.v2 + vf[1]) + co.dh3dx1() * sqr(w.v3 + vf[2]));
         if (co.x2dep() && multi_d)
-          u0.m2 += rdt * (0.0 * sqr(w.v1) + 0.0 * sqr(w.v2) + co.dh3dx2() * sqr(w.v3));
+          u0.m2 += rdt * (0.0 * sqr(w.v1 + vf[0]) + 0.0 * sqr(w.v2 + vf[1]) + co.dh3dx2() * sqr(w.v3 + vf[2]));
       }
       if (a.grav_on) gravity_dust(ga, dt, hx, w, u0);
       if (a.rf_on) shear_dust(sa, dt, w, u0);

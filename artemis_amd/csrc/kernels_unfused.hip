@@ -212,10 +212,12 @@ __global__ __launch_bounds__(TX *TY) void flux_source_kernel(const PackView P, c
       const double vx = f.prim[b * nv + ns + 3 * n + 0][c];
       const double vy = f.prim[b * nv + ns + 3 * n + 1][c];
       const double vz = f.prim[b * nv + ns + 3 * n + 2][c];
+      double vf[3];
+      rotation_velocity(co, P.omf, vf);
       if (co.x1dep())
-        m1 += rdt * (0.0 * sqr(vx) + co.dh2dx1() * sqr(vy) + co.dh3dx1() * sqr(vz));
+        m1 += rdt * (0.0 * sqr(vx + vf[0]) + co.dh2dx1() * sqr(vy + vf[1]) + co.dh3dx1() * sqr(vz + vf[2]));
       if (co.x2dep() && multi_d) {
-        m2 += rdt * (0.0 * sqr(vx) + 0.0 * sqr(vy) + co.dh3dx2() * sqr(vz));
+        m2 += rdt * (0.0 * sqr(vx + vf[0]) + 0.0 * sqr(vy + vf[1]) + co.dh3dx2() * sqr(vz + vf[2]));
       }
     }
     mx[c] = m1;

@@ -28,6 +28,7 @@ struct PackView {
   const double *geom; // [nb][6]
   int coords;           // enum artemis_coords
   const double *metric; // [nb][6][nj+1] x2 trig tables (spherical2D/3D), else null
+  double omf;           // frame frequency for FluxSource's coordinate sources
   FluidView gas, dust;
 };
 
@@ -56,6 +57,7 @@ inline PackView make_pack_view(const artemis_pack_t &p) {
   v.geom = p.geom;
   v.coords = p.coords;
   v.metric = p.metric;
+  v.omf = p.omega_frame;
   v.gas = make_fluid_view(p.gas);
   v.dust = make_fluid_view(p.dust);
   return v;

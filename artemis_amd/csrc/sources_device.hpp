@@ -39,6 +39,37 @@ ADEV GravAcc gravity_accel(const artemis_gravity_t &G, const DCoords &co, int nd
   const double dx[3] = {co.x1v(), co.x2v(), co.x3v()};
   const bool multi_d = ndim >= 2, three_d = ndim == 3;
   const double gm = G.gm, rsft2 = sqr(G.soft);
+  if (G.type == ARTEMIS_GRAVITY_BINARY) { // binary_mass.cpp:86-160
+    const bool cyl = (co.sys == ARTEMIS_CYLINDRICAL);
+    const Frame fr = cart_frame(co.sys, dx, co.cv, co.sv, cyl ? co.cv : co.c3, cyl ? co.sv : co.s3);
+    const double mu1 = 1. / (1.0 + G.q), mu2 = G.q / (1.0 + G.q);
+    double dxc1[3] = {fr.x[0], fr.x[1], fr.x[2]}, dxc2[3];
+    for (int n = 0; n < 3; n++) {
+      dxc2[n] = dxc1[n] - G.pos2[n];
+      dxc1[n] -= G.pos[n];
+    }
+    const double R1 = sqrt(dxc1[0] * dxc1[0] + dxc1[1] * dxc1[1]), R2 = sqrt(dxc2[0] * dxc2[0] + dxc2[1] * dxc2[1]);
+    const double r1 = sqrt(R1 * R1 + dxc1[2] * dxc1[2]), r2 = sqrt(R2 * R2 + dxc2[2] * dxc2[2]);
+    const double rad2_1 = sqr(r1) + sqr(G.soft);
+    const double rad2_2 = sqr(r2) + sqr(G.soft2);
+    const double idr3_1 = 1.0 / (sqrt(rad2_1) * rad2_1);
+    const double idr3_2 = 1.0 / (sqrt(rad2_2) * rad2_2);
+    const double g[3] = {-gm * (mu1 * dxc1[0] * idr3_1 + mu2 * dxc2[0] * idr3_2),
+                         multi_d * (-gm * (mu1 * dxc1[1] * idr3_1 + mu2 * dxc2[1] * idr3_2)),
+                         three_d * (-gm * (mu1 * dxc1[2] * idr3_1 + mu2 * dxc2[2] * idr3_2))};
+    a.gx1 = g[0] * fr.e1[0] + g[1] * fr.e1[1] + g[2] * fr.e1[2];
+    a.gx2 = g[0] * fr.e2[0] + g[1] * fr.e2[1] + g[2] * fr.e2[2];
+    a.gx3 = g[0] * fr.e3[0] + g[1] * fr.e3[1] + g[2] * fr.e3[2];
+    const double sr1 = dt * G.sink_rate, sr2 = dt * G.sink_rate2;
+    const double sramp1 = sr1 * sqr((r1 - G.sink) / G.sink);
+    const double sramp2 = sr2 * sqr((r2 - G.sink2) / G.sink2);
+    const double s1 = sramp1 / (1.0 + sramp1), s2 = sramp2 / (1.0 + sramp2);
+    double fd1 = (s1 < 0.25) ? s1 : 0.25, fd2 = (s2 < 0.25) ? s2 : 0.25; // std::min(0.25, s): NaN keeps 0.25
+    fd1 *= ((sr1 > 0.0) && (G.sink > 0.0) && (r1 <= G.sink));
+    fd2 *= ((sr2 > 0.0) && (G.sink2 > 0.0) && (r2 <= G.sink2));
+    a.fd = fd1 + fd2;
+    return a;
+  }
   double dr;
   if (co.sys == ARTEMIS_SPHERICAL1D || co.sys == ARTEMIS_SPHERICAL2D) { // point_mass.cpp:78-81
     const double rad2 = sqr(dx[0]) + rsft2;

@@ -26,7 +26,8 @@ class MeshBlockPack:
     def __init__(self, nblocks, nx, xmin, xmax, ng=2, ns_gas=1, ns_dust=0, reconstruct="plm",
                  riemann="hllc", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.66666666667,
                  dfloor=1.0e-20, siefloor=1.0e-20, de_switch=0.0, dust_dfloor=1.0e-20,
-                 device="cuda:0", with_fluxes=True, coordinates="cartesian", with_diffusion=False):
+                 device="cuda:0", with_fluxes=True, coordinates="cartesian", with_diffusion=False,
+                 omega_frame=0.0):
         """xmin/xmax: per-block interior bounds, arrays of shape [nblocks, 3]."""
         self.L = capi.load()
         self.dev = torch.device(device)
@@ -75,6 +76,7 @@ class MeshBlockPack:
         p.coords = capi.coord_select(coordinates, self.ndim)
         p.gm1 = gamma - 1.0
         p.geom = self.geom.data_ptr()
+        p.omega_frame = omega_frame  # rotating_frame/omega (FluxSource's frame velocity), 0 when off
         p.gas.nspecies, p.gas.recon, p.gas.riemann = ns_gas, capi.RECON[reconstruct], capi.RSOLVER[riemann]
         p.gas.dfloor, p.gas.siefloor, p.gas.de_switch = dfloor, siefloor, de_switch
         p.gas.prim, p.gas.cons0, p.gas.cons1 = tab(self.gas_prim), tab(self.gas_u0), tab(self.gas_u1)
@@ -303,6 +305,40 @@ def gravity_point(mass, soft=0.0, sink=0.0, sink_rate=0.0, pos=(0.0, 0.0, 0.0), 
     g.type = capi.GRAVITY_POINT
     g.gm, g.soft, g.sink, g.sink_rate = G * mass, soft, sink, sink_rate
     g.pos[:] = list(pos)
+    g.tstart, g.tstop = -1.7976931348623157e308, 1.7976931348623157e308
+    return g
+
+
+def binary_orbit(gm, a, e=0.0, i=0.0, omega=0.0, Omega=0.0, f=180.0):
+    """Orbit (gravity.hpp:30-94): returns solve(t, omf) -> separation vector rb of the pair; angles in degrees."""
+    import math
+    r = lambda deg: deg * math.pi / 180.
+    n = math.sqrt(gm / (a * a * a))
+    coso, sino, cosI, sinI = math.cos(r(omega)), math.sin(r(omega)), math.cos(r(i)), math.sin(r(i))
+    cosO, sinO, cosf0, sinf0 = math.cos(r(Omega)), math.sin(r(Omega)), math.cos(r(f)), math.sin(r(f))
+
+    def solve(t, omf=0.0):
+        sint, cost = math.sin(t * (n - omf)), math.cos(t * (n - omf))
+        cosf = cosf0 * cost - sinf0 * sint
+        sinf = cosf0 * sint + sinf0 * cost
+        rb = a * (1.0 - e * e) / (1.0 + e * cosf)
+        xb, yb = rb * cosf, rb * sinf
+        cosf = xb * coso - sino * yb
+        sinf = xb * sino + coso * yb
+        return ((cosO * cosf - sinO * sinf * cosI), (sinO * cosf + cosO * sinf * cosI), sinf * sinI)
+    return solve
+
+
+def gravity_binary(mass, q, rb, soft1=0.0, soft2=0.0, sink1=0.0, sink2=0.0, sink_rate1=0.0, sink_rate2=0.0,
+                   com=(0.0, 0.0, 0.0), G=1.0):
+    """capi.Gravity of type BINARY for a separation vector rb (binary_mass.cpp:56-70)."""
+    g = capi.Gravity()
+    g.type = capi.GRAVITY_BINARY
+    g.gm, g.q = G * mass, q
+    mu1, mu2 = 1. / (1.0 + q), q / (1.0 + q)
+    g.pos[:] = [com[n] - mu2 * rb[n] for n in range(3)]
+    g.pos2[:] = [com[n] + mu1 * rb[n] for n in range(3)]
+    g.soft, g.soft2, g.sink, g.sink2, g.sink_rate, g.sink_rate2 = soft1, soft2, sink1, sink2, sink_rate1, sink_rate2
     g.tstart, g.tstop = -1.7976931348623157e308, 1.7976931348623157e308
     return g
 

@@ -67,7 +67,7 @@ enum artemis_bc { ARTEMIS_BC_PERIODIC = 0, ARTEMIS_BC_OUTFLOW = 1, ARTEMIS_BC_RE
                   ARTEMIS_BC_IC = 7,          /* DiskBoundaryIC, disk.hpp:597-632 */
                   ARTEMIS_BC_DISK_EXTRAP = 8, /* DiskBoundaryExtrap, disk.hpp:634-825 */
                   ARTEMIS_BC_DISK_VISC = 9    /* DiskBoundaryVisc (`viscous`), disk.hpp:415-595, x1 faces */ };
-enum artemis_gravity_type { ARTEMIS_GRAVITY_UNIFORM = 1, ARTEMIS_GRAVITY_POINT = 2 };
+enum artemis_gravity_type { ARTEMIS_GRAVITY_UNIFORM = 1, ARTEMIS_GRAVITY_POINT = 2, ARTEMIS_GRAVITY_BINARY = 3 };
 enum artemis_drag_type { ARTEMIS_DRAG_SIMPLE_DUST = 1, ARTEMIS_DRAG_SELF = 2 }; /* drag.hpp:57 */
 enum artemis_drag_model { ARTEMIS_DRAG_CONSTANT = 0, ARTEMIS_DRAG_STOKES = 1 }; /* drag.hpp:58 */
 #define ARTEMIS_MAX_DUST_SPECIES 16 /* drag parameter arrays travel by value as kernel arguments */
@@ -101,6 +101,9 @@ typedef struct artemis_pack {
   const double *metric;      /* DEVICE trigonometry tables (see artemis_hip_metric_count / _fill);
                                 required for spherical2D/3D, optional otherwise */
   artemis_fluid_pack_t gas, dust;
+  double omega_frame;        /* rotating_frame/omega when physics/rotating_frame is on, else 0: the frame
+                                velocity RotationVelocity<GEOM>(xv, omf) inside FluxSource's coordinate
+                                source terms (fluid_fluxes.hpp:345, :395-415, :433-437) */
 } artemis_pack_t;
 
 /* ---- Parthenon task functions ---------------------------------------------------------*/
@@ -119,8 +122,10 @@ int artemis_hip_apply_update(const artemis_pack_t *p, double gam0, double gam1, 
 
 /* Gas::FluxSource / Dust::FluxSource (gas.cpp:499-519, dust.cpp:303-326) ->
  * FluxSourceImpl (fluid_fluxes.hpp:300-420): pressure gradient on momentum and -P div(v)
- * on internal energy.  Interior cells only (the reference also scribbles on ghost cells
- * [is-2, ie+1] that PrimToCons overwrites).  Cartesian dust: no-op. */
+ * on internal energy, then the coordinate sources rho dt sum_d dh_d/dx_a (v_d + vf_d)^2 with the
+ * frame velocity vf = RotationVelocity<GEOM>(xv, p->omega_frame) (:345, :395-415).  Interior cells
+ * only (the reference also scribbles on ghost cells [is-2, ie+1] that PrimToCons overwrites; see
+ * DESIGN.md).  Cartesian dust: no-op. */
 int artemis_hip_flux_source(const artemis_pack_t *p, int fluid, double dt, void *stream);
 
 /* ArtemisDerived::SetAuxillaryFields<GEOM> (fill_derived.cpp:30-75). */
@@ -190,14 +195,21 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
  * tstart <= time < tstop: UniformGravity (uniform.cpp:28-84, every coordinate system) or
  * PointMassGravity (point_mass.cpp:27-198: Cartesian with offset mass, softening and sink;
  * spherical1D/2D and axisymmetric with the mass at the origin).  gm = G*mass in code units
- * (gravity.cpp:57).  Reads prim, updates cons0 momenta / total energy (/ density for the
- * sink) of both fluids on interior cells.  cylindrical / spherical3D point mass and the
- * binary / nbody types: ARTEMIS_HIP_EUNSUPPORTED. */
+ * (gravity.cpp:57).  BinaryMassGravity (binary_mass.cpp:27-203): two softened point masses
+ * with sinks at positions the adapter computes from the orbit; Cartesian, cylindrical, spherical3D
+ * (not the axisymmetric systems, gravity.cpp:82-83).  Reads prim, updates cons0 momenta / total
+ * energy (/ density for the sinks) of both fluids on interior cells.  The nbody type:
+ * ARTEMIS_HIP_EUNSUPPORTED. */
 typedef struct artemis_gravity {
   int type;                   /* artemis_gravity_type */
   double g[3];                /* <gravity/uniform> gx1, gx2, gx3 */
-  double gm, soft, sink, sink_rate, pos[3]; /* <gravity/point> */
+  double gm, soft, sink, sink_rate, pos[3]; /* <gravity/point>; BINARY: gm of the pair and body 1's
+                                               soft1, sink1, sink_rate1, position */
   double tstart, tstop;       /* <gravity> tstart, tstop (gravity.cpp:36-38) */
+  /* BINARY (gravity/binary_mass.cpp:27-203): mass ratio q = m2/m1, body 2's softening, sink and
+   * position.  The adapter evaluates Orbit::solve(time, omf) (gravity.hpp:66-94, host libm) per
+   * stage and passes pos = com - mu2 rb, pos2 = com + mu1 rb (binary_mass.cpp:56-70). */
+  double q, soft2, sink2, sink_rate2, pos2[3];
 } artemis_gravity_t;
 int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_t *g, double time,
                                  double dt, void *stream);

@@ -84,8 +84,13 @@ struct Sim {
   Real gx1min, gx1max, gx2min, gx2max, gx3min, gx3max; // global mesh bounds for pgens
   // optional source packages (artemis.cpp:63-72); zero-initialised = disabled
   struct {
-    int type = 0; // 0 off, 1 uniform, 2 point
+    int type = 0; // 0 off, 1 uniform, 2 point, 3 binary
     Real g[3] = {0, 0, 0}, gm = 0, soft = 0, sink = 0, sink_rate = 0, pos[3] = {0, 0, 0};
+    // binary (gravity.cpp:77-111): mass ratio, second body's softening / sink, Orbit (gravity.hpp:30-65)
+    Real q = 0, soft2 = 0, sink2 = 0, sink_rate2 = 0;
+    Real a = 1, e = 0, n = 0, coso = 1, sino = 0, cosO = 1, sinO = 0, cosI = 1, sinI = 0, cosf0 = -1, sinf0 = 0;
+    bool given_pos = false; // a caller supplies pos (body 1) and pos2 itself instead of the orbit
+    Real pos2[3] = {0, 0, 0};
     Real tstart = std::numeric_limits<Real>::lowest(), tstop = std::numeric_limits<Real>::max();
   } grav;
   struct {
@@ -941,118 +946,6 @@ void deep_copy(Sim &s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// utils/fluxes/fluid_fluxes.hpp:300-420  FluxSourceImpl: pressure gradient and P div(v) work for
-// gas (:361-393), then the coordinate source rho*dt*sum_d dh_d/dx_a*(v_d + vf_d)^2 on each
-// momentum whose direction the metric depends on (:395-415).  vf = RotationVelocity(xv, omf)
-// is identically zero here (omf = 0 without <rotating_frame>, gas.cpp:497-502), so it is left
-// out of the sums.  Dust::FluxSource runs only for metric-dependent systems (dust.cpp:303-326)
-// and has no pressure terms.  The reference loops i over [is-2, ie+1] (:325); the ghost-cell
-// writes are overwritten by PrimToCons, so the oracle keeps the range to stay literal (reads
-// stay in bounds because ng >= 2).
-void flux_source(Sim &s, int fluid, Real dt) {
-  const bool gas = (fluid == FL_GAS);
-  const int nsp = gas ? s.c.ns_gas : s.c.ns_dust;
-  if (!nsp) return;
-  const bool multi_d = (s.ndim >= 2), three_d = (s.ndim == 3);
-  {
-    const Coords probe(s, s.ks, s.js, s.is);
-    if (!gas && !(probe.x1dep() || (probe.x2dep() && multi_d) || (probe.x3dep() && three_d)))
-      return;
-  }
-  const ptrdiff_t sj = s.ni, sk = static_cast<ptrdiff_t>(s.ni) * s.nj;
-  std::vector<Real> &u0 = gas ? s.gu0 : s.du0;
-  const std::vector<Real> &prim = gas ? s.gprim : s.dprim;
-#pragma omp parallel for collapse(2) schedule(static)
-  for (int k = s.ks; k <= s.ke; ++k)
-    for (int j = s.js; j <= s.je; ++j)
-      for (int i = s.is - 2; i <= s.ie + 1; ++i) {
-        Coords coords(s, k, j, i);
-        const bool x1dep = coords.x1dep();
-        const bool x2dep = coords.x2dep() && multi_d;
-        const bool x3dep = coords.x3dep() && three_d;
-        Real dhdx1[3] = {0.0, 0.0, 0.0}, dhdx2[3] = {0.0, 0.0, 0.0};
-        if (x1dep) coords.GetConnX1(dhdx1);
-        if (x2dep) coords.GetConnX2(dhdx2);
-        (void)x3dep; // geometry.hpp:107-110: no system has an x3-dependent metric
-        Real ax1[2], ax2[2] = {0.0, 0.0}, ax3[2] = {0.0, 0.0};
-        coords.GetFaceAreaX1(ax1);
-        if (multi_d) coords.GetFaceAreaX2(ax2);
-        if (three_d) coords.GetFaceAreaX3(ax3);
-        const Real vol = coords.Volume();
-        const BBox &b = coords.bnds;
-        const Real dx[3] = {b.x1[1] - b.x1[0], b.x2[1] - b.x2[0], b.x3[1] - b.x3[0]};
-        const size_t c = IDX(s, k, j, i);
-        for (int n = 0; n < nsp; ++n) {
-          // cons pack of FluxSource is <momentum, internal_energy> (gas.cpp:505-511); in the
-          // oracle's full cons layout those are slots ns+3n+d and 5ns+n.
-          Real *mx = u0.data() + (nsp + 3 * n + 0) * s.N;
-          Real *my = u0.data() + (nsp + 3 * n + 1) * s.N;
-          Real *mz = u0.data() + (nsp + 3 * n + 2) * s.N;
-          if (gas) {
-            Real *eg = u0.data() + (5 * nsp + n) * s.N;
-            const Real *p1 = s.gpflux[0].data() + n * s.N, *v1 = s.gvface[0].data() + n * s.N;
-            mx[c] += dt / dx[0] * (p1[c] - p1[c + 1]);
-            eg[c] -= dt / vol * 0.5 * (p1[c] + p1[c + 1]) * (ax1[1] * v1[c + 1] - ax1[0] * v1[c]);
-            if (multi_d) {
-              const Real *p2 = s.gpflux[1].data() + n * s.N, *v2 = s.gvface[1].data() + n * s.N;
-              my[c] += dt / dx[1] * (p2[c] - p2[c + sj]);
-              eg[c] -=
-                  dt / vol * 0.5 * (p2[c] + p2[c + sj]) * (ax2[1] * v2[c + sj] - ax2[0] * v2[c]);
-            }
-            if (three_d) {
-              const Real *p3 = s.gpflux[2].data() + n * s.N, *v3 = s.gvface[2].data() + n * s.N;
-              mz[c] += dt / dx[2] * (p3[c] - p3[c + sk]);
-              eg[c] -=
-                  dt / vol * 0.5 * (p3[c] + p3[c + sk]) * (ax3[1] * v3[c + sk] - ax3[0] * v3[c]);
-            }
-          }
-          const Real dens = prim[n * s.N + c];
-          const Real rdt = dens * dt;
-          const Real vx = prim[(nsp + 3 * n + 0) * s.N + c];
-          const Real vy = prim[(nsp + 3 * n + 1) * s.N + c];
-          const Real vz = prim[(nsp + 3 * n + 2) * s.N + c];
-          if (x1dep)
-            mx[c] += rdt * (dhdx1[0] * SQR(vx) + dhdx1[1] * SQR(vy) + dhdx1[2] * SQR(vz));
-          if (x2dep)
-            my[c] += rdt * (dhdx2[0] * SQR(vx) + dhdx2[1] * SQR(vy) + dhdx2[2] * SQR(vz));
-        }
-      }
-}
-
-// ---------------------------------------------------------------------------------------
-// Coords<GEOM>::ConvertToCylWithVec (geometry.hpp:476-482): only the cylindrical radius and
-// the first component of each basis vector are used by the callers restated here
-// (geometry.hpp:289-306 Cartesian, cylindrical.hpp:117-126 identity, spherical.hpp:191-205 /
-// :382-396 / :556-577, axisymmetric.hpp:134-145).
-struct CylVec {
-  Real R, e1, e2, e3; // xcyl[0], ex1[0], ex2[0], ex3[0]
-};
-inline CylVec to_cyl_with_vec(const Coords &co, const Real xi[3]) {
-  CylVec c;
-  const Real fuzz = 1e-99; // Fuzz<Real>(), artemis.hpp:113-118
-  switch (co.sys) {
-  case CO_CART: {
-    Real R = std::sqrt(xi[0] * xi[0] + xi[1] * xi[1]);
-    const Real cp = xi[0] / (R + fuzz);
-    const Real sp = xi[1] / (R + fuzz);
-    c.R = R, c.e1 = cp, c.e2 = sp, c.e3 = 0.0;
-  } break;
-  case CO_SPH3D:
-  case CO_SPH2D: {
-    const Real ct = std::cos(xi[1]);
-    const Real st = std::sin(xi[1]);
-    c.R = xi[0] * st, c.e1 = st, c.e2 = ct, c.e3 = 0.0;
-  } break;
-  case CO_SPH1D: {
-    const Real ct = 0.0, st = 1.0;
-    c.R = xi[0] * st, c.e1 = st, c.e2 = ct, c.e3 = 0.0;
-  } break;
-  default: // cylindrical, axisymmetric
-    c.R = xi[0], c.e1 = 1.0, c.e2 = 0.0, c.e3 = 0.0;
-  }
-  return c;
-}
-
 // Coords<GEOM>::ConvertToCylWithVec / ConvertToCartWithVec (geometry.hpp:438-482): the converted
 // point and the three rows ex1, ex2, ex3 (components of the problem's unit vectors in the target
 // basis).  Cartesian geometry.hpp:286-301; cylindrical.hpp:96-107, :128-136; spherical.hpp:172-189,
@@ -1163,6 +1056,128 @@ inline void rf_weights(const Coords &co, Real bx1[2], Real bx2[2], Real bx3[2]) 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// utils/fluxes/fluid_fluxes.hpp:300-420  FluxSourceImpl: pressure gradient and P div(v) work for
+// gas (:361-393), then the coordinate source rho*dt*sum_d dh_d/dx_a*(v_d + vf_d)^2 on each
+// momentum whose direction the metric depends on (:395-415), vf = RotationVelocity<GEOM>(xv, omf)
+// (rotating_frame.hpp:31-47) with omf = rotating_frame/omega when that package is on, else 0
+// (:433-437): this is where the centrifugal and Coriolis terms of the curvilinear rotating frame
+// enter the radial / polar momentum equations.  Dust::FluxSource runs only for metric-dependent systems (dust.cpp:303-326)
+// and has no pressure terms.  The reference loops i over [is-2, ie+1] (:325); the ghost-cell
+// writes are overwritten by PrimToCons, so the oracle keeps the range to stay literal (reads
+// stay in bounds because ng >= 2).
+void flux_source(Sim &s, int fluid, Real dt) {
+  const bool gas = (fluid == FL_GAS);
+  const int nsp = gas ? s.c.ns_gas : s.c.ns_dust;
+  if (!nsp) return;
+  const bool multi_d = (s.ndim >= 2), three_d = (s.ndim == 3);
+  {
+    const Coords probe(s, s.ks, s.js, s.is);
+    if (!gas && !(probe.x1dep() || (probe.x2dep() && multi_d) || (probe.x3dep() && three_d)))
+      return;
+  }
+  const ptrdiff_t sj = s.ni, sk = static_cast<ptrdiff_t>(s.ni) * s.nj;
+  std::vector<Real> &u0 = gas ? s.gu0 : s.du0;
+  const std::vector<Real> &prim = gas ? s.gprim : s.dprim;
+  const Real omf = s.rframe.on ? s.rframe.omega : 0.0;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = s.ks; k <= s.ke; ++k)
+    for (int j = s.js; j <= s.je; ++j)
+      for (int i = s.is - 2; i <= s.ie + 1; ++i) {
+        Coords coords(s, k, j, i);
+        const bool x1dep = coords.x1dep();
+        const bool x2dep = coords.x2dep() && multi_d;
+        const bool x3dep = coords.x3dep() && three_d;
+        Real dhdx1[3] = {0.0, 0.0, 0.0}, dhdx2[3] = {0.0, 0.0, 0.0};
+        if (x1dep) coords.GetConnX1(dhdx1);
+        if (x2dep) coords.GetConnX2(dhdx2);
+        (void)x3dep; // geometry.hpp:107-110: no system has an x3-dependent metric
+        Real ax1[2], ax2[2] = {0.0, 0.0}, ax3[2] = {0.0, 0.0};
+        coords.GetFaceAreaX1(ax1);
+        if (multi_d) coords.GetFaceAreaX2(ax2);
+        if (three_d) coords.GetFaceAreaX3(ax3);
+        const Real vol = coords.Volume();
+        const BBox &b = coords.bnds;
+        const Real dx[3] = {b.x1[1] - b.x1[0], b.x2[1] - b.x2[0], b.x3[1] - b.x3[0]};
+        const size_t c = IDX(s, k, j, i);
+        Real vf[3] = {0.0, omf, 0.0}; // RotationVelocity: Cartesian returns {0, omf, 0} (all dh/dx are 0 there)
+        if (coords.sys != CO_CART) {
+          const Real xv[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
+          const Frame fr = to_cyl_frame(coords, xv);
+          const Real vp = omf * fr.x[0];
+          vf[0] = fr.e1[1] * vp, vf[1] = fr.e2[1] * vp, vf[2] = fr.e3[1] * vp;
+        }
+        for (int n = 0; n < nsp; ++n) {
+          // cons pack of FluxSource is <momentum, internal_energy> (gas.cpp:505-511); in the
+          // oracle's full cons layout those are slots ns+3n+d and 5ns+n.
+          Real *mx = u0.data() + (nsp + 3 * n + 0) * s.N;
+          Real *my = u0.data() + (nsp + 3 * n + 1) * s.N;
+          Real *mz = u0.data() + (nsp + 3 * n + 2) * s.N;
+          if (gas) {
+            Real *eg = u0.data() + (5 * nsp + n) * s.N;
+            const Real *p1 = s.gpflux[0].data() + n * s.N, *v1 = s.gvface[0].data() + n * s.N;
+            mx[c] += dt / dx[0] * (p1[c] - p1[c + 1]);
+            eg[c] -= dt / vol * 0.5 * (p1[c] + p1[c + 1]) * (ax1[1] * v1[c + 1] - ax1[0] * v1[c]);
+            if (multi_d) {
+              const Real *p2 = s.gpflux[1].data() + n * s.N, *v2 = s.gvface[1].data() + n * s.N;
+              my[c] += dt / dx[1] * (p2[c] - p2[c + sj]);
+              eg[c] -=
+                  dt / vol * 0.5 * (p2[c] + p2[c + sj]) * (ax2[1] * v2[c + sj] - ax2[0] * v2[c]);
+            }
+            if (three_d) {
+              const Real *p3 = s.gpflux[2].data() + n * s.N, *v3 = s.gvface[2].data() + n * s.N;
+              mz[c] += dt / dx[2] * (p3[c] - p3[c + sk]);
+              eg[c] -=
+                  dt / vol * 0.5 * (p3[c] + p3[c + sk]) * (ax3[1] * v3[c + sk] - ax3[0] * v3[c]);
+            }
+          }
+          const Real dens = prim[n * s.N + c];
+          const Real rdt = dens * dt;
+          const Real vx = prim[(nsp + 3 * n + 0) * s.N + c];
+          const Real vy = prim[(nsp + 3 * n + 1) * s.N + c];
+          const Real vz = prim[(nsp + 3 * n + 2) * s.N + c];
+          if (x1dep)
+            mx[c] += rdt * (dhdx1[0] * SQR(vx + vf[0]) + dhdx1[1] * SQR(vy + vf[1]) + dhdx1[2] * SQR(vz + vf[2]));
+          if (x2dep)
+            my[c] += rdt * (dhdx2[0] * SQR(vx + vf[0]) + dhdx2[1] * SQR(vy + vf[1]) + dhdx2[2] * SQR(vz + vf[2]));
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------------------
+// Coords<GEOM>::ConvertToCylWithVec (geometry.hpp:476-482): only the cylindrical radius and
+// the first component of each basis vector are used by the callers restated here
+// (geometry.hpp:289-306 Cartesian, cylindrical.hpp:117-126 identity, spherical.hpp:191-205 /
+// :382-396 / :556-577, axisymmetric.hpp:134-145).
+struct CylVec {
+  Real R, e1, e2, e3; // xcyl[0], ex1[0], ex2[0], ex3[0]
+};
+inline CylVec to_cyl_with_vec(const Coords &co, const Real xi[3]) {
+  CylVec c;
+  const Real fuzz = 1e-99; // Fuzz<Real>(), artemis.hpp:113-118
+  switch (co.sys) {
+  case CO_CART: {
+    Real R = std::sqrt(xi[0] * xi[0] + xi[1] * xi[1]);
+    const Real cp = xi[0] / (R + fuzz);
+    const Real sp = xi[1] / (R + fuzz);
+    c.R = R, c.e1 = cp, c.e2 = sp, c.e3 = 0.0;
+  } break;
+  case CO_SPH3D:
+  case CO_SPH2D: {
+    const Real ct = std::cos(xi[1]);
+    const Real st = std::sin(xi[1]);
+    c.R = xi[0] * st, c.e1 = st, c.e2 = ct, c.e3 = 0.0;
+  } break;
+  case CO_SPH1D: {
+    const Real ct = 0.0, st = 1.0;
+    c.R = xi[0] * st, c.e1 = st, c.e2 = ct, c.e3 = 0.0;
+  } break;
+  default: // cylindrical, axisymmetric
+    c.R = xi[0], c.e1 = 1.0, c.e2 = 0.0, c.e3 = 0.0;
+  }
+  return c;
+}
+
 // GetSpecificInternalEnergy (artemis_utils.hpp:43-62) on the oracle's gas cons layout
 inline Real specific_internal_energy(const Sim &s, int n, size_t c, const Real hx[3]) {
   const int nsp = s.c.ns_gas;
@@ -1183,6 +1198,24 @@ inline Real specific_internal_energy(const Sim &s, int n, size_t c, const Real h
 // gravity/point_mass.cpp:27-198 PointMassGravity.  Point mass: Cartesian (offset mass,
 // softening, sink), spherical1D/2D and axisymmetric (mass at the origin); cylindrical and
 // spherical3D go through ConvertToCartWithVec like the Cartesian system.
+// gravity.hpp:66-94 Orbit::solve: the separation vector of the binary at time t in a frame
+// rotating with omf (the true anomaly advances uniformly: exact for e = 0)
+template <class G>
+inline void orbit_solve(const G &o, Real t, Real omf, Real pos[3]) {
+  const Real sint = std::sin(t * (o.n - omf));
+  const Real cost = std::cos(t * (o.n - omf));
+  Real cosf = o.cosf0 * cost - o.sinf0 * sint;
+  Real sinf = o.cosf0 * sint + o.sinf0 * cost;
+  const Real rb = o.a * (1.0 - SQR(o.e)) / (1.0 + o.e * cosf);
+  const Real xb = rb * cosf;
+  const Real yb = rb * sinf;
+  cosf = xb * o.coso - o.sino * yb;
+  sinf = xb * o.sino + o.coso * yb;
+  pos[0] = (o.cosO * cosf - o.sinO * sinf * o.cosI);
+  pos[1] = (o.sinO * cosf + o.cosO * sinf * o.cosI);
+  pos[2] = sinf * o.sinI;
+}
+
 void external_gravity(Sim &s, Real time, Real dt) {
   if (s.grav.type == 0) return;
   if (!((time >= s.grav.tstart) && (time < s.grav.tstop))) return; // gravity.cpp:134
@@ -1192,6 +1225,20 @@ void external_gravity(Sim &s, Real time, Real dt) {
   const Real sink_rate = dt * s.grav.sink_rate;
   const Real sink_rad = s.grav.sink;
   const Real rsft2 = SQR(s.grav.soft);
+  // binary_mass.cpp:41-70: positions of the two bodies about the centre of mass `pos`
+  Real pos1[3] = {0, 0, 0}, pos2[3] = {0, 0, 0};
+  const Real mu1 = 1. / (1.0 + s.grav.q), mu2 = s.grav.q / (1.0 + s.grav.q);
+  if (s.grav.type == 3 && s.grav.given_pos) {
+    for (int n = 0; n < 3; n++) pos1[n] = s.grav.pos[n], pos2[n] = s.grav.pos2[n];
+  } else if (s.grav.type == 3) {
+    const Real omf = s.rframe.on ? s.rframe.omega : 0.0;
+    Real rb[3];
+    orbit_solve(s.grav, time, omf, rb);
+    for (int n = 0; n < 3; n++) {
+      pos1[n] = s.grav.pos[n] - mu2 * rb[n];
+      pos2[n] = s.grav.pos[n] + mu1 * rb[n];
+    }
+  }
 #pragma omp parallel for collapse(2) schedule(static)
   for (int k = s.ks; k <= s.ke; ++k)
     for (int j = s.js; j <= s.je; ++j)
@@ -1203,6 +1250,36 @@ void external_gravity(Sim &s, Real time, Real dt) {
         Real gx1 = 0.0, gx2 = 0.0, gx3 = 0.0, fd = 0.0;
         if (s.grav.type == 1) {
           gx1 = s.grav.g[0], gx2 = s.grav.g[1], gx3 = s.grav.g[2];
+        } else if (s.grav.type == 3) { // binary_mass.cpp:86-160
+          const Frame fr = to_cart_frame(coords, dx);
+          Real dxc1[3] = {fr.x[0], fr.x[1], fr.x[2]}, dxc2[3];
+          for (int n = 0; n < 3; n++) {
+            dxc2[n] = dxc1[n] - pos2[n];
+            dxc1[n] -= pos1[n];
+          }
+          auto sph_r = [](const Real x[3]) {
+            const Real R = std::sqrt(x[0] * x[0] + x[1] * x[1]);
+            return std::sqrt(R * R + x[2] * x[2]);
+          };
+          const Real r1 = sph_r(dxc1), r2 = sph_r(dxc2);
+          const Real rad2_1 = SQR(r1) + SQR(s.grav.soft);
+          const Real rad2_2 = SQR(r2) + SQR(s.grav.soft2);
+          const Real idr3_1 = 1.0 / (std::sqrt(rad2_1) * rad2_1);
+          const Real idr3_2 = 1.0 / (std::sqrt(rad2_2) * rad2_2);
+          Real g[3] = {-gm * (mu1 * dxc1[0] * idr3_1 + mu2 * dxc2[0] * idr3_2),
+                       multi_d * (-gm * (mu1 * dxc1[1] * idr3_1 + mu2 * dxc2[1] * idr3_2)),
+                       three_d * (-gm * (mu1 * dxc1[2] * idr3_1 + mu2 * dxc2[2] * idr3_2))};
+          gx1 = g[0] * fr.e1[0] + g[1] * fr.e1[1] + g[2] * fr.e1[2];
+          gx2 = g[0] * fr.e2[0] + g[1] * fr.e2[1] + g[2] * fr.e2[2];
+          gx3 = g[0] * fr.e3[0] + g[1] * fr.e3[1] + g[2] * fr.e3[2];
+          const Real sink_rate2 = dt * s.grav.sink_rate2;
+          const Real sramp1 = sink_rate * SQR((r1 - sink_rad) / sink_rad);
+          const Real sramp2 = sink_rate2 * SQR((r2 - s.grav.sink2) / s.grav.sink2);
+          Real fd1 = std::min(0.25, sramp1 / (1.0 + sramp1));
+          Real fd2 = std::min(0.25, sramp2 / (1.0 + sramp2));
+          fd1 *= ((sink_rate > 0.0) && (sink_rad > 0.0) && (r1 <= sink_rad));
+          fd2 *= ((sink_rate2 > 0.0) && (s.grav.sink2 > 0.0) && (r2 <= s.grav.sink2));
+          fd = fd1 + fd2;
         } else {
           Real dr;
           if (coords.sys == CO_SPH1D || coords.sys == CO_SPH2D) { // point_mass.cpp:78-81
@@ -2750,6 +2827,20 @@ void oracle_set_gravity_point(void *h, double mass, double soft, double sink, do
   Sim &s = *static_cast<Sim *>(h);
   s.grav.type = 2, s.grav.gm = 1.0 * mass, s.grav.soft = soft, s.grav.sink = sink;
   s.grav.sink_rate = sink_rate, s.grav.pos[0] = x, s.grav.pos[1] = y, s.grav.pos[2] = z;
+}
+// <gravity/binary> (gravity.cpp:77-111); angles in radians (the deck's degrees * M_PI / 180.)
+// p = {mass, q, a, e, i, omega, Omega, f, soft1, soft2, sink1, sink2, sink_rate1, sink_rate2, x, y, z}
+void oracle_set_gravity_binary(void *h, const double *p) {
+  Sim &s = *static_cast<Sim *>(h);
+  auto &g = s.grav;
+  g.type = 3, g.gm = 1.0 * p[0], g.q = p[1], g.a = p[2], g.e = p[3];
+  g.n = std::sqrt(g.gm / (g.a * g.a * g.a));
+  g.coso = std::cos(p[5]), g.sino = std::sin(p[5]);
+  g.cosI = std::cos(p[4]), g.sinI = std::sin(p[4]);
+  g.cosO = std::cos(p[6]), g.sinO = std::sin(p[6]);
+  g.cosf0 = std::cos(p[7]), g.sinf0 = std::sin(p[7]);
+  g.soft = p[8], g.soft2 = p[9], g.sink = p[10], g.sink2 = p[11], g.sink_rate = p[12], g.sink_rate2 = p[13];
+  g.pos[0] = p[14], g.pos[1] = p[15], g.pos[2] = p[16];
 }
 void oracle_set_gravity_window(void *h, double tstart, double tstop) {
   Sim &s = *static_cast<Sim *>(h);

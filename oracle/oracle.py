@@ -110,6 +110,7 @@ def lib():
         d, vp, i = C.c_double, C.c_void_p, C.c_int
         L.oracle_set_gravity_uniform.argtypes = [vp, d, d, d]
         L.oracle_set_gravity_point.argtypes = [vp] + [d] * 7
+        L.oracle_set_gravity_binary.argtypes = [vp, C.POINTER(d)]
         L.oracle_set_gravity_window.argtypes = [vp, d, d]
         L.oracle_set_rotating_frame.argtypes = [vp, d, d]
         L.oracle_set_drag.argtypes = [vp, i, i, d, d, C.POINTER(d), C.POINTER(d)]
@@ -255,6 +256,15 @@ class Oracle:
     def set_gravity_point(self, mass, soft=0.0, sink=0.0, sink_rate=0.0, x=0.0, y=0.0, z=0.0):
         """<gravity/point> mass, soft, sink, sink_rate, x, y, z"""
         self.L.oracle_set_gravity_point(self.h, mass, soft, sink, sink_rate, x, y, z)
+
+    def set_gravity_binary(self, mass, q, a, e=0.0, i=0.0, omega=0.0, Omega=0.0, f=180.0, soft1=0.0, soft2=0.0,
+                           sink1=0.0, sink2=0.0, sink_rate1=0.0, sink_rate2=0.0, x=0.0, y=0.0, z=0.0):
+        """<gravity/binary> (angles in degrees like the deck; gravity.cpp:99-104 converts with M_PI / 180.)"""
+        import math
+        r = lambda deg: deg * math.pi / 180.
+        self.L.oracle_set_gravity_binary(self.h, (C.c_double * 17)(
+            mass, q, a, e, r(i), r(omega), r(Omega), r(f), soft1, soft2, sink1, sink2, sink_rate1, sink_rate2,
+            x, y, z))
 
     def set_gravity_window(self, tstart, tstop):
         self.L.oracle_set_gravity_window(self.h, tstart, tstop)

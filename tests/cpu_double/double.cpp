@@ -58,6 +58,7 @@ struct Bound {
     s = static_cast<Sim *>(oracle_create(&c));
     // use the table's f0/dx verbatim so cell edges match the product's kernels bit for bit
     for (int d = 0; d < 3; ++d) s->f0[d] = g[2 * d], s->dx[d] = g[2 * d + 1];
+    if (p->omega_frame != 0.0) s->rframe.on = true, s->rframe.omega = p->omega_frame; // FluxSource's vf
   }
   ~Bound() { oracle_destroy(s); }
   void in(std::vector<Real> &dst, double *const *tab, int nvar) {
@@ -263,7 +264,9 @@ int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_
     Sim &s = *B.s;
     s.grav.type = g->type, s.grav.gm = g->gm, s.grav.soft = g->soft, s.grav.sink = g->sink;
     s.grav.sink_rate = g->sink_rate, s.grav.tstart = g->tstart, s.grav.tstop = g->tstop;
-    for (int d = 0; d < 3; ++d) s.grav.g[d] = g->g[d], s.grav.pos[d] = g->pos[d];
+    for (int d = 0; d < 3; ++d) s.grav.g[d] = g->g[d], s.grav.pos[d] = g->pos[d], s.grav.pos2[d] = g->pos2[d];
+    s.grav.q = g->q, s.grav.soft2 = g->soft2, s.grav.sink2 = g->sink2, s.grav.sink_rate2 = g->sink_rate2;
+    s.grav.given_pos = true;
     external_gravity(s, time, dt);
     B.out(s.gu0, p->gas.cons0, s.nvg), B.out(s.du0, p->dust.cons0, s.nvd);
   }
@@ -406,7 +409,9 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
       const artemis_gravity_t *g = a->gravity;
       s.grav.type = g->type, s.grav.gm = g->gm, s.grav.soft = g->soft, s.grav.sink = g->sink;
       s.grav.sink_rate = g->sink_rate, s.grav.tstart = g->tstart, s.grav.tstop = g->tstop;
-      for (int d = 0; d < 3; ++d) s.grav.g[d] = g->g[d], s.grav.pos[d] = g->pos[d];
+      for (int d = 0; d < 3; ++d) s.grav.g[d] = g->g[d], s.grav.pos[d] = g->pos[d], s.grav.pos2[d] = g->pos2[d];
+      s.grav.q = g->q, s.grav.soft2 = g->soft2, s.grav.sink2 = g->sink2, s.grav.sink_rate2 = g->sink_rate2;
+      s.grav.given_pos = true;
       external_gravity(s, a->time, a->bdt);
     }
     if (a->rf_omega != 0.0) {

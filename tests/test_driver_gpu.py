@@ -770,3 +770,60 @@ def test_alpha_disk_deck_against_oracle_and_reference_pin(hiplib):
     e_m = np.abs((3 * np.pi * al * h ** 2 - mdot) / (3 * np.pi * al * h ** 2)).mean()
     assert e_d <= 2e-3 and e_m <= 2e-3, (e_d, e_m)
     assert abs(e_d - 8.76e-4) < 5e-5 and abs(e_m - 1.811e-3) < 5e-5, (e_d, e_m)
+
+
+def binary_oracle(nx=(256, 512, 1)):
+    o = Oracle(nx, (0.3, 0.0, -0.5), (3.0, 6.283185307179586, 0.5), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.00001, dfloor=1e-10, siefloor=1e-10, cfl=0.3, integrator="rk2", coordinates="cylindrical",
+               bc=("ic", "ic") + ("periodic",) * 4)
+    o.set_gravity_binary(mass=1.0, q=1e-5, a=1.0, e=0.0, f=180.0, soft1=0.0, soft2=0.03)
+    o.set_rotating_frame(1.0, 0.0)
+    o.set_viscosity("alpha", alpha=1e-3, r0=1.0, Omega0=1.0)
+    o.set_drag("self", "constant")
+    big = 1.7976931348623157e308
+    o.set_damping(0, inner=(0.45, -big, -big), inner_rate=(30.0, 0.0, 0.0), outer=(2.8, big, big),
+                  outer_rate=(30.0, 0.0, 0.0))
+    o.pgen_disk(r0=1.0, rho0=1.0, dslope=-0.5, tslope=-1.0, h0=0.05, dens_min=1e-10, pres_min=1e-13)
+    return o
+
+
+def test_binary_deck_bitwise_and_reference_pin(hiplib):
+    """inputs/disk/binary_cyl.in (tst/scripts/binary/binary.py:44-50): the planet's spiral wake after one
+    orbit.  60 cycles at 64 x 128 on one block bit for bit against the oracle (disk pgen, binary
+    gravity with the host-evaluated orbit, alpha viscosity, rotating frame, self damping, `ic`
+    conditions -- no device transcendental anywhere in this deck), then the full 256 x 512 deck on
+    its 128 blocks to t = 2 pi against binary.py:82-131: wake azimuth on the rings R = 0.9 / 1.1
+    within 3 % of the linear prediction, <T>(R) a power law of index -1 (2e-4) and norm h0^2 (5e-3)."""
+    from artemis_amd.driver import Simulation
+    small = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=128", "parthenon/meshblock/nx1=64",
+             "parthenon/meshblock/nx2=128", "parthenon/time/nlim=60"]
+    s = Simulation(DECK("disk", "binary_cyl.in"), small)
+    o = binary_oracle((64, 128, 1))
+    s.evolve(), o.evolve(2 * np.pi, 60)
+    assert s.ncycle == o.ncycle == 60 and s.time == o.time and s.dt == o.dt
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    f = Simulation(DECK("disk", "binary_cyl.in"), ["parthenon/time/tlim={:.16f}".format(2.0 * np.pi)])
+    assert f.nblocks == 128
+    f.evolve()
+    assert abs(f.time - 2 * np.pi) < 1e-12
+    d = np.zeros((512, 256))
+    T = np.zeros((512, 256))
+    for b in range(128):
+        x1a, x1b, x2a, x2b, _, _ = f.block_bounds(b)
+        i0, j0 = int(round((x1a - 0.3) / 2.7 * 256)), int(round(x2a / (2 * np.pi) * 512))
+        P = f.interior(f.field("gas.prim", b))
+        d[j0:j0 + 32, i0:i0 + 32] = P[0, 0]
+        T[j0:j0 + 32, i0:i0 + 32] = P[5, 0] * (1.00001 - 1.0)
+    rc = 0.3 + (np.arange(256) + 0.5) * 2.7 / 256
+    pc = (np.arange(512) + 0.5) * 2 * np.pi / 512
+    sig = d - d.mean(axis=0)[None, :]
+
+    def spiral_pos(r, h=0.05):  # analysis.py:126-142
+        v = (2.0 / (3 * h) * (r ** 1.5 - 1.5 * np.log(r) - 1.0)) % (2 * np.pi)
+        return (np.pi - v) % (2 * np.pi) if r > 1.0 else (np.pi + v) % (2 * np.pi)
+    ii, io = np.argwhere(rc >= 0.9)[0][0], np.argwhere(rc >= 1.1)[0][0]
+    p_i, p_o = pc[np.argmax(sig[:, ii])], pc[np.argmax(sig[:, io])]
+    assert abs(p_i - spiral_pos(0.9)) / spiral_pos(0.9) < 0.03, p_i
+    assert abs(p_o - spiral_pos(1.1)) / spiral_pos(1.1) < 0.03, p_o
+    fit = np.polyfit(np.log(rc), np.log(T.mean(axis=0)), 1)
+    assert abs(fit[0] + 1.0) < 2e-4 and abs(np.exp(fit[1]) - 0.0025) / 0.0025 < 5e-3, fit

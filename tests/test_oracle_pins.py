@@ -363,19 +363,19 @@ def disk_oracle(g, gam, b, nx=None):
 
 
 @pytest.mark.parametrize("g,gam,b,err_ref,dt_ref", [
-    ("axi", 1.0, "ic", 3.480e-3, 3.0281e-4), ("axi", 1.0, "extrap", 3.466e-3, 3.0264e-4),
-    ("axi", 1.4, "ic", 5.765e-3, 1.0688e-3), ("axi", 1.4, "extrap", 5.765e-3, 1.0694e-3),
-    ("cyl", 1.0, "ic", 1.570e-4, 5.3926e-3), ("cyl", 1.4, "extrap", 1.378e-4, 5.1354e-3),
-    ("sph", 1.4, "ic", 4.705e-4, 1.3804e-3)])
+    ("axi", 1.0, "ic", 5.380e-3, 1.0038e-2), ("axi", 1.0, "extrap", 5.365e-3, 1.0895e-2),
+    ("axi", 1.4, "ic", 4.292e-3, 8.7865e-3), ("axi", 1.4, "extrap", 4.269e-3, 8.1003e-3),
+    ("cyl", 1.0, "ic", 1.683e-4, 5.5542e-3), ("cyl", 1.4, "extrap", 1.356e-4, 5.9155e-3),
+    ("sph", 1.4, "ic", 4.600e-4, 1.3094e-3)])
 def test_disk_reference_test_pins(g, gam, b, err_ref, dt_ref):
     """tst/scripts/disk/disk.py:36-45,58-96,118-187 on the shipped uniform-mesh decks
     inputs/disk/disk_{axi,cyl,sph}.in (disk pgen, `ic` / `extrap` user conditions, point-mass
     gravity, alpha viscosity, rotating frame in its angular-momentum-conserving flux form): after
     the test's 10 cycles (5 + 5 across its restart) no NaN, positive density and temperature,
     1e-4 < dt < 3e-2 and density error sqrt(sum d0 (d-d0)^2)/sum d0 <= 6e-3.  The oracle's values
-    (all twelve geometry x polytropic index x condition cases were run once: axi 3.5e-3 / 5.8e-3,
-    cyl 1.4e-4 .. 1.6e-4, sph 4.7e-4 .. 7.2e-4) sit just under the reference's tolerance, which is
-    how a tolerance calibrated on the reference's own output looks.  The Cartesian deck is
+    (all twelve geometry x polytropic index x condition cases were run once: axi 5.4e-3 / 4.3e-3,
+    cyl 1.3e-4 .. 1.7e-4, sph 4.6e-4 .. 5.8e-4) sit under the reference's tolerance, the axisymmetric
+    ones (whose mesh resolves the vertical structure over +-40 scale heights) within 10 % of it.  The Cartesian deck is
     statically refined (SMR) and out of scope."""
     o = disk_oracle(g, gam, b)
     d0 = o.interior(o.gprim)[0].copy()

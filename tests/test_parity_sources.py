@@ -70,6 +70,24 @@ def test_point_mass_gravity(hiplib, coordinates, nx, lo, hi):
     check_cons(o, mb, "PointMassGravity, no sink")
 
 
+@pytest.mark.parametrize("coordinates,nx,lo,hi", GRAV_GEOMS[:3] + GRAV_FRAME)
+def test_binary_gravity(hiplib, coordinates, nx, lo, hi):
+    """BinaryMassGravity (binary_mass.cpp:27-203): two softened point masses with sinks at the
+    positions Orbit::solve (gravity.hpp:66-94) gives for the time of the step, in a frame rotating
+    with omf; Cartesian, cylindrical, spherical3D."""
+    from artemis_amd.pack import binary_orbit, gravity_binary
+    o, mb = pair(nx, lo, hi, ns_gas=2, ns_dust=2, coordinates=coordinates, seed=31)
+    kw = dict(soft1=0.02, soft2=0.03, sink1=0.5, sink2=0.4, sink_rate1=2.0, sink_rate2=5.0)
+    o.set_rotating_frame(0.8, 0.0)
+    o.set_gravity_binary(1.7, 0.3, a=0.9, e=0.2, i=20.0, omega=35.0, Omega=50.0, f=110.0, x=0.1, y=-0.05, z=0.02, **kw)
+    t = 0.37
+    rb = binary_orbit(1.7, 0.9, e=0.2, i=20.0, omega=35.0, Omega=50.0, f=110.0)(t, 0.8)
+    g = gravity_binary(1.7, 0.3, rb, com=(0.1, -0.05, 0.02), **kw)
+    o.ExternalGravity(t, 1.0e-3)
+    mb.ExternalGravity(t, 1.0e-3, g)
+    check_cons(o, mb, "BinaryMassGravity")
+
+
 @pytest.mark.parametrize("coordinates,nx,lo,hi", GRAV_GEOMS + [
     ("cylindrical", (16, 8, 6), (0.5, 0.0, -1.0), (2.0, 6.0, 1.0)),
     ("spherical", (16, 8, 6), (0.3, 0.6, 0.0), (1.5, 2.5, 6.0))])
@@ -116,6 +134,21 @@ def test_rotating_frame_curvilinear(hiplib, coordinates, nx, lo, hi):
         o.CalculateFluxes(fluid, False)
         mb.CalculateFluxes(fluid, False)
     o.set_rotating_frame(0.9, 0.0)
+    mb.pack.omega_frame = 0.9
+    # the centrifugal / Coriolis part lives in FluxSource's coordinate sources: (v + vf)^2 dh/dx with
+    # vf = RotationVelocity(xv, omf) (fluid_fluxes.hpp:345, :395-415)
+    before = mb.gas_u0.clone()
+    for fluid in (0, 1):
+        o.FluxSource(1.5e-3, fluid)
+        mb.FluxSource(1.5e-3, fluid)
+    check_cons(o, mb, "FluxSource in the rotating frame")
+    mb2_u0 = mb.gas_u0.clone()
+    mb.gas_u0.copy_(before)
+    mb.pack.omega_frame = 0.0
+    mb.FluxSource(1.5e-3, 0)
+    assert not torch.equal(mb.gas_u0, mb2_u0)  # the frame velocity matters
+    mb.gas_u0.copy_(mb2_u0)
+    mb.pack.omega_frame = 0.9
     o.RotatingFrameForce(1.5e-3)
     mb.RotatingFrameForce(0.9, 0.0, 0.0, 1.5e-3)
     check_cons(o, mb, "RotatingFrame")
@@ -203,6 +236,11 @@ def test_source_abi_contract(hiplib):
     with pytest.raises(capi.ArtemisHipError) as e:  # ConvertToCartWithVec needs cos / sin of the azimuth
         cyl.ExternalGravity(0.0, 1e-3, gravity_point(1.0))
     assert e.value.code == capi.EINVAL and "metric" in str(e.value)
+    from artemis_amd.pack import gravity_binary
+    axi = MeshBlockPack(1, (8, 8, 1), [(0.5, -1.0, 0.0)], [(1.0, 1.0, 1.0)], ns_dust=1, coordinates="axisymmetric")
+    with pytest.raises(capi.ArtemisHipError) as e:  # gravity.cpp:82-83
+        axi.ExternalGravity(0.0, 1e-3, gravity_binary(1.0, 0.1, (1.0, 0.0, 0.0)))
+    assert e.value.code == capi.EINVAL and "Binary gravity" in str(e.value)
     with pytest.raises(capi.ArtemisHipError) as e:  # rotating_frame.cpp:34-38
         mb.RotatingFrameForce(1.0, 1.5, 0.0, 1e-3)
     assert e.value.code == capi.EINVAL and "qshear" in str(e.value)
