@@ -35,7 +35,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
                        hipStream_t s);
 // kernels_diffusion.hip
 void launch_zero_diffusion_flux(const PackView &P, hipStream_t s);
-void launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s);
+int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s);
 void launch_thermal_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s);
 void launch_diffusion_update(const PackView &P, const artemis_diffusion_t &D, double dt, hipStream_t s);
 void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double cfl, double *dt_dev,

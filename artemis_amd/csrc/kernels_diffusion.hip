@@ -113,108 +113,129 @@ ADEV double velocity_divergence(const PackView &P, double *const *prim, int b, i
   return divv / (2.0 * m.vol);
 }
 
+// Per-cell quantities the face kernels share, written once per stage by viscous_cell_kernel (the
+// reference keeps them in scratch rows per pencil, momentum_diffusion.hpp:620-700): the contravariant
+// velocities v^d = v_d / h_d, VelocityDivergence and the dynamic viscosity.  Arrays of
+// [nb * ns][nk * nj * ni] doubles in a library-owned device buffer.
+struct ViscScratch {
+  double *sv[3], *divu, *mu;
+};
+template <bool CURV>
+__global__ __launch_bounds__(TX *TY) void viscous_cell_kernel(const PackView P, const Box r,
+                                                              const artemis_diffusion_t D, const ViscScratch w) {
+  BOX_CELL(r)
+  const FluidView &f = P.gas;
+  const int ns = f.ns, nv = 6 * ns;
+  const long N = static_cast<long>(P.ni) * P.nj * P.nk;
+  double hx[3];
+  scale_factors<CURV>(P, b, k, j, i, hx);
+  for (int n = 0; n < ns; ++n) {
+    const long q = (static_cast<long>(b) * ns + n) * N + c;
+    for (int d = 0; d < 3; ++d) w.sv[d][q] = f.prim[b * nv + ns + 3 * n + d][c] / hx[d];
+    w.divu[q] = velocity_divergence<CURV>(P, f.prim, b, n, k, j, i);
+    w.mu[q] = coeff_of(D.visc, D.cv, P.gm1, f.prim[b * nv + n][c], f.prim[b * nv + 5 * ns + n][c], b, c);
+  }
+}
+
 // MomentumFluxImpl (momentum_diffusion.hpp:597-755): StrainTensorFace<XDIR> (:28-377) and
 // StressTensorFaceX? (:379-560) of the lower `dir` face of cell (k,j,i)
 template <int DIR, bool CURV>
 __global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, const Box r,
-                                                              const artemis_diffusion_t D) {
+                                                              const artemis_diffusion_t D, const ViscScratch w) {
   BOX_CELL(r)
   const FluidView &f = P.gas;
-  const int ns = f.ns, nv = 6 * ns, nq = 4 * ns;
+  const int ns = f.ns, nq = 4 * ns;
   const int multid = (P.ndim >= 2), threed = (P.ndim == 3);
   const Geo<CURV> ge{P, b};
   const artemis_diffcoeff_t &dp = D.visc;
   constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1);
   const long cm = c - ((DIR == 1) ? 1 : ((DIR == 2) ? P.sj : P.sk));
+  const long N = static_cast<long>(P.ni) * P.nj * P.nk;
   const double fuzz = 1e-99; // Fuzz<Real>()
-  double hx[3], hx_m[3], hxf[3] = {1.0, 1.0, 1.0};
-  ge.hx(k, j, i, hx), ge.hx(k - dk, j - dj, i - di, hx_m);
+  double hxf[3] = {1.0, 1.0, 1.0};
   if constexpr (CURV) make_coords(P, b, k, j, i).face_scale(DIR, hxf); // h_d at the face centroid
+  // dh_a/dx_k of the two cells sharing the face, a = DIR - 1; only dh2dx1, dh3dx1, dh3dx2 can be non-zero
+  double dh0 = 0.0, dh1 = 0.0, dh0_m = 0.0, dh1_m = 0.0;
+  if constexpr (CURV && DIR != 1) {
+    double d21, d31, d32;
+    ge.conn(k, j, i, d21, d31, d32);
+    dh0 = (DIR == 2) ? d21 : d31, dh1 = (DIR == 3) ? d32 : 0.0;
+    ge.conn(k - dk, j - dj, i - di, d21, d31, d32);
+    dh0_m = (DIR == 2) ? d21 : d31, dh1_m = (DIR == 3) ? d32 : 0.0;
+  }
+  // Coords::Distance between cell centres: geometry only, shared by the species
+  double dxa, dxb, dxb_m, dxc, dxc_m;
+  if constexpr (DIR == 1) {
+    dxa = ge.dist(k, j, i, k, j, i - 1);
+    dxb = multid ? ge.dist(k, j - multid, i, k, j + multid, i) : fuzz;
+    dxb_m = multid ? ge.dist(k, j - multid, i - 1, k, j + multid, i - 1) : fuzz;
+    dxc = threed ? ge.dist(k - threed, j, i, k + threed, j, i) : fuzz;
+    dxc_m = threed ? ge.dist(k - threed, j, i - 1, k + threed, j, i - 1) : fuzz;
+  } else if constexpr (DIR == 2) {
+    dxb = ge.dist(k, j, i - 1, k, j, i + 1);
+    dxb_m = ge.dist(k, j - 1, i - 1, k, j - 1, i + 1);
+    dxa = ge.dist(k, j, i, k, j - 1, i);
+    dxc = threed ? ge.dist(k - threed, j, i, k + threed, j, i) : fuzz;
+    dxc_m = threed ? ge.dist(k - threed, j - 1, i, k + threed, j - 1, i) : fuzz;
+  } else {
+    dxb = ge.dist(k, j, i - 1, k, j, i + 1);
+    dxb_m = ge.dist(k - 1, j, i - 1, k - 1, j, i + 1);
+    dxc = ge.dist(k, j - 1, i, k, j + 1, i);
+    dxc_m = ge.dist(k - 1, j - 1, i, k - 1, j + 1, i);
+    dxa = ge.dist(k, j, i, k - 1, j, i);
+  }
+  const long sj = multid * P.sj, sk = threed * P.sk;
   for (int n = 0; n < ns; ++n) {
-    const double *q[3] = {f.prim[b * nv + ns + 3 * n + 0], f.prim[b * nv + ns + 3 * n + 1],
-                          f.prim[b * nv + ns + 3 * n + 2]};
-    auto vel = [&](int comp, int kk, int jj, int ii) {
-      return q[comp][(static_cast<long>(kk) * P.nj + jj) * P.ni + ii];
-    };
-    auto sv = [&](int comp, int kk, int jj, int ii) { // v^comp = v / h_comp of that cell
-      double h[3];
-      ge.hx(kk, jj, ii, h);
-      return vel(comp, kk, jj, ii) / h[comp];
-    };
-    // v^k dh_a/dx_k / h_a of a cell, a = DIR - 1; only dh2dx1, dh3dx1, dh3dx2 can be non-zero
-    auto src_of = [&](int kk, int jj, int ii) {
-      double h[3], d21, d31, d32;
-      ge.hx(kk, jj, ii, h), ge.conn(kk, jj, ii, d21, d31, d32);
-      const double dh0 = (DIR == 2) ? d21 : ((DIR == 3) ? d31 : 0.0);
-      const double dh1 = (DIR == 3) ? d32 : 0.0;
-      return vel(0, kk, jj, ii) / h[0] * dh0 + vel(1, kk, jj, ii) / h[1] * dh1 + vel(2, kk, jj, ii) / h[2] * 0.0;
-    };
-    const double v[3] = {vel(0, k, j, i) / hx[0], vel(1, k, j, i) / hx[1], vel(2, k, j, i) / hx[2]};
+    const long base = (static_cast<long>(b) * ns + n) * N;
+    const double *s0 = w.sv[0] + base, *s1 = w.sv[1] + base, *s2 = w.sv[2] + base;
+    // v^k dh_a/dx_k / h_a of a cell (the third connection row is zero for every system)
+    const double src = s0[c] * dh0 + s1[c] * dh1 + s2[c] * 0.0;
+    const double src_m = s0[cm] * dh0_m + s1[cm] * dh1_m + s2[cm] * 0.0;
     double flx[3];
     if constexpr (DIR == 1) {
-      const double dx1 = ge.dist(k, j, i, k, j, i - 1);
-      const double dx2 = multid ? ge.dist(k, j - multid, i, k, j + multid, i) : fuzz;
-      const double dx2_xm = multid ? ge.dist(k, j - multid, i - 1, k, j + multid, i - 1) : fuzz;
-      const double dx3 = threed ? ge.dist(k - threed, j, i, k + threed, j, i) : fuzz;
-      const double dx3_xm = threed ? ge.dist(k - threed, j, i - 1, k + threed, j, i - 1) : fuzz;
-      const double dv1 = v[0] - sv(0, k, j, i - 1);
-      flx[0] = 2 * dv1 / dx1 + 0.5 * (src_of(k, j, i) + src_of(k, j, i - 1));
-      const double dv2 = v[1] - sv(1, k, j, i - 1);
-      const double dv12 = sv(0, k, j + multid, i) - sv(0, k, j - multid, i);
-      const double dv12_xm = sv(0, k, j + multid, i - 1) - sv(0, k, j - multid, i - 1);
-      flx[1] = multid * 0.5 * (dv12 / dx2 + dv12_xm / dx2_xm) + sqr(hxf[1] / hxf[0]) * dv2 / dx1;
-      const double dv3 = v[2] - sv(2, k, j, i - 1);
-      const double dv13 = sv(0, k + threed, j, i) - sv(0, k - threed, j, i);
-      const double dv13_xm = sv(0, k + threed, j, i - 1) - sv(0, k - threed, j, i - 1);
-      flx[2] = threed * 0.5 * (dv13 / dx3 + dv13_xm / dx3_xm) + sqr(hxf[2] / hxf[0]) * dv3 / dx1;
+      const double dv1 = s0[c] - s0[cm];
+      flx[0] = 2 * dv1 / dxa + 0.5 * (src + src_m);
+      const double dv2 = s1[c] - s1[cm];
+      const double dv12 = s0[c + sj] - s0[c - sj];
+      const double dv12_xm = s0[cm + sj] - s0[cm - sj];
+      flx[1] = multid * 0.5 * (dv12 / dxb + dv12_xm / dxb_m) + sqr(hxf[1] / hxf[0]) * dv2 / dxa;
+      const double dv3 = s2[c] - s2[cm];
+      const double dv13 = s0[c + sk] - s0[c - sk];
+      const double dv13_xm = s0[cm + sk] - s0[cm - sk];
+      flx[2] = threed * 0.5 * (dv13 / dxc + dv13_xm / dxc_m) + sqr(hxf[2] / hxf[0]) * dv3 / dxa;
     } else if constexpr (DIR == 2) {
-      const double dx1 = ge.dist(k, j, i - 1, k, j, i + 1);
-      const double dx1_ym = ge.dist(k, j - 1, i - 1, k, j - 1, i + 1);
-      const double dx2 = ge.dist(k, j, i, k, j - 1, i);
-      const double dx3 = threed ? ge.dist(k - threed, j, i, k + threed, j, i) : fuzz;
-      const double dx3_ym = threed ? ge.dist(k - threed, j - 1, i, k + threed, j - 1, i) : fuzz;
-      const double dv1 = v[0] - sv(0, k, j - 1, i);
-      const double dv21 = sv(1, k, j, i + 1) - sv(1, k, j, i - 1);
-      const double dv21_ym = sv(1, k, j - 1, i + 1) - sv(1, k, j - 1, i - 1);
-      flx[0] = 0.5 * (dv21 / dx1 + dv21_ym / dx1_ym) + sqr(hxf[0] / hxf[1]) * dv1 / dx2;
-      const double dv2 = v[1] - sv(1, k, j - 1, i);
-      flx[1] = 2 * dv2 / dx2 + 0.5 * (src_of(k, j, i) + src_of(k, j - 1, i));
-      const double dv3 = v[2] - sv(2, k, j - 1, i);
-      const double dv23 = sv(1, k + threed, j, i) - sv(1, k - threed, j, i);
-      const double dv23_ym = sv(1, k + threed, j - 1, i) - sv(1, k - threed, j - 1, i);
-      flx[2] = threed * 0.5 * (dv23 / dx3 + dv23_ym / dx3_ym) + sqr(hxf[2] / hxf[1]) * dv3 / dx2;
+      const double dv1 = s0[c] - s0[cm];
+      const double dv21 = s1[c + 1] - s1[c - 1];
+      const double dv21_ym = s1[cm + 1] - s1[cm - 1];
+      flx[0] = 0.5 * (dv21 / dxb + dv21_ym / dxb_m) + sqr(hxf[0] / hxf[1]) * dv1 / dxa;
+      const double dv2 = s1[c] - s1[cm];
+      flx[1] = 2 * dv2 / dxa + 0.5 * (src + src_m);
+      const double dv3 = s2[c] - s2[cm];
+      const double dv23 = s1[c + sk] - s1[c - sk];
+      const double dv23_ym = s1[cm + sk] - s1[cm - sk];
+      flx[2] = threed * 0.5 * (dv23 / dxc + dv23_ym / dxc_m) + sqr(hxf[2] / hxf[1]) * dv3 / dxa;
     } else {
-      const double dx1 = ge.dist(k, j, i - 1, k, j, i + 1);
-      const double dx1_zm = ge.dist(k - 1, j, i - 1, k - 1, j, i + 1);
-      const double dx2 = ge.dist(k, j - 1, i, k, j + 1, i);
-      const double dx2_zm = ge.dist(k - 1, j - 1, i, k - 1, j + 1, i);
-      const double dx3 = ge.dist(k, j, i, k - 1, j, i);
-      const double dv1 = v[0] - sv(0, k - 1, j, i);
-      const double dv31 = sv(2, k, j, i + 1) - sv(2, k, j, i - 1);
-      const double dv31_zm = sv(2, k - 1, j, i + 1) - sv(2, k - 1, j, i - 1);
-      flx[0] = 0.5 * (dv31 / dx1 + dv31_zm / dx1_zm) + sqr(hxf[0] / hxf[2]) * dv1 / dx3;
-      const double dv2 = v[1] - sv(1, k - 1, j, i);
-      const double dv32 = sv(2, k, j + 1, i) - sv(2, k, j - 1, i);
-      const double dv32_zm = sv(2, k - 1, j + 1, i) - sv(2, k - 1, j - 1, i);
-      flx[1] = 0.5 * (dv32 / dx2 + dv32_zm / dx2_zm) + sqr(hxf[1] / hxf[2]) * dv2 / dx3;
-      const double dv3 = v[2] - sv(2, k - 1, j, i);
-      flx[2] = 2 * dv3 / dx3 + 0.5 * (src_of(k, j, i) + src_of(k - 1, j, i));
+      const double dv1 = s0[c] - s0[cm];
+      const double dv31 = s2[c + 1] - s2[c - 1];
+      const double dv31_zm = s2[cm + 1] - s2[cm - 1];
+      flx[0] = 0.5 * (dv31 / dxb + dv31_zm / dxb_m) + sqr(hxf[0] / hxf[2]) * dv1 / dxa;
+      const double dv2 = s1[c] - s1[cm];
+      const double dv32 = s2[c + P.sj] - s2[c - P.sj];
+      const double dv32_zm = s2[cm + P.sj] - s2[cm - P.sj];
+      flx[1] = 0.5 * (dv32 / dxc + dv32_zm / dxc_m) + sqr(hxf[1] / hxf[2]) * dv2 / dxa;
+      const double dv3 = s2[c] - s2[cm];
+      flx[2] = 2 * dv3 / dxa + 0.5 * (src + src_m);
     }
-    const double *rho = f.prim[b * nv + n], *se = f.prim[b * nv + 5 * ns + n];
-    const double mu = coeff_of(dp, D.cv, P.gm1, rho[c], se[c], b, c);
-    const double mu_m = coeff_of(dp, D.cv, P.gm1, rho[cm], se[cm], b, cm);
-    const double mus = face_average(dp.avg, mu, mu_m);
-    const double divu = velocity_divergence<CURV>(P, f.prim, b, n, k, j, i);
-    const double divu_m = velocity_divergence<CURV>(P, f.prim, b, n, k - dk, j - dj, i - di);
+    const double mus = face_average(dp.avg, w.mu[base + c], w.mu[base + cm]);
+    const double divu = w.divu[base + c], divu_m = w.divu[base + cm];
     const double hf = hxf[DIR - 1];
     double fl[3];
     for (int qq = 0; qq < 3; ++qq) fl[qq] = hf * mus * flx[qq];
     fl[DIR - 1] = hf * mus * (flx[DIR - 1] - 1. / 3 * (1. - dp.eta) * (divu + divu_m));
     double *const *qf = f.dflux[DIR - 1];
     for (int qq = 0; qq < 3; ++qq) qf[b * nq + 3 * n + qq][c] += fl[qq];
-    qf[b * nq + 3 * ns + n][c] += 0.5 * (q[0][c] / hx[0] + q[0][cm] / hx_m[0]) * fl[0] +
-                                  0.5 * (q[1][c] / hx[1] + q[1][cm] / hx_m[1]) * fl[1] +
-                                  0.5 * (q[2][c] / hx[2] + q[2][cm] / hx_m[2]) * fl[2];
+    qf[b * nq + 3 * ns + n][c] += 0.5 * (s0[c] + s0[cm]) * fl[0] + 0.5 * (s1[c] + s1[cm]) * fl[1] +
+                                  0.5 * (s2[c] + s2[cm]) * fl[2];
   }
 }
 
@@ -373,10 +394,40 @@ void launch_zero_diffusion_flux(const PackView &P, hipStream_t s) {
     else                                                                                         \
       hipLaunchKernelGGL((kern<DIR, true>), grid_of(fr, P.nb), dim3(TX, TY), 0, s, P, fr, D);     \
   } while (0)
-void launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s) {
-  LAUNCH_DIR(viscous_flux_kernel, 1);
-  if (P.ndim > 1) LAUNCH_DIR(viscous_flux_kernel, 2);
-  if (P.ndim > 2) LAUNCH_DIR(viscous_flux_kernel, 3);
+// library-owned scratch of the viscous tasks, grown on demand (one stream per caller thread)
+thread_local struct {
+  double *p = nullptr;
+  size_t n = 0;
+} g_visc;
+int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s) {
+  const size_t N = static_cast<size_t>(P.ni) * P.nj * P.nk, per = static_cast<size_t>(P.nb) * P.gas.ns * N;
+  if (g_visc.n < 5 * per) {
+    if (g_visc.p) (void)hipFree(g_visc.p);
+    g_visc.p = nullptr, g_visc.n = 0;
+    if (hipMalloc(reinterpret_cast<void **>(&g_visc.p), 5 * per * sizeof(double)) != hipSuccess) return 1;
+    g_visc.n = 5 * per;
+  }
+  ViscScratch w;
+  for (int d = 0; d < 3; ++d) w.sv[d] = g_visc.p + d * per;
+  w.divu = g_visc.p + 3 * per, w.mu = g_visc.p + 4 * per;
+  // cells the face kernels read: the active region grown by one zone in every active direction
+  Box rc = interior(P);
+  rc.il -= 1, rc.iu += 1;
+  if (P.ndim > 1) rc.jl -= 1, rc.ju += 1;
+  if (P.ndim > 2) rc.kl -= 1, rc.ku += 1;
+  const bool curv = P.coords != ARTEMIS_CARTESIAN;
+  if (curv) hipLaunchKernelGGL(viscous_cell_kernel<true>, grid_of(rc, P.nb), dim3(TX, TY), 0, s, P, rc, D, w);
+  else hipLaunchKernelGGL(viscous_cell_kernel<false>, grid_of(rc, P.nb), dim3(TX, TY), 0, s, P, rc, D, w);
+#define LAUNCH_VISC(DIR)                                                                                        \
+  do {                                                                                                          \
+    const Box fr = faces(P, DIR);                                                                               \
+    if (curv) hipLaunchKernelGGL((viscous_flux_kernel<DIR, true>), grid_of(fr, P.nb), dim3(TX, TY), 0, s, P, fr, D, w); \
+    else hipLaunchKernelGGL((viscous_flux_kernel<DIR, false>), grid_of(fr, P.nb), dim3(TX, TY), 0, s, P, fr, D, w);     \
+  } while (0)
+  LAUNCH_VISC(1);
+  if (P.ndim > 1) LAUNCH_VISC(2);
+  if (P.ndim > 2) LAUNCH_VISC(3);
+  return 0;
 }
 void launch_thermal_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s) {
   LAUNCH_DIR(thermal_flux_kernel, 1);
