@@ -365,3 +365,28 @@ def test_alpha_disk_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_pa
         i0 = int(round((key[0] - 0.3) / 1.7 * 64))
         ref = full[:, :, :, i0:i0 + 32]
         assert np.max(np.abs(part - ref)) < 1e-12, key
+
+
+def test_binary_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
+    """inputs/disk/binary_cyl.in at 64 x 128 (binary gravity with the host-evaluated orbit, rotating frame
+    incl. the frame velocity in FluxSource, alpha viscosity, self damping, `ic` radial conditions,
+    periodic azimuth): driver == oracle bit for bit on one block; 2 x 4 blocks on two ranks (the
+    azimuthal wrap-around crosses the rank boundary) agree with the one-block run to round-off."""
+    from test_driver_gpu import binary_oracle
+    small = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=128"]
+    one = dict(deck=["disk", "binary_cyl.in"], cycles=20,
+               overrides=small + ["parthenon/meshblock/nx1=64", "parthenon/meshblock/nx2=128"])
+    r = run_world(1, one, tmp_path, "b1")[0]
+    assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    o = binary_oracle((64, 128, 1))
+    o.evolve(2 * np.pi, 20)
+    assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
+    assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+    two = run_world(2, dict(one, overrides=small), tmp_path, "b2")  # the deck's 32 x 32 blocks: 2 x 4
+    assert [x["meta"]["nblocks"] for x in two] == [4, 4]
+    full = o.interior(o.gprim)
+    scale = np.maximum(np.abs(full).max(axis=(1, 2, 3), keepdims=True), 1e-300)  # v3 is identically zero
+    for key, part in by_bounds(two).items():
+        i0, j0 = int(round((key[0] - 0.3) / 2.7 * 64)), int(round(key[2] / 6.283185307179586 * 128))
+        ref = full[:, :, j0:j0 + 32, i0:i0 + 32]
+        assert np.max(np.abs(part - ref) / scale) < 1e-11, key
