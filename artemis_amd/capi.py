@@ -79,7 +79,8 @@ class BcParams(C.Structure):
                 ("cond_flux", C.c_double), ("cond_g", C.c_double * 3), ("cond_coeff", C.c_double),
                 ("cond_cv", C.c_double), ("cond_type", C.c_int), ("ic_gas", C.c_void_p),
                 ("ic_dust", C.c_void_p), ("disk_omf", C.c_double), ("disk_nu0", C.c_double),
-                ("disk_nu_indx", C.c_double), ("disk_r0", C.c_double), ("disk_mdot", C.c_double)]
+                ("disk_nu_indx", C.c_double), ("disk_r0", C.c_double), ("disk_mdot", C.c_double),
+                ("floor_ghosts", C.c_int)]
 
 
 class Cooling(C.Structure):
@@ -128,6 +129,7 @@ class StageGeneralArgs(C.Structure):
         ("gravity", C.POINTER(Gravity)), ("rf_omega", C.c_double), ("rf_qshear", C.c_double),
         ("drag", C.POINTER(Drag)), ("cfl_gas", C.c_double), ("cfl_dust", C.c_double),
         ("dt_dev", C.c_void_p), ("beta_dt_dev", C.c_void_p),
+        ("diffusion", C.POINTER(Diffusion)), ("cooling", C.POINTER(Cooling)),
     ]
 
 

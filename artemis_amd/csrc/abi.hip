@@ -592,9 +592,17 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
     if (g->type != ARTEMIS_GRAVITY_UNIFORM && p->coords == ARTEMIS_CYLINDRICAL && !p->metric)
       return fail(ARTEMIS_HIP_EINVAL, "point-mass gravity on cylindrical blocks needs the metric tables");
   }
-  if (a->rf_omega != 0.0 && p->coords != ARTEMIS_CARTESIAN)
-    return fail(ARTEMIS_HIP_EUNSUPPORTED,
-                "general stage: the curvilinear rotating frame reads stored mass fluxes; use the per-task kernels");
+  if (a->rf_omega != 0.0 && p->coords != ARTEMIS_CARTESIAN && a->rf_qshear != 0.0) // rotating_frame.cpp:34-38
+    return fail(ARTEMIS_HIP_EINVAL, "rotating_frame/qshear must be zero for non-Cartesian coordinate systems!");
+  if (a->diffusion) {
+    if (int rc = validate_diffusion(p, a->diffusion, true)) return rc;
+  }
+  if (a->cooling) {
+    if (a->drag) return fail(ARTEMIS_HIP_EUNSUPPORTED, "general stage: cooling together with drag runs on the per-task kernels");
+    if (p->gas.nspecies && (!a->cooling->tref || !a->cooling->beta))
+      return fail(ARTEMIS_HIP_EINVAL, "cooling: tref / beta tables are required (artemis_hip_cooling_table_fill)");
+    if (!(a->cooling->cv > 0.0)) return fail(ARTEMIS_HIP_EINVAL, "cooling: specific heat cv must be positive");
+  }
   if (a->drag) {
     if (a->drag->type == ARTEMIS_DRAG_SIMPLE_DUST && (p->gas.nspecies < 1 || p->dust.nspecies < 1))
       return fail(ARTEMIS_HIP_EINVAL, "drag type simple_dust requires do_gas = do_dust = true");

@@ -1,0 +1,77 @@
+// Cell body of Gas::DiffusionUpdate (DiffusionUpdateImpl, utils/diffusion/diffusion.hpp:110-241), shared by
+// the per-task kernel (kernels_diffusion.hip) and the general fused stage (kernels_stage_cell.hip).
+#pragma once
+#include "geometry.hpp"
+#include "pack_view.hpp"
+#include "task_device.hpp"
+
+namespace artemis {
+
+struct DiffCell { // geometry of one cell as the update uses it
+  double ax1[2], ax2[2], ax3[2], vol, hx[3], dhdx1[3], dhdx2[3];
+  int x1dep, x2dep, multi_d, three_d;
+};
+template <bool CURV>
+__device__ __forceinline__ DiffCell diffusion_cell(const PackView &P, int b, int k, int j, int i) {
+  DiffCell d;
+  d.multi_d = (P.ndim > 1), d.three_d = (P.ndim > 2);
+  const CellMetric m = cell_metric<CURV>(P, b, k, j, i);
+  d.ax1[0] = m.ax1[0], d.ax1[1] = m.ax1[1];
+  d.ax2[0] = d.multi_d ? m.ax2[0] : 0.0, d.ax2[1] = d.multi_d ? m.ax2[1] : 0.0;
+  d.ax3[0] = d.three_d ? m.ax3[0] : 0.0, d.ax3[1] = d.three_d ? m.ax3[1] : 0.0;
+  d.vol = m.vol;
+  scale_factors<CURV>(P, b, k, j, i, d.hx);
+  // GetConnX1 = {0, dh2dx1, dh3dx1}, GetConnX2 = {0, 0, dh3dx2}, GetConnX3 = 0 (geometry.hpp:407-418)
+  for (int q = 0; q < 3; ++q) d.dhdx1[q] = 0.0, d.dhdx2[q] = 0.0;
+  d.x1dep = 0, d.x2dep = 0;
+  if constexpr (CURV) {
+    const DCoords co = make_coords(P, b, k, j, i);
+    d.x1dep = co.x1dep(), d.x2dep = co.x2dep() && d.multi_d;
+    if (d.x1dep) d.dhdx1[1] = co.dh2dx1(), d.dhdx1[2] = co.dh3dx1();
+    if (d.x2dep) d.dhdx2[2] = co.dh3dx2();
+  }
+  return d;
+}
+// what the update subtracts from the momenta (dm), total energy (de) and internal energy (deg) of
+// species n in cell c; v = the stage-input primitive velocity of the cell
+__device__ __forceinline__ void diffusion_update_cell(const PackView &P, const DiffCell &g, int b, int n, long c,
+                                                      int do_viscosity, double dt, const double v[3],
+                                                      double dm[3], double &de, double &deg) {
+  const FluidView &f = P.gas;
+  const int ns = f.ns, nq = 4 * ns;
+  const int multi_d = g.multi_d, three_d = g.three_d;
+  const long c2 = c + multi_d * P.sj, c3 = c + three_d * P.sk;
+  auto F = [&](int d, int var, long cc) { return f.dflux[d][b * nq + var][cc]; };
+  const int d2 = multi_d ? 1 : 0, d3 = three_d ? 2 : 0; // inactive directions have no flux table
+  auto divergence = [&](int var) {
+    return (g.ax1[0] * F(0, var, c) - g.ax1[1] * F(0, var, c + 1)) +
+           multi_d * (g.ax2[0] * F(d2, var, c) - g.ax2[1] * F(d2, var, c2)) +
+           three_d * (g.ax3[0] * F(d3, var, c) - g.ax3[1] * F(d3, var, c3));
+  };
+  const int imx1 = 3 * n + 0, imx2 = 3 * n + 1, imx3 = 3 * n + 2, ien = 3 * ns + n;
+  auto metric_src = [&](const double dh[3]) {
+    return dh[0] * 0.5 * (F(0, imx1, c) + F(0, imx1, c + 1)) +
+           multi_d * dh[1] * 0.5 * (F(d2, imx2, c) + F(d2, imx2, c2)) +
+           three_d * dh[2] * 0.5 * (F(d3, imx3, c) + F(d3, imx3, c3));
+  };
+  double divfxm = 0., divfym = 0., divfzm = 0.;
+  if (do_viscosity) {
+    const double zero3[3] = {0.0, 0.0, 0.0};
+    divfxm = divergence(imx1);
+    divfxm /= g.vol;
+    divfxm += g.x1dep * metric_src(g.dhdx1);
+    divfym = divergence(imx2);
+    divfym /= g.vol;
+    divfym += g.x2dep * metric_src(g.dhdx2);
+    divfzm = divergence(imx3);
+    divfzm /= g.vol;
+    divfzm += 0 * metric_src(zero3); // x3dep is false for every system (geometry.hpp:107-110)
+  }
+  double divfe = divergence(ien);
+  divfe /= g.vol;
+  dm[0] = dt * divfxm, dm[1] = dt * divfym, dm[2] = dt * divfzm;
+  de = dt * divfe;
+  deg = dt * divfe - dt * (divfxm * v[0] / g.hx[0] + divfym * v[1] / g.hx[1] + divfzm * v[2] / g.hx[2]);
+}
+
+} // namespace artemis

@@ -612,11 +612,16 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   // stage (artemis_hip_stage_general) for everything else the per-task path can do
   tuned = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
           coords == ARTEMIS_CARTESIAN && !do_gravity && !do_rframe && !do_drag;
-  // diffusion and the curvilinear rotating frame (which reads the stored mass fluxes) run on the
-  // per-task chain
-  fused_possible = !(do_viscosity || do_conduction || do_cooling) && !(do_rframe && coords != ARTEMIS_CARTESIAN);
-  tuned = tuned && fused_possible;
-  use_fused = fused_possible;
+  // the general stage folds DiffusionUpdate (after the diffusion-flux tasks), the curvilinear rotating
+  // frame and beta cooling into its kernel; cooling together with drag runs on the per-task chain
+  fused_possible = !(do_cooling && do_drag);
+  tuned = tuned && fused_possible && !(do_viscosity || do_conduction || do_cooling);
+  // Default path by measurement (scripts/path_timing.py, one MI355X): the cell-centred general stage wins
+  // on Cartesian meshes (2048^2 viscous 1.73e9 vs 1.50e9 zone-cycles/s, SURVEY config 3 2.9e9 vs 1.1e9); in
+  // curvilinear coordinates every face carries PLM_G / scale-factor geometry and solving each face from
+  // both of its cells costs more than the flux arrays save (spherical 3-D blast 1.01e9 vs 1.24e9, disk
+  // decks 5.0e8 vs 6.6e8), so those default to the per-task chain.  artemis_sim_set_path overrides.
+  use_fused = fused_possible && coords == ARTEMIS_CARTESIAN;
   if (!use_fused) ensure_unfused();
   problem_generator();
 }
@@ -756,7 +761,7 @@ void artemis_sim::ensure_unfused() {
     gpflux[d].alloc(nb, ns_gas, N);
     gvface[d].alloc(nb, ns_gas, N);
     dflux[d].alloc(nb, 4 * ns_dust, N);
-    if (do_viscosity || do_conduction) gdflux[d].alloc(nb, 4 * ns_gas, N);
+    if ((do_viscosity || do_conduction) && !gdflux[d].ok()) gdflux[d].alloc(nb, 4 * ns_gas, N);
   }
   unfused_ready = true;
 }
@@ -834,7 +839,15 @@ void artemis_sim::fill_ghosts_finish(int prim_idx, void *hs, int dim, bool apply
     CK(artemis_rt_event_record(ev1, hs), "event");
     CK(artemis_rt_stream_wait_event(stream, ev1), "wait");
   }
-  if (apply_bcs) CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bcpar, stream), "apply_bc");
+  if (apply_bcs) {
+    // user conditions that compute new ghost values (conductive, disk ic / extrap / viscous) rely on the
+    // PrimToCons that follows them to apply the floors; the fused stages do not run PrimToCons
+    artemis_bc_params_t bp = bcpar;
+    bool value_bc = false;
+    for (int q : bc_flat) value_bc = value_bc || q >= ARTEMIS_BC_CONDUCTIVE;
+    bp.floor_ghosts = (use_fused && value_bc) ? 1 : 0;
+    CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc");
+  }
 }
 void artemis_sim::fill_ghosts(int prim_idx) {
   if (!edge_ghosts) {
@@ -1426,6 +1439,9 @@ void artemis_sim::step_general(bool want_dt, bool device_dt) {
     if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
     if (!dprim[q].ok()) dprim[q].alloc(nb, 4 * ns_dust, N);
   }
+  if (do_gas && (do_viscosity || do_conduction))
+    for (int d = 0; d < ndim; ++d)
+      if (!gdflux[d].ok()) gdflux[d].alloc(nb, 4 * ns_gas, N);
   const int A = base;
   int cur = A;
   if (want_dt && !device_dt) {
@@ -1453,6 +1469,14 @@ void artemis_sim::step_general(bool want_dt, bool device_dt) {
     a.cfl_gas = cfl_gas, a.cfl_dust = cfl_dust;
     a.dt_dev = (last && want_dt) ? (device_dt ? tstate.p + 2 : dt_dev.p) : nullptr;
     if (device_dt) a.beta_dt_dev = tstate.p + 3 + (stage - 1); // beta*dt stays on the device
+    const bool diffuse = do_gas && (do_viscosity || do_conduction);
+    if (diffuse) { // artemis_driver.cpp:189-194 on the stage's input primitives
+      CK(artemis_hip_zero_diffusion_flux(&p, stream), "Gas::ZeroDiffusionFlux");
+      if (do_viscosity) CK(artemis_hip_viscous_flux(&p, &diff, stream), "Gas::ViscousFlux");
+      if (do_conduction) CK(artemis_hip_thermal_flux(&p, &diff, stream), "Gas::ThermalFlux");
+      a.diffusion = &diff;
+    }
+    if (do_cooling && do_gas) a.cooling = &cool;
     void *e0 = nullptr, *e1 = nullptr;
     if (time_kernels) {
       e0 = artemis_rt_event_create(), e1 = artemis_rt_event_create();
@@ -1462,6 +1486,10 @@ void artemis_sim::step_general(bool want_dt, bool device_dt) {
     if (time_kernels) {
       CK(artemis_rt_event_record(e1, stream), "event");
       kev.emplace_back(e0, e1);
+    }
+    if (diffuse && a.dt_dev) { // gas.cpp:435-467: the diffusive limits of the new state
+      const artemis_pack_t pn = make_pack(out);
+      CK(artemis_hip_diffusion_dt(&pn, &diff, cfl_gas, a.dt_dev, stream), "dt diffusion");
     }
     fill_ghosts(out);
     cur = out;

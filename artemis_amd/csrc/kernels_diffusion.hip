@@ -17,6 +17,7 @@
 #include "kernels.hpp"
 #include "pack_view.hpp"
 #include "task_device.hpp"
+#include "diffusion_device.hpp"
 
 namespace artemis {
 namespace {
@@ -261,68 +262,25 @@ __global__ __launch_bounds__(TX *TY) void thermal_flux_kernel(const PackView P, 
   }
 }
 
-// DiffusionUpdateImpl (diffusion.hpp:110-241)
+// DiffusionUpdateImpl (diffusion.hpp:110-241); the cell body lives in diffusion_device.hpp, shared
+// with the general fused stage
 template <bool CURV>
 __global__ __launch_bounds__(TX *TY) void diffusion_update_kernel(const PackView P, const Box r,
                                                                   int do_viscosity, double dt) {
   BOX_CELL(r)
   const FluidView &f = P.gas;
-  const int ns = f.ns, nv = 6 * ns, nq = 4 * ns;
-  const int multi_d = (P.ndim > 1), three_d = (P.ndim > 2);
-  const CellMetric m = cell_metric<CURV>(P, b, k, j, i);
-  const double ax1[2] = {m.ax1[0], m.ax1[1]};
-  const double ax2[2] = {multi_d ? m.ax2[0] : 0.0, multi_d ? m.ax2[1] : 0.0};
-  const double ax3[2] = {three_d ? m.ax3[0] : 0.0, three_d ? m.ax3[1] : 0.0};
-  const double vol = m.vol;
-  double hx[3];
-  scale_factors<CURV>(P, b, k, j, i, hx);
-  // GetConnX1 = {0, dh2dx1, dh3dx1}, GetConnX2 = {0, 0, dh3dx2}, GetConnX3 = 0 (geometry.hpp:407-418)
-  double dhdx1[3] = {0.0, 0.0, 0.0}, dhdx2[3] = {0.0, 0.0, 0.0};
-  int x1dep = 0, x2dep = 0;
-  if constexpr (CURV) {
-    const DCoords co = make_coords(P, b, k, j, i);
-    x1dep = co.x1dep(), x2dep = co.x2dep() && multi_d;
-    if (x1dep) dhdx1[1] = co.dh2dx1(), dhdx1[2] = co.dh3dx1();
-    if (x2dep) dhdx2[2] = co.dh3dx2();
-  }
-  const long c2 = c + multi_d * P.sj, c3 = c + three_d * P.sk;
+  const int ns = f.ns, nv = 6 * ns;
+  const DiffCell dc = diffusion_cell<CURV>(P, b, k, j, i);
   for (int n = 0; n < ns; ++n) {
-    auto F = [&](int d, int var, long cc) { return f.dflux[d][b * nq + var][cc]; };
-    const int d2 = multi_d ? 1 : 0, d3 = three_d ? 2 : 0; // inactive directions have no flux table
-    auto divergence = [&](int var) {
-      return (ax1[0] * F(0, var, c) - ax1[1] * F(0, var, c + 1)) +
-             multi_d * (ax2[0] * F(d2, var, c) - ax2[1] * F(d2, var, c2)) +
-             three_d * (ax3[0] * F(d3, var, c) - ax3[1] * F(d3, var, c3));
-    };
-    const int imx1 = 3 * n + 0, imx2 = 3 * n + 1, imx3 = 3 * n + 2, ien = 3 * ns + n;
-    auto metric_src = [&](const double dh[3]) {
-      return dh[0] * 0.5 * (F(0, imx1, c) + F(0, imx1, c + 1)) +
-             multi_d * dh[1] * 0.5 * (F(d2, imx2, c) + F(d2, imx2, c2)) +
-             three_d * dh[2] * 0.5 * (F(d3, imx3, c) + F(d3, imx3, c3));
-    };
-    double divfxm = 0., divfym = 0., divfzm = 0.;
-    if (do_viscosity) {
-      const double zero3[3] = {0.0, 0.0, 0.0};
-      divfxm = divergence(imx1);
-      divfxm /= vol;
-      divfxm += x1dep * metric_src(dhdx1);
-      divfym = divergence(imx2);
-      divfym /= vol;
-      divfym += x2dep * metric_src(dhdx2);
-      divfzm = divergence(imx3);
-      divfzm /= vol;
-      divfzm += 0 * metric_src(zero3); // x3dep is false for every system (geometry.hpp:107-110)
-    }
-    double divfe = divergence(ien);
-    divfe /= vol;
-    f.cons0[b * nv + ns + 3 * n + 0][c] -= dt * divfxm;
-    f.cons0[b * nv + ns + 3 * n + 1][c] -= dt * divfym;
-    f.cons0[b * nv + ns + 3 * n + 2][c] -= dt * divfzm;
-    f.cons0[b * nv + 4 * ns + n][c] -= dt * divfe;
-    f.cons0[b * nv + 5 * ns + n][c] -=
-        dt * divfe - dt * (divfxm * f.prim[b * nv + ns + 3 * n + 0][c] / hx[0] +
-                           divfym * f.prim[b * nv + ns + 3 * n + 1][c] / hx[1] +
-                           divfzm * f.prim[b * nv + ns + 3 * n + 2][c] / hx[2]);
+    const double v[3] = {f.prim[b * nv + ns + 3 * n + 0][c], f.prim[b * nv + ns + 3 * n + 1][c],
+                         f.prim[b * nv + ns + 3 * n + 2][c]};
+    double dm[3], de, deg;
+    diffusion_update_cell(P, dc, b, n, c, do_viscosity, dt, v, dm, de, deg);
+    f.cons0[b * nv + ns + 3 * n + 0][c] -= dm[0];
+    f.cons0[b * nv + ns + 3 * n + 1][c] -= dm[1];
+    f.cons0[b * nv + ns + 3 * n + 2][c] -= dm[2];
+    f.cons0[b * nv + 4 * ns + n][c] -= de;
+    f.cons0[b * nv + 5 * ns + n][c] -= deg;
   }
 }
 

@@ -135,36 +135,30 @@ __global__ __launch_bounds__(TX *TY) void shearing_box_kernel(const PackView P, 
 __global__ __launch_bounds__(TX *TY) void rotating_frame_kernel(const PackView P, double om0, double dt) {
   INTERIOR_CELL
   const int multi_d = (P.ndim >= 2), three_d = (P.ndim == 3);
-  const double omdt = om0 * dt;
-  const double om2dt = omdt * om0;
   const DCoords co = make_coords(P, b, k, j, i);
-  double xv[3];
-  co.centre(xv);
-  const Frame fr = cyl_frame(co.sys, xv, co.cv, co.sv);
-  double bx1[2], bx2[2], bx3[2];
-  co.rf_weights(bx1, bx2, bx3);
+  const RotFrame r = rotating_frame_terms(co, om0, dt);
   const double ax1[2] = {co.area1(0), co.area1(1)};
   const double ax2[2] = {multi_d ? co.area2(0) : 0.0, multi_d ? co.area2(1) : 0.0};
   const double ax3[2] = {three_d ? co.area3(0) : 0.0, three_d ? co.area3(1) : 0.0};
   const double vol = co.volume();
   const long c2 = c + multi_d * P.sj, c3 = c + three_d * P.sk;
   const int d2 = multi_d ? 1 : 0, d3 = three_d ? 2 : 0; // inactive directions have no flux table
-  auto body = [&](const FluidView &f, int nv, int n, bool gas) {
-    const double *f1 = f.flux[0][b * nv + n], *f2 = f.flux[d2][b * nv + n], *f3 = f.flux[d3][b * nv + n];
-    const double divf = (f1[c] * ax1[0] * bx1[0] + f1[c + 1] * ax1[1] * bx1[1]) +
-                        multi_d * (f2[c] * ax2[0] * bx2[0] + f2[c2] * ax2[1] * bx2[1]) +
-                        three_d * (f3[c] * ax3[0] * bx3[0] + f3[c3] * ax3[1] * bx3[1]);
-    f.cons0[b * nv + f.ns + 3 * n + 0][c] -= omdt * (divf / vol) * fr.e1[1];
-    f.cons0[b * nv + f.ns + 3 * n + 1][c] -= omdt * (divf / vol) * fr.e2[1];
-    f.cons0[b * nv + f.ns + 3 * n + 2][c] -= omdt * (divf / vol) * fr.e3[1];
-    if (!gas) return;
-    const double fx[3] = {0.5 * (f1[c] + f1[c + 1]), multi_d * 0.5 * (f2[c] + f2[c2]),
-                          three_d * 0.5 * (f3[c] + f3[c3])};
-    f.cons0[b * nv + 4 * f.ns + n][c] +=
-        om2dt * fr.x[0] * (fx[0] * fr.e1[0] + fx[1] * fr.e2[0] + fx[2] * fr.e3[0]);
-  };
-  for (int n = 0; n < P.gas.ns; ++n) body(P.gas, 6 * P.gas.ns, n, true);
-  for (int n = 0; n < P.dust.ns; ++n) body(P.dust, 4 * P.dust.ns, n, false);
+  for (int n = 0; n < P.gas.ns; ++n) {
+    const int nv = 6 * P.gas.ns;
+    const double *f1 = P.gas.flux[0][b * nv + n], *f2 = P.gas.flux[d2][b * nv + n], *f3 = P.gas.flux[d3][b * nv + n];
+    const double flo[3] = {f1[c], f2[c], f3[c]}, fup[3] = {f1[c + 1], f2[c2], f3[c3]};
+    GasCons u = load_gas_cons(P.gas, b, n, c);
+    rotating_frame_gas(r, multi_d, three_d, flo, fup, ax1, ax2, ax3, vol, u);
+    store_gas_cons(P.gas, b, n, c, u, false);
+  }
+  for (int n = 0; n < P.dust.ns; ++n) {
+    const int nv = 4 * P.dust.ns;
+    const double *f1 = P.dust.flux[0][b * nv + n], *f2 = P.dust.flux[d2][b * nv + n], *f3 = P.dust.flux[d3][b * nv + n];
+    const double flo[3] = {f1[c], f2[c], f3[c]}, fup[3] = {f1[c + 1], f2[c2], f3[c3]};
+    DustCons u = load_dust_cons(P.dust, b, n, c);
+    rotating_frame_dust(r, multi_d, three_d, flo, fup, ax1, ax2, ax3, vol, u);
+    store_dust_cons(P.dust, b, n, c, u, false);
+  }
 }
 
 // Gas::Cooling::BetaCooling<GEOM, powerlaw> (beta_cooling.cpp:40-126); Tref and beta of the cell come
@@ -172,32 +166,15 @@ __global__ __launch_bounds__(TX *TY) void rotating_frame_kernel(const PackView P
 __global__ __launch_bounds__(TX *TY) void cooling_kernel(const PackView P, const artemis_cooling_t C, double dt) {
   INTERIOR_CELL
   const DCoords co = make_coords(P, b, k, j, i);
-  double xv[3], hx[3];
-  co.centre(xv);
+  double hx[3];
   scale_factors_of(co, hx);
-  const Frame fr = cyl_frame(co.sys, xv, co.cv, co.sv);
-  const double rsph2 = fr.x[0] * fr.x[0] + fr.x[2] * fr.x[2];
-  const double ir1 = 1.0 / sqrt(rsph2);
+  const double omdt = cooling_omdt(co, C.gm, dt);
   const double T0 = C.tref[b][c], beta = C.beta[b][c];
-  const double omdt = dt * sqrt(C.gm * ir1 * ir1 * ir1);
-  const FluidView &G = P.gas;
-  const int ns = G.ns, nv = 6 * ns;
-  for (int n = 0; n < ns; ++n) {
-    // GetSpecificInternalEnergy (artemis_utils.hpp:43-62)
-    const double dens = G.cons0[b * nv + n][c];
-    const double u_d = amax(dens, G.dfloor);
-    const double rv1 = G.cons0[b * nv + ns + 3 * n + 0][c] / hx[0];
-    const double rv2 = G.cons0[b * nv + ns + 3 * n + 1][c] / hx[1];
-    const double rv3 = G.cons0[b * nv + ns + 3 * n + 2][c] / hx[2];
-    const double ke = 0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)) / u_d;
-    double *etot = G.cons0[b * nv + 4 * ns + n], *eint = G.cons0[b * nv + 5 * ns + n];
-    const double e_cons = etot[c];
-    const double ue_cons = e_cons - ke;
-    double sie = (ue_cons > G.de_switch * e_cons) ? ue_cons / u_d : eint[c] / u_d;
-    sie = amax(sie, G.siefloor);
-    const double Tn = amax(0.0, sie / C.cv);
-    const double dE = -dens * C.cv * omdt / (beta + omdt) * (Tn - T0);
-    etot[c] += dE, eint[c] += dE;
+  for (int n = 0; n < P.gas.ns; ++n) {
+    GasCons u = load_gas_cons(P.gas, b, n, c);
+    cooling_gas(P.gas, C.cv, omdt, T0, beta, hx, u);
+    const int nv = 6 * P.gas.ns;
+    P.gas.cons0[b * nv + 4 * P.gas.ns + n][c] = u.e, P.gas.cons0[b * nv + 5 * P.gas.ns + n][c] = u.eg;
   }
 }
 

@@ -17,6 +17,7 @@
 // ghost zones only need the FillGhost variables.  Every expression tree is shared with the
 // per-task kernels (task_device.hpp, sources_device.hpp): results are bit-identical.
 #include "device_math.hpp"
+#include "diffusion_device.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
 #include "pack_view.hpp"
@@ -35,6 +36,10 @@ struct CellStageArgs {
   int grav_on, rf_on;
   artemis_gravity_t grav;
   double rf_omega, rf_qshear;
+  // EXTRA instantiations only: DiffusionUpdate from the stored diffusion fluxes, the curvilinear
+  // rotating frame from this cell's own mass fluxes, beta cooling
+  int diff_on, do_viscosity, rfc_on, cool_on;
+  artemis_cooling_t cool;
 };
 
 // Stencil of one variable around cell c along a stride: w[3] = cell c, w[3+m] = cell c + m*st.
@@ -155,7 +160,7 @@ ADEV DustCons prim_to_cons_dust(const FluidView &f, double d, double v1, double 
   return u;
 }
 
-template <int FLUID, int RIEMANN, int RECON, bool CURV>
+template <int FLUID, int RIEMANN, int RECON, bool CURV, bool EXTRA>
 __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, const CellStageArgs a_in) {
   const int i = P.is + blockIdx.x * TX + threadIdx.x;
   const int j = P.js + blockIdx.y * TY + threadIdx.y;
@@ -181,6 +186,17 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
   }
   ShearAcc sa{};
   if (a.rf_on) sa = shear_terms(P.geom + 6 * b, P.ndim, k, i, a.rf_omega, a.rf_qshear);
+  RotFrame rfc{};
+  DiffCell dcell{};
+  double cool_omdt = 0.0, cool_T0 = 0.0, cool_beta = 0.0;
+  if constexpr (EXTRA) {
+    if (a.rfc_on) rfc = rotating_frame_terms(make_coords(P, b, k, j, i), a.rf_omega, a.bdt);
+    if (FLUID == 0 && a.diff_on) dcell = diffusion_cell<CURV>(P, b, k, j, i);
+    if (FLUID == 0 && a.cool_on) {
+      cool_omdt = cooling_omdt(make_coords(P, b, k, j, i), a.cool.gm, a.bdt);
+      cool_T0 = a.cool.tref[b][c], cool_beta = a.cool.beta[b][c];
+    }
+  }
 
   for (int n = 0; n < ns; ++n) {
     const double *qd = a.in[b * nv + n], *q1 = a.in[b * nv + ns + 3 * n + 0];
@@ -189,6 +205,7 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
     // ---- fluxes of the 2*ndim faces; divergence accumulated in ApplyUpdate's order -----------
     double divf[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // d, m1, m2, m3, e, eg
     double plo[3] = {0, 0, 0}, pup[3] = {0, 0, 0}, vlo[3] = {0, 0, 0}, vup[3] = {0, 0, 0};
+    double mlo[3] = {0, 0, 0}, mup[3] = {0, 0, 0}; // mass fluxes (EXTRA: curvilinear rotating frame)
     FluidPrim w; // this cell's stage-input primitives
     w.rho = qd[c], w.v1 = q1[c], w.v2 = q2[c], w.v3 = q3[c], w.sie = (FLUID == 0) ? qe[c] : 0.0;
     for (int dir = 1; dir <= P.ndim; ++dir) {
@@ -237,6 +254,7 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
         }
       }
       if constexpr (FLUID == 0) plo[d] = lo.pf, pup[d] = up.pf, vlo[d] = lo.vf, vup[d] = up.vf;
+      if constexpr (EXTRA) mlo[d] = lo.fd, mup[d] = up.fd;
     }
     // ---- ApplyUpdate (artemis_integrator.hpp:104-106) on u0 = PrimToCons(in), u1 = PrimToCons(u1)
     const double *rd = a.u1[b * nv + n], *r1 = a.u1[b * nv + ns + 3 * n + 0];
@@ -272,14 +290,34 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
         if (co.x2dep() && multi_d)
           u0.m2 += rdt * (0.0 * sqr(w.v1 + vf[0]) + 0.0 * sqr(w.v2 + vf[1]) + co.dh3dx2() * sqr(w.v3 + vf[2]));
       }
+      if constexpr (EXTRA) {
+        if (a.diff_on) { // Gas::DiffusionUpdate (artemis_driver.cpp:218-221)
+          const double v[3] = {w.v1, w.v2, w.v3};
+          double dm[3], de, deg;
+          diffusion_update_cell(P, dcell, b, n, c, a.do_viscosity, dt, v, dm, de, deg);
+          u0.m1 -= dm[0], u0.m2 -= dm[1], u0.m3 -= dm[2];
+          u0.e -= de;
+          u0.eg -= deg;
+        }
+      }
       if (a.grav_on) gravity_gas(ga, dt, hx, w, u0);
       if (a.rf_on) shear_gas(sa, dt, w, u0);
+      if constexpr (EXTRA) {
+        if (a.rfc_on) {
+          const double ax2[2] = {multi_d ? g.ax2[0] : 0.0, multi_d ? g.ax2[1] : 0.0};
+          const double ax3[2] = {three_d ? g.ax3[0] : 0.0, three_d ? g.ax3[1] : 0.0};
+          rotating_frame_gas(rfc, multi_d, three_d, mlo, mup, g.ax1, ax2, ax3, g.vol, u0);
+        }
+      }
       if (a.to_cons) {
         f.cons0[b * nv + n][c] = u0.d;
         f.cons0[b * nv + ns + 3 * n + 0][c] = u0.m1, f.cons0[b * nv + ns + 3 * n + 1][c] = u0.m2;
         f.cons0[b * nv + ns + 3 * n + 2][c] = u0.m3;
         f.cons0[b * nv + 4 * ns + n][c] = u0.e, f.cons0[b * nv + 5 * ns + n][c] = u0.eg;
         continue;
+      }
+      if constexpr (EXTRA) {
+        if (a.cool_on) cooling_gas(f, a.cool.cv, cool_omdt, cool_T0, cool_beta, hx, u0); // :243-248
       }
       // ---- SetAuxillaryFields (fill_derived.cpp:58-71) + ConsToPrim (:132-146)
       const double u_d = (u0.d > f.dfloor) ? u0.d : f.dfloor;
@@ -318,6 +356,13 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
       }
       if (a.grav_on) gravity_dust(ga, dt, hx, w, u0);
       if (a.rf_on) shear_dust(sa, dt, w, u0);
+      if constexpr (EXTRA) {
+        if (a.rfc_on) {
+          const double ax2[2] = {multi_d ? g.ax2[0] : 0.0, multi_d ? g.ax2[1] : 0.0};
+          const double ax3[2] = {three_d ? g.ax3[0] : 0.0, three_d ? g.ax3[1] : 0.0};
+          rotating_frame_dust(rfc, multi_d, three_d, mlo, mup, g.ax1, ax2, ax3, g.vol, u0);
+        }
+      }
       if (a.to_cons) {
         f.cons0[b * nv + n][c] = u0.d;
         f.cons0[b * nv + ns + 3 * n + 0][c] = u0.m1, f.cons0[b * nv + ns + 3 * n + 1][c] = u0.m2;
@@ -336,10 +381,14 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
 template <int FLUID, int RIEMANN, int RECON>
 void launch_geom(const PackView &P, const CellStageArgs &a, hipStream_t s) {
   const dim3 grid((P.ie - P.is + TX) / TX, (P.je - P.js + TY) / TY, (P.ke - P.ks + 1) * P.nb);
-  if (P.coords == ARTEMIS_CARTESIAN)
-    hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, false>), grid, dim3(TX, TY), 0, s, P, a);
-  else
-    hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, true>), grid, dim3(TX, TY), 0, s, P, a);
+  const bool extra = a.diff_on || a.rfc_on || a.cool_on;
+  if (P.coords == ARTEMIS_CARTESIAN) {
+    if (extra) hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, false, true>), grid, dim3(TX, TY), 0, s, P, a);
+    else hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, false, false>), grid, dim3(TX, TY), 0, s, P, a);
+  } else {
+    if (extra) hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, true, true>), grid, dim3(TX, TY), 0, s, P, a);
+    else hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, true, false>), grid, dim3(TX, TY), 0, s, P, a);
+  }
 }
 template <int FLUID, int RIEMANN>
 void launch_recon(const PackView &P, int recon, const CellStageArgs &a, hipStream_t s) {
@@ -357,7 +406,13 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
   a.to_cons = g.drag ? 1 : 0;
   a.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;
   if (a.grav_on) a.grav = *g.gravity;
-  a.rf_on = (g.rf_omega != 0.0), a.rf_omega = g.rf_omega, a.rf_qshear = g.rf_qshear;
+  const bool cart = (P.coords == ARTEMIS_CARTESIAN);
+  a.rf_on = (g.rf_omega != 0.0) && cart, a.rf_omega = g.rf_omega, a.rf_qshear = g.rf_qshear;
+  a.rfc_on = (g.rf_omega != 0.0) && !cart;
+  a.diff_on = (g.diffusion != nullptr) && P.gas.ns > 0;
+  a.do_viscosity = (g.diffusion && g.diffusion->visc.type != ARTEMIS_DIFF_OFF) ? 1 : 0;
+  a.cool_on = (g.cooling != nullptr) && P.gas.ns > 0;
+  if (a.cool_on) a.cool = *g.cooling;
   if (P.gas.ns) {
     a.in = g.gas_in, a.u1 = g.gas_u1, a.out = g.gas_out;
     const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;

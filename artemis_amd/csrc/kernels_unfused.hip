@@ -934,7 +934,39 @@ static void launch_bc_sequential(const PackView &P, int b, const int *bc6,
       }
 }
 
+// PrimToCons's primitive floors (fill_derived.cpp:227, :245, :262) on the ghost zones of block t.b
+__global__ __launch_bounds__(256) void floor_ghost_kernel(const FillTabs t, const PackView P) {
+  const long n = static_cast<long>(P.ni) * P.nj * P.nk;
+  const long c = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const int i = c % P.ni, j = (c / P.ni) % P.nj, k = c / (static_cast<long>(P.ni) * P.nj);
+  if (i >= P.is && i <= P.ie && j >= P.js && j <= P.je && k >= P.ks && k <= P.ke) return;
+  const int nsg = t.nsg, nsd = t.nsd;
+  for (int m = 0; m < nsg; ++m) {
+    double *rho = t.gas[t.b * 6 * nsg + m], *se = t.gas[t.b * 6 * nsg + 5 * nsg + m];
+    const double w_d = rho[c], w_s = se[c];
+    rho[c] = (w_d > P.gas.dfloor) ? w_d : P.gas.dfloor;
+    se[c] = (w_s > P.gas.siefloor) ? w_s : P.gas.siefloor;
+  }
+  for (int m = 0; m < nsd; ++m) {
+    double *rho = t.dust[t.b * 4 * nsd + m];
+    const double w_d = rho[c];
+    rho[c] = (w_d > P.dust.dfloor) ? w_d : P.dust.dfloor;
+  }
+}
+
 int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t *par, hipStream_t s) {
+  struct FloorAfter { // runs when the function returns
+    const PackView &P;
+    const artemis_bc_params_t *par;
+    hipStream_t s;
+    ~FloorAfter() {
+      if (!par || !par->floor_ghosts) return;
+      const long n = static_cast<long>(P.ni) * P.nj * P.nk;
+      for (int b = 0; b < P.nb; ++b)
+        hipLaunchKernelGGL(floor_ghost_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fill_tabs(P, b), P);
+    }
+  } floor_after{P, par, s};
   for (int b = 0; b < P.nb; ++b) {
     ShellArgs a;
     bool any = false, user = false;

@@ -140,6 +140,78 @@ ADEV void gravity_dust(const GravAcc &a, double dt, const double hx[3], const Fl
   }
 }
 
+// ---- RotatingFrame::RotatingFrameImpl<GEOM> (rotating_frame_impl.hpp:95-199) ----------------
+// flo / fup = the MASS flux through the lower / upper face of the cell along x1, x2, x3 (zero for
+// inactive directions); ax* = face areas as the caller's task uses them.
+struct RotFrame {
+  double omdt, om2dt, R, eR[3], ep[3]; // e?[d] = component of the problem's unit vector d along R / phi
+  double b1[2], b2[2], b3[2];
+};
+ADEV RotFrame rotating_frame_terms(const DCoords &co, double om0, double dt) {
+  RotFrame r;
+  r.omdt = om0 * dt;
+  r.om2dt = r.omdt * om0;
+  double xv[3];
+  co.centre(xv);
+  const Frame fr = cyl_frame(co.sys, xv, co.cv, co.sv);
+  r.R = fr.x[0];
+  r.eR[0] = fr.e1[0], r.eR[1] = fr.e2[0], r.eR[2] = fr.e3[0];
+  r.ep[0] = fr.e1[1], r.ep[1] = fr.e2[1], r.ep[2] = fr.e3[1];
+  co.rf_weights(r.b1, r.b2, r.b3);
+  return r;
+}
+ADEV double rotating_frame_divf(const RotFrame &r, int multi_d, int three_d, const double flo[3],
+                                const double fup[3], const double ax1[2], const double ax2[2],
+                                const double ax3[2]) {
+  return (flo[0] * ax1[0] * r.b1[0] + fup[0] * ax1[1] * r.b1[1]) +
+         multi_d * (flo[1] * ax2[0] * r.b2[0] + fup[1] * ax2[1] * r.b2[1]) +
+         three_d * (flo[2] * ax3[0] * r.b3[0] + fup[2] * ax3[1] * r.b3[1]);
+}
+ADEV void rotating_frame_gas(const RotFrame &r, int multi_d, int three_d, const double flo[3],
+                             const double fup[3], const double ax1[2], const double ax2[2],
+                             const double ax3[2], double vol, GasCons &u) {
+  const double divf = rotating_frame_divf(r, multi_d, three_d, flo, fup, ax1, ax2, ax3);
+  u.m1 -= r.omdt * (divf / vol) * r.ep[0];
+  u.m2 -= r.omdt * (divf / vol) * r.ep[1];
+  u.m3 -= r.omdt * (divf / vol) * r.ep[2];
+  const double fx[3] = {0.5 * (flo[0] + fup[0]), multi_d * 0.5 * (flo[1] + fup[1]),
+                        three_d * 0.5 * (flo[2] + fup[2])};
+  u.e += r.om2dt * r.R * (fx[0] * r.eR[0] + fx[1] * r.eR[1] + fx[2] * r.eR[2]);
+}
+ADEV void rotating_frame_dust(const RotFrame &r, int multi_d, int three_d, const double flo[3],
+                              const double fup[3], const double ax1[2], const double ax2[2],
+                              const double ax3[2], double vol, DustCons &u) {
+  const double divf = rotating_frame_divf(r, multi_d, three_d, flo, fup, ax1, ax2, ax3);
+  u.m1 -= r.omdt * (divf / vol) * r.ep[0];
+  u.m2 -= r.omdt * (divf / vol) * r.ep[1];
+  u.m3 -= r.omdt * (divf / vol) * r.ep[2];
+}
+
+// ---- Gas::Cooling::BetaCooling (beta_cooling.cpp:88-124) on one cell's conserved state ----------
+ADEV double cooling_omdt(const DCoords &co, double gm, double dt) {
+  double xv[3];
+  co.centre(xv);
+  const Frame fr = cyl_frame(co.sys, xv, co.cv, co.sv);
+  const double rsph2 = fr.x[0] * fr.x[0] + fr.x[2] * fr.x[2];
+  const double ir1 = 1.0 / sqrt(rsph2);
+  return dt * sqrt(gm * ir1 * ir1 * ir1);
+}
+ADEV void cooling_gas(const FluidView &G, double cv, double omdt, double T0, double beta, const double hx[3],
+                      GasCons &u) {
+  // GetSpecificInternalEnergy (artemis_utils.hpp:43-62)
+  const double dens = u.d;
+  const double u_d = amax(dens, G.dfloor);
+  const double rv1 = u.m1 / hx[0], rv2 = u.m2 / hx[1], rv3 = u.m3 / hx[2];
+  const double ke = 0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)) / u_d;
+  const double e_cons = u.e;
+  const double ue_cons = e_cons - ke;
+  double sie = (ue_cons > G.de_switch * e_cons) ? ue_cons / u_d : u.eg / u_d;
+  sie = amax(sie, G.siefloor);
+  const double Tn = amax(0.0, sie / cv);
+  const double dE = -dens * cv * omdt / (beta + omdt) * (Tn - T0);
+  u.e += dE, u.eg += dE;
+}
+
 // ---- RotatingFrame::ShearingBoxImpl (rotating_frame_impl.hpp:28-93) -------------------------
 struct ShearAcc {
   double dpx, dpz, om0;

@@ -176,8 +176,9 @@ class MeshBlockPack:
 
     def stage_general(self, gam0, gam1, beta_dt, bdt, gas=(None, None, None), dust=(None, None, None),
                       pcm=False, time=0.0, gravity=None, rotating_frame=None, drag=None,
-                      cfl=(0.0, 0.0), dt_dev=None):
-        """artemis_hip_stage_general: gas / dust = (in, u1, out) prim tables."""
+                      cfl=(0.0, 0.0), dt_dev=None, diffusion=None, cooling=None):
+        """artemis_hip_stage_general: gas / dust = (in, u1, out) prim tables; diffusion = capi.Diffusion
+        whose fluxes are already in gas_diff_flux for the `in` primitives; cooling = capi.Cooling."""
         a = capi.StageGeneralArgs()
         a.gam0, a.gam1, a.beta_dt, a.bdt, a.pcm, a.time = gam0, gam1, beta_dt, bdt, int(pcm), time
         a.gas_in, a.gas_u1, a.gas_out = gas
@@ -190,6 +191,10 @@ class MeshBlockPack:
             a.drag = C.pointer(drag)
         a.cfl_gas, a.cfl_dust = cfl
         a.dt_dev = dt_dev
+        if diffusion is not None:
+            a.diffusion = C.pointer(diffusion)
+        if cooling is not None:
+            a.cooling = C.pointer(cooling)
         self._call(self.L.artemis_hip_stage_general, C.byref(a))
 
     # ---- gas diffusion (artemis_driver.cpp:189-193, :218-221) -----------------------------------

@@ -185,6 +185,12 @@ typedef struct artemis_bc_params {
   double disk_omf;
   /* DISK_VISC: ViscosityProfile nu0 (R/r0)^nu_indx (disk.hpp:131-135) and the accretion rate */
   double disk_nu0, disk_nu_indx, disk_r0, disk_mdot;
+  /* non-zero: finish by applying PrimToCons's primitive floors (fill_derived.cpp:227, :245, :262) to
+   * the ghost zones of every block.  The reference runs PrimToCons over the entire block right after
+   * the conditions (artemis_driver.cpp:258-261), which floors what user conditions wrote; a caller of
+   * the fused stages (which rebuild the conserved state in registers and never run PrimToCons) sets
+   * this instead. */
+  int floor_ghosts;
 } artemis_bc_params_t;
 int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_bc_params_t *params,
                          void *stream);
@@ -381,6 +387,13 @@ typedef struct artemis_stage_general_args {
   double *dt_dev;
   const double *beta_dt_dev;  /* optional DEVICE scalar holding beta*dt of this stage; replaces the
                                  host values beta_dt and bdt (synchronisation-free time loop) */
+  /* optional tasks folded into the same kernel (NULL = off).  diffusion: Gas::DiffusionUpdate from
+   * p->gas.diff_flux, which the caller has filled for THIS stage's input primitives
+   * (artemis_hip_zero_diffusion_flux / viscous_flux / thermal_flux on a pack whose gas.prim is
+   * gas_in).  cooling: Gas::Cooling::CoolingSource (not together with drag).  A non-zero rf_omega on
+   * a non-Cartesian pack selects RotatingFrameImpl, evaluated from the cell's own mass fluxes. */
+  const artemis_diffusion_t *diffusion;
+  const artemis_cooling_t *cooling;
 } artemis_stage_general_args_t;
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
                               void *stream);

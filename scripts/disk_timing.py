@@ -1,5 +1,6 @@
 """Throughput of the disk deck (config 4 without refinement) through the driver's per-task chain:
-python scripts/disk_timing.py [sph|cyl|axi] [scale]  (scale multiplies every active mesh dimension)."""
+python scripts/disk_timing.py [sph|cyl|axi] [scale] [fused|unfused]  (scale multiplies every active mesh
+dimension; the path defaults to the driver's choice)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +13,8 @@ ov = ["parthenon/time/nlim=70"]
 for d, n in enumerate(nx, 1):
     ov += [f"parthenon/mesh/nx{d}={n}", f"parthenon/meshblock/nx{d}={n}"]
 s = Simulation(os.path.join(ROOT, "inputs", "disk", f"disk_{g}.in"), ov)
+if len(sys.argv) > 3:
+    s.set_path(sys.argv[3])
 s.evolve(10)
 import torch
 torch.cuda.synchronize()

@@ -252,6 +252,24 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
       if (par->ic_dust) s.ic_d.resize(s.dprim.size()), B.in(s.ic_d, par->ic_dust, s.nvd);
     }
     apply_bcs(*B.s);
+    if (par && par->floor_ghosts) { // PrimToCons's primitive floors on the ghost zones
+      Sim &s = *B.s;
+      for (int k = 0; k < s.nk; ++k)
+        for (int j = 0; j < s.nj; ++j)
+          for (int i = 0; i < s.ni; ++i) {
+            if (i >= s.is && i <= s.ie && j >= s.js && j <= s.je && k >= s.ks && k <= s.ke) continue;
+            const size_t c = IDX(s, k, j, i);
+            for (int n = 0; n < s.c.ns_gas; ++n) {
+              Real &w_d = s.gprim[n * s.N + c], &w_s = s.gprim[(5 * s.c.ns_gas + n) * s.N + c];
+              w_d = (w_d > s.c.dfloor_gas) ? w_d : s.c.dfloor_gas;
+              w_s = (w_s > s.c.siefloor_gas) ? w_s : s.c.siefloor_gas;
+            }
+            for (int n = 0; n < s.c.ns_dust; ++n) {
+              Real &w_d = s.dprim[n * s.N + c];
+              w_d = (w_d > s.c.dfloor_dust) ? w_d : s.c.dfloor_dust;
+            }
+          }
+    }
     B.out(B.s->gprim, p->gas.prim, B.s->nvg), B.out(B.s->dprim, p->dust.prim, B.s->nvd);
   }
   return 0;
@@ -388,6 +406,24 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
 // The general-stage CONTRACT restated with the oracle's task chain (both fluids, every source
 // package): u1 := PrimToCons(*_u1), u0 := PrimToCons(*_in), the reference's task order, interior
 // of the new primitives (rho, v, sie) to *_out.
+// gas diffusion through the oracle's restatement
+static void set_diffusion(Sim &s, const artemis_diffusion_t *d) {
+  auto cp = [](Sim::DiffCoeff &o, const artemis_diffcoeff_t &c) {
+    o.type = c.type, o.avg = c.avg;
+    o.nu_s = o.alpha = o.hcond_0 = o.kappa_0 = c.coeff;
+    o.eta = c.eta, o.r_exp = c.r_exp, o.R0 = c.r0, o.Omega0 = c.omega0;
+    o.temp_exp = c.temp_exp, o.rho_exp = c.rho_exp, o.d0 = c.rho_ref, o.T0 = c.T_ref;
+  };
+  cp(s.visc, d->visc), cp(s.cond, d->cond);
+  s.cv = d->cv;
+}
+static void dflux_io(Bound &B, const artemis_pack_t *p, bool out) {
+  for (int d = 0; d < 3; ++d) {
+    if (!p->gas.diff_flux[d]) continue;
+    if (out) B.out(B.s->qflux[d], p->gas.diff_flux[d], 4 * B.s->c.ns_gas);
+    else B.in(B.s->qflux[d], p->gas.diff_flux[d], 4 * B.s->c.ns_gas);
+  }
+}
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a_in, void *) {
   artemis_stage_general_args_t args = *a_in;
   if (args.beta_dt_dev) args.beta_dt = args.bdt = *args.beta_dt_dev; // "device" memory is host memory here
@@ -405,6 +441,10 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
     calculate_fluxes(s, FL_GAS, a->pcm != 0), calculate_fluxes(s, FL_DUST, a->pcm != 0);
     apply_update(s, a->gam0, a->gam1, a->beta_dt);
     flux_source(s, FL_GAS, a->bdt), flux_source(s, FL_DUST, a->bdt);
+    if (a->diffusion) {
+      dflux_io(B, p, false), set_diffusion(s, a->diffusion);
+      diffusion_update(s, a->bdt);
+    }
     if (a->gravity) {
       const artemis_gravity_t *g = a->gravity;
       s.grav.type = g->type, s.grav.gm = g->gm, s.grav.soft = g->soft, s.grav.sink = g->sink;
@@ -432,6 +472,12 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
       s.gx1min = d->xmin[0], s.gx2min = d->xmin[1], s.gx3min = d->xmin[2];
       s.gx1max = d->xmax[0], s.gx2max = d->xmax[1], s.gx3max = d->xmax[2];
       drag_source(s, a->bdt);
+    }
+    if (a->cooling) {
+      const int gtype = s.grav.type; // set_cooling overwrites the gravity type: keep it for nothing below
+      set_cooling(s, a->cooling);
+      cooling_source(s, a->time, a->bdt);
+      s.grav.type = gtype;
     }
     set_aux(s);
     cons_to_prim(s);
@@ -508,24 +554,6 @@ int artemis_hip_halo_pack_ext(const artemis_pack_t *p, int b, int face, int exte
 }
 int artemis_hip_halo_unpack_ext(const artemis_pack_t *p, int b, int face, int extended, const double *buf, void *) {
   return halo(p, b, face, const_cast<double *>(buf), 1, extended);
-}
-// gas diffusion through the oracle's restatement
-static void set_diffusion(Sim &s, const artemis_diffusion_t *d) {
-  auto cp = [](Sim::DiffCoeff &o, const artemis_diffcoeff_t &c) {
-    o.type = c.type, o.avg = c.avg;
-    o.nu_s = o.alpha = o.hcond_0 = o.kappa_0 = c.coeff;
-    o.eta = c.eta, o.r_exp = c.r_exp, o.R0 = c.r0, o.Omega0 = c.omega0;
-    o.temp_exp = c.temp_exp, o.rho_exp = c.rho_exp, o.d0 = c.rho_ref, o.T0 = c.T_ref;
-  };
-  cp(s.visc, d->visc), cp(s.cond, d->cond);
-  s.cv = d->cv;
-}
-static void dflux_io(Bound &B, const artemis_pack_t *p, bool out) {
-  for (int d = 0; d < 3; ++d) {
-    if (!p->gas.diff_flux[d]) continue;
-    if (out) B.out(B.s->qflux[d], p->gas.diff_flux[d], 4 * B.s->c.ns_gas);
-    else B.in(B.s->qflux[d], p->gas.diff_flux[d], 4 * B.s->c.ns_gas);
-  }
 }
 int artemis_hip_diffusion_radial_fill(const artemis_pack_t *p, const double *geom_host, const double *,
                                       const artemis_diffcoeff_t *c, int block, double *out) {

@@ -299,7 +299,7 @@ def test_blast_reference_curvilinear_1d_bitwise(hiplib, g):
     energy and total energy is conserved (blast.py:177-183 bounds the pressure L2 error by 1)."""
     from artemis_amd.driver import Simulation
     s = Simulation(DECK("blast", "blast.in"), BLAST_GEOM[g] + ["parthenon/meshblock/nx1=1024"])
-    assert s.nblocks == 1 and s.uses_fused_path and not s.uses_tuned_kernel
+    assert s.nblocks == 1 and not s.uses_fused_path  # curvilinear decks default to the per-task chain
     sph = (g == "sph")
     o = Oracle((1024, 1, 1), (0.0, 0.0 if sph else -0.5, -0.5), (1.0, float("{:.16f}".format(np.pi)) if sph else 0.5, 0.5),
                ng=2, reconstruct="plm", riemann="hlle", gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
@@ -463,9 +463,24 @@ def test_general_stage_path_equals_per_task_path(hiplib):
             "gravity/point/mass=1.0e-3", "parthenon/time/nlim=30"]
     axi = BLAST_GEOM["axi"] + ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "problem/radius=0.1",
                                "problem/samples=10", "parthenon/time/nlim=30"]
+    # decks with diffusion, cooling and the curvilinear rotating frame: the general stage folds
+    # DiffusionUpdate, RotatingFrameImpl (from the cell's own mass fluxes) and BetaCooling into its kernel
+    visc = ["physics/viscosity=true", "physics/conduction=true", "gas/viscosity/nu=0.05", "gas/conductivity/cond=0.02",
+            "problem/vx3_bump=1.0e-2", "problem/vx1_bump=2.0e-2", "problem/vx2_bump=-1.5e-2", "problem/sigma=0.5",
+            "parthenon/time/nlim=25"]
+    disk = disk_overrides("sph", 1.4, "ic", one_block=False) + ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32",
+                                                                "parthenon/mesh/nx3=32", "parthenon/time/nlim=8"]
+    alpha = ["parthenon/mesh/x1max=2.0", "physics/viscosity=true", "gas/viscosity/alpha=1.0e-1", "cooling/tcyl=1.0e-2",
+             "problem/mdot=9.42477796e-03", "problem/quiet_start=true", "problem/h0=1.0e-1", "problem/dslope=0.0",
+             "problem/flare=0.0", "parthenon/mesh/nx1=64", "parthenon/mesh/nx2=16", "parthenon/meshblock/nx2=16",
+             "parthenon/time/tlim=8000.0", "parthenon/time/nlim=40"]
+    binary = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=128", "parthenon/time/nlim=20"]
     for deck, ov, dust in ((("advection", "advection.in"), adv + ["dust/reconstruct=plm", "dust/riemann=hlle"], True),
-                           (("blast", "blast.in"), axi, False), (("ssheet", "ssheet.in"), cfg3, True)):
+                           (("blast", "blast.in"), axi, False), (("ssheet", "ssheet.in"), cfg3, True),
+                           (("diffusion", "gaussian_bump.in"), visc, False), (("disk", "disk_sph.in"), disk, False),
+                           (("diffusion", "alpha_disk.in"), alpha, False), (("disk", "binary_cyl.in"), binary, False)):
         f, u = Simulation(DECK(*deck), ov), Simulation(DECK(*deck), ov)
+        f.set_path("fused")  # curvilinear decks default to the per-task chain (it is faster there)
         u.set_path("unfused")
         assert f.uses_fused_path and not f.uses_tuned_kernel and not u.uses_fused_path
         f.evolve(), u.evolve()
@@ -509,7 +524,7 @@ def test_viscous_diffusion_deck_bitwise_and_reference_pin(hiplib):
             "problem/temperature_bump=0.0", f"problem/sigma={np.sqrt(sig2):.8e}", "parthenon/time/tlim=2.0"]
     s = Simulation(DECK("diffusion", "gaussian_bump.in"),
                    base + ["problem/vx3_bump={:.16e}".format(eps * (2.0 * np.pi * sig2) ** -1.0)])
-    assert s.nblocks == 4 and not s.uses_fused_path
+    assert s.nblocks == 4 and s.uses_fused_path and not s.uses_tuned_kernel
     s.evolve()
     w = np.zeros((64, 64))
     for b in range(4):
@@ -693,7 +708,7 @@ def test_disk_decks_against_oracle_and_reference_pins(hiplib, g, gam, b):
     from artemis_amd.driver import Simulation
     from test_oracle_pins import disk_oracle
     s = Simulation(DECK("disk", f"disk_{g}.in"), disk_overrides(g, gam, b))
-    assert s.nblocks == 1 and not s.uses_fused_path
+    assert s.nblocks == 1 and not s.uses_fused_path  # curvilinear decks default to the per-task chain
     o = disk_oracle(g, gam, b)
     d0 = s.interior(s.field("gas.prim"))[0].copy()
     assert np.array_equal(d0, o.interior(o.gprim)[0])  # the problem generator

@@ -150,13 +150,15 @@ SPH3D = dict(deck=["blast", "blast.in"], cycles=5, overrides=[
 
 def test_spherical3d_two_ranks_equal_single_process_bitwise(double_lib, tmp_path):
     """artemis/coordinates = spherical on a 3-D wedge, 2x2x2 blocks with reflecting radial /
-    polar and periodic azimuthal boundaries: the per-task path (the fused kernel is
-    Cartesian-only; the general cell-centred stage runs instead) with the metric tables of each rank's own blocks gives the same bits on 2
-    ranks as on 1, and mass is conserved with the spherical cell volumes."""
+    polar and periodic azimuthal boundaries: the per-task chain (the default in curvilinear
+    coordinates) with the metric tables of each rank's own blocks gives the same bits on 2 ranks as on
+    1 and as the general cell-centred stage; mass is conserved with the spherical cell volumes."""
     one = run_world(1, SPH3D, tmp_path, "s1")
     two = run_world(2, SPH3D, tmp_path, "s2")
-    assert one[0]["meta"]["fused"] and not one[0]["meta"]["tuned"] and one[0]["meta"]["ncycle"] == 5
-    per_task = by_bounds(run_world(1, dict(SPH3D, path="unfused"), tmp_path, "s1u"))
+    assert not one[0]["meta"]["fused"] and one[0]["meta"]["ncycle"] == 5
+    fs = run_world(1, dict(SPH3D, path="fused"), tmp_path, "s1f")
+    assert fs[0]["meta"]["fused"] and not fs[0]["meta"]["tuned"]
+    per_task = by_bounds(fs)
     for r in two:
         for k in ("ncycle", "time", "dt"):
             assert r["meta"][k] == one[0]["meta"][k], k
@@ -252,7 +254,7 @@ def test_viscous_diffusion_deck_driver_equals_oracle_and_block_edges(double_lib,
     one_blk = dict(deck=["diffusion", "gaussian_bump.in"], cycles=30,
                    overrides=VISC + bump + ["parthenon/meshblock/nx1=64", "parthenon/meshblock/nx2=64"])
     r = run_world(1, one_blk, tmp_path, "v1")[0]
-    assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    assert r["meta"]["fused"] and not r["meta"]["tuned"] and r["meta"]["nblocks"] == 1
     o = Oracle((64, 64, 1), (-6.0, -6.0, -0.5), (6.0, 6.0, 0.5), ng=2, reconstruct="plm", riemann="hllc",
                gamma=1.000001, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
                bc=("outflow",) * 4 + ("periodic",) * 2, integrator="rk2")
@@ -300,7 +302,7 @@ def test_conduction_problem_deck_driver_equals_oracle(double_lib, tmp_path):
     from oracle.oracle import Oracle
     spec = dict(deck=["diffusion", "conduction.in"], cycles=200, overrides=["gravity/uniform/gx1=-0.02"])
     r = run_world(1, spec, tmp_path, "k1")[0]
-    assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    assert r["meta"]["fused"] and not r["meta"]["tuned"] and r["meta"]["nblocks"] == 1
     o = Oracle((128, 1, 1), (0.2, -0.5, -0.5), (1.2, 0.5, 0.5), ng=2, reconstruct="plm", riemann="hllc",
                gamma=1.66667, dfloor=1e-10, siefloor=1e-15, cfl=0.3,
                bc=("conductive", "conductive") + ("periodic",) * 4, integrator="rk2")
@@ -329,6 +331,10 @@ def test_disk_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
     o.evolve(62.8, 6)
     assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
     assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+    # the general fused stage (DiffusionUpdate, RotatingFrameImpl from the cell's own mass fluxes) gives
+    # the same bits; curvilinear decks merely default to the per-task chain because it is faster there
+    g = run_world(1, dict(one, path="fused"), tmp_path, "d1f")[0]
+    assert g["meta"]["fused"] and np.array_equal(g["blocks"][0][1], r["blocks"][0][1])
     four = dict(one, overrides=half)  # the deck's 32-zone blocks: 2 x 1 ... at half resolution 2 x 1
     four["overrides"] = half + ["parthenon/meshblock/nx2=16"]
     a, b = run_world(1, four, tmp_path, "d4"), run_world(2, four, tmp_path, "d4r2")

@@ -125,3 +125,70 @@ def test_general_stage_with_sources_and_drag(hiplib, case):
     assert np.array_equal(gbuf[0][I].cpu().numpy()[keep], o.gprim[I][keep])
     same(dbuf[0][I], o.dprim[I], "dust prim")
     assert dtd.item() == min(o.EstimateTimestepMesh(0), o.EstimateTimestepMesh(1))
+
+
+EXTRA_BLOCKS = [
+    ("cartesian", (24, 12, 10), (-1.0, -0.5, 0.25), (1.0, 0.8, 0.95)),
+    ("cartesian", (33, 9, 1), (0.4, -0.5, -0.5), (2.0, 0.8, 0.5)),
+    ("spherical", (16, 8, 8), (0.9, 1.06, -3.1), (5.6, 2.08, 3.1)),
+    ("spherical", (24, 10, 1), (0.6, 1.06, -0.5), (5.6, 2.08, 0.5)),
+    ("cylindrical", (16, 8, 6), (0.8, -3.1, -1.0), (4.3, 3.1, 1.0)),
+    ("axisymmetric", (24, 12, 1), (0.6, -2.0, -0.5), (4.3, 2.0, 0.5)),
+]
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", EXTRA_BLOCKS)
+def test_general_stage_with_diffusion_rotating_frame_and_cooling(hiplib, coordinates, nx, lo, hi):
+    """The optional tasks of the general stage: DiffusionUpdate from the stored viscous + thermal fluxes
+    (alpha viscosity, bulk viscosity, conduction), the rotating frame (shearing box in Cartesian,
+    RotatingFrameImpl from the cell's own mass fluxes elsewhere, plus the frame velocity in
+    FluxSource), point-mass gravity and beta cooling, gas and dust, against the oracle's task chain."""
+    from artemis_amd.pack import MeshBlockPack, diffusion_params, gravity_point
+    cart = coordinates == "cartesian"
+    kw = dict(ng=2, ns_gas=2, ns_dust=1, reconstruct="plm", riemann="hlle", dust_reconstruct="plm",
+              dust_riemann="hlle", gamma=1.4, dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10,
+              coordinates=coordinates)
+    o = Oracle(nx, lo, hi, bc=("outflow",) * 6, cfl=0.3, dust_cfl=0.3, **kw)
+    random_state(o, np.random.default_rng(91), shock=False, mach=0.5, contrast=10.0)
+    om, q = 0.8, (1.5 if cart else 0.0)
+    mb = MeshBlockPack(1, nx, [lo], [hi], with_diffusion=True, omega_frame=om, **kw)
+    push([o], mb)
+    o.DeepCopyConservedData()
+    pos = (0.1, 0.05, 0.0) if coordinates in ("cartesian", "cylindrical") or nx[2] > 1 else (0.0, 0.0, 0.0)
+    o.set_gravity_point(1.3, soft=0.05, x=pos[0], y=pos[1], z=pos[2])
+    o.set_rotating_frame(om, q)
+    o.set_viscosity("alpha", alpha=2e-2, eta_bulk=0.3, r0=0.9, Omega0=1.2)
+    o.set_conductivity("conductivity", cond=0.03, averaging="harmonic")
+    ckw = dict(beta0=2.0, beta_min=1e-3, exp_scale=0.3, tfloor=1e-3, tcyl=0.02, cyl_plaw=-1.0, tsph=0.01, sph_plaw=-0.5)
+    o.set_cooling(**ckw)
+    D = diffusion_params(1.4, viscosity=dict(type="alpha", alpha=2e-2, eta_bulk=0.3, r0=0.9, Omega0=1.2),
+                         conductivity=dict(type="conductivity", cond=0.03, averaging="harmonic"))
+    mb.viscosity_radial_table(D)
+    cool = mb.cooling_params(1.4, 1.3, **ckw)
+    grav = gravity_point(1.3, soft=0.05, pos=pos)
+    dt, time = 2.0e-4, 0.25
+    # oracle: the reference's task order (artemis_driver.cpp:182-255)
+    for fluid in (0, 1):
+        o.CalculateFluxes(fluid, False)
+    o.ZeroDiffusionFlux(), o.ViscousFlux(), o.ThermalFlux()
+    o.ApplyUpdate(0.0, 1.0, dt)
+    for fluid in (0, 1):
+        o.FluxSource(dt, fluid)
+    o.DiffusionUpdate(dt)
+    o.ExternalGravity(time, dt)
+    o.RotatingFrameForce(dt)
+    o.CoolingSource(time, dt)
+    o.SetAuxillaryFields()
+    o.ConsToPrim()
+    # product: diffusion fluxes of the input primitives, then one kernel per fluid
+    mb.ZeroDiffusionFlux(), mb.ViscousFlux(D), mb.ThermalFlux(D)
+    gbuf, gout = mb.new_prim_buffer("o")
+    dbuf, dout = mb.new_dust_prim_buffer("o")
+    dtd = torch.full((1,), 1.7976931348623157e308, dtype=torch.float64, device="cuda")
+    mb.stage_general(0.0, 1.0, dt, dt, gas=(mb.gas_prim_table, mb.gas_prim_table, gout),
+                     dust=(mb.dust_prim_table, mb.dust_prim_table, dout), time=time, gravity=grav,
+                     rotating_frame=(om, q), cfl=(0.3, 0.3), dt_dev=dtd.data_ptr(), diffusion=D, cooling=cool)
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    keep = [v for v in range(12) if not (8 <= v < 10)]  # P is not written
+    assert np.array_equal(gbuf[0][I].cpu().numpy()[keep], o.gprim[I][keep])
+    same(dbuf[0][I], o.dprim[I], "dust prim")
