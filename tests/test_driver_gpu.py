@@ -842,19 +842,3 @@ def test_binary_deck_bitwise_and_reference_pin(hiplib):
     assert abs(p_o - spiral_pos(1.1)) / spiral_pos(1.1) < 0.03, p_o
     fit = np.polyfit(np.log(rc), np.log(T.mean(axis=0)), 1)
     assert abs(fit[0] + 1.0) < 2e-4 and abs(np.exp(fit[1]) - 0.0025) / 0.0025 < 5e-3, fit
-
-
-def test_binary_adiabatic_reference_pin(hiplib):
-    """tst/scripts/binary_adi/binary_adi.py:44-60,104-113: the same deck with gamma = 1.4, here with the LLF
-    solver and the dual-energy switch at 1.0 (internal energy always taken from its own equation):
-    wake azimuths within 3 %.  All six solver x de_switch combinations of the reference test pass
-    on the GPU (scripts/binary_adi_check.py, profiles/r01d_binary_adi_gpu.txt); one is kept here."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
-    from binary_adi_check import wake_errors
-    from artemis_amd.driver import Simulation
-    f = Simulation(DECK("disk", "binary_cyl.in"), ["parthenon/time/tlim={:.16f}".format(2.0 * np.pi),
-                                                   "gas/de_switch=1.0e+00", "gas/gamma=1.4", "gas/riemann=llf"])
-    f.evolve()
-    e_i, e_o = wake_errors(f)
-    assert abs(f.time - 2 * np.pi) < 1e-12 and e_i < 0.03 and e_o < 0.03, (e_i, e_o)
