@@ -619,8 +619,8 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   // Default path by measurement (scripts/path_timing.py, one MI355X): the cell-centred general stage wins
   // on Cartesian meshes (2048^2 viscous 1.73e9 vs 1.50e9 zone-cycles/s, SURVEY config 3 2.9e9 vs 1.1e9); in
   // curvilinear coordinates every face carries PLM_G / scale-factor geometry and solving each face from
-  // both of its cells costs more than the flux arrays save (spherical 3-D blast 1.01e9 vs 1.24e9, disk
-  // decks 5.0e8 vs 6.6e8), so those default to the per-task chain.  artemis_sim_set_path overrides.
+  // both of its cells costs more than the flux arrays save (spherical 3-D blast 1.16e9 vs 1.29e9, disk
+  // decks 5.7e8 vs 6.8e8), so those default to the per-task chain.  artemis_sim_set_path overrides.
   use_fused = fused_possible && coords == ARTEMIS_CARTESIAN;
   if (!use_fused) ensure_unfused();
   problem_generator();

@@ -1,5 +1,6 @@
 // Device glue for geometry_core.hpp: Coords of a PackView cell, PLM_G and its per-cell inputs.
 #pragma once
+#include "device_math.hpp"
 #include "geometry_core.hpp"
 #include "pack_view.hpp"
 
@@ -34,10 +35,33 @@ GDEV void plm_g(double q_im1, double q_i, double q_ip1, double &ql_ip1, double &
   qr_i = q_i - dqm * (x_i - xf0) / dx;
 }
 
-// What PLM_G needs for the cell (k,j,i) along dir (plm.hpp:93-101, :127-135, :161-169).
+// What PLM_G needs for the cell (k,j,i) along dir (plm.hpp:93-101, :127-135, :161-169).  The
+// geometric quotients cr, cl and the refined reciprocals of the three geometric denominators are
+// formed once per cell and shared by every reconstructed variable (device_math.hpp: `div` with a
+// shared reciprocal returns the bits of `/`).
 struct PlmGeo {
   double xvm, xvc, xvp, xf0, xf1, dx;
+  double cr, cl, up, lo; // (x_ip1-x_i)/(xf1-x_i), (x_i-x_im1)/(x_i-xf0), xf1-x_i, x_i-xf0
+  Recip ra, rb, rdx;     // 1/(x_i-x_im1), 1/(x_ip1-x_i), 1/dx
 };
+__device__ __forceinline__ void plm_geo_finish(PlmGeo &g) {
+  g.cr = (g.xvp - g.xvc) / (g.xf1 - g.xvc);
+  g.cl = (g.xvc - g.xvm) / (g.xvc - g.xf0);
+  g.up = g.xf1 - g.xvc, g.lo = g.xvc - g.xf0;
+  g.ra = recip(g.xvc - g.xvm), g.rb = recip(g.xvp - g.xvc), g.rdx = recip(g.dx);
+}
+// PLM_G with the shared geometry: same expression tree as plm_g below
+__device__ __forceinline__ void plm_g_shared(double q_im1, double q_i, double q_ip1, double &ql_ip1,
+                                             double &qr_i, const PlmGeo &g) {
+  const double dql = div((q_i - q_im1) * g.dx, g.ra);
+  const double dqr = div((q_ip1 - q_i) * g.dx, g.rb);
+  const double dq2 = dql * dqr;
+  const double dqm =
+      (dq2 <= 0.0) ? 0.0
+                   : dq2 * (g.cr * dql + g.cl * dqr) / (dql * dql + dqr * dqr + dq2 * (g.cl + g.cr - 2.0));
+  ql_ip1 = q_i + div(dqm * g.up, g.rdx);
+  qr_i = q_i - div(dqm * g.lo, g.rdx);
+}
 GDEV PlmGeo plm_geo(const PackView &P, int b, int dir, int k, int j, int i) {
   PlmGeo g;
   const DCoords c = make_coords(P, b, k, j, i);
@@ -47,6 +71,7 @@ GDEV PlmGeo plm_geo(const PackView &P, int b, int dir, int k, int j, int i) {
   if (dir == 1) g.xvc = c.x1v(), g.xf0 = c.x1[0], g.xf1 = c.x1[1], g.dx = c.width1();
   else if (dir == 2) g.xvc = c.x2v(), g.xf0 = c.x2[0], g.xf1 = c.x2[1], g.dx = c.width2();
   else g.xvc = c.x3v(), g.xf0 = c.x3[0], g.xf1 = c.x3[1], g.dx = c.width3();
+  plm_geo_finish(g);
   return g;
 }
 

@@ -14,8 +14,8 @@ __device__ __forceinline__ void face_states(const double *q, long st, const PlmG
                                             const PlmGeo &gr, double &L, double &R) {
   double unused;
   if constexpr (CURV && RECON == 1) {
-    plm_g(q[-2 * st], q[-st], q[0], L, unused, gl.xvm, gl.xvc, gl.xvp, gl.xf0, gl.xf1, gl.dx);
-    plm_g(q[-st], q[0], q[st], unused, R, gr.xvm, gr.xvc, gr.xvp, gr.xf0, gr.xf1, gr.dx);
+    plm_g_shared(q[-2 * st], q[-st], q[0], L, unused, gl);
+    plm_g_shared(q[-st], q[0], q[st], unused, R, gr);
   } else {
     recon_cell<RECON>(q - st, st, L, unused), recon_cell<RECON>(q, st, unused, R);
   }
