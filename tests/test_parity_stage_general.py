@@ -192,3 +192,44 @@ def test_general_stage_with_diffusion_rotating_frame_and_cooling(hiplib, coordin
     keep = [v for v in range(12) if not (8 <= v < 10)]  # P is not written
     assert np.array_equal(gbuf[0][I].cpu().numpy()[keep], o.gprim[I][keep])
     same(dbuf[0][I], o.dprim[I], "dust prim")
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", EXTRA_BLOCKS[:2] + EXTRA_BLOCKS[4:5])
+def test_general_stage_with_diffusion_and_drag(hiplib, coordinates, nx, lo, hi):
+    """DiffusionUpdate inside the stage kernel followed by the drag / SetAuxillaryFields / ConsToPrim pass
+    (the stage leaves the post-source conserved state in cons0 when drag couples the fluids)."""
+    from artemis_amd.pack import MeshBlockPack, diffusion_params, drag_params
+    kw = dict(ng=2, ns_gas=1, ns_dust=2, reconstruct="plm", riemann="hllc", dust_reconstruct="plm",
+              dust_riemann="hlle", gamma=1.4, dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10,
+              coordinates=coordinates)
+    o = Oracle(nx, lo, hi, bc=("outflow",) * 6, cfl=0.3, dust_cfl=0.3, **kw)
+    random_state(o, np.random.default_rng(93), shock=False, mach=0.5, contrast=10.0)
+    mb = MeshBlockPack(1, nx, [lo], [hi], with_diffusion=True, **kw)
+    push([o], mb)
+    o.DeepCopyConservedData()
+    o.set_viscosity("constant", nu=0.04, eta_bulk=0.5)
+    o.set_conductivity("diffusivity", kappa=0.02)
+    o.set_drag("simple_dust", "constant", tau=[0.05, 2.0])
+    D = diffusion_params(1.4, viscosity=dict(type="constant", nu=0.04, eta_bulk=0.5),
+                         conductivity=dict(type="diffusivity", kappa=0.02))
+    drag = drag_params("simple_dust", "constant", tau=[0.05, 2.0], mesh_min=lo, mesh_max=hi)
+    dt = 2.0e-4
+    for fluid in (0, 1):
+        o.CalculateFluxes(fluid, False)
+    o.ZeroDiffusionFlux(), o.ViscousFlux(), o.ThermalFlux()
+    o.ApplyUpdate(0.0, 1.0, dt)
+    for fluid in (0, 1):
+        o.FluxSource(dt, fluid)
+    o.DiffusionUpdate(dt)
+    o.DragSource(dt)
+    o.SetAuxillaryFields()
+    o.ConsToPrim()
+    mb.ZeroDiffusionFlux(), mb.ViscousFlux(D), mb.ThermalFlux(D)
+    gbuf, gout = mb.new_prim_buffer("o")
+    dbuf, dout = mb.new_dust_prim_buffer("o")
+    mb.stage_general(0.0, 1.0, dt, dt, gas=(mb.gas_prim_table, mb.gas_prim_table, gout),
+                     dust=(mb.dust_prim_table, mb.dust_prim_table, dout), drag=drag, diffusion=D)
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    keep = [0, 1, 2, 3, 5]
+    assert np.array_equal(gbuf[0][I].cpu().numpy()[keep], o.gprim[I][keep])
+    same(dbuf[0][I], o.dprim[I], "dust prim")
