@@ -238,8 +238,8 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
       const bool extrap = (bc[i] == ARTEMIS_BC_STRAT_EXTRAP);
       if ((extrap && d == 1) || (!extrap && d != 1)) // problem_modifier.hpp:117-128
         return fail(ARTEMIS_HIP_EINVAL, "strat conditions: extrap belongs to x1/x3, inflow to x2 faces");
-      if (extrap && d == 2 && p->nx3 > 1) // strat.hpp:520-523 uses std::pow on the density ratio
-        return fail(ARTEMIS_HIP_EUNSUPPORTED, "strat extrap condition on x3 faces is not built");
+      if (extrap && d == 2 && p->nx3 < 2)
+        return fail(ARTEMIS_HIP_EINVAL, "strat extrap condition on x3 faces needs two active zones in x3");
       if (p->coords != ARTEMIS_CARTESIAN)
         return fail(ARTEMIS_HIP_EINVAL, "problem = strat only works for Cartesian Coordinates!");
       if (p->gas.nspecies > 1)

@@ -844,7 +844,9 @@ void artemis_sim::fill_ghosts_finish(int prim_idx, void *hs, int dim, bool apply
     // PrimToCons that follows them to apply the floors; the fused stages do not run PrimToCons
     artemis_bc_params_t bp = bcpar;
     bool value_bc = false;
-    for (int q : bc_flat) value_bc = value_bc || q >= ARTEMIS_BC_CONDUCTIVE;
+    for (size_t q = 0; q < bc_flat.size(); ++q) // (the strat x3 `extrap` continues the density with pow())
+      value_bc = value_bc || bc_flat[q] >= ARTEMIS_BC_CONDUCTIVE ||
+                 (bc_flat[q] == ARTEMIS_BC_STRAT_EXTRAP && (q % 6) / 2 == 2);
     bp.floor_ghosts = (use_fused && value_bc) ? 1 : 0;
     CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc");
   }

@@ -516,6 +516,29 @@ __global__ __launch_bounds__(256) void strat_bc_kernel(const StratBcArgs a, cons
       se[c] = se[ca];
     }
     for (int n = 0; n < nsd; ++n) fill(t.dust, t.b * 4 * nsd, nsd, n);
+  } else if (a.d == 2) { // x3 `extrap` (strat.hpp:476-640): copy, no inflow in v3, density continued as a power
+    // law in z through the first two active zones -- std::pow of a STATE ratio in the reference, pow()
+    // on the device here: agreement with a host libm is to rounding, not bitwise
+    const int ka = (a.side == 0) ? a.st : a.en, kb = (a.side == 0) ? a.st + 1 : a.en - 1;
+    const long ca = c + static_cast<long>(ka - k) * ni * nj, cb = c + static_cast<long>(kb - k) * ni * nj;
+    auto x3v = [&](int kk) { return 0.5 * ((g[4] + kk * g[5]) + (g[4] + (kk + 1) * g[5])); };
+    const double z = x3v(k), z0 = x3v(ka), z1 = x3v(kb);
+    const double dz = (a.side == 0) ? (z1 - z0) : (z0 - z1);
+    auto fill = [&](double *const *tab, int base, int ns, int n) {
+      double *q1 = tab[base + ns + 3 * n + 0], *q2 = tab[base + ns + 3 * n + 1];
+      double *q3 = tab[base + ns + 3 * n + 2], *qd = tab[base + n];
+      const double v1 = q1[ca], v2 = q2[ca], v3 = q3[ca];
+      const double vx3 = (a.side == 0) ? ((v3 > 0.0) ? 0.0 : v3) : ((v3 < 0.0) ? 0.0 : v3);
+      const double dd = qd[ca], dn = qd[cb];
+      const double drho = (a.side == 0) ? dn / dd : dd / dn;
+      q1[c] = v1, q2[c] = v2, q3[c] = vx3, qd[c] = dd * pow(drho, (z - z0) / dz);
+    };
+    if (nsg) {
+      fill(t.gas, t.b * 6 * nsg, nsg, 0);
+      double *se = t.gas[t.b * 6 * nsg + 5 * nsg];
+      se[c] = se[ca];
+    }
+    for (int n = 0; n < nsd; ++n) fill(t.dust, t.b * 4 * nsd, nsd, n);
   } else {
     const int ja = (a.side == 0) ? a.st : a.en;
     const long ca = c + static_cast<long>(ja - j) * ni;

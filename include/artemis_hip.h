@@ -57,7 +57,8 @@ enum artemis_bc { ARTEMIS_BC_PERIODIC = 0, ARTEMIS_BC_OUTFLOW = 1, ARTEMIS_BC_RE
                   ARTEMIS_BC_NONE = 3,
                   /* user conditions of the `strat` problem (pgen/strat.hpp:158-466, registered as
                    * `extrap` / `inflow` at problem_modifier.hpp:114-128): */
-                  ARTEMIS_BC_STRAT_EXTRAP = 4, /* x1 faces */
+                  ARTEMIS_BC_STRAT_EXTRAP = 4, /* x1 faces; x3 faces (density continued with pow() of a state
+                                                 * ratio on the device: to rounding, not bitwise) */
                   ARTEMIS_BC_STRAT_INFLOW = 5, /* x2 faces */
                   /* `conductive` of the `conduction` problem (pgen/conduction.hpp:105-232): fixed heat
                    * flux through inner faces, fixed temperature at outer ones */

@@ -2226,6 +2226,33 @@ void strat_bc(Sim &s, int d, int side) {
           }
           for (int n = 0; n < nd_; ++n)
             fill(s.dprim, nd_, n);
+        } else if (d == 2) { // strat.hpp:476-555 ExtrapInnerX3, :559-640 ExtrapOuterX3
+          const int ka = (side == 0) ? s.ks : s.ke, kb = (side == 0) ? s.ks + 1 : s.ke - 1;
+          const Real z = x3v(bbox(s, k, j, i));
+          const Real z0 = x3v(bbox(s, ka, j, i));
+          const Real z1 = x3v(bbox(s, kb, j, i));
+          const Real dz = (side == 0) ? (z1 - z0) : (z0 - z1);
+          const size_t ca = IDX(s, ka, j, i), cb = IDX(s, kb, j, i);
+          auto fill = [&](std::vector<Real> &q, int nsp, int n) {
+            const Real v1 = q[(nsp + 3 * n + 0) * s.N + ca];
+            const Real v2 = q[(nsp + 3 * n + 1) * s.N + ca];
+            const Real v3 = q[(nsp + 3 * n + 2) * s.N + ca];
+            const Real vx3 = (side == 0) ? ((v3 > 0.0) ? 0.0 : v3) : ((v3 < 0.0) ? 0.0 : v3);
+            const Real dd = q[n * s.N + ca];
+            const Real dn = q[n * s.N + cb];
+            const Real drho = (side == 0) ? dn / dd : dd / dn;
+            const Real dens = dd * std::pow(drho, (z - z0) / dz);
+            q[(nsp + 3 * n + 0) * s.N + c] = v1;
+            q[(nsp + 3 * n + 1) * s.N + c] = v2;
+            q[(nsp + 3 * n + 2) * s.N + c] = vx3;
+            q[n * s.N + c] = dens;
+          };
+          if (ng_) {
+            fill(s.gprim, ng_, 0);
+            s.gprim[(5 * ng_) * s.N + c] = s.gprim[(5 * ng_) * s.N + ca];
+          }
+          for (int n = 0; n < nd_; ++n)
+            fill(s.dprim, nd_, n);
         } else {
           const int ja = (side == 0) ? s.js : s.je;
           const BBox b = bbox(s, k, j, i);
@@ -2506,7 +2533,7 @@ void apply_bcs(Sim &s) {
       if (pass == 1 && d < s.ndim)
         for (int side = 0; side < 2; ++side) {
           const int bc = s.c.bc[2 * d + side];
-          if ((d == 0 && bc == BC_STRAT_EXTRAP) || (d == 1 && bc == BC_STRAT_INFLOW))
+          if ((d != 1 && bc == BC_STRAT_EXTRAP) || (d == 1 && bc == BC_STRAT_INFLOW))
             strat_bc(s, d, side);
           if (bc == BC_CONDUCTIVE) conductive_bc(s, d, side);
           if (bc == BC_DISK_IC || bc == BC_DISK_EXTRAP) disk_bc(s, d, side, bc == BC_DISK_EXTRAP);

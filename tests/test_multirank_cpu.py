@@ -396,3 +396,34 @@ def test_binary_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
         i0, j0 = int(round((key[0] - 0.3) / 2.7 * 64)), int(round(key[2] / 6.283185307179586 * 128))
         ref = full[:, :, j0:j0 + 32, i0:i0 + 32]
         assert np.max(np.abs(part - ref) / scale) < 1e-11, key
+
+
+def test_stratified_box_3d_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
+    """The strat problem in 3-D (Gaussian vertical stratification, vertical gravity of the shearing
+    box, `extrap` on the x3 faces with its power-law density continuation): driver == oracle on one
+    block over 12 cycles; 2 x 2 x 2 blocks on two ranks == one rank."""
+    from oracle.oracle import Oracle
+    box = ["parthenon/mesh/nx1=16", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16", "parthenon/mesh/x3min=-0.2",
+           "parthenon/mesh/x3max=0.2", "parthenon/mesh/ix3_bc=extrap", "parthenon/mesh/ox3_bc=extrap",
+           "gravity/point/mass=1.0e-3"]
+    one_blk = dict(deck=["ssheet", "ssheet.in"], cycles=12,
+                   overrides=box + ["parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16"])
+    r = run_world(1, one_blk, tmp_path, "z1")[0]
+    assert r["meta"]["fused"] and r["meta"]["nblocks"] == 1
+    o = Oracle((16, 16, 16), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.000001, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
+               bc=("extrap", "extrap", "inflow", "inflow", "extrap", "extrap"), integrator="rk2")
+    o.set_rotating_frame(1.0, 1.5)
+    o.set_gravity_point(1e-3, soft=0.03)
+    o.pgen_strat(rho0=1.0, dens_min=1e-10, h=0.05)
+    o.evolve(100.0, 12)
+    assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
+    assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+    rho = o.interior(o.gprim)[0]
+    assert rho[8, 8, 8] > 5.0 * rho[0, 8, 8]  # stratified: the midplane is denser than the top layer
+    eight = dict(one_blk, overrides=box + ["parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8"])
+    a, b = run_world(1, eight, tmp_path, "z8"), run_world(2, eight, tmp_path, "z8r2")
+    assert a[0]["meta"]["nblocks"] == 8 and [x["meta"]["nblocks"] for x in b] == [4, 4]
+    xa, xb = by_bounds(a), by_bounds(b)
+    for key in xa:
+        assert np.array_equal(xa[key], xb[key]), key

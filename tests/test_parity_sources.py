@@ -226,6 +226,24 @@ def test_strat_boundary_conditions(hiplib, nx, ns_dust):
         same(mb.dust_prim[0], o.dprim, "dust ghosts")
 
 
+@pytest.mark.parametrize("ns_dust", [0, 2])
+def test_strat_vertical_extrap_condition(hiplib, ns_dust):
+    """`extrap` on the x3 faces of the 3-D stratified box (strat.hpp:476-640): copy with no inflow in v3 and
+    the density continued as rho_a (rho_b / rho_a)^((z - z_a)/dz) -- std::pow of a state ratio, evaluated
+    with the device's pow(): 1e-13 relative on the densities, everything else bit for bit."""
+    bc = ("extrap", "extrap", "inflow", "inflow", "extrap", "extrap")
+    o, mb = pair((20, 12, 10), (-1.0, -1.0, -0.6), (1.0, 1.0, 0.6), ns_gas=1, ns_dust=ns_dust, seed=33, bc=bc)
+    o.set_rotating_frame(1.1, 1.5)
+    o.ApplyBoundaryConditions()
+    mb.ApplyBoundaryConditions([bc], strat=(1.5, 1.1))
+    a, b = mb.gas_prim[0].cpu().numpy(), o.gprim
+    assert np.array_equal(a[1:], b[1:]) and np.max(np.abs(a[0] - b[0]) / b[0]) < 1e-13
+    assert not np.array_equal(a[0, :2], a[0, 2:4])  # the lower x3 ghost layers were written
+    if ns_dust:
+        a, b = mb.dust_prim[0].cpu().numpy(), o.dprim
+        assert np.array_equal(a[ns_dust:], b[ns_dust:]) and np.max(np.abs(a[:ns_dust] - b[:ns_dust]) / b[:ns_dust]) < 1e-13
+
+
 def test_source_abi_contract(hiplib):
     import ctypes as C
     from artemis_amd import capi
