@@ -77,7 +77,9 @@ class StageArgs(C.Structure):
 class BcParams(C.Structure):
     _fields_ = [("qshear", C.c_double), ("omega", C.c_double), ("cond_temp", C.c_double),
                 ("cond_flux", C.c_double), ("cond_g", C.c_double * 3), ("cond_coeff", C.c_double),
-                ("cond_cv", C.c_double), ("cond_type", C.c_int), ("ic_gas", C.c_void_p),
+                ("cond_cv", C.c_double), ("cond_type", C.c_int), ("cond_temp_exp", C.c_double),
+                ("cond_rho_exp", C.c_double), ("cond_T_ref", C.c_double), ("cond_rho_ref", C.c_double),
+                ("ic_gas", C.c_void_p),
                 ("ic_dust", C.c_void_p), ("disk_omf", C.c_double), ("disk_nu0", C.c_double),
                 ("disk_nu_indx", C.c_double), ("disk_r0", C.c_double), ("disk_mdot", C.c_double),
                 ("floor_ghosts", C.c_int)]

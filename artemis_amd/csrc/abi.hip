@@ -493,9 +493,8 @@ static int validate_diffusion(const artemis_pack_t *p, const artemis_diffusion_t
                 : (c->type != ARTEMIS_CONDUCTIVITY_PLAW && c->type != ARTEMIS_THERMALDIFF_PLAW))
       return fail(ARTEMIS_HIP_EINVAL, is_visc ? "Invalid viscosity type" : "Invalid conductivity type");
     if (c->avg != 0 && c->avg != 1) return fail(ARTEMIS_HIP_EINVAL, "averaging is not supported");
-    if (c->temp_exp != 0.0 || c->rho_exp != 0.0)
-      return fail(ARTEMIS_HIP_EUNSUPPORTED,
-                  "diffusion: temperature / density power laws need std::pow of the state per cell and are not built");
+    if (!is_visc && (c->temp_exp != 0.0 || c->rho_exp != 0.0) && !(c->T_ref > 0.0 && c->rho_ref > 0.0))
+      return fail(ARTEMIS_HIP_EINVAL, "conductivity power laws: T_ref and rho_ref must be positive");
     if (is_visc && (c->type == ARTEMIS_VISCOSITY_ALPHA || c->r_exp != 0.0) && !c->radial)
       return fail(ARTEMIS_HIP_EINVAL,
                   "viscosity: alpha / radial power law need the radial table (artemis_hip_diffusion_radial_fill)");

@@ -536,8 +536,8 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
     bcpar.cond_flux = pin.GetOrAddReal("problem", "flux", 0.0);
     for (int d = 0; d < 3; ++d) bcpar.cond_g[d] = (do_gravity && grav.type == ARTEMIS_GRAVITY_UNIFORM) ? grav.g[d] : 0.0;
     bcpar.cond_coeff = diff.cond.coeff, bcpar.cond_cv = diff.cv, bcpar.cond_type = diff.cond.type;
-    if (diff.cond.temp_exp != 0.0 || diff.cond.rho_exp != 0.0)
-      throw std::runtime_error("conductive boundaries with power-law conductivity are not built");
+    bcpar.cond_temp_exp = diff.cond.temp_exp, bcpar.cond_rho_exp = diff.cond.rho_exp;
+    bcpar.cond_T_ref = diff.cond.T_ref, bcpar.cond_rho_ref = diff.cond.rho_ref;
   }
   // <dust> (dust.cpp:45-110)
   if (do_dust) {

@@ -69,8 +69,7 @@ struct Geo {
   }
 };
 
-// DiffusionCoeff<DIFF>::Get of cell c of block b.  State power laws have zero exponents
-// (std::pow(x, 0.0) == 1.0 for every x); the radial factors come from the host-filled table.
+// DiffusionCoeff<DIFF>::Get of cell c of block b; the radial factors come from the host-filled table.
 ADEV double coeff_of(const artemis_diffcoeff_t &dp, double cv, double gm1, double dens, double sie, int b,
                      long c) {
   switch (dp.type) {
@@ -80,8 +79,15 @@ ADEV double coeff_of(const artemis_diffcoeff_t &dp, double cv, double gm1, doubl
     const double blk = (gm1 + 1.0) * gm1 * dens * sie;
     return dp.coeff * blk / dp.radial[b][c];
   }
-  case ARTEMIS_CONDUCTIVITY_PLAW: return dp.coeff * 1.0 * 1.0;     // :312-316
-  default: return dp.coeff * 1.0 * 1.0 * dens * cv;                // thermaldiff_plaw :353-359
+  default: { // conductivity_plaw :312-316, thermaldiff_plaw :353-359
+    // zero exponents (every shipped deck): std::pow(x, 0.0) == 1.0, bit-exact.  Otherwise the power laws of
+    // the STATE run on the device's pow(): agreement with a host libm is to rounding, not bitwise.
+    double ft = 1.0, fr = 1.0;
+    if (dp.temp_exp != 0.0) ft = pow(amax(0.0, sie / cv) / dp.T_ref, dp.temp_exp);
+    if (dp.rho_exp != 0.0) fr = pow(dens / dp.rho_ref, dp.rho_exp);
+    if (dp.type == ARTEMIS_CONDUCTIVITY_PLAW) return dp.coeff * ft * fr;
+    return dp.coeff * ft * fr * dens * cv;
+  }
   }
 }
 ADEV double face_average(int avg, double mu1, double mu2) { // diffusion_coeff.hpp:139-150

@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void strat_bc_kernel(const StratBcArgs a, cons
 // from hydrostatic balance, velocities copied from the first active zone `ia` along d.
 struct CondBcArgs {
   int d, side, ng, st, en;
-  double g_temp, flux, gx, coeff, cv, gm1;
+  double g_temp, flux, gx, coeff, cv, gm1, temp_exp, rho_exp, T_ref, rho_ref;
   int type;
 };
 __global__ __launch_bounds__(256) void conductive_bc_kernel(const CondBcArgs a, const FillTabs t,
@@ -598,7 +598,10 @@ __global__ __launch_bounds__(256) void conductive_bc_kernel(const CondBcArgs a, 
   double *rho = t.gas[t.b * 6 * nsg + 0], *se = t.gas[t.b * 6 * nsg + 5 * nsg];
   const double da = rho[cA], siea = se[cA];
   const double Ta = amax(0.0, siea / a.cv);
-  const double ka = (a.type == ARTEMIS_CONDUCTIVITY_PLAW) ? a.coeff * 1.0 * 1.0 : a.coeff * 1.0 * 1.0 * da * a.cv;
+  double ft = 1.0, fr = 1.0; // DiffusionCoeff::Get (diffusion_coeff.hpp:312-316, :353-359); pow() only for non-zero exponents
+  if (a.temp_exp != 0.0) ft = pow(Ta / a.T_ref, a.temp_exp);
+  if (a.rho_exp != 0.0) fr = pow(da / a.rho_ref, a.rho_exp);
+  const double ka = (a.type == ARTEMIS_CONDUCTIVITY_PLAW) ? a.coeff * ft * fr : a.coeff * ft * fr * da * a.cv;
   double Tg = a.g_temp;
   if (INNER) Tg = Ta - a.flux * xma / ka;
   const double densg = da * (Ta - 0.5 * a.gx * xma) / (Tg + 0.5 * a.gx * xma);
@@ -933,6 +936,8 @@ static void launch_bc_sequential(const PackView &P, int b, const int *bc6,
           a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
           a.g_temp = par->cond_temp, a.flux = par->cond_flux, a.gx = par->cond_g[d];
           a.coeff = par->cond_coeff, a.cv = par->cond_cv, a.gm1 = P.gm1, a.type = par->cond_type;
+          a.temp_exp = par->cond_temp_exp, a.rho_exp = par->cond_rho_exp, a.T_ref = par->cond_T_ref;
+          a.rho_ref = par->cond_rho_ref;
           hipLaunchKernelGGL(conductive_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P);
         } else if (flag == ARTEMIS_BC_IC || flag == ARTEMIS_BC_DISK_EXTRAP || flag == ARTEMIS_BC_DISK_VISC) {
           DiskBcArgs a;

@@ -165,6 +165,8 @@ class MeshBlockPack:
                 bp.cond_g[:] = list(conductive.get("g", (0.0, 0.0, 0.0)))
                 bp.cond_coeff, bp.cond_cv = conductive["coeff"], conductive["cv"]
                 bp.cond_type = conductive.get("type", capi.CONDUCTIVITY_PLAW)
+                bp.cond_temp_exp, bp.cond_rho_exp = conductive.get("temp_exp", 0.0), conductive.get("rho_exp", 0.0)
+                bp.cond_T_ref, bp.cond_rho_ref = conductive.get("T_ref", 1.0), conductive.get("rho_ref", 1.0)
             par = C.byref(bp)
         self._call(self.L.artemis_hip_apply_bc, arr, par)
 

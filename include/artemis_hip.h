@@ -176,7 +176,9 @@ typedef struct artemis_bc_params {
    * flux, uniform gravity along x1/x2/x3 (0 when gravity is off or not uniform), the constant heat
    * conductivity K or diffusivity (K = kappa*rho*cv) and the IdealGas specific heat */
   double cond_temp, cond_flux, cond_g[3], cond_coeff, cond_cv;
-  int cond_type;              /* ARTEMIS_CONDUCTIVITY_PLAW | ARTEMIS_THERMALDIFF_PLAW (zero exponents) */
+  int cond_type;              /* ARTEMIS_CONDUCTIVITY_PLAW | ARTEMIS_THERMALDIFF_PLAW */
+  double cond_temp_exp, cond_rho_exp, cond_T_ref, cond_rho_ref; /* its power laws (0 exponents: bit-exact;
+                                 otherwise pow() of the state on the device, to rounding) */
   /* disk conditions (pgen/disk.hpp).  IC: DEVICE pointer tables laid out like gas.prim /
    * dust.prim holding the initial primitives over the entire block (the time-independent disk
    * profile DiskBoundaryIC re-evaluates per call, :597-632); ghost zones are copied from them.
@@ -326,8 +328,8 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
  * arithmetic or harmonic face averaging.  The reference evaluates std::pow per cell: the radial
  * factors depend on the cell centre only, so the adapter tabulates them once per mesh with the
  * HOST libm (artemis_hip_diffusion_radial_fill -> artemis_diffcoeff_t.radial) and results stay
- * bit-identical; the temperature / density power laws depend on the state, have no
- * bit-reproducible device counterpart and return ARTEMIS_HIP_EUNSUPPORTED. */
+ * bit-identical; the temperature / density power laws of the conductivity depend on the state:
+ * exactly 1 for zero exponents (bit-exact), pow() on the device otherwise (to rounding). */
 enum artemis_diff_type { ARTEMIS_DIFF_OFF = 0, ARTEMIS_VISCOSITY_PLAW = 1, ARTEMIS_VISCOSITY_ALPHA = 2,
                          ARTEMIS_CONDUCTIVITY_PLAW = 3, ARTEMIS_THERMALDIFF_PLAW = 4 };
 typedef struct artemis_diffcoeff { /* DiffCoeffParams, diffusion_coeff.hpp:58-136 */

@@ -245,6 +245,8 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
       s.grav.type = 1;
       for (int d = 0; d < 3; ++d) s.grav.g[d] = par->cond_g[d];
       s.cond.type = par->cond_type, s.cond.hcond_0 = s.cond.kappa_0 = par->cond_coeff;
+      s.cond.temp_exp = par->cond_temp_exp, s.cond.rho_exp = par->cond_rho_exp;
+      s.cond.T0 = (par->cond_T_ref > 0.0) ? par->cond_T_ref : 1.0, s.cond.d0 = (par->cond_rho_ref > 0.0) ? par->cond_rho_ref : 1.0;
       if (par->cond_cv > 0.0) s.cv = par->cond_cv;
       s.disk.omf = par->disk_omf, s.disk.nu0 = par->disk_nu0, s.disk.nu_indx = par->disk_nu_indx;
       s.disk.r0 = par->disk_r0, s.disk.mdot = par->disk_mdot;

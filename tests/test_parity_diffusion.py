@@ -83,9 +83,9 @@ def test_conduction_only_update_and_contract(hiplib):
     with pytest.raises(capi.ArtemisHipError) as e:
         mb.ViscousFlux(diffusion_params(1.4, viscosity=dict(type="alpha", alpha=0.01)))
     assert e.value.code == capi.EINVAL
-    with pytest.raises(capi.ArtemisHipError) as e:  # state power laws: std::pow of T, rho per cell
-        mb.ThermalFlux(diffusion_params(1.4, conductivity=dict(type="conductivity", cond=0.1, rho_exp=1.0)))
-    assert e.value.code == capi.EUNSUPPORTED
+    with pytest.raises(capi.ArtemisHipError) as e:  # state power laws need positive reference values
+        mb.ThermalFlux(diffusion_params(1.4, conductivity=dict(type="conductivity", cond=0.1, rho_exp=1.0, rho_ref=0.0)))
+    assert e.value.code == capi.EINVAL
     cyl = MeshBlockPack(1, (8, 4, 1), [(0.5, 0.0, -0.5)], [(1.0, 3.0, 0.5)], coordinates="cylindrical",
                         with_diffusion=True)
     cyl.pack.metric = None  # Coords::Distance needs the azimuth's cos / sin
@@ -97,3 +97,31 @@ def test_conduction_only_update_and_contract(hiplib):
         nofl.ThermalFlux(D)
     assert e.value.code == capi.EINVAL
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", CART[:2] + CURVI[2:4])
+@pytest.mark.parametrize("ctype", ["conductivity", "diffusivity"])
+def test_state_power_law_conductivity(hiplib, coordinates, nx, lo, hi, ctype):
+    """K = K0 (T/T_ref)^a (rho/rho_ref)^b (diffusion_coeff.hpp:312-316, :353-359) with a = 2.5 (Spitzer),
+    b = -0.5: std::pow of the state per cell in the reference, pow() on the device here -- fluxes,
+    update and timestep agree to 1e-13 of their maxima instead of bitwise."""
+    from artemis_amd.pack import diffusion_params
+    o, mb = pair(nx, ns_gas=2, seed=57, coordinates=coordinates, lo=lo, hi=hi)
+    ck = dict(cond=0.07) if ctype == "conductivity" else dict(kappa=0.07)
+    law = dict(temp_exp=2.5, rho_exp=-0.5, rho_ref=0.7, T_ref=1.3)
+    o.set_conductivity(ctype, averaging="harmonic", **ck, **law)
+    D = diffusion_params(1.4, conductivity=dict(type=ctype, averaging="harmonic", **ck, **law))
+    o.ZeroDiffusionFlux(), mb.ZeroDiffusionFlux()
+    o.ThermalFlux(), mb.ThermalFlux(D)
+    for d in range(o.ndim):
+        a, b = mb.gas_diff_flux[d][0][face_slices(o, d)].cpu().numpy(), o.qflux(d)[face_slices(o, d)]
+        assert np.max(np.abs(a - b)) < 1e-13 * np.abs(b).max(), d
+    before = o.gu0.copy()
+    o.DiffusionUpdate(2.0e-4), mb.DiffusionUpdate(D, 2.0e-4)
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    a, b = mb.gas_u0[0][I].cpu().numpy(), o.gu0[I]
+    assert np.max(np.abs(a - b)) < 1e-13 * np.abs(b - before[I]).max() + 1e-15 * np.abs(b).max()
+    t = mb.DiffusionTimestep(D, 0.3)
+    ref = o.EstimateTimestepMesh(0)
+    hyd = mb.EstimateTimestepMesh(0, cfl=0.3)
+    assert abs(min(hyd, t) - ref) < 1e-13 * ref

@@ -83,10 +83,6 @@ def test_radial_viscosity_contract(hiplib):
     with pytest.raises(capi.ArtemisHipError) as e:
         mb.ViscousFlux(D2)
     assert e.value.code == capi.EINVAL and "omega0" in str(e.value)
-    D3 = diffusion_params(1.4, conductivity=dict(type="conductivity", cond=0.1, temp_exp=0.5))
-    with pytest.raises(capi.ArtemisHipError) as e:  # state power laws: std::pow per cell and stage
-        mb.ThermalFlux(D3)
-    assert e.value.code == capi.EUNSUPPORTED
     torch.cuda.synchronize()
 
 

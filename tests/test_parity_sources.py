@@ -290,6 +290,31 @@ COND_BLOCKS = [
 ]
 
 
+@pytest.mark.parametrize("coordinates,nx,lo,hi", COND_BLOCKS[:1] + COND_BLOCKS[4:5])
+def test_conductive_boundary_conditions_power_law(hiplib, coordinates, nx, lo, hi):
+    """the same condition with K = K0 (T/T_ref)^2.5 (rho/rho_ref)^-0.5 at the active zone: pow() of the
+    state on the device, 1e-13 on the ghost density and sie."""
+    from artemis_amd import capi
+    bc = ("conductive",) * 6
+    o, mb = pair(nx, lo, hi, ns_gas=1, ns_dust=0, seed=27, bc=bc, coordinates=coordinates)
+    o.set_gravity_uniform(-0.3, 0.2, 0.1)
+    law = dict(temp_exp=2.5, rho_exp=-0.5, rho_ref=0.7, T_ref=1.3)
+    o.set_conductivity("conductivity", cond=0.1, **law)
+    o.pgen_conduction(gas_rho=1.0, gas_temp=0.05, flux=0.01, post_init=False)
+    random_state(o, np.random.default_rng(28), shock=False, contrast=10.0)
+    push([o], mb)
+    o.ApplyBoundaryConditions()
+    mb.ApplyBoundaryConditions([bc], conductive=dict(
+        temp=0.05, flux=0.01, g=(-0.3, 0.2, 0.1), coeff=0.1, cv=1.0 / ((1.4 - 1.0) * 1.0 * 1.0),
+        type=capi.CONDUCTIVITY_PLAW, **law))
+    a, b = mb.gas_prim[0].cpu().numpy(), o.gprim
+    assert np.array_equal(a[1:4], b[1:4])
+    for v in (0, 5):  # (sie is clamped to zero where the extrapolated temperature is negative)
+        assert np.array_equal(np.isfinite(a[v]), np.isfinite(b[v]))
+        m = np.isfinite(b[v])
+        assert np.max(np.abs(a[v][m] - b[v][m])) < 1e-12 * np.abs(b[v][m]).max()
+
+
 @pytest.mark.parametrize("coordinates,nx,lo,hi", COND_BLOCKS)
 @pytest.mark.parametrize("ctype", ["conductivity", "diffusivity"])
 def test_conductive_boundary_conditions(hiplib, coordinates, nx, lo, hi, ctype):
