@@ -427,3 +427,25 @@ def test_stratified_box_3d_driver_equals_oracle_and_ranks_agree(double_lib, tmp_
     xa, xb = by_bounds(a), by_bounds(b)
     for key in xa:
         assert np.array_equal(xa[key], xb[key]), key
+
+
+def test_disk_alpha_deck_driver_equals_oracle(double_lib, tmp_path):
+    """inputs/disk/disk_alpha.in (1-D axisymmetric alpha disk, gamma = 1.4, beta cooling with beta0 = 1e-8,
+    `viscous` conditions, mdot from the deck) for 300 cycles: driver == oracle bit for bit."""
+    from oracle.oracle import Oracle
+    spec = dict(deck=["disk", "disk_alpha.in"], cycles=300, overrides=["parthenon/time/nlim=300"])
+    r = run_world(1, spec, tmp_path, "da")[0]
+    assert r["meta"]["nblocks"] == 1 and not r["meta"]["fused"]
+    o = Oracle((128, 1, 1), (0.3, -3.141592653589793, -0.5), (4.3, 3.141592653589793, 0.5), ng=2, reconstruct="plm",
+               riemann="hllc", gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3, integrator="rk2",
+               coordinates="axisymmetric", bc=("viscous", "viscous") + ("periodic",) * 4)
+    o.set_gravity_point(mass=1.0)
+    o.set_viscosity("alpha", alpha=1e-2, r0=1.0, Omega0=1.0)
+    o.set_cooling(beta0=1e-8, tcyl=0.0025, cyl_plaw=-1.0)
+    o.pgen_disk(r0=1.0, dslope=-0.5, flare=0.0, h0=0.05, dens_min=1e-10, pres_min=1e-15, polytropic_index=1.0,
+                mdot=0.00023561944901923456)
+    d0 = o.interior(o.gprim)[0].copy()
+    o.evolve(628.0, 300)
+    assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
+    assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+    assert np.max(np.abs(o.interior(o.gprim)[0] / d0 - 1.0)) < 0.15  # relaxing towards the viscous steady state
