@@ -212,6 +212,10 @@ def load():
         "artemis_rt_event_sync": (i, [vp]),
         "artemis_rt_event_elapsed_ms": (d, [vp, vp]),
         "artemis_rt_tables_changed": (None, []),
+        "artemis_rt_capture_begin": (i, [vp]),
+        "artemis_rt_capture_end": (vp, [vp]),
+        "artemis_rt_graph_launch": (i, [vp, vp]),
+        "artemis_rt_graph_destroy": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the header and the library disagree

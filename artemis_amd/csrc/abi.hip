@@ -700,5 +700,23 @@ double artemis_rt_event_elapsed_ms(void *e0, void *e1) {
   return ms;
 }
 void artemis_rt_tables_changed(void) { artemis::invalidate_table_cache(); }
+int artemis_rt_capture_begin(void *stream) {
+  return check_hip(hipStreamBeginCapture(S(stream), hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+}
+void *artemis_rt_capture_end(void *stream) {
+  hipGraph_t g = nullptr;
+  if (check_hip(hipStreamEndCapture(S(stream), &g), "hipStreamEndCapture") || !g) return nullptr;
+  hipGraphExec_t e = nullptr;
+  const hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (check_hip(rc, "hipGraphInstantiate")) return nullptr;
+  return e;
+}
+int artemis_rt_graph_launch(void *graph_exec, void *stream) {
+  return check_hip(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), S(stream)), "hipGraphLaunch");
+}
+void artemis_rt_graph_destroy(void *graph_exec) {
+  if (graph_exec) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec));
+}
 
 } // extern "C"

@@ -1659,13 +1659,35 @@ long artemis_sim::evolve(long max_cycles) {
     for (int q = 0; q < nstages; ++q) h[3 + q] = beta[q] * dt;
     CK(artemis_rt_memcpy_h2d(tstate.p, h, sizeof h, stream), "h2d");
     CK(artemis_rt_stream_sync(stream), "sync");
+    // One time step is a fixed launch sequence here (dt lives on the device): capture it into a hipGraph
+    // after a few plain steps (which allocate the ping-pong buffers and scratch) and replay it, one
+    // graph per ping-pong phase.  Single rank, no overlap streams, no per-kernel timing.
+    bool graph_ok = !multi && !time_kernels && overlap == 0 && std::getenv("ARTEMIS_NO_GRAPH") == nullptr;
+    void *gexec[3] = {nullptr, nullptr, nullptr};
+    int gnext[3] = {0, 0, 0};
     for (; n < todo; ++n) {
+      const int key = base;
+      if (graph_ok && n >= 3 && gexec[key]) {
+        base = gnext[key], cons_valid = false;
+        CK(artemis_rt_graph_launch(gexec[key], stream), "graph launch");
+        ncycle++;
+        continue;
+      }
+      const bool capture = graph_ok && n >= 3 && artemis_rt_capture_begin(stream) == 0;
+      if (graph_ok && n >= 3 && !capture) graph_ok = false; // (the CPU stand-in has no graphs)
       step_fused(true, true);
       if (multi && comm.allreduce_min_dev(comm.ctx, tstate.p + 2, stream))
         throw std::runtime_error("allreduce_min_dev failed");
       CK(artemis_hip_advance_dt(tstate.p, tlim, nstages, beta, stream), "advance_dt");
+      if (capture) { // nothing has run yet: instantiate and launch what was recorded
+        gexec[key] = artemis_rt_capture_end(stream);
+        if (!gexec[key]) throw HipFail(std::string("graph capture failed: ") + artemis_hip_last_error());
+        gnext[key] = base;
+        CK(artemis_rt_graph_launch(gexec[key], stream), "graph launch");
+      }
       ncycle++;
     }
+    for (void *g : gexec) artemis_rt_graph_destroy(g);
     CK(artemis_rt_memcpy_d2h(h, tstate.p, sizeof h, stream), "d2h");
     CK(artemis_rt_stream_sync(stream), "sync");
     time = h[0], dt = h[1];

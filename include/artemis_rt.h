@@ -39,6 +39,14 @@ int artemis_rt_event_sync(void *ev);
 double artemis_rt_event_elapsed_ms(void *ev0, void *ev1);
 /* Kept for ABI stability: pointer tables are always read on the device, nothing is cached. */
 void artemis_rt_tables_changed(void);
+/* hipGraph capture of a launch sequence on a (non-default) stream: begin, issue the launches, end ->
+ * an instantiated executable graph (NULL on failure), replayed with _graph_launch.  The host driver
+ * captures one time step of its synchronisation-free loop, so small meshes are not bound by the
+ * launch rate. */
+int artemis_rt_capture_begin(void *stream);
+void *artemis_rt_capture_end(void *stream);
+int artemis_rt_graph_launch(void *graph_exec, void *stream);
+void artemis_rt_graph_destroy(void *graph_exec);
 
 #ifdef __cplusplus
 }

@@ -657,4 +657,8 @@ int artemis_rt_stream_wait_event(void *, void *) { return 0; }
 int artemis_rt_event_sync(void *) { return 0; }
 double artemis_rt_event_elapsed_ms(void *, void *) { return 0.0; }
 void artemis_rt_tables_changed(void) {}
+int artemis_rt_capture_begin(void *) { return 1; } // no graphs on the host stand-in: the driver falls back
+void *artemis_rt_capture_end(void *) { return nullptr; }
+int artemis_rt_graph_launch(void *, void *) { return 1; }
+void artemis_rt_graph_destroy(void *) {}
 }
