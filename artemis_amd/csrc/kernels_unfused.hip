@@ -477,14 +477,20 @@ __global__ __launch_bounds__(256) void bc_kernel(const BcArgs a, const FillTabs 
 // Gas species 0 and every dust species, like the reference's loops.
 struct StratBcArgs {
   int d, side, ng, st, en;
+  int both; // one launch fills the inner and the outer slab (disjoint zones, both read active zones only)
   double q, om0, x1f0, dx1;
 };
-__global__ __launch_bounds__(256) void strat_bc_kernel(const StratBcArgs a, const FillTabs t,
+__global__ __launch_bounds__(256) void strat_bc_kernel(const StratBcArgs a_in, const FillTabs t,
                                                        const double *geom, int ni, int nj, int nk) {
+  StratBcArgs a = a_in;
   int ext[3] = {ni, nj, nk};
   ext[a.d] = a.ng;
   const long ncell = static_cast<long>(ext[0]) * ext[1] * ext[2];
-  const long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (a.both) {
+    a.side = (tid >= ncell) ? 1 : 0;
+    tid -= a.side * ncell;
+  }
   if (tid >= ncell) return;
   int idx[3];
   idx[0] = tid % ext[0];
@@ -947,10 +953,13 @@ static void launch_bc_sequential(const PackView &P, int b, const int *bc6,
           a.ic_gas = par->ic_gas, a.ic_dust = par->ic_dust;
           hipLaunchKernelGGL(disk_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P);
         } else if (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW) {
+          const bool pair = (bc6[2 * d] == bc6[2 * d + 1]); // same condition on both faces: one launch
+          if (pair && side == 1) continue;
           StratBcArgs a;
-          a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
+          a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d], a.both = pair ? 1 : 0;
           a.q = par->qshear, a.om0 = par->omega, a.x1f0 = 0.0, a.dx1 = 0.0;
-          hipLaunchKernelGGL(strat_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P.geom,
+          const long nthr = pair ? 2 * ncell : ncell;
+          hipLaunchKernelGGL(strat_bc_kernel, dim3((nthr + 255) / 256), dim3(256), 0, s, a, t, P.geom,
                              P.ni, P.nj, P.nk);
         } else {
           BcArgs a;
