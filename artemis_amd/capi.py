@@ -172,6 +172,7 @@ def load():
         "artemis_hip_cooling_table_fill": (i, [PPk, vp, vp, C.POINTER(Cooling), i, vp, vp]),
         "artemis_hip_stage_fused": (i, [PPk, C.POINTER(StageArgs), vp]),
         "artemis_hip_stage_general": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
+        "artemis_hip_stage_epilogue": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
         "artemis_hip_zero_diffusion_flux": (i, [PPk, vp]),
         "artemis_hip_viscous_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
         "artemis_hip_thermal_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
@@ -231,7 +232,7 @@ EXPORTS_HIP = [
     "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_metric_count",
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_rotating_frame_force",
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",
-    "artemis_hip_stage_general", "artemis_hip_zero_diffusion_flux",
+    "artemis_hip_stage_general", "artemis_hip_stage_epilogue", "artemis_hip_zero_diffusion_flux",
     "artemis_hip_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
     "artemis_hip_diffusion_dt", "artemis_hip_diffusion_radial_fill", "artemis_hip_halo_count", "artemis_hip_halo_count_ext",
     "artemis_hip_halo_pack_ext", "artemis_hip_halo_unpack_ext",

@@ -615,6 +615,41 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
   return after_launch("stage_general");
 }
 
+int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");
+  if (a->drag) return fail(ARTEMIS_HIP_EUNSUPPORTED, "stage epilogue: drag couples the fluids; use the separate tasks");
+  const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
+  for (const artemis_fluid_pack_t *f : {&p->gas, &p->dust}) {
+    if (!f->nspecies) continue;
+    if (!f->prim || !f->cons0 || !f->cons1) return fail(ARTEMIS_HIP_EINVAL, "stage epilogue: prim / cons0 / cons1 tables are required");
+    for (int d = 0; d < ndim; ++d)
+      if (!f->flux[d] || (f == &p->gas && (!f->pflux[d] || !f->vface[d])))
+        return fail(ARTEMIS_HIP_EINVAL, "stage epilogue: flux / pflux / vface tables are required");
+  }
+  if (a->gravity) {
+    const artemis_gravity_t *g = a->gravity;
+    if (g->type != ARTEMIS_GRAVITY_UNIFORM && g->type != ARTEMIS_GRAVITY_POINT && g->type != ARTEMIS_GRAVITY_BINARY)
+      return fail(ARTEMIS_HIP_EUNSUPPORTED, "gravity type %d (nbody) is not built", g->type);
+    if (g->type == ARTEMIS_GRAVITY_BINARY &&
+        (p->coords == ARTEMIS_AXISYMMETRIC || p->coords == ARTEMIS_SPHERICAL1D || p->coords == ARTEMIS_SPHERICAL2D))
+      return fail(ARTEMIS_HIP_EINVAL, "Binary gravity is not compatable with axisymmetric coordinates!");
+    if (g->type != ARTEMIS_GRAVITY_UNIFORM && p->coords == ARTEMIS_CYLINDRICAL && !p->metric)
+      return fail(ARTEMIS_HIP_EINVAL, "point-mass gravity on cylindrical blocks needs the metric tables");
+  }
+  if (a->rf_omega != 0.0 && p->coords != ARTEMIS_CARTESIAN && a->rf_qshear != 0.0)
+    return fail(ARTEMIS_HIP_EINVAL, "rotating_frame/qshear must be zero for non-Cartesian coordinate systems!");
+  if (a->diffusion)
+    if (int rc = validate_diffusion(p, a->diffusion, true)) return rc;
+  if (a->cooling) {
+    if (p->gas.nspecies && (!a->cooling->tref || !a->cooling->beta))
+      return fail(ARTEMIS_HIP_EINVAL, "cooling: tref / beta tables are required (artemis_hip_cooling_table_fill)");
+    if (!(a->cooling->cv > 0.0)) return fail(ARTEMIS_HIP_EINVAL, "cooling: specific heat cv must be positive");
+  }
+  artemis::launch_stage_epilogue(artemis::make_pack_view(*p), *a, S(stream));
+  return after_launch("stage_epilogue");
+}
+
 int artemis_hip_advance_dt(double *state, double tlim, int nstages, const double *beta, void *stream) {
   if (int rc = device_ready()) return rc;
   if (!state || !beta || nstages < 1 || nstages > 3) return fail(ARTEMIS_HIP_EINVAL, "bad advance_dt arguments");

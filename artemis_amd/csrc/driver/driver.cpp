@@ -1605,20 +1605,34 @@ void artemis_sim::step_unfused() {
       if (do_viscosity) CK(artemis_hip_viscous_flux(&p, &diff, stream), "Gas::ViscousFlux");
       if (do_conduction) CK(artemis_hip_thermal_flux(&p, &diff, stream), "Gas::ThermalFlux");
     }
-    CK(artemis_hip_apply_update(&p, gam0[stage - 1], gam1[stage - 1], beta[stage - 1] * dt, stream), "ApplyUpdate");
-    if (do_gas) CK(artemis_hip_flux_source(&p, ARTEMIS_GAS, bdt, stream), "Gas::FluxSource");
-    if (do_dust) CK(artemis_hip_flux_source(&p, ARTEMIS_DUST, bdt, stream), "Dust::FluxSource");
-    if (do_viscosity || do_conduction) // artemis_driver.cpp:218-221
-      CK(artemis_hip_diffusion_update(&p, &diff, bdt, stream), "Gas::DiffusionUpdate");
-    // artemis_driver.cpp:222-241: gravity, rotating frame, drag, in this order, with the time at
-    // the start of the step (:167)
     place_binary();
-    if (do_gravity) CK(artemis_hip_external_gravity(&p, &grav, time, bdt, stream), "ExternalGravity");
-    if (do_rframe) CK(artemis_hip_rotating_frame_force(&p, rf_omega, rf_qshear, time, bdt, stream), "RotatingFrameForce");
-    if (do_drag) CK(artemis_hip_drag_source(&p, &drag, time, bdt, stream), "DragSource");
-    if (do_cooling && do_gas) CK(artemis_hip_cooling_source(&p, &cool, time, bdt, stream), "CoolingSource"); // :243-248
-    CK(artemis_hip_set_aux(&p, stream), "SetAuxillaryFields");
-    CK(artemis_hip_cons_to_prim(&p, stream), "ConsToPrim");
+    if (!do_drag && std::getenv("ARTEMIS_NO_EPILOGUE") == nullptr) {
+      // everything between the flux tasks and the boundary exchange is cell-local: one pass over the
+      // stored fluxes (ApplyUpdate ... ConsToPrim, artemis_driver.cpp:205-255) instead of eight
+      artemis_stage_general_args_t a;
+      std::memset(&a, 0, sizeof a);
+      a.gam0 = gam0[stage - 1], a.gam1 = gam1[stage - 1], a.beta_dt = beta[stage - 1] * dt, a.bdt = bdt;
+      a.time = time;
+      a.gravity = do_gravity ? &grav : nullptr;
+      a.rf_omega = do_rframe ? rf_omega : 0.0, a.rf_qshear = rf_qshear;
+      a.diffusion = (do_gas && (do_viscosity || do_conduction)) ? &diff : nullptr;
+      a.cooling = (do_cooling && do_gas) ? &cool : nullptr;
+      CK(artemis_hip_stage_epilogue(&p, &a, stream), "stage epilogue");
+    } else {
+      CK(artemis_hip_apply_update(&p, gam0[stage - 1], gam1[stage - 1], beta[stage - 1] * dt, stream), "ApplyUpdate");
+      if (do_gas) CK(artemis_hip_flux_source(&p, ARTEMIS_GAS, bdt, stream), "Gas::FluxSource");
+      if (do_dust) CK(artemis_hip_flux_source(&p, ARTEMIS_DUST, bdt, stream), "Dust::FluxSource");
+      if (do_viscosity || do_conduction) // artemis_driver.cpp:218-221
+        CK(artemis_hip_diffusion_update(&p, &diff, bdt, stream), "Gas::DiffusionUpdate");
+      // artemis_driver.cpp:222-241: gravity, rotating frame, drag, in this order, with the time at
+      // the start of the step (:167)
+      if (do_gravity) CK(artemis_hip_external_gravity(&p, &grav, time, bdt, stream), "ExternalGravity");
+      if (do_rframe) CK(artemis_hip_rotating_frame_force(&p, rf_omega, rf_qshear, time, bdt, stream), "RotatingFrameForce");
+      if (do_drag) CK(artemis_hip_drag_source(&p, &drag, time, bdt, stream), "DragSource");
+      if (do_cooling && do_gas) CK(artemis_hip_cooling_source(&p, &cool, time, bdt, stream), "CoolingSource"); // :243-248
+      CK(artemis_hip_set_aux(&p, stream), "SetAuxillaryFields");
+      CK(artemis_hip_cons_to_prim(&p, stream), "ConsToPrim");
+    }
     fill_ghosts(base);
     CK(artemis_hip_prim_to_cons(&p, stream), "PrimToCons");
   }

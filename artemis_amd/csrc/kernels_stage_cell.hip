@@ -160,7 +160,10 @@ ADEV DustCons prim_to_cons_dust(const FluidView &f, double d, double v1, double 
   return u;
 }
 
-template <int FLUID, int RIEMANN, int RECON, bool CURV, bool EXTRA>
+// STORED: the epilogue form -- face fluxes come from the flux / pressure-flux / face-velocity arrays a
+// preceding CalculateFluxes left in the pack, u0 / u1 from cons0 / cons1, and the new primitives are
+// written in place (nothing here reads a neighbour's primitives).
+template <int FLUID, int RIEMANN, int RECON, bool CURV, bool EXTRA, bool STORED = false>
 __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, const CellStageArgs a_in) {
   const int i = P.is + blockIdx.x * TX + threadIdx.x;
   const int j = P.js + blockIdx.y * TY + threadIdx.y;
@@ -210,6 +213,23 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
     w.rho = qd[c], w.v1 = q1[c], w.v2 = q2[c], w.v3 = q3[c], w.sie = (FLUID == 0) ? qe[c] : 0.0;
     for (int dir = 1; dir <= P.ndim; ++dir) {
       const long st = (dir == 1) ? 1 : ((dir == 2) ? P.sj : P.sk);
+      FaceFlux lo, up;
+      if constexpr (STORED) {
+        const int dd = dir - 1;
+        const long cu = c + st;
+        double *const *fx = f.flux[dd];
+        const int m0 = b * nv + ns + 3 * n;
+        lo.fd = fx[b * nv + n][c], up.fd = fx[b * nv + n][cu];
+        lo.fmx = fx[m0 + dd][c], up.fmx = fx[m0 + dd][cu];
+        lo.fmy = fx[m0 + (dd + 1) % 3][c], up.fmy = fx[m0 + (dd + 1) % 3][cu];
+        lo.fmz = fx[m0 + (dd + 2) % 3][c], up.fmz = fx[m0 + (dd + 2) % 3][cu];
+        if constexpr (FLUID == 0) {
+          lo.fe = fx[b * nv + 4 * ns + n][c], up.fe = fx[b * nv + 4 * ns + n][cu];
+          lo.feg = fx[b * nv + 5 * ns + n][c], up.feg = fx[b * nv + 5 * ns + n][cu];
+          lo.pf = f.pflux[dd][b * ns + n][c], up.pf = f.pflux[dd][b * ns + n][cu];
+          lo.vf = f.vface[dd][b * ns + n][c], up.vf = f.vface[dd][b * ns + n][cu];
+        }
+      } else {
       double wd[7], w1[7], w2[7], w3[7], wp[7], we[7];
       load_stencil<RECON>(qd, c, st, wd), load_stencil<RECON>(q1, c, st, w1);
       load_stencil<RECON>(q2, c, st, w2), load_stencil<RECON>(q3, c, st, w3);
@@ -219,7 +239,6 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
 #pragma unroll
         for (int m = -R; m <= R; ++m) wp[3 + m] = amax(0.0, P.gm1 * wd[3 + m] * we[3 + m]);
       }
-      FaceFlux lo, up;
       if constexpr (RECON == 1 && !CURV) {
         solve_pair_fast<FLUID, RIEMANN>(P, dir - 1, wd, w1, w2, w3, wp, we, lo, up);
       } else {
@@ -227,6 +246,7 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
                                                        wp, we);
         up = face_of_cell<FLUID, RIEMANN, RECON, CURV>(P, f, a.in, b, n, dir, 1, k, j, i, wd, w1, w2, w3,
                                                        wp, we);
+      }
       }
       const double *ax = (dir == 1) ? g.ax1 : ((dir == 2) ? g.ax2 : g.ax3);
       const int d = dir - 1;
@@ -261,8 +281,17 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
     const double *r2 = a.u1[b * nv + ns + 3 * n + 1], *r3 = a.u1[b * nv + ns + 3 * n + 2];
     if constexpr (FLUID == 0) {
       const double *re = a.u1[b * nv + 5 * ns + n];
-      GasCons u0 = prim_to_cons_gas(f, w.rho, w.v1, w.v2, w.v3, w.sie, hx);
-      const GasCons u1 = prim_to_cons_gas(f, rd[c], r1[c], r2[c], r3[c], re[c], hx);
+      GasCons u0, u1;
+      if constexpr (STORED) {
+        auto ld = [&](double *const *t, GasCons &u) {
+          u.d = t[b * nv + n][c], u.m1 = t[b * nv + ns + 3 * n + 0][c], u.m2 = t[b * nv + ns + 3 * n + 1][c];
+          u.m3 = t[b * nv + ns + 3 * n + 2][c], u.e = t[b * nv + 4 * ns + n][c], u.eg = t[b * nv + 5 * ns + n][c];
+        };
+        ld(f.cons0, u0), ld(f.cons1, u1);
+      } else {
+        u0 = prim_to_cons_gas(f, w.rho, w.v1, w.v2, w.v3, w.sie, hx);
+        u1 = prim_to_cons_gas(f, rd[c], r1[c], r2[c], r3[c], re[c], hx);
+      }
       u0.d = a.gam0 * u0.d + a.gam1 * u1.d + divf[0] * a.beta_dt / g.vol;
       u0.m1 = a.gam0 * u0.m1 + a.gam1 * u1.m1 + divf[1] * a.beta_dt / g.vol;
       u0.m2 = a.gam0 * u0.m2 + a.gam1 * u1.m2 + divf[2] * a.beta_dt / g.vol;
@@ -338,8 +367,17 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
       const double w_s = u_u / w_d;
       a.out[b * nv + 5 * ns + n][c] = (w_s > f.siefloor) ? w_s : f.siefloor;
     } else {
-      DustCons u0 = prim_to_cons_dust(f, w.rho, w.v1, w.v2, w.v3, hx);
-      const DustCons u1 = prim_to_cons_dust(f, rd[c], r1[c], r2[c], r3[c], hx);
+      DustCons u0, u1;
+      if constexpr (STORED) {
+        auto ld = [&](double *const *t, DustCons &u) {
+          u.d = t[b * nv + n][c], u.m1 = t[b * nv + ns + 3 * n + 0][c], u.m2 = t[b * nv + ns + 3 * n + 1][c];
+          u.m3 = t[b * nv + ns + 3 * n + 2][c];
+        };
+        ld(f.cons0, u0), ld(f.cons1, u1);
+      } else {
+        u0 = prim_to_cons_dust(f, w.rho, w.v1, w.v2, w.v3, hx);
+        u1 = prim_to_cons_dust(f, rd[c], r1[c], r2[c], r3[c], hx);
+      }
       u0.d = a.gam0 * u0.d + a.gam1 * u1.d + divf[0] * a.beta_dt / g.vol;
       u0.m1 = a.gam0 * u0.m1 + a.gam1 * u1.m1 + divf[1] * a.beta_dt / g.vol;
       u0.m2 = a.gam0 * u0.m2 + a.gam1 * u1.m2 + divf[2] * a.beta_dt / g.vol;
@@ -397,6 +435,34 @@ void launch_recon(const PackView &P, int recon, const CellStageArgs &a, hipStrea
   else launch_geom<FLUID, RIEMANN, 2>(P, a, s);
 }
 } // namespace
+
+// The cell-local remainder of a stage over stored fluxes (see STORED above): one kernel per fluid
+void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t &g, hipStream_t s) {
+  CellStageArgs a;
+  a.gam0 = g.gam0, a.gam1 = g.gam1, a.beta_dt = g.beta_dt, a.bdt = g.bdt;
+  a.bdt_ptr = g.beta_dt_dev;
+  a.to_cons = 0;
+  a.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;
+  if (a.grav_on) a.grav = *g.gravity;
+  const bool cart = (P.coords == ARTEMIS_CARTESIAN);
+  a.rf_on = (g.rf_omega != 0.0) && cart, a.rf_omega = g.rf_omega, a.rf_qshear = g.rf_qshear;
+  a.rfc_on = (g.rf_omega != 0.0) && !cart;
+  a.diff_on = (g.diffusion != nullptr) && P.gas.ns > 0;
+  a.do_viscosity = (g.diffusion && g.diffusion->visc.type != ARTEMIS_DIFF_OFF) ? 1 : 0;
+  a.cool_on = (g.cooling != nullptr) && P.gas.ns > 0;
+  if (a.cool_on) a.cool = *g.cooling;
+  const dim3 grid((P.ie - P.is + TX) / TX, (P.je - P.js + TY) / TY, (P.ke - P.ks + 1) * P.nb);
+  if (P.gas.ns) {
+    a.in = a.u1 = a.out = P.gas.prim;
+    if (cart) hipLaunchKernelGGL((stage_cell_kernel<0, 0, 0, false, true, true>), grid, dim3(TX, TY), 0, s, P, a);
+    else hipLaunchKernelGGL((stage_cell_kernel<0, 0, 0, true, true, true>), grid, dim3(TX, TY), 0, s, P, a);
+  }
+  if (P.dust.ns) {
+    a.in = a.u1 = a.out = P.dust.prim;
+    if (cart) hipLaunchKernelGGL((stage_cell_kernel<1, 1, 0, false, true, true>), grid, dim3(TX, TY), 0, s, P, a);
+    else hipLaunchKernelGGL((stage_cell_kernel<1, 1, 0, true, true, true>), grid, dim3(TX, TY), 0, s, P, a);
+  }
+}
 
 void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
                        int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s) {

@@ -199,6 +199,21 @@ class MeshBlockPack:
             a.cooling = C.pointer(cooling)
         self._call(self.L.artemis_hip_stage_general, C.byref(a))
 
+    def stage_epilogue(self, gam0, gam1, beta_dt, bdt, time=0.0, gravity=None, rotating_frame=None,
+                       diffusion=None, cooling=None):
+        """artemis_hip_stage_epilogue: ApplyUpdate ... ConsToPrim in one pass over the stored fluxes."""
+        a = capi.StageGeneralArgs()
+        a.gam0, a.gam1, a.beta_dt, a.bdt, a.time = gam0, gam1, beta_dt, bdt, time
+        if gravity is not None:
+            a.gravity = C.pointer(gravity)
+        if rotating_frame is not None:
+            a.rf_omega, a.rf_qshear = rotating_frame
+        if diffusion is not None:
+            a.diffusion = C.pointer(diffusion)
+        if cooling is not None:
+            a.cooling = C.pointer(cooling)
+        self._call(self.L.artemis_hip_stage_epilogue, C.byref(a))
+
     # ---- gas diffusion (artemis_driver.cpp:189-193, :218-221) -----------------------------------
     def ZeroDiffusionFlux(self):
         self._call(self.L.artemis_hip_zero_diffusion_flux)

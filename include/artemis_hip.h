@@ -400,6 +400,15 @@ typedef struct artemis_stage_general_args {
 } artemis_stage_general_args_t;
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
                               void *stream);
+/* The cell-local remainder of a stage in ONE pass over stored fluxes: after Gas/Dust::CalculateFluxes
+ * (and the diffusion-flux tasks) have filled flux / pflux / vface (/ diff_flux) for p's primitives,
+ * this does ApplyUpdate on cons0 / cons1, FluxSource, DiffusionUpdate, ExternalGravity,
+ * RotatingFrameForce, CoolingSource, SetAuxillaryFields and ConsToPrim (artemis_driver.cpp:205-255) and
+ * writes the new primitives of the active zones in place.  Same argument struct (gam*, beta_dt, bdt,
+ * time, gravity, rf_*, diffusion, cooling, beta_dt_dev; the prim tables and dt fields are ignored).
+ * cons0 is NOT updated: the PrimToCons that follows the boundary conditions rebuilds it.  Drag couples
+ * the fluids and is not part of it: ARTEMIS_HIP_EUNSUPPORTED, use the separate tasks. */
+int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream);
 
 /* Device-side SetGlobalTimeStep (parthenon EvolutionDriver, upstream): state = DEVICE
  * {time, dt, dt_est, beta_dt[0..2]}.  time += dt; dt = min(2*dt, dt_est), clipped so that

@@ -426,6 +426,45 @@ static void dflux_io(Bound &B, const artemis_pack_t *p, bool out) {
     else B.in(B.s->qflux[d], p->gas.diff_flux[d], 4 * B.s->c.ns_gas);
   }
 }
+// the cell-local remainder of a stage over the stored fluxes, through the oracle's tasks
+int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *) {
+  if (a->drag) return bad("stage epilogue: drag is not part of it");
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    Sim &s = *B.s;
+    B.load_state(), B.load_fluxes();
+    apply_update(s, a->gam0, a->gam1, a->beta_dt);
+    flux_source(s, FL_GAS, a->bdt), flux_source(s, FL_DUST, a->bdt);
+    if (a->diffusion) {
+      dflux_io(B, p, false), set_diffusion(s, a->diffusion);
+      diffusion_update(s, a->bdt);
+    }
+    if (a->gravity) {
+      const artemis_gravity_t *g = a->gravity;
+      s.grav.type = g->type, s.grav.gm = g->gm, s.grav.soft = g->soft, s.grav.sink = g->sink;
+      s.grav.sink_rate = g->sink_rate, s.grav.tstart = g->tstart, s.grav.tstop = g->tstop;
+      for (int d = 0; d < 3; ++d) s.grav.g[d] = g->g[d], s.grav.pos[d] = g->pos[d], s.grav.pos2[d] = g->pos2[d];
+      s.grav.q = g->q, s.grav.soft2 = g->soft2, s.grav.sink2 = g->sink2, s.grav.sink_rate2 = g->sink_rate2;
+      s.grav.given_pos = true;
+      external_gravity(s, a->time, a->bdt);
+    }
+    if (a->rf_omega != 0.0) {
+      s.rframe.on = true, s.rframe.omega = a->rf_omega, s.rframe.qshear = a->rf_qshear;
+      rotating_frame_force(s, a->bdt);
+    }
+    if (a->cooling) {
+      const int gtype = s.grav.type;
+      set_cooling(s, a->cooling);
+      cooling_source(s, a->time, a->bdt);
+      s.grav.type = gtype;
+    }
+    set_aux(s);
+    cons_to_prim(s);
+    B.out(s.gprim, p->gas.prim, s.nvg), B.out(s.dprim, p->dust.prim, s.nvd);
+    B.out(s.gu0, p->gas.cons0, s.nvg), B.out(s.du0, p->dust.cons0, s.nvd);
+  }
+  return 0;
+}
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a_in, void *) {
   artemis_stage_general_args_t args = *a_in;
   if (args.beta_dt_dev) args.beta_dt = args.bdt = *args.beta_dt_dev; // "device" memory is host memory here
