@@ -98,6 +98,9 @@ def main():
                     help="sedov3d = the headline metric (BASELINE configs[1]); ssheet_dust = SURVEY config 3 "
                          "(2-D dusty shearing sheet with drag, general fused stage; --n is the mesh edge, 1 GPU)")
     ap.add_argument("--dust", type=int, default=1, help="ssheet_dust: number of dust species")
+    ap.add_argument("--uniform", action="store_true",
+                    help="sedov3d diagnostic (SURVEY 8d): the same deck with an empty blast region, i.e. a uniform gas at "
+                         "rest -- same kernels, no shocks -- to separate branch-divergence effects from the rest")
     ap.add_argument("--cpu-n", type=int, default=256)
     ap.add_argument("--cpu-cycles", type=int, default=3)
     args = ap.parse_args()
@@ -146,6 +149,8 @@ def main():
         extra = []
         if args.blocks_per_gpu > 1:
             extra = ["parthenon/meshblock/nx3=%d" % (args.n // args.blocks_per_gpu)]
+        if args.uniform:
+            extra = extra + ["problem/radius=0.0"]
         sim = Simulation(deck, overrides(args.gpus, per_gpu, args.warmup + args.steps, extra), comm=comm)
     if args.path == "unfused":
         sim.set_path("unfused")
@@ -186,7 +191,7 @@ def main():
             "config": {
                 "workload": "inputs/blast 3-D Sedov (BASELINE configs[1]): Cartesian %d^3 cells/GPU, "
                             "gas HLLC+PLM, rk2, cfl 0.3, gamma 1.4, outflow, nghost 2, radius 0.03, "
-                            "samples 0" % args.n,
+                            "samples 0%s" % (args.n, " -- UNIFORM-STATE diagnostic (radius 0)" if args.uniform else ""),
                 "cells_per_gpu": local_zones, "path": "fused" if fused else "unfused",
                 "decomposition": "%d rank(s), one %d^3 mesh block each, face-slab halo exchange%s"
                                  % (args.gpus, args.n, "" if world == 1 else
