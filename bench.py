@@ -94,9 +94,11 @@ def main():
                     help="diagnostic: cut each rank's 256^3 into this many mesh blocks along x3")
     ap.add_argument("--loopback", action="store_true",
                     help="diagnostic: route block-to-block slabs of ONE GPU through RCCL send/recv-to-self")
-    ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "ssheet_dust"],
+    ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "ssheet_dust", "disk_sph"],
                     help="sedov3d = the headline metric (BASELINE configs[1]); ssheet_dust = SURVEY config 3 "
-                         "(2-D dusty shearing sheet with drag, general fused stage; --n is the mesh edge, 1 GPU)")
+                         "(2-D dusty shearing sheet with drag, general fused stage; --n is the mesh edge, 1 GPU); "
+                         "disk_sph = BASELINE configs[3] without refinement (inputs/disk/disk_sph.in, spherical-polar "
+                         "alpha disk; --n scales the 128x64x64 deck mesh by n/128, 1 GPU)")
     ap.add_argument("--dust", type=int, default=1, help="ssheet_dust: number of dust species")
     ap.add_argument("--uniform", action="store_true",
                     help="sedov3d diagnostic (SURVEY 8d): the same deck with an empty blast region, i.e. a uniform gas at "
@@ -143,6 +145,16 @@ def main():
               "dust/dfloor=1.0e-10", "dust/stopping_time/type=constant",
               "dust/stopping_time/tau=" + ",".join(["0.1"] * args.dust), "drag/type=simple_dust",
               "parthenon/time/tlim=-1.0", "parthenon/time/nlim=%d" % (args.warmup + args.steps)]
+        sim = Simulation(deck, ov)
+    elif args.workload == "disk_sph":
+        if args.gpus != 1:
+            raise SystemExit("--workload disk_sph is a single-GPU measurement")
+        deck = os.path.join(ROOT, "inputs", "disk", "disk_sph.in")
+        sc = max(1, args.n // 128)
+        dims = (128 * sc, 64 * sc, 64 * sc)
+        ov = ["parthenon/time/nlim=%d" % (args.warmup + args.steps)]
+        for d, m in enumerate(dims, 1):
+            ov += ["parthenon/mesh/nx%d=%d" % (d, m), "parthenon/meshblock/nx%d=%d" % (d, m)]
         sim = Simulation(deck, ov)
     else:
         deck = os.path.join(ROOT, "inputs", "blast", "blast.in")
@@ -200,6 +212,20 @@ def main():
                 "total_energy_check": float(hist[4]),
             },
         }
+        if args.workload == "disk_sph":
+            out["metric"] = "cell-updates/sec (zone-cycles/s), spherical-polar alpha disk"
+            out["config"]["workload"] = ("BASELINE configs[3] without mesh refinement: inputs/disk/disk_sph.in scaled to "
+                                         "%d x %d x %d, gas, point-mass gravity, alpha viscosity, rotating frame, ic "
+                                         "conditions, HLLE + PLM_G, rk2" % dims)
+            out["config"]["decomposition"] = "1 rank, one mesh block"
+            # whole-stage accounting (several kernels per stage): algorithmic bytes of SURVEY 8(d) over the stage time
+            alg = ALG_BYTES_PER_CELL_STAGE * local_zones
+            stage_ms = 1.0e3 * elapsed / args.steps / 2.0
+            out["roofline"] = {"bound": "hbm", "achieved": alg / (stage_ms * 1.0e-3) / 1.0e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": alg / (stage_ms * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "whole stage: 3 flux kernels + viscous pre-pass + 3 viscous-flux kernels + epilogue + "
+                                         "boundary conditions + PrimToCons",
+                               "launch_ms": stage_ms, "launches_timed": 2 * args.steps, "algorithmic_bytes_per_launch": alg}
         if args.workload == "ssheet_dust":
             # B_alg per cell-stage = 8 B * 5 * (6 ns_gas + 4 ns_dust); one "launch" = one stage
             # of the general fused path (gas kernel + dust kernel + drag/aux/c2p finish)
@@ -238,7 +264,9 @@ def main():
                                "kernel": "stage_fused_kernel<hllc,plm>", "launch_ms": kms,
                                "launches_timed": nlaunch,
                                "algorithmic_bytes_per_launch": alg}
-        if args.workload == "ssheet_dust" and not args.no_cpu_baseline:
+        if args.workload == "disk_sph":
+            pass  # (CPU side: tests/test_oracle_pins.py times the oracle on the same deck: ~20 s for 10 cycles of 128x64x64)
+        elif args.workload == "ssheet_dust" and not args.no_cpu_baseline:
             v, secs, cyc, cn = cpu_baseline_ssheet(min(args.n, 512), args.dust, args.cpu_cycles)
             out["cpu_baseline"] = {
                 "value": v, "unit": "zone-cycles/s", "cores": os.cpu_count(), "kind": "port",
