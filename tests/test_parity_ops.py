@@ -2,6 +2,8 @@
 inputs.  fp64 with -ffp-contract=off on both sides, IEEE-correct division and sqrt: the bar
 is BIT-EXACT (np.array_equal), which is stricter than the L-infinity 1e-12 relative tolerance
 BASELINE.md asks for."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -17,6 +19,9 @@ def random_state(o, rng, mach=2.0, contrast=1.0e3, shock=True):
     clamps, dq2 <= 0 limiter zeros) is taken somewhere."""
     ns = o.cfg.ns_gas
     shp = (o.nk, o.nj, o.ni)
+    shift = int(os.environ.get("ARTEMIS_SEED_SHIFT", "0"))  # sweep other random states: advance the stream
+    if shift:
+        rng.random(shift)
     if ns:
         p = o.gprim
         for n in range(ns):
