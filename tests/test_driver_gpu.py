@@ -868,3 +868,60 @@ def test_stratified_box_3d_against_oracle(hiplib):
     I = np.s_[:, f.ks:f.ke + 1, f.js:f.je + 1, f.is_:f.ie + 1]
     assert np.array_equal(f.field("gas.prim")[I][[0, 1, 2, 3, 5]], u.field("gas.prim")[I][[0, 1, 2, 3, 5]])
     disk_close(f.interior(f.field("gas.prim")), o.interior(o.gprim), 1e-11)
+
+
+def test_sedov_full_size_properties(hiplib):
+    """The headline configuration at its full size (BASELINE configs[1]: 256^3 cells on one GPU, HLLC + PLM,
+    rk2, tuned fused kernel), where the oracle is too slow to be the checker: size-independent
+    properties instead.  Mass and total energy conserved to round-off (the blast has not reached
+    the outflow faces), density and internal energy positive and finite, the solution mirror
+    symmetric about the three coordinate planes to round-off, and the fused kernel bit-identical
+    to the per-task chain over three cycles at this size."""
+    from artemis_amd.driver import Simulation
+    big = ["parthenon/mesh/nx1=256", "parthenon/mesh/nx2=256", "parthenon/mesh/nx3=256", "parthenon/mesh/x3min=-1.0",
+           "parthenon/mesh/x3max=1.0", "parthenon/meshblock/nx1=256", "parthenon/meshblock/nx2=256",
+           "parthenon/meshblock/nx3=256", "gas/riemann=hllc", "problem/symmetry=spherical", "problem/radius=0.03",
+           "problem/samples=0"]
+    f = Simulation(DECK("blast", "blast.in"), big + ["parthenon/time/nlim=40"])
+    assert f.uses_fused_path and f.uses_tuned_kernel and f.nblocks == 1
+    h0 = f.history()
+    f.evolve()
+    h1 = f.history()
+    assert f.ncycle == 40
+    assert abs(h1[0] - h0[0]) < 1e-11 * h0[0] and abs(h1[4] - h0[4]) < 1e-11 * h0[4]  # mass, total energy (sums over 1.7e7 zones)
+    assert np.max(np.abs(h1[1:4])) < 1e-11 * h0[4]                                     # no net momentum
+    P = f.interior(f.field("gas.prim"))
+    rho, sie = P[0], P[5]
+    assert np.isfinite(P[[0, 1, 2, 3, 5]]).all() and rho.min() > 0.0 and sie.min() > 0.0
+    assert rho.max() > 1.5 and rho.min() < 0.9  # a shell has formed around an evacuated centre
+    for ax in range(3):
+        assert np.max(np.abs(rho - np.flip(rho, axis=ax))) < 1e-11 * rho.max(), ax
+        v = P[3 - ax]  # the velocity component along this axis is odd
+        assert np.max(np.abs(v + np.flip(v, axis=ax))) < 1e-11 * np.abs(P[1:4]).max(), ax
+    del P, rho, sie
+    a = Simulation(DECK("blast", "blast.in"), big + ["parthenon/time/nlim=3"])
+    u = Simulation(DECK("blast", "blast.in"), big + ["parthenon/time/nlim=3"])
+    u.set_path("unfused")
+    a.evolve(), u.evolve()
+    assert a.time == u.time and a.dt == u.dt
+    assert np.array_equal(a.interior(a.field("gas.prim"))[[0, 1, 2, 3, 5]], u.interior(u.field("gas.prim"))[[0, 1, 2, 3, 5]])
+
+
+def test_dusty_sheet_full_size_paths_agree(hiplib):
+    """SURVEY config 3 at its full size (strat problem, 1024^2, gas + 2 dust species, simple_dust drag,
+    shearing box, point-mass gravity, extrap / inflow conditions): the general fused stage and the
+    per-task chain give the same bits over 6 cycles; densities stay positive and finite."""
+    from artemis_amd.driver import Simulation
+    ov = ["parthenon/mesh/nx1=1024", "parthenon/mesh/nx2=1024", "parthenon/meshblock/nx1=1024",
+          "parthenon/meshblock/nx2=1024", "physics/dust=true", "physics/drag=true", "dust/nspecies=2", "dust/cfl=0.3",
+          "dust/reconstruct=plm", "dust/riemann=hlle", "dust/dfloor=1.0e-10", "dust/stopping_time/type=constant",
+          "dust/stopping_time/tau=0.1, 1.0", "drag/type=simple_dust", "parthenon/time/nlim=6"]
+    f, u = Simulation(DECK("ssheet", "ssheet.in"), ov), Simulation(DECK("ssheet", "ssheet.in"), ov)
+    u.set_path("unfused")
+    assert f.uses_fused_path and not f.uses_tuned_kernel and not u.uses_fused_path
+    f.evolve(), u.evolve()
+    assert f.ncycle == u.ncycle == 6 and f.time == u.time and f.dt == u.dt
+    g, d = f.interior(f.field("gas.prim")), f.interior(f.field("dust.prim"))
+    assert np.array_equal(g[[0, 1, 2, 3, 5]], u.interior(u.field("gas.prim"))[[0, 1, 2, 3, 5]])
+    assert np.array_equal(d, u.interior(u.field("dust.prim")))
+    assert np.isfinite(g[[0, 1, 2, 3, 5]]).all() and np.isfinite(d).all() and g[0].min() > 0 and d[:2].min() > 0
