@@ -40,9 +40,7 @@ inline dim3 grid_for(const Range3 &r, int nb) {
 // the cell above it straight from global memory (neighbouring threads share those lines in
 // L1/L2), then solves the Riemann problem and writes the 8 (gas) / 4 (dust) face outputs.
 template <int FLUID, int RIEMANN, int RECON, bool CURV>
-__global__ __launch_bounds__(TX *TY) void flux_kernel(const PackView P, const Range3 r,
-                                                      const int dir) {
-  CELL_FROM_GRID(r)
+__device__ __forceinline__ void flux_face(const PackView &P, int b, int k, int j, int i, long c, const int dir) {
   PlmGeo gl{}, gr{};
   double hs[3] = {1.0, 1.0, 1.0}; // ScaleMomentumFlux factors (fluid_fluxes.hpp:33-70)
   if constexpr (CURV) {
@@ -110,20 +108,27 @@ __global__ __launch_bounds__(TX *TY) void flux_kernel(const PackView P, const Ra
   }
 }
 
+// One launch for every active direction: the thread of cell (k,j,i) solves the lower x1, x2 and x3 faces
+// it stores (the face of direction d exists where the other two indices are active), so the centre
+// stencil values are fetched once and stay in L1 for the three sweeps.
+template <int FLUID, int RIEMANN, int RECON, bool CURV>
+__global__ __launch_bounds__(TX *TY) void flux_kernel(const PackView P, const Range3 r) {
+  CELL_FROM_GRID(r)
+  for (int dir = 1; dir <= P.ndim; ++dir) {
+    const bool has = (dir == 1) ? (j <= P.je && k <= P.ke)
+                                : ((dir == 2) ? (i <= P.ie && k <= P.ke) : (i <= P.ie && j <= P.je));
+    if (has) flux_face<FLUID, RIEMANN, RECON, CURV>(P, b, k, j, i, c, dir);
+  }
+}
+
 template <int FLUID, int RIEMANN, int RECON>
 void launch_flux_dirs(const PackView &P, hipStream_t s) {
-  for (int dir = 1; dir <= P.ndim; ++dir) {
-    Range3 r{P.is, P.ie, P.js, P.je, P.ks, P.ke};
-    if (dir == 1) r.iu = P.ie + 1; // fluid_fluxes.hpp:105
-    if (dir == 2) r.ju = P.je + 1; // :130 (faces js..je+1)
-    if (dir == 3) r.ku = P.ke + 1; // :172
-    if (P.coords == ARTEMIS_CARTESIAN)
-      hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, false>), grid_for(r, P.nb),
-                         dim3(TX, TY), 0, s, P, r, dir);
-    else
-      hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, true>), grid_for(r, P.nb),
-                         dim3(TX, TY), 0, s, P, r, dir);
-  }
+  // faces [s, e+1] of each active direction (fluid_fluxes.hpp:105, :130, :172): the union of the three ranges
+  Range3 r{P.is, P.ie + 1, P.js, P.je + (P.ndim > 1 ? 1 : 0), P.ks, P.ke + (P.ndim > 2 ? 1 : 0)};
+  if (P.coords == ARTEMIS_CARTESIAN)
+    hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, false>), grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
+  else
+    hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, true>), grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
 }
 template <int FLUID, int RIEMANN>
 void launch_flux_recon(const PackView &P, int recon, hipStream_t s) {
