@@ -65,3 +65,32 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower().replace("cpu oracle (oracle/makefile", ""), \
                     f"{os.path.join(dp, f)} mentions the oracle"
+
+
+def test_ctypes_mirror_matches_the_c_header(tmp_path):
+    """The ctypes structures of artemis_amd/capi.py against the C compiler's view of include/artemis_hip.h:
+    same size for every struct that crosses the boundary and the same offset for the last member
+    (a missing or mistyped field in the middle shifts it)."""
+    import subprocess
+    from artemis_amd import capi
+    pairs = [("artemis_fluid_pack_t", capi.FluidPack, None), ("artemis_pack_t", capi.Pack, "omega_frame"),
+             ("artemis_bc_params_t", capi.BcParams, "floor_ghosts"), ("artemis_gravity_t", capi.Gravity, "pos2"),
+             ("artemis_damping_t", capi.Damping, None), ("artemis_drag_t", capi.Drag, None),
+             ("artemis_cooling_t", capi.Cooling, "beta"), ("artemis_diffcoeff_t", capi.DiffCoeff, "radial"),
+             ("artemis_diffusion_t", capi.Diffusion, "cv"), ("artemis_stage_args_t", capi.StageArgs, None),
+             ("artemis_stage_general_args_t", capi.StageGeneralArgs, "cooling")]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "artemis_hip.h"', 'int main(void) {']
+    for cname, _, last in pairs:
+        src.append(f'  printf("{cname} %zu %zu\\n", sizeof({cname}), '
+                   + (f'offsetof({cname}, {last}));' if last else '(size_t)0);'))
+    src += ['  return 0;', '}']
+    c = tmp_path / "sizes.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    seen = {ln.split()[0]: (int(ln.split()[1]), int(ln.split()[2])) for ln in out if ln.strip()}
+    for cname, ct, last in pairs:
+        assert seen[cname][0] == C.sizeof(ct), (cname, seen[cname][0], C.sizeof(ct))
+        if last:
+            assert seen[cname][1] == getattr(ct, last).offset, (cname, last)
