@@ -24,6 +24,10 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/ but not exported"
     assert set(capi.EXPORTS_HIP) <= set(names)
+    sim = _declared("artemis_driver.h")  # the host driver's own ABI lives in the same library
+    assert len(sim) > 10
+    for n in sim:
+        assert hasattr(L, n), f"{n} declared in include/artemis_driver.h but not exported"
 
 
 def test_no_gpu_fails_loudly_and_validation():
