@@ -225,8 +225,10 @@ int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_
 
 /* RotatingFrame::RotatingFrameForce (rotating_frame/rotating_frame.cpp:56-86).  Cartesian:
  * ShearingBoxImpl (rotating_frame_impl.hpp:28-93), tidal potential differenced across the cell
- * plus the Coriolis force, gas and dust.  Curvilinear flux form (:95-199):
- * ARTEMIS_HIP_EUNSUPPORTED. */
+ * plus the Coriolis force, gas and dust.  Every other system: RotatingFrameImpl<GEOM> (:95-199), the
+ * angular-momentum-conserving source from the mass fluxes CalculateFluxes left in flux[d] (qshear must
+ * be 0, rotating_frame.cpp:34-38); the centrifugal / Coriolis terms of the other two momenta enter
+ * through p->omega_frame in artemis_hip_flux_source. */
 int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, double qshear,
                                      double time, double dt, void *stream);
 
