@@ -875,8 +875,8 @@ def test_sedov_full_size_properties(hiplib):
     rk2, tuned fused kernel), where the oracle is too slow to be the checker: size-independent
     properties instead.  Mass and total energy conserved to round-off (the blast has not reached
     the outflow faces), density and internal energy positive and finite, the solution mirror
-    symmetric about the three coordinate planes to round-off, and the fused kernel bit-identical
-    to the per-task chain over three cycles at this size."""
+    symmetric about the three coordinate planes to round-off, the shock at the Sedov-Taylor radius at
+    t = 0.1 (3411 cycles), and the fused kernel bit-identical to the per-task chain over three cycles."""
     from artemis_amd.driver import Simulation
     big = ["parthenon/mesh/nx1=256", "parthenon/mesh/nx2=256", "parthenon/mesh/nx3=256", "parthenon/mesh/x3min=-1.0",
            "parthenon/mesh/x3max=1.0", "parthenon/meshblock/nx1=256", "parthenon/meshblock/nx2=256",
@@ -899,6 +899,17 @@ def test_sedov_full_size_properties(hiplib):
         v = P[3 - ax]  # the velocity component along this axis is odd
         assert np.max(np.abs(v + np.flip(v, axis=ax))) < 1e-11 * np.abs(P[1:4]).max(), ax
     del P, rho, sie
+    # ... and on to t = 0.1 (3411 cycles, 7 s): the shock sits at the Sedov-Taylor radius
+    # xi0 (E t^2 / rho0)^(1/5), xi0 = 1.033 for gamma = 1.4, E = the deposited energy, to one and a half zones
+    g = Simulation(DECK("blast", "blast.in"), big + ["parthenon/time/tlim=0.1"])
+    g0 = g.history()
+    g.evolve()
+    g1 = g.history()
+    assert abs(g.time - 0.1) < 1e-14 and abs(g1[4] - g0[4]) < 1e-10 * g0[4] and abs(g1[0] - g0[0]) < 1e-11 * g0[0]
+    line = g.interior(g.field("gas.prim"))[4, 128, 128, 128:]
+    r_shock = (np.argmax(line) + 0.5) / 128.0
+    assert abs(r_shock - 1.033 * (g0[4] * 0.1 ** 2) ** 0.2) < 1.5 / 128.0, r_shock
+    g.close()
     a = Simulation(DECK("blast", "blast.in"), big + ["parthenon/time/nlim=3"])
     u = Simulation(DECK("blast", "blast.in"), big + ["parthenon/time/nlim=3"])
     u.set_path("unfused")
