@@ -122,6 +122,16 @@ class Diffusion(C.Structure):
     _fields_ = [("visc", DiffCoeff), ("cond", DiffCoeff), ("cv", C.c_double)]
 
 
+class Refine(C.Structure):
+    _fields_ = [("coords", C.c_int), ("ndim", C.c_int), ("nvar", C.c_int),
+                ("fni", C.c_int), ("fnj", C.c_int), ("fnk", C.c_int), ("cni", C.c_int), ("cnj", C.c_int),
+                ("cnk", C.c_int), ("fgeom", C.c_void_p), ("fmetric", C.c_void_p), ("cgeom", C.c_void_p),
+                ("cmetric", C.c_void_p), ("fine", C.c_void_p), ("coarse", C.c_void_p),
+                ("cis", C.c_int), ("cie", C.c_int), ("cjs", C.c_int), ("cje", C.c_int), ("cks", C.c_int),
+                ("cke", C.c_int), ("cib", C.c_int), ("cjb", C.c_int), ("ckb", C.c_int), ("fib", C.c_int),
+                ("fjb", C.c_int), ("fkb", C.c_int)]
+
+
 class StageGeneralArgs(C.Structure):
     _fields_ = [
         ("gam0", C.c_double), ("gam1", C.c_double), ("beta_dt", C.c_double), ("bdt", C.c_double),
@@ -173,6 +183,8 @@ def load():
         "artemis_hip_stage_fused": (i, [PPk, C.POINTER(StageArgs), vp]),
         "artemis_hip_stage_general": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
         "artemis_hip_stage_epilogue": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
+        "artemis_hip_restrict_average": (i, [C.POINTER(Refine), vp]),
+        "artemis_hip_prolongate_minmod": (i, [C.POINTER(Refine), vp]),
         "artemis_hip_zero_diffusion_flux": (i, [PPk, vp]),
         "artemis_hip_viscous_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
         "artemis_hip_thermal_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
@@ -232,7 +244,8 @@ EXPORTS_HIP = [
     "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_metric_count",
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_rotating_frame_force",
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",
-    "artemis_hip_stage_general", "artemis_hip_stage_epilogue", "artemis_hip_zero_diffusion_flux",
+    "artemis_hip_stage_general", "artemis_hip_stage_epilogue", "artemis_hip_restrict_average",
+    "artemis_hip_prolongate_minmod", "artemis_hip_zero_diffusion_flux",
     "artemis_hip_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
     "artemis_hip_diffusion_dt", "artemis_hip_diffusion_radial_fill", "artemis_hip_halo_count", "artemis_hip_halo_count_ext",
     "artemis_hip_halo_pack_ext", "artemis_hip_halo_unpack_ext",

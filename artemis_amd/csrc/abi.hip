@@ -650,6 +650,37 @@ int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_gene
   return after_launch("stage_epilogue");
 }
 
+static int validate_refine(const artemis_refine_t *r, bool prolongate) {
+  if (!r) return fail(ARTEMIS_HIP_EINVAL, "null refinement descriptor");
+  if (r->coords < ARTEMIS_CARTESIAN || r->coords > ARTEMIS_AXISYMMETRIC) return fail(ARTEMIS_HIP_EINVAL, "Coordinate type not recognized!");
+  if (r->ndim < 1 || r->ndim > 3 || r->nvar < 1) return fail(ARTEMIS_HIP_EINVAL, "bad ndim / nvar");
+  if (!r->fgeom || !r->cgeom || !r->fine || !r->coarse) return fail(ARTEMIS_HIP_EINVAL, "null table");
+  if ((r->coords == ARTEMIS_SPHERICAL2D || r->coords == ARTEMIS_SPHERICAL3D) && (!r->fmetric || !r->cmetric))
+    return fail(ARTEMIS_HIP_EINVAL, "spherical 2-D/3-D needs the metric tables of both index spaces");
+  const int g = prolongate ? 1 : 0; // prolongation reads the coarse neighbours
+  const int clo[3] = {r->cis, r->cjs, r->cks}, chi[3] = {r->cie, r->cje, r->cke}, cn[3] = {r->cni, r->cnj, r->cnk};
+  const int cb[3] = {r->cib, r->cjb, r->ckb}, fb[3] = {r->fib, r->fjb, r->fkb}, fn[3] = {r->fni, r->fnj, r->fnk};
+  for (int d = 0; d < 3; ++d) {
+    const int act = d < r->ndim;
+    if (clo[d] > chi[d] || clo[d] - g * act < 0 || chi[d] + g * act >= cn[d])
+      return fail(ARTEMIS_HIP_EINVAL, "coarse range out of bounds in direction %d", d + 1);
+    const int f0 = act ? (clo[d] - cb[d]) * 2 + fb[d] : fb[d], f1 = act ? (chi[d] - cb[d]) * 2 + fb[d] + 1 : fb[d];
+    if (f0 < 0 || f1 >= fn[d]) return fail(ARTEMIS_HIP_EINVAL, "fine range out of bounds in direction %d", d + 1);
+    if (!act && clo[d] != chi[d]) return fail(ARTEMIS_HIP_EINVAL, "inactive direction %d must be one zone", d + 1);
+  }
+  return device_ready();
+}
+int artemis_hip_restrict_average(const artemis_refine_t *r, void *stream) {
+  if (int rc = validate_refine(r, false)) return rc;
+  artemis::launch_refine(*r, 0, S(stream));
+  return after_launch("RestrictAverage");
+}
+int artemis_hip_prolongate_minmod(const artemis_refine_t *r, void *stream) {
+  if (int rc = validate_refine(r, true)) return rc;
+  artemis::launch_refine(*r, 1, S(stream));
+  return after_launch("ProlongateSharedMinMod");
+}
+
 int artemis_hip_advance_dt(double *state, double tlim, int nstages, const double *beta, void *stream) {
   if (int rc = device_ready()) return rc;
   if (!state || !beta || nstages < 1 || nstages > 3) return fail(ARTEMIS_HIP_EINVAL, "bad advance_dt arguments");

@@ -1,0 +1,117 @@
+// Mesh-refinement data-path operators of the reference (utils/refinement): RestrictAverage<GEOM>
+// (restriction.hpp:42-114, volume-weighted mean of the 2^ndim fine zones of a coarse zone, pairwise
+// summation order kept) and ProlongateSharedMinMod<GEOM> (prolongation.hpp:39-184, one minmod-limited
+// gradient per direction from the coarse neighbours, evaluated at the fine centroids).  One thread per
+// coarse zone; cell-centred fields; every coordinate system through the same DCoords as the hydro path.
+#include "device_math.hpp"
+#include "geometry_core.hpp"
+#include "kernels.hpp"
+
+namespace artemis {
+namespace {
+
+struct RefineView {
+  artemis_refine_t r;
+  long fN, cN;
+};
+ADEV DCoords fine_coords(const artemis_refine_t &r, int k, int j, int i) {
+  return coords_of(r.coords, r.fgeom, r.fmetric, r.fnj, r.fnk, k, j, i);
+}
+ADEV DCoords coarse_coords(const artemis_refine_t &r, int k, int j, int i) {
+  return coords_of(r.coords, r.cgeom, r.cmetric, r.cnj, r.cnk, k, j, i);
+}
+ADEV double centre_of(const DCoords &co, int d) { return d == 1 ? co.x1v() : (d == 2 ? co.x2v() : co.x3v()); }
+
+#define COARSE_CELL                                                                         \
+  const artemis_refine_t &r = R.r;                                                          \
+  const int nci = r.cie - r.cis + 1, ncj = r.cje - r.cjs + 1, nck = r.cke - r.cks + 1;      \
+  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;                  \
+  if (t >= static_cast<long>(nci) * ncj * nck) return;                                      \
+  const int ci = r.cis + static_cast<int>(t % nci), cj = r.cjs + static_cast<int>((t / nci) % ncj); \
+  const int ck = r.cks + static_cast<int>(t / (static_cast<long>(nci) * ncj));              \
+  const bool X1 = r.ndim > 0, X2 = r.ndim > 1, X3 = r.ndim > 2;                             \
+  const int fi = X1 ? (ci - r.cib) * 2 + r.fib : r.fib;                                     \
+  const int fj = X2 ? (cj - r.cjb) * 2 + r.fjb : r.fjb;                                     \
+  const int fk = X3 ? (ck - r.ckb) * 2 + r.fkb : r.fkb;                                     \
+  auto fidx = [&](int k, int j, int i) { return (static_cast<long>(k) * r.fnj + j) * r.fni + i; }; \
+  auto cidx = [&](int k, int j, int i) { return (static_cast<long>(k) * r.cnj + j) * r.cni + i; };
+
+__global__ __launch_bounds__(256) void restrict_kernel(const RefineView R) {
+  COARSE_CELL
+  double vol[2][2][2];
+  for (int ok = 0; ok < 2; ++ok)
+    for (int oj = 0; oj < 2; ++oj)
+      for (int oi = 0; oi < 2; ++oi) vol[ok][oj][oi] = 0;
+  for (int ok = 0; ok < 1 + X3; ++ok)
+    for (int oj = 0; oj < 1 + X2; ++oj)
+      for (int oi = 0; oi < 1 + X1; ++oi) vol[ok][oj][oi] = fine_coords(r, fk + ok, fj + oj, fi + oi).volume();
+  const double tvol = ((vol[0][0][0] + vol[0][1][0]) + (vol[0][0][1] + vol[0][1][1])) +
+                      ((vol[1][0][0] + vol[1][1][0]) + (vol[1][0][1] + vol[1][1][1]));
+  for (int v = 0; v < r.nvar; ++v) {
+    const double *q = r.fine[v];
+    double terms[2][2][2];
+    for (int ok = 0; ok < 2; ++ok)
+      for (int oj = 0; oj < 2; ++oj)
+        for (int oi = 0; oi < 2; ++oi) terms[ok][oj][oi] = 0;
+    for (int ok = 0; ok < 1 + X3; ++ok)
+      for (int oj = 0; oj < 1 + X2; ++oj)
+        for (int oi = 0; oi < 1 + X1; ++oi)
+          terms[ok][oj][oi] = vol[ok][oj][oi] * q[fidx(fk + ok, fj + oj, fi + oi)];
+    r.coarse[v][cidx(ck, cj, ci)] =
+        (((terms[0][0][0] + terms[0][1][0]) + (terms[0][0][1] + terms[0][1][1])) +
+         ((terms[1][0][0] + terms[1][1][0]) + (terms[1][0][1] + terms[1][1][1]))) /
+        tvol;
+  }
+}
+
+__global__ __launch_bounds__(256) void prolongate_kernel(const RefineView R) {
+  COARSE_CELL
+  // GetGridSpacings<GEOM, d> (prolongation.hpp:39-68): geometry only, shared by the variables
+  double dxm[3] = {1, 1, 1}, dxp[3] = {1, 1, 1}, dxfm[3] = {0, 0, 0}, dxfp[3] = {0, 0, 0};
+  for (int d = 1; d <= r.ndim; ++d) {
+    const int dk = (d == 3), dj = (d == 2), di = (d == 1);
+    const double xm = centre_of(coarse_coords(r, ck - dk, cj - dj, ci - di), d);
+    const double xc = centre_of(coarse_coords(r, ck, cj, ci), d);
+    const double xp = centre_of(coarse_coords(r, ck + dk, cj + dj, ci + di), d);
+    const double fxm = centre_of(fine_coords(r, fk, fj, fi), d);
+    const double fxp = centre_of(fine_coords(r, fk + dk, fj + dj, fi + di), d);
+    dxm[d - 1] = xc - xm, dxp[d - 1] = xp - xc, dxfm[d - 1] = xc - fxm, dxfp[d - 1] = fxp - xc;
+  }
+  for (int v = 0; v < r.nvar; ++v) {
+    const double *q = r.coarse[v];
+    const double fc = q[cidx(ck, cj, ci)];
+    double g[3] = {0, 0, 0};
+    for (int d = 1; d <= r.ndim; ++d) { // GradMinMod (:73-80); SIGN(a) = (a < 0) ? -1 : 1 (parthenon, upstream)
+      const int dk = (d == 3), dj = (d == 2), di = (d == 1);
+      const double gxm = (fc - q[cidx(ck - dk, cj - dj, ci - di)]) / dxm[d - 1];
+      const double gxp = (q[cidx(ck + dk, cj + dj, ci + di)] - fc) / dxp[d - 1];
+      const double sm = (gxm < 0.) ? -1. : 1., sp = (gxp < 0.) ? -1. : 1.;
+      const double am = fabs(gxm), ap = fabs(gxp);
+      g[d - 1] = 0.5 * (sm + sp) * ((ap < am) ? ap : am); // std::min(|gxm|, |gxp|)
+    }
+    const double gx1m = g[0], gx1p = g[0], gx2m = g[1], gx2p = g[1], gx3m = g[2], gx3p = g[2];
+    const double dx1fm = dxfm[0], dx1fp = dxfp[0], dx2fm = dxfm[1], dx2fp = dxfp[1], dx3fm = dxfm[2], dx3fp = dxfp[2];
+    double *o = r.fine[v];
+    o[fidx(fk, fj, fi)] = fc - (gx1m * dx1fm + gx2m * dx2fm + gx3m * dx3fm);
+    if (X1) o[fidx(fk, fj, fi + 1)] = fc + (gx1p * dx1fp - gx2m * dx2fm - gx3m * dx3fm);
+    if (X2) o[fidx(fk, fj + 1, fi)] = fc - (gx1m * dx1fm - gx2p * dx2fp + gx3m * dx3fm);
+    if (X2 && X1) o[fidx(fk, fj + 1, fi + 1)] = fc + (gx1p * dx1fp + gx2p * dx2fp - gx3m * dx3fm);
+    if (X3) o[fidx(fk + 1, fj, fi)] = fc - (gx1m * dx1fm + gx2m * dx2fm - gx3p * dx3fp);
+    if (X3 && X1) o[fidx(fk + 1, fj, fi + 1)] = fc + (gx1p * dx1fp - gx2m * dx2fm + gx3p * dx3fp);
+    if (X3 && X2) o[fidx(fk + 1, fj + 1, fi)] = fc - (gx1m * dx1fm - gx2p * dx2fp - gx3p * dx3fp);
+    if (X3 && X2 && X1) o[fidx(fk + 1, fj + 1, fi + 1)] = fc + (gx1p * dx1fp + gx2p * dx2fp + gx3p * dx3fp);
+  }
+}
+} // namespace
+
+void launch_refine(const artemis_refine_t &r, int prolongate, hipStream_t s) {
+  RefineView R;
+  R.r = r;
+  R.fN = static_cast<long>(r.fni) * r.fnj * r.fnk, R.cN = static_cast<long>(r.cni) * r.cnj * r.cnk;
+  const long n = static_cast<long>(r.cie - r.cis + 1) * (r.cje - r.cjs + 1) * (r.cke - r.cks + 1);
+  if (n <= 0) return;
+  if (prolongate) hipLaunchKernelGGL(prolongate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, R);
+  else hipLaunchKernelGGL(restrict_kernel, dim3((n + 255) / 256), dim3(256), 0, s, R);
+}
+
+} // namespace artemis

@@ -412,6 +412,27 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
  * the fluids and is not part of it: ARTEMIS_HIP_EUNSUPPORTED, use the separate tasks. */
 int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream);
 
+/* ---- mesh-refinement data-path operators (the operators only) ---------------
+ * ArtemisUtils::RestrictAverage<GEOM> (utils/refinement/restriction.hpp:42-114) and
+ * ArtemisUtils::ProlongateSharedMinMod<GEOM> (utils/refinement/prolongation.hpp:83-184), the custom
+ * refinement ops Artemis registers for its cell-centred fields, between a fine and a coarse array of one
+ * block.  fgeom / cgeom = DEVICE edge tables {x1f0, dx1, x2f0, dx2, x3f0, dx3} of the fine / coarse index
+ * space, fmetric / cmetric their metric tables (artemis_hip_metric_fill, NULL where not needed); fine /
+ * coarse = DEVICE tables of nvar arrays.  Coarse zones [cis..cie] x [cjs..cje] x [cks..cke] are processed;
+ * coarse index c?b coincides with fine index f?b (the reference's cib.s <-> ib.s).  Prolongation reads the
+ * coarse neighbours at +-1 in every active direction.  The refinement framework around the operators
+ * (block tree, flux correction, load balancing) is not built. */
+typedef struct artemis_refine {
+  int coords, ndim, nvar;
+  int fni, fnj, fnk, cni, cnj, cnk;      /* array extents incl. ghosts */
+  const double *fgeom, *fmetric, *cgeom, *cmetric;
+  double *const *fine, *const *coarse;
+  int cis, cie, cjs, cje, cks, cke;
+  int cib, cjb, ckb, fib, fjb, fkb;
+} artemis_refine_t;
+int artemis_hip_restrict_average(const artemis_refine_t *r, void *stream);
+int artemis_hip_prolongate_minmod(const artemis_refine_t *r, void *stream);
+
 /* Device-side SetGlobalTimeStep (parthenon EvolutionDriver, upstream): state = DEVICE
  * {time, dt, dt_est, beta_dt[0..2]}.  time += dt; dt = min(2*dt, dt_est), clipped so that
  * time + dt <= tlim (tlim <= 0: no limit); dt_est = DBL_MAX for the next cycle's reduction;

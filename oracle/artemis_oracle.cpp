@@ -2873,6 +2873,83 @@ void oracle_set_gravity_window(void *h, double tstart, double tstop) {
   Sim &s = *static_cast<Sim *>(h);
   s.grav.tstart = tstart, s.grav.tstop = tstop;
 }
+// ---------------------------------------------------------------------------------------
+// utils/refinement/restriction.hpp:42-114 RestrictAverage<GEOM> and prolongation.hpp:39-184
+// ProlongateSharedMinMod<GEOM> for cell-centred fields, between the gas primitives of a fine Sim and
+// a coarse Sim (the operators only; the mesh-refinement framework around them is out of scope).
+// r = {cis, cie, cjs, cje, cks, cke,  cib, cjb, ckb,  fib, fjb, fkb}: coarse cells processed and the
+// coarse <-> fine origin (the reference's cib.s <-> ib.s).  SIGN(a) = (a < 0) ? -1 : 1 (parthenon
+// defs.hpp, upstream, recalled).  Parity unpinned: no reference test isolates these operators.
+void oracle_restrict_average(void *hf, void *hc, const int *r) {
+  Sim &f = *static_cast<Sim *>(hf), &c = *static_cast<Sim *>(hc);
+  const int DIM = f.ndim;
+  const bool X1 = DIM > 0, X2 = DIM > 1, X3 = DIM > 2;
+  for (int v = 0; v < f.nvg; ++v)
+    for (int ck = r[4]; ck <= r[5]; ++ck)
+      for (int cj = r[2]; cj <= r[3]; ++cj)
+        for (int ci = r[0]; ci <= r[1]; ++ci) {
+          const int i = X1 ? (ci - r[6]) * 2 + r[9] : r[9];
+          const int j = X2 ? (cj - r[7]) * 2 + r[10] : r[10];
+          const int k = X3 ? (ck - r[8]) * 2 + r[11] : r[11];
+          Real vol[2][2][2], terms[2][2][2];
+          for (int ok = 0; ok < 2; ++ok)
+            for (int oj = 0; oj < 2; ++oj)
+              for (int oi = 0; oi < 2; ++oi) vol[ok][oj][oi] = terms[ok][oj][oi] = 0;
+          for (int ok = 0; ok < 1 + X3; ++ok)
+            for (int oj = 0; oj < 1 + X2; ++oj)
+              for (int oi = 0; oi < 1 + X1; ++oi) {
+                vol[ok][oj][oi] = Coords(f, k + ok, j + oj, i + oi).Volume();
+                terms[ok][oj][oi] = vol[ok][oj][oi] * f.gprim[v * f.N + IDX(f, k + ok, j + oj, i + oi)];
+              }
+          const Real tvol = ((vol[0][0][0] + vol[0][1][0]) + (vol[0][0][1] + vol[0][1][1])) +
+                            ((vol[1][0][0] + vol[1][1][0]) + (vol[1][0][1] + vol[1][1][1]));
+          c.gprim[v * c.N + IDX(c, ck, cj, ci)] =
+              (((terms[0][0][0] + terms[0][1][0]) + (terms[0][0][1] + terms[0][1][1])) +
+               ((terms[1][0][0] + terms[1][1][0]) + (terms[1][0][1] + terms[1][1][1]))) /
+              tvol;
+        }
+}
+void oracle_prolongate_minmod(void *hf, void *hc, const int *r) {
+  Sim &f = *static_cast<Sim *>(hf), &c = *static_cast<Sim *>(hc);
+  const int DIM = f.ndim;
+  const bool X1 = DIM > 0, X2 = DIM > 1, X3 = DIM > 2;
+  auto sign = [](Real a) { return (a < 0.) ? -1. : 1.; };
+  auto centre = [](const Coords &co, int d) { return d == 1 ? co.x1v() : (d == 2 ? co.x2v() : co.x3v()); };
+  for (int v = 0; v < f.nvg; ++v)
+    for (int k = r[4]; k <= r[5]; ++k)
+      for (int j = r[2]; j <= r[3]; ++j)
+        for (int i = r[0]; i <= r[1]; ++i) {
+          const int fi = X1 ? (i - r[6]) * 2 + r[9] : r[9];
+          const int fj = X2 ? (j - r[7]) * 2 + r[10] : r[10];
+          const int fk = X3 ? (k - r[8]) * 2 + r[11] : r[11];
+          const Real *q = c.gprim.data() + v * c.N;
+          const Real fc = q[IDX(c, k, j, i)];
+          Real dxfm[3] = {0, 0, 0}, dxfp[3] = {0, 0, 0}, g[3] = {0, 0, 0};
+          for (int d = 1; d <= DIM; ++d) { // GetGridSpacings<GEOM, d> + GradMinMod
+            const int dk = (d == 3), dj = (d == 2), di = (d == 1);
+            const Real xm = centre(Coords(c, k - dk, j - dj, i - di), d), xc = centre(Coords(c, k, j, i), d);
+            const Real xp = centre(Coords(c, k + dk, j + dj, i + di), d);
+            const Real fxm = centre(Coords(f, fk, fj, fi), d), fxp = centre(Coords(f, fk + dk, fj + dj, fi + di), d);
+            const Real dxm = xc - xm, dxp = xp - xc;
+            dxfm[d - 1] = xc - fxm, dxfp[d - 1] = fxp - xc;
+            const Real gxm = (fc - q[IDX(c, k - dk, j - dj, i - di)]) / dxm;
+            const Real gxp = (q[IDX(c, k + dk, j + dj, i + di)] - fc) / dxp;
+            g[d - 1] = 0.5 * (sign(gxm) + sign(gxp)) * std::min(std::abs(gxm), std::abs(gxp));
+          }
+          const Real gx1m = g[0], gx1p = g[0], gx2m = g[1], gx2p = g[1], gx3m = g[2], gx3p = g[2];
+          const Real dx1fm = dxfm[0], dx1fp = dxfp[0], dx2fm = dxfm[1], dx2fp = dxfp[1], dx3fm = dxfm[2], dx3fp = dxfp[2];
+          Real *o = f.gprim.data() + v * f.N;
+          o[IDX(f, fk, fj, fi)] = fc - (gx1m * dx1fm + gx2m * dx2fm + gx3m * dx3fm);
+          if (X1) o[IDX(f, fk, fj, fi + 1)] = fc + (gx1p * dx1fp - gx2m * dx2fm - gx3m * dx3fm);
+          if (X2) o[IDX(f, fk, fj + 1, fi)] = fc - (gx1m * dx1fm - gx2p * dx2fp + gx3m * dx3fm);
+          if (X2 && X1) o[IDX(f, fk, fj + 1, fi + 1)] = fc + (gx1p * dx1fp + gx2p * dx2fp - gx3m * dx3fm);
+          if (X3) o[IDX(f, fk + 1, fj, fi)] = fc - (gx1m * dx1fm + gx2m * dx2fm - gx3p * dx3fp);
+          if (X3 && X1) o[IDX(f, fk + 1, fj, fi + 1)] = fc + (gx1p * dx1fp - gx2m * dx2fm + gx3p * dx3fp);
+          if (X3 && X2) o[IDX(f, fk + 1, fj + 1, fi)] = fc - (gx1m * dx1fm - gx2p * dx2fp - gx3p * dx3fp);
+          if (X3 && X2 && X1) o[IDX(f, fk + 1, fj + 1, fi + 1)] = fc + (gx1p * dx1fp + gx2p * dx2fp + gx3p * dx3fp);
+        }
+}
+
 // <cooling> type = beta, tref = powerlaw (cooling.cpp:34-63)
 void oracle_set_cooling(void *h, const double *p) {
   Sim &s = *static_cast<Sim *>(h);

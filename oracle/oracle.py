@@ -128,6 +128,8 @@ def lib():
         L.oracle_qflux.argtypes = [vp, i]
         L.oracle_pgen_gaussian_bump.argtypes = [vp, C.POINTER(d)] + [d] * 11
         L.oracle_pgen_conduction.argtypes = [vp] + [d] * 6
+        L.oracle_restrict_average.argtypes = [vp, vp, C.POINTER(i)]
+        L.oracle_prolongate_minmod.argtypes = [vp, vp, C.POINTER(i)]
         L.oracle_set_cooling.argtypes = [vp, C.POINTER(d)]
         L.oracle_cooling_source.argtypes = [vp, d, d]
         L.oracle_pgen_disk.argtypes = [vp, C.POINTER(d)]
@@ -341,6 +343,14 @@ class Oracle:
         self.L.oracle_pgen_conduction(self.h, gas_rho, *gas_v, gas_temp, flux)
         if post_init:
             self.post_init()
+
+    def RestrictAverage(self, coarse, crange, corigin, forigin):
+        """RestrictAverage<GEOM> of this (fine) oracle's gas primitives onto `coarse`'s: crange = (cis, cie,
+        cjs, cje, cks, cke), corigin / forigin = the coarse / fine indices that coincide (cib.s <-> ib.s)."""
+        self.L.oracle_restrict_average(self.h, coarse.h, (C.c_int * 12)(*crange, *corigin, *forigin))
+
+    def ProlongateSharedMinMod(self, coarse, crange, corigin, forigin):
+        self.L.oracle_prolongate_minmod(self.h, coarse.h, (C.c_int * 12)(*crange, *corigin, *forigin))
 
     def set_cooling(self, beta0, beta_min=1e-12, exp_scale=0.0, tfloor=0.0, tcyl=0.0, cyl_plaw=0.0, tsph=0.0,
                     sph_plaw=0.0):

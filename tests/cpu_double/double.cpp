@@ -676,6 +676,9 @@ int artemis_hip_selftest_divsqrt(long, const double *, const double *, double *,
 }
 
 // ---- runtime shim on host memory ----------------------------------------------------------
+// the refinement operators are exercised against the oracle on the GPU only; the host stand-in has no use for them
+int artemis_hip_restrict_average(const artemis_refine_t *, void *) { return bad("refinement operators: GPU library only"); }
+int artemis_hip_prolongate_minmod(const artemis_refine_t *, void *) { return bad("refinement operators: GPU library only"); }
 int artemis_rt_set_device(int) { return 0; }
 void *artemis_rt_malloc(size_t n) { return std::calloc(1, n ? n : 8); }
 void artemis_rt_free(void *p) { std::free(p); }
