@@ -132,6 +132,13 @@ class Refine(C.Structure):
                 ("fjb", C.c_int), ("fkb", C.c_int)]
 
 
+class AmrCriterion(C.Structure):
+    _fields_ = [("coords", C.c_int), ("ndim", C.c_int), ("ni", C.c_int), ("nj", C.c_int), ("nk", C.c_int),
+                ("geom", C.c_void_p), ("metric", C.c_void_p), ("field", C.c_void_p),
+                ("is_", C.c_int), ("ie", C.c_int), ("js", C.c_int), ("je", C.c_int), ("ks", C.c_int),
+                ("ke", C.c_int), ("refine_thr", C.c_double), ("deref_thr", C.c_double), ("scratch", C.c_void_p)]
+
+
 class StageGeneralArgs(C.Structure):
     _fields_ = [
         ("gam0", C.c_double), ("gam1", C.c_double), ("beta_dt", C.c_double), ("bdt", C.c_double),
@@ -185,6 +192,8 @@ def load():
         "artemis_hip_stage_epilogue": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
         "artemis_hip_restrict_average": (i, [C.POINTER(Refine), vp]),
         "artemis_hip_prolongate_minmod": (i, [C.POINTER(Refine), vp]),
+        "artemis_hip_amr_first_derivative": (i, [C.POINTER(AmrCriterion), C.POINTER(C.c_int), C.POINTER(C.c_double), vp]),
+        "artemis_hip_amr_magnitude": (i, [C.POINTER(AmrCriterion), C.POINTER(C.c_int), C.POINTER(C.c_double), vp]),
         "artemis_hip_zero_diffusion_flux": (i, [PPk, vp]),
         "artemis_hip_viscous_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
         "artemis_hip_thermal_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
@@ -245,7 +254,8 @@ EXPORTS_HIP = [
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_rotating_frame_force",
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",
     "artemis_hip_stage_general", "artemis_hip_stage_epilogue", "artemis_hip_restrict_average",
-    "artemis_hip_prolongate_minmod", "artemis_hip_zero_diffusion_flux",
+    "artemis_hip_prolongate_minmod", "artemis_hip_amr_first_derivative", "artemis_hip_amr_magnitude",
+    "artemis_hip_zero_diffusion_flux",
     "artemis_hip_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
     "artemis_hip_diffusion_dt", "artemis_hip_diffusion_radial_fill", "artemis_hip_halo_count", "artemis_hip_halo_count_ext",
     "artemis_hip_halo_pack_ext", "artemis_hip_halo_unpack_ext",

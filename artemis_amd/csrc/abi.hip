@@ -681,6 +681,41 @@ int artemis_hip_prolongate_minmod(const artemis_refine_t *r, void *stream) {
   return after_launch("ProlongateSharedMinMod");
 }
 
+
+static int amr_criterion(const artemis_amr_criterion_t *a, int magnitude, int *tag, double *maxval, void *stream) {
+  if (!a || !tag) return fail(ARTEMIS_HIP_EINVAL, "null refinement criterion / tag");
+  if (a->coords < ARTEMIS_CARTESIAN || a->coords > ARTEMIS_AXISYMMETRIC) return fail(ARTEMIS_HIP_EINVAL, "Coordinate type not recognized!");
+  if (a->ndim < 1 || a->ndim > 3) return fail(ARTEMIS_HIP_EINVAL, "bad ndim");
+  if (!a->geom || !a->field || !a->scratch) return fail(ARTEMIS_HIP_EINVAL, "null table");
+  if ((a->coords == ARTEMIS_SPHERICAL2D || a->coords == ARTEMIS_SPHERICAL3D) && !a->metric && !magnitude)
+    return fail(ARTEMIS_HIP_EINVAL, "spherical 2-D/3-D needs the metric table");
+  *tag = 0;
+  if (maxval) *maxval = 0.0;
+  if (!magnitude && a->ndim == 1) return ARTEMIS_HIP_OK; // amr_criteria.hpp:122-124: AmrTag::same
+  const int lo[3] = {a->is, a->js, a->ks}, hi[3] = {a->ie, a->je, a->ke}, n[3] = {a->ni, a->nj, a->nk};
+  for (int d = 0; d < 3; ++d) {
+    const int g = (!magnitude && d < a->ndim) ? 2 : 0; // the derivative of the grown range reads +-2
+    if (lo[d] > hi[d] || lo[d] - g < 0 || hi[d] + g >= n[d])
+      return fail(ARTEMIS_HIP_EINVAL, "refinement criterion: range out of bounds in direction %d", d + 1);
+  }
+  if (int rc = device_ready()) return rc;
+  artemis::launch_amr_criterion(*a, magnitude, S(stream));
+  double m = 0.0;
+  if (hipMemcpyAsync(&m, a->scratch, sizeof(double), hipMemcpyDeviceToHost, S(stream)) != hipSuccess ||
+      hipStreamSynchronize(S(stream)) != hipSuccess)
+    return fail(ARTEMIS_HIP_EDEVICE, "refinement criterion: %s", hipGetErrorString(hipGetLastError()));
+  if (maxval) *maxval = m;
+  if (magnitude) *tag = (m > a->refine_thr) ? 1 : ((m < a->deref_thr) ? -1 : 0);       // :164-166
+  else *tag = (m > a->refine_thr) ? 1 : ((m < 0.25 * a->refine_thr) ? -1 : 0);          // :126-130
+  return after_launch(magnitude ? "ScalarMagnitude" : "ScalarFirstDerivative");
+}
+int artemis_hip_amr_first_derivative(const artemis_amr_criterion_t *a, int *tag, double *maxval, void *stream) {
+  return amr_criterion(a, 0, tag, maxval, stream);
+}
+int artemis_hip_amr_magnitude(const artemis_amr_criterion_t *a, int *tag, double *maxval, void *stream) {
+  return amr_criterion(a, 1, tag, maxval, stream);
+}
+
 int artemis_hip_advance_dt(double *state, double tlim, int nstages, const double *beta, void *stream) {
   if (int rc = device_ready()) return rc;
   if (!state || !beta || nstages < 1 || nstages > 3) return fail(ARTEMIS_HIP_EINVAL, "bad advance_dt arguments");

@@ -102,6 +102,69 @@ __global__ __launch_bounds__(256) void prolongate_kernel(const RefineView R) {
     if (X3 && X2 && X1) o[fidx(fk + 1, fj + 1, fi + 1)] = fc + (gx1p * dx1fp + gx2p * dx2fp + gx3p * dx3fp);
   }
 }
+
+// ---- refinement criteria (amr_criteria.hpp:28-168): one thread per zone, wave maximum, one atomic ----
+// std::max(l, eps) = (l < eps) ? eps : l drops a NaN eps; so does the comparison below.  The values are
+// non-negative (or dropped), so the IEEE bit pattern orders like an unsigned integer.
+struct CriterionView {
+  artemis_amr_criterion_t a;
+};
+ADEV void block_max(double m, double *out) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const double other = __shfl_down(m, o, 64);
+    m = (m < other) ? other : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m > 0.0)
+    atomicMax(reinterpret_cast<unsigned long long *>(out), static_cast<unsigned long long>(__double_as_longlong(m)));
+}
+__global__ __launch_bounds__(256) void first_derivative_kernel(const CriterionView C) {
+  const artemis_amr_criterion_t &a = C.a;
+  const bool X3 = a.ndim > 2;
+  const int i0 = a.is - 1, j0 = a.js - 1, k0 = X3 ? a.ks - 1 : a.ks;
+  const int ni = a.ie - a.is + 3, nj = a.je - a.js + 3, nk = X3 ? a.ke - a.ks + 3 : 1;
+  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  double eps = 0.0;
+  if (t < static_cast<long>(ni) * nj * nk) {
+    const int i = i0 + static_cast<int>(t % ni), j = j0 + static_cast<int>((t / ni) % nj);
+    const int k = k0 + static_cast<int>(t / (static_cast<long>(ni) * nj));
+    auto co = [&](int kk, int jj, int ii) { return coords_of(a.coords, a.geom, a.metric, a.nj, a.nk, kk, jj, ii); };
+    auto v = [&](int kk, int jj, int ii) { return a.field[(static_cast<long>(kk) * a.nj + jj) * a.ni + ii]; };
+    const double sdx1 = co(k, j, i + 1).x1v() - co(k, j, i - 1).x1v();
+    const double sdx2 = co(k, j + 1, i).x2v() - co(k, j - 1, i).x2v();
+    const DCoords c = co(k, j, i);
+    const double hx1 = 1.0, hx2 = c.hx2v();
+    const double g1 = (v(k, j, i + 1) - v(k, j, i - 1)) / sdx1 / hx1;
+    const double g2 = (v(k, j + 1, i) - v(k, j - 1, i)) / sdx2 / hx2;
+    double e;
+    if (X3) {
+      const double sdx3 = co(k + 1, j, i).x3v() - co(k - 1, j, i).x3v();
+      const double hx3 = c.hx3v();
+      const double g3 = (v(k + 1, j, i) - v(k - 1, j, i)) / sdx3 / hx3;
+      e = sqrt(g1 * g1 + g2 * g2 + g3 * g3);
+      const double w1 = sdx1 * hx1, w2 = sdx2 * hx2, w3 = sdx3 * hx3;
+      e /= (v(k, j, i) / sqrt(w1 * w1 + w2 * w2 + w3 * w3));
+    } else {
+      e = sqrt(g1 * g1 + g2 * g2);
+      const double w1 = sdx1 * hx1, w2 = sdx2 * hx2;
+      e /= (v(k, j, i) / sqrt(w1 * w1 + w2 * w2));
+    }
+    eps = (eps < e) ? e : eps;
+  }
+  block_max(eps, a.scratch);
+}
+__global__ __launch_bounds__(256) void magnitude_kernel(const CriterionView C) {
+  const artemis_amr_criterion_t &a = C.a;
+  const int ni = a.ie - a.is + 1, nj = a.je - a.js + 1, nk = a.ke - a.ks + 1;
+  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  double m = 0.0;
+  if (t < static_cast<long>(ni) * nj * nk) {
+    const int i = a.is + static_cast<int>(t % ni), j = a.js + static_cast<int>((t / ni) % nj);
+    const int k = a.ks + static_cast<int>(t / (static_cast<long>(ni) * nj));
+    const double q = a.field[(static_cast<long>(k) * a.nj + j) * a.ni + i];
+    m = (m < q) ? q : m;
+  }
+  block_max(m, a.scratch);
+}
 } // namespace
 
 void launch_refine(const artemis_refine_t &r, int prolongate, hipStream_t s) {
@@ -112,6 +175,19 @@ void launch_refine(const artemis_refine_t &r, int prolongate, hipStream_t s) {
   if (n <= 0) return;
   if (prolongate) hipLaunchKernelGGL(prolongate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, R);
   else hipLaunchKernelGGL(restrict_kernel, dim3((n + 255) / 256), dim3(256), 0, s, R);
+}
+
+// The block maximum lands in a.scratch (zeroed on the stream first); the caller copies it back.
+void launch_amr_criterion(const artemis_amr_criterion_t &a, int magnitude, hipStream_t s) {
+  CriterionView C;
+  C.a = a;
+  (void)hipMemsetAsync(a.scratch, 0, sizeof(double), s);
+  const bool X3 = a.ndim > 2;
+  const long n = magnitude ? static_cast<long>(a.ie - a.is + 1) * (a.je - a.js + 1) * (a.ke - a.ks + 1)
+                           : static_cast<long>(a.ie - a.is + 3) * (a.je - a.js + 3) * (X3 ? a.ke - a.ks + 3 : 1);
+  if (n <= 0) return;
+  if (magnitude) hipLaunchKernelGGL(magnitude_kernel, dim3((n + 255) / 256), dim3(256), 0, s, C);
+  else hipLaunchKernelGGL(first_derivative_kernel, dim3((n + 255) / 256), dim3(256), 0, s, C);
 }
 
 } // namespace artemis

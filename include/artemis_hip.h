@@ -433,6 +433,29 @@ typedef struct artemis_refine {
 int artemis_hip_restrict_average(const artemis_refine_t *r, void *stream);
 int artemis_hip_prolongate_minmod(const artemis_refine_t *r, void *stream);
 
+/* ---- refinement criteria (utils/refinement/amr_criteria.hpp) ------------------------------------
+ * ArtemisUtils::ScalarFirstDerivative<FIELD, GEOM> (:28-132) and ScalarMagnitude<FIELD> (:137-168): the
+ * block-wide maximum that decides a mesh block's AmrTag, for one cell-centred scalar (the first
+ * component of FIELD: gas density or pressure in the reference's gas package, gas.cpp refine_field).
+ * first_derivative: max over the interior grown by one zone in every active direction of
+ *   |grad q| / (q / stencil diagonal), centred differences over the cell-centre spacing and the
+ *   volume-averaged scale factors; ndim == 1 returns "same" without computing (as the reference does).
+ *   tag = +1 (refine) when the maximum exceeds refine_thr, -1 (derefine) below 0.25 * refine_thr.
+ * magnitude: max of q over the interior; +1 above refine_thr, -1 below deref_thr.
+ * scratch = one DEVICE double (overwritten).  Both calls synchronise `stream` (the reference's
+ * par_reduce does) and write *tag (AmrTag: -1 derefine, 0 same, +1 refine) and, if non-NULL, *maxval. */
+typedef struct artemis_amr_criterion {
+  int coords, ndim;
+  int ni, nj, nk;                     /* array extents incl. ghosts (>= 2 ghost zones for the derivative) */
+  const double *geom, *metric;        /* as artemis_refine_t's fgeom / fmetric */
+  const double *field;                /* DEVICE array [nk][nj][ni] */
+  int is, ie, js, je, ks, ke;         /* interior bounds */
+  double refine_thr, deref_thr;
+  double *scratch;
+} artemis_amr_criterion_t;
+int artemis_hip_amr_first_derivative(const artemis_amr_criterion_t *a, int *tag, double *maxval, void *stream);
+int artemis_hip_amr_magnitude(const artemis_amr_criterion_t *a, int *tag, double *maxval, void *stream);
+
 /* Device-side SetGlobalTimeStep (parthenon EvolutionDriver, upstream): state = DEVICE
  * {time, dt, dt_est, beta_dt[0..2]}.  time += dt; dt = min(2*dt, dt_est), clipped so that
  * time + dt <= tlim (tlim <= 0: no limit); dt_est = DBL_MAX for the next cycle's reduction;

@@ -2909,6 +2909,64 @@ void oracle_restrict_average(void *hf, void *hc, const int *r) {
               tvol;
         }
 }
+// Refinement criteria (utils/refinement/amr_criteria.hpp:28-168) on component `var` of the gas primitives
+// (or, var < 0, on the gas pressure of species 0): the block maximum and the AmrTag (-1 derefine, 0 same,
+// +1 refine).  Parity unpinned: no reference test isolates the criteria.
+int oracle_amr_first_derivative(void *h, int var, double thr, double *maxeps_out) {
+  Sim &s = *static_cast<Sim *>(h);
+  std::vector<Real> pres;
+  const Real *q = s.gprim.data() + (var < 0 ? 0 : var) * s.N;
+  if (var < 0) {
+    pres.resize(s.N);
+    for (size_t n = 0; n < s.N; ++n) pres[n] = (s.c.gamma - 1.0) * s.gprim[n] * s.gprim[4 * s.N + n];
+    q = pres.data();
+  }
+  *maxeps_out = 0.0;
+  if (s.ndim == 1) return 0; // :122-124
+  const bool X3 = s.ndim == 3;
+  Real maxeps = 0.0;
+  for (int k = X3 ? s.ks - 1 : s.ks; k <= (X3 ? s.ke + 1 : s.ks); ++k)
+    for (int j = s.js - 1; j <= s.je + 1; ++j)
+      for (int i = s.is - 1; i <= s.ie + 1; ++i) {
+        const Real sdx1 = Coords(s, k, j, i + 1).x1v() - Coords(s, k, j, i - 1).x1v();
+        const Real sdx2 = Coords(s, k, j + 1, i).x2v() - Coords(s, k, j - 1, i).x2v();
+        Coords co(s, k, j, i);
+        Real hx[3];
+        co.GetScaleFactors(hx); // 2-D: hx1(cc), hx2(cc) at the centre = the same values (:104-105)
+        Real eps;
+        if (X3) {
+          const Real sdx3 = Coords(s, k + 1, j, i).x3v() - Coords(s, k - 1, j, i).x3v();
+          eps = std::sqrt(SQR((q[IDX(s, k, j, i + 1)] - q[IDX(s, k, j, i - 1)]) / sdx1 / hx[0]) +
+                          SQR((q[IDX(s, k, j + 1, i)] - q[IDX(s, k, j - 1, i)]) / sdx2 / hx[1]) +
+                          SQR((q[IDX(s, k + 1, j, i)] - q[IDX(s, k - 1, j, i)]) / sdx3 / hx[2]));
+          eps /= (q[IDX(s, k, j, i)] / std::sqrt(SQR(sdx1 * hx[0]) + SQR(sdx2 * hx[1]) + SQR(sdx3 * hx[2])));
+        } else {
+          eps = std::sqrt(SQR((q[IDX(s, k, j, i + 1)] - q[IDX(s, k, j, i - 1)]) / sdx1 / hx[0]) +
+                          SQR((q[IDX(s, k, j + 1, i)] - q[IDX(s, k, j - 1, i)]) / sdx2 / hx[1]));
+          eps /= (q[IDX(s, k, j, i)] / std::sqrt(SQR(sdx1 * hx[0]) + SQR(sdx2 * hx[1])));
+        }
+        maxeps = std::max(maxeps, eps);
+      }
+  *maxeps_out = maxeps;
+  if (maxeps > thr) return 1;
+  if (maxeps < 0.25 * thr) return -1;
+  return 0;
+}
+int oracle_amr_magnitude(void *h, int var, double refine_above, double deref_below, double *max_out) {
+  Sim &s = *static_cast<Sim *>(h);
+  Real maxvv = 0.0;
+  for (int k = s.ks; k <= s.ke; ++k)
+    for (int j = s.js; j <= s.je; ++j)
+      for (int i = s.is; i <= s.ie; ++i) {
+        const long n = IDX(s, k, j, i);
+        const Real q = var < 0 ? (s.c.gamma - 1.0) * s.gprim[n] * s.gprim[4 * s.N + n] : s.gprim[var * s.N + n];
+        maxvv = std::max(maxvv, q);
+      }
+  *max_out = maxvv;
+  if (maxvv > refine_above) return 1;
+  if (maxvv < deref_below) return -1;
+  return 0;
+}
 void oracle_prolongate_minmod(void *hf, void *hc, const int *r) {
   Sim &f = *static_cast<Sim *>(hf), &c = *static_cast<Sim *>(hc);
   const int DIM = f.ndim;

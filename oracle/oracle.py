@@ -130,6 +130,10 @@ def lib():
         L.oracle_pgen_conduction.argtypes = [vp] + [d] * 6
         L.oracle_restrict_average.argtypes = [vp, vp, C.POINTER(i)]
         L.oracle_prolongate_minmod.argtypes = [vp, vp, C.POINTER(i)]
+        L.oracle_amr_first_derivative.argtypes = [vp, i, d, C.POINTER(d)]
+        L.oracle_amr_first_derivative.restype = i
+        L.oracle_amr_magnitude.argtypes = [vp, i, d, d, C.POINTER(d)]
+        L.oracle_amr_magnitude.restype = i
         L.oracle_set_cooling.argtypes = [vp, C.POINTER(d)]
         L.oracle_cooling_source.argtypes = [vp, d, d]
         L.oracle_pgen_disk.argtypes = [vp, C.POINTER(d)]
@@ -351,6 +355,18 @@ class Oracle:
 
     def ProlongateSharedMinMod(self, coarse, crange, corigin, forigin):
         self.L.oracle_prolongate_minmod(self.h, coarse.h, (C.c_int * 12)(*crange, *corigin, *forigin))
+
+    def ScalarFirstDerivative(self, var, thr):
+        """amr_criteria.hpp:28-132 on gas primitive component `var` (-1: pressure); returns (AmrTag, maxeps)"""
+        m = C.c_double(0.0)
+        tag = self.L.oracle_amr_first_derivative(self.h, var, thr, C.byref(m))
+        return tag, m.value
+
+    def ScalarMagnitude(self, var, refine_above, deref_below):
+        """amr_criteria.hpp:137-168; returns (AmrTag, max)"""
+        m = C.c_double(0.0)
+        tag = self.L.oracle_amr_magnitude(self.h, var, refine_above, deref_below, C.byref(m))
+        return tag, m.value
 
     def set_cooling(self, beta0, beta_min=1e-12, exp_scale=0.0, tfloor=0.0, tcyl=0.0, cyl_plaw=0.0, tsph=0.0,
                     sph_plaw=0.0):

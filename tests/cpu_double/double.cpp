@@ -679,6 +679,8 @@ int artemis_hip_selftest_divsqrt(long, const double *, const double *, double *,
 // the refinement operators are exercised against the oracle on the GPU only; the host stand-in has no use for them
 int artemis_hip_restrict_average(const artemis_refine_t *, void *) { return bad("refinement operators: GPU library only"); }
 int artemis_hip_prolongate_minmod(const artemis_refine_t *, void *) { return bad("refinement operators: GPU library only"); }
+int artemis_hip_amr_first_derivative(const artemis_amr_criterion_t *, int *, double *, void *) { return bad("refinement criteria: GPU library only"); }
+int artemis_hip_amr_magnitude(const artemis_amr_criterion_t *, int *, double *, void *) { return bad("refinement criteria: GPU library only"); }
 int artemis_rt_set_device(int) { return 0; }
 void *artemis_rt_malloc(size_t n) { return std::calloc(1, n ? n : 8); }
 void artemis_rt_free(void *p) { std::free(p); }

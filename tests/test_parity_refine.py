@@ -132,3 +132,77 @@ def test_operator_properties_on_the_oracle(coordinates, nxc, lo, hi):
     of.RestrictAverage(oc, *rr)
     oc.PrimToCons()
     assert abs(oc.history()[0] - mass_fine) < 1e-12 * mass_fine
+
+
+# ---- refinement criteria (utils/refinement/amr_criteria.hpp) ------------------------------------------
+def criterion(o, m, field, thr, deref=0.0):
+    from artemis_amd import capi
+    a = capi.AmrCriterion()
+    a.coords, a.ndim = m.pack.coords, o.ndim
+    a.ni, a.nj, a.nk = o.ni, o.nj, o.nk
+    a.geom, a.metric, a.field = m.geom.data_ptr(), m.pack.metric, field.data_ptr()
+    a.is_, a.ie, a.js, a.je, a.ks, a.ke = o.is_, o.ie, o.js, o.je, o.ks, o.ke
+    a.refine_thr, a.deref_thr = thr, deref
+    scratch = torch.full((1,), -7.0, dtype=torch.float64, device="cuda")
+    a.scratch = scratch.data_ptr()
+    return a, scratch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("coordinates,nxc,lo,hi", BLOCKS)
+@pytest.mark.parametrize("var", [0, -1])
+def test_amr_criteria(hiplib, coordinates, nxc, lo, hi, var):
+    """ScalarFirstDerivative<FIELD, GEOM> and ScalarMagnitude<FIELD> on the gas density / pressure: the
+    block maximum is BIT-EXACT against the oracle (a maximum has no summation order), and the AmrTag
+    follows it through all three outcomes."""
+    from artemis_amd import capi
+    oc, _, mc, _ = meshes(coordinates, nxc, lo, hi)
+    prim = mc.gas_prim[0]
+    field = prim[0].contiguous() if var == 0 else (((oc.cfg.gamma - 1.0) * prim[0]) * prim[4]).contiguous()
+    tag, m = C.c_int(9), C.c_double(-1.0)
+    ref_tag, ref_max = oc.ScalarFirstDerivative(var, 1.0)
+    for thr in ([1.0] if oc.ndim == 1 else [ref_max * 0.5, ref_max * 2.0, ref_max * 8.0]):
+        a, keep = criterion(oc, mc, field, thr)
+        capi.check(mc.L.artemis_hip_amr_first_derivative(C.byref(a), C.byref(tag), C.byref(m), None))
+        want_tag, want = oc.ScalarFirstDerivative(var, thr)
+        assert m.value == want and tag.value == want_tag, (thr, m.value, want, tag.value, want_tag)
+    if oc.ndim > 1:
+        assert ref_max > 0.0 and [oc.ScalarFirstDerivative(var, ref_max * f)[0] for f in (0.5, 2.0, 8.0)] == [1, 0, -1]
+    else:
+        assert (tag.value, m.value) == (0, 0.0)  # 1-D: AmrTag::same without computing (amr_criteria.hpp:122)
+    _, qmax = oc.ScalarMagnitude(var, 1.0, 0.0)
+    for above, below in [(qmax * 0.5, 0.0), (qmax * 2.0, qmax * 0.5), (qmax * 4.0, qmax * 2.0)]:
+        a, keep = criterion(oc, mc, field, above, below)
+        capi.check(mc.L.artemis_hip_amr_magnitude(C.byref(a), C.byref(tag), C.byref(m), None))
+        want_tag, want = oc.ScalarMagnitude(var, above, below)
+        assert m.value == want and tag.value == want_tag, (above, below, m.value, want)
+    assert [oc.ScalarMagnitude(var, qmax * f, qmax * g)[0] for f, g in ((0.5, 0.0), (2.0, 0.5), (4.0, 2.0))] == [1, 0, -1]
+
+
+@pytest.mark.gpu
+def test_amr_criteria_abi_contract(hiplib):
+    from artemis_amd import capi
+    oc, _, mc, _ = meshes("spherical", (8, 6, 4), (0.4, 0.7, 0.0), (1.7, 2.5, 6.0))
+    field = mc.gas_prim[0][0].contiguous()
+    tag, m = C.c_int(0), C.c_double(0.0)
+    a, keep = criterion(oc, mc, field, 1.0)
+    a.ie = oc.ni - 2  # the grown range would read beyond the array
+    assert mc.L.artemis_hip_amr_first_derivative(C.byref(a), C.byref(tag), C.byref(m), None) == capi.EINVAL
+    a, keep = criterion(oc, mc, field, 1.0)
+    a.metric = None
+    assert mc.L.artemis_hip_amr_first_derivative(C.byref(a), C.byref(tag), C.byref(m), None) == capi.EINVAL
+    assert mc.L.artemis_hip_amr_first_derivative(C.byref(a), None, C.byref(m), None) == capi.EINVAL
+
+
+def test_amr_criteria_properties_on_the_oracle():
+    """A uniform field never asks for refinement by gradient; a field with a jump does, and the criterion is
+    invariant under a rescaling of the field (it is normalised by the local value)."""
+    oc, _, _, _ = meshes("cartesian", (16, 10, 1), (-1.0, -0.5, -0.5), (1.0, 0.8, 0.5), gpu=False)
+    oc.gprim[0] = 2.5
+    assert oc.ScalarFirstDerivative(0, 0.1) == (-1, 0.0)
+    oc.gprim[0][:, :, oc.ni // 2:] = 5.0
+    tag, eps = oc.ScalarFirstDerivative(0, 0.1)
+    assert tag == 1 and eps > 0.1
+    oc.gprim[0] *= 8.0
+    assert oc.ScalarFirstDerivative(0, 0.1) == (tag, eps)  # a power of two: exact
+    assert oc.ScalarMagnitude(0, 30.0, 10.0) == (1, 40.0) and oc.ScalarMagnitude(0, 50.0, 45.0) == (-1, 40.0)
