@@ -108,7 +108,7 @@ class Drag(C.Structure):
     _fields_ = [("type", C.c_int), ("model", C.c_int), ("scale", C.c_double),
                 ("grain_density", C.c_double), ("tau", C.c_double * MAX_DUST_SPECIES),
                 ("sizes", C.c_double * MAX_DUST_SPECIES), ("gas", Damping), ("dust", Damping),
-                ("xmin", C.c_double * 3), ("xmax", C.c_double * 3)]
+                ("xmin", C.c_double * 3), ("xmax", C.c_double * 3), ("damp_visc", C.c_void_p)]
 
 
 class DiffCoeff(C.Structure):

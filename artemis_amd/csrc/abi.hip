@@ -338,6 +338,15 @@ int artemis_hip_cooling_source(const artemis_pack_t *p, const artemis_cooling_t 
   return after_launch("CoolingSource");
 }
 
+static int validate_damp_visc(const artemis_drag_t *d) { // drag.cpp:113-121, 137-157
+  if (!d->damp_visc) return ARTEMIS_HIP_OK;
+  const int t = d->damp_visc->type;
+  if (t != ARTEMIS_VISCOSITY_PLAW && t != ARTEMIS_VISCOSITY_ALPHA)
+    return fail(ARTEMIS_HIP_EINVAL, "The chosen viscosity model does not work with damping");
+  if (t == ARTEMIS_VISCOSITY_ALPHA && !d->damp_visc->radial)
+    return fail(ARTEMIS_HIP_EINVAL, "damp_to_visc: alpha viscosity needs its radial table (artemis_hip_diffusion_radial_fill)");
+  return ARTEMIS_HIP_OK;
+}
 int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, double time, double dt,
                             void *stream) {
   (void)time;
@@ -358,6 +367,7 @@ int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, do
     if (d->gas.irate[i] < 0.0 || d->dust.irate[i] < 0.0 || d->gas.ix[i] > d->gas.ox[i] ||
         d->dust.ix[i] > d->dust.ox[i])
       return fail(ARTEMIS_HIP_EINVAL, "bad damping bounds / rates");
+  if (int rc = validate_damp_visc(d)) return rc;
   artemis::launch_drag_source(artemis::make_pack_view(*p), *d, dt, nullptr, S(stream));
   return after_launch("DragSource");
 }
@@ -603,6 +613,7 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
     if (!(a->cooling->cv > 0.0)) return fail(ARTEMIS_HIP_EINVAL, "cooling: specific heat cv must be positive");
   }
   if (a->drag) {
+    if (int rc = validate_damp_visc(a->drag)) return rc;
     if (a->drag->type == ARTEMIS_DRAG_SIMPLE_DUST && (p->gas.nspecies < 1 || p->dust.nspecies < 1))
       return fail(ARTEMIS_HIP_EINVAL, "drag type simple_dust requires do_gas = do_dust = true");
     if (p->dust.nspecies > ARTEMIS_MAX_DUST_SPECIES)

@@ -158,6 +158,7 @@ struct artemis_sim {
   artemis_gravity_t grav;
   Real rf_omega = 0.0, rf_qshear = 0.0;
   artemis_drag_t drag;
+  bool damp_to_visc = false; // <gas/damping> damp_to_visc: drag.damp_visc = &diff.visc at the call sites
   artemis_bc_params_t bcpar = {};
   // gas diffusion (gas.cpp:180-197): viscosity and / or heat conduction
   bool do_viscosity = false, do_conduction = false;
@@ -568,8 +569,11 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
         o.ox[d] = pin.GetOrAddReal(blk, std::string("outer_") + ax[d], DBL_MAX);
         o.orate[d] = pin.GetOrAddReal(blk, std::string("outer_") + ax[d] + "_rate", 0.0);
       }
-      if (present && pin.GetOrAddBoolean(blk, "damp_to_visc", false))
-        throw std::runtime_error("damp_to_visc needs the viscosity package (out of scope)");
+      // drag.hpp:101; only the gas block's flag is read by DragSource (drag.cpp:109,135)
+      if (present && pin.GetOrAddBoolean(blk, "damp_to_visc", false) && blk == "gas/damping") {
+        if (!do_viscosity) throw std::runtime_error("damp_to_visc needs <physics> viscosity = true (the gas package's visc_params)");
+        damp_to_visc = true; // viscosity_plaw or viscosity_alpha: the only kinds <gas/viscosity> produces
+      }
     };
     const bool gd = do_gas && pin.DoesBlockExist("gas/damping"), dd = do_dust && pin.DoesBlockExist("dust/damping");
     if (drag.type == ARTEMIS_DRAG_SELF && ((do_gas && !gd) || (do_dust && !dd)))
@@ -1467,6 +1471,7 @@ void artemis_sim::step_general(bool want_dt, bool device_dt) {
     place_binary();
     a.gravity = do_gravity ? &grav : nullptr;
     a.rf_omega = do_rframe ? rf_omega : 0.0, a.rf_qshear = rf_qshear;
+    drag.damp_visc = damp_to_visc ? &diff.visc : nullptr;
     a.drag = do_drag ? &drag : nullptr;
     a.cfl_gas = cfl_gas, a.cfl_dust = cfl_dust;
     a.dt_dev = (last && want_dt) ? (device_dt ? tstate.p + 2 : dt_dev.p) : nullptr;
@@ -1628,7 +1633,10 @@ void artemis_sim::step_unfused() {
       // the start of the step (:167)
       if (do_gravity) CK(artemis_hip_external_gravity(&p, &grav, time, bdt, stream), "ExternalGravity");
       if (do_rframe) CK(artemis_hip_rotating_frame_force(&p, rf_omega, rf_qshear, time, bdt, stream), "RotatingFrameForce");
-      if (do_drag) CK(artemis_hip_drag_source(&p, &drag, time, bdt, stream), "DragSource");
+      if (do_drag) {
+        drag.damp_visc = damp_to_visc ? &diff.visc : nullptr;
+        CK(artemis_hip_drag_source(&p, &drag, time, bdt, stream), "DragSource");
+      }
       if (do_cooling && do_gas) CK(artemis_hip_cooling_source(&p, &cool, time, bdt, stream), "CoolingSource"); // :243-248
       CK(artemis_hip_set_aux(&p, stream), "SetAuxillaryFields");
       CK(artemis_hip_cons_to_prim(&p, stream), "ConsToPrim");

@@ -69,27 +69,6 @@ struct Geo {
   }
 };
 
-// DiffusionCoeff<DIFF>::Get of cell c of block b; the radial factors come from the host-filled table.
-ADEV double coeff_of(const artemis_diffcoeff_t &dp, double cv, double gm1, double dens, double sie, int b,
-                     long c) {
-  switch (dp.type) {
-  case ARTEMIS_VISCOSITY_PLAW: // diffusion_coeff.hpp:222-224
-    return dp.coeff * dens * (dp.radial ? dp.radial[b][c] : 1.0);
-  case ARTEMIS_VISCOSITY_ALPHA: { // :262-268: alpha B / Omega_K, B = gamma gm1 rho sie (IdealGas)
-    const double blk = (gm1 + 1.0) * gm1 * dens * sie;
-    return dp.coeff * blk / dp.radial[b][c];
-  }
-  default: { // conductivity_plaw :312-316, thermaldiff_plaw :353-359
-    // zero exponents (every shipped deck): std::pow(x, 0.0) == 1.0, bit-exact.  Otherwise the power laws of
-    // the STATE run on the device's pow(): agreement with a host libm is to rounding, not bitwise.
-    double ft = 1.0, fr = 1.0;
-    if (dp.temp_exp != 0.0) ft = pow(amax(0.0, sie / cv) / dp.T_ref, dp.temp_exp);
-    if (dp.rho_exp != 0.0) fr = pow(dens / dp.rho_ref, dp.rho_exp);
-    if (dp.type == ARTEMIS_CONDUCTIVITY_PLAW) return dp.coeff * ft * fr;
-    return dp.coeff * ft * fr * dens * cv;
-  }
-  }
-}
 ADEV double face_average(int avg, double mu1, double mu2) { // diffusion_coeff.hpp:139-150
   return (avg == 0) * (0.5 * (mu1 + mu2)) + (avg == 1) * (2.0 * mu1 * mu2 / (mu1 + mu2));
 }

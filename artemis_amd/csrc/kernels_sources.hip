@@ -5,6 +5,7 @@
 #include <cfloat>
 
 #include "device_math.hpp"
+#include "diffusion_device.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
 #include "pack_view.hpp"
@@ -179,7 +180,13 @@ __global__ __launch_bounds__(TX *TY) void cooling_kernel(const PackView P, const
 }
 
 // ---------------------------------------------------------------------------------------
-// Drag::DragSource (drag.cpp:89-175) with damp_to_visc = false.
+// Drag::DragSource (drag.cpp:89-175); D.damp_visc != NULL = damp_to_visc: the viscosity it points at (host
+// memory) travels to the kernels by value as V.
+static artemis_diffcoeff_t damp_visc_of(const artemis_drag_t &D) {
+  artemis_diffcoeff_t v{};
+  if (D.damp_visc) v = *D.damp_visc;
+  return v;
+}
 __device__ __forceinline__ void damping_ramps(const artemis_damping_t &p, const artemis_drag_t &D,
                                               int ndim, const double xv[3], double dt,
                                               double f[3]) {
@@ -195,7 +202,7 @@ __device__ __forceinline__ void damping_ramps(const artemis_damping_t &p, const 
 }
 
 // SelfDragSourceImpl (drag.hpp:171-294)
-__global__ __launch_bounds__(TX *TY) void self_drag_kernel(const PackView P, const artemis_drag_t D,
+__global__ __launch_bounds__(TX *TY) void self_drag_kernel(const PackView P, const artemis_drag_t D, const artemis_diffcoeff_t V,
                                                            double dt_host, const double *dt_dev) {
   INTERIOR_CELL
   const double dt = dt_dev ? *dt_dev : dt_host;
@@ -215,7 +222,17 @@ __global__ __launch_bounds__(TX *TY) void self_drag_kernel(const PackView P, con
       double *m1 = f.cons0[b * nv + ns + 3 * n + 0], *m2 = f.cons0[b * nv + ns + 3 * n + 1];
       double *m3 = f.cons0[b * nv + ns + 3 * n + 2];
       const double vg[3] = {m1[c] / (hx[0] * dens), m2[c] / (hx[1] * dens), m3[c] / (hx[2] * dens)};
-      const double mu = 0.0; // DiffusionCoeff<null>::Get (diffusion_coeff.hpp:185-189)
+      double mu = 0.0; // DiffusionCoeff<null>::Get (diffusion_coeff.hpp:185-189)
+      if (D.damp_visc) { // drag.hpp:234-240: GetSpecificInternalEnergy of species n, then the viscosity
+        const double u_d = amax(dens, f.dfloor);
+        const double rv1 = m1[c] / hx[0], rv2 = m2[c] / hx[1], rv3 = m3[c] / hx[2];
+        const double ke = 0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)) / u_d;
+        const double e_cons = f.cons0[b * nv + 4 * ns + n][c];
+        const double ue_cons = e_cons - ke;
+        double sie = (ue_cons > f.de_switch * e_cons) ? ue_cons / u_d : f.cons0[b * nv + 5 * ns + n][c] / u_d;
+        sie = amax(sie, f.siefloor);
+        mu = coeff_of(V, 0.0, P.gm1, dens, sie, b, c);
+      }
       const double vR = -1.5 * mu / (cv.R * dens);
       const double vd[3] = {cv.e1 * vR, cv.e2 * vR, cv.e3 * vR};
       const double dm1 = -bg[0] * dens * (vg[0] - vd[0]) / (1.0 + bg[0]);
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(TX *TY) void self_drag_kernel(const PackView P, con
 // new primitives to P.{gas,dust}.prim -- the tail of the general fused stage in one pass
 // (one gas species).
 template <bool FINISH>
-__global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, const artemis_drag_t D,
+__global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, const artemis_drag_t D, const artemis_diffcoeff_t V,
                                                              double dt_host, const double *dt_dev) {
   INTERIOR_CELL
   const double dt = dt_dev ? *dt_dev : dt_host;
@@ -276,7 +293,7 @@ __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, c
     sieg = (ue_cons > G.de_switch * e_cons) ? ue_cons / u_d : G.cons0[b * nvg + 5 * nsg][c] / u_d;
     sieg = amax(sieg, G.siefloor);
   }
-  const double mu = 0.0;
+  const double mu = D.damp_visc ? coeff_of(V, 0.0, P.gm1, dg, sieg, b, c) : 0.0; // drag.hpp:392-393
   const double vR = -1.5 * mu / (cv.R * dg);
   const double vt[3] = {cv.e1 * vR, cv.e2 * vR, cv.e3 * vR};
   double fd[3] = {0., 0., 0.}, fvd[3] = {0., 0., 0.};
@@ -378,16 +395,16 @@ void launch_rotating_frame(const PackView &P, double omega, double dt, hipStream
 void launch_drag_source(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
                         hipStream_t s) {
   if (D.type == ARTEMIS_DRAG_SELF)
-    hipLaunchKernelGGL(self_drag_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt, dt_dev);
+    hipLaunchKernelGGL(self_drag_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
   else
-    hipLaunchKernelGGL(simple_drag_kernel<false>, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt, dt_dev);
+    hipLaunchKernelGGL(simple_drag_kernel<false>, interior_grid(P), dim3(TX, TY), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
 }
 // simple_dust drag + SetAuxillaryFields + ConsToPrim of a one-gas-species pack in one pass: reads
 // cons0, writes the primitives of P (the general fused stage points them at its out tables)
 bool launch_drag_finish(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
                         hipStream_t s) {
   if (D.type != ARTEMIS_DRAG_SIMPLE_DUST || P.gas.ns != 1) return false;
-  hipLaunchKernelGGL(simple_drag_kernel<true>, interior_grid(P), dim3(TX, TY), 0, s, P, D, dt, dt_dev);
+  hipLaunchKernelGGL(simple_drag_kernel<true>, interior_grid(P), dim3(TX, TY), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
   return true;
 }
 

@@ -366,9 +366,14 @@ def gravity_binary(mass, q, rb, soft1=0.0, soft2=0.0, sink1=0.0, sink2=0.0, sink
 
 
 def drag_params(type="simple_dust", model="constant", tau=(), scale=1.0, grain_density=1.0, sizes=(),
-                mesh_min=(0.0, 0.0, 0.0), mesh_max=(1.0, 1.0, 1.0), gas_damping=None, dust_damping=None):
-    """capi.Drag from deck-style values; damping = dict(inner, inner_rate, outer, outer_rate)."""
+                mesh_min=(0.0, 0.0, 0.0), mesh_max=(1.0, 1.0, 1.0), gas_damping=None, dust_damping=None,
+                damp_visc=None):
+    """capi.Drag from deck-style values; damping = dict(inner, inner_rate, outer, outer_rate);
+    damp_visc = the gas viscosity (capi.DiffCoeff with its radial table) for <gas/damping> damp_to_visc."""
     d = capi.Drag()
+    if damp_visc is not None:
+        d._keep = damp_visc  # the C struct holds a pointer to it
+        d.damp_visc = C.addressof(damp_visc)
     d.type = {"simple_dust": capi.DRAG_SIMPLE_DUST, "self": capi.DRAG_SELF}[type]
     d.model = {"constant": capi.DRAG_CONSTANT, "stokes": capi.DRAG_STOKES}[model]
     d.scale, d.grain_density = scale, grain_density

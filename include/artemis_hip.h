@@ -232,7 +232,7 @@ int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_
 int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, double qshear,
                                      double time, double dt, void *stream);
 
-/* Drag::DragSource<GEOM> (drag/drag.cpp:89-175) without damp_to_visc: `self` =
+/* Drag::DragSource<GEOM> (drag/drag.cpp:89-175): `self` =
  * SelfDragSourceImpl (drag.hpp:171-294, damping ramps towards the mesh edges), `simple_dust` =
  * SimpleDragSourceImpl (drag.hpp:296-482, implicit gas-dust momentum exchange; one gas species,
  * <= ARTEMIS_MAX_DUST_SPECIES dust species).  tau[n] already includes `scale` for the constant
@@ -246,6 +246,10 @@ typedef struct artemis_drag {
   double tau[ARTEMIS_MAX_DUST_SPECIES], sizes[ARTEMIS_MAX_DUST_SPECIES];
   artemis_damping_t gas, dust;
   double xmin[3], xmax[3];    /* parthenon/mesh x?min, x?max (drag.cpp:37-42) */
+  /* <gas/damping> damp_to_visc (drag.hpp:101, drag.cpp:109-121,135-157): NULL = off; otherwise the gas
+   * package's viscosity (viscosity_plaw or viscosity_alpha, with its radial table) -- the gas damping
+   * relaxes towards the viscous inflow velocity v_R = -1.5 mu / (R rho) instead of towards rest. */
+  const struct artemis_diffcoeff *damp_visc;
 } artemis_drag_t;
 int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, double time, double dt,
                             void *stream);

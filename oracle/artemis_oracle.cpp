@@ -112,6 +112,7 @@ struct Sim {
     Real scale = 1.0, grain_density = 1.0;
     std::vector<Real> tau, sizes;
     SelfDrag gas, dust;
+    bool damp_to_visc = false; // gas damping relaxes towards the viscous inflow velocity (drag.cpp:109,135)
   } drag;
   struct { // pgen/strat.hpp:44-52 (only what the user BCs read)
     Real q = 0, Om0 = 0;
@@ -1480,8 +1481,10 @@ inline void damping_ramps(const Sim &s, const Sim::SelfDrag &p, const Real xv[3]
          (p.irate[2] * ((xv[2] < p.ix[2]) * SQR((xv[2] - p.ix[2]) / (p.ix[2] - x3min))) +
           p.orate[2] * ((xv[2] > p.ox[2]) * SQR((xv[2] - p.ox[2]) / (p.ox[2] - x3max))));
 }
+inline Real diff_coeff_at(const Sim &s, const Sim::DiffCoeff &dp, Real dens, Real sie, int k, int j, int i);
 void drag_source(Sim &s, Real dt) {
   if (s.drag.type == 0) return;
+  const bool dvisc = s.drag.damp_to_visc; // DiffType::null otherwise: mu = 0 (diffusion_coeff.hpp:185-189)
   const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
   const Real gm1 = s.c.gamma - 1.0;
 #pragma omp parallel for collapse(2) schedule(static)
@@ -1503,7 +1506,8 @@ void drag_source(Sim &s, Real dt) {
             Real *m[3] = {&s.gu0[(ng_ + 3 * n + 0) * s.N + c], &s.gu0[(ng_ + 3 * n + 1) * s.N + c],
                           &s.gu0[(ng_ + 3 * n + 2) * s.N + c]};
             const Real vg[3] = {*m[0] / (hx[0] * dens), *m[1] / (hx[1] * dens), *m[2] / (hx[2] * dens)};
-            const Real mu = 0.0;
+            const Real sien = specific_internal_energy(s, n, c, hx); // drag.hpp:234-235
+            const Real mu = dvisc ? diff_coeff_at(s, s.visc, dens, sien, k, j, i) : 0.0;
             const Real vR = -1.5 * mu / (cv.R * dens);
             const Real vd[3] = {cv.e1 * vR, cv.e2 * vR, cv.e3 * vR};
             const Real dm1 = -bg[0] * dens * (vg[0] - vd[0]) / (1.0 + bg[0]);
@@ -1532,7 +1536,7 @@ void drag_source(Sim &s, Real dt) {
                        &s.gu0[(ng_ + 2) * s.N + c]};
         const Real vg[3] = {*mg[0] / (hx[0] * dg), *mg[1] / (hx[1] * dg), *mg[2] / (hx[2] * dg)};
         const Real sieg = specific_internal_energy(s, 0, c, hx);
-        const Real mu = 0.0;
+        const Real mu = dvisc ? diff_coeff_at(s, s.visc, dg, sieg, k, j, i) : 0.0; // drag.hpp:392-393
         const Real vR = -1.5 * mu / (cv.R * dg);
         const Real vt[3] = {cv.e1 * vR, cv.e2 * vR, cv.e3 * vR};
         Real fd[3] = {0., 0., 0.};
@@ -1603,11 +1607,15 @@ inline Real distance(const Coords &co, const Real a[3], const Real b[3]) {
 // DiffusionCoeff<DIFF>::Get / evaluate (diffusion_coeff.hpp:190-381): dynamic viscosity rho*nu or
 // heat conductivity K of species n in cell (k,j,i).  EOS calls are the IdealGas closed forms
 // (singularity-eos, recalled): T = sie/Cv, Cv constant, B = gamma*gm1*rho*sie.
+inline Real diff_coeff_at(const Sim &s, const Sim::DiffCoeff &dp, Real dens, Real sie, int k, int j, int i);
 inline Real diff_coeff(const Sim &s, const Sim::DiffCoeff &dp, int n, int k, int j, int i) {
   const int nsp = s.c.ns_gas;
   const size_t c = IDX(s, k, j, i);
-  const Real dens = s.gprim[n * s.N + c];
-  const Real sie = s.gprim[(5 * nsp + n) * s.N + c];
+  return diff_coeff_at(s, dp, s.gprim[n * s.N + c], s.gprim[(5 * nsp + n) * s.N + c], k, j, i);
+}
+// Get(dp, coords, dens, sie, eos) with an explicit state (drag.hpp:240,393 pass the conserved density and
+// GetSpecificInternalEnergy)
+inline Real diff_coeff_at(const Sim &s, const Sim::DiffCoeff &dp, Real dens, Real sie, int k, int j, int i) {
   const Coords coords(s, k, j, i);
   const Real xv[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
   switch (dp.type) {
@@ -3039,6 +3047,13 @@ void oracle_set_damping(void *h, int fluid, const double *p) {
   Sim::SelfDrag &d = fluid ? s.drag.dust : s.drag.gas;
   for (int i = 0; i < 3; ++i)
     d.ix[i] = p[i], d.irate[i] = p[3 + i], d.ox[i] = p[6 + i], d.orate[i] = p[9 + i];
+}
+// <gas/damping> damp_to_visc (drag.hpp:101): needs viscosity_plaw or viscosity_alpha (drag.cpp:113-121)
+int oracle_set_damp_to_visc(void *h, int on) {
+  Sim &s = *static_cast<Sim *>(h);
+  if (on && s.visc.type != 1 && s.visc.type != 2) return 1; // "The chosen viscosity model does not work with damping"
+  s.drag.damp_to_visc = on != 0;
+  return 0;
 }
 void oracle_external_gravity(void *h, double time, double dt) {
   external_gravity(*static_cast<Sim *>(h), time, dt);

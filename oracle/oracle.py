@@ -134,6 +134,8 @@ def lib():
         L.oracle_amr_first_derivative.restype = i
         L.oracle_amr_magnitude.argtypes = [vp, i, d, d, C.POINTER(d)]
         L.oracle_amr_magnitude.restype = i
+        L.oracle_set_damp_to_visc.argtypes = [vp, i]
+        L.oracle_set_damp_to_visc.restype = i
         L.oracle_set_cooling.argtypes = [vp, C.POINTER(d)]
         L.oracle_cooling_source.argtypes = [vp, d, d]
         L.oracle_pgen_disk.argtypes = [vp, C.POINTER(d)]
@@ -355,6 +357,12 @@ class Oracle:
 
     def ProlongateSharedMinMod(self, coarse, crange, corigin, forigin):
         self.L.oracle_prolongate_minmod(self.h, coarse.h, (C.c_int * 12)(*crange, *corigin, *forigin))
+
+    def set_damp_to_visc(self, on=True):
+        """<gas/damping> damp_to_visc (drag.hpp:101): the gas damping relaxes towards the viscous inflow
+        velocity of the <gas/viscosity> set before (powerlaw / constant or alpha, drag.cpp:113-121)."""
+        if self.L.oracle_set_damp_to_visc(self.h, int(on)):
+            raise ValueError("The chosen viscosity model does not work with damping")
 
     def ScalarFirstDerivative(self, var, thr):
         """amr_criteria.hpp:28-132 on gas primitive component `var` (-1: pressure); returns (AmrTag, maxeps)"""

@@ -324,6 +324,13 @@ int artemis_hip_cooling_source(const artemis_pack_t *p, const artemis_cooling_t 
   }
   return 0;
 }
+static void set_damp_visc(Sim &s, const artemis_drag_t *d) { // <gas/damping> damp_to_visc
+  s.drag.damp_to_visc = d->damp_visc != nullptr;
+  if (!d->damp_visc) return;
+  const artemis_diffcoeff_t &c = *d->damp_visc;
+  s.visc.type = c.type, s.visc.avg = c.avg, s.visc.nu_s = s.visc.alpha = c.coeff;
+  s.visc.eta = c.eta, s.visc.r_exp = c.r_exp, s.visc.R0 = c.r0, s.visc.Omega0 = c.omega0;
+}
 int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, double, double dt, void *) {
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);
@@ -340,6 +347,7 @@ int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, do
     }
     s.gx1min = d->xmin[0], s.gx2min = d->xmin[1], s.gx3min = d->xmin[2];
     s.gx1max = d->xmax[0], s.gx2max = d->xmax[1], s.gx3max = d->xmax[2];
+    set_damp_visc(s, d);
     drag_source(s, dt);
     B.out(s.gu0, p->gas.cons0, s.nvg), B.out(s.du0, p->dust.cons0, s.nvd);
   }
@@ -512,6 +520,7 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
       }
       s.gx1min = d->xmin[0], s.gx2min = d->xmin[1], s.gx3min = d->xmin[2];
       s.gx1max = d->xmax[0], s.gx2max = d->xmax[1], s.gx3max = d->xmax[2];
+      set_damp_visc(s, d);
       drag_source(s, a->bdt);
     }
     if (a->cooling) {

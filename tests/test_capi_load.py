@@ -79,7 +79,7 @@ def test_ctypes_mirror_matches_the_c_header(tmp_path):
     from artemis_amd import capi
     pairs = [("artemis_fluid_pack_t", capi.FluidPack, None), ("artemis_pack_t", capi.Pack, "omega_frame"),
              ("artemis_bc_params_t", capi.BcParams, "floor_ghosts"), ("artemis_gravity_t", capi.Gravity, "pos2"),
-             ("artemis_damping_t", capi.Damping, None), ("artemis_drag_t", capi.Drag, None),
+             ("artemis_damping_t", capi.Damping, None), ("artemis_drag_t", capi.Drag, "damp_visc"),
              ("artemis_cooling_t", capi.Cooling, "beta"), ("artemis_diffcoeff_t", capi.DiffCoeff, "radial"),
              ("artemis_diffusion_t", capi.Diffusion, "cv"), ("artemis_stage_args_t", capi.StageArgs, None),
              ("artemis_stage_general_args_t", capi.StageGeneralArgs, "cooling"),

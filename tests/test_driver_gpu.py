@@ -752,6 +752,39 @@ def test_disk_decks_own_block_layout(hiplib, g):
         disk_close(part, ref, 1e-12, blk, whole=full)
 
 
+def test_disk_deck_with_damping_towards_the_viscous_inflow(hiplib):
+    """inputs/disk/disk_cyl.in with <physics> drag = true, <drag> type = self and a <gas/damping> node
+    whose damp_to_visc = true (drag.hpp:101, drag.cpp:109-121): the radial wave-killing zones relax the gas
+    towards the alpha-viscosity inflow velocity instead of towards rest.  10 cycles on one block against
+    the oracle, bit for bit (`ic` conditions: no device transcendental on the path)."""
+    from artemis_amd.driver import Simulation
+    from test_oracle_pins import disk_oracle
+    damp = dict(inner=(0.6, -1.7976931348623157e308, -1.7976931348623157e308), inner_rate=(30.0, 0.0, 0.0),
+                outer=(3.5, 1.7976931348623157e308, 1.7976931348623157e308), outer_rate=(30.0, 0.0, 0.0))
+    ov = disk_overrides("cyl", 1.4, "ic") + [
+        "physics/drag=true", "drag/type=self", "gas/damping/inner_x1=0.6", "gas/damping/inner_x1_rate=30.0",
+        "gas/damping/outer_x1=3.5", "gas/damping/outer_x1_rate=30.0", "gas/damping/damp_to_visc=true"]
+    s = Simulation(DECK("disk", "disk_cyl.in"), ov)
+    o = disk_oracle("cyl", 1.4, "ic")
+    o.set_drag("self", "constant")
+    o.set_damping(0, **damp)
+    o.set_damp_to_visc(True)
+    plain = disk_oracle("cyl", 1.4, "ic")
+    plain.set_drag("self", "constant")
+    plain.set_damping(0, **damp)
+    s.evolve(), o.evolve(62.8, 10), plain.evolve(62.8, 10)
+    assert s.ncycle == o.ncycle == 10 and s.time == o.time and s.dt == o.dt
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    assert not np.array_equal(o.gprim, plain.gprim)  # the inflow target is felt
+    f = Simulation(DECK("disk", "disk_cyl.in"), ov)  # ... and through the general fused stage (drag in its tail)
+    f.set_path("fused")
+    f.evolve()
+    assert f.uses_fused_path and f.time == o.time and np.array_equal(f.field("gas.prim"), o.gprim)
+    with pytest.raises(Exception) as e:  # the gas package's visc_params do not exist without viscosity
+        Simulation(DECK("disk", "disk_cyl.in"), ov + ["physics/viscosity=false"])
+    assert "damp_to_visc" in str(e.value)
+
+
 def test_alpha_disk_deck_against_oracle_and_reference_pin(hiplib):
     """inputs/diffusion/alpha_disk.in as tst/scripts/diffusion/alpha_disk.py:44-75 runs it (1-D axisymmetric,
     64 zones, alpha = 0.1, h = 0.1, beta cooling to T = h^2/R, `viscous` conditions): 2000 cycles

@@ -212,6 +212,62 @@ def test_self_drag(hiplib, coordinates, nx, lo, hi):
     check_cons(o, mb, "SelfDragSource")
 
 
+DAMP_VISC = [dict(type="constant", nu=0.02), dict(type="powerlaw", nu=0.03, r_exp=0.5, r0=1.2),
+             dict(type="alpha", alpha=0.05, r0=1.1, Omega0=0.8)]
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", DRAG_GEOMS[2:])
+@pytest.mark.parametrize("visc", DAMP_VISC, ids=lambda v: v["type"])
+@pytest.mark.parametrize("kind", ["self", "simple_dust"])
+def test_drag_damp_to_visc(hiplib, coordinates, nx, lo, hi, visc, kind):
+    """<gas/damping> damp_to_visc (drag.cpp:109-121,135-157): the gas is damped towards the viscous inflow
+    velocity v_R = -1.5 mu / (R rho) along the cylindrical radius, mu from the gas viscosity evaluated with the
+    conserved density and GetSpecificInternalEnergy; the radial factor of mu is the host-filled table, so
+    the task stays bit-exact.  Both couplings, both stopping-time models' shared path, every curvilinear system."""
+    from artemis_amd.pack import diffusion_params, drag_params
+    ns_gas = 2 if kind == "self" else 1
+    o, mb = pair(nx, lo, hi, ns_gas=ns_gas, ns_dust=2, coordinates=coordinates, seed=31)
+    span = [hi[d] - lo[d] for d in range(3)]
+    damp = dict(inner=tuple(lo[d] + 0.3 * span[d] for d in range(3)), inner_rate=(4.0, 1.0, 2.0),
+                outer=tuple(hi[d] - 0.3 * span[d] for d in range(3)), outer_rate=(0.5, 3.0, 1.0))
+    o.set_viscosity(**visc)
+    o.set_damp_to_visc(True)
+    o.set_drag(kind, "constant", tau=[0.05, 2.0])
+    o.set_damping(0, **damp)
+    o.set_damping(1, **damp)
+    D = diffusion_params(1.4, viscosity=visc)
+    if visc["type"] != "constant":
+        mb.viscosity_radial_table(D)
+    d = drag_params(kind, "constant", tau=[0.05, 2.0], mesh_min=lo, mesh_max=hi, gas_damping=damp, dust_damping=damp,
+                    damp_visc=D.visc)
+    before = o.gu0.copy()
+    o.DragSource(0.04)
+    mb.DragSource(0.0, 0.04, d)
+    check_cons(o, mb, "DragSource damp_to_visc " + kind)
+    # and it is not the plain damping: the target velocity changed the answer
+    o2, _ = pair(nx, lo, hi, ns_gas=ns_gas, ns_dust=2, coordinates=coordinates, seed=31)
+    o2.set_drag(kind, "constant", tau=[0.05, 2.0])
+    o2.set_damping(0, **damp), o2.set_damping(1, **damp)
+    o2.DragSource(0.04)
+    assert np.max(np.abs(o2.gu0 - o.gu0)) > 1e-6 * np.max(np.abs(before))
+
+
+def test_damp_to_visc_contract(hiplib):
+    from artemis_amd import capi
+    from artemis_amd.pack import diffusion_params, drag_params
+    o, mb = pair((16, 8, 6), (0.5, 0.0, -1.0), (2.0, 6.0, 1.0), ns_gas=1, ns_dust=1, coordinates="cylindrical")
+    D = diffusion_params(1.4, conductivity=dict(type="conductivity", cond=0.1))
+    with pytest.raises(capi.ArtemisHipError) as e:  # drag.cpp:120
+        mb.DragSource(0.0, 1e-3, drag_params("self", damp_visc=D.cond))
+    assert "does not work with damping" in str(e.value)
+    D = diffusion_params(1.4, viscosity=dict(type="alpha", alpha=0.05, Omega0=1.0))
+    with pytest.raises(capi.ArtemisHipError) as e:
+        mb.DragSource(0.0, 1e-3, drag_params("self", damp_visc=D.visc))
+    assert "radial table" in str(e.value)
+    with pytest.raises(ValueError):
+        o.set_damp_to_visc(True)  # no viscosity set
+
+
 @pytest.mark.parametrize("nx,ns_dust", [((24, 16, 1), 0), ((24, 16, 1), 2), ((16, 12, 6), 1), ((30, 1, 1), 1)])
 def test_strat_boundary_conditions(hiplib, nx, ns_dust):
     """extrap on x1, inflow on x2 (strat.hpp:158-466) incl. the corner zones, where the x2 pass
