@@ -344,6 +344,34 @@ def test_disk_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
         assert np.array_equal(xa[key], xb[key]), key
 
 
+def test_disk_deck_damp_to_visc_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
+    """inputs/disk/disk_axi.in at half resolution with self drag and <gas/damping> damp_to_visc = true (the
+    radial damping zones relax the gas towards the alpha-viscosity inflow velocity, drag.cpp:109-121):
+    driver == oracle bit for bit on one block; four blocks on 1 and 2 ranks agree bit for bit."""
+    from test_oracle_pins import disk_oracle
+    big = 1.7976931348623157e308
+    ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "problem/polytropic_index=1.40", "physics/drag=true",
+          "drag/type=self", "gas/damping/inner_x1=0.6", "gas/damping/inner_x1_rate=30.0", "gas/damping/outer_x1=3.5",
+          "gas/damping/outer_x1_rate=30.0", "gas/damping/damp_to_visc=true"]
+    one = dict(deck=["disk", "disk_axi.in"], cycles=6, overrides=ov + ["parthenon/meshblock/nx1=64",
+                                                                     "parthenon/meshblock/nx2=32"])
+    r = run_world(1, one, tmp_path, "v1")[0]
+    o = disk_oracle("axi", 1.4, "ic", nx=(64, 32, 1))
+    o.set_drag("self", "constant")
+    o.set_damping(0, inner=(0.6, -big, -big), inner_rate=(30.0, 0.0, 0.0), outer=(3.5, big, big),
+                  outer_rate=(30.0, 0.0, 0.0))
+    o.set_damp_to_visc(True)
+    o.evolve(62.8, 6)
+    assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
+    assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
+    four = dict(one, overrides=ov + ["parthenon/meshblock/nx2=16"])
+    a, b = run_world(1, four, tmp_path, "v4"), run_world(2, four, tmp_path, "v4r2")
+    assert a[0]["meta"]["nblocks"] == 4 and [x["meta"]["nblocks"] for x in b] == [2, 2]
+    xa, xb = by_bounds(a), by_bounds(b)
+    for key in xa:
+        assert np.array_equal(xa[key], xb[key]), key
+
+
 def test_alpha_disk_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
     """inputs/diffusion/alpha_disk.in with the overrides of tst/scripts/diffusion/alpha_disk.py (disk pgen with
     mdot, alpha viscosity, beta cooling, `viscous` conditions): driver == oracle bit for bit on one
