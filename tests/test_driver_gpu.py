@@ -752,6 +752,41 @@ def test_disk_decks_own_block_layout(hiplib, g):
         disk_close(part, ref, 1e-12, blk, whole=full)
 
 
+def test_cartesian_disk_deck_uniform_variant(hiplib):
+    """inputs/disk/disk_cart_uniform.in -- the reference's disk_cart.in WITHOUT its static refinement region
+    (SMR is not built), on the deck's own 128^3 as one block, 10 cycles: the Cartesian branch of the disk
+    problem generator (cavity + exponential cut-off, mass at the origin inside the mesh), point-mass gravity
+    and alpha viscosity through the general fused stage, bit for bit against the oracle; and the checks the
+    reference test applies to its refined run hold on this uniform mesh too.  (tst/scripts/disk/disk.py:60-65
+    runs a 64^3 base mesh whose refined region has this zone size; a uniform 64^3 mesh leaves the cavity edge
+    unresolved and the explicit viscous update of the floor-density zones next to it drives dt to 5e-7 --
+    identically in the oracle and on the GPU -- so 64^3 uniform is not a usable stand-in.)"""
+    from artemis_amd.driver import Simulation
+    from oracle.oracle import Oracle
+    ov = [f"parthenon/meshblock/nx{d}=128" for d in (1, 2, 3)]
+    ov += ["parthenon/time/nlim=10", "problem/polytropic_index=1.40", "gas/de_switch=0.0"]
+    s = Simulation(DECK("disk", "disk_cart_uniform.in"), ov)
+    assert s.nblocks == 1 and s.uses_fused_path
+    o = Oracle((128, 128, 128), (-3.0,) * 3, (3.0,) * 3, ng=4, reconstruct="plm", riemann="hllc", gamma=1.4,
+               dfloor=1e-10, siefloor=1e-15, cfl=0.9, integrator="rk2", coordinates="cartesian",
+               bc=("outflow",) * 6, de_switch=0.0)
+    o.set_gravity_point(mass=1.0)
+    o.set_viscosity("alpha", alpha=1e-3, r0=1.0, Omega0=1.0)
+    o.pgen_disk(r0=1.0, rho0=1.0, dslope=-2.25, flare=0.25, h0=0.05, dens_min=1e-10, pres_min=1e-15,
+                polytropic_index=1.4, rcav=0.8, rexp=2.8, quiet_start=True)
+    d0 = s.interior(s.field("gas.prim"))[0].copy()
+    assert np.array_equal(s.field("gas.prim"), o.gprim)  # the problem generator and the first ghost fill
+    s.evolve(), o.evolve(62.8, 10)
+    assert s.ncycle == o.ncycle == 10 and s.time == o.time and s.dt == o.dt
+    assert np.array_equal(s.field("gas.prim"), o.gprim)
+    P = s.interior(s.field("gas.prim"))
+    d, T = P[0], P[5] * 0.4
+    assert not np.isnan(P).any() and d.min() > 0.0 and T.min() > 0.0 and 1e-4 < s.dt < 3e-2
+    err = np.sqrt((d0 * (d - d0) ** 2).sum()) / d0.sum()
+    print("cartesian disk, uniform 128^3: density error", err, "dt", s.dt)
+    assert err <= 6e-3
+
+
 def test_disk_deck_with_damping_towards_the_viscous_inflow(hiplib):
     """inputs/disk/disk_cyl.in with <physics> drag = true, <drag> type = self and a <gas/damping> node
     whose damp_to_visc = true (drag.hpp:101, drag.cpp:109-121): the radial wave-killing zones relax the gas
