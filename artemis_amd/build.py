@@ -11,6 +11,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # -ffp-contract=off: every expression tree stays unfused so results are bit-identical to the
 # CPU oracle (oracle/Makefile uses the same flag).  See DESIGN.md "Floating point".
+# -fno-builtin-sin/-cos (host code): sin(x) and cos(x) of one argument stay two glibc calls instead of one
+# sincos() (the CPU checker under tests/ is built the same way) -- the metric tables and the pgens' trigonometry then cannot depend
+# on which compiler merged what (DESIGN.md "Stated tolerance").
+NO_SINCOS = ["-fno-builtin-sin", "-fno-builtin-cos"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
              "-Wall", "-Wno-unused-function"]
 
@@ -44,7 +48,7 @@ def build_hip(force=False, verbose=False):
     procs = []
     for src in HIP_SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + HIP_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + HIP_FLAGS + (NO_SINCOS if src == "abi.hip" else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -57,7 +61,7 @@ def build_hip(force=False, verbose=False):
         for f in sorted(os.listdir(drv_dir)):
             if f.endswith(".cpp"):
                 obj = os.path.join(LIBDIR, "driver_" + f.replace(".cpp", ".o"))
-                cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off",
+                cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off"] + NO_SINCOS + [
                        "-I", os.path.join(ROOT, "include"), "-c", os.path.join(drv_dir, f), "-o", obj]
                 if verbose:
                     print(" ".join(cmd))

@@ -100,6 +100,8 @@ struct Link { // one directed ghost-slab transfer out of local block b through f
   int tag_send, tag_recv;
 };
 
+constexpr size_t kMaxTimedLaunches = 8192; // HIP event pairs kept per timed evolve()
+
 enum { PG_BLAST, PG_LINWAVE, PG_ADVECTION, PG_CONSTANT, PG_STRAT, PG_BUMP, PG_COND, PG_DISK };
 
 } // namespace
@@ -125,6 +127,7 @@ struct artemis_sim {
   int recon_gas = ARTEMIS_PLM, riemann_gas = ARTEMIS_HLLC, recon_dust = ARTEMIS_PLM,
       riemann_dust = ARTEMIS_HLLE;
   Real gamma = 1.66666666667, dfloor_gas = 1e-20, siefloor_gas = 1e-20, de_switch = 0.0;
+  Real cv_gas = 1.5; // IdealGas specific heat: <gas> cv, or kB / ((gamma-1) amu mu) (gas.cpp:105-116)
   Real dfloor_dust = 1e-20, cfl_gas = 0.8, cfl_dust = 0.8;
   // optional source packages (artemis.cpp:65-72): gravity, rotating_frame, drag
   bool do_gravity = false, do_rframe = false, do_drag = false, do_cooling = false;
@@ -192,6 +195,10 @@ struct artemis_sim {
   bool tuned = false; // the hand-tuned gas kernel covers this deck; otherwise the general cell-centred stage
   int overlap = 0; // 0 off, 1 shell launch + bulk launch, 2 one launch with in-kernel shell signalling
   DevBuf signal; // [0] shell-done counter, [1] wait-kernel timeout flag (as 32-bit words)
+  bool shell_wait_used = false; // an overlap-2 stage ran since the flag was last cleared
+  // "drop-in" accounting mode of the tuned path (bench.py): the last stage also writes the conserved state and
+  // every stage ends with the whole-block PrimToCons a Parthenon host runs as FillDerived (artemis_driver.cpp:261)
+  bool dropin = false;
   // test hook (ARTEMIS_LOOPBACK_COMM=1): route same-rank ghost slabs through the communicator
   // as messages to self, so one GPU exercises the RCCL send/recv path end to end
   bool loopback = false;
@@ -482,12 +489,22 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
     siefloor_gas = pin.GetOrAddReal("gas", "siefloor", 1.0e-20);
     de_switch = pin.GetOrAddReal("gas", "de_switch", 0.0);
     ns_gas = pin.GetOrAddInteger("gas", "nspecies", 1);
+    // gas.cpp:105-116; kB = amu = 1 in scale-free units (units.cpp:68-76)
+    if (pin.DoesParameterExist("gas", "cv")) {
+      if (pin.DoesParameterExist("gas", "mmw")) throw std::runtime_error("Cannot specify both cv and mmw");
+      cv_gas = pin.GetReal("gas", "cv");
+      if (!(cv_gas > 0)) throw std::runtime_error("Only positive cv allowed!");
+    } else {
+      const Real mu = pin.GetOrAddReal("gas", "mu", 1.);
+      if (!(mu > 0)) throw std::runtime_error("Only positive mean molecular weight allowed!");
+      cv_gas = 1.0 / ((gamma - 1.) * 1.0 * mu);
+    }
   }
   // <gas/viscosity>, <gas/conductivity> (gas.cpp:189-197, diffusion_coeff.hpp:84-136)
   std::memset(&diff, 0, sizeof diff);
   if (do_viscosity || do_conduction) {
     if (!do_gas) throw std::runtime_error("Viscosity / conduction requires the gas package");
-    diff.cv = 1.0 / ((gamma - 1.) * 1.0 * pin.GetOrAddReal("gas", "mu", 1.));
+    diff.cv = cv_gas;
     auto averaging = [&](const std::string &blk) {
       const std::string a = pin.GetOrAddString(blk, "averaging", "arithmetic");
       if (a == "arithmetic") return 0;
@@ -984,7 +1001,7 @@ void artemis_sim::problem_generator() {
   // kB = amu = 1 in scale-free units and mu = 1 (gas.cpp:106-116, units.cpp:68-76)
   struct { Real g_rho = 1, g_v[3] = {0, 0, 0}, g_temp = 1, d_rho = 1, d_v[3] = {0, 0, 0}; } cs;
   struct { Real h = 1, rho0 = 1, dens_min = 1e-5, d2g = 0.01; } st;
-  const Real cv = 1.0 / ((gamma - 1.) * 1.0 * pin.GetOrAddReal("gas", "mu", 1.));
+  const Real cv = cv_gas;
   if (pgen == PG_CONSTANT) {
     if (do_gas && ns_gas != 1) throw std::runtime_error("Constant pgen requires a single gas species.");
     if (pin.GetString("problem", "system") != "cartesian")
@@ -1385,7 +1402,7 @@ void artemis_sim::problem_generator() {
   }
   base = 0;
   if (do_cooling && do_gas) {
-    cool.cv = 1.0 / ((gamma - 1.) * 1.0 * pin.GetOrAddReal("gas", "mu", 1.));
+    cool.cv = cv_gas;
     cool_tref.alloc(nb, 1, N), cool_beta.alloc(nb, 1, N);
     const artemis_pack_t pk = make_pack(0);
     std::vector<Real> ht(N), hb(N);
@@ -1485,12 +1502,12 @@ void artemis_sim::step_general(bool want_dt, bool device_dt) {
     }
     if (do_cooling && do_gas) a.cooling = &cool;
     void *e0 = nullptr, *e1 = nullptr;
-    if (time_kernels) {
+    if (time_kernels && kev.size() < kMaxTimedLaunches) {
       e0 = artemis_rt_event_create(), e1 = artemis_rt_event_create();
       CK(artemis_rt_event_record(e0, stream), "event");
     }
     CK(artemis_hip_stage_general(&p, &a, stream), "stage_general");
-    if (time_kernels) {
+    if (e0) {
       CK(artemis_rt_event_record(e1, stream), "event");
       kev.emplace_back(e0, e1);
     }
@@ -1531,7 +1548,7 @@ void artemis_sim::step_fused(bool want_dt, bool device_dt) {
     a.bdt = beta[stage - 1] * dt;     // artemis_driver.cpp:168
     a.pcm = (stage == 1 && integrator == "vl2"); // artemis_driver.cpp:182
     a.prim_in = gprim[cur].tab(), a.prim_u1 = gprim[A].tab(), a.prim_out = gprim[out].tab();
-    a.cons_out = nullptr;
+    a.cons_out = (dropin && last) ? gu0.tab() : nullptr;
     a.cfl = cfl_gas;
     a.dt_dev = (last && want_dt) ? (device_dt ? tstate.p + 2 : dt_dev.p) : nullptr;
     if (device_dt) a.beta_dt_dev = tstate.p + 3 + (stage - 1); // beta*dt stays on the device
@@ -1543,14 +1560,14 @@ void artemis_sim::step_fused(bool want_dt, bool device_dt) {
     static const bool force_ovl = std::getenv("ARTEMIS_FORCE_OVERLAP") != nullptr;
     const bool ovl = overlap && (any_remote || (force_ovl && !links.empty()));
     void *e0 = nullptr, *e1 = nullptr;
-    if (time_kernels) {
+    if (time_kernels && kev.size() < kMaxTimedLaunches) { // (bounded: long runs with timing on must not leak events)
       e0 = artemis_rt_event_create(), e1 = artemis_rt_event_create();
       CK(artemis_rt_event_record(e0, stream), "event");
     }
     if (!ovl) {
       a.region = 0;
       CK(artemis_hip_stage_fused(&p, &a, stream), "stage_fused");
-      if (time_kernels) {
+      if (e0) {
         CK(artemis_rt_event_record(e1, stream), "event");
         kev.emplace_back(e0, e1);
       }
@@ -1561,15 +1578,19 @@ void artemis_sim::step_fused(bool want_dt, bool device_dt) {
       // while the bulk of the same launch is still running.
       unsigned *counter = reinterpret_cast<unsigned *>(signal.p);
       unsigned target = 0;
-      CK(artemis_rt_memset(counter, 0, sizeof(unsigned), stream), "memset");
+      shell_wait_used = true;
+      CK(artemis_rt_memset(counter, 0, sizeof(unsigned), stream), "memset"); // (the timeout flag stays sticky)
       CK(artemis_rt_event_record(ev0, stream), "event");
       a.region = 0, a.shell_done = counter, a.shell_target = &target;
       CK(artemis_hip_stage_fused(&p, &a, stream), "stage_fused");
-      if (time_kernels) {
+      if (e0) {
         CK(artemis_rt_event_record(e1, stream), "event");
         kev.emplace_back(e0, e1);
       }
       CK(artemis_rt_stream_wait_event(comm_stream, ev0), "wait");
+      // (ARTEMIS_TEST_SHELL_TARGET_BUMP: test hook, waits for more workgroups than exist -> the timeout path)
+      static const char *bump = std::getenv("ARTEMIS_TEST_SHELL_TARGET_BUMP");
+      if (bump) target += static_cast<unsigned>(std::atoi(bump));
       CK(artemis_hip_wait_counter(counter, target, counter + 1, comm_stream), "wait_counter");
       fill_ghosts_start(out, comm_stream);
       fill_ghosts_finish(out, comm_stream);
@@ -1582,16 +1603,20 @@ void artemis_sim::step_fused(bool want_dt, bool device_dt) {
       fill_ghosts_start(out, comm_stream);
       a.region = 2;
       CK(artemis_hip_stage_fused(&p, &a, stream), "stage_fused bulk");
-      if (time_kernels) {
+      if (e0) {
         CK(artemis_rt_event_record(e1, stream), "event");
         kev.emplace_back(e0, e1);
       }
       fill_ghosts_finish(out, comm_stream);
     }
+    if (dropin) { // FillDerived = PrimToCons over the entire block (artemis.cpp:123, artemis_driver.cpp:261)
+      const artemis_pack_t po = make_pack(out);
+      CK(artemis_hip_prim_to_cons(&po, stream), "PrimToCons");
+    }
     cur = out;
   }
   base = cur;
-  cons_valid = false;
+  cons_valid = dropin;
 }
 
 // One step on the per-task path (artemis_driver.cpp:157-261 literally).
@@ -1660,6 +1685,8 @@ long artemis_sim::evolve(long max_cycles) {
   }
   for (auto &pr : kev) artemis_rt_event_destroy(pr.first), artemis_rt_event_destroy(pr.second);
   kev.clear();
+  CK(artemis_rt_memset(signal.p, 0, 2 * sizeof(unsigned), stream), "memset"); // counter + sticky timeout flag
+  shell_wait_used = false;
   CK(artemis_rt_device_sync(), "sync");
   const auto t0 = std::chrono::steady_clock::now();
   long n = 0;
@@ -1670,7 +1697,7 @@ long artemis_sim::evolve(long max_cycles) {
   // (a gravity time window is evaluated against the host's clock, which the device loop does not keep)
   // (so is the orbit of a binary)
   const bool grav_window = do_gravity && (grav.tstart > -DBL_MAX || grav.tstop < DBL_MAX || grav.type == ARTEMIS_GRAVITY_BINARY);
-  const bool async_loop = use_fused && tlim <= 0.0 && !grav_window && (!multi || comm.allreduce_min_dev) &&
+  const bool async_loop = use_fused && tlim < 0.0 && !grav_window && (!multi || comm.allreduce_min_dev) &&
                           std::getenv("ARTEMIS_SYNC_LOOP") == nullptr;
   if (async_loop) {
     long todo = -1;
@@ -1713,6 +1740,8 @@ long artemis_sim::evolve(long max_cycles) {
     CK(artemis_rt_memcpy_d2h(h, tstate.p, sizeof h, stream), "d2h");
     CK(artemis_rt_stream_sync(stream), "sync");
     time = h[0], dt = h[1];
+    if (!std::isfinite(dt) || !(dt > 0.0) || !std::isfinite(time))
+      throw std::runtime_error("the device-side time loop produced a non-finite or non-positive dt");
   }
   while (!async_loop && (tlim < 0.0 || time < tlim) && (nlim < 0 || ncycle < nlim) &&
          (max_cycles < 0 || n < max_cycles)) {
@@ -1739,6 +1768,19 @@ long artemis_sim::evolve(long max_cycles) {
   }
   CK(artemis_rt_device_sync(), "sync");
   last_wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (shell_wait_used) {
+    // The comm stream's wait kernel gives up after its spin limit instead of hanging the GPU (the two
+    // streams did not run concurrently, or the counter never reached its target).  The slabs packed
+    // behind it may then hold unfinished shell data: the run is invalid, say so and stop overlapping.
+    unsigned sig[2] = {0u, 0u};
+    CK(artemis_rt_memcpy_d2h(sig, signal.p, sizeof sig, stream), "d2h");
+    CK(artemis_rt_stream_sync(stream), "sync");
+    if (sig[1] != 0u) {
+      overlap = 0;
+      throw HipFail("overlap mode 2: the comm stream timed out waiting for the boundary-shell workgroups "
+                    "(stale ghost zones may have been exchanged); falling back to overlap = 0 -- re-run from a valid state");
+    }
+  }
   kernel_ms_sum = 0.0, kernel_launches = 0;
   for (auto &pr : kev) {
     const double ms = artemis_rt_event_elapsed_ms(pr.first, pr.second);
@@ -1941,6 +1983,19 @@ int artemis_sim_set_overlap(artemis_sim_t *s, int overlap) {
   return 0;
 }
 void artemis_sim_set_kernel_timing(artemis_sim_t *s, int on) { s->time_kernels = on != 0; }
+int artemis_sim_set_dropin(artemis_sim_t *s, int on) {
+  if (on && !(s->use_fused && s->tuned)) {
+    g_sim_err = "drop-in accounting applies to the tuned fused kernel only";
+    return 1;
+  }
+  s->dropin = on != 0;
+  return 0;
+}
+int artemis_sim_overlap(const artemis_sim_t *s) { return s->overlap; }
+void artemis_sim_species(const artemis_sim_t *s, int *ns_gas, int *ns_dust) {
+  if (ns_gas) *ns_gas = s->ns_gas;
+  if (ns_dust) *ns_dust = s->ns_dust;
+}
 void artemis_sim_dims(const artemis_sim_t *s, int *d) {
   d[0] = s->nb, d[1] = s->ni, d[2] = s->nj, d[3] = s->nk, d[4] = s->is, d[5] = s->ie;
   d[6] = s->js, d[7] = s->je, d[8] = s->ks, d[9] = s->ke, d[10] = s->ng;

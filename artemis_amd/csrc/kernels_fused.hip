@@ -566,12 +566,13 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
 // Comm-stream side of the shell-first hand-off: one wave polls the counter (relaxed, agent
 // scope, with s_sleep) until `target` workgroups have published, then acquires.  Kernels queued
 // behind it on the same stream (halo packs) start with clean caches and see the shell's stores.
-__global__ void wait_counter_kernel(unsigned *counter, unsigned target, unsigned *timeout_flag) {
+__global__ void wait_counter_kernel(unsigned *counter, unsigned target, unsigned *timeout_flag,
+                                    unsigned long long spin_limit) {
   if (threadIdx.x != 0) return;
   unsigned long long spins = 0;
   while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
     __builtin_amdgcn_s_sleep(32);
-    if (++spins > (1ull << 26)) { // ~seconds: never hang the GPU on a logic error
+    if (++spins > spin_limit) { // ~seconds: never hang the GPU on a logic error
       if (timeout_flag) *timeout_flag = 1u;
       break;
     }
@@ -622,7 +623,9 @@ void launch_advance_dt(double *state, double tlim, int nstages, const double *be
 }
 
 void launch_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, hipStream_t s) {
-  hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, s, counter, target, timeout_flag);
+  unsigned long long limit = 1ull << 26; // ARTEMIS_WAIT_SPIN_LIMIT: diagnostics / the timeout test
+  if (const char *e = getenv("ARTEMIS_WAIT_SPIN_LIMIT")) limit = std::max(1ll, atoll(e));
+  hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, s, counter, target, timeout_flag, limit);
 }
 
 int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon,

@@ -167,6 +167,9 @@ def _declare(L):
     L.artemis_sim_uses_tuned_kernel.argtypes = [vp]
     L.artemis_sim_set_path.argtypes = [vp, C.c_char_p]
     L.artemis_sim_set_overlap.argtypes = [vp, i]
+    L.artemis_sim_overlap.argtypes = [vp]
+    L.artemis_sim_set_dropin.argtypes = [vp, i]
+    L.artemis_sim_species.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.artemis_sim_set_kernel_timing.argtypes = [vp, i]
     L.artemis_sim_dims.argtypes = [vp, C.POINTER(i)]
     L.artemis_sim_get_field.argtypes = [vp, C.c_char_p, i, vp]
@@ -196,6 +199,9 @@ class Simulation:
         self.L.artemis_sim_dims(self.h, d)
         (self.nblocks, self.ni, self.nj, self.nk, self.is_, self.ie, self.js, self.je, self.ks,
          self.ke, self.ng) = list(d)
+        ng_, nd_ = C.c_int(0), C.c_int(0)
+        self.L.artemis_sim_species(self.h, C.byref(ng_), C.byref(nd_))
+        self.ns_gas, self.ns_dust = ng_.value, nd_.value
 
     def close(self):
         if getattr(self, "h", None):
@@ -234,6 +240,13 @@ class Simulation:
         if self.L.artemis_sim_set_overlap(self.h, mode):
             raise RuntimeError(self.L.artemis_sim_last_error().decode())
 
+    overlap = property(lambda s: s.L.artemis_sim_overlap(s.h))
+
+    def set_dropin(self, on):
+        """Tuned path only: also write cons on the last stage and run the whole-block PrimToCons per stage."""
+        if self.L.artemis_sim_set_dropin(self.h, int(on)):
+            raise RuntimeError(self.L.artemis_sim_last_error().decode())
+
     def set_kernel_timing(self, on):
         self.L.artemis_sim_set_kernel_timing(self.h, int(on))
 
@@ -243,8 +256,9 @@ class Simulation:
         return ms, n.value
 
     def field(self, name, block=0):
-        nvar = {"gas.prim": 6, "gas.cons": 6, "dust.prim": 4, "dust.cons": 4}[name]
-        buf = np.empty((nvar * 8, self.nk, self.nj, self.ni))  # room for up to 8 species
+        nvar = {"gas.prim": 6 * self.ns_gas, "gas.cons": 6 * self.ns_gas, "dust.prim": 4 * self.ns_dust,
+                "dust.cons": 4 * self.ns_dust}[name]
+        buf = np.empty((max(nvar, 1), self.nk, self.nj, self.ni))  # sized from the sim's species counts
         nv = self.L.artemis_sim_get_field(self.h, name.encode(), block, buf.ctypes.data)
         if nv < 0:
             raise RuntimeError(self.L.artemis_sim_last_error().decode())
@@ -259,7 +273,7 @@ class Simulation:
         return list(o)
 
     def history(self):
-        o = (C.c_double * 64)()
+        o = (C.c_double * (6 + 4 * self.ns_dust))()
         n = self.L.artemis_sim_history(self.h, o)
         if n < 0:
             raise RuntimeError(self.L.artemis_sim_last_error().decode())

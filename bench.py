@@ -38,7 +38,7 @@ def overrides(n_gpus, per_gpu, steps_total, extra=()):
     if shape is None:
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
     ov = ["gas/riemann=hllc", "problem/symmetry=spherical", "problem/radius=0.03",
-          "problem/samples=0", "parthenon/time/tlim=-1.0", f"parthenon/time/nlim={steps_total}"]
+          "problem/samples=0", "parthenon/time/tlim=-1.0", "parthenon/time/nlim=-1"]  # every evolve() passes its budget
     for d, (s, n) in enumerate(zip(shape, per_gpu), start=1):
         half = float(s) * n / per_gpu[0] * (per_gpu[0] / 256.0)  # dx = 2/256 whatever the size
         ov += [f"parthenon/mesh/nx{d}={s * n}", f"parthenon/meshblock/nx{d}={n}",
@@ -46,18 +46,45 @@ def overrides(n_gpus, per_gpu, steps_total, extra=()):
     return ov + list(extra)
 
 
-def cpu_baseline(n, cycles):
-    """Time the CPU oracle on the host cores: n^3 Sedov, `cycles` cycles after one warm-up."""
+def cpu_baseline(n, cycles, threads):
+    """Time the CPU oracle on `threads` host cores: n^3 Sedov, `cycles` cycles after one warm-up.
+    (The oracle's pgen and its first cycle first-touch every array inside the same OpenMP
+    k-j decomposition the sweeps use, so pages sit on the NUMA node of the thread that works on them.)"""
     from oracle.oracle import Oracle
     o = Oracle((n, n, n), (-n / 256.0,) * 3, (n / 256.0,) * 3, ng=2, reconstruct="plm",
                riemann="hllc", gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3,
-               bc=("outflow",) * 6, integrator="rk2")
+               bc=("outflow",) * 6, integrator="rk2", nthreads=threads)
     o.pgen_blast(radius=0.03, internal_energy=1.0, p0=1e-5, d0=1.0, samples=0)
     o.evolve(-1.0, 1)
     t0 = time.perf_counter()
     done = o.evolve(-1.0, 1 + cycles)
     dt = time.perf_counter() - t0
     return n ** 3 * done / dt, dt, done
+
+
+def kernel_source_sha1():
+    """Identity of the tuned stage kernel's sources: a PMC traffic record is only quoted next to a
+    timing when it was measured on these very sources (scripts/pmc_traffic.py writes the same hash)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("kernels_fused.hip", "device_math.hpp", "pack_view.hpp"):
+        h.update(open(os.path.join(ROOT, "artemis_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def measured_traffic(name):
+    """HBM bytes per launch from the newest profiles/*<name>*pmc_traffic.json whose source hash matches
+    the kernel sources of this checkout, else None (a stale record is never reported)."""
+    import glob
+    want = kernel_source_sha1()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*%spmc_traffic.json" % name)), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if rec.get("kernel_source_sha1") == want:
+            return rec.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def cpu_baseline_ssheet(n, ndust, cycles):
@@ -86,6 +113,8 @@ def main():
     ap.add_argument("--n", type=int, default=256, help="cells per GPU per dimension")
     ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the `dropin` legs (fused + cons + whole-block PrimToCons, and the per-task chain)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: exchange halos after the whole stage kernel instead of behind its bulk")
     ap.add_argument("--overlap-mode", type=int, default=2, choices=[1, 2],
@@ -144,7 +173,7 @@ def main():
               "dust/nspecies=%d" % args.dust, "dust/cfl=0.3", "dust/reconstruct=plm", "dust/riemann=hlle",
               "dust/dfloor=1.0e-10", "dust/stopping_time/type=constant",
               "dust/stopping_time/tau=" + ",".join(["0.1"] * args.dust), "drag/type=simple_dust",
-              "parthenon/time/tlim=-1.0", "parthenon/time/nlim=%d" % (args.warmup + args.steps)]
+              "parthenon/time/tlim=-1.0", "parthenon/time/nlim=-1"]
         sim = Simulation(deck, ov)
     elif args.workload == "disk_sph":
         if args.gpus != 1:
@@ -152,7 +181,7 @@ def main():
         deck = os.path.join(ROOT, "inputs", "disk", "disk_sph.in")
         sc = max(1, args.n // 128)
         dims = (128 * sc, 64 * sc, 64 * sc)
-        ov = ["parthenon/time/nlim=%d" % (args.warmup + args.steps)]
+        ov = ["parthenon/time/nlim=-1"]
         for d, m in enumerate(dims, 1):
             ov += ["parthenon/mesh/nx%d=%d" % (d, m), "parthenon/meshblock/nx%d=%d" % (d, m)]
         sim = Simulation(deck, ov)
@@ -175,7 +204,8 @@ def main():
         torch.cuda.synchronize()
 
     sim.evolve(args.warmup)
-    sim.set_kernel_timing(True)
+    # The timed region runs the production loop (device-resident dt, hipGraph replay on one rank, no
+    # per-kernel events); per-kernel durations for `roofline` come from a separate short leg below.
     barrier()
     t0 = time.perf_counter()
     done = sim.evolve(args.steps)
@@ -186,11 +216,42 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    sim.set_kernel_timing(True)   # HIP events around the dominant kernel, on the stream it is launched on
+    sim.evolve(max(5, min(args.steps, 40)))
     kms, nlaunch = sim.kernel_ms()
+    sim.set_kernel_timing(False)
+    hist = sim.history()
+    dropin = None
+    if args.workload == "sedov3d" and args.gpus == 1 and not args.loopback and not args.no_dropin and sim.uses_tuned_kernel:
+        # What a Parthenon host sees: (i) the fused kernel also writing `cons` on the last
+        # stage + the whole-block PrimToCons (FillDerived) after every stage's boundary fill; (ii) the
+        # per-task chain of INTEGRATION.md section 2.  Same deck, same state, outside the timed region.
+        def leg(cycles):
+            sim.evolve(2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_ = sim.evolve(cycles)
+            torch.cuda.synchronize()
+            return sim.total_zones * n_ / (time.perf_counter() - t1)
+        sim.set_dropin(True)
+        r_cons = leg(max(10, min(args.steps, 60)))
+        sim.set_dropin(False)
+        sim.set_path("unfused")
+        r_task = leg(max(5, min(args.steps, 25)))
+        sim.set_path("fused")
+        zc_bytes = 2.0 * ALG_BYTES_PER_CELL_STAGE  # rk2: 480 B per zone-cycle
+        dropin = {"unit": "zone-cycles/s",
+                  "fused": None, "fused_cons_p2c": r_cons, "per_task": r_task,
+                  "frac_fused_cons_p2c": r_cons * zc_bytes / 1.0e9 / HBM_PEAK_GBS,
+                  "frac_per_task": r_task * zc_bytes / 1.0e9 / HBM_PEAK_GBS,
+                  "note": "fused = `value` (primitives in, primitives out; cons never materialised); "
+                          "fused_cons_p2c = same kernel also writing cons on the last stage + the whole-block PrimToCons "
+                          "a Parthenon FillDerived runs after every stage's boundary fill; per_task = one kernel per "
+                          "Parthenon task (CalculateFluxes, epilogue = ApplyUpdate..ConsToPrim, BCs, PrimToCons). "
+                          "Fractions use the same 480 B per zone-cycle."}
     total_zones = sim.total_zones
     local_zones = sim.local_zones
     fused = sim.uses_fused_path
-    hist = sim.history()
 
     if rank == 0:
         value = total_zones * args.steps / elapsed
@@ -240,9 +301,11 @@ def main():
                 achieved = alg / (kms * 1.0e-3) / 1.0e9
                 traffic = None
                 pmc = os.path.join(ROOT, "profiles", "r01c_cfg3_pmc_traffic.json")
-                if args.n == 4096 and args.dust == 1 and os.path.exists(pmc):  # measured for this size only
+                if args.n == 4096 and args.dust == 1 and os.path.exists(pmc):  # measured for this size only (round 1)
                     try:
-                        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                        rec = json.load(open(pmc))
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        out["config"]["traffic_measured_at"] = "round 1 kernels (profiles/r01c_cfg3_pmc_traffic.json)"
                     except Exception:
                         traffic = None
                 out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -252,18 +315,20 @@ def main():
         elif fused and nlaunch:
             alg = ALG_BYTES_PER_CELL_STAGE * local_zones  # bytes per launch (one stage, one rank)
             achieved = alg / (kms * 1.0e-3) / 1.0e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            # PMC counters cannot be read from inside the process: scripts/pmc_traffic.py measures them
+            # (separate rocprofv3 --pmc passes of this very command) and tags the record with the hash of
+            # the kernel sources; a record measured on other sources is not reported.
+            traffic, traffic_src = (measured_traffic("") if args.n == 256 else (None, None))
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_source": traffic_src,
                                "kernel": "stage_fused_kernel<hllc,plm>", "launch_ms": kms,
                                "launches_timed": nlaunch,
                                "algorithmic_bytes_per_launch": alg}
+            if dropin:
+                dropin["fused"] = value
+                dropin["frac_fused"] = value * 2.0 * ALG_BYTES_PER_CELL_STAGE / 1.0e9 / HBM_PEAK_GBS
+                out["dropin"] = dropin
         if args.workload == "disk_sph":
             pass  # (CPU side: tests/test_oracle_pins.py times the oracle on the same deck: ~20 s for 10 cycles of 128x64x64)
         elif args.workload == "ssheet_dust" and not args.no_cpu_baseline:

@@ -74,6 +74,15 @@ int artemis_sim_set_path(artemis_sim_t *sim, const char *which);
  * neighbours only).  0 = off; 1 = boundary-shell launch, then bulk launch; 2 = one launch whose
  * shell workgroups run first and signal a device counter the comm stream waits on. */
 int artemis_sim_set_overlap(artemis_sim_t *sim, int overlap);
+/* current mode (a timed-out mode-2 wait resets it to 0 and makes artemis_sim_evolve fail) */
+int artemis_sim_overlap(const artemis_sim_t *sim);
+/* Drop-in accounting for the tuned fused kernel (bench.py's `dropin` object): the last stage also writes
+ * the conserved state (cons_out) and every stage ends with the whole-block PrimToCons a Parthenon host
+ * runs as FillDerived (artemis.cpp:123, artemis_driver.cpp:261) -- what the fused path costs when the host
+ * keeps `cons` as its Independent / Restart state.  Same results; returns non-zero off the tuned path. */
+int artemis_sim_set_dropin(artemis_sim_t *sim, int on);
+/* number of gas / dust species (sizes the buffers of artemis_sim_get_field and artemis_sim_history) */
+void artemis_sim_species(const artemis_sim_t *sim, int *ns_gas, int *ns_dust);
 
 /* Block layout of this rank. dims = {nblocks_local, ni, nj, nk, is, ie, js, je, ks, ke, ng}. */
 void artemis_sim_dims(const artemis_sim_t *sim, int *dims);

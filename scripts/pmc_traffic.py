@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Measure the HBM traffic of the dominant kernel with rocprofv3 PMC counters and write the record
+bench.py quotes as `roofline.traffic`.
+
+    gpurun -- python3 scripts/pmc_traffic.py [--tag r02] [--workload sedov3d|disk_sph|ssheet_dust] [bench args]
+
+Two separate `rocprofv3 --pmc` passes (FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2:
+MI355X_MICROARCH.md "rocprofv3 PMC slots"; nothing but --kernel-trace next to --pmc) of
+`python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline`, whose `dropin` legs also run the per-task
+kernels.  Those give the calibration: gfx950's FETCH_SIZE under-reports coalesced streams (exactly 1/2
+for 16-byte lanes per the guide; this code base loads 8 bytes per lane), so the read correction is
+measured in the same profile on kernels whose byte count is known exactly (cons_to_prim: 5 arrays in,
+5 out over the interior; prim_to_cons: 5 in, 9 out over the whole block) and applied to the stage kernel.
+The record carries the sha1 of the kernel sources: bench.py reports it only while they are unchanged.
+This script never touches the GPU itself; the profiled program is started by rocprofv3.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run_pass(counter, outdir, bench_args):
+    os.makedirs(outdir, exist_ok=True)
+    cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "-o", "p", "--",
+           "python3", os.path.join(ROOT, "bench.py")] + bench_args
+    env = dict(os.environ, TMPDIR="/tmp")
+    with open(os.path.join(outdir, "run.log"), "w") as log:
+        subprocess.check_call(cmd, cwd=ROOT, env=env, stdout=log, stderr=subprocess.STDOUT)
+    files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
+    assert files, "no counter_collection.csv under " + outdir
+    acc = {}
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            k = row["Kernel_Name"]
+            s = acc.setdefault(k, [0.0, 0])
+            s[0] += float(row["Counter_Value"])
+            s[1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+
+def pick(table, *needles):
+    out = {k: v for k, v in table.items() if all(n in k for n in needles)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", default="r02")
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--out", default=None)
+    args, extra = ap.parse_known_args()
+    from bench import ALG_BYTES_PER_CELL_STAGE, kernel_source_sha1
+    bench_args = ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--n", str(args.n)] + extra
+    scratch = os.path.join(ROOT, "gpurun_out", "pmc_%s" % args.tag)
+    fetch = run_pass("FETCH_SIZE", scratch + "_fetch", bench_args)
+    write = run_pass("WRITE_SIZE", scratch + "_write", bench_args)
+    n, ng = args.n, 2
+    interior, entire = float(n) ** 3, float(n + 2 * ng) ** 3
+    kib = 1024.0
+    calib = {}
+    for name, rd, wr in (("cons_to_prim_kernel", 5 * 8 * interior, 5 * 8 * interior),
+                         ("prim_to_cons_kernel", 5 * 8 * entire, 9 * 8 * entire)):
+        f, w = pick(fetch, name), pick(write, name)
+        if f and w:
+            fk, wk = list(f.values())[0][0], list(w.values())[0][0]
+            calib[name] = {"true_read_KiB": rd / kib, "FETCH_SIZE_KiB": fk, "fetch_ratio": fk * kib / rd,
+                           "true_write_KiB": wr / kib, "WRITE_SIZE_KiB": wk, "write_ratio": wk * kib / wr}
+    assert calib, "calibration kernels not in the profile (did the dropin legs run?)"
+    ratio = sum(c["fetch_ratio"] for c in calib.values()) / len(calib)
+    wratio = sum(c["write_ratio"] for c in calib.values()) / len(calib)
+    stage = {}
+    for k, (fk, cnt) in pick(fetch, "stage_fused_kernel").items():
+        wk = write.get(k, (0.0, 0))[0]
+        stage[k] = {"launches": cnt, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
+                    "read_bytes_corrected": fk * kib / ratio, "write_bytes": wk * kib}
+    assert stage, "stage_fused_kernel not in the profile"
+    # mean over launches of all instantiations (rk2: one launch of each of the two stage variants per step,
+    # plus the variants the dropin leg adds -- weight by launch count)
+    tot = sum(v["launches"] for v in stage.values())
+    per_launch = sum(v["launches"] * (v["read_bytes_corrected"] + v["write_bytes"]) for v in stage.values()) / tot
+    rec = {
+        "source": "scripts/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) "
+                  "of `python3 bench.py %s`, MI355X" % " ".join(bench_args),
+        "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch",
+        "kernel_source_sha1": kernel_source_sha1(),
+        "calibration": dict(calib, fetch_correction="true_read = FETCH_SIZE / %.4f (mean of the calibration kernels); "
+                                                    "WRITE_SIZE as reported (calibrates at %.3f)" % (ratio, wratio)),
+        "stage_fused_kernel": stage,
+        "hbm_bytes_per_launch": per_launch,
+        "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_STAGE * interior,
+    }
+    out = args.out or os.path.join(ROOT, "gpurun_out", "%s_pmc_traffic.json" % args.tag)
+    json.dump(rec, open(out, "w"), indent=1)
+    print(json.dumps({"hbm_bytes_per_launch": per_launch, "fetch_ratio": ratio, "write_ratio": wratio, "out": out}))
+
+
+if __name__ == "__main__":
+    main()

@@ -100,3 +100,40 @@ def test_ctypes_mirror_matches_the_c_header(tmp_path):
         assert seen[cname][0] == C.sizeof(ct), (cname, seen[cname][0], C.sizeof(ct))
         if last:
             assert seen[cname][1] == getattr(ct, last).offset, (cname, last)
+
+
+def test_metric_tables_are_plain_glibc_sin_cos():
+    """artemis_hip_metric_fill (host code, no GPU needed) against Python's math.sin / math.cos, which call
+    glibc's sin() and cos() one at a time: BITWISE.  All host code of the repo (this library, the driver, the
+    oracle) is built with -fno-builtin-sin/-cos so no compiler merges a sin + cos pair into sincos(); if a
+    toolchain ever breaks that, this test reports the ulp distance (the stated bound is 4 ulp)."""
+    import math
+    import numpy as np
+    from artemis_amd import capi
+    L = capi.load()
+    p = capi.Pack()
+    p.nblocks, p.nghost, p.nx1, p.nx2, p.nx3 = 1, 2, 8, 12, 6
+    p.coords = capi.SPHERICAL3D
+    geom = np.array([0.2, 0.1, 0.31, 0.2, -1.0, 0.41])
+    n = L.artemis_hip_metric_count(C.byref(p))
+    nj, nk = 16, 10
+    assert n == 6 * (nj + 1) + 2 * (nk + 1)
+    m = np.zeros(n)
+    capi.check(L.artemis_hip_metric_fill(C.byref(p), geom.ctypes.data, m.ctypes.data))
+    st = nj + 1
+    want = np.zeros(n)
+    for j in range(nj + 1):
+        xf = geom[2] + j * geom[3]
+        want[0 * st + j], want[1 * st + j] = math.cos(xf), math.sin(xf)
+    for j in range(nj):  # spherical.hpp:61-68 x2v and the sines / cosine the kernels read
+        x0, x1 = geom[2] + j * geom[3], geom[2] + (j + 1) * geom[3]
+        ctm, ctp = want[j], want[j + 1]
+        x2v = ((want[st + j + 1] - want[st + j]) - x1 * ctp + x0 * ctm) / abs(ctm - ctp)
+        want[2 * st + j], want[3 * st + j] = x2v, math.sin(x2v)
+        want[4 * st + j], want[5 * st + j] = math.sin(0.5 * (x0 + x1)), math.cos(x2v)
+    for k in range(nk):
+        x3v = 0.5 * ((geom[4] + k * geom[5]) + (geom[4] + (k + 1) * geom[5]))
+        want[6 * st + k], want[6 * st + (nk + 1) + k] = math.cos(x3v), math.sin(x3v)
+    if not np.array_equal(m, want):
+        ulp = np.abs(m - want) / np.spacing(np.maximum(np.abs(want), 1e-300))
+        assert False, "metric tables differ from glibc sin / cos by up to %.1f ulp" % ulp.max()

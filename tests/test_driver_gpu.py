@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import Oracle
+from pins import ADVECTION, LINWAVE, advection_history, linwave_waves
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,10 +30,9 @@ def linwave_overrides(N, recon, riem, wave, vflow, mb=None):
 @pytest.mark.parametrize("recon,riem", [("plm", "hllc"), ("plm", "hlle"), ("plm", "llf"), ("ppm", "hllc")])
 def test_linwave_single_block_bitwise_and_thresholds(hiplib, recon, riem):
     from artemis_amd.driver import Simulation
-    thr = {"plm": ([2.23e-7, 2.23e-7, 2.21e-7], [0.29, 0.29, 0.30]),
-           "ppm": ([1.75e-7, 1.75e-7, 1.11e-7], [0.44, 0.44, 0.42])}[recon]
+    thr = (LINWAVE[recon]["rms_err_n32_max"], LINWAVE[recon]["n32_over_n16_max"])  # tests/golden/reference_pins.json
     e32 = []
-    for wi, (wave, vflow) in enumerate([(0, 0.0), (4, 0.0), (3, 1.0)]):
+    for wi, (wave, vflow) in enumerate(linwave_waves()):
         errs = {}
         for N in (16, 32):
             sim = Simulation(DECK("linwave", "linear_wave.in"), linwave_overrides(N, recon, riem, wave, vflow))
@@ -92,16 +92,16 @@ def test_advection_history_pins(hiplib, riem):
         sim.evolve()
         return sim
 
-    def equiv(a, b, tol=1.0e-4):  # advection.py:95-99
+    def equiv(a, b, tol=ADVECTION["equiv_rel_tol"]):  # advection.py:95-99
         return 2.0 * abs(a - b) / (abs(a) + abs(b)) <= tol
     s16, s = run(16), run(32)
-    assert s.nblocks == 16 and s.ncycle == 56 and equiv(s.time, 1.0) and equiv(s.dt, 1.11612e-02)
-    exp = [6.75, 2.25, 4.5, 4.5, 9.45, 6.075, 6.75, 2.25, 4.5, 4.5, 6.75, -2.25, -4.5, -4.5]
-    for g, e in zip(s.history(), exp):
+    H = ADVECTION["history_n32"]  # tests/golden/reference_pins.json
+    assert s.nblocks == H["nbtotal"] and s.ncycle == H["cycle"] and equiv(s.time, H["time"]) and equiv(s.dt, H["dt"])
+    for g, e in zip(s.history(), advection_history()):
         assert equiv(g, e)
     e16, e32 = s16.errors(), s.errors()
     for k in range(3):
-        assert e32[k] <= 2.21e-7 and e32[k] / e16[k] <= 0.30
+        assert e32[k] <= ADVECTION["plm"]["rms_err_n32_max"] and e32[k] / e16[k] <= ADVECTION["plm"]["n32_over_n16_max"]
     assert "%e" % e32[1] == "%e" % e32[2]
 
 

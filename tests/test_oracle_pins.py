@@ -8,15 +8,18 @@ import numpy as np
 import pytest
 
 from oracle.oracle import Oracle
+from pins import ADVECTION, DISK, DRAG, LANDINGS, LINWAVE, PINS, SSHEET, advection_history, linwave_waves
 
-LW = dict(ng=4, gamma=1.66666666667, cfl=0.9, bc=("periodic",) * 6, integrator="rk2")
+# every reference-held number below comes from tests/golden/reference_pins.json (cited there)
+LW = dict(ng=LINWAVE["mesh"]["nghost"], gamma=LINWAVE["gamma"], cfl=LINWAVE["cfl"], bc=("periodic",) * 6,
+          integrator=LINWAVE["integrator"])
 
 
 def _linwave(N, recon, riem, wave, vflow):
     # tst/scripts/hydro/linwave.py:41-63 overrides on inputs/linwave/linear_wave.in
     o = Oracle((N, N // 2, N // 2), (0, 0, 0), (3.0, 1.5, 1.5), reconstruct=recon, riemann=riem, **LW)
-    tlim = o.pgen_linear_wave(wave, 1.0e-6, vflow)
-    o.evolve(tlim, 1000)
+    tlim = o.pgen_linear_wave(wave, LINWAVE["amp"], vflow)
+    o.evolve(tlim, LINWAVE["nlim"])
     return o.linear_wave_errors()[0]
 
 
@@ -24,11 +27,8 @@ def _linwave(N, recon, riem, wave, vflow):
 @pytest.mark.parametrize("riem", ["hllc", "hlle", "llf"])
 def test_linwave_thresholds(recon, riem):
     # thresholds: tst/scripts/hydro/linwave.py:95-107
-    if recon == "plm":
-        err_thr, conv_thr = [2.23e-7, 2.23e-7, 2.21e-7], [0.29, 0.29, 0.30]
-    else:
-        err_thr, conv_thr = [1.75e-7, 1.75e-7, 1.11e-7], [0.44, 0.44, 0.42]
-    waves = [(0, 0.0), (4, 0.0), (3, 1.0)]  # L-sound, R-sound, entropy (linwave.py:64-72)
+    err_thr, conv_thr = LINWAVE[recon]["rms_err_n32_max"], LINWAVE[recon]["n32_over_n16_max"]
+    waves = linwave_waves()  # L-sound, R-sound, entropy (linwave.py:64-72)
     e32 = []
     for wi, (wave, vflow) in enumerate(waves):
         e16 = _linwave(16, recon, riem, wave, vflow)
@@ -44,10 +44,11 @@ def test_linwave_thresholds(recon, riem):
 def test_linwave_threshold_is_tight():
     """The reference's thresholds sit <1% above its own results (plm+hlle sound 2.23e-7,
     plm+llf entropy 2.21e-7): the oracle must land within that margin, not just below."""
-    assert 2.20e-7 < _linwave(32, "plm", "hlle", 0, 0.0) <= 2.23e-7
-    assert 2.19e-7 < _linwave(32, "plm", "llf", 3, 1.0) <= 2.21e-7
-    assert 1.73e-7 < _linwave(32, "ppm", "llf", 0, 0.0) <= 1.75e-7
-    assert 1.09e-7 < _linwave(32, "ppm", "llf", 3, 1.0) <= 1.11e-7
+    L = LANDINGS["linwave_n32"]
+    assert L["plm_hlle_sound"][0] < _linwave(32, "plm", "hlle", 0, 0.0) <= L["plm_hlle_sound"][1] == LINWAVE["plm"]["rms_err_n32_max"][0]
+    assert L["plm_llf_entropy"][0] < _linwave(32, "plm", "llf", 3, 1.0) <= L["plm_llf_entropy"][1] == LINWAVE["plm"]["rms_err_n32_max"][2]
+    assert L["ppm_llf_sound"][0] < _linwave(32, "ppm", "llf", 0, 0.0) <= L["ppm_llf_sound"][1] == LINWAVE["ppm"]["rms_err_n32_max"][0]
+    assert L["ppm_llf_entropy"][0] < _linwave(32, "ppm", "llf", 3, 1.0) <= L["ppm_llf_entropy"][1] == LINWAVE["ppm"]["rms_err_n32_max"][2]
 
 
 def _advection(N, riem):
@@ -62,23 +63,24 @@ def _advection(N, riem):
 
 @pytest.mark.parametrize("riem", ["hlle", "llf"])
 def test_advection_history_and_errors(riem):
-    def equiv(a, b, tol=1.0e-4):  # advection.py:95-99
+    def equiv(a, b, tol=ADVECTION["equiv_rel_tol"]):  # advection.py:95-99
         return 2.0 * abs(a - b) / (abs(a) + abs(b)) <= tol
     o16, _ = _advection(16, riem)
     o, n = _advection(32, riem)
     # advection.py:100-118 (history at t = 1 of the last run: llf, N = 32; hlle agrees to 1e-4)
-    assert n == 56
-    assert equiv(o.time, 1.0)
-    assert equiv(o.dt, 1.11612e-02)
+    H = ADVECTION["history_n32"]
+    assert n == H["cycle"]
+    assert equiv(o.time, H["time"])
+    assert equiv(o.dt, H["dt"])
     h = o.history()
-    expected = [6.75, 2.25, 4.5, 4.5, 9.45, 6.075, 6.75, 2.25, 4.5, 4.5, 6.75, -2.25, -4.5, -4.5]
+    expected = advection_history()
     for got, exp in zip(h, expected):
         assert equiv(got, exp), (got, exp)
     # advection.py:137-178: plm thresholds for gas, dust1, dust2
     e16, e32 = o16.advection_errors(), o.advection_errors()
     for s in range(3):
-        assert e32[s] <= 2.21e-7
-        assert e32[s] / e16[s] <= 0.30
+        assert e32[s] <= ADVECTION["plm"]["rms_err_n32_max"]
+        assert e32[s] / e16[s] <= ADVECTION["plm"]["n32_over_n16_max"]
     # advection.py:179-187: L- and R-going dust errors identical as printed
     assert "%e" % e32[1] == "%e" % e32[2]
 
@@ -216,7 +218,7 @@ def test_drag_reference_test_pins():
     """tst/scripts/drag/drag.py:36-37,57-59,127-129 on inputs/drag/simple_drag.in: for every
     output time up to t = 10 and each of the four stopping times, |<v_dust - v_gas> - ans| <= 3e-3
     with ans = -exp(-(1 + 0.01/10) t / tau), and total momentum conserved to 1e-13."""
-    tau = [1e-2, 0.1, 1.0, 10.0]
+    tau = DRAG["tau"]
     o = Oracle((128, 1, 1), (0.0, -0.5, -0.5), (1.0, 0.5, 0.5), ng=2, ns_gas=1, ns_dust=4,
                reconstruct="plm", riemann="hlle", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.4,
                dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10, cfl=0.3, dust_cfl=0.3,
@@ -235,9 +237,9 @@ def test_drag_reference_test_pins():
             ans = -np.exp(-(1.0 + c) * o.time / tau[d])
             worst = max(worst, abs((dp[4 + 3 * d, 0, 0] - vg).mean() - ans))
         worst_mom = max(worst_mom, abs(mom(o.history()) / m0 - 1))
-    assert worst <= 3e-3, worst          # the oracle gives 2.43e-3: the threshold is a 25 % margin
-    assert worst > 1e-3                  # and not vacuous
-    assert worst_mom <= 1e-13, worst_mom
+    assert worst <= DRAG["velocity_difference_tol"], worst  # the oracle gives 2.43e-3: the threshold is a 25 % margin
+    assert abs(worst - LANDINGS["drag_worst"]) < 2e-5  # ... and not vacuous
+    assert worst_mom <= DRAG["momentum_tol"], worst_mom
 
 
 def test_shearing_sheet_reference_test_pins():
@@ -262,9 +264,9 @@ def test_shearing_sheet_reference_test_pins():
     io = np.argwhere(xc >= 0.1)[0][0]
     pi_ = xc[np.argmax(sig[:, ii])]
     po = xc[np.argmax(sig[:, io])]
-    h = 0.05
-    assert abs(pi_ - 0.75 * 0.1 ** 2 / h) < 0.03, pi_
-    assert abs(po + 0.75 * 0.1 ** 2 / h) < 0.03, po
+    h, tol = SSHEET["h"], SSHEET["wake_position_tol"]
+    assert abs(pi_ - 0.75 * SSHEET["ring_x"] ** 2 / h) < tol, pi_
+    assert abs(po + 0.75 * SSHEET["ring_x"] ** 2 / h) < tol, po
     assert 0.01 < sig.max() < 1.0  # a wake exists and the sheet has not blown up
 
 
@@ -293,7 +295,7 @@ def test_viscous_diffusion_reference_test_pins(d):
         yy, xx = np.meshgrid(xc, xc)
         ans = eps * (2.0 * np.pi * s2) ** (-0.5 * d) * np.exp(-(xx ** 2 + yy ** 2) / (2.0 * s2))
         err = np.abs(ans.ravel() - w.T.ravel()).mean()
-    assert err <= 1e-8, err   # the oracle gives 2.2e-10 (1-D) and 2.6e-11 (2-D)
+    assert err <= PINS["viscous_diffusion"]["mean_abs_err_max"], err   # the oracle gives 2.2e-10 (1-D) and 2.6e-11 (2-D)
     assert err > 1e-13        # a second-order scheme on 64 zones is not exact either
 
 
@@ -317,8 +319,8 @@ def _conduction_answer(x, d, f=0.01, T0=0.05, x0=1.2, xi=0.2, k=0.1):
     return (T0 + (x - x0) * -f / k, T0 + np.log(x / x0) * -f / k, T0 + (1.0 / x - 1.0 / x0) * f / k)[d]
 
 
-@pytest.mark.parametrize("g,d,e64,e128", [("cartesian", 0, 8.34e-3, 4.11e-3), ("axisymmetric", 1, 2.07e-3, 1.04e-3),
-                                          ("spherical", 2, 3.70e-4, 1.91e-4)])
+@pytest.mark.parametrize("g,d,e64,e128", [(g, d, LANDINGS["thermal_diffusion_n64"][g], LANDINGS["thermal_diffusion_n128"][g])
+                                          for d, g in enumerate(("cartesian", "axisymmetric", "spherical"))])
 def test_thermal_diffusion_reference_test_pins(g, d, e64, e128):
     """tst/scripts/diffusion/thermal_diffusion.py:36-70,99-125 on inputs/diffusion/conduction.in in
     Cartesian, axisymmetric and spherical coordinates (conduction pgen, `conductive` boundary
@@ -335,7 +337,7 @@ def test_thermal_diffusion_reference_test_pins(g, d, e64, e128):
     xc = 0.2 + (np.arange(nx) + 0.5) / nx
     err = np.abs(T / _conduction_answer(xc, d) - 1.0).mean()
     assert abs(err - e64) < 0.01 * e64, err
-    assert abs(err / 2.0 - e128) < 0.05 * e128 and e128 <= 5e-3  # the 128-zone value and the reference bound
+    assert abs(err / 2.0 - e128) < 0.05 * e128 and e128 <= PINS["thermal_diffusion"]["mean_rel_err_max"]  # the 128-zone value and the reference bound
 
 
 _PI = 3.141592653589793
@@ -362,11 +364,7 @@ def disk_oracle(g, gam, b, nx=None):
     return o
 
 
-@pytest.mark.parametrize("g,gam,b,err_ref,dt_ref", [
-    ("axi", 1.0, "ic", 5.380e-3, 1.0038e-2), ("axi", 1.0, "extrap", 5.365e-3, 1.0895e-2),
-    ("axi", 1.4, "ic", 4.292e-3, 8.7865e-3), ("axi", 1.4, "extrap", 4.269e-3, 8.1003e-3),
-    ("cyl", 1.0, "ic", 1.683e-4, 5.5542e-3), ("cyl", 1.4, "extrap", 1.356e-4, 5.9155e-3),
-    ("sph", 1.4, "ic", 4.600e-4, 1.3094e-3)])
+@pytest.mark.parametrize("g,gam,b,err_ref,dt_ref", [tuple(c) for c in LANDINGS["disk"]])
 def test_disk_reference_test_pins(g, gam, b, err_ref, dt_ref):
     """tst/scripts/disk/disk.py:36-45,58-96,118-187 on the shipped uniform-mesh decks
     inputs/disk/disk_{axi,cyl,sph}.in (disk pgen, `ic` / `extrap` user conditions, point-mass
@@ -379,13 +377,13 @@ def test_disk_reference_test_pins(g, gam, b, err_ref, dt_ref):
     statically refined (SMR) and out of scope."""
     o = disk_oracle(g, gam, b)
     d0 = o.interior(o.gprim)[0].copy()
-    o.evolve(62.8, 10)
+    o.evolve(62.8, DISK["cycles"])
     P = o.interior(o.gprim)
     d, T = P[0], P[5] * 0.4
-    assert o.ncycle == 10 and not np.isnan(P).any() and d.min() > 0.0 and T.min() > 0.0
-    assert 1e-4 < o.dt < 3e-2 and abs(o.dt - dt_ref) < 2e-4 * dt_ref
+    assert o.ncycle == DISK["cycles"] and not np.isnan(P).any() and d.min() > 0.0 and T.min() > 0.0
+    assert DISK["dt_low"] < o.dt < DISK["dt_high"] and abs(o.dt - dt_ref) < 2e-4 * dt_ref
     err = np.sqrt((d0 * (d - d0) ** 2).sum()) / d0.sum()
-    assert err <= 6e-3 and abs(err - err_ref) < 2e-3 * err_ref, err
+    assert err <= DISK["density_err_max"] and abs(err - err_ref) < 2e-3 * err_ref, err
 
 
 def alpha_disk_oracle(nx=64, alpha=0.1, h=0.1):
@@ -420,5 +418,6 @@ def test_alpha_disk_reference_test_pin():
     e_d = np.abs((1.0 / np.sqrt(r) - dens) * np.sqrt(r)).mean()
     e_m = np.abs((3 * np.pi * 0.1 * 0.1 ** 2 - mdot) / (3 * np.pi * 0.1 * 0.1 ** 2)).mean()
     assert abs(o.time - 8e3) < 1e-9 and o.ncycle > 150000
-    assert e_d <= 2e-3 and e_m <= 2e-3, (e_d, e_m)
-    assert abs(e_d - 8.76e-4) < 2e-5 and abs(e_m - 1.811e-3) < 2e-5, (e_d, e_m)
+    tol = PINS["alpha_disk"]["mean_rel_err_max"]
+    assert e_d <= tol and e_m <= tol, (e_d, e_m)
+    assert abs(e_d - LANDINGS["alpha_disk"]["density"]) < 2e-5 and abs(e_m - LANDINGS["alpha_disk"]["mdot"]) < 2e-5, (e_d, e_m)
