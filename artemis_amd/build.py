@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
 
 # -ffp-contract=off: every expression tree stays unfused so results are bit-identical to the
 # CPU oracle (oracle/Makefile uses the same flag).  See DESIGN.md "Floating point".
@@ -63,11 +64,14 @@ def build_hip(force=False, verbose=False):
                 obj = os.path.join(LIBDIR, "driver_" + f.replace(".cpp", ".o"))
                 cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off"] + NO_SINCOS + [
                        "-I", os.path.join(ROOT, "include"), "-c", os.path.join(drv_dir, f), "-o", obj]
+                if f == "comm_rccl.cpp":  # rccl.h pulls in the HIP runtime API header (types only: no HIP calls there)
+                    cmd += ["-I", os.path.join(ROCM, "include"), "-D__HIP_PLATFORM_AMD__", "-Wno-deprecated-declarations"]
                 if verbose:
                     print(" ".join(cmd))
                 subprocess.check_call(cmd)
                 objs.append(obj)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", target] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", target] + objs + [
+        "-L", os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

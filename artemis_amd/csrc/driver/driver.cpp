@@ -1557,7 +1557,7 @@ void artemis_sim::step_fused(bool want_dt, bool device_dt) {
     for (auto &L : links) any_remote = any_remote || remote(*L), faces |= (1 << L->face);
     a.shell_faces = faces;
     // (ARTEMIS_FORCE_OVERLAP=1: diagnostic, shell-first ordering even when every link is local)
-    static const bool force_ovl = std::getenv("ARTEMIS_FORCE_OVERLAP") != nullptr;
+    const bool force_ovl = std::getenv("ARTEMIS_FORCE_OVERLAP") != nullptr;
     const bool ovl = overlap && (any_remote || (force_ovl && !links.empty()));
     void *e0 = nullptr, *e1 = nullptr;
     if (time_kernels && kev.size() < kMaxTimedLaunches) { // (bounded: long runs with timing on must not leak events)
@@ -1589,7 +1589,7 @@ void artemis_sim::step_fused(bool want_dt, bool device_dt) {
       }
       CK(artemis_rt_stream_wait_event(comm_stream, ev0), "wait");
       // (ARTEMIS_TEST_SHELL_TARGET_BUMP: test hook, waits for more workgroups than exist -> the timeout path)
-      static const char *bump = std::getenv("ARTEMIS_TEST_SHELL_TARGET_BUMP");
+      const char *bump = std::getenv("ARTEMIS_TEST_SHELL_TARGET_BUMP");
       if (bump) target += static_cast<unsigned>(std::atoi(bump));
       CK(artemis_hip_wait_counter(counter, target, counter + 1, comm_stream), "wait_counter");
       fill_ghosts_start(out, comm_stream);

@@ -5,9 +5,9 @@ Usage mirrors `artemis -i <deck> block/key=value ...` (tst/scripts/utils/artemis
     sim = Simulation("inputs/blast/blast.in", ["parthenon/mesh/nx3=256", ...])
     sim.evolve()
 
-With torch.distributed initialised (one process per GPU) the mesh-block grid is split over the
-ranks and ghost slabs travel through torch.distributed point-to-point ops (backend "nccl" =
-RCCL over xGMI on the GPU box; "gloo" in the CPU tests of the host logic).
+One process per GPU: the mesh-block grid is split over the ranks and ghost slabs travel through an
+artemis_comm_t -- RcclComm = the native C++ RCCL transport (GPU runs), TorchComm = callbacks into
+torch.distributed ("gloo" in the CPU tests of the host logic).
 """
 import ctypes as C
 import os
@@ -145,6 +145,52 @@ class TorchComm:
         except Exception as e:
             print("TorchComm.allreduce_sum failed:", repr(e), flush=True)
             return 1
+
+
+class RcclComm:
+    """The native C++ transport (artemis_comm_rccl_*, csrc/driver/comm_rccl.cpp): RCCL called directly from
+    the driver's streams, no Python in the loop.  `share(obj) -> obj` broadcasts rank 0's unique id to every
+    rank over any out-of-band channel (bench.py: a gloo broadcast); a single rank needs none."""
+
+    def __init__(self, rank=0, nranks=1, share=None, lib=None):
+        self.L = lib if lib is not None else capi.load()
+        L = self.L
+        L.artemis_comm_rccl_unique_id.argtypes = [C.c_char_p, C.c_int]
+        L.artemis_comm_rccl_create.restype = C.c_void_p
+        L.artemis_comm_rccl_create.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.artemis_comm_rccl_destroy.argtypes = [C.c_void_p]
+        L.artemis_comm_rccl_count.argtypes = [C.c_void_p]
+        L.artemis_comm_rccl_barrier.argtypes = [C.c_void_p]
+        L.artemis_comm_rccl_last_error.restype = C.c_char_p
+        nbytes = L.artemis_comm_rccl_unique_id_bytes()
+        uid = None
+        if rank == 0:
+            buf = C.create_string_buffer(nbytes)
+            if L.artemis_comm_rccl_unique_id(buf, nbytes):
+                raise RuntimeError("ncclGetUniqueId: " + L.artemis_comm_rccl_last_error().decode())
+            uid = buf.raw
+        if nranks > 1:
+            if share is None:
+                raise ValueError("RcclComm with nranks > 1 needs a `share` callable to distribute the unique id")
+            uid = share(uid)
+        self.h = L.artemis_comm_rccl_create(uid, rank, nranks)
+        if not self.h:
+            raise RuntimeError("artemis_comm_rccl_create: " + L.artemis_comm_rccl_last_error().decode())
+        self.struct = Comm.from_address(self.h)
+        self.rank, self.nranks = rank, nranks
+
+    @property
+    def count(self):
+        return self.L.artemis_comm_rccl_count(self.h)
+
+    def barrier(self):
+        if self.L.artemis_comm_rccl_barrier(self.h):
+            raise RuntimeError("RCCL barrier: " + self.L.artemis_comm_rccl_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.artemis_comm_rccl_destroy(self.h)
+            self.h = None
 
 
 def _declare(L):

@@ -26,6 +26,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# cpu_baseline leg: pin the oracle's OpenMP threads (read when the OpenMP runtime starts, so set before
+# anything loads it)
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 ALG_BYTES_PER_CELL_STAGE = 240.0   # 30 doubles
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -134,11 +138,12 @@ def main():
                          "rest -- same kernels, no shocks -- to separate branch-divergence effects from the rest")
     ap.add_argument("--cpu-n", type=int, default=256)
     ap.add_argument("--cpu-cycles", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all host cores)")
     args = ap.parse_args()
 
     import torch
     from artemis_amd import capi
-    from artemis_amd.driver import Simulation, TorchComm
+    from artemis_amd.driver import RcclComm, Simulation
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -151,16 +156,25 @@ def main():
     L = capi.load()
     capi.check(L.artemis_rt_set_device(local_rank))
     comm = None
+    dist = None
     if world > 1 or args.loopback:
-        import torch.distributed as dist
+        # Data path: the native C++ RCCL transport (csrc/driver/comm_rccl.cpp), called straight from the
+        # driver's streams.  torch.distributed is used for CPU-side plumbing only (gloo): shipping rank 0's
+        # ncclUniqueId and the barrier / max-over-ranks around the timed region.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        share = None
         if world > 1:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+
+            def share(uid):
+                box = [uid]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
         else:
             os.environ["ARTEMIS_LOOPBACK_COMM"] = "1"
-            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29411", rank=0, world_size=1,
-                                    device_id=torch.device("cuda", 0))
-        comm = TorchComm(torch.device("cuda", local_rank))
+        comm = RcclComm(rank, world, share)
+        assert comm.count == world, (comm.count, world)
 
     per_gpu = (args.n, args.n, args.n)
     if args.workload == "ssheet_dust":
@@ -199,8 +213,11 @@ def main():
     sim.set_overlap(args.overlap_mode if want_overlap else 0)
 
     def barrier():
-        if world > 1 or args.loopback:
+        torch.cuda.synchronize()
+        if world > 1:
             dist.barrier()
+        if comm is not None:
+            comm.barrier()  # RCCL all-reduce + stream sync: every rank's device work is done
         torch.cuda.synchronize()
 
     sim.evolve(args.warmup)
@@ -213,7 +230,7 @@ def main():
     elapsed = time.perf_counter() - t0
     assert done == args.steps, (done, args.steps)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sim.set_kernel_timing(True)   # HIP events around the dominant kernel, on the stream it is launched on
@@ -249,6 +266,7 @@ def main():
                           "a Parthenon FillDerived runs after every stage's boundary fill; per_task = one kernel per "
                           "Parthenon task (CalculateFluxes, epilogue = ApplyUpdate..ConsToPrim, BCs, PrimToCons). "
                           "Fractions use the same 480 B per zone-cycle."}
+    rccl_ranks = comm.count if comm is not None else 0
     total_zones = sim.total_zones
     local_zones = sim.local_zones
     fused = sim.uses_fused_path
@@ -270,6 +288,9 @@ def main():
                                  % (args.gpus, args.n, "" if world == 1 else
                                     (" on RCCL, not overlapped" if args.no_overlap else
                                      " on RCCL on a second stream behind the bulk of the stage kernel")),
+                "transport": None if comm is None else
+                             "native C++ RCCL (ncclSend/ncclRecv groups per stage, ncclAllReduce(min) on the device dt); "
+                             "ncclCommCount = %d rank(s)" % rccl_ranks,
                 "total_energy_check": float(hist[4]),
             },
         }
@@ -337,15 +358,23 @@ def main():
                 "value": v, "unit": "zone-cycles/s", "cores": os.cpu_count(), "kind": "port",
                 "sample": "CPU oracle (OpenMP, all host cores), same problem at %d^2, %d cycles, %.1f s" % (cn, cyc, secs)}
         elif args.gpus == 1 and not args.no_cpu_baseline:
-            v, secs, cyc = cpu_baseline(args.cpu_n, args.cpu_cycles)
+            threads = args.cpu_threads or os.cpu_count()
+            v, secs, cyc = cpu_baseline(args.cpu_n, args.cpu_cycles, threads)
+            v1, secs1, cyc1 = cpu_baseline(128, 2, 1)  # the same code on ONE core (128^3: ~4 s)
             out["cpu_baseline"] = {
-                "value": v, "unit": "zone-cycles/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": "CPU oracle (OpenMP, all host cores), Sedov %d^3, %d cycles, %.1f s; a "
-                          "restatement of the reference's CPU path, not the Artemis executable"
-                          % (args.cpu_n, cyc, secs)}
+                "value": v, "unit": "zone-cycles/s", "cores": threads, "kind": "port",
+                "threads": threads, "per_core": v / threads, "one_thread": v1,
+                "parallel_efficiency": v / threads / v1,
+                "sample": "CPU oracle (C++ restatement of the reference's CPU path, NOT the Artemis executable; OpenMP over "
+                          "k-j rows, arrays first-touched by the sweeping threads, OMP_PROC_BIND=%s OMP_PLACES=%s): Sedov %d^3, "
+                          "%d cycles in %.1f s on %d threads of %d host cores; one thread: Sedov 128^3, %d cycles in %.1f s"
+                          % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), args.cpu_n, cyc, secs, threads,
+                             os.cpu_count(), cyc1, secs1)}
         print(json.dumps(out), flush=True)
     sim.close()
-    if world > 1 or args.loopback:
+    if comm is not None:
+        comm.close()
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -12,8 +12,9 @@
  *
  * Decomposition: `nranks` processes, one GPU each; the mesh-block grid is split into a
  * Cartesian grid of rank bricks.  Ghost slabs between blocks of one rank are copied on the
- * device; slabs between ranks go through the `artemis_comm_t` callbacks supplied by the
- * launcher (bench.py binds them to torch.distributed = RCCL over xGMI; tests bind gloo).
+ * device; slabs between ranks go through an `artemis_comm_t`: the native RCCL transport below
+ * (artemis_comm_rccl_create; what bench.py and a C++ host use), or callbacks supplied by the launcher
+ * (the CPU tests of the host logic bind them to torch.distributed / gloo).
  * ===================================================================================== */
 #ifndef ARTEMIS_DRIVER_H_
 #define ARTEMIS_DRIVER_H_
@@ -45,6 +46,26 @@ typedef struct artemis_comm {
   int (*allreduce_min_dev)(void *ctx, double *dev_value, void *stream);
   int (*allreduce_sum)(void *ctx, double *values, int n); /* host array, in place */
 } artemis_comm_t;
+
+/* ---- native transport: RCCL (xGMI inside a node), artemis_amd/csrc/driver/comm_rccl.cpp -------------
+ * The C++ implementation of artemis_comm_t a C++ host links directly -- no Python, no GIL: one
+ * ncclGroupStart/End of ncclSend / ncclRecv per ghost exchange on the driver's comm stream (posted in
+ * tag order on both sides), ncclAllReduce(min) in place on the device dt scalar, ncclAllReduce(sum) for
+ * history / error norms.  Stands where Parthenon's MPI boundary communication and reductions stand
+ * (artemis_driver.cpp:258, :279-297; utils/history.hpp:29-100).
+ *   rank 0:      artemis_comm_rccl_unique_id(buf, sizeof buf)   -> ship the bytes to every rank (any
+ *                out-of-band channel: the launcher's store, MPI_Bcast, a file)
+ *   every rank:  artemis_rt_set_device(local_rank); comm = artemis_comm_rccl_create(id, rank, nranks);
+ *                sim = artemis_sim_create(deck, n, overrides, comm); ...; artemis_comm_rccl_destroy(comm)
+ * create() is collective (ncclCommInitRank).  Returns NULL / non-zero on error
+ * (artemis_comm_rccl_last_error()). */
+int artemis_comm_rccl_unique_id_bytes(void);
+int artemis_comm_rccl_unique_id(char *out, int capacity);
+artemis_comm_t *artemis_comm_rccl_create(const char *unique_id, int rank, int nranks);
+void artemis_comm_rccl_destroy(artemis_comm_t *comm);
+int artemis_comm_rccl_count(const artemis_comm_t *comm);  /* ncclCommCount: ranks RCCL itself reports */
+int artemis_comm_rccl_barrier(artemis_comm_t *comm);      /* all-reduce + stream sync */
+const char *artemis_comm_rccl_last_error(void);
 
 /* deck_text: contents of an input deck; overrides: `block/key=value` strings (may be NULL).
  * comm: NULL for a single process.  Returns NULL on error (artemis_sim_last_error()). */

@@ -35,6 +35,9 @@
 #include <cstring>
 #include <limits>
 #include <vector>
+#include <omp.h>
+#include <cstring>
+#include <memory>
 
 typedef double Real;
 #define SQR(x) ((x) * (x))
@@ -64,6 +67,25 @@ struct oracle_cfg {
 
 namespace {
 
+// Field storage: a vector whose resize() leaves new elements uninitialised, so that the pages of the big
+// arrays are first touched by the OpenMP threads that later sweep them (first_touch() below) instead of by
+// the constructing thread -- on a multi-socket host the serial zero-fill of std::vector would put every
+// page on one NUMA node.  Test infrastructure only; no effect on results.
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    typedef NoInitAlloc<U> other;
+  };
+  template <class U>
+  void construct(U *) noexcept {}
+  template <class U, class A0, class... A>
+  void construct(U *p, A0 &&a0, A &&...a) {
+    ::new (static_cast<void *>(p)) U(std::forward<A0>(a0), std::forward<A>(a)...);
+  }
+};
+typedef std::vector<double, NoInitAlloc<double>> RVec;
+
 struct Sim {
   oracle_cfg c;
   int ndim, ni, nj, nk, is, ie, js, je, ks, ke;
@@ -71,9 +93,9 @@ struct Sim {
   Real f0[3], dx[3]; // Xf(d, idx) = f0[d] + idx*dx[d]   (parthenon UniformCartesian, recalled)
   int nvg, nvd;      // 6*ns_gas, 4*ns_dust
   // gas
-  std::vector<Real> gprim, gu0, gu1, gflux[3], gpflux[3], gvface[3];
+  RVec gprim, gu0, gu1, gflux[3], gpflux[3], gvface[3];
   // dust
-  std::vector<Real> dprim, du0, du1, dflux[3];
+  RVec dprim, du0, du1, dflux[3];
   // driver state
   Real time, dt;
   long ncycle;
@@ -133,7 +155,7 @@ struct Sim {
   } cool;
   // optional: initial primitives kept by a caller; when present the `ic` condition copies ghost
   // zones from here instead of re-evaluating the profile (same values: the profile is static)
-  std::vector<Real> ic_g, ic_d;
+  RVec ic_g, ic_d;
   // diffusion (utils/diffusion/diffusion_coeff.hpp:58-136 DiffCoeffParams); type 0 = package off
   struct DiffCoeff {
     int type = 0; // 1 viscosity_plaw, 2 viscosity_alpha, 3 conductivity_plaw, 4 thermaldiff_plaw
@@ -143,14 +165,14 @@ struct Sim {
   };
   DiffCoeff visc, cond;
   Real cv = 0; // IdealGas Cv = kB / ((gamma-1) amu mu), gas.cpp:106-116 (set at creation)
-  std::vector<Real> qflux[3]; // gas::diff::momentum (3n+d) and gas::diff::energy (3ns+n) face fluxes
+  RVec qflux[3]; // gas::diff::momentum (3n+d) and gas::diff::energy (3ns+n) face fluxes
 };
 
 inline size_t IDX(const Sim &s, int k, int j, int i) {
   return (static_cast<size_t>(k) * s.nj + j) * s.ni + i;
 }
-inline Real *V(std::vector<Real> &a, const Sim &s, int n) { return a.data() + n * s.N; }
-inline const Real *V(const std::vector<Real> &a, const Sim &s, int n) {
+inline Real *V(RVec &a, const Sim &s, int n) { return a.data() + n * s.N; }
+inline const Real *V(const RVec &a, const Sim &s, int n) {
   return a.data() + n * s.N;
 }
 
@@ -721,7 +743,7 @@ inline void llf_dust(const Real wl_idn, const Real wl_ivx, const Real wl_ivy, co
 // Face `f` of a sweep is stored at cell index f (lower face of cell f).
 void solve_row(const Sim &s, int fluid, int riemann, int dir, int nsp, const Real *wl,
                const Real *wr, int rowlen, int lo, int hi, size_t base, ptrdiff_t st,
-               std::vector<Real> *flux, std::vector<Real> *pflux, std::vector<Real> *vface,
+               RVec *flux, RVec *pflux, RVec *vface,
                Real gm1) {
   // wl/wr: [nvars][rowlen] scratch rows (ScratchPad2D of the reference); faces lo..hi.
   const int d = dir - 1;
@@ -778,7 +800,7 @@ void solve_row(const Sim &s, int fluid, int riemann, int dir, int nsp, const Rea
 // face in [il,iu] of row (k,j) are multiplied by the scale factors at the face centroid
 // (lower face of the cell that stores the flux).  No-op for Cartesian (:36).
 void scale_momentum_flux(const Sim &s, int dir, int nsp, int k, int j, int il, int iu,
-                         std::vector<Real> *flux) {
+                         RVec *flux) {
   if (s.c.coords == CO_CART) return;
   const int d = dir - 1;
   for (int n = 0; n < nsp; ++n) {
@@ -808,8 +830,8 @@ void calculate_fluxes(Sim &s, int fluid, bool pcm) {
   int recon = gas ? s.c.recon_gas : s.c.recon_dust;
   if (pcm) recon = RC_PCM; // fluid_fluxes.hpp:225
   const int riemann = gas ? s.c.riemann_gas : s.c.riemann_dust;
-  const std::vector<Real> &prim = gas ? s.gprim : s.dprim;
-  std::vector<Real> *flux = gas ? s.gflux : s.dflux;
+  const RVec &prim = gas ? s.gprim : s.dprim;
+  RVec *flux = gas ? s.gflux : s.dflux;
   const Real gm1 = s.c.gamma - 1.0;
   const int ni = s.ni, nj = s.nj, nk = s.nk;
   // plm.hpp:90,124,158: PLM_G for every non-Cartesian system; PCM and PPM4 ignore GEOM
@@ -817,10 +839,13 @@ void calculate_fluxes(Sim &s, int fluid, bool pcm) {
 
   // X1 sweep
   {
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel
+    {
+    // (row scratch hoisted out of the loops: one allocation per thread, not one per row)
+    std::vector<Real> wl(static_cast<size_t>(nvars) * ni), wr(static_cast<size_t>(nvars) * ni);
+#pragma omp for collapse(2) schedule(static)
     for (int k = s.ks; k <= s.ke; ++k) {
       for (int j = s.js; j <= s.je; ++j) {
-        std::vector<Real> wl(static_cast<size_t>(nvars) * ni), wr(static_cast<size_t>(nvars) * ni);
         const size_t base = IDX(s, k, j, 0);
         for (int n = 0; n < nvars; ++n) {
           const Real *q = prim.data() + n * s.N + base;
@@ -837,6 +862,7 @@ void calculate_fluxes(Sim &s, int fluid, bool pcm) {
                   flux, s.gpflux, s.gvface, gm1);
         scale_momentum_flux(s, 1, nsp, k, j, s.is, s.ie + 1, flux);
       }
+    }
     }
   }
   // X2 sweep: rows along i at fixed (k,j); wl holds ql of face j (from cell j-1).
@@ -902,8 +928,8 @@ void calculate_fluxes(Sim &s, int fluid, bool pcm) {
 // ---------------------------------------------------------------------------------------
 // utils/integrators/artemis_integrator.hpp:57-110  ApplyUpdate (all Conserved+WithFluxes vars:
 // gas D, M, E, eint and dust D, M).
-void apply_update_fluid(Sim &s, std::vector<Real> &u0, const std::vector<Real> &u1,
-                        const std::vector<Real> *flux, int nvars, Real gam0, Real gam1,
+void apply_update_fluid(Sim &s, RVec &u0, const RVec &u1,
+                        const RVec *flux, int nvars, Real gam0, Real gam1,
                         Real beta_dt) {
   const bool multi_d = (s.ndim > 1), three_d = (s.ndim > 2);
   const ptrdiff_t sj = s.ni, sk = static_cast<ptrdiff_t>(s.ni) * s.nj;
@@ -942,8 +968,17 @@ void apply_update(Sim &s, Real gam0, Real gam1, Real beta_dt) {
 
 // utils/integrators/artemis_integrator.hpp:30-51
 void deep_copy(Sim &s) {
-  s.gu1 = s.gu0;
-  s.du1 = s.du0;
+  auto copy = [&](RVec &dst, const RVec &src, int nvar) {
+    if (dst.size() != src.size()) dst.resize(src.size());
+    const size_t plane = static_cast<size_t>(s.ni) * s.nj;
+    const long nk = s.nk;
+#pragma omp parallel for schedule(static)
+    for (long k = 0; k < nk; ++k)
+      for (int n = 0; n < nvar; ++n)
+        std::memcpy(dst.data() + n * s.N + k * plane, src.data() + n * s.N + k * plane, plane * sizeof(Real));
+  };
+  copy(s.gu1, s.gu0, s.nvg);
+  copy(s.du1, s.du0, s.nvd);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1078,8 +1113,8 @@ void flux_source(Sim &s, int fluid, Real dt) {
       return;
   }
   const ptrdiff_t sj = s.ni, sk = static_cast<ptrdiff_t>(s.ni) * s.nj;
-  std::vector<Real> &u0 = gas ? s.gu0 : s.du0;
-  const std::vector<Real> &prim = gas ? s.gprim : s.dprim;
+  RVec &u0 = gas ? s.gu0 : s.du0;
+  const RVec &prim = gas ? s.gprim : s.dprim;
   const Real omf = s.rframe.on ? s.rframe.omega : 0.0;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int k = s.ks; k <= s.ke; ++k)
@@ -1398,7 +1433,7 @@ void rotating_frame_curvilinear(Sim &s, Real dt) {
         const Real vol = coords.Volume();
         const size_t c = IDX(s, k, j, i);
         const size_t c2 = c + multi_d * sj, c3 = c + three_d * sk;
-        auto body = [&](const std::vector<Real> *flux, std::vector<Real> &u0, int nsp, int n, bool gas) {
+        auto body = [&](const RVec *flux, RVec &u0, int nsp, int n, bool gas) {
           const Real *f1 = flux[0].data() + n * s.N, *f2 = flux[1].data() + n * s.N;
           const Real *f3 = flux[2].data() + n * s.N;
           const Real divf = (f1[c] * ax1[0] * bx1[0] + f1[c + 1] * ax1[1] * bx1[1]) +
@@ -1811,7 +1846,7 @@ void viscous_flux(Sim &s) {
             for (int q = 0; q < 3; ++q) f[q] = hf * mus * flx[q];
             // the normal component carries the bulk term (:411, :468, :524)
             f[dir - 1] = hf * mus * (flx[dir - 1] - 1. / 3 * (1. - dp.eta) * (divu + divu_m));
-            std::vector<Real> &qf = s.qflux[dir - 1];
+            RVec &qf = s.qflux[dir - 1];
             for (int q = 0; q < 3; ++q) qf[(3 * n + q) * s.N + c] += f[q];
             const Real *v1 = s.gprim.data() + (nsp + 3 * n + 0) * s.N;
             const Real *v2 = s.gprim.data() + (nsp + 3 * n + 1) * s.N;
@@ -2144,7 +2179,7 @@ Real estimate_dt(const Sim &s, int fluid) {
 // (IndexDomain::inner_x1 etc.), so edges/corners inherit from the previously filled faces.
 // outflow: copy the nearest interior cell; reflecting: mirror about the face and flip the sign
 // of the vector component normal to it.
-void fill_dir(Sim &s, std::vector<Real> &prim, int nvar, int nsp, bool gas, int d, int pass) {
+void fill_dir(Sim &s, RVec &prim, int nvar, int nsp, bool gas, int d, int pass) {
   // pass 0: periodic only; pass 1: physical only
   const int n_act[3] = {s.c.nx1, s.c.nx2, s.c.nx3};
   if (d >= s.ndim) return;
@@ -2215,7 +2250,7 @@ void strat_bc(Sim &s, int d, int side) {
           const Real dx = (side == 0) ? (x1 - x0) : (x0 - x1);
           const Real x = x1v(bbox(s, k, j, i));
           const size_t ca = IDX(s, k, j, ia), cb = IDX(s, k, j, ib);
-          auto fill = [&](std::vector<Real> &q, int nsp, int n) {
+          auto fill = [&](RVec &q, int nsp, int n) {
             const Real v1 = q[(nsp + 3 * n + 0) * s.N + ca];
             const Real v2 = q[(nsp + 3 * n + 1) * s.N + ca];
             const Real v3 = q[(nsp + 3 * n + 2) * s.N + ca];
@@ -2241,7 +2276,7 @@ void strat_bc(Sim &s, int d, int side) {
           const Real z1 = x3v(bbox(s, kb, j, i));
           const Real dz = (side == 0) ? (z1 - z0) : (z0 - z1);
           const size_t ca = IDX(s, ka, j, i), cb = IDX(s, kb, j, i);
-          auto fill = [&](std::vector<Real> &q, int nsp, int n) {
+          auto fill = [&](RVec &q, int nsp, int n) {
             const Real v1 = q[(nsp + 3 * n + 0) * s.N + ca];
             const Real v2 = q[(nsp + 3 * n + 1) * s.N + ca];
             const Real v3 = q[(nsp + 3 * n + 2) * s.N + ca];
@@ -2268,7 +2303,7 @@ void strat_bc(Sim &s, int d, int side) {
           const Real xf = b.x1[0];
           const Real vy0 = -s.strat.q * s.strat.Om0 * x;
           const size_t ca = IDX(s, k, ja, i);
-          auto fill = [&](std::vector<Real> &q, int nsp, int n) {
+          auto fill = [&](RVec &q, int nsp, int n) {
             const Real v1 = q[(nsp + 3 * n + 0) * s.N + ca];
             const Real v2 = q[(nsp + 3 * n + 1) * s.N + ca];
             const Real v3 = q[(nsp + 3 * n + 2) * s.N + ca];
@@ -2637,17 +2672,24 @@ void *oracle_create(const oracle_cfg *cfg) {
   s->f0[1] = c.x2min - g2 * s->dx[1];
   s->f0[2] = c.x3min - g3 * s->dx[2];
   s->nvg = 6 * c.ns_gas, s->nvd = 4 * c.ns_dust;
-  s->gprim.assign(s->nvg * s->N, 0.0), s->gu0.assign(s->nvg * s->N, 0.0);
-  s->gu1.assign(s->nvg * s->N, 0.0);
-  s->dprim.assign(s->nvd * s->N, 0.0), s->du0.assign(s->nvd * s->N, 0.0);
-  s->du1.assign(s->nvd * s->N, 0.0);
+  if (c.nthreads > 0) omp_set_num_threads(c.nthreads);
+  // zero-fill plane by plane with the static k-decomposition the sweeps use (NUMA first touch)
+  auto first_touch = [&](RVec &v, size_t nvar) {
+    v.resize(nvar * s->N);
+    const size_t plane = static_cast<size_t>(s->ni) * s->nj;
+    Real *p = v.data();
+    const long nk = s->nk, N = static_cast<long>(s->N);
+#pragma omp parallel for schedule(static)
+    for (long k = 0; k < nk; ++k)
+      for (size_t n = 0; n < nvar; ++n) std::memset(p + n * N + k * plane, 0, plane * sizeof(Real));
+  };
+  first_touch(s->gprim, s->nvg), first_touch(s->gu0, s->nvg), first_touch(s->gu1, s->nvg);
+  first_touch(s->dprim, s->nvd), first_touch(s->du0, s->nvd), first_touch(s->du1, s->nvd);
   for (int d = 0; d < 3; ++d) {
-    s->gflux[d].assign(s->nvg * s->N, 0.0);
-    s->gpflux[d].assign(c.ns_gas * s->N, 0.0);
-    s->gvface[d].assign(c.ns_gas * s->N, 0.0);
-    s->dflux[d].assign(s->nvd * s->N, 0.0);
+    first_touch(s->gflux[d], s->nvg), first_touch(s->gpflux[d], c.ns_gas), first_touch(s->gvface[d], c.ns_gas);
+    first_touch(s->dflux[d], s->nvd);
   }
-  for (int d = 0; d < 3; ++d) s->qflux[d].assign(static_cast<size_t>(4) * c.ns_gas * s->N, 0.0);
+  for (int d = 0; d < 3; ++d) first_touch(s->qflux[d], static_cast<size_t>(4) * c.ns_gas);
   s->cv = 1.0 / ((c.gamma - 1.) * 1.0 * 1.0);
   s->time = 0.0, s->dt = std::numeric_limits<Real>::max(), s->ncycle = 0;
   s->gx1min = c.x1min, s->gx1max = c.x1max, s->gx2min = c.x2min, s->gx2max = c.x2max;

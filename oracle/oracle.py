@@ -155,7 +155,7 @@ class Oracle:
                  riemann="hllc", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.66666666667,
                  dfloor=1.0e-20, siefloor=1.0e-20, de_switch=0.0, dust_dfloor=1.0e-20, cfl=0.8,
                  dust_cfl=0.8, bc=("periodic",) * 6, integrator="rk2", mesh_bounds=None,
-                 coordinates="cartesian"):
+                 coordinates="cartesian", nthreads=0):
         self.L = lib()
         c = Cfg()
         c.nx1, c.nx2, c.nx3 = nx
@@ -171,7 +171,7 @@ class Oracle:
         for i, b in enumerate(bc):
             c.bc[i] = BC[b] if isinstance(b, str) else b
         c.integrator = INTEG[integrator]
-        c.nthreads = 0
+        c.nthreads = nthreads  # > 0: omp_set_num_threads (process-wide); 0: leave the OpenMP default
         c.coords = coord_select(coordinates, sum(n > 1 for n in nx))
         self.cfg = c
         self.h = C.c_void_p(self.L.oracle_create(C.byref(c)))

@@ -61,11 +61,11 @@ struct Bound {
     if (p->omega_frame != 0.0) s->rframe.on = true, s->rframe.omega = p->omega_frame; // FluxSource's vf
   }
   ~Bound() { oracle_destroy(s); }
-  void in(std::vector<Real> &dst, double *const *tab, int nvar) {
+  void in(RVec &dst, double *const *tab, int nvar) {
     if (!tab) return;
     for (int v = 0; v < nvar; ++v) std::memcpy(dst.data() + v * s->N, tab[b * nvar + v], s->N * sizeof(Real));
   }
-  void out(const std::vector<Real> &src, double *const *tab, int nvar) {
+  void out(const RVec &src, double *const *tab, int nvar) {
     if (!tab) return;
     for (int v = 0; v < nvar; ++v) std::memcpy(tab[b * nvar + v], src.data() + v * s->N, s->N * sizeof(Real));
   }
@@ -127,9 +127,9 @@ int artemis_hip_flux_source(const artemis_pack_t *p, int fluid, double dt, void 
     // interior only, like the product (the oracle's literal [is-2, ie+1] range only scribbles
     // on ghost cells that PrimToCons overwrites)
     Sim &s = *B.s;
-    std::vector<Real> &u0 = gas ? s.gu0 : s.du0;
+    RVec &u0 = gas ? s.gu0 : s.du0;
     const int nv = gas ? s.nvg : s.nvd;
-    std::vector<Real> before = u0;
+    RVec before = u0;
     flux_source(s, fluid, dt);
     for (int v = 0; v < nv; ++v)
       for (int k = 0; k < s.nk; ++k)
@@ -531,7 +531,7 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
     }
     set_aux(s);
     cons_to_prim(s);
-    auto put = [&](const std::vector<Real> &src, double *const *tab, int nvar, bool gas) {
+    auto put = [&](const RVec &src, double *const *tab, int nvar, bool gas) {
       for (int v = 0; v < nvar; ++v) {
         if (gas && v >= 4 * s.c.ns_gas && v < 5 * s.c.ns_gas) continue; // P is not an output
         for (int k = s.ks; k <= s.ke; ++k)

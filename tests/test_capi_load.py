@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(artemis_(?:hip|rt|sim)_\w+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(artemis_(?:hip|rt|sim|comm)_\w+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -175,28 +175,22 @@ def test_driver_rejects_out_of_scope(hiplib):
 
 
 def test_rccl_loopback_halo_exchange(hiplib, monkeypatch):
-    """One GPU, world_size 1, backend nccl (= RCCL): every block-to-block ghost slab is routed
-    through TorchComm as a send/recv to self (ARTEMIS_LOOPBACK_COMM=1), i.e. the exact code
-    path the multi-GPU run uses -- device-pointer tensor views, the comm stream, batched
-    isend/irecv, event hand-back -- and must reproduce the device-copy run bit for bit."""
-    import socket
-    import torch
-    import torch.distributed as dist
-    from artemis_amd.driver import Simulation, TorchComm
+    """One GPU, one rank, the NATIVE C++ RCCL transport (artemis_comm_rccl_*): every block-to-block ghost
+    slab is routed through the communicator as an ncclSend / ncclRecv to self (ARTEMIS_LOOPBACK_COMM=1),
+    i.e. the exact code path the multi-GPU run uses -- the comm stream, one ncclGroup per exchange in tag
+    order, event hand-back, ncclAllReduce(min) on the device dt -- and must reproduce the device-copy run
+    bit for bit."""
+    from artemis_amd.driver import RcclComm, Simulation
     # 128x32x32 in blocks of 128x16x16: each block's tile grid (4 x 2 x 16 planes) is too small to
     # split in x2, so also run a 96x32x24-block layout that does split into shell + bulk
     ov = linwave_overrides(32, "plm", "hllc", 0, 0.0, mb=(16, 8, 8)) + ["parthenon/time/nlim=12"]
     ref = Simulation(DECK("linwave", "linear_wave.in"), ov)
     ref.evolve()
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                            device_id=torch.device("cuda", 0))
+    monkeypatch.setenv("ARTEMIS_LOOPBACK_COMM", "1")
+    comm = RcclComm(0, 1)
     try:
-        monkeypatch.setenv("ARTEMIS_LOOPBACK_COMM", "1")
-        comm = TorchComm(torch.device("cuda", 0))
+        assert comm.count == 1
+        comm.barrier()
         for overlap in (0, 1, 2):
             # overlap: shell kernel -> slabs on the comm stream || bulk kernel on the compute stream
             sim = Simulation(DECK("linwave", "linear_wave.in"), ov, comm=comm)
@@ -209,17 +203,15 @@ def test_rccl_loopback_halo_exchange(hiplib, monkeypatch):
             assert np.array_equal(sim.history(), ref.history())
             sim.close()
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
 def test_rccl_loopback_overlap_split_blocks(hiplib, monkeypatch):
-    """Same loopback route with blocks big enough (96x32x24 cells = 3x4 tiles x 24 planes) for the
-    stage kernel to really split into boundary shell + bulk: overlap on/off and the plain
-    device-copy run agree bit for bit (Sedov deck, outflow + block-to-block faces)."""
-    import socket
-    import torch
-    import torch.distributed as dist
-    from artemis_amd.driver import Simulation, TorchComm
+    """Same loopback route (native RCCL transport) with blocks big enough (96x32x24 cells = 3x4 tiles x 24
+    planes) for the stage kernel to really split into boundary shell + bulk: overlap on/off and the plain
+    device-copy run agree bit for bit (Sedov deck, outflow + block-to-block faces); also the
+    synchronisation-free loop, whose dt all-reduce rides the stream (ncclAllReduce on the device scalar)."""
+    from artemis_amd.driver import RcclComm, Simulation
     ov = ["parthenon/mesh/nx1=192", "parthenon/mesh/nx2=64", "parthenon/mesh/nx3=48",
           "parthenon/mesh/x3min=-1.0", "parthenon/mesh/x3max=1.0", "parthenon/meshblock/nx1=96",
           "parthenon/meshblock/nx2=32", "parthenon/meshblock/nx3=24", "gas/riemann=hllc",
@@ -227,17 +219,11 @@ def test_rccl_loopback_overlap_split_blocks(hiplib, monkeypatch):
     ref = Simulation(DECK("blast", "blast.in"), ov)
     assert ref.nblocks == 8
     ref.evolve()
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                            device_id=torch.device("cuda", 0))
+    monkeypatch.setenv("ARTEMIS_LOOPBACK_COMM", "1")
+    comm = RcclComm(0, 1)
     try:
-        monkeypatch.setenv("ARTEMIS_LOOPBACK_COMM", "1")
-        comm = TorchComm(torch.device("cuda", 0))
-        for overlap in (2, 1, 0):
-            sim = Simulation(DECK("blast", "blast.in"), ov, comm=comm)
+        for overlap, extra in ((2, []), (1, []), (0, []), (2, ["parthenon/time/tlim=-1.0"])):
+            sim = Simulation(DECK("blast", "blast.in"), ov + extra, comm=comm)
             sim.set_overlap(overlap)
             sim.evolve()
             assert sim.ncycle == 8 and sim.dt == ref.dt
@@ -246,7 +232,49 @@ def test_rccl_loopback_overlap_split_blocks(hiplib, monkeypatch):
                                       ref.field("gas.prim", b)[[0, 1, 2, 3, 5]]), (overlap, b)
             sim.close()
     finally:
-        dist.destroy_process_group()
+        comm.close()
+
+
+def test_overlap_wait_timeout_is_reported(hiplib, monkeypatch):
+    """The comm stream's wait kernel gives up after its spin limit instead of hanging the GPU; the driver
+    must then FAIL the run (the slabs behind the wait may hold unfinished shell data) and stop overlapping.
+    Forced here by waiting for more shell workgroups than the launch has."""
+    from artemis_amd.driver import Simulation
+    ov = ["parthenon/mesh/nx1=192", "parthenon/mesh/nx2=64", "parthenon/mesh/nx3=48",
+          "parthenon/mesh/x3min=-1.0", "parthenon/mesh/x3max=1.0", "parthenon/meshblock/nx1=96",
+          "parthenon/meshblock/nx2=32", "parthenon/meshblock/nx3=24", "gas/riemann=hllc",
+          "problem/symmetry=spherical", "problem/radius=0.2", "problem/samples=0", "parthenon/time/nlim=3"]
+    monkeypatch.setenv("ARTEMIS_FORCE_OVERLAP", "1")  # shell-first launches although every link is local
+    ok = Simulation(DECK("blast", "blast.in"), ov)
+    ok.set_overlap(2)
+    ok.evolve()
+    assert ok.ncycle == 3 and ok.overlap == 2
+    monkeypatch.setenv("ARTEMIS_TEST_SHELL_TARGET_BUMP", "100000")
+    monkeypatch.setenv("ARTEMIS_WAIT_SPIN_LIMIT", "2000")
+    bad = Simulation(DECK("blast", "blast.in"), ov)
+    bad.set_overlap(2)
+    with pytest.raises(RuntimeError, match="timed out"):
+        bad.evolve()
+    assert bad.overlap == 0
+    monkeypatch.delenv("ARTEMIS_TEST_SHELL_TARGET_BUMP")
+    bad.close(), ok.close()
+
+
+def test_dropin_accounting_mode_same_bits(hiplib):
+    """bench.py's `dropin` leg: the tuned kernel also writing cons on the last stage + the whole-block
+    PrimToCons per stage gives the same state as the plain fused path and as the per-task chain."""
+    from artemis_amd.driver import Simulation
+    ov = BLAST3D + ["parthenon/time/tlim=-1.0", "parthenon/time/nlim=9"]
+    a, b, c = (Simulation(DECK("blast", "blast.in"), ov) for _ in range(3))
+    b.set_dropin(True)
+    c.set_path("unfused")
+    for s in (a, b, c):
+        s.evolve()
+    assert a.ncycle == b.ncycle == c.ncycle == 9 and a.dt == b.dt == c.dt
+    for name in ("gas.prim", "gas.cons"):
+        assert np.array_equal(a.field(name), b.field(name)) and np.array_equal(a.field(name), c.field(name)), name
+    with pytest.raises(RuntimeError):
+        c.set_dropin(True)  # tuned fused path only
 
 
 def test_sync_free_loop_matches_host_dt_loop(hiplib, monkeypatch):
