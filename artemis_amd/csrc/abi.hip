@@ -462,6 +462,52 @@ int artemis_hip_halo_unpack_ext(const artemis_pack_t *p, int block, int face, in
   return halo_common(p, block, face, const_cast<double *>(buf), 1, extended, stream);
 }
 
+// ---- multilevel block-graph data path (kernels_amr.hip) ------------------------------------------------
+static int validate_ml(const artemis_pack_t *p, const artemis_ml_pack_t *ml) {
+  if (int rc = validate(p)) return rc;
+  if (!ml || !ml->cgeom) return fail(ARTEMIS_HIP_EINVAL, "multilevel: null coarse-buffer pack / edge table");
+  if ((p->gas.nspecies && !ml->gas_coarse) || (p->dust.nspecies && !ml->dust_coarse))
+    return fail(ARTEMIS_HIP_EINVAL, "multilevel: coarse-buffer tables are required");
+  if (p->nghost % 2 != 0) return fail(ARTEMIS_HIP_EINVAL, "multilevel meshes need an even number of ghost zones");
+  if (p->nx1 % 2 != 0 || (p->nx2 > 1 && p->nx2 % 2 != 0) || (p->nx3 > 1 && p->nx3 % 2 != 0))
+    return fail(ARTEMIS_HIP_EINVAL, "multilevel meshes need an even number of zones per mesh block");
+  if ((p->coords == ARTEMIS_SPHERICAL2D || p->coords == ARTEMIS_SPHERICAL3D) && !ml->cmetric)
+    return fail(ARTEMIS_HIP_EINVAL, "multilevel: spherical coarse buffers need their metric tables");
+  return 0;
+}
+int artemis_hip_ml_exchange(const artemis_pack_t *p, const artemis_ml_pack_t *ml, const artemis_ml_op_t *ops_dev, int nops,
+                            double *sendbuf, const double *recvbuf, void *stream) {
+  if (int rc = validate_ml(p, ml)) return rc;
+  if (nops < 0 || (nops > 0 && !ops_dev)) return fail(ARTEMIS_HIP_EINVAL, "multilevel: bad operation list");
+  artemis::launch_ml_exchange(artemis::make_pack_view(*p), *ml, ops_dev, nops, sendbuf, recvbuf, S(stream));
+  return after_launch("ml_exchange");
+}
+int artemis_hip_ml_flux_correction(const artemis_pack_t *p, const artemis_ml_op_t *ops_dev, int nops, double *sendbuf,
+                                   const double *recvbuf, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (nops < 0 || (nops > 0 && !ops_dev)) return fail(ARTEMIS_HIP_EINVAL, "multilevel: bad operation list");
+  const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
+  for (int d = 0; d < ndim; ++d)
+    if ((p->gas.nspecies && (!p->gas.flux[d] || !p->gas.pflux[d])) || (p->dust.nspecies && !p->dust.flux[d]))
+      return fail(ARTEMIS_HIP_EINVAL, "flux correction: flux tables are required");
+  artemis::launch_ml_flux_correction(artemis::make_pack_view(*p), ops_dev, nops, sendbuf, recvbuf, S(stream));
+  return after_launch("ml_flux_correction");
+}
+int artemis_hip_ml_restrict_halos(const artemis_pack_t *p, const artemis_ml_pack_t *ml, const int *blocks_dev, int nblocks,
+                                  void *stream) {
+  if (int rc = validate_ml(p, ml)) return rc;
+  if (nblocks < 0 || (nblocks > 0 && !blocks_dev)) return fail(ARTEMIS_HIP_EINVAL, "multilevel: bad block list");
+  artemis::launch_ml_restrict_halos(artemis::make_pack_view(*p), *ml, blocks_dev, nblocks, S(stream));
+  return after_launch("ml_restrict_halos");
+}
+int artemis_hip_ml_prolongate(const artemis_pack_t *p, const artemis_ml_pack_t *ml, const artemis_ml_box_t *boxes_dev,
+                              int nboxes, void *stream) {
+  if (int rc = validate_ml(p, ml)) return rc;
+  if (nboxes < 0 || (nboxes > 0 && !boxes_dev)) return fail(ARTEMIS_HIP_EINVAL, "multilevel: bad box list");
+  artemis::launch_ml_prolongate(artemis::make_pack_view(*p), *ml, boxes_dev, nboxes, S(stream));
+  return after_launch("ml_prolongate");
+}
+
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream) {
   if (int rc = validate(p)) return rc;
   if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");

@@ -24,6 +24,7 @@
 #include "artemis_rt.h"
 #include "../geometry_core.hpp"
 #include "parameter_input.hpp"
+#include "block_tree.hpp"
 
 #define SQR(x) ((x) * (x))
 typedef double Real;
@@ -85,7 +86,8 @@ struct Field {
 };
 
 struct Block {
-  int lx[3];            // logical location in the global block grid
+  int level = 0;        // refinement level (0 on a uniform mesh)
+  int lx[3];            // logical location in the block grid of its level
   Real xmin[3], xmax[3];
   int bc[6];            // artemis_bc per face (NONE where a neighbour block exists)
   int nbr_rank[6], nbr_block[6];
@@ -111,6 +113,68 @@ struct artemis_sim {
   artemis_comm_t comm;
   bool has_comm = false;
   int rank = 0, nranks = 1;
+
+  // multilevel (static mesh refinement): block tree, operation lists, coarse buffers (block_tree.hpp,
+  // include/artemis_hip.h "multilevel block-graph data path")
+  bool multilevel = false;
+  struct Region {
+    int level;
+    double lo[3], hi[3];
+  };
+  std::vector<Region> regions;
+  long nblocks_global = 0;
+  struct DevArr { // raw device array owned by the driver
+    void *p = nullptr;
+    int n = 0;
+    template <class T>
+    void upload(const std::vector<T> &h) {
+      release();
+      n = static_cast<int>(h.size());
+      if (h.empty()) return;
+      p = artemis_rt_malloc(h.size() * sizeof(T));
+      if (!p) throw HipFail("device allocation failed");
+      CK(artemis_rt_memcpy_h2d(p, h.data(), h.size() * sizeof(T), nullptr), "h2d");
+    }
+    void release() {
+      if (p) artemis_rt_free(p);
+      p = nullptr, n = 0;
+    }
+    ~DevArr() { release(); }
+  };
+  struct {
+    Field gcoarse, dcoarse;       // coarse buffers, laid out like the prim tables
+    DevBuf cgeom, cmetric;
+    DevArr ops_a, ops_u, ops_b;   // ghost ops: packs + direct same/finer | unpacks same/finer | from-coarser
+    DevArr ops_fx, ops_fxu;       // flux correction: packs + direct | unpacks
+    DevArr restrict_blocks, boxes;
+    DevBuf gsend, grecv, fsend, frecv;
+    std::vector<artemis_msg_t> gmsgs, fmsgs;
+    std::vector<int> bc_coarse;
+    int max_level = 0;
+  } ml;
+  struct PeerMsg {
+    int peer, tag;
+    bool is_send;
+    long offset, count;
+  };
+  struct {
+    std::vector<PeerMsg> gmsgs, fmsgs;
+    std::vector<artemis_ml_op_t> a, u, b, fx, fxu;
+    std::vector<int> restrict_blocks;
+    std::vector<artemis_ml_box_t> boxes;
+    long gsend_n = 0, grecv_n = 0, fsend_n = 0, frecv_n = 0;
+  } ml_host;
+  artemis_ml_pack_t make_ml_pack() const {
+    artemis_ml_pack_t m;
+    m.gas_coarse = ml.gcoarse.tab(), m.dust_coarse = ml.dcoarse.tab();
+    m.cgeom = ml.cgeom.p, m.cmetric = ml.cmetric.p;
+    return m;
+  }
+  void build_mesh_multilevel();
+  void allocate_multilevel();
+  void fill_ghosts_multilevel(int prim_idx);
+  void flux_correction_multilevel(const artemis_pack_t &p);
+  void exchange_messages(std::vector<artemis_msg_t> &msgs);
 
   // mesh
   int nx[3], mbnx[3], nblk[3], rgrid[3], rcoord[3], lblk[3];
@@ -365,6 +429,40 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
     nblk[d] = nx[d] / mbnx[d];
   }
   ndim = (nx[2] > 1) ? 3 : ((nx[1] > 1) ? 2 : 1);
+  // <parthenon/mesh> refinement = none | static (| adaptive: the remeshing framework is not built);
+  // <parthenon/static_refinementN> level, x?min, x?max (inputs/disk/disk_cart.in:42,68-75)
+  {
+    const std::string ref = pin.GetOrAddString("parthenon/mesh", "refinement", "none");
+    if (ref == "adaptive") throw std::runtime_error("parthenon/mesh/refinement = adaptive: remeshing is not built (static refinement is)");
+    if (ref != "none" && ref != "static") throw std::runtime_error("parthenon/mesh/refinement must be none|static|adaptive");
+    if (ref == "static") {
+      for (int q = 0; q < 64; ++q) {
+        const std::string blk = "parthenon/static_refinement" + std::to_string(q);
+        if (!pin.DoesBlockExist(blk)) continue;
+        Region r;
+        r.level = pin.GetInteger(blk, "level");
+        if (r.level < 1) throw std::runtime_error(blk + "/level must be >= 1");
+        for (int d = 0; d < 3; ++d) {
+          r.lo[d] = pin.GetOrAddReal(blk, std::string(xn[d]) + "min", xmin[d]);
+          r.hi[d] = pin.GetOrAddReal(blk, std::string(xn[d]) + "max", xmax[d]);
+          if (d < ndim && !(r.lo[d] >= xmin[d] && r.hi[d] <= xmax[d] && r.lo[d] <= r.hi[d]))
+            throw std::runtime_error("Refinement region must be smaller than the whole mesh.");
+        }
+        regions.push_back(r);
+      }
+      multilevel = !regions.empty();
+    }
+    if (multilevel) {
+      if (ng % 2 != 0) throw std::runtime_error("multilevel meshes need an even number of ghost zones");
+      for (int d = 0; d < ndim; ++d)
+        if (mbnx[d] % 2 != 0 || mbnx[d] / 2 < (ng + 1) / 2 + 1)
+          throw std::runtime_error("multilevel meshes need an even meshblock size of at least nghost + 4 zones");
+      for (int f = 0; f < 2 * ndim; ++f)
+        if (mesh_bc[f] > ARTEMIS_BC_REFLECT)
+          throw std::runtime_error("user boundary conditions on a statically refined mesh are not built "
+                                   "(periodic | outflow | reflecting are)");
+    }
+  }
   // geometry::CoordSelect (geometry.hpp:38-56, artemis.cpp:94-97)
   if (sys == "cartesian") coords = ARTEMIS_CARTESIAN;
   else if (sys == "spherical")
@@ -635,7 +733,8 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
           coords == ARTEMIS_CARTESIAN && !do_gravity && !do_rframe && !do_drag;
   // the general stage folds DiffusionUpdate (after the diffusion-flux tasks), the curvilinear rotating
   // frame and beta cooling into its kernel; cooling together with drag runs on the per-task chain
-  fused_possible = !(do_cooling && do_drag);
+  // a refined mesh needs the stage's face fluxes for flux correction (artemis_driver.cpp:196-202): per-task chain
+  fused_possible = !(do_cooling && do_drag) && !multilevel;
   tuned = tuned && fused_possible && !(do_viscosity || do_conduction || do_cooling);
   // Default path by measurement (scripts/path_timing.py, one MI355X): the cell-centred general stage wins
   // on Cartesian meshes (2048^2 viscous 1.73e9 vs 1.50e9 zone-cycles/s, SURVEY config 3 2.9e9 vs 1.1e9); in
@@ -643,11 +742,17 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   // both of its cells costs more than the flux arrays save (spherical 3-D blast 1.16e9 vs 1.29e9, disk
   // decks 5.7e8 vs 6.8e8), so those default to the per-task chain.  artemis_sim_set_path overrides.
   use_fused = fused_possible && coords == ARTEMIS_CARTESIAN;
+  if (multilevel) edge_ghosts = false; // the block-graph exchange fills all 3^ndim - 1 directions itself
   if (!use_fused) ensure_unfused();
   problem_generator();
 }
 
 void artemis_sim::build_mesh() {
+  if (multilevel) {
+    build_mesh_multilevel();
+    return;
+  }
+  nblocks_global = static_cast<long>(nblk[0]) * nblk[1] * nblk[2];
   choose_rank_grid(nranks, nblk, rgrid);
   // rank -> coordinates in the rank grid (x1 fastest)
   rcoord[0] = rank % rgrid[0];
@@ -707,6 +812,219 @@ void artemis_sim::build_mesh() {
   bc_flat.resize(6 * nb);
   for (int b = 0; b < nb; ++b)
     for (int f = 0; f < 6; ++f) bc_flat[6 * b + f] = blocks[b].bc[f];
+}
+
+// Statically refined mesh: leaves of the block tree in Z-order, dealt to the ranks in contiguous runs of
+// (nearly) equal length -- every block costs the same, which is Parthenon's default load balance.
+void artemis_sim::build_mesh_multilevel() {
+  artemis_host::BlockTree tree;
+  tree.ndim = ndim;
+  for (int d = 0; d < 3; ++d) tree.nrb[d] = nblk[d], tree.periodic[d] = (d < ndim) && mesh_bc[2 * d] == ARTEMIS_BC_PERIODIC;
+  for (const Region &r : regions) tree.add_region(r.level, r.lo, r.hi, xmin, xmax);
+  const std::vector<artemis_host::Leaf> leaves = tree.leaves();
+  ml.max_level = tree.max_level();
+  nblocks_global = static_cast<long>(leaves.size());
+  if (nblocks_global < nranks) throw std::runtime_error("fewer mesh blocks than ranks");
+  std::vector<int> rank_of(leaves.size()), local_of(leaves.size());
+  {
+    const long base_n = nblocks_global / nranks, extra = nblocks_global % nranks;
+    long g = 0;
+    for (int r = 0; r < nranks; ++r) {
+      const long cnt = base_n + (r < extra ? 1 : 0);
+      for (long q = 0; q < cnt; ++q, ++g) rank_of[g] = r, local_of[g] = static_cast<int>(q);
+    }
+  }
+  const int g[3] = {ng, ndim > 1 ? ng : 0, ndim > 2 ? ng : 0};
+  ni = mbnx[0] + 2 * g[0], nj = mbnx[1] + 2 * g[1], nk = mbnx[2] + 2 * g[2];
+  is = g[0], ie = g[0] + mbnx[0] - 1, js = g[1], je = g[1] + mbnx[1] - 1;
+  ks = g[2], ke = g[2] + mbnx[2] - 1;
+  N = static_cast<size_t>(ni) * nj * nk;
+  for (int d = 0; d < 3; ++d) rgrid[d] = 1, rcoord[d] = 0, lblk[d] = nblk[d];
+  blocks.clear();
+  for (size_t gb = 0; gb < leaves.size(); ++gb) {
+    if (rank_of[gb] != rank) continue;
+    Block B;
+    B.level = leaves[gb].level, B.gid = static_cast<long>(gb);
+    for (int d = 0; d < 3; ++d) {
+      B.lx[d] = leaves[gb].lx[d];
+      const int n = tree.extent(B.level, d);
+      // parthenon default (uniform) mesh generator on the logical location of the block's level
+      const Real rl = static_cast<Real>(B.lx[d]) / n, rr = static_cast<Real>(B.lx[d] + 1) / n;
+      B.xmin[d] = (B.lx[d] == 0) ? xmin[d] : xmin[d] * (1.0 - rl) + xmax[d] * rl;
+      B.xmax[d] = (B.lx[d] + 1 == n) ? xmax[d] : xmin[d] * (1.0 - rr) + xmax[d] * rr;
+    }
+    for (int f = 0; f < 6; ++f) {
+      const int d = f / 2, side = f % 2;
+      B.nbr_rank[f] = -1, B.nbr_block[f] = -1, B.bc[f] = ARTEMIS_BC_NONE;
+      if (d >= ndim) {
+        B.bc[f] = ARTEMIS_BC_OUTFLOW;
+        continue;
+      }
+      const bool outside = side ? (B.lx[d] + 1 == tree.extent(B.level, d)) : (B.lx[d] == 0);
+      if (outside && mesh_bc[f] != ARTEMIS_BC_PERIODIC) B.bc[f] = mesh_bc[f];
+    }
+    blocks.push_back(B);
+  }
+  nb = static_cast<int>(blocks.size());
+  bc_flat.resize(6 * nb);
+  for (int b = 0; b < nb; ++b)
+    for (int f = 0; f < 6; ++f) bc_flat[6 * b + f] = blocks[b].bc[f];
+
+  // operation lists: keep what touches this rank, global ids -> local indices / message slots
+  const artemis_host::MeshOps M = artemis_host::build_mesh_ops(tree, leaves, mbnx, ng);
+  const int nfill = 5 * ns_gas + 4 * ns_dust;
+  const int nflux = 7 * ns_gas + ((do_viscosity || do_conduction) ? 4 * ns_gas : 0) + 4 * ns_dust;
+  auto split = [&](const std::vector<artemis_host::GlobalOp> &all, int nvar, std::vector<artemis_ml_op_t> &packs_direct,
+                   std::vector<artemis_ml_op_t> &unpacks, std::vector<artemis_ml_op_t> *late, long &send_total,
+                   long &recv_total, std::vector<PeerMsg> &msgs, int tag) {
+    std::vector<long> send_n(nranks, 0), recv_n(nranks, 0);
+    auto slot = [&](const artemis_ml_op_t &o) { return static_cast<long>(nvar) * o.n[0] * o.n[1] * o.n[2]; };
+    for (const auto &G : all) {
+      const int rd = rank_of[G.op.dst_block], rs = rank_of[G.op.src_block];
+      if (rs == rank && rd != rank) send_n[rd] += slot(G.op);
+      if (rd == rank && rs != rank) recv_n[rs] += slot(G.op);
+    }
+    std::vector<long> send_at(nranks, 0), recv_at(nranks, 0);
+    send_total = recv_total = 0;
+    for (int r = 0; r < nranks; ++r) send_at[r] = send_total, send_total += send_n[r], recv_at[r] = recv_total, recv_total += recv_n[r];
+    std::vector<long> sa = send_at, ra = recv_at;
+    for (const auto &G : all) {
+      const int rd = rank_of[G.op.dst_block], rs = rank_of[G.op.src_block];
+      if (rd != rank && rs != rank) continue;
+      artemis_ml_op_t o = G.op;
+      o.dst_block = (rd == rank) ? local_of[G.op.dst_block] : -1;
+      o.src_block = (rs == rank) ? local_of[G.op.src_block] : -1;
+      const bool coarse_dst = (o.kind == ARTEMIS_ML_FROM_COARSER);
+      if (o.dst_block < 0) {
+        o.buf = sa[rd], sa[rd] += slot(o);
+        packs_direct.push_back(o);
+      } else if (o.src_block < 0) {
+        o.buf = ra[rs], ra[rs] += slot(o);
+        ((late && coarse_dst) ? *late : unpacks).push_back(o);
+      } else {
+        ((late && coarse_dst) ? *late : packs_direct).push_back(o);
+      }
+    }
+    msgs.clear(); // one message per peer and direction; buffer addresses are filled in by allocate_multilevel
+    for (int r = 0; r < nranks; ++r) {
+      if (send_n[r]) msgs.push_back(PeerMsg{r, tag, true, send_at[r], send_n[r]});
+      if (recv_n[r]) msgs.push_back(PeerMsg{r, tag, false, recv_at[r], recv_n[r]});
+    }
+  };
+  ml_host.a.clear(), ml_host.u.clear(), ml_host.b.clear(), ml_host.fx.clear(), ml_host.fxu.clear();
+  split(M.ghost, nfill, ml_host.a, ml_host.u, &ml_host.b, ml_host.gsend_n, ml_host.grecv_n, ml_host.gmsgs, 7001);
+  split(M.flux, nflux, ml_host.fx, ml_host.fxu, nullptr, ml_host.fsend_n, ml_host.frecv_n, ml_host.fmsgs, 7002);
+  ml_host.restrict_blocks.clear(), ml_host.boxes.clear();
+  for (size_t gb = 0; gb < leaves.size(); ++gb)
+    if (rank_of[gb] == rank && M.has_coarser[gb]) ml_host.restrict_blocks.push_back(local_of[gb]);
+  for (artemis_ml_box_t bx : M.prolong)
+    if (rank_of[bx.block] == rank) {
+      bx.block = local_of[bx.block];
+      ml_host.boxes.push_back(bx);
+    }
+  // physical conditions on the coarse buffers: only where a prolongation stencil can reach them
+  ml.bc_coarse.assign(6 * nb, ARTEMIS_BC_NONE);
+  for (int b : ml_host.restrict_blocks)
+    for (int f = 0; f < 6; ++f) ml.bc_coarse[6 * b + f] = blocks[b].bc[f];
+  for (int b = 0; b < nb; ++b)
+    for (int f = 2 * ndim; f < 6; ++f) ml.bc_coarse[6 * b + f] = ARTEMIS_BC_OUTFLOW; // inactive directions
+}
+
+void artemis_sim::allocate_multilevel() {
+  const int cg[3] = {ng, ndim > 1 ? ng : 0, ndim > 2 ? ng : 0};
+  const int cnx[3] = {mbnx[0] / 2, ndim > 1 ? mbnx[1] / 2 : 1, ndim > 2 ? mbnx[2] / 2 : 1};
+  const size_t cN = static_cast<size_t>(cnx[0] + 2 * cg[0]) * (cnx[1] + 2 * cg[1]) * (cnx[2] + 2 * cg[2]);
+  ml.gcoarse.alloc(nb, 6 * ns_gas, cN), ml.dcoarse.alloc(nb, 4 * ns_dust, cN);
+  std::vector<Real> hc(6 * nb);
+  for (int b = 0; b < nb; ++b)
+    for (int d = 0; d < 3; ++d) {
+      const Real dx = (blocks[b].xmax[d] - blocks[b].xmin[d]) / cnx[d];
+      hc[6 * b + 2 * d] = blocks[b].xmin[d] - cg[d] * dx, hc[6 * b + 2 * d + 1] = dx;
+    }
+  ml.cgeom.alloc(hc.size());
+  CK(artemis_rt_memcpy_h2d(ml.cgeom.p, hc.data(), hc.size() * sizeof(Real), nullptr), "h2d cgeom");
+  {
+    artemis_pack_t p0;
+    std::memset(&p0, 0, sizeof p0);
+    p0.nblocks = nb, p0.nghost = ng, p0.nx1 = cnx[0], p0.nx2 = cnx[1], p0.nx3 = cnx[2], p0.coords = coords;
+    const long nm = artemis_hip_metric_count(&p0);
+    if (nm > 0) {
+      std::vector<Real> hm(nm, 0.0);
+      CK(artemis_hip_metric_fill(&p0, hc.data(), hm.data()), "coarse metric tables");
+      ml.cmetric.alloc(nm);
+      CK(artemis_rt_memcpy_h2d(ml.cmetric.p, hm.data(), nm * sizeof(Real), nullptr), "h2d cmetric");
+    }
+  }
+  ml.ops_a.upload(ml_host.a), ml.ops_u.upload(ml_host.u), ml.ops_b.upload(ml_host.b);
+  ml.ops_fx.upload(ml_host.fx), ml.ops_fxu.upload(ml_host.fxu);
+  ml.restrict_blocks.upload(ml_host.restrict_blocks), ml.boxes.upload(ml_host.boxes);
+  ml.gsend.alloc(ml_host.gsend_n), ml.grecv.alloc(ml_host.grecv_n), ml.fsend.alloc(ml_host.fsend_n), ml.frecv.alloc(ml_host.frecv_n);
+  auto address = [](const std::vector<PeerMsg> &in, double *sbase, double *rbase, std::vector<artemis_msg_t> &out) {
+    out.clear();
+    for (const PeerMsg &q : in) {
+      artemis_msg_t m;
+      m.peer = q.peer, m.tag = q.tag, m.count = q.count;
+      m.send = q.is_send ? sbase + q.offset : nullptr, m.recv = q.is_send ? nullptr : rbase + q.offset;
+      out.push_back(m);
+    }
+  };
+  address(ml_host.gmsgs, ml.gsend.p, ml.grecv.p, ml.gmsgs);
+  address(ml_host.fmsgs, ml.fsend.p, ml.frecv.p, ml.fmsgs);
+  CK(artemis_rt_device_sync(), "sync");
+}
+
+// Post the per-peer messages of one phase on the comm stream, ordered behind the compute stream's packs
+// and ahead of its unpacks.
+void artemis_sim::exchange_messages(std::vector<artemis_msg_t> &msgs) {
+  if (msgs.empty()) return;
+  if (!has_comm) throw std::runtime_error("remote neighbours but no communicator");
+  CK(artemis_rt_event_record(ev0, stream), "event");
+  CK(artemis_rt_stream_wait_event(comm_stream, ev0), "wait");
+  if (comm.exchange_start(comm.ctx, static_cast<int>(msgs.size()), msgs.data(), comm_stream))
+    throw std::runtime_error("exchange_start failed");
+  if (comm.exchange_finish(comm.ctx, comm_stream)) throw std::runtime_error("exchange_finish failed");
+  CK(artemis_rt_event_record(ev1, comm_stream), "event");
+  CK(artemis_rt_stream_wait_event(stream, ev1), "wait");
+}
+
+// Ghost fill on a refined mesh (AddBoundaryExchangeTasks with pmesh->multilevel, artemis_driver.cpp:258):
+// same-level copies and restricted data from finer neighbours land in the fine ghost zones, coarser
+// neighbours' interiors in the coarse buffers; then ghost-halo restriction, physical conditions on the coarse
+// buffers, prolongation, physical conditions on the fine arrays.  Seven launches whatever the block count.
+void artemis_sim::fill_ghosts_multilevel(int prim_idx) {
+  const artemis_pack_t p = make_pack(prim_idx);
+  const artemis_ml_pack_t m = make_ml_pack();
+  CK(artemis_hip_ml_exchange(&p, &m, static_cast<const artemis_ml_op_t *>(ml.ops_a.p), ml.ops_a.n, ml.gsend.p, ml.grecv.p, stream),
+     "ml exchange (pack / same level / from finer)");
+  exchange_messages(ml.gmsgs);
+  CK(artemis_hip_ml_exchange(&p, &m, static_cast<const artemis_ml_op_t *>(ml.ops_u.p), ml.ops_u.n, ml.gsend.p, ml.grecv.p, stream),
+     "ml exchange (unpack)");
+  CK(artemis_hip_ml_restrict_halos(&p, &m, static_cast<const int *>(ml.restrict_blocks.p), ml.restrict_blocks.n, stream),
+     "ml restrict halos");
+  CK(artemis_hip_ml_exchange(&p, &m, static_cast<const artemis_ml_op_t *>(ml.ops_b.p), ml.ops_b.n, ml.gsend.p, ml.grecv.p, stream),
+     "ml exchange (from coarser)");
+  if (ml.restrict_blocks.n > 0) {
+    artemis_pack_t pc = p; // the coarse buffers as a pack of their own: same tables layout, half the zones
+    pc.nx1 = mbnx[0] / 2, pc.nx2 = (ndim > 1) ? mbnx[1] / 2 : 1, pc.nx3 = (ndim > 2) ? mbnx[2] / 2 : 1;
+    pc.geom = ml.cgeom.p, pc.metric = ml.cmetric.p;
+    pc.gas.prim = ml.gcoarse.tab(), pc.dust.prim = ml.dcoarse.tab();
+    artemis_bc_params_t bp = bcpar;
+    bp.floor_ghosts = 0;
+    CK(artemis_hip_apply_bc(&pc, ml.bc_coarse.data(), &bp, stream), "apply_bc (coarse buffers)");
+    CK(artemis_hip_ml_prolongate(&p, &m, static_cast<const artemis_ml_box_t *>(ml.boxes.p), ml.boxes.n, stream), "ml prolongate");
+  }
+  artemis_bc_params_t bp = bcpar;
+  bp.floor_ghosts = 0;
+  CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc");
+}
+
+// SendBoundBufs<flxcor_send> / ReceiveFluxCorrections / SetFluxCorrections (artemis_driver.cpp:196-202)
+void artemis_sim::flux_correction_multilevel(const artemis_pack_t &p) {
+  CK(artemis_hip_ml_flux_correction(&p, static_cast<const artemis_ml_op_t *>(ml.ops_fx.p), ml.ops_fx.n, ml.fsend.p, ml.frecv.p, stream),
+     "flux correction");
+  exchange_messages(ml.fmsgs);
+  CK(artemis_hip_ml_flux_correction(&p, static_cast<const artemis_ml_op_t *>(ml.ops_fxu.p), ml.ops_fxu.n, ml.fsend.p, ml.frecv.p, stream),
+     "flux correction (unpack)");
 }
 
 void artemis_sim::allocate() {
@@ -770,6 +1088,7 @@ void artemis_sim::allocate() {
       L->tag_recv = static_cast<int>(blocks[b].gid * 6 + f);
       links.push_back(std::move(L));
     }
+  if (multilevel) allocate_multilevel();
   CK(artemis_rt_device_sync(), "sync");
 }
 
@@ -873,6 +1192,10 @@ void artemis_sim::fill_ghosts_finish(int prim_idx, void *hs, int dim, bool apply
   }
 }
 void artemis_sim::fill_ghosts(int prim_idx) {
+  if (multilevel) {
+    fill_ghosts_multilevel(prim_idx);
+    return;
+  }
   if (!edge_ghosts) {
     fill_ghosts_start(prim_idx, stream, -1);
     fill_ghosts_finish(prim_idx, stream, -1, true);
@@ -1030,8 +1353,6 @@ void artemis_sim::problem_generator() {
   if (pgen == PG_DISK) {
     if (!do_gas || ns_gas != 1) throw std::runtime_error("disk pgen requires a single gas species.");
     if (!do_gravity) throw std::runtime_error("disk pgen reads gm of the gravity package: physics/gravity is required");
-    if (coords == ARTEMIS_CARTESIAN && pin.DoesBlockExist("parthenon/static_refinement1"))
-      throw std::runtime_error("static mesh refinement is out of scope of this build");
     dk.gm = grav.gm;
     dk.r0 = pin.GetOrAddReal("problem", "r0", 1.0);
     dk.Omega0 = std::sqrt(dk.gm / (dk.r0 * dk.r0 * dk.r0));
@@ -1635,6 +1956,7 @@ void artemis_sim::step_unfused() {
       if (do_viscosity) CK(artemis_hip_viscous_flux(&p, &diff, stream), "Gas::ViscousFlux");
       if (do_conduction) CK(artemis_hip_thermal_flux(&p, &diff, stream), "Gas::ThermalFlux");
     }
+    if (multilevel) flux_correction_multilevel(p); // artemis_driver.cpp:196-202
     place_binary();
     if (!do_drag && std::getenv("ARTEMIS_NO_EPILOGUE") == nullptr) {
       // everything between the flux tasks and the boundary exchange is cell-local: one pass over the
@@ -1952,8 +2274,12 @@ long artemis_sim_local_zones(const artemis_sim_t *s) {
   return static_cast<long>(s->nb) * s->mbnx[0] * s->mbnx[1] * s->mbnx[2];
 }
 long artemis_sim_total_zones(const artemis_sim_t *s) {
-  return static_cast<long>(s->nx[0]) * s->nx[1] * s->nx[2];
+  return s->nblocks_global * s->mbnx[0] * s->mbnx[1] * s->mbnx[2];
 }
+int artemis_sim_block_level(const artemis_sim_t *s, int block) {
+  return (block >= 0 && block < s->nb) ? s->blocks[block].level : -1;
+}
+long artemis_sim_nblocks_global(const artemis_sim_t *s) { return s->nblocks_global; }
 int artemis_sim_uses_fused_path(const artemis_sim_t *s) { return s->use_fused ? 1 : 0; }
 int artemis_sim_uses_tuned_kernel(const artemis_sim_t *s) { return (s->use_fused && s->tuned) ? 1 : 0; }
 int artemis_sim_set_path(artemis_sim_t *s, const char *which) {

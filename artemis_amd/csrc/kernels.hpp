@@ -46,4 +46,12 @@ void launch_amr_criterion(const artemis_amr_criterion_t &a, int magnitude, hipSt
 void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t &g, hipStream_t s);
 void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
                        int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s);
+// kernels_amr.hip
+void launch_ml_exchange(const PackView &P, const artemis_ml_pack_t &ml, const artemis_ml_op_t *ops, int nops, double *sbuf,
+                        const double *rbuf, hipStream_t s);
+void launch_ml_flux_correction(const PackView &P, const artemis_ml_op_t *ops, int nops, double *sbuf, const double *rbuf,
+                               hipStream_t s);
+void launch_ml_restrict_halos(const PackView &P, const artemis_ml_pack_t &ml, const int *blocks, int nblocks, hipStream_t s);
+void launch_ml_prolongate(const PackView &P, const artemis_ml_pack_t &ml, const artemis_ml_box_t *boxes, int nboxes,
+                          hipStream_t s);
 } // namespace artemis

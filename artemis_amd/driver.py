@@ -217,6 +217,9 @@ def _declare(L):
     L.artemis_sim_set_dropin.argtypes = [vp, i]
     L.artemis_sim_species.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.artemis_sim_set_kernel_timing.argtypes = [vp, i]
+    L.artemis_sim_block_level.argtypes = [vp, i]
+    L.artemis_sim_nblocks_global.restype = l
+    L.artemis_sim_nblocks_global.argtypes = [vp]
     L.artemis_sim_dims.argtypes = [vp, C.POINTER(i)]
     L.artemis_sim_get_field.argtypes = [vp, C.c_char_p, i, vp]
     L.artemis_sim_block_bounds.argtypes = [vp, i, C.POINTER(d)]
@@ -312,6 +315,11 @@ class Simulation:
 
     def interior(self, a):
         return a[..., self.ks:self.ke + 1, self.js:self.je + 1, self.is_:self.ie + 1]
+
+    def block_level(self, block=0):
+        return self.L.artemis_sim_block_level(self.h, block)
+
+    nblocks_global = property(lambda s: s.L.artemis_sim_nblocks_global(s.h))
 
     def block_bounds(self, block=0):
         o = (C.c_double * 6)()

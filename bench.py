@@ -66,6 +66,34 @@ def cpu_baseline(n, cycles, threads):
     return n ** 3 * done / dt, dt, done
 
 
+def host_cores():
+    """What this process may actually use: logical CPUs in its affinity mask, clipped by a cgroup CPU
+    quota, and the SMT width (cpu_baseline runs one thread per physical core)."""
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    smt = 1
+    try:
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        smt = max(1, len(sib.replace("-", ",").split(",")))
+    except Exception:
+        pass
+    usable = logical if quota is None else max(1, min(logical, int(quota)))
+    return {"logical": logical, "cgroup_quota": quota, "smt": smt, "physical_usable": max(1, usable // smt)}
+
+
 def kernel_source_sha1():
     """Identity of the tuned stage kernel's sources: a PMC traffic record is only quoted next to a
     timing when it was measured on these very sources (scripts/pmc_traffic.py writes the same hash)."""
@@ -358,18 +386,20 @@ def main():
                 "value": v, "unit": "zone-cycles/s", "cores": os.cpu_count(), "kind": "port",
                 "sample": "CPU oracle (OpenMP, all host cores), same problem at %d^2, %d cycles, %.1f s" % (cn, cyc, secs)}
         elif args.gpus == 1 and not args.no_cpu_baseline:
-            threads = args.cpu_threads or os.cpu_count()
+            hc = host_cores()
+            threads = args.cpu_threads or hc["physical_usable"]
             v, secs, cyc = cpu_baseline(args.cpu_n, args.cpu_cycles, threads)
             v1, secs1, cyc1 = cpu_baseline(128, 2, 1)  # the same code on ONE core (128^3: ~4 s)
             out["cpu_baseline"] = {
                 "value": v, "unit": "zone-cycles/s", "cores": threads, "kind": "port",
-                "threads": threads, "per_core": v / threads, "one_thread": v1,
+                "threads": threads, "per_core": v / threads, "one_thread": v1, "host": hc,
                 "parallel_efficiency": v / threads / v1,
                 "sample": "CPU oracle (C++ restatement of the reference's CPU path, NOT the Artemis executable; OpenMP over "
                           "k-j rows, arrays first-touched by the sweeping threads, OMP_PROC_BIND=%s OMP_PLACES=%s): Sedov %d^3, "
-                          "%d cycles in %.1f s on %d threads of %d host cores; one thread: Sedov 128^3, %d cycles in %.1f s"
+                          "%d cycles in %.1f s on %d threads (one per usable physical core; %d logical CPUs); one thread: Sedov 128^3, "
+                          "%d cycles in %.1f s.  Thread scaling of this restatement on this host: profiles/r02_cpu_scaling.txt"
                           % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), args.cpu_n, cyc, secs, threads,
-                             os.cpu_count(), cyc1, secs1)}
+                             hc["logical"], cyc1, secs1)}
         print(json.dumps(out), flush=True)
     sim.close()
     if comm is not None:

@@ -85,6 +85,11 @@ long artemis_sim_ncycle(const artemis_sim_t *sim);
 /* interior cells owned by this rank / by all ranks */
 long artemis_sim_local_zones(const artemis_sim_t *sim);
 long artemis_sim_total_zones(const artemis_sim_t *sim);
+/* Statically refined meshes (<parthenon/mesh> refinement = static + <parthenon/static_refinementN>): mesh blocks
+ * of this rank carry their level; every block has the same number of zones.  The refined mesh runs the
+ * per-task chain (flux correction needs the stage's face fluxes). */
+int artemis_sim_block_level(const artemis_sim_t *sim, int block);
+long artemis_sim_nblocks_global(const artemis_sim_t *sim);
 int artemis_sim_uses_fused_path(const artemis_sim_t *sim);
 /* 1 when the fused path runs the hand-tuned gas kernel (artemis_hip_stage_fused), 0 when it runs
  * the general cell-centred stage (artemis_hip_stage_general) or the per-task chain */

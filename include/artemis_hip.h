@@ -437,6 +437,65 @@ typedef struct artemis_refine {
 int artemis_hip_restrict_average(const artemis_refine_t *r, void *stream);
 int artemis_hip_prolongate_minmod(const artemis_refine_t *r, void *stream);
 
+/* ---- multilevel (SMR / AMR) block-graph data path -------------------------------------------------
+ * What Parthenon does around Artemis' tasks on a refined mesh, batched for the GPU: every mesh block of
+ * the pack has the same shape but its own level (its own row of p->geom).  The host builds a list of
+ * box-to-box operations once per mesh (artemis_amd/csrc/driver/block_tree.hpp) and uploads it; each call
+ * below processes a whole list in ONE launch (one workgroup per operation).
+ *   ghost exchange of the FillGhost primitives (AddBoundaryExchangeTasks with pmesh->multilevel,
+ *   artemis_driver.cpp:258; upstream SendBoundBufs / SetBounds / ProlongateBounds, recalled):
+ *     SAME          dst fine ghost box  <-  src fine interior                     (same-level neighbour)
+ *     FROM_FINER    dst fine ghost box  <-  RestrictAverage<GEOM> of 2^ndim src fine zones per dst zone
+ *                                           (restriction.hpp:42-114; the finer neighbour "sends restricted")
+ *     FROM_COARSER  dst COARSE-BUFFER box <- src fine interior of the coarser neighbour
+ *   flux correction (artemis_driver.cpp:196-202):
+ *     FLUX          dst coarse-block face fluxes <- RestrictAverage<el = F_dir> (area-weighted, :57-94) of
+ *                   the 2^(ndim-1) fine faces of the finer neighbour, for every WithFluxes variable (cons
+ *                   D, M, E, e_int; the pressure flux, gas.cpp:212-252) and the Metadata::Flux diffusion
+ *                   fluxes (gas.cpp:276-284); gas::face::velocity is not WithFluxes and is left alone
+ * Source index of destination index i along dimension q: a_q * i + off[q] with a_q = 1 (SAME,
+ * FROM_COARSER), 2 (FROM_FINER; FLUX tangential), 0 (FLUX normal: off = the fine face index).
+ * A block index of -1 means "on another rank": the op then packs into sendbuf (dst remote) or unpacks
+ * from recvbuf (src remote) at `buf`, slot layout [variable][n3][n2][n1] over the op's variables
+ * (ghost ops: the 5 ns_gas + 4 ns_dust FillGhost primitives; FLUX: 6 ns_gas + ns_gas (+ 4 ns_gas with
+ * diffusion fluxes) + 4 ns_dust). */
+enum artemis_ml_kind { ARTEMIS_ML_SAME = 0, ARTEMIS_ML_FROM_FINER = 1, ARTEMIS_ML_FROM_COARSER = 2,
+                       ARTEMIS_ML_FLUX = 3 };
+typedef struct artemis_ml_op {
+  int kind;                 /* artemis_ml_kind */
+  int dst_block, src_block; /* indices into the pack, -1 = remote */
+  int dir;                  /* FLUX: direction 0..2 of the faces */
+  int lo[3], n[3];          /* destination box: first index and extent along x1, x2, x3 */
+  int off[3];
+  long buf;                 /* slot offset in doubles (remote ops) */
+} artemis_ml_op_t;
+typedef struct artemis_ml_box { /* a box of coarse-buffer zones of one block */
+  int block, lo[3], n[3];
+} artemis_ml_box_t;
+typedef struct artemis_ml_pack {
+  /* coarse buffers: one array of (nx/2 + 2 nghost) zones per active dimension for every variable of the
+   * prim tables, laid out like them ([nblocks * 6 ns_gas], [nblocks * 4 ns_dust]) */
+  double *const *gas_coarse, *const *dust_coarse;
+  const double *cgeom;   /* DEVICE [nblocks][6] edge table of the coarse buffers' index space */
+  const double *cmetric; /* their metric tables (artemis_hip_metric_fill on the coarse shape), or NULL */
+} artemis_ml_pack_t;
+/* ops_dev: DEVICE array of nops operations.  sendbuf / recvbuf: DEVICE message buffers (NULL when no op is
+ * remote).  The FillGhost primitives are read from / written to p->gas.prim, p->dust.prim. */
+int artemis_hip_ml_exchange(const artemis_pack_t *p, const artemis_ml_pack_t *ml, const artemis_ml_op_t *ops_dev,
+                            int nops, double *sendbuf, const double *recvbuf, void *stream);
+/* FLUX ops on p->{gas,dust}.flux / pflux / diff_flux (ml may be NULL) */
+int artemis_hip_ml_flux_correction(const artemis_pack_t *p, const artemis_ml_op_t *ops_dev, int nops, double *sendbuf,
+                                   const double *recvbuf, void *stream);
+/* RestrictAverage of blocks_dev[0..nblocks)'s own fine arrays (interior + nghost/2 coarse zones of ghost halo
+ * all round) into their coarse buffers: gives ProlongateSharedMinMod its +-1 stencil next to the zones that
+ * came from a coarser neighbour (upstream: restriction of the ghost halos inside ProlongateBounds). */
+int artemis_hip_ml_restrict_halos(const artemis_pack_t *p, const artemis_ml_pack_t *ml, const int *blocks_dev, int nblocks,
+                                  void *stream);
+/* ProlongateSharedMinMod<GEOM> (prolongation.hpp:83-184) from the coarse buffer into the fine ghost zones
+ * covered by each box (boxes_dev: DEVICE array; coarse index cs + q <-> fine index s + 2 q). */
+int artemis_hip_ml_prolongate(const artemis_pack_t *p, const artemis_ml_pack_t *ml, const artemis_ml_box_t *boxes_dev,
+                              int nboxes, void *stream);
+
 /* ---- refinement criteria (utils/refinement/amr_criteria.hpp) ------------------------------------
  * ArtemisUtils::ScalarFirstDerivative<FIELD, GEOM> (:28-132) and ScalarMagnitude<FIELD> (:137-168): the
  * block-wide maximum that decides a mesh block's AmrTag, for one cell-centred scalar (the first

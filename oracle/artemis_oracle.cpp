@@ -3058,6 +3058,23 @@ void oracle_prolongate_minmod(void *hf, void *hc, const int *r) {
         }
 }
 
+// Lower-face areas Coords<GEOM>::GetFaceArea<dir> (and cell volumes, dir = 0) of every cell of the block,
+// for the multilevel oracle's flux correction (RestrictAverage with el = F1/F2/F3, restriction.hpp:88-94).
+void oracle_face_areas(void *h, int dir, double *out) {
+  Sim &s = *static_cast<Sim *>(h);
+  for (int k = 0; k < s.nk; ++k)
+    for (int j = 0; j < s.nj; ++j)
+      for (int i = 0; i < s.ni; ++i) {
+        Coords co(s, k, j, i);
+        Real a[2] = {0, 0};
+        if (dir == 1) co.GetFaceAreaX1(a);
+        else if (dir == 2) co.GetFaceAreaX2(a);
+        else if (dir == 3) co.GetFaceAreaX3(a);
+        else a[0] = co.Volume();
+        out[IDX(s, k, j, i)] = a[0];
+      }
+}
+
 // <cooling> type = beta, tref = powerlaw (cooling.cpp:34-63)
 void oracle_set_cooling(void *h, const double *p) {
   Sim &s = *static_cast<Sim *>(h);

@@ -134,6 +134,7 @@ def lib():
         L.oracle_amr_first_derivative.restype = i
         L.oracle_amr_magnitude.argtypes = [vp, i, d, d, C.POINTER(d)]
         L.oracle_amr_magnitude.restype = i
+        L.oracle_face_areas.argtypes = [vp, i, vp]
         L.oracle_set_damp_to_visc.argtypes = [vp, i]
         L.oracle_set_damp_to_visc.restype = i
         L.oracle_set_cooling.argtypes = [vp, C.POINTER(d)]
@@ -357,6 +358,12 @@ class Oracle:
 
     def ProlongateSharedMinMod(self, coarse, crange, corigin, forigin):
         self.L.oracle_prolongate_minmod(self.h, coarse.h, (C.c_int * 12)(*crange, *corigin, *forigin))
+
+    def face_areas(self, dir):
+        """Lower-face areas GetFaceArea<dir> (dir = 1..3) or cell volumes (dir = 0), [nk, nj, ni]."""
+        out = np.empty((self.nk, self.nj, self.ni))
+        self.L.oracle_face_areas(self.h, dir, out.ctypes.data)
+        return out
 
     def set_damp_to_visc(self, on=True):
         """<gas/damping> damp_to_visc (drag.hpp:101): the gas damping relaxes towards the viscous inflow

@@ -10,7 +10,9 @@
 #include <cfloat>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <vector>
 
 #include "../../oracle/artemis_oracle.cpp"
 
@@ -686,6 +688,209 @@ int artemis_hip_selftest_divsqrt(long, const double *, const double *, double *,
 
 // ---- runtime shim on host memory ----------------------------------------------------------
 // the refinement operators are exercised against the oracle on the GPU only; the host stand-in has no use for them
+// ---- multilevel block-graph data path on host memory (include/artemis_hip.h), with the oracle's Coords --------
+} // extern "C"
+namespace {
+struct MlHost {
+  const artemis_pack_t *p;
+  const artemis_ml_pack_t *ml;
+  int ndim, ni, nj, nk, cni, cnj, cnk, s[3], cn[3];
+  std::vector<std::unique_ptr<Bound>> fine, coarse;
+  artemis_pack_t pc;
+  MlHost(const artemis_pack_t *p_, const artemis_ml_pack_t *ml_) : p(p_), ml(ml_) {
+    ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
+    const int g = p->nghost, nx[3] = {p->nx1, p->nx2, p->nx3};
+    for (int d = 0; d < 3; ++d) s[d] = (d < ndim) ? g : 0, cn[d] = (d < ndim) ? nx[d] / 2 : 1;
+    ni = nx[0] + 2 * s[0], nj = nx[1] + 2 * s[1], nk = nx[2] + 2 * s[2];
+    cni = cn[0] + 2 * s[0], cnj = cn[1] + 2 * s[1], cnk = cn[2] + 2 * s[2];
+    fine.resize(p->nblocks), coarse.resize(p->nblocks);
+    pc = *p;
+    pc.nx1 = cn[0], pc.nx2 = cn[1], pc.nx3 = cn[2];
+    if (ml) pc.geom = ml->cgeom, pc.metric = ml->cmetric;
+  }
+  Sim &F(int b) {
+    if (!fine[b]) fine[b].reset(new Bound(p, b));
+    return *fine[b]->s;
+  }
+  Sim &C(int b) {
+    if (!coarse[b]) coarse[b].reset(new Bound(&pc, b));
+    return *coarse[b]->s;
+  }
+  int nfill() const { return 5 * p->gas.nspecies + 4 * p->dust.nspecies; }
+  double *var(bool crs, int b, int v) const {
+    const int nsg = p->gas.nspecies, nsd = p->dust.nspecies;
+    if (v < 5 * nsg) {
+      const int slot = (v < 4 * nsg) ? v : v + nsg;
+      return (crs ? ml->gas_coarse : p->gas.prim)[b * 6 * nsg + slot];
+    }
+    return (crs ? ml->dust_coarse : p->dust.prim)[b * 4 * nsd + (v - 5 * nsg)];
+  }
+  size_t fidx(int k, int j, int i) const { return (static_cast<size_t>(k) * nj + j) * ni + i; }
+  size_t cidx(int k, int j, int i) const { return (static_cast<size_t>(k) * cnj + j) * cni + i; }
+  // RestrictAverage (restriction.hpp:73-112) of the fine zones at (fk, fj, fi) of block b, weights w (volumes / areas)
+  template <class W>
+  double restrict8(const double *q, int fk, int fj, int fi, bool I1, bool I2, bool I3, W weight) const {
+    Real w[2][2][2], t[2][2][2];
+    for (int ok = 0; ok < 2; ++ok)
+      for (int oj = 0; oj < 2; ++oj)
+        for (int oi = 0; oi < 2; ++oi) w[ok][oj][oi] = t[ok][oj][oi] = 0;
+    for (int ok = 0; ok < 1 + I3; ++ok)
+      for (int oj = 0; oj < 1 + I2; ++oj)
+        for (int oi = 0; oi < 1 + I1; ++oi) {
+          w[ok][oj][oi] = weight(fk + ok, fj + oj, fi + oi);
+          t[ok][oj][oi] = w[ok][oj][oi] * q[fidx(fk + ok, fj + oj, fi + oi)];
+        }
+    const Real tw = ((w[0][0][0] + w[0][1][0]) + (w[0][0][1] + w[0][1][1])) + ((w[1][0][0] + w[1][1][0]) + (w[1][0][1] + w[1][1][1]));
+    return (((t[0][0][0] + t[0][1][0]) + (t[0][0][1] + t[0][1][1])) + ((t[1][0][0] + t[1][1][0]) + (t[1][0][1] + t[1][1][1]))) / tw;
+  }
+};
+} // namespace
+extern "C" {
+int artemis_hip_ml_exchange(const artemis_pack_t *p, const artemis_ml_pack_t *ml, const artemis_ml_op_t *ops, int nops,
+                            double *sbuf, const double *rbuf, void *) {
+  MlHost H(p, ml);
+  const int nf = H.nfill();
+  for (int q = 0; q < nops; ++q) {
+    const artemis_ml_op_t &op = ops[q];
+    const bool crs = (op.kind == ARTEMIS_ML_FROM_COARSER);
+    const long ncell = static_cast<long>(op.n[0]) * op.n[1] * op.n[2];
+    long t = 0;
+    for (int q2 = 0; q2 < op.n[2]; ++q2)
+      for (int q1 = 0; q1 < op.n[1]; ++q1)
+        for (int q0 = 0; q0 < op.n[0]; ++q0, ++t) {
+          const int i = op.lo[0] + q0, j = op.lo[1] + q1, k = op.lo[2] + q2;
+          const size_t dc = crs ? H.cidx(k, j, i) : H.fidx(k, j, i);
+          for (int v = 0; v < nf; ++v) {
+            double val;
+            if (op.src_block < 0) {
+              val = rbuf[op.buf + v * ncell + t];
+            } else if (op.kind == ARTEMIS_ML_FROM_FINER) {
+              const int fi = 2 * i + op.off[0], fj = (H.ndim > 1) ? 2 * j + op.off[1] : j, fk = (H.ndim > 2) ? 2 * k + op.off[2] : k;
+              Sim &fs = H.F(op.src_block);
+              val = H.restrict8(H.var(false, op.src_block, v), fk, fj, fi, true, H.ndim > 1, H.ndim > 2,
+                                [&](int kk, int jj, int ii) { return Coords(fs, kk, jj, ii).Volume(); });
+            } else {
+              val = H.var(false, op.src_block, v)[H.fidx(k + op.off[2], j + op.off[1], i + op.off[0])];
+            }
+            if (op.dst_block < 0) sbuf[op.buf + v * ncell + t] = val;
+            else H.var(crs, op.dst_block, v)[dc] = val;
+          }
+        }
+  }
+  return 0;
+}
+int artemis_hip_ml_restrict_halos(const artemis_pack_t *p, const artemis_ml_pack_t *ml, const int *blocks, int nblocks, void *) {
+  MlHost H(p, ml);
+  const int h = p->nghost / 2, nf = H.nfill();
+  for (int q = 0; q < nblocks; ++q) {
+    const int b = blocks[q];
+    Sim &fs = H.F(b);
+    const int lo[3] = {H.s[0] - h, H.ndim > 1 ? H.s[1] - h : 0, H.ndim > 2 ? H.s[2] - h : 0};
+    const int hi[3] = {H.s[0] + H.cn[0] + h, H.ndim > 1 ? H.s[1] + H.cn[1] + h : 1, H.ndim > 2 ? H.s[2] + H.cn[2] + h : 1};
+    for (int ck = lo[2]; ck < hi[2]; ++ck)
+      for (int cj = lo[1]; cj < hi[1]; ++cj)
+        for (int ci = lo[0]; ci < hi[0]; ++ci) {
+          const int fi = (ci - H.s[0]) * 2 + H.s[0], fj = (H.ndim > 1) ? (cj - H.s[1]) * 2 + H.s[1] : 0;
+          const int fk = (H.ndim > 2) ? (ck - H.s[2]) * 2 + H.s[2] : 0;
+          for (int v = 0; v < nf; ++v)
+            H.var(true, b, v)[H.cidx(ck, cj, ci)] =
+                H.restrict8(H.var(false, b, v), fk, fj, fi, true, H.ndim > 1, H.ndim > 2,
+                            [&](int kk, int jj, int ii) { return Coords(fs, kk, jj, ii).Volume(); });
+        }
+  }
+  return 0;
+}
+int artemis_hip_ml_prolongate(const artemis_pack_t *p, const artemis_ml_pack_t *ml, const artemis_ml_box_t *boxes, int nboxes, void *) {
+  MlHost H(p, ml);
+  const int nf = H.nfill(), DIM = H.ndim;
+  const bool X1 = true, X2 = DIM > 1, X3 = DIM > 2;
+  auto sign = [](Real a) { return (a < 0.) ? -1. : 1.; };
+  auto centre = [](const Coords &co, int d) { return d == 1 ? co.x1v() : (d == 2 ? co.x2v() : co.x3v()); };
+  for (int q = 0; q < nboxes; ++q) {
+    const artemis_ml_box_t &bx = boxes[q];
+    Sim &f = H.F(bx.block), &c = H.C(bx.block);
+    for (int k = bx.lo[2]; k < bx.lo[2] + bx.n[2]; ++k)
+      for (int j = bx.lo[1]; j < bx.lo[1] + bx.n[1]; ++j)
+        for (int i = bx.lo[0]; i < bx.lo[0] + bx.n[0]; ++i) {
+          const int fi = (i - H.s[0]) * 2 + H.s[0], fj = X2 ? (j - H.s[1]) * 2 + H.s[1] : 0, fk = X3 ? (k - H.s[2]) * 2 + H.s[2] : 0;
+          for (int v = 0; v < nf; ++v) { // prolongation.hpp:83-184
+            const Real *qc = H.var(true, bx.block, v);
+            const Real fc = qc[H.cidx(k, j, i)];
+            Real dxfm[3] = {0, 0, 0}, dxfp[3] = {0, 0, 0}, g[3] = {0, 0, 0};
+            for (int d = 1; d <= DIM; ++d) {
+              const int dk = (d == 3), dj = (d == 2), di = (d == 1);
+              const Real xm = centre(Coords(c, k - dk, j - dj, i - di), d), xc = centre(Coords(c, k, j, i), d);
+              const Real xp = centre(Coords(c, k + dk, j + dj, i + di), d);
+              const Real fxm = centre(Coords(f, fk, fj, fi), d), fxp = centre(Coords(f, fk + dk, fj + dj, fi + di), d);
+              const Real dxm = xc - xm, dxp = xp - xc;
+              dxfm[d - 1] = xc - fxm, dxfp[d - 1] = fxp - xc;
+              const Real gxm = (fc - qc[H.cidx(k - dk, j - dj, i - di)]) / dxm;
+              const Real gxp = (qc[H.cidx(k + dk, j + dj, i + di)] - fc) / dxp;
+              g[d - 1] = 0.5 * (sign(gxm) + sign(gxp)) * std::min(std::abs(gxm), std::abs(gxp));
+            }
+            const Real gx1m = g[0], gx1p = g[0], gx2m = g[1], gx2p = g[1], gx3m = g[2], gx3p = g[2];
+            const Real dx1fm = dxfm[0], dx1fp = dxfp[0], dx2fm = dxfm[1], dx2fp = dxfp[1], dx3fm = dxfm[2], dx3fp = dxfp[2];
+            Real *o = H.var(false, bx.block, v);
+            o[H.fidx(fk, fj, fi)] = fc - (gx1m * dx1fm + gx2m * dx2fm + gx3m * dx3fm);
+            if (X1) o[H.fidx(fk, fj, fi + 1)] = fc + (gx1p * dx1fp - gx2m * dx2fm - gx3m * dx3fm);
+            if (X2) o[H.fidx(fk, fj + 1, fi)] = fc - (gx1m * dx1fm - gx2p * dx2fp + gx3m * dx3fm);
+            if (X2 && X1) o[H.fidx(fk, fj + 1, fi + 1)] = fc + (gx1p * dx1fp + gx2p * dx2fp - gx3m * dx3fm);
+            if (X3) o[H.fidx(fk + 1, fj, fi)] = fc - (gx1m * dx1fm + gx2m * dx2fm - gx3p * dx3fp);
+            if (X3 && X1) o[H.fidx(fk + 1, fj, fi + 1)] = fc + (gx1p * dx1fp - gx2m * dx2fm + gx3p * dx3fp);
+            if (X3 && X2) o[H.fidx(fk + 1, fj + 1, fi)] = fc - (gx1m * dx1fm - gx2p * dx2fp - gx3p * dx3fp);
+            if (X3 && X2 && X1) o[H.fidx(fk + 1, fj + 1, fi + 1)] = fc + (gx1p * dx1fp + gx2p * dx2fp + gx3p * dx3fp);
+          }
+        }
+  }
+  return 0;
+}
+int artemis_hip_ml_flux_correction(const artemis_pack_t *p, const artemis_ml_op_t *ops, int nops, double *sbuf, const double *rbuf,
+                                   void *) {
+  MlHost H(p, nullptr);
+  const int nsg = p->gas.nspecies, nsd = p->dust.nspecies;
+  for (int q = 0; q < nops; ++q) {
+    const artemis_ml_op_t &op = ops[q];
+    const int d = op.dir;
+    const bool diff = nsg > 0 && p->gas.diff_flux[0] != nullptr;
+    std::vector<std::pair<double *const *, int>> sets; // (table, vars per block)
+    sets.push_back({p->gas.flux[d], 6 * nsg}), sets.push_back({p->gas.pflux[d], nsg});
+    if (diff) sets.push_back({p->gas.diff_flux[d], 4 * nsg});
+    sets.push_back({p->dust.flux[d], 4 * nsd});
+    const long ncell = static_cast<long>(op.n[0]) * op.n[1] * op.n[2];
+    const bool I1 = d != 0, I2 = (H.ndim > 1) && d != 1, I3 = (H.ndim > 2) && d != 2;
+    long t = 0;
+    for (int q2 = 0; q2 < op.n[2]; ++q2)
+      for (int q1 = 0; q1 < op.n[1]; ++q1)
+        for (int q0 = 0; q0 < op.n[0]; ++q0, ++t) {
+          const int i = op.lo[0] + q0, j = op.lo[1] + q1, k = op.lo[2] + q2;
+          const int fi = (d == 0) ? op.off[0] : 2 * i + op.off[0];
+          const int fj = (d == 1) ? op.off[1] : ((H.ndim > 1) ? 2 * j + op.off[1] : j);
+          const int fk = (d == 2) ? op.off[2] : ((H.ndim > 2) ? 2 * k + op.off[2] : k);
+          int v = 0;
+          for (auto &st : sets)
+            for (int n = 0; n < st.second; ++n, ++v) {
+              double val;
+              if (op.src_block < 0) {
+                val = rbuf[op.buf + v * ncell + t];
+              } else {
+                Sim &fs = H.F(op.src_block);
+                val = H.restrict8(st.first[op.src_block * st.second + n], fk, fj, fi, I1, I2, I3, [&](int kk, int jj, int ii) {
+                  Real a[2];
+                  Coords co(fs, kk, jj, ii);
+                  if (d == 0) co.GetFaceAreaX1(a);
+                  else if (d == 1) co.GetFaceAreaX2(a);
+                  else co.GetFaceAreaX3(a);
+                  return a[0];
+                });
+              }
+              if (op.dst_block < 0) sbuf[op.buf + v * ncell + t] = val;
+              else st.first[op.dst_block * st.second + n][H.fidx(k, j, i)] = val;
+            }
+        }
+  }
+  return 0;
+}
+
 int artemis_hip_restrict_average(const artemis_refine_t *, void *) { return bad("refinement operators: GPU library only"); }
 int artemis_hip_prolongate_minmod(const artemis_refine_t *, void *) { return bad("refinement operators: GPU library only"); }
 int artemis_hip_amr_first_derivative(const artemis_amr_criterion_t *, int *, double *, void *) { return bad("refinement criteria: GPU library only"); }

@@ -1,0 +1,264 @@
+"""Static mesh refinement (BASELINE configs[3]/[4] data path): block tree, ghost exchange
+across levels (RestrictAverage / ProlongateSharedMinMod on coarse buffers), flux correction.
+
+The checker is oracle/multilevel.py -- a numpy + per-block-oracle restatement written independently of the
+product's C++ driver (different language, different decomposition of the exchange).  Parthenon is absent
+from the reference checkout, so parity against a Parthenon build is UNPINNED; what is pinned:
+  * the HIP path == the multilevel oracle, bit for bit, ghosts included (GPU tests),
+  * the host logic == the oracle on the CPU double, 1 rank and 2 ranks over gloo (CPU tests),
+  * conservation across level boundaries to round-off WITH flux correction (and its violation without),
+  * exactness on a uniform state, reference-held disk.py bounds on inputs/disk/disk_cart.in (tests/golden).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle.multilevel import BlockTree, MultiLevelOracle
+from pins import DISK
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DECK = lambda *p: os.path.join(ROOT, "inputs", *p)
+
+KW = dict(reconstruct="plm", gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3)
+
+
+def region_overrides(n, lo, hi, level=1):
+    blk = "parthenon/static_refinement%d" % n
+    out = ["parthenon/mesh/refinement=static", f"{blk}/level={level}"]
+    for d in range(3):
+        out += [f"{blk}/x{d + 1}min={lo[d]}", f"{blk}/x{d + 1}max={hi[d]}"]
+    return out
+
+
+CASES = {
+    # 2-D cylindrical blast, outflow, refined centre: 12 coarse + 16 fine blocks of 8x8
+    "blast2d": dict(
+        deck=("blast", "blast.in"),
+        ov=["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8",
+            "gas/riemann=hllc", "problem/radius=0.45", "problem/p0=0.1", "problem/samples=0",
+            "problem/symmetry=cylindrical", "parthenon/time/nlim=20"] + region_overrides(1, (-0.3, -0.3, -0.5), (0.3, 0.3, 0.5)),
+        oracle=dict(mesh=(32, 32, 1), block=(8, 8, 1), lo=(-1, -1, -0.5), hi=(1, 1, 0.5), bc=("outflow",) * 6,
+                    regions=[(1, (-0.3, 0.3), (-0.3, 0.3), (-0.5, 0.5))], riemann="hllc"),
+        pgen=dict(radius=0.45, internal_energy=1.0, p0=0.1, d0=1.0, samples=0, symmetry="cylindrical"), nlim=20,
+        blocks=(12, 16)),
+    # 3-D, periodic x1 / x3 with the refined region AT the periodic boundary, reflecting x2, viscosity (edge and
+    # corner ghost zones and diffusion-flux correction matter), rk3
+    "visc3d": dict(
+        deck=("blast", "blast.in"),
+        ov=["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16", "parthenon/mesh/x3min=-1.0",
+            "parthenon/mesh/x3max=1.0", "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8",
+            "parthenon/mesh/ix1_bc=periodic", "parthenon/mesh/ox1_bc=periodic", "parthenon/mesh/ix2_bc=reflecting",
+            "parthenon/mesh/ox2_bc=reflecting", "parthenon/mesh/ix3_bc=periodic", "parthenon/mesh/ox3_bc=periodic",
+            "physics/viscosity=true", "gas/viscosity/type=constant", "gas/viscosity/nu=0.02", "gas/riemann=hlle",
+            "problem/radius=0.45", "problem/samples=0", "problem/symmetry=spherical", "problem/p0=0.1", "problem/x1=-0.7",
+            "parthenon/time/integrator=rk3", "parthenon/time/nlim=6"]
+        + region_overrides(1, (-1.0, -0.2, -0.2), (-0.6, 0.2, 0.2)),
+        oracle=dict(mesh=(32, 16, 16), block=(8, 8, 8), lo=(-1, -1, -1), hi=(1, 1, 1),
+                    bc=("periodic", "periodic", "reflecting", "reflecting", "periodic", "periodic"),
+                    regions=[(1, (-1.0, -0.6), (-0.2, 0.2), (-0.2, 0.2))], riemann="hlle", integrator="rk3"),
+        visc=0.02, pgen=dict(radius=0.45, internal_energy=1.0, p0=0.1, d0=1.0, samples=0, x0=(-0.7, 0, 0)), nlim=6,
+        blocks=(12, 32)),
+    # two refinement levels (a level-2 region forces level 1 around it through 2:1 balance), 2-D, vl2
+    "twolevel2d": dict(
+        deck=("blast", "blast.in"),
+        ov=["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8",
+            "gas/riemann=hllc", "problem/radius=0.2", "problem/samples=0", "problem/symmetry=cylindrical", "problem/p0=0.01",
+            "parthenon/time/integrator=vl2", "parthenon/time/nlim=10"] + region_overrides(1, (-0.05, -0.05, -0.5), (0.05, 0.05, 0.5), 2),
+        oracle=dict(mesh=(64, 64, 1), block=(8, 8, 1), lo=(-1, -1, -0.5), hi=(1, 1, 0.5), bc=("outflow",) * 6,
+                    regions=[(2, (-0.05, 0.05), (-0.05, 0.05), (-0.5, 0.5))], riemann="hllc", integrator="vl2"),
+        pgen=dict(radius=0.2, internal_energy=1.0, p0=0.01, d0=1.0, samples=0, symmetry="cylindrical"), nlim=10,
+        blocks=None),
+}
+
+
+def run_oracle(case):
+    c = CASES[case]
+    o = c["oracle"]
+    kw = dict(KW, riemann=o["riemann"])
+    m = MultiLevelOracle(o["mesh"], o["block"], o["lo"], o["hi"], o["bc"], regions=o["regions"], ng=2,
+                         integrator=o.get("integrator", "rk2"), **kw)
+    if c.get("visc"):
+        m.diffusion = True
+    for blk in m.blocks:
+        if c.get("visc"):
+            blk.set_viscosity("constant", nu=c["visc"])
+        blk.pgen_blast(post_init=False, **c["pgen"])
+    m.post_init()
+    h0 = m.history()
+    m.evolve(0.1, c["nlim"])
+    return m, h0
+
+
+# ---- the tree ------------------------------------------------------------------------------------------------
+def test_block_tree_of_the_shipped_cartesian_disk_deck():
+    """inputs/disk/disk_cart.in: 128^3 root in 16x16x8 blocks, level-1 region [-2,2]^2 x [-1,1] in [-3,3]^3 -- every
+    root block the region overlaps splits: 6^3 = 216 of 1024 -> 1728 fine + 808 coarse blocks; at disk.py's 64^3 root
+    (tst/scripts/disk/disk.py:64-69) 64 of 128 -> 512 + 64."""
+    for nrb, want in (((8, 8, 16), (808, 1728)), ((4, 4, 8), (64, 512))):
+        t = BlockTree(nrb, 3, (False,) * 3)
+        t.add_region(1, (-2, -2, -1), (2, 2, 1), (-3, -3, -3), (3, 3, 3))
+        lv = [l for l, _ in t.leaves()]
+        assert (lv.count(0), lv.count(1)) == want
+    # 2:1 balance over corners: a level-2 block forces level 1 on everything it touches
+    t = BlockTree((8, 8, 1), 2, (False,) * 3)
+    t.add_region(2, (-0.05, -0.05, 0), (0.05, 0.05, 0), (-1, -1, -0.5), (1, 1, 0.5))
+    leaves = t.leaves()
+    idx = {lf: q for q, lf in enumerate(leaves)}
+    for level, loc in leaves:
+        for o in t.directions():
+            kind, what = t.neighbour(level, loc, o)
+            if kind == "coarser":
+                assert (level - 1, what) in idx
+            elif kind == "finer":
+                assert all((level + 1, cl) in idx for cl, _ in what)
+
+
+def test_oracle_conserves_across_levels_only_with_flux_correction():
+    m, h0 = run_oracle("blast2d")
+    h1 = m.history()
+    assert abs(h1[0] - h0[0]) < 1e-13 * h0[0] and abs(h1[4] - h0[4]) < 1e-13 * h0[4]
+    c = CASES["blast2d"]["oracle"]
+    bad = MultiLevelOracle(c["mesh"], c["block"], c["lo"], c["hi"], c["bc"], regions=c["regions"], ng=2,
+                           **dict(KW, riemann="hllc"))
+    bad.flux_correction = lambda: None
+    for blk in bad.blocks:
+        blk.pgen_blast(post_init=False, **CASES["blast2d"]["pgen"])
+    bad.post_init()
+    b0 = bad.history()
+    bad.evolve(0.1, 20)
+    assert abs(bad.history()[4] - b0[4]) > 1e-9 * b0[4]  # the check above is not vacuous
+
+
+def test_oracle_uniform_state_is_static_on_a_refined_mesh():
+    c = CASES["visc3d"]["oracle"]
+    # (rk2: its stage weights 1/2 + 1/2 reproduce a constant exactly; rk3's 1/3 + 2/3 do not, on any mesh)
+    m = MultiLevelOracle(c["mesh"], c["block"], c["lo"], c["hi"], c["bc"], regions=c["regions"], ng=2, integrator="rk2",
+                         **dict(KW, riemann="hlle"))
+    for blk in m.blocks:
+        blk.pgen_blast(radius=1e-9, internal_energy=1.0, p0=0.7, d0=1.3, samples=0, post_init=False)
+    m.post_init()
+    before = [blk.gprim.copy() for blk in m.blocks]
+    m.evolve(-1.0, 3)
+    assert all(np.array_equal(a, blk.gprim) for a, blk in zip(before, m.blocks))
+
+
+# ---- host driver on the CPU double (worker processes: the double exports libartemis_hip.so's symbols) ----------
+def _run_workers(world, spec, tmp_path, tag):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_multirank_cpu import run_world
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpu_double"), "-s"])
+    return run_world(world, spec, tmp_path, tag)
+
+
+@pytest.mark.parametrize("case", ["blast2d", "visc3d", "twolevel2d"])
+def test_host_driver_on_cpu_double_equals_multilevel_oracle(case, tmp_path):
+    c = CASES[case]
+    res = _run_workers(1, dict(deck=list(c["deck"]), overrides=c["ov"]), tmp_path, case)[0]
+    m, h0 = run_oracle(case)
+    assert res["meta"]["nblocks"] == len(m.blocks) and not res["meta"]["fused"]
+    if c["blocks"]:
+        lv = [l for l, _ in m.leaves]
+        assert (lv.count(0), lv.count(1)) == c["blocks"]
+    assert res["meta"]["ncycle"] == m.ncycle == c["nlim"] and res["meta"]["dt"] == m.dt and res["meta"]["time"] == m.time
+    for b, (bounds, prim) in enumerate(res["blocks"]):
+        blk = m.blocks[b]
+        assert list(bounds) == m.block_bounds(b)
+        assert np.array_equal(prim, blk.interior(blk.gprim)), (case, b)
+    h1 = res["hist"]
+    assert abs(h1[0] - h0[0]) < 1e-12 * h0[0] and abs(h1[4] - h0[4]) < 1e-12 * abs(h0[4])
+
+
+def test_refined_blocks_split_over_two_ranks_bitwise(tmp_path):
+    """The Z-ordered leaves are dealt to the ranks in contiguous runs; ghost and flux-correction operations that
+    cross the rank boundary travel as ONE message per peer and phase (gloo here, RCCL on GPUs).  Same bits."""
+    c = CASES["visc3d"]
+    spec = dict(deck=list(c["deck"]), overrides=c["ov"])
+    one = _run_workers(1, spec, tmp_path, "one")
+    two = _run_workers(2, spec, tmp_path, "two")
+    assert sum(r["meta"]["nblocks"] for r in two) == one[0]["meta"]["nblocks"] == 44
+    assert abs(two[0]["meta"]["nblocks"] - two[1]["meta"]["nblocks"]) <= 1
+    for r in two:
+        assert r["meta"]["ncycle"] == one[0]["meta"]["ncycle"] and r["meta"]["dt"] == one[0]["meta"]["dt"]
+    from test_multirank_cpu import by_bounds
+    a, b = by_bounds(one), by_bounds(two)
+    assert a.keys() == b.keys()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    assert np.allclose(two[0]["hist"], one[0]["hist"], rtol=1e-13)
+
+
+# ---- the HIP path ----------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["blast2d", "visc3d", "twolevel2d"])
+def test_hip_driver_equals_multilevel_oracle(hiplib, case):
+    from artemis_amd.driver import Simulation
+    c = CASES[case]
+    s = Simulation(DECK(*c["deck"]), c["ov"])
+    assert not s.uses_fused_path
+    h0 = s.history()
+    s.evolve()
+    m, _ = run_oracle(case)
+    assert s.nblocks == s.nblocks_global == len(m.blocks)
+    assert s.ncycle == m.ncycle and s.dt == m.dt and s.time == m.time
+    for b, blk in enumerate(m.blocks):
+        assert s.block_bounds(b) == m.block_bounds(b) and s.block_level(b) == m.leaves[b][0]
+        got = s.field("gas.prim", b)
+        assert np.array_equal(got[[0, 1, 2, 3, 5]], blk.gprim[[0, 1, 2, 3, 5]]), (case, b)  # ghosts included
+        assert np.array_equal(s.interior(got), blk.interior(blk.gprim)), (case, b)
+    h1 = s.history()
+    assert abs(h1[0] - h0[0]) < 1e-12 * h0[0] and abs(h1[4] - h0[4]) < 1e-12 * abs(h0[4])
+    s.close()
+
+
+def _disk_cart(extra):
+    from artemis_amd.driver import Simulation
+    return Simulation(DECK("disk", "disk_cart.in"), ["parthenon/time/nlim=%d" % DISK["cycles"]] + extra)
+
+
+def _check_disk(s, d0):
+    """tst/scripts/disk/disk.py:118-187 on the `cart` geometry (numbers: tests/golden/reference_pins.json)"""
+    num = den = 0.0
+    for b in range(s.nblocks):
+        P = s.interior(s.field("gas.prim", b))
+        d, T = P[0], P[4] / P[0]
+        assert not np.isnan(P).any() and d.min() > 0.0 and T.min() > 0.0
+        num += (d0[b] * (d - d0[b]) ** 2).sum()
+        den += d0[b].sum()
+    assert DISK["dt_low"] < s.dt < DISK["dt_high"], s.dt
+    err = np.sqrt(num) / den
+    assert err <= DISK["density_err_max"], err
+    return err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gam", DISK["gamma"])
+def test_disk_cart_deck_reference_checks_at_test_resolution(hiplib, gam):
+    """inputs/disk/disk_cart.in UNCHANGED (refinement = static, level 1) with disk.py's own overrides for `cart`
+    (64^3 root, nlim 5 + 5, polytropic index 1 and 1.4): 64 coarse + 512 fine blocks through the HIP driver; the
+    reference's checks pass and mass is conserved to round-off until material reaches the outflow boundary."""
+    s = _disk_cart(["parthenon/mesh/nx%d=%d" % (d + 1, n) for d, n in enumerate(DISK["cart_mesh_override"])]
+                   + ["problem/polytropic_index=%.2f" % gam, "gas/de_switch=0.0"])
+    assert s.nblocks == 576 and [s.block_level(b) for b in range(s.nblocks)].count(1) == 512
+    d0 = [s.interior(s.field("gas.prim", b))[0].copy() for b in range(s.nblocks)]
+    s.evolve()
+    assert s.ncycle == DISK["cycles"]
+    _check_disk(s, d0)
+    s.close()
+
+
+@pytest.mark.gpu
+def test_disk_cart_deck_as_shipped(hiplib):
+    """The deck exactly as shipped: 128^3 root -> 808 coarse + 1728 fine blocks of 16x16x8 (nghost 4, alpha
+    viscosity, point-mass gravity), 10 cycles."""
+    s = _disk_cart([])
+    lv = [s.block_level(b) for b in range(s.nblocks)]
+    assert s.nblocks == 2536 and lv.count(1) == 1728 and s.total_zones == 2536 * 16 * 16 * 8
+    d0 = [s.interior(s.field("gas.prim", b))[0].copy() for b in range(s.nblocks)]
+    s.evolve()
+    assert s.ncycle == DISK["cycles"]
+    _check_disk(s, d0)
+    s.close()
