@@ -90,8 +90,9 @@ def host_cores():
         smt = max(1, len(sib.replace("-", ",").split(",")))
     except Exception:
         pass
-    usable = logical if quota is None else max(1, min(logical, int(quota)))
-    return {"logical": logical, "cgroup_quota": quota, "smt": smt, "physical_usable": max(1, usable // smt)}
+    # a CPU quota is in units of CPU time: run that many threads; without one, one thread per physical core
+    usable = max(1, logical // smt) if quota is None else max(1, min(logical, int(quota)))
+    return {"logical": logical, "cgroup_quota": quota, "smt": smt, "physical_usable": usable}
 
 
 def kernel_source_sha1():
@@ -396,7 +397,7 @@ def main():
                 "parallel_efficiency": v / threads / v1,
                 "sample": "CPU oracle (C++ restatement of the reference's CPU path, NOT the Artemis executable; OpenMP over "
                           "k-j rows, arrays first-touched by the sweeping threads, OMP_PROC_BIND=%s OMP_PLACES=%s): Sedov %d^3, "
-                          "%d cycles in %.1f s on %d threads (one per usable physical core; %d logical CPUs); one thread: Sedov 128^3, "
+                          "%d cycles in %.1f s on %d threads (= the container's CPU quota, else one per physical core; %d logical CPUs); one thread: Sedov 128^3, "
                           "%d cycles in %.1f s.  Thread scaling of this restatement on this host: profiles/r02_cpu_scaling.txt"
                           % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), args.cpu_n, cyc, secs, threads,
                              hc["logical"], cyc1, secs1)}
