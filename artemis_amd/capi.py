@@ -99,6 +99,12 @@ class Gravity(C.Structure):
                 ("sink2", C.c_double), ("sink_rate2", C.c_double), ("pos2", C.c_double * 3)]
 
 
+class NBodyParticle(C.Structure):  # artemis_nbody_particle_t
+    _fields_ = [("gm", C.c_double), ("pos", C.c_double * 3), ("vel", C.c_double * 3), ("xf", C.c_double * 3),
+                ("vf", C.c_double * 3), ("rs", C.c_double), ("racc", C.c_double), ("gamma", C.c_double),
+                ("beta", C.c_double), ("spline", C.c_int), ("couple", C.c_int)]
+
+
 class Damping(C.Structure):
     _fields_ = [("ix", C.c_double * 3), ("ox", C.c_double * 3), ("irate", C.c_double * 3),
                 ("orate", C.c_double * 3)]
@@ -184,6 +190,7 @@ def load():
         "artemis_hip_apply_bc": (i, [PPk, C.POINTER(i), C.POINTER(BcParams), vp]),
         "artemis_hip_external_gravity": (i, [PPk, C.POINTER(Gravity), d, d, vp]),
         "artemis_hip_rotating_frame_force": (i, [PPk, d, d, d, d, vp]),
+        "artemis_hip_nbody_gravity": (i, [PPk, C.POINTER(NBodyParticle), i, d, d, d, C.POINTER(d), vp]),
         "artemis_hip_drag_source": (i, [PPk, C.POINTER(Drag), d, d, vp]),
         "artemis_hip_cooling_source": (i, [PPk, C.POINTER(Cooling), d, d, vp]),
         "artemis_hip_cooling_table_fill": (i, [PPk, vp, vp, C.POINTER(Cooling), i, vp, vp]),
@@ -251,7 +258,8 @@ EXPORTS_HIP = [
     "artemis_hip_set_aux", "artemis_hip_cons_to_prim", "artemis_hip_prim_to_cons",
     "artemis_hip_deep_copy_conserved", "artemis_hip_estimate_dt", "artemis_hip_estimate_dt_async",
     "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_metric_count",
-    "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_rotating_frame_force",
+    "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_nbody_gravity", "artemis_hip_rotating_frame_force",
+    "artemis_hip_ml_exchange", "artemis_hip_ml_flux_correction", "artemis_hip_ml_restrict_halos", "artemis_hip_ml_prolongate",
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",
     "artemis_hip_stage_general", "artemis_hip_stage_epilogue", "artemis_hip_restrict_average",
     "artemis_hip_prolongate_minmod", "artemis_hip_amr_first_derivative", "artemis_hip_amr_magnitude",

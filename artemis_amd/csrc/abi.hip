@@ -10,6 +10,8 @@
 
 #include "../../include/artemis_hip.h"
 #include "../../include/artemis_rt.h"
+#include <vector>
+
 #include "kernels.hpp"
 #include "geometry_core.hpp"
 
@@ -276,6 +278,45 @@ int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_
   if (!((time >= g->tstart) && (time < g->tstop))) return 0; // gravity.cpp:134
   artemis::launch_external_gravity(artemis::make_pack_view(*p), *g, dt, S(stream));
   return after_launch("ExternalGravity");
+}
+
+int artemis_hip_nbody_gravity(const artemis_pack_t *p, const artemis_nbody_particle_t *particles, int npart, double omf,
+                              double time, double dt, double *force, void *stream) {
+  (void)time;
+  if (int rc = validate(p)) return rc;
+  if (npart < 0 || (npart > 0 && (!particles || !force))) return fail(ARTEMIS_HIP_EINVAL, "nbody gravity: null particles / force");
+  if (p->coords != ARTEMIS_CARTESIAN && p->coords != ARTEMIS_CYLINDRICAL && p->coords != ARTEMIS_SPHERICAL3D)
+    return fail(ARTEMIS_HIP_EINVAL, "NBody does not work with axisymmetric coordinates!"); // nbody.cpp:61-62
+  if (p->coords != ARTEMIS_CARTESIAN && !p->metric)
+    return fail(ARTEMIS_HIP_EINVAL, "nbody gravity on curvilinear blocks needs the metric tables");
+  if (!(dt != 0.0)) return fail(ARTEMIS_HIP_EINVAL, "nbody gravity: dt must be non-zero (forces are per unit time)");
+  if (npart == 0) return 0;
+  const artemis::PackView P = artemis::make_pack_view(*p);
+  const int grid = artemis::nbody_grid(P);
+  const size_t pbytes = sizeof(artemis_nbody_particle_t) * npart, rbytes = sizeof(double) * 7 * static_cast<size_t>(npart) * grid;
+  void *dev = nullptr;
+  if (int rc = check_hip(hipMalloc(&dev, pbytes + rbytes + 64), "hipMalloc")) return rc;
+  artemis_nbody_particle_t *pl_dev = static_cast<artemis_nbody_particle_t *>(dev);
+  double *partial = reinterpret_cast<double *>(static_cast<char *>(dev) + ((pbytes + 63) / 64) * 64);
+  std::vector<double> host(static_cast<size_t>(7) * npart * grid);
+  int rc = check_hip(hipMemcpyAsync(pl_dev, particles, pbytes, hipMemcpyHostToDevice, S(stream)), "h2d particles");
+  if (!rc) {
+    artemis::launch_nbody_gravity(P, pl_dev, npart, omf, dt, partial, S(stream));
+    rc = after_launch("NBodyGravity");
+  }
+  if (!rc) rc = check_hip(hipMemcpyAsync(host.data(), partial, rbytes, hipMemcpyDeviceToHost, S(stream)), "d2h partials");
+  if (!rc) rc = check_hip(hipStreamSynchronize(S(stream)), "sync");
+  (void)hipFree(dev);
+  if (rc) return rc;
+  for (int n = 0; n < npart; ++n) {
+    if (!particles[n].couple) continue;
+    for (int q = 0; q < 7; ++q) {
+      double sum = 0.0;
+      for (int w = 0; w < grid; ++w) sum += host[(static_cast<size_t>(n) * grid + w) * 7 + q];
+      force[7 * n + q] += sum;
+    }
+  }
+  return 0;
 }
 
 int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, double qshear,

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -223,6 +224,11 @@ struct artemis_sim {
   artemis_cooling_t cool = {};
   Field cool_tref, cool_beta; // host-filled Tref / beta of every cell (cooling.hpp:47-58, beta_cooling.cpp:98-99)
   artemis_gravity_t grav;
+  // <gravity/nbody> + the nbody package (nbody.cpp:48-130) with <nbody> integrator = none: the particles stay
+  // where the deck puts them; force rows accumulate like the reference's particle_force (nbody_gravity.hpp:210)
+  bool grav_nbody = false, nbody_frame_correction = true;
+  std::vector<artemis_nbody_particle_t> particles;
+  std::vector<double> particle_force; // [npart][7]
   Real rf_omega = 0.0, rf_qshear = 0.0;
   artemis_drag_t drag;
   bool damp_to_visc = false; // <gas/damping> damp_to_visc: drag.damp_visc = &diff.visc at the call sites
@@ -411,9 +417,9 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   do_viscosity = pin.GetOrAddBoolean("physics", "viscosity", false);
   do_conduction = pin.GetOrAddBoolean("physics", "conduction", false);
   do_cooling = pin.GetOrAddBoolean("physics", "cooling", false);
-  for (const char *k : {"nbody", "radiation"})
-    if (pin.GetOrAddBoolean("physics", k, false))
-      throw std::runtime_error(std::string("physics/") + k + " is out of scope of this build");
+  const bool do_nbody = pin.GetOrAddBoolean("physics", "nbody", false);
+  if (pin.GetOrAddBoolean("physics", "radiation", false))
+    throw std::runtime_error("physics/radiation is out of scope of this build");
   // <parthenon/mesh>
   ng = pin.GetOrAddInteger("parthenon/mesh", "nghost", 2);
   const char *xn[3] = {"x1", "x2", "x3"};
@@ -514,8 +520,10 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
       orb.coso = std::cos(obin), orb.sino = std::sin(obin), orb.cosI = std::cos(ibin), orb.sinI = std::sin(ibin);
       orb.cosO = std::cos(Obin), orb.sinO = std::sin(Obin), orb.cosf0 = std::cos(fbin), orb.sinf0 = std::sin(fbin);
     }
-    if (pin.DoesBlockExist("gravity/nbody"))
-      throw std::runtime_error("gravity/nbody is out of scope of this build");
+    if (pin.DoesBlockExist("gravity/nbody")) { // gravity.cpp:110-117
+      count++, grav.type = 0, grav_nbody = true;
+      if (!do_nbody) throw std::runtime_error("You have <gravity/nbody> but not physics/nbody = true!");
+    }
     if (count == 0) throw std::runtime_error("Unknown gravity node!");
     if (count != 1) throw std::runtime_error("artemis only supports 1 gravity type at this time");
   }
@@ -527,6 +535,82 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
     if (coords != ARTEMIS_CARTESIAN && rf_qshear != 0.0) // rotating_frame.cpp:34-38
       throw std::runtime_error("rotating_frame/qshear must be zero for non-Cartesian coordinate systems!");
   }
+  // <nbody> (nbody/nbody.cpp:48-130, nbody/nbody_setup.cpp:160-722): particle blocks only, no integration
+  if (do_nbody) {
+    if (coords == ARTEMIS_AXISYMMETRIC || coords == ARTEMIS_SPHERICAL1D || coords == ARTEMIS_SPHERICAL2D)
+      throw std::runtime_error("NBody does not work with axisymmetric coordinates!");
+    if (pin.GetOrAddString("nbody", "integrator", "ias15") != "none")
+      throw std::runtime_error("nbody/integrator: only `none` (static particles) is built; the REBOUND integration "
+                               "is outside this build -- a host that integrates the particles calls "
+                               "artemis_hip_nbody_gravity with their current state");
+    for (const char *pre : {"nbody/binary", "nbody/triple", "nbody/system", "nbody/planet"})
+      if (!pin.BlocksWithPrefix(pre).empty())
+        throw std::runtime_error(std::string("<") + pre + "*> blocks are not built (use <nbody/particleN>)");
+    struct PP {
+      Real m = 0, rs = 0, racc = 0, gamma = 0, beta = 0, x = 0, y = 0, z = 0, vx = 0, vy = 0, vz = 0;
+      int couple = 1, spline = 0;
+    };
+    std::map<int, PP> parts;
+    for (const std::string &blk : pin.BlocksWithPrefix("nbody/particle")) {
+      const size_t s1 = blk.find('/', 6);
+      const std::string idstr = blk.substr(14, (s1 == std::string::npos ? blk.size() : s1) - 14);
+      const int id = std::stoi(idstr);
+      PP &q = parts[id];
+      if (s1 == std::string::npos) {
+        q.m = pin.GetReal(blk, "mass");
+        q.couple = pin.GetOrAddInteger(blk, "couple", 1);
+      } else {
+        const std::string sub = blk.substr(s1 + 1);
+        if (sub == "soft") {
+          const std::string t = pin.GetString(blk, "type");
+          if (t == "none") q.rs = 0.0, q.spline = 0;
+          else if (t == "plummer") q.rs = pin.GetReal(blk, "radius"), q.spline = 0;
+          else if (t == "spline") q.rs = pin.GetReal(blk, "radius"), q.spline = 1;
+          else throw std::runtime_error("Unknown particle softening type " + t);
+        } else if (sub == "sink") {
+          q.racc = pin.GetReal(blk, "radius"), q.gamma = pin.GetReal(blk, "gamma");
+          q.beta = pin.GetOrAddReal(blk, "beta", 0.0);
+        } else if (sub == "initialize") {
+          q.x = pin.GetOrAddReal(blk, "x", 0.0), q.y = pin.GetOrAddReal(blk, "y", 0.0), q.z = pin.GetOrAddReal(blk, "z", 0.0);
+          q.vx = pin.GetOrAddReal(blk, "vx", 0.0), q.vy = pin.GetOrAddReal(blk, "vy", 0.0), q.vz = pin.GetOrAddReal(blk, "vz", 0.0);
+        }
+      }
+    }
+    if (parts.empty()) throw std::runtime_error("physics/nbody = true but no <nbody/particleN> block");
+    // nbody_setup.cpp:690-714: total mass rescaled to nbody/mtot, positions / velocities shifted by the
+    // mass-weighted sums (not divided by the total mass: kept as the reference has it)
+    Real mtot = 0.0, R[3] = {0, 0, 0}, V[3] = {0, 0, 0};
+    for (auto &kv : parts) {
+      const PP &q = kv.second;
+      mtot += q.m;
+      R[0] += q.m * q.x, R[1] += q.m * q.y, R[2] += q.m * q.z;
+      V[0] += q.m * q.vx, V[1] += q.m * q.vy, V[2] += q.m * q.vz;
+    }
+    Real mresc = pin.GetOrAddReal("nbody", "mtot", -DBL_MAX);
+    if (mresc == -DBL_MAX) mresc = mtot;
+    // frame: nbody.cpp:94-109
+    nbody_frame_correction = (pin.GetOrAddString("nbody", "frame", "global") == "global");
+    const Real Omf = pin.GetOrAddReal("rotating_frame", "omega", 0.0), qsh = pin.GetOrAddReal("rotating_frame", "qshear", 0.0);
+    Real Rf[3] = {0, 0, 0}, Vf[3] = {0, 0, 0};
+    if (nbody_frame_correction && Omf != 0.0 && qsh != 0.0) {
+      const Real R0 = std::pow(SQR(Omf) / (1.0 * mresc), 1.0 / 3.0);
+      Rf[0] = R0, Vf[1] = R0 * Omf;
+    }
+    for (auto &kv : parts) {
+      const PP &q = kv.second;
+      artemis_nbody_particle_t a;
+      std::memset(&a, 0, sizeof a);
+      a.gm = 1.0 * (q.m * mresc / mtot);
+      a.pos[0] = q.x - R[0], a.pos[1] = q.y - R[1], a.pos[2] = q.z - R[2];
+      a.vel[0] = q.vx - V[0], a.vel[1] = q.vy - V[1], a.vel[2] = q.vz - V[2];
+      for (int d = 0; d < 3; ++d) a.xf[d] = Rf[d], a.vf[d] = Vf[d];
+      a.rs = q.rs, a.racc = q.racc, a.gamma = q.gamma, a.beta = q.beta, a.spline = q.spline, a.couple = q.couple;
+      particles.push_back(a);
+    }
+    particle_force.assign(7 * particles.size(), 0.0);
+    if (grav_nbody) grav.gm = 1.0 * mresc; // gravity.cpp:117: gm of the nbody package
+  }
+  if (grav_nbody && !do_nbody) throw std::runtime_error("You have <gravity/nbody> but not physics/nbody = true!");
   // <cooling> (gas/cooling/cooling.cpp:34-88); the tables are filled once the mesh exists
   if (do_cooling) {
     if (pin.GetString("cooling", "type") != "beta") throw std::runtime_error("Unknown cooling type");
@@ -620,7 +704,7 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
         c.eta = pin.GetOrAddReal("gas/viscosity", "eta_bulk", 0.0);
         c.r_exp = pin.GetOrAddReal("gas/viscosity", "r_exp", 0.0);
       } else if (t == "alpha") { // diffusion_coeff.hpp:113-119
-        if (!do_gravity || grav.type == ARTEMIS_GRAVITY_UNIFORM)
+        if (!do_gravity || (grav.type == ARTEMIS_GRAVITY_UNIFORM && !grav_nbody))
           throw std::runtime_error("gas/viscosity/type = alpha reads gm of the gravity package: gravity/point or gravity/binary is required");
         c.type = ARTEMIS_VISCOSITY_ALPHA;
         c.coeff = pin.GetReal("gas/viscosity", "alpha");
@@ -734,7 +818,7 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   // the general stage folds DiffusionUpdate (after the diffusion-flux tasks), the curvilinear rotating
   // frame and beta cooling into its kernel; cooling together with drag runs on the per-task chain
   // a refined mesh needs the stage's face fluxes for flux correction (artemis_driver.cpp:196-202): per-task chain
-  fused_possible = !(do_cooling && do_drag) && !multilevel;
+  fused_possible = !(do_cooling && do_drag) && !multilevel && !grav_nbody; // (n-body: its own task + host reduction)
   tuned = tuned && fused_possible && !(do_viscosity || do_conduction || do_cooling);
   // Default path by measurement (scripts/path_timing.py, one MI355X): the cell-centred general stage wins
   // on Cartesian meshes (2048^2 viscous 1.73e9 vs 1.50e9 zone-cycles/s, SURVEY config 3 2.9e9 vs 1.1e9); in
@@ -1958,7 +2042,7 @@ void artemis_sim::step_unfused() {
     }
     if (multilevel) flux_correction_multilevel(p); // artemis_driver.cpp:196-202
     place_binary();
-    if (!do_drag && std::getenv("ARTEMIS_NO_EPILOGUE") == nullptr) {
+    if (!do_drag && !grav_nbody && std::getenv("ARTEMIS_NO_EPILOGUE") == nullptr) {
       // everything between the flux tasks and the boundary exchange is cell-local: one pass over the
       // stored fluxes (ApplyUpdate ... ConsToPrim, artemis_driver.cpp:205-255) instead of eight
       artemis_stage_general_args_t a;
@@ -1978,7 +2062,14 @@ void artemis_sim::step_unfused() {
         CK(artemis_hip_diffusion_update(&p, &diff, bdt, stream), "Gas::DiffusionUpdate");
       // artemis_driver.cpp:222-241: gravity, rotating frame, drag, in this order, with the time at
       // the start of the step (:167)
-      if (do_gravity) CK(artemis_hip_external_gravity(&p, &grav, time, bdt, stream), "ExternalGravity");
+      if (do_gravity && grav_nbody) { // gravity.cpp:150-155
+        const Real omf = (do_rframe && nbody_frame_correction) ? rf_omega : 0.0;
+        if (time >= grav.tstart && time < grav.tstop)
+          CK(artemis_hip_nbody_gravity(&p, particles.data(), static_cast<int>(particles.size()), omf, time, bdt,
+                                       particle_force.data(), stream), "NBodyGravity");
+      } else if (do_gravity) {
+        CK(artemis_hip_external_gravity(&p, &grav, time, bdt, stream), "ExternalGravity");
+      }
       if (do_rframe) CK(artemis_hip_rotating_frame_force(&p, rf_omega, rf_qshear, time, bdt, stream), "RotatingFrameForce");
       if (do_drag) {
         drag.damp_visc = damp_to_visc ? &diff.visc : nullptr;
@@ -2318,6 +2409,15 @@ int artemis_sim_set_dropin(artemis_sim_t *s, int on) {
   return 0;
 }
 int artemis_sim_overlap(const artemis_sim_t *s) { return s->overlap; }
+int artemis_sim_nbody_force(artemis_sim_t *s, double *out, int reset) {
+  const int n = static_cast<int>(s->particles.size());
+  if (!out) return n; // size query
+  std::vector<double> f = s->particle_force;
+  if (n && s->has_comm && s->nranks > 1 && s->comm.allreduce_sum(s->comm.ctx, f.data(), 7 * n)) return -1; // nbody_advance.cpp:123-131
+  for (int q = 0; q < 7 * n; ++q) out[q] = f[q];
+  if (reset) std::fill(s->particle_force.begin(), s->particle_force.end(), 0.0);
+  return n;
+}
 void artemis_sim_species(const artemis_sim_t *s, int *ns_gas, int *ns_dust) {
   if (ns_gas) *ns_gas = s->ns_gas;
   if (ns_dust) *ns_dust = s->ns_dust;

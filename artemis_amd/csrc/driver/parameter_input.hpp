@@ -63,6 +63,14 @@ class ParameterInput {
     blocks_.insert(block);
   }
   bool DoesBlockExist(const std::string &block) const { return blocks_.count(block) > 0; }
+  // names of the blocks that start with `prefix` (the reference walks its block list the same way,
+  // nbody/nbody_setup.cpp:648-665)
+  std::vector<std::string> BlocksWithPrefix(const std::string &prefix) const {
+    std::vector<std::string> out;
+    for (const std::string &b : blocks_)
+      if (b.compare(0, prefix.size(), prefix) == 0) out.push_back(b);
+    return out;
+  }
   // comma-separated list (parthenon ParameterInput::GetVector, upstream)
   std::vector<double> GetVector(const std::string &b, const std::string &k) const {
     std::vector<double> out;

@@ -16,6 +16,9 @@ void launch_estimate_dt(const PackView &P, int fluid, double cfl, double *dt_dev
 int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t *par, hipStream_t s);
 // kernels_sources.hip
 void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, double dt, hipStream_t s);
+int nbody_grid(const PackView &P);
+void launch_nbody_gravity(const PackView &P, const artemis_nbody_particle_t *pl_dev, int npart, double omf, double dt,
+                          double *partial_dev, hipStream_t s);
 void launch_shearing_box(const PackView &P, double omega, double qshear, double dt, hipStream_t s);
 void launch_rotating_frame(const PackView &P, double omega, double dt, hipStream_t s);
 void launch_cooling(const PackView &P, const artemis_cooling_t &C, double dt, hipStream_t s);

@@ -113,6 +113,153 @@ __global__ __launch_bounds__(TX *TY) void gravity_kernel(const PackView P, const
 }
 
 // ---------------------------------------------------------------------------------------
+// Gravity::NBodyGravity<GEOM> (gravity/nbody_gravity.hpp:28-221) with the particle functions of
+// nbody/particle_base.hpp:96-258.  A fixed grid of workgroups strides over the zones; particle by particle
+// (the reference's order: the conserved state accumulates in that order) each thread updates its zones and
+// sums the seven back-reaction terms, the workgroup reduces them in a fixed tree and stores one partial row.
+struct NBodyView {
+  const artemis_nbody_particle_t *pl; // device
+  int npart;
+  double omf, dt;
+  double *partial; // [npart][gridDim.x][7]
+};
+ADEV double nb_idr3(const artemis_nbody_particle_t &p, const double dr2) { // particle_base.hpp:146-166
+  const double fuzz = 1e-99;
+  const double rs2 = sqr(p.rs);
+  const double idr3_p = 1.0 / (fuzz + sqrt(dr2 + rs2) * (dr2 + rs2));
+  const double dr3 = dr2 * sqrt(dr2);
+  const double u2 = dr2 / (rs2 + fuzz);
+  const double u = sqrt(u2);
+  const double u3 = u * u2;
+  const double h3inv = 1. / (rs2 * p.rs + fuzz);
+  const double idr3_s = (dr2 >= rs2) ? 1.0 / dr3
+                                     : ((u < 0.5) ? h3inv * (32.0 / 3.0 - 192.0 / 5.0 * u2 + 32.0 * u3)
+                                                  : h3inv * (64.0 / 3.0 - 48.0 * u + 192.0 / 5.0 * u2 - 32.0 / 3.0 * u3 -
+                                                             1.0 / (15.0 * u3)));
+  return idr3_p * (1 - p.spline) + p.spline * idr3_s;
+}
+ADEV void nb_accrete(const artemis_nbody_particle_t &p, const double x[3], const double den, const double v[3],
+                     const double vb[3], const double dt, double &dm, double dmom[3], double &dEk) { // :190-245
+  const double fuzz = 1e-99;
+  const double vrel[3] = {v[0] + vb[0], v[1] + vb[1], v[2] + vb[2]};
+  double dx[3], dv[3];
+  for (int d = 0; d < 3; d++) dx[d] = x[d] - (p.pos[d] - p.xf[d]), dv[d] = vrel[d] - (p.vel[d] - p.vf[d]);
+  const double dv2 = sqr(dv[0]) + sqr(dv[1]) + sqr(dv[2]);
+  const double R = sqrt(sqr(dx[0]) + sqr(dx[1]));
+  const double r = sqrt(sqr(R) + sqr(dx[2]));
+  const double ct = dx[2] / (r + fuzz), st = R / (r + fuzz);
+  const double cp = dx[0] / (R + fuzz), sp = dx[1] / (R + fuzz);
+  const double et[3] = {ct * cp, ct * sp, -st}, ep[3] = {-sp, cp, 0.0};
+  const double dvt = dv[0] * et[0] + dv[1] * et[1] + dv[2] * et[2];
+  const double dvp = dv[0] * ep[0] + dv[1] * ep[1] + dv[2] * ep[2];
+  const bool acc = ((p.racc > 0.0) && (r <= p.racc) && (-p.gm / (r + fuzz) + 0.5 * dv2 <= 0.0));
+  const double ramp = sqr((p.racc - r) / (p.racc + fuzz));
+  const double gdt = acc * amin(ramp * p.gamma * dt, 1.0 / 9.0);
+  const double bdt = acc * amin(ramp * p.beta * dt, 1.0 / 9.0);
+  const double fm = -gdt / (1.0 + gdt);
+  dm += den * fm;
+  const double fp = (gdt - bdt) / ((1.0 + gdt) * (1.0 + bdt));
+  const double denp = den * (1.0 + fm);
+  for (int i = 0; i < 3; i++) {
+    const double dmv = den * (fm * v[i] + fp * (dvt * et[i] + dvp * ep[i]));
+    dmom[i] += dmv;
+    const double vxp = (den * v[i] + dmv) / denp;
+    dEk += 0.5 * (v[i] + vxp) * den * (vxp - v[i]) + 0.5 * den * fm * vxp * vxp;
+  }
+}
+__global__ __launch_bounds__(256) void nbody_gravity_kernel(const PackView P, const NBodyView N) {
+  __shared__ double red[4][7];
+  const int nx1 = P.ie - P.is + 1, nx2 = P.je - P.js + 1, nx3 = P.ke - P.ks + 1;
+  const long per_block = static_cast<long>(nx1) * nx2 * nx3, total = per_block * P.nb;
+  for (int np = 0; np < N.npart; ++np) {
+    const artemis_nbody_particle_t pl = N.pl[np];
+    double lf[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (pl.couple) {
+      for (long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+           t += static_cast<long>(gridDim.x) * blockDim.x) {
+        const int b = static_cast<int>(t / per_block);
+        const long r = t - b * per_block;
+        const int i = P.is + static_cast<int>(r % nx1), j = P.js + static_cast<int>((r / nx1) % nx2);
+        const int k = P.ks + static_cast<int>(r / (static_cast<long>(nx1) * nx2));
+        const long c = static_cast<long>(k) * P.sk + static_cast<long>(j) * P.sj + i;
+        const DCoords co = make_coords(P, b, k, j, i);
+        double x[3];
+        co.centre(x);
+        const bool cyl = (co.sys == ARTEMIS_CYLINDRICAL);
+        const Frame fr = cart_frame(co.sys, x, co.cv, co.sv, cyl ? co.cv : co.c3, cyl ? co.sv : co.s3);
+        double hx[3];
+        scale_factors_of(co, hx);
+        const double vol = co.volume();
+        double g[3] = {0.0, 0.0, 0.0};
+        {
+          double dxp[3];
+          for (int d = 0; d < 3; d++) dxp[d] = fr.x[d] - (pl.pos[d] - pl.xf[d]);
+          const double dr2 = sqr(dxp[0]) + sqr(dxp[1]) + sqr(dxp[2]);
+          const double idr3_ = nb_idr3(pl, dr2);
+          for (int d = 0; d < 3; d++) g[d] += -pl.gm * idr3_ * dxp[d];
+        }
+        const double gx1 = g[0] * fr.e1[0] + g[1] * fr.e1[1] + g[2] * fr.e1[2];
+        const double gx2 = g[0] * fr.e2[0] + g[1] * fr.e2[1] + g[2] * fr.e2[2];
+        const double gx3 = g[0] * fr.e3[0] + g[1] * fr.e3[1] + g[2] * fr.e3[2];
+        double vf[3] = {0.0, 0.0, 0.0};
+        if (N.omf != 0.0) {
+          double vrot[3];
+          rotation_velocity(co, N.omf, vrot);
+          vf[0] = fr.e1[0] * vrot[0] + fr.e2[0] * vrot[1] + fr.e3[0] * vrot[2];
+          vf[1] = fr.e1[1] * vrot[0] + fr.e2[1] * vrot[1] + fr.e3[1] * vrot[2];
+          vf[2] = fr.e1[2] * vrot[0] + fr.e2[2] * vrot[1] + fr.e3[2] * vrot[2];
+        }
+        auto fluid = [&](const FluidView &f, int nvar, int n, bool gas) {
+          const int ns = f.ns;
+          const double dens = f.prim[b * nvar + n][c];
+          const double v[3] = {f.prim[b * nvar + ns + 3 * n + 0][c], f.prim[b * nvar + ns + 3 * n + 1][c],
+                               f.prim[b * nvar + ns + 3 * n + 2][c]};
+          double vcart[3];
+          vcart[0] = fr.e1[0] * v[0] + fr.e2[0] * v[1] + fr.e3[0] * v[2];
+          vcart[1] = fr.e1[1] * v[0] + fr.e2[1] * v[1] + fr.e3[1] * v[2];
+          vcart[2] = fr.e1[2] * v[0] + fr.e2[2] * v[1] + fr.e3[2] * v[2];
+          double dm = 0.0, dmom[3] = {0.0, 0.0, 0.0}, dek = 0.0;
+          const double dei = 0.0;
+          nb_accrete(pl, fr.x, dens, vcart, vf, N.dt, dm, dmom, dek);
+          const double dmx1 = dmom[0] * fr.e1[0] + dmom[1] * fr.e1[1] + dmom[2] * fr.e1[2];
+          const double dmx2 = dmom[0] * fr.e2[0] + dmom[1] * fr.e2[1] + dmom[2] * fr.e2[2];
+          const double dmx3 = dmom[0] * fr.e3[0] + dmom[1] * fr.e3[1] + dmom[2] * fr.e3[2];
+          const double rdt = dens * N.dt;
+          f.cons0[b * nvar + n][c] += dm;
+          f.cons0[b * nvar + ns + 3 * n + 0][c] += hx[0] * (rdt * gx1 + dmx1);
+          f.cons0[b * nvar + ns + 3 * n + 1][c] += hx[1] * (rdt * gx2 + dmx2);
+          f.cons0[b * nvar + ns + 3 * n + 2][c] += hx[2] * (rdt * gx3 + dmx3);
+          if (gas) {
+            f.cons0[b * nvar + 4 * ns + n][c] += dek + dei + rdt * (v[0] * gx1 + v[1] * gx2 + v[2] * gx3);
+            f.cons0[b * nvar + 5 * ns + n][c] += dei;
+          }
+          lf[0] -= vol * dm / N.dt;
+          lf[1] -= g[0] * dens * vol;
+          lf[2] -= g[1] * dens * vol;
+          lf[3] -= g[2] * dens * vol;
+          lf[4] -= dmom[0] / N.dt;
+          lf[5] -= dmom[1] / N.dt;
+          lf[6] -= dmom[2] / N.dt;
+        };
+        for (int n = 0; n < P.gas.ns; ++n) fluid(P.gas, 6 * P.gas.ns, n, true);
+        for (int n = 0; n < P.dust.ns; ++n) fluid(P.dust, 4 * P.dust.ns, n, false);
+      }
+    }
+    // fixed-tree reduction: wave shuffles, then the four waves of the workgroup in order
+    for (int q = 0; q < 7; ++q) {
+      double vq = lf[q];
+      for (int off = 32; off > 0; off >>= 1) vq += __shfl_down(vq, off, 64);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = vq;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7)
+      N.partial[(static_cast<long>(np) * gridDim.x + blockIdx.x) * 7 + threadIdx.x] =
+          ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // RotatingFrame::ShearingBoxImpl (rotating_frame_impl.hpp:28-93), Cartesian.
 __global__ __launch_bounds__(TX *TY) void shearing_box_kernel(const PackView P, double om0,
                                                               double qshear, double dt) {
@@ -380,6 +527,16 @@ __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, c
 
 } // namespace
 
+int nbody_grid(const PackView &P) {
+  const long total = static_cast<long>(P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1) * P.nb;
+  return static_cast<int>(std::max<long>(1, std::min<long>(1024, (total + 255) / 256)));
+}
+void launch_nbody_gravity(const PackView &P, const artemis_nbody_particle_t *pl_dev, int npart, double omf, double dt,
+                          double *partial_dev, hipStream_t s) {
+  NBodyView N;
+  N.pl = pl_dev, N.npart = npart, N.omf = omf, N.dt = dt, N.partial = partial_dev;
+  hipLaunchKernelGGL(nbody_gravity_kernel, dim3(nbody_grid(P)), dim3(256), 0, s, P, N);
+}
 void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, double dt, hipStream_t s) {
   hipLaunchKernelGGL(gravity_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, G, dt);
 }

@@ -217,6 +217,7 @@ def _declare(L):
     L.artemis_sim_set_dropin.argtypes = [vp, i]
     L.artemis_sim_species.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.artemis_sim_set_kernel_timing.argtypes = [vp, i]
+    L.artemis_sim_nbody_force.argtypes = [vp, C.POINTER(d), i]
     L.artemis_sim_block_level.argtypes = [vp, i]
     L.artemis_sim_nblocks_global.restype = l
     L.artemis_sim_nblocks_global.argtypes = [vp]
@@ -315,6 +316,14 @@ class Simulation:
 
     def interior(self, a):
         return a[..., self.ks:self.ke + 1, self.js:self.je + 1, self.is_:self.ie + 1]
+
+    def nbody_force(self, reset=False):
+        """[npart, 7] accumulated back-reaction rows of the n-body particles (summed over ranks)."""
+        buf = (C.c_double * max(7 * self.L.artemis_sim_nbody_force(self.h, None, 0), 1))()  # sized by the size query
+        n = self.L.artemis_sim_nbody_force(self.h, buf, int(reset))
+        if n < 0:
+            raise RuntimeError("artemis_sim_nbody_force failed")
+        return np.array(buf[: 7 * n]).reshape(n, 7)
 
     def block_level(self, block=0):
         return self.L.artemis_sim_block_level(self.h, block)

@@ -237,6 +237,22 @@ class MeshBlockPack:
         """gravity: capi.Gravity (see gravity_point / gravity_uniform below)."""
         self._call(self.L.artemis_hip_external_gravity, C.byref(gravity), time, dt)
 
+    def NBodyGravity(self, time, dt, particles, omf=0.0):
+        """Gravity::NBodyGravity: particles = dicts with GM, pos, vel, xf, vf, rs, racc, gamma, beta, spline, couple.
+        Returns the [npart, 7] back-reaction rows of this call."""
+        n = len(particles)
+        arr = (capi.NBodyParticle * n)()
+        for q, p in zip(arr, particles):
+            q.gm = p["GM"]
+            for name in ("pos", "vel", "xf", "vf"):
+                for d_, v in enumerate(p.get(name, (0.0, 0.0, 0.0))):
+                    getattr(q, name)[d_] = v
+            q.rs, q.racc, q.gamma, q.beta = p.get("rs", 0.0), p.get("racc", 0.0), p.get("gamma", 0.0), p.get("beta", 0.0)
+            q.spline, q.couple = int(p.get("spline", 0)), int(p.get("couple", 1))
+        force = (C.c_double * (7 * n))()
+        capi.check(self.L.artemis_hip_nbody_gravity(C.byref(self.pack), arr, n, omf, time, dt, force, self._stream()))
+        return np.array(force[:]).reshape(n, 7)
+
     def viscosity_radial_table(self, D):
         """Tabulate the radial factor of D.visc (powerlaw r_exp != 0, alpha) per cell with the host
         libm (artemis_hip_diffusion_radial_fill), upload it and point D.visc.radial at it."""

@@ -107,6 +107,10 @@ int artemis_sim_overlap(const artemis_sim_t *sim);
  * runs as FillDerived (artemis.cpp:123, artemis_driver.cpp:261) -- what the fused path costs when the host
  * keeps `cons` as its Independent / Restart state.  Same results; returns non-zero off the tuned path. */
 int artemis_sim_set_dropin(artemis_sim_t *sim, int on);
+/* <gravity/nbody> with <nbody> integrator = none: the accumulated particle_force rows [npart][7] = {mass accreted,
+ * gravity force x3, accretion force x3} (nbody_gravity.hpp:129-136), summed over ranks like NBody::Advance does
+ * (nbody_advance.cpp:123-131); reset != 0 zeroes them afterwards.  Returns the number of particles. */
+int artemis_sim_nbody_force(artemis_sim_t *sim, double *out, int reset);
 /* number of gas / dust species (sizes the buffers of artemis_sim_get_field and artemis_sim_history) */
 void artemis_sim_species(const artemis_sim_t *sim, int *ns_gas, int *ns_dust);
 

@@ -207,8 +207,8 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
  * (gravity.cpp:57).  BinaryMassGravity (binary_mass.cpp:27-203): two softened point masses
  * with sinks at positions the adapter computes from the orbit; Cartesian, cylindrical, spherical3D
  * (not the axisymmetric systems, gravity.cpp:82-83).  Reads prim, updates cons0 momenta / total
- * energy (/ density for the sinks) of both fluids on interior cells.  The nbody type:
- * ARTEMIS_HIP_EUNSUPPORTED. */
+ * energy (/ density for the sinks) of both fluids on interior cells.  The nbody type has its own
+ * entry point, artemis_hip_nbody_gravity. */
 typedef struct artemis_gravity {
   int type;                   /* artemis_gravity_type */
   double g[3];                /* <gravity/uniform> gx1, gx2, gx3 */
@@ -222,6 +222,27 @@ typedef struct artemis_gravity {
 } artemis_gravity_t;
 int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_t *g, double time,
                                  double dt, void *stream);
+
+/* Gravity::NBodyGravity<GEOM> (gravity/nbody_gravity.hpp:28-221; gravity type `nbody`, gravity.cpp:110-117,
+ * :150-155): acceleration and accretion from the nbody package's particles (nbody/particle_base.hpp:96-258:
+ * Plummer or spline softening, sink radius with mass / momentum removal) on both fluids, and the back-reaction
+ * on every particle -- {mass accreted, gravity force x3, accretion force x3} per unit time, the seven numbers
+ * NBody::Advance reduces over ranks and hands to REBOUND (nbody/nbody_advance.cpp:123-131).  Cartesian,
+ * cylindrical and spherical3D (nbody.cpp:61: not the axisymmetric systems).
+ *   particles : HOST array, the state the host's N-body integrator currently holds (positions / velocities in
+ *               the simulation frame; xf / vf = frame origin and velocity, particle_base.hpp:86-93)
+ *   omf       : rotating_frame/omega when the frame correction is on (nbody_gravity.hpp:179-186), else 0
+ *   force     : HOST [npart][7], ADDED to (the reference accumulates particle_force over the stage's calls)
+ * Reads prim, updates cons0 of the interior zones particle by particle in order; the fluid update is bitwise
+ * reproducible, the seven sums are reduced in a fixed tree (workgroup partials, then the host in order) and
+ * agree with a serial sum to round-off.  SYNCHRONOUS (the reference's par_reduce returns host values). */
+typedef struct artemis_nbody_particle {
+  double gm, pos[3], vel[3], xf[3], vf[3];
+  double rs, racc, gamma, beta; /* softening radius; sink radius and its mass / momentum removal rates */
+  int spline, couple;           /* soft type spline (1) or plummer / none (0); couple = 0: ignored */
+} artemis_nbody_particle_t;
+int artemis_hip_nbody_gravity(const artemis_pack_t *p, const artemis_nbody_particle_t *particles, int npart, double omf,
+                              double time, double dt, double *force, void *stream);
 
 /* RotatingFrame::RotatingFrameForce (rotating_frame/rotating_frame.cpp:56-86).  Cartesian:
  * ShearingBoxImpl (rotating_frame_impl.hpp:28-93), tidal potential differenced across the cell

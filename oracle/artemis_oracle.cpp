@@ -119,6 +119,15 @@ struct Sim {
     bool on = false;
     Real omega = 0, qshear = 0;
   } rframe;
+  // <gravity/nbody>: the particles of the nbody package as NBodyGravity sees them (nbody/particle_base.hpp:53-93)
+  struct NBodyParticle {
+    Real GM = 0, pos[3] = {0, 0, 0}, vel[3] = {0, 0, 0}, xf[3] = {0, 0, 0}, vf[3] = {0, 0, 0};
+    Real rs = 0, racc = 0, gamma = 0, beta = 0;
+    int spline = 0, couple = 1;
+  };
+  std::vector<NBodyParticle> nbody;
+  bool nbody_frame_correction = true; // <nbody> frame = global (nbody.cpp:97,109)
+  std::vector<Real> pforce;           // [npart][7], accumulated by every NBodyGravity call (nbody_gravity.hpp:210-212)
   struct SelfDrag { // drag.hpp:68-117 SelfDragParams
     Real ix[3], ox[3], irate[3], orate[3];
     SelfDrag() {
@@ -1252,9 +1261,144 @@ inline void orbit_solve(const G &o, Real t, Real omf, Real pos[3]) {
   pos[2] = sinf * o.sinI;
 }
 
+// ---------------------------------------------------------------------------------------
+// gravity/nbody_gravity.hpp:28-221 NBodyGravity<GEOM> with nbody/particle_base.hpp:96-258 (RelativePosition,
+// idr3, grav_accel, accrete, CartToSph).  One sweep per particle like the reference's loop of par_reduce's;
+// the per-particle back-reaction {mass accreted, gravity force x3, accretion force x3} is summed serially in
+// loop order (Kokkos leaves the order unspecified: compare those seven numbers to round-off, the fluid bitwise).
+inline Real nb_idr3(const Sim::NBodyParticle &p, const Real dr2) { // particle_base.hpp:146-166
+  const Real fuzz = 1e-99;
+  const Real rs2 = SQR(p.rs);
+  const Real idr3_p = 1.0 / (fuzz + std::sqrt(dr2 + rs2) * (dr2 + rs2));
+  const Real dr3 = dr2 * std::sqrt(dr2);
+  const Real u2 = dr2 / (rs2 + fuzz);
+  const Real u = std::sqrt(u2);
+  const Real u3 = u * u2;
+  const Real h3inv = 1. / (rs2 * p.rs + fuzz);
+  const Real idr3_s = (dr2 >= rs2) ? 1.0 / dr3
+                                   : ((u < 0.5) ? h3inv * (32.0 / 3.0 - 192.0 / 5.0 * u2 + 32.0 * u3)
+                                                : h3inv * (64.0 / 3.0 - 48.0 * u + 192.0 / 5.0 * u2 - 32.0 / 3.0 * u3 -
+                                                           1.0 / (15.0 * u3)));
+  return idr3_p * (1 - p.spline) + p.spline * idr3_s;
+}
+inline void nb_accrete(const Sim::NBodyParticle &p, const Real x[3], const Real den, const Real v[3], const Real vb[3],
+                       const Real dt, Real *dm, Real *dmom, Real *dEk, Real * /*dEi*/) { // particle_base.hpp:190-245
+  const Real fuzz = 1e-99;
+  const Real vrel[3] = {v[0] + vb[0], v[1] + vb[1], v[2] + vb[2]};
+  Real dx[3], dv[3];
+  for (int d = 0; d < 3; d++) dx[d] = x[d] - (p.pos[d] - p.xf[d]), dv[d] = vrel[d] - (p.vel[d] - p.vf[d]);
+  const Real dv2 = SQR(dv[0]) + SQR(dv[1]) + SQR(dv[2]);
+  // CartToSph (:247-262): only the radius and the two tangential unit vectors are used
+  const Real R = std::sqrt(SQR(dx[0]) + SQR(dx[1]));
+  const Real r = std::sqrt(SQR(R) + SQR(dx[2]));
+  const Real ct = dx[2] / (r + fuzz), st = R / (r + fuzz);
+  const Real cp = dx[0] / (R + fuzz), sp = dx[1] / (R + fuzz);
+  const Real et[3] = {ct * cp, ct * sp, -st}, ep[3] = {-sp, cp, 0.0};
+  const Real dvt = dv[0] * et[0] + dv[1] * et[1] + dv[2] * et[2];
+  const Real dvp = dv[0] * ep[0] + dv[1] * ep[1] + dv[2] * ep[2];
+  const bool acc = ((p.racc > 0.0) && (r <= p.racc) && (-p.GM / (r + fuzz) + 0.5 * dv2 <= 0.0));
+  const Real ramp = SQR((p.racc - r) / (p.racc + fuzz));
+  const Real gdt = acc * std::min(ramp * p.gamma * dt, 1.0 / 9.0);
+  const Real bdt = acc * std::min(ramp * p.beta * dt, 1.0 / 9.0);
+  const Real fm = -gdt / (1.0 + gdt);
+  *dm += den * fm;
+  const Real fp = (gdt - bdt) / ((1.0 + gdt) * (1.0 + bdt));
+  const Real denp = den * (1.0 + fm);
+  for (int i = 0; i < 3; i++) {
+    const Real dmv = den * (fm * v[i] + fp * (dvt * et[i] + dvp * ep[i]));
+    dmom[i] += dmv;
+    const Real vxp = (den * v[i] + dmv) / denp;
+    *dEk += 0.5 * (v[i] + vxp) * den * (vxp - v[i]) + 0.5 * den * fm * vxp * vxp;
+  }
+}
+void nbody_gravity(Sim &s, Real /*time*/, Real dt) {
+  const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
+  const int npart = static_cast<int>(s.nbody.size());
+  s.pforce.resize(static_cast<size_t>(7) * npart, 0.0);
+  Real omf = 0.0;
+  if (s.rframe.on && s.nbody_frame_correction) omf = s.rframe.omega; // nbody_gravity.hpp:179-186
+  for (int np = 0; np < npart; ++np) {
+    const Sim::NBodyParticle &pl = s.nbody[np];
+    Real lforce[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (!pl.couple) continue;
+    for (int k = s.ks; k <= s.ke; ++k)
+      for (int j = s.js; j <= s.je; ++j)
+        for (int i = s.is; i <= s.ie; ++i) {
+          const Coords coords(s, k, j, i);
+          const Real x[3] = {coords.x1v(), coords.x2v(), coords.x3v()};
+          const Frame fr = to_cart_frame(coords, x);
+          const Real *xcart = fr.x, *ex1 = fr.e1, *ex2 = fr.e2, *ex3 = fr.e3;
+          Real hx[3];
+          coords.GetScaleFactors(hx);
+          const Real vol = coords.Volume();
+          Real g[3] = {0.0, 0.0, 0.0};
+          { // grav_accel (:178-187)
+            Real dxp[3];
+            for (int d = 0; d < 3; d++) dxp[d] = xcart[d] - (pl.pos[d] - pl.xf[d]);
+            const Real dr2 = SQR(dxp[0]) + SQR(dxp[1]) + SQR(dxp[2]);
+            const Real idr3_ = nb_idr3(pl, dr2);
+            for (int d = 0; d < 3; d++) g[d] += -pl.GM * idr3_ * dxp[d];
+          }
+          const Real gx1 = g[0] * ex1[0] + g[1] * ex1[1] + g[2] * ex1[2];
+          const Real gx2 = g[0] * ex2[0] + g[1] * ex2[1] + g[2] * ex2[2];
+          const Real gx3 = g[0] * ex3[0] + g[1] * ex3[1] + g[2] * ex3[2];
+          Real vf[3] = {0.0, 0.0, 0.0};
+          if (omf != 0.0) {
+            Real vrot[3] = {0.0, omf, 0.0};
+            if (coords.sys != CO_CART) {
+              const Frame fc = to_cyl_frame(coords, x);
+              const Real vp = omf * fc.x[0];
+              vrot[0] = fc.e1[1] * vp, vrot[1] = fc.e2[1] * vp, vrot[2] = fc.e3[1] * vp;
+            }
+            vf[0] = ex1[0] * vrot[0] + ex2[0] * vrot[1] + ex3[0] * vrot[2];
+            vf[1] = ex1[1] * vrot[0] + ex2[1] * vrot[1] + ex3[1] * vrot[2];
+            vf[2] = ex1[2] * vrot[0] + ex2[2] * vrot[1] + ex3[2] * vrot[2];
+          }
+          const size_t c = IDX(s, k, j, i);
+          auto fluid = [&](RVec &prim, RVec &u0, int nsp, int n, bool gas) {
+            const Real dens = prim[n * s.N + c];
+            const Real v[3] = {prim[(nsp + 3 * n + 0) * s.N + c], prim[(nsp + 3 * n + 1) * s.N + c],
+                               prim[(nsp + 3 * n + 2) * s.N + c]};
+            Real vcart[3];
+            vcart[0] = ex1[0] * v[0] + ex2[0] * v[1] + ex3[0] * v[2];
+            vcart[1] = ex1[1] * v[0] + ex2[1] * v[1] + ex3[1] * v[2];
+            vcart[2] = ex1[2] * v[0] + ex2[2] * v[1] + ex3[2] * v[2];
+            Real dm = 0.0, dmom[3] = {0.0, 0.0, 0.0}, dek = 0.0, dei = 0.0;
+            nb_accrete(pl, xcart, dens, vcart, vf, dt, &dm, dmom, &dek, &dei);
+            const Real dmx1 = dmom[0] * ex1[0] + dmom[1] * ex1[1] + dmom[2] * ex1[2];
+            const Real dmx2 = dmom[0] * ex2[0] + dmom[1] * ex2[1] + dmom[2] * ex2[2];
+            const Real dmx3 = dmom[0] * ex3[0] + dmom[1] * ex3[1] + dmom[2] * ex3[2];
+            const Real rdt = dens * dt;
+            u0[n * s.N + c] += dm;
+            u0[(nsp + 3 * n + 0) * s.N + c] += hx[0] * (rdt * gx1 + dmx1);
+            u0[(nsp + 3 * n + 1) * s.N + c] += hx[1] * (rdt * gx2 + dmx2);
+            u0[(nsp + 3 * n + 2) * s.N + c] += hx[2] * (rdt * gx3 + dmx3);
+            if (gas) {
+              u0[(4 * nsp + n) * s.N + c] += dek + dei + rdt * (v[0] * gx1 + v[1] * gx2 + v[2] * gx3);
+              u0[(5 * nsp + n) * s.N + c] += dei;
+            }
+            lforce[0] -= vol * dm / dt;
+            lforce[1] -= g[0] * dens * vol;
+            lforce[2] -= g[1] * dens * vol;
+            lforce[3] -= g[2] * dens * vol;
+            lforce[4] -= dmom[0] / dt;
+            lforce[5] -= dmom[1] / dt;
+            lforce[6] -= dmom[2] / dt;
+          };
+          for (int n = 0; n < ng_; ++n) fluid(s.gprim, s.gu0, ng_, n, true);
+          for (int n = 0; n < nd_; ++n) fluid(s.dprim, s.du0, nd_, n, false);
+        }
+    for (int q = 0; q < 7; ++q) s.pforce[7 * np + q] += lforce[q];
+  }
+}
+
 void external_gravity(Sim &s, Real time, Real dt) {
   if (s.grav.type == 0) return;
   if (!((time >= s.grav.tstart) && (time < s.grav.tstop))) return; // gravity.cpp:134
+  if (s.grav.type == 4) { // gravity.cpp:150-155
+    nbody_gravity(s, time, dt);
+    return;
+  }
   const int ng_ = s.c.ns_gas, nd_ = s.c.ns_dust;
   const bool multi_d = (s.ndim >= 2), three_d = (s.ndim == 3);
   const Real gm = s.grav.gm;
@@ -2918,6 +3062,32 @@ void oracle_set_gravity_binary(void *h, const double *p) {
   g.cosf0 = std::cos(p[7]), g.sinf0 = std::sin(p[7]);
   g.soft = p[8], g.soft2 = p[9], g.sink = p[10], g.sink2 = p[11], g.sink_rate = p[12], g.sink_rate2 = p[13];
   g.pos[0] = p[14], g.pos[1] = p[15], g.pos[2] = p[16];
+}
+// <gravity/nbody> with the nbody package's particles: par[20 * n + ...] = {GM, pos[3], vel[3], xf[3], vf[3], rs, racc,
+// gamma, beta, spline, couple, 0}
+void oracle_set_gravity_nbody(void *h, int npart, const double *par, int frame_correction) {
+  Sim &s = *static_cast<Sim *>(h);
+  s.grav.type = 4;
+  s.nbody.assign(npart, Sim::NBodyParticle());
+  double gm = 0.0;
+  for (int n = 0; n < npart; ++n) {
+    const double *q = par + 20 * n;
+    Sim::NBodyParticle &p = s.nbody[n];
+    p.GM = q[0];
+    for (int d = 0; d < 3; ++d) p.pos[d] = q[1 + d], p.vel[d] = q[4 + d], p.xf[d] = q[7 + d], p.vf[d] = q[10 + d];
+    p.rs = q[13], p.racc = q[14], p.gamma = q[15], p.beta = q[16];
+    p.spline = static_cast<int>(q[17]), p.couple = static_cast<int>(q[18]);
+    gm += p.GM;
+  }
+  s.grav.gm = gm; // gravity.cpp:117: gm of the nbody package = G * mtot
+  s.nbody_frame_correction = frame_correction != 0;
+  s.pforce.assign(static_cast<size_t>(7) * npart, 0.0);
+}
+// the accumulated particle_force rows (nbody_gravity.hpp:210-212); `reset` zeroes them like NBody::Advance does
+void oracle_nbody_force(void *h, double *out, int reset) {
+  Sim &s = *static_cast<Sim *>(h);
+  for (size_t q = 0; q < s.pforce.size(); ++q) out[q] = s.pforce[q];
+  if (reset) std::fill(s.pforce.begin(), s.pforce.end(), 0.0);
 }
 void oracle_set_gravity_window(void *h, double tstart, double tstop) {
   Sim &s = *static_cast<Sim *>(h);

@@ -112,6 +112,8 @@ def lib():
         L.oracle_set_gravity_point.argtypes = [vp] + [d] * 7
         L.oracle_set_gravity_binary.argtypes = [vp, C.POINTER(d)]
         L.oracle_set_gravity_window.argtypes = [vp, d, d]
+        L.oracle_set_gravity_nbody.argtypes = [vp, i, C.POINTER(d), i]
+        L.oracle_nbody_force.argtypes = [vp, C.POINTER(d), i]
         L.oracle_set_rotating_frame.argtypes = [vp, d, d]
         L.oracle_set_drag.argtypes = [vp, i, i, d, d, C.POINTER(d), C.POINTER(d)]
         L.oracle_set_damping.argtypes = [vp, i, C.POINTER(d)]
@@ -274,6 +276,22 @@ class Oracle:
         self.L.oracle_set_gravity_binary(self.h, (C.c_double * 17)(
             mass, q, a, e, r(i), r(omega), r(Omega), r(f), soft1, soft2, sink1, sink2, sink_rate1, sink_rate2,
             x, y, z))
+
+    def set_gravity_nbody(self, particles, frame_correction=True):
+        """<gravity/nbody> + the nbody package's particles (static: <nbody> integrator = none).  particles: dicts with
+        GM, pos, vel, xf, vf, rs, racc, gamma, beta, spline, couple (nbody/particle_base.hpp:53-93)."""
+        par = []
+        for p in particles:
+            par += [p["GM"], *p.get("pos", (0, 0, 0)), *p.get("vel", (0, 0, 0)), *p.get("xf", (0, 0, 0)),
+                    *p.get("vf", (0, 0, 0)), p.get("rs", 0.0), p.get("racc", 0.0), p.get("gamma", 0.0),
+                    p.get("beta", 0.0), float(p.get("spline", 0)), float(p.get("couple", 1)), 0.0]
+        self._npart = len(particles)
+        self.L.oracle_set_gravity_nbody(self.h, len(particles), (C.c_double * len(par))(*par), int(frame_correction))
+
+    def nbody_force(self, reset=False):
+        out = (C.c_double * (7 * self._npart))()
+        self.L.oracle_nbody_force(self.h, out, int(reset))
+        return np.array(out[:]).reshape(self._npart, 7)
 
     def set_gravity_window(self, tstart, tstop):
         self.L.oracle_set_gravity_window(self.h, tstart, tstop)

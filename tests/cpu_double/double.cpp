@@ -294,6 +294,28 @@ int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_
   }
   return 0;
 }
+int artemis_hip_nbody_gravity(const artemis_pack_t *p, const artemis_nbody_particle_t *pl, int npart, double omf, double time,
+                              double dt, double *force, void *) {
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    Sim &s = *B.s;
+    B.load_state();
+    s.grav.type = 4;
+    s.nbody.assign(npart, Sim::NBodyParticle());
+    for (int n = 0; n < npart; ++n) {
+      Sim::NBodyParticle &q = s.nbody[n];
+      q.GM = pl[n].gm, q.rs = pl[n].rs, q.racc = pl[n].racc, q.gamma = pl[n].gamma, q.beta = pl[n].beta;
+      q.spline = pl[n].spline, q.couple = pl[n].couple;
+      for (int d = 0; d < 3; ++d) q.pos[d] = pl[n].pos[d], q.vel[d] = pl[n].vel[d], q.xf[d] = pl[n].xf[d], q.vf[d] = pl[n].vf[d];
+    }
+    s.rframe.on = (omf != 0.0), s.rframe.omega = omf, s.nbody_frame_correction = true;
+    s.pforce.assign(static_cast<size_t>(7) * npart, 0.0);
+    nbody_gravity(s, time, dt);
+    for (int q = 0; q < 7 * npart; ++q) force[q] += s.pforce[q];
+    B.out(s.gu0, p->gas.cons0, s.nvg), B.out(s.du0, p->dust.cons0, s.nvd);
+  }
+  return 0;
+}
 int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, double qshear, double,
                                      double dt, void *) {
   for (int b = 0; b < p->nblocks; ++b) {
