@@ -205,11 +205,12 @@ ADEV void stage_plane(LdsTile &S, const Ctx &x, const Cell6 &q, const Raw5 &hal)
 // Returns the fluxes through the own cell's lower x1/x2 faces; the upper ones are left in
 // S.FX / S.FY for plane_update.  The perimeter duties rotate over the waves with k so that no
 // wave (and no SIMD) carries the extra Riemann pass every plane.
-template <int RIEMANN, int RECON>
+template <int RIEMANN, int RECON, bool D3>
 ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k, const Cell6 &qc,
                        const bool stage_next, const Cell6 &qn, const Raw5 &hal_next, Flux8 &fx_lo,
                        Flux8 &fy_lo) {
   const int tx = x.tx, ty = x.ty;
+  const bool multi_d = D3 || x.multi_d; // compile-time true in the 3-D instantiation
   const int t = (x.t + 64 * (k % NW)) % NT; // duty index: wave roles rotate with k
   // ---- P1: slopes of the own cell; perimeter slopes on waves 2 (x1) and 3 (x2) -----------
   Cell6 lox, loy;
@@ -222,7 +223,7 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
   }
   SLX(d, 0) SLX(v1, 1) SLX(v2, 2) SLX(v3, 3) SLX(p, 4) SLX(e, 5)
 #undef SLX
-  if (x.multi_d) {
+  if (multi_d) {
 #define SLY(m, n)                                                                          \
   {                                                                                        \
     const double s_ =                                                                      \
@@ -244,7 +245,7 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
       else S.UPX[n][row][0] = up_val<RECON>(q, s_);
     }
   }
-  if (x.multi_d && t >= 192 && t < 256) { // rows j0-1 (upper value) and j0+8 (lower value)
+  if (multi_d && t >= 192 && t < 256) { // rows j0-1 (upper value) and j0+8 (lower value)
     const int u = t - 192, cx = u & 31, side = u >> 5;
     const int ry = side ? FTY + FH : FH - 1;
 #pragma unroll
@@ -262,7 +263,7 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
   fx_lo = solve_face<RIEMANN, 1>(x.gk, L, lox);
   if (tx > 0) { PUT8(S.FX, fx_lo, [ty][tx - 1]); }
   fy_lo = fx_lo;
-  if (x.multi_d) {
+  if (multi_d) {
     GET6(L, S.UPY, [ty][tx]);
     fy_lo = solve_face<RIEMANN, 2>(x.gk, L, loy);
     if (ty > 0) { PUT8(S.FY, fy_lo, [ty - 1][tx]); }
@@ -275,7 +276,7 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
       GET6(r, S.LOX, [u]);
       const Flux8 fe_ = solve_face<RIEMANN, 1>(x.gk, l, r);
       PUT8(S.FX, fe_, [u][FTX - 1]);
-    } else if (x.multi_d && u >= 32) {
+    } else if (multi_d && u >= 32) {
       const int cx = u - 32;
       Cell6 l, r;
       GET6(l, S.UPY, [FTY][cx]);
@@ -290,16 +291,18 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
 
 // Phase P3: gather the upper-face fluxes published by the neighbours, then the whole per-cell
 // chain update -> sources -> aux -> c2p -> p2c -> store (and the CFL reduction).
-template <bool HAS_U1, bool WRITE_CONS, bool WITH_DT>
+template <bool HAS_U1, bool WRITE_CONS, bool WITH_DT, bool D3>
 ADEV void plane_update(LdsTile &S, const PackView &P, const StageK &a, const Ctx &x, const int k,
                        const Cell6 &qc, const Flux8 &fx_lo, const Flux8 &fy_lo, const Flux8 &fz_lo,
                        const Flux8 &fz_hi, const Raw5 &u1raw, double &ldt) {
   const int tx = x.tx, ty = x.ty;
+  const bool multi_d = D3 || x.multi_d;
+  constexpr bool three_d = D3;
   const double gm1 = x.gm1;
   const FluidView &f = P.gas;
   Flux8 fx_hi, fy_hi = fx_lo;
   GET8(fx_hi, S.FX, [ty][tx]);
-  if (x.multi_d) { GET8(fy_hi, S.FY, [ty][tx]); }
+  if (multi_d) { GET8(fy_hi, S.FY, [ty][tx]); }
   if (!x.active) return;
   const double *g = x.g;
   const double dx1 = x.dx1, dx2 = x.dx2;
@@ -327,8 +330,8 @@ ADEV void plane_update(LdsTile &S, const PackView &P, const StageK &a, const Ctx
   auto upd = [&](double u0, double u1, double f1l, double f1h, double f2l, double f2h, double f3l,
                  double f3h) {
     double divf = (ax1 * f1l - ax1 * f1h);
-    if (x.multi_d) divf += (ax2 * f2l - ax2 * f2h);
-    if (x.three_d) divf += (ax3 * f3l - ax3 * f3h);
+    if (multi_d) divf += (ax2 * f2l - ax2 * f2h);
+    if (three_d) divf += (ax3 * f3l - ax3 * f3h);
     return a.gam0 * u0 + a.gam1 * u1 + div(divf * x.beta_dt, rvol);
   };
   const double D = upd(D0, D1, fx_lo.d, fx_hi.d, fy_lo.d, fy_hi.d, fz_lo.d, fz_hi.d);
@@ -341,11 +344,11 @@ ADEV void plane_update(LdsTile &S, const PackView &P, const StageK &a, const Ctx
   const double bdt_vol = div(x.bdt, rvol);
   M1 += div(x.bdt, x.rdx1) * (fx_lo.pf - fx_hi.pf);
   G -= bdt_vol * 0.5 * (fx_lo.pf + fx_hi.pf) * (ax1 * fx_hi.vf - ax1 * fx_lo.vf);
-  if (x.multi_d) {
+  if (multi_d) {
     M2 += div(x.bdt, x.rdx2) * (fy_lo.pf - fy_hi.pf);
     G -= bdt_vol * 0.5 * (fy_lo.pf + fy_hi.pf) * (ax2 * fy_hi.vf - ax2 * fy_lo.vf);
   }
-  if (x.three_d) {
+  if (three_d) {
     M3 += div(x.bdt, rdx3) * (fz_lo.pf - fz_hi.pf);
     G -= bdt_vol * 0.5 * (fz_lo.pf + fz_hi.pf) * (ax3 * fz_hi.vf - ax3 * fz_lo.vf);
   }
@@ -387,13 +390,13 @@ ADEV void plane_update(LdsTile &S, const PackView &P, const StageK &a, const Ctx
     const double cs = sqrt_pos(div(bulk, rd));
     double denom = 0.0;
     denom += div(fabs(w1) + cs, x.rdx1); // 1.0*dx == dx
-    if (x.multi_d) denom += div(fabs(w2) + cs, x.rdx2);
-    if (x.three_d) denom += div(fabs(w3) + cs, rdx3);
+    if (multi_d) denom += div(fabs(w2) + cs, x.rdx2);
+    if (three_d) denom += div(fabs(w3) + cs, rdx3);
     ldt = amin(ldt, div(1.0, denom));
   }
 }
 
-template <int RIEMANN, int RECON, bool HAS_U1, bool WRITE_CONS, bool WITH_DT>
+template <int RIEMANN, int RECON, bool HAS_U1, bool WRITE_CONS, bool WITH_DT, bool D3>
 __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, const StageK a) {
   __shared__ LdsTile S;
   Ctx x;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   local /= bntj;
   const int chunk = local % bnchunk;
   x.b = local / bnchunk;
-  x.three_d = P.ndim > 2, x.multi_d = P.ndim > 1;
+  x.three_d = D3, x.multi_d = D3 || P.ndim > 1; // D3: the 3-D march; otherwise one plane (1-D / 2-D blocks)
   x.i0 = P.is + ti * FTX, x.j0 = P.js + tj * FTY;
   const int i = x.i0 + x.tx, j = x.j0 + x.ty;
   x.active = (i <= P.ie) && (j <= P.je);
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   const double *u1_e = a.prim_u1[x.b * 6 + 5];
   Raw5 u1raw;
   u1raw.d = u1raw.v1 = u1raw.v2 = u1raw.v3 = u1raw.e = 0.0;
-  if (!x.three_d) {
+  if constexpr (!D3) {
     const Cell6 qc = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + k0 * x.sk, x.gm1);
     if constexpr (HAS_U1) u1raw = load_raw(u1_r, u1_1, u1_2, u1_3, u1_e, x.col + k0 * x.sk);
     Flux8 fz, fx_lo, fy_lo;
@@ -482,8 +485,8 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
     if (x.hr >= 0) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + k0 * x.sk);
     stage_plane(S, x, qc, hal);
     __syncthreads();
-    plane_sweeps<RIEMANN, RECON>(S, P, x, k0, qc, false, qc, hal, fx_lo, fy_lo);
-    plane_update<HAS_U1, WRITE_CONS, WITH_DT>(S, P, a, x, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
+    plane_sweeps<RIEMANN, RECON, false>(S, P, x, k0, qc, false, qc, hal, fx_lo, fy_lo);
+    plane_update<HAS_U1, WRITE_CONS, WITH_DT, false>(S, P, a, x, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
   } else {
     // x3 state carried in registers: planes k, k+1, the upper face value of cell k and the
     // flux through face k.
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
       if (x.hr >= 0 && k < k1) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + (k + 1) * x.sk);
       Flux8 fx_lo, fy_lo;
       if (k >= k0) {
-        plane_sweeps<RIEMANN, RECON>(S, P, x, k, qc, k < k1, qn, hal, fx_lo, fy_lo);
+        plane_sweeps<RIEMANN, RECON, true>(S, P, x, k, qc, k < k1, qn, hal, fx_lo, fy_lo);
       } else { // priming trip: stage the first plane
         stage_plane(S, x, qn, hal);
         __syncthreads();
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
 #undef ZSL
       const Flux8 fz_hi = solve_face<RIEMANN, 3>(x.gk, zl, zr);
       if (k >= k0)
-        plane_update<HAS_U1, WRITE_CONS, WITH_DT>(S, P, a, x, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt);
+        plane_update<HAS_U1, WRITE_CONS, WITH_DT, true>(S, P, a, x, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt);
       fz_lo = fz_hi, zl = zl_next, qc = qn, qn = qnn;
     }
   }
@@ -585,7 +588,10 @@ int launch_cfg(const PackView &P, const StageK &k, bool has_u1, bool cons, bool 
   const dim3 grid(k.start[k.nbox]);
   const dim3 block(FTX, FTY);
 #define GO(U, C, D)                                                                        \
-  hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, U, C, D>), grid, block, 0, s, P, k)
+  do {                                                                                     \
+    if (P.ndim > 2) hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, U, C, D, true>), grid, block, 0, s, P, k); \
+    else hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, U, C, D, false>), grid, block, 0, s, P, k); \
+  } while (0)
   if (has_u1) {
     if (cons) { if (dt) GO(true, true, true); else GO(true, true, false); }
     else { if (dt) GO(true, false, true); else GO(true, false, false); }

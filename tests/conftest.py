@@ -8,6 +8,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _usable_cpus():
+    """CPUs this process may really use: affinity mask clipped by a cgroup CPU quota (the GPU box shows 256
+    logical CPUs but grants 16 CPUs of time -- an OpenMP team of 256 threads then crawls)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return n
+
+
+# the CPU oracle (OpenMP) is the checker of nearly every test: size its thread team to the real CPU budget
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, _usable_cpus())))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
