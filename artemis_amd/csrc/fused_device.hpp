@@ -1,0 +1,86 @@
+// Register-level pieces shared by the streaming fused stage kernels (kernels_fused.hip: 3-D march with an LDS
+// tile; kernels_stage2d.hip: 2-D row march with wave shuffles): cell / face records, PCM / PLM face values,
+// the Riemann problem of one face in global momentum order.  Same expression trees as the per-task kernels.
+#pragma once
+#include "device_math.hpp"
+
+namespace artemis {
+namespace fused {
+
+struct Cell6 {
+  double d, v1, v2, v3, p, e;
+};
+
+// Pointers fetched from the pack's tables are generic to the compiler; the arrays live in HBM,
+// so tell it: global_load/global_store instead of flat_* (no LDS-aperture check, vmcnt only).
+typedef const double __attribute__((address_space(1))) *gcptr;
+typedef double __attribute__((address_space(1))) *gptr;
+ADEV double gld(const double *p, long c) { return ((gcptr)p)[c]; }
+ADEV void gst(double *p, long c, double v) { ((gptr)p)[c] = v; }
+
+ADEV Cell6 load_cell(const double *__restrict__ r, const double *__restrict__ v1,
+                     const double *__restrict__ v2, const double *__restrict__ v3,
+                     const double *__restrict__ se, long c, double gm1) {
+  Cell6 q;
+  q.d = gld(r, c), q.v1 = gld(v1, c), q.v2 = gld(v2, c), q.v3 = gld(v3, c), q.e = gld(se, c);
+  q.p = amax(0.0, gm1 * q.d * q.e); // fill_derived.cpp:247 (IdealGas P)
+  return q;
+}
+
+template <int RECON>
+ADEV double slope(double qm, double q, double qp) {
+  if constexpr (RECON == 0) return 0.0;
+  else return plm_dqm_fast(qm, q, qp);
+}
+// q + 0.0 == q and q - 0.0 == q bitwise for every finite q except that -0.0 + 0.0 = +0.0;
+// PCM therefore bypasses the add to stay identical to pcm.hpp:34-88.
+template <int RECON>
+ADEV double up_val(double q, double dqm) {
+  if constexpr (RECON == 0) return q;
+  else return q + dqm;
+}
+template <int RECON>
+ADEV double lo_val(double q, double dqm) {
+  if constexpr (RECON == 0) return q;
+  else return q - dqm;
+}
+
+// Riemann problem of sweep direction DIR (1..3) between global-order states L and R; the
+// result is returned in GLOBAL momentum order (f.m1, f.m2, f.m3).
+struct Flux8 {
+  double d, m1, m2, m3, e, eg, pf, vf;
+};
+struct GasK { // per-thread constants of the solver (hllc.hpp:75-77)
+  double gm1, igm1, gamma, alpha;
+};
+ADEV GasK gas_constants(double gm1) {
+  GasK g;
+  g.gm1 = gm1, g.igm1 = 1.0 / gm1, g.gamma = gm1 + 1.0;
+  g.alpha = (g.gamma + 1.0) / (2.0 * g.gamma);
+  return g;
+}
+template <int RIEMANN, int DIR>
+ADEV Flux8 solve_face(const GasK &gk, const Cell6 &L, const Cell6 &R) {
+  Prim6 l, r;
+  l.d = L.d, l.p = L.p, l.e = L.e, r.d = R.d, r.p = R.p, r.e = R.e;
+  if constexpr (DIR == 1) {
+    l.vx = L.v1, l.vy = L.v2, l.vz = L.v3, r.vx = R.v1, r.vy = R.v2, r.vz = R.v3;
+  } else if constexpr (DIR == 2) { // hllc.hpp:67-69: (ivx,ivy,ivz) = (v2,v3,v1)
+    l.vx = L.v2, l.vy = L.v3, l.vz = L.v1, r.vx = R.v2, r.vy = R.v3, r.vz = R.v1;
+  } else { // (v3,v1,v2)
+    l.vx = L.v3, l.vy = L.v1, l.vz = L.v2, r.vx = R.v3, r.vy = R.v1, r.vz = R.v2;
+  }
+  FaceFlux F;
+  if constexpr (RIEMANN == 0) hllc_gas_fast(gk.gm1, gk.igm1, gk.gamma, gk.alpha, l, r, F);
+  else riemann_gas<RIEMANN>(gk.gm1, l, r, F);
+  Flux8 o;
+  o.d = F.fd, o.e = F.fe, o.eg = F.feg, o.pf = F.pf, o.vf = F.vf;
+  if constexpr (DIR == 1) o.m1 = F.fmx, o.m2 = F.fmy, o.m3 = F.fmz;
+  else if constexpr (DIR == 2) o.m2 = F.fmx, o.m3 = F.fmy, o.m1 = F.fmz;
+  else o.m3 = F.fmx, o.m1 = F.fmy, o.m2 = F.fmz;
+  return o;
+}
+
+
+} // namespace fused
+} // namespace artemis

@@ -49,6 +49,11 @@ void launch_amr_criterion(const artemis_amr_criterion_t &a, int magnitude, hipSt
 void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t &g, hipStream_t s);
 void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
                        int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s);
+// kernels_stage2d.hip
+bool stage2d_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas, int recon_dust,
+                    int riemann_dust);
+void launch_stage2d(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas, int riemann_dust,
+                    hipStream_t s);
 // kernels_amr.hip
 void launch_ml_exchange(const PackView &P, const artemis_ml_pack_t &ml, const artemis_ml_op_t *ops, int nops, double *sbuf,
                         const double *rbuf, hipStream_t s);

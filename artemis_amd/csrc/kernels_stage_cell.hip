@@ -16,6 +16,8 @@
 // Gas pressure of stencil cells is recomputed as max(0, gm1*rho*sie) (fill_derived.cpp:247), so
 // ghost zones only need the FillGhost variables.  Every expression tree is shared with the
 // per-task kernels (task_device.hpp, sources_device.hpp): results are bit-identical.
+#include <cstdlib>
+
 #include "device_math.hpp"
 #include "diffusion_device.hpp"
 #include "geometry.hpp"
@@ -136,28 +138,6 @@ ADEV FaceFlux face_of_cell(const PackView &P, const FluidView &f, double *const 
   if constexpr (CURV) F.fmx *= hs[d], F.fmy *= hs[(d + 1) % 3], F.fmz *= hs[(d + 2) % 3];
   (void)f, (void)prim, (void)n;
   return F;
-}
-
-// PrimToCons of one cell (fill_derived.cpp:229-274): floors are re-applied like the reference does
-ADEV GasCons prim_to_cons_gas(const FluidView &f, double d, double v1, double v2, double v3,
-                              double se, const double hx[3]) {
-  GasCons u;
-  const double w_d = (d > f.dfloor) ? d : f.dfloor;
-  u.d = w_d;
-  u.m1 = w_d * v1 * hx[0], u.m2 = w_d * v2 * hx[1], u.m3 = w_d * v3 * hx[2];
-  const double w_s = (se > f.siefloor) ? se : f.siefloor;
-  u.eg = w_s * w_d;
-  const double ke = 0.5 * w_d * (sqr(v1) + sqr(v2) + sqr(v3));
-  u.e = u.eg + ke;
-  return u;
-}
-ADEV DustCons prim_to_cons_dust(const FluidView &f, double d, double v1, double v2, double v3,
-                                const double hx[3]) {
-  DustCons u;
-  const double w_d = (d > f.dfloor) ? d : f.dfloor;
-  u.d = w_d;
-  u.m1 = w_d * v1 * hx[0], u.m2 = w_d * v2 * hx[1], u.m3 = w_d * v3 * hx[2];
-  return u;
 }
 
 // STORED: the epilogue form -- face fluxes come from the flux / pressure-flux / face-velocity arrays a
@@ -466,6 +446,12 @@ void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t
 
 void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
                        int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s) {
+  // 2-D Cartesian gas (+ <= 2 dust species) with the pointwise sources: the row-march kernel does the whole
+  // stage of both fluids, drag, aux, c2p and dt in one pass (kernels_stage2d.hip; same bits)
+  if (getenv("ARTEMIS_NO_STAGE2D") == nullptr && stage2d_covers(P, g, recon_gas, riemann_gas, recon_dust, riemann_dust)) {
+    launch_stage2d(P, g, recon_gas, riemann_gas, riemann_dust, s);
+    return;
+  }
   CellStageArgs a;
   a.gam0 = g.gam0, a.gam1 = g.gam1, a.beta_dt = g.beta_dt, a.bdt = g.bdt;
   a.bdt_ptr = g.beta_dt_dev;

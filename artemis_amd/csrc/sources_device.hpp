@@ -22,6 +22,29 @@ ADEV void scale_factors_of(const DCoords &co, double hx[3]) {
   hx[0] = 1.0, hx[1] = co.hx2v(), hx[2] = co.hx3v();
 }
 
+// PrimToCons of one cell (fill_derived.cpp:229-274): floors are re-applied like the reference does
+ADEV GasCons prim_to_cons_gas(const FluidView &f, double d, double v1, double v2, double v3,
+                              double se, const double hx[3]) {
+  GasCons u;
+  const double w_d = (d > f.dfloor) ? d : f.dfloor;
+  u.d = w_d;
+  u.m1 = w_d * v1 * hx[0], u.m2 = w_d * v2 * hx[1], u.m3 = w_d * v3 * hx[2];
+  const double w_s = (se > f.siefloor) ? se : f.siefloor;
+  u.eg = w_s * w_d;
+  const double ke = 0.5 * w_d * (sqr(v1) + sqr(v2) + sqr(v3));
+  u.e = u.eg + ke;
+  return u;
+}
+ADEV DustCons prim_to_cons_dust(const FluidView &f, double d, double v1, double v2, double v3,
+                                const double hx[3]) {
+  DustCons u;
+  const double w_d = (d > f.dfloor) ? d : f.dfloor;
+  u.d = w_d;
+  u.m1 = w_d * v1 * hx[0], u.m2 = w_d * v2 * hx[1], u.m3 = w_d * v3 * hx[2];
+  return u;
+}
+
+
 // ---- Gravity::ExternalGravity (gravity.cpp:126-155) ---------------------------------------
 // acceleration components along the coordinate basis and the sink fraction of one cell
 struct GravAcc {

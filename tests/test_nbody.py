@@ -75,7 +75,8 @@ def test_disk_nbody_deck_hip_equals_oracle(hiplib, b):
         assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
     fs, fo = s.nbody_force(), o.nbody_force()
     assert fs.shape == fo.shape == (1, 7)
-    assert np.max(np.abs(fs - fo)) <= 1e-9 * (np.abs(fo).max() + 1e-12)  # sums of ~1e5 signed terms that cancel
+    # sums of ~3e4 signed O(1e-3) terms that cancel to ~1e-15 on an axisymmetric disk: absolute round-off tolerance
+    assert np.max(np.abs(fs - fo)) <= 1e-12
     s.close()
 
 

@@ -47,6 +47,12 @@ CASES = [
     ((20, 8, 6), (-1, -0.5, 0.25), (1, 0.8, 0.95), 1, 1, "pcm", "hllc", "hlle", "cartesian", 2),
     ((70, 9, 1), (-1, -0.5, -0.5), (1, 0.8, 0.5), 1, 1, "plm", "hllc", "hlle", "cartesian", 2),
     ((131, 1, 1), (0, -0.5, -0.5), (1, 0.5, 0.5), 0, 2, "plm", "hlle", "llf", "cartesian", 2),
+    # 2-D Cartesian, one gas species (+ <= 2 dust): the row-march kernel (kernels_stage2d.hip); strips of 60 columns,
+    # ragged last strip, several row chunks
+    ((130, 37, 1), (-1, -0.5, -0.5), (1, 0.8, 0.5), 1, 0, "plm", "hlle", "hlle", "cartesian", 2),
+    ((64, 70, 1), (-1, -0.5, -0.5), (1, 0.8, 0.5), 1, 2, "pcm", "llf", "llf", "cartesian", 2),
+    ((61, 40, 1), (-1, -0.5, -0.5), (1, 0.8, 0.5), 1, 1, "plm", "hllc", "llf", "cartesian", 3),
+    ((121, 33, 1), (-1, -0.5, -0.5), (1, 0.8, 0.5), 1, 2, "plm", "hllc", "hlle", "cartesian", 2),
     ((24, 10, 1), (0.4, 0.5, -0.5), (2.5, 2.6, 0.5), 1, 1, "plm", "hlle", "hlle", "spherical", 2),
     ((16, 8, 6), (0.3, 0.7, 0.0), (1.7, 2.5, 6.0), 2, 1, "plm", "hllc", "hlle", "spherical", 2),
     ((40, 1, 1), (0.0, 0.0, -0.5), (1.0, np.pi, 0.5), 1, 1, "ppm", "hlle", "hlle", "spherical", 3),
@@ -90,7 +96,7 @@ def test_general_stage_hydro(hiplib, nx, lo, hi, nsg, nsd, recon, riem, driem, c
         same(dbuf[0][I], o.dprim[I], "dust prim")
 
 
-@pytest.mark.parametrize("case", [1, 4, 5])
+@pytest.mark.parametrize("case", [1, 4, 5, 7, 8, 9])
 def test_general_stage_with_sources_and_drag(hiplib, case):
     """Cartesian: point-mass gravity + shearing box + simple_dust drag in one stage, with the
     fused dt estimate of the new state."""
