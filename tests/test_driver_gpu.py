@@ -165,7 +165,11 @@ def test_blast2d_shipped_deck_sedov_radius(hiplib):
 def test_driver_rejects_out_of_scope(hiplib):
     from artemis_amd.driver import Simulation
     with pytest.raises(RuntimeError, match="out of scope"):
+        Simulation(DECK("blast", "blast.in"), ["physics/radiation=true"])
+    with pytest.raises(RuntimeError, match="only `none`"):  # REBOUND integration: not built (static particles are)
         Simulation(DECK("blast", "blast.in"), ["physics/nbody=true"])
+    with pytest.raises(RuntimeError, match="adaptive"):
+        Simulation(DECK("blast", "blast.in"), ["parthenon/mesh/refinement=adaptive"])
     with pytest.raises(RuntimeError, match="not recognized"):
         Simulation(DECK("blast", "blast.in"), ["artemis/coordinates=toroidal"])
     with pytest.raises(RuntimeError, match="Cartesian-only"):
