@@ -713,6 +713,12 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
   return after_launch("stage_general");
 }
 
+int artemis_hip_stage_general_variant(const artemis_pack_t *p, const artemis_stage_general_args_t *a) {
+  if (!p || !a) return 0;
+  return artemis::stage_general_variant(artemis::make_pack_view(*p), *a, p->gas.recon, p->gas.riemann, p->dust.recon,
+                                        p->dust.riemann);
+}
+
 int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream) {
   if (int rc = validate(p)) return rc;
   if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");

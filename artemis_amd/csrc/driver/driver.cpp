@@ -263,6 +263,7 @@ struct artemis_sim {
   bool unfused_ready = false;
   bool use_fused = false, fused_possible = false;
   bool tuned = false; // the hand-tuned gas kernel covers this deck; otherwise the general cell-centred stage
+  int general_variant = -1; // what artemis_hip_stage_general ran last (artemis_hip_stage_general_variant)
   int overlap = 0; // 0 off, 1 shell launch + bulk launch, 2 one launch with in-kernel shell signalling
   DevBuf signal; // [0] shell-done counter, [1] wait-kernel timeout flag (as 32-bit words)
   bool shell_wait_used = false; // an overlap-2 stage ran since the flag was last cleared
@@ -1911,6 +1912,7 @@ void artemis_sim::step_general(bool want_dt, bool device_dt) {
       e0 = artemis_rt_event_create(), e1 = artemis_rt_event_create();
       CK(artemis_rt_event_record(e0, stream), "event");
     }
+    general_variant = artemis_hip_stage_general_variant(&p, &a);
     CK(artemis_hip_stage_general(&p, &a, stream), "stage_general");
     if (e0) {
       CK(artemis_rt_event_record(e1, stream), "event");
@@ -2373,6 +2375,12 @@ int artemis_sim_block_level(const artemis_sim_t *s, int block) {
 long artemis_sim_nblocks_global(const artemis_sim_t *s) { return s->nblocks_global; }
 int artemis_sim_uses_fused_path(const artemis_sim_t *s) { return s->use_fused ? 1 : 0; }
 int artemis_sim_uses_tuned_kernel(const artemis_sim_t *s) { return (s->use_fused && s->tuned) ? 1 : 0; }
+const char *artemis_sim_stage_kernel(const artemis_sim_t *s) {
+  if (!s->use_fused) return "per-task chain";
+  if (s->tuned) return "stage_fused_kernel";
+  if (s->general_variant < 0) return "general stage (not run yet)";
+  return s->general_variant == 1 ? "stage2d_kernel" : "stage_cell_kernel";
+}
 int artemis_sim_set_path(artemis_sim_t *s, const char *which) {
   const std::string w = which ? which : "";
   if (w == "fused") {

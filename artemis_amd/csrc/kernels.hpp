@@ -50,6 +50,8 @@ void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t
 void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
                        int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s);
 // kernels_stage2d.hip
+int stage_general_variant(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
+                          int recon_dust, int riemann_dust);
 bool stage2d_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas, int recon_dust,
                     int riemann_dust);
 void launch_stage2d(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas, int riemann_dust,

@@ -332,9 +332,14 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
   x.tx = threadIdx.x, x.ty = threadIdx.y, x.t = x.ty * FTX + x.tx;
   int id = blockIdx.x;
   const bool shell_wg = static_cast<int>(blockIdx.x) < a.nshell;
-  if (a.xcd_swizzle) { // T1: ids round-robin over the 8 XCDs; give each XCD a contiguous run
-    const int per = gridDim.x >> 3;
-    id = (id & 7) * per + (id >> 3);
+  if (a.xcd_swizzle && id >= a.nshell) {
+    // Workgroup ids are dealt round-robin over the 8 XCDs, each with its own L2.  Give every XCD one
+    // contiguous run of the bulk tiles (x1 fastest, then x2, then x3 chunks), so the tiles that share
+    // halo zones and the cache lines a 32-zone row straddles are resident on the same L2.  A bijection
+    // of the bulk ids; shell workgroups keep the lowest ids (the comm stream waits for them).
+    const int r = id - a.nshell, nbulk = static_cast<int>(gridDim.x) - a.nshell;
+    const int q = nbulk >> 3, rem = nbulk & 7, xcd = r & 7;
+    id = a.nshell + xcd * q + min(xcd, rem) + (r >> 3);
   }
   // box lookup with static indices only (a dynamically indexed by-value argument would be
   // spilled to scratch); everything here is wave-uniform scalar work
@@ -636,9 +641,9 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
     add_box(tim0, ntim, tjm0, ntjm, km0, km1);
   }
   if (k.nbox == 0) return 0; // nothing to do in this region
-  // (an XCD-aware id remap measured no gain here -- the kernel is not L2-bound -- and would
-  // break the shell-first id order; kept as an opt-in knob)
-  k.xcd_swizzle = (!k.shell_done && k.start[k.nbox] % 8 == 0 && getenv("ARTEMIS_FUSED_SWIZZLE") != nullptr) ? 1 : 0;
+  // XCD-aware id remap of the bulk workgroups: no effect on the run time (the kernel is VALU-bound) but
+  // it removes the halo / straddled-line re-reads between XCDs from the HBM traffic (profiles/r02*pmc*)
+  k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
   const bool has_u1 = (a.prim_u1 != a.prim_in);
   const bool cons = (a.cons_out != nullptr);
   const bool dt = (a.dt_dev != nullptr);

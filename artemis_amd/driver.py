@@ -211,6 +211,8 @@ def _declare(L):
         f.restype, f.argtypes = l, [vp]
     L.artemis_sim_uses_fused_path.argtypes = [vp]
     L.artemis_sim_uses_tuned_kernel.argtypes = [vp]
+    L.artemis_sim_stage_kernel.argtypes = [vp]
+    L.artemis_sim_stage_kernel.restype = C.c_char_p
     L.artemis_sim_set_path.argtypes = [vp, C.c_char_p]
     L.artemis_sim_set_overlap.argtypes = [vp, i]
     L.artemis_sim_overlap.argtypes = [vp]
@@ -278,6 +280,7 @@ class Simulation:
     total_zones = property(lambda s: s.L.artemis_sim_total_zones(s.h))
     uses_fused_path = property(lambda s: bool(s.L.artemis_sim_uses_fused_path(s.h)))
     uses_tuned_kernel = property(lambda s: bool(s.L.artemis_sim_uses_tuned_kernel(s.h)))
+    stage_kernel = property(lambda s: s.L.artemis_sim_stage_kernel(s.h).decode())
     last_wall_seconds = property(lambda s: s.L.artemis_sim_last_wall_seconds(s.h))
 
     def set_path(self, which):

@@ -100,7 +100,7 @@ def kernel_source_sha1():
     timing when it was measured on these very sources (scripts/pmc_traffic.py writes the same hash)."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("kernels_fused.hip", "device_math.hpp", "pack_view.hpp"):
+    for f in ("kernels_fused.hip", "fused_device.hpp", "device_math.hpp", "pack_view.hpp"):
         h.update(open(os.path.join(ROOT, "artemis_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -115,7 +115,7 @@ def measured_traffic(name):
             rec = json.load(open(path))
         except Exception:
             continue
-        if rec.get("kernel_source_sha1") == want:
+        if rec.get("kernel_source_sha1") == want and not rec.get("env"):  # default knobs only
             return rec.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
     return None, None
 
@@ -349,18 +349,12 @@ def main():
             if fused and nlaunch:
                 alg = bps * local_zones
                 achieved = alg / (kms * 1.0e-3) / 1.0e9
-                traffic = None
-                pmc = os.path.join(ROOT, "profiles", "r01c_cfg3_pmc_traffic.json")
-                if args.n == 4096 and args.dust == 1 and os.path.exists(pmc):  # measured for this size only (round 1)
-                    try:
-                        rec = json.load(open(pmc))
-                        traffic = rec.get("hbm_bytes_per_launch")
-                        out["config"]["traffic_measured_at"] = "round 1 kernels (profiles/r01c_cfg3_pmc_traffic.json)"
-                    except Exception:
-                        traffic = None
+                kname = sim.stage_kernel
                 out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                                   "kernel": "general fused stage: stage_cell_kernel<gas> + <dust> + simple_drag_kernel<finish>",
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,  # no PMC pass of this kernel yet
+                                   "kernel": ("stage2d_kernel: gas + dust fluxes, update, sources, drag, aux, ConsToPrim, dt in one "
+                                              "launch per stage (2-D row march)") if kname == "stage2d_kernel" else
+                                             "general fused stage: stage_cell_kernel<gas> + <dust> + simple_drag_kernel<finish>",
                                    "launch_ms": kms, "launches_timed": nlaunch, "algorithmic_bytes_per_launch": alg}
         elif fused and nlaunch:
             alg = ALG_BYTES_PER_CELL_STAGE * local_zones  # bytes per launch (one stage, one rank)

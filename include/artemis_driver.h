@@ -94,6 +94,9 @@ int artemis_sim_uses_fused_path(const artemis_sim_t *sim);
 /* 1 when the fused path runs the hand-tuned gas kernel (artemis_hip_stage_fused), 0 when it runs
  * the general cell-centred stage (artemis_hip_stage_general) or the per-task chain */
 int artemis_sim_uses_tuned_kernel(const artemis_sim_t *sim);
+/* name of the kernel family the stages run on: "stage_fused_kernel" (tuned 2.5-D), "stage2d_kernel" (2-D row march),
+ * "stage_cell_kernel" (cell-centred general stage) or "per-task chain"; static storage */
+const char *artemis_sim_stage_kernel(const artemis_sim_t *sim);
 /* which: "fused" | "unfused"; selects the kernel path (fused only where supported). */
 int artemis_sim_set_path(artemis_sim_t *sim, const char *which);
 /* Halo exchange on a second stream concurrently with interior compute (fused path, remote

@@ -2,11 +2,10 @@ set -x
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/ -m gpu -q --durations=15 -x > gpurun_out/r02h_suite.log 2>&1; echo "suite rc=$?"
-tail -30 gpurun_out/r02h_suite.log
-for n in 1024 4096; do
-timeout 300 python bench.py --workload ssheet_dust --n $n --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/r02h_cfg3_$n.json; cat gpurun_out/r02h_cfg3_$n.json | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('cfg3 $n', '%.4e'%d['value'], d['roofline']['frac'], d['roofline']['launch_ms'])"
+timeout 600 python -m pytest tests/test_parity_fused.py tests/test_driver_gpu.py -m gpu -x -q -k "fused or sedov or overlap or rccl" 2>&1 | tail -5
+for cfg in "sw16:" "nosw16:ARTEMIS_FUSED_NO_SWIZZLE=1" "sw32:ARTEMIS_FUSED_KCHUNK=32" "sw64:ARTEMIS_FUSED_KCHUNK=64"; do
+  tag=${cfg%%:*}; ev=${cfg#*:}
+  ( [ -n "$ev" ] && export $ev; timeout 300 python bench.py --no-cpu-baseline --no-dropin --steps 200 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('$tag', d['value'], d['roofline']['launch_ms'])"
+    timeout 900 python3 scripts/pmc_traffic.py --tag r02j_$tag )
 done
-timeout 300 python bench.py --workload ssheet_dust --n 4096 --dust 2 --no-cpu-baseline --steps 50 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('cfg3 4096 dust2', '%.4e'%d['value'], d['roofline']['frac'], d['roofline']['launch_ms'])"

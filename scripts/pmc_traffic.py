@@ -85,13 +85,23 @@ def main():
     assert stage, "stage_fused_kernel not in the profile"
     # mean over launches of all instantiations (rk2: one launch of each of the two stage variants per step,
     # plus the variants the dropin leg adds -- weight by launch count)
-    tot = sum(v["launches"] for v in stage.values())
-    per_launch = sum(v["launches"] * (v["read_bytes_corrected"] + v["write_bytes"]) for v in stage.values()) / tot
+    # The bench line's `dropin` legs also launch the WRITE_CONS instantiations (4th template argument true: they
+    # store the conserved state as well); the headline path runs only the two that do not -- one launch of each per
+    # rk2 step -- so `hbm_bytes_per_launch` is the launch-weighted mean over those.
+    def writes_cons(name):
+        targs = name.split("stage_fused_kernel<", 1)[1].split(">", 1)[0].split(",")
+        return targs[3].strip() == "true"
+    for k2, v in stage.items():
+        v["headline_path"] = not writes_cons(k2)
+    head = [v for v in stage.values() if v["headline_path"]] or list(stage.values())
+    tot = sum(v["launches"] for v in head)
+    per_launch = sum(v["launches"] * (v["read_bytes_corrected"] + v["write_bytes"]) for v in head) / tot
     rec = {
         "source": "scripts/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) "
                   "of `python3 bench.py %s`, MI355X" % " ".join(bench_args),
         "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch",
         "kernel_source_sha1": kernel_source_sha1(),
+        "env": {k: v for k, v in os.environ.items() if k.startswith("ARTEMIS_")},
         "calibration": dict(calib, fetch_correction="true_read = FETCH_SIZE / %.4f (mean of the calibration kernels); "
                                                     "WRITE_SIZE as reported (calibrates at %.3f)" % (ratio, wratio)),
         "stage_fused_kernel": stage,

@@ -497,6 +497,7 @@ int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_gene
   }
   return 0;
 }
+int artemis_hip_stage_general_variant(const artemis_pack_t *, const artemis_stage_general_args_t *) { return 0; }
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a_in, void *) {
   artemis_stage_general_args_t args = *a_in;
   if (args.beta_dt_dev) args.beta_dt = args.bdt = *args.beta_dt_dev; // "device" memory is host memory here
