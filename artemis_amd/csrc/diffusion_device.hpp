@@ -34,6 +34,21 @@ struct DiffCell { // geometry of one cell as the update uses it
   double ax1[2], ax2[2], ax3[2], vol, hx[3], dhdx1[3], dhdx2[3];
   int x1dep, x2dep, multi_d, three_d;
 };
+// the same record from a cell's Coords (curvilinear callers that already hold them)
+__device__ __forceinline__ DiffCell diffusion_cell_of(const DCoords &co, const CellMetric &m, const double hx[3], int ndim) {
+  DiffCell d;
+  d.multi_d = (ndim > 1), d.three_d = (ndim > 2);
+  d.ax1[0] = m.ax1[0], d.ax1[1] = m.ax1[1];
+  d.ax2[0] = d.multi_d ? m.ax2[0] : 0.0, d.ax2[1] = d.multi_d ? m.ax2[1] : 0.0;
+  d.ax3[0] = d.three_d ? m.ax3[0] : 0.0, d.ax3[1] = d.three_d ? m.ax3[1] : 0.0;
+  d.vol = m.vol;
+  d.hx[0] = hx[0], d.hx[1] = hx[1], d.hx[2] = hx[2];
+  for (int q = 0; q < 3; ++q) d.dhdx1[q] = 0.0, d.dhdx2[q] = 0.0;
+  d.x1dep = co.x1dep(), d.x2dep = co.x2dep() && d.multi_d;
+  if (d.x1dep) d.dhdx1[1] = co.dh2dx1(), d.dhdx1[2] = co.dh3dx1();
+  if (d.x2dep) d.dhdx2[2] = co.dh3dx2();
+  return d;
+}
 template <bool CURV>
 __device__ __forceinline__ DiffCell diffusion_cell(const PackView &P, int b, int k, int j, int i) {
   DiffCell d;

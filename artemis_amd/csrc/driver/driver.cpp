@@ -826,7 +826,12 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   // curvilinear coordinates every face carries PLM_G / scale-factor geometry and solving each face from
   // both of its cells costs more than the flux arrays save (spherical 3-D blast 1.16e9 vs 1.29e9, disk
   // decks 5.7e8 vs 6.8e8), so those default to the per-task chain.  artemis_sim_set_path overrides.
-  use_fused = fused_possible && coords == ARTEMIS_CARTESIAN;
+  // One exception since round 2: a single gas species without dust / drag / cooling runs the streaming tile
+  // kernel's curvilinear instantiation (artemis_hip_stage_general variant 2: every face solved once, geometry
+  // in registers), which beats the per-task chain (scripts/path_timing.py).
+  const bool curv_tile = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 && !do_drag &&
+                         !do_cooling && getenv("ARTEMIS_NO_FUSED_CURV") == nullptr;
+  use_fused = fused_possible && (coords == ARTEMIS_CARTESIAN || curv_tile);
   if (multilevel) edge_ghosts = false; // the block-graph exchange fills all 3^ndim - 1 directions itself
   if (!use_fused) ensure_unfused();
   problem_generator();
@@ -2379,7 +2384,7 @@ const char *artemis_sim_stage_kernel(const artemis_sim_t *s) {
   if (!s->use_fused) return "per-task chain";
   if (s->tuned) return "stage_fused_kernel";
   if (s->general_variant < 0) return "general stage (not run yet)";
-  return s->general_variant == 1 ? "stage2d_kernel" : "stage_cell_kernel";
+  return s->general_variant == 1 ? "stage2d_kernel" : (s->general_variant == 2 ? "stage_fused_kernel<curvilinear>" : "stage_cell_kernel");
 }
 int artemis_sim_set_path(artemis_sim_t *s, const char *which) {
   const std::string w = which ? which : "";

@@ -50,18 +50,44 @@ __device__ __forceinline__ void plm_geo_finish(PlmGeo &g) {
   g.up = g.xf1 - g.xvc, g.lo = g.xvc - g.xf0;
   g.ra = recip(g.xvc - g.xvm), g.rb = recip(g.xvp - g.xvc), g.rdx = recip(g.dx);
 }
-// PLM_G with the shared geometry: same expression tree as plm_g below
+// PLM_G with the shared geometry: same expression tree as plm_g above.  G = PlmGeo, or any record with the
+// fields dx, cr, cl, up, lo, ra, rb, rdx (the fused kernel keeps a compact copy per thread / in LDS).
+// MODE selects how the five divisions are carried out -- the quotients are the same bits wherever the
+// hand-scheduled division is valid (device_math.hpp):
+//   0  IEEE `/` everywhere (always valid);
+//   1  the three geometric denominators through their shared refined reciprocals, the limited slope's own
+//      quotient with `/` (the per-task and cell-centred kernels);
+//   2  every division hand-scheduled.  ONLY where the caller has checked that no velocity of the stencil is
+//      tiny-but-nonzero: ahead of a shock the differences decay like 1e-40, 1e-80, 1e-160 ..., the cubic
+//      numerator and the squares in the denominator reach the subnormal range while dq2 is still positive,
+//      and 0 / 2e-320 must stay 0 (v_rcp_f64 of a subnormal is not usable).
+template <int MODE = 1, class G>
 __device__ __forceinline__ void plm_g_shared(double q_im1, double q_i, double q_ip1, double &ql_ip1,
-                                             double &qr_i, const PlmGeo &g) {
-  const double dql = div((q_i - q_im1) * g.dx, g.ra);
-  const double dqr = div((q_ip1 - q_i) * g.dx, g.rb);
+                                             double &qr_i, const G &g) {
+  double dql, dqr;
+  if constexpr (MODE == 0) {
+    dql = (q_i - q_im1) * g.dx / g.ra.b, dqr = (q_ip1 - q_i) * g.dx / g.rb.b;
+  } else {
+    dql = div((q_i - q_im1) * g.dx, g.ra), dqr = div((q_ip1 - q_i) * g.dx, g.rb);
+  }
   const double dq2 = dql * dqr;
-  const double dqm =
-      (dq2 <= 0.0) ? 0.0
-                   : dq2 * (g.cr * dql + g.cl * dqr) / (dql * dql + dqr * dqr + dq2 * (g.cl + g.cr - 2.0));
-  ql_ip1 = q_i + div(dqm * g.up, g.rdx);
-  qr_i = q_i - div(dqm * g.lo, g.rdx);
+  const double num = dq2 * (g.cr * dql + g.cl * dqr);
+  const double den = dql * dql + dqr * dqr + dq2 * (g.cl + g.cr - 2.0);
+  double quo;
+  if constexpr (MODE == 2) quo = div(num, den);
+  else quo = num / den;
+  const double dqm = (dq2 <= 0.0) ? 0.0 : quo;
+  if constexpr (MODE == 0) {
+    ql_ip1 = q_i + dqm * g.up / g.rdx.b;
+    qr_i = q_i - dqm * g.lo / g.rdx.b;
+  } else {
+    ql_ip1 = q_i + div(dqm * g.up, g.rdx);
+    qr_i = q_i - div(dqm * g.lo, g.rdx);
+  }
 }
+// a velocity the hand-scheduled PLM_G (MODE 2) cannot take: non-zero and below 2^-200 (differences of
+// admitted values are then 0 or at least 2^-252, their cubes normal)
+__device__ __forceinline__ bool tiny_nonzero(double v) { return v != 0.0 && fabs(v) < 0x1p-200; }
 GDEV PlmGeo plm_geo(const PackView &P, int b, int dir, int k, int j, int i) {
   PlmGeo g;
   const DCoords c = make_coords(P, b, k, j, i);

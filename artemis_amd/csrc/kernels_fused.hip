@@ -26,10 +26,16 @@
 #include <cfloat>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "device_math.hpp"
+#include "diffusion_device.hpp"
 #include "fused_device.hpp"
+#include "geometry.hpp"
 #include "kernels.hpp"
 #include "pack_view.hpp"
+#include "sources_device.hpp"
+#include "task_device.hpp"
 
 namespace artemis {
 namespace {
@@ -88,6 +94,64 @@ struct Ctx { // per-thread constants of the march
   const double *in_r, *in_1, *in_2, *in_3, *in_e;
 };
 
+// ---- curvilinear instantiations (CURV) ----------------------------------------------------------
+// Same tile machinery; what changes is the geometry every step of the reference takes from
+// Coords<GEOM>: the PLM_G weights (plm.hpp:54-73), ScaleMomentumFlux (fluid_fluxes.hpp:33-70), the
+// face areas / volume / widths of the update, the scale factors of PrimToCons / ConsToPrim and
+// FluxSource's coordinate sources -- plus the pointwise tasks the curvilinear decks switch on
+// (ExternalGravity, RotatingFrameImpl from the cell's own mass fluxes, DiffusionUpdate from the stored
+// diffusion fluxes), evaluated with the device functions of the cell-centred general stage: same bits.
+// A thread owns one (i, j) column for the whole march, so whatever depends on (i, j) only is a
+// register constant of the march; the x3 edges (and the x3 trigonometry) are refreshed per plane.
+// These instantiations run ONE workgroup per CU (up to 512 registers per lane, no scratch).
+struct PlmG { // the fields of PlmGeo that plm_g_shared reads (geometry.hpp)
+  double dx, cr, cl, up, lo;
+  Recip ra, rb, rdx;
+};
+ADEV PlmG compact(const PlmGeo &g) {
+  PlmG c;
+  c.dx = g.dx, c.cr = g.cr, c.cl = g.cl, c.up = g.up, c.lo = g.lo, c.ra = g.ra, c.rb = g.rb, c.rdx = g.rdx;
+  return c;
+}
+// PLM_G record of cell kc along x3 for the column whose (i, j) geometry is `co0` (== plm_geo(P, b, 3, kc, j, i))
+ADEV PlmGeo plm_geo_x3(const DCoords &co0, const double *g, int kc) {
+  PlmGeo r;
+  const double f0 = g[4] + (kc - 1) * g[5], f1 = g[4] + kc * g[5];
+  const double f2 = g[4] + (kc + 1) * g[5], f3 = g[4] + (kc + 2) * g[5];
+  r.xvm = 0.5 * (f0 + f1), r.xvc = 0.5 * (f1 + f2), r.xvp = 0.5 * (f2 + f3);
+  r.xf0 = f1, r.xf1 = f2;
+  DCoords c = co0;
+  c.x3[0] = f1, c.x3[1] = f2;
+  r.dx = c.width3();
+  plm_geo_finish(r);
+  return r;
+}
+struct SrcK { // pointwise tasks folded into the curvilinear instantiations
+  int grav_on, rfc_on, diff_on, do_viscosity;
+  double rf_omega;
+  artemis_gravity_t grav;
+};
+template <bool CURV>
+struct SrcArg {};
+template <>
+struct SrcArg<true> {
+  SrcK v;
+};
+struct LdsTileCurv : LdsTile { // + the PLM_G records of the tile perimeter (constant along the march)
+  PlmG GX1[2];      // x1 records of columns i0-1 and i0+32
+  PlmG GX2[2][FTX]; // x2 records of rows j0-1 and j0+8, per column
+  int tiny[2];      // plane (k & 1) holds a tiny-but-nonzero velocity: its slopes take IEEE division
+};
+template <bool CURV>
+struct GeoCtx {};
+template <>
+struct GeoCtx<true> {
+  DCoords co;        // own cell (clamped indices); x3 edges / trigonometry follow the march
+  PlmG g1, g2;       // PLM_G records of the own cell along x1 and x2
+  double h1[3], h2[3], h3[3]; // ScaleMomentumFlux factors at the centroid of the lower x1 / x2 / x3 face
+  const double *m3;  // cos / sin of the x3 cell centres (spherical3D, axisymmetric) or null
+};
+
 ADEV void put6(double (*A)[QY][QX], int r, int c, const Cell6 &q) {
   A[0][r][c] = q.d, A[1][r][c] = q.v1, A[2][r][c] = q.v2;
   A[3][r][c] = q.v3, A[4][r][c] = q.p, A[5][r][c] = q.e;
@@ -121,9 +185,17 @@ ADEV Cell6 finish_cell(const Raw5 &r, double gm1) {
 }
 
 // Stage one plane's primitives (own cell + this thread's halo cell) into S.Q.
-ADEV void stage_plane(LdsTile &S, const Ctx &x, const Cell6 &q, const Raw5 &hal) {
+template <class TILE>
+ADEV void stage_plane(TILE &S, const Ctx &x, const Cell6 &q, const Raw5 &hal) {
   put6(S.Q, x.ty + FH, x.tx + FH, q);
   if (x.hr >= 0) put6(S.Q, x.hr, x.hc, finish_cell(hal, x.gm1));
+}
+// curvilinear tiles also note whether the plane they stage (parity `par`) holds a velocity that PLM_G's
+// hand-scheduled division cannot take (geometry.hpp: tiny_nonzero); the flag was cleared one phase earlier
+ADEV void stage_plane_flag(LdsTileCurv &S, const Ctx &x, const Cell6 &q, const Raw5 &hal, int par) {
+  bool t = tiny_nonzero(q.v1) || tiny_nonzero(q.v2) || tiny_nonzero(q.v3);
+  if (x.hr >= 0) t = t || tiny_nonzero(hal.v1) || tiny_nonzero(hal.v2) || tiny_nonzero(hal.v3);
+  if (__any(t) && (x.t & 63) == 0) S.tiny[par] = 1;
 }
 
 // x1/x2 sweeps of one plane through LDS.  Plane k's primitives are already staged in S.Q (by
@@ -134,10 +206,16 @@ ADEV void stage_plane(LdsTile &S, const Ctx &x, const Cell6 &q, const Raw5 &hal)
 // Returns the fluxes through the own cell's lower x1/x2 faces; the upper ones are left in
 // S.FX / S.FY for plane_update.  The perimeter duties rotate over the waves with k so that no
 // wave (and no SIMD) carries the extra Riemann pass every plane.
-template <int RIEMANN, int RECON, bool D3>
-ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k, const Cell6 &qc,
-                       const bool stage_next, const Cell6 &qn, const Raw5 &hal_next, Flux8 &fx_lo,
-                       Flux8 &fy_lo) {
+template <int RIEMANN, int RECON, bool D3, bool CURV, class TILE>
+ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CURV> &gx, const int k,
+                       const Cell6 &qc, const bool stage_next, const Cell6 &qn, const Raw5 &hal_next,
+                       Flux8 &fx_lo, Flux8 &fy_lo) {
+  constexpr bool PG = CURV && RECON == 1; // PLM_G instead of the uniform-mesh slope
+  bool fastp = true; // PLM_G with every division hand-scheduled (no tiny velocity in this plane's tile)
+  if constexpr (PG) {
+    fastp = (S.tiny[k & 1] == 0);
+    if (x.t == 0) S.tiny[(k + 1) & 1] = 0; // set again when the next plane is staged (after the barrier)
+  }
   const int tx = x.tx, ty = x.ty;
   const bool multi_d = D3 || x.multi_d; // compile-time true in the 3-D instantiation
   const int t = (x.t + 64 * (k % NW)) % NT; // duty index: wave roles rotate with k
@@ -145,20 +223,42 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
   Cell6 lox, loy;
 #define SLX(m, n)                                                                          \
   {                                                                                        \
-    const double s_ =                                                                      \
-        slope<RECON>(S.Q[n][ty + FH][tx + FH - 1], qc.m, S.Q[n][ty + FH][tx + FH + 1]);    \
-    lox.m = lo_val<RECON>(qc.m, s_);                                                       \
-    S.UPX[n][ty][tx + 1] = up_val<RECON>(qc.m, s_);                                        \
+    double up_, lo_;                                                                       \
+    if constexpr (PG) {                                                                    \
+      if (fastp)                                                                           \
+        plm_g_shared<2>(S.Q[n][ty + FH][tx + FH - 1], qc.m, S.Q[n][ty + FH][tx + FH + 1],  \
+                        up_, lo_, gx.g1);                                                  \
+      else                                                                                 \
+        plm_g_shared<0>(S.Q[n][ty + FH][tx + FH - 1], qc.m, S.Q[n][ty + FH][tx + FH + 1],  \
+                        up_, lo_, gx.g1);                                                  \
+    } else {                                                                               \
+      const double s_ =                                                                    \
+          slope<RECON>(S.Q[n][ty + FH][tx + FH - 1], qc.m, S.Q[n][ty + FH][tx + FH + 1]);  \
+      lo_ = lo_val<RECON>(qc.m, s_), up_ = up_val<RECON>(qc.m, s_);                        \
+    }                                                                                      \
+    lox.m = lo_;                                                                           \
+    S.UPX[n][ty][tx + 1] = up_;                                                            \
   }
   SLX(d, 0) SLX(v1, 1) SLX(v2, 2) SLX(v3, 3) SLX(p, 4) SLX(e, 5)
 #undef SLX
   if (multi_d) {
 #define SLY(m, n)                                                                          \
   {                                                                                        \
-    const double s_ =                                                                      \
-        slope<RECON>(S.Q[n][ty + FH - 1][tx + FH], qc.m, S.Q[n][ty + FH + 1][tx + FH]);    \
-    loy.m = lo_val<RECON>(qc.m, s_);                                                       \
-    S.UPY[n][ty + 1][tx] = up_val<RECON>(qc.m, s_);                                        \
+    double up_, lo_;                                                                       \
+    if constexpr (PG) {                                                                    \
+      if (fastp)                                                                           \
+        plm_g_shared<2>(S.Q[n][ty + FH - 1][tx + FH], qc.m, S.Q[n][ty + FH + 1][tx + FH],  \
+                        up_, lo_, gx.g2);                                                  \
+      else                                                                                 \
+        plm_g_shared<0>(S.Q[n][ty + FH - 1][tx + FH], qc.m, S.Q[n][ty + FH + 1][tx + FH],  \
+                        up_, lo_, gx.g2);                                                  \
+    } else {                                                                               \
+      const double s_ =                                                                    \
+          slope<RECON>(S.Q[n][ty + FH - 1][tx + FH], qc.m, S.Q[n][ty + FH + 1][tx + FH]);  \
+      lo_ = lo_val<RECON>(qc.m, s_), up_ = up_val<RECON>(qc.m, s_);                        \
+    }                                                                                      \
+    loy.m = lo_;                                                                           \
+    S.UPY[n][ty + 1][tx] = up_;                                                            \
   }
     SLY(d, 0) SLY(v1, 1) SLY(v2, 2) SLY(v3, 3) SLY(p, 4) SLY(e, 5)
 #undef SLY
@@ -169,9 +269,16 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
 #pragma unroll
     for (int n = 0; n < 6; ++n) {
       const double q = S.Q[n][row + FH][cx];
-      const double s_ = slope<RECON>(S.Q[n][row + FH][cx - 1], q, S.Q[n][row + FH][cx + 1]);
-      if (side) S.LOX[n][row] = lo_val<RECON>(q, s_);
-      else S.UPX[n][row][0] = up_val<RECON>(q, s_);
+      double up_, lo_;
+      if constexpr (PG) {
+        if (fastp) plm_g_shared<2>(S.Q[n][row + FH][cx - 1], q, S.Q[n][row + FH][cx + 1], up_, lo_, S.GX1[side]);
+        else plm_g_shared<0>(S.Q[n][row + FH][cx - 1], q, S.Q[n][row + FH][cx + 1], up_, lo_, S.GX1[side]);
+      } else {
+        const double s_ = slope<RECON>(S.Q[n][row + FH][cx - 1], q, S.Q[n][row + FH][cx + 1]);
+        lo_ = lo_val<RECON>(q, s_), up_ = up_val<RECON>(q, s_);
+      }
+      if (side) S.LOX[n][row] = lo_;
+      else S.UPX[n][row][0] = up_;
     }
   }
   if (multi_d && t >= 192 && t < 256) { // rows j0-1 (upper value) and j0+8 (lower value)
@@ -180,9 +287,16 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
 #pragma unroll
     for (int n = 0; n < 6; ++n) {
       const double q = S.Q[n][ry][cx + FH];
-      const double s_ = slope<RECON>(S.Q[n][ry - 1][cx + FH], q, S.Q[n][ry + 1][cx + FH]);
-      if (side) S.LOY[n][cx] = lo_val<RECON>(q, s_);
-      else S.UPY[n][0][cx] = up_val<RECON>(q, s_);
+      double up_, lo_;
+      if constexpr (PG) {
+        if (fastp) plm_g_shared<2>(S.Q[n][ry - 1][cx + FH], q, S.Q[n][ry + 1][cx + FH], up_, lo_, S.GX2[side][cx]);
+        else plm_g_shared<0>(S.Q[n][ry - 1][cx + FH], q, S.Q[n][ry + 1][cx + FH], up_, lo_, S.GX2[side][cx]);
+      } else {
+        const double s_ = slope<RECON>(S.Q[n][ry - 1][cx + FH], q, S.Q[n][ry + 1][cx + FH]);
+        lo_ = lo_val<RECON>(q, s_), up_ = up_val<RECON>(q, s_);
+      }
+      if (side) S.LOY[n][cx] = lo_;
+      else S.UPY[n][0][cx] = up_;
     }
   }
   __syncthreads();
@@ -190,11 +304,13 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
   Cell6 L;
   GET6(L, S.UPX, [ty][tx]);
   fx_lo = solve_face<RIEMANN, 1>(x.gk, L, lox);
+  if constexpr (CURV) fx_lo.m2 *= gx.h1[1], fx_lo.m3 *= gx.h1[2]; // ScaleMomentumFlux (h1 == 1)
   if (tx > 0) { PUT8(S.FX, fx_lo, [ty][tx - 1]); }
   fy_lo = fx_lo;
   if (multi_d) {
     GET6(L, S.UPY, [ty][tx]);
     fy_lo = solve_face<RIEMANN, 2>(x.gk, L, loy);
+    if constexpr (CURV) fy_lo.m2 *= gx.h2[1], fy_lo.m3 *= gx.h2[2];
     if (ty > 0) { PUT8(S.FY, fy_lo, [ty - 1][tx]); }
   }
   if (t >= 64 && t < 128) { // lanes 0..7: x1 face i0+32 per row; lanes 32..63: x2 face j0+8
@@ -203,25 +319,38 @@ ADEV void plane_sweeps(LdsTile &S, const PackView &P, const Ctx &x, const int k,
       Cell6 l, r;
       GET6(l, S.UPX, [u][FTX]);
       GET6(r, S.LOX, [u]);
-      const Flux8 fe_ = solve_face<RIEMANN, 1>(x.gk, l, r);
+      Flux8 fe_ = solve_face<RIEMANN, 1>(x.gk, l, r);
+      if constexpr (CURV) { // the face below cell (j0+u, i0+32)
+        double hs[3];
+        make_coords(P, x.b, k, min(x.j0 + u, P.nj - 1), min(x.i0 + FTX, P.ni - 1)).face_scale(1, hs);
+        fe_.m2 *= hs[1], fe_.m3 *= hs[2];
+      }
       PUT8(S.FX, fe_, [u][FTX - 1]);
     } else if (multi_d && u >= 32) {
       const int cx = u - 32;
       Cell6 l, r;
       GET6(l, S.UPY, [FTY][cx]);
       GET6(r, S.LOY, [cx]);
-      const Flux8 fe_ = solve_face<RIEMANN, 2>(x.gk, l, r);
+      Flux8 fe_ = solve_face<RIEMANN, 2>(x.gk, l, r);
+      if constexpr (CURV) { // the face below cell (j0+8, i0+cx)
+        double hs[3];
+        make_coords(P, x.b, k, min(x.j0 + FTY, P.nj - 1), min(x.i0 + cx, P.ni - 1)).face_scale(2, hs);
+        fe_.m2 *= hs[1], fe_.m3 *= hs[2];
+      }
       PUT8(S.FY, fe_, [FTY - 1][cx]);
     }
   }
-  if (stage_next) stage_plane(S, x, qn, hal_next);
+  if (stage_next) {
+    stage_plane(S, x, qn, hal_next);
+    if constexpr (PG) stage_plane_flag(S, x, qn, hal_next, (k + 1) & 1);
+  }
   __syncthreads();
 }
 
 // Phase P3: gather the upper-face fluxes published by the neighbours, then the whole per-cell
 // chain update -> sources -> aux -> c2p -> p2c -> store (and the CFL reduction).
-template <bool HAS_U1, bool WRITE_CONS, bool WITH_DT, bool D3>
-ADEV void plane_update(LdsTile &S, const PackView &P, const StageK &a, const Ctx &x, const int k,
+template <bool HAS_U1, bool WRITE_CONS, bool WITH_DT, bool D3, class TILE>
+ADEV void plane_update(TILE &S, const PackView &P, const StageK &a, const Ctx &x, const int k,
                        const Cell6 &qc, const Flux8 &fx_lo, const Flux8 &fy_lo, const Flux8 &fz_lo,
                        const Flux8 &fz_hi, const Raw5 &u1raw, double &ldt) {
   const int tx = x.tx, ty = x.ty;
@@ -325,9 +454,129 @@ ADEV void plane_update(LdsTile &S, const PackView &P, const StageK &a, const Ctx
   }
 }
 
-template <int RIEMANN, int RECON, bool HAS_U1, bool WRITE_CONS, bool WITH_DT, bool D3>
-__global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, const StageK a) {
-  __shared__ LdsTile S;
+// Phase P3 of the curvilinear instantiations: the per-cell chain of the cell-centred general stage
+// (kernels_stage_cell.hip, same device functions, same order) fed with the tile's face fluxes:
+// ApplyUpdate -> FluxSource (pressure + coordinate sources) -> DiffusionUpdate -> ExternalGravity ->
+// RotatingFrameImpl -> SetAuxillaryFields -> ConsToPrim (-> EstimateTimestepMesh of the new state).
+template <bool HAS_U1, bool WITH_DT, bool D3, class TILE>
+ADEV void plane_update_curv(TILE &S, const PackView &P, const StageK &a, const SrcK &sk, const Ctx &x,
+                            const GeoCtx<true> &gx, const int k, const Cell6 &qc, const Flux8 &fx_lo,
+                            const Flux8 &fy_lo_in, const Flux8 &fz_lo_in, const Flux8 &fz_hi_in,
+                            const Raw5 &u1raw, double &ldt) {
+  const int tx = x.tx, ty = x.ty;
+  const bool multi_d = D3 || x.multi_d;
+  constexpr bool three_d = D3;
+  Flux8 fx_hi, fy_hi, fy_lo = fy_lo_in, fz_lo = fz_lo_in, fz_hi = fz_hi_in;
+  GET8(fx_hi, S.FX, [ty][tx]);
+  fy_hi = fx_hi;
+  if (multi_d) { GET8(fy_hi, S.FY, [ty][tx]); }
+  if (!x.active) return;
+  const FluidView &f = P.gas;
+  const int b = x.b;
+  const long c = x.col + static_cast<long>(k) * x.sk;
+  DCoords co = gx.co;
+  co.x3[0] = x.g[4] + k * x.g[5], co.x3[1] = x.g[4] + (k + 1) * x.g[5];
+  if (gx.m3) co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k], co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k];
+  const CellMetric g = cell_metric_of(co);
+  double hx[3];
+  scale_factors_of(co, hx);
+  FluidPrim w;
+  w.rho = qc.d, w.v1 = qc.v1, w.v2 = qc.v2, w.v3 = qc.v3, w.sie = qc.e;
+  GasCons u0 = prim_to_cons_gas(f, w.rho, w.v1, w.v2, w.v3, w.sie, hx);
+  GasCons u1 = u0;
+  if constexpr (HAS_U1) u1 = prim_to_cons_gas(f, u1raw.d, u1raw.v1, u1raw.v2, u1raw.v3, u1raw.e, hx);
+  // ---- ApplyUpdate (artemis_integrator.hpp:88-106)
+  const Recip rvol = recip(g.vol);
+  // (momenta can be tiny-but-nonzero ahead of a shock, where only IEEE division is right: `tiny` selects it)
+  auto upd = [&](bool tiny, double v0, double v1, double f1l, double f1h, double f2l, double f2h, double f3l, double f3h) {
+    double divf = (g.ax1[0] * f1l - g.ax1[1] * f1h);
+    if (multi_d) divf += (g.ax2[0] * f2l - g.ax2[1] * f2h);
+    if (three_d) divf += (g.ax3[0] * f3l - g.ax3[1] * f3h);
+    return a.gam0 * v0 + a.gam1 * v1 + (tiny ? divf * x.beta_dt / g.vol : div(divf * x.beta_dt, rvol));
+  };
+  u0.d = upd(false, u0.d, u1.d, fx_lo.d, fx_hi.d, fy_lo.d, fy_hi.d, fz_lo.d, fz_hi.d);
+  u0.m1 = upd(true, u0.m1, u1.m1, fx_lo.m1, fx_hi.m1, fy_lo.m1, fy_hi.m1, fz_lo.m1, fz_hi.m1);
+  u0.m2 = upd(true, u0.m2, u1.m2, fx_lo.m2, fx_hi.m2, fy_lo.m2, fy_hi.m2, fz_lo.m2, fz_hi.m2);
+  u0.m3 = upd(true, u0.m3, u1.m3, fx_lo.m3, fx_hi.m3, fy_lo.m3, fy_hi.m3, fz_lo.m3, fz_hi.m3);
+  u0.e = upd(false, u0.e, u1.e, fx_lo.e, fx_hi.e, fy_lo.e, fy_hi.e, fz_lo.e, fz_hi.e);
+  u0.eg = upd(false, u0.eg, u1.eg, fx_lo.eg, fx_hi.eg, fy_lo.eg, fy_hi.eg, fz_lo.eg, fz_hi.eg);
+  // ---- FluxSource (fluid_fluxes.hpp:361-415); divisions through refined reciprocals (device_math.hpp: the
+  // bits of `/`), the ones of (i, j)-only denominators being constants of the march
+  const double dt = x.bdt;
+  const double dt_vol = div(dt, rvol);
+  u0.m1 += div(dt, g.dx[0]) * (fx_lo.pf - fx_hi.pf);
+  u0.eg -= dt_vol * 0.5 * (fx_lo.pf + fx_hi.pf) * (g.ax1[1] * fx_hi.vf - g.ax1[0] * fx_lo.vf);
+  if (multi_d) {
+    u0.m2 += div(dt, g.dx[1]) * (fy_lo.pf - fy_hi.pf);
+    u0.eg -= dt_vol * 0.5 * (fy_lo.pf + fy_hi.pf) * (g.ax2[1] * fy_hi.vf - g.ax2[0] * fy_lo.vf);
+  }
+  if (three_d) {
+    u0.m3 += div(dt, g.dx[2]) * (fz_lo.pf - fz_hi.pf);
+    u0.eg -= dt_vol * 0.5 * (fz_lo.pf + fz_hi.pf) * (g.ax3[1] * fz_hi.vf - g.ax3[0] * fz_lo.vf);
+  }
+  {
+    const double rdt = w.rho * dt;
+    double vf[3];
+    rotation_velocity(co, P.omf, vf);
+    if (co.x1dep())
+      u0.m1 += rdt * (0.0 * sqr(w.v1 + vf[0]) + co.dh2dx1() * sqr(w.v2 + vf[1]) + co.dh3dx1() * sqr(w.v3 + vf[2]));
+    if (co.x2dep() && multi_d)
+      u0.m2 += rdt * (0.0 * sqr(w.v1 + vf[0]) + 0.0 * sqr(w.v2 + vf[1]) + co.dh3dx2() * sqr(w.v3 + vf[2]));
+  }
+  if (sk.diff_on) { // Gas::DiffusionUpdate (artemis_driver.cpp:218-221)
+    const DiffCell dcell = diffusion_cell_of(co, g, hx, P.ndim);
+    const double v[3] = {w.v1, w.v2, w.v3};
+    double dm[3], de, deg;
+    diffusion_update_cell(P, dcell, b, 0, c, sk.do_viscosity, dt, v, dm, de, deg);
+    u0.m1 -= dm[0], u0.m2 -= dm[1], u0.m3 -= dm[2];
+    u0.e -= de;
+    u0.eg -= deg;
+  }
+  if (sk.grav_on) gravity_gas(gravity_accel(sk.grav, co, P.ndim, dt), dt, hx, w, u0);
+  if (sk.rfc_on) {
+    const RotFrame rfc = rotating_frame_terms(co, sk.rf_omega, dt);
+    const double mlo[3] = {fx_lo.d, multi_d ? fy_lo.d : 0.0, three_d ? fz_lo.d : 0.0};
+    const double mup[3] = {fx_hi.d, multi_d ? fy_hi.d : 0.0, three_d ? fz_hi.d : 0.0};
+    const double ax2[2] = {multi_d ? g.ax2[0] : 0.0, multi_d ? g.ax2[1] : 0.0};
+    const double ax3[2] = {three_d ? g.ax3[0] : 0.0, three_d ? g.ax3[1] : 0.0};
+    rotating_frame_gas(rfc, multi_d, three_d, mlo, mup, g.ax1, ax2, ax3, g.vol, u0);
+  }
+  // ---- SetAuxillaryFields (fill_derived.cpp:58-71) + ConsToPrim (:132-146)
+  const double w_d = (u0.d > f.dfloor) ? u0.d : f.dfloor;
+  const double u_d2 = amax(u0.d, f.dfloor);
+  const Recip rd2 = recip(u_d2);
+  const double rv1 = u0.m1 / 1.0, rv2 = u0.m2 / hx[1], rv3 = u0.m3 / hx[2]; // hx[0] == 1; momenta: IEEE division
+  const double ke = div(0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)), rd2);
+  const double ue_cons = u0.e - ke;
+  double sie = (ue_cons > f.de_switch * u0.e) ? div(ue_cons, rd2) : div(u0.eg, rd2);
+  sie = amax(sie, f.siefloor);
+  double u_u = sie * w_d;
+  const double uflr = f.siefloor * w_d;
+  u_u = (u_u > uflr) ? u_u : uflr;
+  const Recip rwd = recip(w_d);
+  const double n1 = u0.m1 / (w_d * hx[0]), n2 = u0.m2 / (w_d * hx[1]), n3 = u0.m3 / (w_d * hx[2]);
+  double w_s = div(u_u, rwd);
+  w_s = (w_s > f.siefloor) ? w_s : f.siefloor;
+  gst(a.prim_out[b * 6 + 0], c, w_d);
+  gst(a.prim_out[b * 6 + 1], c, n1);
+  gst(a.prim_out[b * 6 + 2], c, n2);
+  gst(a.prim_out[b * 6 + 3], c, n3);
+  gst(a.prim_out[b * 6 + 4], c, amax(0.0, x.gm1 * w_d * w_s)); // fill_derived.cpp:247 (consumers recompute it anyway)
+  gst(a.prim_out[b * 6 + 5], c, w_s);
+  if constexpr (WITH_DT) { // Gas::EstimateTimestepMesh on the new state (gas.cpp:411-433)
+    const double bulk = (x.gm1 + 1.0) * x.gm1 * w_d * w_s;
+    const double cs = sqrt_pos(div(bulk, rwd));
+    double denom = div(fabs(n1) + cs, co.width1());
+    if (multi_d) denom += div(fabs(n2) + cs, co.width2());
+    if (three_d) denom += div(fabs(n3) + cs, co.width3());
+    ldt = amin(ldt, div(1.0, denom));
+  }
+}
+
+template <int RIEMANN, int RECON, bool HAS_U1, bool WRITE_CONS, bool WITH_DT, bool D3, bool CURV = false>
+__global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const PackView P, const StageK a,
+                                                                       const SrcArg<CURV> src) {
+  __shared__ std::conditional_t<CURV, LdsTileCurv, LdsTile> S;
   Ctx x;
   x.tx = threadIdx.x, x.ty = threadIdx.y, x.t = x.ty * FTX + x.tx;
   int id = blockIdx.x;
@@ -404,6 +653,31 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
     x.hcol = static_cast<long>(gj) * x.sj + gi;
   }
   double ldt = DBL_MAX;
+  GeoCtx<CURV> gx;
+  if constexpr (CURV) {
+    // geometry of the own column; table rows are read with indices clamped into the block (lanes beyond
+    // the last face owner compute unused values)
+    const int jg = max(1, min(jl, P.nj - 2));
+    gx.co = make_coords(P, x.b, k0, jl, il);
+    gx.co.face_scale(1, gx.h1), gx.co.face_scale(2, gx.h2), gx.co.face_scale(3, gx.h3);
+    gx.m3 = nullptr;
+    if (P.metric && (P.coords == ARTEMIS_SPHERICAL3D || P.coords == ARTEMIS_AXISYMMETRIC))
+      gx.m3 = P.metric + x.b * metric_block_stride(P.nj, P.nk) + static_cast<long>(MT_ROWS) * (P.nj + 1);
+    if constexpr (RECON == 1) {
+      gx.g1 = compact(plm_geo(P, x.b, 1, k0, jl, il));
+      gx.g2 = gx.g1;
+      if (x.multi_d) gx.g2 = compact(plm_geo(P, x.b, 2, k0, jg, il));
+      // perimeter records (read after the first barrier below)
+      if (x.t < 2) S.GX1[x.t] = compact(plm_geo(P, x.b, 1, k0, jl, x.t ? min(x.i0 + FTX, P.ni - 2) : x.i0 - 1));
+      if (x.multi_d && x.t >= 64 && x.t < 128) {
+        const int u = x.t - 64, side = u >> 5, cx = u & 31;
+        const int jr = max(1, min(side ? x.j0 + FTY : x.j0 - 1, P.nj - 2));
+        S.GX2[side][cx] = compact(plm_geo(P, x.b, 2, k0, jr, min(x.i0 + cx, P.ni - 1)));
+      }
+      if (x.t == 0) S.tiny[0] = S.tiny[1] = 0;
+      __syncthreads(); // the flags are cleared before any wave sets one for the first staged plane
+    }
+  }
 
   const double *u1_r = a.prim_u1[x.b * 6 + 0], *u1_1 = a.prim_u1[x.b * 6 + 1];
   const double *u1_2 = a.prim_u1[x.b * 6 + 2], *u1_3 = a.prim_u1[x.b * 6 + 3];
@@ -418,9 +692,11 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
     Raw5 hal = u1raw;
     if (x.hr >= 0) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + k0 * x.sk);
     stage_plane(S, x, qc, hal);
+    if constexpr (CURV && RECON == 1) stage_plane_flag(S, x, qc, hal, k0 & 1);
     __syncthreads();
-    plane_sweeps<RIEMANN, RECON, false>(S, P, x, k0, qc, false, qc, hal, fx_lo, fy_lo);
-    plane_update<HAS_U1, WRITE_CONS, WITH_DT, false>(S, P, a, x, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
+    plane_sweeps<RIEMANN, RECON, false, CURV>(S, P, x, gx, k0, qc, false, qc, hal, fx_lo, fy_lo);
+    if constexpr (CURV) plane_update_curv<HAS_U1, WITH_DT, false>(S, P, a, src.v, x, gx, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
+    else plane_update<HAS_U1, WRITE_CONS, WITH_DT, false>(S, P, a, x, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
   } else {
     // x3 state carried in registers: planes k, k+1, the upper face value of cell k and the
     // flux through face k.
@@ -430,9 +706,17 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
     {
       const Cell6 qmm =
           load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k0 - 2) * x.sk, x.gm1);
-#define ZL0(m) zl.m = up_val<RECON>(qc.m, slope<RECON>(qmm.m, qc.m, qn.m));
-      FOR6(ZL0)
+      if constexpr (CURV && RECON == 1) {
+        const PlmGeo g3 = plm_geo_x3(gx.co, x.g, k0 - 1);
+        double unused_;
+#define ZL0(m) plm_g_shared<0>(qmm.m, qc.m, qn.m, zl.m, unused_, g3);
+        FOR6(ZL0)
 #undef ZL0
+      } else {
+#define ZL0(m) zl.m = up_val<RECON>(qc.m, slope<RECON>(qmm.m, qc.m, qn.m));
+        FOR6(ZL0)
+#undef ZL0
+      }
     }
     Flux8 fz_lo;
     fz_lo.d = fz_lo.m1 = fz_lo.m2 = fz_lo.m3 = fz_lo.e = fz_lo.eg = fz_lo.pf = fz_lo.vf = 0.0;
@@ -449,25 +733,46 @@ __global__ __launch_bounds__(NT, 2) void stage_fused_kernel(const PackView P, co
       if (x.hr >= 0 && k < k1) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + (k + 1) * x.sk);
       Flux8 fx_lo, fy_lo;
       if (k >= k0) {
-        plane_sweeps<RIEMANN, RECON, true>(S, P, x, k, qc, k < k1, qn, hal, fx_lo, fy_lo);
+        plane_sweeps<RIEMANN, RECON, true, CURV>(S, P, x, gx, k, qc, k < k1, qn, hal, fx_lo, fy_lo);
       } else { // priming trip: stage the first plane
         stage_plane(S, x, qn, hal);
+        if constexpr (CURV && RECON == 1) stage_plane_flag(S, x, qn, hal, k0 & 1);
         __syncthreads();
       }
       // x3 sweep, registers only: slope of cell k+1, face k+1
       const Cell6 qnn = finish_cell(rnn, x.gm1);
       Cell6 zr, zl_next;
+      if constexpr (CURV && RECON == 1) {
+        const PlmGeo g3 = plm_geo_x3(gx.co, x.g, k + 1);
+        // the own column's three cells decide for the wave whether the hand-scheduled divisions are safe
+        const bool tiny3 = tiny_nonzero(qc.v1) || tiny_nonzero(qc.v2) || tiny_nonzero(qc.v3) || tiny_nonzero(qn.v1) ||
+                           tiny_nonzero(qn.v2) || tiny_nonzero(qn.v3) || tiny_nonzero(qnn.v1) || tiny_nonzero(qnn.v2) ||
+                           tiny_nonzero(qnn.v3);
+        if (!__any(tiny3)) {
+#define ZSL(m) plm_g_shared<2>(qc.m, qn.m, qnn.m, zl_next.m, zr.m, g3);
+          FOR6(ZSL)
+#undef ZSL
+        } else {
+#define ZSL(m) plm_g_shared<0>(qc.m, qn.m, qnn.m, zl_next.m, zr.m, g3);
+          FOR6(ZSL)
+#undef ZSL
+        }
+      } else {
 #define ZSL(m)                                                                             \
   {                                                                                        \
     const double s_ = slope<RECON>(qc.m, qn.m, qnn.m);                                     \
     zr.m = lo_val<RECON>(qn.m, s_);                                                        \
     zl_next.m = up_val<RECON>(qn.m, s_);                                                   \
   }
-      FOR6(ZSL)
+        FOR6(ZSL)
 #undef ZSL
-      const Flux8 fz_hi = solve_face<RIEMANN, 3>(x.gk, zl, zr);
-      if (k >= k0)
-        plane_update<HAS_U1, WRITE_CONS, WITH_DT, true>(S, P, a, x, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt);
+      }
+      Flux8 fz_hi = solve_face<RIEMANN, 3>(x.gk, zl, zr);
+      if constexpr (CURV) fz_hi.m2 *= gx.h3[1], fz_hi.m3 *= gx.h3[2]; // ScaleMomentumFlux at the x3 face
+      if (k >= k0) {
+        if constexpr (CURV) plane_update_curv<HAS_U1, WITH_DT, true>(S, P, a, src.v, x, gx, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt);
+        else plane_update<HAS_U1, WRITE_CONS, WITH_DT, true>(S, P, a, x, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt);
+      }
       fz_lo = fz_hi, zl = zl_next, qc = qn, qn = qnn;
     }
   }
@@ -523,8 +828,8 @@ int launch_cfg(const PackView &P, const StageK &k, bool has_u1, bool cons, bool 
   const dim3 block(FTX, FTY);
 #define GO(U, C, D)                                                                        \
   do {                                                                                     \
-    if (P.ndim > 2) hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, U, C, D, true>), grid, block, 0, s, P, k); \
-    else hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, U, C, D, false>), grid, block, 0, s, P, k); \
+    if (P.ndim > 2) hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, U, C, D, true>), grid, block, 0, s, P, k, SrcArg<false>{}); \
+    else hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, U, C, D, false>), grid, block, 0, s, P, k, SrcArg<false>{}); \
   } while (0)
   if (has_u1) {
     if (cons) { if (dt) GO(true, true, true); else GO(true, true, false); }
@@ -658,6 +963,76 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   }
 #undef RC
   return 4;
+}
+
+// ---- curvilinear decks through artemis_hip_stage_general -----------------------------------------
+// Gas (one species) on any non-Cartesian system, PCM / PLM, with the pointwise tasks plane_update_curv folds
+// in; everything else stays on the cell-centred kernels.
+bool fused_curv_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas) {
+  if (P.coords == ARTEMIS_CARTESIAN || P.gas.ns != 1 || P.dust.ns != 0 || P.ng < 2) return false;
+  if (!g.pcm && recon_gas == ARTEMIS_PPM) return false;
+  if (g.drag || g.cooling) return false;
+  if (g.gravity && g.gravity->type != ARTEMIS_GRAVITY_UNIFORM && g.gravity->type != ARTEMIS_GRAVITY_POINT &&
+      g.gravity->type != ARTEMIS_GRAVITY_BINARY)
+    return false;
+  return true;
+}
+
+namespace {
+template <int RIEMANN, int RECON>
+void launch_curv(const PackView &P, const StageK &k, const SrcArg<true> &src, bool has_u1, bool dt, hipStream_t s) {
+  const dim3 grid(k.start[k.nbox]);
+  const dim3 block(FTX, FTY);
+#define GO(U, D)                                                                           \
+  do {                                                                                     \
+    if (P.ndim > 2) hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, U, false, D, true, true>), grid, block, 0, s, P, k, src); \
+    else hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, U, false, D, false, true>), grid, block, 0, s, P, k, src); \
+  } while (0)
+  if (has_u1) { if (dt) GO(true, true); else GO(true, false); }
+  else { if (dt) GO(false, true); else GO(false, false); }
+#undef GO
+}
+} // namespace
+
+void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
+                             hipStream_t s) {
+  StageK k;
+  k.gam0 = g.gam0, k.gam1 = g.gam1, k.beta_dt = g.beta_dt, k.bdt = g.bdt, k.cfl = g.cfl_gas;
+  k.bdt_ptr = g.beta_dt_dev;
+  k.prim_in = g.gas_in, k.prim_u1 = g.gas_u1, k.prim_out = g.gas_out, k.cons_out = nullptr;
+  k.dt_bits = reinterpret_cast<unsigned long long *>(g.dt_dev);
+  const int nz = P.ke - P.ks + 1;
+  const int NTI = (P.ie - P.is + FTX) / FTX, NTJ = (P.je - P.js + FTY) / FTY;
+  int target_chunk = 16;
+  if (const char *e = getenv("ARTEMIS_FUSED_KCHUNK")) target_chunk = std::max(1, atoi(e));
+  k.nbox = 1, k.start[0] = 0;
+  k.ti0[0] = 0, k.nti[0] = NTI, k.tj0[0] = 0, k.ntj[0] = NTJ, k.kb0[0] = P.ks, k.kb1[0] = P.ke;
+  k.nchunk[0] = (P.ndim > 2) ? std::max(1, nz / target_chunk) : 1;
+  k.kchunk[0] = (nz + k.nchunk[0] - 1) / k.nchunk[0];
+  k.nchunk[0] = (nz + k.kchunk[0] - 1) / k.kchunk[0];
+  k.start[1] = NTI * NTJ * k.nchunk[0] * P.nb;
+  k.nshell = 0, k.shell_done = nullptr;
+  k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
+  SrcArg<true> src;
+  src.v.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;
+  if (src.v.grav_on) src.v.grav = *g.gravity;
+  src.v.rfc_on = (g.rf_omega != 0.0) ? 1 : 0, src.v.rf_omega = g.rf_omega;
+  src.v.diff_on = (g.diffusion != nullptr) ? 1 : 0;
+  src.v.do_viscosity = (g.diffusion && g.diffusion->visc.type != ARTEMIS_DIFF_OFF) ? 1 : 0;
+  const bool has_u1 = (g.gas_u1 != g.gas_in);
+  const bool dt = (g.dt_dev != nullptr);
+  const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;
+#define RC(RS)                                                                             \
+  case RS:                                                                                 \
+    if (recon == ARTEMIS_PCM) launch_curv<RS, 0>(P, k, src, has_u1, dt, s);                \
+    else launch_curv<RS, 1>(P, k, src, has_u1, dt, s);                                     \
+    break;
+  switch (riemann_gas) {
+    RC(0)
+    RC(1)
+    RC(2)
+  }
+#undef RC
 }
 
 } // namespace artemis

@@ -446,15 +446,22 @@ void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t
 
 int stage_general_variant(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
                           int recon_dust, int riemann_dust) {
-  return (getenv("ARTEMIS_NO_STAGE2D") == nullptr && stage2d_covers(P, g, recon_gas, riemann_gas, recon_dust, riemann_dust)) ? 1 : 0;
+  if (getenv("ARTEMIS_NO_STAGE2D") == nullptr && stage2d_covers(P, g, recon_gas, riemann_gas, recon_dust, riemann_dust)) return 1;
+  if (getenv("ARTEMIS_NO_FUSED_CURV") == nullptr && fused_curv_covers(P, g, recon_gas)) return 2;
+  return 0;
 }
 
 void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
                        int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s) {
   // 2-D Cartesian gas (+ <= 2 dust species) with the pointwise sources: the row-march kernel does the whole
   // stage of both fluids, drag, aux, c2p and dt in one pass (kernels_stage2d.hip; same bits)
-  if (stage_general_variant(P, g, recon_gas, riemann_gas, recon_dust, riemann_dust) == 1) {
+  const int variant = stage_general_variant(P, g, recon_gas, riemann_gas, recon_dust, riemann_dust);
+  if (variant == 1) {
     launch_stage2d(P, g, recon_gas, riemann_gas, riemann_dust, s);
+    return;
+  }
+  if (variant == 2) { // curvilinear gas: the streaming tile kernel with the geometry in registers
+    launch_stage_fused_curv(P, g, recon_gas, riemann_gas, s);
     return;
   }
   CellStageArgs a;

@@ -28,16 +28,20 @@ struct CellMetric {
   double ax1[2], ax2[2], ax3[2], vol; // GetFaceAreaX?, Volume
   double dx[3];                       // coordinate widths bnds.x?[1] - bnds.x?[0]
 };
+__device__ __forceinline__ CellMetric cell_metric_of(const DCoords &co) {
+  CellMetric m;
+  m.ax1[0] = co.area1(0), m.ax1[1] = co.area1(1);
+  m.ax2[0] = co.area2(0), m.ax2[1] = co.area2(1);
+  m.ax3[0] = co.area3(0), m.ax3[1] = co.area3(1);
+  m.vol = co.volume();
+  m.dx[0] = co.x1[1] - co.x1[0], m.dx[1] = co.x2[1] - co.x2[0], m.dx[2] = co.x3[1] - co.x3[0];
+  return m;
+}
 template <bool CURV>
 __device__ __forceinline__ CellMetric cell_metric(const PackView &P, int b, int k, int j, int i) {
   CellMetric m;
   if constexpr (CURV) {
-    const DCoords co = make_coords(P, b, k, j, i);
-    m.ax1[0] = co.area1(0), m.ax1[1] = co.area1(1);
-    m.ax2[0] = co.area2(0), m.ax2[1] = co.area2(1);
-    m.ax3[0] = co.area3(0), m.ax3[1] = co.area3(1);
-    m.vol = co.volume();
-    m.dx[0] = co.x1[1] - co.x1[0], m.dx[1] = co.x2[1] - co.x2[0], m.dx[2] = co.x3[1] - co.x3[0];
+    m = cell_metric_of(make_coords(P, b, k, j, i));
   } else {
     const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
     m.ax1[0] = m.ax1[1] = g.dx2 * g.dx3; // geometry.hpp:199-204

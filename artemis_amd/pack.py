@@ -197,6 +197,8 @@ class MeshBlockPack:
             a.diffusion = C.pointer(diffusion)
         if cooling is not None:
             a.cooling = C.pointer(cooling)
+        # which kernel this call takes (0 cell-centred, 1 2-D row march, 2 curvilinear streaming tile)
+        self.last_stage_variant = self.L.artemis_hip_stage_general_variant(C.byref(self.pack), C.byref(a))
         self._call(self.L.artemis_hip_stage_general, C.byref(a))
 
     def stage_epilogue(self, gam0, gam1, beta_dt, bdt, time=0.0, gravity=None, rotating_frame=None,

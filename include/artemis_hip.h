@@ -429,7 +429,8 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
                               void *stream);
 /* Which kernel artemis_hip_stage_general runs for this pack and these arguments (no launch, no device
  * access): 0 = the cell-centred kernels (one per fluid, + the drag finish), 1 = the 2-D row-march kernel
- * (kernels_stage2d.hip: both fluids, drag, aux, ConsToPrim and dt in one launch).  Same results either way;
+ * (kernels_stage2d.hip: both fluids, drag, aux, ConsToPrim and dt in one launch), 2 = the streaming tile kernel
+ * in its curvilinear instantiation (kernels_fused.hip: gas on any non-Cartesian system).  Same results either way;
  * benchmarks name the kernel they timed with this. */
 int artemis_hip_stage_general_variant(const artemis_pack_t *p, const artemis_stage_general_args_t *a);
 /* The cell-local remainder of a stage in ONE pass over stored fluxes: after Gas/Dust::CalculateFluxes

@@ -58,7 +58,17 @@ CASES = [
     ((40, 1, 1), (0.0, 0.0, -0.5), (1.0, np.pi, 0.5), 1, 1, "ppm", "hlle", "hlle", "spherical", 3),
     ((16, 8, 6), (0.5, 0.0, -1.0), (2.0, 6.0, 1.0), 1, 2, "plm", "llf", "hlle", "cylindrical", 2),
     ((24, 12, 1), (0.0, -1.0, -0.5), (2.0, 1.0, 0.5), 1, 1, "plm", "hlle", "hlle", "axisymmetric", 2),
+    # one gas species on a curvilinear mesh: the streaming tile kernel's curvilinear instantiation
+    # (kernels_fused.hip; ragged tiles in x1 and x2, several x3 chunks, every solver, PCM / PLM, 1-D / 2-D / 3-D)
+    ((40, 19, 37), (0.3, 0.7, 0.0), (1.7, 2.5, 6.0), 1, 0, "plm", "hllc", "hlle", "spherical", 2),
+    ((35, 10, 18), (0.5, 0.0, -1.0), (2.0, 6.0, 1.0), 1, 0, "plm", "hlle", "hlle", "cylindrical", 2),
+    ((33, 9, 5), (0.3, 0.7, 0.0), (1.7, 2.5, 6.0), 1, 0, "pcm", "llf", "hlle", "spherical", 2),
+    ((70, 21, 1), (0.4, 0.5, -0.5), (2.5, 2.6, 0.5), 1, 0, "plm", "llf", "hlle", "spherical", 3),
+    ((45, 12, 1), (0.2, -1.0, -0.5), (2.0, 1.0, 0.5), 1, 0, "plm", "hllc", "hlle", "axisymmetric", 2),
+    ((45, 12, 1), (0.5, 0.0, -0.5), (2.0, 6.0, 0.5), 1, 0, "pcm", "hlle", "hlle", "cylindrical", 2),
+    ((77, 1, 1), (0.1, 0.0, -0.5), (1.0, np.pi, 0.5), 1, 0, "plm", "hlle", "hlle", "spherical", 2),
 ]
+CURV_TILE_CASES = range(15, 22)
 
 
 @pytest.mark.parametrize("nx,lo,hi,nsg,nsd,recon,riem,driem,coords,ng", CASES)
@@ -86,6 +96,8 @@ def test_general_stage_hydro(hiplib, nx, lo, hi, nsg, nsd, recon, riem, driem, c
     dt = 1.0e-4
     oracle_stage(o, g0, g1, be, dt, False, 0.0, False, False, False)
     mb.stage_general(g0, g1, be * dt, be * dt, gas=(gin, gu1, gout), dust=(din, du1, dout))
+    if coords != "cartesian" and nsg == 1 and nsd == 0 and recon != "ppm":
+        assert mb.last_stage_variant == 2  # the curvilinear streaming tile kernel really ran
     I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
     if nsg:
         out = mb._extra_prim["o"][0][0][I].cpu().numpy()
@@ -198,6 +210,80 @@ def test_general_stage_with_diffusion_rotating_frame_and_cooling(hiplib, coordin
     keep = [v for v in range(12) if not (8 <= v < 10)]  # P is not written
     assert np.array_equal(gbuf[0][I].cpu().numpy()[keep], o.gprim[I][keep])
     same(dbuf[0][I], o.dprim[I], "dust prim")
+
+
+CURV_SRC_BLOCKS = [
+    ("spherical", (40, 19, 21), (0.9, 1.06, -3.1), (5.6, 2.08, 3.1)),
+    ("spherical", (70, 21, 1), (0.6, 1.06, -0.5), (5.6, 2.08, 0.5)),
+    ("cylindrical", (35, 10, 18), (0.8, -3.1, -1.0), (4.3, 3.1, 1.0)),
+    ("axisymmetric", (45, 12, 1), (0.6, -2.0, -0.5), (4.3, 2.0, 0.5)),
+    ("spherical", (77, 1, 1), (0.6, 0.0, -0.5), (5.6, np.pi, 0.5)),
+]
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", CURV_SRC_BLOCKS)
+@pytest.mark.parametrize("stage2", [False, True])
+def test_curvilinear_tile_kernel_with_sources(hiplib, coordinates, nx, lo, hi, stage2, monkeypatch):
+    """One gas species on a curvilinear block with everything the curvilinear instantiation of the streaming
+    tile kernel folds in: DiffusionUpdate from stored viscous + thermal fluxes, point-mass gravity (off-centre
+    where the system allows), RotatingFrameImpl from the cell's own mass fluxes, the frame velocity in
+    FluxSource's coordinate sources, and the timestep of the new state -- against the oracle's task chain,
+    bit for bit; the cell-centred general stage (ARTEMIS_NO_FUSED_CURV) gives the same bits."""
+    from artemis_amd.pack import MeshBlockPack, diffusion_params, gravity_point
+    kw = dict(ng=2, ns_gas=1, ns_dust=0, reconstruct="plm", riemann="hlle", dust_reconstruct="plm",
+              dust_riemann="hlle", gamma=1.4, dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10,
+              coordinates=coordinates)
+    o = Oracle(nx, lo, hi, bc=("outflow",) * 6, cfl=0.3, dust_cfl=0.3, **kw)
+    random_state(o, np.random.default_rng(91), shock=False, mach=0.5, contrast=10.0)
+    om = 0.8
+    mb = MeshBlockPack(1, nx, [lo], [hi], with_diffusion=True, omega_frame=om, **kw)
+    push([o], mb)
+    o.DeepCopyConservedData()
+    gin = gu1 = mb.gas_prim_table
+    if stage2:
+        o2 = Oracle(nx, lo, hi, bc=("outflow",) * 6, cfl=0.3, dust_cfl=0.3, **kw)
+        random_state(o2, np.random.default_rng(17), shock=False, mach=0.5, contrast=10.0)
+        o.gu1[:] = o2.gu0
+        t, gu1 = mb.new_prim_buffer("u1")
+        t.copy_(torch.from_numpy(o2.gprim[None]).to(t.device))
+    pos = (0.1, 0.05, 0.0) if coordinates == "cylindrical" or nx[2] > 1 else (0.0, 0.0, 0.0)
+    o.set_gravity_point(1.3, soft=0.05, x=pos[0], y=pos[1], z=pos[2])
+    o.set_rotating_frame(om, 0.0)
+    o.set_viscosity("alpha", alpha=2e-2, eta_bulk=0.3, r0=0.9, Omega0=1.2)
+    o.set_conductivity("conductivity", cond=0.03, averaging="harmonic")
+    D = diffusion_params(1.4, viscosity=dict(type="alpha", alpha=2e-2, eta_bulk=0.3, r0=0.9, Omega0=1.2),
+                         conductivity=dict(type="conductivity", cond=0.03, averaging="harmonic"))
+    mb.viscosity_radial_table(D)
+    grav = gravity_point(1.3, soft=0.05, pos=pos)
+    dt, time = 2.0e-4, 0.25
+    g0, g1, be = (0.5, 0.5, 0.5) if stage2 else (0.0, 1.0, 1.0)
+    o.CalculateFluxes(0, False)
+    o.ZeroDiffusionFlux(), o.ViscousFlux(), o.ThermalFlux()
+    o.ApplyUpdate(g0, g1, be * dt)
+    o.FluxSource(be * dt, 0)
+    o.DiffusionUpdate(be * dt)
+    o.ExternalGravity(time, be * dt)
+    o.RotatingFrameForce(be * dt)
+    o.SetAuxillaryFields()
+    o.ConsToPrim()
+    mb.ZeroDiffusionFlux(), mb.ViscousFlux(D), mb.ThermalFlux(D)
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    keep = [0, 1, 2, 3, 5]
+    dts = []
+    for nofuse in (False, True):
+        if nofuse:
+            monkeypatch.setenv("ARTEMIS_NO_FUSED_CURV", "1")
+        gbuf, gout = mb.new_prim_buffer("o%d" % nofuse)
+        dtd = torch.full((1,), 1.7976931348623157e308, dtype=torch.float64, device="cuda")
+        mb.stage_general(g0, g1, be * dt, be * dt, gas=(gin, gu1, gout), time=time, gravity=grav,
+                         rotating_frame=(om, 0.0), cfl=(0.3, 0.3), dt_dev=dtd.data_ptr(), diffusion=D)
+        assert mb.last_stage_variant == (0 if nofuse else 2)
+        assert np.array_equal(gbuf[0][I].cpu().numpy()[keep], o.gprim[I][keep]), nofuse
+        dts.append(dtd.item())
+    # hydro limit of the new state: the tile kernel reduces it itself, the cell-centred path runs
+    # estimate_dt_kernel (checked against the oracle in test_parity_ops); the oracle's number also folds in
+    # the diffusive limits (gas.cpp:435-467), which the driver adds with artemis_hip_diffusion_dt
+    assert dts[0] == dts[1] and dts[0] >= o.EstimateTimestepMesh(0)
 
 
 @pytest.mark.parametrize("coordinates,nx,lo,hi", EXTRA_BLOCKS[:2] + EXTRA_BLOCKS[4:5])
