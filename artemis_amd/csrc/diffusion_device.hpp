@@ -71,26 +71,24 @@ __device__ __forceinline__ DiffCell diffusion_cell(const PackView &P, int b, int
   return d;
 }
 // what the update subtracts from the momenta (dm), total energy (de) and internal energy (deg) of
-// species n in cell c; v = the stage-input primitive velocity of the cell
-__device__ __forceinline__ void diffusion_update_cell(const PackView &P, const DiffCell &g, int b, int n, long c,
-                                                      int do_viscosity, double dt, const double v[3],
-                                                      double dm[3], double &de, double &deg) {
-  const FluidView &f = P.gas;
-  const int ns = f.ns, nq = 4 * ns;
+// species n of a cell; v = the stage-input primitive velocity of the cell.  F(d, var, up) = the diffusion flux
+// `var` (3 n + component, or 3 ns + n for the energy) through the cell's lower (up = 0) or upper (up = 1) face
+// of direction d; for an inactive direction the caller returns a finite stand-in (it is multiplied by 0).
+template <class FX>
+__device__ __forceinline__ void diffusion_update_core(const DiffCell &g, const FX &F, int n, int ns, int do_viscosity,
+                                                      double dt, const double v[3], double dm[3], double &de,
+                                                      double &deg) {
   const int multi_d = g.multi_d, three_d = g.three_d;
-  const long c2 = c + multi_d * P.sj, c3 = c + three_d * P.sk;
-  auto F = [&](int d, int var, long cc) { return f.dflux[d][b * nq + var][cc]; };
-  const int d2 = multi_d ? 1 : 0, d3 = three_d ? 2 : 0; // inactive directions have no flux table
   auto divergence = [&](int var) {
-    return (g.ax1[0] * F(0, var, c) - g.ax1[1] * F(0, var, c + 1)) +
-           multi_d * (g.ax2[0] * F(d2, var, c) - g.ax2[1] * F(d2, var, c2)) +
-           three_d * (g.ax3[0] * F(d3, var, c) - g.ax3[1] * F(d3, var, c3));
+    return (g.ax1[0] * F(0, var, 0) - g.ax1[1] * F(0, var, 1)) +
+           multi_d * (g.ax2[0] * F(1, var, 0) - g.ax2[1] * F(1, var, 1)) +
+           three_d * (g.ax3[0] * F(2, var, 0) - g.ax3[1] * F(2, var, 1));
   };
   const int imx1 = 3 * n + 0, imx2 = 3 * n + 1, imx3 = 3 * n + 2, ien = 3 * ns + n;
   auto metric_src = [&](const double dh[3]) {
-    return dh[0] * 0.5 * (F(0, imx1, c) + F(0, imx1, c + 1)) +
-           multi_d * dh[1] * 0.5 * (F(d2, imx2, c) + F(d2, imx2, c2)) +
-           three_d * dh[2] * 0.5 * (F(d3, imx3, c) + F(d3, imx3, c3));
+    return dh[0] * 0.5 * (F(0, imx1, 0) + F(0, imx1, 1)) +
+           multi_d * dh[1] * 0.5 * (F(1, imx2, 0) + F(1, imx2, 1)) +
+           three_d * dh[2] * 0.5 * (F(2, imx3, 0) + F(2, imx3, 1));
   };
   double divfxm = 0., divfym = 0., divfzm = 0.;
   if (do_viscosity) {
@@ -110,6 +108,17 @@ __device__ __forceinline__ void diffusion_update_cell(const PackView &P, const D
   dm[0] = dt * divfxm, dm[1] = dt * divfym, dm[2] = dt * divfzm;
   de = dt * divfe;
   deg = dt * divfe - dt * (divfxm * v[0] / g.hx[0] + divfym * v[1] / g.hx[1] + divfzm * v[2] / g.hx[2]);
+}
+// ... with the fluxes read from the pack's diffusion-flux arrays at cell c of block b
+__device__ __forceinline__ void diffusion_update_cell(const PackView &P, const DiffCell &g, int b, int n, long c,
+                                                      int do_viscosity, double dt, const double v[3],
+                                                      double dm[3], double &de, double &deg) {
+  const FluidView &f = P.gas;
+  const int ns = f.ns, nq = 4 * ns;
+  const long up[3] = {c + 1, c + g.multi_d * P.sj, c + g.three_d * P.sk};
+  const int dd[3] = {0, g.multi_d ? 1 : 0, g.three_d ? 2 : 0}; // inactive directions have no flux table
+  auto F = [&](int d, int var, int u) { return f.dflux[dd[d]][b * nq + var][u ? up[d] : c]; };
+  diffusion_update_core(g, F, n, ns, do_viscosity, dt, v, dm, de, deg);
 }
 
 } // namespace artemis

@@ -26,12 +26,22 @@ constexpr int TX = 64, TY = 4;
 struct Box {
   int il, iu, jl, ju, kl, ku;
 };
+// Thread shape of the one-thread-per-zone kernels: 64 x 4 by default; for narrow mesh blocks (refined meshes
+// run 16^3 blocks) the x1 extent of the workgroup shrinks to the next power of two >= nx and the rows it
+// frees fold along x2, so that a wave's 64 lanes stay on real zones (a 16-zone row filled a quarter of them).
+inline dim3 tile_threads(int nx) {
+  int tx = TX;
+  while (tx > 8 && tx / 2 >= nx) tx >>= 1;
+  return dim3(tx, TX * TY / tx);
+}
+inline dim3 threads_of(const Box &r) { return tile_threads(r.iu - r.il + 1); }
 inline dim3 grid_of(const Box &r, int nb) {
-  return dim3((r.iu - r.il + TX) / TX, (r.ju - r.jl + TY) / TY, (r.ku - r.kl + 1) * nb);
+  const dim3 t = threads_of(r);
+  return dim3((r.iu - r.il + t.x) / t.x, (r.ju - r.jl + t.y) / t.y, (r.ku - r.kl + 1) * nb);
 }
 #define BOX_CELL(r)                                                                         \
-  const int i = (r).il + blockIdx.x * TX + threadIdx.x;                                    \
-  const int j = (r).jl + blockIdx.y * TY + threadIdx.y;                                    \
+  const int i = (r).il + blockIdx.x * blockDim.x + threadIdx.x;                            \
+  const int j = (r).jl + blockIdx.y * blockDim.y + threadIdx.y;                            \
   const int nkr = (r).ku - (r).kl + 1;                                                     \
   const int b = blockIdx.z / nkr;                                                          \
   const int k = (r).kl + blockIdx.z % nkr;                                                 \
@@ -44,12 +54,19 @@ template <bool CURV>
 struct Geo {
   const PackView &P;
   int b;
+  // optional: the Cartesian images of this block's cell centres (ConvertCoordsToCart, written once per stage by
+  // viscous_cell_kernel), so that a Distance is six cached loads instead of two Coords evaluations
+  const double *xc0 = nullptr, *xc1 = nullptr, *xc2 = nullptr;
   ADEV const double *g() const { return P.geom + 6 * b; }
   ADEV double x1v(int i) const { return 0.5 * ((g()[0] + i * g()[1]) + (g()[0] + (i + 1) * g()[1])); }
   ADEV double x2v(int j) const { return 0.5 * ((g()[2] + j * g()[3]) + (g()[2] + (j + 1) * g()[3])); }
   ADEV double x3v(int k) const { return 0.5 * ((g()[4] + k * g()[5]) + (g()[4] + (k + 1) * g()[5])); }
   ADEV double dist(int k1, int j1, int i1, int k2, int j2, int i2) const {
     if constexpr (CURV) {
+      if (xc0) {
+        const long c1 = (static_cast<long>(k1) * P.nj + j1) * P.ni + i1, c2 = (static_cast<long>(k2) * P.nj + j2) * P.ni + i2;
+        return sqrt(sqr(xc0[c1] - xc0[c2]) + sqr(xc1[c1] - xc1[c2]) + sqr(xc2[c1] - xc2[c2]));
+      }
       double a[3], c[3];
       make_coords(P, b, k1, j1, i1).centre_to_cart(a);
       make_coords(P, b, k2, j2, i2).centre_to_cart(c);
@@ -105,6 +122,7 @@ ADEV double velocity_divergence(const PackView &P, double *const *prim, int b, i
 // [nb * ns][nk * nj * ni] doubles in a library-owned device buffer.
 struct ViscScratch {
   double *sv[3], *divu, *mu;
+  double *xc[3]; // [nb][nk * nj * ni] Cartesian images of the cell centres (curvilinear blocks)
 };
 template <bool CURV>
 __global__ __launch_bounds__(TX *TY) void viscous_cell_kernel(const PackView P, const Box r,
@@ -115,6 +133,11 @@ __global__ __launch_bounds__(TX *TY) void viscous_cell_kernel(const PackView P, 
   const long N = static_cast<long>(P.ni) * P.nj * P.nk;
   double hx[3];
   scale_factors<CURV>(P, b, k, j, i, hx);
+  if constexpr (CURV) { // geometry.hpp:248 of the cell centre, for Coords::Distance in the face kernels
+    double xc[3];
+    make_coords(P, b, k, j, i).centre_to_cart(xc);
+    for (int d = 0; d < 3; ++d) w.xc[d][static_cast<long>(b) * N + c] = xc[d];
+  }
   for (int n = 0; n < ns; ++n) {
     const long q = (static_cast<long>(b) * ns + n) * N + c;
     for (int d = 0; d < 3; ++d) w.sv[d][q] = f.prim[b * nv + ns + 3 * n + d][c] / hx[d];
@@ -132,11 +155,12 @@ __global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, 
   const FluidView &f = P.gas;
   const int ns = f.ns, nq = 4 * ns;
   const int multid = (P.ndim >= 2), threed = (P.ndim == 3);
-  const Geo<CURV> ge{P, b};
+  const long N = static_cast<long>(P.ni) * P.nj * P.nk;
+  Geo<CURV> ge{P, b};
+  if constexpr (CURV) ge.xc0 = w.xc[0] + b * N, ge.xc1 = w.xc[1] + b * N, ge.xc2 = w.xc[2] + b * N;
   const artemis_diffcoeff_t &dp = D.visc;
   constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1);
   const long cm = c - ((DIR == 1) ? 1 : ((DIR == 2) ? P.sj : P.sk));
-  const long N = static_cast<long>(P.ni) * P.nj * P.nk;
   const double fuzz = 1e-99; // Fuzz<Real>()
   double hxf[3] = {1.0, 1.0, 1.0};
   if constexpr (CURV) make_coords(P, b, k, j, i).face_scale(DIR, hxf); // h_d at the face centroid
@@ -327,15 +351,15 @@ inline Box faces(const PackView &P, int dir) {
 
 void launch_zero_diffusion_flux(const PackView &P, hipStream_t s) {
   const Box r{0, P.ni - 1, 0, P.nj - 1, 0, P.nk - 1};
-  hipLaunchKernelGGL(zero_dflux_kernel, grid_of(r, P.nb), dim3(TX, TY), 0, s, P, r);
+  hipLaunchKernelGGL(zero_dflux_kernel, grid_of(r, P.nb), threads_of(r), 0, s, P, r);
 }
 #define LAUNCH_DIR(kern, DIR)                                                                    \
   do {                                                                                           \
     const Box fr = faces(P, DIR);                                                                \
     if (P.coords == ARTEMIS_CARTESIAN)                                                           \
-      hipLaunchKernelGGL((kern<DIR, false>), grid_of(fr, P.nb), dim3(TX, TY), 0, s, P, fr, D);    \
+      hipLaunchKernelGGL((kern<DIR, false>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D);    \
     else                                                                                         \
-      hipLaunchKernelGGL((kern<DIR, true>), grid_of(fr, P.nb), dim3(TX, TY), 0, s, P, fr, D);     \
+      hipLaunchKernelGGL((kern<DIR, true>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D);     \
   } while (0)
 // library-owned scratch of the viscous tasks, grown on demand (one stream per caller thread)
 thread_local struct {
@@ -344,28 +368,30 @@ thread_local struct {
 } g_visc;
 int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s) {
   const size_t N = static_cast<size_t>(P.ni) * P.nj * P.nk, per = static_cast<size_t>(P.nb) * P.gas.ns * N;
-  if (g_visc.n < 5 * per) {
+  const size_t geo = 3 * static_cast<size_t>(P.nb) * N, need = 5 * per + geo;
+  if (g_visc.n < need) {
     if (g_visc.p) (void)hipFree(g_visc.p);
     g_visc.p = nullptr, g_visc.n = 0;
-    if (hipMalloc(reinterpret_cast<void **>(&g_visc.p), 5 * per * sizeof(double)) != hipSuccess) return 1;
-    g_visc.n = 5 * per;
+    if (hipMalloc(reinterpret_cast<void **>(&g_visc.p), need * sizeof(double)) != hipSuccess) return 1;
+    g_visc.n = need;
   }
   ViscScratch w;
   for (int d = 0; d < 3; ++d) w.sv[d] = g_visc.p + d * per;
   w.divu = g_visc.p + 3 * per, w.mu = g_visc.p + 4 * per;
+  for (int d = 0; d < 3; ++d) w.xc[d] = g_visc.p + 5 * per + d * static_cast<size_t>(P.nb) * N;
   // cells the face kernels read: the active region grown by one zone in every active direction
   Box rc = interior(P);
   rc.il -= 1, rc.iu += 1;
   if (P.ndim > 1) rc.jl -= 1, rc.ju += 1;
   if (P.ndim > 2) rc.kl -= 1, rc.ku += 1;
   const bool curv = P.coords != ARTEMIS_CARTESIAN;
-  if (curv) hipLaunchKernelGGL(viscous_cell_kernel<true>, grid_of(rc, P.nb), dim3(TX, TY), 0, s, P, rc, D, w);
-  else hipLaunchKernelGGL(viscous_cell_kernel<false>, grid_of(rc, P.nb), dim3(TX, TY), 0, s, P, rc, D, w);
+  if (curv) hipLaunchKernelGGL(viscous_cell_kernel<true>, grid_of(rc, P.nb), threads_of(rc), 0, s, P, rc, D, w);
+  else hipLaunchKernelGGL(viscous_cell_kernel<false>, grid_of(rc, P.nb), threads_of(rc), 0, s, P, rc, D, w);
 #define LAUNCH_VISC(DIR)                                                                                        \
   do {                                                                                                          \
     const Box fr = faces(P, DIR);                                                                               \
-    if (curv) hipLaunchKernelGGL((viscous_flux_kernel<DIR, true>), grid_of(fr, P.nb), dim3(TX, TY), 0, s, P, fr, D, w); \
-    else hipLaunchKernelGGL((viscous_flux_kernel<DIR, false>), grid_of(fr, P.nb), dim3(TX, TY), 0, s, P, fr, D, w);     \
+    if (curv) hipLaunchKernelGGL((viscous_flux_kernel<DIR, true>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w); \
+    else hipLaunchKernelGGL((viscous_flux_kernel<DIR, false>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);     \
   } while (0)
   LAUNCH_VISC(1);
   if (P.ndim > 1) LAUNCH_VISC(2);
@@ -381,9 +407,9 @@ void launch_diffusion_update(const PackView &P, const artemis_diffusion_t &D, do
   const Box r = interior(P);
   const int visc = D.visc.type != ARTEMIS_DIFF_OFF ? 1 : 0;
   if (P.coords == ARTEMIS_CARTESIAN)
-    hipLaunchKernelGGL(diffusion_update_kernel<false>, grid_of(r, P.nb), dim3(TX, TY), 0, s, P, r, visc, dt);
+    hipLaunchKernelGGL(diffusion_update_kernel<false>, grid_of(r, P.nb), threads_of(r), 0, s, P, r, visc, dt);
   else
-    hipLaunchKernelGGL(diffusion_update_kernel<true>, grid_of(r, P.nb), dim3(TX, TY), 0, s, P, r, visc, dt);
+    hipLaunchKernelGGL(diffusion_update_kernel<true>, grid_of(r, P.nb), threads_of(r), 0, s, P, r, visc, dt);
 }
 void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double cfl, double *dt_dev,
                          hipStream_t s) {

@@ -454,6 +454,25 @@ ADEV void plane_update(TILE &S, const PackView &P, const StageK &a, const Ctx &x
   }
 }
 
+// The cell's diffusion fluxes (one species: 3 momentum components + energy through the lower / upper face of
+// each direction), fetched at the top of a trip so that their latency hides behind the plane's sweeps.
+struct DFlux24 {
+  double lo[3][4], hi[3][4];
+};
+ADEV DFlux24 load_dflux(const PackView &P, int b, long c, bool multi_d, bool three_d) {
+  DFlux24 r;
+  const long up[3] = {c + 1, c + (multi_d ? P.sj : 0), c + (three_d ? P.sk : 0)};
+  const int dd[3] = {0, multi_d ? 1 : 0, three_d ? 2 : 0}; // inactive directions: a finite stand-in (times 0)
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double *q = P.gas.dflux[dd[d]][b * 4 + v];
+      r.lo[d][v] = gld(q, c), r.hi[d][v] = gld(q, up[d]);
+    }
+  return r;
+}
+
 // Phase P3 of the curvilinear instantiations: the per-cell chain of the cell-centred general stage
 // (kernels_stage_cell.hip, same device functions, same order) fed with the tile's face fluxes:
 // ApplyUpdate -> FluxSource (pressure + coordinate sources) -> DiffusionUpdate -> ExternalGravity ->
@@ -462,7 +481,7 @@ template <bool HAS_U1, bool WITH_DT, bool D3, class TILE>
 ADEV void plane_update_curv(TILE &S, const PackView &P, const StageK &a, const SrcK &sk, const Ctx &x,
                             const GeoCtx<true> &gx, const int k, const Cell6 &qc, const Flux8 &fx_lo,
                             const Flux8 &fy_lo_in, const Flux8 &fz_lo_in, const Flux8 &fz_hi_in,
-                            const Raw5 &u1raw, double &ldt) {
+                            const Raw5 &u1raw, const DFlux24 &df, double &ldt) {
   const int tx = x.tx, ty = x.ty;
   const bool multi_d = D3 || x.multi_d;
   constexpr bool three_d = D3;
@@ -527,7 +546,8 @@ ADEV void plane_update_curv(TILE &S, const PackView &P, const StageK &a, const S
     const DiffCell dcell = diffusion_cell_of(co, g, hx, P.ndim);
     const double v[3] = {w.v1, w.v2, w.v3};
     double dm[3], de, deg;
-    diffusion_update_cell(P, dcell, b, 0, c, sk.do_viscosity, dt, v, dm, de, deg);
+    auto F = [&](int d, int var, int u) { return u ? df.hi[d][var] : df.lo[d][var]; };
+    diffusion_update_core(dcell, F, 0, 1, sk.do_viscosity, dt, v, dm, de, deg);
     u0.m1 -= dm[0], u0.m2 -= dm[1], u0.m3 -= dm[2];
     u0.e -= de;
     u0.eg -= deg;
@@ -695,7 +715,11 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
     if constexpr (CURV && RECON == 1) stage_plane_flag(S, x, qc, hal, k0 & 1);
     __syncthreads();
     plane_sweeps<RIEMANN, RECON, false, CURV>(S, P, x, gx, k0, qc, false, qc, hal, fx_lo, fy_lo);
-    if constexpr (CURV) plane_update_curv<HAS_U1, WITH_DT, false>(S, P, a, src.v, x, gx, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
+    if constexpr (CURV) {
+      DFlux24 df{};
+      if (src.v.diff_on) df = load_dflux(P, x.b, x.col + k0 * x.sk, x.multi_d, false);
+      plane_update_curv<HAS_U1, WITH_DT, false>(S, P, a, src.v, x, gx, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, df, ldt);
+    }
     else plane_update<HAS_U1, WRITE_CONS, WITH_DT, false>(S, P, a, x, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
   } else {
     // x3 state carried in registers: planes k, k+1, the upper face value of cell k and the
@@ -731,6 +755,10 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
       // halo cell of plane k+1: staged at the end of this trip's P2, so its latency hides behind
       // the slopes and Riemann problems of plane k
       if (x.hr >= 0 && k < k1) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + (k + 1) * x.sk);
+      DFlux24 df{};
+      if constexpr (CURV) {
+        if (src.v.diff_on && k >= k0) df = load_dflux(P, x.b, x.col + static_cast<long>(k) * x.sk, true, true);
+      }
       Flux8 fx_lo, fy_lo;
       if (k >= k0) {
         plane_sweeps<RIEMANN, RECON, true, CURV>(S, P, x, gx, k, qc, k < k1, qn, hal, fx_lo, fy_lo);
@@ -770,7 +798,7 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
       Flux8 fz_hi = solve_face<RIEMANN, 3>(x.gk, zl, zr);
       if constexpr (CURV) fz_hi.m2 *= gx.h3[1], fz_hi.m3 *= gx.h3[2]; // ScaleMomentumFlux at the x3 face
       if (k >= k0) {
-        if constexpr (CURV) plane_update_curv<HAS_U1, WITH_DT, true>(S, P, a, src.v, x, gx, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt);
+        if constexpr (CURV) plane_update_curv<HAS_U1, WITH_DT, true>(S, P, a, src.v, x, gx, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, df, ldt);
         else plane_update<HAS_U1, WRITE_CONS, WITH_DT, true>(S, P, a, x, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt);
       }
       fz_lo = fz_hi, zl = zl_next, qc = qn, qn = qnn;

@@ -16,16 +16,26 @@ namespace {
 constexpr int TX = 64, TY = 4;
 
 #define INTERIOR_CELL                                                                      \
-  const int i = P.is + blockIdx.x * TX + threadIdx.x;                                      \
-  const int j = P.js + blockIdx.y * TY + threadIdx.y;                                      \
+  const int i = P.is + blockIdx.x * blockDim.x + threadIdx.x;                              \
+  const int j = P.js + blockIdx.y * blockDim.y + threadIdx.y;                              \
   const int nkr = P.ke - P.ks + 1;                                                         \
   const int b = blockIdx.z / nkr;                                                          \
   const int k = P.ks + blockIdx.z % nkr;                                                   \
   if (i > P.ie || j > P.je) return;                                                        \
   const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
 
+// Thread shape of the one-thread-per-zone kernels: 64 x 4 by default; for narrow mesh blocks (refined meshes
+// run 16^3 blocks) the x1 extent of the workgroup shrinks to the next power of two >= nx and the rows it
+// frees fold along x2, so that a wave's 64 lanes stay on real zones (a 16-zone row filled a quarter of them).
+inline dim3 tile_threads(int nx) {
+  int tx = TX;
+  while (tx > 8 && tx / 2 >= nx) tx >>= 1;
+  return dim3(tx, TX * TY / tx);
+}
+inline dim3 interior_threads(const PackView &P) { return tile_threads(P.ie - P.is + 1); }
 inline dim3 interior_grid(const PackView &P) {
-  return dim3((P.ie - P.is + TX) / TX, (P.je - P.js + TY) / TY, (P.ke - P.ks + 1) * P.nb);
+  const dim3 t = interior_threads(P);
+  return dim3((P.ie - P.is + t.x) / t.x, (P.je - P.js + t.y) / t.y, (P.ke - P.ks + 1) * P.nb);
 }
 
 
@@ -538,30 +548,30 @@ void launch_nbody_gravity(const PackView &P, const artemis_nbody_particle_t *pl_
   hipLaunchKernelGGL(nbody_gravity_kernel, dim3(nbody_grid(P)), dim3(256), 0, s, P, N);
 }
 void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, double dt, hipStream_t s) {
-  hipLaunchKernelGGL(gravity_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, G, dt);
+  hipLaunchKernelGGL(gravity_kernel, interior_grid(P), interior_threads(P), 0, s, P, G, dt);
 }
 void launch_shearing_box(const PackView &P, double omega, double qshear, double dt, hipStream_t s) {
-  hipLaunchKernelGGL(shearing_box_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, omega, qshear, dt);
+  hipLaunchKernelGGL(shearing_box_kernel, interior_grid(P), interior_threads(P), 0, s, P, omega, qshear, dt);
 }
 void launch_cooling(const PackView &P, const artemis_cooling_t &C, double dt, hipStream_t s) {
-  hipLaunchKernelGGL(cooling_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, C, dt);
+  hipLaunchKernelGGL(cooling_kernel, interior_grid(P), interior_threads(P), 0, s, P, C, dt);
 }
 void launch_rotating_frame(const PackView &P, double omega, double dt, hipStream_t s) {
-  hipLaunchKernelGGL(rotating_frame_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, omega, dt);
+  hipLaunchKernelGGL(rotating_frame_kernel, interior_grid(P), interior_threads(P), 0, s, P, omega, dt);
 }
 void launch_drag_source(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
                         hipStream_t s) {
   if (D.type == ARTEMIS_DRAG_SELF)
-    hipLaunchKernelGGL(self_drag_kernel, interior_grid(P), dim3(TX, TY), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
+    hipLaunchKernelGGL(self_drag_kernel, interior_grid(P), interior_threads(P), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
   else
-    hipLaunchKernelGGL(simple_drag_kernel<false>, interior_grid(P), dim3(TX, TY), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
+    hipLaunchKernelGGL(simple_drag_kernel<false>, interior_grid(P), interior_threads(P), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
 }
 // simple_dust drag + SetAuxillaryFields + ConsToPrim of a one-gas-species pack in one pass: reads
 // cons0, writes the primitives of P (the general fused stage points them at its out tables)
 bool launch_drag_finish(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
                         hipStream_t s) {
   if (D.type != ARTEMIS_DRAG_SIMPLE_DUST || P.gas.ns != 1) return false;
-  hipLaunchKernelGGL(simple_drag_kernel<true>, interior_grid(P), dim3(TX, TY), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
+  hipLaunchKernelGGL(simple_drag_kernel<true>, interior_grid(P), interior_threads(P), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
   return true;
 }
 

@@ -29,6 +29,18 @@
 namespace artemis {
 namespace {
 constexpr int TX = 64, TY = 4;
+// Thread shape of the one-thread-per-zone kernels: 64 x 4 by default; for narrow mesh blocks (refined meshes
+// run 16^3 blocks) the x1 extent of the workgroup shrinks to the next power of two >= nx and the rows it
+// frees fold along x2, so that a wave's 64 lanes stay on real zones (a 16-zone row filled a quarter of them).
+inline dim3 tile_threads(int nx) {
+  int tx = TX;
+  while (tx > 8 && tx / 2 >= nx) tx >>= 1;
+  return dim3(tx, TX * TY / tx);
+}
+inline dim3 interior_grid(const PackView &P) {
+  const dim3 t = tile_threads(P.ie - P.is + 1);
+  return dim3((P.ie - P.is + t.x) / t.x, (P.je - P.js + t.y) / t.y, (P.ke - P.ks + 1) * P.nb);
+}
 
 struct CellStageArgs {
   double gam0, gam1, beta_dt, bdt;
@@ -145,8 +157,8 @@ ADEV FaceFlux face_of_cell(const PackView &P, const FluidView &f, double *const 
 // written in place (nothing here reads a neighbour's primitives).
 template <int FLUID, int RIEMANN, int RECON, bool CURV, bool EXTRA, bool STORED = false>
 __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, const CellStageArgs a_in) {
-  const int i = P.is + blockIdx.x * TX + threadIdx.x;
-  const int j = P.js + blockIdx.y * TY + threadIdx.y;
+  const int i = P.is + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = P.js + blockIdx.y * blockDim.y + threadIdx.y;
   const int nkr = P.ke - P.ks + 1;
   const int b = blockIdx.z / nkr;
   const int k = P.ks + blockIdx.z % nkr;
@@ -398,14 +410,14 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
 
 template <int FLUID, int RIEMANN, int RECON>
 void launch_geom(const PackView &P, const CellStageArgs &a, hipStream_t s) {
-  const dim3 grid((P.ie - P.is + TX) / TX, (P.je - P.js + TY) / TY, (P.ke - P.ks + 1) * P.nb);
+  const dim3 grid = interior_grid(P);
   const bool extra = a.diff_on || a.rfc_on || a.cool_on;
   if (P.coords == ARTEMIS_CARTESIAN) {
-    if (extra) hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, false, true>), grid, dim3(TX, TY), 0, s, P, a);
-    else hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, false, false>), grid, dim3(TX, TY), 0, s, P, a);
+    if (extra) hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, false, true>), grid, tile_threads(P.ie - P.is + 1), 0, s, P, a);
+    else hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, false, false>), grid, tile_threads(P.ie - P.is + 1), 0, s, P, a);
   } else {
-    if (extra) hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, true, true>), grid, dim3(TX, TY), 0, s, P, a);
-    else hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, true, false>), grid, dim3(TX, TY), 0, s, P, a);
+    if (extra) hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, true, true>), grid, tile_threads(P.ie - P.is + 1), 0, s, P, a);
+    else hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, true, false>), grid, tile_threads(P.ie - P.is + 1), 0, s, P, a);
   }
 }
 template <int FLUID, int RIEMANN>
@@ -431,16 +443,16 @@ void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t
   a.do_viscosity = (g.diffusion && g.diffusion->visc.type != ARTEMIS_DIFF_OFF) ? 1 : 0;
   a.cool_on = (g.cooling != nullptr) && P.gas.ns > 0;
   if (a.cool_on) a.cool = *g.cooling;
-  const dim3 grid((P.ie - P.is + TX) / TX, (P.je - P.js + TY) / TY, (P.ke - P.ks + 1) * P.nb);
+  const dim3 grid = interior_grid(P);
   if (P.gas.ns) {
     a.in = a.u1 = a.out = P.gas.prim;
-    if (cart) hipLaunchKernelGGL((stage_cell_kernel<0, 0, 0, false, true, true>), grid, dim3(TX, TY), 0, s, P, a);
-    else hipLaunchKernelGGL((stage_cell_kernel<0, 0, 0, true, true, true>), grid, dim3(TX, TY), 0, s, P, a);
+    if (cart) hipLaunchKernelGGL((stage_cell_kernel<0, 0, 0, false, true, true>), grid, tile_threads(P.ie - P.is + 1), 0, s, P, a);
+    else hipLaunchKernelGGL((stage_cell_kernel<0, 0, 0, true, true, true>), grid, tile_threads(P.ie - P.is + 1), 0, s, P, a);
   }
   if (P.dust.ns) {
     a.in = a.u1 = a.out = P.dust.prim;
-    if (cart) hipLaunchKernelGGL((stage_cell_kernel<1, 1, 0, false, true, true>), grid, dim3(TX, TY), 0, s, P, a);
-    else hipLaunchKernelGGL((stage_cell_kernel<1, 1, 0, true, true, true>), grid, dim3(TX, TY), 0, s, P, a);
+    if (cart) hipLaunchKernelGGL((stage_cell_kernel<1, 1, 0, false, true, true>), grid, tile_threads(P.ie - P.is + 1), 0, s, P, a);
+    else hipLaunchKernelGGL((stage_cell_kernel<1, 1, 0, true, true, true>), grid, tile_threads(P.ie - P.is + 1), 0, s, P, a);
   }
 }
 

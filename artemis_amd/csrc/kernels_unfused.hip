@@ -21,13 +21,28 @@ constexpr int TX = 64, TY = 4;
 struct Range3 {
   int il, iu, jl, ju, kl, ku;
 };
-inline dim3 grid_for(const Range3 &r, int nb) {
+// Thread shape of the one-thread-per-zone kernels: 64 x 4 by default; for narrow mesh blocks (refined meshes
+// run 16^3 blocks) the x1 extent of the workgroup shrinks to the next power of two >= nx and the rows it
+// frees fold along x2, so that a wave's 64 lanes stay on real zones (a 16-zone row filled a quarter of them).
+inline dim3 tile_threads(int nx) {
+  int tx = TX;
+  while (tx > 8 && tx / 2 >= nx) tx >>= 1;
+  return dim3(tx, TX * TY / tx);
+}
+struct Shape {
+  dim3 grid, block;
+};
+inline Shape shape_for(const Range3 &r, int nb) {
   const int nx = r.iu - r.il + 1, ny = r.ju - r.jl + 1, nz = r.ku - r.kl + 1;
-  return dim3((nx + TX - 1) / TX, (ny + TY - 1) / TY, nz * nb);
+  Shape s;
+  s.block = tile_threads(nx);
+  const int tx = s.block.x, ty = s.block.y;
+  s.grid = dim3((nx + tx - 1) / tx, (ny + ty - 1) / ty, nz * nb);
+  return s;
 }
 #define CELL_FROM_GRID(r)                                                                  \
-  const int i = (r).il + blockIdx.x * TX + threadIdx.x;                                    \
-  const int j = (r).jl + blockIdx.y * TY + threadIdx.y;                                    \
+  const int i = (r).il + blockIdx.x * blockDim.x + threadIdx.x;                            \
+  const int j = (r).jl + blockIdx.y * blockDim.y + threadIdx.y;                            \
   const int nkr = (r).ku - (r).kl + 1;                                                     \
   const int b = blockIdx.z / nkr;                                                          \
   const int k = (r).kl + blockIdx.z % nkr;                                                 \
@@ -126,9 +141,9 @@ void launch_flux_dirs(const PackView &P, hipStream_t s) {
   // faces [s, e+1] of each active direction (fluid_fluxes.hpp:105, :130, :172): the union of the three ranges
   Range3 r{P.is, P.ie + 1, P.js, P.je + (P.ndim > 1 ? 1 : 0), P.ks, P.ke + (P.ndim > 2 ? 1 : 0)};
   if (P.coords == ARTEMIS_CARTESIAN)
-    hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, false>), grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
+    hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, false>), shape_for(r, P.nb).grid, shape_for(r, P.nb).block, 0, s, P, r);
   else
-    hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, true>), grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
+    hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, true>), shape_for(r, P.nb).grid, shape_for(r, P.nb).block, 0, s, P, r);
 }
 template <int FLUID, int RIEMANN>
 void launch_flux_recon(const PackView &P, int recon, hipStream_t s) {
@@ -755,7 +770,20 @@ struct ShellArgs {
   int ng, ndim, nfill;
   long nA, nB, nC;          // cells in the x3-, x2-, x1-ghost regions
 };
-__global__ __launch_bounds__(256) void bc_shell_kernel(const ShellArgs a, const FillTabs t) {
+// Up to BC_BATCH blocks per launch (blockIdx.y): block ids and their six flags travel in the kernel arguments
+// (a refined mesh has hundreds of small blocks on the domain boundary; one launch per block was 30 % of the
+// GPU time of inputs/disk/disk_cart.in, profiles/r02_smr_disk_cart_kernel_stats.csv).
+constexpr int BC_BATCH = 256;
+struct ShellBatch {
+  int blk[BC_BATCH];
+  unsigned char bc[BC_BATCH][6];
+};
+__global__ __launch_bounds__(256) void bc_shell_kernel(ShellArgs a, FillTabs t, const ShellBatch batch) {
+  {
+    const int q = blockIdx.y; // wave-uniform: scalar loads from the kernel-argument segment
+    t.b = batch.blk[q];
+    for (int f = 0; f < 6; ++f) a.bc[f] = batch.bc[q][f];
+  }
   long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
   int idx[3];
   const int g2 = 2 * a.ng;
@@ -864,10 +892,10 @@ static Range3 entire(const PackView &P) { return Range3{0, P.ni - 1, 0, P.nj - 1
 #define LAUNCH_GEOM(kern, r, ...)                                                               \
   do {                                                                                          \
     if (P.coords == ARTEMIS_CARTESIAN)                                                          \
-      hipLaunchKernelGGL((kern<false>), grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r,            \
+      hipLaunchKernelGGL((kern<false>), shape_for(r, P.nb).grid, shape_for(r, P.nb).block, 0, s, P, r,            \
                          ##__VA_ARGS__);                                                        \
     else                                                                                        \
-      hipLaunchKernelGGL((kern<true>), grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r,             \
+      hipLaunchKernelGGL((kern<true>), shape_for(r, P.nb).grid, shape_for(r, P.nb).block, 0, s, P, r,             \
                          ##__VA_ARGS__);                                                        \
   } while (0)
 
@@ -877,7 +905,7 @@ void launch_apply_update(const PackView &P, double gam0, double gam1, double bet
 }
 void launch_flux_source(const PackView &P, int fluid, double dt, hipStream_t s) {
   const Range3 r = interior(P);
-  const dim3 g = grid_for(r, P.nb), t(TX, TY);
+  const dim3 g = shape_for(r, P.nb).grid, t = shape_for(r, P.nb).block;
   const bool curv = P.coords != ARTEMIS_CARTESIAN;
   if (fluid == ARTEMIS_GAS) {
     if (curv) hipLaunchKernelGGL((flux_source_kernel<0, true>), g, t, 0, s, P, r, dt);
@@ -900,12 +928,13 @@ void launch_prim_to_cons(const PackView &P, hipStream_t s) {
 }
 void launch_deep_copy(const PackView &P, hipStream_t s) {
   const Range3 r = entire(P);
-  hipLaunchKernelGGL(deep_copy_kernel, grid_for(r, P.nb), dim3(TX, TY), 0, s, P, r);
+  hipLaunchKernelGGL(deep_copy_kernel, shape_for(r, P.nb).grid, shape_for(r, P.nb).block, 0, s, P, r);
 }
 void launch_estimate_dt(const PackView &P, int fluid, double cfl, double *dt_dev, hipStream_t s) {
   const Range3 r = interior(P);
   auto *bits = reinterpret_cast<unsigned long long *>(dt_dev);
-  const dim3 g3 = grid_for(r, P.nb), t(TX, TY);
+  const dim3 t(TX, TY); // fixed 64 x 4 tiles: grid-stride kernel with a wave reduction
+  const dim3 g3((r.iu - r.il + TX) / TX, (r.ju - r.jl + TY) / TY, (r.ku - r.kl + 1) * P.nb);
   const long ntile = static_cast<long>(g3.x) * g3.y * g3.z;
   const dim3 g(static_cast<unsigned>(ntile < 4096 ? ntile : 4096));
   const bool curv = P.coords != ARTEMIS_CARTESIAN;
@@ -1009,31 +1038,43 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
         hipLaunchKernelGGL(floor_ghost_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fill_tabs(P, b), P);
     }
   } floor_after{P, par, s};
+  ShellArgs a;
+  a.lo[0] = P.is, a.lo[1] = P.js, a.lo[2] = P.ks, a.hi[0] = P.ie, a.hi[1] = P.je, a.hi[2] = P.ke;
+  a.ext[0] = P.ni, a.ext[1] = P.nj, a.ext[2] = P.nk;
+  a.ng = P.ng, a.ndim = P.ndim, a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;
+  const long nz = P.ke - P.ks + 1, ny = P.je - P.js + 1;
+  a.nA = (P.ndim > 2) ? 2L * P.ng * P.nj * P.ni : 0;
+  a.nB = (P.ndim > 1) ? nz * 2L * P.ng * P.ni : 0;
+  a.nC = nz * ny * 2L * P.ng;
+  const long n = a.nA + a.nB + a.nC;
+  ShellBatch batch;
+  int nq = 0;
+  auto flush = [&]() {
+    if (nq == 0) return;
+    for (int f = 0; f < 6; ++f) a.bc[f] = ARTEMIS_BC_NONE; // (the kernel takes the flags from the batch)
+    hipLaunchKernelGGL(bc_shell_kernel, dim3((n + 255) / 256, nq), dim3(256), 0, s, a, fill_tabs(P, 0), batch);
+    nq = 0;
+  };
   for (int b = 0; b < P.nb; ++b) {
-    ShellArgs a;
+    int fl[6];
     bool any = false, user = false;
     for (int f = 0; f < 6; ++f) {
-      a.bc[f] = (f / 2 < P.ndim) ? bc[b * 6 + f] : ARTEMIS_BC_NONE;
-      any = any || (a.bc[f] != ARTEMIS_BC_NONE);
-      user = user || a.bc[f] == ARTEMIS_BC_STRAT_EXTRAP || a.bc[f] == ARTEMIS_BC_STRAT_INFLOW ||
-             a.bc[f] == ARTEMIS_BC_CONDUCTIVE || a.bc[f] == ARTEMIS_BC_IC || a.bc[f] == ARTEMIS_BC_DISK_EXTRAP ||
-             a.bc[f] == ARTEMIS_BC_DISK_VISC;
+      fl[f] = (f / 2 < P.ndim) ? bc[b * 6 + f] : ARTEMIS_BC_NONE;
+      any = any || (fl[f] != ARTEMIS_BC_NONE);
+      user = user || fl[f] == ARTEMIS_BC_STRAT_EXTRAP || fl[f] == ARTEMIS_BC_STRAT_INFLOW ||
+             fl[f] == ARTEMIS_BC_CONDUCTIVE || fl[f] == ARTEMIS_BC_IC || fl[f] == ARTEMIS_BC_DISK_EXTRAP ||
+             fl[f] == ARTEMIS_BC_DISK_VISC;
     }
     if (!any) continue;
     if (user) {
-      launch_bc_sequential(P, b, a.bc, par, s);
+      launch_bc_sequential(P, b, fl, par, s);
       continue;
     }
-    a.lo[0] = P.is, a.lo[1] = P.js, a.lo[2] = P.ks, a.hi[0] = P.ie, a.hi[1] = P.je, a.hi[2] = P.ke;
-    a.ext[0] = P.ni, a.ext[1] = P.nj, a.ext[2] = P.nk;
-    a.ng = P.ng, a.ndim = P.ndim, a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;
-    const long nz = P.ke - P.ks + 1, ny = P.je - P.js + 1;
-    a.nA = (P.ndim > 2) ? 2L * P.ng * P.nj * P.ni : 0;
-    a.nB = (P.ndim > 1) ? nz * 2L * P.ng * P.ni : 0;
-    a.nC = nz * ny * 2L * P.ng;
-    const long n = a.nA + a.nB + a.nC;
-    hipLaunchKernelGGL(bc_shell_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, fill_tabs(P, b));
+    batch.blk[nq] = b;
+    for (int f = 0; f < 6; ++f) batch.bc[nq][f] = static_cast<unsigned char>(fl[f]);
+    if (++nq == BC_BATCH) flush();
   }
+  flush();
   return 0;
 }
 

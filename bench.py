@@ -334,8 +334,10 @@ def main():
             stage_ms = 1.0e3 * elapsed / args.steps / 2.0
             out["roofline"] = {"bound": "hbm", "achieved": alg / (stage_ms * 1.0e-3) / 1.0e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": alg / (stage_ms * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "whole stage: 3 flux kernels + viscous pre-pass + 3 viscous-flux kernels + epilogue + "
-                                         "boundary conditions + PrimToCons",
+                               "kernel": ("whole stage: viscous pre-pass + 3 viscous-flux kernels + %s + boundary conditions"
+                                          % ("stage_fused_kernel<curvilinear> (fluxes, update, sources, DiffusionUpdate, ConsToPrim, dt "
+                                             "in one launch)" if sim.stage_kernel.startswith("stage_fused_kernel") else
+                                             "3 flux kernels + epilogue + PrimToCons (per-task chain)")),
                                "launch_ms": stage_ms, "launches_timed": 2 * args.steps, "algorithmic_bytes_per_launch": alg}
         if args.workload == "ssheet_dust":
             # B_alg per cell-stage = 8 B * 5 * (6 ns_gas + 4 ns_dust); one "launch" = one stage
