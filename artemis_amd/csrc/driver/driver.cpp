@@ -810,8 +810,17 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   if ((do_gas && ng < need(recon_gas)) || (do_dust && ng < need(recon_dust)))
     throw std::runtime_error("reconstruction requires more ghost cells (gas.cpp:61-76)");
 
+  const bool setup_timing = getenv("ARTEMIS_SETUP_TIMING") != nullptr; // host-side phases of the constructor
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto lap = [&](const char *what, std::chrono::steady_clock::time_point t0) {
+    if (setup_timing)
+      std::fprintf(stderr, "[artemis setup] %-20s %8.3f s\n", what, std::chrono::duration<double>(now() - t0).count());
+  };
+  auto t_setup = now();
   build_mesh();
+  lap("build_mesh", t_setup), t_setup = now();
   allocate();
+  lap("allocate", t_setup);
   // one kernel per stage: the hand-tuned gas kernel where it applies, the general cell-centred
   // stage (artemis_hip_stage_general) for everything else the per-task path can do
   tuned = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
@@ -833,8 +842,11 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
                          !do_cooling && getenv("ARTEMIS_NO_FUSED_CURV") == nullptr;
   use_fused = fused_possible && (coords == ARTEMIS_CARTESIAN || curv_tile);
   if (multilevel) edge_ghosts = false; // the block-graph exchange fills all 3^ndim - 1 directions itself
+  t_setup = now();
   if (!use_fused) ensure_unfused();
+  lap("ensure_unfused", t_setup), t_setup = now();
   problem_generator();
+  lap("problem_generator", t_setup);
 }
 
 void artemis_sim::build_mesh() {
