@@ -18,6 +18,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "artemis_driver.h"
@@ -1567,8 +1568,10 @@ void artemis_sim::problem_generator() {
     bp.g_v[2] = pin.GetOrAddReal("problem", "gas_vx3", 0.0);
     bp.g_pres = pin.GetOrAddReal("problem", "gas_pres", 1.0);
   }
-  std::vector<Real> hg(static_cast<size_t>(6) * ns_gas * N), hd(static_cast<size_t>(4) * ns_dust * N);
-  for (int b = 0; b < nb; ++b) {
+  // One block's initial primitives on the host (libm, like the reference's CPU build).  Blocks are independent and
+  // nothing below writes shared state, so a refined mesh (thousands of small blocks, 20 s single-threaded for
+  // inputs/disk/disk_cart.in) is generated by a few host threads; uploads stay on this thread's stream, in order.
+  auto generate_block = [&](const int b, std::vector<Real> &hg, std::vector<Real> &hd) {
     std::fill(hg.begin(), hg.end(), 0.0);
     std::fill(hd.begin(), hd.end(), 0.0);
     for (int k = 0; k < nk; ++k)
@@ -1818,10 +1821,45 @@ void artemis_sim::problem_generator() {
             }
           }
         }
-    if (do_gas) upload_block(gprim[0], b, hg);
-    if (do_dust) upload_block(dprim[0], b, hd);
-    if (ic_gas.ok()) upload_block(ic_gas, b, hg); // as generated, before PrimToCons applies the floors
-    if (ic_dust.ok()) upload_block(ic_dust, b, hd);
+  };
+  {
+    const size_t ng_ = static_cast<size_t>(6) * ns_gas * N, nd_ = static_cast<size_t>(4) * ns_dust * N;
+    int nthreads = 1;
+    if (nb >= 8) {
+      nthreads = static_cast<int>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u));
+      if (const char *e = getenv("ARTEMIS_HOST_THREADS")) nthreads = std::max(1, atoi(e));
+      nthreads = std::min(nthreads, nb);
+    }
+    // batches of `nthreads` blocks: generate concurrently, then upload in block order
+    std::vector<std::vector<Real>> hgs(nthreads, std::vector<Real>(ng_)), hds(nthreads, std::vector<Real>(nd_));
+    for (int b0 = 0; b0 < nb; b0 += nthreads) {
+      const int nbatch = std::min(nthreads, nb - b0);
+      std::vector<std::thread> pool;
+      std::vector<std::exception_ptr> errs(nbatch);
+      for (int t = 1; t < nbatch; ++t)
+        pool.emplace_back([&, t] {
+          try {
+            generate_block(b0 + t, hgs[t], hds[t]);
+          } catch (...) {
+            errs[t] = std::current_exception();
+          }
+        });
+      try {
+        generate_block(b0, hgs[0], hds[0]);
+      } catch (...) {
+        errs[0] = std::current_exception();
+      }
+      for (auto &th : pool) th.join();
+      for (int t = 0; t < nbatch; ++t)
+        if (errs[t]) std::rethrow_exception(errs[t]);
+      for (int t = 0; t < nbatch; ++t) {
+        const int b = b0 + t;
+        if (do_gas) upload_block(gprim[0], b, hgs[t]);
+        if (do_dust) upload_block(dprim[0], b, hds[t]);
+        if (ic_gas.ok()) upload_block(ic_gas, b, hgs[t]); // as generated, before PrimToCons applies the floors
+        if (ic_dust.ok()) upload_block(ic_dust, b, hds[t]);
+      }
+    }
   }
   base = 0;
   if (do_cooling && do_gas) {

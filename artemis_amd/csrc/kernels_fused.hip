@@ -506,19 +506,32 @@ ADEV void plane_update_curv(TILE &S, const PackView &P, const StageK &a, const S
   if constexpr (HAS_U1) u1 = prim_to_cons_gas(f, u1raw.d, u1raw.v1, u1raw.v2, u1raw.v3, u1raw.e, hx);
   // ---- ApplyUpdate (artemis_integrator.hpp:88-106)
   const Recip rvol = recip(g.vol);
-  // (momenta can be tiny-but-nonzero ahead of a shock, where only IEEE division is right: `tiny` selects it)
-  auto upd = [&](bool tiny, double v0, double v1, double f1l, double f1h, double f2l, double f2h, double f3l, double f3h) {
+  // Momenta can be tiny-but-nonzero ahead of a shock, where only IEEE division is right (see plm_g_shared): the
+  // wave checks its three momentum numerators once and takes `/` for them if any lane needs it.
+  auto flux_div = [&](double f1l, double f1h, double f2l, double f2h, double f3l, double f3h) {
     double divf = (g.ax1[0] * f1l - g.ax1[1] * f1h);
     if (multi_d) divf += (g.ax2[0] * f2l - g.ax2[1] * f2h);
     if (three_d) divf += (g.ax3[0] * f3l - g.ax3[1] * f3h);
-    return a.gam0 * v0 + a.gam1 * v1 + (tiny ? divf * x.beta_dt / g.vol : div(divf * x.beta_dt, rvol));
+    return divf * x.beta_dt;
   };
-  u0.d = upd(false, u0.d, u1.d, fx_lo.d, fx_hi.d, fy_lo.d, fy_hi.d, fz_lo.d, fz_hi.d);
-  u0.m1 = upd(true, u0.m1, u1.m1, fx_lo.m1, fx_hi.m1, fy_lo.m1, fy_hi.m1, fz_lo.m1, fz_hi.m1);
-  u0.m2 = upd(true, u0.m2, u1.m2, fx_lo.m2, fx_hi.m2, fy_lo.m2, fy_hi.m2, fz_lo.m2, fz_hi.m2);
-  u0.m3 = upd(true, u0.m3, u1.m3, fx_lo.m3, fx_hi.m3, fy_lo.m3, fy_hi.m3, fz_lo.m3, fz_hi.m3);
-  u0.e = upd(false, u0.e, u1.e, fx_lo.e, fx_hi.e, fy_lo.e, fy_hi.e, fz_lo.e, fz_hi.e);
-  u0.eg = upd(false, u0.eg, u1.eg, fx_lo.eg, fx_hi.eg, fy_lo.eg, fy_hi.eg, fz_lo.eg, fz_hi.eg);
+  const double nd = flux_div(fx_lo.d, fx_hi.d, fy_lo.d, fy_hi.d, fz_lo.d, fz_hi.d);
+  const double n1m = flux_div(fx_lo.m1, fx_hi.m1, fy_lo.m1, fy_hi.m1, fz_lo.m1, fz_hi.m1);
+  const double n2m = flux_div(fx_lo.m2, fx_hi.m2, fy_lo.m2, fy_hi.m2, fz_lo.m2, fz_hi.m2);
+  const double n3m = flux_div(fx_lo.m3, fx_hi.m3, fy_lo.m3, fy_hi.m3, fz_lo.m3, fz_hi.m3);
+  const double ne = flux_div(fx_lo.e, fx_hi.e, fy_lo.e, fy_hi.e, fz_lo.e, fz_hi.e);
+  const double neg = flux_div(fx_lo.eg, fx_hi.eg, fy_lo.eg, fy_hi.eg, fz_lo.eg, fz_hi.eg);
+  double q1m, q2m, q3m;
+  if (__any(tiny_nonzero(n1m) || tiny_nonzero(n2m) || tiny_nonzero(n3m))) {
+    q1m = n1m / g.vol, q2m = n2m / g.vol, q3m = n3m / g.vol;
+  } else {
+    q1m = div(n1m, rvol), q2m = div(n2m, rvol), q3m = div(n3m, rvol);
+  }
+  u0.d = a.gam0 * u0.d + a.gam1 * u1.d + div(nd, rvol);
+  u0.m1 = a.gam0 * u0.m1 + a.gam1 * u1.m1 + q1m;
+  u0.m2 = a.gam0 * u0.m2 + a.gam1 * u1.m2 + q2m;
+  u0.m3 = a.gam0 * u0.m3 + a.gam1 * u1.m3 + q3m;
+  u0.e = a.gam0 * u0.e + a.gam1 * u1.e + div(ne, rvol);
+  u0.eg = a.gam0 * u0.eg + a.gam1 * u1.eg + div(neg, rvol);
   // ---- FluxSource (fluid_fluxes.hpp:361-415); divisions through refined reciprocals (device_math.hpp: the
   // bits of `/`), the ones of (i, j)-only denominators being constants of the march
   const double dt = x.bdt;
@@ -565,7 +578,11 @@ ADEV void plane_update_curv(TILE &S, const PackView &P, const StageK &a, const S
   const double w_d = (u0.d > f.dfloor) ? u0.d : f.dfloor;
   const double u_d2 = amax(u0.d, f.dfloor);
   const Recip rd2 = recip(u_d2);
-  const double rv1 = u0.m1 / 1.0, rv2 = u0.m2 / hx[1], rv3 = u0.m3 / hx[2]; // hx[0] == 1; momenta: IEEE division
+  const bool tiny_m = __any(tiny_nonzero(u0.m1) || tiny_nonzero(u0.m2) || tiny_nonzero(u0.m3)); // momenta: see above
+  double rv2, rv3;
+  if (tiny_m) rv2 = u0.m2 / hx[1], rv3 = u0.m3 / hx[2];
+  else rv2 = div(u0.m2, hx[1]), rv3 = div(u0.m3, hx[2]);
+  const double rv1 = u0.m1 / 1.0; // hx[0] == 1
   const double ke = div(0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)), rd2);
   const double ue_cons = u0.e - ke;
   double sie = (ue_cons > f.de_switch * u0.e) ? div(ue_cons, rd2) : div(u0.eg, rd2);
@@ -574,7 +591,9 @@ ADEV void plane_update_curv(TILE &S, const PackView &P, const StageK &a, const S
   const double uflr = f.siefloor * w_d;
   u_u = (u_u > uflr) ? u_u : uflr;
   const Recip rwd = recip(w_d);
-  const double n1 = u0.m1 / (w_d * hx[0]), n2 = u0.m2 / (w_d * hx[1]), n3 = u0.m3 / (w_d * hx[2]);
+  double n1, n2, n3;
+  if (tiny_m) n1 = u0.m1 / (w_d * hx[0]), n2 = u0.m2 / (w_d * hx[1]), n3 = u0.m3 / (w_d * hx[2]);
+  else n1 = div(u0.m1, rwd), n2 = div(u0.m2, w_d * hx[1]), n3 = div(u0.m3, w_d * hx[2]); // w_d * 1.0 == w_d
   double w_s = div(u_u, rwd);
   w_s = (w_s > f.siefloor) ? w_s : f.siefloor;
   gst(a.prim_out[b * 6 + 0], c, w_d);

@@ -95,26 +95,34 @@ def host_cores():
     return {"logical": logical, "cgroup_quota": quota, "smt": smt, "physical_usable": usable}
 
 
-def kernel_source_sha1():
-    """Identity of the tuned stage kernel's sources: a PMC traffic record is only quoted next to a
-    timing when it was measured on these very sources (scripts/pmc_traffic.py writes the same hash)."""
+def kernel_source_sha1(scope="fused"):
+    """Identity of the kernel sources a PMC traffic record was measured on: it is only quoted next to a timing
+    while they are unchanged (scripts/pmc_traffic.py writes the same hash).  scope "fused": the tuned stage
+    kernel's own sources (the Sedov headline); "all": every device source (whole-stage records of the other
+    workloads, which run several kernels per stage)."""
+    import glob
     import hashlib
     h = hashlib.sha1()
-    for f in ("kernels_fused.hip", "fused_device.hpp", "device_math.hpp", "pack_view.hpp"):
-        h.update(open(os.path.join(ROOT, "artemis_amd", "csrc", f), "rb").read())
+    d = os.path.join(ROOT, "artemis_amd", "csrc")
+    files = (["kernels_fused.hip", "fused_device.hpp", "device_math.hpp", "pack_view.hpp"] if scope == "fused" else
+             sorted(os.path.basename(f) for f in glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp"))))
+    for f in files:
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
 
 
 def measured_traffic(name):
-    """HBM bytes per launch from the newest profiles/*<name>*pmc_traffic.json whose source hash matches
-    the kernel sources of this checkout, else None (a stale record is never reported)."""
+    """HBM bytes per launch (Sedov) / per stage (other workloads) from the newest profiles/r*<name>pmc_traffic.json
+    whose source hash matches this checkout, else None (a stale record is never reported)."""
     import glob
-    want = kernel_source_sha1()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*%spmc_traffic.json" % name)), reverse=True):
         try:
             rec = json.load(open(path))
         except Exception:
             continue
+        if name == "" and rec.get("workload", "sedov3d") != "sedov3d":
+            continue
+        want = kernel_source_sha1(rec.get("sha_scope", "fused"))
         if rec.get("kernel_source_sha1") == want and not rec.get("env"):  # default knobs only
             return rec.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
     return None, None
@@ -332,8 +340,10 @@ def main():
             # whole-stage accounting (several kernels per stage): algorithmic bytes of SURVEY 8(d) over the stage time
             alg = ALG_BYTES_PER_CELL_STAGE * local_zones
             stage_ms = 1.0e3 * elapsed / args.steps / 2.0
+            traffic, traffic_src = (measured_traffic("disk_sph_") if dims == (256, 128, 128) else (None, None))
             out["roofline"] = {"bound": "hbm", "achieved": alg / (stage_ms * 1.0e-3) / 1.0e9, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": alg / (stage_ms * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": alg / (stage_ms * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_source": traffic_src,
                                "kernel": ("whole stage: viscous pre-pass + 3 viscous-flux kernels + %s + boundary conditions"
                                           % ("stage_fused_kernel<curvilinear> (fluxes, update, sources, DiffusionUpdate, ConsToPrim, dt "
                                              "in one launch)" if sim.stage_kernel.startswith("stage_fused_kernel") else
@@ -352,8 +362,9 @@ def main():
                 alg = bps * local_zones
                 achieved = alg / (kms * 1.0e-3) / 1.0e9
                 kname = sim.stage_kernel
+                traffic, traffic_src = (measured_traffic("cfg3_") if (args.n == 4096 and args.dust == 1) else (None, None))
                 out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,  # no PMC pass of this kernel yet
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                    "kernel": ("stage2d_kernel: gas + dust fluxes, update, sources, drag, aux, ConsToPrim, dt in one "
                                               "launch per stage (2-D row march)") if kname == "stage2d_kernel" else
                                              "general fused stage: stage_cell_kernel<gas> + <dust> + simple_drag_kernel<finish>",

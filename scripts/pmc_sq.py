@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""SQ counters of the stage kernels: python3 scripts/pmc_sq.py <tag> -- <program args...>
+Runs `rocprofv3 --pmc <group> --kernel-trace` once per counter group (never with other trace domains) and prints
+per-kernel means for kernels whose name contains 'stage'."""
+import collections, csv, glob, json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GROUPS = [["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU"],
+          ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"],
+          ["SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT"],
+          ["SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_ACTIVE_INST_VMEM"],
+          ["SQ_INST_CYCLES_SALU", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_MISC"]]
+tag = sys.argv[1]
+prog = sys.argv[sys.argv.index("--") + 1:]
+acc = collections.defaultdict(dict)
+for gi, g in enumerate(GROUPS):
+    out = os.path.join(ROOT, "gpurun_out", "sq_%s_%d" % (tag, gi))
+    os.makedirs(out, exist_ok=True)
+    cmd = ["rocprofv3", "--pmc"] + g + ["--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", "python3"] + prog
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        print("group", g, "failed:", r.stdout[-400:])
+        continue
+    tot, cnt = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"]
+            if "stage" not in k:
+                continue
+            tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            if row["Counter_Name"] == g[0]:
+                cnt[k] += 1
+    for k in tot:
+        for c, v in tot[k].items():
+            acc[k][c] = v / max(cnt[k], 1)
+        acc[k]["launches"] = cnt[k]
+res = {k[:150]: v for k, v in acc.items()}
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "sq_%s.json" % tag), "w"), indent=1)
+for k, v in res.items():
+    print(k[:120])
+    print("   ", {c: round(x, 1) for c, x in v.items()})

@@ -52,13 +52,64 @@ def pick(table, *needles):
     return out
 
 
+def whole_stage(args, extra):
+    """disk_sph / ssheet_dust: several kernels per stage, so the record is HBM bytes per STAGE summed over every
+    kernel of the timed run.  FETCH_SIZE is corrected with the ratio calibrated on the Sedov run's known streams
+    (profiles/r*_pmc_traffic.json: 0.620 in every run so far; these workloads launch no kernel with an exactly
+    known byte count)."""
+    from bench import kernel_source_sha1
+    steps = 6
+    n = {"disk_sph": 256, "ssheet_dust": 4096}[args.workload]
+    bench_args = ["--workload", args.workload, "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--n", str(n)] + extra
+    scratch = os.path.join(ROOT, "gpurun_out", "pmc_%s" % args.tag)
+    fetch = run_pass("FETCH_SIZE", scratch + "_fetch", bench_args)
+    write = run_pass("WRITE_SIZE", scratch + "_write", bench_args)
+    ratio, src = 0.6202, "default"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+            rs = [c["fetch_ratio"] for c in rec["calibration"].values() if isinstance(c, dict)]
+            ratio, src = sum(rs) / len(rs), os.path.relpath(path, ROOT)
+            break
+        except Exception:
+            continue
+    kib = 1024.0
+    kernels, total = {}, 0.0
+    for k, (fk, cnt) in fetch.items():
+        wk = write.get(k, (0.0, 0))[0]
+        b = cnt * (fk * kib / ratio + wk * kib)
+        kernels[k[:160]] = {"launches": cnt, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "bytes_total": b}
+        total += b
+    # every launch of the run (initialisation, warm-up and timed cycles alike) is in the profile: normalise by the
+    # launches of the stage kernel, which runs once per stage
+    stage_names = [k for k in fetch if ("stage_fused_kernel" in k or "stage2d_kernel" in k or "stage_cell_kernel" in k)]
+    nstage = sum(fetch[k][1] for k in stage_names)
+    assert nstage, "no stage kernel in the profile"
+    per_stage = total / nstage
+    rec = {
+        "source": "scripts/pmc_traffic.py --workload %s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, "
+                  "--kernel-trace only) of `python3 bench.py %s`, MI355X; bytes of EVERY kernel of the run divided by the "
+                  "number of stage-kernel launches (= stages)" % (args.workload, " ".join(bench_args)),
+        "workload": args.workload, "sha_scope": "all", "kernel_source_sha1": kernel_source_sha1("all"),
+        "env": {k: v for k, v in os.environ.items() if k.startswith("ARTEMIS_")},
+        "fetch_correction": "true_read = FETCH_SIZE / %.4f (calibration of %s)" % (ratio, src),
+        "stages": nstage, "kernels": kernels, "hbm_bytes_per_launch": per_stage,
+    }
+    out = args.out or os.path.join(ROOT, "gpurun_out", "%s_%s_pmc_traffic.json" % (args.tag, {"disk_sph": "disk_sph", "ssheet_dust": "cfg3"}[args.workload]))
+    json.dump(rec, open(out, "w"), indent=1)
+    print(json.dumps({"hbm_bytes_per_stage": per_stage, "stages": nstage, "out": out}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="r02")
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "disk_sph", "ssheet_dust"])
     args, extra = ap.parse_known_args()
     from bench import ALG_BYTES_PER_CELL_STAGE, kernel_source_sha1
+    if args.workload != "sedov3d":
+        return whole_stage(args, extra)
     bench_args = ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--n", str(args.n)] + extra
     scratch = os.path.join(ROOT, "gpurun_out", "pmc_%s" % args.tag)
     fetch = run_pass("FETCH_SIZE", scratch + "_fetch", bench_args)
@@ -100,7 +151,7 @@ def main():
         "source": "scripts/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) "
                   "of `python3 bench.py %s`, MI355X" % " ".join(bench_args),
         "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch",
-        "kernel_source_sha1": kernel_source_sha1(),
+        "workload": "sedov3d", "sha_scope": "fused", "kernel_source_sha1": kernel_source_sha1(),
         "env": {k: v for k, v in os.environ.items() if k.startswith("ARTEMIS_")},
         "calibration": dict(calib, fetch_correction="true_read = FETCH_SIZE / %.4f (mean of the calibration kernels); "
                                                     "WRITE_SIZE as reported (calibrates at %.3f)" % (ratio, wratio)),

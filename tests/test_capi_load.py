@@ -84,7 +84,8 @@ def test_ctypes_mirror_matches_the_c_header(tmp_path):
              ("artemis_diffusion_t", capi.Diffusion, "cv"), ("artemis_stage_args_t", capi.StageArgs, None),
              ("artemis_stage_general_args_t", capi.StageGeneralArgs, "cooling"),
              ("artemis_refine_t", capi.Refine, "fkb"),
-             ("artemis_amr_criterion_t", capi.AmrCriterion, "scratch")]
+             ("artemis_amr_criterion_t", capi.AmrCriterion, "scratch"),
+             ("artemis_nbody_particle_t", capi.NBodyParticle, "couple")]
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "artemis_hip.h"', 'int main(void) {']
     for cname, _, last in pairs:
         src.append(f'  printf("{cname} %zu %zu\\n", sizeof({cname}), '

@@ -150,13 +150,13 @@ SPH3D = dict(deck=["blast", "blast.in"], cycles=5, overrides=[
 
 def test_spherical3d_two_ranks_equal_single_process_bitwise(double_lib, tmp_path):
     """artemis/coordinates = spherical on a 3-D wedge, 2x2x2 blocks with reflecting radial /
-    polar and periodic azimuthal boundaries: the per-task chain (the default in curvilinear
-    coordinates) with the metric tables of each rank's own blocks gives the same bits on 2 ranks as on
-    1 and as the general cell-centred stage; mass is conserved with the spherical cell volumes."""
-    one = run_world(1, SPH3D, tmp_path, "s1")
-    two = run_world(2, SPH3D, tmp_path, "s2")
+    polar and periodic azimuthal boundaries: the per-task chain with the metric tables of each rank's own
+    blocks gives the same bits on 2 ranks as on 1 and as the fused general stage (the default for one gas
+    species on a curvilinear mesh); mass is conserved with the spherical cell volumes."""
+    one = run_world(1, dict(SPH3D, path="unfused"), tmp_path, "s1")
+    two = run_world(2, dict(SPH3D, path="unfused"), tmp_path, "s2")
     assert not one[0]["meta"]["fused"] and one[0]["meta"]["ncycle"] == 5
-    fs = run_world(1, dict(SPH3D, path="fused"), tmp_path, "s1f")
+    fs = run_world(1, SPH3D, tmp_path, "s1f")
     assert fs[0]["meta"]["fused"] and not fs[0]["meta"]["tuned"]
     per_task = by_bounds(fs)
     for r in two:
@@ -325,15 +325,15 @@ def test_disk_deck_driver_equals_oracle_and_ranks_agree(double_lib, tmp_path):
     half = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "problem/polytropic_index=1.40"]
     one = dict(deck=["disk", "disk_axi.in"], cycles=6, overrides=half + ["parthenon/meshblock/nx1=64",
                                                                        "parthenon/meshblock/nx2=32"])
-    r = run_world(1, one, tmp_path, "d1")[0]
+    r = run_world(1, dict(one, path="unfused"), tmp_path, "d1")[0]
     assert not r["meta"]["fused"] and r["meta"]["nblocks"] == 1
     o = disk_oracle("axi", 1.4, "ic", nx=(64, 32, 1))
     o.evolve(62.8, 6)
     assert r["meta"]["time"] == o.time and r["meta"]["dt"] == o.dt
     assert np.array_equal(r["blocks"][0][1], o.interior(o.gprim))
     # the general fused stage (DiffusionUpdate, RotatingFrameImpl from the cell's own mass fluxes) gives
-    # the same bits; curvilinear decks merely default to the per-task chain because it is faster there
-    g = run_world(1, dict(one, path="fused"), tmp_path, "d1f")[0]
+    # the same bits; it is the default for this deck (one gas species on a curvilinear mesh)
+    g = run_world(1, one, tmp_path, "d1f")[0]
     assert g["meta"]["fused"] and np.array_equal(g["blocks"][0][1], r["blocks"][0][1])
     four = dict(one, overrides=half)  # the deck's 32-zone blocks: 2 x 1 ... at half resolution 2 x 1
     four["overrides"] = half + ["parthenon/meshblock/nx2=16"]
