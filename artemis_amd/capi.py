@@ -204,6 +204,7 @@ def load():
         "artemis_hip_amr_magnitude": (i, [C.POINTER(AmrCriterion), C.POINTER(C.c_int), C.POINTER(C.c_double), vp]),
         "artemis_hip_zero_diffusion_flux": (i, [PPk, vp]),
         "artemis_hip_viscous_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
+        "artemis_hip_zero_viscous_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
         "artemis_hip_thermal_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
         "artemis_hip_diffusion_update": (i, [PPk, C.POINTER(Diffusion), d, vp]),
         "artemis_hip_diffusion_dt": (i, [PPk, C.POINTER(Diffusion), d, vp, vp]),
@@ -265,7 +266,7 @@ EXPORTS_HIP = [
     "artemis_hip_stage_general", "artemis_hip_stage_general_variant", "artemis_hip_stage_epilogue", "artemis_hip_restrict_average",
     "artemis_hip_prolongate_minmod", "artemis_hip_amr_first_derivative", "artemis_hip_amr_magnitude",
     "artemis_hip_zero_diffusion_flux",
-    "artemis_hip_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
+    "artemis_hip_viscous_flux", "artemis_hip_zero_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
     "artemis_hip_diffusion_dt", "artemis_hip_diffusion_radial_fill", "artemis_hip_halo_count", "artemis_hip_halo_count_ext",
     "artemis_hip_halo_pack_ext", "artemis_hip_halo_unpack_ext",
     "artemis_hip_halo_pack", "artemis_hip_halo_unpack", "artemis_hip_last_error",

@@ -646,6 +646,13 @@ int artemis_hip_viscous_flux(const artemis_pack_t *p, const artemis_diffusion_t 
     return fail(ARTEMIS_HIP_EDEVICE, "viscous flux: scratch allocation failed");
   return after_launch("ViscousFlux");
 }
+int artemis_hip_zero_viscous_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream) {
+  if (int rc = validate_diffusion(p, d, true)) return rc;
+  if (d->visc.type == ARTEMIS_DIFF_OFF) return artemis_hip_zero_diffusion_flux(p, stream);
+  if (artemis::launch_viscous_flux(artemis::make_pack_view(*p), *d, S(stream), true))
+    return fail(ARTEMIS_HIP_EDEVICE, "viscous flux: scratch allocation failed");
+  return after_launch("ZeroDiffusionFlux + ViscousFlux");
+}
 int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream) {
   if (int rc = validate_diffusion(p, d, true)) return rc;
   if (d->cond.type == ARTEMIS_DIFF_OFF) return 0; // gas.cpp:582-583

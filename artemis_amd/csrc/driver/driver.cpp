@@ -1956,8 +1956,8 @@ void artemis_sim::step_general(bool want_dt, bool device_dt) {
     if (device_dt) a.beta_dt_dev = tstate.p + 3 + (stage - 1); // beta*dt stays on the device
     const bool diffuse = do_gas && (do_viscosity || do_conduction);
     if (diffuse) { // artemis_driver.cpp:189-194 on the stage's input primitives
-      CK(artemis_hip_zero_diffusion_flux(&p, stream), "Gas::ZeroDiffusionFlux");
-      if (do_viscosity) CK(artemis_hip_viscous_flux(&p, &diff, stream), "Gas::ViscousFlux");
+      if (do_viscosity) CK(artemis_hip_zero_viscous_flux(&p, &diff, stream), "Gas::ZeroDiffusionFlux + ViscousFlux");
+      else CK(artemis_hip_zero_diffusion_flux(&p, stream), "Gas::ZeroDiffusionFlux");
       if (do_conduction) CK(artemis_hip_thermal_flux(&p, &diff, stream), "Gas::ThermalFlux");
       a.diffusion = &diff;
     }
@@ -2093,8 +2093,8 @@ void artemis_sim::step_unfused() {
     if (do_gas) CK(artemis_hip_calculate_fluxes(&p, ARTEMIS_GAS, do_pcm, stream), "Gas::CalculateFluxes");
     if (do_dust) CK(artemis_hip_calculate_fluxes(&p, ARTEMIS_DUST, do_pcm, stream), "Dust::CalculateFluxes");
     if (do_viscosity || do_conduction) { // artemis_driver.cpp:189-194
-      CK(artemis_hip_zero_diffusion_flux(&p, stream), "Gas::ZeroDiffusionFlux");
-      if (do_viscosity) CK(artemis_hip_viscous_flux(&p, &diff, stream), "Gas::ViscousFlux");
+      if (do_viscosity) CK(artemis_hip_zero_viscous_flux(&p, &diff, stream), "Gas::ZeroDiffusionFlux + ViscousFlux");
+      else CK(artemis_hip_zero_diffusion_flux(&p, stream), "Gas::ZeroDiffusionFlux");
       if (do_conduction) CK(artemis_hip_thermal_flux(&p, &diff, stream), "Gas::ThermalFlux");
     }
     if (multilevel) flux_correction_multilevel(p); // artemis_driver.cpp:196-202

@@ -41,7 +41,8 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
                              hipStream_t s);
 // kernels_diffusion.hip
 void launch_zero_diffusion_flux(const PackView &P, hipStream_t s);
-int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s);
+// overwrite: ZeroDiffusionFlux folded in (the flux arrays are overwritten on the face ranges)
+int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s, bool overwrite = false);
 void launch_thermal_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s);
 void launch_diffusion_update(const PackView &P, const artemis_diffusion_t &D, double dt, hipStream_t s);
 void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double cfl, double *dt_dev,

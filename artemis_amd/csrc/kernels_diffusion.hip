@@ -11,6 +11,7 @@
 // are kept (multiplications by 1.0 / additions of 0.0 * v) so that NaN/Inf propagate as in the
 // reference's arithmetic.
 #include <cfloat>
+#include <cstdlib>
 
 #include "device_math.hpp"
 #include "geometry.hpp"
@@ -148,10 +149,10 @@ __global__ __launch_bounds__(TX *TY) void viscous_cell_kernel(const PackView P, 
 
 // MomentumFluxImpl (momentum_diffusion.hpp:597-755): StrainTensorFace<XDIR> (:28-377) and
 // StressTensorFaceX? (:379-560) of the lower `dir` face of cell (k,j,i)
-template <int DIR, bool CURV>
-__global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, const Box r,
-                                                              const artemis_diffusion_t D, const ViscScratch w) {
-  BOX_CELL(r)
+// OVERWRITE: store 0.0 + flux instead of adding to the array (ZeroDiffusionFlux folded in: same bits)
+template <int DIR, bool CURV, bool OVERWRITE>
+ADEV void viscous_face(const PackView &P, const artemis_diffusion_t &D, const ViscScratch &w, const int b, const int k,
+                       const int j, const int i, const long c) {
   const FluidView &f = P.gas;
   const int ns = f.ns, nq = 4 * ns;
   const int multid = (P.ndim >= 2), threed = (P.ndim == 3);
@@ -243,11 +244,36 @@ __global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, 
     for (int qq = 0; qq < 3; ++qq) fl[qq] = hf * mus * flx[qq];
     fl[DIR - 1] = hf * mus * (flx[DIR - 1] - 1. / 3 * (1. - dp.eta) * (divu + divu_m));
     double *const *qf = f.dflux[DIR - 1];
-    for (int qq = 0; qq < 3; ++qq) qf[b * nq + 3 * n + qq][c] += fl[qq];
-    qf[b * nq + 3 * ns + n][c] += 0.5 * (s0[c] + s0[cm]) * fl[0] + 0.5 * (s1[c] + s1[cm]) * fl[1] +
-                                  0.5 * (s2[c] + s2[cm]) * fl[2];
+    const double fe = 0.5 * (s0[c] + s0[cm]) * fl[0] + 0.5 * (s1[c] + s1[cm]) * fl[1] + 0.5 * (s2[c] + s2[cm]) * fl[2];
+    if constexpr (OVERWRITE) {
+      for (int qq = 0; qq < 3; ++qq) qf[b * nq + 3 * n + qq][c] = 0.0 + fl[qq];
+      qf[b * nq + 3 * ns + n][c] = 0.0 + fe;
+    } else {
+      for (int qq = 0; qq < 3; ++qq) qf[b * nq + 3 * n + qq][c] += fl[qq];
+      qf[b * nq + 3 * ns + n][c] += fe;
+    }
   }
 }
+template <int DIR, bool CURV>
+__global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, const Box r,
+                                                              const artemis_diffusion_t D, const ViscScratch w) {
+  BOX_CELL(r)
+  viscous_face<DIR, CURV, false>(P, D, w, b, k, j, i, c);
+}
+// The three directions in one pass over the cells of the active region grown by one zone at the upper ends: a
+// thread computes the lower x1 / x2 / x3 faces its cell owns (the shared per-cell scratch is read once instead
+// of three times, nothing is read-modify-written); OVERWRITE also replaces the zeroing pass.
+template <bool CURV, bool OVERWRITE>
+__global__ __launch_bounds__(TX *TY) void viscous_flux3_kernel(const PackView P, const Box r,
+                                                               const artemis_diffusion_t D, const ViscScratch w) {
+  BOX_CELL(r)
+  const bool in1 = i <= P.ie, in2 = j <= P.je || P.ndim < 2, in3 = k <= P.ke || P.ndim < 3;
+  if (in2 && in3) viscous_face<1, CURV, OVERWRITE>(P, D, w, b, k, j, i, c);
+  if (P.ndim > 1 && in1 && in3) viscous_face<2, CURV, OVERWRITE>(P, D, w, b, k, j, i, c);
+  if (P.ndim > 2 && in1 && in2) viscous_face<3, CURV, OVERWRITE>(P, D, w, b, k, j, i, c);
+}
+
+
 
 // ThermalFluxImpl (thermal_diffusion.hpp:30-222)
 template <int DIR, bool CURV>
@@ -366,7 +392,7 @@ thread_local struct {
   double *p = nullptr;
   size_t n = 0;
 } g_visc;
-int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s) {
+int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s, bool overwrite) {
   const size_t N = static_cast<size_t>(P.ni) * P.nj * P.nk, per = static_cast<size_t>(P.nb) * P.gas.ns * N;
   const size_t geo = 3 * static_cast<size_t>(P.nb) * N, need = 5 * per + geo;
   if (g_visc.n < need) {
@@ -387,6 +413,23 @@ int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStre
   const bool curv = P.coords != ARTEMIS_CARTESIAN;
   if (curv) hipLaunchKernelGGL(viscous_cell_kernel<true>, grid_of(rc, P.nb), threads_of(rc), 0, s, P, rc, D, w);
   else hipLaunchKernelGGL(viscous_cell_kernel<false>, grid_of(rc, P.nb), threads_of(rc), 0, s, P, rc, D, w);
+  // one pass for the three directions (ARTEMIS_VISC_SPLIT=1 restores one kernel per direction)
+  const bool split = getenv("ARTEMIS_VISC_SPLIT") != nullptr;
+  if (!split) {
+    Box fr = interior(P);
+    fr.iu = P.ie + 1;
+    if (P.ndim > 1) fr.ju = P.je + 1;
+    if (P.ndim > 2) fr.ku = P.ke + 1;
+    if (curv) {
+      if (overwrite) hipLaunchKernelGGL((viscous_flux3_kernel<true, true>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
+      else hipLaunchKernelGGL((viscous_flux3_kernel<true, false>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
+    } else {
+      if (overwrite) hipLaunchKernelGGL((viscous_flux3_kernel<false, true>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
+      else hipLaunchKernelGGL((viscous_flux3_kernel<false, false>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
+    }
+    return 0;
+  }
+  if (overwrite) launch_zero_diffusion_flux(P, s);
 #define LAUNCH_VISC(DIR)                                                                                        \
   do {                                                                                                          \
     const Box fr = faces(P, DIR);                                                                               \

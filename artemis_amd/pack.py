@@ -223,6 +223,10 @@ class MeshBlockPack:
     def ViscousFlux(self, diffusion):
         self._call(self.L.artemis_hip_viscous_flux, C.byref(diffusion))
 
+    def ZeroViscousFlux(self, diffusion):
+        """ZeroDiffusionFlux + ViscousFlux in one pass (artemis_hip_zero_viscous_flux)."""
+        self._call(self.L.artemis_hip_zero_viscous_flux, C.byref(diffusion))
+
     def ThermalFlux(self, diffusion):
         self._call(self.L.artemis_hip_thermal_flux, C.byref(diffusion))
 

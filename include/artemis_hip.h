@@ -383,6 +383,11 @@ int artemis_hip_diffusion_radial_fill(const artemis_pack_t *p, const double *geo
                                       int block, double *out_host);
 int artemis_hip_zero_diffusion_flux(const artemis_pack_t *p, void *stream);
 int artemis_hip_viscous_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream);
+/* Gas::ZeroDiffusionFlux followed by Gas::ViscousFlux as ONE task (artemis_driver.cpp:189-191 are adjacent in the
+ * task list): the viscous fluxes are STORED (0.0 + flux, the bits of zero-then-add) on the face ranges the update
+ * and the flux correction read, instead of zeroing the arrays and adding to them in three more passes.  Entries
+ * outside those ranges keep their old contents.  With viscosity off it only zeroes. */
+int artemis_hip_zero_viscous_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream);
 int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream);
 int artemis_hip_diffusion_update(const artemis_pack_t *p, const artemis_diffusion_t *d, double dt,
                                  void *stream);

@@ -664,6 +664,10 @@ int artemis_hip_viscous_flux(const artemis_pack_t *p, const artemis_diffusion_t 
   }
   return 0;
 }
+int artemis_hip_zero_viscous_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *s) {
+  if (int rc = artemis_hip_zero_diffusion_flux(p, s)) return rc;
+  return (d->visc.type == ARTEMIS_DIFF_OFF) ? 0 : artemis_hip_viscous_flux(p, d, s);
+}
 int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *) {
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);

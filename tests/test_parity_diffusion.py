@@ -54,6 +54,12 @@ def test_diffusion_tasks(hiplib, coordinates, nx, lo, hi, avg, ctype):
     o.ViscousFlux(), mb.ViscousFlux(D)
     for d in range(o.ndim):
         same(mb.gas_diff_flux[d][0][face_slices(o, d)], o.qflux(d)[face_slices(o, d)], f"viscous flux x{d+1}")
+    # the fused pair (ZeroDiffusionFlux + ViscousFlux in one pass) overwrites whatever the arrays held
+    for d in range(o.ndim):
+        mb.gas_diff_flux[d].fill_(7.25)
+    mb.ZeroViscousFlux(D)
+    for d in range(o.ndim):
+        same(mb.gas_diff_flux[d][0][face_slices(o, d)], o.qflux(d)[face_slices(o, d)], f"zero + viscous flux x{d+1}")
     o.ThermalFlux(), mb.ThermalFlux(D)
     for d in range(o.ndim):
         same(mb.gas_diff_flux[d][0][face_slices(o, d)], o.qflux(d)[face_slices(o, d)], f"visc+thermal flux x{d+1}")
