@@ -49,7 +49,10 @@ def build_hip(force=False, verbose=False):
     procs = []
     for src in HIP_SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + HIP_FLAGS + (NO_SINCOS if src == "abi.hip" else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        # ARTEMIS_HIPFLAGS_<STEM> (e.g. ARTEMIS_HIPFLAGS_KERNELS_FUSED="-mllvm -amdgpu-sched-strategy=max-ilp"):
+        # extra flags for one source, for compiler experiments
+        extra = os.environ.get("ARTEMIS_HIPFLAGS_" + src.replace(".hip", "").upper(), "").split()
+        cmd = [HIPCC] + HIP_FLAGS + extra + (NO_SINCOS if src == "abi.hip" else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -141,6 +141,8 @@ struct LdsTileCurv : LdsTile { // + the PLM_G records of the tile perimeter (con
   PlmG GX1[2];      // x1 records of columns i0-1 and i0+32
   PlmG GX2[2][FTX]; // x2 records of rows j0-1 and j0+8, per column
   int tiny[2];      // plane (k & 1) holds a tiny-but-nonzero velocity: its slopes take IEEE division
+  double HF1[FTY][2]; // ScaleMomentumFlux factors (h2, h3) of the perimeter x1 faces (cell i0+32, row u)
+  double HF2[FTX][2]; // ... of the perimeter x2 faces (cell j0+8, column cx); both constant along the march
 };
 template <bool CURV>
 struct GeoCtx {};
@@ -320,11 +322,7 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
       GET6(l, S.UPX, [u][FTX]);
       GET6(r, S.LOX, [u]);
       Flux8 fe_ = solve_face<RIEMANN, 1>(x.gk, l, r);
-      if constexpr (CURV) { // the face below cell (j0+u, i0+32)
-        double hs[3];
-        make_coords(P, x.b, k, min(x.j0 + u, P.nj - 1), min(x.i0 + FTX, P.ni - 1)).face_scale(1, hs);
-        fe_.m2 *= hs[1], fe_.m3 *= hs[2];
-      }
+      if constexpr (CURV) fe_.m2 *= S.HF1[u][0], fe_.m3 *= S.HF1[u][1]; // the face below cell (j0+u, i0+32)
       PUT8(S.FX, fe_, [u][FTX - 1]);
     } else if (multi_d && u >= 32) {
       const int cx = u - 32;
@@ -332,11 +330,7 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
       GET6(l, S.UPY, [FTY][cx]);
       GET6(r, S.LOY, [cx]);
       Flux8 fe_ = solve_face<RIEMANN, 2>(x.gk, l, r);
-      if constexpr (CURV) { // the face below cell (j0+8, i0+cx)
-        double hs[3];
-        make_coords(P, x.b, k, min(x.j0 + FTY, P.nj - 1), min(x.i0 + cx, P.ni - 1)).face_scale(2, hs);
-        fe_.m2 *= hs[1], fe_.m3 *= hs[2];
-      }
+      if constexpr (CURV) fe_.m2 *= S.HF2[cx][0], fe_.m3 *= S.HF2[cx][1]; // the face below cell (j0+8, i0+cx)
       PUT8(S.FY, fe_, [FTY - 1][cx]);
     }
   }
@@ -493,9 +487,8 @@ ADEV void plane_update_curv(TILE &S, const PackView &P, const StageK &a, const S
   const FluidView &f = P.gas;
   const int b = x.b;
   const long c = x.col + static_cast<long>(k) * x.sk;
-  DCoords co = gx.co;
+  DCoords co = gx.co; // (c3 / s3 of this plane were fetched at the top of the trip)
   co.x3[0] = x.g[4] + k * x.g[5], co.x3[1] = x.g[4] + (k + 1) * x.g[5];
-  if (gx.m3) co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k], co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k];
   const CellMetric g = cell_metric_of(co);
   double hx[3];
   scale_factors_of(co, hx);
@@ -702,6 +695,16 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
     gx.m3 = nullptr;
     if (P.metric && (P.coords == ARTEMIS_SPHERICAL3D || P.coords == ARTEMIS_AXISYMMETRIC))
       gx.m3 = P.metric + x.b * metric_block_stride(P.nj, P.nk) + static_cast<long>(MT_ROWS) * (P.nj + 1);
+    { // perimeter faces' scale factors (no x3 dependence: geometry_core.hpp face_scale)
+      double hs[3];
+      if (x.t < FTY) {
+        make_coords(P, x.b, k0, min(x.j0 + x.t, P.nj - 1), min(x.i0 + FTX, P.ni - 1)).face_scale(1, hs);
+        S.HF1[x.t][0] = hs[1], S.HF1[x.t][1] = hs[2];
+      } else if (x.t >= 64 && x.t < 64 + FTX) {
+        make_coords(P, x.b, k0, min(x.j0 + FTY, P.nj - 1), min(x.i0 + (x.t - 64), P.ni - 1)).face_scale(2, hs);
+        S.HF2[x.t - 64][0] = hs[1], S.HF2[x.t - 64][1] = hs[2];
+      }
+    }
     if constexpr (RECON == 1) {
       gx.g1 = compact(plm_geo(P, x.b, 1, k0, jl, il));
       gx.g2 = gx.g1;
@@ -736,6 +739,7 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
     plane_sweeps<RIEMANN, RECON, false, CURV>(S, P, x, gx, k0, qc, false, qc, hal, fx_lo, fy_lo);
     if constexpr (CURV) {
       DFlux24 df{};
+      if (gx.m3) gx.co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k0], gx.co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k0];
       if (src.v.diff_on) df = load_dflux(P, x.b, x.col + k0 * x.sk, x.multi_d, false);
       plane_update_curv<HAS_U1, WITH_DT, false>(S, P, a, src.v, x, gx, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, df, ldt);
     }
@@ -777,6 +781,8 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
       DFlux24 df{};
       if constexpr (CURV) {
         if (src.v.diff_on && k >= k0) df = load_dflux(P, x.b, x.col + static_cast<long>(k) * x.sk, true, true);
+        // cos / sin of this plane's x3 centre (spherical3D, axisymmetric), also ahead of their use
+        if (gx.m3 && k >= k0) gx.co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k], gx.co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k];
       }
       Flux8 fx_lo, fy_lo;
       if (k >= k0) {
