@@ -831,6 +831,12 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   // a refined mesh needs the stage's face fluxes for flux correction (artemis_driver.cpp:196-202): per-task chain
   fused_possible = !(do_cooling && do_drag) && !multilevel && !grav_nbody; // (n-body: its own task + host reduction)
   tuned = tuned && fused_possible && !(do_viscosity || do_conduction || do_cooling);
+  if (getenv("ARTEMIS_NO_TUNED")) tuned = false; // experiments: route everything through artemis_hip_stage_general
+  // Large 2-D gas meshes on one rank: the row-march kernel behind artemis_hip_stage_general (kernels_stage2d.hip, x2
+  // march in registers) beats the tile kernel's one-plane form -- 1.00e10 vs 7.3e9 zone-cycles/s at 4096^2, a tie at
+  // 1024^2, and the tile kernel wins on small meshes (scripts/tuned2d_timing.py) -- so it takes blocks of >= 2^21 zones.
+  if (tuned && ndim == 2 && nranks == 1 && static_cast<long>(mbnx[0]) * mbnx[1] >= (1L << 21) && !getenv("ARTEMIS_TUNED_2D"))
+    tuned = false;
   // Default path by measurement (scripts/path_timing.py, one MI355X): the cell-centred general stage wins
   // on Cartesian meshes (2048^2 viscous 1.73e9 vs 1.50e9 zone-cycles/s, SURVEY config 3 2.9e9 vs 1.1e9); in
   // curvilinear coordinates every face carries PLM_G / scale-factor geometry and solving each face from
