@@ -1,5 +1,5 @@
 cd /root/repo
 export TMPDIR=/tmp
-timeout 300 python scripts/tuned2d_timing.py 4096
-timeout 300 python scripts/tuned2d_timing.py 1024
-timeout 300 python scripts/tuned2d_timing.py 256
+mkdir -p gpurun_out
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|error|FAILED|assert" | head -20
