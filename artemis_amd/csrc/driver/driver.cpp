@@ -146,6 +146,7 @@ struct artemis_sim {
   struct {
     Field gcoarse, dcoarse;       // coarse buffers, laid out like the prim tables
     DevBuf cgeom, cmetric;
+    std::vector<Real> cgeom_h, cmetric_h; // host copies (the problem generator evaluates `ic` states on them)
     DevArr ops_a, ops_u, ops_b;   // ghost ops: packs + direct same/finer | unpacks same/finer | from-coarser
     DevArr ops_fx, ops_fxu;       // flux correction: packs + direct | unpacks
     DevArr restrict_blocks, boxes;
@@ -240,6 +241,7 @@ struct artemis_sim {
   Field gdflux[3];
   Field visc_radial;  // per-cell radial factor of the viscosity law (host libm), diff.visc.radial
   Field ic_gas, ic_dust; // disk `ic` condition: the initial primitives as generated (disk.hpp:597-632)
+  Field ic_gas_c, ic_dust_c; // ... evaluated on the coarse buffers of a refined mesh (their own zone centres)
   bool edge_ghosts = false; // sequential x1, x2, x3 exchange with extended slabs (viscosity)
   std::string integrator = "rk2";
   int nstages = 2;
@@ -466,9 +468,9 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
         if (mbnx[d] % 2 != 0 || mbnx[d] / 2 < (ng + 1) / 2 + 1)
           throw std::runtime_error("multilevel meshes need an even meshblock size of at least nghost + 4 zones");
       for (int f = 0; f < 2 * ndim; ++f)
-        if (mesh_bc[f] > ARTEMIS_BC_REFLECT)
-          throw std::runtime_error("user boundary conditions on a statically refined mesh are not built "
-                                   "(periodic | outflow | reflecting are)");
+        if (mesh_bc[f] > ARTEMIS_BC_REFLECT && mesh_bc[f] != ARTEMIS_BC_IC)
+          throw std::runtime_error("this user boundary condition on a statically refined mesh is not built "
+                                   "(periodic | outflow | reflecting | ic are)");
     }
   }
   // geometry::CoordSelect (geometry.hpp:38-56, artemis.cpp:94-97)
@@ -1051,6 +1053,7 @@ void artemis_sim::allocate_multilevel() {
       hc[6 * b + 2 * d] = blocks[b].xmin[d] - cg[d] * dx, hc[6 * b + 2 * d + 1] = dx;
     }
   ml.cgeom.alloc(hc.size());
+  ml.cgeom_h = hc;
   CK(artemis_rt_memcpy_h2d(ml.cgeom.p, hc.data(), hc.size() * sizeof(Real), nullptr), "h2d cgeom");
   {
     artemis_pack_t p0;
@@ -1061,6 +1064,7 @@ void artemis_sim::allocate_multilevel() {
       std::vector<Real> hm(nm, 0.0);
       CK(artemis_hip_metric_fill(&p0, hc.data(), hm.data()), "coarse metric tables");
       ml.cmetric.alloc(nm);
+      ml.cmetric_h = hm;
       CK(artemis_rt_memcpy_h2d(ml.cmetric.p, hm.data(), nm * sizeof(Real), nullptr), "h2d cmetric");
     }
   }
@@ -1119,6 +1123,8 @@ void artemis_sim::fill_ghosts_multilevel(int prim_idx) {
     pc.gas.prim = ml.gcoarse.tab(), pc.dust.prim = ml.dcoarse.tab();
     artemis_bc_params_t bp = bcpar;
     bp.floor_ghosts = 0;
+    if (ic_gas_c.ok() || ic_dust_c.ok()) // `ic`: the profile at the coarse buffers' own zone centres
+      bp.ic_gas = ic_gas_c.ok() ? ic_gas_c.tab() : nullptr, bp.ic_dust = ic_dust_c.ok() ? ic_dust_c.tab() : nullptr;
     CK(artemis_hip_apply_bc(&pc, ml.bc_coarse.data(), &bp, stream), "apply_bc (coarse buffers)");
     CK(artemis_hip_ml_prolongate(&p, &m, static_cast<const artemis_ml_box_t *>(ml.boxes.p), ml.boxes.n, stream), "ml prolongate");
   }
@@ -1866,6 +1872,40 @@ void artemis_sim::problem_generator() {
         if (ic_dust.ok()) upload_block(ic_dust, b, hds[t]);
       }
     }
+  }
+  if (multilevel && ic_gas.ok()) {
+    // The `ic` condition on a coarse buffer takes the profile at the buffer's own zone centres (the reference's
+    // DiskBoundaryIC re-evaluates it wherever it is applied): run the generator once more on the coarse geometry
+    // of every block whose buffer carries a physical condition.  The generator reads the block geometry through
+    // the members below, so they are switched to the coarse buffers' for the duration.
+    const int cg[3] = {ng, ndim > 1 ? ng : 0, ndim > 2 ? ng : 0};
+    const int cnx[3] = {mbnx[0] / 2, ndim > 1 ? mbnx[1] / 2 : 1, ndim > 2 ? mbnx[2] / 2 : 1};
+    const int fi = ni, fj = nj, fk = nk, fm[3] = {mbnx[0], mbnx[1], mbnx[2]};
+    const size_t fN = N;
+    std::vector<Real> fgeom, fmetric;
+    fgeom.swap(hgeom), fmetric.swap(hmetric);
+    hgeom = ml.cgeom_h, hmetric = ml.cmetric_h;
+    ni = cnx[0] + 2 * cg[0], nj = cnx[1] + 2 * cg[1], nk = cnx[2] + 2 * cg[2];
+    N = static_cast<size_t>(ni) * nj * nk;
+    for (int d = 0; d < 3; ++d) mbnx[d] = cnx[d];
+    try {
+      ic_gas_c.alloc(nb, 6 * ns_gas, N), ic_dust_c.alloc(nb, 4 * ns_dust, N);
+      std::vector<Real> hgc(static_cast<size_t>(6) * ns_gas * N), hdc(static_cast<size_t>(4) * ns_dust * N);
+      for (int b : ml_host.restrict_blocks) {
+        bool any = false;
+        for (int f = 0; f < 2 * ndim; ++f) any = any || blocks[b].bc[f] == ARTEMIS_BC_IC;
+        if (!any) continue;
+        generate_block(b, hgc, hdc);
+        if (do_gas) upload_block(ic_gas_c, b, hgc);
+        if (do_dust) upload_block(ic_dust_c, b, hdc);
+      }
+    } catch (...) {
+      ni = fi, nj = fj, nk = fk, N = fN, hgeom.swap(fgeom), hmetric.swap(fmetric);
+      for (int d = 0; d < 3; ++d) mbnx[d] = fm[d];
+      throw;
+    }
+    ni = fi, nj = fj, nk = fk, N = fN, hgeom.swap(fgeom), hmetric.swap(fmetric);
+    for (int d = 0; d < 3; ++d) mbnx[d] = fm[d];
   }
   base = 0;
   if (do_cooling && do_gas) {
