@@ -25,8 +25,8 @@ def main():
         extra = ["parthenon/mesh/nx1=256", "parthenon/mesh/nx2=128", "parthenon/mesh/nx3=128", "parthenon/mesh/refinement=static",
                  "parthenon/static_refinement1/level=1", "parthenon/static_refinement1/x1min=0.7",
                  "parthenon/static_refinement1/x1max=1.9", "parthenon/static_refinement1/x2min=1.3",
-                 "parthenon/static_refinement1/x2max=1.85", "parthenon/static_refinement1/x3min=-3.2",
-                 "parthenon/static_refinement1/x3max=3.2"] + extra
+                 "parthenon/static_refinement1/x2max=1.85", "parthenon/static_refinement1/x3min=-3.0",
+                 "parthenon/static_refinement1/x3max=3.0"] + extra
     s = Simulation(os.path.join(ROOT, "inputs", "disk", deck), ["parthenon/time/nlim=100000"] + extra)
     t1 = time.perf_counter()
     s.evolve(3)

@@ -362,3 +362,18 @@ def test_disk_sph_on_a_refined_mesh_hip_equals_multilevel_oracle(hiplib):
         assert np.array_equal(got[[0, 1, 2, 3, 5]], blk.gprim[[0, 1, 2, 3, 5]]), b  # ghosts included
         assert np.array_equal(s.interior(got), blk.interior(blk.gprim)), b
     s.close()
+
+
+def test_disk_sph_on_a_refined_mesh_two_ranks_bitwise(tmp_path):
+    """The same refined spherical disk deck split over 2 ranks (gloo): identical bits, block for block."""
+    spec = dict(deck=["disk", "disk_sph.in"], overrides=DISK_SMR_OV)
+    one = _run_workers(1, spec, tmp_path, "ds1")
+    two = _run_workers(2, spec, tmp_path, "ds2")
+    assert sum(r["meta"]["nblocks"] for r in two) == one[0]["meta"]["nblocks"] == 72
+    from test_multirank_cpu import by_bounds
+    a, b = by_bounds(one), by_bounds(two)
+    assert a.keys() == b.keys()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    for r in two:
+        assert r["meta"]["dt"] == one[0]["meta"]["dt"] and r["meta"]["ncycle"] == 6
