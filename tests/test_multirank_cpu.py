@@ -159,6 +159,10 @@ def test_spherical3d_two_ranks_equal_single_process_bitwise(double_lib, tmp_path
     fs = run_world(1, SPH3D, tmp_path, "s1f")
     assert fs[0]["meta"]["fused"] and not fs[0]["meta"]["tuned"]
     per_task = by_bounds(fs)
+    fs2 = by_bounds(run_world(2, SPH3D, tmp_path, "s2f"))  # the default (fused) path split over two ranks
+    assert fs2.keys() == per_task.keys()
+    for key in fs2:
+        assert np.array_equal(fs2[key], per_task[key]), key
     for r in two:
         for k in ("ncycle", "time", "dt"):
             assert r["meta"][k] == one[0]["meta"][k], k
