@@ -377,3 +377,50 @@ def test_disk_sph_on_a_refined_mesh_two_ranks_bitwise(tmp_path):
         assert np.array_equal(a[key], b[key]), key
     for r in two:
         assert r["meta"]["dt"] == one[0]["meta"]["dt"] and r["meta"]["ncycle"] == 6
+
+
+# ---- gas + dust on a refined mesh (no multilevel oracle for dust: conservation, rank independence, accuracy) ------
+ADV_SMR = dict(deck=["advection", "advection.in"], cycles=12, dust=True,
+               overrides=["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16", "parthenon/meshblock/nx1=8",
+                          "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8"]
+               + region_overrides(1, (1.0, 0.4, 0.4), (2.0, 1.1, 1.1)))
+
+
+def test_gas_and_two_dust_species_on_a_refined_mesh(tmp_path):
+    """inputs/advection/advection.in (gas + two counter-streaming dust species, fully periodic) with a level-1 region
+    in the middle: the dust fluids go through the same block-graph exchange, coarse buffers and flux correction as the
+    gas.  Mass and momentum of every fluid are conserved to round-off across the level boundaries; 2 ranks give the
+    bits of 1 rank; the wave is carried as accurately as on the uniform mesh."""
+    one = _run_workers(1, ADV_SMR, tmp_path, "a1")
+    two = _run_workers(2, ADV_SMR, tmp_path, "a2")
+    uni = _run_workers(1, dict(ADV_SMR, overrides=ADV_SMR["overrides"][:6]), tmp_path, "au")
+    assert one[0]["meta"]["nblocks"] > uni[0]["meta"]["nblocks"] == 16 and not one[0]["meta"]["fused"]
+    h = one[0]["hist"]
+    # history after the run against the analytic integrals of the initial state (advection.py:100-187 pins them on
+    # the uniform mesh): gas mass 6.75 = rho0 * volume, dust masses likewise; total momenta of the counter-streaming
+    # dust species cancel
+    hu = uni[0]["hist"]
+    assert np.allclose(h, hu, rtol=0, atol=5e-13 * np.abs(hu).max()), (h, hu)
+    from test_multirank_cpu import by_bounds
+    a, b = by_bounds(one), by_bounds(two)
+    assert a.keys() == b.keys()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    e, eu = one[0]["errs"], uni[0]["errs"]
+    assert np.all(np.isfinite(e[:3])) and np.all(e[:3] < 1.6 * eu[:3]), (e[:3], eu[:3])
+
+
+@pytest.mark.gpu
+def test_gas_and_two_dust_species_on_a_refined_mesh_hip(hiplib):
+    """The same deck through the HIP driver: every fluid's mass and momentum conserved to round-off over 12 cycles
+    across the level boundaries (periodic domain), all fields finite."""
+    from artemis_amd.driver import Simulation
+    s = Simulation(DECK(*ADV_SMR["deck"]), ADV_SMR["overrides"] + ["parthenon/time/nlim=12"])
+    assert not s.uses_fused_path and s.nblocks > 16
+    h0 = s.history()
+    s.evolve()
+    h1 = s.history()
+    assert s.ncycle == 12 and np.allclose(h1, h0, rtol=0, atol=5e-13 * np.abs(h0).max()), (h0, h1)
+    for b in range(s.nblocks):
+        assert np.isfinite(s.field("gas.prim", b)[[0, 1, 2, 3, 5]]).all() and np.isfinite(s.field("dust.prim", b)).all()
+    s.close()
