@@ -424,3 +424,60 @@ def test_gas_and_two_dust_species_on_a_refined_mesh_hip(hiplib):
     for b in range(s.nblocks):
         assert np.isfinite(s.field("gas.prim", b)[[0, 1, 2, 3, 5]]).all() and np.isfinite(s.field("dust.prim", b)).all()
     s.close()
+
+
+# ---- N-body gravity on a refined cylindrical mesh (configs[4]'s ingredients minus REBOUND and adaptivity) ---------
+NBODY_SMR_OV = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16", "parthenon/meshblock/nx1=8",
+                "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8", "parthenon/time/nlim=6",
+                "problem/polytropic_index=1.00"] + region_overrides(1, (0.8, -0.7, -0.4), (1.6, 0.7, 0.4))
+
+
+def nbody_smr_oracle():
+    from test_nbody import _PI
+    m = MultiLevelOracle((32, 16, 16), (8, 8, 8), (0.3, -_PI, -1.0), (4.3, _PI, 1.0),
+                         ("ic", "ic", "periodic", "periodic", "ic", "ic"),
+                         regions=[(1, (0.8, 1.6), (-0.7, 0.7), (-0.4, 0.4))], ng=2, integrator="rk2", reconstruct="plm",
+                         riemann="hllc", gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3, coordinates="cylindrical")
+    m.diffusion = m.gravity = True
+    for blk in m.blocks + m.coarse:
+        blk.set_gravity_nbody([dict(GM=1.0)])
+        blk.set_viscosity("alpha", alpha=1e-3, r0=1.0, Omega0=1.0)
+        blk.pgen_disk(r0=1.0, rho0=1.0, dslope=-2.25, flare=0.25, h0=0.05, dens_min=1e-10, pres_min=1e-15,
+                      polytropic_index=1.0, post_init=False)
+    m.post_init()
+    m.evolve(62.8, 6)
+    return m
+
+
+def test_nbody_disk_deck_on_a_refined_mesh_cpu_double_equals_multilevel_oracle(tmp_path):
+    """inputs/disk/disk_nbody_cyl.in (cylindrical, `ic` conditions, alpha viscosity, the N-body gravity task with the
+    central particle) at 32 x 16 x 16 in 8^3 blocks with a level-1 region at r ~ 1: host driver on the CPU double ==
+    multilevel oracle, bit for bit, on 1 rank; 2 ranks give the same bits."""
+    spec = dict(deck=["disk", "disk_nbody_cyl.in"], overrides=NBODY_SMR_OV)
+    res = _run_workers(1, spec, tmp_path, "nb1")
+    m = nbody_smr_oracle()
+    r = res[0]
+    assert r["meta"]["nblocks"] == len(m.blocks) and r["meta"]["ncycle"] == m.ncycle == 6
+    assert r["meta"]["dt"] == m.dt and r["meta"]["time"] == m.time
+    for b, (bounds, prim) in enumerate(r["blocks"]):
+        assert list(bounds) == m.block_bounds(b)
+        assert np.array_equal(prim, m.blocks[b].interior(m.blocks[b].gprim)), b
+    two = _run_workers(2, spec, tmp_path, "nb2")
+    from test_multirank_cpu import by_bounds
+    a, b2 = by_bounds(res), by_bounds(two)
+    for key in a:
+        assert np.array_equal(a[key], b2[key]), key
+
+
+@pytest.mark.gpu
+def test_nbody_disk_deck_on_a_refined_mesh_hip_equals_multilevel_oracle(hiplib):
+    from artemis_amd.driver import Simulation
+    s = Simulation(DECK("disk", "disk_nbody_cyl.in"), NBODY_SMR_OV)
+    s.evolve()
+    m = nbody_smr_oracle()
+    assert s.nblocks == len(m.blocks) and s.ncycle == m.ncycle and s.dt == m.dt
+    for b, blk in enumerate(m.blocks):
+        assert np.array_equal(s.interior(s.field("gas.prim", b)), blk.interior(blk.gprim)), b
+    f = s.nbody_force()
+    assert f.shape == (1, 7) and np.all(np.isfinite(f))
+    s.close()
