@@ -1,3 +1,3 @@
 cd /root/repo
 export TMPDIR=/tmp
-timeout 600 python scripts/smr_timing.py 20 sph problem/polytropic_index=1.40 gas/de_switch=1e-2
+timeout 1200 python -m pytest tests/test_multilevel.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|error|FAILED|assert" | head -20
