@@ -1,0 +1,26 @@
+# Round-end evidence run (one gpurun call): GPU suite, smoke, bench lines, rocprof stats, PMC traffic records.
+# Outputs under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
+tag=${1:-r02z}
+cd /root/repo
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|FAILED" | tail -5 > gpurun_out/${tag}_tests.txt; cat gpurun_out/${tag}_tests.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/${tag}_smoke.txt
+timeout 900 python3 scripts/pmc_traffic.py --tag ${tag}
+timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph
+timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust
+cp gpurun_out/${tag}_pmc_traffic.json profiles/r02_pmc_traffic.json; cp gpurun_out/${tag}_disk_sph_pmc_traffic.json profiles/r02_disk_sph_pmc_traffic.json; cp gpurun_out/${tag}_cfg3_pmc_traffic.json profiles/r02_cfg3_pmc_traffic.json
+timeout 600 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err; cat gpurun_out/${tag}_bench_line.json | cut -c1-400
+timeout 300 python bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_cfg3_line.json
+timeout 300 python bench.py --workload disk_sph --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_disk_sph_line.json
+cut -c1-300 gpurun_out/${tag}_cfg3_line.json gpurun_out/${tag}_disk_sph_line.json
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof -o p --output-format csv -- python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_prof.log 2>&1
+find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_bench_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_cfg3_prof -o p --output-format csv -- python3 bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50 > /dev/null 2>&1
+find gpurun_out/${tag}_cfg3_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_cfg3_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_disk_prof -o p --output-format csv -- python3 bench.py --workload disk_sph --no-cpu-baseline --steps 50 > /dev/null 2>&1
+find gpurun_out/${tag}_disk_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_disk_sph_kernel_stats.csv
+timeout 300 python scripts/smr_timing.py 20 | tee gpurun_out/${tag}_smr.txt
+timeout 300 python scripts/smr_timing.py 20 sph problem/polytropic_index=1.40 gas/de_switch=1e-2 | tee -a gpurun_out/${tag}_smr.txt
+for w in blast_sph blast_cyl disk_sph disk_cyl disk_axi; do timeout 300 python scripts/curv_timing.py $w; done | tee gpurun_out/${tag}_curv.txt
+head -4 gpurun_out/${tag}_bench_kernel_stats.csv | cut -c1-200
