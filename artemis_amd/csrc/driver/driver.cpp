@@ -110,7 +110,7 @@ enum { PG_BLAST, PG_LINWAVE, PG_ADVECTION, PG_CONSTANT, PG_STRAT, PG_BUMP, PG_CO
 
 } // namespace
 
-struct artemis_sim {
+struct artemis_sim_impl {
   artemis_host::ParameterInput pin;
   artemis_comm_t comm;
   bool has_comm = false;
@@ -391,7 +391,7 @@ void choose_rank_grid(int nranks, const int nblk[3], int rg[3]) {
 } // namespace
 
 // ---------------------------------------------------------------------------------------
-void artemis_sim::setup(const char *deck, int nover, const char *const *over,
+void artemis_sim_impl::setup(const char *deck, int nover, const char *const *over,
                         const artemis_comm_t *c) {
   pin.LoadFromString(deck);
   for (int q = 0; q < nover; ++q) pin.ApplyOverride(over[q]);
@@ -858,7 +858,7 @@ void artemis_sim::setup(const char *deck, int nover, const char *const *over,
   lap("problem_generator", t_setup);
 }
 
-void artemis_sim::build_mesh() {
+void artemis_sim_impl::build_mesh() {
   if (multilevel) {
     build_mesh_multilevel();
     return;
@@ -927,7 +927,7 @@ void artemis_sim::build_mesh() {
 
 // Statically refined mesh: leaves of the block tree in Z-order, dealt to the ranks in contiguous runs of
 // (nearly) equal length -- every block costs the same, which is Parthenon's default load balance.
-void artemis_sim::build_mesh_multilevel() {
+void artemis_sim_impl::build_mesh_multilevel() {
   artemis_host::BlockTree tree;
   tree.ndim = ndim;
   for (int d = 0; d < 3; ++d) tree.nrb[d] = nblk[d], tree.periodic[d] = (d < ndim) && mesh_bc[2 * d] == ARTEMIS_BC_PERIODIC;
@@ -1041,7 +1041,7 @@ void artemis_sim::build_mesh_multilevel() {
     for (int f = 2 * ndim; f < 6; ++f) ml.bc_coarse[6 * b + f] = ARTEMIS_BC_OUTFLOW; // inactive directions
 }
 
-void artemis_sim::allocate_multilevel() {
+void artemis_sim_impl::allocate_multilevel() {
   const int cg[3] = {ng, ndim > 1 ? ng : 0, ndim > 2 ? ng : 0};
   const int cnx[3] = {mbnx[0] / 2, ndim > 1 ? mbnx[1] / 2 : 1, ndim > 2 ? mbnx[2] / 2 : 1};
   const size_t cN = static_cast<size_t>(cnx[0] + 2 * cg[0]) * (cnx[1] + 2 * cg[1]) * (cnx[2] + 2 * cg[2]);
@@ -1088,7 +1088,7 @@ void artemis_sim::allocate_multilevel() {
 
 // Post the per-peer messages of one phase on the comm stream, ordered behind the compute stream's packs
 // and ahead of its unpacks.
-void artemis_sim::exchange_messages(std::vector<artemis_msg_t> &msgs) {
+void artemis_sim_impl::exchange_messages(std::vector<artemis_msg_t> &msgs) {
   if (msgs.empty()) return;
   if (!has_comm) throw std::runtime_error("remote neighbours but no communicator");
   CK(artemis_rt_event_record(ev0, stream), "event");
@@ -1104,7 +1104,7 @@ void artemis_sim::exchange_messages(std::vector<artemis_msg_t> &msgs) {
 // same-level copies and restricted data from finer neighbours land in the fine ghost zones, coarser
 // neighbours' interiors in the coarse buffers; then ghost-halo restriction, physical conditions on the coarse
 // buffers, prolongation, physical conditions on the fine arrays.  Seven launches whatever the block count.
-void artemis_sim::fill_ghosts_multilevel(int prim_idx) {
+void artemis_sim_impl::fill_ghosts_multilevel(int prim_idx) {
   const artemis_pack_t p = make_pack(prim_idx);
   const artemis_ml_pack_t m = make_ml_pack();
   CK(artemis_hip_ml_exchange(&p, &m, static_cast<const artemis_ml_op_t *>(ml.ops_a.p), ml.ops_a.n, ml.gsend.p, ml.grecv.p, stream),
@@ -1134,7 +1134,7 @@ void artemis_sim::fill_ghosts_multilevel(int prim_idx) {
 }
 
 // SendBoundBufs<flxcor_send> / ReceiveFluxCorrections / SetFluxCorrections (artemis_driver.cpp:196-202)
-void artemis_sim::flux_correction_multilevel(const artemis_pack_t &p) {
+void artemis_sim_impl::flux_correction_multilevel(const artemis_pack_t &p) {
   CK(artemis_hip_ml_flux_correction(&p, static_cast<const artemis_ml_op_t *>(ml.ops_fx.p), ml.ops_fx.n, ml.fsend.p, ml.frecv.p, stream),
      "flux correction");
   exchange_messages(ml.fmsgs);
@@ -1142,7 +1142,7 @@ void artemis_sim::flux_correction_multilevel(const artemis_pack_t &p) {
      "flux correction (unpack)");
 }
 
-void artemis_sim::allocate() {
+void artemis_sim_impl::allocate() {
   // the launcher selects the GPU (artemis_rt_set_device) before creating the simulation
   stream = artemis_rt_stream_create();
   comm_stream = artemis_rt_stream_create();
@@ -1207,7 +1207,7 @@ void artemis_sim::allocate() {
   CK(artemis_rt_device_sync(), "sync");
 }
 
-void artemis_sim::ensure_unfused() {
+void artemis_sim_impl::ensure_unfused() {
   if (unfused_ready) return;
   gu1.alloc(nb, 6 * ns_gas, N);
   du1.alloc(nb, 4 * ns_dust, N);
@@ -1221,11 +1221,11 @@ void artemis_sim::ensure_unfused() {
   unfused_ready = true;
 }
 
-void artemis_sim::upload_block(Field &f, int b, const std::vector<Real> &h) {
+void artemis_sim_impl::upload_block(Field &f, int b, const std::vector<Real> &h) {
   CK(artemis_rt_memcpy_h2d(f.var(b, 0), h.data(), h.size() * sizeof(Real), stream), "h2d");
   CK(artemis_rt_stream_sync(stream), "sync");
 }
-std::vector<Real> artemis_sim::download(const Field &f, int b) {
+std::vector<Real> artemis_sim_impl::download(const Field &f, int b) {
   std::vector<Real> h(static_cast<size_t>(f.nvar) * N);
   CK(artemis_rt_stream_sync(stream), "sync");
   CK(artemis_rt_memcpy_d2h(h.data(), f.var(b, 0), h.size() * sizeof(Real), stream), "d2h");
@@ -1243,7 +1243,7 @@ std::vector<Real> artemis_sim::download(const Field &f, int b) {
 // dim < 0: every face at once (slabs span the interior of the other dimensions; the hydro stencil
 // reads no edge or corner zone).  dim >= 0: only the faces of that dimension, with slabs extended
 // over the ghost zones of the lower dimensions (edge_ghosts mode, one phase per dimension).
-void artemis_sim::fill_ghosts_start(int prim_idx, void *hs, int dim) {
+void artemis_sim_impl::fill_ghosts_start(int prim_idx, void *hs, int dim) {
   if (links.empty()) return;
   const artemis_pack_t p = make_pack(prim_idx);
   const int ext = (dim >= 0) ? 1 : 0;
@@ -1269,7 +1269,7 @@ void artemis_sim::fill_ghosts_start(int prim_idx, void *hs, int dim) {
       throw std::runtime_error("exchange_start failed");
   }
 }
-void artemis_sim::fill_ghosts_finish(int prim_idx, void *hs, int dim, bool apply_bcs) {
+void artemis_sim_impl::fill_ghosts_finish(int prim_idx, void *hs, int dim, bool apply_bcs) {
   const artemis_pack_t p = make_pack(prim_idx);
   const int ext = (dim >= 0) ? 1 : 0;
   bool any_remote = false;
@@ -1306,7 +1306,7 @@ void artemis_sim::fill_ghosts_finish(int prim_idx, void *hs, int dim, bool apply
     CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc");
   }
 }
-void artemis_sim::fill_ghosts(int prim_idx) {
+void artemis_sim_impl::fill_ghosts(int prim_idx) {
   if (multilevel) {
     fill_ghosts_multilevel(prim_idx);
     return;
@@ -1324,7 +1324,7 @@ void artemis_sim::fill_ghosts(int prim_idx) {
     fill_ghosts_finish(prim_idx, stream, d, d == ndim - 1);
   }
 }
-void artemis_sim::materialise_cons() {
+void artemis_sim_impl::materialise_cons() {
   if (cons_valid) return;
   const artemis_pack_t p = make_pack(base);
   CK(artemis_hip_prim_to_cons(&p, stream), "PrimToCons");
@@ -1333,7 +1333,7 @@ void artemis_sim::materialise_cons() {
 
 // ---------------------------------------------------------------------------------------
 // pgen/linear_wave.hpp:117-215 and pgen/advection.hpp:62-168: wavevector set-up
-void artemis_sim::lw_setup(bool eigen) {
+void artemis_sim_impl::lw_setup(bool eigen) {
   const bool multi_d = ndim > 1, three_d = ndim > 2;
   const bool along_x1 = pin.GetOrAddBoolean("problem", "along_x1", false);
   const bool along_x2 = pin.GetOrAddBoolean("problem", "along_x2", false);
@@ -1399,7 +1399,7 @@ static void to_cart(int sys, const Real xi[3], Real xc[3]) {
   }
 }
 
-void artemis_sim::problem_generator() {
+void artemis_sim_impl::problem_generator() {
   const Real gm1 = gamma - 1.0;
   auto xf = [&](int b, int d, int idx) { // Coordinates_t::Xf (geometry.hpp:65-72)
     const Real dx = (blocks[b].xmax[d] - blocks[b].xmin[d]) / mbnx[d];
@@ -1947,7 +1947,7 @@ void artemis_sim::problem_generator() {
 
 // ---------------------------------------------------------------------------------------
 // PostStepTasks -> EstimateTimestep (artemis_driver.cpp:279-297): min over packages, local.
-Real artemis_sim::new_dt_unfused() {
+Real artemis_sim_impl::new_dt_unfused() {
   const artemis_pack_t p = make_pack(base);
   *dt_host = DBL_MAX;
   CK(artemis_rt_memcpy_h2d(dt_dev.p, dt_host, sizeof(double), stream), "h2d");
@@ -1964,7 +1964,7 @@ Real artemis_sim::new_dt_unfused() {
 // One step on the general fused path: one cell-centred kernel per fluid and stage (plus the drag /
 // SetAuxillaryFields / ConsToPrim trio when drag couples the fluids), primitives of both fluids
 // ping-ponged between buffers exactly like the tuned path.
-void artemis_sim::step_general(bool want_dt, bool device_dt) {
+void artemis_sim_impl::step_general(bool want_dt, bool device_dt) {
   for (int q = 1; q < 3; ++q) {
     if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
     if (!dprim[q].ok()) dprim[q].alloc(nb, 4 * ns_dust, N);
@@ -2030,7 +2030,7 @@ void artemis_sim::step_general(bool want_dt, bool device_dt) {
   cons_valid = false;
 }
 
-void artemis_sim::step_fused(bool want_dt, bool device_dt) {
+void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
   if (!tuned) {
     step_general(want_dt, device_dt);
     return;
@@ -2128,7 +2128,7 @@ void artemis_sim::step_fused(bool want_dt, bool device_dt) {
 }
 
 // One step on the per-task path (artemis_driver.cpp:157-261 literally).
-void artemis_sim::step_unfused() {
+void artemis_sim_impl::step_unfused() {
   ensure_unfused();
   materialise_cons();
   const artemis_pack_t p = make_pack(base);
@@ -2190,7 +2190,7 @@ void artemis_sim::step_unfused() {
 
 // parthenon EvolutionDriver::Execute + SetGlobalTimeStep (upstream, recalled; pinned by
 // tst/scripts/advection/advection.py:100-118).
-long artemis_sim::evolve(long max_cycles) {
+long artemis_sim_impl::evolve(long max_cycles) {
   auto global_min = [&](Real v) {
     if (has_comm && nranks > 1 && comm.allreduce_min(comm.ctx, &v)) throw std::runtime_error("allreduce failed");
     return v;
@@ -2306,7 +2306,7 @@ long artemis_sim::evolve(long max_cycles) {
 }
 
 // utils/history.hpp:29-100 (volume integrals of the conserved fields)
-int artemis_sim::history(double *out) {
+int artemis_sim_impl::history(double *out) {
   materialise_cons();
   const int nout = 6 + 4 * ns_dust;
   for (int q = 0; q < nout; ++q) out[q] = 0.0;
@@ -2336,7 +2336,7 @@ int artemis_sim::history(double *out) {
 }
 
 // linear_wave.hpp:267-377 / advection.hpp:224-405 UserWorkAfterLoop
-int artemis_sim::errors(double *out) {
+int artemis_sim_impl::errors(double *out) {
   if (pgen != PG_LINWAVE && pgen != PG_ADVECTION) return 0;
   materialise_cons();
   Real l1[13];
@@ -2429,6 +2429,28 @@ int artemis_sim::errors(double *out) {
     onerr;                                                                                 \
   }
 
+// streams, events and pinned memory of a simulation state are raw handles: release them before the state goes
+static void release_impl(std::unique_ptr<artemis_sim_impl> &p) {
+  if (!p) return;
+  for (auto &pr : p->kev) artemis_rt_event_destroy(pr.first), artemis_rt_event_destroy(pr.second);
+  if (p->dt_host) artemis_rt_free_host(p->dt_host);
+  if (p->ev0) artemis_rt_event_destroy(p->ev0);
+  if (p->ev1) artemis_rt_event_destroy(p->ev1);
+  if (p->stream) artemis_rt_stream_destroy(p->stream);
+  if (p->comm_stream) artemis_rt_stream_destroy(p->comm_stream);
+  p.reset();
+}
+
+// The C handle: owns the simulation state (rebuilt wholesale when an adaptive mesh changes, so the handle's address
+// stays valid for the caller) and what is needed to rebuild it.
+struct artemis_sim {
+  std::unique_ptr<artemis_sim_impl> p;
+  std::string deck;
+  std::vector<std::string> overrides;
+  bool has_comm = false;
+  artemis_comm_t comm;
+};
+
 extern "C" {
 
 const char *artemis_sim_last_error(void) { return g_sim_err.c_str(); }
@@ -2439,9 +2461,19 @@ artemis_sim_t *artemis_sim_create(const char *deck_text, int noverrides,
     g_sim_err = "null deck";
     return nullptr;
   }
-  artemis_sim *s = nullptr;
-  GUARD(s = new artemis_sim(); s->setup(deck_text, noverrides, overrides, comm), {
-    delete s;
+  artemis_sim *s = new artemis_sim();
+  auto build = [&]() {
+    s->deck = deck_text;
+    for (int q = 0; q < noverrides; ++q) s->overrides.push_back(overrides[q]);
+    if (comm) {
+      s->comm = *comm;
+      s->has_comm = true;
+    }
+    s->p.reset(new artemis_sim_impl());
+    s->p->setup(deck_text, noverrides, overrides, comm);
+  };
+  GUARD(build(), {
+    artemis_sim_destroy(s);
     return nullptr;
   })
   return s;
@@ -2449,52 +2481,49 @@ artemis_sim_t *artemis_sim_create(const char *deck_text, int noverrides,
 void artemis_sim_destroy(artemis_sim_t *sim) {
   if (!sim) return;
   artemis_rt_device_sync();
-  for (auto &pr : sim->kev) artemis_rt_event_destroy(pr.first), artemis_rt_event_destroy(pr.second);
-  if (sim->dt_host) artemis_rt_free_host(sim->dt_host);
-  artemis_rt_event_destroy(sim->ev0), artemis_rt_event_destroy(sim->ev1);
-  artemis_rt_stream_destroy(sim->stream), artemis_rt_stream_destroy(sim->comm_stream);
+  release_impl(sim->p);
   delete sim;
 }
 long artemis_sim_evolve(artemis_sim_t *sim, long max_cycles) {
   long n = -1;
-  GUARD(n = sim->evolve(max_cycles), return -1)
+  GUARD(n = sim->p->evolve(max_cycles), return -1)
   return n;
 }
-double artemis_sim_time(const artemis_sim_t *s) { return s->time; }
-double artemis_sim_dt(const artemis_sim_t *s) { return s->dt; }
-double artemis_sim_tlim(const artemis_sim_t *s) { return s->tlim; }
-long artemis_sim_ncycle(const artemis_sim_t *s) { return s->ncycle; }
+double artemis_sim_time(const artemis_sim_t *s) { return s->p->time; }
+double artemis_sim_dt(const artemis_sim_t *s) { return s->p->dt; }
+double artemis_sim_tlim(const artemis_sim_t *s) { return s->p->tlim; }
+long artemis_sim_ncycle(const artemis_sim_t *s) { return s->p->ncycle; }
 long artemis_sim_local_zones(const artemis_sim_t *s) {
-  return static_cast<long>(s->nb) * s->mbnx[0] * s->mbnx[1] * s->mbnx[2];
+  return static_cast<long>(s->p->nb) * s->p->mbnx[0] * s->p->mbnx[1] * s->p->mbnx[2];
 }
 long artemis_sim_total_zones(const artemis_sim_t *s) {
-  return s->nblocks_global * s->mbnx[0] * s->mbnx[1] * s->mbnx[2];
+  return s->p->nblocks_global * s->p->mbnx[0] * s->p->mbnx[1] * s->p->mbnx[2];
 }
 int artemis_sim_block_level(const artemis_sim_t *s, int block) {
-  return (block >= 0 && block < s->nb) ? s->blocks[block].level : -1;
+  return (block >= 0 && block < s->p->nb) ? s->p->blocks[block].level : -1;
 }
-long artemis_sim_nblocks_global(const artemis_sim_t *s) { return s->nblocks_global; }
-int artemis_sim_uses_fused_path(const artemis_sim_t *s) { return s->use_fused ? 1 : 0; }
-int artemis_sim_uses_tuned_kernel(const artemis_sim_t *s) { return (s->use_fused && s->tuned) ? 1 : 0; }
+long artemis_sim_nblocks_global(const artemis_sim_t *s) { return s->p->nblocks_global; }
+int artemis_sim_uses_fused_path(const artemis_sim_t *s) { return s->p->use_fused ? 1 : 0; }
+int artemis_sim_uses_tuned_kernel(const artemis_sim_t *s) { return (s->p->use_fused && s->p->tuned) ? 1 : 0; }
 const char *artemis_sim_stage_kernel(const artemis_sim_t *s) {
-  if (!s->use_fused) return "per-task chain";
-  if (s->tuned) return "stage_fused_kernel";
-  if (s->general_variant < 0) return "general stage (not run yet)";
-  return s->general_variant == 1 ? "stage2d_kernel" : (s->general_variant == 2 ? "stage_fused_kernel<curvilinear>" : "stage_cell_kernel");
+  if (!s->p->use_fused) return "per-task chain";
+  if (s->p->tuned) return "stage_fused_kernel";
+  if (s->p->general_variant < 0) return "general stage (not run yet)";
+  return s->p->general_variant == 1 ? "stage2d_kernel" : (s->p->general_variant == 2 ? "stage_fused_kernel<curvilinear>" : "stage_cell_kernel");
 }
 int artemis_sim_set_path(artemis_sim_t *s, const char *which) {
   const std::string w = which ? which : "";
   if (w == "fused") {
-    if (!s->fused_possible) {
+    if (!s->p->fused_possible) {
       g_sim_err = "the fused paths do not cover gas diffusion";
       return 1;
     }
-    s->use_fused = true;
+    s->p->use_fused = true;
     return 0;
   }
   if (w == "unfused") {
-    GUARD(s->ensure_unfused(), return 1)
-    s->use_fused = false;
+    GUARD(s->p->ensure_unfused(), return 1)
+    s->p->use_fused = false;
     return 0;
   }
   g_sim_err = "path must be fused|unfused";
@@ -2505,56 +2534,56 @@ int artemis_sim_set_overlap(artemis_sim_t *s, int overlap) {
     g_sim_err = "overlap must be 0 (off), 1 (two launches) or 2 (in-kernel signalling)";
     return 1;
   }
-  s->overlap = overlap;
+  s->p->overlap = overlap;
   return 0;
 }
-void artemis_sim_set_kernel_timing(artemis_sim_t *s, int on) { s->time_kernels = on != 0; }
+void artemis_sim_set_kernel_timing(artemis_sim_t *s, int on) { s->p->time_kernels = on != 0; }
 int artemis_sim_set_dropin(artemis_sim_t *s, int on) {
-  if (on && !(s->use_fused && s->tuned)) {
+  if (on && !(s->p->use_fused && s->p->tuned)) {
     g_sim_err = "drop-in accounting applies to the tuned fused kernel only";
     return 1;
   }
-  s->dropin = on != 0;
+  s->p->dropin = on != 0;
   return 0;
 }
-int artemis_sim_overlap(const artemis_sim_t *s) { return s->overlap; }
+int artemis_sim_overlap(const artemis_sim_t *s) { return s->p->overlap; }
 int artemis_sim_nbody_force(artemis_sim_t *s, double *out, int reset) {
-  const int n = static_cast<int>(s->particles.size());
+  const int n = static_cast<int>(s->p->particles.size());
   if (!out) return n; // size query
-  std::vector<double> f = s->particle_force;
-  if (n && s->has_comm && s->nranks > 1 && s->comm.allreduce_sum(s->comm.ctx, f.data(), 7 * n)) return -1; // nbody_advance.cpp:123-131
+  std::vector<double> f = s->p->particle_force;
+  if (n && s->p->has_comm && s->p->nranks > 1 && s->p->comm.allreduce_sum(s->p->comm.ctx, f.data(), 7 * n)) return -1; // nbody_advance.cpp:123-131
   for (int q = 0; q < 7 * n; ++q) out[q] = f[q];
-  if (reset) std::fill(s->particle_force.begin(), s->particle_force.end(), 0.0);
+  if (reset) std::fill(s->p->particle_force.begin(), s->p->particle_force.end(), 0.0);
   return n;
 }
 void artemis_sim_species(const artemis_sim_t *s, int *ns_gas, int *ns_dust) {
-  if (ns_gas) *ns_gas = s->ns_gas;
-  if (ns_dust) *ns_dust = s->ns_dust;
+  if (ns_gas) *ns_gas = s->p->ns_gas;
+  if (ns_dust) *ns_dust = s->p->ns_dust;
 }
 void artemis_sim_dims(const artemis_sim_t *s, int *d) {
-  d[0] = s->nb, d[1] = s->ni, d[2] = s->nj, d[3] = s->nk, d[4] = s->is, d[5] = s->ie;
-  d[6] = s->js, d[7] = s->je, d[8] = s->ks, d[9] = s->ke, d[10] = s->ng;
+  d[0] = s->p->nb, d[1] = s->p->ni, d[2] = s->p->nj, d[3] = s->p->nk, d[4] = s->p->is, d[5] = s->p->ie;
+  d[6] = s->p->js, d[7] = s->p->je, d[8] = s->p->ks, d[9] = s->p->ke, d[10] = s->p->ng;
 }
 void artemis_sim_block_bounds(const artemis_sim_t *s, int b, double *o) {
-  for (int d = 0; d < 3; ++d) o[2 * d] = s->blocks[b].xmin[d], o[2 * d + 1] = s->blocks[b].xmax[d];
+  for (int d = 0; d < 3; ++d) o[2 * d] = s->p->blocks[b].xmin[d], o[2 * d + 1] = s->p->blocks[b].xmax[d];
 }
 int artemis_sim_get_field(artemis_sim_t *s, const char *field, int block, double *host_out) {
   const std::string f = field ? field : "";
-  if (block < 0 || block >= s->nb) {
+  if (block < 0 || block >= s->p->nb) {
     g_sim_err = "bad block";
     return -1;
   }
   int nv = -1;
   GUARD(
       {
-        s->materialise_cons();
+        s->p->materialise_cons();
         const Field *F = nullptr;
-        if (f == "gas.prim") F = &s->gprim[s->base];
-        else if (f == "gas.cons") F = &s->gu0;
-        else if (f == "dust.prim") F = &s->dprim[s->base];
-        else if (f == "dust.cons") F = &s->du0;
+        if (f == "gas.prim") F = &s->p->gprim[s->p->base];
+        else if (f == "gas.cons") F = &s->p->gu0;
+        else if (f == "dust.prim") F = &s->p->dprim[s->p->base];
+        else if (f == "dust.cons") F = &s->p->du0;
         else throw std::runtime_error("unknown field " + f);
-        const std::vector<Real> h = s->download(*F, block);
+        const std::vector<Real> h = s->p->download(*F, block);
         std::memcpy(host_out, h.data(), h.size() * sizeof(Real));
         nv = F->nvar;
       },
@@ -2563,18 +2592,18 @@ int artemis_sim_get_field(artemis_sim_t *s, const char *field, int block, double
 }
 int artemis_sim_history(artemis_sim_t *s, double *out) {
   int n = -1;
-  GUARD(n = s->history(out), return -1)
+  GUARD(n = s->p->history(out), return -1)
   return n;
 }
 int artemis_sim_errors(artemis_sim_t *s, double *out) {
   int n = -1;
-  GUARD(n = s->errors(out), return -1)
+  GUARD(n = s->p->errors(out), return -1)
   return n;
 }
-double artemis_sim_last_wall_seconds(const artemis_sim_t *s) { return s->last_wall; }
+double artemis_sim_last_wall_seconds(const artemis_sim_t *s) { return s->p->last_wall; }
 double artemis_sim_kernel_ms(const artemis_sim_t *s, long *nlaunch) {
-  if (nlaunch) *nlaunch = s->kernel_launches;
-  return s->kernel_launches ? s->kernel_ms_sum / s->kernel_launches : 0.0;
+  if (nlaunch) *nlaunch = s->p->kernel_launches;
+  return s->p->kernel_launches ? s->p->kernel_ms_sum / s->p->kernel_launches : 0.0;
 }
 
 } // extern "C"

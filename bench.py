@@ -375,7 +375,7 @@ def main():
                                              "in one launch)" if sim.stage_kernel.startswith("stage_fused_kernel") else
                                              "3 flux kernels + epilogue + PrimToCons (per-task chain)")),
                                "launch_ms": stage_ms, "launches_timed": 2 * args.steps, "algorithmic_bytes_per_launch": alg}
-        if args.workload == "ssheet_dust":
+        elif args.workload == "ssheet_dust":
             # B_alg per cell-stage = 8 B * 5 * (6 ns_gas + 4 ns_dust); one "launch" = one stage
             # of the general fused path (gas kernel + dust kernel + drag/aux/c2p finish)
             bps = 8.0 * 5.0 * (6 + 4 * args.dust)
@@ -395,7 +395,7 @@ def main():
                                               "launch per stage (2-D row march)") if kname == "stage2d_kernel" else
                                              "general fused stage: stage_cell_kernel<gas> + <dust> + simple_drag_kernel<finish>",
                                    "launch_ms": kms, "launches_timed": nlaunch, "algorithmic_bytes_per_launch": alg}
-        elif fused and nlaunch:
+        elif args.workload == "sedov3d" and fused and nlaunch:
             alg = ALG_BYTES_PER_CELL_STAGE * local_zones  # bytes per launch (one stage, one rank)
             achieved = alg / (kms * 1.0e-3) / 1.0e9
             # PMC counters cannot be read from inside the process: scripts/pmc_traffic.py measures them
