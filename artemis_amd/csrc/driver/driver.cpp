@@ -125,6 +125,18 @@ struct artemis_sim_impl {
   };
   std::vector<Region> regions;
   long nblocks_global = 0;
+  // adaptive refinement (<parthenon/mesh> refinement = adaptive, numlevel, derefine_count; <gas> refine_field,
+  // refine_type, refine_thr, deref_thr: gas.cpp:305-380).  The block tree of an adaptive run changes between cycles:
+  // the C handle then builds a new state on the new leaves (`forced_leaves`) and adopts the old one's data.
+  bool adaptive = false;
+  int amr_max_level = 0, derefine_count = 10;
+  int refine_field = 0; // 0 none, 1 gas density, 2 gas pressure
+  int refine_type = 0;  // 1 gradient (ScalarFirstDerivative), 2 magnitude (ScalarMagnitude)
+  double refine_thr = 0.0, deref_thr = 0.0;
+  bool have_forced = false;
+  std::vector<artemis_host::Leaf> forced_leaves, tree_leaves; // tree_leaves: the leaves this state was built on
+  std::vector<int> amr_tags();                    // AmrTag of every local block (-1 derefine, 0 same, +1 refine)
+  void adopt_state_from(artemis_sim_impl &old);   // copy / prolongate / restrict the conserved state, then re-derive
   struct DevArr { // raw device array owned by the driver
     void *p = nullptr;
     int n = 0;
@@ -443,9 +455,15 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
   // <parthenon/static_refinementN> level, x?min, x?max (inputs/disk/disk_cart.in:42,68-75)
   {
     const std::string ref = pin.GetOrAddString("parthenon/mesh", "refinement", "none");
-    if (ref == "adaptive") throw std::runtime_error("parthenon/mesh/refinement = adaptive: remeshing is not built (static refinement is)");
-    if (ref != "none" && ref != "static") throw std::runtime_error("parthenon/mesh/refinement must be none|static|adaptive");
-    if (ref == "static") {
+    if (ref != "none" && ref != "static" && ref != "adaptive") throw std::runtime_error("parthenon/mesh/refinement must be none|static|adaptive");
+    if (ref == "adaptive") {
+      adaptive = true;
+      amr_max_level = std::max(0, pin.GetOrAddInteger("parthenon/mesh", "numlevel", 1) - 1);
+      derefine_count = pin.GetOrAddInteger("parthenon/mesh", "derefine_count", 10);
+      if (nranks > 1) throw std::runtime_error("parthenon/mesh/refinement = adaptive runs on one rank in this build "
+                                               "(blocks are not migrated between ranks yet)");
+    }
+    if (ref == "static" || ref == "adaptive") {
       for (int q = 0; q < 64; ++q) {
         const std::string blk = "parthenon/static_refinement" + std::to_string(q);
         if (!pin.DoesBlockExist(blk)) continue;
@@ -460,7 +478,7 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
         }
         regions.push_back(r);
       }
-      multilevel = !regions.empty();
+      multilevel = !regions.empty() || adaptive;
     }
     if (multilevel) {
       if (ng % 2 != 0) throw std::runtime_error("multilevel meshes need an even number of ghost zones");
@@ -668,6 +686,18 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
     else if (r == "llf") riemann_gas = ARTEMIS_LLF;
     else throw std::runtime_error("Riemann solver (gas) not recognized.");
     cfl_gas = pin.GetOrAddReal("gas", "cfl", 0.8);
+    { // gas.cpp:305-380: the refinement criterion of the gas package
+      const std::string rf = pin.GetOrAddString("gas", "refine_field", "none");
+      if (rf != "none") {
+        if (rf != "density" && rf != "pressure") throw std::runtime_error("Only density or pressure based criterion currently supported!");
+        refine_field = (rf == "density") ? 1 : 2;
+        const std::string rt = pin.GetString("gas", "refine_type");
+        if (rt != "gradient" && rt != "magnitude") throw std::runtime_error("Only gradient or magnitude based criterion currently supported!");
+        refine_type = (rt == "gradient") ? 1 : 2;
+        refine_thr = pin.GetReal("gas", "refine_thr");
+        if (refine_type == 2) deref_thr = pin.GetReal("gas", "deref_thr");
+      }
+    }
     if (pin.GetOrAddString("gas", "eos", "ideal") != "ideal")
       throw std::runtime_error("only the ideal-gas EOS exists in the reference");
     gamma = pin.GetOrAddReal("gas", "gamma", 1.66666666667);
@@ -931,8 +961,11 @@ void artemis_sim_impl::build_mesh_multilevel() {
   artemis_host::BlockTree tree;
   tree.ndim = ndim;
   for (int d = 0; d < 3; ++d) tree.nrb[d] = nblk[d], tree.periodic[d] = (d < ndim) && mesh_bc[2 * d] == ARTEMIS_BC_PERIODIC;
+  if (have_forced) // an adaptive run's current tree, handed over by the C handle
+    for (const artemis_host::Leaf &lf : forced_leaves) tree.ensure(lf.level, lf.lx);
   for (const Region &r : regions) tree.add_region(r.level, r.lo, r.hi, xmin, xmax);
   const std::vector<artemis_host::Leaf> leaves = tree.leaves();
+  tree_leaves = leaves;
   ml.max_level = tree.max_level();
   nblocks_global = static_cast<long>(leaves.size());
   if (nblocks_global < nranks) throw std::runtime_error("fewer mesh blocks than ranks");
@@ -1946,6 +1979,148 @@ void artemis_sim_impl::problem_generator() {
 }
 
 // ---------------------------------------------------------------------------------------
+// Adaptive refinement.  Tagging = the gas package's CheckRefinementBlock (gas.cpp:305-380: ScalarFirstDerivative or
+// ScalarMagnitude of the density / pressure of species 0) on every local block; the tree update and the rebuild live
+// at the C handle (below), the data hand-over here.
+std::vector<int> artemis_sim_impl::amr_tags() {
+  std::vector<int> tags(nb, 0);
+  if (!refine_field || !refine_type) return tags;
+  materialise_cons(); // PrimToCons over the entire block also refreshes the pressure of the ghost zones
+  DevBuf scratch;
+  scratch.alloc(1);
+  const Field &P = gprim[base];
+  const int var = (refine_field == 1) ? 0 : 4 * ns_gas; // density / pressure of species 0
+  for (int b = 0; b < nb; ++b) {
+    artemis_amr_criterion_t a;
+    std::memset(&a, 0, sizeof a);
+    a.coords = coords, a.ndim = ndim, a.ni = ni, a.nj = nj, a.nk = nk;
+    a.geom = geom.p + 6 * b;
+    a.metric = metric.p ? metric.p + b * artemis::metric_block_stride(nj, nk) : nullptr;
+    a.field = P.var(b, var);
+    a.is = is, a.ie = ie, a.js = js, a.je = je, a.ks = ks, a.ke = ke;
+    a.refine_thr = refine_thr, a.deref_thr = deref_thr, a.scratch = scratch.p;
+    int tag = 0;
+    if (refine_type == 1) CK(artemis_hip_amr_first_derivative(&a, &tag, nullptr, stream), "ScalarFirstDerivative");
+    else CK(artemis_hip_amr_magnitude(&a, &tag, nullptr, stream), "ScalarMagnitude");
+    tags[b] = tag;
+  }
+  return tags;
+}
+
+// The new state takes over from the old one (same deck, another set of leaves): blocks that exist in both are copied,
+// children of a refined block are prolongated from it with ProlongateSharedMinMod, a derefined block is the
+// RestrictAverage of its children -- all on the CONSERVED variables (mass, momentum, energy: what refinement
+// must conserve), ghost zones of the old state included for the prolongation stencil.  Then the sequence every
+// (re)initialisation ends with: ConsToPrim, boundary exchange + conditions, PrimToCons (parthenon Mesh::Initialize).
+void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
+  old.materialise_cons();
+  CK(artemis_rt_stream_sync(old.stream), "sync");
+  typedef std::tuple<int, int, int, int> Key;
+  std::map<Key, int> where;
+  for (int b = 0; b < old.nb; ++b) where[Key(old.blocks[b].level, old.blocks[b].lx[0], old.blocks[b].lx[1], old.blocks[b].lx[2])] = b;
+  const int s3[3] = {is, js, ks}, n3[3] = {mbnx[0], mbnx[1], mbnx[2]};
+  auto refine_args = [&](const artemis_sim_impl &fine_sim, int fb, const artemis_sim_impl &coarse_sim, int cb, const int child[3],
+                         bool gas_vars) {
+    artemis_refine_t r;
+    std::memset(&r, 0, sizeof r);
+    r.coords = coords, r.ndim = ndim, r.nvar = gas_vars ? 6 * ns_gas : 4 * ns_dust;
+    r.fni = r.cni = ni, r.fnj = r.cnj = nj, r.fnk = r.cnk = nk;
+    r.fgeom = fine_sim.geom.p + 6 * fb, r.cgeom = coarse_sim.geom.p + 6 * cb;
+    r.fmetric = fine_sim.metric.p ? fine_sim.metric.p + fb * artemis::metric_block_stride(nj, nk) : nullptr;
+    r.cmetric = coarse_sim.metric.p ? coarse_sim.metric.p + cb * artemis::metric_block_stride(nj, nk) : nullptr;
+    const Field &F = gas_vars ? fine_sim.gu0 : fine_sim.du0, &Cc = gas_vars ? coarse_sim.gu0 : coarse_sim.du0;
+    r.fine = F.tab() + static_cast<size_t>(fb) * r.nvar, r.coarse = Cc.tab() + static_cast<size_t>(cb) * r.nvar;
+    int lo[3], hi[3];
+    for (int d = 0; d < 3; ++d) {
+      const bool act = d < ndim;
+      lo[d] = act ? s3[d] + child[d] * (n3[d] / 2) : s3[d];
+      hi[d] = act ? lo[d] + n3[d] / 2 - 1 : s3[d];
+    }
+    r.cis = lo[0], r.cie = hi[0], r.cjs = lo[1], r.cje = hi[1], r.cks = lo[2], r.cke = hi[2];
+    r.cib = lo[0], r.cjb = lo[1], r.ckb = lo[2], r.fib = s3[0], r.fjb = s3[1], r.fkb = s3[2];
+    return r;
+  };
+  for (int b = 0; b < nb; ++b) {
+    const Block &B = blocks[b];
+    const Key me(B.level, B.lx[0], B.lx[1], B.lx[2]);
+    auto it = where.find(me);
+    if (it != where.end()) { // unchanged block
+      if (do_gas) CK(artemis_rt_memcpy_d2d(gu0.var(b, 0), old.gu0.var(it->second, 0), sizeof(Real) * 6 * ns_gas * N, stream), "d2d");
+      if (do_dust) CK(artemis_rt_memcpy_d2d(du0.var(b, 0), old.du0.var(it->second, 0), sizeof(Real) * 4 * ns_dust * N, stream), "d2d");
+      continue;
+    }
+    int child[3] = {0, 0, 0};
+    Key par(B.level - 1, 0, 0, 0);
+    if (B.level > 0) {
+      int pl[3] = {0, 0, 0};
+      for (int d = 0; d < 3; ++d) pl[d] = (d < ndim) ? B.lx[d] >> 1 : 0, child[d] = (d < ndim) ? B.lx[d] & 1 : 0;
+      par = Key(B.level - 1, pl[0], pl[1], pl[2]);
+    }
+    it = (B.level > 0) ? where.find(par) : where.end();
+    if (it != where.end()) { // refined: prolongate my octant of the parent
+      if (do_gas) {
+        const artemis_refine_t r = refine_args(*this, b, old, it->second, child, true);
+        CK(artemis_hip_prolongate_minmod(&r, stream), "ProlongateSharedMinMod (remesh)");
+      }
+      if (do_dust) {
+        const artemis_refine_t r = refine_args(*this, b, old, it->second, child, false);
+        CK(artemis_hip_prolongate_minmod(&r, stream), "ProlongateSharedMinMod (remesh)");
+      }
+      continue;
+    }
+    // derefined: restrict my 2^ndim children
+    for (int c3 = 0; c3 < (ndim > 2 ? 2 : 1); ++c3)
+      for (int c2 = 0; c2 < (ndim > 1 ? 2 : 1); ++c2)
+        for (int c1 = 0; c1 < 2; ++c1) {
+          const int ch[3] = {c1, c2, c3};
+          const Key ck(B.level + 1, 2 * B.lx[0] + c1, (ndim > 1 ? 2 * B.lx[1] + c2 : 0), (ndim > 2 ? 2 * B.lx[2] + c3 : 0));
+          auto ic = where.find(ck);
+          if (ic == where.end()) throw std::runtime_error("remesh: a new block has no counterpart in the old mesh");
+          if (do_gas) {
+            const artemis_refine_t r = refine_args(old, ic->second, *this, b, ch, true);
+            CK(artemis_hip_restrict_average(&r, stream), "RestrictAverage (remesh)");
+          }
+          if (do_dust) {
+            const artemis_refine_t r = refine_args(old, ic->second, *this, b, ch, false);
+            CK(artemis_hip_restrict_average(&r, stream), "RestrictAverage (remesh)");
+          }
+        }
+  }
+  time = old.time, dt = old.dt, ncycle = old.ncycle, tlim = old.tlim, nlim = old.nlim;
+  particle_force = old.particle_force;
+  overlap = old.overlap, time_kernels = old.time_kernels;
+  base = 0;
+  if (getenv("ARTEMIS_AMR_DEBUG")) { // energy integral of the conserved state before and after the hand-over
+    auto total = [](artemis_sim_impl &S, int var) {
+      double sum = 0.0;
+      for (int b = 0; b < S.nb; ++b) {
+        const std::vector<Real> h = S.download(S.gu0, b);
+        for (int k = S.ks; k <= S.ke; ++k)
+          for (int j = S.js; j <= S.je; ++j)
+            for (int i = S.is; i <= S.ie; ++i)
+              sum += h[static_cast<size_t>(var) * S.N + (static_cast<size_t>(k) * S.nj + j) * S.ni + i] * S.cell_coords(b, k, j, i).volume();
+      }
+      return sum;
+    };
+    std::fprintf(stderr, "[amr] cycle %ld blocks %d -> %d  E %.17g -> %.17g  D %.17g -> %.17g\n", old.ncycle, old.nb, nb,
+                 total(old, 4 * ns_gas), total(*this, 4 * ns_gas), total(old, 0), total(*this, 0));
+  }
+  const artemis_pack_t p = make_pack(0);
+  // ConsToPrim takes the specific internal energy from the internal-energy variable, which is prolongated /
+  // restricted independently of the total energy; SetAuxillaryFields first re-derives it from the (conserved)
+  // total energy exactly as every stage does before its ConsToPrim (artemis_driver.cpp:251-252), so that a remesh
+  // conserves the total energy to round-off instead of to O(dx^2) of the kinetic energy.
+  if (do_gas) CK(artemis_hip_set_aux(&p, stream), "SetAuxillaryFields");
+  CK(artemis_hip_cons_to_prim(&p, stream), "ConsToPrim");
+  fill_ghosts(0);
+  CK(artemis_hip_prim_to_cons(&p, stream), "PrimToCons");
+  cons_valid = true;
+  CK(artemis_rt_stream_sync(stream), "sync");
+  // the step's own estimate came from the old mesh; new fine blocks may need less (never more than it allowed)
+  dt = std::min(dt, new_dt_unfused());
+}
+
+// ---------------------------------------------------------------------------------------
 // PostStepTasks -> EstimateTimestep (artemis_driver.cpp:279-297): min over packages, local.
 Real artemis_sim_impl::new_dt_unfused() {
   const artemis_pack_t p = make_pack(base);
@@ -2449,7 +2624,104 @@ struct artemis_sim {
   std::vector<std::string> overrides;
   bool has_comm = false;
   artemis_comm_t comm;
+  // adaptive runs: consecutive cycles a leaf has asked to be derefined (parthenon's derefine_count rule, upstream)
+  std::map<std::tuple<int, int, int, int>, int> deref_count;
+  long remeshes = 0;
 };
+
+// A fresh state for the same deck on a given set of leaves (the problem generator runs on it: tables, `ic` states
+// and -- during the initial refinement -- the initial condition itself at the new resolution).
+static std::unique_ptr<artemis_sim_impl> build_state(const artemis_sim &h, const std::vector<artemis_host::Leaf> *leaves) {
+  std::unique_ptr<artemis_sim_impl> np(new artemis_sim_impl());
+  if (leaves) np->forced_leaves = *leaves, np->have_forced = true;
+  std::vector<const char *> ov;
+  for (const std::string &o : h.overrides) ov.push_back(o.c_str());
+  try {
+    np->setup(h.deck.c_str(), static_cast<int>(ov.size()), ov.data(), h.has_comm ? &h.comm : nullptr);
+  } catch (...) {
+    release_impl(np);
+    throw;
+  }
+  return np;
+}
+
+// The tree an adaptive mesh moves to: leaves tagged +1 split (up to numlevel - 1 levels above the root grid),
+// sibling groups whose members have all asked for it `derefine_count` cycles in a row merge, and 2:1 balance over
+// faces, edges and corners is restored by the tree itself (BlockTree::refine) -- which also vetoes a merge that a
+// finer neighbour forbids.  Static regions stay refined.  Returns true if the set of leaves changed.
+static bool next_leaves(artemis_sim &h, const std::vector<int> &tags, bool allow_derefine,
+                        std::vector<artemis_host::Leaf> &out) {
+  artemis_sim_impl &S = *h.p;
+  typedef std::tuple<int, int, int, int> Key;
+  const std::vector<artemis_host::Leaf> &old = S.tree_leaves;
+  auto key = [](const artemis_host::Leaf &l) { return Key(l.level, l.lx[0], l.lx[1], l.lx[2]); };
+  std::map<Key, int> tag_of;
+  for (size_t q = 0; q < old.size(); ++q) tag_of[key(old[q])] = tags[q];
+  // derefinement counters
+  std::map<Key, int> cnt;
+  for (const artemis_host::Leaf &l : old) {
+    const Key k = key(l);
+    cnt[k] = (tag_of[k] < 0) ? h.deref_count[k] + 1 : 0;
+  }
+  h.deref_count.swap(cnt);
+  artemis_host::BlockTree t;
+  t.ndim = S.ndim;
+  for (int d = 0; d < 3; ++d) t.nrb[d] = S.nblk[d], t.periodic[d] = (d < S.ndim) && S.mesh_bc[2 * d] == ARTEMIS_BC_PERIODIC;
+  const int nch = 1 << S.ndim;
+  auto merge_ok = [&](const artemis_host::Leaf &l) { // all siblings are leaves that have waited long enough
+    if (!allow_derefine || l.level == 0) return false;
+    artemis_host::Loc par = t.parent(l.lx);
+    for (int c = 0; c < nch; ++c) {
+      artemis_host::Loc sib = {2 * par[0] + (c & 1), S.ndim > 1 ? 2 * par[1] + ((c >> 1) & 1) : 0, S.ndim > 2 ? 2 * par[2] + ((c >> 2) & 1) : 0};
+      auto it = h.deref_count.find(Key(l.level, sib[0], sib[1], sib[2]));
+      if (it == h.deref_count.end() || it->second < S.derefine_count) return false;
+    }
+    return true;
+  };
+  for (const artemis_host::Leaf &l : old) {
+    if (merge_ok(l)) t.ensure(l.level - 1, t.parent(l.lx)); // the parent becomes a leaf unless balance re-splits it
+    else t.ensure(l.level, l.lx);
+  }
+  for (const artemis_host::Leaf &l : old)
+    if (tag_of[key(l)] > 0 && l.level < S.amr_max_level) t.refine(l.level, l.lx);
+  for (const artemis_sim_impl::Region &r : S.regions) t.add_region(r.level, r.lo, r.hi, S.xmin, S.xmax);
+  out = t.leaves();
+  if (out.size() != old.size()) return true;
+  for (size_t q = 0; q < out.size(); ++q)
+    if (key(out[q]) != key(old[q])) return true;
+  return false;
+}
+
+// One remesh check (parthenon LoadBalancingAndAdaptiveMeshRefinement, upstream, after every cycle).  initial: the
+// loop of Mesh::Initialize -- refine only, and the problem generator fills the new mesh instead of a prolongation.
+static bool remesh(artemis_sim &h, bool initial) {
+  if (!h.p->adaptive || !h.p->refine_field) return false;
+  const std::vector<int> tags = h.p->amr_tags();
+  std::vector<artemis_host::Leaf> leaves;
+  if (!next_leaves(h, tags, !initial, leaves)) return false;
+  std::unique_ptr<artemis_sim_impl> np = build_state(h, &leaves);
+  if (!initial) {
+    try {
+      np->adopt_state_from(*h.p);
+    } catch (...) {
+      release_impl(np);
+      throw;
+    }
+  }
+  artemis_rt_device_sync();
+  release_impl(h.p);
+  h.p = std::move(np);
+  // counters of leaves that no longer exist are dropped; new leaves start at zero
+  std::map<std::tuple<int, int, int, int>, int> keep;
+  for (const artemis_host::Leaf &l : h.p->tree_leaves) {
+    const std::tuple<int, int, int, int> k(l.level, l.lx[0], l.lx[1], l.lx[2]);
+    auto it = h.deref_count.find(k);
+    keep[k] = (it == h.deref_count.end()) ? 0 : it->second;
+  }
+  h.deref_count.swap(keep);
+  h.remeshes++;
+  return true;
+}
 
 extern "C" {
 
@@ -2469,8 +2741,11 @@ artemis_sim_t *artemis_sim_create(const char *deck_text, int noverrides,
       s->comm = *comm;
       s->has_comm = true;
     }
-    s->p.reset(new artemis_sim_impl());
-    s->p->setup(deck_text, noverrides, overrides, comm);
+    s->p = build_state(*s, nullptr);
+    // Mesh::Initialize's refinement loop (upstream): tag the initial condition, refine, regenerate -- until the
+    // criterion is satisfied or numlevel is reached
+    for (int pass = 0; s->p->adaptive && pass <= s->p->amr_max_level; ++pass)
+      if (!remesh(*s, true)) break;
   };
   GUARD(build(), {
     artemis_sim_destroy(s);
@@ -2486,7 +2761,21 @@ void artemis_sim_destroy(artemis_sim_t *sim) {
 }
 long artemis_sim_evolve(artemis_sim_t *sim, long max_cycles) {
   long n = -1;
-  GUARD(n = sim->p->evolve(max_cycles), return -1)
+  if (!(sim->p->adaptive && sim->p->refine_field)) {
+    GUARD(n = sim->p->evolve(max_cycles), return -1)
+    return n;
+  }
+  // adaptive mesh: one cycle at a time, a remesh check after each (the state object may be replaced)
+  auto run = [&]() {
+    n = 0;
+    while (max_cycles < 0 || n < max_cycles) {
+      const long k = sim->p->evolve(1);
+      if (k <= 0) break;
+      n += k;
+      remesh(*sim, false);
+    }
+  };
+  GUARD(run(), return -1)
   return n;
 }
 double artemis_sim_time(const artemis_sim_t *s) { return s->p->time; }
@@ -2511,6 +2800,7 @@ const char *artemis_sim_stage_kernel(const artemis_sim_t *s) {
   if (s->p->general_variant < 0) return "general stage (not run yet)";
   return s->p->general_variant == 1 ? "stage2d_kernel" : (s->p->general_variant == 2 ? "stage_fused_kernel<curvilinear>" : "stage_cell_kernel");
 }
+long artemis_sim_remeshes(const artemis_sim_t *s) { return s->remeshes; }
 int artemis_sim_set_path(artemis_sim_t *s, const char *which) {
   const std::string w = which ? which : "";
   if (w == "fused") {

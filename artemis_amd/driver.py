@@ -187,6 +187,13 @@ class RcclComm:
         if self.L.artemis_comm_rccl_barrier(self.h):
             raise RuntimeError("RCCL barrier: " + self.L.artemis_comm_rccl_last_error().decode())
 
+    def _refresh_dims(self):
+        """Block layout of this rank (an adaptive mesh changes it between cycles)."""
+        d = (C.c_int * 11)()
+        self.L.artemis_sim_dims(self.h, d)
+        (self.nblocks, self.ni, self.nj, self.nk, self.is_, self.ie, self.js, self.je, self.ks,
+         self.ke, self.ng) = list(d)
+
     def close(self):
         if getattr(self, "h", None):
             self.L.artemis_comm_rccl_destroy(self.h)
@@ -211,6 +218,8 @@ def _declare(L):
         f.restype, f.argtypes = l, [vp]
     L.artemis_sim_uses_fused_path.argtypes = [vp]
     L.artemis_sim_uses_tuned_kernel.argtypes = [vp]
+    L.artemis_sim_remeshes.argtypes = [vp]
+    L.artemis_sim_remeshes.restype = C.c_long
     L.artemis_sim_stage_kernel.argtypes = [vp]
     L.artemis_sim_stage_kernel.restype = C.c_char_p
     L.artemis_sim_set_path.argtypes = [vp, C.c_char_p]
@@ -247,13 +256,17 @@ class Simulation:
         self.h = self.L.artemis_sim_create(text.encode(), len(overrides), ov, cptr)
         if not self.h:
             raise RuntimeError("artemis_sim_create: " + self.L.artemis_sim_last_error().decode())
+        self._refresh_dims()
+        ng_, nd_ = C.c_int(0), C.c_int(0)
+        self.L.artemis_sim_species(self.h, C.byref(ng_), C.byref(nd_))
+        self.ns_gas, self.ns_dust = ng_.value, nd_.value
+
+    def _refresh_dims(self):
+        """Block layout of this rank (an adaptive mesh changes it between cycles)."""
         d = (C.c_int * 11)()
         self.L.artemis_sim_dims(self.h, d)
         (self.nblocks, self.ni, self.nj, self.nk, self.is_, self.ie, self.js, self.je, self.ks,
          self.ke, self.ng) = list(d)
-        ng_, nd_ = C.c_int(0), C.c_int(0)
-        self.L.artemis_sim_species(self.h, C.byref(ng_), C.byref(nd_))
-        self.ns_gas, self.ns_dust = ng_.value, nd_.value
 
     def close(self):
         if getattr(self, "h", None):
@@ -270,6 +283,7 @@ class Simulation:
         n = self.L.artemis_sim_evolve(self.h, max_cycles)
         if n < 0:
             raise RuntimeError("artemis_sim_evolve: " + self.L.artemis_sim_last_error().decode())
+        self._refresh_dims()
         return n
 
     time = property(lambda s: s.L.artemis_sim_time(s.h))
@@ -281,6 +295,7 @@ class Simulation:
     uses_fused_path = property(lambda s: bool(s.L.artemis_sim_uses_fused_path(s.h)))
     uses_tuned_kernel = property(lambda s: bool(s.L.artemis_sim_uses_tuned_kernel(s.h)))
     stage_kernel = property(lambda s: s.L.artemis_sim_stage_kernel(s.h).decode())
+    remeshes = property(lambda s: s.L.artemis_sim_remeshes(s.h))  # adaptive meshes: tree changes so far
     last_wall_seconds = property(lambda s: s.L.artemis_sim_last_wall_seconds(s.h))
 
     def set_path(self, which):

@@ -97,6 +97,9 @@ int artemis_sim_uses_tuned_kernel(const artemis_sim_t *sim);
 /* name of the kernel family the stages run on: "stage_fused_kernel" (tuned 2.5-D), "stage2d_kernel" (2-D row march),
  * "stage_cell_kernel" (cell-centred general stage) or "per-task chain"; static storage */
 const char *artemis_sim_stage_kernel(const artemis_sim_t *sim);
+/* <parthenon/mesh> refinement = adaptive: how many times the block tree has changed so far (the initial
+ * refinement passes included).  The block layout (artemis_sim_dims, block bounds / levels) changes with it. */
+long artemis_sim_remeshes(const artemis_sim_t *sim);
 /* which: "fused" | "unfused"; selects the kernel path (fused only where supported). */
 int artemis_sim_set_path(artemis_sim_t *sim, const char *which);
 /* Halo exchange on a second stream concurrently with interior compute (fused path, remote

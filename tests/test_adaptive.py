@@ -1,0 +1,120 @@
+"""Adaptive mesh refinement (<parthenon/mesh> refinement = adaptive) through the HIP driver, on the reference's own
+AMR decks (inputs/blast/blast_amr.in, inputs/linwave/linear_wave_amr.in; the reference has no regression test on
+them).  The remeshing logic restates Parthenon's (absent submodule) from its published behaviour: tag with the gas
+package's criterion after every cycle, split tagged leaves up to numlevel - 1, merge sibling groups that asked for it
+derefine_count cycles in a row, keep 2:1 balance, prolongate / restrict the conserved variables with Artemis' own
+operators, then ConsToPrim -> boundary exchange -> PrimToCons.  PARITY UNPINNED against Parthenon; checked here:
+conservation across remeshes, that the fine levels follow the feature, symmetry, derefinement, and accuracy against
+uniform meshes."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DECK = lambda *p: os.path.join(ROOT, "inputs", *p)
+
+
+def levels(s):
+    lv = [s.block_level(b) for b in range(s.nblocks)]
+    return {l: lv.count(l) for l in sorted(set(lv))}
+
+
+def cover(s):
+    """total interior volume fraction check: sum over blocks of (zones x 4^-level) == root zones"""
+    return sum(4.0 ** (-s.block_level(b)) for b in range(s.nblocks))
+
+
+def test_blast_amr_deck_initial_mesh_and_tracking(hiplib):
+    """blast_amr.in as shipped: Mesh::Initialize's refinement loop puts three levels around the blast (the problem
+    generator fills every level: no prolongation of the initial condition); the level-2 blocks stay on the shock as it
+    expands, mass is conserved to round-off across ~10 remeshes, the tree stays symmetric about theta = pi/4 and derefines behind the shock, and the
+    leaves always tile the root mesh."""
+    from artemis_amd.driver import Simulation
+    s = Simulation(DECK("blast", "blast_amr.in"), [])
+    assert not s.uses_fused_path and s.remeshes >= 2
+    lv0 = levels(s)
+    assert set(lv0) == {0, 1, 2} and cover(s) == 256.0
+    # the finest blocks sit at the blast centre (r = 2.5, theta = pi/4)
+    fine = [s.block_bounds(b) for b in range(s.nblocks) if s.block_level(b) == 2]
+    assert any(bb[0] <= 2.5 <= bb[1] and bb[2] <= np.pi / 4 <= bb[3] for bb in fine)
+    h0 = s.history()
+    n_fine0, r0 = lv0[2], s.remeshes
+    s.evolve(300)
+    h1 = s.history()
+    lv1 = levels(s)
+    assert s.remeshes > r0 + 3 and lv1[2] > n_fine0 and cover(s) == 256.0
+    assert abs(h1[0] - h0[0]) < 1e-13 * h0[0]
+    # the tree mirrors about theta = pi/4 (the blast centre): level map on the finest block grid (64 x 64)
+    m = np.zeros((64, 64), int)
+    for b in range(s.nblocks):
+        x = s.block_bounds(b)
+        i0, i1 = int(round((x[0] - 1.0) / 4.0 * 64)), int(round((x[1] - 1.0) / 4.0 * 64))
+        j0, j1 = int(round(x[2] / (np.pi / 2) * 64)), int(round(x[3] / (np.pi / 2) * 64))
+        m[j0:j1, i0:i1] = s.block_level(b)
+    assert np.array_equal(m, m[::-1, :])
+    # ... and has derefined behind the shock: the blast centre is no longer on the finest level
+    jc, ic = 32, int((2.5 - 1.0) / 4.0 * 64)
+    assert m[jc, ic] < 2 and m.max() == 2
+    # the shock is inside level-2 blocks: the largest pressure jump of the mesh lies in one of them
+    best = (-1.0, None)
+    for b in range(s.nblocks):
+        P = s.interior(s.field("gas.prim", b))[4, 0]
+        g = max(np.abs(np.diff(P, axis=0)).max(), np.abs(np.diff(P, axis=1)).max())
+        if g > best[0]:
+            best = (g, s.block_level(b))
+    assert best[1] == 2
+    for b in range(s.nblocks):
+        assert np.isfinite(s.field("gas.prim", b)[[0, 1, 2, 3, 5]]).all()
+    s.close()
+
+
+def test_linear_wave_amr_deck_conserves_and_converges(hiplib):
+    """linear_wave_amr.in as shipped for one period: the refined band rides on the crests (blocks are created ahead of
+    it and merged behind it after derefine_count cycles), mass / momentum / energy are conserved to round-off across
+    every remesh (smooth flow: the prolongation is conservative and no floor acts), and the error after one period
+    lies between the uniform fine and uniform coarse meshes'."""
+    from artemis_amd.driver import Simulation
+    ov = ["problem/nperiod=1"]
+    s = Simulation(DECK("linwave", "linear_wave_amr.in"), ov)
+    lv0 = levels(s)
+    assert set(lv0) == {0, 1} and cover(s) == 32.0
+    h0 = s.history()
+    seen_merge, prev = False, lv0[1]
+    while s.time < s.tlim:
+        if s.evolve(20) == 0:
+            break
+        cur = levels(s).get(1, 0)
+        seen_merge = seen_merge or cur < prev
+        prev = cur
+        assert cover(s) == 32.0
+    h1 = s.history()
+    assert s.remeshes > 10 and seen_merge
+    scale = np.abs(h0).max()  # mass, three momenta, total energy (the internal-energy integral is not conserved)
+    assert np.allclose(h1[:5], h0[:5], rtol=0, atol=2e-13 * scale), (h1[:5] - h0[:5])
+    e_amr = s.errors()[0]
+    s.close()
+    base = ["problem/nperiod=1", "parthenon/mesh/refinement=none", "gas/refine_field=none"]
+    c = Simulation(DECK("linwave", "linear_wave_amr.in"), base)
+    c.evolve()
+    f = Simulation(DECK("linwave", "linear_wave_amr.in"), base + ["parthenon/mesh/nx1=256", "parthenon/mesh/nx2=128"])
+    f.evolve()
+    e_c, e_f = c.errors()[0], f.errors()[0]
+    c.close(), f.close()
+    assert e_f < e_amr < 1.05 * e_c, (e_f, e_amr, e_c)
+
+
+def test_adaptive_mesh_without_a_trigger_equals_the_static_root_mesh(hiplib):
+    """refinement = adaptive with a criterion that never fires: no remesh, and the run equals refinement = static with
+    no region (the same multilevel code path on a one-level tree), bit for bit."""
+    from artemis_amd.driver import Simulation
+    ov = ["problem/nperiod=1", "parthenon/time/nlim=30", "gas/refine_thr=2.0", "gas/deref_thr=0.0"]
+    a = Simulation(DECK("linwave", "linear_wave_amr.in"), ov)
+    b = Simulation(DECK("linwave", "linear_wave_amr.in"), ov + ["parthenon/mesh/refinement=none", "gas/refine_field=none"])
+    b.set_path("unfused")
+    a.evolve(), b.evolve()
+    assert a.remeshes == 0 and a.nblocks == b.nblocks == 32 and a.dt == b.dt
+    for q in range(32):
+        assert np.array_equal(a.interior(a.field("gas.prim", q)), b.interior(b.field("gas.prim", q))), q
+    a.close(), b.close()
