@@ -918,10 +918,66 @@ int artemis_hip_ml_flux_correction(const artemis_pack_t *p, const artemis_ml_op_
   return 0;
 }
 
-int artemis_hip_restrict_average(const artemis_refine_t *, void *) { return bad("refinement operators: GPU library only"); }
-int artemis_hip_prolongate_minmod(const artemis_refine_t *, void *) { return bad("refinement operators: GPU library only"); }
-int artemis_hip_amr_first_derivative(const artemis_amr_criterion_t *, int *, double *, void *) { return bad("refinement criteria: GPU library only"); }
-int artemis_hip_amr_magnitude(const artemis_amr_criterion_t *, int *, double *, void *) { return bad("refinement criteria: GPU library only"); }
+} // extern "C" (helpers with C++ linkage)
+namespace {
+// An oracle Sim on an index space given by its edge table {x1f0, dx1, ...} and array extents (ghosts included in
+// the active dimensions), with room for `nvar` cell-centred arrays in its gas-primitive slots.
+Sim *sim_on(int coords, int ndim, int ng, int ni, int nj, int nk, const double *g, int nvar) {
+  oracle_cfg c;
+  std::memset(&c, 0, sizeof c);
+  c.ng = ng;
+  c.nx1 = ni - 2 * ng, c.nx2 = (ndim > 1) ? nj - 2 * ng : 1, c.nx3 = (ndim > 2) ? nk - 2 * ng : 1;
+  c.ns_gas = (nvar + 5) / 6, c.ns_dust = 0;
+  c.gamma = 1.4, c.dfloor_gas = 1e-300, c.siefloor_gas = 1e-300, c.cfl_gas = 1.0, c.cfl_dust = 1.0;
+  for (int i = 0; i < 6; ++i) c.bc[i] = BC_NONE;
+  c.integrator = INT_RK2;
+  c.coords = coords;
+  const int gh[3] = {ng, ndim > 1 ? ng : 0, ndim > 2 ? ng : 0};
+  const int nx[3] = {c.nx1, c.nx2, c.nx3};
+  double lo[3], hi[3];
+  for (int d = 0; d < 3; ++d) lo[d] = g[2 * d] + gh[d] * g[2 * d + 1], hi[d] = lo[d] + nx[d] * g[2 * d + 1];
+  c.x1min = lo[0], c.x1max = hi[0], c.x2min = lo[1], c.x2max = hi[1], c.x3min = lo[2], c.x3max = hi[2];
+  Sim *s = static_cast<Sim *>(oracle_create(&c));
+  for (int d = 0; d < 3; ++d) s->f0[d] = g[2 * d], s->dx[d] = g[2 * d + 1];
+  return s;
+}
+int refine_op(const artemis_refine_t *r, bool prolong) {
+  // ghost depth: the first active index of the fine / coarse arrays is where interior starts (fib / cib anchors are
+  // given relative to it by the callers of this test double: the driver passes is, js, ks)
+  const int gf = r->fib;
+  Sim *f = sim_on(r->coords, r->ndim, gf, r->fni, r->fnj, r->fnk, r->fgeom, r->nvar);
+  Sim *c = sim_on(r->coords, r->ndim, gf, r->cni, r->cnj, r->cnk, r->cgeom, r->nvar);
+  for (int v = 0; v < r->nvar; ++v) {
+    std::memcpy(f->gprim.data() + static_cast<size_t>(v) * f->N, r->fine[v], f->N * sizeof(Real));
+    std::memcpy(c->gprim.data() + static_cast<size_t>(v) * c->N, r->coarse[v], c->N * sizeof(Real));
+  }
+  const int rr[12] = {r->cis, r->cie, r->cjs, r->cje, r->cks, r->cke, r->cib, r->cjb, r->ckb, r->fib, r->fjb, r->fkb};
+  if (prolong) {
+    oracle_prolongate_minmod(f, c, rr);
+    for (int v = 0; v < r->nvar; ++v) std::memcpy(r->fine[v], f->gprim.data() + static_cast<size_t>(v) * f->N, f->N * sizeof(Real));
+  } else {
+    oracle_restrict_average(f, c, rr);
+    for (int v = 0; v < r->nvar; ++v) std::memcpy(r->coarse[v], c->gprim.data() + static_cast<size_t>(v) * c->N, c->N * sizeof(Real));
+  }
+  oracle_destroy(f), oracle_destroy(c);
+  return 0;
+}
+int criterion(const artemis_amr_criterion_t *a, int *tag, double *maxval, bool magnitude) {
+  Sim *s = sim_on(a->coords, a->ndim, a->is, a->ni, a->nj, a->nk, a->geom, 1);
+  std::memcpy(s->gprim.data(), a->field, s->N * sizeof(Real));
+  double m = 0.0;
+  const int t = magnitude ? oracle_amr_magnitude(s, 0, a->refine_thr, a->deref_thr, &m) : oracle_amr_first_derivative(s, 0, a->refine_thr, &m);
+  oracle_destroy(s);
+  if (tag) *tag = t;
+  if (maxval) *maxval = m;
+  return 0;
+}
+} // namespace
+extern "C" {
+int artemis_hip_restrict_average(const artemis_refine_t *r, void *) { return refine_op(r, false); }
+int artemis_hip_prolongate_minmod(const artemis_refine_t *r, void *) { return refine_op(r, true); }
+int artemis_hip_amr_first_derivative(const artemis_amr_criterion_t *a, int *tag, double *mx, void *) { return criterion(a, tag, mx, false); }
+int artemis_hip_amr_magnitude(const artemis_amr_criterion_t *a, int *tag, double *mx, void *) { return criterion(a, tag, mx, true); }
 int artemis_rt_set_device(int) { return 0; }
 void *artemis_rt_malloc(size_t n) { return std::calloc(1, n ? n : 8); }
 void artemis_rt_free(void *p) { std::free(p); }

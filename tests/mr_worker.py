@@ -32,7 +32,9 @@ def main():
         sim.set_overlap(True)
     n = sim.evolve(spec.get("cycles", -1))
     out = {"ncycle": sim.ncycle, "time": sim.time, "dt": sim.dt, "n": n, "nblocks": sim.nblocks,
-           "fused": sim.uses_fused_path, "tuned": sim.uses_tuned_kernel}
+           "fused": sim.uses_fused_path, "tuned": sim.uses_tuned_kernel, "remeshes": sim.remeshes,
+           "levels": [sim.block_level(b) for b in range(sim.nblocks)]}
+    out["nblocks"] = sim.nblocks  # (an adaptive mesh: the count after the run)
     hist = sim.history()
     errs = sim.errors()
     arrays = {}

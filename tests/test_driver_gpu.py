@@ -168,8 +168,12 @@ def test_driver_rejects_out_of_scope(hiplib):
         Simulation(DECK("blast", "blast.in"), ["physics/radiation=true"])
     with pytest.raises(RuntimeError, match="only `none`"):  # REBOUND integration: not built (static particles are)
         Simulation(DECK("blast", "blast.in"), ["physics/nbody=true"])
-    with pytest.raises(RuntimeError, match="adaptive"):
-        Simulation(DECK("blast", "blast.in"), ["parthenon/mesh/refinement=adaptive"])
+    # refined meshes (static or adaptive): what the block-graph exchange does not cover is refused, not ignored
+    with pytest.raises(RuntimeError, match="even number of ghost zones"):
+        Simulation(DECK("blast", "blast.in"), ["parthenon/mesh/refinement=adaptive", "parthenon/mesh/nghost=3",
+                                               "gas/reconstruct=ppm"])
+    with pytest.raises(RuntimeError, match="user boundary condition"):
+        Simulation(DECK("ssheet", "ssheet.in"), ["parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=2"])
     with pytest.raises(RuntimeError, match="not recognized"):
         Simulation(DECK("blast", "blast.in"), ["artemis/coordinates=toroidal"])
     with pytest.raises(RuntimeError, match="Cartesian-only"):
