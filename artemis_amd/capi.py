@@ -201,6 +201,7 @@ def load():
         "artemis_hip_restrict_average": (i, [C.POINTER(Refine), vp]),
         "artemis_hip_prolongate_minmod": (i, [C.POINTER(Refine), vp]),
         "artemis_hip_amr_first_derivative": (i, [C.POINTER(AmrCriterion), C.POINTER(C.c_int), C.POINTER(C.c_double), vp]),
+        "artemis_hip_amr_block_maxima": (i, [PPk, C.c_int, C.c_int, vp, vp]),
         "artemis_hip_amr_magnitude": (i, [C.POINTER(AmrCriterion), C.POINTER(C.c_int), C.POINTER(C.c_double), vp]),
         "artemis_hip_zero_diffusion_flux": (i, [PPk, vp]),
         "artemis_hip_viscous_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
@@ -263,7 +264,7 @@ EXPORTS_HIP = [
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_nbody_gravity", "artemis_hip_rotating_frame_force",
     "artemis_hip_ml_exchange", "artemis_hip_ml_flux_correction", "artemis_hip_ml_restrict_halos", "artemis_hip_ml_prolongate",
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",
-    "artemis_hip_stage_general", "artemis_hip_stage_general_variant", "artemis_hip_stage_epilogue", "artemis_hip_restrict_average",
+    "artemis_hip_stage_general", "artemis_hip_stage_general_variant", "artemis_hip_stage_epilogue", "artemis_hip_amr_block_maxima", "artemis_hip_restrict_average",
     "artemis_hip_prolongate_minmod", "artemis_hip_amr_first_derivative", "artemis_hip_amr_magnitude",
     "artemis_hip_zero_diffusion_flux",
     "artemis_hip_viscous_flux", "artemis_hip_zero_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",

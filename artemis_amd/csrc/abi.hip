@@ -827,6 +827,16 @@ int artemis_hip_amr_magnitude(const artemis_amr_criterion_t *a, int *tag, double
   return amr_criterion(a, 1, tag, maxval, stream);
 }
 
+int artemis_hip_amr_block_maxima(const artemis_pack_t *p, int field, int magnitude, double *maxima_dev, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (!maxima_dev || field < 0 || field > 1 || !p->gas.nspecies || !p->gas.prim)
+    return fail(ARTEMIS_HIP_EINVAL, "amr_block_maxima: field must be 0 (density) or 1 (pressure) of a gas pack, maxima_dev non-null");
+  if (!magnitude && p->nghost < 2) return fail(ARTEMIS_HIP_EINVAL, "ScalarFirstDerivative needs two ghost zones");
+  const artemis::PackView P = artemis::make_pack_view(*p);
+  artemis::launch_pack_criterion(P, field == 0 ? 0 : 4 * p->gas.nspecies, magnitude, maxima_dev, S(stream));
+  return after_launch("refinement criterion (pack)");
+}
+
 int artemis_hip_advance_dt(double *state, double tlim, int nstages, const double *beta, void *stream) {
   if (int rc = device_ready()) return rc;
   if (!state || !beta || nstages < 1 || nstages > 3) return fail(ARTEMIS_HIP_EINVAL, "bad advance_dt arguments");

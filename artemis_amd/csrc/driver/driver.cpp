@@ -1986,23 +1986,21 @@ std::vector<int> artemis_sim_impl::amr_tags() {
   std::vector<int> tags(nb, 0);
   if (!refine_field || !refine_type) return tags;
   materialise_cons(); // PrimToCons over the entire block also refreshes the pressure of the ghost zones
-  DevBuf scratch;
-  scratch.alloc(1);
-  const Field &P = gprim[base];
-  const int var = (refine_field == 1) ? 0 : 4 * ns_gas; // density / pressure of species 0
+  // one launch for all blocks, one copy back (artemis_hip_amr_block_maxima); thresholds as the per-block calls
+  DevBuf maxima;
+  maxima.alloc(nb);
+  const artemis_pack_t p = make_pack(base);
+  CK(artemis_hip_amr_block_maxima(&p, refine_field == 1 ? 0 : 1, refine_type == 2 ? 1 : 0, maxima.p, stream), "refinement criterion");
+  std::vector<double> h(nb);
+  CK(artemis_rt_memcpy_d2h(h.data(), maxima.p, sizeof(double) * nb, stream), "d2h");
+  CK(artemis_rt_stream_sync(stream), "sync");
   for (int b = 0; b < nb; ++b) {
-    artemis_amr_criterion_t a;
-    std::memset(&a, 0, sizeof a);
-    a.coords = coords, a.ndim = ndim, a.ni = ni, a.nj = nj, a.nk = nk;
-    a.geom = geom.p + 6 * b;
-    a.metric = metric.p ? metric.p + b * artemis::metric_block_stride(nj, nk) : nullptr;
-    a.field = P.var(b, var);
-    a.is = is, a.ie = ie, a.js = js, a.je = je, a.ks = ks, a.ke = ke;
-    a.refine_thr = refine_thr, a.deref_thr = deref_thr, a.scratch = scratch.p;
-    int tag = 0;
-    if (refine_type == 1) CK(artemis_hip_amr_first_derivative(&a, &tag, nullptr, stream), "ScalarFirstDerivative");
-    else CK(artemis_hip_amr_magnitude(&a, &tag, nullptr, stream), "ScalarMagnitude");
-    tags[b] = tag;
+    if (refine_type == 1) { // ScalarFirstDerivative (amr_criteria.hpp:122-131); 1-D blocks are never tagged
+      if (ndim == 1) continue;
+      tags[b] = (h[b] > refine_thr) ? 1 : ((h[b] < 0.25 * refine_thr) ? -1 : 0);
+    } else { // ScalarMagnitude (:160-167)
+      tags[b] = (h[b] > refine_thr) ? 1 : ((h[b] < deref_thr) ? -1 : 0);
+    }
   }
   return tags;
 }

@@ -117,8 +117,7 @@ ADEV void block_max(double m, double *out) {
   if ((threadIdx.x & 63) == 0 && m > 0.0)
     atomicMax(reinterpret_cast<unsigned long long *>(out), static_cast<unsigned long long>(__double_as_longlong(m)));
 }
-__global__ __launch_bounds__(256) void first_derivative_kernel(const CriterionView C) {
-  const artemis_amr_criterion_t &a = C.a;
+ADEV void first_derivative_body(const artemis_amr_criterion_t &a) {
   const bool X3 = a.ndim > 2;
   const int i0 = a.is - 1, j0 = a.js - 1, k0 = X3 ? a.ks - 1 : a.ks;
   const int ni = a.ie - a.is + 3, nj = a.je - a.js + 3, nk = X3 ? a.ke - a.ks + 3 : 1;
@@ -152,8 +151,7 @@ __global__ __launch_bounds__(256) void first_derivative_kernel(const CriterionVi
   }
   block_max(eps, a.scratch);
 }
-__global__ __launch_bounds__(256) void magnitude_kernel(const CriterionView C) {
-  const artemis_amr_criterion_t &a = C.a;
+ADEV void magnitude_body(const artemis_amr_criterion_t &a) {
   const int ni = a.ie - a.is + 1, nj = a.je - a.js + 1, nk = a.ke - a.ks + 1;
   const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
   double m = 0.0;
@@ -165,7 +163,46 @@ __global__ __launch_bounds__(256) void magnitude_kernel(const CriterionView C) {
   }
   block_max(m, a.scratch);
 }
+__global__ __launch_bounds__(256) void first_derivative_kernel(const CriterionView C) { first_derivative_body(C.a); }
+__global__ __launch_bounds__(256) void magnitude_kernel(const CriterionView C) { magnitude_body(C.a); }
+// every block of a pack in one launch (blockIdx.y = mesh block): the criterion of variable `var` of the gas
+// primitives, maxima[b] receives the block maximum
+struct PackCriterion {
+  artemis_amr_criterion_t a; // geom / metric / field / scratch are filled per block in the kernel
+  double *const *prim;
+  int nvar, var;
+  const double *geom, *metric;
+  long metric_stride;
+  double *maxima;
+};
+template <bool MAGNITUDE>
+__global__ __launch_bounds__(256) void pack_criterion_kernel(const PackCriterion C) {
+  artemis_amr_criterion_t a = C.a;
+  const int b = blockIdx.y;
+  a.geom = C.geom + 6 * b, a.metric = C.metric ? C.metric + b * C.metric_stride : nullptr;
+  a.field = C.prim[b * C.nvar + C.var], a.scratch = C.maxima + b;
+  if constexpr (MAGNITUDE) magnitude_body(a);
+  else first_derivative_body(a);
+}
 } // namespace
+
+void launch_pack_criterion(const PackView &P, int var, int magnitude, double *maxima, hipStream_t s) {
+  PackCriterion C;
+  C.a.coords = P.coords, C.a.ndim = P.ndim, C.a.ni = P.ni, C.a.nj = P.nj, C.a.nk = P.nk;
+  C.a.is = P.is, C.a.ie = P.ie, C.a.js = P.js, C.a.je = P.je, C.a.ks = P.ks, C.a.ke = P.ke;
+  C.a.refine_thr = C.a.deref_thr = 0.0;
+  C.prim = P.gas.prim, C.nvar = 6 * P.gas.ns, C.var = var;
+  C.geom = P.geom, C.metric = P.metric, C.metric_stride = metric_block_stride(P.nj, P.nk);
+  C.maxima = maxima;
+  (void)hipMemsetAsync(maxima, 0, sizeof(double) * P.nb, s);
+  const bool X3 = P.ndim > 2;
+  const long n = magnitude ? static_cast<long>(P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1)
+                           : static_cast<long>(P.ie - P.is + 3) * (P.je - P.js + 3) * (X3 ? P.ke - P.ks + 3 : 1);
+  if (n <= 0 || P.nb <= 0) return;
+  const dim3 grid((n + 255) / 256, P.nb);
+  if (magnitude) hipLaunchKernelGGL(pack_criterion_kernel<true>, grid, dim3(256), 0, s, C);
+  else hipLaunchKernelGGL(pack_criterion_kernel<false>, grid, dim3(256), 0, s, C);
+}
 
 void launch_refine(const artemis_refine_t &r, int prolongate, hipStream_t s) {
   RefineView R;

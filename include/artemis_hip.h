@@ -550,6 +550,12 @@ typedef struct artemis_amr_criterion {
 } artemis_amr_criterion_t;
 int artemis_hip_amr_first_derivative(const artemis_amr_criterion_t *a, int *tag, double *maxval, void *stream);
 int artemis_hip_amr_magnitude(const artemis_amr_criterion_t *a, int *tag, double *maxval, void *stream);
+/* The same block maxima for EVERY block of a pack in one launch: field = 0 (gas density of species 0) or 1 (gas
+ * pressure of species 0), magnitude = 0 (ScalarFirstDerivative) or 1 (ScalarMagnitude); maxima_dev = DEVICE array of
+ * p->nblocks doubles.  Asynchronous on `stream` (copy the maxima back and compare with the thresholds as above):
+ * an adaptive mesh of thousands of small blocks is tagged with one launch and one copy instead of a launch and a
+ * synchronisation per block. */
+int artemis_hip_amr_block_maxima(const artemis_pack_t *p, int field, int magnitude, double *maxima_dev, void *stream);
 
 /* Device-side SetGlobalTimeStep (parthenon EvolutionDriver, upstream): state = DEVICE
  * {time, dt, dt_est, beta_dt[0..2]}.  time += dt; dt = min(2*dt, dt_est), clipped so that

@@ -978,6 +978,22 @@ int artemis_hip_restrict_average(const artemis_refine_t *r, void *) { return ref
 int artemis_hip_prolongate_minmod(const artemis_refine_t *r, void *) { return refine_op(r, true); }
 int artemis_hip_amr_first_derivative(const artemis_amr_criterion_t *a, int *tag, double *mx, void *) { return criterion(a, tag, mx, false); }
 int artemis_hip_amr_magnitude(const artemis_amr_criterion_t *a, int *tag, double *mx, void *) { return criterion(a, tag, mx, true); }
+int artemis_hip_amr_block_maxima(const artemis_pack_t *p, int field, int magnitude, double *maxima, void *) {
+  const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1), g = p->nghost;
+  for (int b = 0; b < p->nblocks; ++b) {
+    artemis_amr_criterion_t a;
+    std::memset(&a, 0, sizeof a);
+    a.coords = p->coords, a.ndim = ndim;
+    a.ni = p->nx1 + 2 * g, a.nj = (ndim > 1) ? p->nx2 + 2 * g : 1, a.nk = (ndim > 2) ? p->nx3 + 2 * g : 1;
+    a.geom = p->geom + 6 * b;
+    a.field = p->gas.prim[b * 6 * p->gas.nspecies + (field == 0 ? 0 : 4 * p->gas.nspecies)];
+    a.is = g, a.ie = g + p->nx1 - 1, a.js = (ndim > 1) ? g : 0, a.je = a.js + p->nx2 - 1, a.ks = (ndim > 2) ? g : 0, a.ke = a.ks + p->nx3 - 1;
+    a.refine_thr = 1e300, a.deref_thr = -1e300;
+    int tag;
+    criterion(&a, &tag, maxima + b, magnitude != 0);
+  }
+  return 0;
+}
 int artemis_rt_set_device(int) { return 0; }
 void *artemis_rt_malloc(size_t n) { return std::calloc(1, n ? n : 8); }
 void artemis_rt_free(void *p) { std::free(p); }
