@@ -460,8 +460,6 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
       adaptive = true;
       amr_max_level = std::max(0, pin.GetOrAddInteger("parthenon/mesh", "numlevel", 1) - 1);
       derefine_count = pin.GetOrAddInteger("parthenon/mesh", "derefine_count", 10);
-      if (nranks > 1) throw std::runtime_error("parthenon/mesh/refinement = adaptive runs on one rank in this build "
-                                               "(blocks are not migrated between ranks yet)");
     }
     if (ref == "static" || ref == "adaptive") {
       for (int q = 0; q < 64; ++q) {
@@ -2014,20 +2012,91 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
   old.materialise_cons();
   CK(artemis_rt_stream_sync(old.stream), "sync");
   typedef std::tuple<int, int, int, int> Key;
-  std::map<Key, int> where;
-  for (int b = 0; b < old.nb; ++b) where[Key(old.blocks[b].level, old.blocks[b].lx[0], old.blocks[b].lx[1], old.blocks[b].lx[2])] = b;
+  auto key_of = [](const artemis_host::Leaf &l) { return Key(l.level, l.lx[0], l.lx[1], l.lx[2]); };
+  // global ids: leaves are numbered in Z-order and dealt to the ranks in contiguous runs (build_mesh_multilevel)
+  auto owner = [&](long gid, long nglobal, int &local) {
+    const long base_n = nglobal / nranks, extra = nglobal % nranks;
+    const long cut = extra * (base_n + 1);
+    int r;
+    if (gid < cut) r = static_cast<int>(gid / (base_n + 1)), local = static_cast<int>(gid % (base_n + 1));
+    else r = static_cast<int>(extra + (gid - cut) / base_n), local = static_cast<int>((gid - cut) % base_n);
+    return r;
+  };
+  const std::vector<artemis_host::Leaf> &oldL = old.tree_leaves, &newL = tree_leaves;
+  std::map<Key, long> where;
+  for (size_t g = 0; g < oldL.size(); ++g) where[key_of(oldL[g])] = static_cast<long>(g);
   const int s3[3] = {is, js, ks}, n3[3] = {mbnx[0], mbnx[1], mbnx[2]};
-  auto refine_args = [&](const artemis_sim_impl &fine_sim, int fb, const artemis_sim_impl &coarse_sim, int cb, const int child[3],
-                         bool gas_vars) {
+  const long mstride = artemis::metric_block_stride(nj, nk);
+  // a block as the refinement operators see it: edge table, metric table, tables of its gas / dust arrays
+  struct View {
+    const double *geom, *metric;
+    double *const *gas, *const *dust;
+  };
+  auto local_view = [&](const artemis_sim_impl &S, int b) {
+    View v;
+    v.geom = S.geom.p + 6 * b, v.metric = S.metric.p ? S.metric.p + b * mstride : nullptr;
+    v.gas = S.do_gas ? S.gu0.tab() + static_cast<size_t>(b) * 6 * ns_gas : nullptr;
+    v.dust = S.do_dust ? S.du0.tab() + static_cast<size_t>(b) * 4 * ns_dust : nullptr;
+    return v;
+  };
+  // old blocks that live on another rank arrive in temporaries with tables of their own
+  struct Remote {
+    DevBuf gas, dust, geom, metric;
+    DevArr gtab, dtab;
+    View view;
+  };
+  std::map<long, std::unique_ptr<Remote>> remote; // by old global id
+  auto remote_view = [&](long og) -> View {
+    auto it = remote.find(og);
+    if (it != remote.end()) return it->second->view;
+    std::unique_ptr<Remote> R(new Remote());
+    const artemis_host::Leaf &lf = oldL[og];
+    double g6[6];
+    for (int d = 0; d < 3; ++d) { // the block's edges exactly as build_mesh_multilevel computes them
+      const int n = (d < ndim) ? (nblk[d] << lf.level) : 1;
+      const Real rl = static_cast<Real>(lf.lx[d]) / n, rr = static_cast<Real>(lf.lx[d] + 1) / n;
+      const Real lo = (lf.lx[d] == 0) ? xmin[d] : xmin[d] * (1.0 - rl) + xmax[d] * rl;
+      const Real hi = (lf.lx[d] + 1 == n) ? xmax[d] : xmin[d] * (1.0 - rr) + xmax[d] * rr;
+      const Real dx = (hi - lo) / mbnx[d];
+      g6[2 * d] = lo - ((d < ndim) ? ng : 0) * dx, g6[2 * d + 1] = dx;
+    }
+    R->geom.alloc(6);
+    CK(artemis_rt_memcpy_h2d(R->geom.p, g6, sizeof g6, stream), "h2d");
+    artemis_pack_t p1;
+    std::memset(&p1, 0, sizeof p1);
+    p1.nblocks = 1, p1.nghost = ng, p1.nx1 = mbnx[0], p1.nx2 = mbnx[1], p1.nx3 = mbnx[2], p1.coords = coords;
+    const long nm = artemis_hip_metric_count(&p1);
+    if (nm > 0) {
+      std::vector<Real> hm(nm, 0.0);
+      CK(artemis_hip_metric_fill(&p1, g6, hm.data()), "metric of a migrating block");
+      R->metric.alloc(nm);
+      CK(artemis_rt_memcpy_h2d(R->metric.p, hm.data(), nm * sizeof(Real), stream), "h2d");
+    }
+    CK(artemis_rt_stream_sync(stream), "sync"); // g6 / hm are locals
+    std::vector<double *> hg, hd;
+    if (do_gas) {
+      R->gas.alloc(static_cast<size_t>(6) * ns_gas * N);
+      for (int v = 0; v < 6 * ns_gas; ++v) hg.push_back(R->gas.p + static_cast<size_t>(v) * N);
+      R->gtab.upload(hg);
+    }
+    if (do_dust) {
+      R->dust.alloc(static_cast<size_t>(4) * ns_dust * N);
+      for (int v = 0; v < 4 * ns_dust; ++v) hd.push_back(R->dust.p + static_cast<size_t>(v) * N);
+      R->dtab.upload(hd);
+    }
+    R->view.geom = R->geom.p, R->view.metric = R->metric.p;
+    R->view.gas = static_cast<double *const *>(R->gtab.p), R->view.dust = static_cast<double *const *>(R->dtab.p);
+    const View out = R->view;
+    remote[og] = std::move(R);
+    return out;
+  };
+  auto refine_args = [&](const View &fine, const View &coarse, const int child[3], bool gas_vars) {
     artemis_refine_t r;
     std::memset(&r, 0, sizeof r);
     r.coords = coords, r.ndim = ndim, r.nvar = gas_vars ? 6 * ns_gas : 4 * ns_dust;
     r.fni = r.cni = ni, r.fnj = r.cnj = nj, r.fnk = r.cnk = nk;
-    r.fgeom = fine_sim.geom.p + 6 * fb, r.cgeom = coarse_sim.geom.p + 6 * cb;
-    r.fmetric = fine_sim.metric.p ? fine_sim.metric.p + fb * artemis::metric_block_stride(nj, nk) : nullptr;
-    r.cmetric = coarse_sim.metric.p ? coarse_sim.metric.p + cb * artemis::metric_block_stride(nj, nk) : nullptr;
-    const Field &F = gas_vars ? fine_sim.gu0 : fine_sim.du0, &Cc = gas_vars ? coarse_sim.gu0 : coarse_sim.du0;
-    r.fine = F.tab() + static_cast<size_t>(fb) * r.nvar, r.coarse = Cc.tab() + static_cast<size_t>(cb) * r.nvar;
+    r.fgeom = fine.geom, r.cgeom = coarse.geom, r.fmetric = fine.metric, r.cmetric = coarse.metric;
+    r.fine = gas_vars ? fine.gas : fine.dust, r.coarse = gas_vars ? coarse.gas : coarse.dust;
     int lo[3], hi[3];
     for (int d = 0; d < 3; ++d) {
       const bool act = d < ndim;
@@ -2038,52 +2107,93 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
     r.cib = lo[0], r.cjb = lo[1], r.ckb = lo[2], r.fib = s3[0], r.fjb = s3[1], r.fkb = s3[2];
     return r;
   };
-  for (int b = 0; b < nb; ++b) {
-    const Block &B = blocks[b];
-    const Key me(B.level, B.lx[0], B.lx[1], B.lx[2]);
-    auto it = where.find(me);
-    if (it != where.end()) { // unchanged block
-      if (do_gas) CK(artemis_rt_memcpy_d2d(gu0.var(b, 0), old.gu0.var(it->second, 0), sizeof(Real) * 6 * ns_gas * N, stream), "d2d");
-      if (do_dust) CK(artemis_rt_memcpy_d2d(du0.var(b, 0), old.du0.var(it->second, 0), sizeof(Real) * 4 * ns_dust * N, stream), "d2d");
+  // every (old block -> new block) dependency of the new mesh, in the same order on every rank
+  struct Dep {
+    long og, ng_;      // old / new global id
+    int kind;          // 0 same, 1 new block is a child of og, 2 og is a child of the new block
+    int child[3];
+  };
+  std::vector<Dep> deps;
+  for (size_t g = 0; g < newL.size(); ++g) {
+    const artemis_host::Leaf &B = newL[g];
+    auto it = where.find(key_of(B));
+    if (it != where.end()) {
+      deps.push_back(Dep{it->second, static_cast<long>(g), 0, {0, 0, 0}});
       continue;
     }
-    int child[3] = {0, 0, 0};
-    Key par(B.level - 1, 0, 0, 0);
     if (B.level > 0) {
-      int pl[3] = {0, 0, 0};
-      for (int d = 0; d < 3; ++d) pl[d] = (d < ndim) ? B.lx[d] >> 1 : 0, child[d] = (d < ndim) ? B.lx[d] & 1 : 0;
-      par = Key(B.level - 1, pl[0], pl[1], pl[2]);
-    }
-    it = (B.level > 0) ? where.find(par) : where.end();
-    if (it != where.end()) { // refined: prolongate my octant of the parent
-      if (do_gas) {
-        const artemis_refine_t r = refine_args(*this, b, old, it->second, child, true);
-        CK(artemis_hip_prolongate_minmod(&r, stream), "ProlongateSharedMinMod (remesh)");
+      int pl[3] = {0, 0, 0}, ch[3] = {0, 0, 0};
+      for (int d = 0; d < 3; ++d) pl[d] = (d < ndim) ? B.lx[d] >> 1 : 0, ch[d] = (d < ndim) ? B.lx[d] & 1 : 0;
+      it = where.find(Key(B.level - 1, pl[0], pl[1], pl[2]));
+      if (it != where.end()) {
+        deps.push_back(Dep{it->second, static_cast<long>(g), 1, {ch[0], ch[1], ch[2]}});
+        continue;
       }
-      if (do_dust) {
-        const artemis_refine_t r = refine_args(*this, b, old, it->second, child, false);
-        CK(artemis_hip_prolongate_minmod(&r, stream), "ProlongateSharedMinMod (remesh)");
-      }
-      continue;
     }
-    // derefined: restrict my 2^ndim children
     for (int c3 = 0; c3 < (ndim > 2 ? 2 : 1); ++c3)
       for (int c2 = 0; c2 < (ndim > 1 ? 2 : 1); ++c2)
         for (int c1 = 0; c1 < 2; ++c1) {
-          const int ch[3] = {c1, c2, c3};
-          const Key ck(B.level + 1, 2 * B.lx[0] + c1, (ndim > 1 ? 2 * B.lx[1] + c2 : 0), (ndim > 2 ? 2 * B.lx[2] + c3 : 0));
-          auto ic = where.find(ck);
-          if (ic == where.end()) throw std::runtime_error("remesh: a new block has no counterpart in the old mesh");
-          if (do_gas) {
-            const artemis_refine_t r = refine_args(old, ic->second, *this, b, ch, true);
-            CK(artemis_hip_restrict_average(&r, stream), "RestrictAverage (remesh)");
-          }
-          if (do_dust) {
-            const artemis_refine_t r = refine_args(old, ic->second, *this, b, ch, false);
-            CK(artemis_hip_restrict_average(&r, stream), "RestrictAverage (remesh)");
-          }
+          it = where.find(Key(B.level + 1, 2 * B.lx[0] + c1, (ndim > 1 ? 2 * B.lx[1] + c2 : 0), (ndim > 2 ? 2 * B.lx[2] + c3 : 0)));
+          if (it == where.end()) throw std::runtime_error("remesh: a new block has no counterpart in the old mesh");
+          deps.push_back(Dep{it->second, static_cast<long>(g), 2, {c1, c2, c3}});
         }
   }
+  // blocks that change rank travel whole (conserved variables, ghost zones included), one message per fluid
+  std::vector<artemis_msg_t> msgs;
+  std::map<std::pair<long, int>, bool> sent; // (old gid, destination rank): send an old block to a rank once
+  for (size_t q = 0; q < deps.size(); ++q) {
+    int ol, nl;
+    const int orank = owner(deps[q].og, static_cast<long>(oldL.size()), ol), nrank = owner(deps[q].ng_, static_cast<long>(newL.size()), nl);
+    if (orank == nrank) continue;
+    const int tag = 9000000 + 2 * static_cast<int>(deps[q].og);
+    if (orank == rank) {
+      if (sent[std::make_pair(deps[q].og, nrank)]) continue;
+      sent[std::make_pair(deps[q].og, nrank)] = true;
+      artemis_msg_t m;
+      m.peer = nrank, m.recv = nullptr;
+      if (do_gas) m.tag = tag, m.send = old.gu0.var(ol, 0), m.count = static_cast<long>(6) * ns_gas * N, msgs.push_back(m);
+      if (do_dust) m.tag = tag + 1, m.send = old.du0.var(ol, 0), m.count = static_cast<long>(4) * ns_dust * N, msgs.push_back(m);
+    } else if (nrank == rank) {
+      if (remote.count(deps[q].og)) continue;
+      remote_view(deps[q].og);
+      Remote &R = *remote[deps[q].og];
+      artemis_msg_t m;
+      m.peer = orank, m.send = nullptr;
+      if (do_gas) m.tag = tag, m.recv = R.gas.p, m.count = static_cast<long>(6) * ns_gas * N, msgs.push_back(m);
+      if (do_dust) m.tag = tag + 1, m.recv = R.dust.p, m.count = static_cast<long>(4) * ns_dust * N, msgs.push_back(m);
+    }
+  }
+  exchange_messages(msgs);
+  for (const Dep &D : deps) {
+    int ol, nl;
+    const int orank = owner(D.og, static_cast<long>(oldL.size()), ol), nrank = owner(D.ng_, static_cast<long>(newL.size()), nl);
+    if (nrank != rank) continue;
+    const View src = (orank == rank) ? local_view(old, ol) : remote_view(D.og);
+    const View dst = local_view(*this, nl);
+    if (D.kind == 0) { // unchanged block
+      if (do_gas) {
+        const double *from = (orank == rank) ? old.gu0.var(ol, 0) : remote[D.og]->gas.p;
+        CK(artemis_rt_memcpy_d2d(gu0.var(nl, 0), from, sizeof(Real) * 6 * ns_gas * N, stream), "d2d");
+      }
+      if (do_dust) {
+        const double *from = (orank == rank) ? old.du0.var(ol, 0) : remote[D.og]->dust.p;
+        CK(artemis_rt_memcpy_d2d(du0.var(nl, 0), from, sizeof(Real) * 4 * ns_dust * N, stream), "d2d");
+      }
+    } else if (D.kind == 1) { // refined: prolongate my octant of the parent
+      for (int gas_vars = 1; gas_vars >= 0; --gas_vars) {
+        if ((gas_vars && !do_gas) || (!gas_vars && !do_dust)) continue;
+        const artemis_refine_t r = refine_args(dst, src, D.child, gas_vars != 0);
+        CK(artemis_hip_prolongate_minmod(&r, stream), "ProlongateSharedMinMod (remesh)");
+      }
+    } else { // derefined: restrict this child into its octant of me
+      for (int gas_vars = 1; gas_vars >= 0; --gas_vars) {
+        if ((gas_vars && !do_gas) || (!gas_vars && !do_dust)) continue;
+        const artemis_refine_t r = refine_args(src, dst, D.child, gas_vars != 0);
+        CK(artemis_hip_restrict_average(&r, stream), "RestrictAverage (remesh)");
+      }
+    }
+  }
+  CK(artemis_rt_stream_sync(stream), "sync"); // the temporaries of migrated blocks go out of scope below
   time = old.time, dt = old.dt, ncycle = old.ncycle, tlim = old.tlim, nlim = old.nlim;
   particle_force = old.particle_force;
   overlap = old.overlap, time_kernels = old.time_kernels;
@@ -2115,7 +2225,11 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
   cons_valid = true;
   CK(artemis_rt_stream_sync(stream), "sync");
   // the step's own estimate came from the old mesh; new fine blocks may need less (never more than it allowed)
-  dt = std::min(dt, new_dt_unfused());
+  {
+    Real est = new_dt_unfused();
+    if (has_comm && nranks > 1 && comm.allreduce_min(comm.ctx, &est)) throw std::runtime_error("allreduce failed");
+    dt = std::min(dt, est);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2694,7 +2808,17 @@ static bool next_leaves(artemis_sim &h, const std::vector<int> &tags, bool allow
 // loop of Mesh::Initialize -- refine only, and the problem generator fills the new mesh instead of a prolongation.
 static bool remesh(artemis_sim &h, bool initial) {
   if (!h.p->adaptive || !h.p->refine_field) return false;
-  const std::vector<int> tags = h.p->amr_tags();
+  // tags of this rank's blocks, gathered into the global (Z-ordered) leaf list: every rank then takes the same
+  // decision (an all-reduce(sum) of a vector that is zero outside the rank's own slots)
+  const std::vector<int> local = h.p->amr_tags();
+  std::vector<int> tags(h.p->tree_leaves.size(), 0);
+  {
+    std::vector<double> g(tags.size(), 0.0);
+    for (int b = 0; b < h.p->nb; ++b) g[h.p->blocks[b].gid] = local[b];
+    if (h.p->has_comm && h.p->nranks > 1 && h.p->comm.allreduce_sum(h.p->comm.ctx, g.data(), static_cast<int>(g.size())))
+      throw std::runtime_error("allreduce of the refinement tags failed");
+    for (size_t q = 0; q < g.size(); ++q) tags[q] = static_cast<int>(g[q]);
+  }
   std::vector<artemis_host::Leaf> leaves;
   if (!next_leaves(h, tags, !initial, leaves)) return false;
   std::unique_ptr<artemis_sim_impl> np = build_state(h, &leaves);
