@@ -118,3 +118,34 @@ def test_adaptive_mesh_without_a_trigger_equals_the_static_root_mesh(hiplib):
     for q in range(32):
         assert np.array_equal(a.interior(a.field("gas.prim", q)), b.interior(b.field("gas.prim", q))), q
     a.close(), b.close()
+
+
+def test_disk_with_planet_dust_and_adaptive_mesh(hiplib):
+    """BASELINE configs[4]'s ingredients in one run (minus REBOUND: the planet sits still in the frame that rotates
+    with it): inputs/disk/disk_nbody_cyl.in + a 1e-3 planet at r = 1 with Plummer softening, the rotating frame, one
+    dust species with simple_dust drag, `ic` conditions, and a three-level adaptive mesh refining on the gas density
+    (the midplane of the inner disk).  The run must build its levels from the initial condition, stay finite and
+    positive, keep dt in the disk decks' window, tile the root mesh, and feel the planet (a net force on the star)."""
+    from artemis_amd.driver import Simulation
+    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32", "parthenon/meshblock/nx1=8",
+          "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8", "parthenon/mesh/refinement=adaptive",
+          "parthenon/mesh/numlevel=3", "parthenon/mesh/derefine_count=5", "gas/refine_field=density",
+          "gas/refine_type=magnitude", "gas/refine_thr=0.5", "gas/deref_thr=0.2",
+          "physics/rotating_frame=true", "rotating_frame/omega=1.0",
+          "physics/dust=true", "dust/nspecies=1", "dust/cfl=0.3", "dust/reconstruct=plm", "dust/riemann=hlle",
+          "dust/dfloor=1e-10", "physics/drag=true", "drag/type=simple_dust", "dust/stopping_time/type=constant",
+          "dust/stopping_time/tau=0.1", "dust/sizes=1.0",
+          "nbody/particle2/mass=1.0e-3", "nbody/particle2/couple=1", "nbody/particle2/soft/type=plummer",
+          "nbody/particle2/soft/radius=0.03", "nbody/particle2/initialize/x=1.0", "nbody/particle2/initialize/vy=1.0"]
+    s = Simulation(DECK("disk", "disk_nbody_cyl.in"), ov)
+    lv = levels(s)
+    assert set(lv) == {0, 1, 2} and s.remeshes >= 2 and not s.uses_fused_path
+    assert sum(8.0 ** (-s.block_level(b)) for b in range(s.nblocks)) == 64.0
+    s.evolve(20)
+    assert s.ncycle == 20 and 1e-4 < s.dt < 3e-2
+    for b in range(s.nblocks):
+        g, d = s.field("gas.prim", b)[[0, 1, 2, 3, 5]], s.field("dust.prim", b)
+        assert np.isfinite(g).all() and np.isfinite(d).all() and g[0].min() > 0 and g[4].min() > 0 and d[0].min() > 0
+    f = s.nbody_force()
+    assert f.shape == (2, 7) and np.isfinite(f).all() and np.abs(f[0, :3]).max() > 0.0
+    s.close()
