@@ -60,3 +60,30 @@ def test_cylindrical_blast_amr_on_two_ranks_equals_one_rank_bitwise(tmp_path):
     for key in a:
         assert np.array_equal(a[key], b[key]), key
     assert abs(one[0]["hist"][0] - ini[0]["hist"][0]) < 1e-13 * ini[0]["hist"][0]
+
+
+def test_three_dimensional_adaptive_blast_two_ranks_equal_one_rank(tmp_path):
+    """3-D Cartesian Sedov blast (inputs/blast/blast.in) on an adaptive mesh, 16^3 root in 8^3 blocks, two levels on the
+    pressure gradient: octant bookkeeping of the hand-over in three dimensions.  2 ranks == 1 rank bit for bit, mass and
+    total energy conserved (periodic box: the refined region also crosses the periodic seam)."""
+    from test_multirank_cpu import by_bounds
+    spec = dict(deck=["blast", "blast.in"], cycles=25,
+                overrides=["parthenon/mesh/nx1=16", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16", "parthenon/mesh/x3min=-1.0",
+                           "parthenon/mesh/x3max=1.0", "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8",
+                           "parthenon/meshblock/nx3=8", "parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=2",
+                           "parthenon/mesh/derefine_count=3", "gas/refine_field=pressure", "gas/refine_type=gradient",
+                           "gas/refine_thr=3.0", "problem/symmetry=spherical", "problem/radius=0.35", "problem/samples=0",
+                           "problem/p0=0.05", "problem/x1=-0.4", "problem/x2=-0.4", "problem/x3=-0.4"]
+                + ["parthenon/mesh/%sx%d_bc=periodic" % (io, d) for io in "io" for d in (1, 2, 3)])
+    one = _run_workers(1, spec, tmp_path, "t1")
+    two = _run_workers(2, spec, tmp_path, "t2")
+    ini = _run_workers(1, dict(spec, cycles=0), tmp_path, "t0")
+    lv = one[0]["meta"]["levels"]
+    assert set(lv) == {0, 1} and sum(8.0 ** (-l) for l in lv) == 8.0
+    assert one[0]["meta"]["remeshes"] > ini[0]["meta"]["remeshes"] and one[0]["meta"]["remeshes"] == two[0]["meta"]["remeshes"]
+    a, b = by_bounds(one), by_bounds(two)
+    assert a.keys() == b.keys()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    h0, h1 = ini[0]["hist"], one[0]["hist"]
+    assert abs(h1[0] - h0[0]) < 1e-13 * h0[0] and abs(h1[4] - h0[4]) < 1e-11 * h0[4]

@@ -31,13 +31,22 @@ def free_port():
     return p
 
 
+_RESULTS = {}  # (world, spec) -> results: several tests compare against the same reference run
+
+
 def run_world(world, spec, tmp_path, tag):
+    key = (world, json.dumps(spec, sort_keys=True))
+    if key in _RESULTS:
+        return _RESULTS[key]
     spec = dict(spec, out=str(tmp_path / tag))
     port = str(free_port())
     procs = []
+    # the checker's OpenMP team per rank: the machine's CPUs shared by the ranks (the updates have no cross-thread
+    # floating-point reductions, so the fields do not depend on the team size)
+    threads = str(max(1, min(4, (os.cpu_count() or 1) // world)))
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=port, OMP_NUM_THREADS="1")
+                   MASTER_PORT=port, OMP_NUM_THREADS=threads)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mr_worker.py"),
                                        json.dumps(spec)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
@@ -51,6 +60,7 @@ def run_world(world, spec, tmp_path, tag):
         res.append(dict(meta=json.loads(str(z["meta"])), hist=z["hist"], errs=z["errs"],
                         blocks=[(z["bounds%d" % b], z["prim%d" % b]) for b in range(nblk)],
                         dust=[z["dust%d" % b] for b in range(nblk)] if spec.get("dust") else []))
+    _RESULTS[key] = res
     return res
 
 
