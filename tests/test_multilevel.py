@@ -481,3 +481,49 @@ def test_nbody_disk_deck_on_a_refined_mesh_hip_equals_multilevel_oracle(hiplib):
     f = s.nbody_force()
     assert f.shape == (1, 7) and np.all(np.isfinite(f))
     s.close()
+
+
+# ---- the shearing sheet's user conditions (extrap / inflow) on fine blocks and coarse buffers ---------------------
+SSHEET_SMR_OV = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8",
+                 "parthenon/time/nlim=8", "parthenon/time/tlim=100.0"] + region_overrides(1, (-0.4, -0.9, -0.2), (0.4, 0.9, 0.2))
+
+
+def ssheet_smr_oracle():
+    m = MultiLevelOracle((32, 32, 1), (8, 8, 1), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2),
+                         ("extrap", "extrap", "inflow", "inflow", "extrap", "extrap"),
+                         regions=[(1, (-0.4, 0.4), (-0.9, 0.9), (-0.2, 0.2))], ng=2, integrator="rk2", reconstruct="plm",
+                         riemann="hllc", gamma=1.000001, dfloor=1e-10, siefloor=1e-10, cfl=0.3)
+    m.gravity = m.rframe = True
+    for blk in m.blocks + m.coarse:
+        blk.set_rotating_frame(1.0, 1.5)
+        blk.set_gravity_point(1e-5, soft=0.03)
+        blk.pgen_strat(rho0=1.0, dens_min=1e-10, h=0.05, post_init=False)
+    m.post_init()
+    m.evolve(100.0, 8)
+    return m
+
+
+def test_shearing_sheet_on_a_refined_mesh_cpu_double_equals_multilevel_oracle(tmp_path):
+    """inputs/ssheet/ssheet.in (strat problem, point-mass gravity, shearing box, `extrap` x1 / `inflow` x2 conditions)
+    at 32^2 in 8^2 blocks with a refined strip touching the x2 boundaries: the user conditions act on fine blocks and
+    on the coarse buffers of the blocks next to the level boundary.  Host driver == multilevel oracle bit for bit."""
+    res = _run_workers(1, dict(deck=["ssheet", "ssheet.in"], overrides=SSHEET_SMR_OV), tmp_path, "ss")[0]
+    m = ssheet_smr_oracle()
+    assert res["meta"]["nblocks"] == len(m.blocks) and res["meta"]["ncycle"] == m.ncycle == 8
+    assert res["meta"]["dt"] == m.dt and res["meta"]["time"] == m.time
+    for b, (bounds, prim) in enumerate(res["blocks"]):
+        assert list(bounds) == m.block_bounds(b)
+        assert np.array_equal(prim, m.blocks[b].interior(m.blocks[b].gprim)), b
+
+
+@pytest.mark.gpu
+def test_shearing_sheet_on_a_refined_mesh_hip_equals_multilevel_oracle(hiplib):
+    from artemis_amd.driver import Simulation
+    s = Simulation(DECK("ssheet", "ssheet.in"), SSHEET_SMR_OV)
+    s.evolve()
+    m = ssheet_smr_oracle()
+    assert s.nblocks == len(m.blocks) and s.ncycle == m.ncycle == 8 and s.dt == m.dt
+    for b, blk in enumerate(m.blocks):
+        got = s.field("gas.prim", b)
+        assert np.array_equal(got[[0, 1, 2, 3, 5]], blk.gprim[[0, 1, 2, 3, 5]]), b  # ghosts included
+    s.close()
