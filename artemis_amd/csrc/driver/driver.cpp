@@ -484,10 +484,8 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
         if (mbnx[d] % 2 != 0 || mbnx[d] / 2 < (ng + 1) / 2 + 1)
           throw std::runtime_error("multilevel meshes need an even meshblock size of at least nghost + 4 zones");
       for (int f = 0; f < 2 * ndim; ++f)
-        if (mesh_bc[f] > ARTEMIS_BC_REFLECT && mesh_bc[f] != ARTEMIS_BC_IC && mesh_bc[f] != ARTEMIS_BC_STRAT_EXTRAP &&
-            mesh_bc[f] != ARTEMIS_BC_STRAT_INFLOW)
-          throw std::runtime_error("this user boundary condition on a refined mesh is not built "
-                                   "(periodic | outflow | reflecting | ic | the strat problem's extrap / inflow are)");
+        if (mesh_bc[f] == ARTEMIS_BC_CONDUCTIVE) // (needs the conduction problem's hydrostatic profile per buffer: untested)
+          throw std::runtime_error("the conductive boundary condition on a refined mesh is not built");
     }
   }
   // geometry::CoordSelect (geometry.hpp:38-56, artemis.cpp:94-97)

@@ -527,3 +527,30 @@ def test_shearing_sheet_on_a_refined_mesh_hip_equals_multilevel_oracle(hiplib):
         got = s.field("gas.prim", b)
         assert np.array_equal(got[[0, 1, 2, 3, 5]], blk.gprim[[0, 1, 2, 3, 5]]), b  # ghosts included
     s.close()
+
+
+def test_disk_extrap_condition_on_a_refined_mesh(tmp_path):
+    """The disk problem's `extrap` condition (power-law extrapolation in ln x of density, sie and the inertial azimuthal
+    velocity, pgen/disk.hpp:634-825) on fine blocks and coarse buffers of the refined spherical disk deck: host driver on
+    the CPU double == multilevel oracle (both evaluate log / exp with the host libm here: bit for bit)."""
+    ov = [o for o in DISK_SMR_OV if "nlim" not in o] + ["parthenon/time/nlim=3"]  # (this coarse mesh goes unstable later)
+    ov += ["parthenon/mesh/i%s_bc=extrap" % d for d in ("x1", "x2")] + ["parthenon/mesh/o%s_bc=extrap" % d for d in ("x1", "x2")]
+    res = _run_workers(1, dict(deck=["disk", "disk_sph.in"], overrides=ov), tmp_path, "dex")[0]
+    from test_oracle_pins import _DISK_DECKS
+    D = _DISK_DECKS["sph"]
+    m = MultiLevelOracle((32, 16, 16), (8, 8, 8), D["lo"], D["hi"], D["bc"]("disk_extrap"),
+                         regions=[(1, (0.7, 1.9), (1.3, 1.85), (-1.0, 1.0))], ng=2, integrator="rk2", reconstruct="plm",
+                         riemann=D["riemann"], gamma=1.4, dfloor=1e-10, siefloor=D["siefloor"], cfl=0.3,
+                         coordinates="spherical", de_switch=1e-2)
+    m.diffusion = m.gravity = m.rframe = True
+    for blk in m.blocks + m.coarse:
+        blk.set_gravity_point(mass=1.0)
+        blk.set_rotating_frame(1.0, 0.0)
+        blk.set_viscosity("alpha", alpha=1e-3, r0=1.0, Omega0=1.0)
+        blk.pgen_disk(r0=1.0, rho0=1.0, dslope=-2.25, flare=0.25, h0=0.05, dens_min=1e-10, pres_min=1e-15,
+                      polytropic_index=1.4, post_init=False)
+    m.post_init()
+    m.evolve(62.8, 3)
+    assert res["meta"]["ncycle"] == m.ncycle == 3 and res["meta"]["dt"] == m.dt
+    for b, (bounds, prim) in enumerate(res["blocks"]):
+        assert np.isfinite(prim).all() and np.array_equal(prim, m.blocks[b].interior(m.blocks[b].gprim)), b
