@@ -587,7 +587,20 @@ void launch_stage2d(const PackView &P, const artemis_stage_general_args_t &g, in
   a.nstrip = (nx1 + OWN - 1) / OWN;
   // rows per chunk: long enough to amortise the priming row, short enough for >= ~8 waves per SIMD lane of work
   int rows = 32;
-  if (const char *e = getenv("ARTEMIS_STAGE2D_ROWS")) rows = std::max(1, atoi(e));
+  if (const char *e = getenv("ARTEMIS_STAGE2D_ROWS")) {
+    rows = std::max(1, atoi(e));
+  } else {
+    // One wave per SIMD (launch bound 1): 256 CUs x 4 waves run at a time, so the launch proceeds in rounds of 1024
+    // strip-chunks and a last round that is 60 % empty costs as much as a full one (4096^2: 32 rows -> 8.6 rounds,
+    // 40 rows -> 6.94; measured 0.398 vs 0.411 of the roofline).  Among 24..48 rows take the fullest last round.
+    const long slots = 1024;
+    double best = -1.0;
+    for (int r = 48; r >= 24; r -= 4) {
+      const long waves = static_cast<long>(a.nstrip) * ((nx2 + r - 1) / r) * P.nb;
+      const double fill = static_cast<double>(waves) / static_cast<double>(((waves + slots - 1) / slots) * slots);
+      if (fill > best + 1e-9) best = fill, rows = r;
+    }
+  }
   while (rows > 8 && static_cast<long>(a.nstrip) * ((nx2 + rows - 1) / rows) * P.nb < 4096) rows /= 2;
   a.rows = rows, a.nchunk = (nx2 + rows - 1) / rows;
   const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;

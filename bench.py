@@ -370,7 +370,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": alg / (stage_ms * 1.0e-3) / 1.0e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": alg / (stage_ms * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_source": traffic_src,
-                               "kernel": ("whole stage: viscous pre-pass + 3 viscous-flux kernels + %s + boundary conditions"
+                               "kernel": ("whole stage: viscous pre-pass + one viscous-flux pass (three directions, zeroing folded in) + %s + boundary conditions"
                                           % ("stage_fused_kernel<curvilinear> (fluxes, update, sources, DiffusionUpdate, ConsToPrim, dt "
                                              "in one launch)" if sim.stage_kernel.startswith("stage_fused_kernel") else
                                              "3 flux kernels + epilogue + PrimToCons (per-task chain)")),
