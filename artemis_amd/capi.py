@@ -184,6 +184,7 @@ def load():
         "artemis_hip_set_aux": (i, [PPk, vp]),
         "artemis_hip_cons_to_prim": (i, [PPk, vp]),
         "artemis_hip_prim_to_cons": (i, [PPk, vp]),
+        "artemis_hip_prim_to_cons_ghosts": (i, [PPk, vp]),
         "artemis_hip_deep_copy_conserved": (i, [PPk, vp]),
         "artemis_hip_estimate_dt": (i, [PPk, i, d, C.POINTER(d), vp]),
         "artemis_hip_estimate_dt_async": (i, [PPk, i, d, vp, vp]),
@@ -258,7 +259,7 @@ def load():
 
 EXPORTS_HIP = [
     "artemis_hip_calculate_fluxes", "artemis_hip_apply_update", "artemis_hip_flux_source",
-    "artemis_hip_set_aux", "artemis_hip_cons_to_prim", "artemis_hip_prim_to_cons",
+    "artemis_hip_set_aux", "artemis_hip_cons_to_prim", "artemis_hip_prim_to_cons", "artemis_hip_prim_to_cons_ghosts",
     "artemis_hip_deep_copy_conserved", "artemis_hip_estimate_dt", "artemis_hip_estimate_dt_async",
     "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_metric_count",
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_nbody_gravity", "artemis_hip_rotating_frame_force",

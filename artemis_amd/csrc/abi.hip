@@ -167,6 +167,12 @@ int artemis_hip_prim_to_cons(const artemis_pack_t *p, void *stream) {
   return after_launch("PrimToCons");
 }
 
+int artemis_hip_prim_to_cons_ghosts(const artemis_pack_t *p, void *stream) {
+  if (int rc = validate(p)) return rc;
+  artemis::launch_prim_to_cons(artemis::make_pack_view(*p), S(stream), true);
+  return after_launch("PrimToCons (ghost zones)");
+}
+
 int artemis_hip_deep_copy_conserved(const artemis_pack_t *p, void *stream) {
   if (int rc = validate(p)) return rc;
   artemis::launch_deep_copy(artemis::make_pack_view(*p), S(stream));

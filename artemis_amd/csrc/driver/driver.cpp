@@ -284,7 +284,7 @@ struct artemis_sim_impl {
   bool shell_wait_used = false; // an overlap-2 stage ran since the flag was last cleared
   // "drop-in" accounting mode of the tuned path (bench.py): the last stage also writes the conserved state and
   // every stage ends with the whole-block PrimToCons a Parthenon host runs as FillDerived (artemis_driver.cpp:261)
-  bool dropin = false;
+  int dropin = 0; // 0 off; 1 cons on the last stage + whole-block PrimToCons per stage; 2 cons every stage + ghost-zone PrimToCons
   // test hook (ARTEMIS_LOOPBACK_COMM=1): route same-rank ghost slabs through the communicator
   // as messages to self, so one GPU exercises the RCCL send/recv path end to end
   bool loopback = false;
@@ -2342,7 +2342,7 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
     a.bdt = beta[stage - 1] * dt;     // artemis_driver.cpp:168
     a.pcm = (stage == 1 && integrator == "vl2"); // artemis_driver.cpp:182
     a.prim_in = gprim[cur].tab(), a.prim_u1 = gprim[A].tab(), a.prim_out = gprim[out].tab();
-    a.cons_out = (dropin && last) ? gu0.tab() : nullptr;
+    a.cons_out = ((dropin == 1 && last) || dropin == 2) ? gu0.tab() : nullptr;
     a.cfl = cfl_gas;
     a.dt_dev = (last && want_dt) ? (device_dt ? tstate.p + 2 : dt_dev.p) : nullptr;
     if (device_dt) a.beta_dt_dev = tstate.p + 3 + (stage - 1); // beta*dt stays on the device
@@ -2403,14 +2403,17 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
       }
       fill_ghosts_finish(out, comm_stream);
     }
-    if (dropin) { // FillDerived = PrimToCons over the entire block (artemis.cpp:123, artemis_driver.cpp:261)
+    if (dropin == 1) { // FillDerived = PrimToCons over the entire block (artemis.cpp:123, artemis_driver.cpp:261)
       const artemis_pack_t po = make_pack(out);
       CK(artemis_hip_prim_to_cons(&po, stream), "PrimToCons");
+    } else if (dropin == 2) { // the kernel stored cons of the zones it updated: only the ghost zones are left
+      const artemis_pack_t po = make_pack(out);
+      CK(artemis_hip_prim_to_cons_ghosts(&po, stream), "PrimToCons (ghost zones)");
     }
     cur = out;
   }
   base = cur;
-  cons_valid = dropin;
+  cons_valid = dropin != 0;
 }
 
 // One step on the per-task path (artemis_driver.cpp:157-261 literally).
@@ -2954,7 +2957,7 @@ int artemis_sim_set_dropin(artemis_sim_t *s, int on) {
     g_sim_err = "drop-in accounting applies to the tuned fused kernel only";
     return 1;
   }
-  s->p->dropin = on != 0;
+  s->p->dropin = (on == 2) ? 2 : (on ? 1 : 0);
   return 0;
 }
 int artemis_sim_overlap(const artemis_sim_t *s) { return s->p->overlap; }

@@ -10,7 +10,7 @@ void launch_apply_update(const PackView &P, double gam0, double gam1, double bet
 void launch_flux_source(const PackView &P, int fluid, double dt, hipStream_t s);
 void launch_set_aux(const PackView &P, hipStream_t s);
 void launch_cons_to_prim(const PackView &P, hipStream_t s);
-void launch_prim_to_cons(const PackView &P, hipStream_t s);
+void launch_prim_to_cons(const PackView &P, hipStream_t s, bool ghosts_only = false);
 void launch_deep_copy(const PackView &P, hipStream_t s);
 void launch_estimate_dt(const PackView &P, int fluid, double cfl, double *dt_dev, hipStream_t s);
 int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t *par, hipStream_t s);

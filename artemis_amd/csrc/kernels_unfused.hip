@@ -309,9 +309,12 @@ __global__ __launch_bounds__(TX *TY) void cons_to_prim_kernel(const PackView P, 
 
 // PrimToCons (fill_derived.cpp:212-276), entire block.  P = IdealGas (gm1*rho)*sie clamped
 // at 0 (singularity-eos, recalled).
+// ghosts_only: the active zones are skipped (a fused stage that stores the conserved state of the zones it updates
+// leaves only the ghost zones, filled by the exchange and the physical conditions, to convert)
 template <bool CURV>
-__global__ __launch_bounds__(TX *TY) void prim_to_cons_kernel(const PackView P, const Range3 r) {
+__global__ __launch_bounds__(TX *TY) void prim_to_cons_kernel(const PackView P, const Range3 r, const int ghosts_only) {
   CELL_FROM_GRID(r)
+  if (ghosts_only && i >= P.is && i <= P.ie && j >= P.js && j <= P.je && k >= P.ks && k <= P.ke) return;
   double hx[3];
   scale_factors<CURV>(P, b, k, j, i, hx);
   {
@@ -922,9 +925,9 @@ void launch_cons_to_prim(const PackView &P, hipStream_t s) {
   const Range3 r = interior(P);
   LAUNCH_GEOM(cons_to_prim_kernel, r);
 }
-void launch_prim_to_cons(const PackView &P, hipStream_t s) {
+void launch_prim_to_cons(const PackView &P, hipStream_t s, bool ghosts_only) {
   const Range3 r = entire(P);
-  LAUNCH_GEOM(prim_to_cons_kernel, r);
+  LAUNCH_GEOM(prim_to_cons_kernel, r, ghosts_only ? 1 : 0);
 }
 void launch_deep_copy(const PackView &P, hipStream_t s) {
   const Range3 r = entire(P);

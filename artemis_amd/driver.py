@@ -312,7 +312,7 @@ class Simulation:
 
     def set_dropin(self, on):
         """Tuned path only: also write cons on the last stage and run the whole-block PrimToCons per stage."""
-        if self.L.artemis_sim_set_dropin(self.h, int(on)):
+        if self.L.artemis_sim_set_dropin(self.h, int(on)):  # 0 off, 1 whole-block PrimToCons, 2 ghost-zone PrimToCons
             raise RuntimeError(self.L.artemis_sim_last_error().decode())
 
     def set_kernel_timing(self, on):

@@ -311,20 +311,25 @@ def main():
             n_ = sim.evolve(cycles)
             torch.cuda.synchronize()
             return sim.total_zones * n_ / (time.perf_counter() - t1)
-        sim.set_dropin(True)
+        sim.set_dropin(1)
         r_cons = leg(max(10, min(args.steps, 60)))
-        sim.set_dropin(False)
+        sim.set_dropin(2)
+        r_cons_g = leg(max(10, min(args.steps, 60)))
+        sim.set_dropin(0)
         sim.set_path("unfused")
         r_task = leg(max(5, min(args.steps, 25)))
         sim.set_path("fused")
         zc_bytes = 2.0 * ALG_BYTES_PER_CELL_STAGE  # rk2: 480 B per zone-cycle
         dropin = {"unit": "zone-cycles/s",
-                  "fused": None, "fused_cons_p2c": r_cons, "per_task": r_task,
+                  "fused": None, "fused_cons_p2c": r_cons, "fused_cons_ghost_p2c": r_cons_g, "per_task": r_task,
                   "frac_fused_cons_p2c": r_cons * zc_bytes / 1.0e9 / HBM_PEAK_GBS,
+                  "frac_fused_cons_ghost_p2c": r_cons_g * zc_bytes / 1.0e9 / HBM_PEAK_GBS,
                   "frac_per_task": r_task * zc_bytes / 1.0e9 / HBM_PEAK_GBS,
                   "note": "fused = `value` (primitives in, primitives out; cons never materialised); "
                           "fused_cons_p2c = same kernel also writing cons on the last stage + the whole-block PrimToCons "
-                          "a Parthenon FillDerived runs after every stage's boundary fill; per_task = one kernel per "
+                          "a Parthenon FillDerived runs after every stage's boundary fill; fused_cons_ghost_p2c = the kernel stores cons of "
+                          "the zones it updates in every stage and only the ghost zones go through PrimToCons after the fill "
+                          "(cons equally current after every stage); per_task = one kernel per "
                           "Parthenon task (CalculateFluxes, epilogue = ApplyUpdate..ConsToPrim, BCs, PrimToCons). "
                           "Fractions use the same 480 B per zone-cycle."}
     rccl_ranks = comm.count if comm is not None else 0

@@ -111,7 +111,9 @@ int artemis_sim_overlap(const artemis_sim_t *sim);
 /* Drop-in accounting for the tuned fused kernel (bench.py's `dropin` object): the last stage also writes
  * the conserved state (cons_out) and every stage ends with the whole-block PrimToCons a Parthenon host
  * runs as FillDerived (artemis.cpp:123, artemis_driver.cpp:261) -- what the fused path costs when the host
- * keeps `cons` as its Independent / Restart state.  Same results; returns non-zero off the tuned path. */
+ * keeps `cons` as its Independent / Restart state.  on = 2: every stage stores cons of the zones it updates and only
+ * the ghost zones go through PrimToCons after the exchange (artemis_hip_prim_to_cons_ghosts): `cons` is just as
+ * current after every stage, at 5 % of the conversion work.  Same results; returns non-zero off the tuned path. */
 int artemis_sim_set_dropin(artemis_sim_t *sim, int on);
 /* <gravity/nbody> with <nbody> integrator = none: the accumulated particle_force rows [npart][7] = {mass accreted,
  * gravity force x3, accretion force x3} (nbody_gravity.hpp:129-136), summed over ranks like NBody::Advance does

@@ -137,6 +137,10 @@ int artemis_hip_cons_to_prim(const artemis_pack_t *p, void *stream);
 
 /* ArtemisDerived::PrimToCons<MeshData, GEOM> (fill_derived.cpp:173-277), entire block. */
 int artemis_hip_prim_to_cons(const artemis_pack_t *p, void *stream);
+/* PrimToCons on the GHOST zones only.  For a host that keeps `cons` current: artemis_hip_stage_fused with cons_out set
+ * stores the conserved state of every zone it updates (the bits PrimToCons would give), so after the boundary
+ * exchange only the ghost zones are left to convert -- 5 % of a 256^3 block instead of a whole-block pass. */
+int artemis_hip_prim_to_cons_ghosts(const artemis_pack_t *p, void *stream);
 
 /* ArtemisUtils::DeepCopyConservedData (artemis_integrator.hpp:30-51): u1 <- u0, entire. */
 int artemis_hip_deep_copy_conserved(const artemis_pack_t *p, void *stream);

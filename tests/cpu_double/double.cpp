@@ -204,6 +204,7 @@ int artemis_hip_cons_to_prim(const artemis_pack_t *p, void *) {
   }
   return 0;
 }
+int artemis_hip_prim_to_cons_ghosts(const artemis_pack_t *p, void *s) { return artemis_hip_prim_to_cons(p, s); } // (idempotent on the interior)
 int artemis_hip_prim_to_cons(const artemis_pack_t *p, void *) {
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);

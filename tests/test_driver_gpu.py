@@ -274,14 +274,16 @@ def test_dropin_accounting_mode_same_bits(hiplib):
     PrimToCons per stage gives the same state as the plain fused path and as the per-task chain."""
     from artemis_amd.driver import Simulation
     ov = BLAST3D + ["parthenon/time/tlim=-1.0", "parthenon/time/nlim=9"]
-    a, b, c = (Simulation(DECK("blast", "blast.in"), ov) for _ in range(3))
+    a, b, c, d = (Simulation(DECK("blast", "blast.in"), ov) for _ in range(4))
     b.set_dropin(True)
     c.set_path("unfused")
-    for s in (a, b, c):
+    d.set_dropin(2)  # cons stored by the kernel in every stage + PrimToCons on the ghost zones only
+    for s in (a, b, c, d):
         s.evolve()
-    assert a.ncycle == b.ncycle == c.ncycle == 9 and a.dt == b.dt == c.dt
+    assert a.ncycle == b.ncycle == c.ncycle == d.ncycle == 9 and a.dt == b.dt == c.dt == d.dt
     for name in ("gas.prim", "gas.cons"):
         assert np.array_equal(a.field(name), b.field(name)) and np.array_equal(a.field(name), c.field(name)), name
+        assert np.array_equal(a.field(name), d.field(name)), name
     with pytest.raises(RuntimeError):
         c.set_dropin(True)  # tuned fused path only
 
