@@ -875,6 +875,26 @@ __global__ void wait_counter_kernel(unsigned *counter, unsigned target, unsigned
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// Planes per chunk of the x3 march.  The launch proceeds in rounds of `slots` resident workgroups (256 CUs x 2, or
+// x 1 for the curvilinear instantiations) and a half-empty last round costs a full one; every chunk also pays one
+// priming trip.  Among 8..16 planes take the best product of round fill and march efficiency (256^3: 16 planes,
+// 4096 workgroups = 8 full rounds; 192 x 128^2: 8 planes, 3 full rounds instead of 1.5).
+int pick_chunk(int planes, long tiles, long slots) {
+  if (const char *e = getenv("ARTEMIS_FUSED_KCHUNK")) return std::max(1, atoi(e)); // tuning knob
+  int best = 16;
+  double score = -1.0;
+  for (int c = 16; c >= 8; --c) { // (<= 16: the boundary shell of the overlapped launch is one chunk thick)
+    const int n0 = std::max(1, planes / c);
+    const int kc = (planes + n0 - 1) / n0; // what add_box makes of it
+    const int nchunk = (planes + kc - 1) / kc;
+    const long wgs = tiles * nchunk;
+    const double fill = static_cast<double>(wgs) / static_cast<double>(((wgs + slots - 1) / slots) * slots);
+    const double sc = fill * kc / (kc + 1.0);
+    if (sc > score + 1e-9) score = sc, best = c;
+  }
+  return best;
+}
+
 template <int RIEMANN, int RECON>
 int launch_cfg(const PackView &P, const StageK &k, bool has_u1, bool cons, bool dt, hipStream_t s) {
   const dim3 grid(k.start[k.nbox]);
@@ -936,8 +956,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   k.dt_bits = reinterpret_cast<unsigned long long *>(a.dt_dev);
   const int nz = P.ke - P.ks + 1;
   const int NTI = (P.ie - P.is + FTX) / FTX, NTJ = (P.je - P.js + FTY) / FTY;
-  int target_chunk = 16; // planes per chunk: >= 8 workgroup rounds on 256 CUs x 2 at 256^3
-  if (const char *e = getenv("ARTEMIS_FUSED_KCHUNK")) target_chunk = std::max(1, atoi(e)); // tuning knob
+  const int target_chunk = pick_chunk(nz, static_cast<long>(NTI) * NTJ * P.nb, 512);
   k.nbox = 0;
   k.start[0] = 0;
   auto add_box = [&](int ti0, int nti, int tj0, int ntj, int kb0, int kb1) {
@@ -1056,8 +1075,7 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
   k.dt_bits = reinterpret_cast<unsigned long long *>(g.dt_dev);
   const int nz = P.ke - P.ks + 1;
   const int NTI = (P.ie - P.is + FTX) / FTX, NTJ = (P.je - P.js + FTY) / FTY;
-  int target_chunk = 16;
-  if (const char *e = getenv("ARTEMIS_FUSED_KCHUNK")) target_chunk = std::max(1, atoi(e));
+  const int target_chunk = pick_chunk(nz, static_cast<long>(NTI) * NTJ * P.nb, 256);
   k.nbox = 1, k.start[0] = 0;
   k.ti0[0] = 0, k.nti[0] = NTI, k.tj0[0] = 0, k.ntj[0] = NTJ, k.kb0[0] = P.ks, k.kb1[0] = P.ke;
   k.nchunk[0] = (P.ndim > 2) ? std::max(1, nz / target_chunk) : 1;
