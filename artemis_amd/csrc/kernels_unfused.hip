@@ -311,10 +311,11 @@ __global__ __launch_bounds__(TX *TY) void cons_to_prim_kernel(const PackView P, 
 // at 0 (singularity-eos, recalled).
 // ghosts_only: the active zones are skipped (a fused stage that stores the conserved state of the zones it updates
 // leaves only the ghost zones, filled by the exchange and the physical conditions, to convert)
-template <bool CURV>
-__global__ __launch_bounds__(TX *TY) void prim_to_cons_kernel(const PackView P, const Range3 r, const int ghosts_only) {
+// (GHOSTS is a template argument so that the two forms are separate kernels in a profile)
+template <bool CURV, bool GHOSTS = false>
+__global__ __launch_bounds__(TX *TY) void prim_to_cons_kernel(const PackView P, const Range3 r) {
   CELL_FROM_GRID(r)
-  if (ghosts_only && i >= P.is && i <= P.ie && j >= P.js && j <= P.je && k >= P.ks && k <= P.ke) return;
+  if (GHOSTS && i >= P.is && i <= P.ie && j >= P.js && j <= P.je && k >= P.ks && k <= P.ke) return;
   double hx[3];
   scale_factors<CURV>(P, b, k, j, i, hx);
   {
@@ -927,7 +928,13 @@ void launch_cons_to_prim(const PackView &P, hipStream_t s) {
 }
 void launch_prim_to_cons(const PackView &P, hipStream_t s, bool ghosts_only) {
   const Range3 r = entire(P);
-  LAUNCH_GEOM(prim_to_cons_kernel, r, ghosts_only ? 1 : 0);
+  if (!ghosts_only) {
+    LAUNCH_GEOM(prim_to_cons_kernel, r);
+    return;
+  }
+  const Shape sh = shape_for(r, P.nb);
+  if (P.coords == ARTEMIS_CARTESIAN) hipLaunchKernelGGL((prim_to_cons_kernel<false, true>), sh.grid, sh.block, 0, s, P, r);
+  else hipLaunchKernelGGL((prim_to_cons_kernel<true, true>), sh.grid, sh.block, 0, s, P, r);
 }
 void launch_deep_copy(const PackView &P, hipStream_t s) {
   const Range3 r = entire(P);

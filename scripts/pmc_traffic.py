@@ -119,7 +119,7 @@ def main():
     kib = 1024.0
     calib = {}
     for name, rd, wr in (("cons_to_prim_kernel", 5 * 8 * interior, 5 * 8 * interior),
-                         ("prim_to_cons_kernel", 5 * 8 * entire, 9 * 8 * entire)):
+                         ("prim_to_cons_kernel<false, false>", 5 * 8 * entire, 9 * 8 * entire)):  # (not the ghost-zone form <false, true>)
         f, w = pick(fetch, name), pick(write, name)
         if f and w:
             fk, wk = list(f.values())[0][0], list(w.values())[0][0]
