@@ -125,7 +125,7 @@ class DiffCoeff(C.Structure):
 
 
 class Diffusion(C.Structure):
-    _fields_ = [("visc", DiffCoeff), ("cond", DiffCoeff), ("cv", C.c_double)]
+    _fields_ = [("visc", DiffCoeff), ("cond", DiffCoeff), ("cv", C.c_double), ("dist", C.c_void_p)]
 
 
 class Refine(C.Structure):
@@ -205,6 +205,8 @@ def load():
         "artemis_hip_amr_block_maxima": (i, [PPk, C.c_int, C.c_int, vp, vp]),
         "artemis_hip_amr_magnitude": (i, [C.POINTER(AmrCriterion), C.POINTER(C.c_int), C.POINTER(C.c_double), vp]),
         "artemis_hip_zero_diffusion_flux": (i, [PPk, vp]),
+        "artemis_hip_viscous_distance_count": (C.c_size_t, [PPk]),
+        "artemis_hip_viscous_distance_fill": (i, [PPk, vp, vp]),
         "artemis_hip_viscous_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
         "artemis_hip_zero_viscous_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
         "artemis_hip_thermal_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
@@ -267,7 +269,7 @@ EXPORTS_HIP = [
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",
     "artemis_hip_stage_general", "artemis_hip_stage_general_variant", "artemis_hip_stage_epilogue", "artemis_hip_amr_block_maxima", "artemis_hip_restrict_average",
     "artemis_hip_prolongate_minmod", "artemis_hip_amr_first_derivative", "artemis_hip_amr_magnitude",
-    "artemis_hip_zero_diffusion_flux",
+    "artemis_hip_zero_diffusion_flux", "artemis_hip_viscous_distance_count", "artemis_hip_viscous_distance_fill",
     "artemis_hip_viscous_flux", "artemis_hip_zero_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
     "artemis_hip_diffusion_dt", "artemis_hip_diffusion_radial_fill", "artemis_hip_halo_count", "artemis_hip_halo_count_ext",
     "artemis_hip_halo_pack_ext", "artemis_hip_halo_unpack_ext",

@@ -638,6 +638,18 @@ int artemis_hip_diffusion_radial_fill(const artemis_pack_t *p, const double *geo
       }
   return 0;
 }
+size_t artemis_hip_viscous_distance_count(const artemis_pack_t *p) {
+  if (validate(p)) return 0;
+  return artemis::viscous_distance_count(artemis::make_pack_view(*p));
+}
+int artemis_hip_viscous_distance_fill(const artemis_pack_t *p, double *table_dev, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (!table_dev) return fail(ARTEMIS_HIP_EINVAL, "viscous distance fill: table_dev is NULL");
+  if (artemis_hip_metric_count(p) > 0 && !p->metric)
+    return fail(ARTEMIS_HIP_EINVAL, "viscous distance fill: this coordinate system needs p->metric (artemis_hip_metric_fill)");
+  artemis::launch_viscous_distance_fill(artemis::make_pack_view(*p), table_dev, S(stream));
+  return after_launch("viscous distance fill");
+}
 int artemis_hip_zero_diffusion_flux(const artemis_pack_t *p, void *stream) {
   if (int rc = validate(p)) return rc;
   for (int dd = 0; dd < ((p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1)); ++dd)

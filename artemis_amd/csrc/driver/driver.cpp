@@ -252,6 +252,7 @@ struct artemis_sim_impl {
   artemis_diffusion_t diff;
   Field gdflux[3];
   Field visc_radial;  // per-cell radial factor of the viscosity law (host libm), diff.visc.radial
+  DevBuf diff_dist;   // Coords::Distance table of the diffusion flux tasks (static geometry), diff.dist
   Field ic_gas, ic_dust; // disk `ic` condition: the initial primitives as generated (disk.hpp:597-632)
   Field ic_gas_c, ic_dust_c; // ... evaluated on the coarse buffers of a refined mesh (their own zone centres)
   bool edge_ghosts = false; // sequential x1, x2, x3 exchange with extended slabs (viscosity)
@@ -1961,6 +1962,14 @@ void artemis_sim_impl::problem_generator() {
       upload_block(visc_radial, b, hr);
     }
     diff.visc.radial = visc_radial.tab();
+  }
+  if ((do_viscosity || do_conduction) && !getenv("ARTEMIS_NO_DISTANCE_TABLE")) {
+    // Coords::Distance between neighbouring cell centres is geometry: tabulated once per mesh (a remesh builds
+    // a new state through this constructor path, so the table follows the blocks)
+    const artemis_pack_t pk = make_pack(0);
+    diff_dist.alloc(artemis_hip_viscous_distance_count(&pk));
+    CK(artemis_hip_viscous_distance_fill(&pk, diff_dist.p, stream), "viscous distance table");
+    diff.dist = diff_dist.p;
   }
   // PostInitialization = PrimToCons on every block (main.cpp:43, fill_derived.cpp:284-287),
   // then parthenon Mesh::Initialize communicates boundaries (upstream, recalled):

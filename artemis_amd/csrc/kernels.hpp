@@ -42,6 +42,8 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
 // kernels_diffusion.hip
 void launch_zero_diffusion_flux(const PackView &P, hipStream_t s);
 // overwrite: ZeroDiffusionFlux folded in (the flux arrays are overwritten on the face ranges)
+size_t viscous_distance_count(const PackView &P);
+void launch_viscous_distance_fill(const PackView &P, double *tab, hipStream_t s);
 int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s, bool overwrite = false);
 void launch_thermal_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s);
 void launch_diffusion_update(const PackView &P, const artemis_diffusion_t &D, double dt, hipStream_t s);

@@ -58,10 +58,30 @@ struct Geo {
   // optional: the Cartesian images of this block's cell centres (ConvertCoordsToCart, written once per stage by
   // viscous_cell_kernel), so that a Distance is six cached loads instead of two Coords evaluations
   const double *xc0 = nullptr, *xc1 = nullptr, *xc2 = nullptr;
+  // optional: the table of artemis_hip_viscous_distance_fill (static geometry, host-owned): [6][nb][N] doubles,
+  // q = 0..2 Distance(cell, its lower x1 / x2 / x3 neighbour), q = 3..5 Distance(lower, upper neighbour)
+  const double *dtab = nullptr;
+  ADEV double dtab_at(int q, long c) const {
+    const long N = static_cast<long>(P.ni) * P.nj * P.nk;
+    return dtab[(static_cast<long>(q) * P.nb + b) * N + c];
+  }
   ADEV const double *g() const { return P.geom + 6 * b; }
   ADEV double x1v(int i) const { return 0.5 * ((g()[0] + i * g()[1]) + (g()[0] + (i + 1) * g()[1])); }
   ADEV double x2v(int j) const { return 0.5 * ((g()[2] + j * g()[3]) + (g()[2] + (j + 1) * g()[3])); }
   ADEV double x3v(int k) const { return 0.5 * ((g()[4] + k * g()[5]) + (g()[4] + (k + 1) * g()[5])); }
+  // Distance(cell c, lower neighbour along DIR) / Distance(lower, upper neighbour of c along DIR)
+  template <int DIR>
+  ADEV double dist_lower(int k, int j, int i) const {
+    constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1);
+    if (dtab) return dtab_at(DIR - 1, (static_cast<long>(k) * P.nj + j) * P.ni + i);
+    return dist(k, j, i, k - dk, j - dj, i - di);
+  }
+  template <int DIR>
+  ADEV double dist_across(int k, int j, int i) const {
+    constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1);
+    if (dtab) return dtab_at(2 + DIR, (static_cast<long>(k) * P.nj + j) * P.ni + i);
+    return dist(k - dk, j - dj, i - di, k + dk, j + dj, i + di);
+  }
   ADEV double dist(int k1, int j1, int i1, int k2, int j2, int i2) const {
     if constexpr (CURV) {
       if (xc0) {
@@ -98,9 +118,10 @@ __global__ __launch_bounds__(TX *TY) void zero_dflux_kernel(const PackView P, co
     for (int n = 0; n < nv; ++n) P.gas.dflux[d][b * nv + n][c] = 0.0;
 }
 
-// VelocityDivergence (momentum_diffusion.hpp:562-591) of cell (k,j,i), species n
+// VelocityDivergence (momentum_diffusion.hpp:562-591) of cell (k,j,i), species n: the numerator; the caller
+// divides by vol2 = 2 * cell volume
 template <bool CURV>
-ADEV double velocity_divergence(const PackView &P, double *const *prim, int b, int n, int k, int j, int i) {
+ADEV double velocity_divergence(const PackView &P, double *const *prim, int b, int n, int k, int j, int i, double &vol2) {
   const int ns = P.gas.ns, nv = 6 * ns;
   const int multid = (P.ndim >= 2), threed = (P.ndim == 3);
   const CellMetric m = cell_metric<CURV>(P, b, k, j, i);
@@ -114,7 +135,8 @@ ADEV double velocity_divergence(const PackView &P, double *const *prim, int b, i
   const double divv = a1[1] * (v1[c] + v1[c + 1]) - a1[0] * (v1[c] + v1[c - 1]) +
                       multid * a2[1] * (v2[c] + v2[c + sj]) - multid * a2[0] * (v2[c] + v2[c - sj]) +
                       threed * a3[1] * (v3[c] + v3[c + sk]) - threed * a3[0] * (v3[c] + v3[c - sk]);
-  return divv / (2.0 * m.vol);
+  vol2 = 2.0 * m.vol;
+  return divv;
 }
 
 // Per-cell quantities the face kernels share, written once per stage by viscous_cell_kernel (the
@@ -134,15 +156,25 @@ __global__ __launch_bounds__(TX *TY) void viscous_cell_kernel(const PackView P, 
   const long N = static_cast<long>(P.ni) * P.nj * P.nk;
   double hx[3];
   scale_factors<CURV>(P, b, k, j, i, hx);
-  if constexpr (CURV) { // geometry.hpp:248 of the cell centre, for Coords::Distance in the face kernels
+  if (CURV && !D.dist) { // geometry.hpp:248 of the cell centre, for Coords::Distance in the face kernels
     double xc[3];
     make_coords(P, b, k, j, i).centre_to_cart(xc);
     for (int d = 0; d < 3; ++d) w.xc[d][static_cast<long>(b) * N + c] = xc[d];
   }
   for (int n = 0; n < ns; ++n) {
     const long q = (static_cast<long>(b) * ns + n) * N + c;
-    for (int d = 0; d < 3; ++d) w.sv[d][q] = f.prim[b * nv + ns + 3 * n + d][c] / hx[d];
-    w.divu[q] = velocity_divergence<CURV>(P, f.prim, b, n, k, j, i);
+    const double v[3] = {f.prim[b * nv + ns + 3 * n + 0][c], f.prim[b * nv + ns + 3 * n + 1][c], f.prim[b * nv + ns + 3 * n + 2][c]};
+    double vol2;
+    const double divv = velocity_divergence<CURV>(P, f.prim, b, n, k, j, i, vol2);
+    // four quotients by geometry of order one: reciprocal form unless a numerator of this wave is tiny (see QuotF)
+    const bool odd = tiny_nonzero(v[0]) | tiny_nonzero(v[1]) | tiny_nonzero(v[2]) | tiny_nonzero(divv);
+    if (__any(odd)) {
+      for (int d = 0; d < 3; ++d) w.sv[d][q] = v[d] / hx[d];
+      w.divu[q] = divv / vol2;
+    } else {
+      for (int d = 0; d < 3; ++d) w.sv[d][q] = CURV ? div(v[d], hx[d]) : v[d];
+      w.divu[q] = div(divv, vol2);
+    }
     w.mu[q] = coeff_of(D.visc, D.cv, P.gm1, f.prim[b * nv + n][c], f.prim[b * nv + 5 * ns + n][c], b, c);
   }
 }
@@ -150,6 +182,44 @@ __global__ __launch_bounds__(TX *TY) void viscous_cell_kernel(const PackView P, 
 // MomentumFluxImpl (momentum_diffusion.hpp:597-755): StrainTensorFace<XDIR> (:28-377) and
 // StressTensorFaceX? (:379-560) of the lower `dir` face of cell (k,j,i)
 // OVERWRITE: store 0.0 + flux instead of adding to the array (ZeroDiffusionFlux folded in: same bits)
+//
+// The strain rows of the three directions have one shape.  With d = DIR - 1 the face-normal component and
+// t the two others in ascending order,
+//   flx[d] = (2 dv_d) / dxa + 0.5 (src + src_m)
+//   flx[t] = M_t 0.5 (dvt / dx_t + dvt_m / dx_t_m) + ((h_t / h_d)^2 dv_t) / dxa
+// where dv_* are differences of the contravariant velocities across the face, dvt / dvt_m the differences of the
+// normal velocity across the two cells along t, and dx_* the Coords::Distance between the centres involved.
+// Nine quotients per face: QuotF divides with one refined reciprocal per denominator (device_math.hpp: the
+// bits of an IEEE division for numerators that are zero or not tiny, which the caller checks per wave); QuotI is
+// the plain division.
+struct QuotF {
+  Recip r;
+  ADEV explicit QuotF(double b) : r(recip(b)) {}
+  ADEV double operator()(double a) const { return div(a, r); }
+};
+struct QuotI {
+  double b;
+  ADEV explicit QuotI(double b_) : b(b_) {}
+  ADEV double operator()(double a) const { return a / b; }
+};
+struct StrainIn {
+  double n_a[3];        // numerators over dxa: 2 dv_d and (h_t / h_d)^2 dv_t, by component
+  double n_t[2], n_tm[2]; // dvt, dvt_m of the two transverse components
+  double half_src;      // 0.5 (src + src_m)
+  double mfac[2];       // M_t * 0.5
+  double mu1, mu2;
+};
+template <int DIR, class Q>
+ADEV void strain_rows(const StrainIn &in, double dxa, const double dxt[2], const double dxtm[2], int avg, double flx[3],
+                      double &mus) {
+  constexpr int d = DIR - 1, t0 = (DIR == 1) ? 1 : 0, t1 = (DIR == 3) ? 1 : 2;
+  const Q qa(dxa), qb(dxt[0]), qbm(dxtm[0]), qc(dxt[1]), qcm(dxtm[1]);
+  flx[d] = qa(in.n_a[d]) + in.half_src;
+  flx[t0] = in.mfac[0] * (qb(in.n_t[0]) + qbm(in.n_tm[0])) + qa(in.n_a[t0]);
+  flx[t1] = in.mfac[1] * (qc(in.n_t[1]) + qcm(in.n_tm[1])) + qa(in.n_a[t1]);
+  const Q qm(in.mu1 + in.mu2); // face_average (diffusion_coeff.hpp:139-150)
+  mus = (avg == 0) * (0.5 * (in.mu1 + in.mu2)) + (avg == 1) * qm(2.0 * in.mu1 * in.mu2);
+}
 template <int DIR, bool CURV, bool OVERWRITE>
 ADEV void viscous_face(const PackView &P, const artemis_diffusion_t &D, const ViscScratch &w, const int b, const int k,
                        const int j, const int i, const long c) {
@@ -158,10 +228,13 @@ ADEV void viscous_face(const PackView &P, const artemis_diffusion_t &D, const Vi
   const int multid = (P.ndim >= 2), threed = (P.ndim == 3);
   const long N = static_cast<long>(P.ni) * P.nj * P.nk;
   Geo<CURV> ge{P, b};
+  ge.dtab = D.dist;
   if constexpr (CURV) ge.xc0 = w.xc[0] + b * N, ge.xc1 = w.xc[1] + b * N, ge.xc2 = w.xc[2] + b * N;
   const artemis_diffcoeff_t &dp = D.visc;
   constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1);
-  const long cm = c - ((DIR == 1) ? 1 : ((DIR == 2) ? P.sj : P.sk));
+  constexpr int d = DIR - 1, t0 = (DIR == 1) ? 1 : 0, t1 = (DIR == 3) ? 1 : 2;
+  const long sd = (DIR == 1) ? 1 : ((DIR == 2) ? P.sj : P.sk);
+  const long cm = c - sd;
   const double fuzz = 1e-99; // Fuzz<Real>()
   double hxf[3] = {1.0, 1.0, 1.0};
   if constexpr (CURV) make_coords(P, b, k, j, i).face_scale(DIR, hxf); // h_d at the face centroid
@@ -174,77 +247,70 @@ ADEV void viscous_face(const PackView &P, const artemis_diffusion_t &D, const Vi
     ge.conn(k - dk, j - dj, i - di, d21, d31, d32);
     dh0_m = (DIR == 2) ? d21 : d31, dh1_m = (DIR == 3) ? d32 : 0.0;
   }
-  // Coords::Distance between cell centres: geometry only, shared by the species
-  double dxa, dxb, dxb_m, dxc, dxc_m;
+  // Coords::Distance between cell centres: geometry only, shared by the species.  dxt / dxtm: across the face's
+  // own cell and across its lower neighbour, along the two transverse directions
+  const double dxa = ge.template dist_lower<DIR>(k, j, i);
+  double dxt[2], dxtm[2];
+  long st[2]; // strides of the transverse directions (0 where the direction is not active)
   if constexpr (DIR == 1) {
-    dxa = ge.dist(k, j, i, k, j, i - 1);
-    dxb = multid ? ge.dist(k, j - multid, i, k, j + multid, i) : fuzz;
-    dxb_m = multid ? ge.dist(k, j - multid, i - 1, k, j + multid, i - 1) : fuzz;
-    dxc = threed ? ge.dist(k - threed, j, i, k + threed, j, i) : fuzz;
-    dxc_m = threed ? ge.dist(k - threed, j, i - 1, k + threed, j, i - 1) : fuzz;
+    dxt[0] = multid ? ge.template dist_across<2>(k, j, i) : fuzz;
+    dxtm[0] = multid ? ge.template dist_across<2>(k, j, i - 1) : fuzz;
+    dxt[1] = threed ? ge.template dist_across<3>(k, j, i) : fuzz;
+    dxtm[1] = threed ? ge.template dist_across<3>(k, j, i - 1) : fuzz;
+    st[0] = multid * P.sj, st[1] = threed * P.sk;
   } else if constexpr (DIR == 2) {
-    dxb = ge.dist(k, j, i - 1, k, j, i + 1);
-    dxb_m = ge.dist(k, j - 1, i - 1, k, j - 1, i + 1);
-    dxa = ge.dist(k, j, i, k, j - 1, i);
-    dxc = threed ? ge.dist(k - threed, j, i, k + threed, j, i) : fuzz;
-    dxc_m = threed ? ge.dist(k - threed, j - 1, i, k + threed, j - 1, i) : fuzz;
+    dxt[0] = ge.template dist_across<1>(k, j, i);
+    dxtm[0] = ge.template dist_across<1>(k, j - 1, i);
+    dxt[1] = threed ? ge.template dist_across<3>(k, j, i) : fuzz;
+    dxtm[1] = threed ? ge.template dist_across<3>(k, j - 1, i) : fuzz;
+    st[0] = 1, st[1] = threed * P.sk;
   } else {
-    dxb = ge.dist(k, j, i - 1, k, j, i + 1);
-    dxb_m = ge.dist(k - 1, j, i - 1, k - 1, j, i + 1);
-    dxc = ge.dist(k, j - 1, i, k, j + 1, i);
-    dxc_m = ge.dist(k - 1, j - 1, i, k - 1, j + 1, i);
-    dxa = ge.dist(k, j, i, k - 1, j, i);
+    dxt[0] = ge.template dist_across<1>(k, j, i);
+    dxtm[0] = ge.template dist_across<1>(k - 1, j, i);
+    dxt[1] = ge.template dist_across<2>(k, j, i);
+    dxtm[1] = ge.template dist_across<2>(k - 1, j, i);
+    st[0] = 1, st[1] = P.sj;
   }
-  const long sj = multid * P.sj, sk = threed * P.sk;
+  // (h_t / h_d)^2 at the face centroid: geometry of order one, always the reciprocal form
+  double ratio[2] = {1.0, 1.0};
+  if constexpr (CURV) {
+    const QuotF qh(hxf[d]);
+    ratio[0] = sqr(qh(hxf[t0])), ratio[1] = sqr(qh(hxf[t1]));
+  }
   for (int n = 0; n < ns; ++n) {
     const long base = (static_cast<long>(b) * ns + n) * N;
-    const double *s0 = w.sv[0] + base, *s1 = w.sv[1] + base, *s2 = w.sv[2] + base;
+    const double *sv[3] = {w.sv[0] + base, w.sv[1] + base, w.sv[2] + base};
+    const double *sn = sv[d];
+    const double s_c[3] = {sv[0][c], sv[1][c], sv[2][c]}, s_m[3] = {sv[0][cm], sv[1][cm], sv[2][cm]};
     // v^k dh_a/dx_k / h_a of a cell (the third connection row is zero for every system)
-    const double src = s0[c] * dh0 + s1[c] * dh1 + s2[c] * 0.0;
-    const double src_m = s0[cm] * dh0_m + s1[cm] * dh1_m + s2[cm] * 0.0;
-    double flx[3];
-    if constexpr (DIR == 1) {
-      const double dv1 = s0[c] - s0[cm];
-      flx[0] = 2 * dv1 / dxa + 0.5 * (src + src_m);
-      const double dv2 = s1[c] - s1[cm];
-      const double dv12 = s0[c + sj] - s0[c - sj];
-      const double dv12_xm = s0[cm + sj] - s0[cm - sj];
-      flx[1] = multid * 0.5 * (dv12 / dxb + dv12_xm / dxb_m) + sqr(hxf[1] / hxf[0]) * dv2 / dxa;
-      const double dv3 = s2[c] - s2[cm];
-      const double dv13 = s0[c + sk] - s0[c - sk];
-      const double dv13_xm = s0[cm + sk] - s0[cm - sk];
-      flx[2] = threed * 0.5 * (dv13 / dxc + dv13_xm / dxc_m) + sqr(hxf[2] / hxf[0]) * dv3 / dxa;
-    } else if constexpr (DIR == 2) {
-      const double dv1 = s0[c] - s0[cm];
-      const double dv21 = s1[c + 1] - s1[c - 1];
-      const double dv21_ym = s1[cm + 1] - s1[cm - 1];
-      flx[0] = 0.5 * (dv21 / dxb + dv21_ym / dxb_m) + sqr(hxf[0] / hxf[1]) * dv1 / dxa;
-      const double dv2 = s1[c] - s1[cm];
-      flx[1] = 2 * dv2 / dxa + 0.5 * (src + src_m);
-      const double dv3 = s2[c] - s2[cm];
-      const double dv23 = s1[c + sk] - s1[c - sk];
-      const double dv23_ym = s1[cm + sk] - s1[cm - sk];
-      flx[2] = threed * 0.5 * (dv23 / dxc + dv23_ym / dxc_m) + sqr(hxf[2] / hxf[1]) * dv3 / dxa;
-    } else {
-      const double dv1 = s0[c] - s0[cm];
-      const double dv31 = s2[c + 1] - s2[c - 1];
-      const double dv31_zm = s2[cm + 1] - s2[cm - 1];
-      flx[0] = 0.5 * (dv31 / dxb + dv31_zm / dxb_m) + sqr(hxf[0] / hxf[2]) * dv1 / dxa;
-      const double dv2 = s1[c] - s1[cm];
-      const double dv32 = s2[c + P.sj] - s2[c - P.sj];
-      const double dv32_zm = s2[cm + P.sj] - s2[cm - P.sj];
-      flx[1] = 0.5 * (dv32 / dxc + dv32_zm / dxc_m) + sqr(hxf[1] / hxf[2]) * dv2 / dxa;
-      const double dv3 = s2[c] - s2[cm];
-      flx[2] = 2 * dv3 / dxa + 0.5 * (src + src_m);
+    const double src = s_c[0] * dh0 + s_c[1] * dh1 + s_c[2] * 0.0;
+    const double src_m = s_m[0] * dh0_m + s_m[1] * dh1_m + s_m[2] * 0.0;
+    StrainIn in;
+    in.n_a[d] = 2 * (s_c[d] - s_m[d]);
+    in.n_a[t0] = ratio[0] * (s_c[t0] - s_m[t0]);
+    in.n_a[t1] = ratio[1] * (s_c[t1] - s_m[t1]);
+    for (int t = 0; t < 2; ++t) {
+      in.n_t[t] = sn[c + st[t]] - sn[c - st[t]];
+      in.n_tm[t] = sn[cm + st[t]] - sn[cm - st[t]];
     }
-    const double mus = face_average(dp.avg, w.mu[base + c], w.mu[base + cm]);
+    in.half_src = 0.5 * (src + src_m);
+    if constexpr (DIR == 1) in.mfac[0] = multid * 0.5, in.mfac[1] = threed * 0.5;
+    else if constexpr (DIR == 2) in.mfac[0] = 0.5, in.mfac[1] = threed * 0.5;
+    else in.mfac[0] = 0.5, in.mfac[1] = 0.5;
+    in.mu1 = w.mu[base + c], in.mu2 = w.mu[base + cm];
+    double flx[3], mus;
+    const bool odd = tiny_nonzero(in.n_a[0]) | tiny_nonzero(in.n_a[1]) | tiny_nonzero(in.n_a[2]) | tiny_nonzero(in.n_t[0]) |
+                     tiny_nonzero(in.n_tm[0]) | tiny_nonzero(in.n_t[1]) | tiny_nonzero(in.n_tm[1]) |
+                     tiny_nonzero(in.mu1 * in.mu2) | !(in.mu1 + in.mu2 > 0x1p-200);
+    if (__any(odd)) strain_rows<DIR, QuotI>(in, dxa, dxt, dxtm, dp.avg, flx, mus);
+    else strain_rows<DIR, QuotF>(in, dxa, dxt, dxtm, dp.avg, flx, mus);
     const double divu = w.divu[base + c], divu_m = w.divu[base + cm];
     const double hf = hxf[DIR - 1];
     double fl[3];
     for (int qq = 0; qq < 3; ++qq) fl[qq] = hf * mus * flx[qq];
     fl[DIR - 1] = hf * mus * (flx[DIR - 1] - 1. / 3 * (1. - dp.eta) * (divu + divu_m));
     double *const *qf = f.dflux[DIR - 1];
-    const double fe = 0.5 * (s0[c] + s0[cm]) * fl[0] + 0.5 * (s1[c] + s1[cm]) * fl[1] + 0.5 * (s2[c] + s2[cm]) * fl[2];
+    const double fe = 0.5 * (s_c[0] + s_m[0]) * fl[0] + 0.5 * (s_c[1] + s_m[1]) * fl[1] + 0.5 * (s_c[2] + s_m[2]) * fl[2];
     if constexpr (OVERWRITE) {
       for (int qq = 0; qq < 3; ++qq) qf[b * nq + 3 * n + qq][c] = 0.0 + fl[qq];
       qf[b * nq + 3 * ns + n][c] = 0.0 + fe;
@@ -266,6 +332,8 @@ __global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, 
 template <bool CURV, bool OVERWRITE>
 __global__ __launch_bounds__(TX *TY) void viscous_flux3_kernel(const PackView P, const Box r,
                                                                const artemis_diffusion_t D, const ViscScratch w) {
+  // (a k-march form -- one thread per (i, j) column of 8 planes, the (x1, x2)-only metric hoisted out of the plane
+  // loop -- was measured at 470 us against 306 us for this one on the 256 x 128^2 spherical disk: 249 registers)
   BOX_CELL(r)
   const bool in1 = i <= P.ie, in2 = j <= P.je || P.ndim < 2, in3 = k <= P.ke || P.ndim < 3;
   if (in2 && in3) viscous_face<1, CURV, OVERWRITE>(P, D, w, b, k, j, i, c);
@@ -275,6 +343,23 @@ __global__ __launch_bounds__(TX *TY) void viscous_flux3_kernel(const PackView P,
 
 
 
+// artemis_hip_viscous_distance_fill: the six Coords::Distance values (geometry.hpp:407-412) a cell contributes
+// to the face kernels, evaluated exactly as Geo::dist does without its cache.  Static geometry: the host fills
+// the table once per mesh.  Entries whose neighbours fall outside the block's arrays are left alone (never read).
+template <bool CURV>
+__global__ __launch_bounds__(TX *TY) void distance_fill_kernel(const PackView P, const Box r, double *tab) {
+  BOX_CELL(r)
+  const Geo<CURV> ge{P, b};
+  const long N = static_cast<long>(P.ni) * P.nj * P.nk;
+  const int hi[3] = {P.ni - 1, P.nj - 1, P.nk - 1}, at[3] = {i, j, k};
+  for (int dir = 0; dir < P.ndim; ++dir) {
+    const int di = (dir == 0), dj = (dir == 1), dk = (dir == 2);
+    if (at[dir] >= 1) tab[(static_cast<long>(dir) * P.nb + b) * N + c] = ge.dist(k, j, i, k - dk, j - dj, i - di);
+    if (at[dir] >= 1 && at[dir] < hi[dir])
+      tab[(static_cast<long>(3 + dir) * P.nb + b) * N + c] = ge.dist(k - dk, j - dj, i - di, k + dk, j + dj, i + di);
+  }
+}
+
 // ThermalFluxImpl (thermal_diffusion.hpp:30-222)
 template <int DIR, bool CURV>
 __global__ __launch_bounds__(TX *TY) void thermal_flux_kernel(const PackView P, const Box r,
@@ -282,11 +367,11 @@ __global__ __launch_bounds__(TX *TY) void thermal_flux_kernel(const PackView P, 
   BOX_CELL(r)
   const FluidView &f = P.gas;
   const int ns = f.ns, nv = 6 * ns, nq = 4 * ns;
-  const Geo<CURV> ge{P, b};
+  Geo<CURV> ge{P, b};
+  ge.dtab = D.dist;
   const artemis_diffcoeff_t &dp = D.cond;
-  constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1);
   const long cm = c - ((DIR == 1) ? 1 : ((DIR == 2) ? P.sj : P.sk));
-  const double dx = ge.dist(k, j, i, k - dk, j - dj, i - di);
+  const double dx = ge.template dist_lower<DIR>(k, j, i);
   for (int n = 0; n < ns; ++n) {
     const double *rho = f.prim[b * nv + n], *se = f.prim[b * nv + 5 * ns + n];
     const double T = amax(0.0, se[c] / D.cv);   // IdealGas TemperatureFromDensityInternalEnergy
@@ -392,6 +477,12 @@ thread_local struct {
   double *p = nullptr;
   size_t n = 0;
 } g_visc;
+size_t viscous_distance_count(const PackView &P) { return 6 * static_cast<size_t>(P.nb) * P.ni * P.nj * P.nk; }
+void launch_viscous_distance_fill(const PackView &P, double *tab, hipStream_t s) {
+  const Box r{0, P.ni - 1, 0, P.nj - 1, 0, P.nk - 1};
+  if (P.coords != ARTEMIS_CARTESIAN) hipLaunchKernelGGL(distance_fill_kernel<true>, grid_of(r, P.nb), threads_of(r), 0, s, P, r, tab);
+  else hipLaunchKernelGGL(distance_fill_kernel<false>, grid_of(r, P.nb), threads_of(r), 0, s, P, r, tab);
+}
 int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s, bool overwrite) {
   const size_t N = static_cast<size_t>(P.ni) * P.nj * P.nk, per = static_cast<size_t>(P.nb) * P.gas.ns * N;
   const size_t geo = 3 * static_cast<size_t>(P.nb) * N, need = 5 * per + geo;

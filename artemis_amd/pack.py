@@ -275,6 +275,15 @@ class MeshBlockPack:
         D.visc.radial = self._radial_tab.data_ptr()
         return self._radial
 
+    def distance_table(self, D):
+        """Fill the static Coords::Distance table of this pack (artemis_hip_viscous_distance_fill) and point
+        D.dist at it: the viscous / thermal flux tasks then look the distances up (same bits)."""
+        n = int(self.L.artemis_hip_viscous_distance_count(C.byref(self.pack)))
+        self._dist = torch.zeros(n, dtype=torch.float64, device=self.dev)
+        self._call(self.L.artemis_hip_viscous_distance_fill, self._dist.data_ptr())
+        D.dist = self._dist.data_ptr()
+        return self._dist
+
     def cooling_params(self, gamma, gm, beta0, beta_min=1e-12, exp_scale=0.0, tfloor=0.0, tcyl=0.0, cyl_plaw=0.0,
                        tsph=0.0, sph_plaw=0.0, mu=1.0):
         """capi.Cooling from the <cooling> keys, with the Tref / beta tables filled on the host

@@ -376,7 +376,16 @@ typedef struct artemis_diffcoeff { /* DiffCoeffParams, diffusion_coeff.hpp:58-13
 typedef struct artemis_diffusion {
   artemis_diffcoeff_t visc, cond;
   double cv;                  /* IdealGas specific heat: T = sie / cv (gas.cpp:106-116) */
+  const double *dist;         /* optional DEVICE table of artemis_hip_viscous_distance_count(p) doubles filled by
+                                 artemis_hip_viscous_distance_fill: the Coords::Distance values between neighbouring
+                                 cell centres (geometry.hpp:407-412) the flux tasks divide by.  They are static
+                                 geometry; with the table the viscous / thermal flux tasks look them up instead of
+                                 evaluating 15 square roots per cell and stage (same bits).  NULL = on the fly. */
 } artemis_diffusion_t;
+/* The table behind artemis_diffusion_t.dist: [6][nblocks][(nx3+2g)(nx2+2g)(nx1+2g)] doubles (directions that are
+ * not active stay untouched).  Fill once per mesh (again after a remesh or a change of p->geom / p->metric). */
+size_t artemis_hip_viscous_distance_count(const artemis_pack_t *p);
+int artemis_hip_viscous_distance_fill(const artemis_pack_t *p, double *table_dev, void *stream);
 /* Radial factor of one block's cells for a viscosity law, on the HOST with the host libm:
  * PLAW  -> std::pow(R / r0, r_exp), R = ConvertToCyl(cell centre)[0]   (diffusion_coeff.hpp:222-224)
  * ALPHA -> omega0 * std::pow(r / r0, -1.5), r = ConvertToSph(centre)[0]  (:262-264)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """SQ counters of the stage kernels: python3 scripts/pmc_sq.py <tag> -- <program args...>
 Runs `rocprofv3 --pmc <group> --kernel-trace` once per counter group (never with other trace domains) and prints
-per-kernel means for kernels whose name contains 'stage'."""
+per-kernel means for kernels whose name contains 'stage' (or one of the comma-separated PMC_SQ_KERNELS)."""
 import collections, csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GROUPS = [["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU"],
@@ -24,7 +24,7 @@ for gi, g in enumerate(GROUPS):
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            if "stage" not in k:
+            if not any(n in k for n in os.environ.get("PMC_SQ_KERNELS", "stage").split(",")):
                 continue
             tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
             if row["Counter_Name"] == g[0]:

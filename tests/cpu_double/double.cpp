@@ -648,6 +648,12 @@ int artemis_hip_diffusion_radial_fill(const artemis_pack_t *p, const double *geo
       }
   return 0;
 }
+// the distance table is an optimisation of the device kernels; the double evaluates Coords::Distance directly
+size_t artemis_hip_viscous_distance_count(const artemis_pack_t *p) {
+  const int g = p->nghost;
+  return 6 * static_cast<size_t>(p->nblocks) * (p->nx1 + 2 * g) * (p->nx2 > 1 ? p->nx2 + 2 * g : 1) * (p->nx3 > 1 ? p->nx3 + 2 * g : 1);
+}
+int artemis_hip_viscous_distance_fill(const artemis_pack_t *, double *, void *) { return 0; }
 int artemis_hip_zero_diffusion_flux(const artemis_pack_t *p, void *) {
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);

@@ -41,8 +41,8 @@ CART = [("cartesian", nx, (-1.0, -0.5, 0.25), (1.0, 0.8, 0.95))
 
 @pytest.mark.parametrize("coordinates,nx,lo,hi", CART + CURVI)
 @pytest.mark.parametrize("avg", ["arithmetic", "harmonic"])
-@pytest.mark.parametrize("ctype", ["conductivity", "diffusivity"])
-def test_diffusion_tasks(hiplib, coordinates, nx, lo, hi, avg, ctype):
+@pytest.mark.parametrize("ctype,table", [("conductivity", False), ("diffusivity", False), ("conductivity", True)])
+def test_diffusion_tasks(hiplib, coordinates, nx, lo, hi, avg, ctype, table):
     from artemis_amd.pack import diffusion_params
     o, mb = pair(nx, ns_gas=2, seed=51, coordinates=coordinates, lo=lo, hi=hi)
     o.set_viscosity("constant", nu=0.03, eta_bulk=0.4, averaging=avg)
@@ -50,6 +50,8 @@ def test_diffusion_tasks(hiplib, coordinates, nx, lo, hi, avg, ctype):
     o.set_conductivity(ctype, averaging=avg, **ck)
     D = diffusion_params(1.4, viscosity=dict(type="constant", nu=0.03, eta_bulk=0.4, averaging=avg),
                          conductivity=dict(type=ctype, averaging=avg, **ck))
+    if table:  # the static Coords::Distance table (artemis_hip_viscous_distance_fill): same bits as on the fly
+        mb.distance_table(D)
     o.ZeroDiffusionFlux(), mb.ZeroDiffusionFlux()
     o.ViscousFlux(), mb.ViscousFlux(D)
     for d in range(o.ndim):
@@ -69,6 +71,32 @@ def test_diffusion_tasks(hiplib, coordinates, nx, lo, hi, avg, ctype):
     # Gas::EstimateTimestepMesh = cfl * min(hydro, viscous, conductive) (gas.cpp:435-467)
     hyd = mb.EstimateTimestepMesh(0, cfl=0.3)
     assert min(hyd, mb.DiffusionTimestep(D, 0.3)) == o.EstimateTimestepMesh(0)
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", [CART[0], CURVI[2], CURVI[3]])
+@pytest.mark.parametrize("table", [False, True])
+def test_viscous_flux_with_vanishing_velocities(hiplib, coordinates, nx, lo, hi, table):
+    """The face kernels divide through shared reciprocals, which is the bits of an IEEE division only while the
+    numerators are zero or not tiny; a wave that sees a tiny one takes the plain divisions.  Velocities of
+    1e-300 (ahead of a shock they decay like that), exact zeros and ordinary values side by side."""
+    from artemis_amd.pack import diffusion_params
+    o, mb = pair(nx, ns_gas=1, seed=77, coordinates=coordinates, lo=lo, hi=hi)
+    rng = np.random.default_rng(5)
+    w = o.gprim  # [nvar, nk, nj, ni]: density, three velocities, ...
+    scale = rng.choice([1.0, 0.0, 1e-300, 1e-306, 1e-250, 1e-160, 1e-40], size=w[1].shape,
+                       p=[0.35, 0.15, 0.1, 0.1, 0.1, 0.1, 0.1])
+    for v in (1, 2, 3):
+        w[v] *= scale
+    o.PrimToCons()
+    push([o], mb)
+    o.set_viscosity("constant", nu=0.03, eta_bulk=0.4, averaging="harmonic")
+    D = diffusion_params(1.4, viscosity=dict(type="constant", nu=0.03, eta_bulk=0.4, averaging="harmonic"))
+    if table:
+        mb.distance_table(D)
+    o.ZeroDiffusionFlux(), o.ViscousFlux()
+    mb.ZeroViscousFlux(D)
+    for d in range(o.ndim):
+        same(mb.gas_diff_flux[d][0][face_slices(o, d)], o.qflux(d)[face_slices(o, d)], f"viscous flux x{d+1}")
 
 
 def test_conduction_only_update_and_contract(hiplib):
