@@ -1968,6 +1968,7 @@ void artemis_sim_impl::problem_generator() {
     // a new state through this constructor path, so the table follows the blocks)
     const artemis_pack_t pk = make_pack(0);
     diff_dist.alloc(artemis_hip_viscous_distance_count(&pk));
+    CK(artemis_rt_device_sync(), "sync"); // (the allocation is cleared on the null stream)
     CK(artemis_hip_viscous_distance_fill(&pk, diff_dist.p, stream), "viscous distance table");
     diff.dist = diff_dist.p;
   }

@@ -35,18 +35,43 @@ inline dim3 tile_threads(int nx) {
   while (tx > 8 && tx / 2 >= nx) tx >>= 1;
   return dim3(tx, TX * TY / tx);
 }
-inline dim3 threads_of(const Box &r) { return tile_threads(r.iu - r.il + 1); }
+// (ranges the tiles cover badly are walked flat, 256 consecutive zones per workgroup: see kernels_unfused.hip)
+inline bool flat_range(const Box &r) {
+  const int nx = r.iu - r.il + 1, ny = r.ju - r.jl + 1;
+  const dim3 t = tile_threads(nx);
+  const long covered = static_cast<long>((nx + t.x - 1) / t.x) * t.x * ((ny + t.y - 1) / t.y) * t.y;
+  return static_cast<long>(nx) * ny * 10 < covered * 8 && !getenv("ARTEMIS_NO_FLAT_RANGES");
+}
+inline dim3 threads_of(const Box &r) { return flat_range(r) ? dim3(TX * TY, 1, 1) : tile_threads(r.iu - r.il + 1); }
 inline dim3 grid_of(const Box &r, int nb) {
-  const dim3 t = threads_of(r);
-  return dim3((r.iu - r.il + t.x) / t.x, (r.ju - r.jl + t.y) / t.y, (r.ku - r.kl + 1) * nb);
+  const int nx = r.iu - r.il + 1, ny = r.ju - r.jl + 1, nz = r.ku - r.kl + 1;
+  if (flat_range(r)) return dim3(static_cast<unsigned>((static_cast<long>(nx) * ny * nz + TX * TY - 1) / (TX * TY)), 1, nb);
+  const dim3 t = tile_threads(nx);
+  return dim3((nx + t.x - 1) / t.x, (ny + t.y - 1) / t.y, nz * nb);
+}
+struct CellIdx {
+  int i, j, k, b;
+  bool ok;
+};
+__device__ __forceinline__ CellIdx cell_of_box(const Box &r) {
+  CellIdx q;
+  if (blockDim.y == 1) { // flat walk
+    const int nx = r.iu - r.il + 1, ny = r.ju - r.jl + 1;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, row = p / nx;
+    q.i = r.il + (p - row * nx), q.j = r.jl + row % ny, q.k = r.kl + row / ny, q.b = blockIdx.z;
+    q.ok = q.k <= r.ku;
+  } else {
+    const int nkr = r.ku - r.kl + 1;
+    q.i = r.il + blockIdx.x * blockDim.x + threadIdx.x, q.j = r.jl + blockIdx.y * blockDim.y + threadIdx.y;
+    q.b = blockIdx.z / nkr, q.k = r.kl + blockIdx.z % nkr;
+    q.ok = q.i <= r.iu && q.j <= r.ju;
+  }
+  return q;
 }
 #define BOX_CELL(r)                                                                         \
-  const int i = (r).il + blockIdx.x * blockDim.x + threadIdx.x;                            \
-  const int j = (r).jl + blockIdx.y * blockDim.y + threadIdx.y;                            \
-  const int nkr = (r).ku - (r).kl + 1;                                                     \
-  const int b = blockIdx.z / nkr;                                                          \
-  const int k = (r).kl + blockIdx.z % nkr;                                                 \
-  if (i > (r).iu || j > (r).ju) return;                                                    \
+  const CellIdx ci_ = cell_of_box(r);                                                      \
+  if (!ci_.ok) return;                                                                     \
+  const int i = ci_.i, j = ci_.j, k = ci_.k, b = ci_.b;                                    \
   const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
 
 // Geometry of one block as the diffusion tasks need it: cell centres, Coords::Distance between two

@@ -1,3 +1,4 @@
 cd /root/repo
 export TMPDIR=/tmp
-PMC_SQ_KERNELS=viscous timeout 900 python3 scripts/pmc_sq.py visc -- bench.py --workload disk_sph --no-cpu-baseline --steps 6 --warmup 2 2>&1 | tail -8
+timeout 1500 python -m pytest tests/test_multilevel.py tests/test_adaptive.py tests/test_parity_disk.py tests/test_driver_gpu.py -x -q -m gpu > gpurun_out/drv_tests.log 2>&1
+grep -E "passed|failed|^E " gpurun_out/drv_tests.log | head -10
