@@ -258,6 +258,7 @@ int artemis_hip_apply_bc(const artemis_pack_t *p, const int *bc, const artemis_b
   const int rc = artemis::launch_apply_bc(artemis::make_pack_view(*p), bc, params, S(stream));
   if (rc == 1) return fail(ARTEMIS_HIP_EDEVICE, "could not read pointer tables from the device");
   if (rc == 2) return fail(ARTEMIS_HIP_EUNSUPPORTED, "too many FillGhost variables (max 64)");
+  if (rc == 3) return fail(ARTEMIS_HIP_EUNSUPPORTED, "boundary conditions: a block's ghost shell holds 2^31 zones or more");
   return after_launch("ApplyBoundaryConditions");
 }
 

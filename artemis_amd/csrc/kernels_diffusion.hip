@@ -40,7 +40,7 @@ inline bool flat_range(const Box &r) {
   const int nx = r.iu - r.il + 1, ny = r.ju - r.jl + 1;
   const dim3 t = tile_threads(nx);
   const long covered = static_cast<long>((nx + t.x - 1) / t.x) * t.x * ((ny + t.y - 1) / t.y) * t.y;
-  return static_cast<long>(nx) * ny * 10 < covered * 8 && !getenv("ARTEMIS_NO_FLAT_RANGES");
+  return static_cast<long>(nx) * ny * 10 < covered * 6 && !getenv("ARTEMIS_NO_FLAT_RANGES");
 }
 inline dim3 threads_of(const Box &r) { return flat_range(r) ? dim3(TX * TY, 1, 1) : tile_threads(r.iu - r.il + 1); }
 inline dim3 grid_of(const Box &r, int nb) {

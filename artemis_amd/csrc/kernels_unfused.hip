@@ -32,8 +32,8 @@ inline dim3 tile_threads(int nx) {
 struct Shape {
   dim3 grid, block;
 };
-// Ranges the tiles cover badly -- the 17 x 17 x 9 face range or the 24 x 24 x 16 array of a 16 x 16 x 8 block of a
-// refined mesh fill 38 % / 75 % of the lanes of 32 x 8 tiles -- are walked FLAT instead: 256 consecutive zones of
+// Ranges the tiles cover badly -- the 17 x 17 x 9 face range of a 16 x 16 x 8 block of a
+// refined mesh fills 38 % of the lanes of 32 x 8 tiles; below 60 % a range is walked FLAT instead: 256 consecutive zones of
 // the range per workgroup (block shape (256, 1, 1), which no tile has, is how the kernels tell).
 inline Shape shape_for(const Range3 &r, int nb) {
   const int nx = r.iu - r.il + 1, ny = r.ju - r.jl + 1, nz = r.ku - r.kl + 1;
@@ -42,7 +42,7 @@ inline Shape shape_for(const Range3 &r, int nb) {
   const int tx = s.block.x, ty = s.block.y;
   s.grid = dim3((nx + tx - 1) / tx, (ny + ty - 1) / ty, nz * nb);
   const long covered = static_cast<long>(s.grid.x) * tx * s.grid.y * ty, used = static_cast<long>(nx) * ny;
-  if (used * 10 < covered * 8 && !getenv("ARTEMIS_NO_FLAT_RANGES")) {
+  if (used * 10 < covered * 6 && !getenv("ARTEMIS_NO_FLAT_RANGES")) {
     s.block = dim3(TX * TY, 1, 1);
     s.grid = dim3(static_cast<unsigned>((used * nz + TX * TY - 1) / (TX * TY)), 1, nb);
   }
@@ -812,27 +812,30 @@ __global__ __launch_bounds__(256) void bc_shell_kernel(ShellArgs a, FillTabs t, 
     t.b = batch.blk[q];
     for (int f = 0; f < 6; ++f) a.bc[f] = batch.bc[q][f];
   }
-  long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  // (the three regions of one block hold < 2^31 zones: the launcher checks; 32-bit divisions)
+  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned nA = static_cast<unsigned>(a.nA), nB = static_cast<unsigned>(a.nB), nC = static_cast<unsigned>(a.nC);
+  const unsigned e0 = a.ext[0], e1 = a.ext[1];
   int idx[3];
-  const int g2 = 2 * a.ng;
-  if (tid < a.nA) { // k in ghost planes, all j, all i
-    idx[0] = tid % a.ext[0];
-    idx[1] = (tid / a.ext[0]) % a.ext[1];
-    const int kk = tid / (static_cast<long>(a.ext[0]) * a.ext[1]);
-    idx[2] = (kk < a.ng) ? kk : a.hi[2] + 1 + (kk - a.ng);
-  } else if (tid < a.nA + a.nB) { // k interior, j in ghost rows
-    tid -= a.nA;
-    idx[0] = tid % a.ext[0];
-    const int jj = (tid / a.ext[0]) % g2;
-    idx[1] = (jj < a.ng) ? jj : a.hi[1] + 1 + (jj - a.ng);
-    idx[2] = a.lo[2] + tid / (static_cast<long>(a.ext[0]) * g2);
-  } else if (tid < a.nA + a.nB + a.nC) { // k, j interior, i in ghost columns
-    tid -= a.nA + a.nB;
-    const int ii = tid % g2;
-    idx[0] = (ii < a.ng) ? ii : a.hi[0] + 1 + (ii - a.ng);
-    const int ny = a.hi[1] - a.lo[1] + 1;
-    idx[1] = a.lo[1] + (tid / g2) % ny;
-    idx[2] = a.lo[2] + tid / (static_cast<long>(g2) * ny);
+  const unsigned g2 = 2 * a.ng;
+  if (tid < nA) { // k in ghost planes, all j, all i
+    const unsigned row = tid / e0, kk = row / e1;
+    idx[0] = tid - row * e0;
+    idx[1] = row - kk * e1;
+    idx[2] = (static_cast<int>(kk) < a.ng) ? kk : a.hi[2] + 1 + (kk - a.ng);
+  } else if (tid < nA + nB) { // k interior, j in ghost rows
+    tid -= nA;
+    const unsigned row = tid / e0, kk = row / g2, jj = row - kk * g2;
+    idx[0] = tid - row * e0;
+    idx[1] = (static_cast<int>(jj) < a.ng) ? jj : a.hi[1] + 1 + (jj - a.ng);
+    idx[2] = a.lo[2] + kk;
+  } else if (tid < nA + nB + nC) { // k, j interior, i in ghost columns
+    tid -= nA + nB;
+    const unsigned ny = a.hi[1] - a.lo[1] + 1;
+    const unsigned row = tid / g2, ii = tid - row * g2, kk = row / ny;
+    idx[0] = (static_cast<int>(ii) < a.ng) ? ii : a.hi[0] + 1 + (ii - a.ng);
+    idx[1] = a.lo[1] + (row - kk * ny);
+    idx[2] = a.lo[2] + kk;
   } else {
     return;
   }
@@ -855,18 +858,30 @@ __global__ __launch_bounds__(256) void bc_shell_kernel(ShellArgs a, FillTabs t, 
   if (!moved) return;
   const long cd = (static_cast<long>(idx[2]) * a.ext[1] + idx[1]) * a.ext[0] + idx[0];
   const long cs = (static_cast<long>(src[2]) * a.ext[1] + src[1]) * a.ext[0] + src[0];
-  for (int v = 0; v < a.nfill; ++v) {
-    bool n0, n1, n2;
-    double *q = fill_var(t, v, 0, n0);
-    fill_var(t, v, 1, n1);
-    fill_var(t, v, 2, n2);
-    // sequential passes multiply by -1.0 once per reflecting wall crossed along the
-    // component's own direction
-    double val = q[cs];
-    if ((refl & 1) && n0) val = -1.0 * val;
-    if ((refl & 2) && n1) val = -1.0 * val;
-    if ((refl & 4) && n2) val = -1.0 * val;
-    q[cd] = val;
+  // the variables are separate arrays: five loads in flight before the five stores (one variable at a time was a
+  // chain of pointer load -> value load -> store per variable, 55 us for the shell of a 256^3 block)
+  constexpr int NV = 5;
+  for (int v0 = 0; v0 < a.nfill; v0 += NV) {
+    double *q[NV];
+    double val[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int v = (v0 + u < a.nfill) ? v0 + u : v0;
+      bool n0, n1, n2;
+      q[u] = fill_var(t, v, 0, n0);
+      fill_var(t, v, 1, n1);
+      fill_var(t, v, 2, n2);
+      // sequential passes multiply by -1.0 once per reflecting wall crossed along the
+      // component's own direction
+      double w = q[u][cs];
+      if ((refl & 1) && n0) w = -1.0 * w;
+      if ((refl & 2) && n1) w = -1.0 * w;
+      if ((refl & 4) && n2) w = -1.0 * w;
+      val[u] = w;
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+      if (v0 + u < a.nfill) q[u][cd] = val[u];
   }
 }
 
@@ -1081,6 +1096,7 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
   a.nB = (P.ndim > 1) ? nz * 2L * P.ng * P.ni : 0;
   a.nC = nz * ny * 2L * P.ng;
   const long n = a.nA + a.nB + a.nC;
+  if (n >= (1L << 31)) return 3; // (a block with 2^31 shell zones)
   ShellBatch batch;
   int nq = 0;
   auto flush = [&]() {
