@@ -355,7 +355,7 @@ __global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, 
 // thread computes the lower x1 / x2 / x3 faces its cell owns (the shared per-cell scratch is read once instead
 // of three times, nothing is read-modify-written); OVERWRITE also replaces the zeroing pass.
 template <bool CURV, bool OVERWRITE>
-__global__ __launch_bounds__(TX *TY) void viscous_flux3_kernel(const PackView P, const Box r,
+__global__ __launch_bounds__(TX *TY, 4) void viscous_flux3_kernel(const PackView P, const Box r,
                                                                const artemis_diffusion_t D, const ViscScratch w) {
   // (a k-march form -- one thread per (i, j) column of 8 planes, the (x1, x2)-only metric hoisted out of the plane
   // loop -- was measured at 470 us against 306 us for this one on the 256 x 128^2 spherical disk: 249 registers)

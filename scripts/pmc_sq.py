@@ -8,7 +8,10 @@ GROUPS = [["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU"],
           ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"],
           ["SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT"],
           ["SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_ACTIVE_INST_VMEM"],
-          ["SQ_INST_CYCLES_SALU", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_MISC"]]
+          ["SQ_INST_CYCLES_SALU", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_MISC"],
+          ["SQC_ICACHE_REQ", "SQC_ICACHE_HITS", "SQC_ICACHE_MISSES", "SQ_IFETCH"]]
+if os.environ.get("PMC_SQ_GROUPS"):  # e.g. PMC_SQ_GROUPS=0,5
+    GROUPS = [GROUPS[int(x)] for x in os.environ["PMC_SQ_GROUPS"].split(",")]
 tag = sys.argv[1]
 prog = sys.argv[sys.argv.index("--") + 1:]
 acc = collections.defaultdict(dict)
