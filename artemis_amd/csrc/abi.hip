@@ -125,7 +125,12 @@ int artemis_hip_calculate_fluxes(const artemis_pack_t *p, int fluid, int pcm, vo
   const artemis_fluid_pack_t &f = (fluid == ARTEMIS_GAS) ? p->gas : p->dust;
   if (f.nspecies == 0) return 0;
   const artemis::PackView P = artemis::make_pack_view(*p);
-  artemis::launch_calculate_fluxes(P, fluid, f.riemann, pcm ? ARTEMIS_PCM : f.recon, S(stream));
+  const int recon = pcm ? ARTEMIS_PCM : f.recon;
+  // gas on Cartesian blocks at least a tile wide: the LDS-staged march of the fused stage with the task's stores
+  if (fluid == ARTEMIS_GAS && artemis::fused_flux_covers(P, recon) && p->gas.flux[0] && p->gas.pflux[0] && p->gas.vface[0]) {
+    if (artemis::launch_flux_fused(P, f.riemann, recon, S(stream)) == 0) return after_launch("CalculateFluxes (tile march)");
+  }
+  artemis::launch_calculate_fluxes(P, fluid, f.riemann, recon, S(stream));
   return after_launch("CalculateFluxes");
 }
 

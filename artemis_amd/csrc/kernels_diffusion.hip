@@ -192,7 +192,7 @@ __global__ __launch_bounds__(TX *TY) void viscous_cell_kernel(const PackView P, 
     double vol2;
     const double divv = velocity_divergence<CURV>(P, f.prim, b, n, k, j, i, vol2);
     // four quotients by geometry of order one: reciprocal form unless a numerator of this wave is tiny (see QuotF)
-    const bool odd = tiny_nonzero(v[0]) | tiny_nonzero(v[1]) | tiny_nonzero(v[2]) | tiny_nonzero(divv);
+    const bool odd = tiny_nonzero(v[0]) || tiny_nonzero(v[1]) || tiny_nonzero(v[2]) || tiny_nonzero(divv);
     if (__any(odd)) {
       for (int d = 0; d < 3; ++d) w.sv[d][q] = v[d] / hx[d];
       w.divu[q] = divv / vol2;
@@ -324,9 +324,9 @@ ADEV void viscous_face(const PackView &P, const artemis_diffusion_t &D, const Vi
     else in.mfac[0] = 0.5, in.mfac[1] = 0.5;
     in.mu1 = w.mu[base + c], in.mu2 = w.mu[base + cm];
     double flx[3], mus;
-    const bool odd = tiny_nonzero(in.n_a[0]) | tiny_nonzero(in.n_a[1]) | tiny_nonzero(in.n_a[2]) | tiny_nonzero(in.n_t[0]) |
-                     tiny_nonzero(in.n_tm[0]) | tiny_nonzero(in.n_t[1]) | tiny_nonzero(in.n_tm[1]) |
-                     tiny_nonzero(in.mu1 * in.mu2) | !(in.mu1 + in.mu2 > 0x1p-200);
+    const bool odd = tiny_nonzero(in.n_a[0]) || tiny_nonzero(in.n_a[1]) || tiny_nonzero(in.n_a[2]) || tiny_nonzero(in.n_t[0]) ||
+                     tiny_nonzero(in.n_tm[0]) || tiny_nonzero(in.n_t[1]) || tiny_nonzero(in.n_tm[1]) ||
+                     tiny_nonzero(in.mu1 * in.mu2) || !(in.mu1 + in.mu2 > 0x1p-200);
     if (__any(odd)) strain_rows<DIR, QuotI>(in, dxa, dxt, dxtm, dp.avg, flx, mus);
     else strain_rows<DIR, QuotF>(in, dxa, dxt, dxtm, dp.avg, flx, mus);
     const double divu = w.divu[base + c], divu_m = w.divu[base + cm];

@@ -341,6 +341,47 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
   __syncthreads();
 }
 
+// Phase P3 of the flux TASK (artemis_hip_calculate_fluxes through the tile march, FLUXES = true): instead of
+// updating the zone, store what CalculateFluxesImpl stores (fluid_fluxes.hpp:78-213) -- the eight outputs of the
+// zone's lower x1 / x2 / x3 faces, and of the block's last face of a direction from the zone next to it.  Faces
+// [s, e+1] of each direction over the active extent of the others, every face exactly once.
+template <bool D3, class TILE>
+ADEV void plane_store_fluxes(TILE &S, const PackView &P, const Ctx &x, const int k, const Flux8 &fx_lo,
+                             const Flux8 &fy_lo, const Flux8 &fz_lo, const Flux8 &fz_hi) {
+  if (!x.active) return;
+  const int tx = x.tx, ty = x.ty;
+  const bool multi_d = D3 || x.multi_d;
+  const FluidView &f = P.gas;
+  const long c = x.col + static_cast<long>(k) * x.sk;
+  const int b6 = x.b * 6;
+  auto put = [&](int d, const Flux8 &fl, long at) {
+    f.flux[d][b6 + 0][at] = fl.d;
+    f.flux[d][b6 + 1][at] = fl.m1, f.flux[d][b6 + 2][at] = fl.m2, f.flux[d][b6 + 3][at] = fl.m3;
+    f.flux[d][b6 + 4][at] = fl.e;  // IEN shares the IPR slot (hllc.hpp:72)
+    f.flux[d][b6 + 5][at] = fl.eg; // IEG shares the ISE slot (hllc.hpp:73)
+    f.pflux[d][x.b][at] = fl.pf;
+    f.vface[d][x.b][at] = fl.vf;
+  };
+  put(0, fx_lo, c);
+  if (x.i0 + tx == P.ie) {
+    Flux8 hi;
+    GET8(hi, S.FX, [ty][tx]);
+    put(0, hi, c + 1);
+  }
+  if (multi_d) {
+    put(1, fy_lo, c);
+    if (x.j0 + ty == P.je) {
+      Flux8 hi;
+      GET8(hi, S.FY, [ty][tx]);
+      put(1, hi, c + x.sj);
+    }
+  }
+  if constexpr (D3) {
+    put(2, fz_lo, c);
+    if (k == P.ke) put(2, fz_hi, c + x.sk);
+  }
+}
+
 // Phase P3: gather the upper-face fluxes published by the neighbours, then the whole per-cell
 // chain update -> sources -> aux -> c2p -> p2c -> store (and the CFL reduction).
 template <bool HAS_U1, bool WRITE_CONS, bool WITH_DT, bool D3, class TILE>
@@ -605,7 +646,7 @@ ADEV void plane_update_curv(TILE &S, const PackView &P, const StageK &a, const S
   }
 }
 
-template <int RIEMANN, int RECON, bool HAS_U1, bool WRITE_CONS, bool WITH_DT, bool D3, bool CURV = false>
+template <int RIEMANN, int RECON, bool HAS_U1, bool WRITE_CONS, bool WITH_DT, bool D3, bool CURV = false, bool FLUXES = false>
 __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const PackView P, const StageK a,
                                                                        const SrcArg<CURV> src) {
   __shared__ std::conditional_t<CURV, LdsTileCurv, LdsTile> S;
@@ -743,6 +784,7 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
       if (src.v.diff_on) df = load_dflux(P, x.b, x.col + k0 * x.sk, x.multi_d, false);
       plane_update_curv<HAS_U1, WITH_DT, false>(S, P, a, src.v, x, gx, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, df, ldt);
     }
+    else if constexpr (FLUXES) plane_store_fluxes<false>(S, P, x, k0, fx_lo, fy_lo, fz, fz);
     else plane_update<HAS_U1, WRITE_CONS, WITH_DT, false>(S, P, a, x, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
   } else {
     // x3 state carried in registers: planes k, k+1, the upper face value of cell k and the
@@ -824,6 +866,7 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
       if constexpr (CURV) fz_hi.m2 *= gx.h3[1], fz_hi.m3 *= gx.h3[2]; // ScaleMomentumFlux at the x3 face
       if (k >= k0) {
         if constexpr (CURV) plane_update_curv<HAS_U1, WITH_DT, true>(S, P, a, src.v, x, gx, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, df, ldt);
+        else if constexpr (FLUXES) plane_store_fluxes<true>(S, P, x, k, fx_lo, fy_lo, fz_lo, fz_hi);
         else plane_update<HAS_U1, WRITE_CONS, WITH_DT, true>(S, P, a, x, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt);
       }
       fz_lo = fz_hi, zl = zl_next, qc = qn, qn = qnn;
@@ -1028,6 +1071,60 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   case RS:                                                                                 \
     return (recon == ARTEMIS_PCM) ? launch_cfg<RS, 0>(P, k, has_u1, cons, dt, s)           \
                                   : launch_cfg<RS, 1>(P, k, has_u1, cons, dt, s);
+  switch (riemann) {
+    RC(0)
+    RC(1)
+    RC(2)
+  }
+#undef RC
+  return 4;
+}
+
+// ---- Gas::CalculateFluxes through the tile march -------------------------------------------------
+// The per-task flux kernel (kernels_unfused.hip) reads every stencil value from L1 / L2 and solves each face
+// from scratch in a one-thread-per-zone launch; this is the same LDS-staged march as the fused stage with the
+// update phase replaced by the stores of the task, for the decks the Cartesian march covers: one gas species,
+// PCM / PLM, blocks at least a tile wide.  Same device functions as the fused stage, which is bit-identical to the
+// per-task chain, so the task's outputs do not change.
+bool fused_flux_covers(const PackView &P, int recon) {
+  if (getenv("ARTEMIS_NO_TILED_FLUX")) return false;
+  if (P.coords != ARTEMIS_CARTESIAN || P.gas.ns != 1 || P.ng < 2 || P.ndim < 2) return false;
+  if (recon != ARTEMIS_PCM && recon != ARTEMIS_PLM) return false;
+  return (P.ie - P.is + 1) >= FTX && (P.je - P.js + 1) >= FTY;
+}
+namespace {
+template <int RIEMANN, int RECON>
+void launch_flux_cfg(const PackView &P, const StageK &k, hipStream_t s) {
+  const dim3 grid(k.start[k.nbox]);
+  const dim3 block(FTX, FTY);
+  if (P.ndim > 2)
+    hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, false, false, false, true, false, true>), grid, block, 0, s, P, k, SrcArg<false>{});
+  else
+    hipLaunchKernelGGL((stage_fused_kernel<RIEMANN, RECON, false, false, false, false, false, true>), grid, block, 0, s, P, k, SrcArg<false>{});
+}
+} // namespace
+int launch_flux_fused(const PackView &P, int riemann, int recon, hipStream_t s) {
+  StageK k;
+  k.gam0 = k.gam1 = k.beta_dt = k.bdt = k.cfl = 0.0;
+  k.bdt_ptr = nullptr;
+  k.prim_in = P.gas.prim, k.prim_u1 = P.gas.prim, k.prim_out = nullptr, k.cons_out = nullptr;
+  k.dt_bits = nullptr;
+  const int nz = P.ke - P.ks + 1;
+  const int NTI = (P.ie - P.is + FTX) / FTX, NTJ = (P.je - P.js + FTY) / FTY;
+  const int target_chunk = pick_chunk(nz, static_cast<long>(NTI) * NTJ * P.nb, 512);
+  k.nbox = 1, k.start[0] = 0;
+  k.ti0[0] = 0, k.nti[0] = NTI, k.tj0[0] = 0, k.ntj[0] = NTJ, k.kb0[0] = P.ks, k.kb1[0] = P.ke;
+  k.nchunk[0] = (P.ndim > 2) ? std::max(1, nz / target_chunk) : 1;
+  k.kchunk[0] = (nz + k.nchunk[0] - 1) / k.nchunk[0];
+  k.nchunk[0] = (nz + k.kchunk[0] - 1) / k.kchunk[0];
+  k.start[1] = NTI * NTJ * k.nchunk[0] * P.nb;
+  k.nshell = 0, k.shell_done = nullptr;
+  k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
+#define RC(RS)                                                                             \
+  case RS:                                                                                 \
+    if (recon == ARTEMIS_PCM) launch_flux_cfg<RS, 0>(P, k, s);                             \
+    else launch_flux_cfg<RS, 1>(P, k, s);                                                  \
+    return 0;
   switch (riemann) {
     RC(0)
     RC(1)

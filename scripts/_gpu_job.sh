@@ -1,7 +1,10 @@
 cd /root/repo
 export TMPDIR=/tmp
-for m in 1 2; do
-ARTEMIS_FORCE_OVERLAP=1 timeout 300 python bench.py --no-cpu-baseline --no-dropin --overlap-mode $m 2>&1 | cut -c60-135
-done
-timeout 300 python bench.py --no-cpu-baseline --no-dropin 2>&1 | cut -c60-135
-ARTEMIS_FORCE_OVERLAP=1 timeout 600 python -m pytest tests/test_driver_gpu.py -x -q -m gpu -k "overlap or sedov or blast" 2>&1 | tail -2
+timeout 1500 python -m pytest tests/test_parity_ops.py -x -q -m gpu > gpurun_out/t.log 2>&1; grep -E "passed|failed|^E " gpurun_out/t.log | head
+timeout 1500 python -m pytest tests/test_driver_gpu.py tests/test_parity_fused.py -x -q -m gpu > gpurun_out/t2.log 2>&1; grep -E "passed|failed|^E " gpurun_out/t2.log | head
+timeout 600 python bench.py --no-cpu-baseline > gpurun_out/flux_line.json 2>/dev/null
+python - <<PY
+import json
+d=json.loads(open('gpurun_out/flux_line.json').read())
+print(d['value'], d['dropin'])
+PY

@@ -108,6 +108,13 @@ CASES = [  # nx, ng, recon, riemann
     ((70, 9, 1), 2, "plm", "hllc"),   # 2-D, ragged vs the 64x4 thread tile
     ((131, 1, 1), 2, "plm", "hllc"),  # 1-D
     ((5, 3, 2), 2, "plm", "hllc"),    # tiny block
+    # blocks at least a 32 x 8 tile wide: the task runs through the LDS-staged tile march (ragged tiles, chunks)
+    ((40, 17, 21), 2, "plm", "hllc"),
+    ((40, 17, 21), 2, "plm", "hlle"),
+    ((40, 17, 21), 3, "plm", "llf"),
+    ((67, 9, 5), 2, "pcm", "hllc"),
+    ((64, 16, 1), 2, "plm", "hlle"),
+    ((33, 8, 1), 4, "pcm", "llf"),
 ]
 
 
@@ -121,6 +128,27 @@ def test_calculate_fluxes_gas(hiplib, nx, ng, recon, riem):
         same(mb.gas_flux[d][0][sl], o.gflux(d)[sl], f"flux x{d+1}")
         same(mb.gas_pflux[d][0][sl], o.gpflux(d)[sl], f"pflux x{d+1}")
         same(mb.gas_vface[d][0][sl], o.gvface(d)[sl], f"vface x{d+1}")
+
+
+@pytest.mark.parametrize("riem", ["hllc", "hlle", "llf"])
+def test_calculate_fluxes_tile_march_equals_per_task_kernel(hiplib, riem, monkeypatch):
+    """Several blocks wide enough for the tile march: artemis_hip_calculate_fluxes through the march, through the
+    one-thread-per-zone kernel (ARTEMIS_NO_TILED_FLUX) and the oracle agree bit for bit on every face output."""
+    oracles, mb = make_pair((48, 20, 19), recon="plm", riem=riem, seed=21, nb=3)
+    mb.CalculateFluxes(0, False)
+    tiled = [[mb.gas_flux[d].clone(), mb.gas_pflux[d].clone(), mb.gas_vface[d].clone()] for d in range(3)]
+    monkeypatch.setenv("ARTEMIS_NO_TILED_FLUX", "1")
+    for d in range(3):
+        mb.gas_flux[d].zero_(), mb.gas_pflux[d].zero_(), mb.gas_vface[d].zero_()
+    mb.CalculateFluxes(0, False)
+    for b, o in enumerate(oracles):
+        o.CalculateFluxes(0, False)
+        for d in range(3):
+            sl = face_slices(o, d)
+            same(tiled[d][0][b][sl], o.gflux(d)[sl], f"block {b} flux x{d+1}")
+            same(tiled[d][1][b][sl], o.gpflux(d)[sl], f"block {b} pflux x{d+1}")
+            same(tiled[d][2][b][sl], o.gvface(d)[sl], f"block {b} vface x{d+1}")
+            assert torch.equal(tiled[d][0][b][sl], mb.gas_flux[d][b][sl])
 
 
 def test_calculate_fluxes_pcm_override(hiplib):
