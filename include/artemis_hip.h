@@ -113,7 +113,13 @@ typedef struct artemis_pack {
  * ArtemisUtils::CalculateFluxes<FLUID> (fluid_fluxes.hpp:78-292).  Reads prim (stencil +-2
  * PLM / +-3 PPM per direction), writes flux[d], and for gas pflux[d], vface[d], on faces
  * [s, e+1] of every active direction.  `pcm` forces first-order reconstruction (VL2 stage
- * 1, artemis_driver.cpp:182). */
+ * 1, artemis_driver.cpp:182).
+ * Gas, one species, PCM / PLM, Cartesian blocks of at least 32 x 8 zones in 2-D / 3-D run through the
+ * LDS-staged tile march of the fused stage (same device functions, same bits).  That path reads density,
+ * velocity and specific internal energy and derives the pressure as FillDerived stores it
+ * (max(0, (gamma-1) rho sie), fill_derived.cpp:246-262) instead of loading prim's pressure block: the input
+ * is a state FillDerived has visited, as everywhere in the reference's task list.  ARTEMIS_NO_TILED_FLUX=1
+ * keeps the one-thread-per-zone kernel, which loads the stored pressure. */
 int artemis_hip_calculate_fluxes(const artemis_pack_t *p, int fluid, int pcm, void *stream);
 
 /* ArtemisUtils::ApplyUpdate<GEOM> (artemis_integrator.hpp:57-110) for every

@@ -87,6 +87,46 @@ def test_fused_step_matches_oracle(hiplib, nx, ng, recon, riem, bcname, integ):
         same(mb.gas_u0[0], o.gu0, f"cons after fused step {step}")
 
 
+@pytest.mark.parametrize("riem", ["hllc", "hlle", "llf"])
+def test_fused_step_with_vanishing_velocities(hiplib, riem):
+    """The stated limit of the tuned Cartesian kernel's bit parity.  Ahead of a shock the
+    velocities decay like 1e-40, 1e-80, 1e-160, 1e-320.  The kernel's hand-scheduled divisions are the bits of IEEE
+    divisions while the numerator is zero or at least 2^-969 (1e-292): the product of two velocity differences of
+    1e-150 in a limited slope, or a momentum of 1e-305 divided by the density, is not, and such a quotient may be
+    off in its last place.  Everything those quotients can reach is itself below 1e-140.  So, on a state with such
+    velocities next to exact zeros and ordinary values: every entry of magnitude >= 1e-120 is bit-identical to the
+    oracle, and the others -- physically zero -- agree to 1e-12 relative (1e-313 absolute among subnormals)."""
+    bc = ("outflow",) * 6
+    o, mb, bufs = setup((40, 20, 36), 2, "plm", riem, bc, seed=13)
+    rng = np.random.default_rng(3)
+    w = o.gprim
+    scale = rng.choice([1.0, 0.0, 1e-300, 1e-306, 1e-250, 1e-160, 1e-150, 1e-100, 1e-40], size=w[1].shape,
+                       p=[0.3, 0.1, 0.1, 0.1, 0.08, 0.08, 0.08, 0.08, 0.08])
+    for v in (1, 2, 3):
+        w[v] *= scale
+    o.ApplyBoundaryConditions()
+    o.PrimToCons()
+    mb.gas_prim[0].copy_(torch.from_numpy(o.gprim.copy()))
+    for step in range(2):
+        dt = o.new_dt()
+        o.dt = dt
+        o.step()
+        fused_step(mb, bufs, "rk2", dt, [bc])
+        mb.PrimToCons()
+        for got, ref, what in ((mb.gas_prim[0].cpu().numpy(), o.gprim, "prim"), (mb.gas_u0[0].cpu().numpy(), o.gu0, "cons")):
+            big = np.abs(ref) >= 1e-120
+            bad = big & (got != ref)
+            assert not bad.any(), (f"{what}, step {step}: {np.count_nonzero(bad)} entries above 1e-120 differ, the largest "
+                                   f"{np.abs(ref[bad]).max():.3e} (gpu {got[bad][0]:.17e} ref {ref[bad][0]:.17e})")
+            assert np.all(np.abs(got[~big]) < 1e-119)
+            err = np.abs(got[~big] - ref[~big])
+            assert np.all(err <= 1e-12 * np.abs(ref[~big]) + 1e-313), f"{what}, step {step}: {err.max():.3e}"
+            # and the difference is confined to a handful of zones
+            assert np.count_nonzero(got != ref) < 1e-3 * ref.size
+        # continue from the oracle's bits so that the second step starts from identical states
+        mb.gas_prim[0].copy_(torch.from_numpy(o.gprim.copy()))
+
+
 def test_fused_blast_with_fused_dt_and_cons(hiplib):
     """Sedov deck: the last stage also writes u0 and min-combines the CFL timestep."""
     import math
