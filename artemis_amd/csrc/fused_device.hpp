@@ -60,7 +60,7 @@ ADEV GasK gas_constants(double gm1) {
   return g;
 }
 template <int RIEMANN, int DIR>
-ADEV Flux8 solve_face(const GasK &gk, const Cell6 &L, const Cell6 &R) {
+ADEV Flux8 solve_face(const GasK &gk, const Cell6 &L, const Cell6 &R, const bool fast = true) {
   Prim6 l, r;
   l.d = L.d, l.p = L.p, l.e = L.e, r.d = R.d, r.p = R.p, r.e = R.e;
   if constexpr (DIR == 1) {
@@ -71,8 +71,14 @@ ADEV Flux8 solve_face(const GasK &gk, const Cell6 &L, const Cell6 &R) {
     l.vx = L.v3, l.vy = L.v1, l.vz = L.v2, r.vx = R.v3, r.vy = R.v1, r.vz = R.v2;
   }
   FaceFlux F;
-  if constexpr (RIEMANN == 0) hllc_gas_fast(gk.gm1, gk.igm1, gk.gamma, gk.alpha, l, r, F);
-  else riemann_gas<RIEMANN>(gk.gm1, l, r, F);
+  if constexpr (RIEMANN == 0) {
+    // wave-uniform: hllc_gas_fast's hand-scheduled divisions are the bits of hllc_gas's only while no numerator is
+    // tiny (callers without that knowledge pass true and live with DESIGN.md section 4's limit)
+    if (fast) hllc_gas_fast(gk.gm1, gk.igm1, gk.gamma, gk.alpha, l, r, F);
+    else hllc_gas(gk.gm1, l, r, F);
+  } else {
+    riemann_gas<RIEMANN>(gk.gm1, l, r, F);
+  }
   Flux8 o;
   o.d = F.fd, o.e = F.fe, o.eg = F.feg, o.pf = F.pf, o.vf = F.vf;
   if constexpr (DIR == 1) o.m1 = F.fmx, o.m2 = F.fmy, o.m3 = F.fmz;

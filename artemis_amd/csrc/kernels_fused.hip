@@ -192,12 +192,25 @@ ADEV void stage_plane(TILE &S, const Ctx &x, const Cell6 &q, const Raw5 &hal) {
   put6(S.Q, x.ty + FH, x.tx + FH, q);
   if (x.hr >= 0) put6(S.Q, x.hr, x.hc, finish_cell(hal, x.gm1));
 }
-// curvilinear tiles also note whether the plane they stage (parity `par`) holds a velocity that PLM_G's
-// hand-scheduled division cannot take (geometry.hpp: tiny_nonzero); the flag was cleared one phase earlier
-ADEV void stage_plane_flag(LdsTileCurv &S, const Ctx &x, const Cell6 &q, const Raw5 &hal, int par) {
+// Guarded tiles (the curvilinear kernel and the flux task) note whether the plane they stage (parity `par`) holds a
+// velocity the hand-scheduled divisions cannot take (geometry.hpp: tiny_nonzero -- ahead of a shock velocities decay
+// like 1e-40, 1e-80, 1e-160, 1e-320): that plane's slopes and Riemann problems then take the IEEE divisions.  The
+// flag was cleared one phase earlier.  The Cartesian tile is exactly 80 KB, so its two flags live in corner zones of
+// the staged tile that no stencil reads and no thread stages (rows 0 x columns 0 / 1 of the halo frame).
+ADEV int &tiny_flag(LdsTileCurv &S, int par) { return S.tiny[par]; }
+ADEV int &tiny_flag(LdsTile &S, int par) { return reinterpret_cast<int *>(&S.Q[5][0][0])[2 * par]; }
+template <class TILE>
+ADEV void stage_plane_flag(TILE &S, const Ctx &x, const Cell6 &q, const Raw5 &hal, int par) {
   bool t = tiny_nonzero(q.v1) || tiny_nonzero(q.v2) || tiny_nonzero(q.v3);
   if (x.hr >= 0) t = t || tiny_nonzero(hal.v1) || tiny_nonzero(hal.v2) || tiny_nonzero(hal.v3);
-  if (__any(t) && (x.t & 63) == 0) S.tiny[par] = 1;
+  if (__any(t) && (x.t & 63) == 0) tiny_flag(S, par) = 1;
+}
+ADEV bool tiny_v(const Cell6 &q) { return tiny_nonzero(q.v1) || tiny_nonzero(q.v2) || tiny_nonzero(q.v3); }
+// uniform-mesh slope with the division the plane may take
+template <int RECON>
+ADEV double slope_sel(double qm, double q, double qp, bool fast) {
+  if constexpr (RECON == 0) return 0.0;
+  else return fast ? plm_dqm_fast(qm, q, qp) : plm_dqm(qm, q, qp);
 }
 
 // x1/x2 sweeps of one plane through LDS.  Plane k's primitives are already staged in S.Q (by
@@ -208,15 +221,15 @@ ADEV void stage_plane_flag(LdsTileCurv &S, const Ctx &x, const Cell6 &q, const R
 // Returns the fluxes through the own cell's lower x1/x2 faces; the upper ones are left in
 // S.FX / S.FY for plane_update.  The perimeter duties rotate over the waves with k so that no
 // wave (and no SIMD) carries the extra Riemann pass every plane.
-template <int RIEMANN, int RECON, bool D3, bool CURV, class TILE>
+template <int RIEMANN, int RECON, bool D3, bool CURV, bool GUARD, class TILE>
 ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CURV> &gx, const int k,
                        const Cell6 &qc, const bool stage_next, const Cell6 &qn, const Raw5 &hal_next,
                        Flux8 &fx_lo, Flux8 &fy_lo) {
   constexpr bool PG = CURV && RECON == 1; // PLM_G instead of the uniform-mesh slope
-  bool fastp = true; // PLM_G with every division hand-scheduled (no tiny velocity in this plane's tile)
-  if constexpr (PG) {
-    fastp = (S.tiny[k & 1] == 0);
-    if (x.t == 0) S.tiny[(k + 1) & 1] = 0; // set again when the next plane is staged (after the barrier)
+  bool fastp = true; // every division hand-scheduled (no tiny velocity in this plane's tile)
+  if constexpr (GUARD) {
+    fastp = (tiny_flag(S, k & 1) == 0);
+    if (x.t == 0) tiny_flag(S, (k + 1) & 1) = 0; // set again when the next plane is staged (after the barrier)
   }
   const int tx = x.tx, ty = x.ty;
   const bool multi_d = D3 || x.multi_d; // compile-time true in the 3-D instantiation
@@ -235,7 +248,7 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
                         up_, lo_, gx.g1);                                                  \
     } else {                                                                               \
       const double s_ =                                                                    \
-          slope<RECON>(S.Q[n][ty + FH][tx + FH - 1], qc.m, S.Q[n][ty + FH][tx + FH + 1]);  \
+          slope_sel<RECON>(S.Q[n][ty + FH][tx + FH - 1], qc.m, S.Q[n][ty + FH][tx + FH + 1], fastp);  \
       lo_ = lo_val<RECON>(qc.m, s_), up_ = up_val<RECON>(qc.m, s_);                        \
     }                                                                                      \
     lox.m = lo_;                                                                           \
@@ -256,7 +269,7 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
                         up_, lo_, gx.g2);                                                  \
     } else {                                                                               \
       const double s_ =                                                                    \
-          slope<RECON>(S.Q[n][ty + FH - 1][tx + FH], qc.m, S.Q[n][ty + FH + 1][tx + FH]);  \
+          slope_sel<RECON>(S.Q[n][ty + FH - 1][tx + FH], qc.m, S.Q[n][ty + FH + 1][tx + FH], fastp);  \
       lo_ = lo_val<RECON>(qc.m, s_), up_ = up_val<RECON>(qc.m, s_);                        \
     }                                                                                      \
     loy.m = lo_;                                                                           \
@@ -276,7 +289,7 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
         if (fastp) plm_g_shared<2>(S.Q[n][row + FH][cx - 1], q, S.Q[n][row + FH][cx + 1], up_, lo_, S.GX1[side]);
         else plm_g_shared<0>(S.Q[n][row + FH][cx - 1], q, S.Q[n][row + FH][cx + 1], up_, lo_, S.GX1[side]);
       } else {
-        const double s_ = slope<RECON>(S.Q[n][row + FH][cx - 1], q, S.Q[n][row + FH][cx + 1]);
+        const double s_ = slope_sel<RECON>(S.Q[n][row + FH][cx - 1], q, S.Q[n][row + FH][cx + 1], fastp);
         lo_ = lo_val<RECON>(q, s_), up_ = up_val<RECON>(q, s_);
       }
       if (side) S.LOX[n][row] = lo_;
@@ -294,7 +307,7 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
         if (fastp) plm_g_shared<2>(S.Q[n][ry - 1][cx + FH], q, S.Q[n][ry + 1][cx + FH], up_, lo_, S.GX2[side][cx]);
         else plm_g_shared<0>(S.Q[n][ry - 1][cx + FH], q, S.Q[n][ry + 1][cx + FH], up_, lo_, S.GX2[side][cx]);
       } else {
-        const double s_ = slope<RECON>(S.Q[n][ry - 1][cx + FH], q, S.Q[n][ry + 1][cx + FH]);
+        const double s_ = slope_sel<RECON>(S.Q[n][ry - 1][cx + FH], q, S.Q[n][ry + 1][cx + FH], fastp);
         lo_ = lo_val<RECON>(q, s_), up_ = up_val<RECON>(q, s_);
       }
       if (side) S.LOY[n][cx] = lo_;
@@ -305,13 +318,13 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
   // ---- P2: Riemann problems at the own lower faces; perimeter faces on wave 1 ------------
   Cell6 L;
   GET6(L, S.UPX, [ty][tx]);
-  fx_lo = solve_face<RIEMANN, 1>(x.gk, L, lox);
+  fx_lo = solve_face<RIEMANN, 1>(x.gk, L, lox, fastp);
   if constexpr (CURV) fx_lo.m2 *= gx.h1[1], fx_lo.m3 *= gx.h1[2]; // ScaleMomentumFlux (h1 == 1)
   if (tx > 0) { PUT8(S.FX, fx_lo, [ty][tx - 1]); }
   fy_lo = fx_lo;
   if (multi_d) {
     GET6(L, S.UPY, [ty][tx]);
-    fy_lo = solve_face<RIEMANN, 2>(x.gk, L, loy);
+    fy_lo = solve_face<RIEMANN, 2>(x.gk, L, loy, fastp);
     if constexpr (CURV) fy_lo.m2 *= gx.h2[1], fy_lo.m3 *= gx.h2[2];
     if (ty > 0) { PUT8(S.FY, fy_lo, [ty - 1][tx]); }
   }
@@ -321,7 +334,7 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
       Cell6 l, r;
       GET6(l, S.UPX, [u][FTX]);
       GET6(r, S.LOX, [u]);
-      Flux8 fe_ = solve_face<RIEMANN, 1>(x.gk, l, r);
+      Flux8 fe_ = solve_face<RIEMANN, 1>(x.gk, l, r, fastp);
       if constexpr (CURV) fe_.m2 *= S.HF1[u][0], fe_.m3 *= S.HF1[u][1]; // the face below cell (j0+u, i0+32)
       PUT8(S.FX, fe_, [u][FTX - 1]);
     } else if (multi_d && u >= 32) {
@@ -329,14 +342,14 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
       Cell6 l, r;
       GET6(l, S.UPY, [FTY][cx]);
       GET6(r, S.LOY, [cx]);
-      Flux8 fe_ = solve_face<RIEMANN, 2>(x.gk, l, r);
+      Flux8 fe_ = solve_face<RIEMANN, 2>(x.gk, l, r, fastp);
       if constexpr (CURV) fe_.m2 *= S.HF2[cx][0], fe_.m3 *= S.HF2[cx][1]; // the face below cell (j0+8, i0+cx)
       PUT8(S.FY, fe_, [FTY - 1][cx]);
     }
   }
   if (stage_next) {
     stage_plane(S, x, qn, hal_next);
-    if constexpr (PG) stage_plane_flag(S, x, qn, hal_next, (k + 1) & 1);
+    if constexpr (GUARD) stage_plane_flag(S, x, qn, hal_next, (k + 1) & 1);
   }
   __syncthreads();
 }
@@ -757,9 +770,14 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
         const int jr = max(1, min(side ? x.j0 + FTY : x.j0 - 1, P.nj - 2));
         S.GX2[side][cx] = compact(plm_geo(P, x.b, 2, k0, jr, min(x.i0 + cx, P.ni - 1)));
       }
-      if (x.t == 0) S.tiny[0] = S.tiny[1] = 0;
-      __syncthreads(); // the flags are cleared before any wave sets one for the first staged plane
     }
+  }
+  // the plane flags: PLM_G's cubic numerators need them in the curvilinear kernel; the flux TASK keeps every output
+  // bit exact with them (the fused Cartesian stage does without: DESIGN.md section 4)
+  constexpr bool GUARD = (CURV && RECON == 1) || FLUXES;
+  if constexpr (GUARD) {
+    if (x.t == 0) tiny_flag(S, 0) = tiny_flag(S, 1) = 0;
+    __syncthreads(); // the flags are cleared before any wave sets one for the first staged plane (and the tables are in)
   }
 
   const double *u1_r = a.prim_u1[x.b * 6 + 0], *u1_1 = a.prim_u1[x.b * 6 + 1];
@@ -775,9 +793,9 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
     Raw5 hal = u1raw;
     if (x.hr >= 0) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + k0 * x.sk);
     stage_plane(S, x, qc, hal);
-    if constexpr (CURV && RECON == 1) stage_plane_flag(S, x, qc, hal, k0 & 1);
+    if constexpr (GUARD) stage_plane_flag(S, x, qc, hal, k0 & 1);
     __syncthreads();
-    plane_sweeps<RIEMANN, RECON, false, CURV>(S, P, x, gx, k0, qc, false, qc, hal, fx_lo, fy_lo);
+    plane_sweeps<RIEMANN, RECON, false, CURV, GUARD>(S, P, x, gx, k0, qc, false, qc, hal, fx_lo, fy_lo);
     if constexpr (CURV) {
       DFlux24 df{};
       if (gx.m3) gx.co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k0], gx.co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k0];
@@ -802,7 +820,8 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
         FOR6(ZL0)
 #undef ZL0
       } else {
-#define ZL0(m) zl.m = up_val<RECON>(qc.m, slope<RECON>(qmm.m, qc.m, qn.m));
+        const bool f0 = !(FLUXES && __any(tiny_v(qmm) || tiny_v(qc) || tiny_v(qn)));
+#define ZL0(m) zl.m = up_val<RECON>(qc.m, slope_sel<RECON>(qmm.m, qc.m, qn.m, f0));
         FOR6(ZL0)
 #undef ZL0
       }
@@ -828,14 +847,17 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
       }
       Flux8 fx_lo, fy_lo;
       if (k >= k0) {
-        plane_sweeps<RIEMANN, RECON, true, CURV>(S, P, x, gx, k, qc, k < k1, qn, hal, fx_lo, fy_lo);
+        plane_sweeps<RIEMANN, RECON, true, CURV, GUARD>(S, P, x, gx, k, qc, k < k1, qn, hal, fx_lo, fy_lo);
       } else { // priming trip: stage the first plane
         stage_plane(S, x, qn, hal);
-        if constexpr (CURV && RECON == 1) stage_plane_flag(S, x, qn, hal, k0 & 1);
+        if constexpr (GUARD) stage_plane_flag(S, x, qn, hal, k0 & 1);
         __syncthreads();
       }
       // x3 sweep, registers only: slope of cell k+1, face k+1
       const Cell6 qnn = finish_cell(rnn, x.gm1);
+      // face k+1 reads the own column's planes k-1 .. k+2: the three in registers decide for the wave (the slope of
+      // cell k entered zl in the previous trip under that trip's check)
+      const bool fast_col = !(FLUXES && __any(tiny_v(qc) || tiny_v(qn) || tiny_v(qnn)));
       Cell6 zr, zl_next;
       if constexpr (CURV && RECON == 1) {
         const PlmGeo g3 = plm_geo_x3(gx.co, x.g, k + 1);
@@ -855,14 +877,14 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
       } else {
 #define ZSL(m)                                                                             \
   {                                                                                        \
-    const double s_ = slope<RECON>(qc.m, qn.m, qnn.m);                                     \
+    const double s_ = slope_sel<RECON>(qc.m, qn.m, qnn.m, fast_col);                       \
     zr.m = lo_val<RECON>(qn.m, s_);                                                        \
     zl_next.m = up_val<RECON>(qn.m, s_);                                                   \
   }
         FOR6(ZSL)
 #undef ZSL
       }
-      Flux8 fz_hi = solve_face<RIEMANN, 3>(x.gk, zl, zr);
+      Flux8 fz_hi = solve_face<RIEMANN, 3>(x.gk, zl, zr, fast_col);
       if constexpr (CURV) fz_hi.m2 *= gx.h3[1], fz_hi.m3 *= gx.h3[2]; // ScaleMomentumFlux at the x3 face
       if (k >= k0) {
         if constexpr (CURV) plane_update_curv<HAS_U1, WITH_DT, true>(S, P, a, src.v, x, gx, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, df, ldt);

@@ -151,6 +151,28 @@ def test_calculate_fluxes_tile_march_equals_per_task_kernel(hiplib, riem, monkey
             assert torch.equal(tiled[d][0][b][sl], mb.gas_flux[d][b][sl])
 
 
+@pytest.mark.parametrize("riem", ["hllc", "hlle", "llf"])
+def test_calculate_fluxes_tile_march_with_vanishing_velocities(hiplib, riem):
+    """The flux task keeps every output bit exact next to velocities of 1e-150 .. 1e-320 (shock precursors): the
+    tile march notes tile planes and columns that hold such a velocity and takes the IEEE divisions there."""
+    (o,), mb = make_pair((48, 20, 19), recon="plm", riem=riem, seed=31)
+    rng = np.random.default_rng(7)
+    w = o.gprim
+    scale = rng.choice([1.0, 0.0, 1e-300, 1e-306, 1e-250, 1e-160, 1e-150, 1e-100, 1e-40], size=w[1].shape,
+                       p=[0.3, 0.1, 0.1, 0.1, 0.08, 0.08, 0.08, 0.08, 0.08])
+    for v in (1, 2, 3):
+        w[v] *= scale
+    o.PrimToCons()
+    push([o], mb)
+    o.CalculateFluxes(0, False)
+    mb.CalculateFluxes(0, False)
+    for d in range(3):
+        sl = face_slices(o, d)
+        same(mb.gas_flux[d][0][sl], o.gflux(d)[sl], f"flux x{d+1}")
+        same(mb.gas_pflux[d][0][sl], o.gpflux(d)[sl], f"pflux x{d+1}")
+        same(mb.gas_vface[d][0][sl], o.gvface(d)[sl], f"vface x{d+1}")
+
+
 def test_calculate_fluxes_pcm_override(hiplib):
     # artemis_driver.cpp:182: VL2 stage 1 forces PCM whatever gas/reconstruct says
     (o,), mb = make_pair((16, 8, 8), recon="plm", riem="hllc", seed=2)
