@@ -139,11 +139,13 @@ def main():
     # The bench line's `dropin` legs also launch the WRITE_CONS instantiations (4th template argument true: they
     # store the conserved state as well); the headline path runs only the two that do not -- one launch of each per
     # rk2 step -- so `hbm_bytes_per_launch` is the launch-weighted mean over those.
-    def writes_cons(name):
-        targs = name.split("stage_fused_kernel<", 1)[1].split(">", 1)[0].split(",")
-        return targs[3].strip() == "true"
+    # The per-task leg runs the FLUXES instantiation (8th argument true: the flux TASK through the tile march, 24
+    # stores per zone) -- not the headline path either.
+    def off_headline(name):
+        targs = [t.strip() for t in name.split("stage_fused_kernel<", 1)[1].split(">", 1)[0].split(",")]
+        return targs[3] == "true" or (len(targs) > 7 and targs[7] == "true")
     for k2, v in stage.items():
-        v["headline_path"] = not writes_cons(k2)
+        v["headline_path"] = not off_headline(k2)
     head = [v for v in stage.values() if v["headline_path"]] or list(stage.values())
     tot = sum(v["launches"] for v in head)
     per_launch = sum(v["launches"] * (v["read_bytes_corrected"] + v["write_bytes"]) for v in head) / tot
