@@ -9,6 +9,8 @@ timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | 
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag}
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust
+# (on the box: the bench lines below quote the records just measured; scripts/collect_evidence.sh copies them locally)
+cp gpurun_out/${tag}_pmc_traffic.json profiles/r02_pmc_traffic.json; cp gpurun_out/${tag}_disk_sph_pmc_traffic.json profiles/r02_disk_sph_pmc_traffic.json; cp gpurun_out/${tag}_cfg3_pmc_traffic.json profiles/r02_cfg3_pmc_traffic.json
 timeout 600 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err; cat gpurun_out/${tag}_bench_line.json | cut -c1-400
 timeout 300 python bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_cfg3_line.json
 timeout 300 python bench.py --workload disk_sph --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_disk_sph_line.json
