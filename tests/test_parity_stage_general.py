@@ -108,6 +108,45 @@ def test_general_stage_hydro(hiplib, nx, lo, hi, nsg, nsd, recon, riem, driem, c
         same(dbuf[0][I], o.dprim[I], "dust prim")
 
 
+@pytest.mark.parametrize("case", [6, 9])
+def test_row_march_kernel_with_vanishing_velocities(hiplib, case):
+    """The 2-D row-march kernel shares the tuned Cartesian kernel's hand-scheduled divisions and therefore its stated
+    limit (DESIGN.md section 4, test_parity_fused.py::test_fused_step_with_vanishing_velocities): next to velocities
+    of 1e-150 .. 1e-320 every gas and dust value of magnitude >= 1e-120 is bit-identical to the oracle, the others
+    agree to 1e-12 relative (1e-313 absolute among subnormals)."""
+    nx, lo, hi, nsg, nsd, recon, riem, driem, coords, ng = CASES[case]
+    o, mb = build(nx, lo, hi, nsg, nsd, recon, riem, driem, coords, ng, seed=33)
+    rng = np.random.default_rng(9)
+    choices, prob = [1.0, 0.0, 1e-300, 1e-306, 1e-250, 1e-160, 1e-150, 1e-100, 1e-40], [0.3, 0.1, 0.1, 0.1, 0.08, 0.08, 0.08, 0.08, 0.08]
+    for arr, ns in ((o.gprim, nsg), (o.dprim if nsd else None, nsd)):
+        if arr is None:
+            continue
+        scale = rng.choice(choices, size=arr[0].shape, p=prob)
+        for v in range(ns, 4 * ns):
+            arr[v] *= scale
+    o.PrimToCons()
+    push([o], mb)
+    gin, din = mb.gas_prim_table, mb.dust_prim_table
+    _, gout = mb.new_prim_buffer("o")
+    dbuf, dout = mb.new_dust_prim_buffer("o") if nsd else (None, None)
+    o.DeepCopyConservedData()
+    dt = 1.0e-4
+    oracle_stage(o, 0.0, 1.0, 1.0, dt, False, 0.0, False, False, False)
+    mb.stage_general(0.0, 1.0, dt, dt, gas=(gin, gin, gout), dust=(din, din, dout))
+    assert mb.last_stage_variant == 1  # the row-march kernel really ran
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    keep = [v for v in range(6 * nsg) if not (4 * nsg <= v < 5 * nsg)]  # P is not written
+    pairs = [(mb._extra_prim["o"][0][0][I].cpu().numpy()[keep], o.gprim[I][keep], "gas")]
+    if nsd:
+        pairs.append((dbuf[0][I].cpu().numpy(), o.dprim[I], "dust"))
+    for got, ref, what in pairs:
+        big = np.abs(ref) >= 1e-120
+        bad = big & (got != ref)
+        assert not bad.any(), f"{what}: {np.count_nonzero(bad)} entries above 1e-120 differ, the largest {np.abs(ref[bad]).max():.3e}"
+        err = np.abs(got[~big] - ref[~big])
+        assert np.all(err <= 1e-12 * np.abs(ref[~big]) + 1e-313), f"{what}: {err.max():.3e}"
+
+
 @pytest.mark.parametrize("case", [1, 4, 5, 7, 8, 9])
 def test_general_stage_with_sources_and_drag(hiplib, case):
     """Cartesian: point-mass gravity + shearing box + simple_dust drag in one stage, with the
