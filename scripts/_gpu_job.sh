@@ -1,2 +1,5 @@
 cd /root/repo
-timeout 600 python -m pytest tests/test_adaptive.py -q -m gpu -k "distance_table" > gpurun_out/t.log 2>&1; grep -E "passed|failed|^E  |Error" gpurun_out/t.log | head -8
+timeout 300 python scripts/curv_timing.py disk_sph | cut -c1-70
+ARTEMIS_FUSED_KCHUNK=64 timeout 300 python scripts/curv_timing.py disk_sph | cut -c1-70
+ARTEMIS_FUSED_KCHUNK=16 timeout 300 python scripts/curv_timing.py disk_sph | cut -c1-70
+timeout 300 python scripts/curv_timing.py disk_sph | cut -c1-70
