@@ -1,5 +1,2 @@
 cd /root/repo
-timeout 300 python scripts/curv_timing.py disk_sph | cut -c1-70
-ARTEMIS_FUSED_KCHUNK=64 timeout 300 python scripts/curv_timing.py disk_sph | cut -c1-70
-ARTEMIS_FUSED_KCHUNK=16 timeout 300 python scripts/curv_timing.py disk_sph | cut -c1-70
-timeout 300 python scripts/curv_timing.py disk_sph | cut -c1-70
+timeout 900 python -m pytest tests/test_driver_gpu.py -q -m gpu -k "long_sedov" > gpurun_out/t.log 2>&1; grep -E "passed|failed|^E  |Error" gpurun_out/t.log | head -12
