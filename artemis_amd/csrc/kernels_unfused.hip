@@ -806,14 +806,9 @@ struct ShellBatch {
   int blk[BC_BATCH];
   unsigned char bc[BC_BATCH][6];
 };
-__global__ __launch_bounds__(256) void bc_shell_kernel(ShellArgs a, FillTabs t, const ShellBatch batch) {
-  {
-    const int q = blockIdx.y; // wave-uniform: scalar loads from the kernel-argument segment
-    t.b = batch.blk[q];
-    for (int f = 0; f < 6; ++f) a.bc[f] = batch.bc[q][f];
-  }
-  // (the three regions of one block hold < 2^31 zones: the launcher checks; 32-bit divisions)
-  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+// ghost zone `tid` of the shell (regions A, B, C in turn) -> its array offset `cd`, the offset `cs` of the active zone
+// it copies and the reflecting walls crossed; false where nothing is to be done
+__device__ __forceinline__ bool shell_zone(const ShellArgs &a, unsigned tid, long &cd, long &cs, int &refl) {
   const unsigned nA = static_cast<unsigned>(a.nA), nB = static_cast<unsigned>(a.nB), nC = static_cast<unsigned>(a.nC);
   const unsigned e0 = a.ext[0], e1 = a.ext[1];
   int idx[3];
@@ -837,10 +832,10 @@ __global__ __launch_bounds__(256) void bc_shell_kernel(ShellArgs a, FillTabs t, 
     idx[1] = a.lo[1] + (row - kk * ny);
     idx[2] = a.lo[2] + kk;
   } else {
-    return;
+    return false;
   }
   int src[3] = {idx[0], idx[1], idx[2]};
-  int refl = 0; // bit d set: reflecting wall crossed along d
+  refl = 0; // bit d set: reflecting wall crossed along d
   bool moved = false;
   for (int d = 0; d < a.ndim; ++d) {
     const int n_act = a.hi[d] - a.lo[d] + 1;
@@ -855,33 +850,57 @@ __global__ __launch_bounds__(256) void bc_shell_kernel(ShellArgs a, FillTabs t, 
     else src[d] = inner ? 2 * a.lo[d] - 1 - idx[d] : 2 * a.hi[d] + 1 - idx[d], refl |= (1 << d);
     moved = true;
   }
-  if (!moved) return;
-  const long cd = (static_cast<long>(idx[2]) * a.ext[1] + idx[1]) * a.ext[0] + idx[0];
-  const long cs = (static_cast<long>(src[2]) * a.ext[1] + src[1]) * a.ext[0] + src[0];
-  // the variables are separate arrays: five loads in flight before the five stores (one variable at a time was a
-  // chain of pointer load -> value load -> store per variable, 55 us for the shell of a 256^3 block)
+  cd = (static_cast<long>(idx[2]) * a.ext[1] + idx[1]) * a.ext[0] + idx[0];
+  cs = (static_cast<long>(src[2]) * a.ext[1] + src[1]) * a.ext[0] + src[0];
+  return moved;
+}
+// SHELL_ZONES zones per thread, a workgroup stride apart (coalesced): their loads of five variables are all in
+// flight before the first store -- the kernel is a chain of dependent memory round trips, not bandwidth
+constexpr int SHELL_ZONES = 4;
+__global__ __launch_bounds__(256) void bc_shell_kernel(ShellArgs a, FillTabs t, const ShellBatch batch) {
+  {
+    const int q = blockIdx.y; // wave-uniform: scalar loads from the kernel-argument segment
+    t.b = batch.blk[q];
+    for (int f = 0; f < 6; ++f) a.bc[f] = batch.bc[q][f];
+  }
+  // (the three regions of one block hold < 2^31 zones: the launcher checks; 32-bit divisions)
+  long cd[SHELL_ZONES], cs[SHELL_ZONES];
+  int refl[SHELL_ZONES];
+  bool on[SHELL_ZONES];
+#pragma unroll
+  for (int z = 0; z < SHELL_ZONES; ++z) {
+    const unsigned tid = (blockIdx.x * SHELL_ZONES + z) * blockDim.x + threadIdx.x;
+    cd[z] = cs[z] = 0, refl[z] = 0;
+    on[z] = shell_zone(a, tid, cd[z], cs[z], refl[z]);
+  }
   constexpr int NV = 5;
   for (int v0 = 0; v0 < a.nfill; v0 += NV) {
     double *q[NV];
-    double val[NV];
+    bool nrm[NV][3];
+    double val[NV][SHELL_ZONES];
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int v = (v0 + u < a.nfill) ? v0 + u : v0;
-      bool n0, n1, n2;
-      q[u] = fill_var(t, v, 0, n0);
-      fill_var(t, v, 1, n1);
-      fill_var(t, v, 2, n2);
-      // sequential passes multiply by -1.0 once per reflecting wall crossed along the
-      // component's own direction
-      double w = q[u][cs];
-      if ((refl & 1) && n0) w = -1.0 * w;
-      if ((refl & 2) && n1) w = -1.0 * w;
-      if ((refl & 4) && n2) w = -1.0 * w;
-      val[u] = w;
+      q[u] = fill_var(t, v, 0, nrm[u][0]);
+      fill_var(t, v, 1, nrm[u][1]);
+      fill_var(t, v, 2, nrm[u][2]);
+#pragma unroll
+      for (int z = 0; z < SHELL_ZONES; ++z) val[u][z] = on[z] ? q[u][cs[z]] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < NV; ++u)
-      if (v0 + u < a.nfill) q[u][cd] = val[u];
+    for (int u = 0; u < NV; ++u) {
+      if (v0 + u >= a.nfill) continue;
+#pragma unroll
+      for (int z = 0; z < SHELL_ZONES; ++z) {
+        if (!on[z]) continue;
+        // sequential passes multiply by -1.0 once per reflecting wall crossed along the component's own direction
+        double w = val[u][z];
+        if ((refl[z] & 1) && nrm[u][0]) w = -1.0 * w;
+        if ((refl[z] & 2) && nrm[u][1]) w = -1.0 * w;
+        if ((refl[z] & 4) && nrm[u][2]) w = -1.0 * w;
+        q[u][cd[z]] = w;
+      }
+    }
   }
 }
 
@@ -1102,7 +1121,7 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
   auto flush = [&]() {
     if (nq == 0) return;
     for (int f = 0; f < 6; ++f) a.bc[f] = ARTEMIS_BC_NONE; // (the kernel takes the flags from the batch)
-    hipLaunchKernelGGL(bc_shell_kernel, dim3((n + 255) / 256, nq), dim3(256), 0, s, a, fill_tabs(P, 0), batch);
+    hipLaunchKernelGGL(bc_shell_kernel, dim3((n + 256 * SHELL_ZONES - 1) / (256 * SHELL_ZONES), nq), dim3(256), 0, s, a, fill_tabs(P, 0), batch);
     nq = 0;
   };
   for (int b = 0; b < P.nb; ++b) {

@@ -1,2 +1,11 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_driver_gpu.py -q -m gpu -k "long_sedov" > gpurun_out/t.log 2>&1; grep -E "passed|failed|^E  |Error" gpurun_out/t.log | head -12
+export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/bc_prof3 -o p --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-dropin > gpurun_out/bc_line3.json 2>/dev/null
+cut -c60-135 gpurun_out/bc_line3.json
+f=$(find gpurun_out/bc_prof3 -name "*kernel_stats.csv" | head -1)
+python - <<PY
+import csv
+for r in list(csv.DictReader(open('$f')))[:4]:
+    print(r['Name'][30:100], r['Calls'], round(float(r['AverageNs'])/1e3,1), r['Percentage'])
+PY
+timeout 300 python bench.py --no-cpu-baseline --no-dropin 2>/dev/null | cut -c60-135
