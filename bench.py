@@ -147,6 +147,11 @@ def cpu_baseline_ssheet(n, ndust, cycles):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C
+    # stdio when a communicator is created): keep the caller's stdout for the line and send everything else that
+    # lands on descriptor 1 to stderr.
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -439,7 +444,7 @@ def main():
                           "%d cycles in %.1f s.  Thread scaling of this restatement on this host: profiles/r02_cpu_scaling.txt"
                           % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), args.cpu_n, cyc, secs, threads,
                              hc["logical"], cyc1, secs1)}
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     sim.close()
     if comm is not None:
         comm.close()

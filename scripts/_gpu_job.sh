@@ -1,6 +1,4 @@
 cd /root/repo
-export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_driver_gpu.py tests/test_parity_fused.py tests/test_parity_ops.py -x -q -m gpu > gpurun_out/t.log 2>&1; grep -E "passed|failed|^E  " gpurun_out/t.log | head -6
-timeout 300 python bench.py --no-cpu-baseline --no-dropin 2>/dev/null | cut -c60-135
-ARTEMIS_NO_X1_GHOSTS=1 timeout 300 python bench.py --no-cpu-baseline --no-dropin 2>/dev/null | cut -c60-135
-timeout 300 python bench.py --no-cpu-baseline --no-dropin 2>/dev/null | cut -c60-135
+timeout 300 python bench.py --no-cpu-baseline --no-dropin --loopback --steps 20 > gpurun_out/o1.txt 2> gpurun_out/e1.txt; wc -l gpurun_out/o1.txt; cut -c1-80 gpurun_out/o1.txt; grep -c "RCCL version" gpurun_out/e1.txt
+timeout 600 python bench.py --steps 20 > gpurun_out/o2.txt 2> gpurun_out/e2.txt; wc -l gpurun_out/o2.txt; python -c "
+import json; d=json.loads(open('gpurun_out/o2.txt').read()); print(d['value'], d['cpu_baseline']['value'], d['roofline']['frac'])"
