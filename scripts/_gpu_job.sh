@@ -1,4 +1,4 @@
 cd /root/repo
-timeout 300 python bench.py --no-cpu-baseline --no-dropin --loopback --steps 20 > gpurun_out/o1.txt 2> gpurun_out/e1.txt; wc -l gpurun_out/o1.txt; cut -c1-80 gpurun_out/o1.txt; grep -c "RCCL version" gpurun_out/e1.txt
-timeout 600 python bench.py --steps 20 > gpurun_out/o2.txt 2> gpurun_out/e2.txt; wc -l gpurun_out/o2.txt; python -c "
-import json; d=json.loads(open('gpurun_out/o2.txt').read()); print(d['value'], d['cpu_baseline']['value'], d['roofline']['frac'])"
+for sh in 0 11 27 1009 5 77; do
+ARTEMIS_SEED_SHIFT=$sh timeout 900 python -m pytest tests/test_parity_fused.py tests/test_parity_stage_general.py tests/test_parity_ops.py -q -m gpu -k "vanishing" > gpurun_out/seed_$sh.log 2>&1; echo "shift $sh: $(grep -E 'passed|failed' gpurun_out/seed_$sh.log | tail -1)"; grep -E "^E  .*Assert" gpurun_out/seed_$sh.log | head -3
+done

@@ -95,7 +95,8 @@ def test_fused_step_with_vanishing_velocities(hiplib, riem):
     1e-150 in a limited slope, or a momentum of 1e-305 divided by the density, is not, and such a quotient may be
     off in its last place.  Everything those quotients can reach is itself below 1e-140.  So, on a state with such
     velocities next to exact zeros and ordinary values: every entry of magnitude >= 1e-120 is bit-identical to the
-    oracle, and the others -- physically zero -- agree to 1e-12 relative (1e-313 absolute among subnormals)."""
+    oracle, and the others -- physically zero -- agree to 1e-135 absolute (an ulp of the largest of them; relative
+    to a value that small cancellation makes the difference look larger)."""
     bc = ("outflow",) * 6
     o, mb, bufs = setup((40, 20, 36), 2, "plm", riem, bc, seed=13)
     rng = np.random.default_rng(3)
@@ -120,7 +121,7 @@ def test_fused_step_with_vanishing_velocities(hiplib, riem):
                                    f"{np.abs(ref[bad]).max():.3e} (gpu {got[bad][0]:.17e} ref {ref[bad][0]:.17e})")
             assert np.all(np.abs(got[~big]) < 1e-119)
             err = np.abs(got[~big] - ref[~big])
-            assert np.all(err <= 1e-12 * np.abs(ref[~big]) + 1e-313), f"{what}, step {step}: {err.max():.3e}"
+            assert np.all(err < 1e-135), f"{what}, step {step}: {err.max():.3e}"
             # and the difference is confined to a handful of zones
             assert np.count_nonzero(got != ref) < 1e-3 * ref.size
         # continue from the oracle's bits so that the second step starts from identical states
