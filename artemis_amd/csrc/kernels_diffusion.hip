@@ -575,7 +575,7 @@ void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double
   const Box r = interior(P);
   const dim3 g3 = grid_of(r, P.nb);
   const long ntile = static_cast<long>(g3.x) * g3.y * g3.z;
-  const dim3 g(static_cast<unsigned>(ntile < 4096 ? ntile : 4096));
+  const dim3 g(static_cast<unsigned>(ntile < 1024 ? ntile : 1024)); // (one atomicMin per workgroup on ONE address: 512 / 1024 / 4096 / 16384 workgroups: 77 / 52 / 67 / 194 us)
   auto *bits = reinterpret_cast<unsigned long long *>(dt_dev);
   const bool curv = P.coords != ARTEMIS_CARTESIAN;
   for (const artemis_diffcoeff_t *c : {&D.visc, &D.cond}) {
