@@ -39,18 +39,23 @@ def run_world(world, spec, tmp_path, tag):
     if key in _RESULTS:
         return _RESULTS[key]
     spec = dict(spec, out=str(tmp_path / tag))
-    port = str(free_port())
-    procs = []
     # the checker's OpenMP team per rank: the machine's CPUs shared by the ranks (the updates have no cross-thread
     # floating-point reductions, so the fields do not depend on the team size)
     threads = str(max(1, min(4, (os.cpu_count() or 1) // world)))
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=port, OMP_NUM_THREADS=threads)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mr_worker.py"),
-                                       json.dumps(spec)], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for attempt in range(2):  # (the probed port can be taken between the probe and the rendezvous: one retry)
+        port = str(free_port())
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=port, OMP_NUM_THREADS=threads)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mr_worker.py"),
+                                           json.dumps(spec)], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+        rendezvous = any(p.returncode != 0 and ("Address already in use" in o or "Connection re" in o or "timed out" in o.lower())
+                         for p, o in zip(procs, outs))
+        if not (rendezvous and attempt == 0):
+            break
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
     res = []
