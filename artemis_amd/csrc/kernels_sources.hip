@@ -159,7 +159,9 @@ ADEV void nb_accrete(const artemis_nbody_particle_t &p, const double x[3], const
   const double r = sqrt(sqr(R) + sqr(dx[2]));
   const double ct = dx[2] / (r + fuzz), st = R / (r + fuzz);
   const double cp = dx[0] / (R + fuzz), sp = dx[1] / (R + fuzz);
-  const double et[3] = {ct * cp, ct * sp, -st}, ep[3] = {-sp, cp, 0.0};
+  // particle_base.hpp:201 binds [dr, er, et, ep] to CartToSph's {xout, ex1, ex2, ex3} (:255-257): et / ep are the
+  // second / third ROWS as written there, not the textbook unit vectors -- kept as the reference has it
+  const double et[3] = {st * sp, ct * sp, cp}, ep[3] = {ct, -st, 0.0};
   const double dvt = dv[0] * et[0] + dv[1] * et[1] + dv[2] * et[2];
   const double dvp = dv[0] * ep[0] + dv[1] * ep[1] + dv[2] * ep[2];
   const bool acc = ((p.racc > 0.0) && (r <= p.racc) && (-p.gm / (r + fuzz) + 0.5 * dv2 <= 0.0));

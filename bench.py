@@ -4,11 +4,16 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: under a launcher (WORLD_SIZE set) this process is one rank; without one the
+process becomes a plain parent that starts N child processes of this file (one per LOCAL_RANK, rendezvous
+on 127.0.0.1), relays rank 0's JSON line and exits non-zero if any child does -- it never touches the GPU
+itself (self_launch() runs before torch or the HIP library are imported).
+
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): the
 reference's Sedov deck inputs/blast/blast.in in 3-D -- Cartesian 256^3 cells per GPU, gas only,
 HLLC + PLM, rk2, cfl 0.3, gamma 1.4, outflow, nghost 2, floors 1e-10 -- weak-scaled over the
 GPUs of one node (256x256x512, 256x512x512, 256x512x1024 for 2/4/8 GPUs, one 256^3 mesh block
-per rank, ranks cut along x3 then x2).  One "step" = one full cycle: every RK stage (fused flux/update/source/c2p kernel +
+per rank, ranks cut along x3 then x2, never along x1: rank grid 1x1x2, 1x2x2, 1x2x4 -- see DECOMPOSITION).  One "step" = one full cycle: every RK stage (fused flux/update/source/c2p kernel +
 ghost fill), the CFL reduction and, for N > 1, the halo exchange and the dt all-reduce.
 Initial data are generated on the host and are resident in HBM before the timed region.
 
@@ -35,10 +40,64 @@ ALG_BYTES_PER_CELL_STAGE = 240.0   # 30 doubles
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+# Rank grid (x1, x2, x3) per GPU count.  BASELINE.md 2.2 suggests 2x2x2 -> 512^3 at 8 GPUs; this bench keeps the same
+# zones per GPU and the same total (2^27 zones at 8 GPUs) but never cuts x1: an x1 face slab is two zones out of
+# every 260-zone row (16-byte pieces of 128-byte lines for the pack / unpack kernels and for the boundary shell of
+# the stage kernel), while x2 / x3 slabs are whole rows.  1x2x4 also never gives a rank more faces to exchange than
+# 2x2x2 does (interior ranks 3, end ranks 2; 2x2x2: 3 everywhere).  DESIGN.md section 6 states the same grid.
+DECOMPOSITION = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (1, 2, 4)}
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` without a launcher: start N children of this file (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, one per GPU), relay rank 0's stdout (the JSON line), exit non-zero if any child fails.  Runs before
+    anything that could initialise the GPU; the children are ordinary child processes (no exec of this process).
+    ARTEMIS_BENCH_CHILD_CMD (a JSON list) replaces `[python, bench.py]` -- the hook of tests/test_bench_launcher.py."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    child = json.loads(os.environ["ARTEMIS_BENCH_CHILD_CMD"]) if os.environ.get("ARTEMIS_BENCH_CHILD_CMD") else \
+        [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("ARTEMIS_BENCH_CHILD_CMD", None)
+        procs.append(subprocess.Popen(child + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+    reader.start()  # (a blocking read here would never notice another rank dying while rank 0 waits for it)
+    rcs = [None] * n
+    deadline = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs) and deadline is None:
+            deadline = time.time() + float(os.environ.get("ARTEMIS_BENCH_GRACE_S", "30"))  # a rank died: the others may sit in a collective for ever
+        if deadline is not None and time.time() > deadline:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.kill()  # exactly the children started above
+                    rcs[r] = p.wait()
+        time.sleep(0.05)
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: rank(s) failed: %s" % bad, file=sys.stderr, flush=True)
+        raise SystemExit(next(rc for _, rc in bad) or 1)
+    reader.join()
+    sys.stdout.buffer.write(got[0])
+    sys.stdout.flush()
+    raise SystemExit(0)
+
+
 def overrides(n_gpus, per_gpu, steps_total, extra=()):
     # weak scaling grows the mesh along x3, then x2: ranks are never cut along x1, so rows stay
     # 256 cells long and the boundary shell of the stage kernel stays thin
-    shape = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (1, 2, 4)}.get(n_gpus)
+    shape = DECOMPOSITION.get(n_gpus)
     if shape is None:
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
     ov = ["gas/riemann=hllc", "problem/symmetry=spherical", "problem/radius=0.03",
@@ -150,8 +209,6 @@ def main():
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C
     # stdio when a communicator is created): keep the caller's stdout for the line and send everything else that
     # lands on descriptor 1 to stderr.
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -182,6 +239,12 @@ def main():
     ap.add_argument("--cpu-cycles", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all host cores)")
     args = ap.parse_args()
+    if args.gpus not in DECOMPOSITION:
+        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(sys.argv[1:], args.gpus)  # does not return
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     from artemis_amd import capi
@@ -272,7 +335,8 @@ def main():
             extra = ["parthenon/meshblock/nx3=%d" % (args.n // args.blocks_per_gpu)]
         if args.uniform:
             extra = extra + ["problem/radius=0.0"]
-        sim = Simulation(deck, overrides(args.gpus, per_gpu, args.warmup + args.steps, extra), comm=comm)
+        make_sim = lambda: Simulation(deck, overrides(args.gpus, per_gpu, args.warmup + args.steps, extra), comm=comm)
+        sim = make_sim()
     if args.path == "unfused":
         sim.set_path("unfused")
     want_overlap = (world > 1 or args.loopback or bool(os.environ.get("ARTEMIS_FORCE_OVERLAP"))) and not args.no_overlap
@@ -286,7 +350,29 @@ def main():
             comm.barrier()  # RCCL all-reduce + stream sync: every rank's device work is done
         torch.cuda.synchronize()
 
-    sim.evolve(args.warmup)
+    wait_timeout = False
+    try:
+        sim.evolve(args.warmup)
+        bad = 0
+    except RuntimeError as e:
+        # overlap mode 2's wait kernel gave up (its polling wave was not co-resident with the stage kernel's grid):
+        # the driver has already switched overlapping off; say so and carry on with two launches per stage
+        if "timed out" not in str(e) or not want_overlap:
+            raise
+        bad = 1
+    if world > 1:  # every rank takes the same mode
+        flag = torch.tensor([bad], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        bad = int(flag.item())
+    if bad:  # start again from the initial condition (the failed run's ghost zones may hold unfinished shell data)
+        wait_timeout = True
+        sim.close()
+        sim = make_sim()
+        if args.path == "unfused":
+            sim.set_path("unfused")
+        sim.set_overlap(1)
+        sim.evolve(args.warmup)
+    overlap_used = sim.overlap
     # The timed region runs the production loop (device-resident dt, hipGraph replay on one rank, no
     # per-kernel events); per-kernel durations for `roofline` come from a separate short leg below.
     barrier()
@@ -355,10 +441,16 @@ def main():
                             "gas HLLC+PLM, rk2, cfl 0.3, gamma 1.4, outflow, nghost 2, radius 0.03, "
                             "samples 0%s" % (args.n, " -- UNIFORM-STATE diagnostic (radius 0)" if args.uniform else ""),
                 "cells_per_gpu": local_zones, "path": "fused" if fused else "unfused",
-                "decomposition": "%d rank(s), one %d^3 mesh block each, face-slab halo exchange%s"
-                                 % (args.gpus, args.n, "" if world == 1 else
-                                    (" on RCCL, not overlapped" if args.no_overlap else
-                                     " on RCCL on a second stream behind the bulk of the stage kernel")),
+                "decomposition": "%d rank(s) as a %dx%dx%d grid (x1, x2, x3; never cut along x1: x1 face slabs are 16-byte "
+                                 "pieces of every row, x2 / x3 slabs whole rows; same zones per GPU and in total as BASELINE.md's "
+                                 "2x2x2), one %d^3 mesh block each, face-slab halo exchange%s"
+                                 % ((args.gpus,) + DECOMPOSITION[args.gpus] + (args.n, "" if world == 1 else
+                                    (" on RCCL, not overlapped" if not overlap_used else
+                                     " on RCCL on a second stream behind the bulk of the stage kernel"))),
+                "rank_grid": list(DECOMPOSITION[args.gpus]),
+                "overlap_mode": overlap_used,  # 0 none, 1 shell + bulk launches, 2 one launch + device counter
+                "overlap_wait_timeout": wait_timeout,  # mode 2's wait kernel gave up during warm-up -> mode 1 was used
+                "ncclCommCount": rccl_ranks,
                 "transport": None if comm is None else
                              ("FALLBACK torch.distributed nccl backend (native RCCL transport failed: %s)" % comm.fallback
                               if getattr(comm, "fallback", None) else

@@ -1288,12 +1288,13 @@ inline void nb_accrete(const Sim::NBodyParticle &p, const Real x[3], const Real 
   Real dx[3], dv[3];
   for (int d = 0; d < 3; d++) dx[d] = x[d] - (p.pos[d] - p.xf[d]), dv[d] = vrel[d] - (p.vel[d] - p.vf[d]);
   const Real dv2 = SQR(dv[0]) + SQR(dv[1]) + SQR(dv[2]);
-  // CartToSph (:247-262): only the radius and the two tangential unit vectors are used
+  // CartToSph (:247-262): [dr, er, et, ep] = {xout, ex1, ex2, ex3} (:201), i.e. et = ex2 = {st sp, ct sp, cp} and
+  // ep = ex3 = {ct, -st, 0} exactly as written at :256-257 (rows of the matrix, not the textbook unit vectors)
   const Real R = std::sqrt(SQR(dx[0]) + SQR(dx[1]));
   const Real r = std::sqrt(SQR(R) + SQR(dx[2]));
   const Real ct = dx[2] / (r + fuzz), st = R / (r + fuzz);
   const Real cp = dx[0] / (R + fuzz), sp = dx[1] / (R + fuzz);
-  const Real et[3] = {ct * cp, ct * sp, -st}, ep[3] = {-sp, cp, 0.0};
+  const Real et[3] = {st * sp, ct * sp, cp}, ep[3] = {ct, -st, 0.0};
   const Real dvt = dv[0] * et[0] + dv[1] * et[1] + dv[2] * et[2];
   const Real dvp = dv[0] * ep[0] + dv[1] * ep[1] + dv[2] * ep[2];
   const bool acc = ((p.racc > 0.0) && (r <= p.racc) && (-p.GM / (r + fuzz) + 0.5 * dv2 <= 0.0));

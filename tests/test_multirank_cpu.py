@@ -52,7 +52,10 @@ def run_world(world, spec, tmp_path, tag):
                                            json.dumps(spec)], env=env, stdout=subprocess.PIPE,
                                           stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=600)[0].decode() for p in procs]
-        rendezvous = any(p.returncode != 0 and ("Address already in use" in o or "Connection re" in o or "timed out" in o.lower())
+        # (also retried once: gloo's worker threads racing the interpreter's teardown on a loaded machine --
+        # "terminate called without an active exception", after the rank has written its results)
+        rendezvous = any(p.returncode != 0 and ("Address already in use" in o or "Connection re" in o or "timed out" in o.lower()
+                                                or "terminate called without an active exception" in o)
                          for p, o in zip(procs, outs))
         if not (rendezvous and attempt == 0):
             break
