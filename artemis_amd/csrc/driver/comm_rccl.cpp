@@ -74,6 +74,12 @@ int allreduce_min_dev(void *vctx, double *dev_value, void *stream) {
              : 1;
 }
 
+// Host-value reductions run on the context's private stream.  PRECONDITION (RCCL orders the operations of one
+// communicator by issue order on every rank, whatever stream they are on): no exchange group of the driver may be
+// in flight -- every caller (SetGlobalTimeStep's host min in the synchronising loop, history / error sums, the
+// refinement tags, remesh) comes after the driver has synchronised its compute and comm streams, and every rank
+// reaches the call at the same point of the cycle.  The device-resident dt reduction (allreduce_min_dev) is the one
+// that runs in stream order behind exchanges.
 int host_allreduce(RcclCtx *c, double *values, int n, ncclRedOp_t op) {
   for (int done = 0; done < n; done += RcclCtx::kScratch) {
     const int m = std::min(RcclCtx::kScratch, n - done);
@@ -135,6 +141,8 @@ artemis_comm_t *artemis_comm_rccl_create(const char *unique_id, int rank, int nr
   if (!c->stream || !c->scratch) {
     g_comm_err = std::string("device resources: ") + artemis_hip_last_error();
     ncclCommDestroy(c->comm);
+    if (c->scratch) artemis_rt_free(c->scratch); // whichever of the two was obtained
+    if (c->stream) artemis_rt_stream_destroy(c->stream);
     delete c;
     return nullptr;
   }

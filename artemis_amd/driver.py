@@ -187,13 +187,6 @@ class RcclComm:
         if self.L.artemis_comm_rccl_barrier(self.h):
             raise RuntimeError("RCCL barrier: " + self.L.artemis_comm_rccl_last_error().decode())
 
-    def _refresh_dims(self):
-        """Block layout of this rank (an adaptive mesh changes it between cycles)."""
-        d = (C.c_int * 11)()
-        self.L.artemis_sim_dims(self.h, d)
-        (self.nblocks, self.ni, self.nj, self.nk, self.is_, self.ie, self.js, self.je, self.ks,
-         self.ke, self.ng) = list(d)
-
     def close(self):
         if getattr(self, "h", None):
             self.L.artemis_comm_rccl_destroy(self.h)
