@@ -91,6 +91,14 @@ int validate_fluid(const artemis_pack_t *p, int fluid, int pcm) {
                 recon == ARTEMIS_PCM ? "PCM" : (recon == ARTEMIS_PLM ? "PLM" : "PPM"), need);
   return 0;
 }
+// ApplyUpdate / DeepCopyConservedData read BOTH registers: a pack whose cons1 tables were never filled from the u1
+// MeshData (artemis_driver.cpp:137-139) is an error here, not a device fault
+int validate_registers(const artemis_pack_t *p, const char *task) {
+  for (const artemis_fluid_pack_t *f : {&p->gas, &p->dust})
+    if (f->nspecies > 0 && (!f->cons0 || !f->cons1))
+      return fail(ARTEMIS_HIP_EINVAL, "%s needs the cons0 (u0) and cons1 (u1) tables of every fluid in the pack", task);
+  return 0;
+}
 inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
 int after_launch(const char *what) { return check_hip(hipGetLastError(), what); }
 
@@ -137,6 +145,7 @@ int artemis_hip_calculate_fluxes(const artemis_pack_t *p, int fluid, int pcm, vo
 int artemis_hip_apply_update(const artemis_pack_t *p, double gam0, double gam1, double beta_dt,
                              void *stream) {
   if (int rc = validate(p)) return rc;
+  if (int rc = validate_registers(p, "ApplyUpdate")) return rc;
   artemis::launch_apply_update(artemis::make_pack_view(*p), gam0, gam1, beta_dt, S(stream));
   return after_launch("ApplyUpdate");
 }
@@ -180,6 +189,7 @@ int artemis_hip_prim_to_cons_ghosts(const artemis_pack_t *p, void *stream) {
 
 int artemis_hip_deep_copy_conserved(const artemis_pack_t *p, void *stream) {
   if (int rc = validate(p)) return rc;
+  if (int rc = validate_registers(p, "DeepCopyConservedData")) return rc;
   artemis::launch_deep_copy(artemis::make_pack_view(*p), S(stream));
   return after_launch("DeepCopyConservedData");
 }

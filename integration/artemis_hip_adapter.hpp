@@ -1,18 +1,28 @@
 // artemis_hip_adapter.hpp -- the file a maintainer adds to lanl/artemis (src/utils/) to route the hydro tasks
 // through libartemis_hip.so.  It fills an `artemis_pack_t` (include/artemis_hip.h) from the SparsePacks the
-// reference's own task functions build, once per MeshData partition (again after a remesh), and forwards each
-// task.  Nothing else in Artemis changes: StateDescriptor registration, the TaskList of
+// reference's own task functions build, once per MeshData partition (again when the mesh or the MeshData changes),
+// and forwards each task.  Nothing else in Artemis changes: StateDescriptor registration, the TaskList of
 // ArtemisDriver<GEOM>::StepTasks (artemis_driver.cpp:145-273), problem generators and decks stay as they are.
 //
-// Compile-checked in this repository against a declarations-only stand-in for the few Parthenon / Artemis names
-// it touches (tests/mock_parthenon/, tests/test_integration_adapter.py); in Artemis it includes the real headers.
+// Checked in this repository two ways (tests/test_integration_adapter.py): compiled with -Wall -Werror against a
+// stand-in for the few Parthenon / Artemis names it touches (tests/mock_parthenon/), and RUN -- the reference's task
+// list for an RK2 step, two MeshData partitions, through these forwarders on the CPU test double of the library --
+// against the oracle, bit for bit (tests/adapter_live/run_stage.cpp).  In Artemis it includes the real headers.
 #ifndef ARTEMIS_HIP_ADAPTER_HPP_
 #define ARTEMIS_HIP_ADAPTER_HPP_
 
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
 #include <vector>
 
 #include "artemis.hpp"     // Real, Coordinates, RSolver, ReconstructionMethod, the gas:: / dust:: field types
 #include "artemis_hip.h"   // this repository's include/
+#include "drag/drag.hpp"                         // Drag::Coupling, SelfDragParams, StoppingTimeParams
+#include "gravity/gravity.hpp"                   // Gravity::GravityType, Orbit
+#include "nbody/particle_base.hpp"               // NBody::Particle
+#include "utils/diffusion/diffusion_coeff.hpp"   // Diffusion::DiffCoeffParams
 
 namespace ArtemisHip {
 using parthenon::MeshData;
@@ -20,13 +30,22 @@ using parthenon::ParArray1D;
 using parthenon::TaskStatus;
 using TE = parthenon::TopologicalElement;
 
-// Device tables of one fluid + what is shared by the pack.  One instance per MeshData partition.
+// Device tables of one MeshData partition.  What identifies the data they point at is remembered (`probe0`,
+// `probe1`: the address of the first conserved variable of the first block of the u0 / u1 MeshData, and the block
+// count): a remesh, a restart or another MeshData of the same partition id moves them and the tables are rebuilt
+// on the next call -- no hook into Parthenon's remesher is needed (Invalidate() is there for hosts that have one).
 struct PackCache {
   artemis_pack_t p{};
   ParArray1D<Real *> gprim, gcons0, gcons1, gflux[3], gpflux[3], gvface[3], gdflux[3];
   ParArray1D<Real *> dprim, dcons0, dcons1, dflux[3];
   ParArray1D<Real> geom, metric;
-  bool built = false;
+  std::vector<Real> geom_host, metric_host;
+  const Real *probe0 = nullptr, *probe1 = nullptr;
+  int nb = -1;
+  // package tables that depend on the mesh (built on first use after a rebuild)
+  ParArray1D<Real> visc_radial_data;
+  ParArray1D<const Real *> visc_radial;
+  bool visc_radial_built = false;
 };
 
 // entry [b * nvar + v] = address of variable v of block b at (k, j, i) = (0, 0, 0)
@@ -47,7 +66,7 @@ void FillFluxTable(ParArray1D<Real *> &tab, const Pack &v, const int nb, const i
       DEFAULT_LOOP_PATTERN, "ArtemisHip::FillFluxTable", parthenon::DevExecSpace(), 0, nb - 1, 0, nvar - 1,
       KOKKOS_LAMBDA(const int b, const int n) { t(b * nvar + n) = &v.flux(b, dir, first + n, 0, 0, 0); });
 }
-// face field (gas.face.velocity) on the faces of direction dir
+// face field (gas.face.velocity, gas.diff.*) on the faces of direction dir
 template <typename Pack>
 void FillFaceTable(ParArray1D<Real *> &tab, const Pack &v, const int nb, const int nvar, const int dir) {
   tab = ParArray1D<Real *>("artemis_hip face table", nb * nvar);
@@ -58,16 +77,40 @@ void FillFaceTable(ParArray1D<Real *> &tab, const Pack &v, const int nb, const i
       KOKKOS_LAMBDA(const int b, const int n) { t(b * nvar + n) = &v(b, te, n, 0, 0, 0); });
 }
 
-// u0 = the MeshData the task receives, u1 = the start-of-step copy (artemis_driver.cpp:137-139); may be the same
-// object for tasks that do not read cons1.
-inline artemis_pack_t &GetPack(PackCache &c, MeshData<Real> *u0, MeshData<Real> *u1) {
-  if (c.built) return c.p;
+// the descriptors Gas / Dust::CalculateFluxes build (gas.cpp:479-488, dust.cpp:287-290): pack order rho[n],
+// v[ns+3n+d], P[4ns+n], sie[5ns+n]; D[n], M[ns+3n+d], E[4ns+n], e_int[5ns+n]
+inline auto &GasPrimDesc(parthenon::ResolvedPackages *res) {
+  static auto d = parthenon::MakePackDescriptor<gas::prim::density, gas::prim::velocity, gas::prim::pressure, gas::prim::sie>(
+      res, {}, {parthenon::PDOpt::WithFluxes});
+  return d;
+}
+inline auto &GasConsDesc(parthenon::ResolvedPackages *res) {
+  static auto d = parthenon::MakePackDescriptor<gas::cons::density, gas::cons::momentum, gas::cons::total_energy,
+                                                gas::cons::internal_energy>(res, {}, {parthenon::PDOpt::WithFluxes});
+  return d;
+}
+inline auto &DustPrimDesc(parthenon::ResolvedPackages *res) {
+  static auto d = parthenon::MakePackDescriptor<dust::prim::density, dust::prim::velocity>(res);
+  return d;
+}
+inline auto &DustConsDesc(parthenon::ResolvedPackages *res) {
+  static auto d = parthenon::MakePackDescriptor<dust::cons::density, dust::cons::momentum>(res, {}, {parthenon::PDOpt::WithFluxes});
+  return d;
+}
+// address of the first conserved variable of the first block: what a MeshData's data "is" for the cache
+inline const Real *Probe(MeshData<Real> *md) {
+  auto pm = md->GetParentPointer();
+  auto *res = pm->resolved_packages.get();
+  if (pm->packages.Get("artemis")->template Param<bool>("do_gas")) return &GasConsDesc(res).GetPack(md)(0, 0, 0, 0, 0);
+  return &DustConsDesc(res).GetPack(md)(0, 0, 0, 0, 0);
+}
+
+// everything that comes from u0: sizes, parameters, prim / cons0 / flux tables, edge and metric tables
+inline void BuildFromU0(PackCache &c, MeshData<Real> *u0) {
   auto pm = u0->GetParentPointer();
   auto &artemis_pkg = pm->packages.Get("artemis");
   const bool do_gas = artemis_pkg->template Param<bool>("do_gas");
   const bool do_dust = artemis_pkg->template Param<bool>("do_dust");
-  const bool do_diffusion = do_gas && (artemis_pkg->template Param<bool>("do_viscosity") ||
-                                       artemis_pkg->template Param<bool>("do_conduction"));
   const int nb = u0->NumBlocks();
   const auto ib = u0->GetBoundsI(parthenon::IndexDomain::interior);
   const auto jb = u0->GetBoundsJ(parthenon::IndexDomain::interior);
@@ -80,8 +123,6 @@ inline artemis_pack_t &GetPack(PackCache &c, MeshData<Real> *u0, MeshData<Real> 
   p.coords = static_cast<int>(artemis_pkg->template Param<Coordinates>("coords")); // same enum order (artemis.hpp:78-86)
   const int ndim = (p.nx3 > 1) ? 3 : ((p.nx2 > 1) ? 2 : 1);
   auto *res = pm->resolved_packages.get();
-  using parthenon::MakePackDescriptor;
-  using parthenon::PDOpt;
 
   if (do_gas) {
     auto &pkg = pm->packages.Get("gas");
@@ -92,36 +133,22 @@ inline artemis_pack_t &GetPack(PackCache &c, MeshData<Real> *u0, MeshData<Real> 
     p.gas.riemann = static_cast<int>(pkg->template Param<RSolver>("rsolver"));
     p.gas.dfloor = pkg->template Param<Real>("dfloor"), p.gas.siefloor = pkg->template Param<Real>("siefloor");
     p.gas.de_switch = pkg->template Param<Real>("de_switch");
-    // the descriptors Gas::CalculateFluxes builds (gas.cpp:479-488): pack order rho[n], v[ns+3n+d], P[4ns+n], sie[5ns+n]
-    static auto dprim = MakePackDescriptor<gas::prim::density, gas::prim::velocity, gas::prim::pressure, gas::prim::sie>(
-        res, {}, {PDOpt::WithFluxes});
-    static auto dcons = MakePackDescriptor<gas::cons::density, gas::cons::momentum, gas::cons::total_energy,
-                                           gas::cons::internal_energy>(res, {}, {PDOpt::WithFluxes});
-    static auto dface = MakePackDescriptor<gas::face::velocity>(res);
-    auto vprim = dprim.GetPack(u0);
-    auto vcons0 = dcons.GetPack(u0), vcons1 = dcons.GetPack(u1);
+    static auto dface = parthenon::MakePackDescriptor<gas::face::velocity>(res);
+    auto vprim = GasPrimDesc(res).GetPack(u0);
+    auto vcons0 = GasConsDesc(res).GetPack(u0);
     auto vface = dface.GetPack(u0);
     FillTable(c.gprim, vprim, nb, 6 * ns, 0), p.gas.prim = c.gprim.data();
     FillTable(c.gcons0, vcons0, nb, 6 * ns, 0), p.gas.cons0 = c.gcons0.data();
-    FillTable(c.gcons1, vcons1, nb, 6 * ns, 0), p.gas.cons1 = c.gcons1.data();
     for (int d = 0; d < ndim; ++d) {
       FillFluxTable(c.gflux[d], vcons0, nb, 6 * ns, 0, d + 1), p.gas.flux[d] = c.gflux[d].data();
       // interface pressure = the flux slot of gas.prim.pressure (hllc.hpp:166): pack index 4 ns + n
       FillFluxTable(c.gpflux[d], vprim, nb, ns, 4 * ns, d + 1), p.gas.pflux[d] = c.gpflux[d].data();
       FillFaceTable(c.gvface[d], vface, nb, ns, d + 1), p.gas.vface[d] = c.gvface[d].data(); // hllc.hpp:179
     }
-    if (do_diffusion) { // gas::diff::momentum (3 n + component) then gas::diff::energy (3 ns + n), gas.cpp:276-284
-      static auto ddiff = MakePackDescriptor<gas::diff::momentum, gas::diff::energy>(res);
+    if (pkg->template Param<bool>("do_diffusion")) { // gas::diff::momentum (3 n + component) then gas::diff::energy (3 ns + n), gas.cpp:276-284
+      static auto ddiff = parthenon::MakePackDescriptor<gas::diff::momentum, gas::diff::energy>(res);
       auto vdiff = ddiff.GetPack(u0);
-      for (int d = 0; d < ndim; ++d) {
-        c.gdflux[d] = ParArray1D<Real *>("artemis_hip diffusion flux table", nb * 4 * ns);
-        auto t = c.gdflux[d];
-        const TE te = (d == 0) ? TE::F1 : ((d == 1) ? TE::F2 : TE::F3);
-        parthenon::par_for(
-            DEFAULT_LOOP_PATTERN, "ArtemisHip::FillDiffTable", parthenon::DevExecSpace(), 0, nb - 1, 0, 4 * ns - 1,
-            KOKKOS_LAMBDA(const int b, const int n) { t(b * 4 * ns + n) = &vdiff(b, te, n, 0, 0, 0); });
-        p.gas.diff_flux[d] = c.gdflux[d].data();
-      }
+      for (int d = 0; d < ndim; ++d) FillFaceTable(c.gdflux[d], vdiff, nb, 4 * ns, d + 1), p.gas.diff_flux[d] = c.gdflux[d].data();
     }
   }
   if (do_dust) {
@@ -131,49 +158,83 @@ inline artemis_pack_t &GetPack(PackCache &c, MeshData<Real> *u0, MeshData<Real> 
     p.dust.recon = static_cast<int>(pkg->template Param<ReconstructionMethod>("recon"));
     p.dust.riemann = static_cast<int>(pkg->template Param<RSolver>("rsolver"));
     p.dust.dfloor = pkg->template Param<Real>("dfloor");
-    static auto dprim = MakePackDescriptor<dust::prim::density, dust::prim::velocity>(res);            // dust.cpp:287-290
-    static auto dcons = MakePackDescriptor<dust::cons::density, dust::cons::momentum>(res, {}, {PDOpt::WithFluxes});
-    auto vprim = dprim.GetPack(u0);
-    auto vcons0 = dcons.GetPack(u0), vcons1 = dcons.GetPack(u1);
+    auto vprim = DustPrimDesc(res).GetPack(u0);
+    auto vcons0 = DustConsDesc(res).GetPack(u0);
     FillTable(c.dprim, vprim, nb, 4 * ns, 0), p.dust.prim = c.dprim.data();
     FillTable(c.dcons0, vcons0, nb, 4 * ns, 0), p.dust.cons0 = c.dcons0.data();
-    FillTable(c.dcons1, vcons1, nb, 4 * ns, 0), p.dust.cons1 = c.dcons1.data();
     for (int d = 0; d < ndim; ++d) FillFluxTable(c.dflux[d], vcons0, nb, 4 * ns, 0, d + 1), p.dust.flux[d] = c.dflux[d].data();
   }
   if (artemis_pkg->template Param<bool>("do_rotating_frame")) // fluid_fluxes.hpp:433-437
     p.omega_frame = pm->packages.Get("rotating_frame")->template Param<Real>("omega");
 
   // edge table: Coordinates_t::Xf<d>(idx) = xf0 + idx * dx with idx counted from the first ghost zone
-  // (geometry.hpp:65-72); host copy kept for the metric tables
-  std::vector<Real> geom_host(6 * nb);
+  // (geometry.hpp:65-72); host copy kept for the metric / radial tables
+  c.geom_host.assign(6 * nb, 0.0);
   for (int b = 0; b < nb; ++b) {
     const auto &pco = u0->GetBlockData(b)->GetBlockPointer()->coords;
-    geom_host[6 * b + 0] = pco.template Xf<parthenon::X1DIR>(0), geom_host[6 * b + 1] = pco.template Dxf<parthenon::X1DIR>();
-    geom_host[6 * b + 2] = pco.template Xf<parthenon::X2DIR>(0), geom_host[6 * b + 3] = pco.template Dxf<parthenon::X2DIR>();
-    geom_host[6 * b + 4] = pco.template Xf<parthenon::X3DIR>(0), geom_host[6 * b + 5] = pco.template Dxf<parthenon::X3DIR>();
+    c.geom_host[6 * b + 0] = pco.template Xf<parthenon::X1DIR>(0), c.geom_host[6 * b + 1] = pco.template Dxf<parthenon::X1DIR>();
+    c.geom_host[6 * b + 2] = pco.template Xf<parthenon::X2DIR>(0), c.geom_host[6 * b + 3] = pco.template Dxf<parthenon::X2DIR>();
+    c.geom_host[6 * b + 4] = pco.template Xf<parthenon::X3DIR>(0), c.geom_host[6 * b + 5] = pco.template Dxf<parthenon::X3DIR>();
   }
   c.geom = ParArray1D<Real>("artemis_hip geom", 6 * nb);
-  parthenon::deep_copy_from_host(c.geom, geom_host.data(), geom_host.size());
+  parthenon::deep_copy_from_host(c.geom, c.geom_host.data(), c.geom_host.size());
   p.geom = c.geom.data();
   // the trigonometry Coords<GEOM> evaluates per cell (spherical.hpp:53-146, ConvertCoordsToCart of every system):
-  // tabulated once per remesh with the host libm (count is 0 for Cartesian and spherical1D)
+  // tabulated once per (re)mesh with the host libm (count is 0 for Cartesian and spherical1D)
   const long nm = artemis_hip_metric_count(&p);
+  c.metric_host.assign(nm > 0 ? nm : 0, 0.0);
   if (nm > 0) {
-    std::vector<Real> m(nm);
-    PARTHENON_REQUIRE(artemis_hip_metric_fill(&p, geom_host.data(), m.data()) == 0, artemis_hip_last_error());
+    PARTHENON_REQUIRE(artemis_hip_metric_fill(&p, c.geom_host.data(), c.metric_host.data()) == 0, artemis_hip_last_error());
     c.metric = ParArray1D<Real>("artemis_hip metric", nm);
-    parthenon::deep_copy_from_host(c.metric, m.data(), m.size());
+    parthenon::deep_copy_from_host(c.metric, c.metric_host.data(), c.metric_host.size());
     p.metric = c.metric.data();
   }
-  c.built = true;
-  return p;
+  c.nb = nb;
+  c.probe1 = nullptr; // the cons1 tables belong to the previous mesh
+  c.visc_radial_built = false;
+}
+// the u1 register (the start-of-step copy, artemis_driver.cpp:137-139, 157-163): only the cons tables differ
+inline void BuildFromU1(PackCache &c, MeshData<Real> *u1) {
+  auto pm = u1->GetParentPointer();
+  auto *res = pm->resolved_packages.get();
+  const int nb = c.nb;
+  if (c.p.gas.nspecies > 0) {
+    auto v = GasConsDesc(res).GetPack(u1);
+    FillTable(c.gcons1, v, nb, 6 * c.p.gas.nspecies, 0), c.p.gas.cons1 = c.gcons1.data();
+  }
+  if (c.p.dust.nspecies > 0) {
+    auto v = DustConsDesc(res).GetPack(u1);
+    FillTable(c.dcons1, v, nb, 4 * c.p.dust.nspecies, 0), c.p.dust.cons1 = c.dcons1.data();
+  }
 }
 
-// ---- the task bodies (the reference's signatures; artemis_driver.cpp:184-255) -------------------------------------
-inline PackCache &Cache(MeshData<Real> *md) {
-  static std::vector<PackCache> caches(64); // one per partition; clear `built` on remesh
-  return caches[md->GetPartitionId() % 64];
+inline std::map<int, PackCache> &Caches() {
+  static std::map<int, PackCache> caches; // one per MeshData partition
+  return caches;
 }
+// For hosts with a remesh hook; not required (GetPack notices moved data by itself).
+inline void Invalidate() { Caches().clear(); }
+
+// u0 = the MeshData the task receives; u1 = the start-of-step copy for the tasks that read it (ApplyUpdate,
+// DeepCopyConservedData), nullptr otherwise -- the cons1 tables are then left as they are.
+inline PackCache &GetCache(MeshData<Real> *u0, MeshData<Real> *u1 = nullptr) {
+  PackCache &c = Caches()[u0->GetPartitionId()];
+  const Real *p0 = Probe(u0);
+  if (c.nb != u0->NumBlocks() || c.probe0 != p0) {
+    BuildFromU0(c, u0);
+    c.probe0 = p0;
+  }
+  if (u1) {
+    const Real *p1 = Probe(u1);
+    if (c.probe1 != p1) {
+      BuildFromU1(c, u1);
+      c.probe1 = p1;
+    }
+  }
+  return c;
+}
+inline artemis_pack_t &GetPack(MeshData<Real> *u0, MeshData<Real> *u1 = nullptr) { return GetCache(u0, u1).p; }
+
 inline void *Stream() { return nullptr; } // or Kokkos::HIP().hip_stream(): the library shares the process's HIP runtime
 
 #define ARTEMIS_HIP_TASK(call)                                        \
@@ -183,35 +244,314 @@ inline void *Stream() { return nullptr; } // or Kokkos::HIP().hip_stream(): the 
     return TaskStatus::complete;                                      \
   } while (0)
 
+// ---- the task bodies (the reference's signatures; artemis_driver.cpp:157-255) -------------------------------------
+inline TaskStatus DeepCopyConservedData(MeshData<Real> *to, MeshData<Real> *from) { // artemis_integrator.hpp:30-51
+  ARTEMIS_HIP_TASK(artemis_hip_deep_copy_conserved(&GetPack(from, to), Stream()));
+}
 inline TaskStatus GasCalculateFluxes(MeshData<Real> *md, const bool pcm) { // Gas::CalculateFluxes, gas.cpp:473-494
-  ARTEMIS_HIP_TASK(artemis_hip_calculate_fluxes(&GetPack(Cache(md), md, md), ARTEMIS_GAS, pcm, Stream()));
+  ARTEMIS_HIP_TASK(artemis_hip_calculate_fluxes(&GetPack(md), ARTEMIS_GAS, pcm, Stream()));
 }
 inline TaskStatus DustCalculateFluxes(MeshData<Real> *md, const bool pcm) { // Dust::CalculateFluxes, dust.cpp:281-298
-  ARTEMIS_HIP_TASK(artemis_hip_calculate_fluxes(&GetPack(Cache(md), md, md), ARTEMIS_DUST, pcm, Stream()));
+  ARTEMIS_HIP_TASK(artemis_hip_calculate_fluxes(&GetPack(md), ARTEMIS_DUST, pcm, Stream()));
 }
 inline TaskStatus ApplyUpdate(MeshData<Real> *u0, MeshData<Real> *u1, const int stage,
                               const parthenon::LowStorageIntegrator *integ) { // artemis_integrator.hpp:57-110
   const Real g0 = integ->gam0[stage - 1], g1 = integ->gam1[stage - 1], bdt = integ->beta[stage - 1] * integ->dt;
-  ARTEMIS_HIP_TASK(artemis_hip_apply_update(&GetPack(Cache(u0), u0, u1), g0, g1, bdt, Stream()));
+  ARTEMIS_HIP_TASK(artemis_hip_apply_update(&GetPack(u0, u1), g0, g1, bdt, Stream()));
 }
 inline TaskStatus GasFluxSource(MeshData<Real> *md, const Real dt) { // Gas::FluxSource, gas.cpp:499-519
-  ARTEMIS_HIP_TASK(artemis_hip_flux_source(&GetPack(Cache(md), md, md), ARTEMIS_GAS, dt, Stream()));
+  ARTEMIS_HIP_TASK(artemis_hip_flux_source(&GetPack(md), ARTEMIS_GAS, dt, Stream()));
+}
+inline TaskStatus DustFluxSource(MeshData<Real> *md, const Real dt) { // Dust::FluxSource, dust.cpp:303-326
+  ARTEMIS_HIP_TASK(artemis_hip_flux_source(&GetPack(md), ARTEMIS_DUST, dt, Stream()));
 }
 inline TaskStatus SetAuxillaryFields(MeshData<Real> *md) { // fill_derived.cpp:30-75
-  ARTEMIS_HIP_TASK(artemis_hip_set_aux(&GetPack(Cache(md), md, md), Stream()));
+  ARTEMIS_HIP_TASK(artemis_hip_set_aux(&GetPack(md), Stream()));
 }
 inline void ConsToPrim(MeshData<Real> *md) { // PreCommFillDerivedMesh, artemis.cpp:122
-  PARTHENON_REQUIRE(artemis_hip_cons_to_prim(&GetPack(Cache(md), md, md), Stream()) == 0, artemis_hip_last_error());
+  PARTHENON_REQUIRE(artemis_hip_cons_to_prim(&GetPack(md), Stream()) == 0, artemis_hip_last_error());
 }
 inline void PrimToCons(MeshData<Real> *md) { // PreFillDerivedMesh, artemis.cpp:123
-  PARTHENON_REQUIRE(artemis_hip_prim_to_cons(&GetPack(Cache(md), md, md), Stream()) == 0, artemis_hip_last_error());
+  PARTHENON_REQUIRE(artemis_hip_prim_to_cons(&GetPack(md), Stream()) == 0, artemis_hip_last_error());
 }
-inline Real GasEstimateTimestepMesh(MeshData<Real> *md) { // gas.cpp:392-468
+
+// ---- gas diffusion (artemis_driver.cpp:189-193, :218-221) ----------------------------------------------------------
+inline artemis_diffcoeff_t Coeff(const Diffusion::DiffCoeffParams &dp) { // diffusion_coeff.hpp:58-136
+  artemis_diffcoeff_t c;
+  std::memset(&c, 0, sizeof c);
+  c.avg = (dp.avg == Diffusion::DiffAvg::harmonic) ? 1 : 0;
+  switch (dp.type) {
+  case Diffusion::DiffType::viscosity_plaw:
+    c.type = ARTEMIS_VISCOSITY_PLAW, c.coeff = dp.nu_s, c.eta = dp.eta, c.r_exp = dp.r_exp, c.r0 = dp.R0;
+    break;
+  case Diffusion::DiffType::viscosity_alpha:
+    c.type = ARTEMIS_VISCOSITY_ALPHA, c.coeff = dp.alpha, c.eta = dp.eta, c.r0 = dp.R0, c.omega0 = dp.Omega0;
+    break;
+  case Diffusion::DiffType::conductivity_plaw:
+    c.type = ARTEMIS_CONDUCTIVITY_PLAW, c.coeff = dp.hcond_0;
+    c.temp_exp = dp.temp_exp, c.rho_exp = dp.rho_exp, c.rho_ref = dp.d0, c.T_ref = dp.T0;
+    break;
+  case Diffusion::DiffType::thermaldiff_plaw:
+    c.type = ARTEMIS_THERMALDIFF_PLAW, c.coeff = dp.kappa_0;
+    c.temp_exp = dp.temp_exp, c.rho_exp = dp.rho_exp, c.rho_ref = dp.d0, c.T_ref = dp.T0;
+    break;
+  default: c.type = ARTEMIS_DIFF_OFF;
+  }
+  return c;
+}
+// the gas package's diffusion parameters as the library takes them; the radial factor of a viscosity law
+// (std::pow of the cell centre: diffusion_coeff.hpp:222-224, :262-264) is tabulated per block with the host libm
+inline artemis_diffusion_t Diffusion_(PackCache &c, MeshData<Real> *md) {
+  auto pm = md->GetParentPointer();
+  auto &pkg = pm->packages.Get("gas");
+  artemis_diffusion_t d;
+  std::memset(&d, 0, sizeof d);
+  if (pkg->template Param<bool>("do_viscosity")) d.visc = Coeff(pkg->template Param<Diffusion::DiffCoeffParams>("visc_params"));
+  if (pkg->template Param<bool>("do_conduction")) d.cond = Coeff(pkg->template Param<Diffusion::DiffCoeffParams>("cond_params"));
+  d.cv = pkg->template Param<ArtemisUtils::EOS>("eos_h").SpecificHeatFromDensityTemperature(1.0, 1.0);
+  const bool radial = d.visc.type == ARTEMIS_VISCOSITY_ALPHA || (d.visc.type == ARTEMIS_VISCOSITY_PLAW && d.visc.r_exp != 0.0);
+  if (radial) {
+    const artemis_pack_t &p = c.p;
+    const int ndim = (p.nx3 > 1) ? 3 : ((p.nx2 > 1) ? 2 : 1);
+    const long N = static_cast<long>(p.nx1 + 2 * p.nghost) * (ndim > 1 ? p.nx2 + 2 * p.nghost : 1) * (ndim > 2 ? p.nx3 + 2 * p.nghost : 1);
+    if (!c.visc_radial_built) {
+      std::vector<Real> h(static_cast<size_t>(N) * p.nblocks);
+      for (int b = 0; b < p.nblocks; ++b)
+        PARTHENON_REQUIRE(artemis_hip_diffusion_radial_fill(&p, c.geom_host.data(), c.metric_host.empty() ? nullptr : c.metric_host.data(),
+                                                            &d.visc, b, h.data() + static_cast<size_t>(b) * N) == 0,
+                          artemis_hip_last_error());
+      c.visc_radial_data = ParArray1D<Real>("artemis_hip viscosity radial factor", static_cast<int>(h.size()));
+      parthenon::deep_copy_from_host(c.visc_radial_data, h.data(), h.size());
+      c.visc_radial = ParArray1D<const Real *>("artemis_hip viscosity radial table", p.nblocks);
+      auto t = c.visc_radial;
+      const Real *base = c.visc_radial_data.data();
+      parthenon::par_for(
+          DEFAULT_LOOP_PATTERN, "ArtemisHip::FillRadialTable", parthenon::DevExecSpace(), 0, p.nblocks - 1, 0, 0,
+          KOKKOS_LAMBDA(const int b, const int) { t(b) = base + static_cast<size_t>(b) * N; });
+      c.visc_radial_built = true;
+    }
+    d.visc.radial = c.visc_radial.data();
+  }
+  return d;
+}
+inline TaskStatus GasZeroDiffusionFlux(MeshData<Real> *md) { // Gas::ZeroDiffusionFlux, gas.cpp:522-540
+  ARTEMIS_HIP_TASK(artemis_hip_zero_diffusion_flux(&GetPack(md), Stream()));
+}
+inline TaskStatus GasViscousFlux(MeshData<Real> *md) { // Gas::ViscousFlux<GEOM>, gas.cpp:545-575
+  PackCache &c = GetCache(md);
+  const artemis_diffusion_t d = Diffusion_(c, md);
+  ARTEMIS_HIP_TASK(artemis_hip_viscous_flux(&c.p, &d, Stream()));
+}
+inline TaskStatus GasThermalFlux(MeshData<Real> *md) { // Gas::ThermalFlux<GEOM>, gas.cpp:580-610
+  PackCache &c = GetCache(md);
+  const artemis_diffusion_t d = Diffusion_(c, md);
+  ARTEMIS_HIP_TASK(artemis_hip_thermal_flux(&c.p, &d, Stream()));
+}
+inline TaskStatus GasDiffusionUpdate(MeshData<Real> *md, const Real dt) { // Gas::DiffusionUpdate<GEOM>, gas.cpp:615-641
+  PackCache &c = GetCache(md);
+  const artemis_diffusion_t d = Diffusion_(c, md);
+  ARTEMIS_HIP_TASK(artemis_hip_diffusion_update(&c.p, &d, dt, Stream()));
+}
+
+// ---- source tasks between FluxSource and SetAuxillaryFields (artemis_driver.cpp:222-248) ---------------------------
+inline TaskStatus ExternalGravity(MeshData<Real> *md, const Real time, const Real dt) { // gravity/gravity.cpp:126-155
+  auto pm = md->GetParentPointer();
+  auto &pkg = pm->packages.Get("gravity");
+  const auto gtype = pkg->template Param<Gravity::GravityType>("type");
+  artemis_gravity_t g;
+  std::memset(&g, 0, sizeof g);
+  g.tstart = pkg->template Param<Real>("tstart"), g.tstop = pkg->template Param<Real>("tstop");
+  if (gtype == Gravity::GravityType::uniform) {
+    g.type = ARTEMIS_GRAVITY_UNIFORM;
+    g.g[0] = pkg->template Param<Real>("gx1"), g.g[1] = pkg->template Param<Real>("gx2"), g.g[2] = pkg->template Param<Real>("gx3");
+  } else if (gtype == Gravity::GravityType::point) {
+    g.type = ARTEMIS_GRAVITY_POINT;
+    g.gm = pkg->template Param<Real>("gm"), g.soft = pkg->template Param<Real>("soft");
+    g.sink = pkg->template Param<Real>("sink"), g.sink_rate = pkg->template Param<Real>("sink_rate");
+    g.pos[0] = pkg->template Param<Real>("x"), g.pos[1] = pkg->template Param<Real>("y"), g.pos[2] = pkg->template Param<Real>("z");
+  } else if (gtype == Gravity::GravityType::binary) { // binary_mass.cpp:40-70: the orbit is solved on the host per call
+    g.type = ARTEMIS_GRAVITY_BINARY;
+    g.gm = pkg->template Param<Real>("gm"), g.q = pkg->template Param<Real>("q");
+    g.soft = pkg->template Param<Real>("soft1"), g.soft2 = pkg->template Param<Real>("soft2");
+    g.sink = pkg->template Param<Real>("sink1"), g.sink2 = pkg->template Param<Real>("sink2");
+    g.sink_rate = pkg->template Param<Real>("sink_rate1"), g.sink_rate2 = pkg->template Param<Real>("sink_rate2");
+    const Real com[3] = {pkg->template Param<Real>("x"), pkg->template Param<Real>("y"), pkg->template Param<Real>("z")};
+    auto orb = pkg->template Param<Gravity::Orbit>("orb");
+    Real omf = 0.0;
+    if (pm->packages.Get("artemis")->template Param<bool>("do_rotating_frame"))
+      omf = pm->packages.Get("rotating_frame")->template Param<Real>("omega");
+    Real rb[3], vb[3];
+    orb.solve(time, omf, rb, vb);
+    const Real mu1 = 1.0 / (1.0 + g.q), mu2 = g.q / (1.0 + g.q);
+    for (int d = 0; d < 3; ++d) g.pos[d] = com[d] - mu2 * rb[d], g.pos2[d] = com[d] + mu1 * rb[d];
+  } else if (gtype == Gravity::GravityType::nbody) { // gravity.cpp:150-155 -> nbody_gravity.hpp:160-221
+    auto &nb = pm->packages.Get("nbody");
+    if (nb->template Param<int>("npart") <= 0) return TaskStatus::complete;
+    if (!((time >= g.tstart) && (time < g.tstop))) return TaskStatus::complete; // gravity.cpp:134
+    Real omf = 0.0;
+    if (pm->packages.Get("artemis")->template Param<bool>("do_rotating_frame") && nb->template Param<bool>("frame_correction"))
+      omf = pm->packages.Get("rotating_frame")->template Param<Real>("omega");
+    auto particles = nb->template Param<ParArray1D<NBody::Particle>>("particles").GetHostMirrorAndCopy();
+    const int npart = static_cast<int>(particles.size());
+    std::vector<artemis_nbody_particle_t> pl(npart);
+    for (int n = 0; n < npart; ++n) {
+      const NBody::Particle &q = particles(n);
+      artemis_nbody_particle_t &a = pl[n];
+      std::memset(&a, 0, sizeof a);
+      a.gm = q.GM, a.rs = q.rs, a.racc = q.racc, a.gamma = q.gamma, a.beta = q.beta, a.spline = q.spline, a.couple = q.couple;
+      for (int d = 0; d < 3; ++d) a.pos[d] = q.pos[d], a.vel[d] = q.vel[d], a.xf[d] = q.xf[d], a.vf[d] = q.vf[d];
+    }
+    auto pforce = nb->template Param<parthenon::ParArray2D<Real>>("particle_force");
+    auto pforce_h = pforce.GetHostMirrorAndCopy();
+    std::vector<double> f(static_cast<size_t>(7) * npart, 0.0);
+    PARTHENON_REQUIRE(artemis_hip_nbody_gravity(&GetPack(md), pl.data(), npart, omf, time, dt, f.data(), Stream()) == 0,
+                      artemis_hip_last_error());
+    for (int n = 0; n < npart; ++n)
+      for (int i = 0; i < 7; ++i) pforce_h(n, i) += f[static_cast<size_t>(7) * n + i]; // nbody_gravity.hpp:213-215
+    pforce.DeepCopy(pforce_h);
+    return TaskStatus::complete;
+  } else {
+    PARTHENON_FAIL("Unknown gravity node!");
+  }
+  ARTEMIS_HIP_TASK(artemis_hip_external_gravity(&GetPack(md), &g, time, dt, Stream()));
+}
+inline TaskStatus RotatingFrameForce(MeshData<Real> *md, const Real time, const Real dt) { // rotating_frame.cpp:56-86
+  auto &pkg = md->GetParentPointer()->packages.Get("rotating_frame");
+  ARTEMIS_HIP_TASK(artemis_hip_rotating_frame_force(&GetPack(md), pkg->template Param<Real>("omega"),
+                                                    pkg->template Param<Real>("qshear"), time, dt, Stream()));
+}
+inline TaskStatus DragSource(MeshData<Real> *md, const Real time, const Real dt) { // Drag::DragSource<GEOM>, drag.cpp:89-175
+  auto pm = md->GetParentPointer();
+  auto &pkg = pm->packages.Get("drag");
+  PackCache &c = GetCache(md);
+  artemis_drag_t d;
+  std::memset(&d, 0, sizeof d);
+  const auto ctype = pkg->template Param<Drag::Coupling>("type");
+  d.type = (ctype == Drag::Coupling::simple_dust) ? ARTEMIS_DRAG_SIMPLE_DUST : ARTEMIS_DRAG_SELF;
+  auto damping = [](const Drag::SelfDragParams &s) {
+    artemis_damping_t o;
+    for (int i = 0; i < 3; ++i) o.ix[i] = s.ix[i], o.ox[i] = s.ox[i], o.irate[i] = s.irate[i], o.orate[i] = s.orate[i];
+    return o;
+  };
+  const auto gpar = pkg->template Param<Drag::SelfDragParams>("gas_self_drag");
+  d.gas = damping(gpar), d.dust = damping(pkg->template Param<Drag::SelfDragParams>("dust_self_drag"));
+  d.xmin[0] = pkg->template Param<Real>("x1min"), d.xmin[1] = pkg->template Param<Real>("x2min"), d.xmin[2] = pkg->template Param<Real>("x3min");
+  d.xmax[0] = pkg->template Param<Real>("x1max"), d.xmax[1] = pkg->template Param<Real>("x2max"), d.xmax[2] = pkg->template Param<Real>("x3max");
+  d.scale = 1.0, d.grain_density = 1.0;
+  if (ctype == Drag::Coupling::simple_dust) {
+    const auto sp = pkg->template Param<Drag::StoppingTimeParams>("stopping_time_params");
+    auto &dust_pkg = pm->packages.Get("dust");
+    const int nd = dust_pkg->template Param<int>("nspecies");
+    PARTHENON_REQUIRE(nd <= ARTEMIS_MAX_DUST_SPECIES, "too many dust species for artemis_drag_t");
+    d.model = (sp.model == Drag::DragModel::stokes) ? ARTEMIS_DRAG_STOKES : ARTEMIS_DRAG_CONSTANT;
+    d.scale = sp.scale;
+    auto tau_h = sp.tau.GetHostMirrorAndCopy(); // already scaled for the constant model (drag.hpp:129-137)
+    for (int n = 0; n < nd; ++n) d.tau[n] = tau_h(n);
+    if (sp.model == Drag::DragModel::stokes) { // drag.hpp:407-409
+      d.grain_density = dust_pkg->template Param<Real>("grain_density");
+      auto sizes = dust_pkg->template Param<ParArray1D<Real>>("h_sizes");
+      for (int n = 0; n < nd; ++n) d.sizes[n] = sizes(n);
+    }
+  }
+  artemis_diffusion_t diff; // <gas/damping> damp_to_visc: the gas package's viscosity (drag.cpp:109-121)
+  if (gpar.damp_to_visc) {
+    diff = Diffusion_(c, md);
+    PARTHENON_REQUIRE(diff.visc.type == ARTEMIS_VISCOSITY_PLAW || diff.visc.type == ARTEMIS_VISCOSITY_ALPHA,
+                      "The chosen viscosity model does not work with damping");
+    d.damp_visc = &diff.visc;
+  }
+  ARTEMIS_HIP_TASK(artemis_hip_drag_source(&c.p, &d, time, dt, Stream()));
+}
+
+// ---- time step (StateDescriptor::EstimateTimestepMesh of the gas and dust packages) --------------------------------
+inline Real GasEstimateTimestepMesh(MeshData<Real> *md) { // gas.cpp:392-468 (incl. the diffusive limits, :435-467)
+  auto &pkg = md->GetParentPointer()->packages.Get("gas");
+  const Real cfl = pkg->template Param<Real>("cfl");
+  PackCache &c = GetCache(md);
+  if (pkg->template Param<bool>("do_diffusion")) { // min(hydro, viscous, conductive) on one device scalar
+    const artemis_diffusion_t d = Diffusion_(c, md);
+    ParArray1D<Real> dt_dev("artemis_hip dt", 1);
+    const Real big = std::numeric_limits<Real>::max();
+    parthenon::deep_copy_from_host(dt_dev, &big, 1);
+    PARTHENON_REQUIRE(artemis_hip_estimate_dt_async(&c.p, ARTEMIS_GAS, cfl, dt_dev.data(), Stream()) == 0, artemis_hip_last_error());
+    PARTHENON_REQUIRE(artemis_hip_diffusion_dt(&c.p, &d, cfl, dt_dev.data(), Stream()) == 0, artemis_hip_last_error());
+    return dt_dev.GetHostMirrorAndCopy()(0); // (deep_copy fences the stream)
+  }
   double dt = 0.0;
-  const Real cfl = md->GetParentPointer()->packages.Get("gas")->template Param<Real>("cfl");
-  PARTHENON_REQUIRE(artemis_hip_estimate_dt(&GetPack(Cache(md), md, md), ARTEMIS_GAS, cfl, &dt, Stream()) == 0,
-                    artemis_hip_last_error());
+  PARTHENON_REQUIRE(artemis_hip_estimate_dt(&c.p, ARTEMIS_GAS, cfl, &dt, Stream()) == 0, artemis_hip_last_error());
   return dt;
+}
+inline Real DustEstimateTimestepMesh(MeshData<Real> *md) { // dust.cpp:239-276
+  const Real cfl = md->GetParentPointer()->packages.Get("dust")->template Param<Real>("cfl");
+  double dt = 0.0;
+  PARTHENON_REQUIRE(artemis_hip_estimate_dt(&GetPack(md), ARTEMIS_DUST, cfl, &dt, Stream()) == 0, artemis_hip_last_error());
+  return dt;
+}
+
+// ---- opt-in fast path ------------------------------------------------------------------------------------------------
+// One launch for CalculateFluxes .. ConsToPrim of a stage (artemis_driver.cpp:184-255 with every optional package
+// off: gas, one species, Cartesian, PCM / PLM).  A host that takes it replaces the tasks from Gas::CalculateFluxes
+// to PreCommFillDerived by this one and FillDerived (artemis_driver.cpp:261) by StageFusedFillDerived: `cons` of u0 is
+// current after every stage exactly as with the task chain (the kernel stores the conserved state of the zones it
+// updates; only the ghost zones are converted after the boundary exchange).  The kernel reads the primitives at the
+// start of the stage AND at the start of the step (it rebuilds u1 from them; the primitives are OneCopy in Artemis,
+// gas.cpp:244-270, so the u1 MeshData does not hold them) and must not write where it reads: the adapter keeps two
+// primitive buffers of its own per partition -- the start-of-step snapshot and the stage's output, copied back into
+// u0's arrays.  (A host that can swap the variables' data pointers instead saves the copies; the repository's own
+// driver ping-pongs three buffers.)
+template <typename TA, typename TB>
+inline void CopyArrays(const TA &dst, const TB &src, const int nentries, const long N) {
+  parthenon::par_for(
+      DEFAULT_LOOP_PATTERN, "ArtemisHip::CopyArrays", parthenon::DevExecSpace(), 0, nentries - 1, 0, 0,
+      KOKKOS_LAMBDA(const int e, const int) {
+        Real *d = dst(e);
+        const Real *q = src(e);
+        for (long n = 0; n < N; ++n) d[n] = q[n];
+      });
+}
+struct StageBuffers {
+  ParArray1D<Real> step_data, new_data;
+  ParArray1D<Real *> step, out;
+  const Real *probe = nullptr;
+};
+inline std::map<int, StageBuffers> &StageBufferCache() {
+  static std::map<int, StageBuffers> m;
+  return m;
+}
+inline TaskStatus StageFused(MeshData<Real> *u0, const int stage, const parthenon::LowStorageIntegrator *integ, const bool pcm) {
+  PackCache &c = GetCache(u0);
+  const artemis_pack_t &p = c.p;
+  const int ndim = (p.nx3 > 1) ? 3 : ((p.nx2 > 1) ? 2 : 1);
+  const long N = static_cast<long>(p.nx1 + 2 * p.nghost) * (ndim > 1 ? p.nx2 + 2 * p.nghost : 1) * (ndim > 2 ? p.nx3 + 2 * p.nghost : 1);
+  const int nent = p.nblocks * 6 * p.gas.nspecies;
+  StageBuffers &sb = StageBufferCache()[u0->GetPartitionId()];
+  if (sb.probe != c.probe0 || sb.step.size() != nent) {
+    sb.step_data = ParArray1D<Real>("artemis_hip start-of-step primitives", static_cast<int>(nent * N));
+    sb.new_data = ParArray1D<Real>("artemis_hip stage output primitives", static_cast<int>(nent * N));
+    sb.step = ParArray1D<Real *>("artemis_hip table", nent), sb.out = ParArray1D<Real *>("artemis_hip table", nent);
+    auto ts = sb.step, to = sb.out;
+    Real *bs = sb.step_data.data(), *bo = sb.new_data.data();
+    parthenon::par_for(
+        DEFAULT_LOOP_PATTERN, "ArtemisHip::FillStageTables", parthenon::DevExecSpace(), 0, nent - 1, 0, 0,
+        KOKKOS_LAMBDA(const int e, const int) { ts(e) = bs + e * N, to(e) = bo + e * N; });
+    sb.probe = c.probe0;
+  }
+  if (stage == 1) CopyArrays(sb.step, c.gprim, nent, N); // the primitives at the start of the step
+  CopyArrays(sb.out, c.gprim, nent, N);                  // (valid ghost zones in the output buffer)
+  artemis_stage_args_t a;
+  std::memset(&a, 0, sizeof a);
+  a.gam0 = integ->gam0[stage - 1], a.gam1 = integ->gam1[stage - 1];
+  a.beta_dt = a.bdt = integ->beta[stage - 1] * integ->dt;
+  a.pcm = pcm;
+  a.prim_in = p.gas.prim, a.prim_u1 = (stage == 1) ? p.gas.prim : sb.step.data(), a.prim_out = sb.out.data();
+  a.cons_out = p.gas.cons0;
+  const int rc = artemis_hip_stage_fused(&p, &a, Stream());
+  PARTHENON_REQUIRE(rc == 0, artemis_hip_last_error());
+  CopyArrays(c.gprim, sb.out, nent, N);
+  return TaskStatus::complete;
+}
+inline void StageFusedFillDerived(MeshData<Real> *md) {
+  PARTHENON_REQUIRE(artemis_hip_prim_to_cons_ghosts(&GetPack(md), Stream()) == 0, artemis_hip_last_error());
 }
 #undef ARTEMIS_HIP_TASK
 

@@ -86,6 +86,13 @@ int bad(const char *m) {
   d_err = m;
   return ARTEMIS_HIP_EINVAL;
 }
+// abi.hip validate_registers: the same contract on the host
+int need_registers(const artemis_pack_t *p, const char *task) {
+  for (const artemis_fluid_pack_t *f : {&p->gas, &p->dust})
+    if (f->nspecies > 0 && (!f->cons0 || !f->cons1))
+      return bad((std::string(task) + " needs the cons0 (u0) and cons1 (u1) tables of every fluid in the pack").c_str());
+  return 0;
+}
 } // namespace
 
 extern "C" {
@@ -111,6 +118,7 @@ int artemis_hip_calculate_fluxes(const artemis_pack_t *p, int fluid, int pcm, vo
   return 0;
 }
 int artemis_hip_apply_update(const artemis_pack_t *p, double g0, double g1, double bdt, void *) {
+  if (int rc = need_registers(p, "ApplyUpdate")) return rc;
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);
     B.load_state(), B.load_fluxes();
@@ -216,6 +224,7 @@ int artemis_hip_prim_to_cons(const artemis_pack_t *p, void *) {
   return 0;
 }
 int artemis_hip_deep_copy_conserved(const artemis_pack_t *p, void *) {
+  if (int rc = need_registers(p, "DeepCopyConservedData")) return rc;
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);
     B.load_state();
