@@ -2223,11 +2223,12 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
                  total(old, 4 * ns_gas), total(*this, 4 * ns_gas), total(old, 0), total(*this, 0));
   }
   const artemis_pack_t p = make_pack(0);
-  // ConsToPrim takes the specific internal energy from the internal-energy variable, which is prolongated /
-  // restricted independently of the total energy; SetAuxillaryFields first re-derives it from the (conserved)
-  // total energy exactly as every stage does before its ConsToPrim (artemis_driver.cpp:251-252), so that a remesh
-  // conserves the total energy to round-off instead of to O(dx^2) of the kinetic energy.
-  if (do_gas) CK(artemis_hip_set_aux(&p, stream), "SetAuxillaryFields");
+  // What Mesh::Initialize does for a modified mesh (upstream): PreCommFillDerived = ConsToPrim, the boundary
+  // exchange, FillDerived = PrimToCons (artemis.cpp:122-123).  SetAuxillaryFields is a task of the stage list, not a
+  // package callback, and is NOT called here (fill_derived.cpp:28 says so): ConsToPrim takes the specific internal
+  // energy from the internal-energy variable as it was prolongated / restricted, and PrimToCons rebuilds the total
+  // energy from it -- a remesh therefore conserves mass and momentum to round-off and the total energy to the
+  // O(dx^2) difference between the two energy variables, exactly as the reference.
   CK(artemis_hip_cons_to_prim(&p, stream), "ConsToPrim");
   fill_ghosts(0);
   CK(artemis_hip_prim_to_cons(&p, stream), "PrimToCons");
@@ -2792,13 +2793,31 @@ static bool next_leaves(artemis_sim &h, const std::vector<int> &tags, bool allow
   t.ndim = S.ndim;
   for (int d = 0; d < 3; ++d) t.nrb[d] = S.nblk[d], t.periodic[d] = (d < S.ndim) && S.mesh_bc[2 * d] == ARTEMIS_BC_PERIODIC;
   const int nch = 1 << S.ndim;
-  auto merge_ok = [&](const artemis_host::Leaf &l) { // all siblings are leaves that have waited long enough
+  // the tree the step ran on: a leaf with a FINER neighbour (face, edge or corner) is not flagged for derefinement
+  // this cycle, however long it has asked (upstream MeshRefinement::SetRefinement: the `nblevel > level` count) --
+  // so a block loses at most one level per remesh and a coarse-fine-finer staircase unwinds from the top
+  artemis_host::BlockTree told;
+  told.ndim = S.ndim;
+  for (int d = 0; d < 3; ++d) told.nrb[d] = t.nrb[d], told.periodic[d] = t.periodic[d];
+  for (const artemis_host::Leaf &l : old) told.ensure(l.level, l.lx);
+  auto finer_neighbour = [&](int level, const artemis_host::Loc &lx) {
+    for (int o3 = (S.ndim > 2 ? -1 : 0); o3 <= (S.ndim > 2 ? 1 : 0); ++o3)
+      for (int o2 = (S.ndim > 1 ? -1 : 0); o2 <= (S.ndim > 1 ? 1 : 0); ++o2)
+        for (int o1 = -1; o1 <= 1; ++o1) {
+          if (!o1 && !o2 && !o3) continue;
+          artemis_host::Loc n = {lx[0] + o1, lx[1] + o2, lx[2] + o3};
+          if (told.wrap(level, n) && told.is_internal(level, n)) return true;
+        }
+    return false;
+  };
+  auto merge_ok = [&](const artemis_host::Leaf &l) { // all siblings are leaves flagged for derefinement this cycle
     if (!allow_derefine || l.level == 0) return false;
     artemis_host::Loc par = t.parent(l.lx);
     for (int c = 0; c < nch; ++c) {
       artemis_host::Loc sib = {2 * par[0] + (c & 1), S.ndim > 1 ? 2 * par[1] + ((c >> 1) & 1) : 0, S.ndim > 2 ? 2 * par[2] + ((c >> 2) & 1) : 0};
       auto it = h.deref_count.find(Key(l.level, sib[0], sib[1], sib[2]));
       if (it == h.deref_count.end() || it->second < S.derefine_count) return false;
+      if (finer_neighbour(l.level, sib)) return false;
     }
     return true;
   };
@@ -2876,9 +2895,10 @@ artemis_sim_t *artemis_sim_create(const char *deck_text, int noverrides,
       s->has_comm = true;
     }
     s->p = build_state(*s, nullptr);
-    // Mesh::Initialize's refinement loop (upstream): tag the initial condition, refine, regenerate -- until the
-    // criterion is satisfied or numlevel is reached
-    for (int pass = 0; s->p->adaptive && pass <= s->p->amr_max_level; ++pass)
+    // Mesh::Initialize's refinement loop (upstream): tag the initial condition, refine, regenerate -- until the mesh
+    // stops changing (blocks that 2:1 balance created are tagged one pass later than the ones tags created, so this
+    // can take more than numlevel passes; the cap only guards against a criterion that never settles)
+    for (int pass = 0; s->p->adaptive && pass < 8 * (s->p->amr_max_level + 2); ++pass)
       if (!remesh(*s, true)) break;
   };
   GUARD(build(), {

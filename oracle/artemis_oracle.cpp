@@ -3084,6 +3084,9 @@ void oracle_set_gravity_nbody(void *h, int npart, const double *par, int frame_c
   s.nbody_frame_correction = frame_correction != 0;
   s.pforce.assign(static_cast<size_t>(7) * npart, 0.0);
 }
+// gm of the gravity package when it is not the plain sum of the particles' GM: nbody.cpp:109 registers G * mtot with mtot
+// = <nbody> mtot or the sum of the deck's masses BEFORE the rescale of nbody_setup.cpp:707 (which can move the sum by an ulp)
+void oracle_set_gravity_gm(void *h, double gm) { static_cast<Sim *>(h)->grav.gm = gm; }
 // the accumulated particle_force rows (nbody_gravity.hpp:210-212); `reset` zeroes them like NBody::Advance does
 void oracle_nbody_force(void *h, double *out, int reset) {
   Sim &s = *static_cast<Sim *>(h);
@@ -3101,11 +3104,21 @@ void oracle_set_gravity_window(void *h, double tstart, double tstop) {
 // r = {cis, cie, cjs, cje, cks, cke,  cib, cjb, ckb,  fib, fjb, fkb}: coarse cells processed and the
 // coarse <-> fine origin (the reference's cib.s <-> ib.s).  SIGN(a) = (a < 0) ? -1 : 1 (parthenon
 // defs.hpp, upstream, recalled).  Parity unpinned: no reference test isolates these operators.
-void oracle_restrict_average(void *hf, void *hc, const int *r) {
+// `field` selects the cell-centred arrays the operator acts on (the reference registers the same operators for every
+// field, utils/artemis_utils.cpp:92-112): 0 gas primitives, 1 gas conserved u0, 2 dust primitives, 3 dust conserved u0
+static RVec &refine_field(Sim &s, int field, int *nvar) {
+  *nvar = (field < 2) ? s.nvg : s.nvd;
+  return field == 0 ? s.gprim : (field == 1 ? s.gu0 : (field == 2 ? s.dprim : s.du0));
+}
+void oracle_restrict_average_field(void *hf, void *hc, const int *r, int field);
+void oracle_restrict_average(void *hf, void *hc, const int *r) { oracle_restrict_average_field(hf, hc, r, 0); }
+void oracle_restrict_average_field(void *hf, void *hc, const int *r, int field) {
   Sim &f = *static_cast<Sim *>(hf), &c = *static_cast<Sim *>(hc);
   const int DIM = f.ndim;
   const bool X1 = DIM > 0, X2 = DIM > 1, X3 = DIM > 2;
-  for (int v = 0; v < f.nvg; ++v)
+  int nvar = 0;
+  RVec &fq = refine_field(f, field, &nvar), &cq = refine_field(c, field, &nvar);
+  for (int v = 0; v < nvar; ++v)
     for (int ck = r[4]; ck <= r[5]; ++ck)
       for (int cj = r[2]; cj <= r[3]; ++cj)
         for (int ci = r[0]; ci <= r[1]; ++ci) {
@@ -3120,28 +3133,24 @@ void oracle_restrict_average(void *hf, void *hc, const int *r) {
             for (int oj = 0; oj < 1 + X2; ++oj)
               for (int oi = 0; oi < 1 + X1; ++oi) {
                 vol[ok][oj][oi] = Coords(f, k + ok, j + oj, i + oi).Volume();
-                terms[ok][oj][oi] = vol[ok][oj][oi] * f.gprim[v * f.N + IDX(f, k + ok, j + oj, i + oi)];
+                terms[ok][oj][oi] = vol[ok][oj][oi] * fq[v * f.N + IDX(f, k + ok, j + oj, i + oi)];
               }
           const Real tvol = ((vol[0][0][0] + vol[0][1][0]) + (vol[0][0][1] + vol[0][1][1])) +
                             ((vol[1][0][0] + vol[1][1][0]) + (vol[1][0][1] + vol[1][1][1]));
-          c.gprim[v * c.N + IDX(c, ck, cj, ci)] =
+          cq[v * c.N + IDX(c, ck, cj, ci)] =
               (((terms[0][0][0] + terms[0][1][0]) + (terms[0][0][1] + terms[0][1][1])) +
                ((terms[1][0][0] + terms[1][1][0]) + (terms[1][0][1] + terms[1][1][1]))) /
               tvol;
         }
 }
 // Refinement criteria (utils/refinement/amr_criteria.hpp:28-168) on component `var` of the gas primitives
-// (or, var < 0, on the gas pressure of species 0): the block maximum and the AmrTag (-1 derefine, 0 same,
+// (or, var < 0, on the stored gas pressure of species 0): the block maximum and the AmrTag (-1 derefine, 0 same,
 // +1 refine).  Parity unpinned: no reference test isolates the criteria.
 int oracle_amr_first_derivative(void *h, int var, double thr, double *maxeps_out) {
   Sim &s = *static_cast<Sim *>(h);
-  std::vector<Real> pres;
-  const Real *q = s.gprim.data() + (var < 0 ? 0 : var) * s.N;
-  if (var < 0) {
-    pres.resize(s.N);
-    for (size_t n = 0; n < s.N; ++n) pres[n] = (s.c.gamma - 1.0) * s.gprim[n] * s.gprim[4 * s.N + n];
-    q = pres.data();
-  }
+  // FIELD = gas::prim::pressure reads the STORED pressure of species 0 (amr_criteria.hpp:45-46: a pack of FIELD),
+  // pack slot 4 ns_gas -- what FillDerived left there (fill_derived.cpp:246-262), ghost zones included
+  const Real *q = s.gprim.data() + (var < 0 ? 4 * s.c.ns_gas : var) * s.N;
   *maxeps_out = 0.0;
   if (s.ndim == 1) return 0; // :122-124
   const bool X3 = s.ndim == 3;
@@ -3180,7 +3189,7 @@ int oracle_amr_magnitude(void *h, int var, double refine_above, double deref_bel
     for (int j = s.js; j <= s.je; ++j)
       for (int i = s.is; i <= s.ie; ++i) {
         const long n = IDX(s, k, j, i);
-        const Real q = var < 0 ? (s.c.gamma - 1.0) * s.gprim[n] * s.gprim[4 * s.N + n] : s.gprim[var * s.N + n];
+        const Real q = var < 0 ? s.gprim[(4 * s.c.ns_gas) * s.N + n] : s.gprim[var * s.N + n];
         maxvv = std::max(maxvv, q);
       }
   *max_out = maxvv;
@@ -3188,20 +3197,24 @@ int oracle_amr_magnitude(void *h, int var, double refine_above, double deref_bel
   if (maxvv < deref_below) return -1;
   return 0;
 }
-void oracle_prolongate_minmod(void *hf, void *hc, const int *r) {
+void oracle_prolongate_minmod_field(void *hf, void *hc, const int *r, int field);
+void oracle_prolongate_minmod(void *hf, void *hc, const int *r) { oracle_prolongate_minmod_field(hf, hc, r, 0); }
+void oracle_prolongate_minmod_field(void *hf, void *hc, const int *r, int field) {
   Sim &f = *static_cast<Sim *>(hf), &c = *static_cast<Sim *>(hc);
   const int DIM = f.ndim;
   const bool X1 = DIM > 0, X2 = DIM > 1, X3 = DIM > 2;
+  int nvar = 0;
+  RVec &fq = refine_field(f, field, &nvar), &cq = refine_field(c, field, &nvar);
   auto sign = [](Real a) { return (a < 0.) ? -1. : 1.; };
   auto centre = [](const Coords &co, int d) { return d == 1 ? co.x1v() : (d == 2 ? co.x2v() : co.x3v()); };
-  for (int v = 0; v < f.nvg; ++v)
+  for (int v = 0; v < nvar; ++v)
     for (int k = r[4]; k <= r[5]; ++k)
       for (int j = r[2]; j <= r[3]; ++j)
         for (int i = r[0]; i <= r[1]; ++i) {
           const int fi = X1 ? (i - r[6]) * 2 + r[9] : r[9];
           const int fj = X2 ? (j - r[7]) * 2 + r[10] : r[10];
           const int fk = X3 ? (k - r[8]) * 2 + r[11] : r[11];
-          const Real *q = c.gprim.data() + v * c.N;
+          const Real *q = cq.data() + v * c.N;
           const Real fc = q[IDX(c, k, j, i)];
           Real dxfm[3] = {0, 0, 0}, dxfp[3] = {0, 0, 0}, g[3] = {0, 0, 0};
           for (int d = 1; d <= DIM; ++d) { // GetGridSpacings<GEOM, d> + GradMinMod
@@ -3217,7 +3230,7 @@ void oracle_prolongate_minmod(void *hf, void *hc, const int *r) {
           }
           const Real gx1m = g[0], gx1p = g[0], gx2m = g[1], gx2p = g[1], gx3m = g[2], gx3p = g[2];
           const Real dx1fm = dxfm[0], dx1fp = dxfp[0], dx2fm = dxfm[1], dx2fp = dxfp[1], dx3fm = dxfm[2], dx3fp = dxfp[2];
-          Real *o = f.gprim.data() + v * f.N;
+          Real *o = fq.data() + v * f.N;
           o[IDX(f, fk, fj, fi)] = fc - (gx1m * dx1fm + gx2m * dx2fm + gx3m * dx3fm);
           if (X1) o[IDX(f, fk, fj, fi + 1)] = fc + (gx1p * dx1fp - gx2m * dx2fm - gx3m * dx3fm);
           if (X2) o[IDX(f, fk, fj + 1, fi)] = fc - (gx1m * dx1fm - gx2p * dx2fp + gx3m * dx3fm);

@@ -153,36 +153,48 @@ class MultiLevelOracle:
         nrb = tuple(mesh_nx[d] // block_nx[d] for d in range(3))
         periodic = tuple(bc[2 * d] == "periodic" for d in range(3))
         self.tree = BlockTree(nrb, self.ndim, periodic)
+        self.regions = list(regions)
         for level, r1, r2, r3 in regions:
             self.tree.add_region(level, (r1[0], r2[0], r3[0]), (r1[1], r2[1], r3[1]), xmin, xmax)
+        self.kw = dict(kw, ng=ng, integrator=integrator)
+        self.time, self.dt, self.ncycle = 0.0, None, 0
+        self._build_blocks()
+
+    def make_block(self, level, loc):
+        """(fine block oracle, its coarse-buffer oracle) of the leaf at a logical location."""
+        xmin, xmax, bc = self.xmin, self.xmax, self.bc
+        periodic = self.tree.periodic
+        lo, hi, bcs = [], [], []
+        ext = self.tree.extent(level)
+        for d in range(3):
+            n = ext[d]
+            edge = lambda l: (xmin[d] if l == 0 else xmax[d] if l == n else
+                              xmin[d] * (1.0 - l / n) + xmax[d] * (l / n))
+            lo.append(edge(loc[d])), hi.append(edge(loc[d] + 1))
+            for side in (0, 1):
+                outside = (loc[d] == 0) if side == 0 else (loc[d] + 1 == n)
+                if d >= self.ndim:
+                    bcs.append("outflow")
+                elif outside and not periodic[d]:
+                    bcs.append(bc[2 * d + side])
+                else:
+                    bcs.append("none")
+        o = Oracle(self.nx, lo, hi, bc=bcs, mesh_bounds=sum(([xmin[d], xmax[d]] for d in range(3)), []), **self.kw)
+        cnx = tuple(n // 2 if n > 1 else 1 for n in self.nx)
+        return o, Oracle(cnx, lo, hi, bc=bcs, **self.kw)
+
+    def _build_blocks(self, keep=None):
+        """One oracle (+ coarse buffer) per leaf of self.tree; `keep` maps leaves to existing (block, coarse) pairs
+        that are reused (an adaptive mesh keeps the blocks that do not change)."""
         self.leaves = self.tree.leaves()
         self.index = {lf: b for b, lf in enumerate(self.leaves)}
         self.blocks, self.coarse = [], []
-        self.kw = dict(kw, ng=ng, integrator=integrator)
-        for level, loc in self.leaves:
-            lo, hi, bcs = [], [], []
-            ext = self.tree.extent(level)
-            for d in range(3):
-                n = ext[d]
-                edge = lambda l: (xmin[d] if l == 0 else xmax[d] if l == n else
-                                  xmin[d] * (1.0 - l / n) + xmax[d] * (l / n))
-                lo.append(edge(loc[d])), hi.append(edge(loc[d] + 1))
-                for side in (0, 1):
-                    outside = (loc[d] == 0) if side == 0 else (loc[d] + 1 == n)
-                    if d >= self.ndim:
-                        bcs.append("outflow")
-                    elif outside and not periodic[d]:
-                        bcs.append(bc[2 * d + side])
-                    else:
-                        bcs.append("none")
-            o = Oracle(self.nx, lo, hi, bc=bcs, mesh_bounds=sum(([xmin[d], xmax[d]] for d in range(3)), []), **self.kw)
-            self.blocks.append(o)
-            cnx = tuple(n // 2 if n > 1 else 1 for n in self.nx)
-            self.coarse.append(Oracle(cnx, lo, hi, bc=bcs, **self.kw))
-        o = self.blocks[0]
-        ns = o.cfg.ns_gas
+        for lf in self.leaves:
+            o, c = keep[lf] if keep and lf in keep else self.make_block(*lf)
+            self.blocks.append(o), self.coarse.append(c)
+        ns = self.blocks[0].cfg.ns_gas
         self.fill = [v for v in range(6 * ns) if not (4 * ns <= v < 5 * ns)]  # pressure is not FillGhost
-        self.time, self.dt, self.ncycle = 0.0, None, 0
+        self.has_dust = self.blocks[0].cfg.ns_dust > 0
         self._classify()
 
     # ---- geometry of the exchange ------------------------------------------------------------------
@@ -224,8 +236,26 @@ class MultiLevelOracle:
         return (slice(None),) + tuple(slice(box[d][0] + shift[d], box[d][1] + shift[d]) for d in (2, 1, 0))
 
     def _assign(self, dst, box, src, shift=(0, 0, 0)):
+        """FillGhost variables of oracle `src` -> oracle `dst`: gas rho, v, sie (gas.cpp:244-270) and every dust
+        primitive (dust.cpp:201-213)."""
+        a, b = self._sl(box)[1:], self._sl(box, shift)[1:]
+        dg, sg = dst.gprim, src.gprim
         for v in self.fill:
-            dst[v][self._sl(box)[1:]] = src[v][self._sl(box, shift)[1:]]
+            dg[v][a] = sg[v][b]
+        if self.has_dust:
+            dd, sd = dst.dprim, src.dprim
+            for v in range(dd.shape[0]):
+                dd[v][a] = sd[v][b]
+
+    def _restrict(self, fine, coarse, crange, S):
+        fine.RestrictAverage(coarse, crange, S, S)
+        if self.has_dust:
+            fine.RestrictAverage(coarse, crange, S, S, field="dust.prim")
+
+    def _prolongate(self, fine, coarse, crange, S):
+        fine.ProlongateSharedMinMod(coarse, crange, S, S)
+        if self.has_dust:
+            fine.ProlongateSharedMinMod(coarse, crange, S, S, field="dust.prim")
 
     def fill_ghosts(self):
         """Boundary exchange of the FillGhost primitives + physical conditions (module docstring)."""
@@ -236,13 +266,13 @@ class MultiLevelOracle:
         span = lambda lo, n: tuple(v for d in range(3) for v in (lo[d], lo[d] + n[d] - 1))
         # 1. every block restricts its interior into its own coarse buffer
         for o, c in zip(self.blocks, self.coarse):
-            o.RestrictAverage(c, span(S, cnx), S, S)
+            self._restrict(o, c, span(S, cnx), S)
         # 2. transfers; every source is an interior (fine array or coarse buffer) prepared above
         for b, (level, loc) in enumerate(self.leaves):
-            me, mec = self.blocks[b].gprim, self.coarse[b].gprim
+            me, mec = self.blocks[b], self.coarse[b]
             for o, (kind, who, what) in self.nbr[b].items():
                 if kind == "same":
-                    self._assign(me, self._ghost_box(o, ng, nx), self.blocks[who].gprim,
+                    self._assign(me, self._ghost_box(o, ng, nx), self.blocks[who],
                                  tuple(-o[d] * nx[d] for d in range(3)))
                 elif kind == "finer":
                     for cb, cl, c in who:
@@ -254,14 +284,14 @@ class MultiLevelOracle:
                                 box[d] = (h0, h0 + cnx[d])
                             # child's coarse-buffer index of my zone i: -o nx + (i - s) - c nx/2 + s
                             shift.append(-o[d] * nx[d] - c[d] * cnx[d] if d < self.ndim else 0)
-                        self._assign(me, box, self.coarse[cb].gprim, shift)
+                        self._assign(me, box, self.coarse[cb], shift)
                 elif kind == "coarser":
                     n_wrapped = t.wrap(level, tuple(loc[d] + o[d] for d in range(3)))
                     shift = []
                     for d in range(3):
                         rel = n_wrapped[d] - o[d]  # my location relative to the (wrapped) neighbour
                         shift.append(rel * cnx[d] - what[d] * nx[d] if d < self.ndim else 0)
-                    self._assign(mec, self._ghost_box(o, cng, cnx), self.blocks[who].gprim, shift)
+                    self._assign(mec, self._ghost_box(o, cng, cnx), self.blocks[who], shift)
         # 3.-5. blocks with a coarser neighbour: restrict the ghost halos that hold fine data, physical
         # conditions on the coarse buffer, prolongate into the zones facing coarser neighbours
         for b in range(len(self.leaves)):
@@ -272,12 +302,12 @@ class MultiLevelOracle:
             for o, (kind, _, _) in kinds.items():
                 if kind in ("same", "finer"):
                     box = self._ghost_box(o, ng // 2, cnx)
-                    o_.RestrictAverage(c_, tuple(v for d in range(3) for v in (box[d][0], box[d][1] - 1)), S, S)
+                    self._restrict(o_, c_, tuple(v for d in range(3) for v in (box[d][0], box[d][1] - 1)), S)
             c_.ApplyBoundaryConditions()
             for o, (kind, _, _) in kinds.items():
                 if kind == "coarser":
                     box = self._ghost_box(o, ng // 2, cnx)
-                    o_.ProlongateSharedMinMod(c_, tuple(v for d in range(3) for v in (box[d][0], box[d][1] - 1)), S, S)
+                    self._prolongate(o_, c_, tuple(v for d in range(3) for v in (box[d][0], box[d][1] - 1)), S)
         # 6. physical conditions on the fine arrays
         for o in self.blocks:
             o.ApplyBoundaryConditions()

@@ -113,6 +113,7 @@ def lib():
         L.oracle_set_gravity_binary.argtypes = [vp, C.POINTER(d)]
         L.oracle_set_gravity_window.argtypes = [vp, d, d]
         L.oracle_set_gravity_nbody.argtypes = [vp, i, C.POINTER(d), i]
+        L.oracle_set_gravity_gm.argtypes = [vp, d]
         L.oracle_nbody_force.argtypes = [vp, C.POINTER(d), i]
         L.oracle_set_rotating_frame.argtypes = [vp, d, d]
         L.oracle_set_drag.argtypes = [vp, i, i, d, d, C.POINTER(d), C.POINTER(d)]
@@ -132,6 +133,8 @@ def lib():
         L.oracle_pgen_conduction.argtypes = [vp] + [d] * 6
         L.oracle_restrict_average.argtypes = [vp, vp, C.POINTER(i)]
         L.oracle_prolongate_minmod.argtypes = [vp, vp, C.POINTER(i)]
+        L.oracle_restrict_average_field.argtypes = [vp, vp, C.POINTER(i), i]
+        L.oracle_prolongate_minmod_field.argtypes = [vp, vp, C.POINTER(i), i]
         L.oracle_amr_first_derivative.argtypes = [vp, i, d, C.POINTER(d)]
         L.oracle_amr_first_derivative.restype = i
         L.oracle_amr_magnitude.argtypes = [vp, i, d, d, C.POINTER(d)]
@@ -277,7 +280,7 @@ class Oracle:
             mass, q, a, e, r(i), r(omega), r(Omega), r(f), soft1, soft2, sink1, sink2, sink_rate1, sink_rate2,
             x, y, z))
 
-    def set_gravity_nbody(self, particles, frame_correction=True):
+    def set_gravity_nbody(self, particles, frame_correction=True, gm=None):
         """<gravity/nbody> + the nbody package's particles (static: <nbody> integrator = none).  particles: dicts with
         GM, pos, vel, xf, vf, rs, racc, gamma, beta, spline, couple (nbody/particle_base.hpp:53-93)."""
         par = []
@@ -287,6 +290,8 @@ class Oracle:
                     p.get("beta", 0.0), float(p.get("spline", 0)), float(p.get("couple", 1)), 0.0]
         self._npart = len(particles)
         self.L.oracle_set_gravity_nbody(self.h, len(particles), (C.c_double * len(par))(*par), int(frame_correction))
+        if gm is not None:  # nbody.cpp:109: G * mtot as read / summed before the rescale (default: the sum of the GM given)
+            self.L.oracle_set_gravity_gm(self.h, C.c_double(gm))
 
     def nbody_force(self, reset=False):
         out = (C.c_double * (7 * self._npart))()
@@ -369,13 +374,18 @@ class Oracle:
         if post_init:
             self.post_init()
 
-    def RestrictAverage(self, coarse, crange, corigin, forigin):
-        """RestrictAverage<GEOM> of this (fine) oracle's gas primitives onto `coarse`'s: crange = (cis, cie,
-        cjs, cje, cks, cke), corigin / forigin = the coarse / fine indices that coincide (cib.s <-> ib.s)."""
-        self.L.oracle_restrict_average(self.h, coarse.h, (C.c_int * 12)(*crange, *corigin, *forigin))
+    REFINE_FIELDS = {"gas.prim": 0, "gas.cons": 1, "dust.prim": 2, "dust.cons": 3}
 
-    def ProlongateSharedMinMod(self, coarse, crange, corigin, forigin):
-        self.L.oracle_prolongate_minmod(self.h, coarse.h, (C.c_int * 12)(*crange, *corigin, *forigin))
+    def RestrictAverage(self, coarse, crange, corigin, forigin, field="gas.prim"):
+        """RestrictAverage<GEOM> of this (fine) oracle's `field` arrays (default: the gas primitives) onto `coarse`'s:
+        crange = (cis, cie, cjs, cje, cks, cke), corigin / forigin = the coarse / fine indices that coincide
+        (cib.s <-> ib.s)."""
+        self.L.oracle_restrict_average_field(self.h, coarse.h, (C.c_int * 12)(*crange, *corigin, *forigin),
+                                             self.REFINE_FIELDS[field])
+
+    def ProlongateSharedMinMod(self, coarse, crange, corigin, forigin, field="gas.prim"):
+        self.L.oracle_prolongate_minmod_field(self.h, coarse.h, (C.c_int * 12)(*crange, *corigin, *forigin),
+                                              self.REFINE_FIELDS[field])
 
     def face_areas(self, dir):
         """Lower-face areas GetFaceArea<dir> (dir = 1..3) or cell volumes (dir = 0), [nk, nj, ni]."""

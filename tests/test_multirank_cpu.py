@@ -72,11 +72,11 @@ def run_world(world, spec, tmp_path, tag):
     return res
 
 
-def by_bounds(results):
+def by_bounds(results, which="gas"):
     d = {}
     for r in results:
-        for bounds, prim in r["blocks"]:
-            d[tuple(np.round(bounds, 12))] = prim
+        for q, (bounds, prim) in enumerate(r["blocks"]):
+            d[tuple(np.round(bounds, 12))] = prim if which == "gas" else r["dust"][q]
     return d
 
 

@@ -158,7 +158,7 @@ def test_amr_criteria(hiplib, coordinates, nxc, lo, hi, var):
     from artemis_amd import capi
     oc, _, mc, _ = meshes(coordinates, nxc, lo, hi)
     prim = mc.gas_prim[0]
-    field = prim[0].contiguous() if var == 0 else (((oc.cfg.gamma - 1.0) * prim[0]) * prim[4]).contiguous()
+    field = prim[0].contiguous() if var == 0 else prim[4].contiguous()  # FIELD = gas.prim.pressure: the stored array
     tag, m = C.c_int(9), C.c_double(-1.0)
     ref_tag, ref_max = oc.ScalarFirstDerivative(var, 1.0)
     for thr in ([1.0] if oc.ndim == 1 else [ref_max * 0.5, ref_max * 2.0, ref_max * 8.0]):
