@@ -196,6 +196,7 @@ def load():
         "artemis_hip_cooling_source": (i, [PPk, C.POINTER(Cooling), d, d, vp]),
         "artemis_hip_cooling_table_fill": (i, [PPk, vp, vp, C.POINTER(Cooling), i, vp, vp]),
         "artemis_hip_stage_fused": (i, [PPk, C.POINTER(StageArgs), vp]),
+        "artemis_hip_stage_fused_redo_shell": (i, [PPk, C.POINTER(StageArgs), vp]),
         "artemis_hip_stage_general": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
         "artemis_hip_stage_general_variant": (i, [PPk, C.POINTER(StageGeneralArgs)]),
         "artemis_hip_stage_epilogue": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
@@ -263,7 +264,7 @@ EXPORTS_HIP = [
     "artemis_hip_calculate_fluxes", "artemis_hip_apply_update", "artemis_hip_flux_source",
     "artemis_hip_set_aux", "artemis_hip_cons_to_prim", "artemis_hip_prim_to_cons", "artemis_hip_prim_to_cons_ghosts",
     "artemis_hip_deep_copy_conserved", "artemis_hip_estimate_dt", "artemis_hip_estimate_dt_async",
-    "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_metric_count",
+    "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_stage_fused_redo_shell", "artemis_hip_metric_count",
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_nbody_gravity", "artemis_hip_rotating_frame_force",
     "artemis_hip_ml_exchange", "artemis_hip_ml_flux_correction", "artemis_hip_ml_restrict_halos", "artemis_hip_ml_prolongate",
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",

@@ -591,8 +591,16 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
   const int recon = a->pcm ? ARTEMIS_PCM : p->gas.recon;
   const int rc = artemis::launch_stage_fused(artemis::make_pack_view(*p), *a, p->gas.riemann, recon,
                                              S(stream));
+  if (rc == 5) return fail(ARTEMIS_HIP_EDEVICE, "fused stage: no memory for the redo lists");
   if (rc) return fail(ARTEMIS_HIP_EUNSUPPORTED, "fused stage: configuration not built (rc=%d)", rc);
   return after_launch("stage_fused");
+}
+int artemis_hip_stage_fused_redo_shell(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (!a || !a->prim_in || !a->prim_u1 || !a->prim_out) return fail(ARTEMIS_HIP_EINVAL, "fused stage (shell redo): the stage's own arguments are required");
+  const int recon = a->pcm ? ARTEMIS_PCM : p->gas.recon;
+  artemis::launch_stage_fused_redo_shell(artemis::make_pack_view(*p), *a, p->gas.riemann, recon, S(stream));
+  return after_launch("stage_fused_redo_shell");
 }
 
 // Diffusion guards shared by the four tasks (see include/artemis_hip.h for what is built)

@@ -2397,6 +2397,8 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
       const char *bump = std::getenv("ARTEMIS_TEST_SHELL_TARGET_BUMP");
       if (bump) target += static_cast<unsigned>(std::atoi(bump));
       CK(artemis_hip_wait_counter(counter, target, counter + 1, comm_stream), "wait_counter");
+      // shell zones the kernel deferred to the exact path (next to vanishing velocities) are final before they are packed
+      CK(artemis_hip_stage_fused_redo_shell(&p, &a, comm_stream), "stage_fused (shell redo)");
       fill_ghosts_start(out, comm_stream);
       fill_ghosts_finish(out, comm_stream);
     } else {

@@ -32,6 +32,27 @@ ADEV double slope(double qm, double q, double qp) {
   if constexpr (RECON == 0) return 0.0;
   else return plm_dqm_fast(qm, q, qp);
 }
+// uniform-mesh slope with the division the caller may take (wave-uniform `fast`: no tiny velocity in reach, so the
+// hand-scheduled division gives the bits of `/`)
+template <int RECON>
+ADEV double slope_sel(double qm, double q, double qp, bool fast) {
+  if constexpr (RECON == 0) return 0.0;
+  else return fast ? plm_dqm_fast(qm, q, qp) : plm_dqm(qm, q, qp);
+}
+// a velocity the hand-scheduled divisions cannot take: non-zero and below 2^-200 (differences of admitted values are
+// then 0 or at least 2^-252, their squares and cubes normal); a momentum whose square over a density must keep its
+// last place
+ADEV bool tiny_vel(double v) { return v != 0.0 && fabs(v) < 0x1p-200; }
+ADEV bool tiny_mom(double m) { return m != 0.0 && fabs(m) < 0x1p-480; }
+// The same two tests on three components at once through the exponent (v_frexp_exp_i32_f64: 0 for zero, inf and NaN,
+// the true exponent for subnormals; |v| < 2^-200 <=> frexp exponent < -199): five instructions instead of six
+// compares and their mask arithmetic.
+ADEV bool tiny_vel3(double a, double b, double c) {
+  return min(min(__builtin_amdgcn_frexp_exp(a), __builtin_amdgcn_frexp_exp(b)), __builtin_amdgcn_frexp_exp(c)) < -199;
+}
+ADEV bool tiny_mom3(double a, double b, double c) {
+  return min(min(__builtin_amdgcn_frexp_exp(a), __builtin_amdgcn_frexp_exp(b)), __builtin_amdgcn_frexp_exp(c)) < -479;
+}
 // q + 0.0 == q and q - 0.0 == q bitwise for every finite q except that -0.0 + 0.0 = +0.0;
 // PCM therefore bypasses the add to stay identical to pcm.hpp:34-88.
 template <int RECON>

@@ -36,6 +36,7 @@ void launch_advance_dt(double *state, double tlim, int nstages, const double *be
 void launch_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, hipStream_t s);
 int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon,
                        hipStream_t s);
+int launch_stage_fused_redo_shell(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon, hipStream_t s);
 bool fused_flux_covers(const PackView &P, int recon);
 int launch_flux_fused(const PackView &P, int riemann, int recon, hipStream_t s);
 bool fused_curv_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas);

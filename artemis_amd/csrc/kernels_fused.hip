@@ -63,6 +63,13 @@ struct StageK {
   // release) and count themselves into *shell_done when finished
   int nshell;
   unsigned *shell_done;
+  // detect-and-redo (Cartesian stage): zones whose stencil holds a velocity the hand-scheduled divisions cannot take
+  // skip their stores and append their id (block * zones-per-block + cell index) to a list; stage_redo_kernel
+  // recomputes them with IEEE arithmetic from the untouched input buffer.  [0]: bulk workgroups, [1]: shell
+  // workgroups of a shell-first launch (redone on the stream that waits for the shell).  Null: no detection.
+  unsigned *redo_cnt0, *redo_cnt1;
+  unsigned long long *redo_list0, *redo_list1;
+  unsigned redo_cap; // entries per list (>= the zones of the launch, so it only binds if a shell list is never drained)
 };
 
 struct LdsTile {
@@ -201,17 +208,11 @@ ADEV int &tiny_flag(LdsTileCurv &S, int par) { return S.tiny[par]; }
 ADEV int &tiny_flag(LdsTile &S, int par) { return reinterpret_cast<int *>(&S.Q[5][0][0])[2 * par]; }
 template <class TILE>
 ADEV void stage_plane_flag(TILE &S, const Ctx &x, const Cell6 &q, const Raw5 &hal, int par) {
-  bool t = tiny_nonzero(q.v1) || tiny_nonzero(q.v2) || tiny_nonzero(q.v3);
-  if (x.hr >= 0) t = t || tiny_nonzero(hal.v1) || tiny_nonzero(hal.v2) || tiny_nonzero(hal.v3);
+  bool t = tiny_vel3(q.v1, q.v2, q.v3);
+  if (x.hr >= 0) t = t || tiny_vel3(hal.v1, hal.v2, hal.v3);
   if (__any(t) && (x.t & 63) == 0) tiny_flag(S, par) = 1;
 }
-ADEV bool tiny_v(const Cell6 &q) { return tiny_nonzero(q.v1) || tiny_nonzero(q.v2) || tiny_nonzero(q.v3); }
-// uniform-mesh slope with the division the plane may take
-template <int RECON>
-ADEV double slope_sel(double qm, double q, double qp, bool fast) {
-  if constexpr (RECON == 0) return 0.0;
-  else return fast ? plm_dqm_fast(qm, q, qp) : plm_dqm(qm, q, qp);
-}
+ADEV bool tiny_v(const Cell6 &q) { return tiny_vel3(q.v1, q.v2, q.v3); }
 
 // x1/x2 sweeps of one plane through LDS.  Plane k's primitives are already staged in S.Q (by
 // the previous plane's call, or by the prologue).  TWO barriers per plane:
@@ -221,14 +222,17 @@ ADEV double slope_sel(double qm, double q, double qp, bool fast) {
 // Returns the fluxes through the own cell's lower x1/x2 faces; the upper ones are left in
 // S.FX / S.FY for plane_update.  The perimeter duties rotate over the waves with k so that no
 // wave (and no SIMD) carries the extra Riemann pass every plane.
-template <int RIEMANN, int RECON, bool D3, bool CURV, bool GUARD, class TILE>
+// DETECT (the Cartesian stage): the plane flags are kept but every division stays hand-scheduled; `flagged` tells the
+// caller that this plane's tile (halo included) holds a tiny velocity, so that the zones concerned are redone exactly.
+template <int RIEMANN, int RECON, bool D3, bool CURV, bool GUARD, bool DETECT, class TILE>
 ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CURV> &gx, const int k,
                        const Cell6 &qc, const bool stage_next, const Cell6 &qn, const Raw5 &hal_next,
-                       Flux8 &fx_lo, Flux8 &fy_lo) {
+                       Flux8 &fx_lo, Flux8 &fy_lo, bool &flagged) {
   constexpr bool PG = CURV && RECON == 1; // PLM_G instead of the uniform-mesh slope
   bool fastp = true; // every division hand-scheduled (no tiny velocity in this plane's tile)
-  if constexpr (GUARD) {
-    fastp = (tiny_flag(S, k & 1) == 0);
+  if constexpr (GUARD || DETECT) {
+    flagged = (tiny_flag(S, k & 1) != 0);
+    if constexpr (GUARD) fastp = !flagged;
     if (x.t == 0) tiny_flag(S, (k + 1) & 1) = 0; // set again when the next plane is staged (after the barrier)
   }
   const int tx = x.tx, ty = x.ty;
@@ -349,7 +353,7 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
   }
   if (stage_next) {
     stage_plane(S, x, qn, hal_next);
-    if constexpr (GUARD) stage_plane_flag(S, x, qn, hal_next, (k + 1) & 1);
+    if constexpr (GUARD || DETECT) stage_plane_flag(S, x, qn, hal_next, (k + 1) & 1);
   }
   __syncthreads();
 }
@@ -397,10 +401,20 @@ ADEV void plane_store_fluxes(TILE &S, const PackView &P, const Ctx &x, const int
 
 // Phase P3: gather the upper-face fluxes published by the neighbours, then the whole per-cell
 // chain update -> sources -> aux -> c2p -> p2c -> store (and the CFL reduction).
+// `bad`: the zone's stencil holds a tiny velocity (the caller's plane flag and own-column bits).  Such a zone -- and one
+// whose updated momenta come out tiny -- keeps its hands off memory: no store, no contribution to dt; its id goes to
+// the redo list and stage_redo_kernel computes it with IEEE arithmetic.
+ADEV void redo_append(const StageK &a, const PackView &P, int b, long c, bool shell_wg) {
+  unsigned *cnt = shell_wg ? a.redo_cnt1 : a.redo_cnt0;
+  unsigned long long *list = shell_wg ? a.redo_list1 : a.redo_list0;
+  const unsigned at = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (at < a.redo_cap)
+    list[at] = static_cast<unsigned long long>(b) * (static_cast<unsigned long long>(P.nk) * P.nj * P.ni) + static_cast<unsigned long long>(c);
+}
 template <bool HAS_U1, bool WRITE_CONS, bool WITH_DT, bool D3, class TILE>
 ADEV void plane_update(TILE &S, const PackView &P, const StageK &a, const Ctx &x, const int k,
                        const Cell6 &qc, const Flux8 &fx_lo, const Flux8 &fy_lo, const Flux8 &fz_lo,
-                       const Flux8 &fz_hi, const Raw5 &u1raw, double &ldt) {
+                       const Flux8 &fz_hi, const Raw5 &u1raw, double &ldt, const bool bad_in, const bool shell_wg) {
   const int tx = x.tx, ty = x.ty;
   const bool multi_d = D3 || x.multi_d;
   constexpr bool three_d = D3;
@@ -470,6 +484,10 @@ ADEV void plane_update(TILE &S, const PackView &P, const StageK &a, const Ctx &x
     G = sie * w_d;
     const double uflr = f.siefloor * w_d;
     G = (G > uflr) ? G : uflr;
+  }
+  if (a.redo_cnt0 && (bad_in || tiny_mom3(M1, M2, M3))) {
+    redo_append(a, P, b, c, shell_wg);
+    return;
   }
   // the PrimToCons floors that follow (fill_derived.cpp:229,244) are idempotent here
   const double w1 = div(M1, rd), w2 = div(M2, rd), w3 = div(M3, rd);
@@ -775,7 +793,12 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
   // the plane flags: PLM_G's cubic numerators need them in the curvilinear kernel; the flux TASK keeps every output
   // bit exact with them (the fused Cartesian stage does without: DESIGN.md section 4)
   constexpr bool GUARD = (CURV && RECON == 1) || FLUXES;
-  if constexpr (GUARD) {
+  // the Cartesian stage: detect-and-redo instead of a second code path (which costs registers it does not have)
+#ifndef ARTEMIS_DETECT
+#define ARTEMIS_DETECT 1
+#endif
+  constexpr bool DETECT = !CURV && !FLUXES && (ARTEMIS_DETECT != 0);
+  if constexpr (GUARD || DETECT) {
     if (x.t == 0) tiny_flag(S, 0) = tiny_flag(S, 1) = 0;
     __syncthreads(); // the flags are cleared before any wave sets one for the first staged plane (and the tables are in)
   }
@@ -793,9 +816,10 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
     Raw5 hal = u1raw;
     if (x.hr >= 0) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + k0 * x.sk);
     stage_plane(S, x, qc, hal);
-    if constexpr (GUARD) stage_plane_flag(S, x, qc, hal, k0 & 1);
+    if constexpr (GUARD || DETECT) stage_plane_flag(S, x, qc, hal, k0 & 1);
     __syncthreads();
-    plane_sweeps<RIEMANN, RECON, false, CURV, GUARD>(S, P, x, gx, k0, qc, false, qc, hal, fx_lo, fy_lo);
+    bool flagged = false;
+    plane_sweeps<RIEMANN, RECON, false, CURV, GUARD, DETECT>(S, P, x, gx, k0, qc, false, qc, hal, fx_lo, fy_lo, flagged);
     if constexpr (CURV) {
       DFlux24 df{};
       if (gx.m3) gx.co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k0], gx.co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k0];
@@ -803,16 +827,24 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
       plane_update_curv<HAS_U1, WITH_DT, false>(S, P, a, src.v, x, gx, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, df, ldt);
     }
     else if constexpr (FLUXES) plane_store_fluxes<false>(S, P, x, k0, fx_lo, fy_lo, fz, fz);
-    else plane_update<HAS_U1, WRITE_CONS, WITH_DT, false>(S, P, a, x, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt);
+    else plane_update<HAS_U1, WRITE_CONS, WITH_DT, false>(S, P, a, x, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, ldt,
+                                                          flagged, shell_wg);
   } else {
     // x3 state carried in registers: planes k, k+1, the upper face value of cell k and the
     // flux through face k.
     Cell6 qc = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k0 - 1) * x.sk, x.gm1);
     Cell6 qn = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + k0 * x.sk, x.gm1);
     Cell6 zl;
+    // DETECT: the x3 sweep of zone k reads planes k-2 .. k+2 of its own column.  Planes k+1 and k+2 are in registers
+    // when zone k is updated and are tested there; planes k-1 and k-2 are remembered as the (wave-uniform, hence
+    // scalar: the kernel has no vector register to spare) plane flags of the two trips before, bit 0 = plane k-1 --
+    // tile-wide and therefore conservative.  The chunk's first zones see planes below the chunk through `below`.
+    [[maybe_unused]] unsigned fhist = 0;
+    [[maybe_unused]] bool ahead1 = false; // the own column's plane k+1 holds a tiny velocity
     {
       const Cell6 qmm =
           load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k0 - 2) * x.sk, x.gm1);
+      if constexpr (DETECT) fhist = __any(tiny_v(qmm) || tiny_v(qc)) ? 3u : 0u, ahead1 = tiny_v(qn); // planes k0-2, k0-1 (not staged by this chunk); k0
       if constexpr (CURV && RECON == 1) {
         const PlmGeo g3 = plm_geo_x3(gx.co, x.g, k0 - 1);
         double unused_;
@@ -846,15 +878,22 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
         if (gx.m3 && k >= k0) gx.co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k], gx.co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k];
       }
       Flux8 fx_lo, fy_lo;
+      bool flagged = false;
       if (k >= k0) {
-        plane_sweeps<RIEMANN, RECON, true, CURV, GUARD>(S, P, x, gx, k, qc, k < k1, qn, hal, fx_lo, fy_lo);
+        plane_sweeps<RIEMANN, RECON, true, CURV, GUARD, DETECT>(S, P, x, gx, k, qc, k < k1, qn, hal, fx_lo, fy_lo, flagged);
       } else { // priming trip: stage the first plane
         stage_plane(S, x, qn, hal);
-        if constexpr (GUARD) stage_plane_flag(S, x, qn, hal, k0 & 1);
+        if constexpr (GUARD || DETECT) stage_plane_flag(S, x, qn, hal, k0 & 1);
         __syncthreads();
       }
       // x3 sweep, registers only: slope of cell k+1, face k+1
       const Cell6 qnn = finish_cell(rnn, x.gm1);
+      [[maybe_unused]] bool ahead = false;
+      if constexpr (DETECT) { // planes k+1, k+2 of the own column (k+1 was tested as this trip's k+2 one trip ago)
+        const bool a2 = tiny_v(qnn);
+        ahead = ahead1 || a2;
+        ahead1 = a2;
+      }
       // face k+1 reads the own column's planes k-1 .. k+2: the three in registers decide for the wave (the slope of
       // cell k entered zl in the previous trip under that trip's check)
       const bool fast_col = !(FLUXES && __any(tiny_v(qc) || tiny_v(qn) || tiny_v(qnn)));
@@ -889,9 +928,13 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
       if (k >= k0) {
         if constexpr (CURV) plane_update_curv<HAS_U1, WITH_DT, true>(S, P, a, src.v, x, gx, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, df, ldt);
         else if constexpr (FLUXES) plane_store_fluxes<true>(S, P, x, k, fx_lo, fy_lo, fz_lo, fz_hi);
-        else plane_update<HAS_U1, WRITE_CONS, WITH_DT, true>(S, P, a, x, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt);
+        else plane_update<HAS_U1, WRITE_CONS, WITH_DT, true>(S, P, a, x, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt,
+                                                             flagged || (fhist & 3u) != 0u || ahead, shell_wg);
       }
       fz_lo = fz_hi, zl = zl_next, qc = qn, qn = qnn;
+      if constexpr (DETECT) {
+        if (k >= k0) fhist = (fhist << 1) | (flagged ? 1u : 0u);
+      }
     }
   }
 
@@ -938,6 +981,151 @@ __global__ void wait_counter_kernel(unsigned *counter, unsigned target, unsigned
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// ---- detect-and-redo: the exact path of the zones the Cartesian stage kernel deferred ------------------------------
+// One thread per listed zone: the whole stage of that zone -- 2 ndim faces from register stencils, ApplyUpdate,
+// FluxSource, SetAuxillaryFields, ConsToPrim, PrimToCons, the zone's timestep -- with IEEE `/` and sqrt and the
+// expression trees of the per-task kernels (device_math.hpp plm_dqm / hllc_gas / riemann_gas, kernels_stage_cell.hip's
+// gas branch): the bits of the per-task chain and of the oracle whatever the magnitudes.  Reads prim_in (stencil) and
+// prim_u1 (the zone itself, not yet overwritten: the stage kernel skipped its stores) and writes prim_out / cons_out.
+// Normally the list is empty (the kernel reads the count and returns); velocities of 1e-61 and below next to a shock
+// precursor are what fills it.
+struct RedoK {
+  double gam0, gam1, beta_dt, bdt, cfl;
+  const double *bdt_ptr;
+  double *const *prim_in, *const *prim_u1, *const *prim_out, *const *cons_out;
+  unsigned long long *dt_bits;
+  unsigned *cnt;   // entries in the list; reset to zero by the last workgroup of this kernel (no memset between stages)
+  unsigned *done;  // its ticket counter
+  unsigned cap;
+  const unsigned long long *list;
+  int has_u1;
+};
+template <int RIEMANN, int RECON>
+__global__ __launch_bounds__(256) void stage_redo_kernel(const PackView P, const RedoK a) {
+  const unsigned n = min(__hip_atomic_load(a.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.cap);
+  const GasK gk = gas_constants(P.gm1);
+  const FluidView &f = P.gas;
+  const unsigned long long N = static_cast<unsigned long long>(P.nk) * P.nj * P.ni;
+  double beta_dt = a.beta_dt, bdt = a.bdt;
+  if (a.bdt_ptr) beta_dt = bdt = *a.bdt_ptr;
+  const bool multi_d = P.ndim > 1, three_d = P.ndim > 2;
+  for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    const unsigned long long id = a.list[q];
+    const int b = static_cast<int>(id / N);
+    const long c = static_cast<long>(id % N);
+    const int k = static_cast<int>(c / P.sk), j = static_cast<int>((c % P.sk) / P.sj), i = static_cast<int>(c % P.sj);
+    const double *qr = a.prim_in[b * 6 + 0], *q1 = a.prim_in[b * 6 + 1], *q2 = a.prim_in[b * 6 + 2];
+    const double *q3 = a.prim_in[b * 6 + 3], *qe = a.prim_in[b * 6 + 5];
+    const double *g = P.geom + 6 * b;
+    const double dx1 = (g[0] + (i + 1) * g[1]) - (g[0] + i * g[1]);
+    const double dx2 = (g[2] + (j + 1) * g[3]) - (g[2] + j * g[3]);
+    const double dx3 = (g[4] + (k + 1) * g[5]) - (g[4] + k * g[5]);
+    const double ax1 = dx2 * dx3, ax2 = dx1 * dx3, ax3 = dx1 * dx2, vol = dx1 * dx2 * dx3; // geometry.hpp:199-225
+    Flux8 lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) lo[d].d = lo[d].m1 = lo[d].m2 = lo[d].m3 = lo[d].e = lo[d].eg = lo[d].pf = lo[d].vf = 0.0, hi[d] = lo[d];
+    auto faces = [&](auto DIRTAG, long st, Flux8 &flo, Flux8 &fhi) {
+      constexpr int DIR = decltype(DIRTAG)::value;
+      Cell6 w[5];
+#pragma unroll
+      for (int m = 0; m < 5; ++m) w[m] = load_cell(qr, q1, q2, q3, qe, c + (m - 2) * st, P.gm1);
+      Cell6 Ll, Rl, Lu, Ru;
+#define RD(v)                                                                                          \
+  {                                                                                                    \
+    double sm = 0.0, sc = 0.0, sp = 0.0;                                                               \
+    if constexpr (RECON == 1) sm = plm_dqm(w[0].v, w[1].v, w[2].v), sc = plm_dqm(w[1].v, w[2].v, w[3].v), sp = plm_dqm(w[2].v, w[3].v, w[4].v); \
+    Ll.v = up_val<RECON>(w[1].v, sm), Rl.v = lo_val<RECON>(w[2].v, sc);                                \
+    Lu.v = up_val<RECON>(w[2].v, sc), Ru.v = lo_val<RECON>(w[3].v, sp);                                \
+  }
+      FOR6(RD)
+#undef RD
+      flo = solve_face<RIEMANN, DIR>(gk, Ll, Rl, false);
+      fhi = solve_face<RIEMANN, DIR>(gk, Lu, Ru, false);
+    };
+    faces(std::integral_constant<int, 1>{}, 1, lo[0], hi[0]);
+    if (multi_d) faces(std::integral_constant<int, 2>{}, P.sj, lo[1], hi[1]);
+    if (three_d) faces(std::integral_constant<int, 3>{}, P.sk, lo[2], hi[2]);
+    // u0 = PrimToCons(prim_in), u1 = PrimToCons(prim_u1)  (fill_derived.cpp:226-255)
+    const Cell6 qc = load_cell(qr, q1, q2, q3, qe, c, P.gm1);
+    const double D0 = qc.d, M10 = qc.d * qc.v1 * 1.0, M20 = qc.d * qc.v2 * 1.0, M30 = qc.d * qc.v3 * 1.0;
+    const double G0 = qc.e * qc.d;
+    const double E0 = G0 + 0.5 * qc.d * (sqr(qc.v1) + sqr(qc.v2) + sqr(qc.v3));
+    double D1 = D0, M11 = M10, M21 = M20, M31 = M30, G1 = G0, E1 = E0;
+    if (a.has_u1) {
+      const double r1 = a.prim_u1[b * 6 + 0][c], a1 = a.prim_u1[b * 6 + 1][c], a2 = a.prim_u1[b * 6 + 2][c];
+      const double a3 = a.prim_u1[b * 6 + 3][c], e1 = a.prim_u1[b * 6 + 5][c];
+      D1 = r1, M11 = r1 * a1 * 1.0, M21 = r1 * a2 * 1.0, M31 = r1 * a3 * 1.0;
+      G1 = e1 * r1;
+      E1 = G1 + 0.5 * r1 * (sqr(a1) + sqr(a2) + sqr(a3));
+    }
+    auto upd = [&](double u0, double u1, double f1l, double f1h, double f2l, double f2h, double f3l, double f3h) {
+      double divf = (ax1 * f1l - ax1 * f1h); // artemis_integrator.hpp:88-106
+      if (multi_d) divf += (ax2 * f2l - ax2 * f2h);
+      if (three_d) divf += (ax3 * f3l - ax3 * f3h);
+      return a.gam0 * u0 + a.gam1 * u1 + divf * beta_dt / vol;
+    };
+    const double D = upd(D0, D1, lo[0].d, hi[0].d, lo[1].d, hi[1].d, lo[2].d, hi[2].d);
+    double M1 = upd(M10, M11, lo[0].m1, hi[0].m1, lo[1].m1, hi[1].m1, lo[2].m1, hi[2].m1);
+    double M2 = upd(M20, M21, lo[0].m2, hi[0].m2, lo[1].m2, hi[1].m2, lo[2].m2, hi[2].m2);
+    double M3 = upd(M30, M31, lo[0].m3, hi[0].m3, lo[1].m3, hi[1].m3, lo[2].m3, hi[2].m3);
+    const double E = upd(E0, E1, lo[0].e, hi[0].e, lo[1].e, hi[1].e, lo[2].e, hi[2].e);
+    double G = upd(G0, G1, lo[0].eg, hi[0].eg, lo[1].eg, hi[1].eg, lo[2].eg, hi[2].eg);
+    // FluxSource (fluid_fluxes.hpp:365-392)
+    M1 += bdt / dx1 * (lo[0].pf - hi[0].pf);
+    G -= bdt / vol * 0.5 * (lo[0].pf + hi[0].pf) * (ax1 * hi[0].vf - ax1 * lo[0].vf);
+    if (multi_d) {
+      M2 += bdt / dx2 * (lo[1].pf - hi[1].pf);
+      G -= bdt / vol * 0.5 * (lo[1].pf + hi[1].pf) * (ax2 * hi[1].vf - ax2 * lo[1].vf);
+    }
+    if (three_d) {
+      M3 += bdt / dx3 * (lo[2].pf - hi[2].pf);
+      G -= bdt / vol * 0.5 * (lo[2].pf + hi[2].pf) * (ax3 * hi[2].vf - ax3 * lo[2].vf);
+    }
+    // SetAuxillaryFields (fill_derived.cpp:54-73, artemis_utils.hpp:43-62) + ConsToPrim (:137-151)
+    const double w_d = (D > f.dfloor) ? D : f.dfloor;
+    {
+      const double ke = 0.5 * (sqr(M1 / 1.0) + sqr(M2 / 1.0) + sqr(M3 / 1.0)) / w_d;
+      const double ue = E - ke;
+      double sie = ((ue > f.de_switch * E) ? ue : G) / w_d;
+      sie = amax(sie, f.siefloor);
+      G = sie * w_d;
+      const double uflr = f.siefloor * w_d;
+      G = (G > uflr) ? G : uflr;
+    }
+    const double w1 = M1 / w_d, w2 = M2 / w_d, w3 = M3 / w_d;
+    double w_s = G / w_d;
+    w_s = (w_s > f.siefloor) ? w_s : f.siefloor;
+    const double w_p = amax(0.0, P.gm1 * w_d * w_s); // fill_derived.cpp:247
+    a.prim_out[b * 6 + 0][c] = w_d, a.prim_out[b * 6 + 1][c] = w1, a.prim_out[b * 6 + 2][c] = w2;
+    a.prim_out[b * 6 + 3][c] = w3, a.prim_out[b * 6 + 4][c] = w_p, a.prim_out[b * 6 + 5][c] = w_s;
+    if (a.cons_out) { // PrimToCons (fill_derived.cpp:226-255)
+      const double u_u = w_s * w_d;
+      a.cons_out[b * 6 + 0][c] = w_d, a.cons_out[b * 6 + 1][c] = w_d * w1 * 1.0, a.cons_out[b * 6 + 2][c] = w_d * w2 * 1.0;
+      a.cons_out[b * 6 + 3][c] = w_d * w3 * 1.0;
+      a.cons_out[b * 6 + 4][c] = u_u + 0.5 * w_d * (sqr(w1) + sqr(w2) + sqr(w3));
+      a.cons_out[b * 6 + 5][c] = u_u;
+    }
+    if (a.dt_bits) { // Gas::EstimateTimestepMesh on the new state (gas.cpp:411-433)
+      const double bulk = (P.gm1 + 1.0) * P.gm1 * w_d * w_s;
+      const double cs = sqrt(bulk / w_d);
+      double denom = 0.0;
+      denom += (fabs(w1) + cs) / dx1;
+      if (multi_d) denom += (fabs(w2) + cs) / dx2;
+      if (three_d) denom += (fabs(w3) + cs) / dx3;
+      atomicMin(a.dt_bits, static_cast<unsigned long long>(__double_as_longlong(a.cfl * (1.0 / denom))));
+    }
+  }
+  // every workgroup has read the count by now; the last one to get here empties the list for the next stage
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == gridDim.x - 1) {
+      __hip_atomic_store(a.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.done, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // Planes per chunk of the x3 march.  The launch proceeds in rounds of `slots` resident workgroups (256 CUs x 2, or
@@ -1013,6 +1201,65 @@ void launch_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_f
   hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, s, counter, target, timeout_flag, limit);
 }
 
+// Redo lists of the calling thread: [0] bulk, [1] shell; each a counter and room for every zone of the largest pack
+// seen.  Allocated on first use (outside any stream capture: the host driver's first plain steps), grown on demand.
+namespace {
+struct RedoBufs {
+  unsigned *cnt = nullptr; // two entry counters + two ticket counters (zero between launches)
+  unsigned long long *list[2] = {nullptr, nullptr};
+  size_t cap = 0;
+};
+thread_local RedoBufs g_redo;
+bool redo_enabled() { return getenv("ARTEMIS_NO_REDO") == nullptr; }
+bool ensure_redo(size_t zones) {
+  if (g_redo.cnt && g_redo.cap >= zones) return true;
+  (void)hipDeviceSynchronize();
+  if (g_redo.list[0]) (void)hipFree(g_redo.list[0]);
+  if (g_redo.list[1]) (void)hipFree(g_redo.list[1]);
+  g_redo.list[0] = g_redo.list[1] = nullptr, g_redo.cap = 0;
+  if (!g_redo.cnt) {
+    if (hipMalloc(reinterpret_cast<void **>(&g_redo.cnt), 4 * sizeof(unsigned)) != hipSuccess) return false;
+    if (hipMemset(g_redo.cnt, 0, 4 * sizeof(unsigned)) != hipSuccess) return false;
+  }
+  for (int q = 0; q < 2; ++q)
+    if (hipMalloc(reinterpret_cast<void **>(&g_redo.list[q]), zones * sizeof(unsigned long long)) != hipSuccess) return false;
+  g_redo.cap = zones;
+  return true;
+}
+template <int RIEMANN, int RECON>
+void launch_redo_cfg(const PackView &P, const RedoK &r, hipStream_t s) {
+  hipLaunchKernelGGL((stage_redo_kernel<RIEMANN, RECON>), dim3(128), dim3(256), 0, s, P, r);
+}
+void launch_redo(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon, int which, hipStream_t s) {
+  RedoK r;
+  r.gam0 = a.gam0, r.gam1 = a.gam1, r.beta_dt = a.beta_dt, r.bdt = a.bdt, r.cfl = a.cfl;
+  r.bdt_ptr = a.beta_dt_dev;
+  r.prim_in = a.prim_in, r.prim_u1 = a.prim_u1, r.prim_out = a.prim_out, r.cons_out = a.cons_out;
+  r.dt_bits = reinterpret_cast<unsigned long long *>(a.dt_dev);
+  r.cnt = g_redo.cnt + which, r.done = g_redo.cnt + 2 + which, r.cap = static_cast<unsigned>(std::min<size_t>(g_redo.cap, 0xffffffffu));
+  r.list = g_redo.list[which];
+  r.has_u1 = (a.prim_u1 != a.prim_in) ? 1 : 0;
+#define RC(RS)                                                                             \
+  case RS:                                                                                 \
+    if (recon == ARTEMIS_PCM) launch_redo_cfg<RS, 0>(P, r, s);                             \
+    else launch_redo_cfg<RS, 1>(P, r, s);                                                  \
+    break;
+  switch (riemann) {
+    RC(0)
+    RC(1)
+    RC(2)
+  }
+#undef RC
+}
+} // namespace
+// The shell list of the calling thread's last shell-first launch (artemis_stage_args_t.shell_done), on the stream
+// that has waited for the shell counter.
+int launch_stage_fused_redo_shell(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon, hipStream_t s) {
+  if (!redo_enabled() || !g_redo.cnt) return 0;
+  launch_redo(P, a, riemann, recon, 1, s);
+  return 0;
+}
+
 int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon,
                        hipStream_t s) {
   if (recon == ARTEMIS_PPM) return 3; // PPM stays on the per-task path
@@ -1085,23 +1332,38 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
     add_box(tim0, ntim, tjm0, ntjm, km0, km1);
   }
   if (k.nbox == 0) return 0; // nothing to do in this region
+  // detect-and-redo: zones next to vanishing velocities are deferred to the exact kernel (below)
+  k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
+  const bool redo = redo_enabled();
+  if (redo) {
+    const size_t zones = static_cast<size_t>(P.nb) * (P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1);
+    if (!ensure_redo(zones)) return 5;
+    k.redo_cnt0 = g_redo.cnt, k.redo_cnt1 = g_redo.cnt + 1;
+    k.redo_list0 = g_redo.list[0], k.redo_list1 = g_redo.list[1];
+    k.redo_cap = static_cast<unsigned>(std::min<size_t>(g_redo.cap, 0xffffffffu));
+  }
   // XCD-aware id remap of the bulk workgroups: no effect on the run time (the kernel is VALU-bound) but
   // it removes the halo / straddled-line re-reads between XCDs from the HBM traffic (profiles/r02*pmc*)
   k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
   const bool has_u1 = (a.prim_u1 != a.prim_in);
   const bool cons = (a.cons_out != nullptr);
   const bool dt = (a.dt_dev != nullptr);
+  int rc = 4;
 #define RC(RS)                                                                             \
   case RS:                                                                                 \
-    return (recon == ARTEMIS_PCM) ? launch_cfg<RS, 0>(P, k, has_u1, cons, dt, s)           \
-                                  : launch_cfg<RS, 1>(P, k, has_u1, cons, dt, s);
+    rc = (recon == ARTEMIS_PCM) ? launch_cfg<RS, 0>(P, k, has_u1, cons, dt, s)             \
+                                : launch_cfg<RS, 1>(P, k, has_u1, cons, dt, s);            \
+    break;
   switch (riemann) {
     RC(0)
     RC(1)
     RC(2)
   }
 #undef RC
-  return 4;
+  // the bulk list on the launch's own stream; the shell list of a shell-first launch belongs to the stream that waits
+  // for the shell (launch_stage_fused_redo_shell)
+  if (rc == 0 && redo) launch_redo(P, a, riemann, recon, 0, s);
+  return rc;
 }
 
 // ---- Gas::CalculateFluxes through the tile march -------------------------------------------------
@@ -1143,6 +1405,7 @@ int launch_flux_fused(const PackView &P, int riemann, int recon, hipStream_t s) 
   k.nchunk[0] = (nz + k.kchunk[0] - 1) / k.kchunk[0];
   k.start[1] = NTI * NTJ * k.nchunk[0] * P.nb;
   k.nshell = 0, k.shell_done = nullptr;
+  k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
 #define RC(RS)                                                                             \
   case RS:                                                                                 \
@@ -1204,6 +1467,7 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
   k.nchunk[0] = (nz + k.kchunk[0] - 1) / k.kchunk[0];
   k.start[1] = NTI * NTJ * k.nchunk[0] * P.nb;
   k.nshell = 0, k.shell_done = nullptr;
+  k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
   SrcArg<true> src;
   src.v.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;

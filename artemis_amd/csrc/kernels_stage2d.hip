@@ -98,26 +98,26 @@ ADEV DFlux solve_dust(const Dust4 &L, const Dust4 &R) {
 
 // x1 sweep of one row through the wave: fluxes through the lower and the upper x1 face of the lane's cell
 template <int RIEMANN, int RECON>
-ADEV void x1_gas(const GasK &gk, const Cell6 &q, Flux8 &lo, Flux8 &up) {
+ADEV void x1_gas(const GasK &gk, const Cell6 &q, Flux8 &lo, Flux8 &up, const bool fast) {
   Cell6 L, R;
 #define SW(m)                                                                    \
   {                                                                              \
-    const double s_ = slope<RECON>(lane_below(q.m), q.m, lane_above(q.m));       \
+    const double s_ = slope_sel<RECON>(lane_below(q.m), q.m, lane_above(q.m), fast); \
     R.m = lo_val<RECON>(q.m, s_);                                                \
     L.m = lane_below(up_val<RECON>(q.m, s_));                                    \
   }
   G6(SW)
 #undef SW
-  lo = solve_face<RIEMANN, 1>(gk, L, R);
+  lo = solve_face<RIEMANN, 1>(gk, L, R, fast);
   up.d = lane_above(lo.d), up.m1 = lane_above(lo.m1), up.m2 = lane_above(lo.m2), up.m3 = lane_above(lo.m3);
   up.e = lane_above(lo.e), up.eg = lane_above(lo.eg), up.pf = lane_above(lo.pf), up.vf = lane_above(lo.vf);
 }
 template <int RIEMANN, int RECON>
-ADEV void x1_dust(const Dust4 &q, DFlux &lo, DFlux &up) {
+ADEV void x1_dust(const Dust4 &q, DFlux &lo, DFlux &up, const bool fast) {
   Dust4 L, R;
 #define SW(m)                                                                    \
   {                                                                              \
-    const double s_ = slope<RECON>(lane_below(q.m), q.m, lane_above(q.m));       \
+    const double s_ = slope_sel<RECON>(lane_below(q.m), q.m, lane_above(q.m), fast); \
     R.m = lo_val<RECON>(q.m, s_);                                                \
     L.m = lane_below(up_val<RECON>(q.m, s_));                                    \
   }
@@ -199,9 +199,17 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
     Cell6 qc = load_cell(g_r, g_1, g_2, g_3, g_e, col + (j0 - 1) * sj, gm1);
     Cell6 qn = load_cell(g_r, g_1, g_2, g_3, g_e, col + j0 * sj, gm1);
     Cell6 zl;
+    // Guard (exactness next to vanishing velocities): one bit per row, newest in bit 0 -- some lane
+    // of this wave holds a gas or dust velocity below 2^-200 in that row.  A trip whose five-row window (the x2 stencil
+    // of row j; the x1 stencil lives in the wave's own lanes) has a bit set takes IEEE divisions throughout.
+    unsigned th = 0;
+    auto tiny6 = [](const Cell6 &q) { return tiny_vel(q.v1) || tiny_vel(q.v2) || tiny_vel(q.v3); };
+    auto tiny4 = [](const Dust4 &q) { return tiny_vel(q.v1) || tiny_vel(q.v2) || tiny_vel(q.v3); };
     {
       const Cell6 qmm = load_cell(g_r, g_1, g_2, g_3, g_e, col + (j0 - 2) * sj, gm1);
-#define ZL0(m) zl.m = up_val<RECON>(qc.m, slope<RECON>(qmm.m, qc.m, qn.m));
+      th = (__any(tiny6(qmm)) ? 4u : 0u) | (__any(tiny6(qc)) ? 2u : 0u) | (__any(tiny6(qn)) ? 1u : 0u);
+      const bool f0 = (th == 0u);
+#define ZL0(m) zl.m = up_val<RECON>(qc.m, slope_sel<RECON>(qmm.m, qc.m, qn.m, f0));
       G6(ZL0)
 #undef ZL0
     }
@@ -214,7 +222,10 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
       dc[n] = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], col + (j0 - 1) * sj);
       dn[n] = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], col + j0 * sj);
       const Dust4 dmm = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], col + (j0 - 2) * sj);
-#define ZL0(m) dzl[n].m = up_val<RECON>(dc[n].m, slope<RECON>(dmm.m, dc[n].m, dn[n].m));
+      const unsigned td = (__any(tiny4(dmm)) ? 4u : 0u) | (__any(tiny4(dc[n])) ? 2u : 0u) | (__any(tiny4(dn[n])) ? 1u : 0u);
+      th |= td;
+      const bool f0 = (td == 0u);
+#define ZL0(m) dzl[n].m = up_val<RECON>(dc[n].m, slope_sel<RECON>(dmm.m, dc[n].m, dn[n].m, f0));
       D4(ZL0)
 #undef ZL0
       dy_lo[n].d = dy_lo[n].m1 = dy_lo[n].m2 = dy_lo[n].m3 = 0.0;
@@ -230,6 +241,14 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
       Dust4 dnn[ND > 0 ? ND : 1];
 #pragma unroll
       for (int n = 0; n < ND; ++n) dnn[n] = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], cnn);
+      {
+        bool t = tiny6(qnn);
+#pragma unroll
+        for (int n = 0; n < ND; ++n) t = t || tiny4(dnn[n]);
+        th = (th << 1) | (__any(t) ? 1u : 0u); // bits 0..4 = rows j+2 .. j-2
+      }
+      bool fast = (th & 31u) == 0u; // wave-uniform
+      auto GD = [&](double num, const Recip &r) { return fast ? div(num, r) : num / r.b; };
       const CellMetric g = cell_metric<false>(P, b, 0, j, i);
       const double hx[3] = {1.0, 1.0, 1.0};
       // Division: the cell epilogue of the general stage is ~90 IEEE divisions per cell (27 instructions each).
@@ -244,31 +263,31 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
       double divf[6] = {0, 0, 0, 0, 0, 0}, tm1 = 0.0, tm2 = 0.0, teg1 = 0.0, teg2 = 0.0;
       if (live) {
         Flux8 lo, up;
-        x1_gas<RG, RECON>(gk, qc, lo, up);
+        x1_gas<RG, RECON>(gk, qc, lo, up, fast);
         divf[0] = (g.ax1[0] * lo.d - g.ax1[1] * up.d), divf[1] = (g.ax1[0] * lo.m1 - g.ax1[1] * up.m1);
         divf[2] = (g.ax1[0] * lo.m2 - g.ax1[1] * up.m2), divf[3] = (g.ax1[0] * lo.m3 - g.ax1[1] * up.m3);
         divf[4] = (g.ax1[0] * lo.e - g.ax1[1] * up.e), divf[5] = (g.ax1[0] * lo.eg - g.ax1[1] * up.eg);
-        tm1 = div(bdt, rdx0) * (lo.pf - up.pf); // FluxSource (fluid_fluxes.hpp:361-392)
-        teg1 = div(bdt, rvol) * 0.5 * (lo.pf + up.pf) * (g.ax1[1] * up.vf - g.ax1[0] * lo.vf);
+        tm1 = GD(bdt, rdx0) * (lo.pf - up.pf); // FluxSource (fluid_fluxes.hpp:361-392)
+        teg1 = GD(bdt, rvol) * 0.5 * (lo.pf + up.pf) * (g.ax1[1] * up.vf - g.ax1[0] * lo.vf);
       }
       // ---- gas: x2 sweep, registers only: slope of row j+1, face j+1 ---------------------------------------
       {
         Cell6 zr, zl_next;
 #define ZS(m)                                                \
   {                                                          \
-    const double s_ = slope<RECON>(qc.m, qn.m, qnn.m);       \
+    const double s_ = slope_sel<RECON>(qc.m, qn.m, qnn.m, fast); \
     zr.m = lo_val<RECON>(qn.m, s_);                          \
     zl_next.m = up_val<RECON>(qn.m, s_);                     \
   }
         G6(ZS)
 #undef ZS
-        const Flux8 up = solve_face<RG, 2>(gk, zl, zr);
+        const Flux8 up = solve_face<RG, 2>(gk, zl, zr, fast);
         if (live) {
           divf[0] += (g.ax2[0] * fy_lo.d - g.ax2[1] * up.d), divf[1] += (g.ax2[0] * fy_lo.m1 - g.ax2[1] * up.m1);
           divf[2] += (g.ax2[0] * fy_lo.m2 - g.ax2[1] * up.m2), divf[3] += (g.ax2[0] * fy_lo.m3 - g.ax2[1] * up.m3);
           divf[4] += (g.ax2[0] * fy_lo.e - g.ax2[1] * up.e), divf[5] += (g.ax2[0] * fy_lo.eg - g.ax2[1] * up.eg);
-          tm2 = div(bdt, rdx1) * (fy_lo.pf - up.pf);
-          teg2 = div(bdt, rvol) * 0.5 * (fy_lo.pf + up.pf) * (g.ax2[1] * up.vf - g.ax2[0] * fy_lo.vf);
+          tm2 = GD(bdt, rdx1) * (fy_lo.pf - up.pf);
+          teg2 = GD(bdt, rvol) * 0.5 * (fy_lo.pf + up.pf) * (g.ax2[1] * up.vf - g.ax2[0] * fy_lo.vf);
         }
         fy_lo = up, zl = zl_next;
       }
@@ -288,12 +307,12 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
         GasCons u1 = u0;
         if constexpr (HAS_U1)
           u1 = prim_to_cons_gas(fg, gld(u_r, ccur), gld(u_1, ccur), gld(u_2, ccur), gld(u_3, ccur), gld(u_e, ccur), hx);
-        u0.d = a.gam0 * u0.d + a.gam1 * u1.d + div(divf[0] * beta_dt, rvol);
-        u0.m1 = a.gam0 * u0.m1 + a.gam1 * u1.m1 + div(divf[1] * beta_dt, rvol);
-        u0.m2 = a.gam0 * u0.m2 + a.gam1 * u1.m2 + div(divf[2] * beta_dt, rvol);
-        u0.m3 = a.gam0 * u0.m3 + a.gam1 * u1.m3 + div(divf[3] * beta_dt, rvol);
-        u0.e = a.gam0 * u0.e + a.gam1 * u1.e + div(divf[4] * beta_dt, rvol);
-        u0.eg = a.gam0 * u0.eg + a.gam1 * u1.eg + div(divf[5] * beta_dt, rvol);
+        u0.d = a.gam0 * u0.d + a.gam1 * u1.d + GD(divf[0] * beta_dt, rvol);
+        u0.m1 = a.gam0 * u0.m1 + a.gam1 * u1.m1 + GD(divf[1] * beta_dt, rvol);
+        u0.m2 = a.gam0 * u0.m2 + a.gam1 * u1.m2 + GD(divf[2] * beta_dt, rvol);
+        u0.m3 = a.gam0 * u0.m3 + a.gam1 * u1.m3 + GD(divf[3] * beta_dt, rvol);
+        u0.e = a.gam0 * u0.e + a.gam1 * u1.e + GD(divf[4] * beta_dt, rvol);
+        u0.eg = a.gam0 * u0.eg + a.gam1 * u1.eg + GD(divf[5] * beta_dt, rvol);
         u0.m1 += tm1;
         u0.eg -= teg1;
         u0.m2 += tm2;
@@ -309,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
         double dv[4] = {0, 0, 0, 0};
         if (live) {
           DFlux lo, up;
-          x1_dust<RD, RECON>(dc[n], lo, up);
+          x1_dust<RD, RECON>(dc[n], lo, up, fast);
           dv[0] = (g.ax1[0] * lo.d - g.ax1[1] * up.d), dv[1] = (g.ax1[0] * lo.m1 - g.ax1[1] * up.m1);
           dv[2] = (g.ax1[0] * lo.m2 - g.ax1[1] * up.m2), dv[3] = (g.ax1[0] * lo.m3 - g.ax1[1] * up.m3);
         }
@@ -317,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
           Dust4 dzr, dzl_next;
 #define ZS(m)                                                          \
   {                                                                    \
-    const double s_ = slope<RECON>(dc[n].m, dn[n].m, dnn[n].m);        \
+    const double s_ = slope_sel<RECON>(dc[n].m, dn[n].m, dnn[n].m, fast); \
     dzr.m = lo_val<RECON>(dn[n].m, s_);                                \
     dzl_next.m = up_val<RECON>(dn[n].m, s_);                           \
   }
@@ -335,10 +354,10 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
           wd.rho = dc[n].d, wd.v1 = dc[n].v1, wd.v2 = dc[n].v2, wd.v3 = dc[n].v3, wd.sie = 0.0;
           DustCons v0 = prim_to_cons_dust(fd, dc[n].d, dc[n].v1, dc[n].v2, dc[n].v3, hx), v1 = v0;
           if constexpr (HAS_U1) v1 = prim_to_cons_dust(fd, gld(e_r[n], ccur), gld(e_1[n], ccur), gld(e_2[n], ccur), gld(e_3[n], ccur), hx);
-          v0.d = a.gam0 * v0.d + a.gam1 * v1.d + div(dv[0] * beta_dt, rvol);
-          v0.m1 = a.gam0 * v0.m1 + a.gam1 * v1.m1 + div(dv[1] * beta_dt, rvol);
-          v0.m2 = a.gam0 * v0.m2 + a.gam1 * v1.m2 + div(dv[2] * beta_dt, rvol);
-          v0.m3 = a.gam0 * v0.m3 + a.gam1 * v1.m3 + div(dv[3] * beta_dt, rvol);
+          v0.d = a.gam0 * v0.d + a.gam1 * v1.d + GD(dv[0] * beta_dt, rvol);
+          v0.m1 = a.gam0 * v0.m1 + a.gam1 * v1.m1 + GD(dv[1] * beta_dt, rvol);
+          v0.m2 = a.gam0 * v0.m2 + a.gam1 * v1.m2 + GD(dv[2] * beta_dt, rvol);
+          v0.m3 = a.gam0 * v0.m3 + a.gam1 * v1.m3 + GD(dv[3] * beta_dt, rvol);
           if (a.grav_on) gravity_dust(ga, bdt, hx, wd, v0);
           if (a.rf_on) shear_dust(sa, bdt, wd, v0);
           ud[n] = v0;
@@ -352,6 +371,12 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
         double dmom[ND > 0 ? ND : 1][3];
 #pragma unroll
         for (int n = 0; n < ND; ++n) dmom[n][0] = ud[n].m1, dmom[n][1] = ud[n].m2, dmom[n][2] = ud[n].m3;
+        { // updated momenta whose quotients the hand-scheduled division would not round like `/`: IEEE for this row
+          bool tm = tiny_mom(mnew[0]) || tiny_mom(mnew[1]) || tiny_mom(mnew[2]);
+#pragma unroll
+          for (int n = 0; n < ND; ++n) tm = tm || tiny_mom(dmom[n][0]) || tiny_mom(dmom[n][1]) || tiny_mom(dmom[n][2]);
+          if (__any(tm)) fast = false;
+        }
         if constexpr (DRAG) {
           const artemis_drag_t &D = a.drag;
           const double xv[3] = {co.x1v(), co.x2v(), co.x3v()};
@@ -370,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
           double vg[3];
           if (fastdiv) {
             const Recip rg = recip(dg); // hx * dg == dg (hx = 1)
-            vg[0] = div(mg[0], rg), vg[1] = div(mg[1], rg), vg[2] = div(mg[2], rg);
+            vg[0] = GD(mg[0], rg), vg[1] = GD(mg[1], rg), vg[2] = GD(mg[2], rg);
           } else {
             vg[0] = mg[0] / (hx[0] * dg), vg[1] = mg[1] / (hx[1] * dg), vg[2] = mg[2] / (hx[2] * dg);
           }
@@ -379,10 +404,10 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
             const double u_d = amax(dg, fg.dfloor);
             const Recip ru = recip(u_d); // floored: positive
             const double rv1 = mg[0] / hx[0], rv2 = mg[1] / hx[1], rv3 = mg[2] / hx[2];
-            const double ke = div(0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)), ru);
+            const double ke = GD(0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)), ru);
             const double e_cons = u0.e;
             const double ue_cons = e_cons - ke;
-            sieg = div((ue_cons > fg.de_switch * e_cons) ? ue_cons : u0.eg, ru);
+            sieg = GD((ue_cons > fg.de_switch * e_cons) ? ue_cons : u0.eg, ru);
             sieg = amax(sieg, fg.siefloor);
           }
           const double mu = 0.0; // damp_to_visc is not routed here (stage2d_covers refuses it)
@@ -402,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
             const double dens = ud[n].d;
             if (fastdiv) {
               const Recip rdn = recip(dens);
-              vdv[n][0] = div(dmom[n][0], rdn), vdv[n][1] = div(dmom[n][1], rdn), vdv[n][2] = div(dmom[n][2], rdn);
+              vdv[n][0] = GD(dmom[n][0], rdn), vdv[n][1] = GD(dmom[n][1], rdn), vdv[n][2] = GD(dmom[n][2], rdn);
             } else {
               vdv[n][0] = dmom[n][0] / (hx[0] * dens), vdv[n][1] = dmom[n][1] / (hx[1] * dens), vdv[n][2] = dmom[n][2] / (hx[2] * dens);
             }
@@ -411,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
             const double alpha = bdt * ((tc <= 0.0) ? DBL_MAX : 1.0 / tc);
             alph[n] = alpha;
             for (int d = 0; d < 3; d++) {
-              const double rhop = div(dens * alpha, recip(1.0 + alpha + bd[d]));
+              const double rhop = GD(dens * alpha, recip(1.0 + alpha + bd[d]));
               rhopv[n][d] = rhop;
               fdd[d] += rhop * (1.0 + bd[d]);
               fvd[d] += rhop * (vdv[n][d] + bd[d] * vdt[d]);
@@ -420,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
           double vgp[3];
           for (int d = 0; d < 3; d++) {
             const double num = (dg * (vg[d] + bg[d] * vt[d]) + fvd[d]), den = (dg * (1.0 + bg[d]) + fdd[d]);
-            vgp[d] = (__all(normal_pos(den) || !owned) != 0) ? div(num, recip(den)) : num / den;
+            vgp[d] = (__all(normal_pos(den) || !owned) != 0) ? GD(num, recip(den)) : num / den;
           }
           double delta_g[3] = {0.0, 0.0, 0.0};
           for (int d = 0; d < 3; d++) fvd[d] = 0.;
@@ -436,14 +461,14 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
               const double delta = rhop * ((vgp[d] - vd[d] + bd[d] * (vgp[d] - vdt[d])));
               delta_d += delta;
               delta_g[d] -= delta;
-              delta_d -= div(bd[d] * dens, recip(1. + alpha + bd[d])) * (vd[d] - vdt[d] + alpha * (vgp[d] - vdt[d]));
+              delta_d -= GD(bd[d] * dens, recip(1. + alpha + bd[d])) * (vd[d] - vdt[d] + alpha * (vgp[d] - vdt[d]));
               fvd[d] += rhop * (vd[d] - vt[d] + bd[d] * (vdt[d] - vt[d]));
               newm[d] = dmom[n][d] + hx[d] * delta_d;
             }
             dmom[n][0] = newm[0], dmom[n][1] = newm[1], dmom[n][2] = newm[2];
           }
           for (int d = 0; d < 3; d++) {
-            const double prefac = div(dg * bg[d], recip(1.0 + bg[d] + fdd[d])); // denominator >= 1
+            const double prefac = GD(dg * bg[d], recip(1.0 + bg[d] + fdd[d])); // denominator >= 1
             delta_g[d] -= prefac * (dg * (vg[d] - vt[d]) + fvd[d]);
             mnew[d] = mg[d] + hx[d] * delta_g[d];
             en += 0.5 * (vg[d] + vgp[d]) * delta_g[d];
@@ -456,15 +481,15 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
           const double dens = ud[n].d;
           const double w_d = (dens > fd.dfloor) ? dens : fd.dfloor;
           const Recip rwd = recip(w_d); // floored; w_d * hx == w_d (hx = 1)
-          const double w1 = div(dmom[n][0], rwd), w2 = div(dmom[n][1], rwd), w3 = div(dmom[n][2], rwd);
+          const double w1 = GD(dmom[n][0], rwd), w2 = GD(dmom[n][1], rwd), w3 = GD(dmom[n][2], rwd);
           gst(a.dout[b * 4 * ND + n], c, w_d);
           gst(a.dout[b * 4 * ND + ND + 3 * n + 0], c, w1);
           gst(a.dout[b * 4 * ND + ND + 3 * n + 1], c, w2);
           gst(a.dout[b * 4 * ND + ND + 3 * n + 2], c, w3);
           if (a.dt_bits) { // Dust::EstimateTimestepMesh (dust.cpp:256-272)
             double denom = 0.0;
-            denom += div(fabs(w1), rdx0); // 1.0 * dx == dx
-            denom += div(fabs(w2), rdx1);
+            denom += GD(fabs(w1), rdx0); // 1.0 * dx == dx
+            denom += GD(fabs(w2), rdx1);
             ldt_d = amin(ldt_d, 1.0 / denom); // (IEEE: a dust at rest gives 1 / 0 = inf like the reference)
           }
         }
@@ -475,27 +500,27 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
           const double u_d2 = amax(dgas, fg.dfloor);
           const Recip r2 = recip(u_d2), rw = recip(u_d); // floored densities (equal unless the state is NaN)
           const double rv1 = mnew[0] / hx[0], rv2 = mnew[1] / hx[1], rv3 = mnew[2] / hx[2];
-          const double ke = div(0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)), r2);
+          const double ke = GD(0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)), r2);
           const double ue_cons = en - ke;
-          double sie = div((ue_cons > fg.de_switch * en) ? ue_cons : u0.eg, r2);
+          double sie = GD((ue_cons > fg.de_switch * en) ? ue_cons : u0.eg, r2);
           sie = amax(sie, fg.siefloor);
           double u_u = sie * u_d;
           const double uflr = fg.siefloor * u_d;
           u_u = (u_u > uflr) ? u_u : uflr;
           const double w_d = u_d;
-          const double w1 = div(mnew[0], rw), w2 = div(mnew[1], rw), w3 = div(mnew[2], rw);
-          double w_s = div(u_u, rw);
+          const double w1 = GD(mnew[0], rw), w2 = GD(mnew[1], rw), w3 = GD(mnew[2], rw);
+          double w_s = GD(u_u, rw);
           w_s = (w_s > fg.siefloor) ? w_s : fg.siefloor;
           gst(a.gout[b * 6 + 0], c, w_d);
           gst(a.gout[b * 6 + 1], c, w1), gst(a.gout[b * 6 + 2], c, w2), gst(a.gout[b * 6 + 3], c, w3);
           gst(a.gout[b * 6 + 5], c, w_s);
           if (a.dt_bits) { // Gas::EstimateTimestepMesh (gas.cpp:411-433)
             const double bulk = (gm1 + 1.0) * gm1 * w_d * w_s;
-            const double cs = sqrt_pos(div(bulk, rw)); // positive: floored density and sie
+            const double cs = sqrt_pos(GD(bulk, rw)); // positive: floored density and sie
             double denom = 0.0;
-            denom += div(fabs(w1) + cs, rdx0);
-            denom += div(fabs(w2) + cs, rdx1);
-            ldt_g = amin(ldt_g, div(1.0, recip(denom)));
+            denom += GD(fabs(w1) + cs, rdx0);
+            denom += GD(fabs(w2) + cs, rdx1);
+            ldt_g = amin(ldt_g, GD(1.0, recip(denom)));
           }
         }
       }

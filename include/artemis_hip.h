@@ -326,7 +326,18 @@ int artemis_hip_cooling_source(const artemis_pack_t *p, const artemis_cooling_t 
  *               EstimateTimestepMesh for the last stage).
  * Results are bit-identical to the unfused sequence above. Gas only (dust: DESIGN.md).
  * The P entries of prim_out are written; ghosts of prim_out are NOT touched (apply_bc /
- * halo exchange follow, as in the reference). */
+ * halo exchange follow, as in the reference).
+ *
+ * Exactness next to vanishing velocities (detect-and-redo).  The kernel divides through hand-scheduled refined
+ * reciprocals, which give the bits of an IEEE division unless a numerator is non-zero and below 2^-969 -- reachable only
+ * from velocities below 2^-200 (1e-61: ahead of a shock the limited slopes square the perturbation from zone to zone).
+ * A zone whose stencil holds such a velocity is therefore NOT stored by the kernel; its id goes to a list (library-owned,
+ * per calling thread) and a second, list-driven kernel enqueued behind it on `stream` by the same call computes it with
+ * IEEE arithmetic from prim_in / prim_u1.  The list is normally empty; ARTEMIS_NO_REDO=1 switches the mechanism off
+ * (every zone is then stored by the fast kernel: the pre-round-3 behaviour with its 1e-120 parity limit).  The one case
+ * the call cannot finish by itself is the shell of a shell-first launch (shell_done != NULL): those zones must be
+ * final before the stream that waits for the shell packs them -- call artemis_hip_stage_fused_redo_shell with the same
+ * arguments on THAT stream, after artemis_hip_wait_counter. */
 typedef struct artemis_stage_args {
   double gam0, gam1, beta_dt; /* LowStorageIntegrator weights, artemis_integrator.hpp:64-66 */
   double bdt;                 /* beta*dt handed to FluxSource, artemis_driver.cpp:168,211 */
@@ -353,6 +364,7 @@ typedef struct artemis_stage_args {
                                  whose ghosts are cut from this block; 0 = all six */
 } artemis_stage_args_t;
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
+int artemis_hip_stage_fused_redo_shell(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
 /* ---- gas diffusion (viscosity, heat conduction) ------------------------------------------
  * Gas::ZeroDiffusionFlux / ViscousFlux<GEOM> / ThermalFlux<GEOM> / DiffusionUpdate<GEOM>
  * (gas.cpp:522-641 -> utils/diffusion/{diffusion,momentum_diffusion,thermal_diffusion}.hpp),

@@ -184,9 +184,9 @@ def test_disk_with_planet_dust_and_adaptive_mesh(hiplib):
 # ---- HIP driver == the independent adaptive oracle -----------------------------------------------------------------
 @pytest.mark.parametrize("name,kw,cycles,batch,min_remeshes,levels", [
     ("blast_amr", dict(n=128, derefine_count=5), 120, 20, 6, {0, 1, 2}),        # the deck's own 128^2 root mesh
-    ("linear_wave_amr", dict(derefine_count=3), 80, 20, 6, {0, 1}),            # as shipped
+    ("linear_wave_amr", dict(derefine_count=3), 100, 20, 5, {0, 1}),           # as shipped
     ("disk_planet_dust_amr", dict(), 40, 10, 8, {1, 2, 3}),                    # BASELINE configs[4], numlevel = 4
-    ("disk_planet_dust_amr", dict(n=64, thr=0.5), 20, 10, 3, {1, 2, 3}),       # the same on a 64^2 root (300+ blocks)
+    ("disk_planet_dust_amr", dict(n=64, thr=0.5), 20, 10, 2, {1, 2, 3}),       # the same on a 64^2 root (300+ blocks)
 ])
 def test_hip_driver_equals_adaptive_oracle(hiplib, name, kw, cycles, batch, min_remeshes, levels):
     """The HIP driver against oracle/adaptive.py (an independent restatement of the remeshing: tests/amr_cases.py,

@@ -110,10 +110,10 @@ def test_general_stage_hydro(hiplib, nx, lo, hi, nsg, nsd, recon, riem, driem, c
 
 @pytest.mark.parametrize("case", [6, 9])
 def test_row_march_kernel_with_vanishing_velocities(hiplib, case):
-    """The 2-D row-march kernel shares the tuned Cartesian kernel's hand-scheduled divisions and therefore its stated
-    limit (DESIGN.md section 4, test_parity_fused.py::test_fused_step_with_vanishing_velocities): next to velocities
-    of 1e-150 .. 1e-320 every gas and dust value of magnitude >= 1e-120 is bit-identical to the oracle, the others
-    agree to 1e-135 absolute."""
+    """The 2-D row-march kernel shares the tuned Cartesian kernel's hand-scheduled divisions; a wave whose five-row
+    window holds a gas or dust velocity below 2^-200 (or whose updated momenta come out below 2^-480) takes IEEE
+    divisions for that row (kernels_stage2d.hip `fast`).  Next to velocities of 1e-150 .. 1e-320, exact zeros and
+    ordinary values every gas and dust value equals the oracle's bit for bit."""
     nx, lo, hi, nsg, nsd, recon, riem, driem, coords, ng = CASES[case]
     o, mb = build(nx, lo, hi, nsg, nsd, recon, riem, driem, coords, ng, seed=33)
     rng = np.random.default_rng(9)
@@ -140,11 +140,8 @@ def test_row_march_kernel_with_vanishing_velocities(hiplib, case):
     if nsd:
         pairs.append((dbuf[0][I].cpu().numpy(), o.dprim[I], "dust"))
     for got, ref, what in pairs:
-        big = np.abs(ref) >= 1e-120
-        bad = big & (got != ref)
-        assert not bad.any(), f"{what}: {np.count_nonzero(bad)} entries above 1e-120 differ, the largest {np.abs(ref[bad]).max():.3e}"
-        err = np.abs(got[~big] - ref[~big])
-        assert np.all(err < 1e-135), f"{what}: {err.max():.3e}"
+        bad = got != ref
+        assert not bad.any(), f"{what}: {np.count_nonzero(bad)} entries differ, the largest of magnitude {np.abs(ref[bad]).max():.3e}"
 
 
 @pytest.mark.parametrize("case", [1, 4, 5, 7, 8, 9])
