@@ -71,6 +71,7 @@ class StageArgs(C.Structure):
         ("cfl", C.c_double), ("dt_dev", C.c_void_p), ("region", C.c_int),
         ("shell_done", C.c_void_p), ("shell_target", C.POINTER(C.c_uint)),
         ("beta_dt_dev", C.c_void_p), ("shell_faces", C.c_int),
+        ("tiny_in", C.c_void_p), ("tiny_out", C.c_void_p), ("tiny_clear", C.c_void_p),
     ]
 
 

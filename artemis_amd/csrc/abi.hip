@@ -592,6 +592,7 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
   const int rc = artemis::launch_stage_fused(artemis::make_pack_view(*p), *a, p->gas.riemann, recon,
                                              S(stream));
   if (rc == 5) return fail(ARTEMIS_HIP_EDEVICE, "fused stage: no memory for the redo lists");
+  if (rc == 6) return fail(ARTEMIS_HIP_EUNSUPPORTED, "fused stage: mesh blocks of 2^29 zones or more (ghost zones included) are not addressed by the tile march");
   if (rc) return fail(ARTEMIS_HIP_EUNSUPPORTED, "fused stage: configuration not built (rc=%d)", rc);
   return after_launch("stage_fused");
 }

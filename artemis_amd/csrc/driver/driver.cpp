@@ -282,6 +282,12 @@ struct artemis_sim_impl {
   int general_variant = -1; // what artemis_hip_stage_general ran last (artemis_hip_stage_general_variant)
   int overlap = 0; // 0 off, 1 shell launch + bulk launch, 2 one launch with in-kernel shell signalling
   DevBuf signal; // [0] shell-done counter, [1] wait-kernel timeout flag (as 32-bit words)
+  // artemis_stage_args_t.tiny_in / tiny_out / tiny_clear: one 32-bit word per stage of a step through which a tuned stage
+  // tells the next one whether ANY velocity below 2^-200 exists in the state it wrote; without one the next stage
+  // skips the per-zone detection.  Valid while this driver is the only producer of the primitives: one rank (halo
+  // slabs from other ranks are not scanned), copy-type physical conditions, consecutive tuned stages.
+  DevBuf tiny_words;
+  bool tiny_valid = false;
   bool shell_wait_used = false; // an overlap-2 stage ran since the flag was last cleared
   // "drop-in" accounting mode of the tuned path (bench.py): the last stage also writes the conserved state and
   // every stage ends with the whole-block PrimToCons a Parthenon host runs as FillDerived (artemis_driver.cpp:261)
@@ -1209,6 +1215,7 @@ void artemis_sim_impl::allocate() {
   dt_dev.alloc(1);
   tstate.alloc(6);
   signal.alloc(2);
+  tiny_words.alloc(2); // (up to four 32-bit words: nstages <= 3)
   dt_host = static_cast<double *>(artemis_rt_malloc_host(sizeof(double)));
   if (!dt_host) throw HipFail("pinned allocation failed");
   gprim[0].alloc(nb, 6 * ns_gas, N);
@@ -2262,6 +2269,7 @@ Real artemis_sim_impl::new_dt_unfused() {
 // SetAuxillaryFields / ConsToPrim trio when drag couples the fluids), primitives of both fluids
 // ping-ponged between buffers exactly like the tuned path.
 void artemis_sim_impl::step_general(bool want_dt, bool device_dt) {
+  tiny_valid = false; // (another producer of the primitives)
   for (int q = 1; q < 3; ++q) {
     if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
     if (!dprim[q].ok()) dprim[q].alloc(nb, 4 * ns_dust, N);
@@ -2360,6 +2368,22 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
     bool any_remote = false;
     int faces = 0; // faces through which some block of the pack feeds a neighbour
     for (auto &L : links) any_remote = any_remote || remote(*L), faces |= (1 << L->face);
+    {
+      bool copy_bcs = true; // conditions that only copy zones this driver wrote (a user condition computes new values)
+      for (int f = 0; f < 6; ++f)
+        copy_bcs = copy_bcs && (mesh_bc[f] == ARTEMIS_BC_PERIODIC || mesh_bc[f] == ARTEMIS_BC_OUTFLOW ||
+                                mesh_bc[f] == ARTEMIS_BC_REFLECT || mesh_bc[f] == ARTEMIS_BC_NONE);
+      if (!any_remote && !loopback && copy_bcs && nstages >= 2 && std::getenv("ARTEMIS_NO_TINY_HINT") == nullptr) {
+        // word q describes the state before stage q + 1 of a step (the same pointers every step: a captured
+        // graph of one step stays valid); the state after the last stage is the next step's word 0
+        unsigned *w = reinterpret_cast<unsigned *>(tiny_words.p);
+        a.tiny_in = tiny_valid ? w + (stage - 1) : nullptr;
+        a.tiny_out = w + (stage % nstages), a.tiny_clear = w + (stage - 1);
+        tiny_valid = true;
+      } else {
+        tiny_valid = false;
+      }
+    }
     a.shell_faces = faces;
     // (ARTEMIS_FORCE_OVERLAP=1: diagnostic, shell-first ordering even when every link is local)
     const bool force_ovl = std::getenv("ARTEMIS_FORCE_OVERLAP") != nullptr;
@@ -2431,6 +2455,7 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
 
 // One step on the per-task path (artemis_driver.cpp:157-261 literally).
 void artemis_sim_impl::step_unfused() {
+  tiny_valid = false; // (another producer of the primitives)
   ensure_unfused();
   materialise_cons();
   const artemis_pack_t p = make_pack(base);

@@ -17,10 +17,18 @@ typedef const double __attribute__((address_space(1))) *gcptr;
 typedef double __attribute__((address_space(1))) *gptr;
 ADEV double gld(const double *p, long c) { return ((gcptr)p)[c]; }
 ADEV void gst(double *p, long c, double v) { ((gptr)p)[c] = v; }
+// The same with a 32-bit element index: the byte offset c * 8 is formed in 32 bits and zero-extended, i.e. exactly the
+// `global_load ... v_off, s[base:base+1]` form (uniform 64-bit base in SGPRs + one 32-bit VGPR offset shared by every
+// array of the cell) -- no 64-bit address arithmetic per load.  Callers guarantee arrays below 2^29 elements (4 GiB).
+typedef const char __attribute__((address_space(1))) *gcbytes;
+typedef char __attribute__((address_space(1))) *gbytes;
+ADEV double gld(const double *p, unsigned c) { return *(gcptr)((gcbytes)p + (c << 3)); }
+ADEV void gst(double *p, unsigned c, double v) { *(gptr)((gbytes)p + (c << 3)) = v; }
 
+template <class IDX>
 ADEV Cell6 load_cell(const double *__restrict__ r, const double *__restrict__ v1,
                      const double *__restrict__ v2, const double *__restrict__ v3,
-                     const double *__restrict__ se, long c, double gm1) {
+                     const double *__restrict__ se, IDX c, double gm1) {
   Cell6 q;
   q.d = gld(r, c), q.v1 = gld(v1, c), q.v2 = gld(v2, c), q.v3 = gld(v3, c), q.e = gld(se, c);
   q.p = amax(0.0, gm1 * q.d * q.e); // fill_derived.cpp:247 (IdealGas P)

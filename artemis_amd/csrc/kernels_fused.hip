@@ -70,6 +70,8 @@ struct StageK {
   unsigned *redo_cnt0, *redo_cnt1;
   unsigned long long *redo_list0, *redo_list1;
   unsigned redo_cap; // entries per list (>= the zones of the launch, so it only binds if a shell list is never drained)
+  const unsigned *tiny_in; // artemis_stage_args_t: detection runs only if *tiny_in != 0 (null: always)
+  unsigned *tiny_out;
 };
 
 struct LdsTile {
@@ -90,13 +92,13 @@ using namespace fused;
 struct Ctx { // per-thread constants of the march
   int tx, ty, t, b, i0, j0;
   bool active, multi_d, three_d;
-  long col, sj, sk;
+  unsigned col, sj, sk; // element offsets in 32 bits (arrays below 2^29 elements: launch_* check it)
   double dx1, dx2, gm1;
   double beta_dt, bdt; // artemis_integrator.hpp:66, artemis_driver.cpp:168
   GasK gk;
   Recip rdx1, rdx2;
   int hr, hc;   // LDS slot (Q row/col) of the halo cell this thread stages, or hr < 0
-  long hcol;    // its column offset within a plane
+  unsigned hcol; // its column offset within a plane
   const double *g;
   const double *in_r, *in_1, *in_2, *in_3, *in_e;
 };
@@ -181,7 +183,7 @@ struct Raw5 { // a cell's five stored primitives, as loaded (pressure not yet de
   double d, v1, v2, v3, e;
 };
 ADEV Raw5 load_raw(const double *r, const double *v1, const double *v2, const double *v3,
-                   const double *se, long c) {
+                   const double *se, unsigned c) {
   Raw5 q;
   q.d = gld(r, c), q.v1 = gld(v1, c), q.v2 = gld(v2, c), q.v3 = gld(v3, c), q.e = gld(se, c);
   return q;
@@ -227,13 +229,15 @@ ADEV bool tiny_v(const Cell6 &q) { return tiny_vel3(q.v1, q.v2, q.v3); }
 template <int RIEMANN, int RECON, bool D3, bool CURV, bool GUARD, bool DETECT, class TILE>
 ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CURV> &gx, const int k,
                        const Cell6 &qc, const bool stage_next, const Cell6 &qn, const Raw5 &hal_next,
-                       Flux8 &fx_lo, Flux8 &fy_lo, bool &flagged) {
+                       Flux8 &fx_lo, Flux8 &fy_lo, bool &flagged, const bool det = true) {
   constexpr bool PG = CURV && RECON == 1; // PLM_G instead of the uniform-mesh slope
   bool fastp = true; // every division hand-scheduled (no tiny velocity in this plane's tile)
   if constexpr (GUARD || DETECT) {
-    flagged = (tiny_flag(S, k & 1) != 0);
-    if constexpr (GUARD) fastp = !flagged;
-    if (x.t == 0) tiny_flag(S, (k + 1) & 1) = 0; // set again when the next plane is staged (after the barrier)
+    if (GUARD || det) { // (det: wave-uniform, the stage's input may hold a tiny velocity at all)
+      flagged = (tiny_flag(S, k & 1) != 0);
+      if constexpr (GUARD) fastp = !flagged;
+      if (x.t == 0) tiny_flag(S, (k + 1) & 1) = 0; // set again when the next plane is staged (after the barrier)
+    }
   }
   const int tx = x.tx, ty = x.ty;
   const bool multi_d = D3 || x.multi_d; // compile-time true in the 3-D instantiation
@@ -333,27 +337,42 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
     if (ty > 0) { PUT8(S.FY, fy_lo, [ty - 1][tx]); }
   }
   if (t >= 64 && t < 128) { // lanes 0..7: x1 face i0+32 per row; lanes 32..63: x2 face j0+8
+    // ONE Riemann pass for both kinds of perimeter face: the x2 lanes hand the solver their states with the velocity
+    // components rotated (v2, v3, v1) -- which is what solve_face<.., 2> does internally (hllc.hpp:67-69) -- and rotate
+    // the momentum fluxes back, so the duty wave runs three solver passes per plane instead of four (same bits).
     const int u = t - 64;
-    if (u < FTY) {
-      Cell6 l, r;
-      GET6(l, S.UPX, [u][FTX]);
-      GET6(r, S.LOX, [u]);
-      Flux8 fe_ = solve_face<RIEMANN, 1>(x.gk, l, r, fastp);
-      if constexpr (CURV) fe_.m2 *= S.HF1[u][0], fe_.m3 *= S.HF1[u][1]; // the face below cell (j0+u, i0+32)
-      PUT8(S.FX, fe_, [u][FTX - 1]);
-    } else if (multi_d && u >= 32) {
+    const bool isx = (u < FTY), isy = multi_d && (u >= 32);
+    if (isx || isy) {
       const int cx = u - 32;
       Cell6 l, r;
-      GET6(l, S.UPY, [FTY][cx]);
-      GET6(r, S.LOY, [cx]);
-      Flux8 fe_ = solve_face<RIEMANN, 2>(x.gk, l, r, fastp);
-      if constexpr (CURV) fe_.m2 *= S.HF2[cx][0], fe_.m3 *= S.HF2[cx][1]; // the face below cell (j0+8, i0+cx)
-      PUT8(S.FY, fe_, [FTY - 1][cx]);
+      if (isx) {
+        GET6(l, S.UPX, [u][FTX]);
+        GET6(r, S.LOX, [u]);
+      } else {
+        GET6(l, S.UPY, [FTY][cx]);
+        GET6(r, S.LOY, [cx]);
+        double a_ = l.v1;
+        l.v1 = l.v2, l.v2 = l.v3, l.v3 = a_;
+        a_ = r.v1;
+        r.v1 = r.v2, r.v2 = r.v3, r.v3 = a_;
+      }
+      Flux8 fe_ = solve_face<RIEMANN, 1>(x.gk, l, r, fastp);
+      if (isx) {
+        if constexpr (CURV) fe_.m2 *= S.HF1[u][0], fe_.m3 *= S.HF1[u][1]; // the face below cell (j0+u, i0+32)
+        PUT8(S.FX, fe_, [u][FTX - 1]);
+      } else {
+        const double n_ = fe_.m1; // (normal, t1, t2) = (m2, m3, m1) of the block's frame
+        fe_.m1 = fe_.m3, fe_.m3 = fe_.m2, fe_.m2 = n_;
+        if constexpr (CURV) fe_.m2 *= S.HF2[cx][0], fe_.m3 *= S.HF2[cx][1]; // the face below cell (j0+8, i0+cx)
+        PUT8(S.FY, fe_, [FTY - 1][cx]);
+      }
     }
   }
   if (stage_next) {
     stage_plane(S, x, qn, hal_next);
-    if constexpr (GUARD || DETECT) stage_plane_flag(S, x, qn, hal_next, (k + 1) & 1);
+    if constexpr (GUARD || DETECT) {
+      if (GUARD || det) stage_plane_flag(S, x, qn, hal_next, (k + 1) & 1);
+    }
   }
   __syncthreads();
 }
@@ -369,7 +388,7 @@ ADEV void plane_store_fluxes(TILE &S, const PackView &P, const Ctx &x, const int
   const int tx = x.tx, ty = x.ty;
   const bool multi_d = D3 || x.multi_d;
   const FluidView &f = P.gas;
-  const long c = x.col + static_cast<long>(k) * x.sk;
+  const long c = static_cast<long>(x.col + static_cast<unsigned>(k) * x.sk);
   const int b6 = x.b * 6;
   auto put = [&](int d, const Flux8 &fl, long at) {
     f.flux[d][b6 + 0][at] = fl.d;
@@ -404,7 +423,7 @@ ADEV void plane_store_fluxes(TILE &S, const PackView &P, const Ctx &x, const int
 // `bad`: the zone's stencil holds a tiny velocity (the caller's plane flag and own-column bits).  Such a zone -- and one
 // whose updated momenta come out tiny -- keeps its hands off memory: no store, no contribution to dt; its id goes to
 // the redo list and stage_redo_kernel computes it with IEEE arithmetic.
-ADEV void redo_append(const StageK &a, const PackView &P, int b, long c, bool shell_wg) {
+ADEV void redo_append(const StageK &a, const PackView &P, int b, unsigned c, bool shell_wg) {
   unsigned *cnt = shell_wg ? a.redo_cnt1 : a.redo_cnt0;
   unsigned long long *list = shell_wg ? a.redo_list1 : a.redo_list0;
   const unsigned at = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -430,7 +449,7 @@ ADEV void plane_update(TILE &S, const PackView &P, const StageK &a, const Ctx &x
   const double ax1 = dx2 * dx3, ax2 = dx1 * dx3, ax3 = dx1 * dx2; // geometry.hpp:199-216
   const double vol = dx1 * dx2 * dx3;                             // geometry.hpp:219-225
   const int b = x.b;
-  const long c = x.col + static_cast<long>(k) * x.sk;
+  const unsigned c = x.col + static_cast<unsigned>(k) * x.sk;
   // u0 = PrimToCons(prim_in), u1 = PrimToCons(prim_u1)  (fill_derived.cpp:226-255)
   const double D0 = qc.d;
   const double M10 = qc.d * qc.v1 * 1.0, M20 = qc.d * qc.v2 * 1.0, M30 = qc.d * qc.v3 * 1.0;
@@ -494,6 +513,9 @@ ADEV void plane_update(TILE &S, const PackView &P, const StageK &a, const Ctx &x
   double w_s = div(G, rd);
   w_s = (w_s > f.siefloor) ? w_s : f.siefloor;
   const double w_p = amax(0.0, gm1 * w_d * w_s); // fill_derived.cpp:247
+  if (a.tiny_out) { // report a vanishing velocity to the stage that will read this state (artemis_stage_args_t.tiny_out)
+    if (tiny_vel3(w1, w2, w3)) __hip_atomic_fetch_or(a.tiny_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   gst(a.prim_out[b * 6 + 0], c, w_d);
   gst(a.prim_out[b * 6 + 1], c, w1);
   gst(a.prim_out[b * 6 + 2], c, w2);
@@ -558,7 +580,7 @@ ADEV void plane_update_curv(TILE &S, const PackView &P, const StageK &a, const S
   if (!x.active) return;
   const FluidView &f = P.gas;
   const int b = x.b;
-  const long c = x.col + static_cast<long>(k) * x.sk;
+  const unsigned c = x.col + static_cast<unsigned>(k) * x.sk;
   DCoords co = gx.co; // (c3 / s3 of this plane were fetched at the top of the trip)
   co.x3[0] = x.g[4] + k * x.g[5], co.x3[1] = x.g[4] + (k + 1) * x.g[5];
   const CellMetric g = cell_metric_of(co);
@@ -733,8 +755,8 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
   x.in_r = a.prim_in[x.b * 6 + 0], x.in_1 = a.prim_in[x.b * 6 + 1];
   x.in_2 = a.prim_in[x.b * 6 + 2], x.in_3 = a.prim_in[x.b * 6 + 3];
   x.in_e = a.prim_in[x.b * 6 + 5];
-  x.sj = P.sj, x.sk = P.sk;
-  x.col = static_cast<long>(jl) * x.sj + il;
+  x.sj = static_cast<unsigned>(P.sj), x.sk = static_cast<unsigned>(P.sk);
+  x.col = static_cast<unsigned>(jl) * x.sj + static_cast<unsigned>(il);
   // geometry.hpp:65-72: widths along x1 and x2 do not change along the march
   x.dx1 = (x.g[0] + (i + 1) * x.g[1]) - (x.g[0] + i * x.g[1]);
   x.dx2 = (x.g[2] + (j + 1) * x.g[3]) - (x.g[2] + j * x.g[3]);
@@ -754,7 +776,7 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
   if (x.hr >= 0) {
     const int gi = min(max(x.i0 - FH + x.hc, 0), P.ni - 1);
     const int gj = min(max(x.j0 - FH + x.hr, 0), P.nj - 1);
-    x.hcol = static_cast<long>(gj) * x.sj + gi;
+    x.hcol = static_cast<unsigned>(gj) * x.sj + static_cast<unsigned>(gi);
   }
   double ldt = DBL_MAX;
   GeoCtx<CURV> gx;
@@ -798,6 +820,11 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
 #define ARTEMIS_DETECT 1
 #endif
   constexpr bool DETECT = !CURV && !FLUXES && (ARTEMIS_DETECT != 0);
+  // ... and only in stages whose input may hold such a velocity (wave-uniform; artemis_stage_args_t.tiny_in)
+  bool detect = DETECT && a.redo_cnt0 != nullptr;
+  if constexpr (DETECT) {
+    if (detect && a.tiny_in) detect = (*a.tiny_in != 0u);
+  }
   if constexpr (GUARD || DETECT) {
     if (x.t == 0) tiny_flag(S, 0) = tiny_flag(S, 1) = 0;
     __syncthreads(); // the flags are cleared before any wave sets one for the first staged plane (and the tables are in)
@@ -816,14 +843,16 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
     Raw5 hal = u1raw;
     if (x.hr >= 0) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + k0 * x.sk);
     stage_plane(S, x, qc, hal);
-    if constexpr (GUARD || DETECT) stage_plane_flag(S, x, qc, hal, k0 & 1);
+    if constexpr (GUARD || DETECT) {
+      if (GUARD || detect) stage_plane_flag(S, x, qc, hal, k0 & 1);
+    }
     __syncthreads();
     bool flagged = false;
-    plane_sweeps<RIEMANN, RECON, false, CURV, GUARD, DETECT>(S, P, x, gx, k0, qc, false, qc, hal, fx_lo, fy_lo, flagged);
+    plane_sweeps<RIEMANN, RECON, false, CURV, GUARD, DETECT>(S, P, x, gx, k0, qc, false, qc, hal, fx_lo, fy_lo, flagged, detect);
     if constexpr (CURV) {
       DFlux24 df{};
       if (gx.m3) gx.co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k0], gx.co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k0];
-      if (src.v.diff_on) df = load_dflux(P, x.b, x.col + k0 * x.sk, x.multi_d, false);
+      if (src.v.diff_on) df = load_dflux(P, x.b, static_cast<long>(x.col + static_cast<unsigned>(k0) * x.sk), x.multi_d, false);
       plane_update_curv<HAS_U1, WITH_DT, false>(S, P, a, src.v, x, gx, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, df, ldt);
     }
     else if constexpr (FLUXES) plane_store_fluxes<false>(S, P, x, k0, fx_lo, fy_lo, fz, fz);
@@ -844,7 +873,9 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
     {
       const Cell6 qmm =
           load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k0 - 2) * x.sk, x.gm1);
-      if constexpr (DETECT) fhist = __any(tiny_v(qmm) || tiny_v(qc)) ? 3u : 0u, ahead1 = tiny_v(qn); // planes k0-2, k0-1 (not staged by this chunk); k0
+      if constexpr (DETECT) {
+        if (detect) fhist = __any(tiny_v(qmm) || tiny_v(qc)) ? 3u : 0u, ahead1 = tiny_v(qn); // planes k0-2, k0-1 (not staged by this chunk); k0
+      }
       if constexpr (CURV && RECON == 1) {
         const PlmGeo g3 = plm_geo_x3(gx.co, x.g, k0 - 1);
         double unused_;
@@ -866,33 +897,37 @@ __global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const Pac
       // their latency hides behind the x1/x2 sweeps (barriers do not drain vmcnt).
       const Raw5 rnn = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k + 2) * x.sk);
       if constexpr (HAS_U1) {
-        if (k >= k0) u1raw = load_raw(u1_r, u1_1, u1_2, u1_3, u1_e, x.col + static_cast<long>(k) * x.sk);
+        if (k >= k0) u1raw = load_raw(u1_r, u1_1, u1_2, u1_3, u1_e, x.col + static_cast<unsigned>(k) * x.sk);
       }
       // halo cell of plane k+1: staged at the end of this trip's P2, so its latency hides behind
       // the slopes and Riemann problems of plane k
       if (x.hr >= 0 && k < k1) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + (k + 1) * x.sk);
       DFlux24 df{};
       if constexpr (CURV) {
-        if (src.v.diff_on && k >= k0) df = load_dflux(P, x.b, x.col + static_cast<long>(k) * x.sk, true, true);
+        if (src.v.diff_on && k >= k0) df = load_dflux(P, x.b, static_cast<long>(x.col + static_cast<unsigned>(k) * x.sk), true, true);
         // cos / sin of this plane's x3 centre (spherical3D, axisymmetric), also ahead of their use
         if (gx.m3 && k >= k0) gx.co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k], gx.co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k];
       }
       Flux8 fx_lo, fy_lo;
       bool flagged = false;
       if (k >= k0) {
-        plane_sweeps<RIEMANN, RECON, true, CURV, GUARD, DETECT>(S, P, x, gx, k, qc, k < k1, qn, hal, fx_lo, fy_lo, flagged);
+        plane_sweeps<RIEMANN, RECON, true, CURV, GUARD, DETECT>(S, P, x, gx, k, qc, k < k1, qn, hal, fx_lo, fy_lo, flagged, detect);
       } else { // priming trip: stage the first plane
         stage_plane(S, x, qn, hal);
-        if constexpr (GUARD || DETECT) stage_plane_flag(S, x, qn, hal, k0 & 1);
+        if constexpr (GUARD || DETECT) {
+          if (GUARD || detect) stage_plane_flag(S, x, qn, hal, k0 & 1);
+        }
         __syncthreads();
       }
       // x3 sweep, registers only: slope of cell k+1, face k+1
       const Cell6 qnn = finish_cell(rnn, x.gm1);
       [[maybe_unused]] bool ahead = false;
       if constexpr (DETECT) { // planes k+1, k+2 of the own column (k+1 was tested as this trip's k+2 one trip ago)
-        const bool a2 = tiny_v(qnn);
-        ahead = ahead1 || a2;
-        ahead1 = a2;
+        if (detect) {
+          const bool a2 = tiny_v(qnn);
+          ahead = ahead1 || a2;
+          ahead1 = a2;
+        }
       }
       // face k+1 reads the own column's planes k-1 .. k+2: the three in registers decide for the wave (the slope of
       // cell k entered zl in the previous trip under that trip's check)
@@ -996,6 +1031,7 @@ struct RedoK {
   const double *bdt_ptr;
   double *const *prim_in, *const *prim_u1, *const *prim_out, *const *cons_out;
   unsigned long long *dt_bits;
+  unsigned *tiny_out, *tiny_clear;
   unsigned *cnt;   // entries in the list; reset to zero by the last workgroup of this kernel (no memset between stages)
   unsigned *done;  // its ticket counter
   unsigned cap;
@@ -1098,6 +1134,7 @@ __global__ __launch_bounds__(256) void stage_redo_kernel(const PackView P, const
     double w_s = G / w_d;
     w_s = (w_s > f.siefloor) ? w_s : f.siefloor;
     const double w_p = amax(0.0, P.gm1 * w_d * w_s); // fill_derived.cpp:247
+    if (a.tiny_out && tiny_vel3(w1, w2, w3)) __hip_atomic_fetch_or(a.tiny_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     a.prim_out[b * 6 + 0][c] = w_d, a.prim_out[b * 6 + 1][c] = w1, a.prim_out[b * 6 + 2][c] = w2;
     a.prim_out[b * 6 + 3][c] = w3, a.prim_out[b * 6 + 4][c] = w_p, a.prim_out[b * 6 + 5][c] = w_s;
     if (a.cons_out) { // PrimToCons (fill_derived.cpp:226-255)
@@ -1123,6 +1160,7 @@ __global__ __launch_bounds__(256) void stage_redo_kernel(const PackView P, const
     const unsigned ticket = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket == gridDim.x - 1) {
       __hip_atomic_store(a.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.tiny_clear) __hip_atomic_store(a.tiny_clear, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(a.done, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1236,6 +1274,7 @@ void launch_redo(const PackView &P, const artemis_stage_args_t &a, int riemann, 
   r.bdt_ptr = a.beta_dt_dev;
   r.prim_in = a.prim_in, r.prim_u1 = a.prim_u1, r.prim_out = a.prim_out, r.cons_out = a.cons_out;
   r.dt_bits = reinterpret_cast<unsigned long long *>(a.dt_dev);
+  r.tiny_out = a.tiny_out, r.tiny_clear = (which == 0) ? a.tiny_clear : nullptr;
   r.cnt = g_redo.cnt + which, r.done = g_redo.cnt + 2 + which, r.cap = static_cast<unsigned>(std::min<size_t>(g_redo.cap, 0xffffffffu));
   r.list = g_redo.list[which];
   r.has_u1 = (a.prim_u1 != a.prim_in) ? 1 : 0;
@@ -1260,9 +1299,12 @@ int launch_stage_fused_redo_shell(const PackView &P, const artemis_stage_args_t 
   return 0;
 }
 
+// the tile march addresses cells with 32-bit byte offsets (fused_device.hpp gld / gst)
+static bool offsets_fit(const PackView &P) { return static_cast<long>(P.nk) * P.nj * P.ni < (1L << 29); }
 int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon,
                        hipStream_t s) {
   if (recon == ARTEMIS_PPM) return 3; // PPM stays on the per-task path
+  if (!offsets_fit(P)) return 6;
   StageK k;
   k.gam0 = a.gam0, k.gam1 = a.gam1, k.beta_dt = a.beta_dt, k.bdt = a.bdt, k.cfl = a.cfl;
   k.bdt_ptr = a.beta_dt_dev;
@@ -1334,6 +1376,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   if (k.nbox == 0) return 0; // nothing to do in this region
   // detect-and-redo: zones next to vanishing velocities are deferred to the exact kernel (below)
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
+  k.tiny_in = a.tiny_in, k.tiny_out = a.tiny_out;
   const bool redo = redo_enabled();
   if (redo) {
     const size_t zones = static_cast<size_t>(P.nb) * (P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1);
@@ -1374,6 +1417,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
 // per-task chain, so the task's outputs do not change.
 bool fused_flux_covers(const PackView &P, int recon) {
   if (getenv("ARTEMIS_NO_TILED_FLUX")) return false;
+  if (static_cast<long>(P.nk) * P.nj * P.ni >= (1L << 29)) return false;
   if (P.coords != ARTEMIS_CARTESIAN || P.gas.ns != 1 || P.ng < 2 || P.ndim < 2) return false;
   if (recon != ARTEMIS_PCM && recon != ARTEMIS_PLM) return false;
   return (P.ie - P.is + 1) >= FTX && (P.je - P.js + 1) >= FTY;
@@ -1406,6 +1450,7 @@ int launch_flux_fused(const PackView &P, int riemann, int recon, hipStream_t s) 
   k.start[1] = NTI * NTJ * k.nchunk[0] * P.nb;
   k.nshell = 0, k.shell_done = nullptr;
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
+  k.tiny_in = nullptr, k.tiny_out = nullptr;
   k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
 #define RC(RS)                                                                             \
   case RS:                                                                                 \
@@ -1425,6 +1470,7 @@ int launch_flux_fused(const PackView &P, int riemann, int recon, hipStream_t s) 
 // Gas (one species) on any non-Cartesian system, PCM / PLM, with the pointwise tasks plane_update_curv folds
 // in; everything else stays on the cell-centred kernels.
 bool fused_curv_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas) {
+  if (static_cast<long>(P.nk) * P.nj * P.ni >= (1L << 29)) return false;
   if (P.coords == ARTEMIS_CARTESIAN || P.gas.ns != 1 || P.dust.ns != 0 || P.ng < 2) return false;
   if (!g.pcm && recon_gas == ARTEMIS_PPM) return false;
   if (g.drag || g.cooling) return false;
@@ -1468,6 +1514,7 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
   k.start[1] = NTI * NTJ * k.nchunk[0] * P.nb;
   k.nshell = 0, k.shell_done = nullptr;
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
+  k.tiny_in = nullptr, k.tiny_out = nullptr;
   k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
   SrcArg<true> src;
   src.v.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;

@@ -362,6 +362,20 @@ typedef struct artemis_stage_args {
                                  can keep dt on the device and never synchronise */
   int shell_faces;            /* bit f set: face f (0..5 = ix1,ox1,ix2,ox2,ix3,ox3) has a neighbour
                                  whose ghosts are cut from this block; 0 = all six */
+  /* Optional hint words (DEVICE, one unsigned each; all NULL = detect in every stage, the safe default).  The per-zone
+   * detection of vanishing velocities (below) costs ~2.5 % of the kernel; a caller who controls EVERY producer of the
+   * primitives it passes as prim_in can let the kernel skip it in stages where no such velocity exists anywhere:
+   *   tiny_out   the launch ORs 1 into it when it stores a velocity below 2^-200 (the redo kernel likewise);
+   *   tiny_in    the word a previous launch produced as tiny_out for the state now in prim_in: detection runs only if
+   *              it is non-zero.  Valid only if every zone of prim_in (ghost zones included) was written by launches
+   *              that reported into that word, or copied from such zones (periodic / outflow / reflecting conditions,
+   *              same-rank block-to-block slabs);
+   *   tiny_clear zeroed AFTER the launch's kernels have finished (by the list-driven kernel the call enqueues behind the
+   *              stage kernel): normally the stage's own tiny_in word, so that a ring of one word per stage of a time
+   *              step -- in = word[s], out = word[(s + 1) % nstages] -- needs no memset and uses the same pointers every
+   *              step.  With separate region 1 / 2 launches pass it only with the last launch of the stage. */
+  const unsigned *tiny_in;
+  unsigned *tiny_out, *tiny_clear;
 } artemis_stage_args_t;
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
 int artemis_hip_stage_fused_redo_shell(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);

@@ -55,6 +55,31 @@ def test_linwave_single_block_bitwise_and_thresholds(hiplib, recon, riem):
     assert "%e" % e32[0] == "%e" % e32[1]  # linwave.py:135-143
 
 
+@pytest.mark.parametrize("amp", [1.0e-59, 1.0e-200])
+def test_driver_run_with_vanishing_velocities_is_exact(hiplib, amp):
+    """The host driver on its tuned fused path (hint words rotating between the stages, hipGraph replay) with a wave of
+    amplitude 1e-59 / 1e-200: the velocities are amp * sin(k.x) -- below 2^-200 near the nodes, resp. everywhere -- so
+    the stage kernel defers those zones (resp. all of them) to the exact list-driven kernel in every stage.  After 12
+    cycles: every bit of the primitives and of the conserved state equals the oracle's, and so does dt."""
+    from artemis_amd.driver import Simulation
+    N = 32
+    ov = [x for x in linwave_overrides(N, "plm", "hllc", 0, 0.0) if not x.startswith(("problem/amp", "parthenon/time/nlim"))]
+    sim = Simulation(DECK("linwave", "linear_wave.in"), ov + ["problem/amp=%r" % amp, "parthenon/time/nlim=12"])
+    assert sim.uses_tuned_kernel
+    sim.evolve()
+    o = Oracle((N, N // 2, N // 2), (0, 0, 0), (3.0, 1.5, 1.5), ng=4, reconstruct="plm", riemann="hllc",
+               gamma=1.66666666667, cfl=0.9, bc=("periodic",) * 6)
+    tlim = o.pgen_linear_wave(0, amp, 0.0)
+    o.evolve(tlim, 12)
+    assert sim.ncycle == o.ncycle == 12 and sim.time == o.time and sim.dt == o.dt
+    I = np.s_[:, o.ks:o.ke + 1, o.js:o.je + 1, o.is_:o.ie + 1]
+    v = np.abs(o.gprim[I][1:4])
+    assert np.count_nonzero((v > 0) & (v < 2.0 ** -200)) > 50  # the regime is really there
+    assert np.array_equal(sim.field("gas.prim")[I], o.gprim[I])
+    assert np.array_equal(sim.field("gas.cons")[I], o.gu0[I])
+    sim.close()
+
+
 def test_linwave_reference_block_layout(hiplib):
     """The reference test runs N/4-sized mesh blocks (linwave.py:50-52): 4x2x2 blocks on one
     rank, ghost slabs copied block to block on the device.  Agreement with the one-block

@@ -147,6 +147,49 @@ def test_fused_step_with_vanishing_velocities_cons_and_dt(hiplib):
         assert dt_dev.item() == o.new_dt(), "fused EstimateTimestepMesh"
 
 
+def test_hint_words_report_vanishing_velocities_to_the_next_stage(hiplib):
+    """artemis_stage_args_t.tiny_in / tiny_out / tiny_clear: a ring of one word per stage through which a launch tells
+    the next one whether the state it wrote holds a velocity below 2^-200 anywhere; a zero lets the next launch skip the
+    per-zone detection.  With vanishing velocities in the state (stage 1 runs with tiny_in = NULL: detect), the launch
+    reports 1, stage 2 -- given that word -- detects and the step equals the oracle bit for bit; without any, the words
+    stay zero, both stages run without detection, and the step equals the oracle as well.  Each stage's tiny_in word is
+    cleared behind it (tiny_clear) so that the same two pointers serve every step."""
+    from artemis_amd import capi
+    bc = ("outflow",) * 6
+    words = torch.zeros(4, dtype=torch.int32, device="cuda")
+    W = lambda q: words.data_ptr() + 4 * q
+    flat = [capi.BCS[x] for x in bc]
+    for tiny in (True, False):
+        o, mb, bufs = setup((40, 20, 36), 2, "plm", "hllc", bc, seed=5)
+        if tiny:
+            rng = np.random.default_rng(8)
+            w = o.gprim
+            scale = rng.choice([1.0, 0.0, 1e-300, 1e-160, 1e-100], size=w[1].shape, p=[0.6, 0.1, 0.1, 0.1, 0.1])
+            for v in (1, 2, 3):
+                w[v] *= scale
+            o.ApplyBoundaryConditions()
+            o.PrimToCons()
+            mb.gas_prim[0].copy_(torch.from_numpy(o.gprim.copy()))
+        dt = o.new_dt()
+        o.dt = dt
+        o.step()
+        A, B, _ = bufs
+        words.zero_()
+        # stage 1: the caller knows nothing about its input (tiny_in = NULL: detect); reports into word 1
+        mb.stage_fused(0.0, 1.0, dt, dt, A[1], A[1], B[1], tiny_in=None, tiny_out=W(1), tiny_clear=W(0))
+        mb.call_on(mb.pack_with_prim(B[1]), mb.L.artemis_hip_apply_bc, (C.c_int * 6)(*flat), None)
+        torch.cuda.synchronize()
+        assert int(words[1].item()) == (1 if tiny else 0), words
+        # stage 2: in = word 1, out = word 0, word 1 cleared behind it
+        mb.stage_fused(0.5, 0.5, 0.5 * dt, 0.5 * dt, B[1], A[1], A[1], tiny_in=W(1), tiny_out=W(0), tiny_clear=W(1))
+        mb.call_on(mb.pack_with_prim(A[1]), mb.L.artemis_hip_apply_bc, (C.c_int * 6)(*flat), None)
+        mb.PrimToCons()
+        torch.cuda.synchronize()
+        assert int(words[1].item()) == 0 and int(words[0].item()) == (1 if tiny else 0), words
+        same(mb.gas_prim[0], o.gprim, "prim after the step (tiny=%s)" % tiny)
+        same(mb.gas_u0[0], o.gu0, "cons after the step (tiny=%s)" % tiny)
+
+
 def test_fused_step_without_redo_shows_the_limit_the_redo_removes(hiplib, monkeypatch):
     """ARTEMIS_NO_REDO=1 (the pre-round-3 kernel: every zone stored by the fast path): on the same state a handful of
     values below 1e-120 differ from the oracle -- i.e. the test above is not vacuous, the redo list is what makes it
