@@ -50,6 +50,12 @@ struct S2Args {
   double cfl_gas, cfl_dust;
   unsigned long long *dt_bits;
   int rows, nstrip, nchunk;
+  // detect-and-redo (as the tile march, kernels_fused.hip): a wave whose five-row window holds a gas or dust velocity
+  // below 2^-200, or whose updated momenta come out below 2^-480, does not store that row but lists it (block, strip,
+  // row); the EXACT instantiation of this kernel -- IEEE divisions throughout, launched over the list -- computes it.
+  unsigned *redo_cnt, *redo_done;
+  unsigned long long *redo_list;
+  unsigned redo_cap;
 };
 
 struct Dust4 {
@@ -73,7 +79,8 @@ ADEV double lane_above(double v) { // the value held by lane + 1
                           __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false));
 }
 
-ADEV Dust4 load_dust(const double *r, const double *v1, const double *v2, const double *v3, long c) {
+template <class IDX>
+ADEV Dust4 load_dust(const double *r, const double *v1, const double *v2, const double *v3, IDX c) {
   Dust4 q;
   q.d = gld(r, c), q.v1 = gld(v1, c), q.v2 = gld(v2, c), q.v3 = gld(v3, c);
   return q;
@@ -97,8 +104,9 @@ ADEV DFlux solve_dust(const Dust4 &L, const Dust4 &R) {
 #define D4(X) X(d) X(v1) X(v2) X(v3)
 
 // x1 sweep of one row through the wave: fluxes through the lower and the upper x1 face of the lane's cell
-template <int RIEMANN, int RECON>
-ADEV void x1_gas(const GasK &gk, const Cell6 &q, Flux8 &lo, Flux8 &up, const bool fast) {
+template <int RIEMANN, int RECON, bool FAST>
+ADEV void x1_gas(const GasK &gk, const Cell6 &q, Flux8 &lo, Flux8 &up) {
+  constexpr bool fast = FAST;
   Cell6 L, R;
 #define SW(m)                                                                    \
   {                                                                              \
@@ -112,8 +120,9 @@ ADEV void x1_gas(const GasK &gk, const Cell6 &q, Flux8 &lo, Flux8 &up, const boo
   up.d = lane_above(lo.d), up.m1 = lane_above(lo.m1), up.m2 = lane_above(lo.m2), up.m3 = lane_above(lo.m3);
   up.e = lane_above(lo.e), up.eg = lane_above(lo.eg), up.pf = lane_above(lo.pf), up.vf = lane_above(lo.vf);
 }
-template <int RIEMANN, int RECON>
-ADEV void x1_dust(const Dust4 &q, DFlux &lo, DFlux &up, const bool fast) {
+template <int RIEMANN, int RECON, bool FAST>
+ADEV void x1_dust(const Dust4 &q, DFlux &lo, DFlux &up) {
+  constexpr bool fast = FAST;
   Dust4 L, R;
 #define SW(m)                                                                    \
   {                                                                              \
@@ -161,20 +170,33 @@ ADEV void damping_ramps2(const artemis_damping_t &p, const artemis_drag_t &D, in
 // face states and fluxes, one HLLC problem in flight); at two waves per SIMD the same code spills 200-400 bytes per
 // lane to scratch and measures 23 % slower (3.07 vs 3.98e9 zone-cycles/s on config 3 at 4096^2).  A single wave
 // still hides HBM latency: each trip issues the loads of row j + 2 first and consumes them ~1500 instructions later.
-template <int RG, int RD, int RECON, int ND, bool HAS_U1, bool DRAG>
+template <int RG, int RD, int RECON, int ND, bool HAS_U1, bool DRAG, bool EXACT = false>
 __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const S2Args a) {
   const int lane = threadIdx.x & 63;
   const long wave = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   const long per_block = static_cast<long>(a.nstrip) * a.nchunk;
-  const int b = static_cast<int>(wave / per_block);
   double ldt_g = DBL_MAX, ldt_d = DBL_MAX;
-  if (b < P.nb) {
-    const int w = static_cast<int>(wave - b * per_block);
-    const int strip = w % a.nstrip, chunk = w / a.nstrip;
+  constexpr bool fast = !EXACT; // compile-time: the EXACT instantiation divides with `/` and takes plm_dqm / hllc_gas
+  // EXACT: one listed (block, strip, row) per wave and trip of this loop; otherwise one (block, strip, chunk) per wave
+  const long nwork = EXACT ? static_cast<long>(min(__hip_atomic_load(a.redo_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.redo_cap))
+                           : per_block * P.nb;
+  for (long work = wave; work < nwork; work += EXACT ? static_cast<long>(gridDim.x) * 4 : nwork) {
+    int b, strip, j0, j1;
+    if constexpr (EXACT) {
+      const unsigned long long e = a.redo_list[work];
+      const unsigned bs = static_cast<unsigned>(e >> 32);
+      b = static_cast<int>(bs / static_cast<unsigned>(a.nstrip)), strip = static_cast<int>(bs % static_cast<unsigned>(a.nstrip));
+      j0 = j1 = static_cast<int>(e & 0xffffffffu);
+    } else {
+      b = static_cast<int>(work / per_block);
+      const int w = static_cast<int>(work - b * per_block);
+      strip = w % a.nstrip;
+      const int chunk = w / a.nstrip;
+      j0 = P.js + chunk * a.rows, j1 = min(P.je, j0 + a.rows - 1);
+    }
     const int i = P.is + strip * OWN + lane - HALO;
     const int il = min(max(i, 0), P.ni - 1);
     const bool owned = (lane >= HALO) && (lane < HALO + OWN) && (i <= P.ie);
-    const int j0 = P.js + chunk * a.rows, j1 = min(P.je, j0 + a.rows - 1);
     double beta_dt = a.beta_dt, bdt = a.bdt;
     if (a.bdt_ptr) beta_dt = bdt = *a.bdt_ptr;
     const GasK gk = gas_constants(P.gm1);
@@ -193,8 +215,10 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
       e_r[n] = a.du1[b * 4 * ND + n], e_1[n] = a.du1[b * 4 * ND + ND + 3 * n + 0];
       e_2[n] = a.du1[b * 4 * ND + ND + 3 * n + 1], e_3[n] = a.du1[b * 4 * ND + ND + 3 * n + 2];
     }
-    const long sj = P.sj;
-    const long col = il; // k = 0 in a 2-D block
+    // element offsets in 32 bits (fused_device.hpp gld / gst: SGPR base + one VGPR byte offset per cell); stage2d_covers
+    // refuses blocks of 2^29 zones or more
+    const unsigned sj = static_cast<unsigned>(P.sj);
+    const unsigned col = static_cast<unsigned>(il); // k = 0 in a 2-D block
     // ---- prime the x2 march: rows j0-2, j0-1, j0 --------------------------------------------------------
     Cell6 qc = load_cell(g_r, g_1, g_2, g_3, g_e, col + (j0 - 1) * sj, gm1);
     Cell6 qn = load_cell(g_r, g_1, g_2, g_3, g_e, col + j0 * sj, gm1);
@@ -203,13 +227,13 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
     // of this wave holds a gas or dust velocity below 2^-200 in that row.  A trip whose five-row window (the x2 stencil
     // of row j; the x1 stencil lives in the wave's own lanes) has a bit set takes IEEE divisions throughout.
     unsigned th = 0;
-    auto tiny6 = [](const Cell6 &q) { return tiny_vel(q.v1) || tiny_vel(q.v2) || tiny_vel(q.v3); };
-    auto tiny4 = [](const Dust4 &q) { return tiny_vel(q.v1) || tiny_vel(q.v2) || tiny_vel(q.v3); };
+    const bool detect = !EXACT && a.redo_cnt != nullptr; // wave-uniform
+    auto tiny6 = [](const Cell6 &q) { return tiny_vel3(q.v1, q.v2, q.v3); };
+    auto tiny4 = [](const Dust4 &q) { return tiny_vel3(q.v1, q.v2, q.v3); };
     {
       const Cell6 qmm = load_cell(g_r, g_1, g_2, g_3, g_e, col + (j0 - 2) * sj, gm1);
-      th = (__any(tiny6(qmm)) ? 4u : 0u) | (__any(tiny6(qc)) ? 2u : 0u) | (__any(tiny6(qn)) ? 1u : 0u);
-      const bool f0 = (th == 0u);
-#define ZL0(m) zl.m = up_val<RECON>(qc.m, slope_sel<RECON>(qmm.m, qc.m, qn.m, f0));
+      if (detect) th = (__any(tiny6(qmm)) ? 4u : 0u) | (__any(tiny6(qc)) ? 2u : 0u) | (__any(tiny6(qn)) ? 1u : 0u);
+#define ZL0(m) zl.m = up_val<RECON>(qc.m, slope_sel<RECON>(qmm.m, qc.m, qn.m, fast));
       G6(ZL0)
 #undef ZL0
     }
@@ -222,10 +246,8 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
       dc[n] = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], col + (j0 - 1) * sj);
       dn[n] = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], col + j0 * sj);
       const Dust4 dmm = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], col + (j0 - 2) * sj);
-      const unsigned td = (__any(tiny4(dmm)) ? 4u : 0u) | (__any(tiny4(dc[n])) ? 2u : 0u) | (__any(tiny4(dn[n])) ? 1u : 0u);
-      th |= td;
-      const bool f0 = (td == 0u);
-#define ZL0(m) dzl[n].m = up_val<RECON>(dc[n].m, slope_sel<RECON>(dmm.m, dc[n].m, dn[n].m, f0));
+      if (detect) th |= (__any(tiny4(dmm)) ? 4u : 0u) | (__any(tiny4(dc[n])) ? 2u : 0u) | (__any(tiny4(dn[n])) ? 1u : 0u);
+#define ZL0(m) dzl[n].m = up_val<RECON>(dc[n].m, slope_sel<RECON>(dmm.m, dc[n].m, dn[n].m, fast));
       D4(ZL0)
 #undef ZL0
       dy_lo[n].d = dy_lo[n].m1 = dy_lo[n].m2 = dy_lo[n].m3 = 0.0;
@@ -234,20 +256,20 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
     ShearAcc sa{}; // the shearing-box terms depend on the column only (rotating_frame_impl.hpp:43-60)
     if (a.rf_on) sa = shear_terms(geo, 2, 0, i, a.rf_omega, a.rf_qshear);
     for (int j = j0 - 1; j <= j1; ++j) { // the first trip only primes the flux through face j0
-      const long cnn = col + static_cast<long>(j + 2) * sj, ccur = col + static_cast<long>(j) * sj;
+      const unsigned cnn = col + static_cast<unsigned>(j + 2) * sj, ccur = col + static_cast<unsigned>(j) * sj;
       const bool live = (j >= j0); // wave-uniform
       // this trip's HBM loads first; consumed after the sweeps
       const Cell6 qnn = load_cell(g_r, g_1, g_2, g_3, g_e, cnn, gm1);
       Dust4 dnn[ND > 0 ? ND : 1];
 #pragma unroll
       for (int n = 0; n < ND; ++n) dnn[n] = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], cnn);
-      {
+      if (detect) {
         bool t = tiny6(qnn);
 #pragma unroll
         for (int n = 0; n < ND; ++n) t = t || tiny4(dnn[n]);
         th = (th << 1) | (__any(t) ? 1u : 0u); // bits 0..4 = rows j+2 .. j-2
       }
-      bool fast = (th & 31u) == 0u; // wave-uniform
+      bool skip_row = (th & 31u) != 0u; // wave-uniform: this row goes to the exact kernel
       auto GD = [&](double num, const Recip &r) { return fast ? div(num, r) : num / r.b; };
       const CellMetric g = cell_metric<false>(P, b, 0, j, i);
       const double hx[3] = {1.0, 1.0, 1.0};
@@ -263,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
       double divf[6] = {0, 0, 0, 0, 0, 0}, tm1 = 0.0, tm2 = 0.0, teg1 = 0.0, teg2 = 0.0;
       if (live) {
         Flux8 lo, up;
-        x1_gas<RG, RECON>(gk, qc, lo, up, fast);
+        x1_gas<RG, RECON, fast>(gk, qc, lo, up);
         divf[0] = (g.ax1[0] * lo.d - g.ax1[1] * up.d), divf[1] = (g.ax1[0] * lo.m1 - g.ax1[1] * up.m1);
         divf[2] = (g.ax1[0] * lo.m2 - g.ax1[1] * up.m2), divf[3] = (g.ax1[0] * lo.m3 - g.ax1[1] * up.m3);
         divf[4] = (g.ax1[0] * lo.e - g.ax1[1] * up.e), divf[5] = (g.ax1[0] * lo.eg - g.ax1[1] * up.eg);
@@ -328,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
         double dv[4] = {0, 0, 0, 0};
         if (live) {
           DFlux lo, up;
-          x1_dust<RD, RECON>(dc[n], lo, up, fast);
+          x1_dust<RD, RECON, fast>(dc[n], lo, up);
           dv[0] = (g.ax1[0] * lo.d - g.ax1[1] * up.d), dv[1] = (g.ax1[0] * lo.m1 - g.ax1[1] * up.m1);
           dv[2] = (g.ax1[0] * lo.m2 - g.ax1[1] * up.m2), dv[3] = (g.ax1[0] * lo.m3 - g.ax1[1] * up.m3);
         }
@@ -371,11 +393,20 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
         double dmom[ND > 0 ? ND : 1][3];
 #pragma unroll
         for (int n = 0; n < ND; ++n) dmom[n][0] = ud[n].m1, dmom[n][1] = ud[n].m2, dmom[n][2] = ud[n].m3;
-        { // updated momenta whose quotients the hand-scheduled division would not round like `/`: IEEE for this row
-          bool tm = tiny_mom(mnew[0]) || tiny_mom(mnew[1]) || tiny_mom(mnew[2]);
+        if (detect) { // updated momenta whose quotients the hand-scheduled division would not round like `/`
+          bool tm = tiny_mom3(mnew[0], mnew[1], mnew[2]);
 #pragma unroll
-          for (int n = 0; n < ND; ++n) tm = tm || tiny_mom(dmom[n][0]) || tiny_mom(dmom[n][1]) || tiny_mom(dmom[n][2]);
-          if (__any(tm)) fast = false;
+          for (int n = 0; n < ND; ++n) tm = tm || tiny_mom3(dmom[n][0], dmom[n][1], dmom[n][2]);
+          if (__any(tm)) skip_row = true;
+          if (skip_row) { // (uniform over the active lanes) one entry per wave and row
+            if (lane == __builtin_ctzll(__ballot(1))) {
+              const unsigned at = __hip_atomic_fetch_add(a.redo_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (at < a.redo_cap)
+                a.redo_list[at] = (static_cast<unsigned long long>(static_cast<unsigned>(b) * static_cast<unsigned>(a.nstrip) + static_cast<unsigned>(strip)) << 32) |
+                                  static_cast<unsigned>(j);
+            }
+            continue; // no store, no dt contribution: the exact kernel does both
+          }
         }
         if constexpr (DRAG) {
           const artemis_drag_t &D = a.drag;
@@ -475,7 +506,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
           }
         }
         // dust ConsToPrim (fill_derived.cpp:155-164)
-        const long c = static_cast<long>(j) * sj + i;
+        const unsigned c = static_cast<unsigned>(j) * sj + static_cast<unsigned>(i);
 #pragma unroll
         for (int n = 0; n < ND; ++n) {
           const double dens = ud[n].d;
@@ -537,13 +568,49 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
         atomicMin(a.dt_bits, static_cast<unsigned long long>(__double_as_longlong(a.cfl_dust * ldt_d)));
     }
   }
+  if constexpr (EXACT) { // every workgroup has read the count; the last one empties the list for the next stage
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(a.redo_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == gridDim.x - 1) {
+        __hip_atomic_store(a.redo_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.redo_done, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// the rows the calling thread's launches deferred (one counter + ticket and one list, grown on demand outside captures)
+struct Redo2d {
+  unsigned *cnt = nullptr;
+  unsigned long long *list = nullptr;
+  size_t cap = 0;
+};
+thread_local Redo2d g_redo2d;
+bool ensure_redo2d(size_t rows) {
+  if (g_redo2d.cnt && g_redo2d.cap >= rows) return true;
+  (void)hipDeviceSynchronize();
+  if (g_redo2d.list) (void)hipFree(g_redo2d.list);
+  g_redo2d.list = nullptr, g_redo2d.cap = 0;
+  if (!g_redo2d.cnt) {
+    if (hipMalloc(reinterpret_cast<void **>(&g_redo2d.cnt), 2 * sizeof(unsigned)) != hipSuccess) return false;
+    if (hipMemset(g_redo2d.cnt, 0, 2 * sizeof(unsigned)) != hipSuccess) return false;
+  }
+  if (hipMalloc(reinterpret_cast<void **>(&g_redo2d.list), rows * sizeof(unsigned long long)) != hipSuccess) return false;
+  g_redo2d.cap = rows;
+  return true;
 }
 
 template <int RG, int RD, int RECON, int ND>
 void launch_flags(const PackView &P, const S2Args &a, hipStream_t s) {
   const long waves = static_cast<long>(a.nstrip) * a.nchunk * P.nb;
   const dim3 grid(static_cast<unsigned>((waves + 3) / 4)), block(256);
-#define GO(U, D) hipLaunchKernelGGL((stage2d_kernel<RG, RD, RECON, ND, U, D>), grid, block, 0, s, P, a)
+  const dim3 rgrid(256); // the exact kernel: 1024 waves stride over the listed rows (normally none)
+#define GO(U, D)                                                                                                    \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((stage2d_kernel<RG, RD, RECON, ND, U, D, false>), grid, block, 0, s, P, a);                  \
+    if (a.redo_cnt) hipLaunchKernelGGL((stage2d_kernel<RG, RD, RECON, ND, U, D, true>), rgrid, block, 0, s, P, a);  \
+  } while (0)
   if constexpr (ND > 0) {
     if (a.has_u1) {
       if (a.drag_on) GO(true, true);
@@ -576,6 +643,7 @@ void launch_rc(const PackView &P, int recon, const S2Args &a, hipStream_t s) {
 bool stage2d_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas, int recon_dust,
                     int riemann_dust) {
   if (P.coords != ARTEMIS_CARTESIAN || P.ndim != 2 || P.ng < 2) return false;
+  if (static_cast<long>(P.nj) * P.ni >= (1L << 29)) return false; // 32-bit cell offsets
   if (P.gas.ns != 1 || P.dust.ns > 2) return false;
   if (recon_gas == ARTEMIS_PPM || (P.dust.ns && (recon_dust != recon_gas || riemann_dust == ARTEMIS_HLLC))) return false;
   if (g.diffusion || g.cooling) return false;
@@ -610,24 +678,29 @@ void launch_stage2d(const PackView &P, const artemis_stage_general_args_t &g, in
   a.dt_bits = reinterpret_cast<unsigned long long *>(g.dt_dev);
   const int nx1 = P.ie - P.is + 1, nx2 = P.je - P.js + 1;
   a.nstrip = (nx1 + OWN - 1) / OWN;
-  // rows per chunk: long enough to amortise the priming row, short enough for >= ~8 waves per SIMD lane of work
+  // Rows per chunk.  One wave per SIMD (launch bound 1): 256 CUs x 4 waves run at a time, so the launch proceeds in
+  // rounds of 1024 strip-chunks, every wave of a round marching rows + 1 trips (one priming trip) after loading three
+  // rows -- and a last round that is nearly empty costs as much as a full one.  Take the chunk length with the least
+  // rounds x (rows + 2): 4096^2 -> 40 rows, 7 rounds; 1024^2 -> 19 rows, ONE round of 972 waves (round 2 halved the
+  // chunks until there were 4096 waves, which made 3078 chunks of 6 rows = four rounds of 8 trips, 1.5 x the time).
   int rows = 32;
   if (const char *e = getenv("ARTEMIS_STAGE2D_ROWS")) {
     rows = std::max(1, atoi(e));
   } else {
-    // One wave per SIMD (launch bound 1): 256 CUs x 4 waves run at a time, so the launch proceeds in rounds of 1024
-    // strip-chunks and a last round that is 60 % empty costs as much as a full one (4096^2: 32 rows -> 8.6 rounds,
-    // 40 rows -> 6.94; measured 0.398 vs 0.411 of the roofline).  Among 24..48 rows take the fullest last round.
     const long slots = 1024;
-    double best = -1.0;
-    for (int r = 48; r >= 24; r -= 4) {
+    long best = -1;
+    for (int r = std::min(64, nx2); r >= std::min(4, nx2); --r) {
       const long waves = static_cast<long>(a.nstrip) * ((nx2 + r - 1) / r) * P.nb;
-      const double fill = static_cast<double>(waves) / static_cast<double>(((waves + slots - 1) / slots) * slots);
-      if (fill > best + 1e-9) best = fill, rows = r;
+      const long cost = ((waves + slots - 1) / slots) * (r + 2);
+      if (best < 0 || cost < best) best = cost, rows = r;
     }
   }
-  while (rows > 8 && static_cast<long>(a.nstrip) * ((nx2 + rows - 1) / rows) * P.nb < 4096) rows /= 2;
   a.rows = rows, a.nchunk = (nx2 + rows - 1) / rows;
+  a.redo_cnt = a.redo_done = nullptr, a.redo_list = nullptr, a.redo_cap = 0;
+  if (getenv("ARTEMIS_NO_REDO") == nullptr && ensure_redo2d(static_cast<size_t>(P.nb) * a.nstrip * nx2)) {
+    a.redo_cnt = g_redo2d.cnt, a.redo_done = g_redo2d.cnt + 1, a.redo_list = g_redo2d.list;
+    a.redo_cap = static_cast<unsigned>(std::min<size_t>(g_redo2d.cap, 0xffffffffu));
+  }
   const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;
   const int rd = (P.dust.ns && riemann_dust == ARTEMIS_LLF) ? 2 : 1;
 #define RR(G_)                                             \
