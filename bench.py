@@ -187,13 +187,27 @@ def measured_traffic(name):
     return None, None
 
 
-def cpu_baseline_ssheet(n, ndust, cycles):
+def measured_valu():
+    """VALU wave-instructions per launch of the headline stage kernel from the newest profiles/r*_pmc_sq.json whose
+    source hash matches this checkout (scripts/pmc_sq.py with PMC_SQ_RECORD), else None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if rec.get("kernel_source_sha1") == kernel_source_sha1("fused") and not rec.get("env"):
+            return rec.get("valu_wave_instructions_per_launch"), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def cpu_baseline_ssheet(n, ndust, cycles, threads):
     """The config-3 workload on the CPU oracle: n^2 dusty shearing sheet with drag."""
     from oracle.oracle import Oracle
     o = Oracle((n, n, 1), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2), ng=2, ns_gas=1, ns_dust=ndust, reconstruct="plm",
                riemann="hllc", dust_reconstruct="plm", dust_riemann="hlle", gamma=1.000001, dfloor=1e-10,
                siefloor=1e-10, dust_dfloor=1e-10, cfl=0.3, dust_cfl=0.3,
-               bc=("extrap", "extrap", "inflow", "inflow", "extrap", "extrap"), integrator="rk2")
+               bc=("extrap", "extrap", "inflow", "inflow", "extrap", "extrap"), integrator="rk2", nthreads=threads)
     o.set_rotating_frame(1.0, 1.5)
     o.set_gravity_point(1e-5, soft=0.03)
     o.set_drag("simple_dust", "constant", tau=[0.1] * ndust)
@@ -510,6 +524,15 @@ def main():
                                "kernel": "stage_fused_kernel<hllc,plm>", "launch_ms": kms,
                                "launches_timed": nlaunch,
                                "algorithmic_bytes_per_launch": alg}
+            # The kernel is bound by fp64 instruction issue, not by HBM: quote that roofline too.  floor = VALU
+            # wave-instructions per launch (SQ_INSTS_VALU, profiles/) x 4 issue cycles / (1024 SIMDs x 2.4 GHz).
+            valu, valu_src = (measured_valu() if args.n == 256 else (None, None))
+            if valu:
+                floor_ms = valu * 4.0 / (1024.0 * 2.4e9) * 1.0e3
+                out["roofline"]["fp64_issue"] = {"bound": "valu", "valu_wave_instructions_per_launch": valu,
+                                                 "lane_instructions_per_zone_stage": valu * 64.0 / local_zones,
+                                                 "issue_floor_ms": floor_ms, "frac": floor_ms / kms, "source": valu_src,
+                                                 "peak": "1024 SIMDs x 16 fp64 lanes x 2.4 GHz (MI355X_MICROARCH.md)"}
             if dropin:
                 dropin["fused"] = value
                 dropin["frac_fused"] = value * 2.0 * ALG_BYTES_PER_CELL_STAGE / 1.0e9 / HBM_PEAK_GBS
@@ -517,10 +540,14 @@ def main():
         if args.workload == "disk_sph":
             pass  # (CPU side: tests/test_oracle_pins.py times the oracle on the same deck: ~20 s for 10 cycles of 128x64x64)
         elif args.workload == "ssheet_dust" and not args.no_cpu_baseline:
-            v, secs, cyc, cn = cpu_baseline_ssheet(min(args.n, 512), args.dust, args.cpu_cycles)
+            hc = host_cores()
+            threads = args.cpu_threads or hc["physical_usable"]
+            v, secs, cyc, cn = cpu_baseline_ssheet(min(args.n, 512), args.dust, args.cpu_cycles, threads)
             out["cpu_baseline"] = {
-                "value": v, "unit": "zone-cycles/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": "CPU oracle (OpenMP, all host cores), same problem at %d^2, %d cycles, %.1f s" % (cn, cyc, secs)}
+                "value": v, "unit": "zone-cycles/s", "cores": threads, "kind": "port", "threads": threads, "host": hc,
+                "sample": "CPU oracle (C++ restatement of the reference's CPU path, OpenMP over rows) on %d threads (the "
+                          "container's CPU quota, else one per physical core), same problem at %d^2, %d cycles, %.1f s"
+                          % (threads, cn, cyc, secs)}
         elif args.gpus == 1 and not args.no_cpu_baseline:
             hc = host_cores()
             threads = args.cpu_threads or hc["physical_usable"]

@@ -1,6 +1,6 @@
 # Round-end evidence run (one gpurun call): GPU suite, smoke, bench lines, rocprof stats, PMC traffic records.
 # Outputs under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
-tag=${1:-r02z}
+tag=${1:-r03z}
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -10,9 +10,12 @@ timeout 900 python3 scripts/pmc_traffic.py --tag ${tag}
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust
 # (on the box: the bench lines below quote the records just measured; scripts/collect_evidence.sh copies them locally)
-cp gpurun_out/${tag}_pmc_traffic.json profiles/r02_pmc_traffic.json; cp gpurun_out/${tag}_disk_sph_pmc_traffic.json profiles/r02_disk_sph_pmc_traffic.json; cp gpurun_out/${tag}_cfg3_pmc_traffic.json profiles/r02_cfg3_pmc_traffic.json
+PMC_SQ_GROUPS=0,1 PMC_SQ_RECORD=${tag} timeout 600 python3 scripts/pmc_sq.py ${tag} -- bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-dropin > gpurun_out/${tag}_pmc_sq.txt 2>&1
+cp gpurun_out/${tag}_pmc_traffic.json profiles/r03_pmc_traffic.json; cp gpurun_out/${tag}_disk_sph_pmc_traffic.json profiles/r03_disk_sph_pmc_traffic.json; cp gpurun_out/${tag}_cfg3_pmc_traffic.json profiles/r03_cfg3_pmc_traffic.json; cp gpurun_out/${tag}_pmc_sq.json profiles/r03_pmc_sq.json
 timeout 600 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err; cat gpurun_out/${tag}_bench_line.json | cut -c1-400
 timeout 300 python bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_cfg3_line.json
+timeout 300 python bench.py --workload ssheet_dust --n 1024 --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_line.json
+timeout 300 python bench.py --workload ssheet_dust --n 1024 --dust 2 --no-cpu-baseline --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_2dust_line.json
 timeout 300 python bench.py --workload disk_sph --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_disk_sph_line.json
 cut -c1-300 gpurun_out/${tag}_cfg3_line.json gpurun_out/${tag}_disk_sph_line.json
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof -o p --output-format csv -- python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_prof.log 2>&1
