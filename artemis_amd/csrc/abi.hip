@@ -571,6 +571,50 @@ int artemis_hip_ml_prolongate(const artemis_pack_t *p, const artemis_ml_pack_t *
   return after_launch("ml_prolongate");
 }
 
+// ---- refined meshes on the one-kernel stages: fine-side faces, then the coarse zones next to them redone ----------
+static int validate_diffusion(const artemis_pack_t *p, const artemis_diffusion_t *d, bool need_flux);
+static int validate_ml_fix(const artemis_pack_t *p, const artemis_stage_general_args_t *a) {
+  if (int rc = validate(p)) return rc;
+  if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");
+  if (int rc = validate_fluid(p, ARTEMIS_GAS, a->pcm)) return rc;
+  if (int rc = validate_fluid(p, ARTEMIS_DUST, a->pcm)) return rc;
+  if (a->drag) return fail(ARTEMIS_HIP_EUNSUPPORTED, "refined-mesh fix-up: drag couples the fluids after the update; use the per-task chain");
+  if (p->gas.nspecies && (!a->gas_in || !a->gas_u1 || !a->gas_out))
+    return fail(ARTEMIS_HIP_EINVAL, "refined-mesh fix-up: gas_in / gas_u1 / gas_out are required");
+  if (p->dust.nspecies && (!a->dust_in || !a->dust_u1 || !a->dust_out))
+    return fail(ARTEMIS_HIP_EINVAL, "refined-mesh fix-up: dust_in / dust_u1 / dust_out are required");
+  const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1);
+  for (int d = 0; d < ndim; ++d)
+    if ((p->gas.nspecies && (!p->gas.flux[d] || !p->gas.pflux[d] || !p->gas.vface[d])) || (p->dust.nspecies && !p->dust.flux[d]))
+      return fail(ARTEMIS_HIP_EINVAL, "refined-mesh fix-up: flux / pflux / vface tables are required");
+  return 0;
+}
+int artemis_hip_ml_face_fluxes(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
+                               const artemis_ml_face_box_t *boxes_dev, int nboxes, void *stream) {
+  if (int rc = validate_ml_fix(p, a)) return rc;
+  if (nboxes < 0 || (nboxes > 0 && !boxes_dev)) return fail(ARTEMIS_HIP_EINVAL, "multilevel: bad box list");
+  artemis::launch_ml_face_fluxes(artemis::make_pack_view(*p), *a, p->gas.recon, p->gas.riemann, p->dust.recon,
+                                 p->dust.riemann, boxes_dev, nboxes, S(stream));
+  return after_launch("ml_face_fluxes");
+}
+int artemis_hip_ml_stage_fixup(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
+                               const artemis_ml_fix_cell_t *cells_dev, int ncells, void *stream) {
+  if (int rc = validate_ml_fix(p, a)) return rc;
+  if (ncells < 0 || (ncells > 0 && !cells_dev)) return fail(ARTEMIS_HIP_EINVAL, "multilevel: bad zone list");
+  if (a->gravity) {
+    const artemis_gravity_t *g = a->gravity;
+    if (g->type != ARTEMIS_GRAVITY_UNIFORM && g->type != ARTEMIS_GRAVITY_POINT && g->type != ARTEMIS_GRAVITY_BINARY)
+      return fail(ARTEMIS_HIP_EUNSUPPORTED, "gravity type %d (nbody) is not built", g->type);
+  }
+  if (a->diffusion)
+    if (int rc = validate_diffusion(p, a->diffusion, true)) return rc;
+  if (a->cooling && p->gas.nspecies && (!a->cooling->tref || !a->cooling->beta))
+    return fail(ARTEMIS_HIP_EINVAL, "cooling: tref / beta tables are required (artemis_hip_cooling_table_fill)");
+  artemis::launch_ml_stage_fixup(artemis::make_pack_view(*p), *a, p->gas.recon, p->gas.riemann, p->dust.recon,
+                                 p->dust.riemann, cells_dev, ncells, S(stream));
+  return after_launch("ml_stage_fixup");
+}
+
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream) {
   if (int rc = validate(p)) return rc;
   if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");

@@ -8,6 +8,7 @@
 //   PostStepTasks        artemis_driver.cpp:279-297 (EstimateTimestep)
 //   Execute loop / SetGlobalTimeStep   parthenon EvolutionDriver (upstream, recalled)
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -161,6 +162,7 @@ struct artemis_sim_impl {
     std::vector<Real> cgeom_h, cmetric_h; // host copies (the problem generator evaluates `ic` states on them)
     DevArr ops_a, ops_u, ops_b;   // ghost ops: packs + direct same/finer | unpacks same/finer | from-coarser
     DevArr ops_fx, ops_fxu;       // flux correction: packs + direct | unpacks
+    DevArr fine_boxes, fix_cells; // one-kernel stages: fine-side faces to solve | coarse zones to redo (artemis_hip.h)
     DevArr restrict_blocks, boxes;
     DevBuf gsend, grecv, fsend, frecv;
     std::vector<artemis_msg_t> gmsgs, fmsgs;
@@ -177,6 +179,8 @@ struct artemis_sim_impl {
     std::vector<artemis_ml_op_t> a, u, b, fx, fxu;
     std::vector<int> restrict_blocks;
     std::vector<artemis_ml_box_t> boxes;
+    std::vector<artemis_ml_face_box_t> fine_boxes;
+    std::vector<artemis_ml_fix_cell_t> fix_cells;
     long gsend_n = 0, grecv_n = 0, fsend_n = 0, frecv_n = 0;
   } ml_host;
   artemis_ml_pack_t make_ml_pack() const {
@@ -278,6 +282,9 @@ struct artemis_sim_impl {
   double *dt_host = nullptr;    // pinned
   bool unfused_ready = false;
   bool use_fused = false, fused_possible = false;
+  // refined meshes: the one-kernel stages on every block + the fix-up of the zones on coarse-fine faces
+  // (step_ml_fused; include/artemis_hip.h "flux correction as a thin fix-up"); ml_tuned: the tuned gas kernel
+  bool ml_fused = false, ml_fused_possible = false, ml_tuned = false;
   bool tuned = false; // the hand-tuned gas kernel covers this deck; otherwise the general cell-centred stage
   int general_variant = -1; // what artemis_hip_stage_general ran last (artemis_hip_stage_general_variant)
   int overlap = 0; // 0 off, 1 shell launch + bulk launch, 2 one launch with in-kernel shell signalling
@@ -355,6 +362,7 @@ struct artemis_sim_impl {
   void materialise_cons();
   Real new_dt_unfused();
   void step_fused(bool want_dt, bool device_dt);
+  void step_ml_fused();
   void step_unfused();
   long evolve(long max_cycles);
   void upload_block(Field &f, int b, const std::vector<Real> &h);
@@ -884,6 +892,14 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
   const bool curv_tile = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 && !do_drag &&
                          !do_cooling && getenv("ARTEMIS_NO_FUSED_CURV") == nullptr;
   use_fused = fused_possible && (coords == ARTEMIS_CARTESIAN || curv_tile);
+  // Refined meshes: the same stage kernels on every block, then the coarse zones on coarse-fine faces redone with the
+  // corrected fluxes (step_ml_fused).  Not with drag (it couples the fluids after the update) or n-body gravity (its own
+  // task and host reduction): those decks keep the per-task chain.
+  ml_fused_possible = multilevel && !do_drag && !grav_nbody && (coords == ARTEMIS_CARTESIAN || curv_tile);
+  ml_tuned = ml_fused_possible && do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
+             coords == ARTEMIS_CARTESIAN && !do_gravity && !do_rframe && !do_viscosity && !do_conduction && !do_cooling &&
+             getenv("ARTEMIS_NO_TUNED") == nullptr;
+  ml_fused = ml_fused_possible && getenv("ARTEMIS_NO_ML_FUSED") == nullptr;
   if (multilevel) edge_ghosts = false; // the block-graph exchange fills all 3^ndim - 1 directions itself
   t_setup = now();
   if (!use_fused) ensure_unfused();
@@ -1062,6 +1078,44 @@ void artemis_sim_impl::build_mesh_multilevel() {
   ml_host.a.clear(), ml_host.u.clear(), ml_host.b.clear(), ml_host.fx.clear(), ml_host.fxu.clear();
   split(M.ghost, nfill, ml_host.a, ml_host.u, &ml_host.b, ml_host.gsend_n, ml_host.grecv_n, ml_host.gmsgs, 7001);
   split(M.flux, nflux, ml_host.fx, ml_host.fxu, nullptr, ml_host.fsend_n, ml_host.frecv_n, ml_host.fmsgs, 7002);
+  // The one-kernel stages keep no flux arrays: the fine side of every coarse-fine face is solved on its own
+  // (fine_boxes: the faces a FLUX op restricts, artemis_hip_ml_flux_kernel's index map) and the coarse zones that
+  // touch a corrected face are redone with it (fix_cells; a zone on a block edge can touch several).
+  ml_host.fine_boxes.clear(), ml_host.fix_cells.clear();
+  {
+    std::map<std::array<int, 4>, unsigned> touched;
+    auto visit = [&](const artemis_ml_op_t &o) {
+      const int d = o.dir;
+      if (o.src_block >= 0) {
+        artemis_ml_face_box_t fb;
+        fb.block = o.src_block, fb.dir = d;
+        for (int q = 0; q < 3; ++q) {
+          if (q == d) fb.lo[q] = o.off[q], fb.n[q] = 1;
+          else if (q < ndim) fb.lo[q] = 2 * o.lo[q] + o.off[q], fb.n[q] = 2 * o.n[q];
+          else fb.lo[q] = o.lo[q], fb.n[q] = o.n[q];
+        }
+        ml_host.fine_boxes.push_back(fb);
+      }
+      if (o.dst_block >= 0) {
+        const int s0[3] = {is, js, ks};
+        const bool lower = (o.lo[d] == s0[d]); // my lower boundary face; otherwise the upper one, stored one zone up
+        for (int k = o.lo[2]; k < o.lo[2] + o.n[2]; ++k)
+          for (int j = o.lo[1]; j < o.lo[1] + o.n[1]; ++j)
+            for (int i = o.lo[0]; i < o.lo[0] + o.n[0]; ++i) {
+              std::array<int, 4> key = {o.dst_block, k, j, i};
+              if (!lower) key[3 - d] -= 1;
+              touched[key] |= 1u << (2 * d + (lower ? 0 : 1));
+            }
+      }
+    };
+    for (const auto &o : ml_host.fx) visit(o);
+    for (const auto &o : ml_host.fxu) visit(o);
+    for (const auto &kv : touched) {
+      artemis_ml_fix_cell_t c;
+      c.block = kv.first[0], c.k = kv.first[1], c.j = kv.first[2], c.i = kv.first[3], c.faces = kv.second;
+      ml_host.fix_cells.push_back(c);
+    }
+  }
   ml_host.restrict_blocks.clear(), ml_host.boxes.clear();
   for (size_t gb = 0; gb < leaves.size(); ++gb)
     if (rank_of[gb] == rank && M.has_coarser[gb]) ml_host.restrict_blocks.push_back(local_of[gb]);
@@ -1107,6 +1161,7 @@ void artemis_sim_impl::allocate_multilevel() {
   }
   ml.ops_a.upload(ml_host.a), ml.ops_u.upload(ml_host.u), ml.ops_b.upload(ml_host.b);
   ml.ops_fx.upload(ml_host.fx), ml.ops_fxu.upload(ml_host.fxu);
+  ml.fine_boxes.upload(ml_host.fine_boxes), ml.fix_cells.upload(ml_host.fix_cells);
   ml.restrict_blocks.upload(ml_host.restrict_blocks), ml.boxes.upload(ml_host.boxes);
   ml.gsend.alloc(ml_host.gsend_n), ml.grecv.alloc(ml_host.grecv_n), ml.fsend.alloc(ml_host.fsend_n), ml.frecv.alloc(ml_host.frecv_n);
   auto address = [](const std::vector<PeerMsg> &in, double *sbase, double *rbase, std::vector<artemis_msg_t> &out) {
@@ -1167,6 +1222,12 @@ void artemis_sim_impl::fill_ghosts_multilevel(int prim_idx) {
   }
   artemis_bc_params_t bp = bcpar;
   bp.floor_ghosts = 0;
+  if (ml_fused) { // no PrimToCons follows on the one-kernel path: the conditions that compute values floor them here
+    bool value_bc = false;
+    for (size_t q = 0; q < bc_flat.size(); ++q)
+      value_bc = value_bc || bc_flat[q] >= ARTEMIS_BC_CONDUCTIVE || (bc_flat[q] == ARTEMIS_BC_STRAT_EXTRAP && (q % 6) / 2 == 2);
+    bp.floor_ghosts = value_bc ? 1 : 0;
+  }
   CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc");
 }
 
@@ -2453,6 +2514,69 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
   cons_valid = dropin != 0;
 }
 
+// One step on a refined mesh with the one-kernel stages: every block through artemis_hip_stage_fused /
+// artemis_hip_stage_general as on a uniform mesh (no flux arrays), then the flux correction of
+// artemis_driver.cpp:196-202 as a fix-up -- the fine side's faces on the coarse-fine boundaries solved on their own,
+// restricted (and sent between ranks) by the same artemis_hip_ml_flux_correction calls as the per-task chain, and the
+// coarse zones that touch such a face redone with them.  Same bits as step_unfused (tests/test_multilevel.py runs both).
+void artemis_sim_impl::step_ml_fused() {
+  tiny_valid = false;
+  ensure_unfused(); // the flux arrays the fine-side faces and their restrictions live in
+  for (int q = 1; q < 3; ++q) {
+    if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
+    if (!dprim[q].ok()) dprim[q].alloc(nb, 4 * ns_dust, N);
+  }
+  const int A = base;
+  int cur = A;
+  for (int stage = 1; stage <= nstages; ++stage) {
+    // the fix-up reads the stage's input AND the start-of-step state after the stage kernel has written its output:
+    // the output never aliases either (three buffers; the last stage's output becomes the new base)
+    const int out = (cur == A) ? (A + 1) % 3 : 3 - cur - A;
+    const artemis_pack_t p = make_pack(cur);
+    artemis_stage_general_args_t a;
+    std::memset(&a, 0, sizeof a);
+    a.gam0 = gam0[stage - 1], a.gam1 = gam1[stage - 1];
+    a.beta_dt = beta[stage - 1] * dt, a.bdt = beta[stage - 1] * dt;
+    a.pcm = (stage == 1 && integrator == "vl2");
+    a.time = time;
+    a.gas_in = gprim[cur].tab(), a.gas_u1 = gprim[A].tab(), a.gas_out = gprim[out].tab();
+    a.dust_in = dprim[cur].tab(), a.dust_u1 = dprim[A].tab(), a.dust_out = dprim[out].tab();
+    place_binary();
+    a.gravity = do_gravity ? &grav : nullptr;
+    a.rf_omega = do_rframe ? rf_omega : 0.0, a.rf_qshear = rf_qshear;
+    a.cfl_gas = cfl_gas, a.cfl_dust = cfl_dust;
+    a.dt_dev = nullptr; // the timestep is estimated after the fix-up (new_dt_unfused)
+    const bool diffuse = do_gas && (do_viscosity || do_conduction);
+    if (diffuse) { // artemis_driver.cpp:189-194 on the stage's input primitives
+      if (do_viscosity) CK(artemis_hip_zero_viscous_flux(&p, &diff, stream), "Gas::ZeroDiffusionFlux + ViscousFlux");
+      else CK(artemis_hip_zero_diffusion_flux(&p, stream), "Gas::ZeroDiffusionFlux");
+      if (do_conduction) CK(artemis_hip_thermal_flux(&p, &diff, stream), "Gas::ThermalFlux");
+      a.diffusion = &diff;
+    }
+    if (do_cooling && do_gas) a.cooling = &cool;
+    if (ml_tuned) {
+      artemis_stage_args_t t;
+      std::memset(&t, 0, sizeof t);
+      t.gam0 = a.gam0, t.gam1 = a.gam1, t.beta_dt = a.beta_dt, t.bdt = a.bdt, t.pcm = a.pcm;
+      t.prim_in = a.gas_in, t.prim_u1 = a.gas_u1, t.prim_out = a.gas_out;
+      t.cfl = cfl_gas;
+      CK(artemis_hip_stage_fused(&p, &t, stream), "stage_fused");
+    } else {
+      general_variant = artemis_hip_stage_general_variant(&p, &a);
+      CK(artemis_hip_stage_general(&p, &a, stream), "stage_general");
+    }
+    CK(artemis_hip_ml_face_fluxes(&p, &a, static_cast<const artemis_ml_face_box_t *>(ml.fine_boxes.p), ml.fine_boxes.n, stream),
+       "fine-side faces of the coarse-fine boundaries");
+    flux_correction_multilevel(p);
+    CK(artemis_hip_ml_stage_fixup(&p, &a, static_cast<const artemis_ml_fix_cell_t *>(ml.fix_cells.p), ml.fix_cells.n, stream),
+       "coarse zones on coarse-fine faces");
+    fill_ghosts(out);
+    cur = out;
+  }
+  base = cur;
+  cons_valid = false;
+}
+
 // One step on the per-task path (artemis_driver.cpp:157-261 literally).
 void artemis_sim_impl::step_unfused() {
   tiny_valid = false; // (another producer of the primitives)
@@ -2598,7 +2722,8 @@ long artemis_sim_impl::evolve(long max_cycles) {
       CK(artemis_rt_stream_sync(stream), "sync");
       est = dev_reduce ? *dt_host : global_min(*dt_host);
     } else {
-      step_unfused();
+      if (ml_fused) step_ml_fused();
+      else step_unfused();
       est = global_min(new_dt_unfused());
     }
     time += dt;
@@ -2880,6 +3005,7 @@ static bool remesh(artemis_sim &h, bool initial) {
   std::vector<artemis_host::Leaf> leaves;
   if (!next_leaves(h, tags, !initial, leaves)) return false;
   std::unique_ptr<artemis_sim_impl> np = build_state(h, &leaves);
+  np->ml_fused = np->ml_fused_possible && h.p->ml_fused; // (artemis_sim_set_path outlives a remesh)
   if (!initial) {
     try {
       np->adopt_state_from(*h.p);
@@ -2973,9 +3099,13 @@ int artemis_sim_block_level(const artemis_sim_t *s, int block) {
   return (block >= 0 && block < s->p->nb) ? s->p->blocks[block].level : -1;
 }
 long artemis_sim_nblocks_global(const artemis_sim_t *s) { return s->p->nblocks_global; }
-int artemis_sim_uses_fused_path(const artemis_sim_t *s) { return s->p->use_fused ? 1 : 0; }
+int artemis_sim_uses_fused_path(const artemis_sim_t *s) { return (s->p->use_fused || (s->p->multilevel && s->p->ml_fused)) ? 1 : 0; }
 int artemis_sim_uses_tuned_kernel(const artemis_sim_t *s) { return (s->p->use_fused && s->p->tuned) ? 1 : 0; }
 const char *artemis_sim_stage_kernel(const artemis_sim_t *s) {
+  if (s->p->multilevel && s->p->ml_fused) {
+    if (s->p->ml_tuned) return "stage_fused_kernel + coarse-fine fix-up";
+    return s->p->general_variant == 2 ? "stage_fused_kernel<curvilinear> + coarse-fine fix-up" : "stage_cell_kernel + coarse-fine fix-up";
+  }
   if (!s->p->use_fused) return "per-task chain";
   if (s->p->tuned) return "stage_fused_kernel";
   if (s->p->general_variant < 0) return "general stage (not run yet)";
@@ -2984,6 +3114,14 @@ const char *artemis_sim_stage_kernel(const artemis_sim_t *s) {
 long artemis_sim_remeshes(const artemis_sim_t *s) { return s->remeshes; }
 int artemis_sim_set_path(artemis_sim_t *s, const char *which) {
   const std::string w = which ? which : "";
+  if (s->p->multilevel && (w == "fused" || w == "unfused")) {
+    if (w == "fused" && !s->p->ml_fused_possible) {
+      g_sim_err = "refined meshes: the one-kernel stages do not cover drag, n-body gravity or the curvilinear decks of the cell-centred stage";
+      return 1;
+    }
+    s->p->ml_fused = (w == "fused");
+    return 0;
+  }
   if (w == "fused") {
     if (!s->p->fused_possible) {
       g_sim_err = "the fused paths do not cover gas diffusion";

@@ -60,6 +60,10 @@ void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t
 void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
                        int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s);
 // kernels_stage2d.hip
+void launch_ml_face_fluxes(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
+                           int recon_dust, int riemann_dust, const artemis_ml_face_box_t *boxes, int nboxes, hipStream_t s);
+void launch_ml_stage_fixup(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
+                           int recon_dust, int riemann_dust, const artemis_ml_fix_cell_t *cells, int ncells, hipStream_t s);
 int stage_general_variant(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
                           int recon_dust, int riemann_dust);
 bool stage2d_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas, int recon_dust,

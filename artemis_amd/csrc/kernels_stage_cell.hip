@@ -54,7 +54,25 @@ struct CellStageArgs {
   // rotating frame from this cell's own mass fluxes, beta cooling
   int diff_on, do_viscosity, rfc_on, cool_on;
   artemis_cooling_t cool;
+  // FIX instantiations only (refined meshes, artemis_hip_ml_stage_fixup): the zones to redo
+  const artemis_ml_fix_cell_t *fix;
+  int nfix;
 };
+
+// The flux fields SetFluxCorrections replaces on a coarse-fine face (kernels_amr.hip flux_ptr: the six conserved
+// fluxes and the pressure flux of gas, the four of dust), read from the arrays at the zone that stores the face;
+// the face velocity is not a flux field and keeps the value the zone computed.
+template <int FLUID>
+ADEV void load_corrected(const FluidView &f, int b, int nv, int ns, int n, int dd, long cf, FaceFlux &F) {
+  double *const *fx = f.flux[dd];
+  const int m0 = b * nv + ns + 3 * n;
+  F.fd = fx[b * nv + n][cf];
+  F.fmx = fx[m0 + dd][cf], F.fmy = fx[m0 + (dd + 1) % 3][cf], F.fmz = fx[m0 + (dd + 2) % 3][cf];
+  if constexpr (FLUID == 0) {
+    F.fe = fx[b * nv + 4 * ns + n][cf], F.feg = fx[b * nv + 5 * ns + n][cf];
+    F.pf = f.pflux[dd][b * ns + n][cf];
+  }
+}
 
 // Stencil of one variable around cell c along a stride: w[3] = cell c, w[3+m] = cell c + m*st.
 template <int RECON>
@@ -155,14 +173,26 @@ ADEV FaceFlux face_of_cell(const PackView &P, const FluidView &f, double *const 
 // STORED: the epilogue form -- face fluxes come from the flux / pressure-flux / face-velocity arrays a
 // preceding CalculateFluxes left in the pack, u0 / u1 from cons0 / cons1, and the new primitives are
 // written in place (nothing here reads a neighbour's primitives).
-template <int FLUID, int RIEMANN, int RECON, bool CURV, bool EXTRA, bool STORED = false>
+// FIX: the zones of a list instead of the interior of every block (flat 256-thread workgroups), with the faces
+// flagged per zone taking the corrected fluxes of a refined mesh from the flux arrays (include/artemis_hip.h,
+// "flux correction as a thin fix-up").
+template <int FLUID, int RIEMANN, int RECON, bool CURV, bool EXTRA, bool STORED = false, bool FIX = false>
 __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, const CellStageArgs a_in) {
-  const int i = P.is + blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = P.js + blockIdx.y * blockDim.y + threadIdx.y;
-  const int nkr = P.ke - P.ks + 1;
-  const int b = blockIdx.z / nkr;
-  const int k = P.ks + blockIdx.z % nkr;
-  if (i > P.ie || j > P.je) return;
+  int i, j, k, b;
+  unsigned fixed_faces = 0u;
+  if constexpr (FIX) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a_in.nfix) return;
+    const artemis_ml_fix_cell_t fc = a_in.fix[t];
+    i = fc.i, j = fc.j, k = fc.k, b = fc.block, fixed_faces = fc.faces;
+  } else {
+    i = P.is + blockIdx.x * blockDim.x + threadIdx.x;
+    j = P.js + blockIdx.y * blockDim.y + threadIdx.y;
+    const int nkr = P.ke - P.ks + 1;
+    b = blockIdx.z / nkr;
+    k = P.ks + blockIdx.z % nkr;
+    if (i > P.ie || j > P.je) return;
+  }
   const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
   CellStageArgs a = a_in;
   if (a.bdt_ptr) a.beta_dt = a.bdt = *a.bdt_ptr; // wave-uniform scalar load
@@ -238,6 +268,10 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
                                                        wp, we);
         up = face_of_cell<FLUID, RIEMANN, RECON, CURV>(P, f, a.in, b, n, dir, 1, k, j, i, wd, w1, w2, w3,
                                                        wp, we);
+      }
+      if constexpr (FIX) {
+        if ((fixed_faces >> (2 * (dir - 1))) & 1u) load_corrected<FLUID>(f, b, nv, ns, n, dir - 1, c, lo);
+        if ((fixed_faces >> (2 * (dir - 1) + 1)) & 1u) load_corrected<FLUID>(f, b, nv, ns, n, dir - 1, c + st, up);
       }
       }
       const double *ax = (dir == 1) ? g.ax1 : ((dir == 2) ? g.ax2 : g.ax3);
@@ -426,13 +460,12 @@ void launch_recon(const PackView &P, int recon, const CellStageArgs &a, hipStrea
   else if (recon == ARTEMIS_PLM) launch_geom<FLUID, RIEMANN, 1>(P, a, s);
   else launch_geom<FLUID, RIEMANN, 2>(P, a, s);
 }
-} // namespace
-
-// The cell-local remainder of a stage over stored fluxes (see STORED above): one kernel per fluid
-void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t &g, hipStream_t s) {
+// The arguments every form of the cell stage derives from the C ABI's (to_cons = 0, no zone list)
+CellStageArgs cell_args(const PackView &P, const artemis_stage_general_args_t &g) {
   CellStageArgs a;
   a.gam0 = g.gam0, a.gam1 = g.gam1, a.beta_dt = g.beta_dt, a.bdt = g.bdt;
   a.bdt_ptr = g.beta_dt_dev;
+  a.in = a.u1 = a.out = nullptr;
   a.to_cons = 0;
   a.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;
   if (a.grav_on) a.grav = *g.gravity;
@@ -443,6 +476,129 @@ void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t
   a.do_viscosity = (g.diffusion && g.diffusion->visc.type != ARTEMIS_DIFF_OFF) ? 1 : 0;
   a.cool_on = (g.cooling != nullptr) && P.gas.ns > 0;
   if (a.cool_on) a.cool = *g.cooling;
+  a.fix = nullptr, a.nfix = 0;
+  return a;
+}
+
+// ---- refined meshes: the fine side's faces on coarse-fine boundaries (artemis_hip_ml_face_fluxes) -----------------
+// One workgroup per box; a thread solves the lower face of direction bx.dir of a zone of the box from register
+// stencils of the `prim` tables (pressure recomputed like the stage kernels: the pressure slot of ghost zones is
+// not maintained on the one-kernel paths) with face_of_cell -- the per-task flux kernel's expression trees -- and
+// stores the task's outputs for that face.
+template <int FLUID, int RIEMANN, int RECON, bool CURV>
+__global__ __launch_bounds__(256) void ml_face_flux_kernel(const PackView P, double *const *prim,
+                                                           const artemis_ml_face_box_t *__restrict__ boxes) {
+  const artemis_ml_face_box_t bx = boxes[blockIdx.x];
+  const FluidView &f = (FLUID == 0) ? P.gas : P.dust;
+  const int ns = f.ns, nv = (FLUID == 0 ? 6 : 4) * ns;
+  const int b = bx.block, dir = bx.dir + 1, d = bx.dir;
+  const long st = (dir == 1) ? 1 : ((dir == 2) ? P.sj : P.sk);
+  const long ncell = static_cast<long>(bx.n[0]) * bx.n[1] * bx.n[2];
+  constexpr int R = (RECON == 2) ? 3 : ((RECON == 1) ? 2 : 1);
+  for (long t = threadIdx.x; t < ncell; t += blockDim.x) {
+    const int i = bx.lo[0] + static_cast<int>(t % bx.n[0]), j = bx.lo[1] + static_cast<int>((t / bx.n[0]) % bx.n[1]);
+    const int k = bx.lo[2] + static_cast<int>(t / (static_cast<long>(bx.n[0]) * bx.n[1]));
+    const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
+    for (int n = 0; n < ns; ++n) {
+      const double *qd = prim[b * nv + n], *q1 = prim[b * nv + ns + 3 * n + 0];
+      const double *q2 = prim[b * nv + ns + 3 * n + 1], *q3 = prim[b * nv + ns + 3 * n + 2];
+      const double *qe = (FLUID == 0) ? prim[b * nv + 5 * ns + n] : nullptr;
+      double wd[7], w1[7], w2[7], w3[7], wp[7], we[7];
+#pragma unroll
+      for (int m = 0; m < 7; ++m) wd[m] = w1[m] = w2[m] = w3[m] = wp[m] = we[m] = 0.0;
+#pragma unroll
+      for (int m = -R; m < R; ++m) { // the R zones on either side of the face (zone c is the one above it)
+        wd[3 + m] = qd[c + m * st], w1[3 + m] = q1[c + m * st], w2[3 + m] = q2[c + m * st], w3[3 + m] = q3[c + m * st];
+        if constexpr (FLUID == 0) {
+          we[3 + m] = qe[c + m * st];
+          wp[3 + m] = amax(0.0, P.gm1 * wd[3 + m] * we[3 + m]);
+        }
+      }
+      const FaceFlux F = face_of_cell<FLUID, RIEMANN, RECON, CURV>(P, f, prim, b, n, dir, 0, k, j, i, wd, w1, w2, w3, wp, we);
+      const int m0 = b * nv + ns + 3 * n;
+      f.flux[d][b * nv + n][c] = F.fd;
+      f.flux[d][m0 + d][c] = F.fmx, f.flux[d][m0 + (d + 1) % 3][c] = F.fmy, f.flux[d][m0 + (d + 2) % 3][c] = F.fmz;
+      if constexpr (FLUID == 0) {
+        f.flux[d][b * nv + 4 * ns + n][c] = F.fe, f.flux[d][b * nv + 5 * ns + n][c] = F.feg;
+        f.pflux[d][b * ns + n][c] = F.pf;
+        f.vface[d][b * ns + n][c] = F.vf;
+      }
+    }
+  }
+}
+
+template <int FLUID, int RIEMANN, int RECON>
+void launch_faces_geom(const PackView &P, double *const *prim, const artemis_ml_face_box_t *boxes, int nboxes, hipStream_t s) {
+  if (P.coords == ARTEMIS_CARTESIAN)
+    hipLaunchKernelGGL((ml_face_flux_kernel<FLUID, RIEMANN, RECON, false>), dim3(nboxes), dim3(256), 0, s, P, prim, boxes);
+  else
+    hipLaunchKernelGGL((ml_face_flux_kernel<FLUID, RIEMANN, RECON, true>), dim3(nboxes), dim3(256), 0, s, P, prim, boxes);
+}
+template <int FLUID, int RIEMANN>
+void launch_faces_recon(const PackView &P, int recon, double *const *prim, const artemis_ml_face_box_t *boxes, int nboxes,
+                        hipStream_t s) {
+  if (recon == ARTEMIS_PCM) launch_faces_geom<FLUID, RIEMANN, 0>(P, prim, boxes, nboxes, s);
+  else if (recon == ARTEMIS_PLM) launch_faces_geom<FLUID, RIEMANN, 1>(P, prim, boxes, nboxes, s);
+  else launch_faces_geom<FLUID, RIEMANN, 2>(P, prim, boxes, nboxes, s);
+}
+
+template <int FLUID, int RIEMANN, int RECON>
+void launch_fix_geom(const PackView &P, const CellStageArgs &a, hipStream_t s) {
+  const dim3 grid((a.nfix + TX * TY - 1) / (TX * TY)), block(TX * TY);
+  if (P.coords == ARTEMIS_CARTESIAN)
+    hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, false, true, false, true>), grid, block, 0, s, P, a);
+  else
+    hipLaunchKernelGGL((stage_cell_kernel<FLUID, RIEMANN, RECON, true, true, false, true>), grid, block, 0, s, P, a);
+}
+template <int FLUID, int RIEMANN>
+void launch_fix_recon(const PackView &P, int recon, const CellStageArgs &a, hipStream_t s) {
+  if (recon == ARTEMIS_PCM) launch_fix_geom<FLUID, RIEMANN, 0>(P, a, s);
+  else if (recon == ARTEMIS_PLM) launch_fix_geom<FLUID, RIEMANN, 1>(P, a, s);
+  else launch_fix_geom<FLUID, RIEMANN, 2>(P, a, s);
+}
+} // namespace
+
+void launch_ml_face_fluxes(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
+                           int recon_dust, int riemann_dust, const artemis_ml_face_box_t *boxes, int nboxes, hipStream_t s) {
+  if (nboxes <= 0) return;
+  if (P.gas.ns) {
+    const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;
+    if (riemann_gas == ARTEMIS_HLLC) launch_faces_recon<0, 0>(P, recon, g.gas_in, boxes, nboxes, s);
+    else if (riemann_gas == ARTEMIS_HLLE) launch_faces_recon<0, 1>(P, recon, g.gas_in, boxes, nboxes, s);
+    else launch_faces_recon<0, 2>(P, recon, g.gas_in, boxes, nboxes, s);
+  }
+  if (P.dust.ns) {
+    const int recon = g.pcm ? ARTEMIS_PCM : recon_dust;
+    if (riemann_dust == ARTEMIS_HLLE) launch_faces_recon<1, 1>(P, recon, g.dust_in, boxes, nboxes, s);
+    else launch_faces_recon<1, 2>(P, recon, g.dust_in, boxes, nboxes, s);
+  }
+}
+
+// The listed zones once more, flagged faces from the corrected flux arrays (FIX above): one launch per fluid
+void launch_ml_stage_fixup(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
+                           int recon_dust, int riemann_dust, const artemis_ml_fix_cell_t *cells, int ncells, hipStream_t s) {
+  if (ncells <= 0) return;
+  CellStageArgs a = cell_args(P, g);
+  a.fix = cells, a.nfix = ncells;
+  if (P.gas.ns) {
+    a.in = g.gas_in, a.u1 = g.gas_u1, a.out = g.gas_out;
+    const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;
+    if (riemann_gas == ARTEMIS_HLLC) launch_fix_recon<0, 0>(P, recon, a, s);
+    else if (riemann_gas == ARTEMIS_HLLE) launch_fix_recon<0, 1>(P, recon, a, s);
+    else launch_fix_recon<0, 2>(P, recon, a, s);
+  }
+  if (P.dust.ns) {
+    a.in = g.dust_in, a.u1 = g.dust_u1, a.out = g.dust_out;
+    const int recon = g.pcm ? ARTEMIS_PCM : recon_dust;
+    if (riemann_dust == ARTEMIS_HLLE) launch_fix_recon<1, 1>(P, recon, a, s);
+    else launch_fix_recon<1, 2>(P, recon, a, s);
+  }
+}
+
+// The cell-local remainder of a stage over stored fluxes (see STORED above): one kernel per fluid
+void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t &g, hipStream_t s) {
+  CellStageArgs a = cell_args(P, g);
+  const bool cart = (P.coords == ARTEMIS_CARTESIAN);
   const dim3 grid = interior_grid(P);
   if (P.gas.ns) {
     a.in = a.u1 = a.out = P.gas.prim;
@@ -476,19 +632,8 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
     launch_stage_fused_curv(P, g, recon_gas, riemann_gas, s);
     return;
   }
-  CellStageArgs a;
-  a.gam0 = g.gam0, a.gam1 = g.gam1, a.beta_dt = g.beta_dt, a.bdt = g.bdt;
-  a.bdt_ptr = g.beta_dt_dev;
+  CellStageArgs a = cell_args(P, g);
   a.to_cons = g.drag ? 1 : 0;
-  a.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;
-  if (a.grav_on) a.grav = *g.gravity;
-  const bool cart = (P.coords == ARTEMIS_CARTESIAN);
-  a.rf_on = (g.rf_omega != 0.0) && cart, a.rf_omega = g.rf_omega, a.rf_qshear = g.rf_qshear;
-  a.rfc_on = (g.rf_omega != 0.0) && !cart;
-  a.diff_on = (g.diffusion != nullptr) && P.gas.ns > 0;
-  a.do_viscosity = (g.diffusion && g.diffusion->visc.type != ARTEMIS_DIFF_OFF) ? 1 : 0;
-  a.cool_on = (g.cooling != nullptr) && P.gas.ns > 0;
-  if (a.cool_on) a.cool = *g.cooling;
   if (P.gas.ns) {
     a.in = g.gas_in, a.u1 = g.gas_u1, a.out = g.gas_out;
     const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;

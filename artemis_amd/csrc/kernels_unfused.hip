@@ -5,6 +5,7 @@
 // Thread mapping everywhere: threadIdx.x walks i (contiguous, coalesced 8-byte lanes),
 // blockIdx.y/threadIdx.y walk j, blockIdx.z walks (block, k).
 #include <cfloat>
+#include <map>
 #include <vector>
 
 #include "device_math.hpp"
@@ -468,6 +469,18 @@ struct FillTabs {
   double *const *dust; // [nb][4*nsd]
   int nsg, nsd, b;
 };
+// The blocks one launch of a per-face condition kernel serves (blockIdx.y picks the block): a refined disk has
+// hundreds of boundary blocks per face, and one 5 us launch per block and face was 14 % of its GPU time.
+constexpr int FACE_BATCH = 240;
+struct BlockList {
+  int n; // 0: the block is FillTabs::b (single-block launch)
+  int b[FACE_BATCH];
+};
+__device__ __forceinline__ FillTabs tabs_of(const FillTabs &t, const BlockList &l) {
+  FillTabs o = t;
+  if (l.n > 0) o.b = l.b[blockIdx.y];
+  return o;
+}
 // v-th FillGhost variable of block b and whether it is the velocity component along d
 __device__ __forceinline__ double *fill_var(const FillTabs &t, int v, int d, bool &normal) {
   const int ngas = 5 * t.nsg;
@@ -482,8 +495,9 @@ __device__ __forceinline__ double *fill_var(const FillTabs &t, int v, int d, boo
   return t.dust[t.b * 4 * t.nsd + w];
 }
 
-__global__ __launch_bounds__(256) void bc_kernel(const BcArgs a, const FillTabs t, int ni, int nj,
-                                                 int nk) {
+__global__ __launch_bounds__(256) void bc_kernel(const BcArgs a, const FillTabs t_in, int ni, int nj,
+                                                 int nk, const BlockList bl) {
+  const FillTabs t = tabs_of(t_in, bl);
   // slab extents: ng along d, full extent along the others
   int ext[3] = {ni, nj, nk};
   ext[a.d] = a.ng;
@@ -528,8 +542,9 @@ struct StratBcArgs {
   int both; // one launch fills the inner and the outer slab (disjoint zones, both read active zones only)
   double q, om0, x1f0, dx1;
 };
-__global__ __launch_bounds__(256) void strat_bc_kernel(const StratBcArgs a_in, const FillTabs t,
-                                                       const double *geom, int ni, int nj, int nk) {
+__global__ __launch_bounds__(256) void strat_bc_kernel(const StratBcArgs a_in, const FillTabs t_in,
+                                                       const double *geom, int ni, int nj, int nk, const BlockList bl) {
+  const FillTabs t = tabs_of(t_in, bl);
   StratBcArgs a = a_in;
   int ext[3] = {ni, nj, nk};
   ext[a.d] = a.ng;
@@ -624,8 +639,9 @@ struct CondBcArgs {
   double g_temp, flux, gx, coeff, cv, gm1, temp_exp, rho_exp, T_ref, rho_ref;
   int type;
 };
-__global__ __launch_bounds__(256) void conductive_bc_kernel(const CondBcArgs a, const FillTabs t,
-                                                            const PackView P) {
+__global__ __launch_bounds__(256) void conductive_bc_kernel(const CondBcArgs a, const FillTabs t_in,
+                                                            const PackView P, const BlockList bl) {
+  const FillTabs t = tabs_of(t_in, bl);
   const int ni = P.ni, nj = P.nj, nk = P.nk;
   int ext[3] = {ni, nj, nk};
   ext[a.d] = a.ng;
@@ -684,7 +700,9 @@ struct DiskBcArgs {
   double omf, nu0, nu_indx, r0, mdot;
   double *const *ic_gas, *const *ic_dust;
 };
-__global__ __launch_bounds__(256) void disk_bc_kernel(const DiskBcArgs a, const FillTabs t, const PackView P) {
+__global__ __launch_bounds__(256) void disk_bc_kernel(const DiskBcArgs a, const FillTabs t_in, const PackView P,
+                                                      const BlockList bl) {
+  const FillTabs t = tabs_of(t_in, bl);
   const int ni = P.ni, nj = P.nj, nk = P.nk;
   int ext[3] = {ni, nj, nk};
   ext[a.d] = a.ng;
@@ -1023,58 +1041,78 @@ static FillTabs fill_tabs(const PackView &P, int b) {
   return t;
 }
 
-// Sequential fallback used when a block carries a user (strat) condition: those read
+// Sequential fallback used when a block carries a user (strat / disk / conductive) condition: those read
 // neighbouring zones of the fill direction and limit velocities, so they do not compose into
 // index maps.  Order as parthenon applies it: periodic images of every direction, then x1,
-// x2, x3 physical / user conditions, each over the entire extent of the other dimensions.
-static void launch_bc_sequential(const PackView &P, int b, const int *bc6,
+// x2, x3 physical / user conditions, each over the entire extent of the other dimensions.  The order only binds
+// within a block, so the blocks that carry the same condition on the same face share a launch (blockIdx.y).
+static void launch_bc_sequential(const PackView &P, const std::vector<int> &blocks, const int *bc,
                                  const artemis_bc_params_t *par, hipStream_t s) {
-  const FillTabs t = fill_tabs(P, b);
+  if (blocks.empty()) return;
   const int st[3] = {P.is, P.js, P.ks}, en[3] = {P.ie, P.je, P.ke}, ext[3] = {P.ni, P.nj, P.nk};
+  auto flag_of = [&](int b, int f) { return (f / 2 < P.ndim) ? bc[b * 6 + f] : static_cast<int>(ARTEMIS_BC_NONE); };
   for (int pass = 0; pass < 2; ++pass)
     for (int d = 0; d < P.ndim; ++d)
       for (int side = 0; side < 2; ++side) {
-        const int flag = bc6[2 * d + side];
-        if (flag == ARTEMIS_BC_NONE || (pass == 0) != (flag == ARTEMIS_BC_PERIODIC)) continue;
         long ncell = P.ng;
         for (int q = 0; q < 3; ++q)
           if (q != d) ncell *= ext[q];
-        if (flag == ARTEMIS_BC_CONDUCTIVE) {
-          CondBcArgs a;
-          a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
-          a.g_temp = par->cond_temp, a.flux = par->cond_flux, a.gx = par->cond_g[d];
-          a.coeff = par->cond_coeff, a.cv = par->cond_cv, a.gm1 = P.gm1, a.type = par->cond_type;
-          a.temp_exp = par->cond_temp_exp, a.rho_exp = par->cond_rho_exp, a.T_ref = par->cond_T_ref;
-          a.rho_ref = par->cond_rho_ref;
-          hipLaunchKernelGGL(conductive_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P);
-        } else if (flag == ARTEMIS_BC_IC || flag == ARTEMIS_BC_DISK_EXTRAP || flag == ARTEMIS_BC_DISK_VISC) {
-          DiskBcArgs a;
-          a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
-          a.extrap = (flag != ARTEMIS_BC_IC), a.visc = (flag == ARTEMIS_BC_DISK_VISC), a.omf = par->disk_omf;
-          a.nu0 = par->disk_nu0, a.nu_indx = par->disk_nu_indx, a.r0 = par->disk_r0, a.mdot = par->disk_mdot;
-          a.ic_gas = par->ic_gas, a.ic_dust = par->ic_dust;
-          hipLaunchKernelGGL(disk_bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P);
-        } else if (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW) {
-          const bool pair = (bc6[2 * d] == bc6[2 * d + 1]); // same condition on both faces: one launch
+        // group the blocks by (condition, same-on-both-faces)
+        std::map<std::pair<int, int>, std::vector<int>> groups;
+        for (int b : blocks) {
+          const int flag = flag_of(b, 2 * d + side);
+          if (flag == ARTEMIS_BC_NONE || (pass == 0) != (flag == ARTEMIS_BC_PERIODIC)) continue;
+          const bool strat = (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW);
+          const int pair = (strat && flag_of(b, 2 * d) == flag_of(b, 2 * d + 1)) ? 1 : 0; // one launch fills both faces
           if (pair && side == 1) continue;
-          StratBcArgs a;
-          a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d], a.both = pair ? 1 : 0;
-          a.q = par->qshear, a.om0 = par->omega, a.x1f0 = 0.0, a.dx1 = 0.0;
-          const long nthr = pair ? 2 * ncell : ncell;
-          hipLaunchKernelGGL(strat_bc_kernel, dim3((nthr + 255) / 256), dim3(256), 0, s, a, t, P.geom,
-                             P.ni, P.nj, P.nk);
-        } else {
-          BcArgs a;
-          a.d = d, a.side = side, a.bc = flag, a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;
-          a.n_act = en[d] - st[d] + 1, a.st = st[d], a.en = en[d], a.ng = P.ng;
-          hipLaunchKernelGGL(bc_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P.ni, P.nj,
-                             P.nk);
+          groups[std::make_pair(flag, pair)].push_back(b);
+        }
+        for (auto &kv : groups) {
+          const int flag = kv.first.first, pair = kv.first.second;
+          const std::vector<int> &bs = kv.second;
+          for (size_t q0 = 0; q0 < bs.size(); q0 += FACE_BATCH) {
+            BlockList bl;
+            bl.n = static_cast<int>(std::min<size_t>(FACE_BATCH, bs.size() - q0));
+            for (int q = 0; q < bl.n; ++q) bl.b[q] = bs[q0 + q];
+            const FillTabs t = fill_tabs(P, bl.b[0]);
+            const unsigned ny = static_cast<unsigned>(bl.n);
+            if (flag == ARTEMIS_BC_CONDUCTIVE) {
+              CondBcArgs a;
+              a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
+              a.g_temp = par->cond_temp, a.flux = par->cond_flux, a.gx = par->cond_g[d];
+              a.coeff = par->cond_coeff, a.cv = par->cond_cv, a.gm1 = P.gm1, a.type = par->cond_type;
+              a.temp_exp = par->cond_temp_exp, a.rho_exp = par->cond_rho_exp, a.T_ref = par->cond_T_ref;
+              a.rho_ref = par->cond_rho_ref;
+              hipLaunchKernelGGL(conductive_bc_kernel, dim3((ncell + 255) / 256, ny), dim3(256), 0, s, a, t, P, bl);
+            } else if (flag == ARTEMIS_BC_IC || flag == ARTEMIS_BC_DISK_EXTRAP || flag == ARTEMIS_BC_DISK_VISC) {
+              DiskBcArgs a;
+              a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
+              a.extrap = (flag != ARTEMIS_BC_IC), a.visc = (flag == ARTEMIS_BC_DISK_VISC), a.omf = par->disk_omf;
+              a.nu0 = par->disk_nu0, a.nu_indx = par->disk_nu_indx, a.r0 = par->disk_r0, a.mdot = par->disk_mdot;
+              a.ic_gas = par->ic_gas, a.ic_dust = par->ic_dust;
+              hipLaunchKernelGGL(disk_bc_kernel, dim3((ncell + 255) / 256, ny), dim3(256), 0, s, a, t, P, bl);
+            } else if (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW) {
+              StratBcArgs a;
+              a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d], a.both = pair ? 1 : 0;
+              a.q = par->qshear, a.om0 = par->omega, a.x1f0 = 0.0, a.dx1 = 0.0;
+              const long nthr = pair ? 2 * ncell : ncell;
+              hipLaunchKernelGGL(strat_bc_kernel, dim3((nthr + 255) / 256, ny), dim3(256), 0, s, a, t, P.geom,
+                                 P.ni, P.nj, P.nk, bl);
+            } else {
+              BcArgs a;
+              a.d = d, a.side = side, a.bc = flag, a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;
+              a.n_act = en[d] - st[d] + 1, a.st = st[d], a.en = en[d], a.ng = P.ng;
+              hipLaunchKernelGGL(bc_kernel, dim3((ncell + 255) / 256, ny), dim3(256), 0, s, a, t, P.ni, P.nj,
+                                 P.nk, bl);
+            }
+          }
         }
       }
 }
 
 // PrimToCons's primitive floors (fill_derived.cpp:227, :245, :262) on the ghost zones of block t.b
-__global__ __launch_bounds__(256) void floor_ghost_kernel(const FillTabs t, const PackView P) {
+__global__ __launch_bounds__(256) void floor_ghost_kernel(const FillTabs t_in, const PackView P, const BlockList bl) {
+  const FillTabs t = tabs_of(t_in, bl);
   const long n = static_cast<long>(P.ni) * P.nj * P.nk;
   const long c = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (c >= n) return;
@@ -1099,13 +1137,30 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
     const PackView &P;
     const artemis_bc_params_t *par;
     hipStream_t s;
+    const int *bc;
     ~FloorAfter() {
       if (!par || !par->floor_ghosts) return;
+      // only a condition that computes values can leave something below a floor, and only in the block it fills
+      // (copies, restrictions and limited prolongations of floored zones are floored): those blocks, batched
       const long n = static_cast<long>(P.ni) * P.nj * P.nk;
-      for (int b = 0; b < P.nb; ++b)
-        hipLaunchKernelGGL(floor_ghost_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fill_tabs(P, b), P);
+      BlockList bl;
+      bl.n = 0;
+      auto flush = [&]() {
+        if (bl.n == 0) return;
+        hipLaunchKernelGGL(floor_ghost_kernel, dim3((n + 255) / 256, bl.n), dim3(256), 0, s, fill_tabs(P, bl.b[0]), P, bl);
+        bl.n = 0;
+      };
+      for (int b = 0; b < P.nb; ++b) {
+        bool value = false;
+        for (int f = 0; f < 2 * P.ndim; ++f)
+          value = value || bc[b * 6 + f] >= ARTEMIS_BC_CONDUCTIVE || bc[b * 6 + f] == ARTEMIS_BC_STRAT_EXTRAP;
+        if (!value) continue;
+        bl.b[bl.n++] = b;
+        if (bl.n == FACE_BATCH) flush();
+      }
+      flush();
     }
-  } floor_after{P, par, s};
+  } floor_after{P, par, s, bc};
   ShellArgs a;
   a.lo[0] = P.is, a.lo[1] = P.js, a.lo[2] = P.ks, a.hi[0] = P.ie, a.hi[1] = P.je, a.hi[2] = P.ke;
   a.ext[0] = P.ni, a.ext[1] = P.nj, a.ext[2] = P.nk;
@@ -1118,6 +1173,7 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
   if (n >= (1L << 31)) return 3; // (a block with 2^31 shell zones)
   ShellBatch batch;
   int nq = 0;
+  std::vector<int> user_blocks; // blocks with a user condition: per-face launches, batched over the blocks
   auto flush = [&]() {
     if (nq == 0) return;
     for (int f = 0; f < 6; ++f) a.bc[f] = ARTEMIS_BC_NONE; // (the kernel takes the flags from the batch)
@@ -1136,7 +1192,7 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
     }
     if (!any) continue;
     if (user) {
-      launch_bc_sequential(P, b, fl, par, s);
+      user_blocks.push_back(b);
       continue;
     }
     batch.blk[nq] = b;
@@ -1144,6 +1200,7 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
     if (++nq == BC_BATCH) flush();
   }
   flush();
+  launch_bc_sequential(P, user_blocks, bc, par, s);
   return 0;
 }
 

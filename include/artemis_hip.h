@@ -573,6 +573,37 @@ int artemis_hip_ml_restrict_halos(const artemis_pack_t *p, const artemis_ml_pack
 int artemis_hip_ml_prolongate(const artemis_pack_t *p, const artemis_ml_pack_t *ml, const artemis_ml_box_t *boxes_dev,
                               int nboxes, void *stream);
 
+/* ---- one-kernel stages on a refined mesh: flux correction as a thin fix-up ------------------------
+ * The reference corrects the coarse side of every coarse-fine face between CalculateFluxes and ApplyUpdate
+ * (artemis_driver.cpp:196-202), which is why its stage needs the flux arrays.  Only the coarse zones that touch such
+ * a face see the corrected flux, so a refined mesh can run the one-kernel stages (artemis_hip_stage_fused,
+ * artemis_hip_stage_general: no flux arrays) on every block and then redo exactly those zones:
+ *   1. artemis_hip_stage_fused / artemis_hip_stage_general on the whole pack (prim_in -> prim_out);
+ *   2. artemis_hip_ml_face_fluxes: the fine side's faces on the coarse-fine boundaries, from prim_in, into the
+ *      flux / pflux arrays of the pack (only those entries) -- what CalculateFluxes leaves there;
+ *   3. artemis_hip_ml_flux_correction (and the messages between ranks) exactly as on the per-task chain: the
+ *      restricted fine fluxes land in the coarse blocks' flux / pflux / diff_flux entries of those faces;
+ *   4. artemis_hip_ml_stage_fixup: the listed coarse zones again, the whole stage from prim_in with the same device
+ *      functions as artemis_hip_stage_general's cell-centred form, except that the faces flagged in `faces` take
+ *      their mass / momentum / energy / pressure fluxes from the arrays step 3 wrote (the face velocity is not a
+ *      flux field and stays the zone's own, as in the reference) -- the same sum, in the same order, as
+ *      ApplyUpdate after SetFluxCorrections; results overwrite prim_out at those zones.
+ * Diffusion fluxes: the caller computed them for the whole pack before step 1 (artemis_hip_zero_viscous_flux);
+ * step 3 corrects them in place and step 4 reads them like the stage kernels do.  args: the arguments of step 1
+ * (dt_dev is ignored: estimate the timestep after the fix-up).  Drag is not supported here (it couples the
+ * fluids after the update; such decks keep the per-task chain on refined meshes). */
+typedef struct artemis_ml_face_box { /* faces of direction dir stored at the zones of a box of one block */
+  int block, dir, lo[3], n[3];
+} artemis_ml_face_box_t;
+typedef struct artemis_ml_fix_cell {
+  int block, k, j, i;
+  unsigned faces; /* bit 2 d + side: the lower (side 0) / upper (side 1) face of direction d is a corrected one */
+} artemis_ml_fix_cell_t;
+int artemis_hip_ml_face_fluxes(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
+                               const artemis_ml_face_box_t *boxes_dev, int nboxes, void *stream);
+int artemis_hip_ml_stage_fixup(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
+                               const artemis_ml_fix_cell_t *cells_dev, int ncells, void *stream);
+
 /* ---- refinement criteria (utils/refinement/amr_criteria.hpp) ------------------------------------
  * ArtemisUtils::ScalarFirstDerivative<FIELD, GEOM> (:28-132) and ScalarMagnitude<FIELD> (:137-168): the
  * block-wide maximum that decides a mesh block's AmrTag, for one cell-centred scalar (the first

@@ -10,6 +10,7 @@
 #include <cfloat>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -509,13 +510,10 @@ int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_gene
   return 0;
 }
 int artemis_hip_stage_general_variant(const artemis_pack_t *, const artemis_stage_general_args_t *) { return 0; }
-int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a_in, void *) {
-  artemis_stage_general_args_t args = *a_in;
-  if (args.beta_dt_dev) args.beta_dt = args.bdt = *args.beta_dt_dev; // "device" memory is host memory here
-  const artemis_stage_general_args_t *a = &args;
-  if ((p->gas.nspecies && a->gas_in == a->gas_out) || (p->dust.nspecies && a->dust_in == a->dust_out))
-    return bad("*_out must not alias *_in");
-  for (int b = 0; b < p->nblocks; ++b) {
+// One block through the stage (shared by artemis_hip_stage_general and the refined-mesh fix-up, which redoes the
+// listed zones of the block with the corrected fluxes of their flagged faces)
+static void stage_block(const artemis_pack_t *p, const artemis_stage_general_args_t *a, int b,
+                        const std::vector<const artemis_ml_fix_cell_t *> *fix) {
     Bound B(p, b);
     Sim &s = *B.s;
     B.in(s.gprim, a->gas_u1, s.nvg), B.in(s.dprim, a->dust_u1, s.nvd);
@@ -524,6 +522,18 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
     B.in(s.gprim, a->gas_in, s.nvg), B.in(s.dprim, a->dust_in, s.nvd);
     prim_to_cons(s);
     calculate_fluxes(s, FL_GAS, a->pcm != 0), calculate_fluxes(s, FL_DUST, a->pcm != 0);
+    if (fix) { // refined meshes: the flagged faces take the corrected flux fields from the pack's arrays
+      for (const artemis_ml_fix_cell_t *fc : *fix)
+        for (int d = 0; d < 3; ++d)
+          for (int side = 0; side < 2; ++side) {
+            if (!((fc->faces >> (2 * d + side)) & 1u)) continue;
+            const long st = (d == 0) ? 1 : ((d == 1) ? s.ni : static_cast<long>(s.ni) * s.nj);
+            const long cf = IDX(s, fc->k, fc->j, fc->i) + side * st;
+            for (int v = 0; v < s.nvg; ++v) s.gflux[d][v * s.N + cf] = p->gas.flux[d][b * s.nvg + v][cf];
+            for (int v = 0; v < s.c.ns_gas; ++v) s.gpflux[d][v * s.N + cf] = p->gas.pflux[d][b * s.c.ns_gas + v][cf];
+            for (int v = 0; v < s.nvd; ++v) s.dflux[d][v * s.N + cf] = p->dust.flux[d][b * s.nvd + v][cf];
+          }
+    }
     apply_update(s, a->gam0, a->gam1, a->beta_dt);
     flux_source(s, FL_GAS, a->bdt), flux_source(s, FL_DUST, a->bdt);
     if (a->diffusion) {
@@ -570,6 +580,10 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
     auto put = [&](const RVec &src, double *const *tab, int nvar, bool gas) {
       for (int v = 0; v < nvar; ++v) {
         if (gas && v >= 4 * s.c.ns_gas && v < 5 * s.c.ns_gas) continue; // P is not an output
+        if (fix) { // only the listed zones
+          for (const artemis_ml_fix_cell_t *fc : *fix) tab[b * nvar + v][IDX(s, fc->k, fc->j, fc->i)] = src[v * s.N + IDX(s, fc->k, fc->j, fc->i)];
+          continue;
+        }
         for (int k = s.ks; k <= s.ke; ++k)
           for (int j = s.js; j <= s.je; ++j)
             std::memcpy(tab[b * nvar + v] + IDX(s, k, j, s.is), src.data() + v * s.N + IDX(s, k, j, s.is),
@@ -582,7 +596,54 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
       if (s.c.ns_gas) *a->dt_dev = std::min(*a->dt_dev, a->cfl_gas * estimate_dt(s, FL_GAS));
       if (s.c.ns_dust) *a->dt_dev = std::min(*a->dt_dev, a->cfl_dust * estimate_dt(s, FL_DUST));
     }
+}
+int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a_in, void *) {
+  artemis_stage_general_args_t args = *a_in;
+  if (args.beta_dt_dev) args.beta_dt = args.bdt = *args.beta_dt_dev; // "device" memory is host memory here
+  const artemis_stage_general_args_t *a = &args;
+  if ((p->gas.nspecies && a->gas_in == a->gas_out) || (p->dust.nspecies && a->dust_in == a->dust_out))
+    return bad("*_out must not alias *_in");
+  for (int b = 0; b < p->nblocks; ++b) stage_block(p, a, b, nullptr);
+  return 0;
+}
+// include/artemis_hip.h "flux correction as a thin fix-up": the fine side's faces ...
+int artemis_hip_ml_face_fluxes(const artemis_pack_t *p, const artemis_stage_general_args_t *a, const artemis_ml_face_box_t *boxes,
+                               int nboxes, void *) {
+  if (a->drag) return bad("refined-mesh fix-up: drag is not supported");
+  std::map<int, std::vector<const artemis_ml_face_box_t *>> per_block;
+  for (int q = 0; q < nboxes; ++q) per_block[boxes[q].block].push_back(&boxes[q]);
+  for (auto &kv : per_block) {
+    const int b = kv.first;
+    Bound B(p, b);
+    Sim &s = *B.s;
+    B.in(s.gprim, a->gas_in, s.nvg), B.in(s.dprim, a->dust_in, s.nvd);
+    prim_to_cons(s); // (refreshes the pressure of every zone, ghosts included)
+    calculate_fluxes(s, FL_GAS, a->pcm != 0), calculate_fluxes(s, FL_DUST, a->pcm != 0);
+    for (const artemis_ml_face_box_t *bx : kv.second) {
+      const int d = bx->dir;
+      for (int k = bx->lo[2]; k < bx->lo[2] + bx->n[2]; ++k)
+        for (int j = bx->lo[1]; j < bx->lo[1] + bx->n[1]; ++j)
+          for (int i = bx->lo[0]; i < bx->lo[0] + bx->n[0]; ++i) {
+            const long c = IDX(s, k, j, i);
+            for (int v = 0; v < s.nvg; ++v) p->gas.flux[d][b * s.nvg + v][c] = s.gflux[d][v * s.N + c];
+            for (int v = 0; v < s.c.ns_gas; ++v) p->gas.pflux[d][b * s.c.ns_gas + v][c] = s.gpflux[d][v * s.N + c];
+            for (int v = 0; v < s.c.ns_gas; ++v) p->gas.vface[d][b * s.c.ns_gas + v][c] = s.gvface[d][v * s.N + c];
+            for (int v = 0; v < s.nvd; ++v) p->dust.flux[d][b * s.nvd + v][c] = s.dflux[d][v * s.N + c];
+          }
+    }
   }
+  return 0;
+}
+// ... and the coarse zones that touch them, redone
+int artemis_hip_ml_stage_fixup(const artemis_pack_t *p, const artemis_stage_general_args_t *a_in, const artemis_ml_fix_cell_t *cells,
+                               int ncells, void *) {
+  artemis_stage_general_args_t args = *a_in;
+  if (args.beta_dt_dev) args.beta_dt = args.bdt = *args.beta_dt_dev;
+  args.dt_dev = nullptr;
+  if (args.drag) return bad("refined-mesh fix-up: drag is not supported");
+  std::map<int, std::vector<const artemis_ml_fix_cell_t *>> per_block;
+  for (int q = 0; q < ncells; ++q) per_block[cells[q].block].push_back(&cells[q]);
+  for (auto &kv : per_block) stage_block(p, &args, kv.first, &kv.second);
   return 0;
 }
 

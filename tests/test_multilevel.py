@@ -173,12 +173,17 @@ def _run_workers(world, spec, tmp_path, tag):
     return run_world(world, spec, tmp_path, tag)
 
 
+# Two ways through a stage on a refined mesh, both bit-identical to the oracle: the per-task chain ("unfused": flux
+# arrays, SetFluxCorrections between CalculateFluxes and ApplyUpdate as the reference does it) and the one-kernel
+# stages with the correction as a fix-up of the coarse zones on coarse-fine faces ("fused", the default where it
+# applies: include/artemis_hip.h).
+@pytest.mark.parametrize("path", ["fused", "unfused"])
 @pytest.mark.parametrize("case", ["blast2d", "visc3d", "twolevel2d", "sph3d"])
-def test_host_driver_on_cpu_double_equals_multilevel_oracle(case, tmp_path):
+def test_host_driver_on_cpu_double_equals_multilevel_oracle(case, path, tmp_path):
     c = CASES[case]
-    res = _run_workers(1, dict(deck=list(c["deck"]), overrides=c["ov"]), tmp_path, case)[0]
+    res = _run_workers(1, dict(deck=list(c["deck"]), overrides=c["ov"], path=path), tmp_path, case)[0]
     m, h0 = run_oracle(case)
-    assert res["meta"]["nblocks"] == len(m.blocks) and not res["meta"]["fused"]
+    assert res["meta"]["nblocks"] == len(m.blocks) and res["meta"]["fused"] == (path == "fused")
     if c["blocks"]:
         lv = [l for l, _ in m.leaves]
         assert (lv.count(0), lv.count(1)) == c["blocks"]
@@ -212,12 +217,19 @@ def test_refined_blocks_split_over_two_ranks_bitwise(tmp_path):
 
 # ---- the HIP path ----------------------------------------------------------------------------------------------
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["fused", "unfused"])
 @pytest.mark.parametrize("case", ["blast2d", "visc3d", "twolevel2d", "sph3d"])
-def test_hip_driver_equals_multilevel_oracle(hiplib, case):
+def test_hip_driver_equals_multilevel_oracle(hiplib, case, path):
+    """`fused`: every block through the one-kernel stage (the tuned tile kernel for the Cartesian blast, its
+    curvilinear instantiation for sph3d, the cell-centred stage for the viscous deck), then the coarse zones on
+    coarse-fine faces redone with the restricted fine fluxes -- the same sum as ApplyUpdate after
+    SetFluxCorrections, which is what `unfused` (the per-task chain) computes literally.  Both equal the oracle."""
     from artemis_amd.driver import Simulation
     c = CASES[case]
     s = Simulation(DECK(*c["deck"]), c["ov"])
-    assert not s.uses_fused_path
+    assert s.uses_fused_path  # the default on refined meshes without drag / n-body
+    s.set_path(path)
+    assert s.uses_fused_path == (path == "fused")
     h0 = s.history()
     s.evolve()
     m, _ = run_oracle(case)
@@ -296,7 +308,7 @@ def test_disk_sph_deck_with_a_static_refinement_region(hiplib):
     reg = region_overrides(1, (0.7, 1.3, -1.0), (1.9, 1.85, 1.0))
     s = Simulation(DECK("disk", "disk_sph.in"), ov + reg)
     lv = [s.block_level(b) for b in range(s.nblocks)]
-    assert s.nblocks == 72 and lv.count(1) == 64 and not s.uses_fused_path
+    assert s.nblocks == 72 and lv.count(1) == 64 and s.uses_fused_path
     d0 = [s.interior(s.field("gas.prim", b))[0].copy() for b in range(s.nblocks)]
     h0 = s.history()
     s.evolve()
@@ -342,7 +354,7 @@ def disk_smr_oracle():
 def test_disk_sph_on_a_refined_mesh_cpu_double_equals_multilevel_oracle(tmp_path):
     res = _run_workers(1, dict(deck=["disk", "disk_sph.in"], overrides=DISK_SMR_OV), tmp_path, "dsmr")[0]
     m = disk_smr_oracle()
-    assert res["meta"]["nblocks"] == len(m.blocks) and not res["meta"]["fused"]
+    assert res["meta"]["nblocks"] == len(m.blocks) and res["meta"]["fused"]
     assert res["meta"]["ncycle"] == m.ncycle == 6 and res["meta"]["dt"] == m.dt and res["meta"]["time"] == m.time
     for b, (bounds, prim) in enumerate(res["blocks"]):
         blk = m.blocks[b]
@@ -394,7 +406,7 @@ def test_gas_and_two_dust_species_on_a_refined_mesh(tmp_path):
     one = _run_workers(1, ADV_SMR, tmp_path, "a1")
     two = _run_workers(2, ADV_SMR, tmp_path, "a2")
     uni = _run_workers(1, dict(ADV_SMR, overrides=ADV_SMR["overrides"][:6]), tmp_path, "au")
-    assert one[0]["meta"]["nblocks"] > uni[0]["meta"]["nblocks"] == 16 and not one[0]["meta"]["fused"]
+    assert one[0]["meta"]["nblocks"] > uni[0]["meta"]["nblocks"] == 16 and one[0]["meta"]["fused"]
     h = one[0]["hist"]
     # history after the run against the analytic integrals of the initial state (advection.py:100-187 pins them on
     # the uniform mesh): gas mass 6.75 = rho0 * volume, dust masses likewise; total momenta of the counter-streaming
@@ -416,7 +428,7 @@ def test_gas_and_two_dust_species_on_a_refined_mesh_hip(hiplib):
     across the level boundaries (periodic domain), all fields finite."""
     from artemis_amd.driver import Simulation
     s = Simulation(DECK(*ADV_SMR["deck"]), ADV_SMR["overrides"] + ["parthenon/time/nlim=12"])
-    assert not s.uses_fused_path and s.nblocks > 16
+    assert s.uses_fused_path and s.nblocks > 16
     h0 = s.history()
     s.evolve()
     h1 = s.history()
