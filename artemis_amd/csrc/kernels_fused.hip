@@ -1022,7 +1022,7 @@ __global__ void wait_counter_kernel(unsigned *counter, unsigned target, unsigned
 // One thread per listed zone: the whole stage of that zone -- 2 ndim faces from register stencils, ApplyUpdate,
 // FluxSource, SetAuxillaryFields, ConsToPrim, PrimToCons, the zone's timestep -- with IEEE `/` and sqrt and the
 // expression trees of the per-task kernels (device_math.hpp plm_dqm / hllc_gas / riemann_gas, kernels_stage_cell.hip's
-// gas branch): the bits of the per-task chain and of the oracle whatever the magnitudes.  Reads prim_in (stencil) and
+// gas branch): the bits of the per-task chain whatever the magnitudes.  Reads prim_in (stencil) and
 // prim_u1 (the zone itself, not yet overwritten: the stage kernel skipped its stores) and writes prim_out / cons_out.
 // Normally the list is empty (the kernel reads the count and returns); velocities of 1e-61 and below next to a shock
 // precursor are what fills it.
