@@ -270,7 +270,7 @@ EXPORTS_HIP = [
     "artemis_hip_ml_exchange", "artemis_hip_ml_flux_correction", "artemis_hip_ml_restrict_halos", "artemis_hip_ml_prolongate",
     "artemis_hip_ml_face_fluxes", "artemis_hip_ml_stage_fixup",
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",
-    "artemis_hip_stage_general", "artemis_hip_stage_general_variant", "artemis_hip_stage_epilogue", "artemis_hip_amr_block_maxima", "artemis_hip_restrict_average",
+    "artemis_hip_stage_general", "artemis_hip_stage_general_variant", "artemis_hip_stage_epilogue", "artemis_hip_stage_epilogue_cons", "artemis_hip_stage_finish", "artemis_hip_amr_block_maxima", "artemis_hip_restrict_average",
     "artemis_hip_prolongate_minmod", "artemis_hip_amr_first_derivative", "artemis_hip_amr_magnitude",
     "artemis_hip_zero_diffusion_flux", "artemis_hip_viscous_distance_count", "artemis_hip_viscous_distance_fill",
     "artemis_hip_viscous_flux", "artemis_hip_zero_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",

@@ -813,7 +813,7 @@ int artemis_hip_stage_general_variant(const artemis_pack_t *p, const artemis_sta
                                         p->dust.riemann);
 }
 
-int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream) {
+static int stage_epilogue_common(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream, bool to_cons) {
   if (int rc = validate(p)) return rc;
   if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");
   if (a->drag) return fail(ARTEMIS_HIP_EUNSUPPORTED, "stage epilogue: drag couples the fluids; use the separate tasks");
@@ -844,9 +844,37 @@ int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_gene
       return fail(ARTEMIS_HIP_EINVAL, "cooling: tref / beta tables are required (artemis_hip_cooling_table_fill)");
     if (!(a->cooling->cv > 0.0)) return fail(ARTEMIS_HIP_EINVAL, "cooling: specific heat cv must be positive");
   }
-  artemis::launch_stage_epilogue(artemis::make_pack_view(*p), *a, S(stream));
-  return after_launch("stage_epilogue");
+  if (to_cons && a->cooling) return fail(ARTEMIS_HIP_EUNSUPPORTED, "stage epilogue (cons): cooling acts after drag; use the separate tasks");
+  artemis::launch_stage_epilogue(artemis::make_pack_view(*p), *a, S(stream), to_cons);
+  return after_launch(to_cons ? "stage_epilogue_cons" : "stage_epilogue");
 }
+int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream) {
+  return stage_epilogue_common(p, a, stream, false);
+}
+int artemis_hip_stage_epilogue_cons(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream) {
+  return stage_epilogue_common(p, a, stream, true);
+}
+int artemis_hip_stage_finish(const artemis_pack_t *p, const artemis_drag_t *drag, double time, double dt, void *stream) {
+  (void)time;
+  if (int rc = validate(p)) return rc;
+  if (int rc = validate_registers(p, "stage finish")) return rc;
+  for (const artemis_fluid_pack_t *f : {&p->gas, &p->dust})
+    if (f->nspecies && !f->prim) return fail(ARTEMIS_HIP_EINVAL, "stage finish: prim tables are required");
+  const artemis::PackView P = artemis::make_pack_view(*p);
+  if (drag) {
+    if (int rc = validate_damp_visc(drag)) return rc;
+    if (drag->type == ARTEMIS_DRAG_SIMPLE_DUST && (p->gas.nspecies < 1 || p->dust.nspecies < 1))
+      return fail(ARTEMIS_HIP_EINVAL, "drag type simple_dust requires do_gas = do_dust = true");
+    if (p->dust.nspecies > ARTEMIS_MAX_DUST_SPECIES)
+      return fail(ARTEMIS_HIP_EUNSUPPORTED, "drag: more than %d dust species", ARTEMIS_MAX_DUST_SPECIES);
+    if (artemis::launch_drag_finish(P, *drag, dt, nullptr, S(stream))) return after_launch("stage_finish");
+    artemis::launch_drag_source(P, *drag, dt, nullptr, S(stream));
+  }
+  if (P.gas.ns) artemis::launch_set_aux(P, S(stream));
+  artemis::launch_cons_to_prim(P, S(stream));
+  return after_launch("stage_finish");
+}
+
 
 static int validate_refine(const artemis_refine_t *r, bool prolongate) {
   if (!r) return fail(ARTEMIS_HIP_EINVAL, "null refinement descriptor");

@@ -2608,6 +2608,31 @@ void artemis_sim_impl::step_unfused() {
       a.diffusion = (do_gas && (do_viscosity || do_conduction)) ? &diff : nullptr;
       a.cooling = (do_cooling && do_gas) ? &cool : nullptr;
       CK(artemis_hip_stage_epilogue(&p, &a, stream), "stage epilogue");
+    } else if (!(do_cooling && do_gas) && std::getenv("ARTEMIS_NO_EPILOGUE") == nullptr) {
+      // drag and / or N-body gravity: the same pass up to the sources that may run before them, the state left
+      // conserved; then NBodyGravity and RotatingFrameForce as tasks (artemis_driver.cpp:222-236 order); then
+      // DragSource + SetAuxillaryFields + ConsToPrim in one pass -- three to five launches instead of ten
+      artemis_stage_general_args_t a;
+      std::memset(&a, 0, sizeof a);
+      a.gam0 = gam0[stage - 1], a.gam1 = gam1[stage - 1], a.beta_dt = beta[stage - 1] * dt, a.bdt = bdt;
+      a.time = time;
+      a.diffusion = (do_gas && (do_viscosity || do_conduction)) ? &diff : nullptr;
+      if (!grav_nbody) {
+        a.gravity = do_gravity ? &grav : nullptr;
+        a.rf_omega = do_rframe ? rf_omega : 0.0, a.rf_qshear = rf_qshear;
+      }
+      CK(artemis_hip_stage_epilogue_cons(&p, &a, stream), "stage epilogue (conserved)");
+      if (grav_nbody) {
+        if (do_gravity) { // gravity.cpp:150-155
+          const Real omf = (do_rframe && nbody_frame_correction) ? rf_omega : 0.0;
+          if (time >= grav.tstart && time < grav.tstop)
+            CK(artemis_hip_nbody_gravity(&p, particles.data(), static_cast<int>(particles.size()), omf, time, bdt,
+                                         particle_force.data(), stream), "NBodyGravity");
+        }
+        if (do_rframe) CK(artemis_hip_rotating_frame_force(&p, rf_omega, rf_qshear, time, bdt, stream), "RotatingFrameForce");
+      }
+      drag.damp_visc = damp_to_visc ? &diff.visc : nullptr;
+      CK(artemis_hip_stage_finish(&p, do_drag ? &drag : nullptr, time, bdt, stream), "DragSource + SetAuxillaryFields + ConsToPrim");
     } else {
       CK(artemis_hip_apply_update(&p, gam0[stage - 1], gam1[stage - 1], beta[stage - 1] * dt, stream), "ApplyUpdate");
       if (do_gas) CK(artemis_hip_flux_source(&p, ARTEMIS_GAS, bdt, stream), "Gas::FluxSource");

@@ -56,7 +56,7 @@ void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double
 void launch_refine(const artemis_refine_t &r, int prolongate, hipStream_t s);
 void launch_amr_criterion(const artemis_amr_criterion_t &a, int magnitude, hipStream_t s);
 void launch_pack_criterion(const PackView &P, int var, int magnitude, double *maxima, hipStream_t s);
-void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t &g, hipStream_t s);
+void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t &g, hipStream_t s, bool to_cons = false);
 void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
                        int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s);
 // kernels_stage2d.hip

@@ -179,29 +179,54 @@ ADEV void nb_accrete(const artemis_nbody_particle_t &p, const double x[3], const
     dEk += 0.5 * (v[i] + vxp) * den * (vxp - v[i]) + 0.5 * den * fm * vxp * vxp;
   }
 }
+// Zone-outer, particle-inner: the geometry of a zone (coordinates, Cartesian frame, scale factors, volume, frame
+// velocity) is formed once and the mesh is walked once, whatever the number of particles; at a zone the additions
+// happen in particle order, as before (round 2 walked the mesh once per particle: 5.8 ms per stage on the 29 M-zone
+// configs[4] mesh, the most expensive kernel of its stage).  The seven running sums of up to NB_CHUNK particles stay
+// in registers (predicated adds: the particle loop is not unrolled); more particles take more passes.
+constexpr int NB_CHUNK = 4;
 __global__ __launch_bounds__(256) void nbody_gravity_kernel(const PackView P, const NBodyView N) {
   __shared__ double red[4][7];
+  __shared__ artemis_nbody_particle_t spl[NB_CHUNK];
   const int nx1 = P.ie - P.is + 1, nx2 = P.je - P.js + 1, nx3 = P.ke - P.ks + 1;
   const long per_block = static_cast<long>(nx1) * nx2 * nx3, total = per_block * P.nb;
-  for (int np = 0; np < N.npart; ++np) {
-    const artemis_nbody_particle_t pl = N.pl[np];
-    double lf[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (pl.couple) {
-      for (long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
-           t += static_cast<long>(gridDim.x) * blockDim.x) {
-        const int b = static_cast<int>(t / per_block);
-        const long r = t - b * per_block;
-        const int i = P.is + static_cast<int>(r % nx1), j = P.js + static_cast<int>((r / nx1) % nx2);
-        const int k = P.ks + static_cast<int>(r / (static_cast<long>(nx1) * nx2));
-        const long c = static_cast<long>(k) * P.sk + static_cast<long>(j) * P.sj + i;
-        const DCoords co = make_coords(P, b, k, j, i);
-        double x[3];
-        co.centre(x);
-        const bool cyl = (co.sys == ARTEMIS_CYLINDRICAL);
-        const Frame fr = cart_frame(co.sys, x, co.cv, co.sv, cyl ? co.cv : co.c3, cyl ? co.sv : co.s3);
-        double hx[3];
-        scale_factors_of(co, hx);
-        const double vol = co.volume();
+  for (int np0 = 0; np0 < N.npart; np0 += NB_CHUNK) {
+    const int nloc = (N.npart - np0 < NB_CHUNK) ? N.npart - np0 : NB_CHUNK;
+    __syncthreads();
+    if (threadIdx.x < nloc) spl[threadIdx.x] = N.pl[np0 + threadIdx.x];
+    __syncthreads();
+    double lf[NB_CHUNK][7];
+#pragma unroll
+    for (int q = 0; q < NB_CHUNK; ++q)
+#pragma unroll
+      for (int m = 0; m < 7; ++m) lf[q][m] = 0.0;
+    for (long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+         t += static_cast<long>(gridDim.x) * blockDim.x) {
+      const int b = static_cast<int>(t / per_block);
+      const long r = t - b * per_block;
+      const int i = P.is + static_cast<int>(r % nx1), j = P.js + static_cast<int>((r / nx1) % nx2);
+      const int k = P.ks + static_cast<int>(r / (static_cast<long>(nx1) * nx2));
+      const long c = static_cast<long>(k) * P.sk + static_cast<long>(j) * P.sj + i;
+      const DCoords co = make_coords(P, b, k, j, i);
+      double x[3];
+      co.centre(x);
+      const bool cyl = (co.sys == ARTEMIS_CYLINDRICAL);
+      const Frame fr = cart_frame(co.sys, x, co.cv, co.sv, cyl ? co.cv : co.c3, cyl ? co.sv : co.s3);
+      double hx[3];
+      scale_factors_of(co, hx);
+      const double vol = co.volume();
+      double vf[3] = {0.0, 0.0, 0.0};
+      if (N.omf != 0.0) {
+        double vrot[3];
+        rotation_velocity(co, N.omf, vrot);
+        vf[0] = fr.e1[0] * vrot[0] + fr.e2[0] * vrot[1] + fr.e3[0] * vrot[2];
+        vf[1] = fr.e1[1] * vrot[0] + fr.e2[1] * vrot[1] + fr.e3[1] * vrot[2];
+        vf[2] = fr.e1[2] * vrot[0] + fr.e2[2] * vrot[1] + fr.e3[2] * vrot[2];
+      }
+#pragma unroll 1
+      for (int q = 0; q < nloc; ++q) {
+        const artemis_nbody_particle_t &pl = spl[q];
+        if (!pl.couple) continue;
         double g[3] = {0.0, 0.0, 0.0};
         {
           double dxp[3];
@@ -213,14 +238,7 @@ __global__ __launch_bounds__(256) void nbody_gravity_kernel(const PackView P, co
         const double gx1 = g[0] * fr.e1[0] + g[1] * fr.e1[1] + g[2] * fr.e1[2];
         const double gx2 = g[0] * fr.e2[0] + g[1] * fr.e2[1] + g[2] * fr.e2[2];
         const double gx3 = g[0] * fr.e3[0] + g[1] * fr.e3[1] + g[2] * fr.e3[2];
-        double vf[3] = {0.0, 0.0, 0.0};
-        if (N.omf != 0.0) {
-          double vrot[3];
-          rotation_velocity(co, N.omf, vrot);
-          vf[0] = fr.e1[0] * vrot[0] + fr.e2[0] * vrot[1] + fr.e3[0] * vrot[2];
-          vf[1] = fr.e1[1] * vrot[0] + fr.e2[1] * vrot[1] + fr.e3[1] * vrot[2];
-          vf[2] = fr.e1[2] * vrot[0] + fr.e2[2] * vrot[1] + fr.e3[2] * vrot[2];
-        }
+        double f7[7] = {0, 0, 0, 0, 0, 0, 0}; // this particle's terms from this zone, in the old order of additions
         auto fluid = [&](const FluidView &f, int nvar, int n, bool gas) {
           const int ns = f.ns;
           const double dens = f.prim[b * nvar + n][c];
@@ -245,29 +263,37 @@ __global__ __launch_bounds__(256) void nbody_gravity_kernel(const PackView P, co
             f.cons0[b * nvar + 4 * ns + n][c] += dek + dei + rdt * (v[0] * gx1 + v[1] * gx2 + v[2] * gx3);
             f.cons0[b * nvar + 5 * ns + n][c] += dei;
           }
-          lf[0] -= vol * dm / N.dt;
-          lf[1] -= g[0] * dens * vol;
-          lf[2] -= g[1] * dens * vol;
-          lf[3] -= g[2] * dens * vol;
-          lf[4] -= dmom[0] / N.dt;
-          lf[5] -= dmom[1] / N.dt;
-          lf[6] -= dmom[2] / N.dt;
+          f7[0] -= vol * dm / N.dt;
+          f7[1] -= g[0] * dens * vol;
+          f7[2] -= g[1] * dens * vol;
+          f7[3] -= g[2] * dens * vol;
+          f7[4] -= dmom[0] / N.dt;
+          f7[5] -= dmom[1] / N.dt;
+          f7[6] -= dmom[2] / N.dt;
         };
         for (int n = 0; n < P.gas.ns; ++n) fluid(P.gas, 6 * P.gas.ns, n, true);
         for (int n = 0; n < P.dust.ns; ++n) fluid(P.dust, 4 * P.dust.ns, n, false);
+#pragma unroll
+        for (int qq = 0; qq < NB_CHUNK; ++qq)
+#pragma unroll
+          for (int m = 0; m < 7; ++m) lf[qq][m] += (qq == q) ? f7[m] : 0.0;
       }
     }
     // fixed-tree reduction: wave shuffles, then the four waves of the workgroup in order
-    for (int q = 0; q < 7; ++q) {
-      double vq = lf[q];
-      for (int off = 32; off > 0; off >>= 1) vq += __shfl_down(vq, off, 64);
-      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = vq;
+#pragma unroll
+    for (int q = 0; q < NB_CHUNK; ++q) {
+      if (q >= nloc) continue; // (workgroup-uniform)
+      for (int m = 0; m < 7; ++m) {
+        double vq = lf[q][m];
+        for (int off = 32; off > 0; off >>= 1) vq += __shfl_down(vq, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][m] = vq;
+      }
+      __syncthreads();
+      if (threadIdx.x < 7)
+        N.partial[(static_cast<long>(np0 + q) * gridDim.x + blockIdx.x) * 7 + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+      __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x < 7)
-      N.partial[(static_cast<long>(np) * gridDim.x + blockIdx.x) * 7 + threadIdx.x] =
-          ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
-    __syncthreads();
   }
 }
 
@@ -541,7 +567,7 @@ __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, c
 
 int nbody_grid(const PackView &P) {
   const long total = static_cast<long>(P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1) * P.nb;
-  return static_cast<int>(std::max<long>(1, std::min<long>(1024, (total + 255) / 256)));
+  return static_cast<int>(std::max<long>(1, std::min<long>(2048, (total + 255) / 256)));
 }
 void launch_nbody_gravity(const PackView &P, const artemis_nbody_particle_t *pl_dev, int npart, double omf, double dt,
                           double *partial_dev, hipStream_t s) {

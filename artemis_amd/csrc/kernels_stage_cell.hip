@@ -596,8 +596,9 @@ void launch_ml_stage_fixup(const PackView &P, const artemis_stage_general_args_t
 }
 
 // The cell-local remainder of a stage over stored fluxes (see STORED above): one kernel per fluid
-void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t &g, hipStream_t s) {
+void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t &g, hipStream_t s, bool to_cons) {
   CellStageArgs a = cell_args(P, g);
+  a.to_cons = to_cons ? 1 : 0; // artemis_hip_stage_epilogue_cons: stop after the sources, state left in cons0
   const bool cart = (P.coords == ARTEMIS_CARTESIAN);
   const dim3 grid = interior_grid(P);
   if (P.gas.ns) {

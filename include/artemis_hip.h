@@ -492,6 +492,17 @@ int artemis_hip_stage_general_variant(const artemis_pack_t *p, const artemis_sta
  * cons0 is NOT updated: the PrimToCons that follows the boundary conditions rebuilds it.  Drag couples
  * the fluids and is not part of it: ARTEMIS_HIP_EUNSUPPORTED, use the separate tasks. */
 int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream);
+/* The same pass when something still has to act on the conserved state before SetAuxillaryFields: DragSource (it
+ * couples the fluids) or NBodyGravity (a task of its own with a reduction the host reads).
+ *   artemis_hip_stage_epilogue_cons: ApplyUpdate, FluxSource, DiffusionUpdate and -- when given -- ExternalGravity and
+ *     RotatingFrameForce, in this order (artemis_driver.cpp:205-236), result left in cons0 (cons1 and the primitives
+ *     untouched).  With N-body gravity pass gravity = NULL and rf_omega = 0 and run artemis_hip_nbody_gravity and
+ *     artemis_hip_rotating_frame_force after it, as the reference orders them.  cooling / drag must be NULL.
+ *   artemis_hip_stage_finish: DragSource (drag != NULL), SetAuxillaryFields and ConsToPrim of cons0 into the
+ *     primitives of the active zones, one pass when one gas species is coupled by simple_dust drag.
+ * Together they replace eight launches of the per-task chain by two or three; same bits. */
+int artemis_hip_stage_epilogue_cons(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream);
+int artemis_hip_stage_finish(const artemis_pack_t *p, const artemis_drag_t *drag, double time, double dt, void *stream);
 
 /* ---- mesh-refinement data-path operators (the operators only) ---------------
  * ArtemisUtils::RestrictAverage<GEOM> (utils/refinement/restriction.hpp:42-114) and

@@ -471,8 +471,9 @@ static void dflux_io(Bound &B, const artemis_pack_t *p, bool out) {
   }
 }
 // the cell-local remainder of a stage over the stored fluxes, through the oracle's tasks
-int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *) {
+static int stage_epilogue_common(const artemis_pack_t *p, const artemis_stage_general_args_t *a, bool to_cons) {
   if (a->drag) return bad("stage epilogue: drag is not part of it");
+  if (to_cons && a->cooling) return bad("stage epilogue (cons): cooling acts after drag");
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);
     Sim &s = *B.s;
@@ -502,12 +503,29 @@ int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_gene
       cooling_source(s, a->time, a->bdt);
       s.grav.type = gtype;
     }
+    if (to_cons) { // artemis_hip_stage_epilogue_cons: the state stays conserved, in cons0
+      B.out(s.gu0, p->gas.cons0, s.nvg), B.out(s.du0, p->dust.cons0, s.nvd);
+      continue;
+    }
     set_aux(s);
     cons_to_prim(s);
     B.out(s.gprim, p->gas.prim, s.nvg), B.out(s.dprim, p->dust.prim, s.nvd);
     B.out(s.gu0, p->gas.cons0, s.nvg), B.out(s.du0, p->dust.cons0, s.nvd);
   }
   return 0;
+}
+int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *) {
+  return stage_epilogue_common(p, a, false);
+}
+int artemis_hip_stage_epilogue_cons(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *) {
+  return stage_epilogue_common(p, a, true);
+}
+int artemis_hip_stage_finish(const artemis_pack_t *p, const artemis_drag_t *drag, double time, double dt, void *st) {
+  if (drag)
+    if (int rc = artemis_hip_drag_source(p, drag, time, dt, st)) return rc;
+  if (p->gas.nspecies)
+    if (int rc = artemis_hip_set_aux(p, st)) return rc;
+  return artemis_hip_cons_to_prim(p, st);
 }
 int artemis_hip_stage_general_variant(const artemis_pack_t *, const artemis_stage_general_args_t *) { return 0; }
 // One block through the stage (shared by artemis_hip_stage_general and the refined-mesh fix-up, which redoes the
