@@ -146,6 +146,14 @@ class AmrCriterion(C.Structure):
                 ("ke", C.c_int), ("refine_thr", C.c_double), ("deref_thr", C.c_double), ("scratch", C.c_void_p)]
 
 
+class MlFaceBox(C.Structure):  # artemis_ml_face_box_t
+    _fields_ = [("block", C.c_int), ("dir", C.c_int), ("lo", C.c_int * 3), ("n", C.c_int * 3)]
+
+
+class MlFixCell(C.Structure):  # artemis_ml_fix_cell_t
+    _fields_ = [("block", C.c_int), ("k", C.c_int), ("j", C.c_int), ("i", C.c_int), ("faces", C.c_uint)]
+
+
 class StageGeneralArgs(C.Structure):
     _fields_ = [
         ("gam0", C.c_double), ("gam1", C.c_double), ("beta_dt", C.c_double), ("bdt", C.c_double),
@@ -201,6 +209,10 @@ def load():
         "artemis_hip_stage_general": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
         "artemis_hip_stage_general_variant": (i, [PPk, C.POINTER(StageGeneralArgs)]),
         "artemis_hip_stage_epilogue": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
+        "artemis_hip_stage_epilogue_cons": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
+        "artemis_hip_ml_face_fluxes": (i, [PPk, C.POINTER(StageGeneralArgs), vp, i, vp]),
+        "artemis_hip_ml_stage_fixup": (i, [PPk, C.POINTER(StageGeneralArgs), vp, i, vp]),
+        "artemis_hip_stage_finish": (i, [PPk, C.POINTER(Drag), d, d, vp]),
         "artemis_hip_restrict_average": (i, [C.POINTER(Refine), vp]),
         "artemis_hip_prolongate_minmod": (i, [C.POINTER(Refine), vp]),
         "artemis_hip_amr_first_derivative": (i, [C.POINTER(AmrCriterion), C.POINTER(C.c_int), C.POINTER(C.c_double), vp]),

@@ -197,9 +197,30 @@ class MeshBlockPack:
             a.diffusion = C.pointer(diffusion)
         if cooling is not None:
             a.cooling = C.pointer(cooling)
+        self._last_general_args = a
         # which kernel this call takes (0 cell-centred, 1 2-D row march, 2 curvilinear streaming tile)
         self.last_stage_variant = self.L.artemis_hip_stage_general_variant(C.byref(self.pack), C.byref(a))
         self._call(self.L.artemis_hip_stage_general, C.byref(a))
+
+    # ---- refined meshes on the one-kernel stages (include/artemis_hip.h "flux correction as a thin fix-up") ----
+    def _device_records(self, records, ctype):
+        arr = (ctype * len(records))(*records)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        return host.to(self.gas_prim.device if self.gas_prim.numel() else self.dust_prim.device)
+
+    def ml_face_fluxes(self, boxes):
+        """artemis_hip_ml_face_fluxes with the arguments of the last stage_general call; boxes = [(block, dir, lo, n)]."""
+        recs = [capi.MlFaceBox(b, d, (C.c_int * 3)(*lo), (C.c_int * 3)(*n)) for b, d, lo, n in boxes]
+        dev = self._device_records(recs, capi.MlFaceBox)
+        self._call(self.L.artemis_hip_ml_face_fluxes, C.byref(self._last_general_args), C.c_void_p(dev.data_ptr()), len(recs))
+        torch.cuda.synchronize()
+
+    def ml_stage_fixup(self, cells):
+        """artemis_hip_ml_stage_fixup with the arguments of the last stage_general call; cells = [(block, k, j, i, faces)]."""
+        recs = [capi.MlFixCell(*c) for c in cells]
+        dev = self._device_records(recs, capi.MlFixCell)
+        self._call(self.L.artemis_hip_ml_stage_fixup, C.byref(self._last_general_args), C.c_void_p(dev.data_ptr()), len(recs))
+        torch.cuda.synchronize()
 
     def stage_epilogue(self, gam0, gam1, beta_dt, bdt, time=0.0, gravity=None, rotating_frame=None,
                        diffusion=None, cooling=None):
@@ -215,6 +236,22 @@ class MeshBlockPack:
         if cooling is not None:
             a.cooling = C.pointer(cooling)
         self._call(self.L.artemis_hip_stage_epilogue, C.byref(a))
+
+    def stage_epilogue_cons(self, gam0, gam1, beta_dt, bdt, time=0.0, gravity=None, rotating_frame=None, diffusion=None):
+        """artemis_hip_stage_epilogue_cons: ApplyUpdate ... RotatingFrameForce over the stored fluxes, state left in cons0."""
+        a = capi.StageGeneralArgs()
+        a.gam0, a.gam1, a.beta_dt, a.bdt, a.time = gam0, gam1, beta_dt, bdt, time
+        if gravity is not None:
+            a.gravity = C.pointer(gravity)
+        if rotating_frame is not None:
+            a.rf_omega, a.rf_qshear = rotating_frame
+        if diffusion is not None:
+            a.diffusion = C.pointer(diffusion)
+        self._call(self.L.artemis_hip_stage_epilogue_cons, C.byref(a))
+
+    def stage_finish(self, time, dt, drag=None):
+        """artemis_hip_stage_finish: [DragSource] + SetAuxillaryFields + ConsToPrim of cons0 into the primitives."""
+        self._call(self.L.artemis_hip_stage_finish, C.byref(drag) if drag is not None else None, time, dt)
 
     # ---- gas diffusion (artemis_driver.cpp:189-193, :218-221) -----------------------------------
     def ZeroDiffusionFlux(self):

@@ -417,3 +417,146 @@ def test_stage_epilogue_over_stored_fluxes(hiplib, coordinates, nx, lo, hi, stag
     keep = [v for v in range(12) if not (8 <= v < 10)]  # P is ConsToPrim's business only after PrimToCons
     assert np.array_equal(mb.gas_prim[0][I].cpu().numpy()[keep], o.gprim[I][keep])
     same(mb.dust_prim[0][I], o.dprim[I], "dust prim")
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", EXTRA_BLOCKS)
+@pytest.mark.parametrize("with_drag", [True, False])
+def test_stage_epilogue_cons_then_finish(hiplib, coordinates, nx, lo, hi, with_drag):
+    """The per-task chain of a deck with drag (or N-body gravity) in two passes: artemis_hip_stage_epilogue_cons leaves
+    ApplyUpdate + FluxSource + DiffusionUpdate + ExternalGravity + RotatingFrameForce in cons0 (checked on its own: that
+    is where NBodyGravity acts), artemis_hip_stage_finish does DragSource + SetAuxillaryFields + ConsToPrim -- every bit
+    of the eight reference tasks run one by one."""
+    from artemis_amd.pack import MeshBlockPack, diffusion_params, gravity_point, drag_params
+    cart = coordinates == "cartesian"
+    kw = dict(ng=2, ns_gas=1, ns_dust=2, reconstruct="plm", riemann="hllc", dust_reconstruct="plm",
+              dust_riemann="hlle", gamma=1.4, dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10,
+              coordinates=coordinates)
+    o = Oracle(nx, lo, hi, bc=("outflow",) * 6, cfl=0.3, dust_cfl=0.3, **kw)
+    random_state(o, np.random.default_rng(195), shock=False, mach=0.5, contrast=10.0)
+    om, q = 0.8, (1.5 if cart else 0.0)
+    mb = MeshBlockPack(1, nx, [lo], [hi], with_diffusion=True, omega_frame=om, **kw)
+    o.DeepCopyConservedData()
+    o2 = Oracle(nx, lo, hi, bc=("outflow",) * 6, **kw)
+    random_state(o2, np.random.default_rng(196), shock=False, mach=0.5, contrast=10.0)
+    o.gu1[:] = o2.gu0
+    o.du1[:] = o2.du0
+    push([o], mb)
+    pos = (0.1, 0.05, 0.0) if coordinates in ("cartesian", "cylindrical") or nx[2] > 1 else (0.0, 0.0, 0.0)
+    o.set_gravity_point(1.3, soft=0.05, x=pos[0], y=pos[1], z=pos[2])
+    o.set_rotating_frame(om, q)
+    o.set_viscosity("constant", nu=0.03, eta_bulk=0.3)
+    tau = [0.05, 2.0]
+    o.set_drag("simple_dust", "constant", tau=tau)
+    D = diffusion_params(1.4, viscosity=dict(type="constant", nu=0.03, eta_bulk=0.3))
+    drag = drag_params("simple_dust", "constant", tau=tau, mesh_min=lo, mesh_max=hi)
+    grav = gravity_point(1.3, soft=0.05, pos=pos)
+    g0, g1, be = 0.5, 0.5, 0.5
+    dt, time = 2.0e-4, 0.25
+    for fluid in (0, 1):
+        o.CalculateFluxes(fluid, False)
+        mb.CalculateFluxes(fluid, False)
+    o.ZeroDiffusionFlux(), o.ViscousFlux()
+    mb.ZeroDiffusionFlux(), mb.ViscousFlux(D)
+    o.ApplyUpdate(g0, g1, be * dt)
+    for fluid in (0, 1):
+        o.FluxSource(be * dt, fluid)
+    o.DiffusionUpdate(be * dt)
+    o.ExternalGravity(time, be * dt)
+    o.RotatingFrameForce(be * dt)
+    mb.stage_epilogue_cons(g0, g1, be * dt, be * dt, time=time, gravity=grav, rotating_frame=(om, q), diffusion=D)
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    assert np.array_equal(mb.gas_u0[0][I].cpu().numpy(), o.gu0[I])
+    assert np.array_equal(mb.dust_u0[0][I].cpu().numpy(), o.du0[I])
+    if with_drag:
+        o.DragSource(be * dt)
+    o.SetAuxillaryFields()
+    o.ConsToPrim()
+    mb.stage_finish(time, be * dt, drag if with_drag else None)
+    keep = [0, 1, 2, 3, 5]  # P is ConsToPrim's business only after PrimToCons
+    assert np.array_equal(mb.gas_prim[0][I].cpu().numpy()[keep], o.gprim[I][keep])
+    same(mb.dust_prim[0][I], o.dprim[I], "dust prim")
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", EXTRA_BLOCKS[:1] + EXTRA_BLOCKS[3:5])
+def test_refined_mesh_fixup_contract(hiplib, coordinates, nx, lo, hi):
+    """The two entry points behind the one-kernel stages on refined meshes, on one block (the multi-block runs are in
+    test_multilevel.py):
+      * artemis_hip_ml_face_fluxes over a slab of faces stores exactly what CalculateFluxes stores there;
+      * artemis_hip_ml_stage_fixup redoes the listed zones with the flagged faces' mass / momentum / energy / pressure
+        fluxes taken from the flux arrays -- here altered by hand on the upper x1 boundary face and the lower x2 one, the
+        way SetFluxCorrections alters them -- and equals the reference chain (ApplyUpdate ... ConsToPrim) run on the altered
+        arrays bit for bit, face velocity untouched; zones not listed keep the stage kernel's result."""
+    from artemis_amd.pack import MeshBlockPack, diffusion_params, gravity_point
+    kw = dict(ng=2, ns_gas=1, ns_dust=1, reconstruct="plm", riemann="hllc", dust_reconstruct="plm",
+              dust_riemann="hlle", gamma=1.4, dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10,
+              coordinates=coordinates)
+    o = Oracle(nx, lo, hi, bc=("outflow",) * 6, cfl=0.3, dust_cfl=0.3, **kw)
+    random_state(o, np.random.default_rng(295), shock=False, mach=0.5, contrast=10.0)
+    mb = MeshBlockPack(1, nx, [lo], [hi], with_diffusion=True, **kw)
+    o.DeepCopyConservedData()
+    push([o], mb)
+    ndim = 3 if nx[2] > 1 else (2 if nx[1] > 1 else 1)
+    o.set_viscosity("constant", nu=0.03, eta_bulk=0.3)
+    D = diffusion_params(1.4, viscosity=dict(type="constant", nu=0.03, eta_bulk=0.3))
+    dt = 2.0e-4
+    # per-task fluxes on both sides (the arrays the fix-up reads its flagged faces from)
+    for fluid in (0, 1):
+        o.CalculateFluxes(fluid, False)
+        mb.CalculateFluxes(fluid, False)
+    want = [mb.gas_flux[d].clone() for d in range(ndim)], [mb.gas_pflux[d].clone() for d in range(ndim)], \
+           [mb.gas_vface[d].clone() for d in range(ndim)], [mb.dust_flux[d].clone() for d in range(ndim)]
+    for d in range(ndim):  # wipe, then let ml_face_fluxes restore two slabs
+        mb.gas_flux[d].fill_(7.0), mb.gas_pflux[d].fill_(7.0), mb.gas_vface[d].fill_(7.0), mb.dust_flux[d].fill_(7.0)
+    o.ZeroDiffusionFlux(), o.ViscousFlux()
+    mb.ZeroDiffusionFlux(), mb.ViscousFlux(D)
+    gbuf, gout = mb.new_prim_buffer("o")
+    dbuf, dout = mb.new_dust_prim_buffer("o")
+    mb.stage_general(0.0, 1.0, dt, dt, gas=(mb.gas_prim_table, mb.gas_prim_table, gout),
+                     dust=(mb.dust_prim_table, mb.dust_prim_table, dout), diffusion=D)
+    stage_g, stage_d = gbuf.clone(), dbuf.clone()
+    n = [o.ie - o.is_ + 1, o.je - o.js + 1, o.ke - o.ks + 1]
+    boxes = [(0, 0, (o.ie + 1, o.js, o.ks), (1, n[1], n[2]))]
+    if ndim > 1:
+        boxes.append((0, 1, (o.is_, o.js, o.ks), (n[0], 1, n[2])))
+    mb.ml_face_fluxes(boxes)
+    sl = [(slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.ie + 1, o.ie + 2)),
+          (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.js + 1), slice(o.is_, o.ie + 1))]
+    for (b, d, _, _), I in zip(boxes, sl):
+        for got, ref in zip((mb.gas_flux[d], mb.gas_pflux[d], mb.gas_vface[d], mb.dust_flux[d]),
+                            (want[0][d], want[1][d], want[2][d], want[3][d])):
+            assert torch.equal(got[0][I], ref[0][I]), ("face fluxes", d)
+    # SetFluxCorrections by hand: other numbers in the flux fields of those two faces, on both sides
+    rng = np.random.default_rng(7)
+    for (b, d, _, _), I in zip(boxes, sl):
+        for arr_o, arr_m in ((o.gflux(d), mb.gas_flux[d]), (o.gpflux(d), mb.gas_pflux[d]), (o.dflux(d), mb.dust_flux[d])):
+            f = 1.0 + 0.05 * rng.standard_normal(arr_o[I].shape)
+            arr_o[I] = arr_o[I] * f
+            arr_m[0][I] = torch.from_numpy(np.ascontiguousarray(arr_o[I])).to(arr_m.device)
+    o.ApplyUpdate(0.0, 1.0, dt)
+    for fluid in (0, 1):
+        o.FluxSource(dt, fluid)
+    o.DiffusionUpdate(dt)
+    o.SetAuxillaryFields()
+    o.ConsToPrim()
+    cells = {}
+    for k in range(o.ks, o.ke + 1):
+        for j in range(o.js, o.je + 1):
+            cells[(k, j, o.ie)] = cells.get((k, j, o.ie), 0) | 2      # upper x1 face
+        if ndim > 1:
+            for i in range(o.is_, o.ie + 1):
+                cells[(k, o.js, i)] = cells.get((k, o.js, i), 0) | 4  # lower x2 face
+    mb.ml_stage_fixup([(0, k, j, i, f) for (k, j, i), f in cells.items()])
+    keep = [0, 1, 2, 3, 5]
+    g, dd = gbuf[0].cpu().numpy(), dbuf[0].cpu().numpy()
+    listed = np.zeros(g.shape[1:], dtype=bool)
+    for (k, j, i) in cells:
+        listed[k, j, i] = True
+    inter = np.zeros_like(listed)
+    inter[o.ks:o.ke + 1, o.js:o.je + 1, o.is_:o.ie + 1] = True
+    assert listed.sum() > 0 and np.array_equal(g[keep][:, listed], o.gprim[keep][:, listed])
+    assert np.array_equal(dd[:, listed], o.dprim[:, listed])
+    rest = inter & ~listed
+    assert np.array_equal(g[keep][:, rest], stage_g[0].cpu().numpy()[keep][:, rest])
+    assert np.array_equal(dd[:, rest], stage_d[0].cpu().numpy()[:, rest])
+    # and the altered fluxes did matter: the stage kernel's own result differs at the listed zones
+    assert not np.array_equal(stage_g[0].cpu().numpy()[0][listed], g[0][listed])
