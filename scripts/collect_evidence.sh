@@ -4,12 +4,13 @@ cd /root/repo
 g=gpurun_out
 for f in pmc_traffic disk_sph_pmc_traffic cfg3_pmc_traffic pmc_sq; do cp $g/${tag}_$f.json profiles/r03_$f.json; done
 for f in bench_line cfg3_line cfg3_1024_line cfg3_1024_2dust_line disk_sph_line; do cp $g/${tag}_$f.json profiles/r03_$f.json; done
-for f in bench cfg3 disk_sph; do cp $g/${tag}_${f}_kernel_stats.csv profiles/r03_${f}_kernel_stats.csv; done
+for f in bench cfg3 cfg3_1024 disk_sph smr_cart smr_sph amr; do cp $g/${tag}_${f}_kernel_stats.csv profiles/r03_${f}_kernel_stats.csv; done
 {
   echo "# scripts/final_gpu_job.sh $tag on one MI355X (gpurun), $(date -u +%Y-%m-%d) -- GPU suite, smoke, SMR timings, curvilinear timings"
   echo "## pytest -m gpu"; cat $g/${tag}_tests.txt
   echo "## __graft_entry__.smoke()"; cat $g/${tag}_smoke.txt
   echo "## scripts/smr_timing.py 20 (inputs/disk/disk_cart.in as shipped) and ... sph (refined spherical disk)"; cat $g/${tag}_smr.txt
+  echo "## scripts/amr_timing.py 10 128 128 16 16 gas/refine_thr=2.0 x3 in [-0.2, 0.2] (the configs[4] combination in 3-D)"; cat $g/${tag}_amr.txt
   echo "## scripts/curv_timing.py"; cat $g/${tag}_curv.txt
 } > profiles/r03_final_suite_smoke_timings.txt
 python - <<'PY'

@@ -4,7 +4,7 @@ tag=${1:-r03z}
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|FAILED" | tail -5 > gpurun_out/${tag}_tests.txt; cat gpurun_out/${tag}_tests.txt
+timeout 3300 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|FAILED" | tail -5 > gpurun_out/${tag}_tests.txt; cat gpurun_out/${tag}_tests.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/${tag}_smoke.txt
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag}
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph
@@ -24,7 +24,20 @@ timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_cfg3_prof -o p
 find gpurun_out/${tag}_cfg3_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_cfg3_kernel_stats.csv
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_disk_prof -o p --output-format csv -- python3 bench.py --workload disk_sph --no-cpu-baseline --steps 50 > /dev/null 2>&1
 find gpurun_out/${tag}_disk_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_disk_sph_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_cfg3_1024_prof -o p --output-format csv -- python3 bench.py --workload ssheet_dust --n 1024 --no-cpu-baseline --steps 100 > /dev/null 2>&1
+find gpurun_out/${tag}_cfg3_1024_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_cfg3_1024_kernel_stats.csv
+# refined meshes: the shipped Cartesian SMR disk, the refined spherical disk (configs[3]'s combination), both paths; the configs[4] combination in 3-D
 timeout 300 python scripts/smr_timing.py 20 | tee gpurun_out/${tag}_smr.txt
+ARTEMIS_NO_ML_FUSED=1 timeout 300 python scripts/smr_timing.py 20 | sed 's/^/per-task chain: /' | tee -a gpurun_out/${tag}_smr.txt
 timeout 300 python scripts/smr_timing.py 20 sph problem/polytropic_index=1.40 gas/de_switch=1e-2 | tee -a gpurun_out/${tag}_smr.txt
+ARTEMIS_NO_ML_FUSED=1 timeout 300 python scripts/smr_timing.py 20 sph problem/polytropic_index=1.40 gas/de_switch=1e-2 | sed 's/^/per-task chain: /' | tee -a gpurun_out/${tag}_smr.txt
+timeout 900 python3 scripts/amr_timing.py 10 128 128 16 16 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2 2>&1 | tail -1 | tee gpurun_out/${tag}_amr.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_smr_cart_prof -o p --output-format csv -- python3 scripts/smr_timing.py 10 > /dev/null 2>&1
+find gpurun_out/${tag}_smr_cart_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_smr_cart_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_smr_sph_prof -o p --output-format csv -- python3 scripts/smr_timing.py 10 sph problem/polytropic_index=1.40 gas/de_switch=1e-2 > /dev/null 2>&1
+find gpurun_out/${tag}_smr_sph_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_smr_sph_kernel_stats.csv
+timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_amr_prof -o p --output-format csv -- python3 scripts/amr_timing.py 5 128 128 16 16 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2 > /dev/null 2>&1
+find gpurun_out/${tag}_amr_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_amr_kernel_stats.csv
+rm -f gpurun_out/${tag}_*prof/*kernel_trace.csv
 for w in blast_sph blast_cyl disk_sph disk_cyl disk_axi; do timeout 300 python scripts/curv_timing.py $w; done | tee gpurun_out/${tag}_curv.txt
 head -4 gpurun_out/${tag}_bench_kernel_stats.csv | cut -c1-200
