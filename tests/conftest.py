@@ -38,3 +38,15 @@ def hiplib():
     assert torch.cuda.is_available(), "GPU test on a box without a GPU"
     assert L.artemis_hip_device_count() >= 1
     return L
+
+
+@pytest.fixture
+def one_openmp_thread():
+    """For 1-D problems: a short row is no work for a thread team (the fork / join of every sweep costs 100x the
+    arithmetic on 8 threads).  Process-wide OpenMP setting, restored afterwards."""
+    import ctypes
+    g = ctypes.CDLL("libgomp.so.1")
+    n = g.omp_get_max_threads()
+    g.omp_set_num_threads(1)
+    yield
+    g.omp_set_num_threads(n)

@@ -16,6 +16,18 @@ DECK = os.path.join(ROOT, "inputs", "linwave", "linear_wave.in")
 L1D = LANDINGS["linwave_1d_256"]
 
 
+@pytest.fixture(autouse=True)
+def one_openmp_thread():
+    """A 256-zone row is no work for a thread team: with the suite's default of 8 threads the fork / join of every sweep
+    is 100x the arithmetic (106 s for one of these runs, 1 s on one thread).  Process-wide setting, restored afterwards."""
+    import ctypes
+    g = ctypes.CDLL("libgomp.so.1")
+    n = g.omp_get_max_threads()
+    g.omp_set_num_threads(1)
+    yield
+    g.omp_set_num_threads(n)
+
+
 def overrides(N, wave, vflow):
     return [f"parthenon/mesh/nx1={N}", "parthenon/mesh/nx2=1", "parthenon/mesh/nx3=1",
             f"parthenon/meshblock/nx1={N}", "parthenon/meshblock/nx2=1", "parthenon/meshblock/nx3=1",

@@ -400,6 +400,7 @@ def alpha_disk_oracle(nx=64, alpha=0.1, h=0.1):
     return o
 
 
+@pytest.mark.usefixtures("one_openmp_thread")
 def test_alpha_disk_reference_test_pin():
     """tst/scripts/diffusion/alpha_disk.py:36-75,82-139: a 1-D axisymmetric alpha disk (alpha = 0.1,
     h = 0.1, locally isothermal through beta cooling with beta0 = 0, `viscous` inflow / outflow
