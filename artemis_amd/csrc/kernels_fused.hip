@@ -40,6 +40,9 @@
 namespace artemis {
 namespace {
 
+#ifndef ARTEMIS_CURV_OCC2
+#define ARTEMIS_CURV_OCC2 0 // experiment: force the curvilinear instantiations to two waves per SIMD (spills)
+#endif
 #ifndef ARTEMIS_FTY
 #define ARTEMIS_FTY 8
 #endif
@@ -700,7 +703,7 @@ ADEV void plane_update_curv(TILE &S, const PackView &P, const StageK &a, const S
 }
 
 template <int RIEMANN, int RECON, bool HAS_U1, bool WRITE_CONS, bool WITH_DT, bool D3, bool CURV = false, bool FLUXES = false>
-__global__ __launch_bounds__(NT, CURV ? 1 : 2) void stage_fused_kernel(const PackView P, const StageK a,
+__global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stage_fused_kernel(const PackView P, const StageK a,
                                                                        const SrcArg<CURV> src) {
   __shared__ std::conditional_t<CURV, LdsTileCurv, LdsTile> S;
   Ctx x;

@@ -240,7 +240,7 @@ def main():
                     help="diagnostic: cut each rank's 256^3 into this many mesh blocks along x3")
     ap.add_argument("--loopback", action="store_true",
                     help="diagnostic: route block-to-block slabs of ONE GPU through RCCL send/recv-to-self")
-    ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "ssheet_dust", "disk_sph"],
+    ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "ssheet_dust", "disk_sph", "disk_sph_smr", "disk_amr"],
                     help="sedov3d = the headline metric (BASELINE configs[1]); ssheet_dust = SURVEY config 3 "
                          "(2-D dusty shearing sheet with drag, general fused stage; --n is the mesh edge, 1 GPU); "
                          "disk_sph = BASELINE configs[3] without refinement (inputs/disk/disk_sph.in, spherical-polar "
@@ -342,6 +342,40 @@ def main():
         for d, m in enumerate(dims, 1):
             ov += ["parthenon/mesh/nx%d=%d" % (d, m), "parthenon/meshblock/nx%d=%d" % (d, m)]
         sim = Simulation(deck, ov)
+    elif args.workload == "disk_sph_smr":
+        # BASELINE configs[3]'s combination on one GPU: the spherical-polar disk deck x 2 in 32^3 blocks with a level-1
+        # static region around the midplane (scripts/smr_timing.py sph; tests/test_multilevel.py runs its small form)
+        if args.gpus != 1:
+            raise SystemExit("--workload disk_sph_smr is a single-GPU measurement")
+        deck = os.path.join(ROOT, "inputs", "disk", "disk_sph.in")
+        ov = ["parthenon/time/nlim=-1", "parthenon/mesh/nx1=256", "parthenon/mesh/nx2=128", "parthenon/mesh/nx3=128",
+              "parthenon/mesh/refinement=static", "parthenon/static_refinement1/level=1",
+              "parthenon/static_refinement1/x1min=0.7", "parthenon/static_refinement1/x1max=1.9",
+              "parthenon/static_refinement1/x2min=1.3", "parthenon/static_refinement1/x2max=1.85",
+              "parthenon/static_refinement1/x3min=-3.0", "parthenon/static_refinement1/x3max=3.0",
+              "problem/polytropic_index=1.40", "gas/de_switch=1e-2"]
+        sim = Simulation(deck, ov)
+    elif args.workload == "disk_amr":
+        # BASELINE configs[4]'s combination on one GPU, 3-D: inputs/disk/disk_nbody_cyl.in + a planet + one dust species
+        # with drag + the rotating frame + adaptive refinement to four levels (scripts/amr_timing.py; the 2-D form runs
+        # against the adaptive oracle in tests/test_adaptive.py)
+        if args.gpus != 1:
+            raise SystemExit("--workload disk_amr is a single-GPU measurement")
+        deck = os.path.join(ROOT, "inputs", "disk", "disk_nbody_cyl.in")
+        mb = 16
+        ov = ["parthenon/mesh/nx1=128", "parthenon/mesh/nx2=128", "parthenon/mesh/nx3=16",
+              "parthenon/mesh/x3min=-0.2", "parthenon/mesh/x3max=0.2",
+              "parthenon/meshblock/nx1=%d" % mb, "parthenon/meshblock/nx2=%d" % mb, "parthenon/meshblock/nx3=%d" % mb,
+              "parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=4", "parthenon/mesh/derefine_count=5",
+              "gas/refine_field=pressure", "gas/refine_type=gradient", "gas/refine_thr=2.0",
+              "physics/rotating_frame=true", "rotating_frame/omega=1.0",
+              "physics/dust=true", "dust/nspecies=1", "dust/cfl=0.3", "dust/reconstruct=plm", "dust/riemann=hlle",
+              "dust/dfloor=1e-10", "physics/drag=true", "drag/type=simple_dust", "dust/stopping_time/type=constant",
+              "dust/stopping_time/tau=0.1", "dust/sizes=1.0",
+              "nbody/particle2/mass=1.0e-2", "nbody/particle2/couple=1", "nbody/particle2/soft/type=plummer",
+              "nbody/particle2/soft/radius=0.03", "nbody/particle2/initialize/x=1.0", "nbody/particle2/initialize/vy=1.0",
+              "parthenon/time/nlim=-1"]
+        sim = Simulation(deck, ov)
     else:
         deck = os.path.join(ROOT, "inputs", "blast", "blast.in")
         extra = []
@@ -391,7 +425,13 @@ def main():
     # per-kernel events); per-kernel durations for `roofline` come from a separate short leg below.
     barrier()
     t0 = time.perf_counter()
-    done = sim.evolve(args.steps)
+    if args.workload == "disk_amr":  # the mesh changes between cycles: count the zones of every cycle
+        zone_cycles, done, remesh0 = 0, 0, sim.remeshes
+        for _ in range(args.steps):
+            zone_cycles += sim.total_zones
+            done += sim.evolve(1)
+    else:
+        done = sim.evolve(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     assert done == args.steps, (done, args.steps)
@@ -399,10 +439,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    sim.set_kernel_timing(True)   # HIP events around the dominant kernel, on the stream it is launched on
-    sim.evolve(max(5, min(args.steps, 40)))
-    kms, nlaunch = sim.kernel_ms()
-    sim.set_kernel_timing(False)
+    kms, nlaunch = 0.0, 0
+    if args.workload not in ("disk_sph_smr", "disk_amr"):  # (refined meshes: whole-stage accounting below)
+        sim.set_kernel_timing(True)   # HIP events around the dominant kernel, on the stream it is launched on
+        sim.evolve(max(5, min(args.steps, 40)))
+        kms, nlaunch = sim.kernel_ms()
+        sim.set_kernel_timing(False)
     hist = sim.history()
     dropin = None
     if args.workload == "sedov3d" and args.gpus == 1 and not args.loopback and not args.no_dropin and sim.uses_tuned_kernel:
@@ -444,6 +486,8 @@ def main():
 
     if rank == 0:
         value = total_zones * args.steps / elapsed
+        if args.workload == "disk_amr":
+            value = zone_cycles / elapsed
         out = {
             "metric": "cell-updates/sec (zone-cycles/s), 256^3/GPU Sedov",
             "value": value, "unit": "zone-cycles/s", "n_gpus": args.gpus, "steps": args.steps,
@@ -491,6 +535,29 @@ def main():
                                              "in one launch)" if sim.stage_kernel.startswith("stage_fused_kernel") else
                                              "3 flux kernels + epilogue + PrimToCons (per-task chain)")),
                                "launch_ms": stage_ms, "launches_timed": 2 * args.steps, "algorithmic_bytes_per_launch": alg}
+        elif args.workload in ("disk_sph_smr", "disk_amr"):
+            smr = args.workload == "disk_sph_smr"
+            levels = sorted(set(sim.block_level(b) for b in range(sim.nblocks)))
+            out["metric"] = ("cell-updates/sec (zone-cycles/s), spherical-polar alpha disk with static refinement" if smr else
+                             "cell-updates/sec (zone-cycles/s), cylindrical disk + planet + dust, 4-level adaptive refinement")
+            out["config"]["workload"] = (
+                ("BASELINE configs[3]'s combination on one GPU: inputs/disk/disk_sph.in x 2 (256 x 128 x 128 root, 32^3 blocks) + a "
+                 "level-1 static region around the midplane, gas, point-mass gravity, alpha viscosity, rotating frame, ic "
+                 "conditions, HLLE + PLM_G, rk2; %d blocks, %d zones" % (sim.nblocks, total_zones)) if smr else
+                ("BASELINE configs[4]'s combination on one GPU, 3-D: inputs/disk/disk_nbody_cyl.in (128 x 128 x 16 root over |z| < 0.2, "
+                 "16^3 blocks) + planet (N-body gravity, integrator none) + one dust species with simple_dust drag + rotating "
+                 "frame + alpha viscosity + adaptive refinement on the pressure gradient, numlevel 4; %d blocks on levels %s, "
+                 "%d zones at the end, %d remeshes in the timed region" % (sim.nblocks, levels, total_zones, sim.remeshes - remesh0)))
+            out["config"]["decomposition"] = "1 rank, %d mesh blocks (Z-ordered leaves)" % sim.nblocks
+            out["config"]["stage_path"] = sim.stage_kernel
+            bps = ALG_BYTES_PER_CELL_STAGE if smr else 8.0 * 5.0 * (6 + 4)  # 8 B * 5 * (6 ns_gas + 4 ns_dust)
+            stage_ms = 1.0e3 * elapsed / args.steps / 2.0
+            alg = bps * (total_zones if smr else zone_cycles / args.steps)
+            out["roofline"] = {"bound": "hbm", "achieved": alg / (stage_ms * 1.0e-3) / 1.0e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": alg / (stage_ms * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "whole stage (stage kernels, diffusion fluxes, flux correction, block-graph exchange, "
+                                         "conditions; per cycle also the timestep%s)" % ("" if smr else ", tagging and remeshes"),
+                               "launch_ms": stage_ms, "launches_timed": 2 * args.steps, "algorithmic_bytes_per_launch": alg}
         elif args.workload == "ssheet_dust":
             # B_alg per cell-stage = 8 B * 5 * (6 ns_gas + 4 ns_dust); one "launch" = one stage
             # of the general fused path (gas kernel + dust kernel + drag/aux/c2p finish)
@@ -537,7 +604,7 @@ def main():
                 dropin["fused"] = value
                 dropin["frac_fused"] = value * 2.0 * ALG_BYTES_PER_CELL_STAGE / 1.0e9 / HBM_PEAK_GBS
                 out["dropin"] = dropin
-        if args.workload == "disk_sph":
+        if args.workload in ("disk_sph", "disk_sph_smr", "disk_amr"):
             pass  # (CPU side: tests/test_oracle_pins.py times the oracle on the same deck: ~20 s for 10 cycles of 128x64x64)
         elif args.workload == "ssheet_dust" and not args.no_cpu_baseline:
             hc = host_cores()

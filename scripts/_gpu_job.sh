@@ -3,4 +3,6 @@
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests/test_parity_stage_general.py -x -q -m gpu -k "fixup or finish" 2>&1 | grep -E "passed|failed|Error|error|assert|^E " | tail -25 | tee gpurun_out/r03q_tests.txt
+timeout 600 python bench.py --workload disk_sph_smr --steps 20 --warmup 3 > gpurun_out/r03r_smr_line.json 2> gpurun_out/r03r_smr.err; cut -c1-1500 gpurun_out/r03r_smr_line.json; tail -3 gpurun_out/r03r_smr.err
+timeout 900 python bench.py --workload disk_amr --steps 10 --warmup 3 > gpurun_out/r03r_amr_line.json 2> gpurun_out/r03r_amr.err; cut -c1-1800 gpurun_out/r03r_amr_line.json; tail -3 gpurun_out/r03r_amr.err
+timeout 900 python3 scripts/amr_timing.py 10 128 128 32 32 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2 2>&1 | tail -1 | cut -c1-300

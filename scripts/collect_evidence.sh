@@ -3,7 +3,7 @@ tag=${1:-r03z}
 cd /root/repo
 g=gpurun_out
 for f in pmc_traffic disk_sph_pmc_traffic cfg3_pmc_traffic pmc_sq; do cp $g/${tag}_$f.json profiles/r03_$f.json; done
-for f in bench_line cfg3_line cfg3_1024_line cfg3_1024_2dust_line disk_sph_line; do cp $g/${tag}_$f.json profiles/r03_$f.json; done
+for f in bench_line cfg3_line cfg3_1024_line cfg3_1024_2dust_line disk_sph_line disk_sph_smr_line disk_amr_line; do cp $g/${tag}_$f.json profiles/r03_$f.json; done
 for f in bench cfg3 cfg3_1024 disk_sph smr_cart smr_sph amr; do cp $g/${tag}_${f}_kernel_stats.csv profiles/r03_${f}_kernel_stats.csv; done
 {
   echo "# scripts/final_gpu_job.sh $tag on one MI355X (gpurun), $(date -u +%Y-%m-%d) -- GPU suite, smoke, SMR timings, curvilinear timings"

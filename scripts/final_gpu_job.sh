@@ -17,7 +17,9 @@ timeout 300 python bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --
 timeout 300 python bench.py --workload ssheet_dust --n 1024 --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_line.json
 timeout 300 python bench.py --workload ssheet_dust --n 1024 --dust 2 --no-cpu-baseline --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_2dust_line.json
 timeout 300 python bench.py --workload disk_sph --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_disk_sph_line.json
-cut -c1-300 gpurun_out/${tag}_cfg3_line.json gpurun_out/${tag}_disk_sph_line.json
+timeout 600 python bench.py --workload disk_sph_smr --steps 40 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_sph_smr_line.json
+timeout 900 python bench.py --workload disk_amr --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json
+cut -c1-300 gpurun_out/${tag}_cfg3_line.json gpurun_out/${tag}_disk_sph_line.json gpurun_out/${tag}_disk_sph_smr_line.json gpurun_out/${tag}_disk_amr_line.json
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof -o p --output-format csv -- python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_prof.log 2>&1
 find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_bench_kernel_stats.csv
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_cfg3_prof -o p --output-format csv -- python3 bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50 > /dev/null 2>&1
@@ -32,6 +34,7 @@ ARTEMIS_NO_ML_FUSED=1 timeout 300 python scripts/smr_timing.py 20 | sed 's/^/per
 timeout 300 python scripts/smr_timing.py 20 sph problem/polytropic_index=1.40 gas/de_switch=1e-2 | tee -a gpurun_out/${tag}_smr.txt
 ARTEMIS_NO_ML_FUSED=1 timeout 300 python scripts/smr_timing.py 20 sph problem/polytropic_index=1.40 gas/de_switch=1e-2 | sed 's/^/per-task chain: /' | tee -a gpurun_out/${tag}_smr.txt
 timeout 900 python3 scripts/amr_timing.py 10 128 128 16 16 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2 2>&1 | tail -1 | tee gpurun_out/${tag}_amr.txt
+timeout 900 python3 scripts/amr_timing.py 10 128 128 32 32 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2 2>&1 | tail -1 | sed 's/^/32^3 blocks (the deck\x27s own block size): /' | tee -a gpurun_out/${tag}_amr.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_smr_cart_prof -o p --output-format csv -- python3 scripts/smr_timing.py 10 > /dev/null 2>&1
 find gpurun_out/${tag}_smr_cart_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_smr_cart_kernel_stats.csv
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_smr_sph_prof -o p --output-format csv -- python3 scripts/smr_timing.py 10 sph problem/polytropic_index=1.40 gas/de_switch=1e-2 > /dev/null 2>&1
