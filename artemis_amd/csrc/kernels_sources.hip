@@ -4,6 +4,8 @@
 // conserved variables of the same cell: pure streaming kernels, thread x walks i.
 #include <cfloat>
 
+#include <cstdlib>
+
 #include "device_math.hpp"
 #include "diffusion_device.hpp"
 #include "geometry.hpp"
@@ -136,6 +138,10 @@ struct NBodyView {
 ADEV double nb_idr3(const artemis_nbody_particle_t &p, const double dr2) { // particle_base.hpp:146-166
   const double fuzz = 1e-99;
   const double rs2 = sqr(p.rs);
+  // Plummer softening away from the particle: the spline expression is finite (its quotients have denominators above
+  // 1e-300) and enters as 0 * finite = +-0 added to a positive number -- the Plummer term alone, same bits, one
+  // division and one square root instead of four and three
+  if (p.spline == 0 && dr2 > 1e-200) return 1.0 / (fuzz + sqrt(dr2 + rs2) * (dr2 + rs2)) * 1.0;
   const double idr3_p = 1.0 / (fuzz + sqrt(dr2 + rs2) * (dr2 + rs2));
   const double dr3 = dr2 * sqrt(dr2);
   const double u2 = dr2 / (rs2 + fuzz);
@@ -155,6 +161,26 @@ ADEV void nb_accrete(const artemis_nbody_particle_t &p, const double x[3], const
   double dx[3], dv[3];
   for (int d = 0; d < 3; d++) dx[d] = x[d] - (p.pos[d] - p.xf[d]), dv[d] = vrel[d] - (p.vel[d] - p.vf[d]);
   const double dv2 = sqr(dv[0]) + sqr(dv[1]) + sqr(dv[2]);
+  // Outside the accretion radius (every zone of a particle with racc <= 0, nearly every zone otherwise) `acc` is
+  // false and gdt = bdt = +0, fm = -0.0, fp = +0.0: dm and dmom receive +-0 (unchanged), denp = den * (1 + -0.0) = den,
+  // and what is left is dEk += 0.5 (v + vxp) den (vxp - v) with vxp = (den v) / den -- not always v in floating point,
+  // so the three divisions stay; the other seven, the unit vectors and the ramp are skipped.  (Velocities and
+  // positions are finite, so the skipped products are 0 * finite.)  Same bits as the full expression below.
+  {
+    bool acc_ = false;
+    if (p.racc > 0.0) {
+      const double R_ = sqrt(sqr(dx[0]) + sqr(dx[1]));
+      const double r_ = sqrt(sqr(R_) + sqr(dx[2]));
+      acc_ = (r_ <= p.racc) && (-p.gm / (r_ + fuzz) + 0.5 * dv2 <= 0.0);
+    }
+    if (!acc_) {
+      for (int i = 0; i < 3; i++) {
+        const double vxp = (den * v[i]) / den;
+        dEk += 0.5 * (v[i] + vxp) * den * (vxp - v[i]);
+      }
+      return;
+    }
+  }
   const double R = sqrt(sqr(dx[0]) + sqr(dx[1]));
   const double r = sqrt(sqr(R) + sqr(dx[2]));
   const double ct = dx[2] / (r + fuzz), st = R / (r + fuzz);
@@ -280,6 +306,142 @@ __global__ __launch_bounds__(256) void nbody_gravity_kernel(const PackView P, co
       }
     }
     // fixed-tree reduction: wave shuffles, then the four waves of the workgroup in order
+#pragma unroll
+    for (int q = 0; q < NB_CHUNK; ++q) {
+      if (q >= nloc) continue; // (workgroup-uniform)
+      for (int m = 0; m < 7; ++m) {
+        double vq = lf[q][m];
+        for (int off = 32; off > 0; off >>= 1) vq += __shfl_down(vq, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][m] = vq;
+      }
+      __syncthreads();
+      if (threadIdx.x < 7)
+        N.partial[(static_cast<long>(np0 + q) * gridDim.x + blockIdx.x) * 7 + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+      __syncthreads();
+    }
+  }
+}
+
+// The usual case -- at most one species per fluid, fewer than 2^31 zones -- with the zone's state in registers: the
+// four / four primitives and six / four conserved variables of gas / dust are loaded together at the top of the
+// iteration (independent loads: one memory latency per zone instead of one per read-modify-write), every particle
+// acts on the registers in order, one store each at the end.  Same additions in the same order as the kernel above.
+template <bool GAS, bool DUST>
+__global__ __launch_bounds__(256) void nbody_gravity_one_kernel(const PackView P, const NBodyView N) {
+  __shared__ double red[4][7];
+  __shared__ artemis_nbody_particle_t spl[NB_CHUNK];
+  const unsigned nx1 = P.ie - P.is + 1, nx2 = P.je - P.js + 1, nx3 = P.ke - P.ks + 1;
+  const unsigned per_block = nx1 * nx2 * nx3, total = per_block * P.nb;
+  for (int np0 = 0; np0 < N.npart; np0 += NB_CHUNK) {
+    const int nloc = (N.npart - np0 < NB_CHUNK) ? N.npart - np0 : NB_CHUNK;
+    __syncthreads();
+    if (threadIdx.x < nloc) spl[threadIdx.x] = N.pl[np0 + threadIdx.x];
+    __syncthreads();
+    double lf[NB_CHUNK][7];
+#pragma unroll
+    for (int q = 0; q < NB_CHUNK; ++q)
+#pragma unroll
+      for (int m = 0; m < 7; ++m) lf[q][m] = 0.0;
+    bool any = false;
+    for (int q = 0; q < nloc; ++q) any = any || spl[q].couple;
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; any && t < total; t += gridDim.x * blockDim.x) {
+      const unsigned b = t / per_block, r = t - b * per_block;
+      const unsigned row = r / nx1;
+      const int i = P.is + static_cast<int>(r - row * nx1), j = P.js + static_cast<int>(row % nx2), k = P.ks + static_cast<int>(row / nx2);
+      const long c = static_cast<long>(k) * P.sk + static_cast<long>(j) * P.sj + i;
+      // every load of the iteration up front
+      double wg[4] = {0, 0, 0, 0}, ug[6] = {0, 0, 0, 0, 0, 0}, wd[4] = {0, 0, 0, 0}, ud[4] = {0, 0, 0, 0};
+      if constexpr (GAS) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wg[m] = P.gas.prim[b * 6 + m][c];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) ug[m] = P.gas.cons0[b * 6 + m][c];
+      }
+      if constexpr (DUST) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wd[m] = P.dust.prim[b * 4 + m][c], ud[m] = P.dust.cons0[b * 4 + m][c];
+      }
+      const DCoords co = make_coords(P, b, k, j, i);
+      double x[3];
+      co.centre(x);
+      const bool cyl = (co.sys == ARTEMIS_CYLINDRICAL);
+      const Frame fr = cart_frame(co.sys, x, co.cv, co.sv, cyl ? co.cv : co.c3, cyl ? co.sv : co.s3);
+      double hx[3];
+      scale_factors_of(co, hx);
+      const double vol = co.volume();
+      double vf[3] = {0.0, 0.0, 0.0};
+      if (N.omf != 0.0) {
+        double vrot[3];
+        rotation_velocity(co, N.omf, vrot);
+        vf[0] = fr.e1[0] * vrot[0] + fr.e2[0] * vrot[1] + fr.e3[0] * vrot[2];
+        vf[1] = fr.e1[1] * vrot[0] + fr.e2[1] * vrot[1] + fr.e3[1] * vrot[2];
+        vf[2] = fr.e1[2] * vrot[0] + fr.e2[2] * vrot[1] + fr.e3[2] * vrot[2];
+      }
+      double vcg[3], vcd[3]; // Cartesian velocities of the two fluids (particle-independent)
+      vcg[0] = fr.e1[0] * wg[1] + fr.e2[0] * wg[2] + fr.e3[0] * wg[3];
+      vcg[1] = fr.e1[1] * wg[1] + fr.e2[1] * wg[2] + fr.e3[1] * wg[3];
+      vcg[2] = fr.e1[2] * wg[1] + fr.e2[2] * wg[2] + fr.e3[2] * wg[3];
+      vcd[0] = fr.e1[0] * wd[1] + fr.e2[0] * wd[2] + fr.e3[0] * wd[3];
+      vcd[1] = fr.e1[1] * wd[1] + fr.e2[1] * wd[2] + fr.e3[1] * wd[3];
+      vcd[2] = fr.e1[2] * wd[1] + fr.e2[2] * wd[2] + fr.e3[2] * wd[3];
+#pragma unroll 1
+      for (int q = 0; q < nloc; ++q) {
+        const artemis_nbody_particle_t &pl = spl[q];
+        if (!pl.couple) continue;
+        double g[3] = {0.0, 0.0, 0.0};
+        {
+          double dxp[3];
+          for (int d = 0; d < 3; d++) dxp[d] = fr.x[d] - (pl.pos[d] - pl.xf[d]);
+          const double dr2 = sqr(dxp[0]) + sqr(dxp[1]) + sqr(dxp[2]);
+          const double idr3_ = nb_idr3(pl, dr2);
+          for (int d = 0; d < 3; d++) g[d] += -pl.gm * idr3_ * dxp[d];
+        }
+        const double gx1 = g[0] * fr.e1[0] + g[1] * fr.e1[1] + g[2] * fr.e1[2];
+        const double gx2 = g[0] * fr.e2[0] + g[1] * fr.e2[1] + g[2] * fr.e2[2];
+        const double gx3 = g[0] * fr.e3[0] + g[1] * fr.e3[1] + g[2] * fr.e3[2];
+        double f7[7] = {0, 0, 0, 0, 0, 0, 0};
+        auto fluid = [&](const double *w, const double *vcart, double *u, bool gas) {
+          const double dens = w[0];
+          double dm = 0.0, dmom[3] = {0.0, 0.0, 0.0}, dek = 0.0;
+          const double dei = 0.0;
+          nb_accrete(pl, fr.x, dens, vcart, vf, N.dt, dm, dmom, dek);
+          const double dmx1 = dmom[0] * fr.e1[0] + dmom[1] * fr.e1[1] + dmom[2] * fr.e1[2];
+          const double dmx2 = dmom[0] * fr.e2[0] + dmom[1] * fr.e2[1] + dmom[2] * fr.e2[2];
+          const double dmx3 = dmom[0] * fr.e3[0] + dmom[1] * fr.e3[1] + dmom[2] * fr.e3[2];
+          const double rdt = dens * N.dt;
+          u[0] += dm;
+          u[1] += hx[0] * (rdt * gx1 + dmx1);
+          u[2] += hx[1] * (rdt * gx2 + dmx2);
+          u[3] += hx[2] * (rdt * gx3 + dmx3);
+          if (gas) {
+            u[4] += dek + dei + rdt * (w[1] * gx1 + w[2] * gx2 + w[3] * gx3);
+            u[5] += dei;
+          }
+          f7[0] -= vol * dm / N.dt;
+          f7[1] -= g[0] * dens * vol;
+          f7[2] -= g[1] * dens * vol;
+          f7[3] -= g[2] * dens * vol;
+          f7[4] -= dmom[0] / N.dt;
+          f7[5] -= dmom[1] / N.dt;
+          f7[6] -= dmom[2] / N.dt;
+        };
+        if constexpr (GAS) fluid(wg, vcg, ug, true);
+        if constexpr (DUST) fluid(wd, vcd, ud, false);
+#pragma unroll
+        for (int qq = 0; qq < NB_CHUNK; ++qq)
+#pragma unroll
+          for (int m = 0; m < 7; ++m) lf[qq][m] += (qq == q) ? f7[m] : 0.0;
+      }
+      if constexpr (GAS) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) P.gas.cons0[b * 6 + m][c] = ug[m];
+      }
+      if constexpr (DUST) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) P.dust.cons0[b * 4 + m][c] = ud[m];
+      }
+    }
 #pragma unroll
     for (int q = 0; q < NB_CHUNK; ++q) {
       if (q >= nloc) continue; // (workgroup-uniform)
@@ -573,6 +735,14 @@ void launch_nbody_gravity(const PackView &P, const artemis_nbody_particle_t *pl_
                           double *partial_dev, hipStream_t s) {
   NBodyView N;
   N.pl = pl_dev, N.npart = npart, N.omf = omf, N.dt = dt, N.partial = partial_dev;
+  const long total = static_cast<long>(P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1) * P.nb;
+  if (P.gas.ns <= 1 && P.dust.ns <= 1 && total < (1L << 31) - (1L << 20) && getenv("ARTEMIS_NBODY_GENERAL") == nullptr) {
+    const dim3 grid(nbody_grid(P)), block(256);
+    if (P.gas.ns && P.dust.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<true, true>), grid, block, 0, s, P, N);
+    else if (P.gas.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<true, false>), grid, block, 0, s, P, N);
+    else if (P.dust.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<false, true>), grid, block, 0, s, P, N);
+    return;
+  }
   hipLaunchKernelGGL(nbody_gravity_kernel, dim3(nbody_grid(P)), dim3(256), 0, s, P, N);
 }
 void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, double dt, hipStream_t s) {
