@@ -975,6 +975,13 @@ void *artemis_rt_malloc(size_t bytes) {
   if (device_ready()) return nullptr;
   void *p = nullptr;
   if (check_hip(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc")) return nullptr;
+  // ARTEMIS_POISON=1 (debugging aid): fresh device memory holds NaN patterns, so that a read of something never
+  // written shows up as NaN instead of depending on what the allocator handed back
+  static const bool poison = std::getenv("ARTEMIS_POISON") != nullptr;
+  if (poison && bytes) {
+    (void)hipMemset(p, 0xFF, bytes);
+    (void)hipDeviceSynchronize();
+  }
   return p;
 }
 void artemis_rt_free(void *p) {
