@@ -566,3 +566,41 @@ def test_disk_extrap_condition_on_a_refined_mesh(tmp_path):
     assert res["meta"]["ncycle"] == m.ncycle == 3 and res["meta"]["dt"] == m.dt
     for b, (bounds, prim) in enumerate(res["blocks"]):
         assert np.isfinite(prim).all() and np.array_equal(prim, m.blocks[b].interior(m.blocks[b].gprim)), b
+
+
+# ---- one dimension: the smallest refined mesh (1-D blocks are never tagged by the criteria, but a static region works) ---
+SMR1D = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=1", "parthenon/mesh/nx3=1", "parthenon/meshblock/nx1=8",
+         "parthenon/meshblock/nx2=1", "parthenon/meshblock/nx3=1", "gas/riemann=hllc", "problem/radius=0.2", "problem/samples=0",
+         "problem/p0=0.1", "parthenon/time/nlim=20"] + region_overrides(1, (-0.3, -0.5, -0.5), (0.3, 0.5, 0.5))
+
+
+def test_one_dimensional_refined_mesh_both_paths_agree_cpu_double(tmp_path):
+    """A 1-D blast with a level-1 region in the middle (4 coarse + 8 fine blocks of 8 zones): the tuned kernel's 1-D form +
+    the coarse-fine fix-up (two zones per coarse block touch a corrected face) equals the per-task chain bit for bit, and
+    mass is conserved to round-off across the level boundaries."""
+    got = {}
+    for path in ("fused", "unfused"):
+        got[path] = _run_workers(1, dict(deck=["blast", "blast.in"], overrides=SMR1D, path=path), tmp_path, "smr1d" + path)[0]
+        assert got[path]["meta"]["nblocks"] == 12 and got[path]["meta"]["fused"] == (path == "fused")
+        assert sorted(got[path]["meta"]["levels"]) == [0] * 4 + [1] * 8
+    assert got["fused"]["meta"]["dt"] == got["unfused"]["meta"]["dt"] and got["fused"]["meta"]["ncycle"] == 20
+    for (ba, pa), (bb, pb) in zip(got["fused"]["blocks"], got["unfused"]["blocks"]):
+        assert list(ba) == list(bb) and np.array_equal(pa, pb)
+    assert np.allclose(got["fused"]["hist"], got["unfused"]["hist"], rtol=0, atol=1e-14)
+
+
+@pytest.mark.gpu
+def test_one_dimensional_refined_mesh_both_paths_agree_hip(hiplib):
+    from artemis_amd.driver import Simulation
+    out = {}
+    for path in ("fused", "unfused"):
+        s = Simulation(DECK("blast", "blast.in"), SMR1D)
+        s.set_path(path)
+        h0 = s.history()
+        s.evolve()
+        h1 = s.history()
+        assert s.nblocks == 12 and s.ncycle == 20 and abs(h1[0] - h0[0]) < 1e-13 * h0[0]
+        out[path] = (s.dt, [s.field("gas.prim", b)[[0, 1, 2, 3, 5]].copy() for b in range(s.nblocks)])
+        s.close()
+    assert out["fused"][0] == out["unfused"][0]
+    assert all(np.array_equal(a, b) for a, b in zip(out["fused"][1], out["unfused"][1]))
