@@ -79,8 +79,9 @@ __device__ __forceinline__ CellIdx cell_from_grid(const Range3 &r) {
 // reconstructs the upper face value of the cell below the face and the lower face value of
 // the cell above it straight from global memory (neighbouring threads share those lines in
 // L1/L2), then solves the Riemann problem and writes the 8 (gas) / 4 (dust) face outputs.
+// One face: the reconstruction and the Riemann problem of species n at the lower `dir` face of cell (k,j,i).
 template <int FLUID, int RIEMANN, int RECON, bool CURV>
-__device__ __forceinline__ void flux_face(const PackView &P, int b, int k, int j, int i, long c, const int dir) {
+__device__ __forceinline__ FaceFlux flux_face(const PackView &P, int b, int k, int j, int i, long c, const int dir, const int n) {
   PlmGeo gl{}, gr{};
   double hs[3] = {1.0, 1.0, 1.0}; // ScaleMomentumFlux factors (fluid_fluxes.hpp:33-70)
   if constexpr (CURV) {
@@ -95,69 +96,80 @@ __device__ __forceinline__ void flux_face(const PackView &P, int b, int k, int j
   const int nv = (FLUID == 0) ? 6 * ns : 4 * ns;
   const long st = (dir == 1) ? 1 : ((dir == 2) ? P.sj : P.sk);
   const int d = dir - 1;
-  for (int n = 0; n < ns; ++n) {
-    const int IDN = n;
-    const int ivx = ns + 3 * n + d;
-    const int ivy = ns + 3 * n + (d + 1) % 3;
-    const int ivz = ns + 3 * n + (d + 2) % 3;
-    const int IPR = 4 * ns + n, ISE = 5 * ns + n;
-    FaceFlux F;
-    if constexpr (FLUID == 0) {
-      Prim6 L, R;
-      const double *q;
-      q = f.prim[b * nv + IDN] + c;
-      face_states<RECON, CURV>(q, st, gl, gr, L.d, R.d);
-      q = f.prim[b * nv + ivx] + c;
-      face_states<RECON, CURV>(q, st, gl, gr, L.vx, R.vx);
-      q = f.prim[b * nv + ivy] + c;
-      face_states<RECON, CURV>(q, st, gl, gr, L.vy, R.vy);
-      q = f.prim[b * nv + ivz] + c;
-      face_states<RECON, CURV>(q, st, gl, gr, L.vz, R.vz);
-      q = f.prim[b * nv + IPR] + c;
-      face_states<RECON, CURV>(q, st, gl, gr, L.p, R.p);
-      q = f.prim[b * nv + ISE] + c;
-      face_states<RECON, CURV>(q, st, gl, gr, L.e, R.e);
-      riemann_gas<RIEMANN>(P.gm1, L, R, F);
-      if constexpr (CURV) F.fmx *= hs[d], F.fmy *= hs[(d + 1) % 3], F.fmz *= hs[(d + 2) % 3];
-      f.flux[d][b * nv + IDN][c] = F.fd;
-      f.flux[d][b * nv + ivx][c] = F.fmx;
-      f.flux[d][b * nv + ivy][c] = F.fmy;
-      f.flux[d][b * nv + ivz][c] = F.fmz;
-      f.flux[d][b * nv + IPR][c] = F.fe;  // IEN shares the IPR slot (hllc.hpp:72)
-      f.flux[d][b * nv + ISE][c] = F.feg; // IEG shares the ISE slot (hllc.hpp:73)
-      f.pflux[d][b * ns + n][c] = F.pf;
-      f.vface[d][b * ns + n][c] = F.vf;
-    } else {
-      Prim4 L, R;
-      const double *q;
-      q = f.prim[b * nv + IDN] + c;
-      face_states<RECON, CURV>(q, st, gl, gr, L.d, R.d);
-      q = f.prim[b * nv + ivx] + c;
-      face_states<RECON, CURV>(q, st, gl, gr, L.vx, R.vx);
-      q = f.prim[b * nv + ivy] + c;
-      face_states<RECON, CURV>(q, st, gl, gr, L.vy, R.vy);
-      q = f.prim[b * nv + ivz] + c;
-      face_states<RECON, CURV>(q, st, gl, gr, L.vz, R.vz);
-      riemann_dust<RIEMANN>(L, R, F);
-      if constexpr (CURV) F.fmx *= hs[d], F.fmy *= hs[(d + 1) % 3], F.fmz *= hs[(d + 2) % 3];
-      f.flux[d][b * nv + IDN][c] = F.fd;
-      f.flux[d][b * nv + ivx][c] = F.fmx;
-      f.flux[d][b * nv + ivy][c] = F.fmy;
-      f.flux[d][b * nv + ivz][c] = F.fmz;
-    }
+  const int IDN = n;
+  const int ivx = ns + 3 * n + d;
+  const int ivy = ns + 3 * n + (d + 1) % 3;
+  const int ivz = ns + 3 * n + (d + 2) % 3;
+  const int IPR = 4 * ns + n, ISE = 5 * ns + n;
+  FaceFlux F;
+  if constexpr (FLUID == 0) {
+    Prim6 L, R;
+    const double *q;
+    q = f.prim[b * nv + IDN] + c;
+    face_states<RECON, CURV>(q, st, gl, gr, L.d, R.d);
+    q = f.prim[b * nv + ivx] + c;
+    face_states<RECON, CURV>(q, st, gl, gr, L.vx, R.vx);
+    q = f.prim[b * nv + ivy] + c;
+    face_states<RECON, CURV>(q, st, gl, gr, L.vy, R.vy);
+    q = f.prim[b * nv + ivz] + c;
+    face_states<RECON, CURV>(q, st, gl, gr, L.vz, R.vz);
+    q = f.prim[b * nv + IPR] + c;
+    face_states<RECON, CURV>(q, st, gl, gr, L.p, R.p);
+    q = f.prim[b * nv + ISE] + c;
+    face_states<RECON, CURV>(q, st, gl, gr, L.e, R.e);
+    riemann_gas<RIEMANN>(P.gm1, L, R, F);
+  } else {
+    Prim4 L, R;
+    const double *q;
+    q = f.prim[b * nv + IDN] + c;
+    face_states<RECON, CURV>(q, st, gl, gr, L.d, R.d);
+    q = f.prim[b * nv + ivx] + c;
+    face_states<RECON, CURV>(q, st, gl, gr, L.vx, R.vx);
+    q = f.prim[b * nv + ivy] + c;
+    face_states<RECON, CURV>(q, st, gl, gr, L.vy, R.vy);
+    q = f.prim[b * nv + ivz] + c;
+    face_states<RECON, CURV>(q, st, gl, gr, L.vz, R.vz);
+    riemann_dust<RIEMANN>(L, R, F);
+  }
+  if constexpr (CURV) F.fmx *= hs[d], F.fmy *= hs[(d + 1) % 3], F.fmz *= hs[(d + 2) % 3];
+  return F;
+}
+template <int FLUID>
+__device__ __forceinline__ void store_face(const PackView &P, int b, long c, const int dir, const int n, const FaceFlux &F) {
+  const FluidView &f = (FLUID == 0) ? P.gas : P.dust;
+  const int ns = f.ns, nv = (FLUID == 0) ? 6 * ns : 4 * ns, d = dir - 1;
+  const int ivx = ns + 3 * n + d, ivy = ns + 3 * n + (d + 1) % 3, ivz = ns + 3 * n + (d + 2) % 3;
+  f.flux[d][b * nv + n][c] = F.fd;
+  f.flux[d][b * nv + ivx][c] = F.fmx;
+  f.flux[d][b * nv + ivy][c] = F.fmy;
+  f.flux[d][b * nv + ivz][c] = F.fmz;
+  if constexpr (FLUID == 0) {
+    f.flux[d][b * nv + 4 * ns + n][c] = F.fe;  // IEN shares the IPR slot (hllc.hpp:72)
+    f.flux[d][b * nv + 5 * ns + n][c] = F.feg; // IEG shares the ISE slot (hllc.hpp:73)
+    f.pflux[d][b * ns + n][c] = F.pf;
+    f.vface[d][b * ns + n][c] = F.vf;
   }
 }
 
 // One launch for every active direction: the thread of cell (k,j,i) solves the lower x1, x2 and x3 faces
 // it stores (the face of direction d exists where the other two indices are active), so the centre
-// stencil values are fetched once and stay in L1 for the three sweeps.
+// stencil values are fetched once and stay in L1 for the three sweeps.  The three faces of a species are solved
+// first and stored afterwards: a store through the pointer tables may alias anything as far as the compiler knows,
+// so stores between the sweeps kept the next sweep's loads from being issued early (three load -> solve -> store
+// chains per thread, latency-bound at 3-4 waves per SIMD).
 template <int FLUID, int RIEMANN, int RECON, bool CURV>
 __global__ __launch_bounds__(TX *TY) void flux_kernel(const PackView P, const Range3 r) {
   CELL_FROM_GRID(r)
-  for (int dir = 1; dir <= P.ndim; ++dir) {
-    const bool has = (dir == 1) ? (j <= P.je && k <= P.ke)
-                                : ((dir == 2) ? (i <= P.ie && k <= P.ke) : (i <= P.ie && j <= P.je));
-    if (has) flux_face<FLUID, RIEMANN, RECON, CURV>(P, b, k, j, i, c, dir);
+  const int ns = (FLUID == 0) ? P.gas.ns : P.dust.ns;
+  const bool has1 = (j <= P.je && k <= P.ke), has2 = P.ndim > 1 && (i <= P.ie && k <= P.ke), has3 = P.ndim > 2 && (i <= P.ie && j <= P.je);
+  for (int n = 0; n < ns; ++n) {
+    FaceFlux F1{}, F2{}, F3{};
+    if (has1) F1 = flux_face<FLUID, RIEMANN, RECON, CURV>(P, b, k, j, i, c, 1, n);
+    if (has2) F2 = flux_face<FLUID, RIEMANN, RECON, CURV>(P, b, k, j, i, c, 2, n);
+    if (has3) F3 = flux_face<FLUID, RIEMANN, RECON, CURV>(P, b, k, j, i, c, 3, n);
+    if (has1) store_face<FLUID>(P, b, c, 1, n, F1);
+    if (has2) store_face<FLUID>(P, b, c, 2, n, F2);
+    if (has3) store_face<FLUID>(P, b, c, 3, n, F3);
   }
 }
 
