@@ -60,6 +60,7 @@ class Pack(C.Structure):
         ("coords", C.c_int), ("gm1", C.c_double), ("geom", C.c_void_p),
         ("metric", C.c_void_p),
         ("gas", FluidPack), ("dust", FluidPack), ("omega_frame", C.c_double),
+        ("plm_table", C.c_void_p),
     ]
 
 
@@ -210,6 +211,8 @@ def load():
         "artemis_hip_stage_general_variant": (i, [PPk, C.POINTER(StageGeneralArgs)]),
         "artemis_hip_stage_epilogue": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
         "artemis_hip_stage_epilogue_cons": (i, [PPk, C.POINTER(StageGeneralArgs), vp]),
+        "artemis_hip_plm_table_count": (C.c_long, [PPk]),
+        "artemis_hip_plm_table_fill": (i, [PPk, vp, vp]),
         "artemis_hip_ml_face_fluxes": (i, [PPk, C.POINTER(StageGeneralArgs), vp, i, vp]),
         "artemis_hip_ml_stage_fixup": (i, [PPk, C.POINTER(StageGeneralArgs), vp, i, vp]),
         "artemis_hip_stage_finish": (i, [PPk, C.POINTER(Drag), d, d, vp]),
@@ -280,7 +283,7 @@ EXPORTS_HIP = [
     "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_stage_fused_redo_shell", "artemis_hip_metric_count",
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_nbody_gravity", "artemis_hip_rotating_frame_force",
     "artemis_hip_ml_exchange", "artemis_hip_ml_flux_correction", "artemis_hip_ml_restrict_halos", "artemis_hip_ml_prolongate",
-    "artemis_hip_ml_face_fluxes", "artemis_hip_ml_stage_fixup",
+    "artemis_hip_ml_face_fluxes", "artemis_hip_ml_stage_fixup", "artemis_hip_plm_table_count", "artemis_hip_plm_table_fill",
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",
     "artemis_hip_stage_general", "artemis_hip_stage_general_variant", "artemis_hip_stage_epilogue", "artemis_hip_stage_epilogue_cons", "artemis_hip_stage_finish", "artemis_hip_amr_block_maxima", "artemis_hip_restrict_average",
     "artemis_hip_prolongate_minmod", "artemis_hip_amr_first_derivative", "artemis_hip_amr_magnitude",

@@ -571,6 +571,23 @@ int artemis_hip_ml_prolongate(const artemis_pack_t *p, const artemis_ml_pack_t *
   return after_launch("ml_prolongate");
 }
 
+long artemis_hip_plm_table_count(const artemis_pack_t *p) {
+  if (!p) return 0;
+  return artemis::plm_table_count(artemis::make_pack_view(*p));
+}
+int artemis_hip_plm_table_fill(const artemis_pack_t *p, double *table_dev, void *stream) {
+  // geometry only: shape, coordinate system, edge table (no fluid needs to be in the pack)
+  if (!p || p->nblocks < 1 || p->nx1 < 1 || p->nx2 < 1 || p->nx3 < 1 || p->nghost < 1 || !p->geom)
+    return fail(ARTEMIS_HIP_EINVAL, "plm table: the pack needs its shape and edge table");
+  if (p->coords < ARTEMIS_CARTESIAN || p->coords > ARTEMIS_AXISYMMETRIC) return fail(ARTEMIS_HIP_EINVAL, "Invalid artemis/coordinate system!");
+  if (device_ready()) return fail(ARTEMIS_HIP_EDEVICE, "no HIP device");
+  if (!table_dev) return fail(ARTEMIS_HIP_EINVAL, "plm table: null table");
+  if ((p->coords == ARTEMIS_SPHERICAL2D || p->coords == ARTEMIS_SPHERICAL3D) && !p->metric)
+    return fail(ARTEMIS_HIP_EINVAL, "plm table: spherical blocks need the metric tables first");
+  artemis::launch_plm_table_fill(artemis::make_pack_view(*p), table_dev, S(stream));
+  return after_launch("plm_table_fill");
+}
+
 // ---- refined meshes on the one-kernel stages: fine-side faces, then the coarse zones next to them redone ----------
 static int validate_diffusion(const artemis_pack_t *p, const artemis_diffusion_t *d, bool need_flux);
 static int validate_ml_fix(const artemis_pack_t *p, const artemis_stage_general_args_t *a) {

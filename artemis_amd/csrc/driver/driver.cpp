@@ -271,6 +271,7 @@ struct artemis_sim_impl {
   Field gu0, gu1, gflux[3], gpflux[3], gvface[3];
   Field dprim[3], du0, du1, dflux[3]; // dust primitives ping-pong with the same index as gprim
   DevBuf geom, dt_dev, metric;
+  DevBuf plmtab; // PLM_G geometry table (artemis_hip_plm_table_fill), curvilinear meshes
   std::vector<Real> hgeom, hmetric; // host copies of the edge and x2-trig tables
   int coords = ARTEMIS_CARTESIAN;   // geometry::CoordSelect(artemis/coordinates, ndim)
   // geometry::Coords<GEOM> of cell (k,j,i) of local block b (host side: pgens, history)
@@ -336,6 +337,7 @@ struct artemis_sim_impl {
     p.geom = geom.p;
     p.metric = metric.p;
     p.omega_frame = do_rframe ? rf_omega : 0.0; // fluid_fluxes.hpp:433-437
+    p.plm_table = plmtab.p;
     p.gas.nspecies = ns_gas, p.gas.recon = recon_gas, p.gas.riemann = riemann_gas;
     p.gas.dfloor = dfloor_gas, p.gas.siefloor = siefloor_gas, p.gas.de_switch = de_switch;
     p.gas.prim = gprim[prim_idx].tab(), p.gas.cons0 = gu0.tab(), p.gas.cons1 = gu1.tab();
@@ -1213,6 +1215,7 @@ void artemis_sim_impl::fill_ghosts_multilevel(int prim_idx) {
     pc.nx1 = mbnx[0] / 2, pc.nx2 = (ndim > 1) ? mbnx[1] / 2 : 1, pc.nx3 = (ndim > 2) ? mbnx[2] / 2 : 1;
     pc.geom = ml.cgeom.p, pc.metric = ml.cmetric.p;
     pc.gas.prim = ml.gcoarse.tab(), pc.dust.prim = ml.dcoarse.tab();
+    pc.plm_table = nullptr; // (the fine blocks' table; nothing on the coarse buffers reconstructs)
     artemis_bc_params_t bp = bcpar;
     bp.floor_ghosts = 0;
     if (ic_gas_c.ok() || ic_dust_c.ok()) // `ic`: the profile at the coarse buffers' own zone centres
@@ -1272,6 +1275,16 @@ void artemis_sim_impl::allocate() {
       metric.alloc(nm);
       CK(artemis_rt_memcpy_h2d(metric.p, hmetric.data(), nm * sizeof(Real), nullptr), "h2d metric");
     }
+  }
+  if (coords != ARTEMIS_CARTESIAN && getenv("ARTEMIS_NO_PLM_TABLE") == nullptr) {
+    // PLM_G's geometric weights, once per mesh (the per-task and cell-centred kernels read them instead of forming
+    // ~40 quotients per zone; the tile kernels keep theirs in registers)
+    artemis_pack_t p0;
+    std::memset(&p0, 0, sizeof p0);
+    p0.nblocks = nb, p0.nghost = ng, p0.nx1 = mbnx[0], p0.nx2 = mbnx[1], p0.nx3 = mbnx[2];
+    p0.coords = coords, p0.geom = geom.p, p0.metric = metric.p;
+    plmtab.alloc(artemis_hip_plm_table_count(&p0));
+    CK(artemis_hip_plm_table_fill(&p0, plmtab.p, nullptr), "PLM_G table");
   }
   dt_dev.alloc(1);
   tstate.alloc(6);

@@ -101,4 +101,40 @@ GDEV PlmGeo plm_geo(const PackView &P, int b, int dir, int k, int j, int i) {
   return g;
 }
 
+// The same record from the table of artemis_hip_plm_table_fill (pack_view.hpp: nine rows per block and direction):
+// the index-only fields are loads, the cell width along the sweep -- Coords::width<dir> = h (x_f1 - x_f0) with
+// h = 1, x1v or x1v sin(x2v) -- is formed from the tabulated x1 centroid exactly as width2 / width3 form it, and
+// its refined reciprocal follows.  xvm / xvc / xvp / xf0 / xf1 are not filled: plm_g_shared does not read them.
+__device__ __forceinline__ PlmGeo plm_geo_tab(const PackView &P, int b, int dir, int k, int j, int i) {
+  PlmGeo g;
+  const int L = P.plm_len;
+  const int idx = (dir == 1) ? i : ((dir == 2) ? j : k);
+  const double *t = P.plm_tab + (static_cast<long>(b) * 3 + (dir - 1)) * PLM_TAB_ROWS * L + idx;
+  g.cr = t[0], g.cl = t[L], g.up = t[2 * L], g.lo = t[3 * L];
+  g.ra.b = t[4 * L], g.ra.y = t[5 * L], g.rb.b = t[6 * L], g.rb.y = t[7 * L];
+  g.xvm = g.xvc = g.xvp = g.xf0 = g.xf1 = 0.0;
+  const double *ge = P.geom + 6 * b;
+  const int sys = P.coords;
+  const bool sph23 = (sys == ARTEMIS_SPHERICAL2D || sys == ARTEMIS_SPHERICAL3D);
+  const bool sph = sph23 || sys == ARTEMIS_SPHERICAL1D;
+  if (dir == 1) {
+    const double f0 = ge[0] + i * ge[1], f1 = ge[0] + (i + 1) * ge[1];
+    g.dx = 1.0 * (f1 - f0); // width1
+  } else {
+    const double x1v = P.plm_tab[(static_cast<long>(b) * 3 * PLM_TAB_ROWS + 8) * L + i];
+    if (dir == 2) {
+      const double f0 = ge[2] + j * ge[3], f1 = ge[2] + (j + 1) * ge[3];
+      const double h = (sph || sys == ARTEMIS_CYLINDRICAL) ? x1v : 1.0; // width2
+      g.dx = h * (f1 - f0);
+    } else {
+      const double f0 = ge[4] + k * ge[5], f1 = ge[4] + (k + 1) * ge[5];
+      double h = 1.0; // width3
+      if (sph23) h = x1v * (P.metric + b * metric_block_stride(P.nj, P.nk))[MT_SINV * (P.nj + 1) + j];
+      else if (sys == ARTEMIS_AXISYMMETRIC) h = x1v;
+      g.dx = h * (f1 - f0);
+    }
+  }
+  g.rdx = recip(g.dx);
+  return g;
+}
 } // namespace artemis

@@ -31,6 +31,8 @@ long halo_count(const PackView &P, int face, int extended = 0);
 int launch_halo(const PackView &P, int block, int face, double *buf, int unpack, int extended,
                 hipStream_t s);
 void invalidate_table_cache();
+long plm_table_count(const PackView &P);
+void launch_plm_table_fill(const PackView &P, double *tab, hipStream_t s);
 // kernels_fused.hip
 void launch_advance_dt(double *state, double tlim, int nstages, const double *beta, hipStream_t s);
 void launch_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, hipStream_t s);

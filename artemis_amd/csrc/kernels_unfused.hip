@@ -80,14 +80,19 @@ __device__ __forceinline__ CellIdx cell_from_grid(const Range3 &r) {
 // the cell above it straight from global memory (neighbouring threads share those lines in
 // L1/L2), then solves the Riemann problem and writes the 8 (gas) / 4 (dust) face outputs.
 // One face: the reconstruction and the Riemann problem of species n at the lower `dir` face of cell (k,j,i).
-template <int FLUID, int RIEMANN, int RECON, bool CURV>
+template <int FLUID, int RIEMANN, int RECON, bool CURV, bool TAB = false>
 __device__ __forceinline__ FaceFlux flux_face(const PackView &P, int b, int k, int j, int i, long c, const int dir, const int n) {
   PlmGeo gl{}, gr{};
   double hs[3] = {1.0, 1.0, 1.0}; // ScaleMomentumFlux factors (fluid_fluxes.hpp:33-70)
   if constexpr (CURV) {
     if constexpr (RECON == 1) {
-      gl = plm_geo(P, b, dir, k - (dir == 3), j - (dir == 2), i - (dir == 1));
-      gr = plm_geo(P, b, dir, k, j, i);
+      if constexpr (TAB) { // PLM_G's weights from the per-mesh table (artemis_hip_plm_table_fill)
+        gl = plm_geo_tab(P, b, dir, k - (dir == 3), j - (dir == 2), i - (dir == 1));
+        gr = plm_geo_tab(P, b, dir, k, j, i);
+      } else {
+        gl = plm_geo(P, b, dir, k - (dir == 3), j - (dir == 2), i - (dir == 1));
+        gr = plm_geo(P, b, dir, k, j, i);
+      }
     }
     make_coords(P, b, k, j, i).face_scale(dir, hs);
   }
@@ -157,11 +162,24 @@ __device__ __forceinline__ void store_face(const PackView &P, int b, long c, con
 // first and stored afterwards: a store through the pointer tables may alias anything as far as the compiler knows,
 // so stores between the sweeps kept the next sweep's loads from being issued early (three load -> solve -> store
 // chains per thread, latency-bound at 3-4 waves per SIMD).
-template <int FLUID, int RIEMANN, int RECON, bool CURV>
+template <int FLUID, int RIEMANN, int RECON, bool CURV, bool TAB = false>
 __global__ __launch_bounds__(TX *TY) void flux_kernel(const PackView P, const Range3 r) {
   CELL_FROM_GRID(r)
   const int ns = (FLUID == 0) ? P.gas.ns : P.dust.ns;
   const bool has1 = (j <= P.je && k <= P.ke), has2 = P.ndim > 1 && (i <= P.ie && k <= P.ke), has3 = P.ndim > 2 && (i <= P.ie && j <= P.je);
+  if constexpr (TAB) {
+    // with the geometry table a face is cheap in registers only while its two records are the only ones alive: one
+    // face at a time (solve, store), which also keeps the next face's table loads behind this face's stores
+    // (direction outermost: the records do not depend on the species, and hoisted out of a species loop all six
+    // would be alive at once)
+    if (has1)
+      for (int n = 0; n < ns; ++n) store_face<FLUID>(P, b, c, 1, n, flux_face<FLUID, RIEMANN, RECON, CURV, true>(P, b, k, j, i, c, 1, n));
+    if (has2)
+      for (int n = 0; n < ns; ++n) store_face<FLUID>(P, b, c, 2, n, flux_face<FLUID, RIEMANN, RECON, CURV, true>(P, b, k, j, i, c, 2, n));
+    if (has3)
+      for (int n = 0; n < ns; ++n) store_face<FLUID>(P, b, c, 3, n, flux_face<FLUID, RIEMANN, RECON, CURV, true>(P, b, k, j, i, c, 3, n));
+    return;
+  }
   for (int n = 0; n < ns; ++n) {
     FaceFlux F1{}, F2{}, F3{};
     if (has1) F1 = flux_face<FLUID, RIEMANN, RECON, CURV>(P, b, k, j, i, c, 1, n);
@@ -179,6 +197,8 @@ void launch_flux_dirs(const PackView &P, hipStream_t s) {
   Range3 r{P.is, P.ie + 1, P.js, P.je + (P.ndim > 1 ? 1 : 0), P.ks, P.ke + (P.ndim > 2 ? 1 : 0)};
   if (P.coords == ARTEMIS_CARTESIAN)
     hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, false>), shape_for(r, P.nb).grid, shape_for(r, P.nb).block, 0, s, P, r);
+  else if (RECON == 1 && P.plm_tab != nullptr)
+    hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, true, true>), shape_for(r, P.nb).grid, shape_for(r, P.nb).block, 0, s, P, r);
   else
     hipLaunchKernelGGL((flux_kernel<FLUID, RIEMANN, RECON, true>), shape_for(r, P.nb).grid, shape_for(r, P.nb).block, 0, s, P, r);
 }
@@ -1246,6 +1266,32 @@ int launch_halo(const PackView &P, int block, int face, double *buf, int unpack,
   hipLaunchKernelGGL(halo_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, t, P.ni, P.nj, buf,
                      unpack);
   return 0;
+}
+
+// ---- PLM_G geometry table (artemis_hip_plm_table_fill; layout: pack_view.hpp, geometry.hpp plm_geo_tab) ---------
+namespace {
+__global__ __launch_bounds__(256) void plm_table_kernel(const PackView P, double *tab) {
+  const int L = P.plm_len;
+  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<long>(P.nb) * 3 * L) return;
+  const int idx = static_cast<int>(t % L), d = static_cast<int>((t / L) % 3), b = static_cast<int>(t / (3L * L));
+  const int n = (d == 0) ? P.ni : ((d == 1) ? P.nj : P.nk);
+  double *row = tab + (static_cast<long>(b) * 3 + d) * PLM_TAB_ROWS * L + idx;
+  double v[PLM_TAB_ROWS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (d < P.ndim && idx >= 1 && idx <= n - 2) { // (the record reads the centroids of idx - 1 and idx + 1)
+    const PlmGeo g = plm_geo(P, b, d + 1, (d == 2) ? idx : 0, (d == 1) ? idx : 0, (d == 0) ? idx : 0);
+    v[0] = g.cr, v[1] = g.cl, v[2] = g.up, v[3] = g.lo, v[4] = g.ra.b, v[5] = g.ra.y, v[6] = g.rb.b, v[7] = g.rb.y;
+  }
+  if (d == 0 && idx < n) v[8] = make_coords(P, b, 0, 0, idx).x1v();
+  for (int q = 0; q < PLM_TAB_ROWS; ++q) row[q * L] = v[q];
+}
+} // namespace
+long plm_table_count(const PackView &P) { return static_cast<long>(P.nb) * 3 * PLM_TAB_ROWS * P.plm_len; }
+void launch_plm_table_fill(const PackView &P, double *tab, hipStream_t s) {
+  PackView Q = P;
+  Q.plm_tab = nullptr; // (the fill evaluates the functions themselves)
+  const long n = static_cast<long>(P.nb) * 3 * P.plm_len;
+  hipLaunchKernelGGL(plm_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Q, tab);
 }
 
 } // namespace artemis

@@ -29,8 +29,11 @@ struct PackView {
   int coords;           // enum artemis_coords
   const double *metric; // [nb][6][nj+1] x2 trig tables (spherical2D/3D), else null
   double omf;           // frame frequency for FluxSource's coordinate sources
+  const double *plm_tab; // PLM_G weights per (block, direction, index) (artemis_hip_plm_table_fill), or null
+  int plm_len;           // row length of that table: max(ni, nj, nk)
   FluidView gas, dust;
 };
+constexpr int PLM_TAB_ROWS = 9; // cr, cl, up, lo, ra.b, ra.y, rb.b, rb.y, x1v (direction 1 rows only)
 
 inline FluidView make_fluid_view(const artemis_fluid_pack_t &f) {
   FluidView v;
@@ -58,6 +61,8 @@ inline PackView make_pack_view(const artemis_pack_t &p) {
   v.coords = p.coords;
   v.metric = p.metric;
   v.omf = p.omega_frame;
+  v.plm_tab = p.plm_table;
+  v.plm_len = (v.ni > v.nj) ? ((v.ni > v.nk) ? v.ni : v.nk) : ((v.nj > v.nk) ? v.nj : v.nk);
   v.gas = make_fluid_view(p.gas);
   v.dust = make_fluid_view(p.dust);
   return v;

@@ -4,6 +4,7 @@ method is a single call through the C ABI of libartemis_hip.so; torch only owns 
 allocations and the stream.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -97,9 +98,25 @@ class MeshBlockPack:
             self.metric_host = mt
             self.metric = torch.from_numpy(mt).to(self.dev)
             p.metric = self.metric.data_ptr()
+        # PLM_G's geometric weights (artemis_hip_plm_table_fill): on by default for curvilinear packs, as the host driver
+        # runs; ARTEMIS_NO_PLM_TABLE=1 (or set_plm_table(False)) makes the kernels form them per face
+        self.plm_table = None
+        if coordinates != "cartesian" and not os.environ.get("ARTEMIS_NO_PLM_TABLE"):
+            self.set_plm_table(True)
         self.gas_prim_table = p.gas.prim
         self.dust_prim_table = p.dust.prim
         self._extra_prim = {}
+
+    def set_plm_table(self, on):
+        if not on:
+            self.pack.plm_table = None
+            return
+        if self.plm_table is None:
+            n = self.L.artemis_hip_plm_table_count(C.byref(self.pack))
+            self.plm_table = torch.zeros(n, dtype=torch.float64, device=self.dev)
+            capi.check(self.L.artemis_hip_plm_table_fill(C.byref(self.pack), C.c_void_p(self.plm_table.data_ptr()), None))
+            torch.cuda.synchronize()
+        self.pack.plm_table = self.plm_table.data_ptr()
 
     # ---- helpers -------------------------------------------------------------------------
     def _stream(self):

@@ -105,7 +105,21 @@ typedef struct artemis_pack {
   double omega_frame;        /* rotating_frame/omega when physics/rotating_frame is on, else 0: the frame
                                 velocity RotationVelocity<GEOM>(xv, omf) inside FluxSource's coordinate
                                 source terms (fluid_fluxes.hpp:345, :395-415, :433-437) */
+  const double *plm_table;   /* optional DEVICE table of PLM_G's geometric weights (artemis_hip_plm_table_count /
+                                _fill), or NULL: CalculateFluxes then forms them per face */
 } artemis_pack_t;
+
+/* PLM_G (plm.hpp:54-73) weighs every limited slope with quotients of cell-centroid and face positions along the
+ * sweep direction -- geometry of the block, a function of the index along that direction only: (x_i+1 - x_i) /
+ * (x_f1 - x_i), (x_i - x_i-1) / (x_i - x_f0), the two face offsets and the refined reciprocals of the two centroid
+ * distances, plus the x1 centroid of every column (the cell widths of PLM_G's x2 / x3 sweeps carry it as a factor and
+ * stay per cell).  Forming them per face costs ~40 divisions per zone in CalculateFluxes on a curvilinear mesh (half of
+ * that kernel's instructions -- though only 3 % of its time, which goes to memory latency); the table holds them once
+ * per mesh: 3 directions x 9 rows of max(ni, nj, nk) doubles
+ * per block, filled on the device with the same functions the kernels would call -- the same bits.  Host-owned like
+ * the metric tables: fill after p->geom / p->metric are in place (and again after a remesh), point p->plm_table at it. */
+long artemis_hip_plm_table_count(const artemis_pack_t *p);
+int artemis_hip_plm_table_fill(const artemis_pack_t *p, double *table_dev, void *stream);
 
 /* ---- Parthenon task functions ---------------------------------------------------------*/
 

@@ -38,7 +38,7 @@ struct PackCache {
   artemis_pack_t p{};
   ParArray1D<Real *> gprim, gcons0, gcons1, gflux[3], gpflux[3], gvface[3], gdflux[3];
   ParArray1D<Real *> dprim, dcons0, dcons1, dflux[3];
-  ParArray1D<Real> geom, metric;
+  ParArray1D<Real> geom, metric, plm_table;
   std::vector<Real> geom_host, metric_host;
   const Real *probe0 = nullptr, *probe1 = nullptr;
   int nb = -1;
@@ -188,6 +188,13 @@ inline void BuildFromU0(PackCache &c, MeshData<Real> *u0) {
     c.metric = ParArray1D<Real>("artemis_hip metric", nm);
     parthenon::deep_copy_from_host(c.metric, c.metric_host.data(), c.metric_host.size());
     p.metric = c.metric.data();
+  }
+  // PLM_G's geometric weights (plm.hpp:54-73), once per (re)mesh on the device (curvilinear meshes; optional)
+  p.plm_table = nullptr;
+  if (p.coords != ARTEMIS_CARTESIAN) {
+    c.plm_table = ParArray1D<Real>("artemis_hip plm table", artemis_hip_plm_table_count(&p));
+    PARTHENON_REQUIRE(artemis_hip_plm_table_fill(&p, c.plm_table.data(), nullptr) == 0, artemis_hip_last_error());
+    p.plm_table = c.plm_table.data();
   }
   c.nb = nb;
   c.probe1 = nullptr; // the cons1 tables belong to the previous mesh

@@ -159,6 +159,16 @@ long artemis_hip_metric_count(const artemis_pack_t *p) {
   const int nk = p->nx3 + ((p->nx3 > 1) ? 2 * p->nghost : 0);
   return static_cast<long>(p->nblocks) * (6L * (nj + 1) + 2L * (nk + 1));
 }
+// (the double evaluates PLM_G through the oracle: the table is accepted and ignored)
+long artemis_hip_plm_table_count(const artemis_pack_t *p) {
+  const int g1 = p->nghost, g2 = (p->nx2 > 1) ? p->nghost : 0, g3 = (p->nx3 > 1) ? p->nghost : 0;
+  const int ni = p->nx1 + 2 * g1, nj = p->nx2 + 2 * g2, nk = p->nx3 + 2 * g3;
+  return static_cast<long>(p->nblocks) * 3 * 9 * std::max(ni, std::max(nj, nk));
+}
+int artemis_hip_plm_table_fill(const artemis_pack_t *p, double *table, void *) {
+  std::memset(table, 0, sizeof(double) * artemis_hip_plm_table_count(p));
+  return 0;
+}
 int artemis_hip_metric_fill(const artemis_pack_t *p, const double *g, double *out) {
   if (artemis_hip_metric_count(p) == 0) return 0;
   const int nj = p->nx2 + ((p->nx2 > 1) ? 2 * p->nghost : 0), st = nj + 1;

@@ -46,10 +46,15 @@ def make_pair(coordinates, nx, lo, hi, ng=2, ns_gas=1, ns_dust=0, recon="plm", r
 
 @pytest.mark.parametrize("coordinates,nx,lo,hi", GEOMS)
 @pytest.mark.parametrize("recon,riem", [("plm", "hlle"), ("plm", "hllc"), ("ppm", "llf"), ("pcm", "hlle")])
-def test_fluxes_curvilinear(hiplib, coordinates, nx, lo, hi, recon, riem):
-    """PLM_G (plm.hpp:54-73) + ScaleMomentumFlux (fluid_fluxes.hpp:33-70), gas and dust."""
+@pytest.mark.parametrize("table", [True, False])
+def test_fluxes_curvilinear(hiplib, coordinates, nx, lo, hi, recon, riem, table):
+    """PLM_G (plm.hpp:54-73) + ScaleMomentumFlux (fluid_fluxes.hpp:33-70), gas and dust; PLM_G's geometric weights
+    read from the per-mesh table of artemis_hip_plm_table_fill (`table`, what the host driver does) or formed per
+    face: the same bits either way."""
     ng = 3 if recon == "ppm" else 2
     o, mb = make_pair(coordinates, nx, lo, hi, ng=ng, ns_gas=2, ns_dust=1, recon=recon, riem=riem, seed=11)
+    assert mb.plm_table is not None  # (on by default for curvilinear packs)
+    mb.set_plm_table(table)
     for fluid in (0, 1):
         o.CalculateFluxes(fluid, False)
         mb.CalculateFluxes(fluid, False)
