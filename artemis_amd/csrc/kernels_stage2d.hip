@@ -605,7 +605,12 @@ template <int RG, int RD, int RECON, int ND>
 void launch_flags(const PackView &P, const S2Args &a, hipStream_t s) {
   const long waves = static_cast<long>(a.nstrip) * a.nchunk * P.nb;
   const dim3 grid(static_cast<unsigned>((waves + 3) / 4)), block(256);
-  const dim3 rgrid(256); // the exact kernel: 1024 waves stride over the listed rows (normally none)
+  // the exact kernel: its waves stride over the listed rows (normally none).  An empty pass of this register-heavy
+  // kernel costs by its grid -- 7.4 us at 256 workgroups, 5 % of a 1024^2 stage --, so the grid is sized by the main
+  // launch: one exact workgroup per 32 main ones, between 8 and 256
+  static const int rg_env = getenv("ARTEMIS_STAGE2D_RGRID") ? atoi(getenv("ARTEMIS_STAGE2D_RGRID")) : 0;
+  const unsigned rg = rg_env > 0 ? static_cast<unsigned>(rg_env) : std::min(256u, std::max(8u, grid.x / 32u));
+  const dim3 rgrid(rg);
 #define GO(U, D)                                                                                                    \
   do {                                                                                                              \
     hipLaunchKernelGGL((stage2d_kernel<RG, RD, RECON, ND, U, D, false>), grid, block, 0, s, P, a);                  \
