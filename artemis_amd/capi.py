@@ -73,6 +73,7 @@ class StageArgs(C.Structure):
         ("shell_done", C.c_void_p), ("shell_target", C.POINTER(C.c_uint)),
         ("beta_dt_dev", C.c_void_p), ("shell_faces", C.c_int),
         ("tiny_in", C.c_void_p), ("tiny_out", C.c_void_p), ("tiny_clear", C.c_void_p),
+        ("x1_outflow", C.c_int),
     ]
 
 
@@ -84,7 +85,7 @@ class BcParams(C.Structure):
                 ("ic_gas", C.c_void_p),
                 ("ic_dust", C.c_void_p), ("disk_omf", C.c_double), ("disk_nu0", C.c_double),
                 ("disk_nu_indx", C.c_double), ("disk_r0", C.c_double), ("disk_mdot", C.c_double),
-                ("floor_ghosts", C.c_int)]
+                ("floor_ghosts", C.c_int), ("x1_interior_done", C.c_int)]
 
 
 class Cooling(C.Structure):

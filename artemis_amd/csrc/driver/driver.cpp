@@ -282,6 +282,12 @@ struct artemis_sim_impl {
   DevBuf tstate; // device-resident {time, dt, dt_est, beta_dt[3]} for the synchronisation-free loop
   double *dt_host = nullptr;    // pinned
   bool unfused_ready = false;
+  // step_fused with outflow x1 faces: the tuned kernel stages the edge zone instead of reading the x1 ghost columns, the
+  // per-stage boundary fill leaves them alone (artemis_stage_args_t.x1_outflow, artemis_bc_params_t.x1_interior_done)
+  // and evolve() fills them once before it returns
+  int x1_done_hint = 0;
+  bool x1_ghosts_stale = false;
+  void fill_stale_x1_ghosts();
   bool use_fused = false, fused_possible = false;
   // refined meshes: the one-kernel stages on every block + the fix-up of the zones on coarse-fine faces
   // (step_ml_fused; include/artemis_hip.h "flux correction as a thin fix-up"); ml_tuned: the tuned gas kernel
@@ -1415,6 +1421,7 @@ void artemis_sim_impl::fill_ghosts_finish(int prim_idx, void *hs, int dim, bool 
       value_bc = value_bc || bc_flat[q] >= ARTEMIS_BC_CONDUCTIVE ||
                  (bc_flat[q] == ARTEMIS_BC_STRAT_EXTRAP && (q % 6) / 2 == 2);
     bp.floor_ghosts = (use_fused && value_bc) ? 1 : 0;
+    bp.x1_interior_done = x1_done_hint;
     CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc");
   }
 }
@@ -2459,6 +2466,16 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
       }
     }
     a.shell_faces = faces;
+    {
+      // outflow x1 faces on every block (the decomposition never cuts x1) and nobody else reading the state inside the
+      // loop (no drop-in accounting): the x1 ghost columns stay unfilled until evolve() returns
+      bool both = (dropin == 0) && std::getenv("ARTEMIS_NO_X1_LAZY") == nullptr;
+      for (int b = 0; b < nb && both; ++b)
+        both = bc_flat[6 * b + 0] == ARTEMIS_BC_OUTFLOW && bc_flat[6 * b + 1] == ARTEMIS_BC_OUTFLOW;
+      a.x1_outflow = both ? 3 : 0;
+      x1_done_hint = a.x1_outflow;
+      x1_ghosts_stale = x1_ghosts_stale || both;
+    }
     // (ARTEMIS_FORCE_OVERLAP=1: diagnostic, shell-first ordering even when every link is local)
     const bool force_ovl = std::getenv("ARTEMIS_FORCE_OVERLAP") != nullptr;
     const bool ovl = overlap && (any_remote || (force_ovl && !links.empty()));
@@ -2525,6 +2542,16 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
   }
   base = cur;
   cons_valid = dropin != 0;
+  x1_done_hint = 0;
+}
+// the x1 ghost columns the stage loop left alone (see x1_done_hint): the plain boundary fill of the current state
+void artemis_sim_impl::fill_stale_x1_ghosts() {
+  if (!x1_ghosts_stale) return;
+  const artemis_pack_t p = make_pack(base);
+  artemis_bc_params_t bp = bcpar;
+  bp.floor_ghosts = 0, bp.x1_interior_done = 0;
+  CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc (x1 ghost columns)");
+  x1_ghosts_stale = false;
 }
 
 // One step on a refined mesh with the one-kernel stages: every block through artemis_hip_stage_fused /
@@ -2772,6 +2799,7 @@ long artemis_sim_impl::evolve(long max_cycles) {
     if (tlim > 0.0 && time < tlim && (tlim - time) < ndt) ndt = tlim - time;
     dt = ndt;
   }
+  fill_stale_x1_ghosts(); // (inside the timed region: part of the work)
   CK(artemis_rt_device_sync(), "sync");
   last_wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (shell_wait_used) {

@@ -75,6 +75,7 @@ struct StageK {
   unsigned redo_cap; // entries per list (>= the zones of the launch, so it only binds if a shell list is never drained)
   const unsigned *tiny_in; // artemis_stage_args_t: detection runs only if *tiny_in != 0 (null: always)
   unsigned *tiny_out;
+  int x1_outflow; // artemis_stage_args_t: bit 0 / 1 = do not read the x1 ghost columns of an outflow face (stage the edge zone)
 };
 
 struct LdsTile {
@@ -742,7 +743,9 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
   const int i = x.i0 + x.tx, j = x.j0 + x.ty;
   x.active = (i <= P.ie) && (j <= P.je);
   // clamped indices: inactive lanes still serve as neighbours and face owners
-  const int il = min(i, P.ni - 1), jl = min(j, P.nj - 1);
+  int il = min(i, P.ni - 1);
+  const int jl = min(j, P.nj - 1);
+  if (a.x1_outflow & 2) il = min(il, P.ie); // (ragged tiles: the lanes past the last zone stand in for the outflow ghosts)
   const int k0 = bkb0 + chunk * bkchunk;
   const int k1 = min(bkb1, k0 + bkchunk - 1);
   if (k0 > k1) { // empty chunk (cannot happen with the box builder, kept for safety)
@@ -777,7 +780,9 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
     x.hc = (cc < 2) ? cc : FTX + cc;
   }
   if (x.hr >= 0) {
-    const int gi = min(max(x.i0 - FH + x.hc, 0), P.ni - 1);
+    int gi = min(max(x.i0 - FH + x.hc, 0), P.ni - 1);
+    if (a.x1_outflow & 1) gi = max(gi, P.is); // outflow: the ghost zones hold the edge zone's value -- stage that
+    if (a.x1_outflow & 2) gi = min(gi, P.ie);
     const int gj = min(max(x.j0 - FH + x.hr, 0), P.nj - 1);
     x.hcol = static_cast<unsigned>(gj) * x.sj + static_cast<unsigned>(gi);
   }
@@ -1035,6 +1040,7 @@ struct RedoK {
   double *const *prim_in, *const *prim_u1, *const *prim_out, *const *cons_out;
   unsigned long long *dt_bits;
   unsigned *tiny_out, *tiny_clear;
+  int x1_outflow;
   unsigned *cnt;   // entries in the list; reset to zero by the last workgroup of this kernel (no memset between stages)
   unsigned *done;  // its ticket counter
   unsigned cap;
@@ -1069,7 +1075,16 @@ __global__ __launch_bounds__(256) void stage_redo_kernel(const PackView P, const
       constexpr int DIR = decltype(DIRTAG)::value;
       Cell6 w[5];
 #pragma unroll
-      for (int m = 0; m < 5; ++m) w[m] = load_cell(qr, q1, q2, q3, qe, c + (m - 2) * st, P.gm1);
+      for (int m = 0; m < 5; ++m) {
+        long cm = c + (m - 2) * st;
+        if (DIR == 1 && a.x1_outflow) { // the stage kernel's rule: an outflow ghost column is the edge zone (not read from memory)
+          int im = i + (m - 2);
+          if ((a.x1_outflow & 1) && im < P.is) im = P.is;
+          if ((a.x1_outflow & 2) && im > P.ie) im = P.ie;
+          cm = c + (im - i);
+        }
+        w[m] = load_cell(qr, q1, q2, q3, qe, cm, P.gm1);
+      }
       Cell6 Ll, Rl, Lu, Ru;
 #define RD(v)                                                                                          \
   {                                                                                                    \
@@ -1278,6 +1293,7 @@ void launch_redo(const PackView &P, const artemis_stage_args_t &a, int riemann, 
   r.prim_in = a.prim_in, r.prim_u1 = a.prim_u1, r.prim_out = a.prim_out, r.cons_out = a.cons_out;
   r.dt_bits = reinterpret_cast<unsigned long long *>(a.dt_dev);
   r.tiny_out = a.tiny_out, r.tiny_clear = (which == 0) ? a.tiny_clear : nullptr;
+  r.x1_outflow = a.x1_outflow & 3;
   r.cnt = g_redo.cnt + which, r.done = g_redo.cnt + 2 + which, r.cap = static_cast<unsigned>(std::min<size_t>(g_redo.cap, 0xffffffffu));
   r.list = g_redo.list[which];
   r.has_u1 = (a.prim_u1 != a.prim_in) ? 1 : 0;
@@ -1380,6 +1396,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   // detect-and-redo: zones next to vanishing velocities are deferred to the exact kernel (below)
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.tiny_in = a.tiny_in, k.tiny_out = a.tiny_out;
+  k.x1_outflow = a.x1_outflow & 3;
   const bool redo = redo_enabled();
   if (redo) {
     const size_t zones = static_cast<size_t>(P.nb) * (P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1);
@@ -1454,6 +1471,7 @@ int launch_flux_fused(const PackView &P, int riemann, int recon, hipStream_t s) 
   k.nshell = 0, k.shell_done = nullptr;
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.tiny_in = nullptr, k.tiny_out = nullptr;
+  k.x1_outflow = 0;
   k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
 #define RC(RS)                                                                             \
   case RS:                                                                                 \
@@ -1518,6 +1536,7 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
   k.nshell = 0, k.shell_done = nullptr;
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.tiny_in = nullptr, k.tiny_out = nullptr;
+  k.x1_outflow = 0;
   k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
   SrcArg<true> src;
   src.v.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;

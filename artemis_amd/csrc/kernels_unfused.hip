@@ -1201,6 +1201,12 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
   a.nA = (P.ndim > 2) ? 2L * P.ng * P.nj * P.ni : 0;
   a.nB = (P.ndim > 1) ? nz * 2L * P.ng * P.ni : 0;
   a.nC = nz * ny * 2L * P.ng;
+  if (par && (par->x1_interior_done & 3) == 3) { // the caller's stage kernel does not read the x1 ghost columns of active rows
+    bool user = false;
+    for (int b = 0; b < P.nb && !user; ++b)
+      for (int f = 0; f < 2 * P.ndim; ++f) user = user || bc[b * 6 + f] >= ARTEMIS_BC_STRAT_EXTRAP;
+    if (!user) a.nC = 0;
+  }
   const long n = a.nA + a.nB + a.nC;
   if (n >= (1L << 31)) return 3; // (a block with 2^31 shell zones)
   ShellBatch batch;
@@ -1208,6 +1214,10 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
   std::vector<int> user_blocks; // blocks with a user condition: per-face launches, batched over the blocks
   auto flush = [&]() {
     if (nq == 0) return;
+    if (n == 0) { // (1-D blocks whose only shell region was left to the caller)
+      nq = 0;
+      return;
+    }
     for (int f = 0; f < 6; ++f) a.bc[f] = ARTEMIS_BC_NONE; // (the kernel takes the flags from the batch)
     hipLaunchKernelGGL(bc_shell_kernel, dim3((n + 256 * SHELL_ZONES - 1) / (256 * SHELL_ZONES), nq), dim3(256), 0, s, a, fill_tabs(P, 0), batch);
     nq = 0;
