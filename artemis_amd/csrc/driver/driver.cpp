@@ -282,10 +282,12 @@ struct artemis_sim_impl {
   DevBuf tstate; // device-resident {time, dt, dt_est, beta_dt[3]} for the synchronisation-free loop
   double *dt_host = nullptr;    // pinned
   bool unfused_ready = false;
-  // step_fused with outflow x1 faces: the tuned kernel stages the edge zone instead of reading the x1 ghost columns, the
-  // per-stage boundary fill leaves them alone (artemis_stage_args_t.x1_outflow, artemis_bc_params_t.x1_interior_done)
-  // and evolve() fills them once before it returns
+  // step_fused with outflow faces: the tuned kernel stages the edge zone instead of reading the ghost zones behind them
+  // (artemis_stage_args_t.outflow_faces); the per-stage boundary fill leaves the x1 ghost columns alone
+  // (artemis_bc_params_t.x1_interior_done) or is skipped altogether when every physical face of the rank is such a face,
+  // and evolve() fills the ghost zones once before it returns
   int x1_done_hint = 0;
+  bool skip_bc_hint = false;
   bool x1_ghosts_stale = false;
   void fill_stale_x1_ghosts();
   bool use_fused = false, fused_possible = false;
@@ -1422,7 +1424,7 @@ void artemis_sim_impl::fill_ghosts_finish(int prim_idx, void *hs, int dim, bool 
                  (bc_flat[q] == ARTEMIS_BC_STRAT_EXTRAP && (q % 6) / 2 == 2);
     bp.floor_ghosts = (use_fused && value_bc) ? 1 : 0;
     bp.x1_interior_done = x1_done_hint;
-    CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc");
+    if (!skip_bc_hint) CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc");
   }
 }
 void artemis_sim_impl::fill_ghosts(int prim_idx) {
@@ -2469,12 +2471,25 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
     {
       // outflow x1 faces on every block (the decomposition never cuts x1) and nobody else reading the state inside the
       // loop (no drop-in accounting): the x1 ghost columns stay unfilled until evolve() returns
-      bool both = (dropin == 0) && std::getenv("ARTEMIS_NO_X1_LAZY") == nullptr;
-      for (int b = 0; b < nb && both; ++b)
-        both = bc_flat[6 * b + 0] == ARTEMIS_BC_OUTFLOW && bc_flat[6 * b + 1] == ARTEMIS_BC_OUTFLOW;
-      a.x1_outflow = both ? 3 : 0;
-      x1_done_hint = a.x1_outflow;
-      x1_ghosts_stale = x1_ghosts_stale || both;
+      int mask = 0;
+      bool all_covered = true; // every physical face of every block is an outflow face of the mask
+      if (dropin == 0 && std::getenv("ARTEMIS_NO_X1_LAZY") == nullptr) {
+        for (int f = 0; f < 2 * ndim; ++f) {
+          bool every = true;
+          for (int b = 0; b < nb && every; ++b) every = bc_flat[6 * b + f] == ARTEMIS_BC_OUTFLOW;
+          if (every) mask |= 1 << f;
+        }
+        if (std::getenv("ARTEMIS_LAZY_X1_ONLY")) mask &= 3; // (experiments)
+      }
+      for (int b = 0; b < nb; ++b)
+        for (int f = 0; f < 2 * ndim; ++f)
+          all_covered = all_covered && (bc_flat[6 * b + f] == ARTEMIS_BC_NONE || ((mask >> f) & 1));
+      a.outflow_faces = mask;
+      x1_done_hint = ((mask & 3) == 3) ? 3 : 0;
+      skip_bc_hint = mask != 0 && all_covered;
+      if (!skip_bc_hint && x1_done_hint == 0) a.outflow_faces = mask = 0; // (nothing to gain: keep the plain protocol)
+      if (!skip_bc_hint) a.outflow_faces = mask & 3;                       // (the boundary fill still provides x2 / x3 ghosts)
+      x1_ghosts_stale = x1_ghosts_stale || a.outflow_faces != 0;
     }
     // (ARTEMIS_FORCE_OVERLAP=1: diagnostic, shell-first ordering even when every link is local)
     const bool force_ovl = std::getenv("ARTEMIS_FORCE_OVERLAP") != nullptr;
@@ -2542,7 +2557,7 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
   }
   base = cur;
   cons_valid = dropin != 0;
-  x1_done_hint = 0;
+  x1_done_hint = 0, skip_bc_hint = false;
 }
 // the x1 ghost columns the stage loop left alone (see x1_done_hint): the plain boundary fill of the current state
 void artemis_sim_impl::fill_stale_x1_ghosts() {
@@ -2550,7 +2565,7 @@ void artemis_sim_impl::fill_stale_x1_ghosts() {
   const artemis_pack_t p = make_pack(base);
   artemis_bc_params_t bp = bcpar;
   bp.floor_ghosts = 0, bp.x1_interior_done = 0;
-  CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc (x1 ghost columns)");
+  CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc (ghost zones the stage loop left alone)");
   x1_ghosts_stale = false;
 }
 

@@ -75,7 +75,7 @@ struct StageK {
   unsigned redo_cap; // entries per list (>= the zones of the launch, so it only binds if a shell list is never drained)
   const unsigned *tiny_in; // artemis_stage_args_t: detection runs only if *tiny_in != 0 (null: always)
   unsigned *tiny_out;
-  int x1_outflow; // artemis_stage_args_t: bit 0 / 1 = do not read the x1 ghost columns of an outflow face (stage the edge zone)
+  int outflow; // artemis_stage_args_t.outflow_faces: bit f = do not read the ghost zones behind face f (stage the edge zone)
 };
 
 struct LdsTile {
@@ -744,8 +744,9 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
   x.active = (i <= P.ie) && (j <= P.je);
   // clamped indices: inactive lanes still serve as neighbours and face owners
   int il = min(i, P.ni - 1);
-  const int jl = min(j, P.nj - 1);
-  if (a.x1_outflow & 2) il = min(il, P.ie); // (ragged tiles: the lanes past the last zone stand in for the outflow ghosts)
+  int jl = min(j, P.nj - 1);
+  if (a.outflow & 8) jl = min(jl, P.je);
+  if (a.outflow & 2) il = min(il, P.ie); // (ragged tiles: the lanes past the last zone stand in for the outflow ghosts)
   const int k0 = bkb0 + chunk * bkchunk;
   const int k1 = min(bkb1, k0 + bkchunk - 1);
   if (k0 > k1) { // empty chunk (cannot happen with the box builder, kept for safety)
@@ -781,9 +782,11 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
   }
   if (x.hr >= 0) {
     int gi = min(max(x.i0 - FH + x.hc, 0), P.ni - 1);
-    if (a.x1_outflow & 1) gi = max(gi, P.is); // outflow: the ghost zones hold the edge zone's value -- stage that
-    if (a.x1_outflow & 2) gi = min(gi, P.ie);
-    const int gj = min(max(x.j0 - FH + x.hr, 0), P.nj - 1);
+    if (a.outflow & 1) gi = max(gi, P.is); // outflow: the ghost zones hold the edge zone's value -- stage that
+    if (a.outflow & 2) gi = min(gi, P.ie);
+    int gj = min(max(x.j0 - FH + x.hr, 0), P.nj - 1);
+    if (a.outflow & 4) gj = max(gj, P.js);
+    if (a.outflow & 8) gj = min(gj, P.je);
     x.hcol = static_cast<unsigned>(gj) * x.sj + static_cast<unsigned>(gi);
   }
   double ldt = DBL_MAX;
@@ -869,7 +872,13 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
   } else {
     // x3 state carried in registers: planes k, k+1, the upper face value of cell k and the
     // flux through face k.
-    Cell6 qc = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k0 - 1) * x.sk, x.gm1);
+    // planes behind an outflow x3 face are the first / last active plane (StageK::outflow): wave-uniform index arithmetic
+    auto kpl = [&](int kk) {
+      if (a.outflow & 16) kk = max(kk, P.ks);
+      if (a.outflow & 32) kk = min(kk, P.ke);
+      return static_cast<unsigned>(kk);
+    };
+    Cell6 qc = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + kpl(k0 - 1) * x.sk, x.gm1);
     Cell6 qn = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + k0 * x.sk, x.gm1);
     Cell6 zl;
     // DETECT: the x3 sweep of zone k reads planes k-2 .. k+2 of its own column.  Planes k+1 and k+2 are in registers
@@ -880,7 +889,7 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
     [[maybe_unused]] bool ahead1 = false; // the own column's plane k+1 holds a tiny velocity
     {
       const Cell6 qmm =
-          load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k0 - 2) * x.sk, x.gm1);
+          load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + kpl(k0 - 2) * x.sk, x.gm1);
       if constexpr (DETECT) {
         if (detect) fhist = __any(tiny_v(qmm) || tiny_v(qc)) ? 3u : 0u, ahead1 = tiny_v(qn); // planes k0-2, k0-1 (not staged by this chunk); k0
       }
@@ -903,7 +912,7 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
     for (int k = k0 - 1; k <= k1; ++k) { // the first trip only primes fz_lo (face k0)
       // Issue this trip's HBM loads first; they are consumed after the plane's LDS phases, so
       // their latency hides behind the x1/x2 sweeps (barriers do not drain vmcnt).
-      const Raw5 rnn = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + (k + 2) * x.sk);
+      const Raw5 rnn = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + kpl(k + 2) * x.sk);
       if constexpr (HAS_U1) {
         if (k >= k0) u1raw = load_raw(u1_r, u1_1, u1_2, u1_3, u1_e, x.col + static_cast<unsigned>(k) * x.sk);
       }
@@ -1040,7 +1049,7 @@ struct RedoK {
   double *const *prim_in, *const *prim_u1, *const *prim_out, *const *cons_out;
   unsigned long long *dt_bits;
   unsigned *tiny_out, *tiny_clear;
-  int x1_outflow;
+  int outflow;
   unsigned *cnt;   // entries in the list; reset to zero by the last workgroup of this kernel (no memset between stages)
   unsigned *done;  // its ticket counter
   unsigned cap;
@@ -1077,11 +1086,13 @@ __global__ __launch_bounds__(256) void stage_redo_kernel(const PackView P, const
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
         long cm = c + (m - 2) * st;
-        if (DIR == 1 && a.x1_outflow) { // the stage kernel's rule: an outflow ghost column is the edge zone (not read from memory)
-          int im = i + (m - 2);
-          if ((a.x1_outflow & 1) && im < P.is) im = P.is;
-          if ((a.x1_outflow & 2) && im > P.ie) im = P.ie;
-          cm = c + (im - i);
+        if (a.outflow) { // the stage kernel's rule: the ghost zones behind an outflow face are the edge zone (not read from memory)
+          const int at = (DIR == 1) ? i : ((DIR == 2) ? j : k), lo = (DIR == 1) ? P.is : ((DIR == 2) ? P.js : P.ks);
+          const int hi = (DIR == 1) ? P.ie : ((DIR == 2) ? P.je : P.ke);
+          int am = at + (m - 2);
+          if (((a.outflow >> (2 * (DIR - 1))) & 1) && am < lo) am = lo;
+          if (((a.outflow >> (2 * (DIR - 1) + 1)) & 1) && am > hi) am = hi;
+          cm = c + (am - at) * st;
         }
         w[m] = load_cell(qr, q1, q2, q3, qe, cm, P.gm1);
       }
@@ -1293,7 +1304,7 @@ void launch_redo(const PackView &P, const artemis_stage_args_t &a, int riemann, 
   r.prim_in = a.prim_in, r.prim_u1 = a.prim_u1, r.prim_out = a.prim_out, r.cons_out = a.cons_out;
   r.dt_bits = reinterpret_cast<unsigned long long *>(a.dt_dev);
   r.tiny_out = a.tiny_out, r.tiny_clear = (which == 0) ? a.tiny_clear : nullptr;
-  r.x1_outflow = a.x1_outflow & 3;
+  r.outflow = a.outflow_faces & 63;
   r.cnt = g_redo.cnt + which, r.done = g_redo.cnt + 2 + which, r.cap = static_cast<unsigned>(std::min<size_t>(g_redo.cap, 0xffffffffu));
   r.list = g_redo.list[which];
   r.has_u1 = (a.prim_u1 != a.prim_in) ? 1 : 0;
@@ -1396,7 +1407,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   // detect-and-redo: zones next to vanishing velocities are deferred to the exact kernel (below)
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.tiny_in = a.tiny_in, k.tiny_out = a.tiny_out;
-  k.x1_outflow = a.x1_outflow & 3;
+  k.outflow = a.outflow_faces & 63;
   const bool redo = redo_enabled();
   if (redo) {
     const size_t zones = static_cast<size_t>(P.nb) * (P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1);
@@ -1471,7 +1482,7 @@ int launch_flux_fused(const PackView &P, int riemann, int recon, hipStream_t s) 
   k.nshell = 0, k.shell_done = nullptr;
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.tiny_in = nullptr, k.tiny_out = nullptr;
-  k.x1_outflow = 0;
+  k.outflow = 0;
   k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
 #define RC(RS)                                                                             \
   case RS:                                                                                 \
@@ -1536,7 +1547,7 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
   k.nshell = 0, k.shell_done = nullptr;
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.tiny_in = nullptr, k.tiny_out = nullptr;
-  k.x1_outflow = 0;
+  k.outflow = 0;
   k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
   SrcArg<true> src;
   src.v.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;

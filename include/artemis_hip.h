@@ -219,7 +219,7 @@ typedef struct artemis_bc_params {
    * this instead. */
   int floor_ghosts;
   /* 3: leave the x1 ghost columns of the ACTIVE rows alone (both x1 faces; the x2 / x3 ghost rows and planes are
-   * filled over the entire x1 extent as always).  For callers of artemis_hip_stage_fused with x1_outflow = 3, which
+   * filled over the entire x1 extent as always).  For callers of artemis_hip_stage_fused with outflow_faces bits 0 and 1, which
    * does not read those columns.  Ignored when a block of the pack carries a user condition.  0 = fill everything. */
   int x1_interior_done;
 } artemis_bc_params_t;
@@ -394,12 +394,13 @@ typedef struct artemis_stage_args {
    *              step.  With separate region 1 / 2 launches pass it only with the last launch of the stage. */
   const unsigned *tiny_in;
   unsigned *tiny_out, *tiny_clear;
-  /* bit 0 / bit 1: the lower / upper x1 face of EVERY block of the pack is a parthenon `outflow` boundary and the kernel
-   * shall not read the x1 ghost columns behind it: it stages the first / last active zone of the row in their place --
-   * the value an outflow condition puts there.  A caller that sets this may leave those columns unfilled between
-   * stages (artemis_bc_params_t.x1_interior_done skips them: the strided third of the boundary shell and most of its
-   * cost) as long as it fills them before anything else reads the state.  0 = read the ghost columns. */
-  int x1_outflow;
+  /* bit f (f = 0..5: lower / upper x1, x2, x3 face): that face of EVERY block of the pack is a parthenon `outflow`
+   * boundary and the kernel shall not read the ghost zones behind it: it stages the first / last active zone of the row,
+   * column or march in their place -- the value an outflow condition puts there.  A caller that sets a bit may leave
+   * those ghost zones unfilled between stages (artemis_bc_params_t.x1_interior_done for the x1 columns -- the strided
+   * third of the boundary shell and most of its cost --, or no artemis_hip_apply_bc call at all when every physical
+   * face of the pack is covered) as long as it fills them before anything else reads the state.  0 = read the ghosts. */
+  int outflow_faces;
 } artemis_stage_args_t;
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
 int artemis_hip_stage_fused_redo_shell(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
