@@ -288,8 +288,8 @@ struct artemis_sim_impl {
   // and evolve() fills the ghost zones once before it returns
   int x1_done_hint = 0;
   bool skip_bc_hint = false;
-  bool x1_ghosts_stale = false;
-  void fill_stale_x1_ghosts();
+  bool ghosts_stale = false;
+  void fill_stale_ghosts();
   bool use_fused = false, fused_possible = false;
   // refined meshes: the one-kernel stages on every block + the fix-up of the zones on coarse-fine faces
   // (step_ml_fused; include/artemis_hip.h "flux correction as a thin fix-up"); ml_tuned: the tuned gas kernel
@@ -2469,8 +2469,11 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
     }
     a.shell_faces = faces;
     {
-      // outflow x1 faces on every block (the decomposition never cuts x1) and nobody else reading the state inside the
-      // loop (no drop-in accounting): the x1 ghost columns stay unfilled until evolve() returns
+      // Faces that are `outflow` on every block of this rank (x1 always is on the Sedov deck: the decomposition never
+      // cuts x1), with nobody else reading the state inside the loop (no drop-in accounting): the kernel stages the edge
+      // zone instead of the ghost zones behind them.  If that covers every physical face of the rank the per-stage
+      // boundary fill is skipped; otherwise only the x1 ghost columns are left alone (both x1 faces covered) and the
+      // kernel keeps reading the x2 / x3 ghosts the fill provides.  evolve() completes the ghost zones before it returns.
       int mask = 0;
       bool all_covered = true; // every physical face of every block is an outflow face of the mask
       if (dropin == 0 && std::getenv("ARTEMIS_NO_X1_LAZY") == nullptr) {
@@ -2489,7 +2492,7 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
       skip_bc_hint = mask != 0 && all_covered;
       if (!skip_bc_hint && x1_done_hint == 0) a.outflow_faces = mask = 0; // (nothing to gain: keep the plain protocol)
       if (!skip_bc_hint) a.outflow_faces = mask & 3;                       // (the boundary fill still provides x2 / x3 ghosts)
-      x1_ghosts_stale = x1_ghosts_stale || a.outflow_faces != 0;
+      ghosts_stale = ghosts_stale || a.outflow_faces != 0;
     }
     // (ARTEMIS_FORCE_OVERLAP=1: diagnostic, shell-first ordering even when every link is local)
     const bool force_ovl = std::getenv("ARTEMIS_FORCE_OVERLAP") != nullptr;
@@ -2559,14 +2562,14 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
   cons_valid = dropin != 0;
   x1_done_hint = 0, skip_bc_hint = false;
 }
-// the x1 ghost columns the stage loop left alone (see x1_done_hint): the plain boundary fill of the current state
-void artemis_sim_impl::fill_stale_x1_ghosts() {
-  if (!x1_ghosts_stale) return;
+// the ghost zones the stage loop left alone (see skip_bc_hint / x1_done_hint): the plain boundary fill of the current state
+void artemis_sim_impl::fill_stale_ghosts() {
+  if (!ghosts_stale) return;
   const artemis_pack_t p = make_pack(base);
   artemis_bc_params_t bp = bcpar;
   bp.floor_ghosts = 0, bp.x1_interior_done = 0;
   CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc (ghost zones the stage loop left alone)");
-  x1_ghosts_stale = false;
+  ghosts_stale = false;
 }
 
 // One step on a refined mesh with the one-kernel stages: every block through artemis_hip_stage_fused /
@@ -2814,7 +2817,7 @@ long artemis_sim_impl::evolve(long max_cycles) {
     if (tlim > 0.0 && time < tlim && (tlim - time) < ndt) ndt = tlim - time;
     dt = ndt;
   }
-  fill_stale_x1_ghosts(); // (inside the timed region: part of the work)
+  fill_stale_ghosts(); // (inside the timed region: part of the work)
   CK(artemis_rt_device_sync(), "sync");
   last_wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (shell_wait_used) {
