@@ -347,3 +347,53 @@ def test_fused_stage_with_active_floors(hiplib, general):
     got, ref = out[0].cpu().numpy()[I], o.gprim[I]
     keep = [0, 1, 2, 3, 5]  # the general stage does not write the pressure slot
     assert np.array_equal(got[keep], ref[keep])
+
+
+@pytest.mark.parametrize("nx,ng,recon", [((40, 20, 36), 2, "plm"), ((33, 9, 17), 2, "pcm"), ((64, 16, 70), 3, "plm"),
+                                         ((70, 23, 1), 2, "plm"), ((97, 1, 1), 2, "plm")])
+@pytest.mark.parametrize("tiny", [False, True])
+def test_outflow_faces_are_not_read(hiplib, nx, ng, recon, tiny):
+    """artemis_stage_args_t.outflow_faces: with a bit set the kernel (and its exact pass: `tiny` puts vanishing velocities
+    into the state) stages the edge zone instead of reading the ghost zones behind that face.  Two RK2 steps in which the
+    ghost zones of the stage inputs hold NaN and NO boundary fill runs between the stages equal the oracle's steps with
+    its outflow conditions after every stage, bit for bit on the active zones -- full tiles, ragged tiles, several
+    k-chunks, three ghost zones, 2-D and 1-D; with one face left out of the mask the result changes, i.e. the mask is
+    what keeps the ghost zones unread."""
+    bc = ("outflow",) * 6
+    o, mb, bufs = setup(nx, ng, recon, "hllc", bc, seed=31)
+    ndim = 3 if nx[2] > 1 else (2 if nx[1] > 1 else 1)
+    if tiny:
+        rng = np.random.default_rng(8)
+        scale = rng.choice([1.0, 0.0, 1e-300, 1e-250, 1e-160], size=o.gprim[1].shape, p=[0.6, 0.1, 0.1, 0.1, 0.1])
+        for v in (1, 2, 3):
+            o.gprim[v] *= scale
+        o.ApplyBoundaryConditions()
+        o.PrimToCons()
+        mb.gas_prim[0].copy_(torch.from_numpy(o.gprim.copy()))
+    I = np.s_[:, o.ks:o.ke + 1, o.js:o.je + 1, o.is_:o.ie + 1]
+    inner = torch.zeros(mb.gas_prim[0].shape[1:], dtype=torch.bool, device="cuda")
+    inner[o.ks:o.ke + 1, o.js:o.je + 1, o.is_:o.ie + 1] = True
+
+    def poison(t):  # NaN in every ghost zone of a prim buffer
+        t[0][:, ~inner] = float("nan")
+
+    mask = (1 << (2 * ndim)) - 1
+    A, B, Cc = bufs
+    for step in range(2):
+        dt = o.new_dt()
+        o.dt = dt
+        o.step()
+        cur = A
+        for s_, (g0, g1, be) in enumerate(COEFF["rk2"]):
+            out = A if s_ == 1 else B
+            poison(cur[0])
+            if s_ == 1:  # (the last stage writes over the start-of-step buffer: its zones are read cell-wise only)
+                assert out is A
+            mb.stage_fused(g0, g1, be * dt, be * dt, cur[1], A[1], out[1], outflow_faces=mask)
+            cur = out
+        same(mb.gas_prim[0][I][[0, 1, 2, 3, 5]], o.gprim[I][[0, 1, 2, 3, 5]], f"step {step}")
+    # one face missing from the mask: its NaN ghosts are read (the floors of ConsToPrim turn the NaN into floor values)
+    poison(A[0])
+    mb.stage_fused(0.0, 1.0, 1e-4, 1e-4, A[1], A[1], B[1], outflow_faces=mask)
+    mb.stage_fused(0.0, 1.0, 1e-4, 1e-4, A[1], A[1], Cc[1], outflow_faces=mask & ~2)
+    assert not torch.equal(B[0][0][I][0], Cc[0][0][I][0])
