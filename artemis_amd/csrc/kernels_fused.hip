@@ -1362,18 +1362,19 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   const int NTI = (P.ie - P.is + FTX) / FTX, NTJ = (P.je - P.js + FTY) / FTY;
   // A launch without a boundary shell (no overlapped exchange: one rank, or links handled after the kernel) takes long
   // chunks -- up to 128 planes: at 256^3 two chunks per tile column, 512 workgroups, exactly one round of the chip's
-  // slots, and the priming trip once per 128 planes instead of once per 16 (0.941 -> 0.916 ms).  Shell-first and
-  // shell / bulk launches keep <= 16: the shell is one chunk thick.
+  // slots, and the priming trip once per 128 planes instead of once per 16 (0.941 -> 0.916 ms).  Launches with a shell
+  // keep <= 16 for the shell boxes (the x3 shell is one chunk thick) and give the bulk box long chunks of its own.
   const bool has_shell = a.shell_done != nullptr || a.region != 0;
   const int target_chunk = pick_chunk(nz, static_cast<long>(NTI) * NTJ * P.nb, 512, has_shell ? 16 : 128);
   k.nbox = 0;
   k.start[0] = 0;
+  int box_chunk = target_chunk; // (the bulk box of a launch with a shell takes long chunks of its own, below)
   auto add_box = [&](int ti0, int nti, int tj0, int ntj, int kb0, int kb1) {
     if (nti <= 0 || ntj <= 0 || kb1 < kb0) return;
     const int q = k.nbox++;
     k.ti0[q] = ti0, k.nti[q] = nti, k.tj0[q] = tj0, k.ntj[q] = ntj, k.kb0[q] = kb0, k.kb1[q] = kb1;
     const int planes = kb1 - kb0 + 1;
-    k.nchunk[q] = (P.ndim > 2) ? std::max(1, planes / target_chunk) : 1;
+    k.nchunk[q] = (P.ndim > 2) ? std::max(1, planes / box_chunk) : 1;
     k.kchunk[q] = (planes + k.nchunk[q] - 1) / k.nchunk[q];
     k.nchunk[q] = (planes + k.kchunk[q] - 1) / k.kchunk[q];
     k.start[q + 1] = k.start[q] + nti * ntj * k.nchunk[q] * P.nb;
@@ -1412,6 +1413,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
     if (split) {
       add_shell();
       k.nshell = k.start[k.nbox];
+      box_chunk = pick_chunk(km1 - km0 + 1, static_cast<long>(ntim) * ntjm * P.nb, 512, 128); // the bulk: long chunks
       add_box(tim0, ntim, tjm0, ntjm, km0, km1);
     } else {
       add_box(0, NTI, 0, NTJ, P.ks, P.ke);
@@ -1424,6 +1426,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   } else if (a.region == 1) {
     add_shell();
   } else if (split) {
+    box_chunk = pick_chunk(km1 - km0 + 1, static_cast<long>(ntim) * ntjm * P.nb, 512, 128); // the bulk: long chunks
     add_box(tim0, ntim, tjm0, ntjm, km0, km1);
   }
   if (k.nbox == 0) return 0; // nothing to do in this region

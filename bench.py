@@ -234,8 +234,9 @@ def main():
                     help="skip the `dropin` legs (fused + cons + whole-block PrimToCons, and the per-task chain)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: exchange halos after the whole stage kernel instead of behind its bulk")
-    ap.add_argument("--overlap-mode", type=int, default=2, choices=[1, 2],
-                    help="2: one launch, shell workgroups first + device counter; 1: shell and bulk launches")
+    ap.add_argument("--overlap-mode", type=int, default=1, choices=[1, 2],
+                    help="1 (default): shell launch, then bulk launch, the exchange behind an event between them; "
+                         "2: one launch, shell workgroups first + a device counter a one-wave kernel polls")
     ap.add_argument("--blocks-per-gpu", type=int, default=1,
                     help="diagnostic: cut each rank's 256^3 into this many mesh blocks along x3")
     ap.add_argument("--loopback", action="store_true",
