@@ -757,6 +757,22 @@ int artemis_hip_zero_viscous_flux(const artemis_pack_t *p, const artemis_diffusi
     return fail(ARTEMIS_HIP_EDEVICE, "viscous flux: scratch allocation failed");
   return after_launch("ZeroDiffusionFlux + ViscousFlux");
 }
+int artemis_hip_viscous_source_covers(const artemis_pack_t *p) {
+  if (!p || p->nblocks <= 0 || p->nx1 <= 0) return 0;
+  return artemis::viscous_source_covers(artemis::make_pack_view(*p)) ? 1 : 0;
+}
+int artemis_hip_viscous_source(const artemis_pack_t *p, const artemis_diffusion_t *d, double dt, const double *dt_dev,
+                               double *const *sums, void *stream) {
+  if (int rc = validate_diffusion(p, d, false)) return rc;
+  if (!sums) return fail(ARTEMIS_HIP_EINVAL, "viscous source: null output table");
+  if (!p->gas.prim) return fail(ARTEMIS_HIP_EINVAL, "viscous source: gas.prim table is required");
+  if (d->visc.type == ARTEMIS_DIFF_OFF) return fail(ARTEMIS_HIP_EINVAL, "viscous source: viscosity is off");
+  const artemis::PackView P = artemis::make_pack_view(*p);
+  if (!artemis::viscous_source_covers(P))
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "viscous source: 3-D blocks of one gas species, at least 8 x 8 zones wide (use the flux tasks)");
+  artemis::launch_viscous_source(P, *d, dt, dt_dev, sums, S(stream));
+  return after_launch("viscous source");
+}
 int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream) {
   if (int rc = validate_diffusion(p, d, true)) return rc;
   if (d->cond.type == ARTEMIS_DIFF_OFF) return 0; // gas.cpp:582-583
@@ -802,7 +818,9 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
   if (a->rf_omega != 0.0 && p->coords != ARTEMIS_CARTESIAN && a->rf_qshear != 0.0) // rotating_frame.cpp:34-38
     return fail(ARTEMIS_HIP_EINVAL, "rotating_frame/qshear must be zero for non-Cartesian coordinate systems!");
   if (a->diffusion) {
-    if (int rc = validate_diffusion(p, a->diffusion, true)) return rc;
+    if (int rc = validate_diffusion(p, a->diffusion, a->diffusion_sums == nullptr)) return rc;
+    if (a->diffusion_sums && p->gas.nspecies != 1)
+      return fail(ARTEMIS_HIP_EINVAL, "general stage: diffusion_sums are for one gas species");
   }
   if (a->cooling) {
     if (a->drag) return fail(ARTEMIS_HIP_EUNSUPPORTED, "general stage: cooling together with drag runs on the per-task kernels");

@@ -35,7 +35,8 @@ struct DiffCell { // geometry of one cell as the update uses it
   int x1dep, x2dep, multi_d, three_d;
 };
 // the same record from a cell's Coords (curvilinear callers that already hold them)
-__device__ __forceinline__ DiffCell diffusion_cell_of(const DCoords &co, const CellMetric &m, const double hx[3], int ndim) {
+template <class CO>
+__device__ __forceinline__ DiffCell diffusion_cell_of(const CO &co, const CellMetric &m, const double hx[3], int ndim) {
   DiffCell d;
   d.multi_d = (ndim > 1), d.three_d = (ndim > 2);
   d.ax1[0] = m.ax1[0], d.ax1[1] = m.ax1[1];

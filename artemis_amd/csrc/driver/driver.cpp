@@ -255,6 +255,7 @@ struct artemis_sim_impl {
   bool do_viscosity = false, do_conduction = false;
   artemis_diffusion_t diff;
   Field gdflux[3];
+  Field gdsum;        // artemis_hip_viscous_source's five sums per zone (the one-kernel stages on uniform meshes)
   Field visc_radial;  // per-cell radial factor of the viscosity law (host libm), diff.visc.radial
   DevBuf diff_dist;   // Coords::Distance table of the diffusion flux tasks (static geometry), diff.dist
   Field ic_gas, ic_dust; // disk `ic` condition: the initial primitives as generated (disk.hpp:597-632)
@@ -2357,7 +2358,15 @@ void artemis_sim_impl::step_general(bool want_dt, bool device_dt) {
     if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
     if (!dprim[q].ok()) dprim[q].alloc(nb, 4 * ns_dust, N);
   }
-  if (do_gas && (do_viscosity || do_conduction))
+  // Viscosity without heat conduction: ZeroDiffusionFlux + ViscousFlux + the viscous part of DiffusionUpdate as one
+  // source (artemis_hip_viscous_source: five sums per zone, no diffusion-flux arrays) where the march covers the pack
+  bool visc_source = false;
+  if (do_gas && do_viscosity && !do_conduction && !getenv("ARTEMIS_NO_VISC_SOURCE")) {
+    const artemis_pack_t p0 = make_pack(base);
+    visc_source = artemis_hip_viscous_source_covers(&p0) != 0;
+  }
+  if (visc_source && !gdsum.ok()) gdsum.alloc(nb, 5, N);
+  if (do_gas && (do_viscosity || do_conduction) && !visc_source)
     for (int d = 0; d < ndim; ++d)
       if (!gdflux[d].ok()) gdflux[d].alloc(nb, 4 * ns_gas, N);
   const int A = base;
@@ -2390,9 +2399,14 @@ void artemis_sim_impl::step_general(bool want_dt, bool device_dt) {
     if (device_dt) a.beta_dt_dev = tstate.p + 3 + (stage - 1); // beta*dt stays on the device
     const bool diffuse = do_gas && (do_viscosity || do_conduction);
     if (diffuse) { // artemis_driver.cpp:189-194 on the stage's input primitives
-      if (do_viscosity) CK(artemis_hip_zero_viscous_flux(&p, &diff, stream), "Gas::ZeroDiffusionFlux + ViscousFlux");
-      else CK(artemis_hip_zero_diffusion_flux(&p, stream), "Gas::ZeroDiffusionFlux");
-      if (do_conduction) CK(artemis_hip_thermal_flux(&p, &diff, stream), "Gas::ThermalFlux");
+      if (visc_source) {
+        CK(artemis_hip_viscous_source(&p, &diff, a.bdt, a.beta_dt_dev, gdsum.tab(), stream), "viscous source");
+        a.diffusion_sums = gdsum.tab();
+      } else {
+        if (do_viscosity) CK(artemis_hip_zero_viscous_flux(&p, &diff, stream), "Gas::ZeroDiffusionFlux + ViscousFlux");
+        else CK(artemis_hip_zero_diffusion_flux(&p, stream), "Gas::ZeroDiffusionFlux");
+        if (do_conduction) CK(artemis_hip_thermal_flux(&p, &diff, stream), "Gas::ThermalFlux");
+      }
       a.diffusion = &diff;
     }
     if (do_cooling && do_gas) a.cooling = &cool;

@@ -137,4 +137,60 @@ __device__ __forceinline__ PlmGeo plm_geo_tab(const PackView &P, int b, int dir,
   g.rdx = recip(g.dx);
   return g;
 }
+
+// ---- per-workgroup geometry tables (the march kernels: kernels_curv.hip, kernels_diffusion.hip) --------------------
+// A march along x3 visits the same (i, j) columns plane after plane, and in every system the reference supports the
+// metric depends on (x1, x2) only.  Keeping a column's Coords-derived constants in registers costs ~100 doubles per
+// thread (one wave per SIMD); recomputing them per plane costs a dozen IEEE divisions per zone.  These tables hold
+// what is expensive -- per column index the x1 edges and every x1-only expression with a division in it, per row
+// index the x2 edges, the tabulated trigonometry and the x2-only quotients -- once per workgroup in LDS; a thread
+// rebuilds the Coords of any zone of its tile (own, halo, perimeter) from one column and one row entry and lets
+// DCoordsT<true> do the remaining multiplications.  Filled with the CACHED = false functions: the same bits.
+enum { GI_X1LO = 0, GI_X1HI, GI_X1V, GI_RCEN, GI_RFAC, GI_DH2, GI_DH3, GI_NF };
+enum { GJ_X2LO = 0, GJ_X2HI, GJ_CF0, GJ_CF1, GJ_SF0, GJ_SF1, GJ_X2C, GJ_SV, GJ_SC, GJ_CV, GJ_DH32, GJ_RDC, GJ_NF };
+template <int NX, int NY>
+struct GeoTabs {
+  double gi[GI_NF][NX]; // column x <-> zone index clamp(ibase + x, 0, ni - 1)
+  double gj[GJ_NF][NY]; // row y    <-> zone index clamp(jbase + y, 0, nj - 1)
+};
+// Threads [0, NX) fill the columns, threads [64, 64 + NY) the rows (NY <= 64: a second wave); the caller
+// synchronises the workgroup before the first read.
+template <int NX, int NY>
+__device__ __forceinline__ void geotabs_fill(GeoTabs<NX, NY> &G, const PackView &P, int b, int ibase, int jbase, int t) {
+  static_assert(NX <= 64 && NY <= 64, "one wave per table");
+  if (t < NX) {
+    const int ii = min(max(ibase + t, 0), P.ni - 1);
+    const DCoords c = make_coords(P, b, 0, 0, ii); // (x1-only members: the x2 / x3 indices do not enter)
+    G.gi[GI_X1LO][t] = c.x1[0], G.gi[GI_X1HI][t] = c.x1[1];
+    G.gi[GI_X1V][t] = c.x1v(), G.gi[GI_RCEN][t] = c.rcen(), G.gi[GI_RFAC][t] = c.rfac();
+    G.gi[GI_DH2][t] = c.dh2dx1(), G.gi[GI_DH3][t] = c.dh3dx1();
+  } else if (t >= 64 && t < 64 + NY) {
+    const int y = t - 64;
+    const int jj = min(max(jbase + y, 0), P.nj - 1);
+    const DCoords c = make_coords(P, b, 0, jj, 0);
+    G.gj[GJ_X2LO][y] = c.x2[0], G.gj[GJ_X2HI][y] = c.x2[1];
+    G.gj[GJ_CF0][y] = c.cf[0], G.gj[GJ_CF1][y] = c.cf[1], G.gj[GJ_SF0][y] = c.sf[0], G.gj[GJ_SF1][y] = c.sf[1];
+    G.gj[GJ_X2C][y] = c.x2c, G.gj[GJ_SV][y] = c.sv, G.gj[GJ_SC][y] = c.sc, G.gj[GJ_CV][y] = c.cv;
+    G.gj[GJ_DH32][y] = c.dh3dx2();
+    G.gj[GJ_RDC][y] = c.sph23() ? recip(fabs(c.cf[0] - c.cf[1])).y : 0.0;
+  }
+}
+// Coords of the zone at (column x, row y) of the tables on plane k (x3 edges from the block's edge table; c3 / s3 =
+// cos / sin of the plane's x3 centre where the system has them, else 1 / 0)
+template <int NX, int NY>
+__device__ __forceinline__ DCoordsT<true> geotabs_coords(const GeoTabs<NX, NY> &G, int sys, const double *g, int x, int y,
+                                                         int k, double c3, double s3) {
+  DCoordsT<true> c;
+  c.sys = sys;
+  c.x1[0] = G.gi[GI_X1LO][x], c.x1[1] = G.gi[GI_X1HI][x];
+  c.k_x1v = G.gi[GI_X1V][x], c.k_rcen = G.gi[GI_RCEN][x], c.k_rfac = G.gi[GI_RFAC][x];
+  c.k_dh2dx1 = G.gi[GI_DH2][x], c.k_dh3dx1 = G.gi[GI_DH3][x];
+  c.x2[0] = G.gj[GJ_X2LO][y], c.x2[1] = G.gj[GJ_X2HI][y];
+  c.cf[0] = G.gj[GJ_CF0][y], c.cf[1] = G.gj[GJ_CF1][y], c.sf[0] = G.gj[GJ_SF0][y], c.sf[1] = G.gj[GJ_SF1][y];
+  c.x2c = G.gj[GJ_X2C][y], c.sv = G.gj[GJ_SV][y], c.sc = G.gj[GJ_SC][y], c.cv = G.gj[GJ_CV][y];
+  c.k_dh3dx2 = G.gj[GJ_DH32][y], c.k_rdc = G.gj[GJ_RDC][y];
+  c.x3[0] = g[4] + k * g[5], c.x3[1] = g[4] + (k + 1) * g[5];
+  c.c3 = c3, c.s3 = s3;
+  return c;
+}
 } // namespace artemis

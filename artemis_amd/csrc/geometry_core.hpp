@@ -35,13 +35,23 @@ GDEV long metric_block_stride(int nj, int nk) {
   return static_cast<long>(MT_ROWS) * (nj + 1) + static_cast<long>(MT3_ROWS) * (nk + 1);
 }
 
-struct DCoords {
+// CACHED = true (device kernels that rebuild a cell's Coords every plane of a march from small LDS tables instead
+// of keeping ~100 doubles of geometry per thread in registers, kernels_curv.hip / kernels_diffusion.hip): the few
+// member functions that contain a DIVISION -- x1v, rcen, rsq3 / 3, the connection coefficients, and the quotient
+// inside hx3v -- return values that were computed once per workgroup by the CACHED = false functions of the same
+// struct (the same expression trees, hence the same bits) and travel in the k_* fields; everything else is the
+// multiplications and additions below, evaluated where they are needed.  k_rdc is the refined reciprocal of
+// |cos(x2f0) - cos(x2f1)| (device_math.hpp `recip`: `div` through it returns the bits of `/` for these
+// order-one operands, as everywhere in the march kernels).
+template <bool CACHED>
+struct DCoordsT {
   int sys;
   double x1[2], x2[2], x3[2];
   double cf[2], sf[2]; // cos / sin of the two x2 faces         (spherical2D/3D only)
   double x2c, sv, sc;  // x2 centroid, sin(centroid), sin(0.5*(x2[0]+x2[1]))
   double cv;           // cos(centroid) (basis vectors of ConvertVecToCyl, spherical.hpp:198-205)
   double c3, s3;       // cos / sin of the x3 cell centre (spherical3D, axisymmetric)
+  double k_x1v, k_rcen, k_rfac, k_dh2dx1, k_dh3dx1, k_dh3dx2, k_rdc; // CACHED only (see above)
 
   GDEV bool sph23() const { return sys == ARTEMIS_SPHERICAL2D || sys == ARTEMIS_SPHERICAL3D; }
   GDEV bool sph() const { return sys == ARTEMIS_SPHERICAL1D || sph23(); }
@@ -53,6 +63,7 @@ struct DCoords {
   GDEV double rsq3() const { return x1[0] * x1[0] + x1[0] * x1[1] + x1[1] * x1[1]; }
 
   GDEV double x1v() const {
+    if constexpr (CACHED) return k_x1v;
     if (sph()) { // spherical.hpp:57-60
       const double dr2 = x1[0] * x1[0] + x1[1] * x1[1];
       return 0.75 * (x1[0] + x1[1]) * dr2 / (dr2 + x1[0] * x1[1]);
@@ -63,7 +74,14 @@ struct DCoords {
   }
   GDEV double x2v() const { return sph23() ? x2c : 0.5 * (x2[0] + x2[1]); }
   GDEV double x3v() const { return 0.5 * (x3[0] + x3[1]); }
-  GDEV double rcen() const { return 2.0 / 3.0 * rsq3() / (x1[0] + x1[1]); }
+  GDEV double rcen() const {
+    if constexpr (CACHED) return k_rcen;
+    return 2.0 / 3.0 * rsq3() / (x1[0] + x1[1]);
+  }
+  GDEV double rfac() const { // the radial factor of the spherical volume (spherical.hpp:126)
+    if constexpr (CACHED) return k_rfac;
+    return rsq3() / 3.0;
+  }
 
   // volume-averaged scale factors (GetScaleFactors, geometry.hpp:384-388)
   GDEV double hx2v() const { // spherical.hpp:70, cylindrical.hpp:51; spherical1D keeps 1
@@ -73,6 +91,13 @@ struct DCoords {
     if (sph23()) { // spherical.hpp:71-82
       const double dsc = sf[1] * cf[1] - sf[0] * cf[0];
       const double dx2 = x2[1] - x2[0];
+#ifdef __HIPCC__
+      if constexpr (CACHED) {
+        const double num = x1v() * 0.5 * (dx2 - dsc), den = fabs(cf[0] - cf[1]);
+        const double q = num * k_rdc; // device_math.hpp div(): the refined-reciprocal form of num / den
+        return __builtin_fma(__builtin_fma(-den, q, num), k_rdc, q);
+      }
+#endif
       return x1v() * 0.5 * (dx2 - dsc) / fabs(cf[0] - cf[1]);
     }
     if (sys == ARTEMIS_AXISYMMETRIC) return x1v(); // axisymmetric.hpp:46
@@ -127,7 +152,7 @@ struct DCoords {
   GDEV double volume() const {
     const double dx1 = x1[1] - x1[0], dx2 = x2[1] - x2[0], dx3 = x3[1] - x3[0];
     if (sph()) { // spherical.hpp:124-133
-      const double rfac = rsq3() / 3.0;
+      const double rfac = this->rfac();
       if (sys == ARTEMIS_SPHERICAL1D) return rfac * dx1;
       const double dc = fabs(cf[0] - cf[1]);
       if (sys == ARTEMIS_SPHERICAL2D) return rfac * dx1 * dc;
@@ -139,16 +164,19 @@ struct DCoords {
   }
   // connection coefficients (GetConnX1/X2, geometry.hpp:407-418)
   GDEV double dh2dx1() const {
+    if constexpr (CACHED) return k_dh2dx1;
     if (sph()) return 3.0 / 2.0 * (x1[0] + x1[1]) / rsq3(); // spherical.hpp:135-138
     if (sys == ARTEMIS_CYLINDRICAL) return 1.0 / (0.5 * (x1[0] + x1[1])); // cylindrical.hpp:80
     return 0.0;
   }
   GDEV double dh3dx1() const {
+    if constexpr (CACHED) return k_dh3dx1;
     if (sph()) return 3.0 / 2.0 * (x1[0] + x1[1]) / rsq3(); // spherical.hpp:139-142
     if (sys == ARTEMIS_AXISYMMETRIC) return 1.0 / (0.5 * (x1[0] + x1[1])); // axisymmetric.hpp:71
     return 0.0;
   }
   GDEV double dh3dx2() const { // spherical.hpp:143-146
+    if constexpr (CACHED) return k_dh3dx2;
     return sph23() ? (sf[1] - sf[0]) / fabs(cf[0] - cf[1]) : 0.0;
   }
   // frames of the cell centre with the tabulated trigonometry
@@ -210,6 +238,7 @@ struct DCoords {
     }
   }
 };
+using DCoords = DCoordsT<false>;
 
 // ConvertToCylWithVec / ConvertToCartWithVec (geometry.hpp:438-482): the converted point x and the
 // rows e1, e2, e3 = components of the problem's unit vectors in the target basis.  (ct, st) =

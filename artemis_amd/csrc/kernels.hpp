@@ -50,6 +50,9 @@ void launch_zero_diffusion_flux(const PackView &P, hipStream_t s);
 size_t viscous_distance_count(const PackView &P);
 void launch_viscous_distance_fill(const PackView &P, double *tab, hipStream_t s);
 int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s, bool overwrite = false);
+bool viscous_source_covers(const PackView &P);
+void launch_viscous_source(const PackView &P, const artemis_diffusion_t &D, double dt, const double *dt_dev, double *const *out,
+                           hipStream_t s);
 void launch_thermal_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s);
 void launch_diffusion_update(const PackView &P, const artemis_diffusion_t &D, double dt, hipStream_t s);
 void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double cfl, double *dt_dev,

@@ -19,6 +19,9 @@
 #include "pack_view.hpp"
 #include "task_device.hpp"
 #include "diffusion_device.hpp"
+#include "sources_device.hpp"
+#include "fused_device.hpp"
+#include <type_traits>
 
 namespace artemis {
 namespace {
@@ -122,6 +125,7 @@ struct Geo {
     }
   }
   ADEV void hx(int k, int j, int i, double h[3]) const { scale_factors<CURV>(P, b, k, j, i, h); }
+  ADEV DCoords coords(int k, int j, int i) const { return make_coords(P, b, k, j, i); }
   // {dh2dx1, dh3dx1, dh3dx2}: the only non-zero connection coefficients (geometry.hpp:236-246)
   ADEV void conn(int k, int j, int i, double &d21, double &d31, double &d32) const {
     d21 = d31 = d32 = 0.0;
@@ -245,6 +249,99 @@ ADEV void strain_rows(const StrainIn &in, double dxa, const double dxt[2], const
   const Q qm(in.mu1 + in.mu2); // face_average (diffusion_coeff.hpp:139-150)
   mus = (avg == 0) * (0.5 * (in.mu1 + in.mu2)) + (avg == 1) * qm(2.0 * in.mu1 * in.mu2);
 }
+// Geometry of one face as the stress rows use it (shared by the species): scale factors at the face centroid, the
+// connection coefficients of the two cells that share the face, the Coords::Distance values, (h_t / h_d)^2.
+struct FaceGeo {
+  double hxf[3];
+  double dh0, dh1, dh0_m, dh1_m;
+  double dxa, dxt[2], dxtm[2];
+  double ratio[2];
+  double mfac[2];
+};
+template <int DIR, bool CURV, class GEO>
+ADEV FaceGeo face_geometry(const PackView &P, const GEO &ge, const int b, const int k, const int j, const int i) {
+  const int multid = (P.ndim >= 2), threed = (P.ndim == 3);
+  constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1);
+  constexpr int d = DIR - 1, t0 = (DIR == 1) ? 1 : 0, t1 = (DIR == 3) ? 1 : 2;
+  const double fuzz = 1e-99; // Fuzz<Real>()
+  FaceGeo f;
+  f.hxf[0] = f.hxf[1] = f.hxf[2] = 1.0;
+  if constexpr (CURV) ge.coords(k, j, i).face_scale(DIR, f.hxf); // h_d at the face centroid
+  // dh_a/dx_k of the two cells sharing the face, a = DIR - 1; only dh2dx1, dh3dx1, dh3dx2 can be non-zero
+  f.dh0 = f.dh1 = f.dh0_m = f.dh1_m = 0.0;
+  if constexpr (CURV && DIR != 1) {
+    double d21, d31, d32;
+    ge.conn(k, j, i, d21, d31, d32);
+    f.dh0 = (DIR == 2) ? d21 : d31, f.dh1 = (DIR == 3) ? d32 : 0.0;
+    ge.conn(k - dk, j - dj, i - di, d21, d31, d32);
+    f.dh0_m = (DIR == 2) ? d21 : d31, f.dh1_m = (DIR == 3) ? d32 : 0.0;
+  }
+  // Coords::Distance between cell centres: geometry only, shared by the species.  dxt / dxtm: across the face's
+  // own cell and across its lower neighbour, along the two transverse directions
+  f.dxa = ge.template dist_lower<DIR>(k, j, i);
+  if constexpr (DIR == 1) {
+    f.dxt[0] = multid ? ge.template dist_across<2>(k, j, i) : fuzz;
+    f.dxtm[0] = multid ? ge.template dist_across<2>(k, j, i - 1) : fuzz;
+    f.dxt[1] = threed ? ge.template dist_across<3>(k, j, i) : fuzz;
+    f.dxtm[1] = threed ? ge.template dist_across<3>(k, j, i - 1) : fuzz;
+    f.mfac[0] = multid * 0.5, f.mfac[1] = threed * 0.5;
+  } else if constexpr (DIR == 2) {
+    f.dxt[0] = ge.template dist_across<1>(k, j, i);
+    f.dxtm[0] = ge.template dist_across<1>(k, j - 1, i);
+    f.dxt[1] = threed ? ge.template dist_across<3>(k, j, i) : fuzz;
+    f.dxtm[1] = threed ? ge.template dist_across<3>(k, j - 1, i) : fuzz;
+    f.mfac[0] = 0.5, f.mfac[1] = threed * 0.5;
+  } else {
+    f.dxt[0] = ge.template dist_across<1>(k, j, i);
+    f.dxtm[0] = ge.template dist_across<1>(k - 1, j, i);
+    f.dxt[1] = ge.template dist_across<2>(k, j, i);
+    f.dxtm[1] = ge.template dist_across<2>(k - 1, j, i);
+    f.mfac[0] = 0.5, f.mfac[1] = 0.5;
+  }
+  // (h_t / h_d)^2 at the face centroid: geometry of order one, always the reciprocal form
+  f.ratio[0] = f.ratio[1] = 1.0;
+  if constexpr (CURV) {
+    const QuotF qh(f.hxf[d]);
+    f.ratio[0] = sqr(qh(f.hxf[t0])), f.ratio[1] = sqr(qh(f.hxf[t1]));
+  }
+  return f;
+}
+// What one species contributes at the face: contravariant velocities of the two cells sharing it (s_c: the cell
+// whose lower face it is, s_m: its lower neighbour), the differences of the NORMAL contravariant velocity across
+// each of the two cells along the two transverse directions, their dynamic viscosities and velocity divergences.
+struct FaceIn {
+  double s_c[3], s_m[3];
+  double n_t[2], n_tm[2];
+  double mu1, mu2, divu, divu_m;
+};
+// The stress rows of the face: fl[0..2] = momentum fluxes, fe = energy flux (momentum_diffusion.hpp:379-560).
+// `valid`: lanes that do not stand for a face (ragged tiles of the marching kernel) must not steer the wave.
+template <int DIR>
+ADEV void viscous_face_core(const FaceGeo &g, const FaceIn &q, const int avg, const double eta, double fl[3], double &fe,
+                            const bool valid = true) {
+  constexpr int d = DIR - 1, t0 = (DIR == 1) ? 1 : 0, t1 = (DIR == 3) ? 1 : 2;
+  // v^k dh_a/dx_k / h_a of a cell (the third connection row is zero for every system)
+  const double src = q.s_c[0] * g.dh0 + q.s_c[1] * g.dh1 + q.s_c[2] * 0.0;
+  const double src_m = q.s_m[0] * g.dh0_m + q.s_m[1] * g.dh1_m + q.s_m[2] * 0.0;
+  StrainIn in;
+  in.n_a[d] = 2 * (q.s_c[d] - q.s_m[d]);
+  in.n_a[t0] = g.ratio[0] * (q.s_c[t0] - q.s_m[t0]);
+  in.n_a[t1] = g.ratio[1] * (q.s_c[t1] - q.s_m[t1]);
+  for (int t = 0; t < 2; ++t) in.n_t[t] = q.n_t[t], in.n_tm[t] = q.n_tm[t];
+  in.half_src = 0.5 * (src + src_m);
+  in.mfac[0] = g.mfac[0], in.mfac[1] = g.mfac[1];
+  in.mu1 = q.mu1, in.mu2 = q.mu2;
+  double flx[3], mus;
+  const bool odd = valid && (tiny_nonzero(in.n_a[0]) || tiny_nonzero(in.n_a[1]) || tiny_nonzero(in.n_a[2]) || tiny_nonzero(in.n_t[0]) ||
+                             tiny_nonzero(in.n_tm[0]) || tiny_nonzero(in.n_t[1]) || tiny_nonzero(in.n_tm[1]) ||
+                             tiny_nonzero(in.mu1 * in.mu2) || !(in.mu1 + in.mu2 > 0x1p-200));
+  if (__any(odd)) strain_rows<DIR, QuotI>(in, g.dxa, g.dxt, g.dxtm, avg, flx, mus);
+  else strain_rows<DIR, QuotF>(in, g.dxa, g.dxt, g.dxtm, avg, flx, mus);
+  const double hf = g.hxf[DIR - 1];
+  for (int qq = 0; qq < 3; ++qq) fl[qq] = hf * mus * flx[qq];
+  fl[DIR - 1] = hf * mus * (flx[DIR - 1] - 1. / 3 * (1. - eta) * (q.divu + q.divu_m));
+  fe = 0.5 * (q.s_c[0] + q.s_m[0]) * fl[0] + 0.5 * (q.s_c[1] + q.s_m[1]) * fl[1] + 0.5 * (q.s_c[2] + q.s_m[2]) * fl[2];
+}
 template <int DIR, bool CURV, bool OVERWRITE>
 ADEV void viscous_face(const PackView &P, const artemis_diffusion_t &D, const ViscScratch &w, const int b, const int k,
                        const int j, const int i, const long c) {
@@ -256,86 +353,29 @@ ADEV void viscous_face(const PackView &P, const artemis_diffusion_t &D, const Vi
   ge.dtab = D.dist;
   if constexpr (CURV) ge.xc0 = w.xc[0] + b * N, ge.xc1 = w.xc[1] + b * N, ge.xc2 = w.xc[2] + b * N;
   const artemis_diffcoeff_t &dp = D.visc;
-  constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1);
-  constexpr int d = DIR - 1, t0 = (DIR == 1) ? 1 : 0, t1 = (DIR == 3) ? 1 : 2;
+  constexpr int d = DIR - 1;
   const long sd = (DIR == 1) ? 1 : ((DIR == 2) ? P.sj : P.sk);
   const long cm = c - sd;
-  const double fuzz = 1e-99; // Fuzz<Real>()
-  double hxf[3] = {1.0, 1.0, 1.0};
-  if constexpr (CURV) make_coords(P, b, k, j, i).face_scale(DIR, hxf); // h_d at the face centroid
-  // dh_a/dx_k of the two cells sharing the face, a = DIR - 1; only dh2dx1, dh3dx1, dh3dx2 can be non-zero
-  double dh0 = 0.0, dh1 = 0.0, dh0_m = 0.0, dh1_m = 0.0;
-  if constexpr (CURV && DIR != 1) {
-    double d21, d31, d32;
-    ge.conn(k, j, i, d21, d31, d32);
-    dh0 = (DIR == 2) ? d21 : d31, dh1 = (DIR == 3) ? d32 : 0.0;
-    ge.conn(k - dk, j - dj, i - di, d21, d31, d32);
-    dh0_m = (DIR == 2) ? d21 : d31, dh1_m = (DIR == 3) ? d32 : 0.0;
-  }
-  // Coords::Distance between cell centres: geometry only, shared by the species.  dxt / dxtm: across the face's
-  // own cell and across its lower neighbour, along the two transverse directions
-  const double dxa = ge.template dist_lower<DIR>(k, j, i);
-  double dxt[2], dxtm[2];
+  const FaceGeo fg = face_geometry<DIR, CURV>(P, ge, b, k, j, i);
   long st[2]; // strides of the transverse directions (0 where the direction is not active)
-  if constexpr (DIR == 1) {
-    dxt[0] = multid ? ge.template dist_across<2>(k, j, i) : fuzz;
-    dxtm[0] = multid ? ge.template dist_across<2>(k, j, i - 1) : fuzz;
-    dxt[1] = threed ? ge.template dist_across<3>(k, j, i) : fuzz;
-    dxtm[1] = threed ? ge.template dist_across<3>(k, j, i - 1) : fuzz;
-    st[0] = multid * P.sj, st[1] = threed * P.sk;
-  } else if constexpr (DIR == 2) {
-    dxt[0] = ge.template dist_across<1>(k, j, i);
-    dxtm[0] = ge.template dist_across<1>(k, j - 1, i);
-    dxt[1] = threed ? ge.template dist_across<3>(k, j, i) : fuzz;
-    dxtm[1] = threed ? ge.template dist_across<3>(k, j - 1, i) : fuzz;
-    st[0] = 1, st[1] = threed * P.sk;
-  } else {
-    dxt[0] = ge.template dist_across<1>(k, j, i);
-    dxtm[0] = ge.template dist_across<1>(k - 1, j, i);
-    dxt[1] = ge.template dist_across<2>(k, j, i);
-    dxtm[1] = ge.template dist_across<2>(k - 1, j, i);
-    st[0] = 1, st[1] = P.sj;
-  }
-  // (h_t / h_d)^2 at the face centroid: geometry of order one, always the reciprocal form
-  double ratio[2] = {1.0, 1.0};
-  if constexpr (CURV) {
-    const QuotF qh(hxf[d]);
-    ratio[0] = sqr(qh(hxf[t0])), ratio[1] = sqr(qh(hxf[t1]));
-  }
+  if constexpr (DIR == 1) st[0] = multid * P.sj, st[1] = threed * P.sk;
+  else if constexpr (DIR == 2) st[0] = 1, st[1] = threed * P.sk;
+  else st[0] = 1, st[1] = P.sj;
   for (int n = 0; n < ns; ++n) {
     const long base = (static_cast<long>(b) * ns + n) * N;
     const double *sv[3] = {w.sv[0] + base, w.sv[1] + base, w.sv[2] + base};
     const double *sn = sv[d];
-    const double s_c[3] = {sv[0][c], sv[1][c], sv[2][c]}, s_m[3] = {sv[0][cm], sv[1][cm], sv[2][cm]};
-    // v^k dh_a/dx_k / h_a of a cell (the third connection row is zero for every system)
-    const double src = s_c[0] * dh0 + s_c[1] * dh1 + s_c[2] * 0.0;
-    const double src_m = s_m[0] * dh0_m + s_m[1] * dh1_m + s_m[2] * 0.0;
-    StrainIn in;
-    in.n_a[d] = 2 * (s_c[d] - s_m[d]);
-    in.n_a[t0] = ratio[0] * (s_c[t0] - s_m[t0]);
-    in.n_a[t1] = ratio[1] * (s_c[t1] - s_m[t1]);
+    FaceIn q;
+    for (int m = 0; m < 3; ++m) q.s_c[m] = sv[m][c], q.s_m[m] = sv[m][cm];
     for (int t = 0; t < 2; ++t) {
-      in.n_t[t] = sn[c + st[t]] - sn[c - st[t]];
-      in.n_tm[t] = sn[cm + st[t]] - sn[cm - st[t]];
+      q.n_t[t] = sn[c + st[t]] - sn[c - st[t]];
+      q.n_tm[t] = sn[cm + st[t]] - sn[cm - st[t]];
     }
-    in.half_src = 0.5 * (src + src_m);
-    if constexpr (DIR == 1) in.mfac[0] = multid * 0.5, in.mfac[1] = threed * 0.5;
-    else if constexpr (DIR == 2) in.mfac[0] = 0.5, in.mfac[1] = threed * 0.5;
-    else in.mfac[0] = 0.5, in.mfac[1] = 0.5;
-    in.mu1 = w.mu[base + c], in.mu2 = w.mu[base + cm];
-    double flx[3], mus;
-    const bool odd = tiny_nonzero(in.n_a[0]) || tiny_nonzero(in.n_a[1]) || tiny_nonzero(in.n_a[2]) || tiny_nonzero(in.n_t[0]) ||
-                     tiny_nonzero(in.n_tm[0]) || tiny_nonzero(in.n_t[1]) || tiny_nonzero(in.n_tm[1]) ||
-                     tiny_nonzero(in.mu1 * in.mu2) || !(in.mu1 + in.mu2 > 0x1p-200);
-    if (__any(odd)) strain_rows<DIR, QuotI>(in, dxa, dxt, dxtm, dp.avg, flx, mus);
-    else strain_rows<DIR, QuotF>(in, dxa, dxt, dxtm, dp.avg, flx, mus);
-    const double divu = w.divu[base + c], divu_m = w.divu[base + cm];
-    const double hf = hxf[DIR - 1];
-    double fl[3];
-    for (int qq = 0; qq < 3; ++qq) fl[qq] = hf * mus * flx[qq];
-    fl[DIR - 1] = hf * mus * (flx[DIR - 1] - 1. / 3 * (1. - dp.eta) * (divu + divu_m));
+    q.mu1 = w.mu[base + c], q.mu2 = w.mu[base + cm];
+    q.divu = w.divu[base + c], q.divu_m = w.divu[base + cm];
+    double fl[3], fe;
+    viscous_face_core<DIR>(fg, q, dp.avg, dp.eta, fl, fe);
     double *const *qf = f.dflux[DIR - 1];
-    const double fe = 0.5 * (s_c[0] + s_m[0]) * fl[0] + 0.5 * (s_c[1] + s_m[1]) * fl[1] + 0.5 * (s_c[2] + s_m[2]) * fl[2];
     if constexpr (OVERWRITE) {
       for (int qq = 0; qq < 3; ++qq) qf[b * nq + 3 * n + qq][c] = 0.0 + fl[qq];
       qf[b * nq + 3 * ns + n][c] = 0.0 + fe;
@@ -367,6 +407,277 @@ __global__ __launch_bounds__(TX *TY, 4) void viscous_flux3_kernel(const PackView
 }
 
 
+
+// ---- viscous source: ZeroDiffusionFlux + ViscousFlux + the viscous part of DiffusionUpdate as ONE tile march ---------
+// The three tasks above move a lot of memory for what they compute: viscous_cell_kernel writes five doubles per zone,
+// viscous_flux3_kernel reads them back through ~50 cached loads per thread and stores twelve face fluxes per zone, and
+// the stage kernel reads 24 of those per zone to form the five numbers DiffusionUpdate subtracts from the zone's momenta
+// and energies (diffusion.hpp:110-241) -- on the spherical disk deck two thirds of the stage's HBM traffic.  This kernel
+// produces those five numbers directly: a 256-thread workgroup owns a VTX x VTY column of zones and marches along x3,
+//   * the primitive velocities of the arriving plane staged once in LDS (halo 2),
+//   * the contravariant velocities v^d = v_d / h_d of three planes in an LDS ring (halo 1, corners included: the
+//     cross derivatives of momentum_diffusion.hpp:95-141 read them),
+//   * VelocityDivergence and the dynamic viscosity of the tile and of the ring of its face neighbours for the plane
+//     the faces are formed on (the own column's values of the planes below and above live in registers),
+//   * every face inside the tile computed once (the lower x1 / x2 faces of each zone go to the neighbour through LDS,
+//     the x3 face is carried along the march), the faces on the tile's upper perimeter by one wave whose turn
+//     rotates with k,
+// with the device functions of the three tasks (viscous_face_core, coeff_of, diffusion_update_core): the same bits
+// as ZeroDiffusionFlux -> ViscousFlux -> DiffusionUpdate, without a diffusion-flux array.  HBM per zone: five
+// primitives, the radial factor of the viscosity law and the distance table in, five doubles out.
+// 3-D blocks, one gas species, viscosity only (conduction adds to the same energy flux and keeps the flux arrays).
+struct VsArgs {
+  artemis_diffusion_t D;
+  double dt;
+  const double *dt_ptr;
+  double *const *out; // [nblocks * 5]: what DiffusionUpdate subtracts from M1, M2, M3, E and e_int
+  int nti, ntj, nchunk, kchunk;
+};
+template <int VTX>
+struct VsTile {
+  static constexpr int VTY = 256 / VTX, QX = VTX + 4, QY = VTY + 4, SX = VTX + 2, SY = VTY + 2;
+  double V[3][QY][QX];                  // primitive velocities of the plane being staged
+  double S[3][3][SY][SX];               // [plane mod 3][component]: contravariant velocities
+  double DV[2][SY][SX], MU[2][SY][SX];  // [plane mod 2]: tile + the ring of its face neighbours
+  double FX[4][VTY][VTX + 1], FY[4][VTY + 1][VTX]; // lower x1 / x2 faces: 3 momentum fluxes + the energy flux
+};
+struct Vel5 {
+  double d, v1, v2, v3, e;
+};
+// What face_geometry asks of a block's geometry, answered from the workgroup's LDS tables (geometry.hpp GeoTabs: the
+// staged rectangle's columns and rows) instead of per-thread registers; distances from the host's table, or on the fly
+template <bool CURV, int NX, int NY>
+struct TileGeo {
+  const PackView &P;
+  const int b, ibase, jbase;
+  const GeoTabs<NX, NY> &G;
+  const double *dtab;
+  ADEV int col(int i) const { return min(max(i - ibase, 0), NX - 1); }
+  ADEV int row(int j) const { return min(max(j - jbase, 0), NY - 1); }
+  ADEV DCoordsT<true> coords(int k, int j, int i) const {
+    return geotabs_coords(G, P.coords, P.geom + 6 * b, col(i), row(j), k, 1.0, 0.0); // (nothing here reads c3 / s3)
+  }
+  ADEV void conn(int, int j, int i, double &d21, double &d31, double &d32) const {
+    d21 = d31 = d32 = 0.0;
+    if constexpr (CURV) d21 = G.gi[GI_DH2][col(i)], d31 = G.gi[GI_DH3][col(i)], d32 = G.gj[GJ_DH32][row(j)];
+  }
+  template <int DIR>
+  ADEV double dist_lower(int k, int j, int i) const {
+    if (dtab) return fused::gld(dtab + (static_cast<long>(DIR - 1) * P.nb + b) * (static_cast<long>(P.ni) * P.nj * P.nk),
+                                static_cast<unsigned>((k * P.nj + j) * P.ni + i));
+    return Geo<CURV>{P, b}.template dist_lower<DIR>(k, j, i);
+  }
+  template <int DIR>
+  ADEV double dist_across(int k, int j, int i) const {
+    if (dtab) return fused::gld(dtab + (static_cast<long>(2 + DIR) * P.nb + b) * (static_cast<long>(P.ni) * P.nj * P.nk),
+                                static_cast<unsigned>((k * P.nj + j) * P.ni + i));
+    return Geo<CURV>{P, b}.template dist_across<DIR>(k, j, i);
+  }
+};
+ADEV Vel5 load5(double *const *prim, int b, unsigned c) {
+  Vel5 q;
+  q.d = fused::gld(prim[b * 6 + 0], c), q.v1 = fused::gld(prim[b * 6 + 1], c), q.v2 = fused::gld(prim[b * 6 + 2], c);
+  q.v3 = fused::gld(prim[b * 6 + 3], c), q.e = fused::gld(prim[b * 6 + 5], c);
+  return q;
+}
+#ifndef VS_OCC
+#define VS_OCC 2
+#endif
+template <bool CURV, int VTX>
+__global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackView P, const VsArgs a) {
+  using T = VsTile<VTX>;
+  constexpr int VTY = T::VTY, QX = T::QX, QY = T::QY;
+  __shared__ T L;
+  __shared__ GeoTabs<QX, QY> GT;
+  const int t = threadIdx.x, tx = t % VTX, ty = t / VTX;
+  int id = blockIdx.x;
+  const int ti = id % a.nti;
+  id /= a.nti;
+  const int tj = id % a.ntj;
+  id /= a.ntj;
+  const int chunk = id % a.nchunk, b = id / a.nchunk;
+  const int i0 = P.is + ti * VTX, j0 = P.js + tj * VTY;
+  const int k0 = P.ks + chunk * a.kchunk, k1 = min(P.ke, k0 + a.kchunk - 1);
+  const int i = i0 + tx, j = j0 + ty;
+  const bool active = (i <= P.ie) && (j <= P.je);
+  const bool facev = (i <= P.ie + 1) && (j <= P.je + 1); // the lane's lower faces exist (ragged tiles)
+  const int il = min(i, P.ni - 1), jl = min(j, P.nj - 1);
+  const unsigned sj = static_cast<unsigned>(P.sj), sk = static_cast<unsigned>(P.sk);
+  const unsigned col = static_cast<unsigned>(jl) * sj + static_cast<unsigned>(il);
+  double *const *prim = P.gas.prim;
+  const artemis_diffcoeff_t &dp = a.D.visc;
+  const double dt = a.dt_ptr ? *a.dt_ptr : a.dt;
+  const TileGeo<CURV, QX, QY> ge{P, b, i0 - 2, j0 - 2, GT, a.D.dist};
+  geotabs_fill(GT, P, b, i0 - 2, j0 - 2, t);
+  __syncthreads();
+  // the halo zone this thread stages (every plane of the march), its place in the staged rectangle and its duties
+  constexpr int NH = QX * QY - 256;
+  int hr = -1, hc = -1;
+  if (t < NH) {
+    if (t < 2 * QX) hr = t / QX, hc = t % QX;
+    else if (t < 4 * QX) hr = VTY + 2 + (t - 2 * QX) / QX, hc = (t - 2 * QX) % QX;
+    else {
+      const int u = t - 4 * QX, cc = u & 3;
+      hr = 2 + (u >> 2), hc = (cc < 2) ? cc : VTX + cc;
+    }
+  }
+  const bool h_any = hr >= 0;
+  const int gi = min(max(i0 - 2 + hc, 0), P.ni - 1), gj = min(max(j0 - 2 + hr, 0), P.nj - 1);
+  const unsigned hcol = static_cast<unsigned>(gj) * sj + static_cast<unsigned>(gi);
+  const bool h_s = h_any && hr >= 1 && hr <= QY - 2 && hc >= 1 && hc <= QX - 2; // within one zone of the tile
+  const bool h_ring = h_any && (((hr == 1 || hr == QY - 2) && hc >= 2 && hc <= QX - 3) ||
+                                ((hc == 1 || hc == QX - 2) && hr >= 2 && hr <= QY - 3)); // a face neighbour of the tile
+  // volume-averaged scale factors of the own and of the halo zone (no x3 dependence in any system)
+  auto contravariant = [&](const double v[3], int jj, int ii, double s[3]) { // viscous_cell_kernel's quotients
+    if constexpr (!CURV) {
+      s[0] = v[0], s[1] = v[1], s[2] = v[2];
+    } else {
+      double h[3]; // (rebuilt from the tables every plane: six doubles less to carry through the march)
+      scale_factors_of(ge.coords(k0, jj, ii), h);
+      const bool odd = tiny_nonzero(v[0]) || tiny_nonzero(v[1]) || tiny_nonzero(v[2]);
+      if (__any(odd)) {
+        for (int d = 0; d < 3; ++d) s[d] = v[d] / h[d];
+      } else {
+        for (int d = 0; d < 3; ++d) s[d] = div(v[d], h[d]);
+      }
+    }
+  };
+  // VelocityDivergence (momentum_diffusion.hpp:562-591) of the zone at (row, column) of the staged rectangle, plane kk
+  auto divergence = [&](int kk, int gjj, int gii, int qr, int qc, double v3m, double v3c, double v3p) {
+    const CellMetric m = cell_metric_of(ge.coords(kk, gjj, gii));
+    const double divv = m.ax1[1] * (L.V[0][qr][qc] + L.V[0][qr][qc + 1]) - m.ax1[0] * (L.V[0][qr][qc] + L.V[0][qr][qc - 1]) +
+                        1 * m.ax2[1] * (L.V[1][qr][qc] + L.V[1][qr + 1][qc]) - 1 * m.ax2[0] * (L.V[1][qr][qc] + L.V[1][qr - 1][qc]) +
+                        1 * m.ax3[1] * (v3c + v3p) - 1 * m.ax3[0] * (v3c + v3m);
+    const double vol2 = 2.0 * m.vol;
+    return __any(tiny_nonzero(divv)) ? divv / vol2 : div(divv, vol2);
+  };
+  // rolling state of the own column and of the halo column: planes k (velocities), k + 1, k + 2
+  Vel5 rn = load5(prim, b, col + static_cast<unsigned>(k0 - 1) * sk), hn = rn;
+  double vc[3] = {0.0, 0.0, fused::gld(prim[b * 6 + 3], col + static_cast<unsigned>(k0 - 2) * sk)}, h3c = 0.0;
+  if (h_any) hn = load5(prim, b, hcol + static_cast<unsigned>(k0 - 1) * sk), h3c = fused::gld(prim[b * 6 + 3], hcol + static_cast<unsigned>(k0 - 2) * sk);
+  double dv_c = 0.0, mu_c = 0.0;
+  double f3lo[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = k0 - 2; k <= k1; ++k) {
+    // this trip's loads first (plane k + 2: its x3 velocity closes the divergence of plane k + 1)
+    const unsigned cnn = static_cast<unsigned>(min(k + 2, P.nk - 1)) * sk;
+    const Vel5 rnn = load5(prim, b, col + cnn);
+    Vel5 hnn = rnn;
+    if (h_any) hnn = load5(prim, b, hcol + cnn);
+    const int pn = (k + 1 + 3) % 3, pc = (k + 3) % 3, pm = (k + 2) % 3; // ring slots of planes k + 1, k, k - 1
+    const int dn = (k + 1) & 1, dc = k & 1;
+    const unsigned cn1 = col + static_cast<unsigned>(k + 1) * sk;
+    // ---- (a) stage plane k + 1: primitive and contravariant velocities ------------------------------------------
+    {
+      const double v[3] = {rn.v1, rn.v2, rn.v3};
+      double s[3];
+      contravariant(v, jl, il, s);
+      for (int m = 0; m < 3; ++m) L.V[m][ty + 2][tx + 2] = v[m], L.S[pn][m][ty + 1][tx + 1] = s[m];
+      if (h_any) {
+        const double w[3] = {hn.v1, hn.v2, hn.v3};
+        for (int m = 0; m < 3; ++m) L.V[m][hr][hc] = w[m];
+      }
+      if (t < 192) { // (waves 0..2 hold every halo thread: keep the wave-uniform division choice inside them)
+        const double w[3] = {hn.v1, hn.v2, hn.v3};
+        double sh[3];
+        contravariant(w, gj, gi, sh);
+        if (h_s)
+          for (int m = 0; m < 3; ++m) L.S[pn][m][hr - 1][hc - 1] = sh[m];
+      }
+    }
+    __syncthreads();
+    // ---- (b) VelocityDivergence and viscosity of plane k + 1: own zone, ring zones ------------------------------
+    const double dv_n = divergence(k + 1, jl, il, ty + 2, tx + 2, vc[2], rn.v3, rnn.v3);
+    const double mu_n = coeff_of(dp, a.D.cv, P.gm1, rn.d, rn.e, b, static_cast<long>(cn1));
+    L.DV[dn][ty + 1][tx + 1] = dv_n, L.MU[dn][ty + 1][tx + 1] = mu_n;
+    if (t < 192) {
+      const int qr = h_ring ? hr : 2, qc = h_ring ? hc : 2;
+      const double dvh = divergence(k + 1, gj, gi, qr, qc, h3c, hn.v3, hnn.v3);
+      const double muh = coeff_of(dp, a.D.cv, P.gm1, hn.d, hn.e, b, static_cast<long>(hcol + static_cast<unsigned>(k + 1) * sk));
+      if (h_ring) L.DV[dn][hr - 1][hc - 1] = dvh, L.MU[dn][hr - 1][hc - 1] = muh;
+    }
+    // ---- (c) faces ------------------------------------------------------------------------------------------------
+    // the stress rows of the lower DIR face of the zone at (row sy, column sx) of the S rectangle, block indices (kk, jj, ii)
+    auto face12 = [&](auto DIRTAG, int sy, int sx, int jj, int ii, bool valid, double fl[3], double &fe) {
+      constexpr int DIR = decltype(DIRTAG)::value;
+      constexpr int dy = (DIR == 2), dx = (DIR == 1), nc = DIR - 1;
+      const FaceGeo fg = face_geometry<DIR, CURV>(P, ge, b, k, jj, ii);
+      FaceIn q;
+      for (int m = 0; m < 3; ++m) q.s_c[m] = L.S[pc][m][sy][sx], q.s_m[m] = L.S[pc][m][sy - dy][sx - dx];
+      // transverse directions: (x2, x3) for an x1 face, (x1, x3) for an x2 face
+      q.n_t[0] = L.S[pc][nc][sy + dx][sx + dy] - L.S[pc][nc][sy - dx][sx - dy];
+      q.n_tm[0] = L.S[pc][nc][sy - dy + dx][sx - dx + dy] - L.S[pc][nc][sy - dy - dx][sx - dx - dy];
+      q.n_t[1] = L.S[pn][nc][sy][sx] - L.S[pm][nc][sy][sx];
+      q.n_tm[1] = L.S[pn][nc][sy - dy][sx - dx] - L.S[pm][nc][sy - dy][sx - dx];
+      q.mu1 = L.MU[dc][sy][sx], q.mu2 = L.MU[dc][sy - dy][sx - dx];
+      q.divu = L.DV[dc][sy][sx], q.divu_m = L.DV[dc][sy - dy][sx - dx];
+      viscous_face_core<DIR>(fg, q, dp.avg, dp.eta, fl, fe, valid);
+    };
+    double f3hi[4] = {0.0, 0.0, 0.0, 0.0};
+    if (k >= k0 - 1) { // the x3 face between planes k and k + 1 (the lower face of zone k + 1), registers + the ring
+      const FaceGeo fg = face_geometry<3, CURV>(P, ge, b, k + 1, jl, il);
+      FaceIn q;
+      const int sy = ty + 1, sx = tx + 1;
+      for (int m = 0; m < 3; ++m) q.s_c[m] = L.S[pn][m][sy][sx], q.s_m[m] = L.S[pc][m][sy][sx];
+      q.n_t[0] = L.S[pn][2][sy][sx + 1] - L.S[pn][2][sy][sx - 1];
+      q.n_tm[0] = L.S[pc][2][sy][sx + 1] - L.S[pc][2][sy][sx - 1];
+      q.n_t[1] = L.S[pn][2][sy + 1][sx] - L.S[pn][2][sy - 1][sx];
+      q.n_tm[1] = L.S[pc][2][sy + 1][sx] - L.S[pc][2][sy - 1][sx];
+      q.mu1 = mu_n, q.mu2 = mu_c, q.divu = dv_n, q.divu_m = dv_c;
+      viscous_face_core<3>(fg, q, dp.avg, dp.eta, f3hi, f3hi[3], active);
+    }
+    if (k >= k0) {
+      {
+        double fl[4];
+        face12(std::integral_constant<int, 1>{}, ty + 1, tx + 1, jl, il, facev, fl, fl[3]);
+        for (int m = 0; m < 4; ++m) L.FX[m][ty][tx] = fl[m];
+      }
+      {
+        double fl[4];
+        face12(std::integral_constant<int, 2>{}, ty + 1, tx + 1, jl, il, facev, fl, fl[3]);
+        for (int m = 0; m < 4; ++m) L.FY[m][ty][tx] = fl[m];
+      }
+      // the tile's upper perimeter: the x1 faces of column i0 + VTX on one wave, the x2 faces of row j0 + VTY on the
+      // next; the turn rotates with k
+      const int duty = (t + 64 * (k & 3)) & 255;
+      if (duty < VTY) {
+        const int jj = min(j0 + duty, P.nj - 1), ii = min(i0 + VTX, P.ni - 1);
+        double fl[4];
+        face12(std::integral_constant<int, 1>{}, duty + 1, VTX + 1, jj, ii, (j0 + duty <= P.je) && (i0 + VTX <= P.ie + 1), fl, fl[3]);
+        for (int m = 0; m < 4; ++m) L.FX[m][duty][VTX] = fl[m];
+      } else if (duty >= 64 && duty < 64 + VTX) {
+        const int u = duty - 64;
+        const int jj = min(j0 + VTY, P.nj - 1), ii = min(i0 + u, P.ni - 1);
+        double fl[4];
+        face12(std::integral_constant<int, 2>{}, VTY + 1, u + 1, jj, ii, (i0 + u <= P.ie) && (j0 + VTY <= P.je + 1), fl, fl[3]);
+        for (int m = 0; m < 4; ++m) L.FY[m][VTY][u] = fl[m];
+      }
+    }
+    __syncthreads();
+    // ---- (d) DiffusionUpdate's sums of zone k (diffusion.hpp:110-241) -----------------------------------------------
+    if (k >= k0 && active) {
+      double F[3][2][4];
+      for (int m = 0; m < 4; ++m) {
+        F[0][0][m] = 0.0 + L.FX[m][ty][tx], F[0][1][m] = 0.0 + L.FX[m][ty][tx + 1];
+        F[1][0][m] = 0.0 + L.FY[m][ty][tx], F[1][1][m] = 0.0 + L.FY[m][ty + 1][tx];
+        F[2][0][m] = 0.0 + f3lo[m], F[2][1][m] = 0.0 + f3hi[m];
+      }
+      const auto co = ge.coords(k, j, i);
+      double hx[3];
+      scale_factors_of(co, hx);
+      const DiffCell g = diffusion_cell_of(co, cell_metric_of(co), hx, 3);
+      double dm[3], de, deg;
+      auto FF = [&](int d, int var, int u) { return F[d][u][var]; };
+      diffusion_update_core(g, FF, 0, 1, 1, dt, vc, dm, de, deg);
+      const unsigned c = col + static_cast<unsigned>(k) * sk;
+      fused::gst(a.out[b * 5 + 0], c, dm[0]), fused::gst(a.out[b * 5 + 1], c, dm[1]), fused::gst(a.out[b * 5 + 2], c, dm[2]);
+      fused::gst(a.out[b * 5 + 3], c, de), fused::gst(a.out[b * 5 + 4], c, deg);
+    }
+    vc[0] = rn.v1, vc[1] = rn.v2, vc[2] = rn.v3, rn = rnn;
+    h3c = hn.v3, hn = hnn;
+    dv_c = dv_n, mu_c = mu_n;
+    for (int m = 0; m < 4; ++m) f3lo[m] = f3hi[m];
+  }
+}
 
 // artemis_hip_viscous_distance_fill: the six Coords::Distance values (geometry.hpp:407-412) a cell contributes
 // to the face kernels, evaluated exactly as Geo::dist does without its cache.  Static geometry: the host fills
@@ -556,6 +867,40 @@ int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStre
   if (P.ndim > 1) LAUNCH_VISC(2);
   if (P.ndim > 2) LAUNCH_VISC(3);
   return 0;
+}
+// Does the viscous-source march cover this pack?  (3-D blocks of one gas species, 32-bit zone offsets.)
+bool viscous_source_covers(const PackView &P) {
+  if (getenv("ARTEMIS_NO_VISC_SOURCE")) return false;
+  if (P.ndim != 3 || P.gas.ns != 1 || P.ng < 2) return false;
+  if (static_cast<long>(P.nk) * P.nj * P.ni >= (1L << 29)) return false;
+  return (P.ie - P.is + 1) >= 8 && (P.je - P.js + 1) >= 8;
+}
+void launch_viscous_source(const PackView &P, const artemis_diffusion_t &D, double dt, const double *dt_dev, double *const *out,
+                           hipStream_t s) {
+  VsArgs a;
+  a.D = D, a.dt = dt, a.dt_ptr = dt_dev, a.out = out;
+  const int nx = P.ie - P.is + 1, ny = P.je - P.js + 1, nz = P.ke - P.ks + 1;
+  // tile shape: 32 x 8, or 16 x 16 where a 32-zone row would leave half the lanes without a zone (16-zone blocks)
+  const bool narrow = (nx % 32 != 0) && (nx % 16 == 0 || nx < 32);
+  const int vtx = narrow ? 16 : 32, vty = 256 / vtx;
+  a.nti = (nx + vtx - 1) / vtx, a.ntj = (ny + vty - 1) / vty;
+  // chunks along x3: two priming trips each, so long ones -- but enough workgroups for two rounds of the chip's slots
+  const long tiles = static_cast<long>(a.nti) * a.ntj * P.nb;
+  int kch = 32;
+  if (const char *e = getenv("ARTEMIS_VISC_KCHUNK")) kch = std::max(1, atoi(e));
+  else
+    while (kch > 8 && tiles * ((nz + kch - 1) / kch) < 1024) kch >>= 1;
+  a.nchunk = (nz + kch - 1) / kch, a.kchunk = (nz + a.nchunk - 1) / a.nchunk;
+  a.nchunk = (nz + a.kchunk - 1) / a.kchunk;
+  const dim3 grid(static_cast<unsigned>(tiles * a.nchunk)), block(256);
+  const bool curv = P.coords != ARTEMIS_CARTESIAN;
+  if (curv) {
+    if (narrow) hipLaunchKernelGGL((viscous_source_kernel<true, 16>), grid, block, 0, s, P, a);
+    else hipLaunchKernelGGL((viscous_source_kernel<true, 32>), grid, block, 0, s, P, a);
+  } else {
+    if (narrow) hipLaunchKernelGGL((viscous_source_kernel<false, 16>), grid, block, 0, s, P, a);
+    else hipLaunchKernelGGL((viscous_source_kernel<false, 32>), grid, block, 0, s, P, a);
+  }
 }
 void launch_thermal_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s) {
   LAUNCH_DIR(thermal_flux_kernel, 1);

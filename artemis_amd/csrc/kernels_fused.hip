@@ -145,6 +145,7 @@ ADEV PlmGeo plm_geo_x3(const DCoords &co0, const double *g, int kc) {
 }
 struct SrcK { // pointwise tasks folded into the curvilinear instantiations
   int grav_on, rfc_on, diff_on, do_viscosity;
+  double *const *dsum; // artemis_stage_general_args_t.diffusion_sums or null
   double rf_omega;
   artemis_gravity_t grav;
 };
@@ -567,7 +568,14 @@ ADEV void plane_update(TILE &S, const PackView &P, const StageK &a, const Ctx &x
 // each direction), fetched at the top of a trip so that their latency hides behind the plane's sweeps.
 struct DFlux24 {
   double lo[3][4], hi[3][4];
+  double sum[5]; // ... or the five sums DiffusionUpdate subtracts, precomputed by artemis_hip_viscous_source
 };
+ADEV DFlux24 load_dsum(double *const *dsum, int b, unsigned c) {
+  DFlux24 r{};
+#pragma unroll
+  for (int q = 0; q < 5; ++q) r.sum[q] = gld(dsum[b * 5 + q], c);
+  return r;
+}
 ADEV DFlux24 load_dflux(const PackView &P, int b, long c, bool multi_d, bool three_d) {
   DFlux24 r;
   const long up[3] = {c + 1, c + (multi_d ? P.sj : 0), c + (three_d ? P.sk : 0)};
@@ -664,11 +672,15 @@ ADEV void plane_update_curv(TILE &S, const PackView &P, const StageK &a, const S
       u0.m2 += rdt * (0.0 * sqr(w.v1 + vf[0]) + 0.0 * sqr(w.v2 + vf[1]) + co.dh3dx2() * sqr(w.v3 + vf[2]));
   }
   if (sk.diff_on) { // Gas::DiffusionUpdate (artemis_driver.cpp:218-221)
-    const DiffCell dcell = diffusion_cell_of(co, g, hx, P.ndim);
-    const double v[3] = {w.v1, w.v2, w.v3};
     double dm[3], de, deg;
-    auto F = [&](int d, int var, int u) { return u ? df.hi[d][var] : df.lo[d][var]; };
-    diffusion_update_core(dcell, F, 0, 1, sk.do_viscosity, dt, v, dm, de, deg);
+    if (sk.dsum) {
+      dm[0] = df.sum[0], dm[1] = df.sum[1], dm[2] = df.sum[2], de = df.sum[3], deg = df.sum[4];
+    } else {
+      const DiffCell dcell = diffusion_cell_of(co, g, hx, P.ndim);
+      const double v[3] = {w.v1, w.v2, w.v3};
+      auto F = [&](int d, int var, int u) { return u ? df.hi[d][var] : df.lo[d][var]; };
+      diffusion_update_core(dcell, F, 0, 1, sk.do_viscosity, dt, v, dm, de, deg);
+    }
     u0.m1 -= dm[0], u0.m2 -= dm[1], u0.m3 -= dm[2];
     u0.e -= de;
     u0.eg -= deg;
@@ -880,7 +892,8 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
     if constexpr (CURV) {
       DFlux24 df{};
       if (gx.m3) gx.co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k0], gx.co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k0];
-      if (src.v.diff_on) df = load_dflux(P, x.b, static_cast<long>(x.col + static_cast<unsigned>(k0) * x.sk), x.multi_d, false);
+      if (src.v.diff_on) df = src.v.dsum ? load_dsum(src.v.dsum, x.b, x.col + static_cast<unsigned>(k0) * x.sk)
+                                         : load_dflux(P, x.b, static_cast<long>(x.col + static_cast<unsigned>(k0) * x.sk), x.multi_d, false);
       plane_update_curv<HAS_U1, WITH_DT, false>(S, P, a, src.v, x, gx, k0, qc, fx_lo, fy_lo, fz, fz, u1raw, df, ldt);
     }
     else if constexpr (FLUXES) plane_store_fluxes<false>(S, P, x, k0, fx_lo, fy_lo, fz, fz);
@@ -938,7 +951,9 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
       if (x.hr >= 0 && k < k1) hal = load_raw(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.hcol + (k + 1) * x.sk);
       DFlux24 df{};
       if constexpr (CURV) {
-        if (src.v.diff_on && k >= k0) df = load_dflux(P, x.b, static_cast<long>(x.col + static_cast<unsigned>(k) * x.sk), true, true);
+        if (src.v.diff_on && k >= k0)
+          df = src.v.dsum ? load_dsum(src.v.dsum, x.b, x.col + static_cast<unsigned>(k) * x.sk)
+                          : load_dflux(P, x.b, static_cast<long>(x.col + static_cast<unsigned>(k) * x.sk), true, true);
         // cos / sin of this plane's x3 centre (spherical3D, axisymmetric), also ahead of their use
         if (gx.m3 && k >= k0) gx.co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k], gx.co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k];
       }
@@ -1581,6 +1596,7 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
   src.v.rfc_on = (g.rf_omega != 0.0) ? 1 : 0, src.v.rf_omega = g.rf_omega;
   src.v.diff_on = (g.diffusion != nullptr) ? 1 : 0;
   src.v.do_viscosity = (g.diffusion && g.diffusion->visc.type != ARTEMIS_DIFF_OFF) ? 1 : 0;
+  src.v.dsum = src.v.diff_on ? g.diffusion_sums : nullptr;
   const bool has_u1 = (g.gas_u1 != g.gas_in);
   const bool dt = (g.dt_dev != nullptr);
   const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;

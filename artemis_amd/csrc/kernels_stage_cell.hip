@@ -53,6 +53,7 @@ struct CellStageArgs {
   // EXTRA instantiations only: DiffusionUpdate from the stored diffusion fluxes, the curvilinear
   // rotating frame from this cell's own mass fluxes, beta cooling
   int diff_on, do_viscosity, rfc_on, cool_on;
+  double *const *dsum; // artemis_stage_general_args_t.diffusion_sums (one gas species) or null
   artemis_cooling_t cool;
   // FIX instantiations only (refined meshes, artemis_hip_ml_stage_fixup): the zones to redo
   const artemis_ml_fix_cell_t *fix;
@@ -349,7 +350,12 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
         if (a.diff_on) { // Gas::DiffusionUpdate (artemis_driver.cpp:218-221)
           const double v[3] = {w.v1, w.v2, w.v3};
           double dm[3], de, deg;
-          diffusion_update_cell(P, dcell, b, n, c, a.do_viscosity, dt, v, dm, de, deg);
+          if (a.dsum) { // the five sums, formed by artemis_hip_viscous_source for this stage's input primitives
+            dm[0] = a.dsum[b * 5 + 0][c], dm[1] = a.dsum[b * 5 + 1][c], dm[2] = a.dsum[b * 5 + 2][c];
+            de = a.dsum[b * 5 + 3][c], deg = a.dsum[b * 5 + 4][c];
+          } else {
+            diffusion_update_cell(P, dcell, b, n, c, a.do_viscosity, dt, v, dm, de, deg);
+          }
           u0.m1 -= dm[0], u0.m2 -= dm[1], u0.m3 -= dm[2];
           u0.e -= de;
           u0.eg -= deg;
@@ -474,6 +480,7 @@ CellStageArgs cell_args(const PackView &P, const artemis_stage_general_args_t &g
   a.rfc_on = (g.rf_omega != 0.0) && !cart;
   a.diff_on = (g.diffusion != nullptr) && P.gas.ns > 0;
   a.do_viscosity = (g.diffusion && g.diffusion->visc.type != ARTEMIS_DIFF_OFF) ? 1 : 0;
+  a.dsum = (a.diff_on && P.gas.ns == 1) ? g.diffusion_sums : nullptr;
   a.cool_on = (g.cooling != nullptr) && P.gas.ns > 0;
   if (a.cool_on) a.cool = *g.cooling;
   a.fix = nullptr, a.nfix = 0;

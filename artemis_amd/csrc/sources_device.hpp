@@ -18,7 +18,8 @@ struct FluidPrim { // rho, velocity and (gas) specific internal energy of one sp
 };
 
 // Volume-averaged scale factors of any system (GetScaleFactors, geometry.hpp:384-388)
-ADEV void scale_factors_of(const DCoords &co, double hx[3]) {
+template <class CO>
+ADEV void scale_factors_of(const CO &co, double hx[3]) {
   hx[0] = 1.0, hx[1] = co.hx2v(), hx[2] = co.hx3v();
 }
 
@@ -51,7 +52,8 @@ struct GravAcc {
   double gx1, gx2, gx3, fd;
   bool uniform;
 };
-ADEV GravAcc gravity_accel(const artemis_gravity_t &G, const DCoords &co, int ndim, double dt) {
+template <class CO>
+ADEV GravAcc gravity_accel(const artemis_gravity_t &G, const CO &co, int ndim, double dt) {
   GravAcc a;
   a.gx1 = 0.0, a.gx2 = 0.0, a.gx3 = 0.0, a.fd = 0.0;
   a.uniform = (G.type == ARTEMIS_GRAVITY_UNIFORM);
@@ -170,7 +172,8 @@ struct RotFrame {
   double omdt, om2dt, R, eR[3], ep[3]; // e?[d] = component of the problem's unit vector d along R / phi
   double b1[2], b2[2], b3[2];
 };
-ADEV RotFrame rotating_frame_terms(const DCoords &co, double om0, double dt) {
+template <class CO>
+ADEV RotFrame rotating_frame_terms(const CO &co, double om0, double dt) {
   RotFrame r;
   r.omdt = om0 * dt;
   r.om2dt = r.omdt * om0;
@@ -211,7 +214,8 @@ ADEV void rotating_frame_dust(const RotFrame &r, int multi_d, int three_d, const
 }
 
 // ---- Gas::Cooling::BetaCooling (beta_cooling.cpp:88-124) on one cell's conserved state ----------
-ADEV double cooling_omdt(const DCoords &co, double gm, double dt) {
+template <class CO>
+ADEV double cooling_omdt(const CO &co, double gm, double dt) {
   double xv[3];
   co.centre(xv);
   const Frame fr = cyl_frame(co.sys, xv, co.cv, co.sv);

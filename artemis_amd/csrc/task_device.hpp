@@ -28,7 +28,8 @@ struct CellMetric {
   double ax1[2], ax2[2], ax3[2], vol; // GetFaceAreaX?, Volume
   double dx[3];                       // coordinate widths bnds.x?[1] - bnds.x?[0]
 };
-__device__ __forceinline__ CellMetric cell_metric_of(const DCoords &co) {
+template <class CO>
+__device__ __forceinline__ CellMetric cell_metric_of(const CO &co) {
   CellMetric m;
   m.ax1[0] = co.area1(0), m.ax1[1] = co.area1(1);
   m.ax2[0] = co.area2(0), m.ax2[1] = co.area2(1);

@@ -195,9 +195,10 @@ class MeshBlockPack:
 
     def stage_general(self, gam0, gam1, beta_dt, bdt, gas=(None, None, None), dust=(None, None, None),
                       pcm=False, time=0.0, gravity=None, rotating_frame=None, drag=None,
-                      cfl=(0.0, 0.0), dt_dev=None, diffusion=None, cooling=None):
+                      cfl=(0.0, 0.0), dt_dev=None, diffusion=None, cooling=None, diffusion_sums=None):
         """artemis_hip_stage_general: gas / dust = (in, u1, out) prim tables; diffusion = capi.Diffusion
-        whose fluxes are already in gas_diff_flux for the `in` primitives; cooling = capi.Cooling."""
+        whose fluxes are already in gas_diff_flux for the `in` primitives -- or, with diffusion_sums (the table
+        viscous_source returned for them), no flux array at all; cooling = capi.Cooling."""
         a = capi.StageGeneralArgs()
         a.gam0, a.gam1, a.beta_dt, a.bdt, a.pcm, a.time = gam0, gam1, beta_dt, bdt, int(pcm), time
         a.gas_in, a.gas_u1, a.gas_out = gas
@@ -214,6 +215,8 @@ class MeshBlockPack:
             a.diffusion = C.pointer(diffusion)
         if cooling is not None:
             a.cooling = C.pointer(cooling)
+        if diffusion_sums is not None:
+            a.diffusion_sums = diffusion_sums
         self._last_general_args = a
         # which kernel this call takes (0 cell-centred, 1 2-D row march, 2 curvilinear streaming tile)
         self.last_stage_variant = self.L.artemis_hip_stage_general_variant(C.byref(self.pack), C.byref(a))
@@ -283,6 +286,18 @@ class MeshBlockPack:
 
     def ThermalFlux(self, diffusion):
         self._call(self.L.artemis_hip_thermal_flux, C.byref(diffusion))
+
+    def viscous_source_covers(self):
+        return bool(self.L.artemis_hip_viscous_source_covers(C.byref(self.pack)))
+
+    def viscous_source(self, diffusion, dt):
+        """artemis_hip_viscous_source on gas_prim: returns (sums tensor [nb, 5, nk, nj, ni], its device table pointer)."""
+        if getattr(self, "_vsums", None) is None:
+            self._vsums = torch.zeros((self.gas_prim.shape[0], 5) + tuple(self.gas_prim.shape[2:]), dtype=torch.float64,
+                                      device=self.gas_prim.device)
+            self._vsums_tab = _ptr_table(self._vsums)
+        self._call(self.L.artemis_hip_viscous_source, C.byref(diffusion), dt, None, self._vsums_tab.data_ptr())
+        return self._vsums, self._vsums_tab.data_ptr()
 
     def DiffusionUpdate(self, diffusion, dt):
         self._call(self.L.artemis_hip_diffusion_update, C.byref(diffusion), dt)

@@ -461,6 +461,22 @@ int artemis_hip_zero_viscous_flux(const artemis_pack_t *p, const artemis_diffusi
 int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream);
 int artemis_hip_diffusion_update(const artemis_pack_t *p, const artemis_diffusion_t *d, double dt,
                                  void *stream);
+/* Gas::ZeroDiffusionFlux, Gas::ViscousFlux and the viscous part of Gas::DiffusionUpdate (artemis_driver.cpp:189-191,
+ * :218-221; momentum_diffusion.hpp:591-759, diffusion.hpp:110-241) as ONE source: for every active zone the five numbers
+ * DiffusionUpdate subtracts from the zone's conserved state -- dt * div(viscous momentum flux) with its metric terms
+ * for M1, M2, M3, dt * div(viscous energy flux) for E, and that minus the work term dt * (div F_M) . v / h for e_int --
+ * formed from p->gas.prim (the stage's input primitives, ghost zones filled, edge and corner zones included) in one
+ * LDS-staged march, with the expression trees of the three tasks: the bits DiffusionUpdate would subtract after
+ * ZeroDiffusionFlux -> ViscousFlux, but no diffusion-flux array is read or written (twelve stores and twenty-four
+ * loads per zone and stage less).  Hand the result to artemis_hip_stage_general as `diffusion_sums`.
+ *   dt / dt_dev : beta * dt of the stage (dt_dev: optional DEVICE scalar that replaces dt)
+ *   sums        : DEVICE table [nblocks * 5] of cell arrays (entire-block extents; only active zones are written)
+ * artemis_hip_viscous_source_covers: non-zero when the march covers the pack (3-D blocks at least 8 x 8 zones wide,
+ * one gas species); otherwise, and whenever heat conduction is on (it adds to the same energy flux) or a flux
+ * correction needs the face fluxes themselves, use the flux tasks. */
+int artemis_hip_viscous_source_covers(const artemis_pack_t *p);
+int artemis_hip_viscous_source(const artemis_pack_t *p, const artemis_diffusion_t *d, double dt, const double *dt_dev,
+                               double *const *sums, void *stream);
 /* min-combines cfl * min(viscous, conductive limit) into the DEVICE scalar *dt_dev */
 int artemis_hip_diffusion_dt(const artemis_pack_t *p, const artemis_diffusion_t *d, double cfl,
                              double *dt_dev, void *stream);
@@ -499,6 +515,10 @@ typedef struct artemis_stage_general_args {
    * a non-Cartesian pack selects RotatingFrameImpl, evaluated from the cell's own mass fluxes. */
   const artemis_diffusion_t *diffusion;
   const artemis_cooling_t *cooling;
+  /* optional: the result of artemis_hip_viscous_source for THIS stage's input primitives (DEVICE table
+   * [nblocks * 5]).  With it (and `diffusion` non-NULL) DiffusionUpdate subtracts these sums instead of forming them
+   * from p->gas.diff_flux, which is then not read.  Same bits. */
+  double *const *diffusion_sums;
 } artemis_stage_general_args_t;
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
                               void *stream);

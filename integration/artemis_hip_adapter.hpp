@@ -12,6 +12,7 @@
 #define ARTEMIS_HIP_ADAPTER_HPP_
 
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -30,10 +31,14 @@ using parthenon::ParArray1D;
 using parthenon::TaskStatus;
 using TE = parthenon::TopologicalElement;
 
-// Device tables of one MeshData partition.  What identifies the data they point at is remembered (`probe0`,
-// `probe1`: the address of the first conserved variable of the first block of the u0 / u1 MeshData, and the block
-// count): a remesh, a restart or another MeshData of the same partition id moves them and the tables are rebuilt
-// on the next call -- no hook into Parthenon's remesher is needed (Invalidate() is there for hosts that have one).
+// Device tables of one MeshData partition.  What identifies the data they point at is remembered: `sig0` / `sig1`, a
+// hash over EVERY block of the u0 / u1 MeshData of its global id, its logical location (level, lx1, lx2, lx3) and the
+// address of its MeshBlockData object, plus `probe0` / `probe1`, the address of the first conserved variable of the
+// first block, and the block count.  A remesh keeps unchanged blocks as the same objects at the same addresses and
+// replaces refined, derefined or migrated ones by new objects with other locations / ids, so any change of any block
+// of the partition -- not only of its first one -- changes the signature and the tables are rebuilt on the next call;
+// a restart or a reallocation moves the probe.  No hook into Parthenon's remesher is needed (Invalidate() is there
+// for hosts that have one).
 struct PackCache {
   artemis_pack_t p{};
   ParArray1D<Real *> gprim, gcons0, gcons1, gflux[3], gpflux[3], gvface[3], gdflux[3];
@@ -41,6 +46,7 @@ struct PackCache {
   ParArray1D<Real> geom, metric, plm_table;
   std::vector<Real> geom_host, metric_host;
   const Real *probe0 = nullptr, *probe1 = nullptr;
+  std::uint64_t sig0 = 0, sig1 = 0;
   int nb = -1;
   // package tables that depend on the mesh (built on first use after a rebuild)
   ParArray1D<Real> visc_radial_data;
@@ -103,6 +109,27 @@ inline const Real *Probe(MeshData<Real> *md) {
   auto *res = pm->resolved_packages.get();
   if (pm->packages.Get("artemis")->template Param<bool>("do_gas")) return &GasConsDesc(res).GetPack(md)(0, 0, 0, 0, 0);
   return &DustConsDesc(res).GetPack(md)(0, 0, 0, 0, 0);
+}
+
+// identity of the blocks of a MeshData (FNV-1a over gid, logical location and MeshBlockData address of every block):
+// host-side, a handful of integer operations per block and call
+inline std::uint64_t Signature(MeshData<Real> *md) {
+  std::uint64_t h = 1469598103934665603ull;
+  auto mix = [&h](std::uint64_t v) {
+    for (int q = 0; q < 8; ++q) h = (h ^ ((v >> (8 * q)) & 0xffu)) * 1099511628211ull;
+  };
+  const int nb = md->NumBlocks();
+  mix(static_cast<std::uint64_t>(nb));
+  for (int b = 0; b < nb; ++b) {
+    auto &mbd = md->GetBlockData(b);
+    const auto *pmb = mbd->GetBlockPointer();
+    mix(static_cast<std::uint64_t>(pmb->gid));
+    mix(static_cast<std::uint64_t>(pmb->loc.level()));
+    mix(static_cast<std::uint64_t>(pmb->loc.lx1())), mix(static_cast<std::uint64_t>(pmb->loc.lx2()));
+    mix(static_cast<std::uint64_t>(pmb->loc.lx3()));
+    mix(static_cast<std::uint64_t>(reinterpret_cast<std::uintptr_t>(mbd.get())));
+  }
+  return h;
 }
 
 // everything that comes from u0: sizes, parameters, prim / cons0 / flux tables, edge and metric tables
@@ -219,7 +246,7 @@ inline std::map<int, PackCache> &Caches() {
   static std::map<int, PackCache> caches; // one per MeshData partition
   return caches;
 }
-// For hosts with a remesh hook; not required (GetPack notices moved data by itself).
+// For hosts with a remesh hook; not required (GetCache notices changed blocks and moved data by itself).
 inline void Invalidate() { Caches().clear(); }
 
 // u0 = the MeshData the task receives; u1 = the start-of-step copy for the tasks that read it (ApplyUpdate,
@@ -227,15 +254,17 @@ inline void Invalidate() { Caches().clear(); }
 inline PackCache &GetCache(MeshData<Real> *u0, MeshData<Real> *u1 = nullptr) {
   PackCache &c = Caches()[u0->GetPartitionId()];
   const Real *p0 = Probe(u0);
-  if (c.nb != u0->NumBlocks() || c.probe0 != p0) {
+  const std::uint64_t s0 = Signature(u0);
+  if (c.nb != u0->NumBlocks() || c.probe0 != p0 || c.sig0 != s0) {
     BuildFromU0(c, u0);
-    c.probe0 = p0;
+    c.probe0 = p0, c.sig0 = s0;
   }
   if (u1) {
     const Real *p1 = Probe(u1);
-    if (c.probe1 != p1) {
+    const std::uint64_t s1 = Signature(u1);
+    if (c.probe1 != p1 || c.sig1 != s1) {
       BuildFromU1(c, u1);
-      c.probe1 = p1;
+      c.probe1 = p1, c.sig1 = s1;
     }
   }
   return c;
@@ -503,23 +532,43 @@ inline Real DustEstimateTimestepMesh(MeshData<Real> *md) { // dust.cpp:239-276
 // updates; only the ghost zones are converted after the boundary exchange).  The kernel reads the primitives at the
 // start of the stage AND at the start of the step (it rebuilds u1 from them; the primitives are OneCopy in Artemis,
 // gas.cpp:244-270, so the u1 MeshData does not hold them) and must not write where it reads: the adapter keeps two
-// primitive buffers of its own per partition -- the start-of-step snapshot and the stage's output, copied back into
-// u0's arrays.  (A host that can swap the variables' data pointers instead saves the copies; the repository's own
+// primitive buffers of its own per partition -- the start-of-step snapshot and the stage's output -- and moves the
+// active zones between them and u0's arrays in ONE device pass per stage (CopyInterior).  (A host that can swap the variables' data pointers instead saves the copies; the repository's own
 // driver ping-pongs three buffers.)
-template <typename TA, typename TB>
-inline void CopyArrays(const TA &dst, const TB &src, const int nentries, const long N) {
+// One thread per (table entry, zone): the copies are bandwidth-bound device passes, not serial host-style loops.
+// CopyInterior: dst(e)[z] = src(e)[z] over the ACTIVE zones z of every entry (the stage kernel writes no ghost zone,
+// so none is copied back); with `keep` the value dst held goes to keep(e)[z] first -- the start-of-step snapshot and
+// the copy-back of stage 1 in one pass.  Extents in long: a table of 6 x 260^3 zones has more than 2^31 elements.
+struct ZoneBox {
+  int nx1, nx2, nx3, g1, g2, g3;
+  long ni, nj;
+};
+inline ZoneBox ActiveZones(const artemis_pack_t &p) {
+  ZoneBox z;
+  z.nx1 = p.nx1, z.nx2 = p.nx2, z.nx3 = p.nx3;
+  z.g1 = p.nghost, z.g2 = (p.nx2 > 1) ? p.nghost : 0, z.g3 = (p.nx3 > 1) ? p.nghost : 0;
+  z.ni = p.nx1 + 2 * z.g1, z.nj = p.nx2 + 2 * z.g2;
+  return z;
+}
+template <typename TA, typename TB, typename TC>
+inline void CopyInterior(const TA &dst, const TB &src, const TC &keep, const bool with_keep, const int nentries,
+                         const ZoneBox zb) {
+  const int nact = zb.nx1 * zb.nx2 * zb.nx3; // (< 2^31: one block)
   parthenon::par_for(
-      DEFAULT_LOOP_PATTERN, "ArtemisHip::CopyArrays", parthenon::DevExecSpace(), 0, nentries - 1, 0, 0,
-      KOKKOS_LAMBDA(const int e, const int) {
+      DEFAULT_LOOP_PATTERN, "ArtemisHip::CopyInterior", parthenon::DevExecSpace(), 0, nentries - 1, 0, nact - 1,
+      KOKKOS_LAMBDA(const int e, const int q) {
+        const int i = q % zb.nx1, j = (q / zb.nx1) % zb.nx2, k = q / (zb.nx1 * zb.nx2);
+        const long z = (static_cast<long>(k + zb.g3) * zb.nj + (j + zb.g2)) * zb.ni + (i + zb.g1);
         Real *d = dst(e);
-        const Real *q = src(e);
-        for (long n = 0; n < N; ++n) d[n] = q[n];
+        if (with_keep) keep(e)[z] = d[z];
+        d[z] = src(e)[z];
       });
 }
 struct StageBuffers {
   ParArray1D<Real> step_data, new_data;
   ParArray1D<Real *> step, out;
   const Real *probe = nullptr;
+  std::uint64_t sig = 0;
 };
 inline std::map<int, StageBuffers> &StageBufferCache() {
   static std::map<int, StageBuffers> m;
@@ -532,19 +581,17 @@ inline TaskStatus StageFused(MeshData<Real> *u0, const int stage, const partheno
   const long N = static_cast<long>(p.nx1 + 2 * p.nghost) * (ndim > 1 ? p.nx2 + 2 * p.nghost : 1) * (ndim > 2 ? p.nx3 + 2 * p.nghost : 1);
   const int nent = p.nblocks * 6 * p.gas.nspecies;
   StageBuffers &sb = StageBufferCache()[u0->GetPartitionId()];
-  if (sb.probe != c.probe0 || sb.step.size() != nent) {
-    sb.step_data = ParArray1D<Real>("artemis_hip start-of-step primitives", static_cast<int>(nent * N));
-    sb.new_data = ParArray1D<Real>("artemis_hip stage output primitives", static_cast<int>(nent * N));
+  if (sb.probe != c.probe0 || sb.sig != c.sig0 || sb.step.size() != nent) {
+    sb.step_data = ParArray1D<Real>("artemis_hip start-of-step primitives", static_cast<long>(nent) * N);
+    sb.new_data = ParArray1D<Real>("artemis_hip stage output primitives", static_cast<long>(nent) * N);
     sb.step = ParArray1D<Real *>("artemis_hip table", nent), sb.out = ParArray1D<Real *>("artemis_hip table", nent);
     auto ts = sb.step, to = sb.out;
     Real *bs = sb.step_data.data(), *bo = sb.new_data.data();
     parthenon::par_for(
         DEFAULT_LOOP_PATTERN, "ArtemisHip::FillStageTables", parthenon::DevExecSpace(), 0, nent - 1, 0, 0,
         KOKKOS_LAMBDA(const int e, const int) { ts(e) = bs + e * N, to(e) = bo + e * N; });
-    sb.probe = c.probe0;
+    sb.probe = c.probe0, sb.sig = c.sig0;
   }
-  if (stage == 1) CopyArrays(sb.step, c.gprim, nent, N); // the primitives at the start of the step
-  CopyArrays(sb.out, c.gprim, nent, N);                  // (valid ghost zones in the output buffer)
   artemis_stage_args_t a;
   std::memset(&a, 0, sizeof a);
   a.gam0 = integ->gam0[stage - 1], a.gam1 = integ->gam1[stage - 1];
@@ -554,7 +601,9 @@ inline TaskStatus StageFused(MeshData<Real> *u0, const int stage, const partheno
   a.cons_out = p.gas.cons0;
   const int rc = artemis_hip_stage_fused(&p, &a, Stream());
   PARTHENON_REQUIRE(rc == 0, artemis_hip_last_error());
-  CopyArrays(c.gprim, sb.out, nent, N);
+  // new primitives into u0's arrays (active zones; the boundary exchange that follows fills the ghost zones); in
+  // stage 1 the values they replace are the start-of-step primitives the later stages rebuild u1 from
+  CopyInterior(c.gprim, sb.out, sb.step, stage == 1, nent, ActiveZones(p));
   return TaskStatus::complete;
 }
 inline void StageFusedFillDerived(MeshData<Real> *md) {

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Per-kernel times of one bench.py command on the GPU box: rocprofv3 --kernel-trace --stats, summary to gpurun_out/<tag>_kernel_stats.csv
+#   scripts/prof_kernels.sh <tag> <bench.py arguments ...>
+tag=$1; shift
+export TMPDIR=/tmp
+out=/tmp/prof_$tag
+rm -rf $out
+rocprofv3 --kernel-trace --stats -d $out -o p -- python3 bench.py "$@" > gpurun_out/${tag}_prof_stdout.log 2>&1
+f=$(find $out -name '*kernel_stats.csv' | head -1)
+mkdir -p gpurun_out
+cp "$f" gpurun_out/${tag}_kernel_stats.csv
+python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:14]:
+    print("%-100s calls %6s  avg %10.1f us  total %6.2f%%" % (r["Name"][:100], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+PY

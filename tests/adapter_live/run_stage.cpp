@@ -12,6 +12,10 @@
 //     fused : gas through the opt-in StageFused / StageFusedFillDerived forwarders
 //     realloc = 1: after the first step every variable moves to a new allocation (what a remesh or a restart does
 //                  to the addresses) -- the adapter has to notice by itself
+//     realloc = 2: ONE partition holding both blocks; after the first step the SECOND block is replaced by a new
+//                  MeshBlock / MeshBlockData object with another gid and logical location and fresh allocations (what
+//                  a remesh does to a refined, derefined or migrated block) while the first block stays where it
+//                  was -- the adapter's tables of the second block must follow
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -79,6 +83,20 @@ void reallocate(Partition &P) {
       kv.second = it->second;
     }
 }
+// the block is replaced: new MeshBlock (other gid / logical location), new MeshBlockData objects, new allocations
+// with the same contents -- the old objects stay alive (a stale table would silently keep writing into them)
+std::vector<std::shared_ptr<MeshBlockData<Real>>> graveyard;
+std::vector<std::shared_ptr<MeshBlock>> new_blocks;
+void replace_block(Partition &P) {
+  auto nb = std::make_shared<MeshBlock>(P.blk);
+  nb->gid = P.blk.gid + 100, nb->loc.lev = P.blk.loc.lev + 1, nb->loc.l1 = 2 * P.blk.loc.l1 + 1;
+  new_blocks.push_back(nb);
+  graveyard.push_back(P.b0), graveyard.push_back(P.b1);
+  auto n0 = std::make_shared<MeshBlockData<Real>>(*P.b0), n1 = std::make_shared<MeshBlockData<Real>>(*P.b1);
+  n0->pmb = n1->pmb = nb.get();
+  P.b0 = n0, P.b1 = n1;
+  reallocate(P);
+}
 // parthenon's outflow condition on the FillGhost primitives: x1, then x2, then x3, each over the entire extent of the others
 void outflow(Partition &P, bool dust) {
   std::vector<std::pair<Variable *, int>> fields;
@@ -111,7 +129,8 @@ int main(int argc, char **argv) {
   const std::string mode = argv[1];
   const Real dt = std::atof(argv[4]);
   const int nsteps = std::atoi(argv[5]);
-  const bool realloc_after_first = std::atoi(argv[6]) != 0;
+  const int realloc_mode = std::atoi(argv[6]);
+  const bool realloc_after_first = realloc_mode == 1, one_partition = realloc_mode == 2;
   const bool full = mode == "full", fused = mode == "fused";
   const bool dust = full, diffusion = full;
 
@@ -155,6 +174,13 @@ int main(int argc, char **argv) {
 
   Partition part[2];
   for (int q = 0; q < 2; ++q) build(part[q], &mesh, q, dust, diffusion);
+  for (int q = 0; q < 2; ++q) part[q].blk.gid = q, part[q].blk.loc.l1 = q;
+  const int npart = one_partition ? 1 : 2;
+  auto gather = [&]() { // realloc = 2: partition 0 holds both blocks
+    if (!one_partition) return;
+    part[0].u0.blocks = {part[0].b0, part[1].b0}, part[0].u1.blocks = {part[0].b1, part[1].b1};
+  };
+  gather();
 
   // initial primitives (entire blocks) from the Python side: per partition gas [6][N] then dust [4][N]
   FILE *f = std::fopen(argv[2], "rb");
@@ -177,17 +203,21 @@ int main(int argc, char **argv) {
   integ.nstages = 2, integ.dt = dt, integ.gam0 = {0.0, 0.5}, integ.gam1 = {1.0, 0.5}, integ.beta = {1.0, 0.5};
   Real dt_est = 0.0;
   try {
-    for (int q = 0; q < 2; ++q) ArtemisHip::PrimToCons(&part[q].u0); // PostInitialization (main.cpp:43)
+    for (int q = 0; q < npart; ++q) ArtemisHip::PrimToCons(&part[q].u0); // PostInitialization (main.cpp:43)
     Real time = 0.0;
     for (int step = 0; step < nsteps; ++step) {
-      for (int q = 0; q < 2; ++q) ArtemisHip::DeepCopyConservedData(&part[q].u1, &part[q].u0); // artemis_driver.cpp:157-163
+      for (int q = 0; q < npart; ++q) ArtemisHip::DeepCopyConservedData(&part[q].u1, &part[q].u0); // artemis_driver.cpp:157-163
       for (int stage = 1; stage <= integ.nstages; ++stage) {
         const Real bdt = integ.beta[stage - 1] * integ.dt;
-        for (int q = 0; q < 2; ++q) { // one task list per partition (artemis_driver.cpp:170-262)
+        for (int q = 0; q < npart; ++q) { // one task list per partition (artemis_driver.cpp:170-262)
           MeshData<Real> *u0 = &part[q].u0, *u1 = &part[q].u1;
+          auto bcs = [&]() {
+            outflow(part[q], dust);
+            if (one_partition) outflow(part[1], dust);
+          };
           if (fused) {
             ArtemisHip::StageFused(u0, stage, &integ, false);
-            outflow(part[q], dust);
+            bcs();
             ArtemisHip::StageFusedFillDerived(u0);
             continue;
           }
@@ -201,13 +231,14 @@ int main(int argc, char **argv) {
           if (full) ArtemisHip::ExternalGravity(u0, time, bdt), ArtemisHip::RotatingFrameForce(u0, time, bdt), ArtemisHip::DragSource(u0, time, bdt);
           ArtemisHip::SetAuxillaryFields(u0);
           ArtemisHip::ConsToPrim(u0);
-          outflow(part[q], dust);
+          bcs();
           ArtemisHip::PrimToCons(u0);
         }
       }
       time += integ.dt;
       if (step == 0 && realloc_after_first)
         for (int q = 0; q < 2; ++q) reallocate(part[q]);
+      if (step == 0 && one_partition) replace_block(part[1]), gather();
     }
     // PostStepTasks: EstimateTimestep on the "base" MeshData (artemis_driver.cpp:286-288) -- here u0
     dt_est = ArtemisHip::GasEstimateTimestepMesh(&part[0].u0);

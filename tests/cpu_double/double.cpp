@@ -779,6 +779,11 @@ int artemis_hip_zero_viscous_flux(const artemis_pack_t *p, const artemis_diffusi
   if (int rc = artemis_hip_zero_diffusion_flux(p, s)) return rc;
   return (d->visc.type == ARTEMIS_DIFF_OFF) ? 0 : artemis_hip_viscous_flux(p, d, s);
 }
+// the viscous-source march is a device-side reorganisation of the three tasks above: this double keeps the tasks
+int artemis_hip_viscous_source_covers(const artemis_pack_t *) { return 0; }
+int artemis_hip_viscous_source(const artemis_pack_t *, const artemis_diffusion_t *, double, const double *, double *const *, void *) {
+  return ARTEMIS_HIP_EUNSUPPORTED;
+}
 int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *) {
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);

@@ -47,7 +47,7 @@ template <class T>
 struct ParArray1D { // a reference-counted 1-D array (host memory here)
   std::shared_ptr<std::vector<T>> v;
   ParArray1D() = default;
-  ParArray1D(const std::string &, int n) : v(std::make_shared<std::vector<T>>(static_cast<size_t>(n))) {}
+  ParArray1D(const std::string &, long n) : v(std::make_shared<std::vector<T>>(static_cast<size_t>(n))) {}
   T &operator()(int i) const { return (*v)[static_cast<size_t>(i)]; }
   T *data() const { return v ? v->data() : nullptr; }
   int size() const { return v ? static_cast<int>(v->size()) : 0; }
@@ -96,8 +96,18 @@ struct Coordinates_t { // uniform logically-Cartesian block: Xf(idx) = xf0 + idx
     return dx[D - 1];
   }
 };
+struct LogicalLocation { // position of a block in the refinement tree
+  int lev = 0;
+  long l1 = 0, l2 = 0, l3 = 0;
+  int level() const { return lev; }
+  long lx1() const { return l1; }
+  long lx2() const { return l2; }
+  long lx3() const { return l3; }
+};
 struct MeshBlock {
   Coordinates_t coords;
+  int gid = 0;
+  LogicalLocation loc;
 };
 struct Mesh {
   Packages packages;

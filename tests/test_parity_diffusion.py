@@ -159,3 +159,116 @@ def test_state_power_law_conductivity(hiplib, coordinates, nx, lo, hi, ctype):
     ref = o.EstimateTimestepMesh(0)
     hyd = mb.EstimateTimestepMesh(0, cfl=0.3)
     assert abs(min(hyd, t) - ref) < 1e-13 * ref
+
+
+# ---- the viscous source march (artemis_hip_viscous_source): ZeroDiffusionFlux + ViscousFlux + DiffusionUpdate's sums ----
+VSRC = [
+    ("cartesian", (40, 19, 21), (-1.0, -0.5, 0.25), (1.0, 0.8, 0.95)),       # ragged 32 x 8 tiles, ragged chunk
+    ("cartesian", (16, 16, 8), (-1.0, -0.5, 0.25), (1.0, 0.8, 0.95)),        # the 16 x 16 tile (refined-mesh blocks)
+    ("spherical", (40, 19, 21), (0.9, 1.06, -3.1), (5.6, 2.08, 3.1)),
+    ("spherical", (64, 16, 12), (0.3, 0.7, 0.0), (1.7, 2.5, 2 * np.pi)),
+    ("spherical", (16, 16, 16), (0.4, 0.9, 0.0), (0.9, 2.2, 1.5)),
+    ("cylindrical", (35, 10, 18), (0.8, -3.1, -1.0), (4.3, 3.1, 1.0)),
+    ("cylindrical", (16, 32, 9), (0.5, 0.0, -1.0), (2.0, 2 * np.pi, 1.0)),
+    ("axisymmetric", (24, 12, 10), (0.7, -1.0, 0.0), (2.0, 1.0, 1.0)),
+]
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", VSRC)
+@pytest.mark.parametrize("law,tiny", [("alpha", False), ("constant", False), ("constant", True), ("powerlaw", False)])
+def test_viscous_source_march(hiplib, coordinates, nx, lo, hi, law, tiny, monkeypatch):
+    """artemis_hip_viscous_source == ZeroDiffusionFlux -> ViscousFlux -> DiffusionUpdate of the oracle: conserved state
+    minus the five sums equals the oracle's updated state bit for bit on every active zone -- three viscosity laws, both
+    face averages, with and without the distance table, velocities of 1e-300 next to zeros and ordinary values
+    (`tiny`: the waves that see one take the plain divisions), short chunks (three priming planes per chunk)."""
+    from artemis_amd.pack import diffusion_params
+    o, mb = pair(nx, ns_gas=1, seed=63, coordinates=coordinates, lo=lo, hi=hi)
+    if tiny:
+        rng = np.random.default_rng(5)
+        scale = rng.choice([1.0, 0.0, 1e-300, 1e-306, 1e-250, 1e-160, 1e-40], size=o.gprim[1].shape,
+                           p=[0.35, 0.15, 0.1, 0.1, 0.1, 0.1, 0.1])
+        for v in (1, 2, 3):
+            o.gprim[v] *= scale
+        o.PrimToCons()
+        push([o], mb)
+    avg = "harmonic" if law == "constant" else "arithmetic"
+    if law == "alpha":
+        visc = dict(type="alpha", alpha=2e-2, eta_bulk=0.3, r0=0.9, Omega0=1.2, averaging=avg)
+        o.set_viscosity("alpha", alpha=2e-2, eta_bulk=0.3, r0=0.9, Omega0=1.2, averaging=avg)
+    elif law == "powerlaw":
+        visc = dict(type="powerlaw", nu=0.05, r_exp=-0.5, r0=0.8, eta_bulk=1.5, averaging=avg)
+        o.set_viscosity("powerlaw", nu=0.05, r_exp=-0.5, r0=0.8, eta_bulk=1.5, averaging=avg)
+    else:
+        visc = dict(type="constant", nu=0.03, eta_bulk=0.4, averaging=avg)
+        o.set_viscosity("constant", nu=0.03, eta_bulk=0.4, averaging=avg)
+    D = diffusion_params(1.4, viscosity=visc)
+    if law != "constant":
+        mb.viscosity_radial_table(D)
+    assert mb.viscous_source_covers()
+    dt = 2.0e-4
+    o.ZeroDiffusionFlux(), o.ViscousFlux()
+    before = o.gu0.copy()
+    o.DiffusionUpdate(dt)
+    I = (slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    for table, kchunk in ((False, None), (True, "5")):
+        if table:
+            mb.distance_table(D)
+        if kchunk:
+            monkeypatch.setenv("ARTEMIS_VISC_KCHUNK", kchunk)
+        sums, _ = mb.viscous_source(D, dt)
+        got = sums[0].cpu().numpy()
+        for q in range(5):
+            assert np.array_equal(before[1 + q][I] - got[q][I], o.gu0[1 + q][I]), (table, q)
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi", [VSRC[2], VSRC[5], VSRC[0]])
+@pytest.mark.parametrize("stage2", [False, True])
+def test_stage_general_with_viscous_sums(hiplib, coordinates, nx, lo, hi, stage2, monkeypatch):
+    """The stage kernels fed with the sums instead of the twelve flux arrays (artemis_stage_general_args_t.diffusion_sums):
+    the streaming tile kernel on curvilinear blocks and the cell-centred kernel, against the oracle's task chain."""
+    from artemis_amd.pack import MeshBlockPack, diffusion_params, gravity_point
+    kw = dict(ng=2, ns_gas=1, ns_dust=0, reconstruct="plm", riemann="hlle", dust_reconstruct="plm", dust_riemann="hlle",
+              gamma=1.4, dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10, coordinates=coordinates)
+    o = Oracle(nx, lo, hi, bc=("outflow",) * 6, cfl=0.3, dust_cfl=0.3, **kw)
+    random_state(o, np.random.default_rng(91), shock=False, mach=0.5, contrast=10.0)
+    om = 0.8 if coordinates != "cartesian" else 0.0
+    mb = MeshBlockPack(1, nx, [lo], [hi], with_diffusion=False, omega_frame=om, **kw)
+    push([o], mb)
+    o.DeepCopyConservedData()
+    gin = gu1 = mb.gas_prim_table
+    if stage2:
+        o2 = Oracle(nx, lo, hi, bc=("outflow",) * 6, cfl=0.3, dust_cfl=0.3, **kw)
+        random_state(o2, np.random.default_rng(17), shock=False, mach=0.5, contrast=10.0)
+        o.gu1[:] = o2.gu0
+        t, gu1 = mb.new_prim_buffer("u1")
+        t.copy_(torch.from_numpy(o2.gprim[None]).to(t.device))
+    o.set_gravity_point(1.3, soft=0.05, x=0.1, y=0.05, z=0.0)
+    grav = gravity_point(1.3, soft=0.05, pos=(0.1, 0.05, 0.0))
+    if om:
+        o.set_rotating_frame(om, 0.0)
+    o.set_viscosity("alpha", alpha=2e-2, eta_bulk=0.3, r0=0.9, Omega0=1.2)
+    D = diffusion_params(1.4, viscosity=dict(type="alpha", alpha=2e-2, eta_bulk=0.3, r0=0.9, Omega0=1.2))
+    mb.viscosity_radial_table(D)
+    mb.distance_table(D)
+    dt, time = 2.0e-4, 0.25
+    g0, g1, be = (0.5, 0.5, 0.5) if stage2 else (0.0, 1.0, 1.0)
+    o.CalculateFluxes(0, False)
+    o.ZeroDiffusionFlux(), o.ViscousFlux()
+    o.ApplyUpdate(g0, g1, be * dt)
+    o.FluxSource(be * dt, 0)
+    o.DiffusionUpdate(be * dt)
+    o.ExternalGravity(time, be * dt)
+    if om:
+        o.RotatingFrameForce(be * dt)
+    o.SetAuxillaryFields()
+    o.ConsToPrim()
+    _, sums = mb.viscous_source(D, be * dt)
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    keep = [0, 1, 2, 3, 5]
+    for nofuse in (False, True):
+        if nofuse:
+            monkeypatch.setenv("ARTEMIS_NO_FUSED_CURV", "1")
+        gbuf, gout = mb.new_prim_buffer("o%d" % nofuse)
+        mb.stage_general(g0, g1, be * dt, be * dt, gas=(gin, gu1, gout), time=time, gravity=grav,
+                         rotating_frame=(om, 0.0), cfl=(0.3, 0.3), diffusion=D, diffusion_sums=sums)
+        assert np.array_equal(gbuf[0][I].cpu().numpy()[keep], o.gprim[I][keep]), nofuse
