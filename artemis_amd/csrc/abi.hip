@@ -767,6 +767,7 @@ int artemis_hip_viscous_source(const artemis_pack_t *p, const artemis_diffusion_
   if (!sums) return fail(ARTEMIS_HIP_EINVAL, "viscous source: null output table");
   if (!p->gas.prim) return fail(ARTEMIS_HIP_EINVAL, "viscous source: gas.prim table is required");
   if (d->visc.type == ARTEMIS_DIFF_OFF) return fail(ARTEMIS_HIP_EINVAL, "viscous source: viscosity is off");
+  if (!d->dist) return fail(ARTEMIS_HIP_EINVAL, "viscous source: the distance table is required (artemis_hip_viscous_distance_fill)");
   const artemis::PackView P = artemis::make_pack_view(*p);
   if (!artemis::viscous_source_covers(P))
     return fail(ARTEMIS_HIP_EUNSUPPORTED, "viscous source: 3-D blocks of one gas species, at least 8 x 8 zones wide (use the flux tasks)");

@@ -9,15 +9,21 @@
 namespace artemis {
 
 // DiffusionCoeff<DIFF>::Get of cell c of block b (also the drag package's damp_to_visc, drag.hpp:240,393); the radial factors come from the host-filled table.
+// Dynamic viscosity with the cell's radial factor already in hand (`rad`: dp.radial[b][c], or 1 where the law has no
+// table): the march kernels fetch it with the cell's primitives, a plane ahead of its use.  `fast`: the caller has
+// checked (wave-wide) that no numerator is tiny, so the refined-reciprocal division returns the bits of `/`.
+ADEV double viscosity_of(const artemis_diffcoeff_t &dp, double gm1, double dens, double sie, double rad, bool fast = false) {
+  if (dp.type == ARTEMIS_VISCOSITY_PLAW) return dp.coeff * dens * rad; // diffusion_coeff.hpp:222-224
+  const double blk = (gm1 + 1.0) * gm1 * dens * sie; // :262-268: alpha B / Omega_K, B = gamma gm1 rho sie (IdealGas)
+  return fast ? div(dp.coeff * blk, rad) : dp.coeff * blk / rad;
+}
 ADEV double coeff_of(const artemis_diffcoeff_t &dp, double cv, double gm1, double dens, double sie, int b,
                      long c) {
   switch (dp.type) {
-  case ARTEMIS_VISCOSITY_PLAW: // diffusion_coeff.hpp:222-224
-    return dp.coeff * dens * (dp.radial ? dp.radial[b][c] : 1.0);
-  case ARTEMIS_VISCOSITY_ALPHA: { // :262-268: alpha B / Omega_K, B = gamma gm1 rho sie (IdealGas)
-    const double blk = (gm1 + 1.0) * gm1 * dens * sie;
-    return dp.coeff * blk / dp.radial[b][c];
-  }
+  case ARTEMIS_VISCOSITY_PLAW:
+    return viscosity_of(dp, gm1, dens, sie, dp.radial ? dp.radial[b][c] : 1.0);
+  case ARTEMIS_VISCOSITY_ALPHA:
+    return viscosity_of(dp, gm1, dens, sie, dp.radial[b][c]);
   default: { // conductivity_plaw :312-316, thermaldiff_plaw :353-359
     // zero exponents (every shipped deck): std::pow(x, 0.0) == 1.0, bit-exact.  Otherwise the power laws of
     // the STATE run on the device's pow(): agreement with a host libm is to rounding, not bitwise.
@@ -75,7 +81,10 @@ __device__ __forceinline__ DiffCell diffusion_cell(const PackView &P, int b, int
 // species n of a cell; v = the stage-input primitive velocity of the cell.  F(d, var, up) = the diffusion flux
 // `var` (3 n + component, or 3 ns + n for the energy) through the cell's lower (up = 0) or upper (up = 1) face
 // of direction d; for an inactive direction the caller returns a finite stand-in (it is multiplied by 0).
-template <class FX>
+// FAST (the march kernels): the seven quotients by geometry -- four by the cell volume, three by the scale factors --
+// through shared refined reciprocals (device_math.hpp: the bits of `/` while no numerator is tiny-but-nonzero); the
+// wave looks at its numerators first and takes the plain divisions if any lane holds such a value.
+template <bool FAST = false, class FX>
 __device__ __forceinline__ void diffusion_update_core(const DiffCell &g, const FX &F, int n, int ns, int do_viscosity,
                                                       double dt, const double v[3], double dm[3], double &de,
                                                       double &deg) {
@@ -91,24 +100,34 @@ __device__ __forceinline__ void diffusion_update_core(const DiffCell &g, const F
            multi_d * dh[1] * 0.5 * (F(1, imx2, 0) + F(1, imx2, 1)) +
            three_d * dh[2] * 0.5 * (F(2, imx3, 0) + F(2, imx3, 1));
   };
+  auto small = [](double x) { return x != 0.0 && fabs(x) < 0x1p-200; }; // (geometry.hpp tiny_nonzero)
   double divfxm = 0., divfym = 0., divfzm = 0.;
+  if (do_viscosity) divfxm = divergence(imx1), divfym = divergence(imx2), divfzm = divergence(imx3);
+  double divfe = divergence(ien);
+  bool fastv = false;
+  Recip rvol{};
+  if constexpr (FAST) {
+    fastv = !__any(small(divfxm) || small(divfym) || small(divfzm) || small(divfe));
+    if (fastv) rvol = recip(g.vol);
+  }
+  auto by_vol = [&](double x) { return (FAST && fastv) ? div(x, rvol) : x / g.vol; };
   if (do_viscosity) {
     const double zero3[3] = {0.0, 0.0, 0.0};
-    divfxm = divergence(imx1);
-    divfxm /= g.vol;
+    divfxm = by_vol(divfxm);
     divfxm += g.x1dep * metric_src(g.dhdx1);
-    divfym = divergence(imx2);
-    divfym /= g.vol;
+    divfym = by_vol(divfym);
     divfym += g.x2dep * metric_src(g.dhdx2);
-    divfzm = divergence(imx3);
-    divfzm /= g.vol;
+    divfzm = by_vol(divfzm);
     divfzm += 0 * metric_src(zero3); // x3dep is false for every system (geometry.hpp:107-110)
   }
-  double divfe = divergence(ien);
-  divfe /= g.vol;
+  divfe = by_vol(divfe);
   dm[0] = dt * divfxm, dm[1] = dt * divfym, dm[2] = dt * divfzm;
   de = dt * divfe;
-  deg = dt * divfe - dt * (divfxm * v[0] / g.hx[0] + divfym * v[1] / g.hx[1] + divfzm * v[2] / g.hx[2]);
+  const double w1 = divfxm * v[0], w2 = divfym * v[1], w3 = divfzm * v[2];
+  bool fasth = false;
+  if constexpr (FAST) fasth = !__any(small(w1) || small(w2) || small(w3));
+  auto by_h = [&](double x, double h) { return (FAST && fasth) ? div(x, h) : x / h; };
+  deg = dt * divfe - dt * (by_h(w1, g.hx[0]) + by_h(w2, g.hx[1]) + by_h(w3, g.hx[2]));
 }
 // ... with the fluxes read from the pack's diffusion-flux arrays at cell c of block b
 __device__ __forceinline__ void diffusion_update_cell(const PackView &P, const DiffCell &g, int b, int n, long c,

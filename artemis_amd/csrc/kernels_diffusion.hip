@@ -258,12 +258,12 @@ struct FaceGeo {
   double ratio[2];
   double mfac[2];
 };
+// ... its metric part (everything but the distances)
 template <int DIR, bool CURV, class GEO>
-ADEV FaceGeo face_geometry(const PackView &P, const GEO &ge, const int b, const int k, const int j, const int i) {
+ADEV FaceGeo face_metric(const PackView &P, const GEO &ge, const int b, const int k, const int j, const int i) {
   const int multid = (P.ndim >= 2), threed = (P.ndim == 3);
   constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1);
   constexpr int d = DIR - 1, t0 = (DIR == 1) ? 1 : 0, t1 = (DIR == 3) ? 1 : 2;
-  const double fuzz = 1e-99; // Fuzz<Real>()
   FaceGeo f;
   f.hxf[0] = f.hxf[1] = f.hxf[2] = 1.0;
   if constexpr (CURV) ge.coords(k, j, i).face_scale(DIR, f.hxf); // h_d at the face centroid
@@ -276,6 +276,23 @@ ADEV FaceGeo face_geometry(const PackView &P, const GEO &ge, const int b, const 
     ge.conn(k - dk, j - dj, i - di, d21, d31, d32);
     f.dh0_m = (DIR == 2) ? d21 : d31, f.dh1_m = (DIR == 3) ? d32 : 0.0;
   }
+  if constexpr (DIR == 1) f.mfac[0] = multid * 0.5, f.mfac[1] = threed * 0.5;
+  else if constexpr (DIR == 2) f.mfac[0] = 0.5, f.mfac[1] = threed * 0.5;
+  else f.mfac[0] = 0.5, f.mfac[1] = 0.5;
+  // (h_t / h_d)^2 at the face centroid: geometry of order one, always the reciprocal form
+  f.ratio[0] = f.ratio[1] = 1.0;
+  if constexpr (CURV) {
+    const QuotF qh(f.hxf[d]);
+    f.ratio[0] = sqr(qh(f.hxf[t0])), f.ratio[1] = sqr(qh(f.hxf[t1]));
+  }
+  f.dxa = f.dxt[0] = f.dxt[1] = f.dxtm[0] = f.dxtm[1] = 1.0; // (the caller's part)
+  return f;
+}
+template <int DIR, bool CURV, class GEO>
+ADEV FaceGeo face_geometry(const PackView &P, const GEO &ge, const int b, const int k, const int j, const int i) {
+  const int multid = (P.ndim >= 2), threed = (P.ndim == 3);
+  const double fuzz = 1e-99; // Fuzz<Real>()
+  FaceGeo f = face_metric<DIR, CURV>(P, ge, b, k, j, i);
   // Coords::Distance between cell centres: geometry only, shared by the species.  dxt / dxtm: across the face's
   // own cell and across its lower neighbour, along the two transverse directions
   f.dxa = ge.template dist_lower<DIR>(k, j, i);
@@ -284,25 +301,16 @@ ADEV FaceGeo face_geometry(const PackView &P, const GEO &ge, const int b, const 
     f.dxtm[0] = multid ? ge.template dist_across<2>(k, j, i - 1) : fuzz;
     f.dxt[1] = threed ? ge.template dist_across<3>(k, j, i) : fuzz;
     f.dxtm[1] = threed ? ge.template dist_across<3>(k, j, i - 1) : fuzz;
-    f.mfac[0] = multid * 0.5, f.mfac[1] = threed * 0.5;
   } else if constexpr (DIR == 2) {
     f.dxt[0] = ge.template dist_across<1>(k, j, i);
     f.dxtm[0] = ge.template dist_across<1>(k, j - 1, i);
     f.dxt[1] = threed ? ge.template dist_across<3>(k, j, i) : fuzz;
     f.dxtm[1] = threed ? ge.template dist_across<3>(k, j - 1, i) : fuzz;
-    f.mfac[0] = 0.5, f.mfac[1] = threed * 0.5;
   } else {
     f.dxt[0] = ge.template dist_across<1>(k, j, i);
     f.dxtm[0] = ge.template dist_across<1>(k - 1, j, i);
     f.dxt[1] = ge.template dist_across<2>(k, j, i);
     f.dxtm[1] = ge.template dist_across<2>(k - 1, j, i);
-    f.mfac[0] = 0.5, f.mfac[1] = 0.5;
-  }
-  // (h_t / h_d)^2 at the face centroid: geometry of order one, always the reciprocal form
-  f.ratio[0] = f.ratio[1] = 1.0;
-  if constexpr (CURV) {
-    const QuotF qh(f.hxf[d]);
-    f.ratio[0] = sqr(qh(f.hxf[t0])), f.ratio[1] = sqr(qh(f.hxf[t1]));
   }
   return f;
 }
@@ -422,7 +430,11 @@ __global__ __launch_bounds__(TX *TY, 4) void viscous_flux3_kernel(const PackView
 //   * every face inside the tile computed once (the lower x1 / x2 faces of each zone go to the neighbour through LDS,
 //     the x3 face is carried along the march), the faces on the tile's upper perimeter by one wave whose turn
 //     rotates with k,
-// with the device functions of the three tasks (viscous_face_core, coeff_of, diffusion_update_core): the same bits
+//   * every global load of a trip -- the primitives and the viscosity law's radial factor two planes ahead, the zone's
+//     six entries of the distance table one plane ahead (neighbours read them from LDS) -- issued at the top of the
+//     trip and consumed after the plane's LDS phases: the first version fetched distances and radial factors where
+//     it needed them, seven exposed memory latencies per plane, and ran at a fifth of the instruction rate,
+// with the device functions of the three tasks (viscous_face_core, viscosity_of, diffusion_update_core): the same bits
 // as ZeroDiffusionFlux -> ViscousFlux -> DiffusionUpdate, without a diffusion-flux array.  HBM per zone: five
 // primitives, the radial factor of the viscosity law and the distance table in, five doubles out.
 // 3-D blocks, one gas species, viscosity only (conduction adds to the same energy flux and keeps the flux arrays).
@@ -432,6 +444,7 @@ struct VsArgs {
   const double *dt_ptr;
   double *const *out; // [nblocks * 5]: what DiffusionUpdate subtracts from M1, M2, M3, E and e_int
   int nti, ntj, nchunk, kchunk;
+  int abl; // timing experiments (ARTEMIS_VS_ABL; results wrong by construction): 1 no barriers, 2 no distance loads, 4 no faces, 8 no ring duty
 };
 template <int VTX>
 struct VsTile {
@@ -440,57 +453,58 @@ struct VsTile {
   double S[3][3][SY][SX];               // [plane mod 3][component]: contravariant velocities
   double DV[2][SY][SX], MU[2][SY][SX];  // [plane mod 2]: tile + the ring of its face neighbours
   double FX[4][VTY][VTX + 1], FY[4][VTY + 1][VTX]; // lower x1 / x2 faces: 3 momentum fluxes + the energy flux
+  double DA[3][VTY][VTX];               // Distance across the zone along x1, x2, x3 (plane k), for the neighbours
 };
-struct Vel5 {
-  double d, v1, v2, v3, e;
+struct Vel6 {
+  double d, v1, v2, v3, e, rad;
 };
-// What face_geometry asks of a block's geometry, answered from the workgroup's LDS tables (geometry.hpp GeoTabs: the
-// staged rectangle's columns and rows) instead of per-thread registers; distances from the host's table, or on the fly
-template <bool CURV, int NX, int NY>
+// What face_metric / face_geometry ask of a block's geometry, answered from the workgroup's LDS tables (geometry.hpp
+// GeoTabs: the staged rectangle's columns and rows) instead of per-thread registers (the distances the march reads
+// from the host's table itself, a plane ahead)
+template <int SYS, int NX, int NY>
 struct TileGeo {
+  static constexpr bool CURV = (SYS != ARTEMIS_CARTESIAN);
   const PackView &P;
   const int b, ibase, jbase;
   const GeoTabs<NX, NY> &G;
-  const double *dtab;
   ADEV int col(int i) const { return min(max(i - ibase, 0), NX - 1); }
   ADEV int row(int j) const { return min(max(j - jbase, 0), NY - 1); }
   ADEV DCoordsT<true> coords(int k, int j, int i) const {
-    return geotabs_coords(G, P.coords, P.geom + 6 * b, col(i), row(j), k, 1.0, 0.0); // (nothing here reads c3 / s3)
+    // SYS is a compile-time constant: every switch on the coordinate system inside Coords folds away
+    return geotabs_coords(G, SYS, P.geom + 6 * b, col(i), row(j), k, 1.0, 0.0); // (nothing here reads c3 / s3)
   }
   ADEV void conn(int, int j, int i, double &d21, double &d31, double &d32) const {
     d21 = d31 = d32 = 0.0;
     if constexpr (CURV) d21 = G.gi[GI_DH2][col(i)], d31 = G.gi[GI_DH3][col(i)], d32 = G.gj[GJ_DH32][row(j)];
   }
-  template <int DIR>
-  ADEV double dist_lower(int k, int j, int i) const {
-    if (dtab) return fused::gld(dtab + (static_cast<long>(DIR - 1) * P.nb + b) * (static_cast<long>(P.ni) * P.nj * P.nk),
-                                static_cast<unsigned>((k * P.nj + j) * P.ni + i));
-    return Geo<CURV>{P, b}.template dist_lower<DIR>(k, j, i);
-  }
-  template <int DIR>
-  ADEV double dist_across(int k, int j, int i) const {
-    if (dtab) return fused::gld(dtab + (static_cast<long>(2 + DIR) * P.nb + b) * (static_cast<long>(P.ni) * P.nj * P.nk),
-                                static_cast<unsigned>((k * P.nj + j) * P.ni + i));
-    return Geo<CURV>{P, b}.template dist_across<DIR>(k, j, i);
-  }
 };
-ADEV Vel5 load5(double *const *prim, int b, unsigned c) {
-  Vel5 q;
+ADEV Vel6 load6(double *const *prim, const double *radial, int b, unsigned c) {
+  Vel6 q;
   q.d = fused::gld(prim[b * 6 + 0], c), q.v1 = fused::gld(prim[b * 6 + 1], c), q.v2 = fused::gld(prim[b * 6 + 2], c);
   q.v3 = fused::gld(prim[b * 6 + 3], c), q.e = fused::gld(prim[b * 6 + 5], c);
+  q.rad = radial ? fused::gld(radial, c) : 1.0;
   return q;
 }
 #ifndef VS_OCC
 #define VS_OCC 2
 #endif
-template <bool CURV, int VTX>
+// SYS: the coordinate system as a template constant -- the march is instruction-bound, and with a run-time system the
+// Coords members compile to a six-way branch each (the first build of this kernel: 14 700 instructions, half of them
+// scalar branches); the per-task kernels keep the run-time switch, they wait for memory anyway.
+template <int SYS, int VTX>
 __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackView P, const VsArgs a) {
+  constexpr bool CURV = (SYS != ARTEMIS_CARTESIAN);
   using T = VsTile<VTX>;
   constexpr int VTY = T::VTY, QX = T::QX, QY = T::QY;
   __shared__ T L;
   __shared__ GeoTabs<QX, QY> GT;
   const int t = threadIdx.x, tx = t % VTX, ty = t / VTX;
   int id = blockIdx.x;
+  { // workgroup ids are dealt round-robin over the 8 XCDs: give each XCD's L2 one contiguous run of tiles (the halo
+    // columns and the 128-byte lines a row segment straddles are then fetched from HBM once, not once per XCD)
+    const int n = static_cast<int>(gridDim.x), q = n >> 3, rem = n & 7, xcd = id & 7;
+    id = xcd * q + min(xcd, rem) + (id >> 3);
+  }
   const int ti = id % a.nti;
   id /= a.nti;
   const int tj = id % a.ntj;
@@ -506,20 +520,28 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
   const unsigned col = static_cast<unsigned>(jl) * sj + static_cast<unsigned>(il);
   double *const *prim = P.gas.prim;
   const artemis_diffcoeff_t &dp = a.D.visc;
+  const double *radial = dp.radial ? dp.radial[b] : nullptr;
   const double dt = a.dt_ptr ? *a.dt_ptr : a.dt;
-  const TileGeo<CURV, QX, QY> ge{P, b, i0 - 2, j0 - 2, GT, a.D.dist};
+  const TileGeo<SYS, QX, QY> ge{P, b, i0 - 2, j0 - 2, GT};
   geotabs_fill(GT, P, b, i0 - 2, j0 - 2, t);
   __syncthreads();
+  // the distance table: [6][nb][N]; q = 0..2 to the lower neighbour along x1, x2, x3, q = 3..5 across the zone
+  const long NN = static_cast<long>(P.ni) * P.nj * P.nk;
+  const double *dtab = a.D.dist + static_cast<long>(b) * NN; // (required: launch_viscous_source's caller checks)
+  const long dq = static_cast<long>(P.nb) * NN;
   // the halo zone this thread stages (every plane of the march), its place in the staged rectangle and its duties
-  constexpr int NH = QX * QY - 256;
+  // numbering: the ring of the tile's face neighbours first (2 VTX + 2 VTY zones: they also carry a divergence and a
+  // viscosity), the four corners of the one-zone frame, then the outer frame -- so the duties end on a wave boundary
+  // early (32 x 8: ring in waves 0 and 1; 16 x 16: wave 0)
+  constexpr int NH = QX * QY - 256, NRING = 2 * VTX + 2 * VTY, NS1 = NRING + 4;
   int hr = -1, hc = -1;
-  if (t < NH) {
-    if (t < 2 * QX) hr = t / QX, hc = t % QX;
-    else if (t < 4 * QX) hr = VTY + 2 + (t - 2 * QX) / QX, hc = (t - 2 * QX) % QX;
-    else {
-      const int u = t - 4 * QX, cc = u & 3;
-      hr = 2 + (u >> 2), hc = (cc < 2) ? cc : VTX + cc;
-    }
+  if (t < 2 * VTX) hr = (t < VTX) ? 1 : QY - 2, hc = 2 + t % VTX;
+  else if (t < NRING) hc = ((t - 2 * VTX) < VTY) ? 1 : QX - 2, hr = 2 + (t - 2 * VTX) % VTY;
+  else if (t < NS1) hr = ((t - NRING) & 1) ? QY - 2 : 1, hc = ((t - NRING) & 2) ? QX - 2 : 1;
+  else if (t < NH) {
+    const int u = t - NS1; // outer frame: rows 0 and QY - 1 (QX zones each), columns 0 and QX - 1 (rows 1 .. QY - 2)
+    if (u < 2 * QX) hr = (u < QX) ? 0 : QY - 1, hc = u % QX;
+    else hc = ((u - 2 * QX) < QY - 2) ? 0 : QX - 1, hr = 1 + (u - 2 * QX) % (QY - 2);
   }
   const bool h_any = hr >= 0;
   const int gi = min(max(i0 - 2 + hc, 0), P.ni - 1), gj = min(max(j0 - 2 + hr, 0), P.nj - 1);
@@ -527,7 +549,6 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
   const bool h_s = h_any && hr >= 1 && hr <= QY - 2 && hc >= 1 && hc <= QX - 2; // within one zone of the tile
   const bool h_ring = h_any && (((hr == 1 || hr == QY - 2) && hc >= 2 && hc <= QX - 3) ||
                                 ((hc == 1 || hc == QX - 2) && hr >= 2 && hr <= QY - 3)); // a face neighbour of the tile
-  // volume-averaged scale factors of the own and of the halo zone (no x3 dependence in any system)
   auto contravariant = [&](const double v[3], int jj, int ii, double s[3]) { // viscous_cell_kernel's quotients
     if constexpr (!CURV) {
       s[0] = v[0], s[1] = v[1], s[2] = v[2];
@@ -551,32 +572,81 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
     const double vol2 = 2.0 * m.vol;
     return __any(tiny_nonzero(divv)) ? divv / vol2 : div(divv, vol2);
   };
-  // rolling state of the own column and of the halo column: planes k (velocities), k + 1, k + 2
-  Vel5 rn = load5(prim, b, col + static_cast<unsigned>(k0 - 1) * sk), hn = rn;
-  double vc[3] = {0.0, 0.0, fused::gld(prim[b * 6 + 3], col + static_cast<unsigned>(k0 - 2) * sk)}, h3c = 0.0;
-  if (h_any) hn = load5(prim, b, hcol + static_cast<unsigned>(k0 - 1) * sk), h3c = fused::gld(prim[b * 6 + 3], hcol + static_cast<unsigned>(k0 - 2) * sk);
+  auto viscosity = [&](const Vel6 &q) { // (alpha law: one quotient by the radial factor; tiny numerators take `/`)
+    const bool odd = dp.type == ARTEMIS_VISCOSITY_ALPHA && tiny_nonzero(q.d * q.e);
+    return viscosity_of(dp, P.gm1, q.d, q.e, q.rad, !__any(odd));
+  };
+  // Rolling state.  Nothing a trip loads is consumed in that trip: the own / halo zone's primitives arrive one plane
+  // before they are staged (the x3 velocity two planes before: it closes the divergence of the plane below), the
+  // distances one trip before the faces that use them.
+  const int kmax = P.nk - 1;
+  auto plane = [&](int kk) { return static_cast<unsigned>(min(max(kk, 0), kmax)) * sk; };
+  Vel6 rn = load6(prim, radial, b, col + plane(k0 - 1)), hn = rn;
+  double vc[3] = {0.0, 0.0, fused::gld(prim[b * 6 + 3], col + plane(k0 - 2))}, h3c = 0.0;
+  double v3n2 = fused::gld(prim[b * 6 + 3], col + plane(k0)), h3n2 = 0.0; // x3 velocity of plane k + 2
+  if (h_any) {
+    hn = load6(prim, radial, b, hcol + plane(k0 - 1));
+    h3c = fused::gld(prim[b * 6 + 3], hcol + plane(k0 - 2)), h3n2 = fused::gld(prim[b * 6 + 3], hcol + plane(k0));
+  }
   double dv_c = 0.0, mu_c = 0.0;
   double f3lo[4] = {0.0, 0.0, 0.0, 0.0};
+  // the own zone's distances: plane k (to the lower x1 / x2 neighbour, across the zone along x1, x2, x3) and what the x3
+  // face above it needs of plane k + 1 (to the lower x3 neighbour, across along x1 and x2)
+  double dl1 = 1.0, dl2 = 1.0, da1 = 1.0, da2 = 1.0, da3 = 1.0;
+  double ul3 = 1.0, ua1 = 1.0, ua2 = 1.0;
+  if (!(a.abl & 2)) {
+    const unsigned c1 = col + plane(k0 - 1);
+    ul3 = fused::gld(dtab + 2 * dq, c1), ua1 = fused::gld(dtab + 3 * dq, c1), ua2 = fused::gld(dtab + 4 * dq, c1);
+  }
+  double nb0 = 1.0, nb1 = 1.0, nb2 = 1.0, nb3 = 1.0; // across the lower neighbours just outside the tile (edge lanes), plane k
+  double dd0 = 1.0, dd1 = 1.0, dd2 = 1.0;            // this trip's perimeter duty: to the lower neighbour, across x2|x1, across x3
   for (int k = k0 - 2; k <= k1; ++k) {
-    // this trip's loads first (plane k + 2: its x3 velocity closes the divergence of plane k + 1)
-    const unsigned cnn = static_cast<unsigned>(min(k + 2, P.nk - 1)) * sk;
-    const Vel5 rnn = load5(prim, b, col + cnn);
-    Vel5 hnn = rnn;
-    if (h_any) hnn = load5(prim, b, hcol + cnn);
+    const bool live = k >= k0; // (wave-uniform) faces of plane k are formed
+    // ---- this trip's global loads, all of them, first -------------------------------------------------------------
+    Vel6 rnn = load6(prim, radial, b, col + plane(k + 2)); // (its v3 slot is replaced by the value fetched a trip ago)
+    const double v3n3 = fused::gld(prim[b * 6 + 3], col + plane(k + 3));
+    Vel6 hnn = rnn;
+    double h3n3 = v3n3;
+    if (h_any) hnn = load6(prim, radial, b, hcol + plane(k + 2)), h3n3 = fused::gld(prim[b * 6 + 3], hcol + plane(k + 3));
+    const unsigned cn1 = col + static_cast<unsigned>(k + 1) * sk, cn2 = col + plane(k + 2);
+    double nl1 = 1.0, nl2 = 1.0, na3 = 1.0;  // plane k + 1: for the next trip's x1 / x2 faces
+    double wl3 = 1.0, wa1 = 1.0, wa2 = 1.0;  // plane k + 2: for the next trip's x3 face
+    // ... and what the NEXT trip's faces need from outside the tile, so that no load is waited for in the trip that
+    // issues it: across the lower x1 (tx == 0) / x2 (ty == 0) neighbour, and the perimeter duty's own three distances
+    double nnb0 = 1.0, nnb1 = 1.0, nnb2 = 1.0, nnb3 = 1.0, ndd0 = 1.0, ndd1 = 1.0, ndd2 = 1.0;
+    const int duty = (t + 64 * (k & 3)) & 255, dutyn = (t + 64 * ((k + 1) & 3)) & 255;
+    const bool duty1 = live && duty < VTY, duty2 = live && duty >= 64 && duty < 64 + VTX;
+    const int dj1 = min(j0 + duty, P.nj - 1), di1 = min(i0 + VTX, P.ni - 1);        // the x1 face of zone (j0 + duty, i0 + VTX)
+    const int dj2 = min(j0 + VTY, P.nj - 1), di2 = min(i0 + (duty - 64), P.ni - 1); // the x2 face of zone (j0 + VTY, i0 + duty - 64)
+    if (!(a.abl & 2)) {
+      nl1 = fused::gld(dtab, cn1), nl2 = fused::gld(dtab + dq, cn1), na3 = fused::gld(dtab + 5 * dq, cn1);
+      wl3 = fused::gld(dtab + 2 * dq, cn2), wa1 = fused::gld(dtab + 3 * dq, cn2), wa2 = fused::gld(dtab + 4 * dq, cn2);
+      if (k + 1 >= k0 && k < k1) { // (trip k + 1 forms faces)
+        if (tx == 0) nnb0 = fused::gld(dtab + 4 * dq, cn1 - 1), nnb1 = fused::gld(dtab + 5 * dq, cn1 - 1);
+        if (ty == 0) nnb2 = fused::gld(dtab + 3 * dq, cn1 - sj), nnb3 = fused::gld(dtab + 5 * dq, cn1 - sj);
+        if (dutyn < VTY) {
+          const unsigned cd = static_cast<unsigned>(((k + 1) * P.nj + min(j0 + dutyn, P.nj - 1)) * P.ni + di1);
+          ndd0 = fused::gld(dtab, cd), ndd1 = fused::gld(dtab + 4 * dq, cd), ndd2 = fused::gld(dtab + 5 * dq, cd);
+        } else if (dutyn >= 64 && dutyn < 64 + VTX) {
+          const unsigned cd = static_cast<unsigned>(((k + 1) * P.nj + dj2) * P.ni + min(i0 + (dutyn - 64), P.ni - 1));
+          ndd0 = fused::gld(dtab + dq, cd), ndd1 = fused::gld(dtab + 3 * dq, cd), ndd2 = fused::gld(dtab + 5 * dq, cd);
+        }
+      }
+    }
     const int pn = (k + 1 + 3) % 3, pc = (k + 3) % 3, pm = (k + 2) % 3; // ring slots of planes k + 1, k, k - 1
     const int dn = (k + 1) & 1, dc = k & 1;
-    const unsigned cn1 = col + static_cast<unsigned>(k + 1) * sk;
-    // ---- (a) stage plane k + 1: primitive and contravariant velocities ------------------------------------------
+    // ---- (a) stage plane k + 1: primitive and contravariant velocities; the zone's distances of plane k ------------
     {
       const double v[3] = {rn.v1, rn.v2, rn.v3};
       double s[3];
       contravariant(v, jl, il, s);
       for (int m = 0; m < 3; ++m) L.V[m][ty + 2][tx + 2] = v[m], L.S[pn][m][ty + 1][tx + 1] = s[m];
+      L.DA[0][ty][tx] = da1, L.DA[1][ty][tx] = da2, L.DA[2][ty][tx] = da3;
       if (h_any) {
         const double w[3] = {hn.v1, hn.v2, hn.v3};
         for (int m = 0; m < 3; ++m) L.V[m][hr][hc] = w[m];
       }
-      if (t < 192) { // (waves 0..2 hold every halo thread: keep the wave-uniform division choice inside them)
+      if (t < ((NS1 + 63) & ~63)) { // (whole waves: the division choice is wave-uniform)
         const double w[3] = {hn.v1, hn.v2, hn.v3};
         double sh[3];
         contravariant(w, gj, gi, sh);
@@ -584,23 +654,16 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
           for (int m = 0; m < 3; ++m) L.S[pn][m][hr - 1][hc - 1] = sh[m];
       }
     }
-    __syncthreads();
-    // ---- (b) VelocityDivergence and viscosity of plane k + 1: own zone, ring zones ------------------------------
-    const double dv_n = divergence(k + 1, jl, il, ty + 2, tx + 2, vc[2], rn.v3, rnn.v3);
-    const double mu_n = coeff_of(dp, a.D.cv, P.gm1, rn.d, rn.e, b, static_cast<long>(cn1));
-    L.DV[dn][ty + 1][tx + 1] = dv_n, L.MU[dn][ty + 1][tx + 1] = mu_n;
-    if (t < 192) {
-      const int qr = h_ring ? hr : 2, qc = h_ring ? hc : 2;
-      const double dvh = divergence(k + 1, gj, gi, qr, qc, h3c, hn.v3, hnn.v3);
-      const double muh = coeff_of(dp, a.D.cv, P.gm1, hn.d, hn.e, b, static_cast<long>(hcol + static_cast<unsigned>(k + 1) * sk));
-      if (h_ring) L.DV[dn][hr - 1][hc - 1] = dvh, L.MU[dn][hr - 1][hc - 1] = muh;
-    }
-    // ---- (c) faces ------------------------------------------------------------------------------------------------
-    // the stress rows of the lower DIR face of the zone at (row sy, column sx) of the S rectangle, block indices (kk, jj, ii)
-    auto face12 = [&](auto DIRTAG, int sy, int sx, int jj, int ii, bool valid, double fl[3], double &fe) {
+    if (!(a.abl & 1)) __syncthreads();
+    // ---- (c) faces of plane k ----------------------------------------------------------------------------------------
+    // the stress rows of the lower DIR face of the zone at (row sy, column sx) of the S rectangle, block indices (k, jj, ii);
+    // d5 = {to the lower neighbour, across the zone / across the lower neighbour along the first transverse direction,
+    // the same along x3}
+    auto face12 = [&](auto DIRTAG, int sy, int sx, int jj, int ii, bool valid, const double d5[5], double fl[3], double &fe) {
       constexpr int DIR = decltype(DIRTAG)::value;
       constexpr int dy = (DIR == 2), dx = (DIR == 1), nc = DIR - 1;
-      const FaceGeo fg = face_geometry<DIR, CURV>(P, ge, b, k, jj, ii);
+      FaceGeo fg = face_metric<DIR, CURV>(P, ge, b, k, jj, ii);
+      fg.dxa = d5[0], fg.dxt[0] = d5[1], fg.dxtm[0] = d5[2], fg.dxt[1] = d5[3], fg.dxtm[1] = d5[4];
       FaceIn q;
       for (int m = 0; m < 3; ++m) q.s_c[m] = L.S[pc][m][sy][sx], q.s_m[m] = L.S[pc][m][sy - dy][sx - dx];
       // transverse directions: (x2, x3) for an x1 face, (x1, x3) for an x2 face
@@ -612,9 +675,49 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
       q.divu = L.DV[dc][sy][sx], q.divu_m = L.DV[dc][sy - dy][sx - dx];
       viscous_face_core<DIR>(fg, q, dp.avg, dp.eta, fl, fe, valid);
     };
+    if (live && !(a.abl & 4)) {
+      {
+        const double d5[5] = {dl1, da2, (tx == 0) ? nb0 : L.DA[1][ty][max(tx - 1, 0)], da3, (tx == 0) ? nb1 : L.DA[2][ty][max(tx - 1, 0)]};
+        double fl[4];
+        face12(std::integral_constant<int, 1>{}, ty + 1, tx + 1, jl, il, facev, d5, fl, fl[3]);
+        for (int m = 0; m < 4; ++m) L.FX[m][ty][tx] = fl[m];
+      }
+      {
+        const double d5[5] = {dl2, da1, (ty == 0) ? nb2 : L.DA[0][max(ty - 1, 0)][tx], da3, (ty == 0) ? nb3 : L.DA[2][max(ty - 1, 0)][tx]};
+        double fl[4];
+        face12(std::integral_constant<int, 2>{}, ty + 1, tx + 1, jl, il, facev, d5, fl, fl[3]);
+        for (int m = 0; m < 4; ++m) L.FY[m][ty][tx] = fl[m];
+      }
+      // the tile's upper perimeter: the x1 faces of column i0 + VTX on one wave, the x2 faces of row j0 + VTY on the
+      // next; the turn rotates with k
+      if (duty1) {
+        const double d5[5] = {dd0, dd1, L.DA[1][duty][VTX - 1], dd2, L.DA[2][duty][VTX - 1]};
+        double fl[4];
+        face12(std::integral_constant<int, 1>{}, duty + 1, VTX + 1, dj1, di1, (j0 + duty <= P.je) && (i0 + VTX <= P.ie + 1), d5, fl, fl[3]);
+        for (int m = 0; m < 4; ++m) L.FX[m][duty][VTX] = fl[m];
+      } else if (duty2) {
+        const int u = duty - 64;
+        const double d5[5] = {dd0, dd1, L.DA[0][VTY - 1][u], dd2, L.DA[2][VTY - 1][u]};
+        double fl[4];
+        face12(std::integral_constant<int, 2>{}, VTY + 1, u + 1, dj2, di2, (i0 + u <= P.ie) && (j0 + VTY <= P.je + 1), d5, fl, fl[3]);
+        for (int m = 0; m < 4; ++m) L.FY[m][VTY][u] = fl[m];
+      }
+    }
+    // ---- (b) VelocityDivergence and viscosity of plane k + 1: own zone, ring zones ------------------------------
+    const double dv_n = divergence(k + 1, jl, il, ty + 2, tx + 2, vc[2], rn.v3, v3n2);
+    const double mu_n = viscosity(rn);
+    L.DV[dn][ty + 1][tx + 1] = dv_n, L.MU[dn][ty + 1][tx + 1] = mu_n;
+    if (t < ((NRING + 63) & ~63) && !(a.abl & 8)) {
+      const int qr = h_ring ? hr : 2, qc = h_ring ? hc : 2;
+      const double dvh = divergence(k + 1, gj, gi, qr, qc, h3c, hn.v3, h3n2);
+      const double muh = viscosity(hn);
+      if (h_ring) L.DV[dn][hr - 1][hc - 1] = dvh, L.MU[dn][hr - 1][hc - 1] = muh;
+    }
+    // ---- the x3 face between planes k and k + 1 (the lower face of zone k + 1): registers + the ring ----------------
     double f3hi[4] = {0.0, 0.0, 0.0, 0.0};
-    if (k >= k0 - 1) { // the x3 face between planes k and k + 1 (the lower face of zone k + 1), registers + the ring
-      const FaceGeo fg = face_geometry<3, CURV>(P, ge, b, k + 1, jl, il);
+    if (k >= k0 - 1) {
+      FaceGeo fg = face_metric<3, CURV>(P, ge, b, k + 1, jl, il);
+      fg.dxa = ul3, fg.dxt[0] = ua1, fg.dxtm[0] = da1, fg.dxt[1] = ua2, fg.dxtm[1] = da2;
       FaceIn q;
       const int sy = ty + 1, sx = tx + 1;
       for (int m = 0; m < 3; ++m) q.s_c[m] = L.S[pn][m][sy][sx], q.s_m[m] = L.S[pc][m][sy][sx];
@@ -625,36 +728,9 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
       q.mu1 = mu_n, q.mu2 = mu_c, q.divu = dv_n, q.divu_m = dv_c;
       viscous_face_core<3>(fg, q, dp.avg, dp.eta, f3hi, f3hi[3], active);
     }
-    if (k >= k0) {
-      {
-        double fl[4];
-        face12(std::integral_constant<int, 1>{}, ty + 1, tx + 1, jl, il, facev, fl, fl[3]);
-        for (int m = 0; m < 4; ++m) L.FX[m][ty][tx] = fl[m];
-      }
-      {
-        double fl[4];
-        face12(std::integral_constant<int, 2>{}, ty + 1, tx + 1, jl, il, facev, fl, fl[3]);
-        for (int m = 0; m < 4; ++m) L.FY[m][ty][tx] = fl[m];
-      }
-      // the tile's upper perimeter: the x1 faces of column i0 + VTX on one wave, the x2 faces of row j0 + VTY on the
-      // next; the turn rotates with k
-      const int duty = (t + 64 * (k & 3)) & 255;
-      if (duty < VTY) {
-        const int jj = min(j0 + duty, P.nj - 1), ii = min(i0 + VTX, P.ni - 1);
-        double fl[4];
-        face12(std::integral_constant<int, 1>{}, duty + 1, VTX + 1, jj, ii, (j0 + duty <= P.je) && (i0 + VTX <= P.ie + 1), fl, fl[3]);
-        for (int m = 0; m < 4; ++m) L.FX[m][duty][VTX] = fl[m];
-      } else if (duty >= 64 && duty < 64 + VTX) {
-        const int u = duty - 64;
-        const int jj = min(j0 + VTY, P.nj - 1), ii = min(i0 + u, P.ni - 1);
-        double fl[4];
-        face12(std::integral_constant<int, 2>{}, VTY + 1, u + 1, jj, ii, (i0 + u <= P.ie) && (j0 + VTY <= P.je + 1), fl, fl[3]);
-        for (int m = 0; m < 4; ++m) L.FY[m][VTY][u] = fl[m];
-      }
-    }
-    __syncthreads();
+    if (!(a.abl & 1)) __syncthreads();
     // ---- (d) DiffusionUpdate's sums of zone k (diffusion.hpp:110-241) -----------------------------------------------
-    if (k >= k0 && active) {
+    if (live && active) {
       double F[3][2][4];
       for (int m = 0; m < 4; ++m) {
         F[0][0][m] = 0.0 + L.FX[m][ty][tx], F[0][1][m] = 0.0 + L.FX[m][ty][tx + 1];
@@ -667,15 +743,19 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
       const DiffCell g = diffusion_cell_of(co, cell_metric_of(co), hx, 3);
       double dm[3], de, deg;
       auto FF = [&](int d, int var, int u) { return F[d][u][var]; };
-      diffusion_update_core(g, FF, 0, 1, 1, dt, vc, dm, de, deg);
+      diffusion_update_core<true>(g, FF, 0, 1, 1, dt, vc, dm, de, deg);
       const unsigned c = col + static_cast<unsigned>(k) * sk;
       fused::gst(a.out[b * 5 + 0], c, dm[0]), fused::gst(a.out[b * 5 + 1], c, dm[1]), fused::gst(a.out[b * 5 + 2], c, dm[2]);
       fused::gst(a.out[b * 5 + 3], c, de), fused::gst(a.out[b * 5 + 4], c, deg);
     }
-    vc[0] = rn.v1, vc[1] = rn.v2, vc[2] = rn.v3, rn = rnn;
-    h3c = hn.v3, hn = hnn;
+    vc[0] = rn.v1, vc[1] = rn.v2, vc[2] = rn.v3;
+    rn = rnn, rn.v3 = v3n2, v3n2 = v3n3;
+    h3c = hn.v3, hn = hnn, hn.v3 = h3n2, h3n2 = h3n3;
     dv_c = dv_n, mu_c = mu_n;
     for (int m = 0; m < 4; ++m) f3lo[m] = f3hi[m];
+    dl1 = nl1, dl2 = nl2, da1 = ua1, da2 = ua2, da3 = na3;
+    ul3 = wl3, ua1 = wa1, ua2 = wa2;
+    nb0 = nnb0, nb1 = nnb1, nb2 = nnb2, nb3 = nnb3, dd0 = ndd0, dd1 = ndd1, dd2 = ndd2;
   }
 }
 
@@ -872,6 +952,7 @@ int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStre
 bool viscous_source_covers(const PackView &P) {
   if (getenv("ARTEMIS_NO_VISC_SOURCE")) return false;
   if (P.ndim != 3 || P.gas.ns != 1 || P.ng < 2) return false;
+  if (P.coords == ARTEMIS_SPHERICAL1D || P.coords == ARTEMIS_SPHERICAL2D) return false; // (never 3-D blocks)
   if (static_cast<long>(P.nk) * P.nj * P.ni >= (1L << 29)) return false;
   return (P.ie - P.is + 1) >= 8 && (P.je - P.js + 1) >= 8;
 }
@@ -879,6 +960,7 @@ void launch_viscous_source(const PackView &P, const artemis_diffusion_t &D, doub
                            hipStream_t s) {
   VsArgs a;
   a.D = D, a.dt = dt, a.dt_ptr = dt_dev, a.out = out;
+  a.abl = getenv("ARTEMIS_VS_ABL") ? atoi(getenv("ARTEMIS_VS_ABL")) : 0;
   const int nx = P.ie - P.is + 1, ny = P.je - P.js + 1, nz = P.ke - P.ks + 1;
   // tile shape: 32 x 8, or 16 x 16 where a 32-zone row would leave half the lanes without a zone (16-zone blocks)
   const bool narrow = (nx % 32 != 0) && (nx % 16 == 0 || nx < 32);
@@ -889,18 +971,23 @@ void launch_viscous_source(const PackView &P, const artemis_diffusion_t &D, doub
   int kch = 32;
   if (const char *e = getenv("ARTEMIS_VISC_KCHUNK")) kch = std::max(1, atoi(e));
   else
-    while (kch > 8 && tiles * ((nz + kch - 1) / kch) < 1024) kch >>= 1;
+    while (kch > 8 && tiles * ((nz + kch - 1) / kch) < 512) kch >>= 1; // (512 = the slots of the chip at two workgroups per CU)
   a.nchunk = (nz + kch - 1) / kch, a.kchunk = (nz + a.nchunk - 1) / a.nchunk;
   a.nchunk = (nz + a.kchunk - 1) / a.kchunk;
   const dim3 grid(static_cast<unsigned>(tiles * a.nchunk)), block(256);
-  const bool curv = P.coords != ARTEMIS_CARTESIAN;
-  if (curv) {
-    if (narrow) hipLaunchKernelGGL((viscous_source_kernel<true, 16>), grid, block, 0, s, P, a);
-    else hipLaunchKernelGGL((viscous_source_kernel<true, 32>), grid, block, 0, s, P, a);
-  } else {
-    if (narrow) hipLaunchKernelGGL((viscous_source_kernel<false, 16>), grid, block, 0, s, P, a);
-    else hipLaunchKernelGGL((viscous_source_kernel<false, 32>), grid, block, 0, s, P, a);
+#define VS_GO(SYS)                                                                                 \
+  case SYS:                                                                                       \
+    if (narrow) hipLaunchKernelGGL((viscous_source_kernel<SYS, 16>), grid, block, 0, s, P, a);    \
+    else hipLaunchKernelGGL((viscous_source_kernel<SYS, 32>), grid, block, 0, s, P, a);           \
+    break;
+  switch (P.coords) {
+    VS_GO(ARTEMIS_CARTESIAN)
+    VS_GO(ARTEMIS_CYLINDRICAL)
+    VS_GO(ARTEMIS_SPHERICAL3D)
+    VS_GO(ARTEMIS_AXISYMMETRIC)
+  default: break;
   }
+#undef VS_GO
 }
 void launch_thermal_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s) {
   LAUNCH_DIR(thermal_flux_kernel, 1);

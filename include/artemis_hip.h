@@ -469,6 +469,7 @@ int artemis_hip_diffusion_update(const artemis_pack_t *p, const artemis_diffusio
  * LDS-staged march, with the expression trees of the three tasks: the bits DiffusionUpdate would subtract after
  * ZeroDiffusionFlux -> ViscousFlux, but no diffusion-flux array is read or written (twelve stores and twenty-four
  * loads per zone and stage less).  Hand the result to artemis_hip_stage_general as `diffusion_sums`.
+ *   d->dist     : REQUIRED here (artemis_hip_viscous_distance_fill): the march reads the table a plane ahead of its use
  *   dt / dt_dev : beta * dt of the stage (dt_dev: optional DEVICE scalar that replaces dt)
  *   sums        : DEVICE table [nblocks * 5] of cell arrays (entire-block extents; only active zones are written)
  * artemis_hip_viscous_source_covers: non-zero when the march covers the pack (3-D blocks at least 8 x 8 zones wide,
