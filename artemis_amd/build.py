@@ -20,7 +20,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", 
              "-Wall", "-Wno-unused-function"]
 
 HIP_SOURCES = ["abi.hip", "kernels_unfused.hip", "kernels_fused.hip", "kernels_sources.hip", "kernels_stage_cell.hip",
-               "kernels_diffusion.hip", "kernels_refine.hip", "kernels_amr.hip", "kernels_stage2d.hip",
+               "kernels_diffusion.hip", "kernels_refine.hip", "kernels_amr.hip", "kernels_stage2d.hip", "kernels_curv.hip",
                "selftest.hip"]
 
 

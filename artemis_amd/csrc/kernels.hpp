@@ -44,6 +44,9 @@ int launch_flux_fused(const PackView &P, int riemann, int recon, hipStream_t s);
 bool fused_curv_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas);
 void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
                              hipStream_t s);
+// kernels_curv.hip
+bool curv_march_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas);
+void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas, hipStream_t s);
 // kernels_diffusion.hip
 void launch_zero_diffusion_flux(const PackView &P, hipStream_t s);
 // overwrite: ZeroDiffusionFlux folded in (the flux arrays are overwritten on the face ranges)

@@ -636,8 +636,10 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
     launch_stage2d(P, g, recon_gas, riemann_gas, riemann_dust, s);
     return;
   }
-  if (variant == 2) { // curvilinear gas: the streaming tile kernel with the geometry in registers
-    launch_stage_fused_curv(P, g, recon_gas, riemann_gas, s);
+  if (variant == 2) { // curvilinear gas: the streaming tile march with its geometry in LDS tables (kernels_curv.hip), or
+    // -- diffusion from stored flux arrays -- the older instantiation with the geometry in registers
+    if (curv_march_covers(P, g, recon_gas)) launch_stage_curv(P, g, recon_gas, riemann_gas, s);
+    else launch_stage_fused_curv(P, g, recon_gas, riemann_gas, s);
     return;
   }
   CellStageArgs a = cell_args(P, g);
