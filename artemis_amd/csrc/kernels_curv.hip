@@ -355,9 +355,10 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     if (a.grav_on) gravity_gas(gravity_accel(a.grav, co, P.ndim, dt), dt, hx, w, u0);
     if (a.rfc_on) { // sources_device.hpp rotating_frame_gas on the folded sums
       const RotFrame rfc = rotating_frame_terms(co, a.rf_omega, dt);
-      u0.m1 -= rfc.omdt * (s.rfd / cm.vol) * rfc.ep[0];
-      u0.m2 -= rfc.omdt * (s.rfd / cm.vol) * rfc.ep[1];
-      u0.m3 -= rfc.omdt * (s.rfd / cm.vol) * rfc.ep[2];
+      const double qv = __any(tiny_nonzero(s.rfd)) ? s.rfd / cm.vol : div(s.rfd, rvol); // (divf / vol)
+      u0.m1 -= rfc.omdt * qv * rfc.ep[0];
+      u0.m2 -= rfc.omdt * qv * rfc.ep[1];
+      u0.m3 -= rfc.omdt * qv * rfc.ep[2];
       u0.e += rfc.om2dt * rfc.R * (s.rfx[0] * rfc.eR[0] + s.rfx[1] * rfc.eR[1] + s.rfx[2] * rfc.eR[2]);
     }
     // ---- SetAuxillaryFields (fill_derived.cpp:58-71) + ConsToPrim (:132-146)
@@ -400,8 +401,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
 
   // ---- one plane: the x1 / x2 sweeps (two barriers), then the caller's x3 part and update ----------------------------
   // plane k's primitives are staged; returns the zone's x1 and x2 sums folded into `s` and leaves what the update needs
-  auto plane = [&](const int k, const Cell6 &qc, const bool stage_next, const Cell6 &qn, const Raw5 &hal_next, Sums &s,
-                   const DCoordsT<true> &co, const CellMetric &cm, const double dt_vol) {
+  auto plane = [&](const int k, const Cell6 &qc, const bool stage_next, const Cell6 &qn, const Raw5 &hal_next, Sums &s) {
     bool fastp = true;
     if constexpr (PG) {
       fastp = (S.tiny[k & 1] == 0);
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     Flux8 fx_lo = solve_face<RIEMANN, 1>(gk, L, lox, fastp);
     {
       double h[3];
-      co.face_scale(1, h); // ScaleMomentumFlux (fluid_fluxes.hpp:33-70; h1 == 1)
+      CO(tx + FH, ty + FH, k).face_scale(1, h); // ScaleMomentumFlux (fluid_fluxes.hpp:33-70; h1 == 1)
       fx_lo.m2 *= h[1], fx_lo.m3 *= h[2];
     }
     Flux8 fy_lo = fx_lo;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       CGET6(L, S.UPY, [ty][tx]);
       fy_lo = solve_face<RIEMANN, 2>(gk, L, loy, fastp);
       double h[3];
-      co.face_scale(2, h);
+      CO(tx + FH, ty + FH, k).face_scale(2, h);
       fy_lo.m2 *= h[1], fy_lo.m3 *= h[2];
       if (ty > 0) { CPUT8(S.FY, fy_lo, [ty - 1][tx]); }
     }
@@ -523,6 +523,10 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       fx_hi.m3 = lane_above(fx_lo.m3), fx_hi.e = lane_above(fx_lo.e), fx_hi.eg = lane_above(fx_lo.eg);
       fx_hi.pf = lane_above(fx_lo.pf), fx_hi.vf = lane_above(fx_lo.vf);
       if (tx == FTX - 1) { CGET8(fx_hi, S.FXE, [ty]); }
+      // (the zone's Coords are rebuilt from the tables in every phase that needs them: nothing of them crosses a barrier)
+      const auto co = CO(tx + FH, ty + FH, k);
+      const CellMetric cm = cell_metric_of(co);
+      const double dt_vol = div(bdt, recip(cm.vol));
       double b1[2], b2[2], b3[2];
       co.rf_weights(b1, b2, b3);
       fold(std::integral_constant<int, 1>{}, s, fx_lo, fx_hi, cm.ax1[0], cm.ax1[1], b1[0], b1[1], div(bdt, cm.dx[0]), dt_vol, true);
@@ -550,15 +554,14 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     if (hr >= 0) hal = load_raw(in_r, in_1, in_2, in_3, in_e, hcol + static_cast<unsigned>(k0) * sk);
     stage_plane(qc, hal, k0 & 1);
     __syncthreads();
+    Sums s;
+    plane(k0, qc, false, qc, hal, s);
     double c3 = 1.0, s3 = 0.0;
     if (m3) c3 = m3[MT3_COS * (P.nk + 1) + k0], s3 = m3[MT3_SIN * (P.nk + 1) + k0];
     const auto co = CO(tx + FH, ty + FH, k0, c3, s3);
     const CellMetric cm = cell_metric_of(co);
     double hx[3];
     scale_factors_of(co, hx);
-    const double dt_vol = div(bdt, recip(cm.vol));
-    Sums s;
-    plane(k0, qc, false, qc, hal, s, co, cm, dt_vol);
     s.tm[2] = s.te[2] = 0.0, s.rfx[2] = 0 * 0.5 * (0.0 + 0.0);
     s.rfd = s.rfd + 0 * (0.0 * 0.0 * 0.0 + 0.0 * 0.0 * 0.0);
     update(k0, co, cm, hx, qc, s, u1raw, ds);
@@ -589,11 +592,8 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       double c3 = 1.0, s3 = 0.0;
       if (m3 && live) c3 = m3[MT3_COS * (P.nk + 1) + k], s3 = m3[MT3_SIN * (P.nk + 1) + k];
       Sums s;
-      const auto co = CO(tx + FH, ty + FH, max(k, k0), c3, s3);
-      const CellMetric cm = cell_metric_of(co);
-      const double dt_vol = div(bdt, recip(cm.vol));
       if (live) {
-        plane(k, qc, k < k1, qn, hal, s, co, cm, dt_vol);
+        plane(k, qc, k < k1, qn, hal, s);
       } else { // priming trip: stage the first plane
         stage_plane(qn, hal, k0 & 1);
         __syncthreads();
@@ -623,6 +623,9 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
         fz_hi.m2 *= h[1], fz_hi.m3 *= h[2];
       }
       if (live) {
+        const auto co = CO(tx + FH, ty + FH, k, c3, s3);
+        const CellMetric cm = cell_metric_of(co);
+        const double dt_vol = div(bdt, recip(cm.vol));
         double b1[2], b2[2], b3[2];
         co.rf_weights(b1, b2, b3);
         fold(std::integral_constant<int, 3>{}, s, fz_lo, fz_hi, cm.ax3[0], cm.ax3[1], b3[0], b3[1], div(bdt, cm.dx[2]), dt_vol, true);
