@@ -231,6 +231,7 @@ def load():
         "artemis_hip_thermal_flux": (i, [PPk, C.POINTER(Diffusion), vp]),
         "artemis_hip_diffusion_update": (i, [PPk, C.POINTER(Diffusion), d, vp]),
         "artemis_hip_viscous_source_covers": (i, [PPk]),
+        "artemis_hip_ml_viscous_faces": (i, [PPk, C.POINTER(Diffusion), vp, i, vp, i, vp]),
         "artemis_hip_viscous_source": (i, [PPk, C.POINTER(Diffusion), d, vp, PP, vp]),
         "artemis_hip_diffusion_dt": (i, [PPk, C.POINTER(Diffusion), d, vp, vp]),
         "artemis_hip_diffusion_radial_fill": (i, [PPk, vp, vp, C.POINTER(DiffCoeff), i, vp]),
@@ -293,7 +294,7 @@ EXPORTS_HIP = [
     "artemis_hip_prolongate_minmod", "artemis_hip_amr_first_derivative", "artemis_hip_amr_magnitude",
     "artemis_hip_zero_diffusion_flux", "artemis_hip_viscous_distance_count", "artemis_hip_viscous_distance_fill",
     "artemis_hip_viscous_flux", "artemis_hip_zero_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
-    "artemis_hip_viscous_source_covers", "artemis_hip_viscous_source",
+    "artemis_hip_viscous_source_covers", "artemis_hip_viscous_source", "artemis_hip_ml_viscous_faces",
     "artemis_hip_diffusion_dt", "artemis_hip_diffusion_radial_fill", "artemis_hip_halo_count", "artemis_hip_halo_count_ext",
     "artemis_hip_halo_pack_ext", "artemis_hip_halo_unpack_ext",
     "artemis_hip_halo_pack", "artemis_hip_halo_unpack", "artemis_hip_last_error",

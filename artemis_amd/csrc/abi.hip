@@ -774,6 +774,17 @@ int artemis_hip_viscous_source(const artemis_pack_t *p, const artemis_diffusion_
   artemis::launch_viscous_source(P, *d, dt, dt_dev, sums, S(stream));
   return after_launch("viscous source");
 }
+int artemis_hip_ml_viscous_faces(const artemis_pack_t *p, const artemis_diffusion_t *d, const artemis_ml_face_box_t *boxes_dev,
+                                 int nboxes, const artemis_ml_fix_cell_t *cells_dev, int ncells, void *stream) {
+  if (int rc = validate_diffusion(p, d, true)) return rc;
+  if (p->gas.nspecies != 1) return fail(ARTEMIS_HIP_EUNSUPPORTED, "listed viscous faces: one gas species");
+  if (d->visc.type == ARTEMIS_DIFF_OFF) return fail(ARTEMIS_HIP_EINVAL, "listed viscous faces: viscosity is off");
+  if (nboxes < 0 || ncells < 0 || (nboxes > 0 && !boxes_dev) || (ncells > 0 && !cells_dev))
+    return fail(ARTEMIS_HIP_EINVAL, "listed viscous faces: bad list");
+  if (!p->gas.prim) return fail(ARTEMIS_HIP_EINVAL, "listed viscous faces: gas.prim table is required");
+  artemis::launch_viscous_listed_faces(artemis::make_pack_view(*p), *d, boxes_dev, nboxes, cells_dev, ncells, S(stream));
+  return after_launch("listed viscous faces");
+}
 int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *stream) {
   if (int rc = validate_diffusion(p, d, true)) return rc;
   if (d->cond.type == ARTEMIS_DIFF_OFF) return 0; // gas.cpp:582-583

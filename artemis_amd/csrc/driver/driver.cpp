@@ -2619,10 +2619,20 @@ void artemis_sim_impl::step_ml_fused() {
     a.cfl_gas = cfl_gas, a.cfl_dust = cfl_dust;
     a.dt_dev = nullptr; // the timestep is estimated after the fix-up (new_dt_unfused)
     const bool diffuse = do_gas && (do_viscosity || do_conduction);
+    // viscosity alone: the five sums of artemis_hip_viscous_source for the whole pack, and the viscous fluxes themselves
+    // only on the faces the flux correction touches (artemis_hip_ml_viscous_faces, below)
+    const bool visc_source = diffuse && do_viscosity && !do_conduction && ns_gas == 1 && !getenv("ARTEMIS_NO_VISC_SOURCE") &&
+                             artemis_hip_viscous_source_covers(&p) != 0;
+    if (visc_source && !gdsum.ok()) gdsum.alloc(nb, 5, N);
     if (diffuse) { // artemis_driver.cpp:189-194 on the stage's input primitives
-      if (do_viscosity) CK(artemis_hip_zero_viscous_flux(&p, &diff, stream), "Gas::ZeroDiffusionFlux + ViscousFlux");
-      else CK(artemis_hip_zero_diffusion_flux(&p, stream), "Gas::ZeroDiffusionFlux");
-      if (do_conduction) CK(artemis_hip_thermal_flux(&p, &diff, stream), "Gas::ThermalFlux");
+      if (visc_source) {
+        CK(artemis_hip_viscous_source(&p, &diff, a.bdt, nullptr, gdsum.tab(), stream), "viscous source");
+        a.diffusion_sums = gdsum.tab();
+      } else {
+        if (do_viscosity) CK(artemis_hip_zero_viscous_flux(&p, &diff, stream), "Gas::ZeroDiffusionFlux + ViscousFlux");
+        else CK(artemis_hip_zero_diffusion_flux(&p, stream), "Gas::ZeroDiffusionFlux");
+        if (do_conduction) CK(artemis_hip_thermal_flux(&p, &diff, stream), "Gas::ThermalFlux");
+      }
       a.diffusion = &diff;
     }
     if (do_cooling && do_gas) a.cooling = &cool;
@@ -2639,6 +2649,12 @@ void artemis_sim_impl::step_ml_fused() {
     }
     CK(artemis_hip_ml_face_fluxes(&p, &a, static_cast<const artemis_ml_face_box_t *>(ml.fine_boxes.p), ml.fine_boxes.n, stream),
        "fine-side faces of the coarse-fine boundaries");
+    if (visc_source) {
+      CK(artemis_hip_ml_viscous_faces(&p, &diff, static_cast<const artemis_ml_face_box_t *>(ml.fine_boxes.p), ml.fine_boxes.n,
+                                      static_cast<const artemis_ml_fix_cell_t *>(ml.fix_cells.p), ml.fix_cells.n, stream),
+         "viscous fluxes of the faces the flux correction touches");
+      a.diffusion_sums = nullptr; // the fix-up forms the listed zones' sums from the corrected arrays
+    }
     flux_correction_multilevel(p);
     CK(artemis_hip_ml_stage_fixup(&p, &a, static_cast<const artemis_ml_fix_cell_t *>(ml.fix_cells.p), ml.fix_cells.n, stream),
        "coarse zones on coarse-fine faces");
@@ -3202,11 +3218,13 @@ int artemis_sim_uses_tuned_kernel(const artemis_sim_t *s) { return (s->p->use_fu
 const char *artemis_sim_stage_kernel(const artemis_sim_t *s) {
   if (s->p->multilevel && s->p->ml_fused) {
     if (s->p->ml_tuned) return "stage_fused_kernel + coarse-fine fix-up";
+    if (s->p->general_variant == 3) return "stage_curv_kernel + coarse-fine fix-up";
     return s->p->general_variant == 2 ? "stage_fused_kernel<curvilinear> + coarse-fine fix-up" : "stage_cell_kernel + coarse-fine fix-up";
   }
   if (!s->p->use_fused) return "per-task chain";
   if (s->p->tuned) return "stage_fused_kernel";
   if (s->p->general_variant < 0) return "general stage (not run yet)";
+  if (s->p->general_variant == 3) return "stage_curv_kernel";
   return s->p->general_variant == 1 ? "stage2d_kernel" : (s->p->general_variant == 2 ? "stage_fused_kernel<curvilinear>" : "stage_cell_kernel");
 }
 long artemis_sim_remeshes(const artemis_sim_t *s) { return s->remeshes; }

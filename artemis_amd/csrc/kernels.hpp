@@ -53,6 +53,8 @@ void launch_zero_diffusion_flux(const PackView &P, hipStream_t s);
 size_t viscous_distance_count(const PackView &P);
 void launch_viscous_distance_fill(const PackView &P, double *tab, hipStream_t s);
 int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s, bool overwrite = false);
+void launch_viscous_listed_faces(const PackView &P, const artemis_diffusion_t &D, const artemis_ml_face_box_t *boxes, int nboxes,
+                                 const artemis_ml_fix_cell_t *cells, int ncells, hipStream_t s);
 bool viscous_source_covers(const PackView &P);
 void launch_viscous_source(const PackView &P, const artemis_diffusion_t &D, double dt, const double *dt_dev, double *const *out,
                            hipStream_t s);

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
     const double v3n3 = fused::gld(prim[b * 6 + 3], col + plane(k + 3));
     Vel6 hnn = rnn;
     double h3n3 = v3n3;
-    if (h_any) hnn = load6(prim, radial, b, hcol + plane(k + 2)), h3n3 = fused::gld(prim[b * 6 + 3], hcol + plane(k + 3));
+    if (h_any && !(a.abl & 64)) hnn = load6(prim, radial, b, hcol + plane(k + 2)), h3n3 = fused::gld(prim[b * 6 + 3], hcol + plane(k + 3));
     const unsigned cn1 = col + static_cast<unsigned>(k + 1) * sk, cn2 = col + plane(k + 2);
     double nl1 = 1.0, nl2 = 1.0, na3 = 1.0;  // plane k + 1: for the next trip's x1 / x2 faces
     double wl3 = 1.0, wa1 = 1.0, wa2 = 1.0;  // plane k + 2: for the next trip's x3 face
@@ -745,8 +745,10 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
       auto FF = [&](int d, int var, int u) { return F[d][u][var]; };
       diffusion_update_core<true>(g, FF, 0, 1, 1, dt, vc, dm, de, deg);
       const unsigned c = col + static_cast<unsigned>(k) * sk;
-      fused::gst(a.out[b * 5 + 0], c, dm[0]), fused::gst(a.out[b * 5 + 1], c, dm[1]), fused::gst(a.out[b * 5 + 2], c, dm[2]);
-      fused::gst(a.out[b * 5 + 3], c, de), fused::gst(a.out[b * 5 + 4], c, deg);
+      if (!(a.abl & 32) || dm[0] == 1.2345) {
+        fused::gst(a.out[b * 5 + 0], c, dm[0]), fused::gst(a.out[b * 5 + 1], c, dm[1]), fused::gst(a.out[b * 5 + 2], c, dm[2]);
+        fused::gst(a.out[b * 5 + 3], c, de), fused::gst(a.out[b * 5 + 4], c, deg);
+      }
     }
     vc[0] = rn.v1, vc[1] = rn.v2, vc[2] = rn.v3;
     rn = rnn, rn.v3 = v3n2, v3n2 = v3n3;
@@ -757,6 +759,86 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
     ul3 = wl3, ua1 = wa1, ua2 = wa2;
     nb0 = nnb0, nb1 = nnb1, nb2 = nnb2, nb3 = nnb3, dd0 = ndd0, dd1 = ndd1, dd2 = ndd2;
   }
+}
+
+// ---- viscous fluxes of LISTED faces (refined meshes on the one-kernel stages) ------------------------------------
+// With artemis_hip_viscous_source no diffusion-flux array is filled for the pack, but the flux correction of a refined
+// mesh needs the viscous fluxes themselves on two small sets of faces: the fine side of every coarse-fine boundary (to
+// restrict) and the six faces of every coarse zone the fix-up redoes.  These kernels evaluate exactly those, each face
+// from the primitives around it: the per-zone quantities viscous_cell_kernel would have stored (v / h,
+// VelocityDivergence / (2 V), the dynamic viscosity) formed on the spot with the same expressions, then
+// viscous_face_core -- the bits ZeroDiffusionFlux + ViscousFlux leave in those entries.  One gas species.
+template <int DIR, bool CURV>
+ADEV void viscous_face_direct(const PackView &P, const artemis_diffusion_t &D, const int b, const int k, const int j, const int i) {
+  const FluidView &f = P.gas;
+  const int multid = (P.ndim >= 2), threed = (P.ndim == 3);
+  constexpr int dk = (DIR == 3), dj = (DIR == 2), di = (DIR == 1), d = DIR - 1;
+  Geo<CURV> ge{P, b};
+  ge.dtab = D.dist;
+  const FaceGeo fg = face_geometry<DIR, CURV>(P, ge, b, k, j, i);
+  auto at = [&](int kk, int jj, int ii) { return (static_cast<long>(kk) * P.nj + jj) * P.ni + ii; };
+  auto sv = [&](int comp, int kk, int jj, int ii) { // contravariant velocity component of a zone (IEEE quotient)
+    double hx[3];
+    scale_factors<CURV>(P, b, kk, jj, ii, hx);
+    return f.prim[b * 6 + 1 + comp][at(kk, jj, ii)] / hx[comp];
+  };
+  auto divu = [&](int kk, int jj, int ii) {
+    double vol2;
+    const double divv = velocity_divergence<CURV>(P, f.prim, b, 0, kk, jj, ii, vol2);
+    return divv / vol2;
+  };
+  auto mu = [&](int kk, int jj, int ii) {
+    const long c = at(kk, jj, ii);
+    return coeff_of(D.visc, D.cv, P.gm1, f.prim[b * 6 + 0][c], f.prim[b * 6 + 5][c], b, c);
+  };
+  // the two transverse directions (as viscous_face's strides: inactive directions repeat the zone itself)
+  int tk[2], tj[2], ti[2];
+  if constexpr (DIR == 1) tk[0] = 0, tj[0] = multid, ti[0] = 0, tk[1] = threed, tj[1] = 0, ti[1] = 0;
+  else if constexpr (DIR == 2) tk[0] = 0, tj[0] = 0, ti[0] = 1, tk[1] = threed, tj[1] = 0, ti[1] = 0;
+  else tk[0] = 0, tj[0] = 0, ti[0] = 1, tk[1] = 0, tj[1] = 1, ti[1] = 0;
+  FaceIn q;
+  for (int m = 0; m < 3; ++m) q.s_c[m] = sv(m, k, j, i), q.s_m[m] = sv(m, k - dk, j - dj, i - di);
+  for (int t = 0; t < 2; ++t) {
+    q.n_t[t] = sv(d, k + tk[t], j + tj[t], i + ti[t]) - sv(d, k - tk[t], j - tj[t], i - ti[t]);
+    q.n_tm[t] = sv(d, k - dk + tk[t], j - dj + tj[t], i - di + ti[t]) - sv(d, k - dk - tk[t], j - dj - tj[t], i - di - ti[t]);
+  }
+  q.mu1 = mu(k, j, i), q.mu2 = mu(k - dk, j - dj, i - di);
+  q.divu = divu(k, j, i), q.divu_m = divu(k - dk, j - dj, i - di);
+  double fl[3], fe;
+  viscous_face_core<DIR>(fg, q, D.visc.avg, D.visc.eta, fl, fe);
+  const long c = at(k, j, i);
+  double *const *qf = f.dflux[DIR - 1];
+  for (int qq = 0; qq < 3; ++qq) qf[b * 4 + qq][c] = 0.0 + fl[qq];
+  qf[b * 4 + 3][c] = 0.0 + fe;
+}
+template <bool CURV>
+ADEV void viscous_face_any(const PackView &P, const artemis_diffusion_t &D, int dir, int b, int k, int j, int i) {
+  if (dir == 0) viscous_face_direct<1, CURV>(P, D, b, k, j, i);
+  else if (dir == 1) viscous_face_direct<2, CURV>(P, D, b, k, j, i);
+  else viscous_face_direct<3, CURV>(P, D, b, k, j, i);
+}
+// one workgroup per face box (the faces of direction bx.dir stored at the zones of the box)
+template <bool CURV>
+__global__ __launch_bounds__(256) void viscous_box_faces_kernel(const PackView P, const artemis_diffusion_t D,
+                                                                const artemis_ml_face_box_t *__restrict__ boxes) {
+  const artemis_ml_face_box_t bx = boxes[blockIdx.x];
+  const long ncell = static_cast<long>(bx.n[0]) * bx.n[1] * bx.n[2];
+  for (long t = threadIdx.x; t < ncell; t += blockDim.x) {
+    const int i = bx.lo[0] + static_cast<int>(t % bx.n[0]), j = bx.lo[1] + static_cast<int>((t / bx.n[0]) % bx.n[1]);
+    const int k = bx.lo[2] + static_cast<int>(t / (static_cast<long>(bx.n[0]) * bx.n[1]));
+    viscous_face_any<CURV>(P, D, bx.dir, bx.block, k, j, i);
+  }
+}
+// the 2 ndim faces of every listed zone: thread (zone, face slot 2 d + side)
+template <bool CURV>
+__global__ __launch_bounds__(256) void viscous_cell_faces_kernel(const PackView P, const artemis_diffusion_t D,
+                                                                 const artemis_ml_fix_cell_t *__restrict__ cells, int ncells) {
+  const long q = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= 6L * ncells) return;
+  const artemis_ml_fix_cell_t z = cells[q / 6];
+  const int slot = static_cast<int>(q % 6), d = slot >> 1, side = slot & 1;
+  if (d >= P.ndim) return;
+  viscous_face_any<CURV>(P, D, d, z.block, z.k + ((d == 2) ? side : 0), z.j + ((d == 1) ? side : 0), z.i + ((d == 0) ? side : 0));
 }
 
 // artemis_hip_viscous_distance_fill: the six Coords::Distance values (geometry.hpp:407-412) a cell contributes
@@ -947,6 +1029,19 @@ int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStre
   if (P.ndim > 1) LAUNCH_VISC(2);
   if (P.ndim > 2) LAUNCH_VISC(3);
   return 0;
+}
+void launch_viscous_listed_faces(const PackView &P, const artemis_diffusion_t &D, const artemis_ml_face_box_t *boxes, int nboxes,
+                                 const artemis_ml_fix_cell_t *cells, int ncells, hipStream_t s) {
+  const bool curv = P.coords != ARTEMIS_CARTESIAN;
+  if (nboxes > 0) {
+    if (curv) hipLaunchKernelGGL(viscous_box_faces_kernel<true>, dim3(nboxes), dim3(256), 0, s, P, D, boxes);
+    else hipLaunchKernelGGL(viscous_box_faces_kernel<false>, dim3(nboxes), dim3(256), 0, s, P, D, boxes);
+  }
+  if (ncells > 0) {
+    const dim3 grid(static_cast<unsigned>((6L * ncells + 255) / 256));
+    if (curv) hipLaunchKernelGGL(viscous_cell_faces_kernel<true>, grid, dim3(256), 0, s, P, D, cells, ncells);
+    else hipLaunchKernelGGL(viscous_cell_faces_kernel<false>, grid, dim3(256), 0, s, P, D, cells, ncells);
+  }
 }
 // Does the viscous-source march cover this pack?  (3-D blocks of one gas species, 32-bit zone offsets.)
 bool viscous_source_covers(const PackView &P) {

@@ -623,7 +623,7 @@ void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t
 int stage_general_variant(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
                           int recon_dust, int riemann_dust) {
   if (getenv("ARTEMIS_NO_STAGE2D") == nullptr && stage2d_covers(P, g, recon_gas, riemann_gas, recon_dust, riemann_dust)) return 1;
-  if (getenv("ARTEMIS_NO_FUSED_CURV") == nullptr && fused_curv_covers(P, g, recon_gas)) return 2;
+  if (getenv("ARTEMIS_NO_FUSED_CURV") == nullptr && fused_curv_covers(P, g, recon_gas)) return curv_march_covers(P, g, recon_gas) ? 3 : 2;
   return 0;
 }
 
@@ -636,10 +636,12 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
     launch_stage2d(P, g, recon_gas, riemann_gas, riemann_dust, s);
     return;
   }
-  if (variant == 2) { // curvilinear gas: the streaming tile march with its geometry in LDS tables (kernels_curv.hip), or
-    // -- diffusion from stored flux arrays -- the older instantiation with the geometry in registers
-    if (curv_march_covers(P, g, recon_gas)) launch_stage_curv(P, g, recon_gas, riemann_gas, s);
-    else launch_stage_fused_curv(P, g, recon_gas, riemann_gas, s);
+  if (variant == 3) { // curvilinear gas: the streaming tile march with its geometry in LDS tables (kernels_curv.hip)
+    launch_stage_curv(P, g, recon_gas, riemann_gas, s);
+    return;
+  }
+  if (variant == 2) { // ... with diffusion from stored flux arrays: the older instantiation, geometry in registers
+    launch_stage_fused_curv(P, g, recon_gas, riemann_gas, s);
     return;
   }
   CellStageArgs a = cell_args(P, g);

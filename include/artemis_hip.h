@@ -525,9 +525,10 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
                               void *stream);
 /* Which kernel artemis_hip_stage_general runs for this pack and these arguments (no launch, no device
  * access): 0 = the cell-centred kernels (one per fluid, + the drag finish), 1 = the 2-D row-march kernel
- * (kernels_stage2d.hip: both fluids, drag, aux, ConsToPrim and dt in one launch), 2 = the streaming tile kernel
- * in its curvilinear instantiation (kernels_fused.hip: gas on any non-Cartesian system).  Same results either way;
- * benchmarks name the kernel they timed with this. */
+ * (kernels_stage2d.hip: both fluids, drag, aux, ConsToPrim and dt in one launch), 3 = the curvilinear tile march
+ * (kernels_curv.hip: gas on any non-Cartesian system, geometry in LDS tables, two waves per SIMD; diffusion only as
+ * diffusion_sums), 2 = its predecessor with the geometry in registers (kernels_fused.hip: taken when the diffusion
+ * fluxes come from stored arrays).  Same results either way; benchmarks name the kernel they timed with this. */
 int artemis_hip_stage_general_variant(const artemis_pack_t *p, const artemis_stage_general_args_t *a);
 /* The cell-local remainder of a stage in ONE pass over stored fluxes: after Gas/Dust::CalculateFluxes
  * (and the diffusion-flux tasks) have filled flux / pflux / vface (/ diff_flux) for p's primitives,
@@ -658,6 +659,15 @@ typedef struct artemis_ml_fix_cell {
 } artemis_ml_fix_cell_t;
 int artemis_hip_ml_face_fluxes(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
                                const artemis_ml_face_box_t *boxes_dev, int nboxes, void *stream);
+/* The same for the viscous fluxes when step 1 ran on artemis_hip_viscous_source's sums (no diffusion-flux array was
+ * filled for the pack): Gas::ZeroDiffusionFlux + ViscousFlux evaluated on exactly the faces the flux correction
+ * touches -- the faces of the boxes (the fine side of the coarse-fine boundaries, as above) and the 2 ndim faces of
+ * every listed zone (what artemis_hip_ml_stage_fixup reads) -- from p->gas.prim (the stage's input primitives) into
+ * those entries of p->gas.diff_flux: the same bits the whole-pack tasks would leave there.  Then steps 3 and 4 as
+ * before, step 4 with diffusion_sums = NULL so that it forms the listed zones' sums from the corrected arrays.
+ * One gas species; viscosity only. */
+int artemis_hip_ml_viscous_faces(const artemis_pack_t *p, const artemis_diffusion_t *d, const artemis_ml_face_box_t *boxes_dev,
+                                 int nboxes, const artemis_ml_fix_cell_t *cells_dev, int ncells, void *stream);
 int artemis_hip_ml_stage_fixup(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
                                const artemis_ml_fix_cell_t *cells_dev, int ncells, void *stream);
 

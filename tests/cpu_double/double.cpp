@@ -784,6 +784,10 @@ int artemis_hip_viscous_source_covers(const artemis_pack_t *) { return 0; }
 int artemis_hip_viscous_source(const artemis_pack_t *, const artemis_diffusion_t *, double, const double *, double *const *, void *) {
   return ARTEMIS_HIP_EUNSUPPORTED;
 }
+int artemis_hip_ml_viscous_faces(const artemis_pack_t *, const artemis_diffusion_t *, const artemis_ml_face_box_t *, int,
+                                 const artemis_ml_fix_cell_t *, int, void *) {
+  return ARTEMIS_HIP_EUNSUPPORTED; // (never reached: artemis_hip_viscous_source_covers is 0 on this double)
+}
 int artemis_hip_thermal_flux(const artemis_pack_t *p, const artemis_diffusion_t *d, void *) {
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);

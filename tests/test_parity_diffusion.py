@@ -270,4 +270,5 @@ def test_stage_general_with_viscous_sums(hiplib, coordinates, nx, lo, hi, stage2
         gbuf, gout = mb.new_prim_buffer("o%d" % nofuse)
         mb.stage_general(g0, g1, be * dt, be * dt, gas=(gin, gu1, gout), time=time, gravity=grav,
                          rotating_frame=(om, 0.0), cfl=(0.3, 0.3), diffusion=D, diffusion_sums=sums)
+        assert mb.last_stage_variant == (0 if nofuse or coordinates == "cartesian" else 3)
         assert np.array_equal(gbuf[0][I].cpu().numpy()[keep], o.gprim[I][keep]), nofuse

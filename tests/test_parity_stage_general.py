@@ -97,7 +97,7 @@ def test_general_stage_hydro(hiplib, nx, lo, hi, nsg, nsd, recon, riem, driem, c
     oracle_stage(o, g0, g1, be, dt, False, 0.0, False, False, False)
     mb.stage_general(g0, g1, be * dt, be * dt, gas=(gin, gu1, gout), dust=(din, du1, dout))
     if coords != "cartesian" and nsg == 1 and nsd == 0 and recon != "ppm":
-        assert mb.last_stage_variant == 2  # the curvilinear streaming tile kernel really ran
+        assert mb.last_stage_variant == 3  # the curvilinear tile march (kernels_curv.hip) really ran
     I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
     if nsg:
         out = mb._extra_prim["o"][0][0][I].cpu().numpy()
