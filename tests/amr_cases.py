@@ -47,14 +47,18 @@ def linear_wave_amr(derefine_count=10):
     return dict(deck=("linwave", "linear_wave_amr.in"), overrides=ov, oracle=oracle, tlim=-1.0, dust=False)
 
 
-def disk_planet_dust_amr(n=32, planet=1.0e-2, thr=0.8, derefine_count=3):
+def disk_planet_dust_amr(n=32, planet=1.0e-2, thr=0.8, derefine_count=3, nz=1, zlim=1.0):
     """BASELINE configs[4]: inputs/disk/disk_nbody_cyl.in (cylindrical disk, `ic` conditions, alpha viscosity, N-body
     gravity) in 2-D with a planet on a circular orbit at r = 1 (static in the frame rotating with it: <nbody>
     integrator = none, the REBOUND integration is outside this build), one dust species with simple_dust drag, and
     FOUR refinement levels (numlevel = 4) on the pressure-gradient criterion -- the criterion and numlevel
-    inputs/disk/binary_nbody_cyl.in:40-41,77-79 carries.  The planet's growing wake drives refinement to level 3."""
-    ov = ["parthenon/mesh/nx1=%d" % n, "parthenon/mesh/nx2=%d" % n, "parthenon/mesh/nx3=1", "parthenon/meshblock/nx1=8",
-          "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=1", "parthenon/mesh/refinement=adaptive",
+    inputs/disk/binary_nbody_cyl.in:40-41,77-79 carries.  The planet's growing wake drives refinement to level 3.
+    nz > 1: the same in THREE dimensions (8^3 blocks, nz root zones over |z| < zlim -- a slab thin against the scale
+    height, so that the criterion follows the planet's wake as in 2-D rather than the vertical stratification, which
+    would refine the whole midplane to the finest level: thousands of 8^3 blocks for a Python-driven oracle)."""
+    ov = ["parthenon/mesh/nx1=%d" % n, "parthenon/mesh/nx2=%d" % n, "parthenon/mesh/nx3=%d" % nz, "parthenon/meshblock/nx1=8",
+          "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=%d" % (8 if nz > 1 else 1),
+          "parthenon/mesh/x3min=%r" % -zlim, "parthenon/mesh/x3max=%r" % zlim, "parthenon/mesh/refinement=adaptive",
           "parthenon/mesh/numlevel=4", "parthenon/mesh/derefine_count=%d" % derefine_count, "gas/refine_field=pressure",
           "gas/refine_type=gradient", "gas/refine_thr=%r" % thr,
           "physics/rotating_frame=true", "rotating_frame/omega=1.0",
@@ -87,7 +91,7 @@ def disk_planet_dust_amr(n=32, planet=1.0e-2, thr=0.8, derefine_count=3):
 
     def oracle():
         from oracle.adaptive import AdaptiveOracle
-        m = AdaptiveOracle((n, n, 1), (8, 8, 1), (0.3, -PI, -1.0), (4.3, PI, 1.0),
+        m = AdaptiveOracle((n, n, nz), (8, 8, 8 if nz > 1 else 1), (0.3, -PI, -zlim), (4.3, PI, zlim),
                            ("ic", "ic", "periodic", "periodic", "ic", "ic"), numlevel=4, refine_field="pressure",
                            refine_type="gradient", refine_thr=thr, derefine_count=derefine_count, setup=setup,
                            pgen=lambda o: o.pgen_disk(r0=1.0, rho0=1.0, dslope=-2.25, flare=0.25, h0=0.05, dens_min=1e-10,

@@ -187,13 +187,18 @@ def test_disk_with_planet_dust_and_adaptive_mesh(hiplib):
     ("linear_wave_amr", dict(derefine_count=3), 100, 20, 5, {0, 1}),           # as shipped
     ("disk_planet_dust_amr", dict(), 40, 10, 8, {1, 2, 3}),                    # BASELINE configs[4], numlevel = 4
     ("disk_planet_dust_amr", dict(n=64, thr=0.5), 20, 10, 2, {1, 2, 3}),       # the same on a 64^2 root (300+ blocks)
+    # ... and in THREE dimensions: 16 x 16 x 8 root in 8^3 blocks, four levels, 312 -> 560 blocks of both fluids
+    ("disk_planet_dust_amr", dict(n=16, planet=3e-2, thr=2.5, nz=8, zlim=0.01), 18, 6, 4, {1, 2, 3}),
 ])
 def test_hip_driver_equals_adaptive_oracle(hiplib, name, kw, cycles, batch, min_remeshes, levels):
     """The HIP driver against oracle/adaptive.py (an independent restatement of the remeshing: tests/amr_cases.py,
     tests/test_adaptive_oracle.py) after every batch of cycles: same leaves in the same Z-order, same levels and bounds,
     same dt and time, and every leaf equal bit for bit, ghost zones included -- across >= min_remeshes remeshes with
     refinement and derefinement.  The configs[4] rows run inputs/disk/disk_nbody_cyl.in with a planet, a dust species with
-    drag, alpha viscosity, the rotating frame, `ic` conditions and FOUR levels."""
+    drag, alpha viscosity, the rotating frame, `ic` conditions and FOUR levels; the last one in 3-D (8^3 blocks: octant
+    hand-over, x3 restriction / prolongation / flux correction of both fluids, the N-body task and the viscous cross
+    terms in all three planes; a 16 x 16 x 8 root rather than 32 x 32 x 8 because the oracle is a Python loop over
+    per-block C oracles: 560 blocks at the end)."""
     import amr_cases
     from artemis_amd.driver import Simulation
     case = getattr(amr_cases, name)(**kw)

@@ -117,3 +117,28 @@ def test_config4_disk_planet_dust_two_ranks_equal_one_rank(tmp_path):
     da, db = by_bounds(one, "dust"), by_bounds(two, "dust")
     for key in da:
         assert np.array_equal(da[key], db[key]), key
+
+
+def test_config4_in_three_dimensions_two_ranks_equal_one_rank(tmp_path):
+    """The same deck in THREE dimensions (tests/amr_cases.py with nz = 8: 16 x 16 x 8 root in 8^3 blocks, four levels,
+    312 -> 368 blocks of gas and dust over the first remesh of the run): octants of both fluids migrate between the
+    ranks, x3 restriction / prolongation / flux correction run across the rank boundary, and 2 ranks reproduce 1 rank
+    bit for bit.  (The GPU driver == the adaptive oracle on this case over 18 cycles: tests/test_adaptive.py.)"""
+    import amr_cases
+    from test_multirank_cpu import by_bounds
+    case = amr_cases.disk_planet_dust_amr(n=16, planet=3e-2, thr=2.5, nz=8, zlim=0.01)
+    spec = dict(deck=list(case["deck"]), cycles=5, dust=True, overrides=case["overrides"])
+    one = _run_workers(1, spec, tmp_path, "d1")
+    two = _run_workers(2, spec, tmp_path, "d2")
+    assert one[0]["meta"]["remeshes"] == two[0]["meta"]["remeshes"] == two[1]["meta"]["remeshes"] >= 4
+    assert max(one[0]["meta"]["levels"]) == 3 and len(one[0]["meta"]["levels"]) > 312
+    assert sorted(one[0]["meta"]["levels"]) == sorted(two[0]["meta"]["levels"] + two[1]["meta"]["levels"])
+    for r in two:
+        assert r["meta"]["ncycle"] == one[0]["meta"]["ncycle"] == 5 and r["meta"]["dt"] == one[0]["meta"]["dt"]
+    a, b = by_bounds(one), by_bounds(two)
+    assert a.keys() == b.keys()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    da, db = by_bounds(one, "dust"), by_bounds(two, "dust")
+    for key in da:
+        assert np.array_equal(da[key], db[key]), key
