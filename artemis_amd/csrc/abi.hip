@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/artemis_hip.h"
 #include "../../include/artemis_rt.h"
@@ -1018,10 +1020,28 @@ int artemis_rt_set_device(int dev) {
   if (int rc = device_ready()) return rc;
   return check_hip(hipSetDevice(dev), "hipSetDevice");
 }
+// device bytes handed out through this shim: current and high-water mark (artemis_rt_device_bytes)
+namespace {
+std::mutex g_bytes_mu;
+std::unordered_map<void *, size_t> g_bytes_of;
+size_t g_bytes_now = 0, g_bytes_peak = 0;
+} // namespace
+void artemis_rt_device_bytes(size_t *current, size_t *peak, int reset_peak) {
+  std::lock_guard<std::mutex> lk(g_bytes_mu);
+  if (current) *current = g_bytes_now;
+  if (peak) *peak = g_bytes_peak;
+  if (reset_peak) g_bytes_peak = g_bytes_now;
+}
 void *artemis_rt_malloc(size_t bytes) {
   if (device_ready()) return nullptr;
   void *p = nullptr;
   if (check_hip(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc")) return nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_bytes_mu);
+    g_bytes_of[p] = bytes;
+    g_bytes_now += bytes;
+    if (g_bytes_now > g_bytes_peak) g_bytes_peak = g_bytes_now;
+  }
   // ARTEMIS_POISON=1 (debugging aid): fresh device memory holds NaN patterns, so that a read of something never
   // written shows up as NaN instead of depending on what the allocator handed back
   static const bool poison = std::getenv("ARTEMIS_POISON") != nullptr;
@@ -1032,7 +1052,13 @@ void *artemis_rt_malloc(size_t bytes) {
   return p;
 }
 void artemis_rt_free(void *p) {
-  if (p) (void)hipFree(p);
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_bytes_mu);
+    auto it = g_bytes_of.find(p);
+    if (it != g_bytes_of.end()) g_bytes_now -= it->second, g_bytes_of.erase(it);
+  }
+  (void)hipFree(p);
 }
 void *artemis_rt_malloc_host(size_t bytes) {
   if (device_ready()) return nullptr;

@@ -83,6 +83,11 @@ struct Field {
   }
   double *const *tab() const { return static_cast<double *const *>(table); }
   double *var(int b, int v) const { return data.p + (static_cast<size_t>(b) * nvar + v) * N; }
+  void release() {
+    data.release();
+    if (table) artemis_rt_free(table);
+    table = nullptr;
+  }
   ~Field() {
     if (table) artemis_rt_free(table);
   }
@@ -138,6 +143,23 @@ struct artemis_sim_impl {
   std::vector<artemis_host::Leaf> forced_leaves, tree_leaves; // tree_leaves: the leaves this state was built on
   std::vector<int> amr_tags();                    // AmrTag of every local block (-1 derefine, 0 same, +1 refine)
   void adopt_state_from(artemis_sim_impl &old);   // copy / prolongate / restrict the conserved state, then re-derive
+  // A remesh during the run builds the new state with `adopting` set: the problem generator then runs only on the blocks
+  // whose `ic` conditions keep reading its output (adopt_state_from overwrites everything else), and the old state
+  // gives up everything but its conserved variables and geometry before the new one allocates (release_for_adoption)
+  bool adopting = false;
+  void release_for_adoption();
+  // ... and takes the tables that are pure functions of a block's position (the `ic` states on the block and on its
+  // coarse buffer, the radial factor of the viscosity law) from the old state for every block both meshes hold on this
+  // rank -- device-to-device row copies instead of a host libm pass per zone
+  const artemis_sim_impl *reuse_from = nullptr;
+  std::vector<char> ic_coarse_valid; // per block: its coarse-buffer `ic` state has been generated (or copied)
+  int reuse_block(int b) const {     // the old state's local block with this block's level and logical location, or -1
+    if (!reuse_from) return -1;
+    const Block &B = blocks[b];
+    auto it = reuse_lookup.find(std::make_tuple(B.level, B.lx[0], B.lx[1], B.lx[2]));
+    return it == reuse_lookup.end() ? -1 : it->second;
+  }
+  std::map<std::tuple<int, int, int, int>, int> reuse_lookup;
   struct DevArr { // raw device array owned by the driver
     void *p = nullptr;
     int n = 0;
@@ -1970,16 +1992,25 @@ void artemis_sim_impl::problem_generator() {
       const int nbatch = std::min(nthreads, nb - b0);
       std::vector<std::thread> pool;
       std::vector<std::exception_ptr> errs(nbatch);
+      // (a remesh during the run: only the blocks whose `ic` faces keep reading the generated state need it)
+      auto wanted = [&](int b) {
+        if (!adopting) return true;
+        if (!ic_gas.ok()) return false;
+        if (reuse_from && reuse_from->ic_gas.ok() && reuse_block(b) >= 0) return false; // copied from the old state below
+        for (int f = 0; f < 6; ++f)
+          if (blocks[b].bc[f] == ARTEMIS_BC_IC) return true;
+        return false;
+      };
       for (int t = 1; t < nbatch; ++t)
         pool.emplace_back([&, t] {
           try {
-            generate_block(b0 + t, hgs[t], hds[t]);
+            if (wanted(b0 + t)) generate_block(b0 + t, hgs[t], hds[t]);
           } catch (...) {
             errs[t] = std::current_exception();
           }
         });
       try {
-        generate_block(b0, hgs[0], hds[0]);
+        if (wanted(b0)) generate_block(b0, hgs[0], hds[0]);
       } catch (...) {
         errs[0] = std::current_exception();
       }
@@ -1988,11 +2019,20 @@ void artemis_sim_impl::problem_generator() {
         if (errs[t]) std::rethrow_exception(errs[t]);
       for (int t = 0; t < nbatch; ++t) {
         const int b = b0 + t;
+        if (!wanted(b)) continue;
         if (do_gas) upload_block(gprim[0], b, hgs[t]);
         if (do_dust) upload_block(dprim[0], b, hds[t]);
         if (ic_gas.ok()) upload_block(ic_gas, b, hgs[t]); // as generated, before PrimToCons applies the floors
         if (ic_dust.ok()) upload_block(ic_dust, b, hds[t]);
       }
+    }
+  }
+  if (adopting && reuse_from && ic_gas.ok() && reuse_from->ic_gas.ok()) {
+    for (int b = 0; b < nb; ++b) {
+      const int ob = reuse_block(b);
+      if (ob < 0) continue;
+      CK(artemis_rt_memcpy_d2d(ic_gas.var(b, 0), reuse_from->ic_gas.var(ob, 0), sizeof(Real) * 6 * ns_gas * N, stream), "d2d");
+      if (do_dust) CK(artemis_rt_memcpy_d2d(ic_dust.var(b, 0), reuse_from->ic_dust.var(ob, 0), sizeof(Real) * 4 * ns_dust * N, stream), "d2d");
     }
   }
   if (multilevel && ic_gas.ok()) {
@@ -2012,11 +2052,19 @@ void artemis_sim_impl::problem_generator() {
     for (int d = 0; d < 3; ++d) mbnx[d] = cnx[d];
     try {
       ic_gas_c.alloc(nb, 6 * ns_gas, N), ic_dust_c.alloc(nb, 4 * ns_dust, N);
+      ic_coarse_valid.assign(nb, 0);
       std::vector<Real> hgc(static_cast<size_t>(6) * ns_gas * N), hdc(static_cast<size_t>(4) * ns_dust * N);
       for (int b : ml_host.restrict_blocks) {
         bool any = false;
         for (int f = 0; f < 2 * ndim; ++f) any = any || blocks[b].bc[f] == ARTEMIS_BC_IC;
         if (!any) continue;
+        ic_coarse_valid[b] = 1;
+        const int ob = adopting ? reuse_block(b) : -1;
+        if (ob >= 0 && reuse_from->ic_gas_c.ok() && ob < static_cast<int>(reuse_from->ic_coarse_valid.size()) && reuse_from->ic_coarse_valid[ob]) {
+          if (do_gas) CK(artemis_rt_memcpy_d2d(ic_gas_c.var(b, 0), reuse_from->ic_gas_c.var(ob, 0), sizeof(Real) * 6 * ns_gas * N, stream), "d2d");
+          if (do_dust) CK(artemis_rt_memcpy_d2d(ic_dust_c.var(b, 0), reuse_from->ic_dust_c.var(ob, 0), sizeof(Real) * 4 * ns_dust * N, stream), "d2d");
+          continue;
+        }
         generate_block(b, hgc, hdc);
         if (do_gas) upload_block(ic_gas_c, b, hgc);
         if (do_dust) upload_block(ic_dust_c, b, hdc);
@@ -2046,11 +2094,36 @@ void artemis_sim_impl::problem_generator() {
     // the std::pow of the cell position in DiffusionCoeff::Get (diffusion_coeff.hpp:222-224, :262-264)
     visc_radial.alloc(nb, 1, N);
     const artemis_pack_t pk = make_pack(0);
-    std::vector<Real> hr(N);
-    for (int b = 0; b < nb; ++b) {
-      CK(artemis_hip_diffusion_radial_fill(&pk, hgeom.data(), hmetric.empty() ? nullptr : hmetric.data(),
-                                           &diff.visc, b, hr.data()), "viscosity radial table");
-      upload_block(visc_radial, b, hr);
+    // host libm per zone (one std::pow): a few threads, each its own run of blocks; uploads in block order afterwards
+    int nthreads = 1;
+    if (nb >= 8) {
+      nthreads = static_cast<int>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u));
+      if (const char *e = getenv("ARTEMIS_HOST_THREADS")) nthreads = std::max(1, atoi(e));
+      nthreads = std::min(nthreads, nb);
+    }
+    const int chunk = 64; // blocks per batch: bounds the host staging memory
+    std::vector<std::vector<Real>> hr(static_cast<size_t>(std::min(nb, chunk)), std::vector<Real>(N));
+    for (int b0 = 0; b0 < nb; b0 += chunk) {
+      const int nbatch = std::min(chunk, nb - b0);
+      std::vector<std::thread> pool;
+      std::vector<int> rcs(nthreads, 0);
+      const bool can_copy = adopting && reuse_from && reuse_from->visc_radial.ok();
+      auto work = [&](int t) {
+        for (int q = t; q < nbatch; q += nthreads)
+          if (can_copy && reuse_block(b0 + q) >= 0) continue; // copied from the old state below
+          else if (int rc = artemis_hip_diffusion_radial_fill(&pk, hgeom.data(), hmetric.empty() ? nullptr : hmetric.data(),
+                                                         &diff.visc, b0 + q, hr[q].data()))
+            rcs[t] = rc;
+      };
+      for (int t = 1; t < nthreads; ++t) pool.emplace_back(work, t);
+      work(0);
+      for (auto &th : pool) th.join();
+      for (int t = 0; t < nthreads; ++t) CK(rcs[t], "viscosity radial table");
+      for (int q = 0; q < nbatch; ++q) {
+        const int ob = can_copy ? reuse_block(b0 + q) : -1;
+        if (ob >= 0) CK(artemis_rt_memcpy_d2d(visc_radial.var(b0 + q, 0), reuse_from->visc_radial.var(ob, 0), sizeof(Real) * N, stream), "d2d");
+        else upload_block(visc_radial, b0 + q, hr[q]);
+      }
     }
     diff.visc.radial = visc_radial.tab();
   }
@@ -2067,6 +2140,10 @@ void artemis_sim_impl::problem_generator() {
   // then parthenon Mesh::Initialize communicates boundaries (upstream, recalled):
   // PreCommFillDerived (ConsToPrim, artemis.cpp:122) -> exchange + physical BCs ->
   // FillDerived (PrimToCons, artemis.cpp:123).
+  if (adopting) { // adopt_state_from brings the state and runs this sequence on it
+    CK(artemis_rt_stream_sync(stream), "sync");
+    return;
+  }
   const artemis_pack_t p = make_pack(0);
   CK(artemis_hip_prim_to_cons(&p, stream), "PrimToCons");
   CK(artemis_hip_cons_to_prim(&p, stream), "ConsToPrim");
@@ -2074,6 +2151,26 @@ void artemis_sim_impl::problem_generator() {
   CK(artemis_hip_prim_to_cons(&p, stream), "PrimToCons");
   cons_valid = true;
   CK(artemis_rt_stream_sync(stream), "sync");
+}
+
+// What the old state of a remesh still owes the new one is its conserved variables (and the geometry they live on);
+// everything else -- primitive ping-pong buffers, the start-of-step copy, flux and diffusion-flux arrays, coarse
+// buffers, operation lists, message buffers, tables -- is returned to the allocator BEFORE the new state is built, so
+// that the two meshes coexist at ~1.2 x instead of 2 x the memory.  The old state cannot step any more afterwards.
+void artemis_sim_impl::release_for_adoption() {
+  materialise_cons();
+  CK(artemis_rt_stream_sync(stream), "sync");
+  if (comm_stream) CK(artemis_rt_stream_sync(comm_stream), "sync");
+  for (int q = 0; q < 3; ++q) gprim[q].release(), dprim[q].release();
+  gu1.release(), du1.release();
+  for (int d = 0; d < 3; ++d) gflux[d].release(), gpflux[d].release(), gvface[d].release(), dflux[d].release(), gdflux[d].release();
+  gdsum.release(), diff_dist.release(); // (visc_radial and the `ic` states stay: the new state copies rows from them)
+  cool_tref.release(), cool_beta.release();
+  plmtab.release();
+  ml.gcoarse.release(), ml.dcoarse.release(), ml.cgeom.release(), ml.cmetric.release();
+  ml.ops_a.release(), ml.ops_u.release(), ml.ops_b.release(), ml.ops_fx.release(), ml.ops_fxu.release();
+  ml.fine_boxes.release(), ml.fix_cells.release(), ml.restrict_blocks.release(), ml.boxes.release();
+  ml.gsend.release(), ml.grecv.release(), ml.fsend.release(), ml.frecv.release();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2109,7 +2206,7 @@ std::vector<int> artemis_sim_impl::amr_tags() {
 // must conserve), ghost zones of the old state included for the prolongation stencil.  Then the sequence every
 // (re)initialisation ends with: ConsToPrim, boundary exchange + conditions, PrimToCons (parthenon Mesh::Initialize).
 void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
-  old.materialise_cons();
+  if (old.gprim[0].ok()) old.materialise_cons(); // (after release_for_adoption the conserved state is all there is)
   CK(artemis_rt_stream_sync(old.stream), "sync");
   typedef std::tuple<int, int, int, int> Key;
   auto key_of = [](const artemis_host::Leaf &l) { return Key(l.level, l.lx[0], l.lx[1], l.lx[2]); };
@@ -3018,13 +3115,26 @@ struct artemis_sim {
   // adaptive runs: consecutive cycles a leaf has asked to be derefined (parthenon's derefine_count rule, upstream)
   std::map<std::tuple<int, int, int, int>, int> deref_count;
   long remeshes = 0;
+  // wall-clock seconds of the remeshes of the run (after the initial refinement): total, building the new state,
+  // handing the data over; and how many there were
+  double remesh_s = 0.0, remesh_build_s = 0.0, remesh_adopt_s = 0.0, remesh_tag_s = 0.0;
+  long remesh_n = 0;
 };
 
 // A fresh state for the same deck on a given set of leaves (the problem generator runs on it: tables, `ic` states
 // and -- during the initial refinement -- the initial condition itself at the new resolution).
-static std::unique_ptr<artemis_sim_impl> build_state(const artemis_sim &h, const std::vector<artemis_host::Leaf> *leaves) {
+static std::unique_ptr<artemis_sim_impl> build_state(const artemis_sim &h, const std::vector<artemis_host::Leaf> *leaves,
+                                                     bool adopting = false) {
   std::unique_ptr<artemis_sim_impl> np(new artemis_sim_impl());
   if (leaves) np->forced_leaves = *leaves, np->have_forced = true;
+  np->adopting = adopting;
+  if (adopting && h.p) {
+    np->reuse_from = h.p.get();
+    for (int b = 0; b < h.p->nb; ++b) {
+      const Block &B = h.p->blocks[b];
+      np->reuse_lookup[std::make_tuple(B.level, B.lx[0], B.lx[1], B.lx[2])] = b;
+    }
+  }
   std::vector<const char *> ov;
   for (const std::string &o : h.overrides) ov.push_back(o.c_str());
   try {
@@ -3105,6 +3215,8 @@ static bool next_leaves(artemis_sim &h, const std::vector<int> &tags, bool allow
 // loop of Mesh::Initialize -- refine only, and the problem generator fills the new mesh instead of a prolongation.
 static bool remesh(artemis_sim &h, bool initial) {
   if (!h.p->adaptive || !h.p->refine_field) return false;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   // tags of this rank's blocks, gathered into the global (Z-ordered) leaf list: every rank then takes the same
   // decision (an all-reduce(sum) of a vector that is zero outside the rank's own slots)
   const std::vector<int> local = h.p->amr_tags();
@@ -3117,18 +3229,27 @@ static bool remesh(artemis_sim &h, bool initial) {
     for (size_t q = 0; q < g.size(); ++q) tags[q] = static_cast<int>(g[q]);
   }
   std::vector<artemis_host::Leaf> leaves;
-  if (!next_leaves(h, tags, !initial, leaves)) return false;
-  std::unique_ptr<artemis_sim_impl> np = build_state(h, &leaves);
+  const bool changed = next_leaves(h, tags, !initial, leaves);
+  if (!initial) h.remesh_tag_s += since(t_start);
+  if (!changed) return false;
+  const auto t_build = std::chrono::steady_clock::now();
+  const bool lean = !initial && getenv("ARTEMIS_FULL_REMESH") == nullptr;
+  if (lean) h.p->release_for_adoption();
+  std::unique_ptr<artemis_sim_impl> np = build_state(h, &leaves, lean);
   np->ml_fused = np->ml_fused_possible && h.p->ml_fused; // (artemis_sim_set_path outlives a remesh)
   if (!initial) {
+    h.remesh_build_s += since(t_build);
+    const auto t_adopt = std::chrono::steady_clock::now();
     try {
       np->adopt_state_from(*h.p);
     } catch (...) {
       release_impl(np);
       throw;
     }
+    h.remesh_adopt_s += since(t_adopt);
   }
   artemis_rt_device_sync();
+  np->reuse_from = nullptr, np->reuse_lookup.clear(); // (the old state goes away)
   release_impl(h.p);
   h.p = std::move(np);
   // counters of leaves that no longer exist are dropped; new leaves start at zero
@@ -3140,6 +3261,7 @@ static bool remesh(artemis_sim &h, bool initial) {
   }
   h.deref_count.swap(keep);
   h.remeshes++;
+  if (!initial) h.remesh_s += since(t_start), h.remesh_n++;
   return true;
 }
 
@@ -3228,6 +3350,10 @@ const char *artemis_sim_stage_kernel(const artemis_sim_t *s) {
   return s->p->general_variant == 1 ? "stage2d_kernel" : (s->p->general_variant == 2 ? "stage_fused_kernel<curvilinear>" : "stage_cell_kernel");
 }
 long artemis_sim_remeshes(const artemis_sim_t *s) { return s->remeshes; }
+long artemis_sim_remesh_seconds(const artemis_sim_t *s, double *out) {
+  if (out) out[0] = s->remesh_s, out[1] = s->remesh_build_s, out[2] = s->remesh_adopt_s, out[3] = s->remesh_tag_s;
+  return s->remesh_n;
+}
 int artemis_sim_set_path(artemis_sim_t *s, const char *which) {
   const std::string w = which ? which : "";
   if (s->p->multilevel && (w == "fused" || w == "unfused")) {

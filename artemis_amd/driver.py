@@ -213,6 +213,10 @@ def _declare(L):
     L.artemis_sim_uses_tuned_kernel.argtypes = [vp]
     L.artemis_sim_remeshes.argtypes = [vp]
     L.artemis_sim_remeshes.restype = C.c_long
+    L.artemis_sim_remesh_seconds.argtypes = [vp, C.POINTER(C.c_double)]
+    L.artemis_sim_remesh_seconds.restype = C.c_long
+    L.artemis_rt_device_bytes.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int]
+    L.artemis_rt_device_bytes.restype = None
     L.artemis_sim_stage_kernel.argtypes = [vp]
     L.artemis_sim_stage_kernel.restype = C.c_char_p
     L.artemis_sim_set_path.argtypes = [vp, C.c_char_p]
@@ -289,6 +293,18 @@ class Simulation:
     uses_tuned_kernel = property(lambda s: bool(s.L.artemis_sim_uses_tuned_kernel(s.h)))
     stage_kernel = property(lambda s: s.L.artemis_sim_stage_kernel(s.h).decode())
     remeshes = property(lambda s: s.L.artemis_sim_remeshes(s.h))  # adaptive meshes: tree changes so far
+
+    def remesh_seconds(self):
+        """(number of remeshes during the run, total seconds, build seconds, hand-over seconds, tagging seconds)"""
+        out = (C.c_double * 4)()
+        n = self.L.artemis_sim_remesh_seconds(self.h, out)
+        return (n,) + tuple(out)
+
+    def device_bytes(self, reset_peak=False):
+        """(current, peak) bytes of device memory held through the library's runtime shim"""
+        cur, peak = C.c_size_t(0), C.c_size_t(0)
+        self.L.artemis_rt_device_bytes(C.byref(cur), C.byref(peak), int(reset_peak))
+        return cur.value, peak.value
     last_wall_seconds = property(lambda s: s.L.artemis_sim_last_wall_seconds(s.h))
 
     def set_path(self, which):

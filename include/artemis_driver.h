@@ -100,6 +100,10 @@ const char *artemis_sim_stage_kernel(const artemis_sim_t *sim);
 /* <parthenon/mesh> refinement = adaptive: how many times the block tree has changed so far (the initial
  * refinement passes included).  The block layout (artemis_sim_dims, block bounds / levels) changes with it. */
 long artemis_sim_remeshes(const artemis_sim_t *sim);
+/* Wall-clock cost of the remeshes DURING the run (the initial refinement passes are set-up): returns their number and
+ * fills out[4] = {total seconds, of which building the new mesh's state, handing the data over, and -- over all
+ * cycles, remeshed or not -- evaluating the refinement criterion and the tree}. */
+long artemis_sim_remesh_seconds(const artemis_sim_t *sim, double *out);
 /* which: "fused" | "unfused"; selects the kernel path (fused only where supported). */
 int artemis_sim_set_path(artemis_sim_t *sim, const char *which);
 /* Halo exchange on a second stream concurrently with interior compute (fused path, remote

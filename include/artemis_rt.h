@@ -21,6 +21,9 @@ extern "C" {
 int artemis_rt_set_device(int dev);
 void *artemis_rt_malloc(size_t bytes);      /* device memory (HBM) */
 void artemis_rt_free(void *p);
+/* bytes of device memory currently held through artemis_rt_malloc, and their high-water mark since the start (or
+ * since the last call with reset_peak != 0) -- what a remesh, which builds the new mesh next to the old one, costs */
+void artemis_rt_device_bytes(size_t *current, size_t *peak, int reset_peak);
 void *artemis_rt_malloc_host(size_t bytes); /* pinned host memory */
 void artemis_rt_free_host(void *p);
 int artemis_rt_memcpy_h2d(void *dst, const void *src, size_t n, void *stream);

@@ -42,6 +42,9 @@ def main():
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     lv = [s.block_level(b) for b in range(s.nblocks)]
+    rs = s.remesh_seconds()
+    print("remesh: n %d total %.3f s (build %.3f, hand-over %.3f; tagging over all cycles %.3f) device bytes now / peak %.2f / %.2f GB"
+          % (rs[0], rs[1], rs[2], rs[3], rs[4], s.device_bytes()[0] / 1e9, s.device_bytes()[1] / 1e9), flush=True)
     print("blocks", s.nblocks, "levels", sorted(set(lv)), "zones", s.total_zones, "setup %.2f s" % (t1 - t0), "cycles", n,
           "remeshes", s.remeshes - r0, "%.2f ms/cycle" % (1e3 * (t3 - t2) / n), "%.3e zone-cycles/s" % (zc / (t3 - t2)),
           "kernel", s.stage_kernel, "dt", s.dt, flush=True)

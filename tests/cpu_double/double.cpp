@@ -1116,6 +1116,10 @@ int artemis_hip_amr_block_maxima(const artemis_pack_t *p, int field, int magnitu
 }
 int artemis_rt_set_device(int) { return 0; }
 void *artemis_rt_malloc(size_t n) { return std::calloc(1, n ? n : 8); }
+void artemis_rt_device_bytes(size_t *current, size_t *peak, int) {
+  if (current) *current = 0;
+  if (peak) *peak = 0;
+}
 void artemis_rt_free(void *p) { std::free(p); }
 void *artemis_rt_malloc_host(size_t n) { return std::calloc(1, n ? n : 8); }
 void artemis_rt_free_host(void *p) { std::free(p); }
