@@ -152,6 +152,25 @@ struct artemis_sim_impl {
   // coarse buffer, the radial factor of the viscosity law) from the old state for every block both meshes hold on this
   // rank -- device-to-device row copies instead of a host libm pass per zone
   const artemis_sim_impl *reuse_from = nullptr;
+  // rows [b] <- src rows [ob(b)] of a [nb][nvar][N] field for every block with ob(b) >= 0: leaves are Z-ordered in both
+  // meshes, so unchanged blocks come in long runs with a constant offset -- one copy per run, not per block
+  template <class OB>
+  void copy_rows(Field &dst, const Field &src, const OB &ob) {
+    const size_t row = static_cast<size_t>(dst.nvar) * dst.N;
+    int b = 0;
+    while (b < nb) {
+      const int o0 = ob(b);
+      if (o0 < 0) {
+        ++b;
+        continue;
+      }
+      int len = 1;
+      while (b + len < nb && ob(b + len) == o0 + len) ++len;
+      CK(artemis_rt_memcpy_d2d(dst.data.p + static_cast<size_t>(b) * row, src.data.p + static_cast<size_t>(o0) * row,
+                               sizeof(Real) * row * len, stream), "d2d");
+      b += len;
+    }
+  }
   std::vector<char> ic_coarse_valid; // per block: its coarse-buffer `ic` state has been generated (or copied)
   int reuse_block(int b) const {     // the old state's local block with this block's level and logical location, or -1
     if (!reuse_from) return -1;
@@ -2028,12 +2047,9 @@ void artemis_sim_impl::problem_generator() {
     }
   }
   if (adopting && reuse_from && ic_gas.ok() && reuse_from->ic_gas.ok()) {
-    for (int b = 0; b < nb; ++b) {
-      const int ob = reuse_block(b);
-      if (ob < 0) continue;
-      CK(artemis_rt_memcpy_d2d(ic_gas.var(b, 0), reuse_from->ic_gas.var(ob, 0), sizeof(Real) * 6 * ns_gas * N, stream), "d2d");
-      if (do_dust) CK(artemis_rt_memcpy_d2d(ic_dust.var(b, 0), reuse_from->ic_dust.var(ob, 0), sizeof(Real) * 4 * ns_dust * N, stream), "d2d");
-    }
+    auto ob = [&](int b) { return reuse_block(b); };
+    copy_rows(ic_gas, reuse_from->ic_gas, ob);
+    if (do_dust) copy_rows(ic_dust, reuse_from->ic_dust, ob);
   }
   if (multilevel && ic_gas.ok()) {
     // The `ic` condition on a coarse buffer takes the profile at the buffer's own zone centres (the reference's
@@ -2119,12 +2135,10 @@ void artemis_sim_impl::problem_generator() {
       work(0);
       for (auto &th : pool) th.join();
       for (int t = 0; t < nthreads; ++t) CK(rcs[t], "viscosity radial table");
-      for (int q = 0; q < nbatch; ++q) {
-        const int ob = can_copy ? reuse_block(b0 + q) : -1;
-        if (ob >= 0) CK(artemis_rt_memcpy_d2d(visc_radial.var(b0 + q, 0), reuse_from->visc_radial.var(ob, 0), sizeof(Real) * N, stream), "d2d");
-        else upload_block(visc_radial, b0 + q, hr[q]);
-      }
+      for (int q = 0; q < nbatch; ++q)
+        if (!(can_copy && reuse_block(b0 + q) >= 0)) upload_block(visc_radial, b0 + q, hr[q]);
     }
+    if (adopting && reuse_from && reuse_from->visc_radial.ok()) copy_rows(visc_radial, reuse_from->visc_radial, [&](int b) { return reuse_block(b); });
     diff.visc.radial = visc_radial.tab();
   }
   if ((do_viscosity || do_conduction) && !getenv("ARTEMIS_NO_DISTANCE_TABLE")) {
@@ -2361,6 +2375,7 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
     }
   }
   exchange_messages(msgs);
+  std::vector<int> same_local(nb, -1); // new local block -> old local block it is a copy of
   for (const Dep &D : deps) {
     int ol, nl;
     const int orank = owner(D.og, static_cast<long>(oldL.size()), ol), nrank = owner(D.ng_, static_cast<long>(newL.size()), nl);
@@ -2368,14 +2383,12 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
     const View src = (orank == rank) ? local_view(old, ol) : remote_view(D.og);
     const View dst = local_view(*this, nl);
     if (D.kind == 0) { // unchanged block
-      if (do_gas) {
-        const double *from = (orank == rank) ? old.gu0.var(ol, 0) : remote[D.og]->gas.p;
-        CK(artemis_rt_memcpy_d2d(gu0.var(nl, 0), from, sizeof(Real) * 6 * ns_gas * N, stream), "d2d");
+      if (orank == rank) {
+        same_local[nl] = ol; // copied in runs below
+        continue;
       }
-      if (do_dust) {
-        const double *from = (orank == rank) ? old.du0.var(ol, 0) : remote[D.og]->dust.p;
-        CK(artemis_rt_memcpy_d2d(du0.var(nl, 0), from, sizeof(Real) * 4 * ns_dust * N, stream), "d2d");
-      }
+      if (do_gas) CK(artemis_rt_memcpy_d2d(gu0.var(nl, 0), remote[D.og]->gas.p, sizeof(Real) * 6 * ns_gas * N, stream), "d2d");
+      if (do_dust) CK(artemis_rt_memcpy_d2d(du0.var(nl, 0), remote[D.og]->dust.p, sizeof(Real) * 4 * ns_dust * N, stream), "d2d");
     } else if (D.kind == 1) { // refined: prolongate my octant of the parent
       for (int gas_vars = 1; gas_vars >= 0; --gas_vars) {
         if ((gas_vars && !do_gas) || (!gas_vars && !do_dust)) continue;
@@ -2389,6 +2402,11 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
         CK(artemis_hip_restrict_average(&r, stream), "RestrictAverage (remesh)");
       }
     }
+  }
+  {
+    auto ob = [&](int b) { return same_local[b]; };
+    if (do_gas) copy_rows(gu0, old.gu0, ob);
+    if (do_dust) copy_rows(du0, old.du0, ob);
   }
   CK(artemis_rt_stream_sync(stream), "sync"); // the temporaries of migrated blocks go out of scope below
   time = old.time, dt = old.dt, ncycle = old.ncycle, tlim = old.tlim, nlim = old.nlim;
@@ -3213,7 +3231,7 @@ static bool next_leaves(artemis_sim &h, const std::vector<int> &tags, bool allow
 
 // One remesh check (parthenon LoadBalancingAndAdaptiveMeshRefinement, upstream, after every cycle).  initial: the
 // loop of Mesh::Initialize -- refine only, and the problem generator fills the new mesh instead of a prolongation.
-static bool remesh(artemis_sim &h, bool initial) {
+static bool remesh(artemis_sim &h, bool initial, long force_refine_gid = -1) {
   if (!h.p->adaptive || !h.p->refine_field) return false;
   const auto t_start = std::chrono::steady_clock::now();
   auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
@@ -3227,6 +3245,10 @@ static bool remesh(artemis_sim &h, bool initial) {
     if (h.p->has_comm && h.p->nranks > 1 && h.p->comm.allreduce_sum(h.p->comm.ctx, g.data(), static_cast<int>(g.size())))
       throw std::runtime_error("allreduce of the refinement tags failed");
     for (size_t q = 0; q < g.size(); ++q) tags[q] = static_cast<int>(g[q]);
+  }
+  if (force_refine_gid >= 0) { // artemis_sim_force_refine: this leaf splits whatever the criterion says, nothing merges
+    for (int &t : tags) t = std::max(t, 0);
+    if (force_refine_gid < static_cast<long>(tags.size())) tags[force_refine_gid] = 1;
   }
   std::vector<artemis_host::Leaf> leaves;
   const bool changed = next_leaves(h, tags, !initial, leaves);
@@ -3350,6 +3372,11 @@ const char *artemis_sim_stage_kernel(const artemis_sim_t *s) {
   return s->p->general_variant == 1 ? "stage2d_kernel" : (s->p->general_variant == 2 ? "stage_fused_kernel<curvilinear>" : "stage_cell_kernel");
 }
 long artemis_sim_remeshes(const artemis_sim_t *s) { return s->remeshes; }
+int artemis_sim_force_refine(artemis_sim_t *s, long gid) {
+  int changed = 0;
+  GUARD(changed = remesh(*s, false, gid) ? 1 : 0, return -1)
+  return changed;
+}
 long artemis_sim_remesh_seconds(const artemis_sim_t *s, double *out) {
   if (out) out[0] = s->remesh_s, out[1] = s->remesh_build_s, out[2] = s->remesh_adopt_s, out[3] = s->remesh_tag_s;
   return s->remesh_n;

@@ -213,6 +213,8 @@ def _declare(L):
     L.artemis_sim_uses_tuned_kernel.argtypes = [vp]
     L.artemis_sim_remeshes.argtypes = [vp]
     L.artemis_sim_remeshes.restype = C.c_long
+    L.artemis_sim_force_refine.argtypes = [vp, C.c_long]
+    L.artemis_sim_force_refine.restype = C.c_int
     L.artemis_sim_remesh_seconds.argtypes = [vp, C.POINTER(C.c_double)]
     L.artemis_sim_remesh_seconds.restype = C.c_long
     L.artemis_rt_device_bytes.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int]
@@ -293,6 +295,14 @@ class Simulation:
     uses_tuned_kernel = property(lambda s: bool(s.L.artemis_sim_uses_tuned_kernel(s.h)))
     stage_kernel = property(lambda s: s.L.artemis_sim_stage_kernel(s.h).decode())
     remeshes = property(lambda s: s.L.artemis_sim_remeshes(s.h))  # adaptive meshes: tree changes so far
+
+    def force_refine(self, gid):
+        """Split leaf `gid` (global Z-order index) through the ordinary remesh machinery; True if the mesh changed."""
+        rc = self.L.artemis_sim_force_refine(self.h, gid)
+        if rc < 0:
+            raise RuntimeError(self.L.artemis_sim_last_error().decode())
+        self._refresh_dims()
+        return bool(rc)
 
     def remesh_seconds(self):
         """(number of remeshes during the run, total seconds, build seconds, hand-over seconds, tagging seconds)"""

@@ -125,6 +125,42 @@ def cpu_baseline(n, cycles, threads):
     return n ** 3 * done / dt, dt, done
 
 
+def cpu_baseline_disk(kind, cycles, threads):
+    """The disk workloads on the CPU oracle, bounded: `sph` = inputs/disk/disk_sph.in as shipped, 128 x 64 x 64 (gas, point-mass
+    gravity, alpha viscosity, rotating frame, ic conditions); `cyl_dust` = the cylindrical disk of configs[4] on a
+    uniform 128 x 128 x 16 mesh over |z| < 0.2 (bench.py's root mesh) with one dust species, simple_dust drag, the planet as N-body gravity, alpha
+    viscosity and the rotating frame (the oracle has no adaptive mesh of its own: oracle/adaptive.py drives it per block)."""
+    import math
+    from oracle.oracle import Oracle
+    pi = 3.141592653589793
+    if kind == "sph":
+        nx = (128, 64, 64)
+        o = Oracle(nx, (0.2, 1.059856161608513, -pi), (5.6, 2.081736491981280, pi), ng=2, reconstruct="plm", riemann="hlle",
+                   gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3, integrator="rk2", coordinates="spherical",
+                   bc=("ic", "ic", "ic", "ic", "periodic", "periodic"), nthreads=threads)
+        o.set_gravity_point(mass=1.0)
+        o.set_rotating_frame(1.0, 0.0)
+        o.set_viscosity("alpha", alpha=1e-3, r0=1.0, Omega0=1.0)
+    else:
+        nx = (128, 128, 16)
+        o = Oracle(nx, (0.3, -pi, -0.2), (4.3, pi, 0.2), ng=2, reconstruct="plm", riemann="hllc", gamma=1.4, dfloor=1e-10,
+                   siefloor=1e-10, cfl=0.3, integrator="rk2", coordinates="cylindrical", ns_dust=1, dust_reconstruct="plm",
+                   dust_riemann="hlle", dust_dfloor=1e-10, dust_cfl=0.3,
+                   bc=("ic", "ic", "periodic", "periodic", "ic", "ic"), nthreads=threads)
+        parts = [dict(GM=1.0, pos=(-0.01, 0.0, 0.0), vel=(0.0, -0.01, 0.0), rs=0.0, spline=0, couple=1),
+                 dict(GM=0.01, pos=(0.99, 0.0, 0.0), vel=(0.0, 0.99, 0.0), rs=0.03, spline=0, couple=1)]
+        o.set_gravity_nbody(parts, frame_correction=True, gm=1.01)
+        o.set_rotating_frame(1.0, 0.0)
+        o.set_viscosity("alpha", alpha=1e-3, r0=1.0, Omega0=math.sqrt(1.01))
+        o.set_drag("simple_dust", "constant", tau=[0.1])
+    o.pgen_disk(r0=1.0, rho0=1.0, dslope=-2.25, flare=0.25, h0=0.05, dens_min=1e-10, pres_min=1e-15, polytropic_index=1.0)
+    o.evolve(62.8, 1)
+    t0 = time.perf_counter()
+    o.evolve(62.8, 1 + cycles)
+    dt = time.perf_counter() - t0
+    return nx[0] * nx[1] * nx[2] * cycles / dt, dt, cycles, nx
+
+
 def host_cores():
     """What this process may actually use: logical CPUs in its affinity mask, clipped by a cgroup CPU
     quota, and the SMT width (cpu_baseline runs one thread per physical core)."""
@@ -440,6 +476,33 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    remesh_leg = None
+    if args.workload == "disk_amr":
+        # The remesh machinery on THIS mesh, outside the timed region: five leaves below the finest level, spread over
+        # the Z-ordered list, are split one after the other as if the criterion had tagged them (2:1 balance, new
+        # state, hand-over, tables), one cycle in between.  The disk is in equilibrium, so the deck's own criterion
+        # leaves the 3-D mesh alone for hundreds of cycles (the thin-slab form of tests/amr_cases.py remeshes every
+        # few cycles and is what the parity tests run).
+        n_timed, s_timed = sim.remesh_seconds()[:2]
+        remeshes_timed = int(sim.remeshes - remesh0)
+        blocks0, each = sim.nblocks, []
+        sim.device_bytes(reset_peak=True)
+        cand = [g for g in range(sim.nblocks) if sim.block_level(g) < max(sim.block_level(b) for b in range(sim.nblocks))]
+        picks = [cand[(2 * q + 1) * len(cand) // 10] for q in range(5)] if cand else []
+        for gid in picks:
+            before = sim.remesh_seconds()[1]
+            if sim.force_refine(min(gid, sim.nblocks - 1)):
+                each.append(1.0e3 * (sim.remesh_seconds()[1] - before))
+            sim.evolve(1)
+        torch.cuda.synchronize()
+        cycle_ms = 1.0e3 * elapsed / args.steps
+        remesh_leg = {"remeshes_in_timed_region": remeshes_timed, "seconds_in_timed_region": s_timed,
+                      "forced": len(each), "ms_each": each, "ms_mean": (sum(each) / len(each)) if each else None,
+                      "cycle_ms": cycle_ms, "remesh_over_cycle": (sum(each) / len(each) / cycle_ms) if each else None,
+                      "blocks_before": blocks0, "blocks_after": sim.nblocks,
+                      "device_bytes_now": sim.device_bytes()[0], "device_bytes_peak_during_remesh": sim.device_bytes()[1],
+                      "what": "five forced single-leaf refinements through the ordinary remesh path (artemis_sim_force_refine), "
+                              "one cycle apart, after the timed region"}
     kms, nlaunch = 0.0, 0
     if args.workload not in ("disk_sph_smr", "disk_amr"):  # (refined meshes: whole-stage accounting below)
         sim.set_kernel_timing(True)   # HIP events around the dominant kernel, on the stream it is launched on
@@ -531,10 +594,13 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": alg / (stage_ms * 1.0e-3) / 1.0e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": alg / (stage_ms * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_source": traffic_src,
-                               "kernel": ("whole stage: viscous pre-pass + one viscous-flux pass (three directions, zeroing folded in) + %s + boundary conditions"
-                                          % ("stage_fused_kernel<curvilinear> (fluxes, update, sources, DiffusionUpdate, ConsToPrim, dt "
-                                             "in one launch)" if sim.stage_kernel.startswith("stage_fused_kernel") else
-                                             "3 flux kernels + epilogue + PrimToCons (per-task chain)")),
+                               "kernel": ("whole stage: %s + boundary conditions"
+                                          % ("viscous_source_kernel (ZeroDiffusionFlux + ViscousFlux + DiffusionUpdate's sums, one tile march) + "
+                                             "stage_curv_kernel (fluxes, update, sources, ConsToPrim, dt in one tile march, geometry in LDS tables)"
+                                             if sim.stage_kernel == "stage_curv_kernel" else
+                                             ("viscous pre-pass + viscous-flux pass + stage_fused_kernel<curvilinear>"
+                                              if sim.stage_kernel.startswith("stage_fused_kernel") else
+                                              "3 flux kernels + epilogue + PrimToCons (per-task chain)"))),
                                "launch_ms": stage_ms, "launches_timed": 2 * args.steps, "algorithmic_bytes_per_launch": alg}
         elif args.workload in ("disk_sph_smr", "disk_amr"):
             smr = args.workload == "disk_sph_smr"
@@ -548,7 +614,7 @@ def main():
                 ("BASELINE configs[4]'s combination on one GPU, 3-D: inputs/disk/disk_nbody_cyl.in (128 x 128 x 16 root over |z| < 0.2, "
                  "16^3 blocks) + planet (N-body gravity, integrator none) + one dust species with simple_dust drag + rotating "
                  "frame + alpha viscosity + adaptive refinement on the pressure gradient, numlevel 4; %d blocks on levels %s, "
-                 "%d zones at the end, %d remeshes in the timed region" % (sim.nblocks, levels, total_zones, sim.remeshes - remesh0)))
+                 "%d zones at the end, %d remeshes in the timed region" % (sim.nblocks, levels, total_zones, remesh_leg["remeshes_in_timed_region"] if remesh_leg else 0)))
             out["config"]["decomposition"] = "1 rank, %d mesh blocks (Z-ordered leaves)" % sim.nblocks
             out["config"]["stage_path"] = sim.stage_kernel
             bps = ALG_BYTES_PER_CELL_STAGE if smr else 8.0 * 5.0 * (6 + 4)  # 8 B * 5 * (6 ns_gas + 4 ns_dust)
@@ -559,6 +625,8 @@ def main():
                                "kernel": "whole stage (stage kernels, diffusion fluxes, flux correction, block-graph exchange, "
                                          "conditions; per cycle also the timestep%s)" % ("" if smr else ", tagging and remeshes"),
                                "launch_ms": stage_ms, "launches_timed": 2 * args.steps, "algorithmic_bytes_per_launch": alg}
+            if remesh_leg:
+                out["remesh"] = remesh_leg
         elif args.workload == "ssheet_dust":
             # B_alg per cell-stage = 8 B * 5 * (6 ns_gas + 4 ns_dust); one "launch" = one stage
             # of the general fused path (gas kernel + dust kernel + drag/aux/c2p finish)
@@ -605,8 +673,19 @@ def main():
                 dropin["fused"] = value
                 dropin["frac_fused"] = value * 2.0 * ALG_BYTES_PER_CELL_STAGE / 1.0e9 / HBM_PEAK_GBS
                 out["dropin"] = dropin
-        if args.workload in ("disk_sph", "disk_sph_smr", "disk_amr"):
-            pass  # (CPU side: tests/test_oracle_pins.py times the oracle on the same deck: ~20 s for 10 cycles of 128x64x64)
+        if args.workload in ("disk_sph", "disk_sph_smr", "disk_amr") and not args.no_cpu_baseline:
+            hc = host_cores()
+            threads = args.cpu_threads or hc["physical_usable"]
+            kind = "cyl_dust" if args.workload == "disk_amr" else "sph"
+            v, secs, cyc, cnx = cpu_baseline_disk(kind, 3, threads)
+            out["cpu_baseline"] = {
+                "value": v, "unit": "zone-cycles/s", "cores": threads, "kind": "port", "threads": threads, "host": hc,
+                "sample": "CPU oracle (C++ restatement of the reference's CPU path, OpenMP) on %d threads: %s at %d x %d x %d "
+                          "(uniform mesh), %d cycles in %.1f s"
+                          % (threads, "the cylindrical disk + planet + dust + drag + viscosity of configs[4]" if kind == "cyl_dust"
+                             else "inputs/disk/disk_sph.in", cnx[0], cnx[1], cnx[2], cyc, secs)}
+        elif args.workload in ("disk_sph", "disk_sph_smr", "disk_amr"):
+            pass
         elif args.workload == "ssheet_dust" and not args.no_cpu_baseline:
             hc = host_cores()
             threads = args.cpu_threads or hc["physical_usable"]

@@ -104,6 +104,11 @@ long artemis_sim_remeshes(const artemis_sim_t *sim);
  * fills out[4] = {total seconds, of which building the new mesh's state, handing the data over, and -- over all
  * cycles, remeshed or not -- evaluating the refinement criterion and the tree}. */
 long artemis_sim_remesh_seconds(const artemis_sim_t *sim, double *out);
+/* Measurement hook (bench.py's remesh leg): split the leaf with global (Z-order) index gid as if the refinement
+ * criterion had tagged it -- the ordinary remesh machinery runs (2:1 balance, new state, hand-over of the data, block
+ * migration between ranks) and is timed like any other remesh.  Collective over the ranks (same gid everywhere).
+ * Returns 1 if the mesh changed, 0 if not (the leaf is at the finest level), < 0 on error. */
+int artemis_sim_force_refine(artemis_sim_t *sim, long gid);
 /* which: "fused" | "unfused"; selects the kernel path (fused only where supported). */
 int artemis_sim_set_path(artemis_sim_t *sim, const char *which);
 /* Halo exchange on a second stream concurrently with interior compute (fused path, remote
