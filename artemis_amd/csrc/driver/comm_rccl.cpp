@@ -35,6 +35,13 @@ struct RcclCtx {
   void *stream = nullptr;   // private stream for the host-value reductions
   double *scratch = nullptr; // device, kScratch doubles
   static constexpr int kScratch = 256;
+  // ordering of the communicator's operations across streams: the last group / device reduction posted on a caller's
+  // stream leaves an event; a host-value reduction makes the private stream wait for it before it posts its own
+  void *last_op = nullptr;
+  bool last_op_set = false;
+  void posted_on(void *s) {
+    if (last_op && artemis_rt_event_record(last_op, s) == 0) last_op_set = true;
+  }
 };
 
 bool ok(ncclResult_t r, const char *what) {
@@ -61,6 +68,7 @@ int exchange_start(void *vctx, int nmsg, const artemis_msg_t *msgs, void *stream
     if (m->send) good = good && ok(ncclSend(m->send, static_cast<size_t>(m->count), ncclDouble, m->peer, c->comm, s), "ncclSend");
   }
   const bool ended = ok(ncclGroupEnd(), "ncclGroupEnd");
+  c->posted_on(stream);
   return (good && ended) ? 0 : 1;
 }
 
@@ -68,19 +76,23 @@ int exchange_finish(void *, void *) { return 0; } // stream order does it
 
 int allreduce_min_dev(void *vctx, double *dev_value, void *stream) {
   RcclCtx *c = static_cast<RcclCtx *>(vctx);
-  return ok(ncclAllReduce(dev_value, dev_value, 1, ncclDouble, ncclMin, c->comm, static_cast<hipStream_t>(stream)),
-            "ncclAllReduce(min)")
-             ? 0
-             : 1;
+  const bool good = ok(ncclAllReduce(dev_value, dev_value, 1, ncclDouble, ncclMin, c->comm, static_cast<hipStream_t>(stream)),
+                       "ncclAllReduce(min)");
+  c->posted_on(stream);
+  return good ? 0 : 1;
 }
 
-// Host-value reductions run on the context's private stream.  PRECONDITION (RCCL orders the operations of one
-// communicator by issue order on every rank, whatever stream they are on): no exchange group of the driver may be
-// in flight -- every caller (SetGlobalTimeStep's host min in the synchronising loop, history / error sums, the
-// refinement tags, remesh) comes after the driver has synchronised its compute and comm streams, and every rank
-// reaches the call at the same point of the cycle.  The device-resident dt reduction (allreduce_min_dev) is the one
-// that runs in stream order behind exchanges.
+// Host-value reductions run on the context's private stream.  RCCL orders the operations of one communicator by issue
+// order on every rank, whatever stream they are on; every caller (SetGlobalTimeStep's host min in the synchronising
+// loop, history / error sums, the refinement tags, remesh) reaches the call at the same point of the cycle on every
+// rank.  That the communicator's previous operation -- an exchange group or the device-resident dt reduction on one of
+// the driver's streams -- is also BEHIND this one on the device is enforced here, not assumed: the private stream
+// waits for the event that operation left (RcclCtx::posted_on) before the reduction is posted.
 int host_allreduce(RcclCtx *c, double *values, int n, ncclRedOp_t op) {
+  if (c->last_op_set) {
+    if (artemis_rt_stream_wait_event(c->stream, c->last_op)) return 1;
+    c->last_op_set = false;
+  }
   for (int done = 0; done < n; done += RcclCtx::kScratch) {
     const int m = std::min(RcclCtx::kScratch, n - done);
     if (artemis_rt_memcpy_h2d(c->scratch, values + done, m * sizeof(double), c->stream)) return 1;
@@ -138,11 +150,13 @@ artemis_comm_t *artemis_comm_rccl_create(const char *unique_id, int rank, int nr
   c->rank = rank, c->nranks = nranks;
   c->stream = artemis_rt_stream_create();
   c->scratch = static_cast<double *>(artemis_rt_malloc(RcclCtx::kScratch * sizeof(double)));
-  if (!c->stream || !c->scratch) {
+  c->last_op = artemis_rt_event_create();
+  if (!c->stream || !c->scratch || !c->last_op) {
     g_comm_err = std::string("device resources: ") + artemis_hip_last_error();
     ncclCommDestroy(c->comm);
-    if (c->scratch) artemis_rt_free(c->scratch); // whichever of the two was obtained
+    if (c->scratch) artemis_rt_free(c->scratch); // whichever of them was obtained
     if (c->stream) artemis_rt_stream_destroy(c->stream);
+    if (c->last_op) artemis_rt_event_destroy(c->last_op);
     delete c;
     return nullptr;
   }
@@ -173,6 +187,7 @@ void artemis_comm_rccl_destroy(artemis_comm_t *comm) {
   ncclCommDestroy(c->comm);
   artemis_rt_free(c->scratch);
   artemis_rt_stream_destroy(c->stream);
+  artemis_rt_event_destroy(c->last_op);
   delete c;
 }
 

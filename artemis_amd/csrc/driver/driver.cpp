@@ -2666,11 +2666,15 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
     } else {
       // boundary shell first; its slabs travel on the comm stream while the bulk is computed
       a.region = 1;
+      unsigned *const clear_word = a.tiny_clear;
+      a.tiny_clear = nullptr; // (include/artemis_hip.h: with region 1 / 2 launches only the LAST launch of the stage clears
+                              //  the hint word -- the bulk launch still has to read it)
       CK(artemis_hip_stage_fused(&p, &a, stream), "stage_fused shell");
       CK(artemis_rt_event_record(ev0, stream), "event");
       CK(artemis_rt_stream_wait_event(comm_stream, ev0), "wait");
       fill_ghosts_start(out, comm_stream);
       a.region = 2;
+      a.tiny_clear = clear_word;
       CK(artemis_hip_stage_fused(&p, &a, stream), "stage_fused bulk");
       if (e0) {
         CK(artemis_rt_event_record(e1, stream), "event");

@@ -63,7 +63,8 @@ def self_launch(argv, n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this driver; a user's value wins)
         env.pop("ARTEMIS_BENCH_CHILD_CMD", None)
         procs.append(subprocess.Popen(child + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
     import threading
@@ -368,7 +369,8 @@ def main():
               "dust/dfloor=1.0e-10", "dust/stopping_time/type=constant",
               "dust/stopping_time/tau=" + ",".join(["0.1"] * args.dust), "drag/type=simple_dust",
               "parthenon/time/tlim=-1.0", "parthenon/time/nlim=-1"]
-        sim = Simulation(deck, ov)
+        make_sim = lambda: Simulation(deck, ov)
+        sim = make_sim()
     elif args.workload == "disk_sph":
         if args.gpus != 1:
             raise SystemExit("--workload disk_sph is a single-GPU measurement")
@@ -378,7 +380,8 @@ def main():
         ov = ["parthenon/time/nlim=-1"]
         for d, m in enumerate(dims, 1):
             ov += ["parthenon/mesh/nx%d=%d" % (d, m), "parthenon/meshblock/nx%d=%d" % (d, m)]
-        sim = Simulation(deck, ov)
+        make_sim = lambda: Simulation(deck, ov)
+        sim = make_sim()
     elif args.workload == "disk_sph_smr":
         # BASELINE configs[3]'s combination on one GPU: the spherical-polar disk deck x 2 in 32^3 blocks with a level-1
         # static region around the midplane (scripts/smr_timing.py sph; tests/test_multilevel.py runs its small form)
@@ -391,7 +394,8 @@ def main():
               "parthenon/static_refinement1/x2min=1.3", "parthenon/static_refinement1/x2max=1.85",
               "parthenon/static_refinement1/x3min=-3.0", "parthenon/static_refinement1/x3max=3.0",
               "problem/polytropic_index=1.40", "gas/de_switch=1e-2"]
-        sim = Simulation(deck, ov)
+        make_sim = lambda: Simulation(deck, ov)
+        sim = make_sim()
     elif args.workload == "disk_amr":
         # BASELINE configs[4]'s combination on one GPU, 3-D: inputs/disk/disk_nbody_cyl.in + a planet + one dust species
         # with drag + the rotating frame + adaptive refinement to four levels (scripts/amr_timing.py; the 2-D form runs
@@ -412,7 +416,8 @@ def main():
               "nbody/particle2/mass=1.0e-2", "nbody/particle2/couple=1", "nbody/particle2/soft/type=plummer",
               "nbody/particle2/soft/radius=0.03", "nbody/particle2/initialize/x=1.0", "nbody/particle2/initialize/vy=1.0",
               "parthenon/time/nlim=-1"]
-        sim = Simulation(deck, ov)
+        make_sim = lambda: Simulation(deck, ov)
+        sim = make_sim()
     else:
         deck = os.path.join(ROOT, "inputs", "blast", "blast.in")
         extra = []
@@ -472,10 +477,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert done == args.steps, (done, args.steps)
+    elapsed_min = elapsed_max = elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
+        tmin = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        elapsed = elapsed_max = float(t.item())
+        elapsed_min = float(tmin.item())
     remesh_leg = None
     if args.workload == "disk_amr":
         # The remesh machinery on THIS mesh, outside the timed region: five leaves below the finest level, spread over
@@ -510,6 +519,26 @@ def main():
         kms, nlaunch = sim.kernel_ms()
         sim.set_kernel_timing(False)
     hist = sim.history()
+    overlap_emulation = None
+    if (args.workload == "sedov3d" and args.gpus == 1 and not args.loopback and not args.no_dropin and sim.uses_tuned_kernel
+            and args.blocks_per_gpu == 1 and not os.environ.get("ARTEMIS_FORCE_OVERLAP")):
+        # What a rank of an N > 1 run does per stage, emulated on this one GPU: the same zones as two blocks stacked along
+        # x3 with the shell-first / bulk launch order forced (ARTEMIS_FORCE_OVERLAP: the boundary shell of every block is
+        # launched first and its slabs are packed on the comm stream while the bulk runs; the "link" is a device copy).
+        # The N > 1 expectation per GPU, before any xGMI time, is this number rather than the one-block headline.
+        os.environ["ARTEMIS_FORCE_OVERLAP"] = "1"
+        try:
+            s2 = Simulation(deck, overrides(1, per_gpu, 64, ["parthenon/meshblock/nx3=%d" % (args.n // 2)]))
+            s2.set_overlap(1)
+            s2.evolve(5)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n2 = s2.evolve(max(10, min(args.steps, 40)))
+            torch.cuda.synchronize()
+            overlap_emulation = s2.total_zones * n2 / (time.perf_counter() - t1)
+            s2.close()
+        finally:
+            del os.environ["ARTEMIS_FORCE_OVERLAP"]
     dropin = None
     if args.workload == "sedov3d" and args.gpus == 1 and not args.loopback and not args.no_dropin and sim.uses_tuned_kernel:
         # What a Parthenon host sees: (i) the fused kernel also writing `cons` on the last
@@ -573,6 +602,8 @@ def main():
                 "overlap_mode": overlap_used,  # 0 none, 1 shell + bulk launches, 2 one launch + device counter
                 "overlap_wait_timeout": wait_timeout,  # mode 2's wait kernel gave up during warm-up -> mode 1 was used
                 "ncclCommCount": rccl_ranks,
+                "ncclCommCount_matches_gpus": (rccl_ranks == args.gpus) if comm is not None else None,
+                "rank_ms_per_step": {"min": 1.0e3 * elapsed_min / args.steps, "max": 1.0e3 * elapsed_max / args.steps},
                 "transport": None if comm is None else
                              ("FALLBACK torch.distributed nccl backend (native RCCL transport failed: %s)" % comm.fallback
                               if getattr(comm, "fallback", None) else
@@ -581,6 +612,10 @@ def main():
                 "total_energy_check": float(hist[4]),
             },
         }
+        if overlap_emulation is not None:
+            out["config"]["overlap_emulation_zcps"] = overlap_emulation
+            out["config"]["overlap_emulation"] = ("the same zones as two blocks stacked along x3, shell-first + bulk launches forced "
+                                                  "(mode 1) on one GPU: what one rank of an N > 1 run does per stage, before link time")
         if args.workload == "disk_sph":
             out["metric"] = "cell-updates/sec (zone-cycles/s), spherical-polar alpha disk"
             out["config"]["workload"] = ("BASELINE configs[3] without mesh refinement: inputs/disk/disk_sph.in scaled to "
