@@ -603,8 +603,12 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
   for (int k = k0 - 2; k <= k1; ++k) {
     const bool live = k >= k0; // (wave-uniform) faces of plane k are formed
     // ---- this trip's global loads, all of them, first -------------------------------------------------------------
-    Vel6 rnn = load6(prim, radial, b, col + plane(k + 2)); // (its v3 slot is replaced by the value fetched a trip ago)
-    const double v3n3 = fused::gld(prim[b * 6 + 3], col + plane(k + 3));
+    Vel6 rnn = rn;
+    double v3n3 = v3n2;
+    if (!(a.abl & 128)) {
+      rnn = load6(prim, radial, b, col + plane(k + 2)); // (its v3 slot is replaced by the value fetched a trip ago)
+      v3n3 = fused::gld(prim[b * 6 + 3], col + plane(k + 3));
+    }
     Vel6 hnn = rnn;
     double h3n3 = v3n3;
     if (h_any && !(a.abl & 64)) hnn = load6(prim, radial, b, hcol + plane(k + 2)), h3n3 = fused::gld(prim[b * 6 + 3], hcol + plane(k + 3));
