@@ -343,6 +343,32 @@ int artemis_hip_nbody_gravity(const artemis_pack_t *p, const artemis_nbody_parti
   return 0;
 }
 
+static int validate_nbody_coords(const artemis_pack_t *p) {
+  if (p->coords != ARTEMIS_CARTESIAN && p->coords != ARTEMIS_CYLINDRICAL && p->coords != ARTEMIS_SPHERICAL3D)
+    return fail(ARTEMIS_HIP_EINVAL, "NBody does not work with axisymmetric coordinates!"); // nbody.cpp:61-62
+  if (p->coords != ARTEMIS_CARTESIAN && !p->metric)
+    return fail(ARTEMIS_HIP_EINVAL, "nbody gravity on curvilinear blocks needs the metric tables");
+  return 0;
+}
+int artemis_hip_nbody_force_scratch(const artemis_pack_t *p) {
+  if (validate(p)) return -1;
+  return artemis::nbody_grid(artemis::make_pack_view(*p));
+}
+int artemis_hip_nbody_force_sums(const artemis_pack_t *p, const artemis_nbody_particle_t *particles_dev, int npart, double omf,
+                                 double dt, const double *dt_dev, double *scratch_dev, double *force_dev, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (npart < 0 || npart > 128 || (npart > 0 && (!particles_dev || !scratch_dev || !force_dev)))
+    return fail(ARTEMIS_HIP_EINVAL, "nbody force sums: 0 <= npart <= 128, particles / scratch / force are DEVICE arrays");
+  if (int rc = validate_nbody_coords(p)) return rc;
+  if (!dt_dev && !(dt != 0.0)) return fail(ARTEMIS_HIP_EINVAL, "nbody gravity: dt must be non-zero (forces are per unit time)");
+  if (npart == 0) return 0;
+  const artemis::PackView P = artemis::make_pack_view(*p);
+  if (!artemis::nbody_force_sums_covers(P))
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "nbody force sums: at most one species per fluid (use artemis_hip_nbody_gravity)");
+  artemis::launch_nbody_force_sums(P, particles_dev, npart, omf, dt, dt_dev, scratch_dev, force_dev, S(stream));
+  return after_launch("nbody force sums");
+}
+
 int artemis_hip_rotating_frame_force(const artemis_pack_t *p, double omega, double qshear,
                                      double time, double dt, void *stream) {
   (void)time;
@@ -592,12 +618,26 @@ int artemis_hip_plm_table_fill(const artemis_pack_t *p, double *table_dev, void 
 
 // ---- refined meshes on the one-kernel stages: fine-side faces, then the coarse zones next to them redone ----------
 static int validate_diffusion(const artemis_pack_t *p, const artemis_diffusion_t *d, bool need_flux);
+static int validate_stage_nbody(const artemis_pack_t *p, const artemis_stage_general_args_t *a) {
+  if (a->nbody_n < 0 || (a->nbody_n > 0 && !a->nbody_dev)) return fail(ARTEMIS_HIP_EINVAL, "stage: nbody_dev / nbody_n");
+  if (a->nbody_n == 0) return 0;
+  if (a->gravity) return fail(ARTEMIS_HIP_EINVAL, "stage: N-body gravity and an external gravity type are exclusive (gravity.cpp:60-118)");
+  if (a->cooling) return fail(ARTEMIS_HIP_EUNSUPPORTED, "stage: N-body gravity together with cooling runs on the per-task chain");
+  if (p->gas.nspecies > 1 || p->dust.nspecies > 1)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "stage: N-body gravity inside the stage takes at most one species per fluid");
+  return validate_nbody_coords(p);
+}
 static int validate_ml_fix(const artemis_pack_t *p, const artemis_stage_general_args_t *a) {
   if (int rc = validate(p)) return rc;
   if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");
   if (int rc = validate_fluid(p, ARTEMIS_GAS, a->pcm)) return rc;
   if (int rc = validate_fluid(p, ARTEMIS_DUST, a->pcm)) return rc;
-  if (a->drag) return fail(ARTEMIS_HIP_EUNSUPPORTED, "refined-mesh fix-up: drag couples the fluids after the update; use the per-task chain");
+  if (a->drag && !a->defer_finish)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "refined-mesh fix-up: drag couples the fluids after the update: set defer_finish and run "
+                                          "artemis_hip_stage_finish after the fix-up");
+  if (int rc = validate_stage_nbody(p, a)) return rc;
+  if (a->defer_finish && ((p->gas.nspecies && !p->gas.cons0) || (p->dust.nspecies && !p->dust.cons0)))
+    return fail(ARTEMIS_HIP_EINVAL, "defer_finish: cons0 tables are required");
   if (p->gas.nspecies && (!a->gas_in || !a->gas_u1 || !a->gas_out))
     return fail(ARTEMIS_HIP_EINVAL, "refined-mesh fix-up: gas_in / gas_u1 / gas_out are required");
   if (p->dust.nspecies && (!a->dust_in || !a->dust_u1 || !a->dust_out))
@@ -831,6 +871,7 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
   }
   if (a->rf_omega != 0.0 && p->coords != ARTEMIS_CARTESIAN && a->rf_qshear != 0.0) // rotating_frame.cpp:34-38
     return fail(ARTEMIS_HIP_EINVAL, "rotating_frame/qshear must be zero for non-Cartesian coordinate systems!");
+  if (int rc = validate_stage_nbody(p, a)) return rc;
   if (a->diffusion) {
     if (int rc = validate_diffusion(p, a->diffusion, a->diffusion_sums == nullptr)) return rc;
     if (a->diffusion_sums && p->gas.nspecies != 1)
@@ -851,6 +892,10 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
     if ((p->gas.nspecies && !p->gas.cons0) || (p->dust.nspecies && !p->dust.cons0))
       return fail(ARTEMIS_HIP_EINVAL, "general stage with drag: cons0 tables are required as scratch");
   }
+  if (a->defer_finish && ((p->gas.nspecies && !p->gas.cons0) || (p->dust.nspecies && !p->dust.cons0)))
+    return fail(ARTEMIS_HIP_EINVAL, "general stage, defer_finish: cons0 tables are required");
+  if (a->defer_finish && a->cooling)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "general stage: defer_finish with cooling (it follows drag in the task list)");
   artemis::launch_stage_cell(artemis::make_pack_view(*p), *a, p->gas.recon, p->gas.riemann,
                              p->dust.recon, p->dust.riemann, S(stream));
   return after_launch("stage_general");

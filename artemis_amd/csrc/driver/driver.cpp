@@ -288,6 +288,13 @@ struct artemis_sim_impl {
   bool grav_nbody = false, nbody_frame_correction = true;
   std::vector<artemis_nbody_particle_t> particles;
   std::vector<double> particle_force; // [npart][7]
+  // the one-kernel stages take the particles from the device and leave the seven sums per particle in device
+  // accumulators (artemis_hip_nbody_force_sums): no synchronisation inside the stage loop
+  DevBuf nb_dev, nb_force_dev, nb_scratch;
+  std::vector<artemis_nbody_particle_t> nb_uploaded;
+  bool nbody_in_stage = false; // N-body gravity can run inside artemis_hip_stage_general's kernels
+  void nbody_stage_args(const artemis_pack_t &p, artemis_stage_general_args_t &a, Real bdt);
+  void flush_nbody_force();
   Real rf_omega = 0.0, rf_qshear = 0.0;
   artemis_drag_t drag;
   bool damp_to_visc = false; // <gas/damping> damp_to_visc: drag.damp_visc = &diff.visc at the call sites
@@ -925,7 +932,11 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
   // the general stage folds DiffusionUpdate (after the diffusion-flux tasks), the curvilinear rotating
   // frame and beta cooling into its kernel; cooling together with drag runs on the per-task chain
   // a refined mesh needs the stage's face fluxes for flux correction (artemis_driver.cpp:196-202): per-task chain
-  fused_possible = !(do_cooling && do_drag) && !multilevel && !grav_nbody; // (n-body: its own task + host reduction)
+  // N-body gravity rides inside the stage kernels (artemis_stage_general_args_t.nbody_dev) for at most one species per
+  // fluid; its seven sums per particle come from artemis_hip_nbody_force_sums, accumulated on the device
+  nbody_in_stage = grav_nbody && ns_gas <= 1 && ns_dust <= 1 && !do_cooling && getenv("ARTEMIS_NBODY_TASK") == nullptr &&
+                   (coords == ARTEMIS_CARTESIAN || coords == ARTEMIS_CYLINDRICAL || coords == ARTEMIS_SPHERICAL3D);
+  fused_possible = !(do_cooling && do_drag) && !multilevel && (!grav_nbody || nbody_in_stage);
   tuned = tuned && fused_possible && !(do_viscosity || do_conduction || do_cooling);
   if (getenv("ARTEMIS_NO_TUNED")) tuned = false; // experiments: route everything through artemis_hip_stage_general
   // Large 2-D gas meshes on one rank: the row-march kernel behind artemis_hip_stage_general (kernels_stage2d.hip, x2
@@ -941,13 +952,17 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
   // One exception since round 2: a single gas species without dust / drag / cooling runs the streaming tile
   // kernel's curvilinear instantiation (artemis_hip_stage_general variant 2: every face solved once, geometry
   // in registers), which beats the per-task chain (scripts/path_timing.py).
-  const bool curv_tile = do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 && !do_drag &&
+  // Since round 4 a dust species beside it, drag and N-body gravity come along: the gas march leaves the conserved
+  // state for the drag finish, the dust runs on its cell-centred kernel (kernels_stage_cell.hip launch_stage_cell).
+  const bool curv_tile = do_gas && ns_gas == 1 && ns_dust <= 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
+                         (!do_dust || getenv("ARTEMIS_NO_CURV_DUST") == nullptr) &&
                          !do_cooling && getenv("ARTEMIS_NO_FUSED_CURV") == nullptr;
   use_fused = fused_possible && (coords == ARTEMIS_CARTESIAN || curv_tile);
   // Refined meshes: the same stage kernels on every block, then the coarse zones on coarse-fine faces redone with the
-  // corrected fluxes (step_ml_fused).  Not with drag (it couples the fluids after the update) or n-body gravity (its own
-  // task and host reduction): those decks keep the per-task chain.
-  ml_fused_possible = multilevel && !do_drag && !grav_nbody && (coords == ARTEMIS_CARTESIAN || curv_tile);
+  // corrected fluxes (step_ml_fused).  Drag couples the fluids after the update: the stage and the fix-up stop at the
+  // conserved state (defer_finish) and artemis_hip_stage_finish runs once over every zone after the fix-up.
+  ml_fused_possible = multilevel && !(do_cooling && do_drag) && (!grav_nbody || nbody_in_stage) &&
+                      (coords == ARTEMIS_CARTESIAN || curv_tile);
   ml_tuned = ml_fused_possible && do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
              coords == ARTEMIS_CARTESIAN && !do_gravity && !do_rframe && !do_viscosity && !do_conduction && !do_cooling &&
              getenv("ARTEMIS_NO_TUNED") == nullptr;
@@ -2410,6 +2425,7 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
   }
   CK(artemis_rt_stream_sync(stream), "sync"); // the temporaries of migrated blocks go out of scope below
   time = old.time, dt = old.dt, ncycle = old.ncycle, tlim = old.tlim, nlim = old.nlim;
+  old.flush_nbody_force();
   particle_force = old.particle_force;
   overlap = old.overlap, time_kernels = old.time_kernels;
   base = 0;
@@ -2512,6 +2528,7 @@ void artemis_sim_impl::step_general(bool want_dt, bool device_dt) {
     a.cfl_gas = cfl_gas, a.cfl_dust = cfl_dust;
     a.dt_dev = (last && want_dt) ? (device_dt ? tstate.p + 2 : dt_dev.p) : nullptr;
     if (device_dt) a.beta_dt_dev = tstate.p + 3 + (stage - 1); // beta*dt stays on the device
+    if (do_gravity && grav_nbody) nbody_stage_args(p, a, a.bdt);
     const bool diffuse = do_gas && (do_viscosity || do_conduction);
     if (diffuse) { // artemis_driver.cpp:189-194 on the stage's input primitives
       if (visc_source) {
@@ -2545,6 +2562,44 @@ void artemis_sim_impl::step_general(bool want_dt, bool device_dt) {
   }
   base = cur;
   cons_valid = false;
+}
+
+// Gravity::NBodyGravity inside the stage (gravity.cpp:150-155 decides whether the task runs): the particle array on the
+// device (re-sent when the host copy changed), the accelerations applied by the stage kernels, the seven sums per
+// particle by one light pass over the stage's input primitives.
+void artemis_sim_impl::nbody_stage_args(const artemis_pack_t &p, artemis_stage_general_args_t &a, Real bdt) {
+  a.gravity = nullptr;
+  if (!(time >= grav.tstart && time < grav.tstop) || particles.empty()) return;
+  const int np = static_cast<int>(particles.size());
+  const size_t bytes = sizeof(artemis_nbody_particle_t) * particles.size();
+  if (!nb_dev.p) {
+    nb_dev.alloc((bytes + sizeof(double) - 1) / sizeof(double));
+    nb_force_dev.alloc(7 * particles.size());
+  }
+  const int rows = artemis_hip_nbody_force_scratch(&p);
+  if (rows < 0) throw HipFail(std::string("nbody force scratch: ") + artemis_hip_last_error());
+  if (nb_scratch.n < static_cast<size_t>(7) * np * rows) nb_scratch.alloc(static_cast<size_t>(7) * np * rows);
+  if (nb_uploaded.size() != particles.size() || std::memcmp(nb_uploaded.data(), particles.data(), bytes) != 0) {
+    CK(artemis_rt_stream_sync(stream), "sync"); // (kernels in flight read the old array)
+    CK(artemis_rt_memcpy_h2d(nb_dev.p, particles.data(), bytes, stream), "h2d particles");
+    CK(artemis_rt_stream_sync(stream), "sync");
+    nb_uploaded = particles;
+  }
+  a.nbody_dev = reinterpret_cast<const artemis_nbody_particle_t *>(nb_dev.p);
+  a.nbody_n = np;
+  a.nbody_omf = (do_rframe && nbody_frame_correction) ? rf_omega : 0.0;
+  CK(artemis_hip_nbody_force_sums(&p, a.nbody_dev, np, a.nbody_omf, bdt, a.beta_dt_dev, nb_scratch.p, nb_force_dev.p, stream),
+     "NBodyGravity (force sums)");
+}
+// the device accumulators into the host rows (before anybody reads them, and before a remesh hands the rows on)
+void artemis_sim_impl::flush_nbody_force() {
+  if (!nb_force_dev.p || particles.empty()) return;
+  std::vector<double> h(7 * particles.size());
+  CK(artemis_rt_stream_sync(stream), "sync");
+  CK(artemis_rt_memcpy_d2h(h.data(), nb_force_dev.p, h.size() * sizeof(double), stream), "d2h");
+  CK(artemis_rt_stream_sync(stream), "sync");
+  for (size_t q = 0; q < h.size(); ++q) particle_force[q] += h[q];
+  CK(artemis_rt_memset(nb_force_dev.p, 0, h.size() * sizeof(double), stream), "memset");
 }
 
 void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
@@ -2737,6 +2792,11 @@ void artemis_sim_impl::step_ml_fused() {
     a.rf_omega = do_rframe ? rf_omega : 0.0, a.rf_qshear = rf_qshear;
     a.cfl_gas = cfl_gas, a.cfl_dust = cfl_dust;
     a.dt_dev = nullptr; // the timestep is estimated after the fix-up (new_dt_unfused)
+    if (do_gravity && grav_nbody) nbody_stage_args(p, a, a.bdt);
+    if (do_drag) { // DragSource couples the fluids: it runs once, over every zone, after the fix-up
+      drag.damp_visc = damp_to_visc ? &diff.visc : nullptr;
+      a.drag = &drag, a.defer_finish = 1;
+    }
     const bool diffuse = do_gas && (do_viscosity || do_conduction);
     // viscosity alone: the five sums of artemis_hip_viscous_source for the whole pack, and the viscous fluxes themselves
     // only on the faces the flux correction touches (artemis_hip_ml_viscous_faces, below)
@@ -2777,6 +2837,10 @@ void artemis_sim_impl::step_ml_fused() {
     flux_correction_multilevel(p);
     CK(artemis_hip_ml_stage_fixup(&p, &a, static_cast<const artemis_ml_fix_cell_t *>(ml.fix_cells.p), ml.fix_cells.n, stream),
        "coarse zones on coarse-fine faces");
+    if (a.defer_finish) {
+      const artemis_pack_t po = make_pack(out);
+      CK(artemis_hip_stage_finish(&po, &drag, time, a.bdt, stream), "DragSource + SetAuxillaryFields + ConsToPrim");
+    }
     fill_ghosts(out);
     cur = out;
   }
@@ -3432,6 +3496,12 @@ int artemis_sim_overlap(const artemis_sim_t *s) { return s->p->overlap; }
 int artemis_sim_nbody_force(artemis_sim_t *s, double *out, int reset) {
   const int n = static_cast<int>(s->p->particles.size());
   if (!out) return n; // size query
+  try {
+    s->p->flush_nbody_force();
+  } catch (const std::exception &e) {
+    g_sim_err = e.what();
+    return -1;
+  }
   std::vector<double> f = s->p->particle_force;
   if (n && s->p->has_comm && s->p->nranks > 1 && s->p->comm.allreduce_sum(s->p->comm.ctx, f.data(), 7 * n)) return -1; // nbody_advance.cpp:123-131
   for (int q = 0; q < 7 * n; ++q) out[q] = f[q];

@@ -19,6 +19,9 @@ void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, doub
 int nbody_grid(const PackView &P);
 void launch_nbody_gravity(const PackView &P, const artemis_nbody_particle_t *pl_dev, int npart, double omf, double dt,
                           double *partial_dev, hipStream_t s);
+bool nbody_force_sums_covers(const PackView &P);
+void launch_nbody_force_sums(const PackView &P, const artemis_nbody_particle_t *pl_dev, int npart, double omf, double dt,
+                             const double *dt_dev, double *partial_dev, double *force_dev, hipStream_t s);
 void launch_shearing_box(const PackView &P, double omega, double qshear, double dt, hipStream_t s);
 void launch_rotating_frame(const PackView &P, double omega, double dt, hipStream_t s);
 void launch_cooling(const PackView &P, const artemis_cooling_t &C, double dt, hipStream_t s);

@@ -37,6 +37,7 @@
 #include "kernels.hpp"
 #include "pack_view.hpp"
 #include "sources_device.hpp"
+#include "nbody_device.hpp"
 #include "task_device.hpp"
 
 namespace artemis {
@@ -56,6 +57,10 @@ struct CurvK {
   double rf_omega;
   artemis_gravity_t grav;
   double *const *dsum;
+  int to_cons;                          // 1: stop after the sources, conserved state to P.gas.cons0 (drag follows)
+  const artemis_nbody_particle_t *nb_pl; // N-body gravity in the gravity task's slot (device array), nb_n particles
+  int nb_n;
+  double nb_omf;
 };
 
 enum { PW_CR = 0, PW_CL, PW_UP, PW_LO, PW_RAB, PW_RAY, PW_RBB, PW_RBY, PW_NF, // PLM_G weights that depend on one index only
@@ -125,7 +130,8 @@ ADEV double lane_above(double v) {
 }
 
 // Workgroup `id` of the launch: tile (ti, tj), chunk and block (ids dealt so that each XCD's L2 sees one run of tiles)
-template <int SYS, int RIEMANN, int RECON, bool D3, int FTX>
+// EXT: the instantiations that stop at the conserved state (drag follows) and / or carry N-body gravity
+template <int SYS, int RIEMANN, int RECON, bool D3, int FTX, bool EXT = false>
 __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, const CurvK a) {
   using T = CurvTile<FTX>;
   constexpr int FTY = T::FTY, QX = T::QX, QY = T::QY, FH = 2;
@@ -353,6 +359,12 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       u0.eg -= ds[4];
     }
     if (a.grav_on) gravity_gas(gravity_accel(a.grav, co, P.ndim, dt), dt, hx, w, u0);
+    if constexpr (EXT) if (a.nb_n) { // Gravity::NBodyGravity (nbody_device.hpp), particle by particle on the registers
+      const double wv[4] = {w.rho, w.v1, w.v2, w.v3};
+      double u[6] = {u0.d, u0.m1, u0.m2, u0.m3, u0.e, u0.eg};
+      nb_apply<true>(a.nb_pl, a.nb_n, co, a.nb_omf, dt, wv, u);
+      u0.d = u[0], u0.m1 = u[1], u0.m2 = u[2], u0.m3 = u[3], u0.e = u[4], u0.eg = u[5];
+    }
     if (a.rfc_on) { // sources_device.hpp rotating_frame_gas on the folded sums
       const RotFrame rfc = rotating_frame_terms(co, a.rf_omega, dt);
       const double qv = __any(tiny_nonzero(s.rfd)) ? s.rfd / cm.vol : div(s.rfd, rvol); // (divf / vol)
@@ -360,6 +372,11 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       u0.m2 -= rfc.omdt * qv * rfc.ep[1];
       u0.m3 -= rfc.omdt * qv * rfc.ep[2];
       u0.e += rfc.om2dt * rfc.R * (s.rfx[0] * rfc.eR[0] + s.rfx[1] * rfc.eR[1] + s.rfx[2] * rfc.eR[2]);
+    }
+    if constexpr (EXT) if (a.to_cons) { // DragSource couples the fluids next: the conserved state as the tasks would hold it
+      gst(f.cons0[b * 6 + 0], c, u0.d), gst(f.cons0[b * 6 + 1], c, u0.m1), gst(f.cons0[b * 6 + 2], c, u0.m2);
+      gst(f.cons0[b * 6 + 3], c, u0.m3), gst(f.cons0[b * 6 + 4], c, u0.e), gst(f.cons0[b * 6 + 5], c, u0.eg);
+      return;
     }
     // ---- SetAuxillaryFields (fill_derived.cpp:58-71) + ConsToPrim (:132-146)
     const double w_d = (u0.d > f.dfloor) ? u0.d : f.dfloor;
@@ -651,6 +668,11 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
 
 template <int SYS, int RIEMANN, int RECON, bool D3>
 void launch_tile(const PackView &P, const CurvK &k, bool narrow, unsigned grid, hipStream_t s) {
+  if (k.to_cons || k.nb_n) {
+    if (narrow) hipLaunchKernelGGL((stage_curv_kernel<SYS, RIEMANN, RECON, D3, 16, true>), dim3(grid), dim3(256), 0, s, P, k);
+    else hipLaunchKernelGGL((stage_curv_kernel<SYS, RIEMANN, RECON, D3, 32, true>), dim3(grid), dim3(256), 0, s, P, k);
+    return;
+  }
   if (narrow) hipLaunchKernelGGL((stage_curv_kernel<SYS, RIEMANN, RECON, D3, 16>), dim3(grid), dim3(256), 0, s, P, k);
   else hipLaunchKernelGGL((stage_curv_kernel<SYS, RIEMANN, RECON, D3, 32>), dim3(grid), dim3(256), 0, s, P, k);
 }
@@ -671,14 +693,17 @@ void launch_sys(const PackView &P, const CurvK &k, int riemann, int recon, bool 
 } // namespace
 
 // Gas (one species) on a non-Cartesian system, PCM / PLM, with the pointwise tasks the kernel folds in; diffusion only
-// as artemis_hip_viscous_source's sums (the flux-array form stays on kernels_fused.hip's instantiation).
+// as artemis_hip_viscous_source's sums (the flux-array form stays on kernels_fused.hip's instantiation).  A dust
+// species beside it, drag and N-body gravity are fine: the dust runs on its cell-centred kernel and the drag finish
+// couples the two (launch_stage_cell).
 bool curv_march_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas) {
   if (getenv("ARTEMIS_NO_CURV_MARCH")) return false;
   if (static_cast<long>(P.nk) * P.nj * P.ni >= (1L << 29)) return false;
-  if (P.coords == ARTEMIS_CARTESIAN || P.gas.ns != 1 || P.dust.ns != 0 || P.ng < 2) return false;
+  if (P.coords == ARTEMIS_CARTESIAN || P.gas.ns != 1 || P.dust.ns > 1 || P.ng < 2) return false;
   if (!g.pcm && recon_gas == ARTEMIS_PPM) return false;
-  if (g.drag || g.cooling) return false;
+  if (g.cooling) return false;
   if (g.diffusion && !g.diffusion_sums) return false;
+  if (g.nbody_n && P.coords != ARTEMIS_CYLINDRICAL && P.coords != ARTEMIS_SPHERICAL3D) return false;
   if (g.gravity && g.gravity->type != ARTEMIS_GRAVITY_UNIFORM && g.gravity->type != ARTEMIS_GRAVITY_POINT &&
       g.gravity->type != ARTEMIS_GRAVITY_BINARY)
     return false;
@@ -699,7 +724,9 @@ void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g,
   k.gam0 = g.gam0, k.gam1 = g.gam1, k.beta_dt = g.beta_dt, k.bdt = g.bdt, k.cfl = g.cfl_gas;
   k.bdt_ptr = g.beta_dt_dev;
   k.prim_in = g.gas_in, k.prim_u1 = g.gas_u1, k.prim_out = g.gas_out;
-  k.dt_bits = reinterpret_cast<unsigned long long *>(g.dt_dev);
+  k.to_cons = (g.drag || g.defer_finish) ? 1 : 0;
+  k.dt_bits = k.to_cons ? nullptr : reinterpret_cast<unsigned long long *>(g.dt_dev);
+  k.nb_pl = g.nbody_dev, k.nb_n = g.nbody_n, k.nb_omf = g.nbody_omf;
   k.has_u1 = (g.gas_u1 != g.gas_in) ? 1 : 0;
   const int nx = P.ie - P.is + 1, ny = P.je - P.js + 1, nz = P.ke - P.ks + 1;
   // tile shape: 32 x 8, or 16 x 16 where a 32-zone row would leave half the lanes without a zone (16-zone blocks)

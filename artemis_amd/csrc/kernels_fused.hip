@@ -1546,7 +1546,7 @@ bool fused_curv_covers(const PackView &P, const artemis_stage_general_args_t &g,
   if (static_cast<long>(P.nk) * P.nj * P.ni >= (1L << 29)) return false;
   if (P.coords == ARTEMIS_CARTESIAN || P.gas.ns != 1 || P.dust.ns != 0 || P.ng < 2) return false;
   if (!g.pcm && recon_gas == ARTEMIS_PPM) return false;
-  if (g.drag || g.cooling) return false;
+  if (g.drag || g.cooling || g.nbody_n || g.defer_finish) return false;
   if (g.gravity && g.gravity->type != ARTEMIS_GRAVITY_UNIFORM && g.gravity->type != ARTEMIS_GRAVITY_POINT &&
       g.gravity->type != ARTEMIS_GRAVITY_BINARY)
     return false;

@@ -10,6 +10,7 @@
 #include "diffusion_device.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "nbody_device.hpp"
 #include "pack_view.hpp"
 #include "sources_device.hpp"
 
@@ -133,78 +134,9 @@ struct NBodyView {
   const artemis_nbody_particle_t *pl; // device
   int npart;
   double omf, dt;
-  double *partial; // [npart][gridDim.x][7]
+  const double *dt_ptr; // optional device scalar replacing dt (one-kernel kernel only)
+  double *partial;      // [npart][gridDim.x][7]
 };
-ADEV double nb_idr3(const artemis_nbody_particle_t &p, const double dr2) { // particle_base.hpp:146-166
-  const double fuzz = 1e-99;
-  const double rs2 = sqr(p.rs);
-  // Plummer softening away from the particle: the spline expression is finite (its quotients have denominators above
-  // 1e-300) and enters as 0 * finite = +-0 added to a positive number -- the Plummer term alone, same bits, one
-  // division and one square root instead of four and three
-  if (p.spline == 0 && dr2 > 1e-200) return 1.0 / (fuzz + sqrt(dr2 + rs2) * (dr2 + rs2)) * 1.0;
-  const double idr3_p = 1.0 / (fuzz + sqrt(dr2 + rs2) * (dr2 + rs2));
-  const double dr3 = dr2 * sqrt(dr2);
-  const double u2 = dr2 / (rs2 + fuzz);
-  const double u = sqrt(u2);
-  const double u3 = u * u2;
-  const double h3inv = 1. / (rs2 * p.rs + fuzz);
-  const double idr3_s = (dr2 >= rs2) ? 1.0 / dr3
-                                     : ((u < 0.5) ? h3inv * (32.0 / 3.0 - 192.0 / 5.0 * u2 + 32.0 * u3)
-                                                  : h3inv * (64.0 / 3.0 - 48.0 * u + 192.0 / 5.0 * u2 - 32.0 / 3.0 * u3 -
-                                                             1.0 / (15.0 * u3)));
-  return idr3_p * (1 - p.spline) + p.spline * idr3_s;
-}
-ADEV void nb_accrete(const artemis_nbody_particle_t &p, const double x[3], const double den, const double v[3],
-                     const double vb[3], const double dt, double &dm, double dmom[3], double &dEk) { // :190-245
-  const double fuzz = 1e-99;
-  const double vrel[3] = {v[0] + vb[0], v[1] + vb[1], v[2] + vb[2]};
-  double dx[3], dv[3];
-  for (int d = 0; d < 3; d++) dx[d] = x[d] - (p.pos[d] - p.xf[d]), dv[d] = vrel[d] - (p.vel[d] - p.vf[d]);
-  const double dv2 = sqr(dv[0]) + sqr(dv[1]) + sqr(dv[2]);
-  // Outside the accretion radius (every zone of a particle with racc <= 0, nearly every zone otherwise) `acc` is
-  // false and gdt = bdt = +0, fm = -0.0, fp = +0.0: dm and dmom receive +-0 (unchanged), denp = den * (1 + -0.0) = den,
-  // and what is left is dEk += 0.5 (v + vxp) den (vxp - v) with vxp = (den v) / den -- not always v in floating point,
-  // so the three divisions stay; the other seven, the unit vectors and the ramp are skipped.  (Velocities and
-  // positions are finite, so the skipped products are 0 * finite.)  Same bits as the full expression below.
-  {
-    bool acc_ = false;
-    if (p.racc > 0.0) {
-      const double R_ = sqrt(sqr(dx[0]) + sqr(dx[1]));
-      const double r_ = sqrt(sqr(R_) + sqr(dx[2]));
-      acc_ = (r_ <= p.racc) && (-p.gm / (r_ + fuzz) + 0.5 * dv2 <= 0.0);
-    }
-    if (!acc_) {
-      for (int i = 0; i < 3; i++) {
-        const double vxp = (den * v[i]) / den;
-        dEk += 0.5 * (v[i] + vxp) * den * (vxp - v[i]);
-      }
-      return;
-    }
-  }
-  const double R = sqrt(sqr(dx[0]) + sqr(dx[1]));
-  const double r = sqrt(sqr(R) + sqr(dx[2]));
-  const double ct = dx[2] / (r + fuzz), st = R / (r + fuzz);
-  const double cp = dx[0] / (R + fuzz), sp = dx[1] / (R + fuzz);
-  // particle_base.hpp:201 binds [dr, er, et, ep] to CartToSph's {xout, ex1, ex2, ex3} (:255-257): et / ep are the
-  // second / third ROWS as written there, not the textbook unit vectors -- kept as the reference has it
-  const double et[3] = {st * sp, ct * sp, cp}, ep[3] = {ct, -st, 0.0};
-  const double dvt = dv[0] * et[0] + dv[1] * et[1] + dv[2] * et[2];
-  const double dvp = dv[0] * ep[0] + dv[1] * ep[1] + dv[2] * ep[2];
-  const bool acc = ((p.racc > 0.0) && (r <= p.racc) && (-p.gm / (r + fuzz) + 0.5 * dv2 <= 0.0));
-  const double ramp = sqr((p.racc - r) / (p.racc + fuzz));
-  const double gdt = acc * amin(ramp * p.gamma * dt, 1.0 / 9.0);
-  const double bdt = acc * amin(ramp * p.beta * dt, 1.0 / 9.0);
-  const double fm = -gdt / (1.0 + gdt);
-  dm += den * fm;
-  const double fp = (gdt - bdt) / ((1.0 + gdt) * (1.0 + bdt));
-  const double denp = den * (1.0 + fm);
-  for (int i = 0; i < 3; i++) {
-    const double dmv = den * (fm * v[i] + fp * (dvt * et[i] + dvp * ep[i]));
-    dmom[i] += dmv;
-    const double vxp = (den * v[i] + dmv) / denp;
-    dEk += 0.5 * (v[i] + vxp) * den * (vxp - v[i]) + 0.5 * den * fm * vxp * vxp;
-  }
-}
 // Zone-outer, particle-inner: the geometry of a zone (coordinates, Cartesian frame, scale factors, volume, frame
 // velocity) is formed once and the mesh is walked once, whatever the number of particles; at a zone the additions
 // happen in particle order, as before (round 2 walked the mesh once per particle: 5.8 ms per stage on the 29 M-zone
@@ -327,10 +259,13 @@ __global__ __launch_bounds__(256) void nbody_gravity_kernel(const PackView P, co
 // four / four primitives and six / four conserved variables of gas / dust are loaded together at the top of the
 // iteration (independent loads: one memory latency per zone instead of one per read-modify-write), every particle
 // acts on the registers in order, one store each at the end.  Same additions in the same order as the kernel above.
-template <bool GAS, bool DUST>
-__global__ __launch_bounds__(256) void nbody_gravity_one_kernel(const PackView P, const NBodyView N) {
+// APPLY = false: the seven sums alone (artemis_hip_nbody_force_sums: the stage kernels apply the accelerations themselves).
+template <bool GAS, bool DUST, bool APPLY = true>
+__global__ __launch_bounds__(256) void nbody_gravity_one_kernel(const PackView P, const NBodyView N_in) {
   __shared__ double red[4][7];
   __shared__ artemis_nbody_particle_t spl[NB_CHUNK];
+  NBodyView N = N_in;
+  if (N.dt_ptr) N.dt = *N.dt_ptr;
   const unsigned nx1 = P.ie - P.is + 1, nx2 = P.je - P.js + 1, nx3 = P.ke - P.ks + 1;
   const unsigned per_block = nx1 * nx2 * nx3, total = per_block * P.nb;
   for (int np0 = 0; np0 < N.npart; np0 += NB_CHUNK) {
@@ -355,89 +290,40 @@ __global__ __launch_bounds__(256) void nbody_gravity_one_kernel(const PackView P
       if constexpr (GAS) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) wg[m] = P.gas.prim[b * 6 + m][c];
+        if constexpr (APPLY) {
 #pragma unroll
-        for (int m = 0; m < 6; ++m) ug[m] = P.gas.cons0[b * 6 + m][c];
+          for (int m = 0; m < 6; ++m) ug[m] = P.gas.cons0[b * 6 + m][c];
+        }
       }
       if constexpr (DUST) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) wd[m] = P.dust.prim[b * 4 + m][c], ud[m] = P.dust.cons0[b * 4 + m][c];
+        for (int m = 0; m < 4; ++m) wd[m] = P.dust.prim[b * 4 + m][c];
+        if constexpr (APPLY) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) ud[m] = P.dust.cons0[b * 4 + m][c];
+        }
       }
-      const DCoords co = make_coords(P, b, k, j, i);
-      double x[3];
-      co.centre(x);
-      const bool cyl = (co.sys == ARTEMIS_CYLINDRICAL);
-      const Frame fr = cart_frame(co.sys, x, co.cv, co.sv, cyl ? co.cv : co.c3, cyl ? co.sv : co.s3);
-      double hx[3];
-      scale_factors_of(co, hx);
-      const double vol = co.volume();
-      double vf[3] = {0.0, 0.0, 0.0};
-      if (N.omf != 0.0) {
-        double vrot[3];
-        rotation_velocity(co, N.omf, vrot);
-        vf[0] = fr.e1[0] * vrot[0] + fr.e2[0] * vrot[1] + fr.e3[0] * vrot[2];
-        vf[1] = fr.e1[1] * vrot[0] + fr.e2[1] * vrot[1] + fr.e3[1] * vrot[2];
-        vf[2] = fr.e1[2] * vrot[0] + fr.e2[2] * vrot[1] + fr.e3[2] * vrot[2];
-      }
+      const NbZone z = nb_zone(make_coords(P, b, k, j, i), N.omf);
       double vcg[3], vcd[3]; // Cartesian velocities of the two fluids (particle-independent)
-      vcg[0] = fr.e1[0] * wg[1] + fr.e2[0] * wg[2] + fr.e3[0] * wg[3];
-      vcg[1] = fr.e1[1] * wg[1] + fr.e2[1] * wg[2] + fr.e3[1] * wg[3];
-      vcg[2] = fr.e1[2] * wg[1] + fr.e2[2] * wg[2] + fr.e3[2] * wg[3];
-      vcd[0] = fr.e1[0] * wd[1] + fr.e2[0] * wd[2] + fr.e3[0] * wd[3];
-      vcd[1] = fr.e1[1] * wd[1] + fr.e2[1] * wd[2] + fr.e3[1] * wd[3];
-      vcd[2] = fr.e1[2] * wd[1] + fr.e2[2] * wd[2] + fr.e3[2] * wd[3];
+      nb_cart_velocity(z.fr, wg, vcg), nb_cart_velocity(z.fr, wd, vcd);
 #pragma unroll 1
       for (int q = 0; q < nloc; ++q) {
         const artemis_nbody_particle_t &pl = spl[q];
         if (!pl.couple) continue;
-        double g[3] = {0.0, 0.0, 0.0};
-        {
-          double dxp[3];
-          for (int d = 0; d < 3; d++) dxp[d] = fr.x[d] - (pl.pos[d] - pl.xf[d]);
-          const double dr2 = sqr(dxp[0]) + sqr(dxp[1]) + sqr(dxp[2]);
-          const double idr3_ = nb_idr3(pl, dr2);
-          for (int d = 0; d < 3; d++) g[d] += -pl.gm * idr3_ * dxp[d];
-        }
-        const double gx1 = g[0] * fr.e1[0] + g[1] * fr.e1[1] + g[2] * fr.e1[2];
-        const double gx2 = g[0] * fr.e2[0] + g[1] * fr.e2[1] + g[2] * fr.e2[2];
-        const double gx3 = g[0] * fr.e3[0] + g[1] * fr.e3[1] + g[2] * fr.e3[2];
+        const NbPull pull = nb_pull(pl, z.fr);
         double f7[7] = {0, 0, 0, 0, 0, 0, 0};
-        auto fluid = [&](const double *w, const double *vcart, double *u, bool gas) {
-          const double dens = w[0];
-          double dm = 0.0, dmom[3] = {0.0, 0.0, 0.0}, dek = 0.0;
-          const double dei = 0.0;
-          nb_accrete(pl, fr.x, dens, vcart, vf, N.dt, dm, dmom, dek);
-          const double dmx1 = dmom[0] * fr.e1[0] + dmom[1] * fr.e1[1] + dmom[2] * fr.e1[2];
-          const double dmx2 = dmom[0] * fr.e2[0] + dmom[1] * fr.e2[1] + dmom[2] * fr.e2[2];
-          const double dmx3 = dmom[0] * fr.e3[0] + dmom[1] * fr.e3[1] + dmom[2] * fr.e3[2];
-          const double rdt = dens * N.dt;
-          u[0] += dm;
-          u[1] += hx[0] * (rdt * gx1 + dmx1);
-          u[2] += hx[1] * (rdt * gx2 + dmx2);
-          u[3] += hx[2] * (rdt * gx3 + dmx3);
-          if (gas) {
-            u[4] += dek + dei + rdt * (w[1] * gx1 + w[2] * gx2 + w[3] * gx3);
-            u[5] += dei;
-          }
-          f7[0] -= vol * dm / N.dt;
-          f7[1] -= g[0] * dens * vol;
-          f7[2] -= g[1] * dens * vol;
-          f7[3] -= g[2] * dens * vol;
-          f7[4] -= dmom[0] / N.dt;
-          f7[5] -= dmom[1] / N.dt;
-          f7[6] -= dmom[2] / N.dt;
-        };
-        if constexpr (GAS) fluid(wg, vcg, ug, true);
-        if constexpr (DUST) fluid(wd, vcd, ud, false);
+        if constexpr (GAS) nb_fluid<true, APPLY, true>(pl, z, pull, N.dt, wg, vcg, ug, f7);
+        if constexpr (DUST) nb_fluid<false, APPLY, true>(pl, z, pull, N.dt, wd, vcd, ud, f7);
 #pragma unroll
         for (int qq = 0; qq < NB_CHUNK; ++qq)
 #pragma unroll
           for (int m = 0; m < 7; ++m) lf[qq][m] += (qq == q) ? f7[m] : 0.0;
       }
-      if constexpr (GAS) {
+      if constexpr (GAS && APPLY) {
 #pragma unroll
         for (int m = 0; m < 6; ++m) P.gas.cons0[b * 6 + m][c] = ug[m];
       }
-      if constexpr (DUST) {
+      if constexpr (DUST && APPLY) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) P.dust.cons0[b * 4 + m][c] = ud[m];
       }
@@ -725,6 +611,17 @@ __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, c
   }
 }
 
+__global__ void nbody_force_sum_kernel(const artemis_nbody_particle_t *pl, int npart, int grid, const double *partial,
+                                       double *force) {
+  const int t = threadIdx.x;
+  if (t >= 7 * npart) return;
+  const int n = t / 7, q = t - 7 * n;
+  if (!pl[n].couple) return;
+  double sum = 0.0;
+  for (int w = 0; w < grid; ++w) sum += partial[(static_cast<long>(n) * grid + w) * 7 + q];
+  force[7 * n + q] += sum;
+}
+
 } // namespace
 
 int nbody_grid(const PackView &P) {
@@ -734,7 +631,7 @@ int nbody_grid(const PackView &P) {
 void launch_nbody_gravity(const PackView &P, const artemis_nbody_particle_t *pl_dev, int npart, double omf, double dt,
                           double *partial_dev, hipStream_t s) {
   NBodyView N;
-  N.pl = pl_dev, N.npart = npart, N.omf = omf, N.dt = dt, N.partial = partial_dev;
+  N.pl = pl_dev, N.npart = npart, N.omf = omf, N.dt = dt, N.dt_ptr = nullptr, N.partial = partial_dev;
   const long total = static_cast<long>(P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1) * P.nb;
   if (P.gas.ns <= 1 && P.dust.ns <= 1 && total < (1L << 31) - (1L << 20) && getenv("ARTEMIS_NBODY_GENERAL") == nullptr) {
     const dim3 grid(nbody_grid(P)), block(256);
@@ -744,6 +641,24 @@ void launch_nbody_gravity(const PackView &P, const artemis_nbody_particle_t *pl_
     return;
   }
   hipLaunchKernelGGL(nbody_gravity_kernel, dim3(nbody_grid(P)), dim3(256), 0, s, P, N);
+}
+// The seven sums per particle alone, accumulated on the device: force[7 n + q] += sum over the workgroups' partial rows
+// in index order (the additions artemis_hip_nbody_gravity makes on the host, same order).
+bool nbody_force_sums_covers(const PackView &P) {
+  const long total = static_cast<long>(P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1) * P.nb;
+  return P.gas.ns <= 1 && P.dust.ns <= 1 && total < (1L << 31) - (1L << 20);
+}
+void launch_nbody_force_sums(const PackView &P, const artemis_nbody_particle_t *pl_dev, int npart, double omf, double dt,
+                             const double *dt_dev, double *partial_dev, double *force_dev, hipStream_t s) {
+  NBodyView N;
+  N.pl = pl_dev, N.npart = npart, N.omf = omf, N.dt = dt, N.dt_ptr = dt_dev, N.partial = partial_dev;
+  const dim3 grid(nbody_grid(P)), block(256);
+  if (P.gas.ns && P.dust.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<true, true, false>), grid, block, 0, s, P, N);
+  else if (P.gas.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<true, false, false>), grid, block, 0, s, P, N);
+  else if (P.dust.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<false, true, false>), grid, block, 0, s, P, N);
+  else return;
+  hipLaunchKernelGGL(nbody_force_sum_kernel, dim3(1), dim3(64 * ((7 * npart + 63) / 64)), 0, s, pl_dev, npart,
+                     static_cast<int>(grid.x), partial_dev, force_dev);
 }
 void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, double dt, hipStream_t s) {
   hipLaunchKernelGGL(gravity_kernel, interior_grid(P), interior_threads(P), 0, s, P, G, dt);

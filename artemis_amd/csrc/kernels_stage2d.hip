@@ -651,7 +651,7 @@ bool stage2d_covers(const PackView &P, const artemis_stage_general_args_t &g, in
   if (static_cast<long>(P.nj) * P.ni >= (1L << 29)) return false; // 32-bit cell offsets
   if (P.gas.ns != 1 || P.dust.ns > 2) return false;
   if (recon_gas == ARTEMIS_PPM || (P.dust.ns && (recon_dust != recon_gas || riemann_dust == ARTEMIS_HLLC))) return false;
-  if (g.diffusion || g.cooling) return false;
+  if (g.diffusion || g.cooling || g.nbody_n || g.defer_finish) return false;
   if (g.drag && (g.drag->type != ARTEMIS_DRAG_SIMPLE_DUST || g.drag->damp_visc || P.dust.ns == 0)) return false;
   if (g.gravity && g.gravity->type != ARTEMIS_GRAVITY_UNIFORM && g.gravity->type != ARTEMIS_GRAVITY_POINT &&
       g.gravity->type != ARTEMIS_GRAVITY_BINARY)

@@ -22,6 +22,7 @@
 #include "diffusion_device.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "nbody_device.hpp"
 #include "pack_view.hpp"
 #include "sources_device.hpp"
 #include "task_device.hpp"
@@ -55,6 +56,10 @@ struct CellStageArgs {
   int diff_on, do_viscosity, rfc_on, cool_on;
   double *const *dsum; // artemis_stage_general_args_t.diffusion_sums (one gas species) or null
   artemis_cooling_t cool;
+  // Gravity::NBodyGravity in the gravity task's slot (artemis_stage_general_args_t.nbody_dev)
+  const artemis_nbody_particle_t *nb_pl;
+  int nb_n;
+  double nb_omf;
   // FIX instantiations only (refined meshes, artemis_hip_ml_stage_fixup): the zones to redo
   const artemis_ml_fix_cell_t *fix;
   int nfix;
@@ -362,6 +367,12 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
         }
       }
       if (a.grav_on) gravity_gas(ga, dt, hx, w, u0);
+      if (a.nb_n) { // nbody_device.hpp: every coupled particle in order on the registers
+        const double wv[4] = {w.rho, w.v1, w.v2, w.v3};
+        double u[6] = {u0.d, u0.m1, u0.m2, u0.m3, u0.e, u0.eg};
+        nb_apply<true>(a.nb_pl, a.nb_n, make_coords(P, b, k, j, i), a.nb_omf, dt, wv, u);
+        u0.d = u[0], u0.m1 = u[1], u0.m2 = u[2], u0.m3 = u[3], u0.e = u[4], u0.eg = u[5];
+      }
       if (a.rf_on) shear_gas(sa, dt, w, u0);
       if constexpr (EXTRA) {
         if (a.rfc_on) {
@@ -425,6 +436,12 @@ __global__ __launch_bounds__(TX *TY) void stage_cell_kernel(const PackView P, co
           u0.m2 += rdt * (0.0 * sqr(w.v1 + vf[0]) + 0.0 * sqr(w.v2 + vf[1]) + co.dh3dx2() * sqr(w.v3 + vf[2]));
       }
       if (a.grav_on) gravity_dust(ga, dt, hx, w, u0);
+      if (a.nb_n) {
+        const double wv[4] = {w.rho, w.v1, w.v2, w.v3};
+        double u[4] = {u0.d, u0.m1, u0.m2, u0.m3};
+        nb_apply<false>(a.nb_pl, a.nb_n, make_coords(P, b, k, j, i), a.nb_omf, dt, wv, u);
+        u0.d = u[0], u0.m1 = u[1], u0.m2 = u[2], u0.m3 = u[3];
+      }
       if (a.rf_on) shear_dust(sa, dt, w, u0);
       if constexpr (EXTRA) {
         if (a.rfc_on) {
@@ -484,6 +501,7 @@ CellStageArgs cell_args(const PackView &P, const artemis_stage_general_args_t &g
   a.cool_on = (g.cooling != nullptr) && P.gas.ns > 0;
   if (a.cool_on) a.cool = *g.cooling;
   a.fix = nullptr, a.nfix = 0;
+  a.nb_pl = g.nbody_dev, a.nb_n = g.nbody_n, a.nb_omf = g.nbody_omf;
   return a;
 }
 
@@ -587,6 +605,7 @@ void launch_ml_stage_fixup(const PackView &P, const artemis_stage_general_args_t
   if (ncells <= 0) return;
   CellStageArgs a = cell_args(P, g);
   a.fix = cells, a.nfix = ncells;
+  a.to_cons = g.defer_finish ? 1 : 0;
   if (P.gas.ns) {
     a.in = g.gas_in, a.u1 = g.gas_u1, a.out = g.gas_out;
     const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;
@@ -623,7 +642,10 @@ void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t
 int stage_general_variant(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
                           int recon_dust, int riemann_dust) {
   if (getenv("ARTEMIS_NO_STAGE2D") == nullptr && stage2d_covers(P, g, recon_gas, riemann_gas, recon_dust, riemann_dust)) return 1;
-  if (getenv("ARTEMIS_NO_FUSED_CURV") == nullptr && fused_curv_covers(P, g, recon_gas)) return curv_march_covers(P, g, recon_gas) ? 3 : 2;
+  if (getenv("ARTEMIS_NO_FUSED_CURV") == nullptr) {
+    if (curv_march_covers(P, g, recon_gas)) return 3;
+    if (fused_curv_covers(P, g, recon_gas)) return 2;
+  }
   return 0;
 }
 
@@ -636,17 +658,16 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
     launch_stage2d(P, g, recon_gas, riemann_gas, riemann_dust, s);
     return;
   }
-  if (variant == 3) { // curvilinear gas: the streaming tile march with its geometry in LDS tables (kernels_curv.hip)
-    launch_stage_curv(P, g, recon_gas, riemann_gas, s);
-    return;
-  }
-  if (variant == 2) { // ... with diffusion from stored flux arrays: the older instantiation, geometry in registers
+  if (variant == 2) { // curvilinear gas with diffusion from stored flux arrays: the older march, geometry in registers
     launch_stage_fused_curv(P, g, recon_gas, riemann_gas, s);
     return;
   }
+  const bool to_cons = g.drag || g.defer_finish;
   CellStageArgs a = cell_args(P, g);
-  a.to_cons = g.drag ? 1 : 0;
-  if (P.gas.ns) {
+  a.to_cons = to_cons ? 1 : 0;
+  if (variant == 3) { // curvilinear gas: the streaming tile march with its geometry in LDS tables (kernels_curv.hip)
+    launch_stage_curv(P, g, recon_gas, riemann_gas, s);
+  } else if (P.gas.ns) {
     a.in = g.gas_in, a.u1 = g.gas_u1, a.out = g.gas_out;
     const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;
     if (riemann_gas == ARTEMIS_HLLC) launch_recon<0, 0>(P, recon, a, s);
@@ -659,6 +680,7 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
     if (riemann_dust == ARTEMIS_HLLE) launch_recon<1, 1>(P, recon, a, s);
     else launch_recon<1, 2>(P, recon, a, s);
   }
+  if (g.defer_finish) return; // the caller finishes (artemis_hip_stage_finish) once its fix-up has run
   PackView Q = P; // the new state: prim tables are the out tables
   Q.gas.prim = g.gas_out, Q.dust.prim = g.dust_out;
   if (g.drag) { // coupled update on cons0, then SetAuxillaryFields and ConsToPrim into the out tables
@@ -669,7 +691,7 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
     }
   }
   if (g.dt_dev) { // EstimateTimestepMesh of the new state (gas.cpp:411-433, dust.cpp:256-272)
-    if (Q.gas.ns) launch_estimate_dt(Q, ARTEMIS_GAS, g.cfl_gas, g.dt_dev, s);
+    if (Q.gas.ns && !(variant == 3 && !to_cons)) launch_estimate_dt(Q, ARTEMIS_GAS, g.cfl_gas, g.dt_dev, s); // (the march has its own)
     if (Q.dust.ns) launch_estimate_dt(Q, ARTEMIS_DUST, g.cfl_dust, g.dt_dev, s);
   }
 }

@@ -195,7 +195,8 @@ class MeshBlockPack:
 
     def stage_general(self, gam0, gam1, beta_dt, bdt, gas=(None, None, None), dust=(None, None, None),
                       pcm=False, time=0.0, gravity=None, rotating_frame=None, drag=None,
-                      cfl=(0.0, 0.0), dt_dev=None, diffusion=None, cooling=None, diffusion_sums=None):
+                      cfl=(0.0, 0.0), dt_dev=None, diffusion=None, cooling=None, diffusion_sums=None, nbody=None,
+                      nbody_omf=0.0, defer_finish=False):
         """artemis_hip_stage_general: gas / dust = (in, u1, out) prim tables; diffusion = capi.Diffusion
         whose fluxes are already in gas_diff_flux for the `in` primitives -- or, with diffusion_sums (the table
         viscous_source returned for them), no flux array at all; cooling = capi.Cooling."""
@@ -217,6 +218,10 @@ class MeshBlockPack:
             a.cooling = C.pointer(cooling)
         if diffusion_sums is not None:
             a.diffusion_sums = diffusion_sums
+        if nbody is not None:  # (device array, count) of nbody_device(): Gravity::NBodyGravity inside the stage
+            self._nbody_keep = nbody
+            a.nbody_dev, a.nbody_n, a.nbody_omf = nbody[0].data_ptr(), nbody[1], nbody_omf
+        a.defer_finish = int(defer_finish)
         self._last_general_args = a
         # which kernel this call takes (0 cell-centred, 1 2-D row march, 2 curvilinear streaming tile)
         self.last_stage_variant = self.L.artemis_hip_stage_general_variant(C.byref(self.pack), C.byref(a))
@@ -312,9 +317,8 @@ class MeshBlockPack:
         """gravity: capi.Gravity (see gravity_point / gravity_uniform below)."""
         self._call(self.L.artemis_hip_external_gravity, C.byref(gravity), time, dt)
 
-    def NBodyGravity(self, time, dt, particles, omf=0.0):
-        """Gravity::NBodyGravity: particles = dicts with GM, pos, vel, xf, vf, rs, racc, gamma, beta, spline, couple.
-        Returns the [npart, 7] back-reaction rows of this call."""
+    @staticmethod
+    def _particle_array(particles):
         n = len(particles)
         arr = (capi.NBodyParticle * n)()
         for q, p in zip(arr, particles):
@@ -324,6 +328,28 @@ class MeshBlockPack:
                     getattr(q, name)[d_] = v
             q.rs, q.racc, q.gamma, q.beta = p.get("rs", 0.0), p.get("racc", 0.0), p.get("gamma", 0.0), p.get("beta", 0.0)
             q.spline, q.couple = int(p.get("spline", 0)), int(p.get("couple", 1))
+        return arr
+
+    def nbody_device(self, particles):
+        """The particle dicts of NBodyGravity as a DEVICE array for stage_general(nbody=...) / nbody_force_sums."""
+        arr = self._particle_array(particles)
+        return self._device_records(list(arr), capi.NBodyParticle), len(particles)
+
+    def nbody_force_sums(self, nbody, omf, dt):
+        """artemis_hip_nbody_force_sums of the pack's primitives: the [npart, 7] rows (device accumulators from zero)."""
+        dev, n = nbody
+        rows = self.L.artemis_hip_nbody_force_scratch(C.byref(self.pack))
+        scratch = torch.zeros(7 * n * rows, dtype=torch.float64, device=dev.device)
+        force = torch.zeros(7 * n, dtype=torch.float64, device=dev.device)
+        capi.check(self.L.artemis_hip_nbody_force_sums(C.byref(self.pack), C.c_void_p(dev.data_ptr()), n, omf, dt, None,
+                                                       C.c_void_p(scratch.data_ptr()), C.c_void_p(force.data_ptr()), self._stream()))
+        return force.cpu().numpy().reshape(n, 7)
+
+    def NBodyGravity(self, time, dt, particles, omf=0.0):
+        """Gravity::NBodyGravity: particles = dicts with GM, pos, vel, xf, vf, rs, racc, gamma, beta, spline, couple.
+        Returns the [npart, 7] back-reaction rows of this call."""
+        n = len(particles)
+        arr = self._particle_array(particles)
         force = (C.c_double * (7 * n))()
         capi.check(self.L.artemis_hip_nbody_gravity(C.byref(self.pack), arr, n, omf, time, dt, force, self._stream()))
         return np.array(force[:]).reshape(n, 7)

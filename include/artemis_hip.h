@@ -495,7 +495,10 @@ int artemis_hip_diffusion_dt(const artemis_pack_t *p, const artemis_diffusion_t 
  *   drag  : the coupled update needs scratch for the conserved state: p->gas.cons0 and
  *           p->dust.cons0 must be valid tables (their contents are overwritten)
  *   dt_dev: optional DEVICE scalar min-combined with cfl*min(...) of the new state
- * Bit-identical to the per-task sequence; p->{gas,dust}.prim are not used. */
+ * Bit-identical to the per-task sequence; p->{gas,dust}.prim are not used.
+ * Curvilinear packs with one gas species run the gas on the tile march (kernels_curv.hip) also with dust, drag and
+ * N-body gravity around it: the march leaves the gas conserved state in cons0 when drag follows, the dust runs on its
+ * cell-centred kernel, and the drag finish couples them. */
 typedef struct artemis_stage_general_args {
   double gam0, gam1, beta_dt, bdt;
   int pcm;
@@ -520,6 +523,21 @@ typedef struct artemis_stage_general_args {
    * [nblocks * 5]).  With it (and `diffusion` non-NULL) DiffusionUpdate subtracts these sums instead of forming them
    * from p->gas.diff_flux, which is then not read.  Same bits. */
   double *const *diffusion_sums;
+  /* optional: Gravity::NBodyGravity (gravity/nbody_gravity.hpp:28-221) folded into the stage in the task's slot of
+   * the list (after DiffusionUpdate, before RotatingFrameForce: artemis_driver.cpp:218-236) -- nbody_dev is a DEVICE
+   * array of nbody_n particles, nbody_omf the frame rate its frame correction uses (0 = none); `gravity` must be
+   * NULL with it (the reference has ONE gravity type).  The kernels add each coupled particle's acceleration and
+   * accretion terms to the conserved state they hold, particle by particle, from the stage's input primitives: the
+   * bits artemis_hip_nbody_gravity leaves.  The seven back-reaction sums per particle are NOT formed here: they depend
+   * on the input primitives alone -- artemis_hip_nbody_force_sums.  Cartesian, cylindrical and spherical 3-D packs. */
+  const artemis_nbody_particle_t *nbody_dev;
+  int nbody_n;
+  double nbody_omf;
+  /* 1 = stop after the sources with the conserved state of the active zones in p->{gas,dust}.cons0 (no DragSource,
+   * SetAuxillaryFields, ConsToPrim or dt): a refined mesh with drag redoes its listed coarse zones the same way
+   * (artemis_hip_ml_stage_fixup with the same flag) and then runs artemis_hip_stage_finish on a pack whose prim tables
+   * are the *_out tables. */
+  int defer_finish;
 } artemis_stage_general_args_t;
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
                               void *stream);
@@ -550,6 +568,17 @@ int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_gene
  * Together they replace eight launches of the per-task chain by two or three; same bits. */
 int artemis_hip_stage_epilogue_cons(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream);
 int artemis_hip_stage_finish(const artemis_pack_t *p, const artemis_drag_t *drag, double time, double dt, void *stream);
+/* The seven sums per particle of Gravity::NBodyGravity (mass-accretion rate, gravitational force, accreted-momentum
+ * rate: nbody_gravity.hpp:190-215) of p's primitives, without touching the fluid: one pass over the pack (the task
+ * kernel's force-only instantiation), then force_dev[7 n + q] += the workgroups' partial rows in index order -- the
+ * additions artemis_hip_nbody_gravity makes on the host, on the device, so the stage loop needs no synchronisation.
+ *   particles_dev : DEVICE array [npart]          dt / dt_dev : beta * dt of the stage (dt_dev replaces dt)
+ *   scratch_dev   : DEVICE doubles, 7 * npart * artemis_hip_nbody_force_scratch(p) of them
+ *   force_dev     : DEVICE accumulators [7 * npart], zeroed by the caller once
+ * At most one species per fluid, npart <= 128. */
+int artemis_hip_nbody_force_scratch(const artemis_pack_t *p);
+int artemis_hip_nbody_force_sums(const artemis_pack_t *p, const artemis_nbody_particle_t *particles_dev, int npart, double omf,
+                                 double dt, const double *dt_dev, double *scratch_dev, double *force_dev, void *stream);
 
 /* ---- mesh-refinement data-path operators (the operators only) ---------------
  * ArtemisUtils::RestrictAverage<GEOM> (utils/refinement/restriction.hpp:42-114) and

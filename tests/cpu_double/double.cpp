@@ -315,22 +315,42 @@ int artemis_hip_external_gravity(const artemis_pack_t *p, const artemis_gravity_
   }
   return 0;
 }
+static void set_nbody(Sim &s, const artemis_nbody_particle_t *pl, int npart, double omf) {
+  s.grav.type = 4;
+  s.nbody.assign(npart, Sim::NBodyParticle());
+  for (int n = 0; n < npart; ++n) {
+    Sim::NBodyParticle &q = s.nbody[n];
+    q.GM = pl[n].gm, q.rs = pl[n].rs, q.racc = pl[n].racc, q.gamma = pl[n].gamma, q.beta = pl[n].beta;
+    q.spline = pl[n].spline, q.couple = pl[n].couple;
+    for (int d = 0; d < 3; ++d) q.pos[d] = pl[n].pos[d], q.vel[d] = pl[n].vel[d], q.xf[d] = pl[n].xf[d], q.vf[d] = pl[n].vf[d];
+  }
+  s.rframe.on = (omf != 0.0), s.rframe.omega = omf, s.nbody_frame_correction = true;
+  s.pforce.assign(static_cast<size_t>(7) * npart, 0.0);
+}
+int artemis_hip_nbody_force_scratch(const artemis_pack_t *) { return 1; }
+// the seven sums alone: the task on a copy of the block (its fluid update is discarded)
+int artemis_hip_nbody_force_sums(const artemis_pack_t *p, const artemis_nbody_particle_t *pl, int npart, double omf, double dt,
+                                 const double *dt_dev, double *, double *force, void *) {
+  if (dt_dev) dt = *dt_dev;
+  for (int b = 0; b < p->nblocks; ++b) {
+    Bound B(p, b);
+    Sim &s = *B.s;
+    B.in(s.gprim, p->gas.prim, s.nvg), B.in(s.dprim, p->dust.prim, s.nvd);
+    prim_to_cons(s);
+    set_nbody(s, pl, npart, omf);
+    s.grav.tstart = -1e300, s.grav.tstop = 1e300;
+    nbody_gravity(s, 0.0, dt);
+    for (int q = 0; q < 7 * npart; ++q) force[q] += s.pforce[q];
+  }
+  return 0;
+}
 int artemis_hip_nbody_gravity(const artemis_pack_t *p, const artemis_nbody_particle_t *pl, int npart, double omf, double time,
                               double dt, double *force, void *) {
   for (int b = 0; b < p->nblocks; ++b) {
     Bound B(p, b);
     Sim &s = *B.s;
     B.load_state();
-    s.grav.type = 4;
-    s.nbody.assign(npart, Sim::NBodyParticle());
-    for (int n = 0; n < npart; ++n) {
-      Sim::NBodyParticle &q = s.nbody[n];
-      q.GM = pl[n].gm, q.rs = pl[n].rs, q.racc = pl[n].racc, q.gamma = pl[n].gamma, q.beta = pl[n].beta;
-      q.spline = pl[n].spline, q.couple = pl[n].couple;
-      for (int d = 0; d < 3; ++d) q.pos[d] = pl[n].pos[d], q.vel[d] = pl[n].vel[d], q.xf[d] = pl[n].xf[d], q.vf[d] = pl[n].vf[d];
-    }
-    s.rframe.on = (omf != 0.0), s.rframe.omega = omf, s.nbody_frame_correction = true;
-    s.pforce.assign(static_cast<size_t>(7) * npart, 0.0);
+    set_nbody(s, pl, npart, omf);
     nbody_gravity(s, time, dt);
     for (int q = 0; q < 7 * npart; ++q) force[q] += s.pforce[q];
     B.out(s.gu0, p->gas.cons0, s.nvg), B.out(s.du0, p->dust.cons0, s.nvd);
@@ -582,9 +602,32 @@ static void stage_block(const artemis_pack_t *p, const artemis_stage_general_arg
       s.grav.given_pos = true;
       external_gravity(s, a->time, a->bdt);
     }
+    if (a->nbody_n) { // Gravity::NBodyGravity in the gravity task's slot ("device" memory is host memory here)
+      set_nbody(s, a->nbody_dev, a->nbody_n, a->nbody_omf);
+      s.grav.tstart = -1e300, s.grav.tstop = 1e300;
+      nbody_gravity(s, a->time, a->bdt);
+      s.rframe.on = (p->omega_frame != 0.0), s.rframe.omega = p->omega_frame;
+    }
     if (a->rf_omega != 0.0) {
       s.rframe.on = true, s.rframe.omega = a->rf_omega, s.rframe.qshear = a->rf_qshear;
       rotating_frame_force(s, a->bdt);
+    }
+    if (a->defer_finish) { // the conserved state of the zones, for artemis_hip_stage_finish
+      auto putc = [&](const RVec &src, double *const *tab, int nvar) {
+        for (int v = 0; v < nvar; ++v) {
+          if (fix) {
+            for (const artemis_ml_fix_cell_t *fc : *fix) tab[b * nvar + v][IDX(s, fc->k, fc->j, fc->i)] = src[v * s.N + IDX(s, fc->k, fc->j, fc->i)];
+            continue;
+          }
+          for (int k = s.ks; k <= s.ke; ++k)
+            for (int j = s.js; j <= s.je; ++j)
+              std::memcpy(tab[b * nvar + v] + IDX(s, k, j, s.is), src.data() + v * s.N + IDX(s, k, j, s.is),
+                          (s.ie - s.is + 1) * sizeof(Real));
+        }
+      };
+      if (s.c.ns_gas) putc(s.gu0, p->gas.cons0, s.nvg);
+      if (s.c.ns_dust) putc(s.du0, p->dust.cons0, s.nvd);
+      return;
     }
     if (a->drag) {
       const artemis_drag_t *d = a->drag;
@@ -642,7 +685,6 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
 // include/artemis_hip.h "flux correction as a thin fix-up": the fine side's faces ...
 int artemis_hip_ml_face_fluxes(const artemis_pack_t *p, const artemis_stage_general_args_t *a, const artemis_ml_face_box_t *boxes,
                                int nboxes, void *) {
-  if (a->drag) return bad("refined-mesh fix-up: drag is not supported");
   std::map<int, std::vector<const artemis_ml_face_box_t *>> per_block;
   for (int q = 0; q < nboxes; ++q) per_block[boxes[q].block].push_back(&boxes[q]);
   for (auto &kv : per_block) {
@@ -673,7 +715,7 @@ int artemis_hip_ml_stage_fixup(const artemis_pack_t *p, const artemis_stage_gene
   artemis_stage_general_args_t args = *a_in;
   if (args.beta_dt_dev) args.beta_dt = args.bdt = *args.beta_dt_dev;
   args.dt_dev = nullptr;
-  if (args.drag) return bad("refined-mesh fix-up: drag is not supported");
+  if (args.drag && !args.defer_finish) return bad("refined-mesh fix-up: drag needs defer_finish");
   std::map<int, std::vector<const artemis_ml_fix_cell_t *>> per_block;
   for (int q = 0; q < ncells; ++q) per_block[cells[q].block].push_back(&cells[q]);
   for (auto &kv : per_block) stage_block(p, &args, kv.first, &kv.second);

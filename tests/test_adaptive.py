@@ -169,7 +169,7 @@ def test_disk_with_planet_dust_and_adaptive_mesh(hiplib):
           "nbody/particle2/soft/radius=0.03", "nbody/particle2/initialize/x=1.0", "nbody/particle2/initialize/vy=1.0"]
     s = Simulation(DECK("disk", "disk_nbody_cyl.in"), ov)
     lv = levels(s)
-    assert set(lv) == {0, 1, 2} and s.remeshes >= 2 and not s.uses_fused_path
+    assert set(lv) == {0, 1, 2} and s.remeshes >= 2 and s.uses_fused_path  # (round 4: drag + n-body inside the one-kernel stages)
     assert sum(8.0 ** (-s.block_level(b)) for b in range(s.nblocks)) == 64.0
     s.evolve(20)
     assert s.ncycle == 20 and 1e-4 < s.dt < 3e-2
@@ -204,7 +204,7 @@ def test_hip_driver_equals_adaptive_oracle(hiplib, name, kw, cycles, batch, min_
     case = getattr(amr_cases, name)(**kw)
     s = Simulation(amr_cases.DECK(*case["deck"]), case["overrides"])
     m = case["oracle"]()
-    assert s.remeshes == m.remeshes and s.uses_fused_path == (name != "disk_planet_dust_amr")  # drag + n-body: the per-task chain
+    assert s.remeshes == m.remeshes and s.uses_fused_path  # (configs[4] too since round 4: drag + n-body inside the stages)
     r0, done, seen = s.remeshes, 0, set()
     while done < cycles:
         done += s.evolve(min(batch, cycles - done))

@@ -53,8 +53,11 @@ def test_disk_nbody_reference_test_pin(gam, b):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["fused", "unfused"])
 @pytest.mark.parametrize("b", NB["bc"])
-def test_disk_nbody_deck_hip_equals_oracle(hiplib, b):
+def test_disk_nbody_deck_hip_equals_oracle(hiplib, b, path):
+    """path = fused (the default since round 4): NBodyGravity inside the curvilinear tile march, its seven sums per
+    particle from artemis_hip_nbody_force_sums in device accumulators; unfused: the task with its host-side reduction."""
     from artemis_amd.driver import Simulation
     nx = (64, 32, 16)
     ov = ["parthenon/time/nlim=6"] + [f"parthenon/mesh/nx{d + 1}={n}" for d, n in enumerate(nx)] + \
@@ -62,7 +65,9 @@ def test_disk_nbody_deck_hip_equals_oracle(hiplib, b):
     for d in ("x1", "x3"):
         ov += [f"parthenon/mesh/i{d}_bc={b}", f"parthenon/mesh/o{d}_bc={b}"]
     s = Simulation(DECK, ov)
-    assert not s.uses_fused_path  # NBodyGravity is a task of its own with a host-visible reduction
+    assert s.uses_fused_path
+    s.set_path(path)
+    assert s.uses_fused_path == (path == "fused")
     s.evolve()
     o = nbody_disk_oracle(nx, 1.0, b)
     o.evolve(62.8, 6)

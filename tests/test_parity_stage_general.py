@@ -560,3 +560,79 @@ def test_refined_mesh_fixup_contract(hiplib, coordinates, nx, lo, hi):
     assert np.array_equal(dd[:, rest], stage_d[0].cpu().numpy()[:, rest])
     # and the altered fluxes did matter: the stage kernel's own result differs at the listed zones
     assert not np.array_equal(stage_g[0].cpu().numpy()[0][listed], g[0][listed])
+
+
+NBODY_BLOCKS = [
+    ("cartesian", (24, 12, 10), (-1.0, -0.5, -0.35), (1.0, 0.8, 0.35), 0),
+    ("cylindrical", (35, 18, 20), (0.5, -3.1, -0.6), (2.3, 3.1, 0.6), 3),   # the tile march + dust cell kernel + drag finish
+    ("cylindrical", (16, 16, 1), (0.5, -3.1, -0.5), (2.3, 3.1, 0.5), 3),    # ... 2-D
+    ("spherical", (34, 12, 20), (0.5, 1.1, -3.1), (2.3, 2.04, 3.1), 3),
+]
+
+
+@pytest.mark.parametrize("coordinates,nx,lo,hi,variant", NBODY_BLOCKS)
+@pytest.mark.parametrize("mode", ["drag", "defer", "gas_only"])
+def test_general_stage_with_nbody_gravity_and_drag(hiplib, coordinates, nx, lo, hi, variant, mode):
+    """Gravity::NBodyGravity inside the one-kernel stage (artemis_stage_general_args_t.nbody_dev): a spline-softened
+    accreting sink, a Plummer particle with a momentum sink and an uncoupled one, with the frame correction of a
+    rotating frame, followed by the rotating-frame task and simple_dust drag -- against the oracle's task chain
+    (artemis_driver.cpp:182-255), bit for bit; the seven sums per particle (artemis_hip_nbody_force_sums) to 1e-12.
+    mode = drag: DragSource + SetAuxillaryFields + ConsToPrim inside the call; defer: the call stops at the conserved
+    state (defer_finish, what a refined mesh does around its fix-up) and artemis_hip_stage_finish completes it;
+    gas_only: no dust, no drag (the march stores primitives itself)."""
+    from artemis_amd.pack import MeshBlockPack, drag_params
+    cart = coordinates == "cartesian"
+    nsd = 0 if mode == "gas_only" else 1
+    kw = dict(ng=2, ns_gas=1, ns_dust=nsd, reconstruct="plm", riemann="hllc", dust_reconstruct="plm", dust_riemann="hlle",
+              gamma=1.4, dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10, coordinates=coordinates)
+    o = Oracle(nx, lo, hi, bc=("outflow",) * 6, cfl=0.3, dust_cfl=0.3, **kw)
+    random_state(o, np.random.default_rng(17), shock=False, mach=0.5, contrast=10.0)
+    om = 0.8
+    mb = MeshBlockPack(1, nx, [lo], [hi], with_fluxes=False, omega_frame=om, **kw)
+    push([o], mb)
+    o.DeepCopyConservedData()
+    parts = [dict(GM=1.3, pos=(1.1, -0.1, 0.05), vel=(0.1, 0.4, -0.2), rs=0.3, racc=0.9, gamma=4.0, beta=0.0, spline=1),
+             dict(GM=0.4, pos=(-0.9, 0.75, 0.1), vel=(0.0, -0.3, 0.1), xf=(0.01, 0.02, 0.0), vf=(0.0, 0.1, 0.0), rs=0.1,
+                  racc=0.8, gamma=2.0, beta=6.0, spline=0),
+             dict(GM=5.0, pos=(0.0, 0.0, 0.0), couple=0)]
+    o.set_rotating_frame(om, 1.5 if cart else 0.0)
+    o.set_gravity_nbody(parts, frame_correction=True)
+    tau = [0.05]
+    if nsd:
+        o.set_drag("simple_dust", "constant", tau=tau)
+    dt, time = 2.0e-3, 0.1
+    for fluid in (0, 1):
+        o.CalculateFluxes(fluid, False)
+    o.ApplyUpdate(0.0, 1.0, dt)
+    for fluid in (0, 1):
+        o.FluxSource(dt, fluid)
+    o.ExternalGravity(time, dt)
+    want_force = o.nbody_force(reset=True)
+    o.RotatingFrameForce(dt)
+    if nsd:
+        o.DragSource(dt)
+    o.SetAuxillaryFields()
+    o.ConsToPrim()
+    nb = mb.nbody_device(parts)
+    got_force = mb.nbody_force_sums(nb, om, dt)
+    scale = np.abs(want_force).max(axis=1, keepdims=True) + 1e-300
+    assert np.all(got_force[2] == 0.0) and np.max(np.abs(got_force - want_force) / scale) < 1e-12, (got_force, want_force)
+    drag = drag_params("simple_dust", "constant", tau=tau, mesh_min=lo, mesh_max=hi) if nsd else None
+    gbuf, gout = mb.new_prim_buffer("o")
+    dbuf, dout = mb.new_dust_prim_buffer("o") if nsd else (None, None)
+    mb.stage_general(0.0, 1.0, dt, dt, gas=(mb.gas_prim_table, mb.gas_prim_table, gout),
+                     dust=(mb.dust_prim_table, mb.dust_prim_table, dout) if nsd else (None, None, None), time=time,
+                     rotating_frame=(om, 1.5 if cart else 0.0), drag=drag, nbody=nb, nbody_omf=om,
+                     defer_finish=(mode == "defer"))
+    assert mb.last_stage_variant == variant
+    I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
+    keep = [0, 1, 2, 3, 5]
+    if mode == "defer":  # the finish works on the pack's own primitive tables
+        mb.stage_finish(time, dt, drag)
+        got_g, got_d = mb.gas_prim[0][I].cpu().numpy(), mb.dust_prim[0][I]
+    else:
+        got_g, got_d = gbuf[0][I].cpu().numpy(), (dbuf[0][I] if nsd else None)
+    bad = got_g[keep] != o.gprim[I][keep]
+    assert not bad.any(), (np.count_nonzero(bad), np.argwhere(bad)[:5])
+    if nsd:
+        same(got_d, o.dprim[I], "dust prim")
