@@ -49,7 +49,8 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
                              hipStream_t s);
 // kernels_curv.hip
 bool curv_march_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas);
-void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas, hipStream_t s);
+bool curv_march_covers_dust(const PackView &P, const artemis_stage_general_args_t &g, int recon_dust, int riemann_dust);
+void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g, int fluid, int recon, int riemann, hipStream_t s);
 // kernels_diffusion.hip
 void launch_zero_diffusion_flux(const PackView &P, hipStream_t s);
 // overwrite: ZeroDiffusionFlux folded in (the flux arrays are overwritten on the face ranges)

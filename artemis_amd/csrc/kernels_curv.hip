@@ -104,18 +104,45 @@ ADEV Cell6 finish_cell(const Raw5 &r, double gm1) {
   q.p = amax(0.0, gm1 * q.d * q.e); // fill_derived.cpp:247 (IdealGas P)
   return q;
 }
+// Riemann problem of sweep direction DIR for the kernel's fluid: the gas solvers of fused_device.hpp, or Dust's HLLE / LLF
+// (dust/riemann: task_device.hpp riemann_dust) with the energy, pressure-flux and face-velocity slots left at zero
+template <bool DUST, int RIEMANN, int DIR>
+ADEV Flux8 solve_fluid(const GasK &gk, const Cell6 &L, const Cell6 &R, const bool fast) {
+  if constexpr (!DUST) {
+    return solve_face<RIEMANN, DIR>(gk, L, R, fast);
+  } else {
+    Prim4 l, r;
+    l.d = L.d, r.d = R.d;
+    if constexpr (DIR == 1) l.vx = L.v1, l.vy = L.v2, l.vz = L.v3, r.vx = R.v1, r.vy = R.v2, r.vz = R.v3;
+    else if constexpr (DIR == 2) l.vx = L.v2, l.vy = L.v3, l.vz = L.v1, r.vx = R.v2, r.vy = R.v3, r.vz = R.v1;
+    else l.vx = L.v3, l.vy = L.v1, l.vz = L.v2, r.vx = R.v3, r.vy = R.v1, r.vz = R.v2;
+    FaceFlux F;
+    riemann_dust<(RIEMANN == 2) ? 2 : 1>(l, r, F);
+    Flux8 o;
+    o.d = F.fd, o.e = o.eg = o.pf = o.vf = 0.0;
+    if constexpr (DIR == 1) o.m1 = F.fmx, o.m2 = F.fmy, o.m3 = F.fmz;
+    else if constexpr (DIR == 2) o.m2 = F.fmx, o.m3 = F.fmy, o.m1 = F.fmz;
+    else o.m3 = F.fmx, o.m1 = F.fmy, o.m2 = F.fmz;
+    return o;
+  }
+}
+// The dust instantiation (DUST) carries rho, v1, v2, v3 only: the pressure / energy slots of the staged cell and the
+// energy / pressure-flux / face-velocity slots of a face flux are skipped (every X body below is guarded by its index).
 #define CFOR6(X) X(d, 0) X(v1, 1) X(v2, 2) X(v3, 3) X(p, 4) X(e, 5)
 #define CGET6(dst, A, ...)                                                                 \
   dst.d = A[0] __VA_ARGS__, dst.v1 = A[1] __VA_ARGS__, dst.v2 = A[2] __VA_ARGS__,          \
-  dst.v3 = A[3] __VA_ARGS__, dst.p = A[4] __VA_ARGS__, dst.e = A[5] __VA_ARGS__
+  dst.v3 = A[3] __VA_ARGS__;                                                               \
+  if constexpr (!DUST) dst.p = A[4] __VA_ARGS__, dst.e = A[5] __VA_ARGS__
 #define CPUT8(A, fl, ...)                                                                  \
   A[0] __VA_ARGS__ = fl.d, A[1] __VA_ARGS__ = fl.m1, A[2] __VA_ARGS__ = fl.m2,             \
-  A[3] __VA_ARGS__ = fl.m3, A[4] __VA_ARGS__ = fl.e, A[5] __VA_ARGS__ = fl.eg,             \
-  A[6] __VA_ARGS__ = fl.pf, A[7] __VA_ARGS__ = fl.vf
+  A[3] __VA_ARGS__ = fl.m3;                                                                \
+  if constexpr (!DUST)                                                                     \
+  A[4] __VA_ARGS__ = fl.e, A[5] __VA_ARGS__ = fl.eg, A[6] __VA_ARGS__ = fl.pf, A[7] __VA_ARGS__ = fl.vf
 #define CGET8(fl, A, ...)                                                                  \
   fl.d = A[0] __VA_ARGS__, fl.m1 = A[1] __VA_ARGS__, fl.m2 = A[2] __VA_ARGS__,             \
-  fl.m3 = A[3] __VA_ARGS__, fl.e = A[4] __VA_ARGS__, fl.eg = A[5] __VA_ARGS__,             \
-  fl.pf = A[6] __VA_ARGS__, fl.vf = A[7] __VA_ARGS__
+  fl.m3 = A[3] __VA_ARGS__;                                                                \
+  if constexpr (!DUST)                                                                     \
+  fl.e = A[4] __VA_ARGS__, fl.eg = A[5] __VA_ARGS__, fl.pf = A[6] __VA_ARGS__, fl.vf = A[7] __VA_ARGS__
 
 // the value held by the lane below / above (kernels_stage2d.hip: wave_shr:1 / wave_shl:1, one move per dword)
 ADEV double lane_below(double v) {
@@ -131,10 +158,13 @@ ADEV double lane_above(double v) {
 
 // Workgroup `id` of the launch: tile (ti, tj), chunk and block (ids dealt so that each XCD's L2 sees one run of tiles)
 // EXT: the instantiations that stop at the conserved state (drag follows) and / or carry N-body gravity
-template <int SYS, int RIEMANN, int RECON, bool D3, int FTX, bool EXT = false>
+// DUST: the march of the dust species (rho, v: Dust::CalculateFluxes' HLLE / LLF, Dust::FluxSource's coordinate source,
+// gravity / N-body / rotating frame on four conserved variables, Dust's ConsToPrim and timestep)
+template <int SYS, int RIEMANN, int RECON, bool D3, int FTX, bool EXT = false, bool DUST = false>
 __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, const CurvK a) {
   using T = CurvTile<FTX>;
   constexpr int FTY = T::FTY, QX = T::QX, QY = T::QY, FH = 2;
+  constexpr int NV = DUST ? 4 : 6; // staged variables; also the stride of the fluid's pointer tables (one species)
   constexpr bool PG = (RECON == 1); // PLM_G
   __shared__ T S;
   const int t = threadIdx.x, tx = t % FTX, ty = t / FTX;
@@ -160,13 +190,23 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   double beta_dt = a.beta_dt, bdt = a.bdt;
   if (a.bdt_ptr) beta_dt = bdt = *a.bdt_ptr;
   const double *g = P.geom + 6 * b;
-  const double *in_r = a.prim_in[b * 6 + 0], *in_1 = a.prim_in[b * 6 + 1], *in_2 = a.prim_in[b * 6 + 2];
-  const double *in_3 = a.prim_in[b * 6 + 3], *in_e = a.prim_in[b * 6 + 5];
-  const double *u1_r = a.prim_u1[b * 6 + 0], *u1_1 = a.prim_u1[b * 6 + 1], *u1_2 = a.prim_u1[b * 6 + 2];
-  const double *u1_3 = a.prim_u1[b * 6 + 3], *u1_e = a.prim_u1[b * 6 + 5];
+  const double *in_r = a.prim_in[b * NV + 0], *in_1 = a.prim_in[b * NV + 1], *in_2 = a.prim_in[b * NV + 2];
+  const double *in_3 = a.prim_in[b * NV + 3], *in_e = DUST ? in_r : a.prim_in[b * NV + (NV - 1)]; // (dust: never loaded)
+  const double *u1_r = a.prim_u1[b * NV + 0], *u1_1 = a.prim_u1[b * NV + 1], *u1_2 = a.prim_u1[b * NV + 2];
+  const double *u1_3 = a.prim_u1[b * NV + 3], *u1_e = DUST ? u1_r : a.prim_u1[b * NV + (NV - 1)];
   const unsigned sj = static_cast<unsigned>(P.sj), sk = static_cast<unsigned>(P.sk);
   const unsigned col = static_cast<unsigned>(jl) * sj + static_cast<unsigned>(il);
-  const FluidView &f = P.gas;
+  const FluidView &f = DUST ? P.dust : P.gas;
+  auto ldraw = [&](const double *r_, const double *v1_, const double *v2_, const double *v3_, const double *e_, unsigned c_) {
+    Raw5 q;
+    q.d = gld(r_, c_), q.v1 = gld(v1_, c_), q.v2 = gld(v2_, c_), q.v3 = gld(v3_, c_);
+    if constexpr (DUST) q.e = 0.0;
+    else q.e = gld(e_, c_);
+    return q;
+  };
+  auto ldcell = [&](const double *r_, const double *v1_, const double *v2_, const double *v3_, const double *e_, unsigned c_) {
+    return finish_cell(ldraw(r_, v1_, v2_, v3_, e_, c_), gm1);
+  };
   // cos / sin of the x3 cell centres (spherical3D, axisymmetric): ConvertCoordsToCart of the gravity task
   const double *m3 = nullptr;
   if ((SYS == ARTEMIS_SPHERICAL3D || SYS == ARTEMIS_AXISYMMETRIC) && P.metric)
@@ -264,13 +304,13 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     }
   };
   auto stage_plane = [&](const Cell6 &q, const Raw5 &hal, int par) {
-#define PUTQ(m, n) S.Q[n][ty + FH][tx + FH] = q.m;
+#define PUTQ(m, n) if constexpr (n < NV) S.Q[n][ty + FH][tx + FH] = q.m;
     CFOR6(PUTQ)
 #undef PUTQ
     bool tny = tiny_vel3(q.v1, q.v2, q.v3);
     if (hr >= 0) {
       const Cell6 h = finish_cell(hal, gm1);
-#define PUTH(m, n) S.Q[n][hr][hc] = h.m;
+#define PUTH(m, n) if constexpr (n < NV) S.Q[n][hr][hc] = h.m;
       CFOR6(PUTH)
 #undef PUTH
       tny = tny || tiny_vel3(hal.v1, hal.v2, hal.v3);
@@ -291,14 +331,19 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
                   double dtdx, double dt_vol, bool on) {
     constexpr int D = decltype(DTAG)::value;
     const double t0 = (A0 * lo.d - A1 * hi.d), t1 = (A0 * lo.m1 - A1 * hi.m1), t2 = (A0 * lo.m2 - A1 * hi.m2);
-    const double t3 = (A0 * lo.m3 - A1 * hi.m3), t4 = (A0 * lo.e - A1 * hi.e), t5 = (A0 * lo.eg - A1 * hi.eg);
+    const double t3 = (A0 * lo.m3 - A1 * hi.m3);
     if constexpr (D == 1) {
-      s.dv[0] = t0, s.dv[1] = t1, s.dv[2] = t2, s.dv[3] = t3, s.dv[4] = t4, s.dv[5] = t5;
+      s.dv[0] = t0, s.dv[1] = t1, s.dv[2] = t2, s.dv[3] = t3;
     } else if (on) {
-      s.dv[0] += t0, s.dv[1] += t1, s.dv[2] += t2, s.dv[3] += t3, s.dv[4] += t4, s.dv[5] += t5;
+      s.dv[0] += t0, s.dv[1] += t1, s.dv[2] += t2, s.dv[3] += t3;
     }
-    s.tm[D - 1] = dtdx * (lo.pf - hi.pf);
-    s.te[D - 1] = dt_vol * 0.5 * (lo.pf + hi.pf) * (A1 * hi.vf - A0 * lo.vf);
+    if constexpr (!DUST) {
+      const double t4 = (A0 * lo.e - A1 * hi.e), t5 = (A0 * lo.eg - A1 * hi.eg);
+      if constexpr (D == 1) s.dv[4] = t4, s.dv[5] = t5;
+      else if (on) s.dv[4] += t4, s.dv[5] += t5;
+      s.tm[D - 1] = dtdx * (lo.pf - hi.pf);
+      s.te[D - 1] = dt_vol * 0.5 * (lo.pf + hi.pf) * (A1 * hi.vf - A0 * lo.vf);
+    }
     // sources_device.hpp rotating_frame_divf / rotating_frame_gas (inactive directions enter as 0 * (0 + 0))
     const double flo = on ? lo.d : 0.0, fup = on ? hi.d : 0.0, a0 = on ? A0 : 0.0, a1 = on ? A1 : 0.0;
     const double term = (flo * a0 * W0 + fup * a1 * W1);
@@ -312,6 +357,66 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     const unsigned c = col + static_cast<unsigned>(k) * sk;
     FluidPrim w;
     w.rho = qc.d, w.v1 = qc.v1, w.v2 = qc.v2, w.v3 = qc.v3, w.sie = qc.e;
+    if constexpr (DUST) { // the same tasks on Dust's four conserved variables (kernels_stage_cell.hip's dust branch)
+      DustCons u0 = prim_to_cons_dust(f, w.rho, w.v1, w.v2, w.v3, hx);
+      DustCons u1 = u0;
+      if (a.has_u1) u1 = prim_to_cons_dust(f, u1raw.d, u1raw.v1, u1raw.v2, u1raw.v3, hx);
+      const Recip rvol = recip(cm.vol);
+      const double nd = s.dv[0] * beta_dt, n1m = s.dv[1] * beta_dt, n2m = s.dv[2] * beta_dt, n3m = s.dv[3] * beta_dt;
+      double qd, q1m, q2m, q3m; // (mass and momentum fluxes of a dust at rest can be tiny-but-nonzero: IEEE then)
+      if (__any(tiny_nonzero(nd) || tiny_nonzero(n1m) || tiny_nonzero(n2m) || tiny_nonzero(n3m))) {
+        qd = nd / cm.vol, q1m = n1m / cm.vol, q2m = n2m / cm.vol, q3m = n3m / cm.vol;
+      } else {
+        qd = div(nd, rvol), q1m = div(n1m, rvol), q2m = div(n2m, rvol), q3m = div(n3m, rvol);
+      }
+      u0.d = a.gam0 * u0.d + a.gam1 * u1.d + qd;
+      u0.m1 = a.gam0 * u0.m1 + a.gam1 * u1.m1 + q1m;
+      u0.m2 = a.gam0 * u0.m2 + a.gam1 * u1.m2 + q2m;
+      u0.m3 = a.gam0 * u0.m3 + a.gam1 * u1.m3 + q3m;
+      const double dt = bdt;
+      { // Dust::FluxSource (dust.cpp:303-326): the coordinate source only
+        const double rdt = w.rho * dt;
+        double vf[3];
+        rotation_velocity(co, P.omf, vf);
+        if (co.x1dep())
+          u0.m1 += rdt * (0.0 * sqr(w.v1 + vf[0]) + co.dh2dx1() * sqr(w.v2 + vf[1]) + co.dh3dx1() * sqr(w.v3 + vf[2]));
+        if (co.x2dep() && multi_d)
+          u0.m2 += rdt * (0.0 * sqr(w.v1 + vf[0]) + 0.0 * sqr(w.v2 + vf[1]) + co.dh3dx2() * sqr(w.v3 + vf[2]));
+      }
+      if (a.grav_on) gravity_dust(gravity_accel(a.grav, co, P.ndim, dt), dt, hx, w, u0);
+      if (a.nb_n) {
+        const double wv[4] = {w.rho, w.v1, w.v2, w.v3};
+        double u[4] = {u0.d, u0.m1, u0.m2, u0.m3};
+        nb_apply<false>(a.nb_pl, a.nb_n, co, a.nb_omf, dt, wv, u);
+        u0.d = u[0], u0.m1 = u[1], u0.m2 = u[2], u0.m3 = u[3];
+      }
+      if (a.rfc_on) { // sources_device.hpp rotating_frame_dust on the folded sums
+        const RotFrame rfc = rotating_frame_terms(co, a.rf_omega, dt);
+        const double qv = s.rfd / cm.vol;
+        u0.m1 -= rfc.omdt * qv * rfc.ep[0];
+        u0.m2 -= rfc.omdt * qv * rfc.ep[1];
+        u0.m3 -= rfc.omdt * qv * rfc.ep[2];
+      }
+      if (a.to_cons) {
+        gst(f.cons0[b * 4 + 0], c, u0.d), gst(f.cons0[b * 4 + 1], c, u0.m1), gst(f.cons0[b * 4 + 2], c, u0.m2);
+        gst(f.cons0[b * 4 + 3], c, u0.m3);
+        return;
+      }
+      const double w_d = (u0.d > f.dfloor) ? u0.d : f.dfloor; // ConsToPrim (fill_derived.cpp:155-164)
+      const double n1 = u0.m1 / (w_d * hx[0]), n2 = u0.m2 / (w_d * hx[1]), n3 = u0.m3 / (w_d * hx[2]);
+      gst(a.prim_out[b * 4 + 0], c, w_d);
+      gst(a.prim_out[b * 4 + 1], c, n1);
+      gst(a.prim_out[b * 4 + 2], c, n2);
+      gst(a.prim_out[b * 4 + 3], c, n3);
+      if (a.dt_bits) { // Dust::EstimateTimestepMesh (dust.cpp:256-272; a dust at rest gives 1 / 0 = inf like the reference)
+        double denom = 0.0;
+        denom += fabs(n1) / co.width1();
+        if (multi_d) denom += fabs(n2) / co.width2();
+        if (D3) denom += fabs(n3) / co.width3();
+        ldt = amin(ldt, 1.0 / denom);
+      }
+      return;
+    }
     GasCons u0 = prim_to_cons_gas(f, w.rho, w.v1, w.v2, w.v3, w.sie, hx);
     GasCons u1 = u0;
     if (a.has_u1) u1 = prim_to_cons_gas(f, u1raw.d, u1raw.v1, u1raw.v2, u1raw.v3, u1raw.e, hx);
@@ -432,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       PlmG r{};
       if constexpr (PG) r = rec_x1(tx + FH);
 #define SLX(m, n)                                                                                 \
-  {                                                                                               \
+  if constexpr (n < NV) {                                                                         \
     double up_;                                                                                   \
     faces_of(S.Q[n][ty + FH][tx + FH - 1], qc.m, S.Q[n][ty + FH][tx + FH + 1], r, fastp, up_, lox.m); \
     L.m = lane_below(up_);                                                                        \
@@ -445,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       PlmG r{};
       if constexpr (PG) r = rec_x2(tx + FH, ty + FH);
 #define SLY(m, n)                                                                                 \
-  {                                                                                               \
+  if constexpr (n < NV) {                                                                         \
     double up_;                                                                                   \
     faces_of(S.Q[n][ty + FH - 1][tx + FH], qc.m, S.Q[n][ty + FH + 1][tx + FH], r, fastp, up_, loy.m); \
     S.UPY[n][ty + 1][tx] = up_;                                                                   \
@@ -459,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       PlmG r{};
       if constexpr (PG) r = rec_x1(cx);
 #pragma unroll
-      for (int n = 0; n < 6; ++n) {
+      for (int n = 0; n < NV; ++n) {
         double up_, lo_;
         faces_of(S.Q[n][row + FH][cx - 1], S.Q[n][row + FH][cx], S.Q[n][row + FH][cx + 1], r, fastp, up_, lo_);
         if (side) S.LOXE[n][row] = lo_;
@@ -472,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       PlmG r{};
       if constexpr (PG) r = rec_x2(cx + FH, ry);
 #pragma unroll
-      for (int n = 0; n < 6; ++n) {
+      for (int n = 0; n < NV; ++n) {
         double up_, lo_;
         faces_of(S.Q[n][ry - 1][cx + FH], S.Q[n][ry][cx + FH], S.Q[n][ry + 1][cx + FH], r, fastp, up_, lo_);
         if (side) S.LOY[n][cx] = lo_;
@@ -482,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     __syncthreads();
     // ---- P2: Riemann problems at the own lower faces; the tile's upper perimeter on one duty wave --------------------
     if (tx == 0) { CGET6(L, S.UPX0, [ty]); }
-    Flux8 fx_lo = solve_face<RIEMANN, 1>(gk, L, lox, fastp);
+    Flux8 fx_lo = solve_fluid<DUST, RIEMANN, 1>(gk, L, lox, fastp);
     {
       double h[3];
       CO(tx + FH, ty + FH, k).face_scale(1, h); // ScaleMomentumFlux (fluid_fluxes.hpp:33-70; h1 == 1)
@@ -491,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     Flux8 fy_lo = fx_lo;
     if (multi_d) {
       CGET6(L, S.UPY, [ty][tx]);
-      fy_lo = solve_face<RIEMANN, 2>(gk, L, loy, fastp);
+      fy_lo = solve_fluid<DUST, RIEMANN, 2>(gk, L, loy, fastp);
       double h[3];
       CO(tx + FH, ty + FH, k).face_scale(2, h);
       fy_lo.m2 *= h[1], fy_lo.m3 *= h[2];
@@ -515,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
           a_ = r.v1;
           r.v1 = r.v2, r.v2 = r.v3, r.v3 = a_;
         }
-        Flux8 fe_ = solve_face<RIEMANN, 1>(gk, l, r, fastp);
+        Flux8 fe_ = solve_fluid<DUST, RIEMANN, 1>(gk, l, r, fastp);
         double h[3];
         if (isx) {
           CO(FTX + FH, u + FH, k).face_scale(1, h); // the face below zone (j0+u, i0+FTX)
@@ -537,8 +642,11 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     {
       Flux8 fx_hi;
       fx_hi.d = lane_above(fx_lo.d), fx_hi.m1 = lane_above(fx_lo.m1), fx_hi.m2 = lane_above(fx_lo.m2);
-      fx_hi.m3 = lane_above(fx_lo.m3), fx_hi.e = lane_above(fx_lo.e), fx_hi.eg = lane_above(fx_lo.eg);
-      fx_hi.pf = lane_above(fx_lo.pf), fx_hi.vf = lane_above(fx_lo.vf);
+      fx_hi.m3 = lane_above(fx_lo.m3);
+      if constexpr (!DUST) {
+        fx_hi.e = lane_above(fx_lo.e), fx_hi.eg = lane_above(fx_lo.eg);
+        fx_hi.pf = lane_above(fx_lo.pf), fx_hi.vf = lane_above(fx_lo.vf);
+      }
       if (tx == FTX - 1) { CGET8(fx_hi, S.FXE, [ty]); }
       // (the zone's Coords are rebuilt from the tables in every phase that needs them: nothing of them crosses a barrier)
       const auto co = CO(tx + FH, ty + FH, k);
@@ -564,11 +672,11 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   };
   if constexpr (!D3) {
     const unsigned c0 = col + static_cast<unsigned>(k0) * sk;
-    const Cell6 qc = load_cell(in_r, in_1, in_2, in_3, in_e, c0, gm1);
-    if (a.has_u1) u1raw = load_raw(u1_r, u1_1, u1_2, u1_3, u1_e, c0);
+    const Cell6 qc = ldcell(in_r, in_1, in_2, in_3, in_e, c0);
+    if (a.has_u1) u1raw = ldraw(u1_r, u1_1, u1_2, u1_3, u1_e, c0);
     if (a.diff_on) load_ds(c0);
     Raw5 hal = u1raw;
-    if (hr >= 0) hal = load_raw(in_r, in_1, in_2, in_3, in_e, hcol + static_cast<unsigned>(k0) * sk);
+    if (hr >= 0) hal = ldraw(in_r, in_1, in_2, in_3, in_e, hcol + static_cast<unsigned>(k0) * sk);
     stage_plane(qc, hal, k0 & 1);
     __syncthreads();
     Sums s;
@@ -583,15 +691,15 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     s.rfd = s.rfd + 0 * (0.0 * 0.0 * 0.0 + 0.0 * 0.0 * 0.0);
     update(k0, co, cm, hx, qc, s, u1raw, ds);
   } else {
-    Cell6 qc = load_cell(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k0 - 1) * sk, gm1);
-    Cell6 qn = load_cell(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k0) * sk, gm1);
+    Cell6 qc = ldcell(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k0 - 1) * sk);
+    Cell6 qn = ldcell(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k0) * sk);
     Cell6 zl;
     {
-      const Cell6 qmm = load_cell(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k0 - 2) * sk, gm1);
+      const Cell6 qmm = ldcell(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k0 - 2) * sk);
       PlmG r{};
       if constexpr (PG) r = rec_x3(tx + FH, ty + FH, k0 - 1);
       double unused_;
-#define ZL0(m, n) faces_of(qmm.m, qc.m, qn.m, r, false, zl.m, unused_);
+#define ZL0(m, n) if constexpr (n < NV) faces_of(qmm.m, qc.m, qn.m, r, false, zl.m, unused_);
       CFOR6(ZL0)
 #undef ZL0
     }
@@ -600,11 +708,11 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     Raw5 hal = u1raw; // halo zone of plane k+1 (staged by trip k)
     for (int k = k0 - 1; k <= k1; ++k) { // the first trip only primes fz_lo (face k0)
       // this trip's HBM loads first; consumed after the plane's LDS phases
-      const Raw5 rnn = load_raw(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k + 2) * sk);
+      const Raw5 rnn = ldraw(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k + 2) * sk);
       const bool live = k >= k0;
       const unsigned ck = col + static_cast<unsigned>(max(k, 0)) * sk;
-      if (a.has_u1 && live) u1raw = load_raw(u1_r, u1_1, u1_2, u1_3, u1_e, ck);
-      if (hr >= 0 && k < k1) hal = load_raw(in_r, in_1, in_2, in_3, in_e, hcol + static_cast<unsigned>(k + 1) * sk);
+      if (a.has_u1 && live) u1raw = ldraw(u1_r, u1_1, u1_2, u1_3, u1_e, ck);
+      if (hr >= 0 && k < k1) hal = ldraw(in_r, in_1, in_2, in_3, in_e, hcol + static_cast<unsigned>(k + 1) * sk);
       if (a.diff_on && live) load_ds(ck);
       double c3 = 1.0, s3 = 0.0;
       if (m3 && live) c3 = m3[MT3_COS * (P.nk + 1) + k], s3 = m3[MT3_SIN * (P.nk + 1) + k];
@@ -629,11 +737,11 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
                              tiny_nonzero(qnn.v3);
           fast3 = !__any(tiny3);
         }
-#define ZSL(m, n) faces_of(qc.m, qn.m, qnn.m, r, fast3, zl_next.m, zr.m);
+#define ZSL(m, n) if constexpr (n < NV) faces_of(qc.m, qn.m, qnn.m, r, fast3, zl_next.m, zr.m);
         CFOR6(ZSL)
 #undef ZSL
       }
-      Flux8 fz_hi = solve_face<RIEMANN, 3>(gk, zl, zr, true);
+      Flux8 fz_hi = solve_fluid<DUST, RIEMANN, 3>(gk, zl, zr, true);
       {
         double h[3];
         CO(tx + FH, ty + FH, k0).face_scale(3, h); // ScaleMomentumFlux at the x3 face (no x3 dependence)
@@ -667,6 +775,11 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
 }
 
 template <int SYS, int RIEMANN, int RECON, bool D3>
+void launch_tile_dust(const PackView &P, const CurvK &k, bool narrow, unsigned grid, hipStream_t s) {
+  if (narrow) hipLaunchKernelGGL((stage_curv_kernel<SYS, RIEMANN, RECON, D3, 16, true, true>), dim3(grid), dim3(256), 0, s, P, k);
+  else hipLaunchKernelGGL((stage_curv_kernel<SYS, RIEMANN, RECON, D3, 32, true, true>), dim3(grid), dim3(256), 0, s, P, k);
+}
+template <int SYS, int RIEMANN, int RECON, bool D3>
 void launch_tile(const PackView &P, const CurvK &k, bool narrow, unsigned grid, hipStream_t s) {
   if (k.to_cons || k.nb_n) {
     if (narrow) hipLaunchKernelGGL((stage_curv_kernel<SYS, RIEMANN, RECON, D3, 16, true>), dim3(grid), dim3(256), 0, s, P, k);
@@ -675,6 +788,16 @@ void launch_tile(const PackView &P, const CurvK &k, bool narrow, unsigned grid, 
   }
   if (narrow) hipLaunchKernelGGL((stage_curv_kernel<SYS, RIEMANN, RECON, D3, 16>), dim3(grid), dim3(256), 0, s, P, k);
   else hipLaunchKernelGGL((stage_curv_kernel<SYS, RIEMANN, RECON, D3, 32>), dim3(grid), dim3(256), 0, s, P, k);
+}
+template <int SYS, bool D3>
+void launch_sys_dust(const PackView &P, const CurvK &k, int riemann, int recon, bool narrow, unsigned grid, hipStream_t s) {
+  if (riemann == ARTEMIS_LLF) {
+    if (recon == ARTEMIS_PCM) launch_tile_dust<SYS, 2, 0, D3>(P, k, narrow, grid, s);
+    else launch_tile_dust<SYS, 2, 1, D3>(P, k, narrow, grid, s);
+  } else {
+    if (recon == ARTEMIS_PCM) launch_tile_dust<SYS, 1, 0, D3>(P, k, narrow, grid, s);
+    else launch_tile_dust<SYS, 1, 1, D3>(P, k, narrow, grid, s);
+  }
 }
 template <int SYS, bool D3>
 void launch_sys(const PackView &P, const CurvK &k, int riemann, int recon, bool narrow, unsigned grid, hipStream_t s) {
@@ -719,15 +842,25 @@ bool curv_march_covers(const PackView &P, const artemis_stage_general_args_t &g,
   }
 }
 
-void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas, hipStream_t s) {
+// The dust species beside it on the same march (DUST instantiations): PCM / PLM, HLLE / LLF
+bool curv_march_covers_dust(const PackView &P, const artemis_stage_general_args_t &g, int recon_dust, int riemann_dust) {
+  if (P.dust.ns != 1 || getenv("ARTEMIS_NO_CURV_DUST_MARCH")) return false;
+  if (!g.pcm && recon_dust == ARTEMIS_PPM) return false;
+  return riemann_dust == ARTEMIS_HLLE || riemann_dust == ARTEMIS_LLF;
+}
+
+// fluid 0: the gas march; fluid 1: the dust march (same tiles, same chunks)
+void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g, int fluid, int recon_in, int riemann, hipStream_t s) {
+  const bool dust = fluid != 0;
   CurvK k;
-  k.gam0 = g.gam0, k.gam1 = g.gam1, k.beta_dt = g.beta_dt, k.bdt = g.bdt, k.cfl = g.cfl_gas;
+  k.gam0 = g.gam0, k.gam1 = g.gam1, k.beta_dt = g.beta_dt, k.bdt = g.bdt, k.cfl = dust ? g.cfl_dust : g.cfl_gas;
   k.bdt_ptr = g.beta_dt_dev;
-  k.prim_in = g.gas_in, k.prim_u1 = g.gas_u1, k.prim_out = g.gas_out;
+  if (dust) k.prim_in = g.dust_in, k.prim_u1 = g.dust_u1, k.prim_out = g.dust_out;
+  else k.prim_in = g.gas_in, k.prim_u1 = g.gas_u1, k.prim_out = g.gas_out;
   k.to_cons = (g.drag || g.defer_finish) ? 1 : 0;
   k.dt_bits = k.to_cons ? nullptr : reinterpret_cast<unsigned long long *>(g.dt_dev);
   k.nb_pl = g.nbody_dev, k.nb_n = g.nbody_n, k.nb_omf = g.nbody_omf;
-  k.has_u1 = (g.gas_u1 != g.gas_in) ? 1 : 0;
+  k.has_u1 = (k.prim_u1 != k.prim_in) ? 1 : 0;
   const int nx = P.ie - P.is + 1, ny = P.je - P.js + 1, nz = P.ke - P.ks + 1;
   // tile shape: 32 x 8, or 16 x 16 where a 32-zone row would leave half the lanes without a zone (16-zone blocks)
   const bool narrow = (nx % 32 != 0) && (nx % 16 == 0 || nx < 32) && ny > 8;
@@ -745,25 +878,31 @@ void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g,
   k.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;
   if (k.grav_on) k.grav = *g.gravity;
   k.rfc_on = (g.rf_omega != 0.0) ? 1 : 0, k.rf_omega = g.rf_omega;
-  k.diff_on = (g.diffusion != nullptr) ? 1 : 0;
-  k.dsum = g.diffusion_sums;
+  k.diff_on = (!dust && g.diffusion != nullptr) ? 1 : 0;
+  k.dsum = dust ? nullptr : g.diffusion_sums;
   const unsigned grid = static_cast<unsigned>(tiles * k.nchunk);
-  const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;
+  const int recon = g.pcm ? ARTEMIS_PCM : recon_in;
   const bool d3 = P.ndim > 2;
+#define CURV_SYS(SYSV, D3V)                                                          \
+  do {                                                                               \
+    if (dust) launch_sys_dust<SYSV, D3V>(P, k, riemann, recon, narrow, grid, s);     \
+    else launch_sys<SYSV, D3V>(P, k, riemann, recon, narrow, grid, s);               \
+  } while (0)
   switch (P.coords) {
   case ARTEMIS_CYLINDRICAL:
-    if (d3) launch_sys<ARTEMIS_CYLINDRICAL, true>(P, k, riemann_gas, recon, narrow, grid, s);
-    else launch_sys<ARTEMIS_CYLINDRICAL, false>(P, k, riemann_gas, recon, narrow, grid, s);
+    if (d3) CURV_SYS(ARTEMIS_CYLINDRICAL, true);
+    else CURV_SYS(ARTEMIS_CYLINDRICAL, false);
     break;
-  case ARTEMIS_SPHERICAL1D: launch_sys<ARTEMIS_SPHERICAL1D, false>(P, k, riemann_gas, recon, narrow, grid, s); break;
-  case ARTEMIS_SPHERICAL2D: launch_sys<ARTEMIS_SPHERICAL2D, false>(P, k, riemann_gas, recon, narrow, grid, s); break;
-  case ARTEMIS_SPHERICAL3D: launch_sys<ARTEMIS_SPHERICAL3D, true>(P, k, riemann_gas, recon, narrow, grid, s); break;
+  case ARTEMIS_SPHERICAL1D: CURV_SYS(ARTEMIS_SPHERICAL1D, false); break;
+  case ARTEMIS_SPHERICAL2D: CURV_SYS(ARTEMIS_SPHERICAL2D, false); break;
+  case ARTEMIS_SPHERICAL3D: CURV_SYS(ARTEMIS_SPHERICAL3D, true); break;
   case ARTEMIS_AXISYMMETRIC:
-    if (d3) launch_sys<ARTEMIS_AXISYMMETRIC, true>(P, k, riemann_gas, recon, narrow, grid, s);
-    else launch_sys<ARTEMIS_AXISYMMETRIC, false>(P, k, riemann_gas, recon, narrow, grid, s);
+    if (d3) CURV_SYS(ARTEMIS_AXISYMMETRIC, true);
+    else CURV_SYS(ARTEMIS_AXISYMMETRIC, false);
     break;
   default: break;
   }
+#undef CURV_SYS
 }
 
 } // namespace artemis

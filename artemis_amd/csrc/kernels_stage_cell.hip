@@ -666,7 +666,7 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
   CellStageArgs a = cell_args(P, g);
   a.to_cons = to_cons ? 1 : 0;
   if (variant == 3) { // curvilinear gas: the streaming tile march with its geometry in LDS tables (kernels_curv.hip)
-    launch_stage_curv(P, g, recon_gas, riemann_gas, s);
+    launch_stage_curv(P, g, 0, recon_gas, riemann_gas, s);
   } else if (P.gas.ns) {
     a.in = g.gas_in, a.u1 = g.gas_u1, a.out = g.gas_out;
     const int recon = g.pcm ? ARTEMIS_PCM : recon_gas;
@@ -674,7 +674,10 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
     else if (riemann_gas == ARTEMIS_HLLE) launch_recon<0, 1>(P, recon, a, s);
     else launch_recon<0, 2>(P, recon, a, s);
   }
-  if (P.dust.ns) {
+  const bool dust_march = variant == 3 && curv_march_covers_dust(P, g, recon_dust, riemann_dust);
+  if (dust_march) { // the dust species on the same march (kernels_curv.hip, DUST instantiations)
+    launch_stage_curv(P, g, 1, recon_dust, riemann_dust, s);
+  } else if (P.dust.ns) {
     a.in = g.dust_in, a.u1 = g.dust_u1, a.out = g.dust_out;
     const int recon = g.pcm ? ARTEMIS_PCM : recon_dust;
     if (riemann_dust == ARTEMIS_HLLE) launch_recon<1, 1>(P, recon, a, s);
@@ -692,7 +695,7 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
   }
   if (g.dt_dev) { // EstimateTimestepMesh of the new state (gas.cpp:411-433, dust.cpp:256-272)
     if (Q.gas.ns && !(variant == 3 && !to_cons)) launch_estimate_dt(Q, ARTEMIS_GAS, g.cfl_gas, g.dt_dev, s); // (the march has its own)
-    if (Q.dust.ns) launch_estimate_dt(Q, ARTEMIS_DUST, g.cfl_dust, g.dt_dev, s);
+    if (Q.dust.ns && !(dust_march && !to_cons)) launch_estimate_dt(Q, ARTEMIS_DUST, g.cfl_dust, g.dt_dev, s);
   }
 }
 
