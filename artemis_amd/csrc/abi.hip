@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <map>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -847,6 +848,17 @@ int artemis_hip_diffusion_dt(const artemis_pack_t *p, const artemis_diffusion_t 
   return after_launch("Diffusion::EstimateTimestep");
 }
 
+int artemis_hip_timestep_all(const artemis_pack_t *p, double cfl_gas, double cfl_dust, const artemis_diffusion_t *d,
+                             double *dt_dev, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (d)
+    if (int rc = validate_diffusion(p, d, false)) return rc;
+  if (!dt_dev) return fail(ARTEMIS_HIP_EINVAL, "null dt_dev");
+  if (p->gas.nspecies == 0 && p->dust.nspecies == 0) return 0;
+  artemis::launch_timestep_all(artemis::make_pack_view(*p), d, cfl_gas, cfl_dust, dt_dev, S(stream));
+  return after_launch("EstimateTimestepMesh (all limits)");
+}
+
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
                               void *stream) {
   if (int rc = validate(p)) return rc;
@@ -1038,11 +1050,13 @@ int artemis_hip_amr_magnitude(const artemis_amr_criterion_t *a, int *tag, double
 
 int artemis_hip_amr_block_maxima(const artemis_pack_t *p, int field, int magnitude, double *maxima_dev, void *stream) {
   if (int rc = validate(p)) return rc;
-  if (!maxima_dev || field < 0 || field > 1 || !p->gas.nspecies || !p->gas.prim)
-    return fail(ARTEMIS_HIP_EINVAL, "amr_block_maxima: field must be 0 (density) or 1 (pressure) of a gas pack, maxima_dev non-null");
+  if (!maxima_dev || field < 0 || field > 2 || !p->gas.nspecies || !p->gas.prim)
+    return fail(ARTEMIS_HIP_EINVAL, "amr_block_maxima: field must be 0 (density), 1 (pressure) or 2 (pressure from rho, sie) of a gas pack, "
+                                    "maxima_dev non-null");
   if (!magnitude && p->nghost < 2) return fail(ARTEMIS_HIP_EINVAL, "ScalarFirstDerivative needs two ghost zones");
   const artemis::PackView P = artemis::make_pack_view(*p);
-  artemis::launch_pack_criterion(P, field == 0 ? 0 : 4 * p->gas.nspecies, magnitude, maxima_dev, S(stream));
+  if (field == 2) artemis::launch_pack_criterion(P, 0, 5 * p->gas.nspecies, magnitude, maxima_dev, S(stream));
+  else artemis::launch_pack_criterion(P, field == 0 ? 0 : 4 * p->gas.nspecies, -1, magnitude, maxima_dev, S(stream));
   return after_launch("refinement criterion (pack)");
 }
 
@@ -1077,14 +1091,76 @@ void artemis_rt_device_bytes(size_t *current, size_t *peak, int reset_peak) {
   if (peak) *peak = g_bytes_peak;
   if (reset_peak) g_bytes_peak = g_bytes_now;
 }
+// A remesh frees tens of GB and allocates about as much again in buffers whose sizes differ by a fraction of a percent
+// (a handful of blocks more or fewer): through hipFree / hipMalloc that unmaps and re-maps the lot (1.3 - 1.5 s per
+// remesh on the 29 M-zone configs[4] mesh, twenty cycle-times).  Freed buffers are kept instead -- sizes rounded up to
+// 1/16 of their power of two, so that consecutive states land in the same size class -- and handed out again; the
+// cache is trimmed to ARTEMIS_POOL_GB (default 64) and emptied when the device runs out.  ARTEMIS_NO_POOL=1: plain calls.
+namespace {
+struct PoolEntry {
+  void *p;
+  unsigned long seq; // when it was freed: the cache is trimmed oldest first
+};
+std::multimap<size_t, PoolEntry> g_pool; // capacity -> free buffer
+size_t g_pool_bytes = 0;
+unsigned long g_pool_seq = 0;
+size_t size_class(size_t bytes) {
+  if (bytes < (size_t(1) << 16)) return (bytes + 255) & ~size_t(255);
+  size_t p2 = 1;
+  while ((p2 << 1) <= bytes) p2 <<= 1;
+  const size_t g = p2 >> 4;
+  return (bytes + g - 1) / g * g;
+}
+bool pool_on() {
+  static const bool on = std::getenv("ARTEMIS_NO_POOL") == nullptr;
+  return on;
+}
+size_t pool_limit() {
+  static const size_t lim = [] {
+    const char *e = std::getenv("ARTEMIS_POOL_GB");
+    return static_cast<size_t>((e ? std::atof(e) : 64.0) * 1073741824.0);
+  }();
+  return lim;
+}
+void pool_trim_locked(size_t keep) { // least recently freed first (what earlier, smaller meshes left behind goes first)
+  while (g_pool_bytes > keep && !g_pool.empty()) {
+    auto it = g_pool.begin();
+    for (auto q = g_pool.begin(); q != g_pool.end(); ++q)
+      if (q->second.seq < it->second.seq) it = q;
+    g_pool_bytes -= it->first, g_bytes_now -= it->first;
+    (void)hipFree(it->second.p);
+    g_pool.erase(it);
+  }
+}
+} // namespace
 void *artemis_rt_malloc(size_t bytes) {
   if (device_ready()) return nullptr;
   void *p = nullptr;
-  if (check_hip(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc")) return nullptr;
-  {
+  const size_t cap = pool_on() ? size_class(bytes ? bytes : 8) : (bytes ? bytes : 8);
+  if (pool_on()) {
     std::lock_guard<std::mutex> lk(g_bytes_mu);
-    g_bytes_of[p] = bytes;
-    g_bytes_now += bytes;
+    auto it = g_pool.lower_bound(cap);
+    if (it != g_pool.end() && it->first <= cap + cap / 8) {
+      p = it->second.p;
+      g_pool_bytes -= it->first;
+      g_bytes_of[p] = it->first;
+      g_pool.erase(it);
+    }
+  }
+  if (!p) {
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess && pool_on()) { // out of memory with buffers cached: give them back and try again
+      (void)hipGetLastError();
+      {
+        std::lock_guard<std::mutex> lk(g_bytes_mu);
+        pool_trim_locked(0);
+      }
+      e = hipMalloc(&p, cap);
+    }
+    if (check_hip(e, "hipMalloc")) return nullptr;
+    std::lock_guard<std::mutex> lk(g_bytes_mu);
+    g_bytes_of[p] = cap;
+    g_bytes_now += cap; // (the device footprint: live buffers and cached ones, at their capacities)
     if (g_bytes_now > g_bytes_peak) g_bytes_peak = g_bytes_now;
   }
   // ARTEMIS_POISON=1 (debugging aid): fresh device memory holds NaN patterns, so that a read of something never
@@ -1098,12 +1174,29 @@ void *artemis_rt_malloc(size_t bytes) {
 }
 void artemis_rt_free(void *p) {
   if (!p) return;
+  size_t cap = 0;
   {
     std::lock_guard<std::mutex> lk(g_bytes_mu);
     auto it = g_bytes_of.find(p);
-    if (it != g_bytes_of.end()) g_bytes_now -= it->second, g_bytes_of.erase(it);
+    if (it != g_bytes_of.end()) cap = it->second, g_bytes_of.erase(it);
   }
-  (void)hipFree(p);
+  if (!pool_on() || cap == 0) {
+    if (cap) {
+      std::lock_guard<std::mutex> lk(g_bytes_mu);
+      g_bytes_now -= cap;
+    }
+    (void)hipFree(p);
+    return;
+  }
+  (void)hipDeviceSynchronize(); // what hipFree guarantees: nothing in flight still uses the buffer
+  std::lock_guard<std::mutex> lk(g_bytes_mu);
+  g_pool.emplace(cap, PoolEntry{p, ++g_pool_seq});
+  g_pool_bytes += cap;
+  pool_trim_locked(pool_limit());
+}
+void artemis_rt_pool_trim(size_t keep_bytes) {
+  std::lock_guard<std::mutex> lk(g_bytes_mu);
+  pool_trim_locked(keep_bytes);
 }
 void *artemis_rt_malloc_host(size_t bytes) {
   if (device_ready()) return nullptr;

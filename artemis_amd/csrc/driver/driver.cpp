@@ -52,6 +52,9 @@ struct DevBuf {
     p = static_cast<double *>(artemis_rt_malloc(std::max<size_t>(count, 1) * sizeof(double)));
     if (!p) throw HipFail(std::string("device allocation failed: ") + artemis_hip_last_error());
     CK(artemis_rt_memset(p, 0, std::max<size_t>(count, 1) * sizeof(double), nullptr), "memset");
+    // (buffers come back from artemis_rt's cache: the zeroing, on the null stream, is complete before any of the
+    //  driver's non-blocking streams touches the buffer)
+    CK(artemis_rt_stream_sync(nullptr), "sync");
   }
   void release() {
     if (p) artemis_rt_free(p);
@@ -290,7 +293,7 @@ struct artemis_sim_impl {
   std::vector<double> particle_force; // [npart][7]
   // the one-kernel stages take the particles from the device and leave the seven sums per particle in device
   // accumulators (artemis_hip_nbody_force_sums): no synchronisation inside the stage loop
-  DevBuf nb_dev, nb_force_dev, nb_scratch;
+  DevBuf nb_dev, nb_force_dev, nb_scratch, amr_maxima;
   std::vector<artemis_nbody_particle_t> nb_uploaded;
   bool nbody_in_stage = false; // N-body gravity can run inside artemis_hip_stage_general's kernels
   void nbody_stage_args(const artemis_pack_t &p, artemis_stage_general_args_t &a, Real bdt);
@@ -2022,29 +2025,34 @@ void artemis_sim_impl::problem_generator() {
     }
     // batches of `nthreads` blocks: generate concurrently, then upload in block order
     std::vector<std::vector<Real>> hgs(nthreads, std::vector<Real>(ng_)), hds(nthreads, std::vector<Real>(nd_));
-    for (int b0 = 0; b0 < nb; b0 += nthreads) {
-      const int nbatch = std::min(nthreads, nb - b0);
+    // (a remesh during the run: only the blocks whose `ic` faces keep reading the generated state need it, and of
+    //  those only the ones the old state cannot hand over -- a handful, so the batches run over that list)
+    auto wanted = [&](int b) {
+      if (!adopting) return true;
+      if (!ic_gas.ok()) return false;
+      if (reuse_from && reuse_from->ic_gas.ok() && reuse_block(b) >= 0) return false; // copied from the old state below
+      for (int f = 0; f < 6; ++f)
+        if (blocks[b].bc[f] == ARTEMIS_BC_IC) return true;
+      return false;
+    };
+    std::vector<int> todo;
+    for (int b = 0; b < nb; ++b)
+      if (wanted(b)) todo.push_back(b);
+    const int ntodo = static_cast<int>(todo.size());
+    for (int q0 = 0; q0 < ntodo; q0 += nthreads) {
+      const int nbatch = std::min(nthreads, ntodo - q0);
       std::vector<std::thread> pool;
       std::vector<std::exception_ptr> errs(nbatch);
-      // (a remesh during the run: only the blocks whose `ic` faces keep reading the generated state need it)
-      auto wanted = [&](int b) {
-        if (!adopting) return true;
-        if (!ic_gas.ok()) return false;
-        if (reuse_from && reuse_from->ic_gas.ok() && reuse_block(b) >= 0) return false; // copied from the old state below
-        for (int f = 0; f < 6; ++f)
-          if (blocks[b].bc[f] == ARTEMIS_BC_IC) return true;
-        return false;
-      };
       for (int t = 1; t < nbatch; ++t)
         pool.emplace_back([&, t] {
           try {
-            if (wanted(b0 + t)) generate_block(b0 + t, hgs[t], hds[t]);
+            generate_block(todo[q0 + t], hgs[t], hds[t]);
           } catch (...) {
             errs[t] = std::current_exception();
           }
         });
       try {
-        if (wanted(b0)) generate_block(b0, hgs[0], hds[0]);
+        generate_block(todo[q0], hgs[0], hds[0]);
       } catch (...) {
         errs[0] = std::current_exception();
       }
@@ -2052,8 +2060,7 @@ void artemis_sim_impl::problem_generator() {
       for (int t = 0; t < nbatch; ++t)
         if (errs[t]) std::rethrow_exception(errs[t]);
       for (int t = 0; t < nbatch; ++t) {
-        const int b = b0 + t;
-        if (!wanted(b)) continue;
+        const int b = todo[q0 + t];
         if (do_gas) upload_block(gprim[0], b, hgs[t]);
         if (do_dust) upload_block(dprim[0], b, hds[t]);
         if (ic_gas.ok()) upload_block(ic_gas, b, hgs[t]); // as generated, before PrimToCons applies the floors
@@ -2133,25 +2140,27 @@ void artemis_sim_impl::problem_generator() {
       nthreads = std::min(nthreads, nb);
     }
     const int chunk = 64; // blocks per batch: bounds the host staging memory
-    std::vector<std::vector<Real>> hr(static_cast<size_t>(std::min(nb, chunk)), std::vector<Real>(N));
-    for (int b0 = 0; b0 < nb; b0 += chunk) {
-      const int nbatch = std::min(chunk, nb - b0);
+    const bool can_copy = adopting && reuse_from && reuse_from->visc_radial.ok();
+    std::vector<int> todo; // (a remesh: the blocks the old state cannot hand over)
+    for (int b = 0; b < nb; ++b)
+      if (!(can_copy && reuse_block(b) >= 0)) todo.push_back(b);
+    const int ntodo = static_cast<int>(todo.size());
+    std::vector<std::vector<Real>> hr(static_cast<size_t>(std::min(std::max(ntodo, 1), chunk)), std::vector<Real>(N));
+    for (int q0 = 0; q0 < ntodo; q0 += chunk) {
+      const int nbatch = std::min(chunk, ntodo - q0);
       std::vector<std::thread> pool;
       std::vector<int> rcs(nthreads, 0);
-      const bool can_copy = adopting && reuse_from && reuse_from->visc_radial.ok();
       auto work = [&](int t) {
         for (int q = t; q < nbatch; q += nthreads)
-          if (can_copy && reuse_block(b0 + q) >= 0) continue; // copied from the old state below
-          else if (int rc = artemis_hip_diffusion_radial_fill(&pk, hgeom.data(), hmetric.empty() ? nullptr : hmetric.data(),
-                                                         &diff.visc, b0 + q, hr[q].data()))
+          if (int rc = artemis_hip_diffusion_radial_fill(&pk, hgeom.data(), hmetric.empty() ? nullptr : hmetric.data(),
+                                                         &diff.visc, todo[q0 + q], hr[q].data()))
             rcs[t] = rc;
       };
-      for (int t = 1; t < nthreads; ++t) pool.emplace_back(work, t);
+      for (int t = 1; t < std::min(nthreads, nbatch); ++t) pool.emplace_back(work, t);
       work(0);
       for (auto &th : pool) th.join();
       for (int t = 0; t < nthreads; ++t) CK(rcs[t], "viscosity radial table");
-      for (int q = 0; q < nbatch; ++q)
-        if (!(can_copy && reuse_block(b0 + q) >= 0)) upload_block(visc_radial, b0 + q, hr[q]);
+      for (int q = 0; q < nbatch; ++q) upload_block(visc_radial, todo[q0 + q], hr[q]);
     }
     if (adopting && reuse_from && reuse_from->visc_radial.ok()) copy_rows(visc_radial, reuse_from->visc_radial, [&](int b) { return reuse_block(b); });
     diff.visc.radial = visc_radial.tab();
@@ -2209,12 +2218,13 @@ void artemis_sim_impl::release_for_adoption() {
 std::vector<int> artemis_sim_impl::amr_tags() {
   std::vector<int> tags(nb, 0);
   if (!refine_field || !refine_type) return tags;
-  materialise_cons(); // PrimToCons over the entire block also refreshes the pressure of the ghost zones
-  // one launch for all blocks, one copy back (artemis_hip_amr_block_maxima); thresholds as the per-block calls
-  DevBuf maxima;
-  maxima.alloc(nb);
+  // one launch for all blocks, one copy back (artemis_hip_amr_block_maxima); thresholds as the per-block calls.  The
+  // pressure is recomputed from rho and sie (field 2: the bits PrimToCons over the entire block would leave in the
+  // pressure slot, ghost zones included, without that pass)
+  if (amr_maxima.n < static_cast<size_t>(nb)) amr_maxima.alloc(nb);
+  DevBuf &maxima = amr_maxima;
   const artemis_pack_t p = make_pack(base);
-  CK(artemis_hip_amr_block_maxima(&p, refine_field == 1 ? 0 : 1, refine_type == 2 ? 1 : 0, maxima.p, stream), "refinement criterion");
+  CK(artemis_hip_amr_block_maxima(&p, refine_field == 1 ? 0 : 2, refine_type == 2 ? 1 : 0, maxima.p, stream), "refinement criterion");
   std::vector<double> h(nb);
   CK(artemis_rt_memcpy_d2h(h.data(), maxima.p, sizeof(double) * nb, stream), "d2h");
   CK(artemis_rt_stream_sync(stream), "sync");
@@ -2470,10 +2480,9 @@ Real artemis_sim_impl::new_dt_unfused() {
   const artemis_pack_t p = make_pack(base);
   *dt_host = DBL_MAX;
   CK(artemis_rt_memcpy_h2d(dt_dev.p, dt_host, sizeof(double), stream), "h2d");
-  if (do_gas) CK(artemis_hip_estimate_dt_async(&p, ARTEMIS_GAS, cfl_gas, dt_dev.p, stream), "dt gas");
-  if (do_dust) CK(artemis_hip_estimate_dt_async(&p, ARTEMIS_DUST, cfl_dust, dt_dev.p, stream), "dt dust");
-  if (do_viscosity || do_conduction) // gas.cpp:435-467: cfl * min(hydro, viscous, conductive)
-    CK(artemis_hip_diffusion_dt(&p, &diff, cfl_gas, dt_dev.p, stream), "dt diffusion");
+  // gas.cpp:411-467 (cfl * min(hydro, viscous, conductive)) and dust.cpp:256-272 in one pass over the state
+  CK(artemis_hip_timestep_all(&p, cfl_gas, cfl_dust, (do_gas && (do_viscosity || do_conduction)) ? &diff : nullptr, dt_dev.p, stream),
+     "EstimateTimestepMesh");
   CK(artemis_rt_memcpy_d2h(dt_host, dt_dev.p, sizeof(double), stream), "d2h");
   CK(artemis_rt_stream_sync(stream), "sync");
   return *dt_host;
@@ -3379,6 +3388,7 @@ artemis_sim_t *artemis_sim_create(const char *deck_text, int noverrides,
     // can take more than numlevel passes; the cap only guards against a criterion that never settles)
     for (int pass = 0; s->p->adaptive && pass < 8 * (s->p->amr_max_level + 2); ++pass)
       if (!remesh(*s, true)) break;
+    if (s->p->adaptive) artemis_rt_pool_trim(0); // (what the smaller meshes of the loop left in artemis_rt's buffer cache)
   };
   GUARD(build(), {
     artemis_sim_destroy(s);

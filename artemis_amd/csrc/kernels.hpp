@@ -64,12 +64,14 @@ void launch_viscous_source(const PackView &P, const artemis_diffusion_t &D, doub
                            hipStream_t s);
 void launch_thermal_flux(const PackView &P, const artemis_diffusion_t &D, hipStream_t s);
 void launch_diffusion_update(const PackView &P, const artemis_diffusion_t &D, double dt, hipStream_t s);
+void launch_timestep_all(const PackView &P, const artemis_diffusion_t *D, double cfl_gas, double cfl_dust, double *dt_dev,
+                         hipStream_t s);
 void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double cfl, double *dt_dev,
                          hipStream_t s);
 // kernels_stage_cell.hip
 void launch_refine(const artemis_refine_t &r, int prolongate, hipStream_t s);
 void launch_amr_criterion(const artemis_amr_criterion_t &a, int magnitude, hipStream_t s);
-void launch_pack_criterion(const PackView &P, int var, int magnitude, double *maxima, hipStream_t s);
+void launch_pack_criterion(const PackView &P, int var, int var_sie, int magnitude, double *maxima, hipStream_t s);
 void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t &g, hipStream_t s, bool to_cons = false);
 void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas,
                        int riemann_gas, int recon_dust, int riemann_dust, hipStream_t s);

@@ -11,6 +11,7 @@
 // are kept (multiplications by 1.0 / additions of 0.0 * v) so that NaN/Inf propagate as in the
 // reference's arithmetic.
 #include <cfloat>
+#include <cstring>
 #include <cstdlib>
 
 #include "device_math.hpp"
@@ -952,6 +953,87 @@ __global__ __launch_bounds__(TX *TY) void diffusion_dt_kernel(const PackView P, 
   }
 }
 
+// Gas::EstimateTimestepMesh (gas.cpp:411-467: hydrodynamic, viscous and conductive limits) and
+// Dust::EstimateTimestepMesh (dust.cpp:256-272) of one state in ONE pass: every limit is a minimum over the zones and
+// min is exact, so combining them in one kernel gives the bits of the separate tasks with one read of the primitives.
+template <bool CURV>
+__global__ __launch_bounds__(TX *TY) void timestep_all_kernel(const PackView P, const Box r, const artemis_diffcoeff_t visc,
+                                                              const artemis_diffcoeff_t cond, double cv, double cfl_gas,
+                                                              double cfl_dust, unsigned long long *dt_bits) {
+  const int gx = (r.iu - r.il + TX) / TX, gy = (r.ju - r.jl + TY) / TY;
+  const int nkr = r.ku - r.kl + 1;
+  const long ntile = static_cast<long>(gx) * gy * nkr * P.nb;
+  double lg = DBL_MAX, ld = DBL_MAX, lv = DBL_MAX, lc = DBL_MAX; // gas hydro, dust, viscous, conductive
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int i = r.il + static_cast<int>(tile % gx) * TX + threadIdx.x;
+    const int j = r.jl + static_cast<int>((tile / gx) % gy) * TY + threadIdx.y;
+    const int bz = static_cast<int>(tile / (static_cast<long>(gx) * gy));
+    const int b = bz / nkr, k = r.kl + bz % nkr;
+    if (i > r.iu || j > r.ju) continue;
+    const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
+    double dx[3]; // GetCellWidths (geometry.hpp:352-361)
+    if constexpr (CURV) {
+      const DCoords co = make_coords(P, b, k, j, i);
+      dx[0] = co.width1(), dx[1] = co.width2(), dx[2] = co.width3();
+    } else {
+      const CellGeom g = cell_geom(P.geom + 6 * b, k, j, i);
+      dx[0] = 1.0 * g.dx1, dx[1] = 1.0 * g.dx2, dx[2] = 1.0 * g.dx3;
+    }
+    double min_dx = DBL_MAX;
+    for (int d = 0; d < P.ndim; d++) min_dx = amin(min_dx, dx[d]);
+    {
+      const int ns = P.gas.ns, nv = 6 * ns;
+      for (int n = 0; n < ns; ++n) {
+        const double dens = P.gas.prim[b * nv + n][c];
+        const double sie = P.gas.prim[b * nv + 5 * ns + n][c];
+        const double bulk = (P.gm1 + 1.0) * P.gm1 * dens * sie; // IdealGas bulk modulus
+        const double cs = sqrt(bulk / dens);
+        double denom = 0.0;
+        for (int d = 0; d < P.ndim; d++) {
+          const double ss = fabs(P.gas.prim[b * nv + ns + 3 * n + d][c]) + cs;
+          denom += ss / dx[d];
+        }
+        lg = amin(lg, 1.0 / denom);
+        if (visc.type != ARTEMIS_DIFF_OFF) { // Diffusion::EstimateTimestep (diffusion.hpp:66-108)
+          double mu = coeff_of(visc, cv, P.gm1, dens, sie, b, c);
+          if (visc.type == ARTEMIS_VISCOSITY_PLAW || visc.type == ARTEMIS_VISCOSITY_ALPHA) mu *= (1.0 + (visc.eta > 1.0) * (visc.eta - 1.0)) / dens;
+          lv = amin(lv, sqr(min_dx) / (mu + 1e-99));
+        }
+        if (cond.type != ARTEMIS_DIFF_OFF) {
+          double mu = coeff_of(cond, cv, P.gm1, dens, sie, b, c);
+          if (cond.type == ARTEMIS_CONDUCTIVITY_PLAW) mu /= (dens * cv);
+          lc = amin(lc, sqr(min_dx) / (mu + 1e-99));
+        }
+      }
+    }
+    {
+      const int ns = P.dust.ns, nv = 4 * ns;
+      for (int n = 0; n < ns; ++n) {
+        double denom = 0.0;
+        for (int d = 0; d < P.ndim; d++) denom += fabs(P.dust.prim[b * nv + ns + 3 * n + d][c]) / dx[d];
+        ld = amin(ld, 1.0 / denom);
+      }
+    }
+  }
+  // the four candidates as the tasks would min-combine them
+  double m = DBL_MAX;
+  if (P.gas.ns) {
+    m = fmin(m, cfl_gas * lg);
+    if (visc.type != ARTEMIS_DIFF_OFF) m = fmin(m, cfl_gas * (lv / (2.0 * P.ndim)));
+    if (cond.type != ARTEMIS_DIFF_OFF) m = fmin(m, cfl_gas * (lc / (2.0 * P.ndim)));
+  }
+  if (P.dust.ns) m = fmin(m, cfl_dust * ld);
+  for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+  __shared__ double wmin[TY];
+  if (threadIdx.x == 0) wmin[threadIdx.y] = m;
+  __syncthreads();
+  if (threadIdx.y == 0 && threadIdx.x == 0) {
+    double q = wmin[0];
+    for (int w = 1; w < TY; ++w) q = fmin(q, wmin[w]);
+    atomicMin(dt_bits, static_cast<unsigned long long>(__double_as_longlong(q)));
+  }
+}
+
 inline Box interior(const PackView &P) { return Box{P.is, P.ie, P.js, P.je, P.ks, P.ke}; }
 inline Box faces(const PackView &P, int dir) {
   Box r = interior(P);
@@ -1100,6 +1182,23 @@ void launch_diffusion_update(const PackView &P, const artemis_diffusion_t &D, do
     hipLaunchKernelGGL(diffusion_update_kernel<false>, grid_of(r, P.nb), threads_of(r), 0, s, P, r, visc, dt);
   else
     hipLaunchKernelGGL(diffusion_update_kernel<true>, grid_of(r, P.nb), threads_of(r), 0, s, P, r, visc, dt);
+}
+void launch_timestep_all(const PackView &P, const artemis_diffusion_t *D, double cfl_gas, double cfl_dust, double *dt_dev,
+                         hipStream_t s) {
+  const Box r = interior(P);
+  const dim3 g3 = grid_of(r, P.nb);
+  const long ntile = static_cast<long>(g3.x) * g3.y * g3.z;
+  const dim3 g(static_cast<unsigned>(ntile < 1024 ? ntile : 1024));
+  auto *bits = reinterpret_cast<unsigned long long *>(dt_dev);
+  artemis_diffcoeff_t off;
+  std::memset(&off, 0, sizeof off);
+  off.type = ARTEMIS_DIFF_OFF;
+  const artemis_diffcoeff_t visc = D ? D->visc : off, cond = D ? D->cond : off;
+  const double cv = D ? D->cv : 0.0;
+  if (P.coords != ARTEMIS_CARTESIAN)
+    hipLaunchKernelGGL(timestep_all_kernel<true>, g, dim3(TX, TY), 0, s, P, r, visc, cond, cv, cfl_gas, cfl_dust, bits);
+  else
+    hipLaunchKernelGGL(timestep_all_kernel<false>, g, dim3(TX, TY), 0, s, P, r, visc, cond, cv, cfl_gas, cfl_dust, bits);
 }
 void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double cfl, double *dt_dev,
                          hipStream_t s) {

@@ -117,7 +117,8 @@ ADEV void block_max(double m, double *out) {
   if ((threadIdx.x & 63) == 0 && m > 0.0)
     atomicMax(reinterpret_cast<unsigned long long *>(out), static_cast<unsigned long long>(__double_as_longlong(m)));
 }
-ADEV void first_derivative_body(const artemis_amr_criterion_t &a) {
+// sie != null: the field is the gas density and the criterion runs on the pressure max(0, gm1 rho sie) (fill_derived.cpp:247)
+ADEV void first_derivative_body(const artemis_amr_criterion_t &a, const double *sie = nullptr, double gm1 = 0.0) {
   const bool X3 = a.ndim > 2;
   const int i0 = a.is - 1, j0 = a.js - 1, k0 = X3 ? a.ks - 1 : a.ks;
   const int ni = a.ie - a.is + 3, nj = a.je - a.js + 3, nk = X3 ? a.ke - a.ks + 3 : 1;
@@ -127,7 +128,10 @@ ADEV void first_derivative_body(const artemis_amr_criterion_t &a) {
     const int i = i0 + static_cast<int>(t % ni), j = j0 + static_cast<int>((t / ni) % nj);
     const int k = k0 + static_cast<int>(t / (static_cast<long>(ni) * nj));
     auto co = [&](int kk, int jj, int ii) { return coords_of(a.coords, a.geom, a.metric, a.nj, a.nk, kk, jj, ii); };
-    auto v = [&](int kk, int jj, int ii) { return a.field[(static_cast<long>(kk) * a.nj + jj) * a.ni + ii]; };
+    auto v = [&](int kk, int jj, int ii) {
+      const long c_ = (static_cast<long>(kk) * a.nj + jj) * a.ni + ii;
+      return sie ? amax(0.0, gm1 * a.field[c_] * sie[c_]) : a.field[c_];
+    };
     const double sdx1 = co(k, j, i + 1).x1v() - co(k, j, i - 1).x1v();
     const double sdx2 = co(k, j + 1, i).x2v() - co(k, j - 1, i).x2v();
     const DCoords c = co(k, j, i);
@@ -151,14 +155,15 @@ ADEV void first_derivative_body(const artemis_amr_criterion_t &a) {
   }
   block_max(eps, a.scratch);
 }
-ADEV void magnitude_body(const artemis_amr_criterion_t &a) {
+ADEV void magnitude_body(const artemis_amr_criterion_t &a, const double *sie = nullptr, double gm1 = 0.0) {
   const int ni = a.ie - a.is + 1, nj = a.je - a.js + 1, nk = a.ke - a.ks + 1;
   const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
   double m = 0.0;
   if (t < static_cast<long>(ni) * nj * nk) {
     const int i = a.is + static_cast<int>(t % ni), j = a.js + static_cast<int>((t / ni) % nj);
     const int k = a.ks + static_cast<int>(t / (static_cast<long>(ni) * nj));
-    const double q = a.field[(static_cast<long>(k) * a.nj + j) * a.ni + i];
+    const long c_ = (static_cast<long>(k) * a.nj + j) * a.ni + i;
+    const double q = sie ? amax(0.0, gm1 * a.field[c_] * sie[c_]) : a.field[c_];
     m = (m < q) ? q : m;
   }
   block_max(m, a.scratch);
@@ -170,7 +175,8 @@ __global__ __launch_bounds__(256) void magnitude_kernel(const CriterionView C) {
 struct PackCriterion {
   artemis_amr_criterion_t a; // geom / metric / field / scratch are filled per block in the kernel
   double *const *prim;
-  int nvar, var;
+  int nvar, var, var_sie; // var_sie >= 0: pressure recomputed from density (var) and sie
+  double gm1;
   const double *geom, *metric;
   long metric_stride;
   double *maxima;
@@ -181,17 +187,18 @@ __global__ __launch_bounds__(256) void pack_criterion_kernel(const PackCriterion
   const int b = blockIdx.y;
   a.geom = C.geom + 6 * b, a.metric = C.metric ? C.metric + b * C.metric_stride : nullptr;
   a.field = C.prim[b * C.nvar + C.var], a.scratch = C.maxima + b;
-  if constexpr (MAGNITUDE) magnitude_body(a);
-  else first_derivative_body(a);
+  const double *sie = (C.var_sie >= 0) ? C.prim[b * C.nvar + C.var_sie] : nullptr;
+  if constexpr (MAGNITUDE) magnitude_body(a, sie, C.gm1);
+  else first_derivative_body(a, sie, C.gm1);
 }
 } // namespace
 
-void launch_pack_criterion(const PackView &P, int var, int magnitude, double *maxima, hipStream_t s) {
+void launch_pack_criterion(const PackView &P, int var, int var_sie, int magnitude, double *maxima, hipStream_t s) {
   PackCriterion C;
   C.a.coords = P.coords, C.a.ndim = P.ndim, C.a.ni = P.ni, C.a.nj = P.nj, C.a.nk = P.nk;
   C.a.is = P.is, C.a.ie = P.ie, C.a.js = P.js, C.a.je = P.je, C.a.ks = P.ks, C.a.ke = P.ke;
   C.a.refine_thr = C.a.deref_thr = 0.0;
-  C.prim = P.gas.prim, C.nvar = 6 * P.gas.ns, C.var = var;
+  C.prim = P.gas.prim, C.nvar = 6 * P.gas.ns, C.var = var, C.var_sie = var_sie, C.gm1 = P.gm1;
   C.geom = P.geom, C.metric = P.metric, C.metric_stride = metric_block_stride(P.nj, P.nk);
   C.maxima = maxima;
   (void)hipMemsetAsync(maxima, 0, sizeof(double) * P.nb, s);

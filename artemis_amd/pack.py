@@ -312,6 +312,13 @@ class MeshBlockPack:
         self._call(self.L.artemis_hip_diffusion_dt, C.byref(diffusion), cfl, t.data_ptr())
         return t.item()
 
+    def TimestepAll(self, cfl_gas, cfl_dust, diffusion=None):
+        """artemis_hip_timestep_all: gas (hydro + diffusive limits) and dust timestep of the pack's primitives in one pass."""
+        t = torch.full((1,), 1.7976931348623157e308, dtype=torch.float64, device=self.dev)
+        self._call(self.L.artemis_hip_timestep_all, cfl_gas, cfl_dust, C.byref(diffusion) if diffusion is not None else None,
+                   t.data_ptr())
+        return t.item()
+
     # ---- source-term tasks (artemis_driver.cpp:222-241) ---------------------------------------
     def ExternalGravity(self, time, dt, gravity):
         """gravity: capi.Gravity (see gravity_point / gravity_uniform below)."""

@@ -498,15 +498,20 @@ def main():
         sim.device_bytes(reset_peak=True)
         cand = [g for g in range(sim.nblocks) if sim.block_level(g) < max(sim.block_level(b) for b in range(sim.nblocks))]
         picks = [cand[(2 * q + 1) * len(cand) // 10] for q in range(5)] if cand else []
+        parts0 = sim.remesh_seconds()
         for gid in picks:
             before = sim.remesh_seconds()[1]
             if sim.force_refine(min(gid, sim.nblocks - 1)):
                 each.append(1.0e3 * (sim.remesh_seconds()[1] - before))
             sim.evolve(1)
+        parts1 = sim.remesh_seconds()
+        split_ms = {k: 1.0e3 * (parts1[q] - parts0[q]) / max(1, len(each))
+                    for q, k in ((2, "build_state"), (3, "hand_over"), (4, "tagging_incl_cycles_without_remesh"))}
         torch.cuda.synchronize()
         cycle_ms = 1.0e3 * elapsed / args.steps
         remesh_leg = {"remeshes_in_timed_region": remeshes_timed, "seconds_in_timed_region": s_timed,
                       "forced": len(each), "ms_each": each, "ms_mean": (sum(each) / len(each)) if each else None,
+                      "ms_mean_split": split_ms,
                       "cycle_ms": cycle_ms, "remesh_over_cycle": (sum(each) / len(each) / cycle_ms) if each else None,
                       "blocks_before": blocks0, "blocks_after": sim.nblocks,
                       "device_bytes_now": sim.device_bytes()[0], "device_bytes_peak_during_remesh": sim.device_bytes()[1],

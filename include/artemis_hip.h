@@ -482,6 +482,13 @@ int artemis_hip_viscous_source(const artemis_pack_t *p, const artemis_diffusion_
 int artemis_hip_diffusion_dt(const artemis_pack_t *p, const artemis_diffusion_t *d, double cfl,
                              double *dt_dev, void *stream);
 
+/* Gas::EstimateTimestepMesh with its diffusive limits (gas.cpp:411-467) and Dust::EstimateTimestepMesh (dust.cpp:256-272)
+ * of p's primitives in ONE pass: what artemis_hip_estimate_dt_async for both fluids and artemis_hip_diffusion_dt
+ * min-combine into *dt_dev, with one read of the state (every limit is a minimum over the zones: same bits).
+ * d = NULL: no diffusive limits. */
+int artemis_hip_timestep_all(const artemis_pack_t *p, double cfl_gas, double cfl_dust, const artemis_diffusion_t *d,
+                             double *dt_dev, void *stream);
+
 /* General fused stage: the same contract as artemis_hip_stage_fused for EVERY configuration the
  * per-task entry points accept -- gas and/or dust, any number of species, PCM/PLM/PPM, all six
  * coordinate systems, with ExternalGravity, RotatingFrameForce and DragSource between FluxSource
@@ -722,8 +729,10 @@ typedef struct artemis_amr_criterion {
 } artemis_amr_criterion_t;
 int artemis_hip_amr_first_derivative(const artemis_amr_criterion_t *a, int *tag, double *maxval, void *stream);
 int artemis_hip_amr_magnitude(const artemis_amr_criterion_t *a, int *tag, double *maxval, void *stream);
-/* The same block maxima for EVERY block of a pack in one launch: field = 0 (gas density of species 0) or 1 (gas
- * pressure of species 0), magnitude = 0 (ScalarFirstDerivative) or 1 (ScalarMagnitude); maxima_dev = DEVICE array of
+/* The same block maxima for EVERY block of a pack in one launch: field = 0 (gas density of species 0), 1 (gas
+ * pressure of species 0, read from the primitives' pressure slot) or 2 (the same pressure recomputed as
+ * max(0, (gamma - 1) rho sie), fill_derived.cpp:247 -- for callers whose pressure slot is not maintained in the
+ * ghost zones: the one-kernel stages), magnitude = 0 (ScalarFirstDerivative) or 1 (ScalarMagnitude); maxima_dev = DEVICE array of
  * p->nblocks doubles.  Asynchronous on `stream` (copy the maxima back and compare with the thresholds as above):
  * an adaptive mesh of thousands of small blocks is tagged with one launch and one copy instead of a launch and a
  * synchronisation per block. */

@@ -21,9 +21,18 @@ extern "C" {
 int artemis_rt_set_device(int dev);
 void *artemis_rt_malloc(size_t bytes);      /* device memory (HBM) */
 void artemis_rt_free(void *p);
-/* bytes of device memory currently held through artemis_rt_malloc, and their high-water mark since the start (or
- * since the last call with reset_peak != 0) -- what a remesh, which builds the new mesh next to the old one, costs */
+/* artemis_rt_malloc / artemis_rt_free keep freed buffers in size classes (1/16 of a power of two) and hand them out
+ * again: a remesh frees and allocates tens of GB in buffers whose sizes barely change, and hipFree + hipMalloc of that
+ * costs seconds.  ARTEMIS_POOL_GB (default 64) bounds the cache; it is emptied when the device runs out of memory;
+ * ARTEMIS_NO_POOL=1 turns it off.  artemis_rt_free synchronises the device first, as hipFree does.
+ * artemis_rt_device_bytes: the device footprint through artemis_rt_malloc (live and cached buffers at their
+ * capacities) and its high-water mark since the start (or since the last call with reset_peak != 0) -- what a remesh,
+ * which builds the new mesh next to what it keeps of the old one, costs. */
 void artemis_rt_device_bytes(size_t *current, size_t *peak, int reset_peak);
+/* give cached buffers back to the device until at most keep_bytes of them are left (oldest first); the driver calls it
+ * with 0 once the initial mesh is built (the smaller meshes of the initial refinement loop leave buffers nobody asks
+ * for again) */
+void artemis_rt_pool_trim(size_t keep_bytes);
 void *artemis_rt_malloc_host(size_t bytes); /* pinned host memory */
 void artemis_rt_free_host(void *p);
 int artemis_rt_memcpy_h2d(void *dst, const void *src, size_t n, void *stream);

@@ -857,6 +857,15 @@ int artemis_hip_diffusion_dt(const artemis_pack_t *p, const artemis_diffusion_t 
   }
   return 0;
 }
+int artemis_hip_timestep_all(const artemis_pack_t *p, double cfl_gas, double cfl_dust, const artemis_diffusion_t *d, double *dt_dev,
+                             void *s) {
+  if (p->gas.nspecies)
+    if (int rc = artemis_hip_estimate_dt_async(p, ARTEMIS_GAS, cfl_gas, dt_dev, s)) return rc;
+  if (p->dust.nspecies)
+    if (int rc = artemis_hip_estimate_dt_async(p, ARTEMIS_DUST, cfl_dust, dt_dev, s)) return rc;
+  if (d && p->gas.nspecies) return artemis_hip_diffusion_dt(p, d, cfl_gas, dt_dev, s);
+  return 0;
+}
 int artemis_hip_wait_counter(unsigned *, unsigned, unsigned *, void *) { return 0; }
 int artemis_hip_advance_dt(double *st, double tlim, int nstages, const double *beta, void *) {
   double time = st[0], dt = st[1];
@@ -1149,6 +1158,14 @@ int artemis_hip_amr_block_maxima(const artemis_pack_t *p, int field, int magnitu
     a.ni = p->nx1 + 2 * g, a.nj = (ndim > 1) ? p->nx2 + 2 * g : 1, a.nk = (ndim > 2) ? p->nx3 + 2 * g : 1;
     a.geom = p->geom + 6 * b;
     a.field = p->gas.prim[b * 6 * p->gas.nspecies + (field == 0 ? 0 : 4 * p->gas.nspecies)];
+    std::vector<double> pres;
+    if (field == 2) { // the pressure recomputed from rho and sie (fill_derived.cpp:247)
+      const size_t n = static_cast<size_t>(a.ni) * a.nj * a.nk;
+      const double *rho = p->gas.prim[b * 6 * p->gas.nspecies], *sie = p->gas.prim[b * 6 * p->gas.nspecies + 5 * p->gas.nspecies];
+      pres.resize(n);
+      for (size_t c = 0; c < n; ++c) pres[c] = std::max(0.0, p->gm1 * rho[c] * sie[c]);
+      a.field = pres.data();
+    }
     a.is = g, a.ie = g + p->nx1 - 1, a.js = (ndim > 1) ? g : 0, a.je = a.js + p->nx2 - 1, a.ks = (ndim > 2) ? g : 0, a.ke = a.ks + p->nx3 - 1;
     a.refine_thr = 1e300, a.deref_thr = -1e300;
     int tag;
@@ -1163,6 +1180,7 @@ void artemis_rt_device_bytes(size_t *current, size_t *peak, int) {
   if (peak) *peak = 0;
 }
 void artemis_rt_free(void *p) { std::free(p); }
+void artemis_rt_pool_trim(size_t) {}
 void *artemis_rt_malloc_host(size_t n) { return std::calloc(1, n ? n : 8); }
 void artemis_rt_free_host(void *p) { std::free(p); }
 int artemis_rt_memcpy_h2d(void *d, const void *s, size_t n, void *) { std::memcpy(d, s, n); return 0; }

@@ -71,6 +71,13 @@ def test_diffusion_tasks(hiplib, coordinates, nx, lo, hi, avg, ctype, table):
     # Gas::EstimateTimestepMesh = cfl * min(hydro, viscous, conductive) (gas.cpp:435-467)
     hyd = mb.EstimateTimestepMesh(0, cfl=0.3)
     assert min(hyd, mb.DiffusionTimestep(D, 0.3)) == o.EstimateTimestepMesh(0)
+    # ... and every limit of both fluids in one pass (artemis_hip_timestep_all)
+    want = o.EstimateTimestepMesh(0)
+    if o.cfg.ns_dust:
+        want = min(want, o.EstimateTimestepMesh(1))
+    assert mb.TimestepAll(0.3, o.cfg.cfl_dust, D) == want
+    assert mb.TimestepAll(0.3, o.cfg.cfl_dust, None) == min(
+        hyd, o.EstimateTimestepMesh(1) if o.cfg.ns_dust else np.inf)
 
 
 @pytest.mark.parametrize("coordinates,nx,lo,hi", [CART[0], CURVI[2], CURVI[3]])
