@@ -611,15 +611,27 @@ __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, c
   }
 }
 
-__global__ void nbody_force_sum_kernel(const artemis_nbody_particle_t *pl, int npart, int grid, const double *partial,
-                                       double *force) {
-  const int t = threadIdx.x;
-  if (t >= 7 * npart) return;
+// force[7 n + q] += the rows of `partial` in index order.  The rows come through LDS in chunks (coalesced loads by the
+// whole workgroup); thread (n, q) then adds its column of the chunk in order.
+__global__ __launch_bounds__(1024) void nbody_force_sum_kernel(const artemis_nbody_particle_t *pl, int npart, int grid,
+                                                              int chunk_rows, const double *partial, double *force) {
+  extern __shared__ double rows[]; // [chunk_rows][npart][7]
+  const int t = threadIdx.x, nq = 7 * npart;
   const int n = t / 7, q = t - 7 * n;
-  if (!pl[n].couple) return;
+  const bool mine = t < nq && pl[n].couple;
   double sum = 0.0;
-  for (int w = 0; w < grid; ++w) sum += partial[(static_cast<long>(n) * grid + w) * 7 + q];
-  force[7 * n + q] += sum;
+  for (int w0 = 0; w0 < grid; w0 += chunk_rows) {
+    const int nr = min(chunk_rows, grid - w0);
+    __syncthreads();
+    for (int e = t; e < nr * nq; e += blockDim.x) {
+      const int w = e / nq, col = e - w * nq, pn = col / 7, pq = col - 7 * pn;
+      rows[e] = partial[(static_cast<long>(pn) * grid + (w0 + w)) * 7 + pq];
+    }
+    __syncthreads();
+    if (mine)
+      for (int w = 0; w < nr; ++w) sum += rows[w * nq + t];
+  }
+  if (mine) force[7 * n + q] += sum;
 }
 
 } // namespace
@@ -657,8 +669,10 @@ void launch_nbody_force_sums(const PackView &P, const artemis_nbody_particle_t *
   else if (P.gas.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<true, false, false>), grid, block, 0, s, P, N);
   else if (P.dust.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<false, true, false>), grid, block, 0, s, P, N);
   else return;
-  hipLaunchKernelGGL(nbody_force_sum_kernel, dim3(1), dim3(64 * ((7 * npart + 63) / 64)), 0, s, pl_dev, npart,
-                     static_cast<int>(grid.x), partial_dev, force_dev);
+  const int nq = 7 * npart; // (<= 896: artemis_hip_nbody_force_sums takes at most 128 particles)
+  const int chunk_rows = std::max(1, std::min<int>(grid.x, 32768 / (8 * nq)));
+  hipLaunchKernelGGL(nbody_force_sum_kernel, dim3(1), dim3(std::max(256, 64 * ((nq + 63) / 64))), sizeof(double) * chunk_rows * nq, s,
+                     pl_dev, npart, static_cast<int>(grid.x), chunk_rows, partial_dev, force_dev);
 }
 void launch_external_gravity(const PackView &P, const artemis_gravity_t &G, double dt, hipStream_t s) {
   hipLaunchKernelGGL(gravity_kernel, interior_grid(P), interior_threads(P), 0, s, P, G, dt);
