@@ -390,11 +390,12 @@ inline TaskStatus GasDiffusionUpdate(MeshData<Real> *md, const Real dt) { // Gas
 }
 
 // ---- source tasks between FluxSource and SetAuxillaryFields (artemis_driver.cpp:222-248) ---------------------------
-inline TaskStatus ExternalGravity(MeshData<Real> *md, const Real time, const Real dt) { // gravity/gravity.cpp:126-155
+// the gravity package's parameters as the library takes them (uniform, point, binary: gravity.cpp:36-118); false for
+// the N-body type, whose particle list travels separately
+inline bool GravityParams(MeshData<Real> *md, const Real time, artemis_gravity_t &g) {
   auto pm = md->GetParentPointer();
   auto &pkg = pm->packages.Get("gravity");
   const auto gtype = pkg->template Param<Gravity::GravityType>("type");
-  artemis_gravity_t g;
   std::memset(&g, 0, sizeof g);
   g.tstart = pkg->template Param<Real>("tstart"), g.tstop = pkg->template Param<Real>("tstop");
   if (gtype == Gravity::GravityType::uniform) {
@@ -420,7 +421,18 @@ inline TaskStatus ExternalGravity(MeshData<Real> *md, const Real time, const Rea
     orb.solve(time, omf, rb, vb);
     const Real mu1 = 1.0 / (1.0 + g.q), mu2 = g.q / (1.0 + g.q);
     for (int d = 0; d < 3; ++d) g.pos[d] = com[d] - mu2 * rb[d], g.pos2[d] = com[d] + mu1 * rb[d];
-  } else if (gtype == Gravity::GravityType::nbody) { // gravity.cpp:150-155 -> nbody_gravity.hpp:160-221
+  } else if (gtype == Gravity::GravityType::nbody) {
+    return false;
+  } else {
+    PARTHENON_FAIL("Unknown gravity node!");
+  }
+  return true;
+}
+inline TaskStatus ExternalGravity(MeshData<Real> *md, const Real time, const Real dt) { // gravity/gravity.cpp:126-155
+  auto pm = md->GetParentPointer();
+  auto &pkg = pm->packages.Get("gravity");
+  artemis_gravity_t g;
+  if (!GravityParams(md, time, g)) { // gravity.cpp:150-155 -> nbody_gravity.hpp:160-221
     auto &nb = pm->packages.Get("nbody");
     if (nb->template Param<int>("npart") <= 0) return TaskStatus::complete;
     if (!((time >= g.tstart) && (time < g.tstop))) return TaskStatus::complete; // gravity.cpp:134
@@ -446,9 +458,8 @@ inline TaskStatus ExternalGravity(MeshData<Real> *md, const Real time, const Rea
       for (int i = 0; i < 7; ++i) pforce_h(n, i) += f[static_cast<size_t>(7) * n + i]; // nbody_gravity.hpp:213-215
     pforce.DeepCopy(pforce_h);
     return TaskStatus::complete;
-  } else {
-    PARTHENON_FAIL("Unknown gravity node!");
   }
+  (void)pkg;
   ARTEMIS_HIP_TASK(artemis_hip_external_gravity(&GetPack(md), &g, time, dt, Stream()));
 }
 inline TaskStatus RotatingFrameForce(MeshData<Real> *md, const Real time, const Real dt) { // rotating_frame.cpp:56-86
@@ -456,11 +467,11 @@ inline TaskStatus RotatingFrameForce(MeshData<Real> *md, const Real time, const 
   ARTEMIS_HIP_TASK(artemis_hip_rotating_frame_force(&GetPack(md), pkg->template Param<Real>("omega"),
                                                     pkg->template Param<Real>("qshear"), time, dt, Stream()));
 }
-inline TaskStatus DragSource(MeshData<Real> *md, const Real time, const Real dt) { // Drag::DragSource<GEOM>, drag.cpp:89-175
+// the drag package's parameters as the library takes them (drag.cpp:35-86); `diff` receives the gas viscosity when
+// <gas/damping> damp_to_visc points the damping at it (d.damp_visc then points into diff: keep both alive)
+inline void DragParams(PackCache &c, MeshData<Real> *md, artemis_drag_t &d, artemis_diffusion_t &diff) {
   auto pm = md->GetParentPointer();
   auto &pkg = pm->packages.Get("drag");
-  PackCache &c = GetCache(md);
-  artemis_drag_t d;
   std::memset(&d, 0, sizeof d);
   const auto ctype = pkg->template Param<Drag::Coupling>("type");
   d.type = (ctype == Drag::Coupling::simple_dust) ? ARTEMIS_DRAG_SIMPLE_DUST : ARTEMIS_DRAG_SELF;
@@ -489,13 +500,18 @@ inline TaskStatus DragSource(MeshData<Real> *md, const Real time, const Real dt)
       for (int n = 0; n < nd; ++n) d.sizes[n] = sizes(n);
     }
   }
-  artemis_diffusion_t diff; // <gas/damping> damp_to_visc: the gas package's viscosity (drag.cpp:109-121)
-  if (gpar.damp_to_visc) {
+  if (gpar.damp_to_visc) { // the gas package's viscosity (drag.cpp:109-121)
     diff = Diffusion_(c, md);
     PARTHENON_REQUIRE(diff.visc.type == ARTEMIS_VISCOSITY_PLAW || diff.visc.type == ARTEMIS_VISCOSITY_ALPHA,
                       "The chosen viscosity model does not work with damping");
     d.damp_visc = &diff.visc;
   }
+}
+inline TaskStatus DragSource(MeshData<Real> *md, const Real time, const Real dt) { // Drag::DragSource<GEOM>, drag.cpp:89-175
+  PackCache &c = GetCache(md);
+  artemis_drag_t d;
+  artemis_diffusion_t diff;
+  DragParams(c, md, d, diff);
   ARTEMIS_HIP_TASK(artemis_hip_drag_source(&c.p, &d, time, dt, Stream()));
 }
 
@@ -608,6 +624,106 @@ inline TaskStatus StageFused(MeshData<Real> *u0, const int stage, const partheno
 }
 inline void StageFusedFillDerived(MeshData<Real> *md) {
   PARTHENON_REQUIRE(artemis_hip_prim_to_cons_ghosts(&GetPack(md), Stream()) == 0, artemis_hip_last_error());
+}
+
+// ---- the DEFAULT stage task: CalculateFluxes .. ConsToPrim (artemis_driver.cpp:182-255) as ONE task -----------------
+// What a maintainer wires into StepTasks: per stage
+//     if (ArtemisHip::StageCovered(u0)) { Stage(u0, stage, integrator, pcm, time); <boundary exchange>; StageFillDerived(u0); }
+//     else                              { the per-task forwarders above, in the reference's order }
+// Stage takes the tuned Cartesian kernel (StageFused above: it also stores the conserved state, so only the ghost zones
+// are converted afterwards) where that applies, and artemis_hip_stage_general for everything else the one-kernel
+// stages cover: gas and / or dust, any coordinate system, PCM / PLM / PPM, viscosity and conduction (their flux tasks
+// run inside Stage), uniform / point / binary gravity, the rotating frame, drag.  Not covered (StageCovered is false,
+// the per-task list stays): the N-body gravity type (its particle list lives with the NBody package and its
+// back-reaction sums go to the host: see artemis_stage_general_args_t.nbody_dev for a host that keeps the particles
+// on the device), cooling (this header forwards no CoolingSource: artemis_stage_general_args_t.cooling exists for a
+// host that fills artemis_cooling_t), radiation.
+inline bool StageCovered(MeshData<Real> *md) {
+  auto pm = md->GetParentPointer();
+  auto &art = pm->packages.Get("artemis");
+  auto flag = [&](const char *n) { return art->template Param<bool>(n); }; // (artemis.cpp:73-83 registers every do_* flag)
+  if (flag("do_radiation") || flag("do_cooling")) return false;
+  if (flag("do_gravity") && pm->packages.Get("gravity")->template Param<Gravity::GravityType>("type") == Gravity::GravityType::nbody)
+    return false;
+  return true;
+}
+inline bool StageTakesTunedKernel(MeshData<Real> *md) {
+  auto pm = md->GetParentPointer();
+  auto &art = pm->packages.Get("artemis");
+  auto flag = [&](const char *n) { return art->template Param<bool>(n); }; // (artemis.cpp:73-83 registers every do_* flag)
+  const artemis_pack_t &p = GetCache(md).p;
+  return p.coords == ARTEMIS_CARTESIAN && p.gas.nspecies == 1 && p.dust.nspecies == 0 && p.gas.recon != ARTEMIS_PPM &&
+         !flag("do_gravity") && !flag("do_rotating_frame") && !flag("do_drag") && !flag("do_cooling") && !flag("do_viscosity") &&
+         !flag("do_conduction");
+}
+struct GeneralBuffers {
+  StageBuffers gas, dust;
+};
+inline std::map<int, GeneralBuffers> &GeneralBufferCache() {
+  static std::map<int, GeneralBuffers> m;
+  return m;
+}
+inline void EnsureStageBuffers(StageBuffers &sb, const PackCache &c, const int nent, const long N) {
+  if (sb.probe == c.probe0 && sb.sig == c.sig0 && sb.step.size() == nent) return;
+  sb.step_data = ParArray1D<Real>("artemis_hip start-of-step primitives", static_cast<long>(nent) * N);
+  sb.new_data = ParArray1D<Real>("artemis_hip stage output primitives", static_cast<long>(nent) * N);
+  sb.step = ParArray1D<Real *>("artemis_hip table", nent), sb.out = ParArray1D<Real *>("artemis_hip table", nent);
+  auto ts = sb.step, to = sb.out;
+  Real *bs = sb.step_data.data(), *bo = sb.new_data.data();
+  parthenon::par_for(
+      DEFAULT_LOOP_PATTERN, "ArtemisHip::FillStageTables", parthenon::DevExecSpace(), 0, nent - 1, 0, 0,
+      KOKKOS_LAMBDA(const int e, const int) { ts(e) = bs + e * N, to(e) = bo + e * N; });
+  sb.probe = c.probe0, sb.sig = c.sig0;
+}
+inline TaskStatus Stage(MeshData<Real> *u0, const int stage, const parthenon::LowStorageIntegrator *integ, const bool pcm,
+                        const Real time) {
+  if (StageTakesTunedKernel(u0)) return StageFused(u0, stage, integ, pcm);
+  auto pm = u0->GetParentPointer();
+  auto &art = pm->packages.Get("artemis");
+  auto flag = [&](const char *n) { return art->template Param<bool>(n); }; // (artemis.cpp:73-83 registers every do_* flag)
+  PackCache &c = GetCache(u0);
+  const artemis_pack_t &p = c.p;
+  const int ndim = (p.nx3 > 1) ? 3 : ((p.nx2 > 1) ? 2 : 1);
+  const long N = static_cast<long>(p.nx1 + 2 * p.nghost) * (ndim > 1 ? p.nx2 + 2 * p.nghost : 1) * (ndim > 2 ? p.nx3 + 2 * p.nghost : 1);
+  const int ng = p.nblocks * 6 * p.gas.nspecies, nd = p.nblocks * 4 * p.dust.nspecies;
+  GeneralBuffers &gb = GeneralBufferCache()[u0->GetPartitionId()];
+  if (ng) EnsureStageBuffers(gb.gas, c, ng, N);
+  if (nd) EnsureStageBuffers(gb.dust, c, nd, N);
+  artemis_stage_general_args_t a;
+  std::memset(&a, 0, sizeof a);
+  a.gam0 = integ->gam0[stage - 1], a.gam1 = integ->gam1[stage - 1];
+  a.beta_dt = a.bdt = integ->beta[stage - 1] * integ->dt;
+  a.pcm = pcm, a.time = time;
+  if (ng) a.gas_in = p.gas.prim, a.gas_u1 = (stage == 1) ? p.gas.prim : gb.gas.step.data(), a.gas_out = gb.gas.out.data();
+  if (nd) a.dust_in = p.dust.prim, a.dust_u1 = (stage == 1) ? p.dust.prim : gb.dust.step.data(), a.dust_out = gb.dust.out.data();
+  artemis_gravity_t grav;
+  if (flag("do_gravity")) {
+    PARTHENON_REQUIRE(GravityParams(u0, time, grav), "ArtemisHip::Stage: N-body gravity keeps the per-task list (StageCovered)");
+    a.gravity = &grav;
+  }
+  if (flag("do_rotating_frame")) {
+    auto &rf = pm->packages.Get("rotating_frame");
+    a.rf_omega = rf->template Param<Real>("omega"), a.rf_qshear = rf->template Param<Real>("qshear");
+  }
+  artemis_drag_t drag;
+  artemis_diffusion_t drag_visc, diff;
+  if (flag("do_drag")) DragParams(c, u0, drag, drag_visc), a.drag = &drag;
+  if (ng && (flag("do_viscosity") || flag("do_conduction"))) { // the diffusion-flux tasks of this stage's input (artemis_driver.cpp:189-193)
+    diff = Diffusion_(c, u0);
+    PARTHENON_REQUIRE(artemis_hip_zero_viscous_flux(&p, &diff, Stream()) == 0, artemis_hip_last_error());
+    if (diff.cond.type != ARTEMIS_DIFF_OFF) PARTHENON_REQUIRE(artemis_hip_thermal_flux(&p, &diff, Stream()) == 0, artemis_hip_last_error());
+    a.diffusion = &diff;
+  }
+  PARTHENON_REQUIRE(artemis_hip_stage_general(&p, &a, Stream()) == 0, artemis_hip_last_error());
+  if (ng) CopyInterior(c.gprim, gb.gas.out, gb.gas.step, stage == 1, ng, ActiveZones(p));
+  if (nd) CopyInterior(c.dprim, gb.dust.out, gb.dust.step, stage == 1, nd, ActiveZones(p));
+  return TaskStatus::complete;
+}
+// FillDerived after the boundary exchange (artemis_driver.cpp:261): the tuned kernel stored the conserved state of the
+// zones it updated, so only the ghost zones are converted; the general stage stores primitives only
+inline void StageFillDerived(MeshData<Real> *md) {
+  if (StageTakesTunedKernel(md)) StageFusedFillDerived(md);
+  else PrimToCons(md);
 }
 #undef ARTEMIS_HIP_TASK
 

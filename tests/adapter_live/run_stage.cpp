@@ -10,6 +10,10 @@
 //     gas   : gas, HLLC + PLM, per-task forwarders
 //     full  : gas + one dust species, uniform gravity, shearing box, simple_dust drag, constant viscosity
 //     fused : gas through the opt-in StageFused / StageFusedFillDerived forwarders
+//     stage_gas / stage_full : the `gas` / `full` problems through the DEFAULT stage task of INTEGRATION.md section 3
+//             (ArtemisHip::StageCovered -> Stage -> boundary conditions -> StageFillDerived: the tuned kernel for gas
+//             alone, artemis_hip_stage_general with the diffusion-flux tasks inside for gas + dust + gravity +
+//             shearing box + drag + viscosity)
 //     realloc = 1: after the first step every variable moves to a new allocation (what a remesh or a restart does
 //                  to the addresses) -- the adapter has to notice by itself
 //     realloc = 2: ONE partition holding both blocks; after the first step the SECOND block is replaced by a new
@@ -131,7 +135,8 @@ int main(int argc, char **argv) {
   const int nsteps = std::atoi(argv[5]);
   const int realloc_mode = std::atoi(argv[6]);
   const bool realloc_after_first = realloc_mode == 1, one_partition = realloc_mode == 2;
-  const bool full = mode == "full", fused = mode == "fused";
+  const bool stage_task = mode == "stage_gas" || mode == "stage_full";
+  const bool full = mode == "full" || mode == "stage_full", fused = mode == "fused";
   const bool dust = full, diffusion = full;
 
   Mesh mesh;
@@ -139,6 +144,8 @@ int main(int argc, char **argv) {
   auto art = pkg("artemis");
   art->AddParam("do_gas", true), art->AddParam("do_dust", dust), art->AddParam("coords", Coordinates::cartesian);
   art->AddParam("do_rotating_frame", full), art->AddParam("do_viscosity", diffusion), art->AddParam("do_conduction", false);
+  art->AddParam("do_gravity", full), art->AddParam("do_drag", full), art->AddParam("do_nbody", false);
+  art->AddParam("do_cooling", false), art->AddParam("do_radiation", false), art->AddParam("do_diffusion", diffusion);
   auto gas = pkg("gas");
   gas->AddParam("nspecies", 1), gas->AddParam("adiabatic_index", Real(1.4));
   gas->AddParam("recon", ReconstructionMethod::plm), gas->AddParam("rsolver", RSolver::hllc);
@@ -219,6 +226,14 @@ int main(int argc, char **argv) {
             ArtemisHip::StageFused(u0, stage, &integ, false);
             bcs();
             ArtemisHip::StageFusedFillDerived(u0);
+            continue;
+          }
+          if (stage_task) { // the default wiring: one task per stage where the library covers the package set
+            if (!ArtemisHip::StageCovered(u0)) return 6;
+            if (ArtemisHip::StageTakesTunedKernel(u0) != (mode == "stage_gas")) return 7;
+            ArtemisHip::Stage(u0, stage, &integ, false, time);
+            bcs();
+            ArtemisHip::StageFillDerived(u0);
             continue;
           }
           ArtemisHip::GasCalculateFluxes(u0, false);

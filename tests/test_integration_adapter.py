@@ -98,7 +98,7 @@ def initial_state(seed, dust):
 
 def oracle_run(mode, g, d, dt, nsteps):
     from oracle.oracle import Oracle
-    full = mode == "full"
+    full = mode in ("full", "stage_full")
     o = Oracle(NX, LO, HI, ng=NG, ns_gas=1, ns_dust=1 if full else 0, reconstruct="plm", riemann="hllc",
                dust_reconstruct="plm", dust_riemann="hlle", gamma=1.4, dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10,
                cfl=0.3, dust_cfl=0.3, bc=("outflow",) * 6, integrator="rk2")
@@ -138,17 +138,21 @@ def run_harness(harness, tmp_path, mode, states, dt, nsteps, realloc):
 
 
 @pytest.mark.parametrize("mode,realloc", [("gas", 0), ("gas", 1), ("full", 0), ("full", 1), ("fused", 1), ("gas", 2),
-                                          ("full", 2), ("fused", 2)])
+                                          ("full", 2), ("fused", 2), ("stage_gas", 1), ("stage_full", 0),
+                                          ("stage_full", 1), ("stage_full", 2)])
 def test_rk2_steps_through_the_adapter_equal_the_oracle(harness, tmp_path, mode, realloc):
     """Two RK2 steps of the reference's task list through the forwarders == the oracle, every bit of the primitives AND
     of the conserved state u0 (ghost zones included), on both partitions; with `realloc` every variable moves to a new
     allocation between the steps (a remesh / restart changes addresses like that) and the adapter must rebuild its
     tables by itself.  `full`: gas + dust + gravity + shearing box + drag + viscosity through the widened forwarders;
-    `fused`: the opt-in StageFused / StageFusedFillDerived pair (cons current after every stage).  realloc = 2: both
+    `fused`: the opt-in StageFused / StageFusedFillDerived pair (cons current after every stage); `stage_gas` /
+    `stage_full`: the DEFAULT wiring of INTEGRATION.md section 3 -- StageCovered -> Stage -> conditions ->
+    StageFillDerived, one task per stage (the tuned kernel for gas alone; artemis_hip_stage_general with the
+    diffusion-flux tasks inside for gas + dust + gravity + shearing box + drag + viscosity).  realloc = 2: both
     blocks in ONE partition and, between the steps, the SECOND block replaced by a new block object with another gid /
     logical location and fresh allocations while the first stays put -- what a remesh does to a refined or migrated
     block next to an unchanged one; a cache keyed on the partition's first block alone would keep the stale tables."""
-    dust = mode == "full"
+    dust = mode in ("full", "stage_full")
     states = [initial_state(11, dust), initial_state(29, dust)]
     dt, nsteps = 2.0e-3, 2
     got, dt_est = run_harness(harness, tmp_path, mode, states, dt, nsteps, realloc)
@@ -156,7 +160,7 @@ def test_rk2_steps_through_the_adapter_equal_the_oracle(harness, tmp_path, mode,
     for q, (g, d) in enumerate(states):
         o = oracle_run(mode, g, d, dt, nsteps)
         dts.append(o.new_dt())
-        keep = [0, 1, 2, 3, 5] if mode == "fused" else list(range(6))  # (the fused stage keeps P on interior zones only)
+        keep = [0, 1, 2, 3, 5] if mode in ("fused", "stage_gas") else list(range(6))  # (the fused stage keeps P on interior zones only)
         assert np.array_equal(got[q][0][keep], o.gprim[keep]), (mode, q, "gas prim")
         assert np.array_equal(got[q][1], o.gu0), (mode, q, "gas cons")
         if dust:
