@@ -296,6 +296,9 @@ struct artemis_sim_impl {
   DevBuf nb_dev, nb_force_dev, nb_scratch, amr_maxima;
   std::vector<artemis_nbody_particle_t> nb_uploaded;
   bool nbody_in_stage = false; // N-body gravity can run inside artemis_hip_stage_general's kernels
+  // refined meshes: the cost model of the Z-order split (see build_mesh_multilevel) and what it achieved
+  std::vector<double> lb_level_cost;
+  double lb_flux_face_cost = 0.0, lb_max_over_mean = 1.0;
   void nbody_stage_args(const artemis_pack_t &p, artemis_stage_general_args_t &a, Real bdt);
   void flush_nbody_force();
   Real rf_omega = 0.0, rf_qshear = 0.0;
@@ -539,6 +542,9 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
       derefine_count = pin.GetOrAddInteger("parthenon/mesh", "derefine_count", 10);
     }
     if (ref == "static" || ref == "adaptive") {
+      // the rank split's cost model (this driver's own block, not a reference parameter): see build_mesh_multilevel
+      if (pin.DoesParameterExist("artemis_amd/loadbalance", "level_cost")) lb_level_cost = pin.GetVector("artemis_amd/loadbalance", "level_cost");
+      lb_flux_face_cost = pin.GetOrAddReal("artemis_amd/loadbalance", "flux_face_cost", 0.0);
       for (int q = 0; q < 64; ++q) {
         const std::string blk = "parthenon/static_refinement" + std::to_string(q);
         if (!pin.DoesBlockExist(blk)) continue;
@@ -1059,14 +1065,57 @@ void artemis_sim_impl::build_mesh_multilevel() {
   ml.max_level = tree.max_level();
   nblocks_global = static_cast<long>(leaves.size());
   if (nblocks_global < nranks) throw std::runtime_error("fewer mesh blocks than ranks");
+  // operation lists of the whole mesh (global ids): the split below may weigh blocks by what they take part in
+  const artemis_host::MeshOps M = artemis_host::build_mesh_ops(tree, leaves, mbnx, ng);
   std::vector<int> rank_of(leaves.size()), local_of(leaves.size());
   {
-    const long base_n = nblocks_global / nranks, extra = nblocks_global % nranks;
-    long g = 0;
-    for (int r = 0; r < nranks; ++r) {
-      const long cnt = base_n + (r < extra ? 1 : 0);
-      for (long q = 0; q < cnt; ++q, ++g) rank_of[g] = r, local_of[g] = static_cast<int>(q);
+    // Cost of a block = zones (the same for every block) x the stage cost of its level (<artemis_amd/loadbalance>
+    // level_cost = c0, c1, ...; default 1: every block costs the same, which is Parthenon's default and what measurements
+    // of the one-kernel stages give -- the stage kernels do not know levels) + flux_face_cost per coarse-fine face
+    // operation the block takes part in (fine-side face solves, restriction, the coarse side's fix-up zones; default 0).
+    // Contiguous Z-order runs whose cumulative cost is as even as the block granularity allows.
+    std::vector<double> cost(leaves.size(), 1.0);
+    bool uniform = true;
+    for (size_t gb = 0; gb < leaves.size(); ++gb) {
+      const int lv = leaves[gb].level;
+      if (lv < static_cast<int>(lb_level_cost.size())) cost[gb] = lb_level_cost[lv];
     }
+    if (lb_flux_face_cost != 0.0)
+      for (const artemis_host::GlobalOp &o : M.flux) {
+        if (o.op.dst_block >= 0) cost[o.op.dst_block] += lb_flux_face_cost;
+        if (o.op.src_block >= 0) cost[o.op.src_block] += lb_flux_face_cost;
+      }
+    for (double c : cost) uniform = uniform && c == cost[0];
+    if (uniform) { // equal counts (the first `extra` ranks take one more)
+      const long base_n = nblocks_global / nranks, extra = nblocks_global % nranks;
+      long g = 0;
+      for (int r = 0; r < nranks; ++r) {
+        const long cnt = base_n + (r < extra ? 1 : 0);
+        for (long q = 0; q < cnt; ++q, ++g) rank_of[g] = r, local_of[g] = static_cast<int>(q);
+      }
+    } else {
+      double total = 0.0;
+      for (double c : cost) total += c;
+      long g = 0;
+      double done = 0.0;
+      for (int r = 0; r < nranks; ++r) {
+        // rank r's run ends where the cumulative cost is nearest to (r + 1) / nranks of the total, leaving at least one
+        // block for every rank still to come
+        const double target = total * (r + 1) / nranks;
+        long q = 0;
+        const long must_leave = nranks - 1 - r;
+        while (g < nblocks_global - must_leave &&
+               (q == 0 || r == nranks - 1 || std::fabs(done + cost[g] - target) <= std::fabs(done - target))) {
+          rank_of[g] = r, local_of[g] = static_cast<int>(q);
+          done += cost[g], ++g, ++q;
+        }
+      }
+    }
+    std::vector<double> per_rank(nranks, 0.0);
+    for (size_t gb = 0; gb < leaves.size(); ++gb) per_rank[rank_of[gb]] += cost[gb];
+    double mx = 0.0, sum = 0.0;
+    for (double c : per_rank) mx = std::max(mx, c), sum += c;
+    lb_max_over_mean = mx / (sum / nranks);
   }
   const int g[3] = {ng, ndim > 1 ? ng : 0, ndim > 2 ? ng : 0};
   ni = mbnx[0] + 2 * g[0], nj = mbnx[1] + 2 * g[1], nk = mbnx[2] + 2 * g[2];
@@ -1105,7 +1154,6 @@ void artemis_sim_impl::build_mesh_multilevel() {
     for (int f = 0; f < 6; ++f) bc_flat[6 * b + f] = blocks[b].bc[f];
 
   // operation lists: keep what touches this rank, global ids -> local indices / message slots
-  const artemis_host::MeshOps M = artemis_host::build_mesh_ops(tree, leaves, mbnx, ng);
   const int nfill = 5 * ns_gas + 4 * ns_dust;
   const int nflux = 7 * ns_gas + ((do_viscosity || do_conduction) ? 4 * ns_gas : 0) + 4 * ns_dust;
   auto split = [&](const std::vector<artemis_host::GlobalOp> &all, int nvar, std::vector<artemis_ml_op_t> &packs_direct,
@@ -3450,6 +3498,7 @@ const char *artemis_sim_stage_kernel(const artemis_sim_t *s) {
   return s->p->general_variant == 1 ? "stage2d_kernel" : (s->p->general_variant == 2 ? "stage_fused_kernel<curvilinear>" : "stage_cell_kernel");
 }
 long artemis_sim_remeshes(const artemis_sim_t *s) { return s->remeshes; }
+double artemis_sim_load_balance(const artemis_sim_t *s) { return s->p->lb_max_over_mean; }
 int artemis_sim_force_refine(artemis_sim_t *s, long gid) {
   int changed = 0;
   GUARD(changed = remesh(*s, false, gid) ? 1 : 0, return -1)

@@ -215,6 +215,8 @@ def _declare(L):
     L.artemis_sim_remeshes.restype = C.c_long
     L.artemis_sim_force_refine.argtypes = [vp, C.c_long]
     L.artemis_sim_force_refine.restype = C.c_int
+    L.artemis_sim_load_balance.argtypes = [vp]
+    L.artemis_sim_load_balance.restype = C.c_double
     L.artemis_sim_remesh_seconds.argtypes = [vp, C.POINTER(C.c_double)]
     L.artemis_sim_remesh_seconds.restype = C.c_long
     L.artemis_rt_device_bytes.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int]
@@ -316,6 +318,11 @@ class Simulation:
         self.L.artemis_rt_device_bytes(C.byref(cur), C.byref(peak), int(reset_peak))
         return cur.value, peak.value
     last_wall_seconds = property(lambda s: s.L.artemis_sim_last_wall_seconds(s.h))
+
+    @property
+    def load_balance(self):
+        """max over ranks / mean of the cost of the Z-order rank split of a refined mesh (1 = even)."""
+        return self.L.artemis_sim_load_balance(self.h)
 
     def set_path(self, which):
         if self.L.artemis_sim_set_path(self.h, which.encode()):

@@ -667,6 +667,8 @@ def main():
                                "launch_ms": stage_ms, "launches_timed": 2 * args.steps, "algorithmic_bytes_per_launch": alg}
             if remesh_leg:
                 out["remesh"] = remesh_leg
+                out["remesh_ms_mean"] = remesh_leg["ms_mean"]
+                out["device_bytes_peak"] = remesh_leg["device_bytes_peak_during_remesh"]
         elif args.workload == "ssheet_dust":
             # B_alg per cell-stage = 8 B * 5 * (6 ns_gas + 4 ns_dust); one "launch" = one stage
             # of the general fused path (gas kernel + dust kernel + drag/aux/c2p finish)

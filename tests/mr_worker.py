@@ -33,7 +33,7 @@ def main():
     n = sim.evolve(spec.get("cycles", -1))
     out = {"ncycle": sim.ncycle, "time": sim.time, "dt": sim.dt, "n": n, "nblocks": sim.nblocks,
            "fused": sim.uses_fused_path, "tuned": sim.uses_tuned_kernel, "remeshes": sim.remeshes,
-           "levels": [sim.block_level(b) for b in range(sim.nblocks)]}
+           "levels": [sim.block_level(b) for b in range(sim.nblocks)], "load_balance": sim.load_balance}
     out["nblocks"] = sim.nblocks  # (an adaptive mesh: the count after the run)
     hist = sim.history()
     errs = sim.errors()

@@ -215,6 +215,46 @@ def test_refined_blocks_split_over_two_ranks_bitwise(tmp_path):
     assert np.allclose(two[0]["hist"], one[0]["hist"], rtol=1e-13)
 
 
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_cost_weighted_split_is_bitwise_and_reports_its_balance(tmp_path, nranks):
+    """<artemis_amd/loadbalance>: blocks weighed by level (a fine block counted 3x a root block here) and by the
+    coarse-fine face operations they take part in; the Z-order runs then even the cumulative cost, not the block count.
+    The result does not depend on the split -- 2 and 4 ranks equal 1 rank bit for bit -- and every rank reports the
+    same max / mean cost ratio, which the weighted split keeps below what equal counts give under the same costs."""
+    c = CASES["visc3d"]
+    # the refined region moved into a corner of the mesh (later overrides win): ONE of the 16 root blocks splits, so the
+    # Z-ordered list starts with its eight children -- an uneven cost per run of equal length
+    ov = c["ov"] + region_overrides(1, (-1.0, -1.0, -1.0), (-0.6, -0.6, -0.6))
+    lb = ["artemis_amd/loadbalance/level_cost=1.0,3.0", "artemis_amd/loadbalance/flux_face_cost=0.05"]
+    one = _run_workers(1, dict(deck=list(c["deck"]), overrides=ov), tmp_path, "one")
+    many = _run_workers(nranks, dict(deck=list(c["deck"]), overrides=ov + lb), tmp_path, "w%d" % nranks)
+    counts = [r["meta"]["nblocks"] for r in many]
+    assert sum(counts) == one[0]["meta"]["nblocks"] == 23 and min(counts) >= 1
+    assert max(counts) - min(counts) > 1  # (not the equal-count split)
+    ratios = {r["meta"]["load_balance"] for r in many}
+    assert len(ratios) == 1
+    ratio = ratios.pop()
+    # what equal counts would give under the same costs: contiguous runs of 44 / nranks blocks of the Z-ordered leaves
+    levels = [lv for r in many for lv in r["meta"]["levels"]]  # (ranks hold contiguous runs in rank order)
+    cost = [3.0 if lv else 1.0 for lv in levels]
+    n = len(cost)
+    base, extra = divmod(n, nranks)
+    runs, g = [], 0
+    for r in range(nranks):
+        k = base + (1 if r < extra else 0)
+        runs.append(sum(cost[g:g + k]))
+        g += k
+    equal_counts = max(runs) / (sum(runs) / nranks)
+    print("cost-weighted split on %d ranks: max / mean = %.3f (equal counts under the same level costs: %.3f), blocks per rank %s"
+          % (nranks, ratio, equal_counts, counts))
+    assert 1.0 <= ratio < equal_counts and ratio < 1.35
+    from test_multirank_cpu import by_bounds
+    a, b = by_bounds(one), by_bounds(many)
+    assert a.keys() == b.keys()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+
+
 # ---- the HIP path ----------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", ["fused", "unfused"])
