@@ -566,9 +566,8 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
       for (int d = 0; d < ndim; ++d)
         if (mbnx[d] % 2 != 0 || mbnx[d] / 2 < (ng + 1) / 2 + 1)
           throw std::runtime_error("multilevel meshes need an even meshblock size of at least nghost + 4 zones");
-      for (int f = 0; f < 2 * ndim; ++f)
-        if (mesh_bc[f] == ARTEMIS_BC_CONDUCTIVE) // (needs the conduction problem's hydrostatic profile per buffer: untested)
-          throw std::runtime_error("the conductive boundary condition on a refined mesh is not built");
+      // (the conductive condition of the conduction problem, conduction.hpp:125-255, runs on the coarse buffers like on
+      //  the fine arrays: it is local to the boundary zone and takes its geometry from the pack it is called on)
     }
   }
   // geometry::CoordSelect (geometry.hpp:38-56, artemis.cpp:94-97)

@@ -1,17 +1,19 @@
 # Round-end evidence run (one gpurun call): GPU suite, smoke, bench lines, rocprof stats, PMC traffic records.
 # Outputs under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
-tag=${1:-r03z}
+tag=${1:-r04z}
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 3300 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|FAILED" | tail -5 > gpurun_out/${tag}_tests.txt; cat gpurun_out/${tag}_tests.txt
+if [ -z "$SKIP_SUITE" ]; then timeout 3300 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|FAILED" | tail -5 > gpurun_out/${tag}_tests.txt; cat gpurun_out/${tag}_tests.txt; fi
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/${tag}_smoke.txt
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag}
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust
 # (on the box: the bench lines below quote the records just measured; scripts/collect_evidence.sh copies them locally)
 PMC_SQ_GROUPS=0,1 PMC_SQ_RECORD=${tag} timeout 600 python3 scripts/pmc_sq.py ${tag} -- bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-dropin > gpurun_out/${tag}_pmc_sq.txt 2>&1
-cp gpurun_out/${tag}_pmc_traffic.json profiles/r03_pmc_traffic.json; cp gpurun_out/${tag}_disk_sph_pmc_traffic.json profiles/r03_disk_sph_pmc_traffic.json; cp gpurun_out/${tag}_cfg3_pmc_traffic.json profiles/r03_cfg3_pmc_traffic.json; cp gpurun_out/${tag}_pmc_sq.json profiles/r03_pmc_sq.json
+PMC_SQ_GROUPS=0,1 PMC_SQ_KERNELS=stage_curv,viscous_source timeout 600 python3 scripts/pmc_sq.py ${tag}_disk_sph -- bench.py --workload disk_sph --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_disk_sph_pmc_sq.txt 2>&1
+cp gpurun_out/sq_${tag}_disk_sph.json gpurun_out/${tag}_disk_sph_pmc_sq.json
+cp gpurun_out/${tag}_pmc_traffic.json profiles/r04_pmc_traffic.json; cp gpurun_out/${tag}_disk_sph_pmc_traffic.json profiles/r04_disk_sph_pmc_traffic.json; cp gpurun_out/${tag}_cfg3_pmc_traffic.json profiles/r04_cfg3_pmc_traffic.json; cp gpurun_out/${tag}_pmc_sq.json profiles/r04_pmc_sq.json
 timeout 600 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err; cat gpurun_out/${tag}_bench_line.json | cut -c1-400
 timeout 300 python bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_cfg3_line.json
 timeout 300 python bench.py --workload ssheet_dust --n 1024 --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_line.json

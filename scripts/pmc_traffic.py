@@ -82,7 +82,8 @@ def whole_stage(args, extra):
         total += b
     # every launch of the run (initialisation, warm-up and timed cycles alike) is in the profile: normalise by the
     # launches of the stage kernel, which runs once per stage
-    stage_names = [k for k in fetch if ("stage_fused_kernel" in k or "stage2d_kernel" in k or "stage_cell_kernel" in k)]
+    stage_names = [k for k in fetch if ("stage_fused_kernel" in k or "stage2d_kernel" in k or "stage_cell_kernel" in k or
+                                        "stage_curv_kernel" in k)]
     nstage = sum(fetch[k][1] for k in stage_names)
     assert nstage, "no stage kernel in the profile"
     per_stage = total / nstage

@@ -255,6 +255,59 @@ def test_cost_weighted_split_is_bitwise_and_reports_its_balance(tmp_path, nranks
         assert np.array_equal(a[key], b[key]), key
 
 
+# ---- the conduction problem's `conductive` user condition on coarse buffers (pgen/conduction.hpp:125-255) --------
+COND_SMR_OV = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8",
+               "parthenon/mesh/x2min=-0.25", "parthenon/mesh/x2max=0.25", "gravity/uniform/gx1=-0.02",
+               "parthenon/time/nlim=8"] + region_overrides(1, (0.2, -0.25, -0.5), (0.4, 0.0, 0.5))
+
+
+def conduction_smr_oracle():
+    """inputs/diffusion/conduction.in in 2-D with a refined region AT the inner conductive boundary: the fine blocks
+    there have coarser neighbours along x2 and x1, so their coarse buffers carry the conductive condition before the
+    prolongation reads them."""
+    m = MultiLevelOracle((32, 16, 1), (8, 8, 1), (0.2, -0.25, -0.5), (1.2, 0.25, 0.5),
+                         ("conductive", "conductive") + ("periodic",) * 4, regions=[(1, (0.2, 0.4), (-0.25, 0.0), (-0.5, 0.5))],
+                         ng=2, integrator="rk2", reconstruct="plm", riemann="hllc", gamma=1.66667, dfloor=1e-10,
+                         siefloor=1e-15, cfl=0.3)
+    m.diffusion = m.gravity = m.drag = True
+    for o in m.blocks + m.coarse:
+        o.set_gravity_uniform(-0.02, 0.0, 0.0)
+        o.set_conductivity("conductivity", cond=0.1)
+        o.set_drag("self", "constant")
+        o.set_damping(0, inner=(4.0, -1.7976931348623157e308, -1.7976931348623157e308), inner_rate=(1.0e4, 0.0, 0.0))
+        o.pgen_conduction(gas_rho=1.0, gas_temp=0.05, flux=0.01, post_init=False)
+    m.post_init()
+    m.evolve(40.0, 8)
+    return m
+
+
+def test_conductive_condition_on_coarse_buffers_equals_multilevel_oracle_cpu(tmp_path):
+    res = _run_workers(1, dict(deck=["diffusion", "conduction.in"], overrides=COND_SMR_OV), tmp_path, "cond")[0]
+    m = conduction_smr_oracle()
+    assert res["meta"]["nblocks"] == len(m.blocks) and set(res["meta"]["levels"]) == {0, 1}
+    assert res["meta"]["ncycle"] == m.ncycle == 8 and res["meta"]["dt"] == m.dt and res["meta"]["time"] == m.time
+    for b, (bounds, prim) in enumerate(res["blocks"]):
+        blk = m.blocks[b]
+        assert list(bounds) == m.block_bounds(b)
+        assert np.array_equal(prim, blk.interior(blk.gprim)), b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["fused", "unfused"])
+def test_conductive_condition_on_coarse_buffers_equals_multilevel_oracle(hiplib, path):
+    from artemis_amd.driver import Simulation
+    s = Simulation(DECK("diffusion", "conduction.in"), COND_SMR_OV)
+    s.set_path(path)
+    s.evolve()
+    m = conduction_smr_oracle()
+    assert s.nblocks == len(m.blocks) and s.ncycle == m.ncycle == 8 and s.dt == m.dt and s.time == m.time
+    for b, blk in enumerate(m.blocks):
+        assert s.block_bounds(b) == m.block_bounds(b) and s.block_level(b) == m.leaves[b][0]
+        got = s.field("gas.prim", b)
+        assert np.array_equal(got[[0, 1, 2, 3, 5]], blk.gprim[[0, 1, 2, 3, 5]]), b  # ghost zones included
+    s.close()
+
+
 # ---- the HIP path ----------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", ["fused", "unfused"])
