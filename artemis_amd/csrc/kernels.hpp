@@ -49,6 +49,24 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
                              hipStream_t s);
 // kernels_curv.hip
 bool curv_march_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas);
+// Chunks of an x3 march (kernels_curv.hip, the viscous source): a launch proceeds in rounds of `slots` resident
+// workgroups and a half-empty last round costs a full one; every chunk pays `prime` priming trips (in units of a full
+// trip: measured, a priming trip of the stage march costs about half a trip).  The number of chunks
+// (each of at most cmax planes) with the best product of round fill and march efficiency; ties go to fewer chunks.
+inline int pick_march_chunks(int planes, long tiles, long slots, int cmax, double prime) {
+  int best = (planes + cmax - 1) / cmax;
+  double score = -1.0;
+  for (int n = (planes + cmax - 1) / cmax; n <= planes && n <= 64; ++n) {
+    const int kc = (planes + n - 1) / n;
+    if (kc < 4 && n > (planes + cmax - 1) / cmax) break;
+    const int nchunk = (planes + kc - 1) / kc;
+    const long wgs = tiles * nchunk;
+    const double fill = static_cast<double>(wgs) / static_cast<double>(((wgs + slots - 1) / slots) * slots);
+    const double sc = fill * kc / static_cast<double>(kc + prime);
+    if (sc > score + 1e-9) score = sc, best = nchunk;
+  }
+  return best;
+}
 bool curv_march_covers_dust(const PackView &P, const artemis_stage_general_args_t &g, int recon_dust, int riemann_dust);
 void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g, int fluid, int recon, int riemann, hipStream_t s);
 // kernels_diffusion.hip

@@ -870,8 +870,8 @@ void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g,
   // chunks along x3 (one priming trip each): long ones, but enough workgroups for the chip's 512 slots
   int kch = CKMAX;
   if (const char *e = getenv("ARTEMIS_CURV_KCHUNK")) kch = std::min(CKMAX, std::max(1, atoi(e)));
-  else
-    while (kch > 8 && tiles * ((nz + kch - 1) / kch) < 512) kch >>= 1;
+  else if (P.ndim > 2) // full rounds of the 512 slots (two workgroups per CU) x few priming trips: kernels.hpp
+    kch = (nz + pick_march_chunks(nz, tiles, 512, CKMAX, 0.5) - 1) / pick_march_chunks(nz, tiles, 512, CKMAX, 0.5);
   k.nchunk = (P.ndim > 2) ? (nz + kch - 1) / kch : 1;
   k.kchunk = (nz + k.nchunk - 1) / k.nchunk;
   k.nchunk = (P.ndim > 2) ? (nz + k.kchunk - 1) / k.kchunk : 1;

@@ -1152,8 +1152,10 @@ void launch_viscous_source(const PackView &P, const artemis_diffusion_t &D, doub
   const long tiles = static_cast<long>(a.nti) * a.ntj * P.nb;
   int kch = 32;
   if (const char *e = getenv("ARTEMIS_VISC_KCHUNK")) kch = std::max(1, atoi(e));
-  else
-    while (kch > 8 && tiles * ((nz + kch - 1) / kch) < 512) kch >>= 1; // (512 = the slots of the chip at two workgroups per CU)
+  else { // full rounds of the chip's 512 slots (two workgroups per CU), two priming trips per chunk: kernels.hpp
+    const int n = pick_march_chunks(nz, tiles, 512, 64, 1.0);
+    kch = (nz + n - 1) / n;
+  }
   a.nchunk = (nz + kch - 1) / kch, a.kchunk = (nz + a.nchunk - 1) / a.nchunk;
   a.nchunk = (nz + a.kchunk - 1) / a.kchunk;
   const dim3 grid(static_cast<unsigned>(tiles * a.nchunk)), block(256);
