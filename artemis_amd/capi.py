@@ -73,7 +73,7 @@ class StageArgs(C.Structure):
         ("shell_done", C.c_void_p), ("shell_target", C.POINTER(C.c_uint)),
         ("beta_dt_dev", C.c_void_p), ("shell_faces", C.c_int),
         ("tiny_in", C.c_void_p), ("tiny_out", C.c_void_p), ("tiny_clear", C.c_void_p),
-        ("outflow_faces", C.c_int),
+        ("outflow_faces", C.c_int), ("redo_scratch", C.c_void_p),
     ]
 
 
@@ -207,6 +207,7 @@ def load():
         "artemis_hip_rotating_frame_force": (i, [PPk, d, d, d, d, vp]),
         "artemis_hip_nbody_gravity": (i, [PPk, C.POINTER(NBodyParticle), i, d, d, d, C.POINTER(d), vp]),
         "artemis_hip_nbody_force_scratch": (i, [PPk]),
+        "artemis_hip_redo_scratch_bytes": (C.c_size_t, [PPk]),
         "artemis_hip_timestep_all": (i, [PPk, d, d, C.POINTER(Diffusion), vp, vp]),
         "artemis_hip_nbody_force_sums": (i, [PPk, vp, i, d, d, vp, vp, vp, vp]),
         "artemis_hip_drag_source": (i, [PPk, C.POINTER(Drag), d, d, vp]),
@@ -292,7 +293,7 @@ EXPORTS_HIP = [
     "artemis_hip_deep_copy_conserved", "artemis_hip_estimate_dt", "artemis_hip_estimate_dt_async",
     "artemis_hip_apply_bc", "artemis_hip_stage_fused", "artemis_hip_stage_fused_redo_shell", "artemis_hip_metric_count",
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_nbody_gravity", "artemis_hip_nbody_force_scratch",
-    "artemis_hip_nbody_force_sums", "artemis_hip_timestep_all", "artemis_hip_rotating_frame_force",
+    "artemis_hip_nbody_force_sums", "artemis_hip_timestep_all", "artemis_hip_redo_scratch_bytes", "artemis_hip_rotating_frame_force",
     "artemis_hip_ml_exchange", "artemis_hip_ml_flux_correction", "artemis_hip_ml_restrict_halos", "artemis_hip_ml_prolongate",
     "artemis_hip_ml_face_fluxes", "artemis_hip_ml_stage_fixup", "artemis_hip_plm_table_count", "artemis_hip_plm_table_fill",
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",

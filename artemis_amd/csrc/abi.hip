@@ -675,6 +675,11 @@ int artemis_hip_ml_stage_fixup(const artemis_pack_t *p, const artemis_stage_gene
   return after_launch("ml_stage_fixup");
 }
 
+size_t artemis_hip_redo_scratch_bytes(const artemis_pack_t *p) {
+  if (!p) return 0;
+  const size_t zones = static_cast<size_t>(p->nblocks) * p->nx1 * p->nx2 * p->nx3;
+  return 64 + 2 * zones * sizeof(unsigned long long);
+}
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream) {
   if (int rc = validate(p)) return rc;
   if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");

@@ -293,13 +293,18 @@ struct artemis_sim_impl {
   std::vector<double> particle_force; // [npart][7]
   // the one-kernel stages take the particles from the device and leave the seven sums per particle in device
   // accumulators (artemis_hip_nbody_force_sums): no synchronisation inside the stage loop
-  DevBuf nb_dev, nb_force_dev, nb_scratch, amr_maxima;
+  DevBuf nb_dev, nb_force_dev, nb_scratch, amr_maxima, redo_scratch;
   std::vector<artemis_nbody_particle_t> nb_uploaded;
   bool nbody_in_stage = false; // N-body gravity can run inside artemis_hip_stage_general's kernels
   // refined meshes: the cost model of the Z-order split (see build_mesh_multilevel) and what it achieved
   std::vector<double> lb_level_cost;
   double lb_flux_face_cost = 0.0, lb_max_over_mean = 1.0;
   void nbody_stage_args(const artemis_pack_t &p, artemis_stage_general_args_t &a, Real bdt);
+  void ensure_redo_scratch() { // the tuned kernel's detect-and-redo lists of THIS state (artemis_stage_args_t.redo_scratch)
+    if (redo_scratch.p) return;
+    const artemis_pack_t p = make_pack(base);
+    redo_scratch.alloc((artemis_hip_redo_scratch_bytes(&p) + sizeof(double) - 1) / sizeof(double));
+  }
   void flush_nbody_force();
   Real rf_omega = 0.0, rf_qshear = 0.0;
   artemis_drag_t drag;
@@ -2665,6 +2670,7 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
   }
   for (int q = 1; q < 3; ++q)
     if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
+  ensure_redo_scratch();
   const int A = base;
   int cur = A;
   if (want_dt && !device_dt) {
@@ -2685,6 +2691,7 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
     a.pcm = (stage == 1 && integrator == "vl2"); // artemis_driver.cpp:182
     a.prim_in = gprim[cur].tab(), a.prim_u1 = gprim[A].tab(), a.prim_out = gprim[out].tab();
     a.cons_out = ((dropin == 1 && last) || dropin == 2) ? gu0.tab() : nullptr;
+    a.redo_scratch = redo_scratch.p; // (this state's own detect-and-redo lists: several states may be in flight on one thread)
     a.cfl = cfl_gas;
     a.dt_dev = (last && want_dt) ? (device_dt ? tstate.p + 2 : dt_dev.p) : nullptr;
     if (device_dt) a.beta_dt_dev = tstate.p + 3 + (stage - 1); // beta*dt stays on the device
@@ -2877,6 +2884,8 @@ void artemis_sim_impl::step_ml_fused() {
       t.gam0 = a.gam0, t.gam1 = a.gam1, t.beta_dt = a.beta_dt, t.bdt = a.bdt, t.pcm = a.pcm;
       t.prim_in = a.gas_in, t.prim_u1 = a.gas_u1, t.prim_out = a.gas_out;
       t.cfl = cfl_gas;
+      ensure_redo_scratch();
+      t.redo_scratch = redo_scratch.p;
       CK(artemis_hip_stage_fused(&p, &t, stream), "stage_fused");
     } else {
       general_variant = artemis_hip_stage_general_variant(&p, &a);

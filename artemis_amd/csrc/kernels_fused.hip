@@ -1325,6 +1325,21 @@ bool ensure_redo(size_t zones) {
   g_redo.cap = zones;
   return true;
 }
+size_t pack_zones(const PackView &P) {
+  return static_cast<size_t>(P.nb) * (P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1);
+}
+// the lists of this call: the caller's scratch ([16 unsigned | list 0 | list 1], artemis_hip_redo_scratch_bytes) or
+// the calling thread's own
+RedoBufs redo_bufs_of(const PackView &P, const artemis_stage_args_t &a) {
+  if (!a.redo_scratch) return g_redo;
+  RedoBufs B;
+  const size_t zones = pack_zones(P);
+  B.cnt = static_cast<unsigned *>(a.redo_scratch);
+  B.list[0] = reinterpret_cast<unsigned long long *>(static_cast<char *>(a.redo_scratch) + 64);
+  B.list[1] = B.list[0] + zones;
+  B.cap = zones;
+  return B;
+}
 template <int RIEMANN, int RECON>
 void launch_redo_cfg(const PackView &P, const RedoK &r, hipStream_t s) {
   // (an empty pass costs by its grid: 5.5 us at 128 workgroups, every stage; the lists are short when they are not empty)
@@ -1338,8 +1353,9 @@ void launch_redo(const PackView &P, const artemis_stage_args_t &a, int riemann, 
   r.dt_bits = reinterpret_cast<unsigned long long *>(a.dt_dev);
   r.tiny_out = a.tiny_out, r.tiny_clear = (which == 0) ? a.tiny_clear : nullptr;
   r.outflow = a.outflow_faces & 63;
-  r.cnt = g_redo.cnt + which, r.done = g_redo.cnt + 2 + which, r.cap = static_cast<unsigned>(std::min<size_t>(g_redo.cap, 0xffffffffu));
-  r.list = g_redo.list[which];
+  const RedoBufs B = redo_bufs_of(P, a);
+  r.cnt = B.cnt + which, r.done = B.cnt + 2 + which, r.cap = static_cast<unsigned>(std::min<size_t>(B.cap, 0xffffffffu));
+  r.list = B.list[which];
   r.has_u1 = (a.prim_u1 != a.prim_in) ? 1 : 0;
 #define RC(RS)                                                                             \
   case RS:                                                                                 \
@@ -1357,7 +1373,7 @@ void launch_redo(const PackView &P, const artemis_stage_args_t &a, int riemann, 
 // The shell list of the calling thread's last shell-first launch (artemis_stage_args_t.shell_done), on the stream
 // that has waited for the shell counter.
 int launch_stage_fused_redo_shell(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon, hipStream_t s) {
-  if (!redo_enabled() || !g_redo.cnt) return 0;
+  if (!redo_enabled() || (!a.redo_scratch && !g_redo.cnt)) return 0;
   launch_redo(P, a, riemann, recon, 1, s);
   return 0;
 }
@@ -1451,11 +1467,11 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   k.outflow = a.outflow_faces & 63;
   const bool redo = redo_enabled();
   if (redo) {
-    const size_t zones = static_cast<size_t>(P.nb) * (P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1);
-    if (!ensure_redo(zones)) return 5;
-    k.redo_cnt0 = g_redo.cnt, k.redo_cnt1 = g_redo.cnt + 1;
-    k.redo_list0 = g_redo.list[0], k.redo_list1 = g_redo.list[1];
-    k.redo_cap = static_cast<unsigned>(std::min<size_t>(g_redo.cap, 0xffffffffu));
+    if (!a.redo_scratch && !ensure_redo(pack_zones(P))) return 5;
+    const RedoBufs B = redo_bufs_of(P, a);
+    k.redo_cnt0 = B.cnt, k.redo_cnt1 = B.cnt + 1;
+    k.redo_list0 = B.list[0], k.redo_list1 = B.list[1];
+    k.redo_cap = static_cast<unsigned>(std::min<size_t>(B.cap, 0xffffffffu));
   }
   // XCD-aware id remap of the bulk workgroups: no effect on the run time (the kernel is VALU-bound) but
   // it removes the halo / straddled-line re-reads between XCDs from the HBM traffic (profiles/r02*pmc*)

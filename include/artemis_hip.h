@@ -68,6 +68,7 @@
 #ifndef ARTEMIS_HIP_H_
 #define ARTEMIS_HIP_H_
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -433,7 +434,17 @@ typedef struct artemis_stage_args {
    * third of the boundary shell and most of its cost --, or no artemis_hip_apply_bc call at all when every physical
    * face of the pack is covered) as long as it fills them before anything else reads the state.  0 = read the ghosts. */
   int outflow_faces;
+  /* Optional DEVICE scratch for the detect-and-redo lists (zones next to vanishing velocities, deferred to the exact
+   * kernel), artemis_hip_redo_scratch_bytes(p) bytes, zeroed once by the caller.  NULL = the library's own buffers, one
+   * set per calling THREAD (allocated on first use, grown with a device synchronisation): fine for one state and one
+   * compute stream per thread.  A caller with several states or streams in flight on one thread passes one scratch
+   * per state -- two launches must not share lists -- and the same scratch to artemis_hip_stage_fused_redo_shell.  The
+   * lists have room for every active zone of the pack, so they cannot overflow as long as each launch's list is
+   * drained (the call enqueues the draining kernel itself; the shell list of a shell_done launch is drained by
+   * artemis_hip_stage_fused_redo_shell). */
+  void *redo_scratch;
 } artemis_stage_args_t;
+size_t artemis_hip_redo_scratch_bytes(const artemis_pack_t *p);
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
 int artemis_hip_stage_fused_redo_shell(const artemis_pack_t *p, const artemis_stage_args_t *a, void *stream);
 /* ---- gas diffusion (viscosity, heat conduction) ------------------------------------------

@@ -421,6 +421,7 @@ int artemis_hip_drag_source(const artemis_pack_t *p, const artemis_drag_t *d, do
 
 // The fused-stage CONTRACT restated with the unfused oracle chain: u0 := PrimToCons(prim_in),
 // u1 := PrimToCons(prim_u1), then the reference's task order; prim_out receives the interior.
+size_t artemis_hip_redo_scratch_bytes(const artemis_pack_t *) { return 64; }
 int artemis_hip_stage_fused_redo_shell(const artemis_pack_t *, const artemis_stage_args_t *, void *) { return 0; } // (the double is exact everywhere)
 int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t *a, void *) {
   if (p->gas.nspecies != 1 || p->dust.nspecies != 0) {
