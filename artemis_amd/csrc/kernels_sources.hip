@@ -278,8 +278,9 @@ __global__ __launch_bounds__(256) void nbody_gravity_one_kernel(const PackView P
     for (int q = 0; q < NB_CHUNK; ++q)
 #pragma unroll
       for (int m = 0; m < 7; ++m) lf[q][m] = 0.0;
-    bool any = false;
-    for (int q = 0; q < nloc; ++q) any = any || spl[q].couple;
+    bool any = false, any_acc = false; // (any_acc: some coupled particle of the chunk accretes -- velocities are needed)
+    for (int q = 0; q < nloc; ++q) any = any || spl[q].couple, any_acc = any_acc || (spl[q].couple && spl[q].racc > 0.0);
+    const int nprim = (APPLY || any_acc) ? 4 : 1; // (workgroup-uniform: the sums of non-accreting particles read densities only)
     for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; any && t < total; t += gridDim.x * blockDim.x) {
       const unsigned b = t / per_block, r = t - b * per_block;
       const unsigned row = r / nx1;
@@ -289,7 +290,8 @@ __global__ __launch_bounds__(256) void nbody_gravity_one_kernel(const PackView P
       double wg[4] = {0, 0, 0, 0}, ug[6] = {0, 0, 0, 0, 0, 0}, wd[4] = {0, 0, 0, 0}, ud[4] = {0, 0, 0, 0};
       if constexpr (GAS) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) wg[m] = P.gas.prim[b * 6 + m][c];
+        for (int m = 0; m < 4; ++m)
+          if (m < nprim) wg[m] = P.gas.prim[b * 6 + m][c];
         if constexpr (APPLY) {
 #pragma unroll
           for (int m = 0; m < 6; ++m) ug[m] = P.gas.cons0[b * 6 + m][c];
@@ -297,7 +299,8 @@ __global__ __launch_bounds__(256) void nbody_gravity_one_kernel(const PackView P
       }
       if constexpr (DUST) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) wd[m] = P.dust.prim[b * 4 + m][c];
+        for (int m = 0; m < 4; ++m)
+          if (m < nprim) wd[m] = P.dust.prim[b * 4 + m][c];
         if constexpr (APPLY) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) ud[m] = P.dust.cons0[b * 4 + m][c];

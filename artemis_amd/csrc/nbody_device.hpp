@@ -138,7 +138,9 @@ ADEV void nb_fluid(const artemis_nbody_particle_t &pl, const NbZone &z, const Nb
   const double dens = w[0];
   double dm = 0.0, dmom[3] = {0.0, 0.0, 0.0}, dek = 0.0;
   const double dei = 0.0;
-  nb_accrete(pl, z.fr.x, dens, vcart, z.vf, dt, dm, dmom, dek);
+  // (the sums alone: a particle without an accretion radius leaves dm and dmom at exactly zero -- particle_base.hpp:213,
+  //  `acc` is false -- and the kinetic-energy term is not part of the sums)
+  if (APPLY || pl.racc > 0.0) nb_accrete(pl, z.fr.x, dens, vcart, z.vf, dt, dm, dmom, dek);
   if constexpr (APPLY) {
     const Frame &fr = z.fr;
     const double dmx1 = dmom[0] * fr.e1[0] + dmom[1] * fr.e1[1] + dmom[2] * fr.e1[2];
