@@ -278,6 +278,7 @@ def main():
                     help="diagnostic: cut each rank's 256^3 into this many mesh blocks along x3")
     ap.add_argument("--loopback", action="store_true",
                     help="diagnostic: route block-to-block slabs of ONE GPU through RCCL send/recv-to-self")
+    ap.add_argument("--no-remesh-leg", action="store_true", help="disk_amr: skip the forced-remesh measurement after the timed region")
     ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "ssheet_dust", "disk_sph", "disk_sph_smr", "disk_amr"],
                     help="sedov3d = the headline metric (BASELINE configs[1]); ssheet_dust = SURVEY config 3 "
                          "(2-D dusty shearing sheet with drag, general fused stage; --n is the mesh edge, 1 GPU); "
@@ -486,7 +487,7 @@ def main():
         elapsed = elapsed_max = float(t.item())
         elapsed_min = float(tmin.item())
     remesh_leg = None
-    if args.workload == "disk_amr":
+    if args.workload == "disk_amr" and not args.no_remesh_leg:
         # The remesh machinery on THIS mesh, outside the timed region: five leaves below the finest level, spread over
         # the Z-ordered list, are split one after the other as if the criterion had tagged them (2:1 balance, new
         # state, hand-over, tables), one cycle in between.  The disk is in equilibrium, so the deck's own criterion
@@ -660,8 +661,11 @@ def main():
             bps = ALG_BYTES_PER_CELL_STAGE if smr else 8.0 * 5.0 * (6 + 4)  # 8 B * 5 * (6 ns_gas + 4 ns_dust)
             stage_ms = 1.0e3 * elapsed / args.steps / 2.0
             alg = bps * (total_zones if smr else zone_cycles / args.steps)
+            # measured HBM bytes per stage over EVERY kernel of the run (scripts/pmc_traffic.py --workload ...; hash-matched)
+            traffic, traffic_src = measured_traffic(args.workload + "_") if fused else (None, None)
             out["roofline"] = {"bound": "hbm", "achieved": alg / (stage_ms * 1.0e-3) / 1.0e9, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": alg / (stage_ms * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": alg / (stage_ms * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_source": traffic_src,
                                "kernel": "whole stage (stage kernels, diffusion fluxes, flux correction, block-graph exchange, "
                                          "conditions; per cycle also the timestep%s)" % ("" if smr else ", tagging and remeshes"),
                                "launch_ms": stage_ms, "launches_timed": 2 * args.steps, "algorithmic_bytes_per_launch": alg}

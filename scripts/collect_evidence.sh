@@ -2,7 +2,7 @@
 tag=${1:-r04z}
 cd /root/repo
 g=gpurun_out
-for f in pmc_traffic disk_sph_pmc_traffic cfg3_pmc_traffic pmc_sq disk_sph_pmc_sq; do cp $g/${tag}_$f.json profiles/r04_$f.json; done
+for f in pmc_traffic disk_sph_pmc_traffic cfg3_pmc_traffic disk_sph_smr_pmc_traffic disk_amr_pmc_traffic pmc_sq disk_sph_pmc_sq; do cp $g/${tag}_$f.json profiles/r04_$f.json; done
 for f in bench_line cfg3_line cfg3_1024_line cfg3_1024_2dust_line disk_sph_line disk_sph_smr_line disk_amr_line; do cp $g/${tag}_$f.json profiles/r04_$f.json; done
 for f in bench cfg3 cfg3_1024 disk_sph smr_cart smr_sph amr; do cp $g/${tag}_${f}_kernel_stats.csv profiles/r04_${f}_kernel_stats.csv; done
 {
@@ -16,7 +16,7 @@ for f in bench cfg3 cfg3_1024 disk_sph smr_cart smr_sph amr; do cp $g/${tag}_${f
 python - <<'PY'
 import json
 from bench import kernel_source_sha1
-for f, scope in (("pmc_traffic", "fused"), ("disk_sph_pmc_traffic", "all"), ("cfg3_pmc_traffic", "all")):
+for f, scope in (("pmc_traffic", "fused"), ("disk_sph_pmc_traffic", "all"), ("cfg3_pmc_traffic", "all"), ("disk_sph_smr_pmc_traffic", "all"), ("disk_amr_pmc_traffic", "all")):
     rec = json.load(open("profiles/r04_%s.json" % f))
     print(f, "sha matches working tree:", rec["kernel_source_sha1"] == kernel_source_sha1(scope), round(rec["hbm_bytes_per_launch"] / 1e9, 3), "GB")
 PY

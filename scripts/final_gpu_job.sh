@@ -9,6 +9,9 @@ timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | 
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag}
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust
+timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph_smr
+timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_amr
+cp gpurun_out/${tag}_disk_sph_smr_pmc_traffic.json profiles/r04_disk_sph_smr_pmc_traffic.json; cp gpurun_out/${tag}_disk_amr_pmc_traffic.json profiles/r04_disk_amr_pmc_traffic.json
 # (on the box: the bench lines below quote the records just measured; scripts/collect_evidence.sh copies them locally)
 PMC_SQ_GROUPS=0,1 PMC_SQ_RECORD=${tag} timeout 600 python3 scripts/pmc_sq.py ${tag} -- bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-dropin > gpurun_out/${tag}_pmc_sq.txt 2>&1
 PMC_SQ_GROUPS=0,1 PMC_SQ_KERNELS=stage_curv,viscous_source timeout 600 python3 scripts/pmc_sq.py ${tag}_disk_sph -- bench.py --workload disk_sph --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_disk_sph_pmc_sq.txt 2>&1

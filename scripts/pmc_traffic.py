@@ -59,8 +59,10 @@ def whole_stage(args, extra):
     known byte count)."""
     from bench import kernel_source_sha1
     steps = 6
-    n = {"disk_sph": 256, "ssheet_dust": 4096}[args.workload]
-    bench_args = ["--workload", args.workload, "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--n", str(n)] + extra
+    n = {"disk_sph": 256, "ssheet_dust": 4096}.get(args.workload)
+    bench_args = ["--workload", args.workload, "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline"] + (["--n", str(n)] if n else []) + extra
+    if args.workload == "disk_amr":  # (stages only: the forced-remesh measurement that follows the timed region is left out;
+        bench_args.append("--no-remesh-leg")  #  the kernels of the initial refinement loop stay in: a few % of the total)
     scratch = os.path.join(ROOT, "gpurun_out", "pmc_%s" % args.tag)
     fetch = run_pass("FETCH_SIZE", scratch + "_fetch", bench_args)
     write = run_pass("WRITE_SIZE", scratch + "_write", bench_args)
@@ -82,8 +84,13 @@ def whole_stage(args, extra):
         total += b
     # every launch of the run (initialisation, warm-up and timed cycles alike) is in the profile: normalise by the
     # launches of the stage kernel, which runs once per stage
-    stage_names = [k for k in fetch if ("stage_fused_kernel" in k or "stage2d_kernel" in k or "stage_cell_kernel" in k or
-                                        "stage_curv_kernel" in k)]
+    # one stage = one launch of the GAS stage kernel over the whole pack (the dust march is the instantiation whose last
+    # template argument is true; the refined meshes' fix-up instantiations of stage_cell_kernel end in `true>` as well)
+    stage_names = [k for k in fetch if ("stage_fused_kernel" in k or "stage2d_kernel" in k or
+                                        ("stage_cell_kernel<0" in k and "true>(" not in k) or
+                                        ("stage_curv_kernel" in k and "false>(" in k))]
+    if any("stage_curv_kernel" in k for k in stage_names):  # (a curvilinear pack: its stages are the march's launches)
+        stage_names = [k for k in stage_names if "stage_curv_kernel" in k]
     nstage = sum(fetch[k][1] for k in stage_names)
     assert nstage, "no stage kernel in the profile"
     per_stage = total / nstage
@@ -96,7 +103,7 @@ def whole_stage(args, extra):
         "fetch_correction": "true_read = FETCH_SIZE / %.4f (calibration of %s)" % (ratio, src),
         "stages": nstage, "kernels": kernels, "hbm_bytes_per_launch": per_stage,
     }
-    out = args.out or os.path.join(ROOT, "gpurun_out", "%s_%s_pmc_traffic.json" % (args.tag, {"disk_sph": "disk_sph", "ssheet_dust": "cfg3"}[args.workload]))
+    out = args.out or os.path.join(ROOT, "gpurun_out", "%s_%s_pmc_traffic.json" % (args.tag, {"ssheet_dust": "cfg3"}.get(args.workload, args.workload)))
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps({"hbm_bytes_per_stage": per_stage, "stages": nstage, "out": out}))
 
@@ -106,7 +113,7 @@ def main():
     ap.add_argument("--tag", default="r02")
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "disk_sph", "ssheet_dust"])
+    ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "disk_sph", "ssheet_dust", "disk_sph_smr", "disk_amr"])
     args, extra = ap.parse_known_args()
     from bench import ALG_BYTES_PER_CELL_STAGE, kernel_source_sha1
     if args.workload != "sedov3d":
