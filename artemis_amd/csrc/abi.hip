@@ -1141,11 +1141,15 @@ void pool_trim_locked(size_t keep) { // least recently freed first (what earlier
 void *artemis_rt_malloc(size_t bytes) {
   if (device_ready()) return nullptr;
   void *p = nullptr;
-  const size_t cap = pool_on() ? size_class(bytes ? bytes : 8) : (bytes ? bytes : 8);
+  // a cached buffer serves if it fits (up to a quarter larger); a fresh one gets 3 % of headroom before its size class is
+  // taken, so that a mesh that keeps growing by a few blocks per remesh does not cross a class boundary -- a fresh
+  // hipMalloc of GBs -- right after the buffers were made
+  const size_t need = pool_on() ? size_class(bytes ? bytes : 8) : (bytes ? bytes : 8);
+  const size_t cap = pool_on() ? size_class((bytes ? bytes : 8) + bytes / 32) : need;
   if (pool_on()) {
     std::lock_guard<std::mutex> lk(g_bytes_mu);
-    auto it = g_pool.lower_bound(cap);
-    if (it != g_pool.end() && it->first <= cap + cap / 8) {
+    auto it = g_pool.lower_bound(need);
+    if (it != g_pool.end() && it->first <= need + need / 4) {
       p = it->second.p;
       g_pool_bytes -= it->first;
       g_bytes_of[p] = it->first;
