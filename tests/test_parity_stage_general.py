@@ -67,6 +67,13 @@ CASES = [
     ((45, 12, 1), (0.2, -1.0, -0.5), (2.0, 1.0, 0.5), 1, 0, "plm", "hllc", "hlle", "axisymmetric", 2),
     ((45, 12, 1), (0.5, 0.0, -0.5), (2.0, 6.0, 0.5), 1, 0, "pcm", "hlle", "hlle", "cylindrical", 2),
     ((77, 1, 1), (0.1, 0.0, -0.5), (1.0, np.pi, 0.5), 1, 0, "plm", "hlle", "hlle", "spherical", 2),
+    # one gas + ONE dust species on a curvilinear mesh: the dust species on the same march (DUST instantiations of
+    # stage_curv_kernel: HLLE and LLF, PCM and PLM, 3-D with several x3 chunks and ragged tiles, 2-D, 1-D)
+    ((35, 18, 20), (0.5, 0.0, -1.0), (2.0, 6.0, 1.0), 1, 1, "plm", "llf", "llf", "cylindrical", 2),
+    ((34, 12, 20), (0.3, 0.7, 0.0), (1.7, 2.5, 6.0), 1, 1, "pcm", "hlle", "hlle", "spherical", 2),
+    ((40, 19, 21), (0.3, 0.7, 0.0), (1.7, 2.5, 6.0), 1, 1, "plm", "hllc", "hlle", "spherical", 2),
+    ((45, 12, 1), (0.5, 0.0, -0.5), (2.0, 6.0, 0.5), 1, 1, "plm", "hlle", "llf", "cylindrical", 2),
+    ((77, 1, 1), (0.1, 0.0, -0.5), (1.0, np.pi, 0.5), 1, 1, "plm", "hlle", "hlle", "spherical", 2),
 ]
 CURV_TILE_CASES = range(15, 22)
 
@@ -96,7 +103,7 @@ def test_general_stage_hydro(hiplib, nx, lo, hi, nsg, nsd, recon, riem, driem, c
     dt = 1.0e-4
     oracle_stage(o, g0, g1, be, dt, False, 0.0, False, False, False)
     mb.stage_general(g0, g1, be * dt, be * dt, gas=(gin, gu1, gout), dust=(din, du1, dout))
-    if coords != "cartesian" and nsg == 1 and nsd == 0 and recon != "ppm":
+    if coords != "cartesian" and nsg == 1 and nsd <= 1 and recon != "ppm":
         assert mb.last_stage_variant == 3  # the curvilinear tile march (kernels_curv.hip) really ran
     I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
     if nsg:
