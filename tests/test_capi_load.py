@@ -138,3 +138,36 @@ def test_metric_tables_are_plain_glibc_sin_cos():
     if not np.array_equal(m, want):
         ulp = np.abs(m - want) / np.spacing(np.maximum(np.abs(want), 1e-300))
         assert False, "metric tables differ from glibc sin / cos by up to %.1f ulp" % ulp.max()
+
+
+@pytest.mark.gpu
+def test_device_buffer_cache_contract():
+    """artemis_rt_malloc / artemis_rt_free (include/artemis_rt.h): a freed buffer comes back for a request of its size
+    class (a remesh frees and re-requests tens of GB whose sizes barely change), a fresh buffer carries headroom so that a
+    slightly larger request right after still fits it, the footprint counts cached buffers, and a trim gives them back."""
+    from artemis_amd import capi
+    L = capi.load()
+    cur, peak = C.c_size_t(), C.c_size_t()
+
+    def footprint():
+        L.artemis_rt_device_bytes(C.byref(cur), C.byref(peak), 0)
+        return cur.value
+
+    L.artemis_rt_pool_trim(0)
+    base = footprint()
+    n = 200 << 20
+    a = L.artemis_rt_malloc(n)
+    assert a and footprint() - base >= n
+    held = footprint()
+    L.artemis_rt_free(a)
+    assert footprint() == held                     # cached, not returned to the device
+    b = L.artemis_rt_malloc(n + (n >> 9))          # 0.2 % larger: the same buffer (3 % of headroom on a fresh allocation)
+    assert b == a and footprint() == held
+    c = L.artemis_rt_malloc(n)                      # a second live buffer is a new allocation
+    assert c and c != b and footprint() > held
+    L.artemis_rt_free(b), L.artemis_rt_free(c)
+    d = L.artemis_rt_malloc(n - (n >> 4))           # 6 % smaller: a cached buffer of up to a quarter more serves
+    assert d in (a, c)
+    L.artemis_rt_free(d)
+    L.artemis_rt_pool_trim(0)
+    assert footprint() == base
