@@ -260,6 +260,7 @@ def load():
         "artemis_rt_free": (None, [vp]),
         "artemis_rt_device_bytes": (None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), i]),
         "artemis_rt_pool_trim": (None, [C.c_size_t]),
+        "artemis_rt_pool_limit": (None, [C.c_size_t]),
         "artemis_rt_malloc_host": (vp, [C.c_size_t]),
         "artemis_rt_free_host": (None, [vp]),
         "artemis_rt_memcpy_h2d": (i, [vp, vp, C.c_size_t, vp]),

@@ -1087,7 +1087,6 @@ int artemis_rt_set_device(int dev) {
 // device bytes handed out through this shim: current and high-water mark (artemis_rt_device_bytes)
 namespace {
 std::mutex g_bytes_mu;
-std::unordered_map<void *, size_t> g_bytes_of;
 size_t g_bytes_now = 0, g_bytes_peak = 0;
 } // namespace
 void artemis_rt_device_bytes(size_t *current, size_t *peak, int reset_peak) {
@@ -1098,16 +1097,24 @@ void artemis_rt_device_bytes(size_t *current, size_t *peak, int reset_peak) {
 }
 // A remesh frees tens of GB and allocates about as much again in buffers whose sizes differ by a fraction of a percent
 // (a handful of blocks more or fewer): through hipFree / hipMalloc that unmaps and re-maps the lot (1.3 - 1.5 s per
-// remesh on the 29 M-zone configs[4] mesh, twenty cycle-times).  Freed buffers are kept instead -- sizes rounded up to
-// 1/16 of their power of two, so that consecutive states land in the same size class -- and handed out again; the
-// cache is trimmed to ARTEMIS_POOL_GB (default 64) and emptied when the device runs out.  ARTEMIS_NO_POOL=1: plain calls.
+// remesh on the 29 M-zone configs[4] mesh, twenty cycle-times).  With the cache enabled (artemis_rt_pool_limit: the
+// standalone driver turns it on for adaptive meshes; a library host such as the Parthenon adapter never pays for it
+// unless it asks) freed buffers are kept instead -- per device, sizes rounded up to 1/16 of their power of two, so that
+// consecutive states land in the same size class -- and handed out again; the cache is trimmed to the limit and
+// emptied when the device runs out.
 namespace {
 struct PoolEntry {
   void *p;
   unsigned long seq; // when it was freed: the cache is trimmed oldest first
+  int dev;           // the device the buffer lives on: only handed out while that device is current
+};
+struct LiveEntry {
+  size_t cap;
+  int dev;
 };
 std::multimap<size_t, PoolEntry> g_pool; // capacity -> free buffer
-size_t g_pool_bytes = 0;
+std::unordered_map<void *, LiveEntry> g_live;
+size_t g_pool_bytes = 0, g_pool_limit = 0; // limit 0: the cache is off (plain hipMalloc / hipFree)
 unsigned long g_pool_seq = 0;
 size_t size_class(size_t bytes) {
   if (bytes < (size_t(1) << 16)) return (bytes + 255) & ~size_t(255);
@@ -1115,17 +1122,6 @@ size_t size_class(size_t bytes) {
   while ((p2 << 1) <= bytes) p2 <<= 1;
   const size_t g = p2 >> 4;
   return (bytes + g - 1) / g * g;
-}
-bool pool_on() {
-  static const bool on = std::getenv("ARTEMIS_NO_POOL") == nullptr;
-  return on;
-}
-size_t pool_limit() {
-  static const size_t lim = [] {
-    const char *e = std::getenv("ARTEMIS_POOL_GB");
-    return static_cast<size_t>((e ? std::atof(e) : 64.0) * 1073741824.0);
-  }();
-  return lim;
 }
 void pool_trim_locked(size_t keep) { // least recently freed first (what earlier, smaller meshes left behind goes first)
   while (g_pool_bytes > keep && !g_pool.empty()) {
@@ -1138,27 +1134,40 @@ void pool_trim_locked(size_t keep) { // least recently freed first (what earlier
   }
 }
 } // namespace
+void artemis_rt_pool_limit(size_t limit_bytes) {
+  std::lock_guard<std::mutex> lk(g_bytes_mu);
+  g_pool_limit = limit_bytes;
+  pool_trim_locked(limit_bytes);
+}
 void *artemis_rt_malloc(size_t bytes) {
   if (device_ready()) return nullptr;
   void *p = nullptr;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  bool pool;
+  {
+    std::lock_guard<std::mutex> lk(g_bytes_mu);
+    pool = g_pool_limit > 0;
+  }
   // a cached buffer serves if it fits (up to a quarter larger); a fresh one gets 3 % of headroom before its size class is
   // taken, so that a mesh that keeps growing by a few blocks per remesh does not cross a class boundary -- a fresh
   // hipMalloc of GBs -- right after the buffers were made
-  const size_t need = pool_on() ? size_class(bytes ? bytes : 8) : (bytes ? bytes : 8);
-  const size_t cap = pool_on() ? size_class((bytes ? bytes : 8) + bytes / 32) : need;
-  if (pool_on()) {
+  const size_t need = pool ? size_class(bytes ? bytes : 8) : (bytes ? bytes : 8);
+  const size_t cap = pool ? size_class((bytes ? bytes : 8) + bytes / 32) : need;
+  if (pool) {
     std::lock_guard<std::mutex> lk(g_bytes_mu);
-    auto it = g_pool.lower_bound(need);
-    if (it != g_pool.end() && it->first <= need + need / 4) {
+    for (auto it = g_pool.lower_bound(need); it != g_pool.end() && it->first <= need + need / 4; ++it) {
+      if (it->second.dev != dev) continue; // (a buffer of another device is not this device's memory)
       p = it->second.p;
       g_pool_bytes -= it->first;
-      g_bytes_of[p] = it->first;
+      g_live[p] = LiveEntry{it->first, dev};
       g_pool.erase(it);
+      break;
     }
   }
   if (!p) {
     hipError_t e = hipMalloc(&p, cap);
-    if (e != hipSuccess && pool_on()) { // out of memory with buffers cached: give them back and try again
+    if (e != hipSuccess) { // out of memory with buffers cached: give them back and try again
       (void)hipGetLastError();
       {
         std::lock_guard<std::mutex> lk(g_bytes_mu);
@@ -1168,7 +1177,7 @@ void *artemis_rt_malloc(size_t bytes) {
     }
     if (check_hip(e, "hipMalloc")) return nullptr;
     std::lock_guard<std::mutex> lk(g_bytes_mu);
-    g_bytes_of[p] = cap;
+    g_live[p] = LiveEntry{cap, dev};
     g_bytes_now += cap; // (the device footprint: live buffers and cached ones, at their capacities)
     if (g_bytes_now > g_bytes_peak) g_bytes_peak = g_bytes_now;
   }
@@ -1183,25 +1192,24 @@ void *artemis_rt_malloc(size_t bytes) {
 }
 void artemis_rt_free(void *p) {
   if (!p) return;
-  size_t cap = 0;
+  LiveEntry le{0, 0};
+  bool pool;
   {
     std::lock_guard<std::mutex> lk(g_bytes_mu);
-    auto it = g_bytes_of.find(p);
-    if (it != g_bytes_of.end()) cap = it->second, g_bytes_of.erase(it);
+    auto it = g_live.find(p);
+    if (it != g_live.end()) le = it->second, g_live.erase(it);
+    pool = g_pool_limit > 0 && le.cap > 0 && le.cap <= g_pool_limit;
+    if (!pool && le.cap) g_bytes_now -= le.cap;
   }
-  if (!pool_on() || cap == 0) {
-    if (cap) {
-      std::lock_guard<std::mutex> lk(g_bytes_mu);
-      g_bytes_now -= cap;
-    }
-    (void)hipFree(p);
+  if (!pool) {
+    (void)hipFree(p); // (synchronises by itself)
     return;
   }
   (void)hipDeviceSynchronize(); // what hipFree guarantees: nothing in flight still uses the buffer
   std::lock_guard<std::mutex> lk(g_bytes_mu);
-  g_pool.emplace(cap, PoolEntry{p, ++g_pool_seq});
-  g_pool_bytes += cap;
-  pool_trim_locked(pool_limit());
+  g_pool.emplace(le.cap, PoolEntry{p, ++g_pool_seq, le.dev});
+  g_pool_bytes += le.cap;
+  pool_trim_locked(g_pool_limit);
 }
 void artemis_rt_pool_trim(size_t keep_bytes) {
   std::lock_guard<std::mutex> lk(g_bytes_mu);

@@ -144,6 +144,7 @@ struct artemis_sim_impl {
   double refine_thr = 0.0, deref_thr = 0.0;
   bool have_forced = false;
   std::vector<artemis_host::Leaf> forced_leaves, tree_leaves; // tree_leaves: the leaves this state was built on
+  std::vector<int> split_rank, split_local; // owner rank / local index of every leaf (global id) under this state's Z-order split
   std::vector<int> amr_tags();                    // AmrTag of every local block (-1 derefine, 0 same, +1 refine)
   void adopt_state_from(artemis_sim_impl &old);   // copy / prolongate / restrict the conserved state, then re-derive
   // A remesh during the run builds the new state with `adopting` set: the problem generator then runs only on the blocks
@@ -947,7 +948,9 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
   // a refined mesh needs the stage's face fluxes for flux correction (artemis_driver.cpp:196-202): per-task chain
   // N-body gravity rides inside the stage kernels (artemis_stage_general_args_t.nbody_dev) for at most one species per
   // fluid; its seven sums per particle come from artemis_hip_nbody_force_sums, accumulated on the device
+  // (artemis_hip_nbody_force_sums keeps one LDS slot set per particle: at most 128; larger sets take the gravity task)
   nbody_in_stage = grav_nbody && ns_gas <= 1 && ns_dust <= 1 && !do_cooling && getenv("ARTEMIS_NBODY_TASK") == nullptr &&
+                   particles.size() <= 128 &&
                    (coords == ARTEMIS_CARTESIAN || coords == ARTEMIS_CYLINDRICAL || coords == ARTEMIS_SPHERICAL3D);
   fused_possible = !(do_cooling && do_drag) && !multilevel && (!grav_nbody || nbody_in_stage);
   tuned = tuned && fused_possible && !(do_viscosity || do_conduction || do_cooling);
@@ -1121,6 +1124,7 @@ void artemis_sim_impl::build_mesh_multilevel() {
     for (double c : per_rank) mx = std::max(mx, c), sum += c;
     lb_max_over_mean = mx / (sum / nranks);
   }
+  split_rank = rank_of, split_local = local_of; // (adopt_state_from: a remesh asks both states who owns a leaf)
   const int g[3] = {ng, ndim > 1 ? ng : 0, ndim > 2 ? ng : 0};
   ni = mbnx[0] + 2 * g[0], nj = mbnx[1] + 2 * g[1], nk = mbnx[2] + 2 * g[2];
   is = g[0], ie = g[0] + mbnx[0] - 1, js = g[1], je = g[1] + mbnx[1] - 1;
@@ -2301,14 +2305,12 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
   CK(artemis_rt_stream_sync(old.stream), "sync");
   typedef std::tuple<int, int, int, int> Key;
   auto key_of = [](const artemis_host::Leaf &l) { return Key(l.level, l.lx[0], l.lx[1], l.lx[2]); };
-  // global ids: leaves are numbered in Z-order and dealt to the ranks in contiguous runs (build_mesh_multilevel)
-  auto owner = [&](long gid, long nglobal, int &local) {
-    const long base_n = nglobal / nranks, extra = nglobal % nranks;
-    const long cut = extra * (base_n + 1);
-    int r;
-    if (gid < cut) r = static_cast<int>(gid / (base_n + 1)), local = static_cast<int>(gid % (base_n + 1));
-    else r = static_cast<int>(extra + (gid - cut) / base_n), local = static_cast<int>((gid - cut) % base_n);
-    return r;
+  // global ids: leaves are numbered in Z-order and dealt to the ranks in contiguous runs (build_mesh_multilevel); the
+  // runs are equal counts or cost-weighted (<artemis_amd/loadbalance>), so each state carries its own split
+  auto owner = [&](const artemis_sim_impl &S, long gid, int &local) {
+    if (gid < 0 || gid >= static_cast<long>(S.split_rank.size())) throw std::runtime_error("adopt_state_from: leaf id outside the state's split");
+    local = S.split_local[gid];
+    return S.split_rank[gid];
   };
   const std::vector<artemis_host::Leaf> &oldL = old.tree_leaves, &newL = tree_leaves;
   std::map<Key, long> where;
@@ -2431,7 +2433,7 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
   std::map<std::pair<long, int>, bool> sent; // (old gid, destination rank): send an old block to a rank once
   for (size_t q = 0; q < deps.size(); ++q) {
     int ol, nl;
-    const int orank = owner(deps[q].og, static_cast<long>(oldL.size()), ol), nrank = owner(deps[q].ng_, static_cast<long>(newL.size()), nl);
+    const int orank = owner(old, deps[q].og, ol), nrank = owner(*this, deps[q].ng_, nl);
     if (orank == nrank) continue;
     const int tag = 9000000 + 2 * static_cast<int>(deps[q].og);
     if (orank == rank) {
@@ -2455,7 +2457,7 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
   std::vector<int> same_local(nb, -1); // new local block -> old local block it is a copy of
   for (const Dep &D : deps) {
     int ol, nl;
-    const int orank = owner(D.og, static_cast<long>(oldL.size()), ol), nrank = owner(D.ng_, static_cast<long>(newL.size()), nl);
+    const int orank = owner(old, D.og, ol), nrank = owner(*this, D.ng_, nl);
     if (nrank != rank) continue;
     const View src = (orank == rank) ? local_view(old, ol) : remote_view(D.og);
     const View dst = local_view(*this, nl);
@@ -3270,6 +3272,9 @@ struct artemis_sim {
   // handing the data over; and how many there were
   double remesh_s = 0.0, remesh_build_s = 0.0, remesh_adopt_s = 0.0, remesh_tag_s = 0.0;
   long remesh_n = 0;
+  // A lean remesh releases the old state's work arrays BEFORE the new state allocates (peak = resident bytes); if the
+  // new state then cannot be built or filled, the old one can no longer step: the handle is dead and says why
+  std::string dead;
 };
 
 // A fresh state for the same deck on a given set of leaves (the problem generator runs on it: tables, `ic` states
@@ -3389,19 +3394,23 @@ static bool remesh(artemis_sim &h, bool initial, long force_refine_gid = -1) {
   if (!changed) return false;
   const auto t_build = std::chrono::steady_clock::now();
   const bool lean = !initial && getenv("ARTEMIS_FULL_REMESH") == nullptr;
-  if (lean) h.p->release_for_adoption();
-  std::unique_ptr<artemis_sim_impl> np = build_state(h, &leaves, lean);
-  np->ml_fused = np->ml_fused_possible && h.p->ml_fused; // (artemis_sim_set_path outlives a remesh)
-  if (!initial) {
-    h.remesh_build_s += since(t_build);
-    const auto t_adopt = std::chrono::steady_clock::now();
-    try {
+  std::unique_ptr<artemis_sim_impl> np;
+  try {
+    if (lean) h.p->release_for_adoption();
+    np = build_state(h, &leaves, lean);
+    np->ml_fused = np->ml_fused_possible && h.p->ml_fused; // (artemis_sim_set_path outlives a remesh)
+    if (!initial) {
+      h.remesh_build_s += since(t_build);
+      const auto t_adopt = std::chrono::steady_clock::now();
       np->adopt_state_from(*h.p);
-    } catch (...) {
-      release_impl(np);
-      throw;
+      h.remesh_adopt_s += since(t_adopt);
     }
-    h.remesh_adopt_s += since(t_adopt);
+  } catch (const std::exception &e) {
+    if (np) release_impl(np);
+    if (lean) // the old state has given up its primitives, fluxes, coarse buffers and tables: it cannot step again
+      h.dead = std::string("remesh failed after the old state released its work arrays (") + e.what() +
+               "); the simulation cannot continue -- ARTEMIS_FULL_REMESH=1 keeps the old state whole at twice the peak memory";
+    throw;
   }
   artemis_rt_device_sync();
   np->reuse_from = nullptr, np->reuse_lookup.clear(); // (the old state goes away)
@@ -3439,6 +3448,11 @@ artemis_sim_t *artemis_sim_create(const char *deck_text, int noverrides,
       s->has_comm = true;
     }
     s->p = build_state(*s, nullptr);
+    if (s->p->adaptive && s->p->refine_field && getenv("ARTEMIS_NO_POOL") == nullptr) {
+      // adaptive meshes re-allocate tens of GB per remesh: artemis_rt's buffer cache (off by default for library hosts)
+      const char *e = getenv("ARTEMIS_POOL_GB");
+      artemis_rt_pool_limit(static_cast<size_t>((e ? atof(e) : 64.0) * 1073741824.0));
+    }
     // Mesh::Initialize's refinement loop (upstream): tag the initial condition, refine, regenerate -- until the mesh
     // stops changing (blocks that 2:1 balance created are tagged one pass later than the ones tags created, so this
     // can take more than numlevel passes; the cap only guards against a criterion that never settles)
@@ -3460,6 +3474,10 @@ void artemis_sim_destroy(artemis_sim_t *sim) {
 }
 long artemis_sim_evolve(artemis_sim_t *sim, long max_cycles) {
   long n = -1;
+  if (!sim->dead.empty()) {
+    g_sim_err = sim->dead;
+    return -1;
+  }
   if (!(sim->p->adaptive && sim->p->refine_field)) {
     GUARD(n = sim->p->evolve(max_cycles), return -1)
     return n;
@@ -3509,6 +3527,10 @@ long artemis_sim_remeshes(const artemis_sim_t *s) { return s->remeshes; }
 double artemis_sim_load_balance(const artemis_sim_t *s) { return s->p->lb_max_over_mean; }
 int artemis_sim_force_refine(artemis_sim_t *s, long gid) {
   int changed = 0;
+  if (!s->dead.empty()) {
+    g_sim_err = s->dead;
+    return -1;
+  }
   GUARD(changed = remesh(*s, false, gid) ? 1 : 0, return -1)
   return changed;
 }

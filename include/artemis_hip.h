@@ -63,7 +63,8 @@
  *    ARTEMIS_STAGE2D_ROWS, ARTEMIS_STAGE2D_RGRID, ARTEMIS_FUSED_NO_SWIZZLE, ARTEMIS_VS_ABL (ablation bits of the
  *    viscous-source march: the results are WRONG with it, timing only)
  *  memory
- *    ARTEMIS_NO_POOL=1, ARTEMIS_POOL_GB=n   artemis_rt's buffer cache (artemis_rt.h)
+ *    ARTEMIS_NO_POOL=1, ARTEMIS_POOL_GB=n   the standalone driver enables artemis_rt's buffer cache for adaptive meshes
+ *                              with this limit (default 64) / not at all; library hosts: artemis_rt_pool_limit (artemis_rt.h)
  * ===================================================================================== */
 #ifndef ARTEMIS_HIP_H_
 #define ARTEMIS_HIP_H_

@@ -21,13 +21,18 @@ extern "C" {
 int artemis_rt_set_device(int dev);
 void *artemis_rt_malloc(size_t bytes);      /* device memory (HBM) */
 void artemis_rt_free(void *p);
-/* artemis_rt_malloc / artemis_rt_free keep freed buffers in size classes (1/16 of a power of two) and hand them out
- * again: a remesh frees and allocates tens of GB in buffers whose sizes barely change, and hipFree + hipMalloc of that
- * costs seconds.  ARTEMIS_POOL_GB (default 64) bounds the cache; it is emptied when the device runs out of memory;
- * ARTEMIS_NO_POOL=1 turns it off.  artemis_rt_free synchronises the device first, as hipFree does.
+/* Optional buffer cache behind artemis_rt_malloc / artemis_rt_free, OFF unless artemis_rt_pool_limit(bytes > 0) was
+ * called (the standalone driver turns it on for adaptive meshes: ARTEMIS_POOL_GB, default 64; a library host -- the
+ * Parthenon adapter -- shares the device with Kokkos' allocator and never pays for it unless it asks).  When on, freed
+ * buffers are kept per device in size classes (1/16 of a power of two) and handed out again to the device they live on: a
+ * remesh frees and allocates tens of GB in buffers whose sizes barely change, and hipFree + hipMalloc of that costs
+ * seconds.  The cache is trimmed to the limit, emptied when hipMalloc runs out of memory, and given back on request
+ * (artemis_rt_pool_trim) -- a host under memory pressure calls artemis_rt_pool_trim(0) or artemis_rt_pool_limit(0).
+ * artemis_rt_free of a cached buffer synchronises the device first, as hipFree does.
  * artemis_rt_device_bytes: the device footprint through artemis_rt_malloc (live and cached buffers at their
  * capacities) and its high-water mark since the start (or since the last call with reset_peak != 0) -- what a remesh,
  * which builds the new mesh next to what it keeps of the old one, costs. */
+void artemis_rt_pool_limit(size_t limit_bytes);
 void artemis_rt_device_bytes(size_t *current, size_t *peak, int reset_peak);
 /* give cached buffers back to the device until at most keep_bytes of them are left (oldest first); the driver calls it
  * with 0 once the initial mesh is built (the smaller meshes of the initial refinement loop leave buffers nobody asks

@@ -637,9 +637,14 @@ inline void StageFusedFillDerived(MeshData<Real> *md) {
 // the per-task list stays): the N-body gravity type (its particle list lives with the NBody package and its
 // back-reaction sums go to the host: see artemis_stage_general_args_t.nbody_dev for a host that keeps the particles
 // on the device), cooling (this header forwards no CoolingSource: artemis_stage_general_args_t.cooling exists for a
-// host that fills artemis_cooling_t), radiation.
+// host that fills artemis_cooling_t), radiation -- and REFINED MESHES (pmesh->multilevel): the one-kernel stages keep
+// no flux arrays, so the block SendBoundBufs<flxcor_send> .. SetFluxCorrections (artemis_driver.cpp:196-202) that this
+// task would replace has nothing to send and conservation at coarse-fine faces would be lost silently.  A refined mesh
+// keeps the per-task list, whose CalculateFluxes forwarders fill Parthenon's flux arrays (or the host wires the
+// face-flux / fix-up sequence of INTEGRATION.md section 3a itself).
 inline bool StageCovered(MeshData<Real> *md) {
   auto pm = md->GetParentPointer();
+  if (pm->multilevel) return false;
   auto &art = pm->packages.Get("artemis");
   auto flag = [&](const char *n) { return art->template Param<bool>(n); }; // (artemis.cpp:73-83 registers every do_* flag)
   if (flag("do_radiation") || flag("do_cooling")) return false;
@@ -677,6 +682,9 @@ inline void EnsureStageBuffers(StageBuffers &sb, const PackCache &c, const int n
 }
 inline TaskStatus Stage(MeshData<Real> *u0, const int stage, const parthenon::LowStorageIntegrator *integ, const bool pcm,
                         const Real time) {
+  PARTHENON_REQUIRE(!u0->GetParentPointer()->multilevel,
+                    "ArtemisHip::Stage stores no flux arrays: a refined mesh keeps the per-task list (StageCovered) so that "
+                    "the flux correction of artemis_driver.cpp:196-202 has fluxes to send");
   if (StageTakesTunedKernel(u0)) return StageFused(u0, stage, integ, pcm);
   auto pm = u0->GetParentPointer();
   auto &art = pm->packages.Get("artemis");

@@ -4,6 +4,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 out=/tmp/prof_$tag
 rm -rf $out
+mkdir -p gpurun_out
 rocprofv3 --kernel-trace --stats -d $out -o p --output-format csv -- python3 "$@" > gpurun_out/${tag}_prof_stdout.log 2>&1
 f=$(find $out -name '*kernel_stats.csv' | head -1)
 cp "$f" gpurun_out/${tag}_kernel_stats.csv

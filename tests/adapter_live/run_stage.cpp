@@ -11,6 +11,7 @@
 //     full  : gas + one dust species, uniform gravity, shearing box, simple_dust drag, constant viscosity
 //     fused : gas through the opt-in StageFused / StageFusedFillDerived forwarders
 //     stage_gas / stage_full : the `gas` / `full` problems through the DEFAULT stage task of INTEGRATION.md section 3
+//     covered_multilevel     : Mesh::multilevel set -> StageCovered must be false and Stage must refuse (exit 0)
 //             (ArtemisHip::StageCovered -> Stage -> boundary conditions -> StageFillDerived: the tuned kernel for gas
 //             alone, artemis_hip_stage_general with the diffusion-flux tasks inside for gas + dust + gravity +
 //             shearing box + drag + viscosity)
@@ -209,6 +210,19 @@ int main(int argc, char **argv) {
   LowStorageIntegrator integ; // rk2
   integ.nstages = 2, integ.dt = dt, integ.gam0 = {0.0, 0.5}, integ.gam1 = {1.0, 0.5}, integ.beta = {1.0, 0.5};
   Real dt_est = 0.0;
+  if (mode == "covered_multilevel") {
+    // a refined mesh: the default wiring must fall back to the per-task list (the one-kernel stages store no flux
+    // arrays for artemis_driver.cpp:196-202's flux correction) and Stage itself must refuse, loudly
+    if (!ArtemisHip::StageCovered(&part[0].u0)) return 10; // (sanity: covered on the uniform mesh)
+    mesh.multilevel = true;
+    if (ArtemisHip::StageCovered(&part[0].u0)) return 8;
+    try {
+      ArtemisHip::Stage(&part[0].u0, 1, &integ, false, 0.0);
+    } catch (const std::exception &e) {
+      return std::string(e.what()).find("per-task list") != std::string::npos ? 0 : 11;
+    }
+    return 9;
+  }
   try {
     for (int q = 0; q < npart; ++q) ArtemisHip::PrimToCons(&part[q].u0); // PostInitialization (main.cpp:43)
     Real time = 0.0;

@@ -1182,6 +1182,7 @@ void artemis_rt_device_bytes(size_t *current, size_t *peak, int) {
 }
 void artemis_rt_free(void *p) { std::free(p); }
 void artemis_rt_pool_trim(size_t) {}
+void artemis_rt_pool_limit(size_t) {}
 void *artemis_rt_malloc_host(size_t n) { return std::calloc(1, n ? n : 8); }
 void artemis_rt_free_host(void *p) { std::free(p); }
 int artemis_rt_memcpy_h2d(void *d, const void *s, size_t n, void *) { std::memcpy(d, s, n); return 0; }

@@ -113,6 +113,7 @@ struct Mesh {
   Packages packages;
   std::shared_ptr<ResolvedPackages> resolved_packages = std::make_shared<ResolvedPackages>();
   int remesh_count = 0;
+  bool multilevel = false; // parthenon::Mesh::multilevel: static or adaptive refinement is on
 };
 // one variable of one block: ncomp cell arrays [nk][nj][ni] (+ flux slots per direction / face copies)
 struct Variable {

@@ -142,3 +142,31 @@ def test_config4_in_three_dimensions_two_ranks_equal_one_rank(tmp_path):
     da, db = by_bounds(one, "dust"), by_bounds(two, "dust")
     for key in da:
         assert np.array_equal(da[key], db[key]), key
+
+
+def test_cost_weighted_split_on_an_adaptive_mesh_equals_one_rank(tmp_path):
+    """<artemis_amd/loadbalance> level_cost / flux_face_cost deal the Z-ordered leaves to the ranks in runs of UNEQUAL
+    block counts.  A run-time remesh asks both the old and the new state who owns a leaf and which local slot it has
+    (adopt_state_from): with the equal-count formula there, blocks would be copied from wrong slots and the migration
+    messages of two ranks would not match (round-4 advisor finding).  Each state now carries its own split: 2 and 3
+    ranks with weighted costs reproduce 1 rank bit for bit across the remeshes of linear_wave_amr, with block counts
+    that differ between the ranks."""
+    from test_multirank_cpu import by_bounds
+    lb = ["artemis_amd/loadbalance/level_cost=1.0,3.0", "artemis_amd/loadbalance/flux_face_cost=0.25"]
+    spec = dict(LINWAVE, overrides=LINWAVE["overrides"] + lb)
+    one = _run_workers(1, LINWAVE, tmp_path, "w1")
+    a = by_bounds(one)
+    uneven = []
+    for nr in (2, 3):
+        many = _run_workers(nr, spec, tmp_path, "w%d" % nr)
+        counts = [r["meta"]["nblocks"] for r in many]
+        uneven.append(len(set(counts)) > 1)
+        assert sum(counts) == one[0]["meta"]["nblocks"]
+        for r in many:
+            assert r["meta"]["remeshes"] == one[0]["meta"]["remeshes"] >= 3
+            assert r["meta"]["ncycle"] == 45 and r["meta"]["dt"] == one[0]["meta"]["dt"]
+        b = by_bounds(many)
+        assert a.keys() == b.keys()
+        for key in a:
+            assert np.array_equal(a[key], b[key]), (nr, key)
+    assert any(uneven)  # (the weighted split really dealt unequal counts in at least one of the worlds)

@@ -144,7 +144,9 @@ def test_metric_tables_are_plain_glibc_sin_cos():
 def test_device_buffer_cache_contract():
     """artemis_rt_malloc / artemis_rt_free (include/artemis_rt.h): a freed buffer comes back for a request of its size
     class (a remesh frees and re-requests tens of GB whose sizes barely change), a fresh buffer carries headroom so that a
-    slightly larger request right after still fits it, the footprint counts cached buffers, and a trim gives them back."""
+    slightly larger request right after still fits it, the footprint counts cached buffers, and a trim gives them back.
+    The cache is opt-in (artemis_rt_pool_limit; the standalone driver enables it for adaptive meshes): without it a free
+    returns the memory to the device at once -- a library host shares the device with other allocators."""
     from artemis_amd import capi
     L = capi.load()
     cur, peak = C.c_size_t(), C.c_size_t()
@@ -153,9 +155,14 @@ def test_device_buffer_cache_contract():
         L.artemis_rt_device_bytes(C.byref(cur), C.byref(peak), 0)
         return cur.value
 
-    L.artemis_rt_pool_trim(0)
+    L.artemis_rt_pool_limit(0)
     base = footprint()
     n = 200 << 20
+    a = L.artemis_rt_malloc(n)
+    assert a and footprint() - base == n            # cache off: exact size, no size class
+    L.artemis_rt_free(a)
+    assert footprint() == base                      # ... and a free gives the memory back
+    L.artemis_rt_pool_limit(8 << 30)
     a = L.artemis_rt_malloc(n)
     assert a and footprint() - base >= n
     held = footprint()
@@ -171,3 +178,4 @@ def test_device_buffer_cache_contract():
     L.artemis_rt_free(d)
     L.artemis_rt_pool_trim(0)
     assert footprint() == base
+    L.artemis_rt_pool_limit(0)

@@ -169,6 +169,20 @@ def test_rk2_steps_through_the_adapter_equal_the_oracle(harness, tmp_path, mode,
     assert dt_est == (min(dts) if realloc == 2 else dts[0])
 
 
+def test_default_wiring_leaves_refined_meshes_to_the_task_list(harness, tmp_path):
+    """pmesh->multilevel: the one-kernel stage stores no flux arrays, so the flux correction the replaced task block
+    contains (artemis_driver.cpp:196-202) would silently have nothing to send.  StageCovered must be false there and
+    Stage itself must fail with PARTHENON_REQUIRE's exception (round-4 advisor finding)."""
+    states = [initial_state(11, False), initial_state(29, False)]
+    src = tmp_path / "ml.in"
+    with open(src, "wb") as f:
+        for g, _ in states:
+            f.write(np.ascontiguousarray(g).tobytes())
+    r = subprocess.run([harness, "covered_multilevel", str(src), str(tmp_path / "ml.out"), "1e-3", "1", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+
+
 def test_a_stale_u1_register_is_caught(harness, tmp_path):
     """Sanity of the check itself: the oracle run with the round-2 defect emulated (stage 2 combining u0 with ITSELF
     instead of with the start-of-step copy) differs from the adapter's result at O(dt) -- i.e. the comparison above
