@@ -40,15 +40,20 @@ def _deps():
     return out
 
 
-def build_hip(force=False, verbose=False):
+def build_hip(force=False, verbose=False, only=None):
+    """only = ["kernels_curv.hip", ...] (development): recompile just these sources and relink with the objects of the
+    last full build (the caller knows that nothing else depends on what changed)."""
     os.makedirs(LIBDIR, exist_ok=True)
     target = os.path.join(LIBDIR, "libartemis_hip.so")
-    if not (force or _newer(target, _deps())):
+    if not (force or only or _newer(target, _deps())):
         return target
     objs = []
     procs = []
     for src in HIP_SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        if only and src not in only and os.path.exists(obj):
+            objs.append(obj)
+            continue
         # ARTEMIS_HIPFLAGS_<STEM> (e.g. ARTEMIS_HIPFLAGS_KERNELS_FUSED="-mllvm -amdgpu-sched-strategy=max-ilp"):
         # extra flags for one source, for compiler experiments
         extra = os.environ.get("ARTEMIS_HIPFLAGS_" + src.replace(".hip", "").upper(), "").split()
@@ -65,6 +70,9 @@ def build_hip(force=False, verbose=False):
         for f in sorted(os.listdir(drv_dir)):
             if f.endswith(".cpp"):
                 obj = os.path.join(LIBDIR, "driver_" + f.replace(".cpp", ".o"))
+                if only and f not in only and os.path.exists(obj):
+                    objs.append(obj)
+                    continue
                 cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off"] + NO_SINCOS + [
                        "-I", os.path.join(ROOT, "include"), "-c", os.path.join(drv_dir, f), "-o", obj]
                 if f == "comm_rccl.cpp":  # rccl.h pulls in the HIP runtime API header (types only: no HIP calls there)
@@ -82,4 +90,4 @@ def build_hip(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_hip(force="-f" in sys.argv, verbose=True))
+    print(build_hip(force="-f" in sys.argv, verbose=True, only=[a for a in sys.argv[1:] if not a.startswith("-")] or None))

@@ -284,6 +284,60 @@ ADEV void hlle_gas(const double gm1, const Prim6 &L, const Prim6 &R, FaceFlux &F
   F.vf = frho / ((frho >= 0.0) ? L.d : R.d);
 }
 
+// hlle.hpp:56-222 (gas) again, same expression trees, with the hand-scheduled division and square root: the
+// reciprocals of sqrt(rho_l) + sqrt(rho_r), sqrt(rho_l), sqrt(rho_r), rho_l, rho_r and bp - bm are refined once and
+// every quotient that shares one takes three fmas (`div` returns the bits of `/` for these operands: densities are
+// floored, sound speeds positive, bp - bm >= 2e-20).  The one square root whose argument can vanish -- gm1 * a, a the
+// Roe enthalpy minus the kinetic energy -- takes the IEEE sqrt unless the whole wave holds normal positive values.
+// Callers pass through here only where hllc_gas_fast would be admissible too (no tiny-but-nonzero velocity in reach).
+ADEV void hlle_gas_fast(const double gm1, const double igm1, const double gamma, const Prim6 &L, const Prim6 &R,
+                        FaceFlux &F) {
+  const double sqrtdl = sqrt_pos(L.d);
+  const double sqrtdr = sqrt_pos(R.d);
+  const double isdlpdr = div(1.0, recip(sqrtdl + sqrtdr));
+  const double ux = (sqrtdl * L.vx + sqrtdr * R.vx) * isdlpdr;
+  const double uy = (sqrtdl * L.vy + sqrtdr * R.vy) * isdlpdr;
+  const double uz = (sqrtdl * L.vz + sqrtdr * R.vz) * isdlpdr;
+  const double el = L.p * igm1 + 0.5 * L.d * (sqr(L.vx) + sqr(L.vy) + sqr(L.vz));
+  const double er = R.p * igm1 + 0.5 * R.d * (sqr(R.vx) + sqr(R.vy) + sqr(R.vz));
+  const double hroe = (div(el + L.p, recip(sqrtdl)) + div(er + R.p, recip(sqrtdr))) * isdlpdr;
+  const Recip rdl = recip(L.d), rdr = recip(R.d);
+  const double cl = sqrt_pos(div(gamma * L.p, rdl));
+  const double cr = sqrt_pos(div(gamma * R.p, rdr));
+  double a = hroe - 0.5 * (sqr(ux) + sqr(uy) + sqr(uz));
+  {
+    const double x = gm1 * a;
+    // (a < 0 gives 0 whatever the root; a NaN or a vanishing argument sends the wave through sqrt())
+    const bool plain = (a >= 0.0) && !(x > 0x1p-900);
+    double r;
+    if (__builtin_amdgcn_ballot_w64(plain) != 0 || __builtin_amdgcn_ballot_w64(a != a) != 0) r = sqrt(x);
+    else r = sqrt_pos(x);
+    a = (a < 0.0) ? 0.0 : r;
+  }
+  const double sl = amin(ux - a, L.vx - cl);
+  const double sr = amax(ux + a, R.vx + cr);
+  const double bp = (sr > 0.0) ? sr : 1.0e-20;
+  const double bm = (sl < 0.0) ? sl : -1.0e-20;
+  const double ql = L.vx - bm;
+  const double qr = R.vx - bp;
+  const double fl_d = L.d * ql, fr_d = R.d * qr;
+  const double fl_mx = L.d * L.vx * ql, fr_mx = R.d * R.vx * qr;
+  const double fl_my = L.d * L.vy * ql, fr_my = R.d * R.vy * qr;
+  const double fl_mz = L.d * L.vz * ql, fr_mz = R.d * R.vz * qr;
+  const double fl_e = el * ql + L.p * L.vx, fr_e = er * qr + R.p * R.vx;
+  const double w = (bp != bm) ? div(0.5 * (bp + bm), recip(bp - bm)) : 0.0;
+  F.pf = 0.5 * (L.p + R.p) + w * (L.p - R.p);
+  const double frho = 0.5 * (fl_d + fr_d) + w * (fl_d - fr_d);
+  F.fd = frho;
+  F.fmx = 0.5 * (fl_mx + fr_mx) + w * (fl_mx - fr_mx);
+  F.fmy = 0.5 * (fl_my + fr_my) + w * (fl_my - fr_my);
+  F.fmz = 0.5 * (fl_mz + fr_mz) + w * (fl_mz - fr_mz);
+  F.fe = 0.5 * (fl_e + fr_e) + w * (fl_e - fr_e);
+  const bool up = (frho >= 0.0);
+  F.feg = frho * (up ? L.e : R.e);
+  F.vf = div(frho, pick(up, rdl, rdr));
+}
+
 // utils/fluxes/riemann/llf.hpp:47-170, gas branch
 ADEV void llf_gas(const double gm1, const Prim6 &L, const Prim6 &R, FaceFlux &F) {
   const double igm1 = 1.0 / gm1;
@@ -316,6 +370,40 @@ ADEV void llf_gas(const double gm1, const Prim6 &L, const Prim6 &R, FaceFlux &F)
   F.vf = frho / ((frho >= 0.0) ? L.d : R.d);
 }
 
+// llf.hpp:47-170 (gas) with the hand-scheduled division and square root (rho_l, rho_r refined once: sound speeds and
+// the face velocity)
+ADEV void llf_gas_fast(const double gm1, const double igm1, const double gamma, const Prim6 &L, const Prim6 &R,
+                       FaceFlux &F) {
+  const double ml = L.d * L.vx;
+  const double mr = R.d * R.vx;
+  const double fsum_d = ml + mr;
+  const double fsum_mx = ml * L.vx + mr * R.vx;
+  const double fsum_my = ml * L.vy + mr * R.vy;
+  const double fsum_mz = ml * L.vz + mr * R.vz;
+  const double el = L.p * igm1 + 0.5 * L.d * (sqr(L.vx) + sqr(L.vy) + sqr(L.vz));
+  const double er = R.p * igm1 + 0.5 * R.d * (sqr(R.vx) + sqr(R.vy) + sqr(R.vz));
+  const double fsum_e = (el + L.p) * L.vx + (er + R.p) * R.vx;
+  const Recip rdl = recip(L.d), rdr = recip(R.d);
+  const double cl = sqrt_pos(div(gamma * L.p, rdl));
+  const double cr = sqrt_pos(div(gamma * R.p, rdr));
+  const double a = amax((fabs(L.vx) + cl), (fabs(R.vx) + cr));
+  const double du_d = a * (R.d - L.d);
+  const double du_mx = a * (R.d * R.vx - L.d * L.vx);
+  const double du_my = a * (R.d * R.vy - L.d * L.vy);
+  const double du_mz = a * (R.d * R.vz - L.d * L.vz);
+  const double du_e = a * (er - el);
+  F.pf = 0.5 * (L.p + R.p);
+  const double frho = 0.5 * (fsum_d - du_d);
+  F.fd = frho;
+  F.fmx = 0.5 * (fsum_mx - du_mx);
+  F.fmy = 0.5 * (fsum_my - du_my);
+  F.fmz = 0.5 * (fsum_mz - du_mz);
+  F.fe = 0.5 * (fsum_e - du_e);
+  const bool up = (frho >= 0.0);
+  F.feg = frho * (up ? L.e : R.e);
+  F.vf = div(frho, pick(up, rdl, rdr));
+}
+
 template <int RIEMANN>
 ADEV void riemann_gas(const double gm1, const Prim6 &L, const Prim6 &R, FaceFlux &F) {
   if constexpr (RIEMANN == 0) hllc_gas(gm1, L, R, F);
@@ -341,6 +429,29 @@ ADEV void hlle_dust(const Prim4 &L, const Prim4 &R, FaceFlux &F) {
   const double fl_mz = L.d * L.vz * ql, fr_mz = R.d * R.vz * qr;
   double w = 0.0;
   if (bp != bm) w = 0.5 * (bp + bm) / (bp - bm);
+  F.fd = 0.5 * (fl_d + fr_d) + w * (fl_d - fr_d);
+  F.fmx = 0.5 * (fl_mx + fr_mx) + w * (fl_mx - fr_mx);
+  F.fmy = 0.5 * (fl_my + fr_my) + w * (fl_my - fr_my);
+  F.fmz = 0.5 * (fl_mz + fr_mz) + w * (fl_mz - fr_mz);
+}
+
+// hlle.hpp:56-222 (dust) with the hand-scheduled division and square root (dust densities are floored)
+ADEV void hlle_dust_fast(const Prim4 &L, const Prim4 &R, FaceFlux &F) {
+  const double sqrtdl = sqrt_pos(L.d);
+  const double sqrtdr = sqrt_pos(R.d);
+  const double isdlpdr = div(1.0, recip(sqrtdl + sqrtdr));
+  const double ux = (sqrtdl * L.vx + sqrtdr * R.vx) * isdlpdr;
+  const double sl = amin(ux, L.vx);
+  const double sr = amax(ux, R.vx);
+  const double bp = (sr > 0.0) ? sr : 1.0e-20;
+  const double bm = (sl < 0.0) ? sl : -1.0e-20;
+  const double ql = L.vx - bm;
+  const double qr = R.vx - bp;
+  const double fl_d = L.d * ql, fr_d = R.d * qr;
+  const double fl_mx = L.d * L.vx * ql, fr_mx = R.d * R.vx * qr;
+  const double fl_my = L.d * L.vy * ql, fr_my = R.d * R.vy * qr;
+  const double fl_mz = L.d * L.vz * ql, fr_mz = R.d * R.vz * qr;
+  const double w = (bp != bm) ? div(0.5 * (bp + bm), recip(bp - bm)) : 0.0;
   F.fd = 0.5 * (fl_d + fr_d) + w * (fl_d - fr_d);
   F.fmx = 0.5 * (fl_mx + fr_mx) + w * (fl_mx - fr_mx);
   F.fmy = 0.5 * (fl_my + fr_my) + w * (fl_my - fr_my);

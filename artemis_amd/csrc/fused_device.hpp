@@ -105,8 +105,12 @@ ADEV Flux8 solve_face(const GasK &gk, const Cell6 &L, const Cell6 &R, const bool
     // tiny (callers without that knowledge pass true and live with DESIGN.md section 4's limit)
     if (fast) hllc_gas_fast(gk.gm1, gk.igm1, gk.gamma, gk.alpha, l, r, F);
     else hllc_gas(gk.gm1, l, r, F);
+  } else if constexpr (RIEMANN == 1) { // (the same wave-uniform choice for HLLE and LLF)
+    if (fast) hlle_gas_fast(gk.gm1, gk.igm1, gk.gamma, l, r, F);
+    else hlle_gas(gk.gm1, l, r, F);
   } else {
-    riemann_gas<RIEMANN>(gk.gm1, l, r, F);
+    if (fast) llf_gas_fast(gk.gm1, gk.igm1, gk.gamma, l, r, F);
+    else llf_gas(gk.gm1, l, r, F);
   }
   Flux8 o;
   o.d = F.fd, o.e = F.fe, o.eg = F.feg, o.pf = F.pf, o.vf = F.vf;

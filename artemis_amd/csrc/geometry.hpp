@@ -152,12 +152,16 @@ template <int NX, int NY>
 struct GeoTabs {
   double gi[GI_NF][NX]; // column x <-> zone index clamp(ibase + x, 0, ni - 1)
   double gj[GJ_NF][NY]; // row y    <-> zone index clamp(jbase + y, 0, nj - 1)
+  double x3f0, dx3;     // the block's x3 edge table {x3f0, dx3}: a global load of them inside the march would be a
+                        // vector load (stores are in flight, so no scalar load) with a vmcnt(0) wait behind it -- which
+                        // also waits for every prefetch of the trip
 };
 // Threads [0, NX) fill the columns, threads [64, 64 + NY) the rows (NY <= 64: a second wave); the caller
 // synchronises the workgroup before the first read.
 template <int NX, int NY>
 __device__ __forceinline__ void geotabs_fill(GeoTabs<NX, NY> &G, const PackView &P, int b, int ibase, int jbase, int t) {
   static_assert(NX <= 64 && NY <= 64, "one wave per table");
+  if (t == 64 + NY) G.x3f0 = P.geom[6 * b + 4], G.dx3 = P.geom[6 * b + 5];
   if (t < NX) {
     const int ii = min(max(ibase + t, 0), P.ni - 1);
     const DCoords c = make_coords(P, b, 0, 0, ii); // (x1-only members: the x2 / x3 indices do not enter)
@@ -178,8 +182,8 @@ __device__ __forceinline__ void geotabs_fill(GeoTabs<NX, NY> &G, const PackView 
 // Coords of the zone at (column x, row y) of the tables on plane k (x3 edges from the block's edge table; c3 / s3 =
 // cos / sin of the plane's x3 centre where the system has them, else 1 / 0)
 template <int NX, int NY>
-__device__ __forceinline__ DCoordsT<true> geotabs_coords(const GeoTabs<NX, NY> &G, int sys, const double *g, int x, int y,
-                                                         int k, double c3, double s3) {
+__device__ __forceinline__ DCoordsT<true> geotabs_coords(const GeoTabs<NX, NY> &G, int sys, int x, int y, int k, double c3,
+                                                         double s3) {
   DCoordsT<true> c;
   c.sys = sys;
   c.x1[0] = G.gi[GI_X1LO][x], c.x1[1] = G.gi[GI_X1HI][x];
@@ -189,7 +193,8 @@ __device__ __forceinline__ DCoordsT<true> geotabs_coords(const GeoTabs<NX, NY> &
   c.cf[0] = G.gj[GJ_CF0][y], c.cf[1] = G.gj[GJ_CF1][y], c.sf[0] = G.gj[GJ_SF0][y], c.sf[1] = G.gj[GJ_SF1][y];
   c.x2c = G.gj[GJ_X2C][y], c.sv = G.gj[GJ_SV][y], c.sc = G.gj[GJ_SC][y], c.cv = G.gj[GJ_CV][y];
   c.k_dh3dx2 = G.gj[GJ_DH32][y], c.k_rdc = G.gj[GJ_RDC][y];
-  c.x3[0] = g[4] + k * g[5], c.x3[1] = g[4] + (k + 1) * g[5];
+  const double f0 = G.x3f0, d3 = G.dx3;
+  c.x3[0] = f0 + k * d3, c.x3[1] = f0 + (k + 1) * d3;
   c.c3 = c3, c.s3 = s3;
   return c;
 }

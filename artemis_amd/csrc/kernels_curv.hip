@@ -40,6 +40,22 @@
 #include "nbody_device.hpp"
 #include "task_device.hpp"
 
+// -DCURV_PROF (development builds only: ARTEMIS_HIPFLAGS_KERNELS_CURV=-DCURV_PROF): every wave sums the shader-clock
+// cycles it spends in each phase of a plane (work and waiting alike) into g_curv_prof; artemis_hip_debug_curv_prof reads them
+#ifdef CURV_PROF
+__device__ unsigned long long g_curv_prof[16];
+#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(slot)                                              \
+  do {                                                          \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    prof_acc[slot] += now_ - prof_t;                            \
+    prof_t = now_;                                              \
+  } while (0)
+#else
+#define PROF_DECL
+#define PROF(slot)
+#endif
+
 namespace artemis {
 namespace {
 using namespace fused;
@@ -66,6 +82,29 @@ struct CurvK {
 enum { PW_CR = 0, PW_CL, PW_UP, PW_LO, PW_RAB, PW_RAY, PW_RBB, PW_RBY, PW_NF, // PLM_G weights that depend on one index only
        PW_DX = PW_NF, PW_RDB, PW_RDY, PW1_NF };                               // + the cell width along x1 (x1 records)
 
+// Workgroup constants the update reads on every plane.  As kernel arguments they sit in scalar registers for the whole
+// march -- with ~20 array pointers, the pack's bounds and the solver constants that is more than the 100-odd a wave has,
+// so the compiler parks them in VGPR lanes (v_writelane / v_readlane around every use) and, at 256 VGPRs, in scratch.
+// One thread copies them to LDS once; a use is a broadcast ds_read next to the instruction that consumes it.
+struct CurvConst {
+  double gam0, gam1, beta_dt, bdt, cfl, rf_omega, omf, nb_omf;
+  double dfloor, siefloor, de_switch;
+  artemis_gravity_t grav;
+  // the block's output / viscous-sum / conserved arrays.  Read from the pointer tables inside the march they would be
+  // vector loads (the kernel has stores in flight: no scalar load) followed by vmcnt(0) -- a wait for every prefetch
+  double *out[6], *cons0[6];
+  const double *dsum[5], *u1[5]; // (u1: rho, v1, v2, v3, sie of the start-of-step state)
+};
+// artemis_gravity_t as gravity_accel reads it: the law's type from the kernel argument (a scalar: the branches on it stay
+// scalar branches), every number from the LDS copy
+struct GravLds {
+  const int type;
+  const artemis_gravity_t &L;
+  const double (&g)[3] = L.g, (&pos)[3] = L.pos, (&pos2)[3] = L.pos2;
+  const double &gm = L.gm, &soft = L.soft, &sink = L.sink, &sink_rate = L.sink_rate, &q = L.q, &soft2 = L.soft2,
+               &sink2 = L.sink2, &sink_rate2 = L.sink_rate2;
+};
+
 template <int FTX_>
 struct CurvTile {
   static constexpr int FTX = FTX_, FTY = 256 / FTX_, QX = FTX + 4, QY = FTY + 4;
@@ -81,8 +120,11 @@ struct CurvTile {
   double PX1[PW1_NF][QX];       // PLM_G records along x1, per column
   double PX2[PW_NF][QY];        // PLM_G weights along x2, per row (the width is (i, j): formed where it is used)
   double PX3[PW_NF][CKMAX + 4]; // ... along x3, planes k0-1 .. k1+1
+  double ZL[6][256];            // the zone's upper x3 face value, parked between two x3 sweeps (12 VGPRs less through a plane)
+  double C3[CKMAX], S3[CKMAX];  // cos / sin of the x3 centres of the chunk's planes (spherical3D, axisymmetric; else 1 / 0)
   int tiny[2];                  // plane (k & 1) holds a tiny-but-nonzero velocity: its slopes take IEEE division
   double wmin[4];
+  CurvConst C;
 };
 static_assert(sizeof(CurvTile<32>) <= 80 * 1024 && sizeof(CurvTile<16>) <= 80 * 1024, "two workgroups per CU");
 
@@ -117,7 +159,9 @@ ADEV Flux8 solve_fluid(const GasK &gk, const Cell6 &L, const Cell6 &R, const boo
     else if constexpr (DIR == 2) l.vx = L.v2, l.vy = L.v3, l.vz = L.v1, r.vx = R.v2, r.vy = R.v3, r.vz = R.v1;
     else l.vx = L.v3, l.vy = L.v1, l.vz = L.v2, r.vx = R.v3, r.vy = R.v1, r.vz = R.v2;
     FaceFlux F;
-    riemann_dust<(RIEMANN == 2) ? 2 : 1>(l, r, F);
+    if constexpr (RIEMANN == 2) llf_dust(l, r, F); // (no division, no root)
+    else if (fast) hlle_dust_fast(l, r, F);
+    else hlle_dust(l, r, F);
     Flux8 o;
     o.d = F.fd, o.e = o.eg = o.pf = o.vf = 0.0;
     if constexpr (DIR == 1) o.m1 = F.fmx, o.m2 = F.fmy, o.m3 = F.fmz;
@@ -129,6 +173,9 @@ ADEV Flux8 solve_fluid(const GasK &gk, const Cell6 &L, const Cell6 &R, const boo
 // The dust instantiation (DUST) carries rho, v1, v2, v3 only: the pressure / energy slots of the staged cell and the
 // energy / pressure-flux / face-velocity slots of a face flux are skipped (every X body below is guarded by its index).
 #define CFOR6(X) X(d, 0) X(v1, 1) X(v2, 2) X(v3, 3) X(p, 4) X(e, 5)
+// ... with a scheduling fence after the third variable: three slope chains interleave (six would need the registers of
+// twelve more doubles)
+#define CFOR6_33(X) X(d, 0) X(v1, 1) X(v2, 2) __builtin_amdgcn_sched_barrier(0); X(v3, 3) X(p, 4) X(e, 5)
 #define CGET6(dst, A, ...)                                                                 \
   dst.d = A[0] __VA_ARGS__, dst.v1 = A[1] __VA_ARGS__, dst.v2 = A[2] __VA_ARGS__,          \
   dst.v3 = A[3] __VA_ARGS__;                                                               \
@@ -187,16 +234,25 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   const int k1 = D3 ? min(P.ke, k0 + a.kchunk - 1) : P.ks;
   const double gm1 = P.gm1;
   const GasK gk = gas_constants(gm1);
-  double beta_dt = a.beta_dt, bdt = a.bdt;
-  if (a.bdt_ptr) beta_dt = bdt = *a.bdt_ptr;
+  const FluidView &f = DUST ? P.dust : P.gas;
+  if (t == 0) { // (read back after the barrier that follows the geometry tables)
+    CurvConst c;
+    c.gam0 = a.gam0, c.gam1 = a.gam1, c.beta_dt = a.beta_dt, c.bdt = a.bdt, c.cfl = a.cfl, c.rf_omega = a.rf_omega;
+    if (a.bdt_ptr) c.beta_dt = c.bdt = *a.bdt_ptr;
+    c.omf = P.omf, c.nb_omf = a.nb_omf;
+    c.dfloor = f.dfloor, c.siefloor = f.siefloor, c.de_switch = f.de_switch;
+    c.grav = a.grav;
+    for (int q = 0; q < NV; ++q) c.out[q] = a.prim_out[b * NV + q], c.cons0[q] = a.to_cons ? f.cons0[b * NV + q] : nullptr;
+    for (int q = 0; q < 5; ++q) c.dsum[q] = (!DUST && a.diff_on) ? a.dsum[b * 5 + q] : nullptr;
+    for (int q = 0; q < 4; ++q) c.u1[q] = a.prim_u1[b * NV + q];
+    c.u1[4] = a.prim_u1[b * NV + (DUST ? 0 : NV - 1)]; // (dust: never loaded)
+    S.C = c;
+  }
   const double *g = P.geom + 6 * b;
   const double *in_r = a.prim_in[b * NV + 0], *in_1 = a.prim_in[b * NV + 1], *in_2 = a.prim_in[b * NV + 2];
   const double *in_3 = a.prim_in[b * NV + 3], *in_e = DUST ? in_r : a.prim_in[b * NV + (NV - 1)]; // (dust: never loaded)
-  const double *u1_r = a.prim_u1[b * NV + 0], *u1_1 = a.prim_u1[b * NV + 1], *u1_2 = a.prim_u1[b * NV + 2];
-  const double *u1_3 = a.prim_u1[b * NV + 3], *u1_e = DUST ? u1_r : a.prim_u1[b * NV + (NV - 1)];
   const unsigned sj = static_cast<unsigned>(P.sj), sk = static_cast<unsigned>(P.sk);
   const unsigned col = static_cast<unsigned>(jl) * sj + static_cast<unsigned>(il);
-  const FluidView &f = DUST ? P.dust : P.gas;
   auto ldraw = [&](const double *r_, const double *v1_, const double *v2_, const double *v3_, const double *e_, unsigned c_) {
     Raw5 q;
     q.d = gld(r_, c_), q.v1 = gld(v1_, c_), q.v2 = gld(v2_, c_), q.v3 = gld(v3_, c_);
@@ -222,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     const int u = t - 4 * FTX, cc = u & 3;
     hr = (u >> 2) + FH, hc = (cc < 2) ? cc : FTX + cc;
   }
-  unsigned hcol = 0;
+  unsigned hcol = col; // (threads without a halo duty: their own column)
   if (hr >= 0) {
     const int gi = min(max(i0 - FH + hc, 0), P.ni - 1), gj = min(max(j0 - FH + hr, 0), P.nj - 1);
     hcol = static_cast<unsigned>(gj) * sj + static_cast<unsigned>(gi);
@@ -264,10 +320,14 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     }
   }
   if (t == 0) S.tiny[0] = S.tiny[1] = 0;
+  if (t >= 64 && t < 64 + (k1 - k0 + 1)) { // (a second wave: the first fills the x3 weights)
+    const int kk = k0 + (t - 64);
+    S.C3[t - 64] = m3 ? m3[MT3_COS * (P.nk + 1) + kk] : 1.0, S.S3[t - 64] = m3 ? m3[MT3_SIN * (P.nk + 1) + kk] : 0.0;
+  }
   __syncthreads();
   // Coords of the zone at (column x, row y) of the staged rectangle on plane kk; c3 / s3 only where a caller reads them
   auto CO = [&](int x, int y, int kk, double c3 = 1.0, double s3 = 0.0) {
-    return geotabs_coords(S.G, SYS, g, x, y, kk, c3, s3);
+    return geotabs_coords(S.G, SYS, x, y, kk, c3, s3);
   };
   auto rec_x1 = [&](int x) {
     PlmG r;
@@ -293,15 +353,13 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     r.rdx = recip(r.dx);
     return r;
   };
-  // face values of one cell along a direction: PCM / PLM_G with the guard of kernels_fused.hip (`fastp`: no velocity of
-  // the staged plane is tiny-but-nonzero, so every division may be the hand-scheduled one)
-  auto faces_of = [&](double qm, double q, double qp, const PlmG &r, bool fastp, double &up_, double &lo_) {
-    if constexpr (PG) {
-      if (fastp) plm_g_shared<2>(qm, q, qp, up_, lo_, r);
-      else plm_g_shared<0>(qm, q, qp, up_, lo_, r);
-    } else {
-      up_ = q, lo_ = q; // pcm.hpp:34-88
-    }
+  // face values of one cell along a direction: PCM / PLM_G with the guard of kernels_fused.hip.  FT = std::true_type: no
+  // velocity of the stencil is tiny-but-nonzero, so every division may be the hand-scheduled one; the choice is made ONCE
+  // per plane and phase (one branch around all variables of both sweeps: the six slope chains of a sweep share a basic
+  // block and interleave) instead of once per variable
+  auto faces_of = [&](auto FT, double qm, double q, double qp, const PlmG &r, double &up_, double &lo_) {
+    if constexpr (PG) plm_g_shared<decltype(FT)::value ? 2 : 0>(qm, q, qp, up_, lo_, r);
+    else up_ = q, lo_ = q; // pcm.hpp:34-88
   };
   auto stage_plane = [&](const Cell6 &q, const Raw5 &hal, int par) {
 #define PUTQ(m, n) if constexpr (n < NV) S.Q[n][ty + FH][tx + FH] = q.m;
@@ -318,6 +376,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     if (PG && __any(tny) && (t & 63) == 0) S.tiny[par] = 1;
   };
   double ldt = DBL_MAX;
+  PROF_DECL;
 
   // ---- the update of zone (k, j, i) from the folded sums -----------------------------------------------------------
   struct Sums { // what ApplyUpdate, FluxSource and RotatingFrameImpl sum over the faces, in their order of additions
@@ -354,60 +413,64 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   auto update = [&](const int k, const DCoordsT<true> &co, const CellMetric &cm, const double hx[3], const Cell6 &qc, Sums &s,
                     const Raw5 &u1raw, const double ds[5]) {
     if (!active) return;
+    const CurvConst &KC = S.C; // (LDS: every read below is a broadcast ds_read at its use)
     const unsigned c = col + static_cast<unsigned>(k) * sk;
     FluidPrim w;
     w.rho = qc.d, w.v1 = qc.v1, w.v2 = qc.v2, w.v3 = qc.v3, w.sie = qc.e;
     if constexpr (DUST) { // the same tasks on Dust's four conserved variables (kernels_stage_cell.hip's dust branch)
-      DustCons u0 = prim_to_cons_dust(f, w.rho, w.v1, w.v2, w.v3, hx);
+      DustCons u0 = prim_to_cons_dust(KC, w.rho, w.v1, w.v2, w.v3, hx);
       DustCons u1 = u0;
-      if (a.has_u1) u1 = prim_to_cons_dust(f, u1raw.d, u1raw.v1, u1raw.v2, u1raw.v3, hx);
+      if (a.has_u1) u1 = prim_to_cons_dust(KC, u1raw.d, u1raw.v1, u1raw.v2, u1raw.v3, hx);
       const Recip rvol = recip(cm.vol);
-      const double nd = s.dv[0] * beta_dt, n1m = s.dv[1] * beta_dt, n2m = s.dv[2] * beta_dt, n3m = s.dv[3] * beta_dt;
+      const double nd = s.dv[0] * KC.beta_dt, n1m = s.dv[1] * KC.beta_dt, n2m = s.dv[2] * KC.beta_dt, n3m = s.dv[3] * KC.beta_dt;
       double qd, q1m, q2m, q3m; // (mass and momentum fluxes of a dust at rest can be tiny-but-nonzero: IEEE then)
       if (__any(tiny_nonzero(nd) || tiny_nonzero(n1m) || tiny_nonzero(n2m) || tiny_nonzero(n3m))) {
         qd = nd / cm.vol, q1m = n1m / cm.vol, q2m = n2m / cm.vol, q3m = n3m / cm.vol;
       } else {
         qd = div(nd, rvol), q1m = div(n1m, rvol), q2m = div(n2m, rvol), q3m = div(n3m, rvol);
       }
-      u0.d = a.gam0 * u0.d + a.gam1 * u1.d + qd;
-      u0.m1 = a.gam0 * u0.m1 + a.gam1 * u1.m1 + q1m;
-      u0.m2 = a.gam0 * u0.m2 + a.gam1 * u1.m2 + q2m;
-      u0.m3 = a.gam0 * u0.m3 + a.gam1 * u1.m3 + q3m;
-      const double dt = bdt;
+      u0.d = KC.gam0 * u0.d + KC.gam1 * u1.d + qd;
+      u0.m1 = KC.gam0 * u0.m1 + KC.gam1 * u1.m1 + q1m;
+      u0.m2 = KC.gam0 * u0.m2 + KC.gam1 * u1.m2 + q2m;
+      u0.m3 = KC.gam0 * u0.m3 + KC.gam1 * u1.m3 + q3m;
+      const double dt = KC.bdt;
       { // Dust::FluxSource (dust.cpp:303-326): the coordinate source only
         const double rdt = w.rho * dt;
         double vf[3];
-        rotation_velocity(co, P.omf, vf);
+        rotation_velocity(co, KC.omf, vf);
         if (co.x1dep())
           u0.m1 += rdt * (0.0 * sqr(w.v1 + vf[0]) + co.dh2dx1() * sqr(w.v2 + vf[1]) + co.dh3dx1() * sqr(w.v3 + vf[2]));
         if (co.x2dep() && multi_d)
           u0.m2 += rdt * (0.0 * sqr(w.v1 + vf[0]) + 0.0 * sqr(w.v2 + vf[1]) + co.dh3dx2() * sqr(w.v3 + vf[2]));
       }
-      if (a.grav_on) gravity_dust(gravity_accel(a.grav, co, P.ndim, dt), dt, hx, w, u0);
+      if (a.grav_on) {
+        GravLds G{a.grav.type, KC.grav};
+        gravity_dust(gravity_accel<true>(G, co, P.ndim, dt), dt, hx, w, u0);
+      }
       if (a.nb_n) {
         const double wv[4] = {w.rho, w.v1, w.v2, w.v3};
         double u[4] = {u0.d, u0.m1, u0.m2, u0.m3};
-        nb_apply<false>(a.nb_pl, a.nb_n, co, a.nb_omf, dt, wv, u);
+        nb_apply<false>(a.nb_pl, a.nb_n, co, KC.nb_omf, dt, wv, u);
         u0.d = u[0], u0.m1 = u[1], u0.m2 = u[2], u0.m3 = u[3];
       }
       if (a.rfc_on) { // sources_device.hpp rotating_frame_dust on the folded sums
-        const RotFrame rfc = rotating_frame_terms(co, a.rf_omega, dt);
+        const RotFrame rfc = rotating_frame_terms(co, KC.rf_omega, dt);
         const double qv = s.rfd / cm.vol;
         u0.m1 -= rfc.omdt * qv * rfc.ep[0];
         u0.m2 -= rfc.omdt * qv * rfc.ep[1];
         u0.m3 -= rfc.omdt * qv * rfc.ep[2];
       }
       if (a.to_cons) {
-        gst(f.cons0[b * 4 + 0], c, u0.d), gst(f.cons0[b * 4 + 1], c, u0.m1), gst(f.cons0[b * 4 + 2], c, u0.m2);
-        gst(f.cons0[b * 4 + 3], c, u0.m3);
+        gst(KC.cons0[0], c, u0.d), gst(KC.cons0[1], c, u0.m1), gst(KC.cons0[2], c, u0.m2);
+        gst(KC.cons0[3], c, u0.m3);
         return;
       }
-      const double w_d = (u0.d > f.dfloor) ? u0.d : f.dfloor; // ConsToPrim (fill_derived.cpp:155-164)
+      const double w_d = (u0.d > KC.dfloor) ? u0.d : KC.dfloor; // ConsToPrim (fill_derived.cpp:155-164)
       const double n1 = u0.m1 / (w_d * hx[0]), n2 = u0.m2 / (w_d * hx[1]), n3 = u0.m3 / (w_d * hx[2]);
-      gst(a.prim_out[b * 4 + 0], c, w_d);
-      gst(a.prim_out[b * 4 + 1], c, n1);
-      gst(a.prim_out[b * 4 + 2], c, n2);
-      gst(a.prim_out[b * 4 + 3], c, n3);
+      gst(KC.out[0], c, w_d);
+      gst(KC.out[1], c, n1);
+      gst(KC.out[2], c, n2);
+      gst(KC.out[3], c, n3);
       if (a.dt_bits) { // Dust::EstimateTimestepMesh (dust.cpp:256-272; a dust at rest gives 1 / 0 = inf like the reference)
         double denom = 0.0;
         denom += fabs(n1) / co.width1();
@@ -417,13 +480,13 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       }
       return;
     }
-    GasCons u0 = prim_to_cons_gas(f, w.rho, w.v1, w.v2, w.v3, w.sie, hx);
+    GasCons u0 = prim_to_cons_gas(KC, w.rho, w.v1, w.v2, w.v3, w.sie, hx);
     GasCons u1 = u0;
-    if (a.has_u1) u1 = prim_to_cons_gas(f, u1raw.d, u1raw.v1, u1raw.v2, u1raw.v3, u1raw.e, hx);
+    if (a.has_u1) u1 = prim_to_cons_gas(KC, u1raw.d, u1raw.v1, u1raw.v2, u1raw.v3, u1raw.e, hx);
     // ---- ApplyUpdate (artemis_integrator.hpp:88-106)
     const Recip rvol = recip(cm.vol);
-    const double nd = s.dv[0] * beta_dt, n1m = s.dv[1] * beta_dt, n2m = s.dv[2] * beta_dt, n3m = s.dv[3] * beta_dt;
-    const double ne = s.dv[4] * beta_dt, neg = s.dv[5] * beta_dt;
+    const double nd = s.dv[0] * KC.beta_dt, n1m = s.dv[1] * KC.beta_dt, n2m = s.dv[2] * KC.beta_dt, n3m = s.dv[3] * KC.beta_dt;
+    const double ne = s.dv[4] * KC.beta_dt, neg = s.dv[5] * KC.beta_dt;
     // momenta can be tiny-but-nonzero ahead of a shock, where only IEEE division is right: wave-uniform choice
     double q1m, q2m, q3m;
     if (__any(tiny_nonzero(n1m) || tiny_nonzero(n2m) || tiny_nonzero(n3m))) {
@@ -431,14 +494,14 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     } else {
       q1m = div(n1m, rvol), q2m = div(n2m, rvol), q3m = div(n3m, rvol);
     }
-    u0.d = a.gam0 * u0.d + a.gam1 * u1.d + div(nd, rvol);
-    u0.m1 = a.gam0 * u0.m1 + a.gam1 * u1.m1 + q1m;
-    u0.m2 = a.gam0 * u0.m2 + a.gam1 * u1.m2 + q2m;
-    u0.m3 = a.gam0 * u0.m3 + a.gam1 * u1.m3 + q3m;
-    u0.e = a.gam0 * u0.e + a.gam1 * u1.e + div(ne, rvol);
-    u0.eg = a.gam0 * u0.eg + a.gam1 * u1.eg + div(neg, rvol);
+    u0.d = KC.gam0 * u0.d + KC.gam1 * u1.d + div(nd, rvol);
+    u0.m1 = KC.gam0 * u0.m1 + KC.gam1 * u1.m1 + q1m;
+    u0.m2 = KC.gam0 * u0.m2 + KC.gam1 * u1.m2 + q2m;
+    u0.m3 = KC.gam0 * u0.m3 + KC.gam1 * u1.m3 + q3m;
+    u0.e = KC.gam0 * u0.e + KC.gam1 * u1.e + div(ne, rvol);
+    u0.eg = KC.gam0 * u0.eg + KC.gam1 * u1.eg + div(neg, rvol);
     // ---- FluxSource (fluid_fluxes.hpp:361-415)
-    const double dt = bdt;
+    const double dt = KC.bdt;
     u0.m1 += s.tm[0];
     u0.eg -= s.te[0];
     if (multi_d) {
@@ -452,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     {
       const double rdt = w.rho * dt;
       double vf[3];
-      rotation_velocity(co, P.omf, vf);
+      rotation_velocity(co, KC.omf, vf);
       if (co.x1dep())
         u0.m1 += rdt * (0.0 * sqr(w.v1 + vf[0]) + co.dh2dx1() * sqr(w.v2 + vf[1]) + co.dh3dx1() * sqr(w.v3 + vf[2]));
       if (co.x2dep() && multi_d)
@@ -463,15 +526,18 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       u0.e -= ds[3];
       u0.eg -= ds[4];
     }
-    if (a.grav_on) gravity_gas(gravity_accel(a.grav, co, P.ndim, dt), dt, hx, w, u0);
+    if (a.grav_on) {
+      GravLds G{a.grav.type, KC.grav};
+      gravity_gas(gravity_accel<true>(G, co, P.ndim, dt), dt, hx, w, u0);
+    }
     if constexpr (EXT) if (a.nb_n) { // Gravity::NBodyGravity (nbody_device.hpp), particle by particle on the registers
       const double wv[4] = {w.rho, w.v1, w.v2, w.v3};
       double u[6] = {u0.d, u0.m1, u0.m2, u0.m3, u0.e, u0.eg};
-      nb_apply<true>(a.nb_pl, a.nb_n, co, a.nb_omf, dt, wv, u);
+      nb_apply<true>(a.nb_pl, a.nb_n, co, KC.nb_omf, dt, wv, u);
       u0.d = u[0], u0.m1 = u[1], u0.m2 = u[2], u0.m3 = u[3], u0.e = u[4], u0.eg = u[5];
     }
     if (a.rfc_on) { // sources_device.hpp rotating_frame_gas on the folded sums
-      const RotFrame rfc = rotating_frame_terms(co, a.rf_omega, dt);
+      const RotFrame rfc = rotating_frame_terms(co, KC.rf_omega, dt);
       const double qv = __any(tiny_nonzero(s.rfd)) ? s.rfd / cm.vol : div(s.rfd, rvol); // (divf / vol)
       u0.m1 -= rfc.omdt * qv * rfc.ep[0];
       u0.m2 -= rfc.omdt * qv * rfc.ep[1];
@@ -479,13 +545,13 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       u0.e += rfc.om2dt * rfc.R * (s.rfx[0] * rfc.eR[0] + s.rfx[1] * rfc.eR[1] + s.rfx[2] * rfc.eR[2]);
     }
     if constexpr (EXT) if (a.to_cons) { // DragSource couples the fluids next: the conserved state as the tasks would hold it
-      gst(f.cons0[b * 6 + 0], c, u0.d), gst(f.cons0[b * 6 + 1], c, u0.m1), gst(f.cons0[b * 6 + 2], c, u0.m2);
-      gst(f.cons0[b * 6 + 3], c, u0.m3), gst(f.cons0[b * 6 + 4], c, u0.e), gst(f.cons0[b * 6 + 5], c, u0.eg);
+      gst(KC.cons0[0], c, u0.d), gst(KC.cons0[1], c, u0.m1), gst(KC.cons0[2], c, u0.m2);
+      gst(KC.cons0[3], c, u0.m3), gst(KC.cons0[4], c, u0.e), gst(KC.cons0[5], c, u0.eg);
       return;
     }
     // ---- SetAuxillaryFields (fill_derived.cpp:58-71) + ConsToPrim (:132-146)
-    const double w_d = (u0.d > f.dfloor) ? u0.d : f.dfloor;
-    const double u_d2 = amax(u0.d, f.dfloor);
+    const double w_d = (u0.d > KC.dfloor) ? u0.d : KC.dfloor;
+    const double u_d2 = amax(u0.d, KC.dfloor);
     const Recip rd2 = recip(u_d2);
     const bool tiny_m = __any(tiny_nonzero(u0.m1) || tiny_nonzero(u0.m2) || tiny_nonzero(u0.m3));
     double rv2, rv3;
@@ -494,23 +560,23 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     const double rv1 = u0.m1 / 1.0; // hx[0] == 1
     const double ke = div(0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)), rd2);
     const double ue_cons = u0.e - ke;
-    double sie = (ue_cons > f.de_switch * u0.e) ? div(ue_cons, rd2) : div(u0.eg, rd2);
-    sie = amax(sie, f.siefloor);
+    double sie = (ue_cons > KC.de_switch * u0.e) ? div(ue_cons, rd2) : div(u0.eg, rd2);
+    sie = amax(sie, KC.siefloor);
     double u_u = sie * w_d;
-    const double uflr = f.siefloor * w_d;
+    const double uflr = KC.siefloor * w_d;
     u_u = (u_u > uflr) ? u_u : uflr;
     const Recip rwd = recip(w_d);
     double n1, n2, n3;
     if (tiny_m) n1 = u0.m1 / (w_d * hx[0]), n2 = u0.m2 / (w_d * hx[1]), n3 = u0.m3 / (w_d * hx[2]);
     else n1 = div(u0.m1, rwd), n2 = div(u0.m2, w_d * hx[1]), n3 = div(u0.m3, w_d * hx[2]); // w_d * 1.0 == w_d
     double w_s = div(u_u, rwd);
-    w_s = (w_s > f.siefloor) ? w_s : f.siefloor;
-    gst(a.prim_out[b * 6 + 0], c, w_d);
-    gst(a.prim_out[b * 6 + 1], c, n1);
-    gst(a.prim_out[b * 6 + 2], c, n2);
-    gst(a.prim_out[b * 6 + 3], c, n3);
-    gst(a.prim_out[b * 6 + 4], c, amax(0.0, gm1 * w_d * w_s)); // fill_derived.cpp:247 (consumers recompute it anyway)
-    gst(a.prim_out[b * 6 + 5], c, w_s);
+    w_s = (w_s > KC.siefloor) ? w_s : KC.siefloor;
+    gst(KC.out[0], c, w_d);
+    gst(KC.out[1], c, n1);
+    gst(KC.out[2], c, n2);
+    gst(KC.out[3], c, n3);
+    gst(KC.out[4], c, amax(0.0, gm1 * w_d * w_s)); // fill_derived.cpp:247 (consumers recompute it anyway)
+    gst(KC.out[5], c, w_s);
     if (a.dt_bits) { // Gas::EstimateTimestepMesh on the new state (gas.cpp:411-433)
       const double bulk = (gm1 + 1.0) * gm1 * w_d * w_s;
       const double cs = sqrt_pos(div(bulk, rwd));
@@ -521,14 +587,13 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     }
   };
 
-  // ---- one plane: the x1 / x2 sweeps (two barriers), then the caller's x3 part and update ----------------------------
-  // plane k's primitives are staged; returns the zone's x1 and x2 sums folded into `s` and leaves what the update needs
-  auto plane = [&](const int k, const Cell6 &qc, const bool stage_next, const Cell6 &qn, const Raw5 &hal_next, Sums &s) {
-    bool fastp = true;
-    if constexpr (PG) {
-      fastp = (S.tiny[k & 1] == 0);
-      if (t == 0) S.tiny[(k + 1) & 1] = 0; // set again when the next plane is staged (after the first barrier)
-    }
+  // ---- one plane, phases 1 and 2: the x1 / x2 sweeps (two barriers) ----------------------------------------------------
+  // plane k's primitives are staged; leaves the fluxes through the zone's lower x1 / x2 faces in fx_lo / fy_lo and the
+  // tile's face fluxes in S.FY / S.FXE.  FT: the plane holds no tiny-but-nonzero velocity (workgroup-uniform).
+  auto phase12 = [&](auto FT, const int k, const Cell6 &qc, const bool stage_next, const Cell6 &qn, const Raw5 &hal_next,
+                     Flux8 &fx_lo, Flux8 &fy_lo) {
+    constexpr bool fastp = decltype(FT)::value;
+    PROF(0); // (since the end of the previous plane: this trip's loads issued)
     const int duty = (t + 64 * (k & 3)) & 255; // wave roles rotate with k
     if (duty >= 64) __builtin_amdgcn_s_setprio(2); // the duty waves first (kernels_fused.hip: -5 %)
     // ---- P1: slopes of the own zone; the tile's edge columns and rows on the duty waves -----------------------------
@@ -539,23 +604,24 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
 #define SLX(m, n)                                                                                 \
   if constexpr (n < NV) {                                                                         \
     double up_;                                                                                   \
-    faces_of(S.Q[n][ty + FH][tx + FH - 1], qc.m, S.Q[n][ty + FH][tx + FH + 1], r, fastp, up_, lox.m); \
+    faces_of(FT, S.Q[n][ty + FH][tx + FH - 1], qc.m, S.Q[n][ty + FH][tx + FH + 1], r, up_, lox.m); \
     L.m = lane_below(up_);                                                                        \
     if (tx == FTX - 1) S.UPXE[n][ty] = up_;                                                       \
   }
-      CFOR6(SLX)
+      CFOR6_33(SLX)
 #undef SLX
     }
+    __builtin_amdgcn_sched_barrier(0); // (one sweep's six chains interleave; two sweeps' would not fit the registers)
     if (multi_d) {
       PlmG r{};
       if constexpr (PG) r = rec_x2(tx + FH, ty + FH);
 #define SLY(m, n)                                                                                 \
   if constexpr (n < NV) {                                                                         \
     double up_;                                                                                   \
-    faces_of(S.Q[n][ty + FH - 1][tx + FH], qc.m, S.Q[n][ty + FH + 1][tx + FH], r, fastp, up_, loy.m); \
+    faces_of(FT, S.Q[n][ty + FH - 1][tx + FH], qc.m, S.Q[n][ty + FH + 1][tx + FH], r, up_, loy.m); \
     S.UPY[n][ty + 1][tx] = up_;                                                                   \
   }
-      CFOR6(SLY)
+      CFOR6_33(SLY)
 #undef SLY
     }
     if (duty >= 128 && duty < 128 + 2 * FTY) { // columns i0-1 (upper value) and i0+FTX (lower value)
@@ -566,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
 #pragma unroll
       for (int n = 0; n < NV; ++n) {
         double up_, lo_;
-        faces_of(S.Q[n][row + FH][cx - 1], S.Q[n][row + FH][cx], S.Q[n][row + FH][cx + 1], r, fastp, up_, lo_);
+        faces_of(FT, S.Q[n][row + FH][cx - 1], S.Q[n][row + FH][cx], S.Q[n][row + FH][cx + 1], r, up_, lo_);
         if (side) S.LOXE[n][row] = lo_;
         else S.UPX0[n][row] = up_;
       }
@@ -579,21 +645,23 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
 #pragma unroll
       for (int n = 0; n < NV; ++n) {
         double up_, lo_;
-        faces_of(S.Q[n][ry - 1][cx + FH], S.Q[n][ry][cx + FH], S.Q[n][ry + 1][cx + FH], r, fastp, up_, lo_);
+        faces_of(FT, S.Q[n][ry - 1][cx + FH], S.Q[n][ry][cx + FH], S.Q[n][ry + 1][cx + FH], r, up_, lo_);
         if (side) S.LOY[n][cx] = lo_;
         else S.UPY[n][0][cx] = up_;
       }
     }
+    PROF(1);
     __syncthreads();
+    PROF(2);
     // ---- P2: Riemann problems at the own lower faces; the tile's upper perimeter on one duty wave --------------------
     if (tx == 0) { CGET6(L, S.UPX0, [ty]); }
-    Flux8 fx_lo = solve_fluid<DUST, RIEMANN, 1>(gk, L, lox, fastp);
+    fx_lo = solve_fluid<DUST, RIEMANN, 1>(gk, L, lox, fastp);
     {
       double h[3];
       CO(tx + FH, ty + FH, k).face_scale(1, h); // ScaleMomentumFlux (fluid_fluxes.hpp:33-70; h1 == 1)
       fx_lo.m2 *= h[1], fx_lo.m3 *= h[2];
     }
-    Flux8 fy_lo = fx_lo;
+    fy_lo = fx_lo;
     if (multi_d) {
       CGET6(L, S.UPY, [ty][tx]);
       fy_lo = solve_fluid<DUST, RIEMANN, 2>(gk, L, loy, fastp);
@@ -637,29 +705,33 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     }
     __builtin_amdgcn_s_setprio(0);
     if (stage_next) stage_plane(qn, hal_next, (k + 1) & 1);
+    PROF(3);
     __syncthreads();
-    // ---- P3 (first part): the upper faces from the neighbours, folded at once -----------------------------------------
-    {
-      Flux8 fx_hi;
-      fx_hi.d = lane_above(fx_lo.d), fx_hi.m1 = lane_above(fx_lo.m1), fx_hi.m2 = lane_above(fx_lo.m2);
-      fx_hi.m3 = lane_above(fx_lo.m3);
-      if constexpr (!DUST) {
-        fx_hi.e = lane_above(fx_lo.e), fx_hi.eg = lane_above(fx_lo.eg);
-        fx_hi.pf = lane_above(fx_lo.pf), fx_hi.vf = lane_above(fx_lo.vf);
-      }
-      if (tx == FTX - 1) { CGET8(fx_hi, S.FXE, [ty]); }
-      // (the zone's Coords are rebuilt from the tables in every phase that needs them: nothing of them crosses a barrier)
-      const auto co = CO(tx + FH, ty + FH, k);
-      const CellMetric cm = cell_metric_of(co);
-      const double dt_vol = div(bdt, recip(cm.vol));
-      double b1[2], b2[2], b3[2];
-      co.rf_weights(b1, b2, b3);
-      fold(std::integral_constant<int, 1>{}, s, fx_lo, fx_hi, cm.ax1[0], cm.ax1[1], b1[0], b1[1], div(bdt, cm.dx[0]), dt_vol, true);
-      Flux8 fy_hi = fx_hi;
-      if (multi_d) { CGET8(fy_hi, S.FY, [ty][tx]); }
-      fold(std::integral_constant<int, 2>{}, s, fy_lo, fy_hi, cm.ax2[0], cm.ax2[1], b2[0], b2[1], multi_d ? div(bdt, cm.dx[1]) : 0.0,
-           dt_vol, multi_d);
+    PROF(4);
+  };
+  // (the wave-uniform, in fact workgroup-uniform, choice: S.tiny is read between two barriers by every thread)
+  auto plane12 = [&](const int k, const Cell6 &qc, const bool stage_next, const Cell6 &qn, const Raw5 &hal_next, Flux8 &fx_lo,
+                     Flux8 &fy_lo) {
+    bool fastp = true;
+    if constexpr (PG) {
+      fastp = (S.tiny[k & 1] == 0);
+      if (t == 0) S.tiny[(k + 1) & 1] = 0; // set again when the next plane is staged (after the first barrier)
     }
+    if (fastp) phase12(std::true_type{}, k, qc, stage_next, qn, hal_next, fx_lo, fy_lo);
+    else phase12(std::false_type{}, k, qc, stage_next, qn, hal_next, fx_lo, fy_lo);
+  };
+  // ---- after the second barrier: the upper x1 / x2 faces from the neighbours; everything folded with ONE rebuild of the
+  // zone's Coords / CellMetric from the tables (nothing of them crosses a barrier) ----------------------------------
+  auto upper12 = [&](const Flux8 &fx_lo, Flux8 &fx_hi, Flux8 &fy_hi) {
+    fx_hi.d = lane_above(fx_lo.d), fx_hi.m1 = lane_above(fx_lo.m1), fx_hi.m2 = lane_above(fx_lo.m2);
+    fx_hi.m3 = lane_above(fx_lo.m3);
+    if constexpr (!DUST) {
+      fx_hi.e = lane_above(fx_lo.e), fx_hi.eg = lane_above(fx_lo.eg);
+      fx_hi.pf = lane_above(fx_lo.pf), fx_hi.vf = lane_above(fx_lo.vf);
+    }
+    if (tx == FTX - 1) { CGET8(fx_hi, S.FXE, [ty]); }
+    fy_hi = fx_hi;
+    if (multi_d) { CGET8(fy_hi, S.FY, [ty][tx]); }
   };
 
   // ---- the march ------------------------------------------------------------------------------------------------------
@@ -668,23 +740,32 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   double ds[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   auto load_ds = [&](unsigned c) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) ds[q] = gld(a.dsum[b * 5 + q], c);
+    for (int q = 0; q < 5; ++q) ds[q] = gld(S.C.dsum[q], c);
   };
   if constexpr (!D3) {
     const unsigned c0 = col + static_cast<unsigned>(k0) * sk;
     const Cell6 qc = ldcell(in_r, in_1, in_2, in_3, in_e, c0);
-    if (a.has_u1) u1raw = ldraw(u1_r, u1_1, u1_2, u1_3, u1_e, c0);
+    if (a.has_u1) u1raw = ldraw(S.C.u1[0], S.C.u1[1], S.C.u1[2], S.C.u1[3], S.C.u1[4], c0);
     if (a.diff_on) load_ds(c0);
     Raw5 hal = u1raw;
     if (hr >= 0) hal = ldraw(in_r, in_1, in_2, in_3, in_e, hcol + static_cast<unsigned>(k0) * sk);
     stage_plane(qc, hal, k0 & 1);
     __syncthreads();
     Sums s;
-    plane(k0, qc, false, qc, hal, s);
+    Flux8 fx_lo, fy_lo, fx_hi, fy_hi;
+    plane12(k0, qc, false, qc, hal, fx_lo, fy_lo);
+    upper12(fx_lo, fx_hi, fy_hi);
     double c3 = 1.0, s3 = 0.0;
-    if (m3) c3 = m3[MT3_COS * (P.nk + 1) + k0], s3 = m3[MT3_SIN * (P.nk + 1) + k0];
+    c3 = S.C3[0], s3 = S.S3[0];
     const auto co = CO(tx + FH, ty + FH, k0, c3, s3);
     const CellMetric cm = cell_metric_of(co);
+    const double bdt = S.C.bdt;
+        const double dt_vol = div(bdt, recip(cm.vol));
+    double b1[2], b2[2], b3[2];
+    co.rf_weights(b1, b2, b3);
+    fold(std::integral_constant<int, 1>{}, s, fx_lo, fx_hi, cm.ax1[0], cm.ax1[1], b1[0], b1[1], div(bdt, cm.dx[0]), dt_vol, true);
+    fold(std::integral_constant<int, 2>{}, s, fy_lo, fy_hi, cm.ax2[0], cm.ax2[1], b2[0], b2[1], multi_d ? div(bdt, cm.dx[1]) : 0.0,
+         dt_vol, multi_d);
     double hx[3];
     scale_factors_of(co, hx);
     s.tm[2] = s.te[2] = 0.0, s.rfx[2] = 0 * 0.5 * (0.0 + 0.0);
@@ -699,10 +780,12 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       PlmG r{};
       if constexpr (PG) r = rec_x3(tx + FH, ty + FH, k0 - 1);
       double unused_;
-#define ZL0(m, n) if constexpr (n < NV) faces_of(qmm.m, qc.m, qn.m, r, false, zl.m, unused_);
+#define ZL0(m, n) if constexpr (n < NV) faces_of(std::false_type{}, qmm.m, qc.m, qn.m, r, zl.m, unused_);
       CFOR6(ZL0)
 #undef ZL0
     }
+#define ZPUT(m, n) if constexpr (n < NV) S.ZL[n][t] = zl.m;
+    CFOR6(ZPUT)
     Flux8 fz_lo;
     fz_lo.d = fz_lo.m1 = fz_lo.m2 = fz_lo.m3 = fz_lo.e = fz_lo.eg = fz_lo.pf = fz_lo.vf = 0.0;
     Raw5 hal = u1raw; // halo zone of plane k+1 (staged by trip k)
@@ -711,45 +794,76 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       const Raw5 rnn = ldraw(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k + 2) * sk);
       const bool live = k >= k0;
       const unsigned ck = col + static_cast<unsigned>(max(k, 0)) * sk;
-      if (a.has_u1 && live) u1raw = ldraw(u1_r, u1_1, u1_2, u1_3, u1_e, ck);
-      if (hr >= 0 && k < k1) hal = ldraw(in_r, in_1, in_2, in_3, in_e, hcol + static_cast<unsigned>(k + 1) * sk);
-      if (a.diff_on && live) load_ds(ck);
-      double c3 = 1.0, s3 = 0.0;
-      if (m3 && live) c3 = m3[MT3_COS * (P.nk + 1) + k], s3 = m3[MT3_SIN * (P.nk + 1) + k];
+      // (UNCONDITIONAL, like every load of the trip: behind a branch the compiler's s_waitcnt for an OLDER load must
+      // assume the younger ones were not issued and waits for them as well -- the prefetch would be waited for in full.
+      // Threads without a halo zone fetch their own zone again: hcol == col for them, the line is in L1.)
+      hal = ldraw(in_r, in_1, in_2, in_3, in_e, hcol + static_cast<unsigned>(min(k + 1, P.nk - 1)) * sk);
       Sums s;
       if (live) {
-        plane(k, qc, k < k1, qn, hal, s);
+        Flux8 fx_lo, fy_lo, fx_hi, fy_hi;
+        plane12(k, qc, k < k1, qn, hal, fx_lo, fy_lo);
+        upper12(fx_lo, fx_hi, fy_hi);
+        // the x1 / x2 faces are folded at once (only the sums live through the x3 sweep); the zone's Coords are rebuilt
+        // from the tables wherever they are needed: nothing of them crosses a barrier or the sweep
+        const auto co = CO(tx + FH, ty + FH, k);
+        const CellMetric cm = cell_metric_of(co);
+        const double bdt = S.C.bdt;
+        const double dt_vol = div(bdt, recip(cm.vol));
+        double b1[2], b2[2], b3[2];
+        co.rf_weights(b1, b2, b3);
+        fold(std::integral_constant<int, 1>{}, s, fx_lo, fx_hi, cm.ax1[0], cm.ax1[1], b1[0], b1[1], div(bdt, cm.dx[0]), dt_vol, true);
+        fold(std::integral_constant<int, 2>{}, s, fy_lo, fy_hi, cm.ax2[0], cm.ax2[1], b2[0], b2[1], div(bdt, cm.dx[1]), dt_vol, true);
+        PROF(5);
       } else { // priming trip: stage the first plane
         stage_plane(qn, hal, k0 & 1);
         __syncthreads();
       }
       // x3 sweep, registers only: slope of zone k+1, face k+1
       const Cell6 qnn = finish_cell(rnn, gm1);
+      // what only the update reads (start-of-step state, viscous sums) is fetched here, AFTER the trip's prefetch has been
+      // consumed (these loads sit behind run-time conditions: see above): the x3 sweep covers their latency, and ten
+      // doubles less are alive through the plane's two LDS phases
+      // (the trip's prefetch has arrived -- the halo zone was staged before the last barrier --, so this wait is free; it
+      // tells the compiler's counter model so, wherever its scheduler moves the conditional loads below)
+      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+      if (a.has_u1 && live) u1raw = ldraw(S.C.u1[0], S.C.u1[1], S.C.u1[2], S.C.u1[3], S.C.u1[4], ck);
+      if (a.diff_on && live) load_ds(ck);
       Cell6 zr, zl_next;
-      {
+      Flux8 fz_hi;
+      auto sweep3 = [&](auto FT) {
         PlmG r{};
-        bool fast3 = true;
-        if constexpr (PG) {
-          r = rec_x3(tx + FH, ty + FH, k + 1);
-          // the own column's three zones decide for the wave whether the hand-scheduled divisions are safe
-          const bool tiny3 = tiny_nonzero(qc.v1) || tiny_nonzero(qc.v2) || tiny_nonzero(qc.v3) || tiny_nonzero(qn.v1) ||
-                             tiny_nonzero(qn.v2) || tiny_nonzero(qn.v3) || tiny_nonzero(qnn.v1) || tiny_nonzero(qnn.v2) ||
-                             tiny_nonzero(qnn.v3);
-          fast3 = !__any(tiny3);
-        }
-#define ZSL(m, n) if constexpr (n < NV) faces_of(qc.m, qn.m, qnn.m, r, fast3, zl_next.m, zr.m);
-        CFOR6(ZSL)
+        if constexpr (PG) r = rec_x3(tx + FH, ty + FH, k + 1);
+#define ZSL(m, n) if constexpr (n < NV) faces_of(FT, qc.m, qn.m, qnn.m, r, zl_next.m, zr.m);
+        CFOR6_33(ZSL)
 #undef ZSL
+        Cell6 zl; // (written by this thread in the previous trip: no barrier needed)
+#define ZGET(m, n) if constexpr (n < NV) zl.m = S.ZL[n][t];
+        CFOR6(ZGET)
+#undef ZGET
+        fz_hi = solve_fluid<DUST, RIEMANN, 3>(gk, zl, zr, true);
+        zl = zl_next;
+        CFOR6(ZPUT)
+      };
+      bool fast3 = true;
+      if constexpr (PG) {
+        // the own column's three zones decide for the wave whether the hand-scheduled divisions are safe
+        const bool tiny3 = tiny_nonzero(qc.v1) || tiny_nonzero(qc.v2) || tiny_nonzero(qc.v3) || tiny_nonzero(qn.v1) ||
+                           tiny_nonzero(qn.v2) || tiny_nonzero(qn.v3) || tiny_nonzero(qnn.v1) || tiny_nonzero(qnn.v2) ||
+                           tiny_nonzero(qnn.v3);
+        fast3 = !__any(tiny3);
       }
-      Flux8 fz_hi = solve_fluid<DUST, RIEMANN, 3>(gk, zl, zr, true);
+      if (fast3) sweep3(std::true_type{});
+      else sweep3(std::false_type{});
+      PROF(6);
       {
         double h[3];
         CO(tx + FH, ty + FH, k0).face_scale(3, h); // ScaleMomentumFlux at the x3 face (no x3 dependence)
         fz_hi.m2 *= h[1], fz_hi.m3 *= h[2];
       }
       if (live) {
-        const auto co = CO(tx + FH, ty + FH, k, c3, s3);
+        const auto co = CO(tx + FH, ty + FH, k, S.C3[k - k0], S.S3[k - k0]);
         const CellMetric cm = cell_metric_of(co);
+        const double bdt = S.C.bdt;
         const double dt_vol = div(bdt, recip(cm.vol));
         double b1[2], b2[2], b3[2];
         co.rf_weights(b1, b2, b3);
@@ -757,10 +871,17 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
         double hx[3];
         scale_factors_of(co, hx);
         update(k, co, cm, hx, qc, s, u1raw, ds);
+        PROF(7);
       }
-      fz_lo = fz_hi, zl = zl_next, qc = qn, qn = qnn;
+      fz_lo = fz_hi, qc = qn, qn = qnn;
     }
+#undef ZPUT
   }
+#ifdef CURV_PROF
+  PROF(8);
+  if ((t & 63) == 0)
+    for (int q = 0; q < 10; ++q) atomicAdd(&g_curv_prof[q], prof_acc[q]);
+#endif
   if (a.dt_bits) {
     __syncthreads();
     for (int off = 32; off > 0; off >>= 1) ldt = fmin(ldt, __shfl_down(ldt, off, 64));
@@ -769,7 +890,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     if (t == 0) {
       double m = S.wmin[0];
       for (int w = 1; w < 4; ++w) m = fmin(m, S.wmin[w]);
-      if (m < DBL_MAX) atomicMin(a.dt_bits, static_cast<unsigned long long>(__double_as_longlong(a.cfl * m)));
+      if (m < DBL_MAX) atomicMin(a.dt_bits, static_cast<unsigned long long>(__double_as_longlong(S.C.cfl * m)));
     }
   }
 }
@@ -905,4 +1026,14 @@ void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g,
 #undef CURV_SYS
 }
 
+#ifdef CURV_PROF
+extern "C" int artemis_hip_debug_curv_prof(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_curv_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_curv_prof), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 } // namespace artemis

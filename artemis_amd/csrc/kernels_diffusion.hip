@@ -445,7 +445,6 @@ struct VsArgs {
   const double *dt_ptr;
   double *const *out; // [nblocks * 5]: what DiffusionUpdate subtracts from M1, M2, M3, E and e_int
   int nti, ntj, nchunk, kchunk;
-  int abl; // timing experiments (ARTEMIS_VS_ABL; results wrong by construction): 1 no barriers, 2 no distance loads, 4 no faces, 8 no ring duty
 };
 template <int VTX>
 struct VsTile {
@@ -472,18 +471,25 @@ struct TileGeo {
   ADEV int row(int j) const { return min(max(j - jbase, 0), NY - 1); }
   ADEV DCoordsT<true> coords(int k, int j, int i) const {
     // SYS is a compile-time constant: every switch on the coordinate system inside Coords folds away
-    return geotabs_coords(G, SYS, P.geom + 6 * b, col(i), row(j), k, 1.0, 0.0); // (nothing here reads c3 / s3)
+    return geotabs_coords(G, SYS, col(i), row(j), k, 1.0, 0.0); // (nothing here reads c3 / s3)
   }
   ADEV void conn(int, int j, int i, double &d21, double &d31, double &d32) const {
     d21 = d31 = d32 = 0.0;
     if constexpr (CURV) d21 = G.gi[GI_DH2][col(i)], d31 = G.gi[GI_DH3][col(i)], d32 = G.gj[GJ_DH32][row(j)];
   }
 };
-ADEV Vel6 load6(double *const *prim, const double *radial, int b, unsigned c) {
+// The block's five primitive arrays, read from the pack's pointer table ONCE, before the march: inside it the kernel has
+// stores in flight, a table entry would come through a vector load (no scalar load next to stores) with a vmcnt(0) wait
+// behind it -- which also waits for every prefetch of the trip.
+struct Prim5Ptr {
+  const double *d, *v1, *v2, *v3, *e;
+};
+// (radial: the viscosity law's radial factor, or -- no such law -- any array of the block: the caller ignores the value)
+ADEV Vel6 load6(const Prim5Ptr &p, const double *radial, unsigned c) {
   Vel6 q;
-  q.d = fused::gld(prim[b * 6 + 0], c), q.v1 = fused::gld(prim[b * 6 + 1], c), q.v2 = fused::gld(prim[b * 6 + 2], c);
-  q.v3 = fused::gld(prim[b * 6 + 3], c), q.e = fused::gld(prim[b * 6 + 5], c);
-  q.rad = radial ? fused::gld(radial, c) : 1.0;
+  q.d = fused::gld(p.d, c), q.v1 = fused::gld(p.v1, c), q.v2 = fused::gld(p.v2, c);
+  q.v3 = fused::gld(p.v3, c), q.e = fused::gld(p.e, c);
+  q.rad = fused::gld(radial, c);
   return q;
 }
 #ifndef VS_OCC
@@ -519,9 +525,12 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
   const int il = min(i, P.ni - 1), jl = min(j, P.nj - 1);
   const unsigned sj = static_cast<unsigned>(P.sj), sk = static_cast<unsigned>(P.sk);
   const unsigned col = static_cast<unsigned>(jl) * sj + static_cast<unsigned>(il);
-  double *const *prim = P.gas.prim;
+  const Prim5Ptr prim{P.gas.prim[b * 6 + 0], P.gas.prim[b * 6 + 1], P.gas.prim[b * 6 + 2], P.gas.prim[b * 6 + 3], P.gas.prim[b * 6 + 5]};
+  double *const o_m1 = a.out[b * 5 + 0], *const o_m2 = a.out[b * 5 + 1], *const o_m3 = a.out[b * 5 + 2];
+  double *const o_e = a.out[b * 5 + 3], *const o_eg = a.out[b * 5 + 4];
   const artemis_diffcoeff_t &dp = a.D.visc;
-  const double *radial = dp.radial ? dp.radial[b] : nullptr;
+  const bool has_radial = dp.radial != nullptr;
+  const double *radial = has_radial ? dp.radial[b] : prim.d; // (load6 fetches unconditionally)
   const double dt = a.dt_ptr ? *a.dt_ptr : a.dt;
   const TileGeo<SYS, QX, QY> ge{P, b, i0 - 2, j0 - 2, GT};
   geotabs_fill(GT, P, b, i0 - 2, j0 - 2, t);
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
   }
   const bool h_any = hr >= 0;
   const int gi = min(max(i0 - 2 + hc, 0), P.ni - 1), gj = min(max(j0 - 2 + hr, 0), P.nj - 1);
-  const unsigned hcol = static_cast<unsigned>(gj) * sj + static_cast<unsigned>(gi);
+  const unsigned hcol = h_any ? static_cast<unsigned>(gj) * sj + static_cast<unsigned>(gi) : col;
   const bool h_s = h_any && hr >= 1 && hr <= QY - 2 && hc >= 1 && hc <= QX - 2; // within one zone of the tile
   const bool h_ring = h_any && (((hr == 1 || hr == QY - 2) && hc >= 2 && hc <= QX - 3) ||
                                 ((hc == 1 || hc == QX - 2) && hr >= 2 && hr <= QY - 3)); // a face neighbour of the tile
@@ -575,19 +584,19 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
   };
   auto viscosity = [&](const Vel6 &q) { // (alpha law: one quotient by the radial factor; tiny numerators take `/`)
     const bool odd = dp.type == ARTEMIS_VISCOSITY_ALPHA && tiny_nonzero(q.d * q.e);
-    return viscosity_of(dp, P.gm1, q.d, q.e, q.rad, !__any(odd));
+    return viscosity_of(dp, P.gm1, q.d, q.e, has_radial ? q.rad : 1.0, !__any(odd));
   };
   // Rolling state.  Nothing a trip loads is consumed in that trip: the own / halo zone's primitives arrive one plane
   // before they are staged (the x3 velocity two planes before: it closes the divergence of the plane below), the
   // distances one trip before the faces that use them.
   const int kmax = P.nk - 1;
   auto plane = [&](int kk) { return static_cast<unsigned>(min(max(kk, 0), kmax)) * sk; };
-  Vel6 rn = load6(prim, radial, b, col + plane(k0 - 1)), hn = rn;
-  double vc[3] = {0.0, 0.0, fused::gld(prim[b * 6 + 3], col + plane(k0 - 2))}, h3c = 0.0;
-  double v3n2 = fused::gld(prim[b * 6 + 3], col + plane(k0)), h3n2 = 0.0; // x3 velocity of plane k + 2
+  Vel6 rn = load6(prim, radial, col + plane(k0 - 1)), hn = rn;
+  double vc[3] = {0.0, 0.0, fused::gld(prim.v3, col + plane(k0 - 2))}, h3c = 0.0;
+  double v3n2 = fused::gld(prim.v3, col + plane(k0)), h3n2 = 0.0; // x3 velocity of plane k + 2
   if (h_any) {
-    hn = load6(prim, radial, b, hcol + plane(k0 - 1));
-    h3c = fused::gld(prim[b * 6 + 3], hcol + plane(k0 - 2)), h3n2 = fused::gld(prim[b * 6 + 3], hcol + plane(k0));
+    hn = load6(prim, radial, hcol + plane(k0 - 1));
+    h3c = fused::gld(prim.v3, hcol + plane(k0 - 2)), h3n2 = fused::gld(prim.v3, hcol + plane(k0));
   }
   double dv_c = 0.0, mu_c = 0.0;
   double f3lo[4] = {0.0, 0.0, 0.0, 0.0};
@@ -595,24 +604,33 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
   // face above it needs of plane k + 1 (to the lower x3 neighbour, across along x1 and x2)
   double dl1 = 1.0, dl2 = 1.0, da1 = 1.0, da2 = 1.0, da3 = 1.0;
   double ul3 = 1.0, ua1 = 1.0, ua2 = 1.0;
-  if (!(a.abl & 2)) {
+  {
     const unsigned c1 = col + plane(k0 - 1);
     ul3 = fused::gld(dtab + 2 * dq, c1), ua1 = fused::gld(dtab + 3 * dq, c1), ua2 = fused::gld(dtab + 4 * dq, c1);
   }
   double nb0 = 1.0, nb1 = 1.0, nb2 = 1.0, nb3 = 1.0; // across the lower neighbours just outside the tile (edge lanes), plane k
   double dd0 = 1.0, dd1 = 1.0, dd2 = 1.0;            // this trip's perimeter duty: to the lower neighbour, across x2|x1, across x3
+  double pend[5] = {0.0, 0.0, 0.0, 0.0, 0.0}; // the sums of the zone finished in the previous trip
+  unsigned pend_c = 0;
+  bool pend_on = false;
+  auto flush = [&]() {
+    if (pend_on) {
+      fused::gst(o_m1, pend_c, pend[0]), fused::gst(o_m2, pend_c, pend[1]), fused::gst(o_m3, pend_c, pend[2]);
+      fused::gst(o_e, pend_c, pend[3]), fused::gst(o_eg, pend_c, pend[4]);
+    }
+    pend_on = false;
+  };
   for (int k = k0 - 2; k <= k1; ++k) {
     const bool live = k >= k0; // (wave-uniform) faces of plane k are formed
+    flush();
     // ---- this trip's global loads, all of them, first -------------------------------------------------------------
-    Vel6 rnn = rn;
-    double v3n3 = v3n2;
-    if (!(a.abl & 128)) {
-      rnn = load6(prim, radial, b, col + plane(k + 2)); // (its v3 slot is replaced by the value fetched a trip ago)
-      v3n3 = fused::gld(prim[b * 6 + 3], col + plane(k + 3));
-    }
-    Vel6 hnn = rnn;
-    double h3n3 = v3n3;
-    if (h_any && !(a.abl & 64)) hnn = load6(prim, radial, b, hcol + plane(k + 2)), h3n3 = fused::gld(prim[b * 6 + 3], hcol + plane(k + 3));
+    // Every load of the own / halo zone is UNCONDITIONAL (threads without a halo zone fetch their own zone again: hcol ==
+    // col for them): behind a branch, the compiler's s_waitcnt for an older load has to assume the younger ones were not
+    // issued, i.e. it waits for all of them.  And nothing may read a value in the trip that loads it -- not even a copy.
+    const Vel6 rnn = load6(prim, radial, col + plane(k + 2)); // (its v3 slot is replaced by the value fetched a trip ago)
+    const double v3n3 = fused::gld(prim.v3, col + plane(k + 3));
+    const Vel6 hnn = load6(prim, radial, hcol + plane(k + 2));
+    const double h3n3 = fused::gld(prim.v3, hcol + plane(k + 3));
     const unsigned cn1 = col + static_cast<unsigned>(k + 1) * sk, cn2 = col + plane(k + 2);
     double nl1 = 1.0, nl2 = 1.0, na3 = 1.0;  // plane k + 1: for the next trip's x1 / x2 faces
     double wl3 = 1.0, wa1 = 1.0, wa2 = 1.0;  // plane k + 2: for the next trip's x3 face
@@ -623,7 +641,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
     const bool duty1 = live && duty < VTY, duty2 = live && duty >= 64 && duty < 64 + VTX;
     const int dj1 = min(j0 + duty, P.nj - 1), di1 = min(i0 + VTX, P.ni - 1);        // the x1 face of zone (j0 + duty, i0 + VTX)
     const int dj2 = min(j0 + VTY, P.nj - 1), di2 = min(i0 + (duty - 64), P.ni - 1); // the x2 face of zone (j0 + VTY, i0 + duty - 64)
-    if (!(a.abl & 2)) {
+    {
       nl1 = fused::gld(dtab, cn1), nl2 = fused::gld(dtab + dq, cn1), na3 = fused::gld(dtab + 5 * dq, cn1);
       wl3 = fused::gld(dtab + 2 * dq, cn2), wa1 = fused::gld(dtab + 3 * dq, cn2), wa2 = fused::gld(dtab + 4 * dq, cn2);
       if (k + 1 >= k0 && k < k1) { // (trip k + 1 forms faces)
@@ -659,7 +677,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
           for (int m = 0; m < 3; ++m) L.S[pn][m][hr - 1][hc - 1] = sh[m];
       }
     }
-    if (!(a.abl & 1)) __syncthreads();
+    __syncthreads();
     // ---- (c) faces of plane k ----------------------------------------------------------------------------------------
     // the stress rows of the lower DIR face of the zone at (row sy, column sx) of the S rectangle, block indices (k, jj, ii);
     // d5 = {to the lower neighbour, across the zone / across the lower neighbour along the first transverse direction,
@@ -680,7 +698,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
       q.divu = L.DV[dc][sy][sx], q.divu_m = L.DV[dc][sy - dy][sx - dx];
       viscous_face_core<DIR>(fg, q, dp.avg, dp.eta, fl, fe, valid);
     };
-    if (live && !(a.abl & 4)) {
+    if (live) {
       {
         const double d5[5] = {dl1, da2, (tx == 0) ? nb0 : L.DA[1][ty][max(tx - 1, 0)], da3, (tx == 0) ? nb1 : L.DA[2][ty][max(tx - 1, 0)]};
         double fl[4];
@@ -712,7 +730,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
     const double dv_n = divergence(k + 1, jl, il, ty + 2, tx + 2, vc[2], rn.v3, v3n2);
     const double mu_n = viscosity(rn);
     L.DV[dn][ty + 1][tx + 1] = dv_n, L.MU[dn][ty + 1][tx + 1] = mu_n;
-    if (t < ((NRING + 63) & ~63) && !(a.abl & 8)) {
+    if (t < ((NRING + 63) & ~63)) {
       const int qr = h_ring ? hr : 2, qc = h_ring ? hc : 2;
       const double dvh = divergence(k + 1, gj, gi, qr, qc, h3c, hn.v3, h3n2);
       const double muh = viscosity(hn);
@@ -733,7 +751,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
       q.mu1 = mu_n, q.mu2 = mu_c, q.divu = dv_n, q.divu_m = dv_c;
       viscous_face_core<3>(fg, q, dp.avg, dp.eta, f3hi, f3hi[3], active);
     }
-    if (!(a.abl & 1)) __syncthreads();
+    __syncthreads();
     // ---- (d) DiffusionUpdate's sums of zone k (diffusion.hpp:110-241) -----------------------------------------------
     if (live && active) {
       double F[3][2][4];
@@ -749,11 +767,10 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
       double dm[3], de, deg;
       auto FF = [&](int d, int var, int u) { return F[d][u][var]; };
       diffusion_update_core<true>(g, FF, 0, 1, 1, dt, vc, dm, de, deg);
-      const unsigned c = col + static_cast<unsigned>(k) * sk;
-      if (!(a.abl & 32) || dm[0] == 1.2345) {
-        fused::gst(a.out[b * 5 + 0], c, dm[0]), fused::gst(a.out[b * 5 + 1], c, dm[1]), fused::gst(a.out[b * 5 + 2], c, dm[2]);
-        fused::gst(a.out[b * 5 + 3], c, de), fused::gst(a.out[b * 5 + 4], c, deg);
-      }
+      // (stored at the top of the next trip, in front of its loads: as the youngest memory operations of this trip the
+      // stores would be waited for by the next trip's first read of a prefetched value)
+      pend[0] = dm[0], pend[1] = dm[1], pend[2] = dm[2], pend[3] = de, pend[4] = deg;
+      pend_c = col + static_cast<unsigned>(k) * sk, pend_on = true;
     }
     vc[0] = rn.v1, vc[1] = rn.v2, vc[2] = rn.v3;
     rn = rnn, rn.v3 = v3n2, v3n2 = v3n3;
@@ -764,6 +781,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
     ul3 = wl3, ua1 = wa1, ua2 = wa2;
     nb0 = nnb0, nb1 = nnb1, nb2 = nnb2, nb3 = nnb3, dd0 = ndd0, dd1 = ndd1, dd2 = ndd2;
   }
+  flush();
 }
 
 // ---- viscous fluxes of LISTED faces (refined meshes on the one-kernel stages) ------------------------------------
@@ -1142,7 +1160,6 @@ void launch_viscous_source(const PackView &P, const artemis_diffusion_t &D, doub
                            hipStream_t s) {
   VsArgs a;
   a.D = D, a.dt = dt, a.dt_ptr = dt_dev, a.out = out;
-  a.abl = getenv("ARTEMIS_VS_ABL") ? atoi(getenv("ARTEMIS_VS_ABL")) : 0;
   const int nx = P.ie - P.is + 1, ny = P.je - P.js + 1, nz = P.ke - P.ks + 1;
   // tile shape: 32 x 8, or 16 x 16 where a 32-zone row would leave half the lanes without a zone (16-zone blocks)
   const bool narrow = (nx % 32 != 0) && (nx % 16 == 0 || nx < 32);

@@ -24,7 +24,9 @@ ADEV void scale_factors_of(const CO &co, double hx[3]) {
 }
 
 // PrimToCons of one cell (fill_derived.cpp:229-274): floors are re-applied like the reference does
-ADEV GasCons prim_to_cons_gas(const FluidView &f, double d, double v1, double v2, double v3,
+// (F: a FluidView, or any record with dfloor / siefloor -- the march kernels keep the floors in LDS)
+template <class F>
+ADEV GasCons prim_to_cons_gas(const F &f, double d, double v1, double v2, double v3,
                               double se, const double hx[3]) {
   GasCons u;
   const double w_d = (d > f.dfloor) ? d : f.dfloor;
@@ -36,7 +38,8 @@ ADEV GasCons prim_to_cons_gas(const FluidView &f, double d, double v1, double v2
   u.e = u.eg + ke;
   return u;
 }
-ADEV DustCons prim_to_cons_dust(const FluidView &f, double d, double v1, double v2, double v3,
+template <class F>
+ADEV DustCons prim_to_cons_dust(const F &f, double d, double v1, double v2, double v3,
                                 const double hx[3]) {
   DustCons u;
   const double w_d = (d > f.dfloor) ? d : f.dfloor;
@@ -52,8 +55,13 @@ struct GravAcc {
   double gx1, gx2, gx3, fd;
   bool uniform;
 };
-template <class CO>
-ADEV GravAcc gravity_accel(const artemis_gravity_t &G, const CO &co, int ndim, double dt) {
+// FAST (the march kernels, which wait for their own instructions): the point-mass law of the Cartesian-frame systems
+// with the hand-scheduled square root and division of device_math.hpp wherever the whole wave holds positive normal
+// operands (the cylindrical radius of a zone centre vanishes only on the axis; such a wave takes the plain forms), and
+// the sink's two quotients skipped when no lane has a sink rate: the fraction is then exactly + 0.0
+// (min(0.5, x) * false, NaN-safe as written).  Same bits as FAST = false.
+template <bool FAST = false, class CO, class GR>
+ADEV GravAcc gravity_accel(const GR &G, const CO &co, int ndim, double dt) {
   GravAcc a;
   a.gx1 = 0.0, a.gx2 = 0.0, a.gx3 = 0.0, a.fd = 0.0;
   a.uniform = (G.type == ARTEMIS_GRAVITY_UNIFORM);
@@ -114,11 +122,21 @@ ADEV GravAcc gravity_accel(const artemis_gravity_t &G, const CO &co, int ndim, d
     const Frame fr = cart_frame(co.sys, dx, co.cv, co.sv, cyl ? co.cv : co.c3, cyl ? co.sv : co.s3);
     double dxc[3] = {fr.x[0], fr.x[1], fr.x[2]};
     for (int n = 0; n < 3; n++) dxc[n] -= G.pos[n];
-    const double R = sqrt(dxc[0] * dxc[0] + dxc[1] * dxc[1]);
-    const double r = sqrt(R * R + dxc[2] * dxc[2]);
-    dr = r;
-    const double rad2 = sqr(dr) + rsft2;
-    const double idr3 = 1.0 / (sqrt(rad2) * rad2);
+    const double R2 = dxc[0] * dxc[0] + dxc[1] * dxc[1];
+    double idr3;
+    if (FAST && !__any(!(R2 > 0x1p-400) || !(R2 < 0x1p400) || !(fabs(dxc[2]) < 0x1p200) || !(rsft2 < 0x1p400))) {
+      const double R = sqrt_pos(R2);
+      const double r = sqrt_pos(R * R + dxc[2] * dxc[2]);
+      dr = r;
+      const double rad2 = sqr(dr) + rsft2;
+      idr3 = div(1.0, recip(sqrt_pos(rad2) * rad2));
+    } else {
+      const double R = sqrt(R2);
+      const double r = sqrt(R * R + dxc[2] * dxc[2]);
+      dr = r;
+      const double rad2 = sqr(dr) + rsft2;
+      idr3 = 1.0 / (sqrt(rad2) * rad2);
+    }
     const double g[3] = {-gm * dxc[0] * idr3, (multi_d) * (-gm * dxc[1] * idr3),
                          (three_d) * (-gm * dxc[2] * idr3)};
     a.gx1 = g[0] * fr.e1[0] + g[1] * fr.e1[1] + g[2] * fr.e1[2];
@@ -126,6 +144,10 @@ ADEV GravAcc gravity_accel(const artemis_gravity_t &G, const CO &co, int ndim, d
     a.gx3 = g[0] * fr.e3[0] + g[1] * fr.e3[1] + g[2] * fr.e3[2];
   }
   const double sink_rate = dt * G.sink_rate;
+  if (FAST && !__any(sink_rate != 0.0)) { // (sramp is 0 or NaN, sfrac 0 or NaN, the minimum 0 or 0.5, times false)
+    a.fd = 0.0;
+    return a;
+  }
   const double sramp = sink_rate * sqr((dr - G.sink) / G.sink); // quad_ramp, gravity.hpp:116
   const double sfrac = sramp / (1.0 + sramp);
   a.fd = (sfrac < 0.5) ? sfrac : 0.5; // std::min(0.5, sfrac): a NaN ratio (sink = 0) keeps 0.5

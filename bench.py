@@ -219,8 +219,13 @@ def measured_traffic(name):
         if name == "" and rec.get("workload", "sedov3d") != "sedov3d":
             continue
         want = kernel_source_sha1(rec.get("sha_scope", "fused"))
-        if rec.get("kernel_source_sha1") == want and not rec.get("env"):  # default knobs only
-            return rec.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
+        if rec.get("kernel_source_sha1") != want or rec.get("env"):  # this checkout's kernels, default knobs only
+            continue
+        if name == "" and (not rec.get("headline_launches") or rec.get("headline_launches") != rec.get("headline_launches_expected")):
+            # a Sedov record must be a mean over full-size launches of the two headline instantiations and nothing
+            # else (round 4's mixed in the half-size shell / bulk launches of the overlap emulation): refuse it
+            continue
+        return rec.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -269,6 +274,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the `dropin` legs (fused + cons + whole-block PrimToCons, and the per-task chain)")
+    ap.add_argument("--no-overlap-emulation", action="store_true",
+                    help="skip the `overlap_emulation` leg (two half-size blocks, shell-first + bulk launches): profiles of "
+                         "the headline kernel then hold 256^3 launches only")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: exchange halos after the whole stage kernel instead of behind its bulk")
     ap.add_argument("--overlap-mode", type=int, default=1, choices=[1, 2],
@@ -526,7 +534,7 @@ def main():
         sim.set_kernel_timing(False)
     hist = sim.history()
     overlap_emulation = None
-    if (args.workload == "sedov3d" and args.gpus == 1 and not args.loopback and not args.no_dropin and sim.uses_tuned_kernel
+    if (args.workload == "sedov3d" and args.gpus == 1 and not args.loopback and not args.no_overlap_emulation and sim.uses_tuned_kernel
             and args.blocks_per_gpu == 1 and not os.environ.get("ARTEMIS_FORCE_OVERLAP")):
         # What a rank of an N > 1 run does per stage, emulated on this one GPU: the same zones as two blocks stacked along
         # x3 with the shell-first / bulk launch order forced (ARTEMIS_FORCE_OVERLAP: the boundary shell of every block is
