@@ -25,6 +25,21 @@ typedef char __attribute__((address_space(1))) *gbytes;
 ADEV double gld(const double *p, unsigned c) { return *(gcptr)((gcbytes)p + (c << 3)); }
 ADEV void gst(double *p, unsigned c, double v) { *(gptr)((gbytes)p + (c << 3)) = v; }
 
+// Tables the kernel never writes -- the pack's pointer tables, a block's edge table -- read INSIDE a march.  As a plain
+// global load such a read is a VECTOR load (the kernel has stores in flight, so the compiler may not use the scalar
+// cache) of a wave-uniform address, and the s_waitcnt vmcnt(0) behind it also waits for every prefetch of the trip.
+// Through the constant address space it is a scalar load (K-cache, lgkmcnt).  `opaque` keeps the index from being
+// loop-invariant to the compiler, which would otherwise hoist twenty such loads out of the march and park the results
+// in scalar registers it does not have (v_writelane / v_readlane around every use).
+template <class T>
+ADEV T kload(const T *p) {
+  return *(const __attribute__((address_space(4))) T *)(p);
+}
+ADEV int opaque(int i) {
+  asm volatile("" : "+s"(i));
+  return i;
+}
+
 template <class IDX>
 ADEV Cell6 load_cell(const double *__restrict__ r, const double *__restrict__ v1,
                      const double *__restrict__ v2, const double *__restrict__ v3,

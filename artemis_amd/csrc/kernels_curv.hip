@@ -828,6 +828,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
       if (a.has_u1 && live) u1raw = ldraw(S.C.u1[0], S.C.u1[1], S.C.u1[2], S.C.u1[3], S.C.u1[4], ck);
       if (a.diff_on && live) load_ds(ck);
+      PROF(9);
       Cell6 zr, zl_next;
       Flux8 fz_hi;
       auto sweep3 = [&](auto FT) {

@@ -37,6 +37,26 @@
 #include "sources_device.hpp"
 #include "task_device.hpp"
 
+// -DFUSED_PROF (development builds only: ARTEMIS_HIPFLAGS_KERNELS_FUSED=-DFUSED_PROF): every wave sums the shader-clock
+// cycles it spends in each phase of a plane (work and waiting alike); artemis_hip_debug_fused_prof reads the totals
+#ifdef FUSED_PROF
+__device__ unsigned long long g_fused_prof[16];
+#define FPROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define FPROF(slot)                                               \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    prof_acc[slot] += now_ - prof_t;                              \
+    prof_t = now_;                                                \
+  } while (0)
+#define FPROF_ARGS , unsigned long long &prof_t, unsigned long long *prof_acc
+#define FPROF_PASS , prof_t, prof_acc
+#else
+#define FPROF_DECL
+#define FPROF(slot)
+#define FPROF_ARGS
+#define FPROF_PASS
+#endif
+
 namespace artemis {
 namespace {
 
@@ -238,7 +258,8 @@ ADEV bool tiny_v(const Cell6 &q) { return tiny_vel3(q.v1, q.v2, q.v3); }
 template <int RIEMANN, int RECON, bool D3, bool CURV, bool GUARD, bool DETECT, class TILE>
 ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CURV> &gx, const int k,
                        const Cell6 &qc, const bool stage_next, const Cell6 &qn, const Raw5 &hal_next,
-                       Flux8 &fx_lo, Flux8 &fy_lo, bool &flagged, const bool det = true) {
+                       Flux8 &fx_lo, Flux8 &fy_lo, bool &flagged, const bool det FPROF_ARGS) {
+  FPROF(0);
   constexpr bool PG = CURV && RECON == 1; // PLM_G instead of the uniform-mesh slope
   bool fastp = true; // every division hand-scheduled (no tiny velocity in this plane's tile)
   if constexpr (GUARD || DETECT) {
@@ -341,7 +362,9 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
       else S.UPY[n][0][cx] = up_;
     }
   }
+  FPROF(1);
   __syncthreads();
+  FPROF(2);
   // ---- P2: Riemann problems at the own lower faces; perimeter faces on wave 1 ------------
   Cell6 L;
   GET6(L, S.UPX, [ty][tx]);
@@ -390,13 +413,16 @@ ADEV void plane_sweeps(TILE &S, const PackView &P, const Ctx &x, const GeoCtx<CU
 #if ARTEMIS_PERI_PRIO
   __builtin_amdgcn_s_setprio(0); // the duties are done
 #endif
+  FPROF(9);
   if (stage_next) {
     stage_plane(S, x, qn, hal_next);
     if constexpr (GUARD || DETECT) {
       if (GUARD || det) stage_plane_flag(S, x, qn, hal_next, (k + 1) & 1);
     }
   }
+  FPROF(3);
   __syncthreads();
+  FPROF(4);
 }
 
 // Phase P3 of the flux TASK (artemis_hip_calculate_fluxes through the tile march, FLUXES = true): instead of
@@ -465,9 +491,10 @@ ADEV void plane_update(TILE &S, const PackView &P, const StageK &a, const Ctx &x
   GET8(fx_hi, S.FX, [ty][tx]);
   if (multi_d) { GET8(fy_hi, S.FY, [ty][tx]); }
   if (!x.active) return;
-  const double *g = x.g;
+  const double *g = x.g + opaque(4); // (scalar loads at their use: fused_device.hpp kload)
   const double dx1 = x.dx1, dx2 = x.dx2;
-  const double dx3 = (g[4] + (k + 1) * g[5]) - (g[4] + k * g[5]);
+  const double g4 = kload(g), g5 = kload(g + 1);
+  const double dx3 = (g4 + (k + 1) * g5) - (g4 + k * g5);
   const double ax1 = dx2 * dx3, ax2 = dx1 * dx3, ax3 = dx1 * dx2; // geometry.hpp:199-216
   const double vol = dx1 * dx2 * dx3;                             // geometry.hpp:219-225
   const int b = x.b;
@@ -538,20 +565,22 @@ ADEV void plane_update(TILE &S, const PackView &P, const StageK &a, const Ctx &x
   if (a.tiny_out) { // report a vanishing velocity to the stage that will read this state (artemis_stage_args_t.tiny_out)
     if (tiny_vel3(w1, w2, w3)) __hip_atomic_fetch_or(a.tiny_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  gst(a.prim_out[b * 6 + 0], c, w_d);
-  gst(a.prim_out[b * 6 + 1], c, w1);
-  gst(a.prim_out[b * 6 + 2], c, w2);
-  gst(a.prim_out[b * 6 + 3], c, w3);
-  gst(a.prim_out[b * 6 + 4], c, w_p);
-  gst(a.prim_out[b * 6 + 5], c, w_s);
+  double *const *po = a.prim_out + opaque(b * 6);
+  gst(kload(po + 0), c, w_d);
+  gst(kload(po + 1), c, w1);
+  gst(kload(po + 2), c, w2);
+  gst(kload(po + 3), c, w3);
+  gst(kload(po + 4), c, w_p);
+  gst(kload(po + 5), c, w_s);
   if constexpr (WRITE_CONS) { // PrimToCons (fill_derived.cpp:226-255)
     const double u_u = w_s * w_d;
-    gst(a.cons_out[b * 6 + 0], c, w_d);
-    gst(a.cons_out[b * 6 + 1], c, w_d * w1 * 1.0);
-    gst(a.cons_out[b * 6 + 2], c, w_d * w2 * 1.0);
-    gst(a.cons_out[b * 6 + 3], c, w_d * w3 * 1.0);
-    gst(a.cons_out[b * 6 + 4], c, u_u + 0.5 * w_d * (sqr(w1) + sqr(w2) + sqr(w3)));
-    gst(a.cons_out[b * 6 + 5], c, u_u);
+    double *const *co = a.cons_out + opaque(b * 6);
+    gst(kload(co + 0), c, w_d);
+    gst(kload(co + 1), c, w_d * w1 * 1.0);
+    gst(kload(co + 2), c, w_d * w2 * 1.0);
+    gst(kload(co + 3), c, w_d * w3 * 1.0);
+    gst(kload(co + 4), c, u_u + 0.5 * w_d * (sqr(w1) + sqr(w2) + sqr(w3)));
+    gst(kload(co + 5), c, u_u);
   }
   if constexpr (WITH_DT) { // Gas::EstimateTimestepMesh on the new state (gas.cpp:411-433)
     const double bulk = (gm1 + 1.0) * gm1 * w_d * w_s;
@@ -819,6 +848,7 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
     x.hcol = static_cast<unsigned>(gj) * x.sj + static_cast<unsigned>(gi);
   }
   double ldt = DBL_MAX;
+  FPROF_DECL;
   GeoCtx<CURV> gx;
   if constexpr (CURV) {
     // geometry of the own column; table rows are read with indices clamped into the block (lanes beyond
@@ -888,7 +918,7 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
     }
     __syncthreads();
     bool flagged = false;
-    plane_sweeps<RIEMANN, RECON, false, CURV, GUARD, DETECT>(S, P, x, gx, k0, qc, false, qc, hal, fx_lo, fy_lo, flagged, detect);
+    plane_sweeps<RIEMANN, RECON, false, CURV, GUARD, DETECT>(S, P, x, gx, k0, qc, false, qc, hal, fx_lo, fy_lo, flagged, detect FPROF_PASS);
     if constexpr (CURV) {
       DFlux24 df{};
       if (gx.m3) gx.co.c3 = gx.m3[MT3_COS * (P.nk + 1) + k0], gx.co.s3 = gx.m3[MT3_SIN * (P.nk + 1) + k0];
@@ -960,7 +990,7 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
       Flux8 fx_lo, fy_lo;
       bool flagged = false;
       if (k >= k0) {
-        plane_sweeps<RIEMANN, RECON, true, CURV, GUARD, DETECT>(S, P, x, gx, k, qc, k < k1, qn, hal, fx_lo, fy_lo, flagged, detect);
+        plane_sweeps<RIEMANN, RECON, true, CURV, GUARD, DETECT>(S, P, x, gx, k, qc, k < k1, qn, hal, fx_lo, fy_lo, flagged, detect FPROF_PASS);
       } else { // priming trip: stage the first plane
         stage_plane(S, x, qn, hal);
         if constexpr (GUARD || DETECT) {
@@ -970,6 +1000,10 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
       }
       // x3 sweep, registers only: slope of cell k+1, face k+1
       const Cell6 qnn = finish_cell(rnn, x.gm1);
+#ifdef FUSED_PROF
+      if (qnn.d == -1.2345) prof_acc[8]++; // (the prefetch has arrived when the clock is read)
+#endif
+      FPROF(5);
       [[maybe_unused]] bool ahead = false;
       if constexpr (DETECT) { // planes k+1, k+2 of the own column (k+1 was tested as this trip's k+2 one trip ago)
         if (detect) {
@@ -1009,12 +1043,14 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
       }
       Flux8 fz_hi = solve_face<RIEMANN, 3>(x.gk, zl, zr, fast_col);
       if constexpr (CURV) fz_hi.m2 *= gx.h3[1], fz_hi.m3 *= gx.h3[2]; // ScaleMomentumFlux at the x3 face
+      FPROF(6);
       if (k >= k0) {
         if constexpr (CURV) plane_update_curv<HAS_U1, WITH_DT, true>(S, P, a, src.v, x, gx, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, df, ldt);
         else if constexpr (FLUXES) plane_store_fluxes<true>(S, P, x, k, fx_lo, fy_lo, fz_lo, fz_hi);
         else plane_update<HAS_U1, WRITE_CONS, WITH_DT, true>(S, P, a, x, k, qc, fx_lo, fy_lo, fz_lo, fz_hi, u1raw, ldt,
                                                              flagged || (fhist & 3u) != 0u || ahead, shell_wg);
       }
+      FPROF(7);
       fz_lo = fz_hi, zl = zl_next, qc = qn, qn = qnn;
       if constexpr (DETECT) {
         if (k >= k0) fhist = (fhist << 1) | (flagged ? 1u : 0u);
@@ -1022,6 +1058,11 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
     }
   }
 
+#ifdef FUSED_PROF
+  FPROF(8);
+  if ((x.t & 63) == 0)
+    for (int q = 0; q < 10; ++q) atomicAdd(&g_fused_prof[q], prof_acc[q]);
+#endif
   if constexpr (WITH_DT) {
     __syncthreads(); // LOX is reused as reduction scratch
     for (int off = 32; off > 0; off >>= 1) ldt = fmin(ldt, __shfl_down(ldt, off, 64));
@@ -1629,4 +1670,14 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
 #undef RC
 }
 
+#ifdef FUSED_PROF
+extern "C" int artemis_hip_debug_fused_prof(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fused_prof), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 } // namespace artemis

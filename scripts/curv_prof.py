@@ -17,6 +17,6 @@ torch.cuda.synchronize()
 f(buf, 0)
 v = [buf[i] for i in range(10)]
 tot = float(sum(v)) or 1.0
-names = ["loads/loop top", "P1 work", "barrier 1", "P2 work + stage next", "barrier 2", "fold x1 x2", "x3 sweep", "fold x3 + update", "tail", "-"]
+names = ["loads/loop top", "P1 work", "barrier 1", "P2 work + stage next", "barrier 2", "fold x1 x2", "x3 sweep", "fold x3 + update", "tail", "qnn + wait + u1/ds issue"]
 for n, x in zip(names, v):
     print("%-22s %6.2f %%  %.3e" % (n, 100.0 * x / tot, x))
