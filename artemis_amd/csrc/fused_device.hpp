@@ -50,6 +50,22 @@ ADEV Cell6 load_cell(const double *__restrict__ r, const double *__restrict__ v1
   return q;
 }
 
+struct Raw5 { // a cell's five stored primitives, as loaded (pressure not yet derived)
+  double d, v1, v2, v3, e;
+};
+ADEV Raw5 load_raw(const double *r, const double *v1, const double *v2, const double *v3,
+                   const double *se, unsigned c) {
+  Raw5 q;
+  q.d = gld(r, c), q.v1 = gld(v1, c), q.v2 = gld(v2, c), q.v3 = gld(v3, c), q.e = gld(se, c);
+  return q;
+}
+ADEV Cell6 finish_cell(const Raw5 &r, double gm1) {
+  Cell6 q;
+  q.d = r.d, q.v1 = r.v1, q.v2 = r.v2, q.v3 = r.v3, q.e = r.e;
+  q.p = amax(0.0, gm1 * q.d * q.e); // fill_derived.cpp:247 (IdealGas P)
+  return q;
+}
+
 template <int RECON>
 ADEV double slope(double qm, double q, double qp) {
   if constexpr (RECON == 0) return 0.0;

@@ -132,20 +132,6 @@ struct PlmG { // what plm_g_shared reads
   double dx, cr, cl, up, lo;
   Recip ra, rb, rdx;
 };
-struct Raw5 {
-  double d, v1, v2, v3, e;
-};
-ADEV Raw5 load_raw(const double *r, const double *v1, const double *v2, const double *v3, const double *se, unsigned c) {
-  Raw5 q;
-  q.d = gld(r, c), q.v1 = gld(v1, c), q.v2 = gld(v2, c), q.v3 = gld(v3, c), q.e = gld(se, c);
-  return q;
-}
-ADEV Cell6 finish_cell(const Raw5 &r, double gm1) {
-  Cell6 q;
-  q.d = r.d, q.v1 = r.v1, q.v2 = r.v2, q.v3 = r.v3, q.e = r.e;
-  q.p = amax(0.0, gm1 * q.d * q.e); // fill_derived.cpp:247 (IdealGas P)
-  return q;
-}
 // Riemann problem of sweep direction DIR for the kernel's fluid: the gas solvers of fused_device.hpp, or Dust's HLLE / LLF
 // (dust/riemann: task_device.hpp riemann_dust) with the energy, pressure-flux and face-velocity slots left at zero
 template <bool DUST, int RIEMANN, int DIR>

@@ -208,21 +208,6 @@ ADEV void put6(double (*A)[QY][QX], int r, int c, const Cell6 &q) {
   fl.m3 = A[3] __VA_ARGS__, fl.e = A[4] __VA_ARGS__, fl.eg = A[5] __VA_ARGS__,             \
   fl.pf = A[6] __VA_ARGS__, fl.vf = A[7] __VA_ARGS__
 
-struct Raw5 { // a cell's five stored primitives, as loaded (pressure not yet derived)
-  double d, v1, v2, v3, e;
-};
-ADEV Raw5 load_raw(const double *r, const double *v1, const double *v2, const double *v3,
-                   const double *se, unsigned c) {
-  Raw5 q;
-  q.d = gld(r, c), q.v1 = gld(v1, c), q.v2 = gld(v2, c), q.v3 = gld(v3, c), q.e = gld(se, c);
-  return q;
-}
-ADEV Cell6 finish_cell(const Raw5 &r, double gm1) {
-  Cell6 q;
-  q.d = r.d, q.v1 = r.v1, q.v2 = r.v2, q.v3 = r.v3, q.e = r.e;
-  q.p = amax(0.0, gm1 * q.d * q.e); // fill_derived.cpp:247 (IdealGas P)
-  return q;
-}
 
 // Stage one plane's primitives (own cell + this thread's halo cell) into S.Q.
 template <class TILE>

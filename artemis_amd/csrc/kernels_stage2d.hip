@@ -252,26 +252,46 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
 #undef ZL0
       dy_lo[n].d = dy_lo[n].m1 = dy_lo[n].m2 = dy_lo[n].m3 = 0.0;
     }
+    // the block's edge table, read ONCE: inside the march (stores in flight) a read of it would be a vector load of a
+    // uniform address with a vmcnt(0) wait behind it, i.e. a wait for the row prefetch that was just issued
     const double *geo = P.geom + 6 * b;
+    const double gl[6] = {geo[0], geo[1], geo[2], geo[3], geo[4], geo[5]};
     ShearAcc sa{}; // the shearing-box terms depend on the column only (rotating_frame_impl.hpp:43-60)
-    if (a.rf_on) sa = shear_terms(geo, 2, 0, i, a.rf_omega, a.rf_qshear);
+    if (a.rf_on) sa = shear_terms(gl, 2, 0, i, a.rf_omega, a.rf_qshear);
+    // ... and the block's output arrays
+    double *const o_r = a.gout[b * 6 + 0], *const o_1 = a.gout[b * 6 + 1], *const o_2 = a.gout[b * 6 + 2];
+    double *const o_3 = a.gout[b * 6 + 3], *const o_e = a.gout[b * 6 + 5];
+    double *p_r[ND > 0 ? ND : 1], *p_1[ND > 0 ? ND : 1], *p_2[ND > 0 ? ND : 1], *p_3[ND > 0 ? ND : 1];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+      p_r[n] = a.dout[b * 4 * ND + n], p_1[n] = a.dout[b * 4 * ND + ND + 3 * n + 0];
+      p_2[n] = a.dout[b * 4 * ND + ND + 3 * n + 1], p_3[n] = a.dout[b * 4 * ND + ND + 3 * n + 2];
+    }
     for (int j = j0 - 1; j <= j1; ++j) { // the first trip only primes the flux through face j0
       const unsigned cnn = col + static_cast<unsigned>(j + 2) * sj, ccur = col + static_cast<unsigned>(j) * sj;
       const bool live = (j >= j0); // wave-uniform
       // this trip's HBM loads first; consumed after the sweeps
-      const Cell6 qnn = load_cell(g_r, g_1, g_2, g_3, g_e, cnn, gm1);
+      // (every load of the trip here, unconditionally, and nothing reads one before the sweeps: the single wave of a SIMD
+      // has nobody to hide a memory wait behind)
+      const Raw5 rnn = load_raw(g_r, g_1, g_2, g_3, g_e, cnn);
       Dust4 dnn[ND > 0 ? ND : 1];
 #pragma unroll
       for (int n = 0; n < ND; ++n) dnn[n] = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], cnn);
-      if (detect) {
-        bool t = tiny6(qnn);
+      Raw5 g1raw{};           // start-of-step state of row j (stages after the first)
+      Dust4 d1raw[ND > 0 ? ND : 1];
+      if constexpr (HAS_U1) {
+        g1raw = load_raw(u_r, u_1, u_2, u_3, u_e, ccur);
 #pragma unroll
-        for (int n = 0; n < ND; ++n) t = t || tiny4(dnn[n]);
-        th = (th << 1) | (__any(t) ? 1u : 0u); // bits 0..4 = rows j+2 .. j-2
+        for (int n = 0; n < ND; ++n) d1raw[n] = load_dust(e_r[n], e_1[n], e_2[n], e_3[n], ccur);
       }
-      bool skip_row = (th & 31u) != 0u; // wave-uniform: this row goes to the exact kernel
       auto GD = [&](double num, const Recip &r) { return fast ? div(num, r) : num / r.b; };
-      const CellMetric g = cell_metric<false>(P, b, 0, j, i);
+      CellMetric g;
+      {
+        const CellGeom cg = cell_geom(gl, 0, j, i); // task_device.hpp cell_metric<false>, from the preloaded edge table
+        g.ax1[0] = g.ax1[1] = cg.dx2 * cg.dx3, g.ax2[0] = g.ax2[1] = cg.dx1 * cg.dx3, g.ax3[0] = g.ax3[1] = cg.dx1 * cg.dx2;
+        g.vol = cg.dx1 * cg.dx2 * cg.dx3;
+        g.dx[0] = cg.dx1, g.dx[1] = cg.dx2, g.dx[2] = cg.dx3;
+      }
       const double hx[3] = {1.0, 1.0, 1.0};
       // Division: the cell epilogue of the general stage is ~90 IEEE divisions per cell (27 instructions each).
       // Denominators that are geometry or floored state get ONE refined reciprocal shared by every quotient
@@ -293,6 +313,14 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
         teg1 = GD(bdt, rvol) * 0.5 * (lo.pf + up.pf) * (g.ax1[1] * up.vf - g.ax1[0] * lo.vf);
       }
       // ---- gas: x2 sweep, registers only: slope of row j+1, face j+1 ---------------------------------------
+      const Cell6 qnn = finish_cell(rnn, gm1); // (the prefetched row is first read here, behind the x1 sweep)
+      if (detect) {
+        bool t = tiny6(qnn);
+#pragma unroll
+        for (int n = 0; n < ND; ++n) t = t || tiny4(dnn[n]);
+        th = (th << 1) | (__any(t) ? 1u : 0u); // bits 0..4 = rows j+2 .. j-2
+      }
+      bool skip_row = (th & 31u) != 0u; // wave-uniform: this row goes to the exact kernel
       {
         Cell6 zr, zl_next;
 #define ZS(m)                                                \
@@ -317,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
       GravAcc ga{};
       DCoords co;
       if (live) {
-        if (a.grav_on || DRAG) co = make_coords(P, b, 0, j, i);
+        if (a.grav_on || DRAG) co = coords_of(ARTEMIS_CARTESIAN, gl, nullptr, P.nj, P.nk, 0, j, i);
         if (a.grav_on) ga = gravity_accel(a.grav, co, 2, bdt);
       }
       // ---- gas: ApplyUpdate, FluxSource, gravity, shearing box ----------------------------------------------
@@ -328,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
         u0 = prim_to_cons_gas(fg, qc.d, qc.v1, qc.v2, qc.v3, qc.e, hx);
         GasCons u1 = u0;
         if constexpr (HAS_U1)
-          u1 = prim_to_cons_gas(fg, gld(u_r, ccur), gld(u_1, ccur), gld(u_2, ccur), gld(u_3, ccur), gld(u_e, ccur), hx);
+          u1 = prim_to_cons_gas(fg, g1raw.d, g1raw.v1, g1raw.v2, g1raw.v3, g1raw.e, hx);
         u0.d = a.gam0 * u0.d + a.gam1 * u1.d + GD(divf[0] * beta_dt, rvol);
         u0.m1 = a.gam0 * u0.m1 + a.gam1 * u1.m1 + GD(divf[1] * beta_dt, rvol);
         u0.m2 = a.gam0 * u0.m2 + a.gam1 * u1.m2 + GD(divf[2] * beta_dt, rvol);
@@ -375,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
           FluidPrim wd;
           wd.rho = dc[n].d, wd.v1 = dc[n].v1, wd.v2 = dc[n].v2, wd.v3 = dc[n].v3, wd.sie = 0.0;
           DustCons v0 = prim_to_cons_dust(fd, dc[n].d, dc[n].v1, dc[n].v2, dc[n].v3, hx), v1 = v0;
-          if constexpr (HAS_U1) v1 = prim_to_cons_dust(fd, gld(e_r[n], ccur), gld(e_1[n], ccur), gld(e_2[n], ccur), gld(e_3[n], ccur), hx);
+          if constexpr (HAS_U1) v1 = prim_to_cons_dust(fd, d1raw[n].d, d1raw[n].v1, d1raw[n].v2, d1raw[n].v3, hx);
           v0.d = a.gam0 * v0.d + a.gam1 * v1.d + GD(dv[0] * beta_dt, rvol);
           v0.m1 = a.gam0 * v0.m1 + a.gam1 * v1.m1 + GD(dv[1] * beta_dt, rvol);
           v0.m2 = a.gam0 * v0.m2 + a.gam1 * v1.m2 + GD(dv[2] * beta_dt, rvol);
@@ -513,10 +541,10 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
           const double w_d = (dens > fd.dfloor) ? dens : fd.dfloor;
           const Recip rwd = recip(w_d); // floored; w_d * hx == w_d (hx = 1)
           const double w1 = GD(dmom[n][0], rwd), w2 = GD(dmom[n][1], rwd), w3 = GD(dmom[n][2], rwd);
-          gst(a.dout[b * 4 * ND + n], c, w_d);
-          gst(a.dout[b * 4 * ND + ND + 3 * n + 0], c, w1);
-          gst(a.dout[b * 4 * ND + ND + 3 * n + 1], c, w2);
-          gst(a.dout[b * 4 * ND + ND + 3 * n + 2], c, w3);
+          gst(p_r[n], c, w_d);
+          gst(p_1[n], c, w1);
+          gst(p_2[n], c, w2);
+          gst(p_3[n], c, w3);
           if (a.dt_bits) { // Dust::EstimateTimestepMesh (dust.cpp:256-272)
             double denom = 0.0;
             denom += GD(fabs(w1), rdx0); // 1.0 * dx == dx
@@ -542,9 +570,9 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
           const double w1 = GD(mnew[0], rw), w2 = GD(mnew[1], rw), w3 = GD(mnew[2], rw);
           double w_s = GD(u_u, rw);
           w_s = (w_s > fg.siefloor) ? w_s : fg.siefloor;
-          gst(a.gout[b * 6 + 0], c, w_d);
-          gst(a.gout[b * 6 + 1], c, w1), gst(a.gout[b * 6 + 2], c, w2), gst(a.gout[b * 6 + 3], c, w3);
-          gst(a.gout[b * 6 + 5], c, w_s);
+          gst(o_r, c, w_d);
+          gst(o_1, c, w1), gst(o_2, c, w2), gst(o_3, c, w3);
+          gst(o_e, c, w_s);
           if (a.dt_bits) { // Gas::EstimateTimestepMesh (gas.cpp:411-433)
             const double bulk = (gm1 + 1.0) * gm1 * w_d * w_s;
             const double cs = sqrt_pos(GD(bulk, rw)); // positive: floored density and sie
