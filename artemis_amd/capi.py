@@ -261,6 +261,8 @@ def load():
         "artemis_rt_device_bytes": (None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), i]),
         "artemis_rt_pool_trim": (None, [C.c_size_t]),
         "artemis_rt_pool_limit": (None, [C.c_size_t]),
+        "artemis_hip_set_option": (C.c_int, [C.c_char_p, C.c_long]),
+        "artemis_hip_get_option": (C.c_long, [C.c_char_p]),
         "artemis_rt_malloc_host": (vp, [C.c_size_t]),
         "artemis_rt_free_host": (None, [vp]),
         "artemis_rt_memcpy_h2d": (i, [vp, vp, C.c_size_t, vp]),
@@ -315,3 +317,21 @@ EXPORTS_HIP = [
 def check(rc):
     if rc != 0:
         raise ArtemisHipError(rc, load().artemis_hip_last_error().decode())
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def option(name, value=1):
+    """`with capi.option("no_fused_curv"):` -- one of the library's switches (include/artemis_hip.h) set for the block
+    and restored after it (the table is read from the environment only once, when the library first needs it)."""
+    L = load()
+    old = L.artemis_hip_get_option(name.encode())
+    if old < 0:
+        raise KeyError(name)
+    check(L.artemis_hip_set_option(name.encode(), int(value)))
+    try:
+        yield
+    finally:
+        L.artemis_hip_set_option(name.encode(), old)

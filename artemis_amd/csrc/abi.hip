@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "options.hpp"
 #include "geometry_core.hpp"
 
 namespace {
@@ -1183,7 +1184,7 @@ void *artemis_rt_malloc(size_t bytes) {
   }
   // ARTEMIS_POISON=1 (debugging aid): fresh device memory holds NaN patterns, so that a read of something never
   // written shows up as NaN instead of depending on what the allocator handed back
-  static const bool poison = std::getenv("ARTEMIS_POISON") != nullptr;
+  const bool poison = artemis::opt(artemis::OPT_POISON) != 0;
   if (poison && bytes) {
     (void)hipMemset(p, 0xFF, bytes);
     (void)hipDeviceSynchronize();

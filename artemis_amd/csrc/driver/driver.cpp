@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "artemis_driver.h"
+#include "../options.hpp"
 #include "artemis_hip.h"
 #include "artemis_rt.h"
 #include "../geometry_core.hpp"
@@ -495,8 +496,7 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
   for (int q = 0; q < nover; ++q) pin.ApplyOverride(over[q]);
   if (c) {
     comm = *c, has_comm = true, rank = c->rank, nranks = c->nranks;
-    const char *lb = std::getenv("ARTEMIS_LOOPBACK_COMM");
-    loopback = lb && lb[0] == '1';
+    loopback = artemis::opt(artemis::OPT_LOOPBACK_COMM) == 1;
   }
   // <artemis> (artemis.cpp:48-53,93-97)
   const std::string problem = pin.GetString("artemis", "problem");
@@ -928,7 +928,7 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
   if ((do_gas && ng < need(recon_gas)) || (do_dust && ng < need(recon_dust)))
     throw std::runtime_error("reconstruction requires more ghost cells (gas.cpp:61-76)");
 
-  const bool setup_timing = getenv("ARTEMIS_SETUP_TIMING") != nullptr; // host-side phases of the constructor
+  const bool setup_timing = artemis::opt(artemis::OPT_SETUP_TIMING) != 0; // host-side phases of the constructor
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto lap = [&](const char *what, std::chrono::steady_clock::time_point t0) {
     if (setup_timing)
@@ -949,16 +949,16 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
   // N-body gravity rides inside the stage kernels (artemis_stage_general_args_t.nbody_dev) for at most one species per
   // fluid; its seven sums per particle come from artemis_hip_nbody_force_sums, accumulated on the device
   // (artemis_hip_nbody_force_sums keeps one LDS slot set per particle: at most 128; larger sets take the gravity task)
-  nbody_in_stage = grav_nbody && ns_gas <= 1 && ns_dust <= 1 && !do_cooling && getenv("ARTEMIS_NBODY_TASK") == nullptr &&
+  nbody_in_stage = grav_nbody && ns_gas <= 1 && ns_dust <= 1 && !do_cooling && !artemis::opt(artemis::OPT_NBODY_TASK) &&
                    particles.size() <= 128 &&
                    (coords == ARTEMIS_CARTESIAN || coords == ARTEMIS_CYLINDRICAL || coords == ARTEMIS_SPHERICAL3D);
   fused_possible = !(do_cooling && do_drag) && !multilevel && (!grav_nbody || nbody_in_stage);
   tuned = tuned && fused_possible && !(do_viscosity || do_conduction || do_cooling);
-  if (getenv("ARTEMIS_NO_TUNED")) tuned = false; // experiments: route everything through artemis_hip_stage_general
+  if (artemis::opt(artemis::OPT_NO_TUNED)) tuned = false; // experiments: route everything through artemis_hip_stage_general
   // Large 2-D gas meshes on one rank: the row-march kernel behind artemis_hip_stage_general (kernels_stage2d.hip, x2
   // march in registers) beats the tile kernel's one-plane form -- 1.00e10 vs 7.3e9 zone-cycles/s at 4096^2, a tie at
   // 1024^2, and the tile kernel wins on small meshes (scripts/tuned2d_timing.py) -- so it takes blocks of >= 2^21 zones.
-  if (tuned && ndim == 2 && nranks == 1 && static_cast<long>(mbnx[0]) * mbnx[1] >= (1L << 21) && !getenv("ARTEMIS_TUNED_2D"))
+  if (tuned && ndim == 2 && nranks == 1 && static_cast<long>(mbnx[0]) * mbnx[1] >= (1L << 21) && !artemis::opt(artemis::OPT_TUNED_2D))
     tuned = false;
   // Default path by measurement (scripts/path_timing.py, one MI355X): the cell-centred general stage wins
   // on Cartesian meshes (2048^2 viscous 1.73e9 vs 1.50e9 zone-cycles/s, SURVEY config 3 2.9e9 vs 1.1e9); in
@@ -971,8 +971,8 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
   // Since round 4 a dust species beside it, drag and N-body gravity come along: the gas march leaves the conserved
   // state for the drag finish, the dust runs on its cell-centred kernel (kernels_stage_cell.hip launch_stage_cell).
   const bool curv_tile = do_gas && ns_gas == 1 && ns_dust <= 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
-                         (!do_dust || getenv("ARTEMIS_NO_CURV_DUST") == nullptr) &&
-                         !do_cooling && getenv("ARTEMIS_NO_FUSED_CURV") == nullptr;
+                         (!do_dust || !artemis::opt(artemis::OPT_NO_CURV_DUST)) &&
+                         !do_cooling && !artemis::opt(artemis::OPT_NO_FUSED_CURV);
   use_fused = fused_possible && (coords == ARTEMIS_CARTESIAN || curv_tile);
   // Refined meshes: the same stage kernels on every block, then the coarse zones on coarse-fine faces redone with the
   // corrected fluxes (step_ml_fused).  Drag couples the fluids after the update: the stage and the fix-up stop at the
@@ -981,8 +981,8 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
                       (coords == ARTEMIS_CARTESIAN || curv_tile);
   ml_tuned = ml_fused_possible && do_gas && !do_dust && ns_gas == 1 && recon_gas != ARTEMIS_PPM && ng >= 2 &&
              coords == ARTEMIS_CARTESIAN && !do_gravity && !do_rframe && !do_viscosity && !do_conduction && !do_cooling &&
-             getenv("ARTEMIS_NO_TUNED") == nullptr;
-  ml_fused = ml_fused_possible && getenv("ARTEMIS_NO_ML_FUSED") == nullptr;
+             !artemis::opt(artemis::OPT_NO_TUNED);
+  ml_fused = ml_fused_possible && !artemis::opt(artemis::OPT_NO_ML_FUSED);
   if (multilevel) edge_ghosts = false; // the block-graph exchange fills all 3^ndim - 1 directions itself
   t_setup = now();
   if (!use_fused) ensure_unfused();
@@ -1169,10 +1169,17 @@ void artemis_sim_impl::build_mesh_multilevel() {
                    long &recv_total, std::vector<PeerMsg> &msgs, int tag) {
     std::vector<long> send_n(nranks, 0), recv_n(nranks, 0);
     auto slot = [&](const artemis_ml_op_t &o) { return static_cast<long>(nvar) * o.n[0] * o.n[1] * o.n[2]; };
+    // LOOPBACK_COMM on one rank (a transport test: ncclSend / ncclRecv to self): the Z-ordered leaf list is cut into two
+    // virtual halves and every operation between them travels as it would between two ranks -- packed into the send
+    // buffer, sent to this rank itself, unpacked from the receive buffer (restriction on the fly, coarse-buffer
+    // destinations and flux corrections included)
+    const bool lb = loopback && nranks == 1;
+    auto half = [&](int g) { return (2L * g >= nblocks_global) ? 1 : 0; };
+    auto cross = [&](const artemis_host::GlobalOp &G) { return lb && half(G.op.dst_block) != half(G.op.src_block); };
     for (const auto &G : all) {
       const int rd = rank_of[G.op.dst_block], rs = rank_of[G.op.src_block];
-      if (rs == rank && rd != rank) send_n[rd] += slot(G.op);
-      if (rd == rank && rs != rank) recv_n[rs] += slot(G.op);
+      if (rs == rank && (rd != rank || cross(G))) send_n[rd] += slot(G.op);
+      if (rd == rank && (rs != rank || cross(G))) recv_n[rs] += slot(G.op);
     }
     std::vector<long> send_at(nranks, 0), recv_at(nranks, 0);
     send_total = recv_total = 0;
@@ -1185,7 +1192,13 @@ void artemis_sim_impl::build_mesh_multilevel() {
       o.dst_block = (rd == rank) ? local_of[G.op.dst_block] : -1;
       o.src_block = (rs == rank) ? local_of[G.op.src_block] : -1;
       const bool coarse_dst = (o.kind == ARTEMIS_ML_FROM_COARSER);
-      if (o.dst_block < 0) {
+      if (cross(G)) { // (both ends are mine: the pack and the unpack of the same slot)
+        artemis_ml_op_t pk = o, un = o;
+        pk.dst_block = -1, pk.buf = sa[rd], sa[rd] += slot(o);
+        un.src_block = -1, un.buf = ra[rs], ra[rs] += slot(o);
+        packs_direct.push_back(pk);
+        ((late && coarse_dst) ? *late : unpacks).push_back(un);
+      } else if (o.dst_block < 0) {
         o.buf = sa[rd], sa[rd] += slot(o);
         packs_direct.push_back(o);
       } else if (o.src_block < 0) {
@@ -1400,7 +1413,7 @@ void artemis_sim_impl::allocate() {
       CK(artemis_rt_memcpy_h2d(metric.p, hmetric.data(), nm * sizeof(Real), nullptr), "h2d metric");
     }
   }
-  if (coords != ARTEMIS_CARTESIAN && getenv("ARTEMIS_NO_PLM_TABLE") == nullptr) {
+  if (coords != ARTEMIS_CARTESIAN && !artemis::opt(artemis::OPT_NO_PLM_TABLE)) {
     // PLM_G's geometric weights, once per mesh (the per-task and cell-centred kernels read them instead of forming
     // ~40 quotients per zone; the tile kernels keep theirs in registers)
     artemis_pack_t p0;
@@ -2076,7 +2089,7 @@ void artemis_sim_impl::problem_generator() {
     int nthreads = 1;
     if (nb >= 8) {
       nthreads = static_cast<int>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u));
-      if (const char *e = getenv("ARTEMIS_HOST_THREADS")) nthreads = std::max(1, atoi(e));
+      if (artemis::opt(artemis::OPT_HOST_THREADS) > 0) nthreads = static_cast<int>(artemis::opt(artemis::OPT_HOST_THREADS));
       nthreads = std::min(nthreads, nb);
     }
     // batches of `nthreads` blocks: generate concurrently, then upload in block order
@@ -2192,7 +2205,7 @@ void artemis_sim_impl::problem_generator() {
     int nthreads = 1;
     if (nb >= 8) {
       nthreads = static_cast<int>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u));
-      if (const char *e = getenv("ARTEMIS_HOST_THREADS")) nthreads = std::max(1, atoi(e));
+      if (artemis::opt(artemis::OPT_HOST_THREADS) > 0) nthreads = static_cast<int>(artemis::opt(artemis::OPT_HOST_THREADS));
       nthreads = std::min(nthreads, nb);
     }
     const int chunk = 64; // blocks per batch: bounds the host staging memory
@@ -2221,7 +2234,7 @@ void artemis_sim_impl::problem_generator() {
     if (adopting && reuse_from && reuse_from->visc_radial.ok()) copy_rows(visc_radial, reuse_from->visc_radial, [&](int b) { return reuse_block(b); });
     diff.visc.radial = visc_radial.tab();
   }
-  if ((do_viscosity || do_conduction) && !getenv("ARTEMIS_NO_DISTANCE_TABLE")) {
+  if ((do_viscosity || do_conduction) && !artemis::opt(artemis::OPT_NO_DISTANCE_TABLE)) {
     // Coords::Distance between neighbouring cell centres is geometry: tabulated once per mesh (a remesh builds
     // a new state through this constructor path, so the table follows the blocks)
     const artemis_pack_t pk = make_pack(0);
@@ -2493,7 +2506,7 @@ void artemis_sim_impl::adopt_state_from(artemis_sim_impl &old) {
   particle_force = old.particle_force;
   overlap = old.overlap, time_kernels = old.time_kernels;
   base = 0;
-  if (getenv("ARTEMIS_AMR_DEBUG")) { // energy integral of the conserved state before and after the hand-over
+  if (artemis::opt(artemis::OPT_AMR_DEBUG)) { // energy integral of the conserved state before and after the hand-over
     auto total = [](artemis_sim_impl &S, int var) {
       double sum = 0.0;
       for (int b = 0; b < S.nb; ++b) {
@@ -2555,7 +2568,7 @@ void artemis_sim_impl::step_general(bool want_dt, bool device_dt) {
   // Viscosity without heat conduction: ZeroDiffusionFlux + ViscousFlux + the viscous part of DiffusionUpdate as one
   // source (artemis_hip_viscous_source: five sums per zone, no diffusion-flux arrays) where the march covers the pack
   bool visc_source = false;
-  if (do_gas && do_viscosity && !do_conduction && !getenv("ARTEMIS_NO_VISC_SOURCE")) {
+  if (do_gas && do_viscosity && !do_conduction && !artemis::opt(artemis::OPT_NO_VISC_SOURCE)) {
     const artemis_pack_t p0 = make_pack(base);
     visc_source = artemis_hip_viscous_source_covers(&p0) != 0;
   }
@@ -2705,7 +2718,7 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
       for (int f = 0; f < 6; ++f)
         copy_bcs = copy_bcs && (mesh_bc[f] == ARTEMIS_BC_PERIODIC || mesh_bc[f] == ARTEMIS_BC_OUTFLOW ||
                                 mesh_bc[f] == ARTEMIS_BC_REFLECT || mesh_bc[f] == ARTEMIS_BC_NONE);
-      if (!any_remote && !loopback && copy_bcs && nstages >= 2 && std::getenv("ARTEMIS_NO_TINY_HINT") == nullptr) {
+      if (!any_remote && !loopback && copy_bcs && nstages >= 2 && !artemis::opt(artemis::OPT_NO_TINY_HINT)) {
         // word q describes the state before stage q + 1 of a step (the same pointers every step: a captured
         // graph of one step stays valid); the state after the last stage is the next step's word 0
         unsigned *w = reinterpret_cast<unsigned *>(tiny_words.p);
@@ -2725,13 +2738,12 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
       // kernel keeps reading the x2 / x3 ghosts the fill provides.  evolve() completes the ghost zones before it returns.
       int mask = 0;
       bool all_covered = true; // every physical face of every block is an outflow face of the mask
-      if (dropin == 0 && std::getenv("ARTEMIS_NO_X1_LAZY") == nullptr) {
+      if (dropin == 0) {
         for (int f = 0; f < 2 * ndim; ++f) {
           bool every = true;
           for (int b = 0; b < nb && every; ++b) every = bc_flat[6 * b + f] == ARTEMIS_BC_OUTFLOW;
           if (every) mask |= 1 << f;
         }
-        if (std::getenv("ARTEMIS_LAZY_X1_ONLY")) mask &= 3; // (experiments)
       }
       for (int b = 0; b < nb; ++b)
         for (int f = 0; f < 2 * ndim; ++f)
@@ -2744,7 +2756,7 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
       ghosts_stale = ghosts_stale || a.outflow_faces != 0;
     }
     // (ARTEMIS_FORCE_OVERLAP=1: diagnostic, shell-first ordering even when every link is local)
-    const bool force_ovl = std::getenv("ARTEMIS_FORCE_OVERLAP") != nullptr;
+    const bool force_ovl = artemis::opt(artemis::OPT_FORCE_OVERLAP) != 0;
     const bool ovl = overlap && (any_remote || (force_ovl && !links.empty()));
     void *e0 = nullptr, *e1 = nullptr;
     if (time_kernels && kev.size() < kMaxTimedLaunches) { // (bounded: long runs with timing on must not leak events)
@@ -2776,8 +2788,7 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
       }
       CK(artemis_rt_stream_wait_event(comm_stream, ev0), "wait");
       // (ARTEMIS_TEST_SHELL_TARGET_BUMP: test hook, waits for more workgroups than exist -> the timeout path)
-      const char *bump = std::getenv("ARTEMIS_TEST_SHELL_TARGET_BUMP");
-      if (bump) target += static_cast<unsigned>(std::atoi(bump));
+      target += static_cast<unsigned>(artemis::opt(artemis::OPT_TEST_SHELL_TARGET_BUMP));
       CK(artemis_hip_wait_counter(counter, target, counter + 1, comm_stream), "wait_counter");
       // shell zones the kernel deferred to the exact path (next to vanishing velocities) are final before they are packed
       CK(artemis_hip_stage_fused_redo_shell(&p, &a, comm_stream), "stage_fused (shell redo)");
@@ -2865,7 +2876,7 @@ void artemis_sim_impl::step_ml_fused() {
     const bool diffuse = do_gas && (do_viscosity || do_conduction);
     // viscosity alone: the five sums of artemis_hip_viscous_source for the whole pack, and the viscous fluxes themselves
     // only on the faces the flux correction touches (artemis_hip_ml_viscous_faces, below)
-    const bool visc_source = diffuse && do_viscosity && !do_conduction && ns_gas == 1 && !getenv("ARTEMIS_NO_VISC_SOURCE") &&
+    const bool visc_source = diffuse && do_viscosity && !do_conduction && ns_gas == 1 && !artemis::opt(artemis::OPT_NO_VISC_SOURCE) &&
                              artemis_hip_viscous_source_covers(&p) != 0;
     if (visc_source && !gdsum.ok()) gdsum.alloc(nb, 5, N);
     if (diffuse) { // artemis_driver.cpp:189-194 on the stage's input primitives
@@ -2934,7 +2945,7 @@ void artemis_sim_impl::step_unfused() {
     }
     if (multilevel) flux_correction_multilevel(p); // artemis_driver.cpp:196-202
     place_binary();
-    if (!do_drag && !grav_nbody && std::getenv("ARTEMIS_NO_EPILOGUE") == nullptr) {
+    if (!do_drag && !grav_nbody && !artemis::opt(artemis::OPT_NO_EPILOGUE)) {
       // everything between the flux tasks and the boundary exchange is cell-local: one pass over the
       // stored fluxes (ApplyUpdate ... ConsToPrim, artemis_driver.cpp:205-255) instead of eight
       artemis_stage_general_args_t a;
@@ -2946,7 +2957,7 @@ void artemis_sim_impl::step_unfused() {
       a.diffusion = (do_gas && (do_viscosity || do_conduction)) ? &diff : nullptr;
       a.cooling = (do_cooling && do_gas) ? &cool : nullptr;
       CK(artemis_hip_stage_epilogue(&p, &a, stream), "stage epilogue");
-    } else if (!(do_cooling && do_gas) && std::getenv("ARTEMIS_NO_EPILOGUE") == nullptr) {
+    } else if (!(do_cooling && do_gas) && !artemis::opt(artemis::OPT_NO_EPILOGUE)) {
       // drag and / or N-body gravity: the same pass up to the sources that may run before them, the state left
       // conserved; then NBodyGravity and RotatingFrameForce as tasks (artemis_driver.cpp:222-236 order); then
       // DragSource + SetAuxillaryFields + ConsToPrim in one pass -- three to five launches instead of ten
@@ -3028,7 +3039,7 @@ long artemis_sim_impl::evolve(long max_cycles) {
   // (so is the orbit of a binary)
   const bool grav_window = do_gravity && (grav.tstart > -DBL_MAX || grav.tstop < DBL_MAX || grav.type == ARTEMIS_GRAVITY_BINARY);
   const bool async_loop = use_fused && tlim < 0.0 && !grav_window && (!multi || comm.allreduce_min_dev) &&
-                          std::getenv("ARTEMIS_SYNC_LOOP") == nullptr;
+                          !artemis::opt(artemis::OPT_SYNC_LOOP);
   if (async_loop) {
     long todo = -1;
     if (nlim >= 0) todo = nlim - ncycle;
@@ -3041,7 +3052,7 @@ long artemis_sim_impl::evolve(long max_cycles) {
     // One time step is a fixed launch sequence here (dt lives on the device): capture it into a hipGraph
     // after a few plain steps (which allocate the ping-pong buffers and scratch) and replay it, one
     // graph per ping-pong phase.  Single rank, no overlap streams, no per-kernel timing.
-    bool graph_ok = !multi && !time_kernels && overlap == 0 && std::getenv("ARTEMIS_NO_GRAPH") == nullptr;
+    bool graph_ok = !multi && !time_kernels && overlap == 0 && !artemis::opt(artemis::OPT_NO_GRAPH);
     void *gexec[3] = {nullptr, nullptr, nullptr};
     int gnext[3] = {0, 0, 0};
     for (; n < todo; ++n) {
@@ -3393,7 +3404,7 @@ static bool remesh(artemis_sim &h, bool initial, long force_refine_gid = -1) {
   if (!initial) h.remesh_tag_s += since(t_start);
   if (!changed) return false;
   const auto t_build = std::chrono::steady_clock::now();
-  const bool lean = !initial && getenv("ARTEMIS_FULL_REMESH") == nullptr;
+  const bool lean = !initial && !artemis::opt(artemis::OPT_FULL_REMESH);
   std::unique_ptr<artemis_sim_impl> np;
   try {
     if (lean) h.p->release_for_adoption();
@@ -3448,10 +3459,10 @@ artemis_sim_t *artemis_sim_create(const char *deck_text, int noverrides,
       s->has_comm = true;
     }
     s->p = build_state(*s, nullptr);
-    if (s->p->adaptive && s->p->refine_field && getenv("ARTEMIS_NO_POOL") == nullptr) {
+    if (s->p->adaptive && s->p->refine_field && !artemis::opt(artemis::OPT_NO_POOL)) {
       // adaptive meshes re-allocate tens of GB per remesh: artemis_rt's buffer cache (off by default for library hosts)
-      const char *e = getenv("ARTEMIS_POOL_GB");
-      artemis_rt_pool_limit(static_cast<size_t>((e ? atof(e) : 64.0) * 1073741824.0));
+      const long gb = artemis::opt(artemis::OPT_POOL_GB); // (ARTEMIS_POOL_GB / artemis_hip_set_option("pool_gb", n); default 64)
+      artemis_rt_pool_limit(static_cast<size_t>(gb > 0 ? gb : 64) << 30);
     }
     // Mesh::Initialize's refinement loop (upstream): tag the initial condition, refine, regenerate -- until the mesh
     // stops changing (blocks that 2:1 balance created are tagged one pass later than the ones tags created, so this

@@ -35,6 +35,7 @@
 #include "fused_device.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "options.hpp"
 #include "pack_view.hpp"
 #include "sources_device.hpp"
 #include "nbody_device.hpp"
@@ -928,7 +929,7 @@ void launch_sys(const PackView &P, const CurvK &k, int riemann, int recon, bool 
 // species beside it, drag and N-body gravity are fine: the dust runs on its cell-centred kernel and the drag finish
 // couples the two (launch_stage_cell).
 bool curv_march_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas) {
-  if (getenv("ARTEMIS_NO_CURV_MARCH")) return false;
+  if (opt(OPT_NO_CURV_MARCH)) return false;
   if (static_cast<long>(P.nk) * P.nj * P.ni >= (1L << 29)) return false;
   if (P.coords == ARTEMIS_CARTESIAN || P.gas.ns != 1 || P.dust.ns > 1 || P.ng < 2) return false;
   if (!g.pcm && recon_gas == ARTEMIS_PPM) return false;
@@ -952,7 +953,7 @@ bool curv_march_covers(const PackView &P, const artemis_stage_general_args_t &g,
 
 // The dust species beside it on the same march (DUST instantiations): PCM / PLM, HLLE / LLF
 bool curv_march_covers_dust(const PackView &P, const artemis_stage_general_args_t &g, int recon_dust, int riemann_dust) {
-  if (P.dust.ns != 1 || getenv("ARTEMIS_NO_CURV_DUST_MARCH")) return false;
+  if (P.dust.ns != 1 || opt(OPT_NO_CURV_DUST_MARCH)) return false;
   if (!g.pcm && recon_dust == ARTEMIS_PPM) return false;
   return riemann_dust == ARTEMIS_HLLE || riemann_dust == ARTEMIS_LLF;
 }
@@ -977,7 +978,7 @@ void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g,
   const long tiles = static_cast<long>(k.nti) * k.ntj * P.nb;
   // chunks along x3 (one priming trip each): long ones, but enough workgroups for the chip's 512 slots
   int kch = CKMAX;
-  if (const char *e = getenv("ARTEMIS_CURV_KCHUNK")) kch = std::min(CKMAX, std::max(1, atoi(e)));
+  if (opt(OPT_CURV_KCHUNK) > 0) kch = std::min<int>(CKMAX, static_cast<int>(opt(OPT_CURV_KCHUNK)));
   else if (P.ndim > 2) // full rounds of the 512 slots (two workgroups per CU) x few priming trips: kernels.hpp
     kch = (nz + pick_march_chunks(nz, tiles, 512, CKMAX, 0.5) - 1) / pick_march_chunks(nz, tiles, 512, CKMAX, 0.5);
   k.nchunk = (P.ndim > 2) ? (nz + kch - 1) / kch : 1;

@@ -17,12 +17,29 @@
 #include "device_math.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "options.hpp"
 #include "pack_view.hpp"
 #include "task_device.hpp"
 #include "diffusion_device.hpp"
 #include "sources_device.hpp"
 #include "fused_device.hpp"
 #include <type_traits>
+
+// -DVS_PROF (development builds only: ARTEMIS_HIPFLAGS_KERNELS_DIFFUSION=-DVS_PROF): per-phase shader-clock sums of the
+// viscous-source march; artemis_hip_debug_vs_prof reads them
+#ifdef VS_PROF
+__device__ unsigned long long g_vs_prof[16];
+#define VPROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define VPROF(slot)                                               \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    prof_acc[slot] += now_ - prof_t;                              \
+    prof_t = now_;                                                \
+  } while (0)
+#else
+#define VPROF_DECL
+#define VPROF(slot)
+#endif
 
 namespace artemis {
 namespace {
@@ -44,7 +61,7 @@ inline bool flat_range(const Box &r) {
   const int nx = r.iu - r.il + 1, ny = r.ju - r.jl + 1;
   const dim3 t = tile_threads(nx);
   const long covered = static_cast<long>((nx + t.x - 1) / t.x) * t.x * ((ny + t.y - 1) / t.y) * t.y;
-  return static_cast<long>(nx) * ny * 10 < covered * 6 && !getenv("ARTEMIS_NO_FLAT_RANGES");
+  return static_cast<long>(nx) * ny * 10 < covered * 6 && !opt(OPT_NO_FLAT_RANGES);
 }
 inline dim3 threads_of(const Box &r) { return flat_range(r) ? dim3(TX * TY, 1, 1) : tile_threads(r.iu - r.il + 1); }
 inline dim3 grid_of(const Box &r, int nb) {
@@ -394,12 +411,6 @@ ADEV void viscous_face(const PackView &P, const artemis_diffusion_t &D, const Vi
     }
   }
 }
-template <int DIR, bool CURV>
-__global__ __launch_bounds__(TX *TY) void viscous_flux_kernel(const PackView P, const Box r,
-                                                              const artemis_diffusion_t D, const ViscScratch w) {
-  BOX_CELL(r)
-  viscous_face<DIR, CURV, false>(P, D, w, b, k, j, i, c);
-}
 // The three directions in one pass over the cells of the active region grown by one zone at the upper ends: a
 // thread computes the lower x1 / x2 / x3 faces its cell owns (the shared per-cell scratch is read once instead
 // of three times, nothing is read-modify-written); OVERWRITE also replaces the zeroing pass.
@@ -485,10 +496,16 @@ struct Prim5Ptr {
   const double *d, *v1, *v2, *v3, *e;
 };
 // (radial: the viscosity law's radial factor, or -- no such law -- any array of the block: the caller ignores the value)
+// WITH_V3 = false: the march fetches a plane's x3 velocity one trip ahead of the rest of the zone (it closes the
+// divergence of the plane below) and puts it into the record itself -- no second load of the same value.  The march
+// waits about 200 cycles per vector-memory instruction it issues (32 a trip): every one that can go, goes.
+template <bool WITH_V3 = true>
 ADEV Vel6 load6(const Prim5Ptr &p, const double *radial, unsigned c) {
   Vel6 q;
   q.d = fused::gld(p.d, c), q.v1 = fused::gld(p.v1, c), q.v2 = fused::gld(p.v2, c);
-  q.v3 = fused::gld(p.v3, c), q.e = fused::gld(p.e, c);
+  if constexpr (WITH_V3) q.v3 = fused::gld(p.v3, c);
+  else q.v3 = 0.0;
+  q.e = fused::gld(p.e, c);
   q.rad = fused::gld(radial, c);
   return q;
 }
@@ -620,16 +637,21 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
     }
     pend_on = false;
   };
+  VPROF_DECL;
   for (int k = k0 - 2; k <= k1; ++k) {
     const bool live = k >= k0; // (wave-uniform) faces of plane k are formed
+#ifdef VS_PROF
+    __builtin_amdgcn_s_waitcnt(0x0F70); // (profiling builds: the wait for the previous trip's loads gets its own slot)
+#endif
+    VPROF(0);
     flush();
     // ---- this trip's global loads, all of them, first -------------------------------------------------------------
     // Every load of the own / halo zone is UNCONDITIONAL (threads without a halo zone fetch their own zone again: hcol ==
     // col for them): behind a branch, the compiler's s_waitcnt for an older load has to assume the younger ones were not
     // issued, i.e. it waits for all of them.  And nothing may read a value in the trip that loads it -- not even a copy.
-    const Vel6 rnn = load6(prim, radial, col + plane(k + 2)); // (its v3 slot is replaced by the value fetched a trip ago)
+    const Vel6 rnn = load6<false>(prim, radial, col + plane(k + 2)); // (its v3 slot: the value fetched a trip ago)
     const double v3n3 = fused::gld(prim.v3, col + plane(k + 3));
-    const Vel6 hnn = load6(prim, radial, hcol + plane(k + 2));
+    const Vel6 hnn = load6<false>(prim, radial, hcol + plane(k + 2));
     const double h3n3 = fused::gld(prim.v3, hcol + plane(k + 3));
     const unsigned cn1 = col + static_cast<unsigned>(k + 1) * sk, cn2 = col + plane(k + 2);
     double nl1 = 1.0, nl2 = 1.0, na3 = 1.0;  // plane k + 1: for the next trip's x1 / x2 faces
@@ -658,6 +680,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
     }
     const int pn = (k + 1 + 3) % 3, pc = (k + 3) % 3, pm = (k + 2) % 3; // ring slots of planes k + 1, k, k - 1
     const int dn = (k + 1) & 1, dc = k & 1;
+    VPROF(1);
     // ---- (a) stage plane k + 1: primitive and contravariant velocities; the zone's distances of plane k ------------
     {
       const double v[3] = {rn.v1, rn.v2, rn.v3};
@@ -677,7 +700,9 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
           for (int m = 0; m < 3; ++m) L.S[pn][m][hr - 1][hc - 1] = sh[m];
       }
     }
+    VPROF(2);
     __syncthreads();
+    VPROF(3);
     // ---- (c) faces of plane k ----------------------------------------------------------------------------------------
     // the stress rows of the lower DIR face of the zone at (row sy, column sx) of the S rectangle, block indices (k, jj, ii);
     // d5 = {to the lower neighbour, across the zone / across the lower neighbour along the first transverse direction,
@@ -726,6 +751,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
         for (int m = 0; m < 4; ++m) L.FY[m][VTY][u] = fl[m];
       }
     }
+    VPROF(4);
     // ---- (b) VelocityDivergence and viscosity of plane k + 1: own zone, ring zones ------------------------------
     const double dv_n = divergence(k + 1, jl, il, ty + 2, tx + 2, vc[2], rn.v3, v3n2);
     const double mu_n = viscosity(rn);
@@ -736,6 +762,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
       const double muh = viscosity(hn);
       if (h_ring) L.DV[dn][hr - 1][hc - 1] = dvh, L.MU[dn][hr - 1][hc - 1] = muh;
     }
+    VPROF(5);
     // ---- the x3 face between planes k and k + 1 (the lower face of zone k + 1): registers + the ring ----------------
     double f3hi[4] = {0.0, 0.0, 0.0, 0.0};
     if (k >= k0 - 1) {
@@ -751,7 +778,9 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
       q.mu1 = mu_n, q.mu2 = mu_c, q.divu = dv_n, q.divu_m = dv_c;
       viscous_face_core<3>(fg, q, dp.avg, dp.eta, f3hi, f3hi[3], active);
     }
+    VPROF(6);
     __syncthreads();
+    VPROF(7);
     // ---- (d) DiffusionUpdate's sums of zone k (diffusion.hpp:110-241) -----------------------------------------------
     if (live && active) {
       double F[3][2][4];
@@ -772,6 +801,7 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
       pend[0] = dm[0], pend[1] = dm[1], pend[2] = dm[2], pend[3] = de, pend[4] = deg;
       pend_c = col + static_cast<unsigned>(k) * sk, pend_on = true;
     }
+    VPROF(8);
     vc[0] = rn.v1, vc[1] = rn.v2, vc[2] = rn.v3;
     rn = rnn, rn.v3 = v3n2, v3n2 = v3n3;
     h3c = hn.v3, hn = hnn, hn.v3 = h3n2, h3n2 = h3n3;
@@ -782,6 +812,11 @@ __global__ __launch_bounds__(256, VS_OCC) void viscous_source_kernel(const PackV
     nb0 = nnb0, nb1 = nnb1, nb2 = nnb2, nb3 = nnb3, dd0 = ndd0, dd1 = ndd1, dd2 = ndd2;
   }
   flush();
+#ifdef VS_PROF
+  VPROF(9);
+  if ((t & 63) == 0)
+    for (int q = 0; q < 10; ++q) atomicAdd(&g_vs_prof[q], prof_acc[q]);
+#endif
 }
 
 // ---- viscous fluxes of LISTED faces (refined meshes on the one-kernel stages) ------------------------------------
@@ -1107,32 +1142,18 @@ int launch_viscous_flux(const PackView &P, const artemis_diffusion_t &D, hipStre
   const bool curv = P.coords != ARTEMIS_CARTESIAN;
   if (curv) hipLaunchKernelGGL(viscous_cell_kernel<true>, grid_of(rc, P.nb), threads_of(rc), 0, s, P, rc, D, w);
   else hipLaunchKernelGGL(viscous_cell_kernel<false>, grid_of(rc, P.nb), threads_of(rc), 0, s, P, rc, D, w);
-  // one pass for the three directions (ARTEMIS_VISC_SPLIT=1 restores one kernel per direction)
-  const bool split = getenv("ARTEMIS_VISC_SPLIT") != nullptr;
-  if (!split) {
-    Box fr = interior(P);
-    fr.iu = P.ie + 1;
-    if (P.ndim > 1) fr.ju = P.je + 1;
-    if (P.ndim > 2) fr.ku = P.ke + 1;
-    if (curv) {
-      if (overwrite) hipLaunchKernelGGL((viscous_flux3_kernel<true, true>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
-      else hipLaunchKernelGGL((viscous_flux3_kernel<true, false>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
-    } else {
-      if (overwrite) hipLaunchKernelGGL((viscous_flux3_kernel<false, true>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
-      else hipLaunchKernelGGL((viscous_flux3_kernel<false, false>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
-    }
-    return 0;
+  // one pass for the three directions
+  Box fr = interior(P);
+  fr.iu = P.ie + 1;
+  if (P.ndim > 1) fr.ju = P.je + 1;
+  if (P.ndim > 2) fr.ku = P.ke + 1;
+  if (curv) {
+    if (overwrite) hipLaunchKernelGGL((viscous_flux3_kernel<true, true>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
+    else hipLaunchKernelGGL((viscous_flux3_kernel<true, false>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
+  } else {
+    if (overwrite) hipLaunchKernelGGL((viscous_flux3_kernel<false, true>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
+    else hipLaunchKernelGGL((viscous_flux3_kernel<false, false>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);
   }
-  if (overwrite) launch_zero_diffusion_flux(P, s);
-#define LAUNCH_VISC(DIR)                                                                                        \
-  do {                                                                                                          \
-    const Box fr = faces(P, DIR);                                                                               \
-    if (curv) hipLaunchKernelGGL((viscous_flux_kernel<DIR, true>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w); \
-    else hipLaunchKernelGGL((viscous_flux_kernel<DIR, false>), grid_of(fr, P.nb), threads_of(fr), 0, s, P, fr, D, w);     \
-  } while (0)
-  LAUNCH_VISC(1);
-  if (P.ndim > 1) LAUNCH_VISC(2);
-  if (P.ndim > 2) LAUNCH_VISC(3);
   return 0;
 }
 void launch_viscous_listed_faces(const PackView &P, const artemis_diffusion_t &D, const artemis_ml_face_box_t *boxes, int nboxes,
@@ -1150,7 +1171,7 @@ void launch_viscous_listed_faces(const PackView &P, const artemis_diffusion_t &D
 }
 // Does the viscous-source march cover this pack?  (3-D blocks of one gas species, 32-bit zone offsets.)
 bool viscous_source_covers(const PackView &P) {
-  if (getenv("ARTEMIS_NO_VISC_SOURCE")) return false;
+  if (opt(OPT_NO_VISC_SOURCE)) return false;
   if (P.ndim != 3 || P.gas.ns != 1 || P.ng < 2) return false;
   if (P.coords == ARTEMIS_SPHERICAL1D || P.coords == ARTEMIS_SPHERICAL2D) return false; // (never 3-D blocks)
   if (static_cast<long>(P.nk) * P.nj * P.ni >= (1L << 29)) return false;
@@ -1168,7 +1189,7 @@ void launch_viscous_source(const PackView &P, const artemis_diffusion_t &D, doub
   // chunks along x3: two priming trips each, so long ones -- but enough workgroups for two rounds of the chip's slots
   const long tiles = static_cast<long>(a.nti) * a.ntj * P.nb;
   int kch = 32;
-  if (const char *e = getenv("ARTEMIS_VISC_KCHUNK")) kch = std::max(1, atoi(e));
+  if (opt(OPT_VISC_KCHUNK) > 0) kch = static_cast<int>(opt(OPT_VISC_KCHUNK));
   else { // full rounds of the chip's 512 slots (two workgroups per CU), two priming trips per chunk: kernels.hpp
     const int n = pick_march_chunks(nz, tiles, 512, 64, 1.0);
     kch = (nz + n - 1) / n;
@@ -1235,4 +1256,14 @@ void launch_diffusion_dt(const PackView &P, const artemis_diffusion_t &D, double
   }
 }
 
+#ifdef VS_PROF
+extern "C" int artemis_hip_debug_vs_prof(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vs_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_vs_prof), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 } // namespace artemis

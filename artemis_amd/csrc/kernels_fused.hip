@@ -33,6 +33,7 @@
 #include "fused_device.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "options.hpp"
 #include "pack_view.hpp"
 #include "sources_device.hpp"
 #include "task_device.hpp"
@@ -1258,7 +1259,7 @@ __global__ __launch_bounds__(256) void stage_redo_kernel(const PackView P, const
 // priming trip.  Among 8..16 planes take the best product of round fill and march efficiency (256^3: 16 planes,
 // 4096 workgroups = 8 full rounds; 192 x 128^2: 8 planes, 3 full rounds instead of 1.5).
 int pick_chunk(int planes, long tiles, long slots, int cmax = 16) {
-  if (const char *e = getenv("ARTEMIS_FUSED_KCHUNK")) return std::max(1, atoi(e)); // tuning knob
+  if (opt(OPT_FUSED_KCHUNK) > 0) return static_cast<int>(opt(OPT_FUSED_KCHUNK)); // tuning knob
   int best = 16;
   double score = -1.0;
   // (<= 16 where the launch has a boundary shell, which is one chunk thick; launches without one take up to 128 planes
@@ -1322,7 +1323,7 @@ void launch_advance_dt(double *state, double tlim, int nstages, const double *be
 
 void launch_wait_counter(unsigned *counter, unsigned target, unsigned *timeout_flag, hipStream_t s) {
   unsigned long long limit = 1ull << 26; // ARTEMIS_WAIT_SPIN_LIMIT: diagnostics / the timeout test
-  if (const char *e = getenv("ARTEMIS_WAIT_SPIN_LIMIT")) limit = std::max(1ll, atoll(e));
+  if (opt(OPT_WAIT_SPIN_LIMIT) > 0) limit = opt(OPT_WAIT_SPIN_LIMIT);
   hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, s, counter, target, timeout_flag, limit);
 }
 
@@ -1335,7 +1336,7 @@ struct RedoBufs {
   size_t cap = 0;
 };
 thread_local RedoBufs g_redo;
-bool redo_enabled() { return getenv("ARTEMIS_NO_REDO") == nullptr; }
+bool redo_enabled() { return opt(OPT_NO_REDO) == 0; }
 bool ensure_redo(size_t zones) {
   if (g_redo.cnt && g_redo.cap >= zones) return true;
   (void)hipDeviceSynchronize();
@@ -1501,7 +1502,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   }
   // XCD-aware id remap of the bulk workgroups: no effect on the run time (the kernel is VALU-bound) but
   // it removes the halo / straddled-line re-reads between XCDs from the HBM traffic (profiles/r02*pmc*)
-  k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
+  k.xcd_swizzle = opt(OPT_FUSED_NO_SWIZZLE) ? 0 : 1;
   const bool has_u1 = (a.prim_u1 != a.prim_in);
   const bool cons = (a.cons_out != nullptr);
   const bool dt = (a.dt_dev != nullptr);
@@ -1530,7 +1531,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
 // PCM / PLM, blocks at least a tile wide.  Same device functions as the fused stage, which is bit-identical to the
 // per-task chain, so the task's outputs do not change.
 bool fused_flux_covers(const PackView &P, int recon) {
-  if (getenv("ARTEMIS_NO_TILED_FLUX")) return false;
+  if (opt(OPT_NO_TILED_FLUX)) return false;
   if (static_cast<long>(P.nk) * P.nj * P.ni >= (1L << 29)) return false;
   if (P.coords != ARTEMIS_CARTESIAN || P.gas.ns != 1 || P.ng < 2 || P.ndim < 2) return false;
   if (recon != ARTEMIS_PCM && recon != ARTEMIS_PLM) return false;
@@ -1566,7 +1567,7 @@ int launch_flux_fused(const PackView &P, int riemann, int recon, hipStream_t s) 
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.tiny_in = nullptr, k.tiny_out = nullptr;
   k.outflow = 0;
-  k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
+  k.xcd_swizzle = opt(OPT_FUSED_NO_SWIZZLE) ? 0 : 1;
 #define RC(RS)                                                                             \
   case RS:                                                                                 \
     if (recon == ARTEMIS_PCM) launch_flux_cfg<RS, 0>(P, k, s);                             \
@@ -1631,7 +1632,7 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.tiny_in = nullptr, k.tiny_out = nullptr;
   k.outflow = 0;
-  k.xcd_swizzle = (getenv("ARTEMIS_FUSED_NO_SWIZZLE") == nullptr) ? 1 : 0;
+  k.xcd_swizzle = opt(OPT_FUSED_NO_SWIZZLE) ? 0 : 1;
   SrcArg<true> src;
   src.v.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;
   if (src.v.grav_on) src.v.grav = *g.gravity;

@@ -10,6 +10,7 @@
 #include "diffusion_device.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "options.hpp"
 #include "nbody_device.hpp"
 #include "pack_view.hpp"
 #include "sources_device.hpp"
@@ -648,7 +649,7 @@ void launch_nbody_gravity(const PackView &P, const artemis_nbody_particle_t *pl_
   NBodyView N;
   N.pl = pl_dev, N.npart = npart, N.omf = omf, N.dt = dt, N.dt_ptr = nullptr, N.partial = partial_dev;
   const long total = static_cast<long>(P.ie - P.is + 1) * (P.je - P.js + 1) * (P.ke - P.ks + 1) * P.nb;
-  if (P.gas.ns <= 1 && P.dust.ns <= 1 && total < (1L << 31) - (1L << 20) && getenv("ARTEMIS_NBODY_GENERAL") == nullptr) {
+  if (P.gas.ns <= 1 && P.dust.ns <= 1 && total < (1L << 31) - (1L << 20) && !opt(OPT_NBODY_GENERAL)) {
     const dim3 grid(nbody_grid(P)), block(256);
     if (P.gas.ns && P.dust.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<true, true>), grid, block, 0, s, P, N);
     else if (P.gas.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<true, false>), grid, block, 0, s, P, N);

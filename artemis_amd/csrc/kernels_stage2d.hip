@@ -26,6 +26,7 @@
 #include "fused_device.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "options.hpp"
 #include "pack_view.hpp"
 #include "sources_device.hpp"
 #include "task_device.hpp"
@@ -636,7 +637,7 @@ void launch_flags(const PackView &P, const S2Args &a, hipStream_t s) {
   // the exact kernel: its waves stride over the listed rows (normally none).  An empty pass of this register-heavy
   // kernel costs by its grid -- 7.4 us at 256 workgroups, 5 % of a 1024^2 stage --, so the grid is sized by the main
   // launch: one exact workgroup per 32 main ones, between 8 and 256
-  static const int rg_env = getenv("ARTEMIS_STAGE2D_RGRID") ? atoi(getenv("ARTEMIS_STAGE2D_RGRID")) : 0;
+  const int rg_env = static_cast<int>(opt(OPT_STAGE2D_RGRID));
   const unsigned rg = rg_env > 0 ? static_cast<unsigned>(rg_env) : std::min(256u, std::max(8u, grid.x / 32u));
   const dim3 rgrid(rg);
 #define GO(U, D)                                                                                                    \
@@ -717,8 +718,8 @@ void launch_stage2d(const PackView &P, const artemis_stage_general_args_t &g, in
   // rounds x (rows + 2): 4096^2 -> 40 rows, 7 rounds; 1024^2 -> 19 rows, ONE round of 972 waves (round 2 halved the
   // chunks until there were 4096 waves, which made 3078 chunks of 6 rows = four rounds of 8 trips, 1.5 x the time).
   int rows = 32;
-  if (const char *e = getenv("ARTEMIS_STAGE2D_ROWS")) {
-    rows = std::max(1, atoi(e));
+  if (opt(OPT_STAGE2D_ROWS) > 0) {
+    rows = static_cast<int>(opt(OPT_STAGE2D_ROWS));
   } else {
     const long slots = 1024;
     long best = -1;
@@ -730,7 +731,7 @@ void launch_stage2d(const PackView &P, const artemis_stage_general_args_t &g, in
   }
   a.rows = rows, a.nchunk = (nx2 + rows - 1) / rows;
   a.redo_cnt = a.redo_done = nullptr, a.redo_list = nullptr, a.redo_cap = 0;
-  if (getenv("ARTEMIS_NO_REDO") == nullptr && ensure_redo2d(static_cast<size_t>(P.nb) * a.nstrip * nx2)) {
+  if (!opt(OPT_NO_REDO) && ensure_redo2d(static_cast<size_t>(P.nb) * a.nstrip * nx2)) {
     a.redo_cnt = g_redo2d.cnt, a.redo_done = g_redo2d.cnt + 1, a.redo_list = g_redo2d.list;
     a.redo_cap = static_cast<unsigned>(std::min<size_t>(g_redo2d.cap, 0xffffffffu));
   }

@@ -22,6 +22,7 @@
 #include "diffusion_device.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "options.hpp"
 #include "nbody_device.hpp"
 #include "pack_view.hpp"
 #include "sources_device.hpp"
@@ -641,8 +642,8 @@ void launch_stage_epilogue(const PackView &P, const artemis_stage_general_args_t
 
 int stage_general_variant(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas, int riemann_gas,
                           int recon_dust, int riemann_dust) {
-  if (getenv("ARTEMIS_NO_STAGE2D") == nullptr && stage2d_covers(P, g, recon_gas, riemann_gas, recon_dust, riemann_dust)) return 1;
-  if (getenv("ARTEMIS_NO_FUSED_CURV") == nullptr) {
+  if (!opt(OPT_NO_STAGE2D) && stage2d_covers(P, g, recon_gas, riemann_gas, recon_dust, riemann_dust)) return 1;
+  if (!opt(OPT_NO_FUSED_CURV)) {
     if (curv_march_covers(P, g, recon_gas)) return 3;
     if (fused_curv_covers(P, g, recon_gas)) return 2;
   }

@@ -11,6 +11,7 @@
 #include "device_math.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "options.hpp"
 #include "task_device.hpp"
 #include "pack_view.hpp"
 
@@ -43,7 +44,7 @@ inline Shape shape_for(const Range3 &r, int nb) {
   const int tx = s.block.x, ty = s.block.y;
   s.grid = dim3((nx + tx - 1) / tx, (ny + ty - 1) / ty, nz * nb);
   const long covered = static_cast<long>(s.grid.x) * tx * s.grid.y * ty, used = static_cast<long>(nx) * ny;
-  if (used * 10 < covered * 6 && !getenv("ARTEMIS_NO_FLAT_RANGES")) {
+  if (used * 10 < covered * 6 && !opt(OPT_NO_FLAT_RANGES)) {
     s.block = dim3(TX * TY, 1, 1);
     s.grid = dim3(static_cast<unsigned>((used * nz + TX * TY - 1) / (TX * TY)), 1, nb);
   }

@@ -284,6 +284,10 @@ def main():
                          "2: one launch, shell workgroups first + a device counter a one-wave kernel polls")
     ap.add_argument("--blocks-per-gpu", type=int, default=1,
                     help="diagnostic: cut each rank's 256^3 into this many mesh blocks along x3")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: if the native C++ RCCL transport cannot be created, carry on over torch.distributed's nccl "
+                         "backend (reported in config.transport) instead of failing -- a scaling line is the product's own "
+                         "transport unless this is given")
     ap.add_argument("--loopback", action="store_true",
                     help="diagnostic: route block-to-block slabs of ONE GPU through RCCL send/recv-to-self")
     ap.add_argument("--no-remesh-leg", action="store_true", help="disk_amr: skip the forced-remesh measurement after the timed region")
@@ -338,7 +342,7 @@ def main():
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
         else:
-            os.environ["ARTEMIS_LOOPBACK_COMM"] = "1"
+            capi.check(L.artemis_hip_set_option(b"loopback_comm", 1))
         transport_note = None
         try:
             comm = RcclComm(rank, world, share)
@@ -352,9 +356,12 @@ def main():
             # every rank must take the same transport
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and not args.allow_fallback:
+                raise SystemExit("bench.py: the native RCCL transport could not be created on every rank (%s); "
+                                 "--allow-fallback measures over torch.distributed's nccl backend instead" % transport_note)
             if int(flag.item()) == 0:
-                # Last resort so that a scaling run still yields a number: torch.distributed's nccl (= RCCL) backend
-                # behind the same artemis_comm_t callbacks.  The JSON line says so; the native path is the product.
+                # Opt-in last resort (--allow-fallback): torch.distributed's nccl (= RCCL) backend behind the same
+                # artemis_comm_t callbacks.  The JSON line says so; the native path is the product.
                 from artemis_amd.driver import TorchComm
                 if comm is not None:
                     comm.close()
@@ -438,7 +445,8 @@ def main():
         sim = make_sim()
     if args.path == "unfused":
         sim.set_path("unfused")
-    want_overlap = (world > 1 or args.loopback or bool(os.environ.get("ARTEMIS_FORCE_OVERLAP"))) and not args.no_overlap
+    force_overlap = L.artemis_hip_get_option(b"force_overlap") > 0  # (ARTEMIS_FORCE_OVERLAP in the environment)
+    want_overlap = (world > 1 or args.loopback or force_overlap) and not args.no_overlap
     sim.set_overlap(args.overlap_mode if want_overlap else 0)
 
     def barrier():
@@ -535,12 +543,12 @@ def main():
     hist = sim.history()
     overlap_emulation = None
     if (args.workload == "sedov3d" and args.gpus == 1 and not args.loopback and not args.no_overlap_emulation and sim.uses_tuned_kernel
-            and args.blocks_per_gpu == 1 and not os.environ.get("ARTEMIS_FORCE_OVERLAP")):
+            and args.blocks_per_gpu == 1 and not force_overlap):
         # What a rank of an N > 1 run does per stage, emulated on this one GPU: the same zones as two blocks stacked along
         # x3 with the shell-first / bulk launch order forced (ARTEMIS_FORCE_OVERLAP: the boundary shell of every block is
         # launched first and its slabs are packed on the comm stream while the bulk runs; the "link" is a device copy).
         # The N > 1 expectation per GPU, before any xGMI time, is this number rather than the one-block headline.
-        os.environ["ARTEMIS_FORCE_OVERLAP"] = "1"
+        capi.check(L.artemis_hip_set_option(b"force_overlap", 1))
         try:
             s2 = Simulation(deck, overrides(1, per_gpu, 64, ["parthenon/meshblock/nx3=%d" % (args.n // 2)]))
             s2.set_overlap(1)
@@ -552,7 +560,7 @@ def main():
             overlap_emulation = s2.total_zones * n2 / (time.perf_counter() - t1)
             s2.close()
         finally:
-            del os.environ["ARTEMIS_FORCE_OVERLAP"]
+            L.artemis_hip_set_option(b"force_overlap", 0)
     dropin = None
     if args.workload == "sedov3d" and args.gpus == 1 and not args.loopback and not args.no_dropin and sim.uses_tuned_kernel:
         # What a Parthenon host sees: (i) the fused kernel also writing `cons` on the last

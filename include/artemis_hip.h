@@ -33,38 +33,38 @@
  *    system, fluid_fluxes.hpp:235,258,290; too few ghost cells, gas.cpp:61-76) map to
  *    ARTEMIS_HIP_EINVAL.
  *
- * Environment switches (read by the library and by the host driver; all are debugging / measurement aids -- results do
- * not depend on them unless stated, and none is needed in production):
- *  correctness aids
- *    ARTEMIS_POISON=1          device memory handed out by artemis_rt_malloc is filled with NaN patterns first: a read of
- *                              something never written shows up as NaN instead of whatever the allocator returned
- *    ARTEMIS_NO_REDO=1         artemis_hip_stage_fused: switches off the detect-and-redo of zones next to vanishing
- *                              velocities (the kernel's hand-scheduled divisions are then NOT exact there: DESIGN.md
- *                              section 4 states the bound) -- for measuring what the mechanism costs
- *    ARTEMIS_NO_TINY_HINT=1    ... and the per-stage hint words that let a plane skip the IEEE path
- *    ARTEMIS_AMR_DEBUG=1       the driver prints the energy integral before and after a remesh hand-over
+ * Switches (debugging / measurement aids of the library and of the host driver -- results do not depend on them unless
+ * stated, and none is needed in production):
+ *  They live in ONE table (artemis_amd/csrc/options.hpp) that is filled from the environment once,
+ *  when the library first needs it -- ARTEMIS_<NAME> present = its integer value, or 1 when it holds no number -- and is
+ *  changed at run time only through artemis_hip_set_option("<name>", value) below (names case-insensitive, with or
+ *  without the ARTEMIS_ prefix).  No launch path calls getenv.
  *  path selection (every path gives the same bits; tests use these to compare them)
- *    ARTEMIS_NO_TUNED, ARTEMIS_TUNED_2D, ARTEMIS_NO_STAGE2D, ARTEMIS_NO_FUSED_CURV, ARTEMIS_NO_CURV_MARCH,
- *    ARTEMIS_NO_CURV_DUST, ARTEMIS_NO_CURV_DUST_MARCH, ARTEMIS_NO_ML_FUSED, ARTEMIS_NO_EPILOGUE, ARTEMIS_NO_TILED_FLUX,
- *    ARTEMIS_NO_VISC_SOURCE (the diffusion-flux tasks instead of artemis_hip_viscous_source), ARTEMIS_VISC_SPLIT,
- *    ARTEMIS_NBODY_TASK (N-body gravity as its own task with the host-side reduction), ARTEMIS_NBODY_GENERAL,
- *    ARTEMIS_NO_PLM_TABLE, ARTEMIS_NO_DISTANCE_TABLE, ARTEMIS_NO_FLAT_RANGES, ARTEMIS_FULL_REMESH (a remesh rebuilds
- *    the whole state next to the old one instead of the lean hand-over)
+ *    NO_TUNED, TUNED_2D, NO_STAGE2D, NO_FUSED_CURV, NO_CURV_MARCH, NO_CURV_DUST, NO_CURV_DUST_MARCH, NO_ML_FUSED,
+ *    NO_EPILOGUE, NO_TILED_FLUX, NO_VISC_SOURCE (the diffusion-flux tasks instead of artemis_hip_viscous_source),
+ *    NBODY_TASK (N-body gravity as its own task with the host-side reduction), NBODY_GENERAL, NO_PLM_TABLE,
+ *    NO_DISTANCE_TABLE, NO_FLAT_RANGES, FULL_REMESH (a remesh rebuilds the whole state next to the old one instead of
+ *    the lean hand-over)
+ *  exactness machinery
+ *    NO_REDO         artemis_hip_stage_fused / the 2-D row march: switches off the detect-and-redo of zones next to
+ *                    vanishing velocities (the hand-scheduled divisions are then NOT exact there: DESIGN.md section 4
+ *                    states the bound) -- for measuring what the mechanism costs
+ *    NO_TINY_HINT    ... and the per-stage hint words that let a plane skip the IEEE path
  *  host loop
- *    ARTEMIS_NO_GRAPH=1        the driver launches every stage kernel itself instead of replaying a captured hipGraph of
- *                              one step (single rank, no overlap, no kernel timing: the only case a graph is used)
- *    ARTEMIS_SYNC_LOOP=1       the time step comes back to the host every cycle (no device-resident dt)
- *    ARTEMIS_FORCE_OVERLAP=1   the shell-first / bulk launch order of a multi-rank run on one rank (bench.py's emulation)
- *    ARTEMIS_NO_X1_LAZY, ARTEMIS_LAZY_X1_ONLY   ghost zones behind outflow faces are filled every stage / only x1 is lazy
- *    ARTEMIS_LOOPBACK_COMM, ARTEMIS_WAIT_SPIN_LIMIT, ARTEMIS_TEST_SHELL_TARGET_BUMP   transport test hooks
- *    ARTEMIS_HOST_THREADS=n    host threads of the problem generator; ARTEMIS_SETUP_TIMING=1 prints its phases
+ *    NO_GRAPH        the driver launches every stage kernel itself instead of replaying a captured hipGraph of one step
+ *    SYNC_LOOP       the time step comes back to the host every cycle (no device-resident dt)
+ *    FORCE_OVERLAP   the shell-first / bulk launch order of a multi-rank run on one rank (bench.py's emulation)
+ *    LOOPBACK_COMM, WAIT_SPIN_LIMIT, TEST_SHELL_TARGET_BUMP   transport test hooks
+ *    HOST_THREADS=n  host threads of the problem generator; SETUP_TIMING prints its phases; AMR_DEBUG prints the energy
+ *                    integral before and after a remesh hand-over
  *  tuning knobs (measurement)
- *    ARTEMIS_FUSED_KCHUNK, ARTEMIS_CURV_KCHUNK, ARTEMIS_VISC_KCHUNK   planes per x3 chunk of the three march kernels
- *    ARTEMIS_STAGE2D_ROWS, ARTEMIS_STAGE2D_RGRID, ARTEMIS_FUSED_NO_SWIZZLE, ARTEMIS_VS_ABL (ablation bits of the
- *    viscous-source march: the results are WRONG with it, timing only)
+ *    FUSED_KCHUNK, CURV_KCHUNK, VISC_KCHUNK   planes per x3 chunk of the three march kernels
+ *    STAGE2D_ROWS, STAGE2D_RGRID, FUSED_NO_SWIZZLE
  *  memory
- *    ARTEMIS_NO_POOL=1, ARTEMIS_POOL_GB=n   the standalone driver enables artemis_rt's buffer cache for adaptive meshes
- *                              with this limit (default 64) / not at all; library hosts: artemis_rt_pool_limit (artemis_rt.h)
+ *    NO_POOL, POOL_GB=n   the standalone driver enables artemis_rt's buffer cache for adaptive meshes with this limit
+ *                    (default 64) / not at all; library hosts: artemis_rt_pool_limit (artemis_rt.h)
+ *    POISON          fresh device memory from artemis_rt_malloc holds NaN patterns (a read of something never written
+ *                    shows up as NaN instead of whatever the allocator returned)
  * ===================================================================================== */
 #ifndef ARTEMIS_HIP_H_
 #define ARTEMIS_HIP_H_
@@ -823,6 +823,10 @@ int artemis_hip_selftest_divsqrt(long n, const double *a, const double *b, doubl
 
 /* ---- Library state ---------------------------------------------------------------------*/
 const char *artemis_hip_last_error(void);
+/* The library's switches (list above): set one at run time (ARTEMIS_HIP_EINVAL: unknown name) / read it back (-1: unknown).  Not thread-safe against
+ * launches in flight on other threads: set options before the work they steer. */
+int artemis_hip_set_option(const char *name, long value);
+long artemis_hip_get_option(const char *name);
 /* Number of visible HIP devices (0 = none; every compute entry point then fails loudly with
  * ARTEMIS_HIP_EDEVICE -- there is no CPU fallback in this library). */
 int artemis_hip_device_count(void);

@@ -10,13 +10,15 @@ buf = (C.c_ulonglong * 16)()
 sys.argv = ["curv_timing.py"] + sys.argv[1:]
 import torch
 torch.cuda.synchronize()
-f = L.artemis_hip_debug_curv_prof
+which = os.environ.get("PROF_KERNEL", "curv")
+f = getattr(L, "artemis_hip_debug_%s_prof" % which)
 f(buf, 1)
 runpy.run_path(os.path.join(ROOT, "scripts", "curv_timing.py"), run_name="__main__")
 torch.cuda.synchronize()
 f(buf, 0)
 v = [buf[i] for i in range(10)]
 tot = float(sum(v)) or 1.0
-names = ["loads/loop top", "P1 work", "barrier 1", "P2 work + stage next", "barrier 2", "fold x1 x2", "x3 sweep", "fold x3 + update", "tail", "qnn + wait + u1/ds issue"]
+vs_names = ["loop top + deferred stores", "issue the trip's loads", "(a) stage plane k+1", "barrier 1", "(c) x1 / x2 faces + duty", "(b) divergence, viscosity", "x3 face", "barrier 2", "(d) sums of zone k", "tail"]
+names = vs_names if which == "vs" else ["loads/loop top", "P1 work", "barrier 1", "P2 work + stage next", "barrier 2", "fold x1 x2", "x3 sweep", "fold x3 + update", "tail", "qnn + wait + u1/ds issue"]
 for n, x in zip(names, v):
     print("%-22s %6.2f %%  %.3e" % (n, 100.0 * x / tot, x))

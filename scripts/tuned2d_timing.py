@@ -17,7 +17,8 @@ def main():
           "gas/riemann=hllc", "problem/radius=0.1", "problem/samples=0", "parthenon/time/tlim=-1.0", "parthenon/time/nlim=-1"]
     for path in ("fused", "general"):
         if path == "general":
-            os.environ["ARTEMIS_NO_TUNED"] = "1"
+            from artemis_amd import capi
+            capi.load().artemis_hip_set_option(b"no_tuned", 1)
         s = Simulation(os.path.join(ROOT, "inputs", "blast", "blast.in"), ov)
         s.evolve(5)
         s.set_kernel_timing(True)

@@ -50,3 +50,36 @@ def one_openmp_thread():
     g.omp_set_num_threads(1)
     yield
     g.omp_set_num_threads(n)
+
+
+OPTION_NAMES = ["NO_TUNED", "TUNED_2D", "NO_STAGE2D", "NO_FUSED_CURV", "NO_CURV_MARCH", "NO_CURV_DUST", "NO_CURV_DUST_MARCH",
+                "NO_ML_FUSED", "NO_EPILOGUE", "NO_TILED_FLUX", "NO_VISC_SOURCE", "NBODY_TASK", "NBODY_GENERAL", "NO_PLM_TABLE",
+                "NO_DISTANCE_TABLE", "NO_FLAT_RANGES", "FULL_REMESH", "NO_REDO", "NO_TINY_HINT", "NO_GRAPH", "SYNC_LOOP",
+                "FORCE_OVERLAP", "LOOPBACK_COMM", "WAIT_SPIN_LIMIT", "TEST_SHELL_TARGET_BUMP", "HOST_THREADS", "SETUP_TIMING",
+                "AMR_DEBUG", "FUSED_KCHUNK", "CURV_KCHUNK", "VISC_KCHUNK", "STAGE2D_ROWS", "STAGE2D_RGRID", "FUSED_NO_SWIZZLE",
+                "NO_POOL", "POOL_GB", "POISON"]
+
+
+@pytest.fixture(autouse=True)
+def _library_options_restored():
+    """The library's switches (artemis_hip_set_option) are process-wide: whatever a test sets is put back after it."""
+    from artemis_amd import capi
+    if not os.path.exists(capi.LIB_PATH):
+        yield
+        return
+    L = capi.load()
+    before = {n: L.artemis_hip_get_option(n.encode()) for n in OPTION_NAMES}
+    yield
+    for n, v in before.items():
+        if v >= 0:
+            L.artemis_hip_set_option(n.encode(), v)
+
+
+@pytest.fixture
+def option():
+    """option("no_redo") / option("visc_kchunk", 5): set one of the library's switches for the rest of the test."""
+    from artemis_amd import capi
+
+    def set_(name, value=1):
+        capi.check(capi.load().artemis_hip_set_option(name.encode(), int(value)))
+    return set_

@@ -111,7 +111,7 @@ def test_linear_wave_amr_deck_conserves_and_converges(hiplib):
     assert e_f < e_amr < 1.05 * e_c, (e_f, e_amr, e_c)
 
 
-def test_adaptive_mesh_with_viscosity_distance_table_follows_the_blocks(hiplib, monkeypatch):
+def test_adaptive_mesh_with_viscosity_distance_table_follows_the_blocks(hiplib, monkeypatch, option):
     """The static Coords::Distance table of the viscous fluxes (artemis_hip_viscous_distance_fill) is rebuilt with
     every remesh: an adaptive viscous run with the table equals the same run evaluating the distances on the fly,
     bit for bit, blocks and levels included."""
@@ -128,7 +128,7 @@ def test_adaptive_mesh_with_viscosity_distance_table_follows_the_blocks(hiplib, 
         return out
 
     a = run()
-    monkeypatch.setenv("ARTEMIS_NO_DISTANCE_TABLE", "1")
+    option("no_distance_table", 1)
     b = run()
     assert a[0] == b[0] and a[0] >= 2 and a[1] == b[1] and a[3] == b[3]
     for x, y in zip(a[2], b[2]):
@@ -218,3 +218,18 @@ def test_hip_driver_equals_adaptive_oracle(hiplib, name, kw, cycles, batch, min_
         want = m.nbody_force()  # per-block partial sums of the oracle, blocks that left the mesh included
         assert f.shape == want.shape == (2, 7) and np.abs(f - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), (f, want)
     s.close()
+
+
+@pytest.mark.gpu
+def test_config4_at_bench_size_one_kernel_stages_equal_the_task_chain(hiplib):
+    """BASELINE configs[4]'s combination at the size bench.py --workload disk_amr runs (128 x 128 x 16 root over |z| < 0.2 in
+    16^3 blocks, four adaptive levels: ~7000 blocks, 29 M zones of gas and dust): the one-kernel stages (curvilinear tile
+    marches, viscous source, N-body and drag inside, flux correction as a fix-up) against the per-task chain -- same mesh,
+    same dt, every leaf of both fluids equal bit for bit after three cycles; the particle forces to round-off (their sums
+    are formed in a different order).  (The small forms of the deck run against the adaptive oracle above.)"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "amr_paths_check.py"), "3"], capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert " 0 of " in r.stdout and "leaf arrays differ" in r.stdout, r.stdout[-500:]

@@ -231,7 +231,7 @@ def test_driver_rejects_out_of_scope(hiplib):
         Simulation(DECK("blast", "blast.in"), ["gas/reconstruct=ppm"])
 
 
-def test_rccl_loopback_halo_exchange(hiplib, monkeypatch):
+def test_rccl_loopback_halo_exchange(hiplib, monkeypatch, option):
     """One GPU, one rank, the NATIVE C++ RCCL transport (artemis_comm_rccl_*): every block-to-block ghost
     slab is routed through the communicator as an ncclSend / ncclRecv to self (ARTEMIS_LOOPBACK_COMM=1),
     i.e. the exact code path the multi-GPU run uses -- the comm stream, one ncclGroup per exchange in tag
@@ -243,7 +243,7 @@ def test_rccl_loopback_halo_exchange(hiplib, monkeypatch):
     ov = linwave_overrides(32, "plm", "hllc", 0, 0.0, mb=(16, 8, 8)) + ["parthenon/time/nlim=12"]
     ref = Simulation(DECK("linwave", "linear_wave.in"), ov)
     ref.evolve()
-    monkeypatch.setenv("ARTEMIS_LOOPBACK_COMM", "1")
+    option("loopback_comm", 1)
     comm = RcclComm(0, 1)
     try:
         assert comm.count == 1
@@ -263,7 +263,7 @@ def test_rccl_loopback_halo_exchange(hiplib, monkeypatch):
         comm.close()
 
 
-def test_rccl_loopback_overlap_split_blocks(hiplib, monkeypatch):
+def test_rccl_loopback_overlap_split_blocks(hiplib, monkeypatch, option):
     """Same loopback route (native RCCL transport) with blocks big enough (96x32x24 cells = 3x4 tiles x 24
     planes) for the stage kernel to really split into boundary shell + bulk: overlap on/off and the plain
     device-copy run agree bit for bit (Sedov deck, outflow + block-to-block faces); also the
@@ -276,7 +276,7 @@ def test_rccl_loopback_overlap_split_blocks(hiplib, monkeypatch):
     ref = Simulation(DECK("blast", "blast.in"), ov)
     assert ref.nblocks == 8
     ref.evolve()
-    monkeypatch.setenv("ARTEMIS_LOOPBACK_COMM", "1")
+    option("loopback_comm", 1)
     comm = RcclComm(0, 1)
     try:
         for overlap, extra in ((2, []), (1, []), (0, []), (2, ["parthenon/time/tlim=-1.0"])):
@@ -292,7 +292,7 @@ def test_rccl_loopback_overlap_split_blocks(hiplib, monkeypatch):
         comm.close()
 
 
-def test_overlap_wait_timeout_is_reported(hiplib, monkeypatch):
+def test_overlap_wait_timeout_is_reported(hiplib, monkeypatch, option):
     """The comm stream's wait kernel gives up after its spin limit instead of hanging the GPU; the driver
     must then FAIL the run (the slabs behind the wait may hold unfinished shell data) and stop overlapping.
     Forced here by waiting for more shell workgroups than the launch has."""
@@ -301,19 +301,19 @@ def test_overlap_wait_timeout_is_reported(hiplib, monkeypatch):
           "parthenon/mesh/x3min=-1.0", "parthenon/mesh/x3max=1.0", "parthenon/meshblock/nx1=96",
           "parthenon/meshblock/nx2=32", "parthenon/meshblock/nx3=24", "gas/riemann=hllc",
           "problem/symmetry=spherical", "problem/radius=0.2", "problem/samples=0", "parthenon/time/nlim=3"]
-    monkeypatch.setenv("ARTEMIS_FORCE_OVERLAP", "1")  # shell-first launches although every link is local
+    option("force_overlap", 1)  # shell-first launches although every link is local
     ok = Simulation(DECK("blast", "blast.in"), ov)
     ok.set_overlap(2)
     ok.evolve()
     assert ok.ncycle == 3 and ok.overlap == 2
-    monkeypatch.setenv("ARTEMIS_TEST_SHELL_TARGET_BUMP", "100000")
-    monkeypatch.setenv("ARTEMIS_WAIT_SPIN_LIMIT", "2000")
+    option("test_shell_target_bump", 100000)
+    option("wait_spin_limit", 2000)
     bad = Simulation(DECK("blast", "blast.in"), ov)
     bad.set_overlap(2)
     with pytest.raises(RuntimeError, match="timed out"):
         bad.evolve()
     assert bad.overlap == 0
-    monkeypatch.delenv("ARTEMIS_TEST_SHELL_TARGET_BUMP")
+    option("test_shell_target_bump", 0)
     bad.close(), ok.close()
 
 
@@ -336,14 +336,14 @@ def test_dropin_accounting_mode_same_bits(hiplib):
         c.set_dropin(True)  # tuned fused path only
 
 
-def test_sync_free_loop_matches_host_dt_loop(hiplib, monkeypatch):
+def test_sync_free_loop_matches_host_dt_loop(hiplib, monkeypatch, option):
     """No time limit -> {time, dt, dt_est} live on the device, the stage kernels read dt there
     and the loop never synchronises.  Same bits as the host-side dt loop and as the oracle."""
     from artemis_amd.driver import Simulation
     ov = BLAST3D + ["parthenon/time/tlim=-1.0", "parthenon/time/nlim=14"]
     a = Simulation(DECK("blast", "blast.in"), ov)
     a.evolve()
-    monkeypatch.setenv("ARTEMIS_SYNC_LOOP", "1")
+    option("sync_loop", 1)
     b = Simulation(DECK("blast", "blast.in"), ov)
     b.evolve()
     o = Oracle((48, 40, 32), (-1, -1, -1), (1, 1, 1), ng=2, reconstruct="plm", riemann="hllc",
@@ -583,7 +583,7 @@ def test_general_stage_path_equals_per_task_path(hiplib):
         assert np.allclose(f.history(), u.history(), rtol=1e-13, atol=1e-15)
 
 
-def test_general_stage_sync_free_loop(hiplib, monkeypatch):
+def test_general_stage_sync_free_loop(hiplib, monkeypatch, option):
     """Without a time limit the general fused stage also keeps {time, dt, beta*dt} on the device
     (artemis_hip_advance_dt) and never synchronises; same bits as the host-side dt loop."""
     from artemis_amd.driver import Simulation
@@ -594,7 +594,7 @@ def test_general_stage_sync_free_loop(hiplib, monkeypatch):
     a = Simulation(DECK("ssheet", "ssheet.in"), ov)
     assert a.uses_fused_path and not a.uses_tuned_kernel
     a.evolve()
-    monkeypatch.setenv("ARTEMIS_SYNC_LOOP", "1")
+    option("sync_loop", 1)
     b = Simulation(DECK("ssheet", "ssheet.in"), ov)
     b.evolve()
     assert a.ncycle == b.ncycle == 25 and a.time == b.time and a.dt == b.dt

@@ -338,6 +338,37 @@ def test_hip_driver_equals_multilevel_oracle(hiplib, case, path):
     s.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["fused", "unfused"])
+@pytest.mark.parametrize("case", ["visc3d", "sph3d", "twolevel2d"])
+def test_refined_mesh_exchange_through_rccl_loopback(hiplib, case, path, option):
+    """The block-graph exchange and the flux correction of a refined mesh through the NATIVE C++ RCCL transport on one
+    GPU: with LOOPBACK_COMM the Z-ordered leaf list is cut into two virtual halves and every operation between them --
+    same-level slabs, restriction on the fly into a coarser neighbour, copies into a finer neighbour's coarse buffer,
+    restricted fine fluxes (viscous ones included) -- is packed into the send buffer, sent to this rank itself with
+    ncclSend / ncclRecv on the comm stream, and unpacked from the receive buffer: the code path two GPUs take.  Bitwise
+    equal to the run that copies on the device (which tests above hold against the multilevel oracle)."""
+    from artemis_amd.driver import RcclComm, Simulation
+    c = CASES[case]
+    ref = Simulation(DECK(*c["deck"]), c["ov"])
+    ref.set_path(path)
+    ref.evolve()
+    option("loopback_comm", 1)
+    comm = RcclComm(0, 1)
+    try:
+        sim = Simulation(DECK(*c["deck"]), c["ov"], comm=comm)
+        sim.set_path(path)
+        sim.evolve()
+        assert sim.nblocks == ref.nblocks and sim.ncycle == ref.ncycle and sim.dt == ref.dt and sim.time == ref.time
+        for b in range(sim.nblocks):
+            assert np.array_equal(sim.field("gas.prim", b)[[0, 1, 2, 3, 5]], ref.field("gas.prim", b)[[0, 1, 2, 3, 5]]), (case, b)
+        assert np.array_equal(sim.history(), ref.history())
+        sim.close()
+    finally:
+        comm.close()
+        ref.close()
+
+
 def _disk_cart(extra):
     from artemis_amd.driver import Simulation
     return Simulation(DECK("disk", "disk_cart.in"), ["parthenon/time/nlim=%d" % DISK["cycles"]] + extra)

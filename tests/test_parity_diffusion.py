@@ -183,7 +183,7 @@ VSRC = [
 
 @pytest.mark.parametrize("coordinates,nx,lo,hi", VSRC)
 @pytest.mark.parametrize("law,tiny", [("alpha", False), ("constant", False), ("constant", True), ("powerlaw", False)])
-def test_viscous_source_march(hiplib, coordinates, nx, lo, hi, law, tiny, monkeypatch):
+def test_viscous_source_march(hiplib, coordinates, nx, lo, hi, law, tiny, monkeypatch, option):
     """artemis_hip_viscous_source == ZeroDiffusionFlux -> ViscousFlux -> DiffusionUpdate of the oracle: conserved state
     minus the five sums equals the oracle's updated state bit for bit on every active zone -- three viscosity laws, both
     face averages, velocities of 1e-300 next to zeros and ordinary values
@@ -220,7 +220,7 @@ def test_viscous_source_march(hiplib, coordinates, nx, lo, hi, law, tiny, monkey
     mb.distance_table(D)  # (required by the march: it reads the table a plane ahead)
     for kchunk in (None, "5"):
         if kchunk:
-            monkeypatch.setenv("ARTEMIS_VISC_KCHUNK", kchunk)
+            option("visc_kchunk", int(kchunk))
         sums, _ = mb.viscous_source(D, dt)
         got = sums[0].cpu().numpy()
         for q in range(5):
@@ -229,7 +229,7 @@ def test_viscous_source_march(hiplib, coordinates, nx, lo, hi, law, tiny, monkey
 
 @pytest.mark.parametrize("coordinates,nx,lo,hi", [VSRC[2], VSRC[5], VSRC[0]])
 @pytest.mark.parametrize("stage2", [False, True])
-def test_stage_general_with_viscous_sums(hiplib, coordinates, nx, lo, hi, stage2, monkeypatch):
+def test_stage_general_with_viscous_sums(hiplib, coordinates, nx, lo, hi, stage2, monkeypatch, option):
     """The stage kernels fed with the sums instead of the twelve flux arrays (artemis_stage_general_args_t.diffusion_sums):
     the streaming tile kernel on curvilinear blocks and the cell-centred kernel, against the oracle's task chain."""
     from artemis_amd.pack import MeshBlockPack, diffusion_params, gravity_point
@@ -273,7 +273,7 @@ def test_stage_general_with_viscous_sums(hiplib, coordinates, nx, lo, hi, stage2
     keep = [0, 1, 2, 3, 5]
     for nofuse in (False, True):
         if nofuse:
-            monkeypatch.setenv("ARTEMIS_NO_FUSED_CURV", "1")
+            option("no_fused_curv", 1)
         gbuf, gout = mb.new_prim_buffer("o%d" % nofuse)
         mb.stage_general(g0, g1, be * dt, be * dt, gas=(gin, gu1, gout), time=time, gravity=grav,
                          rotating_frame=(om, 0.0), cfl=(0.3, 0.3), diffusion=D, diffusion_sums=sums)

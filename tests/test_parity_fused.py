@@ -190,11 +190,11 @@ def test_hint_words_report_vanishing_velocities_to_the_next_stage(hiplib):
         same(mb.gas_u0[0], o.gu0, "cons after the step (tiny=%s)" % tiny)
 
 
-def test_fused_step_without_redo_shows_the_limit_the_redo_removes(hiplib, monkeypatch):
+def test_fused_step_without_redo_shows_the_limit_the_redo_removes(hiplib, monkeypatch, option):
     """ARTEMIS_NO_REDO=1 (the pre-round-3 kernel: every zone stored by the fast path): on the same state a handful of
     values below 1e-120 differ from the oracle -- i.e. the test above is not vacuous, the redo list is what makes it
     exact."""
-    monkeypatch.setenv("ARTEMIS_NO_REDO", "1")
+    option("no_redo", 1)
     bc = ("outflow",) * 6
     o, mb, bufs = setup((40, 20, 36), 2, "plm", "hllc", bc, seed=13)
     rng = np.random.default_rng(3)

@@ -131,13 +131,13 @@ def test_calculate_fluxes_gas(hiplib, nx, ng, recon, riem):
 
 
 @pytest.mark.parametrize("riem", ["hllc", "hlle", "llf"])
-def test_calculate_fluxes_tile_march_equals_per_task_kernel(hiplib, riem, monkeypatch):
+def test_calculate_fluxes_tile_march_equals_per_task_kernel(hiplib, riem, monkeypatch, option):
     """Several blocks wide enough for the tile march: artemis_hip_calculate_fluxes through the march, through the
     one-thread-per-zone kernel (ARTEMIS_NO_TILED_FLUX) and the oracle agree bit for bit on every face output."""
     oracles, mb = make_pair((48, 20, 19), recon="plm", riem=riem, seed=21, nb=3)
     mb.CalculateFluxes(0, False)
     tiled = [[mb.gas_flux[d].clone(), mb.gas_pflux[d].clone(), mb.gas_vface[d].clone()] for d in range(3)]
-    monkeypatch.setenv("ARTEMIS_NO_TILED_FLUX", "1")
+    option("no_tiled_flux", 1)
     for d in range(3):
         mb.gas_flux[d].zero_(), mb.gas_pflux[d].zero_(), mb.gas_vface[d].zero_()
     mb.CalculateFluxes(0, False)

@@ -266,7 +266,7 @@ CURV_SRC_BLOCKS = [
 
 @pytest.mark.parametrize("coordinates,nx,lo,hi", CURV_SRC_BLOCKS)
 @pytest.mark.parametrize("stage2", [False, True])
-def test_curvilinear_tile_kernel_with_sources(hiplib, coordinates, nx, lo, hi, stage2, monkeypatch):
+def test_curvilinear_tile_kernel_with_sources(hiplib, coordinates, nx, lo, hi, stage2, monkeypatch, option):
     """One gas species on a curvilinear block with everything the curvilinear instantiation of the streaming
     tile kernel folds in: DiffusionUpdate from stored viscous + thermal fluxes, point-mass gravity (off-centre
     where the system allows), RotatingFrameImpl from the cell's own mass fluxes, the frame velocity in
@@ -315,7 +315,7 @@ def test_curvilinear_tile_kernel_with_sources(hiplib, coordinates, nx, lo, hi, s
     dts = []
     for nofuse in (False, True):
         if nofuse:
-            monkeypatch.setenv("ARTEMIS_NO_FUSED_CURV", "1")
+            option("no_fused_curv", 1)
         gbuf, gout = mb.new_prim_buffer("o%d" % nofuse)
         dtd = torch.full((1,), 1.7976931348623157e308, dtype=torch.float64, device="cuda")
         mb.stage_general(g0, g1, be * dt, be * dt, gas=(gin, gu1, gout), time=time, gravity=grav,
