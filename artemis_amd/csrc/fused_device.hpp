@@ -35,6 +35,17 @@ template <class T>
 ADEV T kload(const T *p) {
   return *(const __attribute__((address_space(4))) T *)(p);
 }
+// ... a plain-data record (size a multiple of 8 bytes) word by word
+template <class T>
+ADEV T kload_record(const T *p) {
+  static_assert(sizeof(T) % 8 == 0, "kload_record: whole 8-byte words");
+  T out;
+  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p);
+  unsigned long long *dst = reinterpret_cast<unsigned long long *>(&out);
+#pragma unroll
+  for (unsigned q = 0; q < sizeof(T) / 8; ++q) dst[q] = kload(src + q);
+  return out;
+}
 ADEV int opaque(int i) {
   asm volatile("" : "+s"(i));
   return i;

@@ -3,6 +3,7 @@
 // DragSource.  Each reads primitives / conserved variables of one cell and updates the
 // conserved variables of the same cell: pure streaming kernels, thread x walks i.
 #include <cfloat>
+#include <type_traits>
 
 #include <cstdlib>
 
@@ -424,6 +425,17 @@ static artemis_diffcoeff_t damp_visc_of(const artemis_drag_t &D) {
   if (D.damp_visc) v = *D.damp_visc;
   return v;
 }
+// any <gas|dust/damping> rate non-zero?  Otherwise every ramp is dt * (0 * a + 0 * b) with finite a, b -- the zone
+// centre lies strictly inside the damping bounds the deck reader fills in -- i.e. + 0.0, and the kernels skip them.
+static int damping_on(const artemis_drag_t &D) {
+  bool on = false;
+  for (int d = 0; d < 3; ++d) {
+    on = on || D.gas.irate[d] != 0.0 || D.gas.orate[d] != 0.0 || D.dust.irate[d] != 0.0 || D.dust.orate[d] != 0.0;
+    // (a threshold ON the mesh bound makes the ramp's quotient x / 0: evaluated as written then)
+    on = on || D.gas.ix[d] == D.xmin[d] || D.gas.ox[d] == D.xmax[d] || D.dust.ix[d] == D.xmin[d] || D.dust.ox[d] == D.xmax[d];
+  }
+  return on ? 1 : 0;
+}
 __device__ __forceinline__ void damping_ramps(const artemis_damping_t &p, const artemis_drag_t &D,
                                               int ndim, const double xv[3], double dt,
                                               double f[3]) {
@@ -501,9 +513,14 @@ __global__ __launch_bounds__(TX *TY) void self_drag_kernel(const PackView P, con
 // SetAuxillaryFields (fill_derived.cpp:58-71) and ConsToPrim (:132-164) of the cell and write the
 // new primitives to P.{gas,dust}.prim -- the tail of the general fused stage in one pass
 // (one gas species).
-template <bool FINISH>
+// Every input (pointer-table entries and values) is read BEFORE the first store and every result is stored at the end:
+// behind a store the table entries -- wave-uniform addresses -- could no longer come through the scalar cache, and each
+// would be a vector load with a full memory wait behind it (one thread per zone: nothing else hides it).  MAXD: the
+// dust species the registers hold (more species: the generic loop below, stores interleaved as before).
+constexpr int DRAG_MAXD = 4;
+template <bool FINISH, int ND> // ND: the number of dust species as a compile-time constant (0 .. DRAG_MAXD), or -1 = any
 __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, const artemis_drag_t D, const artemis_diffcoeff_t V,
-                                                             double dt_host, const double *dt_dev) {
+                                                             double dt_host, const double *dt_dev, const int damp_on) {
   INTERIOR_CELL
   const double dt = dt_dev ? *dt_dev : dt_host;
   const DCoords co = make_coords(P, b, k, j, i);
@@ -511,23 +528,56 @@ __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, c
   double hx[3];
   scale_factors_of(co, hx);
   const CylVec cv = to_cyl_with_vec(co, xv);
-  double bg[3], bd[3];
-  damping_ramps(D.gas, D, P.ndim, xv, dt, bg);
-  damping_ramps(D.dust, D, P.ndim, xv, dt, bd);
+  double bg[3] = {0.0, 0.0, 0.0}, bd[3] = {0.0, 0.0, 0.0};
+  if (damp_on) { // (uniform; twelve divisions per zone otherwise spent on dt * (0 * x + 0 * y) = +0: damping_on below)
+    damping_ramps(D.gas, D, P.ndim, xv, dt, bg);
+    damping_ramps(D.dust, D, P.ndim, xv, dt, bd);
+  }
   const FluidView &G = P.gas, &F = P.dust;
-  const int nsg = G.ns, nvg = 6 * nsg, nsd = F.ns, nvd = 4 * nsd;
+  const int nsg = G.ns, nvg = 6 * nsg, nsd = (ND >= 0) ? ND : F.ns, nvd = 4 * nsd;
+  // ---- inputs ----------------------------------------------------------------------------------------------------------
+  double *const pg_m[3] = {G.cons0[b * nvg + nsg + 0], G.cons0[b * nvg + nsg + 1], G.cons0[b * nvg + nsg + 2]};
+  double *const pg_e = G.cons0[b * nvg + 4 * nsg];
+  double *const og_d = FINISH ? G.prim[b * nvg + 0] : nullptr, *const og_s = FINISH ? G.prim[b * nvg + 5 * nsg] : nullptr;
+  double *const og_v[3] = {FINISH ? G.prim[b * nvg + nsg + 0] : nullptr, FINISH ? G.prim[b * nvg + nsg + 1] : nullptr,
+                           FINISH ? G.prim[b * nvg + nsg + 2] : nullptr};
   const double dg = G.cons0[b * nvg + 0][c];
-  double *mg[3] = {G.cons0[b * nvg + nsg + 0], G.cons0[b * nvg + nsg + 1], G.cons0[b * nvg + nsg + 2]};
-  const double vg[3] = {mg[0][c] / (hx[0] * dg), mg[1][c] / (hx[1] * dg), mg[2][c] / (hx[2] * dg)};
-  // GetSpecificInternalEnergy (artemis_utils.hpp:43-62), species 0
-  double sieg;
+  const double mg0[3] = {pg_m[0][c], pg_m[1][c], pg_m[2][c]};
+  const double e_cons = pg_e[c];
+  const double eg_cons = G.cons0[b * nvg + 5 * nsg][c];
+  constexpr int nreg = (ND >= 0) ? ND : 0; // species held in registers
+  constexpr int NR = nreg > 0 ? nreg : 1;
+  double dens_[NR], md_[NR][3];
+  double *pd_m[NR][3], *od_d[NR], *od_v[NR][3];
+#pragma unroll
+  for (int n = 0; n < nreg; ++n)
+    {
+      dens_[n] = F.cons0[b * nvd + n][c];
+      od_d[n] = FINISH ? F.prim[b * nvd + n] : nullptr;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        pd_m[n][d] = F.cons0[b * nvd + nsd + 3 * n + d];
+        md_[n][d] = pd_m[n][d][c];
+        od_v[n][d] = FINISH ? F.prim[b * nvd + nsd + 3 * n + d] : nullptr;
+      }
+    }
+  auto dust_dens = [&](int n) { return (ND >= 0) ? dens_[ND >= 0 ? n : 0] : F.cons0[b * nvd + n][c]; };
+  auto dust_mom = [&](int n, int d) { return (ND >= 0) ? md_[ND >= 0 ? n : 0][d] : F.cons0[b * nvd + nsd + 3 * n + d][c]; };
+  double en = 0.0, mnew[3] = {0.0, 0.0, 0.0};
+  constexpr int NRr = (ND > 0) ? ND : 1;
+  double newd[NRr][3];
+  auto coupled = [&](auto FT) {
+    constexpr bool FAST = decltype(FT)::value;
+    auto dv = [](double num, double den) { return FAST ? div(num, den) : num / den; };
+  // ---- the coupled update (drag.hpp:296-482) ------------------------------------------------------------------------
+  const double vg[3] = {dv(mg0[0], hx[0] * dg), dv(mg0[1], hx[1] * dg), dv(mg0[2], hx[2] * dg)};
+  double sieg; // GetSpecificInternalEnergy (artemis_utils.hpp:43-62), species 0
   {
     const double u_d = amax(dg, G.dfloor);
-    const double rv1 = mg[0][c] / hx[0], rv2 = mg[1][c] / hx[1], rv3 = mg[2][c] / hx[2];
-    const double ke = 0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)) / u_d;
-    const double e_cons = G.cons0[b * nvg + 4 * nsg][c];
+    const double rv1 = dv(mg0[0], hx[0]), rv2 = dv(mg0[1], hx[1]), rv3 = dv(mg0[2], hx[2]);
+    const double ke = dv(0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)), u_d);
     const double ue_cons = e_cons - ke;
-    sieg = (ue_cons > G.de_switch * e_cons) ? ue_cons / u_d : G.cons0[b * nvg + 5 * nsg][c] / u_d;
+    sieg = (ue_cons > G.de_switch * e_cons) ? dv(ue_cons, u_d) : dv(eg_cons, u_d);
     sieg = amax(sieg, G.siefloor);
   }
   const double mu = D.damp_visc ? coeff_of(V, 0.0, P.gm1, dg, sieg, b, c) : 0.0; // drag.hpp:392-393
@@ -538,80 +588,100 @@ __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, c
   const bool stokes = (D.model == ARTEMIS_DRAG_STOKES);
   if (stokes) vth = sqrt(8.0 / M_PI * P.gm1 * sieg);
   const double vdt[3] = {0.0, 0.0, 0.0};
+#pragma unroll
   for (int n = 0; n < nsd; ++n) {
-    const double dens = F.cons0[b * nvd + n][c];
-    const double vd[3] = {F.cons0[b * nvd + nsd + 3 * n + 0][c] / (hx[0] * dens),
-                          F.cons0[b * nvd + nsd + 3 * n + 1][c] / (hx[1] * dens),
-                          F.cons0[b * nvd + nsd + 3 * n + 2][c] / (hx[2] * dens)};
+    const double dens = dust_dens(n);
+    const double vd[3] = {dv(dust_mom(n, 0), hx[0] * dens), dv(dust_mom(n, 1), hx[1] * dens), dv(dust_mom(n, 2), hx[2] * dens)};
     double tc = D.tau[n];
     if (stokes) tc = D.scale * D.grain_density / dg * D.sizes[n] / vth;
     const double alpha = dt * ((tc <= 0.0) ? DBL_MAX : 1.0 / tc);
     for (int d = 0; d < 3; d++) {
-      const double rhop = dens * alpha / (1.0 + alpha + bd[d]);
+      const double rhop = dv(dens * alpha, 1.0 + alpha + bd[d]);
       fd[d] += rhop * (1.0 + bd[d]);
       fvd[d] += rhop * (vd[d] + bd[d] * vdt[d]);
     }
   }
   double vgp[3];
   for (int d = 0; d < 3; d++)
-    vgp[d] = (dg * (vg[d] + bg[d] * vt[d]) + fvd[d]) / (dg * (1.0 + bg[d]) + fd[d]);
+    vgp[d] = dv(dg * (vg[d] + bg[d] * vt[d]) + fvd[d], dg * (1.0 + bg[d]) + fd[d]);
   double delta_g[3] = {0.0, 0.0, 0.0};
   for (int d = 0; d < 3; d++) fvd[d] = 0.;
+#pragma unroll
   for (int n = 0; n < nsd; ++n) {
-    const double dens = F.cons0[b * nvd + n][c];
-    const double vd[3] = {F.cons0[b * nvd + nsd + 3 * n + 0][c] / (hx[0] * dens),
-                          F.cons0[b * nvd + nsd + 3 * n + 1][c] / (hx[1] * dens),
-                          F.cons0[b * nvd + nsd + 3 * n + 2][c] / (hx[2] * dens)};
+    const double dens = dust_dens(n);
+    const double vd[3] = {dv(dust_mom(n, 0), hx[0] * dens), dv(dust_mom(n, 1), hx[1] * dens), dv(dust_mom(n, 2), hx[2] * dens)};
     double tc = D.tau[n];
     if (stokes) tc = D.scale * D.grain_density / dg * D.sizes[n] / vth;
     const double alpha = dt * ((tc <= 0.0) ? DBL_MAX : 1.0 / tc);
     for (int d = 0; d < 3; d++) {
       double delta_d = 0.;
-      const double rhop = dens * alpha / (1.0 + alpha + bd[d]);
+      const double rhop = dv(dens * alpha, 1.0 + alpha + bd[d]);
       const double delta = rhop * ((vgp[d] - vd[d] + bd[d] * (vgp[d] - vdt[d])));
       delta_d += delta;
       delta_g[d] -= delta;
-      delta_d -= bd[d] * dens / (1. + alpha + bd[d]) * (vd[d] - vdt[d] + alpha * (vgp[d] - vdt[d]));
+      delta_d -= dv(bd[d] * dens, 1. + alpha + bd[d]) * (vd[d] - vdt[d] + alpha * (vgp[d] - vdt[d]));
       fvd[d] += rhop * (vd[d] - vt[d] + bd[d] * (vdt[d] - vt[d]));
+      const double m = dust_mom(n, d) + hx[d] * delta_d;
+      double out = m;
       if constexpr (FINISH) {
         const double w_d = (dens > F.dfloor) ? dens : F.dfloor;
-        const double m = F.cons0[b * nvd + nsd + 3 * n + d][c] + hx[d] * delta_d;
-        F.prim[b * nvd + nsd + 3 * n + d][c] = m / (w_d * hx[d]);
-        if (d == 0) F.prim[b * nvd + n][c] = w_d;
+        out = dv(m, w_d * hx[d]);
+      }
+      if constexpr (ND >= 0) {
+        newd[n][d] = out;
+      } else if constexpr (FINISH) { // (more species than the registers hold: stored at once, as the first form of this kernel did)
+        F.prim[b * nvd + nsd + 3 * n + d][c] = out;
+        if (d == 0) F.prim[b * nvd + n][c] = (dens > F.dfloor) ? dens : F.dfloor;
       } else {
-        F.cons0[b * nvd + nsd + 3 * n + d][c] += hx[d] * delta_d;
+        F.cons0[b * nvd + nsd + 3 * n + d][c] = out;
       }
     }
   }
-  double en = G.cons0[b * nvg + 4 * nsg][c];
-  double mnew[3];
+  en = e_cons;
   for (int d = 0; d < 3; d++) {
-    const double prefac = dg * bg[d] / (1.0 + bg[d] + fd[d]);
+    const double prefac = dv(dg * bg[d], 1.0 + bg[d] + fd[d]);
     delta_g[d] -= prefac * (dg * (vg[d] - vt[d]) + fvd[d]);
-    mnew[d] = mg[d][c] + hx[d] * delta_g[d];
-    if constexpr (!FINISH) mg[d][c] = mnew[d];
+    mnew[d] = mg0[d] + hx[d] * delta_g[d];
     en += 0.5 * (vg[d] + vgp[d]) * delta_g[d];
   }
+  };
+  // (IEEE divisions throughout: this one-thread-per-zone kernel waits for memory, not for its ~35 divisions -- the guarded
+  // hand-scheduled form measured 10 % slower on the 29 M-zone configs[4] mesh)
+  coupled(std::false_type{});
+  // ---- stores ------------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int n = 0; n < nreg; ++n)
+    {
+      if constexpr (FINISH) {
+        od_d[n][c] = (dens_[n] > F.dfloor) ? dens_[n] : F.dfloor;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) od_v[n][d][c] = newd[n][d];
+      } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pd_m[n][d][c] = newd[n][d];
+      }
+    }
   if constexpr (!FINISH) {
-    G.cons0[b * nvg + 4 * nsg][c] = en;
+    for (int d = 0; d < 3; ++d) pg_m[d][c] = mnew[d];
+    pg_e[c] = en;
   } else {
     const double u_d = (dg > G.dfloor) ? dg : G.dfloor;
     const double u_d2 = amax(dg, G.dfloor);
     const double rv1 = mnew[0] / hx[0], rv2 = mnew[1] / hx[1], rv3 = mnew[2] / hx[2];
     const double ke = 0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)) / u_d2;
     const double ue_cons = en - ke;
-    double sie = (ue_cons > G.de_switch * en) ? ue_cons / u_d2 : G.cons0[b * nvg + 5 * nsg][c] / u_d2;
+    double sie = (ue_cons > G.de_switch * en) ? ue_cons / u_d2 : eg_cons / u_d2;
     sie = amax(sie, G.siefloor);
     double u_u = sie * u_d;
     const double uflr = G.siefloor * u_d;
     u_u = (u_u > uflr) ? u_u : uflr;
     const double w_d = u_d;
-    G.prim[b * nvg + 0][c] = w_d;
-    G.prim[b * nvg + nsg + 0][c] = mnew[0] / (w_d * hx[0]);
-    G.prim[b * nvg + nsg + 1][c] = mnew[1] / (w_d * hx[1]);
-    G.prim[b * nvg + nsg + 2][c] = mnew[2] / (w_d * hx[2]);
     const double w_s = u_u / w_d;
-    G.prim[b * nvg + 5 * nsg][c] = (w_s > G.siefloor) ? w_s : G.siefloor;
+    og_d[c] = w_d;
+    og_v[0][c] = mnew[0] / (w_d * hx[0]);
+    og_v[1][c] = mnew[1] / (w_d * hx[1]);
+    og_v[2][c] = mnew[2] / (w_d * hx[2]);
+    og_s[c] = (w_s > G.siefloor) ? w_s : G.siefloor;
   }
 }
 
@@ -690,19 +760,34 @@ void launch_cooling(const PackView &P, const artemis_cooling_t &C, double dt, hi
 void launch_rotating_frame(const PackView &P, double omega, double dt, hipStream_t s) {
   hipLaunchKernelGGL(rotating_frame_kernel, interior_grid(P), interior_threads(P), 0, s, P, omega, dt);
 }
+template <bool FINISH>
+static void launch_simple_drag(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev, hipStream_t s) {
+#define DRAG_ND(N)                                                                                                            \
+  hipLaunchKernelGGL((simple_drag_kernel<FINISH, N>), interior_grid(P), interior_threads(P), 0, s, P, D, damp_visc_of(D), dt, \
+                     dt_dev, damping_on(D))
+  switch (P.dust.ns) {
+  case 0: DRAG_ND(0); break;
+  case 1: DRAG_ND(1); break;
+  case 2: DRAG_ND(2); break;
+  case 3: DRAG_ND(3); break;
+  case 4: DRAG_ND(4); break;
+  default: DRAG_ND(-1);
+  }
+#undef DRAG_ND
+}
 void launch_drag_source(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
                         hipStream_t s) {
   if (D.type == ARTEMIS_DRAG_SELF)
     hipLaunchKernelGGL(self_drag_kernel, interior_grid(P), interior_threads(P), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
   else
-    hipLaunchKernelGGL(simple_drag_kernel<false>, interior_grid(P), interior_threads(P), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
+    launch_simple_drag<false>(P, D, dt, dt_dev, s);
 }
 // simple_dust drag + SetAuxillaryFields + ConsToPrim of a one-gas-species pack in one pass: reads
 // cons0, writes the primitives of P (the general fused stage points them at its out tables)
 bool launch_drag_finish(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
                         hipStream_t s) {
   if (D.type != ARTEMIS_DRAG_SIMPLE_DUST || P.gas.ns != 1) return false;
-  hipLaunchKernelGGL(simple_drag_kernel<true>, interior_grid(P), interior_threads(P), 0, s, P, D, damp_visc_of(D), dt, dt_dev);
+  launch_simple_drag<true>(P, D, dt, dt_dev, s);
   return true;
 }
 

@@ -6,6 +6,7 @@
 // force-only instantiation (artemis_hip_nbody_force_sums): they depend on the stage's input primitives alone.
 #pragma once
 #include "device_math.hpp"
+#include "fused_device.hpp"
 #include "geometry.hpp"
 #include "sources_device.hpp"
 
@@ -175,7 +176,7 @@ ADEV void nb_apply(const artemis_nbody_particle_t *pl, int npart, const CO &co, 
   nb_cart_velocity(z.fr, w, vc);
 #pragma unroll 1
   for (int n = 0; n < npart; ++n) {
-    const artemis_nbody_particle_t p = pl[n]; // (wave-uniform address: scalar loads)
+    const artemis_nbody_particle_t p = fused::kload_record(pl + n); // (never written by a kernel: a scalar load also behind stores)
     if (!p.couple) continue;
     const NbPull q = nb_pull(p, z.fr);
     nb_fluid<GAS, true, false>(p, z, q, dt, w, vc, u, nullptr);
