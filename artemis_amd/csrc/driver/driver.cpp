@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -426,6 +427,8 @@ struct artemis_sim_impl {
   void build_mesh();
   void allocate();
   void ensure_unfused();
+  void ensure_flux_arrays();
+  bool flux_ready = false;
   void problem_generator();
   void fill_ghosts(int prim_idx);
   void step_general(bool want_dt, bool device_dt);
@@ -1456,10 +1459,10 @@ void artemis_sim_impl::allocate() {
   CK(artemis_rt_device_sync(), "sync");
 }
 
-void artemis_sim_impl::ensure_unfused() {
-  if (unfused_ready) return;
-  gu1.alloc(nb, 6 * ns_gas, N);
-  du1.alloc(nb, 4 * ns_dust, N);
+// the flux arrays alone: what the one-kernel stages of a refined mesh need next to their primitive buffers (the
+// fine-side faces of coarse-fine boundaries and their restrictions live in them); the per-task chain also needs u1
+void artemis_sim_impl::ensure_flux_arrays() {
+  if (flux_ready) return;
   for (int d = 0; d < 3; ++d) {
     gflux[d].alloc(nb, 6 * ns_gas, N);
     gpflux[d].alloc(nb, ns_gas, N);
@@ -1467,6 +1470,13 @@ void artemis_sim_impl::ensure_unfused() {
     dflux[d].alloc(nb, 4 * ns_dust, N);
     if ((do_viscosity || do_conduction) && !gdflux[d].ok()) gdflux[d].alloc(nb, 4 * ns_gas, N);
   }
+  flux_ready = true;
+}
+void artemis_sim_impl::ensure_unfused() {
+  if (unfused_ready) return;
+  gu1.alloc(nb, 6 * ns_gas, N);
+  du1.alloc(nb, 4 * ns_dust, N);
+  ensure_flux_arrays();
   unfused_ready = true;
 }
 
@@ -1650,6 +1660,14 @@ static void to_cart(int sys, const Real xi[3], Real xc[3]) {
 }
 
 void artemis_sim_impl::problem_generator() {
+  const bool pg_timing = artemis::opt(artemis::OPT_SETUP_TIMING) != 0;
+  auto pg_t0 = std::chrono::steady_clock::now();
+  auto pg_lap = [&](const char *what) {
+    if (pg_timing)
+      std::fprintf(stderr, "[artemis setup]   pgen: %-24s %8.3f s\n", what,
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - pg_t0).count());
+    pg_t0 = std::chrono::steady_clock::now();
+  };
   const Real gm1 = gamma - 1.0;
   auto xf = [&](int b, int d, int idx) { // Coordinates_t::Xf (geometry.hpp:65-72)
     const Real dx = (blocks[b].xmax[d] - blocks[b].xmin[d]) / mbnx[d];
@@ -1833,12 +1851,25 @@ void artemis_sim_impl::problem_generator() {
   // One block's initial primitives on the host (libm, like the reference's CPU build).  Blocks are independent and
   // nothing below writes shared state, so a refined mesh (thousands of small blocks, 20 s single-threaded for
   // inputs/disk/disk_cart.in) is generated by a few host threads; uploads stay on this thread's stream, in order.
-  auto generate_block = [&](const int b, std::vector<Real> &hg, std::vector<Real> &hd) {
+  // only_ic_ghosts (a remesh: the state itself is handed over by adopt_state_from): the generated values are read as the
+  // `ic` condition's states alone, i.e. in the ghost zones behind the block's `ic` faces -- a tenth of the block; the
+  // host libm evaluations of the other zones (a quarter of a second per 270 new blocks) are skipped, their entries stay 0
+  auto generate_block = [&](const int b, std::vector<Real> &hg, std::vector<Real> &hd, const bool only_ic_ghosts = false) {
     std::fill(hg.begin(), hg.end(), 0.0);
     std::fill(hd.begin(), hd.end(), 0.0);
+    const int g3[3] = {ng, ndim > 1 ? ng : 0, ndim > 2 ? ng : 0};
+    auto behind_ic_face = [&](int k, int j, int i) {
+      const int idx[3] = {i, j, k};
+      for (int d = 0; d < ndim; ++d) {
+        if (idx[d] < g3[d] && blocks[b].bc[2 * d] == ARTEMIS_BC_IC) return true;
+        if (idx[d] >= g3[d] + mbnx[d] && blocks[b].bc[2 * d + 1] == ARTEMIS_BC_IC) return true;
+      }
+      return false;
+    };
     for (int k = 0; k < nk; ++k)
       for (int j = 0; j < nj; ++j)
         for (int i = 0; i < ni; ++i) {
+          if (only_ic_ghosts && !behind_ic_face(k, j, i)) continue;
           const Real b1[2] = {xf(b, 0, i), xf(b, 0, i + 1)}, b2[2] = {xf(b, 1, j), xf(b, 1, j + 1)};
           const Real b3[2] = {xf(b, 2, k), xf(b, 2, k + 1)};
           const Real xv[3] = {0.5 * (b1[0] + b1[1]), 0.5 * (b2[0] + b2[1]), 0.5 * (b3[0] + b3[1])};
@@ -2115,13 +2146,13 @@ void artemis_sim_impl::problem_generator() {
       for (int t = 1; t < nbatch; ++t)
         pool.emplace_back([&, t] {
           try {
-            generate_block(todo[q0 + t], hgs[t], hds[t]);
+            generate_block(todo[q0 + t], hgs[t], hds[t], adopting);
           } catch (...) {
             errs[t] = std::current_exception();
           }
         });
       try {
-        generate_block(todo[q0], hgs[0], hds[0]);
+        generate_block(todo[q0], hgs[0], hds[0], adopting);
       } catch (...) {
         errs[0] = std::current_exception();
       }
@@ -2130,18 +2161,20 @@ void artemis_sim_impl::problem_generator() {
         if (errs[t]) std::rethrow_exception(errs[t]);
       for (int t = 0; t < nbatch; ++t) {
         const int b = todo[q0 + t];
-        if (do_gas) upload_block(gprim[0], b, hgs[t]);
-        if (do_dust) upload_block(dprim[0], b, hds[t]);
+        if (do_gas && !adopting) upload_block(gprim[0], b, hgs[t]); // (a remesh: adopt_state_from brings the state)
+        if (do_dust && !adopting) upload_block(dprim[0], b, hds[t]);
         if (ic_gas.ok()) upload_block(ic_gas, b, hgs[t]); // as generated, before PrimToCons applies the floors
         if (ic_dust.ok()) upload_block(ic_dust, b, hds[t]);
       }
     }
   }
+  pg_lap("generate + upload blocks");
   if (adopting && reuse_from && ic_gas.ok() && reuse_from->ic_gas.ok()) {
     auto ob = [&](int b) { return reuse_block(b); };
     copy_rows(ic_gas, reuse_from->ic_gas, ob);
     if (do_dust) copy_rows(ic_dust, reuse_from->ic_dust, ob);
   }
+  pg_lap("copy ic rows");
   if (multilevel && ic_gas.ok()) {
     // The `ic` condition on a coarse buffer takes the profile at the buffer's own zone centres (the reference's
     // DiskBoundaryIC re-evaluates it wherever it is applied): run the generator once more on the coarse geometry
@@ -2172,7 +2205,7 @@ void artemis_sim_impl::problem_generator() {
           if (do_dust) CK(artemis_rt_memcpy_d2d(ic_dust_c.var(b, 0), reuse_from->ic_dust_c.var(ob, 0), sizeof(Real) * 4 * ns_dust * N, stream), "d2d");
           continue;
         }
-        generate_block(b, hgc, hdc);
+        generate_block(b, hgc, hdc, true); // (coarse buffers: the `ic` condition's ghost zones are all that is ever read)
         if (do_gas) upload_block(ic_gas_c, b, hgc);
         if (do_dust) upload_block(ic_dust_c, b, hdc);
       }
@@ -2184,6 +2217,7 @@ void artemis_sim_impl::problem_generator() {
     ni = fi, nj = fj, nk = fk, N = fN, hgeom.swap(fgeom), hmetric.swap(fmetric);
     for (int d = 0; d < 3; ++d) mbnx[d] = fm[d];
   }
+  pg_lap("coarse-buffer ic states");
   base = 0;
   if (do_cooling && do_gas) {
     cool.cv = cv_gas;
@@ -2234,6 +2268,7 @@ void artemis_sim_impl::problem_generator() {
     if (adopting && reuse_from && reuse_from->visc_radial.ok()) copy_rows(visc_radial, reuse_from->visc_radial, [&](int b) { return reuse_block(b); });
     diff.visc.radial = visc_radial.tab();
   }
+  pg_lap("viscosity radial table");
   if ((do_viscosity || do_conduction) && !artemis::opt(artemis::OPT_NO_DISTANCE_TABLE)) {
     // Coords::Distance between neighbouring cell centres is geometry: tabulated once per mesh (a remesh builds
     // a new state through this constructor path, so the table follows the blocks)
@@ -2247,6 +2282,7 @@ void artemis_sim_impl::problem_generator() {
   // then parthenon Mesh::Initialize communicates boundaries (upstream, recalled):
   // PreCommFillDerived (ConsToPrim, artemis.cpp:122) -> exchange + physical BCs ->
   // FillDerived (PrimToCons, artemis.cpp:123).
+  pg_lap("distance table");
   if (adopting) { // adopt_state_from brings the state and runs this sequence on it
     CK(artemis_rt_stream_sync(stream), "sync");
     return;
@@ -2843,7 +2879,7 @@ void artemis_sim_impl::fill_stale_ghosts() {
 // coarse zones that touch such a face redone with them.  Same bits as step_unfused (tests/test_multilevel.py runs both).
 void artemis_sim_impl::step_ml_fused() {
   tiny_valid = false;
-  ensure_unfused(); // the flux arrays the fine-side faces and their restrictions live in
+  ensure_flux_arrays(); // (the fine-side faces and their restrictions live in them; no u1: 160 B per zone less)
   for (int q = 1; q < 3; ++q) {
     if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
     if (!dprim[q].ok()) dprim[q].alloc(nb, 4 * ns_dust, N);
@@ -3283,6 +3319,10 @@ struct artemis_sim {
   // handing the data over; and how many there were
   double remesh_s = 0.0, remesh_build_s = 0.0, remesh_adopt_s = 0.0, remesh_tag_s = 0.0;
   long remesh_n = 0;
+  // the last remesh of the run: leaves before / after, leaves created (not in the old mesh) / destroyed (not in the new
+  // one), its wall-clock seconds (total, build, hand-over)
+  long last_remesh[4] = {0, 0, 0, 0};
+  double last_remesh_s[3] = {0.0, 0.0, 0.0};
   // A lean remesh releases the old state's work arrays BEFORE the new state allocates (peak = resident bytes); if the
   // new state then cannot be built or filled, the old one can no longer step: the handle is dead and says why
   std::string dead;
@@ -3380,7 +3420,7 @@ static bool next_leaves(artemis_sim &h, const std::vector<int> &tags, bool allow
 
 // One remesh check (parthenon LoadBalancingAndAdaptiveMeshRefinement, upstream, after every cycle).  initial: the
 // loop of Mesh::Initialize -- refine only, and the problem generator fills the new mesh instead of a prolongation.
-static bool remesh(artemis_sim &h, bool initial, long force_refine_gid = -1) {
+static bool remesh(artemis_sim &h, bool initial, long force_refine_gid = -1, const std::vector<long> *inject = nullptr) {
   if (!h.p->adaptive || !h.p->refine_field) return false;
   const auto t_start = std::chrono::steady_clock::now();
   auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
@@ -3399,10 +3439,24 @@ static bool remesh(artemis_sim &h, bool initial, long force_refine_gid = -1) {
     for (int &t : tags) t = std::max(t, 0);
     if (force_refine_gid < static_cast<long>(tags.size())) tags[force_refine_gid] = 1;
   }
+  if (inject) // artemis_sim_inject_refine_tags: these leaves are tagged +1 NEXT TO what the criterion says (merges go on)
+    for (long g : *inject)
+      if (g >= 0 && g < static_cast<long>(tags.size())) tags[g] = 1;
   std::vector<artemis_host::Leaf> leaves;
   const bool changed = next_leaves(h, tags, !initial, leaves);
   if (!initial) h.remesh_tag_s += since(t_start);
   if (!changed) return false;
+  { // what this remesh changes, in leaves
+    std::set<std::tuple<int, int, int, int>> was, is;
+    for (const artemis_host::Leaf &l : h.p->tree_leaves) was.insert(std::make_tuple(l.level, l.lx[0], l.lx[1], l.lx[2]));
+    for (const artemis_host::Leaf &l : leaves) is.insert(std::make_tuple(l.level, l.lx[0], l.lx[1], l.lx[2]));
+    long created = 0, destroyed = 0;
+    for (const auto &k : is) created += was.count(k) ? 0 : 1;
+    for (const auto &k : was) destroyed += is.count(k) ? 0 : 1;
+    h.last_remesh[0] = static_cast<long>(was.size()), h.last_remesh[1] = static_cast<long>(is.size());
+    h.last_remesh[2] = created, h.last_remesh[3] = destroyed;
+  }
+  const double build_before = h.remesh_build_s, adopt_before = h.remesh_adopt_s;
   const auto t_build = std::chrono::steady_clock::now();
   const bool lean = !initial && !artemis::opt(artemis::OPT_FULL_REMESH);
   std::unique_ptr<artemis_sim_impl> np;
@@ -3427,6 +3481,10 @@ static bool remesh(artemis_sim &h, bool initial, long force_refine_gid = -1) {
   np->reuse_from = nullptr, np->reuse_lookup.clear(); // (the old state goes away)
   release_impl(h.p);
   h.p = std::move(np);
+  // What is left in artemis_rt's buffer cache now belonged to the old mesh and fitted nothing of the new one: the next
+  // remesh re-uses the buffers THIS state releases, never these -- give them back (a mesh that grows by 3 % per remesh
+  // otherwise drags up to the cache limit of stale slabs along)
+  if (!initial) artemis_rt_pool_trim(0);
   // counters of leaves that no longer exist are dropped; new leaves start at zero
   std::map<std::tuple<int, int, int, int>, int> keep;
   for (const artemis_host::Leaf &l : h.p->tree_leaves) {
@@ -3436,7 +3494,11 @@ static bool remesh(artemis_sim &h, bool initial, long force_refine_gid = -1) {
   }
   h.deref_count.swap(keep);
   h.remeshes++;
-  if (!initial) h.remesh_s += since(t_start), h.remesh_n++;
+  if (!initial) {
+    h.remesh_s += since(t_start), h.remesh_n++;
+    h.last_remesh_s[0] = since(t_start), h.last_remesh_s[1] = h.remesh_build_s - build_before;
+    h.last_remesh_s[2] = h.remesh_adopt_s - adopt_before;
+  }
   return true;
 }
 
@@ -3543,6 +3605,20 @@ int artemis_sim_force_refine(artemis_sim_t *s, long gid) {
     return -1;
   }
   GUARD(changed = remesh(*s, false, gid) ? 1 : 0, return -1)
+  return changed;
+}
+void artemis_sim_last_remesh(const artemis_sim_t *s, long *leaves4, double *seconds3) {
+  for (int q = 0; q < 4 && leaves4; ++q) leaves4[q] = s->last_remesh[q];
+  for (int q = 0; q < 3 && seconds3; ++q) seconds3[q] = s->last_remesh_s[q];
+}
+int artemis_sim_inject_refine_tags(artemis_sim_t *s, const long *gids, int n) {
+  int changed = 0;
+  if (!s->dead.empty()) {
+    g_sim_err = s->dead;
+    return -1;
+  }
+  const std::vector<long> v(gids, gids + (n > 0 ? n : 0));
+  GUARD(changed = remesh(*s, false, -1, &v) ? 1 : 0, return -1)
   return changed;
 }
 long artemis_sim_remesh_seconds(const artemis_sim_t *s, double *out) {

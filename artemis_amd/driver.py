@@ -215,10 +215,14 @@ def _declare(L):
     L.artemis_sim_remeshes.restype = C.c_long
     L.artemis_sim_force_refine.argtypes = [vp, C.c_long]
     L.artemis_sim_force_refine.restype = C.c_int
+    L.artemis_sim_inject_refine_tags.argtypes = [vp, C.POINTER(C.c_long), C.c_int]
+    L.artemis_sim_inject_refine_tags.restype = C.c_int
     L.artemis_sim_load_balance.argtypes = [vp]
     L.artemis_sim_load_balance.restype = C.c_double
     L.artemis_sim_remesh_seconds.argtypes = [vp, C.POINTER(C.c_double)]
     L.artemis_sim_remesh_seconds.restype = C.c_long
+    L.artemis_sim_last_remesh.argtypes = [vp, C.POINTER(C.c_long), C.POINTER(C.c_double)]
+    L.artemis_sim_last_remesh.restype = None
     L.artemis_rt_device_bytes.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int]
     L.artemis_rt_device_bytes.restype = None
     L.artemis_sim_stage_kernel.argtypes = [vp]
@@ -306,11 +310,26 @@ class Simulation:
         self._refresh_dims()
         return bool(rc)
 
+    def inject_refine_tags(self, gids):
+        """Tag the listed leaves +1 next to the criterion's own tags and run one remesh check; True if the mesh changed."""
+        arr = (C.c_long * len(gids))(*gids)
+        rc = self.L.artemis_sim_inject_refine_tags(self.h, arr, len(gids))
+        if rc < 0:
+            raise RuntimeError(self.L.artemis_sim_last_error().decode())
+        self._refresh_dims()
+        return bool(rc)
+
     def remesh_seconds(self):
         """(number of remeshes during the run, total seconds, build seconds, hand-over seconds, tagging seconds)"""
         out = (C.c_double * 4)()
         n = self.L.artemis_sim_remesh_seconds(self.h, out)
         return (n,) + tuple(out)
+
+    def last_remesh(self):
+        """The most recent remesh: (leaves before, after, created, destroyed), (seconds total, build, hand-over)"""
+        lv, sec = (C.c_long * 4)(), (C.c_double * 3)()
+        self.L.artemis_sim_last_remesh(self.h, lv, sec)
+        return tuple(lv), tuple(sec)
 
     def device_bytes(self, reset_peak=False):
         """(current, peak) bytes of device memory held through the library's runtime shim"""

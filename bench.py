@@ -261,6 +261,26 @@ def cpu_baseline_ssheet(n, ndust, cycles, threads):
     return n * n * done / dt, dt, done, n
 
 
+def batch_of_leaves(sim, fraction=0.025):
+    """Every 1/fraction-th leaf below the finest level, spread over the Z-ordered list: what a criterion that fires on a
+    moving feature tags in one go."""
+    top = max(sim.block_level(b) for b in range(sim.nblocks))
+    cand = [g for g in range(sim.nblocks) if sim.block_level(g) < top]
+    step = max(1, int(round(1.0 / fraction)))
+    return cand[step // 2::step]
+
+
+def record_remesh(sim, events, what, call):
+    """Run one remesh-triggering call and append what it did (leaves, milliseconds, split) to events."""
+    n0 = sim.remeshes
+    changed = call()
+    if changed and sim.remeshes != n0:
+        lv, sec = sim.last_remesh()
+        events.append({"what": what, "leaves_before": lv[0], "leaves_after": lv[1], "created": lv[2], "destroyed": lv[3],
+                       "ms": 1.0e3 * sec[0], "ms_build_state": 1.0e3 * sec[1], "ms_hand_over": 1.0e3 * sec[2]})
+    return changed
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C
     # stdio when a communicator is created): keep the caller's stdout for the line and send everything else that
@@ -290,7 +310,11 @@ def main():
                          "transport unless this is given")
     ap.add_argument("--loopback", action="store_true",
                     help="diagnostic: route block-to-block slabs of ONE GPU through RCCL send/recv-to-self")
-    ap.add_argument("--no-remesh-leg", action="store_true", help="disk_amr: skip the forced-remesh measurement after the timed region")
+    ap.add_argument("--no-remesh-leg", action="store_true", help="disk_amr: skip the remesh measurements after the timed region")
+    ap.add_argument("--remesh-in-timed-region", action="store_true",
+                    help="disk_amr: inject the batched refinement tags of the remesh leg INSIDE the timed region (every "
+                         "4th cycle ~2.5 %% of the leaves; the criterion merges them again derefine_count cycles later), so "
+                         "that `value` includes the cost of a mesh that keeps changing")
     ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "ssheet_dust", "disk_sph", "disk_sph_smr", "disk_amr"],
                     help="sedov3d = the headline metric (BASELINE configs[1]); ssheet_dust = SURVEY config 3 "
                          "(2-D dusty shearing sheet with drag, general fused stage; --n is the mesh edge, 1 GPU); "
@@ -486,9 +510,17 @@ def main():
     t0 = time.perf_counter()
     if args.workload == "disk_amr":  # the mesh changes between cycles: count the zones of every cycle
         zone_cycles, done, remesh0 = 0, 0, sim.remeshes
-        for _ in range(args.steps):
+        timed_events = []
+        for cyc in range(args.steps):
+            if args.remesh_in_timed_region and cyc % 4 == 3:
+                record_remesh(sim, timed_events, "injected tags", lambda: sim.inject_refine_tags(batch_of_leaves(sim)))
             zone_cycles += sim.total_zones
+            r_before = sim.remeshes
             done += sim.evolve(1)
+            if args.remesh_in_timed_region and sim.remeshes != r_before:
+                lv, sec = sim.last_remesh()
+                timed_events.append({"what": "criterion (after cycle)", "leaves_before": lv[0], "leaves_after": lv[1], "created": lv[2],
+                                     "destroyed": lv[3], "ms": 1.0e3 * sec[0], "ms_build_state": 1.0e3 * sec[1], "ms_hand_over": 1.0e3 * sec[2]})
     else:
         done = sim.evolve(args.steps)
     barrier()
@@ -534,6 +566,40 @@ def main():
                       "device_bytes_now": sim.device_bytes()[0], "device_bytes_peak_during_remesh": sim.device_bytes()[1],
                       "what": "five forced single-leaf refinements through the ordinary remesh path (artemis_sim_force_refine), "
                               "one cycle apart, after the timed region"}
+    if remesh_leg is not None:
+        # ... and MANY leaves at once, the way a criterion that follows a moving feature tags them: five times, four cycles
+        # apart, ~2.5 % of the leaves (spread over the Z-ordered list) get the tag +1 next to the deck's own tags; the
+        # criterion does not want them refined, so `derefine_count` (5) cycles later the SAME leaves merge again -- remeshes
+        # of that size by the ordinary path, tagged by gas/refine_* itself.  (The deck's own criterion alone leaves this
+        # mesh unchanged for hundreds of cycles: the disk is in equilibrium and features move one finest zone in ~6 cycles.)
+        events = []
+        sim.device_bytes(reset_peak=True)
+        zones_at = []
+        for cyc in range(28):
+            if cyc % 4 == 0 and cyc < 20:
+                record_remesh(sim, events, "injected tags (+1 on ~2.5 % of the leaves)", lambda: sim.inject_refine_tags(batch_of_leaves(sim)))
+            r_before = sim.remeshes
+            sim.evolve(1)
+            if sim.remeshes != r_before:
+                lv, sec = sim.last_remesh()
+                events.append({"what": "the deck's criterion (merges what it does not want refined)", "leaves_before": lv[0],
+                               "leaves_after": lv[1], "created": lv[2], "destroyed": lv[3], "ms": 1.0e3 * sec[0],
+                               "ms_build_state": 1.0e3 * sec[1], "ms_hand_over": 1.0e3 * sec[2]})
+            zones_at.append(sim.total_zones)
+        torch.cuda.synchronize()
+        big = [e for e in events if (e["created"] + e["destroyed"]) >= 0.02 * e["leaves_before"]]
+        cur_b, peak_b = sim.device_bytes()
+        remesh_leg["batched"] = {
+            "events": events, "remeshes": len(events), "remeshes_changing_2pct_of_leaves": len(big),
+            "ms_mean": (sum(e["ms"] for e in big) / len(big)) if big else None,
+            "ms_max": max((e["ms"] for e in big), default=None),
+            "build_state_share": (sum(e["ms_build_state"] for e in big) / max(1e-30, sum(e["ms"] for e in big))) if big else None,
+            "over_cycle_mean": (sum(e["ms"] for e in big) / len(big) / remesh_leg["cycle_ms"]) if big else None,
+            "over_cycle_max": (max(e["ms"] for e in big) / remesh_leg["cycle_ms"]) if big else None,
+            "device_bytes_now": cur_b, "device_bytes_peak": peak_b, "zones_now": sim.total_zones,
+            "bytes_per_zone_now": cur_b / max(1, sim.total_zones), "bytes_per_zone_peak": peak_b / max(1, min(zones_at)),
+            "what": "28 cycles after the timed region; five batches of injected +1 tags, the merges the criterion orders five "
+                    "cycles after each"}
     kms, nlaunch = 0.0, 0
     if args.workload not in ("disk_sph_smr", "disk_amr"):  # (refined meshes: whole-stage accounting below)
         sim.set_kernel_timing(True)   # HIP events around the dominant kernel, on the stream it is launched on
@@ -685,6 +751,8 @@ def main():
                                "kernel": "whole stage (stage kernels, diffusion fluxes, flux correction, block-graph exchange, "
                                          "conditions; per cycle also the timestep%s)" % ("" if smr else ", tagging and remeshes"),
                                "launch_ms": stage_ms, "launches_timed": 2 * args.steps, "algorithmic_bytes_per_launch": alg}
+            if remesh_leg and args.remesh_in_timed_region:
+                remesh_leg["timed_region_events"] = timed_events
             if remesh_leg:
                 out["remesh"] = remesh_leg
                 out["remesh_ms_mean"] = remesh_leg["ms_mean"]

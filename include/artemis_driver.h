@@ -104,11 +104,20 @@ long artemis_sim_remeshes(const artemis_sim_t *sim);
  * fills out[4] = {total seconds, of which building the new mesh's state, handing the data over, and -- over all
  * cycles, remeshed or not -- evaluating the refinement criterion and the tree}. */
 long artemis_sim_remesh_seconds(const artemis_sim_t *sim, double *out);
+/* The most recent remesh: leaves4 = {leaves before, leaves after, leaves created (not in the old mesh), leaves destroyed
+ * (not in the new one)}, seconds3 = {total, building the new state, handing the data over} (zeros before the first
+ * remesh of the run; either pointer may be NULL). */
+void artemis_sim_last_remesh(const artemis_sim_t *sim, long *leaves4, double *seconds3);
 /* Measurement hook (bench.py's remesh leg): split the leaf with global (Z-order) index gid as if the refinement
  * criterion had tagged it -- the ordinary remesh machinery runs (2:1 balance, new state, hand-over of the data, block
  * migration between ranks) and is timed like any other remesh.  Collective over the ranks (same gid everywhere).
  * Returns 1 if the mesh changed, 0 if not (the leaf is at the finest level), < 0 on error. */
 int artemis_sim_force_refine(artemis_sim_t *sim, long gid);
+/* ... many leaves at once, the way a criterion tags them: the listed leaves (global Z-order indices) get the tag +1
+ * NEXT TO the tags the deck's own criterion gives every other leaf, derefinement counters included -- so leaves the
+ * criterion does not want refined merge again `derefine_count` cycles later, by the ordinary path.  One remesh check is
+ * run at once (collective; the same list on every rank).  Returns 1 if the mesh changed, 0 if not, < 0 on error. */
+int artemis_sim_inject_refine_tags(artemis_sim_t *sim, const long *gids, int n);
 /* Refined meshes: the largest rank's cost over the mean cost of the Z-order rank split (1 = perfectly even).  The cost
  * of a block is 1 by default (Parthenon's unit cost per block); the driver's own deck block
  *   <artemis_amd/loadbalance>  level_cost = c0, c1, ...   flux_face_cost = c
