@@ -3067,40 +3067,41 @@ long artemis_sim_impl::evolve(long max_cycles) {
   CK(artemis_rt_device_sync(), "sync");
   const auto t0 = std::chrono::steady_clock::now();
   long n = 0;
-  // Without a time limit nothing on the host depends on dt: keep {time, dt, dt_est} on the device
-  // (kernels read dt there, artemis_hip_advance_dt applies SetGlobalTimeStep's rules) and never
-  // synchronise inside the loop, so launches queue ahead of the GPU.
+  // The one-kernel stages keep {time, dt, dt_est} on the device (kernels read dt there, artemis_hip_advance_dt applies
+  // SetGlobalTimeStep's rules): the host only decides when to stop, and synchronises as rarely as that allows.
   const bool multi = has_comm && (nranks > 1 || loopback);
   // (a gravity time window is evaluated against the host's clock, which the device loop does not keep)
   // (so is the orbit of a binary)
   const bool grav_window = do_gravity && (grav.tstart > -DBL_MAX || grav.tstop < DBL_MAX || grav.type == ARTEMIS_GRAVITY_BINARY);
-  const bool async_loop = use_fused && tlim < 0.0 && !grav_window && (!multi || comm.allreduce_min_dev) &&
-                          !artemis::opt(artemis::OPT_SYNC_LOOP);
-  if (async_loop) {
+  const bool async_ok = use_fused && !grav_window && (!multi || comm.allreduce_min_dev) && !artemis::opt(artemis::OPT_SYNC_LOOP);
+  void *gexec[3] = {nullptr, nullptr, nullptr};
+  int gnext[3] = {0, 0, 0};
+  long plain_steps = 0; // (the first few steps of an evolve() run plainly: they allocate the ping-pong buffers and scratch)
+  // One time step is a fixed launch sequence when dt lives on the device: capture it into a hipGraph after a few plain
+  // steps and replay it, one graph per ping-pong phase.  Single rank, no overlap streams, no per-kernel timing.
+  bool graph_ok = !multi && !time_kernels && overlap == 0 && !artemis::opt(artemis::OPT_NO_GRAPH);
+  auto cycles_left = [&]() {
     long todo = -1;
     if (nlim >= 0) todo = nlim - ncycle;
-    if (max_cycles >= 0) todo = (todo < 0) ? max_cycles : std::min(todo, max_cycles);
-    if (todo < 0) throw std::runtime_error("no tlim, no nlim and no cycle budget: nothing bounds the run");
+    if (max_cycles >= 0) todo = (todo < 0) ? max_cycles - n : std::min(todo, max_cycles - n);
+    return todo;
+  };
+  // `todo` cycles with {time, dt, dt_est} on the device and no synchronisation inside
+  auto run_async = [&](long todo) {
     double h[6] = {time, dt, DBL_MAX, 0.0, 0.0, 0.0};
     for (int q = 0; q < nstages; ++q) h[3 + q] = beta[q] * dt;
     CK(artemis_rt_memcpy_h2d(tstate.p, h, sizeof h, stream), "h2d");
     CK(artemis_rt_stream_sync(stream), "sync");
-    // One time step is a fixed launch sequence here (dt lives on the device): capture it into a hipGraph
-    // after a few plain steps (which allocate the ping-pong buffers and scratch) and replay it, one
-    // graph per ping-pong phase.  Single rank, no overlap streams, no per-kernel timing.
-    bool graph_ok = !multi && !time_kernels && overlap == 0 && !artemis::opt(artemis::OPT_NO_GRAPH);
-    void *gexec[3] = {nullptr, nullptr, nullptr};
-    int gnext[3] = {0, 0, 0};
-    for (; n < todo; ++n) {
+    for (long m = 0; m < todo; ++m, ++n, ++plain_steps) {
       const int key = base;
-      if (graph_ok && n >= 3 && gexec[key]) {
+      if (graph_ok && plain_steps >= 3 && gexec[key]) {
         base = gnext[key], cons_valid = false;
         CK(artemis_rt_graph_launch(gexec[key], stream), "graph launch");
         ncycle++;
         continue;
       }
-      const bool capture = graph_ok && n >= 3 && artemis_rt_capture_begin(stream) == 0;
-      if (graph_ok && n >= 3 && !capture) graph_ok = false; // (the CPU stand-in has no graphs)
+      const bool capture = graph_ok && plain_steps >= 3 && artemis_rt_capture_begin(stream) == 0;
+      if (graph_ok && plain_steps >= 3 && !capture) graph_ok = false; // (the CPU stand-in has no graphs)
       step_fused(true, true);
       if (multi && comm.allreduce_min_dev(comm.ctx, tstate.p + 2, stream))
         throw std::runtime_error("allreduce_min_dev failed");
@@ -3113,15 +3114,36 @@ long artemis_sim_impl::evolve(long max_cycles) {
       }
       ncycle++;
     }
-    for (void *g : gexec) artemis_rt_graph_destroy(g);
     CK(artemis_rt_memcpy_d2h(h, tstate.p, sizeof h, stream), "d2h");
     CK(artemis_rt_stream_sync(stream), "sync");
     time = h[0], dt = h[1];
     if (!std::isfinite(dt) || !(dt > 0.0) || !std::isfinite(time))
       throw std::runtime_error("the device-side time loop produced a non-finite or non-positive dt");
+  };
+  if (async_ok && tlim < 0.0) {
+    // Without a time limit nothing on the host depends on dt: never synchronise inside the loop, so launches queue
+    // ahead of the GPU.
+    const long todo = cycles_left();
+    if (todo < 0) throw std::runtime_error("no tlim, no nlim and no cycle budget: nothing bounds the run");
+    run_async(todo);
   }
-  while (!async_loop && (tlim < 0.0 || time < tlim) && (nlim < 0 || ncycle < nlim) &&
+  while (!(async_ok && tlim < 0.0) && (tlim < 0.0 || time < tlim) && (nlim < 0 || ncycle < nlim) &&
          (max_cycles < 0 || n < max_cycles)) {
+    if (async_ok) {
+      // With a time limit the host decides one thing only: when to stop.  SetGlobalTimeStep at most doubles dt, so k
+      // cycles from here end no later than time + dt (2^k - 1): while that stays below tlim the loop condition holds
+      // for every one of them whatever the estimates turn out to be, and they run as above (advance_dt applies the
+      // same rules, the tlim clamp included).  Close to tlim the cycles run one by one below.
+      long k = 0;
+      const double room = (tlim - time) / dt;
+      while (k < 40 && std::ldexp(1.0, static_cast<int>(k)) * 1.001 < room) ++k; // time + dt 2^(k-1) < tlim, with a margin
+      const long todo = cycles_left();
+      if (todo >= 0) k = std::min(k, todo);
+      if (k >= 2) {
+        run_async(k);
+        continue;
+      }
+    }
     Real est;
     if (use_fused) {
       step_fused(true, false);
@@ -3144,6 +3166,7 @@ long artemis_sim_impl::evolve(long max_cycles) {
     if (tlim > 0.0 && time < tlim && (tlim - time) < ndt) ndt = tlim - time;
     dt = ndt;
   }
+  for (void *g : gexec) artemis_rt_graph_destroy(g);
   fill_stale_ghosts(); // (inside the timed region: part of the work)
   CK(artemis_rt_device_sync(), "sync");
   last_wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

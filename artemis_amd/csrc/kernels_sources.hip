@@ -350,6 +350,89 @@ __global__ __launch_bounds__(256) void nbody_gravity_one_kernel(const PackView P
   }
 }
 
+// The seven sums alone (artemis_hip_nbody_force_sums) as a march: a workgroup takes NX x NY columns of one block at a time
+// and walks x3.  What a zone needs of its column -- table pointers, the x1 / x2 parts of the coordinates -- is formed once
+// per column and no zone index is recovered by division.  One partial row per workgroup as above; the order of the
+// additions differs from the kernel above (the sums are compared to round-off everywhere, never bit for bit).
+template <bool GAS, bool DUST, int NX>
+__global__ __launch_bounds__(256) void nbody_force_march_kernel(const PackView P, const NBodyView N_in, int tiles_i, int tiles_j) {
+  constexpr int NY = 256 / NX;
+  __shared__ double red[4][7];
+  __shared__ artemis_nbody_particle_t spl[NB_CHUNK];
+  NBodyView N = N_in;
+  if (N.dt_ptr) N.dt = *N.dt_ptr;
+  const int x = threadIdx.x % NX, y = threadIdx.x / NX;
+  const int per = tiles_i * tiles_j, units = per * P.nb;
+  for (int np0 = 0; np0 < N.npart; np0 += NB_CHUNK) {
+    const int nloc = (N.npart - np0 < NB_CHUNK) ? N.npart - np0 : NB_CHUNK;
+    __syncthreads();
+    if (threadIdx.x < nloc) spl[threadIdx.x] = N.pl[np0 + threadIdx.x];
+    __syncthreads();
+    double lf[NB_CHUNK][7];
+#pragma unroll
+    for (int q = 0; q < NB_CHUNK; ++q)
+#pragma unroll
+      for (int m = 0; m < 7; ++m) lf[q][m] = 0.0;
+    bool any = false, any_acc = false;
+    for (int q = 0; q < nloc; ++q) any = any || spl[q].couple, any_acc = any_acc || (spl[q].couple && spl[q].racc > 0.0);
+    const int nprim = any_acc ? 4 : 1; // (the sums of non-accreting particles read densities only)
+    for (int u = blockIdx.x; any && u < units; u += gridDim.x) {
+      const int b = u / per, tt = u - b * per, tj = tt / tiles_i, ti = tt - tj * tiles_i;
+      const int i = P.is + ti * NX + x, j = P.js + tj * NY + y;
+      if (i > P.ie || j > P.je) continue;
+      const double *gp[4] = {nullptr, nullptr, nullptr, nullptr}, *dp[4] = {nullptr, nullptr, nullptr, nullptr};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if constexpr (GAS)
+          if (m < nprim) gp[m] = P.gas.prim[b * 6 + m];
+        if constexpr (DUST)
+          if (m < nprim) dp[m] = P.dust.prim[b * 4 + m];
+      }
+      for (int k = P.ks; k <= P.ke; ++k) {
+        const long c = static_cast<long>(k) * P.sk + static_cast<long>(j) * P.sj + i;
+        double wg[4] = {0, 0, 0, 0}, wd[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          if constexpr (GAS)
+            if (m < nprim) wg[m] = gp[m][c];
+          if constexpr (DUST)
+            if (m < nprim) wd[m] = dp[m][c];
+        }
+        const NbZone z = nb_zone(make_coords(P, b, k, j, i), N.omf);
+        double vcg[3], vcd[3];
+        nb_cart_velocity(z.fr, wg, vcg), nb_cart_velocity(z.fr, wd, vcd);
+#pragma unroll 1
+        for (int q = 0; q < nloc; ++q) {
+          const artemis_nbody_particle_t &pl = spl[q];
+          if (!pl.couple) continue;
+          const NbPull pull = nb_pull(pl, z.fr);
+          double f7[7] = {0, 0, 0, 0, 0, 0, 0};
+          if constexpr (GAS) nb_fluid<true, false, true>(pl, z, pull, N.dt, wg, vcg, nullptr, f7);
+          if constexpr (DUST) nb_fluid<false, false, true>(pl, z, pull, N.dt, wd, vcd, nullptr, f7);
+#pragma unroll
+          for (int qq = 0; qq < NB_CHUNK; ++qq)
+#pragma unroll
+            for (int m = 0; m < 7; ++m) lf[qq][m] += (qq == q) ? f7[m] : 0.0;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NB_CHUNK; ++q) {
+      if (q >= nloc) continue; // (workgroup-uniform)
+      for (int m = 0; m < 7; ++m) {
+        double vq = lf[q][m];
+        for (int off = 32; off > 0; off >>= 1) vq += __shfl_down(vq, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][m] = vq;
+      }
+      __syncthreads();
+      if (threadIdx.x < 7)
+        N.partial[(static_cast<long>(np0 + q) * gridDim.x + blockIdx.x) * 7 + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+      __syncthreads();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // RotatingFrame::ShearingBoxImpl (rotating_frame_impl.hpp:28-93), Cartesian.
 __global__ __launch_bounds__(TX *TY) void shearing_box_kernel(const PackView P, double om0,
@@ -738,11 +821,22 @@ void launch_nbody_force_sums(const PackView &P, const artemis_nbody_particle_t *
                              const double *dt_dev, double *partial_dev, double *force_dev, hipStream_t s) {
   NBodyView N;
   N.pl = pl_dev, N.npart = npart, N.omf = omf, N.dt = dt, N.dt_ptr = dt_dev, N.partial = partial_dev;
-  const dim3 grid(nbody_grid(P)), block(256);
-  if (P.gas.ns && P.dust.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<true, true, false>), grid, block, 0, s, P, N);
-  else if (P.gas.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<true, false, false>), grid, block, 0, s, P, N);
-  else if (P.dust.ns) hipLaunchKernelGGL((nbody_gravity_one_kernel<false, true, false>), grid, block, 0, s, P, N);
-  else return;
+  const int nx1 = P.ie - P.is + 1, nx2 = P.je - P.js + 1;
+  const int NX = nx1 <= 16 ? 16 : (nx1 <= 32 ? 32 : 64), NY = 256 / NX;
+  const int tiles_i = (nx1 + NX - 1) / NX, tiles_j = (nx2 + NY - 1) / NY;
+  // (one partial row per workgroup in the caller's scratch: artemis_hip_nbody_force_scratch rows at most)
+  const dim3 grid(static_cast<unsigned>(std::min<long>(nbody_grid(P), static_cast<long>(tiles_i) * tiles_j * P.nb))), block(256);
+  if (!P.gas.ns && !P.dust.ns) return;
+#define FORCE_MARCH(G, D)                                                                                              \
+  do {                                                                                                                 \
+    if (NX == 16) hipLaunchKernelGGL((nbody_force_march_kernel<G, D, 16>), grid, block, 0, s, P, N, tiles_i, tiles_j); \
+    else if (NX == 32) hipLaunchKernelGGL((nbody_force_march_kernel<G, D, 32>), grid, block, 0, s, P, N, tiles_i, tiles_j); \
+    else hipLaunchKernelGGL((nbody_force_march_kernel<G, D, 64>), grid, block, 0, s, P, N, tiles_i, tiles_j);          \
+  } while (0)
+  if (P.gas.ns && P.dust.ns) FORCE_MARCH(true, true);
+  else if (P.gas.ns) FORCE_MARCH(true, false);
+  else FORCE_MARCH(false, true);
+#undef FORCE_MARCH
   const int nq = 7 * npart; // (<= 896: artemis_hip_nbody_force_sums takes at most 128 particles)
   const int chunk_rows = std::max(1, std::min<int>(grid.x, 32768 / (8 * nq)));
   hipLaunchKernelGGL(nbody_force_sum_kernel, dim3(1), dim3(std::max(256, 64 * ((nq + 63) / 64))), sizeof(double) * chunk_rows * nq, s,

@@ -158,13 +158,17 @@ ADEV void nb_fluid(const artemis_nbody_particle_t &pl, const NbZone &z, const Nb
     }
   }
   if constexpr (FORCE) {
-    f7[0] -= z.vol * dm / dt;
+    // (a particle without an accretion radius in the sums-only form: dm and dmom are exactly +0, the four quotients are +-0
+    //  and leave sums that started at +0 as they are -- four fp64 divisions per fluid, particle and zone not made)
+    if (APPLY || pl.racc > 0.0) {
+      f7[0] -= z.vol * dm / dt;
+      f7[4] -= dmom[0] / dt;
+      f7[5] -= dmom[1] / dt;
+      f7[6] -= dmom[2] / dt;
+    }
     f7[1] -= q.g[0] * dens * z.vol;
     f7[2] -= q.g[1] * dens * z.vol;
     f7[3] -= q.g[2] * dens * z.vol;
-    f7[4] -= dmom[0] / dt;
-    f7[5] -= dmom[1] / dt;
-    f7[6] -= dmom[2] / dt;
   }
 }
 // Every coupled particle in order on one fluid of a zone held in registers (the one-kernel stages)

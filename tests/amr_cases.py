@@ -47,7 +47,7 @@ def linear_wave_amr(derefine_count=10):
     return dict(deck=("linwave", "linear_wave_amr.in"), overrides=ov, oracle=oracle, tlim=-1.0, dust=False)
 
 
-def disk_planet_dust_amr(n=32, planet=1.0e-2, thr=0.8, derefine_count=3, nz=1, zlim=1.0):
+def disk_planet_dust_amr(n=32, planet=1.0e-2, thr=0.8, derefine_count=3, nz=1, zlim=1.0, h0=0.05, rlim=(0.3, 4.3), nphi=None, zp=0.0):
     """BASELINE configs[4]: inputs/disk/disk_nbody_cyl.in (cylindrical disk, `ic` conditions, alpha viscosity, N-body
     gravity) in 2-D with a planet on a circular orbit at r = 1 (static in the frame rotating with it: <nbody>
     integrator = none, the REBOUND integration is outside this build), one dust species with simple_dust drag, and
@@ -56,9 +56,11 @@ def disk_planet_dust_amr(n=32, planet=1.0e-2, thr=0.8, derefine_count=3, nz=1, z
     nz > 1: the same in THREE dimensions (8^3 blocks, nz root zones over |z| < zlim -- a slab thin against the scale
     height, so that the criterion follows the planet's wake as in 2-D rather than the vertical stratification, which
     would refine the whole midplane to the finest level: thousands of 8^3 blocks for a Python-driven oracle)."""
-    ov = ["parthenon/mesh/nx1=%d" % n, "parthenon/mesh/nx2=%d" % n, "parthenon/mesh/nx3=%d" % nz, "parthenon/meshblock/nx1=8",
+    nphi = nphi or n
+    ov = ["parthenon/mesh/nx1=%d" % n, "parthenon/mesh/nx2=%d" % nphi, "parthenon/mesh/nx3=%d" % nz, "parthenon/meshblock/nx1=8",
           "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=%d" % (8 if nz > 1 else 1),
-          "parthenon/mesh/x3min=%r" % -zlim, "parthenon/mesh/x3max=%r" % zlim, "parthenon/mesh/refinement=adaptive",
+          "parthenon/mesh/x3min=%r" % -zlim, "parthenon/mesh/x3max=%r" % zlim, "parthenon/mesh/x1min=%r" % rlim[0],
+          "parthenon/mesh/x1max=%r" % rlim[1], "problem/h0=%r" % h0, "parthenon/mesh/refinement=adaptive",
           "parthenon/mesh/numlevel=4", "parthenon/mesh/derefine_count=%d" % derefine_count, "gas/refine_field=pressure",
           "gas/refine_type=gradient", "gas/refine_thr=%r" % thr,
           "physics/rotating_frame=true", "rotating_frame/omega=1.0",
@@ -67,11 +69,12 @@ def disk_planet_dust_amr(n=32, planet=1.0e-2, thr=0.8, derefine_count=3, nz=1, z
           "dust/stopping_time/tau=0.1", "dust/sizes=1.0",
           "nbody/particle2/mass=%r" % planet, "nbody/particle2/couple=1", "nbody/particle2/soft/type=plummer",
           "nbody/particle2/soft/radius=0.03", "nbody/particle2/initialize/x=1.0", "nbody/particle2/initialize/vy=1.0",
+          "nbody/particle2/initialize/z=%r" % zp,
           "parthenon/time/nlim=-1"]
     # nbody/nbody_setup.cpp:690-714 restated: total mass rescaled to <nbody> mtot (absent: the sum), positions and
     # velocities shifted by the mass-weighted sums as written there (not divided by the total mass)
     raw = [dict(m=1.0, x=0.0, y=0.0, z=0.0, vx=0.0, vy=0.0, vz=0.0, rs=0.0),
-           dict(m=planet, x=1.0, y=0.0, z=0.0, vx=0.0, vy=1.0, vz=0.0, rs=0.03)]
+           dict(m=planet, x=1.0, y=0.0, z=zp, vx=0.0, vy=1.0, vz=0.0, rs=0.03)]
     mtot, R, V = 0.0, [0.0] * 3, [0.0] * 3
     for p in raw:
         mtot += p["m"]
@@ -91,10 +94,10 @@ def disk_planet_dust_amr(n=32, planet=1.0e-2, thr=0.8, derefine_count=3, nz=1, z
 
     def oracle():
         from oracle.adaptive import AdaptiveOracle
-        m = AdaptiveOracle((n, n, nz), (8, 8, 8 if nz > 1 else 1), (0.3, -PI, -zlim), (4.3, PI, zlim),
+        m = AdaptiveOracle((n, nphi, nz), (8, 8, 8 if nz > 1 else 1), (rlim[0], -PI, -zlim), (rlim[1], PI, zlim),
                            ("ic", "ic", "periodic", "periodic", "ic", "ic"), numlevel=4, refine_field="pressure",
                            refine_type="gradient", refine_thr=thr, derefine_count=derefine_count, setup=setup,
-                           pgen=lambda o: o.pgen_disk(r0=1.0, rho0=1.0, dslope=-2.25, flare=0.25, h0=0.05, dens_min=1e-10,
+                           pgen=lambda o: o.pgen_disk(r0=1.0, rho0=1.0, dslope=-2.25, flare=0.25, h0=h0, dens_min=1e-10,
                                                       pres_min=1e-15, polytropic_index=1.0, post_init=False),
                            ng=2, integrator="rk2", reconstruct="plm", riemann="hllc", gamma=1.4, dfloor=1e-10,
                            siefloor=1e-10, cfl=0.3, ns_dust=1, dust_reconstruct="plm", dust_riemann="hlle",
@@ -102,6 +105,13 @@ def disk_planet_dust_amr(n=32, planet=1.0e-2, thr=0.8, derefine_count=3, nz=1, z
         m.diffusion = m.gravity = m.rframe = m.drag = True
         return m.initialize()
     return dict(deck=("disk", "disk_nbody_cyl.in"), overrides=ov, oracle=oracle, tlim=62.8, dust=True)
+
+
+# configs[4] with real vertical extent: |z| <= 0.2 over 0.5 < r < 2.5 with h0 = 0.2 (one scale height at the planet, 2.4 at
+# the inner edge), 16 x 32 x 8 root zones in 8^3 blocks, the planet 0.08 above the midplane.  thr = 1.5 leaves the
+# midplane of the inner disk at level 2 and takes the layers at |z| > 0.1 there to level 3 (the vertical pressure gradient
+# is what fires), and the planet's envelope refines around z = 0.08 over the first dozen cycles.
+THICK_DISK = dict(n=16, nphi=32, planet=6e-2, thr=1.5, derefine_count=2, nz=8, zlim=0.2, h0=0.2, rlim=(0.5, 2.5), zp=0.08)
 
 
 def compare(sim, m, dust, ghosts=True):

@@ -64,3 +64,14 @@ def test_config4_disk_planet_dust_four_levels_host_logic_equals_adaptive_oracle(
     criterion.  30 cycles, >= 8 remeshes, levels 1..3 present (the root level refines completely at start-up)."""
     m = run_case(double, amr_cases.disk_planet_dust_amr(), 30, 5, 8, {1, 2, 3})
     assert max(l for l, _ in m.leaves) == 3  # four levels: 0 (root) .. 3
+
+
+def test_config4_with_real_vertical_extent_host_logic_equals_adaptive_oracle(double):
+    """configs[4] in three dimensions over |z| <= 0.2 (amr_cases.THICK_DISK: one scale height at the planet, 2.4 at the
+    inner edge; 16 x 32 x 8 root in 8^3 blocks, four levels).  The vertical pressure gradient holds the layers at
+    |z| > 0.1 of the inner disk at level 3 from the start while the midplane there stays at level 2, and the planet --
+    0.08 above the midplane -- refines its surroundings over three remeshes (400 -> 456 -> 470 -> 484 blocks of gas and
+    dust in 13 cycles).  (The thin-slab 3-D row is tests/test_adaptive.py's, on the GPU; this one also runs there.)"""
+    m = run_case(double, amr_cases.disk_planet_dust_amr(**amr_cases.THICK_DISK), 13, 5, 3, {1, 2, 3})
+    high = [b for b, (lv, _) in enumerate(m.leaves) if lv == 3 and min(abs(m.block_bounds(b)[4]), abs(m.block_bounds(b)[5])) >= 0.1]
+    assert len(high) >= 200 and len(m.blocks) == 484

@@ -361,6 +361,34 @@ def test_sync_free_loop_matches_host_dt_loop(hiplib, monkeypatch, option):
     assert c.ncycle == 14 and c.time == a.time and np.array_equal(c.field("gas.prim"), a.field("gas.prim"))
 
 
+def test_loop_with_a_time_limit_synchronises_in_chunks_and_matches_host_dt_loop(hiplib, option):
+    """With a time limit the host only decides when to stop: dt at most doubles per cycle, so while
+    time + dt (2^k - 1) stays below tlim the next k cycles run with {time, dt} on the device and no synchronisation,
+    and the last cycles before tlim one by one.  Same cycle count, time == tlim exactly, same dt and the same bits as the
+    host-side dt loop (ARTEMIS_SYNC_LOOP) and as the oracle; an evolve() budget that ends inside a chunk resumes."""
+    from artemis_amd.driver import Simulation
+    ov = BLAST3D + ["parthenon/time/tlim=0.04", "parthenon/time/nlim=-1"]
+    a = Simulation(DECK("blast", "blast.in"), ov)
+    a.evolve()
+    option("sync_loop", 1)
+    b = Simulation(DECK("blast", "blast.in"), ov)
+    b.evolve()
+    option("sync_loop", 0)
+    o = Oracle((48, 40, 32), (-1, -1, -1), (1, 1, 1), ng=2, reconstruct="plm", riemann="hllc",
+               gamma=1.4, dfloor=1e-10, siefloor=1e-10, cfl=0.3, bc=("outflow",) * 6)
+    o.pgen_blast(radius=0.2, internal_energy=1.0, p0=1e-5, d0=1.0, samples=4)
+    o.evolve(0.04, 100000)
+    assert a.ncycle == b.ncycle == o.ncycle and a.ncycle > 20
+    assert a.time == b.time == o.time == 0.04 and a.dt == b.dt == o.dt
+    assert np.array_equal(a.field("gas.prim"), b.field("gas.prim"))
+    assert np.array_equal(a.field("gas.prim"), o.gprim)
+    c = Simulation(DECK("blast", "blast.in"), ov)
+    c.evolve(7)
+    c.evolve(5)
+    c.evolve()
+    assert c.ncycle == a.ncycle and c.time == a.time and np.array_equal(c.field("gas.prim"), a.field("gas.prim"))
+
+
 # tst/scripts/coords/blast.py:36-80: the reference's curvilinear Sedov configurations
 BLAST_GEOM = {
     "axi": ["artemis/coordinates=axisymmetric", "parthenon/mesh/x1min=0.0", "parthenon/mesh/x1max=2.0",
