@@ -730,6 +730,7 @@ __global__ __launch_bounds__(256) void conductive_bc_kernel(const CondBcArgs a, 
 // agreement with a host libm is to rounding (a few ulp), not bitwise.
 struct DiskBcArgs {
   int d, side, ng, st, en, extrap, visc;
+  int both; // `ic` on both faces of d: one launch, the second half of the threads takes the upper face (pure copies)
   double omf, nu0, nu_indx, r0, mdot;
   double *const *ic_gas, *const *ic_dust;
 };
@@ -740,13 +741,15 @@ __global__ __launch_bounds__(256) void disk_bc_kernel(const DiskBcArgs a, const 
   int ext[3] = {ni, nj, nk};
   ext[a.d] = a.ng;
   const long ncell = static_cast<long>(ext[0]) * ext[1] * ext[2];
-  const long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  long tid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  int side = a.side;
+  if (a.both && tid >= ncell) tid -= ncell, side = 1;
   if (tid >= ncell) return;
   int idx[3];
   idx[0] = tid % ext[0];
   idx[1] = (tid / ext[0]) % ext[1];
   idx[2] = tid / (static_cast<long>(ext[0]) * ext[1]);
-  idx[a.d] = (a.side == 0) ? a.st - 1 - idx[a.d] : a.en + 1 + idx[a.d];
+  idx[a.d] = (side == 0) ? a.st - 1 - idx[a.d] : a.en + 1 + idx[a.d];
   const long c = (static_cast<long>(idx[2]) * nj + idx[1]) * ni + idx[0];
   const int nsg = t.nsg, nsd = t.nsd;
   if (!a.extrap) {
@@ -1095,7 +1098,8 @@ static void launch_bc_sequential(const PackView &P, const std::vector<int> &bloc
         for (int b : blocks) {
           const int flag = flag_of(b, 2 * d + side);
           if (flag == ARTEMIS_BC_NONE || (pass == 0) != (flag == ARTEMIS_BC_PERIODIC)) continue;
-          const bool strat = (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW);
+          // (`ic` copies ghost zones from the initial state: nothing it reads is written by a fill, so its two faces share a launch too)
+          const bool strat = (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW || flag == ARTEMIS_BC_IC);
           const int pair = (strat && flag_of(b, 2 * d) == flag_of(b, 2 * d + 1)) ? 1 : 0; // one launch fills both faces
           if (pair && side == 1) continue;
           groups[std::make_pair(flag, pair)].push_back(b);
@@ -1122,8 +1126,9 @@ static void launch_bc_sequential(const PackView &P, const std::vector<int> &bloc
               a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d];
               a.extrap = (flag != ARTEMIS_BC_IC), a.visc = (flag == ARTEMIS_BC_DISK_VISC), a.omf = par->disk_omf;
               a.nu0 = par->disk_nu0, a.nu_indx = par->disk_nu_indx, a.r0 = par->disk_r0, a.mdot = par->disk_mdot;
-              a.ic_gas = par->ic_gas, a.ic_dust = par->ic_dust;
-              hipLaunchKernelGGL(disk_bc_kernel, dim3((ncell + 255) / 256, ny), dim3(256), 0, s, a, t, P, bl);
+              a.ic_gas = par->ic_gas, a.ic_dust = par->ic_dust, a.both = pair ? 1 : 0;
+              const long nthr = pair ? 2 * ncell : ncell;
+              hipLaunchKernelGGL(disk_bc_kernel, dim3((nthr + 255) / 256, ny), dim3(256), 0, s, a, t, P, bl);
             } else if (flag == ARTEMIS_BC_STRAT_EXTRAP || flag == ARTEMIS_BC_STRAT_INFLOW) {
               StratBcArgs a;
               a.d = d, a.side = side, a.ng = P.ng, a.st = st[d], a.en = en[d], a.both = pair ? 1 : 0;

@@ -1,51 +1,57 @@
 # Round-end evidence run (one gpurun call): GPU suite, smoke, bench lines, rocprof stats, PMC traffic records.
-# Outputs under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
-tag=${1:-r04z}
+# Outputs under gpurun_out/<tag>_*; scripts/collect_evidence.sh copies what is to be judged into profiles/<round>_*.
+# SKIP_SUITE=1 leaves the pytest run out; ROUND names the profiles/ prefix the bench lines look their records up under.
+tag=${1:-r05z}
+ROUND=${ROUND:-r05}
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-if [ -z "$SKIP_SUITE" ]; then timeout 3300 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|FAILED" | tail -5 > gpurun_out/${tag}_tests.txt; cat gpurun_out/${tag}_tests.txt; fi
+if [ -z "$SKIP_SUITE" ]; then timeout 3600 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|FAILED" | tail -5 > gpurun_out/${tag}_tests.txt; cat gpurun_out/${tag}_tests.txt; fi
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/${tag}_smoke.txt
-timeout 900 python3 scripts/pmc_traffic.py --tag ${tag}
+# ---- HBM traffic (PMC; separate FETCH_SIZE / WRITE_SIZE passes).  The Sedov record is a mean over full-size launches of the
+# two headline instantiations only (scripts/pmc_traffic.py asserts the launch count; bench.py refuses a record without it)
+timeout 1200 python3 scripts/pmc_traffic.py --tag ${tag}
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph
-timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust
-timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph_smr
-timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_amr
-cp gpurun_out/${tag}_disk_sph_smr_pmc_traffic.json profiles/r04_disk_sph_smr_pmc_traffic.json; cp gpurun_out/${tag}_disk_amr_pmc_traffic.json profiles/r04_disk_amr_pmc_traffic.json
-# (on the box: the bench lines below quote the records just measured; scripts/collect_evidence.sh copies them locally)
-PMC_SQ_GROUPS=0,1 PMC_SQ_RECORD=${tag} timeout 600 python3 scripts/pmc_sq.py ${tag} -- bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-dropin > gpurun_out/${tag}_pmc_sq.txt 2>&1
+timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 1024
+timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 4096
+timeout 1200 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph_smr
+timeout 1800 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_amr
+# ---- SQ counters: the headline kernel alone (no drop-in legs, no overlap emulation: 256^3 launches only), the disk march
+PMC_SQ_GROUPS=0,1 PMC_SQ_RECORD=${tag} timeout 600 python3 scripts/pmc_sq.py ${tag} -- bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-dropin --no-overlap-emulation > gpurun_out/${tag}_pmc_sq.txt 2>&1
 PMC_SQ_GROUPS=0,1 PMC_SQ_KERNELS=stage_curv,viscous_source timeout 600 python3 scripts/pmc_sq.py ${tag}_disk_sph -- bench.py --workload disk_sph --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_disk_sph_pmc_sq.txt 2>&1
 cp gpurun_out/sq_${tag}_disk_sph.json gpurun_out/${tag}_disk_sph_pmc_sq.json
-cp gpurun_out/${tag}_pmc_traffic.json profiles/r04_pmc_traffic.json; cp gpurun_out/${tag}_disk_sph_pmc_traffic.json profiles/r04_disk_sph_pmc_traffic.json; cp gpurun_out/${tag}_cfg3_pmc_traffic.json profiles/r04_cfg3_pmc_traffic.json; cp gpurun_out/${tag}_pmc_sq.json profiles/r04_pmc_sq.json
-timeout 600 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err; cat gpurun_out/${tag}_bench_line.json | cut -c1-400
+# (on the box: the bench lines below quote the records just measured)
+for f in pmc_traffic disk_sph_pmc_traffic cfg3_pmc_traffic cfg3_1024_pmc_traffic disk_sph_smr_pmc_traffic disk_amr_pmc_traffic pmc_sq; do cp gpurun_out/${tag}_$f.json profiles/${ROUND}_$f.json; done
+# ---- bench lines
+timeout 900 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err; cat gpurun_out/${tag}_bench_line.json | cut -c1-400
 timeout 300 python bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_cfg3_line.json
 timeout 300 python bench.py --workload ssheet_dust --n 1024 --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_line.json
 timeout 300 python bench.py --workload ssheet_dust --n 1024 --dust 2 --no-cpu-baseline --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_2dust_line.json
 timeout 300 python bench.py --workload disk_sph --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_disk_sph_line.json
 timeout 600 python bench.py --workload disk_sph_smr --steps 40 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_sph_smr_line.json
-timeout 900 python bench.py --workload disk_amr --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json
-cut -c1-300 gpurun_out/${tag}_cfg3_line.json gpurun_out/${tag}_disk_sph_line.json gpurun_out/${tag}_disk_sph_smr_line.json gpurun_out/${tag}_disk_amr_line.json
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof -o p --output-format csv -- python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_prof.log 2>&1
-find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_bench_kernel_stats.csv
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_cfg3_prof -o p --output-format csv -- python3 bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50 > /dev/null 2>&1
-find gpurun_out/${tag}_cfg3_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_cfg3_kernel_stats.csv
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_disk_prof -o p --output-format csv -- python3 bench.py --workload disk_sph --no-cpu-baseline --steps 50 > /dev/null 2>&1
-find gpurun_out/${tag}_disk_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_disk_sph_kernel_stats.csv
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_cfg3_1024_prof -o p --output-format csv -- python3 bench.py --workload ssheet_dust --n 1024 --no-cpu-baseline --steps 100 > /dev/null 2>&1
-find gpurun_out/${tag}_cfg3_1024_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_cfg3_1024_kernel_stats.csv
-# refined meshes: the shipped Cartesian SMR disk, the refined spherical disk (configs[3]'s combination), both paths; the configs[4] combination in 3-D
+timeout 1500 python bench.py --workload disk_amr --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json
+cut -c1-300 gpurun_out/${tag}_cfg3_line.json gpurun_out/${tag}_cfg3_1024_line.json gpurun_out/${tag}_disk_sph_line.json gpurun_out/${tag}_disk_sph_smr_line.json gpurun_out/${tag}_disk_amr_line.json
+# ---- rocprofv3 kernel statistics.  The headline profile holds 256^3 launches of the two headline instantiations ONLY
+prof() { # prof <name> <program args ...>
+  local name=$1; shift
+  timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_${name}_prof -o p --output-format csv -- python3 "$@" > gpurun_out/${tag}_${name}_prof.log 2>&1
+  find gpurun_out/${tag}_${name}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_${name}_kernel_stats.csv
+}
+prof bench bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-dropin --no-overlap-emulation
+prof bench_default bench.py --steps 200 --warmup 10 --no-cpu-baseline
+prof cfg3 bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50
+prof cfg3_1024 bench.py --workload ssheet_dust --n 1024 --no-cpu-baseline --steps 100
+prof disk_sph bench.py --workload disk_sph --no-cpu-baseline --steps 50
+prof smr_cart scripts/smr_timing.py 10
+prof smr_sph scripts/smr_timing.py 10 sph problem/polytropic_index=1.40 gas/de_switch=1e-2
+prof amr scripts/amr_timing.py 5 128 128 16 16 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2
+rm -f gpurun_out/${tag}_*prof/*kernel_trace.csv gpurun_out/${tag}_*prof/*/*kernel_trace.csv
+# ---- refined meshes: the shipped Cartesian SMR disk, the refined spherical disk (configs[3]'s combination), both paths; configs[4] in 3-D
 timeout 300 python scripts/smr_timing.py 20 | tee gpurun_out/${tag}_smr.txt
 ARTEMIS_NO_ML_FUSED=1 timeout 300 python scripts/smr_timing.py 20 | sed 's/^/per-task chain: /' | tee -a gpurun_out/${tag}_smr.txt
 timeout 300 python scripts/smr_timing.py 20 sph problem/polytropic_index=1.40 gas/de_switch=1e-2 | tee -a gpurun_out/${tag}_smr.txt
 ARTEMIS_NO_ML_FUSED=1 timeout 300 python scripts/smr_timing.py 20 sph problem/polytropic_index=1.40 gas/de_switch=1e-2 | sed 's/^/per-task chain: /' | tee -a gpurun_out/${tag}_smr.txt
 timeout 900 python3 scripts/amr_timing.py 10 128 128 16 16 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2 2>&1 | tail -1 | tee gpurun_out/${tag}_amr.txt
 timeout 900 python3 scripts/amr_timing.py 10 128 128 32 32 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2 2>&1 | tail -1 | sed 's/^/32^3 blocks (the deck\x27s own block size): /' | tee -a gpurun_out/${tag}_amr.txt
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_smr_cart_prof -o p --output-format csv -- python3 scripts/smr_timing.py 10 > /dev/null 2>&1
-find gpurun_out/${tag}_smr_cart_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_smr_cart_kernel_stats.csv
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_smr_sph_prof -o p --output-format csv -- python3 scripts/smr_timing.py 10 sph problem/polytropic_index=1.40 gas/de_switch=1e-2 > /dev/null 2>&1
-find gpurun_out/${tag}_smr_sph_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_smr_sph_kernel_stats.csv
-timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_amr_prof -o p --output-format csv -- python3 scripts/amr_timing.py 5 128 128 16 16 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2 > /dev/null 2>&1
-find gpurun_out/${tag}_amr_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_amr_kernel_stats.csv
-rm -f gpurun_out/${tag}_*prof/*kernel_trace.csv
 for w in blast_sph blast_cyl disk_sph disk_cyl disk_axi; do timeout 300 python scripts/curv_timing.py $w; done | tee gpurun_out/${tag}_curv.txt
 head -4 gpurun_out/${tag}_bench_kernel_stats.csv | cut -c1-200

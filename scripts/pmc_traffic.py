@@ -60,14 +60,14 @@ def whole_stage(args, extra):
     (profiles/r*_pmc_traffic.json: 0.620 in every run so far; these workloads launch no kernel with an exactly
     known byte count)."""
     from bench import kernel_source_sha1
-    steps = 6
-    n = {"disk_sph": 256, "ssheet_dust": 4096}.get(args.workload)
-    bench_args = ["--workload", args.workload, "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline"] + (["--n", str(n)] if n else []) + extra
-    if args.workload == "disk_amr":  # (stages only: the forced-remesh measurement that follows the timed region is left out;
-        bench_args.append("--no-remesh-leg")  #  the kernels of the initial refinement loop stay in: a few % of the total)
-    scratch = os.path.join(ROOT, "gpurun_out", "pmc_%s" % args.tag)
-    fetch = run_pass("FETCH_SIZE", scratch + "_fetch", bench_args)
-    write = run_pass("WRITE_SIZE", scratch + "_write", bench_args)
+    n = {"disk_sph": 256, "ssheet_dust": args.n if args.n in (1024, 4096) else 4096}.get(args.workload)
+    refined = args.workload in ("disk_amr", "disk_sph_smr")
+
+    def bench_args_for(steps):
+        a = ["--workload", args.workload, "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline"] + (["--n", str(n)] if n else []) + extra
+        if args.workload == "disk_amr":  # (stages only: the remesh measurements that follow the timed region are left out)
+            a.append("--no-remesh-leg")
+        return a
     ratio, src = 0.6202, "default"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
@@ -78,34 +78,61 @@ def whole_stage(args, extra):
         except Exception:
             continue
     kib = 1024.0
-    kernels, total = {}, 0.0
-    for k, (fk, cnt) in fetch.items():
-        wk = write.get(k, (0.0, 0))[0]
-        b = cnt * (fk * kib / ratio + wk * kib)
-        kernels[k[:160]] = {"launches": cnt, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "bytes_total": b}
-        total += b
-    # every launch of the run (initialisation, warm-up and timed cycles alike) is in the profile: normalise by the
-    # launches of the stage kernel, which runs once per stage
-    # one stage = one launch of the GAS stage kernel over the whole pack (the dust march is the instantiation whose last
-    # template argument is true; the refined meshes' fix-up instantiations of stage_cell_kernel end in `true>` as well)
-    stage_names = [k for k in fetch if ("stage_fused_kernel" in k or "stage2d_kernel" in k or
-                                        ("stage_cell_kernel<0" in k and "true>(" not in k) or
-                                        ("stage_curv_kernel" in k and "false>(" in k))]
-    if any("stage_curv_kernel" in k for k in stage_names):  # (a curvilinear pack: its stages are the march's launches)
-        stage_names = [k for k in stage_names if "stage_curv_kernel" in k]
-    nstage = sum(fetch[k][1] for k in stage_names)
-    assert nstage, "no stage kernel in the profile"
-    per_stage = total / nstage
+
+    def is_stage(k, names):
+        # one stage = one launch of the GAS stage kernel over the whole pack (the dust march is the instantiation whose last
+        # template argument is true; the refined meshes' fix-up instantiations of stage_cell_kernel end in `true>` as well)
+        hit = ("stage_fused_kernel" in k or "stage2d_kernel" in k or ("stage_cell_kernel<0" in k and "true>(" not in k) or
+               ("stage_curv_kernel" in k and "false>(" in k))
+        if any("stage_curv_kernel" in q for q in names):  # (a curvilinear pack: its stages are the march's launches)
+            hit = hit and "stage_curv_kernel" in k
+        return hit
+
+    def measure(steps, tagx):
+        bench_args = bench_args_for(steps)
+        scratch = os.path.join(ROOT, "gpurun_out", "pmc_%s%s" % (args.tag, tagx))
+        fetch = run_pass("FETCH_SIZE", scratch + "_fetch", bench_args)
+        write = run_pass("WRITE_SIZE", scratch + "_write", bench_args)
+        kernels = {}
+        for k, (fk, cnt) in fetch.items():
+            wk = write.get(k, (0.0, 0))[0]
+            kernels[k[:160]] = {"launches": cnt, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "bytes_total": cnt * (fk * kib / ratio + wk * kib)}
+        nstage = sum(v["launches"] for k, v in kernels.items() if is_stage(k, kernels))
+        assert nstage, "no stage kernel in the profile"
+        return bench_args, kernels, nstage
+    # every launch of a run (initialisation, warm-up and timed cycles alike) is in its profile.  Uniform meshes: normalise
+    # by the launches of the stage kernel, which runs once per stage (the set-up is a fraction of a per cent).  Refined
+    # meshes: the initial refinement loop launches as many bytes as several stages, so TWO runs that differ in the number
+    # of timed cycles only are profiled and the record is the DIFFERENCE of their totals over the difference of their stages.
+    bench_args, kernels, nstage = measure(6, "")
+    total = sum(v["bytes_total"] for v in kernels.values())
+    method = "bytes of EVERY kernel of the run divided by the number of stage-kernel launches (= stages)"
+    if refined:
+        _, k2, n2 = measure(12, "_b")
+        t2 = sum(v["bytes_total"] for v in k2.values())
+        assert n2 > nstage
+        per_kernel = {}
+        for k, v in k2.items():
+            d = v["bytes_total"] - kernels.get(k, {"bytes_total": 0.0})["bytes_total"]
+            per_kernel[k] = {"launches_in_the_extra_cycles": v["launches"] - kernels.get(k, {"launches": 0})["launches"],
+                             "bytes_per_stage": d / (n2 - nstage)}
+        per_stage = (t2 - total) / (n2 - nstage)
+        method = ("two runs, --steps 6 and --steps 12: (bytes of every kernel of the second - of the first) / (stages of the "
+                  "second - of the first): the set-up and the initial refinement loop cancel")
+        kernels = {"first_run": kernels, "difference_per_stage": per_kernel}
+        nstage = n2 - nstage
+    else:
+        per_stage = total / nstage
     rec = {
         "source": "scripts/pmc_traffic.py --workload %s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, "
-                  "--kernel-trace only) of `python3 bench.py %s`, MI355X; bytes of EVERY kernel of the run divided by the "
-                  "number of stage-kernel launches (= stages)" % (args.workload, " ".join(bench_args)),
+                  "--kernel-trace only) of `python3 bench.py %s`, MI355X; %s" % (args.workload, " ".join(bench_args), method),
         "workload": args.workload, "sha_scope": "all", "kernel_source_sha1": kernel_source_sha1("all"),
         "env": {k: v for k, v in os.environ.items() if k.startswith("ARTEMIS_")},
         "fetch_correction": "true_read = FETCH_SIZE / %.4f (calibration of %s)" % (ratio, src),
         "stages": nstage, "kernels": kernels, "hbm_bytes_per_launch": per_stage,
     }
-    out = args.out or os.path.join(ROOT, "gpurun_out", "%s_%s_pmc_traffic.json" % (args.tag, {"ssheet_dust": "cfg3"}.get(args.workload, args.workload)))
+    out = args.out or os.path.join(ROOT, "gpurun_out", "%s_%s_pmc_traffic.json" % (args.tag, {"ssheet_dust": "cfg3" if n == 4096 else "cfg3_%d" % n}.get(args.workload, args.workload)))
+    rec["n"] = n
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps({"hbm_bytes_per_stage": per_stage, "stages": nstage, "out": out}))
 

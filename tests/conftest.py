@@ -64,13 +64,16 @@ OPTION_NAMES = ["NO_TUNED", "TUNED_2D", "NO_STAGE2D", "NO_FUSED_CURV", "NO_CURV_
 def _library_options_restored():
     """The library's switches (artemis_hip_set_option) are process-wide: whatever a test sets is put back after it."""
     from artemis_amd import capi
-    if not os.path.exists(capi.LIB_PATH):
-        yield
-        return
-    L = capi.load()
-    before = {n: L.artemis_hip_get_option(n.encode()) for n in OPTION_NAMES}
+    # (never load the library on a test's behalf: it is opened RTLD_GLOBAL, and a test that runs the CPU double in this
+    #  process -- tests/test_adaptive_oracle.py -- must not find the product's symbols ahead of the double's own)
+    L = capi._lib
+    before = {n: L.artemis_hip_get_option(n.encode()) for n in OPTION_NAMES} if L is not None else {}
     yield
-    for n, v in before.items():
+    L = capi._lib
+    if L is None:
+        return
+    for n in OPTION_NAMES:
+        v = before.get(n, 0)  # (loaded during the test: every switch starts at 0)
         if v >= 0:
             L.artemis_hip_set_option(n.encode(), v)
 
