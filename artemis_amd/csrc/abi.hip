@@ -3,6 +3,7 @@
 // No CPU fallback: without a HIP device every compute entry point returns
 // ARTEMIS_HIP_EDEVICE.
 #include <cfloat>
+#include <cstring>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -756,21 +757,38 @@ int artemis_hip_diffusion_radial_fill(const artemis_pack_t *p, const double *geo
     return fail(ARTEMIS_HIP_EINVAL, "radial table: spherical 2-D/3-D blocks need the host metric table");
   const artemis::PackView P = artemis::make_pack_view(*p);
   const double *m = metric_host ? metric_host + block * artemis::metric_block_stride(P.nj, P.nk) : nullptr;
+  // (std::pow is the cost of this table.  Its argument repeats along x2 in cylindrical coordinates -- both radii are
+  //  functions of (x1, x3) there -- and along x3 / x2 elsewhere for one of the two laws: the row above is remembered,
+  //  and a zone whose argument has the same bits takes its value: the same result, a twentieth of the calls)
+  std::vector<double> prev_arg(P.ni), prev_val(P.ni);
   for (int k = 0; k < P.nk; ++k)
-    for (int j = 0; j < P.nj; ++j)
+    for (int j = 0; j < P.nj; ++j) {
+      if (p->coords == ARTEMIS_CYLINDRICAL && j > 0) { // (both radii are functions of (x1, x3): the row below, as it is)
+        double *row = out_host + (static_cast<long>(k) * P.nj + j) * P.ni;
+        std::memcpy(row, row - P.ni, sizeof(double) * P.ni);
+        continue;
+      }
       for (int i = 0; i < P.ni; ++i) {
         const artemis::DCoords co = artemis::coords_of(p->coords, geom_host + 6 * block, m, P.nj, P.nk, k, j, i);
         double xv[3];
         co.centre(xv);
-        double v;
+        double arg;
         if (c->type == ARTEMIS_VISCOSITY_PLAW) {
           const artemis::Frame fr = artemis::cyl_frame(co.sys, xv, co.cv, co.sv);
-          v = std::pow(fr.x[0] / c->r0, c->r_exp);
+          arg = fr.x[0] / c->r0;
         } else {
-          v = c->omega0 * std::pow(artemis::sph_radius(co.sys, xv) / c->r0, -1.5);
+          arg = artemis::sph_radius(co.sys, xv) / c->r0;
+        }
+        double v;
+        if ((j > 0 || k > 0) && std::memcmp(&arg, &prev_arg[i], sizeof arg) == 0) {
+          v = prev_val[i];
+        } else {
+          v = (c->type == ARTEMIS_VISCOSITY_PLAW) ? std::pow(arg, c->r_exp) : c->omega0 * std::pow(arg, -1.5);
+          prev_arg[i] = arg, prev_val[i] = v;
         }
         out_host[(static_cast<long>(k) * P.nj + j) * P.ni + i] = v;
       }
+    }
   return 0;
 }
 size_t artemis_hip_viscous_distance_count(const artemis_pack_t *p) {

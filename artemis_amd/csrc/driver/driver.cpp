@@ -86,12 +86,35 @@ struct Field {
     CK(artemis_rt_memcpy_h2d(table, h.data(), h.size() * sizeof(double *), nullptr), "h2d");
     CK(artemis_rt_device_sync(), "sync");
   }
+  // Rows for the blocks of `need` only; every other block's table entries point at one shared row (row 0) that nothing
+  // reads: flux arrays of a refined mesh on the one-kernel stages, which are touched on coarse-fine faces alone.
+  std::vector<int> slot;
+  void alloc_sparse(int nb_, int nvar_, size_t N_, const std::vector<char> &need) {
+    nb = nb_, nvar = nvar_, N = N_;
+    if (nvar == 0) return;
+    slot.assign(nb, 0);
+    int rows = 1;
+    for (int b = 0; b < nb; ++b)
+      if (need[b]) slot[b] = rows++;
+    data.alloc(static_cast<size_t>(rows) * nvar * N);
+    std::vector<double *> h(static_cast<size_t>(nb) * nvar);
+    for (int b = 0; b < nb; ++b)
+      for (int v = 0; v < nvar; ++v) h[static_cast<size_t>(b) * nvar + v] = var(b, v);
+    table = artemis_rt_malloc(h.size() * sizeof(double *));
+    if (!table) throw HipFail("table allocation failed");
+    CK(artemis_rt_memcpy_h2d(table, h.data(), h.size() * sizeof(double *), nullptr), "h2d");
+    CK(artemis_rt_device_sync(), "sync");
+  }
   double *const *tab() const { return static_cast<double *const *>(table); }
-  double *var(int b, int v) const { return data.p + (static_cast<size_t>(b) * nvar + v) * N; }
+  double *var(int b, int v) const {
+    const size_t row = slot.empty() ? static_cast<size_t>(b) : static_cast<size_t>(slot[b]);
+    return data.p + (row * nvar + v) * N;
+  }
   void release() {
     data.release();
     if (table) artemis_rt_free(table);
     table = nullptr;
+    slot.clear();
   }
   ~Field() {
     if (table) artemis_rt_free(table);
@@ -427,8 +450,8 @@ struct artemis_sim_impl {
   void build_mesh();
   void allocate();
   void ensure_unfused();
-  void ensure_flux_arrays();
-  bool flux_ready = false;
+  void ensure_flux_arrays(bool sparse_ok = false);
+  bool flux_ready = false, flux_sparse = false;
   void problem_generator();
   void fill_ghosts(int prim_idx);
   void step_general(bool want_dt, bool device_dt);
@@ -1064,6 +1087,14 @@ void artemis_sim_impl::build_mesh() {
 // Statically refined mesh: leaves of the block tree in Z-order, dealt to the ranks in contiguous runs of
 // (nearly) equal length -- every block costs the same, which is Parthenon's default load balance.
 void artemis_sim_impl::build_mesh_multilevel() {
+  const bool timing = artemis::opt(artemis::OPT_SETUP_TIMING) != 0;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mlap = [&](const char *what) {
+    if (!timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[artemis setup]   mesh: %-28s %.3f s\n", what, std::chrono::duration<double>(t - t_last).count());
+    t_last = t;
+  };
   artemis_host::BlockTree tree;
   tree.ndim = ndim;
   for (int d = 0; d < 3; ++d) tree.nrb[d] = nblk[d], tree.periodic[d] = (d < ndim) && mesh_bc[2 * d] == ARTEMIS_BC_PERIODIC;
@@ -1076,7 +1107,9 @@ void artemis_sim_impl::build_mesh_multilevel() {
   nblocks_global = static_cast<long>(leaves.size());
   if (nblocks_global < nranks) throw std::runtime_error("fewer mesh blocks than ranks");
   // operation lists of the whole mesh (global ids): the split below may weigh blocks by what they take part in
+  mlap("tree + leaves");
   const artemis_host::MeshOps M = artemis_host::build_mesh_ops(tree, leaves, mbnx, ng);
+  mlap("operation lists");
   std::vector<int> rank_of(leaves.size()), local_of(leaves.size());
   {
     // Cost of a block = zones (the same for every block) x the stage cost of its level (<artemis_amd/loadbalance>
@@ -1217,15 +1250,19 @@ void artemis_sim_impl::build_mesh_multilevel() {
       if (recv_n[r]) msgs.push_back(PeerMsg{r, tag, false, recv_at[r], recv_n[r]});
     }
   };
+  mlap("split + blocks");
   ml_host.a.clear(), ml_host.u.clear(), ml_host.b.clear(), ml_host.fx.clear(), ml_host.fxu.clear();
   split(M.ghost, nfill, ml_host.a, ml_host.u, &ml_host.b, ml_host.gsend_n, ml_host.grecv_n, ml_host.gmsgs, 7001);
   split(M.flux, nflux, ml_host.fx, ml_host.fxu, nullptr, ml_host.fsend_n, ml_host.frecv_n, ml_host.fmsgs, 7002);
   // The one-kernel stages keep no flux arrays: the fine side of every coarse-fine face is solved on its own
   // (fine_boxes: the faces a FLUX op restricts, artemis_hip_ml_flux_kernel's index map) and the coarse zones that
   // touch a corrected face are redone with it (fix_cells; a zone on a block edge can touch several).
+  mlap("rank lists");
   ml_host.fine_boxes.clear(), ml_host.fix_cells.clear();
   {
-    std::map<std::array<int, 4>, unsigned> touched;
+    // (fine boxes in list order; the coarse zones grouped by block through a per-block mask -- a std::map keyed by zone
+    //  cost 12-15 ms per remesh on the configs[4] mesh, a third of the mesh build)
+    std::vector<std::vector<const artemis_ml_op_t *>> by_block(nb);
     auto visit = [&](const artemis_ml_op_t &o) {
       const int d = o.dir;
       if (o.src_block >= 0) {
@@ -1238,26 +1275,40 @@ void artemis_sim_impl::build_mesh_multilevel() {
         }
         ml_host.fine_boxes.push_back(fb);
       }
-      if (o.dst_block >= 0) {
-        const int s0[3] = {is, js, ks};
+      if (o.dst_block >= 0) by_block[o.dst_block].push_back(&o);
+    };
+    for (const auto &o : ml_host.fx) visit(o);
+    for (const auto &o : ml_host.fxu) visit(o);
+    std::vector<unsigned char> mask(N, 0);
+    std::vector<int> hit;
+    const int s0[3] = {is, js, ks};
+    for (int blk = 0; blk < nb; ++blk) {
+      if (by_block[blk].empty()) continue;
+      hit.clear();
+      for (const artemis_ml_op_t *op : by_block[blk]) {
+        const artemis_ml_op_t &o = *op;
+        const int d = o.dir;
         const bool lower = (o.lo[d] == s0[d]); // my lower boundary face; otherwise the upper one, stored one zone up
         for (int k = o.lo[2]; k < o.lo[2] + o.n[2]; ++k)
           for (int j = o.lo[1]; j < o.lo[1] + o.n[1]; ++j)
             for (int i = o.lo[0]; i < o.lo[0] + o.n[0]; ++i) {
-              std::array<int, 4> key = {o.dst_block, k, j, i};
-              if (!lower) key[3 - d] -= 1;
-              touched[key] |= 1u << (2 * d + (lower ? 0 : 1));
+              int q[3] = {i, j, k};
+              if (!lower) q[d] -= 1;
+              const int c = (q[2] * nj + q[1]) * ni + q[0];
+              if (!mask[c]) hit.push_back(c);
+              mask[c] |= static_cast<unsigned char>(1u << (2 * d + (lower ? 0 : 1)));
             }
       }
-    };
-    for (const auto &o : ml_host.fx) visit(o);
-    for (const auto &o : ml_host.fxu) visit(o);
-    for (const auto &kv : touched) {
-      artemis_ml_fix_cell_t c;
-      c.block = kv.first[0], c.k = kv.first[1], c.j = kv.first[2], c.i = kv.first[3], c.faces = kv.second;
-      ml_host.fix_cells.push_back(c);
+      std::sort(hit.begin(), hit.end()); // (k, j, i) order within the block, as the keyed map gave it
+      for (int c : hit) {
+        artemis_ml_fix_cell_t fc;
+        fc.block = blk, fc.k = c / (nj * ni), fc.j = (c / ni) % nj, fc.i = c % ni, fc.faces = mask[c];
+        ml_host.fix_cells.push_back(fc);
+        mask[c] = 0;
+      }
     }
   }
+  mlap("fix-up zones");
   ml_host.restrict_blocks.clear(), ml_host.boxes.clear();
   for (size_t gb = 0; gb < leaves.size(); ++gb)
     if (rank_of[gb] == rank && M.has_coarser[gb]) ml_host.restrict_blocks.push_back(local_of[gb]);
@@ -1461,16 +1512,34 @@ void artemis_sim_impl::allocate() {
 
 // the flux arrays alone: what the one-kernel stages of a refined mesh need next to their primitive buffers (the
 // fine-side faces of coarse-fine boundaries and their restrictions live in them); the per-task chain also needs u1
-void artemis_sim_impl::ensure_flux_arrays() {
-  if (flux_ready) return;
-  for (int d = 0; d < 3; ++d) {
-    gflux[d].alloc(nb, 6 * ns_gas, N);
-    gpflux[d].alloc(nb, ns_gas, N);
-    gvface[d].alloc(nb, ns_gas, N);
-    dflux[d].alloc(nb, 4 * ns_dust, N);
-    if ((do_viscosity || do_conduction) && !gdflux[d].ok()) gdflux[d].alloc(nb, 4 * ns_gas, N);
+// sparse_ok: the caller touches flux arrays only on coarse-fine faces (the one-kernel stages of a refined mesh: the fine
+// side's faces, their restrictions, the faces of the fix-up zones) -- rows then exist for the blocks that own such a
+// face alone (48 arrays per zone otherwise: a third of a refined mesh's footprint).  A later caller that needs every
+// block's rows (the per-task chain) gets them allocated afresh.
+void artemis_sim_impl::ensure_flux_arrays(bool sparse_ok) {
+  if (flux_ready && (!flux_sparse || sparse_ok)) return;
+  const bool sparse = sparse_ok && multilevel && !artemis::opt(artemis::OPT_DENSE_FLUX);
+  std::vector<char> need;
+  if (sparse) {
+    need.assign(nb, 0);
+    auto mark = [&](int b) {
+      if (b >= 0 && b < nb) need[b] = 1;
+    };
+    for (const auto &o : ml_host.fx) mark(o.dst_block), mark(o.src_block);
+    for (const auto &o : ml_host.fxu) mark(o.dst_block), mark(o.src_block);
+    for (const auto &fb : ml_host.fine_boxes) mark(fb.block);
+    for (const auto &c : ml_host.fix_cells) mark(c.block);
   }
-  flux_ready = true;
+  auto make = [&](Field &f, int nvar) {
+    f.release();
+    if (sparse) f.alloc_sparse(nb, nvar, N, need);
+    else f.alloc(nb, nvar, N);
+  };
+  for (int d = 0; d < 3; ++d) {
+    make(gflux[d], 6 * ns_gas), make(gpflux[d], ns_gas), make(gvface[d], ns_gas), make(dflux[d], 4 * ns_dust);
+    if (do_viscosity || do_conduction) make(gdflux[d], 4 * ns_gas);
+  }
+  flux_ready = true, flux_sparse = sparse;
 }
 void artemis_sim_impl::ensure_unfused() {
   if (unfused_ready) return;
@@ -1866,10 +1935,27 @@ void artemis_sim_impl::problem_generator() {
       }
       return false;
     };
-    for (int k = 0; k < nk; ++k)
+    // The disk profile in cylindrical coordinates is a function of (x1, x3) alone -- ComputeDiskProfile reads R and z,
+    // the x2 faces of the pressure gradient sit at the centre's R and z and enter with a zero unit-vector component --
+    // and it is ~150 libm calls per zone: a zone takes the values of the zone one row down (same i, same k) when that
+    // one was computed.  The same bits as evaluating it again, a twentieth of the time of a remesh's generator pass.
+    const bool row_memo = (pgen == PG_DISK && coords == ARTEMIS_CYLINDRICAL);
+    std::vector<long> memo_cell(row_memo ? ni : 0, -1);
+    for (int k = 0; k < nk; ++k) {
+      if (row_memo) std::fill(memo_cell.begin(), memo_cell.end(), -1L);
       for (int j = 0; j < nj; ++j)
         for (int i = 0; i < ni; ++i) {
           if (only_ic_ghosts && !behind_ic_face(k, j, i)) continue;
+          if (row_memo) {
+            const size_t c_ = (static_cast<size_t>(k) * nj + j) * ni + i;
+            if (memo_cell[i] >= 0) {
+              const size_t m_ = static_cast<size_t>(memo_cell[i]);
+              for (int v = 0; v < 6 * ns_gas; ++v) hg[v * N + c_] = hg[v * N + m_];
+              for (int v = 0; v < 4 * ns_dust; ++v) hd[v * N + c_] = hd[v * N + m_];
+              continue;
+            }
+            memo_cell[i] = static_cast<long>(c_);
+          }
           const Real b1[2] = {xf(b, 0, i), xf(b, 0, i + 1)}, b2[2] = {xf(b, 1, j), xf(b, 1, j + 1)};
           const Real b3[2] = {xf(b, 2, k), xf(b, 2, k + 1)};
           const Real xv[3] = {0.5 * (b1[0] + b1[1]), 0.5 * (b2[0] + b2[1]), 0.5 * (b3[0] + b3[1])};
@@ -2114,6 +2200,7 @@ void artemis_sim_impl::problem_generator() {
             }
           }
         }
+    }
   };
   {
     const size_t ng_ = static_cast<size_t>(6) * ns_gas * N, nd_ = static_cast<size_t>(4) * ns_dust * N;
@@ -2242,13 +2329,13 @@ void artemis_sim_impl::problem_generator() {
       if (artemis::opt(artemis::OPT_HOST_THREADS) > 0) nthreads = static_cast<int>(artemis::opt(artemis::OPT_HOST_THREADS));
       nthreads = std::min(nthreads, nb);
     }
-    const int chunk = 64; // blocks per batch: bounds the host staging memory
+    const int chunk = 1024; // blocks per batch: bounds the host staging memory
     const bool can_copy = adopting && reuse_from && reuse_from->visc_radial.ok();
     std::vector<int> todo; // (a remesh: the blocks the old state cannot hand over)
     for (int b = 0; b < nb; ++b)
       if (!(can_copy && reuse_block(b) >= 0)) todo.push_back(b);
     const int ntodo = static_cast<int>(todo.size());
-    std::vector<std::vector<Real>> hr(static_cast<size_t>(std::min(std::max(ntodo, 1), chunk)), std::vector<Real>(N));
+    std::vector<Real> hr(static_cast<size_t>(std::min(std::max(ntodo, 1), chunk)) * N);
     for (int q0 = 0; q0 < ntodo; q0 += chunk) {
       const int nbatch = std::min(chunk, ntodo - q0);
       std::vector<std::thread> pool;
@@ -2256,14 +2343,20 @@ void artemis_sim_impl::problem_generator() {
       auto work = [&](int t) {
         for (int q = t; q < nbatch; q += nthreads)
           if (int rc = artemis_hip_diffusion_radial_fill(&pk, hgeom.data(), hmetric.empty() ? nullptr : hmetric.data(),
-                                                         &diff.visc, todo[q0 + q], hr[q].data()))
+                                                         &diff.visc, todo[q0 + q], hr.data() + static_cast<size_t>(q) * N))
             rcs[t] = rc;
       };
       for (int t = 1; t < std::min(nthreads, nbatch); ++t) pool.emplace_back(work, t);
       work(0);
       for (auto &th : pool) th.join();
       for (int t = 0; t < nthreads; ++t) CK(rcs[t], "viscosity radial table");
-      for (int q = 0; q < nbatch; ++q) upload_block(visc_radial, todo[q0 + q], hr[q]);
+      for (int q = 0; q < nbatch;) { // runs of consecutive blocks: one copy each, one synchronisation per chunk
+        int len = 1;
+        while (q + len < nbatch && todo[q0 + q + len] == todo[q0 + q] + len) ++len;
+        CK(artemis_rt_memcpy_h2d(visc_radial.var(todo[q0 + q], 0), hr.data() + static_cast<size_t>(q) * N, sizeof(Real) * N * len, stream), "h2d");
+        q += len;
+      }
+      CK(artemis_rt_stream_sync(stream), "sync");
     }
     if (adopting && reuse_from && reuse_from->visc_radial.ok()) copy_rows(visc_radial, reuse_from->visc_radial, [&](int b) { return reuse_block(b); });
     diff.visc.radial = visc_radial.tab();
@@ -2879,7 +2972,15 @@ void artemis_sim_impl::fill_stale_ghosts() {
 // coarse zones that touch such a face redone with them.  Same bits as step_unfused (tests/test_multilevel.py runs both).
 void artemis_sim_impl::step_ml_fused() {
   tiny_valid = false;
-  ensure_flux_arrays(); // (the fine-side faces and their restrictions live in them; no u1: 160 B per zone less)
+  // (the fine-side faces and their restrictions live in the flux arrays; no u1: 160 B per zone less.  Diffusion fluxes
+  //  written for the whole pack -- heat conduction, or a pack the viscous-source march does not cover -- need every row)
+  {
+    const artemis_pack_t p0 = make_pack(base);
+    const bool diffuse0 = do_gas && (do_viscosity || do_conduction);
+    const bool vs0 = diffuse0 && do_viscosity && !do_conduction && ns_gas == 1 && !artemis::opt(artemis::OPT_NO_VISC_SOURCE) &&
+                     artemis_hip_viscous_source_covers(&p0) != 0;
+    ensure_flux_arrays(!diffuse0 || vs0);
+  }
   for (int q = 1; q < 3; ++q) {
     if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
     if (!dprim[q].ok()) dprim[q].alloc(nb, 4 * ns_dust, N);

@@ -65,6 +65,8 @@
  *                    (default 64) / not at all; library hosts: artemis_rt_pool_limit (artemis_rt.h)
  *    POISON          fresh device memory from artemis_rt_malloc holds NaN patterns (a read of something never written
  *                    shows up as NaN instead of whatever the allocator returned)
+ *    DENSE_FLUX      the standalone driver gives every block of a refined mesh its flux arrays on the one-kernel stages
+ *                    too (default: rows only for the blocks that own a coarse-fine face, the only place they are used)
  * ===================================================================================== */
 #ifndef ARTEMIS_HIP_H_
 #define ARTEMIS_HIP_H_

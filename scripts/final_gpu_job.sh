@@ -1,13 +1,20 @@
 # Round-end evidence run (one gpurun call): GPU suite, smoke, bench lines, rocprof stats, PMC traffic records.
 # Outputs under gpurun_out/<tag>_*; scripts/collect_evidence.sh copies what is to be judged into profiles/<round>_*.
-# SKIP_SUITE=1 leaves the pytest run out; ROUND names the profiles/ prefix the bench lines look their records up under.
+# A gpurun call is limited to 60 minutes: PARTS selects what runs (default: everything that fits one call without the
+# suite is "pmc sq bench prof timings"; "suite" alone takes ~25 minutes).  ROUND names the profiles/ prefix the bench
+# lines look their records up under.
+PARTS=${PARTS:-"suite pmc sq bench prof timings"}
+has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 tag=${1:-r05z}
 ROUND=${ROUND:-r05}
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-if [ -z "$SKIP_SUITE" ]; then timeout 3600 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|FAILED" | tail -5 > gpurun_out/${tag}_tests.txt; cat gpurun_out/${tag}_tests.txt; fi
+if has suite; then
+timeout 3000 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|FAILED" | tail -5 > gpurun_out/${tag}_tests.txt; cat gpurun_out/${tag}_tests.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/${tag}_smoke.txt
+fi
+if has pmc; then
 # ---- HBM traffic (PMC; separate FETCH_SIZE / WRITE_SIZE passes).  The Sedov record is a mean over full-size launches of the
 # two headline instantiations only (scripts/pmc_traffic.py asserts the launch count; bench.py refuses a record without it)
 timeout 1200 python3 scripts/pmc_traffic.py --tag ${tag}
@@ -16,12 +23,16 @@ timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust -
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 4096
 timeout 1200 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph_smr
 timeout 1800 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_amr
+fi
+if has sq; then
 # ---- SQ counters: the headline kernel alone (no drop-in legs, no overlap emulation: 256^3 launches only), the disk march
 PMC_SQ_GROUPS=0,1 PMC_SQ_RECORD=${tag} timeout 600 python3 scripts/pmc_sq.py ${tag} -- bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-dropin --no-overlap-emulation > gpurun_out/${tag}_pmc_sq.txt 2>&1
 PMC_SQ_GROUPS=0,1 PMC_SQ_KERNELS=stage_curv,viscous_source timeout 600 python3 scripts/pmc_sq.py ${tag}_disk_sph -- bench.py --workload disk_sph --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_disk_sph_pmc_sq.txt 2>&1
 cp gpurun_out/sq_${tag}_disk_sph.json gpurun_out/${tag}_disk_sph_pmc_sq.json
-# (on the box: the bench lines below quote the records just measured)
-for f in pmc_traffic disk_sph_pmc_traffic cfg3_pmc_traffic cfg3_1024_pmc_traffic disk_sph_smr_pmc_traffic disk_amr_pmc_traffic pmc_sq; do cp gpurun_out/${tag}_$f.json profiles/${ROUND}_$f.json; done
+fi
+# (on the box: the bench lines below quote the records measured by this or an earlier call)
+for f in pmc_traffic disk_sph_pmc_traffic cfg3_pmc_traffic cfg3_1024_pmc_traffic disk_sph_smr_pmc_traffic disk_amr_pmc_traffic pmc_sq; do cp gpurun_out/${tag}_$f.json profiles/${ROUND}_$f.json 2>/dev/null; done
+if has bench; then
 # ---- bench lines
 timeout 900 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err; cat gpurun_out/${tag}_bench_line.json | cut -c1-400
 timeout 300 python bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_cfg3_line.json
@@ -31,6 +42,8 @@ timeout 300 python bench.py --workload disk_sph --no-cpu-baseline --steps 50 2>/
 timeout 600 python bench.py --workload disk_sph_smr --steps 40 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_sph_smr_line.json
 timeout 1500 python bench.py --workload disk_amr --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json
 cut -c1-300 gpurun_out/${tag}_cfg3_line.json gpurun_out/${tag}_cfg3_1024_line.json gpurun_out/${tag}_disk_sph_line.json gpurun_out/${tag}_disk_sph_smr_line.json gpurun_out/${tag}_disk_amr_line.json
+fi
+if has prof; then
 # ---- rocprofv3 kernel statistics.  The headline profile holds 256^3 launches of the two headline instantiations ONLY
 prof() { # prof <name> <program args ...>
   local name=$1; shift
@@ -46,6 +59,8 @@ prof smr_cart scripts/smr_timing.py 10
 prof smr_sph scripts/smr_timing.py 10 sph problem/polytropic_index=1.40 gas/de_switch=1e-2
 prof amr scripts/amr_timing.py 5 128 128 16 16 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2
 rm -f gpurun_out/${tag}_*prof/*kernel_trace.csv gpurun_out/${tag}_*prof/*/*kernel_trace.csv
+fi
+if has timings; then
 # ---- refined meshes: the shipped Cartesian SMR disk, the refined spherical disk (configs[3]'s combination), both paths; configs[4] in 3-D
 timeout 300 python scripts/smr_timing.py 20 | tee gpurun_out/${tag}_smr.txt
 ARTEMIS_NO_ML_FUSED=1 timeout 300 python scripts/smr_timing.py 20 | sed 's/^/per-task chain: /' | tee -a gpurun_out/${tag}_smr.txt
@@ -54,4 +69,5 @@ ARTEMIS_NO_ML_FUSED=1 timeout 300 python scripts/smr_timing.py 20 sph problem/po
 timeout 900 python3 scripts/amr_timing.py 10 128 128 16 16 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2 2>&1 | tail -1 | tee gpurun_out/${tag}_amr.txt
 timeout 900 python3 scripts/amr_timing.py 10 128 128 32 32 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2 2>&1 | tail -1 | sed 's/^/32^3 blocks (the deck\x27s own block size): /' | tee -a gpurun_out/${tag}_amr.txt
 for w in blast_sph blast_cyl disk_sph disk_cyl disk_axi; do timeout 300 python scripts/curv_timing.py $w; done | tee gpurun_out/${tag}_curv.txt
-head -4 gpurun_out/${tag}_bench_kernel_stats.csv | cut -c1-200
+fi
+head -4 gpurun_out/${tag}_bench_kernel_stats.csv 2>/dev/null | cut -c1-200

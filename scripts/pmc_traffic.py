@@ -131,7 +131,7 @@ def whole_stage(args, extra):
         "fetch_correction": "true_read = FETCH_SIZE / %.4f (calibration of %s)" % (ratio, src),
         "stages": nstage, "kernels": kernels, "hbm_bytes_per_launch": per_stage,
     }
-    out = args.out or os.path.join(ROOT, "gpurun_out", "%s_%s_pmc_traffic.json" % (args.tag, {"ssheet_dust": "cfg3" if n == 4096 else "cfg3_%d" % n}.get(args.workload, args.workload)))
+    out = args.out or os.path.join(ROOT, "gpurun_out", "%s_%s_pmc_traffic.json" % (args.tag, ("cfg3" if n == 4096 else "cfg3_%d" % n) if args.workload == "ssheet_dust" else args.workload))
     rec["n"] = n
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps({"hbm_bytes_per_stage": per_stage, "stages": nstage, "out": out}))
