@@ -1172,9 +1172,10 @@ void *artemis_rt_malloc(size_t bytes) {
   // taken, so that a mesh that keeps growing by a few blocks per remesh does not cross a class boundary -- a fresh
   // hipMalloc of GBs -- right after the buffers were made
   const size_t need = pool ? size_class(bytes ? bytes : 8) : (bytes ? bytes : 8);
-  // (headroom of a fresh buffer: 3 %, or 6 % from 64 MB up -- the per-field slabs of an adaptive mesh, which grow by a
-  //  few per cent per remesh when a feature is being refined: a fresh hipMalloc of GBs every remesh otherwise)
-  const size_t cap = pool ? size_class((bytes ? bytes : 8) + (bytes >= (size_t(64) << 20) ? bytes / 16 : bytes / 32)) : need;
+  // (headroom of a fresh buffer: 3 %, or 12 % from 64 MB up -- the per-field slabs of an adaptive mesh, which grow by a
+  //  few per cent per remesh while a feature is being refined.  Every slab crosses its class in the same remesh, and
+  //  mapping 70 GB afresh costs 0.4 s: with 6 % that was every second or third such remesh, with 12 % every fifth)
+  const size_t cap = pool ? size_class((bytes ? bytes : 8) + (bytes >= (size_t(64) << 20) ? bytes / 8 : bytes / 32)) : need;
   if (pool) {
     std::lock_guard<std::mutex> lk(g_bytes_mu);
     for (auto it = g_pool.lower_bound(need); it != g_pool.end() && it->first <= need + need / 4; ++it) {
