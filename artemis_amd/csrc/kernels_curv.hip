@@ -362,6 +362,12 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     }
     if (PG && __any(tny) && (t & 63) == 0) S.tiny[par] = 1;
   };
+  // Instantiations in which the five sums do not fit next to the x3 sweep (HLLC in spherical coordinates, or with the
+  // N-body frame): the compiler spilled two of them as they arrived -- load, wait, store, twice per trip.  There the two
+  // energy sums are fetched by the update where it subtracts them (their latency is the other wave's to cover).
+  constexpr bool DS_SPLIT = !DUST && D3 && ((SYS == ARTEMIS_SPHERICAL3D && (RIEMANN == 0 || EXT)) || (RIEMANN == 0 && EXT && FTX == 32));
+  // (how many of the five are prefetched: spherical HLLC with the N-body frame has room for two)
+  constexpr int DS_EARLY = !DS_SPLIT ? 5 : ((SYS == ARTEMIS_SPHERICAL3D && RIEMANN == 0 && EXT) ? 2 : 3);
   double ldt = DBL_MAX;
   PROF_DECL;
 
@@ -509,9 +515,14 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
         u0.m2 += rdt * (0.0 * sqr(w.v1 + vf[0]) + 0.0 * sqr(w.v2 + vf[1]) + co.dh3dx2() * sqr(w.v3 + vf[2]));
     }
     if (a.diff_on) { // Gas::DiffusionUpdate (artemis_driver.cpp:218-221): artemis_hip_viscous_source's sums
-      u0.m1 -= ds[0], u0.m2 -= ds[1], u0.m3 -= ds[2];
-      u0.e -= ds[3];
-      u0.eg -= ds[4];
+      auto dsv = [&](auto q) { // (a compile-time index: prefetched, or fetched here)
+        if constexpr (decltype(q)::value < DS_EARLY) return ds[decltype(q)::value];
+        else return gld(KC.dsum[decltype(q)::value], c);
+      };
+      u0.m1 -= dsv(std::integral_constant<int, 0>{}), u0.m2 -= dsv(std::integral_constant<int, 1>{});
+      u0.m3 -= dsv(std::integral_constant<int, 2>{});
+      u0.e -= dsv(std::integral_constant<int, 3>{});
+      u0.eg -= dsv(std::integral_constant<int, 4>{});
     }
     if (a.grav_on) {
       GravLds G{a.grav.type, KC.grav};
@@ -725,15 +736,16 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   Raw5 u1raw;
   u1raw.d = u1raw.v1 = u1raw.v2 = u1raw.v3 = u1raw.e = 0.0;
   double ds[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  auto load_ds = [&](unsigned c) {
+  auto load_ds = [&](unsigned c, int q0, int q1) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) ds[q] = gld(S.C.dsum[q], c);
+    for (int q = 0; q < 5; ++q)
+      if (q >= q0 && q < q1) ds[q] = gld(S.C.dsum[q], c);
   };
   if constexpr (!D3) {
     const unsigned c0 = col + static_cast<unsigned>(k0) * sk;
     const Cell6 qc = ldcell(in_r, in_1, in_2, in_3, in_e, c0);
     if (a.has_u1) u1raw = ldraw(S.C.u1[0], S.C.u1[1], S.C.u1[2], S.C.u1[3], S.C.u1[4], c0);
-    if (a.diff_on) load_ds(c0);
+    if (a.diff_on) load_ds(c0, 0, 5);
     Raw5 hal = u1raw;
     if (hr >= 0) hal = ldraw(in_r, in_1, in_2, in_3, in_e, hcol + static_cast<unsigned>(k0) * sk);
     stage_plane(qc, hal, k0 & 1);
@@ -814,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       // tells the compiler's counter model so, wherever its scheduler moves the conditional loads below)
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
       if (a.has_u1 && live) u1raw = ldraw(S.C.u1[0], S.C.u1[1], S.C.u1[2], S.C.u1[3], S.C.u1[4], ck);
-      if (a.diff_on && live) load_ds(ck);
+      if (a.diff_on && live) load_ds(ck, 0, DS_EARLY);
       PROF(9);
       Cell6 zr, zl_next;
       Flux8 fz_hi;

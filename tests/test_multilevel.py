@@ -369,6 +369,33 @@ def test_refined_mesh_exchange_through_rccl_loopback(hiplib, case, path, option)
         ref.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["visc3d", "sph3d"])
+def test_flux_rows_only_on_blocks_with_coarse_fine_faces(hiplib, case, option):
+    """On the one-kernel stages of a refined mesh the flux arrays are touched on coarse-fine faces alone (the fine side's
+    faces, their restrictions, the faces of the fix-up zones), so the driver gives rows to the blocks that own such a face
+    and points every other block's table entries at one shared row.  Same bits as with every block's rows
+    (ARTEMIS_DENSE_FLUX), and switching to the per-task chain afterwards -- which writes every block's fluxes -- allocates
+    the full set (the result still equals the run that started dense)."""
+    from artemis_amd.driver import Simulation
+    c = CASES[case]
+    option("dense_flux", 1)
+    ref = Simulation(DECK(*c["deck"]), c["ov"])
+    ref.evolve(4)
+    option("dense_flux", 0)
+    sim = Simulation(DECK(*c["deck"]), c["ov"])
+    sim.evolve(4)
+    assert sim.uses_fused_path and sim.ncycle == ref.ncycle == 4 and sim.dt == ref.dt
+    for b in range(sim.nblocks):
+        assert np.array_equal(sim.field("gas.prim", b), ref.field("gas.prim", b)), (case, b)
+    ref.set_path("unfused"), sim.set_path("unfused")
+    ref.evolve(3), sim.evolve(3)
+    assert sim.dt == ref.dt
+    for b in range(sim.nblocks):
+        assert np.array_equal(sim.field("gas.prim", b), ref.field("gas.prim", b)), (case, b)
+    sim.close(), ref.close()
+
+
 def _disk_cart(extra):
     from artemis_amd.driver import Simulation
     return Simulation(DECK("disk", "disk_cart.in"), ["parthenon/time/nlim=%d" % DISK["cycles"]] + extra)
