@@ -1168,17 +1168,18 @@ void *artemis_rt_malloc(size_t bytes) {
     std::lock_guard<std::mutex> lk(g_bytes_mu);
     pool = g_pool_limit > 0;
   }
-  // a cached buffer serves if it fits (up to a quarter larger); a fresh one gets 3 % of headroom before its size class is
+  // a cached buffer serves if it fits (up to half as large again); a fresh one gets 3 % of headroom before its size class is
   // taken, so that a mesh that keeps growing by a few blocks per remesh does not cross a class boundary -- a fresh
   // hipMalloc of GBs -- right after the buffers were made
   const size_t need = pool ? size_class(bytes ? bytes : 8) : (bytes ? bytes : 8);
-  // (headroom of a fresh buffer: 3 %, or 12 % from 64 MB up -- the per-field slabs of an adaptive mesh, which grow by a
+  // (headroom of a fresh buffer: 3 %, or 20 % from 64 MB up -- the per-field slabs of an adaptive mesh, which grow by a
   //  few per cent per remesh while a feature is being refined.  Every slab crosses its class in the same remesh, and
-  //  mapping 70 GB afresh costs 0.4 s: with 6 % that was every second or third such remesh, with 12 % every fifth)
-  const size_t cap = pool ? size_class((bytes ? bytes : 8) + (bytes >= (size_t(64) << 20) ? bytes / 8 : bytes / 32)) : need;
+  //  mapping 70 GB afresh costs 0.4 s: with 6 % that was every second or third such remesh, with 12 % every fifth, with
+  //  20 % every seventh or eighth; what a shrinking mesh leaves behind goes back at the trim after each remesh)
+  const size_t cap = pool ? size_class((bytes ? bytes : 8) + (bytes >= (size_t(64) << 20) ? bytes / 5 : bytes / 32)) : need;
   if (pool) {
     std::lock_guard<std::mutex> lk(g_bytes_mu);
-    for (auto it = g_pool.lower_bound(need); it != g_pool.end() && it->first <= need + need / 4; ++it) {
+    for (auto it = g_pool.lower_bound(need); it != g_pool.end() && it->first <= need + need / 2; ++it) { // (covers the headroom below)
       if (it->second.dev != dev) continue; // (a buffer of another device is not this device's memory)
       p = it->second.p;
       g_pool_bytes -= it->first;

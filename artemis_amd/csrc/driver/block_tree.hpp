@@ -14,6 +14,8 @@
 #include <set>
 #include <stdexcept>
 #include <tuple>
+#include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "artemis_hip.h"
@@ -108,9 +110,13 @@ class BlockTree {
   }
 
  private:
-  typedef std::tuple<int, int, int, int> Key;
-  static Key key(int level, const Loc &l) { return Key(level, l[0], l[1], l[2]); }
-  std::set<Key> internal_;
+  // (level, lx) packed into one word: 4 + 3 x 20 bits (a root grid of a few thousand blocks per dimension refined
+  // sixteen times would not fit any memory either).  Hashed: the neighbour searches of a remesh make ~10^6 look-ups
+  typedef std::uint64_t Key;
+  static Key key(int level, const Loc &l) {
+    return (static_cast<Key>(level) << 60) | (static_cast<Key>(l[0]) << 40) | (static_cast<Key>(l[1]) << 20) | static_cast<Key>(l[2]);
+  }
+  std::unordered_set<Key> internal_;
   int max_level_ = 0;
   void walk(int level, const Loc &l, std::vector<Leaf> &out) const {
     if (!is_internal(level, l)) {
@@ -141,20 +147,17 @@ struct MeshOps {
 inline MeshOps build_mesh_ops(const BlockTree &t, const std::vector<Leaf> &leaves, const int nx[3], int ng) {
   MeshOps M;
   M.has_coarser.assign(leaves.size(), 0);
-  std::set<std::tuple<int, int, int, int>> dummy;
   // id lookup
-  struct Less {
-    bool operator()(const std::tuple<int, int, int, int> &a, const std::tuple<int, int, int, int> &b) const { return a < b; }
+  std::unordered_map<std::uint64_t, int> table;
+  table.reserve(leaves.size() * 2);
+  auto pack = [](int level, const Loc &l) {
+    return (static_cast<std::uint64_t>(level) << 60) | (static_cast<std::uint64_t>(l[0]) << 40) |
+           (static_cast<std::uint64_t>(l[1]) << 20) | static_cast<std::uint64_t>(l[2]);
   };
-  std::vector<std::pair<std::tuple<int, int, int, int>, int>> table;
-  table.reserve(leaves.size());
-  for (size_t b = 0; b < leaves.size(); ++b)
-    table.push_back({std::make_tuple(leaves[b].level, leaves[b].lx[0], leaves[b].lx[1], leaves[b].lx[2]), static_cast<int>(b)});
-  std::sort(table.begin(), table.end());
+  for (size_t b = 0; b < leaves.size(); ++b) table.emplace(pack(leaves[b].level, leaves[b].lx), static_cast<int>(b));
   auto id_of = [&](int level, const Loc &l) {
-    const auto k = std::make_tuple(level, l[0], l[1], l[2]);
-    auto it = std::lower_bound(table.begin(), table.end(), std::make_pair(k, -1));
-    if (it == table.end() || it->first != k) throw std::logic_error("block tree: leaf expected (2:1 balance violated?)");
+    auto it = table.find(pack(level, l));
+    if (it == table.end()) throw std::logic_error("block tree: leaf expected (2:1 balance violated?)");
     return it->second;
   };
   const int ndim = t.ndim;

@@ -173,7 +173,7 @@ def test_device_buffer_cache_contract():
     c = L.artemis_rt_malloc(n)                      # a second live buffer is a new allocation
     assert c and c != b and footprint() > held
     L.artemis_rt_free(b), L.artemis_rt_free(c)
-    d = L.artemis_rt_malloc(n - (n >> 4))           # 6 % smaller: a cached buffer of up to a quarter more serves
+    d = L.artemis_rt_malloc(n - (n >> 4))           # 6 % smaller: a cached buffer of up to half as much again serves
     assert d in (a, c)
     L.artemis_rt_free(d)
     L.artemis_rt_pool_trim(0)
