@@ -1013,16 +1013,21 @@ template <bool CURV>
 __global__ __launch_bounds__(TX *TY) void timestep_all_kernel(const PackView P, const Box r, const artemis_diffcoeff_t visc,
                                                               const artemis_diffcoeff_t cond, double cv, double cfl_gas,
                                                               double cfl_dust, unsigned long long *dt_bits) {
-  // zones in a flat order (x1 fastest inside a block): every lane has a zone whatever the block's width -- a 64-wide
-  // thread row on the 16^3 blocks of a refined mesh keeps a quarter of the lanes busy
+  // zones in a flat order inside a block (x1 fastest): every lane has a zone whatever the block's width -- a 64-wide
+  // thread row on the 16^3 blocks of a refined mesh keeps a quarter of the lanes busy.  A workgroup's 256 zones belong
+  // to ONE block: the block index is wave-uniform, so the table pointers and the edge table are scalar loads and a
+  // zone's nine values are one level of vector loads (with the block index per lane every array was pointer load ->
+  // data load, and the kernel waited 84 % of its cycles: 1.18 ms per pass over the configs[4] mesh)
   const unsigned nx = r.iu - r.il + 1, ny = r.ju - r.jl + 1, nz = r.ku - r.kl + 1;
-  const unsigned long per_block = static_cast<unsigned long>(nx) * ny * nz, total = per_block * P.nb;
+  const unsigned per_block = nx * ny * nz, tpb = (per_block + TX * TY - 1) / (TX * TY);
+  const unsigned long ntile = static_cast<unsigned long>(tpb) * P.nb;
   const unsigned tid = threadIdx.y * TX + threadIdx.x;
   double lg = DBL_MAX, ld = DBL_MAX, lv = DBL_MAX, lc = DBL_MAX; // gas hydro, dust, viscous, conductive
-  for (unsigned long t = static_cast<unsigned long>(blockIdx.x) * (TX * TY) + tid; t < total;
-       t += static_cast<unsigned long>(gridDim.x) * (TX * TY)) {
-    const int b = static_cast<int>(t / per_block);
-    const unsigned rr = static_cast<unsigned>(t - b * per_block), row = rr / nx;
+  for (unsigned long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int b = static_cast<int>(tile / tpb);
+    const unsigned rr = static_cast<unsigned>(tile - static_cast<unsigned long>(b) * tpb) * (TX * TY) + tid;
+    if (rr >= per_block) continue;
+    const unsigned row = rr / nx;
     const int i = r.il + static_cast<int>(rr - row * nx), j = r.jl + static_cast<int>(row % ny), k = r.kl + static_cast<int>(row / ny);
     const long c = (static_cast<long>(k) * P.nj + j) * P.ni + i;
     double dx[3]; // GetCellWidths (geometry.hpp:352-361)
@@ -1227,8 +1232,8 @@ void launch_diffusion_update(const PackView &P, const artemis_diffusion_t &D, do
 void launch_timestep_all(const PackView &P, const artemis_diffusion_t *D, double cfl_gas, double cfl_dust, double *dt_dev,
                          hipStream_t s) {
   const Box r = interior(P);
-  const long zones = static_cast<long>(r.iu - r.il + 1) * (r.ju - r.jl + 1) * (r.ku - r.kl + 1) * P.nb;
-  const long ntile = (zones + TX * TY - 1) / (TX * TY);
+  const long per_block = static_cast<long>(r.iu - r.il + 1) * (r.ju - r.jl + 1) * (r.ku - r.kl + 1);
+  const long ntile = (per_block + TX * TY - 1) / (TX * TY) * P.nb;
   const dim3 g(static_cast<unsigned>(ntile < 2048 ? std::max<long>(ntile, 1) : 2048));
   auto *bits = reinterpret_cast<unsigned long long *>(dt_dev);
   artemis_diffcoeff_t off;
