@@ -179,3 +179,38 @@ def test_device_buffer_cache_contract():
     L.artemis_rt_pool_trim(0)
     assert footprint() == base
     L.artemis_rt_pool_limit(0)
+
+
+def test_option_table_contract():
+    """artemis_hip_set_option / artemis_hip_get_option (csrc/options.hpp): every switch include/artemis_hip.h documents is a
+    name of the table, names are case-insensitive with or without the ARTEMIS_ prefix, unknown names are refused (EINVAL /
+    -1), and the table is filled from ARTEMIS_<NAME> once, at first use -- checked in a child process so that this
+    process's table (and library) stay as they are."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, %r)
+os.environ["ARTEMIS_VISC_KCHUNK"] = "7"
+os.environ["ARTEMIS_NO_REDO"] = "yes"
+from artemis_amd import capi
+L = C.CDLL(capi.LIB_PATH)
+L.artemis_hip_get_option.restype = C.c_long
+L.artemis_hip_set_option.argtypes = [C.c_char_p, C.c_long]
+assert L.artemis_hip_get_option(b"VISC_KCHUNK") == 7 and L.artemis_hip_get_option(b"artemis_visc_kchunk") == 7
+assert L.artemis_hip_get_option(b"no_redo") == 1          # set, but not a number: a plain switch
+assert L.artemis_hip_get_option(b"NO_GRAPH") == 0
+os.environ["ARTEMIS_NO_GRAPH"] = "1"                      # (the environment is read once)
+assert L.artemis_hip_get_option(b"NO_GRAPH") == 0
+assert L.artemis_hip_set_option(b"no_graph", 1) == 0 and L.artemis_hip_get_option(b"NO_GRAPH") == 1
+assert L.artemis_hip_set_option(b"no_such_switch", 1) != 0 and L.artemis_hip_get_option(b"no_such_switch") == -1
+import re
+doc = open(os.path.join(%r, "include", "artemis_hip.h")).read()
+head = doc[:doc.index("#ifndef ARTEMIS_HIP_H_")]
+names = set(re.findall(r"\b([A-Z][A-Z0-9_]{3,})\b", head)) - {"ARTEMIS", "NULL", "EINVAL", "ARTEMIS_HIP_EINVAL", "NAME"}
+known = [n for n in names if L.artemis_hip_get_option(n.encode()) >= 0]
+assert len(known) >= 30, sorted(known)
+print("ok", len(known))
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
