@@ -31,7 +31,7 @@ rows = [("256^3 Sedov, RK2, HLLC + PLM (BASELINE configs[1]: the headline)", "be
         ("disk_sph.in x 2: 256 x 128^2 spherical, alpha viscosity, gravity, rotating frame", "disk_sph_line", "disk_sph_pmc_traffic"),
         ("... with a refined midplane region (configs[3]'s combination; 464 blocks of 32^3)", "disk_sph_smr_line", "disk_sph_smr_pmc_traffic"),
         ("configs[4] in 3-D: cylindrical disk + planet + dust + drag, four adaptive levels, 7 064 blocks of 16^3", "disk_amr_line", "disk_amr_pmc_traffic")]
-print("| workload (`bench.py --workload ...`) | zone-cycles/s | ms per step | kernel(s) of a stage: ms | achieved / 8 TB/s | HBM traffic, measured / algorithmic per stage | CPU oracle (16 threads) |")
+print("| workload (`bench.py --workload ...`) | zone-cycles/s | ms per step | kernel(s) of a stage: ms | achieved / 8 TB/s | HBM traffic, measured / algorithmic per stage | CPU oracle, zone-cycles/s (threads: `cpu_baseline.threads` of the line) |")
 print("|---|---|---|---|---|---|---|")
 for what, ln, tr in rows:
     d = line(ln)
@@ -53,7 +53,7 @@ if d:
     fi = rf.get("fp64_issue") or {}
     print()
     print("Headline details: VALU lane-instructions per zone-stage %s, fp64-issue floor fraction %s; drop-in contracts %s; "
-          "overlap emulation %s zone-cycles/s." % (fi.get("valu_per_zone"), fi.get("frac"),
+          "overlap emulation %s zone-cycles/s." % (fi.get("lane_instructions_per_zone_stage"), fi.get("frac"),
                                                     json.dumps({k: (v.get("value") if isinstance(v, dict) else v) for k, v in (d.get("dropin") or {}).items()}),
                                                     d["config"].get("overlap_emulation_zcps")))
 d = line("disk_amr_line")
