@@ -1160,13 +1160,15 @@ __global__ __launch_bounds__(256) void floor_ghost_kernel(const FillTabs t_in, c
   for (int m = 0; m < nsg; ++m) {
     double *rho = t.gas[t.b * 6 * nsg + m], *se = t.gas[t.b * 6 * nsg + 5 * nsg + m];
     const double w_d = rho[c], w_s = se[c];
-    rho[c] = (w_d > P.gas.dfloor) ? w_d : P.gas.dfloor;
-    se[c] = (w_s > P.gas.siefloor) ? w_s : P.gas.siefloor;
+    // (stored only where the floor acts -- almost nowhere: the pass is then reads alone; `!(w > floor)` is the
+    //  reference's `(w > floor) ? w : floor` with NaN going to the floor as well)
+    if (!(w_d > P.gas.dfloor)) rho[c] = P.gas.dfloor;
+    if (!(w_s > P.gas.siefloor)) se[c] = P.gas.siefloor;
   }
   for (int m = 0; m < nsd; ++m) {
     double *rho = t.dust[t.b * 4 * nsd + m];
     const double w_d = rho[c];
-    rho[c] = (w_d > P.dust.dfloor) ? w_d : P.dust.dfloor;
+    if (!(w_d > P.dust.dfloor)) rho[c] = P.dust.dfloor;
   }
 }
 
