@@ -186,6 +186,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if os.path.isdir(os.path.join(_HERE, "csrc")) and not os.environ.get("ARTEMIS_NO_BUILD_CHECK"):
+        # In a source checkout the library that is loaded IS the working tree: bring it up to date (a no-op when every
+        # object's content hash matches; hipcc cross-compiles without a GPU) and refuse a binary that still differs.
+        from . import build as _build
+        _build.build_hip()
+        _build.verify()
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (hipcc --offload-arch=gfx950). No fallback exists.")
@@ -224,6 +230,7 @@ def load():
         "artemis_hip_ml_face_fluxes": (i, [PPk, C.POINTER(StageGeneralArgs), vp, i, vp]),
         "artemis_hip_ml_stage_fixup": (i, [PPk, C.POINTER(StageGeneralArgs), vp, i, vp]),
         "artemis_hip_stage_finish": (i, [PPk, C.POINTER(Drag), d, d, vp]),
+        "artemis_hip_stage_finish_cells": (i, [PPk, C.POINTER(Drag), d, d, vp, i, vp]),
         "artemis_hip_restrict_average": (i, [C.POINTER(Refine), vp]),
         "artemis_hip_prolongate_minmod": (i, [C.POINTER(Refine), vp]),
         "artemis_hip_amr_first_derivative": (i, [C.POINTER(AmrCriterion), C.POINTER(C.c_int), C.POINTER(C.c_double), vp]),
@@ -255,6 +262,8 @@ def load():
         "artemis_hip_last_error": (C.c_char_p, []),
         "artemis_hip_device_count": (i, []),
         "artemis_hip_version": (C.c_char_p, []),
+        "artemis_hip_source_sha": (C.c_char_p, []),
+        "artemis_hip_object_sha": (C.c_char_p, [C.c_char_p]),
         "artemis_rt_set_device": (i, [i]),
         "artemis_rt_malloc": (vp, [C.c_size_t]),
         "artemis_rt_free": (None, [vp]),
@@ -302,7 +311,7 @@ EXPORTS_HIP = [
     "artemis_hip_ml_exchange", "artemis_hip_ml_flux_correction", "artemis_hip_ml_restrict_halos", "artemis_hip_ml_prolongate",
     "artemis_hip_ml_face_fluxes", "artemis_hip_ml_stage_fixup", "artemis_hip_plm_table_count", "artemis_hip_plm_table_fill",
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",
-    "artemis_hip_stage_general", "artemis_hip_stage_general_variant", "artemis_hip_stage_epilogue", "artemis_hip_stage_epilogue_cons", "artemis_hip_stage_finish", "artemis_hip_amr_block_maxima", "artemis_hip_restrict_average",
+    "artemis_hip_stage_general", "artemis_hip_stage_general_variant", "artemis_hip_stage_epilogue", "artemis_hip_stage_epilogue_cons", "artemis_hip_stage_finish", "artemis_hip_stage_finish_cells", "artemis_hip_amr_block_maxima", "artemis_hip_restrict_average",
     "artemis_hip_prolongate_minmod", "artemis_hip_amr_first_derivative", "artemis_hip_amr_magnitude",
     "artemis_hip_zero_diffusion_flux", "artemis_hip_viscous_distance_count", "artemis_hip_viscous_distance_fill",
     "artemis_hip_viscous_flux", "artemis_hip_zero_viscous_flux", "artemis_hip_thermal_flux", "artemis_hip_diffusion_update",
@@ -310,8 +319,19 @@ EXPORTS_HIP = [
     "artemis_hip_diffusion_dt", "artemis_hip_diffusion_radial_fill", "artemis_hip_halo_count", "artemis_hip_halo_count_ext",
     "artemis_hip_halo_pack_ext", "artemis_hip_halo_unpack_ext",
     "artemis_hip_halo_pack", "artemis_hip_halo_unpack", "artemis_hip_last_error",
-    "artemis_hip_device_count", "artemis_hip_version",
+    "artemis_hip_device_count", "artemis_hip_version", "artemis_hip_source_sha", "artemis_hip_object_sha",
 ]
+
+
+def source_sha():
+    """sha1 of the sources the loaded library was built from (== artemis_amd.build.tree_sha() in a checkout)."""
+    return load().artemis_hip_source_sha().decode()
+
+
+def object_sha(unit):
+    """Content hash of one translation unit of the loaded library, e.g. "kernels_fused" (None: no such unit)."""
+    v = load().artemis_hip_object_sha(unit.encode())
+    return v.decode() if v else None
 
 
 def check(rc):

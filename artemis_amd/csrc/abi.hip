@@ -635,6 +635,7 @@ static int validate_ml_fix(const artemis_pack_t *p, const artemis_stage_general_
   if (!a) return fail(ARTEMIS_HIP_EINVAL, "null stage args");
   if (int rc = validate_fluid(p, ARTEMIS_GAS, a->pcm)) return rc;
   if (int rc = validate_fluid(p, ARTEMIS_DUST, a->pcm)) return rc;
+  if (a->defer_finish < 0 || a->defer_finish > 2) return fail(ARTEMIS_HIP_EINVAL, "defer_finish must be 0, 1 or 2");
   if (a->drag && !a->defer_finish)
     return fail(ARTEMIS_HIP_EUNSUPPORTED, "refined-mesh fix-up: drag couples the fluids after the update: set defer_finish and run "
                                           "artemis_hip_stage_finish after the fix-up");
@@ -983,6 +984,23 @@ int artemis_hip_stage_epilogue(const artemis_pack_t *p, const artemis_stage_gene
 }
 int artemis_hip_stage_epilogue_cons(const artemis_pack_t *p, const artemis_stage_general_args_t *a, void *stream) {
   return stage_epilogue_common(p, a, stream, true);
+}
+int artemis_hip_stage_finish_cells(const artemis_pack_t *p, const artemis_drag_t *drag, double time, double dt,
+                                   const artemis_ml_fix_cell_t *cells_dev, int ncells, void *stream) {
+  (void)time;
+  if (int rc = validate(p)) return rc;
+  if (int rc = validate_registers(p, "stage finish")) return rc;
+  if (ncells < 0 || (ncells > 0 && !cells_dev)) return fail(ARTEMIS_HIP_EINVAL, "stage finish: bad zone list");
+  for (const artemis_fluid_pack_t *f : {&p->gas, &p->dust})
+    if (f->nspecies && (!f->prim || !f->cons0)) return fail(ARTEMIS_HIP_EINVAL, "stage finish: prim and cons0 tables are required");
+  if (!drag || drag->type != ARTEMIS_DRAG_SIMPLE_DUST || p->gas.nspecies != 1 || p->dust.nspecies < 1)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "stage finish of listed zones: one gas species coupled by simple_dust drag");
+  if (int rc = validate_damp_visc(drag)) return rc;
+  if (p->dust.nspecies > ARTEMIS_MAX_DUST_SPECIES)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "drag: more than %d dust species", ARTEMIS_MAX_DUST_SPECIES);
+  if (ncells == 0) return ARTEMIS_HIP_OK;
+  artemis::launch_drag_finish_cells(artemis::make_pack_view(*p), *drag, dt, cells_dev, ncells, S(stream));
+  return after_launch("stage_finish_cells");
 }
 int artemis_hip_stage_finish(const artemis_pack_t *p, const artemis_drag_t *drag, double time, double dt, void *stream) {
   (void)time;

@@ -3008,7 +3008,9 @@ void artemis_sim_impl::step_ml_fused() {
     if (do_gravity && grav_nbody) nbody_stage_args(p, a, a.bdt);
     if (do_drag) { // DragSource couples the fluids: it runs once, over every zone, after the fix-up
       drag.damp_visc = damp_to_visc ? &diff.visc : nullptr;
-      a.drag = &drag, a.defer_finish = 1;
+      // one gas species coupled by simple_dust drag: the stage finishes every zone itself (inside the dust march where
+      // it runs) and only the fix-up's listed zones are finished again afterwards; other laws: every zone after the fix-up
+      a.drag = &drag, a.defer_finish = (drag.type == ARTEMIS_DRAG_SIMPLE_DUST && ns_gas == 1 && ns_dust >= 1) ? 2 : 1;
     }
     const bool diffuse = do_gas && (do_viscosity || do_conduction);
     // viscosity alone: the five sums of artemis_hip_viscous_source for the whole pack, and the viscous fluxes themselves
@@ -3052,7 +3054,12 @@ void artemis_sim_impl::step_ml_fused() {
     flux_correction_multilevel(p);
     CK(artemis_hip_ml_stage_fixup(&p, &a, static_cast<const artemis_ml_fix_cell_t *>(ml.fix_cells.p), ml.fix_cells.n, stream),
        "coarse zones on coarse-fine faces");
-    if (a.defer_finish) {
+    if (a.defer_finish == 2) {
+      const artemis_pack_t po = make_pack(out);
+      CK(artemis_hip_stage_finish_cells(&po, &drag, time, a.bdt, static_cast<const artemis_ml_fix_cell_t *>(ml.fix_cells.p),
+                                        ml.fix_cells.n, stream),
+         "DragSource + SetAuxillaryFields + ConsToPrim of the fix-up zones");
+    } else if (a.defer_finish) {
       const artemis_pack_t po = make_pack(out);
       CK(artemis_hip_stage_finish(&po, &drag, time, a.bdt, stream), "DragSource + SetAuxillaryFields + ConsToPrim");
     }

@@ -30,6 +30,9 @@ void launch_drag_source(const PackView &P, const artemis_drag_t &D, double dt, c
                         hipStream_t s);
 bool launch_drag_finish(const PackView &P, const artemis_drag_t &D, double dt, const double *dt_dev,
                         hipStream_t s);
+bool launch_drag_finish_cells(const PackView &P, const artemis_drag_t &D, double dt, const artemis_ml_fix_cell_t *cells,
+                              int ncells, hipStream_t s);
+bool drag_finish_in_march(const PackView &P, const artemis_drag_t &D);
 long halo_count(const PackView &P, int face, int extended = 0);
 int launch_halo(const PackView &P, int block, int face, double *buf, int unpack, int extended,
                 hipStream_t s);
@@ -68,7 +71,10 @@ inline int pick_march_chunks(int planes, long tiles, long slots, int cmax, doubl
   return best;
 }
 bool curv_march_covers_dust(const PackView &P, const artemis_stage_general_args_t &g, int recon_dust, int riemann_dust);
-void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g, int fluid, int recon, int riemann, hipStream_t s);
+// finish (fluid 1 only): the dust march also runs DragSource + SetAuxillaryFields + ConsToPrim of both fluids (the gas march has
+// left its conserved state in P.gas.cons0) and, with g.dt_dev, both fluids' timestep limits
+void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g, int fluid, int recon, int riemann, hipStream_t s,
+                       bool finish = false);
 // kernels_diffusion.hip
 void launch_zero_diffusion_flux(const PackView &P, hipStream_t s);
 // overwrite: ZeroDiffusionFlux folded in (the flux arrays are overwritten on the face ranges)

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "device_math.hpp"
@@ -75,6 +76,10 @@ struct CurvK {
   artemis_gravity_t grav;
   double *const *dsum;
   int to_cons;                          // 1: stop after the sources, conserved state to P.gas.cons0 (drag follows)
+  int finish;                           // DUST march: DragSource (simple_dust) + SetAuxillaryFields + ConsToPrim of BOTH fluids here
+  DragLaw1 drag;                        //   (the gas march has left its conserved state in P.gas.cons0)
+  double *const *gas_out;               //   the gas primitives' output tables
+  double cfl_gas;                       //   (the gas fluid's timestep limit is formed here too)
   const artemis_nbody_particle_t *nb_pl; // N-body gravity in the gravity task's slot (device array), nb_n particles
   int nb_n;
   double nb_omf;
@@ -95,6 +100,11 @@ struct CurvConst {
   // vector loads (the kernel has stores in flight: no scalar load) followed by vmcnt(0) -- a wait for every prefetch
   double *out[6], *cons0[6];
   const double *dsum[5], *u1[5]; // (u1: rho, v1, v2, v3, sie of the start-of-step state)
+  // DUST march with the drag finish (CurvK.finish): the gas conserved state it reads, the gas primitives it writes
+  const double *gcons[6];
+  double *gout[5]; // rho, v1, v2, v3, sie
+  double g_dfloor, g_siefloor, g_de_switch, cfl_gas;
+  DragLaw1 drag;
 };
 // artemis_gravity_t as gravity_accel reads it: the law's type from the kernel argument (a scalar: the branches on it stay
 // scalar branches), every number from the LDS copy
@@ -234,6 +244,18 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     for (int q = 0; q < 4; ++q) c.u1[q] = a.prim_u1[b * NV + q];
     c.u1[4] = a.prim_u1[b * NV + (DUST ? 0 : NV - 1)]; // (dust: never loaded)
     S.C = c;
+    if constexpr (DUST) {
+      if (a.finish) { // (field by field, straight to LDS: an aggregate copy under this condition would live in scratch)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) S.C.gcons[q] = P.gas.cons0[b * 6 + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S.C.gout[q] = a.gas_out[b * 6 + q];
+        S.C.gout[4] = a.gas_out[b * 6 + 5];
+        S.C.g_dfloor = P.gas.dfloor, S.C.g_siefloor = P.gas.siefloor, S.C.g_de_switch = P.gas.de_switch, S.C.cfl_gas = a.cfl_gas;
+        S.C.drag.stokes = a.drag.stokes, S.C.drag.tau = a.drag.tau, S.C.drag.scale = a.drag.scale;
+        S.C.drag.grain_density = a.drag.grain_density, S.C.drag.size = a.drag.size;
+      }
+    }
   }
   const double *g = P.geom + 6 * b;
   const double *in_r = a.prim_in[b * NV + 0], *in_1 = a.prim_in[b * NV + 1], *in_2 = a.prim_in[b * NV + 2];
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   constexpr bool DS_SPLIT = !DUST && D3 && ((SYS == ARTEMIS_SPHERICAL3D && (RIEMANN == 0 || EXT)) || (RIEMANN == 0 && EXT && FTX == 32));
   // (how many of the five are prefetched: spherical HLLC with the N-body frame has room for two)
   constexpr int DS_EARLY = !DS_SPLIT ? 5 : ((SYS == ARTEMIS_SPHERICAL3D && RIEMANN == 0 && EXT) ? 2 : 3);
-  double ldt = DBL_MAX;
+  double ldt = DBL_MAX, ldt_gas = DBL_MAX;
   PROF_DECL;
 
   // ---- the update of zone (k, j, i) from the folded sums -----------------------------------------------------------
@@ -404,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   };
 
   auto update = [&](const int k, const DCoordsT<true> &co, const CellMetric &cm, const double hx[3], const Cell6 &qc, Sums &s,
-                    const Raw5 &u1raw, const double ds[5]) {
+                    const Raw5 &u1raw, const double ds[5], const GasCons &gcz) {
     if (!active) return;
     const CurvConst &KC = S.C; // (LDS: every read below is a broadcast ds_read at its use)
     const unsigned c = col + static_cast<unsigned>(k) * sk;
@@ -456,6 +478,40 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       if (a.to_cons) {
         gst(KC.cons0[0], c, u0.d), gst(KC.cons0[1], c, u0.m1), gst(KC.cons0[2], c, u0.m2);
         gst(KC.cons0[3], c, u0.m3);
+        return;
+      }
+      if (a.finish) { // DragSource couples the fluids pointwise, on this zone's two conserved states (drag.hpp:296-482)
+        const GasCons ug = gcz;
+        struct { double dfloor, siefloor, de_switch; } GF{KC.g_dfloor, KC.g_siefloor, KC.g_de_switch};
+        const double xv[3] = {co.x1v(), co.x2v(), co.x3v()};
+        const CylVec cv = to_cyl_with_vec(co, xv);
+        const double zero3[3] = {0.0, 0.0, 0.0};
+        // the hand-scheduled divisions round like `/` unless a momentum is tiny-but-nonzero or a density is not a
+        // positive normal number: wave-uniform choice
+        const bool odd = tiny_nonzero(ug.m1) || tiny_nonzero(ug.m2) || tiny_nonzero(ug.m3) || tiny_nonzero(u0.m1) ||
+                         tiny_nonzero(u0.m2) || tiny_nonzero(u0.m3) || !(ug.d > 1.0e-280 && ug.d < 1.0e280) ||
+                         !(u0.d > 1.0e-280 && u0.d < 1.0e280) || !(ug.e > 1.0e-280 && ug.e < 1.0e280) ||
+                         !(ug.eg > 1.0e-280 && ug.eg < 1.0e280);
+        DragFinish1 o;
+        if (__any(odd)) o = simple_drag1_finish<false>(KC.drag, GF, KC, gm1, dt, hx, cv, zero3, zero3, ug, u0);
+        else o = simple_drag1_finish<true>(KC.drag, GF, KC, gm1, dt, hx, cv, zero3, zero3, ug, u0);
+        gst(KC.out[0], c, o.dd), gst(KC.out[1], c, o.d1), gst(KC.out[2], c, o.d2), gst(KC.out[3], c, o.d3);
+        gst(KC.gout[0], c, o.gd), gst(KC.gout[1], c, o.g1), gst(KC.gout[2], c, o.g2), gst(KC.gout[3], c, o.g3);
+        gst(KC.gout[4], c, o.gs);
+        if (a.dt_bits) { // EstimateTimestepMesh of both fluids on the new state (dust.cpp:256-272, gas.cpp:411-433)
+          double denom = 0.0;
+          denom += fabs(o.d1) / co.width1();
+          if (multi_d) denom += fabs(o.d2) / co.width2();
+          if (D3) denom += fabs(o.d3) / co.width3();
+          ldt = amin(ldt, 1.0 / denom);
+          const double bulk = (gm1 + 1.0) * gm1 * o.gd * o.gs; // IdealGas bulk modulus
+          const double cs = sqrt(bulk / o.gd);
+          double dg_ = 0.0;
+          dg_ += (fabs(o.g1) + cs) / co.width1();
+          if (multi_d) dg_ += (fabs(o.g2) + cs) / co.width2();
+          if (D3) dg_ += (fabs(o.g3) + cs) / co.width3();
+          ldt_gas = amin(ldt_gas, 1.0 / dg_);
+        }
         return;
       }
       const double w_d = (u0.d > KC.dfloor) ? u0.d : KC.dfloor; // ConsToPrim (fill_derived.cpp:155-164)
@@ -736,6 +792,14 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   Raw5 u1raw;
   u1raw.d = u1raw.v1 = u1raw.v2 = u1raw.v3 = u1raw.e = 0.0;
   double ds[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  GasCons gcz; // DUST march with the drag finish: the zone's gas conserved state
+  gcz.d = gcz.m1 = gcz.m2 = gcz.m3 = gcz.e = gcz.eg = 0.0;
+  auto load_gc = [&](unsigned c) {
+    GasCons z;
+    z.d = gld(S.C.gcons[0], c), z.m1 = gld(S.C.gcons[1], c), z.m2 = gld(S.C.gcons[2], c);
+    z.m3 = gld(S.C.gcons[3], c), z.e = gld(S.C.gcons[4], c), z.eg = gld(S.C.gcons[5], c);
+    return z;
+  };
   auto load_ds = [&](unsigned c, int q0, int q1) {
 #pragma unroll
     for (int q = 0; q < 5; ++q)
@@ -746,6 +810,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     const Cell6 qc = ldcell(in_r, in_1, in_2, in_3, in_e, c0);
     if (a.has_u1) u1raw = ldraw(S.C.u1[0], S.C.u1[1], S.C.u1[2], S.C.u1[3], S.C.u1[4], c0);
     if (a.diff_on) load_ds(c0, 0, 5);
+    if constexpr (DUST) if (a.finish) gcz = load_gc(c0);
     Raw5 hal = u1raw;
     if (hr >= 0) hal = ldraw(in_r, in_1, in_2, in_3, in_e, hcol + static_cast<unsigned>(k0) * sk);
     stage_plane(qc, hal, k0 & 1);
@@ -769,7 +834,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     scale_factors_of(co, hx);
     s.tm[2] = s.te[2] = 0.0, s.rfx[2] = 0 * 0.5 * (0.0 + 0.0);
     s.rfd = s.rfd + 0 * (0.0 * 0.0 * 0.0 + 0.0 * 0.0 * 0.0);
-    update(k0, co, cm, hx, qc, s, u1raw, ds);
+    update(k0, co, cm, hx, qc, s, u1raw, ds, gcz);
   } else {
     Cell6 qc = ldcell(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k0 - 1) * sk);
     Cell6 qn = ldcell(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k0) * sk);
@@ -827,6 +892,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
       if (a.has_u1 && live) u1raw = ldraw(S.C.u1[0], S.C.u1[1], S.C.u1[2], S.C.u1[3], S.C.u1[4], ck);
       if (a.diff_on && live) load_ds(ck, 0, DS_EARLY);
+      if constexpr (DUST) if (a.finish && live) gcz = load_gc(ck);
       PROF(9);
       Cell6 zr, zl_next;
       Flux8 fz_hi;
@@ -870,7 +936,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
         fold(std::integral_constant<int, 3>{}, s, fz_lo, fz_hi, cm.ax3[0], cm.ax3[1], b3[0], b3[1], div(bdt, cm.dx[2]), dt_vol, true);
         double hx[3];
         scale_factors_of(co, hx);
-        update(k, co, cm, hx, qc, s, u1raw, ds);
+        update(k, co, cm, hx, qc, s, u1raw, ds, gcz);
         PROF(7);
       }
       fz_lo = fz_hi, qc = qn, qn = qnn;
@@ -891,6 +957,17 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       double m = S.wmin[0];
       for (int w = 1; w < 4; ++w) m = fmin(m, S.wmin[w]);
       if (m < DBL_MAX) atomicMin(a.dt_bits, static_cast<unsigned long long>(__double_as_longlong(S.C.cfl * m)));
+    }
+    if constexpr (DUST) if (a.finish) { // ... and the gas fluid's limit of the same zones
+      __syncthreads();
+      for (int off = 32; off > 0; off >>= 1) ldt_gas = fmin(ldt_gas, __shfl_down(ldt_gas, off, 64));
+      if ((t & 63) == 0) S.wmin[t >> 6] = ldt_gas;
+      __syncthreads();
+      if (t == 0) {
+        double m = S.wmin[0];
+        for (int w = 1; w < 4; ++w) m = fmin(m, S.wmin[w]);
+        if (m < DBL_MAX) atomicMin(a.dt_bits, static_cast<unsigned long long>(__double_as_longlong(S.C.cfl_gas * m)));
+      }
     }
   }
 }
@@ -971,14 +1048,22 @@ bool curv_march_covers_dust(const PackView &P, const artemis_stage_general_args_
 }
 
 // fluid 0: the gas march; fluid 1: the dust march (same tiles, same chunks)
-void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g, int fluid, int recon_in, int riemann, hipStream_t s) {
+void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g, int fluid, int recon_in, int riemann, hipStream_t s,
+                       bool finish) {
   const bool dust = fluid != 0;
   CurvK k;
   k.gam0 = g.gam0, k.gam1 = g.gam1, k.beta_dt = g.beta_dt, k.bdt = g.bdt, k.cfl = dust ? g.cfl_dust : g.cfl_gas;
   k.bdt_ptr = g.beta_dt_dev;
   if (dust) k.prim_in = g.dust_in, k.prim_u1 = g.dust_u1, k.prim_out = g.dust_out;
   else k.prim_in = g.gas_in, k.prim_u1 = g.gas_u1, k.prim_out = g.gas_out;
-  k.to_cons = (g.drag || g.defer_finish) ? 1 : 0;
+  k.to_cons = (g.drag || g.defer_finish == 1) ? 1 : 0;
+  k.finish = 0, k.gas_out = g.gas_out, k.cfl_gas = g.cfl_gas;
+  std::memset(&k.drag, 0, sizeof k.drag);
+  if (dust && finish) { // the dust march couples the fluids itself and writes both fluids' primitives (stage_finish_in_march)
+    k.to_cons = 0, k.finish = 1;
+    k.drag.stokes = (g.drag->model == ARTEMIS_DRAG_STOKES) ? 1 : 0, k.drag.tau = g.drag->tau[0], k.drag.scale = g.drag->scale;
+    k.drag.grain_density = g.drag->grain_density, k.drag.size = g.drag->sizes[0];
+  }
   k.dt_bits = k.to_cons ? nullptr : reinterpret_cast<unsigned long long *>(g.dt_dev);
   k.nb_pl = g.nbody_dev, k.nb_n = g.nbody_n, k.nb_omf = g.nbody_omf;
   k.has_u1 = (k.prim_u1 != k.prim_in) ? 1 : 0;

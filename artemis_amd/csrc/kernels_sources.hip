@@ -44,26 +44,7 @@ inline dim3 interior_grid(const PackView &P) {
 }
 
 
-// Coords<GEOM>::ConvertToCylWithVec (geometry.hpp:476-482): cylindrical radius of the cell
-// centroid and the first component of each basis vector (geometry.hpp:289-306,
-// cylindrical.hpp:117-126, spherical.hpp:191-205 / :382-396 / :556-577, axisymmetric.hpp:134-145).
-struct CylVec {
-  double R, e1, e2, e3;
-};
-__device__ __forceinline__ CylVec to_cyl_with_vec(const DCoords &co, const double xv[3]) {
-  CylVec c;
-  switch (co.sys) {
-  case ARTEMIS_CARTESIAN: {
-    const double R = sqrt(xv[0] * xv[0] + xv[1] * xv[1]);
-    c.R = R, c.e1 = xv[0] / (R + 1e-99), c.e2 = xv[1] / (R + 1e-99), c.e3 = 0.0; // Fuzz<Real>()
-  } break;
-  case ARTEMIS_SPHERICAL3D:
-  case ARTEMIS_SPHERICAL2D: c.R = xv[0] * co.sv, c.e1 = co.sv, c.e2 = co.cv, c.e3 = 0.0; break;
-  case ARTEMIS_SPHERICAL1D: c.R = xv[0] * 1.0, c.e1 = 1.0, c.e2 = 0.0, c.e3 = 0.0; break;
-  default: c.R = xv[0], c.e1 = 1.0, c.e2 = 0.0, c.e3 = 0.0;
-  }
-  return c;
-}
+// (Coords<GEOM>::ConvertToCylWithVec: sources_device.hpp to_cyl_with_vec)
 
 // ---------------------------------------------------------------------------------------
 // Gravity::ExternalGravity (gravity.cpp:126-155): UniformGravity (uniform.cpp:28-84) and
@@ -602,10 +583,8 @@ __global__ __launch_bounds__(TX *TY) void self_drag_kernel(const PackView P, con
 // dust species the registers hold (more species: the generic loop below, stores interleaved as before).
 constexpr int DRAG_MAXD = 4;
 template <bool FINISH, int ND> // ND: the number of dust species as a compile-time constant (0 .. DRAG_MAXD), or -1 = any
-__global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, const artemis_drag_t D, const artemis_diffcoeff_t V,
-                                                             double dt_host, const double *dt_dev, const int damp_on) {
-  INTERIOR_CELL
-  const double dt = dt_dev ? *dt_dev : dt_host;
+ADEV void simple_drag_zone(const PackView &P, const artemis_drag_t &D, const artemis_diffcoeff_t &V, const double dt,
+                           const int damp_on, const int b, const int k, const int j, const int i, const long c) {
   const DCoords co = make_coords(P, b, k, j, i);
   const double xv[3] = {co.x1v(), co.x2v(), co.x3v()};
   double hx[3];
@@ -767,6 +746,24 @@ __global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, c
     og_s[c] = (w_s > G.siefloor) ? w_s : G.siefloor;
   }
 }
+template <bool FINISH, int ND>
+__global__ __launch_bounds__(TX *TY) void simple_drag_kernel(const PackView P, const artemis_drag_t D, const artemis_diffcoeff_t V,
+                                                             double dt_host, const double *dt_dev, const int damp_on) {
+  INTERIOR_CELL
+  simple_drag_zone<FINISH, ND>(P, D, V, dt_dev ? *dt_dev : dt_host, damp_on, b, k, j, i, c);
+}
+// ... of the LISTED zones only (a refined mesh's fix-up zones, whose conserved state artemis_hip_ml_stage_fixup has just
+// rewritten: artemis_hip_stage_finish_cells)
+template <int ND>
+__global__ __launch_bounds__(256) void simple_drag_cells_kernel(const PackView P, const artemis_drag_t D, const artemis_diffcoeff_t V,
+                                                                double dt, const int damp_on,
+                                                                const artemis_ml_fix_cell_t *__restrict__ cells, const int ncells) {
+  const int q = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+  if (q >= ncells) return;
+  const artemis_ml_fix_cell_t z = cells[q];
+  const long c = (static_cast<long>(z.k) * P.nj + z.j) * P.ni + z.i;
+  simple_drag_zone<true, ND>(P, D, V, dt, damp_on, z.block, z.k, z.j, z.i, c);
+}
 
 // force[7 n + q] += the rows of `partial` in index order.  The rows come through LDS in chunks (coalesced loads by the
 // whole workgroup); thread (n, q) then adds its column of the chunk in order.
@@ -883,6 +880,28 @@ bool launch_drag_finish(const PackView &P, const artemis_drag_t &D, double dt, c
   if (D.type != ARTEMIS_DRAG_SIMPLE_DUST || P.gas.ns != 1) return false;
   launch_simple_drag<true>(P, D, dt, dt_dev, s);
   return true;
+}
+bool launch_drag_finish_cells(const PackView &P, const artemis_drag_t &D, double dt, const artemis_ml_fix_cell_t *cells,
+                              int ncells, hipStream_t s) {
+  if (D.type != ARTEMIS_DRAG_SIMPLE_DUST || P.gas.ns != 1) return false;
+  if (ncells <= 0) return true;
+#define DRAG_ND(N)                                                                                                     \
+  hipLaunchKernelGGL((simple_drag_cells_kernel<N>), dim3((ncells + 255) / 256), dim3(256), 0, s, P, D, damp_visc_of(D), dt, \
+                     damping_on(D), cells, ncells)
+  switch (P.dust.ns) {
+  case 0: DRAG_ND(0); break;
+  case 1: DRAG_ND(1); break;
+  case 2: DRAG_ND(2); break;
+  case 3: DRAG_ND(3); break;
+  case 4: DRAG_ND(4); break;
+  default: DRAG_ND(-1);
+  }
+#undef DRAG_ND
+  return true;
+}
+// can the dust march do the drag finish itself (kernels_curv.hip, simple_drag1_finish)?
+bool drag_finish_in_march(const PackView &P, const artemis_drag_t &D) {
+  return D.type == ARTEMIS_DRAG_SIMPLE_DUST && P.gas.ns == 1 && P.dust.ns == 1 && !D.damp_visc && !damping_on(D);
 }
 
 } // namespace artemis

@@ -663,7 +663,10 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
     launch_stage_fused_curv(P, g, recon_gas, riemann_gas, s);
     return;
   }
-  const bool to_cons = g.drag || g.defer_finish;
+  // defer_finish: 1 = stop at the conserved state (the caller finishes every zone); 2 = finish every zone here, the caller
+  // re-finishes its listed fix-up zones (artemis_hip_stage_finish_cells); 0 = no fix-up follows
+  const bool defer = g.defer_finish == 1;
+  const bool to_cons = g.drag || defer;
   CellStageArgs a = cell_args(P, g);
   a.to_cons = to_cons ? 1 : 0;
   if (variant == 3) { // curvilinear gas: the streaming tile march with its geometry in LDS tables (kernels_curv.hip)
@@ -676,15 +679,19 @@ void launch_stage_cell(const PackView &P, const artemis_stage_general_args_t &g,
     else launch_recon<0, 2>(P, recon, a, s);
   }
   const bool dust_march = variant == 3 && curv_march_covers_dust(P, g, recon_dust, riemann_dust);
+  // one dust species coupled by simple_dust drag: the dust march does the coupled update, SetAuxillaryFields and
+  // ConsToPrim of both fluids on its registers (no conserved round trip of the dust, no finish launch)
+  const bool finish_in_march = dust_march && g.drag && !defer && !opt(OPT_NO_DRAG_IN_MARCH) && drag_finish_in_march(P, *g.drag);
   if (dust_march) { // the dust species on the same march (kernels_curv.hip, DUST instantiations)
-    launch_stage_curv(P, g, 1, recon_dust, riemann_dust, s);
+    launch_stage_curv(P, g, 1, recon_dust, riemann_dust, s, finish_in_march);
   } else if (P.dust.ns) {
     a.in = g.dust_in, a.u1 = g.dust_u1, a.out = g.dust_out;
     const int recon = g.pcm ? ARTEMIS_PCM : recon_dust;
     if (riemann_dust == ARTEMIS_HLLE) launch_recon<1, 1>(P, recon, a, s);
     else launch_recon<1, 2>(P, recon, a, s);
   }
-  if (g.defer_finish) return; // the caller finishes (artemis_hip_stage_finish) once its fix-up has run
+  if (defer) return; // the caller finishes (artemis_hip_stage_finish) once its fix-up has run
+  if (finish_in_march) return; // (both fluids' primitives and timestep limits are done)
   PackView Q = P; // the new state: prim tables are the out tables
   Q.gas.prim = g.gas_out, Q.dust.prim = g.dust_out;
   if (g.drag) { // coupled update on cons0, then SetAuxillaryFields and ConsToPrim into the out tables

@@ -1,6 +1,9 @@
 // Register-level forms of the pointwise source tasks, shared by the per-task kernels
 // (kernels_sources.hip) and the cell-centred fused stage (kernels_stage_cell.hip).
 #pragma once
+#include <cfloat>
+#include <cmath>
+
 #include "device_math.hpp"
 #include "geometry.hpp"
 #include "pack_view.hpp"
@@ -259,6 +262,130 @@ ADEV void cooling_gas(const FluidView &G, double cv, double omdt, double T0, dou
   const double Tn = amax(0.0, sie / cv);
   const double dE = -dens * cv * omdt / (beta + omdt) * (Tn - T0);
   u.e += dE, u.eg += dE;
+}
+
+// ---- Coords<GEOM>::ConvertToCylWithVec (geometry.hpp:476-482) ------------------------------------
+// cylindrical radius of the cell centroid and the first component of each basis vector (geometry.hpp:289-306,
+// cylindrical.hpp:117-126, spherical.hpp:191-205 / :382-396 / :556-577, axisymmetric.hpp:134-145).
+struct CylVec {
+  double R, e1, e2, e3;
+};
+template <class CO>
+ADEV CylVec to_cyl_with_vec(const CO &co, const double xv[3]) {
+  CylVec c;
+  switch (co.sys) {
+  case ARTEMIS_CARTESIAN: {
+    const double R = sqrt(xv[0] * xv[0] + xv[1] * xv[1]);
+    c.R = R, c.e1 = xv[0] / (R + 1e-99), c.e2 = xv[1] / (R + 1e-99), c.e3 = 0.0; // Fuzz<Real>()
+  } break;
+  case ARTEMIS_SPHERICAL3D:
+  case ARTEMIS_SPHERICAL2D: c.R = xv[0] * co.sv, c.e1 = co.sv, c.e2 = co.cv, c.e3 = 0.0; break;
+  case ARTEMIS_SPHERICAL1D: c.R = xv[0] * 1.0, c.e1 = 1.0, c.e2 = 0.0, c.e3 = 0.0; break;
+  default: c.R = xv[0], c.e1 = 1.0, c.e2 = 0.0, c.e3 = 0.0;
+  }
+  return c;
+}
+
+// ---- Drag::DragSource, simple_dust (SimpleDragSourceImpl, drag.hpp:296-482) for ONE gas and ONE dust species on one
+// zone's conserved state, followed by SetAuxillaryFields (fill_derived.cpp:58-71) and ConsToPrim (:132-164) of both
+// fluids: the register-level form of kernels_sources.hip's simple_drag_kernel<FINISH = true, ND = 1> (same expression
+// trees, statement by statement; that kernel reads and writes arrays, this one a march's registers).  No damp_to_visc
+// (mu = 0 as DiffusionCoeff<null>::Get gives it); bg / bd = the damping ramps of the zone (+ 0.0 when no rate is set).
+// FAST: every quotient through the hand-scheduled division of device_math.hpp -- the caller has checked that no momentum
+// of the wave is tiny-but-nonzero and that every density is a positive normal number; otherwise IEEE `/` as written.
+struct DragLaw1 {
+  int stokes;
+  double tau, scale, grain_density, size;
+};
+struct DragFinish1 {
+  double gd, g1, g2, g3, gs; // gas rho, v, sie
+  double dd, d1, d2, d3;     // dust rho, v
+};
+template <bool FAST, class FG, class FD>
+ADEV DragFinish1 simple_drag1_finish(const DragLaw1 &D, const FG &G, const FD &F, const double gm1, const double dt,
+                                     const double hx[3], const CylVec &cv, const double bg[3], const double bd[3],
+                                     const GasCons &ug, const DustCons &ud) {
+  auto dv = [](double num, double den) { return FAST ? div(num, den) : num / den; };
+  const double dg = ug.d, e_cons = ug.e, eg_cons = ug.eg;
+  const double mg0[3] = {ug.m1, ug.m2, ug.m3};
+  const double dens = ud.d;
+  const double md[3] = {ud.m1, ud.m2, ud.m3};
+  const double vg[3] = {dv(mg0[0], hx[0] * dg), dv(mg0[1], hx[1] * dg), dv(mg0[2], hx[2] * dg)};
+  double sieg; // GetSpecificInternalEnergy (artemis_utils.hpp:43-62), species 0
+  {
+    const double u_d = amax(dg, G.dfloor);
+    const double rv1 = dv(mg0[0], hx[0]), rv2 = dv(mg0[1], hx[1]), rv3 = dv(mg0[2], hx[2]);
+    const double ke = dv(0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)), u_d);
+    const double ue_cons = e_cons - ke;
+    sieg = (ue_cons > G.de_switch * e_cons) ? dv(ue_cons, u_d) : dv(eg_cons, u_d);
+    sieg = amax(sieg, G.siefloor);
+  }
+  const double mu = 0.0; // drag.hpp:392-393 with DiffusionCoeff<null>
+  const double vR = -1.5 * mu / (cv.R * dg);
+  const double vt[3] = {cv.e1 * vR, cv.e2 * vR, cv.e3 * vR};
+  double fd[3] = {0., 0., 0.}, fvd[3] = {0., 0., 0.};
+  double vth = 0.0;
+  if (D.stokes) vth = sqrt(8.0 / M_PI * gm1 * sieg);
+  const double vdt[3] = {0.0, 0.0, 0.0};
+  const double vd[3] = {dv(md[0], hx[0] * dens), dv(md[1], hx[1] * dens), dv(md[2], hx[2] * dens)};
+  double tc = D.tau;
+  if (D.stokes) tc = D.scale * D.grain_density / dg * D.size / vth;
+  const double alpha = dt * ((tc <= 0.0) ? DBL_MAX : 1.0 / tc);
+  double rhopv[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const double rhop = dv(dens * alpha, 1.0 + alpha + bd[d]);
+    rhopv[d] = rhop;
+    fd[d] += rhop * (1.0 + bd[d]);
+    fvd[d] += rhop * (vd[d] + bd[d] * vdt[d]);
+  }
+  double vgp[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) vgp[d] = dv(dg * (vg[d] + bg[d] * vt[d]) + fvd[d], dg * (1.0 + bg[d]) + fd[d]);
+  double delta_g[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int d = 0; d < 3; d++) fvd[d] = 0.;
+  DragFinish1 o;
+  const double w_dd = (dens > F.dfloor) ? dens : F.dfloor;
+  double newd[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    double delta_d = 0.;
+    const double rhop = rhopv[d]; // (the reference's second pass re-evaluates the same expression)
+    const double delta = rhop * ((vgp[d] - vd[d] + bd[d] * (vgp[d] - vdt[d])));
+    delta_d += delta;
+    delta_g[d] -= delta;
+    delta_d -= dv(bd[d] * dens, 1. + alpha + bd[d]) * (vd[d] - vdt[d] + alpha * (vgp[d] - vdt[d]));
+    fvd[d] += rhop * (vd[d] - vt[d] + bd[d] * (vdt[d] - vt[d]));
+    const double m = md[d] + hx[d] * delta_d;
+    newd[d] = dv(m, w_dd * hx[d]); // Dust ConsToPrim (fill_derived.cpp:155-164)
+  }
+  o.dd = w_dd, o.d1 = newd[0], o.d2 = newd[1], o.d3 = newd[2];
+  double en = e_cons, mnew[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const double prefac = dv(dg * bg[d], 1.0 + bg[d] + fd[d]);
+    delta_g[d] -= prefac * (dg * (vg[d] - vt[d]) + fvd[d]);
+    mnew[d] = mg0[d] + hx[d] * delta_g[d];
+    en += 0.5 * (vg[d] + vgp[d]) * delta_g[d];
+  }
+  // SetAuxillaryFields + ConsToPrim of the gas
+  const double u_d = (dg > G.dfloor) ? dg : G.dfloor;
+  const double u_d2 = amax(dg, G.dfloor);
+  const double rv1 = dv(mnew[0], hx[0]), rv2 = dv(mnew[1], hx[1]), rv3 = dv(mnew[2], hx[2]);
+  const double ke = dv(0.5 * (sqr(rv1) + sqr(rv2) + sqr(rv3)), u_d2);
+  const double ue_cons = en - ke;
+  double sie = (ue_cons > G.de_switch * en) ? dv(ue_cons, u_d2) : dv(eg_cons, u_d2);
+  sie = amax(sie, G.siefloor);
+  double u_u = sie * u_d;
+  const double uflr = G.siefloor * u_d;
+  u_u = (u_u > uflr) ? u_u : uflr;
+  const double w_d = u_d;
+  const double w_s = dv(u_u, w_d);
+  o.gd = w_d;
+  o.g1 = dv(mnew[0], w_d * hx[0]), o.g2 = dv(mnew[1], w_d * hx[1]), o.g3 = dv(mnew[2], w_d * hx[2]);
+  o.gs = (w_s > G.siefloor) ? w_s : G.siefloor;
+  return o;
 }
 
 // ---- RotatingFrame::ShearingBoxImpl (rotating_frame_impl.hpp:28-93) -------------------------

@@ -191,25 +191,19 @@ def host_cores():
     return {"logical": logical, "cgroup_quota": quota, "smt": smt, "physical_usable": usable}
 
 
-def kernel_source_sha1(scope="fused"):
-    """Identity of the kernel sources a PMC traffic record was measured on: it is only quoted next to a timing
-    while they are unchanged (scripts/pmc_traffic.py writes the same hash).  scope "fused": the tuned stage
-    kernel's own sources (the Sedov headline); "all": every device source (whole-stage records of the other
-    workloads, which run several kernels per stage)."""
-    import glob
-    import hashlib
-    h = hashlib.sha1()
-    d = os.path.join(ROOT, "artemis_amd", "csrc")
-    files = (["kernels_fused.hip", "fused_device.hpp", "device_math.hpp", "pack_view.hpp"] if scope == "fused" else
-             sorted(os.path.basename(f) for f in glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp"))))
-    for f in files:
-        h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()
+def library_identity(scope="fused"):
+    """Identity of the code a PMC record was measured on, as the LOADED LIBRARY reports it (artemis_amd/build.py compiles
+    the content hashes in): scope "fused" = the translation unit of the tuned stage kernel (source, every header it
+    reaches, flags, compiler) -- the Sedov headline; "all" = every source of the library (whole-stage records of the other
+    workloads, which run several kernels per stage).  A record is quoted next to a timing only while the library that
+    produced the timing reports the identity the record carries (scripts/pmc_traffic.py writes it the same way)."""
+    from artemis_amd import capi
+    return capi.object_sha("kernels_fused") if scope == "fused" else capi.source_sha()
 
 
 def measured_traffic(name):
     """HBM bytes per launch (Sedov) / per stage (other workloads) from the newest profiles/r*<name>pmc_traffic.json
-    whose source hash matches this checkout, else None (a stale record is never reported)."""
+    whose identity is the loaded library's, else None (a stale record is never reported)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*%spmc_traffic.json" % name)), reverse=True):
         try:
@@ -218,8 +212,8 @@ def measured_traffic(name):
             continue
         if name == "" and rec.get("workload", "sedov3d") != "sedov3d":
             continue
-        want = kernel_source_sha1(rec.get("sha_scope", "fused"))
-        if rec.get("kernel_source_sha1") != want or rec.get("env"):  # this checkout's kernels, default knobs only
+        want = library_identity(rec.get("sha_scope", "fused"))
+        if rec.get("library_identity") != want or rec.get("env"):  # the loaded library's own code, default knobs only
             continue
         if name == "" and (not rec.get("headline_launches") or rec.get("headline_launches") != rec.get("headline_launches_expected")):
             # a Sedov record must be a mean over full-size launches of the two headline instantiations and nothing
@@ -231,14 +225,14 @@ def measured_traffic(name):
 
 def measured_valu():
     """VALU wave-instructions per launch of the headline stage kernel from the newest profiles/r*_pmc_sq.json whose
-    source hash matches this checkout (scripts/pmc_sq.py with PMC_SQ_RECORD), else None."""
+    identity is the loaded library's (scripts/pmc_sq.py with PMC_SQ_RECORD), else None."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")), reverse=True):
         try:
             rec = json.load(open(path))
         except Exception:
             continue
-        if rec.get("kernel_source_sha1") == kernel_source_sha1("fused") and not rec.get("env"):
+        if rec.get("library_identity") == library_identity("fused") and not rec.get("env"):
             return rec.get("valu_wave_instructions_per_launch"), os.path.relpath(path, ROOT)
     return None, None
 
@@ -321,6 +315,9 @@ def main():
                          "disk_sph = BASELINE configs[3] without refinement (inputs/disk/disk_sph.in, spherical-polar "
                          "alpha disk; --n scales the 128x64x64 deck mesh by n/128, 1 GPU)")
     ap.add_argument("--dust", type=int, default=1, help="ssheet_dust: number of dust species")
+    ap.add_argument("--amr-block", type=int, default=16, choices=[16, 32],
+                    help="disk_amr: zones per block edge -- 16 (default: the stress case, 7 064 blocks at N = 1) or 32 (the block "
+                         "size of the reference's deck inputs/disk/disk_nbody_cyl.in)")
     ap.add_argument("--uniform", action="store_true",
                     help="sedov3d diagnostic (SURVEY 8d): the same deck with an empty blast region, i.e. a uniform gas at "
                          "rest -- same kernels, no shocks -- to separate branch-divergence effects from the rest")
@@ -330,6 +327,11 @@ def main():
     args = ap.parse_args()
     if args.gpus not in DECOMPOSITION:
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    if args.gpus > 1 and args.workload in ("ssheet_dust", "disk_sph"):
+        raise SystemExit("--workload %s is a single-GPU measurement (one mesh block); the N-GPU workloads are sedov3d, "
+                         "disk_sph_smr and disk_amr" % args.workload)
+    if args.gpus > 1 and args.remesh_in_timed_region:
+        raise SystemExit("--remesh-in-timed-region injects tags by local leaf index: a single-GPU measurement")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(sys.argv[1:], args.gpus)  # does not return
     result_fd = os.dup(1)
@@ -399,8 +401,6 @@ def main():
 
     per_gpu = (args.n, args.n, args.n)
     if args.workload == "ssheet_dust":
-        if args.gpus != 1:
-            raise SystemExit("--workload ssheet_dust is a single-GPU measurement")
         deck = os.path.join(ROOT, "inputs", "ssheet", "ssheet.in")
         n = str(args.n)
         ov = ["parthenon/mesh/nx1=" + n, "parthenon/mesh/nx2=" + n, "parthenon/meshblock/nx1=" + n,
@@ -412,8 +412,6 @@ def main():
         make_sim = lambda: Simulation(deck, ov)
         sim = make_sim()
     elif args.workload == "disk_sph":
-        if args.gpus != 1:
-            raise SystemExit("--workload disk_sph is a single-GPU measurement")
         deck = os.path.join(ROOT, "inputs", "disk", "disk_sph.in")
         sc = max(1, args.n // 128)
         dims = (128 * sc, 64 * sc, 64 * sc)
@@ -423,28 +421,27 @@ def main():
         make_sim = lambda: Simulation(deck, ov)
         sim = make_sim()
     elif args.workload == "disk_sph_smr":
-        # BASELINE configs[3]'s combination on one GPU: the spherical-polar disk deck x 2 in 32^3 blocks with a level-1
-        # static region around the midplane (scripts/smr_timing.py sph; tests/test_multilevel.py runs its small form)
-        if args.gpus != 1:
-            raise SystemExit("--workload disk_sph_smr is a single-GPU measurement")
+        # BASELINE configs[3] (an 8-GPU configuration): the spherical-polar disk deck x 2 in 32^3 blocks with a level-1
+        # static region around the midplane (scripts/smr_timing.py sph; tests/test_multilevel.py runs its small form).
+        # N ranks: the root mesh grows N-fold along x3 (azimuth; same domain, same zones per GPU), the Z-ordered leaf
+        # list is cut into N consecutive runs, ghost zones between runs travel through the native RCCL transport.
         deck = os.path.join(ROOT, "inputs", "disk", "disk_sph.in")
-        ov = ["parthenon/time/nlim=-1", "parthenon/mesh/nx1=256", "parthenon/mesh/nx2=128", "parthenon/mesh/nx3=128",
+        ov = ["parthenon/time/nlim=-1", "parthenon/mesh/nx1=256", "parthenon/mesh/nx2=128", "parthenon/mesh/nx3=%d" % (128 * args.gpus),
               "parthenon/mesh/refinement=static", "parthenon/static_refinement1/level=1",
               "parthenon/static_refinement1/x1min=0.7", "parthenon/static_refinement1/x1max=1.9",
               "parthenon/static_refinement1/x2min=1.3", "parthenon/static_refinement1/x2max=1.85",
               "parthenon/static_refinement1/x3min=-3.0", "parthenon/static_refinement1/x3max=3.0",
               "problem/polytropic_index=1.40", "gas/de_switch=1e-2"]
-        make_sim = lambda: Simulation(deck, ov)
+        make_sim = lambda: Simulation(deck, ov, comm=comm)
         sim = make_sim()
     elif args.workload == "disk_amr":
-        # BASELINE configs[4]'s combination on one GPU, 3-D: inputs/disk/disk_nbody_cyl.in + a planet + one dust species
+        # BASELINE configs[4] (an 8-GPU configuration), 3-D: inputs/disk/disk_nbody_cyl.in + a planet + one dust species
         # with drag + the rotating frame + adaptive refinement to four levels (scripts/amr_timing.py; the 2-D form runs
-        # against the adaptive oracle in tests/test_adaptive.py)
-        if args.gpus != 1:
-            raise SystemExit("--workload disk_amr is a single-GPU measurement")
+        # against the adaptive oracle in tests/test_adaptive.py).  N ranks: the root mesh grows N-fold along x2 (azimuth),
+        # Z-order runs of leaves per rank, blocks migrate at remeshes.  --amr-block 32 = the deck's own block size.
         deck = os.path.join(ROOT, "inputs", "disk", "disk_nbody_cyl.in")
-        mb = 16
-        ov = ["parthenon/mesh/nx1=128", "parthenon/mesh/nx2=128", "parthenon/mesh/nx3=16",
+        mb = args.amr_block
+        ov = ["parthenon/mesh/nx1=128", "parthenon/mesh/nx2=%d" % (128 * args.gpus), "parthenon/mesh/nx3=%d" % max(16, mb),
               "parthenon/mesh/x3min=-0.2", "parthenon/mesh/x3max=0.2",
               "parthenon/meshblock/nx1=%d" % mb, "parthenon/meshblock/nx2=%d" % mb, "parthenon/meshblock/nx3=%d" % mb,
               "parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=4", "parthenon/mesh/derefine_count=5",
@@ -456,7 +453,7 @@ def main():
               "nbody/particle2/mass=1.0e-2", "nbody/particle2/couple=1", "nbody/particle2/soft/type=plummer",
               "nbody/particle2/soft/radius=0.03", "nbody/particle2/initialize/x=1.0", "nbody/particle2/initialize/vy=1.0",
               "parthenon/time/nlim=-1"]
-        make_sim = lambda: Simulation(deck, ov)
+        make_sim = lambda: Simulation(deck, ov, comm=comm)
         sim = make_sim()
     else:
         deck = os.path.join(ROOT, "inputs", "blast", "blast.in")
@@ -470,7 +467,8 @@ def main():
     if args.path == "unfused":
         sim.set_path("unfused")
     force_overlap = L.artemis_hip_get_option(b"force_overlap") > 0  # (ARTEMIS_FORCE_OVERLAP in the environment)
-    want_overlap = (world > 1 or args.loopback or force_overlap) and not args.no_overlap
+    # (shell-first overlap is the uniform-mesh stage's; on refined meshes the exchange is ordered behind the stage kernels)
+    want_overlap = (world > 1 or args.loopback or force_overlap) and not args.no_overlap and args.workload == "sedov3d"
     sim.set_overlap(args.overlap_mode if want_overlap else 0)
 
     def barrier():
@@ -536,7 +534,7 @@ def main():
         elapsed = elapsed_max = float(t.item())
         elapsed_min = float(tmin.item())
     remesh_leg = None
-    if args.workload == "disk_amr" and not args.no_remesh_leg:
+    if args.workload == "disk_amr" and not args.no_remesh_leg and world == 1 and not args.loopback:  # (the legs pick leaves by local index: one rank)
         # The remesh machinery on THIS mesh, outside the timed region: five leaves below the finest level, spread over
         # the Z-ordered list, are split one after the other as if the criterion had tagged them (2:1 balance, new
         # state, hand-over, tables), one cycle in between.  The disk is in equilibrium, so the deck's own criterion
@@ -662,6 +660,14 @@ def main():
                           "Parthenon task (CalculateFluxes, epilogue = ApplyUpdate..ConsToPrim, BCs, PrimToCons). "
                           "Fractions use the same 480 B per zone-cycle."}
     rccl_ranks = comm.count if comm is not None else 0
+    nblocks_global = sim.nblocks_global
+    load_balance = sim.load_balance
+    rank_zones = [sim.local_zones]
+    if world > 1:
+        rz = torch.zeros(world, dtype=torch.int64)
+        rz[rank] = sim.local_zones
+        dist.all_reduce(rz)
+        rank_zones = [int(v) for v in rz.tolist()]
     total_zones = sim.total_zones
     local_zones = sim.local_zones
     fused = sim.uses_fused_path
@@ -732,14 +738,25 @@ def main():
             out["metric"] = ("cell-updates/sec (zone-cycles/s), spherical-polar alpha disk with static refinement" if smr else
                              "cell-updates/sec (zone-cycles/s), cylindrical disk + planet + dust, 4-level adaptive refinement")
             out["config"]["workload"] = (
-                ("BASELINE configs[3]'s combination on one GPU: inputs/disk/disk_sph.in x 2 (256 x 128 x 128 root, 32^3 blocks) + a "
+                ("BASELINE configs[3]'s combination on %d GPU(s): inputs/disk/disk_sph.in x 2 (256 x 128 x %d root, 32^3 blocks) + a "
                  "level-1 static region around the midplane, gas, point-mass gravity, alpha viscosity, rotating frame, ic "
-                 "conditions, HLLE + PLM_G, rk2; %d blocks, %d zones" % (sim.nblocks, total_zones)) if smr else
-                ("BASELINE configs[4]'s combination on one GPU, 3-D: inputs/disk/disk_nbody_cyl.in (128 x 128 x 16 root over |z| < 0.2, "
-                 "16^3 blocks) + planet (N-body gravity, integrator none) + one dust species with simple_dust drag + rotating "
-                 "frame + alpha viscosity + adaptive refinement on the pressure gradient, numlevel 4; %d blocks on levels %s, "
-                 "%d zones at the end, %d remeshes in the timed region" % (sim.nblocks, levels, total_zones, int(sim_remeshes_timed))))
-            out["config"]["decomposition"] = "1 rank, %d mesh blocks (Z-ordered leaves)" % sim.nblocks
+                 "conditions, HLLE + PLM_G, rk2; %d blocks, %d zones" % (args.gpus, 128 * args.gpus, nblocks_global, total_zones)) if smr else
+                ("BASELINE configs[4]'s combination on %d GPU(s), 3-D: inputs/disk/disk_nbody_cyl.in (128 x %d x %d root over |z| < 0.2, "
+                 "%d^3 blocks) + planet (N-body gravity, integrator none) + one dust species with simple_dust drag + rotating "
+                 "frame + alpha viscosity + adaptive refinement on the pressure gradient, numlevel 4; %d blocks on levels (rank 0) %s, "
+                 "%d zones at the end, %d remeshes in the timed region" % (args.gpus, 128 * args.gpus, max(16, args.amr_block), args.amr_block, nblocks_global, levels, total_zones, int(sim_remeshes_timed))))
+            out["config"]["decomposition"] = (
+                "%d rank(s): the Z-ordered leaf list (%d blocks) cut into consecutive runs of equal cost, one per rank; the root mesh "
+                "grows with the rank count along the azimuth (%s) so that zones per GPU stay fixed; ghost zones, coarse-buffer "
+                "fills and flux corrections between runs go through %s, one message per peer and phase; remeshes migrate whole "
+                "blocks" % (args.gpus, nblocks_global, "x3" if smr else "x2",
+                            "the native C++ RCCL transport" if comm is not None else "device copies (one rank)"))
+            out["config"]["blocks_global"] = nblocks_global
+            out["config"]["blocks_rank0"] = sim.nblocks
+            out["config"]["zones_per_rank"] = rank_zones
+            out["config"]["load_balance_max_over_mean"] = load_balance
+            out["config"]["loopback"] = bool(args.loopback)
+            out["config"]["rank_grid"] = None  # (Z-order runs, not a brick grid)
             out["config"]["stage_path"] = sim.stage_kernel
             bps = ALG_BYTES_PER_CELL_STAGE if smr else 8.0 * 5.0 * (6 + 4)  # 8 B * 5 * (6 ns_gas + 4 ns_dust)
             stage_ms = 1.0e3 * elapsed / args.steps / 2.0

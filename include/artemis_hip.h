@@ -40,7 +40,8 @@
  *  changed at run time only through artemis_hip_set_option("<name>", value) below (names case-insensitive, with or
  *  without the ARTEMIS_ prefix).  No launch path calls getenv.
  *  path selection (every path gives the same bits; tests use these to compare them)
- *    NO_TUNED, TUNED_2D, NO_STAGE2D, NO_FUSED_CURV, NO_CURV_MARCH, NO_CURV_DUST, NO_CURV_DUST_MARCH, NO_ML_FUSED,
+ *    NO_TUNED, TUNED_2D, NO_STAGE2D, NO_FUSED_CURV, NO_CURV_MARCH, NO_CURV_DUST, NO_CURV_DUST_MARCH, NO_DRAG_IN_MARCH
+ *    (the drag finish as its own launch instead of inside the dust march), NO_ML_FUSED,
  *    NO_EPILOGUE, NO_TILED_FLUX, NO_VISC_SOURCE (the diffusion-flux tasks instead of artemis_hip_viscous_source),
  *    NBODY_TASK (N-body gravity as its own task with the host-side reduction), NBODY_GENERAL, NO_PLM_TABLE,
  *    NO_DISTANCE_TABLE, NO_FLAT_RANGES, FULL_REMESH (a remesh rebuilds the whole state next to the old one instead of
@@ -589,7 +590,13 @@ typedef struct artemis_stage_general_args {
   /* 1 = stop after the sources with the conserved state of the active zones in p->{gas,dust}.cons0 (no DragSource,
    * SetAuxillaryFields, ConsToPrim or dt): a refined mesh with drag redoes its listed coarse zones the same way
    * (artemis_hip_ml_stage_fixup with the same flag) and then runs artemis_hip_stage_finish on a pack whose prim tables
-   * are the *_out tables. */
+   * are the *_out tables.
+   * 2 = the stage finishes EVERY zone itself, as with 0 (where one dust species is coupled by simple_dust drag the dust
+   * march does it on its registers: no conserved round trip, no finish launch), and the caller -- whose
+   * artemis_hip_ml_stage_fixup, given the same flag, leaves the conserved state of its LISTED zones in cons0 -- finishes
+   * those zones again with artemis_hip_stage_finish_cells.  Same bits as 1: DragSource, SetAuxillaryFields and
+   * ConsToPrim are pointwise (drag.hpp:296-482, fill_derived.cpp:58-164).  p->{gas,dust}.cons0 are required;
+   * what they hold for zones outside the list afterwards is unspecified. */
   int defer_finish;
 } artemis_stage_general_args_t;
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
@@ -730,8 +737,8 @@ int artemis_hip_ml_prolongate(const artemis_pack_t *p, const artemis_ml_pack_t *
  *      ApplyUpdate after SetFluxCorrections; results overwrite prim_out at those zones.
  * Diffusion fluxes: the caller computed them for the whole pack before step 1 (artemis_hip_zero_viscous_flux);
  * step 3 corrects them in place and step 4 reads them like the stage kernels do.  args: the arguments of step 1
- * (dt_dev is ignored: estimate the timestep after the fix-up).  Drag is not supported here (it couples the
- * fluids after the update; such decks keep the per-task chain on refined meshes). */
+ * (dt_dev is ignored: estimate the timestep after the fix-up).  Drag couples the fluids after the update: see
+ * artemis_hip_stage_finish_cells below. */
 typedef struct artemis_ml_face_box { /* faces of direction dir stored at the zones of a box of one block */
   int block, dir, lo[3], n[3];
 } artemis_ml_face_box_t;
@@ -752,6 +759,14 @@ int artemis_hip_ml_viscous_faces(const artemis_pack_t *p, const artemis_diffusio
                                  int nboxes, const artemis_ml_fix_cell_t *cells_dev, int ncells, void *stream);
 int artemis_hip_ml_stage_fixup(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
                                const artemis_ml_fix_cell_t *cells_dev, int ncells, void *stream);
+/* Drag on a refined mesh (DragSource follows the flux correction in the task list, artemis_driver.cpp:196-255): run steps
+ * 1 and 4 with args.defer_finish = 2 -- step 1 then finishes every zone itself, step 4 leaves the conserved state of the
+ * listed zones in p->{gas,dust}.cons0 -- and finish the listed zones with
+ *   artemis_hip_stage_finish_cells: DragSource (drag != NULL), SetAuxillaryFields and ConsToPrim of cons0 into the
+ *     primitives of p (point its prim tables at the *_out tables), for the listed zones only; `faces` is ignored.
+ * (defer_finish = 1 is the older form: steps 1 and 4 stop at cons0 and artemis_hip_stage_finish runs over every zone.) */
+int artemis_hip_stage_finish_cells(const artemis_pack_t *p, const artemis_drag_t *drag, double time, double dt,
+                                   const artemis_ml_fix_cell_t *cells_dev, int ncells, void *stream);
 
 /* ---- refinement criteria (utils/refinement/amr_criteria.hpp) ------------------------------------
  * ArtemisUtils::ScalarFirstDerivative<FIELD, GEOM> (:28-132) and ScalarMagnitude<FIELD> (:137-168): the
@@ -833,6 +848,13 @@ long artemis_hip_get_option(const char *name);
  * ARTEMIS_HIP_EDEVICE -- there is no CPU fallback in this library). */
 int artemis_hip_device_count(void);
 const char *artemis_hip_version(void);
+/* Identity of the sources this library was built from (artemis_amd/build.py generates the table at build time):
+ * artemis_hip_source_sha() = sha1 over every file of csrc/ and include/ plus the compiler flags;
+ * artemis_hip_object_sha("kernels_fused") = sha256 over that translation unit, the headers it reaches, its command line
+ * and the compiler version (NULL: no such unit).  A measurement record (profiles/) names the identity it was taken on
+ * and is quoted only by a library that reports the same one. */
+const char *artemis_hip_source_sha(void);
+const char *artemis_hip_object_sha(const char *unit);
 
 #ifdef __cplusplus
 }

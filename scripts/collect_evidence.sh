@@ -16,8 +16,8 @@ for f in bench bench_default cfg3 cfg3_1024 disk_sph smr_cart smr_sph amr; do cp
 } > profiles/${ROUND}_final_suite_smoke_timings.txt
 python - <<PY
 import json
-from bench import kernel_source_sha1
+from bench import library_identity
 for f, scope in (("pmc_traffic", "fused"), ("disk_sph_pmc_traffic", "all"), ("cfg3_pmc_traffic", "all"), ("cfg3_1024_pmc_traffic", "all"), ("disk_sph_smr_pmc_traffic", "all"), ("disk_amr_pmc_traffic", "all")):
     rec = json.load(open("profiles/${ROUND}_%s.json" % f))
-    print(f, "sha matches working tree:", rec["kernel_source_sha1"] == kernel_source_sha1(scope), round(rec["hbm_bytes_per_launch"] / 1e9, 3), "GB")
+    print(f, "record identity == loaded library:", rec["library_identity"] == library_identity(scope), round(rec["hbm_bytes_per_launch"] / 1e9, 3), "GB")
 PY

@@ -10,6 +10,9 @@ ROUND=${ROUND:-r05}
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+# the binary is the tree: rebuild whatever differs from the sources that travelled (a no-op when nothing does), verify
+# the identities compiled into the library, and put them into the evidence
+python3 -c "from artemis_amd import build as b; b.build_hip(force=bool(int('${FORCE_BUILD:-0}'))); print('library source sha', b.verify())" | tee gpurun_out/${tag}_identity.txt || exit 1
 if has suite; then
 timeout 3000 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|FAILED" | tail -5 > gpurun_out/${tag}_tests.txt; cat gpurun_out/${tag}_tests.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/${tag}_smoke.txt

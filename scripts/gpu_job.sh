@@ -1,0 +1,32 @@
+# One gpurun call of round 6's development loop: identity check, then whatever PARTS names.
+#   PARTS="suite loopback lines" scripts/gpu_job.sh <tag>
+PARTS=${PARTS:-"suite loopback lines"}
+has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
+tag=${1:-j}
+cd /root/repo
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+python3 -c "from artemis_amd import build as b; b.build_hip(); print('library source sha', b.verify())" 2>&1 | tail -1 | tee gpurun_out/${tag}_identity.txt || exit 1
+if has suite; then
+timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > gpurun_out/${tag}_tests.txt; tail -3 gpurun_out/${tag}_tests.txt
+fi
+if has refined; then
+timeout 1800 python -m pytest tests/test_multilevel.py tests/test_adaptive.py tests/test_parity_refine.py -m gpu -q -x 2>&1 | tail -15 > gpurun_out/${tag}_tests_refined.txt; tail -3 gpurun_out/${tag}_tests_refined.txt
+fi
+if has loopback; then
+timeout 600 python bench.py --workload disk_sph_smr --loopback --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_smr_loopback_line.json 2> gpurun_out/${tag}_smr_loopback.err; tail -3 gpurun_out/${tag}_smr_loopback.err; cut -c1-300 gpurun_out/${tag}_smr_loopback_line.json
+timeout 900 python bench.py --workload disk_amr --loopback --steps 6 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_amr_loopback_line.json 2> gpurun_out/${tag}_amr_loopback.err; tail -3 gpurun_out/${tag}_amr_loopback.err; cut -c1-300 gpurun_out/${tag}_amr_loopback_line.json
+fi
+if has lines; then
+timeout 600 python bench.py --no-cpu-baseline --steps 100 2>/dev/null > gpurun_out/${tag}_bench_line.json; cut -c1-200 gpurun_out/${tag}_bench_line.json
+timeout 300 python bench.py --workload ssheet_dust --n 1024 --no-cpu-baseline --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_line.json; cut -c1-200 gpurun_out/${tag}_cfg3_1024_line.json
+timeout 300 python bench.py --workload disk_sph --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_disk_sph_line.json; cut -c1-200 gpurun_out/${tag}_disk_sph_line.json
+timeout 600 python bench.py --workload disk_sph_smr --no-cpu-baseline --steps 40 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_sph_smr_line.json; cut -c1-200 gpurun_out/${tag}_disk_sph_smr_line.json
+timeout 900 python bench.py --workload disk_amr --no-cpu-baseline --no-remesh-leg --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json; cut -c1-200 gpurun_out/${tag}_disk_amr_line.json
+fi
+if has amrprof; then
+timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_amr_prof -o p --output-format csv -- python3 scripts/amr_timing.py 5 128 128 16 16 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2 > gpurun_out/${tag}_amr_prof.log 2>&1
+find gpurun_out/${tag}_amr_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_amr_kernel_stats.csv
+rm -rf gpurun_out/${tag}_amr_prof
+tail -2 gpurun_out/${tag}_amr_prof.log
+fi

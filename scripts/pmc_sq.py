@@ -42,10 +42,10 @@ if os.environ.get("PMC_SQ_RECORD"):
     # the record bench.py quotes as roofline.fp64_issue (only while the kernel sources are unchanged): mean VALU
     # wave-instructions per launch over the headline stage kernels (non-curvilinear, non-flux instantiations)
     sys.path.insert(0, ROOT)
-    from bench import kernel_source_sha1
+    from bench import library_identity
     ks = {k: v for k, v in res.items() if "stage_fused_kernel" in k and "SQ_INSTS_VALU" in v}
     if ks:
-        rec = {"kernel_source_sha1": kernel_source_sha1("fused"), "command": " ".join(prog), "env": {},
+        rec = {"library_identity": library_identity("fused"), "command": " ".join(prog), "env": {},
                "valu_wave_instructions_per_launch": sum(v["SQ_INSTS_VALU"] for v in ks.values()) / len(ks),
                "valu_active_cycles": sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in ks.values()) / len(ks),
                "wave_cycles": sum(v.get("SQ_WAVE_CYCLES", 0.0) for v in ks.values()) / len(ks),

@@ -13,7 +13,8 @@ the kernel-timing leg's cycles)) and the record is refused by bench.py if the pr
 for 16-byte lanes per the guide; this code base loads 8 bytes per lane), so the read correction is
 measured in the same profile on kernels whose byte count is known exactly (cons_to_prim: 5 arrays in,
 5 out over the interior; prim_to_cons: 5 in, 9 out over the whole block) and applied to the stage kernel.
-The record carries the sha1 of the kernel sources: bench.py reports it only while they are unchanged.
+The record carries the identity the loaded library reports for its own code (artemis_hip_object_sha / artemis_hip_source_sha):
+bench.py quotes it only from a library that reports the same one.
 This script never touches the GPU itself; the profiled program is started by rocprofv3.
 """
 import argparse
@@ -59,7 +60,7 @@ def whole_stage(args, extra):
     kernel of the timed run.  FETCH_SIZE is corrected with the ratio calibrated on the Sedov run's known streams
     (profiles/r*_pmc_traffic.json: 0.620 in every run so far; these workloads launch no kernel with an exactly
     known byte count)."""
-    from bench import kernel_source_sha1
+    from bench import library_identity
     n = {"disk_sph": 256, "ssheet_dust": args.n if args.n in (1024, 4096) else 4096}.get(args.workload)
     refined = args.workload in ("disk_amr", "disk_sph_smr")
 
@@ -126,7 +127,7 @@ def whole_stage(args, extra):
     rec = {
         "source": "scripts/pmc_traffic.py --workload %s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, "
                   "--kernel-trace only) of `python3 bench.py %s`, MI355X; %s" % (args.workload, " ".join(bench_args), method),
-        "workload": args.workload, "sha_scope": "all", "kernel_source_sha1": kernel_source_sha1("all"),
+        "workload": args.workload, "sha_scope": "all", "library_identity": library_identity("all"),
         "env": {k: v for k, v in os.environ.items() if k.startswith("ARTEMIS_")},
         "fetch_correction": "true_read = FETCH_SIZE / %.4f (calibration of %s)" % (ratio, src),
         "stages": nstage, "kernels": kernels, "hbm_bytes_per_launch": per_stage,
@@ -144,7 +145,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "disk_sph", "ssheet_dust", "disk_sph_smr", "disk_amr"])
     args, extra = ap.parse_known_args()
-    from bench import ALG_BYTES_PER_CELL_STAGE, kernel_source_sha1
+    from bench import ALG_BYTES_PER_CELL_STAGE, library_identity
     if args.workload != "sedov3d":
         return whole_stage(args, extra)
     steps, warmup = 6, 2
@@ -193,7 +194,7 @@ def main():
         "source": "scripts/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) "
                   "of `python3 bench.py %s`, MI355X" % " ".join(bench_args),
         "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch",
-        "workload": "sedov3d", "sha_scope": "fused", "kernel_source_sha1": kernel_source_sha1(),
+        "workload": "sedov3d", "sha_scope": "fused", "library_identity": library_identity("fused"),
         "env": {k: v for k, v in os.environ.items() if k.startswith("ARTEMIS_")},
         "calibration": dict(calib, fetch_correction="true_read = FETCH_SIZE / %.4f (mean of the calibration kernels); "
                                                     "WRITE_SIZE as reported (calibrates at %.3f)" % (ratio, wratio)),

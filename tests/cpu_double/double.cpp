@@ -563,6 +563,55 @@ int artemis_hip_stage_finish(const artemis_pack_t *p, const artemis_drag_t *drag
     if (int rc = artemis_hip_set_aux(p, st)) return rc;
   return artemis_hip_cons_to_prim(p, st);
 }
+// ... of the listed zones only (defer_finish = 2: the stage has finished every zone, the fix-up has rewritten the
+// conserved state of its listed zones): the block's cons0 through the same three tasks, the listed zones' primitives out
+int artemis_hip_stage_finish_cells(const artemis_pack_t *p, const artemis_drag_t *d, double, double dt, const artemis_ml_fix_cell_t *cells,
+                                   int ncells, void *) {
+  if (!d) return bad("stage finish of listed zones: drag is required");
+  std::map<int, std::vector<const artemis_ml_fix_cell_t *>> per_block;
+  for (int q = 0; q < ncells; ++q) per_block[cells[q].block].push_back(&cells[q]);
+  for (auto &kv : per_block) {
+    const int b = kv.first;
+    Bound B(p, b);
+    Sim &s = *B.s;
+    B.in(s.gu0, p->gas.cons0, s.nvg), B.in(s.du0, p->dust.cons0, s.nvd);
+    // (zones outside the list hold whatever the tables held: the tasks are pointwise and only listed zones are copied out;
+    //  give them a valid state so that nothing traps on the way)
+    {
+      std::vector<char> listed(s.N, 0);
+      for (const artemis_ml_fix_cell_t *fc : kv.second) listed[IDX(s, fc->k, fc->j, fc->i)] = 1;
+      for (long c = 0; c < static_cast<long>(s.N); ++c) {
+        if (listed[c]) continue;
+        for (int v = 0; v < s.nvg; ++v) s.gu0[v * s.N + c] = (v < s.c.ns_gas || v >= 4 * s.c.ns_gas) ? 1.0 : 0.0;
+        for (int v = 0; v < s.nvd; ++v) s.du0[v * s.N + c] = (v < s.c.ns_dust) ? 1.0 : 0.0;
+      }
+    }
+    s.drag.type = d->type, s.drag.model = d->model, s.drag.scale = d->scale;
+    s.drag.grain_density = d->grain_density;
+    s.drag.tau.assign(d->tau, d->tau + s.c.ns_dust), s.drag.sizes.assign(d->sizes, d->sizes + s.c.ns_dust);
+    for (int i = 0; i < 3; ++i) {
+      s.drag.gas.ix[i] = d->gas.ix[i], s.drag.gas.ox[i] = d->gas.ox[i];
+      s.drag.gas.irate[i] = d->gas.irate[i], s.drag.gas.orate[i] = d->gas.orate[i];
+      s.drag.dust.ix[i] = d->dust.ix[i], s.drag.dust.ox[i] = d->dust.ox[i];
+      s.drag.dust.irate[i] = d->dust.irate[i], s.drag.dust.orate[i] = d->dust.orate[i];
+    }
+    s.gx1min = d->xmin[0], s.gx2min = d->xmin[1], s.gx3min = d->xmin[2];
+    s.gx1max = d->xmax[0], s.gx2max = d->xmax[1], s.gx3max = d->xmax[2];
+    set_damp_visc(s, d);
+    drag_source(s, dt);
+    set_aux(s);
+    cons_to_prim(s);
+    for (const artemis_ml_fix_cell_t *fc : kv.second) {
+      const long c = IDX(s, fc->k, fc->j, fc->i);
+      for (int v = 0; v < s.nvg; ++v) {
+        if (v >= 4 * s.c.ns_gas && v < 5 * s.c.ns_gas) continue; // P is not an output
+        p->gas.prim[b * s.nvg + v][c] = s.gprim[v * s.N + c];
+      }
+      for (int v = 0; v < s.nvd; ++v) p->dust.prim[b * s.nvd + v][c] = s.dprim[v * s.N + c];
+    }
+  }
+  return 0;
+}
 int artemis_hip_stage_general_variant(const artemis_pack_t *, const artemis_stage_general_args_t *) { return 0; }
 // One block through the stage (shared by artemis_hip_stage_general and the refined-mesh fix-up, which redoes the
 // listed zones of the block with the corrected fluxes of their flagged faces)
@@ -613,7 +662,7 @@ static void stage_block(const artemis_pack_t *p, const artemis_stage_general_arg
       s.rframe.on = true, s.rframe.omega = a->rf_omega, s.rframe.qshear = a->rf_qshear;
       rotating_frame_force(s, a->bdt);
     }
-    if (a->defer_finish) { // the conserved state of the zones, for artemis_hip_stage_finish
+    if (a->defer_finish == 1 || (a->defer_finish && fix)) { // the conserved state of the zones, for artemis_hip_stage_finish (_cells)
       auto putc = [&](const RVec &src, double *const *tab, int nvar) {
         for (int v = 0; v < nvar; ++v) {
           if (fix) {

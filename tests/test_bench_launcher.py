@@ -66,6 +66,20 @@ def test_bench_launcher_fails_when_a_rank_fails(tmp_path):
     assert "rank(s) failed" in r.stderr
 
 
+def test_the_refined_workloads_accept_n_ranks(tmp_path):
+    """BASELINE configs[3] / [4] are 8-GPU configurations: `--workload disk_sph_smr|disk_amr --gpus N` reaches the ranks
+    (missing 1); the one-block workloads refuse N > 1 before anything is started."""
+    for w in ("disk_sph_smr", "disk_amr"):
+        r = launch(tmp_path, 2, extra=["--workload", w])
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert json.loads(r.stdout)["argv"] == ["--gpus", "2", "--steps", "3", "--workload", w]
+    for w in ("ssheet_dust", "disk_sph"):
+        r = launch(tmp_path, 2, extra=["--workload", w])
+        assert r.returncode != 0 and "single-GPU measurement" in r.stderr and r.stdout.strip() == ""
+    r = launch(tmp_path, 2, extra=["--workload", "disk_amr", "--remesh-in-timed-region"])
+    assert r.returncode != 0 and "single-GPU measurement" in r.stderr
+
+
 def test_bench_rejects_unsupported_rank_counts(tmp_path):
     r = launch(tmp_path, 3)
     assert r.returncode != 0 and "1, 2, 4 or 8" in r.stderr

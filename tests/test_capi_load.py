@@ -30,6 +30,52 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/artemis_driver.h but not exported"
 
 
+def test_the_binary_is_the_working_tree():
+    """Every object of lib/ carries the content hash (source + the headers it reaches + command line + compiler) of the
+    working tree, and the identities compiled into libartemis_hip.so equal them: what is loaded, tested and profiled can
+    be rebuilt from this checkout (round 5 shipped one object of an uncommitted experiment; mtimes could not see it)."""
+    from artemis_amd import build, capi
+    L = capi.load()
+    assert build.stale_objects() == []
+    assert capi.source_sha() == build.tree_sha()
+    want = build.object_hashes()
+    assert set(want) >= {"abi", "kernels_fused", "kernels_amr", "kernels_curv", "driver_driver", "driver_comm_rccl"}
+    for unit, sha in want.items():
+        assert capi.object_sha(unit) == sha, unit
+    assert capi.object_sha("no_such_unit") is None
+    assert build.verify(L) == build.tree_sha()
+
+
+def test_a_touched_header_makes_exactly_its_users_stale(tmp_path, monkeypatch):
+    """The hash follows the include graph: a change in kernels_amr.hip concerns that unit alone, one in
+    device_math.hpp every kernel file that reaches it and not the host driver; a reverted edit leaves nothing stale."""
+    from artemis_amd import build
+    base = build.object_hashes()
+    real_closure = build._closure
+
+    def edited(which):
+        def closure(path, seen=None):
+            out = real_closure(path, seen)
+            for p in list(out):
+                if os.path.basename(p) == which:
+                    out[p] = out[p] + b"// edit\n"
+            return out
+        return closure
+    monkeypatch.setattr(build, "_closure", edited("kernels_amr.hip"))
+    now = build.object_hashes()
+    assert [u for u in base if base[u] != now[u]] == ["kernels_amr"]
+    monkeypatch.setattr(build, "_closure", edited("device_math.hpp"))
+    now = build.object_hashes()
+    changed = {u for u in base if base[u] != now[u]}
+    assert {"kernels_fused", "kernels_curv", "kernels_unfused"} <= changed and not any(u.startswith("driver_") for u in changed)
+    monkeypatch.setattr(build, "_closure", real_closure)
+    assert build.object_hashes() == base
+    # only= refuses to link when something outside the list is stale
+    monkeypatch.setattr(build, "_closure", edited("device_math.hpp"))
+    with pytest.raises(RuntimeError, match="stale too"):
+        build.build_hip(only=["kernels_amr.hip"])
+
+
 def test_no_gpu_fails_loudly_and_validation():
     import torch
     from artemis_amd import capi
