@@ -30,3 +30,9 @@ find gpurun_out/${tag}_amr_prof -name "*kernel_stats.csv" | head -1 | xargs -I{}
 rm -rf gpurun_out/${tag}_amr_prof
 tail -2 gpurun_out/${tag}_amr_prof.log
 fi
+if has drag; then
+timeout 1800 python -m pytest tests -m gpu -q -x -k "drag or dust or disk or nbody or config4 or cfg4" 2>&1 | tail -15 > gpurun_out/${tag}_tests_drag.txt; tail -3 gpurun_out/${tag}_tests_drag.txt
+fi
+if has amrline; then
+timeout 900 python bench.py --workload disk_amr --no-cpu-baseline --no-remesh-leg --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json; cut -c1-200 gpurun_out/${tag}_disk_amr_line.json
+fi
