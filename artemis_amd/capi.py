@@ -169,6 +169,7 @@ class StageGeneralArgs(C.Structure):
         ("diffusion_sums", PP),
         ("nbody_dev", C.c_void_p), ("nbody_n", C.c_int), ("nbody_omf", C.c_double),
         ("defer_finish", C.c_int),
+        ("strat_faces", C.c_int), ("strat_qshear", C.c_double), ("strat_omega", C.c_double),
     ]
 
 

@@ -933,6 +933,10 @@ int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_gener
     return fail(ARTEMIS_HIP_EINVAL, "general stage, defer_finish: cons0 tables are required");
   if (a->defer_finish && a->cooling)
     return fail(ARTEMIS_HIP_EUNSUPPORTED, "general stage: defer_finish with cooling (it follows drag in the task list)");
+  if (a->strat_faces && artemis::stage_general_variant(artemis::make_pack_view(*p), *a, p->gas.recon, p->gas.riemann, p->dust.recon,
+                                                       p->dust.riemann) != 1)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "general stage: strat_faces (conditions inside the kernel) is served by the 2-D row "
+                                          "march only, for all four faces of one block (strat_faces = 15)");
   artemis::launch_stage_cell(artemis::make_pack_view(*p), *a, p->gas.recon, p->gas.riemann,
                              p->dust.recon, p->dust.riemann, S(stream));
   return after_launch("stage_general");

@@ -2753,6 +2753,17 @@ void artemis_sim_impl::step_general(bool want_dt, bool device_dt) {
       CK(artemis_rt_event_record(e0, stream), "event");
     }
     general_variant = artemis_hip_stage_general_variant(&p, &a);
+    // One block whose four faces carry the `strat` problem's conditions (inputs/ssheet: x1 extrap, x2 inflow) on the 2-D
+    // row march: the kernel forms the conditions' values on the rows it loads and reads no ghost zone -- the two boundary
+    // launches per stage (7 % of a 1024^2 stage) are gone; evolve() completes the ghost zones before it returns.
+    bool strat_in_kernel = false;
+    if (general_variant == 1 && nb == 1 && links.empty() && ndim == 2 && !artemis::opt(artemis::OPT_NO_STRAT_IN_KERNEL) &&
+        bc_flat[0] == ARTEMIS_BC_STRAT_EXTRAP && bc_flat[1] == ARTEMIS_BC_STRAT_EXTRAP && bc_flat[2] == ARTEMIS_BC_STRAT_INFLOW &&
+        bc_flat[3] == ARTEMIS_BC_STRAT_INFLOW) {
+      a.strat_faces = 15, a.strat_qshear = bcpar.qshear, a.strat_omega = bcpar.omega;
+      strat_in_kernel = artemis_hip_stage_general_variant(&p, &a) == 1;
+      if (!strat_in_kernel) a.strat_faces = 0;
+    }
     CK(artemis_hip_stage_general(&p, &a, stream), "stage_general");
     if (e0) {
       CK(artemis_rt_event_record(e1, stream), "event");
@@ -2762,7 +2773,8 @@ void artemis_sim_impl::step_general(bool want_dt, bool device_dt) {
       const artemis_pack_t pn = make_pack(out);
       CK(artemis_hip_diffusion_dt(&pn, &diff, cfl_gas, a.dt_dev, stream), "dt diffusion");
     }
-    fill_ghosts(out);
+    if (strat_in_kernel) ghosts_stale = true; // (no neighbour, no other condition: nothing else to fill)
+    else fill_ghosts(out);
     cur = out;
   }
   base = cur;

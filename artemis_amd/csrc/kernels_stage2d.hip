@@ -57,6 +57,10 @@ struct S2Args {
   unsigned *redo_cnt, *redo_done;
   unsigned long long *redo_list;
   unsigned redo_cap;
+  // the `strat` problem's user conditions applied to the rows as they are loaded (artemis_stage_general_args_t.strat_faces):
+  // the kernel then reads no ghost zone of the block
+  int bc_strat;
+  double bc_q, bc_om0;
 };
 
 struct Dust4 {
@@ -167,6 +171,35 @@ ADEV void damping_ramps2(const artemis_damping_t &p, const artemis_drag_t &D, in
           p.orate[2] * ((xv[2] > p.ox[2]) * sqr((xv[2] - p.ox[2]) / (p.ox[2] - D.xmax[2]))));
 }
 
+// ---- the `strat` problem's conditions on a row in registers (pgen/strat.hpp:158-466, as kernels_unfused.hip's
+// strat_bc_kernel fills them into the ghost zones) ------------------------------------------------------------------------
+// x1 `extrap` (:188-226, :262-299): density, sie and v3 of the first active zone, v1 copied unless it points into the
+// domain, v2 continued linearly in x1v through the first two active zones.  la / lb: the lanes that hold those two zones
+// (wave-uniform); `mine`: this lane is a ghost column of that side; x, x0, x1: the zone centres.
+ADEV double rd_lane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <class Q>
+ADEV void strat_x1(Q &q, bool with_e, double &e_slot, const bool mine, const int upper, const int la, const int lb, const double x,
+                   const double x0, const double x1) {
+  const double d = rd_lane(q.d, la), v1 = rd_lane(q.v1, la), v2 = rd_lane(q.v2, la), v3 = rd_lane(q.v3, la);
+  const double v2n = rd_lane(q.v2, lb);
+  const double dx = upper ? (x0 - x1) : (x1 - x0);
+  const double vx1 = upper ? ((v1 < 0.0) ? 0.0 : v1) : ((v1 > 0.0) ? 0.0 : v1);
+  const double vx2 = upper ? (v2 + (v2 - v2n) * (x - x0) / dx) : (v2 + (v2n - v2) * (x - x0) / dx);
+  double es = 0.0;
+  if (with_e) es = rd_lane(e_slot, la);
+  if (mine) {
+    q.d = d, q.v1 = vx1, q.v2 = vx2, q.v3 = v3;
+    if (with_e) e_slot = es;
+  }
+}
+// x2 `inflow` (:352-392, :437-466): a copy of the first active row with v2 = -q Om0 x1v where the shear carries material
+// into the box (lower face: x1f >= 0, upper face: x1f < 0) and one-way outflow elsewhere
+ADEV double strat_x2_v2(const double v2, const int upper, const double xf, const double vy0) {
+  return upper ? ((xf < 0) ? ((v2 < 0.0) ? 0.0 : v2) : vy0) : ((xf >= 0) ? ((v2 > 0.) ? 0.0 : v2) : vy0);
+}
+
 // One wave per SIMD (launch bound 1): the march keeps ~360 registers live (three rows of both fluids, the carried
 // face states and fluxes, one HLLC problem in flight); at two waves per SIMD the same code spills 200-400 bytes per
 // lane to scratch and measures 23 % slower (3.07 vs 3.98e9 zone-cycles/s on config 3 at 4096^2).  A single wave
@@ -220,10 +253,62 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
     // refuses blocks of 2^29 zones or more
     const unsigned sj = static_cast<unsigned>(P.sj);
     const unsigned col = static_cast<unsigned>(il); // k = 0 in a 2-D block
+    // the block's edge table, read ONCE: inside the march (stores in flight) a read of it would be a vector load of a
+    // uniform address with a vmcnt(0) wait behind it, i.e. a wait for the row prefetch that was just issued
+    const double *geo = P.geom + 6 * b;
+    const double gl[6] = {geo[0], geo[1], geo[2], geo[3], geo[4], geo[5]};
+    // ---- the user conditions of the block's faces, in registers (a.bc_strat): row r of the march is read from the
+    // nearest ACTIVE row; ghost columns take the x1 condition of that row's first two active zones (which sit in lanes of
+    // this wave), then a ghost row takes the x2 condition -- parthenon's order (x1 over the entire x2 extent, then x2 over
+    // the entire x1 extent).  Wave-uniform branches; waves away from the block's edges skip all of it.
+    const bool bcs = a.bc_strat != 0;
+    // (the strip and the row are wave-uniform: said so explicitly, the tests below are then scalar compares and branches
+    //  and nothing of the conditions' arithmetic is alive outside the rare waves / rows that need it)
+    const int strip_u = __builtin_amdgcn_readfirstlane(strip);
+    const bool edge_x = bcs && (strip_u == 0 || (P.ie - P.is - strip_u * OWN + HALO) < 63);
+    auto row_of = [&](int r) { return bcs ? min(max(r, P.js), P.je) : r; };
+    auto bc_row = [&](Raw5 &g, Dust4 *dq, int r) {
+      const int ru = __builtin_amdgcn_readfirstlane(r);
+      const bool ghost_row = ru < P.js || ru > P.je;
+      if (!(edge_x || ghost_row)) return;
+      auto x1v = [&](int ii) { return 0.5 * ((gl[0] + ii * gl[1]) + (gl[0] + (ii + 1) * gl[1])); };
+      const double bx = x1v(i);
+      const int lane_is = HALO - strip_u * OWN;               // the lane that holds column is (strip 0: lane 2)
+      const int lane_ie = P.ie - P.is - strip_u * OWN + HALO; // ... column ie
+      double none = 0.0;
+      if (strip_u == 0) {
+        const double x0 = x1v(P.is), x1 = x1v(P.is + 1);
+        strat_x1(g, true, g.e, i < P.is, 0, lane_is, lane_is + 1, bx, x0, x1);
+#pragma unroll
+        for (int n = 0; n < ND; ++n) strat_x1(dq[n], false, none, i < P.is, 0, lane_is, lane_is + 1, bx, x0, x1);
+      }
+      if (lane_ie < 63) {
+        const double x0 = x1v(P.ie), x1 = x1v(P.ie - 1);
+        strat_x1(g, true, g.e, i > P.ie, 1, lane_ie, lane_ie - 1, bx, x0, x1);
+#pragma unroll
+        for (int n = 0; n < ND; ++n) strat_x1(dq[n], false, none, i > P.ie, 1, lane_ie, lane_ie - 1, bx, x0, x1);
+      }
+      if (ghost_row) {
+        const double bxf = gl[0] + i * gl[1], bvy0 = -a.bc_q * a.bc_om0 * bx;
+        g.v2 = strat_x2_v2(g.v2, ru > P.je, bxf, bvy0);
+#pragma unroll
+        for (int n = 0; n < ND; ++n) dq[n].v2 = strat_x2_v2(dq[n].v2, ru > P.je, bxf, bvy0);
+      }
+    };
+    // one row of both fluids as the march wants it (the three rows of the priming)
+    auto load_row = [&](int r, Cell6 &gq, Dust4 *dq) {
+      const unsigned c = col + static_cast<unsigned>(row_of(r)) * sj;
+      Raw5 q = load_raw(g_r, g_1, g_2, g_3, g_e, c);
+#pragma unroll
+      for (int n = 0; n < ND; ++n) dq[n] = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], c);
+      if (bcs) bc_row(q, dq, r);
+      gq = finish_cell(q, gm1);
+    };
     // ---- prime the x2 march: rows j0-2, j0-1, j0 --------------------------------------------------------
-    Cell6 qc = load_cell(g_r, g_1, g_2, g_3, g_e, col + (j0 - 1) * sj, gm1);
-    Cell6 qn = load_cell(g_r, g_1, g_2, g_3, g_e, col + j0 * sj, gm1);
-    Cell6 zl;
+    Cell6 qc, qn, zl;
+    Dust4 dc[ND > 0 ? ND : 1], dn[ND > 0 ? ND : 1], dzl[ND > 0 ? ND : 1];
+    load_row(j0 - 1, qc, dc);
+    load_row(j0, qn, dn);
     // Guard (exactness next to vanishing velocities): one bit per row, newest in bit 0 -- some lane
     // of this wave holds a gas or dust velocity below 2^-200 in that row.  A trip whose five-row window (the x2 stencil
     // of row j; the x1 stencil lives in the wave's own lanes) has a bit set takes IEEE divisions throughout.
@@ -231,32 +316,26 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
     const bool detect = !EXACT && a.redo_cnt != nullptr; // wave-uniform
     auto tiny6 = [](const Cell6 &q) { return tiny_vel3(q.v1, q.v2, q.v3); };
     auto tiny4 = [](const Dust4 &q) { return tiny_vel3(q.v1, q.v2, q.v3); };
+    Flux8 fy_lo;
+    fy_lo.d = fy_lo.m1 = fy_lo.m2 = fy_lo.m3 = fy_lo.e = fy_lo.eg = fy_lo.pf = fy_lo.vf = 0.0;
+    DFlux dy_lo[ND > 0 ? ND : 1];
     {
-      const Cell6 qmm = load_cell(g_r, g_1, g_2, g_3, g_e, col + (j0 - 2) * sj, gm1);
+      Cell6 qmm;
+      Dust4 dmm[ND > 0 ? ND : 1];
+      load_row(j0 - 2, qmm, dmm);
       if (detect) th = (__any(tiny6(qmm)) ? 4u : 0u) | (__any(tiny6(qc)) ? 2u : 0u) | (__any(tiny6(qn)) ? 1u : 0u);
 #define ZL0(m) zl.m = up_val<RECON>(qc.m, slope_sel<RECON>(qmm.m, qc.m, qn.m, fast));
       G6(ZL0)
 #undef ZL0
-    }
-    Flux8 fy_lo;
-    fy_lo.d = fy_lo.m1 = fy_lo.m2 = fy_lo.m3 = fy_lo.e = fy_lo.eg = fy_lo.pf = fy_lo.vf = 0.0;
-    Dust4 dc[ND > 0 ? ND : 1], dn[ND > 0 ? ND : 1], dzl[ND > 0 ? ND : 1];
-    DFlux dy_lo[ND > 0 ? ND : 1];
 #pragma unroll
-    for (int n = 0; n < ND; ++n) {
-      dc[n] = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], col + (j0 - 1) * sj);
-      dn[n] = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], col + j0 * sj);
-      const Dust4 dmm = load_dust(d_r[n], d_1[n], d_2[n], d_3[n], col + (j0 - 2) * sj);
-      if (detect) th |= (__any(tiny4(dmm)) ? 4u : 0u) | (__any(tiny4(dc[n])) ? 2u : 0u) | (__any(tiny4(dn[n])) ? 1u : 0u);
-#define ZL0(m) dzl[n].m = up_val<RECON>(dc[n].m, slope_sel<RECON>(dmm.m, dc[n].m, dn[n].m, fast));
-      D4(ZL0)
+      for (int n = 0; n < ND; ++n) {
+        if (detect) th |= (__any(tiny4(dmm[n])) ? 4u : 0u) | (__any(tiny4(dc[n])) ? 2u : 0u) | (__any(tiny4(dn[n])) ? 1u : 0u);
+#define ZL0(m) dzl[n].m = up_val<RECON>(dc[n].m, slope_sel<RECON>(dmm[n].m, dc[n].m, dn[n].m, fast));
+        D4(ZL0)
 #undef ZL0
-      dy_lo[n].d = dy_lo[n].m1 = dy_lo[n].m2 = dy_lo[n].m3 = 0.0;
+        dy_lo[n].d = dy_lo[n].m1 = dy_lo[n].m2 = dy_lo[n].m3 = 0.0;
+      }
     }
-    // the block's edge table, read ONCE: inside the march (stores in flight) a read of it would be a vector load of a
-    // uniform address with a vmcnt(0) wait behind it, i.e. a wait for the row prefetch that was just issued
-    const double *geo = P.geom + 6 * b;
-    const double gl[6] = {geo[0], geo[1], geo[2], geo[3], geo[4], geo[5]};
     ShearAcc sa{}; // the shearing-box terms depend on the column only (rotating_frame_impl.hpp:43-60)
     if (a.rf_on) sa = shear_terms(gl, 2, 0, i, a.rf_omega, a.rf_qshear);
     // ... and the block's output arrays
@@ -269,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
       p_2[n] = a.dout[b * 4 * ND + ND + 3 * n + 1], p_3[n] = a.dout[b * 4 * ND + ND + 3 * n + 2];
     }
     for (int j = j0 - 1; j <= j1; ++j) { // the first trip only primes the flux through face j0
-      const unsigned cnn = col + static_cast<unsigned>(j + 2) * sj, ccur = col + static_cast<unsigned>(j) * sj;
+      const unsigned cnn = col + static_cast<unsigned>(row_of(j + 2)) * sj, ccur = col + static_cast<unsigned>(j) * sj;
       const bool live = (j >= j0); // wave-uniform
       // this trip's HBM loads first; consumed after the sweeps
       // (every load of the trip here, unconditionally, and nothing reads one before the sweeps: the single wave of a SIMD
@@ -314,7 +393,10 @@ __global__ __launch_bounds__(256, 1) void stage2d_kernel(const PackView P, const
         teg1 = GD(bdt, rvol) * 0.5 * (lo.pf + up.pf) * (g.ax1[1] * up.vf - g.ax1[0] * lo.vf);
       }
       // ---- gas: x2 sweep, registers only: slope of row j+1, face j+1 ---------------------------------------
-      const Cell6 qnn = finish_cell(rnn, gm1); // (the prefetched row is first read here, behind the x1 sweep)
+      // (the prefetched row is first read here, behind the x1 sweep)
+      Raw5 rnb = rnn;
+      if (bcs) bc_row(rnb, dnn, j + 2);
+      const Cell6 qnn = finish_cell(rnb, gm1);
       if (detect) {
         bool t = tiny6(qnn);
 #pragma unroll
@@ -681,6 +763,7 @@ bool stage2d_covers(const PackView &P, const artemis_stage_general_args_t &g, in
   if (P.gas.ns != 1 || P.dust.ns > 2) return false;
   if (recon_gas == ARTEMIS_PPM || (P.dust.ns && (recon_dust != recon_gas || riemann_dust == ARTEMIS_HLLC))) return false;
   if (g.diffusion || g.cooling || g.nbody_n || g.defer_finish) return false;
+  if (g.strat_faces && (g.strat_faces != 15 || P.nb != 1 || P.ie - P.is < 1)) return false; // (all four faces of ONE block)
   if (g.drag && (g.drag->type != ARTEMIS_DRAG_SIMPLE_DUST || g.drag->damp_visc || P.dust.ns == 0)) return false;
   if (g.gravity && g.gravity->type != ARTEMIS_GRAVITY_UNIFORM && g.gravity->type != ARTEMIS_GRAVITY_POINT &&
       g.gravity->type != ARTEMIS_GRAVITY_BINARY)
@@ -709,6 +792,7 @@ void launch_stage2d(const PackView &P, const artemis_stage_general_args_t &g, in
     // bounds are finite, so the skipped value is exactly +0 for the positive dt of a step)
   }
   a.cfl_gas = g.cfl_gas, a.cfl_dust = g.cfl_dust;
+  a.bc_strat = g.strat_faces ? 1 : 0, a.bc_q = g.strat_qshear, a.bc_om0 = g.strat_omega;
   a.dt_bits = reinterpret_cast<unsigned long long *>(g.dt_dev);
   const int nx1 = P.ie - P.is + 1, nx2 = P.je - P.js + 1;
   a.nstrip = (nx1 + OWN - 1) / OWN;

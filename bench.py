@@ -309,12 +309,16 @@ def main():
                     help="disk_amr: inject the batched refinement tags of the remesh leg INSIDE the timed region (every "
                          "4th cycle ~2.5 %% of the leaves; the criterion merges them again derefine_count cycles later), so "
                          "that `value` includes the cost of a mesh that keeps changing")
-    ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "ssheet_dust", "disk_sph", "disk_sph_smr", "disk_amr"],
+    ap.add_argument("--workload", default="sedov3d", choices=["sedov3d", "ssheet_dust", "disk_sph", "disk_sph_smr", "disk_amr", "linwave3d"],
                     help="sedov3d = the headline metric (BASELINE configs[1]); ssheet_dust = SURVEY config 3 "
                          "(2-D dusty shearing sheet with drag, general fused stage; --n is the mesh edge, 1 GPU); "
                          "disk_sph = BASELINE configs[3] without refinement (inputs/disk/disk_sph.in, spherical-polar "
                          "alpha disk; --n scales the 128x64x64 deck mesh by n/128, 1 GPU)")
     ap.add_argument("--dust", type=int, default=1, help="ssheet_dust: number of dust species")
+    ap.add_argument("--recon", default="ppm", choices=["plm", "ppm"],
+                    help="linwave3d (inputs/linwave/linear_wave.in at n^3 in one block, HLLC, periodic): the reconstruction -- ppm "
+                         "runs the cell-centred general stage (PPM is not in the tile marches: DESIGN.md section 8), plm the "
+                         "tuned tile march; the pair states the gap")
     ap.add_argument("--amr-block", type=int, default=16, choices=[16, 32],
                     help="disk_amr: zones per block edge -- 16 (default: the stress case, 7 064 blocks at N = 1) or 32 (the block "
                          "size of the reference's deck inputs/disk/disk_nbody_cyl.in)")
@@ -327,7 +331,7 @@ def main():
     args = ap.parse_args()
     if args.gpus not in DECOMPOSITION:
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
-    if args.gpus > 1 and args.workload in ("ssheet_dust", "disk_sph"):
+    if args.gpus > 1 and args.workload in ("ssheet_dust", "disk_sph", "linwave3d"):
         raise SystemExit("--workload %s is a single-GPU measurement (one mesh block); the N-GPU workloads are sedov3d, "
                          "disk_sph_smr and disk_amr" % args.workload)
     if args.gpus > 1 and args.remesh_in_timed_region:
@@ -418,6 +422,15 @@ def main():
         ov = ["parthenon/time/nlim=-1"]
         for d, m in enumerate(dims, 1):
             ov += ["parthenon/mesh/nx%d=%d" % (d, m), "parthenon/meshblock/nx%d=%d" % (d, m)]
+        make_sim = lambda: Simulation(deck, ov)
+        sim = make_sim()
+    elif args.workload == "linwave3d":
+        deck = os.path.join(ROOT, "inputs", "linwave", "linear_wave.in")
+        n = args.n
+        ov = ["parthenon/time/nlim=-1", "problem/nperiod=1000", "gas/reconstruct=" + args.recon,
+              "parthenon/mesh/nghost=%d" % (3 if args.recon == "ppm" else 2)]
+        for d in (1, 2, 3):
+            ov += ["parthenon/mesh/nx%d=%d" % (d, n), "parthenon/meshblock/nx%d=%d" % (d, n)]
         make_sim = lambda: Simulation(deck, ov)
         sim = make_sim()
     elif args.workload == "disk_sph_smr":
@@ -784,6 +797,18 @@ def main():
                 out["remesh"] = remesh_leg
                 out["remesh_ms_mean"] = remesh_leg["ms_mean"]
                 out["device_bytes_peak"] = remesh_leg["device_bytes_peak_during_remesh"]
+        elif args.workload == "linwave3d":
+            out["metric"] = "cell-updates/sec (zone-cycles/s), %d^3 linear wave, %s + HLLC" % (args.n, args.recon.upper())
+            out["config"]["workload"] = ("inputs/linwave/linear_wave.in in 3-D at %d^3 (one block, periodic), gas, HLLC + %s, rk2, "
+                                         "cfl 0.9: what a deck outside the tile marches' coverage runs on" % (args.n, args.recon.upper()))
+            out["config"]["decomposition"] = "1 rank, one mesh block"
+            out["config"]["stage_path"] = sim.stage_kernel
+            if nlaunch:
+                alg = ALG_BYTES_PER_CELL_STAGE * local_zones
+                achieved = alg / (kms * 1.0e-3) / 1.0e9
+                out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                   "traffic": None, "kernel": sim.stage_kernel, "launch_ms": kms, "launches_timed": nlaunch,
+                                   "algorithmic_bytes_per_launch": alg}
         elif args.workload == "ssheet_dust":
             # B_alg per cell-stage = 8 B * 5 * (6 ns_gas + 4 ns_dust); one "launch" = one stage
             # of the general fused path (gas kernel + dust kernel + drag/aux/c2p finish)
@@ -830,7 +855,9 @@ def main():
                 dropin["fused"] = value
                 dropin["frac_fused"] = value * 2.0 * ALG_BYTES_PER_CELL_STAGE / 1.0e9 / HBM_PEAK_GBS
                 out["dropin"] = dropin
-        if args.workload in ("disk_sph", "disk_sph_smr", "disk_amr") and not args.no_cpu_baseline:
+        if args.workload == "linwave3d":
+            pass  # (a gap measurement: no CPU leg)
+        elif args.workload in ("disk_sph", "disk_sph_smr", "disk_amr") and not args.no_cpu_baseline:
             hc = host_cores()
             threads = args.cpu_threads or hc["physical_usable"]
             kind = "cyl_dust" if args.workload == "disk_amr" else "sph"

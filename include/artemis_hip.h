@@ -41,7 +41,8 @@
  *  without the ARTEMIS_ prefix).  No launch path calls getenv.
  *  path selection (every path gives the same bits; tests use these to compare them)
  *    NO_TUNED, TUNED_2D, NO_STAGE2D, NO_FUSED_CURV, NO_CURV_MARCH, NO_CURV_DUST, NO_CURV_DUST_MARCH, NO_DRAG_IN_MARCH
- *    (the drag finish as its own launch instead of inside the dust march), NO_ML_FUSED,
+ *    (the drag finish as its own launch instead of inside the dust march), NO_STRAT_IN_KERNEL (the `strat` conditions as
+ *    boundary-fill launches instead of inside the 2-D row march), NO_ML_FUSED,
  *    NO_EPILOGUE, NO_TILED_FLUX, NO_VISC_SOURCE (the diffusion-flux tasks instead of artemis_hip_viscous_source),
  *    NBODY_TASK (N-body gravity as its own task with the host-side reduction), NBODY_GENERAL, NO_PLM_TABLE,
  *    NO_DISTANCE_TABLE, NO_FLAT_RANGES, FULL_REMESH (a remesh rebuilds the whole state next to the old one instead of
@@ -598,6 +599,17 @@ typedef struct artemis_stage_general_args {
    * ConsToPrim are pointwise (drag.hpp:296-482, fill_derived.cpp:58-164).  p->{gas,dust}.cons0 are required;
    * what they hold for zones outside the list afterwards is unspecified. */
   int defer_finish;
+  /* Boundary conditions applied by the stage kernel itself, on the rows it loads (0 = none: the caller fills every ghost
+   * zone before the call, the plain contract).  strat_faces = 15 (bits 0..3 = the inner / outer x1 and x2 faces): the
+   * block's x1 faces carry the `strat` problem's `extrap` condition and its x2 faces `inflow` (pgen/strat.hpp:158-466,
+   * ARTEMIS_BC_STRAT_EXTRAP / ARTEMIS_BC_STRAT_INFLOW of artemis_hip_apply_bc, with its qshear / omega) -- the kernel
+   * then reads NO ghost zone of gas_in / dust_in and forms the conditions' values in registers, in parthenon's order (x1
+   * over the entire x2 extent, then x2): the same bits as artemis_hip_apply_bc followed by the plain call.  The ghost zones
+   * of the *_out arrays are left as they were; artemis_hip_apply_bc completes them whenever somebody else reads them.
+   * Served by the 2-D row march only (artemis_hip_stage_general_variant == 1, one block): otherwise
+   * ARTEMIS_HIP_EUNSUPPORTED. */
+  int strat_faces;
+  double strat_qshear, strat_omega;
 } artemis_stage_general_args_t;
 int artemis_hip_stage_general(const artemis_pack_t *p, const artemis_stage_general_args_t *a,
                               void *stream);

@@ -36,3 +36,11 @@ fi
 if has amrline; then
 timeout 900 python bench.py --workload disk_amr --no-cpu-baseline --no-remesh-leg --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json; cut -c1-200 gpurun_out/${tag}_disk_amr_line.json
 fi
+if has cfg3; then
+timeout 1200 python -m pytest tests/test_driver_gpu.py tests/test_parity_stage_general.py -m gpu -q -x -k "strat or sheet or stage2d or row_march or 2d or dusty" 2>&1 | tail -8 > gpurun_out/${tag}_tests_cfg3.txt; tail -3 gpurun_out/${tag}_tests_cfg3.txt
+for n in 1024 4096; do timeout 300 python bench.py --workload ssheet_dust --n $n --no-cpu-baseline --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_${n}_line.json; cut -c1-220 gpurun_out/${tag}_cfg3_${n}_line.json; done
+timeout 300 python bench.py --workload ssheet_dust --n 1024 --dust 2 --no-cpu-baseline --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_2dust_line.json; cut -c1-220 gpurun_out/${tag}_cfg3_1024_2dust_line.json
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_cfg3_prof -o p --output-format csv -- python3 bench.py --workload ssheet_dust --n 1024 --no-cpu-baseline --steps 100 > gpurun_out/${tag}_cfg3_prof.log 2>&1
+find gpurun_out/${tag}_cfg3_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_cfg3_1024_kernel_stats.csv
+rm -rf gpurun_out/${tag}_cfg3_prof
+fi

@@ -1122,3 +1122,43 @@ def test_dusty_sheet_full_size_paths_agree(hiplib):
     assert np.array_equal(g[[0, 1, 2, 3, 5]], u.interior(u.field("gas.prim"))[[0, 1, 2, 3, 5]])
     assert np.array_equal(d, u.interior(u.field("dust.prim")))
     assert np.isfinite(g[[0, 1, 2, 3, 5]]).all() and np.isfinite(d).all() and g[0].min() > 0 and d[:2].min() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx1,nx2,ndust", [(128, 128, 0), (61, 40, 1), (121, 23, 2), (64, 96, 1), (180, 19, 1), (7, 9, 1)])
+def test_strat_conditions_inside_the_row_march(hiplib, option, nx1, nx2, ndust):
+    """The `strat` problem's user conditions (pgen/strat.hpp:158-466: x1 `extrap`, x2 `inflow`) formed by the 2-D row march on
+    the rows it loads (artemis_stage_general_args_t.strat_faces: no boundary-fill launch, no ghost zone read) against the
+    same run with the conditions as artemis_hip_apply_bc launches between the stages: every zone of the final state, ghost
+    zones and corners included, bit for bit -- on widths that put the outer x1 edge in every position of a wave (61 = one
+    owned lane in the last strip, 121, 180 = exactly three strips, 7 = narrower than a strip) -- and against the oracle."""
+    from artemis_amd.driver import Simulation
+    ov = ["parthenon/mesh/nx1=%d" % nx1, "parthenon/mesh/nx2=%d" % nx2, "parthenon/meshblock/nx1=%d" % nx1,
+          "parthenon/meshblock/nx2=%d" % nx2, "parthenon/time/nlim=12"]
+    if ndust:
+        ov += ["physics/dust=true", "physics/drag=true", "dust/nspecies=%d" % ndust, "dust/cfl=0.3", "dust/reconstruct=plm",
+               "dust/riemann=hlle", "dust/dfloor=1.0e-10", "dust/stopping_time/type=constant",
+               "dust/stopping_time/tau=" + ", ".join(["0.1", "1.0"][:ndust]), "drag/type=simple_dust"]
+    a = Simulation(DECK("ssheet", "ssheet.in"), ov)
+    a.evolve()
+    assert a.nblocks == 1 and a.stage_kernel == "stage2d_kernel"
+    option("no_strat_in_kernel")
+    b = Simulation(DECK("ssheet", "ssheet.in"), ov)
+    b.evolve()
+    assert a.ncycle == b.ncycle == 12 and a.time == b.time and a.dt == b.dt
+    keep = [0, 1, 2, 3, 5]  # (the pressure slot is not a FillGhost variable)
+    assert np.array_equal(a.field("gas.prim")[keep], b.field("gas.prim")[keep])
+    if ndust:
+        assert np.array_equal(a.field("dust.prim"), b.field("dust.prim"))
+    o = Oracle((nx1, nx2, 1), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2), ng=2, ns_gas=1, ns_dust=ndust, reconstruct="plm", riemann="hllc",
+               dust_reconstruct="plm", dust_riemann="hlle", gamma=1.000001, dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10,
+               cfl=0.3, dust_cfl=0.3, bc=("extrap", "extrap", "inflow", "inflow", "extrap", "extrap"), integrator="rk2")
+    o.set_rotating_frame(1.0, 1.5)
+    o.set_gravity_point(1e-5, soft=0.03)
+    if ndust:
+        o.set_drag("simple_dust", "constant", tau=[0.1, 1.0][:ndust])
+    o.pgen_strat(rho0=1.0, dens_min=1e-10, h=0.05)
+    o.evolve(100.0, 12)
+    assert a.dt == o.dt and np.array_equal(a.field("gas.prim")[keep], o.gprim[keep])
+    if ndust:
+        assert np.array_equal(a.field("dust.prim"), o.dprim)
