@@ -52,12 +52,17 @@ struct RestrictW {
 ADEV RestrictW restrict_weights(const PackView &P, int b, int fk, int fj, int fi) {
   RestrictW w;
   const bool X1 = P.ndim > 0, X2 = P.ndim > 1, X3 = P.ndim > 2;
+  // (fixed 2 x 2 x 2 trip counts with the activity test inside: fully unrolled, every index a constant, so the eight
+  //  weights live in registers -- with run-time loop bounds they were 64 bytes of scratch per lane)
+#pragma unroll
   for (int ok = 0; ok < 2; ++ok)
+#pragma unroll
     for (int oj = 0; oj < 2; ++oj)
-      for (int oi = 0; oi < 2; ++oi) w.vol[ok][oj][oi] = 0;
-  for (int ok = 0; ok < 1 + X3; ++ok)
-    for (int oj = 0; oj < 1 + X2; ++oj)
-      for (int oi = 0; oi < 1 + X1; ++oi) w.vol[ok][oj][oi] = fine_coords(P, b, fk + ok, fj + oj, fi + oi).volume();
+#pragma unroll
+      for (int oi = 0; oi < 2; ++oi) {
+        const bool on = (ok == 0 || X3) && (oj == 0 || X2) && (oi == 0 || X1);
+        w.vol[ok][oj][oi] = on ? fine_coords(P, b, fk + (X3 ? ok : 0), fj + (X2 ? oj : 0), fi + (X1 ? oi : 0)).volume() : 0.0;
+      }
   w.tvol = ((w.vol[0][0][0] + w.vol[0][1][0]) + (w.vol[0][0][1] + w.vol[0][1][1])) +
            ((w.vol[1][0][0] + w.vol[1][1][0]) + (w.vol[1][0][1] + w.vol[1][1][1]));
   return w;
@@ -65,13 +70,17 @@ ADEV RestrictW restrict_weights(const PackView &P, int b, int fk, int fj, int fi
 ADEV double restrict_value(const PackView &P, const RestrictW &w, const double *q, int fk, int fj, int fi) {
   const bool X1 = P.ndim > 0, X2 = P.ndim > 1, X3 = P.ndim > 2;
   double t[2][2][2];
+#pragma unroll
   for (int ok = 0; ok < 2; ++ok)
+#pragma unroll
     for (int oj = 0; oj < 2; ++oj)
-      for (int oi = 0; oi < 2; ++oi) t[ok][oj][oi] = 0;
-  for (int ok = 0; ok < 1 + X3; ++ok)
-    for (int oj = 0; oj < 1 + X2; ++oj)
-      for (int oi = 0; oi < 1 + X1; ++oi)
-        t[ok][oj][oi] = w.vol[ok][oj][oi] * q[(static_cast<long>(fk + ok) * P.nj + (fj + oj)) * P.ni + fi + oi];
+#pragma unroll
+      for (int oi = 0; oi < 2; ++oi) {
+        const bool on = (ok == 0 || X3) && (oj == 0 || X2) && (oi == 0 || X1);
+        // (an inactive offset reads the zone itself: a valid address, the value is not used)
+        const double v = q[(static_cast<long>(fk + (X3 ? ok : 0)) * P.nj + (fj + (X2 ? oj : 0))) * P.ni + fi + (X1 ? oi : 0)];
+        t[ok][oj][oi] = on ? w.vol[ok][oj][oi] * v : 0.0;
+      }
   return (((t[0][0][0] + t[0][1][0]) + (t[0][0][1] + t[0][1][1])) + ((t[1][0][0] + t[1][1][0]) + (t[1][0][1] + t[1][1][1]))) /
          w.tvol;
 }
@@ -222,27 +231,35 @@ __global__ __launch_bounds__(256) void ml_flux_kernel(const PackView P, const ar
     const int fj = (d == 1) ? op.off[1] : ((P.ndim > 1) ? 2 * j + op.off[1] : j);
     const int fk = (d == 2) ? op.off[2] : ((P.ndim > 2) ? 2 * k + op.off[2] : k);
     double area[2][2][2];
+#pragma unroll
     for (int ok = 0; ok < 2; ++ok)
+#pragma unroll
       for (int oj = 0; oj < 2; ++oj)
-        for (int oi = 0; oi < 2; ++oi) area[ok][oj][oi] = 0;
-    for (int ok = 0; ok < 1 + I3; ++ok)
-      for (int oj = 0; oj < 1 + I2; ++oj)
-        for (int oi = 0; oi < 1 + I1; ++oi) {
-          const DCoords co = fine_coords(P, op.src_block, fk + ok, fj + oj, fi + oi);
-          area[ok][oj][oi] = (d == 0) ? co.area1(0) : ((d == 1) ? co.area2(0) : co.area3(0));
+#pragma unroll
+        for (int oi = 0; oi < 2; ++oi) {
+          const bool on = (ok == 0 || I3) && (oj == 0 || I2) && (oi == 0 || I1);
+          double a_ = 0.0;
+          if (on) {
+            const DCoords co = fine_coords(P, op.src_block, fk + ok, fj + oj, fi + oi);
+            a_ = (d == 0) ? co.area1(0) : ((d == 1) ? co.area2(0) : co.area3(0));
+          }
+          area[ok][oj][oi] = a_;
         }
     const double tvol = ((area[0][0][0] + area[0][1][0]) + (area[0][0][1] + area[0][1][1])) +
                         ((area[1][0][0] + area[1][1][0]) + (area[1][0][1] + area[1][1][1]));
     for (int v = 0; v < nflux; ++v) {
       const double *q = flux_ptr(P, op.src_block, d, v, with_diff);
       double tm[2][2][2];
+#pragma unroll
       for (int ok = 0; ok < 2; ++ok)
+#pragma unroll
         for (int oj = 0; oj < 2; ++oj)
-          for (int oi = 0; oi < 2; ++oi) tm[ok][oj][oi] = 0;
-      for (int ok = 0; ok < 1 + I3; ++ok)
-        for (int oj = 0; oj < 1 + I2; ++oj)
-          for (int oi = 0; oi < 1 + I1; ++oi)
-            tm[ok][oj][oi] = area[ok][oj][oi] * q[(static_cast<long>(fk + ok) * P.nj + (fj + oj)) * P.ni + fi + oi];
+#pragma unroll
+          for (int oi = 0; oi < 2; ++oi) {
+            const bool on = (ok == 0 || I3) && (oj == 0 || I2) && (oi == 0 || I1);
+            const double v = q[(static_cast<long>(fk + (I3 ? ok : 0)) * P.nj + (fj + (I2 ? oj : 0))) * P.ni + fi + (I1 ? oi : 0)];
+            tm[ok][oj][oi] = on ? area[ok][oj][oi] * v : 0.0;
+          }
       const double val = (((tm[0][0][0] + tm[0][1][0]) + (tm[0][0][1] + tm[0][1][1])) +
                           ((tm[1][0][0] + tm[1][1][0]) + (tm[1][0][1] + tm[1][1][1]))) /
                          tvol;

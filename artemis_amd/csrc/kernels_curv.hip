@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   using T = CurvTile<FTX>;
   constexpr int FTY = T::FTY, QX = T::QX, QY = T::QY, FH = 2;
   constexpr int NV = DUST ? 4 : 6; // staged variables; also the stride of the fluid's pointer tables (one species)
-  constexpr bool PG = (RECON == 1); // PLM_G
+  constexpr bool PG = (RECON == 1);                       // a limited slope (PLM): the tiny-velocity guard applies
+  constexpr bool PGG = PG && SYS != ARTEMIS_CARTESIAN;    // PLM_G: the slope takes geometric weights (plm.hpp:54-73)
   __shared__ T S;
   const int t = threadIdx.x, tx = t % FTX, ty = t / FTX;
   int id = blockIdx.x;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   }
   // ---- the workgroup's geometry tables -----------------------------------------------------------------------------
   geotabs_fill(S.G, P, b, i0 - FH, j0 - FH, t);
-  if constexpr (PG) {
+  if constexpr (PGG) {
     auto coords = [&](int kk, int jj, int ii) { return coords_of(SYS, g, mrow, P.nj, P.nk, kk, jj, ii); };
     if (t >= 128 && t < 128 + QX) { // x1 records, columns i0-2 .. i0+FTX+1 (those next to the array's ends are never read)
       const int x = t - 128, ii = min(max(i0 - FH + x, 1), P.ni - 2);
@@ -367,8 +368,14 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
   // per plane and phase (one branch around all variables of both sweeps: the six slope chains of a sweep share a basic
   // block and interleave) instead of once per variable
   auto faces_of = [&](auto FT, double qm, double q, double qp, const PlmG &r, double &up_, double &lo_) {
-    if constexpr (PG) plm_g_shared<decltype(FT)::value ? 2 : 0>(qm, q, qp, up_, lo_, r);
-    else up_ = q, lo_ = q; // pcm.hpp:34-88
+    if constexpr (PGG) {
+      plm_g_shared<decltype(FT)::value ? 2 : 0>(qm, q, qp, up_, lo_, r);
+    } else if constexpr (PG) { // Cartesian: plm.hpp:32-47, uniform spacing (fused_device.hpp slope_sel / up_val / lo_val)
+      const double s_ = decltype(FT)::value ? plm_dqm_fast(qm, q, qp) : plm_dqm(qm, q, qp);
+      up_ = q + s_, lo_ = q - s_;
+    } else {
+      up_ = q, lo_ = q; // pcm.hpp:34-88
+    }
   };
   auto stage_plane = [&](const Cell6 &q, const Raw5 &hal, int par) {
 #define PUTQ(m, n) if constexpr (n < NV) S.Q[n][ty + FH][tx + FH] = q.m;
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     Cell6 lox, loy, L;
     {
       PlmG r{};
-      if constexpr (PG) r = rec_x1(tx + FH);
+      if constexpr (PGG) r = rec_x1(tx + FH);
 #define SLX(m, n)                                                                                 \
   if constexpr (n < NV) {                                                                         \
     double up_;                                                                                   \
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     __builtin_amdgcn_sched_barrier(0); // (one sweep's six chains interleave; two sweeps' would not fit the registers)
     if (multi_d) {
       PlmG r{};
-      if constexpr (PG) r = rec_x2(tx + FH, ty + FH);
+      if constexpr (PGG) r = rec_x2(tx + FH, ty + FH);
 #define SLY(m, n)                                                                                 \
   if constexpr (n < NV) {                                                                         \
     double up_;                                                                                   \
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       const int u = duty - 128, row = u >> 1, side = u & 1;
       const int cx = side ? FTX + FH : FH - 1;
       PlmG r{};
-      if constexpr (PG) r = rec_x1(cx);
+      if constexpr (PGG) r = rec_x1(cx);
 #pragma unroll
       for (int n = 0; n < NV; ++n) {
         double up_, lo_;
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       const int u = duty - 192, cx = u % FTX, side = u / FTX;
       const int ry = side ? FTY + FH : FH - 1;
       PlmG r{};
-      if constexpr (PG) r = rec_x2(cx + FH, ry);
+      if constexpr (PGG) r = rec_x2(cx + FH, ry);
 #pragma unroll
       for (int n = 0; n < NV; ++n) {
         double up_, lo_;
@@ -842,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
     {
       const Cell6 qmm = ldcell(in_r, in_1, in_2, in_3, in_e, col + static_cast<unsigned>(k0 - 2) * sk);
       PlmG r{};
-      if constexpr (PG) r = rec_x3(tx + FH, ty + FH, k0 - 1);
+      if constexpr (PGG) r = rec_x3(tx + FH, ty + FH, k0 - 1);
       double unused_;
 #define ZL0(m, n) if constexpr (n < NV) faces_of(std::false_type{}, qmm.m, qc.m, qn.m, r, zl.m, unused_);
       CFOR6(ZL0)
@@ -898,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void stage_curv_kernel(const PackView P, co
       Flux8 fz_hi;
       auto sweep3 = [&](auto FT) {
         PlmG r{};
-        if constexpr (PG) r = rec_x3(tx + FH, ty + FH, k + 1);
+        if constexpr (PGG) r = rec_x3(tx + FH, ty + FH, k + 1);
 #define ZSL(m, n) if constexpr (n < NV) faces_of(FT, qc.m, qn.m, qnn.m, r, zl_next.m, zr.m);
         CFOR6_33(ZSL)
 #undef ZSL
@@ -1020,7 +1027,12 @@ void launch_sys(const PackView &P, const CurvK &k, int riemann, int recon, bool 
 bool curv_march_covers(const PackView &P, const artemis_stage_general_args_t &g, int recon_gas) {
   if (opt(OPT_NO_CURV_MARCH)) return false;
   if (static_cast<long>(P.nk) * P.nj * P.ni >= (1L << 29)) return false;
-  if (P.coords == ARTEMIS_CARTESIAN || P.gas.ns != 1 || P.dust.ns > 1 || P.ng < 2) return false;
+  if (P.gas.ns != 1 || P.dust.ns > 1 || P.ng < 2) return false;
+  // Cartesian packs with the pointwise sources the tuned kernel (kernels_fused.hip) and the 2-D row march do not carry --
+  // gravity, viscosity as sums -- on the same march: plain PLM, every metric factor 1 (SYS = cartesian instantiations);
+  // the rotating frame of a Cartesian pack is the shearing box, which this march does not have
+  if (P.coords == ARTEMIS_CARTESIAN && (P.dust.ns != 0 || g.rf_omega != 0.0 || g.nbody_n || P.ndim < 2 || opt(OPT_NO_CART_MARCH)))
+    return false;
   if (!g.pcm && recon_gas == ARTEMIS_PPM) return false;
   if (g.cooling) return false;
   if (g.diffusion && !g.diffusion_sums) return false;
@@ -1031,6 +1043,7 @@ bool curv_march_covers(const PackView &P, const artemis_stage_general_args_t &g,
   // the systems by dimensionality (geometry.hpp:38-56 CoordSelect): anything else keeps the older kernel
   const int nd = P.ndim;
   switch (P.coords) {
+  case ARTEMIS_CARTESIAN: return nd >= 2;
   case ARTEMIS_CYLINDRICAL: return nd >= 2;
   case ARTEMIS_SPHERICAL1D: return nd == 1;
   case ARTEMIS_SPHERICAL2D: return nd == 2;
@@ -1095,6 +1108,10 @@ void launch_stage_curv(const PackView &P, const artemis_stage_general_args_t &g,
     else launch_sys<SYSV, D3V>(P, k, riemann, recon, narrow, grid, s);               \
   } while (0)
   switch (P.coords) {
+  case ARTEMIS_CARTESIAN: // (gas only: curv_march_covers)
+    if (d3) launch_sys<ARTEMIS_CARTESIAN, true>(P, k, riemann, recon, narrow, grid, s);
+    else launch_sys<ARTEMIS_CARTESIAN, false>(P, k, riemann, recon, narrow, grid, s);
+    break;
   case ARTEMIS_CYLINDRICAL:
     if (d3) CURV_SYS(ARTEMIS_CYLINDRICAL, true);
     else CURV_SYS(ARTEMIS_CYLINDRICAL, false);

@@ -221,7 +221,7 @@ class MeshBlockPack:
         if nbody is not None:  # (device array, count) of nbody_device(): Gravity::NBodyGravity inside the stage
             self._nbody_keep = nbody
             a.nbody_dev, a.nbody_n, a.nbody_omf = nbody[0].data_ptr(), nbody[1], nbody_omf
-        a.defer_finish = int(defer_finish)
+        a.defer_finish = int(defer_finish)  # (False / True, or the ABI's 0 / 1 / 2)
         self._last_general_args = a
         # which kernel this call takes (0 cell-centred, 1 2-D row march, 2 curvilinear streaming tile)
         self.last_stage_variant = self.L.artemis_hip_stage_general_variant(C.byref(self.pack), C.byref(a))
@@ -277,6 +277,14 @@ class MeshBlockPack:
     def stage_finish(self, time, dt, drag=None):
         """artemis_hip_stage_finish: [DragSource] + SetAuxillaryFields + ConsToPrim of cons0 into the primitives."""
         self._call(self.L.artemis_hip_stage_finish, C.byref(drag) if drag is not None else None, time, dt)
+
+    def stage_finish_cells(self, time, dt, drag, cells):
+        """artemis_hip_stage_finish_cells: the same three tasks on the listed zones only; cells = [(block, k, j, i, faces)]."""
+        recs = [capi.MlFixCell(*c) for c in cells]
+        dev = self._device_records(recs, capi.MlFixCell)
+        self._call(self.L.artemis_hip_stage_finish_cells, C.byref(drag) if drag is not None else None, time, dt,
+                   C.c_void_p(dev.data_ptr()), len(recs))
+        torch.cuda.synchronize()
 
     # ---- gas diffusion (artemis_driver.cpp:189-193, :218-221) -----------------------------------
     def ZeroDiffusionFlux(self):

@@ -1,10 +1,11 @@
 # Copy the outputs of `scripts/final_gpu_job.sh <tag>` (merged back under gpurun_out/) into profiles/<round>_*.
-tag=${1:-r05z}
-ROUND=${ROUND:-r05}
+tag=${1:-r06z}
+ROUND=${ROUND:-r06}
 cd /root/repo
 g=gpurun_out
 for f in pmc_traffic disk_sph_pmc_traffic cfg3_pmc_traffic cfg3_1024_pmc_traffic disk_sph_smr_pmc_traffic disk_amr_pmc_traffic pmc_sq disk_sph_pmc_sq; do cp $g/${tag}_$f.json profiles/${ROUND}_$f.json; done
-for f in bench_line cfg3_line cfg3_1024_line cfg3_1024_2dust_line disk_sph_line disk_sph_smr_line disk_amr_line; do cp $g/${tag}_$f.json profiles/${ROUND}_$f.json; done
+for f in bench_line cfg3_line cfg3_1024_line cfg3_1024_2dust_line disk_sph_line disk_sph_smr_line disk_amr_line disk_amr_block32_line disk_amr_remesh_in_timed_region_line disk_sph_smr_loopback_line disk_amr_loopback_line linwave3d_ppm_line linwave3d_plm_line; do cp $g/${tag}_$f.json profiles/${ROUND}_$f.json; done
+cp $g/${tag}_identity.txt profiles/${ROUND}_identity.txt
 for f in bench bench_default cfg3 cfg3_1024 disk_sph smr_cart smr_sph amr; do cp $g/${tag}_${f}_kernel_stats.csv profiles/${ROUND}_${f}_kernel_stats.csv; done
 {
   echo "# scripts/final_gpu_job.sh $tag on one MI355X (gpurun), $(date -u +%Y-%m-%d) -- GPU suite, smoke, SMR timings, curvilinear timings"

@@ -5,8 +5,8 @@
 # lines look their records up under.
 PARTS=${PARTS:-"suite pmc sq bench prof timings"}
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
-tag=${1:-r05z}
-ROUND=${ROUND:-r05}
+tag=${1:-r06z}
+ROUND=${ROUND:-r06}
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -44,6 +44,12 @@ timeout 300 python bench.py --workload ssheet_dust --n 1024 --dust 2 --no-cpu-ba
 timeout 300 python bench.py --workload disk_sph --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_disk_sph_line.json
 timeout 600 python bench.py --workload disk_sph_smr --steps 40 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_sph_smr_line.json
 timeout 1500 python bench.py --workload disk_amr --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json
+# ... the deck's own 32^3 blocks, the mesh changing inside the timed region, the N-rank legs through RCCL on one device, the PPM gap
+timeout 900 python bench.py --workload disk_amr --amr-block 32 --steps 20 --warmup 5 --no-cpu-baseline --no-remesh-leg 2>/dev/null > gpurun_out/${tag}_disk_amr_block32_line.json
+timeout 1500 python bench.py --workload disk_amr --steps 24 --warmup 5 --no-cpu-baseline --no-remesh-leg --remesh-in-timed-region 2>/dev/null > gpurun_out/${tag}_disk_amr_remesh_in_timed_region_line.json
+timeout 600 python bench.py --workload disk_sph_smr --loopback --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null > gpurun_out/${tag}_disk_sph_smr_loopback_line.json
+timeout 900 python bench.py --workload disk_amr --loopback --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null > gpurun_out/${tag}_disk_amr_loopback_line.json
+for r in ppm plm; do timeout 300 python bench.py --workload linwave3d --recon $r --steps 30 --warmup 5 2>/dev/null > gpurun_out/${tag}_linwave3d_${r}_line.json; done
 cut -c1-300 gpurun_out/${tag}_cfg3_line.json gpurun_out/${tag}_cfg3_1024_line.json gpurun_out/${tag}_disk_sph_line.json gpurun_out/${tag}_disk_sph_smr_line.json gpurun_out/${tag}_disk_amr_line.json
 fi
 if has prof; then

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 python3 -c "from artemis_amd import build as b; b.build_hip(); print('library source sha', b.verify())" 2>&1 | tail -1 | tee gpurun_out/${tag}_identity.txt || exit 1
 if has suite; then
-timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > gpurun_out/${tag}_tests.txt; tail -3 gpurun_out/${tag}_tests.txt
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/${tag}_tests.txt; tail -3 gpurun_out/${tag}_tests.txt
 fi
 if has refined; then
 timeout 1800 python -m pytest tests/test_multilevel.py tests/test_adaptive.py tests/test_parity_refine.py -m gpu -q -x 2>&1 | tail -15 > gpurun_out/${tag}_tests_refined.txt; tail -3 gpurun_out/${tag}_tests_refined.txt
@@ -43,4 +43,15 @@ timeout 300 python bench.py --workload ssheet_dust --n 1024 --dust 2 --no-cpu-ba
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_cfg3_prof -o p --output-format csv -- python3 bench.py --workload ssheet_dust --n 1024 --no-cpu-baseline --steps 100 > gpurun_out/${tag}_cfg3_prof.log 2>&1
 find gpurun_out/${tag}_cfg3_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_cfg3_1024_kernel_stats.csv
 rm -rf gpurun_out/${tag}_cfg3_prof
+fi
+if has cart; then
+timeout 2400 python -m pytest tests -m gpu -q -x -k "cart or Cart or multilevel or stage_general or gravity or visc or diffusion or blast" 2>&1 | tail -8 > gpurun_out/${tag}_tests_cart.txt; tail -3 gpurun_out/${tag}_tests_cart.txt
+timeout 300 python scripts/smr_timing.py 20 | tee gpurun_out/${tag}_smr.txt
+timeout 300 python scripts/smr_timing.py 20 sph problem/polytropic_index=1.40 gas/de_switch=1e-2 | tee -a gpurun_out/${tag}_smr.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_smrc_prof -o p --output-format csv -- python3 scripts/smr_timing.py 10 > gpurun_out/${tag}_smrc_prof.log 2>&1
+find gpurun_out/${tag}_smrc_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_smr_cart_kernel_stats.csv
+rm -rf gpurun_out/${tag}_smrc_prof
+fi
+if has ppm; then
+for r in ppm plm; do timeout 300 python bench.py --workload linwave3d --recon $r --steps 30 --warmup 5 2>gpurun_out/${tag}_linwave_$r.err > gpurun_out/${tag}_linwave_${r}_line.json; cut -c1-200 gpurun_out/${tag}_linwave_${r}_line.json; tail -2 gpurun_out/${tag}_linwave_$r.err; done
 fi

@@ -74,6 +74,12 @@ CASES = [
     ((40, 19, 21), (0.3, 0.7, 0.0), (1.7, 2.5, 6.0), 1, 1, "plm", "hllc", "hlle", "spherical", 2),
     ((45, 12, 1), (0.5, 0.0, -0.5), (2.0, 6.0, 0.5), 1, 1, "plm", "hlle", "llf", "cylindrical", 2),
     ((77, 1, 1), (0.1, 0.0, -0.5), (1.0, np.pi, 0.5), 1, 1, "plm", "hlle", "hlle", "spherical", 2),
+    # one gas species on a 3-D CARTESIAN block through artemis_hip_stage_general: the same tile march, SYS = cartesian
+    # (plain PLM, every metric factor 1; round 6 -- the deck-level users are Cartesian packs with gravity / viscosity,
+    # e.g. inputs/disk/disk_cart.in): 32 x 8 and 16 x 16 tiles, ragged in x1 and x2, several x3 chunks, ng 2 and 4
+    ((40, 19, 37), (-1, -0.5, 0.25), (1, 0.8, 0.95), 1, 0, "plm", "hlle", "hlle", "cartesian", 2),
+    ((16, 16, 8), (-1, -0.5, 0.25), (1, 0.8, 0.95), 1, 0, "plm", "hllc", "hlle", "cartesian", 4),
+    ((33, 9, 5), (-1, -0.5, 0.25), (1, 0.8, 0.95), 1, 0, "pcm", "llf", "hlle", "cartesian", 2),
 ]
 CURV_TILE_CASES = range(15, 22)
 
@@ -105,6 +111,8 @@ def test_general_stage_hydro(hiplib, nx, lo, hi, nsg, nsd, recon, riem, driem, c
     mb.stage_general(g0, g1, be * dt, be * dt, gas=(gin, gu1, gout), dust=(din, du1, dout))
     if coords != "cartesian" and nsg == 1 and nsd <= 1 and recon != "ppm":
         assert mb.last_stage_variant == 3  # the curvilinear tile march (kernels_curv.hip) really ran
+    if coords == "cartesian" and nx[2] > 1 and nsg == 1 and nsd == 0 and recon != "ppm":
+        assert mb.last_stage_variant == 3  # ... and its Cartesian instantiation
     I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
     if nsg:
         out = mb._extra_prim["o"][0][0][I].cpu().numpy()
@@ -578,16 +586,23 @@ NBODY_BLOCKS = [
 
 
 @pytest.mark.parametrize("coordinates,nx,lo,hi,variant", NBODY_BLOCKS)
-@pytest.mark.parametrize("mode", ["drag", "defer", "gas_only"])
-def test_general_stage_with_nbody_gravity_and_drag(hiplib, coordinates, nx, lo, hi, variant, mode):
+@pytest.mark.parametrize("mode", ["drag", "drag_launch", "defer", "finish2", "defer_cells", "gas_only"])
+def test_general_stage_with_nbody_gravity_and_drag(hiplib, coordinates, nx, lo, hi, variant, mode, option):
     """Gravity::NBodyGravity inside the one-kernel stage (artemis_stage_general_args_t.nbody_dev): a spline-softened
     accreting sink, a Plummer particle with a momentum sink and an uncoupled one, with the frame correction of a
     rotating frame, followed by the rotating-frame task and simple_dust drag -- against the oracle's task chain
     (artemis_driver.cpp:182-255), bit for bit; the seven sums per particle (artemis_hip_nbody_force_sums) to 1e-12.
     mode = drag: DragSource + SetAuxillaryFields + ConsToPrim inside the call; defer: the call stops at the conserved
     state (defer_finish, what a refined mesh does around its fix-up) and artemis_hip_stage_finish completes it;
-    gas_only: no dust, no drag (the march stores primitives itself)."""
+    gas_only: no dust, no drag (the march stores primitives itself).  Round 6: `drag` on the curvilinear marches couples
+    the fluids INSIDE the dust march (simple_drag1_finish on its registers) -- drag_launch is the same call with the finish
+    as its own launch (NO_DRAG_IN_MARCH); finish2 = defer_finish 2 (the stage finishes every zone itself, what a refined
+    mesh asks for since round 6); defer_cells = the stage stops at the conserved state and artemis_hip_stage_finish_cells
+    finishes a LISTED third of the zones into NaN-filled primitive tables: listed zones equal the oracle, no other zone
+    is touched."""
     from artemis_amd.pack import MeshBlockPack, drag_params
+    if mode == "drag_launch":
+        option("no_drag_in_march")
     cart = coordinates == "cartesian"
     nsd = 0 if mode == "gas_only" else 1
     kw = dict(ng=2, ns_gas=1, ns_dust=nsd, reconstruct="plm", riemann="hllc", dust_reconstruct="plm", dust_riemann="hlle",
@@ -630,10 +645,22 @@ def test_general_stage_with_nbody_gravity_and_drag(hiplib, coordinates, nx, lo, 
     mb.stage_general(0.0, 1.0, dt, dt, gas=(mb.gas_prim_table, mb.gas_prim_table, gout),
                      dust=(mb.dust_prim_table, mb.dust_prim_table, dout) if nsd else (None, None, None), time=time,
                      rotating_frame=(om, 1.5 if cart else 0.0), drag=drag, nbody=nb, nbody_omf=om,
-                     defer_finish=(mode == "defer"))
+                     defer_finish={"defer": 1, "defer_cells": 1, "finish2": 2}.get(mode, 0))
     assert mb.last_stage_variant == variant
     I = (slice(None), slice(o.ks, o.ke + 1), slice(o.js, o.je + 1), slice(o.is_, o.ie + 1))
     keep = [0, 1, 2, 3, 5]
+    if mode == "defer_cells":  # the listed zones only, into poisoned tables
+        mb.gas_prim.fill_(float("nan")), mb.dust_prim.fill_(float("nan"))
+        zones = [(0, k, j, i, 0) for k in range(o.ks, o.ke + 1) for j in range(o.js, o.je + 1) for i in range(o.is_, o.ie + 1)][::3]
+        mb.stage_finish_cells(time, dt, drag, zones)
+        got_g, got_d = mb.gas_prim[0].cpu().numpy(), mb.dust_prim[0].cpu().numpy()
+        listed = np.zeros(got_g.shape[1:], dtype=bool)
+        for _, k, j, i, _f in zones:
+            listed[k, j, i] = True
+        assert np.array_equal(got_g[keep][:, listed], o.gprim[keep][:, listed])
+        assert np.array_equal(got_d[:, listed], o.dprim[:, listed])
+        assert np.isnan(got_g[keep][:, ~listed]).all() and np.isnan(got_d[:, ~listed]).all()
+        return
     if mode == "defer":  # the finish works on the pack's own primitive tables
         mb.stage_finish(time, dt, drag)
         got_g, got_d = mb.gas_prim[0][I].cpu().numpy(), mb.dust_prim[0][I]
