@@ -75,8 +75,12 @@ struct Field {
   int nb = 0, nvar = 0;
   size_t N = 0;
   bool ok() const { return data.p != nullptr; }
+  // refined meshes: the ghost zones behind `ic` faces hold the initial state (they are constants of the run and nothing
+  // but the boundary fill writes them: the block-graph exchange only fills zones that face a neighbour)
+  bool ic_filled = false;
   void alloc(int nb_, int nvar_, size_t N_) {
     nb = nb_, nvar = nvar_, N = N_;
+    ic_filled = false;
     if (nvar == 0) return;
     data.alloc(static_cast<size_t>(nb) * nvar * N);
     std::vector<double *> h(static_cast<size_t>(nb) * nvar);
@@ -1416,13 +1420,26 @@ void artemis_sim_impl::fill_ghosts_multilevel(int prim_idx) {
   }
   artemis_bc_params_t bp = bcpar;
   bp.floor_ghosts = 0;
+  // `ic` faces copy the initial state into ghost zones nobody else writes on a refined mesh (the exchange, the
+  // restriction and the prolongation touch zones that face a neighbour only; the stage kernels store active zones): once a
+  // buffer holds them they stay -- the fill is skipped for them (on the configs[4] mesh: every physical condition, 19 + 13
+  // launches per stage)
+  Field &owner = do_gas ? gprim[prim_idx] : dprim[prim_idx];
+  const bool skip_ic = ml_fused && owner.ic_filled && !artemis::opt(artemis::OPT_NO_IC_SKIP);
+  bool has_ic = false;
+  std::vector<int> bc_eff(bc_flat.begin(), bc_flat.end());
+  for (int &f : bc_eff) {
+    has_ic = has_ic || f == ARTEMIS_BC_IC;
+    if (skip_ic && f == ARTEMIS_BC_IC) f = ARTEMIS_BC_NONE;
+  }
   if (ml_fused) { // no PrimToCons follows on the one-kernel path: the conditions that compute values floor them here
     bool value_bc = false;
-    for (size_t q = 0; q < bc_flat.size(); ++q)
-      value_bc = value_bc || bc_flat[q] >= ARTEMIS_BC_CONDUCTIVE || (bc_flat[q] == ARTEMIS_BC_STRAT_EXTRAP && (q % 6) / 2 == 2);
+    for (size_t q = 0; q < bc_eff.size(); ++q)
+      value_bc = value_bc || bc_eff[q] >= ARTEMIS_BC_CONDUCTIVE || (bc_eff[q] == ARTEMIS_BC_STRAT_EXTRAP && (q % 6) / 2 == 2);
     bp.floor_ghosts = value_bc ? 1 : 0;
   }
-  CK(artemis_hip_apply_bc(&p, bc_flat.data(), &bp, stream), "apply_bc");
+  CK(artemis_hip_apply_bc(&p, bc_eff.data(), &bp, stream), "apply_bc");
+  if (ml_fused && has_ic) owner.ic_filled = true;
 }
 
 // SendBoundBufs<flxcor_send> / ReceiveFluxCorrections / SetFluxCorrections (artemis_driver.cpp:196-202)

@@ -851,6 +851,15 @@ struct ShellArgs {
   int lo[3], hi[3], ext[3]; // interior bounds and array extents
   int ng, ndim, nfill;
   long nA, nB, nC;          // cells in the x3-, x2-, x1-ghost regions
+  // `ic` faces (ARTEMIS_BC_IC: the ghost zone takes the initial state's value AT ITS OWN PLACE, pgen/disk.hpp) ride the same
+  // launch: a zone whose LAST covering pass is an `ic` pass reads the initial-state tables instead of the state.  Passes
+  // run periodic images first, then x1, x2, x3 physical conditions: the last one is the highest physical direction in
+  // which the zone is a ghost zone; copy conditions of higher directions have remapped their own index by then, lower
+  // directions and periodic images were overwritten.  The primitive floors PrimToCons would apply behind a value
+  // condition (fill_derived.cpp:227-262) are applied to those zones here (floor_ghost_kernel's test).
+  double *const *ic_gas, *const *ic_dust;
+  double g_dfloor, g_siefloor, d_dfloor;
+  int floor_ic;
 };
 // Up to BC_BATCH blocks per launch (blockIdx.y): block ids and their six flags travel in the kernel arguments
 // (a refined mesh has hundreds of small blocks on the domain boundary; one launch per block was 30 % of the
@@ -862,7 +871,7 @@ struct ShellBatch {
 };
 // ghost zone `tid` of the shell (regions A, B, C in turn) -> its array offset `cd`, the offset `cs` of the active zone
 // it copies and the reflecting walls crossed; false where nothing is to be done
-__device__ __forceinline__ bool shell_zone(const ShellArgs &a, unsigned tid, long &cd, long &cs, int &refl) {
+__device__ __forceinline__ bool shell_zone(const ShellArgs &a, unsigned tid, long &cd, long &cs, int &refl, bool &from_ic) {
   const unsigned nA = static_cast<unsigned>(a.nA), nB = static_cast<unsigned>(a.nB), nC = static_cast<unsigned>(a.nC);
   const unsigned e0 = a.ext[0], e1 = a.ext[1];
   int idx[3];
@@ -891,6 +900,13 @@ __device__ __forceinline__ bool shell_zone(const ShellArgs &a, unsigned tid, lon
   int src[3] = {idx[0], idx[1], idx[2]};
   refl = 0; // bit d set: reflecting wall crossed along d
   bool moved = false;
+  // the highest direction whose `ic` pass covers the zone (none: -1)
+  int icd = -1;
+  for (int d = 0; d < a.ndim; ++d) {
+    const int flag = (idx[d] < a.lo[d]) ? a.bc[2 * d] : ((idx[d] > a.hi[d]) ? a.bc[2 * d + 1] : static_cast<int>(ARTEMIS_BC_NONE));
+    if (flag == ARTEMIS_BC_IC) icd = d;
+  }
+  from_ic = icd >= 0;
   for (int d = 0; d < a.ndim; ++d) {
     const int n_act = a.hi[d] - a.lo[d] + 1;
     int flag = ARTEMIS_BC_NONE;
@@ -898,6 +914,12 @@ __device__ __forceinline__ bool shell_zone(const ShellArgs &a, unsigned tid, lon
     else if (idx[d] > a.hi[d]) flag = a.bc[2 * d + 1];
     else continue;
     if (flag == ARTEMIS_BC_NONE) continue;
+    if (flag == ARTEMIS_BC_IC) {
+      moved = true;
+      continue;
+    }
+    // (behind an `ic` pass only the copy conditions of HIGHER directions still act; periodic images came first of all)
+    if (from_ic && (d < icd || flag == ARTEMIS_BC_PERIODIC)) continue;
     const bool inner = idx[d] < a.lo[d];
     if (flag == ARTEMIS_BC_PERIODIC) src[d] = inner ? idx[d] + n_act : idx[d] - n_act;
     else if (flag == ARTEMIS_BC_OUTFLOW) src[d] = inner ? a.lo[d] : a.hi[d];
@@ -920,13 +942,16 @@ __global__ __launch_bounds__(256) void bc_shell_kernel(ShellArgs a, FillTabs t, 
   // (the three regions of one block hold < 2^31 zones: the launcher checks; 32-bit divisions)
   long cd[SHELL_ZONES], cs[SHELL_ZONES];
   int refl[SHELL_ZONES];
-  bool on[SHELL_ZONES];
+  bool on[SHELL_ZONES], ic[SHELL_ZONES];
 #pragma unroll
   for (int z = 0; z < SHELL_ZONES; ++z) {
     const unsigned tid = (blockIdx.x * SHELL_ZONES + z) * blockDim.x + threadIdx.x;
-    cd[z] = cs[z] = 0, refl[z] = 0;
-    on[z] = shell_zone(a, tid, cd[z], cs[z], refl[z]);
+    cd[z] = cs[z] = 0, refl[z] = 0, ic[z] = false;
+    on[z] = shell_zone(a, tid, cd[z], cs[z], refl[z], ic[z]);
   }
+  FillTabs ti = t; // the initial state's tables, same layout (only read where a zone comes from an `ic` pass)
+  if (a.ic_gas) ti.gas = a.ic_gas;
+  if (a.ic_dust) ti.dust = a.ic_dust;
   constexpr int NV = 5;
   for (int v0 = 0; v0 < a.nfill; v0 += NV) {
     double *q[NV];
@@ -938,8 +963,10 @@ __global__ __launch_bounds__(256) void bc_shell_kernel(ShellArgs a, FillTabs t, 
       q[u] = fill_var(t, v, 0, nrm[u][0]);
       fill_var(t, v, 1, nrm[u][1]);
       fill_var(t, v, 2, nrm[u][2]);
+      bool unused_;
+      const double *qi = fill_var(ti, v, 0, unused_);
 #pragma unroll
-      for (int z = 0; z < SHELL_ZONES; ++z) val[u][z] = on[z] ? q[u][cs[z]] : 0.0;
+      for (int z = 0; z < SHELL_ZONES; ++z) val[u][z] = on[z] ? (ic[z] ? qi[cs[z]] : q[u][cs[z]]) : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
@@ -952,6 +979,12 @@ __global__ __launch_bounds__(256) void bc_shell_kernel(ShellArgs a, FillTabs t, 
         if ((refl[z] & 1) && nrm[u][0]) w = -1.0 * w;
         if ((refl[z] & 2) && nrm[u][1]) w = -1.0 * w;
         if ((refl[z] & 4) && nrm[u][2]) w = -1.0 * w;
+        if (a.floor_ic && ic[z]) { // floor_ghost_kernel's test on the floored variables: gas rho, gas sie, dust rho
+          const int v = v0 + u, ngas = 5 * t.nsg;
+          if (v < t.nsg) w = (w > a.g_dfloor) ? w : a.g_dfloor;
+          else if (v >= 4 * t.nsg && v < ngas) w = (w > a.g_siefloor) ? w : a.g_siefloor;
+          else if (v >= ngas && v < ngas + t.nsd) w = (w > a.d_dfloor) ? w : a.d_dfloor;
+        }
         q[u][cd[z]] = w;
       }
     }
@@ -1173,11 +1206,14 @@ __global__ __launch_bounds__(256) void floor_ghost_kernel(const FillTabs t_in, c
 }
 
 int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t *par, hipStream_t s) {
+  // `ic` faces on the one-launch fill (the initial-state tables of every fluid present are at hand)
+  const bool ic_in_shell = par && (!P.gas.ns || par->ic_gas) && (!P.dust.ns || par->ic_dust) && !opt(OPT_NO_IC_IN_SHELL);
   struct FloorAfter { // runs when the function returns
     const PackView &P;
     const artemis_bc_params_t *par;
     hipStream_t s;
     const int *bc;
+    const bool ic_in_shell;
     ~FloorAfter() {
       if (!par || !par->floor_ghosts) return;
       // only a condition that computes values can leave something below a floor, and only in the block it fills
@@ -1192,19 +1228,23 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
       };
       for (int b = 0; b < P.nb; ++b) {
         bool value = false;
-        for (int f = 0; f < 2 * P.ndim; ++f)
-          value = value || bc[b * 6 + f] >= ARTEMIS_BC_CONDUCTIVE || bc[b * 6 + f] == ARTEMIS_BC_STRAT_EXTRAP;
+        for (int f = 0; f < 2 * P.ndim; ++f) // (`ic` zones are floored where the one-launch fill writes them)
+          value = value || (bc[b * 6 + f] >= ARTEMIS_BC_CONDUCTIVE && !(ic_in_shell && bc[b * 6 + f] == ARTEMIS_BC_IC)) ||
+                  bc[b * 6 + f] == ARTEMIS_BC_STRAT_EXTRAP;
         if (!value) continue;
         bl.b[bl.n++] = b;
         if (bl.n == FACE_BATCH) flush();
       }
       flush();
     }
-  } floor_after{P, par, s, bc};
+  } floor_after{P, par, s, bc, ic_in_shell};
   ShellArgs a;
   a.lo[0] = P.is, a.lo[1] = P.js, a.lo[2] = P.ks, a.hi[0] = P.ie, a.hi[1] = P.je, a.hi[2] = P.ke;
   a.ext[0] = P.ni, a.ext[1] = P.nj, a.ext[2] = P.nk;
   a.ng = P.ng, a.ndim = P.ndim, a.nfill = 5 * P.gas.ns + 4 * P.dust.ns;
+  a.ic_gas = ic_in_shell ? par->ic_gas : nullptr, a.ic_dust = ic_in_shell ? par->ic_dust : nullptr;
+  a.g_dfloor = P.gas.dfloor, a.g_siefloor = P.gas.siefloor, a.d_dfloor = P.dust.dfloor;
+  a.floor_ic = (par && par->floor_ghosts) ? 1 : 0;
   const long nz = P.ke - P.ks + 1, ny = P.je - P.js + 1;
   a.nA = (P.ndim > 2) ? 2L * P.ng * P.nj * P.ni : 0;
   a.nB = (P.ndim > 1) ? nz * 2L * P.ng * P.ni : 0;
@@ -1237,7 +1277,7 @@ int launch_apply_bc(const PackView &P, const int *bc, const artemis_bc_params_t 
       fl[f] = (f / 2 < P.ndim) ? bc[b * 6 + f] : ARTEMIS_BC_NONE;
       any = any || (fl[f] != ARTEMIS_BC_NONE);
       user = user || fl[f] == ARTEMIS_BC_STRAT_EXTRAP || fl[f] == ARTEMIS_BC_STRAT_INFLOW ||
-             fl[f] == ARTEMIS_BC_CONDUCTIVE || fl[f] == ARTEMIS_BC_IC || fl[f] == ARTEMIS_BC_DISK_EXTRAP ||
+             fl[f] == ARTEMIS_BC_CONDUCTIVE || (fl[f] == ARTEMIS_BC_IC && !ic_in_shell) || fl[f] == ARTEMIS_BC_DISK_EXTRAP ||
              fl[f] == ARTEMIS_BC_DISK_VISC;
     }
     if (!any) continue;

@@ -9,7 +9,7 @@ namespace artemis {
 
 #define ARTEMIS_OPTION_LIST(X)                                                                      \
   /* path selection, device library */                                                              \
-  X(NO_TUNED) X(TUNED_2D) X(NO_STAGE2D) X(NO_FUSED_CURV) X(NO_CURV_MARCH) X(NO_CURV_DUST) X(NO_CURV_DUST_MARCH) X(NO_DRAG_IN_MARCH) X(NO_STRAT_IN_KERNEL) X(NO_CART_MARCH) \
+  X(NO_TUNED) X(TUNED_2D) X(NO_STAGE2D) X(NO_FUSED_CURV) X(NO_CURV_MARCH) X(NO_CURV_DUST) X(NO_CURV_DUST_MARCH) X(NO_DRAG_IN_MARCH) X(NO_STRAT_IN_KERNEL) X(NO_CART_MARCH) X(NO_IC_IN_SHELL) X(NO_IC_SKIP) \
   X(NO_ML_FUSED) X(NO_EPILOGUE) X(NO_TILED_FLUX) X(NO_VISC_SOURCE) X(NBODY_TASK) X(NBODY_GENERAL)    \
   X(NO_PLM_TABLE) X(NO_DISTANCE_TABLE) X(NO_FLAT_RANGES) X(FULL_REMESH)                              \
   /* exactness machinery (measuring what it costs) */                                                \

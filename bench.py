@@ -822,7 +822,8 @@ def main():
                 alg = bps * local_zones
                 achieved = alg / (kms * 1.0e-3) / 1.0e9
                 kname = sim.stage_kernel
-                traffic, traffic_src = (measured_traffic("cfg3_" if args.n == 4096 else "cfg3_%d_" % args.n) if args.dust == 1 else (None, None))
+                traffic, traffic_src = measured_traffic(("cfg3_" if args.n == 4096 else "cfg3_%d_" % args.n) +
+                                                        ("" if args.dust == 1 else "%ddust_" % args.dust))
                 out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                    "kernel": ("stage2d_kernel: gas + dust fluxes, update, sources, drag, aux, ConsToPrim, dt in one "

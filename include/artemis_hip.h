@@ -43,7 +43,9 @@
  *    NO_TUNED, TUNED_2D, NO_STAGE2D, NO_FUSED_CURV, NO_CURV_MARCH, NO_CURV_DUST, NO_CURV_DUST_MARCH, NO_DRAG_IN_MARCH
  *    (the drag finish as its own launch instead of inside the dust march), NO_STRAT_IN_KERNEL (the `strat` conditions as
  *    boundary-fill launches instead of inside the 2-D row march), NO_CART_MARCH (Cartesian packs with gravity / viscosity on
- *    the cell-centred stage instead of the tile march of kernels_curv.hip), NO_ML_FUSED,
+ *    the cell-centred stage instead of the tile march of kernels_curv.hip), NO_IC_IN_SHELL (`ic` faces as their own
+ *    boundary-fill launches instead of inside the one-launch fill of the copy-type conditions), NO_IC_SKIP (host driver, refined
+ *    meshes: `ic` faces refilled at every ghost fill although their zones never change), NO_ML_FUSED,
  *    NO_EPILOGUE, NO_TILED_FLUX, NO_VISC_SOURCE (the diffusion-flux tasks instead of artemis_hip_viscous_source),
  *    NBODY_TASK (N-body gravity as its own task with the host-side reduction), NBODY_GENERAL, NO_PLM_TABLE,
  *    NO_DISTANCE_TABLE, NO_FLAT_RANGES, FULL_REMESH (a remesh rebuilds the whole state next to the old one instead of

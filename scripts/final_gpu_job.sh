@@ -24,6 +24,7 @@ timeout 1200 python3 scripts/pmc_traffic.py --tag ${tag}
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 1024
 timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 4096
+timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 1024 --out gpurun_out/${tag}_cfg3_1024_2dust_pmc_traffic.json --dust 2
 timeout 1200 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph_smr
 timeout 1800 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_amr
 fi
@@ -34,7 +35,7 @@ PMC_SQ_GROUPS=0,1 PMC_SQ_KERNELS=stage_curv,viscous_source timeout 600 python3 s
 cp gpurun_out/sq_${tag}_disk_sph.json gpurun_out/${tag}_disk_sph_pmc_sq.json
 fi
 # (on the box: the bench lines below quote the records measured by this or an earlier call)
-for f in pmc_traffic disk_sph_pmc_traffic cfg3_pmc_traffic cfg3_1024_pmc_traffic disk_sph_smr_pmc_traffic disk_amr_pmc_traffic pmc_sq; do cp gpurun_out/${tag}_$f.json profiles/${ROUND}_$f.json 2>/dev/null; done
+for f in pmc_traffic disk_sph_pmc_traffic cfg3_pmc_traffic cfg3_1024_pmc_traffic cfg3_1024_2dust_pmc_traffic disk_sph_smr_pmc_traffic disk_amr_pmc_traffic pmc_sq; do cp gpurun_out/${tag}_$f.json profiles/${ROUND}_$f.json 2>/dev/null; done
 if has bench; then
 # ---- bench lines
 timeout 900 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err; cat gpurun_out/${tag}_bench_line.json | cut -c1-400

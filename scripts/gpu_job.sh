@@ -55,3 +55,10 @@ fi
 if has ppm; then
 for r in ppm plm; do timeout 300 python bench.py --workload linwave3d --recon $r --steps 30 --warmup 5 2>gpurun_out/${tag}_linwave_$r.err > gpurun_out/${tag}_linwave_${r}_line.json; cut -c1-200 gpurun_out/${tag}_linwave_${r}_line.json; tail -2 gpurun_out/${tag}_linwave_$r.err; done
 fi
+if has disk; then
+timeout 2400 python -m pytest tests -m gpu -q -k "disk or multilevel or adaptive or bc or boundary or ic or refine" 2>&1 | tail -8 > gpurun_out/${tag}_tests_disk.txt; tail -3 gpurun_out/${tag}_tests_disk.txt
+timeout 300 python bench.py --workload disk_sph --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_disk_sph_line.json; cut -c1-200 gpurun_out/${tag}_disk_sph_line.json
+timeout 600 python bench.py --workload disk_sph_smr --no-cpu-baseline --steps 40 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_sph_smr_line.json; cut -c1-200 gpurun_out/${tag}_disk_sph_smr_line.json
+timeout 900 python bench.py --workload disk_amr --no-cpu-baseline --no-remesh-leg --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json; cut -c1-200 gpurun_out/${tag}_disk_amr_line.json
+timeout 900 python bench.py --workload disk_amr --amr-block 32 --no-cpu-baseline --no-remesh-leg --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr32_line.json; cut -c1-200 gpurun_out/${tag}_disk_amr32_line.json
+fi
