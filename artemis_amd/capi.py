@@ -73,7 +73,7 @@ class StageArgs(C.Structure):
         ("shell_done", C.c_void_p), ("shell_target", C.POINTER(C.c_uint)),
         ("beta_dt_dev", C.c_void_p), ("shell_faces", C.c_int),
         ("tiny_in", C.c_void_p), ("tiny_out", C.c_void_p), ("tiny_clear", C.c_void_p),
-        ("outflow_faces", C.c_int), ("redo_scratch", C.c_void_p),
+        ("outflow_faces", C.c_int), ("outflow_faces_by_block", C.c_void_p), ("redo_scratch", C.c_void_p),
     ]
 
 

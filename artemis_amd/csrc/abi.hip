@@ -700,6 +700,8 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
   if (a->shell_done && a->region != 0)
     return fail(ARTEMIS_HIP_EINVAL, "fused stage: shell_done requires region 0");
   if (p->nghost < 2) return fail(ARTEMIS_HIP_EUNSUPPORTED, "fused stage: needs nghost >= 2");
+  if (a->outflow_faces_by_block && p->nblocks > 10)
+    return fail(ARTEMIS_HIP_EUNSUPPORTED, "fused stage: outflow_faces_by_block serves packs of up to 10 blocks");
   const int recon = a->pcm ? ARTEMIS_PCM : p->gas.recon;
   const int rc = artemis::launch_stage_fused(artemis::make_pack_view(*p), *a, p->gas.riemann, recon,
                                              S(stream));

@@ -377,6 +377,7 @@ struct artemis_sim_impl {
   // (artemis_bc_params_t.x1_interior_done) or is skipped altogether when every physical face of the rank is such a face,
   // and evolve() fills the ghost zones once before it returns
   int x1_done_hint = 0;
+  std::vector<unsigned char> outflow_by_block; // artemis_stage_args_t.outflow_faces_by_block of the current stage loop
   bool skip_bc_hint = false;
   bool ghosts_stale = false;
   void fill_stale_ghosts();
@@ -2906,12 +2907,33 @@ void artemis_sim_impl::step_fused(bool want_dt, bool device_dt) {
       for (int b = 0; b < nb; ++b)
         for (int f = 0; f < 2 * ndim; ++f)
           all_covered = all_covered && (bc_flat[6 * b + f] == ARTEMIS_BC_NONE || ((mask >> f) & 1));
+      // Several blocks per rank (stacked blocks: the face between two of them is a neighbour's, the outer ones are physical):
+      // the same rule block by block -- every physical face of every block is `outflow` -- with one mask per block
+      outflow_by_block.clear();
+      if (dropin == 0 && !all_covered && nb > 1 && nb <= 10) {
+        bool every_physical_is_outflow = true;
+        int common = 63;
+        for (int b = 0; b < nb; ++b) {
+          int mb = 0;
+          for (int f = 0; f < 2 * ndim; ++f) {
+            if (bc_flat[6 * b + f] == ARTEMIS_BC_OUTFLOW) mb |= 1 << f;
+            else every_physical_is_outflow = every_physical_is_outflow && bc_flat[6 * b + f] == ARTEMIS_BC_NONE;
+          }
+          outflow_by_block.push_back(static_cast<unsigned char>(mb));
+          common &= mb;
+        }
+        if (every_physical_is_outflow) mask = common | 64, all_covered = true; // (bit 6: "by block"; stripped below)
+        else outflow_by_block.clear();
+      }
+      const bool by_block = (mask & 64) != 0;
+      mask &= 63;
       a.outflow_faces = mask;
+      a.outflow_faces_by_block = by_block ? outflow_by_block.data() : nullptr;
       x1_done_hint = ((mask & 3) == 3) ? 3 : 0;
-      skip_bc_hint = mask != 0 && all_covered;
+      skip_bc_hint = (mask != 0 || by_block) && all_covered;
       if (!skip_bc_hint && x1_done_hint == 0) a.outflow_faces = mask = 0; // (nothing to gain: keep the plain protocol)
       if (!skip_bc_hint) a.outflow_faces = mask & 3;                       // (the boundary fill still provides x2 / x3 ghosts)
-      ghosts_stale = ghosts_stale || a.outflow_faces != 0;
+      ghosts_stale = ghosts_stale || a.outflow_faces != 0 || a.outflow_faces_by_block != nullptr;
     }
     // (ARTEMIS_FORCE_OVERLAP=1: diagnostic, shell-first ordering even when every link is local)
     const bool force_ovl = artemis::opt(artemis::OPT_FORCE_OVERLAP) != 0;

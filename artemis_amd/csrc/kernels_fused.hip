@@ -101,7 +101,13 @@ struct StageK {
   const unsigned *tiny_in; // artemis_stage_args_t: detection runs only if *tiny_in != 0 (null: always)
   unsigned *tiny_out;
   int outflow; // artemis_stage_args_t.outflow_faces: bit f = do not read the ghost zones behind face f (stage the edge zone)
+  // ... block by block (outflow_faces_by_block): six bits per block, up to ten blocks; outflow_pb = 1 selects it
+  unsigned long long outflow_blk;
+  int outflow_pb;
 };
+ADEV int outflow_of(const int outflow, const unsigned long long blk, const int pb, const int b) {
+  return pb ? static_cast<int>((blk >> (6 * b)) & 63ull) : outflow;
+}
 
 struct LdsTile {
   double Q[6][QY][QX];          // staged primitives of plane k (rho, v1, v2, v3, P, sie)
@@ -789,8 +795,9 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
   // clamped indices: inactive lanes still serve as neighbours and face owners
   int il = min(i, P.ni - 1);
   int jl = min(j, P.nj - 1);
-  if (a.outflow & 8) jl = min(jl, P.je);
-  if (a.outflow & 2) il = min(il, P.ie); // (ragged tiles: the lanes past the last zone stand in for the outflow ghosts)
+  const int outflow = outflow_of(a.outflow, a.outflow_blk, a.outflow_pb, x.b); // (wave-uniform: the block is)
+  if (outflow & 8) jl = min(jl, P.je);
+  if (outflow & 2) il = min(il, P.ie); // (ragged tiles: the lanes past the last zone stand in for the outflow ghosts)
   const int k0 = bkb0 + chunk * bkchunk;
   const int k1 = min(bkb1, k0 + bkchunk - 1);
   if (k0 > k1) { // empty chunk (cannot happen with the box builder, kept for safety)
@@ -826,11 +833,11 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
   }
   if (x.hr >= 0) {
     int gi = min(max(x.i0 - FH + x.hc, 0), P.ni - 1);
-    if (a.outflow & 1) gi = max(gi, P.is); // outflow: the ghost zones hold the edge zone's value -- stage that
-    if (a.outflow & 2) gi = min(gi, P.ie);
+    if (outflow & 1) gi = max(gi, P.is); // outflow: the ghost zones hold the edge zone's value -- stage that
+    if (outflow & 2) gi = min(gi, P.ie);
     int gj = min(max(x.j0 - FH + x.hr, 0), P.nj - 1);
-    if (a.outflow & 4) gj = max(gj, P.js);
-    if (a.outflow & 8) gj = min(gj, P.je);
+    if (outflow & 4) gj = max(gj, P.js);
+    if (outflow & 8) gj = min(gj, P.je);
     x.hcol = static_cast<unsigned>(gj) * x.sj + static_cast<unsigned>(gi);
   }
   double ldt = DBL_MAX;
@@ -920,8 +927,8 @@ __global__ __launch_bounds__(NT, (CURV && !ARTEMIS_CURV_OCC2) ? 1 : 2) void stag
     // flux through face k.
     // planes behind an outflow x3 face are the first / last active plane (StageK::outflow): wave-uniform index arithmetic
     auto kpl = [&](int kk) {
-      if (a.outflow & 16) kk = max(kk, P.ks);
-      if (a.outflow & 32) kk = min(kk, P.ke);
+      if (outflow & 16) kk = max(kk, P.ks);
+      if (outflow & 32) kk = min(kk, P.ke);
       return static_cast<unsigned>(kk);
     };
     Cell6 qc = load_cell(x.in_r, x.in_1, x.in_2, x.in_3, x.in_e, x.col + kpl(k0 - 1) * x.sk, x.gm1);
@@ -1109,6 +1116,8 @@ struct RedoK {
   unsigned long long *dt_bits;
   unsigned *tiny_out, *tiny_clear;
   int outflow;
+  unsigned long long outflow_blk;
+  int outflow_pb;
   unsigned *cnt;   // entries in the list; reset to zero by the last workgroup of this kernel (no memset between stages)
   unsigned *done;  // its ticket counter
   unsigned cap;
@@ -1145,12 +1154,13 @@ __global__ __launch_bounds__(256) void stage_redo_kernel(const PackView P, const
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
         long cm = c + (m - 2) * st;
-        if (a.outflow) { // the stage kernel's rule: the ghost zones behind an outflow face are the edge zone (not read from memory)
+        const int outflow = outflow_of(a.outflow, a.outflow_blk, a.outflow_pb, b);
+        if (outflow) { // the stage kernel's rule: the ghost zones behind an outflow face are the edge zone (not read from memory)
           const int at = (DIR == 1) ? i : ((DIR == 2) ? j : k), lo = (DIR == 1) ? P.is : ((DIR == 2) ? P.js : P.ks);
           const int hi = (DIR == 1) ? P.ie : ((DIR == 2) ? P.je : P.ke);
           int am = at + (m - 2);
-          if (((a.outflow >> (2 * (DIR - 1))) & 1) && am < lo) am = lo;
-          if (((a.outflow >> (2 * (DIR - 1) + 1)) & 1) && am > hi) am = hi;
+          if (((outflow >> (2 * (DIR - 1))) & 1) && am < lo) am = lo;
+          if (((outflow >> (2 * (DIR - 1) + 1)) & 1) && am > hi) am = hi;
           cm = c + (am - at) * st;
         }
         w[m] = load_cell(qr, q1, q2, q3, qe, cm, P.gm1);
@@ -1372,6 +1382,13 @@ void launch_redo_cfg(const PackView &P, const RedoK &r, hipStream_t s) {
   // (an empty pass costs by its grid: 5.5 us at 128 workgroups, every stage; the lists are short when they are not empty)
   hipLaunchKernelGGL((stage_redo_kernel<RIEMANN, RECON>), dim3(32), dim3(256), 0, s, P, r);
 }
+// artemis_stage_args_t.outflow_faces_by_block (a HOST array) packed into six bits per block; 0: the pack-wide mask applies
+static int pack_outflow(const PackView &P, const artemis_stage_args_t &a, unsigned long long &blk) {
+  blk = 0;
+  if (!a.outflow_faces_by_block) return 0;
+  for (int b = 0; b < P.nb && b < 10; ++b) blk |= static_cast<unsigned long long>(a.outflow_faces_by_block[b] & 63) << (6 * b);
+  return 1;
+}
 void launch_redo(const PackView &P, const artemis_stage_args_t &a, int riemann, int recon, int which, hipStream_t s) {
   RedoK r;
   r.gam0 = a.gam0, r.gam1 = a.gam1, r.beta_dt = a.beta_dt, r.bdt = a.bdt, r.cfl = a.cfl;
@@ -1380,6 +1397,7 @@ void launch_redo(const PackView &P, const artemis_stage_args_t &a, int riemann, 
   r.dt_bits = reinterpret_cast<unsigned long long *>(a.dt_dev);
   r.tiny_out = a.tiny_out, r.tiny_clear = (which == 0) ? a.tiny_clear : nullptr;
   r.outflow = a.outflow_faces & 63;
+  r.outflow_pb = pack_outflow(P, a, r.outflow_blk);
   const RedoBufs B = redo_bufs_of(P, a);
   r.cnt = B.cnt + which, r.done = B.cnt + 2 + which, r.cap = static_cast<unsigned>(std::min<size_t>(B.cap, 0xffffffffu));
   r.list = B.list[which];
@@ -1492,6 +1510,7 @@ int launch_stage_fused(const PackView &P, const artemis_stage_args_t &a, int rie
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.tiny_in = a.tiny_in, k.tiny_out = a.tiny_out;
   k.outflow = a.outflow_faces & 63;
+  k.outflow_pb = pack_outflow(P, a, k.outflow_blk);
   const bool redo = redo_enabled();
   if (redo) {
     if (!a.redo_scratch && !ensure_redo(pack_zones(P))) return 5;
@@ -1566,7 +1585,7 @@ int launch_flux_fused(const PackView &P, int riemann, int recon, hipStream_t s) 
   k.nshell = 0, k.shell_done = nullptr;
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.tiny_in = nullptr, k.tiny_out = nullptr;
-  k.outflow = 0;
+  k.outflow = 0, k.outflow_blk = 0, k.outflow_pb = 0;
   k.xcd_swizzle = opt(OPT_FUSED_NO_SWIZZLE) ? 0 : 1;
 #define RC(RS)                                                                             \
   case RS:                                                                                 \
@@ -1631,7 +1650,7 @@ void launch_stage_fused_curv(const PackView &P, const artemis_stage_general_args
   k.nshell = 0, k.shell_done = nullptr;
   k.redo_cnt0 = k.redo_cnt1 = nullptr, k.redo_list0 = k.redo_list1 = nullptr, k.redo_cap = 0;
   k.tiny_in = nullptr, k.tiny_out = nullptr;
-  k.outflow = 0;
+  k.outflow = 0, k.outflow_blk = 0, k.outflow_pb = 0;
   k.xcd_swizzle = opt(OPT_FUSED_NO_SWIZZLE) ? 0 : 1;
   SrcArg<true> src;
   src.v.grav_on = (g.gravity && (g.time >= g.gravity->tstart) && (g.time < g.gravity->tstop)) ? 1 : 0;

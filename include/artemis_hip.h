@@ -442,6 +442,10 @@ typedef struct artemis_stage_args {
    * third of the boundary shell and most of its cost --, or no artemis_hip_apply_bc call at all when every physical
    * face of the pack is covered) as long as it fills them before anything else reads the state.  0 = read the ghosts. */
   int outflow_faces;
+  /* Optional HOST array [nblocks]: the same mask block by block (outflow_faces is then ignored) -- a pack whose blocks
+   * differ in which of their faces are physical (two blocks of a rank stacked along x3: the face between them is a
+   * neighbour's, the outer ones are outflow).  Packs of up to 10 blocks; more: ARTEMIS_HIP_EUNSUPPORTED. */
+  const unsigned char *outflow_faces_by_block;
   /* Optional DEVICE scratch for the detect-and-redo lists (zones next to vanishing velocities, deferred to the exact
    * kernel), artemis_hip_redo_scratch_bytes(p) bytes, zeroed once by the caller.  NULL = the library's own buffers, one
    * set per calling THREAD (allocated on first use, grown with a device synchronisation): fine for one state and one

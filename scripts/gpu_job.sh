@@ -62,3 +62,16 @@ timeout 600 python bench.py --workload disk_sph_smr --no-cpu-baseline --steps 40
 timeout 900 python bench.py --workload disk_amr --no-cpu-baseline --no-remesh-leg --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json; cut -c1-200 gpurun_out/${tag}_disk_amr_line.json
 timeout 900 python bench.py --workload disk_amr --amr-block 32 --no-cpu-baseline --no-remesh-leg --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr32_line.json; cut -c1-200 gpurun_out/${tag}_disk_amr32_line.json
 fi
+if has remesh; then
+timeout 600 python scripts/remesh_profile.py > gpurun_out/${tag}_remesh_profile.txt 2>&1; tail -80 gpurun_out/${tag}_remesh_profile.txt
+fi
+if has sphprof; then
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_sph_prof -o p --output-format csv -- python3 bench.py --workload disk_sph --no-cpu-baseline --steps 50 > gpurun_out/${tag}_sph_prof.log 2>&1
+find gpurun_out/${tag}_sph_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_disk_sph_kernel_stats.csv
+rm -rf gpurun_out/${tag}_sph_prof
+fi
+if has headline; then
+timeout 2400 python -m pytest tests/test_parity_fused.py tests/test_driver_gpu.py tests/test_multilevel.py -m gpu -q 2>&1 | tail -6 > gpurun_out/${tag}_tests_fused.txt; grep -E "passed|failed" gpurun_out/${tag}_tests_fused.txt
+timeout 600 python bench.py --no-cpu-baseline --steps 100 2>/dev/null > gpurun_out/${tag}_bench_line.json; python3 -c "
+import json; d=json.load(open('gpurun_out/${tag}_bench_line.json')); print('headline', d['value'], d['roofline']['frac'], 'emulation', d['config'].get('overlap_emulation_zcps'), 'dropin', {k: v for k, v in d.get('dropin', {}).items() if k.startswith('fused') or k == 'per_task'})"
+fi

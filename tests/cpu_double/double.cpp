@@ -446,8 +446,9 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
     prim_to_cons(s);
     s.gu1 = s.gu0;
     B.in(s.gprim, a->prim_in, 6);
-    if (a->outflow_faces) { // the ghost zones behind these faces are not read: they are the edge zones (outflow)
-      for (int f = 0; f < 6; ++f) s.c.bc[f] = ((a->outflow_faces >> f) & 1) ? BC_OUTFLOW : BC_NONE;
+    const int outflow = a->outflow_faces_by_block ? a->outflow_faces_by_block[b] : a->outflow_faces;
+    if (outflow) { // the ghost zones behind these faces are not read: they are the edge zones (outflow)
+      for (int f = 0; f < 6; ++f) s.c.bc[f] = ((outflow >> f) & 1) ? BC_OUTFLOW : BC_NONE;
       apply_bcs(s);
       for (int f = 0; f < 6; ++f) s.c.bc[f] = BC_NONE;
     }
