@@ -270,6 +270,7 @@ def load():
         "artemis_rt_free": (None, [vp]),
         "artemis_rt_device_bytes": (None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), i]),
         "artemis_rt_pool_trim": (None, [C.c_size_t]),
+        "artemis_rt_pool_bytes": (C.c_size_t, []),
         "artemis_rt_pool_limit": (None, [C.c_size_t]),
         "artemis_hip_set_option": (C.c_int, [C.c_char_p, C.c_long]),
         "artemis_hip_get_option": (C.c_long, [C.c_char_p]),

@@ -995,7 +995,7 @@ int artemis_hip_stage_finish_cells(const artemis_pack_t *p, const artemis_drag_t
                                    const artemis_ml_fix_cell_t *cells_dev, int ncells, void *stream) {
   (void)time;
   if (int rc = validate(p)) return rc;
-  if (int rc = validate_registers(p, "stage finish")) return rc;
+  // (cons0 alone: the three tasks read and write the current conserved state; the start-of-step copy plays no part)
   if (ncells < 0 || (ncells > 0 && !cells_dev)) return fail(ARTEMIS_HIP_EINVAL, "stage finish: bad zone list");
   for (const artemis_fluid_pack_t *f : {&p->gas, &p->dust})
     if (f->nspecies && (!f->prim || !f->cons0)) return fail(ARTEMIS_HIP_EINVAL, "stage finish: prim and cons0 tables are required");
@@ -1011,9 +1011,8 @@ int artemis_hip_stage_finish_cells(const artemis_pack_t *p, const artemis_drag_t
 int artemis_hip_stage_finish(const artemis_pack_t *p, const artemis_drag_t *drag, double time, double dt, void *stream) {
   (void)time;
   if (int rc = validate(p)) return rc;
-  if (int rc = validate_registers(p, "stage finish")) return rc;
-  for (const artemis_fluid_pack_t *f : {&p->gas, &p->dust})
-    if (f->nspecies && !f->prim) return fail(ARTEMIS_HIP_EINVAL, "stage finish: prim tables are required");
+  for (const artemis_fluid_pack_t *f : {&p->gas, &p->dust}) // (cons0 alone: the start-of-step copy plays no part)
+    if (f->nspecies && (!f->prim || !f->cons0)) return fail(ARTEMIS_HIP_EINVAL, "stage finish: prim and cons0 tables are required");
   const artemis::PackView P = artemis::make_pack_view(*p);
   if (drag) {
     if (int rc = validate_damp_visc(drag)) return rc;
@@ -1257,6 +1256,10 @@ void artemis_rt_free(void *p) {
   g_pool.emplace(le.cap, PoolEntry{p, ++g_pool_seq, le.dev});
   g_pool_bytes += le.cap;
   pool_trim_locked(g_pool_limit);
+}
+size_t artemis_rt_pool_bytes(void) {
+  std::lock_guard<std::mutex> lk(g_bytes_mu);
+  return g_pool_bytes;
 }
 void artemis_rt_pool_trim(size_t keep_bytes) {
   std::lock_guard<std::mutex> lk(g_bytes_mu);

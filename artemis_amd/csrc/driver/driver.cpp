@@ -455,6 +455,7 @@ struct artemis_sim_impl {
   void build_mesh();
   void allocate();
   void ensure_unfused();
+  void ensure_ml_flux_arrays();
   void ensure_flux_arrays(bool sparse_ok = false);
   bool flux_ready = false, flux_sparse = false;
   void problem_generator();
@@ -1016,7 +1017,12 @@ void artemis_sim_impl::setup(const char *deck, int nover, const char *const *ove
   ml_fused = ml_fused_possible && !artemis::opt(artemis::OPT_NO_ML_FUSED);
   if (multilevel) edge_ghosts = false; // the block-graph exchange fills all 3^ndim - 1 directions itself
   t_setup = now();
-  if (!use_fused) ensure_unfused();
+  // (the per-task chain's start-of-step copies and dense flux arrays: not on the one-kernel paths -- a refined mesh on
+  //  step_ml_fused allocates flux rows for the blocks that own a coarse-fine face when its first step asks for them, and
+  //  artemis_sim_set_path("unfused") / step_unfused allocate the rest on demand.  On the configs[4] mesh that is a sixth
+  //  of the footprint.)
+  if (!use_fused && !ml_fused) ensure_unfused();
+  else if (ml_fused) ensure_ml_flux_arrays(); // (here, not in the first step: a remesh returns its cache to the device after the build)
   lap("ensure_unfused", t_setup), t_setup = now();
   problem_generator();
   lap("problem_generator", t_setup);
@@ -1558,6 +1564,23 @@ void artemis_sim_impl::ensure_flux_arrays(bool sparse_ok) {
     if (do_viscosity || do_conduction) make(gdflux[d], 4 * ns_gas);
   }
   flux_ready = true, flux_sparse = sparse;
+}
+// step_ml_fused's flux arrays: rows for the blocks that own a coarse-fine face, unless the diffusion fluxes are written for
+// the whole pack (heat conduction, or a pack the viscous-source march does not cover)
+void artemis_sim_impl::ensure_ml_flux_arrays() {
+  const artemis_pack_t p0 = make_pack(base);
+  const bool diffuse0 = do_gas && (do_viscosity || do_conduction);
+  const bool vs0 = diffuse0 && do_viscosity && !do_conduction && ns_gas == 1 && !artemis::opt(artemis::OPT_NO_VISC_SOURCE) &&
+                   artemis_hip_viscous_source_covers(&p0) != 0;
+  ensure_flux_arrays(!diffuse0 || vs0);
+  // ... and everything else a step asks for, NOW: a remesh builds the new state while the old one's released buffers
+  // sit in the allocator's cache and returns what is left to the device afterwards -- a buffer first asked for by the
+  // first step would be a fresh hipMalloc of GBs after every remesh (and its predecessor a hipFree)
+  for (int q = 1; q < 3; ++q) {
+    if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
+    if (!dprim[q].ok()) dprim[q].alloc(nb, 4 * ns_dust, N);
+  }
+  if (vs0 && !gdsum.ok()) gdsum.alloc(nb, 5, N);
 }
 void artemis_sim_impl::ensure_unfused() {
   if (unfused_ready) return;
@@ -3025,13 +3048,7 @@ void artemis_sim_impl::step_ml_fused() {
   tiny_valid = false;
   // (the fine-side faces and their restrictions live in the flux arrays; no u1: 160 B per zone less.  Diffusion fluxes
   //  written for the whole pack -- heat conduction, or a pack the viscous-source march does not cover -- need every row)
-  {
-    const artemis_pack_t p0 = make_pack(base);
-    const bool diffuse0 = do_gas && (do_viscosity || do_conduction);
-    const bool vs0 = diffuse0 && do_viscosity && !do_conduction && ns_gas == 1 && !artemis::opt(artemis::OPT_NO_VISC_SOURCE) &&
-                     artemis_hip_viscous_source_covers(&p0) != 0;
-    ensure_flux_arrays(!diffuse0 || vs0);
-  }
+  ensure_ml_flux_arrays();
   for (int q = 1; q < 3; ++q) {
     if (!gprim[q].ok()) gprim[q].alloc(nb, 6 * ns_gas, N);
     if (!dprim[q].ok()) dprim[q].alloc(nb, 4 * ns_dust, N);
@@ -3663,10 +3680,12 @@ static bool remesh(artemis_sim &h, bool initial, long force_refine_gid = -1, con
   np->reuse_from = nullptr, np->reuse_lookup.clear(); // (the old state goes away)
   release_impl(h.p);
   h.p = std::move(np);
-  // What is left in artemis_rt's buffer cache now belonged to the old mesh and fitted nothing of the new one: the next
-  // remesh re-uses the buffers THIS state releases, never these -- give them back (a mesh that grows by 3 % per remesh
-  // otherwise drags up to the cache limit of stale slabs along)
-  if (!initial) artemis_rt_pool_trim(0);
+  // What is left in artemis_rt's buffer cache now belonged to the old mesh.  It stays there (round 6): the cache's own
+  // limit returns the oldest buffers a few at a time as newer ones arrive.  Returning everything after every remesh
+  // (round 5, ARTEMIS_TRIM_POOL=1) kept the footprint 30 % lower but stalled the device for 1.1 - 1.8 s whenever the
+  // slabs of a whole size class went back at once -- three times in fifteen remeshes of the growing configs[4] mesh,
+  // sixty cycles of work each (scripts/remesh_cycles.py).
+  if (!initial && artemis::opt(artemis::OPT_TRIM_POOL)) artemis_rt_pool_trim(0);
   // counters of leaves that no longer exist are dropped; new leaves start at zero
   std::map<std::tuple<int, int, int, int>, int> keep;
   for (const artemis_host::Leaf &l : h.p->tree_leaves) {

@@ -20,7 +20,7 @@ namespace artemis {
   /* tuning knobs */                                                                                  \
   X(FUSED_KCHUNK) X(CURV_KCHUNK) X(VISC_KCHUNK) X(STAGE2D_ROWS) X(STAGE2D_RGRID) X(FUSED_NO_SWIZZLE)  \
   /* memory */                                                                                        \
-  X(NO_POOL) X(POOL_GB) X(POISON) X(DENSE_FLUX)
+  X(NO_POOL) X(POOL_GB) X(TRIM_POOL) X(POISON) X(DENSE_FLUX)
 
 enum Opt {
 #define X(name) OPT_##name,

@@ -225,6 +225,8 @@ def _declare(L):
     L.artemis_sim_last_remesh.restype = None
     L.artemis_rt_device_bytes.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int]
     L.artemis_rt_device_bytes.restype = None
+    L.artemis_rt_pool_bytes.restype = C.c_size_t
+    L.artemis_rt_pool_bytes.argtypes = []
     L.artemis_sim_stage_kernel.argtypes = [vp]
     L.artemis_sim_stage_kernel.restype = C.c_char_p
     L.artemis_sim_set_path.argtypes = [vp, C.c_char_p]
@@ -336,6 +338,10 @@ class Simulation:
         cur, peak = C.c_size_t(0), C.c_size_t(0)
         self.L.artemis_rt_device_bytes(C.byref(cur), C.byref(peak), int(reset_peak))
         return cur.value, peak.value
+
+    def cached_bytes(self):
+        """bytes of device_bytes()[0] that sit free in the library's buffer cache (artemis_rt_pool_trim(0) returns them)"""
+        return self.L.artemis_rt_pool_bytes()
     last_wall_seconds = property(lambda s: s.L.artemis_sim_last_wall_seconds(s.h))
 
     @property

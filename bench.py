@@ -609,6 +609,8 @@ def main():
             "over_cycle_mean": (sum(e["ms"] for e in big) / len(big) / remesh_leg["cycle_ms"]) if big else None,
             "over_cycle_max": (max(e["ms"] for e in big) / remesh_leg["cycle_ms"]) if big else None,
             "device_bytes_now": cur_b, "device_bytes_peak": peak_b, "zones_now": sim.total_zones,
+            "device_bytes_cached": sim.cached_bytes(),  # (of device_bytes_now: free buffers the library's cache holds for the next remesh)
+            "bytes_per_zone_live": (cur_b - sim.cached_bytes()) / max(1, sim.total_zones),
             "bytes_per_zone_now": cur_b / max(1, sim.total_zones), "bytes_per_zone_peak": peak_b / max(1, min(zones_at)),
             "what": "28 cycles after the timed region; five batches of injected +1 tags, the merges the criterion orders five "
                     "cycles after each"}

@@ -66,6 +66,8 @@
  *    FUSED_KCHUNK, CURV_KCHUNK, VISC_KCHUNK   planes per x3 chunk of the three march kernels
  *    STAGE2D_ROWS, STAGE2D_RGRID, FUSED_NO_SWIZZLE
  *  memory
+ *    TRIM_POOL       ... and, set, returns what is left in it to the device after every remesh (30 % less footprint; stalls of
+ *                    1 - 2 s when a whole size class of slabs goes back at once)
  *    NO_POOL, POOL_GB=n   the standalone driver enables artemis_rt's buffer cache for adaptive meshes with this limit
  *                    (default 64) / not at all; library hosts: artemis_rt_pool_limit (artemis_rt.h)
  *    POISON          fresh device memory from artemis_rt_malloc holds NaN patterns (a read of something never written

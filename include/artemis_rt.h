@@ -34,6 +34,8 @@ void artemis_rt_free(void *p);
  * which builds the new mesh next to what it keeps of the old one, costs. */
 void artemis_rt_pool_limit(size_t limit_bytes);
 void artemis_rt_device_bytes(size_t *current, size_t *peak, int reset_peak);
+/* ... of which cached (free, ready to be handed out again): what a host could get back with artemis_rt_pool_trim(0) */
+size_t artemis_rt_pool_bytes(void);
 /* give cached buffers back to the device until at most keep_bytes of them are left (oldest first); the driver calls it
  * with 0 once the initial mesh is built (the smaller meshes of the initial refinement loop leave buffers nobody asks
  * for again) */

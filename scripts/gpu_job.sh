@@ -75,3 +75,10 @@ timeout 2400 python -m pytest tests/test_parity_fused.py tests/test_driver_gpu.p
 timeout 600 python bench.py --no-cpu-baseline --steps 100 2>/dev/null > gpurun_out/${tag}_bench_line.json; python3 -c "
 import json; d=json.load(open('gpurun_out/${tag}_bench_line.json')); print('headline', d['value'], d['roofline']['frac'], 'emulation', d['config'].get('overlap_emulation_zcps'), 'dropin', {k: v for k, v in d.get('dropin', {}).items() if k.startswith('fused') or k == 'per_task'})"
 fi
+if has amrfull; then
+timeout 2400 python -m pytest tests/test_adaptive.py tests/test_multilevel.py -m gpu -q 2>&1 | tail -6 > gpurun_out/${tag}_tests_amr.txt; grep -E "passed|failed" gpurun_out/${tag}_tests_amr.txt
+timeout 1500 python bench.py --workload disk_amr --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_full_line.json; python3 -c "
+import json; d=json.load(open('gpurun_out/${tag}_disk_amr_full_line.json')); r=d['remesh']; b=r['batched']; print('value', d['value'], 'frac', d['roofline']['frac'], 'single ms', r['ms_mean'], 'over cycle', r['remesh_over_cycle'], 'batched ms mean/max', b['ms_mean'], b['ms_max'], 'over cycle', b['over_cycle_mean'], 'B/zone now/peak', b['bytes_per_zone_now'], b['bytes_per_zone_peak'], 'build share', b['build_state_share'])"
+timeout 1500 python bench.py --workload disk_amr --steps 24 --warmup 5 --no-cpu-baseline --no-remesh-leg --remesh-in-timed-region 2>/dev/null > gpurun_out/${tag}_disk_amr_remesh_in_timed_region_line.json; python3 -c "
+import json; d=json.load(open('gpurun_out/${tag}_disk_amr_remesh_in_timed_region_line.json')); r=d['remesh_in_timed_region']; print('with remeshes in the timed region', d['value'], 'cycle ms', r['cycle_ms_with_them'], 'events', [(e['created'], e['destroyed'], round(e['ms'],1)) for e in r['events']])"
+fi

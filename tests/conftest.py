@@ -57,7 +57,7 @@ OPTION_NAMES = ["NO_TUNED", "TUNED_2D", "NO_STAGE2D", "NO_FUSED_CURV", "NO_CURV_
                 "NO_DISTANCE_TABLE", "NO_FLAT_RANGES", "FULL_REMESH", "NO_REDO", "NO_TINY_HINT", "NO_GRAPH", "SYNC_LOOP",
                 "FORCE_OVERLAP", "LOOPBACK_COMM", "WAIT_SPIN_LIMIT", "TEST_SHELL_TARGET_BUMP", "HOST_THREADS", "SETUP_TIMING",
                 "AMR_DEBUG", "FUSED_KCHUNK", "CURV_KCHUNK", "VISC_KCHUNK", "STAGE2D_ROWS", "STAGE2D_RGRID", "FUSED_NO_SWIZZLE",
-                "NO_POOL", "POOL_GB", "POISON", "DENSE_FLUX"]
+                "NO_POOL", "POOL_GB", "TRIM_POOL", "POISON", "DENSE_FLUX"]
 
 
 @pytest.fixture(autouse=True)

@@ -1232,6 +1232,7 @@ void artemis_rt_device_bytes(size_t *current, size_t *peak, int) {
 }
 void artemis_rt_free(void *p) { std::free(p); }
 void artemis_rt_pool_trim(size_t) {}
+size_t artemis_rt_pool_bytes(void) { return 0; }
 void artemis_rt_pool_limit(size_t) {}
 void *artemis_rt_malloc_host(size_t n) { return std::calloc(1, n ? n : 8); }
 void artemis_rt_free_host(void *p) { std::free(p); }
