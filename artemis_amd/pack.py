@@ -428,13 +428,16 @@ class MeshBlockPack:
 
     def stage_fused(self, gam0, gam1, beta_dt, bdt, prim_in, prim_u1, prim_out, cons_out=None,
                     pcm=False, cfl=0.0, dt_dev=None, region=0, shell_faces=0, tiny_in=None, tiny_out=None,
-                    tiny_clear=None, outflow_faces=0):
+                    tiny_clear=None, outflow_faces=0, outflow_faces_by_block=None):
         a = capi.StageArgs()
         a.gam0, a.gam1, a.beta_dt, a.bdt, a.pcm = gam0, gam1, beta_dt, bdt, int(pcm)
         a.prim_in, a.prim_u1, a.prim_out, a.cons_out = prim_in, prim_u1, prim_out, cons_out
         a.cfl, a.dt_dev, a.region, a.shell_faces = cfl, dt_dev, region, shell_faces
         a.tiny_in, a.tiny_out, a.tiny_clear = tiny_in, tiny_out, tiny_clear  # device words (int addresses) or None
         a.outflow_faces = outflow_faces  # bit f: do not read the ghost zones behind (outflow) face f
+        if outflow_faces_by_block is not None:  # ... one mask per block (a host array)
+            self._ofb = (C.c_ubyte * len(outflow_faces_by_block))(*outflow_faces_by_block)
+            a.outflow_faces_by_block = C.cast(self._ofb, C.c_void_p)
         self._call(self.L.artemis_hip_stage_fused, C.byref(a))
 
     def halo_count(self, face):

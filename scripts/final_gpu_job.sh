@@ -28,6 +28,9 @@ timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust -
 timeout 1200 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph_smr
 timeout 1800 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_amr
 fi
+if has pmcsmr; then
+timeout 1700 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph_smr
+fi
 if has sq; then
 # ---- SQ counters: the headline kernel alone (no drop-in legs, no overlap emulation: 256^3 launches only), the disk march
 PMC_SQ_GROUPS=0,1 PMC_SQ_RECORD=${tag} timeout 600 python3 scripts/pmc_sq.py ${tag} -- bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-dropin --no-overlap-emulation > gpurun_out/${tag}_pmc_sq.txt 2>&1
@@ -60,14 +63,16 @@ prof() { # prof <name> <program args ...>
   timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_${name}_prof -o p --output-format csv -- python3 "$@" > gpurun_out/${tag}_${name}_prof.log 2>&1
   find gpurun_out/${tag}_${name}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_${name}_kernel_stats.csv
 }
-prof bench bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-dropin --no-overlap-emulation
-prof bench_default bench.py --steps 200 --warmup 10 --no-cpu-baseline
-prof cfg3 bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50
-prof cfg3_1024 bench.py --workload ssheet_dust --n 1024 --no-cpu-baseline --steps 100
-prof disk_sph bench.py --workload disk_sph --no-cpu-baseline --steps 50
-prof smr_cart scripts/smr_timing.py 10
-prof smr_sph scripts/smr_timing.py 10 sph problem/polytropic_index=1.40 gas/de_switch=1e-2
-prof amr scripts/amr_timing.py 5 128 128 16 16 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2
+# (PROF_LIST selects a subset: a gpurun call is limited to an hour)
+wantp() { case " ${PROF_LIST:-bench bench_default cfg3 cfg3_1024 disk_sph smr_cart smr_sph amr} " in *" $1 "*) return 0;; *) return 1;; esac; }
+wantp bench && prof bench bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-dropin --no-overlap-emulation
+wantp bench_default && prof bench_default bench.py --steps 200 --warmup 10 --no-cpu-baseline
+wantp cfg3 && prof cfg3 bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50
+wantp cfg3_1024 && prof cfg3_1024 bench.py --workload ssheet_dust --n 1024 --no-cpu-baseline --steps 100
+wantp disk_sph && prof disk_sph bench.py --workload disk_sph --no-cpu-baseline --steps 50
+wantp smr_cart && prof smr_cart scripts/smr_timing.py 10
+wantp smr_sph && prof smr_sph scripts/smr_timing.py 10 sph problem/polytropic_index=1.40 gas/de_switch=1e-2
+wantp amr && prof amr scripts/amr_timing.py 5 128 128 16 16 gas/refine_thr=2.0 parthenon/mesh/x3min=-0.2 parthenon/mesh/x3max=0.2
 rm -f gpurun_out/${tag}_*prof/*kernel_trace.csv gpurun_out/${tag}_*prof/*/*kernel_trace.csv
 fi
 if has timings; then

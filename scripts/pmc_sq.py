@@ -4,6 +4,17 @@ Runs `rocprofv3 --pmc <group> --kernel-trace` once per counter group (never with
 per-kernel means for kernels whose name contains 'stage' (or one of the comma-separated PMC_SQ_KERNELS)."""
 import collections, csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def library_identity(scope):
+    """bench.library_identity(scope), asked of a SHORT-LIVED CHILD: this script starts the profiled program through
+    rocprofv3, which replaces itself with it -- a hop the GPU boxes refuse once the starting process tree has had the HIP
+    runtime loaded, which dlopen of libartemis_hip.so does."""
+    import subprocess
+    out = subprocess.check_output([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; print(bench.library_identity(%r))" % (ROOT, scope)],
+                                  stderr=subprocess.DEVNULL)
+    return out.decode().strip().splitlines()[-1]
+
 GROUPS = [["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU"],
           ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"],
           ["SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT"],
@@ -42,7 +53,6 @@ if os.environ.get("PMC_SQ_RECORD"):
     # the record bench.py quotes as roofline.fp64_issue (only while the kernel sources are unchanged): mean VALU
     # wave-instructions per launch over the headline stage kernels (non-curvilinear, non-flux instantiations)
     sys.path.insert(0, ROOT)
-    from bench import library_identity
     ks = {k: v for k, v in res.items() if "stage_fused_kernel" in k and "SQ_INSTS_VALU" in v}
     if ks:
         rec = {"library_identity": library_identity("fused"), "command": " ".join(prog), "env": {},

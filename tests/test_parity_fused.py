@@ -397,3 +397,58 @@ def test_outflow_faces_are_not_read(hiplib, nx, ng, recon, tiny):
     mb.stage_fused(0.0, 1.0, 1e-4, 1e-4, A[1], A[1], B[1], outflow_faces=mask)
     mb.stage_fused(0.0, 1.0, 1e-4, 1e-4, A[1], A[1], Cc[1], outflow_faces=mask & ~2)
     assert not torch.equal(B[0][0][I][0], Cc[0][0][I][0])
+
+
+def test_outflow_faces_block_by_block(hiplib):
+    """artemis_stage_args_t.outflow_faces_by_block: one mask per block of the pack.  Two blocks with different states;
+    block 0's six faces are all in its mask, block 1's mask leaves its upper x3 face out (a neighbour would fill those
+    ghost zones).  With NaN in every ghost zone of block 0 and in every masked ghost zone of block 1 -- its upper x3
+    ghost planes hold the outflow values -- both blocks equal their oracle's stage with outflow conditions; with NaN in
+    block 1's upper x3 ghost planes as well only block 1 changes: the masks act block by block."""
+    from artemis_amd.pack import MeshBlockPack
+    nx, ng = (40, 20, 36), 2
+    kw = dict(ng=ng, reconstruct="plm", riemann="hllc", gamma=1.4, dfloor=1e-10, siefloor=1e-10)
+    los, his = [(-1.0, -0.7, 0.1), (0.2, -0.3, 1.3)], [(1.0, 0.9, 1.3), (2.2, 1.3, 2.5)]
+    os_ = []
+    for q in range(2):
+        o = Oracle(nx, los[q], his[q], cfl=0.3, bc=("outflow",) * 6, integrator="rk2", **kw)
+        random_state(o, np.random.default_rng(40 + q), mach=1.0, contrast=30.0)
+        o.ApplyBoundaryConditions()
+        o.PrimToCons()
+        os_.append(o)
+    mb = MeshBlockPack(2, nx, los, his, with_fluxes=False, **kw)
+    for q in range(2):
+        mb.gas_prim[q].copy_(torch.from_numpy(os_[q].gprim.copy()))
+    o = os_[0]
+    inner = torch.zeros(mb.gas_prim[0].shape[1:], dtype=torch.bool, device="cuda")
+    inner[o.ks:o.ke + 1, o.js:o.je + 1, o.is_:o.ie + 1] = True
+    upper3 = torch.zeros_like(inner)
+    upper3[o.ke + 1:, :, :] = True  # (the upper x3 ghost planes over the entire x1 / x2 extent)
+    start = mb.gas_prim.clone()
+    B, C2 = mb.new_prim_buffer("B"), mb.new_prim_buffer("C")
+    dt = 1.0e-4
+    for oo in os_:
+        oo.DeepCopyConservedData()
+    I = np.s_[:, o.ks:o.ke + 1, o.js:o.je + 1, o.is_:o.ie + 1]
+    want = []
+    for oo in os_:
+        oo.CalculateFluxes(0, False)
+        oo.ApplyUpdate(0.0, 1.0, dt)
+        oo.FluxSource(dt, 0)
+        oo.SetAuxillaryFields()
+        oo.ConsToPrim()
+        want.append(oo.gprim[I][[0, 1, 2, 3, 5]])
+    keep = [0, 1, 2, 3, 5]
+    # run 1: block 1's upper x3 ghost planes keep their (outflow) values
+    mb.gas_prim[0][:, ~inner] = float("nan")
+    mb.gas_prim[1][:, ~inner & ~upper3] = float("nan")
+    mb.stage_fused(0.0, 1.0, dt, dt, mb.pack.gas.prim, mb.pack.gas.prim, B[1], outflow_faces_by_block=[63, 31])
+    for q in range(2):
+        same(B[0][q][I][keep], want[q], f"block {q}")
+    # run 2: NaN there too -- block 1 reads them (bit 5 is not in its mask), block 0 is untouched by that
+    mb.gas_prim.copy_(start)
+    mb.gas_prim[0][:, ~inner] = float("nan")
+    mb.gas_prim[1][:, ~inner] = float("nan")
+    mb.stage_fused(0.0, 1.0, dt, dt, mb.pack.gas.prim, mb.pack.gas.prim, C2[1], outflow_faces_by_block=[63, 31])
+    same(C2[0][0][I][keep], want[0], "block 0 with every mask bit")
+    assert not torch.equal(C2[0][1][I][0], B[0][1][I][0])
