@@ -55,7 +55,9 @@ def _closure(path, seen=None):
     """The file and every quoted header it reaches (searched like the compiler does: next to the including file, then
     csrc/, csrc/driver/, include/).  System headers (<...>) belong to the image and are covered by the compiler version."""
     seen = {} if seen is None else seen
-    path = os.path.realpath(path)
+    # (abspath, not realpath: the GPU boxes reach the tree through a symlink, and a hash that saw the link's target here
+    #  and the link there made every box recompile a library that was up to date)
+    path = os.path.abspath(path)
     if path in seen:
         return seen
     txt = open(path, "rb").read()

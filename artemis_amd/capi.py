@@ -311,6 +311,7 @@ EXPORTS_HIP = [
     "artemis_hip_metric_fill", "artemis_hip_external_gravity", "artemis_hip_nbody_gravity", "artemis_hip_nbody_force_scratch",
     "artemis_hip_nbody_force_sums", "artemis_hip_timestep_all", "artemis_hip_redo_scratch_bytes", "artemis_hip_rotating_frame_force",
     "artemis_hip_ml_exchange", "artemis_hip_ml_flux_correction", "artemis_hip_ml_restrict_halos", "artemis_hip_ml_prolongate",
+    "artemis_hip_ml_floor_ghosts",
     "artemis_hip_ml_face_fluxes", "artemis_hip_ml_stage_fixup", "artemis_hip_plm_table_count", "artemis_hip_plm_table_fill",
     "artemis_hip_drag_source", "artemis_hip_cooling_source", "artemis_hip_cooling_table_fill",
     "artemis_hip_stage_general", "artemis_hip_stage_general_variant", "artemis_hip_stage_epilogue", "artemis_hip_stage_epilogue_cons", "artemis_hip_stage_finish", "artemis_hip_stage_finish_cells", "artemis_hip_amr_block_maxima", "artemis_hip_restrict_average",

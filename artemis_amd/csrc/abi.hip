@@ -601,6 +601,14 @@ int artemis_hip_ml_prolongate(const artemis_pack_t *p, const artemis_ml_pack_t *
   artemis::launch_ml_prolongate(artemis::make_pack_view(*p), *ml, boxes_dev, nboxes, S(stream));
   return after_launch("ml_prolongate");
 }
+int artemis_hip_ml_floor_ghosts(const artemis_pack_t *p, const int *blocks_dev, int nblocks, void *stream) {
+  if (int rc = validate(p)) return rc;
+  if (nblocks < 0 || (nblocks > 0 && !blocks_dev)) return fail(ARTEMIS_HIP_EINVAL, "multilevel: bad block list");
+  if ((p->gas.nspecies && !p->gas.prim) || (p->dust.nspecies && !p->dust.prim))
+    return fail(ARTEMIS_HIP_EINVAL, "multilevel: primitive tables are required");
+  artemis::launch_ml_floor_ghosts(artemis::make_pack_view(*p), blocks_dev, nblocks, S(stream));
+  return after_launch("ml_floor_ghosts");
+}
 
 long artemis_hip_plm_table_count(const artemis_pack_t *p) {
   if (!p) return 0;

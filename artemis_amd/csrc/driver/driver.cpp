@@ -238,6 +238,7 @@ struct artemis_sim_impl {
     DevArr ops_fx, ops_fxu;       // flux correction: packs + direct | unpacks
     DevArr fine_boxes, fix_cells; // one-kernel stages: fine-side faces to solve | coarse zones to redo (artemis_hip.h)
     DevArr restrict_blocks, boxes;
+    DevArr floor_blocks;          // blocks whose ghost zones took restricted or prolongated values (artemis_hip_ml_floor_ghosts)
     DevBuf gsend, grecv, fsend, frecv;
     std::vector<artemis_msg_t> gmsgs, fmsgs;
     std::vector<int> bc_coarse;
@@ -251,7 +252,7 @@ struct artemis_sim_impl {
   struct {
     std::vector<PeerMsg> gmsgs, fmsgs;
     std::vector<artemis_ml_op_t> a, u, b, fx, fxu;
-    std::vector<int> restrict_blocks;
+    std::vector<int> restrict_blocks, floor_blocks;
     std::vector<artemis_ml_box_t> boxes;
     std::vector<artemis_ml_face_box_t> fine_boxes;
     std::vector<artemis_ml_fix_cell_t> fix_cells;
@@ -1328,6 +1329,18 @@ void artemis_sim_impl::build_mesh_multilevel() {
       bx.block = local_of[bx.block];
       ml_host.boxes.push_back(bx);
     }
+  // blocks next to a level boundary: a finer neighbour's restricted zones (direct or unpacked) or a prolongation landed
+  // in their ghost zones -- the one-kernel path floors those like the reference's PrimToCons (fill_ghosts_multilevel)
+  {
+    std::vector<unsigned char> at_level_boundary(nb, 0);
+    for (int b : ml_host.restrict_blocks) at_level_boundary[b] = 1;
+    for (const auto *list : {&ml_host.a, &ml_host.u})
+      for (const artemis_ml_op_t &o : *list)
+        if (o.kind == ARTEMIS_ML_FROM_FINER && o.dst_block >= 0) at_level_boundary[o.dst_block] = 1;
+    ml_host.floor_blocks.clear();
+    for (int b = 0; b < nb; ++b)
+      if (at_level_boundary[b]) ml_host.floor_blocks.push_back(b);
+  }
   // physical conditions on the coarse buffers: only where a prolongation stencil can reach them
   ml.bc_coarse.assign(6 * nb, ARTEMIS_BC_NONE);
   for (int b : ml_host.restrict_blocks)
@@ -1367,6 +1380,7 @@ void artemis_sim_impl::allocate_multilevel() {
   ml.ops_fx.upload(ml_host.fx), ml.ops_fxu.upload(ml_host.fxu);
   ml.fine_boxes.upload(ml_host.fine_boxes), ml.fix_cells.upload(ml_host.fix_cells);
   ml.restrict_blocks.upload(ml_host.restrict_blocks), ml.boxes.upload(ml_host.boxes);
+  ml.floor_blocks.upload(ml_host.floor_blocks);
   ml.gsend.alloc(ml_host.gsend_n), ml.grecv.alloc(ml_host.grecv_n), ml.fsend.alloc(ml_host.fsend_n), ml.frecv.alloc(ml_host.frecv_n);
   auto address = [](const std::vector<PeerMsg> &in, double *sbase, double *rbase, std::vector<artemis_msg_t> &out) {
     out.clear();
@@ -1447,6 +1461,11 @@ void artemis_sim_impl::fill_ghosts_multilevel(int prim_idx) {
   }
   CK(artemis_hip_apply_bc(&p, bc_eff.data(), &bp, stream), "apply_bc");
   if (ml_fused && has_ic) owner.ic_filled = true;
+  // the reference's PrimToCons floors every ghost zone behind the fill (fill_derived.cpp:227-262).  Same-level copies of
+  // floored zones are floored; restricted averages and prolongations are not always (a rounding below a floor all eight
+  // zones sit on, three limited slopes adding up): the blocks that took either, one launch
+  if (ml_fused && !artemis::opt(artemis::OPT_NO_ML_FLOOR))
+    CK(artemis_hip_ml_floor_ghosts(&p, static_cast<const int *>(ml.floor_blocks.p), ml.floor_blocks.n, stream), "ml floor ghosts");
 }
 
 // SendBoundBufs<flxcor_send> / ReceiveFluxCorrections / SetFluxCorrections (artemis_driver.cpp:196-202)
@@ -2446,7 +2465,7 @@ void artemis_sim_impl::release_for_adoption() {
   plmtab.release();
   ml.gcoarse.release(), ml.dcoarse.release(), ml.cgeom.release(), ml.cmetric.release();
   ml.ops_a.release(), ml.ops_u.release(), ml.ops_b.release(), ml.ops_fx.release(), ml.ops_fxu.release();
-  ml.fine_boxes.release(), ml.fix_cells.release(), ml.restrict_blocks.release(), ml.boxes.release();
+  ml.fine_boxes.release(), ml.fix_cells.release(), ml.restrict_blocks.release(), ml.boxes.release(), ml.floor_blocks.release();
   ml.gsend.release(), ml.grecv.release(), ml.fsend.release(), ml.frecv.release();
 }
 

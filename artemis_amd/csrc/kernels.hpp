@@ -118,4 +118,5 @@ void launch_ml_flux_correction(const PackView &P, const artemis_ml_op_t *ops, in
 void launch_ml_restrict_halos(const PackView &P, const artemis_ml_pack_t &ml, const int *blocks, int nblocks, hipStream_t s);
 void launch_ml_prolongate(const PackView &P, const artemis_ml_pack_t &ml, const artemis_ml_box_t *boxes, int nboxes,
                           hipStream_t s);
+void launch_ml_floor_ghosts(const PackView &P, const int *blocks, int nblocks, hipStream_t s);
 } // namespace artemis

@@ -195,6 +195,35 @@ __global__ __launch_bounds__(256) void ml_prolongate_kernel(const MlView M, cons
   }
 }
 
+// ---- PrimToCons's primitive floors on the ghost zones of the blocks next to a level boundary ----------------------
+// The reference converts every zone of every block after the boundary fill (fill_derived.cpp:227, :245, :262) and that
+// conversion floors gas density, gas sie and dust density where they sit.  The one-kernel stages keep no conserved ghost
+// zones and skip the conversion; same-level copies of floored zones are floored, but a restricted average can round one
+// ulp below a floor its eight zones sit on and the sum of three limited slopes of a prolongation can undershoot the lowest
+// neighbour.  This pass applies the floors to the ghost zones of the listed blocks, behind the physical conditions (which
+// read the zones as the fill left them, like the reference).  Reads alone almost everywhere: stored only where a floor acts.
+__global__ __launch_bounds__(256) void ml_floor_ghosts_kernel(const PackView P, const int *__restrict__ blocks) {
+  const int b = blocks[blockIdx.y];
+  const long n = static_cast<long>(P.ni) * P.nj * P.nk;
+  const long c = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const int i = c % P.ni, j = (c / P.ni) % P.nj, k = c / (static_cast<long>(P.ni) * P.nj);
+  if (i >= P.is && i <= P.ie && j >= P.js && j <= P.je && k >= P.ks && k <= P.ke) return;
+  const int nsg = P.gas.ns, nsd = P.dust.ns;
+  for (int m = 0; m < nsg; ++m) {
+    double *rho = P.gas.prim[b * 6 * nsg + m], *se = P.gas.prim[b * 6 * nsg + 5 * nsg + m];
+    const double w_d = rho[c], w_s = se[c];
+    // (`!(w > floor)`: the reference's `(w > floor) ? w : floor`, NaN going to the floor as well)
+    if (!(w_d > P.gas.dfloor)) rho[c] = P.gas.dfloor;
+    if (!(w_s > P.gas.siefloor)) se[c] = P.gas.siefloor;
+  }
+  for (int m = 0; m < nsd; ++m) {
+    double *rho = P.dust.prim[b * 4 * nsd + m];
+    const double w_d = rho[c];
+    if (!(w_d > P.dust.dfloor)) rho[c] = P.dust.dfloor;
+  }
+}
+
 // ---- flux correction: RestrictAverage<GEOM, el = F_dir> (restriction.hpp:57-112) --------------------------
 // v-th flux array of direction d of block b: gas cons fluxes (6 ns), the pressure flux (ns), the diffusion
 // fluxes (4 ns, when the caller has them), dust fluxes (4 ns)
@@ -305,6 +334,12 @@ void launch_ml_prolongate(const PackView &P, const artemis_ml_pack_t &ml, const 
                           hipStream_t s) {
   if (nboxes <= 0) return;
   hipLaunchKernelGGL(ml_prolongate_kernel, dim3(nboxes), dim3(256), 0, s, make_ml_view(P, ml), boxes);
+}
+
+void launch_ml_floor_ghosts(const PackView &P, const int *blocks, int nblocks, hipStream_t s) {
+  if (nblocks <= 0) return;
+  const long n = static_cast<long>(P.ni) * P.nj * P.nk;
+  hipLaunchKernelGGL(ml_floor_ghosts_kernel, dim3((n + 255) / 256, nblocks), dim3(256), 0, s, P, blocks);
 }
 
 } // namespace artemis

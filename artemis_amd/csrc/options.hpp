@@ -13,7 +13,7 @@ namespace artemis {
   X(NO_ML_FUSED) X(NO_EPILOGUE) X(NO_TILED_FLUX) X(NO_VISC_SOURCE) X(NBODY_TASK) X(NBODY_GENERAL)    \
   X(NO_PLM_TABLE) X(NO_DISTANCE_TABLE) X(NO_FLAT_RANGES) X(FULL_REMESH)                              \
   /* exactness machinery (measuring what it costs) */                                                \
-  X(NO_REDO) X(NO_TINY_HINT)                                                                         \
+  X(NO_REDO) X(NO_TINY_HINT) X(NO_ML_FLOOR)                                                                   \
   /* host loop */                                                                                    \
   X(NO_GRAPH) X(SYNC_LOOP) X(FORCE_OVERLAP) X(LOOPBACK_COMM) X(WAIT_SPIN_LIMIT) X(TEST_SHELL_TARGET_BUMP)  \
   X(HOST_THREADS) X(SETUP_TIMING) X(AMR_DEBUG)                                                        \

@@ -55,6 +55,10 @@
  *                    vanishing velocities (the hand-scheduled divisions are then NOT exact there: DESIGN.md section 4
  *                    states the bound) -- for measuring what the mechanism costs
  *    NO_TINY_HINT    ... and the per-stage hint words that let a plane skip the IEEE path
+ *    NO_ML_FLOOR     host driver, refined meshes on the one-kernel stages: leaves out artemis_hip_ml_floor_ghosts (ghost
+ *                    zones that took restricted or prolongated values then keep what rounding left below a floor, which
+ *                    the reference's PrimToCons would have floored: NOT bit-exact where a floor binds next to a level
+ *                    boundary) -- for measuring what the pass costs
  *  host loop
  *    NO_GRAPH        the driver launches every stage kernel itself instead of replaying a captured hipGraph of one step
  *    SYNC_LOOP       the time step comes back to the host every cycle (no device-resident dt)
@@ -740,6 +744,13 @@ int artemis_hip_ml_restrict_halos(const artemis_pack_t *p, const artemis_ml_pack
  * covered by each box (boxes_dev: DEVICE array; coarse index cs + q <-> fine index s + 2 q). */
 int artemis_hip_ml_prolongate(const artemis_pack_t *p, const artemis_ml_pack_t *ml, const artemis_ml_box_t *boxes_dev,
                               int nboxes, void *stream);
+/* The primitive floors of the PrimToCons that follows the boundary fill in the reference (fill_derived.cpp:227, :245,
+ * :262: gas density, gas sie, dust density) on every ghost zone of blocks_dev[0..nblocks).  A caller that runs
+ * artemis_hip_prim_to_cons over the whole block after the fill does not need it; the one-kernel stages keep no conserved
+ * ghost zones and call this instead, last of the fill, for the blocks that took restricted or prolongated values: a
+ * restricted average can round an ulp below a floor all its zones sit on, the three limited slopes of a prolongation can
+ * add up to less than the lowest neighbour.  Zones above the floors are read, not written. */
+int artemis_hip_ml_floor_ghosts(const artemis_pack_t *p, const int *blocks_dev, int nblocks, void *stream);
 
 /* ---- one-kernel stages on a refined mesh: flux correction as a thin fix-up ------------------------
  * The reference corrects the coarse side of every coarse-fine face between CalculateFluxes and ApplyUpdate

@@ -52,7 +52,7 @@ def one_openmp_thread():
     g.omp_set_num_threads(n)
 
 
-OPTION_NAMES = ["NO_TUNED", "TUNED_2D", "NO_STAGE2D", "NO_FUSED_CURV", "NO_CURV_MARCH", "NO_CURV_DUST", "NO_CURV_DUST_MARCH", "NO_DRAG_IN_MARCH", "NO_STRAT_IN_KERNEL", "NO_CART_MARCH", "NO_IC_IN_SHELL", "NO_IC_SKIP",
+OPTION_NAMES = ["NO_TUNED", "TUNED_2D", "NO_STAGE2D", "NO_FUSED_CURV", "NO_CURV_MARCH", "NO_CURV_DUST", "NO_CURV_DUST_MARCH", "NO_DRAG_IN_MARCH", "NO_STRAT_IN_KERNEL", "NO_CART_MARCH", "NO_IC_IN_SHELL", "NO_IC_SKIP", "NO_ML_FLOOR",
                 "NO_ML_FUSED", "NO_EPILOGUE", "NO_TILED_FLUX", "NO_VISC_SOURCE", "NBODY_TASK", "NBODY_GENERAL", "NO_PLM_TABLE",
                 "NO_DISTANCE_TABLE", "NO_FLAT_RANGES", "FULL_REMESH", "NO_REDO", "NO_TINY_HINT", "NO_GRAPH", "SYNC_LOOP",
                 "FORCE_OVERLAP", "LOOPBACK_COMM", "WAIT_SPIN_LIMIT", "TEST_SHELL_TARGET_BUMP", "HOST_THREADS", "SETUP_TIMING",

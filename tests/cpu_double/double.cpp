@@ -1093,6 +1093,32 @@ int artemis_hip_ml_prolongate(const artemis_pack_t *p, const artemis_ml_pack_t *
   }
   return 0;
 }
+int artemis_hip_ml_floor_ghosts(const artemis_pack_t *p, const int *blocks, int nblocks, void *) {
+  // PrimToCons's primitive floors (fill_derived.cpp:227, :245, :262) on the ghost zones of the listed blocks
+  const int ndim = (p->nx3 > 1) ? 3 : ((p->nx2 > 1) ? 2 : 1), g = p->nghost;
+  const int ni = p->nx1 + 2 * g, nj = (ndim > 1) ? p->nx2 + 2 * g : 1, nk = (ndim > 2) ? p->nx3 + 2 * g : 1;
+  const int lo[3] = {g, ndim > 1 ? g : 0, ndim > 2 ? g : 0}, hi[3] = {g + p->nx1 - 1, lo[1] + p->nx2 - 1, lo[2] + p->nx3 - 1};
+  const int nsg = p->gas.nspecies, nsd = p->dust.nspecies;
+  for (int q = 0; q < nblocks; ++q) {
+    const int b = blocks[q];
+    for (int k = 0; k < nk; ++k)
+      for (int j = 0; j < nj; ++j)
+        for (int i = 0; i < ni; ++i) {
+          if (i >= lo[0] && i <= hi[0] && j >= lo[1] && j <= hi[1] && k >= lo[2] && k <= hi[2]) continue;
+          const size_t c = (static_cast<size_t>(k) * nj + j) * ni + i;
+          for (int n = 0; n < nsg; ++n) {
+            Real &w_d = p->gas.prim[b * 6 * nsg + n][c], &w_s = p->gas.prim[b * 6 * nsg + 5 * nsg + n][c];
+            w_d = (w_d > p->gas.dfloor) ? w_d : p->gas.dfloor;
+            w_s = (w_s > p->gas.siefloor) ? w_s : p->gas.siefloor;
+          }
+          for (int n = 0; n < nsd; ++n) {
+            Real &w_d = p->dust.prim[b * 4 * nsd + n][c];
+            w_d = (w_d > p->dust.dfloor) ? w_d : p->dust.dfloor;
+          }
+        }
+  }
+  return 0;
+}
 int artemis_hip_ml_flux_correction(const artemis_pack_t *p, const artemis_ml_op_t *ops, int nops, double *sbuf, const double *rbuf,
                                    void *) {
   MlHost H(p, nullptr);

@@ -46,6 +46,23 @@ def test_the_binary_is_the_working_tree():
     assert build.verify(L) == build.tree_sha()
 
 
+def test_object_hashes_do_not_depend_on_how_the_tree_is_reached(tmp_path):
+    """The GPU boxes reach the checkout through a symlink (/root/repo -> a scratch directory).  An object hash that saw the
+    link in one place and its target in another called every object stale there, and every box recompiled an up-to-date
+    library (round 6, four minutes of each call): through a symlinked root nothing is stale and the hashes are the same."""
+    import subprocess
+    import sys
+    from artemis_amd import build
+    link = tmp_path / "checkout"
+    os.symlink(ROOT, link)
+    code = ("import sys, json; sys.path.insert(0, %r); from artemis_amd import build; "
+            "print(json.dumps([build.stale_objects(), build.object_hashes(), build.tree_sha()]))" % str(link))
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=str(tmp_path)).decode().strip().splitlines()[-1]
+    import json
+    stale, hashes, tree = json.loads(out)
+    assert stale == [] and hashes == build.object_hashes() and tree == build.tree_sha()
+
+
 def test_a_touched_header_makes_exactly_its_users_stale(tmp_path, monkeypatch):
     """The hash follows the include graph: a change in kernels_amr.hip concerns that unit alone, one in
     device_math.hpp every kernel file that reaches it and not the host driver; a reverted edit leaves nothing stale."""

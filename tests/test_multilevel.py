@@ -755,3 +755,89 @@ def test_one_dimensional_refined_mesh_both_paths_agree_hip(hiplib):
         s.close()
     assert out["fused"][0] == out["unfused"][0]
     assert all(np.array_equal(a, b) for a, b in zip(out["fused"][1], out["unfused"][1]))
+
+
+# inputs/disk/disk_nbody_cyl.in with a planet, one dust species under simple_dust drag, the rotating frame and a three-level
+# adaptive mesh: `ic` conditions on x1 and x3, an atmosphere sitting on the density floors, level boundaries inside it
+PLANET_AMR_OV = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32", "parthenon/meshblock/nx1=8",
+                 "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8", "parthenon/mesh/refinement=adaptive",
+                 "parthenon/mesh/numlevel=3", "parthenon/mesh/derefine_count=5", "gas/refine_field=density",
+                 "gas/refine_type=magnitude", "gas/refine_thr=0.5", "gas/deref_thr=0.2",
+                 "physics/rotating_frame=true", "rotating_frame/omega=1.0",
+                 "physics/dust=true", "dust/nspecies=1", "dust/cfl=0.3", "dust/reconstruct=plm", "dust/riemann=hlle",
+                 "dust/dfloor=1e-10", "physics/drag=true", "drag/type=simple_dust", "dust/stopping_time/type=constant",
+                 "dust/stopping_time/tau=0.1", "dust/sizes=1.0",
+                 "nbody/particle2/mass=1.0e-3", "nbody/particle2/couple=1", "nbody/particle2/soft/type=plummer",
+                 "nbody/particle2/soft/radius=0.03", "nbody/particle2/initialize/x=1.0", "nbody/particle2/initialize/vy=1.0"]
+
+
+def _planet_amr_run(path=None, cycles=12):
+    from artemis_amd.driver import Simulation
+    s = Simulation(DECK("disk", "disk_nbody_cyl.in"), PLANET_AMR_OV)
+    if path:
+        s.set_path(path)
+    s.evolve(cycles)
+    out = dict(dt=s.dt, nb=s.nblocks, remeshes=s.remeshes, kernel=s.stage_kernel,
+               gas=[s.field("gas.prim", b)[[0, 1, 2, 3, 5]] for b in range(s.nblocks)],
+               dust=[s.field("dust.prim", b) for b in range(s.nblocks)])
+    s.close()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["no_ic_skip", "no_ic_in_shell", "no_drag_in_march", "trim_pool"])
+def test_round6_shortcuts_on_a_refined_disk_are_bitwise_neutral(hiplib, option, switch):
+    """Round 6 took launches and passes out of the refined-mesh stage: `ic` faces skipped once a buffer holds them
+    (NO_IC_SKIP), `ic` faces inside the one-launch boundary fill (NO_IC_IN_SHELL), the drag finish inside the dust march
+    (NO_DRAG_IN_MARCH), the allocator's cache kept across remeshes (TRIM_POOL restores the old behaviour).  Each switch
+    selects the older path; every zone of every leaf -- ghost zones included -- and dt must not move."""
+    a = _planet_amr_run()
+    option(switch)
+    b = _planet_amr_run()
+    assert a["dt"] == b["dt"] and a["nb"] == b["nb"] and a["remeshes"] == b["remeshes"]
+    for q in range(a["nb"]):
+        assert np.array_equal(a["gas"][q], b["gas"][q], equal_nan=True), (switch, "gas", q)
+        assert np.array_equal(a["dust"][q], b["dust"][q], equal_nan=True), (switch, "dust", q)
+
+
+@pytest.mark.gpu
+def test_floors_bind_next_to_level_boundaries_one_kernel_stages_equal_the_task_chain(hiplib, option):
+    """The reference's PrimToCons floors every ghost zone behind the boundary fill (fill_derived.cpp:227-262).  Where the
+    atmosphere sits on the density floor a restricted average rounds below it and a prolongation undershoots it; the
+    one-kernel stages keep no conserved ghost zones, so the fill ends with artemis_hip_ml_floor_ghosts on the blocks next to
+    a level boundary.  Against the per-task chain (the reference's sequence literally, PrimToCons over whole blocks): every
+    zone of every leaf, ghost zones included, and dt -- and the deck does exercise it: without the pass (NO_ML_FLOOR) the two
+    part ways in the second cycle."""
+    a = _planet_amr_run()
+    b = _planet_amr_run(path="unfused")
+    assert "stage_curv_kernel" in a["kernel"] and "per-task" in b["kernel"]
+    assert a["dt"] == b["dt"] and a["nb"] == b["nb"] and a["remeshes"] == b["remeshes"]
+    for q in range(a["nb"]):
+        assert np.array_equal(a["gas"][q], b["gas"][q], equal_nan=True), ("gas", q)
+        assert np.array_equal(a["dust"][q], b["dust"][q], equal_nan=True), ("dust", q)
+    option("no_ml_floor")
+    c = _planet_amr_run(cycles=2)
+    d = _planet_amr_run(path="unfused", cycles=2)
+    assert any(not np.array_equal(x, y, equal_nan=True) for x, y in zip(c["gas"], d["gas"]))
+
+
+@pytest.mark.gpu
+def test_cartesian_tile_march_equals_the_cell_centred_stage_on_the_shipped_disk_deck(hiplib, option):
+    """inputs/disk/disk_cart.in (statically refined Cartesian disk, gravity + alpha viscosity, nghost 4) runs the SYS =
+    cartesian instantiation of the tile march since round 6; NO_CART_MARCH sends it back to the cell-centred stage: same
+    bits in every zone of every leaf, same dt."""
+    def run():
+        s = _disk_cart(["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/mesh/nx3=64"])
+        s.evolve(6)
+        kern = s.stage_kernel
+        out = (s.dt, s.nblocks, kern, [s.field("gas.prim", b)[[0, 1, 2, 3, 5]] for b in range(s.nblocks)])
+        s.close()
+        return out
+    a = run()
+    assert "stage_curv_kernel" in a[2]
+    option("no_cart_march")
+    b = run()
+    assert "stage_curv_kernel" not in b[2]
+    assert a[0] == b[0] and a[1] == b[1]
+    for q in range(a[1]):
+        assert np.array_equal(a[3][q], b[3][q], equal_nan=True), q

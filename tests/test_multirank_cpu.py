@@ -48,6 +48,7 @@ def run_world(world, spec, tmp_path, tag):
         for r in range(world):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=port, OMP_NUM_THREADS=threads)
+            env.update(spec.get("env", {}))  # (option switches of the run: ARTEMIS_<NAME>)
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mr_worker.py"),
                                            json.dumps(spec)], env=env, stdout=subprocess.PIPE,
                                           stderr=subprocess.STDOUT))

@@ -217,3 +217,86 @@ def test_disk_condition_contract(hiplib):
         mb.ApplyBoundaryConditions([bc], disk=dict(omf=0.7))
     assert e.value.code == capi.EINVAL and "ic_gas" in str(e.value)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [
+    ("ic", "ic", "none", "none", "ic", "ic"),
+    ("ic", "none", "none", "none", "ic", "none"),
+    ("ic", "ic", "periodic", "periodic", "outflow", "ic"),
+    ("outflow", "ic", "ic", "reflecting", "periodic", "periodic"),
+    ("reflecting", "reflecting", "ic", "ic", "ic", "outflow"),
+    ("none", "ic", "outflow", "none", "none", "ic"),
+])
+@pytest.mark.parametrize("nx", [(16, 8, 8), (12, 6, 1), (4, 4, 4), (8, 8, 8)])
+def test_ic_faces_inside_the_one_launch_fill(hiplib, option, flags, nx):
+    """`ic` faces ride the one-launch boundary fill of the copy-type conditions since round 6 (bc_shell_kernel: a zone whose
+    last covering pass is an `ic` pass reads the initial-state tables).  Against the sequential per-face passes
+    (NO_IC_IN_SHELL: parthenon's order literally -- periodic images, then x1, x2, x3 over the entire extent of the other
+    directions) on random states, random initial-state tables, several blocks, gas + dust, every mixture of `ic` with
+    neighbour faces (none), periodic, outflow and reflecting ones, 3-D and 2-D: every zone of every array, bit for bit."""
+    import torch
+    from artemis_amd.pack import MeshBlockPack, _ptr_table
+    ndim = 3 if nx[2] > 1 else 2
+    if ndim == 2:
+        flags = flags[:4] + ("none", "none")
+    kw = dict(ng=2, ns_gas=1, ns_dust=2, reconstruct="plm", riemann="hlle", dust_reconstruct="plm", dust_riemann="hlle",
+              gamma=1.4, dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10, coordinates="cylindrical")
+    los = [(0.5, 0.0, -1.0), (0.5, 1.0, -1.0), (0.5, 2.0, -1.0)]
+    his = [(2.0, 1.0, 1.0), (2.0, 2.0, 1.0), (2.0, 3.0, 1.0)]
+    mb = MeshBlockPack(3, nx, los, his, with_fluxes=False, **kw)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    state_g = torch.rand(mb.gas_prim.shape, generator=g, dtype=torch.float64) + 0.1
+    state_d = torch.rand(mb.dust_prim.shape, generator=g, dtype=torch.float64) + 0.1
+    ic_g = (torch.rand(mb.gas_prim.shape, generator=g, dtype=torch.float64) + 2.0).cuda()
+    ic_d = (torch.rand(mb.dust_prim.shape, generator=g, dtype=torch.float64) + 2.0).cuda()
+    ic_g[:, 0, 0, 1, 1] = 1e-12  # (a value below the floors: no floor pass runs on this per-task call, it must survive)
+    tg, td = _ptr_table(ic_g), _ptr_table(ic_d)
+    disk = dict(ic_gas=tg.data_ptr(), ic_dust=td.data_ptr())
+    out = []
+    for old in (False, True):
+        if old:
+            option("no_ic_in_shell")
+        mb.gas_prim.copy_(state_g), mb.dust_prim.copy_(state_d)
+        mb.ApplyBoundaryConditions([flags] * 3, disk=disk)
+        torch.cuda.synchronize()
+        out.append((mb.gas_prim.cpu().numpy().copy(), mb.dust_prim.cpu().numpy().copy()))
+    keep = [0, 1, 2, 3, 5]
+    assert np.array_equal(out[0][0][:, keep], out[1][0][:, keep])
+    assert np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx", [(4, 4, 4), (8, 8, 8)])
+def test_ic_faces_of_many_blocks_with_their_own_flags(hiplib, option, nx):
+    """The coarse buffers of a refined disk: hundreds of small blocks (more than one batch of the one-launch fill), each
+    with its own mixture of `ic` and neighbour faces, gas + one dust species.  One-launch fill == sequential passes."""
+    import torch
+    from artemis_amd.pack import MeshBlockPack, _ptr_table
+    nb = 600
+    kw = dict(ng=2, ns_gas=1, ns_dust=1, reconstruct="plm", riemann="hlle", dust_reconstruct="plm", dust_riemann="hlle",
+              gamma=1.4, dfloor=1e-10, siefloor=1e-10, dust_dfloor=1e-10, coordinates="cylindrical")
+    los = [(0.5, 0.01 * b, -1.0) for b in range(nb)]
+    his = [(2.0, 0.01 * (b + 1), 1.0) for b in range(nb)]
+    mb = MeshBlockPack(nb, nx, los, his, with_fluxes=False, **kw)
+    rng = np.random.default_rng(11)
+    names = ["none", "ic", "ic", "none", "outflow", "reflecting"]
+    flags = [tuple(names[q] for q in rng.integers(0, 4 if b % 3 else 6, size=6)) for b in range(nb)]
+    g = torch.Generator(device="cpu").manual_seed(7)
+    state_g = torch.rand(mb.gas_prim.shape, generator=g, dtype=torch.float64) + 0.1
+    state_d = torch.rand(mb.dust_prim.shape, generator=g, dtype=torch.float64) + 0.1
+    ic_g = (torch.rand(mb.gas_prim.shape, generator=g, dtype=torch.float64) + 2.0).cuda()
+    ic_d = (torch.rand(mb.dust_prim.shape, generator=g, dtype=torch.float64) + 2.0).cuda()
+    tg, td = _ptr_table(ic_g), _ptr_table(ic_d)
+    disk = dict(ic_gas=tg.data_ptr(), ic_dust=td.data_ptr())
+    out = []
+    for old in (False, True):
+        if old:
+            option("no_ic_in_shell")
+        mb.gas_prim.copy_(state_g), mb.dust_prim.copy_(state_d)
+        mb.ApplyBoundaryConditions(flags, disk=disk)
+        torch.cuda.synchronize()
+        out.append((mb.gas_prim.cpu().numpy().copy(), mb.dust_prim.cpu().numpy().copy()))
+    keep = [0, 1, 2, 3, 5]
+    assert np.array_equal(out[0][0][:, keep], out[1][0][:, keep])
+    assert np.array_equal(out[0][1], out[1][1])
