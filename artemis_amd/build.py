@@ -45,9 +45,18 @@ _INCLUDE_RE = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
 _versions = {}
 
 
+def _tool_env():
+    """The environment compilers run in: this process's without a profiler's hooks.  Under `rocprofv3 -- python3 ...` every
+    child inherits the tool's LD_PRELOAD and logs timestamped lines to stderr -- `hipcc --version` then differed from call
+    to call, every object looked stale and each profiled process recompiled the whole library (minutes per PMC pass)."""
+    drop = ("LD_PRELOAD", "ROCP", "ROCPROF", "HSA_TOOLS", "ROCTX", "ROCTRACER")
+    return {k: v for k, v in os.environ.items() if not k.startswith(drop)}
+
+
 def _compiler_version(exe):
     if exe not in _versions:
-        _versions[exe] = subprocess.run([exe, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+        _versions[exe] = subprocess.run([exe, "--version"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                        env=_tool_env()).stdout.decode()
     return _versions[exe]
 
 
@@ -176,7 +185,7 @@ def build_hip(force=False, verbose=False, only=None):
             full = cmd + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(full), flush=True)
-            procs.append((name, obj, full, subprocess.Popen(full)))
+            procs.append((name, obj, full, subprocess.Popen(full, env=_tool_env())))
         failed = []
         for name, obj, full, p in procs:
             if p.wait() != 0:
@@ -189,12 +198,12 @@ def build_hip(force=False, verbose=False, only=None):
         with open(id_src, "w") as f:
             f.write(id_txt)
         id_obj = os.path.join(LIBDIR, "source_id.o")
-        subprocess.check_call(["g++", "-O1", "-fPIC", "-c", id_src, "-o", id_obj])
+        subprocess.check_call(["g++", "-O1", "-fPIC", "-c", id_src, "-o", id_obj], env=_tool_env())
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", target + ".tmp"] + [u[2] for u in units] + [id_obj] + [
             "-L", os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        subprocess.check_call(cmd, env=_tool_env())
         os.replace(target + ".tmp", target)
     return target
 

@@ -20,13 +20,15 @@ fi
 if has pmc; then
 # ---- HBM traffic (PMC; separate FETCH_SIZE / WRITE_SIZE passes).  The Sedov record is a mean over full-size launches of the
 # two headline instantiations only (scripts/pmc_traffic.py asserts the launch count; bench.py refuses a record without it)
-timeout 1200 python3 scripts/pmc_traffic.py --tag ${tag}
-timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph
-timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 1024
-timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 4096
-timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 1024 --out gpurun_out/${tag}_cfg3_1024_2dust_pmc_traffic.json --dust 2
-timeout 1200 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph_smr
-timeout 1800 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_amr
+# (PMC_LIST selects a subset: every record is two profiled runs, 3-5 minutes)
+wantm() { case " ${PMC_LIST:-sedov disk_sph cfg3_1024 cfg3 cfg3_2dust smr amr} " in *" $1 "*) return 0;; *) return 1;; esac; }
+wantm sedov && timeout 1200 python3 scripts/pmc_traffic.py --tag ${tag}
+wantm disk_sph && timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph
+wantm cfg3_1024 && timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 1024
+wantm cfg3 && timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 4096
+wantm cfg3_2dust && timeout 900 python3 scripts/pmc_traffic.py --tag ${tag} --workload ssheet_dust --n 1024 --out gpurun_out/${tag}_cfg3_1024_2dust_pmc_traffic.json --dust 2
+wantm smr && timeout 1200 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph_smr
+wantm amr && timeout 1800 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_amr
 fi
 if has pmcsmr; then
 timeout 1700 python3 scripts/pmc_traffic.py --tag ${tag} --workload disk_sph_smr
@@ -41,20 +43,22 @@ fi
 for f in pmc_traffic disk_sph_pmc_traffic cfg3_pmc_traffic cfg3_1024_pmc_traffic cfg3_1024_2dust_pmc_traffic disk_sph_smr_pmc_traffic disk_amr_pmc_traffic pmc_sq; do cp gpurun_out/${tag}_$f.json profiles/${ROUND}_$f.json 2>/dev/null; done
 if has bench; then
 # ---- bench lines
-timeout 900 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err; cat gpurun_out/${tag}_bench_line.json | cut -c1-400
-timeout 300 python bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_cfg3_line.json
-timeout 300 python bench.py --workload ssheet_dust --n 1024 --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_line.json
-timeout 300 python bench.py --workload ssheet_dust --n 1024 --dust 2 --no-cpu-baseline --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_2dust_line.json
-timeout 300 python bench.py --workload disk_sph --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_disk_sph_line.json
-timeout 600 python bench.py --workload disk_sph_smr --steps 40 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_sph_smr_line.json
-timeout 1500 python bench.py --workload disk_amr --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json
+# (BENCH_LIST selects a subset)
+wantb() { case " ${BENCH_LIST:-sedov cfg3 cfg3_1024 cfg3_2dust disk_sph smr amr amr32 amr_remesh smr_loop amr_loop linwave} " in *" $1 "*) return 0;; *) return 1;; esac; }
+wantb sedov && timeout 900 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err; cat gpurun_out/${tag}_bench_line.json | cut -c1-400
+wantb cfg3 && timeout 300 python bench.py --workload ssheet_dust --n 4096 --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_cfg3_line.json
+wantb cfg3_1024 && timeout 300 python bench.py --workload ssheet_dust --n 1024 --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_line.json
+wantb cfg3_2dust && timeout 300 python bench.py --workload ssheet_dust --n 1024 --dust 2 --no-cpu-baseline --steps 100 2>/dev/null > gpurun_out/${tag}_cfg3_1024_2dust_line.json
+wantb disk_sph && timeout 300 python bench.py --workload disk_sph --no-cpu-baseline --steps 50 2>/dev/null > gpurun_out/${tag}_disk_sph_line.json
+wantb smr && timeout 600 python bench.py --workload disk_sph_smr --steps 40 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_sph_smr_line.json
+wantb amr && timeout 1500 python bench.py --workload disk_amr --steps 20 --warmup 5 2>/dev/null > gpurun_out/${tag}_disk_amr_line.json
 # ... the deck's own 32^3 blocks, the mesh changing inside the timed region, the N-rank legs through RCCL on one device, the PPM gap
-timeout 900 python bench.py --workload disk_amr --amr-block 32 --steps 20 --warmup 5 --no-cpu-baseline --no-remesh-leg 2>/dev/null > gpurun_out/${tag}_disk_amr_block32_line.json
-timeout 1500 python bench.py --workload disk_amr --steps 24 --warmup 5 --no-cpu-baseline --no-remesh-leg --remesh-in-timed-region 2>/dev/null > gpurun_out/${tag}_disk_amr_remesh_in_timed_region_line.json
-timeout 600 python bench.py --workload disk_sph_smr --loopback --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null > gpurun_out/${tag}_disk_sph_smr_loopback_line.json
-timeout 900 python bench.py --workload disk_amr --loopback --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null > gpurun_out/${tag}_disk_amr_loopback_line.json
-for r in ppm plm; do timeout 300 python bench.py --workload linwave3d --recon $r --steps 30 --warmup 5 2>/dev/null > gpurun_out/${tag}_linwave3d_${r}_line.json; done
-cut -c1-300 gpurun_out/${tag}_cfg3_line.json gpurun_out/${tag}_cfg3_1024_line.json gpurun_out/${tag}_disk_sph_line.json gpurun_out/${tag}_disk_sph_smr_line.json gpurun_out/${tag}_disk_amr_line.json
+wantb amr32 && timeout 900 python bench.py --workload disk_amr --amr-block 32 --steps 20 --warmup 5 --no-cpu-baseline --no-remesh-leg 2>/dev/null > gpurun_out/${tag}_disk_amr_block32_line.json
+wantb amr_remesh && timeout 1500 python bench.py --workload disk_amr --steps 24 --warmup 5 --no-cpu-baseline --no-remesh-leg --remesh-in-timed-region 2>/dev/null > gpurun_out/${tag}_disk_amr_remesh_in_timed_region_line.json
+wantb smr_loop && timeout 600 python bench.py --workload disk_sph_smr --loopback --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null > gpurun_out/${tag}_disk_sph_smr_loopback_line.json
+wantb amr_loop && timeout 900 python bench.py --workload disk_amr --loopback --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null > gpurun_out/${tag}_disk_amr_loopback_line.json
+wantb linwave && for r in ppm plm; do timeout 300 python bench.py --workload linwave3d --recon $r --steps 30 --warmup 5 2>/dev/null > gpurun_out/${tag}_linwave3d_${r}_line.json; done
+cut -c1-300 gpurun_out/${tag}_cfg3_line.json gpurun_out/${tag}_cfg3_1024_line.json gpurun_out/${tag}_disk_sph_line.json gpurun_out/${tag}_disk_sph_smr_line.json gpurun_out/${tag}_disk_amr_line.json 2>/dev/null
 fi
 if has prof; then
 # ---- rocprofv3 kernel statistics.  The headline profile holds 256^3 launches of the two headline instantiations ONLY

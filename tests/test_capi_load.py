@@ -277,3 +277,20 @@ print("ok", len(known))
 """ % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_object_hashes_do_not_depend_on_a_profilers_environment(monkeypatch):
+    """Under `rocprofv3 -- python3 bench.py` every child process inherits the tool's LD_PRELOAD and writes its log lines to
+    stderr; `hipcc --version` -- part of every object's hash -- must not see either (it did: each profiled process found
+    the whole library stale and recompiled it)."""
+    from artemis_amd import build
+    build._versions.clear()
+    want = build.object_hashes()
+    monkeypatch.setenv("LD_PRELOAD", "/nonexistent/librocprofiler-sdk-tool.so")  # (the loader complains on stderr in every child)
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/nonexistent/librocprofiler-sdk-tool.so")
+    build._versions.clear()
+    try:
+        assert build.object_hashes() == want
+        assert "LD_PRELOAD" not in build._tool_env() and "ROCP_TOOL_LIBRARIES" not in build._tool_env()
+    finally:
+        build._versions.clear()
