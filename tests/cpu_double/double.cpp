@@ -327,6 +327,29 @@ static void set_nbody(Sim &s, const artemis_nbody_particle_t *pl, int npart, dou
   s.rframe.on = (omf != 0.0), s.rframe.omega = omf, s.nbody_frame_correction = true;
   s.pforce.assign(static_cast<size_t>(7) * npart, 0.0);
 }
+// A stage kernel reads the primitives as the caller left them; the oracle's PrimToCons floors them in place.  Where a
+// ghost zone arrives below a floor -- a caller that left out the floors behind a refined-mesh fill
+// (artemis_hip_ml_floor_ghosts) -- the double must not repair that silently: the supplied value goes back in, so that
+// the run parts from the reference's the way the device's would (sane values only: never-written corner zones stay
+// floored, nothing reads them into an active zone).
+static void prim_to_cons_as_supplied(Sim &s) {
+  const int nsg = s.c.ns_gas, nsd = s.c.ns_dust;
+  RVec rho(s.gprim.begin(), s.gprim.begin() + static_cast<size_t>(nsg) * s.N);
+  RVec sie(s.gprim.begin() + static_cast<size_t>(5 * nsg) * s.N, s.gprim.begin() + static_cast<size_t>(6 * nsg) * s.N);
+  RVec drho(s.dprim.begin(), s.dprim.begin() + static_cast<size_t>(nsd) * s.N);
+  prim_to_cons(s);
+  auto back = [](Real raw, Real &now) {
+    if (std::isfinite(raw) && raw > 0.0 && raw < now) now = raw;
+  };
+  for (int k = 0; k < s.nk; ++k)
+    for (int j = 0; j < s.nj; ++j)
+      for (int i = 0; i < s.ni; ++i) {
+        if (i >= s.is && i <= s.ie && j >= s.js && j <= s.je && k >= s.ks && k <= s.ke) continue;
+        const size_t c = IDX(s, k, j, i);
+        for (int n = 0; n < nsg; ++n) back(rho[n * s.N + c], s.gprim[n * s.N + c]), back(sie[n * s.N + c], s.gprim[(5 * nsg + n) * s.N + c]);
+        for (int n = 0; n < nsd; ++n) back(drho[n * s.N + c], s.dprim[n * s.N + c]);
+      }
+}
 int artemis_hip_nbody_force_scratch(const artemis_pack_t *) { return 1; }
 // the seven sums alone: the task on a copy of the block (its fluid update is discarded)
 int artemis_hip_nbody_force_sums(const artemis_pack_t *p, const artemis_nbody_particle_t *pl, int npart, double omf, double dt,
@@ -452,7 +475,7 @@ int artemis_hip_stage_fused(const artemis_pack_t *p, const artemis_stage_args_t 
       apply_bcs(s);
       for (int f = 0; f < 6; ++f) s.c.bc[f] = BC_NONE;
     }
-    prim_to_cons(s);
+    prim_to_cons_as_supplied(s);
     calculate_fluxes(s, FL_GAS, a->pcm != 0);
     const double beta_dt = a->beta_dt_dev ? *a->beta_dt_dev : a->beta_dt;
     const double bdt = a->beta_dt_dev ? *a->beta_dt_dev : a->bdt;
@@ -624,7 +647,7 @@ static void stage_block(const artemis_pack_t *p, const artemis_stage_general_arg
     prim_to_cons(s);
     s.gu1 = s.gu0, s.du1 = s.du0;
     B.in(s.gprim, a->gas_in, s.nvg), B.in(s.dprim, a->dust_in, s.nvd);
-    prim_to_cons(s);
+    prim_to_cons_as_supplied(s);
     calculate_fluxes(s, FL_GAS, a->pcm != 0), calculate_fluxes(s, FL_DUST, a->pcm != 0);
     if (fix) { // refined meshes: the flagged faces take the corrected flux fields from the pack's arrays
       for (const artemis_ml_fix_cell_t *fc : *fix)
@@ -743,7 +766,7 @@ int artemis_hip_ml_face_fluxes(const artemis_pack_t *p, const artemis_stage_gene
     Bound B(p, b);
     Sim &s = *B.s;
     B.in(s.gprim, a->gas_in, s.nvg), B.in(s.dprim, a->dust_in, s.nvd);
-    prim_to_cons(s); // (refreshes the pressure of every zone, ghosts included)
+    prim_to_cons_as_supplied(s); // (refreshes the pressure of every zone, ghosts included)
     calculate_fluxes(s, FL_GAS, a->pcm != 0), calculate_fluxes(s, FL_DUST, a->pcm != 0);
     for (const artemis_ml_face_box_t *bx : kv.second) {
       const int d = bx->dir;

@@ -784,6 +784,30 @@ def _planet_amr_run(path=None, cycles=12):
     return out
 
 
+def test_floors_behind_the_refined_fill_cpu_double(tmp_path):
+    """The same on the CPU double, small: the planet-disk deck (dust, drag, rotating frame) on a static three-level mesh whose
+    level boundaries lie in the floored atmosphere next to the inner radial boundary.  One-kernel stages == per-task chain in
+    every active zone; without artemis_hip_ml_floor_ghosts (NO_ML_FLOOR) they part within three cycles.  (The double's stage
+    reads ghost zones as supplied -- tests/cpu_double/double.cpp::prim_to_cons_as_supplied -- as the device's kernels do.)"""
+    drop = ("mesh/nx", "refinement=", "numlevel", "derefine_count", "gas/refine", "gas/deref")
+    ov = [o for o in PLANET_AMR_OV if not any(d in o for d in drop)]
+    ov += ["parthenon/mesh/nx1=16", "parthenon/mesh/nx2=8", "parthenon/mesh/nx3=16"]
+    ov += region_overrides(1, (0.3, -3.0, -0.2), (0.7, 3.0, 0.2), level=2)
+    runs = {}
+    for tag, path, env in (("fused", "fused", {}), ("unfused", "unfused", {}), ("nofloor", "fused", {"ARTEMIS_NO_ML_FLOOR": "1"})):
+        spec = dict(deck=["disk", "disk_nbody_cyl.in"], overrides=ov, path=path, cycles=3, dust=True, env=env)
+        runs[tag] = _run_workers(1, spec, tmp_path, "floor_" + tag)[0]
+        lv = runs[tag]["meta"]["levels"]
+        assert (lv.count(0), lv.count(1), lv.count(2)) == (2, 12, 32) and runs[tag]["meta"]["fused"] == (path == "fused")
+
+    def parted(a, b):
+        gas = sum(1 for (_, x), (_, y) in zip(a["blocks"], b["blocks"]) if not np.array_equal(x, y))
+        return gas + sum(1 for x, y in zip(a["dust"], b["dust"]) if not np.array_equal(x, y))
+    assert runs["fused"]["meta"]["dt"] == runs["unfused"]["meta"]["dt"]
+    assert parted(runs["fused"], runs["unfused"]) == 0
+    assert parted(runs["nofloor"], runs["unfused"]) > 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("switch", ["no_ic_skip", "no_ic_in_shell", "no_drag_in_march", "trim_pool"])
 def test_round6_shortcuts_on_a_refined_disk_are_bitwise_neutral(hiplib, option, switch):
