@@ -806,6 +806,14 @@ def test_floors_behind_the_refined_fill_cpu_double(tmp_path):
     assert runs["fused"]["meta"]["dt"] == runs["unfused"]["meta"]["dt"]
     assert parted(runs["fused"], runs["unfused"]) == 0
     assert parted(runs["nofloor"], runs["unfused"]) > 0
+    # two ranks: restricted zones arrive in messages too (the unpack operations put their blocks on the list)
+    from test_multirank_cpu import by_bounds
+    spec = dict(deck=["disk", "disk_nbody_cyl.in"], overrides=ov, path="fused", cycles=3, dust=True)
+    two = _run_workers(2, spec, tmp_path, "floor_two")
+    one, both = by_bounds([runs["fused"]]), by_bounds(two)
+    assert sorted(one) == sorted(both)
+    for key in one:
+        assert np.array_equal(one[key], both[key]), key
 
 
 @pytest.mark.gpu
