@@ -1,8 +1,8 @@
 # Round-end evidence run (one gpurun call): GPU suite, smoke, bench lines, rocprof stats, PMC traffic records.
 # Outputs under gpurun_out/<tag>_*; scripts/collect_evidence.sh copies what is to be judged into profiles/<round>_*.
-# A gpurun call is limited to 60 minutes: PARTS selects what runs (default: everything that fits one call without the
-# suite is "pmc sq bench prof timings"; "suite" alone takes ~25 minutes).  ROUND names the profiles/ prefix the bench
-# lines look their records up under.
+# PARTS selects what runs (suite ~6 minutes; pmc ~5; sq ~1; bench ~6; prof ~3; timings ~1 -- the PMC passes took 100 minutes
+# as long as every profiled process recompiled the library, artemis_amd/build.py::_tool_env); PMC_LIST / BENCH_LIST /
+# PROF_LIST select within a part.  ROUND names the profiles/ prefix the bench lines look their records up under.
 PARTS=${PARTS:-"suite pmc sq bench prof timings"}
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 tag=${1:-r06z}
